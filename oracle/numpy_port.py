@@ -1,0 +1,680 @@
+"""float64 numpy restatement of the hot path (TEST INFRASTRUCTURE ONLY).
+
+Parity status: **parity unpinned** against exoplanet-core / celerite2 (absent
+here, see oracle/__init__.py); pinned against oracle/mp_reference.py, which
+evaluates the mathematical definitions at 34 digits.
+
+Each function cites what it follows:
+  * third-party ops  -> the published algorithm + the reference call site;
+  * Python glue      -> the reference file:line it restates.
+All citations are relative to /root/reference/.
+"""
+import numpy as np
+
+# reference: src/exoplanet/orbits/constants.py:32-37 (literal fall-backs)
+G_grav = 2942.2062175044193
+gcc_per_sun = 5.905271918964842
+au_per_R_sun = 0.00465046726096215
+c_light = 37231.66360672704
+
+TWO_PI_HI = 6.283185307179586
+TWO_PI_LO = 2.4492935982947064e-16
+
+
+# =============================================================================
+# ops.kepler  (call sites: src/exoplanet/orbits/keplerian.py:333,818)
+# =============================================================================
+def _e_minus_sin(E):
+    """E - sin(E) without cancellation for small E (series), direct otherwise."""
+    E = np.asarray(E, dtype=np.float64)
+    E2 = E * E
+    # Taylor: E^3/6 (1 - E^2/20 (1 - E^2/42 (1 - E^2/72 (1 - E^2/110 (1 - E^2/156 (1-E^2/210))))))
+    ser = (
+        E * E2 / 6.0
+        * (1 - E2 / 20 * (1 - E2 / 42 * (1 - E2 / 72 * (1 - E2 / 110 * (1 - E2 / 156 * (1 - E2 / 210 * (1 - E2 / 272)))))))
+    )
+    return np.where(np.abs(E) < 0.9, ser, E - np.sin(E))
+
+
+def kepler_E(M, e):
+    """Eccentric anomaly by Markley (1995, CeMDA 63, 101): cubic Pade starter
+    + one fifth-order correction (fixed cost, no iteration).  M any real."""
+    M = np.asarray(M, dtype=np.float64)
+    e = np.asarray(e, dtype=np.float64) + np.zeros_like(M)
+    # two-term Cody-Waite reduction of M to [-pi, pi]
+    k = np.rint(M / TWO_PI_HI)
+    Mr = (M - k * TWO_PI_HI) - k * TWO_PI_LO
+    sgn = np.where(Mr < 0, -1.0, 1.0)
+    Mr = np.abs(Mr)
+    ome = 1.0 - e
+    pi = np.pi
+    alpha = (3 * pi * pi + 1.6 * pi * (pi - Mr) / (1 + e)) / (pi * pi - 6)
+    d = 3 * ome + alpha * e
+    q = 2 * alpha * d * ome - Mr * Mr
+    r = 3 * alpha * d * (d - ome) * Mr + Mr ** 3
+    w = (np.abs(r) + np.sqrt(q ** 3 + r * r)) ** (2.0 / 3.0)
+    E = (2 * r * w / (w * w + w * q + q * q) + Mr) / d
+    # fifth-order correction; residual via E(1-e) + e(E - sin E)
+    sE, cE = np.sin(E), np.cos(E)
+    f0 = ome * E + e * _e_minus_sin(E) - Mr
+    f1 = 1 - e * cE
+    f2 = e * sE
+    f3 = 1 - f1
+    f4 = -f2
+    d3 = -f0 / (f1 - 0.5 * f0 * f2 / f1)
+    d4 = -f0 / (f1 + 0.5 * d3 * f2 + d3 * d3 * f3 / 6)
+    d5 = -f0 / (f1 + 0.5 * d4 * f2 + d4 * d4 * f3 / 6 + d4 ** 3 * f4 / 24)
+    E = E + d5
+    return sgn * E, k
+
+
+def kepler(M, e):
+    """(sinf, cosf) of the true anomaly.  e outside [0,1) -> NaN."""
+    M = np.asarray(M, dtype=np.float64)
+    e = np.asarray(e, dtype=np.float64) + np.zeros_like(M)
+    E, _ = kepler_E(M, e)
+    # half-angle form: (cos f/2, sin f/2) ~ (sqrt(1-e) cos E/2, sqrt(1+e) sin E/2);
+    # 1 - e cos E = X^2 + Y^2 has no cancellation as e -> 1, E -> 0
+    with np.errstate(invalid="ignore"):
+        X = np.sqrt(1 - e) * np.cos(0.5 * E)
+        Y = np.sqrt(1 + e) * np.sin(0.5 * E)
+    den = X * X + Y * Y
+    cosf = (X * X - Y * Y) / den
+    sinf = 2 * X * Y / den
+    bad = ~((e >= 0) & (e < 1))
+    return np.where(bad, np.nan, sinf), np.where(bad, np.nan, cosf)
+
+
+def kepler_grad(sinf, cosf, e):
+    """df/dM, df/de."""
+    ome2 = 1 - e * e
+    dfdM = (1 + e * cosf) ** 2 / ome2 ** 1.5
+    dfde = (2 + e * cosf) * sinf / ome2
+    return dfdM, dfde
+
+
+# =============================================================================
+# ops.quad_solution_vector  (call site: src/exoplanet/light_curves/limb_dark.py:24)
+#
+# Definition: s_n = int_{visible} g_n dA.  s0, s2: elementary (lens areas).
+# s1: Green's theorem with the azimuthal field g(rho) = (1-(1-rho^2)^{3/2})/(3 rho)
+# gives  s1 = 2pi/3 (1 - Theta(r-b)) + J,
+#        J  = 1/3 int_arc (1-rho^2)^{3/2} dtheta
+# reduced to complete elliptic integrals evaluated with Bulirsch's (1969) `cel`
+# (the same building block Agol, Luger & Foreman-Mackey 2020 use).
+# =============================================================================
+def cel(kc, p, a, b, niter=9):
+    """Bulirsch general complete elliptic integral, vectorised, fixed sweeps.
+    cel = int_0^{pi/2} (a cos^2 + b sin^2)/(cos^2 + p sin^2)/sqrt(cos^2 + kc^2 sin^2)."""
+    kc, p, a, b = np.broadcast_arrays(
+        *[np.asarray(x, dtype=np.float64) for x in (kc, p, a, b)]
+    )
+    # floor: every caller's sin^2 coefficient vanishes with kc^2 (or the result is
+    # multiplied by kc^2), so the floor costs O(1e-16 log) at most
+    kc = np.maximum(np.abs(kc), 1e-8).copy()
+    p = p.copy(); a = a.copy(); b = b.copy()
+    e = kc.copy()
+    em = np.ones_like(kc)
+    pos = p > 0
+    with np.errstate(all="ignore"):
+        ps = np.sqrt(np.where(pos, p, 1.0))
+        f = kc * kc
+        q = 1.0 - f
+        g = 1.0 - p
+        f2 = f - p
+        q2 = q * (b - a * p)
+        pn = np.sqrt(np.where(pos, 1.0, f2 / g))
+        an = (a - b) / g
+        bn = -q2 / (g * g * pn) + an * pn
+        b = np.where(pos, b / ps, bn)
+        a = np.where(pos, a, an)
+        p = np.where(pos, ps, pn)
+        for _ in range(niter):
+            f = a.copy()
+            a = a + b / p
+            g = e / p
+            b = b + f * g
+            b = b + b
+            p = g + p
+            g = em.copy()
+            em = em + kc
+            # every sweep is an exact (Landen) transformation of the integral,
+            # so sweeping past convergence is harmless: no data-dependent exit
+            kc = 2 * np.sqrt(e)
+            e = kc * em
+        return 0.5 * np.pi * (b + a * em) / (em * (em + p))
+
+
+# (pi/2)-normalised moments  beta4[j] = (2/pi) int sin^{2j} cos^4 * (2j-1)!!/(2j)!!
+def _c4_series_coeffs(n=40):
+    out = []
+    cj = 1.0  # (2j-1)!!/(2j)!!
+    # (2/pi) int_0^{pi/2} sin^{2j} cos^4 = 3 (2j-1)!! / (2j+4)!! * ... compute by recurrence
+    # I_j = int sin^{2j} cos^4 = I_{j-1} (2j-1)/(2j+4);  I_0 = 3 pi/16
+    Ij = 3.0 / 16.0 * 2.0  # in units of pi/2
+    for j in range(n):
+        if j > 0:
+            cj *= (2 * j - 1) / (2 * j)
+            Ij *= (2 * j - 1) / (2 * j + 4)
+        out.append(cj * Ij)
+    return np.array(out)
+
+
+_C4 = _c4_series_coeffs()
+
+
+def _int_cos4(k2, kc2, E, K):
+    """C4 = int_0^{pi/2} cos^4/sqrt(1-k2 sin^2): closed form, series for small k2."""
+    with np.errstate(all="ignore"):
+        closed = (2 * (2 * k2 - 1) * E + kc2 * (2 - 3 * k2) * K) / (3 * k2 * k2)
+    ser = np.zeros_like(k2)
+    for c in _C4[::-1]:
+        ser = ser * k2 + c
+    ser = ser * (0.5 * np.pi)
+    return np.where(k2 < 0.3, ser, closed)
+
+
+def quad_solution_vector(b, r):
+    """-> s (...,3), dsdb (...,3), dsdr (...,3).  Takes |b| (the reference test
+    feeds b in [-1.5,1.5], tests/light_curves_test.py:24-27); ds/db carries
+    sign(b)."""
+    b0 = np.asarray(b, dtype=np.float64)
+    r0 = np.asarray(r, dtype=np.float64)
+    b0, r0 = np.broadcast_arrays(b0, r0)
+    sgn = np.where(b0 < 0, -1.0, 1.0)
+    bb = np.abs(b0)
+    shape = bb.shape
+    bb = bb.ravel().copy()
+    rr = r0.ravel().copy()
+    n = bb.size
+    s = np.empty((n, 3)); dsdb = np.zeros((n, 3)); dsdr = np.zeros((n, 3))
+    s[:, 0] = np.pi; s[:, 1] = 2 * np.pi / 3; s[:, 2] = 0.0
+
+    none = (rr <= 0) | (bb >= 1 + rr)
+    full = (~none) & (rr >= 1 + bb)
+    s[full] = 0.0
+    act = ~(none | full)
+    idx = np.nonzero(act)[0]
+    if idx.size:
+        b_ = bb[idx]; r_ = rr[idx]
+        S, DB, DR = _sv_active(b_, r_)
+        s[idx] = S; dsdb[idx] = DB; dsdr[idx] = DR
+    nan = np.isnan(bb) | np.isnan(rr)
+    s[nan] = np.nan; dsdb[nan] = np.nan; dsdr[nan] = np.nan
+    dsdb *= sgn.ravel()[:, None]
+    return s.reshape(shape + (3,)), dsdb.reshape(shape + (3,)), dsdr.reshape(shape + (3,))
+
+
+def _x_minus_sin(x):
+    """x - sin x, series below 0.9 (no cancellation), direct above."""
+    return _e_minus_sin(x)
+
+
+def _i4_num(k):
+    """8 (k - sin k) - (2k - sin 2k)  (= 32 int_0^{k/2} sin^4): series for small k."""
+    k2 = k * k
+    c = [24.0 / 120, 120.0 / 5040, 504.0 / 362880, 2040.0 / 39916800,
+         8184.0 / 6227020800, 32760.0 / 1307674368000, 131064.0 / 355687428096000,
+         524280.0 / 121645100408832000]
+    ser = np.zeros_like(k)
+    for cj in c[::-1]:
+        ser = cj - k2 * ser
+    ser = ser * k ** 5
+    return np.where(np.abs(k) < 0.4, ser, 8 * _x_minus_sin(k) - _x_minus_sin(2 * k))
+
+
+def _sv_active(b, r):
+    """Occultor overlaps the limb (partial) or sits inside the disk (inside)."""
+    n = b.size
+    S = np.empty((n, 3)); DB = np.empty((n, 3)); DR = np.empty((n, 3))
+    r2 = r * r; b2 = b * b
+    inside = b + r <= 1
+    with np.errstate(all="ignore"):
+        # 1-(b-r)^2 and (b+r)^2-1, factored and ordered so that the leading
+        # subtraction is exact (Sterbenz) when the larger radius is near 1
+        x = np.maximum(b, r); y = np.minimum(b, r)
+        A = ((1 - x) + y) * (1 + (x - y))
+        Bm = ((x - 1) + y) * ((x + y) + 1)
+        kite = np.sqrt(np.maximum(0.0, A * Bm))
+        kite = np.where(inside, 0.0, kite)      # = 2 b r sin k0 = 2 b sin k1
+        # arc half-angles about the occultor centre (k0) and the star centre (k1);
+        # atan2 keeps full relative accuracy for grazing (tiny) angles
+        k0 = np.where(inside, np.pi, np.arctan2(kite, b2 + (r - 1) * (r + 1)))
+        k1 = np.where(inside, 0.0, np.arctan2(kite, (1 - r) * (1 + r) + b2))
+        sink0 = np.where(inside, 0.0, kite / (2 * b * r))
+        # moments of sin^2, sin^4 over the half arc u in [0, k0/2]
+        I2 = np.where(inside, np.pi / 4, _x_minus_sin(k0) / 4)
+        I4 = np.where(inside, 3 * np.pi / 16, _i4_num(k0) / 32)
+        u0 = 0.5 * k0
+        rmb_ = r - b
+        q = 1 - 2 * rmb_ * rmb_                 # (2 - 4 (b-r)^2)/2
+        # ---- s0: pi - lens area, lens = two circular segments
+        s0 = np.where(inside, np.pi * (1 - r2),
+                      np.pi - 0.5 * (r2 * _x_minus_sin(2 * k0) + _x_minus_sin(2 * k1)))
+        ds0dr = -2 * r * k0
+        ds0db = 2 * r * sink0
+        # ---- s2 = -int_lens (2 - 4 rho^2) dA via the field rho (1-rho^2) phi_hat
+        #      (vanishes on the limb): only the occultor arc contributes
+        s2 = -4 * r * (A * rmb_ * u0 + (2 * b * A - 4 * b * r * rmb_) * I2 - 8 * b2 * r * I4)
+        ds2dr = -r * (4 * k0 * q - 64 * b * r * I2)
+        ds2db = -4 * r * (-2 * q * u0 + (4 * q + 16 * b * r) * I2 - 32 * b * r * I4)
+
+        # ---- s1
+        sqA = np.sqrt(A)
+        theta = np.where(r > b, 1.0, np.where(r == b, 0.5, 0.0))
+        same = b == r
+        rmb = np.where(same, 1.0, rmb_)
+        # inside (complete integrals, modulus m = 4br/A)
+        m = 4 * b * r / A
+        kc2i = np.maximum(-Bm / A, 0.0)
+        kci = np.sqrt(kc2i)
+        Ei = cel(kci, 1.0, 1.0, kc2i)
+        Ki = cel(kci, 1.0, 1.0, 1.0)
+        t3 = (2 * (2 - m) * Ei - kc2i * Ki) / 3
+        Ji = (2 * sqA / 3) * (A * t3 - (r2 - b2) * Ei)
+        Pi = cel(kci, ((b + r) / rmb) ** 2, A, -Bm)
+        Ji = Ji + np.where(same, 0.0, (2 * (r + b) / (3 * sqA * rmb)) * Pi)
+        ds1dr_i = -4 * r * sqA * Ei
+        ds1db_i = 4 * r * sqA * cel(kci, 1.0, 1.0, -kc2i) / 3
+        # partial (modulus k2 = A/4br)
+        k2 = np.minimum(A / (4 * b * r), 1.0)
+        kc2p = np.maximum(1 - k2, 0.0)
+        kcp = np.sqrt(kc2p)
+        Ep = cel(kcp, 1.0, 1.0, kc2p)
+        Kp = cel(kcp, 1.0, 1.0, 1.0)
+        C2 = cel(kcp, 1.0, 1.0, 0.0)
+        C4 = _int_cos4(k2, kc2p, Ep, Kp)
+        kk = np.sqrt(k2)
+        pref = 4 * sqA * kk
+        Jp = (pref / 6) * (A * C4 - (r2 - b2) * C2)
+        Pp = cel(kcp, 1.0 / (rmb * rmb), 1.0, 0.0)
+        Jp = Jp + np.where(same, 0.0, ((r + b) / (6 * rmb)) * pref * Pp)
+        ds1dr_p = -r * pref * C2
+        ds1db_p = r * pref * (C2 * (1 - 2 * k2) + 2 * k2 * C4)
+
+        J = np.where(inside, Ji, Jp)
+        s1 = 2 * np.pi / 3 * (1 - theta) + J
+        ds1dr = np.where(inside, ds1dr_i, ds1dr_p)
+        ds1db = np.where(inside, ds1db_i, ds1db_p)
+
+        # b == 0: s1 is elementary and every ds/db vanishes by symmetry
+        z = b == 0
+        s1 = np.where(z, 2 * np.pi / 3 * np.maximum(1 - r2, 0.0) ** 1.5, s1)
+        ds1dr = np.where(z, -2 * np.pi * r * np.sqrt(np.maximum(1 - r2, 0.0)), ds1dr)
+        ds1db = np.where(z, 0.0, ds1db)
+        ds0db = np.where(z, 0.0, ds0db)
+        ds2db = np.where(z, 0.0, ds2db)
+    S[:, 0] = s0; S[:, 1] = s1; S[:, 2] = s2
+    DB[:, 0] = ds0db; DB[:, 1] = ds1db; DB[:, 2] = ds2db
+    DR[:, 0] = ds0dr; DR[:, 1] = ds1dr; DR[:, 2] = ds2dr
+    return S, DB, DR
+
+
+# =============================================================================
+# ops.contact_points  (call site: src/exoplanet/orbits/keplerian.py:744-753)
+#
+# Mean anomalies of first / fourth contact: the two roots nearest the transit
+# centre of  rho(f)^2 (1 - sin^2 i sin^2(omega+f)) = L^2,  L = R_star + r.
+# Third-party algorithm unavailable; this is a bracketed bisection on the
+# definition.  flag != 0  <=>  no bracket (caller then evaluates every cadence,
+# keplerian.py:771-775).
+# =============================================================================
+def contact_points(a, e, cosw, sinw, cosi, sini, L):
+    a, e, cosw, sinw, cosi, sini, L = [
+        np.atleast_1d(np.asarray(x, dtype=np.float64)) for x in (a, e, cosw, sinw, cosi, sini, L)
+    ]
+    a, e, cosw, sinw, cosi, sini, L = np.broadcast_arrays(a, e, cosw, sinw, cosi, sini, L)
+    n = a.size
+    Ml = np.zeros(n); Mr = np.zeros(n); flag = np.zeros(n, dtype=np.int32)
+    for i in range(n):
+        Ml[i], Mr[i], flag[i] = _contact_one(
+            a.flat[i], e.flat[i], cosw.flat[i], sinw.flat[i], cosi.flat[i], sini.flat[i], L.flat[i]
+        )
+    return Ml.reshape(a.shape), Mr.reshape(a.shape), flag.reshape(a.shape)
+
+
+def _contact_one(a, e, cosw, sinw, cosi, sini, L):
+    p = a * (1 - e * e)
+
+    def g(th):
+        # th = omega + f - pi/2 ; cos f = sin(omega - th)
+        st, ct = np.sin(th), np.cos(th)
+        cosf = sinw * ct - cosw * st
+        rho = p / (1 + e * cosf)
+        return rho * rho * (st * st + cosi * cosi * ct * ct) - L * L
+
+    if not (g(0.0) < 0):
+        return 0.0, 0.0, 1
+    out = []
+    for sgn in (-1.0, 1.0):
+        lo = 0.0
+        hi = None
+        for k in range(1, 33):
+            th = sgn * k * (0.5 * np.pi / 32)
+            if g(th) > 0:
+                hi = th
+                break
+            lo = th
+        if hi is None:
+            return 0.0, 0.0, 1
+        for _ in range(80):
+            mid = 0.5 * (lo + hi)
+            if g(mid) > 0:
+                hi = mid
+            else:
+                lo = mid
+        th = 0.5 * (lo + hi)
+        # f = th + pi/2 - omega ; half-angle to E, then M = E - e sin E
+        w = np.arctan2(sinw, cosw)
+        f = th + 0.5 * np.pi - w
+        E = 2 * np.arctan2(np.sqrt(1 - e) * np.sin(0.5 * f), np.sqrt(1 + e) * np.cos(0.5 * f))
+        out.append(E - e * np.sin(E))
+    return out[0], out[1], 0
+
+
+# =============================================================================
+# Python glue, restated from the reference's own source
+# =============================================================================
+def get_cl(u1, u2):
+    """reference: src/exoplanet/light_curves/limb_dark.py:11-18"""
+    c0 = 1 - u1 - 1.5 * u2
+    c1 = u1 + 2 * u2
+    c2 = -0.25 * u2
+    norm = np.pi * (c0 + c1 / 1.5)
+    return np.array([c0, c1, c2]) / norm
+
+
+class KeplerianOrbit:
+    """reference: src/exoplanet/orbits/keplerian.py:75-281 (constructor),
+    :283-334 (rotation, anomaly), :380-409 (position), :708-777 (in_transit),
+    :779-804 (_flip), :849-934 (_get_consistent_inputs).  Subset used by the
+    hot path: no units, no Jacobian bookkeeping."""
+
+    def __init__(self, period=None, a=None, t0=None, t_periastron=None, incl=None, b=None,
+                 ecc=None, omega=None, Omega=None, m_planet=0.0, m_star=None, r_star=None,
+                 rho_star=None):
+        A = lambda x: None if x is None else np.atleast_1d(np.asarray(x, dtype=np.float64))
+        a, period, rho_star, r_star, m_star, m_planet = self._consistent(
+            A(a), A(period), A(rho_star), A(r_star), A(m_star), A(m_planet))
+        self.a, self.period, self.rho_star = a, period, rho_star
+        self.r_star, self.m_star, self.m_planet = r_star, m_star, m_planet
+        self.m_total = m_star + m_planet
+        self.n = 2 * np.pi / period                                   # :146
+        self.a_star = a * m_planet / self.m_total                     # :147
+        self.a_planet = -a * m_star / self.m_total                    # :148
+        self.Omega = A(Omega)
+        if ecc is None:                                               # :182-185
+            self.ecc = None
+            self.M0 = 0.5 * np.pi + np.zeros_like(self.n)
+            incl_factor = 1.0
+        else:                                                         # :187-214
+            self.ecc = A(ecc)
+            if omega is None:
+                raise ValueError("both e and omega must be provided")
+            self.omega = A(omega)
+            self.cos_omega = np.cos(self.omega)
+            self.sin_omega = np.sin(self.omega)
+            opsw = 1 + self.sin_omega
+            E0 = 2 * np.arctan2(np.sqrt(1 - self.ecc) * self.cos_omega,
+                                np.sqrt(1 + self.ecc) * opsw)
+            self.M0 = E0 - self.ecc * np.sin(E0)
+            ome2 = 1 - self.ecc ** 2
+            incl_factor = (1 + self.ecc * self.sin_omega) / ome2
+        self.dcosidb = incl_factor * self.r_star / self.a             # :217-219
+        if b is not None:                                             # :221-228
+            if incl is not None:
+                raise ValueError("only one of 'incl', 'b', and 'duration' can be given")
+            self.b = A(b) + np.zeros_like(self.a)
+            self.cos_incl = self.dcosidb * self.b
+            self.incl = np.arccos(self.cos_incl)
+        elif incl is not None:                                        # :229-236
+            self.incl = A(incl) + np.zeros_like(self.a)
+            self.cos_incl = np.cos(self.incl)
+            self.b = self.cos_incl / self.dcosidb
+        else:                                                         # :261-265
+            zla = np.zeros_like(self.a)
+            self.incl = 0.5 * np.pi + zla
+            self.cos_incl = zla
+            self.b = zla
+        if t0 is not None and t_periastron is not None:               # :267-268
+            raise ValueError("you can't define both t0 and t_periastron")
+        if t0 is None and t_periastron is None:
+            t0 = np.zeros_like(self.period)
+        if t0 is None:                                                # :272-277
+            self.t_periastron = A(t_periastron) + np.zeros_like(self.period)
+            self.t0 = self.t_periastron + self.M0 / self.n
+        else:
+            self.t0 = A(t0) + np.zeros_like(self.period)
+            self.t_periastron = self.t0 - self.M0 / self.n
+        self.tref = self.t_periastron - self.t0                       # :279
+        self.sin_incl = np.sin(self.incl)                             # :281
+
+    @staticmethod
+    def _consistent(a, period, rho_star, r_star, m_star, m_planet):
+        """reference: keplerian.py:849-934"""
+        if a is None and period is None:
+            raise ValueError("values must be provided for at least one of a and period")
+        implied = False
+        if a is not None and period is not None:                      # :869-889
+            if rho_star is not None or m_star is not None:
+                raise ValueError("if both a and period are given, you can't also define rho_star or m_star")
+            if r_star is None:
+                r_star = np.array([1.0])
+            m_tot = 4 * np.pi * np.pi * a ** 3 / (G_grav * period ** 2)
+            m_star = m_tot - m_planet
+            rho_star = m_star / (4 * np.pi * r_star ** 3 / 3.0)
+            implied = True
+        if r_star is None and m_star is None:                         # :892-895
+            r_star = np.array([1.0])
+            if rho_star is None:
+                m_star = np.array([1.0])
+        if (not implied) and sum(x is None for x in (rho_star, r_star, m_star)) != 1:
+            raise ValueError("values must be provided for exactly two of rho_star, m_star, and r_star")
+        if rho_star is not None and not implied:                      # :904-910
+            rho_star = rho_star / gcc_per_sun
+        if rho_star is None:                                          # :917-922
+            rho_star = 3 * m_star / (4 * np.pi * r_star ** 3)
+        elif r_star is None:
+            r_star = (3 * m_star / (4 * np.pi * rho_star)) ** (1 / 3)
+        elif m_star is None:
+            m_star = 4 * np.pi * r_star ** 3 * rho_star / 3.0
+        if a is None:                                                 # :925-932
+            a = (G_grav * (m_star + m_planet) * period ** 2 / (4 * np.pi ** 2)) ** (1.0 / 3)
+        elif period is None:
+            period = 2 * np.pi * a ** 1.5 / np.sqrt(G_grav * (m_star + m_planet))
+        return a, period, rho_star * gcc_per_sun, r_star, m_star, m_planet
+
+    def _rotate_vector(self, x, y):
+        """reference: keplerian.py:283-322"""
+        if self.ecc is None:
+            x1, y1 = x, y
+        else:
+            x1 = self.cos_omega * x - self.sin_omega * y
+            y1 = self.sin_omega * x + self.cos_omega * y
+        x2 = x1
+        y2 = self.cos_incl * y1
+        Z = -self.sin_incl * y1
+        if self.Omega is None:
+            return x2, y2, Z
+        cO, sO = np.cos(self.Omega), np.sin(self.Omega)
+        return cO * x2 - sO * y2, sO * x2 + cO * y2, Z
+
+    def _get_true_anomaly(self, t, _pad=True):
+        """reference: keplerian.py:324-334"""
+        tt = t[..., None] if _pad else t
+        M = (tt - self.t0 - self.tref) * self.n
+        if self.ecc is None:
+            return np.sin(M), np.cos(M)
+        return kepler(M, self.ecc + np.zeros_like(M))
+
+    def _get_position(self, a, t, light_delay=False, _pad=True):
+        """reference: keplerian.py:380-409 (and :411-470 for light_delay)"""
+        t = np.asarray(t, dtype=np.float64)
+        if light_delay:
+            return self._get_retarded_position(a, t, _pad=_pad)
+        sinf, cosf = self._get_true_anomaly(t, _pad=_pad)
+        if self.ecc is None:
+            r = a
+        else:
+            r = a * (1.0 - self.ecc ** 2) / (1 + self.ecc * cosf)
+        return self._rotate_vector(r * cosf, r * sinf)
+
+    def _get_retarded_position(self, a, t, z0=0.0, _pad=True):
+        """reference: keplerian.py:411-470"""
+        sinf, cosf = self._get_true_anomaly(t, _pad=_pad)
+        angvel = 2 * np.pi / self.period
+        if self.ecc is None:
+            r = a
+            vamp = angvel * a
+            vz = vamp * self.sin_incl * cosf
+        else:
+            r = a * (1.0 - self.ecc ** 2) / (1 + self.ecc * cosf)
+            vamp = angvel * a / np.sqrt(1 - self.ecc ** 2)
+            cwf = self.cos_omega * cosf - self.sin_omega * sinf
+            vz = vamp * self.sin_incl * (self.ecc * self.cos_omega + cwf)
+        x, y, z = self._rotate_vector(r * cosf, r * sinf)
+        az = -(angvel ** 2) * (a / r) ** 3 * z
+        with np.errstate(all="ignore"):
+            delay = np.where(
+                np.abs(az) < 1.0e-10,
+                (z0 - z) / (c_light + vz),
+                (c_light / az) * ((1 + vz / c_light) - np.sqrt(
+                    (1 + vz / c_light) * (1 + vz / c_light) - 2 * az * (z0 - z) / c_light ** 2)),
+            )
+        new_t = (t[..., None] if _pad else t) - delay
+        return self._get_position(a, new_t, _pad=False)
+
+    def get_relative_position(self, t, light_delay=False):
+        """reference: keplerian.py:517-542"""
+        return tuple(np.squeeze(x) for x in self._get_position(-self.a, t, light_delay=light_delay))
+
+    def in_transit(self, t, r=0.0, texp=None):
+        """reference: keplerian.py:708-777"""
+        t = np.asarray(t, dtype=np.float64)
+        z = np.zeros_like(self.a)
+        r = np.asarray(r, dtype=np.float64) + z
+        R = self.r_star + z
+        hp = 0.5 * self.period
+        dt = np.mod(t[..., None] - self.t0 + hp, self.period) - hp
+        if self.ecc is None:
+            k = r / R
+            arg = np.square(1 + k) - np.square(self.b)
+            factor = R / (self.a * self.sin_incl)
+            hdur = hp * np.arcsin(factor * np.sqrt(arg)) / np.pi
+            t_start, t_end, flag = -hdur, hdur, z
+        else:
+            Ml, Mr, flag = contact_points(self.a, self.ecc, self.cos_omega, self.sin_omega,
+                                          self.cos_incl + z, self.sin_incl + z, R + r)
+            t_start = (Ml - self.M0) / self.n
+            t_start = np.mod(t_start + hp, self.period) - hp
+            t_end = (Mr - self.M0) / self.n
+            t_end = np.mod(t_end + hp, self.period) - hp
+            t_start = np.where(t_start > 0.0, t_start - self.period, t_start)
+            t_end = np.where(t_end < 0.0, t_end + self.period, t_end)
+        if texp is not None:
+            t_start = t_start - 0.5 * texp
+            t_end = t_end + 0.5 * texp
+        mask = np.any((dt >= t_start) & (dt <= t_end), axis=-1)
+        if np.all(flag == 0):
+            return np.arange(t.shape[0])[mask]
+        return np.arange(t.shape[0])
+
+    def _flip(self, r_planet):
+        """reference: keplerian.py:779-804"""
+        if self.ecc is None:
+            return KeplerianOrbit(period=self.period, t_periastron=self.t_periastron + 0.5 * self.period,
+                                  incl=self.incl, Omega=self.Omega, m_star=self.m_planet,
+                                  m_planet=self.m_star, r_star=r_planet)
+        return KeplerianOrbit(period=self.period, t_periastron=self.t_periastron, incl=self.incl,
+                              ecc=self.ecc, omega=self.omega - np.pi, Omega=self.Omega,
+                              m_star=self.m_planet, m_planet=self.m_star, r_star=r_planet)
+
+
+class LimbDarkLightCurve:
+    """reference: src/exoplanet/light_curves/limb_dark.py:27-252"""
+
+    def __init__(self, u1, u2):
+        self.u1, self.u2 = float(u1), float(u2)
+        self.c = get_cl(self.u1, self.u2)
+
+    def _compute_light_curve(self, b, r, los=None):
+        """reference: limb_dark.py:21-24, 234-252"""
+        b = np.asarray(b, dtype=np.float64)
+        r = np.asarray(r, dtype=np.float64) + np.zeros_like(b)
+        s, _, _ = quad_solution_vector(b, r)
+        lc = s @ self.c - 1.0
+        if los is None:
+            return lc
+        return np.where(los > 0, lc, 0.0)
+
+    def get_light_curve(self, orbit=None, r=None, t=None, texp=None, oversample=7, order=0,
+                        use_in_transit=None, light_delay=False):
+        """reference: limb_dark.py:99-232"""
+        if orbit is None:
+            raise ValueError("missing required argument 'orbit'")
+        if r is None:
+            raise ValueError("missing required argument 'r'")
+        if t is None:
+            raise ValueError("missing required argument 't'")
+        use_in_transit = (not light_delay) if use_in_transit is None else use_in_transit
+        r = np.atleast_1d(np.asarray(r, dtype=np.float64)).reshape(-1)
+        t = np.asarray(t, dtype=np.float64)
+        N = t.shape[0]
+        if use_in_transit:
+            model = np.zeros((N, r.size))
+            inds = orbit.in_transit(t, r=r, texp=texp)
+            t = t[inds]
+        if texp is None:
+            tgrid = t
+        else:
+            texp = np.asarray(texp, dtype=np.float64)
+            oversample = int(oversample)
+            oversample += 1 - oversample % 2
+            stencil = np.ones(oversample)
+            if order == 0:
+                dt = np.linspace(-0.5, 0.5, 2 * oversample + 1)[1:-1:2]
+            elif order == 1:
+                dt = np.linspace(-0.5, 0.5, oversample)
+                stencil[1:-1] = 2
+            elif order == 2:
+                dt = np.linspace(-0.5, 0.5, oversample)
+                stencil[1:-1:2] = 4
+                stencil[2:-1:2] = 2
+            else:
+                raise ValueError("order must be <= 2")
+            stencil /= np.sum(stencil)
+            if texp.ndim == 0:
+                dt = texp * dt
+            else:
+                dt = (texp[inds] if use_in_transit else texp)[:, None] * dt
+            tgrid = t[:, None] + dt
+        coords = orbit.get_relative_position(tgrid, light_delay=light_delay)
+        shape = tgrid.shape + (r.size,)
+        b = np.sqrt(coords[0] ** 2 + coords[1] ** 2).reshape(shape)
+        los = np.reshape(coords[2], shape)
+        rs = orbit.r_star
+        lc = self._compute_light_curve(b / rs, (r + np.zeros(shape)) / rs, los / rs)
+        if texp is not None:
+            lc = np.sum(stencil[None, :, None] * lc, axis=1)
+        if use_in_transit:
+            model[inds] = lc
+            return model
+        return lc
+
+
+class SecondaryEclipseLightCurve:
+    """reference: src/exoplanet/light_curves/secondary_eclipse.py:8-70"""
+
+    def __init__(self, u_primary, u_secondary, surface_brightness_ratio):
+        self.primary = LimbDarkLightCurve(u_primary[0], u_primary[1])
+        self.secondary = LimbDarkLightCurve(u_secondary[0], u_secondary[1])
+        self.surface_brightness_ratio = surface_brightness_ratio
+
+    def get_light_curve(self, orbit=None, r=None, t=None, **kw):
+        r = np.atleast_1d(np.asarray(r, dtype=np.float64))
+        orbit2 = orbit._flip(r)
+        lc1 = self.primary.get_light_curve(orbit=orbit, r=r, t=t, **kw)
+        lc2 = self.secondary.get_light_curve(orbit=orbit2, r=orbit.r_star, t=t, **kw)
+        k = r / orbit.r_star
+        flux_ratio = self.surface_brightness_ratio * k ** 2
+        return (lc1 + flux_ratio * lc2) / (1 + flux_ratio)
