@@ -1,0 +1,7 @@
+"""exoplanet_amd -- MI355X-native per-leapfrog-step log-likelihood hot path of
+exoplanet-dev/exoplanet (Kepler solve -> limb-darkened transit flux -> celerite
+GP log-likelihood, value + gradient), as HIP kernels behind the reference's own
+operator interface.  See DESIGN.md."""
+from . import ops  # noqa: F401
+
+__version__ = "0.1.0"

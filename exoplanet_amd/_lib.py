@@ -1,0 +1,77 @@
+"""ctypes binding of the C ABI in include/exoplanet_amd.h.
+
+The shared library is built in-tree by ``__graft_entry__.build()`` (hipcc,
+--offload-arch=gfx950).  There is NO fallback: if the library is missing or an
+op is handed a host tensor, the call raises.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libexoplanet_amd.so")
+ABI_VERSION = 1
+
+_c_dp = ctypes.c_void_p  # device pointers travel as integers
+_i64 = ctypes.c_int64
+_i32 = ctypes.c_int32
+_u32 = ctypes.c_uint32
+
+_SIGNATURES = {
+    "exo_abi_version": (_i32, []),
+    "exo_kepler_f64": (ctypes.c_int, [_c_dp, _c_dp, _c_dp, _c_dp, _i64, _c_dp]),
+    "exo_quad_solution_vector_f64": (ctypes.c_int, [_c_dp, _c_dp, _c_dp, _c_dp, _c_dp, _i64, _c_dp]),
+    "exo_contact_points_f64": (ctypes.c_int, [_c_dp] * 10 + [_i64, _c_dp]),
+    "exo_transit_flux_fwd_f64": (
+        ctypes.c_int,
+        [_c_dp, _i64, _c_dp, _i64, _c_dp, _c_dp, _i32, _c_dp, _c_dp, _i64, _i32, _u32, _c_dp, _c_dp],
+    ),
+    "exo_transit_flux_vjp_workspace_bytes": (_i64, [_i64, _i64, _i32]),
+    "exo_transit_flux_vjp_f64": (
+        ctypes.c_int,
+        [_c_dp, _i64, _c_dp, _i64, _c_dp, _c_dp, _i32, _c_dp, _c_dp, _i64, _i32, _u32,
+         _c_dp, _c_dp, _c_dp, _c_dp, _c_dp, _i64, _c_dp],
+    ),
+}
+
+_ERRORS = {1: "invalid argument", 2: "kernel launch failed", 3: "workspace too small"}
+
+_lib = None
+
+
+class ExtensionMissingError(RuntimeError):
+    pass
+
+
+def exported_symbols():
+    """Names include/exoplanet_amd.h declares (kept in sync by tests/test_abi.py)."""
+    return sorted(_SIGNATURES)
+
+
+def load():
+    """dlopen the HIP library; raises ExtensionMissingError loudly if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ExtensionMissingError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  exoplanet_amd has no CPU or PyTorch fallback."
+        )
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:  # pragma: no cover
+            raise ExtensionMissingError(f"{LIB_PATH} does not export {name}: stale build?") from e
+        fn.restype = res
+        fn.argtypes = args
+    got = lib.exo_abi_version()
+    if got != ABI_VERSION:
+        raise ExtensionMissingError(f"ABI mismatch: library reports {got}, bindings expect {ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def check(status, what):
+    if status != 0:
+        raise RuntimeError(f"{what}: {_ERRORS.get(status, f'error {status}')}")

@@ -1,0 +1,332 @@
+// exo_math.hpp -- fp64 device math for the transit hot path on gfx950 (CDNA4).
+//
+//   kepler_half()   Kepler's equation -> half-angle true-anomaly components
+//   quad_sv()       quadratic limb-darkening solution vector (+ d/db, d/dr)
+//
+// These replace the arithmetic of the reference's third-party ops
+//   ops.kepler               (call site /root/reference/src/exoplanet/orbits/keplerian.py:333)
+//   ops.quad_solution_vector (call site /root/reference/src/exoplanet/light_curves/limb_dark.py:24)
+// The third-party sources are not available; everything here is derived from
+// the mathematical definitions and checked against
+// oracle/mp_reference.py.
+//
+// One (cadence, sub-exposure, planet) per lane.  No MFMA: there is no dense
+// contraction anywhere on this path.  Iterative pieces (the AGM sweeps of the
+// elliptic integrals) exit on a wavefront vote so a wave never spins on lanes
+// that have already converged and never diverges inside the sweep.
+//
+// The header is also compiled for the host by tests/ (g++, EXO_HOST_BUILD) to
+// check the arithmetic on CPU before it ever runs on a GPU; that build is a
+// test harness, not a product path.
+#pragma once
+#include <math.h>
+
+#ifdef EXO_HOST_BUILD
+#define EXO_HD inline
+#define EXO_WAVE_ALL(c) (c)
+#define EXO_WAVE_ANY(c) (c)
+#else
+#include <hip/hip_runtime.h>
+#define EXO_HD __device__ __forceinline__
+// 64-wide wavefront votes (gfx950): uniform branch conditions
+#define EXO_WAVE_ALL(c) (__all((int)(c)))
+#define EXO_WAVE_ANY(c) (__any((int)(c)))
+#endif
+
+namespace exo {
+
+constexpr double kPi = 3.14159265358979323846;
+constexpr double kHalfPi = 1.57079632679489661923;
+constexpr double kTwoPiHi = 6.283185307179586;       // fl(2 pi)
+constexpr double kTwoPiLo = 2.4492935982947064e-16;  // 2 pi - fl(2 pi)
+constexpr double kTwoThirdsPi = 2.09439510239319549231;
+
+// x - sin(x) for x >= 0 given an independently known sin(x).
+// Taylor series below 0.9 (no cancellation), direct above.
+EXO_HD double x_minus_sin(double x, double sinx) {
+  const double x2 = x * x;
+  double s = 1.0 - x2 * (1.0 / 272.0);
+  s = 1.0 - x2 * (1.0 / 210.0) * s;
+  s = 1.0 - x2 * (1.0 / 156.0) * s;
+  s = 1.0 - x2 * (1.0 / 110.0) * s;
+  s = 1.0 - x2 * (1.0 / 72.0) * s;
+  s = 1.0 - x2 * (1.0 / 42.0) * s;
+  s = 1.0 - x2 * (1.0 / 20.0) * s;
+  s = x * x2 * (1.0 / 6.0) * s;
+  return (x < 0.9) ? s : (x - sinx);
+}
+
+// ---------------------------------------------------------------------------
+// Kepler solver.  Markley (1995) cubic starter + one fifth-order correction:
+// fixed cost, so there is nothing to vote on.  Works on half angles so that
+// 1 - e cos E = X^2 + Y^2 carries no cancellation as e -> 1.
+//
+//   in : M (any real), e in [0,1), se = sqrt(1-e), pe = sqrt(1+e)
+//   out: X = sqrt(1-e) cos(E/2),  Y = sqrt(1+e) sin(E/2)   (signed)
+//        so that  den = X^2+Y^2 = 1 - e cos E,
+//                 den cos f = X^2 - Y^2 (= cos E - e),
+//                 den sin f = 2 X Y     (= sqrt(1-e^2) sin E)
+//        sh, ch = sin(E/2), cos(E/2) (signed) for the reverse pass.
+// ---------------------------------------------------------------------------
+struct KeplerHalf {
+  double X, Y, sh, ch;
+};
+
+EXO_HD KeplerHalf kepler_half(double M, double e, double se, double pe) {
+  // two-term Cody-Waite reduction to [-pi, pi]
+  const double k = rint(M * (1.0 / kTwoPiHi));
+  double Mr = fma(-k, kTwoPiHi, M);
+  Mr = fma(-k, kTwoPiLo, Mr);
+  const double sgn = (Mr < 0.0) ? -1.0 : 1.0;
+  Mr = fabs(Mr);
+  const double ome = 1.0 - e;
+  double sh, ch, E;
+  if (EXO_WAVE_ALL(e == 0.0)) {
+    // circular orbit (the reference's ecc=None branch, keplerian.py:331-332)
+    E = Mr;
+    sincos(0.5 * E, &sh, &ch);
+  } else {
+    // --- starter (Markley 1995 eqs. 15-20)
+    const double alpha = (3.0 * kPi * kPi + 1.6 * kPi * (kPi - Mr) / (1.0 + e)) * (1.0 / (kPi * kPi - 6.0));
+    const double d = 3.0 * ome + alpha * e;
+    const double q = 2.0 * alpha * d * ome - Mr * Mr;
+    const double r = (3.0 * alpha * d * (d - ome) + Mr * Mr) * Mr;
+    double w = cbrt(fabs(r) + sqrt(q * q * q + r * r));
+    w = w * w;
+    E = (2.0 * r * w / (w * w + w * q + q * q) + Mr) / d;
+    // --- one fifth-order correction (eqs. 21-24); residual as
+    //     (1-e) E + e (E - sin E) to survive e -> 1, E -> 0
+    sincos(0.5 * E, &sh, &ch);
+    const double sinE = 2.0 * sh * ch;
+    const double f0 = ome * E + e * x_minus_sin(E, sinE) - Mr;
+    const double f1 = ome + 2.0 * e * sh * sh;  // 1 - e cos E
+    const double f2 = e * sinE;
+    const double f3 = 1.0 - f1;
+    const double d3 = -f0 / (f1 - 0.5 * f0 * f2 / f1);
+    const double d4 = -f0 / (f1 + 0.5 * d3 * f2 + d3 * d3 * f3 * (1.0 / 6.0));
+    const double d5 = -f0 / (f1 + 0.5 * d4 * f2 + d4 * d4 * f3 * (1.0 / 6.0) - d4 * d4 * d4 * f2 * (1.0 / 24.0));
+    // |d5| <= 4.4e-4 over the whole (M,e) domain: rotate (sh,ch) by d5/2 with
+    // a 4th-order Taylor rotation instead of a second sincos
+    const double h = 0.5 * d5, h2 = h * h;
+    const double sd = h * (1.0 - h2 * (1.0 / 6.0));
+    const double cd = 1.0 - h2 * (0.5 - h2 * (1.0 / 24.0));
+    const double sh2 = sh * cd + ch * sd;
+    ch = ch * cd - sh * sd;
+    sh = sh2;
+  }
+  KeplerHalf o;
+  o.sh = sgn * sh;
+  o.ch = ch;
+  o.X = se * ch;
+  o.Y = pe * o.sh;
+  return o;
+}
+
+// ---------------------------------------------------------------------------
+// Three complete elliptic integrals on one shared AGM ladder (Bulirsch 1969
+// `cel`; sharing the ladder between integrals follows the idea in Agol, Luger &
+// Foreman-Mackey 2020):
+//   B = int cos^2/Delta,  D = int sin^2/Delta          (p = 1)
+//   P = int (aP cos^2 + bP sin^2)/(cos^2 + p sin^2)/Delta
+// Delta = sqrt(cos^2 + kc^2 sin^2), all over [0, pi/2].  p > 0 required.
+// Every sweep is an exact Landen transformation, so sweeping past convergence
+// is harmless: the exit test is a wavefront vote (uniform branch).
+// ---------------------------------------------------------------------------
+struct Cel3 {
+  double B, D, P;
+};
+
+EXO_HD Cel3 cel3(double kc, double p, double aP, double bP) {
+  // floor: every caller's sin^2 coefficient vanishes with kc^2 (or the result
+  // is multiplied by kc^2), so the floor costs O(1e-16 log) at most
+  kc = fmax(fabs(kc), 1e-8);
+  double e = kc, em = 1.0;
+  double aB = 1.0, bB = 0.0, aD = 0.0, bD = 1.0, p1 = 1.0;
+  double pp = sqrt(p);
+  bP = bP / pp;
+#pragma unroll 1
+  for (int it = 0; it < 12; ++it) {
+    const double ip1 = 1.0 / p1, ipp = 1.0 / pp;
+    const double g1 = e * ip1, gP = e * ipp;
+    double f = aB;
+    aB = fma(bB, ip1, aB);
+    bB = 2.0 * fma(f, g1, bB);
+    f = aD;
+    aD = fma(bD, ip1, aD);
+    bD = 2.0 * fma(f, g1, bD);
+    p1 = g1 + p1;
+    f = aP;
+    aP = fma(bP, ipp, aP);
+    bP = 2.0 * fma(f, gP, bP);
+    pp = gP + pp;
+    const double g = em;
+    em += kc;
+    if (EXO_WAVE_ALL(!(fabs(g - kc) > g * 1.0e-8))) break;
+    kc = 2.0 * sqrt(e);
+    e = kc * em;
+  }
+  Cel3 o;
+  const double q1 = kHalfPi / (em * (em + p1));
+  o.B = q1 * fma(aB, em, bB);
+  o.D = q1 * fma(aD, em, bD);
+  o.P = kHalfPi * fma(aP, em, bP) / (em * (em + pp));
+  return o;
+}
+
+// C4 = int_0^{pi/2} cos^4/sqrt(1 - k2 sin^2): Maclaurin series in k2 (k2 < 0.1)
+EXO_HD double int_cos4_series(double k2) {
+  // c_j = (2j-1)!!/(2j)!! * (2/pi) int sin^{2j} cos^4
+  const double c[18] = {3.75000000000000000e-01, 3.12500000000000000e-02, 8.78906250000000000e-03, 3.66210937500000000e-03, 1.86920166015625000e-03, 1.08146667480468750e-03, 6.81549310684204102e-04, 4.57070767879486084e-04, 3.21377883665263653e-04, 2.34540930250659585e-04, 1.76394324626016896e-04, 1.35996323706422118e-04, 1.07056629822466221e-04, 8.57825559474889587e-05, 6.97940661670976015e-05, 5.75458918103226302e-05, 4.80048628730208747e-05, 4.04623031491638797e-05};
+  double s = c[17];
+#pragma unroll
+  for (int j = 16; j >= 0; --j) s = fma(s, k2, c[j]);
+  return kHalfPi * s;
+}
+
+// 8 (k - sin k) - (2k - sin 2k) = 32 int_0^{k/2} sin^4, series for k < 0.4
+EXO_HD double i4_series(double k) {
+  const double k2 = k * k;
+  const double c[8] = {24.0 / 120, 120.0 / 5040, 504.0 / 362880, 2040.0 / 39916800,
+                       8184.0 / 6227020800.0, 32760.0 / 1307674368000.0, 131064.0 / 355687428096000.0,
+                       524280.0 / 121645100408832000.0};
+  double s = c[7];
+#pragma unroll
+  for (int j = 6; j >= 0; --j) s = fma(-k2, s, c[j]);
+  return s * k2 * k2 * k;
+}
+
+// ---------------------------------------------------------------------------
+// Solution vector s = (s0, s1, s2) = int_{visible disk} (1, mu, 4 mu^2 - 2) dA
+// for an occultor of radius r at separation b >= 0, and (optionally) ds/db,
+// ds/dr.  See DESIGN.md section 3.2 for the derivation:
+//   s0 = pi - (two circular segments)
+//   s2 = -int_arc (1-rho^2) r (r + b cos phi) dphi      (field rho(1-rho^2) phi^)
+//   s1 = 2pi/3 (1 - Theta(r-b)) + 1/3 int_arc (1-rho^2)^{3/2} dtheta
+//   ds_n/dr = -r int_arc g_n dphi,  ds_n/db = -r int_arc g_n cos phi dphi
+// WITH_GRAD is a compile-time switch so the forward kernel carries no
+// derivative arithmetic.
+// ---------------------------------------------------------------------------
+struct SV {
+  double s0, s1, s2;
+  double db0, db1, db2;
+  double dr0, dr1, dr2;
+};
+
+template <bool WITH_GRAD>
+EXO_HD void quad_sv(double b, double r, SV& o) {
+  o.s0 = kPi; o.s1 = kTwoThirdsPi; o.s2 = 0.0;
+  o.db0 = o.db1 = o.db2 = 0.0;
+  o.dr0 = o.dr1 = o.dr2 = 0.0;
+  if (b != b || r != r) {
+    const double nan = b + r;
+    o.s0 = o.s1 = o.s2 = nan;
+    o.db0 = o.db1 = o.db2 = o.dr0 = o.dr1 = o.dr2 = nan;
+    return;
+  }
+  const bool none = (r <= 0.0) || (b >= 1.0 + r);
+  const bool full = !none && (r >= 1.0 + b);
+  if (full) { o.s0 = 0.0; o.s1 = 0.0; o.s2 = 0.0; }
+  const bool act = !(none || full);
+  if (!EXO_WAVE_ANY(act)) return;
+  if (!act) { b = 0.5; r = 0.1; }  // benign stand-in so idle lanes stay finite
+
+  const double r2 = r * r, b2 = b * b;
+  const bool inside = (b + r <= 1.0);
+  // 1-(b-r)^2 and (b+r)^2-1, factored and ordered so that the leading
+  // subtraction is exact (Sterbenz) when the larger radius is near 1
+  const double x = fmax(b, r), y = fmin(b, r);
+  const double A = ((1.0 - x) + y) * (1.0 + (x - y));
+  const double Bm = ((x - 1.0) + y) * ((x + y) + 1.0);
+  const double sqA = sqrt(A);
+  const double br = b * r;
+  const double rmb = r - b;
+
+  // ---- arc geometry (partial overlap only)
+  double k0 = kPi, u0 = kHalfPi, I2 = 0.25 * kPi, I4 = 0.1875 * kPi, sink0 = 0.0;
+  double seg = 0.0;  // lens area (two circular segments)
+  if (EXO_WAVE_ANY(!inside)) {
+    const double kite = sqrt(fmax(0.0, A * Bm));       // 2 b r sin k0 = 2 b sin k1
+    const double c0n = b2 + (r - 1.0) * (r + 1.0);      // 2 b r cos k0
+    const double c1n = (1.0 - r) * (1.0 + r) + b2;      // 2 b cos k1
+    const double pk0 = atan2(kite, c0n);
+    const double pk1 = atan2(kite, c1n);
+    const double i2br = 0.5 / br, i2b = 0.5 / b;
+    const double s0k = kite * i2br, c0k = c0n * i2br;
+    const double s1k = kite * i2b, c1k = c1n * i2b;
+    const double xms_k0 = x_minus_sin(pk0, s0k);
+    const double xms_2k0 = x_minus_sin(2.0 * pk0, 2.0 * s0k * c0k);
+    const double xms_2k1 = x_minus_sin(2.0 * pk1, 2.0 * s1k * c1k);
+    const double pI4 = (pk0 < 0.4) ? i4_series(pk0) : (8.0 * xms_k0 - xms_2k0);
+    if (!inside) {
+      k0 = pk0; u0 = 0.5 * pk0; sink0 = s0k;
+      I2 = 0.25 * xms_k0;
+      I4 = (1.0 / 32.0) * pI4;
+      seg = 0.5 * (r2 * xms_2k0 + xms_2k1);
+    }
+  }
+  if (inside) seg = kPi * r2;
+  const double q = 1.0 - 2.0 * rmb * rmb;
+  const double s0 = kPi - seg;
+  const double s2 = -4.0 * r * (A * rmb * u0 + (2.0 * b * A - 4.0 * br * rmb) * I2 - 8.0 * b2 * r * I4);
+
+  // ---- s1: one shared AGM ladder serves both geometries
+  //   inside : modulus m = 4br/A,  kc^2 = -Bm/A,  P = cel(kc, ((b+r)/(b-r))^2, A, -Bm)
+  //   partial: modulus k2 = A/4br, kc^2 = 1-k2,   P = cel(kc, 1/(b-r)^2, 1, 0)
+  const bool same = (b == r);
+  const double rmb_s = same ? 1.0 : rmb;
+  const double irmb = 1.0 / rmb_s;
+  const double iA = 1.0 / A;
+  const double m_in = 4.0 * br * iA;
+  const double k2 = inside ? 0.0 : fmin(A / (4.0 * br), 1.0);
+  const double kc2 = inside ? fmax(-Bm * iA, 0.0) : fmax(1.0 - k2, 0.0);
+  const double kc = sqrt(kc2);
+  const double bpr = b + r;
+  const double pP = inside ? (bpr * irmb) * (bpr * irmb) : irmb * irmb;
+  const Cel3 c3 = cel3(kc, pP, inside ? A : 1.0, inside ? -Bm : 0.0);
+  const double Ek = fma(kc2, c3.D, c3.B);   // E
+  const double Kk = c3.B + c3.D;            // K
+  const double theta = (r > b) ? 1.0 : (same ? 0.5 : 0.0);
+  double J;
+  double pref = 0.0, C2 = 0.0, C4 = 0.0;
+  if (inside) {
+    const double t3 = (2.0 * (2.0 - m_in) * Ek - kc2 * Kk) * (1.0 / 3.0);  // int Delta^3
+    J = (2.0 * sqA * (1.0 / 3.0)) * (A * t3 - (r2 - b2) * Ek);
+    if (!same) J += (2.0 * bpr * irmb / (3.0 * sqA)) * c3.P;
+  } else {
+    C2 = c3.B;
+    // closed form loses eps/k2^2; switch to the series where that matters
+    if (EXO_WAVE_ANY(k2 < 0.1)) {
+      const double ser = int_cos4_series(k2);
+      C4 = (k2 < 0.1) ? ser : ((3.0 * k2 - 1.0) * c3.B + kc2 * c3.D) / (3.0 * k2);
+    } else {
+      C4 = ((3.0 * k2 - 1.0) * c3.B + kc2 * c3.D) / (3.0 * k2);
+    }
+    pref = 4.0 * sqA * sqrt(k2);
+    J = (pref * (1.0 / 6.0)) * (A * C4 - (r2 - b2) * C2);
+    if (!same) J += (bpr * irmb * (1.0 / 6.0)) * pref * c3.P;
+  }
+  const double s1 = kTwoThirdsPi * (1.0 - theta) + J;
+
+  if (act) { o.s0 = s0; o.s1 = s1; o.s2 = s2; }
+
+  if (WITH_GRAD) {
+    const double dr0 = -2.0 * r * k0;
+    const double db0 = 2.0 * r * sink0;
+    const double dr2 = -r * (4.0 * k0 * q - 64.0 * br * I2);
+    const double db2 = -4.0 * r * (-2.0 * q * u0 + (4.0 * q + 16.0 * br) * I2 - 32.0 * br * I4);
+    double dr1, db1;
+    if (inside) {
+      dr1 = -4.0 * r * sqA * Ek;
+      db1 = (4.0 / 3.0) * r * sqA * fma(-kc2, c3.D, c3.B);  // int cos(2u) Delta
+    } else {
+      dr1 = -r * pref * C2;
+      db1 = r * pref * (C2 * (1.0 - 2.0 * k2) + 2.0 * k2 * C4);
+    }
+    if (act) {
+      o.db0 = db0; o.db1 = db1; o.db2 = db2;
+      o.dr0 = dr0; o.dr1 = dr1; o.dr2 = dr2;
+    }
+  }
+}
+
+}  // namespace exo

@@ -1,0 +1,579 @@
+// exo_transit.hip -- HIP kernels + C ABI for the Kepler / limb-darkened transit
+// part of the hot path (gfx950, wave64, fp64 VALU; no MFMA -- nothing here is a
+// dense contraction).
+//
+// Work decomposition
+//   grid.x : tiles of kTile = kBlock * kCPT consecutive cadences
+//   grid.y : posterior draws (independent parameter sets)
+//   lane   : one cadence (all sub-exposures and planets are register loops, so
+//            a wave is 64 consecutive cadences: transits are contiguous in time
+//            and whole waves are uniformly in / out of transit except at edges)
+//   t, gflux, flux: coalesced 8-B-per-lane streams; per-(draw, planet) constants
+//            are derived once per block by the first lanes and staged in LDS,
+//            then read back as broadcasts.
+//
+// Reference lines restated by the fused kernel (all under /root/reference/src/exoplanet):
+//   orbits/keplerian.py:324-334   M = (t - t0 - tref) n ; kepler(M, e)
+//   orbits/keplerian.py:400-409   r = a (1-e^2)/(1+e cos f) ; rotate
+//   orbits/keplerian.py:303-314   omega rotation, inclination projection
+//   orbits/keplerian.py:729-731,765-769   in-transit window test
+//   light_curves/limb_dark.py:178-226     exposure stencil, b, los, s.c - 1, los > 0
+//   light_curves/secondary_eclipse.py:45-70   flipped orbit + blend
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/exoplanet_amd.h"
+#include "exo_math.hpp"
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kWaves = kBlock / 64;
+constexpr int kCPT = 2;                 // cadences per lane
+constexpr int kTile = kBlock * kCPT;    // cadences per block
+constexpr int kNG = 10;                 // compact gradient slots per planet
+// compact slot order
+enum { G_N = 0, G_TP, G_ECC, G_COSW, G_SINW, G_COSI, G_AOR, G_ROR, G_FR, G_PAD };
+
+// Per-(draw, planet) constants derived once per block and staged in LDS.
+struct PlanetConst {
+  double n, tp, e, se, pe, sq1me2, cw, sw, ci, si, aor, ror, iror;
+  double t0, period, iperiod, ts, te, fr, ts2, te2;
+};
+
+struct Shared {
+  PlanetConst pc[EXO_MAX_PLANETS];
+  double c[6];
+  double sdt[EXO_MAX_SUBEXP + 1];
+  double sw[EXO_MAX_SUBEXP + 1];
+  double red[kWaves][kNG + 6];
+};
+
+__device__ __forceinline__ void stage_constants(Shared& sh, const double* __restrict__ params,
+                                                const double* __restrict__ ld,
+                                                const double* __restrict__ stencil_dt,
+                                                const double* __restrict__ stencil_w, int n_sub,
+                                                int n_planet, int64_t draw, bool secondary) {
+  const int tid = threadIdx.x;
+  if (tid < n_planet) {
+    const double* p = params + (draw * n_planet + tid) * EXO_NPAR;
+    PlanetConst& c = sh.pc[tid];
+    const double e = p[EXO_P_ECC];
+    // e outside [0,1) -> NaN everywhere (docstring keplerian.py:58)
+    const bool ok = (e >= 0.0) && (e < 1.0);
+    c.n = p[EXO_P_N]; c.tp = p[EXO_P_TP]; c.e = e;
+    c.se = ok ? sqrt(1.0 - e) : __builtin_nan("");
+    c.pe = sqrt(1.0 + e);
+    c.sq1me2 = c.se * c.pe;
+    c.cw = p[EXO_P_COSW]; c.sw = p[EXO_P_SINW];
+    c.ci = p[EXO_P_COSI]; c.si = p[EXO_P_SINI];
+    c.aor = p[EXO_P_AOR]; c.ror = p[EXO_P_ROR]; c.iror = 1.0 / p[EXO_P_ROR];
+    c.t0 = p[EXO_P_T0]; c.period = p[EXO_P_PERIOD]; c.iperiod = 1.0 / p[EXO_P_PERIOD];
+    c.ts = p[EXO_P_TS]; c.te = p[EXO_P_TE];
+    c.fr = p[EXO_P_FRATIO]; c.ts2 = p[EXO_P_TS2]; c.te2 = p[EXO_P_TE2];
+  }
+  const int nld = secondary ? 6 : 3;
+  if (tid >= 64 && tid < 64 + nld) sh.c[tid - 64] = ld[draw * nld + (tid - 64)];
+  if (tid >= 128 && tid < 128 + n_sub) {
+    sh.sdt[tid - 128] = stencil_dt ? stencil_dt[tid - 128] : 0.0;
+    sh.sw[tid - 128] = stencil_w ? stencil_w[tid - 128] : 1.0;
+  }
+  __syncthreads();
+}
+
+// in-transit window test, keplerian.py:730-731,765-769 (dt wrapped to +-P/2)
+__device__ __forceinline__ bool in_window(double t, const PlanetConst& c, double htexp, bool secondary) {
+  const double hp = 0.5 * c.period;
+  double x = t - c.t0 + hp;
+  x = x - c.period * floor(x * c.iperiod);
+  const double dt = x - hp;
+  bool in = (dt >= c.ts - htexp) && (dt <= c.te + htexp);
+  if (secondary) {
+    double y = t - c.t0;
+    y = y - c.period * floor(y * c.iperiod);  // [0, P)
+    in = in || ((y >= c.ts2 - htexp) && (y <= c.te2 + htexp));
+  }
+  return in;
+}
+
+struct GradAcc {
+  double g[kNG];
+};
+
+// One (cadence, sub-exposure, planet) sample.  Returns the flux contribution F
+// and, if GRAD, adds gw * dF/d(theta) into acc / accld.
+template <bool GRAD, bool SECONDARY>
+__device__ __forceinline__ double eval_sample(double tt, const PlanetConst& c, const double* cld,
+                                              double gw, GradAcc& acc, double* accld) {
+  const double M = (tt - c.tp) * c.n;
+  const exo::KeplerHalf kh = exo::kepler_half(M, c.e, c.se, c.pe);
+  const double X2 = kh.X * kh.X, Y2 = kh.Y * kh.Y;
+  const double cx = X2 - Y2;            // (1 - e cos E) cos f = cos E - e
+  const double sx = 2.0 * kh.X * kh.Y;  // (1 - e cos E) sin f = sqrt(1-e^2) sin E
+  // position relative to the star in units of R_star; the reference passes a = -self.a
+  // (keplerian.py:540) and r = a (1-e^2)/(1+e cos f) = a (1 - e cos E)
+  const double xo = -c.aor * cx, yo = -c.aor * sx;
+  const double x1 = c.cw * xo - c.sw * yo;
+  const double y1 = c.sw * xo + c.cw * yo;
+  const double Ys = c.ci * y1;
+  const double Z = -c.si * y1;
+  const double b2 = x1 * x1 + Ys * Ys;
+  const double lim = 1.0 + c.ror;
+  const bool front = !(Z <= 0.0);  // NaN counts as in front so that NaN parameters propagate
+  const bool behind = SECONDARY && (Z < 0.0);
+  // NaN parameters must propagate: treat NaN b2 as active
+  const bool act = (front || behind) && !(b2 >= lim * lim);
+  if (!EXO_WAVE_ANY(act)) return 0.0;
+  const double b = sqrt(b2);
+  // transit: (b, ror) on the star; occultation: star of radius 1/ror passes in
+  // front of the planet, in units of the planet radius (secondary_eclipse.py:56-58)
+  const bool occ = SECONDARY && behind;
+  const double bq = occ ? b * c.iror : b;
+  const double rq = occ ? c.iror : c.ror;
+  exo::SV sv;
+  exo::quad_sv<GRAD>(act ? bq : 2.0 + rq, rq, sv);
+  const double* cc = occ ? cld + 3 : cld;
+  const double Fq = fma(sv.s0, cc[0], fma(sv.s1, cc[1], sv.s2 * cc[2])) - 1.0;
+  double F;
+  double wq = 1.0;  // dF/dFq
+  if (SECONDARY) {
+    const double inv = 1.0 / (1.0 + c.fr);
+    wq = occ ? c.fr * inv : inv;
+    F = act ? Fq * wq : 0.0;
+  } else {
+    F = act ? Fq : 0.0;
+  }
+  if (GRAD) {
+    if (act) {
+      const double gq = gw * wq;
+      // limb-darkening coefficients
+      const int o = occ ? 3 : 0;
+      accld[o + 0] += gq * sv.s0;
+      accld[o + 1] += gq * sv.s1;
+      accld[o + 2] += gq * sv.s2;
+      double bbar_q = gq * fma(sv.db0, cc[0], fma(sv.db1, cc[1], sv.db2 * cc[2]));
+      double rbar_q = gq * fma(sv.dr0, cc[0], fma(sv.dr1, cc[1], sv.dr2 * cc[2]));
+      double bbar, rorbar;
+      if (occ) {
+        // bq = b / ror, rq = 1 / ror ; F = fr Fq / (1 + fr)
+        bbar = bbar_q * c.iror;
+        rorbar = -(bbar_q * b + rbar_q) * c.iror * c.iror;
+        acc.g[G_FR] += gw * Fq * (1.0 / ((1.0 + c.fr) * (1.0 + c.fr)));
+      } else {
+        bbar = bbar_q;
+        rorbar = rbar_q;
+        if (SECONDARY) acc.g[G_FR] -= gw * Fq * (1.0 / ((1.0 + c.fr) * (1.0 + c.fr)));
+      }
+      acc.g[G_ROR] += rorbar;
+      const double ib = (b > 0.0) ? 1.0 / b : 0.0;
+      const double x1bar = bbar * x1 * ib;
+      const double Ysbar = bbar * Ys * ib;
+      const double y1bar = Ysbar * c.ci;
+      acc.g[G_COSI] += Ysbar * y1;
+      const double xobar = c.cw * x1bar + c.sw * y1bar;
+      const double yobar = -c.sw * x1bar + c.cw * y1bar;
+      acc.g[G_COSW] += x1bar * xo + y1bar * yo;
+      acc.g[G_SINW] += -x1bar * yo + y1bar * xo;
+      acc.g[G_AOR] += -(xobar * cx + yobar * sx);
+      const double cxbar = -c.aor * xobar, sxbar = -c.aor * yobar;
+      // cx = cos E - e, sx = sqrt(1-e^2) sin E ; dE/dM = 1/den, dE/de = sin E/den
+      const double sinE = 2.0 * kh.sh * kh.ch;
+      const double cosE = kh.ch * kh.ch - kh.sh * kh.sh;
+      const double iden = 1.0 / (X2 + Y2);
+      const double Ebar = fma(-sinE, cxbar, c.sq1me2 * cosE * sxbar);
+      const double Mbar = Ebar * iden;
+      acc.g[G_ECC] += Mbar * sinE - cxbar - c.e * sinE / c.sq1me2 * sxbar;
+      acc.g[G_N] += Mbar * (tt - c.tp);
+      acc.g[G_TP] -= Mbar * c.n;
+    }
+  }
+  return F;
+}
+
+// ---------------------------------------------------------------------------
+// Forward kernel
+// ---------------------------------------------------------------------------
+template <bool SECONDARY>
+__global__ __launch_bounds__(kBlock) void transit_fwd_kernel(
+    const double* __restrict__ t, int64_t n_cad, const double* __restrict__ texp, int64_t n_texp,
+    const double* __restrict__ stencil_dt, const double* __restrict__ stencil_w, int n_sub,
+    const double* __restrict__ params, const double* __restrict__ ld, int n_planet, uint32_t flags,
+    double* __restrict__ flux) {
+  __shared__ Shared sh;
+  const int64_t draw = blockIdx.y;
+  stage_constants(sh, params, ld, stencil_dt, stencil_w, n_sub, n_planet, draw, SECONDARY);
+  const bool per_planet = flags & EXO_FLAG_PER_PLANET;
+  const bool window = flags & EXO_FLAG_WINDOW;
+  const int64_t base = (int64_t)blockIdx.x * kTile + threadIdx.x;
+  double tv[kCPT], te[kCPT], fsum[kCPT];
+  bool valid[kCPT];
+#pragma unroll
+  for (int j = 0; j < kCPT; ++j) {
+    const int64_t i = base + (int64_t)j * kBlock;
+    valid[j] = i < n_cad;
+    tv[j] = valid[j] ? t[i] : 0.0;
+    te[j] = (n_texp == 0) ? 0.0 : (n_texp == 1 ? texp[0] : (valid[j] ? texp[i] : 0.0));
+    fsum[j] = 0.0;
+  }
+  GradAcc dummy;
+  double dummyld[6];
+  for (int p = 0; p < n_planet; ++p) {
+    const PlanetConst& c = sh.pc[p];
+#pragma unroll
+    for (int j = 0; j < kCPT; ++j) {
+      double f = 0.0;
+      const bool go = valid[j] && (!window || in_window(tv[j], c, 0.5 * te[j], SECONDARY));
+      if (EXO_WAVE_ANY(go)) {
+        for (int k = 0; k < n_sub; ++k) {
+          const double tt = fma(te[j], sh.sdt[k], tv[j]);
+          const double F = eval_sample<false, SECONDARY>(tt, c, sh.c, 0.0, dummy, dummyld);
+          f = fma(sh.sw[k], go ? F : 0.0, f);
+        }
+      }
+      if (per_planet) {
+        if (valid[j]) flux[(draw * n_cad + base + (int64_t)j * kBlock) * n_planet + p] = f;
+      } else {
+        fsum[j] += f;
+      }
+    }
+  }
+  if (!per_planet) {
+#pragma unroll
+    for (int j = 0; j < kCPT; ++j)
+      if (valid[j]) flux[draw * n_cad + base + (int64_t)j * kBlock] = fsum[j];
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Reverse kernel (recompute-forward).  Stage 1: per-block partial sums, in a
+// fixed order (wave shuffle tree, then waves in index order) so the result is
+// bit-reproducible run to run.  Stage 2 (reduce kernel) sums blocks in order.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+
+template <bool SECONDARY>
+__global__ __launch_bounds__(kBlock) void transit_vjp_kernel(
+    const double* __restrict__ t, int64_t n_cad, const double* __restrict__ texp, int64_t n_texp,
+    const double* __restrict__ stencil_dt, const double* __restrict__ stencil_w, int n_sub,
+    const double* __restrict__ params, const double* __restrict__ ld, int n_planet, uint32_t flags,
+    const double* __restrict__ gflux, double* __restrict__ flux_out, double* __restrict__ partial) {
+  __shared__ Shared sh;
+  const int64_t draw = blockIdx.y;
+  stage_constants(sh, params, ld, stencil_dt, stencil_w, n_sub, n_planet, draw, SECONDARY);
+  const bool per_planet = flags & EXO_FLAG_PER_PLANET;
+  const bool window = flags & EXO_FLAG_WINDOW;
+  const int64_t base = (int64_t)blockIdx.x * kTile + threadIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int ng_draw = n_planet * kNG + 6;
+  double* __restrict__ pout = partial + ((int64_t)draw * gridDim.x + blockIdx.x) * ng_draw;
+
+  double tv[kCPT], te[kCPT], fsum[kCPT], gsum[kCPT];
+  bool valid[kCPT];
+#pragma unroll
+  for (int j = 0; j < kCPT; ++j) {
+    const int64_t i = base + (int64_t)j * kBlock;
+    valid[j] = i < n_cad;
+    tv[j] = valid[j] ? t[i] : 0.0;
+    te[j] = (n_texp == 0) ? 0.0 : (n_texp == 1 ? texp[0] : (valid[j] ? texp[i] : 0.0));
+    fsum[j] = 0.0;
+    gsum[j] = (!per_planet && valid[j]) ? gflux[draw * n_cad + i] : 0.0;
+  }
+  double accld[6] = {0, 0, 0, 0, 0, 0};
+  for (int p = 0; p < n_planet; ++p) {
+    const PlanetConst& c = sh.pc[p];
+    GradAcc acc;
+#pragma unroll
+    for (int s = 0; s < kNG; ++s) acc.g[s] = 0.0;
+#pragma unroll
+    for (int j = 0; j < kCPT; ++j) {
+      double f = 0.0;
+      const bool go = valid[j] && (!window || in_window(tv[j], c, 0.5 * te[j], SECONDARY));
+      if (EXO_WAVE_ANY(go)) {
+        double g = gsum[j];
+        if (per_planet) g = valid[j] ? gflux[(draw * n_cad + base + (int64_t)j * kBlock) * n_planet + p] : 0.0;
+        for (int k = 0; k < n_sub; ++k) {
+          const double tt = fma(te[j], sh.sdt[k], tv[j]);
+          const double gw = go ? g * sh.sw[k] : 0.0;
+          const double F = eval_sample<true, SECONDARY>(tt, c, sh.c, gw, acc, accld);
+          f = fma(sh.sw[k], go ? F : 0.0, f);
+        }
+      }
+      if (flux_out) {
+        if (per_planet) {
+          if (valid[j]) flux_out[(draw * n_cad + base + (int64_t)j * kBlock) * n_planet + p] = f;
+        } else {
+          fsum[j] += f;
+        }
+      }
+    }
+    // block reduction of this planet's kNG slots
+#pragma unroll
+    for (int s = 0; s < kNG; ++s) {
+      const double v = wave_sum(acc.g[s]);
+      if (lane == 0) sh.red[wave][s] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < kNG) {
+      double v = 0.0;
+#pragma unroll
+      for (int w = 0; w < kWaves; ++w) v += sh.red[w][threadIdx.x];
+      pout[p * kNG + threadIdx.x] = v;
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int s = 0; s < 6; ++s) {
+    const double v = wave_sum(accld[s]);
+    if (lane == 0) sh.red[wave][kNG + s] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 6) {
+    double v = 0.0;
+#pragma unroll
+    for (int w = 0; w < kWaves; ++w) v += sh.red[w][kNG + threadIdx.x];
+    pout[n_planet * kNG + threadIdx.x] = v;
+  }
+  if (flux_out && !per_planet) {
+#pragma unroll
+    for (int j = 0; j < kCPT; ++j)
+      if (valid[j]) flux_out[draw * n_cad + base + (int64_t)j * kBlock] = fsum[j];
+  }
+}
+
+// Stage 2: one block per draw; thread s sums slot s over the blocks in order.
+__global__ __launch_bounds__(kBlock) void transit_vjp_reduce_kernel(
+    const double* __restrict__ partial, int nblk, int n_planet, bool secondary,
+    double* __restrict__ gparams, double* __restrict__ gld) {
+  const int64_t draw = blockIdx.x;
+  const int ng_draw = n_planet * kNG + 6;
+  const int s = threadIdx.x;
+  if (s >= ng_draw) return;
+  const double* __restrict__ src = partial + draw * nblk * (int64_t)ng_draw + s;
+  double v = 0.0;
+  for (int b = 0; b < nblk; ++b) v += src[(int64_t)b * ng_draw];
+  if (s < n_planet * kNG) {
+    const int p = s / kNG, k = s % kNG;
+    // compact slot -> EXO_P_* slot
+    const int map[kNG] = {EXO_P_N, EXO_P_TP, EXO_P_ECC, EXO_P_COSW, EXO_P_SINW,
+                          EXO_P_COSI, EXO_P_AOR, EXO_P_ROR, EXO_P_FRATIO, -1};
+    if (map[k] >= 0) gparams[(draw * n_planet + p) * EXO_NPAR + map[k]] = v;
+  } else {
+    const int k = s - n_planet * kNG;
+    const int nld = secondary ? 6 : 3;
+    if (k < nld) gld[draw * nld + k] = v;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Elementwise ops (the reference's standalone Ops)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void kepler_kernel(const double* __restrict__ M,
+                                                        const double* __restrict__ ecc,
+                                                        double* __restrict__ sinf,
+                                                        double* __restrict__ cosf, int64_t n) {
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+    const double e = ecc[i];
+    const bool ok = (e >= 0.0) && (e < 1.0);
+    const double es = ok ? e : 0.5;
+    const exo::KeplerHalf kh = exo::kepler_half(M[i], es, sqrt(1.0 - es), sqrt(1.0 + es));
+    const double X2 = kh.X * kh.X, Y2 = kh.Y * kh.Y;
+    const double iden = 1.0 / (X2 + Y2);
+    const double nan = __builtin_nan("");
+    sinf[i] = ok ? 2.0 * kh.X * kh.Y * iden : nan;
+    cosf[i] = ok ? (X2 - Y2) * iden : nan;
+  }
+}
+
+template <bool GRAD>
+__global__ __launch_bounds__(kBlock) void quad_sv_kernel(const double* __restrict__ b,
+                                                         const double* __restrict__ r,
+                                                         double* __restrict__ s,
+                                                         double* __restrict__ dsdb,
+                                                         double* __restrict__ dsdr, int64_t n) {
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  // uniform trip count so the wavefront votes inside quad_sv see whole waves
+  const int64_t n_round = (n + stride - 1) / stride * stride;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n_round; i += stride) {
+    const bool v = i < n;
+    const double bs = v ? b[i] : 2.0;
+    const double rr = v ? r[i] : 0.1;
+    const double sg = bs < 0.0 ? -1.0 : 1.0;
+    exo::SV o;
+    exo::quad_sv<GRAD>(fabs(bs), rr, o);
+    if (v) {
+      s[3 * i] = o.s0; s[3 * i + 1] = o.s1; s[3 * i + 2] = o.s2;
+      if (GRAD) {
+        dsdb[3 * i] = sg * o.db0; dsdb[3 * i + 1] = sg * o.db1; dsdb[3 * i + 2] = sg * o.db2;
+        dsdr[3 * i] = o.dr0; dsdr[3 * i + 1] = o.dr1; dsdr[3 * i + 2] = o.dr2;
+      }
+    }
+  }
+}
+
+// Contact points: roots of rho(f)^2 (1 - sin^2 i sin^2(omega+f)) = L^2 nearest
+// the transit centre, by a coarse outward scan for the bracket + bisection on
+// the definition.  O(planets) work, one element per lane.
+__device__ __forceinline__ double contact_g(double th, double p, double e, double cw, double sw,
+                                            double ci, double L) {
+  double st, ct;
+  sincos(th, &st, &ct);
+  const double cosf = sw * ct - cw * st;  // th = omega + f - pi/2
+  const double rho = p / (1.0 + e * cosf);
+  return rho * rho * (st * st + ci * ci * ct * ct) - L * L;
+}
+
+__global__ __launch_bounds__(64) void contact_points_kernel(
+    const double* __restrict__ a, const double* __restrict__ e_, const double* __restrict__ cosw,
+    const double* __restrict__ sinw, const double* __restrict__ cosi, const double* __restrict__ sini,
+    const double* __restrict__ L_, double* __restrict__ Ml, double* __restrict__ Mr,
+    int32_t* __restrict__ flag, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  if (i >= n) return;
+  const double e = e_[i], cw = cosw[i], sw = sinw[i], ci = cosi[i], L = L_[i];
+  (void)sini;
+  const double p = a[i] * (1.0 - e * e);
+  double out[2] = {0.0, 0.0};
+  int bad = !(contact_g(0.0, p, e, cw, sw, ci, L) < 0.0);
+  for (int side = 0; side < 2 && !bad; ++side) {
+    const double sgn = side == 0 ? -1.0 : 1.0;
+    double lo = 0.0, hi = 0.0;
+    bool found = false;
+    for (int k = 1; k <= 32; ++k) {
+      const double th = sgn * k * (exo::kHalfPi / 32.0);
+      if (contact_g(th, p, e, cw, sw, ci, L) > 0.0) { hi = th; found = true; break; }
+      lo = th;
+    }
+    if (!found) { bad = 1; break; }
+    for (int it = 0; it < 80; ++it) {
+      const double mid = 0.5 * (lo + hi);
+      if (contact_g(mid, p, e, cw, sw, ci, L) > 0.0) hi = mid; else lo = mid;
+    }
+    const double th = 0.5 * (lo + hi);
+    const double f = th + exo::kHalfPi - atan2(sw, cw);
+    double shf, chf;
+    sincos(0.5 * f, &shf, &chf);
+    const double E = 2.0 * atan2(sqrt(1.0 - e) * shf, sqrt(1.0 + e) * chf);
+    out[side] = E - e * sin(E);
+  }
+  Ml[i] = bad ? 0.0 : out[0];
+  Mr[i] = bad ? 0.0 : out[1];
+  flag[i] = bad;
+}
+
+inline int launch_status() { return hipGetLastError() == hipSuccess ? EXO_OK : EXO_ERR_LAUNCH; }
+
+inline int elementwise_grid(int64_t n) {
+  const int64_t want = (n + kBlock - 1) / kBlock;
+  return (int)(want < 1 ? 1 : (want > 256 * 8 ? 256 * 8 : want));  // 8 blocks per CU, grid-stride the rest
+}
+
+inline bool transit_args_ok(int64_t n_cad, int64_t n_texp, int32_t n_sub, int64_t n_draw, int32_t n_planet) {
+  return n_cad >= 0 && n_draw >= 0 && n_draw <= 65535 && n_planet >= 1 && n_planet <= EXO_MAX_PLANETS &&
+         n_sub >= 1 && n_sub <= EXO_MAX_SUBEXP && (n_texp == 0 || n_texp == 1 || n_texp == n_cad);
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t exo_abi_version(void) { return 1; }
+
+int exo_kepler_f64(const double* M, const double* ecc, double* sinf, double* cosf, int64_t n, void* stream) {
+  if (n < 0 || (n > 0 && (!M || !ecc || !sinf || !cosf))) return EXO_ERR_INVALID_ARGUMENT;
+  if (n == 0) return EXO_OK;
+  hipLaunchKernelGGL(kepler_kernel, dim3(elementwise_grid(n)), dim3(kBlock), 0, (hipStream_t)stream, M, ecc,
+                     sinf, cosf, n);
+  return launch_status();
+}
+
+int exo_quad_solution_vector_f64(const double* b, const double* r, double* s, double* dsdb, double* dsdr,
+                                 int64_t n, void* stream) {
+  if (n < 0 || (n > 0 && (!b || !r || !s)) || ((dsdb == nullptr) != (dsdr == nullptr)))
+    return EXO_ERR_INVALID_ARGUMENT;
+  if (n == 0) return EXO_OK;
+  const dim3 grid(elementwise_grid(n)), block(kBlock);
+  if (dsdb)
+    hipLaunchKernelGGL(quad_sv_kernel<true>, grid, block, 0, (hipStream_t)stream, b, r, s, dsdb, dsdr, n);
+  else
+    hipLaunchKernelGGL(quad_sv_kernel<false>, grid, block, 0, (hipStream_t)stream, b, r, s, dsdb, dsdr, n);
+  return launch_status();
+}
+
+int exo_contact_points_f64(const double* a, const double* e, const double* cosw, const double* sinw,
+                           const double* cosi, const double* sini, const double* L, double* M_left,
+                           double* M_right, int32_t* flag, int64_t n, void* stream) {
+  if (n < 0 || (n > 0 && (!a || !e || !cosw || !sinw || !cosi || !sini || !L || !M_left || !M_right || !flag)))
+    return EXO_ERR_INVALID_ARGUMENT;
+  if (n == 0) return EXO_OK;
+  hipLaunchKernelGGL(contact_points_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, (hipStream_t)stream,
+                     a, e, cosw, sinw, cosi, sini, L, M_left, M_right, flag, n);
+  return launch_status();
+}
+
+int exo_transit_flux_fwd_f64(const double* t, int64_t n_cad, const double* texp, int64_t n_texp,
+                             const double* stencil_dt, const double* stencil_w, int32_t n_sub,
+                             const double* params, const double* ld, int64_t n_draw, int32_t n_planet,
+                             uint32_t flags, double* flux, void* stream) {
+  if (!transit_args_ok(n_cad, n_texp, n_sub, n_draw, n_planet)) return EXO_ERR_INVALID_ARGUMENT;
+  if (n_cad == 0 || n_draw == 0) return EXO_OK;
+  if (!t || !params || !ld || !flux || (n_texp > 0 && (!texp || !stencil_dt || !stencil_w)))
+    return EXO_ERR_INVALID_ARGUMENT;
+  const dim3 grid((unsigned)((n_cad + kTile - 1) / kTile), (unsigned)n_draw), block(kBlock);
+  if (flags & EXO_FLAG_SECONDARY)
+    hipLaunchKernelGGL(transit_fwd_kernel<true>, grid, block, 0, (hipStream_t)stream, t, n_cad, texp, n_texp,
+                       stencil_dt, stencil_w, n_sub, params, ld, n_planet, flags, flux);
+  else
+    hipLaunchKernelGGL(transit_fwd_kernel<false>, grid, block, 0, (hipStream_t)stream, t, n_cad, texp, n_texp,
+                       stencil_dt, stencil_w, n_sub, params, ld, n_planet, flags, flux);
+  return launch_status();
+}
+
+int64_t exo_transit_flux_vjp_workspace_bytes(int64_t n_cad, int64_t n_draw, int32_t n_planet) {
+  if (n_cad < 0 || n_draw < 0 || n_planet < 1) return -1;
+  const int64_t nblk = (n_cad + kTile - 1) / kTile;
+  return nblk * n_draw * (int64_t)(n_planet * kNG + 6) * (int64_t)sizeof(double);
+}
+
+int exo_transit_flux_vjp_f64(const double* t, int64_t n_cad, const double* texp, int64_t n_texp,
+                             const double* stencil_dt, const double* stencil_w, int32_t n_sub,
+                             const double* params, const double* ld, int64_t n_draw, int32_t n_planet,
+                             uint32_t flags, const double* gflux, double* flux_out, double* gparams,
+                             double* gld, void* workspace, int64_t workspace_bytes, void* stream) {
+  if (!transit_args_ok(n_cad, n_texp, n_sub, n_draw, n_planet)) return EXO_ERR_INVALID_ARGUMENT;
+  if (n_draw == 0) return EXO_OK;
+  if (!params || !ld || !gparams || !gld || (n_cad > 0 && (!t || !gflux)) ||
+      (n_texp > 0 && (!texp || !stencil_dt || !stencil_w)))
+    return EXO_ERR_INVALID_ARGUMENT;
+  const bool secondary = flags & EXO_FLAG_SECONDARY;
+  hipStream_t st = (hipStream_t)stream;
+  // gradient slots that no kernel writes (SINI, T0, PERIOD, windows) must read 0
+  if (hipMemsetAsync(gparams, 0, sizeof(double) * n_draw * n_planet * EXO_NPAR, st) != hipSuccess)
+    return EXO_ERR_LAUNCH;
+  if (n_cad == 0) {
+    return hipMemsetAsync(gld, 0, sizeof(double) * n_draw * (secondary ? 6 : 3), st) == hipSuccess
+               ? EXO_OK : EXO_ERR_LAUNCH;
+  }
+  if (n_planet * kNG + 6 > kBlock) return EXO_ERR_INVALID_ARGUMENT;
+  const int64_t need = exo_transit_flux_vjp_workspace_bytes(n_cad, n_draw, n_planet);
+  if (!workspace || workspace_bytes < need) return EXO_ERR_WORKSPACE;
+  const int nblk = (int)((n_cad + kTile - 1) / kTile);
+  const dim3 grid((unsigned)nblk, (unsigned)n_draw), block(kBlock);
+  double* partial = (double*)workspace;
+  if (secondary)
+    hipLaunchKernelGGL(transit_vjp_kernel<true>, grid, block, 0, st, t, n_cad, texp, n_texp, stencil_dt,
+                       stencil_w, n_sub, params, ld, n_planet, flags, gflux, flux_out, partial);
+  else
+    hipLaunchKernelGGL(transit_vjp_kernel<false>, grid, block, 0, st, t, n_cad, texp, n_texp, stencil_dt,
+                       stencil_w, n_sub, params, ld, n_planet, flags, gflux, flux_out, partial);
+  if (launch_status() != EXO_OK) return EXO_ERR_LAUNCH;
+  hipLaunchKernelGGL(transit_vjp_reduce_kernel, dim3((unsigned)n_draw), dim3(kBlock), 0, st, partial, nblk,
+                     n_planet, secondary, gparams, gld);
+  return launch_status();
+}
+
+}  // extern "C"

@@ -1,0 +1,241 @@
+"""Device ops behind the reference's ``exoplanet.compat.ops`` names.
+
+Drop-in for the three callables the reference imports from exoplanet_core
+(/root/reference/src/exoplanet/compat.py:27,56):
+
+    ops.kepler(M, ecc) -> (sinf, cosf)                 keplerian.py:333,818
+    ops.quad_solution_vector(b, r) -> s[..., 3]        limb_dark.py:24
+    ops.contact_points(a, e, cosw, sinw, cosi, sini, L)
+        -> (M_left, M_right, flag)                     keplerian.py:744-753
+
+plus the fused op that replaces the whole elementwise graph between the time
+array and the flux array (``transit_flux``).  All take float64 ROCm tensors and
+run hand-written HIP kernels through the C ABI (include/exoplanet_amd.h); each
+has value + gradient (torch.autograd).  There is no CPU / eager fallback.
+"""
+import torch
+
+from . import _lib
+
+NPAR = 16
+(P_N, P_TP, P_ECC, P_COSW, P_SINW, P_COSI, P_SINI, P_AOR, P_ROR, P_T0, P_PERIOD, P_TS, P_TE,
+ P_FRATIO, P_TS2, P_TE2) = range(16)
+FLAG_PER_PLANET = 1
+FLAG_WINDOW = 2
+FLAG_SECONDARY = 4
+MAX_PLANETS = 16
+MAX_SUBEXP = 63
+
+
+def _stream(t):
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _dev(x, name):
+    if not isinstance(x, torch.Tensor):
+        raise TypeError(f"{name} must be a torch.Tensor")
+    if not x.is_cuda:
+        raise RuntimeError(
+            f"{name} lives on {x.device}: exoplanet_amd ops run only on a ROCm device "
+            "(HIP kernels through libexoplanet_amd.so); there is no CPU fallback"
+        )
+    if x.dtype != torch.float64:
+        raise TypeError(f"{name} must be float64 (the reference casts everything to float64, utils.py:18)")
+    return x.contiguous()
+
+
+def _ptr(x):
+    return 0 if x is None else x.data_ptr()
+
+
+# ------------------------------------------------------------------------------
+# kepler
+# ------------------------------------------------------------------------------
+class _Kepler(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, M, ecc):
+        M = _dev(M, "M")
+        ecc = _dev(ecc, "ecc")
+        if M.shape != ecc.shape:
+            raise ValueError("kepler: M and ecc must have the same shape (the caller broadcasts, keplerian.py:333)")
+        sinf = torch.empty_like(M)
+        cosf = torch.empty_like(M)
+        lib = _lib.load()
+        with torch.cuda.device(M.device):
+            _lib.check(lib.exo_kepler_f64(_ptr(M), _ptr(ecc), _ptr(sinf), _ptr(cosf), M.numel(), _stream(M)),
+                       "exo_kepler_f64")
+        ctx.save_for_backward(sinf, cosf, ecc)
+        return sinf, cosf
+
+    @staticmethod
+    def backward(ctx, gs, gc):
+        sinf, cosf, e = ctx.saved_tensors
+        # df/dM = (1+e cosf)^2/(1-e^2)^{3/2},  df/de = (2+e cosf) sinf/(1-e^2)
+        ome2 = 1 - e * e
+        gf = gs * cosf - gc * sinf
+        dfdM = (1 + e * cosf) ** 2 / ome2 ** 1.5
+        dfde = (2 + e * cosf) * sinf / ome2
+        return gf * dfdM, gf * dfde
+
+
+def kepler(M, ecc):
+    """sin and cos of the true anomaly; same shape as ``M`` (= shape of ``ecc``)."""
+    return _Kepler.apply(M, ecc)
+
+
+# ------------------------------------------------------------------------------
+# quad_solution_vector
+# ------------------------------------------------------------------------------
+class _QuadSV(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, b, r):
+        b = _dev(b, "b")
+        r = _dev(r, "r")
+        if b.shape != r.shape:
+            raise ValueError("quad_solution_vector: b and r must have the same shape")
+        need = b.requires_grad or r.requires_grad
+        s = torch.empty(b.shape + (3,), dtype=torch.float64, device=b.device)
+        dsdb = torch.empty_like(s) if need else None
+        dsdr = torch.empty_like(s) if need else None
+        lib = _lib.load()
+        with torch.cuda.device(b.device):
+            _lib.check(
+                lib.exo_quad_solution_vector_f64(_ptr(b), _ptr(r), _ptr(s), _ptr(dsdb), _ptr(dsdr), b.numel(),
+                                                 _stream(b)),
+                "exo_quad_solution_vector_f64",
+            )
+        if need:
+            ctx.save_for_backward(dsdb, dsdr)
+        return s
+
+    @staticmethod
+    def backward(ctx, gs):
+        dsdb, dsdr = ctx.saved_tensors
+        return (gs * dsdb).sum(-1), (gs * dsdr).sum(-1)
+
+
+def quad_solution_vector(b, r):
+    """s[..., 3] for separations ``b`` (|b| is used) and radius ratios ``r``."""
+    return _QuadSV.apply(b, r)
+
+
+# ------------------------------------------------------------------------------
+# contact_points (no gradient: it only selects cadences, keplerian.py:769-775)
+# ------------------------------------------------------------------------------
+@torch.no_grad()
+def contact_points(a, e, cosw, sinw, cosi, sini, L):
+    args = torch.broadcast_tensors(*[x.detach() for x in (a, e, cosw, sinw, cosi, sini, L)])
+    args = [_dev(x, n) for x, n in zip(args, ("a", "e", "cosw", "sinw", "cosi", "sini", "L"))]
+    ref = args[0]
+    Ml = torch.empty_like(ref)
+    Mr = torch.empty_like(ref)
+    flag = torch.empty(ref.shape, dtype=torch.int32, device=ref.device)
+    lib = _lib.load()
+    with torch.cuda.device(ref.device):
+        _lib.check(
+            lib.exo_contact_points_f64(*[_ptr(x) for x in args], _ptr(Ml), _ptr(Mr), _ptr(flag), ref.numel(),
+                                       _stream(ref)),
+            "exo_contact_points_f64",
+        )
+    return Ml, Mr, flag
+
+
+# ------------------------------------------------------------------------------
+# fused transit flux
+# ------------------------------------------------------------------------------
+def _transit_args(t, texp, stencil_dt, stencil_w, params, ld, flags):
+    t = _dev(t, "t")
+    params = _dev(params, "params")
+    ld = _dev(ld, "ld")
+    if t.dim() != 1:
+        raise ValueError("t must be 1-D (n_cad,)")
+    if params.dim() != 3 or params.shape[-1] != NPAR:
+        raise ValueError(f"params must be (n_draw, n_planet, {NPAR})")
+    D, P, _ = params.shape
+    nld = 6 if flags & FLAG_SECONDARY else 3
+    if ld.shape != (D, nld):
+        raise ValueError(f"ld must be (n_draw, {nld})")
+    if not 1 <= P <= MAX_PLANETS:
+        raise ValueError(f"1 <= n_planet <= {MAX_PLANETS}")
+    if texp is None:
+        n_texp, n_sub = 0, 1
+        stencil_dt = stencil_w = None
+    else:
+        texp = _dev(texp, "texp").reshape(-1)
+        stencil_dt = _dev(stencil_dt, "stencil_dt")
+        stencil_w = _dev(stencil_w, "stencil_w")
+        n_texp, n_sub = texp.numel(), stencil_dt.numel()
+        if n_texp not in (1, t.numel()):
+            raise ValueError("texp must be a scalar or have one entry per cadence")
+        if stencil_w.numel() != n_sub or not 1 <= n_sub <= MAX_SUBEXP:
+            raise ValueError(f"stencil must have 1..{MAX_SUBEXP} points")
+    return t, texp, n_texp, stencil_dt, stencil_w, n_sub, params, ld, D, P
+
+
+class _TransitFlux(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, t, texp, stencil_dt, stencil_w, params, ld, flags):
+        t, texp, n_texp, sdt, sw, n_sub, params, ld, D, P = _transit_args(
+            t, texp, stencil_dt, stencil_w, params, ld, flags)
+        N = t.numel()
+        shape = (D, N, P) if flags & FLAG_PER_PLANET else (D, N)
+        flux = torch.empty(shape, dtype=torch.float64, device=t.device)
+        lib = _lib.load()
+        with torch.cuda.device(t.device):
+            _lib.check(
+                lib.exo_transit_flux_fwd_f64(_ptr(t), N, _ptr(texp), n_texp, _ptr(sdt), _ptr(sw), n_sub,
+                                             _ptr(params), _ptr(ld), D, P, flags, _ptr(flux), _stream(t)),
+                "exo_transit_flux_fwd_f64",
+            )
+        ctx.save_for_backward(t, texp, sdt, sw, params, ld)
+        ctx.meta = (n_texp, n_sub, D, P, flags)
+        return flux
+
+    @staticmethod
+    def backward(ctx, gflux):
+        t, texp, sdt, sw, params, ld = ctx.saved_tensors
+        n_texp, n_sub, D, P, flags = ctx.meta
+        _, gparams, gld = _vjp(t, texp, n_texp, sdt, sw, n_sub, params, ld, D, P, flags, gflux, False)
+        return None, None, None, None, gparams, gld, None
+
+
+def _vjp(t, texp, n_texp, sdt, sw, n_sub, params, ld, D, P, flags, gflux, want_flux):
+    N = t.numel()
+    gflux = _dev(gflux, "gflux")
+    shape = (D, N, P) if flags & FLAG_PER_PLANET else (D, N)
+    if tuple(gflux.shape) != shape:
+        raise ValueError(f"gflux must have shape {shape}")
+    lib = _lib.load()
+    nbytes = lib.exo_transit_flux_vjp_workspace_bytes(N, D, P)
+    ws = torch.empty(max(nbytes // 8, 1), dtype=torch.float64, device=t.device)
+    gparams = torch.empty_like(params)
+    gld = torch.empty_like(ld)
+    flux = torch.empty(shape, dtype=torch.float64, device=t.device) if want_flux else None
+    with torch.cuda.device(t.device):
+        _lib.check(
+            lib.exo_transit_flux_vjp_f64(_ptr(t), N, _ptr(texp), n_texp, _ptr(sdt), _ptr(sw), n_sub, _ptr(params),
+                                         _ptr(ld), D, P, flags, _ptr(gflux), _ptr(flux), _ptr(gparams), _ptr(gld),
+                                         _ptr(ws), nbytes, _stream(t)),
+            "exo_transit_flux_vjp_f64",
+        )
+    return flux, gparams, gld
+
+
+def transit_flux(t, params, ld, texp=None, stencil_dt=None, stencil_w=None, flags=0):
+    """Fused light curve for ``n_draw`` parameter sets.
+
+    t (n_cad,), params (n_draw, n_planet, 16) (slot meaning: include/exoplanet_amd.h),
+    ld (n_draw, 3|6).  Returns (n_draw, n_cad) or, with FLAG_PER_PLANET,
+    (n_draw, n_cad, n_planet).  Differentiable w.r.t. ``params`` and ``ld``.
+    """
+    return _TransitFlux.apply(t, texp, stencil_dt, stencil_w, params, ld, int(flags))
+
+
+@torch.no_grad()
+def transit_flux_value_and_vjp(t, params, ld, gflux, texp=None, stencil_dt=None, stencil_w=None, flags=0):
+    """One sweep over t: flux AND the cotangents of (params, ld) for a given
+    ``gflux`` -- 24 B per (draw, cadence).  Returns (flux, gparams, gld)."""
+    flags = int(flags)
+    t, texp, n_texp, sdt, sw, n_sub, params, ld, D, P = _transit_args(t, texp, stencil_dt, stencil_w, params, ld,
+                                                                      flags)
+    return _vjp(t, texp, n_texp, sdt, sw, n_sub, params, ld, D, P, flags, gflux, True)

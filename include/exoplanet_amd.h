@@ -1,0 +1,138 @@
+/* exoplanet_amd.h -- C ABI of libexoplanet_amd.so (MI355X / gfx950).
+ *
+ * Drop-in boundary for the per-leapfrog-step log-likelihood hot path of
+ * exoplanet-dev/exoplanet.  Every entry point replaces one third-party Op that
+ * the reference reaches through `exoplanet.compat.ops`
+ * (/root/reference/src/exoplanet/compat.py:27,56) or through celerite2, or one
+ * block of elementwise PyTensor graph between those Ops.  The binding a
+ * maintainer would add on the reference side is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - all pointers are DEVICE pointers (HBM), float64, C-contiguous;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream);
+ *     calls are asynchronous and stream-ordered, nothing is allocated inside;
+ *   - return value: 0 = launched, EXO_ERR_* otherwise (no exceptions cross the
+ *     boundary); numeric failure is in-band (NaN in -> NaN out, `flag` words);
+ *   - the library keeps no global state: re-entrant, one process per GPU.
+ */
+#ifndef EXOPLANET_AMD_H
+#define EXOPLANET_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EXO_OK 0
+#define EXO_ERR_INVALID_ARGUMENT 1
+#define EXO_ERR_LAUNCH 2
+#define EXO_ERR_WORKSPACE 3
+
+/* ABI version, bumped whenever a signature or a layout below changes. */
+int32_t exo_abi_version(void);
+
+/* ---------------------------------------------------------------------------
+ * ops.kepler(M, ecc) -> (sinf, cosf)
+ * replaces exoplanet_core's Kepler Op; reference call sites
+ *   src/exoplanet/orbits/keplerian.py:333  (ecc pre-broadcast to M's shape)
+ *   src/exoplanet/orbits/keplerian.py:818
+ * ecc outside [0,1) -> NaN (docstring keplerian.py:58).
+ * ------------------------------------------------------------------------- */
+int exo_kepler_f64(const double* M, const double* ecc, double* sinf, double* cosf,
+                   int64_t n, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * ops.quad_solution_vector(b, r) -> s[..., 3]   (+ ds/db, ds/dr, nullable)
+ * replaces exoplanet_core's quad_solution_vector Op; reference call site
+ *   src/exoplanet/light_curves/limb_dark.py:24
+ * Takes |b| (tests/light_curves_test.py:24-27 feed b < 0); dsdb carries sign(b).
+ * s, dsdb, dsdr are [n][3].  Pass dsdb = dsdr = NULL for value only.
+ * ------------------------------------------------------------------------- */
+int exo_quad_solution_vector_f64(const double* b, const double* r, double* s,
+                                 double* dsdb, double* dsdr, int64_t n, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * ops.contact_points(a, e, cosw, sinw, cosi, sini, L) -> (M_left, M_right, flag)
+ * replaces exoplanet_core's contact_points Op; reference call site
+ *   src/exoplanet/orbits/keplerian.py:744-753
+ * flag != 0 means "no contact found"; the caller then evaluates every cadence
+ * (keplerian.py:771-775).
+ * ------------------------------------------------------------------------- */
+int exo_contact_points_f64(const double* a, const double* e, const double* cosw,
+                           const double* sinw, const double* cosi, const double* sini,
+                           const double* L, double* M_left, double* M_right,
+                           int32_t* flag, int64_t n, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * Fused transit flux: everything between the time array and the flux array of
+ *   LimbDarkLightCurve.get_light_curve   (src/exoplanet/light_curves/limb_dark.py:99-232)
+ *   KeplerianOrbit._get_true_anomaly / _get_position / _rotate_vector
+ *                                        (src/exoplanet/orbits/keplerian.py:283-334,380-409)
+ *   KeplerianOrbit.in_transit mask       (keplerian.py:729-731,765-769)
+ *   SecondaryEclipseLightCurve blend     (src/exoplanet/light_curves/secondary_eclipse.py:45-70)
+ * for `n_draw` independent parameter sets (posterior draws / chains) at once.
+ *
+ * Per-(draw, planet) parameter record, EXO_NPAR doubles, all lengths in units
+ * of the stellar radius (the O(P) algebra that produces them stays on the host
+ * side, in autograd):
+ * ------------------------------------------------------------------------- */
+#define EXO_NPAR 16
+#define EXO_P_N 0       /* mean motion 2 pi / period            keplerian.py:146     */
+#define EXO_P_TP 1      /* t_periastron = t0 - M0/n             keplerian.py:277     */
+#define EXO_P_ECC 2     /* eccentricity (0 for ecc=None)                              */
+#define EXO_P_COSW 3    /* cos(omega)   (1 for ecc=None)        keplerian.py:303-308 */
+#define EXO_P_SINW 4    /* sin(omega)   (0 for ecc=None)                              */
+#define EXO_P_COSI 5    /* cos(incl)                            keplerian.py:227,312 */
+#define EXO_P_SINI 6    /* sin(incl)  (only its sign is used: los > 0 test)          */
+#define EXO_P_AOR 7     /* a / R_star                                                 */
+#define EXO_P_ROR 8     /* r_planet / R_star                                          */
+#define EXO_P_T0 9      /* reference transit time (window phase) keplerian.py:731    */
+#define EXO_P_PERIOD 10 /* period                                                     */
+#define EXO_P_TS 11     /* first contact  - t0 (<= 0), without texp keplerian.py:755-762 */
+#define EXO_P_TE 12     /* fourth contact - t0 (>= 0)                                 */
+#define EXO_P_FRATIO 13 /* secondary: sbr * ror^2                secondary_eclipse.py:68 */
+#define EXO_P_TS2 14    /* secondary-eclipse window start - t0 (may exceed +-P/2)    */
+#define EXO_P_TE2 15    /* secondary-eclipse window end   - t0                        */
+
+/* flags */
+#define EXO_FLAG_PER_PLANET 1u /* flux is [n_draw][n_cad][n_planet] instead of summed [n_draw][n_cad] */
+#define EXO_FLAG_WINDOW 2u     /* skip cadences outside [TS,TE] (+- texp/2): use_in_transit semantics */
+#define EXO_FLAG_SECONDARY 4u  /* also evaluate the occultation of the planet; ld is [n_draw][6]      */
+
+#define EXO_MAX_PLANETS 16
+#define EXO_MAX_SUBEXP 63
+
+/* Forward.
+ *   t          [n_cad]                  shared by all draws
+ *   texp       NULL (n_texp = 0), scalar (n_texp = 1) or per cadence (n_texp = n_cad)
+ *   stencil_dt [n_sub], stencil_w [n_sub]   exposure stencil in units of texp
+ *                                       (limb_dark.py:181-197); n_sub = 1 if no texp
+ *   params     [n_draw][n_planet][EXO_NPAR]
+ *   ld         [n_draw][3] Green's-basis coefficients c of get_cl (limb_dark.py:11-18),
+ *              or [n_draw][6] = primary c then secondary c with EXO_FLAG_SECONDARY
+ *   flux       out, see EXO_FLAG_PER_PLANET                                        */
+int exo_transit_flux_fwd_f64(const double* t, int64_t n_cad, const double* texp, int64_t n_texp,
+                             const double* stencil_dt, const double* stencil_w, int32_t n_sub,
+                             const double* params, const double* ld, int64_t n_draw,
+                             int32_t n_planet, uint32_t flags, double* flux, void* stream);
+
+/* Bytes of scratch the reverse pass needs (deterministic two-stage reduction). */
+int64_t exo_transit_flux_vjp_workspace_bytes(int64_t n_cad, int64_t n_draw, int32_t n_planet);
+
+/* Reverse (recompute-forward): given gflux (same shape as flux) accumulate
+ *   gparams [n_draw][n_planet][EXO_NPAR]  (slots SINI, T0, PERIOD, TS.. are 0)
+ *   gld     [n_draw][3 or 6]
+ * and, if flux_out != NULL, also write the forward value in the same pass
+ * (value + gradient in one sweep over t: 24 B per (draw, cadence)).           */
+int exo_transit_flux_vjp_f64(const double* t, int64_t n_cad, const double* texp, int64_t n_texp,
+                             const double* stencil_dt, const double* stencil_w, int32_t n_sub,
+                             const double* params, const double* ld, int64_t n_draw,
+                             int32_t n_planet, uint32_t flags, const double* gflux,
+                             double* flux_out, double* gparams, double* gld, void* workspace,
+                             int64_t workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EXOPLANET_AMD_H */

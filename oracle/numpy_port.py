@@ -19,6 +19,11 @@ c_light = 37231.66360672704
 
 TWO_PI_HI = 6.283185307179586
 TWO_PI_LO = 2.4492935982947064e-16
+# three-part split of 2 pi (30 + 30 + 53 bits): k * C1 and k * C2 are exact in
+# float64 for |k| < 2^23, which stands in for the fused multiply-add numpy lacks
+TWO_PI_C1 = 6.283185303211212
+TWO_PI_C2 = 3.9683743166540886e-09
+TWO_PI_C3 = 2.068073192717642e-18
 
 
 # =============================================================================
@@ -41,9 +46,9 @@ def kepler_E(M, e):
     + one fifth-order correction (fixed cost, no iteration).  M any real."""
     M = np.asarray(M, dtype=np.float64)
     e = np.asarray(e, dtype=np.float64) + np.zeros_like(M)
-    # two-term Cody-Waite reduction of M to [-pi, pi]
+    # Cody-Waite reduction of M to [-pi, pi] with exact partial products
     k = np.rint(M / TWO_PI_HI)
-    Mr = (M - k * TWO_PI_HI) - k * TWO_PI_LO
+    Mr = ((M - k * TWO_PI_C1) - k * TWO_PI_C2) - k * TWO_PI_C3
     sgn = np.where(Mr < 0, -1.0, 1.0)
     Mr = np.abs(Mr)
     ome = 1.0 - e
@@ -678,3 +683,179 @@ class SecondaryEclipseLightCurve:
         k = r / orbit.r_star
         flux_ratio = self.surface_brightness_ratio * k ** 2
         return (lc1 + flux_ratio * lc2) / (1 + flux_ratio)
+
+
+# =============================================================================
+# Record-level restatement of the fused kernel's contract (include/exoplanet_amd.h)
+# built from the pieces above; forward-mode Jacobian (the kernel is reverse-mode,
+# so the two derivations are independent).
+# =============================================================================
+NPAR = 16
+(P_N, P_TP, P_ECC, P_COSW, P_SINW, P_COSI, P_SINI, P_AOR, P_ROR, P_T0, P_PERIOD, P_TS, P_TE,
+ P_FRATIO, P_TS2, P_TE2) = range(16)
+GRAD_SLOTS = (P_N, P_TP, P_ECC, P_COSW, P_SINW, P_COSI, P_AOR, P_ROR, P_FRATIO)
+
+
+def exposure_stencil(oversample=7, order=0):
+    """reference: limb_dark.py:181-197 -> (dt, weights) in units of texp"""
+    oversample = int(oversample)
+    oversample += 1 - oversample % 2
+    w = np.ones(oversample)
+    if order == 0:
+        dt = np.linspace(-0.5, 0.5, 2 * oversample + 1)[1:-1:2]
+    elif order == 1:
+        dt = np.linspace(-0.5, 0.5, oversample)
+        w[1:-1] = 2
+    elif order == 2:
+        dt = np.linspace(-0.5, 0.5, oversample)
+        w[1:-1:2] = 4
+        w[2:-1:2] = 2
+    else:
+        raise ValueError("order must be <= 2")
+    return dt, w / np.sum(w)
+
+
+def _window_mask(t, rec, htexp, secondary):
+    hp = 0.5 * rec[P_PERIOD]
+    dt = np.mod(t - rec[P_T0] + hp, rec[P_PERIOD]) - hp
+    m = (dt >= rec[P_TS] - htexp) & (dt <= rec[P_TE] + htexp)
+    if secondary:
+        y = np.mod(t - rec[P_T0], rec[P_PERIOD])
+        m |= (y >= rec[P_TS2] - htexp) & (y <= rec[P_TE2] + htexp)
+    return m
+
+
+def _sample(tt, rec, c, secondary, jac):
+    """flux of one planet at times tt (any shape) -> F, and if jac: dict slot->dF, dF/dc (..,3|6)."""
+    n, tp, e = rec[P_N], rec[P_TP], rec[P_ECC]
+    cw, sw, ci, si, aor, ror, fr = (rec[P_COSW], rec[P_SINW], rec[P_COSI], rec[P_SINI], rec[P_AOR],
+                                    rec[P_ROR], rec[P_FRATIO])
+    M = (tt - tp) * n
+    sinf, cosf = kepler(M, e + np.zeros_like(M))
+    den = 1 + e * cosf
+    rho = -aor * (1 - e * e) / den
+    xo, yo = rho * cosf, rho * sinf
+    x1 = cw * xo - sw * yo
+    y1 = sw * xo + cw * yo
+    Ys = ci * y1
+    Z = -si * y1
+    b = np.sqrt(x1 * x1 + Ys * Ys)
+    front = Z > 0
+    behind = secondary & (Z < 0)
+    occ = behind
+    bq = np.where(occ, b / ror, b)
+    rq = np.where(occ, 1.0 / ror, ror) + np.zeros_like(b)
+    s, dsdb, dsdr = quad_solution_vector(bq, rq)
+    cc = np.where(occ[..., None], c[3:6] if secondary else c[:3], c[:3])
+    Fq = np.sum(s * cc, axis=-1) - 1.0
+    act = front | behind
+    if secondary:
+        wq = np.where(occ, fr / (1 + fr), 1 / (1 + fr))
+    else:
+        wq = 1.0
+    F = np.where(act, Fq * wq, 0.0)
+    if not jac:
+        return F, None, None
+    dFq_db = np.sum(dsdb * cc, axis=-1)
+    dFq_dr = np.sum(dsdr * cc, axis=-1)
+    dfdM, dfde = kepler_grad(sinf, cosf, e)
+    with np.errstate(all="ignore"):
+        ib = np.where(b > 0, 1.0 / b, 0.0)
+
+    def chain(dxo, dyo, dcw=0.0, dsw=0.0, dci=0.0):
+        dx1 = cw * dxo - sw * dyo + dcw * xo - dsw * yo
+        dy1 = sw * dxo + cw * dyo + dsw * xo + dcw * yo
+        dYs = ci * dy1 + dci * y1
+        return (x1 * dx1 + Ys * dYs) * ib
+
+    drho_df = rho * e * sinf / den
+    dxo_df = drho_df * cosf - rho * sinf
+    dyo_df = drho_df * sinf + rho * cosf
+    db_df = chain(dxo_df, dyo_df)
+    drho_de = rho * (-2 * e / (1 - e * e) - cosf / den)
+    db = {
+        P_N: db_df * dfdM * (tt - tp),
+        P_TP: db_df * dfdM * (-n),
+        P_ECC: db_df * dfde + chain(drho_de * cosf, drho_de * sinf),
+        P_COSW: chain(0.0, 0.0, dcw=1.0),
+        P_SINW: chain(0.0, 0.0, dsw=1.0),
+        P_COSI: chain(0.0, 0.0, dci=1.0),
+        P_AOR: b / aor,
+    }
+    scale_b = np.where(occ, 1.0 / ror, 1.0)  # d bq / d b
+    out = {}
+    for k, v in db.items():
+        out[k] = np.where(act, wq * dFq_db * scale_b * v, 0.0)
+    d_ror = np.where(occ, dFq_db * (-b / ror ** 2) + dFq_dr * (-1.0 / ror ** 2), dFq_dr)
+    out[P_ROR] = np.where(act, wq * d_ror, 0.0)
+    if secondary:
+        out[P_FRATIO] = np.where(act, np.where(occ, 1.0, -1.0) * Fq / (1 + fr) ** 2, 0.0)
+    else:
+        out[P_FRATIO] = np.zeros_like(F)
+    nld = 6 if secondary else 3
+    dc = np.zeros(F.shape + (nld,))
+    # Outside the overlap s = (pi, 2pi/3, 0) and s.c - 1 == 0 only because c is
+    # normalised (pi c0 + 2pi/3 c1 = 1, limb_dark.py:17-18).  The fused op DEFINES
+    # the flux as exactly 0 there, so those samples carry no c-cotangent; after
+    # the chain through get_cl both conventions give identical d/du.
+    overlap = act & (b < 1 + ror)
+    sw_ = np.where(overlap, wq, 0.0)[..., None] * s
+    if secondary:
+        dc[..., :3] = np.where(occ[..., None], 0.0, sw_)
+        dc[..., 3:] = np.where(occ[..., None], sw_, 0.0)
+    else:
+        dc[..., :3] = sw_
+    return F, out, dc
+
+
+def transit_flux(t, params, ld, texp=None, stencil_dt=None, stencil_w=None, per_planet=False, window=False,
+                 secondary=False, jac=False):
+    """flux [D,N] or [D,N,P]; with jac also J_params [D,N,(P),P,NPAR] is too big, so
+    returns a callable-free form: (flux, dF_dparams [D,P,NPAR,N(,only own planet)], dF_dld [D,N(,P),nld])."""
+    t = np.asarray(t, dtype=np.float64)
+    params = np.asarray(params, dtype=np.float64)
+    ld = np.asarray(ld, dtype=np.float64)
+    D, P, _ = params.shape
+    N = t.size
+    if texp is None:
+        sdt, sw_ = np.zeros(1), np.ones(1)
+        tex = np.zeros(N)
+    else:
+        sdt, sw_ = np.asarray(stencil_dt, dtype=np.float64), np.asarray(stencil_w, dtype=np.float64)
+        tex = np.asarray(texp, dtype=np.float64).reshape(-1) + np.zeros(N)
+    tgrid = t[:, None] + tex[:, None] * sdt[None, :]           # [N,K]
+    nld = 6 if secondary else 3
+    flux = np.zeros((D, N, P))
+    dpar = np.zeros((D, P, NPAR, N)) if jac else None           # d flux[d,:,p] / d params[d,p,slot]
+    dld = np.zeros((D, N, P, nld)) if jac else None
+    for d in range(D):
+        for p in range(P):
+            rec = params[d, p]
+            F, dF, dc = _sample(tgrid, rec, ld[d], secondary, jac)
+            if window:
+                m = _window_mask(t, rec, 0.5 * tex, secondary)
+            else:
+                m = np.ones(N, dtype=bool)
+            flux[d, :, p] = np.where(m, F @ sw_, 0.0)
+            if jac:
+                for k, v in dF.items():
+                    dpar[d, p, k] = np.where(m, v @ sw_, 0.0)
+                dld[d, :, p] = np.where(m[:, None], np.einsum("nkc,k->nc", dc, sw_), 0.0)
+    if not per_planet:
+        fl = flux.sum(axis=2)
+    else:
+        fl = flux
+    return (fl, dpar, dld) if jac else fl
+
+
+def transit_flux_vjp(t, params, ld, gflux, **kw):
+    """Cotangents (gparams [D,P,NPAR], gld [D,nld]) for gflux shaped like the flux."""
+    per_planet = kw.get("per_planet", False)
+    fl, dpar, dld = transit_flux(t, params, ld, jac=True, **kw)
+    D, P, _ = np.asarray(params).shape
+    g = np.asarray(gflux, dtype=np.float64)
+    if not per_planet:
+        g = np.repeat(g[:, :, None], P, axis=2)
+    gparams = np.einsum("dpkn,dnp->dpk", dpar, g)
+    gld = np.einsum("dnpc,dnp->dc", dld, g)
+    return fl, gparams, gld
