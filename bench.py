@@ -1,0 +1,272 @@
+#!/usr/bin/env python
+"""bench.py -- light-curve evaluations / s (value + gradient) at 150 000 cadences.
+
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it
+is launched under torch.distributed.run, one rank per GPU (RCCL).  Rank 0
+prints ONE JSON line.
+
+Workload = BASELINE.json configs[1] ("C2"): single planet, e = 0.3,
+omega = 1.1, P = 3.5 d, t0 = 1, b = 0.3, r = 0.1, (u1, u2) = (0.3, 0.2), 150 000
+two-minute cadences, EVERY cadence evaluated (use_in_transit=False, the
+roofline case), float64, cotangent gbar ~ N(0,1).  One *evaluation* = forward
+flux for all 150 000 cadences of one posterior draw + the VJP of gbar back to
+all orbit / limb-darkening parameters.  One *step* = one pass of the hot path
+over a batch of `--draws-per-gpu` draws (base parameters x (1 + 1e-3 N(0,1))):
+leaf parameters -> KeplerianOrbit algebra (torch) -> fused HIP kernel (value +
+VJP in one sweep) -> autograd back to the leaves; with N > 1 ranks each own
+their draws (weak scaling) and exchange only the per-draw scalar sum(gbar*flux)
+by one all-reduce.  Inputs are resident in HBM before the timed region.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+N_CAD = 150_000
+CADENCE = 2.0 / 1440.0
+ALG_BYTES_PER_UNIT = 24          # read t 8 + read gbar 8 + write flux 8 per (draw, cadence), SURVEY.md 8d
+HBM_PEAK_GBS = 8000.0            # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def hip_runtime():
+    for name in ("libamdhip64.so", "libamdhip64.so.7", "libamdhip64.so.6"):
+        try:
+            return ctypes.CDLL(name)
+        except OSError:
+            continue
+    raise RuntimeError("libamdhip64 not found")
+
+
+class HipEvents:
+    """K (start, stop) hipEvent pairs recorded by the C ABI around the dominant kernel."""
+
+    def __init__(self, k):
+        self.hip = hip_runtime()
+        self.hip.hipEventCreate.argtypes = [ctypes.POINTER(ctypes.c_void_p)]
+        self.hip.hipEventElapsedTime.argtypes = [ctypes.POINTER(ctypes.c_float), ctypes.c_void_p, ctypes.c_void_p]
+        self.pairs = []
+        for _ in range(k):
+            a, b = ctypes.c_void_p(), ctypes.c_void_p()
+            assert self.hip.hipEventCreate(ctypes.byref(a)) == 0
+            assert self.hip.hipEventCreate(ctypes.byref(b)) == 0
+            self.pairs.append((a, b))
+
+    def handles(self, i):
+        a, b = self.pairs[i]
+        return a.value, b.value
+
+    def mean_ms(self):
+        out = []
+        for a, b in self.pairs:
+            ms = ctypes.c_float()
+            assert self.hip.hipEventElapsedTime(ctypes.byref(ms), a, b) == 0
+            out.append(ms.value)
+        return float(np.mean(out)), out
+
+
+def make_leaves(n_draw, seed, dev):
+    """C2 base parameters x (1 + 1e-3 N(0,1)), one row per draw, as autograd leaves."""
+    rng = np.random.default_rng(seed)
+    base = dict(period=3.5, t0=1.0, b=0.3, ecc=0.3, omega=1.1, r=0.1, u1=0.3, u2=0.2)
+    leaves = {}
+    for k, v in base.items():
+        x = v * (1 + 1e-3 * rng.normal(size=(n_draw, 1)))
+        if k == "ecc":
+            x = np.clip(x, 0.0, 0.95)
+        if k in ("u1", "u2"):
+            x = x[:, 0]
+        leaves[k] = torch.tensor(x, dtype=torch.float64, device=dev, requires_grad=True)
+    return leaves
+
+
+def step(xo, ops, leaves, t, gbar, events=(None, None), use_in_transit=False):
+    """one pass of the hot path over the batch: returns (flux, L[d], grads of the leaves)"""
+    orbit = xo.KeplerianOrbit(period=leaves["period"], t0=leaves["t0"], b=leaves["b"], ecc=leaves["ecc"],
+                              omega=leaves["omega"])
+    rec, _ = orbit.kernel_records(leaves["r"], use_in_transit=use_in_transit)
+    c = xo.light_curves.get_cl(leaves["u1"], leaves["u2"])
+    flags = ops.FLAG_WINDOW if use_in_transit else 0
+    flux, L = ops.transit_flux_dot(t, rec.contiguous(), c.contiguous(), gbar, flags=flags, events=events)
+    grads = torch.autograd.grad(L.sum(), list(leaves.values()))
+    return flux, L, grads
+
+
+def time_steps(fn, steps, warmup, dist, dev):
+    for _ in range(warmup):
+        fn(-1)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for i in range(steps):
+        fn(i)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    return time.perf_counter() - t0
+
+
+def cpu_baseline(seconds_target=12.0):
+    """The oracle's C port (scalar, 1 core) on a bounded sample of the same workload."""
+    from oracle import c_port as C
+    from oracle import numpy_port as P
+
+    rng = np.random.default_rng(2)
+    t = np.arange(N_CAD) * CADENCE
+    orbit = P.KeplerianOrbit(period=3.5, t0=1.0, b=0.3, ecc=0.3, omega=1.1)
+    rec = np.zeros((1, 1, P.NPAR))
+    rec[0, 0, [P.P_N, P.P_TP, P.P_ECC, P.P_COSW, P.P_SINW, P.P_COSI, P.P_SINI, P.P_AOR, P.P_ROR]] = [
+        orbit.n[0], orbit.t_periastron[0], 0.3, np.cos(1.1), np.sin(1.1), orbit.cos_incl[0], orbit.sin_incl[0],
+        orbit.a[0], 0.1]
+    rec[0, 0, [P.P_T0, P.P_PERIOD, P.P_TS, P.P_TE, P.P_TS2, P.P_TE2]] = [1.0, 3.5, -np.inf, np.inf, -np.inf, np.inf]
+    c = P.get_cl(0.3, 0.2)[None]
+    g = rng.normal(size=(1, N_CAD))
+    C.transit(t, rec, c, g)  # warm
+    n, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < seconds_target:
+        C.transit(t, rec, c, g)
+        n += 1
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "evals/s", "cores": 1, "kind": "port",
+            "sample": f"{n} evaluations (value+VJP, every cadence) of the {N_CAD}-cadence C2 system, "
+                      f"oracle/c scalar port, {dt:.1f} s on 1 of {os.cpu_count()} host cores"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--draws-per-gpu", type=int, default=256)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist_mod.init_process_group("nccl", device_id=dev)
+        dist = dist_mod
+
+    import exoplanet_amd as xo
+    from exoplanet_amd import ops, _lib
+
+    _lib.load()  # fail loudly if the HIP library is missing
+    D = args.draws_per_gpu
+    t = torch.arange(N_CAD, dtype=torch.float64, device=dev) * CADENCE
+    gbar = torch.as_tensor(np.random.default_rng(2 + rank).normal(size=(D, N_CAD)), device=dev)
+    leaves = make_leaves(D, 100 + rank, dev)
+    L_all = torch.zeros(world * D, dtype=torch.float64, device=dev)
+    events = HipEvents(args.steps)
+
+    def one(i, use_in_transit=False, ev=True):
+        evs = events.handles(i) if (ev and i >= 0) else (None, None)
+        flux, L, grads = step(xo, ops, leaves, t, gbar, events=evs, use_in_transit=use_in_transit)
+        if dist is not None:
+            L_all.zero_()
+            L_all[rank * D:(rank + 1) * D] = L.detach()
+            dist.all_reduce(L_all)     # the only collective: per-draw scalars, 8 B x D x N
+        return flux, L, grads
+
+    wall = time_steps(one, args.steps, args.warmup, dist, dev)
+    wall_t = torch.tensor([wall], dtype=torch.float64, device=dev)
+    if dist is not None:
+        dist.all_reduce(wall_t, op=dist.ReduceOp.MAX)
+    wall = float(wall_t.item())
+    kernel_ms, _ = events.mean_ms()
+
+    out = None
+    if rank == 0:
+        evals = world * D * args.steps
+        alg_bytes = ALG_BYTES_PER_UNIT * D * N_CAD
+        achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+        out = {
+            "metric": "light-curve evals/sec (value+grad) at 150k cadences",
+            "value": evals / wall,
+            "unit": "evals/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * wall / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": "BASELINE configs[1] (C2): single planet e=0.3 Kepler solve + quadratic limb-darkened "
+                            "transit, 150000 cadences, value+grad, every cadence evaluated (use_in_transit=False)",
+                "n_cadences": N_CAD, "draws_per_gpu": D, "global_draws": world * D,
+                "parallelism": f"draws sharded over {world} GPU(s); all-reduce of per-draw scalars only",
+                "step": "leaf params -> torch orbit algebra -> fused HIP value+VJP kernel -> autograd to leaves",
+            },
+            "roofline": {
+                "bound": "hbm", "kernel": "transit_vjp_kernel<false>",
+                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None,
+                "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": kernel_ms,
+                "note": "24 B per (draw, cadence) x draws x cadences / mean hipEvent time of the kernel over the "
+                        "timed steps; the every-cadence case is fp64-VALU bound (Kepler solve per sample), "
+                        "see DESIGN.md section 5",
+            },
+        }
+
+    if not args.no_extras:
+        # reference-default semantics (use_in_transit=True): same step, windows on.  Not `value`.
+        ex_steps = max(5, args.steps // 2)
+        ev2 = HipEvents(ex_steps)
+        events_backup, events = events, ev2
+
+        def one_win(i):
+            evs = ev2.handles(i) if i >= 0 else (None, None)
+            return step(xo, ops, leaves, t, gbar, events=evs, use_in_transit=True)
+
+        wall2 = time_steps(one_win, ex_steps, 2, dist, dev)
+        k2, _ = ev2.mean_ms()
+        # op-level time of the one-sweep kernel call alone (no torch glue)
+        orbit = xo.KeplerianOrbit(period=leaves["period"], t0=leaves["t0"], b=leaves["b"], ecc=leaves["ecc"],
+                                  omega=leaves["omega"])
+        rec = orbit.kernel_records(leaves["r"])[0].detach().contiguous()
+        c = xo.light_curves.get_cl(leaves["u1"], leaves["u2"]).detach().contiguous()
+        wall3 = time_steps(lambda i: ops.transit_flux_value_and_vjp(t, rec, c, gbar), ex_steps, 2, dist, dev)
+        if rank == 0:
+            out["extras"] = {
+                "in_transit_only": {"evals_per_s": world * D * ex_steps / wall2, "kernel_ms": k2,
+                                    "alg_GBps": ALG_BYTES_PER_UNIT * D * N_CAD / (k2 * 1e-3) / 1e9,
+                                    "note": "reference default use_in_transit=True (contact-point windows)"},
+                "op_level_every_cadence": {"evals_per_s": world * D * ex_steps / wall3,
+                                           "ms_per_step": 1e3 * wall3 / ex_steps,
+                                           "note": "fused kernel call only, no orbit algebra / autograd"},
+            }
+        events = events_backup
+
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -46,7 +46,7 @@ struct Shared {
   double c[6];
   double sdt[EXO_MAX_SUBEXP + 1];
   double sw[EXO_MAX_SUBEXP + 1];
-  double red[kWaves][kNG + 6];
+  double red[kWaves][kNG + 7];
 };
 
 __device__ __forceinline__ void stage_constants(Shared& sh, const double* __restrict__ params,
@@ -268,7 +268,7 @@ __global__ __launch_bounds__(kBlock) void transit_vjp_kernel(
   const bool window = flags & EXO_FLAG_WINDOW;
   const int64_t base = (int64_t)blockIdx.x * kTile + threadIdx.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int ng_draw = n_planet * kNG + 6;
+  const int ng_draw = n_planet * kNG + 7;
   double* __restrict__ pout = partial + ((int64_t)draw * gridDim.x + blockIdx.x) * ng_draw;
 
   double tv[kCPT], te[kCPT], fsum[kCPT], gsum[kCPT];
@@ -282,7 +282,7 @@ __global__ __launch_bounds__(kBlock) void transit_vjp_kernel(
     fsum[j] = 0.0;
     gsum[j] = (!per_planet && valid[j]) ? gflux[draw * n_cad + i] : 0.0;
   }
-  double accld[6] = {0, 0, 0, 0, 0, 0};
+  double accld[7] = {0, 0, 0, 0, 0, 0, 0};  // 6 limb-darkening slots + sum(gflux * flux)
   for (int p = 0; p < n_planet; ++p) {
     const PlanetConst& c = sh.pc[p];
     GradAcc acc;
@@ -300,6 +300,7 @@ __global__ __launch_bounds__(kBlock) void transit_vjp_kernel(
           const double gw = go ? g * sh.sw[k] : 0.0;
           const double F = eval_sample<true, SECONDARY>(tt, c, sh.c, gw, acc, accld);
           f = fma(sh.sw[k], go ? F : 0.0, f);
+          accld[6] = fma(gw, F, accld[6]);
         }
       }
       if (flux_out) {
@@ -326,12 +327,12 @@ __global__ __launch_bounds__(kBlock) void transit_vjp_kernel(
     __syncthreads();
   }
 #pragma unroll
-  for (int s = 0; s < 6; ++s) {
+  for (int s = 0; s < 7; ++s) {
     const double v = wave_sum(accld[s]);
     if (lane == 0) sh.red[wave][kNG + s] = v;
   }
   __syncthreads();
-  if (threadIdx.x < 6) {
+  if (threadIdx.x < 7) {
     double v = 0.0;
 #pragma unroll
     for (int w = 0; w < kWaves; ++w) v += sh.red[w][kNG + threadIdx.x];
@@ -347,9 +348,9 @@ __global__ __launch_bounds__(kBlock) void transit_vjp_kernel(
 // Stage 2: one block per draw; thread s sums slot s over the blocks in order.
 __global__ __launch_bounds__(kBlock) void transit_vjp_reduce_kernel(
     const double* __restrict__ partial, int nblk, int n_planet, bool secondary,
-    double* __restrict__ gparams, double* __restrict__ gld) {
+    double* __restrict__ gparams, double* __restrict__ gld, double* __restrict__ flux_dot) {
   const int64_t draw = blockIdx.x;
-  const int ng_draw = n_planet * kNG + 6;
+  const int ng_draw = n_planet * kNG + 7;
   const int s = threadIdx.x;
   if (s >= ng_draw) return;
   const double* __restrict__ src = partial + draw * nblk * (int64_t)ng_draw + s;
@@ -365,6 +366,7 @@ __global__ __launch_bounds__(kBlock) void transit_vjp_reduce_kernel(
     const int k = s - n_planet * kNG;
     const int nld = secondary ? 6 : 3;
     if (k < nld) gld[draw * nld + k] = v;
+    if (k == 6 && flux_dot) flux_dot[draw] = v;
   }
 }
 
@@ -481,7 +483,7 @@ inline bool transit_args_ok(int64_t n_cad, int64_t n_texp, int32_t n_sub, int64_
 
 extern "C" {
 
-int32_t exo_abi_version(void) { return 1; }
+int32_t exo_abi_version(void) { return 2; }
 
 int exo_kepler_f64(const double* M, const double* ecc, double* sinf, double* cosf, int64_t n, void* stream) {
   if (n < 0 || (n > 0 && (!M || !ecc || !sinf || !cosf))) return EXO_ERR_INVALID_ARGUMENT;
@@ -515,35 +517,46 @@ int exo_contact_points_f64(const double* a, const double* e, const double* cosw,
   return launch_status();
 }
 
-int exo_transit_flux_fwd_f64(const double* t, int64_t n_cad, const double* texp, int64_t n_texp,
-                             const double* stencil_dt, const double* stencil_w, int32_t n_sub,
-                             const double* params, const double* ld, int64_t n_draw, int32_t n_planet,
-                             uint32_t flags, double* flux, void* stream) {
+int exo_transit_flux_fwd_ev_f64(const double* t, int64_t n_cad, const double* texp, int64_t n_texp,
+                                const double* stencil_dt, const double* stencil_w, int32_t n_sub,
+                                const double* params, const double* ld, int64_t n_draw, int32_t n_planet,
+                                uint32_t flags, double* flux, void* stream, void* ev_start, void* ev_stop) {
   if (!transit_args_ok(n_cad, n_texp, n_sub, n_draw, n_planet)) return EXO_ERR_INVALID_ARGUMENT;
   if (n_cad == 0 || n_draw == 0) return EXO_OK;
   if (!t || !params || !ld || !flux || (n_texp > 0 && (!texp || !stencil_dt || !stencil_w)))
     return EXO_ERR_INVALID_ARGUMENT;
   const dim3 grid((unsigned)((n_cad + kTile - 1) / kTile), (unsigned)n_draw), block(kBlock);
+  if (ev_start) (void)hipEventRecord((hipEvent_t)ev_start, (hipStream_t)stream);
   if (flags & EXO_FLAG_SECONDARY)
     hipLaunchKernelGGL(transit_fwd_kernel<true>, grid, block, 0, (hipStream_t)stream, t, n_cad, texp, n_texp,
                        stencil_dt, stencil_w, n_sub, params, ld, n_planet, flags, flux);
   else
     hipLaunchKernelGGL(transit_fwd_kernel<false>, grid, block, 0, (hipStream_t)stream, t, n_cad, texp, n_texp,
                        stencil_dt, stencil_w, n_sub, params, ld, n_planet, flags, flux);
+  if (ev_stop) (void)hipEventRecord((hipEvent_t)ev_stop, (hipStream_t)stream);
   return launch_status();
+}
+
+int exo_transit_flux_fwd_f64(const double* t, int64_t n_cad, const double* texp, int64_t n_texp,
+                             const double* stencil_dt, const double* stencil_w, int32_t n_sub,
+                             const double* params, const double* ld, int64_t n_draw, int32_t n_planet,
+                             uint32_t flags, double* flux, void* stream) {
+  return exo_transit_flux_fwd_ev_f64(t, n_cad, texp, n_texp, stencil_dt, stencil_w, n_sub, params, ld, n_draw,
+                                     n_planet, flags, flux, stream, nullptr, nullptr);
 }
 
 int64_t exo_transit_flux_vjp_workspace_bytes(int64_t n_cad, int64_t n_draw, int32_t n_planet) {
   if (n_cad < 0 || n_draw < 0 || n_planet < 1) return -1;
   const int64_t nblk = (n_cad + kTile - 1) / kTile;
-  return nblk * n_draw * (int64_t)(n_planet * kNG + 6) * (int64_t)sizeof(double);
+  return nblk * n_draw * (int64_t)(n_planet * kNG + 7) * (int64_t)sizeof(double);
 }
 
-int exo_transit_flux_vjp_f64(const double* t, int64_t n_cad, const double* texp, int64_t n_texp,
-                             const double* stencil_dt, const double* stencil_w, int32_t n_sub,
-                             const double* params, const double* ld, int64_t n_draw, int32_t n_planet,
-                             uint32_t flags, const double* gflux, double* flux_out, double* gparams,
-                             double* gld, void* workspace, int64_t workspace_bytes, void* stream) {
+int exo_transit_flux_vjp_ev_f64(const double* t, int64_t n_cad, const double* texp, int64_t n_texp,
+                                const double* stencil_dt, const double* stencil_w, int32_t n_sub,
+                                const double* params, const double* ld, int64_t n_draw, int32_t n_planet,
+                                uint32_t flags, const double* gflux, double* flux_out, double* gparams,
+                                double* gld, double* flux_dot, void* workspace, int64_t workspace_bytes,
+                                void* stream, void* ev_start, void* ev_stop) {
   if (!transit_args_ok(n_cad, n_texp, n_sub, n_draw, n_planet)) return EXO_ERR_INVALID_ARGUMENT;
   if (n_draw == 0) return EXO_OK;
   if (!params || !ld || !gparams || !gld || (n_cad > 0 && (!t || !gflux)) ||
@@ -555,25 +568,39 @@ int exo_transit_flux_vjp_f64(const double* t, int64_t n_cad, const double* texp,
   if (hipMemsetAsync(gparams, 0, sizeof(double) * n_draw * n_planet * EXO_NPAR, st) != hipSuccess)
     return EXO_ERR_LAUNCH;
   if (n_cad == 0) {
+    if (flux_dot && hipMemsetAsync(flux_dot, 0, sizeof(double) * n_draw, st) != hipSuccess) return EXO_ERR_LAUNCH;
     return hipMemsetAsync(gld, 0, sizeof(double) * n_draw * (secondary ? 6 : 3), st) == hipSuccess
                ? EXO_OK : EXO_ERR_LAUNCH;
   }
-  if (n_planet * kNG + 6 > kBlock) return EXO_ERR_INVALID_ARGUMENT;
+  if (n_planet * kNG + 7 > kBlock) return EXO_ERR_INVALID_ARGUMENT;
   const int64_t need = exo_transit_flux_vjp_workspace_bytes(n_cad, n_draw, n_planet);
   if (!workspace || workspace_bytes < need) return EXO_ERR_WORKSPACE;
   const int nblk = (int)((n_cad + kTile - 1) / kTile);
   const dim3 grid((unsigned)nblk, (unsigned)n_draw), block(kBlock);
   double* partial = (double*)workspace;
+  if (ev_start) (void)hipEventRecord((hipEvent_t)ev_start, st);
   if (secondary)
     hipLaunchKernelGGL(transit_vjp_kernel<true>, grid, block, 0, st, t, n_cad, texp, n_texp, stencil_dt,
                        stencil_w, n_sub, params, ld, n_planet, flags, gflux, flux_out, partial);
   else
     hipLaunchKernelGGL(transit_vjp_kernel<false>, grid, block, 0, st, t, n_cad, texp, n_texp, stencil_dt,
                        stencil_w, n_sub, params, ld, n_planet, flags, gflux, flux_out, partial);
+  if (ev_stop) (void)hipEventRecord((hipEvent_t)ev_stop, st);
   if (launch_status() != EXO_OK) return EXO_ERR_LAUNCH;
   hipLaunchKernelGGL(transit_vjp_reduce_kernel, dim3((unsigned)n_draw), dim3(kBlock), 0, st, partial, nblk,
-                     n_planet, secondary, gparams, gld);
+                     n_planet, secondary, gparams, gld, flux_dot);
   return launch_status();
+}
+
+int exo_transit_flux_vjp_f64(const double* t, int64_t n_cad, const double* texp, int64_t n_texp,
+                             const double* stencil_dt, const double* stencil_w, int32_t n_sub,
+                             const double* params, const double* ld, int64_t n_draw, int32_t n_planet,
+                             uint32_t flags, const double* gflux, double* flux_out, double* gparams,
+                             double* gld, double* flux_dot, void* workspace, int64_t workspace_bytes,
+                             void* stream) {
+  return exo_transit_flux_vjp_ev_f64(t, n_cad, texp, n_texp, stencil_dt, stencil_w, n_sub, params, ld, n_draw,
+                                     n_planet, flags, gflux, flux_out, gparams, gld, flux_dot, workspace,
+                                     workspace_bytes, stream, nullptr, nullptr);
 }
 
 }  // extern "C"

@@ -1,0 +1,189 @@
+"""Quadratically limb-darkened light curves on the fused HIP kernel.
+
+Host-side mirror of ``exoplanet.light_curves.LimbDarkLightCurve``
+(/root/reference/src/exoplanet/light_curves/limb_dark.py): same constructor,
+same ``get_light_curve`` arguments / defaults / errors / output shape
+``(n_cadence, n_planet)``.  For a :class:`~exoplanet_amd.orbits.KeplerianOrbit`
+(the hot path) nothing O(N) happens in torch: the orbit packs per-(draw,
+planet) records and one kernel goes from the time array to the flux array.
+Any other orbit object (anything with ``get_relative_position``; with
+``light_delay`` also a KeplerianOrbit) takes the composed path: its positions
+feed ``ops.quad_solution_vector`` exactly as limb_dark.py:215-226 does.
+
+Batched parameters (leading draw dimensions on the orbit / ``r`` / ``u``)
+return ``(*draws, n_cadence, n_planet)``.
+"""
+import math
+import warnings
+
+import numpy as np
+import torch
+
+from .. import ops
+from ..orbits.keplerian import KeplerianOrbit, _vec, as_tensor
+
+__all__ = ["LimbDarkLightCurve"]
+
+
+def get_cl(u1, u2):
+    """(u1, u2) -> Green's-basis coefficients c, normalised so that an unocculted
+    star has unit flux (limb_dark.py:11-18)."""
+    u1 = as_tensor(u1)
+    u2 = as_tensor(u2, u1)
+    c0 = 1 - u1 - 1.5 * u2
+    c1 = u1 + 2 * u2
+    c2 = -0.25 * u2
+    norm = math.pi * (c0 + c1 / 1.5)
+    return torch.stack(torch.broadcast_tensors(c0, c1, c2), dim=-1) / norm.unsqueeze(-1)
+
+
+def exposure_stencil(oversample=7, order=0):
+    """sub-exposure offsets (in units of texp) and weights (limb_dark.py:181-197)"""
+    oversample = int(oversample)
+    oversample += 1 - oversample % 2
+    stencil = np.ones(oversample)
+    if order == 0:
+        dt = np.linspace(-0.5, 0.5, 2 * oversample + 1)[1:-1:2]
+    elif order == 1:
+        dt = np.linspace(-0.5, 0.5, oversample)
+        stencil[1:-1] = 2
+    elif order == 2:
+        dt = np.linspace(-0.5, 0.5, oversample)
+        stencil[1:-1:2] = 4
+        stencil[2:-1:2] = 2
+    else:
+        raise ValueError("order must be <= 2")
+    return dt, stencil / np.sum(stencil)
+
+
+def quad_limbdark_light_curve(c, b, r):
+    """dot(s(b, r), c) - 1 (limb_dark.py:21-24)"""
+    b = as_tensor(b)
+    r = as_tensor(r, b)
+    b, r = torch.broadcast_tensors(b, r)
+    s = ops.quad_solution_vector(b.contiguous(), r.contiguous())
+    return (s * c).sum(-1) - 1.0
+
+
+class LimbDarkLightCurve:
+    """A quadratically limb darkened light curve.
+
+    Args:
+        u1, u2: the limb darkening coefficients (scalars, or one per draw).
+            Passing a length-2 vector as ``u1`` alone is accepted with a
+            DeprecationWarning, as in the reference (limb_dark.py:43-64).
+    """
+
+    def __init__(self, u1, u2=None, model=None):
+        if u2 is None:
+            warnings.warn("using a vector of limb darkening coefficients is deprecated; use u1 and u2 directly",
+                          DeprecationWarning)
+            u = as_tensor(u1)
+            if u.dim() != 1 or u.shape[0] != 2:
+                raise AssertionError("only quadratic limb darkening is supported; use `starry` for more flexibility")
+            self.u1, self.u2 = u[0], u[1]
+        else:
+            self.u1 = as_tensor(u1)
+            self.u2 = as_tensor(u2, self.u1)
+        self.c = get_cl(self.u1, self.u2)
+
+    def get_ror_from_approx_transit_depth(self, delta, b, jac=False):
+        """radius ratio for an approximate depth in the small-planet limit (limb_dark.py:70-97)"""
+        b = as_tensor(b)
+        delta = as_tensor(delta, b)
+        f0 = 1 - 2 * self.u1 / 6.0 - 2 * self.u2 / 12.0
+        arg = 1 - torch.sqrt(1 - b ** 2)
+        f = 1 - self.u1 * arg - self.u2 * arg ** 2
+        factor = f0 / f
+        ror = torch.sqrt(delta * factor)
+        if not jac:
+            return ror.reshape(b.shape)
+        return ror.reshape(b.shape), (0.5 * factor / ror).reshape(b.shape)
+
+    # ------------------------------------------------------------------
+    def get_light_curve(self, orbit=None, r=None, t=None, texp=None, oversample=7, order=0,
+                        use_in_transit=None, light_delay=False):
+        """Relative flux ``(n_cadence, n_planet)``; arguments as in the reference
+        (limb_dark.py:99-153).  ``use_in_transit`` defaults to ``not light_delay``."""
+        if orbit is None:
+            raise ValueError("missing required argument 'orbit'")
+        if r is None:
+            raise ValueError("missing required argument 'r'")
+        if t is None:
+            raise ValueError("missing required argument 't'")
+        use_in_transit = (not light_delay) if use_in_transit is None else use_in_transit
+        if texp is not None:
+            stencil = exposure_stencil(oversample, order)   # raises for order > 2 like the reference
+        else:
+            stencil = None
+        if isinstance(orbit, KeplerianOrbit) and not light_delay and type(orbit)._warp_times is KeplerianOrbit._warp_times:
+            return self._fused(orbit, r, t, texp, stencil, use_in_transit)
+        return self._composed(orbit, r, t, texp, stencil, use_in_transit, light_delay)
+
+    # ---- hot path: one kernel from t to flux
+    def _fused(self, orbit, r, t, texp, stencil, use_in_transit, secondary=None):
+        t = as_tensor(t, orbit.a)
+        if t.dim() != 1:
+            raise ValueError("t must be a vector of times")
+        rec, batch = orbit.kernel_records(r, use_in_transit=use_in_transit,
+                                          secondary_sbr=None if secondary is None else secondary[1])
+        D, P = rec.shape[0], rec.shape[1]
+        c = self.c if secondary is None else torch.cat(torch.broadcast_tensors(self.c, secondary[0]), dim=-1)
+        nld = c.shape[-1]
+        ld = c.expand(batch + (nld,)).reshape(D, nld)
+        flags = ops.FLAG_PER_PLANET | (ops.FLAG_WINDOW if use_in_transit else 0)
+        if secondary is not None:
+            flags |= ops.FLAG_SECONDARY
+        kw = {}
+        if texp is not None:
+            dt, w = stencil
+            kw = dict(texp=as_tensor(texp, t).reshape(-1).detach(),
+                      stencil_dt=torch.as_tensor(dt, dtype=torch.float64, device=t.device),
+                      stencil_w=torch.as_tensor(w, dtype=torch.float64, device=t.device))
+        flux = ops.transit_flux(t.detach(), rec.contiguous(), ld.contiguous(), flags=flags, **kw)
+        return flux.reshape(batch + (t.shape[0], P))
+
+    # ---- generic orbit objects: ops.quad_solution_vector on their positions
+    def _composed(self, orbit, r, t, texp, stencil, use_in_transit, light_delay):
+        t = as_tensor(t)
+        r = _vec(r, t).reshape(-1)
+        n_all = t.shape[0]
+        if use_in_transit:
+            inds = orbit.in_transit(t, r=r, texp=texp, light_delay=light_delay)
+            t = t[inds]
+        if texp is None:
+            tgrid = t
+        else:
+            dt, w = stencil
+            texp_t = as_tensor(texp, t)
+            dt = torch.as_tensor(dt, dtype=torch.float64, device=t.device)
+            if texp_t.dim() == 0:
+                dt = texp_t * dt
+            else:
+                dt = (texp_t[inds] if use_in_transit else texp_t).unsqueeze(-1) * dt
+            tgrid = t.unsqueeze(-1) + dt
+        coords = orbit.get_relative_position(tgrid, light_delay=light_delay)
+        shape = tuple(tgrid.shape) + (r.shape[0],)
+        b = torch.sqrt(coords[0] ** 2 + coords[1] ** 2).reshape(shape)
+        los = coords[2].reshape(shape)
+        rs = orbit.r_star
+        lc = self._compute_light_curve(b / rs, (r + torch.zeros(shape, dtype=torch.float64, device=t.device)) / rs,
+                                       los / rs)
+        if texp is not None:
+            wt = torch.as_tensor(w, dtype=torch.float64, device=t.device)
+            lc = (wt[None, :, None] * lc).sum(dim=1)
+        if use_in_transit:
+            out = torch.zeros((n_all, r.shape[0]), dtype=torch.float64, device=t.device)
+            return out.index_put((inds,), lc)
+        return lc
+
+    def _compute_light_curve(self, b, r, los=None):
+        """flux for separations ``b`` and radius ratios ``r`` in units of the stellar
+        radius; zero where ``los <= 0`` (limb_dark.py:234-252)"""
+        b = as_tensor(b)
+        r = as_tensor(r, b)
+        c = self.c.to(b.device)
+        lc = quad_limbdark_light_curve(c, b, r)
+        if los is None:
+            return lc
+        return torch.where(as_tensor(los, b) > 0, lc, torch.zeros_like(lc))

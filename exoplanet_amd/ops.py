@@ -195,11 +195,11 @@ class _TransitFlux(torch.autograd.Function):
     def backward(ctx, gflux):
         t, texp, sdt, sw, params, ld = ctx.saved_tensors
         n_texp, n_sub, D, P, flags = ctx.meta
-        _, gparams, gld = _vjp(t, texp, n_texp, sdt, sw, n_sub, params, ld, D, P, flags, gflux, False)
+        _, gparams, gld, _ = _vjp(t, texp, n_texp, sdt, sw, n_sub, params, ld, D, P, flags, gflux, False)
         return None, None, None, None, gparams, gld, None
 
 
-def _vjp(t, texp, n_texp, sdt, sw, n_sub, params, ld, D, P, flags, gflux, want_flux):
+def _vjp(t, texp, n_texp, sdt, sw, n_sub, params, ld, D, P, flags, gflux, want_flux, events=(None, None)):
     N = t.numel()
     gflux = _dev(gflux, "gflux")
     shape = (D, N, P) if flags & FLAG_PER_PLANET else (D, N)
@@ -210,15 +210,17 @@ def _vjp(t, texp, n_texp, sdt, sw, n_sub, params, ld, D, P, flags, gflux, want_f
     ws = torch.empty(max(nbytes // 8, 1), dtype=torch.float64, device=t.device)
     gparams = torch.empty_like(params)
     gld = torch.empty_like(ld)
+    dot = torch.empty(D, dtype=torch.float64, device=t.device)
     flux = torch.empty(shape, dtype=torch.float64, device=t.device) if want_flux else None
     with torch.cuda.device(t.device):
         _lib.check(
-            lib.exo_transit_flux_vjp_f64(_ptr(t), N, _ptr(texp), n_texp, _ptr(sdt), _ptr(sw), n_sub, _ptr(params),
-                                         _ptr(ld), D, P, flags, _ptr(gflux), _ptr(flux), _ptr(gparams), _ptr(gld),
-                                         _ptr(ws), nbytes, _stream(t)),
+            lib.exo_transit_flux_vjp_ev_f64(_ptr(t), N, _ptr(texp), n_texp, _ptr(sdt), _ptr(sw), n_sub,
+                                            _ptr(params), _ptr(ld), D, P, flags, _ptr(gflux), _ptr(flux),
+                                            _ptr(gparams), _ptr(gld), _ptr(dot), _ptr(ws), nbytes, _stream(t),
+                                            events[0], events[1]),
             "exo_transit_flux_vjp_f64",
         )
-    return flux, gparams, gld
+    return flux, gparams, gld, dot
 
 
 def transit_flux(t, params, ld, texp=None, stencil_dt=None, stencil_w=None, flags=0):
@@ -232,10 +234,42 @@ def transit_flux(t, params, ld, texp=None, stencil_dt=None, stencil_w=None, flag
 
 
 @torch.no_grad()
-def transit_flux_value_and_vjp(t, params, ld, gflux, texp=None, stencil_dt=None, stencil_w=None, flags=0):
+def transit_flux_value_and_vjp(t, params, ld, gflux, texp=None, stencil_dt=None, stencil_w=None, flags=0,
+                               events=(None, None)):
     """One sweep over t: flux AND the cotangents of (params, ld) for a given
-    ``gflux`` -- 24 B per (draw, cadence).  Returns (flux, gparams, gld)."""
+    ``gflux`` -- 24 B per (draw, cadence).  Returns (flux, gparams, gld).
+    ``events``: optional (hipEvent_t, hipEvent_t) handles (ints) recorded around
+    the dominant kernel (profiling hook of the C ABI)."""
     flags = int(flags)
     t, texp, n_texp, sdt, sw, n_sub, params, ld, D, P = _transit_args(t, texp, stencil_dt, stencil_w, params, ld,
                                                                       flags)
-    return _vjp(t, texp, n_texp, sdt, sw, n_sub, params, ld, D, P, flags, gflux, True)
+    return _vjp(t, texp, n_texp, sdt, sw, n_sub, params, ld, D, P, flags, gflux, True, events)[:3]
+
+
+class _TransitFluxDot(torch.autograd.Function):
+    """(flux, L) with L[d] = sum_n gflux[d, n] * flux[d, n]: because the cotangent
+    is known up front, forward runs the one-sweep value+vjp kernel and stores
+    the parameter cotangents; backward only scales them by dL."""
+
+    @staticmethod
+    def forward(ctx, t, texp, stencil_dt, stencil_w, params, ld, gflux, flags, events):
+        t, texp, n_texp, sdt, sw, n_sub, params, ld, D, P = _transit_args(
+            t, texp, stencil_dt, stencil_w, params, ld, flags)
+        flux, gparams, gld, dot = _vjp(t, texp, n_texp, sdt, sw, n_sub, params, ld, D, P, flags, gflux, True,
+                                       events)
+        ctx.save_for_backward(gparams, gld)
+        ctx.mark_non_differentiable(flux)
+        return flux, dot
+
+    @staticmethod
+    def backward(ctx, _gflux_unused, gdot):
+        gparams, gld = ctx.saved_tensors
+        return (None, None, None, None, gdot[:, None, None] * gparams, gdot[:, None] * gld, None, None, None)
+
+
+def transit_flux_dot(t, params, ld, gflux, texp=None, stencil_dt=None, stencil_w=None, flags=0,
+                     events=(None, None)):
+    """One-sweep value + gradient for a cotangent known in advance: returns
+    ``(flux, L)`` with ``L[d] = (gflux[d] * flux[d]).sum()``; ``L`` is
+    differentiable w.r.t. ``params`` and ``ld`` (flux itself is returned detached)."""
+    return _TransitFluxDot.apply(t, texp, stencil_dt, stencil_w, params, ld, gflux, int(flags), events)

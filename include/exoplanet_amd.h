@@ -117,6 +117,16 @@ int exo_transit_flux_fwd_f64(const double* t, int64_t n_cad, const double* texp,
                              const double* params, const double* ld, int64_t n_draw,
                              int32_t n_planet, uint32_t flags, double* flux, void* stream);
 
+/* Profiling hook shared by the fused entry points below: if `ev_start` /
+ * `ev_stop` (hipEvent_t passed as void*, may be NULL) are given, they are
+ * recorded on `stream` immediately before / after the DOMINANT kernel of the
+ * call, so a caller can time that kernel alone without a profiler attached.   */
+int exo_transit_flux_fwd_ev_f64(const double* t, int64_t n_cad, const double* texp, int64_t n_texp,
+                                const double* stencil_dt, const double* stencil_w, int32_t n_sub,
+                                const double* params, const double* ld, int64_t n_draw,
+                                int32_t n_planet, uint32_t flags, double* flux, void* stream,
+                                void* ev_start, void* ev_stop);
+
 /* Bytes of scratch the reverse pass needs (deterministic two-stage reduction). */
 int64_t exo_transit_flux_vjp_workspace_bytes(int64_t n_cad, int64_t n_draw, int32_t n_planet);
 
@@ -124,13 +134,22 @@ int64_t exo_transit_flux_vjp_workspace_bytes(int64_t n_cad, int64_t n_draw, int3
  *   gparams [n_draw][n_planet][EXO_NPAR]  (slots SINI, T0, PERIOD, TS.. are 0)
  *   gld     [n_draw][3 or 6]
  * and, if flux_out != NULL, also write the forward value in the same pass
- * (value + gradient in one sweep over t: 24 B per (draw, cadence)).           */
+ * (value + gradient in one sweep over t: 24 B per (draw, cadence)); if
+ * flux_dot != NULL, flux_dot[n_draw] receives sum_n gflux * flux per draw (the
+ * scalar whose gradient gparams / gld are).                                    */
 int exo_transit_flux_vjp_f64(const double* t, int64_t n_cad, const double* texp, int64_t n_texp,
                              const double* stencil_dt, const double* stencil_w, int32_t n_sub,
                              const double* params, const double* ld, int64_t n_draw,
                              int32_t n_planet, uint32_t flags, const double* gflux,
-                             double* flux_out, double* gparams, double* gld, void* workspace,
-                             int64_t workspace_bytes, void* stream);
+                             double* flux_out, double* gparams, double* gld, double* flux_dot,
+                             void* workspace, int64_t workspace_bytes, void* stream);
+int exo_transit_flux_vjp_ev_f64(const double* t, int64_t n_cad, const double* texp, int64_t n_texp,
+                                const double* stencil_dt, const double* stencil_w, int32_t n_sub,
+                                const double* params, const double* ld, int64_t n_draw,
+                                int32_t n_planet, uint32_t flags, const double* gflux,
+                                double* flux_out, double* gparams, double* gld, double* flux_dot,
+                                void* workspace, int64_t workspace_bytes, void* stream, void* ev_start,
+                                void* ev_stop);
 
 #ifdef __cplusplus
 }
