@@ -3,7 +3,7 @@
 // dense contraction).
 //
 // Work decomposition
-//   grid.x : tiles of kTile = kBlock * kCPT consecutive cadences
+//   grid.x : runs of tiles_per_block tiles of kBlock consecutive cadences
 //   grid.y : posterior draws (independent parameter sets)
 //   lane   : one cadence (all sub-exposures and planets are register loops, so
 //            a wave is 64 consecutive cadences: transits are contiguous in time
@@ -29,8 +29,8 @@ namespace {
 
 constexpr int kBlock = 256;
 constexpr int kWaves = kBlock / 64;
-constexpr int kCPT = 2;                 // cadences per lane
-constexpr int kTile = kBlock * kCPT;    // cadences per block
+constexpr int kTargetBlocks = 256 * 16;  // ~16 resident-or-queued blocks per CU: fills the chip, amortises
+                                         // the per-block constant staging and gradient reduction
 constexpr int kNG = 10;                 // compact gradient slots per planet
 // compact slot order
 enum { G_N = 0, G_TP, G_ECC, G_COSW, G_SINW, G_COSI, G_AOR, G_ROR, G_FR, G_PAD };
@@ -191,63 +191,58 @@ __device__ __forceinline__ double eval_sample(double tt, const PlanetConst& c, c
 }
 
 // ---------------------------------------------------------------------------
-// Forward kernel
+// Forward kernel.  A block owns `tiles_per_block` consecutive tiles of kBlock
+// cadences of one draw and walks them planet by planet (planet-outer keeps the
+// per-planet constants in registers); for planet > 0 of a summed light curve
+// the same lane re-reads and adds to its own flux element (no race).
 // ---------------------------------------------------------------------------
 template <bool SECONDARY>
 __global__ __launch_bounds__(kBlock) void transit_fwd_kernel(
     const double* __restrict__ t, int64_t n_cad, const double* __restrict__ texp, int64_t n_texp,
     const double* __restrict__ stencil_dt, const double* __restrict__ stencil_w, int n_sub,
     const double* __restrict__ params, const double* __restrict__ ld, int n_planet, uint32_t flags,
-    double* __restrict__ flux) {
+    int tiles_per_block, double* __restrict__ flux) {
   __shared__ Shared sh;
   const int64_t draw = blockIdx.y;
   stage_constants(sh, params, ld, stencil_dt, stencil_w, n_sub, n_planet, draw, SECONDARY);
   const bool per_planet = flags & EXO_FLAG_PER_PLANET;
   const bool window = flags & EXO_FLAG_WINDOW;
-  const int64_t base = (int64_t)blockIdx.x * kTile + threadIdx.x;
-  double tv[kCPT], te[kCPT], fsum[kCPT];
-  bool valid[kCPT];
-#pragma unroll
-  for (int j = 0; j < kCPT; ++j) {
-    const int64_t i = base + (int64_t)j * kBlock;
-    valid[j] = i < n_cad;
-    tv[j] = valid[j] ? t[i] : 0.0;
-    te[j] = (n_texp == 0) ? 0.0 : (n_texp == 1 ? texp[0] : (valid[j] ? texp[i] : 0.0));
-    fsum[j] = 0.0;
-  }
+  const int64_t first = (int64_t)blockIdx.x * tiles_per_block * kBlock + threadIdx.x;
   GradAcc dummy;
   double dummyld[6];
   for (int p = 0; p < n_planet; ++p) {
     const PlanetConst& c = sh.pc[p];
-#pragma unroll
-    for (int j = 0; j < kCPT; ++j) {
+    for (int tile = 0; tile < tiles_per_block; ++tile) {
+      const int64_t i = first + (int64_t)tile * kBlock;
+      const bool valid = i < n_cad;
+      const double tv = valid ? t[i] : 0.0;
+      const double te = (n_texp == 0) ? 0.0 : (n_texp == 1 ? texp[0] : (valid ? texp[i] : 0.0));
       double f = 0.0;
-      const bool go = valid[j] && (!window || in_window(tv[j], c, 0.5 * te[j], SECONDARY));
+      const bool go = valid && (!window || in_window(tv, c, 0.5 * te, SECONDARY));
       if (EXO_WAVE_ANY(go)) {
         for (int k = 0; k < n_sub; ++k) {
-          const double tt = fma(te[j], sh.sdt[k], tv[j]);
+          const double tt = fma(te, sh.sdt[k], tv);
           const double F = eval_sample<false, SECONDARY>(tt, c, sh.c, 0.0, dummy, dummyld);
           f = fma(sh.sw[k], go ? F : 0.0, f);
         }
       }
-      if (per_planet) {
-        if (valid[j]) flux[(draw * n_cad + base + (int64_t)j * kBlock) * n_planet + p] = f;
-      } else {
-        fsum[j] += f;
+      if (valid) {
+        if (per_planet) {
+          flux[(draw * n_cad + i) * n_planet + p] = f;
+        } else {
+          double* dst = flux + draw * n_cad + i;
+          *dst = (p == 0) ? f : (*dst + f);
+        }
       }
     }
-  }
-  if (!per_planet) {
-#pragma unroll
-    for (int j = 0; j < kCPT; ++j)
-      if (valid[j]) flux[draw * n_cad + base + (int64_t)j * kBlock] = fsum[j];
   }
 }
 
 // ---------------------------------------------------------------------------
-// Reverse kernel (recompute-forward).  Stage 1: per-block partial sums, in a
-// fixed order (wave shuffle tree, then waves in index order) so the result is
-// bit-reproducible run to run.  Stage 2 (reduce kernel) sums blocks in order.
+// Reverse kernel (recompute-forward), same walk.  Gradient slots accumulate in
+// registers over all of a block's tiles and are reduced ONCE per planet per
+// block: stage 1 = wave shuffle tree then waves in index order (fixed order,
+// bit-reproducible run to run); stage 2 (reduce kernel) sums blocks in order.
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
@@ -260,54 +255,48 @@ __global__ __launch_bounds__(kBlock) void transit_vjp_kernel(
     const double* __restrict__ t, int64_t n_cad, const double* __restrict__ texp, int64_t n_texp,
     const double* __restrict__ stencil_dt, const double* __restrict__ stencil_w, int n_sub,
     const double* __restrict__ params, const double* __restrict__ ld, int n_planet, uint32_t flags,
-    const double* __restrict__ gflux, double* __restrict__ flux_out, double* __restrict__ partial) {
+    int tiles_per_block, const double* __restrict__ gflux, double* __restrict__ flux_out,
+    double* __restrict__ partial) {
   __shared__ Shared sh;
   const int64_t draw = blockIdx.y;
   stage_constants(sh, params, ld, stencil_dt, stencil_w, n_sub, n_planet, draw, SECONDARY);
   const bool per_planet = flags & EXO_FLAG_PER_PLANET;
   const bool window = flags & EXO_FLAG_WINDOW;
-  const int64_t base = (int64_t)blockIdx.x * kTile + threadIdx.x;
+  const int64_t first = (int64_t)blockIdx.x * tiles_per_block * kBlock + threadIdx.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int ng_draw = n_planet * kNG + 7;
   double* __restrict__ pout = partial + ((int64_t)draw * gridDim.x + blockIdx.x) * ng_draw;
 
-  double tv[kCPT], te[kCPT], fsum[kCPT], gsum[kCPT];
-  bool valid[kCPT];
-#pragma unroll
-  for (int j = 0; j < kCPT; ++j) {
-    const int64_t i = base + (int64_t)j * kBlock;
-    valid[j] = i < n_cad;
-    tv[j] = valid[j] ? t[i] : 0.0;
-    te[j] = (n_texp == 0) ? 0.0 : (n_texp == 1 ? texp[0] : (valid[j] ? texp[i] : 0.0));
-    fsum[j] = 0.0;
-    gsum[j] = (!per_planet && valid[j]) ? gflux[draw * n_cad + i] : 0.0;
-  }
   double accld[7] = {0, 0, 0, 0, 0, 0, 0};  // 6 limb-darkening slots + sum(gflux * flux)
   for (int p = 0; p < n_planet; ++p) {
     const PlanetConst& c = sh.pc[p];
     GradAcc acc;
 #pragma unroll
     for (int s = 0; s < kNG; ++s) acc.g[s] = 0.0;
-#pragma unroll
-    for (int j = 0; j < kCPT; ++j) {
+    for (int tile = 0; tile < tiles_per_block; ++tile) {
+      const int64_t i = first + (int64_t)tile * kBlock;
+      const bool valid = i < n_cad;
+      const double tv = valid ? t[i] : 0.0;
+      const double te = (n_texp == 0) ? 0.0 : (n_texp == 1 ? texp[0] : (valid ? texp[i] : 0.0));
       double f = 0.0;
-      const bool go = valid[j] && (!window || in_window(tv[j], c, 0.5 * te[j], SECONDARY));
+      const bool go = valid && (!window || in_window(tv, c, 0.5 * te, SECONDARY));
       if (EXO_WAVE_ANY(go)) {
-        double g = gsum[j];
-        if (per_planet) g = valid[j] ? gflux[(draw * n_cad + base + (int64_t)j * kBlock) * n_planet + p] : 0.0;
+        const double g = !valid ? 0.0
+                         : (per_planet ? gflux[(draw * n_cad + i) * n_planet + p] : gflux[draw * n_cad + i]);
         for (int k = 0; k < n_sub; ++k) {
-          const double tt = fma(te[j], sh.sdt[k], tv[j]);
+          const double tt = fma(te, sh.sdt[k], tv);
           const double gw = go ? g * sh.sw[k] : 0.0;
           const double F = eval_sample<true, SECONDARY>(tt, c, sh.c, gw, acc, accld);
           f = fma(sh.sw[k], go ? F : 0.0, f);
           accld[6] = fma(gw, F, accld[6]);
         }
       }
-      if (flux_out) {
+      if (flux_out && valid) {
         if (per_planet) {
-          if (valid[j]) flux_out[(draw * n_cad + base + (int64_t)j * kBlock) * n_planet + p] = f;
+          flux_out[(draw * n_cad + i) * n_planet + p] = f;
         } else {
-          fsum[j] += f;
+          double* dst = flux_out + draw * n_cad + i;
+          *dst = (p == 0) ? f : (*dst + f);
         }
       }
     }
@@ -337,11 +326,6 @@ __global__ __launch_bounds__(kBlock) void transit_vjp_kernel(
 #pragma unroll
     for (int w = 0; w < kWaves; ++w) v += sh.red[w][kNG + threadIdx.x];
     pout[n_planet * kNG + threadIdx.x] = v;
-  }
-  if (flux_out && !per_planet) {
-#pragma unroll
-    for (int j = 0; j < kCPT; ++j)
-      if (valid[j]) flux_out[draw * n_cad + base + (int64_t)j * kBlock] = fsum[j];
   }
 }
 
@@ -474,6 +458,19 @@ inline int elementwise_grid(int64_t n) {
   return (int)(want < 1 ? 1 : (want > 256 * 8 ? 256 * 8 : want));  // 8 blocks per CU, grid-stride the rest
 }
 
+// blocks per draw and tiles per block: enough blocks to fill 256 CUs several
+// times over, few enough that each block amortises its prologue / reduction
+inline void transit_geometry(int64_t n_cad, int64_t n_draw, int* blocks_per_draw, int* tiles_per_block) {
+  const int64_t n_tiles = (n_cad + kBlock - 1) / kBlock;
+  int64_t bpd = (kTargetBlocks + n_draw - 1) / n_draw;
+  if (bpd > n_tiles) bpd = n_tiles;
+  if (bpd < 1) bpd = 1;
+  const int64_t tpb = (n_tiles + bpd - 1) / bpd;
+  bpd = (n_tiles + tpb - 1) / tpb;
+  *blocks_per_draw = (int)bpd;
+  *tiles_per_block = (int)tpb;
+}
+
 inline bool transit_args_ok(int64_t n_cad, int64_t n_texp, int32_t n_sub, int64_t n_draw, int32_t n_planet) {
   return n_cad >= 0 && n_draw >= 0 && n_draw <= 65535 && n_planet >= 1 && n_planet <= EXO_MAX_PLANETS &&
          n_sub >= 1 && n_sub <= EXO_MAX_SUBEXP && (n_texp == 0 || n_texp == 1 || n_texp == n_cad);
@@ -525,14 +522,16 @@ int exo_transit_flux_fwd_ev_f64(const double* t, int64_t n_cad, const double* te
   if (n_cad == 0 || n_draw == 0) return EXO_OK;
   if (!t || !params || !ld || !flux || (n_texp > 0 && (!texp || !stencil_dt || !stencil_w)))
     return EXO_ERR_INVALID_ARGUMENT;
-  const dim3 grid((unsigned)((n_cad + kTile - 1) / kTile), (unsigned)n_draw), block(kBlock);
+  int bpd, tpb;
+  transit_geometry(n_cad, n_draw, &bpd, &tpb);
+  const dim3 grid((unsigned)bpd, (unsigned)n_draw), block(kBlock);
   if (ev_start) (void)hipEventRecord((hipEvent_t)ev_start, (hipStream_t)stream);
   if (flags & EXO_FLAG_SECONDARY)
     hipLaunchKernelGGL(transit_fwd_kernel<true>, grid, block, 0, (hipStream_t)stream, t, n_cad, texp, n_texp,
-                       stencil_dt, stencil_w, n_sub, params, ld, n_planet, flags, flux);
+                       stencil_dt, stencil_w, n_sub, params, ld, n_planet, flags, tpb, flux);
   else
     hipLaunchKernelGGL(transit_fwd_kernel<false>, grid, block, 0, (hipStream_t)stream, t, n_cad, texp, n_texp,
-                       stencil_dt, stencil_w, n_sub, params, ld, n_planet, flags, flux);
+                       stencil_dt, stencil_w, n_sub, params, ld, n_planet, flags, tpb, flux);
   if (ev_stop) (void)hipEventRecord((hipEvent_t)ev_stop, (hipStream_t)stream);
   return launch_status();
 }
@@ -547,8 +546,9 @@ int exo_transit_flux_fwd_f64(const double* t, int64_t n_cad, const double* texp,
 
 int64_t exo_transit_flux_vjp_workspace_bytes(int64_t n_cad, int64_t n_draw, int32_t n_planet) {
   if (n_cad < 0 || n_draw < 0 || n_planet < 1) return -1;
-  const int64_t nblk = (n_cad + kTile - 1) / kTile;
-  return nblk * n_draw * (int64_t)(n_planet * kNG + 7) * (int64_t)sizeof(double);
+  int bpd, tpb;
+  transit_geometry(n_cad, n_draw < 1 ? 1 : n_draw, &bpd, &tpb);
+  return (int64_t)bpd * n_draw * (int64_t)(n_planet * kNG + 7) * (int64_t)sizeof(double);
 }
 
 int exo_transit_flux_vjp_ev_f64(const double* t, int64_t n_cad, const double* texp, int64_t n_texp,
@@ -575,16 +575,17 @@ int exo_transit_flux_vjp_ev_f64(const double* t, int64_t n_cad, const double* te
   if (n_planet * kNG + 7 > kBlock) return EXO_ERR_INVALID_ARGUMENT;
   const int64_t need = exo_transit_flux_vjp_workspace_bytes(n_cad, n_draw, n_planet);
   if (!workspace || workspace_bytes < need) return EXO_ERR_WORKSPACE;
-  const int nblk = (int)((n_cad + kTile - 1) / kTile);
+  int nblk, tpb;
+  transit_geometry(n_cad, n_draw, &nblk, &tpb);
   const dim3 grid((unsigned)nblk, (unsigned)n_draw), block(kBlock);
   double* partial = (double*)workspace;
   if (ev_start) (void)hipEventRecord((hipEvent_t)ev_start, st);
   if (secondary)
     hipLaunchKernelGGL(transit_vjp_kernel<true>, grid, block, 0, st, t, n_cad, texp, n_texp, stencil_dt,
-                       stencil_w, n_sub, params, ld, n_planet, flags, gflux, flux_out, partial);
+                       stencil_w, n_sub, params, ld, n_planet, flags, tpb, gflux, flux_out, partial);
   else
     hipLaunchKernelGGL(transit_vjp_kernel<false>, grid, block, 0, st, t, n_cad, texp, n_texp, stencil_dt,
-                       stencil_w, n_sub, params, ld, n_planet, flags, gflux, flux_out, partial);
+                       stencil_w, n_sub, params, ld, n_planet, flags, tpb, gflux, flux_out, partial);
   if (ev_stop) (void)hipEventRecord((hipEvent_t)ev_stop, st);
   if (launch_status() != EXO_OK) return EXO_ERR_LAUNCH;
   hipLaunchKernelGGL(transit_vjp_reduce_kernel, dim3((unsigned)n_draw), dim3(kBlock), 0, st, partial, nblk,
