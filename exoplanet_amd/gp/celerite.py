@@ -1,0 +1,148 @@
+"""GaussianProcess on the batched celerite HIP kernels (value + gradient)."""
+import torch
+
+from .. import _lib
+from ..ops import _dev, _ptr, _stream
+from ..orbits.keplerian import as_tensor
+from .terms import Term
+
+__all__ = ["GaussianProcess", "celerite_loglike"]
+
+MAX_J = 8
+
+
+class _CeleriteLogLike(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, t, resid, diag, coef_real, coef_complex):
+        t = _dev(t, "t")
+        resid = _dev(resid, "resid")
+        diag = _dev(diag, "diag")
+        coef_real = _dev(coef_real, "coef_real")
+        coef_complex = _dev(coef_complex, "coef_complex")
+        D, N = resid.shape
+        n_real, n_complex = coef_real.shape[1], coef_complex.shape[1]
+        if t.shape != (N,) or diag.dim() != 2 or diag.shape[1] != N or diag.shape[0] not in (1, D):
+            raise ValueError("shapes: t (N,), resid (D,N), diag (1|D, N)")
+        if coef_real.shape != (D, n_real, 2) or coef_complex.shape != (D, n_complex, 4):
+            raise ValueError("coef_real (D,Jr,2), coef_complex (D,Jc,4)")
+        J = n_real + 2 * n_complex
+        if not 1 <= J <= MAX_J:
+            raise ValueError(f"celerite state width J = {J} outside 1..{MAX_J}")
+        if N < 1:
+            raise ValueError("need at least one cadence")
+        lib = _lib.load()
+        need_grad = any(ctx.needs_input_grad)
+        loglike = torch.empty(D, dtype=torch.float64, device=t.device)
+        nstate = lib.exo_celerite_state_doubles(N, D, n_real, n_complex) if need_grad else 0
+        state = torch.empty(nstate, dtype=torch.float64, device=t.device) if need_grad else None
+        with torch.cuda.device(t.device):
+            _lib.check(
+                lib.exo_celerite_loglike_fwd_f64(_ptr(t), _ptr(resid), _ptr(diag), diag.shape[0], N, _ptr(coef_real),
+                                                 n_real, _ptr(coef_complex), n_complex, D, _ptr(loglike), _ptr(state),
+                                                 nstate, _stream(t)),
+                "exo_celerite_loglike_fwd_f64",
+            )
+        if need_grad:
+            ctx.save_for_backward(t, diag, coef_real, coef_complex, state)
+            ctx.dims = (D, N, n_real, n_complex)
+        return loglike
+
+    @staticmethod
+    def backward(ctx, gll):
+        t, diag, coef_real, coef_complex, state = ctx.saved_tensors
+        D, N, n_real, n_complex = ctx.dims
+        gll = _dev(gll, "gloglike")
+        lib = _lib.load()
+        gresid = torch.empty(D, N, dtype=torch.float64, device=t.device)
+        want_diag = ctx.needs_input_grad[2]
+        shared_diag = diag.shape[0] == 1
+        gdiag = torch.empty(D, N, dtype=torch.float64, device=t.device) if want_diag else None
+        gcr = torch.empty_like(coef_real)
+        gcc = torch.empty_like(coef_complex)
+        with torch.cuda.device(t.device):
+            _lib.check(
+                lib.exo_celerite_loglike_vjp_f64(_ptr(t), _ptr(diag), diag.shape[0], N, _ptr(coef_real), n_real,
+                                                 _ptr(coef_complex), n_complex, D, _ptr(gll), _ptr(state),
+                                                 _ptr(gresid), _ptr(gdiag), None, _ptr(gcr), _ptr(gcc), _stream(t)),
+                "exo_celerite_loglike_vjp_f64",
+            )
+        if want_diag and shared_diag:
+            gdiag = gdiag.sum(0, keepdim=True)
+        return None, gresid, gdiag, gcr, gcc
+
+
+def celerite_loglike(t, resid, diag, coef_real, coef_complex):
+    """log N(resid | 0, K + diag) per draw.  t (N,), resid (D,N), diag (1|D,N),
+    coef_real (D,Jr,2) = (a,c), coef_complex (D,Jc,4) = (a,b,c,d).  Differentiable
+    w.r.t. resid, diag and the coefficients."""
+    return _CeleriteLogLike.apply(t, resid, diag, coef_real, coef_complex)
+
+
+class GaussianProcess:
+    """``GaussianProcess(kernel, t=t, diag=..., yerr=..., mean=...)`` then
+    ``log_likelihood(y)``; modelled on celerite2.GaussianProcess.
+
+    Batched use: kernel hyper-parameters, ``mean`` and ``y`` may carry a leading
+    draw dimension D; ``log_likelihood`` then returns (D,).
+    """
+
+    def __init__(self, kernel, t=None, *, mean=0.0, **kwargs):
+        if not isinstance(kernel, Term):
+            raise TypeError("kernel must be an exoplanet_amd.gp.terms.Term")
+        self.kernel = kernel
+        self.mean = mean
+        self._t = None
+        if t is not None:
+            self.compute(t, **kwargs)
+
+    def compute(self, t, *, yerr=None, diag=None, check_sorted=True, **_):
+        t = as_tensor(t)
+        if t.dim() != 1:
+            raise ValueError("dimension mismatch: t must be 1-D")
+        if check_sorted and t.numel() > 1 and bool((t[1:] < t[:-1]).any()):
+            raise ValueError("the input coordinates must be sorted")
+        if yerr is None and diag is None:
+            var = torch.zeros_like(t)
+        elif yerr is not None:
+            if diag is not None:
+                raise ValueError("only one of 'diag' and 'yerr' can be provided")
+            var = as_tensor(yerr, t) ** 2 + torch.zeros_like(t)
+        else:
+            var = as_tensor(diag, t) + torch.zeros_like(t)
+        if var.shape[-1] != t.shape[0]:
+            raise ValueError("dimension mismatch: diag / yerr must have one entry per cadence")
+        self._t = t
+        self._diag = var if var.dim() == 2 else var.reshape(1, -1)
+
+    def _coefficients(self):
+        """(coef_real (D,Jr,2), coef_complex (D,Jc,4), D, batched?)"""
+        ar, cr, ac, bc, cc, dc = self.kernel.get_coefficients()
+        batch = torch.broadcast_shapes(ar.shape[:-1], ac.shape[:-1])
+        if len(batch) > 1:
+            raise ValueError("at most one draw dimension is supported")
+        D = batch[0] if batch else 1
+        real = torch.stack(torch.broadcast_tensors(ar, cr), dim=-1)
+        cplx = torch.stack(torch.broadcast_tensors(ac, bc, cc, dc), dim=-1)
+        real = real.expand((D,) + tuple(real.shape[-2:]))
+        cplx = cplx.expand((D,) + tuple(cplx.shape[-2:]))
+        return real, cplx, D, bool(batch)
+
+    def log_likelihood(self, y):
+        if self._t is None:
+            raise RuntimeError("you must call 'compute' first")
+        t = self._t
+        y = as_tensor(y, t)
+        mean = self.mean(t) if callable(self.mean) else as_tensor(self.mean, t)
+        if isinstance(mean, torch.Tensor) and mean.dim() == 1 and mean.shape[0] != t.shape[0]:
+            mean = mean.unsqueeze(-1)  # per-draw constant
+        resid = y - mean
+        if resid.shape[-1] != t.shape[0]:
+            raise ValueError("dimension mismatch")
+        real, cplx, D, batched = self._coefficients()
+        squeeze = resid.dim() == 1 and not batched and self._diag.shape[0] == 1
+        D = max(D, resid.shape[0] if resid.dim() == 2 else 1, self._diag.shape[0])
+        resid = resid.expand(D, t.shape[0]).contiguous()
+        real = real.expand(D, real.shape[1], 2).contiguous()
+        cplx = cplx.expand(D, cplx.shape[1], 4).contiguous()
+        ll = celerite_loglike(t.detach(), resid, self._diag.contiguous(), real, cplx)
+        return ll[0] if squeeze else ll

@@ -1,0 +1,156 @@
+"""Kernel terms: each exposes ``get_coefficients()`` -> (ar, cr, ac, bc, cc, dc),
+the representation celerite2's ``Term.get_coefficients`` uses:
+
+    k(tau) = sum_r ar e^{-cr tau} + sum_c e^{-cc tau} (ac cos(dc tau) + bc sin(dc tau))
+
+Parameters may carry leading draw dimensions; coefficients come back with
+shape ``(*draws, n_terms)``.  Everything is torch, so autograd carries the
+kernel hyper-parameters.
+"""
+import math
+
+import torch
+
+from ..orbits.keplerian import as_tensor
+
+__all__ = ["Term", "TermSum", "RealTerm", "ComplexTerm", "SHOTerm", "RotationTerm", "Matern32Term"]
+
+
+def _empty(like):
+    return torch.zeros(like.shape[:-1] + (0,), dtype=torch.float64, device=like.device)
+
+
+class Term:
+    def get_coefficients(self):
+        raise NotImplementedError
+
+    def __add__(self, other):
+        return TermSum(self, other)
+
+    def __radd__(self, other):
+        return TermSum(other, self)
+
+    def get_value(self, tau):
+        """k(tau), dense; for tests and plotting"""
+        ar, cr, ac, bc, cc, dc = self.get_coefficients()
+        tau = as_tensor(tau, ar).abs().unsqueeze(-1)
+        k = (ar * torch.exp(-cr * tau)).sum(-1)
+        k = k + (torch.exp(-cc * tau) * (ac * torch.cos(dc * tau) + bc * torch.sin(dc * tau))).sum(-1)
+        return k
+
+
+class TermSum(Term):
+    def __init__(self, *terms):
+        flat = []
+        for t in terms:
+            flat.extend(t.terms if isinstance(t, TermSum) else [t])
+        if any(not isinstance(t, Term) for t in flat):
+            raise TypeError("terms must be exoplanet_amd.gp.terms.Term instances")
+        self.terms = tuple(flat)
+
+    def get_coefficients(self):
+        parts = [t.get_coefficients() for t in self.terms]
+        batch = torch.broadcast_shapes(*[p[0].shape[:-1] for p in parts])
+        out = []
+        for i in range(6):
+            out.append(torch.cat([p[i].expand(batch + (p[i].shape[-1],)) for p in parts], dim=-1))
+        return tuple(out)
+
+
+class RealTerm(Term):
+    """k = a exp(-c tau)"""
+
+    def __init__(self, *, a, c):
+        self.a = as_tensor(a)
+        self.c = as_tensor(c, self.a)
+
+    def get_coefficients(self):
+        a, c = torch.broadcast_tensors(self.a, self.c)
+        a, c = a.unsqueeze(-1), c.unsqueeze(-1)
+        e = _empty(a)
+        return a, c, e, e, e, e
+
+
+class ComplexTerm(Term):
+    """k = exp(-c tau) (a cos(d tau) + b sin(d tau))"""
+
+    def __init__(self, *, a, b, c, d):
+        self.a = as_tensor(a)
+        self.b, self.c, self.d = as_tensor(b, self.a), as_tensor(c, self.a), as_tensor(d, self.a)
+
+    def get_coefficients(self):
+        a, b, c, d = [x.unsqueeze(-1) for x in torch.broadcast_tensors(self.a, self.b, self.c, self.d)]
+        e = _empty(a)
+        return e, e, a, b, c, d
+
+
+class SHOTerm(Term):
+    """Stochastically driven damped harmonic oscillator.
+
+    Parameterised like celerite2's SHOTerm: amplitude ``S0`` or ``sigma``;
+    frequency ``w0`` or ``rho`` (undamped period); damping ``Q`` or ``tau``.
+    Q < 1/2 gives two real terms, Q >= 1/2 one complex term; a batch of draws
+    must sit on one side (the celerite state width is static).
+    """
+
+    def __init__(self, *, S0=None, sigma=None, w0=None, rho=None, Q=None, tau=None, eps=1e-5):
+        if (w0 is None) == (rho is None):
+            raise ValueError("exactly one of w0 and rho must be given")
+        if (Q is None) == (tau is None):
+            raise ValueError("exactly one of Q and tau must be given")
+        if (S0 is None) == (sigma is None):
+            raise ValueError("exactly one of S0 and sigma must be given")
+        self.eps = eps
+        self.w0 = as_tensor(w0) if w0 is not None else 2 * math.pi / as_tensor(rho)
+        self.Q = as_tensor(Q, self.w0) if Q is not None else 0.5 * self.w0 * as_tensor(tau, self.w0)
+        self.S0 = as_tensor(S0, self.w0) if S0 is not None else as_tensor(sigma, self.w0) ** 2 / (self.w0 * self.Q)
+
+    def get_coefficients(self):
+        S0, w0, Q = torch.broadcast_tensors(self.S0, self.w0, self.Q)
+        over = Q.detach() < 0.5
+        if bool(over.any()) and not bool(over.all()):
+            raise ValueError("SHOTerm: a batch mixes Q < 1/2 and Q >= 1/2 draws (different celerite state layouts)")
+        S0, w0, Q = S0.unsqueeze(-1), w0.unsqueeze(-1), Q.unsqueeze(-1)
+        e = _empty(S0)
+        if bool(over.all()) and over.numel() > 0:
+            f = torch.sqrt(torch.clamp(1.0 - 4.0 * Q ** 2, min=self.eps))
+            pm = torch.tensor([1.0, -1.0], dtype=torch.float64, device=S0.device)
+            ar = 0.5 * S0 * w0 * Q * (1.0 + pm / f)
+            cr = 0.5 * w0 / Q * (1.0 - pm * f)
+            return ar, cr, e, e, e, e
+        f = torch.sqrt(torch.clamp(4.0 * Q ** 2 - 1.0, min=self.eps))
+        a = S0 * w0 * Q
+        c = 0.5 * w0 / Q
+        return e, e, a, a / f, c, c * f
+
+
+class RotationTerm(TermSum):
+    """Two SHOs at the rotation period and its first harmonic (celerite2's RotationTerm)."""
+
+    def __init__(self, *, sigma, period, Q0, dQ, f):
+        sigma, period = as_tensor(sigma), as_tensor(period)
+        Q0, dQ, f = as_tensor(Q0, sigma), as_tensor(dQ, sigma), as_tensor(f, sigma)
+        amp = sigma ** 2 / (1 + f)
+        Q1 = 0.5 + Q0 + dQ
+        w1 = 4 * math.pi * Q1 / (period * torch.sqrt(4 * Q1 ** 2 - 1))
+        S1 = amp / (w1 * Q1)
+        Q2 = 0.5 + Q0
+        w2 = 8 * math.pi * Q2 / (period * torch.sqrt(4 * Q2 ** 2 - 1))
+        S2 = f * amp / (w2 * Q2)
+        super().__init__(SHOTerm(S0=S1, w0=w1, Q=Q1), SHOTerm(S0=S2, w0=w2, Q=Q2))
+
+
+class Matern32Term(Term):
+    """celerite approximation of the Matern-3/2 kernel (one complex term, small eps)"""
+
+    def __init__(self, *, sigma, rho, eps=0.01):
+        self.sigma = as_tensor(sigma)
+        self.rho = as_tensor(rho, self.sigma)
+        self.eps = eps
+
+    def get_coefficients(self):
+        sigma, rho = torch.broadcast_tensors(self.sigma, self.rho)
+        w0 = (math.sqrt(3.0) / rho).unsqueeze(-1)
+        S0 = (sigma ** 2).unsqueeze(-1) / w0
+        e = _empty(w0)
+        return e, e, w0 * S0, w0 * w0 * S0 / self.eps, w0, self.eps + torch.zeros_like(w0)

@@ -151,6 +151,41 @@ int exo_transit_flux_vjp_ev_f64(const double* t, int64_t n_cad, const double* te
                                 void* workspace, int64_t workspace_bytes, void* stream, void* ev_start,
                                 void* ev_stop);
 
+/* ---------------------------------------------------------------------------
+ * celerite GP log-likelihood, value + VJP, for n_draw independent (kernel,
+ * residual) pairs.  Replaces what celerite2 (a dependency of the reference,
+ * /root/reference/setup.py:36; the user's model calls it, the reference tree
+ * itself has no call site) does behind
+ *     gp = GaussianProcess(kernel, t=t, diag=diag);  gp.log_likelihood(y - model)
+ * i.e. celerite2's `factor` + `solve_lower` + `norm` Ops and their reverse Ops.
+ *
+ *   t            [n]               sorted, shared by all draws
+ *   resid        [n_draw][n]       y - mean model, per draw
+ *   diag         [n_diag][n]       white-noise variance (yerr^2 + jitter); n_diag = 1 (shared) or n_draw
+ *   coef_real    [n_draw][n_real][2]     (a, c)        of celerite2 Term.get_coefficients()
+ *   coef_complex [n_draw][n_complex][4]  (a, b, c, d)
+ *   J = n_real + 2 n_complex <= EXO_GP_MAX_J
+ *   loglike      [n_draw]          out; -inf if the matrix is not positive definite
+ *   state        NULL (value only) or exo_celerite_state_doubles() doubles: the
+ *                factorisation (d, W, z, F, S) the reverse pass re-reads,
+ *                laid out [quantity][cadence][draw]
+ * ------------------------------------------------------------------------- */
+#define EXO_GP_MAX_J 8
+int64_t exo_celerite_state_doubles(int64_t n, int64_t n_draw, int32_t n_real, int32_t n_complex);
+int exo_celerite_loglike_fwd_f64(const double* t, const double* resid, const double* diag, int64_t n_diag,
+                                 int64_t n, const double* coef_real, int32_t n_real,
+                                 const double* coef_complex, int32_t n_complex, int64_t n_draw,
+                                 double* loglike, double* state, int64_t state_doubles, void* stream);
+/* Reverse: given gloglike [n_draw] and the saved state, write
+ *   gresid [n_draw][n], gdiag [n_draw][n] (nullable), gdiag_sum [n_draw] (nullable,
+ *   = sum_n d loglike / d diag_n, the cotangent of a scalar jitter),
+ *   gcoef_real [n_draw][n_real][2], gcoef_complex [n_draw][n_complex][4].      */
+int exo_celerite_loglike_vjp_f64(const double* t, const double* diag, int64_t n_diag, int64_t n,
+                                 const double* coef_real, int32_t n_real, const double* coef_complex,
+                                 int32_t n_complex, int64_t n_draw, const double* gloglike,
+                                 const double* state, double* gresid, double* gdiag, double* gdiag_sum,
+                                 double* gcoef_real, double* gcoef_complex, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -859,3 +859,109 @@ def transit_flux_vjp(t, params, ld, gflux, **kw):
     gparams = np.einsum("dpkn,dnp->dpk", dpar, g)
     gld = np.einsum("dnpc,dnp->dc", dld, g)
     return fl, gparams, gld
+
+
+# =============================================================================
+# celerite GP log-likelihood (celerite2 is absent and has NO call site in the
+# reference tree: parity unpinned by construction; pinned here against the dense
+# Cholesky likelihood).  Algorithm: Foreman-Mackey, Agol, Ambikasaran & Angus
+# (2017) as restated with pre-conditioning in Foreman-Mackey (2018):
+# SURVEY.md Appendix B.
+# =============================================================================
+def sho_coefficients(S0, w0, Q, eps=1e-5):
+    """celerite coefficients (ar, cr, ac, bc, cc, dc) of a stochastically driven
+    damped harmonic oscillator; Q < 1/2 -> two real terms, else one complex."""
+    if Q < 0.5:
+        f = np.sqrt(max(1.0 - 4.0 * Q * Q, eps))
+        ar = 0.5 * S0 * w0 * Q * np.array([1.0 + 1.0 / f, 1.0 - 1.0 / f])
+        cr = 0.5 * w0 / Q * np.array([1.0 - f, 1.0 + f])
+        z = np.zeros(0)
+        return ar, cr, z, z, z, z
+    f = np.sqrt(max(4.0 * Q * Q - 1.0, eps))
+    a = S0 * w0 * Q
+    c = 0.5 * w0 / Q
+    z = np.zeros(0)
+    return z, z, np.array([a]), np.array([a / f]), np.array([c]), np.array([c * f])
+
+
+def sho_from_sigma_rho(sigma, rho, Q):
+    w0 = 2 * np.pi / rho
+    S0 = sigma ** 2 / (w0 * Q)
+    return S0, w0
+
+
+def celerite_kernel(tau, ar, cr, ac, bc, cc, dc):
+    tau = np.abs(tau)
+    k = np.zeros_like(tau)
+    for a, c in zip(ar, cr):
+        k += a * np.exp(-c * tau)
+    for a, b, c, d in zip(ac, bc, cc, dc):
+        k += np.exp(-c * tau) * (a * np.cos(d * tau) + b * np.sin(d * tau))
+    return k
+
+
+def gp_loglike_dense(t, y, diag, coeffs):
+    """dense Cholesky Gaussian log-likelihood and its gradient w.r.t.
+    (y, diag, ar, cr, ac, bc, cc, dc) via d loglike = 1/2 alpha^T dK alpha - 1/2 tr(K^-1 dK)."""
+    ar, cr, ac, bc, cc, dc = [np.asarray(x, dtype=np.float64) for x in coeffs]
+    t = np.asarray(t, dtype=np.float64)
+    tau = np.abs(t[:, None] - t[None, :])
+    K = celerite_kernel(tau, ar, cr, ac, bc, cc, dc) + np.diag(diag)
+    L = np.linalg.cholesky(K)
+    alpha = np.linalg.solve(L.T, np.linalg.solve(L, y))
+    ll = -0.5 * y @ alpha - np.sum(np.log(np.diag(L))) - 0.5 * t.size * np.log(2 * np.pi)
+    Kinv = np.linalg.inv(K)
+    Wm = 0.5 * (np.outer(alpha, alpha) - Kinv)          # d ll / d K
+    g = {"y": -alpha, "diag": np.diag(Wm).copy()}
+    g["ar"] = np.array([np.sum(Wm * np.exp(-c * tau)) for c in cr])
+    g["cr"] = np.array([np.sum(Wm * (-tau) * a * np.exp(-c * tau)) for a, c in zip(ar, cr)])
+    ga, gb, gc, gd = [], [], [], []
+    for a, b, c, d in zip(ac, bc, cc, dc):
+        ex = np.exp(-c * tau); co = np.cos(d * tau); si = np.sin(d * tau)
+        ga.append(np.sum(Wm * ex * co)); gb.append(np.sum(Wm * ex * si))
+        gc.append(np.sum(Wm * (-tau) * ex * (a * co + b * si)))
+        gd.append(np.sum(Wm * ex * tau * (-a * si + b * co)))
+    g["ac"], g["bc"], g["cc"], g["dc"] = map(np.array, (ga, gb, gc, gd))
+    return ll, g
+
+
+def celerite_matrices(t, diag, coeffs):
+    """(c, a, U, V) of SURVEY Appendix B from the term coefficients."""
+    ar, cr, ac, bc, cc, dc = [np.asarray(x, dtype=np.float64) for x in coeffs]
+    t = np.asarray(t, dtype=np.float64)
+    N = t.size
+    Jr, Jc = ar.size, ac.size
+    J = Jr + 2 * Jc
+    U = np.empty((N, J)); V = np.empty((N, J)); c = np.empty(J)
+    U[:, :Jr] = ar; V[:, :Jr] = 1.0; c[:Jr] = cr
+    for j in range(Jc):
+        co, si = np.cos(dc[j] * t), np.sin(dc[j] * t)
+        U[:, Jr + 2 * j] = ac[j] * co + bc[j] * si
+        U[:, Jr + 2 * j + 1] = ac[j] * si - bc[j] * co
+        V[:, Jr + 2 * j] = co
+        V[:, Jr + 2 * j + 1] = si
+        c[Jr + 2 * j] = c[Jr + 2 * j + 1] = cc[j]
+    a = np.asarray(diag, dtype=np.float64) + np.sum(ar) + np.sum(ac)
+    return c, a, U, V
+
+
+def celerite_loglike(t, y, diag, coeffs):
+    """O(N J^2) semiseparable Cholesky + forward substitution -> log-likelihood."""
+    c, a, U, V = celerite_matrices(t, diag, coeffs)
+    t = np.asarray(t, dtype=np.float64); y = np.asarray(y, dtype=np.float64)
+    N, J = U.shape
+    S = np.zeros((J, J)); F = np.zeros(J)
+    d = a[0]; W = V[0] / d; z = y[0]
+    acc = z * z / d + np.log(d)
+    for n in range(1, N):
+        P = np.exp(-c * (t[n] - t[n - 1]))
+        S = np.outer(P, P) * (S + d * np.outer(W, W))
+        F = P * (F + W * z)
+        u = S @ U[n]
+        d = a[n] - U[n] @ u
+        if not d > 0:
+            return -np.inf
+        W = (V[n] - u) / d
+        z = y[n] - U[n] @ F
+        acc += z * z / d + np.log(d)
+    return -0.5 * acc - 0.5 * N * np.log(2 * np.pi)
