@@ -1,0 +1,84 @@
+"""CPU: the C-ABI library builds (hipcc cross-compiles without a GPU), loads, and
+exports every symbol include/exoplanet_amd.h declares.  No kernel is launched."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import __graft_entry__ as g
+
+    g.build()
+    from exoplanet_amd import _lib
+
+    return _lib.load()
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "exoplanet_amd.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(exo_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_and_bindings_agree(lib):
+    from exoplanet_amd import _lib
+
+    assert declared_symbols() == _lib.exported_symbols()
+
+
+def test_every_declared_symbol_is_exported(lib):
+    raw = ctypes.CDLL(os.path.join(ROOT, "exoplanet_amd", "lib", "libexoplanet_amd.so"))
+    for name in declared_symbols():
+        assert hasattr(raw, name), name
+
+
+def test_abi_version_and_host_side_helpers(lib):
+    from exoplanet_amd import _lib
+
+    assert lib.exo_abi_version() == _lib.ABI_VERSION
+    # pure host arithmetic: scratch sizes
+    assert lib.exo_transit_flux_vjp_workspace_bytes(150000, 256, 1) > 0
+    assert lib.exo_transit_flux_vjp_workspace_bytes(-1, 1, 1) == -1
+    assert lib.exo_celerite_state_doubles(100, 3, 0, 1) == 100 * 3 * (2 + 4 + 3)
+    assert lib.exo_celerite_state_doubles(100, 3, 0, 0) == -1
+
+
+def test_header_layout_constants_match_python(lib):
+    from exoplanet_amd import ops
+
+    text = open(os.path.join(ROOT, "include", "exoplanet_amd.h")).read()
+    consts = dict(re.findall(r"#define\s+(EXO_[A-Z0-9_]+)\s+(\d+)u?\b", text))
+    assert int(consts["EXO_NPAR"]) == ops.NPAR
+    for name in ("N", "TP", "ECC", "COSW", "SINW", "COSI", "SINI", "AOR", "ROR", "T0", "PERIOD", "TS", "TE", "FRATIO",
+                 "TS2", "TE2"):
+        assert int(consts[f"EXO_P_{name}"]) == getattr(ops, f"P_{name}")
+    assert int(consts["EXO_FLAG_PER_PLANET"]) == ops.FLAG_PER_PLANET
+    assert int(consts["EXO_FLAG_WINDOW"]) == ops.FLAG_WINDOW
+    assert int(consts["EXO_FLAG_SECONDARY"]) == ops.FLAG_SECONDARY
+    assert int(consts["EXO_MAX_PLANETS"]) == ops.MAX_PLANETS
+    assert int(consts["EXO_MAX_SUBEXP"]) == ops.MAX_SUBEXP
+
+
+def test_missing_extension_fails_loudly(monkeypatch):
+    from exoplanet_amd import _lib
+
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libexoplanet_amd.so")
+    with pytest.raises(_lib.ExtensionMissingError, match="no CPU or PyTorch fallback"):
+        _lib.load()
+
+
+def test_ops_reject_host_tensors():
+    import torch
+    from exoplanet_amd import ops
+
+    x = torch.zeros(4, dtype=torch.float64)
+    for fn in (lambda: ops.kepler(x, x), lambda: ops.quad_solution_vector(x, x),
+               lambda: ops.transit_flux(x, torch.zeros(1, 1, 16, dtype=torch.float64), torch.zeros(1, 3, dtype=torch.float64))):
+        with pytest.raises(RuntimeError, match="no CPU fallback"):
+            fn()

