@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libexoplanet_amd.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _c_dp = ctypes.c_void_p  # device pointers travel as integers
 _i64 = ctypes.c_int64
@@ -23,13 +23,14 @@ _SIGNATURES = {
     "exo_contact_points_f64": (ctypes.c_int, [_c_dp] * 10 + [_i64, _c_dp]),
     "exo_transit_flux_fwd_f64": (
         ctypes.c_int,
-        [_c_dp, _i64, _c_dp, _i64, _c_dp, _c_dp, _i32, _c_dp, _c_dp, _i64, _i32, _u32, _c_dp, _c_dp],
+        [_c_dp, _i64, _c_dp, _i64, _c_dp, _c_dp, _i32, _c_dp, _c_dp, _i64, _i32, _u32, _c_dp, _c_dp, _i64, _c_dp],
     ),
     "exo_transit_flux_fwd_ev_f64": (
         ctypes.c_int,
-        [_c_dp, _i64, _c_dp, _i64, _c_dp, _c_dp, _i32, _c_dp, _c_dp, _i64, _i32, _u32, _c_dp, _c_dp, _c_dp, _c_dp],
+        [_c_dp, _i64, _c_dp, _i64, _c_dp, _c_dp, _i32, _c_dp, _c_dp, _i64, _i32, _u32, _c_dp, _c_dp, _i64, _c_dp,
+         _c_dp, _c_dp],
     ),
-    "exo_transit_flux_vjp_workspace_bytes": (_i64, [_i64, _i64, _i32]),
+    "exo_transit_flux_workspace_bytes": (_i64, [_i64, _i64, _i32]),
     "exo_transit_flux_vjp_f64": (
         ctypes.c_int,
         [_c_dp, _i64, _c_dp, _i64, _c_dp, _c_dp, _i32, _c_dp, _c_dp, _i64, _i32, _u32,

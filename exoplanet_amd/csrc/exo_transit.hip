@@ -31,6 +31,7 @@ constexpr int kBlock = 256;
 constexpr int kWaves = kBlock / 64;
 constexpr int kTargetBlocks = 256 * 16;  // ~16 resident-or-queued blocks per CU: fills the chip, amortises
                                          // the per-block constant staging and gradient reduction
+constexpr uint32_t kFlagNoFluxDev = 0x80000000u;
 constexpr int kNG = 10;                 // compact gradient slots per planet
 // compact slot order
 enum { G_N = 0, G_TP, G_ECC, G_COSW, G_SINW, G_COSI, G_AOR, G_ROR, G_FR, G_PAD };
@@ -73,7 +74,7 @@ __device__ __forceinline__ void stage_constants(Shared& sh, const double* __rest
     c.fr = p[EXO_P_FRATIO]; c.ts2 = p[EXO_P_TS2]; c.te2 = p[EXO_P_TE2];
   }
   const int nld = secondary ? 6 : 3;
-  if (tid >= 64 && tid < 64 + nld) sh.c[tid - 64] = ld[draw * nld + (tid - 64)];
+  if (ld && tid >= 64 && tid < 64 + nld) sh.c[tid - 64] = ld[draw * nld + (tid - 64)];
   if (tid >= 128 && tid < 128 + n_sub) {
     sh.sdt[tid - 128] = stencil_dt ? stencil_dt[tid - 128] : 0.0;
     sh.sw[tid - 128] = stencil_w ? stencil_w[tid - 128] : 1.0;
@@ -191,42 +192,142 @@ __device__ __forceinline__ double eval_sample(double tt, const PlanetConst& c, c
 }
 
 // ---------------------------------------------------------------------------
-// Forward kernel.  A block owns `tiles_per_block` consecutive tiles of kBlock
-// cadences of one draw and walks them planet by planet (planet-outer keeps the
-// per-planet constants in registers); for planet > 0 of a summed light curve
-// the same lane re-reads and adds to its own flux element (no race).
+// Kernel A -- "scan": classify every cadence of the block's tiles as active (some
+// planet / sub-exposure overlaps the stellar disk, or -- with windows -- the
+// cadence lies inside some planet's contact window) or inactive.
+//   inactive: flux = 0 is final, written here (the streaming part: read t 8 B,
+//             write flux 8 B per (draw, cadence), one cadence per lane);
+//   active:   the cadence's offset is appended to this wave's list (ballot +
+//             mbcnt prefix: no atomics, fixed order), for kernel B.
+// A carries no elliptic-integral code, so it runs at high occupancy; without
+// windows it is dominated by the Kepler solve per (planet, sub-exposure).
 // ---------------------------------------------------------------------------
 template <bool SECONDARY>
-__global__ __launch_bounds__(kBlock) void transit_fwd_kernel(
+__global__ __launch_bounds__(kBlock) void transit_scan_kernel(
+    const double* __restrict__ t, int64_t n_cad, const double* __restrict__ texp, int64_t n_texp,
+    const double* __restrict__ stencil_dt, int n_sub, const double* __restrict__ params, int n_planet,
+    uint32_t flags, int tiles_per_block, double* __restrict__ flux, int32_t* __restrict__ counts,
+    int32_t* __restrict__ list) {
+  __shared__ Shared sh;
+  const int64_t draw = blockIdx.y;
+  stage_constants(sh, params, nullptr, stencil_dt, nullptr, n_sub, n_planet, draw, SECONDARY);
+  const bool per_planet = flags & EXO_FLAG_PER_PLANET;
+  const bool window = flags & EXO_FLAG_WINDOW;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t blk_base = (int64_t)blockIdx.x * tiles_per_block * kBlock;
+  const int64_t wave_slot = ((int64_t)draw * gridDim.x + blockIdx.x) * kWaves + wave;
+  int32_t* __restrict__ my_list = list + wave_slot * ((int64_t)tiles_per_block * 64);
+  int cnt = 0;
+  for (int tile = 0; tile < tiles_per_block; ++tile) {
+    const int off = tile * kBlock + threadIdx.x;
+    const int64_t i = blk_base + off;
+    const bool valid = i < n_cad;
+    const double tv = valid ? t[i] : 0.0;
+    const double te = (n_texp == 0) ? 0.0 : (n_texp == 1 ? texp[0] : (valid ? texp[i] : 0.0));
+    bool active = false;
+    for (int p = 0; p < n_planet; ++p) {
+      const PlanetConst& c = sh.pc[p];
+      if (window) {
+        active = active || in_window(tv, c, 0.5 * te, SECONDARY);
+      } else {
+        const double lim = 1.0 + c.ror;
+        for (int k = 0; k < n_sub; ++k) {
+          const double tt = fma(te, sh.sdt[k], tv);
+          const exo::KeplerHalf kh = exo::kepler_half((tt - c.tp) * c.n, c.e, c.se, c.pe);
+          const double cx = kh.X * kh.X - kh.Y * kh.Y, sx = 2.0 * kh.X * kh.Y;
+          const double x1 = c.cw * cx - c.sw * sx;   // position / (-a/R)
+          const double y1 = c.sw * cx + c.cw * sx;
+          const double Ys = c.ci * y1;
+          const double Z = c.si * y1 * c.aor;        // = -sin(i) y1 (-a/R)
+          const double b2 = (x1 * x1 + Ys * Ys) * c.aor * c.aor;
+          const bool vis = SECONDARY ? true : !(Z <= 0.0);
+          active = active || (vis && !(b2 >= lim * lim));
+        }
+      }
+    }
+    active = active && valid;
+    const unsigned long long ballot = __ballot(active);
+    if (active) {
+      const int before = __builtin_amdgcn_mbcnt_hi((unsigned)(ballot >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)ballot, 0));
+      my_list[cnt + before] = off;
+    }
+    cnt += __popcll(ballot);
+    if (valid && !active && !(flags & kFlagNoFluxDev)) {
+      if (per_planet) {
+        for (int p = 0; p < n_planet; ++p) flux[(draw * n_cad + i) * n_planet + p] = 0.0;
+      } else {
+        flux[draw * n_cad + i] = 0.0;
+      }
+    }
+  }
+  if (lane == 0) counts[wave_slot] = cnt;
+}
+
+// ---------------------------------------------------------------------------
+// Kernel B -- "heavy": the active cadences of a block (the four wave lists of
+// kernel A, concatenated) processed densely, 256 at a time: Kepler solve again
+// (cheap next to what follows), solution vector with its elliptic integrals,
+// flux, and -- GRAD -- the reverse sweep into per-planet gradient slots that
+// live in registers for the whole block and are reduced once per planet:
+// wave shuffle tree, then waves in index order (bit-reproducible).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+
+template <bool GRAD, bool SECONDARY>
+__global__ __launch_bounds__(kBlock) void transit_heavy_kernel(
     const double* __restrict__ t, int64_t n_cad, const double* __restrict__ texp, int64_t n_texp,
     const double* __restrict__ stencil_dt, const double* __restrict__ stencil_w, int n_sub,
     const double* __restrict__ params, const double* __restrict__ ld, int n_planet, uint32_t flags,
-    int tiles_per_block, double* __restrict__ flux) {
+    int tiles_per_block, const int32_t* __restrict__ counts, const int32_t* __restrict__ list,
+    const double* __restrict__ gflux, double* __restrict__ flux, double* __restrict__ partial) {
   __shared__ Shared sh;
   const int64_t draw = blockIdx.y;
   stage_constants(sh, params, ld, stencil_dt, stencil_w, n_sub, n_planet, draw, SECONDARY);
   const bool per_planet = flags & EXO_FLAG_PER_PLANET;
-  const bool window = flags & EXO_FLAG_WINDOW;
-  const int64_t first = (int64_t)blockIdx.x * tiles_per_block * kBlock + threadIdx.x;
-  GradAcc dummy;
-  double dummyld[6];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t blk_base = (int64_t)blockIdx.x * tiles_per_block * kBlock;
+  const int64_t slot0 = ((int64_t)draw * gridDim.x + blockIdx.x) * kWaves;
+  const int cap = tiles_per_block * 64;
+  // prefix over the four wave lists
+  int pre[kWaves + 1];
+  pre[0] = 0;
+#pragma unroll
+  for (int w = 0; w < kWaves; ++w) pre[w + 1] = pre[w] + counts[slot0 + w];
+  const int total = pre[kWaves];
+  const int ng_draw = n_planet * kNG + 7;
+  double* __restrict__ pout = GRAD ? partial + ((int64_t)draw * gridDim.x + blockIdx.x) * ng_draw : nullptr;
+
+  double accld[7] = {0, 0, 0, 0, 0, 0, 0};  // 6 limb-darkening slots + sum(gflux * flux)
   for (int p = 0; p < n_planet; ++p) {
     const PlanetConst& c = sh.pc[p];
-    for (int tile = 0; tile < tiles_per_block; ++tile) {
-      const int64_t i = first + (int64_t)tile * kBlock;
-      const bool valid = i < n_cad;
-      const double tv = valid ? t[i] : 0.0;
-      const double te = (n_texp == 0) ? 0.0 : (n_texp == 1 ? texp[0] : (valid ? texp[i] : 0.0));
+    GradAcc acc;
+#pragma unroll
+    for (int s = 0; s < kNG; ++s) acc.g[s] = 0.0;
+    for (int j0 = 0; j0 < total; j0 += kBlock) {
+      const int j = j0 + threadIdx.x;
+      const bool has = j < total;
+      int w = 0;
+#pragma unroll
+      for (int q = 1; q < kWaves; ++q) w += (j >= pre[q]) ? 1 : 0;
+      const int off = has ? list[(slot0 + w) * (int64_t)cap + (j - pre[w])] : 0;
+      const int64_t i = blk_base + off;
+      const double tv = t[i];
+      const double te = (n_texp == 0) ? 0.0 : (n_texp == 1 ? texp[0] : texp[i]);
+      double g = 0.0;
+      if (GRAD && has) g = per_planet ? gflux[(draw * n_cad + i) * n_planet + p] : gflux[draw * n_cad + i];
       double f = 0.0;
-      const bool go = valid && (!window || in_window(tv, c, 0.5 * te, SECONDARY));
-      if (EXO_WAVE_ANY(go)) {
-        for (int k = 0; k < n_sub; ++k) {
-          const double tt = fma(te, sh.sdt[k], tv);
-          const double F = eval_sample<false, SECONDARY>(tt, c, sh.c, 0.0, dummy, dummyld);
-          f = fma(sh.sw[k], go ? F : 0.0, f);
-        }
+      for (int k = 0; k < n_sub; ++k) {
+        const double tt = fma(te, sh.sdt[k], tv);
+        const double gw = g * sh.sw[k];
+        const double F = eval_sample<GRAD, SECONDARY>(tt, c, sh.c, gw, acc, accld);
+        f = fma(sh.sw[k], F, f);
+        if (GRAD) accld[6] = fma(gw, F, accld[6]);
       }
-      if (valid) {
+      if (flux && has) {
         if (per_planet) {
           flux[(draw * n_cad + i) * n_planet + p] = f;
         } else {
@@ -235,97 +336,35 @@ __global__ __launch_bounds__(kBlock) void transit_fwd_kernel(
         }
       }
     }
-  }
-}
-
-// ---------------------------------------------------------------------------
-// Reverse kernel (recompute-forward), same walk.  Gradient slots accumulate in
-// registers over all of a block's tiles and are reduced ONCE per planet per
-// block: stage 1 = wave shuffle tree then waves in index order (fixed order,
-// bit-reproducible run to run); stage 2 (reduce kernel) sums blocks in order.
-// ---------------------------------------------------------------------------
-__device__ __forceinline__ double wave_sum(double v) {
+    if (GRAD) {
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-  return v;
-}
-
-template <bool SECONDARY>
-__global__ __launch_bounds__(kBlock) void transit_vjp_kernel(
-    const double* __restrict__ t, int64_t n_cad, const double* __restrict__ texp, int64_t n_texp,
-    const double* __restrict__ stencil_dt, const double* __restrict__ stencil_w, int n_sub,
-    const double* __restrict__ params, const double* __restrict__ ld, int n_planet, uint32_t flags,
-    int tiles_per_block, const double* __restrict__ gflux, double* __restrict__ flux_out,
-    double* __restrict__ partial) {
-  __shared__ Shared sh;
-  const int64_t draw = blockIdx.y;
-  stage_constants(sh, params, ld, stencil_dt, stencil_w, n_sub, n_planet, draw, SECONDARY);
-  const bool per_planet = flags & EXO_FLAG_PER_PLANET;
-  const bool window = flags & EXO_FLAG_WINDOW;
-  const int64_t first = (int64_t)blockIdx.x * tiles_per_block * kBlock + threadIdx.x;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int ng_draw = n_planet * kNG + 7;
-  double* __restrict__ pout = partial + ((int64_t)draw * gridDim.x + blockIdx.x) * ng_draw;
-
-  double accld[7] = {0, 0, 0, 0, 0, 0, 0};  // 6 limb-darkening slots + sum(gflux * flux)
-  for (int p = 0; p < n_planet; ++p) {
-    const PlanetConst& c = sh.pc[p];
-    GradAcc acc;
+      for (int s = 0; s < kNG; ++s) {
+        const double v = wave_sum(acc.g[s]);
+        if (lane == 0) sh.red[wave][s] = v;
+      }
+      __syncthreads();
+      if (threadIdx.x < kNG) {
+        double v = 0.0;
 #pragma unroll
-    for (int s = 0; s < kNG; ++s) acc.g[s] = 0.0;
-    for (int tile = 0; tile < tiles_per_block; ++tile) {
-      const int64_t i = first + (int64_t)tile * kBlock;
-      const bool valid = i < n_cad;
-      const double tv = valid ? t[i] : 0.0;
-      const double te = (n_texp == 0) ? 0.0 : (n_texp == 1 ? texp[0] : (valid ? texp[i] : 0.0));
-      double f = 0.0;
-      const bool go = valid && (!window || in_window(tv, c, 0.5 * te, SECONDARY));
-      if (EXO_WAVE_ANY(go)) {
-        const double g = !valid ? 0.0
-                         : (per_planet ? gflux[(draw * n_cad + i) * n_planet + p] : gflux[draw * n_cad + i]);
-        for (int k = 0; k < n_sub; ++k) {
-          const double tt = fma(te, sh.sdt[k], tv);
-          const double gw = go ? g * sh.sw[k] : 0.0;
-          const double F = eval_sample<true, SECONDARY>(tt, c, sh.c, gw, acc, accld);
-          f = fma(sh.sw[k], go ? F : 0.0, f);
-          accld[6] = fma(gw, F, accld[6]);
-        }
+        for (int w2 = 0; w2 < kWaves; ++w2) v += sh.red[w2][threadIdx.x];
+        pout[p * kNG + threadIdx.x] = v;
       }
-      if (flux_out && valid) {
-        if (per_planet) {
-          flux_out[(draw * n_cad + i) * n_planet + p] = f;
-        } else {
-          double* dst = flux_out + draw * n_cad + i;
-          *dst = (p == 0) ? f : (*dst + f);
-        }
-      }
+      __syncthreads();
     }
-    // block reduction of this planet's kNG slots
+  }
+  if (GRAD) {
 #pragma unroll
-    for (int s = 0; s < kNG; ++s) {
-      const double v = wave_sum(acc.g[s]);
-      if (lane == 0) sh.red[wave][s] = v;
+    for (int s = 0; s < 7; ++s) {
+      const double v = wave_sum(accld[s]);
+      if (lane == 0) sh.red[wave][kNG + s] = v;
     }
     __syncthreads();
-    if (threadIdx.x < kNG) {
+    if (threadIdx.x < 7) {
       double v = 0.0;
 #pragma unroll
-      for (int w = 0; w < kWaves; ++w) v += sh.red[w][threadIdx.x];
-      pout[p * kNG + threadIdx.x] = v;
+      for (int w2 = 0; w2 < kWaves; ++w2) v += sh.red[w2][kNG + threadIdx.x];
+      pout[n_planet * kNG + threadIdx.x] = v;
     }
-    __syncthreads();
-  }
-#pragma unroll
-  for (int s = 0; s < 7; ++s) {
-    const double v = wave_sum(accld[s]);
-    if (lane == 0) sh.red[wave][kNG + s] = v;
-  }
-  __syncthreads();
-  if (threadIdx.x < 7) {
-    double v = 0.0;
-#pragma unroll
-    for (int w = 0; w < kWaves; ++w) v += sh.red[w][kNG + threadIdx.x];
-    pout[n_planet * kNG + threadIdx.x] = v;
   }
 }
 
@@ -471,6 +510,29 @@ inline void transit_geometry(int64_t n_cad, int64_t n_draw, int* blocks_per_draw
   *tiles_per_block = (int)tpb;
 }
 
+// scratch layout shared by forward and reverse: [gradient partials][wave counts][wave lists]
+struct Workspace {
+  double* partial;
+  int32_t* counts;
+  int32_t* list;
+  int64_t bytes;
+};
+
+inline Workspace carve(void* base, int64_t n_draw, int bpd, int tpb, int n_planet) {
+  Workspace w;
+  const int64_t n_partial = n_draw * bpd * (int64_t)(n_planet * kNG + 7);
+  const int64_t n_counts = n_draw * bpd * (int64_t)kWaves;
+  const int64_t n_list = n_counts * (int64_t)tpb * 64;
+  char* p = (char*)base;
+  w.partial = (double*)p;
+  w.counts = (int32_t*)(p + n_partial * 8);
+  w.list = w.counts + ((n_counts + 1) & ~(int64_t)1);
+  w.bytes = n_partial * 8 + (((n_counts + 1) & ~(int64_t)1) + n_list) * 4;
+  return w;
+}
+
+constexpr uint32_t kFlagNoFlux = 0x80000000u;  // internal: scan kernel must not touch flux
+
 inline bool transit_args_ok(int64_t n_cad, int64_t n_texp, int32_t n_sub, int64_t n_draw, int32_t n_planet) {
   return n_cad >= 0 && n_draw >= 0 && n_draw <= 65535 && n_planet >= 1 && n_planet <= EXO_MAX_PLANETS &&
          n_sub >= 1 && n_sub <= EXO_MAX_SUBEXP && (n_texp == 0 || n_texp == 1 || n_texp == n_cad);
@@ -480,7 +542,7 @@ inline bool transit_args_ok(int64_t n_cad, int64_t n_texp, int32_t n_sub, int64_
 
 extern "C" {
 
-int32_t exo_abi_version(void) { return 2; }
+int32_t exo_abi_version(void) { return 3; }
 
 int exo_kepler_f64(const double* M, const double* ecc, double* sinf, double* cosf, int64_t n, void* stream) {
   if (n < 0 || (n > 0 && (!M || !ecc || !sinf || !cosf))) return EXO_ERR_INVALID_ARGUMENT;
@@ -514,41 +576,55 @@ int exo_contact_points_f64(const double* a, const double* e, const double* cosw,
   return launch_status();
 }
 
+int64_t exo_transit_flux_workspace_bytes(int64_t n_cad, int64_t n_draw, int32_t n_planet) {
+  if (n_cad < 0 || n_draw < 0 || n_planet < 1) return -1;
+  if (n_cad == 0 || n_draw == 0) return 0;
+  int bpd, tpb;
+  transit_geometry(n_cad, n_draw, &bpd, &tpb);
+  const Workspace w = carve(nullptr, n_draw, bpd, tpb, n_planet);
+  return w.bytes;
+}
+
 int exo_transit_flux_fwd_ev_f64(const double* t, int64_t n_cad, const double* texp, int64_t n_texp,
                                 const double* stencil_dt, const double* stencil_w, int32_t n_sub,
                                 const double* params, const double* ld, int64_t n_draw, int32_t n_planet,
-                                uint32_t flags, double* flux, void* stream, void* ev_start, void* ev_stop) {
+                                uint32_t flags, double* flux, void* workspace, int64_t workspace_bytes,
+                                void* stream, void* ev_start, void* ev_stop) {
   if (!transit_args_ok(n_cad, n_texp, n_sub, n_draw, n_planet)) return EXO_ERR_INVALID_ARGUMENT;
   if (n_cad == 0 || n_draw == 0) return EXO_OK;
   if (!t || !params || !ld || !flux || (n_texp > 0 && (!texp || !stencil_dt || !stencil_w)))
     return EXO_ERR_INVALID_ARGUMENT;
   int bpd, tpb;
   transit_geometry(n_cad, n_draw, &bpd, &tpb);
+  const Workspace w = carve(workspace, n_draw, bpd, tpb, n_planet);
+  if (!workspace || workspace_bytes < w.bytes) return EXO_ERR_WORKSPACE;
   const dim3 grid((unsigned)bpd, (unsigned)n_draw), block(kBlock);
-  if (ev_start) (void)hipEventRecord((hipEvent_t)ev_start, (hipStream_t)stream);
-  if (flags & EXO_FLAG_SECONDARY)
-    hipLaunchKernelGGL(transit_fwd_kernel<true>, grid, block, 0, (hipStream_t)stream, t, n_cad, texp, n_texp,
-                       stencil_dt, stencil_w, n_sub, params, ld, n_planet, flags, tpb, flux);
+  hipStream_t st = (hipStream_t)stream;
+  const bool secondary = flags & EXO_FLAG_SECONDARY;
+  if (ev_start) (void)hipEventRecord((hipEvent_t)ev_start, st);
+  if (secondary)
+    hipLaunchKernelGGL(transit_scan_kernel<true>, grid, block, 0, st, t, n_cad, texp, n_texp, stencil_dt, n_sub,
+                       params, n_planet, flags, tpb, flux, w.counts, w.list);
   else
-    hipLaunchKernelGGL(transit_fwd_kernel<false>, grid, block, 0, (hipStream_t)stream, t, n_cad, texp, n_texp,
-                       stencil_dt, stencil_w, n_sub, params, ld, n_planet, flags, tpb, flux);
-  if (ev_stop) (void)hipEventRecord((hipEvent_t)ev_stop, (hipStream_t)stream);
+    hipLaunchKernelGGL(transit_scan_kernel<false>, grid, block, 0, st, t, n_cad, texp, n_texp, stencil_dt, n_sub,
+                       params, n_planet, flags, tpb, flux, w.counts, w.list);
+  if (ev_stop) (void)hipEventRecord((hipEvent_t)ev_stop, st);
+  if (launch_status() != EXO_OK) return EXO_ERR_LAUNCH;
+  if (secondary)
+    hipLaunchKernelGGL((transit_heavy_kernel<false, true>), grid, block, 0, st, t, n_cad, texp, n_texp, stencil_dt,
+                       stencil_w, n_sub, params, ld, n_planet, flags, tpb, w.counts, w.list, nullptr, flux, nullptr);
+  else
+    hipLaunchKernelGGL((transit_heavy_kernel<false, false>), grid, block, 0, st, t, n_cad, texp, n_texp, stencil_dt,
+                       stencil_w, n_sub, params, ld, n_planet, flags, tpb, w.counts, w.list, nullptr, flux, nullptr);
   return launch_status();
 }
 
 int exo_transit_flux_fwd_f64(const double* t, int64_t n_cad, const double* texp, int64_t n_texp,
                              const double* stencil_dt, const double* stencil_w, int32_t n_sub,
                              const double* params, const double* ld, int64_t n_draw, int32_t n_planet,
-                             uint32_t flags, double* flux, void* stream) {
+                             uint32_t flags, double* flux, void* workspace, int64_t workspace_bytes, void* stream) {
   return exo_transit_flux_fwd_ev_f64(t, n_cad, texp, n_texp, stencil_dt, stencil_w, n_sub, params, ld, n_draw,
-                                     n_planet, flags, flux, stream, nullptr, nullptr);
-}
-
-int64_t exo_transit_flux_vjp_workspace_bytes(int64_t n_cad, int64_t n_draw, int32_t n_planet) {
-  if (n_cad < 0 || n_draw < 0 || n_planet < 1) return -1;
-  int bpd, tpb;
-  transit_geometry(n_cad, n_draw < 1 ? 1 : n_draw, &bpd, &tpb);
-  return (int64_t)bpd * n_draw * (int64_t)(n_planet * kNG + 7) * (int64_t)sizeof(double);
+                                     n_planet, flags, flux, workspace, workspace_bytes, stream, nullptr, nullptr);
 }
 
 int exo_transit_flux_vjp_ev_f64(const double* t, int64_t n_cad, const double* texp, int64_t n_texp,
@@ -573,22 +649,42 @@ int exo_transit_flux_vjp_ev_f64(const double* t, int64_t n_cad, const double* te
                ? EXO_OK : EXO_ERR_LAUNCH;
   }
   if (n_planet * kNG + 7 > kBlock) return EXO_ERR_INVALID_ARGUMENT;
-  const int64_t need = exo_transit_flux_vjp_workspace_bytes(n_cad, n_draw, n_planet);
-  if (!workspace || workspace_bytes < need) return EXO_ERR_WORKSPACE;
-  int nblk, tpb;
-  transit_geometry(n_cad, n_draw, &nblk, &tpb);
-  const dim3 grid((unsigned)nblk, (unsigned)n_draw), block(kBlock);
-  double* partial = (double*)workspace;
+  int bpd, tpb;
+  transit_geometry(n_cad, n_draw, &bpd, &tpb);
+  const Workspace w = carve(workspace, n_draw, bpd, tpb, n_planet);
+  if (!workspace || workspace_bytes < w.bytes) return EXO_ERR_WORKSPACE;
+  const dim3 grid((unsigned)bpd, (unsigned)n_draw), block(kBlock);
+  // the forward value is a by-product; without a destination the scan kernel's
+  // zeros for inactive cadences go to a scratch row that nobody reads
+  double* flux_dst = flux_out;
   if (ev_start) (void)hipEventRecord((hipEvent_t)ev_start, st);
-  if (secondary)
-    hipLaunchKernelGGL(transit_vjp_kernel<true>, grid, block, 0, st, t, n_cad, texp, n_texp, stencil_dt,
-                       stencil_w, n_sub, params, ld, n_planet, flags, tpb, gflux, flux_out, partial);
-  else
-    hipLaunchKernelGGL(transit_vjp_kernel<false>, grid, block, 0, st, t, n_cad, texp, n_texp, stencil_dt,
-                       stencil_w, n_sub, params, ld, n_planet, flags, tpb, gflux, flux_out, partial);
+  if (flux_dst) {
+    if (secondary)
+      hipLaunchKernelGGL(transit_scan_kernel<true>, grid, block, 0, st, t, n_cad, texp, n_texp, stencil_dt, n_sub,
+                         params, n_planet, flags, tpb, flux_dst, w.counts, w.list);
+    else
+      hipLaunchKernelGGL(transit_scan_kernel<false>, grid, block, 0, st, t, n_cad, texp, n_texp, stencil_dt, n_sub,
+                         params, n_planet, flags, tpb, flux_dst, w.counts, w.list);
+  } else {
+    if (secondary)
+      hipLaunchKernelGGL(transit_scan_kernel<true>, grid, block, 0, st, t, n_cad, texp, n_texp, stencil_dt, n_sub,
+                         params, n_planet, flags | kFlagNoFlux, tpb, flux_dst, w.counts, w.list);
+    else
+      hipLaunchKernelGGL(transit_scan_kernel<false>, grid, block, 0, st, t, n_cad, texp, n_texp, stencil_dt, n_sub,
+                         params, n_planet, flags | kFlagNoFlux, tpb, flux_dst, w.counts, w.list);
+  }
   if (ev_stop) (void)hipEventRecord((hipEvent_t)ev_stop, st);
   if (launch_status() != EXO_OK) return EXO_ERR_LAUNCH;
-  hipLaunchKernelGGL(transit_vjp_reduce_kernel, dim3((unsigned)n_draw), dim3(kBlock), 0, st, partial, nblk,
+  if (secondary)
+    hipLaunchKernelGGL((transit_heavy_kernel<true, true>), grid, block, 0, st, t, n_cad, texp, n_texp, stencil_dt,
+                       stencil_w, n_sub, params, ld, n_planet, flags, tpb, w.counts, w.list, gflux, flux_dst,
+                       w.partial);
+  else
+    hipLaunchKernelGGL((transit_heavy_kernel<true, false>), grid, block, 0, st, t, n_cad, texp, n_texp, stencil_dt,
+                       stencil_w, n_sub, params, ld, n_planet, flags, tpb, w.counts, w.list, gflux, flux_dst,
+                       w.partial);
+  if (launch_status() != EXO_OK) return EXO_ERR_LAUNCH;
+  hipLaunchKernelGGL(transit_vjp_reduce_kernel, dim3((unsigned)n_draw), dim3(kBlock), 0, st, w.partial, bpd,
                      n_planet, secondary, gparams, gld, flux_dot);
   return launch_status();
 }

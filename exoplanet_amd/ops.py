@@ -181,10 +181,13 @@ class _TransitFlux(torch.autograd.Function):
         shape = (D, N, P) if flags & FLAG_PER_PLANET else (D, N)
         flux = torch.empty(shape, dtype=torch.float64, device=t.device)
         lib = _lib.load()
+        nbytes = lib.exo_transit_flux_workspace_bytes(N, D, P)
+        ws = torch.empty(max(nbytes // 8 + 1, 1), dtype=torch.float64, device=t.device)
         with torch.cuda.device(t.device):
             _lib.check(
                 lib.exo_transit_flux_fwd_f64(_ptr(t), N, _ptr(texp), n_texp, _ptr(sdt), _ptr(sw), n_sub,
-                                             _ptr(params), _ptr(ld), D, P, flags, _ptr(flux), _stream(t)),
+                                             _ptr(params), _ptr(ld), D, P, flags, _ptr(flux), _ptr(ws), nbytes,
+                                             _stream(t)),
                 "exo_transit_flux_fwd_f64",
             )
         ctx.save_for_backward(t, texp, sdt, sw, params, ld)
@@ -206,8 +209,8 @@ def _vjp(t, texp, n_texp, sdt, sw, n_sub, params, ld, D, P, flags, gflux, want_f
     if tuple(gflux.shape) != shape:
         raise ValueError(f"gflux must have shape {shape}")
     lib = _lib.load()
-    nbytes = lib.exo_transit_flux_vjp_workspace_bytes(N, D, P)
-    ws = torch.empty(max(nbytes // 8, 1), dtype=torch.float64, device=t.device)
+    nbytes = lib.exo_transit_flux_workspace_bytes(N, D, P)
+    ws = torch.empty(max(nbytes // 8 + 1, 1), dtype=torch.float64, device=t.device)
     gparams = torch.empty_like(params)
     gld = torch.empty_like(ld)
     dot = torch.empty(D, dtype=torch.float64, device=t.device)

@@ -111,11 +111,17 @@ int exo_contact_points_f64(const double* a, const double* e, const double* cosw,
  *   params     [n_draw][n_planet][EXO_NPAR]
  *   ld         [n_draw][3] Green's-basis coefficients c of get_cl (limb_dark.py:11-18),
  *              or [n_draw][6] = primary c then secondary c with EXO_FLAG_SECONDARY
- *   flux       out, see EXO_FLAG_PER_PLANET                                        */
+ *   flux       out, see EXO_FLAG_PER_PLANET
+ *   workspace  exo_transit_flux_workspace_bytes() bytes of scratch                 */
 int exo_transit_flux_fwd_f64(const double* t, int64_t n_cad, const double* texp, int64_t n_texp,
                              const double* stencil_dt, const double* stencil_w, int32_t n_sub,
                              const double* params, const double* ld, int64_t n_draw,
-                             int32_t n_planet, uint32_t flags, double* flux, void* stream);
+                             int32_t n_planet, uint32_t flags, double* flux, void* workspace,
+                             int64_t workspace_bytes, void* stream);
+
+/* Bytes of scratch the fused entry points need (active-cadence lists of the scan
+ * kernel + the deterministic two-stage gradient reduction).                     */
+int64_t exo_transit_flux_workspace_bytes(int64_t n_cad, int64_t n_draw, int32_t n_planet);
 
 /* Profiling hook shared by the fused entry points below: if `ev_start` /
  * `ev_stop` (hipEvent_t passed as void*, may be NULL) are given, they are
@@ -124,11 +130,8 @@ int exo_transit_flux_fwd_f64(const double* t, int64_t n_cad, const double* texp,
 int exo_transit_flux_fwd_ev_f64(const double* t, int64_t n_cad, const double* texp, int64_t n_texp,
                                 const double* stencil_dt, const double* stencil_w, int32_t n_sub,
                                 const double* params, const double* ld, int64_t n_draw,
-                                int32_t n_planet, uint32_t flags, double* flux, void* stream,
-                                void* ev_start, void* ev_stop);
-
-/* Bytes of scratch the reverse pass needs (deterministic two-stage reduction). */
-int64_t exo_transit_flux_vjp_workspace_bytes(int64_t n_cad, int64_t n_draw, int32_t n_planet);
+                                int32_t n_planet, uint32_t flags, double* flux, void* workspace,
+                                int64_t workspace_bytes, void* stream, void* ev_start, void* ev_stop);
 
 /* Reverse (recompute-forward): given gflux (same shape as flux) accumulate
  *   gparams [n_draw][n_planet][EXO_NPAR]  (slots SINI, T0, PERIOD, TS.. are 0)
