@@ -45,21 +45,111 @@ constexpr double kTwoThirdsPi = 2.09439510239319549231;
 // Taylor series below 0.9 (no cancellation), direct above.
 EXO_HD double x_minus_sin(double x, double sinx) {
   const double x2 = x * x;
-  double s = 1.0 - x2 * (1.0 / 272.0);
-  s = 1.0 - x2 * (1.0 / 210.0) * s;
-  s = 1.0 - x2 * (1.0 / 156.0) * s;
-  s = 1.0 - x2 * (1.0 / 110.0) * s;
-  s = 1.0 - x2 * (1.0 / 72.0) * s;
-  s = 1.0 - x2 * (1.0 / 42.0) * s;
-  s = 1.0 - x2 * (1.0 / 20.0) * s;
+  // x^3/6 (1 - x^2/20 + x^4/840 - ...): coefficients (-1)^k 6/(2k+3)!
+  double s = 2.8114572543455207632e-15 * 6.0 * (1.0 / (18.0 * 19.0));   // 6/19!
+  s = fma(s, x2, -6.0 * 2.8114572543455207632e-15);                        // -6/17!
+  s = fma(s, x2, 6.0 * 7.6471637318198164759e-13);                         //  6/15!
+  s = fma(s, x2, -6.0 * 1.6059043836821614599e-10);                        // -6/13!
+  s = fma(s, x2, 6.0 * 2.5052108385441718775e-08);                         //  6/11!
+  s = fma(s, x2, -6.0 * 2.7557319223985890653e-06);                        // -6/9!
+  s = fma(s, x2, 6.0 * 1.9841269841269841270e-04);                         //  6/7!
+  s = fma(s, x2, -6.0 * 8.3333333333333333333e-03);                        // -6/5!
+  s = fma(s, x2, 1.0);
   s = x * x2 * (1.0 / 6.0) * s;
   return (x < 0.9) ? s : (x - sinx);
 }
 
+// Approximate-reciprocal division: v_rcp_f64 seed + two Newton steps + one
+// residual correction (~1 ulp, no denormal / overflow rescue -- callers pass
+// well-scaled operands).  About half the instructions of the IEEE sequence.
+EXO_HD double fast_div(double x, double y) {
+#ifdef EXO_HOST_BUILD
+  return x / y;
+#else
+  double r = __builtin_amdgcn_rcp(y);
+  r = fma(fma(-y, r, 1.0), r, r);
+  r = fma(fma(-y, r, 1.0), r, r);
+  const double q = x * r;
+  return fma(fma(-y, q, x), r, q);
+#endif
+}
+
+// Low-precision building blocks for the fp32 Kepler starter (the starter is only
+// good to ~4e-4 by construction, so single-instruction hardware approximations
+// -- v_rcp_f32, v_sqrt_f32, v_log_f32 / v_exp_f32 -- are ample).
+EXO_HD float fast_rcpf(float y) {
+#ifdef EXO_HOST_BUILD
+  return 1.0f / y;
+#else
+  return __builtin_amdgcn_rcpf(y);
+#endif
+}
+EXO_HD float fast_sqrtf(float y) {
+#ifdef EXO_HOST_BUILD
+  return sqrtf(y);
+#else
+  return __builtin_amdgcn_sqrtf(y);
+#endif
+}
+EXO_HD float fast_cbrtf(float y) {  // y >= 0
+#ifdef EXO_HOST_BUILD
+  return cbrtf(y);
+#else
+  return __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(y) * (1.0f / 3.0f));
+#endif
+}
+// reciprocal to ~1e-8 relative (one Newton step on v_rcp_f64): enough for the
+// intermediate Halley / quartic steps of the correction
+EXO_HD double approx_rcp(double y) {
+#ifdef EXO_HOST_BUILD
+  return 1.0 / y;
+#else
+  const double r = __builtin_amdgcn_rcp(y);
+  return fma(fma(-y, r, 1.0), r, r);
+#endif
+}
+
+// sin and cos for 0 <= x <= pi/2 (a few ulp beyond either end is fine): fold to
+// [0, pi/4] with a two-term pi/2 and evaluate the Taylor polynomials to x^17 /
+// x^16 (truncation < 2e-18).  No range reduction, no slow path: the eccentric
+// half-anomaly never leaves this interval.
+EXO_HD void sincos_halfpi(double x, double* s, double* c) {
+  const bool hi = x > 0.78539816339744830962;
+  const double y = hi ? (1.57079632679489655800 - x) + 6.123233995736766036e-17 : x;
+  const double y2 = y * y;
+  double ps = -2.8114572543455207632e-15;         // -1/17!
+  ps = fma(ps, y2, 7.6471637318198164759e-13);    //  1/15!
+  ps = fma(ps, y2, -1.6059043836821614599e-10);   // -1/13!
+  ps = fma(ps, y2, 2.5052108385441718775e-08);    //  1/11!
+  ps = fma(ps, y2, -2.7557319223985890653e-06);   // -1/9!
+  ps = fma(ps, y2, 1.9841269841269841270e-04);    //  1/7!
+  ps = fma(ps, y2, -8.3333333333333333333e-03);   // -1/5!
+  ps = fma(ps, y2, 1.6666666666666666667e-01);    //  1/3!  (sign applied below)
+  ps = fma(-ps * y2, y, y) ;                       // y - y^3/6 + ...  (ps holds +1/6 - y2/120 ...)
+  double pc = 4.7794773323873852974e-14;          //  1/16!
+  pc = fma(pc, y2, -1.1470745597729724714e-11);   // -1/14!
+  pc = fma(pc, y2, 2.0876756987868098979e-09);    //  1/12!
+  pc = fma(pc, y2, -2.7557319223985890653e-07);   // -1/10!
+  pc = fma(pc, y2, 2.4801587301587301587e-05);    //  1/8!
+  pc = fma(pc, y2, -1.3888888888888888889e-03);   // -1/6!
+  pc = fma(pc, y2, 4.1666666666666666667e-02);    //  1/4!
+  pc = fma(pc, y2, -0.5);
+  pc = fma(pc, y2, 1.0);
+  *s = hi ? pc : ps;
+  *c = hi ? ps : pc;
+}
+
 // ---------------------------------------------------------------------------
 // Kepler solver.  Markley (1995) cubic starter + one fifth-order correction:
-// fixed cost, so there is nothing to vote on.  Works on half angles so that
-// 1 - e cos E = X^2 + Y^2 carries no cancellation as e -> 1.
+// fixed cost, so there is nothing to vote on.
+//   * the starter is only good to ~4e-4 by construction, so it runs in fp32
+//     (twice the fp64 rate, single-instruction rcp / sqrt); 1 - e is formed in
+//     fp64 first so that e -> 1 survives the narrowing;
+//   * the correction runs in fp64 on HALF angles, so that
+//     1 - e cos E = X^2 + Y^2 carries no cancellation as e -> 1, with the
+//     residual written as (1-e) E + e (E - sin E);
+//   * sin / cos of the half angle never leave [0, pi/2]: a branch-free
+//     polynomial, and the final (<= 4.4e-4) update is a Taylor rotation.
 //
 //   in : M (any real), e in [0,1), se = sqrt(1-e), pe = sqrt(1+e)
 //   out: X = sqrt(1-e) cos(E/2),  Y = sqrt(1+e) sin(E/2)   (signed)
@@ -80,38 +170,41 @@ EXO_HD KeplerHalf kepler_half(double M, double e, double se, double pe) {
   const double sgn = (Mr < 0.0) ? -1.0 : 1.0;
   Mr = fabs(Mr);
   const double ome = 1.0 - e;
-  double sh, ch, E;
+  double sh, ch;
   if (EXO_WAVE_ALL(e == 0.0)) {
     // circular orbit (the reference's ecc=None branch, keplerian.py:331-332)
-    E = Mr;
-    sincos(0.5 * E, &sh, &ch);
+    sincos_halfpi(0.5 * Mr, &sh, &ch);
   } else {
-    // --- starter (Markley 1995 eqs. 15-20)
-    const double alpha = (3.0 * kPi * kPi + 1.6 * kPi * (kPi - Mr) / (1.0 + e)) * (1.0 / (kPi * kPi - 6.0));
-    const double d = 3.0 * ome + alpha * e;
-    const double q = 2.0 * alpha * d * ome - Mr * Mr;
-    const double r = (3.0 * alpha * d * (d - ome) + Mr * Mr) * Mr;
-    double w = cbrt(fabs(r) + sqrt(q * q * q + r * r));
+    // --- starter (Markley 1995 eqs. 15-20), fp32
+    const float pif = 3.14159265358979f;
+    const float Mf = (float)Mr, ef = (float)e, omf = (float)ome;
+    const float alpha = fmaf(1.6f * pif * (pif - Mf), fast_rcpf(1.0f + ef), 3.0f * pif * pif) * (1.0f / (pif * pif - 6.0f));
+    const float d = fmaf(alpha, ef, 3.0f * omf);
+    const float q = fmaf(2.0f * alpha * d, omf, -Mf * Mf);
+    const float r = fmaf(3.0f * alpha * d, d - omf, Mf * Mf) * Mf;
+    float w = fast_cbrtf(fabsf(r) + fast_sqrtf(fmaxf(fmaf(q * q, q, r * r), 0.0f)));
     w = w * w;
-    E = (2.0 * r * w / (w * w + w * q + q * q) + Mr) / d;
-    // --- one fifth-order correction (eqs. 21-24); residual as
-    //     (1-e) E + e (E - sin E) to survive e -> 1, E -> 0
-    sincos(0.5 * E, &sh, &ch);
+    const float E1 = fmaf(2.0f * r * w, fast_rcpf(fmaf(w, w + q, q * q)), Mf) * fast_rcpf(d);
+    const double E = (double)E1;
+    // --- one fifth-order correction (eqs. 21-24), fp64
+    sincos_halfpi(0.5 * E, &sh, &ch);
     const double sinE = 2.0 * sh * ch;
-    const double f0 = ome * E + e * x_minus_sin(E, sinE) - Mr;
-    const double f1 = ome + 2.0 * e * sh * sh;  // 1 - e cos E
+    const double f0 = fma(ome, E, fma(e, x_minus_sin(E, sinE), -Mr));
+    const double f1 = fma(2.0 * e * sh, sh, ome);  // 1 - e cos E
     const double f2 = e * sinE;
     const double f3 = 1.0 - f1;
-    const double d3 = -f0 / (f1 - 0.5 * f0 * f2 / f1);
-    const double d4 = -f0 / (f1 + 0.5 * d3 * f2 + d3 * d3 * f3 * (1.0 / 6.0));
-    const double d5 = -f0 / (f1 + 0.5 * d4 * f2 + d4 * d4 * f3 * (1.0 / 6.0) - d4 * d4 * d4 * f2 * (1.0 / 24.0));
+    // d3, d4 only steer the last denominator: ~1e-8 reciprocals are plenty there
+    const double d3 = -f0 * approx_rcp(fma(-0.5 * f0 * f2, approx_rcp(f1), f1));
+    const double d4 = -f0 * approx_rcp(fma(d3 * d3 * (1.0 / 6.0), f3, fma(0.5 * d3, f2, f1)));
+    const double d42 = d4 * d4;
+    const double d5 = -fast_div(f0, fma(-d42 * d4 * (1.0 / 24.0), f2, fma(d42 * (1.0 / 6.0), f3, fma(0.5 * d4, f2, f1))));
     // |d5| <= 4.4e-4 over the whole (M,e) domain: rotate (sh,ch) by d5/2 with
     // a 4th-order Taylor rotation instead of a second sincos
     const double h = 0.5 * d5, h2 = h * h;
-    const double sd = h * (1.0 - h2 * (1.0 / 6.0));
-    const double cd = 1.0 - h2 * (0.5 - h2 * (1.0 / 24.0));
-    const double sh2 = sh * cd + ch * sd;
-    ch = ch * cd - sh * sd;
+    const double sd = h * fma(-h2, 1.0 / 6.0, 1.0);
+    const double cd = fma(-h2, fma(-h2, 1.0 / 24.0, 0.5), 1.0);
+    const double sh2 = fma(sh, cd, ch * sd);
+    ch = fma(ch, cd, -sh * sd);
     sh = sh2;
   }
   KeplerHalf o;

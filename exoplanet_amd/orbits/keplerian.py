@@ -39,6 +39,9 @@ def as_tensor(x, like=None):
     if isinstance(x, torch.Tensor):
         return x if x.dtype == torch.float64 else x.to(torch.float64)
     dev = like.device if isinstance(like, torch.Tensor) else _default_device()
+    if isinstance(x, (int, float)):
+        # a fill kernel rather than a host-to-device copy: legal while a hipGraph is capturing
+        return torch.full((), float(x), dtype=torch.float64, device=dev)
     return torch.as_tensor(x, dtype=torch.float64, device=dev)
 
 
