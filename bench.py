@@ -72,6 +72,17 @@ class HipEvents:
         return float(np.mean(out)), out
 
 
+def measured_traffic(kernel, n_draw):
+    """HBM bytes per launch from the committed PMC passes (profiles/r01_pmc.json),
+    scaled to this run's draw count; None if the profile is absent."""
+    try:
+        p = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc.json")))
+        k = p["kernels"][kernel]
+        return (2.0 * k["fetch_kib"] + k["write_kib"]) * 1024.0 * n_draw / p["draws"]
+    except Exception:
+        return None
+
+
 def make_leaves(n_draw, seed, dev):
     """C2 base parameters x (1 + 1e-3 N(0,1)), one row per draw, as autograd leaves."""
     rng = np.random.default_rng(seed)
@@ -250,7 +261,7 @@ def main():
             "roofline": {
                 "bound": "hbm", "kernel": "transit_scan_kernel<false>",
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": measured_traffic("transit_scan_kernel<false>", D),
                 "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": kernel_ms,
                 "note": "24 B per (draw, cadence) x draws x cadences / mean hipEvent time of the kernel over the "
                         "timed steps; the every-cadence case is fp64-VALU bound (Kepler solve per sample), "
@@ -280,7 +291,8 @@ def main():
             out["extras"] = {
                 "in_transit_only": {"evals_per_s": world * D * ex_steps / wall2, "kernel_ms": k2,
                                     "alg_GBps": ALG_BYTES_PER_UNIT * D * N_CAD / (k2 * 1e-3) / 1e9,
-                                    "note": "reference default use_in_transit=True (contact-point windows)"},
+                                    "note": "reference default use_in_transit=True (contact-point windows); this "
+                                            "extra leg launches eagerly (no hipGraph), so its evals/s is launch-bound"},
                 "op_level_every_cadence": {"evals_per_s": world * D * ex_steps / wall3,
                                            "ms_per_step": 1e3 * wall3 / ex_steps,
                                            "note": "fused kernel call only, no orbit algebra / autograd"},

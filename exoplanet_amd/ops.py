@@ -262,11 +262,14 @@ class _TransitFluxDot(torch.autograd.Function):
                                        events)
         ctx.save_for_backward(gparams, gld)
         ctx.mark_non_differentiable(flux)
+        ctx.set_materialize_grads(False)  # never build a (D, N) zero cotangent for the detached flux
         return flux, dot
 
     @staticmethod
     def backward(ctx, _gflux_unused, gdot):
         gparams, gld = ctx.saved_tensors
+        if gdot is None:
+            return (None,) * 9
         return (None, None, None, None, gdot[:, None, None] * gparams, gdot[:, None] * gld, None, None, None)
 
 
