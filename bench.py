@@ -12,8 +12,8 @@ roofline case), float64, cotangent gbar ~ N(0,1).  One *evaluation* = forward
 flux for all 150 000 cadences of one posterior draw + the VJP of gbar back to
 all orbit / limb-darkening parameters.  One *step* = one pass of the hot path
 over a batch of `--draws-per-gpu` draws (base parameters x (1 + 1e-3 N(0,1))):
-leaf parameters -> KeplerianOrbit algebra (torch) -> fused HIP kernel (value +
-VJP in one sweep) -> autograd back to the leaves; with N > 1 ranks each own
+leaf parameters -> record-packing kernel (KeplerianOrbit algebra + get_cl) ->
+scan + heavy kernels (value + VJP in one sweep) -> packing VJP -> leaf gradients; with N > 1 ranks each own
 their draws (weak scaling) and exchange only the per-draw scalar sum(gbar*flux)
 by one all-reduce.  Inputs are resident in HBM before the timed region.
 """
@@ -102,10 +102,8 @@ def step(xo, ops, leaves, t, gbar, events=(None, None), use_in_transit=False):
     """one pass of the hot path over the batch: returns (flux, L[d], grads of the leaves)"""
     orbit = xo.KeplerianOrbit(period=leaves["period"], t0=leaves["t0"], b=leaves["b"], ecc=leaves["ecc"],
                               omega=leaves["omega"])
-    rec, _ = orbit.kernel_records(leaves["r"], use_in_transit=use_in_transit)
-    c = xo.light_curves.get_cl(leaves["u1"], leaves["u2"])
-    flags = ops.FLAG_WINDOW if use_in_transit else 0
-    flux, L = ops.transit_flux_dot(t, rec.contiguous(), c.contiguous(), gbar, flags=flags, events=events)
+    rec, ld, _, flags = orbit.kernel_inputs(leaves["r"], (leaves["u1"], leaves["u2"]), use_in_transit=use_in_transit)
+    flux, L = ops.transit_flux_dot(t, rec, ld, gbar, flags=flags, events=events)
     grads = torch.autograd.grad(L.sum(), list(leaves.values()))
     return flux, L, grads
 
@@ -198,9 +196,9 @@ def main():
             dist.all_reduce(L_all)     # the only collective: per-draw scalars, 8 B x D x N
         return flux, L, grads
 
-    # The step is ~170 tiny torch kernels (O(P) orbit algebra + its autograd) around
-    # three HIP kernels: launch-bound when issued eagerly, so the timed region
-    # replays it as ONE hipGraph (the collective stays outside the graph).
+    # The step is a dozen short launches (packing kernel, scan, heavy, reduce, packing
+    # VJP and a few tensor-shuffling torch kernels): launch-bound when issued eagerly,
+    # so the timed region replays it as ONE hipGraph (the collective stays outside).
     graph = None
     static = {}
     if not args.no_graph:
@@ -255,8 +253,8 @@ def main():
                             "transit, 150000 cadences, value+grad, every cadence evaluated (use_in_transit=False)",
                 "n_cadences": N_CAD, "draws_per_gpu": D, "global_draws": world * D,
                 "parallelism": f"draws sharded over {world} GPU(s); all-reduce of per-draw scalars only",
-                "step": "leaf params -> torch orbit algebra -> HIP scan + heavy kernels (value+VJP, one sweep) -> "
-                        "autograd to leaves" + ("; replayed as one hipGraph" if graph is not None else "; eager launches"),
+                "step": "leaf params -> record-packing kernel (orbit algebra + get_cl) -> scan + heavy kernels "
+                        "(value+VJP, one sweep) -> packing VJP kernel -> leaf gradients" + ("; replayed as one hipGraph" if graph is not None else "; eager launches"),
             },
             "roofline": {
                 "bound": "hbm", "kernel": "transit_scan_kernel<false>",
@@ -284,8 +282,8 @@ def main():
         # op-level time of the one-sweep kernel call alone (no torch glue)
         orbit = xo.KeplerianOrbit(period=leaves["period"], t0=leaves["t0"], b=leaves["b"], ecc=leaves["ecc"],
                                   omega=leaves["omega"])
-        rec = orbit.kernel_records(leaves["r"])[0].detach().contiguous()
-        c = xo.light_curves.get_cl(leaves["u1"], leaves["u2"]).detach().contiguous()
+        rec, c, _, _ = orbit.kernel_inputs(leaves["r"], (leaves["u1"], leaves["u2"]))
+        rec, c = rec.detach(), c.detach()
         wall3 = time_steps(lambda i: ops.transit_flux_value_and_vjp(t, rec, c, gbar), ex_steps, 2, dist, dev)
         if rank == 0:
             out["extras"] = {

@@ -51,6 +51,8 @@ _SIGNATURES = {
         [_c_dp, _c_dp, _i64, _i64, _c_dp, _i32, _c_dp, _i32, _i64, _c_dp, _c_dp, _c_dp, _c_dp, _c_dp, _c_dp,
          _c_dp, _c_dp],
     ),
+    "exo_pack_records_f64": (ctypes.c_int, [_c_dp, _c_dp, _i64, _i32, _u32, _c_dp, _c_dp, _c_dp]),
+    "exo_pack_records_vjp_f64": (ctypes.c_int, [_c_dp, _c_dp, _i64, _i32, _u32, _c_dp, _c_dp, _c_dp, _c_dp, _c_dp]),
 }
 
 _ERRORS = {1: "invalid argument", 2: "kernel launch failed", 3: "workspace too small"}

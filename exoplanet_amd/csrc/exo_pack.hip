@@ -1,0 +1,242 @@
+// exo_pack.hip -- the O(planets) parameter algebra of KeplerianOrbit.__init__ as
+// ONE kernel (and one reverse kernel), for the standard transit parameterisation
+//   (period, t0, b, ecc, omega, r, m_star, r_star, m_planet[, sbr]; u1, u2)
+// -> the per-(draw, planet) records of the fused light-curve kernels.
+//
+// Restates (all under /root/reference/src/exoplanet):
+//   orbits/keplerian.py:925-928   a = (G (m_star+m_planet) P^2 / 4 pi^2)^(1/3)
+//   orbits/keplerian.py:146       n = 2 pi / P
+//   orbits/keplerian.py:205-210   E0 = 2 atan2(sqrt(1-e) cos w, sqrt(1+e)(1+sin w)),  M0 = E0 - e sin E0
+//   orbits/keplerian.py:212-228   incl_factor, cos i = incl_factor R_star / a * b
+//   orbits/keplerian.py:277-281   t_periastron = t0 - M0 / n ;  sin i
+//   orbits/keplerian.py:733-763   in-transit window (circular closed form / contact points)
+//   orbits/keplerian.py:779-804   _flip for the occultation window
+//   light_curves/limb_dark.py:11-18   get_cl
+//   light_curves/secondary_eclipse.py:67-68   flux_ratio = sbr k^2
+// In torch this is ~170 launch-bound elementwise kernels (forward + autograd) per
+// leapfrog step; here it is two.  One (draw, planet) per lane.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "../../include/exoplanet_amd.h"
+#include "exo_contact.hpp"
+
+namespace {
+
+constexpr double kG = 2942.2062175044193;  // R_sun^3 / M_sun / day^2 (orbits/constants.py:32)
+constexpr double kPi = 3.14159265358979323846;
+
+struct Derived {
+  double a, n, cw, sw, E0, M0, f, cosi, x, y, mtot;
+};
+
+__device__ __forceinline__ Derived derive(const double* in, bool circular) {
+  Derived d;
+  const double P = in[EXO_IN_PERIOD], e = circular ? 0.0 : in[EXO_IN_ECC];
+  d.mtot = in[EXO_IN_MSTAR] + in[EXO_IN_MPLANET];
+  d.a = cbrt(kG * d.mtot * P * P * (1.0 / (4.0 * kPi * kPi)));
+  d.n = 2.0 * kPi / P;
+  if (circular) {
+    d.cw = 1.0; d.sw = 0.0; d.E0 = 0.5 * kPi; d.M0 = 0.5 * kPi; d.f = 1.0; d.x = 1.0; d.y = 1.0;
+  } else {
+    sincos(in[EXO_IN_OMEGA], &d.sw, &d.cw);
+    d.y = sqrt(1.0 - e) * d.cw;
+    d.x = sqrt(1.0 + e) * (1.0 + d.sw);
+    d.E0 = 2.0 * atan2(d.y, d.x);
+    d.M0 = d.E0 - e * sin(d.E0);
+    d.f = (1.0 + e * d.sw) / (1.0 - e * e);
+  }
+  d.cosi = d.f * in[EXO_IN_RSTAR] / d.a * in[EXO_IN_B];
+  return d;
+}
+
+__global__ __launch_bounds__(64) void pack_kernel(const double* __restrict__ orbit_in,
+                                                  const double* __restrict__ ld_in, int64_t n_draw, int n_planet,
+                                                  uint32_t flags, double* __restrict__ params,
+                                                  double* __restrict__ ld) {
+  const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  const bool circular = flags & EXO_PACK_CIRCULAR, secondary = flags & EXO_FLAG_SECONDARY;
+  const bool window = flags & EXO_FLAG_WINDOW;
+  const double inf = __builtin_inf();
+  if (i < n_draw * n_planet) {
+    const double* in = orbit_in + i * EXO_NIN;
+    double* o = params + i * EXO_NPAR;
+    const Derived d = derive(in, circular);
+    const double e = circular ? 0.0 : in[EXO_IN_ECC];
+    const double P = in[EXO_IN_PERIOD], Rs = in[EXO_IN_RSTAR], r = in[EXO_IN_R];
+    const double sini = sqrt(fmax(0.0, 1.0 - d.cosi * d.cosi));  // sin(acos(cos i))
+    o[EXO_P_N] = d.n;
+    o[EXO_P_TP] = in[EXO_IN_T0] - d.M0 / d.n;
+    o[EXO_P_ECC] = e;
+    o[EXO_P_COSW] = d.cw;
+    o[EXO_P_SINW] = d.sw;
+    o[EXO_P_COSI] = d.cosi;
+    o[EXO_P_SINI] = sini;
+    o[EXO_P_AOR] = d.a / Rs;
+    o[EXO_P_ROR] = r / Rs;
+    o[EXO_P_T0] = in[EXO_IN_T0];
+    o[EXO_P_PERIOD] = P;
+    const double k = r / Rs;
+    o[EXO_P_FRATIO] = secondary ? in[EXO_IN_SBR] * k * k : 0.0;
+    double ts = -inf, te = inf, ts2 = -inf, te2 = inf;
+    if (window) {
+      const double hp = 0.5 * P;
+      if (circular) {
+        // Winn (2010) eq. 14, keplerian.py:733-741
+        const double arg = (1.0 + k) * (1.0 + k) - in[EXO_IN_B] * in[EXO_IN_B];
+        const double hdur = hp * asin(Rs / (d.a * sini) * sqrt(arg)) * (1.0 / kPi);
+        ts = -hdur; te = hdur;
+        if (secondary) { ts2 = hp - hdur; te2 = hp + hdur; }  // flipped orbit: half a period later
+      } else {
+        double ml, mr;
+        if (!exo::contact_solve(d.a, e, d.cw, d.sw, d.cosi, Rs + r, &ml, &mr)) {
+          double a0 = (ml - d.M0) / d.n + hp, a1 = (mr - d.M0) / d.n + hp;
+          a0 = a0 - P * floor(a0 / P) - hp;
+          a1 = a1 - P * floor(a1 / P) - hp;
+          ts = a0 > 0.0 ? a0 - P : a0;
+          te = a1 < 0.0 ? a1 + P : a1;
+        }
+        if (secondary) {
+          // occultation = transit of the flipped orbit (omega - pi): same ellipse, same t_periastron
+          const double y2 = -sqrt(1.0 - e) * d.cw, x2 = sqrt(1.0 + e) * (1.0 - d.sw);
+          const double E02 = 2.0 * atan2(y2, x2);
+          const double M02 = E02 - e * sin(E02);
+          if (!exo::contact_solve(d.a, e, -d.cw, -d.sw, d.cosi, Rs + r, &ml, &mr)) {
+            double a0 = (ml - M02) / d.n + hp, a1 = (mr - M02) / d.n + hp;
+            a0 = a0 - P * floor(a0 / P) - hp;
+            a1 = a1 - P * floor(a1 / P) - hp;
+            const double s0 = a0 > 0.0 ? a0 - P : a0, s1 = a1 < 0.0 ? a1 + P : a1;
+            double shift = (M02 - d.M0) / d.n;          // t0(flipped) - t0
+            shift = shift - P * floor(shift / P);       // [0, P)
+            const double lo = shift + s0, hi = shift + s1;
+            if (lo >= 0.0 && hi <= P) { ts2 = lo; te2 = hi; }
+          }
+        }
+      }
+    }
+    o[EXO_P_TS] = ts; o[EXO_P_TE] = te; o[EXO_P_TS2] = ts2; o[EXO_P_TE2] = te2;
+  }
+  // limb darkening: u -> c (get_cl), one draw per lane of the first lanes
+  if (i < n_draw) {
+    const int nset = secondary ? 2 : 1;
+    for (int s = 0; s < nset; ++s) {
+      const double u1 = ld_in[i * 2 * nset + 2 * s], u2 = ld_in[i * 2 * nset + 2 * s + 1];
+      const double c0 = 1.0 - u1 - 1.5 * u2, c1 = u1 + 2.0 * u2, c2 = -0.25 * u2;
+      const double inorm = 1.0 / (kPi * (c0 + c1 * (1.0 / 1.5)));
+      double* o = ld + i * 3 * nset + 3 * s;
+      o[0] = c0 * inorm; o[1] = c1 * inorm; o[2] = c2 * inorm;
+    }
+  }
+}
+
+__global__ __launch_bounds__(64) void pack_vjp_kernel(const double* __restrict__ orbit_in,
+                                                      const double* __restrict__ ld_in, int64_t n_draw,
+                                                      int n_planet, uint32_t flags,
+                                                      const double* __restrict__ gparams,
+                                                      const double* __restrict__ gld,
+                                                      double* __restrict__ gorbit_in, double* __restrict__ gld_in) {
+  const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  const bool circular = flags & EXO_PACK_CIRCULAR, secondary = flags & EXO_FLAG_SECONDARY;
+  if (i < n_draw * n_planet) {
+    const double* in = orbit_in + i * EXO_NIN;
+    const double* g = gparams + i * EXO_NPAR;
+    double* o = gorbit_in + i * EXO_NIN;
+    const Derived d = derive(in, circular);
+    const double e = circular ? 0.0 : in[EXO_IN_ECC];
+    const double P = in[EXO_IN_PERIOD], Rs = in[EXO_IN_RSTAR], r = in[EXO_IN_R], b = in[EXO_IN_B];
+    double Pb = 0, t0b = 0, bb = 0, eb = 0, wb = 0, rb = 0, Msb = 0, Rsb = 0, ab = 0, nb = 0, cwb = 0, swb = 0;
+    // ror = r / Rs ;  aor = a / Rs
+    rb += g[EXO_P_ROR] / Rs;
+    Rsb -= g[EXO_P_ROR] * r / (Rs * Rs);
+    ab += g[EXO_P_AOR] / Rs;
+    Rsb -= g[EXO_P_AOR] * d.a / (Rs * Rs);
+    if (secondary) {  // fratio = sbr r^2 / Rs^2
+      const double gf = g[EXO_P_FRATIO], k = r / Rs;
+      o[EXO_IN_SBR] = gf * k * k;
+      rb += gf * in[EXO_IN_SBR] * 2.0 * k / Rs;
+      Rsb -= gf * in[EXO_IN_SBR] * 2.0 * k * k / Rs;
+    } else {
+      o[EXO_IN_SBR] = 0.0;
+    }
+    // cos i = f Rs b / a
+    const double gci = g[EXO_P_COSI];
+    const double fb = gci * Rs * b / d.a;
+    Rsb += gci * d.f * b / d.a;
+    bb += gci * d.f * Rs / d.a;
+    ab -= gci * d.cosi / d.a;
+    // t_peri = t0 - M0 / n
+    const double gtp = g[EXO_P_TP];
+    t0b += gtp;
+    const double M0b = -gtp / d.n;
+    nb += g[EXO_P_N] + gtp * d.M0 / (d.n * d.n);
+    if (!circular) {
+      const double ome2 = 1.0 - e * e;
+      eb += g[EXO_P_ECC] + fb * (d.sw / ome2 + (1.0 + e * d.sw) * 2.0 * e / (ome2 * ome2));
+      swb += g[EXO_P_SINW] + fb * e / ome2;
+      cwb += g[EXO_P_COSW];
+      // M0 = E0 - e sin E0 ; E0 = 2 atan2(y, x)
+      double sE, cE;
+      sincos(d.E0, &sE, &cE);
+      const double E0b = M0b * (1.0 - e * cE);
+      eb -= M0b * sE;
+      const double h2 = d.x * d.x + d.y * d.y;
+      const double yb = E0b * 2.0 * d.x / h2, xb = -E0b * 2.0 * d.y / h2;
+      const double se = sqrt(1.0 - e), pe = sqrt(1.0 + e);
+      cwb += yb * se;
+      eb -= yb * d.cw * 0.5 / se;
+      swb += xb * pe;
+      eb += xb * (1.0 + d.sw) * 0.5 / pe;
+      wb = -cwb * d.sw + swb * d.cw;
+    }
+    // n = 2 pi / P ;  a = (G mtot P^2 / 4 pi^2)^(1/3)
+    Pb += -nb * d.n / P + ab * 2.0 * d.a / (3.0 * P);
+    Msb += ab * d.a / (3.0 * d.mtot);
+    o[EXO_IN_PERIOD] = Pb; o[EXO_IN_T0] = t0b; o[EXO_IN_B] = bb; o[EXO_IN_ECC] = eb; o[EXO_IN_OMEGA] = wb;
+    o[EXO_IN_R] = rb; o[EXO_IN_MSTAR] = Msb; o[EXO_IN_RSTAR] = Rsb; o[EXO_IN_MPLANET] = Msb;
+  }
+  if (i < n_draw) {
+    const int nset = secondary ? 2 : 1;
+    for (int s = 0; s < nset; ++s) {
+      const double u1 = ld_in[i * 2 * nset + 2 * s], u2 = ld_in[i * 2 * nset + 2 * s + 1];
+      const double* g = gld + i * 3 * nset + 3 * s;
+      const double c0 = 1.0 - u1 - 1.5 * u2, c1 = u1 + 2.0 * u2, c2 = -0.25 * u2;
+      const double nrm = kPi * (c0 + c1 * (1.0 / 1.5)), inorm = 1.0 / nrm;
+      // c_k = C_k / nrm :  dC/du1 = (-1, 1, 0), dC/du2 = (-1.5, 2, -0.25), dnrm/du1 = pi(-1 + 2/3), dnrm/du2 = pi(-1.5 + 4/3)
+      const double dot = (g[0] * c0 + g[1] * c1 + g[2] * c2) * inorm * inorm;
+      gld_in[i * 2 * nset + 2 * s] = (-g[0] + g[1]) * inorm - dot * kPi * (-1.0 + 2.0 / 3.0);
+      gld_in[i * 2 * nset + 2 * s + 1] = (-1.5 * g[0] + 2.0 * g[1] - 0.25 * g[2]) * inorm - dot * kPi * (-1.5 + 4.0 / 3.0);
+    }
+  }
+}
+
+inline int launch_status() { return hipGetLastError() == hipSuccess ? EXO_OK : EXO_ERR_LAUNCH; }
+
+}  // namespace
+
+extern "C" {
+
+int exo_pack_records_f64(const double* orbit_in, const double* ld_in, int64_t n_draw, int32_t n_planet,
+                         uint32_t flags, double* params, double* ld, void* stream) {
+  if (n_draw < 0 || n_planet < 1 || n_planet > EXO_MAX_PLANETS) return EXO_ERR_INVALID_ARGUMENT;
+  if (n_draw == 0) return EXO_OK;
+  if (!orbit_in || !ld_in || !params || !ld) return EXO_ERR_INVALID_ARGUMENT;
+  const int64_t n = n_draw * n_planet;
+  hipLaunchKernelGGL(pack_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, (hipStream_t)stream, orbit_in, ld_in,
+                     n_draw, n_planet, flags, params, ld);
+  return launch_status();
+}
+
+int exo_pack_records_vjp_f64(const double* orbit_in, const double* ld_in, int64_t n_draw, int32_t n_planet,
+                             uint32_t flags, const double* gparams, const double* gld, double* gorbit_in,
+                             double* gld_in, void* stream) {
+  if (n_draw < 0 || n_planet < 1 || n_planet > EXO_MAX_PLANETS) return EXO_ERR_INVALID_ARGUMENT;
+  if (n_draw == 0) return EXO_OK;
+  if (!orbit_in || !ld_in || !gparams || !gld || !gorbit_in || !gld_in) return EXO_ERR_INVALID_ARGUMENT;
+  const int64_t n = n_draw * n_planet;
+  hipLaunchKernelGGL(pack_vjp_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, (hipStream_t)stream, orbit_in,
+                     ld_in, n_draw, n_planet, flags, gparams, gld, gorbit_in, gld_in);
+  return launch_status();
+}
+
+}  // extern "C"

@@ -23,6 +23,7 @@
 #include <stdint.h>
 
 #include "../../include/exoplanet_amd.h"
+#include "exo_contact.hpp"
 #include "exo_math.hpp"
 
 namespace {
@@ -440,18 +441,6 @@ __global__ __launch_bounds__(kBlock) void quad_sv_kernel(const double* __restric
   }
 }
 
-// Contact points: roots of rho(f)^2 (1 - sin^2 i sin^2(omega+f)) = L^2 nearest
-// the transit centre, by a coarse outward scan for the bracket + bisection on
-// the definition.  O(planets) work, one element per lane.
-__device__ __forceinline__ double contact_g(double th, double p, double e, double cw, double sw,
-                                            double ci, double L) {
-  double st, ct;
-  sincos(th, &st, &ct);
-  const double cosf = sw * ct - cw * st;  // th = omega + f - pi/2
-  const double rho = p / (1.0 + e * cosf);
-  return rho * rho * (st * st + ci * ci * ct * ct) - L * L;
-}
-
 __global__ __launch_bounds__(64) void contact_points_kernel(
     const double* __restrict__ a, const double* __restrict__ e_, const double* __restrict__ cosw,
     const double* __restrict__ sinw, const double* __restrict__ cosi, const double* __restrict__ sini,
@@ -459,35 +448,12 @@ __global__ __launch_bounds__(64) void contact_points_kernel(
     int32_t* __restrict__ flag, int64_t n) {
   const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
   if (i >= n) return;
-  const double e = e_[i], cw = cosw[i], sw = sinw[i], ci = cosi[i], L = L_[i];
   (void)sini;
-  const double p = a[i] * (1.0 - e * e);
-  double out[2] = {0.0, 0.0};
-  int bad = !(contact_g(0.0, p, e, cw, sw, ci, L) < 0.0);
-  for (int side = 0; side < 2 && !bad; ++side) {
-    const double sgn = side == 0 ? -1.0 : 1.0;
-    double lo = 0.0, hi = 0.0;
-    bool found = false;
-    for (int k = 1; k <= 32; ++k) {
-      const double th = sgn * k * (exo::kHalfPi / 32.0);
-      if (contact_g(th, p, e, cw, sw, ci, L) > 0.0) { hi = th; found = true; break; }
-      lo = th;
-    }
-    if (!found) { bad = 1; break; }
-    for (int it = 0; it < 80; ++it) {
-      const double mid = 0.5 * (lo + hi);
-      if (contact_g(mid, p, e, cw, sw, ci, L) > 0.0) hi = mid; else lo = mid;
-    }
-    const double th = 0.5 * (lo + hi);
-    const double f = th + exo::kHalfPi - atan2(sw, cw);
-    double shf, chf;
-    sincos(0.5 * f, &shf, &chf);
-    const double E = 2.0 * atan2(sqrt(1.0 - e) * shf, sqrt(1.0 + e) * chf);
-    out[side] = E - e * sin(E);
-  }
-  Ml[i] = bad ? 0.0 : out[0];
-  Mr[i] = bad ? 0.0 : out[1];
-  flag[i] = bad;
+  double ml, mr;
+  const bool bad = exo::contact_solve(a[i], e_[i], cosw[i], sinw[i], cosi[i], L_[i], &ml, &mr);
+  Ml[i] = ml;
+  Mr[i] = mr;
+  flag[i] = bad ? 1 : 0;
 }
 
 inline int launch_status() { return hipGetLastError() == hipSuccess ? EXO_OK : EXO_ERR_LAUNCH; }

@@ -120,28 +120,23 @@ class LimbDarkLightCurve:
             return self._fused(orbit, r, t, texp, stencil, use_in_transit)
         return self._composed(orbit, r, t, texp, stencil, use_in_transit, light_delay)
 
-    # ---- hot path: one kernel from t to flux
+    # ---- hot path: one packing kernel + the fused light-curve kernels, nothing O(N) in torch
     def _fused(self, orbit, r, t, texp, stencil, use_in_transit, secondary=None):
-        t = as_tensor(t, orbit.a)
+        t = as_tensor(t, r if isinstance(r, torch.Tensor) else self.u1)
         if t.dim() != 1:
             raise ValueError("t must be a vector of times")
-        rec, batch = orbit.kernel_records(r, use_in_transit=use_in_transit,
-                                          secondary_sbr=None if secondary is None else secondary[1])
-        D, P = rec.shape[0], rec.shape[1]
-        c = self.c if secondary is None else torch.cat(torch.broadcast_tensors(self.c, secondary[0]), dim=-1)
-        nld = c.shape[-1]
-        ld = c.expand(batch + (nld,)).reshape(D, nld)
-        flags = ops.FLAG_PER_PLANET | (ops.FLAG_WINDOW if use_in_transit else 0)
-        if secondary is not None:
-            flags |= ops.FLAG_SECONDARY
+        sec = None if secondary is None else ((secondary[0].u1, secondary[0].u2), secondary[1])
+        rec, ld, batch, flags = orbit.kernel_inputs(r, (self.u1, self.u2), use_in_transit=use_in_transit,
+                                                    secondary=sec)
+        t = t.to(rec.device)
         kw = {}
         if texp is not None:
             dt, w = stencil
             kw = dict(texp=as_tensor(texp, t).reshape(-1).detach(),
                       stencil_dt=torch.as_tensor(dt, dtype=torch.float64, device=t.device),
                       stencil_w=torch.as_tensor(w, dtype=torch.float64, device=t.device))
-        flux = ops.transit_flux(t.detach(), rec.contiguous(), ld.contiguous(), flags=flags, **kw)
-        return flux.reshape(batch + (t.shape[0], P))
+        flux = ops.transit_flux(t.detach(), rec, ld, flags=flags | ops.FLAG_PER_PLANET, **kw)
+        return flux.reshape(tuple(batch) + (t.shape[0], rec.shape[1]))
 
     # ---- generic orbit objects: ops.quad_solution_vector on their positions
     def _composed(self, orbit, r, t, texp, stencil, use_in_transit, light_delay):

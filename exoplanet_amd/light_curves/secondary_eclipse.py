@@ -39,9 +39,8 @@ class SecondaryEclipseLightCurve:
         if fused:
             use_in_transit = True if use_in_transit is None else use_in_transit
             stencil = exposure_stencil(oversample, order) if texp is not None else None
-            sbr = self.surface_brightness_ratio.to(orbit.a.device)
             return self.primary._fused(orbit, r, t, texp, stencil, use_in_transit,
-                                       secondary=(self.secondary.c.to(orbit.a.device), sbr))
+                                       secondary=(self.secondary, self.surface_brightness_ratio))
         # composed path: exactly the reference's two-orbit blend (secondary_eclipse.py:45-70)
         r = _vec(r)
         orbit2 = orbit._flip(r)

@@ -23,6 +23,9 @@ NPAR = 16
 FLAG_PER_PLANET = 1
 FLAG_WINDOW = 2
 FLAG_SECONDARY = 4
+PACK_CIRCULAR = 8
+NIN = 10
+(IN_PERIOD, IN_T0, IN_B, IN_ECC, IN_OMEGA, IN_R, IN_MSTAR, IN_RSTAR, IN_MPLANET, IN_SBR) = range(10)
 MAX_PLANETS = 16
 MAX_SUBEXP = 63
 
@@ -279,3 +282,51 @@ def transit_flux_dot(t, params, ld, gflux, texp=None, stencil_dt=None, stencil_w
     ``(flux, L)`` with ``L[d] = (gflux[d] * flux[d]).sum()``; ``L`` is
     differentiable w.r.t. ``params`` and ``ld`` (flux itself is returned detached)."""
     return _TransitFluxDot.apply(t, texp, stencil_dt, stencil_w, params, ld, gflux, int(flags), events)
+
+
+# ------------------------------------------------------------------------------
+# record packing: KeplerianOrbit.__init__ algebra + get_cl + windows as one kernel
+# ------------------------------------------------------------------------------
+class _PackRecords(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, orbit_in, ld_in, flags):
+        orbit_in = _dev(orbit_in, "orbit_in")
+        ld_in = _dev(ld_in, "ld_in")
+        if orbit_in.dim() != 3 or orbit_in.shape[-1] != NIN:
+            raise ValueError(f"orbit_in must be (n_draw, n_planet, {NIN})")
+        D, P, _ = orbit_in.shape
+        nset = 2 if flags & FLAG_SECONDARY else 1
+        if ld_in.shape != (D, 2 * nset):
+            raise ValueError(f"ld_in must be (n_draw, {2 * nset})")
+        params = torch.empty(D, P, NPAR, dtype=torch.float64, device=orbit_in.device)
+        ld = torch.empty(D, 3 * nset, dtype=torch.float64, device=orbit_in.device)
+        lib = _lib.load()
+        with torch.cuda.device(orbit_in.device):
+            _lib.check(lib.exo_pack_records_f64(_ptr(orbit_in), _ptr(ld_in), D, P, flags, _ptr(params), _ptr(ld),
+                                                _stream(orbit_in)), "exo_pack_records_f64")
+        ctx.save_for_backward(orbit_in, ld_in)
+        ctx.flags = flags
+        return params, ld
+
+    @staticmethod
+    def backward(ctx, gparams, gld):
+        orbit_in, ld_in = ctx.saved_tensors
+        D, P, _ = orbit_in.shape
+        gparams = _dev(gparams, "gparams")
+        gld = _dev(gld, "gld")
+        go = torch.empty_like(orbit_in)
+        gl = torch.empty_like(ld_in)
+        lib = _lib.load()
+        with torch.cuda.device(orbit_in.device):
+            _lib.check(lib.exo_pack_records_vjp_f64(_ptr(orbit_in), _ptr(ld_in), D, P, ctx.flags, _ptr(gparams),
+                                                    _ptr(gld), _ptr(go), _ptr(gl), _stream(orbit_in)),
+                       "exo_pack_records_vjp_f64")
+        return go, gl, None
+
+
+def pack_records(orbit_in, ld_in, flags=0):
+    """(period, t0, b, ecc, omega, r, m_star, r_star, m_planet, sbr) per (draw, planet) and
+    (u1, u2[, u1s, u2s]) per draw -> kernel records (n_draw, n_planet, 16) and Green's-basis
+    limb-darkening coefficients (n_draw, 3|6): KeplerianOrbit.__init__ + get_cl + windows in
+    one kernel, differentiable.  Slot order: include/exoplanet_amd.h EXO_IN_*."""
+    return _PackRecords.apply(orbit_in, ld_in, int(flags))

@@ -61,11 +61,87 @@ class KeplerianOrbit:
     ``m_star, r_star, rho_star``; one of ``t0`` / ``t_periastron``.
     """
 
+    # attributes computed lazily from the constructor arguments (first access runs the algebra once)
+    _DERIVED = frozenset((
+        "a", "period", "rho_star", "r_star", "m_star", "m_planet", "m_total", "n", "a_star", "a_planet", "K0",
+        "Omega", "cos_Omega", "sin_Omega", "ecc", "omega", "cos_omega", "sin_omega", "M0", "dcosidb", "b",
+        "cos_incl", "incl", "sin_incl", "duration", "t0", "t_periastron", "tref", "jacobians"))
+
     def __init__(self, period=None, a=None, t0=None, t_periastron=None, incl=None, b=None, duration=None,
                  ecc=None, omega=None, sin_omega=None, cos_omega=None, Omega=None, m_planet=0.0,
                  m_star=None, r_star=None, rho_star=None, ror=None, **kwargs):
         if kwargs:
             raise TypeError(f"unsupported arguments {sorted(kwargs)} (astropy units are not handled here)")
+        self._args = dict(period=period, a=a, t0=t0, t_periastron=t_periastron, incl=incl, b=b, duration=duration,
+                          ecc=ecc, omega=omega, sin_omega=sin_omega, cos_omega=cos_omega, Omega=Omega,
+                          m_planet=m_planet, m_star=m_star, r_star=r_star, rho_star=rho_star, ror=ror)
+        self._ready = False
+        self._validate()
+        # the standard transit parameterisation goes through the fused packing kernel and
+        # never needs the attribute algebra; everything else materialises on first access
+        A = self._args
+        self._standard = (
+            period is not None and a is None and t_periastron is None and incl is None and duration is None
+            and rho_star is None and sin_omega is None and cos_omega is None
+            and (ecc is None) == (omega is None) and (m_star is None) == (r_star is None))
+
+    def _validate(self):
+        """argument-combination errors of the reference constructor, without any tensor work
+        (keplerian.py:116-120,189-203,222-232,267-268,850-902)"""
+        A = self._args
+        a, period, rho_star, r_star, m_star = A["a"], A["period"], A["rho_star"], A["r_star"], A["m_star"]
+        duration_circular = A["ecc"] is None and A["duration"] is not None
+        if duration_circular:
+            if A["b"] is None:
+                raise ValueError("'b' must be provided for a circular orbit with a 'duration'")
+            if A["ror"] is None:
+                warnings.warn("When using the 'duration' parameter in KeplerianOrbit, the 'ror' parameter "
+                              "should also be provided.", UserWarning)
+            a = True  # a is implied by the duration
+            if r_star is None:
+                r_star = 1.0
+        if a is None and period is None:
+            raise ValueError("values must be provided for at least one of a and period")
+        implied = False
+        if a is not None and period is not None:
+            if rho_star is not None or m_star is not None:
+                raise ValueError("if both a and period are given, you can't also define rho_star or m_star")
+            implied = True
+        if r_star is None and m_star is None:
+            r_star = 1.0
+            if rho_star is None:
+                m_star = 1.0
+        if (not implied) and sum(x is None for x in (rho_star, r_star, m_star)) != 1:
+            raise ValueError("values must be provided for exactly two of rho_star, m_star, and r_star")
+        if A["ecc"] is not None:
+            if A["omega"] is not None:
+                if A["sin_omega"] is not None and A["cos_omega"] is not None:
+                    raise ValueError("either 'omega' or 'sin_omega' and 'cos_omega' can be provided")
+            elif not (A["sin_omega"] is not None and A["cos_omega"] is not None):
+                raise ValueError("both e and omega must be provided")
+        dur = None if duration_circular else A["duration"]
+        if A["b"] is not None and (A["incl"] is not None or dur is not None):
+            raise ValueError("only one of 'incl', 'b', and 'duration' can be given")
+        if A["incl"] is not None and dur is not None:
+            raise ValueError("only one of 'incl', 'b', and 'duration' can be given")
+        if A["t0"] is not None and A["t_periastron"] is not None:
+            raise ValueError("you can't define both t0 and t_periastron")
+
+    def __getattr__(self, name):
+        # only reached when normal lookup fails: derived attributes before materialisation
+        if name in KeplerianOrbit._DERIVED and not self.__dict__.get("_ready", True):
+            self._materialize()
+            return self.__dict__[name] if name in self.__dict__ else object.__getattribute__(self, name)
+        raise AttributeError(f"{type(self).__name__!s} object has no attribute {name!r}")
+
+    def _materialize(self):
+        """the parameter algebra of the reference constructor (keplerian.py:110-281)"""
+        A = self._args
+        period, a, t0, t_periastron = A["period"], A["a"], A["t0"], A["t_periastron"]
+        incl, b, duration, ecc, omega = A["incl"], A["b"], A["duration"], A["ecc"], A["omega"]
+        sin_omega, cos_omega, Omega = A["sin_omega"], A["cos_omega"], A["Omega"]
+        m_planet, m_star, r_star, rho_star, ror = A["m_planet"], A["m_star"], A["r_star"], A["rho_star"], A["ror"]
+        self._ready = True
         self.jacobians = {}
         like = next((x for x in (period, a, t0, t_periastron, b, incl, ecc, omega, m_star, r_star, rho_star, m_planet)
                      if isinstance(x, torch.Tensor)), None)
@@ -76,11 +152,6 @@ class KeplerianOrbit:
         if ecc is None and duration is not None:
             if r_star is None:
                 r_star = 1.0
-            if b is None:
-                raise ValueError("'b' must be provided for a circular orbit with a 'duration'")
-            if ror is None:
-                warnings.warn("When using the 'duration' parameter in KeplerianOrbit, the 'ror' parameter "
-                              "should also be provided.", UserWarning)
             aor, daordtau = get_aor_from_transit_duration(T(duration), T(period), T(b), ror=T(ror))
             a = T(r_star) * aor
             duration = None
@@ -177,6 +248,12 @@ class KeplerianOrbit:
             self.t_periastron = self.t0 - self.M0 / self.n
         self.tref = self.t_periastron - self.t0
         self.sin_incl = torch.sin(self.incl)
+        if "duration" not in self.__dict__:
+            self.duration = None
+        if self.ecc is None:
+            self.omega = self.cos_omega = self.sin_omega = None
+        if self.Omega is None:
+            self.cos_Omega = self.sin_Omega = None
 
     # ------------------------------------------------------------------ shapes
     @property
@@ -395,10 +472,62 @@ class KeplerianOrbit:
                           m_planet=self.m_star, r_star=r_planet)
 
     # ------------------------------------------------------------------ fused-kernel records
+    def kernel_inputs(self, r, u, use_in_transit=False, secondary=None):
+        """Everything the fused light-curve kernels need, differentiable w.r.t. every
+        orbit / limb-darkening parameter: ``(records (D,P,16), ld (D,3|6), batch_shape, flags)``.
+
+        ``u = (u1, u2)``; ``secondary = ((u1s, u2s), sbr)`` adds the occultation.  For the
+        standard transit parameterisation (period, t0, b[, ecc, omega], r, [m_star, r_star],
+        m_planet) this is ONE packing kernel (ops.pack_records); any other
+        parameterisation runs the attribute algebra in torch."""
+        flags = (ops.FLAG_WINDOW if use_in_transit else 0) | (ops.FLAG_SECONDARY if secondary is not None else 0)
+        if self._standard:
+            A = self._args
+            like = next((x for x in list(A.values()) + [r] if isinstance(x, torch.Tensor)), None)
+            V = lambda x, default: _vec(default if x is None else x, like)  # noqa: E731
+            circular = A["ecc"] is None
+            # the surface-brightness ratio is a per-light-curve scalar (like u): a 1-D value is per draw
+            sbr = as_tensor(secondary[1] if secondary is not None else 0.0, like)
+            sbr = sbr.unsqueeze(-1) if sbr.dim() >= 1 else sbr.reshape(1)
+            cols = [V(A["period"], None), V(A["t0"], 0.0), V(A["b"], 0.0), V(A["ecc"], 0.0), V(A["omega"], 0.0),
+                    V(r, None), V(A["m_star"], 1.0), V(A["r_star"], 1.0), V(A["m_planet"], 0.0), sbr]
+            cols = torch.broadcast_tensors(*cols)
+            shape = cols[0].shape
+            orbit_in = torch.stack(cols, dim=-1).reshape(-1, shape[-1], ops.NIN)
+            batch = tuple(shape[:-1])
+            us = list(u) + (list(secondary[0]) if secondary is not None else [])
+            us = [as_tensor(x, like) for x in us]
+            ld_in = torch.stack(torch.broadcast_tensors(*us), dim=-1)
+            if ld_in.dim() > 2:
+                raise ValueError("limb-darkening coefficients may carry at most one draw dimension")
+            ld_in = ld_in.expand(batch + (len(us),)).reshape(-1, len(us)) if batch else ld_in.reshape(1, len(us))
+            if not batch and ld_in.shape[0] != 1:
+                # draws only on the limb-darkening side: give the orbit the same batch
+                orbit_in = orbit_in.expand(ld_in.shape[0], -1, -1)
+                batch = (ld_in.shape[0],)
+            rec, ld = ops.pack_records(orbit_in.contiguous(), ld_in.contiguous(),
+                                       flags | (ops.PACK_CIRCULAR if circular else 0))
+            return rec, ld, batch, flags
+        from ..light_curves.limb_dark import get_cl  # local import: light_curves imports this module
+
+        rec, batch = self.kernel_records(r, use_in_transit=use_in_transit,
+                                         secondary_sbr=None if secondary is None else secondary[1])
+        c = get_cl(u[0], u[1])
+        if secondary is not None:
+            c = torch.cat(torch.broadcast_tensors(c, get_cl(secondary[0][0], secondary[0][1]).to(c.device)), dim=-1)
+        D = rec.shape[0]
+        if c.dim() == 2 and not batch:
+            batch = (c.shape[0],)
+            rec = rec.expand(c.shape[0], -1, -1)
+            D = c.shape[0]
+        ld = c.to(rec.device).expand(batch + (c.shape[-1],)).reshape(D, c.shape[-1])
+        return rec.contiguous(), ld.contiguous(), batch, flags
+
     def kernel_records(self, r, use_in_transit=False, secondary_sbr=None):
         """Pack the per-(draw, planet) parameter records of the fused transit
-        kernel (layout: include/exoplanet_amd.h, EXO_P_*).  Differentiable with
-        respect to every orbit parameter; returns (D, P, 16) and the batch shape."""
+        kernel (layout: include/exoplanet_amd.h, EXO_P_*) from the orbit's attributes, in
+        torch (any parameterisation).  Differentiable with respect to every orbit
+        parameter; returns (D, P, 16) and the batch shape."""
         shape = self.shape
         z = torch.zeros(shape, dtype=torch.float64, device=self.a.device)
         r = _vec(r, self.a) + z
@@ -420,7 +549,9 @@ class KeplerianOrbit:
         cols[ops.P_FRATIO] = z
         cols[ops.P_TS2], cols[ops.P_TE2] = -inf, inf
         if secondary_sbr is not None:
-            cols[ops.P_FRATIO] = as_tensor(secondary_sbr, self.a) * (r / self.r_star) ** 2 + z
+            sbr = as_tensor(secondary_sbr, self.a)
+            sbr = sbr.unsqueeze(-1) if sbr.dim() >= 1 else sbr
+            cols[ops.P_FRATIO] = sbr * (r / self.r_star) ** 2 + z
         if use_in_transit:
             ts, te, flag = self._transit_window(r)
             bad = flag != 0

@@ -189,6 +189,41 @@ int exo_celerite_loglike_vjp_f64(const double* t, const double* diag, int64_t n_
                                  const double* state, double* gresid, double* gdiag, double* gdiag_sum,
                                  double* gcoef_real, double* gcoef_complex, void* stream);
 
+/* ---------------------------------------------------------------------------
+ * Record packing: the O(planets) algebra of KeplerianOrbit.__init__
+ * (src/exoplanet/orbits/keplerian.py:133-281,849-934), get_cl
+ * (src/exoplanet/light_curves/limb_dark.py:11-18), the in-transit windows
+ * (keplerian.py:733-763) and the secondary flux ratio
+ * (src/exoplanet/light_curves/secondary_eclipse.py:67-68) for the standard
+ * transit parameterisation, as one kernel + one reverse kernel (in the
+ * reference, and in torch, this is ~170 launch-bound elementwise nodes).
+ *
+ *   orbit_in  [n_draw][n_planet][EXO_NIN]   see EXO_IN_* (R_sun, M_sun, days)
+ *   ld_in     [n_draw][2] = (u1, u2), or [n_draw][4] with EXO_FLAG_SECONDARY
+ *   flags     EXO_PACK_CIRCULAR (ecc=None: e = 0, omega unused, keplerian.py:182-185),
+ *             EXO_FLAG_WINDOW (fill TS/TE[, TS2/TE2]; else +-inf), EXO_FLAG_SECONDARY
+ *   params    out [n_draw][n_planet][EXO_NPAR];  ld out [n_draw][3|6]
+ * ------------------------------------------------------------------------- */
+#define EXO_NIN 10
+#define EXO_IN_PERIOD 0
+#define EXO_IN_T0 1
+#define EXO_IN_B 2
+#define EXO_IN_ECC 3
+#define EXO_IN_OMEGA 4
+#define EXO_IN_R 5
+#define EXO_IN_MSTAR 6
+#define EXO_IN_RSTAR 7
+#define EXO_IN_MPLANET 8
+#define EXO_IN_SBR 9
+#define EXO_PACK_CIRCULAR 8u
+int exo_pack_records_f64(const double* orbit_in, const double* ld_in, int64_t n_draw, int32_t n_planet,
+                         uint32_t flags, double* params, double* ld, void* stream);
+/* Reverse: cotangents of params / ld -> cotangents of orbit_in / ld_in (window and
+ * T0 / PERIOD slots carry no gradient: they only select cadences).              */
+int exo_pack_records_vjp_f64(const double* orbit_in, const double* ld_in, int64_t n_draw,
+                             int32_t n_planet, uint32_t flags, const double* gparams,
+                             const double* gld, double* gorbit_in, double* gld_in, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -318,3 +318,149 @@ void oracle_transit(const double* t, int64_t n_cad, const double* texp, int64_t 
     }
   }
 }
+
+/* ------------------------------------------------------------------ celerite
+ * log-likelihood and its reverse recurrence for ONE draw (SURVEY Appendix B;
+ * adjoint derived as in numpy_port.py / DESIGN.md 3.4).  J <= 8.
+ *   coef_real [n_real][2] = (a, c), coef_complex [n_complex][4] = (a, b, c, d)
+ * If gresid != NULL also writes gresid[n], gdiag[n], gcoef_real, gcoef_complex
+ * for d loglike.  Returns loglike (-inf if not positive definite).           */
+#define JMAX 8
+static void make_uv(int J, int n_real, const double* ka, const double* kb, const double* kd, double t,
+                    double* U, double* V) {
+  for (int j = 0; j < J; ++j) {
+    if (j < n_real) { U[j] = ka[j]; V[j] = 1.0; }
+    else if (((j - n_real) & 1) == 0) {
+      double c = cos(kd[j] * t), s = sin(kd[j] * t);
+      U[j] = ka[j] * c + kb[j] * s; U[j + 1] = ka[j] * s - kb[j] * c;
+      V[j] = c; V[j + 1] = s;
+    }
+  }
+}
+
+double oracle_celerite(const double* t, const double* y, const double* diag, int64_t n, const double* coef_real,
+                       int32_t n_real, const double* coef_complex, int32_t n_complex, double* gresid,
+                       double* gdiag, double* gcoef_real, double* gcoef_complex) {
+  const int J = n_real + 2 * n_complex;
+  double ka[JMAX], kb[JMAX], kc[JMAX], kd[JMAX], asum = 0;
+  for (int j = 0; j < J; ++j) {
+    if (j < n_real) { ka[j] = coef_real[2 * j]; kb[j] = 0; kc[j] = coef_real[2 * j + 1]; kd[j] = 0; asum += ka[j]; }
+    else {
+      const double* p = coef_complex + 4 * ((j - n_real) >> 1);
+      ka[j] = p[0]; kb[j] = p[1]; kc[j] = p[2]; kd[j] = p[3];
+      if (((j - n_real) & 1) == 0) asum += p[0];
+    }
+  }
+  const int NS = 2 + 2 * J + J * J;            /* d, z, W, F, S (full) per cadence */
+  double* st = (double*)malloc(sizeof(double) * (size_t)n * NS);
+  double S[JMAX][JMAX] = {{0}}, F[JMAX] = {0}, W[JMAX], U[JMAX], V[JMAX], P[JMAX];
+  make_uv(J, n_real, ka, kb, kd, t[0], U, V);
+  double d = diag[0] + asum, z = y[0], acc;
+  int bad = !(d > 0);
+  for (int j = 0; j < J; ++j) W[j] = V[j] / d;
+  acc = z * z / d + log(d);
+#define SAVE(i)                                                        \
+  do {                                                                 \
+    double* q = st + (size_t)(i) * NS;                                 \
+    q[0] = d; q[1] = z;                                                \
+    for (int j = 0; j < J; ++j) { q[2 + j] = W[j]; q[2 + J + j] = F[j]; } \
+    for (int j = 0; j < J; ++j) for (int l = 0; l < J; ++l) q[2 + 2 * J + j * J + l] = S[j][l]; \
+  } while (0)
+  SAVE(0);
+  for (int64_t i = 1; i < n; ++i) {
+    double dt = t[i] - t[i - 1];
+    for (int j = 0; j < J; ++j) P[j] = exp(-kc[j] * dt);
+    for (int j = 0; j < J; ++j) {
+      F[j] = P[j] * (F[j] + W[j] * z);
+      for (int l = 0; l < J; ++l) S[j][l] = P[j] * P[l] * (S[j][l] + d * W[j] * W[l]);
+    }
+    make_uv(J, n_real, ka, kb, kd, t[i], U, V);
+    double u[JMAX], dn = diag[i] + asum, zf = y[i];
+    for (int j = 0; j < J; ++j) {
+      double s = 0;
+      for (int l = 0; l < J; ++l) s += S[j][l] * U[l];
+      u[j] = s; dn -= U[j] * s; zf -= U[j] * F[j];
+    }
+    d = dn; z = zf;
+    if (!(d > 0)) bad = 1;
+    for (int j = 0; j < J; ++j) W[j] = (V[j] - u[j]) / d;
+    acc += z * z / d + log(d);
+    SAVE(i);
+  }
+  double ll = bad ? -INFINITY : -0.5 * acc - 0.5 * (double)n * log(2 * PI);
+  if (gresid) {
+    double Sb[JMAX][JMAX] = {{0}}, Fb[JMAX] = {0}, Wb[JMAX] = {0}, db = 0, zb = 0, gasum = 0;
+    double ga[JMAX] = {0}, gb[JMAX] = {0}, gc[JMAX] = {0}, gd[JMAX] = {0};
+    for (int64_t i = n - 1; i >= 1; --i) {
+      const double* q = st + (size_t)i * NS; const double* p = st + (size_t)(i - 1) * NS;
+      double d_n = q[0], z_n = q[1], d_p = p[0], z_p = p[1];
+      const double *W_n = q + 2, *F_n = q + 2 + J, *S_n = q + 2 + 2 * J, *W_p = p + 2, *F_p = p + 2 + J, *S_p = p + 2 + 2 * J;
+      double dt = t[i] - t[i - 1];
+      for (int j = 0; j < J; ++j) P[j] = exp(-kc[j] * dt);
+      make_uv(J, n_real, ka, kb, kd, t[i], U, V);
+      double zbar = zb - z_n / d_n, dbar = db + 0.5 * z_n * z_n / (d_n * d_n) - 0.5 / d_n;
+      gresid[i] = zbar;
+      double Ub[JMAX], Vb[JMAX], ub[JMAX], u[JMAX], wdot = 0;
+      for (int j = 0; j < J; ++j) {
+        Ub[j] = -zbar * F_n[j]; Fb[j] -= zbar * U[j];
+        Vb[j] = Wb[j] / d_n; ub[j] = -Vb[j]; wdot += Wb[j] * W_n[j];
+      }
+      dbar -= wdot / d_n;
+      gdiag[i] = dbar; gasum += dbar;
+      for (int j = 0; j < J; ++j) { double s = 0; for (int l = 0; l < J; ++l) s += S_n[j * J + l] * U[l]; u[j] = s; }
+      for (int j = 0; j < J; ++j) { Ub[j] -= dbar * u[j]; ub[j] -= dbar * U[j]; }
+      for (int j = 0; j < J; ++j) {
+        double s = 0;
+        for (int l = 0; l < J; ++l) { Sb[j][l] += ub[j] * U[l]; s += S_n[l * J + j] * ub[l]; }
+        Ub[j] += s;
+      }
+      double Pb[JMAX], Gb[JMAX], Wbp[JMAX], zbp = 0, dbp = 0;
+      for (int j = 0; j < J; ++j) {
+        double G = F_p[j] + W_p[j] * z_p;
+        Pb[j] = Fb[j] * G; Gb[j] = Fb[j] * P[j]; Wbp[j] = Gb[j] * z_p; zbp += Gb[j] * W_p[j];
+      }
+      for (int j = 0; j < J; ++j) {
+        double wsum = 0, psum = 0;
+        for (int l = 0; l < J; ++l) {
+          double T = S_p[j * J + l] + d_p * W_p[j] * W_p[l], sym = Sb[j][l] + Sb[l][j];
+          psum += sym * T * P[l];
+          wsum += sym * P[j] * P[l] * W_p[l];
+        }
+        Pb[j] += psum; Wbp[j] += d_p * wsum;
+      }
+      for (int j = 0; j < J; ++j) for (int l = 0; l < J; ++l) {
+        double Tb = Sb[j][l] * P[j] * P[l];
+        dbp += Tb * W_p[j] * W_p[l]; Sb[j][l] = Tb;
+      }
+      for (int j = 0; j < J; ++j) {
+        gc[j] -= dt * P[j] * Pb[j];
+        if (j < n_real) ga[j] += Ub[j];
+        else if (((j - n_real) & 1) == 0) {
+          double c = V[j], s = V[j + 1];
+          ga[j] += Ub[j] * c + Ub[j + 1] * s; gb[j] += Ub[j] * s - Ub[j + 1] * c;
+          gd[j] += t[i] * (Ub[j] * (-ka[j] * s + kb[j] * c) + Ub[j + 1] * (ka[j] * c + kb[j] * s) - Vb[j] * s + Vb[j + 1] * c);
+        }
+      }
+      db = dbp; zb = zbp;
+      for (int j = 0; j < J; ++j) { Fb[j] = Gb[j]; Wb[j] = Wbp[j]; }
+    }
+    {
+      const double* q = st; double d_n = q[0], z_n = q[1]; const double* W_n = q + 2;
+      double zbar = zb - z_n / d_n, dbar = db + 0.5 * z_n * z_n / (d_n * d_n) - 0.5 / d_n, wdot = 0, Vb[JMAX];
+      gresid[0] = zbar;
+      make_uv(J, n_real, ka, kb, kd, t[0], U, V);
+      for (int j = 0; j < J; ++j) { Vb[j] = Wb[j] / d_n; wdot += Wb[j] * W_n[j]; }
+      dbar -= wdot / d_n; gdiag[0] = dbar; gasum += dbar;
+      for (int j = n_real; j + 1 < J; j += 2) gd[j] += t[0] * (-Vb[j] * V[j + 1] + Vb[j + 1] * V[j]);
+    }
+    for (int j = 0; j < J; ++j) {
+      if (j < n_real) { gcoef_real[2 * j] = ga[j] + gasum; gcoef_real[2 * j + 1] = gc[j]; }
+      else if (((j - n_real) & 1) == 0) {
+        double* o = gcoef_complex + 4 * ((j - n_real) >> 1);
+        o[0] = ga[j] + gasum; o[1] = gb[j]; o[2] = gc[j] + gc[j + 1]; o[3] = gd[j];
+      }
+    }
+  }
+  free(st);
+  return ll;
+}

@@ -69,3 +69,22 @@ def transit(t, params, ld, gflux=None, texp=None, stencil_dt=None, stencil_w=Non
                          ctypes.c_int32(n_sub), _p(params), _p(ld), ctypes.c_int64(D), ctypes.c_int32(P),
                          ctypes.c_uint32(flags), _p(gflux), _p(flux), _p(gp), _p(gl))
     return flux, gp, gl
+
+
+def celerite(t, y, diag, coeffs, grad=False):
+    """log-likelihood of one draw (and, with grad, d/d(y, diag, ar, cr, ac, bc, cc, dc))."""
+    ar, cr, ac, bc, cc, dc = [_c(x) for x in coeffs]
+    t = _c(t); y = _c(y); diag = _c(diag)
+    real = _c(np.stack([ar, cr], -1)) if ar.size else np.zeros((0, 2))
+    cplx = _c(np.stack([ac, bc, cc, dc], -1)) if ac.size else np.zeros((0, 4))
+    fn = lib().oracle_celerite
+    fn.restype = ctypes.c_double
+    if not grad:
+        return fn(_p(t), _p(y), _p(diag), ctypes.c_int64(t.size), _p(real), ctypes.c_int32(ar.size), _p(cplx),
+                  ctypes.c_int32(ac.size), None, None, None, None)
+    gy = np.empty_like(y); gd = np.empty_like(y); gr = np.empty_like(real); gc = np.empty_like(cplx)
+    ll = fn(_p(t), _p(y), _p(diag), ctypes.c_int64(t.size), _p(real), ctypes.c_int32(ar.size), _p(cplx),
+            ctypes.c_int32(ac.size), _p(gy), _p(gd), _p(gr), _p(gc))
+    g = {"y": gy, "diag": gd, "ar": gr[:, 0], "cr": gr[:, 1], "ac": gc[:, 0], "bc": gc[:, 1], "cc": gc[:, 2],
+         "dc": gc[:, 3]}
+    return ll, g
