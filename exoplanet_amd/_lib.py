@@ -19,6 +19,7 @@ _u32 = ctypes.c_uint32
 _SIGNATURES = {
     "exo_abi_version": (_i32, []),
     "exo_kepler_f64": (ctypes.c_int, [_c_dp, _c_dp, _c_dp, _c_dp, _i64, _c_dp]),
+    "exo_selftest_orbit_pos_f32": (ctypes.c_int, [_c_dp, _c_dp, _c_dp, _c_dp, _i64, _c_dp]),
     "exo_quad_solution_vector_f64": (ctypes.c_int, [_c_dp, _c_dp, _c_dp, _c_dp, _c_dp, _i64, _c_dp]),
     "exo_contact_points_f64": (ctypes.c_int, [_c_dp] * 10 + [_i64, _c_dp]),
     "exo_transit_flux_fwd_f64": (

@@ -41,6 +41,8 @@ enum { G_N = 0, G_TP, G_ECC, G_COSW, G_SINW, G_COSI, G_AOR, G_ROR, G_FR, G_PAD }
 struct PlanetConst {
   double n, tp, e, se, pe, sq1me2, cw, sw, ci, si, aor, ror, iror;
   double t0, period, iperiod, ts, te, fr, ts2, te2;
+  // fp32 copies for the conservative classifier of the scan kernel
+  float ef, omf, sqf, cwf, swf, cif, zsf, thrf, zthrf;
 };
 
 struct Shared {
@@ -73,6 +75,15 @@ __device__ __forceinline__ void stage_constants(Shared& sh, const double* __rest
     c.t0 = p[EXO_P_T0]; c.period = p[EXO_P_PERIOD]; c.iperiod = 1.0 / p[EXO_P_PERIOD];
     c.ts = p[EXO_P_TS]; c.te = p[EXO_P_TE];
     c.fr = p[EXO_P_FRATIO]; c.ts2 = p[EXO_P_TS2]; c.te2 = p[EXO_P_TE2];
+    // classifier: accept if (x^2 + y^2) (a/R)^2 < (1 + ror + margin)^2 with the fp32 position error
+    // bound of exo::orbit_pos_f32 folded into the margin (never a false negative)
+    const double margin = 2e-3 + c.aor * (8e-6 + 4e-6 / (1.0 - e));
+    const double lim = (1.0 + c.ror + margin) / c.aor;
+    c.ef = (float)e; c.omf = (float)(1.0 - e); c.sqf = (float)c.sq1me2;
+    c.cwf = (float)c.cw; c.swf = (float)c.sw; c.cif = (float)c.ci;
+    c.zsf = (float)c.si;
+    c.thrf = (float)(lim * lim) * 1.00001f;
+    c.zthrf = (float)(-margin / c.aor);
   }
   const int nld = secondary ? 6 : 3;
   if (ld && tid >= 64 && tid < 64 + nld) sh.c[tid - 64] = ld[draw * nld + (tid - 64)];
@@ -203,7 +214,7 @@ __device__ __forceinline__ double eval_sample(double tt, const PlanetConst& c, c
 // A carries no elliptic-integral code, so it runs at high occupancy; without
 // windows it is dominated by the Kepler solve per (planet, sub-exposure).
 // ---------------------------------------------------------------------------
-template <bool SECONDARY>
+template <bool SECONDARY, bool FAST>
 __global__ __launch_bounds__(kBlock) void transit_scan_kernel(
     const double* __restrict__ t, int64_t n_cad, const double* __restrict__ texp, int64_t n_texp,
     const double* __restrict__ stencil_dt, int n_sub, const double* __restrict__ params, int n_planet,
@@ -234,6 +245,19 @@ __global__ __launch_bounds__(kBlock) void transit_scan_kernel(
         const double lim = 1.0 + c.ror;
         for (int k = 0; k < n_sub; ++k) {
           const double tt = fma(te, sh.sdt[k], tv);
+          if (FAST) {
+            // conservative fp32 classification: only the phase is fp64 (see exo::orbit_pos_f32);
+            // every accepted cadence is re-evaluated in fp64 by the heavy kernel
+            float cx, sx;
+            exo::orbit_pos_f32((tt - c.tp) * c.n, c.ef, c.omf, c.sqf, &cx, &sx);
+            const float x1 = c.cwf * cx - c.swf * sx;
+            const float y1 = c.swf * cx + c.cwf * sx;
+            const float Ys = c.cif * y1;
+            const float Zs = c.zsf * y1;          // Z / (a/R)
+            const bool vis = SECONDARY ? true : !(Zs <= c.zthrf);
+            active = active || (vis && !(fmaf(x1, x1, Ys * Ys) >= c.thrf));
+            continue;
+          }
           const exo::KeplerHalf kh = exo::kepler_half((tt - c.tp) * c.n, c.e, c.se, c.pe);
           const double cx = kh.X * kh.X - kh.Y * kh.Y, sx = 2.0 * kh.X * kh.Y;
           const double x1 = c.cw * cx - c.sw * sx;   // position / (-a/R)
@@ -415,6 +439,20 @@ __global__ __launch_bounds__(kBlock) void kepler_kernel(const double* __restrict
   }
 }
 
+// diagnostic: the fp32 classifier position, so that its error bound can be tested
+__global__ __launch_bounds__(kBlock) void orbit_pos_f32_kernel(const double* __restrict__ M,
+                                                               const double* __restrict__ ecc,
+                                                               double* __restrict__ cx, double* __restrict__ sx,
+                                                               int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  const double e = ecc[i];
+  float a, b;
+  exo::orbit_pos_f32(M[i], (float)e, (float)(1.0 - e), (float)sqrt((1.0 - e) * (1.0 + e)), &a, &b);
+  cx[i] = a;
+  sx[i] = b;
+}
+
 template <bool GRAD>
 __global__ __launch_bounds__(kBlock) void quad_sv_kernel(const double* __restrict__ b,
                                                          const double* __restrict__ r,
@@ -499,6 +537,16 @@ inline Workspace carve(void* base, int64_t n_draw, int bpd, int tpb, int n_plane
 
 constexpr uint32_t kFlagNoFlux = 0x80000000u;  // internal: scan kernel must not touch flux
 
+// scan kernel dispatch on (secondary, exact fp64 classification requested)
+#define EXO_LAUNCH_SCAN(FLAGS, ...)                                                                        \
+  do {                                                                                                     \
+    const bool sec_ = (FLAGS) & EXO_FLAG_SECONDARY, exact_ = (FLAGS) & EXO_FLAG_EXACT_SCAN;                \
+    if (sec_ && exact_) hipLaunchKernelGGL((transit_scan_kernel<true, false>), __VA_ARGS__);               \
+    else if (sec_) hipLaunchKernelGGL((transit_scan_kernel<true, true>), __VA_ARGS__);                     \
+    else if (exact_) hipLaunchKernelGGL((transit_scan_kernel<false, false>), __VA_ARGS__);                 \
+    else hipLaunchKernelGGL((transit_scan_kernel<false, true>), __VA_ARGS__);                              \
+  } while (0)
+
 inline bool transit_args_ok(int64_t n_cad, int64_t n_texp, int32_t n_sub, int64_t n_draw, int32_t n_planet) {
   return n_cad >= 0 && n_draw >= 0 && n_draw <= 65535 && n_planet >= 1 && n_planet <= EXO_MAX_PLANETS &&
          n_sub >= 1 && n_sub <= EXO_MAX_SUBEXP && (n_texp == 0 || n_texp == 1 || n_texp == n_cad);
@@ -515,6 +563,14 @@ int exo_kepler_f64(const double* M, const double* ecc, double* sinf, double* cos
   if (n == 0) return EXO_OK;
   hipLaunchKernelGGL(kepler_kernel, dim3(elementwise_grid(n)), dim3(kBlock), 0, (hipStream_t)stream, M, ecc,
                      sinf, cosf, n);
+  return launch_status();
+}
+
+int exo_selftest_orbit_pos_f32(const double* M, const double* ecc, double* cx, double* sx, int64_t n, void* stream) {
+  if (n < 0 || (n > 0 && (!M || !ecc || !cx || !sx))) return EXO_ERR_INVALID_ARGUMENT;
+  if (n == 0) return EXO_OK;
+  hipLaunchKernelGGL(orbit_pos_f32_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0,
+                     (hipStream_t)stream, M, ecc, cx, sx, n);
   return launch_status();
 }
 
@@ -568,12 +624,8 @@ int exo_transit_flux_fwd_ev_f64(const double* t, int64_t n_cad, const double* te
   hipStream_t st = (hipStream_t)stream;
   const bool secondary = flags & EXO_FLAG_SECONDARY;
   if (ev_start) (void)hipEventRecord((hipEvent_t)ev_start, st);
-  if (secondary)
-    hipLaunchKernelGGL(transit_scan_kernel<true>, grid, block, 0, st, t, n_cad, texp, n_texp, stencil_dt, n_sub,
-                       params, n_planet, flags, tpb, flux, w.counts, w.list);
-  else
-    hipLaunchKernelGGL(transit_scan_kernel<false>, grid, block, 0, st, t, n_cad, texp, n_texp, stencil_dt, n_sub,
-                       params, n_planet, flags, tpb, flux, w.counts, w.list);
+  EXO_LAUNCH_SCAN(flags, grid, block, 0, st, t, n_cad, texp, n_texp, stencil_dt, n_sub, params, n_planet, flags, tpb,
+                  flux, w.counts, w.list);
   if (ev_stop) (void)hipEventRecord((hipEvent_t)ev_stop, st);
   if (launch_status() != EXO_OK) return EXO_ERR_LAUNCH;
   if (secondary)
@@ -624,21 +676,9 @@ int exo_transit_flux_vjp_ev_f64(const double* t, int64_t n_cad, const double* te
   // zeros for inactive cadences go to a scratch row that nobody reads
   double* flux_dst = flux_out;
   if (ev_start) (void)hipEventRecord((hipEvent_t)ev_start, st);
-  if (flux_dst) {
-    if (secondary)
-      hipLaunchKernelGGL(transit_scan_kernel<true>, grid, block, 0, st, t, n_cad, texp, n_texp, stencil_dt, n_sub,
-                         params, n_planet, flags, tpb, flux_dst, w.counts, w.list);
-    else
-      hipLaunchKernelGGL(transit_scan_kernel<false>, grid, block, 0, st, t, n_cad, texp, n_texp, stencil_dt, n_sub,
-                         params, n_planet, flags, tpb, flux_dst, w.counts, w.list);
-  } else {
-    if (secondary)
-      hipLaunchKernelGGL(transit_scan_kernel<true>, grid, block, 0, st, t, n_cad, texp, n_texp, stencil_dt, n_sub,
-                         params, n_planet, flags | kFlagNoFlux, tpb, flux_dst, w.counts, w.list);
-    else
-      hipLaunchKernelGGL(transit_scan_kernel<false>, grid, block, 0, st, t, n_cad, texp, n_texp, stencil_dt, n_sub,
-                         params, n_planet, flags | kFlagNoFlux, tpb, flux_dst, w.counts, w.list);
-  }
+  const uint32_t scan_flags = flux_dst ? flags : (flags | kFlagNoFlux);
+  EXO_LAUNCH_SCAN(flags, grid, block, 0, st, t, n_cad, texp, n_texp, stencil_dt, n_sub, params, n_planet, scan_flags,
+                  tpb, flux_dst, w.counts, w.list);
   if (ev_stop) (void)hipEventRecord((hipEvent_t)ev_stop, st);
   if (launch_status() != EXO_OK) return EXO_ERR_LAUNCH;
   if (secondary)

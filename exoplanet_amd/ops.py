@@ -24,6 +24,7 @@ FLAG_PER_PLANET = 1
 FLAG_WINDOW = 2
 FLAG_SECONDARY = 4
 PACK_CIRCULAR = 8
+FLAG_EXACT_SCAN = 16
 NIN = 10
 (IN_PERIOD, IN_T0, IN_B, IN_ECC, IN_OMEGA, IN_R, IN_MSTAR, IN_RSTAR, IN_MPLANET, IN_SBR) = range(10)
 MAX_PLANETS = 16

@@ -99,6 +99,10 @@ int exo_contact_points_f64(const double* a, const double* e, const double* cosw,
 #define EXO_FLAG_PER_PLANET 1u /* flux is [n_draw][n_cad][n_planet] instead of summed [n_draw][n_cad] */
 #define EXO_FLAG_WINDOW 2u     /* skip cadences outside [TS,TE] (+- texp/2): use_in_transit semantics */
 #define EXO_FLAG_SECONDARY 4u  /* also evaluate the occultation of the planet; ld is [n_draw][6]      */
+/* 8u is EXO_PACK_CIRCULAR (record packing only) */
+#define EXO_FLAG_EXACT_SCAN 16u /* classify cadences with the fp64 Kepler solve instead of the conservative
+                                   fp32 pre-filter.  Results are identical either way (accepted cadences are
+                                   always evaluated in fp64); the flag exists to measure / verify that.      */
 
 #define EXO_MAX_PLANETS 16
 #define EXO_MAX_SUBEXP 63
@@ -122,6 +126,13 @@ int exo_transit_flux_fwd_f64(const double* t, int64_t n_cad, const double* texp,
 /* Bytes of scratch the fused entry points need (active-cadence lists of the scan
  * kernel + the deterministic two-stage gradient reduction).                     */
 int64_t exo_transit_flux_workspace_bytes(int64_t n_cad, int64_t n_draw, int32_t n_planet);
+
+/* Diagnostic for the scan kernel's conservative fp32 cadence classifier: the fp32
+ * estimate of (cos E - e, sqrt(1-e^2) sin E) for mean anomaly M (fp64 phase) and
+ * eccentricity ecc, widened back to double.  The classifier's safety margin assumes
+ * |error| <= 4e-6 + 2e-6/(1-e); tests/test_gpu_scan_filter.py checks that here.   */
+int exo_selftest_orbit_pos_f32(const double* M, const double* ecc, double* cx, double* sx, int64_t n,
+                               void* stream);
 
 /* Profiling hook shared by the fused entry points below: if `ev_start` /
  * `ev_stop` (hipEvent_t passed as void*, may be NULL) are given, they are

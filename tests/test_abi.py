@@ -60,6 +60,8 @@ def test_header_layout_constants_match_python(lib):
     assert int(consts["EXO_FLAG_PER_PLANET"]) == ops.FLAG_PER_PLANET
     assert int(consts["EXO_FLAG_WINDOW"]) == ops.FLAG_WINDOW
     assert int(consts["EXO_FLAG_SECONDARY"]) == ops.FLAG_SECONDARY
+    assert int(consts["EXO_FLAG_EXACT_SCAN"]) == ops.FLAG_EXACT_SCAN
+    assert int(consts["EXO_PACK_CIRCULAR"]) == ops.PACK_CIRCULAR
     assert int(consts["EXO_MAX_PLANETS"]) == ops.MAX_PLANETS
     assert int(consts["EXO_MAX_SUBEXP"]) == ops.MAX_SUBEXP
 

@@ -1,0 +1,111 @@
+"""GPU: the scan kernel's conservative fp32 pre-filter never changes a result.
+Default path (fp32 classification, fp64 evaluation of every accepted cadence) ==
+EXO_FLAG_EXACT_SCAN path (fp64 classification) on stress geometries: high
+eccentricity, very large and very small a/R, grazing impact parameters, exposure
+integration, secondary eclipses, long time baselines."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import numpy_port as P
+from test_gpu_transit import make_record
+
+pytestmark = pytest.mark.gpu
+
+
+def T(a, dev):
+    return torch.as_tensor(np.asarray(a, dtype=np.float64), device=dev)
+
+
+def random_records(rng, D, Pn):
+    rec = np.zeros((D, Pn, P.NPAR))
+    for d in range(D):
+        period = 10 ** rng.uniform(-0.3, 1.8, Pn)
+        ecc = np.where(rng.uniform(size=Pn) < 0.2, 0.0, rng.uniform(0, 0.97, Pn))
+        omega = rng.uniform(-np.pi, np.pi, Pn)
+        a = 10 ** rng.uniform(0.3, 2.7, Pn)              # a/R from 2 to 500
+        b = rng.uniform(0, 1.25, Pn)
+        incl_factor = (1 + ecc * np.sin(omega)) / (1 - ecc ** 2)
+        cosi = np.clip(incl_factor * b / a, 0, 0.999)
+        orbit = P.KeplerianOrbit(period=period, a=a, t0=rng.uniform(0, 5, Pn), incl=np.arccos(cosi), ecc=ecc, omega=omega)
+        rec[d] = make_record(orbit, 10 ** rng.uniform(-2, -0.5, Pn), sbr=0.3)[0]
+    return rec
+
+
+@pytest.mark.parametrize("secondary", [False, True])
+@pytest.mark.parametrize("texp", [None, 0.02])
+def test_filter_never_changes_results(dev, secondary, texp):
+    from exoplanet_amd import ops
+
+    rng = np.random.default_rng(17 + secondary)
+    D, Pn = 24, 3
+    rec = random_records(rng, D, Pn)
+    t = np.sort(np.concatenate([np.linspace(0, 60, 30000), 2000 + np.linspace(0, 20, 10000)]))   # |M| up to 1e4 rad
+    c = np.repeat(np.concatenate([P.get_cl(0.3, 0.2), P.get_cl(0.4, 0.1)])[None], D, 0)
+    c = c if secondary else c[:, :3]
+    g = rng.normal(size=(D, t.size))
+    kw = {}
+    if texp is not None:
+        sdt, sw = P.exposure_stencil(5, 1)
+        kw = dict(texp=T([texp], dev), stencil_dt=T(sdt, dev), stencil_w=T(sw, dev))
+    base = ops.FLAG_SECONDARY if secondary else 0
+    f1, gp1, gl1 = ops.transit_flux_value_and_vjp(T(t, dev), T(rec, dev), T(c, dev), T(g, dev), flags=base, **kw)
+    f2, gp2, gl2 = ops.transit_flux_value_and_vjp(T(t, dev), T(rec, dev), T(c, dev), T(g, dev),
+                                                  flags=base | ops.FLAG_EXACT_SCAN, **kw)
+    assert (f2 != 0).sum().item() > 2000, "stress set has too few in-transit cadences"
+    # same fp64 arithmetic for every accepted cadence; the only difference allowed is the
+    # last bit: the AGM sweeps of the elliptic integrals exit on a wavefront vote, so the
+    # number of (exact, idempotent-to-rounding) extra sweeps depends on a lane's wave-mates
+    assert (f1 == 0).eq(f2 == 0).all()
+    assert (f1 - f2).abs().max().item() < 2e-15
+    # gradients: same terms, possibly summed in a different lane order
+    scale = gp2.abs().amax(dim=(0, 1), keepdim=True) + 1e-300
+    assert ((gp1 - gp2).abs() / scale).max().item() < 1e-11
+    assert torch.allclose(gl1, gl2, rtol=1e-11, atol=1e-12)
+
+
+def test_filter_matches_oracle_on_extremes(dev):
+    """single-draw extremes checked against the C oracle as well"""
+    from exoplanet_amd import ops
+    from oracle import c_port as C
+
+    t = np.linspace(-2, 12, 20000)
+    cases = [dict(period=9.0, a=400.0, t0=1.0, incl=np.arccos(0.5 / 400), ecc=0.9, omega=0.3),
+             dict(period=1.1, a=2.2, t0=0.4, incl=1.45, ecc=0.0, omega=0.0),
+             dict(period=6.5, a=15.0, t0=2.0, incl=np.arccos(1.09 * (1 - 0.6 ** 2) / (1 + 0.6 * np.sin(1.0)) / 15.0), ecc=0.6, omega=1.0)]
+    for okw in cases:
+        if okw["ecc"] == 0.0:
+            okw = {k: v for k, v in okw.items() if k not in ("ecc", "omega")}
+        orbit = P.KeplerianOrbit(**okw)
+        rec = make_record(orbit, np.array([0.1]))
+        c = P.get_cl(0.3, 0.2)[None]
+        want, _, _ = C.transit(t, rec, c)
+        got = ops.transit_flux(T(t, dev), T(rec, dev), T(c, dev))
+        assert want.min() < 0
+        np.testing.assert_allclose(got.cpu().numpy(), want, rtol=0, atol=2e-13)
+
+
+def test_classifier_error_bound(dev):
+    """the margin folded into the scan kernel's threshold assumes
+    |fp32 position error| <= 4e-6 + 2e-6 / (1 - e): measure it."""
+    from exoplanet_amd import _lib
+
+    rng = np.random.default_rng(23)
+    n = 2_000_000
+    e = np.concatenate([rng.uniform(0, 0.99, n // 2), 1 - 10 ** rng.uniform(-3, 0, n // 4), np.zeros(n // 4)])
+    M = np.concatenate([rng.uniform(-np.pi, np.pi, n // 2), rng.uniform(-3e4, 3e4, n // 4),
+                        10 ** rng.uniform(-8, 0.5, n // 4) * rng.choice([-1, 1], n // 4)])
+    rng.shuffle(M)
+    E, _ = P.kepler_E(M, e)
+    want_cx, want_sx = np.cos(E) - e, np.sqrt(1 - e * e) * np.sin(E)
+    cx = torch.empty(n, dtype=torch.float64, device=dev)
+    sx = torch.empty(n, dtype=torch.float64, device=dev)
+    lib = _lib.load()
+    Mt, et = T(M, dev), T(e, dev)     # keep the inputs alive across the asynchronous launch
+    _lib.check(lib.exo_selftest_orbit_pos_f32(Mt.data_ptr(), et.data_ptr(), cx.data_ptr(), sx.data_ptr(),
+                                             n, torch.cuda.current_stream().cuda_stream), "selftest")
+    torch.cuda.synchronize()
+    err = np.maximum(np.abs(cx.cpu().numpy() - want_cx), np.abs(sx.cpu().numpy() - want_sx))
+    bound = 4e-6 + 2e-6 / (1 - e)
+    worst = (err / bound).max()
+    assert worst < 0.5, f"fp32 position error reaches {worst:.2f} of the assumed bound"
