@@ -30,6 +30,7 @@ namespace {
 
 constexpr int kBlock = 256;
 constexpr int kWaves = kBlock / 64;
+constexpr int kTile = 2 * kBlock;         // cadences per tile: two per lane
 constexpr int kTargetBlocks = 256 * 16;  // ~16 resident-or-queued blocks per CU: fills the chip, amortises
                                          // the per-block constant staging and gradient reduction
 constexpr uint32_t kFlagNoFluxDev = 0x80000000u;
@@ -214,7 +215,39 @@ __device__ __forceinline__ double eval_sample(double tt, const PlanetConst& c, c
 // A carries no elliptic-integral code, so it runs at high occupancy; without
 // windows it is dominated by the Kepler solve per (planet, sub-exposure).
 // ---------------------------------------------------------------------------
+// one (planet, sub-exposure) sample of the classifier: true = may overlap the disk
 template <bool SECONDARY, bool FAST>
+__device__ __forceinline__ bool classify_sample(double tt, const PlanetConst& c) {
+  if (FAST) {
+    // conservative fp32 classification: only the phase is fp64 (see exo::orbit_pos_f32);
+    // every accepted cadence is re-evaluated in fp64 by the heavy kernel
+    float cx, sx;
+    exo::orbit_pos_f32((tt - c.tp) * c.n, c.ef, c.omf, c.sqf, &cx, &sx);
+    const float x1 = c.cwf * cx - c.swf * sx;
+    const float y1 = c.swf * cx + c.cwf * sx;
+    const float Ys = c.cif * y1;
+    const float Zs = c.zsf * y1;  // Z / (a/R)
+    const bool vis = SECONDARY ? true : !(Zs <= c.zthrf);
+    return vis && !(fmaf(x1, x1, Ys * Ys) >= c.thrf);
+  }
+  const exo::KeplerHalf kh = exo::kepler_half((tt - c.tp) * c.n, c.e, c.se, c.pe);
+  const double cx = kh.X * kh.X - kh.Y * kh.Y, sx = 2.0 * kh.X * kh.Y;
+  const double x1 = c.cw * cx - c.sw * sx;  // position / (-a/R)
+  const double y1 = c.sw * cx + c.cw * sx;
+  const double Ys = c.ci * y1;
+  const double Z = c.si * y1 * c.aor;       // = -sin(i) y1 (-a/R)
+  const double b2 = (x1 * x1 + Ys * Ys) * c.aor * c.aor;
+  const double lim = 1.0 + c.ror;
+  const bool vis = SECONDARY ? true : !(Z <= 0.0);
+  return vis && !(b2 >= lim * lim);
+}
+
+// A tile is kTile = 2 * kBlock cadences: each lane owns two of them.  VEC2 (n_cad
+// even, so every draw's row is 16-B aligned): the two are adjacent and t / flux
+// move as 16-B accesses; otherwise they are kBlock apart and move as 8-B accesses.
+// The scan kernel zero-fills flux for EVERY cadence (a pure store stream); the
+// heavy kernel, ordered after it on the stream, overwrites the active ones.
+template <bool SECONDARY, bool FAST, bool VEC2>
 __global__ __launch_bounds__(kBlock) void transit_scan_kernel(
     const double* __restrict__ t, int64_t n_cad, const double* __restrict__ texp, int64_t n_texp,
     const double* __restrict__ stencil_dt, int n_sub, const double* __restrict__ params, int n_planet,
@@ -225,64 +258,71 @@ __global__ __launch_bounds__(kBlock) void transit_scan_kernel(
   stage_constants(sh, params, nullptr, stencil_dt, nullptr, n_sub, n_planet, draw, SECONDARY);
   const bool per_planet = flags & EXO_FLAG_PER_PLANET;
   const bool window = flags & EXO_FLAG_WINDOW;
+  const bool store = !(flags & kFlagNoFluxDev);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int64_t blk_base = (int64_t)blockIdx.x * tiles_per_block * kBlock;
+  const int64_t blk_base = (int64_t)blockIdx.x * tiles_per_block * kTile;
   const int64_t wave_slot = ((int64_t)draw * gridDim.x + blockIdx.x) * kWaves + wave;
-  int32_t* __restrict__ my_list = list + wave_slot * ((int64_t)tiles_per_block * 64);
+  int32_t* __restrict__ my_list = list + wave_slot * ((int64_t)tiles_per_block * 128);
   int cnt = 0;
   for (int tile = 0; tile < tiles_per_block; ++tile) {
-    const int off = tile * kBlock + threadIdx.x;
-    const int64_t i = blk_base + off;
-    const bool valid = i < n_cad;
-    const double tv = valid ? t[i] : 0.0;
-    const double te = (n_texp == 0) ? 0.0 : (n_texp == 1 ? texp[0] : (valid ? texp[i] : 0.0));
-    bool active = false;
-    for (int p = 0; p < n_planet; ++p) {
-      const PlanetConst& c = sh.pc[p];
-      if (window) {
-        active = active || in_window(tv, c, 0.5 * te, SECONDARY);
-      } else {
-        const double lim = 1.0 + c.ror;
-        for (int k = 0; k < n_sub; ++k) {
-          const double tt = fma(te, sh.sdt[k], tv);
-          if (FAST) {
-            // conservative fp32 classification: only the phase is fp64 (see exo::orbit_pos_f32);
-            // every accepted cadence is re-evaluated in fp64 by the heavy kernel
-            float cx, sx;
-            exo::orbit_pos_f32((tt - c.tp) * c.n, c.ef, c.omf, c.sqf, &cx, &sx);
-            const float x1 = c.cwf * cx - c.swf * sx;
-            const float y1 = c.swf * cx + c.cwf * sx;
-            const float Ys = c.cif * y1;
-            const float Zs = c.zsf * y1;          // Z / (a/R)
-            const bool vis = SECONDARY ? true : !(Zs <= c.zthrf);
-            active = active || (vis && !(fmaf(x1, x1, Ys * Ys) >= c.thrf));
-            continue;
+    int off[2];
+    off[0] = tile * kTile + (VEC2 ? 2 * (int)threadIdx.x : (int)threadIdx.x);
+    off[1] = off[0] + (VEC2 ? 1 : kBlock);
+    const int64_t i0 = blk_base + off[0], i1 = blk_base + off[1];
+    bool valid[2] = {i0 < n_cad, i1 < n_cad};
+    double tv[2];
+    if (VEC2) {
+      // n_cad even and i0 even: the pair is valid or invalid together
+      const double2 tt2 = valid[0] ? *reinterpret_cast<const double2*>(t + i0) : double2{0.0, 0.0};
+      tv[0] = tt2.x; tv[1] = tt2.y;
+    } else {
+      tv[0] = valid[0] ? t[i0] : 0.0;
+      tv[1] = valid[1] ? t[i1] : 0.0;
+    }
+    if (store) {
+      if (per_planet) {
+        if (VEC2) {
+          if (valid[0]) {
+            double2* dst = reinterpret_cast<double2*>(flux + (draw * n_cad + i0) * n_planet);
+            for (int p = 0; p < n_planet; ++p) dst[p] = double2{0.0, 0.0};
           }
-          const exo::KeplerHalf kh = exo::kepler_half((tt - c.tp) * c.n, c.e, c.se, c.pe);
-          const double cx = kh.X * kh.X - kh.Y * kh.Y, sx = 2.0 * kh.X * kh.Y;
-          const double x1 = c.cw * cx - c.sw * sx;   // position / (-a/R)
-          const double y1 = c.sw * cx + c.cw * sx;
-          const double Ys = c.ci * y1;
-          const double Z = c.si * y1 * c.aor;        // = -sin(i) y1 (-a/R)
-          const double b2 = (x1 * x1 + Ys * Ys) * c.aor * c.aor;
-          const bool vis = SECONDARY ? true : !(Z <= 0.0);
-          active = active || (vis && !(b2 >= lim * lim));
+        } else {
+          for (int v = 0; v < 2; ++v)
+            if (valid[v])
+              for (int p = 0; p < n_planet; ++p) flux[(draw * n_cad + (v ? i1 : i0)) * n_planet + p] = 0.0;
+        }
+      } else if (VEC2) {
+        if (valid[0]) *reinterpret_cast<double2*>(flux + draw * n_cad + i0) = double2{0.0, 0.0};
+      } else {
+        if (valid[0]) flux[draw * n_cad + i0] = 0.0;
+        if (valid[1]) flux[draw * n_cad + i1] = 0.0;
+      }
+    }
+    bool active[2] = {false, false};
+#pragma unroll
+    for (int v = 0; v < 2; ++v) {
+      const int64_t i = v ? i1 : i0;
+      const double te = (n_texp == 0) ? 0.0 : (n_texp == 1 ? texp[0] : (valid[v] ? texp[i] : 0.0));
+      for (int p = 0; p < n_planet; ++p) {
+        const PlanetConst& c = sh.pc[p];
+        if (window) {
+          active[v] = active[v] || in_window(tv[v], c, 0.5 * te, SECONDARY);
+        } else {
+          for (int k = 0; k < n_sub; ++k)
+            active[v] = active[v] || classify_sample<SECONDARY, FAST>(fma(te, sh.sdt[k], tv[v]), c);
         }
       }
+      active[v] = active[v] && valid[v];
     }
-    active = active && valid;
-    const unsigned long long ballot = __ballot(active);
-    if (active) {
-      const int before = __builtin_amdgcn_mbcnt_hi((unsigned)(ballot >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)ballot, 0));
-      my_list[cnt + before] = off;
-    }
-    cnt += __popcll(ballot);
-    if (valid && !active && !(flags & kFlagNoFluxDev)) {
-      if (per_planet) {
-        for (int p = 0; p < n_planet; ++p) flux[(draw * n_cad + i) * n_planet + p] = 0.0;
-      } else {
-        flux[draw * n_cad + i] = 0.0;
+#pragma unroll
+    for (int v = 0; v < 2; ++v) {
+      const unsigned long long ballot = __ballot(active[v]);
+      if (active[v]) {
+        const int before =
+            __builtin_amdgcn_mbcnt_hi((unsigned)(ballot >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)ballot, 0));
+        my_list[cnt + before] = off[v];
       }
+      cnt += __popcll(ballot);
     }
   }
   if (lane == 0) counts[wave_slot] = cnt;
@@ -314,9 +354,9 @@ __global__ __launch_bounds__(kBlock) void transit_heavy_kernel(
   stage_constants(sh, params, ld, stencil_dt, stencil_w, n_sub, n_planet, draw, SECONDARY);
   const bool per_planet = flags & EXO_FLAG_PER_PLANET;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int64_t blk_base = (int64_t)blockIdx.x * tiles_per_block * kBlock;
+  const int64_t blk_base = (int64_t)blockIdx.x * tiles_per_block * kTile;
   const int64_t slot0 = ((int64_t)draw * gridDim.x + blockIdx.x) * kWaves;
-  const int cap = tiles_per_block * 64;
+  const int cap = tiles_per_block * 128;
   // prefix over the four wave lists
   int pre[kWaves + 1];
   pre[0] = 0;
@@ -504,7 +544,7 @@ inline int elementwise_grid(int64_t n) {
 // blocks per draw and tiles per block: enough blocks to fill 256 CUs several
 // times over, few enough that each block amortises its prologue / reduction
 inline void transit_geometry(int64_t n_cad, int64_t n_draw, int* blocks_per_draw, int* tiles_per_block) {
-  const int64_t n_tiles = (n_cad + kBlock - 1) / kBlock;
+  const int64_t n_tiles = (n_cad + kTile - 1) / kTile;
   int64_t bpd = (kTargetBlocks + n_draw - 1) / n_draw;
   if (bpd > n_tiles) bpd = n_tiles;
   if (bpd < 1) bpd = 1;
@@ -526,7 +566,7 @@ inline Workspace carve(void* base, int64_t n_draw, int bpd, int tpb, int n_plane
   Workspace w;
   const int64_t n_partial = n_draw * bpd * (int64_t)(n_planet * kNG + 7);
   const int64_t n_counts = n_draw * bpd * (int64_t)kWaves;
-  const int64_t n_list = n_counts * (int64_t)tpb * 64;
+  const int64_t n_list = n_counts * (int64_t)tpb * 128;
   char* p = (char*)base;
   w.partial = (double*)p;
   w.counts = (int32_t*)(p + n_partial * 8);
@@ -538,13 +578,20 @@ inline Workspace carve(void* base, int64_t n_draw, int bpd, int tpb, int n_plane
 constexpr uint32_t kFlagNoFlux = 0x80000000u;  // internal: scan kernel must not touch flux
 
 // scan kernel dispatch on (secondary, exact fp64 classification requested)
-#define EXO_LAUNCH_SCAN(FLAGS, ...)                                                                        \
-  do {                                                                                                     \
-    const bool sec_ = (FLAGS) & EXO_FLAG_SECONDARY, exact_ = (FLAGS) & EXO_FLAG_EXACT_SCAN;                \
-    if (sec_ && exact_) hipLaunchKernelGGL((transit_scan_kernel<true, false>), __VA_ARGS__);               \
-    else if (sec_) hipLaunchKernelGGL((transit_scan_kernel<true, true>), __VA_ARGS__);                     \
-    else if (exact_) hipLaunchKernelGGL((transit_scan_kernel<false, false>), __VA_ARGS__);                 \
-    else hipLaunchKernelGGL((transit_scan_kernel<false, true>), __VA_ARGS__);                              \
+#define EXO_LAUNCH_SCAN_V(VEC, FLAGS, ...)                                                                \
+  do {                                                                                                    \
+    const bool sec_ = (FLAGS) & EXO_FLAG_SECONDARY, exact_ = (FLAGS) & EXO_FLAG_EXACT_SCAN;               \
+    if (sec_ && exact_) hipLaunchKernelGGL((transit_scan_kernel<true, false, VEC>), __VA_ARGS__);         \
+    else if (sec_) hipLaunchKernelGGL((transit_scan_kernel<true, true, VEC>), __VA_ARGS__);               \
+    else if (exact_) hipLaunchKernelGGL((transit_scan_kernel<false, false, VEC>), __VA_ARGS__);           \
+    else hipLaunchKernelGGL((transit_scan_kernel<false, true, VEC>), __VA_ARGS__);                        \
+  } while (0)
+// 16-B accesses need every draw's row of t / flux 16-B aligned: even n_cad (and
+// base pointers from any allocator are at least 16-B aligned)
+#define EXO_LAUNCH_SCAN(N_CAD, FLAGS, ...)                         \
+  do {                                                             \
+    if (((N_CAD) & 1) == 0) EXO_LAUNCH_SCAN_V(true, FLAGS, __VA_ARGS__); \
+    else EXO_LAUNCH_SCAN_V(false, FLAGS, __VA_ARGS__);             \
   } while (0)
 
 inline bool transit_args_ok(int64_t n_cad, int64_t n_texp, int32_t n_sub, int64_t n_draw, int32_t n_planet) {
@@ -624,8 +671,8 @@ int exo_transit_flux_fwd_ev_f64(const double* t, int64_t n_cad, const double* te
   hipStream_t st = (hipStream_t)stream;
   const bool secondary = flags & EXO_FLAG_SECONDARY;
   if (ev_start) (void)hipEventRecord((hipEvent_t)ev_start, st);
-  EXO_LAUNCH_SCAN(flags, grid, block, 0, st, t, n_cad, texp, n_texp, stencil_dt, n_sub, params, n_planet, flags, tpb,
-                  flux, w.counts, w.list);
+  EXO_LAUNCH_SCAN(n_cad, flags, grid, block, 0, st, t, n_cad, texp, n_texp, stencil_dt, n_sub, params, n_planet, flags,
+                  tpb, flux, w.counts, w.list);
   if (ev_stop) (void)hipEventRecord((hipEvent_t)ev_stop, st);
   if (launch_status() != EXO_OK) return EXO_ERR_LAUNCH;
   if (secondary)
@@ -677,8 +724,8 @@ int exo_transit_flux_vjp_ev_f64(const double* t, int64_t n_cad, const double* te
   double* flux_dst = flux_out;
   if (ev_start) (void)hipEventRecord((hipEvent_t)ev_start, st);
   const uint32_t scan_flags = flux_dst ? flags : (flags | kFlagNoFlux);
-  EXO_LAUNCH_SCAN(flags, grid, block, 0, st, t, n_cad, texp, n_texp, stencil_dt, n_sub, params, n_planet, scan_flags,
-                  tpb, flux_dst, w.counts, w.list);
+  EXO_LAUNCH_SCAN(n_cad, flags, grid, block, 0, st, t, n_cad, texp, n_texp, stencil_dt, n_sub, params, n_planet,
+                  scan_flags, tpb, flux_dst, w.counts, w.list);
   if (ev_stop) (void)hipEventRecord((hipEvent_t)ev_stop, st);
   if (launch_status() != EXO_OK) return EXO_ERR_LAUNCH;
   if (secondary)
