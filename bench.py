@@ -72,13 +72,13 @@ class HipEvents:
         return float(np.mean(out)), out
 
 
-def measured_traffic(kernel, n_draw):
-    """HBM bytes per launch from the committed PMC passes (profiles/r01_pmc.json),
-    scaled to this run's draw count; None if the profile is absent."""
+def measured_traffic(n_draw):
+    """HBM bytes per sweep (scan + heavy kernels) from the committed PMC passes
+    (profiles/r01_pmc.json), scaled to this run's draw count; None if absent."""
     try:
         p = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc.json")))
-        k = p["kernels"][kernel]
-        return (2.0 * k["fetch_kib"] + k["write_kib"]) * 1024.0 * n_draw / p["draws"]
+        tot = sum(2.0 * k["fetch_kib"] + k["write_kib"] for k in p["kernels"].values())
+        return tot * 1024.0 * n_draw / p["draws"]
     except Exception:
         return None
 
@@ -257,13 +257,13 @@ def main():
                         "(value+VJP, one sweep) -> packing VJP kernel -> leaf gradients" + ("; replayed as one hipGraph" if graph is not None else "; eager launches"),
             },
             "roofline": {
-                "bound": "hbm", "kernel": "transit_scan_kernel<false>",
+                "bound": "hbm", "kernel": "transit_scan_kernel + transit_heavy_kernel + transit_vjp_reduce_kernel (one sweep)",
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": measured_traffic("transit_scan_kernel<false>", D),
+                "traffic": measured_traffic(D),
                 "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": kernel_ms,
-                "note": "24 B per (draw, cadence) x draws x cadences / mean hipEvent time of the kernel over the "
-                        "timed steps; the every-cadence case is fp64-VALU bound (Kepler solve per sample), "
-                        "see DESIGN.md section 5",
+                "note": "24 B per (draw, cadence) x draws x cadences / mean hipEvent time of the three kernels that "
+                        "make up the one algorithmic sweep (scan classifies + zero-fills, heavy evaluates active "
+                        "cadences, reduce sums block partials); rocprof per-kernel averages: profiles/",
             },
         }
 

@@ -8,7 +8,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libexoplanet_amd.so")
+# EXOPLANET_AMD_LIB selects another in-tree build of the same ABI (A/B measurements)
+LIB_PATH = os.environ.get("EXOPLANET_AMD_LIB") or os.path.join(_HERE, "lib", "libexoplanet_amd.so")
 ABI_VERSION = 3
 
 _c_dp = ctypes.c_void_p  # device pointers travel as integers

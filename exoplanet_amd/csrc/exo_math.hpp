@@ -289,10 +289,10 @@ EXO_HD Cel3 cel3(double kc, double p, double aP, double bP) {
   double e = kc, em = 1.0;
   double aB = 1.0, bB = 0.0, aD = 0.0, bD = 1.0, p1 = 1.0;
   double pp = sqrt(p);
-  bP = bP / pp;
+  bP = fast_div(bP, pp);
 #pragma unroll 1
   for (int it = 0; it < 12; ++it) {
-    const double ip1 = 1.0 / p1, ipp = 1.0 / pp;
+    const double ip1 = fast_div(1.0, p1), ipp = fast_div(1.0, pp);
     const double g1 = e * ip1, gP = e * ipp;
     double f = aB;
     aB = fma(bB, ip1, aB);
@@ -312,10 +312,10 @@ EXO_HD Cel3 cel3(double kc, double p, double aP, double bP) {
     e = kc * em;
   }
   Cel3 o;
-  const double q1 = kHalfPi / (em * (em + p1));
+  const double q1 = fast_div(kHalfPi, em * (em + p1));
   o.B = q1 * fma(aB, em, bB);
   o.D = q1 * fma(aD, em, bD);
-  o.P = kHalfPi * fma(aP, em, bP) / (em * (em + pp));
+  o.P = fast_div(kHalfPi * fma(aP, em, bP), em * (em + pp));
   return o;
 }
 

@@ -342,8 +342,11 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 
+#ifndef EXO_HEAVY_MIN_WAVES
+#define EXO_HEAVY_MIN_WAVES 1
+#endif
 template <bool GRAD, bool SECONDARY>
-__global__ __launch_bounds__(kBlock) void transit_heavy_kernel(
+__global__ __launch_bounds__(kBlock, EXO_HEAVY_MIN_WAVES) void transit_heavy_kernel(
     const double* __restrict__ t, int64_t n_cad, const double* __restrict__ texp, int64_t n_texp,
     const double* __restrict__ stencil_dt, const double* __restrict__ stencil_w, int n_sub,
     const double* __restrict__ params, const double* __restrict__ ld, int n_planet, uint32_t flags,
@@ -673,7 +676,6 @@ int exo_transit_flux_fwd_ev_f64(const double* t, int64_t n_cad, const double* te
   if (ev_start) (void)hipEventRecord((hipEvent_t)ev_start, st);
   EXO_LAUNCH_SCAN(n_cad, flags, grid, block, 0, st, t, n_cad, texp, n_texp, stencil_dt, n_sub, params, n_planet, flags,
                   tpb, flux, w.counts, w.list);
-  if (ev_stop) (void)hipEventRecord((hipEvent_t)ev_stop, st);
   if (launch_status() != EXO_OK) return EXO_ERR_LAUNCH;
   if (secondary)
     hipLaunchKernelGGL((transit_heavy_kernel<false, true>), grid, block, 0, st, t, n_cad, texp, n_texp, stencil_dt,
@@ -681,6 +683,7 @@ int exo_transit_flux_fwd_ev_f64(const double* t, int64_t n_cad, const double* te
   else
     hipLaunchKernelGGL((transit_heavy_kernel<false, false>), grid, block, 0, st, t, n_cad, texp, n_texp, stencil_dt,
                        stencil_w, n_sub, params, ld, n_planet, flags, tpb, w.counts, w.list, nullptr, flux, nullptr);
+  if (ev_stop) (void)hipEventRecord((hipEvent_t)ev_stop, st);
   return launch_status();
 }
 
@@ -726,7 +729,6 @@ int exo_transit_flux_vjp_ev_f64(const double* t, int64_t n_cad, const double* te
   const uint32_t scan_flags = flux_dst ? flags : (flags | kFlagNoFlux);
   EXO_LAUNCH_SCAN(n_cad, flags, grid, block, 0, st, t, n_cad, texp, n_texp, stencil_dt, n_sub, params, n_planet,
                   scan_flags, tpb, flux_dst, w.counts, w.list);
-  if (ev_stop) (void)hipEventRecord((hipEvent_t)ev_stop, st);
   if (launch_status() != EXO_OK) return EXO_ERR_LAUNCH;
   if (secondary)
     hipLaunchKernelGGL((transit_heavy_kernel<true, true>), grid, block, 0, st, t, n_cad, texp, n_texp, stencil_dt,
@@ -739,6 +741,7 @@ int exo_transit_flux_vjp_ev_f64(const double* t, int64_t n_cad, const double* te
   if (launch_status() != EXO_OK) return EXO_ERR_LAUNCH;
   hipLaunchKernelGGL(transit_vjp_reduce_kernel, dim3((unsigned)n_draw), dim3(kBlock), 0, st, w.partial, bpd,
                      n_planet, secondary, gparams, gld, flux_dot);
+  if (ev_stop) (void)hipEventRecord((hipEvent_t)ev_stop, st);
   return launch_status();
 }
 

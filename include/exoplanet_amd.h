@@ -136,8 +136,9 @@ int exo_selftest_orbit_pos_f32(const double* M, const double* ecc, double* cx, d
 
 /* Profiling hook shared by the fused entry points below: if `ev_start` /
  * `ev_stop` (hipEvent_t passed as void*, may be NULL) are given, they are
- * recorded on `stream` immediately before / after the DOMINANT kernel of the
- * call, so a caller can time that kernel alone without a profiler attached.   */
+ * recorded on `stream` immediately before the first / after the last kernel of the
+ * sweep (scan + heavy [+ reduce]; the small memset of the gradient buffer stays
+ * outside), so a caller can time the kernels alone without a profiler attached. */
 int exo_transit_flux_fwd_ev_f64(const double* t, int64_t n_cad, const double* texp, int64_t n_texp,
                                 const double* stencil_dt, const double* stencil_w, int32_t n_sub,
                                 const double* params, const double* ld, int64_t n_draw,
