@@ -182,8 +182,8 @@ int exo_transit_flux_vjp_ev_f64(const double* t, int64_t n_cad, const double* te
  *   J = n_real + 2 n_complex <= EXO_GP_MAX_J
  *   loglike      [n_draw]          out; -inf if the matrix is not positive definite
  *   state        NULL (value only) or exo_celerite_state_doubles() doubles: the
- *                factorisation (d, W, z, F, S) the reverse pass re-reads,
- *                laid out [quantity][cadence][draw]
+ *                factorisation (d, z; W, F and the rows of S per state index) the reverse
+ *                pass re-reads, laid out [quantity][cadence][draw (x state index)]
  * ------------------------------------------------------------------------- */
 #define EXO_GP_MAX_J 8
 int64_t exo_celerite_state_doubles(int64_t n, int64_t n_draw, int32_t n_real, int32_t n_complex);
