@@ -12,13 +12,14 @@
 //   solve_lower: F_n = P o (F_{n-1} + W_{n-1} z_{n-1}) ;  z_n = y_n - U_n . F_n
 //   loglike    = -1/2 sum (z_n^2 / d_n + log d_n) - N/2 log 2 pi
 //
-// The recurrence is strictly sequential in time, so parallelism is over draws:
-// ONE DRAW PER LANE, the J x J state in registers, U_n / V_n / P_n recomputed in
-// the kernel from the term coefficients (a, b, c, d) instead of being streamed as
-// N x J arrays.  t and diag are wave-uniform (broadcast loads); the per-draw
-// residual rows stream through L1/L2; the saved factorisation (needed by the
-// reverse recurrence) is laid out [quantity][cadence][draw] so that a wave's
-// stores and loads are coalesced.
+// The recurrence is strictly sequential in time, so parallelism is over draws and,
+// inside a draw, over the J state indices: a draw occupies G = next_pow2(J) adjacent
+// lanes (lane j owns row j of S), exchanging values by DPP.  Everything that does
+// not depend on the recurrence (U_n, V_n, P_n: sin / cos / exp) is produced by a
+// fully parallel pre-pass; the log-determinant accumulates as (mantissa, exponent).
+// The saved factorisation (needed by the reverse recurrence) is laid out
+// [quantity][cadence][draw x state index] so that a wave's stores and loads are
+// coalesced, and is read back through a software prefetch ring.
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
