@@ -452,7 +452,7 @@ class KeplerianOrbit:
         t = as_tensor(t, self.n)
         ts, te, flag = self._transit_window(r)
         hp = 0.5 * self.period.detach()
-        dt = torch.remainder(t.detach().unsqueeze(-1) - self.t0.detach() + hp, self.period.detach()) - hp
+        dt = torch.remainder(self._warp_times(t.detach()).detach() + hp, self.period.detach()) - hp
         if texp is not None:
             texp = as_tensor(texp, self.n).detach()
             h = 0.5 * (texp.unsqueeze(-1) if texp.dim() else texp)
