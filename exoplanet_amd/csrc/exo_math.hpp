@@ -217,11 +217,12 @@ EXO_HD KeplerHalf kepler_half(double M, double e, double se, double pe) {
 
 // ---------------------------------------------------------------------------
 // fp32 orbit position for the CONSERVATIVE cadence classifier of the scan
-// kernel.  Only the phase M is fp64 (|M| reaches hundreds of radians: fp32 would
-// lose the transit); everything after the reduction to [-pi, pi] is fp32 on
-// hardware sin / cos: Markley starter + one Halley step + a Taylor rotation.
-// Output: cx = cos E - e, sx = sqrt(1-e^2) sin E (the orbit position in units of
-// -a), with |error| <= 4e-6 + 2e-6 / (1 - e)  (checked on the GPU by
+// kernel.  Only the phase M is fp64 (|M| reaches 10^4 radians: fp32 would lose
+// the transit); after the reduction to [-pi, pi] everything is fp32 on hardware
+// approximations: the Markley starter ALONE (|E1 - E| <= 4.4e-4 by construction,
+// no correction step) and one v_sin / v_cos.
+// Output: cx = cos E1 - e, sx = sqrt(1-e^2) sin E1 (the orbit position in units
+// of -a), with |error| <= 8e-4 (checked on the GPU by
 // tests/test_gpu_scan_filter.py); the caller widens its acceptance threshold by
 // that bound times a/R, so a cadence is never wrongly discarded.  Nothing
 // computed here reaches a result: accepted cadences are re-evaluated in fp64.
@@ -233,13 +234,8 @@ EXO_HD void orbit_pos_f32(double M, float ef, float omf, float sqf, float* cx, f
   Mr = fma(-k, kTwoPiLo, Mr);
   const float Ms = (float)Mr;
   const float Mf = fabsf(Ms);
-  float E, sE, cE;
-  const float inv2pi = 0.15915494309189535f;
-  if (EXO_WAVE_ALL(ef == 0.0f)) {
-    E = Mf;
-    sE = __builtin_amdgcn_sinf(E * inv2pi);
-    cE = __builtin_amdgcn_cosf(E * inv2pi);
-  } else {
+  float E = Mf;
+  if (!EXO_WAVE_ALL(ef == 0.0f)) {
     const float pif = 3.14159265358979f;
     const float alpha = fmaf(1.6f * pif * (pif - Mf), fast_rcpf(1.0f + ef), 3.0f * pif * pif) * (1.0f / (pif * pif - 6.0f));
     const float d = fmaf(alpha, ef, 3.0f * omf);
@@ -247,22 +243,10 @@ EXO_HD void orbit_pos_f32(double M, float ef, float omf, float sqf, float* cx, f
     const float r = fmaf(3.0f * alpha * d, d - omf, Mf * Mf) * Mf;
     float w = fast_cbrtf(fabsf(r) + fast_sqrtf(fmaxf(fmaf(q * q, q, r * r), 0.0f)));
     w = w * w;
-    const float E1 = fmaf(2.0f * r * w, fast_rcpf(fmaf(w, w + q, q * q)), Mf) * fast_rcpf(d);
-    const float s1 = __builtin_amdgcn_sinf(E1 * inv2pi), c1 = __builtin_amdgcn_cosf(E1 * inv2pi);
-    // E - sin E: series below 0.5 (fp32 cancellation), direct above
-    const float E2 = E1 * E1;
-    const float ems = (E1 < 0.5f) ? E1 * E2 * fmaf(E2, fmaf(E2, -1.0f / 5040.0f, 1.0f / 120.0f), -1.0f / 6.0f) * -1.0f
-                                  : (E1 - s1);
-    const float f0 = fmaf(omf, E1, fmaf(ef, ems, -Mf));
-    const float omc = (E1 < 0.5f) ? E2 * fmaf(E2, fmaf(E2, -1.0f / 720.0f, 1.0f / 24.0f), -0.5f) * -1.0f : (1.0f - c1);
-    const float f1 = fmaf(ef, omc, omf);       // 1 - e cos E
-    const float f2 = ef * s1;
-    const float dE = -f0 * fast_rcpf(fmaf(-0.5f * f0 * f2, fast_rcpf(f1), f1));
-    // rotate (s1, c1) by dE (|dE| <= 4.4e-4): second order is ample in fp32
-    const float hd = 0.5f * dE * dE;
-    sE = fmaf(c1, dE, s1) - s1 * hd;
-    cE = fmaf(-s1, dE, c1) - c1 * hd;
+    E = fmaf(2.0f * r * w, fast_rcpf(fmaf(w, w + q, q * q)), Mf) * fast_rcpf(d);
   }
+  const float x = E * 0.15915494309189535f;  // v_sin / v_cos take revolutions
+  const float sE = __builtin_amdgcn_sinf(x), cE = __builtin_amdgcn_cosf(x);
   *cx = cE - ef;
   *sx = (Ms < 0.0f) ? -sqf * sE : sqf * sE;
 }

@@ -78,7 +78,7 @@ __device__ __forceinline__ void stage_constants(Shared& sh, const double* __rest
     c.fr = p[EXO_P_FRATIO]; c.ts2 = p[EXO_P_TS2]; c.te2 = p[EXO_P_TE2];
     // classifier: accept if (x^2 + y^2) (a/R)^2 < (1 + ror + margin)^2 with the fp32 position error
     // bound of exo::orbit_pos_f32 folded into the margin (never a false negative)
-    const double margin = 2e-3 + c.aor * (8e-6 + 4e-6 / (1.0 - e));
+    const double margin = 2e-3 + c.aor * 1.6e-3;   // 2x the 8e-4 bound of exo::orbit_pos_f32
     const double lim = (1.0 + c.ror + margin) / c.aor;
     c.ef = (float)e; c.omf = (float)(1.0 - e); c.sqf = (float)c.sq1me2;
     c.cwf = (float)c.cw; c.swf = (float)c.sw; c.cif = (float)c.ci;

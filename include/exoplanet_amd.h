@@ -130,7 +130,7 @@ int64_t exo_transit_flux_workspace_bytes(int64_t n_cad, int64_t n_draw, int32_t 
 /* Diagnostic for the scan kernel's conservative fp32 cadence classifier: the fp32
  * estimate of (cos E - e, sqrt(1-e^2) sin E) for mean anomaly M (fp64 phase) and
  * eccentricity ecc, widened back to double.  The classifier's safety margin assumes
- * |error| <= 4e-6 + 2e-6/(1-e); tests/test_gpu_scan_filter.py checks that here.   */
+ * |error| <= 8e-4; tests/test_gpu_scan_filter.py checks that here.                 */
 int exo_selftest_orbit_pos_f32(const double* M, const double* ecc, double* cx, double* sx, int64_t n,
                                void* stream);
 
