@@ -41,7 +41,7 @@ enum { G_N = 0, G_TP, G_ECC, G_COSW, G_SINW, G_COSI, G_AOR, G_ROR, G_FR, G_PAD }
 // Per-(draw, planet) constants derived once per block and staged in LDS.
 struct PlanetConst {
   double n, tp, e, se, pe, sq1me2, cw, sw, ci, si, aor, ror, iror;
-  double t0, period, iperiod, ts, te, fr, ts2, te2;
+  double t0, period, iperiod, ts, te, fr, ts2, te2, isq1me2;
   // fp32 copies for the conservative classifier of the scan kernel
   float ef, omf, sqf, cwf, swf, cif, zsf, thrf, zthrf;
 };
@@ -70,6 +70,7 @@ __device__ __forceinline__ void stage_constants(Shared& sh, const double* __rest
     c.se = ok ? sqrt(1.0 - e) : __builtin_nan("");
     c.pe = sqrt(1.0 + e);
     c.sq1me2 = c.se * c.pe;
+    c.isq1me2 = 1.0 / c.sq1me2;
     c.cw = p[EXO_P_COSW]; c.sw = p[EXO_P_SINW];
     c.ci = p[EXO_P_COSI]; c.si = p[EXO_P_SINI];
     c.aor = p[EXO_P_AOR]; c.ror = p[EXO_P_ROR]; c.iror = 1.0 / p[EXO_P_ROR];
@@ -138,7 +139,7 @@ __device__ __forceinline__ double eval_sample(double tt, const PlanetConst& c, c
   // NaN parameters must propagate: treat NaN b2 as active
   const bool act = (front || behind) && !(b2 >= lim * lim);
   if (!EXO_WAVE_ANY(act)) return 0.0;
-  const double b = sqrt(b2);
+  const double b = exo::fast_sqrt(b2);
   // transit: (b, ror) on the star; occultation: star of radius 1/ror passes in
   // front of the planet, in units of the planet radius (secondary_eclipse.py:56-58)
   const bool occ = SECONDARY && behind;
@@ -151,7 +152,7 @@ __device__ __forceinline__ double eval_sample(double tt, const PlanetConst& c, c
   double F;
   double wq = 1.0;  // dF/dFq
   if (SECONDARY) {
-    const double inv = 1.0 / (1.0 + c.fr);
+    const double inv = exo::fast_div(1.0, 1.0 + c.fr);
     wq = occ ? c.fr * inv : inv;
     F = act ? Fq * wq : 0.0;
   } else {
@@ -179,7 +180,7 @@ __device__ __forceinline__ double eval_sample(double tt, const PlanetConst& c, c
         if (SECONDARY) acc.g[G_FR] -= gw * Fq * (1.0 / ((1.0 + c.fr) * (1.0 + c.fr)));
       }
       acc.g[G_ROR] += rorbar;
-      const double ib = (b > 0.0) ? 1.0 / b : 0.0;
+      const double ib = (b > 0.0) ? exo::fast_div(1.0, b) : 0.0;
       const double x1bar = bbar * x1 * ib;
       const double Ysbar = bbar * Ys * ib;
       const double y1bar = Ysbar * c.ci;
@@ -193,10 +194,10 @@ __device__ __forceinline__ double eval_sample(double tt, const PlanetConst& c, c
       // cx = cos E - e, sx = sqrt(1-e^2) sin E ; dE/dM = 1/den, dE/de = sin E/den
       const double sinE = 2.0 * kh.sh * kh.ch;
       const double cosE = kh.ch * kh.ch - kh.sh * kh.sh;
-      const double iden = 1.0 / (X2 + Y2);
+      const double iden = exo::fast_div(1.0, X2 + Y2);
       const double Ebar = fma(-sinE, cxbar, c.sq1me2 * cosE * sxbar);
       const double Mbar = Ebar * iden;
-      acc.g[G_ECC] += Mbar * sinE - cxbar - c.e * sinE / c.sq1me2 * sxbar;
+      acc.g[G_ECC] += Mbar * sinE - cxbar - c.e * sinE * c.isq1me2 * sxbar;
       acc.g[G_N] += Mbar * (tt - c.tp);
       acc.g[G_TP] -= Mbar * c.n;
     }
