@@ -1,0 +1,171 @@
+"""Orbit variants that reuse the Keplerian machinery.
+
+``TTVOrbit``            transit-timing variations: every cadence is measured from its
+                        nearest labelled transit (reference: src/exoplanet/orbits/ttv.py).
+``SimpleTransitOrbit``  straight-line transit from observables, no Kepler solve
+                        (reference: src/exoplanet/orbits/simple.py).
+
+Both go through the light-curve classes' composed path (``ops.kepler`` /
+``ops.quad_solution_vector``): the fused kernels assume one ``t0`` per planet.
+The per-planet transit lists are ragged, so they live in one padded
+``(n_planet, n_transit_max)`` table and a single batched ``searchsorted`` maps all
+cadences of all planets at once.  Unbatched (no draw dimension).
+"""
+import numpy as np
+import torch
+
+from .keplerian import KeplerianOrbit, _vec, as_tensor
+
+__all__ = ["TTVOrbit", "SimpleTransitOrbit", "compute_expected_transit_times"]
+
+
+def compute_expected_transit_times(min_time, max_time, period, t0):
+    """strictly periodic transit times inside [min_time, max_time]: one array per planet"""
+    result = []
+    for per, ref in zip(np.atleast_1d(period), np.atleast_1d(t0)):
+        first = np.floor((min_time - ref) / per)
+        last = np.ceil((max_time - ref) / per)
+        cand = ref + per * np.arange(first, last, 1)
+        result.append(cand[(cand >= min_time) & (cand <= max_time)])
+    return result
+
+
+class _TransitTable:
+    """nearest-transit lookup for all planets at once.
+
+    Row p holds planet p's complete transit list (observed or interpolated);
+    ``edges`` are the midpoints between neighbours, closed by half a period on
+    either side (ttv.py:149-163), padded with +inf; ``centres[p, k]`` is the
+    transit a time in bin k belongs to."""
+
+    def __init__(self, all_times, ttv_period):
+        P = len(all_times)
+        width = max(int(x.shape[0]) for x in all_times)
+        dev = all_times[0].device
+        self.edges = torch.full((P, width + 1), float("inf"), dtype=torch.float64, device=dev)
+        centres = []
+        for p, tts in enumerate(all_times):
+            n = tts.shape[0]
+            mids = 0.5 * (tts[1:] + tts[:-1])
+            row = torch.cat([(tts[0] - 0.5 * ttv_period[p]).reshape(1), mids, (tts[-1] + 0.5 * ttv_period[p]).reshape(1)])
+            self.edges[p, :n + 1] = row.detach()
+            # bins: (-inf, e0] -> first transit, (e_k, e_k+1] -> transit k, beyond the last edge -> last transit
+            c = torch.cat([tts[:1], tts, tts[-1:].expand(width + 1 - n)])
+            centres.append(c)
+        self.centres = torch.stack(centres)          # (P, width + 2), differentiable in the transit times
+
+    def nearest(self, t_by_planet):
+        """t_by_planet (P, ...) -> the matching transit time of each entry, same shape"""
+        flat = t_by_planet.reshape(t_by_planet.shape[0], -1).detach().contiguous()
+        idx = torch.searchsorted(self.edges, flat)
+        return torch.gather(self.centres, 1, idx).reshape(t_by_planet.shape)
+
+
+class TTVOrbit(KeplerianOrbit):
+    """KeplerianOrbit plus exactly one of ``ttvs`` (O-C offsets per labelled transit, per
+    planet) or ``transit_times`` (observed times; the least-squares period and t0 follow
+    from them), optionally ``transit_inds`` (zero-based transit numbers when transits are
+    missing) and, with ``transit_times``, ``delta_log_period``."""
+
+    def __init__(self, *args, ttvs=None, transit_times=None, transit_inds=None, **kwargs):
+        if ttvs is None and transit_times is None:
+            raise ValueError("one of 'ttvs' or 'transit_times' must be defined")
+        flat = lambda x: as_tensor(x).reshape(-1)  # noqa: E731
+        given = [flat(x) for x in (ttvs if ttvs is not None else transit_times)]
+        dev = given[0].device
+        if transit_inds is None:
+            self.transit_inds = [torch.arange(x.shape[0], device=dev) for x in given]
+        else:
+            self.transit_inds = [torch.as_tensor(i, dtype=torch.int64, device=dev).reshape(-1) for i in transit_inds]
+        if ttvs is not None:
+            self.ttvs = given
+        else:
+            # straight-line fit time = intercept + slope * index per planet (ttv.py:99-123)
+            self.transit_times = given
+            fits = [self._line_fit(ix.to(torch.float64), tt) for ix, tt in zip(self.transit_inds, given)]
+            self.ttv_period = torch.stack([f[0] for f in fits])
+            kwargs["t0"] = torch.stack([f[1] for f in fits])
+            self.ttvs = [tt - (f[1] + ix.to(torch.float64) * f[0])
+                         for f, ix, tt in zip(fits, self.transit_inds, given)]
+            if "period" not in kwargs:
+                dlp = kwargs.pop("delta_log_period", None)
+                kwargs["period"] = self.ttv_period if dlp is None else torch.exp(torch.log(self.ttv_period) + as_tensor(dlp))
+        super().__init__(*args, **kwargs)
+        self._standard = False          # one t0 per planet is exactly what this orbit does not have
+        if ttvs is not None:
+            self.ttv_period = self.period
+            self.transit_times = [self.t0[p] + self.period[p] * ix + dv
+                                  for p, (ix, dv) in enumerate(zip(self.transit_inds, self.ttvs))]
+        # fill unobserved transit numbers with the linear ephemeris (ttv.py:141-147)
+        self.all_transit_times = []
+        for p, ix in enumerate(self.transit_inds):
+            grid = self.t0[p] + self.period[p] * torch.arange(int(ix.max().item()) + 1, device=dev)
+            self.all_transit_times.append(grid.index_put((ix,), self.transit_times[p]))
+        self._table = _TransitTable(self.all_transit_times, self.ttv_period)
+
+    @staticmethod
+    def _line_fit(x, y):
+        n = x.shape[0]
+        sx, sxx, sy, sxy = x.sum(), (x * x).sum(), y.sum(), (x * y).sum()
+        det = n * sxx - sx * sx
+        return (n * sxy - sx * sy) / det, (sxx * sy - sx * sxy) / det   # slope, intercept
+
+    def _warp_times(self, t, _pad=True):
+        """time since the nearest labelled transit, shape (..., P) (ttv.py:175-187)"""
+        t = as_tensor(t, self.n)
+        P = self._table.edges.shape[0]
+        per_planet = t.unsqueeze(0).expand((P,) + tuple(t.shape)) if _pad else t.movedim(-1, 0)
+        return (per_planet - self._table.nearest(per_planet)).movedim(0, -1)
+
+
+class SimpleTransitOrbit:
+    """Planets crossing the stellar disk on straight lines at constant speed, set by the
+    observables (period, duration, t0, b): x = speed * dt, y = b R_star, in front of the
+    star only for |dt| < duration / 2."""
+
+    def __init__(self, period, duration, t0=0.0, b=0.0, r_star=1.0, ror=0):
+        self.period = _vec(period)
+        like = self.period
+        self.duration, self.t0, self.b = _vec(duration, like), _vec(t0, like), _vec(b, like)
+        self.r_star = _vec(r_star, like)
+        chord = self.r_star * torch.sqrt((1 + _vec(ror, like)) ** 2 - self.b ** 2)   # half the path across the disk
+        self.speed = 2 * chord / self.duration
+        self._y = self.b * self.r_star
+
+    def _since_transit(self, t):
+        """(N, P) time since the nearest transit centre, in [-period/2, period/2)"""
+        t = as_tensor(t, self.period).unsqueeze(-1)
+        half = 0.5 * self.period
+        return torch.remainder(t - self.t0 + half, self.period) - half
+
+    def get_relative_position(self, t, light_delay=False):
+        if light_delay:
+            raise NotImplementedError("Light travel time delay is not implemented for simple orbits")
+        dt = self._since_transit(t)
+        front = torch.where(dt.abs() < 0.5 * self.duration, 1.0, -1.0).to(torch.float64)
+        return (self.speed * dt).squeeze(), (self._y + 0 * dt).squeeze(), front.squeeze()
+
+    def get_planet_position(self, t, light_delay=False):
+        return self.get_relative_position(t, light_delay=False)
+
+    def get_star_position(self, t, light_delay=False):
+        origin = torch.zeros_like(as_tensor(t, self.period))
+        return origin, origin, origin
+
+    def _no_velocity(self, *_, **__):
+        raise NotImplementedError("a SimpleTransitOrbit has no velocity")
+
+    get_planet_velocity = get_star_velocity = get_radial_velocity = _no_velocity
+
+    def in_transit(self, t, r=None, texp=None, light_delay=False):
+        if light_delay:
+            raise NotImplementedError("Light travel time delay is not implemented for simple orbits")
+        t = as_tensor(t, self.period)
+        if r is None:
+            reach = 0.5 * self.duration
+        else:
+            reach = torch.sqrt((_vec(r, self.period) + self.r_star) ** 2 - self._y ** 2) / self.speed
+        if texp is not None:
+            reach = reach + 0.5 * as_tensor(texp, self.period)
+        hit = (self._since_transit(t).abs() < reach).any(dim=-1)
+        return torch.nonzero(hit).reshape(-1)
