@@ -111,15 +111,20 @@ __device__ __forceinline__ bool in_window(double t, const PlanetConst& c, double
   return in;
 }
 
+// Gradient accumulators of the heavy kernel live in LDS, one column per thread
+// ([slot][thread]: consecutive threads hit consecutive banks).  They are touched only
+// by samples that overlap the disk, and keeping 17 doubles out of the register file is
+// what lets two waves share a SIMD next to the elliptic-integral code.
 struct GradAcc {
-  double g[kNG];
+  double* col;  // &lds[0][threadIdx.x]
+  __device__ __forceinline__ void add(int slot, double v) const { col[slot * kBlock] += v; }
 };
 
 // One (cadence, sub-exposure, planet) sample.  Returns the flux contribution F
-// and, if GRAD, adds gw * dF/d(theta) into acc / accld.
+// and, if GRAD, adds gw * dF/d(theta) into the LDS accumulator columns.
 template <bool GRAD, bool SECONDARY>
 __device__ __forceinline__ double eval_sample(double tt, const PlanetConst& c, const double* cld,
-                                              double gw, GradAcc& acc, double* accld) {
+                                              double gw, const GradAcc& acc) {
   const double M = (tt - c.tp) * c.n;
   const exo::KeplerHalf kh = exo::kepler_half(M, c.e, c.se, c.pe);
   const double X2 = kh.X * kh.X, Y2 = kh.Y * kh.Y;
@@ -163,9 +168,9 @@ __device__ __forceinline__ double eval_sample(double tt, const PlanetConst& c, c
       const double gq = gw * wq;
       // limb-darkening coefficients
       const int o = occ ? 3 : 0;
-      accld[o + 0] += gq * sv.s0;
-      accld[o + 1] += gq * sv.s1;
-      accld[o + 2] += gq * sv.s2;
+      acc.add(kNG + o + 0, gq * sv.s0);
+      acc.add(kNG + o + 1, gq * sv.s1);
+      acc.add(kNG + o + 2, gq * sv.s2);
       double bbar_q = gq * fma(sv.db0, cc[0], fma(sv.db1, cc[1], sv.db2 * cc[2]));
       double rbar_q = gq * fma(sv.dr0, cc[0], fma(sv.dr1, cc[1], sv.dr2 * cc[2]));
       double bbar, rorbar;
@@ -173,23 +178,23 @@ __device__ __forceinline__ double eval_sample(double tt, const PlanetConst& c, c
         // bq = b / ror, rq = 1 / ror ; F = fr Fq / (1 + fr)
         bbar = bbar_q * c.iror;
         rorbar = -(bbar_q * b + rbar_q) * c.iror * c.iror;
-        acc.g[G_FR] += gw * Fq * (1.0 / ((1.0 + c.fr) * (1.0 + c.fr)));
+        acc.add(G_FR, gw * Fq * (1.0 / ((1.0 + c.fr) * (1.0 + c.fr))));
       } else {
         bbar = bbar_q;
         rorbar = rbar_q;
-        if (SECONDARY) acc.g[G_FR] -= gw * Fq * (1.0 / ((1.0 + c.fr) * (1.0 + c.fr)));
+        if (SECONDARY) acc.add(G_FR, -gw * Fq * (1.0 / ((1.0 + c.fr) * (1.0 + c.fr))));
       }
-      acc.g[G_ROR] += rorbar;
+      acc.add(G_ROR, rorbar);
       const double ib = (b > 0.0) ? exo::fast_div(1.0, b) : 0.0;
       const double x1bar = bbar * x1 * ib;
       const double Ysbar = bbar * Ys * ib;
       const double y1bar = Ysbar * c.ci;
-      acc.g[G_COSI] += Ysbar * y1;
+      acc.add(G_COSI, Ysbar * y1);
       const double xobar = c.cw * x1bar + c.sw * y1bar;
       const double yobar = -c.sw * x1bar + c.cw * y1bar;
-      acc.g[G_COSW] += x1bar * xo + y1bar * yo;
-      acc.g[G_SINW] += -x1bar * yo + y1bar * xo;
-      acc.g[G_AOR] += -(xobar * cx + yobar * sx);
+      acc.add(G_COSW, x1bar * xo + y1bar * yo);
+      acc.add(G_SINW, -x1bar * yo + y1bar * xo);
+      acc.add(G_AOR, -(xobar * cx + yobar * sx));
       const double cxbar = -c.aor * xobar, sxbar = -c.aor * yobar;
       // cx = cos E - e, sx = sqrt(1-e^2) sin E ; dE/dM = 1/den, dE/de = sin E/den
       const double sinE = 2.0 * kh.sh * kh.ch;
@@ -197,9 +202,9 @@ __device__ __forceinline__ double eval_sample(double tt, const PlanetConst& c, c
       const double iden = exo::fast_div(1.0, X2 + Y2);
       const double Ebar = fma(-sinE, cxbar, c.sq1me2 * cosE * sxbar);
       const double Mbar = Ebar * iden;
-      acc.g[G_ECC] += Mbar * sinE - cxbar - c.e * sinE * c.isq1me2 * sxbar;
-      acc.g[G_N] += Mbar * (tt - c.tp);
-      acc.g[G_TP] -= Mbar * c.n;
+      acc.add(G_ECC, Mbar * sinE - cxbar - c.e * sinE * c.isq1me2 * sxbar);
+      acc.add(G_N, Mbar * (tt - c.tp));
+      acc.add(G_TP, -Mbar * c.n);
     }
   }
   return F;
@@ -343,8 +348,10 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 
+// two waves per SIMD (<= 256 registers): measured 0.727 ms vs 0.776 ms per sweep at one wave
+// (A/B via EXOPLANET_AMD_LIB), despite ~136 B/lane of scratch in the gradient variant
 #ifndef EXO_HEAVY_MIN_WAVES
-#define EXO_HEAVY_MIN_WAVES 1
+#define EXO_HEAVY_MIN_WAVES 2
 #endif
 template <bool GRAD, bool SECONDARY>
 __global__ __launch_bounds__(kBlock, EXO_HEAVY_MIN_WAVES) void transit_heavy_kernel(
@@ -370,12 +377,19 @@ __global__ __launch_bounds__(kBlock, EXO_HEAVY_MIN_WAVES) void transit_heavy_ker
   const int ng_draw = n_planet * kNG + 7;
   double* __restrict__ pout = GRAD ? partial + ((int64_t)draw * gridDim.x + blockIdx.x) * ng_draw : nullptr;
 
-  double accld[7] = {0, 0, 0, 0, 0, 0, 0};  // 6 limb-darkening slots + sum(gflux * flux)
+  // slots [0, kNG): this planet's parameters; [kNG, kNG + 6): limb darkening; kNG + 6: sum(gflux * flux)
+  __shared__ double lds_acc[kNG + 7][kBlock];
+  const GradAcc acc{GRAD ? &lds_acc[0][threadIdx.x] : nullptr};
+  if (GRAD) {
+#pragma unroll
+    for (int s = 0; s < kNG + 7; ++s) lds_acc[s][threadIdx.x] = 0.0;
+  }
   for (int p = 0; p < n_planet; ++p) {
     const PlanetConst& c = sh.pc[p];
-    GradAcc acc;
+    if (GRAD && p > 0) {
 #pragma unroll
-    for (int s = 0; s < kNG; ++s) acc.g[s] = 0.0;
+      for (int s = 0; s < kNG; ++s) lds_acc[s][threadIdx.x] = 0.0;
+    }
     for (int j0 = 0; j0 < total; j0 += kBlock) {
       const int j = j0 + threadIdx.x;
       const bool has = j < total;
@@ -392,9 +406,9 @@ __global__ __launch_bounds__(kBlock, EXO_HEAVY_MIN_WAVES) void transit_heavy_ker
       for (int k = 0; k < n_sub; ++k) {
         const double tt = fma(te, sh.sdt[k], tv);
         const double gw = g * sh.sw[k];
-        const double F = eval_sample<GRAD, SECONDARY>(tt, c, sh.c, gw, acc, accld);
+        const double F = eval_sample<GRAD, SECONDARY>(tt, c, sh.c, gw, acc);
         f = fma(sh.sw[k], F, f);
-        if (GRAD) accld[6] = fma(gw, F, accld[6]);
+        if (GRAD) acc.add(kNG + 6, gw * F);
       }
       if (flux && has) {
         if (per_planet) {
@@ -408,7 +422,7 @@ __global__ __launch_bounds__(kBlock, EXO_HEAVY_MIN_WAVES) void transit_heavy_ker
     if (GRAD) {
 #pragma unroll
       for (int s = 0; s < kNG; ++s) {
-        const double v = wave_sum(acc.g[s]);
+        const double v = wave_sum(lds_acc[s][threadIdx.x]);
         if (lane == 0) sh.red[wave][s] = v;
       }
       __syncthreads();
@@ -424,7 +438,7 @@ __global__ __launch_bounds__(kBlock, EXO_HEAVY_MIN_WAVES) void transit_heavy_ker
   if (GRAD) {
 #pragma unroll
     for (int s = 0; s < 7; ++s) {
-      const double v = wave_sum(accld[s]);
+      const double v = wave_sum(lds_acc[kNG + s][threadIdx.x]);
       if (lane == 0) sh.red[wave][kNG + s] = v;
     }
     __syncthreads();
