@@ -202,18 +202,12 @@ def main():
     graph = None
     static = {}
     if not args.no_graph:
-        side = torch.cuda.Stream(dev)
-        side.wait_stream(torch.cuda.current_stream(dev))
-        with torch.cuda.stream(side):
-            for _ in range(3):
-                step(xo, ops, leaves, t, gbar)
-        torch.cuda.current_stream(dev).wait_stream(side)
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            static["flux"], static["L"], static["grads"] = step(xo, ops, leaves, t, gbar)
+        names = list(leaves)
+        graph = xo.GraphedStep(lambda *vals: step(xo, ops, dict(zip(names, vals)), t, gbar), *leaves.values())
+        static["flux"], static["L"], static["grads"] = graph.outputs
 
     def one_graph(i):
-        graph.replay()
+        graph()
         if dist is not None:
             L_all.zero_()
             L_all[rank * D:(rank + 1) * D] = static["L"]
