@@ -35,6 +35,7 @@ constexpr int kTargetBlocks = 256 * 16;  // ~16 resident-or-queued blocks per CU
                                          // the per-block constant staging and gradient reduction
 constexpr uint32_t kFlagNoFluxDev = 0x80000000u;
 constexpr int kNG = 10;                 // compact gradient slots per planet
+constexpr int kWin = 5;                 // doubles per record written by transit_window_kernel
 // compact slot order
 enum { G_N = 0, G_TP, G_ECC, G_COSW, G_SINW, G_COSI, G_AOR, G_ROR, G_FR, G_PAD };
 
@@ -44,6 +45,8 @@ struct PlanetConst {
   double t0, period, iperiod, ts, te, fr, ts2, te2, isq1me2;
   // fp32 copies for the conservative classifier of the scan kernel
   float ef, omf, sqf, cwf, swf, cif, zsf, thrf, zthrf;
+  // conjunction windows of the scan kernel's first test (see transit_window_kernel)
+  double nrev, c0, dmid, half[2];
 };
 
 struct Shared {
@@ -54,11 +57,63 @@ struct Shared {
   double red[kWaves][kNG + 7];
 };
 
+// mean anomaly of true anomaly f, continuous and increasing over all f
+__device__ double mean_anomaly_of(double f, double e, double se, double pe) {
+  const double k = rint(f * (0.5 / exo::kPi));
+  const double h = 0.5 * fma(-k, 2.0 * exo::kPi, f);
+  const double E = 2.0 * atan2(se * sin(h), pe * cos(h));
+  return fma(k, 2.0 * exo::kPi, E - e * sin(E));
+}
+
+// Where can the planet overlap the disk at all?  Sky-plane separation (units of R*) is
+//   rho sqrt(cos^2(w+f) + cos^2 i sin^2(w+f)) >= (a/R)(1-e) |cos(w+f)|,
+// so b < 1 + r needs |cos(w+f)| < q = (1+r) / ((a/R)(1-e)) and, for the planet to be in
+// front, sin(w+f) sin i > 0: f within asin(q) of the conjunction f_c = +-pi/2 - w.  Mapped
+// through E(f), M(E) (closed forms in this direction) that is a window of mean anomaly; the
+// occultation window is the same about f_c + pi.  One thread per (draw, planet), run ahead of
+// the scan kernel (libm's fp64 trigonometry would cost the scan kernel half its occupancy);
+// the scan kernel's per-cadence test is then a phase wrap and a compare, and only cadences
+// inside a window go on to the position-based classifier.
+//   out[kWin] = { nrev = n / 2pi, c0 = -(tp nrev + mid_transit), mid_transit - mid_occultation,
+//                 half_transit, half_occultation }
+// in revolutions of mean anomaly: the phase of cadence t is fma(t, nrev, c0), wrapped to +-1/2.
+// q >= 1 or anything non-finite: halves = inf, every cadence goes on.
+__global__ __launch_bounds__(kBlock) void transit_window_kernel(const double* __restrict__ params, int64_t n_rec,
+                                                                double* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n_rec) return;
+  const double* p = params + i * EXO_NPAR;
+  const double e = p[EXO_P_ECC], cw = p[EXO_P_COSW], sw = p[EXO_P_SINW];
+  double* o = out + kWin * i;
+  const double nrev = p[EXO_P_N] * (0.5 / exo::kPi);
+  o[0] = nrev;
+  o[1] = -p[EXO_P_TP] * nrev;
+  o[2] = 0.0;
+  o[3] = o[4] = __builtin_inf();
+  if (!(e >= 0.0 && e < 1.0)) return;  // NaN everywhere: every cadence must reach the heavy kernel
+  const double wn = sqrt(cw * cw + sw * sw);
+  const double q = (1.0 + fabs(p[EXO_P_ROR])) / (fabs(p[EXO_P_AOR]) * (1.0 - e) * wn);
+  if (!(q < 0.999)) return;
+  const double se = sqrt(1.0 - e), pe = sqrt(1.0 + e);
+  const double delta = asin(q) * (1.0 + 1e-6) + 1e-6;
+  const double fc = (p[EXO_P_SINI] < 0.0 ? -0.5 : 0.5) * exo::kPi - atan2(sw, cw);
+  double mid[2];
+  for (int k = 0; k < 2; ++k) {
+    const double f0 = fc + k * exo::kPi;
+    const double lo = mean_anomaly_of(f0 - delta, e, se, pe), hi = mean_anomaly_of(f0 + delta, e, se, pe);
+    mid[k] = 0.5 * (lo + hi) * (0.5 / exo::kPi);
+    o[3 + k] = 0.5 * (hi - lo) * (0.5 / exo::kPi) * (1.0 + 1e-5) + 1e-6;
+  }
+  o[1] = -fma(p[EXO_P_TP], nrev, mid[0]);
+  o[2] = mid[0] - mid[1];
+}
+
 __device__ __forceinline__ void stage_constants(Shared& sh, const double* __restrict__ params,
                                                 const double* __restrict__ ld,
                                                 const double* __restrict__ stencil_dt,
                                                 const double* __restrict__ stencil_w, int n_sub,
-                                                int n_planet, int64_t draw, bool secondary) {
+                                                int n_planet, int64_t draw, bool secondary,
+                                                const double* __restrict__ windows = nullptr) {
   const int tid = threadIdx.x;
   if (tid < n_planet) {
     const double* p = params + (draw * n_planet + tid) * EXO_NPAR;
@@ -86,6 +141,10 @@ __device__ __forceinline__ void stage_constants(Shared& sh, const double* __rest
     c.zsf = (float)c.si;
     c.thrf = (float)(lim * lim) * 1.00001f;
     c.zthrf = (float)(-margin / c.aor);
+    if (windows) {
+      const double* wv = windows + kWin * (draw * n_planet + tid);
+      c.nrev = wv[0]; c.c0 = wv[1]; c.dmid = wv[2]; c.half[0] = wv[3]; c.half[1] = wv[4];
+    }
   }
   const int nld = secondary ? 6 : 3;
   if (ld && tid >= 64 && tid < 64 + nld) sh.c[tid - 64] = ld[draw * nld + (tid - 64)];
@@ -248,87 +307,235 @@ __device__ __forceinline__ bool classify_sample(double tt, const PlanetConst& c)
   return vis && !(b2 >= lim * lim);
 }
 
-// A tile is kTile = 2 * kBlock cadences: each lane owns two of them.  VEC2 (n_cad
-// even, so every draw's row is 16-B aligned): the two are adjacent and t / flux
-// move as 16-B accesses; otherwise they are kBlock apart and move as 8-B accesses.
-// The scan kernel zero-fills flux for EVERY cadence (a pure store stream); the
-// heavy kernel, ordered after it on the stream, overwrites the active ones.
+// Kernel A -- "scan".  Two kinds of block share the launch, told apart by the parity of
+// blockIdx.x, so that both kinds are resident together on every CU:
+//   * fill blocks zero flux for their run of cadences -- a pure stream of 16-B stores
+//     with nothing to wait for (the heavy kernel, ordered after this one on the stream,
+//     overwrites the active cadences).  Stores and loads share one in-order counter on
+//     gfx9, so a wave that alternates "load t, store 0" drains its stores every
+//     iteration; giving the stores to waves that never load is what lets them run at
+//     fill bandwidth;
+//   * classify blocks read t (two cadences per lane, the next tile's pair prefetched),
+//     decide which cadences can overlap the disk and append their offsets to per-wave
+//     lists with ballot + mbcnt (no atomics).
+// VEC2 (n_cad even and t 16-B aligned): a lane's two cadences are adjacent and t moves
+// as 16-B loads; otherwise they are kBlock apart.
+__device__ __forceinline__ void zero_fill(double* __restrict__ dst, int64_t n) {
+  if (n <= 0) return;
+  const int64_t head = (reinterpret_cast<uintptr_t>(dst) & 8) ? 1 : 0;
+  if (threadIdx.x == 0 && head) dst[0] = 0.0;
+  double2* __restrict__ d2 = reinterpret_cast<double2*>(dst + head);
+  const int64_t n2 = (n - head) >> 1;
+  int64_t k = threadIdx.x;
+  for (; k + 3 * kBlock < n2; k += 4 * kBlock) {
+    d2[k] = double2{0.0, 0.0};
+    d2[k + kBlock] = double2{0.0, 0.0};
+    d2[k + 2 * kBlock] = double2{0.0, 0.0};
+    d2[k + 3 * kBlock] = double2{0.0, 0.0};
+  }
+  for (; k < n2; k += kBlock) d2[k] = double2{0.0, 0.0};
+  if (threadIdx.x == 0 && ((n - head) & 1)) dst[n - 1] = 0.0;
+}
+
+// first test of the scan kernel: is the wrapped phase within lim of a conjunction?  NaN -> yes.
+// x - rint(x) through the 1.5 * 2^52 shift (two full-rate adds; |x| < 2^51 revolutions).
+__device__ __forceinline__ double frac_rev(double x) {
+  const double kShift = 6755399441055744.0;
+  return x - ((x + kShift) - kShift);
+}
+template <bool SECONDARY>
+__device__ __forceinline__ bool near_conjunction(double t, double nrev, double c0, double dmid, double lim0,
+                                                 double lim1) {
+  const double x = fma(t, nrev, c0);
+  bool cand = !(fabs(frac_rev(x)) > lim0);
+  if (SECONDARY) cand = cand || !(fabs(frac_rev(x + dmid)) > lim1);
+  return cand;
+}
+
+// a wave-uniform double pinned to scalar registers
+__device__ __forceinline__ double uniform(double x) {
+  const int lo = __builtin_amdgcn_readfirstlane(__double2loint(x));
+  const int hi = __builtin_amdgcn_readfirstlane(__double2hiint(x));
+  return __hiloint2double(hi, lo);
+}
+
+constexpr int kScanDraws = 4;  // draws per classify block on the single-planet path
+
+// ballot + mbcnt append of the active lanes' offsets to a per-wave list (no atomics)
+__device__ __forceinline__ void append_active(bool active, int off, int32_t* __restrict__ lst, int& cnt) {
+  const unsigned long long ballot = __ballot(active);
+  if (active) {
+    const int before =
+        __builtin_amdgcn_mbcnt_hi((unsigned)(ballot >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)ballot, 0));
+    lst[cnt + before] = off;
+  }
+  cnt += __popcll(ballot);
+}
+
+// flags & kFlagGrouped: classify blocks take kScanDraws consecutive draws each (single planet,
+// conjunction windows, one exposure time): t is loaded once per kScanDraws draws and the per-draw
+// window constants sit in scalar registers.
+constexpr uint32_t kFlagGrouped = 0x40000000u;
+
 template <bool SECONDARY, bool FAST, bool VEC2>
 __global__ __launch_bounds__(kBlock) void transit_scan_kernel(
     const double* __restrict__ t, int64_t n_cad, const double* __restrict__ texp, int64_t n_texp,
     const double* __restrict__ stencil_dt, int n_sub, const double* __restrict__ params, int n_planet,
-    uint32_t flags, int tiles_per_block, double* __restrict__ flux, int32_t* __restrict__ counts,
-    int32_t* __restrict__ list) {
+    uint32_t flags, int tiles_per_block, int blocks_per_draw, int64_t n_draw, int64_t n_classify,
+    double* __restrict__ flux, int32_t* __restrict__ counts, int32_t* __restrict__ list,
+    const double* __restrict__ windows) {
   __shared__ Shared sh;
-  const int64_t draw = blockIdx.y;
-  stage_constants(sh, params, nullptr, stencil_dt, nullptr, n_sub, n_planet, draw, SECONDARY);
-  const bool per_planet = flags & EXO_FLAG_PER_PLANET;
+  // 1-D launch: classify blocks first (they feed the next kernel and should start early),
+  // fill blocks after them; workgroups go to the 8 XCDs round-robin on the linear id, so both
+  // kinds spread over all of them.
+  int64_t work = blockIdx.x;
+  if (work >= n_classify) {
+    work -= n_classify;
+    const int64_t draw = work / blocks_per_draw;
+    const int bx = (int)(work - draw * blocks_per_draw);
+    const int64_t lo = (int64_t)bx * tiles_per_block * kTile;
+    const int64_t hi = lo + (int64_t)tiles_per_block * kTile;
+    const int64_t npl = (flags & EXO_FLAG_PER_PLANET) ? n_planet : 1;
+    zero_fill(flux + (draw * n_cad + lo) * npl, ((hi < n_cad ? hi : n_cad) - lo) * npl);
+    return;
+  }
+#ifdef EXO_DEBUG_FILL_ONLY
+  return;
+#endif
+  const bool grouped = FAST && (flags & kFlagGrouped);
+  const int64_t unit = work / blocks_per_draw;  // draw, or group of kScanDraws draws
+  const int bx = (int)(work - unit * blocks_per_draw);
+  const int64_t draw = grouped ? unit * kScanDraws : unit;
+  const int nd = grouped ? (int)((n_draw - draw) < kScanDraws ? (n_draw - draw) : kScanDraws) : 1;
+  // grouped: the nd consecutive single-planet records are staged as if they were nd planets of one draw
+  stage_constants(sh, params + (grouped ? draw * EXO_NPAR : 0), nullptr, stencil_dt, nullptr, n_sub,
+                  grouped ? nd : n_planet, grouped ? 0 : draw, SECONDARY,
+                  FAST ? windows + (grouped ? kWin * draw : 0) : nullptr);
   const bool window = flags & EXO_FLAG_WINDOW;
-  const bool store = !(flags & kFlagNoFluxDev);
+  // half-span of the exposure stencil: widens the conjunction windows
+  double span = 0.0;
+  if (FAST)
+    for (int k = 0; k < n_sub; ++k) span = fmax(span, fabs(sh.sdt[k]));
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int64_t blk_base = (int64_t)blockIdx.x * tiles_per_block * kTile;
-  const int64_t wave_slot = ((int64_t)draw * gridDim.x + blockIdx.x) * kWaves + wave;
-  int32_t* __restrict__ my_list = list + wave_slot * ((int64_t)tiles_per_block * 128);
-  int cnt = 0;
-  for (int tile = 0; tile < tiles_per_block; ++tile) {
-    int off[2];
-    off[0] = tile * kTile + (VEC2 ? 2 * (int)threadIdx.x : (int)threadIdx.x);
-    off[1] = off[0] + (VEC2 ? 1 : kBlock);
-    const int64_t i0 = blk_base + off[0], i1 = blk_base + off[1];
-    bool valid[2] = {i0 < n_cad, i1 < n_cad};
-    double tv[2];
+  const int64_t blk_base = (int64_t)bx * tiles_per_block * kTile;
+  const int64_t list_stride = (int64_t)tiles_per_block * 128;
+  const int64_t wave_slot = ((int64_t)draw * blocks_per_draw + bx) * kWaves + wave;  // of the first draw
+  const int64_t slot_stride = (int64_t)blocks_per_draw * kWaves;                    // draw to draw
+  const int o0 = VEC2 ? 2 * (int)threadIdx.x : (int)threadIdx.x;
+  const int o1 = o0 + (VEC2 ? 1 : kBlock);
+  auto load_pair = [&](int tile, double& a, double& b) {
+    const int64_t i0 = blk_base + tile * kTile + o0, i1 = blk_base + tile * kTile + o1;
     if (VEC2) {
       // n_cad even and i0 even: the pair is valid or invalid together
-      const double2 tt2 = valid[0] ? *reinterpret_cast<const double2*>(t + i0) : double2{0.0, 0.0};
-      tv[0] = tt2.x; tv[1] = tt2.y;
+      const double2 v = (i0 < n_cad) ? *reinterpret_cast<const double2*>(t + i0) : double2{0.0, 0.0};
+      a = v.x; b = v.y;
     } else {
-      tv[0] = valid[0] ? t[i0] : 0.0;
-      tv[1] = valid[1] ? t[i1] : 0.0;
+      a = (i0 < n_cad) ? t[i0] : 0.0;
+      b = (i1 < n_cad) ? t[i1] : 0.0;
     }
-    if (store) {
-      if (per_planet) {
-        if (VEC2) {
-          if (valid[0]) {
-            double2* dst = reinterpret_cast<double2*>(flux + (draw * n_cad + i0) * n_planet);
-            for (int p = 0; p < n_planet; ++p) dst[p] = double2{0.0, 0.0};
-          }
-        } else {
-          for (int v = 0; v < 2; ++v)
-            if (valid[v])
-              for (int p = 0; p < n_planet; ++p) flux[(draw * n_cad + (v ? i1 : i0)) * n_planet + p] = 0.0;
+  };
+  double nx0, nx1;
+  load_pair(0, nx0, nx1);
+  if (grouped) {
+    // Common case per tile: 16 (draw, cadence) phase tests, five full-rate operations each, and
+    // no lane near a conjunction.  Otherwise (transits are contiguous in time and aligned across
+    // neighbouring draws, so this is ~5% of the tiles) a rolled loop over the draws runs the
+    // position-based classifier on the candidates; the per-draw counts live in LDS there.
+    __shared__ int s_cnt[kWaves][kScanDraws];
+    if (lane < kScanDraws) s_cnt[wave][lane] = 0;
+    const double te = n_texp ? texp[0] : 0.0;
+    double nrev[kScanDraws], c0[kScanDraws], dmid[kScanDraws], lim0[kScanDraws], lim1[kScanDraws];
+#pragma unroll
+    for (int j = 0; j < kScanDraws; ++j) {
+      const PlanetConst& c = sh.pc[j < nd ? j : 0];
+      nrev[j] = uniform(c.nrev); c0[j] = uniform(c.c0); dmid[j] = uniform(c.dmid);
+      const double widen = fabs(te) * span * fabs(c.nrev);
+      lim0[j] = uniform(c.half[0] + widen);
+      lim1[j] = SECONDARY ? uniform(c.half[1] + widen) : 0.0;
+    }
+    auto process = [&](int tile, double tv0, double tv1) {
+      const double tv[2] = {tv0, tv1};
+      unsigned cand = 0;
+#pragma unroll
+      for (int j = 0; j < kScanDraws; ++j) {
+#pragma unroll
+        for (int v = 0; v < 2; ++v)
+          cand |= near_conjunction<SECONDARY>(tv[v], nrev[j], c0[j], dmid[j], lim0[j], lim1[j]) ? (1u << (2 * j + v)) : 0u;
+      }
+      // draws past the end of the batch
+      cand &= (1u << (2 * nd)) - 1u;
+      if (__ballot(cand != 0) == 0) return;
+#ifdef EXO_DEBUG_NO_STAGE2
+      return;
+#endif
+      const int off[2] = {tile * kTile + o0, tile * kTile + o1};
+#pragma unroll 1
+      for (int j = 0; j < nd; ++j) {
+        int32_t* __restrict__ lst = list + (wave_slot + j * slot_stride) * list_stride;
+        int cnt = s_cnt[wave][j];
+#pragma unroll 1
+        for (int v = 0; v < 2; ++v) {
+          bool active = false;
+          if ((cand >> (2 * j + v)) & 1u)
+            for (int k = 0; k < n_sub; ++k)
+              active = active || classify_sample<SECONDARY, FAST>(fma(te, sh.sdt[k], tv[v]), sh.pc[j]);
+          append_active(active && (blk_base + off[v] < n_cad), off[v], lst, cnt);
         }
-      } else if (VEC2) {
-        if (valid[0]) *reinterpret_cast<double2*>(flux + draw * n_cad + i0) = double2{0.0, 0.0};
-      } else {
-        if (valid[0]) flux[draw * n_cad + i0] = 0.0;
-        if (valid[1]) flux[draw * n_cad + i1] = 0.0;
+        if (lane == 0) s_cnt[wave][j] = cnt;
+      }
+    };
+    // t runs kAhead tiles ahead of the tests (a block may be alone on its SIMD: no other wave
+    // hides the load latency)
+    constexpr int kAhead = 4;
+    double ring[kAhead][2];
+    ring[0][0] = nx0; ring[0][1] = nx1;
+#pragma unroll
+    for (int u = 1; u < kAhead; ++u) {
+      ring[u][0] = ring[u][1] = 0.0;
+      if (u < tiles_per_block) load_pair(u, ring[u][0], ring[u][1]);
+    }
+    for (int tile0 = 0; tile0 < tiles_per_block; tile0 += kAhead) {
+#pragma unroll
+      for (int u = 0; u < kAhead; ++u) {
+        const int tile = tile0 + u;
+        if (tile < tiles_per_block) {
+          const double a = ring[u][0], b = ring[u][1];
+          if (tile + kAhead < tiles_per_block) load_pair(tile + kAhead, ring[u][0], ring[u][1]);
+          process(tile, a, b);
+        }
       }
     }
-    bool active[2] = {false, false};
+    if (lane < nd) counts[wave_slot + lane * slot_stride] = s_cnt[wave][lane];
+    return;
+  }
+  int32_t* __restrict__ my_list = list + wave_slot * list_stride;
+  int cnt = 0;
+  for (int tile = 0; tile < tiles_per_block; ++tile) {
+    const double tv[2] = {nx0, nx1};
+    if (tile + 1 < tiles_per_block) load_pair(tile + 1, nx0, nx1);
+    const int off[2] = {tile * kTile + o0, tile * kTile + o1};
 #pragma unroll
     for (int v = 0; v < 2; ++v) {
-      const int64_t i = v ? i1 : i0;
-      const double te = (n_texp == 0) ? 0.0 : (n_texp == 1 ? texp[0] : (valid[v] ? texp[i] : 0.0));
+      const int64_t i = blk_base + off[v];
+      const bool valid = i < n_cad;
+      const double te = (n_texp == 0) ? 0.0 : (n_texp == 1 ? texp[0] : (valid ? texp[i] : 0.0));
+      bool active = false;
       for (int p = 0; p < n_planet; ++p) {
         const PlanetConst& c = sh.pc[p];
         if (window) {
-          active[v] = active[v] || in_window(tv[v], c, 0.5 * te, SECONDARY);
+          active = active || in_window(tv[v], c, 0.5 * te, SECONDARY);
         } else {
-          for (int k = 0; k < n_sub; ++k)
-            active[v] = active[v] || classify_sample<SECONDARY, FAST>(fma(te, sh.sdt[k], tv[v]), c);
+          bool cand = true;
+          if (FAST) {
+            const double widen = fabs(te) * span * fabs(c.nrev);
+            cand = near_conjunction<SECONDARY>(tv[v], c.nrev, c.c0, c.dmid, c.half[0] + widen, c.half[1] + widen);
+          }
+          if (cand)
+            for (int k = 0; k < n_sub; ++k)
+              active = active || classify_sample<SECONDARY, FAST>(fma(te, sh.sdt[k], tv[v]), c);
         }
       }
-      active[v] = active[v] && valid[v];
-    }
-#pragma unroll
-    for (int v = 0; v < 2; ++v) {
-      const unsigned long long ballot = __ballot(active[v]);
-      if (active[v]) {
-        const int before =
-            __builtin_amdgcn_mbcnt_hi((unsigned)(ballot >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)ballot, 0));
-        my_list[cnt + before] = off[v];
-      }
-      cnt += __popcll(ballot);
+      append_active(active && valid, off[v], my_list, cnt);
     }
   }
   if (lane == 0) counts[wave_slot] = cnt;
@@ -575,6 +782,7 @@ inline void transit_geometry(int64_t n_cad, int64_t n_draw, int* blocks_per_draw
 // scratch layout shared by forward and reverse: [gradient partials][wave counts][wave lists]
 struct Workspace {
   double* partial;
+  double* windows;
   int32_t* counts;
   int32_t* list;
   int64_t bytes;
@@ -586,10 +794,12 @@ inline Workspace carve(void* base, int64_t n_draw, int bpd, int tpb, int n_plane
   const int64_t n_counts = n_draw * bpd * (int64_t)kWaves;
   const int64_t n_list = n_counts * (int64_t)tpb * 128;
   char* p = (char*)base;
+  const int64_t n_win = kWin * n_draw * n_planet;
   w.partial = (double*)p;
-  w.counts = (int32_t*)(p + n_partial * 8);
+  w.windows = w.partial + n_partial;
+  w.counts = (int32_t*)(p + (n_partial + n_win) * 8);
   w.list = w.counts + ((n_counts + 1) & ~(int64_t)1);
-  w.bytes = n_partial * 8 + (((n_counts + 1) & ~(int64_t)1) + n_list) * 4;
+  w.bytes = (n_partial + n_win) * 8 + (((n_counts + 1) & ~(int64_t)1) + n_list) * 4;
   return w;
 }
 
@@ -604,13 +814,40 @@ constexpr uint32_t kFlagNoFlux = 0x80000000u;  // internal: scan kernel must not
     else if (exact_) hipLaunchKernelGGL((transit_scan_kernel<false, false, VEC>), __VA_ARGS__);           \
     else hipLaunchKernelGGL((transit_scan_kernel<false, true, VEC>), __VA_ARGS__);                        \
   } while (0)
-// 16-B accesses need every draw's row of t / flux 16-B aligned: even n_cad (and
-// base pointers from any allocator are at least 16-B aligned)
-#define EXO_LAUNCH_SCAN(N_CAD, FLAGS, ...)                         \
-  do {                                                             \
-    if (((N_CAD) & 1) == 0) EXO_LAUNCH_SCAN_V(true, FLAGS, __VA_ARGS__); \
-    else EXO_LAUNCH_SCAN_V(false, FLAGS, __VA_ARGS__);             \
+// 16-B loads of t: pairs must not straddle the end (even n_cad) and t must be 16-B aligned
+#define EXO_LAUNCH_SCAN(N_CAD, T, FLAGS, ...)                                                  \
+  do {                                                                                         \
+    if (((N_CAD) & 1) == 0 && (reinterpret_cast<uintptr_t>(T) & 15) == 0)                      \
+      EXO_LAUNCH_SCAN_V(true, FLAGS, __VA_ARGS__);                                             \
+    else                                                                                       \
+      EXO_LAUNCH_SCAN_V(false, FLAGS, __VA_ARGS__);                                            \
   } while (0)
+
+// conjunction windows feed the scan kernel's first test; not needed when the caller supplies
+// contact-point windows or asks for the exact fp64 scan
+inline void launch_windows(const double* params, int64_t n_draw, int n_planet, uint32_t flags, double* windows,
+                           hipStream_t st) {
+  if (flags & (EXO_FLAG_WINDOW | EXO_FLAG_EXACT_SCAN)) return;
+  const int64_t n_rec = n_draw * n_planet;
+  hipLaunchKernelGGL(transit_window_kernel, dim3((unsigned)((n_rec + kBlock - 1) / kBlock)), dim3(kBlock), 0, st,
+                     params, n_rec, windows);
+}
+
+// scan kernel launch: classify blocks (one per draw and tile run, or one per kScanDraws draws on
+// the single-planet path) followed by one fill block per draw and tile run
+struct ScanPlan {
+  uint32_t flags;      // caller's flags + internal ones
+  int64_t n_classify;  // classify blocks
+  dim3 grid;
+};
+inline ScanPlan scan_plan(uint32_t flags, int bpd, int64_t n_draw, int n_planet, int64_t n_texp, bool with_fill) {
+  ScanPlan sp;
+  const bool grouped = n_planet == 1 && n_texp <= 1 && !(flags & (EXO_FLAG_WINDOW | EXO_FLAG_EXACT_SCAN));
+  sp.flags = (flags & 0x0fffffffu) | (grouped ? kFlagGrouped : 0u) | (with_fill ? 0u : kFlagNoFlux);
+  sp.n_classify = (grouped ? (n_draw + kScanDraws - 1) / kScanDraws : n_draw) * bpd;
+  sp.grid = dim3((unsigned)(sp.n_classify + (with_fill ? n_draw * bpd : 0)));
+  return sp;
+}
 
 inline bool transit_args_ok(int64_t n_cad, int64_t n_texp, int32_t n_sub, int64_t n_draw, int32_t n_planet) {
   return n_cad >= 0 && n_draw >= 0 && n_draw <= 65535 && n_planet >= 1 && n_planet <= EXO_MAX_PLANETS &&
@@ -689,8 +926,10 @@ int exo_transit_flux_fwd_ev_f64(const double* t, int64_t n_cad, const double* te
   hipStream_t st = (hipStream_t)stream;
   const bool secondary = flags & EXO_FLAG_SECONDARY;
   if (ev_start) (void)hipEventRecord((hipEvent_t)ev_start, st);
-  EXO_LAUNCH_SCAN(n_cad, flags, grid, block, 0, st, t, n_cad, texp, n_texp, stencil_dt, n_sub, params, n_planet, flags,
-                  tpb, flux, w.counts, w.list);
+  launch_windows(params, n_draw, n_planet, flags, w.windows, st);
+  const ScanPlan sp = scan_plan(flags, bpd, n_draw, n_planet, n_texp, true);
+  EXO_LAUNCH_SCAN(n_cad, t, flags, sp.grid, block, 0, st, t, n_cad, texp, n_texp, stencil_dt, n_sub, params, n_planet,
+                  sp.flags, tpb, bpd, n_draw, sp.n_classify, flux, w.counts, w.list, w.windows);
   if (launch_status() != EXO_OK) return EXO_ERR_LAUNCH;
   if (secondary)
     hipLaunchKernelGGL((transit_heavy_kernel<false, true>), grid, block, 0, st, t, n_cad, texp, n_texp, stencil_dt,
@@ -741,9 +980,10 @@ int exo_transit_flux_vjp_ev_f64(const double* t, int64_t n_cad, const double* te
   // zeros for inactive cadences go to a scratch row that nobody reads
   double* flux_dst = flux_out;
   if (ev_start) (void)hipEventRecord((hipEvent_t)ev_start, st);
-  const uint32_t scan_flags = flux_dst ? flags : (flags | kFlagNoFlux);
-  EXO_LAUNCH_SCAN(n_cad, flags, grid, block, 0, st, t, n_cad, texp, n_texp, stencil_dt, n_sub, params, n_planet,
-                  scan_flags, tpb, flux_dst, w.counts, w.list);
+  launch_windows(params, n_draw, n_planet, flags, w.windows, st);
+  const ScanPlan sp = scan_plan(flags, bpd, n_draw, n_planet, n_texp, flux_dst != nullptr);
+  EXO_LAUNCH_SCAN(n_cad, t, flags, sp.grid, block, 0, st, t, n_cad, texp, n_texp, stencil_dt, n_sub, params, n_planet,
+                  sp.flags, tpb, bpd, n_draw, sp.n_classify, flux_dst, w.counts, w.list, w.windows);
   if (launch_status() != EXO_OK) return EXO_ERR_LAUNCH;
   if (secondary)
     hipLaunchKernelGGL((transit_heavy_kernel<true, true>), grid, block, 0, st, t, n_cad, texp, n_texp, stencil_dt,
