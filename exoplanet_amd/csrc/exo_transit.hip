@@ -44,7 +44,7 @@ struct PlanetConst {
   double n, tp, e, se, pe, sq1me2, cw, sw, ci, si, aor, ror, iror;
   double t0, period, iperiod, ts, te, fr, ts2, te2, isq1me2;
   // fp32 copies for the conservative classifier of the scan kernel
-  float ef, omf, sqf, cwf, swf, cif, zsf, thrf, zthrf;
+  float ef, omf, sqf, cwf, swf, cif, zsf, thrf, zthrf, inthrf;
   // conjunction windows of the scan kernel's first test (see transit_window_kernel)
   double nrev, c0, dmid, half[2];
 };
@@ -141,6 +141,8 @@ __device__ __forceinline__ void stage_constants(Shared& sh, const double* __rest
     c.zsf = (float)c.si;
     c.thrf = (float)(lim * lim) * 1.00001f;
     c.zthrf = (float)(-margin / c.aor);
+    const double lin = fmax(1.0 - c.ror - margin, 0.0) / c.aor;
+    c.inthrf = (float)(lin * lin);
     if (windows) {
       const double* wv = windows + kWin * (draw * n_planet + tid);
       c.nrev = wv[0]; c.c0 = wv[1]; c.dmid = wv[2]; c.half[0] = wv[3]; c.half[1] = wv[4];
@@ -280,9 +282,15 @@ __device__ __forceinline__ double eval_sample(double tt, const PlanetConst& c, c
 // A carries no elliptic-integral code, so it runs at high occupancy; without
 // windows it is dominated by the Kepler solve per (planet, sub-exposure).
 // ---------------------------------------------------------------------------
-// one (planet, sub-exposure) sample of the classifier: true = may overlap the disk
+// one (planet, sub-exposure) sample of the classifier:
+//   0 = cannot overlap the disk,
+//   1 = overlaps, and the small disk looks wholly inside the large one (b + r < 1),
+//   2 = overlaps, may be on the limb.
+// 1 versus 2 only orders the work list (limb cadences run the arc geometry of the solution
+// vector, the others do not, and a wave votes on whether to enter it): a wrong guess costs
+// time, never a result.
 template <bool SECONDARY, bool FAST>
-__device__ __forceinline__ bool classify_sample(double tt, const PlanetConst& c) {
+__device__ __forceinline__ int classify_sample(double tt, const PlanetConst& c) {
   if (FAST) {
     // conservative fp32 classification: only the phase is fp64 (see exo::orbit_pos_f32);
     // every accepted cadence is re-evaluated in fp64 by the heavy kernel
@@ -293,7 +301,8 @@ __device__ __forceinline__ bool classify_sample(double tt, const PlanetConst& c)
     const float Ys = c.cif * y1;
     const float Zs = c.zsf * y1;  // Z / (a/R)
     const bool vis = SECONDARY ? true : !(Zs <= c.zthrf);
-    return vis && !(fmaf(x1, x1, Ys * Ys) >= c.thrf);
+    const float b2s = fmaf(x1, x1, Ys * Ys);
+    return (vis && !(b2s >= c.thrf)) ? ((b2s < c.inthrf) ? 1 : 2) : 0;
   }
   const exo::KeplerHalf kh = exo::kepler_half((tt - c.tp) * c.n, c.e, c.se, c.pe);
   const double cx = kh.X * kh.X - kh.Y * kh.Y, sx = 2.0 * kh.X * kh.Y;
@@ -302,9 +311,9 @@ __device__ __forceinline__ bool classify_sample(double tt, const PlanetConst& c)
   const double Ys = c.ci * y1;
   const double Z = c.si * y1 * c.aor;       // = -sin(i) y1 (-a/R)
   const double b2 = (x1 * x1 + Ys * Ys) * c.aor * c.aor;
-  const double lim = 1.0 + c.ror;
+  const double lim = 1.0 + c.ror, lin = fmax(1.0 - c.ror, 0.0);
   const bool vis = SECONDARY ? true : !(Z <= 0.0);
-  return vis && !(b2 >= lim * lim);
+  return (vis && !(b2 >= lim * lim)) ? ((b2 < lin * lin) ? 1 : 2) : 0;
 }
 
 // Kernel A -- "scan".  Two kinds of block share the launch, told apart by the parity of
@@ -361,15 +370,22 @@ __device__ __forceinline__ double uniform(double x) {
 
 constexpr int kScanDraws = 4;  // draws per classify block on the single-planet path
 
-// ballot + mbcnt append of the active lanes' offsets to a per-wave list (no atomics)
-__device__ __forceinline__ void append_active(bool active, int off, int32_t* __restrict__ lst, int& cnt) {
-  const unsigned long long ballot = __ballot(active);
-  if (active) {
-    const int before =
-        __builtin_amdgcn_mbcnt_hi((unsigned)(ballot >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)ballot, 0));
-    lst[cnt + before] = off;
+// ballot + mbcnt append of the active lanes' offsets to a per-wave list (no atomics).  The list
+// is two-ended: kind 1 grows up from lst[0], kind 2 grows down from lst[cap - 1].
+struct ListCount {
+  int in, limb;
+};
+__device__ __forceinline__ void append_active(int kind, int off, int32_t* __restrict__ lst, int cap, ListCount& cnt) {
+  const unsigned long long b1 = __ballot(kind == 1), b2 = __ballot(kind == 2);
+  if (kind == 1) {
+    const int before = __builtin_amdgcn_mbcnt_hi((unsigned)(b1 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b1, 0));
+    lst[cnt.in + before] = off;
+  } else if (kind == 2) {
+    const int before = __builtin_amdgcn_mbcnt_hi((unsigned)(b2 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b2, 0));
+    lst[cap - 1 - (cnt.limb + before)] = off;
   }
-  cnt += __popcll(ballot);
+  cnt.in += __popcll(b1);
+  cnt.limb += __popcll(b2);
 }
 
 // flags & kFlagGrouped: classify blocks take kScanDraws consecutive draws each (single planet,
@@ -399,9 +415,6 @@ __global__ __launch_bounds__(kBlock) void transit_scan_kernel(
     zero_fill(flux + (draw * n_cad + lo) * npl, ((hi < n_cad ? hi : n_cad) - lo) * npl);
     return;
   }
-#ifdef EXO_DEBUG_FILL_ONLY
-  return;
-#endif
   const bool grouped = FAST && (flags & kFlagGrouped);
   const int64_t unit = work / blocks_per_draw;  // draw, or group of kScanDraws draws
   const int bx = (int)(work - unit * blocks_per_draw);
@@ -441,8 +454,8 @@ __global__ __launch_bounds__(kBlock) void transit_scan_kernel(
     // no lane near a conjunction.  Otherwise (transits are contiguous in time and aligned across
     // neighbouring draws, so this is ~5% of the tiles) a rolled loop over the draws runs the
     // position-based classifier on the candidates; the per-draw counts live in LDS there.
-    __shared__ int s_cnt[kWaves][kScanDraws];
-    if (lane < kScanDraws) s_cnt[wave][lane] = 0;
+    __shared__ ListCount s_cnt[kWaves][kScanDraws];
+    if (lane < kScanDraws) s_cnt[wave][lane] = ListCount{0, 0};
     const double te = n_texp ? texp[0] : 0.0;
     double nrev[kScanDraws], c0[kScanDraws], dmid[kScanDraws], lim0[kScanDraws], lim1[kScanDraws];
 #pragma unroll
@@ -465,21 +478,18 @@ __global__ __launch_bounds__(kBlock) void transit_scan_kernel(
       // draws past the end of the batch
       cand &= (1u << (2 * nd)) - 1u;
       if (__ballot(cand != 0) == 0) return;
-#ifdef EXO_DEBUG_NO_STAGE2
-      return;
-#endif
       const int off[2] = {tile * kTile + o0, tile * kTile + o1};
 #pragma unroll 1
       for (int j = 0; j < nd; ++j) {
         int32_t* __restrict__ lst = list + (wave_slot + j * slot_stride) * list_stride;
-        int cnt = s_cnt[wave][j];
+        ListCount cnt = s_cnt[wave][j];
 #pragma unroll 1
         for (int v = 0; v < 2; ++v) {
-          bool active = false;
+          int kind = 0;
           if ((cand >> (2 * j + v)) & 1u)
             for (int k = 0; k < n_sub; ++k)
-              active = active || classify_sample<SECONDARY, FAST>(fma(te, sh.sdt[k], tv[v]), sh.pc[j]);
-          append_active(active && (blk_base + off[v] < n_cad), off[v], lst, cnt);
+              kind = max(kind, classify_sample<SECONDARY, FAST>(fma(te, sh.sdt[k], tv[v]), sh.pc[j]));
+          append_active((blk_base + off[v] < n_cad) ? kind : 0, off[v], lst, (int)list_stride, cnt);
         }
         if (lane == 0) s_cnt[wave][j] = cnt;
       }
@@ -505,11 +515,15 @@ __global__ __launch_bounds__(kBlock) void transit_scan_kernel(
         }
       }
     }
-    if (lane < nd) counts[wave_slot + lane * slot_stride] = s_cnt[wave][lane];
+    if (lane < nd) {
+      const ListCount cnt = s_cnt[wave][lane];
+      counts[2 * (wave_slot + lane * slot_stride)] = cnt.in;
+      counts[2 * (wave_slot + lane * slot_stride) + 1] = cnt.limb;
+    }
     return;
   }
   int32_t* __restrict__ my_list = list + wave_slot * list_stride;
-  int cnt = 0;
+  ListCount cnt{0, 0};
   for (int tile = 0; tile < tiles_per_block; ++tile) {
     const double tv[2] = {nx0, nx1};
     if (tile + 1 < tiles_per_block) load_pair(tile + 1, nx0, nx1);
@@ -519,11 +533,17 @@ __global__ __launch_bounds__(kBlock) void transit_scan_kernel(
       const int64_t i = blk_base + off[v];
       const bool valid = i < n_cad;
       const double te = (n_texp == 0) ? 0.0 : (n_texp == 1 ? texp[0] : (valid ? texp[i] : 0.0));
-      bool active = false;
+      int kind = 0;
       for (int p = 0; p < n_planet; ++p) {
         const PlanetConst& c = sh.pc[p];
         if (window) {
-          active = active || in_window(tv[v], c, 0.5 * te, SECONDARY);
+          // the caller's windows decide what is evaluated; the classifier only sorts
+          if (in_window(tv[v], c, 0.5 * te, SECONDARY)) {
+            int kw = 1;
+            for (int k = 0; k < n_sub; ++k)
+              kw = max(kw, classify_sample<SECONDARY, FAST>(fma(te, sh.sdt[k], tv[v]), c));
+            kind = max(kind, kw);
+          }
         } else {
           bool cand = true;
           if (FAST) {
@@ -532,13 +552,16 @@ __global__ __launch_bounds__(kBlock) void transit_scan_kernel(
           }
           if (cand)
             for (int k = 0; k < n_sub; ++k)
-              active = active || classify_sample<SECONDARY, FAST>(fma(te, sh.sdt[k], tv[v]), c);
+              kind = max(kind, classify_sample<SECONDARY, FAST>(fma(te, sh.sdt[k], tv[v]), c));
         }
       }
-      append_active(active && valid, off[v], my_list, cnt);
+      append_active(valid ? kind : 0, off[v], my_list, (int)list_stride, cnt);
     }
   }
-  if (lane == 0) counts[wave_slot] = cnt;
+  if (lane == 0) {
+    counts[2 * wave_slot] = cnt.in;
+    counts[2 * wave_slot + 1] = cnt.limb;
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -575,12 +598,13 @@ __global__ __launch_bounds__(kBlock, EXO_HEAVY_MIN_WAVES) void transit_heavy_ker
   const int64_t blk_base = (int64_t)blockIdx.x * tiles_per_block * kTile;
   const int64_t slot0 = ((int64_t)draw * gridDim.x + blockIdx.x) * kWaves;
   const int cap = tiles_per_block * 128;
-  // prefix over the four wave lists
-  int pre[kWaves + 1];
+  // prefix over the eight segments: the four waves' "inside" runs, then their "limb" runs
+  int pre[2 * kWaves + 1];
   pre[0] = 0;
 #pragma unroll
-  for (int w = 0; w < kWaves; ++w) pre[w + 1] = pre[w] + counts[slot0 + w];
-  const int total = pre[kWaves];
+  for (int sgm = 0; sgm < 2 * kWaves; ++sgm)
+    pre[sgm + 1] = pre[sgm] + counts[2 * (slot0 + (sgm & (kWaves - 1))) + (sgm >= kWaves ? 1 : 0)];
+  const int total = pre[2 * kWaves];
   const int ng_draw = n_planet * kNG + 7;
   double* __restrict__ pout = GRAD ? partial + ((int64_t)draw * gridDim.x + blockIdx.x) * ng_draw : nullptr;
 
@@ -600,10 +624,14 @@ __global__ __launch_bounds__(kBlock, EXO_HEAVY_MIN_WAVES) void transit_heavy_ker
     for (int j0 = 0; j0 < total; j0 += kBlock) {
       const int j = j0 + threadIdx.x;
       const bool has = j < total;
-      int w = 0;
+      int sgm = 0;
 #pragma unroll
-      for (int q = 1; q < kWaves; ++q) w += (j >= pre[q]) ? 1 : 0;
-      const int off = has ? list[(slot0 + w) * (int64_t)cap + (j - pre[w])] : 0;
+      for (int q = 1; q < 2 * kWaves; ++q) sgm += (j >= pre[q]) ? 1 : 0;
+      int pos = j;
+#pragma unroll
+      for (int q = 1; q < 2 * kWaves; ++q) pos -= (sgm == q) ? pre[q] : 0;
+      const int64_t lbase = (slot0 + (sgm & (kWaves - 1))) * (int64_t)cap;
+      const int off = has ? list[lbase + (sgm >= kWaves ? cap - 1 - pos : pos)] : 0;
       const int64_t i = blk_base + off;
       const double tv = t[i];
       const double te = (n_texp == 0) ? 0.0 : (n_texp == 1 ? texp[0] : texp[i]);
@@ -791,8 +819,9 @@ struct Workspace {
 inline Workspace carve(void* base, int64_t n_draw, int bpd, int tpb, int n_planet) {
   Workspace w;
   const int64_t n_partial = n_draw * bpd * (int64_t)(n_planet * kNG + 7);
-  const int64_t n_counts = n_draw * bpd * (int64_t)kWaves;
-  const int64_t n_list = n_counts * (int64_t)tpb * 128;
+  const int64_t n_slots = n_draw * bpd * (int64_t)kWaves;
+  const int64_t n_counts = 2 * n_slots;  // (inside, limb) per wave list
+  const int64_t n_list = n_slots * (int64_t)tpb * 128;
   char* p = (char*)base;
   const int64_t n_win = kWin * n_draw * n_planet;
   w.partial = (double*)p;
