@@ -31,10 +31,14 @@ namespace {
 constexpr int kBlock = 256;
 constexpr int kWaves = kBlock / 64;
 constexpr int kTile = 2 * kBlock;         // cadences per tile: two per lane
-constexpr int kTargetBlocks = 256 * 16;  // ~16 resident-or-queued blocks per CU: fills the chip, amortises
+#ifndef EXO_TARGET_BLOCKS
+#define EXO_TARGET_BLOCKS (256 * 16)
+#endif
+constexpr int kTargetBlocks = EXO_TARGET_BLOCKS;  // ~16 resident-or-queued blocks per CU: fills the chip, amortises
                                          // the per-block constant staging and gradient reduction
 constexpr uint32_t kFlagNoFluxDev = 0x80000000u;
 constexpr int kNG = 10;                 // compact gradient slots per planet
+constexpr int kMaxMerge = 8;            // scan blocks per heavy block, at most
 constexpr int kWin = 5;                 // doubles per record written by transit_window_kernel
 // compact slot order
 enum { G_N = 0, G_TP, G_ECC, G_COSW, G_SINW, G_COSI, G_AOR, G_ROR, G_FR, G_PAD };
@@ -54,7 +58,7 @@ struct Shared {
   double c[6];
   double sdt[EXO_MAX_SUBEXP + 1];
   double sw[EXO_MAX_SUBEXP + 1];
-  double red[kWaves][kNG + 7];
+  double red[16][16];  // reduce_columns: up to 16 slots x 16 partial sums
 };
 
 // mean anomaly of true anomaly f, continuous and increasing over all f
@@ -572,10 +576,29 @@ __global__ __launch_bounds__(kBlock) void transit_scan_kernel(
 // live in registers for the whole block and are reduced once per planet:
 // wave shuffle tree, then waves in index order (bit-reproducible).
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ double wave_sum(double v) {
+// Sum the kBlock per-thread columns of accumulator slots [first, first + n) and write the n
+// totals to out[0..n).  Two passes through LDS in a fixed order (bit-reproducible): thread
+// (slot, c) adds the 16 columns c, c + 16, ..., then one thread per slot adds the 16 partials.
+// A shuffle tree per slot costs 17 x 6 dependent cross-lane hops per block and was the bulk of
+// the heavy kernel's per-block overhead.
+__device__ __forceinline__ void reduce_columns(double (*acc)[kBlock], double (*red)[16], int first, int n,
+                                               double* __restrict__ out) {
+  __syncthreads();
+  const int s = threadIdx.x >> 4, c = threadIdx.x & 15;
+  if (s < n) {
+    double v = 0.0;
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-  return v;
+    for (int i = 0; i < kBlock / 16; ++i) v += acc[first + s][c + 16 * i];
+    red[s][c] = v;
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < n) {
+    double v = 0.0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v += red[threadIdx.x][i];
+    out[threadIdx.x] = v;
+  }
+  __syncthreads();
 }
 
 // two waves per SIMD (<= 256 registers): measured 0.727 ms vs 0.776 ms per sweep at one wave
@@ -588,23 +611,37 @@ __global__ __launch_bounds__(kBlock, EXO_HEAVY_MIN_WAVES) void transit_heavy_ker
     const double* __restrict__ t, int64_t n_cad, const double* __restrict__ texp, int64_t n_texp,
     const double* __restrict__ stencil_dt, const double* __restrict__ stencil_w, int n_sub,
     const double* __restrict__ params, const double* __restrict__ ld, int n_planet, uint32_t flags,
-    int tiles_per_block, const int32_t* __restrict__ counts, const int32_t* __restrict__ list,
-    const double* __restrict__ gflux, double* __restrict__ flux, double* __restrict__ partial) {
+    int tiles_per_block, int blocks_per_draw, int merge, const int32_t* __restrict__ counts,
+    const int32_t* __restrict__ list, const double* __restrict__ gflux, double* __restrict__ flux,
+    double* __restrict__ partial) {
   __shared__ Shared sh;
+  __shared__ int s_pre[2 * kWaves * kMaxMerge + 1];
   const int64_t draw = blockIdx.y;
   stage_constants(sh, params, ld, stencil_dt, stencil_w, n_sub, n_planet, draw, SECONDARY);
   const bool per_planet = flags & EXO_FLAG_PER_PLANET;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int64_t blk_base = (int64_t)blockIdx.x * tiles_per_block * kTile;
-  const int64_t slot0 = ((int64_t)draw * gridDim.x + blockIdx.x) * kWaves;
+  // this block works through the lists of `nsub` consecutive scan blocks of its draw
+  const int bx0 = blockIdx.x * merge;
+  const int nsub = (blocks_per_draw - bx0 < merge) ? blocks_per_draw - bx0 : merge;
   const int cap = tiles_per_block * 128;
-  // prefix over the eight segments: the four waves' "inside" runs, then their "limb" runs
-  int pre[2 * kWaves + 1];
-  pre[0] = 0;
-#pragma unroll
-  for (int sgm = 0; sgm < 2 * kWaves; ++sgm)
-    pre[sgm + 1] = pre[sgm] + counts[2 * (slot0 + (sgm & (kWaves - 1))) + (sgm >= kWaves ? 1 : 0)];
-  const int total = pre[2 * kWaves];
+  // segment order: all "inside" runs (scan block by scan block, wave by wave), then all "limb" runs
+  const int nseg = 2 * kWaves * nsub;
+  if ((int)threadIdx.x < nseg) {
+    const int sgm = threadIdx.x;
+    const int kind = sgm / (kWaves * nsub), rem = sgm - kind * (kWaves * nsub);
+    s_pre[sgm + 1] = counts[2 * (((int64_t)draw * blocks_per_draw + bx0) * kWaves + rem) + kind];
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int acc_n = 0;
+    s_pre[0] = 0;
+    for (int sgm = 1; sgm <= nseg; ++sgm) {
+      acc_n += s_pre[sgm];
+      s_pre[sgm] = acc_n;
+    }
+  }
+  __syncthreads();
+  const int total = s_pre[nseg];
   const int ng_draw = n_planet * kNG + 7;
   double* __restrict__ pout = GRAD ? partial + ((int64_t)draw * gridDim.x + blockIdx.x) * ng_draw : nullptr;
 
@@ -624,15 +661,18 @@ __global__ __launch_bounds__(kBlock, EXO_HEAVY_MIN_WAVES) void transit_heavy_ker
     for (int j0 = 0; j0 < total; j0 += kBlock) {
       const int j = j0 + threadIdx.x;
       const bool has = j < total;
+      // last segment whose start is <= j (empty segments share a start: the search lands past them)
       int sgm = 0;
 #pragma unroll
-      for (int q = 1; q < 2 * kWaves; ++q) sgm += (j >= pre[q]) ? 1 : 0;
-      int pos = j;
-#pragma unroll
-      for (int q = 1; q < 2 * kWaves; ++q) pos -= (sgm == q) ? pre[q] : 0;
-      const int64_t lbase = (slot0 + (sgm & (kWaves - 1))) * (int64_t)cap;
-      const int off = has ? list[lbase + (sgm >= kWaves ? cap - 1 - pos : pos)] : 0;
-      const int64_t i = blk_base + off;
+      for (int step = 32; step > 0; step >>= 1) {
+        const int q = sgm + step;
+        if (q < nseg && j >= s_pre[q]) sgm = q;
+      }
+      const int pos = j - s_pre[sgm];
+      const int kind = sgm / (kWaves * nsub), rem = sgm - kind * (kWaves * nsub);  // rem = sub * kWaves + wave
+      const int64_t lbase = (((int64_t)draw * blocks_per_draw + bx0) * kWaves + rem) * (int64_t)cap;
+      const int off = has ? list[lbase + (kind ? cap - 1 - pos : pos)] : 0;
+      const int64_t i = (int64_t)(bx0 + rem / kWaves) * tiles_per_block * kTile + off;
       const double tv = t[i];
       const double te = (n_texp == 0) ? 0.0 : (n_texp == 1 ? texp[0] : texp[i]);
       double g = 0.0;
@@ -654,36 +694,9 @@ __global__ __launch_bounds__(kBlock, EXO_HEAVY_MIN_WAVES) void transit_heavy_ker
         }
       }
     }
-    if (GRAD) {
-#pragma unroll
-      for (int s = 0; s < kNG; ++s) {
-        const double v = wave_sum(lds_acc[s][threadIdx.x]);
-        if (lane == 0) sh.red[wave][s] = v;
-      }
-      __syncthreads();
-      if (threadIdx.x < kNG) {
-        double v = 0.0;
-#pragma unroll
-        for (int w2 = 0; w2 < kWaves; ++w2) v += sh.red[w2][threadIdx.x];
-        pout[p * kNG + threadIdx.x] = v;
-      }
-      __syncthreads();
-    }
+    if (GRAD) reduce_columns(lds_acc, sh.red, 0, kNG, pout + p * kNG);
   }
-  if (GRAD) {
-#pragma unroll
-    for (int s = 0; s < 7; ++s) {
-      const double v = wave_sum(lds_acc[kNG + s][threadIdx.x]);
-      if (lane == 0) sh.red[wave][kNG + s] = v;
-    }
-    __syncthreads();
-    if (threadIdx.x < 7) {
-      double v = 0.0;
-#pragma unroll
-      for (int w2 = 0; w2 < kWaves; ++w2) v += sh.red[w2][kNG + threadIdx.x];
-      pout[n_planet * kNG + threadIdx.x] = v;
-    }
-  }
+  if (GRAD) reduce_columns(lds_acc, sh.red, kNG, 7, pout + n_planet * kNG);
 }
 
 // Stage 2: one block per draw; thread s sums slot s over the blocks in order.
@@ -805,6 +818,20 @@ inline void transit_geometry(int64_t n_cad, int64_t n_draw, int* blocks_per_draw
   bpd = (n_tiles + tpb - 1) / tpb;
   *blocks_per_draw = (int)bpd;
   *tiles_per_block = (int)tpb;
+}
+
+// heavy blocks take the lists of `merge` consecutive scan blocks: the per-block costs of the
+// heavy kernel (constant staging, accumulator reduction, a half-empty last round) are paid
+// kHeavyTargetBlocks times rather than kTargetBlocks times, while the scan kernel keeps its finer
+// blocks
+#ifndef EXO_HEAVY_TARGET_BLOCKS
+#define EXO_HEAVY_TARGET_BLOCKS 1024
+#endif
+inline int heavy_merge(int64_t n_draw, int bpd) {
+  int64_t m = (n_draw * bpd + EXO_HEAVY_TARGET_BLOCKS - 1) / EXO_HEAVY_TARGET_BLOCKS;
+  if (m > kMaxMerge) m = kMaxMerge;
+  if (m > bpd) m = bpd;
+  return m < 1 ? 1 : (int)m;
 }
 
 // scratch layout shared by forward and reverse: [gradient partials][wave counts][wave lists]
@@ -960,12 +987,16 @@ int exo_transit_flux_fwd_ev_f64(const double* t, int64_t n_cad, const double* te
   EXO_LAUNCH_SCAN(n_cad, t, flags, sp.grid, block, 0, st, t, n_cad, texp, n_texp, stencil_dt, n_sub, params, n_planet,
                   sp.flags, tpb, bpd, n_draw, sp.n_classify, flux, w.counts, w.list, w.windows);
   if (launch_status() != EXO_OK) return EXO_ERR_LAUNCH;
+  const int merge = heavy_merge(n_draw, bpd);
+  const dim3 hgrid((unsigned)((bpd + merge - 1) / merge), (unsigned)n_draw);
   if (secondary)
-    hipLaunchKernelGGL((transit_heavy_kernel<false, true>), grid, block, 0, st, t, n_cad, texp, n_texp, stencil_dt,
-                       stencil_w, n_sub, params, ld, n_planet, flags, tpb, w.counts, w.list, nullptr, flux, nullptr);
+    hipLaunchKernelGGL((transit_heavy_kernel<false, true>), hgrid, block, 0, st, t, n_cad, texp, n_texp, stencil_dt,
+                       stencil_w, n_sub, params, ld, n_planet, flags, tpb, bpd, merge, w.counts, w.list, nullptr, flux,
+                       nullptr);
   else
-    hipLaunchKernelGGL((transit_heavy_kernel<false, false>), grid, block, 0, st, t, n_cad, texp, n_texp, stencil_dt,
-                       stencil_w, n_sub, params, ld, n_planet, flags, tpb, w.counts, w.list, nullptr, flux, nullptr);
+    hipLaunchKernelGGL((transit_heavy_kernel<false, false>), hgrid, block, 0, st, t, n_cad, texp, n_texp, stencil_dt,
+                       stencil_w, n_sub, params, ld, n_planet, flags, tpb, bpd, merge, w.counts, w.list, nullptr, flux,
+                       nullptr);
   if (ev_stop) (void)hipEventRecord((hipEvent_t)ev_stop, st);
   return launch_status();
 }
@@ -1014,16 +1045,19 @@ int exo_transit_flux_vjp_ev_f64(const double* t, int64_t n_cad, const double* te
   EXO_LAUNCH_SCAN(n_cad, t, flags, sp.grid, block, 0, st, t, n_cad, texp, n_texp, stencil_dt, n_sub, params, n_planet,
                   sp.flags, tpb, bpd, n_draw, sp.n_classify, flux_dst, w.counts, w.list, w.windows);
   if (launch_status() != EXO_OK) return EXO_ERR_LAUNCH;
+  const int merge = heavy_merge(n_draw, bpd);
+  const int nhb = (bpd + merge - 1) / merge;
+  const dim3 hgrid((unsigned)nhb, (unsigned)n_draw);
   if (secondary)
-    hipLaunchKernelGGL((transit_heavy_kernel<true, true>), grid, block, 0, st, t, n_cad, texp, n_texp, stencil_dt,
-                       stencil_w, n_sub, params, ld, n_planet, flags, tpb, w.counts, w.list, gflux, flux_dst,
-                       w.partial);
+    hipLaunchKernelGGL((transit_heavy_kernel<true, true>), hgrid, block, 0, st, t, n_cad, texp, n_texp, stencil_dt,
+                       stencil_w, n_sub, params, ld, n_planet, flags, tpb, bpd, merge, w.counts, w.list, gflux,
+                       flux_dst, w.partial);
   else
-    hipLaunchKernelGGL((transit_heavy_kernel<true, false>), grid, block, 0, st, t, n_cad, texp, n_texp, stencil_dt,
-                       stencil_w, n_sub, params, ld, n_planet, flags, tpb, w.counts, w.list, gflux, flux_dst,
-                       w.partial);
+    hipLaunchKernelGGL((transit_heavy_kernel<true, false>), hgrid, block, 0, st, t, n_cad, texp, n_texp, stencil_dt,
+                       stencil_w, n_sub, params, ld, n_planet, flags, tpb, bpd, merge, w.counts, w.list, gflux,
+                       flux_dst, w.partial);
   if (launch_status() != EXO_OK) return EXO_ERR_LAUNCH;
-  hipLaunchKernelGGL(transit_vjp_reduce_kernel, dim3((unsigned)n_draw), dim3(kBlock), 0, st, w.partial, bpd,
+  hipLaunchKernelGGL(transit_vjp_reduce_kernel, dim3((unsigned)n_draw), dim3(kBlock), 0, st, w.partial, nhb,
                      n_planet, secondary, gparams, gld, flux_dot);
   if (ev_stop) (void)hipEventRecord((hipEvent_t)ev_stop, st);
   return launch_status();
