@@ -340,13 +340,12 @@ __device__ __forceinline__ void zero_fill(double* __restrict__ dst, int64_t n) {
   double2* __restrict__ d2 = reinterpret_cast<double2*>(dst + head);
   const int64_t n2 = (n - head) >> 1;
   int64_t k = threadIdx.x;
-  for (; k + 3 * kBlock < n2; k += 4 * kBlock) {
-    d2[k] = double2{0.0, 0.0};
-    d2[k + kBlock] = double2{0.0, 0.0};
-    d2[k + 2 * kBlock] = double2{0.0, 0.0};
-    d2[k + 3 * kBlock] = double2{0.0, 0.0};
-  }
-  for (; k < n2; k += kBlock) d2[k] = double2{0.0, 0.0};
+  // non-temporal: the zeros are not read again before they reach HBM, and keeping them out of
+  // L2 leaves it to the heavy kernel that follows (measured: scan -21 us, heavy -10 us)
+  typedef double v2d __attribute__((ext_vector_type(2)));
+  v2d* __restrict__ q2 = reinterpret_cast<v2d*>(d2);
+  const v2d z = {0.0, 0.0};
+  for (; k < n2; k += kBlock) __builtin_nontemporal_store(z, q2 + k);
   if (threadIdx.x == 0 && ((n - head) & 1)) dst[n - 1] = 0.0;
 }
 
