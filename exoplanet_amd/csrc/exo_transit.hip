@@ -176,6 +176,25 @@ __device__ __forceinline__ bool in_window(double t, const PlanetConst& c, double
   return in;
 }
 
+// a wave-uniform double pinned to scalar registers
+__device__ __forceinline__ double uniform(double x) {
+  const int lo = __builtin_amdgcn_readfirstlane(__double2loint(x));
+  const int hi = __builtin_amdgcn_readfirstlane(__double2hiint(x));
+  return __hiloint2double(hi, lo);
+}
+
+// The heavy kernel's view of one planet: the constants eval_sample touches, pinned to scalar
+// registers (they are the same for every lane; read from LDS they would sit in ~50 vector
+// registers for the whole block, next to the elliptic-integral code that needs them all).
+struct PlanetS {
+  double n, tp, e, se, pe, sq1me2, isq1me2, cw, sw, ci, si, aor, ror, iror, fr;
+  __device__ __forceinline__ explicit PlanetS(const PlanetConst& c)
+      : n(uniform(c.n)), tp(uniform(c.tp)), e(uniform(c.e)), se(uniform(c.se)), pe(uniform(c.pe)),
+        sq1me2(uniform(c.sq1me2)), isq1me2(uniform(c.isq1me2)), cw(uniform(c.cw)), sw(uniform(c.sw)),
+        ci(uniform(c.ci)), si(uniform(c.si)), aor(uniform(c.aor)), ror(uniform(c.ror)), iror(uniform(c.iror)),
+        fr(uniform(c.fr)) {}
+};
+
 // Gradient accumulators of the heavy kernel live in LDS, one column per thread
 // ([slot][thread]: consecutive threads hit consecutive banks).  They are touched only
 // by samples that overlap the disk, and keeping 17 doubles out of the register file is
@@ -188,7 +207,7 @@ struct GradAcc {
 // One (cadence, sub-exposure, planet) sample.  Returns the flux contribution F
 // and, if GRAD, adds gw * dF/d(theta) into the LDS accumulator columns.
 template <bool GRAD, bool SECONDARY>
-__device__ __forceinline__ double eval_sample(double tt, const PlanetConst& c, const double* cld,
+__device__ __forceinline__ double eval_sample(double tt, const PlanetS& c, const double* cld,
                                               double gw, const GradAcc& acc) {
   const double M = (tt - c.tp) * c.n;
   const exo::KeplerHalf kh = exo::kepler_half(M, c.e, c.se, c.pe);
@@ -364,12 +383,6 @@ __device__ __forceinline__ bool near_conjunction(double t, double nrev, double c
   return cand;
 }
 
-// a wave-uniform double pinned to scalar registers
-__device__ __forceinline__ double uniform(double x) {
-  const int lo = __builtin_amdgcn_readfirstlane(__double2loint(x));
-  const int hi = __builtin_amdgcn_readfirstlane(__double2hiint(x));
-  return __hiloint2double(hi, lo);
-}
 
 constexpr int kScanDraws = 4;  // draws per classify block on the single-planet path
 
@@ -651,8 +664,12 @@ __global__ __launch_bounds__(kBlock, EXO_HEAVY_MIN_WAVES) void transit_heavy_ker
 #pragma unroll
     for (int s = 0; s < kNG + 7; ++s) lds_acc[s][threadIdx.x] = 0.0;
   }
+  // limb-darkening coefficients, scalar registers as well
+  double cld[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) cld[k] = uniform((SECONDARY || k < 3) ? sh.c[k] : 0.0);
   for (int p = 0; p < n_planet; ++p) {
-    const PlanetConst& c = sh.pc[p];
+    const PlanetS c(sh.pc[p]);
     if (GRAD && p > 0) {
 #pragma unroll
       for (int s = 0; s < kNG; ++s) lds_acc[s][threadIdx.x] = 0.0;
@@ -680,7 +697,7 @@ __global__ __launch_bounds__(kBlock, EXO_HEAVY_MIN_WAVES) void transit_heavy_ker
       for (int k = 0; k < n_sub; ++k) {
         const double tt = fma(te, sh.sdt[k], tv);
         const double gw = g * sh.sw[k];
-        const double F = eval_sample<GRAD, SECONDARY>(tt, c, sh.c, gw, acc);
+        const double F = eval_sample<GRAD, SECONDARY>(tt, c, cld, gw, acc);
         f = fma(sh.sw[k], F, f);
         if (GRAD) acc.add(kNG + 6, gw * F);
       }
