@@ -82,13 +82,32 @@ __device__ double mean_anomaly_of(double f, double e, double se, double pe) {
 //                 half_transit, half_occultation }
 // in revolutions of mean anomaly: the phase of cadence t is fma(t, nrev, c0), wrapped to +-1/2.
 // q >= 1 or anything non-finite: halves = inf, every cadence goes on.
+//
+// With EXO_FLAG_WINDOW the caller's contact-point windows (record slots T0, PERIOD, TS, TE[, TS2,
+// TE2]; keplerian.py:729-731,765-769) are put in the same form instead -- revolutions of the
+// orbit, centre t0 + (ts + te)/2, half-width (te - ts)/2 -- and they alone decide what is
+// evaluated.
 __global__ __launch_bounds__(kBlock) void transit_window_kernel(const double* __restrict__ params, int64_t n_rec,
-                                                                double* __restrict__ out) {
+                                                                uint32_t flags, double* __restrict__ out) {
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (i >= n_rec) return;
   const double* p = params + i * EXO_NPAR;
   const double e = p[EXO_P_ECC], cw = p[EXO_P_COSW], sw = p[EXO_P_SINW];
   double* o = out + kWin * i;
+  if (flags & EXO_FLAG_WINDOW) {
+    const double ip = 1.0 / p[EXO_P_PERIOD];
+    const double ts = p[EXO_P_TS], te = p[EXO_P_TE], ts2 = p[EXO_P_TS2], te2 = p[EXO_P_TE2];
+    const bool fin = (fabs(ts) < __builtin_inf()) && (fabs(te) < __builtin_inf());
+    const bool fin2 = (fabs(ts2) < __builtin_inf()) && (fabs(te2) < __builtin_inf());
+    const double mid = fin ? 0.5 * (ts + te) : 0.0, mid2 = fin2 ? 0.5 * (ts2 + te2) : 0.0;
+    o[0] = ip;
+    o[1] = -(p[EXO_P_T0] + mid) * ip;
+    o[2] = (mid - mid2) * ip;
+    // a hair wider than the reference's closed interval: a cadence exactly at a contact has zero flux
+    o[3] = fin ? fma(0.5 * (te - ts) * ip, 1.0 + 1e-12, 1e-14) : __builtin_inf();
+    o[4] = fin2 ? fma(0.5 * (te2 - ts2) * ip, 1.0 + 1e-12, 1e-14) : __builtin_inf();
+    return;
+  }
   const double nrev = p[EXO_P_N] * (0.5 / exo::kPi);
   o[0] = nrev;
   o[1] = -p[EXO_P_TP] * nrev;
@@ -159,21 +178,6 @@ __device__ __forceinline__ void stage_constants(Shared& sh, const double* __rest
     sh.sw[tid - 128] = stencil_w ? stencil_w[tid - 128] : 1.0;
   }
   __syncthreads();
-}
-
-// in-transit window test, keplerian.py:730-731,765-769 (dt wrapped to +-P/2)
-__device__ __forceinline__ bool in_window(double t, const PlanetConst& c, double htexp, bool secondary) {
-  const double hp = 0.5 * c.period;
-  double x = t - c.t0 + hp;
-  x = x - c.period * floor(x * c.iperiod);
-  const double dt = x - hp;
-  bool in = (dt >= c.ts - htexp) && (dt <= c.te + htexp);
-  if (secondary) {
-    double y = t - c.t0;
-    y = y - c.period * floor(y * c.iperiod);  // [0, P)
-    in = in || ((y >= c.ts2 - htexp) && (y <= c.te2 + htexp));
-  }
-  return in;
 }
 
 // a wave-uniform double pinned to scalar registers
@@ -431,7 +435,9 @@ __global__ __launch_bounds__(kBlock) void transit_scan_kernel(
     zero_fill(flux + (draw * n_cad + lo) * npl, ((hi < n_cad ? hi : n_cad) - lo) * npl);
     return;
   }
-  const bool grouped = FAST && (flags & kFlagGrouped);
+  const bool grouped = flags & kFlagGrouped;
+  const bool window = flags & EXO_FLAG_WINDOW;
+  const bool stage1 = FAST || window;
   const int64_t unit = work / blocks_per_draw;  // draw, or group of kScanDraws draws
   const int bx = (int)(work - unit * blocks_per_draw);
   const int64_t draw = grouped ? unit * kScanDraws : unit;
@@ -439,11 +445,11 @@ __global__ __launch_bounds__(kBlock) void transit_scan_kernel(
   // grouped: the nd consecutive single-planet records are staged as if they were nd planets of one draw
   stage_constants(sh, params + (grouped ? draw * EXO_NPAR : 0), nullptr, stencil_dt, nullptr, n_sub,
                   grouped ? nd : n_planet, grouped ? 0 : draw, SECONDARY,
-                  FAST ? windows + (grouped ? kWin * draw : 0) : nullptr);
-  const bool window = flags & EXO_FLAG_WINDOW;
-  // half-span of the exposure stencil: widens the conjunction windows
-  double span = 0.0;
-  if (FAST)
+                  stage1 ? windows + (grouped ? kWin * draw : 0) : nullptr);
+  // the windows are widened by the half-span of the exposure stencil; the reference widens its
+  // contact windows by texp / 2 whatever the stencil (keplerian.py:765-769)
+  double span = window ? 0.5 : 0.0;
+  if (!window)
     for (int k = 0; k < n_sub; ++k) span = fmax(span, fabs(sh.sdt[k]));
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t blk_base = (int64_t)bx * tiles_per_block * kTile;
@@ -502,9 +508,11 @@ __global__ __launch_bounds__(kBlock) void transit_scan_kernel(
 #pragma unroll 1
         for (int v = 0; v < 2; ++v) {
           int kind = 0;
-          if ((cand >> (2 * j + v)) & 1u)
+          if ((cand >> (2 * j + v)) & 1u) {
             for (int k = 0; k < n_sub; ++k)
               kind = max(kind, classify_sample<SECONDARY, FAST>(fma(te, sh.sdt[k], tv[v]), sh.pc[j]));
+            if (window) kind = max(kind, 1);  // the caller's window decides; the classifier only sorts
+          }
           append_active((blk_base + off[v] < n_cad) ? kind : 0, off[v], lst, (int)list_stride, cnt);
         }
         if (lane == 0) s_cnt[wave][j] = cnt;
@@ -552,23 +560,16 @@ __global__ __launch_bounds__(kBlock) void transit_scan_kernel(
       int kind = 0;
       for (int p = 0; p < n_planet; ++p) {
         const PlanetConst& c = sh.pc[p];
-        if (window) {
-          // the caller's windows decide what is evaluated; the classifier only sorts
-          if (in_window(tv[v], c, 0.5 * te, SECONDARY)) {
-            int kw = 1;
-            for (int k = 0; k < n_sub; ++k)
-              kw = max(kw, classify_sample<SECONDARY, FAST>(fma(te, sh.sdt[k], tv[v]), c));
-            kind = max(kind, kw);
-          }
-        } else {
-          bool cand = true;
-          if (FAST) {
-            const double widen = fabs(te) * span * fabs(c.nrev);
-            cand = near_conjunction<SECONDARY>(tv[v], c.nrev, c.c0, c.dmid, c.half[0] + widen, c.half[1] + widen);
-          }
-          if (cand)
-            for (int k = 0; k < n_sub; ++k)
-              kind = max(kind, classify_sample<SECONDARY, FAST>(fma(te, sh.sdt[k], tv[v]), c));
+        bool cand = true;
+        if (stage1) {
+          const double widen = fabs(te) * span * fabs(c.nrev);
+          cand = near_conjunction<SECONDARY>(tv[v], c.nrev, c.c0, c.dmid, c.half[0] + widen, c.half[1] + widen);
+        }
+        if (cand) {
+          int kp = window ? 1 : 0;  // the caller's window decides; the classifier only sorts
+          for (int k = 0; k < n_sub; ++k)
+            kp = max(kp, classify_sample<SECONDARY, FAST>(fma(te, sh.sdt[k], tv[v]), c));
+          kind = max(kind, kp);
         }
       }
       append_active(valid ? kind : 0, off[v], my_list, (int)list_stride, cnt);
@@ -895,14 +896,14 @@ constexpr uint32_t kFlagNoFlux = 0x80000000u;  // internal: scan kernel must not
       EXO_LAUNCH_SCAN_V(false, FLAGS, __VA_ARGS__);                                            \
   } while (0)
 
-// conjunction windows feed the scan kernel's first test; not needed when the caller supplies
-// contact-point windows or asks for the exact fp64 scan
+// the windows of the scan kernel's first test: not needed when the caller asks for the exact
+// fp64 scan of every cadence
 inline void launch_windows(const double* params, int64_t n_draw, int n_planet, uint32_t flags, double* windows,
                            hipStream_t st) {
-  if (flags & (EXO_FLAG_WINDOW | EXO_FLAG_EXACT_SCAN)) return;
+  if ((flags & EXO_FLAG_EXACT_SCAN) && !(flags & EXO_FLAG_WINDOW)) return;
   const int64_t n_rec = n_draw * n_planet;
   hipLaunchKernelGGL(transit_window_kernel, dim3((unsigned)((n_rec + kBlock - 1) / kBlock)), dim3(kBlock), 0, st,
-                     params, n_rec, windows);
+                     params, n_rec, flags, windows);
 }
 
 // scan kernel launch: classify blocks (one per draw and tile run, or one per kScanDraws draws on
@@ -914,7 +915,8 @@ struct ScanPlan {
 };
 inline ScanPlan scan_plan(uint32_t flags, int bpd, int64_t n_draw, int n_planet, int64_t n_texp, bool with_fill) {
   ScanPlan sp;
-  const bool grouped = n_planet == 1 && n_texp <= 1 && !(flags & (EXO_FLAG_WINDOW | EXO_FLAG_EXACT_SCAN));
+  const bool stage1 = (flags & EXO_FLAG_WINDOW) || !(flags & EXO_FLAG_EXACT_SCAN);
+  const bool grouped = n_planet == 1 && n_texp <= 1 && stage1;
   sp.flags = (flags & 0x0fffffffu) | (grouped ? kFlagGrouped : 0u) | (with_fill ? 0u : kFlagNoFlux);
   sp.n_classify = (grouped ? (n_draw + kScanDraws - 1) / kScanDraws : n_draw) * bpd;
   sp.grid = dim3((unsigned)(sp.n_classify + (with_fill ? n_draw * bpd : 0)));

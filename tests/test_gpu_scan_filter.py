@@ -1,5 +1,6 @@
-"""GPU: the scan kernel's conservative fp32 pre-filter never changes a result.
-Default path (fp32 classification, fp64 evaluation of every accepted cadence) ==
+"""GPU: the scan kernel's conservative pre-filters never change a result.
+Default path (conjunction windows in mean anomaly, then fp32 classification, fp64 evaluation
+of every accepted cadence; single-planet batches take the grouped-draws path) ==
 EXO_FLAG_EXACT_SCAN path (fp64 classification) on stress geometries: high
 eccentricity, very large and very small a/R, grazing impact parameters, exposure
 integration, secondary eclipses, long time baselines."""
@@ -34,11 +35,11 @@ def random_records(rng, D, Pn):
 
 @pytest.mark.parametrize("secondary", [False, True])
 @pytest.mark.parametrize("texp", [None, 0.02])
-def test_filter_never_changes_results(dev, secondary, texp):
+@pytest.mark.parametrize("D,Pn", [(24, 3), (53, 1)])   # one planet: classify blocks take four draws each
+def test_filter_never_changes_results(dev, secondary, texp, D, Pn):
     from exoplanet_amd import ops
 
-    rng = np.random.default_rng(17 + secondary)
-    D, Pn = 24, 3
+    rng = np.random.default_rng(17 + secondary + 2 * Pn)
     rec = random_records(rng, D, Pn)
     t = np.sort(np.concatenate([np.linspace(0, 60, 30000), 2000 + np.linspace(0, 20, 10000)]))   # |M| up to 1e4 rad
     c = np.repeat(np.concatenate([P.get_cl(0.3, 0.2), P.get_cl(0.4, 0.1)])[None], D, 0)
