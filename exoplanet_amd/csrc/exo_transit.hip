@@ -723,6 +723,14 @@ __global__ __launch_bounds__(kBlock) void transit_vjp_reduce_kernel(
   const int64_t draw = blockIdx.x;
   const int ng_draw = n_planet * kNG + 7;
   const int s = threadIdx.x;
+  {
+    // record slots that carry no gradient (SINI, T0, PERIOD, the windows) read 0
+    const int p = s / EXO_NPAR, slot = s % EXO_NPAR;
+    const bool carried = slot == EXO_P_N || slot == EXO_P_TP || slot == EXO_P_ECC || slot == EXO_P_COSW ||
+                         slot == EXO_P_SINW || slot == EXO_P_COSI || slot == EXO_P_AOR || slot == EXO_P_ROR ||
+                         slot == EXO_P_FRATIO;
+    if (p < n_planet && !carried) gparams[(draw * n_planet + p) * EXO_NPAR + slot] = 0.0;
+  }
   if (s >= ng_draw) return;
   const double* __restrict__ src = partial + draw * nblk * (int64_t)ng_draw + s;
   double v = 0.0;
@@ -1040,10 +1048,9 @@ int exo_transit_flux_vjp_ev_f64(const double* t, int64_t n_cad, const double* te
     return EXO_ERR_INVALID_ARGUMENT;
   const bool secondary = flags & EXO_FLAG_SECONDARY;
   hipStream_t st = (hipStream_t)stream;
-  // gradient slots that no kernel writes (SINI, T0, PERIOD, windows) must read 0
-  if (hipMemsetAsync(gparams, 0, sizeof(double) * n_draw * n_planet * EXO_NPAR, st) != hipSuccess)
-    return EXO_ERR_LAUNCH;
   if (n_cad == 0) {
+    if (hipMemsetAsync(gparams, 0, sizeof(double) * n_draw * n_planet * EXO_NPAR, st) != hipSuccess)
+      return EXO_ERR_LAUNCH;
     if (flux_dot && hipMemsetAsync(flux_dot, 0, sizeof(double) * n_draw, st) != hipSuccess) return EXO_ERR_LAUNCH;
     return hipMemsetAsync(gld, 0, sizeof(double) * n_draw * (secondary ? 6 : 3), st) == hipSuccess
                ? EXO_OK : EXO_ERR_LAUNCH;

@@ -34,14 +34,30 @@ def _default_device():
     return torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
 
 
+_SCALARS = {}
+
+
+def _scalar(value, dev):
+    """0-dim constant, one per (value, device), never written to.  Made by a fill kernel rather
+    than a host-to-device copy (legal while a hipGraph is capturing); cached so that a replayed
+    step does not spend a launch per Python scalar -- unless the first request comes during a
+    capture, whose allocations belong to the graph."""
+    key = (value, dev)
+    t = _SCALARS.get(key)
+    if t is None:
+        t = torch.full((), value, dtype=torch.float64, device=dev)
+        if not (dev.type == "cuda" and torch.cuda.is_current_stream_capturing()):
+            _SCALARS[key] = t
+    return t
+
+
 def as_tensor(x, like=None):
     """float64 tensor (the reference casts everything to float64, utils.py:18-22)."""
     if isinstance(x, torch.Tensor):
         return x if x.dtype == torch.float64 else x.to(torch.float64)
     dev = like.device if isinstance(like, torch.Tensor) else _default_device()
     if isinstance(x, (int, float)):
-        # a fill kernel rather than a host-to-device copy: legal while a hipGraph is capturing
-        return torch.full((), float(x), dtype=torch.float64, device=dev)
+        return _scalar(float(x), dev)
     return torch.as_tensor(x, dtype=torch.float64, device=dev)
 
 
