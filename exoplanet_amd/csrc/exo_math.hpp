@@ -100,6 +100,26 @@ EXO_HD double fast_sqrt(double x) {
 #endif
 }
 
+// sqrt(x) and 1/sqrt(x) together (x > 0): the coupled iteration carries h ~ 1/(2 sqrt x) anyway,
+// one more step on h costs two operations -- a division by sqrt(x), or by x, costs seven.
+EXO_HD double fast_sqrt_rs(double x, double* rs) {
+#ifdef EXO_HOST_BUILD
+  const double g = sqrt(x);
+  *rs = 1.0 / g;
+  return g;
+#else
+  const double r0 = __builtin_amdgcn_rsq(x);
+  double g = x * r0, h = 0.5 * r0;
+  double e = fma(-h, g, 0.5);
+  g = fma(g, e, g); h = fma(h, e, h);
+  const double d = fma(-g, g, x);
+  g = fma(d, h, g);
+  e = fma(-h, g, 0.5);
+  *rs = 2.0 * fma(h, e, h);
+  return g;
+#endif
+}
+
 // Low-precision building blocks for the fp32 Kepler starter (the starter is only
 // good to ~4e-4 by construction, so single-instruction hardware approximations
 // -- v_rcp_f32, v_sqrt_f32, v_log_f32 / v_exp_f32 -- are ample).
@@ -399,7 +419,8 @@ EXO_HD void quad_sv(double b, double r, SV& o) {
   const double x = fmax(b, r), y = fmin(b, r);
   const double A = ((1.0 - x) + y) * (1.0 + (x - y));
   const double Bm = ((x - 1.0) + y) * ((x + y) + 1.0);
-  const double sqA = fast_sqrt(A);
+  double isqA;
+  const double sqA = fast_sqrt_rs(A, &isqA);  // A > 0 on every active lane
   const double br = b * r;
   const double rmb = r - b;
 
@@ -437,7 +458,7 @@ EXO_HD void quad_sv(double b, double r, SV& o) {
   const bool same = (b == r);
   const double rmb_s = same ? 1.0 : rmb;
   const double irmb = fast_div(1.0, rmb_s);
-  const double iA = fast_div(1.0, A);
+  const double iA = isqA * isqA;
   const double m_in = 4.0 * br * iA;
   const double k2 = inside ? 0.0 : fmin(fast_div(A, 4.0 * br), 1.0);
   const double kc2 = inside ? fmax(-Bm * iA, 0.0) : fmax(1.0 - k2, 0.0);
@@ -453,7 +474,7 @@ EXO_HD void quad_sv(double b, double r, SV& o) {
   if (inside) {
     const double t3 = (2.0 * (2.0 - m_in) * Ek - kc2 * Kk) * (1.0 / 3.0);  // int Delta^3
     J = (2.0 * sqA * (1.0 / 3.0)) * (A * t3 - (r2 - b2) * Ek);
-    if (!same) J += fast_div(2.0 * bpr * irmb, 3.0 * sqA) * c3.P;
+    if (!same) J += (2.0 / 3.0) * bpr * irmb * isqA * c3.P;
   } else {
     C2 = c3.B;
     // closed form loses eps/k2^2; switch to the series where that matters

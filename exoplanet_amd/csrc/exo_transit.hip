@@ -232,7 +232,12 @@ __device__ __forceinline__ double eval_sample(double tt, const PlanetS& c, const
   // NaN parameters must propagate: treat NaN b2 as active
   const bool act = (front || behind) && !(b2 >= lim * lim);
   if (!EXO_WAVE_ANY(act)) return 0.0;
-  const double b = exo::fast_sqrt(b2);
+  double ib;  // 1 / b, for the reverse sweep
+  double b = exo::fast_sqrt_rs(b2, &ib);
+  if (!(b2 > 0.0)) {  // centre of the disk (no direction: zero gradient through b), or NaN
+    b = (b2 == 0.0) ? 0.0 : b2;
+    ib = 0.0;
+  }
   // transit: (b, ror) on the star; occultation: star of radius 1/ror passes in
   // front of the planet, in units of the planet radius (secondary_eclipse.py:56-58)
   const bool occ = SECONDARY && behind;
@@ -273,7 +278,6 @@ __device__ __forceinline__ double eval_sample(double tt, const PlanetS& c, const
         if (SECONDARY) acc.add(G_FR, -gw * Fq * (1.0 / ((1.0 + c.fr) * (1.0 + c.fr))));
       }
       acc.add(G_ROR, rorbar);
-      const double ib = (b > 0.0) ? exo::fast_div(1.0, b) : 0.0;
       const double x1bar = bbar * x1 * ib;
       const double Ysbar = bbar * Ys * ib;
       const double y1bar = Ysbar * c.ci;
