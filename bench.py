@@ -251,13 +251,18 @@ def main():
                         "(value+VJP, one sweep) -> packing VJP kernel -> leaf gradients" + ("; replayed as one hipGraph" if graph is not None else "; eager launches"),
             },
             "roofline": {
-                "bound": "hbm", "kernel": "transit_scan_kernel + transit_heavy_kernel + transit_vjp_reduce_kernel (one sweep)",
+                "bound": "hbm", "kernel": "transit_window_kernel + transit_scan_kernel + transit_heavy_kernel + transit_vjp_reduce_kernel (one sweep)",
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": measured_traffic(D),
                 "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": kernel_ms,
-                "note": "24 B per (draw, cadence) x draws x cadences / mean hipEvent time of the three kernels that "
-                        "make up the one algorithmic sweep (scan classifies + zero-fills, heavy evaluates active "
-                        "cadences, reduce sums block partials); rocprof per-kernel averages: profiles/",
+                "traffic_frac": (measured_traffic(D) / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if measured_traffic(D) else None,
+                "note": "achieved = 24 B per (draw, cadence) x draws x cadences / mean hipEvent time of the launches "
+                        "that make up the one algorithmic sweep (window constants, scan = classify + zero-fill, "
+                        "heavy = active cadences, reduce = block partials).  The algorithmic count charges a gbar "
+                        "read to every cadence; the kernels read it only for the ~3 % that are in transit, so "
+                        "achieved can exceed peak.  traffic = PMC-measured HBM bytes per sweep (profiles/), "
+                        "traffic_frac = traffic / time / peak: the store stream of zeros is what bounds the scan "
+                        "kernel, VALU latency bounds the heavy one.  rocprof per-kernel averages: profiles/",
             },
         }
 
