@@ -23,6 +23,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/exoplanet_amd.h"
 
@@ -191,14 +192,17 @@ __global__ __launch_bounds__(kWave) void celerite_fwd_kernel(
     const double* __restrict__ t, const double* __restrict__ resid, const double* __restrict__ diag,
     int64_t n_diag, int64_t n, const double* __restrict__ coef_real, int n_real,
     const double* __restrict__ coef_complex, int n_complex, int64_t n_draw, double* __restrict__ loglike,
-    double* __restrict__ state) {
+    double* __restrict__ state, const double* __restrict__ only_flagged) {
   constexpr int G = Group<J>::G;
   const int j = threadIdx.x & (G - 1);
   const int64_t lane_draw = ((int64_t)blockIdx.x * kWave + threadIdx.x) / G;
   const bool live_draw = lane_draw < n_draw;
   const int64_t draw = live_draw ? lane_draw : n_draw - 1;
+  // after the time-parallel path: redo only the draws it could not take (see DeltaCoef)
+  const bool mine = live_draw && (!only_flagged || only_flagged[draw] != 0.0);
+  if (only_flagged && __ballot(mine) == 0) return;
   const LaneCoef k = lane_coef(coef_real, n_real, coef_complex, n_complex, draw, j, J);
-  const bool store = SAVE && live_draw && k.live;
+  const bool store = SAVE && mine && k.live;
   // a_n = diag_n + sum of the a coefficients (first index of each term)
   const double asum = group_sum<G>((k.live && !k.odd) ? k.a : 0.0);
   const StateIdx six{n, n_draw, J};
@@ -325,7 +329,7 @@ __global__ __launch_bounds__(kWave) void celerite_fwd_kernel(
     }
    }
   }
-  if (live_draw && j == 0) {
+  if (mine && j == 0) {
     // not positive definite -> -inf in band (a sampler rejects the point)
     const double logdet = log(lman) + (double)lsum * 0.69314718055994530942;
     loglike[draw] = bad ? -INFINITY : fma(-0.5, acc + logdet, -(double)n * kHalfLog2Pi);
@@ -342,12 +346,13 @@ __global__ __launch_bounds__(kWave) void celerite_vjp_kernel(
     const double* __restrict__ coef_real, int n_real, const double* __restrict__ coef_complex, int n_complex,
     int64_t n_draw, const double* __restrict__ gloglike, const double* __restrict__ state,
     double* __restrict__ gresid, double* __restrict__ gdiag, double* __restrict__ gdiag_sum,
-    double* __restrict__ gcoef_real, double* __restrict__ gcoef_complex) {
+    double* __restrict__ gcoef_real, double* __restrict__ gcoef_complex, const double* __restrict__ only_flagged) {
   constexpr int G = Group<J>::G;
   const int j = threadIdx.x & (G - 1);
   const int64_t lane_draw = ((int64_t)blockIdx.x * kWave + threadIdx.x) / G;
-  const bool live_draw = lane_draw < n_draw;
-  const int64_t draw = live_draw ? lane_draw : n_draw - 1;
+  const bool live_draw = (lane_draw < n_draw) && (!only_flagged || only_flagged[lane_draw < n_draw ? lane_draw : 0] != 0.0);
+  if (only_flagged && __ballot(live_draw) == 0) return;
+  const int64_t draw = lane_draw < n_draw ? lane_draw : n_draw - 1;
   const LaneCoef k = lane_coef(coef_real, n_real, coef_complex, n_complex, draw, j, J);
   const int jj = k.live ? j : 0;  // idle lanes read a valid slot and contribute zeros
   const StateIdx six{n, n_draw, J};
@@ -541,6 +546,791 @@ __global__ __launch_bounds__(kWave) void celerite_vjp_kernel(
   }
 }
 
+
+// ===========================================================================
+// Time-parallel path.  The recurrences above are a Kalman filter in disguise: with a
+// symmetric Delta_n such that Delta_n U_n = V_n (the state covariance of the process the kernel
+// describes, in the rotating frame celerite uses),
+//     P_n = Delta_n - S_n   is the covariance of the one-step prediction of the state,
+//     F_n                   is its mean,
+//     d_n = diag_n + U_n^T P_n U_n,  W_n = P_n U_n / d_n,  z_n   the innovation variance, gain, innovation
+// (diag_n = a_n - U_n^T V_n is the measurement variance).  A run of cadences therefore acts on
+// (F, P) as a filtering element (A, b, C, eta, J) of Sarkka & Garcia-Fernandez (2021):
+//     F' = A (I + P J)^-1 (F + P eta) + b,      P' = A (I + P J)^-1 P A^T + C,
+// built by running the filter from (0, 0) next to two sensitivity matrices, and the run's
+// log-likelihood as a function of its entering state has the closed form
+//     const - 1/2 log det(I + P J) + 1/2 eta^T Y P eta + eta^T Y F - 1/2 F^T J Y F,  Y = (I + P J)^-1.
+// So: split the series into C chunks; (A) build every chunk's element in parallel; (B) walk the
+// C elements per draw to get the state ENTERING each chunk; (C) run the ordinary recurrences inside
+// every chunk in parallel from that state.  The reverse pass needs the adjoint of the entering
+// state of every chunk, and the chain rule across chunks only needs the same elements:
+//     Fbar  += Y^T (eta - J F) gL + Abar^T Fbar',            Abar = A Y
+//     Pbar  += 1/2 (w w^T - J Y) gL + Abar^T Pbar' Abar + sym(Abar^T Fbar' g^T),   g = eta - J Y (F + P eta)
+// (B'), after which the ordinary reverse recurrence runs inside every chunk in parallel (C').
+// Nothing is differentiated through (A), (B): they only supply boundary values of quantities the
+// sequential algorithm also has, so the parameter cotangents are still summed by the ordinary
+// reverse recurrence.  Work is ~2x the sequential algorithm's, spread over C x more lanes.
+//
+// Delta: a real term (a, c): 1 / a.  A complex pair (a, b, c, d) with (cs, sn) = (cos d t, sin d t):
+// H Delta0 H, H = [[cs, sn], [sn, -cs]], Delta0 = [[p, q], [q, r]], r = a / (a^2 + b^2),
+// q = -b / (a^2 + b^2), p = (a^2 + 2 b^2) / (a (a^2 + b^2)) -- the member of the family
+// Delta0 (a, b)^T = (1, 0)^T for which the process noise Delta_{n+1} - phi^2 Delta_n is positive
+// semi-definite exactly when the term is a valid kernel (|b d| <= a c).  Draws with a term outside
+// a > 0, |b d| <= a c are flagged and handled by the sequential kernels.
+// ===========================================================================
+
+struct ChunkGeom {
+  int C;        // chunks
+  int64_t L;    // cadences per chunk (the last may be shorter)
+  int64_t base; // first double of the chunk workspace inside `state`
+};
+
+// chunk workspace, all [chunk][quantity][draw] (a lane is a draw: coalesced)
+struct ChunkWs {
+  int64_t n_draw;
+  int J, C;
+  int64_t base;
+  __host__ __device__ int E() const { return 3 * J * J + 2 * J; }   // A, b, Cm, eta, Jm
+  __host__ __device__ int B() const { return J + J * J; }           // vector + matrix
+  __host__ __device__ int64_t elem(int c, int e, int64_t draw) const { return base + ((int64_t)c * E() + e) * n_draw + draw; }
+  __host__ __device__ int64_t off_bnd() const { return base + (int64_t)C * E() * n_draw; }
+  // q = 0: (F, S) entering chunk c;  1: (F, P) entering chunk c;  2: adjoint of (F, S) entering chunk c + 1
+  __host__ __device__ int64_t bnd(int q, int c, int k, int64_t draw) const {
+    return off_bnd() + (((int64_t)q * C + c) * B() + k) * n_draw + draw;
+  }
+  __host__ __device__ int64_t off_part() const { return off_bnd() + (int64_t)3 * C * B() * n_draw; }
+  __host__ __device__ int64_t part(int c, int k, int64_t draw) const {  // k = 0 acc, 1 logdet, 2 bad
+    return off_part() + ((int64_t)c * 3 + k) * n_draw + draw;
+  }
+  __host__ __device__ int64_t off_gpart() const { return off_part() + (int64_t)3 * C * n_draw; }
+  __host__ __device__ int64_t gpart(int c, int k, int64_t draw) const {  // k = 4 j + {a, b, c, d}; 4 J = gasum
+    return off_gpart() + ((int64_t)c * (4 * J + 1) + k) * n_draw + draw;
+  }
+  __host__ __device__ int64_t off_flag() const { return off_gpart() + (int64_t)C * (4 * J + 1) * n_draw; }
+  __host__ __device__ int64_t total() const { return off_flag() + n_draw - base; }
+};
+
+constexpr int kChunkMaxJ = 6;   // the element kernel keeps three J x J matrices in registers
+
+inline ChunkGeom chunk_plan(int64_t n, int64_t n_draw, int J) {
+  ChunkGeom g{1, n, 0};
+  if (J > kChunkMaxJ) return g;
+  int64_t C;
+  const char* env = getenv("EXO_GP_CHUNKS");
+  if (env && *env) {
+    C = atoll(env);
+  } else {
+    const int G = J <= 1 ? 1 : (J <= 2 ? 2 : (J <= 4 ? 4 : 8));
+    C = (64 * 2048) / (n_draw * G);   // ~2 waves per SIMD
+    if (C > 512) C = 512;
+    if (C < 4) C = 1;
+  }
+  if (C > n / 32) C = n / 32;        // chunks of at least 32 cadences
+  if (C < 2) return g;
+  g.L = (n + C - 1) / C;
+  g.C = (int)((n + g.L - 1) / g.L);
+  if (g.C < 2) { g.C = 1; g.L = n; }
+  return g;
+}
+
+// symmetric J x J in packed upper-triangular storage
+template <int J>
+struct Sym {
+  double v[J * (J + 1) / 2];
+  __device__ __forceinline__ static constexpr int idx(int j, int l) {
+    return j <= l ? j * J - j * (j - 1) / 2 + (l - j) : l * J - l * (l - 1) / 2 + (j - l);
+  }
+  __device__ __forceinline__ double& operator()(int j, int l) { return v[idx(j, l)]; }
+  __device__ __forceinline__ double operator()(int j, int l) const { return v[idx(j, l)]; }
+};
+
+// Delta_n of one draw from its term coefficients and V_n (block diagonal: 1x1 / 2x2 blocks)
+template <int J>
+struct DeltaCoef {
+  double p[J], q[J], r[J];   // per state index: real term -> p = 1/a; pair -> (p, q, r) on both indices
+  bool real[J];
+  bool valid;
+  __device__ void init(const double* __restrict__ coef_real, int n_real, const double* __restrict__ coef_complex,
+                       int n_complex, int64_t draw) {
+    valid = true;
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      if (j < n_real) {
+        const double a = coef_real[(draw * n_real + j) * 2], c = coef_real[(draw * n_real + j) * 2 + 1];
+        real[j] = true;
+        p[j] = 1.0 / a; q[j] = 0.0; r[j] = 0.0;
+        valid = valid && (a > 0.0) && (c >= 0.0) && (a < INFINITY) && (c < INFINITY);
+      } else {
+        const double* k = coef_complex + (draw * n_complex + ((j - n_real) >> 1)) * 4;
+        const double a = k[0], b = k[1], c = k[2], d = k[3];
+        const double h = 1.0 / (a * a + b * b);
+        real[j] = false;
+        r[j] = a * h; q[j] = -b * h; p[j] = (a * a + 2.0 * b * b) * h / a;
+        valid = valid && (a > 0.0) && (fabs(b * d) <= a * c * (1.0 + 1e-12)) && (a < INFINITY) && (fabs(b) < INFINITY) &&
+                (c < INFINITY) && (fabs(d) < INFINITY);
+      }
+    }
+  }
+  // Delta (packed) from V (cos / sin of each pair)
+  __device__ __forceinline__ void eval(const double* V, int n_real, Sym<J>& D) const {
+#pragma unroll
+    for (int k = 0; k < J * (J + 1) / 2; ++k) D.v[k] = 0.0;
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      if (real[j]) {
+        D(j, j) = p[j];
+      } else if (((j - n_real) & 1) == 0 && j + 1 < J) {
+        const double cs = V[j], sn = V[j + 1];
+        D(j, j) = p[j] * cs * cs + 2.0 * q[j] * cs * sn + r[j] * sn * sn;
+        D(j, j + 1) = (p[j] - r[j]) * cs * sn + q[j] * (sn * sn - cs * cs);
+        D(j + 1, j + 1) = p[j] * sn * sn - 2.0 * q[j] * cs * sn + r[j] * cs * cs;
+      }
+    }
+  }
+};
+
+// (A) the filtering element of every (draw, chunk): one lane each
+template <int J>
+__global__ __launch_bounds__(kWave) void celerite_elem_kernel(
+    const double* __restrict__ resid, const double* __restrict__ diag, int64_t n_diag, int64_t n,
+    const double* __restrict__ coef_real, int n_real, const double* __restrict__ coef_complex, int n_complex,
+    int64_t n_draw, double* __restrict__ state, ChunkGeom cg) {
+  const int64_t draw = (int64_t)blockIdx.x * kWave + threadIdx.x;
+  if (draw >= n_draw) return;
+  const int c = blockIdx.y;
+  const int64_t n0 = c * cg.L, n1 = (n0 + cg.L < n) ? n0 + cg.L : n;
+  const StateIdx six{n, n_draw, J};
+  const ChunkWs ws{n_draw, J, cg.C, cg.base};
+  DeltaCoef<J> dc;
+  dc.init(coef_real, n_real, coef_complex, n_complex, draw);
+  const double* __restrict__ y = resid + draw * n;
+  const double* __restrict__ dg = diag + (n_diag == 1 ? 0 : draw * n);
+  double A[J][J], b[J], eta[J];
+  Sym<J> Cm, Jm, Dl;
+#pragma unroll
+  for (int j = 0; j < J; ++j) {
+    b[j] = eta[j] = 0.0;
+#pragma unroll
+    for (int l = 0; l < J; ++l) A[j][l] = (j == l) ? 1.0 : 0.0;
+  }
+#pragma unroll
+  for (int k = 0; k < J * (J + 1) / 2; ++k) Cm.v[k] = Jm.v[k] = 0.0;
+  double U[J], V[J];
+#pragma unroll
+  for (int j = 0; j < J; ++j) { U[j] = state[six.uvp(0, n0, draw, j)]; V[j] = state[six.uvp(1, n0, draw, j)]; }
+  dc.eval(V, n_real, Dl);
+#pragma unroll 1
+  for (int64_t i = n0; i < n1; ++i) {
+    const double yi = y[i], R = dg[i];
+    double r[J], cu[J];
+    double s = R, zeta = yi;
+#pragma unroll
+    for (int l = 0; l < J; ++l) {
+      double rl = 0.0, cl = 0.0;
+#pragma unroll
+      for (int j = 0; j < J; ++j) { rl = fma(A[j][l], U[j], rl); cl = fma(Cm(l, j), U[j], cl); }
+      r[l] = rl; cu[l] = cl;
+      s = fma(U[l], cl, s);
+      zeta = fma(-U[l], b[l], zeta);
+    }
+    const double is = 1.0 / s;
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      eta[j] = fma(r[j] * is, zeta, eta[j]);
+#pragma unroll
+      for (int l = j; l < J; ++l) Jm(j, l) = fma(r[j] * is, r[l], Jm(j, l));
+    }
+    if (i + 1 < n) {
+      double phi[J], Vn[J];
+#pragma unroll
+      for (int j = 0; j < J; ++j) {
+        phi[j] = state[six.uvp(2, i + 1, draw, j)];
+        U[j] = state[six.uvp(0, i + 1, draw, j)];
+        Vn[j] = state[six.uvp(1, i + 1, draw, j)];
+      }
+      Sym<J> Dn;
+      dc.eval(Vn, n_real, Dn);
+#pragma unroll
+      for (int j = 0; j < J; ++j) {
+        const double kj = cu[j] * is;
+        b[j] = phi[j] * fma(kj, zeta, b[j]);
+#pragma unroll
+        for (int l = 0; l < J; ++l) A[j][l] = phi[j] * fma(-kj, r[l], A[j][l]);
+#pragma unroll
+        for (int l = j; l < J; ++l)
+          Cm(j, l) = fma(phi[j] * phi[l], fma(-kj, cu[l], Cm(j, l)) - Dl(j, l), Dn(j, l));  // + Q = Dn - phi phi Dl
+      }
+      Dl = Dn;
+    }
+  }
+  int e = 0;
+#pragma unroll
+  for (int j = 0; j < J; ++j)
+#pragma unroll
+    for (int l = 0; l < J; ++l) state[ws.elem(c, e++, draw)] = A[j][l];
+#pragma unroll
+  for (int j = 0; j < J; ++j) state[ws.elem(c, e++, draw)] = b[j];
+#pragma unroll
+  for (int j = 0; j < J; ++j)
+#pragma unroll
+    for (int l = 0; l < J; ++l) state[ws.elem(c, e++, draw)] = Cm(j, l);
+#pragma unroll
+  for (int j = 0; j < J; ++j) state[ws.elem(c, e++, draw)] = eta[j];
+#pragma unroll
+  for (int j = 0; j < J; ++j)
+#pragma unroll
+    for (int l = 0; l < J; ++l) state[ws.elem(c, e++, draw)] = Jm(j, l);
+}
+
+// solve X Z = B (J x J, NB right-hand sides) in place by Gaussian elimination with partial pivoting
+template <int J, int NB>
+__device__ __forceinline__ void solve_inplace(double (&X)[J][J], double (&B)[J][NB]) {
+#pragma unroll
+  for (int k = 0; k < J; ++k) {
+    int piv = k;
+    double best = fabs(X[k][k]);
+#pragma unroll
+    for (int i = k + 1; i < J; ++i) {
+      const bool better = fabs(X[i][k]) > best;
+      best = better ? fabs(X[i][k]) : best;
+      piv = better ? i : piv;
+    }
+#pragma unroll
+    for (int i = k + 1; i < J; ++i) {
+      if (i == piv) {   // swap rows k and i (selects: piv is a run-time value)
+#pragma unroll
+        for (int l = 0; l < J; ++l) { const double tmp = X[k][l]; X[k][l] = X[i][l]; X[i][l] = tmp; }
+#pragma unroll
+        for (int l = 0; l < NB; ++l) { const double tmp = B[k][l]; B[k][l] = B[i][l]; B[i][l] = tmp; }
+      }
+    }
+    const double ip = 1.0 / X[k][k];
+#pragma unroll
+    for (int i = k + 1; i < J; ++i) {
+      const double f = X[i][k] * ip;
+#pragma unroll
+      for (int l = k + 1; l < J; ++l) X[i][l] = fma(-f, X[k][l], X[i][l]);
+#pragma unroll
+      for (int l = 0; l < NB; ++l) B[i][l] = fma(-f, B[k][l], B[i][l]);
+    }
+  }
+#pragma unroll
+  for (int k = J - 1; k >= 0; --k) {
+    const double ip = 1.0 / X[k][k];
+#pragma unroll
+    for (int l = 0; l < NB; ++l) {
+      double v = B[k][l];
+#pragma unroll
+      for (int i = k + 1; i < J; ++i) v = fma(-X[k][i], B[i][l], v);
+      B[k][l] = v * ip;
+    }
+  }
+}
+
+template <int J>
+struct Elem {
+  double A[J][J], b[J], Cm[J][J], eta[J], Jm[J][J];
+  __device__ void load(const double* __restrict__ state, const ChunkWs& ws, int c, int64_t draw) {
+    int e = 0;
+#pragma unroll
+    for (int j = 0; j < J; ++j)
+#pragma unroll
+      for (int l = 0; l < J; ++l) A[j][l] = state[ws.elem(c, e++, draw)];
+#pragma unroll
+    for (int j = 0; j < J; ++j) b[j] = state[ws.elem(c, e++, draw)];
+#pragma unroll
+    for (int j = 0; j < J; ++j)
+#pragma unroll
+      for (int l = 0; l < J; ++l) Cm[j][l] = state[ws.elem(c, e++, draw)];
+#pragma unroll
+    for (int j = 0; j < J; ++j) eta[j] = state[ws.elem(c, e++, draw)];
+#pragma unroll
+    for (int j = 0; j < J; ++j)
+#pragma unroll
+      for (int l = 0; l < J; ++l) Jm[j][l] = state[ws.elem(c, e++, draw)];
+  }
+};
+
+// (B) the state entering every chunk: one lane per draw, C - 1 element applications
+template <int J>
+__global__ __launch_bounds__(kWave) void celerite_bscan_kernel(const double* __restrict__ coef_real, int n_real,
+                                                               const double* __restrict__ coef_complex, int n_complex,
+                                                               int64_t n, int64_t n_draw, double* __restrict__ state,
+                                                               ChunkGeom cg) {
+  const int64_t draw = (int64_t)blockIdx.x * kWave + threadIdx.x;
+  if (draw >= n_draw) return;
+  const StateIdx six{n, n_draw, J};
+  const ChunkWs ws{n_draw, J, cg.C, cg.base};
+  DeltaCoef<J> dc;
+  dc.init(coef_real, n_real, coef_complex, n_complex, draw);
+  state[ws.off_flag() + draw] = dc.valid ? 0.0 : 1.0;
+  double m[J], P[J][J];
+#pragma unroll
+  for (int j = 0; j < J; ++j) m[j] = 0.0;
+#pragma unroll 1
+  for (int c = 0; c < cg.C; ++c) {
+    const int64_t n0 = c * cg.L;
+    double V[J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) V[j] = state[six.uvp(1, n0, draw, j)];
+    Sym<J> Dl;
+    dc.eval(V, n_real, Dl);
+    if (c == 0) {
+#pragma unroll
+      for (int j = 0; j < J; ++j)
+#pragma unroll
+        for (int l = 0; l < J; ++l) P[j][l] = Dl(j, l);   // S_0 = 0
+    }
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      state[ws.bnd(0, c, j, draw)] = m[j];
+      state[ws.bnd(1, c, j, draw)] = m[j];
+#pragma unroll
+      for (int l = 0; l < J; ++l) {
+        state[ws.bnd(0, c, J + j * J + l, draw)] = Dl(j, l) - P[j][l];
+        state[ws.bnd(1, c, J + j * J + l, draw)] = P[j][l];
+      }
+    }
+    if (c + 1 == cg.C) break;
+    Elem<J> el;
+    el.load(state, ws, c, draw);
+    // X = I + P Jm ;  solve X [YP | ym] = [P | m + P eta]
+    double X[J][J], Bm[J][J + 1];
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      double pe = m[j];
+#pragma unroll
+      for (int l = 0; l < J; ++l) {
+        double x = (j == l) ? 1.0 : 0.0;
+#pragma unroll
+        for (int k = 0; k < J; ++k) x = fma(P[j][k], el.Jm[k][l], x);
+        X[j][l] = x;
+        Bm[j][l] = P[j][l];
+        pe = fma(P[j][l], el.eta[l], pe);
+      }
+      Bm[j][J] = pe;
+    }
+    solve_inplace<J, J + 1>(X, Bm);
+    // m' = A ym + b ;  P' = A (YP) A^T + Cm  (symmetrised)
+    double AY[J][J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      double mj = el.b[j];
+#pragma unroll
+      for (int l = 0; l < J; ++l) {
+        mj = fma(el.A[j][l], Bm[l][J], mj);
+        double v = 0.0;
+#pragma unroll
+        for (int k = 0; k < J; ++k) v = fma(el.A[j][k], Bm[k][l], v);
+        AY[j][l] = v;   // A (YP)
+      }
+      m[j] = mj;
+    }
+#pragma unroll
+    for (int j = 0; j < J; ++j)
+#pragma unroll
+      for (int l = 0; l < J; ++l) {
+        double v = el.Cm[j][l];
+#pragma unroll
+        for (int k = 0; k < J; ++k) v = fma(AY[j][k], el.A[l][k], v);
+        X[j][l] = v;
+      }
+#pragma unroll
+    for (int j = 0; j < J; ++j)
+#pragma unroll
+      for (int l = 0; l < J; ++l) P[j][l] = 0.5 * (X[j][l] + X[l][j]);
+  }
+}
+
+// (B') the adjoint of the state entering every chunk, last to first: one lane per draw
+template <int J>
+__global__ __launch_bounds__(kWave) void celerite_bscan_vjp_kernel(const double* __restrict__ gloglike, int64_t n_draw,
+                                                                   double* __restrict__ state, ChunkGeom cg) {
+  const int64_t draw = (int64_t)blockIdx.x * kWave + threadIdx.x;
+  if (draw >= n_draw) return;
+  const ChunkWs ws{n_draw, J, cg.C, cg.base};
+  const double gL = gloglike[draw];
+  double mb[J], Pb[J][J];   // adjoint of (F, P) entering chunk c + 1
+#pragma unroll
+  for (int j = 0; j < J; ++j) {
+    mb[j] = 0.0;
+#pragma unroll
+    for (int l = 0; l < J; ++l) Pb[j][l] = 0.0;
+  }
+#pragma unroll 1
+  for (int c = cg.C - 1; c >= 0; --c) {
+    // what chunk c's reverse recurrence starts from: adjoint of (F, S) entering chunk c + 1; Sbar = -Pbar
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      state[ws.bnd(2, c, j, draw)] = mb[j];
+#pragma unroll
+      for (int l = 0; l < J; ++l) state[ws.bnd(2, c, J + j * J + l, draw)] = -Pb[j][l];
+    }
+    if (c == 0) break;
+    Elem<J> el;
+    el.load(state, ws, c, draw);
+    double m[J], P[J][J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      m[j] = state[ws.bnd(1, c, j, draw)];
+#pragma unroll
+      for (int l = 0; l < J; ++l) P[j][l] = state[ws.bnd(1, c, J + j * J + l, draw)];
+    }
+    // Y = (I + P Jm)^-1
+    double X[J][J], Y[J][J];
+#pragma unroll
+    for (int j = 0; j < J; ++j)
+#pragma unroll
+      for (int l = 0; l < J; ++l) {
+        double x = (j == l) ? 1.0 : 0.0;
+#pragma unroll
+        for (int k = 0; k < J; ++k) x = fma(P[j][k], el.Jm[k][l], x);
+        X[j][l] = x;
+        Y[j][l] = (j == l) ? 1.0 : 0.0;
+      }
+    solve_inplace<J, J>(X, Y);
+    // w = Y^T (eta - Jm m) ;  v = m + P eta ;  g = eta - Jm Y v ;  JY = Jm Y ;  Ab = A Y
+    double u[J], v[J], w[J], Yv[J], g[J], JY[J][J], Ab[J][J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      double uj = el.eta[j], vj = m[j];
+#pragma unroll
+      for (int l = 0; l < J; ++l) { uj = fma(-el.Jm[j][l], m[l], uj); vj = fma(P[j][l], el.eta[l], vj); }
+      u[j] = uj; v[j] = vj;
+    }
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      double wj = 0.0, yv = 0.0;
+#pragma unroll
+      for (int l = 0; l < J; ++l) { wj = fma(Y[l][j], u[l], wj); yv = fma(Y[j][l], v[l], yv); }
+      w[j] = wj; Yv[j] = yv;
+    }
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      double gj = el.eta[j];
+#pragma unroll
+      for (int l = 0; l < J; ++l) {
+        gj = fma(-el.Jm[j][l], Yv[l], gj);
+        double a = 0.0, jy = 0.0;
+#pragma unroll
+        for (int k = 0; k < J; ++k) { a = fma(el.A[j][k], Y[k][l], a); jy = fma(el.Jm[j][k], Y[k][l], jy); }
+        Ab[j][l] = a; JY[j][l] = jy;
+      }
+      g[j] = gj;
+    }
+    // x = Ab^T mb' ;  T = Pb' Ab
+    double x[J], T[J][J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      double xj = 0.0;
+#pragma unroll
+      for (int l = 0; l < J; ++l) {
+        xj = fma(Ab[l][j], mb[l], xj);
+        double tv = 0.0;
+#pragma unroll
+        for (int k = 0; k < J; ++k) tv = fma(Pb[j][k], Ab[k][l], tv);
+        T[j][l] = tv;
+      }
+      x[j] = xj;
+    }
+    double mbn[J], Pbn[J][J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      mbn[j] = fma(gL, w[j], x[j]);
+#pragma unroll
+      for (int l = 0; l < J; ++l) {
+        double cong = 0.0;
+#pragma unroll
+        for (int k = 0; k < J; ++k) cong = fma(Ab[k][j], T[k][l], cong);
+        Pbn[j][l] = 0.5 * gL * (w[j] * w[l] - 0.5 * (JY[j][l] + JY[l][j])) + cong + 0.5 * (x[j] * g[l] + g[j] * x[l]);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      mb[j] = mbn[j];
+#pragma unroll
+      for (int l = 0; l < J; ++l) Pb[j][l] = 0.5 * (Pbn[j][l] + Pbn[l][j]);
+    }
+  }
+}
+
+// (C) the ordinary recurrences inside every chunk, from the entering state: same lane layout as
+// celerite_fwd_kernel (a draw on G lanes), one wave per (64 / G draws, chunk).  With C x more
+// waves than the sequential kernel the loads are hidden by occupancy: no prefetch ring.
+template <int J>
+__global__ __launch_bounds__(kWave) void celerite_chunk_fwd_kernel(
+    const double* __restrict__ resid, const double* __restrict__ diag, int64_t n_diag, int64_t n,
+    const double* __restrict__ coef_real, int n_real, const double* __restrict__ coef_complex, int n_complex,
+    int64_t n_draw, double* __restrict__ state, ChunkGeom cg) {
+  constexpr int G = Group<J>::G;
+  const int j = threadIdx.x & (G - 1);
+  const int64_t lane_draw = ((int64_t)blockIdx.x * kWave + threadIdx.x) / G;
+  const bool live_draw = lane_draw < n_draw;
+  const int64_t draw = live_draw ? lane_draw : n_draw - 1;
+  const int c = blockIdx.y;
+  const int64_t n0 = c * cg.L, n1 = (n0 + cg.L < n) ? n0 + cg.L : n;
+  const LaneCoef k = lane_coef(coef_real, n_real, coef_complex, n_complex, draw, j, J);
+  const bool store = live_draw && k.live;
+  const double asum = group_sum<G>((k.live && !k.odd) ? k.a : 0.0);
+  const StateIdx six{n, n_draw, J};
+  const ChunkWs ws{n_draw, J, cg.C, cg.base};
+  const double* __restrict__ y = resid + draw * n;
+  const double* __restrict__ dg = diag + (n_diag == 1 ? 0 : draw * n);
+  const int jj = k.live ? j : 0;
+
+  double Srow[J], Wall[J], Uall[J], Pall[J];
+#pragma unroll
+  for (int l = 0; l < J; ++l) { Srow[l] = k.live ? state[ws.bnd(0, c, J + jj * J + l, draw)] : 0.0; Wall[l] = 0.0; }
+  double Fj = k.live ? state[ws.bnd(0, c, jj, draw)] : 0.0;
+  double Wj = 0.0, d = 1.0, z = 0.0;
+  bool bad = false;
+  double acc = 0.0, lman = 1.0;
+  int64_t lsum = 0;
+  const int64_t vstride = n_draw * J, qstride = n * vstride;
+  const double* __restrict__ p_uvp = state + six.uvp(0, n0, draw, jj);
+  double* __restrict__ p_vec = state + six.vec(0, n0, draw, jj);
+  double* __restrict__ p_scal = state + six.scal(0, n0, draw);
+#pragma unroll 1
+  for (int64_t i = n0; i < n1; ++i) {
+    const double Uj = k.live ? p_uvp[0] : 0.0;
+    const double Vj = k.live ? p_uvp[qstride] : 0.0;
+    const double Pj = k.live ? p_uvp[2 * qstride] : 0.0;
+    const double yi = y[i], gi = dg[i];
+    if (i > n0) {
+#pragma unroll
+      for (int l = 0; l < J; ++l) Pall[l] = group_get<G>(Pj, l);
+      Fj = Pj * fma(Wj, z, Fj);
+      const double dwj = d * Wj;
+#pragma unroll
+      for (int l = 0; l < J; ++l) Srow[l] = Pj * Pall[l] * fma(dwj, Wall[l], Srow[l]);
+    }
+#pragma unroll
+    for (int l = 0; l < J; ++l) Uall[l] = group_get<G>(Uj, l);
+    double uj = 0.0;
+#pragma unroll
+    for (int l = 0; l < J; ++l) uj = fma(Srow[l], Uall[l], uj);
+    const double pd = group_sum<G>(Uj * uj), pz = group_sum<G>(Uj * Fj);
+    d = gi + asum - pd;
+    z = yi - pz;
+    bad = bad || !(d > 0.0);
+    const double id = 1.0 / d;
+    Wj = (Vj - uj) * id;
+#pragma unroll
+    for (int l = 0; l < J; ++l) Wall[l] = group_get<G>(Wj, l);
+    acc = fma(z * z, id, acc);
+    int lexp;
+    lman = frexp(lman * (d > 0.0 ? d : 1.0), &lexp);
+    lsum += lexp;
+    if (store) {
+      if (j == 0) { p_scal[0] = d; p_scal[n * n_draw] = z; }
+      p_vec[0] = Wj;
+      p_vec[qstride] = Fj;
+#pragma unroll
+      for (int l = 0; l < J; ++l) p_vec[(2 + l) * qstride] = Srow[l];
+    }
+    p_uvp += vstride; p_vec += vstride; p_scal += n_draw;
+  }
+  if (live_draw && j == 0) {
+    state[ws.part(c, 0, draw)] = acc;
+    state[ws.part(c, 1, draw)] = log(lman) + (double)lsum * 0.69314718055994530942;
+    state[ws.part(c, 2, draw)] = bad ? 1.0 : 0.0;
+  }
+}
+
+// per-draw sum of the chunk partials, in chunk order
+__global__ __launch_bounds__(kWave) void celerite_chunk_loglike_kernel(int64_t n, int64_t n_draw, int J,
+                                                                       const double* __restrict__ state, ChunkGeom cg,
+                                                                       double* __restrict__ loglike) {
+  const int64_t draw = (int64_t)blockIdx.x * kWave + threadIdx.x;
+  if (draw >= n_draw) return;
+  const ChunkWs ws{n_draw, J, cg.C, cg.base};
+  double acc = 0.0, logdet = 0.0, bad = 0.0;
+  for (int c = 0; c < cg.C; ++c) {
+    acc += state[ws.part(c, 0, draw)];
+    logdet += state[ws.part(c, 1, draw)];
+    bad += state[ws.part(c, 2, draw)];
+  }
+  loglike[draw] = (bad > 0.0) ? -INFINITY : fma(-0.5, acc + logdet, -(double)n * kHalfLog2Pi);
+}
+
+// (C') the ordinary reverse recurrence inside every chunk.  It starts from the adjoint of the state
+// entering the NEXT chunk (from (B')) with the reverse of the propagation step into that chunk, and
+// ends with the measurement half of the chunk's first cadence.
+template <int J>
+__global__ __launch_bounds__(kWave) void celerite_chunk_vjp_kernel(
+    const double* __restrict__ t, int64_t n, const double* __restrict__ coef_real, int n_real,
+    const double* __restrict__ coef_complex, int n_complex, int64_t n_draw, const double* __restrict__ gloglike,
+    double* __restrict__ state, ChunkGeom cg, double* __restrict__ gresid, double* __restrict__ gdiag) {
+  constexpr int G = Group<J>::G;
+  const int j = threadIdx.x & (G - 1);
+  const int64_t lane_draw = ((int64_t)blockIdx.x * kWave + threadIdx.x) / G;
+  const bool live_draw = lane_draw < n_draw;
+  const int64_t draw = live_draw ? lane_draw : n_draw - 1;
+  const int c = blockIdx.y;
+  const int64_t n0 = c * cg.L, n1 = (n0 + cg.L < n) ? n0 + cg.L : n;
+  const LaneCoef k = lane_coef(coef_real, n_real, coef_complex, n_complex, draw, j, J);
+  const int jj = k.live ? j : 0;
+  const StateIdx six{n, n_draw, J};
+  const ChunkWs ws{n_draw, J, cg.C, cg.base};
+  const double gL = gloglike[draw];
+  const bool lead = live_draw && j == 0;
+  const int partner = (int)threadIdx.x + ((k.live && !k.real) ? (k.odd ? -1 : 1) : 0);
+  const int jp = k.live ? (partner - ((int)threadIdx.x - j)) : 0;
+
+  double Sb[J];
+#pragma unroll
+  for (int l = 0; l < J; ++l) Sb[l] = k.live ? state[ws.bnd(2, c, J + jj * J + l, draw)] : 0.0;
+  double Fb = k.live ? state[ws.bnd(2, c, jj, draw)] : 0.0;
+  double Wb = 0.0, db = 0.0, zb = 0.0, gasum = 0.0;
+  double ga = 0.0, gb = 0.0, gc = 0.0, gd = 0.0;
+
+  const int64_t vstride = n_draw * J, qstride = n * vstride;
+  const double* __restrict__ sc0 = state + six.scal(0, 0, draw);
+  const double* __restrict__ ve0 = state + six.vec(0, 0, draw, jj);
+  const double* __restrict__ uv0 = state + six.uvp(0, 0, draw, jj);
+  auto load = [&](int64_t i, double& d_, double& z_, double& W_, double& F_, double* S_) {
+    const double* ps = sc0 + i * n_draw;
+    const double* pv = ve0 + i * vstride;
+    d_ = ps[0];
+    z_ = ps[n * n_draw];
+    W_ = k.live ? pv[0] : 0.0;
+    F_ = k.live ? pv[qstride] : 0.0;
+#pragma unroll
+    for (int l = 0; l < J; ++l) S_[l] = k.live ? pv[(2 + l) * qstride] : 0.0;
+  };
+  // reverse of the step (i - 1) -> i :  F_i = P o (F_p + W_p z_p),  S_i = P P^T o (S_p + d_p W_p W_p^T);
+  // on entry Sb, Fb are the adjoints of S_i, F_i; on exit those of S_{i-1}, F_{i-1}, and Wb, db, zb
+  // those of W_{i-1}, d_{i-1}, z_{i-1}
+  auto propagate_adjoint = [&](int64_t i, double d_p, double z_p, double W_p, double F_p, const double* S_p) {
+    const double Pj = k.live ? uv0[i * vstride + 2 * qstride] : 0.0;
+    const double dt = t[i] - t[i - 1];
+    double Pall[J], Wpall[J];
+#pragma unroll
+    for (int l = 0; l < J; ++l) { Pall[l] = group_get<G>(Pj, l); Wpall[l] = group_get<G>(W_p, l); }
+    const double Gj = fma(W_p, z_p, F_p);
+    double Pb = Fb * Gj;
+    const double Gb = Fb * Pj;
+    double Wb_prev = Gb * z_p;
+    const double zb_prev = group_sum<G>(Gb * W_p);
+    double psum = 0.0, wsum = 0.0, dsum = 0.0;
+#pragma unroll
+    for (int l = 0; l < J; ++l) {
+      const double T = fma(d_p * W_p, Wpall[l], S_p[l]);
+      const double Tb = Sb[l] * Pj * Pall[l];
+      psum = fma(2.0 * Sb[l] * T, Pall[l], psum);
+      wsum = fma(2.0 * Tb, Wpall[l], wsum);
+      dsum = fma(Tb, Wpall[l], dsum);
+      Sb[l] = Tb;
+    }
+    Pb += psum;
+    Wb_prev = fma(d_p, wsum, Wb_prev);
+    const double db_prev = group_sum<G>(dsum * W_p);
+    gc = fma(-dt * Pj, Pb, gc);
+    db = db_prev; zb = zb_prev; Fb = Gb; Wb = Wb_prev;
+  };
+
+  double d_n, z_n, W_n, F_n, S_n[J];
+  load(n1 - 1, d_n, z_n, W_n, F_n, S_n);
+  if (n1 < n) propagate_adjoint(n1, d_n, z_n, W_n, F_n, S_n);
+#pragma unroll 1
+  for (int64_t i = n1 - 1; i >= n0; --i) {
+    // measurement half of cadence i
+    const double* pu = uv0 + i * vstride;
+    const double Uj = k.live ? pu[0] : 0.0;
+    const double Vj = k.live ? pu[qstride] : 0.0;
+    const double Vo = k.live ? pu[qstride + (jp - jj)] : 0.0;
+    const double ti = t[i];
+    const double cs = k.odd ? Vo : Vj, sn = k.odd ? Vj : Vo;
+    double Uall[J];
+#pragma unroll
+    for (int l = 0; l < J; ++l) Uall[l] = group_get<G>(Uj, l);
+    const double id = 1.0 / d_n;
+    const double zbar = zb - gL * z_n * id;
+    const double wdot = group_sum<G>(Wb * W_n);
+    const double dbar = db + gL * (0.5 * z_n * z_n * id * id - 0.5 * id) - wdot * id;
+    if (lead) {
+      gresid[draw * n + i] = zbar;
+      if (gdiag) gdiag[draw * n + i] = dbar;
+    }
+    gasum += dbar;
+    double Ub = -zbar * F_n;
+    Fb = fma(-zbar, Uj, Fb);
+    const double Vb = Wb * id;
+    double uj = 0.0;
+#pragma unroll
+    for (int l = 0; l < J; ++l) uj = fma(S_n[l], Uall[l], uj);
+    Ub = fma(-dbar, uj, Ub);
+    const double ubj = -Vb - dbar * Uj;
+    double uball[J];
+#pragma unroll
+    for (int l = 0; l < J; ++l) uball[l] = group_get<G>(ubj, l);
+    double acc_u = 0.0;
+#pragma unroll
+    for (int l = 0; l < J; ++l) {
+      Sb[l] = fma(0.5, fma(ubj, Uall[l], uball[l] * Uj), Sb[l]);
+      acc_u = fma(S_n[l], uball[l], acc_u);
+    }
+    Ub += acc_u;
+    if (k.live && k.real) ga += Ub;
+    {
+      const double Ub_o = __shfl(Ub, partner, 64), Vb_o = __shfl(Vb, partner, 64);
+      if (k.live && !k.real && !k.odd) {
+        ga += Ub * cs + Ub_o * sn;
+        gb += Ub * sn - Ub_o * cs;
+        gd += ti * (Ub * (-k.a * sn + k.b * cs) + Ub_o * (k.a * cs + k.b * sn) - Vb * sn + Vb_o * cs);
+      }
+    }
+    if (i == n0) break;
+    // reverse of the step (i - 1) -> i
+    double d_p, z_p, W_p, F_p, S_p[J];
+    load(i - 1, d_p, z_p, W_p, F_p, S_p);
+    propagate_adjoint(i, d_p, z_p, W_p, F_p, S_p);
+    d_n = d_p; z_n = z_p; W_n = W_p; F_n = F_p;
+#pragma unroll
+    for (int l = 0; l < J; ++l) S_n[l] = S_p[l];
+  }
+  if (live_draw && k.live) {
+    state[ws.gpart(c, 4 * j + 0, draw)] = ga;
+    state[ws.gpart(c, 4 * j + 1, draw)] = gb;
+    state[ws.gpart(c, 4 * j + 2, draw)] = gc;
+    state[ws.gpart(c, 4 * j + 3, draw)] = gd;
+    if (j == 0) state[ws.gpart(c, 4 * J, draw)] = gasum;
+  }
+}
+
+// coefficient cotangents: per (draw, state index) sum of the chunk partials in chunk order, then the
+// same combination as the tail of celerite_vjp_kernel
+__global__ __launch_bounds__(kWave) void celerite_chunk_gcoef_kernel(int64_t n_draw, int n_real, int n_complex,
+                                                                     const double* __restrict__ state, ChunkGeom cg,
+                                                                     double* __restrict__ gdiag_sum,
+                                                                     double* __restrict__ gcoef_real,
+                                                                     double* __restrict__ gcoef_complex) {
+  const int J = n_real + 2 * n_complex;
+  const int64_t e = (int64_t)blockIdx.x * kWave + threadIdx.x;
+  if (e >= n_draw * J) return;
+  const int64_t draw = e / J;
+  const int j = (int)(e - draw * J);
+  const ChunkWs ws{n_draw, J, cg.C, cg.base};
+  auto total = [&](int kk) {
+    double v = 0.0;
+    for (int c = 0; c < cg.C; ++c) v += state[ws.gpart(c, kk, draw)];
+    return v;
+  };
+  const double gasum = total(4 * J);
+  if (j == 0 && gdiag_sum) gdiag_sum[draw] = gasum;
+  if (j < n_real) {
+    double* o = gcoef_real + (draw * n_real + j) * 2;
+    o[0] = total(4 * j) + gasum;
+    o[1] = total(4 * j + 2);
+  } else if (((j - n_real) & 1) == 0) {
+    double* o = gcoef_complex + (draw * n_complex + ((j - n_real) >> 1)) * 4;
+    o[0] = total(4 * j) + gasum;
+    o[1] = total(4 * j + 1);
+    o[2] = total(4 * j + 2) + total(4 * (j + 1) + 2);
+    o[3] = total(4 * j + 3);
+  }
+}
+
 inline int launch_status() { return hipGetLastError() == hipSuccess ? EXO_OK : EXO_ERR_LAUNCH; }
 
 inline bool gp_args_ok(int64_t n, int64_t n_diag, int32_t n_real, int32_t n_complex, int64_t n_draw) {
@@ -556,7 +1346,12 @@ extern "C" {
 int64_t exo_celerite_state_doubles(int64_t n, int64_t n_draw, int32_t n_real, int32_t n_complex) {
   const int64_t J = n_real + 2 * (int64_t)n_complex;
   if (n < 0 || n_draw < 0 || J < 1) return -1;
-  return n * n_draw * (2 + 2 * J + J * J + 3 * J);
+  const int64_t base = n * n_draw * (2 + 2 * J + J * J + 3 * J);
+  if (n == 0 || n_draw == 0) return base;
+  const ChunkGeom cg = chunk_plan(n, n_draw, (int)J);
+  if (cg.C <= 1) return base;
+  const ChunkWs ws{n_draw, (int)J, cg.C, base};
+  return base + ws.total();
 }
 
 #define EXO_GP_DISPATCH(J_, CALL) \
@@ -569,6 +1364,17 @@ int64_t exo_celerite_state_doubles(int64_t n, int64_t n_draw, int32_t n_real, in
     case 6: { constexpr int JJ = 6; CALL; } break; \
     case 7: { constexpr int JJ = 7; CALL; } break; \
     case 8: { constexpr int JJ = 8; CALL; } break; \
+    default: return EXO_ERR_INVALID_ARGUMENT;      \
+  }
+
+#define EXO_GP_DISPATCH_SMALL(J_, CALL) \
+  switch (J_) {                         \
+    case 1: { constexpr int JJ = 1; CALL; } break; \
+    case 2: { constexpr int JJ = 2; CALL; } break; \
+    case 3: { constexpr int JJ = 3; CALL; } break; \
+    case 4: { constexpr int JJ = 4; CALL; } break; \
+    case 5: { constexpr int JJ = 5; CALL; } break; \
+    case 6: { constexpr int JJ = 6; CALL; } break; \
     default: return EXO_ERR_INVALID_ARGUMENT;      \
   }
 
@@ -591,12 +1397,32 @@ int exo_celerite_loglike_fwd_f64(const double* t, const double* resid, const dou
     hipLaunchKernelGGL(celerite_prep_kernel, dim3((unsigned)((n_el + 255) / 256)), dim3(256), 0, st, t, n, coef_real,
                        n_real, coef_complex, n_complex, n_draw, J, state);
     if (launch_status() != EXO_OK) return EXO_ERR_LAUNCH;
+    ChunkGeom cg = chunk_plan(n, n_draw, J);
+    cg.base = n * n_draw * (int64_t)(2 + 2 * J + J * J + 3 * J);
+    const double* only_flagged = nullptr;
+    if (cg.C > 1) {
+      // time-parallel path: elements, entering states, recurrences per chunk, sum of the partials
+      const ChunkWs ws{n_draw, J, cg.C, cg.base};
+      const dim3 per_draw((unsigned)((n_draw + kWave - 1) / kWave));
+      const dim3 egrid(per_draw.x, (unsigned)cg.C), cgrid(grid.x, (unsigned)cg.C);
+      EXO_GP_DISPATCH_SMALL(J, hipLaunchKernelGGL((celerite_elem_kernel<JJ>), egrid, block, 0, st, resid, diag, n_diag,
+                                                  n, coef_real, n_real, coef_complex, n_complex, n_draw, state, cg))
+      EXO_GP_DISPATCH_SMALL(J, hipLaunchKernelGGL((celerite_bscan_kernel<JJ>), per_draw, block, 0, st, coef_real, n_real,
+                                                  coef_complex, n_complex, n, n_draw, state, cg))
+      EXO_GP_DISPATCH_SMALL(J, hipLaunchKernelGGL((celerite_chunk_fwd_kernel<JJ>), cgrid, block, 0, st, resid, diag,
+                                                  n_diag, n, coef_real, n_real, coef_complex, n_complex, n_draw, state,
+                                                  cg))
+      hipLaunchKernelGGL(celerite_chunk_loglike_kernel, per_draw, block, 0, st, n, n_draw, J, state, cg, loglike);
+      if (launch_status() != EXO_OK) return EXO_ERR_LAUNCH;
+      only_flagged = state + ws.off_flag();
+    }
     EXO_GP_DISPATCH(J, hipLaunchKernelGGL((celerite_fwd_kernel<JJ, true>), grid, block, 0, st, t, resid, diag, n_diag,
-                                          n, coef_real, n_real, coef_complex, n_complex, n_draw, loglike, state))
+                                          n, coef_real, n_real, coef_complex, n_complex, n_draw, loglike, state,
+                                          only_flagged))
   } else {
     EXO_GP_DISPATCH(J, hipLaunchKernelGGL((celerite_fwd_kernel<JJ, false>), grid, block, 0, st, t, resid, diag,
                                           n_diag, n, coef_real, n_real, coef_complex, n_complex, n_draw, loglike,
-                                          state))
+                                          state, (const double*)nullptr))
   }
   return launch_status();
 }
@@ -615,9 +1441,26 @@ int exo_celerite_loglike_vjp_f64(const double* t, const double* diag, int64_t n_
   const int64_t per_wave = kWave / G;
   const dim3 grid((unsigned)((n_draw + per_wave - 1) / per_wave)), block(kWave);
   hipStream_t st = (hipStream_t)stream;
+  ChunkGeom cg = chunk_plan(n, n_draw, J);
+  cg.base = n * n_draw * (int64_t)(2 + 2 * J + J * J + 3 * J);
+  const double* only_flagged = nullptr;
+  if (cg.C > 1) {
+    double* wstate = const_cast<double*>(state);   // the chunk workspace lives behind the saved factorisation
+    const ChunkWs ws{n_draw, J, cg.C, cg.base};
+    const dim3 per_draw((unsigned)((n_draw + kWave - 1) / kWave)), cgrid(grid.x, (unsigned)cg.C);
+    EXO_GP_DISPATCH_SMALL(J, hipLaunchKernelGGL((celerite_bscan_vjp_kernel<JJ>), per_draw, block, 0, st, gloglike,
+                                                n_draw, wstate, cg))
+    EXO_GP_DISPATCH_SMALL(J, hipLaunchKernelGGL((celerite_chunk_vjp_kernel<JJ>), cgrid, block, 0, st, t, n, coef_real,
+                                                n_real, coef_complex, n_complex, n_draw, gloglike, wstate, cg, gresid,
+                                                gdiag))
+    hipLaunchKernelGGL(celerite_chunk_gcoef_kernel, dim3((unsigned)((n_draw * J + kWave - 1) / kWave)), block, 0, st,
+                       n_draw, n_real, n_complex, state, cg, gdiag_sum, gcoef_real, gcoef_complex);
+    if (launch_status() != EXO_OK) return EXO_ERR_LAUNCH;
+    only_flagged = state + ws.off_flag();
+  }
   EXO_GP_DISPATCH(J, hipLaunchKernelGGL((celerite_vjp_kernel<JJ>), grid, block, 0, st, t, diag, n_diag, n, coef_real,
                                         n_real, coef_complex, n_complex, n_draw, gloglike, state, gresid, gdiag,
-                                        gdiag_sum, gcoef_real, gcoef_complex))
+                                        gdiag_sum, gcoef_real, gcoef_complex, only_flagged))
   return launch_status();
 }
 

@@ -44,7 +44,15 @@ def test_abi_version_and_host_side_helpers(lib):
     # pure host arithmetic: scratch sizes
     assert lib.exo_transit_flux_workspace_bytes(150000, 256, 1) > 0
     assert lib.exo_transit_flux_workspace_bytes(-1, 1, 1) == -1
-    assert lib.exo_celerite_state_doubles(100, 3, 0, 1) == 100 * 3 * (2 + 4 + 4 + 6)
+    # saved factorisation (+ the chunk workspace of the time-parallel path, when it is taken)
+    base = 100 * 3 * (2 + 4 + 4 + 6)
+    assert lib.exo_celerite_state_doubles(100, 3, 0, 1) >= base
+    import os
+    os.environ["EXO_GP_CHUNKS"] = "0"
+    try:
+        assert lib.exo_celerite_state_doubles(100, 3, 0, 1) == base
+    finally:
+        del os.environ["EXO_GP_CHUNKS"]
     assert lib.exo_celerite_state_doubles(100, 3, 0, 0) == -1
 
 
