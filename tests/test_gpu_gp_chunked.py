@@ -1,0 +1,150 @@
+"""GPU: the time-parallel celerite path (chunk elements + per-draw scan over chunks + ordinary
+recurrences per chunk) against the sequential kernels and the dense oracle.
+
+EXO_GP_CHUNKS (read by the library at call time) forces the number of chunks; 0 = sequential."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import numpy_port as P
+from test_gpu_gp import KERNELS, T, _pack
+
+pytestmark = pytest.mark.gpu
+
+
+class chunks:
+    def __init__(self, c):
+        self.c = c
+
+    def __enter__(self):
+        self.old = os.environ.get("EXO_GP_CHUNKS")
+        if self.c is None:
+            os.environ.pop("EXO_GP_CHUNKS", None)
+        else:
+            os.environ["EXO_GP_CHUNKS"] = str(self.c)
+
+    def __exit__(self, *a):
+        if self.old is None:
+            os.environ.pop("EXO_GP_CHUNKS", None)
+        else:
+            os.environ["EXO_GP_CHUNKS"] = self.old
+
+
+def value_and_grads(dev, t, y, diag, cr, cc):
+    from exoplanet_amd.gp import celerite_loglike
+
+    tt, yt, dt = T(t, dev), T(y, dev, True), T(diag, dev, True)
+    crt, cct = T(cr, dev, True), T(cc, dev, True)
+    ll = celerite_loglike(tt, yt, dt, crt, cct)
+    w = torch.linspace(0.5, 1.5, ll.numel(), dtype=torch.float64, device=ll.device)   # non-trivial cotangent
+    (ll * w).sum().backward()
+    return [x.detach().cpu().numpy() for x in (ll, yt.grad, dt.grad, crt.grad, cct.grad)]
+
+
+def batch(rng, names, D):
+    """D draws: every draw gets the same term structure (KERNELS[name]) with jittered coefficients"""
+    co0 = KERNELS[names]()
+    cr0, cc0 = _pack(co0)
+    cr = cr0 * (1 + 0.05 * rng.normal(size=(D,) + cr0.shape[1:]))
+    cc = cc0 * (1 + 0.02 * rng.normal(size=(D,) + cc0.shape[1:]))
+    if cc.shape[1]:
+        # keep every complex term a valid kernel after the jitter: |b d| <= a c
+        a, b, c, d = (cc[..., k] for k in range(4))
+        cc[..., 1] = np.sign(b) * np.minimum(np.abs(b), 0.999 * a * c / np.abs(d))
+    return cr, cc
+
+
+@pytest.mark.parametrize("name", ["sho_q3", "real1", "mixed_j5", "three_sho_j6"])
+@pytest.mark.parametrize("C", [2, 7, 33])
+def test_chunked_equals_sequential(dev, name, C):
+    rng = np.random.default_rng(11)
+    N, D = 1500, 9
+    t = np.sort(rng.uniform(0, 60, N))
+    y = 0.4 * rng.normal(size=(D, N))
+    diag = 0.05 + 0.05 * rng.uniform(size=(D, N))          # per-draw measurement variance
+    cr, cc = batch(rng, name, D)
+    with chunks(0):
+        want = value_and_grads(dev, t, y, diag, cr, cc)
+    with chunks(C):
+        got = value_and_grads(dev, t, y, diag, cr, cc)
+    np.testing.assert_allclose(got[0], want[0], rtol=1e-12)
+    for g, w in zip(got[1:], want[1:]):
+        if w.size:
+            assert np.abs(g - w).max() / (np.abs(w).max() + 1e-300) < 2e-9
+
+
+def test_chunked_vs_dense_oracle_default_plan(dev):
+    """the library's own chunk plan, a ragged last chunk, against the dense definition"""
+    rng = np.random.default_rng(12)
+    N = 777
+    t = np.sort(rng.uniform(0, 30, N))
+    y = 0.5 * rng.normal(size=N)
+    diag = 0.1 + 0.05 * rng.uniform(size=N)
+    co = KERNELS["mixed_j5"]()
+    want, g = P.gp_loglike_dense(t, y, diag, co)
+    cr, cc = _pack(co)
+    with chunks(None):
+        from exoplanet_amd.gp import celerite_loglike
+        tt, yt, dt = T(t, dev), T(y[None], dev, True), T(diag[None], dev, True)
+        crt, cct = T(cr, dev, True), T(cc, dev, True)
+        ll = celerite_loglike(tt, yt, dt, crt, cct)
+        ll.sum().backward()
+    assert abs(ll.item() - want) < 1e-10 * abs(want)
+    np.testing.assert_allclose(yt.grad.cpu().numpy()[0], g["y"], rtol=1e-8, atol=1e-9)
+    np.testing.assert_allclose(dt.grad.cpu().numpy()[0], g["diag"], rtol=1e-8, atol=1e-9)
+    np.testing.assert_allclose(crt.grad.cpu().numpy()[0][:, 0], g["ar"], rtol=1e-7, atol=1e-8)
+    np.testing.assert_allclose(cct.grad.cpu().numpy()[0][:, 3], g["dc"], rtol=1e-7, atol=1e-8)
+
+
+def test_draws_outside_the_filter_form_fall_back(dev):
+    """A real term with a negative amplitude (valid only as part of the sum) has no positive state
+    covariance: such draws are flagged on the device and redone by the sequential kernels, next to
+    draws of the same batch that take the time-parallel path."""
+    rng = np.random.default_rng(13)
+    N, D = 900, 70                      # more than one wave of draws
+    t = np.sort(rng.uniform(0, 50, N))
+    y = 0.3 * rng.normal(size=(D, N))
+    diag = np.full((1, N), 0.02)
+    cr = np.zeros((D, 2, 2))
+    cc = np.zeros((D, 0, 4))
+    neg = rng.uniform(size=D) < 0.3
+    assert neg.any() and (~neg).any()
+    for d in range(D):
+        s = 0.5 * (1 + 0.1 * rng.normal())
+        cr[d, 0] = [s, 0.5]
+        cr[d, 1] = [(-0.1 if neg[d] else 0.3) * s, 2.0]    # k = s e^{-0.5 tau} - 0.1 s e^{-2 tau} is still a kernel
+    with chunks(0):
+        want = value_and_grads(dev, t, y, diag, cr, cc)
+    with chunks(None):
+        got = value_and_grads(dev, t, y, diag, cr, cc)
+    np.testing.assert_allclose(got[0], want[0], rtol=1e-12)
+    for g, w in zip(got[1:4], want[1:4]):
+        assert np.abs(g - w).max() / (np.abs(w).max() + 1e-300) < 2e-9
+    # the flagged draws were computed by the very same kernels: bit-identical
+    np.testing.assert_array_equal(got[0][neg], want[0][neg])
+    # and one of each kind against the dense definition
+    for d in (int(np.flatnonzero(neg)[0]), int(np.flatnonzero(~neg)[0])):
+        co = (cr[d, :, 0], cr[d, :, 1]) + (np.zeros(0),) * 4
+        ref, _ = P.gp_loglike_dense(t, y[d], diag[0], co)
+        assert abs(got[0][d] - ref) < 1e-10 * abs(ref)
+
+
+def test_not_positive_definite_is_minus_inf_on_both_paths(dev):
+    from exoplanet_amd.gp import celerite_loglike
+
+    N = 600
+    t = np.linspace(0, 10, N)
+    y = np.zeros((2, N))
+    diag = np.full((1, N), -5.0)        # a_n = diag + sum a < 0
+    cr = np.tile(np.array([[[0.3, 0.2]]]), (2, 1, 1))
+    cc = np.zeros((2, 0, 4))
+    for c in (0, 5):
+        with chunks(c):
+            ll = celerite_loglike(T(t, dev), T(y, dev), T(diag, dev), T(cr, dev), T(cc, dev))
+            # forward-only calls save no state and stay sequential; ask for gradients to take the chunked path
+            yt = T(y, dev, True)
+            ll2 = celerite_loglike(T(t, dev), yt, T(diag, dev), T(cr, dev), T(cc, dev))
+        assert torch.isinf(ll).all() and (ll < 0).all()
+        assert torch.isinf(ll2).all() and (ll2 < 0).all()
