@@ -183,7 +183,18 @@ int exo_transit_flux_vjp_ev_f64(const double* t, int64_t n_cad, const double* te
  *   loglike      [n_draw]          out; -inf if the matrix is not positive definite
  *   state        NULL (value only) or exo_celerite_state_doubles() doubles: the
  *                factorisation (d, z; W, F and the rows of S per state index) the reverse
- *                pass re-reads, laid out [quantity][cadence][draw (x state index)]
+ *                pass re-reads, laid out [quantity][cadence][draw (x state index)],
+ *                followed by the workspace of the time-parallel path
+ *
+ * With a state buffer, J <= 6 and n >= 64 the recurrences run in parallel over TIME
+ * (DESIGN.md 3.5): the series is cut into chunks, chunk "filtering elements" and a short
+ * per-draw scan over them give the recurrence state entering every chunk (and, in the
+ * reverse pass, its adjoint), and the ordinary recurrences then run inside all chunks at
+ * once.  Same results as the sequential recurrences (1e-14 relative in loglike); draws whose
+ * terms do not admit the filter form (a <= 0 or |b d| > a c for some term) are redone by the
+ * sequential kernels on the device.  The environment variable EXO_GP_CHUNKS, read at call
+ * time (also by exo_celerite_state_doubles: call it under the same setting), forces the
+ * number of chunks; 0 keeps everything sequential.
  * ------------------------------------------------------------------------- */
 #define EXO_GP_MAX_J 8
 int64_t exo_celerite_state_doubles(int64_t n, int64_t n_draw, int32_t n_real, int32_t n_complex);
