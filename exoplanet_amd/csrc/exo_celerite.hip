@@ -689,10 +689,72 @@ struct DeltaCoef {
   }
 };
 
+// U_n, V_n for all J state indices of one draw (one sincos per complex pair); same arithmetic as
+// lane_uv, so the values are those the pre-pass would have stored
+template <int J>
+struct DrawCoef {
+  LaneCoef k[J];
+  __device__ void init(const double* __restrict__ coef_real, int n_real, const double* __restrict__ coef_complex,
+                       int n_complex, int64_t draw) {
+#pragma unroll
+    for (int j = 0; j < J; ++j) k[j] = lane_coef(coef_real, n_real, coef_complex, n_complex, draw, j, J);
+  }
+  __device__ __forceinline__ void uv(double t, double* U, double* V) const {
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      if (k[j].real) {
+        U[j] = k[j].a; V[j] = 1.0;
+      } else if (!k[j].odd) {
+        double sn, cs;
+        sincos(k[j].d * t, &sn, &cs);
+        U[j] = k[j].a * cs + k[j].b * sn; V[j] = cs;
+        if (j + 1 < J) { U[j + 1] = k[j].a * sn - k[j].b * cs; V[j + 1] = sn; }
+      }
+    }
+  }
+};
+
+// which draws the time-parallel path cannot take (DeltaCoef::valid): 1.0 = redo sequentially
+template <int J>
+__global__ __launch_bounds__(kWave) void celerite_flag_kernel(const double* __restrict__ coef_real, int n_real,
+                                                              const double* __restrict__ coef_complex, int n_complex,
+                                                              int64_t n_draw, double* __restrict__ flag) {
+  const int64_t draw = (int64_t)blockIdx.x * kWave + threadIdx.x;
+  if (draw >= n_draw) return;
+  DeltaCoef<J> dc;
+  dc.init(coef_real, n_real, coef_complex, n_complex, draw);
+  flag[draw] = dc.valid ? 0.0 : 1.0;
+}
+
+// pre-pass for the flagged draws only (the sequential kernels read U, V, P from `state`; the
+// time-parallel kernels recompute them: three fewer arrays across HBM four times)
+__global__ __launch_bounds__(256) void celerite_prep_flagged_kernel(const double* __restrict__ t, int64_t n,
+                                                                    const double* __restrict__ coef_real, int n_real,
+                                                                    const double* __restrict__ coef_complex,
+                                                                    int n_complex, int64_t n_draw, int J,
+                                                                    double* __restrict__ state,
+                                                                    const double* __restrict__ flag) {
+  const int64_t draw = blockIdx.y;
+  if (flag[draw] == 0.0) return;
+  const StateIdx six{n, n_draw, J};
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n * J; e += (int64_t)gridDim.x * 256) {
+    const int64_t i = e / J;
+    const int j = (int)(e - i * J);
+    const LaneCoef k = lane_coef(coef_real, n_real, coef_complex, n_complex, draw, j, J);
+    double U, V, cs, sn;
+    const double ti = t[i];
+    lane_uv(k, ti, &U, &V, &cs, &sn);
+    state[six.uvp(0, i, draw, j)] = U;
+    state[six.uvp(1, i, draw, j)] = V;
+    state[six.uvp(2, i, draw, j)] = i > 0 ? exp(-k.c * (ti - t[i - 1])) : 1.0;
+  }
+}
+
 // (A) the filtering element of every (draw, chunk): one lane each
 template <int J>
 __global__ __launch_bounds__(kWave) void celerite_elem_kernel(
-    const double* __restrict__ resid, const double* __restrict__ diag, int64_t n_diag, int64_t n,
+    const double* __restrict__ t, const double* __restrict__ resid, const double* __restrict__ diag, int64_t n_diag,
+    int64_t n,
     const double* __restrict__ coef_real, int n_real, const double* __restrict__ coef_complex, int n_complex,
     int64_t n_draw, double* __restrict__ state, ChunkGeom cg) {
   const int64_t draw = (int64_t)blockIdx.x * kWave + threadIdx.x;
@@ -703,6 +765,8 @@ __global__ __launch_bounds__(kWave) void celerite_elem_kernel(
   const ChunkWs ws{n_draw, J, cg.C, cg.base};
   DeltaCoef<J> dc;
   dc.init(coef_real, n_real, coef_complex, n_complex, draw);
+  DrawCoef<J> co;
+  co.init(coef_real, n_real, coef_complex, n_complex, draw);
   const double* __restrict__ y = resid + draw * n;
   const double* __restrict__ dg = diag + (n_diag == 1 ? 0 : draw * n);
   double A[J][J], b[J], eta[J];
@@ -715,9 +779,9 @@ __global__ __launch_bounds__(kWave) void celerite_elem_kernel(
   }
 #pragma unroll
   for (int k = 0; k < J * (J + 1) / 2; ++k) Cm.v[k] = Jm.v[k] = 0.0;
-  double U[J], V[J];
-#pragma unroll
-  for (int j = 0; j < J; ++j) { U[j] = state[six.uvp(0, n0, draw, j)]; V[j] = state[six.uvp(1, n0, draw, j)]; }
+  double U[J], V[J], phi[J];
+  double ti = t[n0], dt_prev = -1.0;
+  co.uv(ti, U, V);
   dc.eval(V, n_real, Dl);
 #pragma unroll 1
   for (int64_t i = n0; i < n1; ++i) {
@@ -741,13 +805,15 @@ __global__ __launch_bounds__(kWave) void celerite_elem_kernel(
       for (int l = j; l < J; ++l) Jm(j, l) = fma(r[j] * is, r[l], Jm(j, l));
     }
     if (i + 1 < n) {
-      double phi[J], Vn[J];
+      double Vn[J];
+      const double tn = t[i + 1], dt = tn - ti;
+      ti = tn;
+      if (dt != dt_prev) {   // evenly sampled series reuse the propagators
 #pragma unroll
-      for (int j = 0; j < J; ++j) {
-        phi[j] = state[six.uvp(2, i + 1, draw, j)];
-        U[j] = state[six.uvp(0, i + 1, draw, j)];
-        Vn[j] = state[six.uvp(1, i + 1, draw, j)];
+        for (int j = 0; j < J; ++j) phi[j] = exp(-co.k[j].c * dt);
+        dt_prev = dt;
       }
+      co.uv(tn, U, Vn);
       Sym<J> Dn;
       dc.eval(Vn, n_real, Dn);
 #pragma unroll
@@ -853,26 +919,26 @@ struct Elem {
 
 // (B) the state entering every chunk: one lane per draw, C - 1 element applications
 template <int J>
-__global__ __launch_bounds__(kWave) void celerite_bscan_kernel(const double* __restrict__ coef_real, int n_real,
+__global__ __launch_bounds__(kWave) void celerite_bscan_kernel(const double* __restrict__ t,
+                                                               const double* __restrict__ coef_real, int n_real,
                                                                const double* __restrict__ coef_complex, int n_complex,
                                                                int64_t n, int64_t n_draw, double* __restrict__ state,
                                                                ChunkGeom cg) {
   const int64_t draw = (int64_t)blockIdx.x * kWave + threadIdx.x;
   if (draw >= n_draw) return;
-  const StateIdx six{n, n_draw, J};
   const ChunkWs ws{n_draw, J, cg.C, cg.base};
   DeltaCoef<J> dc;
   dc.init(coef_real, n_real, coef_complex, n_complex, draw);
-  state[ws.off_flag() + draw] = dc.valid ? 0.0 : 1.0;
+  DrawCoef<J> co;
+  co.init(coef_real, n_real, coef_complex, n_complex, draw);
   double m[J], P[J][J];
 #pragma unroll
   for (int j = 0; j < J; ++j) m[j] = 0.0;
 #pragma unroll 1
   for (int c = 0; c < cg.C; ++c) {
     const int64_t n0 = c * cg.L;
-    double V[J];
-#pragma unroll
-    for (int j = 0; j < J; ++j) V[j] = state[six.uvp(1, n0, draw, j)];
+    double U[J], V[J];
+    co.uv(t[n0], U, V);
     Sym<J> Dl;
     dc.eval(V, n_real, Dl);
     if (c == 0) {
@@ -1059,7 +1125,8 @@ __global__ __launch_bounds__(kWave) void celerite_bscan_vjp_kernel(const double*
 // waves than the sequential kernel the loads are hidden by occupancy: no prefetch ring.
 template <int J>
 __global__ __launch_bounds__(kWave) void celerite_chunk_fwd_kernel(
-    const double* __restrict__ resid, const double* __restrict__ diag, int64_t n_diag, int64_t n,
+    const double* __restrict__ t, const double* __restrict__ resid, const double* __restrict__ diag, int64_t n_diag,
+    int64_t n,
     const double* __restrict__ coef_real, int n_real, const double* __restrict__ coef_complex, int n_complex,
     int64_t n_draw, double* __restrict__ state, ChunkGeom cg) {
   constexpr int G = Group<J>::G;
@@ -1087,14 +1154,20 @@ __global__ __launch_bounds__(kWave) void celerite_chunk_fwd_kernel(
   double acc = 0.0, lman = 1.0;
   int64_t lsum = 0;
   const int64_t vstride = n_draw * J, qstride = n * vstride;
-  const double* __restrict__ p_uvp = state + six.uvp(0, n0, draw, jj);
   double* __restrict__ p_vec = state + six.vec(0, n0, draw, jj);
   double* __restrict__ p_scal = state + six.scal(0, n0, draw);
+  double tprev = t[n0 > 0 ? n0 - 1 : 0], dt_prev = -1.0, Pj = 1.0;
 #pragma unroll 1
   for (int64_t i = n0; i < n1; ++i) {
-    const double Uj = k.live ? p_uvp[0] : 0.0;
-    const double Vj = k.live ? p_uvp[qstride] : 0.0;
-    const double Pj = k.live ? p_uvp[2 * qstride] : 0.0;
+    // U, V, P recomputed (same arithmetic as the pre-pass): three arrays fewer through HBM
+    const double ti = t[i], dt = ti - tprev;
+    tprev = ti;
+    double Uj, Vj, cs_, sn_;
+    lane_uv(k, ti, &Uj, &Vj, &cs_, &sn_);
+    if (dt != dt_prev) {   // wave-uniform: evenly sampled series reuse P
+      Pj = k.live ? exp(-k.c * dt) : 0.0;
+      dt_prev = dt;
+    }
     const double yi = y[i], gi = dg[i];
     if (i > n0) {
 #pragma unroll
@@ -1128,7 +1201,7 @@ __global__ __launch_bounds__(kWave) void celerite_chunk_fwd_kernel(
 #pragma unroll
       for (int l = 0; l < J; ++l) p_vec[(2 + l) * qstride] = Srow[l];
     }
-    p_uvp += vstride; p_vec += vstride; p_scal += n_draw;
+    p_vec += vstride; p_scal += n_draw;
   }
   if (live_draw && j == 0) {
     state[ws.part(c, 0, draw)] = acc;
@@ -1175,7 +1248,6 @@ __global__ __launch_bounds__(kWave) void celerite_chunk_vjp_kernel(
   const double gL = gloglike[draw];
   const bool lead = live_draw && j == 0;
   const int partner = (int)threadIdx.x + ((k.live && !k.real) ? (k.odd ? -1 : 1) : 0);
-  const int jp = k.live ? (partner - ((int)threadIdx.x - j)) : 0;
 
   double Sb[J];
 #pragma unroll
@@ -1187,7 +1259,6 @@ __global__ __launch_bounds__(kWave) void celerite_chunk_vjp_kernel(
   const int64_t vstride = n_draw * J, qstride = n * vstride;
   const double* __restrict__ sc0 = state + six.scal(0, 0, draw);
   const double* __restrict__ ve0 = state + six.vec(0, 0, draw, jj);
-  const double* __restrict__ uv0 = state + six.uvp(0, 0, draw, jj);
   auto load = [&](int64_t i, double& d_, double& z_, double& W_, double& F_, double* S_) {
     const double* ps = sc0 + i * n_draw;
     const double* pv = ve0 + i * vstride;
@@ -1198,12 +1269,17 @@ __global__ __launch_bounds__(kWave) void celerite_chunk_vjp_kernel(
 #pragma unroll
     for (int l = 0; l < J; ++l) S_[l] = k.live ? pv[(2 + l) * qstride] : 0.0;
   };
+  double dt_prev = -1.0, Pcache = 1.0;
   // reverse of the step (i - 1) -> i :  F_i = P o (F_p + W_p z_p),  S_i = P P^T o (S_p + d_p W_p W_p^T);
   // on entry Sb, Fb are the adjoints of S_i, F_i; on exit those of S_{i-1}, F_{i-1}, and Wb, db, zb
   // those of W_{i-1}, d_{i-1}, z_{i-1}
   auto propagate_adjoint = [&](int64_t i, double d_p, double z_p, double W_p, double F_p, const double* S_p) {
-    const double Pj = k.live ? uv0[i * vstride + 2 * qstride] : 0.0;
     const double dt = t[i] - t[i - 1];
+    if (dt != dt_prev) {   // wave-uniform: evenly sampled series reuse P
+      Pcache = k.live ? exp(-k.c * dt) : 0.0;
+      dt_prev = dt;
+    }
+    const double Pj = Pcache;
     double Pall[J], Wpall[J];
 #pragma unroll
     for (int l = 0; l < J; ++l) { Pall[l] = group_get<G>(Pj, l); Wpall[l] = group_get<G>(W_p, l); }
@@ -1235,12 +1311,9 @@ __global__ __launch_bounds__(kWave) void celerite_chunk_vjp_kernel(
 #pragma unroll 1
   for (int64_t i = n1 - 1; i >= n0; --i) {
     // measurement half of cadence i
-    const double* pu = uv0 + i * vstride;
-    const double Uj = k.live ? pu[0] : 0.0;
-    const double Vj = k.live ? pu[qstride] : 0.0;
-    const double Vo = k.live ? pu[qstride + (jp - jj)] : 0.0;
     const double ti = t[i];
-    const double cs = k.odd ? Vo : Vj, sn = k.odd ? Vj : Vo;
+    double Uj, Vj, cs, sn;
+    lane_uv(k, ti, &Uj, &Vj, &cs, &sn);
     double Uall[J];
 #pragma unroll
     for (int l = 0; l < J; ++l) Uall[l] = group_get<G>(Uj, l);
@@ -1393,23 +1466,30 @@ int exo_celerite_loglike_fwd_f64(const double* t, const double* resid, const dou
   const dim3 grid((unsigned)((n_draw + per_wave - 1) / per_wave)), block(kWave);
   hipStream_t st = (hipStream_t)stream;
   if (state) {
-    const int64_t n_el = n * n_draw * J;
-    hipLaunchKernelGGL(celerite_prep_kernel, dim3((unsigned)((n_el + 255) / 256)), dim3(256), 0, st, t, n, coef_real,
-                       n_real, coef_complex, n_complex, n_draw, J, state);
-    if (launch_status() != EXO_OK) return EXO_ERR_LAUNCH;
     ChunkGeom cg = chunk_plan(n, n_draw, J);
     cg.base = n * n_draw * (int64_t)(2 + 2 * J + J * J + 3 * J);
     const double* only_flagged = nullptr;
-    if (cg.C > 1) {
-      // time-parallel path: elements, entering states, recurrences per chunk, sum of the partials
+    if (cg.C <= 1) {
+      const int64_t n_el = n * n_draw * J;
+      hipLaunchKernelGGL(celerite_prep_kernel, dim3((unsigned)((n_el + 255) / 256)), dim3(256), 0, st, t, n,
+                         coef_real, n_real, coef_complex, n_complex, n_draw, J, state);
+      if (launch_status() != EXO_OK) return EXO_ERR_LAUNCH;
+    } else {
+      // time-parallel path: flags (+ pre-pass for flagged draws), elements, entering states,
+      // recurrences per chunk, sum of the partials
       const ChunkWs ws{n_draw, J, cg.C, cg.base};
       const dim3 per_draw((unsigned)((n_draw + kWave - 1) / kWave));
+      EXO_GP_DISPATCH_SMALL(J, hipLaunchKernelGGL((celerite_flag_kernel<JJ>), per_draw, block, 0, st, coef_real, n_real,
+                                                  coef_complex, n_complex, n_draw, state + ws.off_flag()))
+      hipLaunchKernelGGL(celerite_prep_flagged_kernel, dim3(8, (unsigned)n_draw), dim3(256), 0, st, t, n, coef_real,
+                         n_real, coef_complex, n_complex, n_draw, J, state, state + ws.off_flag());
       const dim3 egrid(per_draw.x, (unsigned)cg.C), cgrid(grid.x, (unsigned)cg.C);
-      EXO_GP_DISPATCH_SMALL(J, hipLaunchKernelGGL((celerite_elem_kernel<JJ>), egrid, block, 0, st, resid, diag, n_diag,
-                                                  n, coef_real, n_real, coef_complex, n_complex, n_draw, state, cg))
-      EXO_GP_DISPATCH_SMALL(J, hipLaunchKernelGGL((celerite_bscan_kernel<JJ>), per_draw, block, 0, st, coef_real, n_real,
-                                                  coef_complex, n_complex, n, n_draw, state, cg))
-      EXO_GP_DISPATCH_SMALL(J, hipLaunchKernelGGL((celerite_chunk_fwd_kernel<JJ>), cgrid, block, 0, st, resid, diag,
+      EXO_GP_DISPATCH_SMALL(J, hipLaunchKernelGGL((celerite_elem_kernel<JJ>), egrid, block, 0, st, t, resid, diag,
+                                                  n_diag, n, coef_real, n_real, coef_complex, n_complex, n_draw, state,
+                                                  cg))
+      EXO_GP_DISPATCH_SMALL(J, hipLaunchKernelGGL((celerite_bscan_kernel<JJ>), per_draw, block, 0, st, t, coef_real,
+                                                  n_real, coef_complex, n_complex, n, n_draw, state, cg))
+      EXO_GP_DISPATCH_SMALL(J, hipLaunchKernelGGL((celerite_chunk_fwd_kernel<JJ>), cgrid, block, 0, st, t, resid, diag,
                                                   n_diag, n, coef_real, n_real, coef_complex, n_complex, n_draw, state,
                                                   cg))
       hipLaunchKernelGGL(celerite_chunk_loglike_kernel, per_draw, block, 0, st, n, n_draw, J, state, cg, loglike);
