@@ -621,7 +621,9 @@ inline ChunkGeom chunk_plan(int64_t n, int64_t n_draw, int J) {
     C = atoll(env);
   } else {
     const int G = J <= 1 ? 1 : (J <= 2 ? 2 : (J <= 4 ? 4 : 8));
-    C = (64 * 2048) / (n_draw * G);   // ~2 waves per SIMD
+    // ~2 waves per SIMD for the chunk kernels; small J affords more (the per-draw scans over the
+    // chunks cost C J^3): measured optimum at 1024 draws, J = 2 is C = 256
+    C = (64 * 2048 * (J <= 2 ? 4 : 1)) / (n_draw * G);
     if (C > 512) C = 512;
     if (C < 4) C = 1;
   }
