@@ -785,9 +785,17 @@ __global__ __launch_bounds__(kWave) void celerite_elem_kernel(
   double ti = t[n0], dt_prev = -1.0;
   co.uv(ti, U, V);
   dc.eval(V, n_real, Dl);
+  // The element is in information form: it needs a measurement variance that is not tiny next to
+  // the process variance (diag = 0 is a legal celerite model, but 1 / diag is not a number).
+  // Such draws are flagged here and redone by the sequential kernels.
+  double asum = 0.0;
+#pragma unroll
+  for (int j = 0; j < J; ++j) asum += (co.k[j].real || !co.k[j].odd) ? fabs(co.k[j].a) : 0.0;
+  bool ok = true;
 #pragma unroll 1
   for (int64_t i = n0; i < n1; ++i) {
     const double yi = y[i], R = dg[i];
+    ok = ok && (R > 1e-10 * asum) && (R < INFINITY);
     double r[J], cu[J];
     double s = R, zeta = yi;
 #pragma unroll
@@ -831,6 +839,7 @@ __global__ __launch_bounds__(kWave) void celerite_elem_kernel(
       Dl = Dn;
     }
   }
+  if (!ok) state[ws.off_flag() + draw] = 1.0;
   int e = 0;
 #pragma unroll
   for (int j = 0; j < J; ++j)
@@ -1483,12 +1492,14 @@ int exo_celerite_loglike_fwd_f64(const double* t, const double* resid, const dou
       const dim3 per_draw((unsigned)((n_draw + kWave - 1) / kWave));
       EXO_GP_DISPATCH_SMALL(J, hipLaunchKernelGGL((celerite_flag_kernel<JJ>), per_draw, block, 0, st, coef_real, n_real,
                                                   coef_complex, n_complex, n_draw, state + ws.off_flag()))
-      hipLaunchKernelGGL(celerite_prep_flagged_kernel, dim3(8, (unsigned)n_draw), dim3(256), 0, st, t, n, coef_real,
-                         n_real, coef_complex, n_complex, n_draw, J, state, state + ws.off_flag());
+
       const dim3 egrid(per_draw.x, (unsigned)cg.C), cgrid(grid.x, (unsigned)cg.C);
       EXO_GP_DISPATCH_SMALL(J, hipLaunchKernelGGL((celerite_elem_kernel<JJ>), egrid, block, 0, st, t, resid, diag,
                                                   n_diag, n, coef_real, n_real, coef_complex, n_complex, n_draw, state,
                                                   cg))
+      // after the element kernel: it may flag more draws (measurement variance too small)
+      hipLaunchKernelGGL(celerite_prep_flagged_kernel, dim3(8, (unsigned)n_draw), dim3(256), 0, st, t, n, coef_real,
+                         n_real, coef_complex, n_complex, n_draw, J, state, state + ws.off_flag());
       EXO_GP_DISPATCH_SMALL(J, hipLaunchKernelGGL((celerite_bscan_kernel<JJ>), per_draw, block, 0, st, t, coef_real,
                                                   n_real, coef_complex, n_complex, n, n_draw, state, cg))
       EXO_GP_DISPATCH_SMALL(J, hipLaunchKernelGGL((celerite_chunk_fwd_kernel<JJ>), cgrid, block, 0, st, t, resid, diag,

@@ -148,3 +148,25 @@ def test_not_positive_definite_is_minus_inf_on_both_paths(dev):
             ll2 = celerite_loglike(T(t, dev), yt, T(diag, dev), T(cr, dev), T(cc, dev))
         assert torch.isinf(ll).all() and (ll < 0).all()
         assert torch.isinf(ll2).all() and (ll2 < 0).all()
+
+
+def test_no_white_noise_falls_back(dev):
+    """diag = 0 is a legal celerite model (the kernel matrix itself is positive definite) but has no
+    information-form element: flagged by the element kernel, redone sequentially, same numbers"""
+    rng = np.random.default_rng(14)
+    N, D = 500, 3
+    t = np.sort(rng.uniform(0, 20, N))
+    y = 0.3 * rng.normal(size=(D, N))
+    diag = np.zeros((D, N))
+    diag[1] = 0.05                       # one ordinary draw in the batch
+    cr, cc = batch(rng, "mixed_j5", D)
+    with chunks(0):
+        want = value_and_grads(dev, t, y, diag, cr, cc)
+    with chunks(None):
+        got = value_and_grads(dev, t, y, diag, cr, cc)
+    assert np.isfinite(want[0]).all()
+    np.testing.assert_array_equal(got[0][[0, 2]], want[0][[0, 2]])
+    np.testing.assert_allclose(got[0], want[0], rtol=1e-12)
+    for g, w in zip(got[1:], want[1:]):
+        if w.size:
+            assert np.abs(g - w).max() / (np.abs(w).max() + 1e-300) < 2e-9
