@@ -123,6 +123,25 @@ def quad_solution_vector(b, r):
     return _QuadSV.apply(b, r)
 
 
+@torch.no_grad()
+def quad_solution_vector_derivs(b, r):
+    """(s, ds/db, ds/dr), each [..., 3], as plain tensors -- for callers that carry their own
+    differentiation (the PyTensor Op of compat_pytensor.py)."""
+    b = _dev(b, "b")
+    r = _dev(r, "r")
+    if b.shape != r.shape:
+        raise ValueError("quad_solution_vector: b and r must have the same shape")
+    s = torch.empty(b.shape + (3,), dtype=torch.float64, device=b.device)
+    dsdb, dsdr = torch.empty_like(s), torch.empty_like(s)
+    lib = _lib.load()
+    with torch.cuda.device(b.device):
+        _lib.check(
+            lib.exo_quad_solution_vector_f64(_ptr(b), _ptr(r), _ptr(s), _ptr(dsdb), _ptr(dsdr), b.numel(), _stream(b)),
+            "exo_quad_solution_vector_f64",
+        )
+    return s, dsdb, dsdr
+
+
 # ------------------------------------------------------------------------------
 # contact_points (no gradient: it only selects cadences, keplerian.py:769-775)
 # ------------------------------------------------------------------------------

@@ -157,3 +157,20 @@ def test_shard_bounds_cover_everything():
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             sizes = [hi - lo for lo, hi in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_pytensor_adapter_is_import_guarded():
+    """exoplanet_amd.compat_pytensor (the reference-side binding of INTEGRATION.md) needs PyTensor,
+    which this image does not have: it must say so rather than half-import"""
+    import importlib
+    import sys
+
+    try:
+        import pytensor  # noqa: F401
+    except ImportError:
+        sys.modules.pop("exoplanet_amd.compat_pytensor", None)
+        with pytest.raises(ImportError, match="PyTensor"):
+            importlib.import_module("exoplanet_amd.compat_pytensor")
+    else:  # pragma: no cover
+        mod = importlib.import_module("exoplanet_amd.compat_pytensor")
+        assert hasattr(mod.ops, "kepler") and hasattr(mod.ops, "quad_solution_vector") and hasattr(mod.ops, "contact_points")
