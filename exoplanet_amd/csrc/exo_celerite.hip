@@ -1019,14 +1019,85 @@ __global__ __launch_bounds__(kWave) void celerite_bscan_kernel(const double* __r
   }
 }
 
-// (B') the adjoint of the state entering every chunk, last to first: one lane per draw
+// (B'), part 1 -- everything in the chain rule across chunks that does not depend on the adjoint
+// coming from later chunks, for all (draw, chunk) in parallel (the J x J solve lives here):
+//   Abar = A Y,  g = eta - Jm Y (F + P eta),  local adjoints  gL w  and  gL/2 (w w^T - Jm Y),
+// written over the chunk's element (A <- Abar, b <- g, eta <- local Fbar, Cm <- local Pbar).
 template <int J>
-__global__ __launch_bounds__(kWave) void celerite_bscan_vjp_kernel(const double* __restrict__ gloglike, int64_t n_draw,
+__global__ __launch_bounds__(kWave) void celerite_badj_prep_kernel(const double* __restrict__ gloglike, int64_t n_draw,
                                                                    double* __restrict__ state, ChunkGeom cg) {
   const int64_t draw = (int64_t)blockIdx.x * kWave + threadIdx.x;
   if (draw >= n_draw) return;
+  const int c = blockIdx.y + 1;   // chunk 0's entering adjoint is never needed
   const ChunkWs ws{n_draw, J, cg.C, cg.base};
   const double gL = gloglike[draw];
+  Elem<J> el;
+  el.load(state, ws, c, draw);
+  double m[J], P[J][J];
+#pragma unroll
+  for (int j = 0; j < J; ++j) {
+    m[j] = state[ws.bnd(1, c, j, draw)];
+#pragma unroll
+    for (int l = 0; l < J; ++l) P[j][l] = state[ws.bnd(1, c, J + j * J + l, draw)];
+  }
+  double X[J][J], Y[J][J];
+#pragma unroll
+  for (int j = 0; j < J; ++j)
+#pragma unroll
+    for (int l = 0; l < J; ++l) {
+      double x = (j == l) ? 1.0 : 0.0;
+#pragma unroll
+      for (int k = 0; k < J; ++k) x = fma(P[j][k], el.Jm[k][l], x);
+      X[j][l] = x;
+      Y[j][l] = (j == l) ? 1.0 : 0.0;
+    }
+  solve_inplace<J, J>(X, Y);
+  double u[J], v[J], w[J], Yv[J];
+#pragma unroll
+  for (int j = 0; j < J; ++j) {
+    double uj = el.eta[j], vj = m[j];
+#pragma unroll
+    for (int l = 0; l < J; ++l) { uj = fma(-el.Jm[j][l], m[l], uj); vj = fma(P[j][l], el.eta[l], vj); }
+    u[j] = uj; v[j] = vj;
+  }
+#pragma unroll
+  for (int j = 0; j < J; ++j) {
+    double wj = 0.0, yv = 0.0;
+#pragma unroll
+    for (int l = 0; l < J; ++l) { wj = fma(Y[l][j], u[l], wj); yv = fma(Y[j][l], v[l], yv); }
+    w[j] = wj; Yv[j] = yv;
+  }
+  const int oA = 0, ob = J * J, oC = J * J + J, oeta = 2 * J * J + J;
+#pragma unroll
+  for (int j = 0; j < J; ++j) {
+    double gj = el.eta[j];
+#pragma unroll
+    for (int l = 0; l < J; ++l) {
+      gj = fma(-el.Jm[j][l], Yv[l], gj);
+      double a = 0.0, jy = 0.0, jyt = 0.0;
+#pragma unroll
+      for (int k = 0; k < J; ++k) {
+        a = fma(el.A[j][k], Y[k][l], a);
+        jy = fma(el.Jm[j][k], Y[k][l], jy);
+        jyt = fma(el.Jm[l][k], Y[k][j], jyt);
+      }
+      state[ws.elem(c, oA + j * J + l, draw)] = a;
+      state[ws.elem(c, oC + j * J + l, draw)] = 0.5 * gL * (w[j] * w[l] - 0.5 * (jy + jyt));
+    }
+    state[ws.elem(c, ob + j, draw)] = gj;
+    state[ws.elem(c, oeta + j, draw)] = gL * w[j];
+  }
+}
+
+// (B'), part 2 -- the chain itself, last chunk to first, one lane per draw: two J x J products per chunk
+//   Fbar = local + Abar^T Fbar',   Pbar = local + Abar^T Pbar' Abar + sym(Abar^T Fbar' g^T)
+template <int J>
+__global__ __launch_bounds__(kWave) void celerite_bscan_vjp_kernel(int64_t n_draw, double* __restrict__ state,
+                                                                   ChunkGeom cg) {
+  const int64_t draw = (int64_t)blockIdx.x * kWave + threadIdx.x;
+  if (draw >= n_draw) return;
+  const ChunkWs ws{n_draw, J, cg.C, cg.base};
+  const int oA = 0, ob = J * J, oC = J * J + J, oeta = 2 * J * J + J;
   double mb[J], Pb[J][J];   // adjoint of (F, P) entering chunk c + 1
 #pragma unroll
   for (int j = 0; j < J; ++j) {
@@ -1044,59 +1115,13 @@ __global__ __launch_bounds__(kWave) void celerite_bscan_vjp_kernel(const double*
       for (int l = 0; l < J; ++l) state[ws.bnd(2, c, J + j * J + l, draw)] = -Pb[j][l];
     }
     if (c == 0) break;
-    Elem<J> el;
-    el.load(state, ws, c, draw);
-    double m[J], P[J][J];
+    double Ab[J][J], g[J], x[J], T[J][J];
 #pragma unroll
     for (int j = 0; j < J; ++j) {
-      m[j] = state[ws.bnd(1, c, j, draw)];
+      g[j] = state[ws.elem(c, ob + j, draw)];
 #pragma unroll
-      for (int l = 0; l < J; ++l) P[j][l] = state[ws.bnd(1, c, J + j * J + l, draw)];
+      for (int l = 0; l < J; ++l) Ab[j][l] = state[ws.elem(c, oA + j * J + l, draw)];
     }
-    // Y = (I + P Jm)^-1
-    double X[J][J], Y[J][J];
-#pragma unroll
-    for (int j = 0; j < J; ++j)
-#pragma unroll
-      for (int l = 0; l < J; ++l) {
-        double x = (j == l) ? 1.0 : 0.0;
-#pragma unroll
-        for (int k = 0; k < J; ++k) x = fma(P[j][k], el.Jm[k][l], x);
-        X[j][l] = x;
-        Y[j][l] = (j == l) ? 1.0 : 0.0;
-      }
-    solve_inplace<J, J>(X, Y);
-    // w = Y^T (eta - Jm m) ;  v = m + P eta ;  g = eta - Jm Y v ;  JY = Jm Y ;  Ab = A Y
-    double u[J], v[J], w[J], Yv[J], g[J], JY[J][J], Ab[J][J];
-#pragma unroll
-    for (int j = 0; j < J; ++j) {
-      double uj = el.eta[j], vj = m[j];
-#pragma unroll
-      for (int l = 0; l < J; ++l) { uj = fma(-el.Jm[j][l], m[l], uj); vj = fma(P[j][l], el.eta[l], vj); }
-      u[j] = uj; v[j] = vj;
-    }
-#pragma unroll
-    for (int j = 0; j < J; ++j) {
-      double wj = 0.0, yv = 0.0;
-#pragma unroll
-      for (int l = 0; l < J; ++l) { wj = fma(Y[l][j], u[l], wj); yv = fma(Y[j][l], v[l], yv); }
-      w[j] = wj; Yv[j] = yv;
-    }
-#pragma unroll
-    for (int j = 0; j < J; ++j) {
-      double gj = el.eta[j];
-#pragma unroll
-      for (int l = 0; l < J; ++l) {
-        gj = fma(-el.Jm[j][l], Yv[l], gj);
-        double a = 0.0, jy = 0.0;
-#pragma unroll
-        for (int k = 0; k < J; ++k) { a = fma(el.A[j][k], Y[k][l], a); jy = fma(el.Jm[j][k], Y[k][l], jy); }
-        Ab[j][l] = a; JY[j][l] = jy;
-      }
-      g[j] = gj;
-    }
-    // x = Ab^T mb' ;  T = Pb' Ab
-    double x[J], T[J][J];
 #pragma unroll
     for (int j = 0; j < J; ++j) {
       double xj = 0.0;
@@ -1113,13 +1138,13 @@ __global__ __launch_bounds__(kWave) void celerite_bscan_vjp_kernel(const double*
     double mbn[J], Pbn[J][J];
 #pragma unroll
     for (int j = 0; j < J; ++j) {
-      mbn[j] = fma(gL, w[j], x[j]);
+      mbn[j] = state[ws.elem(c, oeta + j, draw)] + x[j];
 #pragma unroll
       for (int l = 0; l < J; ++l) {
-        double cong = 0.0;
+        double cong = state[ws.elem(c, oC + j * J + l, draw)];
 #pragma unroll
         for (int k = 0; k < J; ++k) cong = fma(Ab[k][j], T[k][l], cong);
-        Pbn[j][l] = 0.5 * gL * (w[j] * w[l] - 0.5 * (JY[j][l] + JY[l][j])) + cong + 0.5 * (x[j] * g[l] + g[j] * x[l]);
+        Pbn[j][l] = cong + 0.5 * (x[j] * g[l] + g[j] * x[l]);
       }
     }
 #pragma unroll
@@ -1572,8 +1597,10 @@ int exo_celerite_loglike_vjp_f64(const double* t, const double* diag, int64_t n_
     double* wstate = const_cast<double*>(state);   // the chunk workspace lives behind the saved factorisation
     const ChunkWs ws{n_draw, J, cg.C, cg.base};
     const dim3 per_draw((unsigned)((n_draw + kWave - 1) / kWave)), cgrid(grid.x, (unsigned)cg.C);
-    EXO_GP_DISPATCH_SMALL(J, hipLaunchKernelGGL((celerite_bscan_vjp_kernel<JJ>), per_draw, block, 0, st, gloglike,
-                                                n_draw, wstate, cg))
+    EXO_GP_DISPATCH_SMALL(J, hipLaunchKernelGGL((celerite_badj_prep_kernel<JJ>), dim3(per_draw.x, (unsigned)(cg.C - 1)),
+                                                block, 0, st, gloglike, n_draw, wstate, cg))
+    EXO_GP_DISPATCH_SMALL(J, hipLaunchKernelGGL((celerite_bscan_vjp_kernel<JJ>), per_draw, block, 0, st, n_draw, wstate,
+                                                cg))
     EXO_GP_DISPATCH_SMALL(J, hipLaunchKernelGGL((celerite_chunk_vjp_kernel<JJ>), cgrid, block, 0, st, t, n, coef_real,
                                                 n_real, coef_complex, n_complex, n_draw, gloglike, wstate, cg, gresid,
                                                 gdiag))
