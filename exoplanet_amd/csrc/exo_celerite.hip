@@ -86,6 +86,12 @@ __device__ __forceinline__ double group_get(double v, int l) {
   }
 }
 
+// integer flavour of group_get
+template <int G>
+__device__ __forceinline__ int group_get_int(int v, int l) {
+  return __double2loint(group_get<G>(__hiloint2double(0, v), l));
+}
+
 // butterfly partner lane ^ M within the group
 template <int M>
 __device__ __forceinline__ double xor_get(double v) {
@@ -594,7 +600,7 @@ struct ChunkWs {
   __host__ __device__ int B() const { return J + J * J; }           // vector + matrix
   __host__ __device__ int64_t elem(int c, int e, int64_t draw) const { return base + ((int64_t)c * E() + e) * n_draw + draw; }
   __host__ __device__ int64_t off_bnd() const { return base + (int64_t)C * E() * n_draw; }
-  // q = 0: (F, S) entering chunk c;  1: (F, P) entering chunk c;  2: adjoint of (F, S) entering chunk c + 1
+  // q = 1: (F, P) entering chunk c;  2: adjoint of (F, S) entering chunk c + 1  (0: unused)
   __host__ __device__ int64_t bnd(int q, int c, int k, int64_t draw) const {
     return off_bnd() + (((int64_t)q * C + c) * B() + k) * n_draw + draw;
   }
@@ -947,12 +953,11 @@ __global__ __launch_bounds__(kWave) void celerite_bscan_kernel(const double* __r
   for (int j = 0; j < J; ++j) m[j] = 0.0;
 #pragma unroll 1
   for (int c = 0; c < cg.C; ++c) {
-    const int64_t n0 = c * cg.L;
-    double U[J], V[J];
-    co.uv(t[n0], U, V);
-    Sym<J> Dl;
-    dc.eval(V, n_real, Dl);
     if (c == 0) {
+      double U[J], V[J];
+      co.uv(t[0], U, V);
+      Sym<J> Dl;
+      dc.eval(V, n_real, Dl);
 #pragma unroll
       for (int j = 0; j < J; ++j)
 #pragma unroll
@@ -960,13 +965,9 @@ __global__ __launch_bounds__(kWave) void celerite_bscan_kernel(const double* __r
     }
 #pragma unroll
     for (int j = 0; j < J; ++j) {
-      state[ws.bnd(0, c, j, draw)] = m[j];
       state[ws.bnd(1, c, j, draw)] = m[j];
 #pragma unroll
-      for (int l = 0; l < J; ++l) {
-        state[ws.bnd(0, c, J + j * J + l, draw)] = Dl(j, l) - P[j][l];
-        state[ws.bnd(1, c, J + j * J + l, draw)] = P[j][l];
-      }
+      for (int l = 0; l < J; ++l) state[ws.bnd(1, c, J + j * J + l, draw)] = P[j][l];
     }
     if (c + 1 == cg.C) break;
     Elem<J> el;
@@ -1016,6 +1017,165 @@ __global__ __launch_bounds__(kWave) void celerite_bscan_kernel(const double* __r
     for (int j = 0; j < J; ++j)
 #pragma unroll
       for (int l = 0; l < J; ++l) P[j][l] = 0.5 * (X[j][l] + X[l][j]);
+  }
+}
+
+// row j of Delta_n for the lane that owns state index j (see DeltaCoef for the formulas)
+struct LaneDelta {
+  double dp, dq, dr;
+  __device__ __forceinline__ explicit LaneDelta(const LaneCoef& k) : dp(0.0), dq(0.0), dr(0.0) {
+    if (!k.live) return;
+    if (k.real) {
+      dp = 1.0 / k.a;
+    } else {
+      const double h = 1.0 / (k.a * k.a + k.b * k.b);
+      dr = k.a * h; dq = -k.b * h; dp = (k.a * k.a + 2.0 * k.b * k.b) * h / k.a;
+    }
+  }
+  // cs, sn: cos / sin (d t_n) of the lane's pair (from lane_uv)
+  template <int J>
+  __device__ __forceinline__ void row(const LaneCoef& k, int j, double cs, double sn, double* D) const {
+#pragma unroll
+    for (int l = 0; l < J; ++l) {
+      double v = 0.0;
+      if (k.live) {
+        if (k.real) {
+          if (l == j) v = dp;
+        } else if (!k.odd) {
+          if (l == j) v = dp * cs * cs + 2.0 * dq * cs * sn + dr * sn * sn;
+          if (l == j + 1) v = (dp - dr) * cs * sn + dq * (sn * sn - cs * cs);
+        } else {
+          if (l == j - 1) v = (dp - dr) * cs * sn + dq * (sn * sn - cs * cs);
+          if (l == j) v = dp * sn * sn - 2.0 * dq * cs * sn + dr * cs * cs;
+        }
+      }
+      D[l] = v;
+    }
+  }
+};
+
+// (B) in lane-group form (a draw on G lanes, lane j owns row j of P, A, Cm, Jm): the same chain as
+// celerite_bscan_kernel with the J x J algebra of every step spread over the draw's lanes --
+// products through DPP broadcasts, the solve as Gauss-Jordan with partial pivoting, the pivot row
+// travelling by ds_bpermute.  One lane per draw issues ~2900 instructions per chunk at J = 6 and is
+// bound by exactly that; here a lane issues about a third.
+template <int J>
+__global__ __launch_bounds__(kWave) void celerite_bscan_lg_kernel(const double* __restrict__ t,
+                                                                  const double* __restrict__ coef_real, int n_real,
+                                                                  const double* __restrict__ coef_complex,
+                                                                  int n_complex, int64_t n, int64_t n_draw,
+                                                                  double* __restrict__ state, ChunkGeom cg) {
+  constexpr int G = Group<J>::G;
+  const int j = threadIdx.x & (G - 1);
+  const int gbase = (int)threadIdx.x - j;   // first lane of this draw's group
+  const int64_t lane_draw = ((int64_t)blockIdx.x * kWave + threadIdx.x) / G;
+  const bool live_draw = lane_draw < n_draw;
+  const int64_t draw = live_draw ? lane_draw : n_draw - 1;
+  const LaneCoef k = lane_coef(coef_real, n_real, coef_complex, n_complex, draw, j, J);
+  const bool live = k.live;
+  const int jj = live ? j : 0;
+  const bool store = live_draw && live;
+  const ChunkWs ws{n_draw, J, cg.C, cg.base};
+  const LaneDelta ld(k);
+  double mj = 0.0, Prow[J];
+  {
+    double U_, V_, cs, sn;
+    lane_uv(k, t[0], &U_, &V_, &cs, &sn);
+    ld.row<J>(k, j, cs, sn, Prow);   // S_0 = 0
+  }
+  const int E1 = J * J, E2 = J * J + J, E3 = 2 * J * J + J, E4 = 2 * J * J + 2 * J;   // b, Cm, eta, Jm offsets
+  // element rows of the next chunk are fetched while this one is applied: the loads (and this
+  // chunk's boundary stores) are issued ahead of the arithmetic that hides them
+  double nA[J], nCm[J], nJm[J], nb = 0.0, neta = 0.0;
+  auto fetch = [&](int c) {
+#pragma unroll
+    for (int l = 0; l < J; ++l) {
+      nA[l] = live ? state[ws.elem(c, jj * J + l, draw)] : 0.0;
+      nCm[l] = live ? state[ws.elem(c, E2 + jj * J + l, draw)] : 0.0;
+      nJm[l] = live ? state[ws.elem(c, E4 + jj * J + l, draw)] : 0.0;
+    }
+    nb = live ? state[ws.elem(c, E1 + jj, draw)] : 0.0;
+    neta = live ? state[ws.elem(c, E3 + jj, draw)] : 0.0;
+  };
+  if (cg.C > 1) fetch(0);
+#pragma unroll 1
+  for (int c = 0; c < cg.C; ++c) {
+    double Arow[J], Cmrow[J], Jmrow[J];
+#pragma unroll
+    for (int l = 0; l < J; ++l) { Arow[l] = nA[l]; Cmrow[l] = nCm[l]; Jmrow[l] = nJm[l]; }
+    const double bj = nb, etaj = neta;
+    if (c + 2 < cg.C) fetch(c + 1);
+    // the state entering chunk c as (F, P); the chunk kernel turns P into S = Delta - P itself
+    if (store) {
+      state[ws.bnd(1, c, j, draw)] = mj;
+#pragma unroll
+      for (int l = 0; l < J; ++l) state[ws.bnd(1, c, J + j * J + l, draw)] = Prow[l];
+    }
+    if (c + 1 == cg.C) break;
+    // row j of X = I + P Jm and of the right-hand sides [P | F + P eta]
+    double Xr[J], R[J + 1];
+    double pe = mj;
+#pragma unroll
+    for (int l = 0; l < J; ++l) { Xr[l] = (l == j) ? 1.0 : 0.0; R[l] = Prow[l]; }
+#pragma unroll
+    for (int kk = 0; kk < J; ++kk) {
+      pe = fma(Prow[kk], group_get<G>(etaj, kk), pe);
+#pragma unroll
+      for (int l = 0; l < J; ++l) Xr[l] = fma(Prow[kk], group_get<G>(Jmrow[l], kk), Xr[l]);
+    }
+    R[J] = pe;
+    // Gauss-Jordan, partial pivoting over the rows (= lanes) not used yet
+    bool used = !live;
+    int myvar = -1;
+    double diag = 1.0;
+#pragma unroll
+    for (int kk = 0; kk < J; ++kk) {
+      double best = used ? -1.0 : fabs(Xr[kk]);
+      int who = j;
+#pragma unroll
+      for (int M = 1; M < G; M <<= 1) {
+        const double ov = __shfl_xor(best, M, 64);
+        const int ow = __shfl_xor(who, M, 64);
+        const bool take = (ov > best) || (ov == best && ow < who);
+        best = take ? ov : best;
+        who = take ? ow : who;
+      }
+      const int src = gbase + who;
+      const double piv = __shfl(Xr[kk], src, 64);
+      const double ipiv = 1.0 / piv;
+      const bool me = (j == who);
+      const double f = me ? 0.0 : Xr[kk] * ipiv;
+#pragma unroll
+      for (int l = kk + 1; l < J; ++l) Xr[l] = fma(-f, __shfl(Xr[l], src, 64), Xr[l]);
+#pragma unroll
+      for (int l = 0; l <= J; ++l) R[l] = fma(-f, __shfl(R[l], src, 64), R[l]);
+      if (me) { used = true; myvar = kk; diag = piv; } else { Xr[kk] = 0.0; }
+    }
+    // the lane that pivoted on column kk holds solution row kk; bring row j to lane j
+    const double idiag = 1.0 / diag;
+    int from = j;
+#pragma unroll
+    for (int l = 0; l < J; ++l) from = (group_get_int<G>(myvar, l) == j) ? l : from;
+    double Z[J + 1];
+#pragma unroll
+    for (int l = 0; l <= J; ++l) Z[l] = __shfl(R[l] * idiag, gbase + from, 64);
+    // F' = A ym + b ;  P' = A (YP) A^T + Cm
+    double mnew = bj, AY[J], Pn[J];
+#pragma unroll
+    for (int l = 0; l < J; ++l) { AY[l] = 0.0; Pn[l] = Cmrow[l]; }
+#pragma unroll
+    for (int kk = 0; kk < J; ++kk) {
+      mnew = fma(Arow[kk], group_get<G>(Z[J], kk), mnew);
+#pragma unroll
+      for (int l = 0; l < J; ++l) AY[l] = fma(Arow[kk], group_get<G>(Z[l], kk), AY[l]);
+    }
+#pragma unroll
+    for (int l = 0; l < J; ++l)
+#pragma unroll
+      for (int kk = 0; kk < J; ++kk) Pn[l] = fma(AY[kk], group_get<G>(Arow[kk], l), Pn[l]);
+    mj = live ? mnew : 0.0;
+#pragma unroll
+    for (int l = 0; l < J; ++l) Prow[l] = live ? Pn[l] : 0.0;
   }
 }
 
@@ -1182,9 +1342,16 @@ __global__ __launch_bounds__(kWave) void celerite_chunk_fwd_kernel(
   const int jj = k.live ? j : 0;
 
   double Srow[J], Wall[J], Uall[J], Pall[J];
+  {
+    // entering state from (B) as (F, P): S = Delta_{n0} - P
+    const LaneDelta ld(k);
+    double U_, V_, cs, sn;
+    lane_uv(k, t[n0], &U_, &V_, &cs, &sn);
+    ld.row<J>(k, j, cs, sn, Srow);
 #pragma unroll
-  for (int l = 0; l < J; ++l) { Srow[l] = k.live ? state[ws.bnd(0, c, J + jj * J + l, draw)] : 0.0; Wall[l] = 0.0; }
-  double Fj = k.live ? state[ws.bnd(0, c, jj, draw)] : 0.0;
+    for (int l = 0; l < J; ++l) { Srow[l] -= k.live ? state[ws.bnd(1, c, J + jj * J + l, draw)] : 0.0; Wall[l] = 0.0; }
+  }
+  double Fj = k.live ? state[ws.bnd(1, c, jj, draw)] : 0.0;
   double Wj = 0.0, d = 1.0, z = 0.0;
   bool bad = false;
   double acc = 0.0, lman = 1.0;
@@ -1556,8 +1723,13 @@ int exo_celerite_loglike_fwd_f64(const double* t, const double* resid, const dou
       // after the element kernel: it may flag more draws (measurement variance too small)
       hipLaunchKernelGGL(celerite_prep_flagged_kernel, dim3(8, (unsigned)n_draw), dim3(256), 0, st, t, n, coef_real,
                          n_real, coef_complex, n_complex, n_draw, J, state, state + ws.off_flag());
-      EXO_GP_DISPATCH_SMALL(J, hipLaunchKernelGGL((celerite_bscan_kernel<JJ>), per_draw, block, 0, st, t, coef_real,
-                                                  n_real, coef_complex, n_complex, n, n_draw, state, cg))
+      if (J >= 3) {
+        EXO_GP_DISPATCH_SMALL(J, hipLaunchKernelGGL((celerite_bscan_lg_kernel<JJ>), grid, block, 0, st, t, coef_real,
+                                                    n_real, coef_complex, n_complex, n, n_draw, state, cg))
+      } else {
+        EXO_GP_DISPATCH_SMALL(J, hipLaunchKernelGGL((celerite_bscan_kernel<JJ>), per_draw, block, 0, st, t, coef_real,
+                                                    n_real, coef_complex, n_complex, n, n_draw, state, cg))
+      }
       EXO_GP_DISPATCH_SMALL(J, hipLaunchKernelGGL((celerite_chunk_fwd_kernel<JJ>), cgrid, block, 0, st, t, resid, diag,
                                                   n_diag, n, coef_real, n_real, coef_complex, n_complex, n_draw, state,
                                                   cg))
