@@ -1,7 +1,7 @@
 cd /tmp; export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT
-for C in 64 128 256 512; do
+for C in ${SWEEP:-64 128 256 512}; do
   export EXO_GP_CHUNKS=$C
-  rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/c3s_$C -o p -- python $R/tools/profile_gp.py c3 > /dev/null 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/c3s_$C -o p -- python $R/tools/profile_gp.py ${CFG:-c3} > /dev/null 2>&1
   python - <<PY
 import csv,glob
 f=glob.glob("$R/gpurun_out/c3s_$C/**/*kernel_stats.csv",recursive=True)[0]
