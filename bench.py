@@ -284,8 +284,33 @@ def main():
         rec, c, _, _ = orbit.kernel_inputs(leaves["r"], (leaves["u1"], leaves["u2"]))
         rec, c = rec.detach(), c.detach()
         wall3 = time_steps(lambda i: ops.transit_flux_value_and_vjp(t, rec, c, gbar), ex_steps, 2, dist, dev)
+        # BASELINE configs[2] (C3): the same light curve + a celerite SHO-term GP log-likelihood on
+        # the residual, value + gradient w.r.t. the orbit / limb-darkening leaves (user-level API)
+        c3 = None
+        try:
+            yobs = 5e-4 * torch.randn(N_CAD, dtype=torch.float64, device=dev)
+            ones = torch.ones(D, dtype=torch.float64, device=dev)
+            names = list(leaves)
+
+            def one_c3(i):
+                orbit3 = xo.KeplerianOrbit(period=leaves["period"], t0=leaves["t0"], b=leaves["b"], ecc=leaves["ecc"],
+                                           omega=leaves["omega"])
+                lc = xo.LimbDarkLightCurve(leaves["u1"], leaves["u2"]).get_light_curve(orbit=orbit3, r=leaves["r"], t=t)
+                gp = xo.gp.GaussianProcess(xo.gp.terms.SHOTerm(sigma=1e-3 * ones, rho=5.0 * ones, Q=0.7071 * ones),
+                                           t=t, yerr=5e-4)
+                ll = gp.log_likelihood(yobs - lc.sum(-1))
+                return torch.autograd.grad(ll.sum(), [leaves[k] for k in names])
+
+            c3_steps = 4
+            wall_c3 = time_steps(one_c3, c3_steps, 2, dist, dev)
+            c3 = {"evals_per_s": world * D * c3_steps / wall_c3, "ms_per_step": 1e3 * wall_c3 / c3_steps,
+                  "note": "C3: C2 light curve + SHO-term celerite GP on the residual (recurrences in parallel "
+                          "over time), value + gradient, eager launches"}
+        except Exception as exc:  # an extra leg must not take the headline measurement down with it
+            c3 = {"error": repr(exc)[:200]}
         if rank == 0:
             out["extras"] = {
+                "c3_light_curve_plus_sho_gp": c3,
                 "in_transit_only": {"evals_per_s": world * D * ex_steps / wall2, "kernel_ms": k2,
                                     "alg_GBps": ALG_BYTES_PER_UNIT * D * N_CAD / (k2 * 1e-3) / 1e9,
                                     "note": "reference default use_in_transit=True (contact-point windows); this "
