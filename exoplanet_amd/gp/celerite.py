@@ -127,7 +127,7 @@ class GaussianProcess:
         cplx = cplx.expand((D,) + tuple(cplx.shape[-2:]))
         return real, cplx, D, bool(batch)
 
-    def log_likelihood(self, y):
+    def _prepare(self, y):
         if self._t is None:
             raise RuntimeError("you must call 'compute' first")
         t = self._t
@@ -144,5 +144,59 @@ class GaussianProcess:
         resid = resid.expand(D, t.shape[0]).contiguous()
         real = real.expand(D, real.shape[1], 2).contiguous()
         cplx = cplx.expand(D, cplx.shape[1], 4).contiguous()
+        return t, mean, resid, real, cplx, squeeze
+
+    def log_likelihood(self, y):
+        t, _, resid, real, cplx, squeeze = self._prepare(y)
         ll = celerite_loglike(t.detach(), resid, self._diag.contiguous(), real, cplx)
         return ll[0] if squeeze else ll
+
+    def apply_inverse(self, y):
+        """alpha = (K + diag)^-1 (y - mean), per draw (detached).  It is minus the gradient of the
+        log-likelihood with respect to y, i.e. one forward + one reverse pass of the recurrences."""
+        t, _, resid, real, cplx, squeeze = self._prepare(y)
+        with torch.enable_grad():
+            r = resid.detach().requires_grad_(True)
+            ll = celerite_loglike(t.detach(), r, self._diag.detach().contiguous(), real.detach(), cplx.detach())
+            (g,) = torch.autograd.grad(ll.sum(), r)
+        alpha = -g
+        return alpha[0] if squeeze else alpha
+
+    def predict(self, y, t=None, *, include_mean=True, block=4096):
+        """Conditional mean of the process given ``y`` (celerite2's ``GaussianProcess.predict``
+        without the variance), detached.  At the data times (``t=None``) it is
+        ``y - diag * alpha``; at other times ``K(t, t_data) alpha`` is formed densely in blocks
+        of ``block`` prediction times (O(N M): meant for plots, not for the sampling loop)."""
+        tt, mean, resid, real, cplx, squeeze = self._prepare(y)
+        alpha = self.apply_inverse(y)
+        alpha2 = alpha if alpha.dim() == 2 else alpha.unsqueeze(0)
+        if t is None:
+            mu = resid.detach() - self._diag.detach() * alpha2
+            tq = tt
+        else:
+            tq = as_tensor(t, tt)
+            if tq.dim() != 1:
+                raise ValueError("dimension mismatch: t must be 1-D")
+            out = []
+            re, cx = real.detach(), cplx.detach()
+            for i0 in range(0, tq.shape[0], block):
+                tau = (tq[i0:i0 + block, None] - tt[None, :]).abs()        # (M, N)
+                rows = []
+                for d in range(alpha2.shape[0]):                           # plots: a handful of draws
+                    kv = torch.zeros_like(tau)
+                    for j in range(re.shape[1]):
+                        kv = kv + re[d, j, 0] * torch.exp(-re[d, j, 1] * tau)
+                    for j in range(cx.shape[1]):
+                        a, b, c, dd = cx[d, j]
+                        kv = kv + torch.exp(-c * tau) * (a * torch.cos(dd * tau) + b * torch.sin(dd * tau))
+                    rows.append(kv @ alpha2[d])
+                out.append(torch.stack(rows))
+            mu = torch.cat(out, dim=-1)
+        if include_mean:
+            m = self.mean(tq) if callable(self.mean) else as_tensor(self.mean, tt)
+            if isinstance(m, torch.Tensor) and m.dim() == 1 and m.shape[0] != tq.shape[0]:
+                m = m.unsqueeze(-1)
+            if isinstance(m, torch.Tensor) and m.dim() >= 1 and m.shape[-1] == tt.shape[0] and t is not None:
+                raise ValueError("a tabulated mean cannot be evaluated at new times: pass a callable mean")
+            mu = mu + (m.detach() if isinstance(m, torch.Tensor) else m)
+        return mu[0] if squeeze else mu

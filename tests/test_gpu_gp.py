@@ -159,3 +159,31 @@ def test_transit_plus_gp_end_to_end(dev):
     assert abs(r.grad.item() - fd) < 2e-5 * abs(fd)
     fd = (oracle(0.1, 3.5 + 1e-8) - oracle(0.1, 3.5 - 1e-8)) / 2e-8
     assert abs(period.grad.item() - fd) < 1e-4 * abs(fd)
+
+
+def test_predict_and_apply_inverse_vs_dense(dev):
+    """GaussianProcess.apply_inverse / predict (conditional mean at the data times and at new
+    times) against the dense definition K (K + diag)^-1 (y - mean)"""
+    import exoplanet_amd as xo
+    from exoplanet_amd.gp import terms
+
+    rng = np.random.default_rng(21)
+    N = 300
+    t = np.sort(rng.uniform(0, 25, N))
+    y = 0.4 * rng.normal(size=N) + 1.0
+    yerr = 0.2
+    ts = np.linspace(-1, 26, 57)
+    kernel = terms.SHOTerm(sigma=T(0.8, dev), rho=T(5.0, dev), Q=T(0.7, dev)) + terms.RealTerm(a=T(0.3, dev), c=T(0.2, dev))
+    gp = xo.gp.GaussianProcess(kernel, t=T(t, dev), yerr=yerr, mean=1.0)
+
+    def kfun(tau):
+        return kernel.get_value(T(tau, dev)).cpu().numpy()
+
+    K = kfun(t[:, None] - t[None, :])
+    Ks = kfun(ts[:, None] - t[None, :])
+    alpha = np.linalg.solve(K + yerr**2 * np.eye(N), y - 1.0)
+    np.testing.assert_allclose(gp.apply_inverse(T(y, dev)).cpu().numpy(), alpha, rtol=1e-8, atol=1e-9)
+    np.testing.assert_allclose(gp.predict(T(y, dev)).cpu().numpy(), 1.0 + K @ alpha, rtol=1e-8, atol=1e-9)
+    np.testing.assert_allclose(gp.predict(T(y, dev), t=T(ts, dev)).cpu().numpy(), 1.0 + Ks @ alpha, rtol=1e-8, atol=1e-9)
+    np.testing.assert_allclose(gp.predict(T(y, dev), t=T(ts, dev), include_mean=False).cpu().numpy(), Ks @ alpha,
+                               rtol=1e-8, atol=1e-9)
