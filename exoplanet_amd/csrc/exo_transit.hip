@@ -2,15 +2,18 @@
 // part of the hot path (gfx950, wave64, fp64 VALU; no MFMA -- nothing here is a
 // dense contraction).
 //
-// Work decomposition
-//   grid.x : runs of tiles_per_block tiles of kBlock consecutive cadences
-//   grid.y : posterior draws (independent parameter sets)
-//   lane   : one cadence (all sub-exposures and planets are register loops, so
-//            a wave is 64 consecutive cadences: transits are contiguous in time
-//            and whole waves are uniformly in / out of transit except at edges)
-//   t, gflux, flux: coalesced 8-B-per-lane streams; per-(draw, planet) constants
-//            are derived once per block by the first lanes and staged in LDS,
-//            then read back as broadcasts.
+// One light-curve sweep (value, or value + VJP) is four launches:
+//   transit_window_kernel   per (draw, planet): where in mean anomaly an overlap is possible
+//   transit_scan_kernel     classify blocks: which cadences can overlap the disk -> per-wave work
+//                           lists (inside / limb);  fill blocks: flux = 0 everywhere
+//   transit_heavy_kernel    the listed cadences, dense: Kepler solve, solution vector, flux and
+//                           (GRAD) the reverse sweep into per-block gradient partials
+//   transit_vjp_reduce_kernel   block partials -> gparams, gld, sum(gflux * flux)
+// Work units: a (draw, run of tiles_per_block tiles of 512 consecutive cadences); a lane owns
+// cadences (sub-exposures and planets are register loops), so a wave is a run of consecutive
+// cadences: transits are contiguous in time and whole waves are in / out of transit except at
+// the edges.  Per-(draw, planet) constants are derived once per block, staged in LDS and, in the
+// heavy kernel, pinned to scalar registers.
 //
 // Reference lines restated by the fused kernel (all under /root/reference/src/exoplanet):
 //   orbits/keplerian.py:324-334   M = (t - t0 - tref) n ; kepler(M, e)
@@ -303,15 +306,7 @@ __device__ __forceinline__ double eval_sample(double tt, const PlanetS& c, const
 }
 
 // ---------------------------------------------------------------------------
-// Kernel A -- "scan": classify every cadence of the block's tiles as active (some
-// planet / sub-exposure overlaps the stellar disk, or -- with windows -- the
-// cadence lies inside some planet's contact window) or inactive.
-//   inactive: flux = 0 is final, written here (the streaming part: read t 8 B,
-//             write flux 8 B per (draw, cadence), one cadence per lane);
-//   active:   the cadence's offset is appended to this wave's list (ballot +
-//             mbcnt prefix: no atomics, fixed order), for kernel B.
-// A carries no elliptic-integral code, so it runs at high occupancy; without
-// windows it is dominated by the Kepler solve per (planet, sub-exposure).
+// Scan kernel: the classifier
 // ---------------------------------------------------------------------------
 // one (planet, sub-exposure) sample of the classifier:
 //   0 = cannot overlap the disk,
@@ -347,8 +342,8 @@ __device__ __forceinline__ int classify_sample(double tt, const PlanetConst& c) 
   return (vis && !(b2 >= lim * lim)) ? ((b2 < lin * lin) ? 1 : 2) : 0;
 }
 
-// Kernel A -- "scan".  Two kinds of block share the launch, told apart by the parity of
-// blockIdx.x, so that both kinds are resident together on every CU:
+// The scan kernel.  Two kinds of block share the launch (classify blocks first in the dispatch
+// order, fill blocks after them), so that both kinds are resident together:
 //   * fill blocks zero flux for their run of cadences -- a pure stream of 16-B stores
 //     with nothing to wait for (the heavy kernel, ordered after this one on the stream,
 //     overwrites the active cadences).  Stores and loads share one in-order counter on
@@ -586,12 +581,11 @@ __global__ __launch_bounds__(kBlock) void transit_scan_kernel(
 }
 
 // ---------------------------------------------------------------------------
-// Kernel B -- "heavy": the active cadences of a block (the four wave lists of
-// kernel A, concatenated) processed densely, 256 at a time: Kepler solve again
-// (cheap next to what follows), solution vector with its elliptic integrals,
-// flux, and -- GRAD -- the reverse sweep into per-planet gradient slots that
-// live in registers for the whole block and are reduced once per planet:
-// wave shuffle tree, then waves in index order (bit-reproducible).
+// Heavy kernel: the cadences on the work lists of up to kMaxMerge scan blocks of one draw,
+// concatenated ("inside" runs first, then "limb" runs) and processed densely, 256 at a time:
+// Kepler solve in fp64, solution vector with its elliptic integrals, flux, and -- GRAD -- the
+// reverse sweep into per-planet gradient slots that live in LDS columns for the whole block
+// and are reduced once per planet in a fixed order (bit-reproducible).
 // ---------------------------------------------------------------------------
 // Sum the kBlock per-thread columns of accumulator slots [first, first + n) and write the n
 // totals to out[0..n).  Two passes through LDS in a fixed order (bit-reproducible): thread
