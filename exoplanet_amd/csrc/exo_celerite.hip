@@ -12,14 +12,17 @@
 //   solve_lower: F_n = P o (F_{n-1} + W_{n-1} z_{n-1}) ;  z_n = y_n - U_n . F_n
 //   loglike    = -1/2 sum (z_n^2 / d_n + log d_n) - N/2 log 2 pi
 //
-// The recurrence is strictly sequential in time, so parallelism is over draws and,
-// inside a draw, over the J state indices: a draw occupies G = next_pow2(J) adjacent
-// lanes (lane j owns row j of S), exchanging values by DPP.  Everything that does
-// not depend on the recurrence (U_n, V_n, P_n: sin / cos / exp) is produced by a
-// fully parallel pre-pass; the log-determinant accumulates as (mantissa, exponent).
-// The saved factorisation (needed by the reverse recurrence) is laid out
-// [quantity][cadence][draw x state index] so that a wave's stores and loads are
-// coalesced, and is read back through a software prefetch ring.
+// Two paths.  Sequential (first half of this file; value-only calls, J > 6, short series, draws
+// the other path cannot take): parallelism over draws and, inside a draw, over the J state
+// indices -- a draw occupies G = next_pow2(J) adjacent lanes (lane j owns row j of S), exchanging
+// values by DPP; everything that does not depend on the recurrence (U_n, V_n, P_n: sin / cos /
+// exp) comes from a fully parallel pre-pass; the log-determinant accumulates as (mantissa,
+// exponent); the saved factorisation (needed by the reverse recurrence) is laid out
+// [quantity][cadence][draw x state index] so that a wave's stores and loads are coalesced, and is
+// read back through a software prefetch ring.  Time-parallel (second half, the default with a
+// state buffer): the series is cut into chunks whose entering states -- and, in reverse, their
+// adjoints -- come from Kalman filtering elements and a short scan over the chunks, after which
+// the same recurrences run inside all chunks at once (see the comment block there).
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
