@@ -624,7 +624,7 @@ __global__ __launch_bounds__(kBlock, EXO_HEAVY_MIN_WAVES) void transit_heavy_ker
     const double* __restrict__ params, const double* __restrict__ ld, int n_planet, uint32_t flags,
     int tiles_per_block, int blocks_per_draw, int merge, const int32_t* __restrict__ counts,
     const int32_t* __restrict__ list, const double* __restrict__ gflux, double* __restrict__ flux,
-    double* __restrict__ partial) {
+    double* __restrict__ partial, const double* __restrict__ windows) {
   __shared__ Shared sh;
   __shared__ int s_pre[2 * kWaves * kMaxMerge + 1];
   const int64_t draw = blockIdx.y;
@@ -667,8 +667,21 @@ __global__ __launch_bounds__(kBlock, EXO_HEAVY_MIN_WAVES) void transit_heavy_ker
   double cld[6];
 #pragma unroll
   for (int k = 0; k < 6; ++k) cld[k] = uniform((SECONDARY || k < 3) ? sh.c[k] : 0.0);
+  // Several planets share one work list (a cadence is listed if ANY planet may overlap): a round
+  // whose cadences are all away from planet p's conjunction windows is skipped for p on a wave
+  // vote (the same five-operation test as the scan kernel's first stage), before any Kepler solve.
+  const bool use_win = windows && n_planet > 1;
+  double spanw = (flags & EXO_FLAG_WINDOW) ? 0.5 : 0.0;
+  if (use_win && !(flags & EXO_FLAG_WINDOW))
+    for (int k = 0; k < n_sub; ++k) spanw = fmax(spanw, fabs(sh.sdt[k]));
   for (int p = 0; p < n_planet; ++p) {
     const PlanetS c(sh.pc[p]);
+    double w_nrev = 0.0, w_c0 = 0.0, w_dmid = 0.0, w_h0 = 0.0, w_h1 = 0.0;
+    if (use_win) {
+      const double* wv = windows + kWin * (draw * n_planet + p);
+      w_nrev = uniform(wv[0]); w_c0 = uniform(wv[1]); w_dmid = uniform(wv[2]);
+      w_h0 = uniform(wv[3]); w_h1 = uniform(wv[4]);
+    }
     if (GRAD && p > 0) {
 #pragma unroll
       for (int s = 0; s < kNG; ++s) lds_acc[s][threadIdx.x] = 0.0;
@@ -690,6 +703,11 @@ __global__ __launch_bounds__(kBlock, EXO_HEAVY_MIN_WAVES) void transit_heavy_ker
       const int64_t i = (int64_t)(bx0 + rem / kWaves) * tiles_per_block * kTile + off;
       const double tv = t[i];
       const double te = (n_texp == 0) ? 0.0 : (n_texp == 1 ? texp[0] : texp[i]);
+      if (use_win) {
+        const double widen = fabs(te) * spanw * fabs(w_nrev);
+        const bool near = has && near_conjunction<SECONDARY>(tv, w_nrev, w_c0, w_dmid, w_h0 + widen, w_h1 + widen);
+        if (!EXO_WAVE_ANY(near)) continue;   // the fill left this planet's flux at zero
+      }
       double g = 0.0;
       if (GRAD && has) g = per_planet ? gflux[(draw * n_cad + i) * n_planet + p] : gflux[draw * n_cad + i];
       double f = 0.0;
@@ -1013,14 +1031,15 @@ int exo_transit_flux_fwd_ev_f64(const double* t, int64_t n_cad, const double* te
   if (launch_status() != EXO_OK) return EXO_ERR_LAUNCH;
   const int merge = heavy_merge(n_draw, bpd);
   const dim3 hgrid((unsigned)((bpd + merge - 1) / merge), (unsigned)n_draw);
+  const double* hwin = ((flags & EXO_FLAG_EXACT_SCAN) && !(flags & EXO_FLAG_WINDOW)) ? nullptr : w.windows;
   if (secondary)
     hipLaunchKernelGGL((transit_heavy_kernel<false, true>), hgrid, block, 0, st, t, n_cad, texp, n_texp, stencil_dt,
                        stencil_w, n_sub, params, ld, n_planet, flags, tpb, bpd, merge, w.counts, w.list, nullptr, flux,
-                       nullptr);
+                       nullptr, hwin);
   else
     hipLaunchKernelGGL((transit_heavy_kernel<false, false>), hgrid, block, 0, st, t, n_cad, texp, n_texp, stencil_dt,
                        stencil_w, n_sub, params, ld, n_planet, flags, tpb, bpd, merge, w.counts, w.list, nullptr, flux,
-                       nullptr);
+                       nullptr, hwin);
   if (ev_stop) (void)hipEventRecord((hipEvent_t)ev_stop, st);
   return launch_status();
 }
@@ -1070,15 +1089,16 @@ int exo_transit_flux_vjp_ev_f64(const double* t, int64_t n_cad, const double* te
   if (launch_status() != EXO_OK) return EXO_ERR_LAUNCH;
   const int merge = heavy_merge(n_draw, bpd);
   const int nhb = (bpd + merge - 1) / merge;
+  const double* hwin = ((flags & EXO_FLAG_EXACT_SCAN) && !(flags & EXO_FLAG_WINDOW)) ? nullptr : w.windows;
   const dim3 hgrid((unsigned)nhb, (unsigned)n_draw);
   if (secondary)
     hipLaunchKernelGGL((transit_heavy_kernel<true, true>), hgrid, block, 0, st, t, n_cad, texp, n_texp, stencil_dt,
                        stencil_w, n_sub, params, ld, n_planet, flags, tpb, bpd, merge, w.counts, w.list, gflux,
-                       flux_dst, w.partial);
+                       flux_dst, w.partial, hwin);
   else
     hipLaunchKernelGGL((transit_heavy_kernel<true, false>), hgrid, block, 0, st, t, n_cad, texp, n_texp, stencil_dt,
                        stencil_w, n_sub, params, ld, n_planet, flags, tpb, bpd, merge, w.counts, w.list, gflux,
-                       flux_dst, w.partial);
+                       flux_dst, w.partial, hwin);
   if (launch_status() != EXO_OK) return EXO_ERR_LAUNCH;
   hipLaunchKernelGGL(transit_vjp_reduce_kernel, dim3((unsigned)n_draw), dim3(kBlock), 0, st, w.partial, nhb,
                      n_planet, secondary, gparams, gld, flux_dot);
