@@ -686,30 +686,66 @@ __global__ __launch_bounds__(kBlock, EXO_HEAVY_MIN_WAVES) void transit_heavy_ker
 #pragma unroll
       for (int s = 0; s < kNG; ++s) lds_acc[s][threadIdx.x] = 0.0;
     }
-    for (int j0 = 0; j0 < total; j0 += kBlock) {
-      const int j = j0 + threadIdx.x;
-      const bool has = j < total;
-      // last segment whose start is <= j (empty segments share a start: the search lands past them)
-      int sgm = 0;
+    // Two-deep software pipeline over the rounds: the list entry of round r + 2 and the cadence
+    // data (t, texp, gflux) of round r + 1 are in flight while round r computes -- at two waves
+    // per SIMD nothing else hides the two dependent loads (list -> t, gflux) of a round.
+    auto list_index = [&](int jr, int64_t& base_cad) -> int {
+      int sgm = 0;   // last segment whose start is <= jr (empty segments share a start: the search lands past them)
 #pragma unroll
       for (int step = 32; step > 0; step >>= 1) {
         const int q = sgm + step;
-        if (q < nseg && j >= s_pre[q]) sgm = q;
+        if (q < nseg && jr >= s_pre[q]) sgm = q;
       }
-      const int pos = j - s_pre[sgm];
+      const int pos = jr - s_pre[sgm];
       const int kind = sgm / (kWaves * nsub), rem = sgm - kind * (kWaves * nsub);  // rem = sub * kWaves + wave
       const int64_t lbase = (((int64_t)draw * blocks_per_draw + bx0) * kWaves + rem) * (int64_t)cap;
-      const int off = has ? list[lbase + (kind ? cap - 1 - pos : pos)] : 0;
-      const int64_t i = (int64_t)(bx0 + rem / kWaves) * tiles_per_block * kTile + off;
-      const double tv = t[i];
-      const double te = (n_texp == 0) ? 0.0 : (n_texp == 1 ? texp[0] : texp[i]);
+      base_cad = (int64_t)(bx0 + rem / kWaves) * tiles_per_block * kTile;
+      return list[lbase + (kind ? cap - 1 - pos : pos)];
+    };
+    struct Item { int64_t i; double tv, te, g; };
+    auto load_item = [&](bool has_, int off_, int64_t base_) -> Item {
+      Item it;
+      it.i = has_ ? base_ + off_ : 0;
+      it.tv = t[it.i];
+      it.te = (n_texp == 0) ? 0.0 : (n_texp == 1 ? texp[0] : texp[it.i]);
+      it.g = 0.0;
+      if (GRAD && has_) it.g = per_planet ? gflux[(draw * n_cad + it.i) * n_planet + p] : gflux[draw * n_cad + it.i];
+      return it;
+    };
+    int64_t base_n = 0, base_nn = 0;
+    int off_n = 0, off_nn = 0;
+    {
+      const int j = threadIdx.x;
+      if (j < total) off_n = list_index(j, base_n);
+      if (j + kBlock < total) off_nn = list_index(j + kBlock, base_nn);
+    }
+    // (the gradient variant has no registers to spare for the data of a second round: it keeps
+    // only the list entry one round ahead)
+    constexpr bool kDeep = !GRAD;
+    Item nxt{0, 0.0, 0.0, 0.0};
+    if (kDeep) nxt = load_item((int)threadIdx.x < total, off_n, base_n);
+    for (int j0 = 0; j0 < total; j0 += kBlock) {
+      const int j = j0 + threadIdx.x;
+      const bool has = j < total;
+      Item cur;
+      if (kDeep) {
+        cur = nxt;
+        // round r + 1's data (its list entry arrived a round ago), round r + 2's list entry
+        if (j0 + kBlock < total) nxt = load_item(j + kBlock < total, off_nn, base_nn);
+        if (j + 2 * kBlock < total) off_nn = list_index(j + 2 * kBlock, base_nn);
+      } else {
+        cur = load_item(has, off_n, base_n);
+        off_n = off_nn; base_n = base_nn;
+        if (j + 2 * kBlock < total) off_nn = list_index(j + 2 * kBlock, base_nn);
+      }
+      const int64_t i = cur.i;
+      const double tv = cur.tv, te = cur.te;
       if (use_win) {
         const double widen = fabs(te) * spanw * fabs(w_nrev);
         const bool near = has && near_conjunction<SECONDARY>(tv, w_nrev, w_c0, w_dmid, w_h0 + widen, w_h1 + widen);
         if (!EXO_WAVE_ANY(near)) continue;   // the fill left this planet's flux at zero
       }
-      double g = 0.0;
-      if (GRAD && has) g = per_planet ? gflux[(draw * n_cad + i) * n_planet + p] : gflux[draw * n_cad + i];
+      const double g = cur.g;
       double f = 0.0;
       for (int k = 0; k < n_sub; ++k) {
         const double tt = fma(te, sh.sdt[k], tv);
