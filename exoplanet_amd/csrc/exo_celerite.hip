@@ -794,17 +794,26 @@ __global__ __launch_bounds__(kWave) void celerite_elem_kernel(
   double ti = t[n0], dt_prev = -1.0;
   co.uv(ti, U, V);
   dc.eval(V, n_real, Dl);
-  // The element is in information form: it needs a measurement variance that is not tiny next to
-  // the process variance (diag = 0 is a legal celerite model, but 1 / diag is not a number).
-  // Such draws are flagged here and redone by the sequential kernels.
-  double asum = 0.0;
+  // Conditioning.  The element is in information form (1 / diag) and lives in celerite's rotating
+  // frame, where a complex term's state covariance Delta0 has condition number ~ 4 (b / a)^2: the
+  // J x J solves of the scans lose about  kappa = (1 + max (b/a)^2) sum(a) / min(diag)  times 1e-13
+  // in the gradients (measured against the sequential kernels over random kernels,
+  // tools/gp_cond_scan.py: 1e-9 at kappa = 1e4, 2e-8 at 1e5, 1e-4 at 1e7).  Draws with kappa > 1e5
+  // -- celerite2's Matern-3/2 term (b / a = 100 w0), an SHO term within a few per cent of critical
+  // damping, a signal 1e5 times the white noise, diag = 0 -- are flagged here and redone by the
+  // sequential kernels.  (A whitened state basis would lift the (b / a)^2 factor: DESIGN.md 8.)
+  double asum = 0.0, ba2 = 0.0;
 #pragma unroll
-  for (int j = 0; j < J; ++j) asum += (co.k[j].real || !co.k[j].odd) ? fabs(co.k[j].a) : 0.0;
+  for (int j = 0; j < J; ++j) {
+    asum += (co.k[j].real || !co.k[j].odd) ? fabs(co.k[j].a) : 0.0;
+    if (!co.k[j].real && !co.k[j].odd) ba2 = fmax(ba2, (co.k[j].b * co.k[j].b) / (co.k[j].a * co.k[j].a));
+  }
+  const double rmin = (1.0 + ba2) * asum * 1e-5;
   bool ok = true;
 #pragma unroll 1
   for (int64_t i = n0; i < n1; ++i) {
     const double yi = y[i], R = dg[i];
-    ok = ok && (R > 1e-10 * asum) && (R < INFINITY);
+    ok = ok && (R >= rmin) && (R < INFINITY);
     double r[J], cu[J];
     double s = R, zeta = yi;
 #pragma unroll

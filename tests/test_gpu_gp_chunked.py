@@ -170,3 +170,41 @@ def test_no_white_noise_falls_back(dev):
     for g, w in zip(got[1:], want[1:]):
         if w.size:
             assert np.abs(g - w).max() / (np.abs(w).max() + 1e-300) < 2e-9
+
+
+def test_ill_conditioned_terms_stay_sequential(dev):
+    """celerite2's Matern-3/2 term is a complex term with b / a = 100 w0: in celerite's rotating
+    frame its state covariance has a condition number ~ 4 (b/a)^2, and the J x J solves of the
+    chunk scans would lose that many digits.  The element kernel's conditioning score sends such
+    draws (and signals > 1e5 x the white noise) to the sequential kernels: identical numbers."""
+    import exoplanet_amd as xo
+    from exoplanet_amd.gp import terms
+
+    rng = np.random.default_rng(15)
+    N, D = 800, 6
+    t = T(np.sort(rng.uniform(0, 30, N)), dev)
+    y = T(0.3 * rng.normal(size=(D, N)), dev)
+    sig = T(0.5 * (1 + 0.1 * rng.normal(size=D)), dev, True)
+    rho = T(3.0 * (1 + 0.1 * rng.normal(size=D)), dev, True)
+
+    def both(make_kernel, yerr):
+        out = []
+        for c in (0, None):
+            with chunks(c):
+                gp = xo.gp.GaussianProcess(make_kernel(), t=t, yerr=yerr)
+                ll = gp.log_likelihood(y)
+                g = torch.autograd.grad(ll.sum(), (sig, rho))
+                out.append([x.detach().cpu().numpy() for x in (ll,) + g])
+        return out
+
+    seq, par = both(lambda: terms.Matern32Term(sigma=sig, rho=rho), 0.05)
+    for a, b in zip(seq, par):
+        np.testing.assert_array_equal(a, b)
+    # a well-conditioned term at the same noise level takes the time-parallel path: close, not identical
+    seq, par = both(lambda: terms.SHOTerm(sigma=sig, rho=rho, Q=0.8), 0.05)
+    assert not np.array_equal(seq[0], par[0])
+    np.testing.assert_allclose(par[0], seq[0], rtol=1e-12)
+    # ... until the noise is 1e-6 of the signal
+    seq, par = both(lambda: terms.SHOTerm(sigma=sig, rho=rho, Q=0.8), 5e-4)
+    for a, b in zip(seq, par):
+        np.testing.assert_array_equal(a, b)
