@@ -266,7 +266,9 @@ def main():
             },
         }
 
-    if not args.no_extras:
+    # the extra legs are single-GPU diagnostics: under torch.distributed.run they would only add
+    # barriers that every rank has to reach (an exception on one rank would hang the others)
+    if not args.no_extras and world == 1:
         # reference-default semantics (use_in_transit=True): same step, windows on.  Not `value`.
         ex_steps = max(5, args.steps // 2)
         ev2 = HipEvents(ex_steps)
