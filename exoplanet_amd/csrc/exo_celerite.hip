@@ -28,6 +28,9 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include <mutex>
+#include <unordered_map>
+
 #include "../../include/exoplanet_amd.h"
 
 namespace {
@@ -1650,6 +1653,29 @@ __global__ __launch_bounds__(kWave) void celerite_chunk_gcoef_kernel(int64_t n_d
   }
 }
 
+// The chunk plan a forward call used, remembered per state buffer: the reverse call must cut the
+// series the same way even if EXO_GP_CHUNKS changed in between.
+struct PlanBook {
+  std::mutex mu;
+  std::unordered_map<const void*, ChunkGeom> used;
+  void put(const void* state, const ChunkGeom& g) {
+    std::lock_guard<std::mutex> lock(mu);
+    if (used.size() > 4096) used.clear();
+    used[state] = g;
+  }
+  bool get(const void* state, ChunkGeom* g) {
+    std::lock_guard<std::mutex> lock(mu);
+    const auto it = used.find(state);
+    if (it == used.end()) return false;
+    *g = it->second;
+    return true;
+  }
+};
+inline PlanBook& plan_book() {
+  static PlanBook b;
+  return b;
+}
+
 inline int launch_status() { return hipGetLastError() == hipSuccess ? EXO_OK : EXO_ERR_LAUNCH; }
 
 inline bool gp_args_ok(int64_t n, int64_t n_diag, int32_t n_real, int32_t n_complex, int64_t n_draw) {
@@ -1714,6 +1740,12 @@ int exo_celerite_loglike_fwd_f64(const double* t, const double* resid, const dou
   if (state) {
     ChunkGeom cg = chunk_plan(n, n_draw, J);
     cg.base = n * n_draw * (int64_t)(2 + 2 * J + J * J + 3 * J);
+    if (cg.C > 1) {
+      // the caller sized `state` with exo_celerite_state_doubles(), possibly under another setting
+      const ChunkWs need{n_draw, J, cg.C, cg.base};
+      if (state_doubles < cg.base + need.total()) { cg.C = 1; cg.L = n; }
+    }
+    plan_book().put(state, cg);
     const double* only_flagged = nullptr;
     if (cg.C <= 1) {
       const int64_t n_el = n * n_draw * J;
@@ -1774,8 +1806,11 @@ int exo_celerite_loglike_vjp_f64(const double* t, const double* diag, int64_t n_
   const int64_t per_wave = kWave / G;
   const dim3 grid((unsigned)((n_draw + per_wave - 1) / per_wave)), block(kWave);
   hipStream_t st = (hipStream_t)stream;
-  ChunkGeom cg = chunk_plan(n, n_draw, J);
-  cg.base = n * n_draw * (int64_t)(2 + 2 * J + J * J + 3 * J);
+  ChunkGeom cg;
+  if (!plan_book().get(state, &cg)) {   // a state buffer this process did not fill: the default plan
+    cg = chunk_plan(n, n_draw, J);
+    cg.base = n * n_draw * (int64_t)(2 + 2 * J + J * J + 3 * J);
+  }
   const double* only_flagged = nullptr;
   if (cg.C > 1) {
     double* wstate = const_cast<double*>(state);   // the chunk workspace lives behind the saved factorisation

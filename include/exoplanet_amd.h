@@ -192,9 +192,11 @@ int exo_transit_flux_vjp_ev_f64(const double* t, int64_t n_cad, const double* te
  * reverse pass, its adjoint), and the ordinary recurrences then run inside all chunks at
  * once.  Same results as the sequential recurrences (1e-14 relative in loglike); draws whose
  * terms do not admit the filter form (a <= 0 or |b d| > a c for some term) are redone by the
- * sequential kernels on the device.  The environment variable EXO_GP_CHUNKS, read at call
- * time (also by exo_celerite_state_doubles: call it under the same setting), forces the
- * number of chunks; 0 keeps everything sequential.
+ * sequential kernels on the device.  The environment variable EXO_GP_CHUNKS, read by the
+ * forward call (and by exo_celerite_state_doubles; a buffer sized under another setting that
+ * turns out too small simply selects the sequential path), forces the number of chunks; 0
+ * keeps everything sequential.  The reverse call cuts the series the way the forward call
+ * that filled its state buffer did.
  * ------------------------------------------------------------------------- */
 #define EXO_GP_MAX_J 8
 int64_t exo_celerite_state_doubles(int64_t n, int64_t n_draw, int32_t n_real, int32_t n_complex);

@@ -208,3 +208,29 @@ def test_ill_conditioned_terms_stay_sequential(dev):
     seq, par = both(lambda: terms.SHOTerm(sigma=sig, rho=rho, Q=0.8), 5e-4)
     for a, b in zip(seq, par):
         np.testing.assert_array_equal(a, b)
+
+
+def test_reverse_pass_follows_the_forward_plan(dev):
+    """EXO_GP_CHUNKS changing between the forward and the reverse call (or between the sizing of the
+    state buffer and the forward call) must not change what the reverse pass reads"""
+    from exoplanet_amd.gp import celerite_loglike
+
+    rng = np.random.default_rng(16)
+    N, D = 1200, 5
+    t = np.sort(rng.uniform(0, 40, N))
+    y = 0.4 * rng.normal(size=(D, N))
+    diag = np.full((1, N), 0.05)
+    cr, cc = batch(rng, "mixed_j5", D)
+    with chunks(0):
+        want = value_and_grads(dev, t, y, diag, cr, cc)
+    tt, yt, dt = T(t, dev), T(y, dev, True), T(diag, dev)
+    crt, cct = T(cr, dev, True), T(cc, dev, True)
+    with chunks(9):
+        ll = celerite_loglike(tt, yt, dt, crt, cct)
+    w = torch.linspace(0.5, 1.5, D, dtype=torch.float64, device=ll.device)
+    with chunks(31):
+        (ll * w).sum().backward()
+    np.testing.assert_allclose(ll.detach().cpu().numpy(), want[0], rtol=1e-12)
+    for g, wv in zip((yt.grad, crt.grad, cct.grad), (want[1], want[3], want[4])):
+        g = g.cpu().numpy()
+        assert np.abs(g - wv).max() / (np.abs(wv).max() + 1e-300) < 2e-9
