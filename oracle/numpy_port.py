@@ -945,6 +945,123 @@ def celerite_matrices(t, diag, coeffs):
     return c, a, U, V
 
 
+# ------------------------------------------------------------------------------------------
+# The same log-likelihood in parallel over time (restates exoplanet_amd/csrc/exo_celerite.hip,
+# second half).  The recurrences are a Kalman filter: with a symmetric Delta_n such
+# that Delta_n U_n = V_n,  P_n = Delta_n - S_n  is the one-step prediction covariance and F_n its
+# mean.  A run of cadences acts on the entering (F, P) as a filtering element (A, b, C, eta, J) of
+# Sarkka & Garcia-Fernandez (2021, IEEE TAC 66, "Temporal parallelization of Bayesian smoothers"):
+#     F' = A (I + P J)^-1 (F + P eta) + b ,     P' = A (I + P J)^-1 P A^T + C
+# and its log-likelihood given the entering state is
+#     const - 1/2 log det(I + P J) + 1/2 eta^T Y P eta + eta^T Y F - 1/2 F^T J Y F ,  Y = (I + P J)^-1.
+# ------------------------------------------------------------------------------------------
+def celerite_delta(coeffs, V_n):
+    """Delta_n (J x J): 1/a for a real term; H Delta0 H for a complex pair, Delta0 = [[p, q], [q, r]],
+    r = a/(a^2+b^2), q = -b/(a^2+b^2), p = (a^2+2b^2)/(a(a^2+b^2)), H = [[cs, sn], [sn, -cs]]."""
+    ar, cr, ac, bc, cc, dc = [np.asarray(x, dtype=np.float64) for x in coeffs]
+    Jr, Jc = ar.size, ac.size
+    D = np.zeros((Jr + 2 * Jc, Jr + 2 * Jc))
+    for j in range(Jr):
+        D[j, j] = 1.0 / ar[j]
+    for j in range(Jc):
+        a, b = ac[j], bc[j]
+        h = 1.0 / (a * a + b * b)
+        D0 = np.array([[(a * a + 2 * b * b) * h / a, -b * h], [-b * h, a * h]])
+        cs, sn = V_n[Jr + 2 * j], V_n[Jr + 2 * j + 1]
+        H = np.array([[cs, sn], [sn, -cs]])
+        D[Jr + 2 * j:Jr + 2 * j + 2, Jr + 2 * j:Jr + 2 * j + 2] = H @ D0 @ H
+    return D
+
+
+def celerite_chunk_element(t, y, diag, coeffs, n0, n1):
+    """Filtering element (A, b, C, eta, Jm) of cadences [n0, n1): the filter run from (0, 0) beside
+    the two sensitivity matrices A, Jm.  The last step of the series has no propagation."""
+    c, a, U, V = celerite_matrices(t, diag, coeffs)
+    J = U.shape[1]
+    A = np.eye(J); b = np.zeros(J); C = np.zeros((J, J)); eta = np.zeros(J); Jm = np.zeros((J, J))
+    for i in range(n0, n1):
+        u, R = U[i], diag[i]
+        r, cu = A.T @ u, C @ u
+        s, zeta = R + u @ cu, y[i] - u @ b
+        Jm += np.outer(r, r) / s
+        eta += r * zeta / s
+        if i + 1 < t.size:
+            phi = np.exp(-c * (t[i + 1] - t[i]))
+            Q = celerite_delta(coeffs, V[i + 1]) - np.outer(phi, phi) * celerite_delta(coeffs, V[i])
+            k = cu / s
+            A = phi[:, None] * (A - np.outer(k, r))
+            b = phi * (b + k * zeta)
+            C = np.outer(phi, phi) * (C - np.outer(k, cu)) + Q
+    return A, b, C, eta, Jm
+
+
+def celerite_apply_element(el, F, P):
+    A, b, C, eta, Jm = el
+    Y = np.linalg.inv(np.eye(F.size) + P @ Jm)
+    Pn = A @ Y @ P @ A.T + C
+    return A @ Y @ (F + P @ eta) + b, 0.5 * (Pn + Pn.T)
+
+
+def celerite_chunk_loglike_closed_form(el, F, P, n_cad, const):
+    """log p(y_chunk | entering state) from the element alone; `const` = the value at (F, P) = (0, 0)"""
+    _, _, _, eta, Jm = el
+    Y = np.linalg.inv(np.eye(F.size) + P @ Jm)
+    return (const - 0.5 * np.linalg.slogdet(np.eye(F.size) + P @ Jm)[1] + 0.5 * eta @ Y @ P @ eta
+            + eta @ Y @ F - 0.5 * F @ Jm @ Y @ F)
+
+
+def celerite_run_chunk(t, y, diag, coeffs, n0, n1, F, S):
+    """the ordinary recurrences over [n0, n1) from the entering (F, S); returns the chunk's
+    sum (z^2/d + log d)"""
+    c, a, U, V = celerite_matrices(t, diag, coeffs)
+    acc = 0.0
+    for n in range(n0, n1):
+        if n > n0:
+            Pp = np.exp(-c * (t[n] - t[n - 1]))
+            S = np.outer(Pp, Pp) * (S + d * np.outer(W, W))
+            F = Pp * (F + W * z)
+        u = S @ U[n]
+        d = a[n] - U[n] @ u
+        W = (V[n] - u) / d
+        z = y[n] - U[n] @ F
+        acc += z * z / d + np.log(d)
+    return acc
+
+
+def celerite_loglike_chunked(t, y, diag, coeffs, n_chunks):
+    """celerite_loglike by the time-parallel algorithm: elements per chunk, a scan over the chunks
+    for the entering states, the ordinary recurrences per chunk from those states."""
+    t = np.asarray(t, dtype=np.float64); y = np.asarray(y, dtype=np.float64)
+    diag = np.asarray(diag, dtype=np.float64) + np.zeros_like(t)
+    N = t.size
+    L = -(-N // n_chunks)
+    bounds = [(n0, min(N, n0 + L)) for n0 in range(0, N, L)]
+    _, _, _, V = celerite_matrices(t, diag, coeffs)
+    J = V.shape[1]
+    F, P = np.zeros(J), celerite_delta(coeffs, V[0])          # S_0 = 0
+    acc = 0.0
+    for k, (n0, n1) in enumerate(bounds):
+        acc += celerite_run_chunk(t, y, diag, coeffs, n0, n1, F, celerite_delta(coeffs, V[n0]) - P)
+        if k + 1 < len(bounds):
+            F, P = celerite_apply_element(celerite_chunk_element(t, y, diag, coeffs, n0, n1), F, P)
+    return -0.5 * acc - 0.5 * N * np.log(2 * np.pi)
+
+
+def celerite_chunk_adjoint_step(el, F, P, Fbar_next, Pbar_next, gL=1.0):
+    """one step of the reverse scan over the chunks: the adjoint of the state (F, P) entering a chunk
+    from the adjoint of the state entering the next one -- local term from the closed-form chunk
+    likelihood plus the transposed element map (Abar = A Y, g = eta - Jm Y (F + P eta))."""
+    A, b, C, eta, Jm = el
+    Y = np.linalg.inv(np.eye(F.size) + P @ Jm)
+    w = Y.T @ (eta - Jm @ F)
+    g = eta - Jm @ Y @ (F + P @ eta)
+    Ab = A @ Y
+    x = Ab.T @ Fbar_next
+    Fbar = gL * w + x
+    Pbar = 0.5 * gL * (np.outer(w, w) - Jm @ Y) + Ab.T @ Pbar_next @ Ab + 0.5 * (np.outer(x, g) + np.outer(g, x))
+    return Fbar, 0.5 * (Pbar + Pbar.T)
+
+
 def celerite_loglike(t, y, diag, coeffs):
     """O(N J^2) semiseparable Cholesky + forward substitution -> log-likelihood."""
     c, a, U, V = celerite_matrices(t, diag, coeffs)

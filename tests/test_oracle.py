@@ -184,3 +184,121 @@ def test_reference_properties_on_oracle():
     y = P.SecondaryEclipseLightCurve(u1, u2, s).get_light_curve(orbit=o1, r=ror, t=t)
     f = ror ** 2 * s
     assert np.allclose((y1 + f * y2) / (1 + f), y, atol=5e-6)
+
+
+# ---------------------------------------------------------------------------------------------
+# celerite in parallel over time: the numpy restatement of the algorithm the HIP kernels run
+# (oracle/numpy_port.py) against the sequential recurrence and the dense definition
+# ---------------------------------------------------------------------------------------------
+def _gp_case(rng, N=180):
+    t = np.sort(rng.uniform(0, 30, N))
+    y = 0.5 * rng.normal(size=N)
+    diag = 0.1 + 0.05 * rng.uniform(size=N)
+    co = (np.array([0.3]), np.array([0.2]), np.array([0.5, 0.2]), np.array([0.1, 0.05]),
+          np.array([0.3, 0.1]), np.array([2.0, 0.7]))
+    return t, y, diag, co
+
+
+def test_celerite_time_parallel_restatement_matches_sequential_and_dense():
+    rng = np.random.default_rng(31)
+    t, y, diag, co = _gp_case(rng)
+    want = P.celerite_loglike(t, y, diag, co)
+    dense, _ = P.gp_loglike_dense(t, y, diag, co)
+    assert abs(want - dense) < 1e-10 * abs(dense)
+    for n_chunks in (2, 5, 17):
+        got = P.celerite_loglike_chunked(t, y, diag, co, n_chunks)
+        assert abs(got - want) < 1e-11 * abs(want), n_chunks
+    # SHO term (the degenerate case |b d| = a c: Delta0 is the only admissible one)
+    co2 = P.sho_coefficients(*P.sho_from_sigma_rho(0.8, 5.0, 0.7), 0.7)
+    want2 = P.celerite_loglike(t, y, diag, co2)
+    assert abs(P.celerite_loglike_chunked(t, y, diag, co2, 7) - want2) < 1e-11 * abs(want2)
+
+
+def test_celerite_element_closed_form_likelihood_and_its_gradient():
+    """a chunk's log-likelihood as a function of its entering state: closed form from the element ==
+    running the recurrences from that state; its gradient w.r.t. (F, P) is what the reverse scan over
+    the chunks uses:  d/dF = Y^T (eta - J F),  d/dP = 1/2 (w w^T - J Y)."""
+    rng = np.random.default_rng(32)
+    t, y, diag, co = _gp_case(rng, N=90)
+    _, _, _, V = P.celerite_matrices(t, diag, co)
+    n0, n1 = 30, 61
+    el = P.celerite_chunk_element(t, y, diag, co, n0, n1)
+    J = V.shape[1]
+    Dl = P.celerite_delta(co, V[n0])
+    assert np.allclose(Dl @ P.celerite_matrices(t, diag, co)[2][n0], V[n0], rtol=1e-13, atol=1e-14)   # Delta U = V
+
+    def run(F, Pm):
+        return -0.5 * P.celerite_run_chunk(t, y, diag, co, n0, n1, F, Dl - Pm)
+
+    F0 = 0.1 * rng.normal(size=J)
+    B = rng.normal(size=(J, J))
+    P0 = 0.3 * Dl + 0.01 * B @ B.T
+    const = run(np.zeros(J), np.zeros((J, J)))
+    closed = P.celerite_chunk_loglike_closed_form(el, F0, P0, n1 - n0, const)
+    assert abs(closed - run(F0, P0)) < 1e-10 * abs(closed)
+    # gradient by central differences of the recurrences
+    A, b, C, eta, Jm = el
+    Y = np.linalg.inv(np.eye(J) + P0 @ Jm)
+    w = Y.T @ (eta - Jm @ F0)
+    gP = 0.5 * (np.outer(w, w) - Jm @ Y)
+    h = 1e-6
+    for j in range(J):
+        e = np.zeros(J); e[j] = h
+        assert abs((run(F0 + e, P0) - run(F0 - e, P0)) / (2 * h) - w[j]) < 1e-6 * (1 + abs(w[j]))
+    for j in range(J):
+        for l in range(j, J):
+            E = np.zeros((J, J)); E[j, l] = E[l, j] = h
+            fd = (run(F0, P0 + E) - run(F0, P0 - E)) / (2 * h)
+            an = gP[j, l] + gP[l, j] if l != j else gP[j, j]
+            assert abs(fd - an) < 1e-5 * (1 + abs(an)), (j, l)
+    # the element maps the entering state to the state entering the next chunk
+    Fn, Pn = P.celerite_apply_element(el, F0, P0)
+    c, a, U, Vv = P.celerite_matrices(t, diag, co)
+    S, F = Dl - P0, F0.copy()
+    for n in range(n0, n1):
+        if n > n0:
+            Pp = np.exp(-c * (t[n] - t[n - 1])); S = np.outer(Pp, Pp) * (S + d * np.outer(W, W)); F = Pp * (F + W * z)
+        u = S @ U[n]; d = a[n] - U[n] @ u; W = (Vv[n] - u) / d; z = y[n] - U[n] @ F
+    Pp = np.exp(-c * (t[n1] - t[n1 - 1])); S = np.outer(Pp, Pp) * (S + d * np.outer(W, W)); F = Pp * (F + W * z)
+    assert np.allclose(Fn, F, rtol=1e-10, atol=1e-12)
+    assert np.allclose(P.celerite_delta(co, Vv[n1]) - Pn, S, rtol=1e-9, atol=1e-11)
+
+
+def test_celerite_reverse_scan_over_chunks_by_finite_differences():
+    """adjoint of the state entering a chunk, accumulated over all later chunks by the reverse scan,
+    against central differences of the log-likelihood of the rest of the series"""
+    rng = np.random.default_rng(33)
+    t, y, diag, co = _gp_case(rng, N=120)
+    _, _, _, V = P.celerite_matrices(t, diag, co)
+    J = V.shape[1]
+    bounds = [(30, 55), (55, 90), (90, 120)]
+    els = [P.celerite_chunk_element(t, y, diag, co, a, b) for a, b in bounds]
+
+    def rest(F, Pm):   # log-likelihood of cadences 30.. given the state entering cadence 30
+        acc = 0.0
+        for k, (a, b) in enumerate(bounds):
+            acc += P.celerite_run_chunk(t, y, diag, co, a, b, F, P.celerite_delta(co, V[a]) - Pm)
+            if k + 1 < len(bounds):
+                F, Pm = P.celerite_apply_element(els[k], F, Pm)
+        return -0.5 * acc
+
+    F0 = 0.1 * rng.normal(size=J)
+    B = rng.normal(size=(J, J))
+    P0 = 0.3 * P.celerite_delta(co, V[30]) + 0.01 * B @ B.T
+    states = [(F0, P0)]
+    for k in range(len(bounds) - 1):
+        states.append(P.celerite_apply_element(els[k], *states[-1]))
+    Fb, Pb = np.zeros(J), np.zeros((J, J))
+    for k in reversed(range(len(bounds))):
+        Fb, Pb = P.celerite_chunk_adjoint_step(els[k], states[k][0], states[k][1], Fb, Pb)
+    h = 1e-6
+    for j in range(J):
+        e = np.zeros(J); e[j] = h
+        fd = (rest(F0 + e, P0) - rest(F0 - e, P0)) / (2 * h)
+        assert abs(fd - Fb[j]) < 1e-6 * (1 + abs(Fb[j])), j
+    for j in range(J):
+        for l in range(j, J):
+            E = np.zeros((J, J)); E[j, l] = E[l, j] = h
+            fd = (rest(F0, P0 + E) - rest(F0, P0 - E)) / (2 * h)
+            an = Pb[j, l] + Pb[l, j] if l != j else Pb[j, j]
+            assert abs(fd - an) < 2e-5 * (1 + abs(an)), (j, l)
