@@ -33,8 +33,16 @@ class _CeleriteLogLike(torch.autograd.Function):
         lib = _lib.load()
         need_grad = any(ctx.needs_input_grad)
         loglike = torch.empty(D, dtype=torch.float64, device=t.device)
-        nstate = lib.exo_celerite_state_doubles(N, D, n_real, n_complex) if need_grad else 0
-        state = torch.empty(nstate, dtype=torch.float64, device=t.device) if need_grad else None
+        # The state buffer is what the reverse pass re-reads, and it is also what lets the library run
+        # the recurrences in parallel over time: a value-only call gets one too (scratch, freed on
+        # return) unless the device cannot spare it, in which case the sequential kernels run.
+        nstate = lib.exo_celerite_state_doubles(N, D, n_real, n_complex)
+        try:
+            state = torch.empty(nstate, dtype=torch.float64, device=t.device)
+        except torch.cuda.OutOfMemoryError:
+            if need_grad:
+                raise
+            state, nstate = None, 0
         with torch.cuda.device(t.device):
             _lib.check(
                 lib.exo_celerite_loglike_fwd_f64(_ptr(t), _ptr(resid), _ptr(diag), diag.shape[0], N, _ptr(coef_real),

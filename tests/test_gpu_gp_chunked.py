@@ -234,3 +234,20 @@ def test_reverse_pass_follows_the_forward_plan(dev):
     for g, wv in zip((yt.grad, crt.grad, cct.grad), (want[1], want[3], want[4])):
         g = g.cpu().numpy()
         assert np.abs(g - wv).max() / (np.abs(wv).max() + 1e-300) < 2e-9
+
+
+def test_value_only_calls_take_the_time_parallel_path_too(dev):
+    from exoplanet_amd.gp import celerite_loglike
+
+    rng = np.random.default_rng(17)
+    N, D = 2000, 4
+    t = np.sort(rng.uniform(0, 50, N))
+    y = 0.4 * rng.normal(size=(D, N))
+    diag = np.full((1, N), 0.05)
+    cr, cc = batch(rng, "sho_q3", D)
+    with chunks(0):
+        want = celerite_loglike(T(t, dev), T(y, dev), T(diag, dev), T(cr, dev), T(cc, dev))
+    with chunks(None), torch.no_grad():
+        got = celerite_loglike(T(t, dev), T(y, dev), T(diag, dev), T(cr, dev), T(cc, dev))
+    assert not torch.equal(got, want)          # a different summation order: the chunked kernels ran
+    assert torch.allclose(got, want, rtol=1e-12)
