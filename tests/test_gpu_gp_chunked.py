@@ -143,7 +143,7 @@ def test_not_positive_definite_is_minus_inf_on_both_paths(dev):
     for c in (0, 5):
         with chunks(c):
             ll = celerite_loglike(T(t, dev), T(y, dev), T(diag, dev), T(cr, dev), T(cc, dev))
-            # forward-only calls save no state and stay sequential; ask for gradients to take the chunked path
+            # value-only and value + gradient calls
             yt = T(y, dev, True)
             ll2 = celerite_loglike(T(t, dev), yt, T(diag, dev), T(cr, dev), T(cc, dev))
         assert torch.isinf(ll).all() and (ll < 0).all()
