@@ -221,6 +221,7 @@ __device__ __forceinline__ double eval_sample(double tt, const PlanetS& c, const
   const double X2 = kh.X * kh.X, Y2 = kh.Y * kh.Y;
   const double cx = X2 - Y2;            // (1 - e cos E) cos f = cos E - e
   const double sx = 2.0 * kh.X * kh.Y;  // (1 - e cos E) sin f = sqrt(1-e^2) sin E
+  const double den = X2 + Y2;           // 1 - e cos E, without the cancellation at e -> 1
   // position relative to the star in units of R_star; the reference passes a = -self.a
   // (keplerian.py:540) and r = a (1-e^2)/(1+e cos f) = a (1 - e cos E)
   const double xo = -c.aor * cx, yo = -c.aor * sx;
@@ -292,9 +293,11 @@ __device__ __forceinline__ double eval_sample(double tt, const PlanetS& c, const
       acc.add(G_AOR, -(xobar * cx + yobar * sx));
       const double cxbar = -c.aor * xobar, sxbar = -c.aor * yobar;
       // cx = cos E - e, sx = sqrt(1-e^2) sin E ; dE/dM = 1/den, dE/de = sin E/den
-      const double sinE = 2.0 * kh.sh * kh.ch;
-      const double cosE = kh.ch * kh.ch - kh.sh * kh.sh;
-      const double iden = exo::fast_div(1.0, X2 + Y2);
+      // sin E, cos E back from (cx, sx) rather than from the half angles: two values live across the
+      // solution vector instead of six
+      const double sinE = sx * c.isq1me2;
+      const double cosE = cx + c.e;
+      const double iden = exo::fast_div(1.0, den);
       const double Ebar = fma(-sinE, cxbar, c.sq1me2 * cosE * sxbar);
       const double Mbar = Ebar * iden;
       acc.add(G_ECC, Mbar * sinE - cxbar - c.e * sinE * c.isq1me2 * sxbar);
