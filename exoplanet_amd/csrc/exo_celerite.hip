@@ -32,6 +32,7 @@
 #include <unordered_map>
 
 #include "../../include/exoplanet_amd.h"
+#include "exo_math.hpp"
 
 namespace {
 
@@ -152,7 +153,7 @@ __device__ __forceinline__ void lane_uv(const LaneCoef& k, double t, double* U, 
     return;
   }
   double s, c;
-  sincos(k.d * t, &s, &c);
+  exo::sincos_any(k.d * t, &s, &c);   // branch-free, no large-argument path: half the instructions and registers of libm's
   *cs = c; *sn = s;
   *U = k.odd ? (k.a * s - k.b * c) : (k.a * c + k.b * s);
   *V = k.odd ? s : c;
@@ -720,7 +721,7 @@ struct DrawCoef {
         U[j] = k[j].a; V[j] = 1.0;
       } else if (!k[j].odd) {
         double sn, cs;
-        sincos(k[j].d * t, &sn, &cs);
+        exo::sincos_any(k[j].d * t, &sn, &cs);
         U[j] = k[j].a * cs + k[j].b * sn; V[j] = cs;
         if (j + 1 < J) { U[j + 1] = k[j].a * sn - k[j].b * cs; V[j + 1] = sn; }
       }

@@ -185,6 +185,45 @@ EXO_HD void sincos_halfpi(double x, double* s, double* c) {
   *c = hi ? ps : pc;
 }
 
+// sin and cos of any argument, branch-free: quadrant by a five-term Cody-Waite reduction with
+// 24-bit pieces of pi/2 (every product k * piece is exact for |k| < 2^29, i.e. |x| < 8e8; beyond
+// that the rounding of x itself, half an ulp ~ 1e-7 rad, dwarfs anything a Payne-Hanek path could
+// add), then the Taylor polynomials of sincos_halfpi on [-pi/4, pi/4].  ~45 instructions and no
+// slow path: libm's sincos costs twice that and, inlined, the registers of its large-argument code.
+EXO_HD void sincos_any(double x, double* s, double* c) {
+  const double k = rint(x * 0.6366197723675814);
+  double y = fma(-k, 1.570796251296997, x);
+  y = fma(-k, 7.549789415861596e-08, y);
+  y = fma(-k, 5.390302529957765e-15, y);
+  y = fma(-k, 3.282003415807913e-22, y);
+  y = fma(-k, 1.270655753080676e-29, y);
+  const double y2 = y * y;
+  double ps = -2.8114572543455207632e-15;         // -1/17!
+  ps = fma(ps, y2, 7.6471637318198164759e-13);
+  ps = fma(ps, y2, -1.6059043836821614599e-10);
+  ps = fma(ps, y2, 2.5052108385441718775e-08);
+  ps = fma(ps, y2, -2.7557319223985890653e-06);
+  ps = fma(ps, y2, 1.9841269841269841270e-04);
+  ps = fma(ps, y2, -8.3333333333333333333e-03);
+  ps = fma(ps, y2, 1.6666666666666666667e-01);
+  ps = fma(-ps * y2, y, y);
+  double pc = 4.7794773323873852974e-14;          //  1/16!
+  pc = fma(pc, y2, -1.1470745597729724714e-11);
+  pc = fma(pc, y2, 2.0876756987868098979e-09);
+  pc = fma(pc, y2, -2.7557319223985890653e-07);
+  pc = fma(pc, y2, 2.4801587301587301587e-05);
+  pc = fma(pc, y2, -1.3888888888888888889e-03);
+  pc = fma(pc, y2, 4.1666666666666666667e-02);
+  pc = fma(pc, y2, -0.5);
+  pc = fma(pc, y2, 1.0);
+  // quadrant k mod 4: (s, c) = (ps, pc), (pc, -ps), (-ps, -pc), (-pc, ps)
+  const long long q = (long long)k;
+  const bool swap = q & 1, neg_s = q & 2, neg_c = (q + 1) & 2;
+  const double ss = swap ? pc : ps, cc = swap ? ps : pc;
+  *s = neg_s ? -ss : ss;
+  *c = neg_c ? -cc : cc;
+}
+
 // ---------------------------------------------------------------------------
 // Kepler solver.  Markley (1995) cubic starter + one fifth-order correction:
 // fixed cost, so there is nothing to vote on.
