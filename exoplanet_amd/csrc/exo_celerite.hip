@@ -159,17 +159,18 @@ __device__ __forceinline__ void lane_uv(const LaneCoef& k, double t, double* U, 
   *V = k.odd ? s : c;
 }
 
-// saved-state addressing.  Per draw: d, z at [q][n][draw]; per (draw, j): W, F and the
-// J entries of row j of S at [q][n][draw * J + j] -- lanes of a wave are consecutive
-// (draw, j), so a wave's stores / loads are contiguous.
+// saved-state addressing.  Per (cadence, draw): the pair (d, z), 16 B; per (cadence, draw, j): one
+// record (W_j, F_j, S_j0 .. S_j,J-1) of 2 + J doubles.  Lanes of a wave are consecutive (draw, j), so
+// a wave's records are contiguous and -- for even J -- move as 16-B accesses (8-B accesses reach
+// 0.54-0.70 of the 16-B rate: MI355X_MICROARCH.md).
 struct StateIdx {
   int64_t n, n_draw;
   int J;
   __device__ __forceinline__ int64_t scal(int q, int64_t i, int64_t draw) const {  // q = 0 (d), 1 (z)
-    return ((int64_t)q * n + i) * n_draw + draw;
+    return (i * n_draw + draw) * 2 + q;
   }
   __device__ __forceinline__ int64_t vec(int q, int64_t i, int64_t draw, int j) const {  // q = 0 (W), 1 (F), 2.. (S row)
-    return 2 * n * n_draw + (((int64_t)q * n + i) * n_draw + draw) * J + j;
+    return 2 * n * n_draw + ((i * n_draw + draw) * J + j) * (int64_t)(2 + J) + q;
   }
   // U_n, V_n, P_n (q = 0, 1, 2) written by the parallel pre-pass: the sequential kernels
   // never evaluate a sin, cos or exp
@@ -177,6 +178,41 @@ struct StateIdx {
     return (2 + (int64_t)(2 + J) * J) * n * n_draw + (((int64_t)q * n + i) * n_draw + draw) * J + j;
   }
 };
+
+// one record (W, F, S row) / one (d, z) pair, as 16-B accesses where the record length allows
+template <int J>
+__device__ __forceinline__ void store_record(double* __restrict__ p, double W, double F, const double* S) {
+  constexpr int R = 2 + J;
+  double v[R];
+  v[0] = W; v[1] = F;
+#pragma unroll
+  for (int l = 0; l < J; ++l) v[2 + l] = S[l];
+  if (R % 2 == 0) {
+#pragma unroll
+    for (int q = 0; q < R / 2; ++q) reinterpret_cast<double2*>(p)[q] = double2{v[2 * q], v[2 * q + 1]};
+  } else {
+#pragma unroll
+    for (int q = 0; q < R; ++q) p[q] = v[q];
+  }
+}
+template <int J>
+__device__ __forceinline__ void load_record(const double* __restrict__ p, double& W, double& F, double* S) {
+  constexpr int R = 2 + J;
+  double v[R];
+  if (R % 2 == 0) {
+#pragma unroll
+    for (int q = 0; q < R / 2; ++q) {
+      const double2 x = reinterpret_cast<const double2*>(p)[q];
+      v[2 * q] = x.x; v[2 * q + 1] = x.y;
+    }
+  } else {
+#pragma unroll
+    for (int q = 0; q < R; ++q) v[q] = p[q];
+  }
+  W = v[0]; F = v[1];
+#pragma unroll
+  for (int l = 0; l < J; ++l) S[l] = v[2 + l];
+}
 
 // Pre-pass, fully parallel over (cadence, draw, state index): everything in the
 // recurrences that does not depend on the recurrence itself.
@@ -248,16 +284,14 @@ __global__ __launch_bounds__(kWave) void celerite_fwd_kernel(
   int64_t lsum = lexp;
   double dt_prev = -1.0;
   if (store) {
-    if (j == 0) { state[six.scal(0, 0, draw)] = d; state[six.scal(1, 0, draw)] = z; }
-    state[six.vec(0, 0, draw, j)] = Wj;
-    state[six.vec(1, 0, draw, j)] = 0.0;
-#pragma unroll
-    for (int l = 0; l < J; ++l) state[six.vec(2 + l, 0, draw, j)] = 0.0;
+    if (j == 0) *reinterpret_cast<double2*>(state + six.scal(0, 0, draw)) = double2{d, z};
+    store_record<J>(state + six.vec(0, 0, draw, j), Wj, 0.0, Srow);   // S_0 = 0
   }
   // software prefetch ring: the loads of cadence i + kPF are issued while cadence i
   // computes (one wave per SIMD and a serial chain: nothing else hides HBM latency)
-  const int64_t vstride = n_draw * J;            // one cadence, in doubles, of a per-(draw, j) quantity
-  const int64_t qstride = n * vstride;           // one quantity
+  const int64_t vstride = n_draw * J;            // one cadence, in doubles, of a per-(draw, j) quantity (U, V, P)
+  const int64_t qstride = n * vstride;           // one quantity (U, V, P)
+  const int64_t rstride = vstride * (2 + J);     // one cadence of (W, F, S row) records
   double* __restrict__ p_vec = SAVE ? state + six.vec(0, 0, draw, jj) : nullptr;
   double* __restrict__ p_scal = SAVE ? state + six.scal(0, 0, draw) : nullptr;
   const double* __restrict__ p_uvp = SAVE ? state + six.uvp(0, 0, draw, jj) : nullptr;
@@ -332,13 +366,10 @@ __global__ __launch_bounds__(kWave) void celerite_fwd_kernel(
     lsum += lexp;
     if (store) {
       // running pointers: one add per cadence instead of a 64-bit index product per access
-      p_vec += vstride;
-      p_scal += n_draw;
-      if (j == 0) { p_scal[0] = d; p_scal[n * n_draw] = z; }
-      p_vec[0] = Wj;
-      p_vec[qstride] = Fj;
-#pragma unroll
-      for (int l = 0; l < J; ++l) p_vec[(2 + l) * qstride] = Srow[l];
+      p_vec += rstride;
+      p_scal += 2 * n_draw;
+      if (j == 0) *reinterpret_cast<double2*>(p_scal) = double2{d, z};
+      store_record<J>(p_vec, Wj, Fj, Srow);
     }
    }
   }
@@ -384,15 +415,16 @@ __global__ __launch_bounds__(kWave) void celerite_vjp_kernel(
   const double* __restrict__ sc0 = state + six.scal(0, 0, draw);
   const double* __restrict__ ve0 = state + six.vec(0, 0, draw, jj);
   const double* __restrict__ uv0 = state + six.uvp(0, 0, draw, jj);
+  const int64_t rstride = vstride * (2 + J);   // one cadence of (W, F, S row) records
   auto load = [&](int64_t i, double& d_, double& z_, double& W_, double& F_, double* S_) {
-    const double* ps = sc0 + i * n_draw;   // one index product per group of loads
-    const double* pv = ve0 + i * vstride;
-    d_ = ps[0];
-    z_ = ps[n * n_draw];
-    W_ = k.live ? pv[0] : 0.0;
-    F_ = k.live ? pv[qstride] : 0.0;
+    const double2 dz = *reinterpret_cast<const double2*>(sc0 + i * 2 * n_draw);
+    d_ = dz.x; z_ = dz.y;
+    load_record<J>(ve0 + i * rstride, W_, F_, S_);   // idle lanes read lane 0's record: harmless, zeroed below
+    if (!k.live) {
+      W_ = F_ = 0.0;
 #pragma unroll
-    for (int l = 0; l < J; ++l) S_[l] = k.live ? pv[(2 + l) * qstride] : 0.0;
+      for (int l = 0; l < J; ++l) S_[l] = 0.0;
+    }
   };
   double d_n, z_n, W_n, F_n, S_n[J];
   load(n - 1, d_n, z_n, W_n, F_n, S_n);
@@ -1372,7 +1404,7 @@ __global__ __launch_bounds__(kWave) void celerite_chunk_fwd_kernel(
   bool bad = false;
   double acc = 0.0, lman = 1.0;
   int64_t lsum = 0;
-  const int64_t vstride = n_draw * J, qstride = n * vstride;
+  const int64_t rstride = n_draw * J * (int64_t)(2 + J);   // one cadence of (W, F, S row) records
   double* __restrict__ p_vec = state + six.vec(0, n0, draw, jj);
   double* __restrict__ p_scal = state + six.scal(0, n0, draw);
   double tprev = t[n0 > 0 ? n0 - 1 : 0], dt_prev = -1.0, Pj = 1.0;
@@ -1414,13 +1446,10 @@ __global__ __launch_bounds__(kWave) void celerite_chunk_fwd_kernel(
     lman = frexp(lman * (d > 0.0 ? d : 1.0), &lexp);
     lsum += lexp;
     if (store) {
-      if (j == 0) { p_scal[0] = d; p_scal[n * n_draw] = z; }
-      p_vec[0] = Wj;
-      p_vec[qstride] = Fj;
-#pragma unroll
-      for (int l = 0; l < J; ++l) p_vec[(2 + l) * qstride] = Srow[l];
+      if (j == 0) *reinterpret_cast<double2*>(p_scal) = double2{d, z};
+      store_record<J>(p_vec, Wj, Fj, Srow);
     }
-    p_vec += vstride; p_scal += n_draw;
+    p_vec += rstride; p_scal += 2 * n_draw;
   }
   if (live_draw && j == 0) {
     state[ws.part(c, 0, draw)] = acc;
@@ -1477,15 +1506,16 @@ __global__ __launch_bounds__(kWave) void celerite_chunk_vjp_kernel(
   const int64_t vstride = n_draw * J, qstride = n * vstride;
   const double* __restrict__ sc0 = state + six.scal(0, 0, draw);
   const double* __restrict__ ve0 = state + six.vec(0, 0, draw, jj);
+  const int64_t rstride = vstride * (2 + J);   // one cadence of (W, F, S row) records
   auto load = [&](int64_t i, double& d_, double& z_, double& W_, double& F_, double* S_) {
-    const double* ps = sc0 + i * n_draw;
-    const double* pv = ve0 + i * vstride;
-    d_ = ps[0];
-    z_ = ps[n * n_draw];
-    W_ = k.live ? pv[0] : 0.0;
-    F_ = k.live ? pv[qstride] : 0.0;
+    const double2 dz = *reinterpret_cast<const double2*>(sc0 + i * 2 * n_draw);
+    d_ = dz.x; z_ = dz.y;
+    load_record<J>(ve0 + i * rstride, W_, F_, S_);   // idle lanes read lane 0's record: harmless, zeroed below
+    if (!k.live) {
+      W_ = F_ = 0.0;
 #pragma unroll
-    for (int l = 0; l < J; ++l) S_[l] = k.live ? pv[(2 + l) * qstride] : 0.0;
+      for (int l = 0; l < J; ++l) S_[l] = 0.0;
+    }
   };
   double dt_prev = -1.0, Pcache = 1.0;
   constexpr int kPer = 8 / G;

@@ -183,8 +183,9 @@ int exo_transit_flux_vjp_ev_f64(const double* t, int64_t n_cad, const double* te
  *   loglike      [n_draw]          out; -inf if the matrix is not positive definite
  *   state        NULL (value only) or exo_celerite_state_doubles() doubles: the
  *                factorisation (d, z; W, F and the rows of S per state index) the reverse
- *                pass re-reads, laid out [quantity][cadence][draw (x state index)],
- *                followed by the workspace of the time-parallel path
+ *                pass re-reads -- per (cadence, draw) the pair (d, z), per (cadence, draw, state
+ *                index) one record (W, F, row of S) -- followed by the pre-pass arrays and the
+ *                workspace of the time-parallel path; 16-byte aligned (16-B accesses)
  *
  * With a state buffer, J <= 6 and n >= 64 the recurrences run in parallel over TIME
  * (DESIGN.md 3.5): the series is cut into chunks, chunk "filtering elements" and a short
