@@ -187,9 +187,18 @@ __device__ __forceinline__ void store_record(double* __restrict__ p, double W, d
   v[0] = W; v[1] = F;
 #pragma unroll
   for (int l = 0; l < J; ++l) v[2 + l] = S[l];
+  // Non-temporal for short records: written once per forward pass, read once by the reverse pass,
+  // 10 GB-scale (C3 forward kernel 3.97 -> 3.21 ms).  NOT for long ones: a store instruction then
+  // touches 16 B of every lane's 64-B record, and without L2 to merge the four pieces the writes
+  // reach HBM as partial lines (J = 6 forward kernel 1.1 -> 2.9 ms).
+  typedef double v2d __attribute__((ext_vector_type(2)));
   if (R % 2 == 0) {
 #pragma unroll
-    for (int q = 0; q < R / 2; ++q) reinterpret_cast<double2*>(p)[q] = double2{v[2 * q], v[2 * q + 1]};
+    for (int q = 0; q < R / 2; ++q) {
+      const v2d x = {v[2 * q], v[2 * q + 1]};
+      if (R <= 4) __builtin_nontemporal_store(x, reinterpret_cast<v2d*>(p) + q);
+      else reinterpret_cast<v2d*>(p)[q] = x;
+    }
   } else {
 #pragma unroll
     for (int q = 0; q < R; ++q) p[q] = v[q];
