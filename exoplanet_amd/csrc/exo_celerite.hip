@@ -664,7 +664,7 @@ struct ChunkWs {
   __host__ __device__ int64_t total() const { return off_flag() + n_draw - base; }
 };
 
-constexpr int kChunkMaxJ = 6;   // the element kernel keeps three J x J matrices in registers
+constexpr int kChunkMaxJ = 8;   // = EXO_GP_MAX_J (J = 7, 8: lane-group element kernel, one-lane scan kernels spill)
 
 inline ChunkGeom chunk_plan(int64_t n, int64_t n_draw, int J) {
   ChunkGeom g{1, n, 0};
@@ -1110,6 +1110,106 @@ struct LaneDelta {
     }
   }
 };
+
+// (A) in lane-group form: the element of a (draw, chunk) on the draw's G lanes, lane j owning row j of
+// A, Cm, Jm.  Same arithmetic as celerite_elem_kernel; the column sums A^T U travel by a butterfly,
+// Cm U / the gain by DPP broadcasts.  A lane carries 3 J + 2 doubles of element state instead of
+// 3 J^2 + 2 J (J = 6: the one-lane version needs 256 registers and scratch), and there are G times
+// more lanes to hide the loads.  Used for J >= 3, and the only version for J = 7, 8.
+template <int J>
+__global__ __launch_bounds__(kWave) void celerite_elem_lg_kernel(
+    const double* __restrict__ t, const double* __restrict__ resid, const double* __restrict__ diag, int64_t n_diag,
+    int64_t n, const double* __restrict__ coef_real, int n_real, const double* __restrict__ coef_complex,
+    int n_complex, int64_t n_draw, double* __restrict__ state, ChunkGeom cg) {
+  constexpr int G = Group<J>::G;
+  const int j = threadIdx.x & (G - 1);
+  const int64_t lane_draw = ((int64_t)blockIdx.x * kWave + threadIdx.x) / G;
+  const bool live_draw = lane_draw < n_draw;
+  const int64_t draw = live_draw ? lane_draw : n_draw - 1;
+  const int c = blockIdx.y;
+  const int64_t n0 = c * cg.L, n1 = (n0 + cg.L < n) ? n0 + cg.L : n;
+  const LaneCoef k = lane_coef(coef_real, n_real, coef_complex, n_complex, draw, j, J);
+  const bool live = k.live;
+  const ChunkWs ws{n_draw, J, cg.C, cg.base};
+  const LaneDelta ld(k);
+  const double* __restrict__ y = resid + draw * n;
+  const double* __restrict__ dg = diag + (n_diag == 1 ? 0 : draw * n);
+  // conditioning score (see celerite_elem_kernel)
+  const double asum = group_sum<G>((live && !k.odd) ? fabs(k.a) : 0.0);
+  double ba2 = (live && !k.real && !k.odd) ? (k.b * k.b) / (k.a * k.a) : 0.0;
+  if (G >= 2) ba2 = fmax(ba2, xor_get<1>(ba2));
+  if (G >= 4) ba2 = fmax(ba2, xor_get<2>(ba2));
+  if (G >= 8) ba2 = fmax(ba2, xor_get<4>(ba2));
+  const double rmin = (1.0 + ba2) * asum * 1e-5;
+  bool ok = true;
+
+  // lane j holds COLUMN j of A (so that (A^T U)_j is a local dot product: no butterfly) and rows j of
+  // Cm, Jm
+  double Acol[J], Crow[J], Jrow[J], Dl[J], phiall[J];
+#pragma unroll
+  for (int l = 0; l < J; ++l) { Acol[l] = (live && l == j) ? 1.0 : 0.0; Crow[l] = 0.0; Jrow[l] = 0.0; phiall[l] = 1.0; }
+  double bj = 0.0, etaj = 0.0, phi = 1.0, dt_prev = -1.0;
+  double ti = t[n0];
+  double Uj, Vj, cs, sn;
+  lane_uv(k, ti, &Uj, &Vj, &cs, &sn);
+  ld.row<J>(k, j, cs, sn, Dl);
+#pragma unroll 1
+  for (int64_t i = n0; i < n1; ++i) {
+    const double yi = y[i], R = dg[i];
+    ok = ok && (R >= rmin) && (R < INFINITY);
+    double Uall[J];
+#pragma unroll
+    for (int l = 0; l < J; ++l) Uall[l] = group_get<G>(Uj, l);
+    double rj = 0.0, cuj = 0.0;
+#pragma unroll
+    for (int l = 0; l < J; ++l) {
+      rj = fma(Acol[l], Uall[l], rj);            // (A^T U)_j
+      cuj = fma(Crow[l], Uall[l], cuj);          // (Cm U)_j
+    }
+    const double s = R + group_sum<G>(Uj * cuj);
+    const double zeta = yi - group_sum<G>(Uj * bj);
+    const double is = 1.0 / s;
+    double rall[J];
+#pragma unroll
+    for (int l = 0; l < J; ++l) rall[l] = group_get<G>(rj, l);
+    etaj = fma(rj * is, zeta, etaj);
+#pragma unroll
+    for (int l = 0; l < J; ++l) Jrow[l] = fma(rj * is, rall[l], Jrow[l]);
+    if (i + 1 < n) {
+      const double tn = t[i + 1], dt = tn - ti;
+      ti = tn;
+      if (dt != dt_prev) {   // wave-uniform: evenly sampled series reuse the propagators
+        phi = live ? exp(-k.c * dt) : 0.0;
+#pragma unroll
+        for (int l = 0; l < J; ++l) phiall[l] = group_get<G>(phi, l);
+        dt_prev = dt;
+      }
+      lane_uv(k, tn, &Uj, &Vj, &cs, &sn);
+      double Dn[J];
+      ld.row<J>(k, j, cs, sn, Dn);
+      const double kj = cuj * is;
+      bj = phi * fma(kj, zeta, bj);
+#pragma unroll
+      for (int l = 0; l < J; ++l) {
+        const double cul = group_get<G>(cuj, l);
+        Acol[l] = phiall[l] * fma(-cul * is, rj, Acol[l]);                       // A[l][j] = phi_l (A[l][j] - k_l r_j)
+        Crow[l] = fma(phi * phiall[l], fma(-kj, cul, Crow[l]) - Dl[l], Dn[l]);   // + Q = Dn - phi phi Dl
+        Dl[l] = Dn[l];
+      }
+    }
+  }
+  if (!live_draw || !live) return;
+  if (!ok && j == 0) state[ws.off_flag() + draw] = 1.0;
+  const int E1 = J * J, E2 = J * J + J, E3 = 2 * J * J + J, E4 = 2 * J * J + 2 * J;
+#pragma unroll
+  for (int l = 0; l < J; ++l) {
+    state[ws.elem(c, l * J + j, draw)] = Acol[l];          // A[l][j]
+    state[ws.elem(c, E2 + j * J + l, draw)] = Crow[l];
+    state[ws.elem(c, E4 + j * J + l, draw)] = Jrow[l];
+  }
+  state[ws.elem(c, E1 + j, draw)] = bj;
+  state[ws.elem(c, E3 + j, draw)] = etaj;
+}
 
 // (B) in lane-group form (a draw on G lanes, lane j owns row j of P, A, Cm, Jm): the same chain as
 // celerite_bscan_kernel with the J x J algebra of every step spread over the draw's lanes --
@@ -1760,6 +1860,8 @@ int64_t exo_celerite_state_doubles(int64_t n, int64_t n_draw, int32_t n_real, in
     case 4: { constexpr int JJ = 4; CALL; } break; \
     case 5: { constexpr int JJ = 5; CALL; } break; \
     case 6: { constexpr int JJ = 6; CALL; } break; \
+    case 7: { constexpr int JJ = 7; CALL; } break; \
+    case 8: { constexpr int JJ = 8; CALL; } break; \
     default: return EXO_ERR_INVALID_ARGUMENT;      \
   }
 
@@ -1801,9 +1903,15 @@ int exo_celerite_loglike_fwd_f64(const double* t, const double* resid, const dou
                                                   coef_complex, n_complex, n_draw, state + ws.off_flag()))
 
       const dim3 egrid(per_draw.x, (unsigned)cg.C), cgrid(grid.x, (unsigned)cg.C);
-      EXO_GP_DISPATCH_SMALL(J, hipLaunchKernelGGL((celerite_elem_kernel<JJ>), egrid, block, 0, st, t, resid, diag,
-                                                  n_diag, n, coef_real, n_real, coef_complex, n_complex, n_draw, state,
-                                                  cg))
+      if (J >= 7) {   // the one-lane element kernel is as fast up to J = 6 and does not fit beyond
+        EXO_GP_DISPATCH_SMALL(J, hipLaunchKernelGGL((celerite_elem_lg_kernel<JJ>), cgrid, block, 0, st, t, resid, diag,
+                                                    n_diag, n, coef_real, n_real, coef_complex, n_complex, n_draw,
+                                                    state, cg))
+      } else {
+        EXO_GP_DISPATCH_SMALL(J, hipLaunchKernelGGL((celerite_elem_kernel<JJ>), egrid, block, 0, st, t, resid, diag,
+                                                    n_diag, n, coef_real, n_real, coef_complex, n_complex, n_draw,
+                                                    state, cg))
+      }
       // after the element kernel: it may flag more draws (measurement variance too small)
       hipLaunchKernelGGL(celerite_prep_flagged_kernel, dim3(8, (unsigned)n_draw), dim3(256), 0, st, t, n, coef_real,
                          n_real, coef_complex, n_complex, n_draw, J, state, state + ws.off_flag());

@@ -187,7 +187,7 @@ int exo_transit_flux_vjp_ev_f64(const double* t, int64_t n_cad, const double* te
  *                index) one record (W, F, row of S) -- followed by the pre-pass arrays and the
  *                workspace of the time-parallel path; 16-byte aligned (16-B accesses)
  *
- * With a state buffer, J <= 6 and n >= 64 the recurrences run in parallel over TIME
+ * With a state buffer and n >= 64 the recurrences run in parallel over TIME
  * (DESIGN.md 3.5): the series is cut into chunks, chunk "filtering elements" and a short
  * per-draw scan over them give the recurrence state entering every chunk (and, in the
  * reverse pass, its adjoint), and the ordinary recurrences then run inside all chunks at

@@ -251,3 +251,36 @@ def test_value_only_calls_take_the_time_parallel_path_too(dev):
         got = celerite_loglike(T(t, dev), T(y, dev), T(diag, dev), T(cr, dev), T(cc, dev))
     assert not torch.equal(got, want)          # a different summation order: the chunked kernels ran
     assert torch.allclose(got, want, rtol=1e-12)
+
+
+def test_wide_state_takes_the_time_parallel_path(dev):
+    """J = 7, 8 (lane-group element kernel): chunked == sequential == dense"""
+    rng = np.random.default_rng(18)
+    N, D = 900, 3
+    t = np.sort(rng.uniform(0, 40, N))
+    y = 0.4 * rng.normal(size=(D, N))
+    diag = np.full((1, N), 0.05)
+    parts = [P.sho_coefficients(*P.sho_from_sigma_rho(s, r, q), q)
+             for s, r, q in ((0.4, 20.0, 2.0), (0.3, 10.0, 1.0), (0.2, 2.0, 0.8), (0.25, 5.0, 1.5))]
+    for n_real in (1, 0):                                  # J = 7 (3 pairs + 1 real), J = 8 (4 pairs)
+        sel = parts[:3] if n_real else parts
+        co = tuple(np.concatenate(x) for x in zip(*sel))
+        if n_real:
+            co = (np.array([0.3]), np.array([0.2])) + co[2:]
+        cr0, cc0 = _pack(co)
+        cr = np.repeat(cr0, D, 0) * (1 + 0.02 * rng.normal(size=(D,) + cr0.shape[1:]))
+        cc = np.repeat(cc0, D, 0)
+        cc[..., 0] *= 1 + 0.02 * rng.normal(size=cc[..., 0].shape)
+        cc[..., 1] = cc[..., 0] * (cc0[..., 1] / cc0[..., 0])      # keep b / a: SHO terms sit on |b d| = a c
+        with chunks(0):
+            want = value_and_grads(dev, t, y, diag, cr, cc)
+        with chunks(11):
+            got = value_and_grads(dev, t, y, diag, cr, cc)
+        assert not np.array_equal(got[0], want[0])
+        np.testing.assert_allclose(got[0], want[0], rtol=1e-12)
+        for g, w in zip(got[1:], want[1:]):
+            if w.size:
+                assert np.abs(g - w).max() / (np.abs(w).max() + 1e-300) < 2e-9
+        co_d = (cr[0, :, 0], cr[0, :, 1], cc[0, :, 0], cc[0, :, 1], cc[0, :, 2], cc[0, :, 3])
+        ref, _ = P.gp_loglike_dense(t, y[0], diag[0], co_d)
+        assert abs(got[0][0] - ref) < 1e-10 * abs(ref)

@@ -15,6 +15,10 @@ def run(D, N, kind):
     if kind == "sho":
         ps = [leaf(2e-3), leaf(1.5), leaf(2.0)]
         mk = lambda: terms.SHOTerm(sigma=ps[0], rho=ps[1], Q=ps[2])
+    elif kind == "wide":      # J = 8: four SHO terms
+        ps = [leaf(2e-3), leaf(1.5), leaf(1e-3), leaf(4.0), leaf(5e-4), leaf(9.0), leaf(1.5e-3), leaf(0.7)]
+        mk = lambda: (terms.SHOTerm(sigma=ps[0], rho=ps[1], Q=2.0) + terms.SHOTerm(sigma=ps[2], rho=ps[3], Q=1.0)
+                      + terms.SHOTerm(sigma=ps[4], rho=ps[5], Q=0.8) + terms.SHOTerm(sigma=ps[6], rho=ps[7], Q=3.0))
     else:
         ps = [leaf(2e-3), leaf(3.0), leaf(5.0), leaf(1.5), leaf(0.6), leaf(1e-3), leaf(0.3)]
         mk = lambda: terms.RotationTerm(sigma=ps[0], period=ps[1], Q0=ps[2], dQ=ps[3], f=ps[4]) + terms.RealTerm(a=ps[5] ** 2, c=ps[6])
@@ -39,7 +43,7 @@ if __name__ == "__main__":
         D, N, kind = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
         print(json.dumps(run(D, N, kind)))
         sys.exit(0)
-    for D, N, kind in [(64, 20000, "sho"), (1024, 150000, "sho"), (128, 65000, "rot"), (5, 3000, "rot")]:
+    for D, N, kind in ([(int(a), int(b), c) for a, b, c in [x.split(",") for x in os.environ["CASES"].split()]] if os.environ.get("CASES") else [(64, 20000, "sho"), (1024, 150000, "sho"), (128, 65000, "rot"), (5, 3000, "rot")]):
         out = {}
         for mode, env in (("chunked", {}), ("sequential", {"EXO_GP_CHUNKS": "0"})):
             e = dict(os.environ); e.update(env)
