@@ -12,7 +12,7 @@
 //   solve_lower: F_n = P o (F_{n-1} + W_{n-1} z_{n-1}) ;  z_n = y_n - U_n . F_n
 //   loglike    = -1/2 sum (z_n^2 / d_n + log d_n) - N/2 log 2 pi
 //
-// Two paths.  Sequential (first half of this file; value-only calls, J > 6, short series, draws
+// Two paths.  Sequential (first half of this file; calls without a state buffer, short series, draws
 // the other path cannot take): parallelism over draws and, inside a draw, over the J state
 // indices -- a draw occupies G = next_pow2(J) adjacent lanes (lane j owns row j of S), exchanging
 // values by DPP; everything that does not depend on the recurrence (U_n, V_n, P_n: sin / cos /
