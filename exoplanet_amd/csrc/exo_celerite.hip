@@ -1903,7 +1903,10 @@ int exo_celerite_loglike_fwd_f64(const double* t, const double* resid, const dou
                                                   coef_complex, n_complex, n_draw, state + ws.off_flag()))
 
       const dim3 egrid(per_draw.x, (unsigned)cg.C), cgrid(grid.x, (unsigned)cg.C);
-      if (J >= 7) {   // the one-lane element kernel is as fast up to J = 6 and does not fit beyond
+#ifndef EXO_ELEM_LG_MIN_J
+#define EXO_ELEM_LG_MIN_J 7
+#endif
+      if (J >= EXO_ELEM_LG_MIN_J) {   // the one-lane element kernel is as fast up to J = 6 and does not fit beyond
         EXO_GP_DISPATCH_SMALL(J, hipLaunchKernelGGL((celerite_elem_lg_kernel<JJ>), cgrid, block, 0, st, t, resid, diag,
                                                     n_diag, n, coef_real, n_real, coef_complex, n_complex, n_draw,
                                                     state, cg))
