@@ -390,6 +390,92 @@ __device__ __forceinline__ bool near_conjunction(double t, double nrev, double c
 }
 
 
+// ---------------------------------------------------------------------------
+// Transit-timing variations (reference: orbits/ttv.py:158-187).  Every time is measured from its
+// nearest labelled transit: planet p of a draw has n_edge bin edges (ascending, padded with +inf)
+// and n_edge + 1 shifts; a time t falls in bin k = #{edges < t} (searchsorted, left) and is
+// warped to t - shift[k] before anything else happens to it (shift[k] = transit time k - the
+// record's t0; the mean anomaly and the window phase are then those of the unperturbed orbit).
+// ---------------------------------------------------------------------------
+struct Ttv {
+  const double* edges;   // [n_draw][n_planet][n_edge]
+  const double* shift;   // [n_draw][n_planet][n_edge + 1]
+  double* gshift;        // [n_draw][n_planet][n_edge + 1], reverse sweep only
+  int n_edge;
+};
+
+// one planet's table
+struct TtvRow {
+  const double* __restrict__ edges;
+  const double* __restrict__ shift;
+  int n_edge;
+  __device__ __forceinline__ TtvRow(const Ttv& tv, int64_t rec)
+      : edges(tv.edges + rec * tv.n_edge), shift(tv.shift + rec * (tv.n_edge + 1)), n_edge(tv.n_edge) {}
+  // #{edges < t}: lower bound, branch-free steps (NaN t -> 0)
+  __device__ __forceinline__ int bin(double t) const {
+    int lo = 0, len = n_edge;
+    while (len > 0) {
+      const int half = len >> 1;
+      const bool lt = edges[lo + half] < t;
+      lo = lt ? lo + half + 1 : lo;
+      len = lt ? len - half - 1 : half;
+    }
+    return lo;
+  }
+  // is an edge within hw of t (an exposure of half-width hw straddles two bins)?
+  __device__ __forceinline__ bool straddles(int k, double t, double hw) const {
+    hw = fma(hw, 1e-12, hw);   // the product that made hw was rounded
+    const bool lo = k > 0 && !(t - edges[k - 1] > hw);
+    const bool hi = k < n_edge && !(edges[k] - t > hw);
+    return lo || hi;
+  }
+};
+
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int m = 32; m > 0; m >>= 1) v += __shfl_xor(v, m, 64);
+  return v;
+}
+
+// Reverse sweep of the warp: d L / d shift[k] is the sum over the samples of bin k of their
+// d L / d t_periastron (both enter as t - shift - tp).  eval_sample leaves that sum in the lane's
+// G_TP column; it is moved to the bin (hardware fp64 atomics on the output table -- the one place
+// where the summation order, and with it the last bits, depends on scheduling) and to the G_PAD
+// column, which ends up holding the planet's total.
+struct TtvGrad {
+  double* __restrict__ col;   // &lds_acc[0][threadIdx.x]
+  double* __restrict__ grow;  // gshift row of this (draw, planet)
+  __device__ __forceinline__ double take() const {
+    const double d = col[G_TP * kBlock];
+    col[G_TP * kBlock] = 0.0;
+    col[G_PAD * kBlock] += d;
+    return d;
+  }
+  // one lane on its own (its bin changed in the middle of an exposure)
+  __device__ __forceinline__ void flush_lane(int k) const {
+    const double d = take();
+    if (d != 0.0) unsafeAtomicAdd(grow + k, d);
+  }
+  // the whole wave, after a cadence: consecutive list entries are consecutive cadences of one
+  // transit, so the contributing lanes nearly always share a bin -> one atomic per wave
+  __device__ __forceinline__ void flush_wave(int k) const {
+    const double d = take();
+    const bool nz = d != 0.0;
+    const unsigned long long mask = __ballot(nz);
+    if (mask == 0) return;
+    const int first = __builtin_amdgcn_readfirstlane(__ffsll((long long)mask) - 1);
+    const int k0 = __builtin_amdgcn_readlane(k, first);
+    if (__ballot(nz && k != k0) == 0) {
+      const double sum = wave_sum(d);
+      if ((int)(threadIdx.x & 63) == first) unsafeAtomicAdd(grow + k0, sum);
+    } else if (nz) {
+      unsafeAtomicAdd(grow + k, d);
+    }
+  }
+};
+
+
 constexpr int kScanDraws = 4;  // draws per classify block on the single-planet path
 
 // ballot + mbcnt append of the active lanes' offsets to a per-wave list (no atomics).  The list
@@ -415,13 +501,13 @@ __device__ __forceinline__ void append_active(int kind, int off, int32_t* __rest
 // window constants sit in scalar registers.
 constexpr uint32_t kFlagGrouped = 0x40000000u;
 
-template <bool SECONDARY, bool FAST, bool VEC2>
+template <bool SECONDARY, bool FAST, bool VEC2, bool TTV = false>
 __global__ __launch_bounds__(kBlock) void transit_scan_kernel(
     const double* __restrict__ t, int64_t n_cad, const double* __restrict__ texp, int64_t n_texp,
     const double* __restrict__ stencil_dt, int n_sub, const double* __restrict__ params, int n_planet,
     uint32_t flags, int tiles_per_block, int blocks_per_draw, int64_t n_draw, int64_t n_classify,
     double* __restrict__ flux, int32_t* __restrict__ counts, int32_t* __restrict__ list,
-    const double* __restrict__ windows) {
+    const double* __restrict__ windows, Ttv ttv) {
   __shared__ Shared sh;
   // 1-D launch: classify blocks first (they feed the next kernel and should start early),
   // fill blocks after them; workgroups go to the 8 XCDs round-robin on the linear id, so both
@@ -563,6 +649,29 @@ __global__ __launch_bounds__(kBlock) void transit_scan_kernel(
       for (int p = 0; p < n_planet; ++p) {
         const PlanetConst& c = sh.pc[p];
         bool cand = true;
+        if (TTV) {
+          // the cadence in its own bin; an exposure that reaches into the next bin has
+          // sub-exposures measured from another transit: no window argument covers those,
+          // the classifier sees each of them (the caller's windows, like the reference's
+          // in_transit, warp the mid-exposure time only)
+          const TtvRow row(ttv, draw * n_planet + p);
+          const int kb = row.bin(tv[v]);
+          const double tw = tv[v] - row.shift[kb];
+          const bool mixed = !window && n_texp && row.straddles(kb, tv[v], fabs(te) * span);
+          if (stage1 && !mixed) {
+            const double widen = fabs(te) * span * fabs(c.nrev);
+            cand = near_conjunction<SECONDARY>(tw, c.nrev, c.c0, c.dmid, c.half[0] + widen, c.half[1] + widen);
+          }
+          if (cand) {
+            int kp = window ? 1 : 0;
+            for (int k = 0; k < n_sub; ++k) {
+              const double tt = fma(te, sh.sdt[k], tv[v]);
+              kp = max(kp, classify_sample<SECONDARY, FAST>(tt - row.shift[mixed ? row.bin(tt) : kb], c));
+            }
+            kind = max(kind, kp);
+          }
+          continue;
+        }
         if (stage1) {
           const double widen = fabs(te) * span * fabs(c.nrev);
           cand = near_conjunction<SECONDARY>(tv[v], c.nrev, c.c0, c.dmid, c.half[0] + widen, c.half[1] + widen);
@@ -620,14 +729,14 @@ __device__ __forceinline__ void reduce_columns(double (*acc)[kBlock], double (*r
 #ifndef EXO_HEAVY_MIN_WAVES
 #define EXO_HEAVY_MIN_WAVES 2
 #endif
-template <bool GRAD, bool SECONDARY>
+template <bool GRAD, bool SECONDARY, bool TTV = false>
 __global__ __launch_bounds__(kBlock, EXO_HEAVY_MIN_WAVES) void transit_heavy_kernel(
     const double* __restrict__ t, int64_t n_cad, const double* __restrict__ texp, int64_t n_texp,
     const double* __restrict__ stencil_dt, const double* __restrict__ stencil_w, int n_sub,
     const double* __restrict__ params, const double* __restrict__ ld, int n_planet, uint32_t flags,
     int tiles_per_block, int blocks_per_draw, int merge, const int32_t* __restrict__ counts,
     const int32_t* __restrict__ list, const double* __restrict__ gflux, double* __restrict__ flux,
-    double* __restrict__ partial, const double* __restrict__ windows) {
+    double* __restrict__ partial, const double* __restrict__ windows, Ttv ttv) {
   __shared__ Shared sh;
   __shared__ int s_pre[2 * kWaves * kMaxMerge + 1];
   const int64_t draw = blockIdx.y;
@@ -677,8 +786,15 @@ __global__ __launch_bounds__(kBlock, EXO_HEAVY_MIN_WAVES) void transit_heavy_ker
   double spanw = (flags & EXO_FLAG_WINDOW) ? 0.5 : 0.0;
   if (use_win && !(flags & EXO_FLAG_WINDOW))
     for (int k = 0; k < n_sub; ++k) spanw = fmax(spanw, fabs(sh.sdt[k]));
+  // TTV: how far a sub-exposure can be from its cadence, in units of texp
+  double reach = 0.0;
+  if (TTV)
+    for (int k = 0; k < n_sub; ++k) reach = fmax(reach, fabs(sh.sdt[k]));
   for (int p = 0; p < n_planet; ++p) {
     const PlanetS c(sh.pc[p]);
+    const TtvRow row(ttv, TTV ? draw * n_planet + p : 0);
+    const TtvGrad tgrad{GRAD && TTV ? &lds_acc[0][threadIdx.x] : nullptr,
+                        GRAD && TTV ? ttv.gshift + (draw * n_planet + p) * (int64_t)(ttv.n_edge + 1) : nullptr};
     double w_nrev = 0.0, w_c0 = 0.0, w_dmid = 0.0, w_h0 = 0.0, w_h1 = 0.0;
     if (use_win) {
       const double* wv = windows + kWin * (draw * n_planet + p);
@@ -743,20 +859,45 @@ __global__ __launch_bounds__(kBlock, EXO_HEAVY_MIN_WAVES) void transit_heavy_ker
       }
       const int64_t i = cur.i;
       const double tv = cur.tv, te = cur.te;
+      // TTV: the cadence's bin and shift; `mixed` = some sub-exposure may belong to another bin
+      int kb = 0;
+      double dsh = 0.0;
+      bool mixed = false;
+      if (TTV) {
+        kb = row.bin(tv);
+        dsh = row.shift[kb];
+        mixed = n_texp && row.straddles(kb, tv, fabs(te) * reach);
+      }
       if (use_win) {
         const double widen = fabs(te) * spanw * fabs(w_nrev);
-        const bool near = has && near_conjunction<SECONDARY>(tv, w_nrev, w_c0, w_dmid, w_h0 + widen, w_h1 + widen);
+        const bool near = has && ((mixed && !(flags & EXO_FLAG_WINDOW)) ||
+                                  near_conjunction<SECONDARY>(tv - dsh, w_nrev, w_c0, w_dmid, w_h0 + widen, w_h1 + widen));
         if (!EXO_WAVE_ANY(near)) continue;   // the fill left this planet's flux at zero
       }
       const double g = cur.g;
       double f = 0.0;
+      int kcur = kb;
       for (int k = 0; k < n_sub; ++k) {
-        const double tt = fma(te, sh.sdt[k], tv);
+        double tt = fma(te, sh.sdt[k], tv);
+        if (TTV) {
+          int ks = kb;
+          double sh_k = dsh;
+          if (mixed) {
+            ks = row.bin(tt);
+            sh_k = row.shift[ks];
+          }
+          if (GRAD && ks != kcur) {
+            tgrad.flush_lane(kcur);
+            kcur = ks;
+          }
+          tt -= sh_k;
+        }
         const double gw = g * sh.sw[k];
         const double F = eval_sample<GRAD, SECONDARY>(tt, c, cld, gw, acc);
         f = fma(sh.sw[k], F, f);
         if (GRAD) acc.add(kNG + 6, gw * F);
       }
+      if (GRAD && TTV) tgrad.flush_wave(kcur);
       if (flux && has) {
         if (per_planet) {
           flux[(draw * n_cad + i) * n_planet + p] = f;
@@ -765,6 +906,11 @@ __global__ __launch_bounds__(kBlock, EXO_HEAVY_MIN_WAVES) void transit_heavy_ker
           *dst = (p == 0) ? f : (*dst + f);
         }
       }
+    }
+    if (GRAD && TTV) {
+      // every sample's t_periastron term went through the bins; the planet's total is in G_PAD
+      lds_acc[G_TP][threadIdx.x] = lds_acc[G_PAD][threadIdx.x];
+      lds_acc[G_PAD][threadIdx.x] = 0.0;
     }
     if (GRAD) reduce_columns(lds_acc, sh.red, 0, kNG, pout + p * kNG);
   }
@@ -942,21 +1088,24 @@ inline Workspace carve(void* base, int64_t n_draw, int bpd, int tpb, int n_plane
 constexpr uint32_t kFlagNoFlux = 0x80000000u;  // internal: scan kernel must not touch flux
 
 // scan kernel dispatch on (secondary, exact fp64 classification requested)
-#define EXO_LAUNCH_SCAN_V(VEC, FLAGS, ...)                                                                \
+#define EXO_LAUNCH_SCAN_V(VEC, TTV, FLAGS, ...)                                                           \
   do {                                                                                                    \
     const bool sec_ = (FLAGS) & EXO_FLAG_SECONDARY, exact_ = (FLAGS) & EXO_FLAG_EXACT_SCAN;               \
-    if (sec_ && exact_) hipLaunchKernelGGL((transit_scan_kernel<true, false, VEC>), __VA_ARGS__);         \
-    else if (sec_) hipLaunchKernelGGL((transit_scan_kernel<true, true, VEC>), __VA_ARGS__);               \
-    else if (exact_) hipLaunchKernelGGL((transit_scan_kernel<false, false, VEC>), __VA_ARGS__);           \
-    else hipLaunchKernelGGL((transit_scan_kernel<false, true, VEC>), __VA_ARGS__);                        \
+    if (sec_ && exact_) hipLaunchKernelGGL((transit_scan_kernel<true, false, VEC, TTV>), __VA_ARGS__);    \
+    else if (sec_) hipLaunchKernelGGL((transit_scan_kernel<true, true, VEC, TTV>), __VA_ARGS__);          \
+    else if (exact_) hipLaunchKernelGGL((transit_scan_kernel<false, false, VEC, TTV>), __VA_ARGS__);      \
+    else hipLaunchKernelGGL((transit_scan_kernel<false, true, VEC, TTV>), __VA_ARGS__);                   \
   } while (0)
-// 16-B loads of t: pairs must not straddle the end (even n_cad) and t must be 16-B aligned
-#define EXO_LAUNCH_SCAN(N_CAD, T, FLAGS, ...)                                                  \
+// 16-B loads of t: pairs must not straddle the end (even n_cad) and t must be 16-B aligned.
+// The timing-variation path (HAS_TTV) has one variant: per-cadence table lookups dwarf the loads.
+#define EXO_LAUNCH_SCAN(N_CAD, T, HAS_TTV, FLAGS, ...)                                         \
   do {                                                                                         \
-    if (((N_CAD) & 1) == 0 && (reinterpret_cast<uintptr_t>(T) & 15) == 0)                      \
-      EXO_LAUNCH_SCAN_V(true, FLAGS, __VA_ARGS__);                                             \
+    if (HAS_TTV)                                                                               \
+      EXO_LAUNCH_SCAN_V(false, true, FLAGS, __VA_ARGS__);                                      \
+    else if (((N_CAD) & 1) == 0 && (reinterpret_cast<uintptr_t>(T) & 15) == 0)                 \
+      EXO_LAUNCH_SCAN_V(true, false, FLAGS, __VA_ARGS__);                                      \
     else                                                                                       \
-      EXO_LAUNCH_SCAN_V(false, FLAGS, __VA_ARGS__);                                            \
+      EXO_LAUNCH_SCAN_V(false, false, FLAGS, __VA_ARGS__);                                     \
   } while (0)
 
 // the windows of the scan kernel's first test: not needed when the caller asks for the exact
@@ -976,10 +1125,11 @@ struct ScanPlan {
   int64_t n_classify;  // classify blocks
   dim3 grid;
 };
-inline ScanPlan scan_plan(uint32_t flags, int bpd, int64_t n_draw, int n_planet, int64_t n_texp, bool with_fill) {
+inline ScanPlan scan_plan(uint32_t flags, int bpd, int64_t n_draw, int n_planet, int64_t n_texp, bool with_fill,
+                          bool has_ttv = false) {
   ScanPlan sp;
   const bool stage1 = (flags & EXO_FLAG_WINDOW) || !(flags & EXO_FLAG_EXACT_SCAN);
-  const bool grouped = n_planet == 1 && n_texp <= 1 && stage1;
+  const bool grouped = n_planet == 1 && n_texp <= 1 && stage1 && !has_ttv;
   sp.flags = (flags & 0x0fffffffu) | (grouped ? kFlagGrouped : 0u) | (with_fill ? 0u : kFlagNoFlux);
   sp.n_classify = (grouped ? (n_draw + kScanDraws - 1) / kScanDraws : n_draw) * bpd;
   sp.grid = dim3((unsigned)(sp.n_classify + (with_fill ? n_draw * bpd : 0)));
@@ -995,7 +1145,7 @@ inline bool transit_args_ok(int64_t n_cad, int64_t n_texp, int32_t n_sub, int64_
 
 extern "C" {
 
-int32_t exo_abi_version(void) { return 3; }
+int32_t exo_abi_version(void) { return 4; }
 
 int exo_kepler_f64(const double* M, const double* ecc, double* sinf, double* cosf, int64_t n, void* stream) {
   if (n < 0 || (n > 0 && (!M || !ecc || !sinf || !cosf))) return EXO_ERR_INVALID_ARGUMENT;
@@ -1046,64 +1196,65 @@ int64_t exo_transit_flux_workspace_bytes(int64_t n_cad, int64_t n_draw, int32_t 
   return w.bytes;
 }
 
-int exo_transit_flux_fwd_ev_f64(const double* t, int64_t n_cad, const double* texp, int64_t n_texp,
-                                const double* stencil_dt, const double* stencil_w, int32_t n_sub,
-                                const double* params, const double* ld, int64_t n_draw, int32_t n_planet,
-                                uint32_t flags, double* flux, void* workspace, int64_t workspace_bytes,
-                                void* stream, void* ev_start, void* ev_stop) {
+// forward sweep; ttv.edges == nullptr: no timing variations
+static int transit_fwd(const double* t, int64_t n_cad, const double* texp, int64_t n_texp, const double* stencil_dt,
+                       const double* stencil_w, int32_t n_sub, const double* params, const double* ld,
+                       int64_t n_draw, int32_t n_planet, uint32_t flags, const Ttv& ttv, double* flux,
+                       void* workspace, int64_t workspace_bytes, void* stream, void* ev_start, void* ev_stop) {
   if (!transit_args_ok(n_cad, n_texp, n_sub, n_draw, n_planet)) return EXO_ERR_INVALID_ARGUMENT;
   if (n_cad == 0 || n_draw == 0) return EXO_OK;
   if (!t || !params || !ld || !flux || (n_texp > 0 && (!texp || !stencil_dt || !stencil_w)))
     return EXO_ERR_INVALID_ARGUMENT;
+  const bool has_ttv = ttv.edges != nullptr;
   int bpd, tpb;
   transit_geometry(n_cad, n_draw, &bpd, &tpb);
   const Workspace w = carve(workspace, n_draw, bpd, tpb, n_planet);
   if (!workspace || workspace_bytes < w.bytes) return EXO_ERR_WORKSPACE;
-  const dim3 grid((unsigned)bpd, (unsigned)n_draw), block(kBlock);
+  const dim3 block(kBlock);
   hipStream_t st = (hipStream_t)stream;
   const bool secondary = flags & EXO_FLAG_SECONDARY;
   if (ev_start) (void)hipEventRecord((hipEvent_t)ev_start, st);
   launch_windows(params, n_draw, n_planet, flags, w.windows, st);
-  const ScanPlan sp = scan_plan(flags, bpd, n_draw, n_planet, n_texp, true);
-  EXO_LAUNCH_SCAN(n_cad, t, flags, sp.grid, block, 0, st, t, n_cad, texp, n_texp, stencil_dt, n_sub, params, n_planet,
-                  sp.flags, tpb, bpd, n_draw, sp.n_classify, flux, w.counts, w.list, w.windows);
+  const ScanPlan sp = scan_plan(flags, bpd, n_draw, n_planet, n_texp, true, has_ttv);
+  EXO_LAUNCH_SCAN(n_cad, t, has_ttv, flags, sp.grid, block, 0, st, t, n_cad, texp, n_texp, stencil_dt, n_sub, params,
+                  n_planet, sp.flags, tpb, bpd, n_draw, sp.n_classify, flux, w.counts, w.list, w.windows, ttv);
   if (launch_status() != EXO_OK) return EXO_ERR_LAUNCH;
   const int merge = heavy_merge(n_draw, bpd);
   const dim3 hgrid((unsigned)((bpd + merge - 1) / merge), (unsigned)n_draw);
   const double* hwin = ((flags & EXO_FLAG_EXACT_SCAN) && !(flags & EXO_FLAG_WINDOW)) ? nullptr : w.windows;
-  if (secondary)
-    hipLaunchKernelGGL((transit_heavy_kernel<false, true>), hgrid, block, 0, st, t, n_cad, texp, n_texp, stencil_dt,
-                       stencil_w, n_sub, params, ld, n_planet, flags, tpb, bpd, merge, w.counts, w.list, nullptr, flux,
-                       nullptr, hwin);
-  else
-    hipLaunchKernelGGL((transit_heavy_kernel<false, false>), hgrid, block, 0, st, t, n_cad, texp, n_texp, stencil_dt,
-                       stencil_w, n_sub, params, ld, n_planet, flags, tpb, bpd, merge, w.counts, w.list, nullptr, flux,
-                       nullptr, hwin);
+#define EXO_LAUNCH_HEAVY_FWD(SEC, TTV)                                                                             \
+  hipLaunchKernelGGL((transit_heavy_kernel<false, SEC, TTV>), hgrid, block, 0, st, t, n_cad, texp, n_texp,         \
+                     stencil_dt, stencil_w, n_sub, params, ld, n_planet, flags, tpb, bpd, merge, w.counts, w.list, \
+                     nullptr, flux, nullptr, hwin, ttv)
+  if (has_ttv) {
+    if (secondary) EXO_LAUNCH_HEAVY_FWD(true, true);
+    else EXO_LAUNCH_HEAVY_FWD(false, true);
+  } else {
+    if (secondary) EXO_LAUNCH_HEAVY_FWD(true, false);
+    else EXO_LAUNCH_HEAVY_FWD(false, false);
+  }
+#undef EXO_LAUNCH_HEAVY_FWD
   if (ev_stop) (void)hipEventRecord((hipEvent_t)ev_stop, st);
   return launch_status();
 }
 
-int exo_transit_flux_fwd_f64(const double* t, int64_t n_cad, const double* texp, int64_t n_texp,
-                             const double* stencil_dt, const double* stencil_w, int32_t n_sub,
-                             const double* params, const double* ld, int64_t n_draw, int32_t n_planet,
-                             uint32_t flags, double* flux, void* workspace, int64_t workspace_bytes, void* stream) {
-  return exo_transit_flux_fwd_ev_f64(t, n_cad, texp, n_texp, stencil_dt, stencil_w, n_sub, params, ld, n_draw,
-                                     n_planet, flags, flux, workspace, workspace_bytes, stream, nullptr, nullptr);
-}
-
-int exo_transit_flux_vjp_ev_f64(const double* t, int64_t n_cad, const double* texp, int64_t n_texp,
-                                const double* stencil_dt, const double* stencil_w, int32_t n_sub,
-                                const double* params, const double* ld, int64_t n_draw, int32_t n_planet,
-                                uint32_t flags, const double* gflux, double* flux_out, double* gparams,
-                                double* gld, double* flux_dot, void* workspace, int64_t workspace_bytes,
-                                void* stream, void* ev_start, void* ev_stop) {
+// value + VJP sweep; ttv.edges == nullptr: no timing variations
+static int transit_vjp(const double* t, int64_t n_cad, const double* texp, int64_t n_texp, const double* stencil_dt,
+                       const double* stencil_w, int32_t n_sub, const double* params, const double* ld,
+                       int64_t n_draw, int32_t n_planet, uint32_t flags, const Ttv& ttv, const double* gflux,
+                       double* flux_out, double* gparams, double* gld, double* flux_dot, void* workspace,
+                       int64_t workspace_bytes, void* stream, void* ev_start, void* ev_stop) {
   if (!transit_args_ok(n_cad, n_texp, n_sub, n_draw, n_planet)) return EXO_ERR_INVALID_ARGUMENT;
   if (n_draw == 0) return EXO_OK;
   if (!params || !ld || !gparams || !gld || (n_cad > 0 && (!t || !gflux)) ||
       (n_texp > 0 && (!texp || !stencil_dt || !stencil_w)))
     return EXO_ERR_INVALID_ARGUMENT;
+  const bool has_ttv = ttv.edges != nullptr;
   const bool secondary = flags & EXO_FLAG_SECONDARY;
   hipStream_t st = (hipStream_t)stream;
+  // the bins are accumulated into: start from zero
+  if (has_ttv && hipMemsetAsync(ttv.gshift, 0, sizeof(double) * n_draw * n_planet * (ttv.n_edge + 1), st) != hipSuccess)
+    return EXO_ERR_LAUNCH;
   if (n_cad == 0) {
     if (hipMemsetAsync(gparams, 0, sizeof(double) * n_draw * n_planet * EXO_NPAR, st) != hipSuccess)
       return EXO_ERR_LAUNCH;
@@ -1116,33 +1267,79 @@ int exo_transit_flux_vjp_ev_f64(const double* t, int64_t n_cad, const double* te
   transit_geometry(n_cad, n_draw, &bpd, &tpb);
   const Workspace w = carve(workspace, n_draw, bpd, tpb, n_planet);
   if (!workspace || workspace_bytes < w.bytes) return EXO_ERR_WORKSPACE;
-  const dim3 grid((unsigned)bpd, (unsigned)n_draw), block(kBlock);
-  // the forward value is a by-product; without a destination the scan kernel's
-  // zeros for inactive cadences go to a scratch row that nobody reads
+  const dim3 block(kBlock);
+  // the forward value is a by-product; without a destination the scan kernel skips the fill
   double* flux_dst = flux_out;
   if (ev_start) (void)hipEventRecord((hipEvent_t)ev_start, st);
   launch_windows(params, n_draw, n_planet, flags, w.windows, st);
-  const ScanPlan sp = scan_plan(flags, bpd, n_draw, n_planet, n_texp, flux_dst != nullptr);
-  EXO_LAUNCH_SCAN(n_cad, t, flags, sp.grid, block, 0, st, t, n_cad, texp, n_texp, stencil_dt, n_sub, params, n_planet,
-                  sp.flags, tpb, bpd, n_draw, sp.n_classify, flux_dst, w.counts, w.list, w.windows);
+  const ScanPlan sp = scan_plan(flags, bpd, n_draw, n_planet, n_texp, flux_dst != nullptr, has_ttv);
+  EXO_LAUNCH_SCAN(n_cad, t, has_ttv, flags, sp.grid, block, 0, st, t, n_cad, texp, n_texp, stencil_dt, n_sub, params,
+                  n_planet, sp.flags, tpb, bpd, n_draw, sp.n_classify, flux_dst, w.counts, w.list, w.windows, ttv);
   if (launch_status() != EXO_OK) return EXO_ERR_LAUNCH;
   const int merge = heavy_merge(n_draw, bpd);
   const int nhb = (bpd + merge - 1) / merge;
   const double* hwin = ((flags & EXO_FLAG_EXACT_SCAN) && !(flags & EXO_FLAG_WINDOW)) ? nullptr : w.windows;
   const dim3 hgrid((unsigned)nhb, (unsigned)n_draw);
-  if (secondary)
-    hipLaunchKernelGGL((transit_heavy_kernel<true, true>), hgrid, block, 0, st, t, n_cad, texp, n_texp, stencil_dt,
-                       stencil_w, n_sub, params, ld, n_planet, flags, tpb, bpd, merge, w.counts, w.list, gflux,
-                       flux_dst, w.partial, hwin);
-  else
-    hipLaunchKernelGGL((transit_heavy_kernel<true, false>), hgrid, block, 0, st, t, n_cad, texp, n_texp, stencil_dt,
-                       stencil_w, n_sub, params, ld, n_planet, flags, tpb, bpd, merge, w.counts, w.list, gflux,
-                       flux_dst, w.partial, hwin);
+#define EXO_LAUNCH_HEAVY_VJP(SEC, TTV)                                                                             \
+  hipLaunchKernelGGL((transit_heavy_kernel<true, SEC, TTV>), hgrid, block, 0, st, t, n_cad, texp, n_texp,          \
+                     stencil_dt, stencil_w, n_sub, params, ld, n_planet, flags, tpb, bpd, merge, w.counts, w.list, \
+                     gflux, flux_dst, w.partial, hwin, ttv)
+  if (has_ttv) {
+    if (secondary) EXO_LAUNCH_HEAVY_VJP(true, true);
+    else EXO_LAUNCH_HEAVY_VJP(false, true);
+  } else {
+    if (secondary) EXO_LAUNCH_HEAVY_VJP(true, false);
+    else EXO_LAUNCH_HEAVY_VJP(false, false);
+  }
+#undef EXO_LAUNCH_HEAVY_VJP
   if (launch_status() != EXO_OK) return EXO_ERR_LAUNCH;
   hipLaunchKernelGGL(transit_vjp_reduce_kernel, dim3((unsigned)n_draw), dim3(kBlock), 0, st, w.partial, nhb,
                      n_planet, secondary, gparams, gld, flux_dot);
   if (ev_stop) (void)hipEventRecord((hipEvent_t)ev_stop, st);
   return launch_status();
+}
+
+static bool ttv_args_ok(const double* edges, const double* shift, int32_t n_edge) {
+  return edges && shift && n_edge >= 1 && n_edge <= EXO_MAX_TTV_EDGES;
+}
+
+int exo_transit_flux_fwd_ev_f64(const double* t, int64_t n_cad, const double* texp, int64_t n_texp,
+                                const double* stencil_dt, const double* stencil_w, int32_t n_sub,
+                                const double* params, const double* ld, int64_t n_draw, int32_t n_planet,
+                                uint32_t flags, double* flux, void* workspace, int64_t workspace_bytes,
+                                void* stream, void* ev_start, void* ev_stop) {
+  return transit_fwd(t, n_cad, texp, n_texp, stencil_dt, stencil_w, n_sub, params, ld, n_draw, n_planet, flags,
+                     Ttv{nullptr, nullptr, nullptr, 0}, flux, workspace, workspace_bytes, stream, ev_start, ev_stop);
+}
+
+int exo_transit_flux_fwd_f64(const double* t, int64_t n_cad, const double* texp, int64_t n_texp,
+                             const double* stencil_dt, const double* stencil_w, int32_t n_sub,
+                             const double* params, const double* ld, int64_t n_draw, int32_t n_planet,
+                             uint32_t flags, double* flux, void* workspace, int64_t workspace_bytes, void* stream) {
+  return exo_transit_flux_fwd_ev_f64(t, n_cad, texp, n_texp, stencil_dt, stencil_w, n_sub, params, ld, n_draw,
+                                     n_planet, flags, flux, workspace, workspace_bytes, stream, nullptr, nullptr);
+}
+
+int exo_transit_flux_ttv_fwd_f64(const double* t, int64_t n_cad, const double* texp, int64_t n_texp,
+                                 const double* stencil_dt, const double* stencil_w, int32_t n_sub,
+                                 const double* params, const double* ld, int64_t n_draw, int32_t n_planet,
+                                 uint32_t flags, const double* ttv_edges, const double* ttv_shift, int32_t n_edge,
+                                 double* flux, void* workspace, int64_t workspace_bytes, void* stream) {
+  if (!ttv_args_ok(ttv_edges, ttv_shift, n_edge)) return EXO_ERR_INVALID_ARGUMENT;
+  return transit_fwd(t, n_cad, texp, n_texp, stencil_dt, stencil_w, n_sub, params, ld, n_draw, n_planet, flags,
+                     Ttv{ttv_edges, ttv_shift, nullptr, n_edge}, flux, workspace, workspace_bytes, stream, nullptr,
+                     nullptr);
+}
+
+int exo_transit_flux_vjp_ev_f64(const double* t, int64_t n_cad, const double* texp, int64_t n_texp,
+                                const double* stencil_dt, const double* stencil_w, int32_t n_sub,
+                                const double* params, const double* ld, int64_t n_draw, int32_t n_planet,
+                                uint32_t flags, const double* gflux, double* flux_out, double* gparams,
+                                double* gld, double* flux_dot, void* workspace, int64_t workspace_bytes,
+                                void* stream, void* ev_start, void* ev_stop) {
+  return transit_vjp(t, n_cad, texp, n_texp, stencil_dt, stencil_w, n_sub, params, ld, n_draw, n_planet, flags,
+                     Ttv{nullptr, nullptr, nullptr, 0}, gflux, flux_out, gparams, gld, flux_dot, workspace,
+                     workspace_bytes, stream, ev_start, ev_stop);
 }
 
 int exo_transit_flux_vjp_f64(const double* t, int64_t n_cad, const double* texp, int64_t n_texp,
@@ -1154,6 +1351,19 @@ int exo_transit_flux_vjp_f64(const double* t, int64_t n_cad, const double* texp,
   return exo_transit_flux_vjp_ev_f64(t, n_cad, texp, n_texp, stencil_dt, stencil_w, n_sub, params, ld, n_draw,
                                      n_planet, flags, gflux, flux_out, gparams, gld, flux_dot, workspace,
                                      workspace_bytes, stream, nullptr, nullptr);
+}
+
+int exo_transit_flux_ttv_vjp_f64(const double* t, int64_t n_cad, const double* texp, int64_t n_texp,
+                                 const double* stencil_dt, const double* stencil_w, int32_t n_sub,
+                                 const double* params, const double* ld, int64_t n_draw, int32_t n_planet,
+                                 uint32_t flags, const double* ttv_edges, const double* ttv_shift, int32_t n_edge,
+                                 const double* gflux, double* flux_out, double* gparams, double* gld,
+                                 double* gshift, double* flux_dot, void* workspace, int64_t workspace_bytes,
+                                 void* stream) {
+  if (!ttv_args_ok(ttv_edges, ttv_shift, n_edge) || !gshift) return EXO_ERR_INVALID_ARGUMENT;
+  return transit_vjp(t, n_cad, texp, n_texp, stencil_dt, stencil_w, n_sub, params, ld, n_draw, n_planet, flags,
+                     Ttv{ttv_edges, ttv_shift, gshift, n_edge}, gflux, flux_out, gparams, gld, flux_dot, workspace,
+                     workspace_bytes, stream, nullptr, nullptr);
 }
 
 }  // extern "C"

@@ -116,7 +116,8 @@ class LimbDarkLightCurve:
             stencil = exposure_stencil(oversample, order)   # raises for order > 2 like the reference
         else:
             stencil = None
-        if isinstance(orbit, KeplerianOrbit) and not light_delay and type(orbit)._warp_times is KeplerianOrbit._warp_times:
+        if isinstance(orbit, KeplerianOrbit) and not light_delay and (
+                type(orbit)._warp_times is KeplerianOrbit._warp_times or hasattr(orbit, "kernel_ttv")):
             return self._fused(orbit, r, t, texp, stencil, use_in_transit)
         return self._composed(orbit, r, t, texp, stencil, use_in_transit, light_delay)
 
@@ -130,9 +131,21 @@ class LimbDarkLightCurve:
                                                     secondary=sec)
         t = t.to(rec.device)
         kw = {}
+        if hasattr(orbit, "kernel_ttv"):
+            if secondary is not None:
+                raise ValueError("a TTVOrbit has no flipped orbit (the reference's _flip cannot build one either)")
+            # timing tables and records share one draw batch
+            edges, shift = orbit.kernel_ttv()
+            full = torch.broadcast_shapes(edges.shape[:-2], tuple(batch))
+            P = rec.shape[1]
+            rec = rec.reshape(tuple(batch) + rec.shape[1:]).expand(full + rec.shape[1:]).reshape(-1, P, rec.shape[2])
+            ld = ld.reshape(tuple(batch) + ld.shape[1:]).expand(full + ld.shape[1:]).reshape(-1, ld.shape[1])
+            kw["ttv"] = (edges.expand(full + edges.shape[-2:]).reshape(-1, P, edges.shape[-1]).contiguous(),
+                         shift.expand(full + shift.shape[-2:]).reshape(-1, P, shift.shape[-1]).contiguous())
+            rec, ld, batch = rec.contiguous(), ld.contiguous(), full
         if texp is not None:
             dt, w = stencil
-            kw = dict(texp=as_tensor(texp, t).reshape(-1).detach(),
+            kw.update(texp=as_tensor(texp, t).reshape(-1).detach(),
                       stencil_dt=torch.as_tensor(dt, dtype=torch.float64, device=t.device),
                       stencil_w=torch.as_tensor(w, dtype=torch.float64, device=t.device))
         flux = ops.transit_flux(t.detach(), rec, ld, flags=flags | ops.FLAG_PER_PLANET, **kw)

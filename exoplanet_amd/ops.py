@@ -195,11 +195,26 @@ def _transit_args(t, texp, stencil_dt, stencil_w, params, ld, flags):
     return t, texp, n_texp, stencil_dt, stencil_w, n_sub, params, ld, D, P
 
 
+def _ttv_args(ttv, D, P):
+    """(edges (D, P, E), shift (D, P, E + 1)) of a timing-variation table (include/exoplanet_amd.h)"""
+    if ttv is None:
+        return None, None, 0
+    edges, shift = ttv
+    edges = _dev(edges, "ttv edges")
+    shift = _dev(shift, "ttv shift")
+    if edges.dim() != 3 or tuple(edges.shape[:2]) != (D, P) or edges.shape[2] < 1:
+        raise ValueError("ttv edges must be (n_draw, n_planet, n_edge >= 1)")
+    if tuple(shift.shape) != (D, P, edges.shape[2] + 1):
+        raise ValueError("ttv shift must be (n_draw, n_planet, n_edge + 1)")
+    return edges, shift, int(edges.shape[2])
+
+
 class _TransitFlux(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, t, texp, stencil_dt, stencil_w, params, ld, flags):
+    def forward(ctx, t, texp, stencil_dt, stencil_w, params, ld, flags, ttv_edges, ttv_shift):
         t, texp, n_texp, sdt, sw, n_sub, params, ld, D, P = _transit_args(
             t, texp, stencil_dt, stencil_w, params, ld, flags)
+        edges, shift, n_edge = _ttv_args(None if ttv_edges is None else (ttv_edges, ttv_shift), D, P)
         N = t.numel()
         shape = (D, N, P) if flags & FLAG_PER_PLANET else (D, N)
         flux = torch.empty(shape, dtype=torch.float64, device=t.device)
@@ -207,30 +222,41 @@ class _TransitFlux(torch.autograd.Function):
         nbytes = lib.exo_transit_flux_workspace_bytes(N, D, P)
         ws = torch.empty(max(nbytes // 8 + 1, 1), dtype=torch.float64, device=t.device)
         with torch.cuda.device(t.device):
-            _lib.check(
-                lib.exo_transit_flux_fwd_f64(_ptr(t), N, _ptr(texp), n_texp, _ptr(sdt), _ptr(sw), n_sub,
-                                             _ptr(params), _ptr(ld), D, P, flags, _ptr(flux), _ptr(ws), nbytes,
-                                             _stream(t)),
-                "exo_transit_flux_fwd_f64",
-            )
-        ctx.save_for_backward(t, texp, sdt, sw, params, ld)
+            if n_edge:
+                _lib.check(
+                    lib.exo_transit_flux_ttv_fwd_f64(_ptr(t), N, _ptr(texp), n_texp, _ptr(sdt), _ptr(sw), n_sub,
+                                                     _ptr(params), _ptr(ld), D, P, flags, _ptr(edges), _ptr(shift),
+                                                     n_edge, _ptr(flux), _ptr(ws), nbytes, _stream(t)),
+                    "exo_transit_flux_ttv_fwd_f64",
+                )
+            else:
+                _lib.check(
+                    lib.exo_transit_flux_fwd_f64(_ptr(t), N, _ptr(texp), n_texp, _ptr(sdt), _ptr(sw), n_sub,
+                                                 _ptr(params), _ptr(ld), D, P, flags, _ptr(flux), _ptr(ws), nbytes,
+                                                 _stream(t)),
+                    "exo_transit_flux_fwd_f64",
+                )
+        ctx.save_for_backward(t, texp, sdt, sw, params, ld, edges, shift)
         ctx.meta = (n_texp, n_sub, D, P, flags)
         return flux
 
     @staticmethod
     def backward(ctx, gflux):
-        t, texp, sdt, sw, params, ld = ctx.saved_tensors
+        t, texp, sdt, sw, params, ld, edges, shift = ctx.saved_tensors
         n_texp, n_sub, D, P, flags = ctx.meta
-        _, gparams, gld, _ = _vjp(t, texp, n_texp, sdt, sw, n_sub, params, ld, D, P, flags, gflux, False)
-        return None, None, None, None, gparams, gld, None
+        ttv = None if edges is None else (edges, shift)
+        _, gparams, gld, _, gshift = _vjp(t, texp, n_texp, sdt, sw, n_sub, params, ld, D, P, flags, gflux, False,
+                                          ttv=ttv)
+        return None, None, None, None, gparams, gld, None, None, gshift
 
 
-def _vjp(t, texp, n_texp, sdt, sw, n_sub, params, ld, D, P, flags, gflux, want_flux, events=(None, None)):
+def _vjp(t, texp, n_texp, sdt, sw, n_sub, params, ld, D, P, flags, gflux, want_flux, events=(None, None), ttv=None):
     N = t.numel()
     gflux = _dev(gflux, "gflux")
     shape = (D, N, P) if flags & FLAG_PER_PLANET else (D, N)
     if tuple(gflux.shape) != shape:
         raise ValueError(f"gflux must have shape {shape}")
+    edges, shift, n_edge = _ttv_args(ttv, D, P)
     lib = _lib.load()
     nbytes = lib.exo_transit_flux_workspace_bytes(N, D, P)
     ws = torch.empty(max(nbytes // 8 + 1, 1), dtype=torch.float64, device=t.device)
@@ -238,38 +264,55 @@ def _vjp(t, texp, n_texp, sdt, sw, n_sub, params, ld, D, P, flags, gflux, want_f
     gld = torch.empty_like(ld)
     dot = torch.empty(D, dtype=torch.float64, device=t.device)
     flux = torch.empty(shape, dtype=torch.float64, device=t.device) if want_flux else None
+    gshift = torch.empty_like(shift) if n_edge else None
     with torch.cuda.device(t.device):
-        _lib.check(
-            lib.exo_transit_flux_vjp_ev_f64(_ptr(t), N, _ptr(texp), n_texp, _ptr(sdt), _ptr(sw), n_sub,
-                                            _ptr(params), _ptr(ld), D, P, flags, _ptr(gflux), _ptr(flux),
-                                            _ptr(gparams), _ptr(gld), _ptr(dot), _ptr(ws), nbytes, _stream(t),
-                                            events[0], events[1]),
-            "exo_transit_flux_vjp_f64",
-        )
-    return flux, gparams, gld, dot
+        if n_edge:
+            _lib.check(
+                lib.exo_transit_flux_ttv_vjp_f64(_ptr(t), N, _ptr(texp), n_texp, _ptr(sdt), _ptr(sw), n_sub,
+                                                 _ptr(params), _ptr(ld), D, P, flags, _ptr(edges), _ptr(shift),
+                                                 n_edge, _ptr(gflux), _ptr(flux), _ptr(gparams), _ptr(gld),
+                                                 _ptr(gshift), _ptr(dot), _ptr(ws), nbytes, _stream(t)),
+                "exo_transit_flux_ttv_vjp_f64",
+            )
+        else:
+            _lib.check(
+                lib.exo_transit_flux_vjp_ev_f64(_ptr(t), N, _ptr(texp), n_texp, _ptr(sdt), _ptr(sw), n_sub,
+                                                _ptr(params), _ptr(ld), D, P, flags, _ptr(gflux), _ptr(flux),
+                                                _ptr(gparams), _ptr(gld), _ptr(dot), _ptr(ws), nbytes, _stream(t),
+                                                events[0], events[1]),
+                "exo_transit_flux_vjp_f64",
+            )
+    return flux, gparams, gld, dot, gshift
 
 
-def transit_flux(t, params, ld, texp=None, stencil_dt=None, stencil_w=None, flags=0):
+def transit_flux(t, params, ld, texp=None, stencil_dt=None, stencil_w=None, flags=0, ttv=None):
     """Fused light curve for ``n_draw`` parameter sets.
 
     t (n_cad,), params (n_draw, n_planet, 16) (slot meaning: include/exoplanet_amd.h),
     ld (n_draw, 3|6).  Returns (n_draw, n_cad) or, with FLAG_PER_PLANET,
     (n_draw, n_cad, n_planet).  Differentiable w.r.t. ``params`` and ``ld``.
+    ``ttv = (edges (n_draw, n_planet, E), shift (n_draw, n_planet, E + 1))``: transit-timing
+    variations (every time is measured from the transit of its bin); differentiable
+    w.r.t. ``shift`` as well.
     """
-    return _TransitFlux.apply(t, texp, stencil_dt, stencil_w, params, ld, int(flags))
+    edges, shift = (None, None) if ttv is None else ttv
+    return _TransitFlux.apply(t, texp, stencil_dt, stencil_w, params, ld, int(flags),
+                              None if edges is None else edges.detach(), shift)
 
 
 @torch.no_grad()
 def transit_flux_value_and_vjp(t, params, ld, gflux, texp=None, stencil_dt=None, stencil_w=None, flags=0,
-                               events=(None, None)):
+                               events=(None, None), ttv=None):
     """One sweep over t: flux AND the cotangents of (params, ld) for a given
-    ``gflux`` -- 24 B per (draw, cadence).  Returns (flux, gparams, gld).
+    ``gflux`` -- 24 B per (draw, cadence).  Returns (flux, gparams, gld), plus the
+    cotangent of the shift table when ``ttv`` is given.
     ``events``: optional (hipEvent_t, hipEvent_t) handles (ints) recorded around
     the dominant kernel (profiling hook of the C ABI)."""
     flags = int(flags)
     t, texp, n_texp, sdt, sw, n_sub, params, ld, D, P = _transit_args(t, texp, stencil_dt, stencil_w, params, ld,
                                                                       flags)
-    return _vjp(t, texp, n_texp, sdt, sw, n_sub, params, ld, D, P, flags, gflux, True, events)[:3]
+    out = _vjp(t, texp, n_texp, sdt, sw, n_sub, params, ld, D, P, flags, gflux, True, events, ttv=ttv)
+    return out[:3] if ttv is None else out[:3] + (out[4],)
 
 
 class _TransitFluxDot(torch.autograd.Function):
@@ -278,30 +321,35 @@ class _TransitFluxDot(torch.autograd.Function):
     the parameter cotangents; backward only scales them by dL."""
 
     @staticmethod
-    def forward(ctx, t, texp, stencil_dt, stencil_w, params, ld, gflux, flags, events):
+    def forward(ctx, t, texp, stencil_dt, stencil_w, params, ld, gflux, flags, events, ttv_edges, ttv_shift):
         t, texp, n_texp, sdt, sw, n_sub, params, ld, D, P = _transit_args(
             t, texp, stencil_dt, stencil_w, params, ld, flags)
-        flux, gparams, gld, dot = _vjp(t, texp, n_texp, sdt, sw, n_sub, params, ld, D, P, flags, gflux, True,
-                                       events)
-        ctx.save_for_backward(gparams, gld)
+        ttv = None if ttv_edges is None else (ttv_edges, ttv_shift)
+        flux, gparams, gld, dot, gshift = _vjp(t, texp, n_texp, sdt, sw, n_sub, params, ld, D, P, flags, gflux, True,
+                                               events, ttv=ttv)
+        ctx.save_for_backward(gparams, gld, gshift)
         ctx.mark_non_differentiable(flux)
         ctx.set_materialize_grads(False)  # never build a (D, N) zero cotangent for the detached flux
         return flux, dot
 
     @staticmethod
     def backward(ctx, _gflux_unused, gdot):
-        gparams, gld = ctx.saved_tensors
+        gparams, gld, gshift = ctx.saved_tensors
         if gdot is None:
-            return (None,) * 9
-        return (None, None, None, None, gdot[:, None, None] * gparams, gdot[:, None] * gld, None, None, None)
+            return (None,) * 11
+        return (None, None, None, None, gdot[:, None, None] * gparams, gdot[:, None] * gld, None, None, None, None,
+                None if gshift is None else gdot[:, None, None] * gshift)
 
 
 def transit_flux_dot(t, params, ld, gflux, texp=None, stencil_dt=None, stencil_w=None, flags=0,
-                     events=(None, None)):
+                     events=(None, None), ttv=None):
     """One-sweep value + gradient for a cotangent known in advance: returns
     ``(flux, L)`` with ``L[d] = (gflux[d] * flux[d]).sum()``; ``L`` is
-    differentiable w.r.t. ``params`` and ``ld`` (flux itself is returned detached)."""
-    return _TransitFluxDot.apply(t, texp, stencil_dt, stencil_w, params, ld, gflux, int(flags), events)
+    differentiable w.r.t. ``params`` and ``ld`` (and the ``ttv`` shift table);
+    flux itself is returned detached."""
+    edges, shift = (None, None) if ttv is None else ttv
+    return _TransitFluxDot.apply(t, texp, stencil_dt, stencil_w, params, ld, gflux, int(flags), events,
+                                 None if edges is None else edges.detach(), shift)
 
 
 # ------------------------------------------------------------------------------

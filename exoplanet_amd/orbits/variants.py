@@ -5,11 +5,11 @@
 ``SimpleTransitOrbit``  straight-line transit from observables, no Kepler solve
                         (reference: src/exoplanet/orbits/simple.py).
 
-Both go through the light-curve classes' composed path (``ops.kepler`` /
-``ops.quad_solution_vector``): the fused kernels assume one ``t0`` per planet.
-The per-planet transit lists are ragged, so they live in one padded
-``(n_planet, n_transit_max)`` table and a single batched ``searchsorted`` maps all
-cadences of all planets at once.  Unbatched (no draw dimension).
+``TTVOrbit`` light curves run in the fused kernels (the per-planet transit lists are
+ragged, so they live in one padded ``(..., n_planet, n_transit_max)`` table that the
+kernels search per cadence; include/exoplanet_amd.h, ``exo_transit_flux_ttv_*``); its
+position / velocity methods, and everything of ``SimpleTransitOrbit``, go through the
+composed path (``ops.kepler`` / ``ops.quad_solution_vector``), unbatched.
 """
 import numpy as np
 import torch
@@ -31,31 +31,35 @@ def compute_expected_transit_times(min_time, max_time, period, t0):
 
 
 class _TransitTable:
-    """nearest-transit lookup for all planets at once.
+    """nearest-transit lookup for all planets (and all draws) at once.
 
-    Row p holds planet p's complete transit list (observed or interpolated);
-    ``edges`` are the midpoints between neighbours, closed by half a period on
-    either side (ttv.py:149-163), padded with +inf; ``centres[p, k]`` is the
-    transit a time in bin k belongs to."""
+    Row p holds planet p's complete transit list (observed or interpolated), shape
+    ``batch + (n_p,)``; ``edges`` ``batch + (P, width + 1)`` are the midpoints between
+    neighbours, closed by half a period on either side (ttv.py:158-166), padded with +inf;
+    ``centres[..., p, k]`` is the transit a time in bin k belongs to (ttv.py:167-170)."""
 
     def __init__(self, all_times, ttv_period):
         P = len(all_times)
-        width = max(int(x.shape[0]) for x in all_times)
+        width = max(int(x.shape[-1]) for x in all_times)
+        batch = torch.broadcast_shapes(ttv_period.shape[:-1], *[x.shape[:-1] for x in all_times])
         dev = all_times[0].device
-        self.edges = torch.full((P, width + 1), float("inf"), dtype=torch.float64, device=dev)
+        self.edges = torch.full(batch + (P, width + 1), float("inf"), dtype=torch.float64, device=dev)
         centres = []
         for p, tts in enumerate(all_times):
-            n = tts.shape[0]
-            mids = 0.5 * (tts[1:] + tts[:-1])
-            row = torch.cat([(tts[0] - 0.5 * ttv_period[p]).reshape(1), mids, (tts[-1] + 0.5 * ttv_period[p]).reshape(1)])
-            self.edges[p, :n + 1] = row.detach()
+            tts = tts.expand(batch + tts.shape[-1:])
+            n = tts.shape[-1]
+            half = 0.5 * ttv_period[..., p].expand(batch).unsqueeze(-1)
+            row = torch.cat([tts[..., :1] - half, 0.5 * (tts[..., 1:] + tts[..., :-1]), tts[..., -1:] + half], dim=-1)
+            self.edges[..., p, :n + 1] = row.detach()
             # bins: (-inf, e0] -> first transit, (e_k, e_k+1] -> transit k, beyond the last edge -> last transit
-            c = torch.cat([tts[:1], tts, tts[-1:].expand(width + 1 - n)])
-            centres.append(c)
-        self.centres = torch.stack(centres)          # (P, width + 2), differentiable in the transit times
+            centres.append(torch.cat([tts[..., :1], tts, tts[..., -1:].expand(batch + (width + 1 - n,))], dim=-1))
+        self.centres = torch.stack(centres, dim=-2)   # batch + (P, width + 2), differentiable in the transit times
 
     def nearest(self, t_by_planet):
-        """t_by_planet (P, ...) -> the matching transit time of each entry, same shape"""
+        """t_by_planet (P, ...) -> the matching transit time of each entry, same shape (unbatched tables)"""
+        if self.edges.dim() != 2:
+            raise ValueError("the composed TTVOrbit path is unbatched; batched timing tables go through "
+                             "LimbDarkLightCurve.get_light_curve (fused kernels)")
         flat = t_by_planet.reshape(t_by_planet.shape[0], -1).detach().contiguous()
         idx = torch.searchsorted(self.edges, flat)
         return torch.gather(self.centres, 1, idx).reshape(t_by_planet.shape)
@@ -65,16 +69,25 @@ class TTVOrbit(KeplerianOrbit):
     """KeplerianOrbit plus exactly one of ``ttvs`` (O-C offsets per labelled transit, per
     planet) or ``transit_times`` (observed times; the least-squares period and t0 follow
     from them), optionally ``transit_inds`` (zero-based transit numbers when transits are
-    missing) and, with ``transit_times``, ``delta_log_period``."""
+    missing) and, with ``transit_times``, ``delta_log_period``.
+
+    Beyond the reference: each ``ttvs[p]`` / ``transit_times[p]`` may carry leading draw
+    dimensions ``(..., n_transit_p)`` (broadcast against the other parameters' draw
+    dimensions); ``LimbDarkLightCurve.get_light_curve`` then evaluates all draws in the
+    fused kernels.  The position / velocity methods stay unbatched like the reference."""
 
     def __init__(self, *args, ttvs=None, transit_times=None, transit_inds=None, **kwargs):
         if ttvs is None and transit_times is None:
             raise ValueError("one of 'ttvs' or 'transit_times' must be defined")
-        flat = lambda x: as_tensor(x).reshape(-1)  # noqa: E731
-        given = [flat(x) for x in (ttvs if ttvs is not None else transit_times)]
+
+        def rows(x):
+            x = as_tensor(x)
+            return x.reshape(-1) if x.dim() == 0 else x
+
+        given = [rows(x) for x in (ttvs if ttvs is not None else transit_times)]
         dev = given[0].device
         if transit_inds is None:
-            self.transit_inds = [torch.arange(x.shape[0], device=dev) for x in given]
+            self.transit_inds = [torch.arange(x.shape[-1], device=dev) for x in given]
         else:
             self.transit_inds = [torch.as_tensor(i, dtype=torch.int64, device=dev).reshape(-1) for i in transit_inds]
         if ttvs is not None:
@@ -83,9 +96,10 @@ class TTVOrbit(KeplerianOrbit):
             # straight-line fit time = intercept + slope * index per planet (ttv.py:99-123)
             self.transit_times = given
             fits = [self._line_fit(ix.to(torch.float64), tt) for ix, tt in zip(self.transit_inds, given)]
-            self.ttv_period = torch.stack([f[0] for f in fits])
-            kwargs["t0"] = torch.stack([f[1] for f in fits])
-            self.ttvs = [tt - (f[1] + ix.to(torch.float64) * f[0])
+            slopes = torch.broadcast_tensors(*[f[0] for f in fits])
+            self.ttv_period = torch.stack(slopes, dim=-1)
+            kwargs["t0"] = torch.stack(torch.broadcast_tensors(*[f[1] for f in fits]), dim=-1)
+            self.ttvs = [tt - (f[1].unsqueeze(-1) + ix.to(torch.float64) * f[0].unsqueeze(-1))
                          for f, ix, tt in zip(fits, self.transit_inds, given)]
             if "period" not in kwargs:
                 dlp = kwargs.pop("delta_log_period", None)
@@ -94,28 +108,43 @@ class TTVOrbit(KeplerianOrbit):
         self._standard = False          # one t0 per planet is exactly what this orbit does not have
         if ttvs is not None:
             self.ttv_period = self.period
-            self.transit_times = [self.t0[p] + self.period[p] * ix + dv
+            self.transit_times = [self.t0[..., p:p + 1] + self.period[..., p:p + 1] * ix + dv
                                   for p, (ix, dv) in enumerate(zip(self.transit_inds, self.ttvs))]
         # fill unobserved transit numbers with the linear ephemeris (ttv.py:141-147)
         self.all_transit_times = []
         for p, ix in enumerate(self.transit_inds):
-            grid = self.t0[p] + self.period[p] * torch.arange(int(ix.max().item()) + 1, device=dev)
-            self.all_transit_times.append(grid.index_put((ix,), self.transit_times[p]))
+            count = int(ix.max().item()) + 1
+            grid = self.t0[..., p:p + 1] + self.period[..., p:p + 1] * torch.arange(count, device=dev)
+            obs = self.transit_times[p]
+            shape = torch.broadcast_shapes(grid.shape[:-1], obs.shape[:-1])
+            grid = grid.expand(shape + (count,)).clone()
+            grid[..., ix] = obs.expand(shape + obs.shape[-1:])
+            self.all_transit_times.append(grid)
         self._table = _TransitTable(self.all_transit_times, self.ttv_period)
 
     @staticmethod
     def _line_fit(x, y):
         n = x.shape[0]
-        sx, sxx, sy, sxy = x.sum(), (x * x).sum(), y.sum(), (x * y).sum()
+        sx, sxx, sy, sxy = x.sum(), (x * x).sum(), y.sum(-1), (x * y).sum(-1)
         det = n * sxx - sx * sx
         return (n * sxy - sx * sy) / det, (sxx * sy - sx * sxy) / det   # slope, intercept
 
     def _warp_times(self, t, _pad=True):
         """time since the nearest labelled transit, shape (..., P) (ttv.py:175-187)"""
         t = as_tensor(t, self.n)
-        P = self._table.edges.shape[0]
+        P = self._table.edges.shape[-2]
         per_planet = t.unsqueeze(0).expand((P,) + tuple(t.shape)) if _pad else t.movedim(-1, 0)
         return (per_planet - self._table.nearest(per_planet)).movedim(0, -1)
+
+    def kernel_ttv(self):
+        """the fused kernels' timing tables (include/exoplanet_amd.h): bin edges ``batch + (P, E)``
+        (no gradient, like the reference's searchsorted) and per-bin shifts ``batch + (P, E + 1)``
+        = transit time of the bin - t0, differentiable"""
+        centres = self._table.centres
+        t0 = self.t0
+        shape = torch.broadcast_shapes(centres.shape[:-1], t0.shape)
+        shift = centres.expand(shape + centres.shape[-1:]) - t0.expand(shape).unsqueeze(-1)
+        return self._table.edges.expand(shape + self._table.edges.shape[-1:]), shift
 
 
 class SimpleTransitOrbit:

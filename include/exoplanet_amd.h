@@ -167,6 +167,42 @@ int exo_transit_flux_vjp_ev_f64(const double* t, int64_t n_cad, const double* te
                                 void* ev_stop);
 
 /* ---------------------------------------------------------------------------
+ * The same two sweeps for an orbit with transit-timing variations
+ *   TTVOrbit._get_model_dt / _warp_times   (src/exoplanet/orbits/ttv.py:158-187)
+ * Every time -- cadence or sub-exposure -- is measured from its nearest labelled
+ * transit before it reaches the orbit: planet p of draw d has
+ *   ttv_edges [n_draw][n_planet][n_edge]      ascending bin edges (ttv.py:158-166:
+ *                                             midpoints between consecutive transit times,
+ *                                             closed by half a period either side); rows
+ *                                             with fewer edges are padded with +inf
+ *   ttv_shift [n_draw][n_planet][n_edge + 1]  per bin k = #{edges < t} (searchsorted,
+ *                                             ttv.py:171-172): transit time of the bin
+ *                                             (ttv.py:167-170) MINUS the record's t0
+ * and a time t acts as t - ttv_shift[k(t)]: mean anomaly (t - shift - TP) N, window
+ * phase t - shift - T0.  The reverse sweep adds
+ *   gshift    [n_draw][n_planet][n_edge + 1]  d sum(gflux * flux) / d ttv_shift
+ * (hardware fp64 atomics, one per wave and cadence run: the last bits of gshift depend
+ * on scheduling; everything else is as reproducible as without timing variations).
+ * EXO_FLAG_WINDOW: the caller's windows are tested on the warped mid-exposure time
+ * (keplerian.py:729-731 with ttv.py:181-187).
+ * ------------------------------------------------------------------------- */
+#define EXO_MAX_TTV_EDGES 65536
+int exo_transit_flux_ttv_fwd_f64(const double* t, int64_t n_cad, const double* texp, int64_t n_texp,
+                                 const double* stencil_dt, const double* stencil_w, int32_t n_sub,
+                                 const double* params, const double* ld, int64_t n_draw,
+                                 int32_t n_planet, uint32_t flags, const double* ttv_edges,
+                                 const double* ttv_shift, int32_t n_edge, double* flux,
+                                 void* workspace, int64_t workspace_bytes, void* stream);
+int exo_transit_flux_ttv_vjp_f64(const double* t, int64_t n_cad, const double* texp, int64_t n_texp,
+                                 const double* stencil_dt, const double* stencil_w, int32_t n_sub,
+                                 const double* params, const double* ld, int64_t n_draw,
+                                 int32_t n_planet, uint32_t flags, const double* ttv_edges,
+                                 const double* ttv_shift, int32_t n_edge, const double* gflux,
+                                 double* flux_out, double* gparams, double* gld, double* gshift,
+                                 double* flux_dot, void* workspace, int64_t workspace_bytes,
+                                 void* stream);
+
+/* ---------------------------------------------------------------------------
  * celerite GP log-likelihood, value + VJP, for n_draw independent (kernel,
  * residual) pairs.  Replaces what celerite2 (a dependency of the reference,
  * /root/reference/setup.py:36; the user's model calls it, the reference tree

@@ -504,10 +504,13 @@ class KeplerianOrbit:
         cO, sO = np.cos(self.Omega), np.sin(self.Omega)
         return cO * x2 - sO * y2, sO * x2 + cO * y2, Z
 
+    def _warp_times(self, t, _pad=True):
+        """reference: keplerian.py:324-327"""
+        return (t[..., None] if _pad else t) - self.t0
+
     def _get_true_anomaly(self, t, _pad=True):
-        """reference: keplerian.py:324-334"""
-        tt = t[..., None] if _pad else t
-        M = (tt - self.t0 - self.tref) * self.n
+        """reference: keplerian.py:329-334"""
+        M = (self._warp_times(t, _pad=_pad) - self.tref) * self.n
         if self.ecc is None:
             return np.sin(M), np.cos(M)
         return kepler(M, self.ecc + np.zeros_like(M))
@@ -560,7 +563,7 @@ class KeplerianOrbit:
         r = np.asarray(r, dtype=np.float64) + z
         R = self.r_star + z
         hp = 0.5 * self.period
-        dt = np.mod(t[..., None] - self.t0 + hp, self.period) - hp
+        dt = np.mod(self._warp_times(t) + hp, self.period) - hp
         if self.ecc is None:
             k = r / R
             arg = np.square(1 + k) - np.square(self.b)
@@ -593,6 +596,86 @@ class KeplerianOrbit:
         return KeplerianOrbit(period=self.period, t_periastron=self.t_periastron, incl=self.incl,
                               ecc=self.ecc, omega=self.omega - np.pi, Omega=self.Omega,
                               m_star=self.m_planet, m_planet=self.m_star, r_star=r_planet)
+
+
+class TTVOrbit(KeplerianOrbit):
+    """reference: src/exoplanet/orbits/ttv.py:71-187.  ``ttvs`` / ``transit_times`` /
+    ``transit_inds``: one 1-D array per planet."""
+
+    def __init__(self, *args, ttvs=None, transit_times=None, transit_inds=None, delta_log_period=None, **kwargs):
+        if ttvs is None and transit_times is None:
+            raise ValueError("one of 'ttvs' or 'transit_times' must be defined")
+        if ttvs is not None:
+            # ttv.py:79-89
+            self.ttvs = [np.asarray(x, dtype=np.float64).reshape(-1) for x in ttvs]
+            if transit_inds is None:
+                self.transit_inds = [np.arange(x.size) for x in self.ttvs]
+            else:
+                self.transit_inds = [np.asarray(i, dtype=np.int64).reshape(-1) for i in transit_inds]
+        else:
+            # ttv.py:91-137: least-squares line through (index, time) per planet
+            self.transit_times, self.ttvs, self.transit_inds = [], [], []
+            period, t0 = [], []
+            for i, times in enumerate(transit_times):
+                times = np.asarray(times, dtype=np.float64).reshape(-1)
+                inds = np.arange(times.size) if transit_inds is None else np.asarray(transit_inds[i], dtype=np.int64)
+                self.transit_inds.append(inds)
+                N = times.size
+                sumx, sumx2, sumy, sumxy = np.sum(inds), np.sum(inds ** 2), np.sum(times), np.sum(inds * times)
+                denom = N * sumx2 - sumx ** 2
+                slope = (N * sumxy - sumx * sumy) / denom
+                intercept = (sumx2 * sumy - sumx * sumxy) / denom
+                period.append(slope)
+                t0.append(intercept)
+                self.ttvs.append(times - (intercept + inds * slope))
+                self.transit_times.append(times)
+            kwargs["t0"] = np.array(t0)
+            self.ttv_period = np.array(period)
+            if "period" not in kwargs:
+                kwargs["period"] = (self.ttv_period if delta_log_period is None
+                                    else np.exp(np.log(self.ttv_period) + delta_log_period))
+        super().__init__(*args, **kwargs)
+        t0 = np.atleast_1d(self.t0)
+        per = np.atleast_1d(self.period)
+        if ttvs is not None:
+            # ttv.py:141-147
+            self.ttv_period = per
+            self.transit_times = [t0[i] + per[i] * self.transit_inds[i] + ttv for i, ttv in enumerate(self.ttvs)]
+        # ttv.py:149-156: unobserved transit numbers follow the linear ephemeris
+        self.all_transit_times = []
+        for i, inds in enumerate(self.transit_inds):
+            expect = t0[i] + per[i] * np.arange(inds.max() + 1)
+            expect[inds] = self.transit_times[i]
+            self.all_transit_times.append(expect)
+        # ttv.py:158-170
+        self._bin_edges = [np.concatenate(([tts[0] - 0.5 * self.ttv_period[i]], 0.5 * (tts[1:] + tts[:-1]),
+                                           [tts[-1] + 0.5 * self.ttv_period[i]]))
+                           for i, tts in enumerate(self.all_transit_times)]
+        self._bin_values = [np.concatenate(([tts[0]], tts, [tts[-1]])) for tts in self.all_transit_times]
+
+    def _get_model_dt(self, t):
+        """reference: ttv.py:172-177"""
+        return np.stack([self._bin_values[i][np.searchsorted(self._bin_edges[i], t)]
+                         for i in range(len(self.ttvs))], axis=-1)
+
+    def _warp_times(self, t, _pad=True):
+        """reference: ttv.py:179-187"""
+        if _pad:
+            return t[..., None] - self._get_model_dt(t)
+        return t - self._get_model_dt(t)
+
+    def kernel_tables(self):
+        """the fused entry points' view of the same histogram (include/exoplanet_amd.h,
+        exo_transit_flux_ttv_*): edges (P, E) padded with +inf, shift (P, E + 1) = bin value - t0"""
+        E = max(e.size for e in self._bin_edges)
+        t0 = np.atleast_1d(self.t0)
+        edges = np.full((len(self.ttvs), E), np.inf)
+        shift = np.zeros((len(self.ttvs), E + 1))
+        for i, (e, v) in enumerate(zip(self._bin_edges, self._bin_values)):
+            edges[i, :e.size] = e
+            shift[i, :v.size] = v - t0[i]
+            shift[i, v.size:] = v[-1] - t0[i]
+        return edges, shift
 
 
 class LimbDarkLightCurve:
@@ -809,7 +892,7 @@ def _sample(tt, rec, c, secondary, jac):
 
 
 def transit_flux(t, params, ld, texp=None, stencil_dt=None, stencil_w=None, per_planet=False, window=False,
-                 secondary=False, jac=False):
+                 secondary=False, jac=False, ttv=None):
     """flux [D,N] or [D,N,P]; with jac also J_params [D,N,(P),P,NPAR] is too big, so
     returns a callable-free form: (flux, dF_dparams [D,P,NPAR,N(,only own planet)], dF_dld [D,N(,P),nld])."""
     t = np.asarray(t, dtype=np.float64)
@@ -828,12 +911,21 @@ def transit_flux(t, params, ld, texp=None, stencil_dt=None, stencil_w=None, per_
     flux = np.zeros((D, N, P))
     dpar = np.zeros((D, P, NPAR, N)) if jac else None           # d flux[d,:,p] / d params[d,p,slot]
     dld = np.zeros((D, N, P, nld)) if jac else None
+    # timing variations (ttv.py:172-187): every time of the grid minus the shift of its bin;
+    # dshift[d][p] = (bin of each grid time, d flux sample / d shift of that bin)
+    dshift = [[None] * P for _ in range(D)] if (jac and ttv is not None) else None
     for d in range(D):
         for p in range(P):
             rec = params[d, p]
-            F, dF, dc = _sample(tgrid, rec, ld[d], secondary, jac)
+            tg, tc = tgrid, t
+            if ttv is not None:
+                edges, shift = np.asarray(ttv[0])[d, p], np.asarray(ttv[1])[d, p]
+                bins = np.searchsorted(edges, tgrid)
+                tg = tgrid - shift[bins]
+                tc = t - shift[np.searchsorted(edges, t)]
+            F, dF, dc = _sample(tg, rec, ld[d], secondary, jac)
             if window:
-                m = _window_mask(t, rec, 0.5 * tex, secondary)
+                m = _window_mask(tc, rec, 0.5 * tex, secondary)
             else:
                 m = np.ones(N, dtype=bool)
             flux[d, :, p] = np.where(m, F @ sw_, 0.0)
@@ -841,24 +933,38 @@ def transit_flux(t, params, ld, texp=None, stencil_dt=None, stencil_w=None, per_
                 for k, v in dF.items():
                     dpar[d, p, k] = np.where(m, v @ sw_, 0.0)
                 dld[d, :, p] = np.where(m[:, None], np.einsum("nkc,k->nc", dc, sw_), 0.0)
+                if ttv is not None:
+                    # the shift enters exactly like t_periastron: (t - shift - tp) n
+                    dshift[d][p] = (bins, np.where(m[:, None], dF[P_TP] * sw_[None, :], 0.0))
     if not per_planet:
         fl = flux.sum(axis=2)
     else:
         fl = flux
+    if jac and ttv is not None:
+        return fl, dpar, dld, dshift
     return (fl, dpar, dld) if jac else fl
 
 
 def transit_flux_vjp(t, params, ld, gflux, **kw):
-    """Cotangents (gparams [D,P,NPAR], gld [D,nld]) for gflux shaped like the flux."""
+    """Cotangents (gparams [D,P,NPAR], gld [D,nld]) for gflux shaped like the flux; with
+    ``ttv=(edges, shift)`` also the cotangent of the shift table."""
     per_planet = kw.get("per_planet", False)
-    fl, dpar, dld = transit_flux(t, params, ld, jac=True, **kw)
+    out = transit_flux(t, params, ld, jac=True, **kw)
+    fl, dpar, dld = out[:3]
     D, P, _ = np.asarray(params).shape
     g = np.asarray(gflux, dtype=np.float64)
     if not per_planet:
         g = np.repeat(g[:, :, None], P, axis=2)
     gparams = np.einsum("dpkn,dnp->dpk", dpar, g)
     gld = np.einsum("dnpc,dnp->dc", dld, g)
-    return fl, gparams, gld
+    if kw.get("ttv") is None:
+        return fl, gparams, gld
+    gshift = np.zeros_like(np.asarray(kw["ttv"][1], dtype=np.float64))
+    for d in range(D):
+        for p in range(P):
+            bins, dF = out[3][d][p]
+            np.add.at(gshift[d, p], bins, g[d, :, p][:, None] * dF)
+    return fl, gparams, gld, gshift
 
 
 # =============================================================================

@@ -1,0 +1,265 @@
+"""GPU parity: transit-timing variations in the fused kernels (exo_transit_flux_ttv_*), against
+the oracle's record-level evaluation, its restatement of the reference glue
+(get_light_curve(orbit=TTVOrbit), ttv.py + limb_dark.py) and the composed torch path."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import numpy_port as P
+from test_gpu_transit import T, make_record
+from test_oracle_ttv import expected_times, ttv_case
+
+pytestmark = pytest.mark.gpu
+
+
+def npy(x):
+    return x.detach().cpu().numpy()
+
+
+def check(dev, t, rec, c, tables, texp=None, order=0, oversample=7, window=False, per_planet=False, secondary=False,
+          seed=42):
+    """forward, one-sweep value + VJP and autograd of the HIP path against the oracle"""
+    from exoplanet_amd import ops
+
+    edges, shift = tables
+    D, Pn = rec.shape[:2]
+    kw, tk = {}, {}
+    if texp is not None:
+        sdt, sw = P.exposure_stencil(oversample, order)
+        kw = dict(texp=texp, stencil_dt=sdt, stencil_w=sw)
+        tk = dict(texp=T(np.atleast_1d(texp), dev), stencil_dt=T(sdt, dev), stencil_w=T(sw, dev))
+    g = np.random.default_rng(seed).normal(size=(D, t.size, Pn) if per_planet else (D, t.size))
+    want_f, want_gp, want_gl, want_gs = P.transit_flux_vjp(t, rec, c, g, per_planet=per_planet, window=window,
+                                                           secondary=secondary, ttv=(edges, shift), **kw)
+    flags = ((ops.FLAG_PER_PLANET if per_planet else 0) | (ops.FLAG_WINDOW if window else 0)
+             | (ops.FLAG_SECONDARY if secondary else 0))
+    ttv = (T(edges, dev), T(shift, dev))
+    f = ops.transit_flux(T(t, dev), T(rec, dev), T(c, dev), flags=flags, ttv=ttv, **tk)
+    f2, gp, gl, gs = ops.transit_flux_value_and_vjp(T(t, dev), T(rec, dev), T(c, dev), T(g, dev), flags=flags,
+                                                    ttv=ttv, **tk)
+    assert want_f.min() < -1e-3
+    np.testing.assert_allclose(npy(f), want_f, rtol=0, atol=2e-13)
+    assert torch.equal(f, f2)
+    slots = list(P.GRAD_SLOTS[:-1]) + ([P.GRAD_SLOTS[-1]] if secondary else [])
+    scale = np.abs(want_gp[..., slots]).max() + 1e-30
+    assert np.abs(npy(gp)[..., slots] - want_gp[..., slots]).max() <= 1e-9 * scale + 1e-12
+    np.testing.assert_allclose(npy(gl), want_gl, rtol=1e-10, atol=1e-10)
+    assert np.abs(want_gs).max() > 1e-6
+    assert np.abs(npy(gs) - want_gs).max() <= 1e-9 * np.abs(want_gs).max() + 1e-12
+    # the bins hold the whole t_periastron cotangent, split by transit
+    np.testing.assert_allclose(npy(gs).sum(-1), npy(gp)[..., P.P_TP], rtol=1e-9, atol=1e-9 * scale)
+    return f
+
+
+def case_records(missing=True, draws=1, seed=11):
+    """D draws of the two-planet case: each draw has its own timing offsets"""
+    recs, edges, shifts = [], [], []
+    for d in range(draws):
+        kw = ttv_case(seed=seed + d, missing=missing)
+        orbit = P.TTVOrbit(**kw)
+        recs.append(make_record(orbit, np.array([0.08, 0.05]))[0])
+        e, s = orbit.kernel_tables()
+        edges.append(e)
+        shifts.append(s)
+    return np.stack(recs), (np.stack(edges), np.stack(shifts))
+
+
+@pytest.mark.parametrize("missing", [False, True])
+def test_ttv_parity(dev, missing):
+    rec, tables = case_records(missing)
+    t = np.linspace(0.0, 80.0, 6000)
+    check(dev, t, rec, P.get_cl(0.3, 0.2)[None], tables)
+    check(dev, t, rec, P.get_cl(0.3, 0.2)[None], tables, per_planet=True)
+
+
+@pytest.mark.parametrize("order", [0, 1, 2])
+def test_ttv_parity_texp(dev, order):
+    rec, tables = case_records()
+    t = np.linspace(0.0, 80.0, 5001)     # odd count: the scalar-load variant of the kernels
+    check(dev, t, rec, P.get_cl(0.3, 0.2)[None], tables, texp=0.1, order=order)
+    # one exposure time per cadence
+    texp = np.random.default_rng(1).uniform(0.02, 0.2, t.size)
+    check(dev, t, rec, P.get_cl(0.3, 0.2)[None], tables, texp=texp, order=order, per_planet=True)
+
+
+def test_ttv_draws_have_their_own_tables(dev):
+    rec, tables = case_records(draws=5)
+    c = np.stack([P.get_cl(0.1 + 0.1 * d, 0.2) for d in range(5)])
+    t = np.linspace(-10.0, 95.0, 7000)    # also before the first and after the last labelled transit
+    check(dev, t, rec, c, tables)
+    check(dev, t, rec, c, tables, texp=0.05)
+
+
+def test_ttv_unsorted_times(dev):
+    rec, tables = case_records()
+    t = np.random.default_rng(3).permutation(np.linspace(0.0, 80.0, 6000))
+    check(dev, t, rec, P.get_cl(0.3, 0.2)[None], tables, texp=0.05)
+
+
+def test_ttv_window_semantics(dev):
+    """use_in_transit: the caller's windows act on the warped mid-exposure time
+    (keplerian.py:729-731 through ttv.py:179-187) and give the same light curve"""
+    orbit = P.TTVOrbit(**ttv_case())
+    r = np.array([0.08, 0.05])
+    tables = tuple(x[None] for x in orbit.kernel_tables())
+    t = np.linspace(0.0, 80.0, 6000)
+    c = P.get_cl(0.3, 0.2)[None]
+    for texp in (None, 0.1):
+        a = check(dev, t, make_record(orbit, r, window=True), c, tables, texp=texp, window=True, per_planet=True)
+        b = check(dev, t, make_record(orbit, r), c, tables, texp=texp, per_planet=True)
+        assert torch.allclose(a, b, rtol=0, atol=1e-15)
+
+
+def test_ttv_secondary(dev):
+    """the occultation follows the same warped clock (ops level: the reference's TTVOrbit has no
+    flipped orbit, secondary_eclipse.py:52 would raise)"""
+    orbit = P.TTVOrbit(**ttv_case(missing=False))
+    rec = make_record(orbit, np.array([0.08, 0.05]), sbr=0.4)
+    tables = tuple(x[None] for x in orbit.kernel_tables())
+    c6 = np.concatenate([P.get_cl(0.3, 0.2), P.get_cl(0.1, 0.4)])[None]
+    t = np.linspace(0.0, 80.0, 6000)
+    check(dev, t, rec, c6, tables, secondary=True)
+    check(dev, t, rec, c6, tables, secondary=True, texp=0.1)
+
+
+def test_bin_edge_inside_an_exposure(dev):
+    """arbitrary tables: an edge in the middle of a transit, different clocks on either side --
+    sub-exposures of one cadence then belong to different bins (ttv.py warps every grid time),
+    and their cotangents go to different shift entries"""
+    orbit = P.KeplerianOrbit(period=5.0, t0=1.0, b=0.3, ecc=0.2, omega=0.7)
+    rec = make_record(orbit, np.array([0.1]))
+    edges = np.array([[[-1.5, 1.02, 3.5, 6.03, 8.5, np.inf]]])
+    shift = np.array([[[0.0, 0.0, 0.04, 5.0, 5.03, 10.0, 10.0]]])
+    t = np.linspace(-2.0, 12.0, 4000)
+    c = P.get_cl(0.3, 0.2)[None]
+    for texp, order in ((0.06, 0), (0.3, 2)):
+        check(dev, t, rec, c, (edges, shift), texp=texp, order=order)
+    check(dev, t, rec, c, (edges, shift))
+
+
+def test_single_bin_table_is_a_time_offset(dev):
+    from exoplanet_amd import ops
+
+    orbit = P.KeplerianOrbit(period=3.5, t0=1.0, b=0.3, ecc=0.3, omega=1.1)
+    rec = make_record(orbit, np.array([0.1]))
+    t = np.arange(6000) * (2.0 / 1440.0)
+    c = P.get_cl(0.3, 0.2)[None]
+    edges = np.full((1, 1, 1), np.inf)
+    shift = np.full((1, 1, 2), 0.0123)
+    got = ops.transit_flux(T(t, dev), T(rec, dev), T(c, dev), ttv=(T(edges, dev), T(shift, dev)))
+    want = ops.transit_flux(T(t - 0.0123, dev), T(rec, dev), T(c, dev))
+    assert float(want.min()) < -5e-3
+    np.testing.assert_allclose(npy(got), npy(want), rtol=0, atol=1e-12)
+
+
+def test_argument_checks(dev):
+    from exoplanet_amd import ops
+
+    orbit = P.KeplerianOrbit(period=3.5, t0=1.0, b=0.3)
+    rec = T(make_record(orbit, np.array([0.1])), dev)
+    t = T(np.linspace(0, 5, 100), dev)
+    c = T(P.get_cl(0.3, 0.2)[None], dev)
+    with pytest.raises(ValueError):
+        ops.transit_flux(t, rec, c, ttv=(T(np.zeros((1, 2, 3)), dev), T(np.zeros((1, 2, 4)), dev)))
+    with pytest.raises(ValueError):
+        ops.transit_flux(t, rec, c, ttv=(T(np.zeros((1, 1, 3)), dev), T(np.zeros((1, 1, 3)), dev)))
+    with pytest.raises(RuntimeError):
+        ops.transit_flux(t, rec, c, ttv=(torch.zeros(1, 1, 3, dtype=torch.float64), T(np.zeros((1, 1, 4)), dev)))
+
+
+# ------------------------------------------------------------------ the reference-shaped API
+def torch_case(dev, kw, requires_grad=False, draws=None, seed=0):
+    rng = np.random.default_rng(seed)
+    tk = {}
+    for k, v in kw.items():
+        if k == "transit_inds":
+            tk[k] = v
+        elif k == "ttvs":
+            vals = v if draws is None else [np.stack([x + 0.02 * rng.normal(size=x.shape) for _ in range(draws)])
+                                            for x in v]
+            tk[k] = [T(x, dev).requires_grad_(requires_grad) for x in vals]
+        else:
+            tk[k] = T(v, dev)
+    return tk
+
+
+@pytest.mark.parametrize("texp", [None, 0.08])
+def test_light_curve_api_matches_reference_glue(dev, texp):
+    """LimbDarkLightCurve.get_light_curve(orbit=TTVOrbit): fused kernels == the oracle's
+    restatement of limb_dark.py + ttv.py == the composed torch path, values and gradients"""
+    import exoplanet_amd as xo
+    from exoplanet_amd.orbits import TTVOrbit
+
+    kw = ttv_case()
+    r = np.array([0.08, 0.05])
+    t = np.linspace(0.0, 80.0, 5000)
+    want = P.LimbDarkLightCurve(0.3, 0.2).get_light_curve(orbit=P.TTVOrbit(**kw), r=r, t=t, texp=texp)
+    lc = xo.LimbDarkLightCurve(0.3, 0.2)
+    g = T(np.random.default_rng(2).normal(size=want.shape), dev)
+    grads = []
+    for route in ("fused", "composed"):
+        tk = torch_case(dev, kw, requires_grad=True)
+        period = tk["period"].requires_grad_(True)
+        orbit = TTVOrbit(**tk)
+        if route == "fused":
+            got = lc.get_light_curve(orbit=orbit, r=T(r, dev), t=T(t, dev), texp=texp)
+        else:
+            stencil = None if texp is None else xo.light_curves.limb_dark.exposure_stencil(7, 0)
+            got = lc._composed(orbit, T(r, dev), T(t, dev), texp, stencil, True, False)
+        np.testing.assert_allclose(npy(got), want, rtol=0, atol=1e-12)
+        grads.append(torch.autograd.grad((got * g).sum(), tk["ttvs"] + [period]))
+    for a, b in zip(*grads):
+        assert float(b.abs().max()) > 0
+        np.testing.assert_allclose(npy(a), npy(b), rtol=1e-8, atol=1e-9 * float(b.abs().max()))
+
+
+def test_light_curve_api_draws(dev):
+    """ttvs with a leading draw dimension: every draw equals its own unbatched evaluation"""
+    import exoplanet_amd as xo
+    from exoplanet_amd.orbits import TTVOrbit
+
+    kw = ttv_case()
+    r, t = T(np.array([0.08, 0.05]), dev), T(np.linspace(0.0, 80.0, 5000), dev)
+    lc = xo.LimbDarkLightCurve(0.3, 0.2)
+    tk = torch_case(dev, kw, draws=4, seed=9)
+    flux = lc.get_light_curve(orbit=TTVOrbit(**tk), r=r, t=t, texp=0.05)
+    assert tuple(flux.shape) == (4, 5000, 2)
+    for d in range(4):
+        one = dict(tk, ttvs=[x[d] for x in tk["ttvs"]])
+        want = lc.get_light_curve(orbit=TTVOrbit(**one), r=r, t=t, texp=0.05)
+        assert torch.equal(flux[d], want)
+
+
+def test_transit_times_parameterisation(dev):
+    """transit_times given: least-squares ephemeris (ttv.py:91-137); gradient reaches the times"""
+    import exoplanet_amd as xo
+    from exoplanet_amd.orbits import TTVOrbit
+
+    rng = np.random.default_rng(8)
+    expect = expected_times(0.0, 60.0, [7.3, 11.9], [2.0, 5.5])
+    times = [e + 0.03 * rng.normal(size=e.size) for e in expect]
+    r, t = np.array([0.08, 0.05]), np.linspace(0.0, 60.0, 4000)
+    want = P.LimbDarkLightCurve(0.3, 0.2).get_light_curve(orbit=P.TTVOrbit(transit_times=times, b=np.array([0.2, 0.4])),
+                                                          r=r, t=t)
+    tt = [T(x, dev).requires_grad_(True) for x in times]
+    lc = xo.LimbDarkLightCurve(0.3, 0.2)
+    got = lc.get_light_curve(orbit=TTVOrbit(transit_times=tt, b=T(np.array([0.2, 0.4]), dev)), r=T(r, dev), t=T(t, dev))
+    np.testing.assert_allclose(npy(got), want, rtol=0, atol=1e-12)
+    g = T(rng.normal(size=want.shape), dev)
+    ga = torch.autograd.grad((got * g).sum(), tt)
+    tt2 = [T(x, dev).requires_grad_(True) for x in times]
+    comp = lc._composed(TTVOrbit(transit_times=tt2, b=T(np.array([0.2, 0.4]), dev)), T(r, dev), T(t, dev), None, None,
+                        True, False)
+    gb = torch.autograd.grad((comp * g).sum(), tt2)
+    for a, b in zip(ga, gb):
+        np.testing.assert_allclose(npy(a), npy(b), rtol=1e-8, atol=1e-9 * float(b.abs().max()))
+
+
+def test_secondary_eclipse_with_ttv_orbit_raises_like_the_reference(dev):
+    import exoplanet_amd as xo
+    from exoplanet_amd.orbits import TTVOrbit
+
+    orbit = TTVOrbit(**torch_case(dev, ttv_case()))
+    lc = xo.SecondaryEclipseLightCurve((0.3, 0.2), (0.1, 0.1), 0.3)
+    with pytest.raises(ValueError):
+        lc.get_light_curve(orbit=orbit, r=T(np.array([0.08, 0.05]), dev), t=T(np.linspace(0, 10, 50), dev))
