@@ -54,6 +54,9 @@ struct PlanetConst {
   float ef, omf, sqf, cwf, swf, cif, zsf, thrf, zthrf, inthrf;
   // conjunction windows of the scan kernel's first test (see transit_window_kernel)
   double nrev, c0, dmid, half[2];
+  // timing tables: first edge, bins per unit time, number of finite edges (see TtvRow::locate)
+  double te0, tinv;
+  int tfin;
 };
 
 struct Shared {
@@ -134,12 +137,66 @@ __global__ __launch_bounds__(kBlock) void transit_window_kernel(const double* __
   o[2] = mid[0] - mid[1];
 }
 
+// ---------------------------------------------------------------------------
+// Transit-timing variations (reference: orbits/ttv.py:158-187).  Every time is measured from its
+// nearest labelled transit: planet p of a draw has n_edge bin edges (ascending, padded with +inf)
+// and n_edge + 1 shifts; a time t falls in bin k = #{edges < t} (searchsorted, left) and is
+// warped to t - shift[k] before anything else happens to it (shift[k] = transit time k - the
+// record's t0; the mean anomaly and the window phase are then those of the unperturbed orbit).
+// ---------------------------------------------------------------------------
+struct Ttv {
+  const double* edges;   // [n_draw][n_planet][n_edge]
+  const double* shift;   // [n_draw][n_planet][n_edge + 1]
+  double* gshift;        // [n_draw][n_planet][n_edge + 1], reverse sweep only
+  int n_edge;
+};
+
+// one planet's table
+struct TtvRow {
+  const double* __restrict__ edges;
+  const double* __restrict__ shift;
+  int n_edge;
+  __device__ __forceinline__ TtvRow(const Ttv& tv, int64_t rec)
+      : edges(tv.edges + rec * tv.n_edge), shift(tv.shift + rec * (tv.n_edge + 1)), n_edge(tv.n_edge) {}
+  // #{edges < t}: lower bound, branch-free steps (NaN t -> 0)
+  __device__ __forceinline__ int bin(double t) const {
+    int lo = 0, len = n_edge;
+    while (len > 0) {
+      const int half = len >> 1;
+      const bool lt = edges[lo + half] < t;
+      lo = lt ? lo + half + 1 : lo;
+      len = lt ? len - half - 1 : half;
+    }
+    return lo;
+  }
+  // The same bin from a guess: labelled transits are nearly evenly spaced, so bin ~ 1 + (t - e0) *
+  // inv; the two edges around the guess confirm it (two independent loads instead of a chain of
+  // log2(n_edge) dependent ones), anything else falls back to the search.  lo / hi: the edges of
+  // the bin (-inf / +inf at the ends).
+  __device__ __forceinline__ int locate(double t, double e0, double inv, int n_fin, double& lo, double& hi) const {
+    const double x = (t - e0) * inv;
+    int g = (x > 0.0) ? ((x < (double)n_fin) ? (int)x + 1 : n_fin) : 0;
+    lo = edges[g > 0 ? g - 1 : 0];
+    hi = edges[g < n_edge ? g : n_edge - 1];
+    if (!((g == 0 || lo < t) && (g == n_edge || !(hi < t)))) {
+      g = bin(t);
+      lo = edges[g > 0 ? g - 1 : 0];
+      hi = edges[g < n_edge ? g : n_edge - 1];
+    }
+    lo = g > 0 ? lo : -__builtin_inf();
+    hi = g < n_edge ? hi : __builtin_inf();
+    return g;
+  }
+};
+
+
 __device__ __forceinline__ void stage_constants(Shared& sh, const double* __restrict__ params,
                                                 const double* __restrict__ ld,
                                                 const double* __restrict__ stencil_dt,
                                                 const double* __restrict__ stencil_w, int n_sub,
                                                 int n_planet, int64_t draw, bool secondary,
-                                                const double* __restrict__ windows = nullptr) {
+                                                const double* __restrict__ windows = nullptr,
+                                                const Ttv* ttv = nullptr, int64_t ttv_first = 0) {
   const int tid = threadIdx.x;
   if (tid < n_planet) {
     const double* p = params + (draw * n_planet + tid) * EXO_NPAR;
@@ -172,6 +229,14 @@ __device__ __forceinline__ void stage_constants(Shared& sh, const double* __rest
     if (windows) {
       const double* wv = windows + kWin * (draw * n_planet + tid);
       c.nrev = wv[0]; c.c0 = wv[1]; c.dmid = wv[2]; c.half[0] = wv[3]; c.half[1] = wv[4];
+    }
+    if (ttv) {
+      const TtvRow row(*ttv, ttv_first + draw * n_planet + tid);
+      const int nf = row.bin(__builtin_inf());   // the padding is +inf
+      c.tfin = nf;
+      c.te0 = row.edges[0];
+      const double width = nf > 1 ? row.edges[nf - 1] - row.edges[0] : 0.0;
+      c.tinv = width > 0.0 ? (double)(nf - 1) / width : 0.0;
     }
   }
   const int nld = secondary ? 6 : 3;
@@ -390,62 +455,43 @@ __device__ __forceinline__ bool near_conjunction(double t, double nrev, double c
 }
 
 
-// ---------------------------------------------------------------------------
-// Transit-timing variations (reference: orbits/ttv.py:158-187).  Every time is measured from its
-// nearest labelled transit: planet p of a draw has n_edge bin edges (ascending, padded with +inf)
-// and n_edge + 1 shifts; a time t falls in bin k = #{edges < t} (searchsorted, left) and is
-// warped to t - shift[k] before anything else happens to it (shift[k] = transit time k - the
-// record's t0; the mean anomaly and the window phase are then those of the unperturbed orbit).
-// ---------------------------------------------------------------------------
-struct Ttv {
-  const double* edges;   // [n_draw][n_planet][n_edge]
-  const double* shift;   // [n_draw][n_planet][n_edge + 1]
-  double* gshift;        // [n_draw][n_planet][n_edge + 1], reverse sweep only
-  int n_edge;
-};
-
-// one planet's table
-struct TtvRow {
-  const double* __restrict__ edges;
-  const double* __restrict__ shift;
-  int n_edge;
-  __device__ __forceinline__ TtvRow(const Ttv& tv, int64_t rec)
-      : edges(tv.edges + rec * tv.n_edge), shift(tv.shift + rec * (tv.n_edge + 1)), n_edge(tv.n_edge) {}
-  // #{edges < t}: lower bound, branch-free steps (NaN t -> 0)
-  __device__ __forceinline__ int bin(double t) const {
-    int lo = 0, len = n_edge;
-    while (len > 0) {
-      const int half = len >> 1;
-      const bool lt = edges[lo + half] < t;
-      lo = lt ? lo + half + 1 : lo;
-      len = lt ? len - half - 1 : half;
-    }
-    return lo;
-  }
-  // is an edge within hw of t (an exposure of half-width hw straddles two bins)?
-  __device__ __forceinline__ bool straddles(int k, double t, double hw) const {
-    hw = fma(hw, 1e-12, hw);   // the product that made hw was rounded
-    const bool lo = k > 0 && !(t - edges[k - 1] > hw);
-    const bool hi = k < n_edge && !(edges[k] - t > hw);
-    return lo || hi;
-  }
-};
-
-
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int m = 32; m > 0; m >>= 1) v += __shfl_xor(v, m, 64);
+// sum over the wave, valid in lane 63: row_shr 1/2/4/8 inside the rows of 16, then row_bcast 15 / 31
+// (in-register DPP moves; a ds_bpermute butterfly costs an LDS round trip per step)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_add(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, true);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, true);
+  return v + __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_sum_last(double v) {
+  v = dpp_add<0x111, 0xf>(v);
+  v = dpp_add<0x112, 0xf>(v);
+  v = dpp_add<0x114, 0xf>(v);
+  v = dpp_add<0x118, 0xf>(v);
+  v = dpp_add<0x142, 0xa>(v);   // row_bcast:15 into rows 1 and 3
+  v = dpp_add<0x143, 0xc>(v);   // row_bcast:31 into rows 2 and 3
   return v;
 }
 
 // Reverse sweep of the warp: d L / d shift[k] is the sum over the samples of bin k of their
 // d L / d t_periastron (both enter as t - shift - tp).  eval_sample leaves that sum in the lane's
-// G_TP column; it is moved to the bin (hardware fp64 atomics on the output table -- the one place
-// where the summation order, and with it the last bits, depends on scheduling) and to the G_PAD
-// column, which ends up holding the planet's total.
+// G_TP column; after every cadence it is moved to the bin and to the G_PAD column, which ends up
+// holding the planet's total.  Each wave keeps kBinSlots bins in LDS (direct-mapped on the bin
+// number: a block works through a run of consecutive cadences, i.e. a few transits; one lane per
+// wave touches them, so plain loads and stores -- LDS fp64 atomics measured 100 us slower per
+// sweep) and sends them to the output table with one hardware fp64 atomic each when the planet is
+// done; a bin that finds its slot taken goes to the table directly.  The table is the one place
+// where the summation order -- and with it the last bits -- depends on scheduling.
+constexpr int kBinSlots = 16;
+struct BinCache {
+  double sum[kWaves][kBinSlots];
+  int id[kWaves][kBinSlots];
+};
 struct TtvGrad {
   double* __restrict__ col;   // &lds_acc[0][threadIdx.x]
   double* __restrict__ grow;  // gshift row of this (draw, planet)
+  BinCache* cache;
   __device__ __forceinline__ double take() const {
     const double d = col[G_TP * kBlock];
     col[G_TP * kBlock] = 0.0;
@@ -457,21 +503,41 @@ struct TtvGrad {
     const double d = take();
     if (d != 0.0) unsafeAtomicAdd(grow + k, d);
   }
-  // the whole wave, after a cadence: consecutive list entries are consecutive cadences of one
-  // transit, so the contributing lanes nearly always share a bin -> one atomic per wave
+  // The whole wave, after a cadence.  A wave holds 64 consecutive list entries, i.e. cadences of
+  // one transit or of two neighbouring ones: one pass per distinct bin, each a wave sum and one
+  // addition by the last lane.
   __device__ __forceinline__ void flush_wave(int k) const {
     const double d = take();
-    const bool nz = d != 0.0;
-    const unsigned long long mask = __ballot(nz);
-    if (mask == 0) return;
-    const int first = __builtin_amdgcn_readfirstlane(__ffsll((long long)mask) - 1);
-    const int k0 = __builtin_amdgcn_readlane(k, first);
-    if (__ballot(nz && k != k0) == 0) {
-      const double sum = wave_sum(d);
-      if ((int)(threadIdx.x & 63) == first) unsafeAtomicAdd(grow + k0, sum);
-    } else if (nz) {
-      unsafeAtomicAdd(grow + k, d);
+    unsigned long long todo = __ballot(d != 0.0);
+    while (todo) {
+      const int first = __builtin_amdgcn_readfirstlane(__ffsll((long long)todo) - 1);
+      const int k0 = __builtin_amdgcn_readlane(k, first);
+      const bool mine = k == k0;
+      const double sum = wave_sum_last(mine ? d : 0.0);
+      todo &= ~__ballot(mine);
+      if ((threadIdx.x & 63) == 63) {
+        const int w = threadIdx.x >> 6, slot = k0 & (kBinSlots - 1);
+        const int owner = cache->id[w][slot];
+        if (owner == k0) {
+          cache->sum[w][slot] += sum;
+        } else if (owner < 0) {
+          cache->id[w][slot] = k0;
+          cache->sum[w][slot] = sum;
+        } else {
+          unsafeAtomicAdd(grow + k0, sum);
+        }
+      }
     }
+  }
+  // block-wide, between planets: bins -> output table
+  __device__ __forceinline__ void drain() const {
+    __syncthreads();
+    if (threadIdx.x < kWaves * kBinSlots) {
+      const int k = (&cache->id[0][0])[threadIdx.x];
+      if (k >= 0) unsafeAtomicAdd(grow + k, (&cache->sum[0][0])[threadIdx.x]);
+      (&cache->id[0][0])[threadIdx.x] = -1;
+    }
+    __syncthreads();
   }
 };
 
@@ -533,7 +599,8 @@ __global__ __launch_bounds__(kBlock) void transit_scan_kernel(
   // grouped: the nd consecutive single-planet records are staged as if they were nd planets of one draw
   stage_constants(sh, params + (grouped ? draw * EXO_NPAR : 0), nullptr, stencil_dt, nullptr, n_sub,
                   grouped ? nd : n_planet, grouped ? 0 : draw, SECONDARY,
-                  stage1 ? windows + (grouped ? kWin * draw : 0) : nullptr);
+                  stage1 ? windows + (grouped ? kWin * draw : 0) : nullptr, TTV ? &ttv : nullptr,
+                  grouped ? draw : 0);
   // the windows are widened by the half-span of the exposure stencil; the reference widens its
   // contact windows by texp / 2 whatever the stencil (keplerian.py:765-769)
   double span = window ? 0.5 : 0.0;
@@ -576,14 +643,72 @@ __global__ __launch_bounds__(kBlock) void transit_scan_kernel(
       lim0[j] = uniform(c.half[0] + widen);
       lim1[j] = SECONDARY ? uniform(c.half[1] + widen) : 0.0;
     }
+    // TTV: each draw's current bin -- its edges and its shift -- rides along in scalar registers.
+    // A tile whose cadences (and their exposures) all lie strictly inside that bin costs four
+    // compares and a subtraction more than without timing tables; any other tile (a bin boundary
+    // every few tiles; every tile if the times are not sorted) looks its cadences up one by one
+    // and leaves the bin of its last cadence behind for the next tile.
+    struct BinNow { double lo, hi, sh; };
+    __shared__ BinNow s_now[kWaves][kScanDraws];
+    double b_lo[kScanDraws], b_hi[kScanDraws], b_sh[kScanDraws];
+#pragma unroll
+    for (int j = 0; j < kScanDraws; ++j) {
+      // no bin yet; draws past the end of the batch: one bin that holds everything
+      b_lo[j] = j < nd ? __builtin_inf() : -__builtin_inf();
+      b_hi[j] = -b_lo[j];
+      b_sh[j] = 0.0;
+    }
+    // exposures reaching over an edge are looked at sample by sample (never under the caller's
+    // windows: those warp the mid-exposure time only, like the reference's in_transit)
+    const double hw = (TTV && !window) ? uniform(fma(fabs(te) * span, 1e-12, fabs(te) * span)) : 0.0;
     auto process = [&](int tile, double tv0, double tv1) {
       const double tv[2] = {tv0, tv1};
       unsigned cand = 0;
+      unsigned redo = 0;   // TTV: draws whose cached bin does not hold the whole tile (wave-uniform)
 #pragma unroll
       for (int j = 0; j < kScanDraws; ++j) {
+        double sh_j = 0.0;
+        if (TTV) {
+          const bool inside = (tv0 - b_lo[j] > hw) && (b_hi[j] - tv0 > hw) && (tv1 - b_lo[j] > hw) && (b_hi[j] - tv1 > hw);
+          if (__ballot(!inside) != 0) {
+            redo |= 1u << j;
+            continue;
+          }
+          sh_j = b_sh[j];
+        }
 #pragma unroll
         for (int v = 0; v < 2; ++v)
-          cand |= near_conjunction<SECONDARY>(tv[v], nrev[j], c0[j], dmid[j], lim0[j], lim1[j]) ? (1u << (2 * j + v)) : 0u;
+          cand |= near_conjunction<SECONDARY>(tv[v] - sh_j, nrev[j], c0[j], dmid[j], lim0[j], lim1[j]) ? (1u << (2 * j + v)) : 0u;
+      }
+      if (TTV && redo) {
+#pragma unroll 1
+        for (int j = 0; j < nd; ++j) {
+          if (!((redo >> j) & 1u)) continue;
+          const PlanetConst& c = sh.pc[j];
+          const TtvRow row(ttv, draw + j);
+          const double widen = fabs(te) * span * fabs(c.nrev);
+          BinNow last{0.0, 0.0, 0.0};
+#pragma unroll 1
+          for (int v = 0; v < 2; ++v) {
+            double e_lo, e_hi;
+            const int kb = row.locate(tv[v], c.te0, c.tinv, c.tfin, e_lo, e_hi);
+            const double shv = row.shift[kb];
+            const bool mixed = !window && n_texp && (!(tv[v] - e_lo > hw) || !(e_hi - tv[v] > hw));
+            const bool near = mixed || near_conjunction<SECONDARY>(tv[v] - shv, c.nrev, c.c0, c.dmid, c.half[0] + widen,
+                                                                   c.half[1] + widen);
+            cand |= near ? (1u << (2 * j + v)) : 0u;
+            last = BinNow{e_lo, e_hi, shv};
+          }
+          if (lane == 63) s_now[wave][j] = last;
+        }
+        // (same wave wrote them: program order is enough)
+#pragma unroll
+        for (int j = 0; j < kScanDraws; ++j) {
+          if (((redo >> j) & 1u) && j < nd) {
+            const BinNow nb = s_now[wave][j];
+            b_lo[j] = uniform(nb.lo); b_hi[j] = uniform(nb.hi); b_sh[j] = uniform(nb.sh);
+          }
+        }
       }
       // draws past the end of the batch
       cand &= (1u << (2 * nd)) - 1u;
@@ -597,8 +722,20 @@ __global__ __launch_bounds__(kBlock) void transit_scan_kernel(
         for (int v = 0; v < 2; ++v) {
           int kind = 0;
           if ((cand >> (2 * j + v)) & 1u) {
-            for (int k = 0; k < n_sub; ++k)
-              kind = max(kind, classify_sample<SECONDARY, FAST>(fma(te, sh.sdt[k], tv[v]), sh.pc[j]));
+            if (TTV) {
+              const PlanetConst& c = sh.pc[j];
+              const TtvRow row(ttv, draw + j);
+              double e_lo, e_hi;
+              const int kb = row.locate(tv[v], c.te0, c.tinv, c.tfin, e_lo, e_hi);
+              const bool mixed = !window && n_texp && (!(tv[v] - e_lo > hw) || !(e_hi - tv[v] > hw));
+              for (int k = 0; k < n_sub; ++k) {
+                const double tt = fma(te, sh.sdt[k], tv[v]);
+                kind = max(kind, classify_sample<SECONDARY, FAST>(tt - row.shift[mixed ? row.bin(tt) : kb], c));
+              }
+            } else {
+              for (int k = 0; k < n_sub; ++k)
+                kind = max(kind, classify_sample<SECONDARY, FAST>(fma(te, sh.sdt[k], tv[v]), sh.pc[j]));
+            }
             if (window) kind = max(kind, 1);  // the caller's window decides; the classifier only sorts
           }
           append_active((blk_base + off[v] < n_cad) ? kind : 0, off[v], lst, (int)list_stride, cnt);
@@ -655,9 +792,11 @@ __global__ __launch_bounds__(kBlock) void transit_scan_kernel(
           // the classifier sees each of them (the caller's windows, like the reference's
           // in_transit, warp the mid-exposure time only)
           const TtvRow row(ttv, draw * n_planet + p);
-          const int kb = row.bin(tv[v]);
+          double e_lo, e_hi;
+          const int kb = row.locate(tv[v], c.te0, c.tinv, c.tfin, e_lo, e_hi);
           const double tw = tv[v] - row.shift[kb];
-          const bool mixed = !window && n_texp && row.straddles(kb, tv[v], fabs(te) * span);
+          const double hw = fma(fabs(te) * span, 1e-12, fabs(te) * span);   // the product was rounded
+          const bool mixed = !window && n_texp && (!(tv[v] - e_lo > hw) || !(e_hi - tv[v] > hw));
           if (stage1 && !mixed) {
             const double widen = fabs(te) * span * fabs(c.nrev);
             cand = near_conjunction<SECONDARY>(tw, c.nrev, c.c0, c.dmid, c.half[0] + widen, c.half[1] + widen);
@@ -740,7 +879,10 @@ __global__ __launch_bounds__(kBlock, EXO_HEAVY_MIN_WAVES) void transit_heavy_ker
   __shared__ Shared sh;
   __shared__ int s_pre[2 * kWaves * kMaxMerge + 1];
   const int64_t draw = blockIdx.y;
-  stage_constants(sh, params, ld, stencil_dt, stencil_w, n_sub, n_planet, draw, SECONDARY);
+  __shared__ BinCache s_bins;
+  if (GRAD && TTV && threadIdx.x < kWaves * kBinSlots) (&s_bins.id[0][0])[threadIdx.x] = -1;
+  stage_constants(sh, params, ld, stencil_dt, stencil_w, n_sub, n_planet, draw, SECONDARY, nullptr,
+                  TTV ? &ttv : nullptr);
   const bool per_planet = flags & EXO_FLAG_PER_PLANET;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   // this block works through the lists of `nsub` consecutive scan blocks of its draw
@@ -794,7 +936,10 @@ __global__ __launch_bounds__(kBlock, EXO_HEAVY_MIN_WAVES) void transit_heavy_ker
     const PlanetS c(sh.pc[p]);
     const TtvRow row(ttv, TTV ? draw * n_planet + p : 0);
     const TtvGrad tgrad{GRAD && TTV ? &lds_acc[0][threadIdx.x] : nullptr,
-                        GRAD && TTV ? ttv.gshift + (draw * n_planet + p) * (int64_t)(ttv.n_edge + 1) : nullptr};
+                        GRAD && TTV ? ttv.gshift + (draw * n_planet + p) * (int64_t)(ttv.n_edge + 1) : nullptr,
+                        &s_bins};
+    const double t_e0 = TTV ? uniform(sh.pc[p].te0) : 0.0, t_inv = TTV ? uniform(sh.pc[p].tinv) : 0.0;
+    const int t_fin = TTV ? __builtin_amdgcn_readfirstlane(sh.pc[p].tfin) : 0;
     double w_nrev = 0.0, w_c0 = 0.0, w_dmid = 0.0, w_h0 = 0.0, w_h1 = 0.0;
     if (use_win) {
       const double* wv = windows + kWin * (draw * n_planet + p);
@@ -864,9 +1009,11 @@ __global__ __launch_bounds__(kBlock, EXO_HEAVY_MIN_WAVES) void transit_heavy_ker
       double dsh = 0.0;
       bool mixed = false;
       if (TTV) {
-        kb = row.bin(tv);
+        double e_lo, e_hi;
+        kb = row.locate(tv, t_e0, t_inv, t_fin, e_lo, e_hi);
         dsh = row.shift[kb];
-        mixed = n_texp && row.straddles(kb, tv, fabs(te) * reach);
+        const double hw = fma(fabs(te) * reach, 1e-12, fabs(te) * reach);   // the product was rounded
+        mixed = n_texp && (!(tv - e_lo > hw) || !(e_hi - tv > hw));
       }
       if (use_win) {
         const double widen = fabs(te) * spanw * fabs(w_nrev);
@@ -908,6 +1055,7 @@ __global__ __launch_bounds__(kBlock, EXO_HEAVY_MIN_WAVES) void transit_heavy_ker
       }
     }
     if (GRAD && TTV) {
+      tgrad.drain();
       // every sample's t_periastron term went through the bins; the planet's total is in G_PAD
       lds_acc[G_TP][threadIdx.x] = lds_acc[G_PAD][threadIdx.x];
       lds_acc[G_PAD][threadIdx.x] = 0.0;
@@ -1129,7 +1277,8 @@ inline ScanPlan scan_plan(uint32_t flags, int bpd, int64_t n_draw, int n_planet,
                           bool has_ttv = false) {
   ScanPlan sp;
   const bool stage1 = (flags & EXO_FLAG_WINDOW) || !(flags & EXO_FLAG_EXACT_SCAN);
-  const bool grouped = n_planet == 1 && n_texp <= 1 && stage1 && !has_ttv;
+  const bool grouped = n_planet == 1 && n_texp <= 1 && stage1;
+  (void)has_ttv;
   sp.flags = (flags & 0x0fffffffu) | (grouped ? kFlagGrouped : 0u) | (with_fill ? 0u : kFlagNoFlux);
   sp.n_classify = (grouped ? (n_draw + kScanDraws - 1) / kScanDraws : n_draw) * bpd;
   sp.grid = dim3((unsigned)(sp.n_classify + (with_fill ? n_draw * bpd : 0)));

@@ -90,6 +90,37 @@ def test_ttv_draws_have_their_own_tables(dev):
     check(dev, t, rec, c, tables, texp=0.05)
 
 
+def single_planet_draws(D, seed=21):
+    """D draws of one planet, each with its own timing offsets (the scan kernel's grouped path:
+    four draws per block, each draw's current bin cached between tiles)"""
+    rng = np.random.default_rng(seed)
+    recs, edges, shifts = [], [], []
+    for d in range(D):
+        period, t0 = 6.1 + 0.01 * d, 1.3
+        n_tr = int((80.0 - t0) / period) + 1
+        orbit = P.TTVOrbit(period=np.array([period]), t0=np.array([t0]), b=np.array([0.3]), ecc=np.array([0.2]),
+                           omega=np.array([0.9]), ttvs=[0.04 * rng.normal(size=n_tr)])
+        recs.append(make_record(orbit, np.array([0.07 + 0.005 * d]))[0])
+        e, s = orbit.kernel_tables()
+        edges.append(e)
+        shifts.append(s)
+    E = max(e.shape[1] for e in edges)
+    pad_e = [np.pad(e, ((0, 0), (0, E - e.shape[1])), constant_values=np.inf) for e in edges]
+    pad_s = [np.pad(x, ((0, 0), (0, E + 1 - x.shape[1])), mode="edge") for x in shifts]
+    return np.stack(recs), (np.stack(pad_e), np.stack(pad_s))
+
+
+@pytest.mark.parametrize("D", [1, 4, 6])
+def test_ttv_single_planet_draw_groups(dev, D):
+    rec, tables = single_planet_draws(D)
+    c = np.repeat(P.get_cl(0.3, 0.2)[None], D, 0)
+    t = np.linspace(-3.0, 84.0, 9000)
+    check(dev, t, rec, c, tables)
+    check(dev, t, rec, c, tables, texp=0.07, order=1)
+    check(dev, t[:-1], rec, c, tables, texp=0.07)                       # odd count
+    check(dev, np.random.default_rng(0).permutation(t), rec, c, tables, texp=0.07)
+
+
 def test_ttv_unsorted_times(dev):
     rec, tables = case_records()
     t = np.random.default_rng(3).permutation(np.linspace(0.0, 80.0, 6000))
