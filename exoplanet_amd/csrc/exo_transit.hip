@@ -187,6 +187,43 @@ struct TtvRow {
     hi = g < n_edge ? hi : __builtin_inf();
     return g;
   }
+  // bin of a sub-exposure time tt of a cadence in bin k = (lo, hi]: k or, for an exposure that
+  // reaches over an edge, a neighbour (one confirming load; anything else is searched for)
+  __device__ __forceinline__ int neighbour(double tt, int k, double lo, double hi) const {
+    if (!(tt > lo)) {          // lo is -inf for k = 0: never taken there
+      k -= 1;
+      if (k > 0 && !(edges[k - 1] < tt)) k = bin(tt);
+    } else if (tt > hi) {      // hi is +inf for k = n_edge
+      k += 1;
+      if (k < n_edge && edges[k] < tt) k = bin(tt);
+    }
+    return k;
+  }
+  // Two times at once, shifts included: all six loads of the two guesses are issued before
+  // anything is checked (one memory latency for the pair instead of four in a row).
+  struct Hit { int k; double lo, hi, sh; };
+  __device__ __forceinline__ int guess(double t, double e0, double inv, int n_fin) const {
+    const double x = (t - e0) * inv;
+    return (x > 0.0) ? ((x < (double)n_fin) ? (int)x + 1 : n_fin) : 0;
+  }
+  __device__ __forceinline__ void settle(Hit& h, double t) const {
+    if (!((h.k == 0 || h.lo < t) && (h.k == n_edge || !(h.hi < t)))) {
+      h.k = bin(t);
+      h.lo = edges[h.k > 0 ? h.k - 1 : 0];
+      h.hi = edges[h.k < n_edge ? h.k : n_edge - 1];
+      h.sh = shift[h.k];
+    }
+    h.lo = h.k > 0 ? h.lo : -__builtin_inf();
+    h.hi = h.k < n_edge ? h.hi : __builtin_inf();
+  }
+  __device__ __forceinline__ void locate2(double ta, double tb, double e0, double inv, int n_fin, Hit& a, Hit& b) const {
+    a.k = guess(ta, e0, inv, n_fin);
+    b.k = guess(tb, e0, inv, n_fin);
+    a.lo = edges[a.k > 0 ? a.k - 1 : 0]; a.hi = edges[a.k < n_edge ? a.k : n_edge - 1]; a.sh = shift[a.k];
+    b.lo = edges[b.k > 0 ? b.k - 1 : 0]; b.hi = edges[b.k < n_edge ? b.k : n_edge - 1]; b.sh = shift[b.k];
+    settle(a, ta);
+    settle(b, tb);
+  }
 };
 
 
@@ -567,8 +604,10 @@ __device__ __forceinline__ void append_active(int kind, int off, int32_t* __rest
 // window constants sit in scalar registers.
 constexpr uint32_t kFlagGrouped = 0x40000000u;
 
+// (TTV: held to five waves per SIMD like the others -- four classify blocks per CU are resident
+// at the start of a sweep, and the fifth slot is what lets fill blocks run beside them)
 template <bool SECONDARY, bool FAST, bool VEC2, bool TTV = false>
-__global__ __launch_bounds__(kBlock) void transit_scan_kernel(
+__global__ __launch_bounds__(kBlock, (FAST && TTV) ? 5 : 1) void transit_scan_kernel(
     const double* __restrict__ t, int64_t n_cad, const double* __restrict__ texp, int64_t n_texp,
     const double* __restrict__ stencil_dt, int n_sub, const double* __restrict__ params, int n_planet,
     uint32_t flags, int tiles_per_block, int blocks_per_draw, int64_t n_draw, int64_t n_classify,
@@ -687,19 +726,16 @@ __global__ __launch_bounds__(kBlock) void transit_scan_kernel(
           const PlanetConst& c = sh.pc[j];
           const TtvRow row(ttv, draw + j);
           const double widen = fabs(te) * span * fabs(c.nrev);
-          BinNow last{0.0, 0.0, 0.0};
-#pragma unroll 1
+          TtvRow::Hit hit[2];
+          row.locate2(tv0, tv1, c.te0, c.tinv, c.tfin, hit[0], hit[1]);
+#pragma unroll
           for (int v = 0; v < 2; ++v) {
-            double e_lo, e_hi;
-            const int kb = row.locate(tv[v], c.te0, c.tinv, c.tfin, e_lo, e_hi);
-            const double shv = row.shift[kb];
-            const bool mixed = !window && n_texp && (!(tv[v] - e_lo > hw) || !(e_hi - tv[v] > hw));
-            const bool near = mixed || near_conjunction<SECONDARY>(tv[v] - shv, c.nrev, c.c0, c.dmid, c.half[0] + widen,
-                                                                   c.half[1] + widen);
+            const bool mixed = !window && n_texp && (!(tv[v] - hit[v].lo > hw) || !(hit[v].hi - tv[v] > hw));
+            const bool near = mixed || near_conjunction<SECONDARY>(tv[v] - hit[v].sh, c.nrev, c.c0, c.dmid,
+                                                                   c.half[0] + widen, c.half[1] + widen);
             cand |= near ? (1u << (2 * j + v)) : 0u;
-            last = BinNow{e_lo, e_hi, shv};
           }
-          if (lane == 63) s_now[wave][j] = last;
+          if (lane == 63) s_now[wave][j] = BinNow{hit[1].lo, hit[1].hi, hit[1].sh};
         }
         // (same wave wrote them: program order is enough)
 #pragma unroll
@@ -727,10 +763,13 @@ __global__ __launch_bounds__(kBlock) void transit_scan_kernel(
               const TtvRow row(ttv, draw + j);
               double e_lo, e_hi;
               const int kb = row.locate(tv[v], c.te0, c.tinv, c.tfin, e_lo, e_hi);
+              const double shv = row.shift[kb];
               const bool mixed = !window && n_texp && (!(tv[v] - e_lo > hw) || !(e_hi - tv[v] > hw));
               for (int k = 0; k < n_sub; ++k) {
                 const double tt = fma(te, sh.sdt[k], tv[v]);
-                kind = max(kind, classify_sample<SECONDARY, FAST>(tt - row.shift[mixed ? row.bin(tt) : kb], c));
+                double shk = shv;
+                if (mixed) shk = row.shift[row.neighbour(tt, kb, e_lo, e_hi)];
+                kind = max(kind, classify_sample<SECONDARY, FAST>(tt - shk, c));
               }
             } else {
               for (int k = 0; k < n_sub; ++k)
@@ -794,7 +833,8 @@ __global__ __launch_bounds__(kBlock) void transit_scan_kernel(
           const TtvRow row(ttv, draw * n_planet + p);
           double e_lo, e_hi;
           const int kb = row.locate(tv[v], c.te0, c.tinv, c.tfin, e_lo, e_hi);
-          const double tw = tv[v] - row.shift[kb];
+          const double shv = row.shift[kb];
+          const double tw = tv[v] - shv;
           const double hw = fma(fabs(te) * span, 1e-12, fabs(te) * span);   // the product was rounded
           const bool mixed = !window && n_texp && (!(tv[v] - e_lo > hw) || !(e_hi - tv[v] > hw));
           if (stage1 && !mixed) {
@@ -805,7 +845,9 @@ __global__ __launch_bounds__(kBlock) void transit_scan_kernel(
             int kp = window ? 1 : 0;
             for (int k = 0; k < n_sub; ++k) {
               const double tt = fma(te, sh.sdt[k], tv[v]);
-              kp = max(kp, classify_sample<SECONDARY, FAST>(tt - row.shift[mixed ? row.bin(tt) : kb], c));
+              double shk = shv;
+              if (mixed) shk = row.shift[row.neighbour(tt, kb, e_lo, e_hi)];
+              kp = max(kp, classify_sample<SECONDARY, FAST>(tt - shk, c));
             }
             kind = max(kind, kp);
           }
