@@ -552,8 +552,11 @@ struct TtvGrad {
       const bool mine = k == k0;
       const double sum = wave_sum_last(mine ? d : 0.0);
       todo &= ~__ballot(mine);
+      // (wave number through a scalar register: an address built from threadIdx.x is kept by the
+      // compiler across the whole loop -- in scratch, and a scratch reload waits for every load
+      // in flight, the prefetched list entries included)
+      const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), slot = k0 & (kBinSlots - 1);
       if ((threadIdx.x & 63) == 63) {
-        const int w = threadIdx.x >> 6, slot = k0 & (kBinSlots - 1);
         const int owner = cache->id[w][slot];
         if (owner == k0) {
           cache->sum[w][slot] += sum;
@@ -812,6 +815,10 @@ __global__ __launch_bounds__(kBlock, (FAST && TTV) ? 5 : 1) void transit_scan_ke
   }
   int32_t* __restrict__ my_list = list + wave_slot * list_stride;
   ListCount cnt{0, 0};
+  // TTV: per wave and planet, the bin of the wave's last cadence (edges, shift, number)
+  struct GenBin { double lo, hi, sh; int k; };
+  __shared__ GenBin s_gbin[kWaves][EXO_MAX_PLANETS];
+  if (TTV && lane < n_planet) s_gbin[wave][lane] = GenBin{__builtin_inf(), -__builtin_inf(), 0.0, 0};   // no bin yet
   for (int tile = 0; tile < tiles_per_block; ++tile) {
     const double tv[2] = {nx0, nx1};
     if (tile + 1 < tiles_per_block) load_pair(tile + 1, nx0, nx1);
@@ -830,12 +837,20 @@ __global__ __launch_bounds__(kBlock, (FAST && TTV) ? 5 : 1) void transit_scan_ke
           // sub-exposures measured from another transit: no window argument covers those,
           // the classifier sees each of them (the caller's windows, like the reference's
           // in_transit, warp the mid-exposure time only)
+          // The wave's last bin of this planet is tried first (LDS broadcast): times are usually
+          // sorted, and a bin holds thousands of cadences.
           const TtvRow row(ttv, draw * n_planet + p);
-          double e_lo, e_hi;
-          const int kb = row.locate(tv[v], c.te0, c.tinv, c.tfin, e_lo, e_hi);
-          const double shv = row.shift[kb];
+          const double hw = window ? 0.0 : fma(fabs(te) * span, 1e-12, fabs(te) * span);   // (the product was rounded)
+          const GenBin nb = s_gbin[wave][p];
+          double e_lo = nb.lo, e_hi = nb.hi, shv = nb.sh;
+          int kb = nb.k;
+          const bool inside = (tv[v] - e_lo > hw) && (e_hi - tv[v] > hw);
+          if (__ballot(!inside) != 0) {
+            kb = row.locate(tv[v], c.te0, c.tinv, c.tfin, e_lo, e_hi);
+            shv = row.shift[kb];
+            if (lane == 63) s_gbin[wave][p] = GenBin{e_lo, e_hi, shv, kb};
+          }
           const double tw = tv[v] - shv;
-          const double hw = fma(fabs(te) * span, 1e-12, fabs(te) * span);   // the product was rounded
           const bool mixed = !window && n_texp && (!(tv[v] - e_lo > hw) || !(e_hi - tv[v] > hw));
           if (stage1 && !mixed) {
             const double widen = fabs(te) * span * fabs(c.nrev);
@@ -982,6 +997,10 @@ __global__ __launch_bounds__(kBlock, EXO_HEAVY_MIN_WAVES) void transit_heavy_ker
                         &s_bins};
     const double t_e0 = TTV ? uniform(sh.pc[p].te0) : 0.0, t_inv = TTV ? uniform(sh.pc[p].tinv) : 0.0;
     const int t_fin = TTV ? __builtin_amdgcn_readfirstlane(sh.pc[p].tfin) : 0;
+    // the wave's current bin of this planet (scalar registers): list entries are consecutive
+    // cadences, so a round usually stays in the bin of the one before
+    double c_lo = __builtin_inf(), c_hi = -__builtin_inf(), c_sh = 0.0;
+    int c_k = 0;
     double w_nrev = 0.0, w_c0 = 0.0, w_dmid = 0.0, w_h0 = 0.0, w_h1 = 0.0;
     if (use_win) {
       const double* wv = windows + kWin * (draw * n_planet + p);
@@ -1051,11 +1070,26 @@ __global__ __launch_bounds__(kBlock, EXO_HEAVY_MIN_WAVES) void transit_heavy_ker
       double dsh = 0.0;
       bool mixed = false;
       if (TTV) {
-        double e_lo, e_hi;
-        kb = row.locate(tv, t_e0, t_inv, t_fin, e_lo, e_hi);
-        dsh = row.shift[kb];
         const double hw = fma(fabs(te) * reach, 1e-12, fabs(te) * reach);   // the product was rounded
-        mixed = n_texp && (!(tv - e_lo > hw) || !(e_hi - tv > hw));
+        kb = c_k;
+        dsh = c_sh;
+        const bool inside = (tv - c_lo > hw) && (c_hi - tv > hw);
+        const unsigned long long live = __ballot(has);
+        if (__ballot(has && !inside) != 0) {
+          double e_lo, e_hi;
+          kb = row.locate(tv, t_e0, t_inv, t_fin, e_lo, e_hi);
+          dsh = row.shift[kb];
+          mixed = n_texp && (!(tv - e_lo > hw) || !(e_hi - tv > hw));
+          // the last listed cadence of the wave leaves its bin behind
+          const int last = 63 - __builtin_clzll(live);
+          c_lo = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(e_lo), last),
+                                  __builtin_amdgcn_readlane(__double2loint(e_lo), last));
+          c_hi = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(e_hi), last),
+                                  __builtin_amdgcn_readlane(__double2loint(e_hi), last));
+          c_sh = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(dsh), last),
+                                  __builtin_amdgcn_readlane(__double2loint(dsh), last));
+          c_k = __builtin_amdgcn_readlane(kb, last);
+        }
       }
       if (use_win) {
         const double widen = fabs(te) * spanw * fabs(w_nrev);
