@@ -299,8 +299,8 @@ def main():
                                            omega=leaves["omega"])
                 lc = xo.LimbDarkLightCurve(leaves["u1"], leaves["u2"]).get_light_curve(orbit=orbit3, r=leaves["r"], t=t)
                 gp = xo.gp.GaussianProcess(xo.gp.terms.SHOTerm(sigma=1e-3 * ones, rho=5.0 * ones, Q=0.7071 * ones),
-                                           t=t, yerr=5e-4)
-                ll = gp.log_likelihood(yobs - lc.sum(-1))
+                                           t=t, yerr=5e-4, mean=lc.sum(-1))
+                ll = gp.log_likelihood(yobs)
                 return torch.autograd.grad(ll.sum(), [leaves[k] for k in names])
 
             c3_steps = 4

@@ -245,9 +245,22 @@ __global__ __launch_bounds__(256) void celerite_prep_kernel(const double* __rest
   state[six.uvp(2, i, draw, j)] = i > 0 ? exp(-k.c * (ti - t[i - 1])) : 1.0;
 }
 
+// The series the likelihood is evaluated on: y[draw][n] as given, or -- obs != nullptr -- the
+// residual obs[n] - y[draw][n] of a per-draw model against one observed series, formed on the
+// fly (the subtraction, and the sign flip of its cotangent, never cross HBM as arrays).
+struct Series {
+  const double* y;
+  const double* obs;
+};
+struct SeriesRow {
+  const double* __restrict__ y;
+  const double* __restrict__ obs;
+  __device__ __forceinline__ double operator[](int64_t i) const { return obs ? obs[i] - y[i] : y[i]; }
+};
+
 template <int J, bool SAVE>
 __global__ __launch_bounds__(kWave) void celerite_fwd_kernel(
-    const double* __restrict__ t, const double* __restrict__ resid, const double* __restrict__ diag,
+    const double* __restrict__ t, Series rs, const double* __restrict__ diag,
     int64_t n_diag, int64_t n, const double* __restrict__ coef_real, int n_real,
     const double* __restrict__ coef_complex, int n_complex, int64_t n_draw, double* __restrict__ loglike,
     double* __restrict__ state, const double* __restrict__ only_flagged) {
@@ -264,7 +277,7 @@ __global__ __launch_bounds__(kWave) void celerite_fwd_kernel(
   // a_n = diag_n + sum of the a coefficients (first index of each term)
   const double asum = group_sum<G>((k.live && !k.odd) ? k.a : 0.0);
   const StateIdx six{n, n_draw, J};
-  const double* __restrict__ y = resid + draw * n;
+  const SeriesRow y{rs.y + draw * n, rs.obs};
   const double* __restrict__ dg = diag + (n_diag == 1 ? 0 : draw * n);
 
   double Srow[J], Wall[J], Uall[J], Pall[J];
@@ -399,7 +412,8 @@ __global__ __launch_bounds__(kWave) void celerite_vjp_kernel(
     const double* __restrict__ coef_real, int n_real, const double* __restrict__ coef_complex, int n_complex,
     int64_t n_draw, const double* __restrict__ gloglike, const double* __restrict__ state,
     double* __restrict__ gresid, double* __restrict__ gdiag, double* __restrict__ gdiag_sum,
-    double* __restrict__ gcoef_real, double* __restrict__ gcoef_complex, const double* __restrict__ only_flagged) {
+    double* __restrict__ gcoef_real, double* __restrict__ gcoef_complex, const double* __restrict__ only_flagged,
+    double gsign) {
   constexpr int G = Group<J>::G;
   const int j = threadIdx.x & (G - 1);
   const int64_t lane_draw = ((int64_t)blockIdx.x * kWave + threadIdx.x) / G;
@@ -496,7 +510,7 @@ __global__ __launch_bounds__(kWave) void celerite_vjp_kernel(
     const double wdot = group_sum<G>(Wb * W_n);
     const double dbar = db + gL * (0.5 * z_n * z_n * id * id - 0.5 * id) - wdot * id;
     if (lead) {
-      gresid[draw * n + i] = zbar;
+      gresid[draw * n + i] = gsign * zbar;
       if (gdiag) gdiag[draw * n + i] = dbar;
     }
     gasum += dbar;
@@ -571,7 +585,7 @@ __global__ __launch_bounds__(kWave) void celerite_vjp_kernel(
     const double wdot = group_sum<G>(Wb * W_n);
     const double dbar = db + gL * (0.5 * z_n * z_n * id * id - 0.5 * id) - wdot * id;
     if (lead) {
-      gresid[draw * n] = zbar;
+      gresid[draw * n] = gsign * zbar;
       if (gdiag) gdiag[draw * n] = dbar;
     }
     gasum += dbar;
@@ -809,7 +823,7 @@ __global__ __launch_bounds__(256) void celerite_prep_flagged_kernel(const double
 // (A) the filtering element of every (draw, chunk): one lane each
 template <int J>
 __global__ __launch_bounds__(kWave) void celerite_elem_kernel(
-    const double* __restrict__ t, const double* __restrict__ resid, const double* __restrict__ diag, int64_t n_diag,
+    const double* __restrict__ t, Series rs, const double* __restrict__ diag, int64_t n_diag,
     int64_t n,
     const double* __restrict__ coef_real, int n_real, const double* __restrict__ coef_complex, int n_complex,
     int64_t n_draw, double* __restrict__ state, ChunkGeom cg) {
@@ -823,7 +837,7 @@ __global__ __launch_bounds__(kWave) void celerite_elem_kernel(
   dc.init(coef_real, n_real, coef_complex, n_complex, draw);
   DrawCoef<J> co;
   co.init(coef_real, n_real, coef_complex, n_complex, draw);
-  const double* __restrict__ y = resid + draw * n;
+  const SeriesRow y{rs.y + draw * n, rs.obs};
   const double* __restrict__ dg = diag + (n_diag == 1 ? 0 : draw * n);
   double A[J][J], b[J], eta[J];
   Sym<J> Cm, Jm, Dl;
@@ -1118,7 +1132,7 @@ struct LaneDelta {
 // more lanes to hide the loads.  Used for J >= 3, and the only version for J = 7, 8.
 template <int J>
 __global__ __launch_bounds__(kWave) void celerite_elem_lg_kernel(
-    const double* __restrict__ t, const double* __restrict__ resid, const double* __restrict__ diag, int64_t n_diag,
+    const double* __restrict__ t, Series rs, const double* __restrict__ diag, int64_t n_diag,
     int64_t n, const double* __restrict__ coef_real, int n_real, const double* __restrict__ coef_complex,
     int n_complex, int64_t n_draw, double* __restrict__ state, ChunkGeom cg) {
   constexpr int G = Group<J>::G;
@@ -1132,7 +1146,7 @@ __global__ __launch_bounds__(kWave) void celerite_elem_lg_kernel(
   const bool live = k.live;
   const ChunkWs ws{n_draw, J, cg.C, cg.base};
   const LaneDelta ld(k);
-  const double* __restrict__ y = resid + draw * n;
+  const SeriesRow y{rs.y + draw * n, rs.obs};
   const double* __restrict__ dg = diag + (n_diag == 1 ? 0 : draw * n);
   // conditioning score (see celerite_elem_kernel)
   const double asum = group_sum<G>((live && !k.odd) ? fabs(k.a) : 0.0);
@@ -1478,7 +1492,7 @@ __global__ __launch_bounds__(kWave) void celerite_bscan_vjp_kernel(int64_t n_dra
 // waves than the sequential kernel the loads are hidden by occupancy: no prefetch ring.
 template <int J>
 __global__ __launch_bounds__(kWave) void celerite_chunk_fwd_kernel(
-    const double* __restrict__ t, const double* __restrict__ resid, const double* __restrict__ diag, int64_t n_diag,
+    const double* __restrict__ t, Series rs, const double* __restrict__ diag, int64_t n_diag,
     int64_t n,
     const double* __restrict__ coef_real, int n_real, const double* __restrict__ coef_complex, int n_complex,
     int64_t n_draw, double* __restrict__ state, ChunkGeom cg) {
@@ -1494,7 +1508,7 @@ __global__ __launch_bounds__(kWave) void celerite_chunk_fwd_kernel(
   const double asum = group_sum<G>((k.live && !k.odd) ? k.a : 0.0);
   const StateIdx six{n, n_draw, J};
   const ChunkWs ws{n_draw, J, cg.C, cg.base};
-  const double* __restrict__ y = resid + draw * n;
+  const SeriesRow y{rs.y + draw * n, rs.obs};
   const double* __restrict__ dg = diag + (n_diag == 1 ? 0 : draw * n);
   const int jj = k.live ? j : 0;
 
@@ -1590,7 +1604,8 @@ template <int J>
 __global__ __launch_bounds__(kWave) void celerite_chunk_vjp_kernel(
     const double* __restrict__ t, int64_t n, const double* __restrict__ coef_real, int n_real,
     const double* __restrict__ coef_complex, int n_complex, int64_t n_draw, const double* __restrict__ gloglike,
-    double* __restrict__ state, ChunkGeom cg, double* __restrict__ gresid, double* __restrict__ gdiag) {
+    double* __restrict__ state, ChunkGeom cg, double* __restrict__ gresid, double* __restrict__ gdiag,
+    double gsign) {
   constexpr int G = Group<J>::G;
   const int j = threadIdx.x & (G - 1);
   const int64_t lane_draw = ((int64_t)blockIdx.x * kWave + threadIdx.x) / G;
@@ -1700,7 +1715,7 @@ __global__ __launch_bounds__(kWave) void celerite_chunk_vjp_kernel(
 #pragma unroll
         for (int q = 0; q < kPer; ++q)
           if ((have >> q) & 1u) {
-            gresid[at + q] = buf_r[q];
+            gresid[at + q] = gsign * buf_r[q];
             if (gdiag) gdiag[at + q] = buf_d[q];
           }
         have = 0u;
@@ -1865,12 +1880,11 @@ int64_t exo_celerite_state_doubles(int64_t n, int64_t n_draw, int32_t n_real, in
     default: return EXO_ERR_INVALID_ARGUMENT;      \
   }
 
-int exo_celerite_loglike_fwd_f64(const double* t, const double* resid, const double* diag, int64_t n_diag,
-                                 int64_t n, const double* coef_real, int32_t n_real, const double* coef_complex,
-                                 int32_t n_complex, int64_t n_draw, double* loglike, double* state,
-                                 int64_t state_doubles, void* stream) {
+static int celerite_fwd(const double* t, Series resid, const double* diag, int64_t n_diag, int64_t n,
+                        const double* coef_real, int32_t n_real, const double* coef_complex, int32_t n_complex,
+                        int64_t n_draw, double* loglike, double* state, int64_t state_doubles, void* stream) {
   if (n_draw == 0) return EXO_OK;
-  if (!gp_args_ok(n, n_diag, n_real, n_complex, n_draw) || !t || !resid || !diag || !loglike ||
+  if (!gp_args_ok(n, n_diag, n_real, n_complex, n_draw) || !t || !resid.y || !diag || !loglike ||
       (n_real > 0 && !coef_real) || (n_complex > 0 && !coef_complex))
     return EXO_ERR_INVALID_ARGUMENT;
   if (state && state_doubles < exo_celerite_state_doubles(n, n_draw, n_real, n_complex)) return EXO_ERR_WORKSPACE;
@@ -1943,11 +1957,10 @@ int exo_celerite_loglike_fwd_f64(const double* t, const double* resid, const dou
   return launch_status();
 }
 
-int exo_celerite_loglike_vjp_f64(const double* t, const double* diag, int64_t n_diag, int64_t n,
-                                 const double* coef_real, int32_t n_real, const double* coef_complex,
-                                 int32_t n_complex, int64_t n_draw, const double* gloglike, const double* state,
-                                 double* gresid, double* gdiag, double* gdiag_sum, double* gcoef_real,
-                                 double* gcoef_complex, void* stream) {
+static int celerite_vjp(const double* t, const double* diag, int64_t n_diag, int64_t n, const double* coef_real,
+                        int32_t n_real, const double* coef_complex, int32_t n_complex, int64_t n_draw,
+                        const double* gloglike, const double* state, double* gresid, double gsign, double* gdiag,
+                        double* gdiag_sum, double* gcoef_real, double* gcoef_complex, void* stream) {
   if (n_draw == 0) return EXO_OK;
   if (!gp_args_ok(n, n_diag, n_real, n_complex, n_draw) || !t || !diag || !gloglike || !state || !gresid ||
       (n_real > 0 && (!coef_real || !gcoef_real)) || (n_complex > 0 && (!coef_complex || !gcoef_complex)))
@@ -1973,7 +1986,7 @@ int exo_celerite_loglike_vjp_f64(const double* t, const double* diag, int64_t n_
                                                 cg))
     EXO_GP_DISPATCH_SMALL(J, hipLaunchKernelGGL((celerite_chunk_vjp_kernel<JJ>), cgrid, block, 0, st, t, n, coef_real,
                                                 n_real, coef_complex, n_complex, n_draw, gloglike, wstate, cg, gresid,
-                                                gdiag))
+                                                gdiag, gsign))
     hipLaunchKernelGGL(celerite_chunk_gsum_kernel, dim3(per_draw.x, (unsigned)(4 * J + 1)), block, 0, st, n_draw, J,
                        wstate, cg);
     hipLaunchKernelGGL(celerite_chunk_gcoef_kernel, dim3((unsigned)((n_draw * J + kWave - 1) / kWave)), block, 0, st,
@@ -1983,8 +1996,43 @@ int exo_celerite_loglike_vjp_f64(const double* t, const double* diag, int64_t n_
   }
   EXO_GP_DISPATCH(J, hipLaunchKernelGGL((celerite_vjp_kernel<JJ>), grid, block, 0, st, t, diag, n_diag, n, coef_real,
                                         n_real, coef_complex, n_complex, n_draw, gloglike, state, gresid, gdiag,
-                                        gdiag_sum, gcoef_real, gcoef_complex, only_flagged))
+                                        gdiag_sum, gcoef_real, gcoef_complex, only_flagged, gsign))
   return launch_status();
+}
+
+int exo_celerite_loglike_fwd_f64(const double* t, const double* resid, const double* diag, int64_t n_diag,
+                                 int64_t n, const double* coef_real, int32_t n_real, const double* coef_complex,
+                                 int32_t n_complex, int64_t n_draw, double* loglike, double* state,
+                                 int64_t state_doubles, void* stream) {
+  return celerite_fwd(t, Series{resid, nullptr}, diag, n_diag, n, coef_real, n_real, coef_complex, n_complex, n_draw,
+                      loglike, state, state_doubles, stream);
+}
+
+int exo_celerite_loglike_vjp_f64(const double* t, const double* diag, int64_t n_diag, int64_t n,
+                                 const double* coef_real, int32_t n_real, const double* coef_complex,
+                                 int32_t n_complex, int64_t n_draw, const double* gloglike, const double* state,
+                                 double* gresid, double* gdiag, double* gdiag_sum, double* gcoef_real,
+                                 double* gcoef_complex, void* stream) {
+  return celerite_vjp(t, diag, n_diag, n, coef_real, n_real, coef_complex, n_complex, n_draw, gloglike, state, gresid,
+                      1.0, gdiag, gdiag_sum, gcoef_real, gcoef_complex, stream);
+}
+
+int exo_celerite_loglike_obs_fwd_f64(const double* t, const double* obs, const double* model, const double* diag,
+                                     int64_t n_diag, int64_t n, const double* coef_real, int32_t n_real,
+                                     const double* coef_complex, int32_t n_complex, int64_t n_draw, double* loglike,
+                                     double* state, int64_t state_doubles, void* stream) {
+  if (n_draw > 0 && !obs) return EXO_ERR_INVALID_ARGUMENT;
+  return celerite_fwd(t, Series{model, obs}, diag, n_diag, n, coef_real, n_real, coef_complex, n_complex, n_draw,
+                      loglike, state, state_doubles, stream);
+}
+
+int exo_celerite_loglike_obs_vjp_f64(const double* t, const double* diag, int64_t n_diag, int64_t n,
+                                     const double* coef_real, int32_t n_real, const double* coef_complex,
+                                     int32_t n_complex, int64_t n_draw, const double* gloglike, const double* state,
+                                     double* gmodel, double* gdiag, double* gdiag_sum, double* gcoef_real,
+                                     double* gcoef_complex, void* stream) {
+  return celerite_vjp(t, diag, n_diag, n, coef_real, n_real, coef_complex, n_complex, n_draw, gloglike, state, gmodel,
+                      -1.0, gdiag, gdiag_sum, gcoef_real, gcoef_complex, stream);
 }
 
 }  // extern "C"

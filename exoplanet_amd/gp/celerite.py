@@ -13,9 +13,13 @@ MAX_J = 8
 
 class _CeleriteLogLike(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, t, resid, diag, coef_real, coef_complex):
+    def forward(ctx, t, resid, diag, coef_real, coef_complex, obs):
         t = _dev(t, "t")
         resid = _dev(resid, "resid")
+        if obs is not None:
+            obs = _dev(obs, "obs")
+            if obs.shape != t.shape:
+                raise ValueError("obs must have one entry per cadence")
         diag = _dev(diag, "diag")
         coef_real = _dev(coef_real, "coef_real")
         coef_complex = _dev(coef_complex, "coef_complex")
@@ -44,15 +48,24 @@ class _CeleriteLogLike(torch.autograd.Function):
                 raise
             state, nstate = None, 0
         with torch.cuda.device(t.device):
-            _lib.check(
-                lib.exo_celerite_loglike_fwd_f64(_ptr(t), _ptr(resid), _ptr(diag), diag.shape[0], N, _ptr(coef_real),
-                                                 n_real, _ptr(coef_complex), n_complex, D, _ptr(loglike), _ptr(state),
-                                                 nstate, _stream(t)),
-                "exo_celerite_loglike_fwd_f64",
-            )
+            if obs is None:
+                _lib.check(
+                    lib.exo_celerite_loglike_fwd_f64(_ptr(t), _ptr(resid), _ptr(diag), diag.shape[0], N,
+                                                     _ptr(coef_real), n_real, _ptr(coef_complex), n_complex, D,
+                                                     _ptr(loglike), _ptr(state), nstate, _stream(t)),
+                    "exo_celerite_loglike_fwd_f64",
+                )
+            else:
+                _lib.check(
+                    lib.exo_celerite_loglike_obs_fwd_f64(_ptr(t), _ptr(obs), _ptr(resid), _ptr(diag), diag.shape[0], N,
+                                                         _ptr(coef_real), n_real, _ptr(coef_complex), n_complex, D,
+                                                         _ptr(loglike), _ptr(state), nstate, _stream(t)),
+                    "exo_celerite_loglike_obs_fwd_f64",
+                )
         if need_grad:
             ctx.save_for_backward(t, diag, coef_real, coef_complex, state)
             ctx.dims = (D, N, n_real, n_complex)
+            ctx.with_obs = obs is not None
         return loglike
 
     @staticmethod
@@ -68,22 +81,24 @@ class _CeleriteLogLike(torch.autograd.Function):
         gcr = torch.empty_like(coef_real)
         gcc = torch.empty_like(coef_complex)
         with torch.cuda.device(t.device):
+            entry = lib.exo_celerite_loglike_obs_vjp_f64 if ctx.with_obs else lib.exo_celerite_loglike_vjp_f64
             _lib.check(
-                lib.exo_celerite_loglike_vjp_f64(_ptr(t), _ptr(diag), diag.shape[0], N, _ptr(coef_real), n_real,
-                                                 _ptr(coef_complex), n_complex, D, _ptr(gll), _ptr(state),
-                                                 _ptr(gresid), _ptr(gdiag), None, _ptr(gcr), _ptr(gcc), _stream(t)),
+                entry(_ptr(t), _ptr(diag), diag.shape[0], N, _ptr(coef_real), n_real, _ptr(coef_complex), n_complex, D,
+                      _ptr(gll), _ptr(state), _ptr(gresid), _ptr(gdiag), None, _ptr(gcr), _ptr(gcc), _stream(t)),
                 "exo_celerite_loglike_vjp_f64",
             )
         if want_diag and shared_diag:
             gdiag = gdiag.sum(0, keepdim=True)
-        return None, gresid, gdiag, gcr, gcc
+        return None, gresid, gdiag, gcr, gcc, None
 
 
-def celerite_loglike(t, resid, diag, coef_real, coef_complex):
+def celerite_loglike(t, resid, diag, coef_real, coef_complex, obs=None):
     """log N(resid | 0, K + diag) per draw.  t (N,), resid (D,N), diag (1|D,N),
     coef_real (D,Jr,2) = (a,c), coef_complex (D,Jc,4) = (a,b,c,d).  Differentiable
-    w.r.t. resid, diag and the coefficients."""
-    return _CeleriteLogLike.apply(t, resid, diag, coef_real, coef_complex)
+    w.r.t. resid, diag and the coefficients.  With ``obs`` (N,), ``resid`` is a per-draw
+    MODEL and the likelihood is that of ``obs - resid``, formed inside the kernels (no
+    residual array, no sign-flip pass in the backward); ``obs`` itself gets no gradient."""
+    return _CeleriteLogLike.apply(t, resid, diag, coef_real, coef_complex, None if obs is None else obs.detach())
 
 
 class GaussianProcess:
@@ -135,7 +150,7 @@ class GaussianProcess:
         cplx = cplx.expand((D,) + tuple(cplx.shape[-2:]))
         return real, cplx, D, bool(batch)
 
-    def _prepare(self, y):
+    def _prepare(self, y, fuse=False):
         if self._t is None:
             raise RuntimeError("you must call 'compute' first")
         t = self._t
@@ -143,7 +158,14 @@ class GaussianProcess:
         mean = self.mean(t) if callable(self.mean) else as_tensor(self.mean, t)
         if isinstance(mean, torch.Tensor) and mean.dim() == 1 and mean.shape[0] != t.shape[0]:
             mean = mean.unsqueeze(-1)  # per-draw constant
-        resid = y - mean
+        # one observed series against a per-draw mean model: the kernels form obs - model themselves
+        # (no (D, N) residual array in the forward pass, no (D, N) negation in the backward one)
+        obs = None
+        if (fuse and y.dim() == 1 and not y.requires_grad and isinstance(mean, torch.Tensor) and mean.dim() == 2
+                and mean.shape[-1] == t.shape[0] and y.shape[0] == t.shape[0] and y.is_cuda):
+            obs, resid = y, mean
+        else:
+            resid = y - mean
         if resid.shape[-1] != t.shape[0]:
             raise ValueError("dimension mismatch")
         real, cplx, D, batched = self._coefficients()
@@ -152,17 +174,17 @@ class GaussianProcess:
         resid = resid.expand(D, t.shape[0]).contiguous()
         real = real.expand(D, real.shape[1], 2).contiguous()
         cplx = cplx.expand(D, cplx.shape[1], 4).contiguous()
-        return t, mean, resid, real, cplx, squeeze
+        return t, mean, resid, real, cplx, squeeze, obs
 
     def log_likelihood(self, y):
-        t, _, resid, real, cplx, squeeze = self._prepare(y)
-        ll = celerite_loglike(t.detach(), resid, self._diag.contiguous(), real, cplx)
+        t, _, resid, real, cplx, squeeze, obs = self._prepare(y, fuse=True)
+        ll = celerite_loglike(t.detach(), resid, self._diag.contiguous(), real, cplx, obs=obs)
         return ll[0] if squeeze else ll
 
     def apply_inverse(self, y):
         """alpha = (K + diag)^-1 (y - mean), per draw (detached).  It is minus the gradient of the
         log-likelihood with respect to y, i.e. one forward + one reverse pass of the recurrences."""
-        t, _, resid, real, cplx, squeeze = self._prepare(y)
+        t, _, resid, real, cplx, squeeze, _ = self._prepare(y)
         with torch.enable_grad():
             r = resid.detach().requires_grad_(True)
             ll = celerite_loglike(t.detach(), r, self._diag.detach().contiguous(), real.detach(), cplx.detach())
@@ -175,7 +197,7 @@ class GaussianProcess:
         without the variance), detached.  At the data times (``t=None``) it is
         ``y - diag * alpha``; at other times ``K(t, t_data) alpha`` is formed densely in blocks
         of ``block`` prediction times (O(N M): meant for plots, not for the sampling loop)."""
-        tt, mean, resid, real, cplx, squeeze = self._prepare(y)
+        tt, mean, resid, real, cplx, squeeze, _ = self._prepare(y)
         alpha = self.apply_inverse(y)
         alpha2 = alpha if alpha.dim() == 2 else alpha.unsqueeze(0)
         if t is None:

@@ -251,6 +251,25 @@ int exo_celerite_loglike_vjp_f64(const double* t, const double* diag, int64_t n_
                                  const double* state, double* gresid, double* gdiag, double* gdiag_sum,
                                  double* gcoef_real, double* gcoef_complex, void* stream);
 
+/* The same pair for the usual case of one observed series against a per-draw model:
+ *   resid[d][n] = obs[n] - model[d][n]
+ * is formed inside the kernels (obs [n], model [n_draw][n]), and the reverse entry returns
+ * gmodel = d loglike / d model = -(d loglike / d resid): neither the residual nor the sign
+ * flip of its cotangent exists as an array.  Everything else as above; a state buffer
+ * written by one pair must be read back by the same pair.                                */
+int exo_celerite_loglike_obs_fwd_f64(const double* t, const double* obs, const double* model,
+                                     const double* diag, int64_t n_diag, int64_t n,
+                                     const double* coef_real, int32_t n_real,
+                                     const double* coef_complex, int32_t n_complex, int64_t n_draw,
+                                     double* loglike, double* state, int64_t state_doubles,
+                                     void* stream);
+int exo_celerite_loglike_obs_vjp_f64(const double* t, const double* diag, int64_t n_diag, int64_t n,
+                                     const double* coef_real, int32_t n_real,
+                                     const double* coef_complex, int32_t n_complex, int64_t n_draw,
+                                     const double* gloglike, const double* state, double* gmodel,
+                                     double* gdiag, double* gdiag_sum, double* gcoef_real,
+                                     double* gcoef_complex, void* stream);
+
 /* ---------------------------------------------------------------------------
  * Record packing: the O(planets) algebra of KeplerianOrbit.__init__
  * (src/exoplanet/orbits/keplerian.py:133-281,849-934), get_cl

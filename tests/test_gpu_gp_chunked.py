@@ -284,3 +284,51 @@ def test_wide_state_takes_the_time_parallel_path(dev):
         co_d = (cr[0, :, 0], cr[0, :, 1], cc[0, :, 0], cc[0, :, 1], cc[0, :, 2], cc[0, :, 3])
         ref, _ = P.gp_loglike_dense(t, y[0], diag[0], co_d)
         assert abs(got[0][0] - ref) < 1e-10 * abs(ref)
+
+
+@pytest.mark.parametrize("name", ["sho_q3", "real1", "three_sho_j6"])
+@pytest.mark.parametrize("C", [0, 5, None])
+def test_observed_series_minus_model_inside_the_kernels(dev, name, C):
+    """exo_celerite_loglike_obs_*: obs - model formed on the fly == the explicit residual array,
+    and d/d model == -(d/d resid); sequential, forced-chunk and default plans"""
+    from exoplanet_amd.gp import celerite_loglike
+
+    rng = np.random.default_rng(3)
+    D, N = 5, 1500
+    t = np.sort(rng.uniform(0, 40, N))
+    obs = 1e-3 * rng.normal(size=N)
+    model = 1e-3 * rng.normal(size=(D, N))
+    diag = np.full((1, N), 1e-6)
+    cr, cc = batch(rng, name, D)
+    with chunks(C):
+        want = value_and_grads(dev, t, obs[None] - model, diag, cr, cc)
+        tt, mt, dt = T(t, dev), T(model, dev, True), T(diag, dev, True)
+        crt, cct = T(cr, dev, True), T(cc, dev, True)
+        ll = celerite_loglike(tt, mt, dt, crt, cct, obs=T(obs, dev))
+        w = torch.linspace(0.5, 1.5, D, dtype=torch.float64, device=ll.device)
+        (ll * w).sum().backward()
+    got = [x.detach().cpu().numpy() for x in (ll, mt.grad, dt.grad, crt.grad, cct.grad)]
+    np.testing.assert_array_equal(got[0], want[0])           # same arithmetic, same bits
+    np.testing.assert_array_equal(got[1], -want[1])
+    for a, b in zip(got[2:], want[2:]):
+        np.testing.assert_array_equal(a, b)
+
+
+def test_gaussian_process_mean_model_takes_the_fused_route(dev):
+    """GaussianProcess(kernel, t, yerr, mean=model (D, N)).log_likelihood(y (N,)) == the explicit
+    y - model, values and gradient with respect to the model"""
+    import exoplanet_amd as xo
+
+    rng = np.random.default_rng(4)
+    D, N = 3, 2000
+    t = T(np.sort(rng.uniform(0, 30, N)), dev)
+    y = T(1e-3 * rng.normal(size=N), dev)
+    term = xo.gp.terms.SHOTerm(sigma=T(np.full(D, 1e-3), dev), rho=T(np.full(D, 4.0), dev), Q=T(np.full(D, 0.7), dev))
+    m1 = T(1e-3 * rng.normal(size=(D, N)), dev, True)
+    m2 = m1.detach().clone().requires_grad_(True)
+    ll1 = xo.gp.GaussianProcess(term, t=t, yerr=5e-4, mean=m1).log_likelihood(y)
+    ll2 = xo.gp.GaussianProcess(term, t=t, yerr=5e-4).log_likelihood(y - m2)
+    assert torch.equal(ll1, ll2)
+    g1, = torch.autograd.grad(ll1.sum(), m1)
+    g2, = torch.autograd.grad(ll2.sum(), m2)
+    assert torch.equal(g1, g2)

@@ -87,7 +87,7 @@ def main():
         r = rt[:D3].clone().requires_grad_(True)
         cc = cplx.clone().requires_grad_(True)
         f = ops.transit_flux(tt, r, ct[:D3], flags=ops.FLAG_WINDOW)
-        ll = celerite_loglike(tt, y - f, diag, real, cc)
+        ll = celerite_loglike(tt, f, diag, real, cc, obs=y)      # obs - model formed inside the GP kernels
         torch.autograd.grad(ll.sum(), (r, cc))
 
     dt3 = timeit(c3, 5)
@@ -143,7 +143,7 @@ def main():
         r = r5.clone().requires_grad_(True)
         cc = cplx5.clone().requires_grad_(True)
         f = ops.transit_flux(t5t, r, c5, **kw5)
-        ll = celerite_loglike(t5t, y5 - f, diag5, real5, cc)
+        ll = celerite_loglike(t5t, f, diag5, real5, cc, obs=y5)
         torch.autograd.grad(ll.sum(), (r, cc))
 
     dt5 = timeit(c5f, 5)
