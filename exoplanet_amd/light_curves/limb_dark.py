@@ -56,6 +56,21 @@ def exposure_stencil(oversample=7, order=0):
     return dt, stencil / np.sum(stencil)
 
 
+_UPLOADS = {}
+
+
+def _on_device(host, dev):
+    """float64 device copy of a small host array (an exposure stencil), uploaded once per
+    (content, device): a replayed hipGraph step cannot copy from the host, and need not"""
+    host = np.ascontiguousarray(host, dtype=np.float64)
+    key = (host.tobytes(), str(dev))
+    t = _UPLOADS.get(key)
+    if t is None:
+        t = torch.as_tensor(host, dtype=torch.float64, device=dev)
+        _UPLOADS[key] = t
+    return t
+
+
 def quad_limbdark_light_curve(c, b, r):
     """dot(s(b, r), c) - 1 (limb_dark.py:21-24)"""
     b = as_tensor(b)
@@ -145,9 +160,8 @@ class LimbDarkLightCurve:
             rec, ld, batch = rec.contiguous(), ld.contiguous(), full
         if texp is not None:
             dt, w = stencil
-            kw.update(texp=as_tensor(texp, t).reshape(-1).detach(),
-                      stencil_dt=torch.as_tensor(dt, dtype=torch.float64, device=t.device),
-                      stencil_w=torch.as_tensor(w, dtype=torch.float64, device=t.device))
+            kw.update(texp=as_tensor(texp, t).reshape(-1).detach(), stencil_dt=_on_device(dt, t.device),
+                      stencil_w=_on_device(w, t.device))
         flux = ops.transit_flux(t.detach(), rec, ld, flags=flags | ops.FLAG_PER_PLANET, **kw)
         return flux.reshape(tuple(batch) + (t.shape[0], rec.shape[1]))
 

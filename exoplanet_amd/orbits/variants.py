@@ -65,6 +65,20 @@ class _TransitTable:
         return torch.gather(self.centres, 1, idx).reshape(t_by_planet.shape)
 
 
+_INDEX_CACHE = {}
+
+
+def _device_index(host, dev):
+    """int64 device copy of a small host index array, uploaded once per (content, device): a
+    host-to-device copy is not allowed while a hipGraph is capturing, the cached tensor is"""
+    key = (host.tobytes(), str(dev))
+    t = _INDEX_CACHE.get(key)
+    if t is None:
+        t = torch.as_tensor(host, dtype=torch.int64, device=dev)
+        _INDEX_CACHE[key] = t
+    return t
+
+
 class TTVOrbit(KeplerianOrbit):
     """KeplerianOrbit plus exactly one of ``ttvs`` (O-C offsets per labelled transit, per
     planet) or ``transit_times`` (observed times; the least-squares period and t0 follow
@@ -74,7 +88,11 @@ class TTVOrbit(KeplerianOrbit):
     Beyond the reference: each ``ttvs[p]`` / ``transit_times[p]`` may carry leading draw
     dimensions ``(..., n_transit_p)`` (broadcast against the other parameters' draw
     dimensions); ``LimbDarkLightCurve.get_light_curve`` then evaluates all draws in the
-    fused kernels.  The position / velocity methods stay unbatched like the reference."""
+    fused kernels.  The position / velocity methods stay unbatched like the reference.
+
+    ``transit_inds`` are structure, not parameters: they are read on the host (lists / numpy
+    arrays cost nothing; device tensors are copied back once, which a hipGraph capture does
+    not allow)."""
 
     def __init__(self, *args, ttvs=None, transit_times=None, transit_inds=None, **kwargs):
         if ttvs is None and transit_times is None:
@@ -87,9 +105,15 @@ class TTVOrbit(KeplerianOrbit):
         given = [rows(x) for x in (ttvs if ttvs is not None else transit_times)]
         dev = given[0].device
         if transit_inds is None:
-            self.transit_inds = [torch.arange(x.shape[-1], device=dev) for x in given]
+            self._inds = [None] * len(given)         # 0, 1, 2, ...: nothing missing
+            self._counts = [int(x.shape[-1]) for x in given]
+            self.transit_inds = [torch.arange(n, device=dev) for n in self._counts]
         else:
-            self.transit_inds = [torch.as_tensor(i, dtype=torch.int64, device=dev).reshape(-1) for i in transit_inds]
+            host = [(i.detach().cpu().numpy() if isinstance(i, torch.Tensor) else np.asarray(i)).astype(np.int64).reshape(-1)
+                    for i in transit_inds]
+            self._inds = host
+            self._counts = [int(h.max()) + 1 for h in host]
+            self.transit_inds = [_device_index(h, dev) for h in host]
         if ttvs is not None:
             self.ttvs = given
         else:
@@ -105,22 +129,39 @@ class TTVOrbit(KeplerianOrbit):
                 dlp = kwargs.pop("delta_log_period", None)
                 kwargs["period"] = self.ttv_period if dlp is None else torch.exp(torch.log(self.ttv_period) + as_tensor(dlp))
         super().__init__(*args, **kwargs)
-        self._standard = False          # one t0 per planet is exactly what this orbit does not have
+        # (the base class's `_standard` stands: the fused kernels take the ordinary records plus the
+        # timing tables, so the standard parameterisation still goes through the packing kernel)
+        t0, period = self._ephemeris()
         if ttvs is not None:
-            self.ttv_period = self.period
-            self.transit_times = [self.t0[..., p:p + 1] + self.period[..., p:p + 1] * ix + dv
+            self.ttv_period = period
+            self.transit_times = [t0[..., p:p + 1] + period[..., p:p + 1] * ix + dv
                                   for p, (ix, dv) in enumerate(zip(self.transit_inds, self.ttvs))]
         # fill unobserved transit numbers with the linear ephemeris (ttv.py:141-147)
         self.all_transit_times = []
-        for p, ix in enumerate(self.transit_inds):
-            count = int(ix.max().item()) + 1
-            grid = self.t0[..., p:p + 1] + self.period[..., p:p + 1] * torch.arange(count, device=dev)
+        for p, host in enumerate(self._inds):
             obs = self.transit_times[p]
+            if host is None:
+                self.all_transit_times.append(obs)
+                continue
+            count = self._counts[p]
+            grid = t0[..., p:p + 1] + period[..., p:p + 1] * torch.arange(count, device=dev)
             shape = torch.broadcast_shapes(grid.shape[:-1], obs.shape[:-1])
             grid = grid.expand(shape + (count,)).clone()
-            grid[..., ix] = obs.expand(shape + obs.shape[-1:])
+            grid[..., self.transit_inds[p]] = obs.expand(shape + obs.shape[-1:])
             self.all_transit_times.append(grid)
         self._table = _TransitTable(self.all_transit_times, self.ttv_period)
+
+    def _ephemeris(self):
+        """(t0, period), shape (..., P), without running the base class's attribute algebra when the
+        constructor was handed both (the usual case; the fused path then never needs the algebra)"""
+        A = self._args
+        if A["period"] is not None and A["t_periastron"] is None:
+            like = next((x for x in A.values() if isinstance(x, torch.Tensor)), None)
+            period = _vec(A["period"], like)
+            t0 = _vec(0.0 if A["t0"] is None else A["t0"], like)
+            shape = torch.broadcast_shapes(period.shape, t0.shape)
+            return t0.expand(shape), period.expand(shape)
+        return self.t0, self.period
 
     @staticmethod
     def _line_fit(x, y):
@@ -141,7 +182,7 @@ class TTVOrbit(KeplerianOrbit):
         (no gradient, like the reference's searchsorted) and per-bin shifts ``batch + (P, E + 1)``
         = transit time of the bin - t0, differentiable"""
         centres = self._table.centres
-        t0 = self.t0
+        t0, _ = self._ephemeris()
         shape = torch.broadcast_shapes(centres.shape[:-1], t0.shape)
         shift = centres.expand(shape + centres.shape[-1:]) - t0.expand(shape).unsqueeze(-1)
         return self._table.edges.expand(shape + self._table.edges.shape[-1:]), shift

@@ -294,3 +294,36 @@ def test_secondary_eclipse_with_ttv_orbit_raises_like_the_reference(dev):
     lc = xo.SecondaryEclipseLightCurve((0.3, 0.2), (0.1, 0.1), 0.3)
     with pytest.raises(ValueError):
         lc.get_light_curve(orbit=orbit, r=T(np.array([0.08, 0.05]), dev), t=T(np.linspace(0, 10, 50), dev))
+
+
+def test_ttv_step_replays_as_a_hip_graph(dev):
+    """TTVOrbit construction + fused light curve + backward inside GraphedStep: nothing on the way
+    synchronises with the host or uploads from it (transit_inds are cached on the device)"""
+    import exoplanet_amd as xo
+    from exoplanet_amd.orbits import TTVOrbit
+
+    kw = ttv_case()
+    tk = torch_case(dev, kw, draws=3, seed=4)
+    tk.pop("transit_inds")
+    inds = kw["transit_inds"]
+    t, r = T(np.linspace(0.0, 80.0, 4000), dev), T(np.array([0.08, 0.05]), dev)
+    g = T(np.random.default_rng(1).normal(size=(3, 4000, 2)), dev)
+    names = ["period", "t0", "b", "ecc", "omega"]
+    leaves = [tk[k].clone().requires_grad_(True) for k in names] + [x.clone().requires_grad_(True) for x in tk["ttvs"]]
+
+    def step(*vals):
+        orbit = TTVOrbit(**dict(zip(names, vals[:5])), ttvs=list(vals[5:]), transit_inds=inds)
+        flux = xo.LimbDarkLightCurve(0.3, 0.2).get_light_curve(orbit=orbit, r=r, t=t, texp=0.05)
+        return (flux.detach(),) + torch.autograd.grad((flux * g).sum(), vals)
+
+    want = step(*leaves)
+    graphed = xo.GraphedStep(step, *leaves)
+    got = graphed()
+    for a, b in zip(got, want):
+        np.testing.assert_allclose(npy(a), npy(b), rtol=1e-9, atol=1e-12 * float(b.abs().max()))
+    # new parameter values through the static inputs
+    moved = [x.detach() + 1e-3 for x in leaves[:2]] + [x.detach() for x in leaves[2:]]
+    got = graphed(*moved)
+    want = step(*[x.clone().requires_grad_(True) for x in moved])
+    for a, b in zip(got, want):
+        np.testing.assert_allclose(npy(a), npy(b), rtol=1e-9, atol=1e-12 * float(b.abs().max()))
