@@ -327,3 +327,26 @@ def test_ttv_step_replays_as_a_hip_graph(dev):
     want = step(*[x.clone().requires_grad_(True) for x in moved])
     for a, b in zip(got, want):
         np.testing.assert_allclose(npy(a), npy(b), rtol=1e-9, atol=1e-12 * float(b.abs().max()))
+
+
+def test_large_irregular_table(dev):
+    """4097 bins whose widths grow geometrically: the linear-ephemeris guess is wrong almost
+    everywhere and every lookup falls back to the search (17 levels); shifts keep the planet's
+    clock continuous only on average"""
+    rng = np.random.default_rng(12)
+    orbit = P.KeplerianOrbit(period=0.9, t0=0.2, b=0.3, ecc=0.1, omega=0.4)
+    rec = make_record(orbit, np.array([0.1]))
+    E = 4097
+    edges = np.cumsum(1e-3 * 1.0015 ** np.arange(E))[None, None]          # 0.001 .. ~300, ascending
+    shift = 0.9 * rng.integers(-3, 4, size=(1, 1, E + 1)) + 0.02 * rng.normal(size=(1, 1, E + 1))
+    t = np.sort(rng.uniform(-1.0, edges.max() + 1.0, 6000))
+    c = P.get_cl(0.3, 0.2)[None]
+    check(dev, t, rec, c, (edges, shift))
+    check(dev, t, rec, c, (edges, shift), texp=0.01, order=1)
+    # two planets share nothing but the time axis: generic scan path
+    orbit2 = P.KeplerianOrbit(period=np.array([0.9, 1.7]), t0=np.array([0.2, 0.5]), b=np.array([0.3, 0.1]))
+    rec2 = make_record(orbit2, np.array([0.1, 0.06]))
+    edges2 = np.concatenate([edges, edges[:, :, ::-1].max() - edges[:, :, ::-1] + 1e-3], axis=1)
+    edges2[0, 1] = np.sort(edges2[0, 1])
+    shift2 = np.concatenate([shift, 1.7 * rng.integers(-2, 3, size=(1, 1, E + 1))], axis=1)
+    check(dev, t, rec2, c, (edges2, shift2), texp=0.01)
