@@ -137,3 +137,48 @@ def test_c3_gp_full_size(dev):
         np.testing.assert_allclose(rt.grad.cpu().numpy()[d], gw["y"], rtol=1e-7, atol=1e-7 * np.abs(gw["y"]).max())
         for k, nm in enumerate(("ac", "bc", "cc", "dc")):
             np.testing.assert_allclose(ct.grad.cpu().numpy()[d, :, k], gw[nm], rtol=1e-6)
+
+
+def test_c2_full_size_with_timing_variations(dev):
+    """C2 shape with a timing table per draw (60 transits, 150 000 cadences).  The C port has no
+    timing tables, so each draw is checked transit by transit: a single-planet TTV light curve is
+    the C port's Keplerian one evaluated on the warped clock t - shift[bin(t)]; the per-transit
+    cotangents add up to the t_periastron one; shards equal the batch."""
+    from exoplanet_amd import ops
+
+    rng = np.random.default_rng(7)
+    t = np.arange(150_000) * (2.0 / 1440.0)
+    D, n_tr = 6, 60
+    recs, edges, shifts = [], [], []
+    for d in range(D):
+        orbit = P.TTVOrbit(period=np.array([3.5]), t0=np.array([1.0]), b=np.array([0.3]), ecc=np.array([0.3]),
+                           omega=np.array([1.1]), ttvs=[0.02 * rng.normal(size=n_tr)])
+        recs.append(make_record(orbit, np.array([0.1]))[0])
+        e, s = orbit.kernel_tables()
+        edges.append(e)
+        shifts.append(s)
+    rec = _perturbed(np.stack(recs), 1, rng)
+    edges, shifts = np.stack(edges), np.stack(shifts)
+    c = np.repeat(P.get_cl(0.3, 0.2)[None], D, 0)
+    g = rng.normal(size=(D, t.size))
+    args = (T(t, dev), T(rec, dev), T(c, dev), T(g, dev))
+    f, gp, gl, gs = ops.transit_flux_value_and_vjp(*args, ttv=(T(edges, dev), T(shifts, dev)))
+    sl = list(P.GRAD_SLOTS[:-1])
+    for d in range(D):
+        warped = t - shifts[d, 0][np.searchsorted(edges[d, 0], t)]
+        want_f, want_gp, want_gl = C.transit(warped, rec[d:d + 1], c[d:d + 1], g[d:d + 1])
+        assert (want_f < -1e-3).sum() > 3000
+        assert np.abs(f[d].cpu().numpy() - want_f[0]).max() < 1e-12
+        assert np.abs(gp[d].cpu().numpy()[..., sl] - want_gp[0][..., sl]).max() <= 1e-9 * np.abs(want_gp[..., sl]).max()
+        np.testing.assert_allclose(gl[d].cpu().numpy(), want_gl[0], rtol=1e-9)
+    assert float(gs.abs().max()) > 0
+    np.testing.assert_allclose(gs.sum(-1).cpu().numpy(), gp[..., P.P_TP].cpu().numpy(), rtol=1e-10)
+    # draws in two shards == the batch (gshift goes through atomics: last bits may differ)
+    for lo, hi in ((0, 4), (4, 6)):
+        fs, gps, gls, gss = ops.transit_flux_value_and_vjp(T(t, dev), T(rec[lo:hi], dev), T(c[lo:hi], dev), T(g[lo:hi], dev),
+                                                           ttv=(T(edges[lo:hi], dev), T(shifts[lo:hi], dev)))
+        assert torch.equal(fs, f[lo:hi])
+        # (another batch size is another block decomposition: sums in another order)
+        assert torch.allclose(gps, gp[lo:hi], rtol=1e-11, atol=1e-13 * float(gp.abs().max()))
+        assert torch.allclose(gls, gl[lo:hi], rtol=1e-11)
+        assert torch.allclose(gss, gs[lo:hi], rtol=1e-11, atol=1e-13 * float(gs.abs().max()))
