@@ -638,11 +638,31 @@ __global__ __launch_bounds__(kBlock, (FAST && TTV) ? 5 : 1) void transit_scan_ke
   const int bx = (int)(work - unit * blocks_per_draw);
   const int64_t draw = grouped ? unit * kScanDraws : unit;
   const int nd = grouped ? (int)((n_draw - draw) < kScanDraws ? (n_draw - draw) : kScanDraws) : 1;
+  // TTV: this block's rows of the timing tables (its draw's planets, or its draws' single planets)
+  // are copied to LDS when they fit: under the fill blocks' store stream a lookup that goes to
+  // L2 waits microseconds, and a tile that crosses a bin boundary needs two in a row.
+  constexpr int kTabMax = TTV ? 2048 : 1;
+  __shared__ double s_tab[kTabMax];
+  Ttv tl = ttv;                                                  // the tables as this block reads them
+  int64_t row0 = grouped ? draw : draw * n_planet;               // table row of the block's first record
+  if (TTV) {
+    const int rows = grouped ? nd : n_planet, ne = ttv.n_edge;
+    if (rows * (2 * ne + 1) <= kTabMax) {
+      const double* __restrict__ src_e = ttv.edges + row0 * ne;
+      const double* __restrict__ src_s = ttv.shift + row0 * (ne + 1);
+      for (int q = threadIdx.x; q < rows * ne; q += kBlock) s_tab[q] = src_e[q];
+      for (int q = threadIdx.x; q < rows * (ne + 1); q += kBlock) s_tab[rows * ne + q] = src_s[q];
+      tl.edges = s_tab;
+      tl.shift = s_tab + rows * ne;
+      row0 = 0;
+      __syncthreads();
+    }
+  }
   // grouped: the nd consecutive single-planet records are staged as if they were nd planets of one draw
   stage_constants(sh, params + (grouped ? draw * EXO_NPAR : 0), nullptr, stencil_dt, nullptr, n_sub,
                   grouped ? nd : n_planet, grouped ? 0 : draw, SECONDARY,
-                  stage1 ? windows + (grouped ? kWin * draw : 0) : nullptr, TTV ? &ttv : nullptr,
-                  grouped ? draw : 0);
+                  stage1 ? windows + (grouped ? kWin * draw : 0) : nullptr, TTV ? &tl : nullptr,
+                  grouped ? row0 : row0 - draw * n_planet);
   // the windows are widened by the half-span of the exposure stencil; the reference widens its
   // contact windows by texp / 2 whatever the stencil (keplerian.py:765-769)
   double span = window ? 0.5 : 0.0;
@@ -727,7 +747,7 @@ __global__ __launch_bounds__(kBlock, (FAST && TTV) ? 5 : 1) void transit_scan_ke
         for (int j = 0; j < nd; ++j) {
           if (!((redo >> j) & 1u)) continue;
           const PlanetConst& c = sh.pc[j];
-          const TtvRow row(ttv, draw + j);
+          const TtvRow row(tl, row0 + j);
           const double widen = fabs(te) * span * fabs(c.nrev);
           TtvRow::Hit hit[2];
           row.locate2(tv0, tv1, c.te0, c.tinv, c.tfin, hit[0], hit[1]);
@@ -763,7 +783,7 @@ __global__ __launch_bounds__(kBlock, (FAST && TTV) ? 5 : 1) void transit_scan_ke
           if ((cand >> (2 * j + v)) & 1u) {
             if (TTV) {
               const PlanetConst& c = sh.pc[j];
-              const TtvRow row(ttv, draw + j);
+              const TtvRow row(tl, row0 + j);
               double e_lo, e_hi;
               const int kb = row.locate(tv[v], c.te0, c.tinv, c.tfin, e_lo, e_hi);
               const double shv = row.shift[kb];
@@ -839,7 +859,7 @@ __global__ __launch_bounds__(kBlock, (FAST && TTV) ? 5 : 1) void transit_scan_ke
           // in_transit, warp the mid-exposure time only)
           // The wave's last bin of this planet is tried first (LDS broadcast): times are usually
           // sorted, and a bin holds thousands of cadences.
-          const TtvRow row(ttv, draw * n_planet + p);
+          const TtvRow row(tl, row0 + p);
           const double hw = window ? 0.0 : fma(fabs(te) * span, 1e-12, fabs(te) * span);   // (the product was rounded)
           const GenBin nb = s_gbin[wave][p];
           double e_lo = nb.lo, e_hi = nb.hi, shv = nb.sh;
@@ -938,8 +958,25 @@ __global__ __launch_bounds__(kBlock, EXO_HEAVY_MIN_WAVES) void transit_heavy_ker
   const int64_t draw = blockIdx.y;
   __shared__ BinCache s_bins;
   if (GRAD && TTV && threadIdx.x < kWaves * kBinSlots) (&s_bins.id[0][0])[threadIdx.x] = -1;
+  // TTV: the draw's timing tables in LDS when they fit (a wave's 64 list entries often span two
+  // transits of different planets: a lookup per planet and round; from LDS it costs a tenth)
+  constexpr int kTabMax = TTV ? 2048 : 1;
+  __shared__ double s_tab[kTabMax];
+  Ttv tl = ttv;
+  int64_t row0 = draw * n_planet;
+  if (TTV && n_planet * (2 * ttv.n_edge + 1) <= kTabMax) {
+    const int ne = ttv.n_edge;
+    const double* __restrict__ src_e = ttv.edges + row0 * ne;
+    const double* __restrict__ src_s = ttv.shift + row0 * (ne + 1);
+    for (int q = threadIdx.x; q < n_planet * ne; q += kBlock) s_tab[q] = src_e[q];
+    for (int q = threadIdx.x; q < n_planet * (ne + 1); q += kBlock) s_tab[n_planet * ne + q] = src_s[q];
+    tl.edges = s_tab;
+    tl.shift = s_tab + n_planet * ne;
+    row0 = 0;
+    __syncthreads();
+  }
   stage_constants(sh, params, ld, stencil_dt, stencil_w, n_sub, n_planet, draw, SECONDARY, nullptr,
-                  TTV ? &ttv : nullptr);
+                  TTV ? &tl : nullptr, row0 - draw * n_planet);
   const bool per_planet = flags & EXO_FLAG_PER_PLANET;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   // this block works through the lists of `nsub` consecutive scan blocks of its draw
@@ -991,7 +1028,7 @@ __global__ __launch_bounds__(kBlock, EXO_HEAVY_MIN_WAVES) void transit_heavy_ker
     for (int k = 0; k < n_sub; ++k) reach = fmax(reach, fabs(sh.sdt[k]));
   for (int p = 0; p < n_planet; ++p) {
     const PlanetS c(sh.pc[p]);
-    const TtvRow row(ttv, TTV ? draw * n_planet + p : 0);
+    const TtvRow row(tl, TTV ? row0 + p : 0);
     const TtvGrad tgrad{GRAD && TTV ? &lds_acc[0][threadIdx.x] : nullptr,
                         GRAD && TTV ? ttv.gshift + (draw * n_planet + p) * (int64_t)(ttv.n_edge + 1) : nullptr,
                         &s_bins};
