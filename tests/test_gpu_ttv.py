@@ -350,3 +350,28 @@ def test_large_irregular_table(dev):
     edges2[0, 1] = np.sort(edges2[0, 1])
     shift2 = np.concatenate([shift, 1.7 * rng.integers(-2, 3, size=(1, 1, E + 1))], axis=1)
     check(dev, t, rec2, c, (edges2, shift2), texp=0.01)
+
+
+@pytest.mark.parametrize("planets", [1, 2])
+def test_ttv_fast_classifier_equals_exact_scan(dev, planets):
+    """the conservative fp32 classifier + conjunction windows never drop a cadence on the warped
+    clock either: EXO_FLAG_EXACT_SCAN (fp64 classification of every cadence) gives the same bits"""
+    from exoplanet_amd import ops
+
+    if planets == 1:
+        rec, tables = single_planet_draws(6)
+    else:
+        rec, tables = case_records(draws=3)
+    D = rec.shape[0]
+    c = T(np.repeat(P.get_cl(0.3, 0.2)[None], D, 0), dev)
+    t = T(np.linspace(-3.0, 84.0, 9001), dev)
+    ttv = (T(tables[0], dev), T(tables[1], dev))
+    g = T(np.random.default_rng(0).normal(size=(D, 9001)), dev)
+    sdt, sw = P.exposure_stencil(7, 0)
+    for kw in ({}, dict(texp=T(np.array([0.06]), dev), stencil_dt=T(sdt, dev), stencil_w=T(sw, dev))):
+        fast = ops.transit_flux_value_and_vjp(t, T(rec, dev), c, g, ttv=ttv, **kw)
+        exact = ops.transit_flux_value_and_vjp(t, T(rec, dev), c, g, ttv=ttv, flags=ops.FLAG_EXACT_SCAN, **kw)
+        assert float(fast[0].min()) < -1e-3
+        assert torch.equal(fast[0], exact[0])
+        for a, b in zip(fast[1:3], exact[1:3]):
+            assert torch.allclose(a, b, rtol=1e-12, atol=1e-12 * float(b.abs().max()))
