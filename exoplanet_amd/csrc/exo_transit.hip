@@ -22,6 +22,8 @@
 //   orbits/keplerian.py:729-731,765-769   in-transit window test
 //   light_curves/limb_dark.py:178-226     exposure stencil, b, los, s.c - 1, los > 0
 //   light_curves/secondary_eclipse.py:45-70   flipped orbit + blend
+//   orbits/ttv.py:158-187         bin edges / values, searchsorted, t - transit time of the bin
+//                                 (the TTV template variants of the scan and heavy kernels)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
