@@ -160,18 +160,23 @@ __device__ __forceinline__ void lane_uv(const LaneCoef& k, double t, double* U, 
 }
 
 // saved-state addressing.  Per (cadence, draw): the pair (d, z), 16 B; per (cadence, draw, j): one
-// record (W_j, F_j, S_j0 .. S_j,J-1) of 2 + J doubles.  Lanes of a wave are consecutive (draw, j), so
-// a wave's records are contiguous and -- for even J -- move as 16-B accesses (8-B accesses reach
-// 0.54-0.70 of the 16-B rate: MI355X_MICROARCH.md).
+// record (W_j, F_j, S_j0 .. S_j,J-1) of R = 2 + J doubles, stored PLANAR within the cadence: piece q
+// of every (draw, j) is contiguous -- [cadence][piece][draw x j], pieces of 16 B for even R, of 8 B
+// for odd R (whose cadence stride is not 16-B aligned).  Lanes of a wave are consecutive (draw, j), so
+// every load / store instruction of a wave covers one contiguous kilobyte; record-major records
+// made each instruction touch 16 B of every lane's record -- partial lines at the memory side.
 struct StateIdx {
   int64_t n, n_draw;
   int J;
   __device__ __forceinline__ int64_t scal(int q, int64_t i, int64_t draw) const {  // q = 0 (d), 1 (z)
     return (i * n_draw + draw) * 2 + q;
   }
-  __device__ __forceinline__ int64_t vec(int q, int64_t i, int64_t draw, int j) const {  // q = 0 (W), 1 (F), 2.. (S row)
-    return 2 * n * n_draw + ((i * n_draw + draw) * J + j) * (int64_t)(2 + J) + q;
+  // address of piece 0 of the record of (cadence i, draw, j); piece q is q * piece() doubles further
+  __device__ __forceinline__ int64_t rec(int64_t i, int64_t draw, int j) const {
+    const int64_t lanes = n_draw * J, lane = draw * J + j;
+    return 2 * n * n_draw + i * lanes * (int64_t)(2 + J) + (((2 + J) % 2 == 0) ? 2 * lane : lane);
   }
+  __device__ __forceinline__ int64_t piece() const { return n_draw * J * (int64_t)(((2 + J) % 2 == 0) ? 2 : 1); }
   // U_n, V_n, P_n (q = 0, 1, 2) written by the parallel pre-pass: the sequential kernels
   // never evaluate a sin, cos or exp
   __device__ __forceinline__ int64_t uvp(int q, int64_t i, int64_t draw, int j) const {
@@ -179,44 +184,40 @@ struct StateIdx {
   }
 };
 
-// one record (W, F, S row) / one (d, z) pair, as 16-B accesses where the record length allows
+// one record (W, F, S row): p = piece 0 (StateIdx::rec), ps = StateIdx::piece().  Non-temporal:
+// written once per forward pass, read once by the reverse pass, 10 GB-scale.
 template <int J>
-__device__ __forceinline__ void store_record(double* __restrict__ p, double W, double F, const double* S) {
+__device__ __forceinline__ void store_record(double* __restrict__ p, int64_t ps, double W, double F, const double* S) {
   constexpr int R = 2 + J;
   double v[R];
   v[0] = W; v[1] = F;
 #pragma unroll
   for (int l = 0; l < J; ++l) v[2 + l] = S[l];
-  // Non-temporal for short records: written once per forward pass, read once by the reverse pass,
-  // 10 GB-scale (C3 forward kernel 3.97 -> 3.21 ms).  NOT for long ones: a store instruction then
-  // touches 16 B of every lane's 64-B record, and without L2 to merge the four pieces the writes
-  // reach HBM as partial lines (J = 6 forward kernel 1.1 -> 2.9 ms).
   typedef double v2d __attribute__((ext_vector_type(2)));
   if (R % 2 == 0) {
 #pragma unroll
     for (int q = 0; q < R / 2; ++q) {
       const v2d x = {v[2 * q], v[2 * q + 1]};
-      if (R <= 4) __builtin_nontemporal_store(x, reinterpret_cast<v2d*>(p) + q);
-      else reinterpret_cast<v2d*>(p)[q] = x;
+      __builtin_nontemporal_store(x, reinterpret_cast<v2d*>(p + q * ps));
     }
   } else {
 #pragma unroll
-    for (int q = 0; q < R; ++q) p[q] = v[q];
+    for (int q = 0; q < R; ++q) __builtin_nontemporal_store(v[q], p + q * ps);
   }
 }
 template <int J>
-__device__ __forceinline__ void load_record(const double* __restrict__ p, double& W, double& F, double* S) {
+__device__ __forceinline__ void load_record(const double* __restrict__ p, int64_t ps, double& W, double& F, double* S) {
   constexpr int R = 2 + J;
   double v[R];
   if (R % 2 == 0) {
 #pragma unroll
     for (int q = 0; q < R / 2; ++q) {
-      const double2 x = reinterpret_cast<const double2*>(p)[q];
+      const double2 x = *reinterpret_cast<const double2*>(p + q * ps);
       v[2 * q] = x.x; v[2 * q + 1] = x.y;
     }
   } else {
 #pragma unroll
-    for (int q = 0; q < R; ++q) v[q] = p[q];
+    for (int q = 0; q < R; ++q) v[q] = p[q * ps];
   }
   W = v[0]; F = v[1];
 #pragma unroll
@@ -307,14 +308,14 @@ __global__ __launch_bounds__(kWave) void celerite_fwd_kernel(
   double dt_prev = -1.0;
   if (store) {
     if (j == 0) *reinterpret_cast<double2*>(state + six.scal(0, 0, draw)) = double2{d, z};
-    store_record<J>(state + six.vec(0, 0, draw, j), Wj, 0.0, Srow);   // S_0 = 0
+    store_record<J>(state + six.rec(0, draw, j), six.piece(), Wj, 0.0, Srow);   // S_0 = 0
   }
   // software prefetch ring: the loads of cadence i + kPF are issued while cadence i
   // computes (one wave per SIMD and a serial chain: nothing else hides HBM latency)
   const int64_t vstride = n_draw * J;            // one cadence, in doubles, of a per-(draw, j) quantity (U, V, P)
   const int64_t qstride = n * vstride;           // one quantity (U, V, P)
   const int64_t rstride = vstride * (2 + J);     // one cadence of (W, F, S row) records
-  double* __restrict__ p_vec = SAVE ? state + six.vec(0, 0, draw, jj) : nullptr;
+  double* __restrict__ p_vec = SAVE ? state + six.rec(0, draw, jj) : nullptr;
   double* __restrict__ p_scal = SAVE ? state + six.scal(0, 0, draw) : nullptr;
   const double* __restrict__ p_uvp = SAVE ? state + six.uvp(0, 0, draw, jj) : nullptr;
   constexpr int kPF = 4;
@@ -391,7 +392,7 @@ __global__ __launch_bounds__(kWave) void celerite_fwd_kernel(
       p_vec += rstride;
       p_scal += 2 * n_draw;
       if (j == 0) *reinterpret_cast<double2*>(p_scal) = double2{d, z};
-      store_record<J>(p_vec, Wj, Fj, Srow);
+      store_record<J>(p_vec, six.piece(), Wj, Fj, Srow);
     }
    }
   }
@@ -436,13 +437,13 @@ __global__ __launch_bounds__(kWave) void celerite_vjp_kernel(
 
   const int64_t vstride = n_draw * J, qstride = n * vstride;
   const double* __restrict__ sc0 = state + six.scal(0, 0, draw);
-  const double* __restrict__ ve0 = state + six.vec(0, 0, draw, jj);
+  const double* __restrict__ ve0 = state + six.rec(0, draw, jj);
   const double* __restrict__ uv0 = state + six.uvp(0, 0, draw, jj);
   const int64_t rstride = vstride * (2 + J);   // one cadence of (W, F, S row) records
   auto load = [&](int64_t i, double& d_, double& z_, double& W_, double& F_, double* S_) {
     const double2 dz = *reinterpret_cast<const double2*>(sc0 + i * 2 * n_draw);
     d_ = dz.x; z_ = dz.y;
-    load_record<J>(ve0 + i * rstride, W_, F_, S_);   // idle lanes read lane 0's record: harmless, zeroed below
+    load_record<J>(ve0 + i * rstride, six.piece(), W_, F_, S_);   // idle lanes read lane 0's record: harmless, zeroed below
     if (!k.live) {
       W_ = F_ = 0.0;
 #pragma unroll
@@ -1528,7 +1529,7 @@ __global__ __launch_bounds__(kWave) void celerite_chunk_fwd_kernel(
   double acc = 0.0, lman = 1.0;
   int64_t lsum = 0;
   const int64_t rstride = n_draw * J * (int64_t)(2 + J);   // one cadence of (W, F, S row) records
-  double* __restrict__ p_vec = state + six.vec(0, n0, draw, jj);
+  double* __restrict__ p_vec = state + six.rec(n0, draw, jj);
   double* __restrict__ p_scal = state + six.scal(0, n0, draw);
   double tprev = t[n0 > 0 ? n0 - 1 : 0], dt_prev = -1.0, Pj = 1.0;
 #pragma unroll 1
@@ -1570,7 +1571,7 @@ __global__ __launch_bounds__(kWave) void celerite_chunk_fwd_kernel(
     lsum += lexp;
     if (store) {
       if (j == 0) *reinterpret_cast<double2*>(p_scal) = double2{d, z};
-      store_record<J>(p_vec, Wj, Fj, Srow);
+      store_record<J>(p_vec, six.piece(), Wj, Fj, Srow);
     }
     p_vec += rstride; p_scal += 2 * n_draw;
   }
@@ -1629,12 +1630,12 @@ __global__ __launch_bounds__(kWave) void celerite_chunk_vjp_kernel(
 
   const int64_t vstride = n_draw * J, qstride = n * vstride;
   const double* __restrict__ sc0 = state + six.scal(0, 0, draw);
-  const double* __restrict__ ve0 = state + six.vec(0, 0, draw, jj);
+  const double* __restrict__ ve0 = state + six.rec(0, draw, jj);
   const int64_t rstride = vstride * (2 + J);   // one cadence of (W, F, S row) records
   auto load = [&](int64_t i, double& d_, double& z_, double& W_, double& F_, double* S_) {
     const double2 dz = *reinterpret_cast<const double2*>(sc0 + i * 2 * n_draw);
     d_ = dz.x; z_ = dz.y;
-    load_record<J>(ve0 + i * rstride, W_, F_, S_);   // idle lanes read lane 0's record: harmless, zeroed below
+    load_record<J>(ve0 + i * rstride, six.piece(), W_, F_, S_);   // idle lanes read lane 0's record: harmless, zeroed below
     if (!k.live) {
       W_ = F_ = 0.0;
 #pragma unroll

@@ -220,8 +220,11 @@ int exo_transit_flux_ttv_vjp_f64(const double* t, int64_t n_cad, const double* t
  *   state        NULL (value only) or exo_celerite_state_doubles() doubles: the
  *                factorisation (d, z; W, F and the rows of S per state index) the reverse
  *                pass re-reads -- per (cadence, draw) the pair (d, z), per (cadence, draw, state
- *                index) one record (W, F, row of S) -- followed by the pre-pass arrays and the
- *                workspace of the time-parallel path; 16-byte aligned (16-B accesses)
+ *                index) one record (W, F, row of S), the records of a cadence stored planar
+ *                ([piece][draw x state index]: every access of a wave is one contiguous run) --
+ *                followed by the pre-pass arrays and the workspace of the time-parallel path;
+ *                16-byte aligned (16-B accesses).  Opaque to the caller: whatever wrote it
+ *                (this library, this ABI version) must read it back
  *
  * With a state buffer and n >= 64 the recurrences run in parallel over TIME
  * (DESIGN.md 3.5): the series is cut into chunks, chunk "filtering elements" and a short
