@@ -1388,12 +1388,10 @@ struct ScanPlan {
   int64_t n_classify;  // classify blocks
   dim3 grid;
 };
-inline ScanPlan scan_plan(uint32_t flags, int bpd, int64_t n_draw, int n_planet, int64_t n_texp, bool with_fill,
-                          bool has_ttv = false) {
+inline ScanPlan scan_plan(uint32_t flags, int bpd, int64_t n_draw, int n_planet, int64_t n_texp, bool with_fill) {
   ScanPlan sp;
   const bool stage1 = (flags & EXO_FLAG_WINDOW) || !(flags & EXO_FLAG_EXACT_SCAN);
   const bool grouped = n_planet == 1 && n_texp <= 1 && stage1;
-  (void)has_ttv;
   sp.flags = (flags & 0x0fffffffu) | (grouped ? kFlagGrouped : 0u) | (with_fill ? 0u : kFlagNoFlux);
   sp.n_classify = (grouped ? (n_draw + kScanDraws - 1) / kScanDraws : n_draw) * bpd;
   sp.grid = dim3((unsigned)(sp.n_classify + (with_fill ? n_draw * bpd : 0)));
@@ -1479,7 +1477,7 @@ static int transit_fwd(const double* t, int64_t n_cad, const double* texp, int64
   const bool secondary = flags & EXO_FLAG_SECONDARY;
   if (ev_start) (void)hipEventRecord((hipEvent_t)ev_start, st);
   launch_windows(params, n_draw, n_planet, flags, w.windows, st);
-  const ScanPlan sp = scan_plan(flags, bpd, n_draw, n_planet, n_texp, true, has_ttv);
+  const ScanPlan sp = scan_plan(flags, bpd, n_draw, n_planet, n_texp, true);
   EXO_LAUNCH_SCAN(n_cad, t, has_ttv, flags, sp.grid, block, 0, st, t, n_cad, texp, n_texp, stencil_dt, n_sub, params,
                   n_planet, sp.flags, tpb, bpd, n_draw, sp.n_classify, flux, w.counts, w.list, w.windows, ttv);
   if (launch_status() != EXO_OK) return EXO_ERR_LAUNCH;
@@ -1536,7 +1534,7 @@ static int transit_vjp(const double* t, int64_t n_cad, const double* texp, int64
   double* flux_dst = flux_out;
   if (ev_start) (void)hipEventRecord((hipEvent_t)ev_start, st);
   launch_windows(params, n_draw, n_planet, flags, w.windows, st);
-  const ScanPlan sp = scan_plan(flags, bpd, n_draw, n_planet, n_texp, flux_dst != nullptr, has_ttv);
+  const ScanPlan sp = scan_plan(flags, bpd, n_draw, n_planet, n_texp, flux_dst != nullptr);
   EXO_LAUNCH_SCAN(n_cad, t, has_ttv, flags, sp.grid, block, 0, st, t, n_cad, texp, n_texp, stencil_dt, n_sub, params,
                   n_planet, sp.flags, tpb, bpd, n_draw, sp.n_classify, flux_dst, w.counts, w.list, w.windows, ttv);
   if (launch_status() != EXO_OK) return EXO_ERR_LAUNCH;

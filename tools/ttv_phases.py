@@ -1,15 +1,23 @@
-import csv,sys
-rows=list(csv.DictReader(open(sys.argv[1])))
-rows.sort(key=lambda r:int(r['Start_Timestamp']))
-segs=[];cur={}
+"""Per-phase kernel averages from a rocprofv3 kernel trace of tools/profile_ttv.py: the script runs
+its timed legs one after the other (3 warm-up + 10 timed calls each), so a new leg starts at every
+14th window-kernel launch.   python tools/ttv_phases.py <..._kernel_trace.csv>"""
+import csv
+import sys
+
+CALLS_PER_LEG = 13   # 3 warm-up + 10 timed
+
+rows = sorted(csv.DictReader(open(sys.argv[1])), key=lambda r: int(r["Start_Timestamp"]))
+legs, cur = [], {}
 for r in rows:
-    n=r['Kernel_Name']
-    if 'transit' not in n: continue
-    name=n.split('::')[1].split('(')[0]
-    d=(int(r['End_Timestamp'])-int(r['Start_Timestamp']))/1e3
-    if 'window' in name and cur and len(cur.get(name,[]))>=13:
-        segs.append(cur); cur={}
-    cur.setdefault(name,[]).append(d)
-segs.append(cur)
-for sgm in segs:
-    print({k.replace('transit_','')[:40]:round(sum(v[3:])/max(len(v[3:]),1),1) for k,v in sgm.items() if 'window' not in k and 'reduce' not in k})
+    if "transit" not in r["Kernel_Name"]:
+        continue
+    name = r["Kernel_Name"].split("::")[1].split("(")[0]
+    us = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+    if "window" in name and len(cur.get(name, [])) >= CALLS_PER_LEG:
+        legs.append(cur)
+        cur = {}
+    cur.setdefault(name, []).append(us)
+legs.append(cur)
+for leg in legs:
+    print({k.replace("transit_", "")[:40]: round(sum(v[3:]) / max(len(v[3:]), 1), 1)
+           for k, v in leg.items() if "window" not in k and "reduce" not in k})
