@@ -157,3 +157,36 @@ def test_transit_times_parameterisation_tables():
     ge, gs = got.kernel_ttv()
     np.testing.assert_allclose(ge.numpy(), e, rtol=0, atol=1e-12)
     np.testing.assert_allclose(gs.numpy(), s, rtol=0, atol=1e-12)
+
+
+def test_ephemeris_shortcut_and_fallback():
+    """TTVOrbit reads (t0, period) straight from its arguments when both are given (no attribute
+    algebra on the fused path) and derives them otherwise (t_periastron given): same tables"""
+    from exoplanet_amd.orbits import TTVOrbit
+
+    cpu = lambda x: torch.as_tensor(x, dtype=torch.float64, device="cpu")  # noqa: E731
+    ttvs = [cpu([0.01, -0.02, 0.015, 0.0]), cpu([0.0, 0.03])]
+    a = TTVOrbit(period=cpu([3.0, 7.0]), t0=cpu([1.0, 2.0]), b=cpu([0.1, 0.2]), ecc=cpu([0.1, 0.2]),
+                 omega=cpu([0.3, -0.4]), ttvs=ttvs)
+    assert not a._ready                                        # nothing materialised yet
+    ea, sa = a.kernel_ttv()
+    assert not a._ready
+    b = TTVOrbit(period=cpu([3.0, 7.0]), t_periastron=a.t_periastron, b=cpu([0.1, 0.2]), ecc=cpu([0.1, 0.2]),
+                 omega=cpu([0.3, -0.4]), ttvs=ttvs)
+    eb, sb = b.kernel_ttv()
+    np.testing.assert_allclose(eb.numpy(), ea.numpy(), rtol=0, atol=1e-12)
+    np.testing.assert_allclose(sb.numpy(), sa.numpy(), rtol=0, atol=1e-12)
+    # the transit times follow t0 + period * index + ttv (ttv.py:141-147)
+    np.testing.assert_allclose(a.transit_times[0].numpy(), 1.0 + 3.0 * np.arange(4) + ttvs[0].numpy(), atol=1e-15)
+
+
+def test_transit_inds_from_host_or_device_tensor():
+    from exoplanet_amd.orbits import TTVOrbit
+
+    cpu = lambda x: torch.as_tensor(x, dtype=torch.float64, device="cpu")  # noqa: E731
+    kw = dict(period=cpu([3.0]), t0=cpu([1.0]), b=cpu([0.1]), ttvs=[cpu([0.01, -0.02, 0.015])])
+    want = TTVOrbit(transit_inds=[[0, 2, 5]], **kw).kernel_ttv()
+    for inds in ([np.array([0, 2, 5])], [torch.tensor([0, 2, 5])]):
+        got = TTVOrbit(transit_inds=inds, **kw).kernel_ttv()
+        assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
+    assert want[0].shape[-1] == 7            # six transits (three of them filled in): seven edges
