@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # EXOPLANET_AMD_LIB selects another in-tree build of the same ABI (A/B measurements)
 LIB_PATH = os.environ.get("EXOPLANET_AMD_LIB") or os.path.join(_HERE, "lib", "libexoplanet_amd.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 _c_dp = ctypes.c_void_p  # device pointers travel as integers
 _i64 = ctypes.c_int64
@@ -72,6 +72,8 @@ _SIGNATURES = {
         [_c_dp, _c_dp, _i64, _i64, _c_dp, _i32, _c_dp, _i32, _i64, _c_dp, _c_dp, _c_dp, _c_dp, _c_dp, _c_dp,
          _c_dp, _c_dp],
     ),
+    "exo_radial_velocity_fwd_f64": (ctypes.c_int, [_c_dp, _i64, _c_dp, _i64, _i32, _c_dp, _c_dp]),
+    "exo_radial_velocity_vjp_f64": (ctypes.c_int, [_c_dp, _i64, _c_dp, _i64, _i32, _c_dp, _c_dp, _c_dp]),
     "exo_pack_records_f64": (ctypes.c_int, [_c_dp, _c_dp, _i64, _i32, _u32, _c_dp, _c_dp, _c_dp]),
     "exo_pack_records_vjp_f64": (ctypes.c_int, [_c_dp, _c_dp, _i64, _i32, _u32, _c_dp, _c_dp, _c_dp, _c_dp, _c_dp]),
 }

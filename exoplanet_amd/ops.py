@@ -353,6 +353,52 @@ def transit_flux_dot(t, params, ld, gflux, texp=None, stencil_dt=None, stencil_w
 
 
 # ------------------------------------------------------------------------------
+# radial velocity
+# ------------------------------------------------------------------------------
+RV_NPAR = 6
+RV_N, RV_TP, RV_ECC, RV_COSW, RV_SINW, RV_AMP = range(6)
+
+
+class _RadialVelocity(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, t, params):
+        t = _dev(t, "t")
+        params = _dev(params, "params")
+        if t.dim() != 1:
+            raise ValueError("t must be 1-D (n_cad,)")
+        if params.dim() != 3 or params.shape[-1] != RV_NPAR:
+            raise ValueError(f"params must be (n_draw, n_planet, {RV_NPAR})")
+        D, P, _ = params.shape
+        rv = torch.empty(D, t.numel(), P, dtype=torch.float64, device=t.device)
+        lib = _lib.load()
+        with torch.cuda.device(t.device):
+            _lib.check(lib.exo_radial_velocity_fwd_f64(_ptr(t), t.numel(), _ptr(params), D, P, _ptr(rv), _stream(t)),
+                       "exo_radial_velocity_fwd_f64")
+        ctx.save_for_backward(t, params)
+        return rv
+
+    @staticmethod
+    def backward(ctx, grv):
+        t, params = ctx.saved_tensors
+        D, P, _ = params.shape
+        grv = _dev(grv, "grv")
+        gparams = torch.empty_like(params)
+        lib = _lib.load()
+        with torch.cuda.device(t.device):
+            _lib.check(lib.exo_radial_velocity_vjp_f64(_ptr(t), t.numel(), _ptr(params), D, P, _ptr(grv),
+                                                       _ptr(gparams), _stream(t)), "exo_radial_velocity_vjp_f64")
+        return None, gparams
+
+
+def radial_velocity(t, params):
+    """Stellar reflex radial velocity, one column per planet: t (n_cad,), params
+    (n_draw, n_planet, 6) = (n, t_periastron, ecc, cos omega, sin omega, amplitude)
+    (include/exoplanet_amd.h EXO_RV_*) -> (n_draw, n_cad, n_planet); differentiable
+    w.r.t. ``params``.  One launch each way (keplerian.py:633-677)."""
+    return _RadialVelocity.apply(t.detach(), params)
+
+
+# ------------------------------------------------------------------------------
 # record packing: KeplerianOrbit.__init__ algebra + get_cl + windows as one kernel
 # ------------------------------------------------------------------------------
 class _PackRecords(torch.autograd.Function):

@@ -398,6 +398,33 @@ class KeplerianOrbit:
         """stellar reflex RV, positive = redshift (keplerian.py:633-677).  Without
         ``K`` the result is in m/s (``output_units`` other than None is not supported:
         no astropy)."""
+        if K is None and output_units is not None:
+            raise NotImplementedError("unit conversion needs astropy; the default is m/s")
+        t = as_tensor(t, next((x for x in self._args.values() if isinstance(x, torch.Tensor)), None))
+        if type(self)._warp_times is KeplerianOrbit._warp_times and t.dim() == 1 and t.is_cuda:
+            # one fused launch (and one for the reverse pass): amplitude x (cos w cos f - sin w sin f + e cos w)
+            # with the caller's K, or -- the z-velocity of the star written out (keplerian.py:599-606 through
+            # :283-322) -- conv sin(incl) K0 m_planet
+            if K is not None and self._standard and not self._ready:
+                # standard parameterisation: (n, t_periastron, e, cos w, sin w) straight from the record-
+                # packing kernel -- no attribute algebra for a K-parameterised RV model
+                rec, _, batch, _ = self.kernel_inputs(0.0, (0.0, 0.0))
+                amp = _vec(K, rec).expand(tuple(batch) + (rec.shape[1],)).reshape(-1, rec.shape[1], 1)
+                # record slots N, TP, ECC, COSW, SINW are the first five, in the RV record's order (a slice:
+                # an index list would be uploaded from the host, which a hipGraph capture does not allow)
+                params = torch.cat([rec[..., ops.P_N:ops.P_SINW + 1], amp], dim=-1)
+                rv = ops.radial_velocity(t, params)
+                return rv.reshape(tuple(batch) + (t.shape[0], rec.shape[1])).squeeze()
+            if K is not None:
+                amp = _vec(K, self.n)
+            else:
+                amp = m_per_s_per_Rsun_per_day * self.sin_incl * self.K0 * self.m_planet
+            e, cw, sw = self._ew()
+            cols = torch.broadcast_tensors(self.n, self.t_periastron, e, cw, sw, amp)
+            shape = cols[0].shape
+            params = torch.stack(cols, dim=-1).reshape(-1, shape[-1], ops.RV_NPAR).contiguous()
+            rv = ops.radial_velocity(t, params)
+            return rv.reshape(tuple(shape[:-1]) + (t.shape[0], shape[-1])).squeeze()
         if K is not None:
             sinf, cosf = self._get_true_anomaly(t)
             K = _vec(K, self.n).unsqueeze(-2)
@@ -405,8 +432,6 @@ class KeplerianOrbit:
                 return (K * cosf).squeeze()
             cw, sw, e = self.cos_omega.unsqueeze(-2), self.sin_omega.unsqueeze(-2), self.ecc.unsqueeze(-2)
             return (K * (cw * cosf - sw * sinf + e * cw)).squeeze()
-        if output_units is not None:
-            raise NotImplementedError("unit conversion needs astropy; the default is m/s")
         return -m_per_s_per_Rsun_per_day * self.get_star_velocity(t)[2]
 
     def _get_acceleration(self, a, m, t):

@@ -203,6 +203,28 @@ int exo_transit_flux_ttv_vjp_f64(const double* t, int64_t n_cad, const double* t
                                  void* stream);
 
 /* ---------------------------------------------------------------------------
+ * Stellar reflex radial velocity from the same Kepler solve
+ *   KeplerianOrbit.get_radial_velocity   (src/exoplanet/orbits/keplerian.py:633-677)
+ * for n_draw parameter sets:   rv[d][n][p] = AMP (COSW cos f - SINW sin f + ECC COSW),
+ * f the true anomaly at mean anomaly (t_n - TP) N.  Per-(draw, planet) record, EXO_RV_NPAR
+ * doubles; AMP is the caller's K (keplerian.py:660-669; ECC = 0, COSW = 1, SINW = 0 for a
+ * circular orbit, :658-659) or, for the mass-based form (:671-676, with :599-606 and :283-322),
+ * conv sin(incl) K0 m_planet.  rv / grv are [n_draw][n_cad][n_planet] (the reference returns
+ * one column per planet); gparams [n_draw][n_planet][EXO_RV_NPAR].
+ * ------------------------------------------------------------------------- */
+#define EXO_RV_NPAR 6
+#define EXO_RV_N 0     /* mean motion                      */
+#define EXO_RV_TP 1    /* t_periastron                     */
+#define EXO_RV_ECC 2   /* eccentricity (NaN result outside [0, 1)) */
+#define EXO_RV_COSW 3
+#define EXO_RV_SINW 4
+#define EXO_RV_AMP 5   /* semi-amplitude                   */
+int exo_radial_velocity_fwd_f64(const double* t, int64_t n_cad, const double* params, int64_t n_draw,
+                                int32_t n_planet, double* rv, void* stream);
+int exo_radial_velocity_vjp_f64(const double* t, int64_t n_cad, const double* params, int64_t n_draw,
+                                int32_t n_planet, const double* grv, double* gparams, void* stream);
+
+/* ---------------------------------------------------------------------------
  * celerite GP log-likelihood, value + VJP, for n_draw independent (kernel,
  * residual) pairs.  Replaces what celerite2 (a dependency of the reference,
  * /root/reference/setup.py:36; the user's model calls it, the reference tree

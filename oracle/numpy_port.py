@@ -968,6 +968,45 @@ def transit_flux_vjp(t, params, ld, gflux, **kw):
 
 
 # =============================================================================
+# radial velocity: keplerian.py:633-677
+# =============================================================================
+RV_NPAR = 6
+RV_N, RV_TP, RV_ECC, RV_COSW, RV_SINW, RV_AMP = range(6)
+
+
+def radial_velocity(t, params, jac=False):
+    """rv [D, N, P] = amp (cos w cos f - sin w sin f + e cos w) (keplerian.py:660-669; the mass-based
+    form :671-676 is the same function of f with amp = conv sin(i) K0 m_planet, from :599-606 and
+    :283-322).  params [D, P, 6] = (n, t_periastron, e, cos w, sin w, amp).  With jac: also
+    d rv / d params [D, N, P, 6]."""
+    t = np.asarray(t, dtype=np.float64)
+    params = np.asarray(params, dtype=np.float64)
+    n, tp, e, cw, sw, amp = (params[:, None, :, k] for k in range(RV_NPAR))
+    M = (t[None, :, None] - tp) * n
+    sinf, cosf = kepler(M, e + np.zeros_like(M))
+    g = cw * cosf - sw * sinf + e * cw
+    rv = amp * g
+    if not jac:
+        return rv
+    dfdM, dfde = kepler_grad(sinf, cosf, e)
+    dgdf = -(cw * sinf + sw * cosf)
+    J = np.zeros(rv.shape + (RV_NPAR,))
+    J[..., RV_N] = amp * dgdf * dfdM * (t[None, :, None] - tp)
+    J[..., RV_TP] = -amp * dgdf * dfdM * n
+    J[..., RV_ECC] = amp * (dgdf * dfde + cw)
+    J[..., RV_COSW] = amp * (cosf + e)
+    J[..., RV_SINW] = -amp * sinf
+    J[..., RV_AMP] = g
+    return rv, J
+
+
+def radial_velocity_vjp(t, params, grv):
+    """(rv, gparams [D, P, 6]) for a cotangent grv [D, N, P]"""
+    rv, J = radial_velocity(t, params, jac=True)
+    return rv, np.einsum("dnpk,dnp->dpk", J, np.asarray(grv, dtype=np.float64))
+
+
+# =============================================================================
 # celerite GP log-likelihood (celerite2 is absent and has NO call site in the
 # reference tree: parity unpinned by construction; pinned here against the dense
 # Cholesky likelihood).  Algorithm: Foreman-Mackey, Agol, Ambikasaran & Angus

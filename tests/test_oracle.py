@@ -302,3 +302,31 @@ def test_celerite_reverse_scan_over_chunks_by_finite_differences():
             fd = (rest(F0, P0 + E) - rest(F0, P0 - E)) / (2 * h)
             an = Pb[j, l] + Pb[l, j] if l != j else Pb[j, j]
             assert abs(fd - an) < 2e-5 * (1 + abs(an)), (j, l)
+
+
+def test_radial_velocity_is_minus_the_stars_z_velocity():
+    """/root/reference/tests/orbits/keplerian_test.py:134-154 on the oracle: the closed form used
+    by the fused RV op, with amp = conv sin(i) K0 m_planet, equals -conv d z_star / d t (central
+    differences of the oracle's own star position), and its Jacobian equals finite differences"""
+    conv = 695700000.0 / 86400.0
+    orbit = P.KeplerianOrbit(m_star=1.3, r_star=1.0, t0=np.array([0.5, 3.1]), period=np.array([100.0, 37.3]),
+                             ecc=np.array([0.1, 0.45]), omega=np.array([0.5, -2.0]), incl=np.array([0.25 * np.pi, 1.3]),
+                             m_planet=np.array([0.1, 0.02]))
+    t = np.linspace(0, 100, 700)
+    K0 = orbit.n * orbit.a / orbit.m_total / np.sqrt(1 - orbit.ecc ** 2)
+    params = np.stack([orbit.n, orbit.t_periastron, orbit.ecc, orbit.cos_omega, orbit.sin_omega,
+                       conv * orbit.sin_incl * K0 * orbit.m_planet], axis=-1)[None]
+    rv = P.radial_velocity(t, params)[0]
+    h = 1e-4
+    z = lambda tt: np.stack(orbit._get_position(orbit.a_star, tt))[2]  # noqa: E731
+    want = -conv * (z(t + h) - z(t - h)) / (2 * h)
+    np.testing.assert_allclose(rv, want, rtol=2e-7, atol=1e-7 * np.abs(want).max())
+    # Jacobian of the closed form
+    _, J = P.radial_velocity(t, params, jac=True)
+    for k in range(P.RV_NPAR):
+        up, dn = params.copy(), params.copy()
+        step = 1e-6 * max(1.0, abs(params[0, 0, k]))
+        up[0, :, k] += step
+        dn[0, :, k] -= step
+        fd = (P.radial_velocity(t, up) - P.radial_velocity(t, dn)) / (2 * step)
+        np.testing.assert_allclose(J[..., k], fd, rtol=1e-5, atol=1e-6 * np.abs(fd).max())
