@@ -64,3 +64,46 @@ def test_draw_sharding_world2(tmp_path, n_draw):
     assert a.shape == (n_draw,)
     np.testing.assert_array_equal(a, b)          # every rank sees the same full vector
     np.testing.assert_allclose(a, ref, rtol=1e-13)
+
+
+def _worker_ttv(rank, world, port, n_draw, out_dir):
+    """draws that differ in their transit-timing offsets: the per-draw tables are one more entry
+    of the sharded parameter tree (a list of (n_draw, n_transit) tensors, one per planet)"""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from exoplanet_amd.distributed import shard_bounds, sharded_log_likelihood
+        from oracle import numpy_port as P
+
+        rng = np.random.default_rng(1)
+        t = np.linspace(0.0, 30.0, 900)
+        y = 5e-4 * rng.normal(size=t.size)
+        params = {"r": torch.tensor(0.1 * (1 + 0.05 * rng.normal(size=n_draw)), dtype=torch.float64),
+                  "ttvs": [torch.tensor(0.02 * rng.normal(size=(n_draw, 8)), dtype=torch.float64)]}
+
+        def loglike(local):
+            out = []
+            for rv, ttv in zip(local["r"].numpy(), local["ttvs"][0].numpy()):
+                orbit = P.TTVOrbit(period=np.array([3.5]), t0=np.array([1.0]), b=np.array([0.3]), ttvs=[ttv])
+                f = P.LimbDarkLightCurve(0.3, 0.2).get_light_curve(orbit=orbit, r=np.array([rv]), t=t)[:, 0]
+                out.append(-0.5 * np.sum(((y - f) / 5e-4) ** 2))
+            return torch.tensor(out, dtype=torch.float64)
+
+        full, local = sharded_log_likelihood(loglike, params, n_draw)
+        lo, hi = shard_bounds(n_draw)
+        assert local.shape[0] == hi - lo and torch.equal(full[lo:hi], local)
+        np.save(os.path.join(out_dir, f"full_{rank}.npy"), full.numpy())
+        if rank == 0:
+            np.save(os.path.join(out_dir, "ref.npy"), loglike(params).numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_draw_sharding_with_timing_tables_world2(tmp_path):
+    port = _free_port()
+    mp.spawn(_worker_ttv, args=(2, port, 5, str(tmp_path)), nprocs=2, join=True)
+    a, b, ref = (np.load(tmp_path / f) for f in ("full_0.npy", "full_1.npy", "ref.npy"))
+    np.testing.assert_array_equal(a, b)
+    np.testing.assert_allclose(a, ref, rtol=1e-13)
+    assert np.ptp(ref) > 0          # the draws really differ
