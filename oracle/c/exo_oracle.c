@@ -319,6 +319,68 @@ void oracle_transit(const double* t, int64_t n_cad, const double* texp, int64_t 
   }
 }
 
+/* The same with transit-timing tables (reference: orbits/ttv.py:158-187): every time -- cadence
+ * or sub-exposure -- of planet p acts as t - shift[bin(t)], bin(t) = #{edges < t} (searchsorted,
+ * left); the caller's windows are tested on the warped mid-exposure time.  edges [n_draw][n_planet]
+ * [n_edge] (ascending, +inf padded), shift [..][n_edge + 1]; gshift (with gflux) receives the
+ * cotangent of shift: the t_periastron term of each sample, by bin.                            */
+static int ttv_bin(const double* edges, int n_edge, double t) {
+  int lo = 0, hi = n_edge;             /* first index with edges[i] >= t */
+  while (lo < hi) {
+    int mid = (lo + hi) / 2;
+    if (edges[mid] < t) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+
+void oracle_transit_ttv(const double* t, int64_t n_cad, const double* texp, int64_t n_texp, const double* sdt,
+                        const double* sw, int32_t n_sub, const double* params, const double* ld, int64_t n_draw,
+                        int32_t n_planet, uint32_t flags, const double* edges, const double* shift, int32_t n_edge,
+                        const double* gflux, double* flux, double* gparams, double* gld, double* gshift) {
+  int secondary = (flags & FLAG_SECONDARY) != 0, per_planet = (flags & FLAG_PER_PLANET) != 0;
+  int window = (flags & FLAG_WINDOW) != 0;
+  int nld = secondary ? 6 : 3;
+  double one = 1.0, zero = 0.0;
+  if (n_texp == 0) { sdt = &zero; sw = &one; n_sub = 1; }
+  if (gflux) {
+    memset(gparams, 0, sizeof(double) * n_draw * n_planet * NPAR);
+    memset(gld, 0, sizeof(double) * n_draw * nld);
+    memset(gshift, 0, sizeof(double) * n_draw * n_planet * (n_edge + 1));
+  }
+  for (int64_t d = 0; d < n_draw; ++d) {
+    const double* c = ld + d * nld;
+    for (int64_t i = 0; i < n_cad; ++i) {
+      double te = n_texp == 0 ? 0.0 : (n_texp == 1 ? texp[0] : texp[i]);
+      double fsum = 0.0;
+      for (int p = 0; p < n_planet; ++p) {
+        const double* rec = params + (d * n_planet + p) * NPAR;
+        const double* ed = edges + (d * n_planet + p) * (int64_t)n_edge;
+        const double* sh = shift + (d * n_planet + p) * (int64_t)(n_edge + 1);
+        double f = 0.0;
+        if (!window || in_window(t[i] - sh[ttv_bin(ed, n_edge, t[i])], rec, 0.5 * te, secondary)) {
+          double g0 = 0.0;
+          if (gflux) g0 = per_planet ? gflux[(d * n_cad + i) * n_planet + p] : gflux[d * n_cad + i];
+          for (int k = 0; k < n_sub; ++k) {
+            double tt = t[i] + te * sdt[k];
+            int b = ttv_bin(ed, n_edge, tt);
+            double gtmp[NPAR] = {0};
+            f += sw[k] * sample(tt - sh[b], rec, c, secondary, g0 * sw[k], gflux ? gtmp : NULL,
+                                gflux ? gld + d * nld : NULL);
+            if (gflux) {
+              double* gp = gparams + (d * n_planet + p) * NPAR;
+              for (int q = 0; q < NPAR; ++q) gp[q] += gtmp[q];
+              gshift[(d * n_planet + p) * (int64_t)(n_edge + 1) + b] += gtmp[P_TP];
+            }
+          }
+        }
+        if (per_planet) { if (flux) flux[(d * n_cad + i) * n_planet + p] = f; }
+        else fsum += f;
+      }
+      if (!per_planet && flux) flux[d * n_cad + i] = fsum;
+    }
+  }
+}
+
 /* ------------------------------------------------------------------ celerite
  * log-likelihood and its reverse recurrence for ONE draw (SURVEY Appendix B;
  * adjoint derived as in numpy_port.py / DESIGN.md 3.4).  J <= 8.

@@ -71,6 +71,37 @@ def transit(t, params, ld, gflux=None, texp=None, stencil_dt=None, stencil_w=Non
     return flux, gp, gl
 
 
+def transit_ttv(t, params, ld, ttv, gflux=None, texp=None, stencil_dt=None, stencil_w=None, per_planet=False,
+                window=False, secondary=False):
+    """transit() with timing tables ttv = (edges [D,P,E], shift [D,P,E+1]) (ttv.py:158-187)
+    -> flux, gparams, gld, gshift (the last three None without gflux)."""
+    t = _c(t); params = _c(params); ld = _c(ld)
+    edges, shift = _c(ttv[0]), _c(ttv[1])
+    D, P, _ = params.shape
+    N = t.size
+    E = edges.shape[-1]
+    assert edges.shape == (D, P, E) and shift.shape == (D, P, E + 1)
+    flags = (1 if per_planet else 0) | (2 if window else 0) | (4 if secondary else 0)
+    if texp is None:
+        tex = sdt = sw = None; n_texp = 0; n_sub = 1
+    else:
+        tex = _c(np.atleast_1d(texp)); sdt = _c(stencil_dt); sw = _c(stencil_w)
+        n_texp = tex.size; n_sub = sdt.size
+    shape = (D, N, P) if per_planet else (D, N)
+    flux = np.empty(shape)
+    if gflux is not None:
+        gflux = _c(gflux)
+        assert gflux.shape == shape
+        gp = np.empty_like(params); gl = np.empty_like(ld); gs = np.empty_like(shift)
+    else:
+        gp = gl = gs = None
+    lib().oracle_transit_ttv(_p(t), ctypes.c_int64(N), _p(tex), ctypes.c_int64(n_texp), _p(sdt), _p(sw),
+                             ctypes.c_int32(n_sub), _p(params), _p(ld), ctypes.c_int64(D), ctypes.c_int32(P),
+                             ctypes.c_uint32(flags), _p(edges), _p(shift), ctypes.c_int32(E), _p(gflux), _p(flux),
+                             _p(gp), _p(gl), _p(gs))
+    return flux, gp, gl, gs
+
+
 def celerite(t, y, diag, coeffs, grad=False):
     """log-likelihood of one draw (and, with grad, d/d(y, diag, ar, cr, ac, bc, cc, dc))."""
     ar, cr, ac, bc, cc, dc = [_c(x) for x in coeffs]

@@ -182,3 +182,40 @@ def test_c2_full_size_with_timing_variations(dev):
         assert torch.allclose(gps, gp[lo:hi], rtol=1e-11, atol=1e-13 * float(gp.abs().max()))
         assert torch.allclose(gls, gl[lo:hi], rtol=1e-11)
         assert torch.allclose(gss, gs[lo:hi], rtol=1e-11, atol=1e-13 * float(gs.abs().max()))
+
+
+def test_c4_full_size_with_timing_variations(dev):
+    """C4 shape (4 planets, 200 000 cadences) with per-draw timing tables and a 7-point exposure
+    stencil, directly against the C port (which has the tables too: oracle/c oracle_transit_ttv,
+    pinned to the numpy restatement in tests/test_oracle_ttv.py)"""
+    from exoplanet_amd import ops
+
+    rng = np.random.default_rng(9)
+    t = np.arange(200_000) * (2.0 / 1440.0)
+    periods, t0s = np.array([3.5, 7.9, 13.1, 29.7]), np.array([1.0, 2.3, 5.1, 11.7])
+    D = 2
+    recs, edges, shifts = [], [], []
+    for d in range(D):
+        ttvs = [0.01 * rng.normal(size=int((t[-1] - a) / p) + 1) for p, a in zip(periods, t0s)]
+        orbit = P.TTVOrbit(period=periods, t0=t0s, b=np.array([0.3, 0.1, 0.5, 0.2]), ecc=np.array([0.05, 0.1, 0.2, 0.3]),
+                           omega=np.array([1.1, -0.4, 2.0, 0.3]), ttvs=ttvs)
+        recs.append(make_record(orbit, np.array([0.1, 0.05, 0.07, 0.03]))[0])
+        e, s = orbit.kernel_tables()
+        edges.append(e)
+        shifts.append(s)
+    rec, edges, shifts = np.stack(recs), np.stack(edges), np.stack(shifts)
+    c = np.repeat(P.get_cl(0.3, 0.2)[None], D, 0)
+    g = rng.normal(size=(D, t.size))
+    sdt, sw = P.exposure_stencil(7, 0)
+    texp = 0.02
+    want_f, want_gp, want_gl, want_gs = C.transit_ttv(t, rec, c, (edges, shifts), g, texp=texp, stencil_dt=sdt,
+                                                       stencil_w=sw)
+    f, gp, gl, gs = ops.transit_flux_value_and_vjp(T(t, dev), T(rec, dev), T(c, dev), T(g, dev),
+                                                   texp=T(np.array([texp]), dev), stencil_dt=T(sdt, dev),
+                                                   stencil_w=T(sw, dev), ttv=(T(edges, dev), T(shifts, dev)))
+    assert (want_f < -1e-3).sum() > 5000
+    assert np.abs(f.cpu().numpy() - want_f).max() < 1e-12
+    sl = list(P.GRAD_SLOTS[:-1])
+    assert np.abs(gp.cpu().numpy()[..., sl] - want_gp[..., sl]).max() <= 1e-9 * np.abs(want_gp[..., sl]).max()
+    np.testing.assert_allclose(gl.cpu().numpy(), want_gl, rtol=1e-9)
+    assert np.abs(gs.cpu().numpy() - want_gs).max() <= 1e-9 * np.abs(want_gs).max()

@@ -190,3 +190,26 @@ def test_transit_inds_from_host_or_device_tensor():
         got = TTVOrbit(transit_inds=inds, **kw).kernel_ttv()
         assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
     assert want[0].shape[-1] == 7            # six transits (three of them filled in): seven edges
+
+
+@pytest.mark.parametrize("window,secondary", [(False, False), (True, False), (False, True)])
+def test_c_port_with_timing_tables_equals_numpy(window, secondary):
+    """oracle/c (the fast checker for full-size GPU tests) == oracle/numpy_port on timing tables"""
+    from oracle import c_port as C
+    from test_gpu_transit import make_record
+
+    orbit = P.TTVOrbit(**ttv_case())
+    r = np.array([0.08, 0.05])
+    rec = make_record(orbit, r, sbr=0.4 if secondary else None, window=window)
+    edges, shift = (x[None] for x in orbit.kernel_tables())
+    c = np.concatenate([P.get_cl(0.3, 0.2), P.get_cl(0.1, 0.4)])[None] if secondary else P.get_cl(0.3, 0.2)[None]
+    t = np.linspace(0.0, 80.0, 3000)
+    sdt, sw = P.exposure_stencil(7, 2)
+    kw = dict(texp=0.08, stencil_dt=sdt, stencil_w=sw, window=window, secondary=secondary)
+    g = np.random.default_rng(0).normal(size=(1, t.size))
+    want = P.transit_flux_vjp(t, rec, c, g, ttv=(edges, shift), **kw)
+    got = C.transit_ttv(t, rec, c, (edges, shift), g, **kw)
+    assert want[0].min() < -3e-3
+    np.testing.assert_allclose(got[0], want[0], rtol=0, atol=1e-13)
+    for a, b in zip(got[1:], want[1:]):
+        np.testing.assert_allclose(a, b, rtol=1e-9, atol=1e-10 * np.abs(b).max())
