@@ -310,9 +310,36 @@ def main():
                           "over time), value + gradient, eager launches"}
         except Exception as exc:  # an extra leg must not take the headline measurement down with it
             c3 = {"error": repr(exc)[:200]}
+        # the same C2 step with transit-timing variations -- 60 labelled transits, every
+        # draw its own offsets (gradient to each of them) -- user-level TTVOrbit, replayed as a hipGraph
+        ttv = None
+        try:
+            n_tr = int((float(t[-1]) - 1.0) / 3.5) + 1
+            offs = torch.tensor(0.01 * np.random.default_rng(7).normal(size=(D, n_tr)), dtype=torch.float64,
+                                device=dev, requires_grad=True)
+            tnames = list(leaves) + ["ttvs"]
+
+            def ttv_step(*vals):
+                Lv = dict(zip(tnames, vals))
+                orb = xo.orbits.TTVOrbit(period=Lv["period"], t0=Lv["t0"], b=Lv["b"], ecc=Lv["ecc"], omega=Lv["omega"],
+                                         ttvs=[Lv["ttvs"]])
+                rec_t, ld_t, _, fl = orb.kernel_inputs(Lv["r"], (Lv["u1"], Lv["u2"]))
+                ed, sh = orb.kernel_ttv()
+                _, dot = ops.transit_flux_dot(t, rec_t, ld_t, gbar, flags=fl, ttv=(ed.contiguous(), sh.contiguous()))
+                return (dot.detach(),) + torch.autograd.grad(dot.sum(), vals)
+
+            tg = xo.GraphedStep(ttv_step, *leaves.values(), offs)
+            wall_ttv = time_steps(lambda i: tg(), ex_steps, 2, dist, dev)
+            ttv = {"evals_per_s": world * D * ex_steps / wall_ttv, "ms_per_step": 1e3 * wall_ttv / ex_steps,
+                   "transits": n_tr,
+                   "note": "C2 step with a TTVOrbit (timing tables in the fused kernels, gradients to every "
+                           "per-transit offset), hipGraph replay"}
+        except Exception as exc:
+            ttv = {"error": repr(exc)[:200]}
         if rank == 0:
             out["extras"] = {
                 "c3_light_curve_plus_sho_gp": c3,
+                "c2_with_transit_timing_variations": ttv,
                 "in_transit_only": {"evals_per_s": world * D * ex_steps / wall2, "kernel_ms": k2,
                                     "alg_GBps": ALG_BYTES_PER_UNIT * D * N_CAD / (k2 * 1e-3) / 1e9,
                                     "note": "reference default use_in_transit=True (contact-point windows); this "
