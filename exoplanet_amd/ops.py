@@ -8,8 +8,10 @@ Drop-in for the three callables the reference imports from exoplanet_core
     ops.contact_points(a, e, cosw, sinw, cosi, sini, L)
         -> (M_left, M_right, flag)                     keplerian.py:744-753
 
-plus the fused op that replaces the whole elementwise graph between the time
-array and the flux array (``transit_flux``).  All take float64 ROCm tensors and
+plus the fused ops that replace whole sub-graphs: ``transit_flux`` (everything between
+the time array and the flux array; ``ttv=`` for a TTVOrbit's timing tables),
+``transit_flux_dot`` / ``transit_flux_value_and_vjp`` (value and gradient in one sweep),
+``pack_records`` (the constructor algebra) and ``radial_velocity``.  All take float64 ROCm tensors and
 run hand-written HIP kernels through the C ABI (include/exoplanet_amd.h); each
 has value + gradient (torch.autograd).  There is no CPU / eager fallback.
 """
