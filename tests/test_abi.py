@@ -74,6 +74,33 @@ def test_header_layout_constants_match_python(lib):
     assert int(consts["EXO_MAX_SUBEXP"]) == ops.MAX_SUBEXP
 
 
+def test_rv_layout_constants_and_argument_checks(lib):
+    """EXO_RV_* match the Python side; the newer entry points reject bad arguments on the host,
+    before any launch (no GPU needed for that)"""
+    from exoplanet_amd import ops
+
+    text = open(os.path.join(ROOT, "include", "exoplanet_amd.h")).read()
+    consts = dict(re.findall(r"#define\s+(EXO_[A-Z0-9_]+)\s+(\d+)u?\b", text))
+    assert int(consts["EXO_RV_NPAR"]) == ops.RV_NPAR
+    for name in ("N", "TP", "ECC", "COSW", "SINW", "AMP"):
+        assert int(consts[f"EXO_RV_{name}"]) == getattr(ops, f"RV_{name}")
+    INVALID = 1
+    # radial velocity: negative sizes, no planets, missing pointers
+    assert lib.exo_radial_velocity_fwd_f64(None, -1, None, 1, 1, None, None) == INVALID
+    assert lib.exo_radial_velocity_fwd_f64(None, 10, None, 1, 0, None, None) == INVALID
+    assert lib.exo_radial_velocity_fwd_f64(None, 10, None, 1, 1, None, None) == INVALID
+    assert lib.exo_radial_velocity_fwd_f64(None, 0, None, 3, 2, None, None) == 0          # nothing to do
+    assert lib.exo_radial_velocity_vjp_f64(None, 10, None, 1, 1, None, None, None) == INVALID
+    # timing tables: both tables and a positive edge count are required
+    args = [None, 10, None, 0, None, None, 1, None, None, 1, 1, 0]
+    assert lib.exo_transit_flux_ttv_fwd_f64(*args, None, None, 4, None, None, 0, None) == INVALID
+    assert lib.exo_transit_flux_ttv_fwd_f64(*args, 8, 8, 0, None, None, 0, None) == INVALID
+    assert lib.exo_transit_flux_ttv_fwd_f64(*args, 8, 8, int(consts["EXO_MAX_TTV_EDGES"]) + 1, None, None, 0, None) == INVALID
+    assert lib.exo_transit_flux_ttv_vjp_f64(*args, 8, 8, 4, None, None, None, None, None, None, None, 0, None) == INVALID
+    # observed-minus-model likelihood: the observed series is required
+    assert lib.exo_celerite_loglike_obs_fwd_f64(8, None, 8, 8, 1, 100, None, 0, 8, 1, 2, 8, None, 0, None) == INVALID
+
+
 def test_missing_extension_fails_loudly(monkeypatch):
     from exoplanet_amd import _lib
 
