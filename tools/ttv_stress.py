@@ -67,7 +67,9 @@ for case in range(n_cases):
     if use_texp:
         sdt, sw = P.exposure_stencil(int(rng.choice([3, 5, 7])), int(rng.integers(0, 3)))
         te = 10 ** rng.uniform(-2.5, 0.0)      # up to a day: crosses bin edges
-        kw = dict(texp=T([te]), stencil_dt=T(sdt), stencil_w=T(sw))
+        if rng.uniform() < 0.3:                 # one exposure time per cadence
+            te = te * rng.uniform(0.2, 1.0, N)
+        kw = dict(texp=T(np.atleast_1d(te)), stencil_dt=T(sdt), stencil_w=T(sw))
         ckw = dict(texp=te, stencil_dt=sdt, stencil_w=sw)
     flags = (ops.FLAG_SECONDARY if secondary else 0) | (ops.FLAG_PER_PLANET if per_planet else 0) | (ops.FLAG_WINDOW if window else 0)
     f, gp, gl, gs = ops.transit_flux_value_and_vjp(T(t), T(rec), T(c), T(g), flags=flags, ttv=(T(edges), T(shifts)), **kw)
