@@ -7,20 +7,32 @@ prints ONE JSON line.
 
 Workload = BASELINE.json configs[1] ("C2"): single planet, e = 0.3,
 omega = 1.1, P = 3.5 d, t0 = 1, b = 0.3, r = 0.1, (u1, u2) = (0.3, 0.2), 150 000
-two-minute cadences, EVERY cadence evaluated (use_in_transit=False, the
-roofline case), float64, cotangent gbar ~ N(0,1).  One *evaluation* = forward
-flux for all 150 000 cadences of one posterior draw + the VJP of gbar back to
-all orbit / limb-darkening parameters.  One *step* = one pass of the hot path
-over a batch of `--draws-per-gpu` draws (base parameters x (1 + 1e-3 N(0,1))):
-leaf parameters -> record-packing kernel (KeplerianOrbit algebra + get_cl) ->
-scan + heavy kernels (value + VJP in one sweep) -> packing VJP -> leaf gradients; with N > 1 ranks each own
-their draws (weak scaling) and exchange only the per-draw scalar sum(gbar*flux)
-by one all-reduce.  Inputs are resident in HBM before the timed region.
+two-minute cadences, float64, cotangent gbar ~ N(0,1), use_in_transit=False: the
+output is the DENSE flux array [draws][150 000]; every cadence is classified on
+the device, the ~3 % that can overlap the stellar disk are solved (Kepler +
+solution vector + reverse sweep), the rest are written as zeros.  One
+*evaluation* = forward flux for all 150 000 cadences of one posterior draw + the
+VJP of gbar back to all orbit / limb-darkening parameters.  One *step* = one
+pass of the hot path over a batch of `--draws-per-gpu` draws (base parameters x
+(1 + 1e-3 N(0,1))): leaf parameters -> record-packing kernel (KeplerianOrbit
+algebra + get_cl) -> window + scan + heavy + reduce kernels (value + VJP in one
+sweep) -> packing VJP -> leaf gradients, replayed as one hipGraph.  With N > 1
+ranks each own their draws and exchange only the per-draw scalar sum(gbar*flux):
+ONE collective per step (exoplanet_amd.distributed.LoglikeExchange).  Default is
+weak scaling (fixed draws per GPU); `--global-draws G` fixes the total instead
+(BASELINE C4 / C5: 512 / 1024 draws over 8 GPUs) and reports "strong".
+Inputs are resident in HBM before the timed region.
+
+Timing: `value` comes from EXACTLY --steps steps between barrier + synchronize
+on both sides (max over ranks).  Independently of --steps, `timing` reports
+median / p10 / p90 per step over >= 100 steps and >= 2 s.
 """
 import argparse
 import ctypes
 import json
 import os
+import platform
+import subprocess
 import sys
 import time
 
@@ -32,8 +44,9 @@ sys.path.insert(0, ROOT)
 
 N_CAD = 150_000
 CADENCE = 2.0 / 1440.0
-ALG_BYTES_PER_UNIT = 24          # read t 8 + read gbar 8 + write flux 8 per (draw, cadence), SURVEY.md 8d
+SURVEY_BYTES_PER_UNIT = 24       # SURVEY.md 8d count: read t 8 + read gbar 8 + write flux 8 per (draw, cadence)
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+SCAN_DRAW_GROUP = 4              # draws that share one read of t in the scan kernel (exo_transit.hip, kScanDraws)
 
 
 def hip_runtime():
@@ -46,7 +59,8 @@ def hip_runtime():
 
 
 class HipEvents:
-    """K (start, stop) hipEvent pairs recorded by the C ABI around the dominant kernel."""
+    """K (start, stop) hipEvent pairs recorded by the C ABI around the kernels of one sweep,
+    on the stream they are launched on."""
 
     def __init__(self, k):
         self.hip = hip_runtime()
@@ -63,22 +77,53 @@ class HipEvents:
         a, b = self.pairs[i]
         return a.value, b.value
 
-    def mean_ms(self):
+    def times_ms(self):
         out = []
         for a, b in self.pairs:
             ms = ctypes.c_float()
             assert self.hip.hipEventElapsedTime(ctypes.byref(ms), a, b) == 0
             out.append(ms.value)
-        return float(np.mean(out)), out
+        return out
+
+    def mean_ms(self):
+        v = self.times_ms()
+        return float(np.mean(v)), v
+
+
+def quantiles(ms):
+    ms = np.asarray(ms, dtype=np.float64)
+    return {"iters": int(ms.size), "median_ms": float(np.median(ms)), "p10_ms": float(np.percentile(ms, 10)),
+            "p90_ms": float(np.percentile(ms, 90)), "mean_ms": float(ms.mean())}
+
+
+def stats_loop(fn, dev, n_iters, chunk=100):
+    """per-step durations of n_iters back-to-back steps (torch events on the current stream: the
+    steps are launched on it).  The count is fixed up front -- under torch.distributed every rank
+    must issue the same number of collectives."""
+    ms = []
+    stream = torch.cuda.current_stream(dev)
+    while len(ms) < n_iters:
+        k = min(chunk, n_iters - len(ms))
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(k + 1)]
+        evs[0].record(stream)
+        for i in range(k):
+            fn(-1)
+            evs[i + 1].record(stream)
+        torch.cuda.synchronize(dev)
+        ms.extend(evs[i].elapsed_time(evs[i + 1]) for i in range(k))
+    return quantiles(ms)
 
 
 def measured_traffic(n_draw):
-    """HBM bytes per sweep (scan + heavy kernels) from the committed PMC passes
-    (profiles/r01_pmc.json), scaled to this run's draw count; None if absent."""
+    """HBM bytes per sweep from this round's committed PMC passes (profiles/r02_pmc.json: rocprofv3
+    --pmc FETCH_SIZE / WRITE_SIZE in separate runs, FETCH doubled per the gfx950 note), scaled to
+    this run's draw count.  A cross-reference, not a live measurement: None if the file is absent
+    or was taken on another kernel generation."""
     try:
-        p = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc.json")))
+        p = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc.json")))
         tot = sum(2.0 * k["fetch_kib"] + k["write_kib"] for k in p["kernels"].values())
-        return tot * 1024.0 * n_draw / p["draws"]
+        return {"bytes": tot * 1024.0 * n_draw / p["draws"], "source": "profiles/r02_pmc.json",
+                "draws_profiled": p["draws"]}
     except Exception:
         return None
 
@@ -108,6 +153,12 @@ def step(xo, ops, leaves, t, gbar, events=(None, None), use_in_transit=False):
     return flux, L, grads
 
 
+def exchange_step(exchange, L_local):
+    """the multi-GPU part of a step: one collective, every rank ends up with all per-draw scalars.
+    (tests/test_distributed.py drives this function on CPU under gloo, world size 2.)"""
+    return exchange(L_local)
+
+
 def time_steps(fn, steps, warmup, dist, dev):
     for _ in range(warmup):
         fn(-1)
@@ -123,30 +174,271 @@ def time_steps(fn, steps, warmup, dist, dev):
     return time.perf_counter() - t0
 
 
-def cpu_baseline(seconds_target=12.0):
-    """The oracle's C port (scalar, 1 core) on a bounded sample of the same workload."""
+# ------------------------------------------------------------------------------------------
+# CPU baseline (rank 0, N = 1 only): the oracle's C port -- the thing being CHECKED AGAINST
+# elsewhere, timed here beside the GPU number; never part of `value`.
+# ------------------------------------------------------------------------------------------
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return platform.processor() or "unknown"
+
+
+def cpu_baseline(budget_s=24.0):
+    """oracle/c on the host cores of this box, on a bounded sample of the C2 workload:
+    (i) 1 core, every cadence evaluated (what the reference does with use_in_transit=False);
+    (ii) 1 core, in-transit cadences only (the reference's default use_in_transit=True);
+    (iii) all cores, one draw per thread (PyMC's one process per chain on every core), every cadence;
+    (iv) all cores, in-transit only."""
     from oracle import c_port as C
     from oracle import numpy_port as P
 
+    # the library travels prebuilt; rebuild it for THIS host's cores (-march=native) when a compiler is here
+    try:
+        subprocess.run(["make", "-s", "-B", "-C", os.path.join(ROOT, "oracle", "c")], check=True, timeout=120,
+                       stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    except Exception:
+        pass
+    lib = C.lib()
+    n_threads = int(os.environ.get("EXO_BENCH_CPU_THREADS", os.cpu_count() or 1))
     rng = np.random.default_rng(2)
     t = np.arange(N_CAD) * CADENCE
     orbit = P.KeplerianOrbit(period=3.5, t0=1.0, b=0.3, ecc=0.3, omega=1.1)
-    rec = np.zeros((1, 1, P.NPAR))
-    rec[0, 0, [P.P_N, P.P_TP, P.P_ECC, P.P_COSW, P.P_SINW, P.P_COSI, P.P_SINI, P.P_AOR, P.P_ROR]] = [
-        orbit.n[0], orbit.t_periastron[0], 0.3, np.cos(1.1), np.sin(1.1), orbit.cos_incl[0], orbit.sin_incl[0],
-        orbit.a[0], 0.1]
-    rec[0, 0, [P.P_T0, P.P_PERIOD, P.P_TS, P.P_TE, P.P_TS2, P.P_TE2]] = [1.0, 3.5, -np.inf, np.inf, -np.inf, np.inf]
-    c = P.get_cl(0.3, 0.2)[None]
-    g = rng.normal(size=(1, N_CAD))
-    C.transit(t, rec, c, g)  # warm
-    n, t0 = 0, time.perf_counter()
-    while time.perf_counter() - t0 < seconds_target:
-        C.transit(t, rec, c, g)
-        n += 1
-    dt = time.perf_counter() - t0
-    return {"value": n / dt, "unit": "evals/s", "cores": 1, "kind": "port",
-            "sample": f"{n} evaluations (value+VJP, every cadence) of the {N_CAD}-cadence C2 system, "
-                      f"oracle/c scalar port, {dt:.1f} s on 1 of {os.cpu_count()} host cores"}
+
+    def records(n_draw, window):
+        ts, te = (-np.inf, np.inf)
+        rec = np.zeros((n_draw, 1, P.NPAR))
+        rec[:, 0, [P.P_N, P.P_TP, P.P_ECC, P.P_COSW, P.P_SINW, P.P_COSI, P.P_SINI, P.P_AOR, P.P_ROR]] = [
+            orbit.n[0], orbit.t_periastron[0], 0.3, np.cos(1.1), np.sin(1.1), orbit.cos_incl[0], orbit.sin_incl[0],
+            orbit.a[0], 0.1]
+        if window:   # first / fourth contact relative to t0 (keplerian.py:744-763)
+            Ml, Mr, flag = P.contact_points(orbit.a, orbit.ecc, orbit.cos_omega, orbit.sin_omega, orbit.cos_incl,
+                                            orbit.sin_incl, orbit.r_star + 0.1)
+            assert np.all(flag == 0)
+            hp = 0.5 * orbit.period
+            ts = float(np.ravel(np.mod((Ml - orbit.M0) / orbit.n + hp, orbit.period) - hp)[0])
+            te = float(np.ravel(np.mod((Mr - orbit.M0) / orbit.n + hp, orbit.period) - hp)[0])
+            ts = ts - 3.5 if ts > 0 else ts
+            te = te + 3.5 if te < 0 else te
+        rec[:, 0, [P.P_T0, P.P_PERIOD, P.P_TS, P.P_TE, P.P_TS2, P.P_TE2]] = [1.0, 3.5, ts, te, -np.inf, np.inf]
+        rec[:, 0, P.P_ROR] *= 1 + 1e-3 * rng.normal(size=n_draw)
+        return rec
+
+    def leg(n_draw, threads, window, seconds):
+        lib.oracle_set_threads(int(threads))
+        rec = records(n_draw, window)
+        c = np.repeat(P.get_cl(0.3, 0.2)[None], n_draw, 0)
+        g = rng.normal(size=(n_draw, N_CAD))
+        C.transit(t, rec, c, g, window=window)  # warm
+        n, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < seconds:
+            C.transit(t, rec, c, g, window=window)
+            n += n_draw
+        dt = time.perf_counter() - t0
+        return {"evals_per_s": n / dt, "evals": n, "seconds": dt, "threads": int(threads),
+                "semantics": "in-transit cadences only (use_in_transit=True)" if window else
+                             "every cadence solved (use_in_transit=False)"}
+
+    share = budget_s / 4.0
+    legs = {"one_core_every_cadence": leg(1, 1, False, share)}
+    try:
+        legs["one_core_in_transit"] = leg(1, 1, True, share)
+    except Exception as exc:      # window helper missing in the oracle: report, do not die
+        legs["one_core_in_transit"] = {"error": repr(exc)[:160]}
+    legs["all_cores_every_cadence"] = leg(n_threads, n_threads, False, share)
+    try:
+        legs["all_cores_in_transit"] = leg(4 * n_threads, n_threads, True, share)
+    except Exception as exc:
+        legs["all_cores_in_transit"] = {"error": repr(exc)[:160]}
+    lib.oracle_set_threads(1)
+    one = legs["one_core_every_cadence"]
+    return {"value": one["evals_per_s"], "unit": "evals/s", "cores": 1, "kind": "port",
+            "sample": f"{one['evals']} evaluations (value+VJP, every cadence solved) of the {N_CAD}-cadence C2 "
+                      f"system, oracle/c scalar port, {one['seconds']:.1f} s on 1 of {os.cpu_count()} host cores; "
+                      "legs: the same on all cores (OpenMP, one draw per thread) and with the reference's "
+                      "default in-transit selection",
+            "cpu_model": cpu_model(), "host_cores": os.cpu_count(), "legs": legs,
+            "note": "the reference's own Ops (exoplanet_core, celerite2) are not installable here: kind = port"}
+
+
+# ------------------------------------------------------------------------------------------
+# extras (single GPU diagnostics; never `value`)
+# ------------------------------------------------------------------------------------------
+def time_events(fn, dev, iters, warmup=2):
+    """mean / quantiles of `fn` per call, torch events on the current stream"""
+    for _ in range(warmup):
+        fn()
+    stream = torch.cuda.current_stream(dev)
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(iters + 1)]
+    evs[0].record(stream)
+    for i in range(iters):
+        fn()
+        evs[i + 1].record(stream)
+    torch.cuda.synchronize(dev)
+    return quantiles([evs[i].elapsed_time(evs[i + 1]) for i in range(iters)])
+
+
+def extra_ops(ops, dev, n=150_000_000):
+    """the reference's standalone Ops at n = 1.5e8 elements: GB/s against
+    their algorithmic bytes -- kepler 2 in + 2 out = 32 B/elt; quad_solution_vector 2 in + 3 out =
+    40 B/elt (value) or 2 in + 9 out = 88 B/elt (with ds/db, ds/dr)"""
+    out = {}
+    g = torch.Generator(device=dev).manual_seed(11)
+    M = (torch.rand(n, dtype=torch.float64, device=dev, generator=g) - 0.5) * 800.0
+    e = torch.rand(n, dtype=torch.float64, device=dev, generator=g) * 0.9
+    with torch.no_grad():
+        q = time_events(lambda: ops.kepler(M, e), dev, 10)
+    out["kepler"] = {"n": n, **q, "bytes_per_elt": 32, "GBps": 32.0 * n / (q["median_ms"] * 1e-3) / 1e9,
+                     "frac_of_hbm_peak": 32.0 * n / (q["median_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS}
+    del M, e
+    b = torch.rand(n, dtype=torch.float64, device=dev, generator=g) * 1.3
+    r = torch.full((n,), 0.1, dtype=torch.float64, device=dev)
+    with torch.no_grad():
+        q = time_events(lambda: ops.quad_solution_vector(b, r), dev, 6)
+        out["quad_solution_vector_value"] = {"n": n, **q, "bytes_per_elt": 40,
+                                             "GBps": 40.0 * n / (q["median_ms"] * 1e-3) / 1e9,
+                                             "frac_of_hbm_peak": 40.0 * n / (q["median_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        q = time_events(lambda: ops.quad_solution_vector_derivs(b, r), dev, 6)
+        out["quad_solution_vector_with_derivs"] = {"n": n, **q, "bytes_per_elt": 88,
+                                                   "GBps": 88.0 * n / (q["median_ms"] * 1e-3) / 1e9,
+                                                   "frac_of_hbm_peak": 88.0 * n / (q["median_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS}
+    out["note"] = ("b uniform in [0, 1.3], r = 0.1: 85 % of the elements overlap the disk and evaluate the elliptic "
+                   "integrals -- the op is fp64-VALU-bound there, not HBM-bound (SURVEY.md 8d caveat)")
+    return out
+
+
+def graphed(xo, fn, inputs, dev, iters):
+    """time `fn(*inputs)` replayed as one hipGraph; eager launches if the capture fails"""
+    try:
+        g = xo.GraphedStep(fn, *inputs)
+        q = time_events(lambda: g(), dev, iters)
+        return q, "hipGraph replay"
+    except Exception as exc:
+        torch.cuda.synchronize(dev)
+        q = time_events(lambda: fn(*inputs), dev, max(3, iters // 4))
+        return q, f"eager launches (capture failed: {repr(exc)[:120]})"
+
+
+def extra_c3(xo, leaves, t, dev, D):
+    """BASELINE configs[2] (C3): the C2 light curve + a celerite SHO-term GP log-likelihood on the
+    residual; value + gradient w.r.t. the orbit / limb-darkening leaves and the kernel hyper-parameters"""
+    yobs = 5e-4 * torch.randn(N_CAD, dtype=torch.float64, device=dev)
+    names = list(leaves)
+    hyper = [torch.full((D,), v, dtype=torch.float64, device=dev, requires_grad=True) for v in (1e-3, 5.0, 0.7071)]
+
+    def one(*vals):
+        Lv = dict(zip(names, vals[:len(names)]))
+        sigma, rho, Q = vals[len(names):]
+        orbit = xo.KeplerianOrbit(period=Lv["period"], t0=Lv["t0"], b=Lv["b"], ecc=Lv["ecc"], omega=Lv["omega"])
+        lc = xo.LimbDarkLightCurve(Lv["u1"], Lv["u2"]).get_light_curve(orbit=orbit, r=Lv["r"], t=t)
+        gp = xo.gp.GaussianProcess(xo.gp.terms.SHOTerm(sigma=sigma, rho=rho, Q=Q), t=t, yerr=5e-4, mean=lc.sum(-1))
+        ll = gp.log_likelihood(yobs)
+        return (ll.detach(),) + torch.autograd.grad(ll.sum(), vals)
+
+    q, how = graphed(xo, one, list(leaves.values()) + hyper, dev, 12)
+    J = 2
+    bpu = 48 + 16 * (1 + J + J * J)
+    gbps = bpu * D * N_CAD / (q["median_ms"] * 1e-3) / 1e9
+    return {"evals_per_s": D / (q["median_ms"] * 1e-3), **q, "draws": D, "launch": how,
+            "survey_8d_bytes_per_unit": bpu, "survey_8d_GBps": gbps, "survey_8d_frac_of_hbm_peak": gbps / HBM_PEAK_GBS,
+            "note": "C3: C2 light curve + SHO-term celerite GP on the residual (recurrences in parallel over "
+                    "time), value + gradient of every leaf incl. (sigma, rho, Q) per draw"}
+
+
+def extra_c4(xo, dev, D=64):
+    """BASELINE configs[3] (C4) at its per-GPU size: 4 planets, 200 000 cadences, 64 draws"""
+    rng = np.random.default_rng(4)
+    n = 200_000
+    t = torch.arange(n, dtype=torch.float64, device=dev) * CADENCE
+    base = dict(period=[3.5, 7.9, 13.1, 29.7], t0=[1.0, 2.3, 5.1, 11.7], b=[0.3, 0.1, 0.5, 0.2],
+                ecc=[0.05, 0.1, 0.2, 0.3], omega=[1.1, -0.4, 2.0, 0.3], r=[0.1, 0.05, 0.07, 0.03])
+    leaves = {}
+    for k, v in base.items():
+        x = np.asarray(v)[None, :] * (1 + 1e-3 * rng.normal(size=(D, 4)))
+        if k == "ecc":
+            x = np.clip(x, 0.0, 0.95)
+        leaves[k] = torch.tensor(x, dtype=torch.float64, device=dev, requires_grad=True)
+    leaves["u1"] = torch.full((D,), 0.3, dtype=torch.float64, device=dev, requires_grad=True)
+    leaves["u2"] = torch.full((D,), 0.2, dtype=torch.float64, device=dev, requires_grad=True)
+    gbar = torch.randn(D, n, dtype=torch.float64, device=dev)
+    names = list(leaves)
+    from exoplanet_amd import ops
+
+    def one(*vals):
+        Lv = dict(zip(names, vals))
+        orbit = xo.KeplerianOrbit(period=Lv["period"], t0=Lv["t0"], b=Lv["b"], ecc=Lv["ecc"], omega=Lv["omega"])
+        rec, ld, _, flags = orbit.kernel_inputs(Lv["r"], (Lv["u1"], Lv["u2"]), use_in_transit=False)
+        flux, L = ops.transit_flux_dot(t, rec, ld, gbar, flags=flags)
+        return (L.detach(),) + torch.autograd.grad(L.sum(), vals)
+
+    q, how = graphed(xo, one, list(leaves.values()), dev, 40)
+    gbps = SURVEY_BYTES_PER_UNIT * D * n / (q["median_ms"] * 1e-3) / 1e9
+    return {"evals_per_s": D / (q["median_ms"] * 1e-3), **q, "draws": D, "n_cadences": n, "n_planets": 4,
+            "launch": how, "survey_8d_GBps": gbps, "survey_8d_frac_of_hbm_peak": gbps / HBM_PEAK_GBS,
+            "note": "C4 at the per-GPU size of its 8-GPU statement (512 draws / 8): dense summed flux, value + "
+                    "gradient of all 4 x 6 + 2 leaves per draw"}
+
+
+def extra_c5(xo, dev, D=128):
+    """BASELINE configs[4] (C5) at its per-GPU size: 65 000 long cadences, exposure stencil x 7,
+    secondary eclipse, three SHO terms (J = 6), 128 chains"""
+    rng = np.random.default_rng(5)
+    n = 65_000
+    texp = 29.4 / 1440.0
+    t = torch.arange(n, dtype=torch.float64, device=dev) * texp
+    mk = lambda v: torch.tensor(v * (1 + 1e-3 * rng.normal(size=(D, 1))), dtype=torch.float64, device=dev,  # noqa: E731
+                                requires_grad=True)
+    leaves = {k: mk(v) for k, v in dict(period=2.7, t0=0.4, b=0.2, ecc=0.1, omega=0.7, r=0.08).items()}
+    vec = lambda v: torch.full((D,), v, dtype=torch.float64, device=dev, requires_grad=True)  # noqa: E731
+    leaves.update(sbr=vec(0.3), s1=vec(4e-4), s2=vec(3e-4), s3=vec(2e-4))
+    yobs = 3e-4 * torch.randn(n, dtype=torch.float64, device=dev)
+    ones = torch.ones(D, dtype=torch.float64, device=dev)
+    names = list(leaves)
+    T = xo.gp.terms
+
+    def one(*vals):
+        Lv = dict(zip(names, vals))
+        orbit = xo.KeplerianOrbit(period=Lv["period"], t0=Lv["t0"], b=Lv["b"], ecc=Lv["ecc"], omega=Lv["omega"])
+        lc = xo.SecondaryEclipseLightCurve((0.3, 0.2), (0.4, 0.1), Lv["sbr"]).get_light_curve(
+            orbit=orbit, r=Lv["r"], t=t, texp=texp, oversample=7)
+        kern = (T.SHOTerm(sigma=Lv["s1"], rho=20.0 * ones, Q=2.0 * ones) + T.SHOTerm(sigma=Lv["s2"], rho=10.0 * ones, Q=ones)
+                + T.SHOTerm(sigma=Lv["s3"], rho=2.0 * ones, Q=0.7071 * ones))
+        gp = xo.gp.GaussianProcess(kern, t=t, yerr=3e-4, mean=lc.sum(-1))
+        ll = gp.log_likelihood(yobs)
+        return (ll.detach(),) + torch.autograd.grad(ll.sum(), vals)
+
+    q, how = graphed(xo, one, list(leaves.values()), dev, 12)
+    J = 6
+    bpu = 48 + 16 * (1 + J + J * J)
+    gbps = bpu * D * n / (q["median_ms"] * 1e-3) / 1e9
+    return {"evals_per_s": D / (q["median_ms"] * 1e-3), **q, "draws": D, "n_cadences": n, "launch": how,
+            "survey_8d_bytes_per_unit": bpu, "survey_8d_GBps": gbps, "survey_8d_frac_of_hbm_peak": gbps / HBM_PEAK_GBS,
+            "note": "C5 at the per-GPU size of its 8-GPU statement (1024 chains / 8): secondary-eclipse light "
+                    "curve (7 sub-exposures) + 3-term GP, value + gradient"}
+
+
+def extra_ttv(xo, ops, leaves, t, gbar, dev, D):
+    n_tr = int((float(t[-1]) - 1.0) / 3.5) + 1
+    offs = torch.tensor(0.01 * np.random.default_rng(7).normal(size=(D, n_tr)), dtype=torch.float64, device=dev,
+                        requires_grad=True)
+    tnames = list(leaves) + ["ttvs"]
+
+    def ttv_step(*vals):
+        Lv = dict(zip(tnames, vals))
+        orb = xo.orbits.TTVOrbit(period=Lv["period"], t0=Lv["t0"], b=Lv["b"], ecc=Lv["ecc"], omega=Lv["omega"],
+                                 ttvs=[Lv["ttvs"]])
+        rec_t, ld_t, _, fl = orb.kernel_inputs(Lv["r"], (Lv["u1"], Lv["u2"]))
+        ed, sh = orb.kernel_ttv()
+        _, dot = ops.transit_flux_dot(t, rec_t, ld_t, gbar, flags=fl, ttv=(ed.contiguous(), sh.contiguous()))
+        return (dot.detach(),) + torch.autograd.grad(dot.sum(), vals)
+
+    q, how = graphed(xo, ttv_step, list(leaves.values()) + [offs], dev, 30)
+    return {"evals_per_s": D / (q["median_ms"] * 1e-3), **q, "transits": n_tr, "launch": how,
+            "note": "C2 step with a TTVOrbit (timing tables in the fused kernels, gradients to every per-transit offset)"}
 
 
 def main():
@@ -155,9 +447,12 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--draws-per-gpu", type=int, default=1024)
+    ap.add_argument("--global-draws", type=int, default=0,
+                    help="fix the TOTAL number of draws (strong scaling: BASELINE C4 = 512, C5 = 1024 over 8 GPUs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch the step eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-extras", action="store_true")
+    ap.add_argument("--no-stats", action="store_true", help="skip the >= 100 steps / >= 2 s median / p10 / p90 loop")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -173,32 +468,39 @@ def main():
         import torch.distributed as dist_mod
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist_mod.init_process_group("nccl", device_id=dev)
         dist = dist_mod
 
     import exoplanet_amd as xo
     from exoplanet_amd import ops, _lib
+    from exoplanet_amd.distributed import LoglikeExchange, shard_bounds
 
     _lib.load()  # fail loudly if the HIP library is missing
-    D = args.draws_per_gpu
+    if args.global_draws:
+        lo, hi = shard_bounds(args.global_draws, rank, world)
+        D, n_global, scaling = hi - lo, args.global_draws, "strong"
+    else:
+        D, n_global, scaling = args.draws_per_gpu, world * args.draws_per_gpu, "weak"
     t = torch.arange(N_CAD, dtype=torch.float64, device=dev) * CADENCE
     gbar = torch.as_tensor(np.random.default_rng(2 + rank).normal(size=(D, N_CAD)), device=dev)
     leaves = make_leaves(D, 100 + rank, dev)
-    L_all = torch.zeros(world * D, dtype=torch.float64, device=dev)
-    events = HipEvents(args.steps)
+    exchange = LoglikeExchange(n_global, dev) if dist is not None else None
+    events = HipEvents(max(args.steps, 20))
 
-    def one(i, use_in_transit=False, ev=True):
+    def one(i, ev=True):
         evs = events.handles(i) if (ev and i >= 0) else (None, None)
-        flux, L, grads = step(xo, ops, leaves, t, gbar, events=evs, use_in_transit=use_in_transit)
-        if dist is not None:
-            L_all.zero_()
-            L_all[rank * D:(rank + 1) * D] = L.detach()
-            dist.all_reduce(L_all)     # the only collective: per-draw scalars, 8 B x D x N
+        flux, L, grads = step(xo, ops, leaves, t, gbar, events=evs)
+        if exchange is not None:
+            exchange_step(exchange, L)
         return flux, L, grads
 
-    # The step is a dozen short launches (packing kernel, scan, heavy, reduce, packing
-    # VJP and a few tensor-shuffling torch kernels): launch-bound when issued eagerly,
-    # so the timed region replays it as ONE hipGraph (the collective stays outside).
+    # The step is a dozen short launches (packing kernel, window, scan, heavy, reduce, packing VJP and
+    # a few tensor-shuffling torch kernels): launch-bound when issued eagerly, so the timed region
+    # replays it as ONE hipGraph; the collective -- exactly one call, straight from the graph's static
+    # output -- stays outside the graph.
     graph = None
     static = {}
     if not args.no_graph:
@@ -208,27 +510,46 @@ def main():
 
     def one_graph(i):
         graph()
-        if dist is not None:
-            L_all.zero_()
-            L_all[rank * D:(rank + 1) * D] = static["L"]
-            dist.all_reduce(L_all)
+        if exchange is not None:
+            exchange_step(exchange, static["L"])
 
-    wall = time_steps(one_graph if graph is not None else one, args.steps, args.warmup, dist, dev)
+    run = one_graph if graph is not None else (lambda i: one(i, ev=False))
+    wall = time_steps(run, args.steps, args.warmup, dist, dev)
     wall_t = torch.tensor([wall], dtype=torch.float64, device=dev)
     if dist is not None:
         dist.all_reduce(wall_t, op=dist.ReduceOp.MAX)
     wall = float(wall_t.item())
-    if graph is not None:
-        # hipEvents cannot bracket a node inside a replayed graph: time the dominant
-        # kernel over the same number of directly launched steps, same inputs
-        time_steps(lambda i: one(i), args.steps, 1, None, dev)
-    kernel_ms, _ = events.mean_ms()
+    timing = None
+    if not args.no_stats:
+        # >= 100 steps and >= 2 s, whatever --steps was; the count follows from the
+        # max-over-ranks step time above, so it is the same on every rank
+        n_stat = int(min(6000, max(100, np.ceil(2.0 / max(wall / args.steps, 1e-6)))))
+        timing = stats_loop(run, dev, n_stat)
+        if dist is not None:
+            dist.barrier()
+    # hipEvents cannot bracket a node inside a replayed graph: time the kernels of the sweep over
+    # directly launched steps on the same inputs (events recorded by the C ABI on the launch stream)
+    n_ev = len(events.pairs)
+    for i in range(n_ev):
+        one(i)
+    torch.cuda.synchronize(dev)
+    kernel_ms, per_launch = events.mean_ms()
+    flux_now = static["flux"] if graph is not None else one(-1)[0]
+    n_active = int((flux_now != 0).sum().item())
 
     out = None
     if rank == 0:
-        evals = world * D * args.steps
-        alg_bytes = ALG_BYTES_PER_UNIT * D * N_CAD
-        achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+        evals = n_global * args.steps
+        # bytes this design must move per sweep: the dense flux array once; t once per group of draws
+        # that share a classify block; (t, gbar) and the 4-byte work-list entry (written by the scan
+        # kernel, read by the heavy kernel) for every cadence that is actually solved
+        groups = (D + SCAN_DRAW_GROUP - 1) // SCAN_DRAW_GROUP
+        req = {"flux_write": 8 * D * N_CAD, "t_read_per_draw_group": 8 * N_CAD * groups,
+               "t_and_gbar_active": 16 * n_active, "work_list_write_read": 8 * n_active}
+        req_bytes = sum(req.values())
+        achieved = req_bytes / (kernel_ms * 1e-3) / 1e9
+        survey_bytes = SURVEY_BYTES_PER_UNIT * D * N_CAD
+        traffic = measured_traffic(D)
         out = {
             "metric": "light-curve evals/sec (value+grad) at 150k cadences",
             "value": evals / wall,
@@ -238,117 +559,98 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": 1e3 * wall / args.steps,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": scaling,
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
             "config": {
                 "workload": "BASELINE configs[1] (C2): single planet e=0.3 Kepler solve + quadratic limb-darkened "
-                            "transit, 150000 cadences, value+grad, every cadence evaluated (use_in_transit=False)",
-                "n_cadences": N_CAD, "draws_per_gpu": D, "global_draws": world * D,
-                "parallelism": f"draws sharded over {world} GPU(s); all-reduce of per-draw scalars only",
-                "step": "leaf params -> record-packing kernel (orbit algebra + get_cl) -> scan + heavy kernels "
-                        "(value+VJP, one sweep) -> packing VJP kernel -> leaf gradients" + ("; replayed as one hipGraph" if graph is not None else "; eager launches"),
+                            "transit, 150000 cadences, value+grad, use_in_transit=False: dense flux output, every "
+                            f"cadence classified on the device, {100.0 * n_active / (D * N_CAD):.2f} % solved",
+                "n_cadences": N_CAD, "draws_per_gpu": D, "global_draws": n_global,
+                "parallelism": f"draws sharded over {world} GPU(s); one collective of per-draw scalars per step",
+                "step": "leaf params -> record-packing kernel (orbit algebra + get_cl) -> window + scan + heavy + "
+                        "reduce kernels (value+VJP, one sweep) -> packing VJP kernel -> leaf gradients"
+                        + ("; replayed as one hipGraph" if graph is not None else "; eager launches"),
             },
+            "timing": timing,
             "roofline": {
-                "bound": "hbm", "kernel": "transit_window_kernel + transit_scan_kernel + transit_heavy_kernel + transit_vjp_reduce_kernel (one sweep)",
+                "bound": "hbm",
+                "kernel": "transit_window_kernel + transit_scan_kernel + transit_heavy_kernel + "
+                          "transit_vjp_reduce_kernel (one sweep)",
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": measured_traffic(D),
-                "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": kernel_ms,
-                "traffic_frac": (measured_traffic(D) / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if measured_traffic(D) else None,
-                "note": "achieved = 24 B per (draw, cadence) x draws x cadences / mean hipEvent time of the launches "
-                        "that make up the one algorithmic sweep (window constants, scan = classify + zero-fill, "
-                        "heavy = active cadences, reduce = block partials).  The algorithmic count charges a gbar "
-                        "read to every cadence; the kernels read it only for the ~3 % that are in transit, so "
-                        "achieved can exceed peak.  traffic = PMC-measured HBM bytes per sweep (profiles/), "
-                        "traffic_frac = traffic / time / peak: the store stream of zeros is what bounds the scan "
-                        "kernel, VALU latency bounds the heavy one.  rocprof per-kernel averages: profiles/",
+                "traffic": traffic["bytes"] if traffic else None,
+                "traffic_source": traffic["source"] if traffic else None,
+                "algorithmic_bytes_per_launch": req_bytes, "algorithmic_bytes_breakdown": req,
+                "active_cadences_per_launch": n_active, "kernel_ms": kernel_ms,
+                "kernel_ms_quantiles": quantiles(per_launch),
+                "survey_8d_count": {"bytes_per_unit": SURVEY_BYTES_PER_UNIT, "bytes_per_launch": survey_bytes,
+                                    "GBps": survey_bytes / (kernel_ms * 1e-3) / 1e9,
+                                    "note": "SURVEY.md 8d charges t + gbar + flux = 24 B to EVERY (draw, cadence); "
+                                            "this design reads t once per 4 draws and gbar only for solved cadences, "
+                                            "so this figure is not a fraction of anything: `frac` above is against "
+                                            "the bytes the design must move"},
+                "note": "achieved = algorithmic_bytes_per_launch / mean hipEvent time of the launches of one sweep "
+                        "(window constants, scan = classify + zero-fill, heavy = solved cadences, reduce = block "
+                        "partials), eager launches on the same inputs as the timed graph.  The sweep is two regimes: "
+                        "the scan kernel is bound by the store stream of the dense flux array, the heavy kernel by "
+                        "fp64 VALU issue (~1e3 flop per solved cadence); rocprof per-kernel averages and PMC "
+                        "traffic: profiles/",
             },
         }
 
     # the extra legs are single-GPU diagnostics: under torch.distributed.run they would only add
     # barriers that every rank has to reach (an exception on one rank would hang the others)
-    if not args.no_extras and world == 1:
-        # reference-default semantics (use_in_transit=True): same step, windows on.  Not `value`.
-        ex_steps = max(5, args.steps // 2)
-        ev2 = HipEvents(ex_steps)
-        events_backup, events = events, ev2
+    if not args.no_extras and world == 1 and dist is None:
+        extras = {}
 
-        def one_win(i):
-            evs = ev2.handles(i) if i >= 0 else (None, None)
-            return step(xo, ops, leaves, t, gbar, events=evs, use_in_transit=True)
+        def leg(name, fn):
+            try:
+                extras[name] = fn()
+            except Exception as exc:  # an extra leg must not take the headline measurement down with it
+                extras[name] = {"error": repr(exc)[:300]}
+            torch.cuda.synchronize(dev)
 
-        wall2 = time_steps(one_win, ex_steps, 2, dist, dev)
-        k2, _ = ev2.mean_ms()
-        # op-level time of the one-sweep kernel call alone (no torch glue)
-        orbit = xo.KeplerianOrbit(period=leaves["period"], t0=leaves["t0"], b=leaves["b"], ecc=leaves["ecc"],
-                                  omega=leaves["omega"])
-        rec, c, _, _ = orbit.kernel_inputs(leaves["r"], (leaves["u1"], leaves["u2"]))
-        rec, c = rec.detach(), c.detach()
-        wall3 = time_steps(lambda i: ops.transit_flux_value_and_vjp(t, rec, c, gbar), ex_steps, 2, dist, dev)
-        # BASELINE configs[2] (C3): the same light curve + a celerite SHO-term GP log-likelihood on
-        # the residual, value + gradient w.r.t. the orbit / limb-darkening leaves (user-level API)
-        c3 = None
-        try:
-            yobs = 5e-4 * torch.randn(N_CAD, dtype=torch.float64, device=dev)
-            ones = torch.ones(D, dtype=torch.float64, device=dev)
+        def in_transit():
             names = list(leaves)
+            q, how = graphed(xo, lambda *v: step(xo, ops, dict(zip(names, v)), t, gbar, use_in_transit=True),
+                             list(leaves.values()), dev, 50)
+            return {"evals_per_s": D / (q["median_ms"] * 1e-3), **q, "launch": how,
+                    "note": "the reference's default use_in_transit=True: contact-point windows from the packing "
+                            "kernel decide what is solved"}
 
-            def one_c3(i):
-                orbit3 = xo.KeplerianOrbit(period=leaves["period"], t0=leaves["t0"], b=leaves["b"], ecc=leaves["ecc"],
-                                           omega=leaves["omega"])
-                lc = xo.LimbDarkLightCurve(leaves["u1"], leaves["u2"]).get_light_curve(orbit=orbit3, r=leaves["r"], t=t)
-                gp = xo.gp.GaussianProcess(xo.gp.terms.SHOTerm(sigma=1e-3 * ones, rho=5.0 * ones, Q=0.7071 * ones),
-                                           t=t, yerr=5e-4, mean=lc.sum(-1))
-                ll = gp.log_likelihood(yobs)
-                return torch.autograd.grad(ll.sum(), [leaves[k] for k in names])
+        def op_level():
+            orbit = xo.KeplerianOrbit(period=leaves["period"], t0=leaves["t0"], b=leaves["b"], ecc=leaves["ecc"],
+                                      omega=leaves["omega"])
+            rec, c, _, _ = orbit.kernel_inputs(leaves["r"], (leaves["u1"], leaves["u2"]))
+            rec, c = rec.detach(), c.detach()
+            q = time_events(lambda: ops.transit_flux_value_and_vjp(t, rec, c, gbar), dev, 50)
+            return {"evals_per_s": D / (q["median_ms"] * 1e-3), **q,
+                    "note": "fused kernel call only (4 launches), no orbit algebra / autograd"}
 
-            c3_steps = 4
-            wall_c3 = time_steps(one_c3, c3_steps, 2, dist, dev)
-            c3 = {"evals_per_s": world * D * c3_steps / wall_c3, "ms_per_step": 1e3 * wall_c3 / c3_steps,
-                  "note": "C3: C2 light curve + SHO-term celerite GP on the residual (recurrences in parallel "
-                          "over time), value + gradient, eager launches"}
-        except Exception as exc:  # an extra leg must not take the headline measurement down with it
-            c3 = {"error": repr(exc)[:200]}
-        # the same C2 step with transit-timing variations -- 60 labelled transits, every
-        # draw its own offsets (gradient to each of them) -- user-level TTVOrbit, replayed as a hipGraph
-        ttv = None
-        try:
-            n_tr = int((float(t[-1]) - 1.0) / 3.5) + 1
-            offs = torch.tensor(0.01 * np.random.default_rng(7).normal(size=(D, n_tr)), dtype=torch.float64,
-                                device=dev, requires_grad=True)
-            tnames = list(leaves) + ["ttvs"]
+        def small_batch():
+            res = {}
+            for d in (64, 128, 256):
+                lv = make_leaves(d, 300 + d, dev)
+                gb = gbar[:d].contiguous()
+                nm = list(lv)
+                q, how = graphed(xo, lambda *v: step(xo, ops, dict(zip(nm, v)), t, gb), list(lv.values()), dev, 50)
+                res[str(d)] = {"evals_per_s": d / (q["median_ms"] * 1e-3), "median_ms": q["median_ms"], "launch": how}
+            return res
 
-            def ttv_step(*vals):
-                Lv = dict(zip(tnames, vals))
-                orb = xo.orbits.TTVOrbit(period=Lv["period"], t0=Lv["t0"], b=Lv["b"], ecc=Lv["ecc"], omega=Lv["omega"],
-                                         ttvs=[Lv["ttvs"]])
-                rec_t, ld_t, _, fl = orb.kernel_inputs(Lv["r"], (Lv["u1"], Lv["u2"]))
-                ed, sh = orb.kernel_ttv()
-                _, dot = ops.transit_flux_dot(t, rec_t, ld_t, gbar, flags=fl, ttv=(ed.contiguous(), sh.contiguous()))
-                return (dot.detach(),) + torch.autograd.grad(dot.sum(), vals)
-
-            tg = xo.GraphedStep(ttv_step, *leaves.values(), offs)
-            wall_ttv = time_steps(lambda i: tg(), ex_steps, 2, dist, dev)
-            ttv = {"evals_per_s": world * D * ex_steps / wall_ttv, "ms_per_step": 1e3 * wall_ttv / ex_steps,
-                   "transits": n_tr,
-                   "note": "C2 step with a TTVOrbit (timing tables in the fused kernels, gradients to every "
-                           "per-transit offset), hipGraph replay"}
-        except Exception as exc:
-            ttv = {"error": repr(exc)[:200]}
+        leg("in_transit_only", in_transit)
+        leg("op_level_every_cadence", op_level)
+        leg("c2_small_batches", small_batch)
+        leg("c2_with_transit_timing_variations", lambda: extra_ttv(xo, ops, leaves, t, gbar, dev, D))
+        leg("c3_light_curve_plus_sho_gp", lambda: extra_c3(xo, leaves, t, dev, D))
+        del gbar
+        torch.cuda.empty_cache()
+        leg("c4_four_planets_64_draws", lambda: extra_c4(xo, dev))
+        leg("c5_secondary_eclipse_3term_gp_128_chains", lambda: extra_c5(xo, dev))
+        torch.cuda.empty_cache()
+        leg("ops", lambda: extra_ops(ops, dev))
         if rank == 0:
-            out["extras"] = {
-                "c3_light_curve_plus_sho_gp": c3,
-                "c2_with_transit_timing_variations": ttv,
-                "in_transit_only": {"evals_per_s": world * D * ex_steps / wall2, "kernel_ms": k2,
-                                    "alg_GBps": ALG_BYTES_PER_UNIT * D * N_CAD / (k2 * 1e-3) / 1e9,
-                                    "note": "reference default use_in_transit=True (contact-point windows); this "
-                                            "extra leg launches eagerly (no hipGraph), so its evals/s is launch-bound"},
-                "op_level_every_cadence": {"evals_per_s": world * D * ex_steps / wall3,
-                                           "ms_per_step": 1e3 * wall3 / ex_steps,
-                                           "note": "fused kernel call only, no orbit algebra / autograd"},
-            }
-        events = events_backup
+            out["extras"] = extras
 
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:

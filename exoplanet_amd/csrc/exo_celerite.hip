@@ -12,32 +12,36 @@
 //   solve_lower: F_n = P o (F_{n-1} + W_{n-1} z_{n-1}) ;  z_n = y_n - U_n . F_n
 //   loglike    = -1/2 sum (z_n^2 / d_n + log d_n) - N/2 log 2 pi
 //
-// Two paths.  Sequential (first half of this file; calls without a state buffer, short series, draws
-// the other path cannot take): parallelism over draws and, inside a draw, over the J state
-// indices -- a draw occupies G = next_pow2(J) adjacent lanes (lane j owns row j of S), exchanging
-// values by DPP; everything that does not depend on the recurrence (U_n, V_n, P_n: sin / cos /
-// exp) comes from a fully parallel pre-pass; the log-determinant accumulates as (mantissa,
-// exponent); the saved factorisation (needed by the reverse recurrence) is laid out
-// [quantity][cadence][draw x state index] so that a wave's stores and loads are coalesced, and is
-// read back through a software prefetch ring.  Time-parallel (second half, the default with a
-// state buffer): the series is cut into chunks whose entering states -- and, in reverse, their
-// adjoints -- come from Kalman filtering elements and a short scan over the chunks, after which
-// the same recurrences run inside all chunks at once (see the comment block there).
+// Three sets of kernels.
+//  * Sequential (calls without a state buffer, short series, draws the time-parallel path cannot
+//    take): parallelism over draws and, inside a draw, over the J state indices -- a draw occupies
+//    G = next_pow2(J) adjacent lanes (lane j owns row j of S), exchanging values by DPP; U_n, V_n,
+//    P_n come from a fully parallel pre-pass; the saved factorisation is laid out
+//    [quantity][cadence][draw x state index] and read back through a software prefetch ring.
+//  * Time-parallel, lane-group form (J > 2): the series is cut into chunks whose entering states --
+//    and, in reverse, their adjoints -- come from Kalman filtering elements and a short scan over the
+//    chunks, after which the same recurrences run inside all chunks at once, a draw on G lanes, the
+//    full factorisation saved (see the comment block "Time-parallel path").
+//  * Time-parallel, one lane per (draw, chunk) (J <= 2, exo_celerite_core.hpp): every state index in
+//    the lane's registers -- no cross-lane traffic, none of the G-fold duplicated scalar work -- and a
+//    CHECKPOINTED factorisation: the forward pass stores (F, S) every 4 cadences (10 B per (draw,
+//    cadence) at J = 2 instead of 80), the reverse pass recomputes the cadences of a block from its
+//    checkpoint in registers.
+// The library keeps no state between calls: how a series is cut is a pure function of the call's
+// arguments (gp::chunk_plan), which the forward and the reverse call of a pair share.
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
-#include <stdlib.h>
-
-#include <mutex>
-#include <unordered_map>
 
 #include "../../include/exoplanet_amd.h"
+#include "exo_celerite_core.hpp"
 #include "exo_math.hpp"
 
 namespace {
 
+using namespace gp;
+
 constexpr int kWave = 64;
-constexpr double kHalfLog2Pi = 0.91893853320467274178;
 
 // A draw is spread over G = next_pow2(J) adjacent lanes: lane j of the group owns
 // state index j (row j of the symmetric J x J matrix S, W_j, F_j, U_j, V_j, P_j).
@@ -116,49 +120,6 @@ __device__ __forceinline__ double group_sum(double v) {
   return v;
 }
 
-// per-lane view of the term coefficients: state index j of a real term (a, c) or of
-// a complex pair (a, b, c, d); `odd` marks the second index of a pair
-struct LaneCoef {
-  double a, b, c, d;
-  bool real, odd, live;
-};
-
-__device__ __forceinline__ LaneCoef lane_coef(const double* __restrict__ coef_real, int n_real,
-                                              const double* __restrict__ coef_complex, int n_complex,
-                                              int64_t draw, int j, int J) {
-  LaneCoef k;
-  k.live = j < J;
-  k.real = j < n_real;
-  k.odd = false;
-  k.a = k.b = k.c = k.d = 0.0;
-  if (!k.live) return k;
-  if (k.real) {
-    const double* p = coef_real + (draw * n_real + j) * 2;
-    k.a = p[0]; k.c = p[1];
-  } else {
-    const int jc = (j - n_real) >> 1;
-    const double* p = coef_complex + (draw * n_complex + jc) * 4;
-    k.a = p[0]; k.b = p[1]; k.c = p[2]; k.d = p[3];
-    k.odd = ((j - n_real) & 1) != 0;
-  }
-  return k;
-}
-
-// U_j, V_j of SURVEY Appendix B at time t for this lane's state index
-__device__ __forceinline__ void lane_uv(const LaneCoef& k, double t, double* U, double* V, double* cs, double* sn) {
-  if (k.real || !k.live) {
-    *U = k.live ? k.a : 0.0;
-    *V = k.live ? 1.0 : 0.0;
-    *cs = 1.0; *sn = 0.0;
-    return;
-  }
-  double s, c;
-  exo::sincos_any(k.d * t, &s, &c);   // branch-free, no large-argument path: half the instructions and registers of libm's
-  *cs = c; *sn = s;
-  *U = k.odd ? (k.a * s - k.b * c) : (k.a * c + k.b * s);
-  *V = k.odd ? s : c;
-}
-
 // saved-state addressing.  Per (cadence, draw): the pair (d, z), 16 B; per (cadence, draw, j): one
 // record (W_j, F_j, S_j0 .. S_j,J-1) of R = 2 + J doubles, stored PLANAR within the cadence: piece q
 // of every (draw, j) is contiguous -- [cadence][piece][draw x j], pieces of 16 B for even R, of 8 B
@@ -227,8 +188,7 @@ __device__ __forceinline__ void load_record(const double* __restrict__ p, int64_
 // Pre-pass, fully parallel over (cadence, draw, state index): everything in the
 // recurrences that does not depend on the recurrence itself.
 __global__ __launch_bounds__(256) void celerite_prep_kernel(const double* __restrict__ t, int64_t n,
-                                                            const double* __restrict__ coef_real, int n_real,
-                                                            const double* __restrict__ coef_complex, int n_complex,
+                                                            Coefs cf,
                                                             int64_t n_draw, int J, double* __restrict__ state) {
   const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int64_t per = n_draw * J;
@@ -236,7 +196,7 @@ __global__ __launch_bounds__(256) void celerite_prep_kernel(const double* __rest
   const int64_t i = e / per, rem = e - i * per;
   const int64_t draw = rem / J;
   const int j = (int)(rem - draw * J);
-  const LaneCoef k = lane_coef(coef_real, n_real, coef_complex, n_complex, draw, j, J);
+  const LaneCoef k = lane_coef(cf, draw, j, J);
   const StateIdx six{n, n_draw, J};
   double U, V, cs, sn;
   const double ti = t[i];
@@ -246,24 +206,10 @@ __global__ __launch_bounds__(256) void celerite_prep_kernel(const double* __rest
   state[six.uvp(2, i, draw, j)] = i > 0 ? exp(-k.c * (ti - t[i - 1])) : 1.0;
 }
 
-// The series the likelihood is evaluated on: y[draw][n] as given, or -- obs != nullptr -- the
-// residual obs[n] - y[draw][n] of a per-draw model against one observed series, formed on the
-// fly (the subtraction, and the sign flip of its cotangent, never cross HBM as arrays).
-struct Series {
-  const double* y;
-  const double* obs;
-};
-struct SeriesRow {
-  const double* __restrict__ y;
-  const double* __restrict__ obs;
-  __device__ __forceinline__ double operator[](int64_t i) const { return obs ? obs[i] - y[i] : y[i]; }
-};
-
 template <int J, bool SAVE>
 __global__ __launch_bounds__(kWave) void celerite_fwd_kernel(
     const double* __restrict__ t, Series rs, const double* __restrict__ diag,
-    int64_t n_diag, int64_t n, const double* __restrict__ coef_real, int n_real,
-    const double* __restrict__ coef_complex, int n_complex, int64_t n_draw, double* __restrict__ loglike,
+    int64_t n_diag, int64_t n, Coefs cf, int64_t n_draw, double* __restrict__ loglike,
     double* __restrict__ state, const double* __restrict__ only_flagged) {
   constexpr int G = Group<J>::G;
   const int j = threadIdx.x & (G - 1);
@@ -273,7 +219,7 @@ __global__ __launch_bounds__(kWave) void celerite_fwd_kernel(
   // after the time-parallel path: redo only the draws it could not take (see DeltaCoef)
   const bool mine = live_draw && (!only_flagged || only_flagged[draw] != 0.0);
   if (only_flagged && __ballot(mine) == 0) return;
-  const LaneCoef k = lane_coef(coef_real, n_real, coef_complex, n_complex, draw, j, J);
+  const LaneCoef k = lane_coef(cf, draw, j, J);
   const bool store = SAVE && mine && k.live;
   // a_n = diag_n + sum of the a coefficients (first index of each term)
   const double asum = group_sum<G>((k.live && !k.odd) ? k.a : 0.0);
@@ -410,7 +356,7 @@ __global__ __launch_bounds__(kWave) void celerite_fwd_kernel(
 template <int J>
 __global__ __launch_bounds__(kWave) void celerite_vjp_kernel(
     const double* __restrict__ t, const double* __restrict__ diag, int64_t n_diag, int64_t n,
-    const double* __restrict__ coef_real, int n_real, const double* __restrict__ coef_complex, int n_complex,
+    Coefs cf,
     int64_t n_draw, const double* __restrict__ gloglike, const double* __restrict__ state,
     double* __restrict__ gresid, double* __restrict__ gdiag, double* __restrict__ gdiag_sum,
     double* __restrict__ gcoef_real, double* __restrict__ gcoef_complex, const double* __restrict__ only_flagged,
@@ -421,7 +367,7 @@ __global__ __launch_bounds__(kWave) void celerite_vjp_kernel(
   const bool live_draw = (lane_draw < n_draw) && (!only_flagged || only_flagged[lane_draw < n_draw ? lane_draw : 0] != 0.0);
   if (only_flagged && __ballot(live_draw) == 0) return;
   const int64_t draw = lane_draw < n_draw ? lane_draw : n_draw - 1;
-  const LaneCoef k = lane_coef(coef_real, n_real, coef_complex, n_complex, draw, j, J);
+  const LaneCoef k = lane_coef(cf, draw, j, J);
   const int jj = k.live ? j : 0;  // idle lanes read a valid slot and contribute zeros
   const StateIdx six{n, n_draw, J};
   const double gL = gloglike[draw];
@@ -603,11 +549,12 @@ __global__ __launch_bounds__(kWave) void celerite_vjp_kernel(
   if (!live_draw || !k.live) return;
   if (j == 0 && gdiag_sum) gdiag_sum[draw] = gasum;
   if (k.real) {
-    double* o = gcoef_real + (draw * n_real + j) * 2;
+    // a real term of its own, or one of the two real terms of a pair slot (kind 1)
+    double* o = k.slot < 0 ? gcoef_real + (draw * cf.n_real + j) * 2 : gcoef_complex + draw * cf.n_complex * 4 + k.slot;
     o[0] = ga + gasum;  // a_n = diag_n + sum a
     o[1] = gc;
   } else if (!k.odd) {
-    double* o = gcoef_complex + (draw * n_complex + ((j - n_real) >> 1)) * 4;
+    double* o = gcoef_complex + (draw * cf.n_complex + ((j - cf.n_real) >> 1)) * 4;
     o[0] = ga + gasum;
     o[1] = gb;
     o[2] = gc + gc_o;
@@ -648,161 +595,21 @@ __global__ __launch_bounds__(kWave) void celerite_vjp_kernel(
 // a > 0, |b d| <= a c are flagged and handled by the sequential kernels.
 // ===========================================================================
 
-struct ChunkGeom {
-  int C;        // chunks
-  int64_t L;    // cadences per chunk (the last may be shorter)
-  int64_t base; // first double of the chunk workspace inside `state`
-};
-
-// chunk workspace, all [chunk][quantity][draw] (a lane is a draw: coalesced)
-struct ChunkWs {
-  int64_t n_draw;
-  int J, C;
-  int64_t base;
-  __host__ __device__ int E() const { return 3 * J * J + 2 * J; }   // A, b, Cm, eta, Jm
-  __host__ __device__ int B() const { return J + J * J; }           // vector + matrix
-  __host__ __device__ int64_t elem(int c, int e, int64_t draw) const { return base + ((int64_t)c * E() + e) * n_draw + draw; }
-  __host__ __device__ int64_t off_bnd() const { return base + (int64_t)C * E() * n_draw; }
-  // q = 1: (F, P) entering chunk c;  2: adjoint of (F, S) entering chunk c + 1  (0: unused)
-  __host__ __device__ int64_t bnd(int q, int c, int k, int64_t draw) const {
-    return off_bnd() + (((int64_t)q * C + c) * B() + k) * n_draw + draw;
-  }
-  __host__ __device__ int64_t off_part() const { return off_bnd() + (int64_t)3 * C * B() * n_draw; }
-  __host__ __device__ int64_t part(int c, int k, int64_t draw) const {  // k = 0 acc, 1 logdet, 2 bad
-    return off_part() + ((int64_t)c * 3 + k) * n_draw + draw;
-  }
-  __host__ __device__ int64_t off_gpart() const { return off_part() + (int64_t)3 * C * n_draw; }
-  __host__ __device__ int64_t gpart(int c, int k, int64_t draw) const {  // k = 4 j + {a, b, c, d}; 4 J = gasum
-    return off_gpart() + ((int64_t)c * (4 * J + 1) + k) * n_draw + draw;
-  }
-  __host__ __device__ int64_t off_flag() const { return off_gpart() + (int64_t)C * (4 * J + 1) * n_draw; }
-  __host__ __device__ int64_t total() const { return off_flag() + n_draw - base; }
-};
-
-constexpr int kChunkMaxJ = 8;   // = EXO_GP_MAX_J (J = 7, 8: lane-group element kernel, one-lane scan kernels spill)
-
-inline ChunkGeom chunk_plan(int64_t n, int64_t n_draw, int J) {
-  ChunkGeom g{1, n, 0};
-  if (J > kChunkMaxJ) return g;
-  int64_t C;
-  const char* env = getenv("EXO_GP_CHUNKS");
-  if (env && *env) {
-    C = atoll(env);
-  } else {
-    const int G = J <= 1 ? 1 : (J <= 2 ? 2 : (J <= 4 ? 4 : 8));
-    // ~2 waves per SIMD for the chunk kernels; small J affords more (the per-draw scans over the
-    // chunks cost C J^3): measured optimum at 1024 draws, J = 2 is C = 256
-    C = (64 * 2048 * (J <= 2 ? 4 : 1)) / (n_draw * G);
-    if (C > 512) C = 512;
-    if (C < 4) C = 1;
-  }
-  if (C > n / 32) C = n / 32;        // chunks of at least 32 cadences
-  if (C < 2) return g;
-  g.L = (n + C - 1) / C;
-  g.C = (int)((n + g.L - 1) / g.L);
-  if (g.C < 2) { g.C = 1; g.L = n; }
-  return g;
-}
-
-// symmetric J x J in packed upper-triangular storage
-template <int J>
-struct Sym {
-  double v[J * (J + 1) / 2];
-  __device__ __forceinline__ static constexpr int idx(int j, int l) {
-    return j <= l ? j * J - j * (j - 1) / 2 + (l - j) : l * J - l * (l - 1) / 2 + (j - l);
-  }
-  __device__ __forceinline__ double& operator()(int j, int l) { return v[idx(j, l)]; }
-  __device__ __forceinline__ double operator()(int j, int l) const { return v[idx(j, l)]; }
-};
-
-// Delta_n of one draw from its term coefficients and V_n (block diagonal: 1x1 / 2x2 blocks)
-template <int J>
-struct DeltaCoef {
-  double p[J], q[J], r[J];   // per state index: real term -> p = 1/a; pair -> (p, q, r) on both indices
-  bool real[J];
-  bool valid;
-  __device__ void init(const double* __restrict__ coef_real, int n_real, const double* __restrict__ coef_complex,
-                       int n_complex, int64_t draw) {
-    valid = true;
-#pragma unroll
-    for (int j = 0; j < J; ++j) {
-      if (j < n_real) {
-        const double a = coef_real[(draw * n_real + j) * 2], c = coef_real[(draw * n_real + j) * 2 + 1];
-        real[j] = true;
-        p[j] = 1.0 / a; q[j] = 0.0; r[j] = 0.0;
-        valid = valid && (a > 0.0) && (c >= 0.0) && (a < INFINITY) && (c < INFINITY);
-      } else {
-        const double* k = coef_complex + (draw * n_complex + ((j - n_real) >> 1)) * 4;
-        const double a = k[0], b = k[1], c = k[2], d = k[3];
-        const double h = 1.0 / (a * a + b * b);
-        real[j] = false;
-        r[j] = a * h; q[j] = -b * h; p[j] = (a * a + 2.0 * b * b) * h / a;
-        valid = valid && (a > 0.0) && (fabs(b * d) <= a * c * (1.0 + 1e-12)) && (a < INFINITY) && (fabs(b) < INFINITY) &&
-                (c < INFINITY) && (fabs(d) < INFINITY);
-      }
-    }
-  }
-  // Delta (packed) from V (cos / sin of each pair)
-  __device__ __forceinline__ void eval(const double* V, int n_real, Sym<J>& D) const {
-#pragma unroll
-    for (int k = 0; k < J * (J + 1) / 2; ++k) D.v[k] = 0.0;
-#pragma unroll
-    for (int j = 0; j < J; ++j) {
-      if (real[j]) {
-        D(j, j) = p[j];
-      } else if (((j - n_real) & 1) == 0 && j + 1 < J) {
-        const double cs = V[j], sn = V[j + 1];
-        D(j, j) = p[j] * cs * cs + 2.0 * q[j] * cs * sn + r[j] * sn * sn;
-        D(j, j + 1) = (p[j] - r[j]) * cs * sn + q[j] * (sn * sn - cs * cs);
-        D(j + 1, j + 1) = p[j] * sn * sn - 2.0 * q[j] * cs * sn + r[j] * cs * cs;
-      }
-    }
-  }
-};
-
-// U_n, V_n for all J state indices of one draw (one sincos per complex pair); same arithmetic as
-// lane_uv, so the values are those the pre-pass would have stored
-template <int J>
-struct DrawCoef {
-  LaneCoef k[J];
-  __device__ void init(const double* __restrict__ coef_real, int n_real, const double* __restrict__ coef_complex,
-                       int n_complex, int64_t draw) {
-#pragma unroll
-    for (int j = 0; j < J; ++j) k[j] = lane_coef(coef_real, n_real, coef_complex, n_complex, draw, j, J);
-  }
-  __device__ __forceinline__ void uv(double t, double* U, double* V) const {
-#pragma unroll
-    for (int j = 0; j < J; ++j) {
-      if (k[j].real) {
-        U[j] = k[j].a; V[j] = 1.0;
-      } else if (!k[j].odd) {
-        double sn, cs;
-        exo::sincos_any(k[j].d * t, &sn, &cs);
-        U[j] = k[j].a * cs + k[j].b * sn; V[j] = cs;
-        if (j + 1 < J) { U[j + 1] = k[j].a * sn - k[j].b * cs; V[j + 1] = sn; }
-      }
-    }
-  }
-};
-
 // which draws the time-parallel path cannot take (DeltaCoef::valid): 1.0 = redo sequentially
 template <int J>
-__global__ __launch_bounds__(kWave) void celerite_flag_kernel(const double* __restrict__ coef_real, int n_real,
-                                                              const double* __restrict__ coef_complex, int n_complex,
+__global__ __launch_bounds__(kWave) void celerite_flag_kernel(Coefs cf,
                                                               int64_t n_draw, double* __restrict__ flag) {
   const int64_t draw = (int64_t)blockIdx.x * kWave + threadIdx.x;
   if (draw >= n_draw) return;
   DeltaCoef<J> dc;
-  dc.init(coef_real, n_real, coef_complex, n_complex, draw);
+  dc.init(cf, draw);
   flag[draw] = dc.valid ? 0.0 : 1.0;
 }
 
 // pre-pass for the flagged draws only (the sequential kernels read U, V, P from `state`; the
 // time-parallel kernels recompute them: three fewer arrays across HBM four times)
 __global__ __launch_bounds__(256) void celerite_prep_flagged_kernel(const double* __restrict__ t, int64_t n,
-                                                                    const double* __restrict__ coef_real, int n_real,
-                                                                    const double* __restrict__ coef_complex,
-                                                                    int n_complex, int64_t n_draw, int J,
+                                                                    Coefs cf, int64_t n_draw, int J,
                                                                     double* __restrict__ state,
                                                                     const double* __restrict__ flag) {
   const int64_t draw = blockIdx.y;
@@ -811,284 +618,13 @@ __global__ __launch_bounds__(256) void celerite_prep_flagged_kernel(const double
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n * J; e += (int64_t)gridDim.x * 256) {
     const int64_t i = e / J;
     const int j = (int)(e - i * J);
-    const LaneCoef k = lane_coef(coef_real, n_real, coef_complex, n_complex, draw, j, J);
+    const LaneCoef k = lane_coef(cf, draw, j, J);
     double U, V, cs, sn;
     const double ti = t[i];
     lane_uv(k, ti, &U, &V, &cs, &sn);
     state[six.uvp(0, i, draw, j)] = U;
     state[six.uvp(1, i, draw, j)] = V;
     state[six.uvp(2, i, draw, j)] = i > 0 ? exp(-k.c * (ti - t[i - 1])) : 1.0;
-  }
-}
-
-// (A) the filtering element of every (draw, chunk): one lane each
-template <int J>
-__global__ __launch_bounds__(kWave) void celerite_elem_kernel(
-    const double* __restrict__ t, Series rs, const double* __restrict__ diag, int64_t n_diag,
-    int64_t n,
-    const double* __restrict__ coef_real, int n_real, const double* __restrict__ coef_complex, int n_complex,
-    int64_t n_draw, double* __restrict__ state, ChunkGeom cg) {
-  const int64_t draw = (int64_t)blockIdx.x * kWave + threadIdx.x;
-  if (draw >= n_draw) return;
-  const int c = blockIdx.y;
-  const int64_t n0 = c * cg.L, n1 = (n0 + cg.L < n) ? n0 + cg.L : n;
-  const StateIdx six{n, n_draw, J};
-  const ChunkWs ws{n_draw, J, cg.C, cg.base};
-  DeltaCoef<J> dc;
-  dc.init(coef_real, n_real, coef_complex, n_complex, draw);
-  DrawCoef<J> co;
-  co.init(coef_real, n_real, coef_complex, n_complex, draw);
-  const SeriesRow y{rs.y + draw * n, rs.obs};
-  const double* __restrict__ dg = diag + (n_diag == 1 ? 0 : draw * n);
-  double A[J][J], b[J], eta[J];
-  Sym<J> Cm, Jm, Dl;
-#pragma unroll
-  for (int j = 0; j < J; ++j) {
-    b[j] = eta[j] = 0.0;
-#pragma unroll
-    for (int l = 0; l < J; ++l) A[j][l] = (j == l) ? 1.0 : 0.0;
-  }
-#pragma unroll
-  for (int k = 0; k < J * (J + 1) / 2; ++k) Cm.v[k] = Jm.v[k] = 0.0;
-  double U[J], V[J], phi[J];
-  double ti = t[n0], dt_prev = -1.0;
-  co.uv(ti, U, V);
-  dc.eval(V, n_real, Dl);
-  // Conditioning.  The element is in information form (1 / diag) and lives in celerite's rotating
-  // frame, where a complex term's state covariance Delta0 has condition number ~ 4 (b / a)^2: the
-  // J x J solves of the scans lose about  kappa = (1 + max (b/a)^2) sum(a) / min(diag)  times 1e-13
-  // in the gradients (measured against the sequential kernels over random kernels,
-  // tools/gp_cond_scan.py: 1e-9 at kappa = 1e4, 2e-8 at 1e5, 1e-4 at 1e7).  Draws with kappa > 1e5
-  // -- celerite2's Matern-3/2 term (b / a = 100 w0), an SHO term within a few per cent of critical
-  // damping, a signal 1e5 times the white noise, diag = 0 -- are flagged here and redone by the
-  // sequential kernels.  (A whitened state basis would lift the (b / a)^2 factor: DESIGN.md 8.)
-  double asum = 0.0, ba2 = 0.0;
-#pragma unroll
-  for (int j = 0; j < J; ++j) {
-    asum += (co.k[j].real || !co.k[j].odd) ? fabs(co.k[j].a) : 0.0;
-    if (!co.k[j].real && !co.k[j].odd) ba2 = fmax(ba2, (co.k[j].b * co.k[j].b) / (co.k[j].a * co.k[j].a));
-  }
-  const double rmin = (1.0 + ba2) * asum * 1e-5;
-  bool ok = true;
-#pragma unroll 1
-  for (int64_t i = n0; i < n1; ++i) {
-    const double yi = y[i], R = dg[i];
-    ok = ok && (R >= rmin) && (R < INFINITY);
-    double r[J], cu[J];
-    double s = R, zeta = yi;
-#pragma unroll
-    for (int l = 0; l < J; ++l) {
-      double rl = 0.0, cl = 0.0;
-#pragma unroll
-      for (int j = 0; j < J; ++j) { rl = fma(A[j][l], U[j], rl); cl = fma(Cm(l, j), U[j], cl); }
-      r[l] = rl; cu[l] = cl;
-      s = fma(U[l], cl, s);
-      zeta = fma(-U[l], b[l], zeta);
-    }
-    const double is = 1.0 / s;
-#pragma unroll
-    for (int j = 0; j < J; ++j) {
-      eta[j] = fma(r[j] * is, zeta, eta[j]);
-#pragma unroll
-      for (int l = j; l < J; ++l) Jm(j, l) = fma(r[j] * is, r[l], Jm(j, l));
-    }
-    if (i + 1 < n) {
-      double Vn[J];
-      const double tn = t[i + 1], dt = tn - ti;
-      ti = tn;
-      if (dt != dt_prev) {   // evenly sampled series reuse the propagators
-#pragma unroll
-        for (int j = 0; j < J; ++j) phi[j] = exp(-co.k[j].c * dt);
-        dt_prev = dt;
-      }
-      co.uv(tn, U, Vn);
-      Sym<J> Dn;
-      dc.eval(Vn, n_real, Dn);
-#pragma unroll
-      for (int j = 0; j < J; ++j) {
-        const double kj = cu[j] * is;
-        b[j] = phi[j] * fma(kj, zeta, b[j]);
-#pragma unroll
-        for (int l = 0; l < J; ++l) A[j][l] = phi[j] * fma(-kj, r[l], A[j][l]);
-#pragma unroll
-        for (int l = j; l < J; ++l)
-          Cm(j, l) = fma(phi[j] * phi[l], fma(-kj, cu[l], Cm(j, l)) - Dl(j, l), Dn(j, l));  // + Q = Dn - phi phi Dl
-      }
-      Dl = Dn;
-    }
-  }
-  if (!ok) state[ws.off_flag() + draw] = 1.0;
-  int e = 0;
-#pragma unroll
-  for (int j = 0; j < J; ++j)
-#pragma unroll
-    for (int l = 0; l < J; ++l) state[ws.elem(c, e++, draw)] = A[j][l];
-#pragma unroll
-  for (int j = 0; j < J; ++j) state[ws.elem(c, e++, draw)] = b[j];
-#pragma unroll
-  for (int j = 0; j < J; ++j)
-#pragma unroll
-    for (int l = 0; l < J; ++l) state[ws.elem(c, e++, draw)] = Cm(j, l);
-#pragma unroll
-  for (int j = 0; j < J; ++j) state[ws.elem(c, e++, draw)] = eta[j];
-#pragma unroll
-  for (int j = 0; j < J; ++j)
-#pragma unroll
-    for (int l = 0; l < J; ++l) state[ws.elem(c, e++, draw)] = Jm(j, l);
-}
-
-// solve X Z = B (J x J, NB right-hand sides) in place by Gaussian elimination with partial pivoting
-template <int J, int NB>
-__device__ __forceinline__ void solve_inplace(double (&X)[J][J], double (&B)[J][NB]) {
-#pragma unroll
-  for (int k = 0; k < J; ++k) {
-    int piv = k;
-    double best = fabs(X[k][k]);
-#pragma unroll
-    for (int i = k + 1; i < J; ++i) {
-      const bool better = fabs(X[i][k]) > best;
-      best = better ? fabs(X[i][k]) : best;
-      piv = better ? i : piv;
-    }
-#pragma unroll
-    for (int i = k + 1; i < J; ++i) {
-      if (i == piv) {   // swap rows k and i (selects: piv is a run-time value)
-#pragma unroll
-        for (int l = 0; l < J; ++l) { const double tmp = X[k][l]; X[k][l] = X[i][l]; X[i][l] = tmp; }
-#pragma unroll
-        for (int l = 0; l < NB; ++l) { const double tmp = B[k][l]; B[k][l] = B[i][l]; B[i][l] = tmp; }
-      }
-    }
-    const double ip = 1.0 / X[k][k];
-#pragma unroll
-    for (int i = k + 1; i < J; ++i) {
-      const double f = X[i][k] * ip;
-#pragma unroll
-      for (int l = k + 1; l < J; ++l) X[i][l] = fma(-f, X[k][l], X[i][l]);
-#pragma unroll
-      for (int l = 0; l < NB; ++l) B[i][l] = fma(-f, B[k][l], B[i][l]);
-    }
-  }
-#pragma unroll
-  for (int k = J - 1; k >= 0; --k) {
-    const double ip = 1.0 / X[k][k];
-#pragma unroll
-    for (int l = 0; l < NB; ++l) {
-      double v = B[k][l];
-#pragma unroll
-      for (int i = k + 1; i < J; ++i) v = fma(-X[k][i], B[i][l], v);
-      B[k][l] = v * ip;
-    }
-  }
-}
-
-template <int J>
-struct Elem {
-  double A[J][J], b[J], Cm[J][J], eta[J], Jm[J][J];
-  __device__ void load(const double* __restrict__ state, const ChunkWs& ws, int c, int64_t draw) {
-    int e = 0;
-#pragma unroll
-    for (int j = 0; j < J; ++j)
-#pragma unroll
-      for (int l = 0; l < J; ++l) A[j][l] = state[ws.elem(c, e++, draw)];
-#pragma unroll
-    for (int j = 0; j < J; ++j) b[j] = state[ws.elem(c, e++, draw)];
-#pragma unroll
-    for (int j = 0; j < J; ++j)
-#pragma unroll
-      for (int l = 0; l < J; ++l) Cm[j][l] = state[ws.elem(c, e++, draw)];
-#pragma unroll
-    for (int j = 0; j < J; ++j) eta[j] = state[ws.elem(c, e++, draw)];
-#pragma unroll
-    for (int j = 0; j < J; ++j)
-#pragma unroll
-      for (int l = 0; l < J; ++l) Jm[j][l] = state[ws.elem(c, e++, draw)];
-  }
-};
-
-// (B) the state entering every chunk: one lane per draw, C - 1 element applications
-template <int J>
-__global__ __launch_bounds__(kWave) void celerite_bscan_kernel(const double* __restrict__ t,
-                                                               const double* __restrict__ coef_real, int n_real,
-                                                               const double* __restrict__ coef_complex, int n_complex,
-                                                               int64_t n, int64_t n_draw, double* __restrict__ state,
-                                                               ChunkGeom cg) {
-  const int64_t draw = (int64_t)blockIdx.x * kWave + threadIdx.x;
-  if (draw >= n_draw) return;
-  const ChunkWs ws{n_draw, J, cg.C, cg.base};
-  DeltaCoef<J> dc;
-  dc.init(coef_real, n_real, coef_complex, n_complex, draw);
-  DrawCoef<J> co;
-  co.init(coef_real, n_real, coef_complex, n_complex, draw);
-  double m[J], P[J][J];
-#pragma unroll
-  for (int j = 0; j < J; ++j) m[j] = 0.0;
-#pragma unroll 1
-  for (int c = 0; c < cg.C; ++c) {
-    if (c == 0) {
-      double U[J], V[J];
-      co.uv(t[0], U, V);
-      Sym<J> Dl;
-      dc.eval(V, n_real, Dl);
-#pragma unroll
-      for (int j = 0; j < J; ++j)
-#pragma unroll
-        for (int l = 0; l < J; ++l) P[j][l] = Dl(j, l);   // S_0 = 0
-    }
-#pragma unroll
-    for (int j = 0; j < J; ++j) {
-      state[ws.bnd(1, c, j, draw)] = m[j];
-#pragma unroll
-      for (int l = 0; l < J; ++l) state[ws.bnd(1, c, J + j * J + l, draw)] = P[j][l];
-    }
-    if (c + 1 == cg.C) break;
-    Elem<J> el;
-    el.load(state, ws, c, draw);
-    // X = I + P Jm ;  solve X [YP | ym] = [P | m + P eta]
-    double X[J][J], Bm[J][J + 1];
-#pragma unroll
-    for (int j = 0; j < J; ++j) {
-      double pe = m[j];
-#pragma unroll
-      for (int l = 0; l < J; ++l) {
-        double x = (j == l) ? 1.0 : 0.0;
-#pragma unroll
-        for (int k = 0; k < J; ++k) x = fma(P[j][k], el.Jm[k][l], x);
-        X[j][l] = x;
-        Bm[j][l] = P[j][l];
-        pe = fma(P[j][l], el.eta[l], pe);
-      }
-      Bm[j][J] = pe;
-    }
-    solve_inplace<J, J + 1>(X, Bm);
-    // m' = A ym + b ;  P' = A (YP) A^T + Cm  (symmetrised)
-    double AY[J][J];
-#pragma unroll
-    for (int j = 0; j < J; ++j) {
-      double mj = el.b[j];
-#pragma unroll
-      for (int l = 0; l < J; ++l) {
-        mj = fma(el.A[j][l], Bm[l][J], mj);
-        double v = 0.0;
-#pragma unroll
-        for (int k = 0; k < J; ++k) v = fma(el.A[j][k], Bm[k][l], v);
-        AY[j][l] = v;   // A (YP)
-      }
-      m[j] = mj;
-    }
-#pragma unroll
-    for (int j = 0; j < J; ++j)
-#pragma unroll
-      for (int l = 0; l < J; ++l) {
-        double v = el.Cm[j][l];
-#pragma unroll
-        for (int k = 0; k < J; ++k) v = fma(AY[j][k], el.A[l][k], v);
-        X[j][l] = v;
-      }
-#pragma unroll
-    for (int j = 0; j < J; ++j)
-#pragma unroll
-      for (int l = 0; l < J; ++l) P[j][l] = 0.5 * (X[j][l] + X[l][j]);
   }
 }
 
@@ -1134,8 +670,7 @@ struct LaneDelta {
 template <int J>
 __global__ __launch_bounds__(kWave) void celerite_elem_lg_kernel(
     const double* __restrict__ t, Series rs, const double* __restrict__ diag, int64_t n_diag,
-    int64_t n, const double* __restrict__ coef_real, int n_real, const double* __restrict__ coef_complex,
-    int n_complex, int64_t n_draw, double* __restrict__ state, ChunkGeom cg) {
+    int64_t n, Coefs cf, int64_t n_draw, double* __restrict__ state, ChunkGeom cg) {
   constexpr int G = Group<J>::G;
   const int j = threadIdx.x & (G - 1);
   const int64_t lane_draw = ((int64_t)blockIdx.x * kWave + threadIdx.x) / G;
@@ -1143,9 +678,9 @@ __global__ __launch_bounds__(kWave) void celerite_elem_lg_kernel(
   const int64_t draw = live_draw ? lane_draw : n_draw - 1;
   const int c = blockIdx.y;
   const int64_t n0 = c * cg.L, n1 = (n0 + cg.L < n) ? n0 + cg.L : n;
-  const LaneCoef k = lane_coef(coef_real, n_real, coef_complex, n_complex, draw, j, J);
+  const LaneCoef k = lane_coef(cf, draw, j, J);
   const bool live = k.live;
-  const ChunkWs ws{n_draw, J, cg.C, cg.base};
+  const ChunkWs ws = chunk_ws(n, n_draw, J, cg);
   const LaneDelta ld(k);
   const SeriesRow y{rs.y + draw * n, rs.obs};
   const double* __restrict__ dg = diag + (n_diag == 1 ? 0 : draw * n);
@@ -1233,9 +768,7 @@ __global__ __launch_bounds__(kWave) void celerite_elem_lg_kernel(
 // bound by exactly that; here a lane issues about a third.
 template <int J>
 __global__ __launch_bounds__(kWave) void celerite_bscan_lg_kernel(const double* __restrict__ t,
-                                                                  const double* __restrict__ coef_real, int n_real,
-                                                                  const double* __restrict__ coef_complex,
-                                                                  int n_complex, int64_t n, int64_t n_draw,
+                                                                  Coefs cf, int64_t n, int64_t n_draw,
                                                                   double* __restrict__ state, ChunkGeom cg) {
   constexpr int G = Group<J>::G;
   const int j = threadIdx.x & (G - 1);
@@ -1243,11 +776,11 @@ __global__ __launch_bounds__(kWave) void celerite_bscan_lg_kernel(const double* 
   const int64_t lane_draw = ((int64_t)blockIdx.x * kWave + threadIdx.x) / G;
   const bool live_draw = lane_draw < n_draw;
   const int64_t draw = live_draw ? lane_draw : n_draw - 1;
-  const LaneCoef k = lane_coef(coef_real, n_real, coef_complex, n_complex, draw, j, J);
+  const LaneCoef k = lane_coef(cf, draw, j, J);
   const bool live = k.live;
   const int jj = live ? j : 0;
   const bool store = live_draw && live;
-  const ChunkWs ws{n_draw, J, cg.C, cg.base};
+  const ChunkWs ws = chunk_ws(n, n_draw, J, cg);
   const LaneDelta ld(k);
   double mj = 0.0, Prow[J];
   {
@@ -1351,143 +884,6 @@ __global__ __launch_bounds__(kWave) void celerite_bscan_lg_kernel(const double* 
   }
 }
 
-// (B'), part 1 -- everything in the chain rule across chunks that does not depend on the adjoint
-// coming from later chunks, for all (draw, chunk) in parallel (the J x J solve lives here):
-//   Abar = A Y,  g = eta - Jm Y (F + P eta),  local adjoints  gL w  and  gL/2 (w w^T - Jm Y),
-// written over the chunk's element (A <- Abar, b <- g, eta <- local Fbar, Cm <- local Pbar).
-template <int J>
-__global__ __launch_bounds__(kWave) void celerite_badj_prep_kernel(const double* __restrict__ gloglike, int64_t n_draw,
-                                                                   double* __restrict__ state, ChunkGeom cg) {
-  const int64_t draw = (int64_t)blockIdx.x * kWave + threadIdx.x;
-  if (draw >= n_draw) return;
-  const int c = blockIdx.y + 1;   // chunk 0's entering adjoint is never needed
-  const ChunkWs ws{n_draw, J, cg.C, cg.base};
-  const double gL = gloglike[draw];
-  Elem<J> el;
-  el.load(state, ws, c, draw);
-  double m[J], P[J][J];
-#pragma unroll
-  for (int j = 0; j < J; ++j) {
-    m[j] = state[ws.bnd(1, c, j, draw)];
-#pragma unroll
-    for (int l = 0; l < J; ++l) P[j][l] = state[ws.bnd(1, c, J + j * J + l, draw)];
-  }
-  double X[J][J], Y[J][J];
-#pragma unroll
-  for (int j = 0; j < J; ++j)
-#pragma unroll
-    for (int l = 0; l < J; ++l) {
-      double x = (j == l) ? 1.0 : 0.0;
-#pragma unroll
-      for (int k = 0; k < J; ++k) x = fma(P[j][k], el.Jm[k][l], x);
-      X[j][l] = x;
-      Y[j][l] = (j == l) ? 1.0 : 0.0;
-    }
-  solve_inplace<J, J>(X, Y);
-  double u[J], v[J], w[J], Yv[J];
-#pragma unroll
-  for (int j = 0; j < J; ++j) {
-    double uj = el.eta[j], vj = m[j];
-#pragma unroll
-    for (int l = 0; l < J; ++l) { uj = fma(-el.Jm[j][l], m[l], uj); vj = fma(P[j][l], el.eta[l], vj); }
-    u[j] = uj; v[j] = vj;
-  }
-#pragma unroll
-  for (int j = 0; j < J; ++j) {
-    double wj = 0.0, yv = 0.0;
-#pragma unroll
-    for (int l = 0; l < J; ++l) { wj = fma(Y[l][j], u[l], wj); yv = fma(Y[j][l], v[l], yv); }
-    w[j] = wj; Yv[j] = yv;
-  }
-  const int oA = 0, ob = J * J, oC = J * J + J, oeta = 2 * J * J + J;
-#pragma unroll
-  for (int j = 0; j < J; ++j) {
-    double gj = el.eta[j];
-#pragma unroll
-    for (int l = 0; l < J; ++l) {
-      gj = fma(-el.Jm[j][l], Yv[l], gj);
-      double a = 0.0, jy = 0.0, jyt = 0.0;
-#pragma unroll
-      for (int k = 0; k < J; ++k) {
-        a = fma(el.A[j][k], Y[k][l], a);
-        jy = fma(el.Jm[j][k], Y[k][l], jy);
-        jyt = fma(el.Jm[l][k], Y[k][j], jyt);
-      }
-      state[ws.elem(c, oA + j * J + l, draw)] = a;
-      state[ws.elem(c, oC + j * J + l, draw)] = 0.5 * gL * (w[j] * w[l] - 0.5 * (jy + jyt));
-    }
-    state[ws.elem(c, ob + j, draw)] = gj;
-    state[ws.elem(c, oeta + j, draw)] = gL * w[j];
-  }
-}
-
-// (B'), part 2 -- the chain itself, last chunk to first, one lane per draw: two J x J products per chunk
-//   Fbar = local + Abar^T Fbar',   Pbar = local + Abar^T Pbar' Abar + sym(Abar^T Fbar' g^T)
-template <int J>
-__global__ __launch_bounds__(kWave) void celerite_bscan_vjp_kernel(int64_t n_draw, double* __restrict__ state,
-                                                                   ChunkGeom cg) {
-  const int64_t draw = (int64_t)blockIdx.x * kWave + threadIdx.x;
-  if (draw >= n_draw) return;
-  const ChunkWs ws{n_draw, J, cg.C, cg.base};
-  const int oA = 0, ob = J * J, oC = J * J + J, oeta = 2 * J * J + J;
-  double mb[J], Pb[J][J];   // adjoint of (F, P) entering chunk c + 1
-#pragma unroll
-  for (int j = 0; j < J; ++j) {
-    mb[j] = 0.0;
-#pragma unroll
-    for (int l = 0; l < J; ++l) Pb[j][l] = 0.0;
-  }
-#pragma unroll 1
-  for (int c = cg.C - 1; c >= 0; --c) {
-    // what chunk c's reverse recurrence starts from: adjoint of (F, S) entering chunk c + 1; Sbar = -Pbar
-#pragma unroll
-    for (int j = 0; j < J; ++j) {
-      state[ws.bnd(2, c, j, draw)] = mb[j];
-#pragma unroll
-      for (int l = 0; l < J; ++l) state[ws.bnd(2, c, J + j * J + l, draw)] = -Pb[j][l];
-    }
-    if (c == 0) break;
-    double Ab[J][J], g[J], x[J], T[J][J];
-#pragma unroll
-    for (int j = 0; j < J; ++j) {
-      g[j] = state[ws.elem(c, ob + j, draw)];
-#pragma unroll
-      for (int l = 0; l < J; ++l) Ab[j][l] = state[ws.elem(c, oA + j * J + l, draw)];
-    }
-#pragma unroll
-    for (int j = 0; j < J; ++j) {
-      double xj = 0.0;
-#pragma unroll
-      for (int l = 0; l < J; ++l) {
-        xj = fma(Ab[l][j], mb[l], xj);
-        double tv = 0.0;
-#pragma unroll
-        for (int k = 0; k < J; ++k) tv = fma(Pb[j][k], Ab[k][l], tv);
-        T[j][l] = tv;
-      }
-      x[j] = xj;
-    }
-    double mbn[J], Pbn[J][J];
-#pragma unroll
-    for (int j = 0; j < J; ++j) {
-      mbn[j] = state[ws.elem(c, oeta + j, draw)] + x[j];
-#pragma unroll
-      for (int l = 0; l < J; ++l) {
-        double cong = state[ws.elem(c, oC + j * J + l, draw)];
-#pragma unroll
-        for (int k = 0; k < J; ++k) cong = fma(Ab[k][j], T[k][l], cong);
-        Pbn[j][l] = cong + 0.5 * (x[j] * g[l] + g[j] * x[l]);
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < J; ++j) {
-      mb[j] = mbn[j];
-#pragma unroll
-      for (int l = 0; l < J; ++l) Pb[j][l] = 0.5 * (Pbn[j][l] + Pbn[l][j]);
-    }
-  }
-}
-
 // (C) the ordinary recurrences inside every chunk, from the entering state: same lane layout as
 // celerite_fwd_kernel (a draw on G lanes), one wave per (64 / G draws, chunk).  With C x more
 // waves than the sequential kernel the loads are hidden by occupancy: no prefetch ring.
@@ -1495,7 +891,7 @@ template <int J>
 __global__ __launch_bounds__(kWave) void celerite_chunk_fwd_kernel(
     const double* __restrict__ t, Series rs, const double* __restrict__ diag, int64_t n_diag,
     int64_t n,
-    const double* __restrict__ coef_real, int n_real, const double* __restrict__ coef_complex, int n_complex,
+    Coefs cf,
     int64_t n_draw, double* __restrict__ state, ChunkGeom cg) {
   constexpr int G = Group<J>::G;
   const int j = threadIdx.x & (G - 1);
@@ -1504,11 +900,11 @@ __global__ __launch_bounds__(kWave) void celerite_chunk_fwd_kernel(
   const int64_t draw = live_draw ? lane_draw : n_draw - 1;
   const int c = blockIdx.y;
   const int64_t n0 = c * cg.L, n1 = (n0 + cg.L < n) ? n0 + cg.L : n;
-  const LaneCoef k = lane_coef(coef_real, n_real, coef_complex, n_complex, draw, j, J);
+  const LaneCoef k = lane_coef(cf, draw, j, J);
   const bool store = live_draw && k.live;
   const double asum = group_sum<G>((k.live && !k.odd) ? k.a : 0.0);
   const StateIdx six{n, n_draw, J};
-  const ChunkWs ws{n_draw, J, cg.C, cg.base};
+  const ChunkWs ws = chunk_ws(n, n_draw, J, cg);
   const SeriesRow y{rs.y + draw * n, rs.obs};
   const double* __restrict__ dg = diag + (n_diag == 1 ? 0 : draw * n);
   const int jj = k.live ? j : 0;
@@ -1582,29 +978,12 @@ __global__ __launch_bounds__(kWave) void celerite_chunk_fwd_kernel(
   }
 }
 
-// per-draw sum of the chunk partials, in chunk order
-__global__ __launch_bounds__(kWave) void celerite_chunk_loglike_kernel(int64_t n, int64_t n_draw, int J,
-                                                                       const double* __restrict__ state, ChunkGeom cg,
-                                                                       double* __restrict__ loglike) {
-  const int64_t draw = (int64_t)blockIdx.x * kWave + threadIdx.x;
-  if (draw >= n_draw) return;
-  const ChunkWs ws{n_draw, J, cg.C, cg.base};
-  double acc = 0.0, logdet = 0.0, bad = 0.0;
-  for (int c = 0; c < cg.C; ++c) {
-    acc += state[ws.part(c, 0, draw)];
-    logdet += state[ws.part(c, 1, draw)];
-    bad += state[ws.part(c, 2, draw)];
-  }
-  loglike[draw] = (bad > 0.0) ? -INFINITY : fma(-0.5, acc + logdet, -(double)n * kHalfLog2Pi);
-}
-
 // (C') the ordinary reverse recurrence inside every chunk.  It starts from the adjoint of the state
 // entering the NEXT chunk (from (B')) with the reverse of the propagation step into that chunk, and
 // ends with the measurement half of the chunk's first cadence.
 template <int J>
 __global__ __launch_bounds__(kWave) void celerite_chunk_vjp_kernel(
-    const double* __restrict__ t, int64_t n, const double* __restrict__ coef_real, int n_real,
-    const double* __restrict__ coef_complex, int n_complex, int64_t n_draw, const double* __restrict__ gloglike,
+    const double* __restrict__ t, int64_t n, Coefs cf, int64_t n_draw, const double* __restrict__ gloglike,
     double* __restrict__ state, ChunkGeom cg, double* __restrict__ gresid, double* __restrict__ gdiag,
     double gsign) {
   constexpr int G = Group<J>::G;
@@ -1614,10 +993,10 @@ __global__ __launch_bounds__(kWave) void celerite_chunk_vjp_kernel(
   const int64_t draw = live_draw ? lane_draw : n_draw - 1;
   const int c = blockIdx.y;
   const int64_t n0 = c * cg.L, n1 = (n0 + cg.L < n) ? n0 + cg.L : n;
-  const LaneCoef k = lane_coef(coef_real, n_real, coef_complex, n_complex, draw, j, J);
+  const LaneCoef k = lane_coef(cf, draw, j, J);
   const int jj = k.live ? j : 0;
   const StateIdx six{n, n_draw, J};
-  const ChunkWs ws{n_draw, J, cg.C, cg.base};
+  const ChunkWs ws = chunk_ws(n, n_draw, J, cg);
   const double gL = gloglike[draw];
   const int partner = (int)threadIdx.x + ((k.live && !k.real) ? (k.odd ? -1 : 1) : 0);
 
@@ -1768,91 +1147,140 @@ __global__ __launch_bounds__(kWave) void celerite_chunk_vjp_kernel(
   }
 }
 
-// coefficient cotangents, step 1: sum the chunk partials of one quantity k over the chunks in chunk
-// order (lanes are draws: coalesced), total left in chunk 0's slot
-__global__ __launch_bounds__(kWave) void celerite_chunk_gsum_kernel(int64_t n_draw, int J, double* __restrict__ state,
-                                                                    ChunkGeom cg) {
+// ---------------------------------------------------------------------------------------------
+// One lane per draw / per (draw, chunk): thin wrappers over exo_celerite_core.hpp (the same
+// functions the host harness of tests/ runs lane by lane).  Lanes of a wave are consecutive draws,
+// the chunk is blockIdx.y: every access to the chunk workspace and to the checkpoints is coalesced.
+// ---------------------------------------------------------------------------------------------
+// (A) the filtering element of every (draw, chunk)
+template <int J>
+__global__ __launch_bounds__(kWave) void celerite_elem_kernel(const double* __restrict__ t, Series rs,
+                                                              const double* __restrict__ diag, int64_t n_diag, int64_t n,
+                                                              Coefs cf, int64_t n_draw, double* __restrict__ state,
+                                                              ChunkGeom cg) {
   const int64_t draw = (int64_t)blockIdx.x * kWave + threadIdx.x;
   if (draw >= n_draw) return;
+  elem_lane<J>(t, rs, diag, n_diag, n, cf, n_draw, state, cg, draw, (int)blockIdx.y);
+}
+
+// (B) the state entering every chunk: C - 1 element applications per draw
+template <int J>
+__global__ __launch_bounds__(kWave) void celerite_bscan_kernel(const double* __restrict__ t, Coefs cf, int64_t n,
+                                                               int64_t n_draw, double* __restrict__ state, ChunkGeom cg) {
+  const int64_t draw = (int64_t)blockIdx.x * kWave + threadIdx.x;
+  if (draw >= n_draw) return;
+  bscan_lane<J>(t, cf, n, n_draw, state, cg, draw);
+}
+
+// (B') part 1 (all chunks in parallel; chunk 0's entering adjoint is never needed) and part 2 (the chain)
+template <int J>
+__global__ __launch_bounds__(kWave) void celerite_badj_prep_kernel(const double* __restrict__ gloglike, int64_t n,
+                                                                   int64_t n_draw, double* __restrict__ state,
+                                                                   ChunkGeom cg) {
+  const int64_t draw = (int64_t)blockIdx.x * kWave + threadIdx.x;
+  if (draw >= n_draw) return;
+  badj_prep_lane<J>(gloglike, n, n_draw, state, cg, draw, (int)blockIdx.y + 1);
+}
+template <int J>
+__global__ __launch_bounds__(kWave) void celerite_bscan_vjp_kernel(int64_t n, int64_t n_draw, double* __restrict__ state,
+                                                                   ChunkGeom cg) {
+  const int64_t draw = (int64_t)blockIdx.x * kWave + threadIdx.x;
+  if (draw >= n_draw) return;
+  bscan_vjp_lane<J>(n, n_draw, state, cg, draw);
+}
+
+// (C) / (C') with a checkpointed factorisation, J <= kLaneMaxJ
+template <int J>
+__global__ __launch_bounds__(kWave) void celerite_chunk1_fwd_kernel(const double* __restrict__ t, Series rs,
+                                                                    const double* __restrict__ diag, int64_t n_diag,
+                                                                    int64_t n, Coefs cf, int64_t n_draw,
+                                                                    double* __restrict__ state, ChunkGeom cg) {
+  const int64_t draw = (int64_t)blockIdx.x * kWave + threadIdx.x;
+  if (draw >= n_draw) return;
+  chunk1_fwd_lane<J>(t, rs, diag, n_diag, n, cf, n_draw, state, cg, draw, (int)blockIdx.y, true);
+}
+template <int J>
+__global__ __launch_bounds__(kWave) void celerite_chunk1_vjp_kernel(const double* __restrict__ t, Series rs,
+                                                                    const double* __restrict__ diag, int64_t n_diag,
+                                                                    int64_t n, Coefs cf, int64_t n_draw,
+                                                                    const double* __restrict__ gloglike,
+                                                                    double* __restrict__ state, ChunkGeom cg,
+                                                                    double* __restrict__ gresid, double* __restrict__ gdiag,
+                                                                    double gsign) {
+  const int64_t draw = (int64_t)blockIdx.x * kWave + threadIdx.x;
+  if (draw >= n_draw) return;
+  chunk1_vjp_lane<J>(t, rs, diag, n_diag, n, cf, n_draw, gloglike, state, cg, gresid, gdiag, gsign, draw, (int)blockIdx.y);
+}
+
+// sum over the wave in a fixed order (xor butterfly), result in every lane
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+  return v;
+}
+
+// per-draw sum of the chunk partials: one wave per draw, lane l takes chunks l, l + 64, ... in order
+__global__ __launch_bounds__(kWave) void celerite_chunk_loglike_kernel(int64_t n, int64_t n_draw, int J,
+                                                                       const double* __restrict__ state, ChunkGeom cg,
+                                                                       double* __restrict__ loglike) {
+  const int64_t draw = blockIdx.x;
+  const ChunkWs ws = chunk_ws(n, n_draw, J, cg);
+  double acc = 0.0, logdet = 0.0, bad = 0.0;
+  for (int c = threadIdx.x; c < cg.C; c += kWave) {
+    acc += state[ws.part(c, 0, draw)];
+    logdet += state[ws.part(c, 1, draw)];
+    bad += state[ws.part(c, 2, draw)];
+  }
+  acc = wave_sum(acc); logdet = wave_sum(logdet); bad = wave_sum(bad);
+  if (threadIdx.x == 0) loglike[draw] = (bad > 0.0) ? -INFINITY : fma(-0.5, acc + logdet, -(double)n * kHalfLog2Pi);
+}
+
+// coefficient cotangents, step 1: sum the chunk partials of quantity blockIdx.y of draw blockIdx.x
+// over the chunks (one wave each, fixed order), total left in chunk 0's slot
+__global__ __launch_bounds__(kWave) void celerite_chunk_gsum_kernel(int64_t n, int64_t n_draw, int J,
+                                                                    double* __restrict__ state, ChunkGeom cg) {
+  const int64_t draw = blockIdx.x;
   const int kk = blockIdx.y;
-  const ChunkWs ws{n_draw, J, cg.C, cg.base};
+  const ChunkWs ws = chunk_ws(n, n_draw, J, cg);
   double v = 0.0;
-  for (int c = 0; c < cg.C; ++c) v += state[ws.gpart(c, kk, draw)];
-  state[ws.gpart(0, kk, draw)] = v;
+  for (int c = threadIdx.x; c < cg.C; c += kWave) v += state[ws.gpart(c, kk, draw)];
+  v = wave_sum(v);
+  if (threadIdx.x == 0) state[ws.gpart(0, kk, draw)] = v;
 }
 
 // step 2: the same combination as the tail of celerite_vjp_kernel
-__global__ __launch_bounds__(kWave) void celerite_chunk_gcoef_kernel(int64_t n_draw, int n_real, int n_complex,
+__global__ __launch_bounds__(kWave) void celerite_chunk_gcoef_kernel(int64_t n, int64_t n_draw, Coefs cf,
                                                                      const double* __restrict__ state, ChunkGeom cg,
                                                                      double* __restrict__ gdiag_sum,
                                                                      double* __restrict__ gcoef_real,
                                                                      double* __restrict__ gcoef_complex) {
-  const int J = n_real + 2 * n_complex;
+  const int J = cf.J();
   const int64_t e = (int64_t)blockIdx.x * kWave + threadIdx.x;
   if (e >= n_draw * J) return;
   const int64_t draw = e / J;
-  const int j = (int)(e - draw * J);
-  const ChunkWs ws{n_draw, J, cg.C, cg.base};
-  auto total = [&](int kk) { return state[ws.gpart(0, kk, draw)]; };
-  const double gasum = total(4 * J);
-  if (j == 0 && gdiag_sum) gdiag_sum[draw] = gasum;
-  if (j < n_real) {
-    double* o = gcoef_real + (draw * n_real + j) * 2;
-    o[0] = total(4 * j) + gasum;
-    o[1] = total(4 * j + 2);
-  } else if (((j - n_real) & 1) == 0) {
-    double* o = gcoef_complex + (draw * n_complex + ((j - n_real) >> 1)) * 4;
-    o[0] = total(4 * j) + gasum;
-    o[1] = total(4 * j + 1);
-    o[2] = total(4 * j + 2) + total(4 * (j + 1) + 2);
-    o[3] = total(4 * j + 3);
-  }
-}
-
-// The chunk plan a forward call used, remembered per state buffer: the reverse call must cut the
-// series the same way even if EXO_GP_CHUNKS changed in between.
-struct PlanBook {
-  std::mutex mu;
-  std::unordered_map<const void*, ChunkGeom> used;
-  void put(const void* state, const ChunkGeom& g) {
-    std::lock_guard<std::mutex> lock(mu);
-    if (used.size() > 4096) used.clear();
-    used[state] = g;
-  }
-  bool get(const void* state, ChunkGeom* g) {
-    std::lock_guard<std::mutex> lock(mu);
-    const auto it = used.find(state);
-    if (it == used.end()) return false;
-    *g = it->second;
-    return true;
-  }
-};
-inline PlanBook& plan_book() {
-  static PlanBook b;
-  return b;
+  gcoef_lane(cf, n, n_draw, state, cg, gdiag_sum, gcoef_real, gcoef_complex, draw, (int)(e - draw * J));
 }
 
 inline int launch_status() { return hipGetLastError() == hipSuccess ? EXO_OK : EXO_ERR_LAUNCH; }
 
-inline bool gp_args_ok(int64_t n, int64_t n_diag, int32_t n_real, int32_t n_complex, int64_t n_draw) {
+inline bool gp_args_ok(int64_t n, int64_t n_diag, int32_t n_real, int32_t n_complex, int64_t n_draw, int32_t n_chunks) {
   const int J = n_real + 2 * n_complex;
   return n >= 1 && n_draw >= 1 && n_real >= 0 && n_complex >= 0 && J >= 1 && J <= EXO_GP_MAX_J &&
-         (n_diag == 1 || n_diag == n_draw);
+         (n_diag == 1 || n_diag == n_draw) && n_chunks >= 0;
 }
 
 }  // namespace
 
 extern "C" {
 
-int64_t exo_celerite_state_doubles(int64_t n, int64_t n_draw, int32_t n_real, int32_t n_complex) {
+int64_t exo_celerite_state_doubles(int64_t n, int64_t n_draw, int32_t n_real, int32_t n_complex, int32_t n_chunks) {
   const int64_t J = n_real + 2 * (int64_t)n_complex;
-  if (n < 0 || n_draw < 0 || J < 1) return -1;
-  const int64_t base = n * n_draw * (2 + 2 * J + J * J + 3 * J);
+  if (n < 0 || n_draw < 0 || J < 1 || J > EXO_GP_MAX_J || n_chunks < 0) return -1;
+  const int64_t base = seq_state_doubles(n, n_draw, (int)J);
   if (n == 0 || n_draw == 0) return base;
-  const ChunkGeom cg = chunk_plan(n, n_draw, (int)J);
+  const ChunkGeom cg = chunk_plan(n, n_draw, (int)J, n_chunks);
   if (cg.C <= 1) return base;
-  const ChunkWs ws{n_draw, (int)J, cg.C, base};
-  return base + ws.total();
+  return base + chunk_ws(n, n_draw, (int)J, cg).total();
 }
 
 #define EXO_GP_DISPATCH(J_, CALL) \
@@ -1867,173 +1295,170 @@ int64_t exo_celerite_state_doubles(int64_t n, int64_t n_draw, int32_t n_real, in
     case 8: { constexpr int JJ = 8; CALL; } break; \
     default: return EXO_ERR_INVALID_ARGUMENT;      \
   }
-
-#define EXO_GP_DISPATCH_SMALL(J_, CALL) \
-  switch (J_) {                         \
+// the one-lane chunk kernels exist for J <= kLaneMaxJ only
+#define EXO_GP_DISPATCH_LANE(J_, CALL) \
+  switch (J_) {                        \
     case 1: { constexpr int JJ = 1; CALL; } break; \
     case 2: { constexpr int JJ = 2; CALL; } break; \
-    case 3: { constexpr int JJ = 3; CALL; } break; \
-    case 4: { constexpr int JJ = 4; CALL; } break; \
-    case 5: { constexpr int JJ = 5; CALL; } break; \
-    case 6: { constexpr int JJ = 6; CALL; } break; \
-    case 7: { constexpr int JJ = 7; CALL; } break; \
-    case 8: { constexpr int JJ = 8; CALL; } break; \
     default: return EXO_ERR_INVALID_ARGUMENT;      \
   }
+static_assert(kLaneMaxJ == 2, "EXO_GP_DISPATCH_LANE lists the state widths of the one-lane path");
 
-static int celerite_fwd(const double* t, Series resid, const double* diag, int64_t n_diag, int64_t n,
-                        const double* coef_real, int32_t n_real, const double* coef_complex, int32_t n_complex,
-                        int64_t n_draw, double* loglike, double* state, int64_t state_doubles, void* stream) {
+static int celerite_fwd(const double* t, Series resid, const double* diag, int64_t n_diag, int64_t n, Coefs cf,
+                        int64_t n_draw, double* loglike, double* state, int64_t state_doubles, int32_t n_chunks,
+                        void* stream) {
   if (n_draw == 0) return EXO_OK;
-  if (!gp_args_ok(n, n_diag, n_real, n_complex, n_draw) || !t || !resid.y || !diag || !loglike ||
-      (n_real > 0 && !coef_real) || (n_complex > 0 && !coef_complex))
+  if (!gp_args_ok(n, n_diag, cf.n_real, cf.n_complex, n_draw, n_chunks) || !t || !resid.y || !diag || !loglike ||
+      (cf.n_real > 0 && !cf.real) || (cf.n_complex > 0 && !cf.cplx))
     return EXO_ERR_INVALID_ARGUMENT;
-  if (state && state_doubles < exo_celerite_state_doubles(n, n_draw, n_real, n_complex)) return EXO_ERR_WORKSPACE;
-  const int J = n_real + 2 * n_complex;
+  if (state && state_doubles < exo_celerite_state_doubles(n, n_draw, cf.n_real, cf.n_complex, n_chunks))
+    return EXO_ERR_WORKSPACE;
+  const int J = cf.J();
   const int G = J <= 1 ? 1 : (J <= 2 ? 2 : (J <= 4 ? 4 : 8));
   const int64_t per_wave = kWave / G;
   const dim3 grid((unsigned)((n_draw + per_wave - 1) / per_wave)), block(kWave);
   hipStream_t st = (hipStream_t)stream;
   if (state) {
-    ChunkGeom cg = chunk_plan(n, n_draw, J);
-    cg.base = n * n_draw * (int64_t)(2 + 2 * J + J * J + 3 * J);
-    if (cg.C > 1) {
-      // the caller sized `state` with exo_celerite_state_doubles(), possibly under another setting
-      const ChunkWs need{n_draw, J, cg.C, cg.base};
-      if (state_doubles < cg.base + need.total()) { cg.C = 1; cg.L = n; }
-    }
-    plan_book().put(state, cg);
+    const ChunkGeom cg = chunk_plan(n, n_draw, J, n_chunks);
     const double* only_flagged = nullptr;
     if (cg.C <= 1) {
       const int64_t n_el = n * n_draw * J;
-      hipLaunchKernelGGL(celerite_prep_kernel, dim3((unsigned)((n_el + 255) / 256)), dim3(256), 0, st, t, n,
-                         coef_real, n_real, coef_complex, n_complex, n_draw, J, state);
+      hipLaunchKernelGGL(celerite_prep_kernel, dim3((unsigned)((n_el + 255) / 256)), dim3(256), 0, st, t, n, cf, n_draw,
+                         J, state);
       if (launch_status() != EXO_OK) return EXO_ERR_LAUNCH;
     } else {
       // time-parallel path: flags (+ pre-pass for flagged draws), elements, entering states,
       // recurrences per chunk, sum of the partials
-      const ChunkWs ws{n_draw, J, cg.C, cg.base};
+      const ChunkWs ws = chunk_ws(n, n_draw, J, cg);
       const dim3 per_draw((unsigned)((n_draw + kWave - 1) / kWave));
-      EXO_GP_DISPATCH_SMALL(J, hipLaunchKernelGGL((celerite_flag_kernel<JJ>), per_draw, block, 0, st, coef_real, n_real,
-                                                  coef_complex, n_complex, n_draw, state + ws.off_flag()))
-
+      EXO_GP_DISPATCH(J, hipLaunchKernelGGL((celerite_flag_kernel<JJ>), per_draw, block, 0, st, cf, n_draw,
+                                            state + ws.off_flag()))
       const dim3 egrid(per_draw.x, (unsigned)cg.C), cgrid(grid.x, (unsigned)cg.C);
 #ifndef EXO_ELEM_LG_MIN_J
 #define EXO_ELEM_LG_MIN_J 7
 #endif
       if (J >= EXO_ELEM_LG_MIN_J) {   // the one-lane element kernel is as fast up to J = 6 and does not fit beyond
-        EXO_GP_DISPATCH_SMALL(J, hipLaunchKernelGGL((celerite_elem_lg_kernel<JJ>), cgrid, block, 0, st, t, resid, diag,
-                                                    n_diag, n, coef_real, n_real, coef_complex, n_complex, n_draw,
-                                                    state, cg))
+        EXO_GP_DISPATCH(J, hipLaunchKernelGGL((celerite_elem_lg_kernel<JJ>), cgrid, block, 0, st, t, resid, diag, n_diag,
+                                              n, cf, n_draw, state, cg))
       } else {
-        EXO_GP_DISPATCH_SMALL(J, hipLaunchKernelGGL((celerite_elem_kernel<JJ>), egrid, block, 0, st, t, resid, diag,
-                                                    n_diag, n, coef_real, n_real, coef_complex, n_complex, n_draw,
-                                                    state, cg))
+        EXO_GP_DISPATCH(J, hipLaunchKernelGGL((celerite_elem_kernel<JJ>), egrid, block, 0, st, t, resid, diag, n_diag, n,
+                                              cf, n_draw, state, cg))
       }
       // after the element kernel: it may flag more draws (measurement variance too small)
-      hipLaunchKernelGGL(celerite_prep_flagged_kernel, dim3(8, (unsigned)n_draw), dim3(256), 0, st, t, n, coef_real,
-                         n_real, coef_complex, n_complex, n_draw, J, state, state + ws.off_flag());
+      hipLaunchKernelGGL(celerite_prep_flagged_kernel, dim3(8, (unsigned)n_draw), dim3(256), 0, st, t, n, cf, n_draw, J,
+                         state, state + ws.off_flag());
       if (J >= 3) {
-        EXO_GP_DISPATCH_SMALL(J, hipLaunchKernelGGL((celerite_bscan_lg_kernel<JJ>), grid, block, 0, st, t, coef_real,
-                                                    n_real, coef_complex, n_complex, n, n_draw, state, cg))
+        EXO_GP_DISPATCH(J, hipLaunchKernelGGL((celerite_bscan_lg_kernel<JJ>), grid, block, 0, st, t, cf, n, n_draw, state,
+                                              cg))
       } else {
-        EXO_GP_DISPATCH_SMALL(J, hipLaunchKernelGGL((celerite_bscan_kernel<JJ>), per_draw, block, 0, st, t, coef_real,
-                                                    n_real, coef_complex, n_complex, n, n_draw, state, cg))
+        EXO_GP_DISPATCH(J, hipLaunchKernelGGL((celerite_bscan_kernel<JJ>), per_draw, block, 0, st, t, cf, n, n_draw, state,
+                                              cg))
       }
-      EXO_GP_DISPATCH_SMALL(J, hipLaunchKernelGGL((celerite_chunk_fwd_kernel<JJ>), cgrid, block, 0, st, t, resid, diag,
-                                                  n_diag, n, coef_real, n_real, coef_complex, n_complex, n_draw, state,
-                                                  cg))
-      hipLaunchKernelGGL(celerite_chunk_loglike_kernel, per_draw, block, 0, st, n, n_draw, J, state, cg, loglike);
+      if (cg.lane) {
+        EXO_GP_DISPATCH_LANE(J, hipLaunchKernelGGL((celerite_chunk1_fwd_kernel<JJ>), egrid, block, 0, st, t, resid, diag,
+                                                   n_diag, n, cf, n_draw, state, cg))
+      } else {
+        EXO_GP_DISPATCH(J, hipLaunchKernelGGL((celerite_chunk_fwd_kernel<JJ>), cgrid, block, 0, st, t, resid, diag, n_diag,
+                                              n, cf, n_draw, state, cg))
+      }
+      hipLaunchKernelGGL(celerite_chunk_loglike_kernel, dim3((unsigned)n_draw), block, 0, st, n, n_draw, J, state, cg,
+                         loglike);
       if (launch_status() != EXO_OK) return EXO_ERR_LAUNCH;
       only_flagged = state + ws.off_flag();
     }
-    EXO_GP_DISPATCH(J, hipLaunchKernelGGL((celerite_fwd_kernel<JJ, true>), grid, block, 0, st, t, resid, diag, n_diag,
-                                          n, coef_real, n_real, coef_complex, n_complex, n_draw, loglike, state,
-                                          only_flagged))
+    EXO_GP_DISPATCH(J, hipLaunchKernelGGL((celerite_fwd_kernel<JJ, true>), grid, block, 0, st, t, resid, diag, n_diag, n,
+                                          cf, n_draw, loglike, state, only_flagged))
   } else {
-    EXO_GP_DISPATCH(J, hipLaunchKernelGGL((celerite_fwd_kernel<JJ, false>), grid, block, 0, st, t, resid, diag,
-                                          n_diag, n, coef_real, n_real, coef_complex, n_complex, n_draw, loglike,
-                                          state, (const double*)nullptr))
+    EXO_GP_DISPATCH(J, hipLaunchKernelGGL((celerite_fwd_kernel<JJ, false>), grid, block, 0, st, t, resid, diag, n_diag, n,
+                                          cf, n_draw, loglike, state, (const double*)nullptr))
   }
   return launch_status();
 }
 
-static int celerite_vjp(const double* t, const double* diag, int64_t n_diag, int64_t n, const double* coef_real,
-                        int32_t n_real, const double* coef_complex, int32_t n_complex, int64_t n_draw,
-                        const double* gloglike, const double* state, double* gresid, double gsign, double* gdiag,
-                        double* gdiag_sum, double* gcoef_real, double* gcoef_complex, void* stream) {
+static int celerite_vjp(const double* t, Series resid, const double* diag, int64_t n_diag, int64_t n, Coefs cf,
+                        int64_t n_draw, const double* gloglike, const double* state, int64_t state_doubles,
+                        int32_t n_chunks, double* gresid, double gsign, double* gdiag, double* gdiag_sum,
+                        double* gcoef_real, double* gcoef_complex, void* stream) {
   if (n_draw == 0) return EXO_OK;
-  if (!gp_args_ok(n, n_diag, n_real, n_complex, n_draw) || !t || !diag || !gloglike || !state || !gresid ||
-      (n_real > 0 && (!coef_real || !gcoef_real)) || (n_complex > 0 && (!coef_complex || !gcoef_complex)))
+  if (!gp_args_ok(n, n_diag, cf.n_real, cf.n_complex, n_draw, n_chunks) || !t || !resid.y || !diag || !gloglike ||
+      !state || !gresid || (cf.n_real > 0 && (!cf.real || !gcoef_real)) ||
+      (cf.n_complex > 0 && (!cf.cplx || !gcoef_complex)))
     return EXO_ERR_INVALID_ARGUMENT;
-  const int J = n_real + 2 * n_complex;
+  if (state_doubles < exo_celerite_state_doubles(n, n_draw, cf.n_real, cf.n_complex, n_chunks)) return EXO_ERR_WORKSPACE;
+  const int J = cf.J();
   const int G = J <= 1 ? 1 : (J <= 2 ? 2 : (J <= 4 ? 4 : 8));
   const int64_t per_wave = kWave / G;
   const dim3 grid((unsigned)((n_draw + per_wave - 1) / per_wave)), block(kWave);
   hipStream_t st = (hipStream_t)stream;
-  ChunkGeom cg;
-  if (!plan_book().get(state, &cg)) {   // a state buffer this process did not fill: the default plan
-    cg = chunk_plan(n, n_draw, J);
-    cg.base = n * n_draw * (int64_t)(2 + 2 * J + J * J + 3 * J);
-  }
+  const ChunkGeom cg = chunk_plan(n, n_draw, J, n_chunks);   // the same plan as the forward call's
   const double* only_flagged = nullptr;
   if (cg.C > 1) {
     double* wstate = const_cast<double*>(state);   // the chunk workspace lives behind the saved factorisation
-    const ChunkWs ws{n_draw, J, cg.C, cg.base};
-    const dim3 per_draw((unsigned)((n_draw + kWave - 1) / kWave)), cgrid(grid.x, (unsigned)cg.C);
-    EXO_GP_DISPATCH_SMALL(J, hipLaunchKernelGGL((celerite_badj_prep_kernel<JJ>), dim3(per_draw.x, (unsigned)(cg.C - 1)),
-                                                block, 0, st, gloglike, n_draw, wstate, cg))
-    EXO_GP_DISPATCH_SMALL(J, hipLaunchKernelGGL((celerite_bscan_vjp_kernel<JJ>), per_draw, block, 0, st, n_draw, wstate,
-                                                cg))
-    EXO_GP_DISPATCH_SMALL(J, hipLaunchKernelGGL((celerite_chunk_vjp_kernel<JJ>), cgrid, block, 0, st, t, n, coef_real,
-                                                n_real, coef_complex, n_complex, n_draw, gloglike, wstate, cg, gresid,
-                                                gdiag, gsign))
-    hipLaunchKernelGGL(celerite_chunk_gsum_kernel, dim3(per_draw.x, (unsigned)(4 * J + 1)), block, 0, st, n_draw, J,
-                       wstate, cg);
-    hipLaunchKernelGGL(celerite_chunk_gcoef_kernel, dim3((unsigned)((n_draw * J + kWave - 1) / kWave)), block, 0, st,
-                       n_draw, n_real, n_complex, state, cg, gdiag_sum, gcoef_real, gcoef_complex);
+    const ChunkWs ws = chunk_ws(n, n_draw, J, cg);
+    const dim3 per_draw((unsigned)((n_draw + kWave - 1) / kWave)), cgrid(grid.x, (unsigned)cg.C),
+        egrid(per_draw.x, (unsigned)cg.C);
+    EXO_GP_DISPATCH(J, hipLaunchKernelGGL((celerite_badj_prep_kernel<JJ>), dim3(per_draw.x, (unsigned)(cg.C - 1)), block,
+                                          0, st, gloglike, n, n_draw, wstate, cg))
+    EXO_GP_DISPATCH(J, hipLaunchKernelGGL((celerite_bscan_vjp_kernel<JJ>), per_draw, block, 0, st, n, n_draw, wstate, cg))
+    if (cg.lane) {
+      EXO_GP_DISPATCH_LANE(J, hipLaunchKernelGGL((celerite_chunk1_vjp_kernel<JJ>), egrid, block, 0, st, t, resid, diag,
+                                                 n_diag, n, cf, n_draw, gloglike, wstate, cg, gresid, gdiag, gsign))
+    } else {
+      EXO_GP_DISPATCH(J, hipLaunchKernelGGL((celerite_chunk_vjp_kernel<JJ>), cgrid, block, 0, st, t, n, cf, n_draw,
+                                            gloglike, wstate, cg, gresid, gdiag, gsign))
+    }
+    hipLaunchKernelGGL(celerite_chunk_gsum_kernel, dim3((unsigned)n_draw, (unsigned)(4 * J + 1)), block, 0, st, n, n_draw,
+                       J, wstate, cg);
+    hipLaunchKernelGGL(celerite_chunk_gcoef_kernel, dim3((unsigned)((n_draw * J + kWave - 1) / kWave)), block, 0, st, n,
+                       n_draw, cf, state, cg, gdiag_sum, gcoef_real, gcoef_complex);
     if (launch_status() != EXO_OK) return EXO_ERR_LAUNCH;
     only_flagged = state + ws.off_flag();
   }
-  EXO_GP_DISPATCH(J, hipLaunchKernelGGL((celerite_vjp_kernel<JJ>), grid, block, 0, st, t, diag, n_diag, n, coef_real,
-                                        n_real, coef_complex, n_complex, n_draw, gloglike, state, gresid, gdiag,
-                                        gdiag_sum, gcoef_real, gcoef_complex, only_flagged, gsign))
+  EXO_GP_DISPATCH(J, hipLaunchKernelGGL((celerite_vjp_kernel<JJ>), grid, block, 0, st, t, diag, n_diag, n, cf, n_draw,
+                                        gloglike, state, gresid, gdiag, gdiag_sum, gcoef_real, gcoef_complex,
+                                        only_flagged, gsign))
   return launch_status();
 }
 
 int exo_celerite_loglike_fwd_f64(const double* t, const double* resid, const double* diag, int64_t n_diag,
                                  int64_t n, const double* coef_real, int32_t n_real, const double* coef_complex,
-                                 int32_t n_complex, int64_t n_draw, double* loglike, double* state,
-                                 int64_t state_doubles, void* stream) {
-  return celerite_fwd(t, Series{resid, nullptr}, diag, n_diag, n, coef_real, n_real, coef_complex, n_complex, n_draw,
-                      loglike, state, state_doubles, stream);
+                                 int32_t n_complex, const int32_t* pair_kind, int64_t n_draw, double* loglike,
+                                 double* state, int64_t state_doubles, int32_t n_chunks, void* stream) {
+  return celerite_fwd(t, Series{resid, nullptr}, diag, n_diag, n, Coefs{coef_real, coef_complex, pair_kind, n_real, n_complex},
+                      n_draw, loglike, state, state_doubles, n_chunks, stream);
 }
 
-int exo_celerite_loglike_vjp_f64(const double* t, const double* diag, int64_t n_diag, int64_t n,
+int exo_celerite_loglike_vjp_f64(const double* t, const double* resid, const double* diag, int64_t n_diag, int64_t n,
                                  const double* coef_real, int32_t n_real, const double* coef_complex,
-                                 int32_t n_complex, int64_t n_draw, const double* gloglike, const double* state,
-                                 double* gresid, double* gdiag, double* gdiag_sum, double* gcoef_real,
-                                 double* gcoef_complex, void* stream) {
-  return celerite_vjp(t, diag, n_diag, n, coef_real, n_real, coef_complex, n_complex, n_draw, gloglike, state, gresid,
-                      1.0, gdiag, gdiag_sum, gcoef_real, gcoef_complex, stream);
+                                 int32_t n_complex, const int32_t* pair_kind, int64_t n_draw, const double* gloglike,
+                                 const double* state, int64_t state_doubles, int32_t n_chunks, double* gresid,
+                                 double* gdiag, double* gdiag_sum, double* gcoef_real, double* gcoef_complex,
+                                 void* stream) {
+  return celerite_vjp(t, Series{resid, nullptr}, diag, n_diag, n, Coefs{coef_real, coef_complex, pair_kind, n_real, n_complex},
+                      n_draw, gloglike, state, state_doubles, n_chunks, gresid, 1.0, gdiag, gdiag_sum, gcoef_real,
+                      gcoef_complex, stream);
 }
 
 int exo_celerite_loglike_obs_fwd_f64(const double* t, const double* obs, const double* model, const double* diag,
                                      int64_t n_diag, int64_t n, const double* coef_real, int32_t n_real,
-                                     const double* coef_complex, int32_t n_complex, int64_t n_draw, double* loglike,
-                                     double* state, int64_t state_doubles, void* stream) {
+                                     const double* coef_complex, int32_t n_complex, const int32_t* pair_kind,
+                                     int64_t n_draw, double* loglike, double* state, int64_t state_doubles,
+                                     int32_t n_chunks, void* stream) {
   if (n_draw > 0 && !obs) return EXO_ERR_INVALID_ARGUMENT;
-  return celerite_fwd(t, Series{model, obs}, diag, n_diag, n, coef_real, n_real, coef_complex, n_complex, n_draw,
-                      loglike, state, state_doubles, stream);
+  return celerite_fwd(t, Series{model, obs}, diag, n_diag, n, Coefs{coef_real, coef_complex, pair_kind, n_real, n_complex},
+                      n_draw, loglike, state, state_doubles, n_chunks, stream);
 }
 
-int exo_celerite_loglike_obs_vjp_f64(const double* t, const double* diag, int64_t n_diag, int64_t n,
-                                     const double* coef_real, int32_t n_real, const double* coef_complex,
-                                     int32_t n_complex, int64_t n_draw, const double* gloglike, const double* state,
-                                     double* gmodel, double* gdiag, double* gdiag_sum, double* gcoef_real,
-                                     double* gcoef_complex, void* stream) {
-  return celerite_vjp(t, diag, n_diag, n, coef_real, n_real, coef_complex, n_complex, n_draw, gloglike, state, gmodel,
-                      -1.0, gdiag, gdiag_sum, gcoef_real, gcoef_complex, stream);
+int exo_celerite_loglike_obs_vjp_f64(const double* t, const double* obs, const double* model, const double* diag,
+                                     int64_t n_diag, int64_t n, const double* coef_real, int32_t n_real,
+                                     const double* coef_complex, int32_t n_complex, const int32_t* pair_kind,
+                                     int64_t n_draw, const double* gloglike, const double* state,
+                                     int64_t state_doubles, int32_t n_chunks, double* gmodel, double* gdiag,
+                                     double* gdiag_sum, double* gcoef_real, double* gcoef_complex, void* stream) {
+  if (n_draw > 0 && !obs) return EXO_ERR_INVALID_ARGUMENT;
+  return celerite_vjp(t, Series{model, obs}, diag, n_diag, n, Coefs{coef_real, coef_complex, pair_kind, n_real, n_complex},
+                      n_draw, gloglike, state, state_doubles, n_chunks, gmodel, -1.0, gdiag, gdiag_sum, gcoef_real,
+                      gcoef_complex, stream);
 }
 
 }  // extern "C"

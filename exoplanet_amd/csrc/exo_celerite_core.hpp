@@ -1,0 +1,1085 @@
+// exo_celerite_core.hpp -- the one-lane-per-(draw, chunk) half of the celerite path: term
+// coefficients, the chunk workspace, the Kalman filtering elements and the scans over them, and
+// the recurrences inside a chunk with a CHECKPOINTED factorisation (forward saves the recurrence
+// state every kCkptB cadences; the reverse pass recomputes the cadences of a block from its
+// checkpoint in registers).  Nothing here exchanges data between lanes, so the same code compiles
+// for the host (g++, EXO_HOST_BUILD: tests/gp_host_harness.cpp runs the whole time-parallel
+// pipeline on the CPU against the oracle) and for gfx950, where a lane is a (draw, chunk) and the
+// kernels of exo_celerite.hip are thin wrappers.  Algorithm: exo_celerite.hip header comment and
+// DESIGN.md 3.4 / 3.5 (celerite2 is a dependency of the reference, /root/reference/setup.py:36;
+// the recurrences are the published ones).
+#pragma once
+#include <math.h>
+#include <stdint.h>
+
+#include "exo_math.hpp"
+
+#ifdef EXO_HOST_BUILD
+#define EXO_HDH inline
+#define EXO_RESTRICT __restrict__
+#else
+#define EXO_HDH __host__ __device__ inline
+#define EXO_RESTRICT __restrict__
+#endif
+
+namespace gp {
+
+constexpr double kHalfLog2Pi = 0.91893853320467274178;
+constexpr int kCkptB = 4;   // cadences per checkpoint block of the one-lane chunk kernels
+
+// Term coefficients of a batch of draws, celerite2's Term.get_coefficients() form:
+//   real  [n_draw][n_real][2]     (a, c)
+//   cplx  [n_draw][n_complex][4]  (a, b, c, d)            kind 0 (or kind == nullptr)
+//                                 (a1, c1, a2, c2)         kind 1: the slot holds TWO REAL terms
+//   kind  [n_draw][n_complex] or nullptr
+// A pair slot occupies two state indices either way, so a batch may mix both kinds draw by draw
+// (an SHO term is one complex term for Q >= 1/2 and two real ones for Q < 1/2).
+struct Coefs {
+  const double* real;
+  const double* cplx;
+  const int32_t* kind;
+  int n_real, n_complex;
+  EXO_HDH int J() const { return n_real + 2 * n_complex; }
+};
+
+// per-state-index view: state index j of a real term (a, c) or of a complex pair (a, b, c, d);
+// `odd` marks the second index of a complex pair; `slot` = where the cotangents of a real term go
+// (-1: its own row of gcoef_real; >= 0: doubles slot, slot + 1 of the draw's pair-slot block)
+struct LaneCoef {
+  double a, b, c, d;
+  bool real, odd, live;
+  int slot;
+};
+
+EXO_HD LaneCoef lane_coef(const Coefs& co, int64_t draw, int j, int J) {
+  LaneCoef k;
+  k.live = j < J;
+  k.real = j < co.n_real;
+  k.odd = false;
+  k.slot = -1;
+  k.a = k.b = k.c = k.d = 0.0;
+  if (!k.live) return k;
+  if (k.real) {
+    const double* p = co.real + (draw * co.n_real + j) * 2;
+    k.a = p[0]; k.c = p[1];
+  } else {
+    const int jc = (j - co.n_real) >> 1, second = (j - co.n_real) & 1;
+    const double* p = co.cplx + (draw * co.n_complex + jc) * 4;
+    const bool two_real = co.kind && co.kind[draw * co.n_complex + jc] != 0;
+    if (two_real) {
+      k.real = true;
+      k.a = p[2 * second]; k.c = p[2 * second + 1];
+      k.slot = jc * 4 + 2 * second;
+    } else {
+      k.a = p[0]; k.b = p[1]; k.c = p[2]; k.d = p[3];
+      k.odd = second != 0;
+    }
+  }
+  return k;
+}
+
+// U_j, V_j of SURVEY Appendix B at time t for one state index
+EXO_HD void lane_uv(const LaneCoef& k, double t, double* U, double* V, double* cs, double* sn) {
+  if (k.real || !k.live) {
+    *U = k.live ? k.a : 0.0;
+    *V = k.live ? 1.0 : 0.0;
+    *cs = 1.0; *sn = 0.0;
+    return;
+  }
+  double s, c;
+  exo::sincos_any(k.d * t, &s, &c);   // branch-free, no large-argument path: half the instructions and registers of libm's
+  *cs = c; *sn = s;
+  *U = k.odd ? (k.a * s - k.b * c) : (k.a * c + k.b * s);
+  *V = k.odd ? s : c;
+}
+
+// The series the likelihood is evaluated on: y[draw][n] as given, or -- obs != nullptr -- the
+// residual obs[n] - y[draw][n] of a per-draw model against one observed series, formed on the
+// fly (the subtraction, and the sign flip of its cotangent, never cross HBM as arrays).
+struct Series {
+  const double* y;
+  const double* obs;
+};
+struct SeriesRow {
+  const double* EXO_RESTRICT y;
+  const double* EXO_RESTRICT obs;
+  EXO_HD double operator[](int64_t i) const { return obs ? obs[i] - y[i] : y[i]; }
+};
+
+struct ChunkGeom {
+  int C;        // chunks
+  int64_t L;    // cadences per chunk (the last may be shorter); a multiple of kCkptB on the one-lane path
+  int64_t base; // first double of the chunk workspace inside `state`
+  int lane;     // 1: one-lane chunk kernels with a checkpointed factorisation; 0: lane-group kernels, full factorisation
+};
+
+// chunk workspace, all [chunk][quantity][draw] (a lane is a draw: coalesced)
+struct ChunkWs {
+  int64_t n_draw;
+  int J, C;
+  int64_t base;
+  int64_t n_blk;   // checkpoint blocks (0 on the lane-group path)
+  EXO_HDH int E() const { return 3 * J * J + 2 * J; }   // A, b, Cm, eta, Jm
+  EXO_HDH int B() const { return J + J * J; }           // vector + matrix
+  EXO_HDH int K() const { return J + J * (J + 1) / 2; } // checkpoint: F + packed symmetric S
+  EXO_HDH int64_t elem(int c, int e, int64_t draw) const { return base + ((int64_t)c * E() + e) * n_draw + draw; }
+  EXO_HDH int64_t off_bnd() const { return base + (int64_t)C * E() * n_draw; }
+  // q = 1: (F, P) entering chunk c;  2: adjoint of (F, S) entering chunk c + 1  (0: unused)
+  EXO_HDH int64_t bnd(int q, int c, int k, int64_t draw) const {
+    return off_bnd() + (((int64_t)q * C + c) * B() + k) * n_draw + draw;
+  }
+  EXO_HDH int64_t off_part() const { return off_bnd() + (int64_t)3 * C * B() * n_draw; }
+  EXO_HDH int64_t part(int c, int k, int64_t draw) const {  // k = 0 acc, 1 logdet, 2 bad
+    return off_part() + ((int64_t)c * 3 + k) * n_draw + draw;
+  }
+  EXO_HDH int64_t off_gpart() const { return off_part() + (int64_t)3 * C * n_draw; }
+  EXO_HDH int64_t gpart(int c, int k, int64_t draw) const {  // k = 4 j + {a, b, c, d}; 4 J = gasum
+    return off_gpart() + ((int64_t)c * (4 * J + 1) + k) * n_draw + draw;
+  }
+  EXO_HDH int64_t off_flag() const { return off_gpart() + (int64_t)C * (4 * J + 1) * n_draw; }
+  EXO_HDH int64_t off_ckpt() const { return off_flag() + n_draw; }
+  // checkpoint of global block g (cadences [g kCkptB, (g + 1) kCkptB)): k < J: F_k; then packed S
+  EXO_HDH int64_t ckpt(int64_t g, int k, int64_t draw) const { return off_ckpt() + (g * K() + k) * n_draw + draw; }
+  EXO_HDH int64_t total() const { return off_ckpt() + n_blk * K() * n_draw - base; }
+};
+
+constexpr int kChunkMaxJ = 8;   // = EXO_GP_MAX_J (J = 7, 8: lane-group element kernel, one-lane scan kernels spill)
+#ifndef EXO_LANE_MAX_J
+#define EXO_LANE_MAX_J 2
+#endif
+constexpr int kLaneMaxJ = EXO_LANE_MAX_J;   // one-lane chunk kernels up to this state width (registers: DESIGN.md 4)
+
+// doubles of the full saved factorisation (sequential / lane-group layout) at the head of `state`
+EXO_HDH int64_t seq_state_doubles(int64_t n, int64_t n_draw, int J) {
+  return n * n_draw * (int64_t)(2 + 2 * J + J * J + 3 * J);
+}
+
+// How a series is cut.  n_chunks = 0: the default plan; 1: sequential; > 1: forced.  A pure
+// function of its arguments: the forward and the reverse call of a pair compute the same plan.
+EXO_HDH ChunkGeom chunk_plan(int64_t n, int64_t n_draw, int J, int32_t n_chunks) {
+  ChunkGeom g{1, n, seq_state_doubles(n, n_draw, J), 0};
+  if (J > kChunkMaxJ || J < 1 || n < 64) return g;
+  const bool lane = J <= kLaneMaxJ;
+  int64_t C;
+  if (n_chunks > 0) {
+    C = n_chunks;
+  } else if (lane) {
+    // one lane per (draw, chunk): ~4 waves per SIMD (4096 waves of 64 lanes)
+    C = (64 * 4096) / n_draw;
+    if (C > 512) C = 512;
+    if (C < 4) C = 4;
+  } else {
+    const int G = J <= 1 ? 1 : (J <= 2 ? 2 : (J <= 4 ? 4 : 8));
+    // ~2 waves per SIMD for the lane-group chunk kernels
+    C = (64 * 2048) / (n_draw * G);
+    if (C > 512) C = 512;
+    if (C < 4) C = 1;
+  }
+  if (C > n / 32) C = n / 32;        // chunks of at least 32 cadences
+  if (C < 2) return g;
+  g.L = (n + C - 1) / C;
+  if (lane) g.L = (g.L + kCkptB - 1) / kCkptB * kCkptB;
+  g.C = (int)((n + g.L - 1) / g.L);
+  if (g.C < 2) { g.C = 1; g.L = n; return g; }
+  g.lane = lane ? 1 : 0;
+  return g;
+}
+
+EXO_HDH ChunkWs chunk_ws(int64_t n, int64_t n_draw, int J, const ChunkGeom& g) {
+  return ChunkWs{n_draw, J, g.C, g.base, g.lane ? (n + kCkptB - 1) / kCkptB : 0};
+}
+
+// symmetric J x J in packed upper-triangular storage
+template <int J>
+struct Sym {
+  double v[J * (J + 1) / 2];
+  EXO_HD static constexpr int idx(int j, int l) {
+    return j <= l ? j * J - j * (j - 1) / 2 + (l - j) : l * J - l * (l - 1) / 2 + (j - l);
+  }
+  EXO_HD double& operator()(int j, int l) { return v[idx(j, l)]; }
+  EXO_HD double operator()(int j, int l) const { return v[idx(j, l)]; }
+};
+
+// Delta_n of one draw from its term coefficients and V_n (block diagonal: 1x1 / 2x2 blocks).
+// Delta is symmetric with Delta_n U_n = V_n: the state covariance of the process the kernel
+// describes, in celerite's rotating frame (exo_celerite.hip, "Time-parallel path").
+template <int J>
+struct DeltaCoef {
+  double p[J], q[J], r[J];   // per state index: real term -> p = 1/a; pair -> (p, q, r) on both indices
+  bool real[J], first[J];    // first: first index of a complex pair
+  bool valid;
+  EXO_HD void init(const Coefs& co, int64_t draw) {
+    valid = true;
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      const LaneCoef k = lane_coef(co, draw, j, J);
+      real[j] = k.real;
+      first[j] = !k.real && !k.odd;
+      if (k.real) {
+        p[j] = 1.0 / k.a; q[j] = 0.0; r[j] = 0.0;
+        valid = valid && (k.a > 0.0) && (k.c >= 0.0) && (k.a < INFINITY) && (k.c < INFINITY);
+      } else {
+        const double a = k.a, b = k.b, c = k.c, d = k.d;
+        const double h = 1.0 / (a * a + b * b);
+        r[j] = a * h; q[j] = -b * h; p[j] = (a * a + 2.0 * b * b) * h / a;
+        valid = valid && (a > 0.0) && (fabs(b * d) <= a * c * (1.0 + 1e-12)) && (a < INFINITY) && (fabs(b) < INFINITY) &&
+                (c < INFINITY) && (fabs(d) < INFINITY);
+      }
+    }
+  }
+  // Delta (packed) from V (cos / sin of each pair)
+  EXO_HD void eval(const double* V, Sym<J>& D) const {
+#pragma unroll
+    for (int k = 0; k < J * (J + 1) / 2; ++k) D.v[k] = 0.0;
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      if (real[j]) {
+        D(j, j) = p[j];
+      } else if (first[j] && j + 1 < J) {
+        const double cs = V[j], sn = V[j + 1];
+        D(j, j) = p[j] * cs * cs + 2.0 * q[j] * cs * sn + r[j] * sn * sn;
+        D(j, j + 1) = (p[j] - r[j]) * cs * sn + q[j] * (sn * sn - cs * cs);
+        D(j + 1, j + 1) = p[j] * sn * sn - 2.0 * q[j] * cs * sn + r[j] * cs * cs;
+      }
+    }
+  }
+};
+
+// U_n, V_n for all J state indices of one draw (one sincos per complex pair); same arithmetic as
+// lane_uv, so the values are those the lane-group kernels compute
+template <int J>
+struct DrawCoef {
+  LaneCoef k[J];
+  EXO_HD void init(const Coefs& co, int64_t draw) {
+#pragma unroll
+    for (int j = 0; j < J; ++j) k[j] = lane_coef(co, draw, j, J);
+  }
+  EXO_HD void uv(double t, double* U, double* V) const {
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      if (k[j].real) {
+        U[j] = k[j].a; V[j] = 1.0;
+      } else if (!k[j].odd) {
+        double sn, cs;
+        exo::sincos_any(k[j].d * t, &sn, &cs);
+        U[j] = k[j].a * cs + k[j].b * sn; V[j] = cs;
+        if (j + 1 < J) { U[j + 1] = k[j].a * sn - k[j].b * cs; V[j + 1] = sn; }
+      }
+    }
+  }
+  // U from V alone (V of a pair is (cos, sin)): the reverse pass keeps V and rebuilds U
+  EXO_HD void u_from_v(const double* V, double* U) const {
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      if (k[j].real) {
+        U[j] = k[j].a;
+      } else if (!k[j].odd && j + 1 < J) {
+        U[j] = k[j].a * V[j] + k[j].b * V[j + 1];
+        U[j + 1] = k[j].a * V[j + 1] - k[j].b * V[j];
+      }
+    }
+  }
+  EXO_HD double asum() const {
+    double s = 0.0;
+#pragma unroll
+    for (int j = 0; j < J; ++j) s += (k[j].real || !k[j].odd) ? k[j].a : 0.0;
+    return s;
+  }
+};
+
+// (A) the filtering element of one (draw, chunk)
+template <int J>
+EXO_HD void elem_lane(const double* EXO_RESTRICT t, Series rs, const double* EXO_RESTRICT diag, int64_t n_diag,
+                      int64_t n, const Coefs& cf, int64_t n_draw, double* EXO_RESTRICT state, const ChunkGeom& cg,
+                      int64_t draw, int c) {
+  const int64_t n0 = c * cg.L, n1 = (n0 + cg.L < n) ? n0 + cg.L : n;
+  const ChunkWs ws = chunk_ws(n, n_draw, J, cg);
+  DeltaCoef<J> dc;
+  dc.init(cf, draw);
+  DrawCoef<J> co;
+  co.init(cf, draw);
+  const SeriesRow y{rs.y + draw * n, rs.obs};
+  const double* EXO_RESTRICT dg = diag + (n_diag == 1 ? 0 : draw * n);
+  double A[J][J], b[J], eta[J];
+  Sym<J> Cm, Jm, Dl;
+#pragma unroll
+  for (int j = 0; j < J; ++j) {
+    b[j] = eta[j] = 0.0;
+#pragma unroll
+    for (int l = 0; l < J; ++l) A[j][l] = (j == l) ? 1.0 : 0.0;
+  }
+#pragma unroll
+  for (int k = 0; k < J * (J + 1) / 2; ++k) Cm.v[k] = Jm.v[k] = 0.0;
+  double U[J], V[J], phi[J];
+#pragma unroll
+  for (int j = 0; j < J; ++j) { U[j] = V[j] = 0.0; phi[j] = 1.0; }
+  double ti = t[n0], dt_prev = -1.0;
+  co.uv(ti, U, V);
+  dc.eval(V, Dl);
+  // Conditioning.  The element is in information form (1 / diag) and lives in celerite's rotating
+  // frame, where a complex term's state covariance Delta0 has condition number ~ 4 (b / a)^2: the
+  // J x J solves of the scans lose about  kappa = (1 + max (b/a)^2) sum(a) / min(diag)  times 1e-13
+  // in the gradients (measured against the sequential kernels over random kernels,
+  // tools/gp_cond_scan.py: 1e-9 at kappa = 1e4, 2e-8 at 1e5, 1e-4 at 1e7).  Draws with kappa > 1e5
+  // -- celerite2's Matern-3/2 term (b / a = 100 w0), an SHO term within a few per cent of critical
+  // damping, a signal 1e5 times the white noise, diag = 0 -- are flagged here and redone by the
+  // sequential kernels.  (A whitened state basis would lift the (b / a)^2 factor: DESIGN.md 8.)
+  double asum = 0.0, ba2 = 0.0;
+#pragma unroll
+  for (int j = 0; j < J; ++j) {
+    asum += (co.k[j].real || !co.k[j].odd) ? fabs(co.k[j].a) : 0.0;
+    if (!co.k[j].real && !co.k[j].odd) ba2 = fmax(ba2, (co.k[j].b * co.k[j].b) / (co.k[j].a * co.k[j].a));
+  }
+  const double rmin = (1.0 + ba2) * asum * 1e-5;
+  bool ok = true;
+#pragma unroll 1
+  for (int64_t i = n0; i < n1; ++i) {
+    const double yi = y[i], R = dg[i];
+    ok = ok && (R >= rmin) && (R < INFINITY);
+    double r[J], cu[J];
+    double s = R, zeta = yi;
+#pragma unroll
+    for (int l = 0; l < J; ++l) {
+      double rl = 0.0, cl = 0.0;
+#pragma unroll
+      for (int j = 0; j < J; ++j) { rl = fma(A[j][l], U[j], rl); cl = fma(Cm(l, j), U[j], cl); }
+      r[l] = rl; cu[l] = cl;
+      s = fma(U[l], cl, s);
+      zeta = fma(-U[l], b[l], zeta);
+    }
+    const double is = 1.0 / s;
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      eta[j] = fma(r[j] * is, zeta, eta[j]);
+#pragma unroll
+      for (int l = j; l < J; ++l) Jm(j, l) = fma(r[j] * is, r[l], Jm(j, l));
+    }
+    if (i + 1 < n) {
+      double Vn[J];
+      const double tn = t[i + 1], dt = tn - ti;
+      ti = tn;
+      if (dt != dt_prev) {   // evenly sampled series reuse the propagators
+#pragma unroll
+        for (int j = 0; j < J; ++j) phi[j] = exp(-co.k[j].c * dt);
+        dt_prev = dt;
+      }
+      co.uv(tn, U, Vn);
+      Sym<J> Dn;
+      dc.eval(Vn, Dn);
+#pragma unroll
+      for (int j = 0; j < J; ++j) {
+        const double kj = cu[j] * is;
+        b[j] = phi[j] * fma(kj, zeta, b[j]);
+#pragma unroll
+        for (int l = 0; l < J; ++l) A[j][l] = phi[j] * fma(-kj, r[l], A[j][l]);
+#pragma unroll
+        for (int l = j; l < J; ++l)
+          Cm(j, l) = fma(phi[j] * phi[l], fma(-kj, cu[l], Cm(j, l)) - Dl(j, l), Dn(j, l));  // + Q = Dn - phi phi Dl
+      }
+      Dl = Dn;
+    }
+  }
+  if (!ok) state[ws.off_flag() + draw] = 1.0;
+  int e = 0;
+#pragma unroll
+  for (int j = 0; j < J; ++j)
+#pragma unroll
+    for (int l = 0; l < J; ++l) state[ws.elem(c, e++, draw)] = A[j][l];
+#pragma unroll
+  for (int j = 0; j < J; ++j) state[ws.elem(c, e++, draw)] = b[j];
+#pragma unroll
+  for (int j = 0; j < J; ++j)
+#pragma unroll
+    for (int l = 0; l < J; ++l) state[ws.elem(c, e++, draw)] = Cm(j, l);
+#pragma unroll
+  for (int j = 0; j < J; ++j) state[ws.elem(c, e++, draw)] = eta[j];
+#pragma unroll
+  for (int j = 0; j < J; ++j)
+#pragma unroll
+    for (int l = 0; l < J; ++l) state[ws.elem(c, e++, draw)] = Jm(j, l);
+}
+
+// solve X Z = B (J x J, NB right-hand sides) in place by Gaussian elimination with partial pivoting
+template <int J, int NB>
+EXO_HD void solve_inplace(double (&X)[J][J], double (&B)[J][NB]) {
+#pragma unroll
+  for (int k = 0; k < J; ++k) {
+    int piv = k;
+    double best = fabs(X[k][k]);
+#pragma unroll
+    for (int i = k + 1; i < J; ++i) {
+      const bool better = fabs(X[i][k]) > best;
+      best = better ? fabs(X[i][k]) : best;
+      piv = better ? i : piv;
+    }
+#pragma unroll
+    for (int i = k + 1; i < J; ++i) {
+      if (i == piv) {   // swap rows k and i (selects: piv is a run-time value)
+#pragma unroll
+        for (int l = 0; l < J; ++l) { const double tmp = X[k][l]; X[k][l] = X[i][l]; X[i][l] = tmp; }
+#pragma unroll
+        for (int l = 0; l < NB; ++l) { const double tmp = B[k][l]; B[k][l] = B[i][l]; B[i][l] = tmp; }
+      }
+    }
+    const double ip = 1.0 / X[k][k];
+#pragma unroll
+    for (int i = k + 1; i < J; ++i) {
+      const double f = X[i][k] * ip;
+#pragma unroll
+      for (int l = k + 1; l < J; ++l) X[i][l] = fma(-f, X[k][l], X[i][l]);
+#pragma unroll
+      for (int l = 0; l < NB; ++l) B[i][l] = fma(-f, B[k][l], B[i][l]);
+    }
+  }
+#pragma unroll
+  for (int k = J - 1; k >= 0; --k) {
+    const double ip = 1.0 / X[k][k];
+#pragma unroll
+    for (int l = 0; l < NB; ++l) {
+      double v = B[k][l];
+#pragma unroll
+      for (int i = k + 1; i < J; ++i) v = fma(-X[k][i], B[i][l], v);
+      B[k][l] = v * ip;
+    }
+  }
+}
+
+template <int J>
+struct Elem {
+  double A[J][J], b[J], Cm[J][J], eta[J], Jm[J][J];
+  EXO_HD void load(const double* EXO_RESTRICT state, const ChunkWs& ws, int c, int64_t draw) {
+    int e = 0;
+#pragma unroll
+    for (int j = 0; j < J; ++j)
+#pragma unroll
+      for (int l = 0; l < J; ++l) A[j][l] = state[ws.elem(c, e++, draw)];
+#pragma unroll
+    for (int j = 0; j < J; ++j) b[j] = state[ws.elem(c, e++, draw)];
+#pragma unroll
+    for (int j = 0; j < J; ++j)
+#pragma unroll
+      for (int l = 0; l < J; ++l) Cm[j][l] = state[ws.elem(c, e++, draw)];
+#pragma unroll
+    for (int j = 0; j < J; ++j) eta[j] = state[ws.elem(c, e++, draw)];
+#pragma unroll
+    for (int j = 0; j < J; ++j)
+#pragma unroll
+      for (int l = 0; l < J; ++l) Jm[j][l] = state[ws.elem(c, e++, draw)];
+  }
+};
+
+// (B) the state entering every chunk of one draw: C - 1 element applications
+template <int J>
+EXO_HD void bscan_lane(const double* EXO_RESTRICT t, const Coefs& cf, int64_t n, int64_t n_draw,
+                       double* EXO_RESTRICT state, const ChunkGeom& cg, int64_t draw) {
+  const ChunkWs ws = chunk_ws(n, n_draw, J, cg);
+  DeltaCoef<J> dc;
+  dc.init(cf, draw);
+  DrawCoef<J> co;
+  co.init(cf, draw);
+  double m[J], P[J][J];
+#pragma unroll
+  for (int j = 0; j < J; ++j) {
+    m[j] = 0.0;
+#pragma unroll
+    for (int l = 0; l < J; ++l) P[j][l] = 0.0;
+  }
+#pragma unroll 1
+  for (int c = 0; c < cg.C; ++c) {
+    if (c == 0) {
+      double U[J], V[J];
+#pragma unroll
+      for (int j = 0; j < J; ++j) U[j] = V[j] = 0.0;
+      co.uv(t[0], U, V);
+      Sym<J> Dl;
+      dc.eval(V, Dl);
+#pragma unroll
+      for (int j = 0; j < J; ++j)
+#pragma unroll
+        for (int l = 0; l < J; ++l) P[j][l] = Dl(j, l);   // S_0 = 0
+    }
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      state[ws.bnd(1, c, j, draw)] = m[j];
+#pragma unroll
+      for (int l = 0; l < J; ++l) state[ws.bnd(1, c, J + j * J + l, draw)] = P[j][l];
+    }
+    if (c + 1 == cg.C) break;
+    Elem<J> el;
+    el.load(state, ws, c, draw);
+    // X = I + P Jm ;  solve X [YP | ym] = [P | m + P eta]
+    double X[J][J], Bm[J][J + 1];
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      double pe = m[j];
+#pragma unroll
+      for (int l = 0; l < J; ++l) {
+        double x = (j == l) ? 1.0 : 0.0;
+#pragma unroll
+        for (int k = 0; k < J; ++k) x = fma(P[j][k], el.Jm[k][l], x);
+        X[j][l] = x;
+        Bm[j][l] = P[j][l];
+        pe = fma(P[j][l], el.eta[l], pe);
+      }
+      Bm[j][J] = pe;
+    }
+    solve_inplace<J, J + 1>(X, Bm);
+    // m' = A ym + b ;  P' = A (YP) A^T + Cm  (symmetrised)
+    double AY[J][J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      double mj = el.b[j];
+#pragma unroll
+      for (int l = 0; l < J; ++l) {
+        mj = fma(el.A[j][l], Bm[l][J], mj);
+        double v = 0.0;
+#pragma unroll
+        for (int k = 0; k < J; ++k) v = fma(el.A[j][k], Bm[k][l], v);
+        AY[j][l] = v;   // A (YP)
+      }
+      m[j] = mj;
+    }
+#pragma unroll
+    for (int j = 0; j < J; ++j)
+#pragma unroll
+      for (int l = 0; l < J; ++l) {
+        double v = el.Cm[j][l];
+#pragma unroll
+        for (int k = 0; k < J; ++k) v = fma(AY[j][k], el.A[l][k], v);
+        X[j][l] = v;
+      }
+#pragma unroll
+    for (int j = 0; j < J; ++j)
+#pragma unroll
+      for (int l = 0; l < J; ++l) P[j][l] = 0.5 * (X[j][l] + X[l][j]);
+  }
+}
+
+// (B'), part 1 -- everything in the chain rule across chunks that does not depend on the adjoint
+// coming from later chunks, for one (draw, chunk c >= 1) (the J x J solve lives here):
+//   Abar = A Y,  g = eta - Jm Y (F + P eta),  local adjoints  gL w  and  gL/2 (w w^T - Jm Y),
+// written over the chunk's element (A <- Abar, b <- g, eta <- local Fbar, Cm <- local Pbar).
+template <int J>
+EXO_HD void badj_prep_lane(const double* EXO_RESTRICT gloglike, int64_t n, int64_t n_draw, double* EXO_RESTRICT state,
+                           const ChunkGeom& cg, int64_t draw, int c) {
+  const ChunkWs ws = chunk_ws(n, n_draw, J, cg);
+  const double gL = gloglike[draw];
+  Elem<J> el;
+  el.load(state, ws, c, draw);
+  double m[J], P[J][J];
+#pragma unroll
+  for (int j = 0; j < J; ++j) {
+    m[j] = state[ws.bnd(1, c, j, draw)];
+#pragma unroll
+    for (int l = 0; l < J; ++l) P[j][l] = state[ws.bnd(1, c, J + j * J + l, draw)];
+  }
+  double X[J][J], Y[J][J];
+#pragma unroll
+  for (int j = 0; j < J; ++j)
+#pragma unroll
+    for (int l = 0; l < J; ++l) {
+      double x = (j == l) ? 1.0 : 0.0;
+#pragma unroll
+      for (int k = 0; k < J; ++k) x = fma(P[j][k], el.Jm[k][l], x);
+      X[j][l] = x;
+      Y[j][l] = (j == l) ? 1.0 : 0.0;
+    }
+  solve_inplace<J, J>(X, Y);
+  double u[J], v[J], w[J], Yv[J];
+#pragma unroll
+  for (int j = 0; j < J; ++j) {
+    double uj = el.eta[j], vj = m[j];
+#pragma unroll
+    for (int l = 0; l < J; ++l) { uj = fma(-el.Jm[j][l], m[l], uj); vj = fma(P[j][l], el.eta[l], vj); }
+    u[j] = uj; v[j] = vj;
+  }
+#pragma unroll
+  for (int j = 0; j < J; ++j) {
+    double wj = 0.0, yv = 0.0;
+#pragma unroll
+    for (int l = 0; l < J; ++l) { wj = fma(Y[l][j], u[l], wj); yv = fma(Y[j][l], v[l], yv); }
+    w[j] = wj; Yv[j] = yv;
+  }
+  const int oA = 0, ob = J * J, oC = J * J + J, oeta = 2 * J * J + J;
+#pragma unroll
+  for (int j = 0; j < J; ++j) {
+    double gj = el.eta[j];
+#pragma unroll
+    for (int l = 0; l < J; ++l) {
+      gj = fma(-el.Jm[j][l], Yv[l], gj);
+      double a = 0.0, jy = 0.0, jyt = 0.0;
+#pragma unroll
+      for (int k = 0; k < J; ++k) {
+        a = fma(el.A[j][k], Y[k][l], a);
+        jy = fma(el.Jm[j][k], Y[k][l], jy);
+        jyt = fma(el.Jm[l][k], Y[k][j], jyt);
+      }
+      state[ws.elem(c, oA + j * J + l, draw)] = a;
+      state[ws.elem(c, oC + j * J + l, draw)] = 0.5 * gL * (w[j] * w[l] - 0.5 * (jy + jyt));
+    }
+    state[ws.elem(c, ob + j, draw)] = gj;
+    state[ws.elem(c, oeta + j, draw)] = gL * w[j];
+  }
+}
+
+// (B'), part 2 -- the chain itself, last chunk to first, one draw: two J x J products per chunk
+//   Fbar = local + Abar^T Fbar',   Pbar = local + Abar^T Pbar' Abar + sym(Abar^T Fbar' g^T)
+template <int J>
+EXO_HD void bscan_vjp_lane(int64_t n, int64_t n_draw, double* EXO_RESTRICT state, const ChunkGeom& cg, int64_t draw) {
+  const ChunkWs ws = chunk_ws(n, n_draw, J, cg);
+  const int oA = 0, ob = J * J, oC = J * J + J, oeta = 2 * J * J + J;
+  double mb[J], Pb[J][J];   // adjoint of (F, P) entering chunk c + 1
+#pragma unroll
+  for (int j = 0; j < J; ++j) {
+    mb[j] = 0.0;
+#pragma unroll
+    for (int l = 0; l < J; ++l) Pb[j][l] = 0.0;
+  }
+#pragma unroll 1
+  for (int c = cg.C - 1; c >= 0; --c) {
+    // what chunk c's reverse recurrence starts from: adjoint of (F, S) entering chunk c + 1; Sbar = -Pbar
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      state[ws.bnd(2, c, j, draw)] = mb[j];
+#pragma unroll
+      for (int l = 0; l < J; ++l) state[ws.bnd(2, c, J + j * J + l, draw)] = -Pb[j][l];
+    }
+    if (c == 0) break;
+    double Ab[J][J], g[J], x[J], T[J][J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      g[j] = state[ws.elem(c, ob + j, draw)];
+#pragma unroll
+      for (int l = 0; l < J; ++l) Ab[j][l] = state[ws.elem(c, oA + j * J + l, draw)];
+    }
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      double xj = 0.0;
+#pragma unroll
+      for (int l = 0; l < J; ++l) {
+        xj = fma(Ab[l][j], mb[l], xj);
+        double tv = 0.0;
+#pragma unroll
+        for (int k = 0; k < J; ++k) tv = fma(Pb[j][k], Ab[k][l], tv);
+        T[j][l] = tv;
+      }
+      x[j] = xj;
+    }
+    double mbn[J], Pbn[J][J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      mbn[j] = state[ws.elem(c, oeta + j, draw)] + x[j];
+#pragma unroll
+      for (int l = 0; l < J; ++l) {
+        double cong = state[ws.elem(c, oC + j * J + l, draw)];
+#pragma unroll
+        for (int k = 0; k < J; ++k) cong = fma(Ab[k][j], T[k][l], cong);
+        Pbn[j][l] = cong + 0.5 * (x[j] * g[l] + g[j] * x[l]);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      mb[j] = mbn[j];
+#pragma unroll
+      for (int l = 0; l < J; ++l) Pb[j][l] = 0.5 * (Pbn[j][l] + Pbn[l][j]);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// (C) / (C') on one lane: the ordinary recurrences of one (draw, chunk), all J state indices in
+// the lane's registers, with a checkpointed factorisation.
+// ---------------------------------------------------------------------------------------------
+// the recurrence state at one cadence, as the reverse pass needs it
+template <int J>
+struct Step {
+  Sym<J> S;
+  double F[J], V[J];
+  double d, z;
+};
+
+// One cadence of the forward recurrences.  On entry (S, F) is the state AFTER the propagation into
+// this cadence (for the first cadence of a chunk / of a checkpoint block: the entering state);
+// on exit W, d, z are this cadence's; `advance` then propagates (S, F) to the next cadence.
+template <int J>
+struct Fwd {
+  Sym<J> S;
+  double F[J], W[J], U[J], V[J];
+  double d, z;
+  EXO_HD void measure(double yi, double diag_plus_asum) {
+    double u[J];
+    double pd = 0.0, pz = 0.0;
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      double uj = 0.0;
+#pragma unroll
+      for (int l = 0; l < J; ++l) uj = fma(S(j, l), U[l], uj);
+      u[j] = uj;
+      pd = fma(U[j], uj, pd);
+      pz = fma(U[j], F[j], pz);
+    }
+    d = diag_plus_asum - pd;
+    z = yi - pz;
+    const double id = 1.0 / d;
+#pragma unroll
+    for (int j = 0; j < J; ++j) W[j] = (V[j] - u[j]) * id;
+  }
+  EXO_HD void advance(const double* phi) {
+#pragma unroll
+    for (int j = 0; j < J; ++j) F[j] = phi[j] * fma(W[j], z, F[j]);
+#pragma unroll
+    for (int j = 0; j < J; ++j)
+#pragma unroll
+      for (int l = j; l < J; ++l) S(j, l) = phi[j] * phi[l] * fma(d * W[j], W[l], S(j, l));
+  }
+};
+
+// propagators exp(-c_j dt), recomputed only when dt changes (evenly sampled series reuse them)
+template <int J>
+struct Phi {
+  double v[J];
+  double dt_prev;
+  EXO_HD Phi() : dt_prev(-1.0) {
+#pragma unroll
+    for (int j = 0; j < J; ++j) v[j] = 1.0;
+  }
+  EXO_HD void set(const DrawCoef<J>& co, double dt) {
+    if (dt != dt_prev) {
+#pragma unroll
+      for (int j = 0; j < J; ++j) v[j] = exp(-co.k[j].c * dt);
+      dt_prev = dt;
+    }
+  }
+};
+
+// (C) forward: acc = sum z^2 / d, log det and the "not positive definite" mark of the chunk go to the
+// chunk partials; (F, S) at the first cadence of every checkpoint block goes to the checkpoints.
+template <int J>
+EXO_HD void chunk1_fwd_lane(const double* EXO_RESTRICT t, Series rs, const double* EXO_RESTRICT diag, int64_t n_diag,
+                            int64_t n, const Coefs& cf, int64_t n_draw, double* EXO_RESTRICT state, const ChunkGeom& cg,
+                            int64_t draw, int c, bool save) {
+  const int64_t n0 = c * cg.L, n1 = (n0 + cg.L < n) ? n0 + cg.L : n;
+  const ChunkWs ws = chunk_ws(n, n_draw, J, cg);
+  DrawCoef<J> co;
+  co.init(cf, draw);
+  const double asum = co.asum();
+  const SeriesRow y{rs.y + draw * n, rs.obs};
+  const double* EXO_RESTRICT dg = diag + (n_diag == 1 ? 0 : draw * n);
+  Fwd<J> f;
+#pragma unroll
+  for (int j = 0; j < J; ++j) { f.U[j] = f.V[j] = f.W[j] = 0.0; }
+  {
+    // entering state from (B) as (F, P): S = Delta_{n0} - P
+    DeltaCoef<J> dc;
+    dc.init(cf, draw);
+    co.uv(t[n0], f.U, f.V);
+    Sym<J> Dl;
+    dc.eval(f.V, Dl);
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      f.F[j] = state[ws.bnd(1, c, j, draw)];
+#pragma unroll
+      for (int l = j; l < J; ++l) f.S(j, l) = Dl(j, l) - state[ws.bnd(1, c, J + j * J + l, draw)];
+    }
+  }
+  Phi<J> phi;
+  double tprev = t[n0];
+  double acc = 0.0, lman = 1.0;
+  int64_t lsum = 0;
+  bool bad = false;
+#pragma unroll 1
+  for (int64_t b0 = n0; b0 < n1; b0 += kCkptB) {
+#pragma unroll
+    for (int q = 0; q < kCkptB; ++q) {
+      const int64_t i = b0 + q;
+      if (i < n1) {
+        if (i > n0) {   // (the entering state is already at n0)
+          const double ti = t[i];
+          phi.set(co, ti - tprev);
+          tprev = ti;
+          f.advance(phi.v);
+          co.uv(ti, f.U, f.V);
+        }
+        if (q == 0 && save) {   // checkpoint: the state AT the block's first cadence (after the step into it)
+          const int64_t g = b0 / kCkptB;
+#pragma unroll
+          for (int j = 0; j < J; ++j) state[ws.ckpt(g, j, draw)] = f.F[j];
+#pragma unroll
+          for (int k = 0; k < J * (J + 1) / 2; ++k) state[ws.ckpt(g, J + k, draw)] = f.S.v[k];
+        }
+        f.measure(y[i], dg[i] + asum);
+        bad = bad || !(f.d > 0.0);
+        acc = fma(f.z * f.z, 1.0 / f.d, acc);
+        int lexp;
+        lman = frexp(lman * (f.d > 0.0 ? f.d : 1.0), &lexp);
+        lsum += lexp;
+      }
+    }
+  }
+  state[ws.part(c, 0, draw)] = acc;
+  state[ws.part(c, 1, draw)] = log(lman) + (double)lsum * 0.69314718055994530942;
+  state[ws.part(c, 2, draw)] = bad ? 1.0 : 0.0;
+}
+
+// (C') reverse.  Hand-derived adjoint of the two recurrences (same algebra as celerite_vjp_kernel
+// of exo_celerite.hip, one lane holding every state index): Sb is the SYMMETRISED adjoint of S.
+template <int J>
+struct Rev {
+  double Sb[J][J], Fb[J], Wb[J];
+  double db, zb, gasum;
+  double ga[J], gb[J], gc[J], gd[J];
+
+  // measurement half of cadence i: adjoints of (d, z, W) of this cadence -> (S, F) of this cadence
+  // and the coefficient cotangents through U, V.  W = (V - S U) / d is rebuilt (the step keeps V).
+  // Returns zbar (d loglike / d y_i) and dbar (d loglike / d diag_i).
+  EXO_HD void measure(const DrawCoef<J>& co, const Step<J>& s, double ti, double gL, double* W_out, double* zbar_out,
+                      double* dbar_out) {
+    double U[J], u[J], W[J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) U[j] = 0.0;
+    co.u_from_v(s.V, U);
+    const double id = 1.0 / s.d;
+    double wdot = 0.0;
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      double uj = 0.0;
+#pragma unroll
+      for (int l = 0; l < J; ++l) uj = fma(s.S(j, l), U[l], uj);
+      u[j] = uj;
+      W[j] = (s.V[j] - uj) * id;
+      W_out[j] = W[j];
+      wdot = fma(Wb[j], W[j], wdot);
+    }
+    const double zbar = zb - gL * s.z * id;
+    const double dbar = db + gL * (0.5 * s.z * s.z * id * id - 0.5 * id) - wdot * id;
+    *zbar_out = zbar;
+    *dbar_out = dbar;
+    gasum += dbar;
+    double Ub[J], Vb[J], ub[J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      Ub[j] = fma(-dbar, u[j], -zbar * s.F[j]);
+      Fb[j] = fma(-zbar, U[j], Fb[j]);
+      Vb[j] = Wb[j] * id;
+      ub[j] = -Vb[j] - dbar * U[j];
+    }
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      double acc_u = 0.0;
+#pragma unroll
+      for (int l = 0; l < J; ++l) {
+        Sb[j][l] = fma(0.5, fma(ub[j], U[l], ub[l] * U[j]), Sb[j][l]);   // symmetrised  ub U^T
+        acc_u = fma(s.S(j, l), ub[l], acc_u);                            // (S^T ub)_j, S symmetric
+      }
+      Ub[j] += acc_u;
+    }
+    // coefficient cotangents: a real term's U = a; a complex pair's (a, b, d) collect on its first index
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      if (co.k[j].real) {
+        ga[j] += Ub[j];
+      } else if (!co.k[j].odd && j + 1 < J) {
+        const double cs = s.V[j], sn = s.V[j + 1];
+        const double a = co.k[j].a, b = co.k[j].b;
+        ga[j] += Ub[j] * cs + Ub[j + 1] * sn;
+        gb[j] += Ub[j] * sn - Ub[j + 1] * cs;
+        gd[j] += ti * (Ub[j] * (-a * sn + b * cs) + Ub[j + 1] * (a * cs + b * sn) - Vb[j] * sn + Vb[j + 1] * cs);
+      }
+    }
+  }
+
+  // reverse of the step p -> n (p = n - 1):  F_n = P o (F_p + W_p z_p),  S_n = P P^T o (S_p + d_p W_p W_p^T);
+  // on entry Sb, Fb are the adjoints of S_n, F_n; on exit those of S_p, F_p, and Wb, db, zb those of
+  // W_p, d_p, z_p.  Wp = W of cadence p.
+  EXO_HD void propagate(const Step<J>& p, const double* Wp, const double* phi, double dt) {
+    double Gb[J], Pb[J], Wbn[J];
+    double zbn = 0.0, dbn = 0.0;
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      const double Gj = fma(Wp[j], p.z, p.F[j]);
+      Pb[j] = Fb[j] * Gj;
+      Gb[j] = Fb[j] * phi[j];
+      Wbn[j] = Gb[j] * p.z;
+      zbn = fma(Gb[j], Wp[j], zbn);
+    }
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      double psum = 0.0, wsum = 0.0;
+#pragma unroll
+      for (int l = 0; l < J; ++l) {
+        const double T = fma(p.d * Wp[j], Wp[l], p.S(j, l));
+        const double Tb = Sb[j][l] * phi[j] * phi[l];      // adjoint of T (symmetric)
+        psum = fma(2.0 * Sb[j][l] * T, phi[l], psum);
+        wsum = fma(Tb, Wp[l], wsum);
+        Sb[j][l] = Tb;                                     // becomes the adjoint of S_p
+      }
+      Pb[j] += psum;
+      Wbn[j] = fma(2.0 * p.d, wsum, Wbn[j]);
+      dbn = fma(wsum, Wp[j], dbn);
+      gc[j] = fma(-dt * phi[j], Pb[j], gc[j]);
+    }
+    db = dbn; zb = zbn;
+#pragma unroll
+    for (int j = 0; j < J; ++j) { Fb[j] = Gb[j]; Wb[j] = Wbn[j]; }
+  }
+};
+
+// gsign: +1 writes d loglike / d resid; -1 writes d loglike / d model (obs - model series)
+template <int J>
+EXO_HD void chunk1_vjp_lane(const double* EXO_RESTRICT t, Series rs, const double* EXO_RESTRICT diag, int64_t n_diag,
+                            int64_t n, const Coefs& cf, int64_t n_draw, const double* EXO_RESTRICT gloglike,
+                            double* EXO_RESTRICT state, const ChunkGeom& cg, double* EXO_RESTRICT gresid,
+                            double* EXO_RESTRICT gdiag, double gsign, int64_t draw, int c) {
+  const int64_t n0 = c * cg.L, n1 = (n0 + cg.L < n) ? n0 + cg.L : n;
+  const ChunkWs ws = chunk_ws(n, n_draw, J, cg);
+  DrawCoef<J> co;
+  co.init(cf, draw);
+  const double asum = co.asum();
+  const SeriesRow y{rs.y + draw * n, rs.obs};
+  const double* EXO_RESTRICT dg = diag + (n_diag == 1 ? 0 : draw * n);
+  const double gL = gloglike[draw];
+  Rev<J> r;
+#pragma unroll
+  for (int j = 0; j < J; ++j) {
+    r.Fb[j] = state[ws.bnd(2, c, j, draw)];
+    r.Wb[j] = 0.0;
+    r.ga[j] = r.gb[j] = r.gc[j] = r.gd[j] = 0.0;
+#pragma unroll
+    for (int l = 0; l < J; ++l) r.Sb[j][l] = state[ws.bnd(2, c, J + j * J + l, draw)];
+  }
+  r.db = r.zb = r.gasum = 0.0;
+  Phi<J> phi;
+  // blocks last to first; `pend`: the step from this block's last cadence into cadence `next` (the
+  // first cadence of the block after it, or of the next chunk) still has to be reversed
+  const int64_t nb = (n1 - n0 + kCkptB - 1) / kCkptB;
+  bool pend = n1 < n;
+#pragma unroll 1
+  for (int64_t bi = nb - 1; bi >= 0; --bi) {
+    const int64_t b0 = n0 + bi * kCkptB;
+    const int len = (int)((n1 - b0 < kCkptB) ? n1 - b0 : kCkptB);
+    // recompute the block forward from its checkpoint, keeping every cadence's state
+    Step<J> st[kCkptB];
+    double tt[kCkptB];
+    {
+      Fwd<J> f;
+      const int64_t g = b0 / kCkptB;
+#pragma unroll
+      for (int j = 0; j < J; ++j) { f.F[j] = state[ws.ckpt(g, j, draw)]; f.U[j] = f.V[j] = f.W[j] = 0.0; }
+#pragma unroll
+      for (int k = 0; k < J * (J + 1) / 2; ++k) f.S.v[k] = state[ws.ckpt(g, J + k, draw)];
+      double tprev = t[b0];
+#pragma unroll
+      for (int q = 0; q < kCkptB; ++q) {
+        if (q < len) {
+          const double ti = t[b0 + q];
+          tt[q] = ti;
+          if (q > 0) {
+            phi.set(co, ti - tprev);
+            tprev = ti;
+            f.advance(phi.v);
+          }
+          co.uv(ti, f.U, f.V);
+          f.measure(y[b0 + q], dg[b0 + q] + asum);
+          st[q].S = f.S;
+          st[q].d = f.d; st[q].z = f.z;
+#pragma unroll
+          for (int j = 0; j < J; ++j) { st[q].F[j] = f.F[j]; st[q].V[j] = f.V[j]; }
+        } else {
+          tt[q] = 0.0;
+          st[q] = st[q > 0 ? q - 1 : 0];
+        }
+      }
+    }
+    double zbar[kCkptB], dbar[kCkptB];
+#pragma unroll
+    for (int q = kCkptB - 1; q >= 0; --q) {
+      zbar[q] = dbar[q] = 0.0;
+      if (q < len) {
+        const int64_t i = b0 + q;
+        double W[J];
+        if (q == len - 1 && pend) {
+          // the step from cadence i into cadence i + 1 (first of the block / chunk after this one):
+          // W of cadence i from its saved state
+          double U[J];
+#pragma unroll
+          for (int j = 0; j < J; ++j) U[j] = 0.0;
+          co.u_from_v(st[q].V, U);
+          const double id = 1.0 / st[q].d;
+#pragma unroll
+          for (int j = 0; j < J; ++j) {
+            double uj = 0.0;
+#pragma unroll
+            for (int l = 0; l < J; ++l) uj = fma(st[q].S(j, l), U[l], uj);
+            W[j] = (st[q].V[j] - uj) * id;
+          }
+          const double dt = t[i + 1] - tt[q];
+          phi.set(co, dt);
+          r.propagate(st[q], W, phi.v, dt);
+        }
+        r.measure(co, st[q], tt[q], gL, W, &zbar[q], &dbar[q]);
+        if (q > 0) {
+          // reverse of the step (i - 1) -> i: W of cadence i - 1 is rebuilt inside the next
+          // measure() as well; the few operations are cheaper than a register per state index
+          double U[J], Wp[J];
+#pragma unroll
+          for (int j = 0; j < J; ++j) U[j] = 0.0;
+          co.u_from_v(st[q - 1].V, U);
+          const double id = 1.0 / st[q - 1].d;
+#pragma unroll
+          for (int j = 0; j < J; ++j) {
+            double uj = 0.0;
+#pragma unroll
+            for (int l = 0; l < J; ++l) uj = fma(st[q - 1].S(j, l), U[l], uj);
+            Wp[j] = (st[q - 1].V[j] - uj) * id;
+          }
+          const double dt = tt[q] - tt[q - 1];
+          phi.set(co, dt);
+          r.propagate(st[q - 1], Wp, phi.v, dt);
+        }
+      }
+    }
+    pend = true;   // the step from the previous block's last cadence into b0
+    // gresid / gdiag are [draw][cadence]: the block's cadences are consecutive doubles of one row
+#pragma unroll
+    for (int q = 0; q < kCkptB; ++q) {
+      if (q < len) {
+        gresid[draw * n + b0 + q] = gsign * zbar[q];
+        if (gdiag) gdiag[draw * n + b0 + q] = dbar[q];
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < J; ++j) {
+    state[ws.gpart(c, 4 * j + 0, draw)] = r.ga[j];
+    state[ws.gpart(c, 4 * j + 1, draw)] = r.gb[j];
+    state[ws.gpart(c, 4 * j + 2, draw)] = r.gc[j];
+    state[ws.gpart(c, 4 * j + 3, draw)] = r.gd[j];
+  }
+  state[ws.gpart(c, 4 * J, draw)] = r.gasum;
+}
+
+// coefficient cotangents of one (draw, state index) from the totals over the chunks (left in chunk
+// 0's slots): the same combination as the tail of celerite_vjp_kernel
+EXO_HD void gcoef_lane(const Coefs& cf, int64_t n, int64_t n_draw, const double* EXO_RESTRICT state, const ChunkGeom& cg,
+                       double* EXO_RESTRICT gdiag_sum, double* EXO_RESTRICT gcoef_real, double* EXO_RESTRICT gcoef_complex,
+                       int64_t draw, int j) {
+  const int J = cf.J();
+  const ChunkWs ws = chunk_ws(n, n_draw, J, cg);
+  const LaneCoef k = lane_coef(cf, draw, j, J);
+  const double gasum = state[ws.gpart(0, 4 * J, draw)];
+  if (j == 0 && gdiag_sum) gdiag_sum[draw] = gasum;
+  const double ga = state[ws.gpart(0, 4 * j, draw)], gc = state[ws.gpart(0, 4 * j + 2, draw)];
+  if (k.real) {
+    double* o = k.slot < 0 ? gcoef_real + (draw * cf.n_real + j) * 2 : gcoef_complex + draw * cf.n_complex * 4 + k.slot;
+    o[0] = ga + gasum;  // a_n = diag_n + sum a
+    o[1] = gc;
+  } else if (!k.odd) {
+    double* o = gcoef_complex + (draw * cf.n_complex + ((j - cf.n_real) >> 1)) * 4;
+    o[0] = ga + gasum;
+    o[1] = state[ws.gpart(0, 4 * j + 1, draw)];
+    o[2] = gc + state[ws.gpart(0, 4 * (j + 1) + 2, draw)];   // the decay rate is shared by the pair's two indices
+    o[3] = state[ws.gpart(0, 4 * j + 3, draw)];
+  }
+}
+
+}  // namespace gp

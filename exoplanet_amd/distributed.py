@@ -5,55 +5,86 @@ The reference has no parallelism beyond PyMC's one-process-per-chain
 batch are independent units: rank g of W evaluates draws [lo_g, hi_g) on its own
 GPU (t, y, diag are replicated, a few MB), parameter gradients stay on the
 owning rank, and the ONLY exchange is the per-draw log-likelihood vector -- one
-all-reduce of D doubles (<= 8 KiB at D = 1024) over RCCL / xGMI (torch backend
+collective of D doubles (<= 8 KiB at D = 1024) over RCCL / xGMI (torch backend
 "nccl"); latency-bound, so it is issued exactly once per evaluation.
 """
 import torch
 import torch.distributed as dist
 
-__all__ = ["shard_bounds", "shard", "gather_loglike", "sharded_log_likelihood"]
+__all__ = ["shard_bounds", "shard", "LoglikeExchange", "gather_loglike", "sharded_log_likelihood"]
 
 
-def shard_bounds(n_draw, rank=None, world=None):
-    """[lo, hi) of this rank's contiguous block of draws (blocks differ by <= 1)."""
+def _rank_world(group=None):
+    if not dist.is_initialized():
+        return 0, 1
+    return dist.get_rank(group), dist.get_world_size(group)
+
+
+def shard_bounds(n_draw, rank=None, world=None, group=None):
+    """[lo, hi) of this rank's contiguous block of draws (blocks differ by <= 1).  ``rank`` /
+    ``world`` default to this process's position in ``group`` (the default group if None)."""
+    r, w = _rank_world(group)
     if world is None:
-        world = dist.get_world_size() if dist.is_initialized() else 1
+        world = w
     if rank is None:
-        rank = dist.get_rank() if dist.is_initialized() else 0
+        rank = r
     base, extra = divmod(n_draw, world)
     lo = rank * base + min(rank, extra)
     return lo, lo + base + (1 if rank < extra else 0)
 
 
-def shard(x, n_draw=None, rank=None, world=None):
+def shard(x, n_draw=None, rank=None, world=None, group=None):
     """slice the leading (draw) dimension of a tensor / pytree of tensors for this rank"""
     if isinstance(x, dict):
-        return {k: shard(v, n_draw, rank, world) for k, v in x.items()}
+        return {k: shard(v, n_draw, rank, world, group) for k, v in x.items()}
     if isinstance(x, (list, tuple)):
-        return type(x)(shard(v, n_draw, rank, world) for v in x)
+        return type(x)(shard(v, n_draw, rank, world, group) for v in x)
     n = x.shape[0] if n_draw is None else n_draw
-    lo, hi = shard_bounds(n, rank, world)
+    lo, hi = shard_bounds(n, rank, world, group)
     return x[lo:hi]
 
 
+class LoglikeExchange:
+    """The one collective of a step: every rank receives the full (n_draw,) vector of per-draw
+    scalars.  The output buffer is allocated once; a call issues exactly ONE collective and no
+    other device work when the shards are equal (``all_gather_into_tensor`` straight from the
+    caller's tensor -- e.g. the static output of a replayed hipGraph); ragged shards fall back
+    to "own slice of a zero vector + all-reduce(SUM)".  Rank and world size are those of
+    ``group``.  A single process (or an uninitialised process group) just copies."""
+
+    def __init__(self, n_draw, device, dtype=torch.float64, group=None):
+        self.group = group
+        self.rank, self.world = _rank_world(group)
+        self.n_draw = int(n_draw)
+        self.lo, self.hi = shard_bounds(self.n_draw, self.rank, self.world)
+        self.equal = self.n_draw % self.world == 0
+        self.out = torch.zeros(self.n_draw, dtype=dtype, device=device)
+
+    def __call__(self, local):
+        local = local.detach()
+        if local.shape != (self.hi - self.lo,):
+            raise ValueError(f"rank owns draws [{self.lo},{self.hi}) but got a tensor of shape {tuple(local.shape)}")
+        if self.world == 1:
+            self.out.copy_(local)
+        elif self.equal:
+            dist.all_gather_into_tensor(self.out, local.contiguous(), group=self.group)
+        else:
+            self.out.zero_()
+            self.out[self.lo:self.hi] = local
+            dist.all_reduce(self.out, op=dist.ReduceOp.SUM, group=self.group)
+        return self.out
+
+
 def gather_loglike(local, n_draw, group=None):
-    """every rank receives the full (n_draw,) vector: each fills its own slice of a
-    zero vector and ONE all-reduce(SUM) completes it (equivalent to an all-gather,
-    but valid for ragged shards)."""
-    out = torch.zeros(n_draw, dtype=local.dtype, device=local.device)
-    lo, hi = shard_bounds(n_draw)
-    if hi - lo != local.shape[0]:
-        raise ValueError(f"rank owns draws [{lo},{hi}) but got {local.shape[0]} values")
-    out[lo:hi] = local.detach()
-    if dist.is_initialized() and dist.get_world_size() > 1:
-        dist.all_reduce(out, op=dist.ReduceOp.SUM, group=group)
-    return out
+    """every rank receives the full (n_draw,) vector (one collective; see LoglikeExchange).
+    A fresh output per call: loops should keep a LoglikeExchange instead."""
+    return LoglikeExchange(n_draw, local.device, local.dtype, group)(local)
 
 
-def sharded_log_likelihood(loglike_fn, params, n_draw):
+def sharded_log_likelihood(loglike_fn, params, n_draw, group=None):
     """Evaluate ``loglike_fn(params_shard) -> (n_local,)`` on this rank's draws and
     return (full log-likelihood vector on every rank, local log-likelihoods with
     their autograd graph).  Gradients never leave the owning rank."""
-    local_params = shard(params, n_draw)
+    local_params = shard(params, n_draw, group=group)
     local = loglike_fn(local_params)
-    return gather_loglike(local, n_draw), local
+    return gather_loglike(local, n_draw, group), local

@@ -1,4 +1,6 @@
 """GaussianProcess on the batched celerite HIP kernels (value + gradient)."""
+import os
+
 import torch
 
 from .. import _lib
@@ -11,9 +13,20 @@ __all__ = ["GaussianProcess", "celerite_loglike"]
 MAX_J = 8
 
 
+def default_chunks():
+    """EXO_GP_CHUNKS (0 / unset: the library's plan; 1: sequential recurrences; > 1: that many chunks).
+    Read here, by the caller -- the library itself reads no environment and keeps no state: the
+    value travels to the forward call, and through the autograd context to the reverse call."""
+    v = os.environ.get("EXO_GP_CHUNKS", "").strip()
+    n = int(v) if v else 0
+    if n < 0:
+        raise ValueError("EXO_GP_CHUNKS must be >= 0")
+    return n
+
+
 class _CeleriteLogLike(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, t, resid, diag, coef_real, coef_complex, obs):
+    def forward(ctx, t, resid, diag, coef_real, coef_complex, obs, pair_kind, n_chunks):
         t = _dev(t, "t")
         resid = _dev(resid, "resid")
         if obs is not None:
@@ -29,18 +42,23 @@ class _CeleriteLogLike(torch.autograd.Function):
             raise ValueError("shapes: t (N,), resid (D,N), diag (1|D, N)")
         if coef_real.shape != (D, n_real, 2) or coef_complex.shape != (D, n_complex, 4):
             raise ValueError("coef_real (D,Jr,2), coef_complex (D,Jc,4)")
+        if pair_kind is not None:
+            if not pair_kind.is_cuda or pair_kind.dtype != torch.int32 or tuple(pair_kind.shape) != (D, n_complex):
+                raise ValueError("pair_kind must be an int32 device tensor of shape (D, Jc)")
+            pair_kind = pair_kind.contiguous()
         J = n_real + 2 * n_complex
         if not 1 <= J <= MAX_J:
             raise ValueError(f"celerite state width J = {J} outside 1..{MAX_J}")
         if N < 1:
             raise ValueError("need at least one cadence")
+        n_chunks = int(n_chunks)
         lib = _lib.load()
         need_grad = any(ctx.needs_input_grad)
         loglike = torch.empty(D, dtype=torch.float64, device=t.device)
         # The state buffer is what the reverse pass re-reads, and it is also what lets the library run
         # the recurrences in parallel over time: a value-only call gets one too (scratch, freed on
         # return) unless the device cannot spare it, in which case the sequential kernels run.
-        nstate = lib.exo_celerite_state_doubles(N, D, n_real, n_complex)
+        nstate = lib.exo_celerite_state_doubles(N, D, n_real, n_complex, n_chunks)
         try:
             state = torch.empty(nstate, dtype=torch.float64, device=t.device)
         except torch.cuda.OutOfMemoryError:
@@ -51,27 +69,29 @@ class _CeleriteLogLike(torch.autograd.Function):
             if obs is None:
                 _lib.check(
                     lib.exo_celerite_loglike_fwd_f64(_ptr(t), _ptr(resid), _ptr(diag), diag.shape[0], N,
-                                                     _ptr(coef_real), n_real, _ptr(coef_complex), n_complex, D,
-                                                     _ptr(loglike), _ptr(state), nstate, _stream(t)),
+                                                     _ptr(coef_real), n_real, _ptr(coef_complex), n_complex,
+                                                     _ptr(pair_kind), D, _ptr(loglike), _ptr(state), nstate, n_chunks,
+                                                     _stream(t)),
                     "exo_celerite_loglike_fwd_f64",
                 )
             else:
                 _lib.check(
                     lib.exo_celerite_loglike_obs_fwd_f64(_ptr(t), _ptr(obs), _ptr(resid), _ptr(diag), diag.shape[0], N,
-                                                         _ptr(coef_real), n_real, _ptr(coef_complex), n_complex, D,
-                                                         _ptr(loglike), _ptr(state), nstate, _stream(t)),
+                                                         _ptr(coef_real), n_real, _ptr(coef_complex), n_complex,
+                                                         _ptr(pair_kind), D, _ptr(loglike), _ptr(state), nstate,
+                                                         n_chunks, _stream(t)),
                     "exo_celerite_loglike_obs_fwd_f64",
                 )
         if need_grad:
-            ctx.save_for_backward(t, diag, coef_real, coef_complex, state)
-            ctx.dims = (D, N, n_real, n_complex)
-            ctx.with_obs = obs is not None
+            # the series itself is saved too: the reverse pass of the checkpointed path recomputes from it
+            ctx.save_for_backward(t, resid, diag, coef_real, coef_complex, state, obs, pair_kind)
+            ctx.dims = (D, N, n_real, n_complex, nstate, n_chunks)
         return loglike
 
     @staticmethod
     def backward(ctx, gll):
-        t, diag, coef_real, coef_complex, state = ctx.saved_tensors
-        D, N, n_real, n_complex = ctx.dims
+        t, resid, diag, coef_real, coef_complex, state, obs, pair_kind = ctx.saved_tensors
+        D, N, n_real, n_complex, nstate, n_chunks = ctx.dims
         gll = _dev(gll, "gloglike")
         lib = _lib.load()
         gresid = torch.empty(D, N, dtype=torch.float64, device=t.device)
@@ -81,24 +101,54 @@ class _CeleriteLogLike(torch.autograd.Function):
         gcr = torch.empty_like(coef_real)
         gcc = torch.empty_like(coef_complex)
         with torch.cuda.device(t.device):
-            entry = lib.exo_celerite_loglike_obs_vjp_f64 if ctx.with_obs else lib.exo_celerite_loglike_vjp_f64
-            _lib.check(
-                entry(_ptr(t), _ptr(diag), diag.shape[0], N, _ptr(coef_real), n_real, _ptr(coef_complex), n_complex, D,
-                      _ptr(gll), _ptr(state), _ptr(gresid), _ptr(gdiag), None, _ptr(gcr), _ptr(gcc), _stream(t)),
-                "exo_celerite_loglike_vjp_f64",
-            )
+            tail = (_ptr(diag), diag.shape[0], N, _ptr(coef_real), n_real, _ptr(coef_complex), n_complex, _ptr(pair_kind),
+                    D, _ptr(gll), _ptr(state), nstate, n_chunks, _ptr(gresid), _ptr(gdiag), None, _ptr(gcr), _ptr(gcc),
+                    _stream(t))
+            if obs is None:
+                _lib.check(lib.exo_celerite_loglike_vjp_f64(_ptr(t), _ptr(resid), *tail), "exo_celerite_loglike_vjp_f64")
+            else:
+                _lib.check(lib.exo_celerite_loglike_obs_vjp_f64(_ptr(t), _ptr(obs), _ptr(resid), *tail),
+                           "exo_celerite_loglike_obs_vjp_f64")
         if want_diag and shared_diag:
             gdiag = gdiag.sum(0, keepdim=True)
-        return None, gresid, gdiag, gcr, gcc, None
+        return None, gresid, gdiag, gcr, gcc, None, None, None
 
 
-def celerite_loglike(t, resid, diag, coef_real, coef_complex, obs=None):
+def celerite_loglike(t, resid, diag, coef_real, coef_complex, obs=None, pair_kind=None, n_chunks=None):
     """log N(resid | 0, K + diag) per draw.  t (N,), resid (D,N), diag (1|D,N),
     coef_real (D,Jr,2) = (a,c), coef_complex (D,Jc,4) = (a,b,c,d).  Differentiable
     w.r.t. resid, diag and the coefficients.  With ``obs`` (N,), ``resid`` is a per-draw
     MODEL and the likelihood is that of ``obs - resid``, formed inside the kernels (no
-    residual array, no sign-flip pass in the backward); ``obs`` itself gets no gradient."""
-    return _CeleriteLogLike.apply(t, resid, diag, coef_real, coef_complex, None if obs is None else obs.detach())
+    residual array, no sign-flip pass in the backward); ``obs`` itself gets no gradient.
+    ``pair_kind`` (D,Jc) int32: 1 where a row of ``coef_complex`` holds two real terms
+    (a1, c1, a2, c2) instead of a complex one (include/exoplanet_amd.h).  ``n_chunks``: how the
+    series is cut for the time-parallel recurrences (None: EXO_GP_CHUNKS, else the library's plan)."""
+    if n_chunks is None:
+        n_chunks = default_chunks()
+    return _CeleriteLogLike.apply(t, resid, diag, coef_real, coef_complex, None if obs is None else obs.detach(),
+                                  None if pair_kind is None else pair_kind.detach(), n_chunks)
+
+
+_SORTED = {}
+
+
+def _known_sorted(t):
+    """True if ``t`` is non-decreasing.  A device tensor is looked at once (one host
+    synchronisation) and remembered by (storage, length, version): a sampler calls ``compute`` with
+    the same time array every step, and a step that is being captured into a hipGraph must not
+    synchronise."""
+    if not t.is_cuda:
+        return not bool((t[1:] < t[:-1]).any())
+    key = (t.data_ptr(), t.numel(), t._version, str(t.device))
+    ok = _SORTED.get(key)
+    if ok is None:
+        if torch.cuda.is_current_stream_capturing():
+            return True   # cannot look during a capture; the warm-up runs before it did
+        ok = not bool((t[1:] < t[:-1]).any())
+        if len(_SORTED) > 64:
+            _SORTED.clear()
+        _SORTED[key] = ok
+    return ok
 
 
 class GaussianProcess:
@@ -122,7 +172,7 @@ class GaussianProcess:
         t = as_tensor(t)
         if t.dim() != 1:
             raise ValueError("dimension mismatch: t must be 1-D")
-        if check_sorted and t.numel() > 1 and bool((t[1:] < t[:-1]).any()):
+        if check_sorted and t.numel() > 1 and not _known_sorted(t):
             raise ValueError("the input coordinates must be sorted")
         if yerr is None and diag is None:
             var = torch.zeros_like(t)
@@ -138,17 +188,18 @@ class GaussianProcess:
         self._diag = var if var.dim() == 2 else var.reshape(1, -1)
 
     def _coefficients(self):
-        """(coef_real (D,Jr,2), coef_complex (D,Jc,4), D, batched?)"""
-        ar, cr, ac, bc, cc, dc = self.kernel.get_coefficients()
-        batch = torch.broadcast_shapes(ar.shape[:-1], ac.shape[:-1])
+        """(coef_real (D,Jr,2), pair slots (D,Jc,4), their kind (D,Jc) int32 or None, D, batched?)"""
+        ar, cr, pairs, kind = self.kernel.pair_coefficients()
+        batch = torch.broadcast_shapes(ar.shape[:-1], pairs.shape[:-2])
         if len(batch) > 1:
             raise ValueError("at most one draw dimension is supported")
         D = batch[0] if batch else 1
         real = torch.stack(torch.broadcast_tensors(ar, cr), dim=-1)
-        cplx = torch.stack(torch.broadcast_tensors(ac, bc, cc, dc), dim=-1)
         real = real.expand((D,) + tuple(real.shape[-2:]))
-        cplx = cplx.expand((D,) + tuple(cplx.shape[-2:]))
-        return real, cplx, D, bool(batch)
+        cplx = pairs.expand((D,) + tuple(pairs.shape[-2:]))
+        if kind is not None:
+            kind = kind.expand((D, kind.shape[-1]))
+        return real, cplx, kind, D, bool(batch)
 
     def _prepare(self, y, fuse=False):
         if self._t is None:
@@ -168,26 +219,29 @@ class GaussianProcess:
             resid = y - mean
         if resid.shape[-1] != t.shape[0]:
             raise ValueError("dimension mismatch")
-        real, cplx, D, batched = self._coefficients()
+        real, cplx, kind, D, batched = self._coefficients()
         squeeze = resid.dim() == 1 and not batched and self._diag.shape[0] == 1
         D = max(D, resid.shape[0] if resid.dim() == 2 else 1, self._diag.shape[0])
         resid = resid.expand(D, t.shape[0]).contiguous()
         real = real.expand(D, real.shape[1], 2).contiguous()
         cplx = cplx.expand(D, cplx.shape[1], 4).contiguous()
-        return t, mean, resid, real, cplx, squeeze, obs
+        if kind is not None:
+            kind = kind.expand(D, kind.shape[1]).contiguous()
+        return t, mean, resid, real, cplx, squeeze, obs, kind
 
     def log_likelihood(self, y):
-        t, _, resid, real, cplx, squeeze, obs = self._prepare(y, fuse=True)
-        ll = celerite_loglike(t.detach(), resid, self._diag.contiguous(), real, cplx, obs=obs)
+        t, _, resid, real, cplx, squeeze, obs, kind = self._prepare(y, fuse=True)
+        ll = celerite_loglike(t.detach(), resid, self._diag.contiguous(), real, cplx, obs=obs, pair_kind=kind)
         return ll[0] if squeeze else ll
 
     def apply_inverse(self, y):
         """alpha = (K + diag)^-1 (y - mean), per draw (detached).  It is minus the gradient of the
         log-likelihood with respect to y, i.e. one forward + one reverse pass of the recurrences."""
-        t, _, resid, real, cplx, squeeze, _ = self._prepare(y)
+        t, _, resid, real, cplx, squeeze, _, kind = self._prepare(y)
         with torch.enable_grad():
             r = resid.detach().requires_grad_(True)
-            ll = celerite_loglike(t.detach(), r, self._diag.detach().contiguous(), real.detach(), cplx.detach())
+            ll = celerite_loglike(t.detach(), r, self._diag.detach().contiguous(), real.detach(), cplx.detach(),
+                                  pair_kind=kind)
             (g,) = torch.autograd.grad(ll.sum(), r)
         alpha = -g
         return alpha[0] if squeeze else alpha
@@ -197,7 +251,7 @@ class GaussianProcess:
         without the variance), detached.  At the data times (``t=None``) it is
         ``y - diag * alpha``; at other times ``K(t, t_data) alpha`` is formed densely in blocks
         of ``block`` prediction times (O(N M): meant for plots, not for the sampling loop)."""
-        tt, mean, resid, real, cplx, squeeze, _ = self._prepare(y)
+        tt, mean, resid, real, cplx, squeeze, _, kind = self._prepare(y)
         alpha = self.apply_inverse(y)
         alpha2 = alpha if alpha.dim() == 2 else alpha.unsqueeze(0)
         if t is None:
@@ -218,7 +272,10 @@ class GaussianProcess:
                         kv = kv + re[d, j, 0] * torch.exp(-re[d, j, 1] * tau)
                     for j in range(cx.shape[1]):
                         a, b, c, dd = cx[d, j]
-                        kv = kv + torch.exp(-c * tau) * (a * torch.cos(dd * tau) + b * torch.sin(dd * tau))
+                        if kind is not None and int(kind[d, j]) == 1:      # the slot holds two real terms
+                            kv = kv + a * torch.exp(-b * tau) + c * torch.exp(-dd * tau)
+                        else:
+                            kv = kv + torch.exp(-c * tau) * (a * torch.cos(dd * tau) + b * torch.sin(dd * tau))
                     rows.append(kv @ alpha2[d])
                 out.append(torch.stack(rows))
             mu = torch.cat(out, dim=-1)

@@ -30,6 +30,14 @@ class Term:
     def __radd__(self, other):
         return TermSum(other, self)
 
+    def pair_coefficients(self):
+        """(ar, cr, pairs, kind) -- what the kernels take (include/exoplanet_amd.h): real terms
+        ``ar, cr`` (*draws, Jr); pair slots ``pairs`` (*draws, Jc, 4), each a complex term
+        (a, b, c, d) or, where ``kind`` (*draws, Jc; int32, or None = all complex) is 1, two real
+        terms (a1, c1, a2, c2).  Never synchronises with the host: usable inside a captured step."""
+        ar, cr, ac, bc, cc, dc = self.get_coefficients()
+        return ar, cr, torch.stack(torch.broadcast_tensors(ac, bc, cc, dc), dim=-1), None
+
     def get_value(self, tau):
         """k(tau), dense; for tests and plotting"""
         ar, cr, ac, bc, cc, dc = self.get_coefficients()
@@ -55,6 +63,18 @@ class TermSum(Term):
         for i in range(6):
             out.append(torch.cat([p[i].expand(batch + (p[i].shape[-1],)) for p in parts], dim=-1))
         return tuple(out)
+
+    def pair_coefficients(self):
+        parts = [t.pair_coefficients() for t in self.terms]
+        batch = torch.broadcast_shapes(*[p[0].shape[:-1] for p in parts], *[p[2].shape[:-2] for p in parts])
+        ar = torch.cat([p[0].expand(batch + (p[0].shape[-1],)) for p in parts], dim=-1)
+        cr = torch.cat([p[1].expand(batch + (p[1].shape[-1],)) for p in parts], dim=-1)
+        pairs = torch.cat([p[2].expand(batch + tuple(p[2].shape[-2:])) for p in parts], dim=-2)
+        if all(p[3] is None for p in parts):
+            return ar, cr, pairs, None
+        kinds = [torch.zeros(batch + (p[2].shape[-2],), dtype=torch.int32, device=pairs.device) if p[3] is None
+                 else p[3].expand(batch + (p[3].shape[-1],)) for p in parts]
+        return ar, cr, pairs, torch.cat(kinds, dim=-1)
 
 
 class RealTerm(Term):
@@ -89,8 +109,12 @@ class SHOTerm(Term):
 
     Parameterised like celerite2's SHOTerm: amplitude ``S0`` or ``sigma``;
     frequency ``w0`` or ``rho`` (undamped period); damping ``Q`` or ``tau``.
-    Q < 1/2 gives two real terms, Q >= 1/2 one complex term; a batch of draws
-    must sit on one side (the celerite state width is static).
+    Q < 1/2 gives two real terms, Q >= 1/2 one complex term.  Either way the term occupies one
+    "pair slot" (two state indices) of the kernels, with the kind decided per draw ON THE DEVICE
+    (``pair_coefficients``): a batch of draws may straddle Q = 1/2, and nothing here synchronises
+    with the host -- a whole log-likelihood step can be captured in a hipGraph.  ``get_coefficients``
+    (celerite2's six arrays, whose shapes depend on the regime) needs all draws on one side and
+    looks at Q on the host: it is for plots and tests, not for the sampling loop.
     """
 
     def __init__(self, *, S0=None, sigma=None, w0=None, rho=None, Q=None, tau=None, eps=1e-5):
@@ -104,6 +128,20 @@ class SHOTerm(Term):
         self.w0 = as_tensor(w0) if w0 is not None else 2 * math.pi / as_tensor(rho)
         self.Q = as_tensor(Q, self.w0) if Q is not None else 0.5 * self.w0 * as_tensor(tau, self.w0)
         self.S0 = as_tensor(S0, self.w0) if S0 is not None else as_tensor(sigma, self.w0) ** 2 / (self.w0 * self.Q)
+
+    def pair_coefficients(self):
+        S0, w0, Q = torch.broadcast_tensors(self.S0, self.w0, self.Q)
+        over = Q.detach() < 0.5
+        # both parameterisations, each clamped inside its own domain, the draw's regime selects
+        fo = torch.sqrt(torch.clamp(1.0 - 4.0 * Q ** 2, min=self.eps))
+        fu = torch.sqrt(torch.clamp(4.0 * Q ** 2 - 1.0, min=self.eps))
+        a = S0 * w0 * Q
+        c = 0.5 * w0 / Q
+        two_real = torch.stack([0.5 * a * (1.0 + 1.0 / fo), c * (1.0 - fo), 0.5 * a * (1.0 - 1.0 / fo), c * (1.0 + fo)], dim=-1)
+        one_complex = torch.stack([a, a / fu, c, c * fu], dim=-1)
+        pairs = torch.where(over.unsqueeze(-1), two_real, one_complex).unsqueeze(-2)
+        e = _empty(S0.unsqueeze(-1))
+        return e, e, pairs, over.to(torch.int32).unsqueeze(-1)
 
     def get_coefficients(self):
         S0, w0, Q = torch.broadcast_tensors(self.S0, self.w0, self.Q)

@@ -99,7 +99,7 @@ class _QuadSV(torch.autograd.Function):
         r = _dev(r, "r")
         if b.shape != r.shape:
             raise ValueError("quad_solution_vector: b and r must have the same shape")
-        need = b.requires_grad or r.requires_grad
+        need = any(ctx.needs_input_grad)   # (not .requires_grad: forward runs under no_grad and .contiguous() may copy)
         s = torch.empty(b.shape + (3,), dtype=torch.float64, device=b.device)
         dsdb = torch.empty_like(s) if need else None
         dsdr = torch.empty_like(s) if need else None

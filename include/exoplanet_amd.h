@@ -13,7 +13,8 @@
  *     calls are asynchronous and stream-ordered, nothing is allocated inside;
  *   - return value: 0 = launched, EXO_ERR_* otherwise (no exceptions cross the
  *     boundary); numeric failure is in-band (NaN in -> NaN out, `flag` words);
- *   - the library keeps no global state: re-entrant, one process per GPU.
+ *   - the library keeps no global state (no caches, no environment reads): re-entrant,
+ *     one process per GPU.
  */
 #ifndef EXOPLANET_AMD_H
 #define EXOPLANET_AMD_H
@@ -236,45 +237,53 @@ int exo_radial_velocity_vjp_f64(const double* t, int64_t n_cad, const double* pa
  *   resid        [n_draw][n]       y - mean model, per draw
  *   diag         [n_diag][n]       white-noise variance (yerr^2 + jitter); n_diag = 1 (shared) or n_draw
  *   coef_real    [n_draw][n_real][2]     (a, c)        of celerite2 Term.get_coefficients()
- *   coef_complex [n_draw][n_complex][4]  (a, b, c, d)
+ *   coef_complex [n_draw][n_complex][4]  (a, b, c, d)  -- a "pair slot": two state indices
+ *   pair_kind    NULL, or [n_draw][n_complex] int32: 0 = the slot is a complex term (a, b, c, d);
+ *                1 = the slot holds TWO REAL terms (a1, c1, a2, c2).  An SHO term is one complex
+ *                term for Q >= 1/2 and two real ones for Q < 1/2 (celerite2 terms.SHOTerm): with
+ *                the kind per draw a batch of draws may straddle Q = 1/2 with a static state width
  *   J = n_real + 2 n_complex <= EXO_GP_MAX_J
  *   loglike      [n_draw]          out; -inf if the matrix is not positive definite
- *   state        NULL (value only) or exo_celerite_state_doubles() doubles: the
- *                factorisation (d, z; W, F and the rows of S per state index) the reverse
- *                pass re-reads -- per (cadence, draw) the pair (d, z), per (cadence, draw, state
- *                index) one record (W, F, row of S), the records of a cadence stored planar
- *                ([piece][draw x state index]: every access of a wave is one contiguous run) --
- *                followed by the pre-pass arrays and the workspace of the time-parallel path;
- *                16-byte aligned (16-B accesses).  Opaque to the caller: whatever wrote it
- *                (this library, this ABI version) must read it back
+ *   state        NULL (value only, sequential recurrences) or exo_celerite_state_doubles() doubles,
+ *                16-byte aligned: what the reverse pass re-reads.  Opaque to the caller: whatever
+ *                wrote it (this library, this ABI version, the same n_chunks) must read it back
+ *   n_chunks     how the series is cut for the time-parallel recurrences: 0 = the library's plan,
+ *                1 = sequential recurrences, > 1 = that many chunks (tuning / tests).  The three
+ *                calls of a pair -- exo_celerite_state_doubles, forward, reverse -- must be given
+ *                the same value (and n, n_draw, n_real, n_complex): the plan is a pure function of
+ *                them, the library keeps NO state between calls (EXO_ERR_WORKSPACE if state_doubles
+ *                is smaller than exo_celerite_state_doubles() of the same arguments)
  *
- * With a state buffer and n >= 64 the recurrences run in parallel over TIME
- * (DESIGN.md 3.5): the series is cut into chunks, chunk "filtering elements" and a short
- * per-draw scan over them give the recurrence state entering every chunk (and, in the
- * reverse pass, its adjoint), and the ordinary recurrences then run inside all chunks at
- * once.  Same results as the sequential recurrences (1e-14 relative in loglike); draws whose
- * terms do not admit the filter form (a <= 0 or |b d| > a c for some term) are redone by the
- * sequential kernels on the device.  The environment variable EXO_GP_CHUNKS, read by the
- * forward call (and by exo_celerite_state_doubles; a buffer sized under another setting that
- * turns out too small simply selects the sequential path), forces the number of chunks; 0
- * keeps everything sequential.  The reverse call cuts the series the way the forward call
- * that filled its state buffer did.
+ * With a state buffer and n >= 64 the recurrences run in parallel over TIME: the
+ * series is cut into chunks, chunk "filtering elements" and a short per-draw scan over them give
+ * the recurrence state entering every chunk (and, in the reverse pass, its adjoint), and the
+ * ordinary recurrences then run inside all chunks at once.  J <= 2: one lane per (draw, chunk) and
+ * a CHECKPOINTED factorisation -- the forward pass stores the recurrence state every 4 cadences,
+ * the reverse pass recomputes the cadences in between (which is why it takes the series again);
+ * J > 2: a draw on next_pow2(J) lanes, the full factorisation saved.  Same results as the
+ * sequential recurrences (1e-14 relative in loglike); draws whose terms do not admit the filter
+ * form (a <= 0 or |b d| > a c for some term) or are ill-conditioned are redone by the sequential
+ * kernels on the device.
  * ------------------------------------------------------------------------- */
 #define EXO_GP_MAX_J 8
-int64_t exo_celerite_state_doubles(int64_t n, int64_t n_draw, int32_t n_real, int32_t n_complex);
+int64_t exo_celerite_state_doubles(int64_t n, int64_t n_draw, int32_t n_real, int32_t n_complex,
+                                   int32_t n_chunks);
 int exo_celerite_loglike_fwd_f64(const double* t, const double* resid, const double* diag, int64_t n_diag,
                                  int64_t n, const double* coef_real, int32_t n_real,
-                                 const double* coef_complex, int32_t n_complex, int64_t n_draw,
-                                 double* loglike, double* state, int64_t state_doubles, void* stream);
-/* Reverse: given gloglike [n_draw] and the saved state, write
+                                 const double* coef_complex, int32_t n_complex, const int32_t* pair_kind,
+                                 int64_t n_draw, double* loglike, double* state, int64_t state_doubles,
+                                 int32_t n_chunks, void* stream);
+/* Reverse: given gloglike [n_draw], the series again and the saved state, write
  *   gresid [n_draw][n], gdiag [n_draw][n] (nullable), gdiag_sum [n_draw] (nullable,
  *   = sum_n d loglike / d diag_n, the cotangent of a scalar jitter),
- *   gcoef_real [n_draw][n_real][2], gcoef_complex [n_draw][n_complex][4].      */
-int exo_celerite_loglike_vjp_f64(const double* t, const double* diag, int64_t n_diag, int64_t n,
-                                 const double* coef_real, int32_t n_real, const double* coef_complex,
-                                 int32_t n_complex, int64_t n_draw, const double* gloglike,
-                                 const double* state, double* gresid, double* gdiag, double* gdiag_sum,
-                                 double* gcoef_real, double* gcoef_complex, void* stream);
+ *   gcoef_real [n_draw][n_real][2], gcoef_complex [n_draw][n_complex][4] (a pair slot of kind 1
+ *   receives the cotangents of (a1, c1, a2, c2)).                                  */
+int exo_celerite_loglike_vjp_f64(const double* t, const double* resid, const double* diag, int64_t n_diag,
+                                 int64_t n, const double* coef_real, int32_t n_real,
+                                 const double* coef_complex, int32_t n_complex, const int32_t* pair_kind,
+                                 int64_t n_draw, const double* gloglike, const double* state,
+                                 int64_t state_doubles, int32_t n_chunks, double* gresid, double* gdiag,
+                                 double* gdiag_sum, double* gcoef_real, double* gcoef_complex, void* stream);
 
 /* The same pair for the usual case of one observed series against a per-draw model:
  *   resid[d][n] = obs[n] - model[d][n]
@@ -285,14 +294,16 @@ int exo_celerite_loglike_vjp_f64(const double* t, const double* diag, int64_t n_
 int exo_celerite_loglike_obs_fwd_f64(const double* t, const double* obs, const double* model,
                                      const double* diag, int64_t n_diag, int64_t n,
                                      const double* coef_real, int32_t n_real,
-                                     const double* coef_complex, int32_t n_complex, int64_t n_draw,
-                                     double* loglike, double* state, int64_t state_doubles,
-                                     void* stream);
-int exo_celerite_loglike_obs_vjp_f64(const double* t, const double* diag, int64_t n_diag, int64_t n,
+                                     const double* coef_complex, int32_t n_complex,
+                                     const int32_t* pair_kind, int64_t n_draw, double* loglike,
+                                     double* state, int64_t state_doubles, int32_t n_chunks, void* stream);
+int exo_celerite_loglike_obs_vjp_f64(const double* t, const double* obs, const double* model,
+                                     const double* diag, int64_t n_diag, int64_t n,
                                      const double* coef_real, int32_t n_real,
-                                     const double* coef_complex, int32_t n_complex, int64_t n_draw,
-                                     const double* gloglike, const double* state, double* gmodel,
-                                     double* gdiag, double* gdiag_sum, double* gcoef_real,
+                                     const double* coef_complex, int32_t n_complex,
+                                     const int32_t* pair_kind, int64_t n_draw, const double* gloglike,
+                                     const double* state, int64_t state_doubles, int32_t n_chunks,
+                                     double* gmodel, double* gdiag, double* gdiag_sum, double* gcoef_real,
                                      double* gcoef_complex, void* stream);
 
 /* ---------------------------------------------------------------------------

@@ -280,6 +280,15 @@ static double sample(double tt, const double* rec, const double* c, int secondar
   return Fq * wq;
 }
 
+#ifdef _OPENMP
+#include <omp.h>
+void oracle_set_threads(int n) { omp_set_num_threads(n > 0 ? n : 1); }
+int oracle_max_threads(void) { return omp_get_max_threads(); }
+#else
+void oracle_set_threads(int n) { (void)n; }
+int oracle_max_threads(void) { return 1; }
+#endif
+
 /* value (+ optional vjp).  gflux == NULL -> forward only. */
 void oracle_transit(const double* t, int64_t n_cad, const double* texp, int64_t n_texp, const double* sdt,
                     const double* sw, int32_t n_sub, const double* params, const double* ld, int64_t n_draw,
@@ -294,6 +303,10 @@ void oracle_transit(const double* t, int64_t n_cad, const double* texp, int64_t 
     memset(gparams, 0, sizeof(double) * n_draw * n_planet * NPAR);
     memset(gld, 0, sizeof(double) * n_draw * nld);
   }
+  /* draws are independent (their gradient rows too): the all-core CPU baseline of bench.py runs one
+   * draw per thread -- the analogue of PyMC's one process per chain on every host core.  The
+   * thread count is OMP_NUM_THREADS / oracle_set_threads(); one thread = the scalar port.       */
+#pragma omp parallel for schedule(dynamic, 1) if (n_draw > 1)
   for (int64_t d = 0; d < n_draw; ++d) {
     const double* c = ld + d * nld;
     for (int64_t i = 0; i < n_cad; ++i) {

@@ -1,0 +1,114 @@
+// Test harness ONLY: compiles the one-lane celerite pipeline (exo_celerite_core.hpp) for the host
+// (g++) and runs it lane by lane -- filtering elements, scan, checkpointed chunk recurrences, the
+// adjoint scan and the recomputing reverse recurrences -- so that the whole time-parallel algorithm
+// is checked against the oracle on a machine without a GPU.  Not part of the product; nothing in
+// exoplanet_amd/ loads this.  On the GPU the same functions run one lane per (draw, chunk).
+#define EXO_HOST_BUILD 1
+#ifndef EXO_LANE_MAX_J
+#define EXO_LANE_MAX_J 4
+#endif
+#include "../exoplanet_amd/csrc/exo_celerite_core.hpp"
+
+#include <string.h>
+
+namespace {
+
+template <int J>
+void run_fwd(const double* t, gp::Series rs, const double* diag, int64_t n_diag, int64_t n, const gp::Coefs& cf,
+             int64_t n_draw, double* loglike, double* state, const gp::ChunkGeom& cg) {
+  const gp::ChunkWs ws = gp::chunk_ws(n, n_draw, J, cg);
+  for (int64_t d = 0; d < n_draw; ++d) {
+    gp::DeltaCoef<J> dc;
+    dc.init(cf, d);
+    state[ws.off_flag() + d] = dc.valid ? 0.0 : 1.0;
+  }
+  for (int c = 0; c < cg.C; ++c)
+    for (int64_t d = 0; d < n_draw; ++d) gp::elem_lane<J>(t, rs, diag, n_diag, n, cf, n_draw, state, cg, d, c);
+  for (int64_t d = 0; d < n_draw; ++d) gp::bscan_lane<J>(t, cf, n, n_draw, state, cg, d);
+  for (int c = 0; c < cg.C; ++c)
+    for (int64_t d = 0; d < n_draw; ++d) gp::chunk1_fwd_lane<J>(t, rs, diag, n_diag, n, cf, n_draw, state, cg, d, c, true);
+  for (int64_t d = 0; d < n_draw; ++d) {
+    double acc = 0.0, logdet = 0.0, bad = 0.0;
+    for (int c = 0; c < cg.C; ++c) {
+      acc += state[ws.part(c, 0, d)];
+      logdet += state[ws.part(c, 1, d)];
+      bad += state[ws.part(c, 2, d)];
+    }
+    loglike[d] = (bad > 0.0) ? -INFINITY : fma(-0.5, acc + logdet, -(double)n * gp::kHalfLog2Pi);
+  }
+}
+
+template <int J>
+void run_vjp(const double* t, gp::Series rs, const double* diag, int64_t n_diag, int64_t n, const gp::Coefs& cf,
+             int64_t n_draw, const double* gloglike, double* state, const gp::ChunkGeom& cg, double* gresid,
+             double* gdiag, double gsign, double* gdiag_sum, double* gcr, double* gcc) {
+  const gp::ChunkWs ws = gp::chunk_ws(n, n_draw, J, cg);
+  for (int c = 1; c < cg.C; ++c)
+    for (int64_t d = 0; d < n_draw; ++d) gp::badj_prep_lane<J>(gloglike, n, n_draw, state, cg, d, c);
+  for (int64_t d = 0; d < n_draw; ++d) gp::bscan_vjp_lane<J>(n, n_draw, state, cg, d);
+  for (int c = 0; c < cg.C; ++c)
+    for (int64_t d = 0; d < n_draw; ++d)
+      gp::chunk1_vjp_lane<J>(t, rs, diag, n_diag, n, cf, n_draw, gloglike, state, cg, gresid, gdiag, gsign, d, c);
+  for (int64_t d = 0; d < n_draw; ++d)
+    for (int k = 0; k < 4 * J + 1; ++k) {
+      double v = 0.0;
+      for (int c = 0; c < cg.C; ++c) v += state[ws.gpart(c, k, d)];
+      state[ws.gpart(0, k, d)] = v;
+    }
+  for (int64_t d = 0; d < n_draw; ++d)
+    for (int j = 0; j < J; ++j) gp::gcoef_lane(cf, n, n_draw, state, cg, gdiag_sum, gcr, gcc, d, j);
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t harness_gp_state_doubles(int64_t n, int64_t n_draw, int32_t n_real, int32_t n_complex, int32_t n_chunks) {
+  const int J = n_real + 2 * n_complex;
+  const gp::ChunkGeom cg = gp::chunk_plan(n, n_draw, J, n_chunks);
+  if (cg.C <= 1) return cg.base;
+  return cg.base + gp::chunk_ws(n, n_draw, J, cg).total();
+}
+
+// returns the number of chunks used (1: the plan is sequential, nothing was computed), -1 on bad J
+int harness_gp_fwd(const double* t, const double* y, const double* obs, const double* diag, int64_t n_diag, int64_t n,
+                   const double* real, int32_t n_real, const double* cplx, int32_t n_complex, const int32_t* kind,
+                   int64_t n_draw, int32_t n_chunks, double* loglike, double* state, double* flags) {
+  const gp::Coefs cf{real, cplx, kind, n_real, n_complex};
+  const int J = cf.J();
+  const gp::ChunkGeom cg = gp::chunk_plan(n, n_draw, J, n_chunks);
+  if (cg.C <= 1 || !cg.lane) return cg.C <= 1 ? 1 : -1;
+  const gp::Series rs{y, obs};
+  switch (J) {
+    case 1: run_fwd<1>(t, rs, diag, n_diag, n, cf, n_draw, loglike, state, cg); break;
+    case 2: run_fwd<2>(t, rs, diag, n_diag, n, cf, n_draw, loglike, state, cg); break;
+    case 3: run_fwd<3>(t, rs, diag, n_diag, n, cf, n_draw, loglike, state, cg); break;
+    case 4: run_fwd<4>(t, rs, diag, n_diag, n, cf, n_draw, loglike, state, cg); break;
+    default: return -1;
+  }
+  const gp::ChunkWs ws = gp::chunk_ws(n, n_draw, J, cg);
+  for (int64_t d = 0; d < n_draw; ++d) flags[d] = state[ws.off_flag() + d];
+  return cg.C;
+}
+
+int harness_gp_vjp(const double* t, const double* y, const double* obs, const double* diag, int64_t n_diag, int64_t n,
+                   const double* real, int32_t n_real, const double* cplx, int32_t n_complex, const int32_t* kind,
+                   int64_t n_draw, int32_t n_chunks, const double* gloglike, double* state, double* gresid,
+                   double* gdiag, double* gdiag_sum, double* gcr, double* gcc) {
+  const gp::Coefs cf{real, cplx, kind, n_real, n_complex};
+  const int J = cf.J();
+  const gp::ChunkGeom cg = gp::chunk_plan(n, n_draw, J, n_chunks);
+  if (cg.C <= 1 || !cg.lane) return cg.C <= 1 ? 1 : -1;
+  const gp::Series rs{y, obs};
+  const double gsign = obs ? -1.0 : 1.0;
+  switch (J) {
+    case 1: run_vjp<1>(t, rs, diag, n_diag, n, cf, n_draw, gloglike, state, cg, gresid, gdiag, gsign, gdiag_sum, gcr, gcc); break;
+    case 2: run_vjp<2>(t, rs, diag, n_diag, n, cf, n_draw, gloglike, state, cg, gresid, gdiag, gsign, gdiag_sum, gcr, gcc); break;
+    case 3: run_vjp<3>(t, rs, diag, n_diag, n, cf, n_draw, gloglike, state, cg, gresid, gdiag, gsign, gdiag_sum, gcr, gcc); break;
+    case 4: run_vjp<4>(t, rs, diag, n_diag, n, cf, n_draw, gloglike, state, cg, gresid, gdiag, gsign, gdiag_sum, gcr, gcc); break;
+    default: return -1;
+  }
+  return cg.C;
+}
+
+}  // extern "C"

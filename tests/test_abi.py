@@ -46,14 +46,15 @@ def test_abi_version_and_host_side_helpers(lib):
     assert lib.exo_transit_flux_workspace_bytes(-1, 1, 1) == -1
     # saved factorisation (+ the chunk workspace of the time-parallel path, when it is taken)
     base = 100 * 3 * (2 + 4 + 4 + 6)
-    assert lib.exo_celerite_state_doubles(100, 3, 0, 1) >= base
-    import os
-    os.environ["EXO_GP_CHUNKS"] = "0"
-    try:
-        assert lib.exo_celerite_state_doubles(100, 3, 0, 1) == base
-    finally:
-        del os.environ["EXO_GP_CHUNKS"]
-    assert lib.exo_celerite_state_doubles(100, 3, 0, 0) == -1
+    assert lib.exo_celerite_state_doubles(100, 3, 0, 1, 0) >= base
+    assert lib.exo_celerite_state_doubles(100, 3, 0, 1, 1) == base          # n_chunks = 1: sequential recurrences
+    # the plan is a pure function of the arguments (no environment, no state): same answer twice, and
+    # a forced chunk count changes it
+    a = lib.exo_celerite_state_doubles(150000, 1024, 0, 1, 0)
+    assert a == lib.exo_celerite_state_doubles(150000, 1024, 0, 1, 0) > 150000 * 1024 * (2 + 4 + 4 + 6)
+    assert lib.exo_celerite_state_doubles(150000, 1024, 0, 1, 64) != a
+    assert lib.exo_celerite_state_doubles(100, 3, 0, 0, 0) == -1
+    assert lib.exo_celerite_state_doubles(100, 3, 0, 1, -2) == -1
 
 
 def test_header_layout_constants_match_python(lib):
@@ -98,7 +99,7 @@ def test_rv_layout_constants_and_argument_checks(lib):
     assert lib.exo_transit_flux_ttv_fwd_f64(*args, 8, 8, int(consts["EXO_MAX_TTV_EDGES"]) + 1, None, None, 0, None) == INVALID
     assert lib.exo_transit_flux_ttv_vjp_f64(*args, 8, 8, 4, None, None, None, None, None, None, None, 0, None) == INVALID
     # observed-minus-model likelihood: the observed series is required
-    assert lib.exo_celerite_loglike_obs_fwd_f64(8, None, 8, 8, 1, 100, None, 0, 8, 1, 2, 8, None, 0, None) == INVALID
+    assert lib.exo_celerite_loglike_obs_fwd_f64(8, None, 8, 8, 1, 100, None, 0, 8, 1, None, 2, 8, None, 0, 0, None) == INVALID
 
 
 def test_missing_extension_fails_loudly(monkeypatch):

@@ -107,3 +107,52 @@ def test_draw_sharding_with_timing_tables_world2(tmp_path):
     np.testing.assert_array_equal(a, b)
     np.testing.assert_allclose(a, ref, rtol=1e-13)
     assert np.ptp(ref) > 0          # the draws really differ
+
+
+def _worker_bench_exchange(rank, world, port, n_global, out_dir):
+    """bench.py's own multi-GPU step function (the collective part: exchange_step on a
+    LoglikeExchange), equal shards -> all_gather_into_tensor, ragged -> all-reduce; and the same
+    over a sub-group whose ranks differ from the default group's (shard bounds must
+    come from the group the collective runs on)."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import bench
+        from exoplanet_amd.distributed import LoglikeExchange, gather_loglike, shard_bounds
+
+        lo, hi = shard_bounds(n_global)
+        ex = LoglikeExchange(n_global, torch.device("cpu"))
+        assert ex.equal == (n_global % world == 0)
+        for it in range(3):      # the buffer is reused step after step
+            local = torch.arange(lo, hi, dtype=torch.float64) * (it + 1) + 0.25
+            full = bench.exchange_step(ex, local)
+            want = torch.arange(n_global, dtype=torch.float64) * (it + 1) + 0.25
+            assert torch.equal(full, want), (rank, it, full, want)
+        with pytest.raises(ValueError):
+            ex(torch.zeros(hi - lo + 1, dtype=torch.float64))
+        # a group with the ranks in reverse order: position in the group != global rank
+        grp = dist.new_group(ranks=list(range(world))[::-1])
+        glo, ghi = shard_bounds(n_global, group=grp)
+        assert (glo, ghi) == shard_bounds(n_global, rank=dist.get_rank(grp), world=world)
+        out = gather_loglike(torch.arange(glo, ghi, dtype=torch.float64), n_global, group=grp)
+        assert torch.equal(out, torch.arange(n_global, dtype=torch.float64))
+        np.save(os.path.join(out_dir, f"ok_{rank}.npy"), np.ones(1))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_global", [8, 7])
+def test_bench_exchange_step_world2(tmp_path, n_global):
+    port = _free_port()
+    mp.spawn(_worker_bench_exchange, args=(2, port, n_global, str(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / "ok_0.npy").exists() and (tmp_path / "ok_1.npy").exists()
+
+
+def test_exchange_single_process():
+    from exoplanet_amd.distributed import LoglikeExchange, shard_bounds
+
+    assert shard_bounds(10, rank=1, world=3) == (4, 7)
+    ex = LoglikeExchange(5, torch.device("cpu"))
+    x = torch.arange(5, dtype=torch.float64)
+    assert torch.equal(ex(x), x) and ex(x) is ex.out

@@ -1,7 +1,8 @@
 """GPU: the time-parallel celerite path (chunk elements + per-draw scan over chunks + ordinary
 recurrences per chunk) against the sequential kernels and the dense oracle.
 
-EXO_GP_CHUNKS (read by the library at call time) forces the number of chunks; 0 = sequential."""
+EXO_GP_CHUNKS (read by the Python wrapper, handed to the library as the n_chunks argument of every
+call of a pair) forces the number of chunks; `chunks(0)` below = sequential recurrences (n_chunks = 1)."""
 import os
 
 import numpy as np
@@ -23,7 +24,7 @@ class chunks:
         if self.c is None:
             os.environ.pop("EXO_GP_CHUNKS", None)
         else:
-            os.environ["EXO_GP_CHUNKS"] = str(self.c)
+            os.environ["EXO_GP_CHUNKS"] = str(self.c if self.c else 1)   # 1 = sequential recurrences
 
     def __exit__(self, *a):
         if self.old is None:

@@ -90,8 +90,9 @@ def test_status_codes_for_invalid_arguments(dev):
     assert lib.exo_transit_flux_fwd_f64(p, 4, 0, 0, 0, 0, 1, p, p, 1, 0, 0, p, p, 1 << 20, st) == 1   # n_planet = 0
     assert lib.exo_transit_flux_fwd_f64(p, 4, 0, 0, 0, 0, 1, p, p, 1, 1, 0, p, p, 8, st) == 3         # workspace too small
     assert lib.exo_transit_flux_fwd_f64(p, 4, 0, 3, 0, 0, 1, p, p, 1, 1, 0, p, p, 1 << 20, st) == 1   # n_texp not in {0,1,n}
-    assert lib.exo_celerite_loglike_fwd_f64(p, p, p, 1, 4, p, 9, p, 0, 1, p, 0, 0, st) == 1            # J > 8
-    assert lib.exo_celerite_loglike_fwd_f64(p, p, p, 1, 4, p, 0, p, 1, 1, p, p, 4, st) == 3            # state too small
+    assert lib.exo_celerite_loglike_fwd_f64(p, p, p, 1, 4, p, 9, p, 0, 0, 1, p, 0, 0, 0, st) == 1      # J > 8
+    assert lib.exo_celerite_loglike_fwd_f64(p, p, p, 1, 4, p, 0, p, 1, 0, 1, p, p, 4, 0, st) == 3      # state too small
+    assert lib.exo_celerite_loglike_fwd_f64(p, p, p, 1, 4, p, 0, p, 1, 0, 1, p, 0, 0, -1, st) == 1     # n_chunks < 0
     assert lib.exo_pack_records_f64(p, p, 1, 17, 0, p, p, st) == 1
     torch.cuda.synchronize()
 

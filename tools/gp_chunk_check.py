@@ -45,7 +45,7 @@ if __name__ == "__main__":
         sys.exit(0)
     for D, N, kind in ([(int(a), int(b), c) for a, b, c in [x.split(",") for x in os.environ["CASES"].split()]] if os.environ.get("CASES") else [(64, 20000, "sho"), (1024, 150000, "sho"), (128, 65000, "rot"), (5, 3000, "rot")]):
         out = {}
-        for mode, env in (("chunked", {}), ("sequential", {"EXO_GP_CHUNKS": "0"})):
+        for mode, env in (("chunked", {}), ("sequential", {"EXO_GP_CHUNKS": "1"})):
             e = dict(os.environ); e.update(env)
             r = subprocess.run([sys.executable, __file__, str(D), str(N), kind], env=e, capture_output=True, text=True)
             if r.returncode != 0:

@@ -33,7 +33,7 @@ for case in range(int(sys.argv[2]) if len(sys.argv) > 2 else 60):
     amp2 = cr[..., 0].sum(-1) + cc[..., 0].sum(-1)
     diag = (10 ** rng.uniform(-7, 0, size=(D, 1)) * amp2[:, None]) * (1 + 0.3 * rng.uniform(size=(D, N)))
     y = np.sqrt(amp2)[:, None] * rng.normal(size=(D, N))
-    want = run(t, y, diag, cr, cc, 0); got = run(t, y, diag, cr, cc, None)
+    want = run(t, y, diag, cr, cc, 1)   # n_chunks = 1: sequential recurrences; got = run(t, y, diag, cr, cc, None)
     kappa = amp2 / diag.min(-1) * (1.0 if os.environ.get("KAPPA_PLAIN") else (1 + ((cc[..., 1] / cc[..., 0]) ** 2).max(-1)))
     for d in range(D):
         if not np.isfinite(want[0][d]): continue

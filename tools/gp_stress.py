@@ -48,7 +48,7 @@ for case in range(n_cases):
     amp = np.sqrt(cr[..., 0].sum(-1) + cc[..., 0].sum(-1))
     diag = (10 ** rng.uniform(-6, 0, size=(D, 1)) * amp[:, None] ** 2) * (1 + 0.3 * rng.uniform(size=(D, N)))
     y = amp[:, None] * rng.normal(size=(D, N))
-    want = run(t, y, diag, cr, cc, 0)
+    want = run(t, y, diag, cr, cc, 1)   # n_chunks = 1: sequential recurrences
     for chunks in (None, int(rng.integers(2, 60))):
         got = run(t, y, diag, cr, cc, chunks)
         ok = np.isfinite(want[0])

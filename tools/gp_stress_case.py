@@ -37,7 +37,7 @@ for case in range(target + 1):
     diag = (10 ** rng.uniform(-6, 0, size=(D, 1)) * amp[:, None] ** 2) * (1 + 0.3 * rng.uniform(size=(D, N)))
     y = amp[:, None] * rng.normal(size=(D, N))
     rng.integers(2, 60)
-seq = run(t, y, diag, cr, cc, 0)
+seq = run(t, y, diag, cr, cc, 1)
 chk = run(t, y, diag, cr, cc, None)
 print("case", target, "J", n_real, n_cplx, "N", N, "D", D, "dtm", dtm)
 for d in range(D):
