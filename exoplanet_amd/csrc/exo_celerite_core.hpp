@@ -65,15 +65,19 @@ EXO_HD LaneCoef lane_coef(const Coefs& co, int64_t draw, int j, int J) {
   } else {
     const int jc = (j - co.n_real) >> 1, second = (j - co.n_real) & 1;
     const double* p = co.cplx + (draw * co.n_complex + jc) * 4;
-    const bool two_real = co.kind && co.kind[draw * co.n_complex + jc] != 0;
-    if (two_real) {
-      k.real = true;
-      k.a = p[2 * second]; k.c = p[2 * second + 1];
-      k.slot = jc * 4 + 2 * second;
-    } else {
-      k.a = p[0]; k.b = p[1]; k.c = p[2]; k.d = p[3];
-      k.odd = second != 0;
-    }
+    // the slot's four doubles are loaded whatever its kind and SELECTED afterwards: the kind varies
+    // from lane to lane, and loads through a pointer chosen inside that divergent branch were
+    // miscompiled by hipcc 7.2 for gfx950 (address register left undefined for one side)
+    const double p0 = p[0], p1 = p[1], p2 = p[2], p3 = p[3];
+    const int kd = co.kind ? co.kind[draw * co.n_complex + jc] : 0;
+    const bool two_real = kd != 0;
+    k.real = two_real;
+    k.a = two_real ? (second ? p2 : p0) : p0;
+    k.b = two_real ? 0.0 : p1;
+    k.c = two_real ? (second ? p3 : p1) : p2;
+    k.d = two_real ? 0.0 : p3;
+    k.odd = !two_real && second != 0;
+    k.slot = two_real ? jc * 4 + 2 * second : -1;
   }
   return k;
 }

@@ -44,7 +44,7 @@ constexpr int kTargetBlocks = EXO_TARGET_BLOCKS;  // ~16 resident-or-queued bloc
 constexpr uint32_t kFlagNoFluxDev = 0x80000000u;
 constexpr int kNG = 10;                 // compact gradient slots per planet
 constexpr int kMaxMerge = 8;            // scan blocks per heavy block, at most
-constexpr int kWin = 5;                 // doubles per record written by transit_window_kernel
+constexpr int kWin = 7;                 // doubles per record written by transit_window_kernel
 // compact slot order
 enum { G_N = 0, G_TP, G_ECC, G_COSW, G_SINW, G_COSI, G_AOR, G_ROR, G_FR, G_PAD };
 
@@ -87,9 +87,13 @@ __device__ double mean_anomaly_of(double f, double e, double se, double pe) {
 // the scan kernel's per-cadence test is then a phase wrap and a compare, and only cadences
 // inside a window go on to the position-based classifier.
 //   out[kWin] = { nrev = n / 2pi, c0 = -(tp nrev + mid_transit), mid_transit - mid_occultation,
-//                 half_transit, half_occultation }
+//                 half_transit, half_occultation, inner_transit, inner_occultation }
 // in revolutions of mean anomaly: the phase of cadence t is fma(t, nrev, c0), wrapped to +-1/2.
-// q >= 1 or anything non-finite: halves = inf, every cadence goes on.
+// q >= 1 or anything non-finite: halves = inf, every cadence goes on.  inner_*: an ESTIMATE of the
+// half-width of the part of the window in which the small disk is wholly inside the large one
+// (b + r < 1; 0 if never): the run-enumeration path sorts a window's cadences into "inside" and
+// "limb" with it, so that a wave's vote on entering the arc geometry of the solution vector is
+// nearly always unanimous.  A wrong estimate costs time, never a result.
 //
 // With EXO_FLAG_WINDOW the caller's contact-point windows (record slots T0, PERIOD, TS, TE[, TS2,
 // TE2]; keplerian.py:729-731,765-769) are put in the same form instead -- revolutions of the
@@ -114,6 +118,16 @@ __global__ __launch_bounds__(kBlock) void transit_window_kernel(const double* __
     // a hair wider than the reference's closed interval: a cadence exactly at a contact has zero flux
     o[3] = fin ? fma(0.5 * (te - ts) * ip, 1.0 + 1e-12, 1e-14) : __builtin_inf();
     o[4] = fin2 ? fma(0.5 * (te2 - ts2) * ip, 1.0 + 1e-12, 1e-14) : __builtin_inf();
+    // inner parts: chord ratio sqrt((1-r)^2 - b^2) / sqrt((1+r)^2 - b^2) of the contact window,
+    // b = impact parameter at the conjunction
+    const double wn_ = sqrt(cw * cw + sw * sw), r_ = fabs(p[EXO_P_ROR]);
+    const double sinw_ = wn_ > 0.0 ? sw / wn_ : 0.0;
+    for (int k = 0; k < 2; ++k) {
+      const double bk = fabs(p[EXO_P_AOR] * p[EXO_P_COSI]) * (1.0 - e * e) / (1.0 + (k ? -e : e) * sinw_);
+      const double in2 = (1.0 - r_) * (1.0 - r_) - bk * bk, out2 = (1.0 + r_) * (1.0 + r_) - bk * bk;
+      const double h = o[3 + k];
+      o[5 + k] = (r_ < 1.0 && in2 > 0.0 && out2 > 0.0 && h < __builtin_inf()) ? 0.95 * h * sqrt(in2 / out2) : 0.0;
+    }
     return;
   }
   const double nrev = p[EXO_P_N] * (0.5 / exo::kPi);
@@ -121,6 +135,7 @@ __global__ __launch_bounds__(kBlock) void transit_window_kernel(const double* __
   o[1] = -p[EXO_P_TP] * nrev;
   o[2] = 0.0;
   o[3] = o[4] = __builtin_inf();
+  o[5] = o[6] = 0.0;
   if (!(e >= 0.0 && e < 1.0)) return;  // NaN everywhere: every cadence must reach the heavy kernel
   const double wn = sqrt(cw * cw + sw * sw);
   const double q = (1.0 + fabs(p[EXO_P_ROR])) / (fabs(p[EXO_P_AOR]) * (1.0 - e) * wn);
@@ -134,6 +149,15 @@ __global__ __launch_bounds__(kBlock) void transit_window_kernel(const double* __
     const double lo = mean_anomaly_of(f0 - delta, e, se, pe), hi = mean_anomaly_of(f0 + delta, e, se, pe);
     mid[k] = 0.5 * (lo + hi) * (0.5 / exo::kPi);
     o[3 + k] = 0.5 * (hi - lo) * (0.5 / exo::kPi) * (1.0 + 1e-5) + 1e-6;
+    // inner part: |sky-plane x| < sqrt((1-r)^2 - b^2) at the conjunction's star-planet distance
+    const double sinw = sw / wn, r = fabs(p[EXO_P_ROR]);
+    const double dist = fabs(p[EXO_P_AOR]) * (1.0 - e * e) / (1.0 + (k ? -e : e) * sinw);
+    const double bk = dist * fabs(p[EXO_P_COSI]);
+    const double in2 = (1.0 - r) * (1.0 - r) - bk * bk;
+    if (r < 1.0 && in2 > 0.0 && dist > 0.0) {
+      const double din = asin(fmin(0.95 * sqrt(in2) / dist, 1.0));
+      o[5 + k] = 0.5 * (mean_anomaly_of(f0 + din, e, se, pe) - mean_anomaly_of(f0 - din, e, se, pe)) * (0.5 / exo::kPi);
+    }
   }
   o[1] = -fma(p[EXO_P_TP], nrev, mid[0]);
   o[2] = mid[0] - mid[1];

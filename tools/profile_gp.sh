@@ -1,12 +1,12 @@
 #!/bin/bash
 # rocprofv3 kernel stats of the GP legs of C3 and C5 (tools/profile_gp.py), time-parallel and sequential
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-out=$R/gpurun_out/gp_prof
+out=$R/gpurun_out/${GP_PROF_TAG:-gp_prof}
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 for cfg in c3 c5; do
-  for mode in chunked sequential; do
-    if [ $mode = sequential ]; then export EXO_GP_CHUNKS=0; else unset EXO_GP_CHUNKS; fi
+  for mode in ${GP_PROF_MODES:-chunked sequential}; do
+    if [ $mode = sequential ]; then export EXO_GP_CHUNKS=1; else unset EXO_GP_CHUNKS; fi
     rocprofv3 --kernel-trace --stats --output-format csv -d $out/${cfg}_$mode -o p -- python $R/tools/profile_gp.py $cfg > /dev/null 2>&1
   done
 done
