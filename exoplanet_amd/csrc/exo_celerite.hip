@@ -1152,15 +1152,21 @@ __global__ __launch_bounds__(kWave) void celerite_chunk_vjp_kernel(
 // functions the host harness of tests/ runs lane by lane).  Lanes of a wave are consecutive draws,
 // the chunk is blockIdx.y: every access to the chunk workspace and to the checkpoints is coalesced.
 // ---------------------------------------------------------------------------------------------
+// Term layouts (exo_celerite_core.hpp, DeltaCoef): NR >= 0 -- the first NR state indices are real
+// terms, the rest complex pairs -- is a compile-time constant of the kernel; NR = -1 decides per index
+// at run time.  Every variant is a kernel of its own (its own register budget); a wave votes on the
+// layout of its draws (layout_vote) and returns at once from the variants it did not vote for, so the
+// host may launch several variants of one step when pair kinds are given per draw.
 // (A) the filtering element of every (draw, chunk)
-template <int J>
+template <int J, int NR>
 __global__ __launch_bounds__(kWave) void celerite_elem_kernel(const double* __restrict__ t, Series rs,
                                                               const double* __restrict__ diag, int64_t n_diag, int64_t n,
                                                               Coefs cf, int64_t n_draw, double* __restrict__ state,
                                                               ChunkGeom cg) {
   const int64_t draw = (int64_t)blockIdx.x * kWave + threadIdx.x;
   if (draw >= n_draw) return;
-  elem_lane<J>(t, rs, diag, n_diag, n, cf, n_draw, state, cg, draw, (int)blockIdx.y);
+  if (layout_vote<J>(cf, draw) != NR) return;
+  elem_lane<J, NR>(t, rs, diag, n_diag, n, cf, n_draw, state, cg, draw, (int)blockIdx.y);
 }
 
 // (B) the state entering every chunk: C - 1 element applications per draw
@@ -1190,16 +1196,17 @@ __global__ __launch_bounds__(kWave) void celerite_bscan_vjp_kernel(int64_t n, in
 }
 
 // (C) / (C') with a checkpointed factorisation, J <= kLaneMaxJ
-template <int J>
+template <int J, int NR>
 __global__ __launch_bounds__(kWave) void celerite_chunk1_fwd_kernel(const double* __restrict__ t, Series rs,
                                                                     const double* __restrict__ diag, int64_t n_diag,
                                                                     int64_t n, Coefs cf, int64_t n_draw,
                                                                     double* __restrict__ state, ChunkGeom cg) {
   const int64_t draw = (int64_t)blockIdx.x * kWave + threadIdx.x;
   if (draw >= n_draw) return;
-  chunk1_fwd_lane<J>(t, rs, diag, n_diag, n, cf, n_draw, state, cg, draw, (int)blockIdx.y, true);
+  if (layout_vote<J>(cf, draw) != NR) return;
+  chunk1_fwd_lane<J, NR>(t, rs, diag, n_diag, n, cf, n_draw, state, cg, draw, (int)blockIdx.y, true);
 }
-template <int J>
+template <int J, int NR>
 __global__ __launch_bounds__(kWave) void celerite_chunk1_vjp_kernel(const double* __restrict__ t, Series rs,
                                                                     const double* __restrict__ diag, int64_t n_diag,
                                                                     int64_t n, Coefs cf, int64_t n_draw,
@@ -1209,7 +1216,8 @@ __global__ __launch_bounds__(kWave) void celerite_chunk1_vjp_kernel(const double
                                                                     double gsign) {
   const int64_t draw = (int64_t)blockIdx.x * kWave + threadIdx.x;
   if (draw >= n_draw) return;
-  chunk1_vjp_lane<J>(t, rs, diag, n_diag, n, cf, n_draw, gloglike, state, cg, gresid, gdiag, gsign, draw, (int)blockIdx.y);
+  if (layout_vote<J>(cf, draw) != NR) return;
+  chunk1_vjp_lane<J, NR>(t, rs, diag, n_diag, n, cf, n_draw, gloglike, state, cg, gresid, gdiag, gsign, draw, (int)blockIdx.y);
 }
 
 // sum over the wave in a fixed order (xor butterfly), result in every lane
@@ -1295,14 +1303,31 @@ int64_t exo_celerite_state_doubles(int64_t n, int64_t n_draw, int32_t n_real, in
     case 8: { constexpr int JJ = 8; CALL; } break; \
     default: return EXO_ERR_INVALID_ARGUMENT;      \
   }
-// the one-lane chunk kernels exist for J <= kLaneMaxJ only
-#define EXO_GP_DISPATCH_LANE(J_, CALL) \
-  switch (J_) {                        \
-    case 1: { constexpr int JJ = 1; CALL; } break; \
-    case 2: { constexpr int JJ = 2; CALL; } break; \
-    default: return EXO_ERR_INVALID_ARGUMENT;      \
+static_assert(kLaneMaxJ == 2, "EXO_GP_LAYOUTS lists the layouts of the one-lane path (J <= 2)");
+// CALL with `JJ` and `NR` for every layout variant the draws of a call may need (layout_vote):
+// J = 1: one real term; J = 2: two real terms or one pair slot -- complex, or, with per-draw kinds,
+// either (three launches: waves return at once from the variants they did not vote for); J > 2:
+// run-time flags.
+#define EXO_GP_LAYOUTS(J_, CF, CALL)                                                    \
+  switch (J_) {                                                                         \
+    case 1: { constexpr int JJ = 1, NR = 1; CALL; } break;                              \
+    case 2:                                                                             \
+      if ((CF).n_real == 2) { constexpr int JJ = 2, NR = 2; CALL; }                     \
+      else if (!(CF).kind) { constexpr int JJ = 2, NR = 0; CALL; }                      \
+      else {                                                                            \
+        { constexpr int JJ = 2, NR = 0; CALL; }                                         \
+        { constexpr int JJ = 2, NR = 2; CALL; }                                         \
+        { constexpr int JJ = 2, NR = -1; CALL; }                                        \
+      }                                                                                 \
+      break;                                                                            \
+    case 3: { constexpr int JJ = 3, NR = -1; CALL; } break;                             \
+    case 4: { constexpr int JJ = 4, NR = -1; CALL; } break;                             \
+    case 5: { constexpr int JJ = 5, NR = -1; CALL; } break;                             \
+    case 6: { constexpr int JJ = 6, NR = -1; CALL; } break;                             \
+    case 7: { constexpr int JJ = 7, NR = -1; CALL; } break;                             \
+    case 8: { constexpr int JJ = 8, NR = -1; CALL; } break;                             \
+    default: return EXO_ERR_INVALID_ARGUMENT;                                           \
   }
-static_assert(kLaneMaxJ == 2, "EXO_GP_DISPATCH_LANE lists the state widths of the one-lane path");
 
 static int celerite_fwd(const double* t, Series resid, const double* diag, int64_t n_diag, int64_t n, Coefs cf,
                         int64_t n_draw, double* loglike, double* state, int64_t state_doubles, int32_t n_chunks,
@@ -1341,8 +1366,8 @@ static int celerite_fwd(const double* t, Series resid, const double* diag, int64
         EXO_GP_DISPATCH(J, hipLaunchKernelGGL((celerite_elem_lg_kernel<JJ>), cgrid, block, 0, st, t, resid, diag, n_diag,
                                               n, cf, n_draw, state, cg))
       } else {
-        EXO_GP_DISPATCH(J, hipLaunchKernelGGL((celerite_elem_kernel<JJ>), egrid, block, 0, st, t, resid, diag, n_diag, n,
-                                              cf, n_draw, state, cg))
+        EXO_GP_LAYOUTS(J, cf, hipLaunchKernelGGL((celerite_elem_kernel<JJ, NR>), egrid, block, 0, st, t, resid, diag, n_diag,
+                                                 n, cf, n_draw, state, cg))
       }
       // after the element kernel: it may flag more draws (measurement variance too small)
       hipLaunchKernelGGL(celerite_prep_flagged_kernel, dim3(8, (unsigned)n_draw), dim3(256), 0, st, t, n, cf, n_draw, J,
@@ -1355,8 +1380,8 @@ static int celerite_fwd(const double* t, Series resid, const double* diag, int64
                                               cg))
       }
       if (cg.lane) {
-        EXO_GP_DISPATCH_LANE(J, hipLaunchKernelGGL((celerite_chunk1_fwd_kernel<JJ>), egrid, block, 0, st, t, resid, diag,
-                                                   n_diag, n, cf, n_draw, state, cg))
+        EXO_GP_LAYOUTS(J, cf, hipLaunchKernelGGL((celerite_chunk1_fwd_kernel<(JJ <= kLaneMaxJ ? JJ : 1), NR>), egrid, block, 0,
+                                                 st, t, resid, diag, n_diag, n, cf, n_draw, state, cg))
       } else {
         EXO_GP_DISPATCH(J, hipLaunchKernelGGL((celerite_chunk_fwd_kernel<JJ>), cgrid, block, 0, st, t, resid, diag, n_diag,
                                               n, cf, n_draw, state, cg))
@@ -1401,8 +1426,9 @@ static int celerite_vjp(const double* t, Series resid, const double* diag, int64
                                           0, st, gloglike, n, n_draw, wstate, cg))
     EXO_GP_DISPATCH(J, hipLaunchKernelGGL((celerite_bscan_vjp_kernel<JJ>), per_draw, block, 0, st, n, n_draw, wstate, cg))
     if (cg.lane) {
-      EXO_GP_DISPATCH_LANE(J, hipLaunchKernelGGL((celerite_chunk1_vjp_kernel<JJ>), egrid, block, 0, st, t, resid, diag,
-                                                 n_diag, n, cf, n_draw, gloglike, wstate, cg, gresid, gdiag, gsign))
+      EXO_GP_LAYOUTS(J, cf, hipLaunchKernelGGL((celerite_chunk1_vjp_kernel<(JJ <= kLaneMaxJ ? JJ : 1), NR>), egrid, block, 0,
+                                               st, t, resid, diag, n_diag, n, cf, n_draw, gloglike, wstate, cg, gresid,
+                                               gdiag, gsign))
     } else {
       EXO_GP_DISPATCH(J, hipLaunchKernelGGL((celerite_chunk_vjp_kernel<JJ>), cgrid, block, 0, st, t, n, cf, n_draw,
                                             gloglike, wstate, cg, gresid, gdiag, gsign))

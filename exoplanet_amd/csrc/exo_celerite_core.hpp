@@ -12,7 +12,10 @@
 #include <math.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "exo_math.hpp"
+
 
 #ifdef EXO_HOST_BUILD
 #define EXO_HDH inline
@@ -104,10 +107,47 @@ struct Series {
   const double* y;
   const double* obs;
 };
+// A lane owns one ROW of a [draw][cadence] array: consecutive lanes are n cadences apart, so every
+// load instruction of a wave touches 64 different cache lines, and cadence-by-cadence 8-byte
+// accesses fetch each line eight times over (the lines of 16 waves do not stay in a 32 KB L1:
+// measured 1.6 ms for the forward chunk kernel of C3, 9.8 GB through L2 for 1.2 GB of data).  The
+// chunk kernels therefore move a row kCkptB = 4 cadences at a time, as two 16-byte accesses per
+// lane whenever the row is 16-byte aligned there.
+struct alignas(16) D2 {
+  double x, y;
+};
+EXO_HD void row_load4(const double* EXO_RESTRICT row, int64_t i, int len, double* v) {
+  if (len == 4 && (reinterpret_cast<uintptr_t>(row + i) & 15) == 0) {
+    const D2 a = *reinterpret_cast<const D2*>(row + i), b = *reinterpret_cast<const D2*>(row + i + 2);
+    v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y;
+  } else {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = q < len ? row[i + q] : 0.0;
+  }
+}
+EXO_HD void row_store4(double* EXO_RESTRICT row, int64_t i, int len, const double* v) {
+  if (len == 4 && (reinterpret_cast<uintptr_t>(row + i) & 15) == 0) {
+    *reinterpret_cast<D2*>(row + i) = D2{v[0], v[1]};
+    *reinterpret_cast<D2*>(row + i + 2) = D2{v[2], v[3]};
+  } else {
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (q < len) row[i + q] = v[q];
+  }
+}
+
 struct SeriesRow {
   const double* EXO_RESTRICT y;
   const double* EXO_RESTRICT obs;
   EXO_HD double operator[](int64_t i) const { return obs ? obs[i] - y[i] : y[i]; }
+  // cadences i .. i + 3 (the first `len` of them exist)
+  EXO_HD void load4(int64_t i, int len, double* v) const {
+    row_load4(y, i, len, v);
+    if (obs) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v[q] = (q < len ? obs[i + q] : 0.0) - v[q];
+    }
+  }
 };
 
 struct ChunkGeom {
@@ -146,6 +186,28 @@ struct ChunkWs {
   EXO_HDH int64_t ckpt(int64_t g, int k, int64_t draw) const { return off_ckpt() + (g * K() + k) * n_draw + draw; }
   EXO_HDH int64_t total() const { return off_ckpt() + n_blk * K() * n_draw - base; }
 };
+
+// the series and the measurement variance of one block of four cadences [b0, b0 + 4) clipped to n1.
+// The chunk kernels load the NEXT block's before they work through the current one: a lane's row
+// accesses miss every cache, and with 2-4 waves per SIMD nothing else hides ~1 us of latency per block.
+struct BlockIn {
+  double y[4], g[4];
+};
+EXO_HD void load_block(const SeriesRow& y, const double* EXO_RESTRICT dg, int64_t n_diag, int64_t b0, int64_t n1, BlockIn& o) {
+  const int len = (int)((n1 - b0 < 4) ? (n1 - b0 > 0 ? n1 - b0 : 0) : 4);
+  if (len == 0) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { o.y[q] = 0.0; o.g[q] = 1.0; }
+    return;
+  }
+  y.load4(b0, len, o.y);
+  if (n_diag == 1) {   // shared by all draws: every lane reads the same address
+#pragma unroll
+    for (int q = 0; q < 4; ++q) o.g[q] = q < len ? dg[b0 + q] : 1.0;
+  } else {
+    row_load4(dg, b0, len, o.g);
+  }
+}
 
 constexpr int kChunkMaxJ = 8;   // = EXO_GP_MAX_J (J = 7, 8: lane-group element kernel, one-lane scan kernels spill)
 #ifndef EXO_LANE_MAX_J
@@ -207,11 +269,17 @@ struct Sym {
 // Delta_n of one draw from its term coefficients and V_n (block diagonal: 1x1 / 2x2 blocks).
 // Delta is symmetric with Delta_n U_n = V_n: the state covariance of the process the kernel
 // describes, in celerite's rotating frame (exo_celerite.hip, "Time-parallel path").
-template <int J>
+// NR: the term layout, when it is known at compile time -- the first NR state indices are real terms,
+// the rest complex pairs -- or -1: decided per index at run time (pair slots of mixed kinds).  The
+// one-lane kernels pick the variant by a wave vote (with_layout): with the layout a constant, the
+// per-index selects and branches of the recurrences fold away (a third of their instructions).
+template <int J, int NR = -1>
 struct DeltaCoef {
   double p[J], q[J], r[J];   // per state index: real term -> p = 1/a; pair -> (p, q, r) on both indices
   bool real[J], first[J];    // first: first index of a complex pair
   bool valid;
+  EXO_HD bool is_real(int j) const { return NR < 0 ? real[j] : j < NR; }
+  EXO_HD bool is_first(int j) const { return NR < 0 ? first[j] : (j >= NR && ((j - NR) & 1) == 0); }
   EXO_HD void init(const Coefs& co, int64_t draw) {
     valid = true;
 #pragma unroll
@@ -219,7 +287,7 @@ struct DeltaCoef {
       const LaneCoef k = lane_coef(co, draw, j, J);
       real[j] = k.real;
       first[j] = !k.real && !k.odd;
-      if (k.real) {
+      if (is_real(j)) {
         p[j] = 1.0 / k.a; q[j] = 0.0; r[j] = 0.0;
         valid = valid && (k.a > 0.0) && (k.c >= 0.0) && (k.a < INFINITY) && (k.c < INFINITY);
       } else {
@@ -237,9 +305,9 @@ struct DeltaCoef {
     for (int k = 0; k < J * (J + 1) / 2; ++k) D.v[k] = 0.0;
 #pragma unroll
     for (int j = 0; j < J; ++j) {
-      if (real[j]) {
+      if (is_real(j)) {
         D(j, j) = p[j];
-      } else if (first[j] && j + 1 < J) {
+      } else if (is_first(j) && j + 1 < J) {
         const double cs = V[j], sn = V[j + 1];
         D(j, j) = p[j] * cs * cs + 2.0 * q[j] * cs * sn + r[j] * sn * sn;
         D(j, j + 1) = (p[j] - r[j]) * cs * sn + q[j] * (sn * sn - cs * cs);
@@ -251,19 +319,24 @@ struct DeltaCoef {
 
 // U_n, V_n for all J state indices of one draw (one sincos per complex pair); same arithmetic as
 // lane_uv, so the values are those the lane-group kernels compute
-template <int J>
+template <int J, int NR = -1>
 struct DrawCoef {
   LaneCoef k[J];
+  // rotation of a pair's (cos, sin) by d dt, for the step size dt_rot (see uv_step)
+  double rc[J], rs[J], dt_rot, dt_last;
+  EXO_HD bool is_real(int j) const { return NR < 0 ? k[j].real : j < NR; }
+  EXO_HD bool is_first(int j) const { return NR < 0 ? (!k[j].real && !k[j].odd) : (j >= NR && ((j - NR) & 1) == 0); }
   EXO_HD void init(const Coefs& co, int64_t draw) {
 #pragma unroll
-    for (int j = 0; j < J; ++j) k[j] = lane_coef(co, draw, j, J);
+    for (int j = 0; j < J; ++j) { k[j] = lane_coef(co, draw, j, J); rc[j] = 1.0; rs[j] = 0.0; }
+    dt_rot = dt_last = -1.0;
   }
   EXO_HD void uv(double t, double* U, double* V) const {
 #pragma unroll
     for (int j = 0; j < J; ++j) {
-      if (k[j].real) {
+      if (is_real(j)) {
         U[j] = k[j].a; V[j] = 1.0;
-      } else if (!k[j].odd) {
+      } else if (is_first(j)) {
         double sn, cs;
         exo::sincos_any(k[j].d * t, &sn, &cs);
         U[j] = k[j].a * cs + k[j].b * sn; V[j] = cs;
@@ -275,32 +348,93 @@ struct DrawCoef {
   EXO_HD void u_from_v(const double* V, double* U) const {
 #pragma unroll
     for (int j = 0; j < J; ++j) {
-      if (k[j].real) {
+      if (is_real(j)) {
         U[j] = k[j].a;
-      } else if (!k[j].odd && j + 1 < J) {
+      } else if (is_first(j) && j + 1 < J) {
         U[j] = k[j].a * V[j] + k[j].b * V[j + 1];
         U[j + 1] = k[j].a * V[j + 1] - k[j].b * V[j];
       }
     }
   }
+  // (U, V) at time t, one step dt after the cadence whose V is Vp: on an evenly sampled stretch the
+  // pair's (cos, sin) is ROTATED by d dt (four multiply-adds instead of a 45-instruction sincos).
+  // The rotation for a step size is set up the second time in a row that step size is seen, so an
+  // unevenly sampled series pays one exact evaluation per cadence, as before.  Every kernel of the
+  // one-lane path restarts from the exact values at the same cadences (the first of each block of
+  // four, counted from the chunk start); three rotations in a row drift by ~3e-16, and kernels that
+  // reach a cadence with different step histories may differ there by that much.
+  EXO_HD void uv_step(double t, double dt, const double* Vp, double* U, double* V) {
+    if (dt != dt_rot) {   // wave-uniform on evenly sampled series
+      if (dt == dt_last) {
+#pragma unroll
+        for (int j = 0; j < J; ++j)
+          if (!is_real(j) && is_first(j)) exo::sincos_any(k[j].d * dt, &rs[j], &rc[j]);
+        dt_rot = dt;
+      }
+      dt_last = dt;
+      uv(t, U, V);
+      return;
+    }
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      if (is_real(j)) {
+        V[j] = 1.0;
+      } else if (is_first(j) && j + 1 < J) {
+        const double cs = Vp[j], sn = Vp[j + 1];
+        V[j] = fma(cs, rc[j], -sn * rs[j]);
+        V[j + 1] = fma(sn, rc[j], cs * rs[j]);
+      }
+    }
+    u_from_v(V, U);
+  }
   EXO_HD double asum() const {
     double s = 0.0;
 #pragma unroll
-    for (int j = 0; j < J; ++j) s += (k[j].real || !k[j].odd) ? k[j].a : 0.0;
+    for (int j = 0; j < J; ++j) s += (is_real(j) || is_first(j)) ? k[j].a : 0.0;
     return s;
   }
 };
 
-// (A) the filtering element of one (draw, chunk)
+// The term layout of this lane's draw, voted over the wave: f(std::integral_constant<int, NR>) is
+// called with NR = the number of leading real terms when every lane of the wave has the layout
+// "NR real terms, then complex pairs", and with NR = -1 (run-time flags) otherwise.  J <= 2: the
+// layouts are R (J = 1); R R or one complex pair (J = 2; R R also for a pair slot of kind 1).
 template <int J>
+EXO_HD int layout_vote(const Coefs& cf, int64_t draw) {
+  if (J == 1) return 1;
+  if (J == 2) {
+    const bool rr = cf.n_real == 2 || (cf.kind != nullptr && cf.kind[draw] != 0);   // (n_complex = 1: one slot per draw)
+    if (EXO_WAVE_ALL(!rr)) return 0;
+    if (EXO_WAVE_ALL(rr)) return 2;
+  }
+  return -1;
+}
+// (host harness: the variant as a call; on the device every variant is a kernel of its own -- its own
+// register budget -- and a wave returns at once from the variants it did not vote for)
+template <int J, typename F>
+EXO_HD void with_layout(const Coefs& cf, int64_t draw, F&& f) {
+  const int nr = layout_vote<J>(cf, draw);
+  if (J == 1) {
+    f(std::integral_constant<int, J == 1 ? 1 : -1>{});
+  } else if (J == 2 && nr == 0) {
+    f(std::integral_constant<int, J == 2 ? 0 : -1>{});
+  } else if (J == 2 && nr == 2) {
+    f(std::integral_constant<int, J == 2 ? 2 : -1>{});
+  } else {
+    f(std::integral_constant<int, -1>{});
+  }
+}
+
+// (A) the filtering element of one (draw, chunk)
+template <int J, int NR = -1>
 EXO_HD void elem_lane(const double* EXO_RESTRICT t, Series rs, const double* EXO_RESTRICT diag, int64_t n_diag,
                       int64_t n, const Coefs& cf, int64_t n_draw, double* EXO_RESTRICT state, const ChunkGeom& cg,
                       int64_t draw, int c) {
   const int64_t n0 = c * cg.L, n1 = (n0 + cg.L < n) ? n0 + cg.L : n;
   const ChunkWs ws = chunk_ws(n, n_draw, J, cg);
-  DeltaCoef<J> dc;
+  DeltaCoef<J, NR> dc;
   dc.init(cf, draw);
-  DrawCoef<J> co;
+  DrawCoef<J, NR> co;
   co.init(cf, draw);
   const SeriesRow y{rs.y + draw * n, rs.obs};
   const double* EXO_RESTRICT dg = diag + (n_diag == 1 ? 0 : draw * n);
@@ -331,14 +465,21 @@ EXO_HD void elem_lane(const double* EXO_RESTRICT t, Series rs, const double* EXO
   double asum = 0.0, ba2 = 0.0;
 #pragma unroll
   for (int j = 0; j < J; ++j) {
-    asum += (co.k[j].real || !co.k[j].odd) ? fabs(co.k[j].a) : 0.0;
-    if (!co.k[j].real && !co.k[j].odd) ba2 = fmax(ba2, (co.k[j].b * co.k[j].b) / (co.k[j].a * co.k[j].a));
+    asum += (co.is_real(j) || co.is_first(j)) ? fabs(co.k[j].a) : 0.0;
+    if (!co.is_real(j) && co.is_first(j)) ba2 = fmax(ba2, (co.k[j].b * co.k[j].b) / (co.k[j].a * co.k[j].a));
   }
   const double rmin = (1.0 + ba2) * asum * 1e-5;
   bool ok = true;
+  BlockIn cur, nxt;
+  load_block(y, dg, n_diag, n0, n1, cur);
 #pragma unroll 1
-  for (int64_t i = n0; i < n1; ++i) {
-    const double yi = y[i], R = dg[i];
+  for (int64_t b0 = n0; b0 < n1; b0 += 4) {
+   load_block(y, dg, n_diag, b0 + 4, n1, nxt);   // in flight while this block is worked through
+#pragma unroll
+   for (int q = 0; q < 4; ++q) {
+    const int64_t i = b0 + q;
+    if (i < n1) {
+    const double yi = cur.y[q], R = cur.g[q];
     ok = ok && (R >= rmin) && (R < INFINITY);
     double r[J], cu[J];
     double s = R, zeta = yi;
@@ -351,7 +492,7 @@ EXO_HD void elem_lane(const double* EXO_RESTRICT t, Series rs, const double* EXO
       s = fma(U[l], cl, s);
       zeta = fma(-U[l], b[l], zeta);
     }
-    const double is = 1.0 / s;
+    const double is = exo::fast_rcp(s);
 #pragma unroll
     for (int j = 0; j < J; ++j) {
       eta[j] = fma(r[j] * is, zeta, eta[j]);
@@ -367,7 +508,10 @@ EXO_HD void elem_lane(const double* EXO_RESTRICT t, Series rs, const double* EXO
         for (int j = 0; j < J; ++j) phi[j] = exp(-co.k[j].c * dt);
         dt_prev = dt;
       }
-      co.uv(tn, U, Vn);
+      // exact at the first cadence of every block of four (counted from the chunk start), rotated in between
+      if (((i + 1 - n0) & 3) == 0) co.uv(tn, U, Vn); else co.uv_step(tn, dt, V, U, Vn);
+#pragma unroll
+      for (int j = 0; j < J; ++j) V[j] = Vn[j];
       Sym<J> Dn;
       dc.eval(Vn, Dn);
 #pragma unroll
@@ -382,6 +526,9 @@ EXO_HD void elem_lane(const double* EXO_RESTRICT t, Series rs, const double* EXO
       }
       Dl = Dn;
     }
+    }
+   }
+   cur = nxt;
   }
   if (!ok) state[ws.off_flag() + draw] = 1.0;
   int e = 0;
@@ -709,7 +856,7 @@ template <int J>
 struct Fwd {
   Sym<J> S;
   double F[J], W[J], U[J], V[J];
-  double d, z;
+  double d, z, id;   // id = 1 / d
   EXO_HD void measure(double yi, double diag_plus_asum) {
     double u[J];
     double pd = 0.0, pz = 0.0;
@@ -724,7 +871,7 @@ struct Fwd {
     }
     d = diag_plus_asum - pd;
     z = yi - pz;
-    const double id = 1.0 / d;
+    id = exo::fast_rcp(d);   // seed + two Newton steps: 1 ulp, a third of the IEEE division sequence
 #pragma unroll
     for (int j = 0; j < J; ++j) W[j] = (V[j] - u[j]) * id;
   }
@@ -747,7 +894,8 @@ struct Phi {
 #pragma unroll
     for (int j = 0; j < J; ++j) v[j] = 1.0;
   }
-  EXO_HD void set(const DrawCoef<J>& co, double dt) {
+  template <int NR>
+  EXO_HD void set(const DrawCoef<J, NR>& co, double dt) {
     if (dt != dt_prev) {
 #pragma unroll
       for (int j = 0; j < J; ++j) v[j] = exp(-co.k[j].c * dt);
@@ -758,13 +906,13 @@ struct Phi {
 
 // (C) forward: acc = sum z^2 / d, log det and the "not positive definite" mark of the chunk go to the
 // chunk partials; (F, S) at the first cadence of every checkpoint block goes to the checkpoints.
-template <int J>
+template <int J, int NR = -1>
 EXO_HD void chunk1_fwd_lane(const double* EXO_RESTRICT t, Series rs, const double* EXO_RESTRICT diag, int64_t n_diag,
                             int64_t n, const Coefs& cf, int64_t n_draw, double* EXO_RESTRICT state, const ChunkGeom& cg,
                             int64_t draw, int c, bool save) {
   const int64_t n0 = c * cg.L, n1 = (n0 + cg.L < n) ? n0 + cg.L : n;
   const ChunkWs ws = chunk_ws(n, n_draw, J, cg);
-  DrawCoef<J> co;
+  DrawCoef<J, NR> co;
   co.init(cf, draw);
   const double asum = co.asum();
   const SeriesRow y{rs.y + draw * n, rs.obs};
@@ -774,7 +922,7 @@ EXO_HD void chunk1_fwd_lane(const double* EXO_RESTRICT t, Series rs, const doubl
   for (int j = 0; j < J; ++j) { f.U[j] = f.V[j] = f.W[j] = 0.0; }
   {
     // entering state from (B) as (F, P): S = Delta_{n0} - P
-    DeltaCoef<J> dc;
+    DeltaCoef<J, NR> dc;
     dc.init(cf, draw);
     co.uv(t[n0], f.U, f.V);
     Sym<J> Dl;
@@ -791,18 +939,29 @@ EXO_HD void chunk1_fwd_lane(const double* EXO_RESTRICT t, Series rs, const doubl
   double acc = 0.0, lman = 1.0;
   int64_t lsum = 0;
   bool bad = false;
+  static_assert(kCkptB == 4, "row_load4 / row_store4 move one checkpoint block");
+  BlockIn cur, nxt;
+  load_block(y, dg, n_diag, n0, n1, cur);
 #pragma unroll 1
   for (int64_t b0 = n0; b0 < n1; b0 += kCkptB) {
+    load_block(y, dg, n_diag, b0 + kCkptB, n1, nxt);   // in flight while this block is worked through
 #pragma unroll
     for (int q = 0; q < kCkptB; ++q) {
       const int64_t i = b0 + q;
       if (i < n1) {
         if (i > n0) {   // (the entering state is already at n0)
-          const double ti = t[i];
-          phi.set(co, ti - tprev);
+          const double ti = t[i], dt = ti - tprev;
+          phi.set(co, dt);
           tprev = ti;
           f.advance(phi.v);
-          co.uv(ti, f.U, f.V);
+          if (q == 0) {
+            co.uv(ti, f.U, f.V);
+          } else {
+            double Vp[J];
+#pragma unroll
+            for (int j = 0; j < J; ++j) Vp[j] = f.V[j];
+            co.uv_step(ti, dt, Vp, f.U, f.V);
+          }
         }
         if (q == 0 && save) {   // checkpoint: the state AT the block's first cadence (after the step into it)
           const int64_t g = b0 / kCkptB;
@@ -811,14 +970,15 @@ EXO_HD void chunk1_fwd_lane(const double* EXO_RESTRICT t, Series rs, const doubl
 #pragma unroll
           for (int k = 0; k < J * (J + 1) / 2; ++k) state[ws.ckpt(g, J + k, draw)] = f.S.v[k];
         }
-        f.measure(y[i], dg[i] + asum);
+        f.measure(cur.y[q], cur.g[q] + asum);
         bad = bad || !(f.d > 0.0);
-        acc = fma(f.z * f.z, 1.0 / f.d, acc);
+        acc = fma(f.z * f.z, f.id, acc);
         int lexp;
         lman = frexp(lman * (f.d > 0.0 ? f.d : 1.0), &lexp);
         lsum += lexp;
       }
     }
+    cur = nxt;
   }
   state[ws.part(c, 0, draw)] = acc;
   state[ws.part(c, 1, draw)] = log(lman) + (double)lsum * 0.69314718055994530942;
@@ -827,7 +987,7 @@ EXO_HD void chunk1_fwd_lane(const double* EXO_RESTRICT t, Series rs, const doubl
 
 // (C') reverse.  Hand-derived adjoint of the two recurrences (same algebra as celerite_vjp_kernel
 // of exo_celerite.hip, one lane holding every state index): Sb is the SYMMETRISED adjoint of S.
-template <int J>
+template <int J, int NR = -1>
 struct Rev {
   double Sb[J][J], Fb[J], Wb[J];
   double db, zb, gasum;
@@ -836,13 +996,13 @@ struct Rev {
   // measurement half of cadence i: adjoints of (d, z, W) of this cadence -> (S, F) of this cadence
   // and the coefficient cotangents through U, V.  W = (V - S U) / d is rebuilt (the step keeps V).
   // Returns zbar (d loglike / d y_i) and dbar (d loglike / d diag_i).
-  EXO_HD void measure(const DrawCoef<J>& co, const Step<J>& s, double ti, double gL, double* W_out, double* zbar_out,
+  EXO_HD void measure(const DrawCoef<J, NR>& co, const Step<J>& s, double ti, double gL, double* W_out, double* zbar_out,
                       double* dbar_out) {
     double U[J], u[J], W[J];
 #pragma unroll
     for (int j = 0; j < J; ++j) U[j] = 0.0;
     co.u_from_v(s.V, U);
-    const double id = 1.0 / s.d;
+    const double id = exo::fast_rcp(s.d);
     double wdot = 0.0;
 #pragma unroll
     for (int j = 0; j < J; ++j) {
@@ -880,9 +1040,9 @@ struct Rev {
     // coefficient cotangents: a real term's U = a; a complex pair's (a, b, d) collect on its first index
 #pragma unroll
     for (int j = 0; j < J; ++j) {
-      if (co.k[j].real) {
+      if (co.is_real(j)) {
         ga[j] += Ub[j];
-      } else if (!co.k[j].odd && j + 1 < J) {
+      } else if (co.is_first(j) && j + 1 < J) {
         const double cs = s.V[j], sn = s.V[j + 1];
         const double a = co.k[j].a, b = co.k[j].b;
         ga[j] += Ub[j] * cs + Ub[j + 1] * sn;
@@ -929,20 +1089,20 @@ struct Rev {
 };
 
 // gsign: +1 writes d loglike / d resid; -1 writes d loglike / d model (obs - model series)
-template <int J>
+template <int J, int NR = -1>
 EXO_HD void chunk1_vjp_lane(const double* EXO_RESTRICT t, Series rs, const double* EXO_RESTRICT diag, int64_t n_diag,
                             int64_t n, const Coefs& cf, int64_t n_draw, const double* EXO_RESTRICT gloglike,
                             double* EXO_RESTRICT state, const ChunkGeom& cg, double* EXO_RESTRICT gresid,
                             double* EXO_RESTRICT gdiag, double gsign, int64_t draw, int c) {
   const int64_t n0 = c * cg.L, n1 = (n0 + cg.L < n) ? n0 + cg.L : n;
   const ChunkWs ws = chunk_ws(n, n_draw, J, cg);
-  DrawCoef<J> co;
+  DrawCoef<J, NR> co;
   co.init(cf, draw);
   const double asum = co.asum();
   const SeriesRow y{rs.y + draw * n, rs.obs};
   const double* EXO_RESTRICT dg = diag + (n_diag == 1 ? 0 : draw * n);
   const double gL = gloglike[draw];
-  Rev<J> r;
+  Rev<J, NR> r;
 #pragma unroll
   for (int j = 0; j < J; ++j) {
     r.Fb[j] = state[ws.bnd(2, c, j, draw)];
@@ -957,20 +1117,37 @@ EXO_HD void chunk1_vjp_lane(const double* EXO_RESTRICT t, Series rs, const doubl
   // first cadence of the block after it, or of the next chunk) still has to be reversed
   const int64_t nb = (n1 - n0 + kCkptB - 1) / kCkptB;
   bool pend = n1 < n;
+  constexpr int kK = J + J * (J + 1) / 2;
+  // inputs of a block: its checkpoint (F, packed S) and its cadences of the series
+  BlockIn cur, nxt;
+  double ck[kK], ck_nxt[kK];
+  auto load_ckpt = [&](int64_t b0, double* dst) {
+    const int64_t g = b0 / kCkptB;
+#pragma unroll
+    for (int k = 0; k < kK; ++k) dst[k] = state[ws.ckpt(g, k, draw)];
+  };
+  load_block(y, dg, n_diag, n0 + (nb - 1) * kCkptB, n1, cur);
+  load_ckpt(n0 + (nb - 1) * kCkptB, ck);
+  nxt = cur;
+#pragma unroll
+  for (int k = 0; k < kK; ++k) ck_nxt[k] = ck[k];
 #pragma unroll 1
   for (int64_t bi = nb - 1; bi >= 0; --bi) {
     const int64_t b0 = n0 + bi * kCkptB;
     const int len = (int)((n1 - b0 < kCkptB) ? n1 - b0 : kCkptB);
+    if (bi > 0) {   // the block before this one: in flight while this one is worked through
+      load_block(y, dg, n_diag, b0 - kCkptB, n1, nxt);
+      load_ckpt(b0 - kCkptB, ck_nxt);
+    }
     // recompute the block forward from its checkpoint, keeping every cadence's state
     Step<J> st[kCkptB];
     double tt[kCkptB];
     {
       Fwd<J> f;
-      const int64_t g = b0 / kCkptB;
 #pragma unroll
-      for (int j = 0; j < J; ++j) { f.F[j] = state[ws.ckpt(g, j, draw)]; f.U[j] = f.V[j] = f.W[j] = 0.0; }
+      for (int j = 0; j < J; ++j) { f.F[j] = ck[j]; f.U[j] = f.V[j] = f.W[j] = 0.0; }
 #pragma unroll
-      for (int k = 0; k < J * (J + 1) / 2; ++k) f.S.v[k] = state[ws.ckpt(g, J + k, draw)];
+      for (int k = 0; k < J * (J + 1) / 2; ++k) f.S.v[k] = ck[J + k];
       double tprev = t[b0];
 #pragma unroll
       for (int q = 0; q < kCkptB; ++q) {
@@ -978,12 +1155,18 @@ EXO_HD void chunk1_vjp_lane(const double* EXO_RESTRICT t, Series rs, const doubl
           const double ti = t[b0 + q];
           tt[q] = ti;
           if (q > 0) {
-            phi.set(co, ti - tprev);
+            const double dt = ti - tprev;
+            phi.set(co, dt);
             tprev = ti;
             f.advance(phi.v);
+            double Vp[J];
+#pragma unroll
+            for (int j = 0; j < J; ++j) Vp[j] = f.V[j];
+            co.uv_step(ti, dt, Vp, f.U, f.V);
+          } else {
+            co.uv(ti, f.U, f.V);
           }
-          co.uv(ti, f.U, f.V);
-          f.measure(y[b0 + q], dg[b0 + q] + asum);
+          f.measure(cur.y[q], cur.g[q] + asum);
           st[q].S = f.S;
           st[q].d = f.d; st[q].z = f.z;
 #pragma unroll
@@ -1008,7 +1191,7 @@ EXO_HD void chunk1_vjp_lane(const double* EXO_RESTRICT t, Series rs, const doubl
 #pragma unroll
           for (int j = 0; j < J; ++j) U[j] = 0.0;
           co.u_from_v(st[q].V, U);
-          const double id = 1.0 / st[q].d;
+          const double id = exo::fast_rcp(st[q].d);
 #pragma unroll
           for (int j = 0; j < J; ++j) {
             double uj = 0.0;
@@ -1028,7 +1211,7 @@ EXO_HD void chunk1_vjp_lane(const double* EXO_RESTRICT t, Series rs, const doubl
 #pragma unroll
           for (int j = 0; j < J; ++j) U[j] = 0.0;
           co.u_from_v(st[q - 1].V, U);
-          const double id = 1.0 / st[q - 1].d;
+          const double id = exo::fast_rcp(st[q - 1].d);
 #pragma unroll
           for (int j = 0; j < J; ++j) {
             double uj = 0.0;
@@ -1045,12 +1228,12 @@ EXO_HD void chunk1_vjp_lane(const double* EXO_RESTRICT t, Series rs, const doubl
     pend = true;   // the step from the previous block's last cadence into b0
     // gresid / gdiag are [draw][cadence]: the block's cadences are consecutive doubles of one row
 #pragma unroll
-    for (int q = 0; q < kCkptB; ++q) {
-      if (q < len) {
-        gresid[draw * n + b0 + q] = gsign * zbar[q];
-        if (gdiag) gdiag[draw * n + b0 + q] = dbar[q];
-      }
-    }
+    for (int q = 0; q < kCkptB; ++q) zbar[q] *= gsign;
+    row_store4(gresid + draw * n, b0, len, zbar);
+    if (gdiag) row_store4(gdiag + draw * n, b0, len, dbar);
+    cur = nxt;
+#pragma unroll
+    for (int k = 0; k < kK; ++k) ck[k] = ck_nxt[k];
   }
 #pragma unroll
   for (int j = 0; j < J; ++j) {

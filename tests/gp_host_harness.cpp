@@ -23,10 +23,16 @@ void run_fwd(const double* t, gp::Series rs, const double* diag, int64_t n_diag,
     state[ws.off_flag() + d] = dc.valid ? 0.0 : 1.0;
   }
   for (int c = 0; c < cg.C; ++c)
-    for (int64_t d = 0; d < n_draw; ++d) gp::elem_lane<J>(t, rs, diag, n_diag, n, cf, n_draw, state, cg, d, c);
+    for (int64_t d = 0; d < n_draw; ++d)
+      gp::with_layout<J>(cf, d, [&](auto nr) {
+        gp::elem_lane<J, decltype(nr)::value>(t, rs, diag, n_diag, n, cf, n_draw, state, cg, d, c);
+      });
   for (int64_t d = 0; d < n_draw; ++d) gp::bscan_lane<J>(t, cf, n, n_draw, state, cg, d);
   for (int c = 0; c < cg.C; ++c)
-    for (int64_t d = 0; d < n_draw; ++d) gp::chunk1_fwd_lane<J>(t, rs, diag, n_diag, n, cf, n_draw, state, cg, d, c, true);
+    for (int64_t d = 0; d < n_draw; ++d)
+      gp::with_layout<J>(cf, d, [&](auto nr) {
+        gp::chunk1_fwd_lane<J, decltype(nr)::value>(t, rs, diag, n_diag, n, cf, n_draw, state, cg, d, c, true);
+      });
   for (int64_t d = 0; d < n_draw; ++d) {
     double acc = 0.0, logdet = 0.0, bad = 0.0;
     for (int c = 0; c < cg.C; ++c) {
@@ -48,7 +54,10 @@ void run_vjp(const double* t, gp::Series rs, const double* diag, int64_t n_diag,
   for (int64_t d = 0; d < n_draw; ++d) gp::bscan_vjp_lane<J>(n, n_draw, state, cg, d);
   for (int c = 0; c < cg.C; ++c)
     for (int64_t d = 0; d < n_draw; ++d)
-      gp::chunk1_vjp_lane<J>(t, rs, diag, n_diag, n, cf, n_draw, gloglike, state, cg, gresid, gdiag, gsign, d, c);
+      gp::with_layout<J>(cf, d, [&](auto nr) {
+        gp::chunk1_vjp_lane<J, decltype(nr)::value>(t, rs, diag, n_diag, n, cf, n_draw, gloglike, state, cg, gresid, gdiag,
+                                                    gsign, d, c);
+      });
   for (int64_t d = 0; d < n_draw; ++d)
     for (int k = 0; k < 4 * J + 1; ++k) {
       double v = 0.0;
