@@ -9,14 +9,16 @@ Workload = BASELINE.json configs[1] ("C2"): single planet, e = 0.3
 omega = 1.1, P = 3.5 d, t0 = 1, b = 0.3, r = 0.1, (u1, u2) = (0.3, 0.2), 150 000
 two-minute cadences, float64, cotangent gbar ~ N(0,1), use_in_transit=False: the
 output is the DENSE flux array [draws][150 000]; every cadence is classified on
-the device, the ~3 % that can overlap the stellar disk are solved (Kepler +
-solution vector + reverse sweep), the rest are written as zeros.  One
+the device (binary search of the conjunction windows in the sorted time array),
+the ~3 % that can overlap the stellar disk are solved (Kepler + solution vector
++ reverse sweep), the rest are written as zeros.  One
 *evaluation* = forward flux for all 150 000 cadences of one posterior draw + the
 VJP of gbar back to all orbit / limb-darkening parameters.  One *step* = one
 pass of the hot path over a batch of `--draws-per-gpu` draws (base parameters x
 (1 + 1e-3 N(0,1))): leaf parameters -> record-packing kernel (KeplerianOrbit
-algebra + get_cl) -> window + scan + heavy + reduce kernels (value + VJP in one
-sweep) -> packing VJP -> leaf gradients, replayed as one hipGraph.  With N > 1
+algebra + get_cl) -> window + run-enumeration + heavy + finish kernels (value +
+VJP in one sweep; the heavy kernel zero-fills the dense flux array while it
+solves) -> packing VJP -> leaf gradients, replayed as one hipGraph.  With N > 1
 ranks each own their draws and exchange only the per-draw scalar sum(gbar*flux):
 ONE collective per step (exoplanet_amd.distributed.LoglikeExchange).  Default is
 weak scaling (fixed draws per GPU); `--global-draws G` fixes the total instead
@@ -46,7 +48,6 @@ N_CAD = 150_000
 CADENCE = 2.0 / 1440.0
 SURVEY_BYTES_PER_UNIT = 24       # SURVEY.md 8d count: read t 8 + read gbar 8 + write flux 8 per (draw, cadence)
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
-SCAN_DRAW_GROUP = 4              # draws that share one read of t in the scan kernel (exo_transit.hip, kScanDraws)
 
 
 def hip_runtime():
@@ -534,18 +535,21 @@ def main():
         one(i)
     torch.cuda.synchronize(dev)
     kernel_ms, per_launch = events.mean_ms()
-    flux_now = static["flux"] if graph is not None else one(-1)[0]
-    n_active = int((flux_now != 0).sum().item())
+    # cadences the sweep solves = the runs of the conjunction windows (one sparse sweep, outside any timing)
+    with torch.no_grad():
+        orbit0 = xo.KeplerianOrbit(period=leaves["period"], t0=leaves["t0"], b=leaves["b"], ecc=leaves["ecc"],
+                                   omega=leaves["omega"])
+        rec0, ld0, _, flags0 = orbit0.kernel_inputs(leaves["r"], (leaves["u1"], leaves["u2"]), use_in_transit=False)
+        n_active = ops.transit_flux_sparse(t, rec0.detach(), ld0.detach(), flags=flags0).n_solved()
 
     out = None
     if rank == 0:
         evals = n_global * args.steps
-        # bytes this design must move per sweep: the dense flux array once; t once per group of draws
-        # that share a classify block; (t, gbar) and the 4-byte work-list entry (written by the scan
-        # kernel, read by the heavy kernel) for every cadence that is actually solved
-        groups = (D + SCAN_DRAW_GROUP - 1) // SCAN_DRAW_GROUP
-        req = {"flux_write": 8 * D * N_CAD, "t_read_per_draw_group": 8 * N_CAD * groups,
-               "t_and_gbar_active": 16 * n_active, "work_list_write_read": 8 * n_active}
+        # bytes this design must move per sweep: the dense flux array once (zeros); for every solved
+        # cadence t and gbar in, its flux out to the run-ordered value array, back in and out to its
+        # place in the flux array (the binary searches of the windows are a few MB)
+        req = {"flux_zero_fill": 8 * D * N_CAD, "t_and_gbar_solved": 16 * n_active,
+               "value_array_write_read": 16 * n_active, "flux_write_solved": 8 * n_active}
         req_bytes = sum(req.values())
         achieved = req_bytes / (kernel_ms * 1e-3) / 1e9
         survey_bytes = SURVEY_BYTES_PER_UNIT * D * N_CAD
@@ -569,15 +573,15 @@ def main():
                             f"cadence classified on the device, {100.0 * n_active / (D * N_CAD):.2f} % solved",
                 "n_cadences": N_CAD, "draws_per_gpu": D, "global_draws": n_global,
                 "parallelism": f"draws sharded over {world} GPU(s); one collective of per-draw scalars per step",
-                "step": "leaf params -> record-packing kernel (orbit algebra + get_cl) -> window + scan + heavy + "
-                        "reduce kernels (value+VJP, one sweep) -> packing VJP kernel -> leaf gradients"
+                "step": "leaf params -> record-packing kernel (orbit algebra + get_cl) -> window + run-enumeration + "
+                        "heavy + finish kernels (value+VJP, one sweep) -> packing VJP kernel -> leaf gradients"
                         + ("; replayed as one hipGraph" if graph is not None else "; eager launches"),
             },
             "timing": timing,
             "roofline": {
                 "bound": "hbm",
-                "kernel": "transit_window_kernel + transit_scan_kernel + transit_heavy_kernel + "
-                          "transit_vjp_reduce_kernel (one sweep)",
+                "kernel": "transit_sorted_kernel + transit_window_kernel + transit_enum_kernel + transit_runs_kernel + "
+                          "transit_finish_kernel (one sweep)",
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic["bytes"] if traffic else None,
                 "traffic_source": traffic["source"] if traffic else None,
@@ -587,15 +591,15 @@ def main():
                 "survey_8d_count": {"bytes_per_unit": SURVEY_BYTES_PER_UNIT, "bytes_per_launch": survey_bytes,
                                     "GBps": survey_bytes / (kernel_ms * 1e-3) / 1e9,
                                     "note": "SURVEY.md 8d charges t + gbar + flux = 24 B to EVERY (draw, cadence); "
-                                            "this design reads t once per 4 draws and gbar only for solved cadences, "
-                                            "so this figure is not a fraction of anything: `frac` above is against "
-                                            "the bytes the design must move"},
+                                            "this design finds the cadences to solve by binary search and reads t, gbar "
+                                            "only there, so this figure is not a fraction of anything: `frac` above is "
+                                            "against the bytes the design must move"},
                 "note": "achieved = algorithmic_bytes_per_launch / mean hipEvent time of the launches of one sweep "
-                        "(window constants, scan = classify + zero-fill, heavy = solved cadences, reduce = block "
-                        "partials), eager launches on the same inputs as the timed graph.  The sweep is two regimes: "
-                        "the scan kernel is bound by the store stream of the dense flux array, the heavy kernel by "
-                        "fp64 VALU issue (~1e3 flop per solved cadence); rocprof per-kernel averages and PMC "
-                        "traffic: profiles/",
+                        "(sortedness flags, window constants, run enumeration, heavy = solved cadences + zero-fill of "
+                        "the dense flux, finish = values to their cadences + block partials), eager launches on the "
+                        "same inputs as the timed graph.  The heavy kernel is where the time goes: fp64 VALU issue "
+                        "(~1e3 flop per solved cadence) with the store stream of the dense output interleaved; "
+                        "rocprof per-kernel averages and PMC traffic: profiles/",
             },
         }
 

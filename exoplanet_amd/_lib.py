@@ -33,6 +33,7 @@ _SIGNATURES = {
          _c_dp, _c_dp],
     ),
     "exo_transit_flux_workspace_bytes": (_i64, [_i64, _i64, _i32]),
+    "exo_transit_flux_sparse_layout": (ctypes.c_int, [_i64, _i64, _i32, ctypes.POINTER(_i64)]),
     "exo_transit_flux_vjp_f64": (
         ctypes.c_int,
         [_c_dp, _i64, _c_dp, _i64, _c_dp, _c_dp, _i32, _c_dp, _c_dp, _i64, _i32, _u32,

@@ -1237,6 +1237,373 @@ __global__ __launch_bounds__(kBlock) void transit_vjp_reduce_kernel(
   }
 }
 
+// ===========================================================================
+// Run-enumeration path: sorted times, one exposure time (or none) for all cadences, no timing tables.
+//
+// Where a planet can overlap the disk is known in closed form (the conjunction windows of
+// transit_window_kernel), the windows are periodic in mean anomaly, and t is sorted: so instead of
+// testing every (draw, cadence) -- 1.5e8 phase tests per sweep of C2, 0.12 ms -- each window's run of
+// cadences [lo, hi) is found by binary search in t (a few thousand searches per sweep).  The heavy
+// kernel then works through the runs densely, in full fp64 (no fp32 pre-filter: a cadence in a
+// window but off the disk costs one Kepler solve and returns 0), writes each cadence's flux to a
+// compact per-(draw, planet) value array in run order, and -- dense output -- zero-fills its share of
+// the flux array WHILE it computes (a few 1 KB non-temporal stores per wave and round: the store
+// stream of the dense output hides under the fp64 work instead of preceding it); a last small kernel
+// copies the runs' values to their cadences and sums the gradient partials.  With
+// EXO_FLAG_SPARSE the flux array is never touched: the runs and the value array ARE the output.
+//   t unsorted, a window that cannot be bounded, windows that overlap each other or more than
+//   kRunMax windows in the series: that list becomes the single run [0, n_cad) (every cadence solved).
+// ===========================================================================
+struct Run {
+  int32_t lo, a, b, hi;   // cadences [lo, a) and [b, hi): may touch the limb; [a, b): small disk wholly inside (a hint)
+};
+constexpr int kRunMax = 4096;     // windows per list
+constexpr int kSortBlock = 4096;  // cadences per sortedness flag
+constexpr int kSeg = 512;         // runs of one list a heavy block holds in LDS at a time
+
+struct RunLists {
+  int32_t* nrun;     // [n_list]                 windows of list = (draw, planet, event)
+  Run* runs;         // [n_list][r_max]
+  int32_t* pre_in;   // [n_list][r_max + 1]      exclusive prefix sums of b - a
+  int32_t* pre_all;  // [n_list][r_max + 1]      exclusive prefix sums of hi - lo (= position in the value array)
+  int r_max;
+};
+
+// is t non-decreasing?  one flag per kSortBlock cadences (the pair straddling the block's end included)
+__global__ __launch_bounds__(kBlock) void transit_sorted_kernel(const double* __restrict__ t, int64_t n_cad,
+                                                                int32_t* __restrict__ flags) {
+  const int64_t b0 = (int64_t)blockIdx.x * kSortBlock;
+  bool ok = true;
+  for (int64_t i = b0 + threadIdx.x; i < b0 + kSortBlock && i + 1 < n_cad; i += kBlock) ok = ok && (t[i] <= t[i + 1]);   // NaN: not sorted
+  const int all = __syncthreads_and(ok ? 1 : 0);
+  if (threadIdx.x == 0) flags[blockIdx.x] = all;
+}
+
+// One wave per list (draw, planet, event: 0 = transits, 1 = occultations).
+__global__ __launch_bounds__(64) void transit_enum_kernel(const double* __restrict__ t, int64_t n_cad,
+                                                          const double* __restrict__ texp, int64_t n_texp,
+                                                          const double* __restrict__ stencil_dt, int n_sub, uint32_t flags,
+                                                          const double* __restrict__ windows,
+                                                          const int32_t* __restrict__ sorted, int n_sorted, int n_ev,
+                                                          RunLists rl) {
+  __shared__ int s_len[2][kRunMax + 1];
+  const int64_t list = blockIdx.x, rec = list / n_ev;
+  const int ev = (int)(list - rec * n_ev), lane = threadIdx.x;
+  const double* wv = windows + kWin * rec;
+  const double nrev = wv[0], c0 = wv[1], dmid = wv[2];
+  // the windows are widened by the half-span of the exposure stencil; the reference widens its
+  // contact windows by texp / 2 whatever the stencil (keplerian.py:765-769)
+  double span = (flags & EXO_FLAG_WINDOW) ? 0.5 : 0.0;
+  if (!(flags & EXO_FLAG_WINDOW) && stencil_dt)
+    for (int k = 0; k < n_sub; ++k) span = fmax(span, fabs(stencil_dt[k]));
+  const double te = n_texp ? texp[0] : 0.0;
+  const double widen = fabs(te) * span * fabs(nrev);
+  const double h0 = wv[3] + widen, h1 = wv[4] + widen;
+  bool srt = true;
+  for (int i = lane; i < n_sorted; i += 64) srt = srt && (sorted[i] != 0);
+  srt = __all(srt);
+  // the list degenerates to "every cadence" unless its windows are bounded, periodic in t and disjoint
+  // (the decision is the same for both events of a planet: it only uses what they share)
+  const double x_first = fma(t[0], nrev, c0), x_last = fma(t[n_cad - 1], nrev, c0);
+  bool full = !srt || !(nrev > 0.0) || !(x_first == x_first) || !(x_last == x_last) || !(fabs(x_first) < 1e15) ||
+              !(fabs(x_last) < 1e15) || !(h0 < 0.5);
+  if (n_ev == 2) {
+    const double sep = fabs(frac_rev(dmid));   // transit and occultation centres, in revolutions
+    full = full || !(h1 < 0.5) || !(h0 + h1 < sep);
+  }
+  double kmin[2] = {0.0, 0.0}, kcnt[2] = {0.0, 0.0};
+  if (!full) {
+    for (int e = 0; e < n_ev; ++e) {
+      const double off = e ? dmid : 0.0, h = e ? h1 : h0;
+      kmin[e] = ceil((x_first + off) - h);
+      kcnt[e] = floor((x_last + off) + h) - kmin[e] + 1.0;
+      full = full || (kcnt[e] > (double)rl.r_max);
+    }
+  }
+  Run* __restrict__ runs = rl.runs + list * rl.r_max;
+  int32_t* __restrict__ pin = rl.pre_in + list * (rl.r_max + 1);
+  int32_t* __restrict__ pall = rl.pre_all + list * (rl.r_max + 1);
+  int K;
+  if (full) {
+    // every cadence, as pieces of >= 1024 (the heavy blocks of a draw share a list run by run)
+    int64_t piece = (n_cad + rl.r_max - 1) / rl.r_max;
+    piece = piece < 1024 ? 1024 : piece;
+    K = ev == 0 ? (int)((n_cad + piece - 1) / piece) : 0;
+    for (int k = lane; k < K; k += 64) {
+      const int64_t lo = k * piece, hi = (lo + piece < n_cad) ? lo + piece : n_cad;
+      runs[k] = Run{(int32_t)lo, (int32_t)lo, (int32_t)lo, (int32_t)hi};
+      s_len[0][k] = 0;
+      s_len[1][k] = (int)(hi - lo);
+    }
+  } else {
+    K = kcnt[ev] > 0.0 ? (int)kcnt[ev] : 0;
+    const double off = ev ? dmid : 0.0, h = ev ? h1 : h0, hin = wv[5 + ev];
+    auto first_not = [&](double thr, bool strict, int lo, int hi) {   // first i in [lo, hi) with x_i >= thr (strict: > thr)
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        const double xi = fma(t[mid], nrev, c0) + off;
+        const bool before = strict ? (xi <= thr) : (xi < thr);
+        lo = before ? mid + 1 : lo;
+        hi = before ? hi : mid;
+      }
+      return lo;
+    };
+    for (int k = lane; k < K; k += 64) {
+      const double kc = kmin[ev] + (double)k;
+      Run r;
+      r.lo = first_not(kc - h, false, 0, (int)n_cad);
+      r.hi = first_not(kc + h, true, r.lo, (int)n_cad);
+      if (hin > 0.0) {
+        r.a = first_not(kc - hin, false, r.lo, r.hi);
+        r.b = first_not(kc + hin, true, r.a, r.hi);
+      } else {
+        r.a = r.b = r.lo;
+      }
+      runs[k] = r;
+      s_len[0][k] = r.b - r.a;
+      s_len[1][k] = r.hi - r.lo;
+    }
+  }
+  __syncthreads();
+  // exclusive prefix sums: a lane takes a contiguous share of the runs
+  const int per = (K + 63) / 64, k0 = lane * per, k1 = (k0 + per < K) ? k0 + per : K;
+  int sum_in = 0, sum_all = 0;
+  for (int k = k0; k < k1; ++k) { sum_in += s_len[0][k]; sum_all += s_len[1][k]; }
+  int ex_in = sum_in, ex_all = sum_all;
+#pragma unroll
+  for (int m = 1; m < 64; m <<= 1) {
+    const int o_in = __shfl_up(ex_in, m, 64), o_all = __shfl_up(ex_all, m, 64);
+    if (lane >= m) { ex_in += o_in; ex_all += o_all; }
+  }
+  int run_in = ex_in - sum_in, run_all = ex_all - sum_all;
+  for (int k = k0; k < k1; ++k) {
+    pin[k] = run_in; pall[k] = run_all;
+    run_in += s_len[0][k]; run_all += s_len[1][k];
+  }
+  if (lane == 63) { pin[K] = ex_in; pall[K] = ex_all; rl.nrun[list] = K; }
+}
+
+// this wave's share of a block's zero-fill: 1 KB pieces (64 lanes x 16 B, non-temporal), a few per round
+struct FillCursor {
+  typedef double v2d __attribute__((ext_vector_type(2)));
+  v2d* __restrict__ q2;
+  int64_t n2, next;   // 16-B units in the block's share; this wave's next piece
+  __device__ __forceinline__ FillCursor(double* dst, int64_t n) : q2(nullptr), n2(0), next(threadIdx.x >> 6) {
+    if (!dst || n <= 0) return;
+    const int64_t head = (reinterpret_cast<uintptr_t>(dst) & 8) ? 1 : 0;
+    if (threadIdx.x == 0 && head) dst[0] = 0.0;
+    if (threadIdx.x == 0 && ((n - head) & 1)) dst[n - 1] = 0.0;
+    q2 = reinterpret_cast<v2d*>(dst + head);
+    n2 = (n - head) >> 1;
+  }
+  __device__ __forceinline__ int64_t pieces() const { return (n2 + 63) >> 6; }
+  __device__ __forceinline__ void issue(int count) {
+    const v2d z = {0.0, 0.0};
+    for (int s = 0; s < count && next * 64 < n2; ++s, next += kWaves) {
+      const int64_t k = next * 64 + (threadIdx.x & 63);
+      if (k < n2) __builtin_nontemporal_store(z, q2 + k);
+    }
+  }
+};
+
+template <bool GRAD, bool SECONDARY>
+__global__ __launch_bounds__(kBlock, EXO_HEAVY_MIN_WAVES) void transit_runs_kernel(
+    const double* __restrict__ t, int64_t n_cad, const double* __restrict__ texp, int64_t n_texp,
+    const double* __restrict__ stencil_dt, const double* __restrict__ stencil_w, int n_sub,
+    const double* __restrict__ params, const double* __restrict__ ld, int n_planet, uint32_t flags, int n_ev, RunLists rl,
+    const double* __restrict__ gflux, double* __restrict__ vals, double* __restrict__ fill, double* __restrict__ partial) {
+  __shared__ Shared sh;
+  __shared__ Run s_run[kSeg];
+  __shared__ int s_in[kSeg + 1], s_all[kSeg + 1];
+  __shared__ int s_rounds[2 * EXO_MAX_PLANETS];
+  __shared__ double lds_acc[kNG + 7][kBlock];
+  const int64_t draw = blockIdx.y;
+  const int hb = gridDim.x, bx = blockIdx.x;
+  stage_constants(sh, params, ld, stencil_dt, stencil_w, n_sub, n_planet, draw, SECONDARY);
+  const bool per_planet = flags & EXO_FLAG_PER_PLANET;
+  const int n_lists = n_planet * n_ev;
+  // this block's slice of every list, and the rounds of 256 cadences it will take in all
+  auto slice = [&](int K, int& k0, int& k1) {
+    k0 = (int)((int64_t)K * bx / hb);
+    k1 = (int)((int64_t)K * (bx + 1) / hb);
+  };
+  if ((int)threadIdx.x < n_lists) {
+    const int64_t list = draw * n_lists + threadIdx.x;
+    int k0, k1;
+    slice(rl.nrun[list], k0, k1);
+    const int32_t* pall = rl.pre_all + list * (rl.r_max + 1);
+    int rounds = 0;
+    for (int kb = k0; kb < k1; kb += kSeg) {
+      const int ke = (kb + kSeg < k1) ? kb + kSeg : k1;
+      rounds += (pall[ke] - pall[kb] + kBlock - 1) / kBlock;
+    }
+    s_rounds[threadIdx.x] = rounds;
+  }
+  __syncthreads();
+  int total_rounds = 0;
+  for (int l = 0; l < n_lists; ++l) total_rounds += s_rounds[l];
+  // dense output: this block zeroes its share of the draw's flux, a few pieces per round
+  const int64_t npl = per_planet ? n_planet : 1, n_fill = n_cad * npl;
+  const int64_t f0 = n_fill * bx / hb, f1 = n_fill * (bx + 1) / hb;
+  FillCursor fc(fill ? fill + draw * n_fill + f0 : nullptr, f1 - f0);
+  const int64_t my_pieces = (fc.pieces() + kWaves - 1 - (threadIdx.x >> 6)) / kWaves;   // pieces wave, wave + 4, ...
+  const int per_round = total_rounds > 0 ? (int)((my_pieces + total_rounds - 1) / total_rounds) : 0;
+
+  const int ng_draw = n_planet * kNG + 7;
+  double* __restrict__ pout = GRAD ? partial + ((int64_t)draw * hb + bx) * ng_draw : nullptr;
+  const GradAcc acc{GRAD ? &lds_acc[0][threadIdx.x] : nullptr};
+  if (GRAD) {
+#pragma unroll
+    for (int s = 0; s < kNG + 7; ++s) lds_acc[s][threadIdx.x] = 0.0;
+  }
+  double cld[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) cld[k] = uniform((SECONDARY || k < 3) ? sh.c[k] : 0.0);
+  const double te = (n_texp == 0) ? 0.0 : texp[0];
+  for (int p = 0; p < n_planet; ++p) {
+    const PlanetS c(sh.pc[p]);
+    if (GRAD && p > 0) {
+#pragma unroll
+      for (int s = 0; s < kNG; ++s) lds_acc[s][threadIdx.x] = 0.0;
+    }
+    int64_t vbase = (draw * n_planet + p) * n_cad;   // the planet's values: transits first, occultations behind them
+    for (int ev = 0; ev < n_ev; ++ev) {
+      const int64_t list = (draw * n_planet + p) * n_ev + ev;
+      const int K = rl.nrun[list];
+      const Run* __restrict__ runs = rl.runs + list * rl.r_max;
+      const int32_t* __restrict__ pin = rl.pre_in + list * (rl.r_max + 1);
+      const int32_t* __restrict__ pall = rl.pre_all + list * (rl.r_max + 1);
+      int k0, k1;
+      slice(K, k0, k1);
+      for (int kb = k0; kb < k1; kb += kSeg) {
+        const int m = (kb + kSeg < k1) ? kSeg : k1 - kb;
+        __syncthreads();   // (the previous batch is done with the tables)
+        for (int q = threadIdx.x; q <= m; q += kBlock) {
+          s_in[q] = pin[kb + q];
+          s_all[q] = pall[kb + q];
+          if (q < m) s_run[q] = runs[kb + q];
+        }
+        __syncthreads();
+        const int in0 = s_in[0], all0 = s_all[0];
+        const int tin = s_in[m] - in0, total = s_all[m] - all0;
+        // dense index j of the batch -> cadence i and position v in the value array: "inside" parts of all
+        // runs first, then the limb parts, so that a wave's vote on the arc geometry is nearly unanimous
+        struct Item { int i, v; double tv, g; };
+        auto locate = [&](int j, int& i, int& v) {
+          const bool in = j < tin;
+          const int jj = in ? j : j - tin;
+          int q = 0;
+#pragma unroll
+          for (int step = kSeg / 2; step > 0; step >>= 1) {
+            const int c2 = q + step;
+            if (c2 < m) {
+              const int pv = in ? s_in[c2] - in0 : (s_all[c2] - all0) - (s_in[c2] - in0);
+              q = (jj >= pv) ? c2 : q;
+            }
+          }
+          const Run r = s_run[q];
+          const int off = jj - (in ? s_in[q] - in0 : (s_all[q] - all0) - (s_in[q] - in0));
+          i = in ? r.a + off : ((off < r.a - r.lo) ? r.lo + off : r.b + (off - (r.a - r.lo)));
+          v = s_all[q] + (i - r.lo);
+        };
+        auto load_item = [&](int j) -> Item {
+          Item it{0, 0, 0.0, 0.0};   // lanes past the end of the batch: cadence 0 with a zero cotangent
+          if (j < total) locate(j, it.i, it.v);
+          it.tv = t[it.i];
+          if (GRAD && j < total) it.g = per_planet ? gflux[(draw * n_cad + it.i) * n_planet + p] : gflux[draw * n_cad + it.i];
+          return it;
+        };
+        Item nxt = load_item(threadIdx.x);
+        for (int j0 = 0; j0 < total; j0 += kBlock) {
+          const int j = j0 + threadIdx.x;
+          const bool has = j < total;
+          const Item cur = nxt;
+          if (j0 + kBlock < total) nxt = load_item(j + kBlock);   // in flight while this round computes
+          fc.issue(per_round);
+          double f = 0.0;
+          for (int k = 0; k < n_sub; ++k) {
+            const double tt = fma(te, sh.sdt[k], cur.tv);
+            const double gw = cur.g * sh.sw[k];
+            const double F = eval_sample<GRAD, SECONDARY>(tt, c, cld, gw, acc);
+            f = fma(sh.sw[k], F, f);
+            if (GRAD) acc.add(kNG + 6, gw * F);
+          }
+          if (vals && has) vals[vbase + cur.v] = f;
+        }
+      }
+      vbase += pall[K];
+    }
+    if (GRAD) reduce_columns(lds_acc, sh.red, 0, kNG, pout + p * kNG);
+  }
+  if (GRAD) reduce_columns(lds_acc, sh.red, kNG, 7, pout + n_planet * kNG);
+  fc.issue(1 << 30);   // whatever is left of the fill (all of it for a block without work)
+}
+
+// Last kernel of a sweep on the run-enumeration path, one block per draw: (GRAD) block partials ->
+// gparams, gld, sum(gflux * flux), in block order; (dense output) the runs' values to their cadences,
+// planet by planet (summed flux: a later planet adds to what the earlier ones left).
+__global__ __launch_bounds__(kBlock) void transit_finish_kernel(
+    const double* __restrict__ partial, int nblk, int n_planet, bool secondary, double* __restrict__ gparams,
+    double* __restrict__ gld, double* __restrict__ flux_dot, int64_t n_cad, uint32_t flags, int n_ev, RunLists rl,
+    const double* __restrict__ vals, double* __restrict__ flux) {
+  const int64_t draw = blockIdx.x;
+  const int ng_draw = n_planet * kNG + 7;
+  const int s = threadIdx.x;
+  if (partial) {
+    {
+      // record slots that carry no gradient (SINI, T0, PERIOD, the windows) read 0
+      const int p = s / EXO_NPAR, slot = s % EXO_NPAR;
+      const bool carried = slot == EXO_P_N || slot == EXO_P_TP || slot == EXO_P_ECC || slot == EXO_P_COSW ||
+                           slot == EXO_P_SINW || slot == EXO_P_COSI || slot == EXO_P_AOR || slot == EXO_P_ROR ||
+                           slot == EXO_P_FRATIO;
+      if (p < n_planet && !carried) gparams[(draw * n_planet + p) * EXO_NPAR + slot] = 0.0;
+    }
+    if (s < ng_draw) {
+      const double* __restrict__ src = partial + draw * nblk * (int64_t)ng_draw + s;
+      double v = 0.0;
+      for (int b = 0; b < nblk; ++b) v += src[(int64_t)b * ng_draw];
+      if (s < n_planet * kNG) {
+        const int p = s / kNG, k = s % kNG;
+        const int map[kNG] = {EXO_P_N, EXO_P_TP, EXO_P_ECC, EXO_P_COSW, EXO_P_SINW,
+                              EXO_P_COSI, EXO_P_AOR, EXO_P_ROR, EXO_P_FRATIO, -1};
+        if (map[k] >= 0) gparams[(draw * n_planet + p) * EXO_NPAR + map[k]] = v;
+      } else {
+        const int k = s - n_planet * kNG;
+        const int nld = secondary ? 6 : 3;
+        if (k < nld) gld[draw * nld + k] = v;
+        if (k == 6 && flux_dot) flux_dot[draw] = v;
+      }
+    }
+  }
+  if (!flux || !vals) return;
+  const bool per_planet = flags & EXO_FLAG_PER_PLANET;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int p = 0; p < n_planet; ++p) {
+    int64_t vbase = (draw * n_planet + p) * n_cad;
+    for (int ev = 0; ev < n_ev; ++ev) {
+      const int64_t list = (draw * n_planet + p) * n_ev + ev;
+      const int K = rl.nrun[list];
+      const Run* __restrict__ runs = rl.runs + list * rl.r_max;
+      const int32_t* __restrict__ pall = rl.pre_all + list * (rl.r_max + 1);
+      for (int k = wave; k < K; k += kWaves) {
+        const Run r = runs[k];
+        const double* __restrict__ src = vals + vbase + pall[k] - r.lo;
+        for (int i = r.lo + lane; i < r.hi; i += 64) {
+          const double v = src[i];
+          if (per_planet) {
+            flux[(draw * n_cad + i) * n_planet + p] = v;
+          } else {
+            double* dst = flux + draw * n_cad + i;
+            *dst = (p == 0) ? v : (*dst + v);   // (a planet's transits and occultations never share a cadence)
+          }
+        }
+      }
+      vbase += pall[K];
+    }
+    if (!per_planet && p + 1 < n_planet) __syncthreads();   // planets in order: bit-reproducible sums
+  }
+}
+
 // ---------------------------------------------------------------------------
 // Elementwise ops (the reference's standalone Ops)
 // ---------------------------------------------------------------------------
@@ -1422,6 +1789,84 @@ inline ScanPlan scan_plan(uint32_t flags, int bpd, int64_t n_draw, int n_planet,
   return sp;
 }
 
+// ---- run-enumeration path -------------------------------------------------------------------------
+// heavy blocks per draw: ~1024 blocks in all
+inline int runs_blocks_per_draw(int64_t n_draw) {
+  int64_t hb = (EXO_HEAVY_TARGET_BLOCKS + n_draw - 1) / n_draw;
+  return (int)(hb < 1 ? 1 : (hb > 64 ? 64 : hb));
+}
+inline int runs_r_max(int64_t n_cad) { return (int)(n_cad < kRunMax ? (n_cad < 16 ? 16 : n_cad) : kRunMax); }
+
+// scratch layout of the run-enumeration path (sized for two events per planet whatever the flags)
+struct RunWs {
+  double* partial;
+  double* windows;
+  int32_t* sorted;
+  RunLists rl;
+  double* vals;
+  int hb, n_sorted;
+  int64_t off_nrun, off_runs, off_pre_all, off_vals;   // byte offsets (exo_transit_flux_sparse_layout)
+  int64_t bytes;
+};
+inline RunWs carve_runs(void* base, int64_t n_cad, int64_t n_draw, int n_planet) {
+  RunWs w;
+  w.hb = runs_blocks_per_draw(n_draw);
+  w.n_sorted = (int)((n_cad + kSortBlock - 1) / kSortBlock);
+  w.rl.r_max = runs_r_max(n_cad);
+  const int64_t n_list = n_draw * n_planet * 2;
+  auto up16 = [](int64_t b) { return (b + 15) & ~(int64_t)15; };
+  char* p = (char*)base;
+  int64_t off = 0;
+  w.partial = (double*)(p + off); off = up16(off + 8 * n_draw * w.hb * (int64_t)(n_planet * kNG + 7));
+  w.windows = (double*)(p + off); off = up16(off + 8 * (int64_t)kWin * n_draw * n_planet);
+  w.sorted = (int32_t*)(p + off); off = up16(off + 4 * (int64_t)w.n_sorted);
+  w.off_nrun = off; w.rl.nrun = (int32_t*)(p + off); off = up16(off + 4 * n_list);
+  w.off_runs = off; w.rl.runs = (Run*)(p + off); off = up16(off + (int64_t)sizeof(Run) * n_list * w.rl.r_max);
+  w.rl.pre_in = (int32_t*)(p + off); off = up16(off + 4 * n_list * (int64_t)(w.rl.r_max + 1));
+  w.off_pre_all = off; w.rl.pre_all = (int32_t*)(p + off); off = up16(off + 4 * n_list * (int64_t)(w.rl.r_max + 1));
+  w.off_vals = off; w.vals = (double*)(p + off); off = up16(off + 8 * n_draw * n_planet * n_cad);
+  w.bytes = off;
+  return w;
+}
+// which sweeps take the run-enumeration path (the list path keeps timing tables, per-cadence exposure
+// times and the exact fp64 scan that the tests compare against)
+inline bool runs_path(bool has_ttv, int64_t n_texp, uint32_t flags) {
+  return !has_ttv && n_texp <= 1 && !(flags & EXO_FLAG_EXACT_SCAN);
+}
+
+// launches of one sweep on the run-enumeration path; gflux == nullptr: forward only
+inline int launch_runs_sweep(const double* t, int64_t n_cad, const double* texp, int64_t n_texp, const double* stencil_dt,
+                             const double* stencil_w, int32_t n_sub, const double* params, const double* ld,
+                             int64_t n_draw, int32_t n_planet, uint32_t flags, const double* gflux, double* flux,
+                             double* gparams, double* gld, double* flux_dot, const RunWs& w, hipStream_t st) {
+  const bool secondary = flags & EXO_FLAG_SECONDARY, sparse = flags & EXO_FLAG_SPARSE, grad = gflux != nullptr;
+  const int n_ev = secondary ? 2 : 1;
+  const dim3 block(kBlock);
+  hipLaunchKernelGGL(transit_sorted_kernel, dim3((unsigned)w.n_sorted), block, 0, st, t, n_cad, w.sorted);
+  launch_windows(params, n_draw, n_planet, flags, w.windows, st);
+  hipLaunchKernelGGL(transit_enum_kernel, dim3((unsigned)(n_draw * n_planet * n_ev)), dim3(64), 0, st, t, n_cad, texp, n_texp,
+                     stencil_dt, (int)n_sub, flags, w.windows, w.sorted, w.n_sorted, n_ev, w.rl);
+  if (launch_status() != EXO_OK) return EXO_ERR_LAUNCH;
+  // the values are kept when somebody reads them: the dense output's last kernel, or the caller (sparse)
+  double* vals = (flux || sparse) ? w.vals : nullptr;
+  double* fill = sparse ? nullptr : flux;
+  const dim3 hgrid((unsigned)w.hb, (unsigned)n_draw);
+#define EXO_LAUNCH_RUNS(G, SEC)                                                                                       \
+  hipLaunchKernelGGL((transit_runs_kernel<G, SEC>), hgrid, block, 0, st, t, n_cad, texp, n_texp, stencil_dt, stencil_w, \
+                     (int)n_sub, params, ld, (int)n_planet, flags, n_ev, w.rl, gflux, vals, fill, grad ? w.partial : nullptr)
+  if (grad) {
+    if (secondary) EXO_LAUNCH_RUNS(true, true); else EXO_LAUNCH_RUNS(true, false);
+  } else {
+    if (secondary) EXO_LAUNCH_RUNS(false, true); else EXO_LAUNCH_RUNS(false, false);
+  }
+#undef EXO_LAUNCH_RUNS
+  if (launch_status() != EXO_OK) return EXO_ERR_LAUNCH;
+  if (grad || fill)
+    hipLaunchKernelGGL(transit_finish_kernel, dim3((unsigned)n_draw), block, 0, st, grad ? w.partial : nullptr, w.hb,
+                       (int)n_planet, secondary, gparams, gld, flux_dot, n_cad, flags, n_ev, w.rl, vals, fill);
+  return launch_status();
+}
+
 inline bool transit_args_ok(int64_t n_cad, int64_t n_texp, int32_t n_sub, int64_t n_draw, int32_t n_planet) {
   return n_cad >= 0 && n_draw >= 0 && n_draw <= 65535 && n_planet >= 1 && n_planet <= EXO_MAX_PLANETS &&
          n_sub >= 1 && n_sub <= EXO_MAX_SUBEXP && (n_texp == 0 || n_texp == 1 || n_texp == n_cad);
@@ -1479,7 +1924,15 @@ int64_t exo_transit_flux_workspace_bytes(int64_t n_cad, int64_t n_draw, int32_t 
   int bpd, tpb;
   transit_geometry(n_cad, n_draw, &bpd, &tpb);
   const Workspace w = carve(nullptr, n_draw, bpd, tpb, n_planet);
-  return w.bytes;
+  const RunWs r = carve_runs(nullptr, n_cad, n_draw, n_planet);
+  return w.bytes > r.bytes ? w.bytes : r.bytes;
+}
+
+int exo_transit_flux_sparse_layout(int64_t n_cad, int64_t n_draw, int32_t n_planet, int64_t* out) {
+  if (n_cad < 0 || n_draw < 0 || n_planet < 1 || !out) return EXO_ERR_INVALID_ARGUMENT;
+  const RunWs r = carve_runs(nullptr, n_cad, n_draw, n_planet);
+  out[0] = r.off_nrun; out[1] = r.off_runs; out[2] = r.off_pre_all; out[3] = r.off_vals; out[4] = r.rl.r_max;
+  return EXO_OK;
 }
 
 // forward sweep; ttv.edges == nullptr: no timing variations
@@ -1489,15 +1942,25 @@ static int transit_fwd(const double* t, int64_t n_cad, const double* texp, int64
                        void* workspace, int64_t workspace_bytes, void* stream, void* ev_start, void* ev_stop) {
   if (!transit_args_ok(n_cad, n_texp, n_sub, n_draw, n_planet)) return EXO_ERR_INVALID_ARGUMENT;
   if (n_cad == 0 || n_draw == 0) return EXO_OK;
-  if (!t || !params || !ld || !flux || (n_texp > 0 && (!texp || !stencil_dt || !stencil_w)))
+  if (!t || !params || !ld || (!flux && !(flags & EXO_FLAG_SPARSE)) || (n_texp > 0 && (!texp || !stencil_dt || !stencil_w)))
     return EXO_ERR_INVALID_ARGUMENT;
   const bool has_ttv = ttv.edges != nullptr;
+  hipStream_t st = (hipStream_t)stream;
+  if (runs_path(has_ttv, n_texp, flags)) {
+    const RunWs rw = carve_runs(workspace, n_cad, n_draw, n_planet);
+    if (!workspace || workspace_bytes < rw.bytes) return EXO_ERR_WORKSPACE;
+    if (ev_start) (void)hipEventRecord((hipEvent_t)ev_start, st);
+    const int rc = launch_runs_sweep(t, n_cad, texp, n_texp, stencil_dt, stencil_w, n_sub, params, ld, n_draw, n_planet,
+                                     flags, nullptr, flux, nullptr, nullptr, nullptr, rw, st);
+    if (ev_stop) (void)hipEventRecord((hipEvent_t)ev_stop, st);
+    return rc;
+  }
+  if (flags & EXO_FLAG_SPARSE) return EXO_ERR_INVALID_ARGUMENT;   // the list path has no sparse output
   int bpd, tpb;
   transit_geometry(n_cad, n_draw, &bpd, &tpb);
   const Workspace w = carve(workspace, n_draw, bpd, tpb, n_planet);
   if (!workspace || workspace_bytes < w.bytes) return EXO_ERR_WORKSPACE;
   const dim3 block(kBlock);
-  hipStream_t st = (hipStream_t)stream;
   const bool secondary = flags & EXO_FLAG_SECONDARY;
   if (ev_start) (void)hipEventRecord((hipEvent_t)ev_start, st);
   launch_windows(params, n_draw, n_planet, flags, w.windows, st);
@@ -1549,6 +2012,16 @@ static int transit_vjp(const double* t, int64_t n_cad, const double* texp, int64
                ? EXO_OK : EXO_ERR_LAUNCH;
   }
   if (n_planet * kNG + 7 > kBlock) return EXO_ERR_INVALID_ARGUMENT;
+  if (runs_path(has_ttv, n_texp, flags)) {
+    const RunWs rw = carve_runs(workspace, n_cad, n_draw, n_planet);
+    if (!workspace || workspace_bytes < rw.bytes) return EXO_ERR_WORKSPACE;
+    if (ev_start) (void)hipEventRecord((hipEvent_t)ev_start, st);
+    const int rc = launch_runs_sweep(t, n_cad, texp, n_texp, stencil_dt, stencil_w, n_sub, params, ld, n_draw, n_planet,
+                                     flags, gflux, flux_out, gparams, gld, flux_dot, rw, st);
+    if (ev_stop) (void)hipEventRecord((hipEvent_t)ev_stop, st);
+    return rc;
+  }
+  if (flags & EXO_FLAG_SPARSE) return EXO_ERR_INVALID_ARGUMENT;   // the list path has no sparse output
   int bpd, tpb;
   transit_geometry(n_cad, n_draw, &bpd, &tpb);
   const Workspace w = carve(workspace, n_draw, bpd, tpb, n_planet);

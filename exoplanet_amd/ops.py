@@ -27,6 +27,7 @@ FLAG_WINDOW = 2
 FLAG_SECONDARY = 4
 PACK_CIRCULAR = 8
 FLAG_EXACT_SCAN = 16
+FLAG_SPARSE = 32
 NIN = 10
 (IN_PERIOD, IN_T0, IN_B, IN_ECC, IN_OMEGA, IN_R, IN_MSTAR, IN_RSTAR, IN_MPLANET, IN_SBR) = range(10)
 MAX_PLANETS = 16
@@ -352,6 +353,77 @@ def transit_flux_dot(t, params, ld, gflux, texp=None, stencil_dt=None, stencil_w
     edges, shift = (None, None) if ttv is None else ttv
     return _TransitFluxDot.apply(t, texp, stencil_dt, stencil_w, params, ld, gflux, int(flags), events,
                                  None if edges is None else edges.detach(), shift)
+
+
+class SparseFlux:
+    """Output of a sparse sweep (include/exoplanet_amd.h, EXO_FLAG_SPARSE): for every list
+    (draw, planet, event) the runs of cadences in which the planet can overlap the disk, and the
+    flux of exactly those cadences; every other cadence has flux 0.  Tensors are views into the
+    sweep's workspace (kept alive here)."""
+
+    def __init__(self, ws, layout, n_cad, D, P, n_ev):
+        off_nrun, off_runs, off_pre, off_vals, r_max = layout
+        i32 = ws.view(torch.int32)
+        n_list = D * P * n_ev
+        self.n_cad, self.n_draw, self.n_planet, self.n_ev, self.r_max = n_cad, D, P, n_ev, r_max
+        self.nrun = i32[off_nrun // 4: off_nrun // 4 + n_list].view(D, P, n_ev)
+        self.runs = i32[off_runs // 4: off_runs // 4 + n_list * r_max * 4].view(D, P, n_ev, r_max, 4)
+        self.pre_all = i32[off_pre // 4: off_pre // 4 + n_list * (r_max + 1)].view(D, P, n_ev, r_max + 1)
+        self.vals = ws[off_vals // 8: off_vals // 8 + D * P * n_cad].view(D, P, n_cad)
+        self._ws = ws
+
+    def n_solved(self):
+        """cadences in runs, summed over all lists (one host synchronisation)"""
+        k = self.nrun.long().unsqueeze(-1)
+        return int(torch.gather(self.pre_all.long(), -1, k).sum().item())
+
+    def to_dense(self, per_planet=False):
+        """(D, N) summed flux, or (D, N, P): rebuilt on the host (tests / plots)"""
+        nrun, runs = self.nrun.cpu().numpy(), self.runs.cpu().numpy()
+        pre, vals = self.pre_all.cpu().numpy(), self.vals.cpu().numpy()
+        import numpy as np
+
+        out = np.zeros((self.n_draw, self.n_cad, self.n_planet))
+        for d in range(self.n_draw):
+            for p in range(self.n_planet):
+                base = 0
+                for e in range(self.n_ev):
+                    for k in range(nrun[d, p, e]):
+                        lo, _, _, hi = runs[d, p, e, k]
+                        out[d, lo:hi, p] = vals[d, p, base + pre[d, p, e, k]: base + pre[d, p, e, k] + hi - lo]
+                    base += pre[d, p, e, nrun[d, p, e]]
+        return out if per_planet else out.sum(-1)
+
+
+@torch.no_grad()
+def transit_flux_sparse(t, params, ld, gflux=None, texp=None, stencil_dt=None, stencil_w=None, flags=0):
+    """Sparse sweep: no dense flux array is written.  Returns a :class:`SparseFlux`, and with
+    ``gflux`` (dense cotangent, read only at the solved cadences) also (gparams, gld, dot).
+    Needs sorted times, a scalar (or no) exposure time and no FLAG_EXACT_SCAN."""
+    flags = int(flags) | FLAG_SPARSE
+    t, texp, n_texp, sdt, sw, n_sub, params, ld, D, P = _transit_args(t, texp, stencil_dt, stencil_w, params, ld, flags)
+    N = t.numel()
+    lib = _lib.load()
+    nbytes = lib.exo_transit_flux_workspace_bytes(N, D, P)
+    ws = torch.empty(max(nbytes // 8 + 1, 1), dtype=torch.float64, device=t.device)
+    import ctypes
+
+    lay = (ctypes.c_int64 * 5)()
+    _lib.check(lib.exo_transit_flux_sparse_layout(N, D, P, lay), "exo_transit_flux_sparse_layout")
+    n_ev = 2 if flags & FLAG_SECONDARY else 1
+    with torch.cuda.device(t.device):
+        if gflux is None:
+            _lib.check(lib.exo_transit_flux_fwd_f64(_ptr(t), N, _ptr(texp), n_texp, _ptr(sdt), _ptr(sw), n_sub, _ptr(params),
+                                                    _ptr(ld), D, P, flags, 0, _ptr(ws), nbytes, _stream(t)),
+                       "exo_transit_flux_fwd_f64")
+            return SparseFlux(ws, list(lay), N, D, P, n_ev)
+        gflux = _dev(gflux, "gflux")
+        gparams, gld = torch.empty_like(params), torch.empty_like(ld)
+        dot = torch.empty(D, dtype=torch.float64, device=t.device)
+        _lib.check(lib.exo_transit_flux_vjp_f64(_ptr(t), N, _ptr(texp), n_texp, _ptr(sdt), _ptr(sw), n_sub, _ptr(params),
+                                                _ptr(ld), D, P, flags, _ptr(gflux), 0, _ptr(gparams), _ptr(gld), _ptr(dot),
+                                                _ptr(ws), nbytes, _stream(t)), "exo_transit_flux_vjp_f64")
+    return SparseFlux(ws, list(lay), N, D, P, n_ev), gparams, gld, dot
 
 
 # ------------------------------------------------------------------------------

@@ -105,6 +105,12 @@ int exo_contact_points_f64(const double* a, const double* e, const double* cosw,
                                    fp32 pre-filter.  Results are identical either way (accepted cadences are
                                    always evaluated in fp64); the flag exists to measure / verify that.      */
 
+#define EXO_FLAG_SPARSE 32u     /* run-enumeration sweeps only (sorted t, scalar or no texp, no timing tables, no
+                                   EXO_FLAG_EXACT_SCAN; EXO_ERR_INVALID_ARGUMENT otherwise): the flux array is NOT
+                                   touched (pass NULL); the output is the runs of cadences in which a planet can
+                                   overlap the disk and a compact value array, both inside `workspace`
+                                   (exo_transit_flux_sparse_layout); every other cadence has flux exactly 0.  */
+
 #define EXO_MAX_PLANETS 16
 #define EXO_MAX_SUBEXP 63
 
@@ -127,6 +133,19 @@ int exo_transit_flux_fwd_f64(const double* t, int64_t n_cad, const double* texp,
 /* Bytes of scratch the fused entry points need (active-cadence lists of the scan
  * kernel + the deterministic two-stage gradient reduction).                     */
 int64_t exo_transit_flux_workspace_bytes(int64_t n_cad, int64_t n_draw, int32_t n_planet);
+
+/* Where the sparse output of an EXO_FLAG_SPARSE sweep lives inside `workspace` (same n_cad, n_draw,
+ * n_planet as the sweep).  out[0..4] = byte offsets of nrun, runs, pre_all, vals, and r_max:
+ *   list = (draw * n_planet + planet) * n_ev + event   (n_ev = 2 with EXO_FLAG_SECONDARY: 0 transits,
+ *                                                       1 occultations; else n_ev = 1)
+ *   nrun    int32 [n_list]                 windows of the list that reach into the series
+ *   runs    int32 [n_list][r_max][4]       (lo, a, b, hi): cadences [lo, hi) of window k
+ *   pre_all int32 [n_list][r_max + 1]      exclusive prefix sums of hi - lo
+ *   vals    double [n_draw][n_planet][n_cad]  flux of cadence i of window k of (draw, planet):
+ *           vals[draw][planet][(event ? pre_all[list of event 0][nrun] : 0) + pre_all[list][k] + i - lo]
+ * (per planet, EXO_FLAG_PER_PLANET or not).  If t is not sorted, or a window cannot be bounded, the
+ * list is the whole series cut into a few runs.                                                   */
+int exo_transit_flux_sparse_layout(int64_t n_cad, int64_t n_draw, int32_t n_planet, int64_t* out);
 
 /* Diagnostic for the scan kernel's conservative fp32 cadence classifier: the fp32
  * estimate of (cos E - e, sqrt(1-e^2) sin E) for mean anomaly M (fp64 phase) and

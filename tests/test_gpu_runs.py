@@ -1,0 +1,132 @@
+"""GPU: the run-enumeration sweep (binary-searched conjunction windows, zero-fill hidden in the heavy
+kernel, sparse output) against the list sweep with the exact fp64 scan and the oracle.  The two
+paths evaluate an accepted cadence with the same fp64 code; the only difference is which cadences
+share a wave, i.e. how many AGM steps the wave votes for: fluxes agree to a few 1e-16."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import numpy_port as P
+from test_gpu_transit import make_record
+
+pytestmark = pytest.mark.gpu
+
+
+def T(a, dev):
+    return torch.as_tensor(np.asarray(a, dtype=np.float64), device=dev)
+
+
+def same_flux(a, b, tol=4e-15):
+    """equal up to the wave-vote rounding; exactly zero in the same places"""
+    return bool(((a == 0) == (b == 0)).all()) and float((a - b).abs().max()) <= tol
+
+
+def system(rng, D, planets=1, secondary=False, window=False):
+    if planets == 1:
+        orbit = P.KeplerianOrbit(period=3.5, t0=1.0, b=0.3, ecc=0.3, omega=1.1)
+        r = np.array([0.1])
+    else:
+        orbit = P.KeplerianOrbit(period=np.array([3.5, 7.9, 13.1]), t0=np.array([1.0, 2.3, 5.1]), b=np.array([0.3, 0.1, 0.5]),
+                                 ecc=np.array([0.05, 0.1, 0.2]), omega=np.array([1.1, -0.4, 2.0]))
+        r = np.array([0.1, 0.05, 0.07])
+    rec = np.repeat(make_record(orbit, r, sbr=0.3 if secondary else None, window=window), D, axis=0)
+    for slot in (P.P_ROR, P.P_AOR, P.P_COSI, P.P_TP):
+        rec[:, :, slot] *= 1 + 1e-3 * rng.normal(size=rec.shape[:2])
+    c = P.get_cl(0.3, 0.2)
+    if secondary:
+        c = np.concatenate([c, P.get_cl(0.4, 0.1)])
+    return rec, np.repeat(c[None], D, 0)
+
+
+@pytest.mark.parametrize("planets,secondary,texp,per_planet", [(1, False, False, False), (3, False, True, False),
+                                                               (1, True, True, True), (3, False, False, True)])
+def test_runs_sweep_equals_exact_scan(dev, planets, secondary, texp, per_planet):
+    from exoplanet_amd import ops
+
+    rng = np.random.default_rng(31 + planets)
+    D, N = 7, 20_011
+    t = np.arange(N) * (2.0 / 1440.0) + 0.25
+    rec, c = system(rng, D, planets, secondary)
+    flags = (ops.FLAG_SECONDARY if secondary else 0) | (ops.FLAG_PER_PLANET if per_planet else 0)
+    kw = {}
+    if texp:
+        dt, w = P.exposure_stencil(5, 1)
+        kw = dict(texp=T([0.02], dev), stencil_dt=T(dt, dev), stencil_w=T(w, dev))
+    shape = (D, N, planets) if per_planet else (D, N)
+    g = rng.normal(size=shape)
+    f_ref, gp_ref, gl_ref = ops.transit_flux_value_and_vjp(T(t, dev), T(rec, dev), T(c, dev), T(g, dev), flags=flags | ops.FLAG_EXACT_SCAN, **kw)
+    f, gp, gl = ops.transit_flux_value_and_vjp(T(t, dev), T(rec, dev), T(c, dev), T(g, dev), flags=flags, **kw)
+    assert float(f_ref.min()) < -1e-3
+    assert same_flux(f, f_ref)
+    for a, b in ((gp, gp_ref), (gl, gl_ref)):
+        assert float((a - b).abs().max()) <= 1e-11 * float(b.abs().max())
+    # forward-only entry point
+    f2 = ops.transit_flux(T(t, dev), T(rec, dev), T(c, dev), flags=flags, **kw)
+    assert same_flux(f2, f_ref)
+    # sparse output: the same values at the same cadences, zero elsewhere; same gradients
+    sp, gp_s, gl_s, dot = ops.transit_flux_sparse(T(t, dev), T(rec, dev), T(c, dev), gflux=T(g, dev), flags=flags, **kw)
+    dense = sp.to_dense(per_planet=per_planet)
+    np.testing.assert_allclose(dense, f.cpu().numpy(), rtol=0, atol=4e-15)
+    assert np.array_equal(dense == 0, f.cpu().numpy() == 0)
+    for x, y in ((gp_s, gp), (gl_s, gl)):
+        assert float((x - y).abs().max()) <= 1e-13 * float(y.abs().max())
+    np.testing.assert_allclose(dot.cpu().numpy(), (g * f_ref.cpu().numpy()).reshape(D, -1).sum(-1), rtol=1e-10, atol=1e-14)
+    assert 0 < sp.n_solved() < 0.2 * D * N * planets * (2 if secondary else 1)
+
+
+def test_runs_sweep_with_contact_windows(dev):
+    """EXO_FLAG_WINDOW: the caller's contact windows decide what is solved (use_in_transit semantics)"""
+    from exoplanet_amd import ops
+
+    rng = np.random.default_rng(35)
+    D, N = 5, 30_000
+    t = np.arange(N) * (2.0 / 1440.0)
+    rec, c = system(rng, D, window=True)
+    g = rng.normal(size=(D, N))
+    a = ops.transit_flux_value_and_vjp(T(t, dev), T(rec, dev), T(c, dev), T(g, dev), flags=ops.FLAG_WINDOW | ops.FLAG_EXACT_SCAN)
+    b = ops.transit_flux_value_and_vjp(T(t, dev), T(rec, dev), T(c, dev), T(g, dev), flags=ops.FLAG_WINDOW)
+    assert same_flux(a[0], b[0])
+    for x, y in zip(a[1:], b[1:]):
+        assert float((x - y).abs().max()) <= 1e-11 * float(x.abs().max())
+    want, _, _ = P.transit_flux_vjp(t, rec[:1], c[:1], g[:1])
+    np.testing.assert_allclose(b[0][0].cpu().numpy(), want[0], rtol=0, atol=1e-12)
+
+
+def test_unsorted_times_and_unbounded_windows_fall_back_to_every_cadence(dev):
+    from exoplanet_amd import ops
+
+    rng = np.random.default_rng(36)
+    D, N = 3, 9_000
+    t = np.arange(N) * (2.0 / 1440.0)
+    rec, c = system(rng, D)
+    g = rng.normal(size=(D, N))
+    perm = rng.permutation(N)
+    ref = ops.transit_flux_value_and_vjp(T(t, dev), T(rec, dev), T(c, dev), T(g, dev), flags=ops.FLAG_EXACT_SCAN)
+    got = ops.transit_flux_value_and_vjp(T(t[perm], dev), T(rec, dev), T(c, dev), T(g[:, perm], dev))
+    assert same_flux(got[0], ref[0][:, torch.as_tensor(perm, device=dev)])
+    for x, y in zip(got[1:], ref[1:]):
+        assert float((x - y).abs().max()) <= 1e-11 * float(y.abs().max())
+    # a / R so small that no window can be bounded (q >= 1), and a NaN record: every cadence is solved
+    rec2 = rec.copy()
+    rec2[0, 0, P.P_AOR] = 1.05
+    rec2[1, 0, P.P_N] = np.nan
+    a = ops.transit_flux(T(t, dev), T(rec2, dev), T(c, dev), flags=ops.FLAG_EXACT_SCAN)
+    b = ops.transit_flux(T(t, dev), T(rec2, dev), T(c, dev))
+    assert same_flux(torch.nan_to_num(a, nan=7.0), torch.nan_to_num(b, nan=7.0))
+    assert bool(torch.isnan(b[1]).all()) and bool(torch.isfinite(b[2]).all())
+
+
+def test_short_and_odd_series(dev):
+    """series shorter than a window, a single cadence, odd lengths, flux rows at odd offsets"""
+    from exoplanet_amd import ops
+
+    rng = np.random.default_rng(37)
+    rec, c = system(rng, 4)
+    for N in (1, 2, 63, 513):
+        t = 0.95 + np.arange(N) * (2.0 / 1440.0)
+        g = rng.normal(size=(4, N))
+        a = ops.transit_flux_value_and_vjp(T(t, dev), T(rec, dev), T(c, dev), T(g, dev), flags=ops.FLAG_EXACT_SCAN)
+        b = ops.transit_flux_value_and_vjp(T(t, dev), T(rec, dev), T(c, dev), T(g, dev))
+        assert same_flux(a[0], b[0]), N
+        for x, y in zip(a[1:], b[1:]):
+            assert float((x - y).abs().max()) <= 1e-11 * float(x.abs().max()) + 1e-300
