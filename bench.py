@@ -549,7 +549,7 @@ def main():
         # cadence t and gbar in, its flux out to the run-ordered value array, back in and out to its
         # place in the flux array (the binary searches of the windows are a few MB)
         req = {"flux_zero_fill": 8 * D * N_CAD, "t_and_gbar_solved": 16 * n_active,
-               "value_array_write_read": 16 * n_active, "flux_write_solved": 8 * n_active}
+               "value_and_cadence_arrays_write_read": 24 * n_active, "flux_write_solved": 8 * n_active}
         req_bytes = sum(req.values())
         achieved = req_bytes / (kernel_ms * 1e-3) / 1e9
         survey_bytes = SURVEY_BYTES_PER_UNIT * D * N_CAD

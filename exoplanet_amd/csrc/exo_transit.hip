@@ -99,8 +99,23 @@ __device__ double mean_anomaly_of(double f, double e, double se, double pe) {
 // TE2]; keplerian.py:729-731,765-769) are put in the same form instead -- revolutions of the
 // orbit, centre t0 + (ts + te)/2, half-width (te - ts)/2 -- and they alone decide what is
 // evaluated.
+// (Blocks past the records' -- the run-enumeration path launches n_sorted more -- check that t is
+// non-decreasing: one flag per kSortBlock cadences, the pair straddling the block's end included.)
+constexpr int kSortBlock = 4096;
 __global__ __launch_bounds__(kBlock) void transit_window_kernel(const double* __restrict__ params, int64_t n_rec,
-                                                                uint32_t flags, double* __restrict__ out) {
+                                                                uint32_t flags, double* __restrict__ out,
+                                                                const double* __restrict__ t = nullptr, int64_t n_cad = 0,
+                                                                int32_t* __restrict__ sorted = nullptr) {
+  const int n_rec_blocks = (int)((n_rec + kBlock - 1) / kBlock);
+  if ((int)blockIdx.x >= n_rec_blocks) {
+    const int sb = blockIdx.x - n_rec_blocks;
+    const int64_t b0 = (int64_t)sb * kSortBlock;
+    bool ok = true;
+    for (int64_t k = b0 + threadIdx.x; k < b0 + kSortBlock && k + 1 < n_cad; k += kBlock) ok = ok && (t[k] <= t[k + 1]);   // NaN: not sorted
+    const int all = __syncthreads_and(ok ? 1 : 0);
+    if (threadIdx.x == 0) sorted[sb] = all;
+    return;
+  }
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (i >= n_rec) return;
   const double* p = params + i * EXO_NPAR;
@@ -1258,7 +1273,6 @@ struct Run {
   int32_t lo, a, b, hi;   // cadences [lo, a) and [b, hi): may touch the limb; [a, b): small disk wholly inside (a hint)
 };
 constexpr int kRunMax = 4096;     // windows per list
-constexpr int kSortBlock = 4096;  // cadences per sortedness flag
 constexpr int kSeg = 512;         // runs of one list a heavy block holds in LDS at a time
 
 struct RunLists {
@@ -1268,16 +1282,6 @@ struct RunLists {
   int32_t* pre_all;  // [n_list][r_max + 1]      exclusive prefix sums of hi - lo (= position in the value array)
   int r_max;
 };
-
-// is t non-decreasing?  one flag per kSortBlock cadences (the pair straddling the block's end included)
-__global__ __launch_bounds__(kBlock) void transit_sorted_kernel(const double* __restrict__ t, int64_t n_cad,
-                                                                int32_t* __restrict__ flags) {
-  const int64_t b0 = (int64_t)blockIdx.x * kSortBlock;
-  bool ok = true;
-  for (int64_t i = b0 + threadIdx.x; i < b0 + kSortBlock && i + 1 < n_cad; i += kBlock) ok = ok && (t[i] <= t[i + 1]);   // NaN: not sorted
-  const int all = __syncthreads_and(ok ? 1 : 0);
-  if (threadIdx.x == 0) flags[blockIdx.x] = all;
-}
 
 // One wave per list (draw, planet, event: 0 = transits, 1 = occultations).
 __global__ __launch_bounds__(64) void transit_enum_kernel(const double* __restrict__ t, int64_t n_cad,
@@ -1338,7 +1342,19 @@ __global__ __launch_bounds__(64) void transit_enum_kernel(const double* __restri
   } else {
     K = kcnt[ev] > 0.0 ? (int)kcnt[ev] : 0;
     const double off = ev ? dmid : 0.0, h = ev ? h1 : h0, hin = wv[5 + ev];
-    auto first_not = [&](double thr, bool strict, int lo, int hi) {   // first i in [lo, hi) with x_i >= thr (strict: > thr)
+    // first i in [lo, hi) with x_i >= thr (strict: > thr).  Series are nearly always evenly sampled:
+    // the position guessed from the mean sampling rate is confirmed by its two neighbours (two
+    // independent loads instead of a chain of log2(n) dependent ones); anything else is searched for.
+    const double x_rate = (x_last - x_first) / (double)(n_cad > 1 ? n_cad - 1 : 1);
+    auto first_not = [&](double thr, bool strict, int lo, int hi) {
+      if (x_rate > 0.0 && hi > lo) {
+        const double gq = ceil((thr - off - x_first) / x_rate);
+        int g = gq < (double)lo ? lo : (gq > (double)hi ? hi : (int)gq);
+        const double xa = g > lo ? fma(t[g - 1], nrev, c0) + off : 0.0, xb = g < hi ? fma(t[g], nrev, c0) + off : 0.0;
+        const bool left_before = g == lo || (strict ? (xa <= thr) : (xa < thr));
+        const bool here_not = g == hi || !(strict ? (xb <= thr) : (xb < thr));
+        if (left_before && here_not) return g;
+      }
       while (lo < hi) {
         const int mid = (lo + hi) >> 1;
         const double xi = fma(t[mid], nrev, c0) + off;
@@ -1411,7 +1427,8 @@ __global__ __launch_bounds__(kBlock, EXO_HEAVY_MIN_WAVES) void transit_runs_kern
     const double* __restrict__ t, int64_t n_cad, const double* __restrict__ texp, int64_t n_texp,
     const double* __restrict__ stencil_dt, const double* __restrict__ stencil_w, int n_sub,
     const double* __restrict__ params, const double* __restrict__ ld, int n_planet, uint32_t flags, int n_ev, RunLists rl,
-    const double* __restrict__ gflux, double* __restrict__ vals, double* __restrict__ fill, double* __restrict__ partial) {
+    const double* __restrict__ gflux, double* __restrict__ vals, int32_t* __restrict__ vcad, double* __restrict__ fill,
+    double* __restrict__ partial) {
   __shared__ Shared sh;
   __shared__ Run s_run[kSeg];
   __shared__ int s_in[kSeg + 1], s_all[kSeg + 1];
@@ -1528,7 +1545,10 @@ __global__ __launch_bounds__(kBlock, EXO_HEAVY_MIN_WAVES) void transit_runs_kern
             f = fma(sh.sw[k], F, f);
             if (GRAD) acc.add(kNG + 6, gw * F);
           }
-          if (vals && has) vals[vbase + cur.v] = f;
+          if (vals && has) {
+            vals[vbase + cur.v] = f;
+            if (vcad) vcad[vbase + cur.v] = cur.i;   // (dense output: where the last kernel puts it)
+          }
         }
       }
       vbase += pall[K];
@@ -1545,7 +1565,7 @@ __global__ __launch_bounds__(kBlock, EXO_HEAVY_MIN_WAVES) void transit_runs_kern
 __global__ __launch_bounds__(kBlock) void transit_finish_kernel(
     const double* __restrict__ partial, int nblk, int n_planet, bool secondary, double* __restrict__ gparams,
     double* __restrict__ gld, double* __restrict__ flux_dot, int64_t n_cad, uint32_t flags, int n_ev, RunLists rl,
-    const double* __restrict__ vals, double* __restrict__ flux) {
+    const double* __restrict__ vals, const int32_t* __restrict__ vcad, double* __restrict__ flux) {
   const int64_t draw = blockIdx.x;
   const int ng_draw = n_planet * kNG + 7;
   const int s = threadIdx.x;
@@ -1576,29 +1596,36 @@ __global__ __launch_bounds__(kBlock) void transit_finish_kernel(
     }
   }
   if (!flux || !vals) return;
+  // a thread per value: value and cadence arrays are read contiguously, four loads in flight per thread
   const bool per_planet = flags & EXO_FLAG_PER_PLANET;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int p = 0; p < n_planet; ++p) {
-    int64_t vbase = (draw * n_planet + p) * n_cad;
+    const int64_t vbase = (draw * n_planet + p) * n_cad;
+    int total = 0;
     for (int ev = 0; ev < n_ev; ++ev) {
       const int64_t list = (draw * n_planet + p) * n_ev + ev;
-      const int K = rl.nrun[list];
-      const Run* __restrict__ runs = rl.runs + list * rl.r_max;
-      const int32_t* __restrict__ pall = rl.pre_all + list * (rl.r_max + 1);
-      for (int k = wave; k < K; k += kWaves) {
-        const Run r = runs[k];
-        const double* __restrict__ src = vals + vbase + pall[k] - r.lo;
-        for (int i = r.lo + lane; i < r.hi; i += 64) {
-          const double v = src[i];
-          if (per_planet) {
-            flux[(draw * n_cad + i) * n_planet + p] = v;
-          } else {
-            double* dst = flux + draw * n_cad + i;
-            *dst = (p == 0) ? v : (*dst + v);   // (a planet's transits and occultations never share a cadence)
-          }
+      total += rl.pre_all[list * (rl.r_max + 1) + rl.nrun[list]];
+    }
+    const double* __restrict__ src = vals + vbase;
+    const int32_t* __restrict__ cad = vcad + vbase;
+    for (int e0 = threadIdx.x; e0 < total; e0 += 4 * kBlock) {
+      double v[4];
+      int i[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int e = e0 + u * kBlock;
+        v[u] = e < total ? src[e] : 0.0;
+        i[u] = e < total ? cad[e] : -1;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (i[u] < 0) continue;
+        if (per_planet) {
+          flux[(draw * n_cad + i[u]) * n_planet + p] = v[u];
+        } else {
+          double* dst = flux + draw * n_cad + i[u];
+          *dst = (p == 0) ? v[u] : (*dst + v[u]);   // (a planet's transits and occultations never share a cadence)
         }
       }
-      vbase += pall[K];
     }
     if (!per_planet && p + 1 < n_planet) __syncthreads();   // planets in order: bit-reproducible sums
   }
@@ -1804,6 +1831,7 @@ struct RunWs {
   int32_t* sorted;
   RunLists rl;
   double* vals;
+  int32_t* vcad;   // cadence of every value (dense output only)
   int hb, n_sorted;
   int64_t off_nrun, off_runs, off_pre_all, off_vals;   // byte offsets (exo_transit_flux_sparse_layout)
   int64_t bytes;
@@ -1825,6 +1853,7 @@ inline RunWs carve_runs(void* base, int64_t n_cad, int64_t n_draw, int n_planet)
   w.rl.pre_in = (int32_t*)(p + off); off = up16(off + 4 * n_list * (int64_t)(w.rl.r_max + 1));
   w.off_pre_all = off; w.rl.pre_all = (int32_t*)(p + off); off = up16(off + 4 * n_list * (int64_t)(w.rl.r_max + 1));
   w.off_vals = off; w.vals = (double*)(p + off); off = up16(off + 8 * n_draw * n_planet * n_cad);
+  w.vcad = (int32_t*)(p + off); off = up16(off + 4 * n_draw * n_planet * n_cad);
   w.bytes = off;
   return w;
 }
@@ -1842,8 +1871,11 @@ inline int launch_runs_sweep(const double* t, int64_t n_cad, const double* texp,
   const bool secondary = flags & EXO_FLAG_SECONDARY, sparse = flags & EXO_FLAG_SPARSE, grad = gflux != nullptr;
   const int n_ev = secondary ? 2 : 1;
   const dim3 block(kBlock);
-  hipLaunchKernelGGL(transit_sorted_kernel, dim3((unsigned)w.n_sorted), block, 0, st, t, n_cad, w.sorted);
-  launch_windows(params, n_draw, n_planet, flags, w.windows, st);
+  {
+    const int64_t n_rec = n_draw * n_planet;
+    hipLaunchKernelGGL(transit_window_kernel, dim3((unsigned)((n_rec + kBlock - 1) / kBlock + w.n_sorted)), block, 0, st,
+                       params, n_rec, flags, w.windows, t, n_cad, w.sorted);
+  }
   hipLaunchKernelGGL(transit_enum_kernel, dim3((unsigned)(n_draw * n_planet * n_ev)), dim3(64), 0, st, t, n_cad, texp, n_texp,
                      stencil_dt, (int)n_sub, flags, w.windows, w.sorted, w.n_sorted, n_ev, w.rl);
   if (launch_status() != EXO_OK) return EXO_ERR_LAUNCH;
@@ -1853,7 +1885,8 @@ inline int launch_runs_sweep(const double* t, int64_t n_cad, const double* texp,
   const dim3 hgrid((unsigned)w.hb, (unsigned)n_draw);
 #define EXO_LAUNCH_RUNS(G, SEC)                                                                                       \
   hipLaunchKernelGGL((transit_runs_kernel<G, SEC>), hgrid, block, 0, st, t, n_cad, texp, n_texp, stencil_dt, stencil_w, \
-                     (int)n_sub, params, ld, (int)n_planet, flags, n_ev, w.rl, gflux, vals, fill, grad ? w.partial : nullptr)
+                     (int)n_sub, params, ld, (int)n_planet, flags, n_ev, w.rl, gflux, vals, fill ? w.vcad : nullptr, fill,        \
+                     grad ? w.partial : nullptr)
   if (grad) {
     if (secondary) EXO_LAUNCH_RUNS(true, true); else EXO_LAUNCH_RUNS(true, false);
   } else {
@@ -1863,7 +1896,7 @@ inline int launch_runs_sweep(const double* t, int64_t n_cad, const double* texp,
   if (launch_status() != EXO_OK) return EXO_ERR_LAUNCH;
   if (grad || fill)
     hipLaunchKernelGGL(transit_finish_kernel, dim3((unsigned)n_draw), block, 0, st, grad ? w.partial : nullptr, w.hb,
-                       (int)n_planet, secondary, gparams, gld, flux_dot, n_cad, flags, n_ev, w.rl, vals, fill);
+                       (int)n_planet, secondary, gparams, gld, flux_dot, n_cad, flags, n_ev, w.rl, vals, w.vcad, fill);
   return launch_status();
 }
 
