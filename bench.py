@@ -642,6 +642,40 @@ def main():
                 res[str(d)] = {"evals_per_s": d / (q["median_ms"] * 1e-3), "median_ms": q["median_ms"], "launch": how}
             return res
 
+        def sparse_output():
+            names = list(leaves)
+
+            def sp_step(*vals):
+                Lv = dict(zip(names, vals))
+                orbit = xo.KeplerianOrbit(period=Lv["period"], t0=Lv["t0"], b=Lv["b"], ecc=Lv["ecc"], omega=Lv["omega"])
+                rec, ld, _, flags = orbit.kernel_inputs(Lv["r"], (Lv["u1"], Lv["u2"]), use_in_transit=False)
+                _, L = ops.transit_flux_dot(t, rec, ld, gbar, flags=flags | ops.FLAG_SPARSE)
+                return (L.detach(),) + torch.autograd.grad(L.sum(), vals)
+
+            q, how = graphed(xo, sp_step, list(leaves.values()), dev, 50)
+            return {"evals_per_s": D / (q["median_ms"] * 1e-3), **q, "launch": how,
+                    "note": "the same C2 step with EXO_FLAG_SPARSE: the output is the runs of cadences in which the planet "
+                            "can overlap the disk plus their flux values (every other cadence is exactly 0) -- no 1.23 GB "
+                            "of zeros; what a likelihood needs"}
+
+        def light_delay():
+            names = list(leaves)
+
+            def ld_step(*vals):
+                Lv = dict(zip(names, vals))
+                orbit = xo.KeplerianOrbit(period=Lv["period"], t0=Lv["t0"], b=Lv["b"], ecc=Lv["ecc"], omega=Lv["omega"])
+                rec, ld, _, flags = orbit.kernel_inputs(Lv["r"], (Lv["u1"], Lv["u2"]), use_in_transit=False, light_delay=True)
+                _, L = ops.transit_flux_dot(t, rec, ld, gbar, flags=flags)
+                return (L.detach(),) + torch.autograd.grad(L.sum(), vals)
+
+            q, how = graphed(xo, ld_step, list(leaves.values()), dev, 50)
+            return {"evals_per_s": D / (q["median_ms"] * 1e-3), **q, "launch": how,
+                    "note": "the C2 step with light_delay=True (keplerian.py:411-470): every solved sample is evaluated at "
+                            "its retarded time -- a second Kepler solve and the reverse sweep through the delay, in the "
+                            "same kernel; dense output"}
+
+        leg("c2_sparse_output", sparse_output)
+        leg("c2_light_delay", light_delay)
         leg("in_transit_only", in_transit)
         leg("op_level_every_cadence", op_level)
         leg("c2_small_batches", small_batch)

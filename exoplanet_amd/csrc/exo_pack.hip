@@ -26,6 +26,7 @@ namespace {
 
 constexpr double kG = 2942.2062175044193;  // R_sun^3 / M_sun / day^2 (orbits/constants.py:32)
 constexpr double kPi = 3.14159265358979323846;
+constexpr double kCLight = 37231.66360672704;  // R_sun / day (orbits/constants.py:36)
 
 struct Derived {
   double a, n, cw, sw, E0, M0, f, cosi, x, y, mtot;
@@ -65,7 +66,10 @@ __global__ __launch_bounds__(64) void pack_kernel(const double* __restrict__ orb
     const Derived d = derive(in, circular);
     const double e = circular ? 0.0 : in[EXO_IN_ECC];
     const double P = in[EXO_IN_PERIOD], Rs = in[EXO_IN_RSTAR], r = in[EXO_IN_R];
-    const double sini = sqrt(fmax(0.0, 1.0 - d.cosi * d.cosi));  // sin(acos(cos i))
+    // sin(acos(cos i)); |cos i| > 1 (b beyond the orbit's largest impact parameter): sin i = 0, i.e.
+    // never in front of the star and flux 0, which is what the reference's `switch(los > 0, lc, 0)` gives
+    // for the NaN it computes there (limb_dark.py:252)
+    const double sini = sqrt(fmax(0.0, 1.0 - d.cosi * d.cosi));
     o[EXO_P_N] = d.n;
     o[EXO_P_TP] = in[EXO_IN_T0] - d.M0 / d.n;
     o[EXO_P_ECC] = e;
@@ -116,6 +120,8 @@ __global__ __launch_bounds__(64) void pack_kernel(const double* __restrict__ orb
       }
     }
     o[EXO_P_TS] = ts; o[EXO_P_TE] = te; o[EXO_P_TS2] = ts2; o[EXO_P_TE2] = te2;
+    o[EXO_P_CLIGHT] = kCLight / Rs;   // read only by light-delay sweeps
+    o[EXO_P_CLIGHT + 1] = o[EXO_P_CLIGHT + 2] = o[EXO_P_CLIGHT + 3] = 0.0;
   }
   // limb darkening: u -> c (get_cl), one draw per lane of the first lanes
   if (i < n_draw) {
@@ -159,8 +165,11 @@ __global__ __launch_bounds__(64) void pack_vjp_kernel(const double* __restrict__
     } else {
       o[EXO_IN_SBR] = 0.0;
     }
-    // cos i = f Rs b / a
-    const double gci = g[EXO_P_COSI];
+    // light delay: c / Rs
+    Rsb -= g[EXO_P_CLIGHT] * kCLight / (Rs * Rs);
+    // cos i = f Rs b / a ;  sin i = sqrt(1 - cos^2 i) carries a cotangent with light delay only
+    const double sini_ = sqrt(fmax(0.0, 1.0 - d.cosi * d.cosi));
+    const double gci = g[EXO_P_COSI] - (sini_ > 0.0 ? g[EXO_P_SINI] * d.cosi / sini_ : 0.0);
     const double fb = gci * Rs * b / d.a;
     Rsb += gci * d.f * b / d.a;
     bb += gci * d.f * Rs / d.a;

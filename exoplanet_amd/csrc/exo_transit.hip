@@ -42,16 +42,18 @@ constexpr int kTile = 2 * kBlock;         // cadences per tile: two per lane
 constexpr int kTargetBlocks = EXO_TARGET_BLOCKS;  // ~16 resident-or-queued blocks per CU: fills the chip, amortises
                                          // the per-block constant staging and gradient reduction
 constexpr uint32_t kFlagNoFluxDev = 0x80000000u;
-constexpr int kNG = 10;                 // compact gradient slots per planet
+constexpr int kNG = 12;                 // compact gradient slots per planet
 constexpr int kMaxMerge = 8;            // scan blocks per heavy block, at most
 constexpr int kWin = 7;                 // doubles per record written by transit_window_kernel
 // compact slot order
-enum { G_N = 0, G_TP, G_ECC, G_COSW, G_SINW, G_COSI, G_AOR, G_ROR, G_FR, G_PAD };
+enum { G_N = 0, G_TP, G_ECC, G_COSW, G_SINW, G_COSI, G_AOR, G_ROR, G_FR, G_PAD, G_SINI, G_CL };   // (SINI, CL: light delay only)
+constexpr double kCLight = 37231.66360672704;   // R_sun / day (orbits/constants.py:36)
 
 // Per-(draw, planet) constants derived once per block and staged in LDS.
 struct PlanetConst {
   double n, tp, e, se, pe, sq1me2, cw, sw, ci, si, aor, ror, iror;
   double t0, period, iperiod, ts, te, fr, ts2, te2, isq1me2;
+  double clr;   // speed of light, stellar radii per day (light delay)
   // fp32 copies for the conservative classifier of the scan kernel
   float ef, omf, sqf, cwf, swf, cif, zsf, thrf, zthrf, inthrf;
   // conjunction windows of the scan kernel's first test (see transit_window_kernel)
@@ -143,6 +145,12 @@ __global__ __launch_bounds__(kBlock) void transit_window_kernel(const double* __
       const double h = o[3 + k];
       o[5 + k] = (r_ < 1.0 && in2 > 0.0 && out2 > 0.0 && h < __builtin_inf()) ? 0.95 * h * sqrt(in2 / out2) : 0.0;
     }
+    if (flags & EXO_FLAG_LIGHT_DELAY) {   // as below: the retarded time differs from t by at most this
+      const double vmax = fabs(p[EXO_P_N] * p[EXO_P_AOR]) * (1.0 + e) / sqrt(1.0 - e * e);
+      const double dmax = fabs(p[EXO_P_AOR]) * (1.0 + e) / (fabs(p[EXO_P_CLIGHT]) - vmax);
+      const double wd = (dmax >= 0.0 ? dmax : __builtin_inf()) * ip * 1.05;
+      o[3] += wd; o[4] += wd;
+    }
     return;
   }
   const double nrev = p[EXO_P_N] * (0.5 / exo::kPi);
@@ -176,6 +184,13 @@ __global__ __launch_bounds__(kBlock) void transit_window_kernel(const double* __
   }
   o[1] = -fma(p[EXO_P_TP], nrev, mid[0]);
   o[2] = mid[0] - mid[1];
+  if (flags & EXO_FLAG_LIGHT_DELAY) {
+    // the body is seen where it was up to |z|max / (c - |vz|max) earlier or later: widen by that much
+    const double vmax = fabs(p[EXO_P_N] * p[EXO_P_AOR]) * (1.0 + e) / sqrt(1.0 - e * e);
+    const double dmax = fabs(p[EXO_P_AOR]) * (1.0 + e) / (fabs(p[EXO_P_CLIGHT]) - vmax);
+    const double wd = (dmax >= 0.0 ? dmax : __builtin_inf()) * fabs(nrev) * 1.05;   // (NaN or v >= c: no window)
+    o[3] += wd; o[4] += wd;
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -293,6 +308,7 @@ __device__ __forceinline__ void stage_constants(Shared& sh, const double* __rest
     c.t0 = p[EXO_P_T0]; c.period = p[EXO_P_PERIOD]; c.iperiod = 1.0 / p[EXO_P_PERIOD];
     c.ts = p[EXO_P_TS]; c.te = p[EXO_P_TE];
     c.fr = p[EXO_P_FRATIO]; c.ts2 = p[EXO_P_TS2]; c.te2 = p[EXO_P_TE2];
+    c.clr = p[EXO_P_CLIGHT];
     // classifier: accept if (x^2 + y^2) (a/R)^2 < (1 + ror + margin)^2 with the fp32 position error
     // bound of exo::orbit_pos_f32 folded into the margin (never a false negative)
     const double margin = 2e-3 + c.aor * 1.6e-3;   // 2x the 8e-4 bound of exo::orbit_pos_f32
@@ -337,12 +353,12 @@ __device__ __forceinline__ double uniform(double x) {
 // registers (they are the same for every lane; read from LDS they would sit in ~50 vector
 // registers for the whole block, next to the elliptic-integral code that needs them all).
 struct PlanetS {
-  double n, tp, e, se, pe, sq1me2, isq1me2, cw, sw, ci, si, aor, ror, iror, fr;
+  double n, tp, e, se, pe, sq1me2, isq1me2, cw, sw, ci, si, aor, ror, iror, fr, clr;
   __device__ __forceinline__ explicit PlanetS(const PlanetConst& c)
       : n(uniform(c.n)), tp(uniform(c.tp)), e(uniform(c.e)), se(uniform(c.se)), pe(uniform(c.pe)),
         sq1me2(uniform(c.sq1me2)), isq1me2(uniform(c.isq1me2)), cw(uniform(c.cw)), sw(uniform(c.sw)),
         ci(uniform(c.ci)), si(uniform(c.si)), aor(uniform(c.aor)), ror(uniform(c.ror)), iror(uniform(c.iror)),
-        fr(uniform(c.fr)) {}
+        fr(uniform(c.fr)), clr(uniform(c.clr)) {}
 };
 
 // Gradient accumulators of the heavy kernel live in LDS, one column per thread
@@ -356,9 +372,38 @@ struct GradAcc {
 
 // One (cadence, sub-exposure, planet) sample.  Returns the flux contribution F
 // and, if GRAD, adds gw * dF/d(theta) into the LDS accumulator columns.
-template <bool GRAD, bool SECONDARY>
+// LDELAY (EXO_FLAG_LIGHT_DELAY; keplerian.py:411-470 with z0 = 0): the body is seen where it was at
+// tt - D.  With the relative orbit's line-of-sight position z, velocity vz and acceleration az at tt
+// (a first Kepler solve; a -> -a, r = a (1 - e cos E), vz = n a sin i (e cos w + cos(w + f)) / sqrt(1 -
+// e^2), az = -n^2 z / (1 - e cos E)^3) the reference's
+//     D = (c / az) ((1 + vz / c) - sqrt((1 + vz / c)^2 - 2 az (z0 - z) / c^2)),   (z0 - z) / (c + vz) if |az| < 1e-10
+// is evaluated in the algebraically identical form  D = 2 q / (c (w + s)),  q = z0 - z, w = 1 + vz / c,
+// s = sqrt(w^2 - 2 az q / c^2): no cancellation, and the small-az branch is its limit.  An occultation
+// is the transit of the flipped orbit (keplerian.py:779-804), whose relative position, velocity and
+// acceleration are the negatives: sigma = -1 below.  The reverse sweep takes the cotangent of the
+// retarded time (-n Mbar of the second solve) back through D and the first solve by hand.
+template <bool GRAD, bool SECONDARY, bool LDELAY = false>
 __device__ __forceinline__ double eval_sample(double tt, const PlanetS& c, const double* cld,
                                               double gw, const GradAcc& acc) {
+  // saved by the delay computation for its reverse sweep
+  double ld_cx = 0, ld_sx = 0, ld_den = 0, ld_z = 0, ld_vz = 0, ld_az = 0, ld_w = 0, ld_s = 0, ld_D = 0, ld_sig = 1, ld_t = tt;
+  if (LDELAY) {
+    const exo::KeplerHalf k1 = exo::kepler_half((tt - c.tp) * c.n, c.e, c.se, c.pe);
+    const double X2 = k1.X * k1.X, Y2 = k1.Y * k1.Y;
+    ld_cx = X2 - Y2; ld_sx = 2.0 * k1.X * k1.Y; ld_den = X2 + Y2;
+    const double y1 = -c.aor * (c.sw * ld_cx + c.cw * ld_sx);
+    ld_z = -c.si * y1;
+    const double iden = exo::fast_div(1.0, ld_den);
+    const double cwf = (c.cw * ld_cx - c.sw * ld_sx) * iden;
+    ld_vz = -c.n * c.aor * c.isq1me2 * c.si * (c.e * c.cw + cwf);
+    ld_az = -c.n * c.n * ld_z * iden * iden * iden;
+    ld_sig = (SECONDARY && ld_z < 0.0) ? -1.0 : 1.0;   // behind the star: the flipped orbit's delay
+    const double q = -ld_sig * ld_z, ic = exo::fast_div(1.0, c.clr);
+    ld_w = fma(ld_sig * ld_vz, ic, 1.0);
+    ld_s = sqrt(fma(-2.0 * ld_sig * ld_az * q, ic * ic, ld_w * ld_w));
+    ld_D = 2.0 * q * ic / (ld_w + ld_s);
+    tt -= ld_D;
+  }
   const double M = (tt - c.tp) * c.n;
   const exo::KeplerHalf kh = exo::kepler_half(M, c.e, c.se, c.pe);
   const double X2 = kh.X * kh.X, Y2 = kh.Y * kh.Y;
@@ -446,6 +491,66 @@ __device__ __forceinline__ double eval_sample(double tt, const PlanetS& c, const
       acc.add(G_ECC, Mbar * sinE - cxbar - c.e * sinE * c.isq1me2 * sxbar);
       acc.add(G_N, Mbar * (tt - c.tp));
       acc.add(G_TP, -Mbar * c.n);
+      if (LDELAY) {
+        // tt = t_obs - D: Dbar = -(d / d tt) = -n Mbar; back through D = 2 q / (c (w + s))
+        const double cl = c.clr, ic = 1.0 / cl;
+        const double q = -ld_sig * ld_z, u = ld_w + ld_s;
+        const double Dbar = -Mbar * c.n;
+        double qbar = Dbar * 2.0 * ic / u;
+        double clbar = -Dbar * ld_D * ic;
+        const double ubar = -Dbar * ld_D / u;
+        // s = sqrt(w^2 - 2 sig az q / c^2)
+        const double discbar = ubar / (2.0 * ld_s);
+        double wbar = ubar + discbar * 2.0 * ld_w;
+        const double azbar = discbar * (-2.0 * ld_sig * q * ic * ic);
+        qbar += discbar * (-2.0 * ld_sig * ld_az * ic * ic);
+        clbar += discbar * (4.0 * ld_sig * ld_az * q * ic * ic * ic);
+        // w = 1 + sig vz / c
+        const double vzbar = wbar * ld_sig * ic;
+        clbar -= wbar * ld_sig * ld_vz * ic * ic;
+        acc.add(G_CL, clbar);
+        // q = -sig z ;  az = -n^2 z / den^3
+        const double id1 = 1.0 / ld_den, id3 = id1 * id1 * id1;
+        double zbar = -ld_sig * qbar - azbar * c.n * c.n * id3;
+        double nbar = -azbar * 2.0 * c.n * ld_z * id3;
+        double denbar = azbar * 3.0 * c.n * c.n * ld_z * id3 * id1;
+        // vz = vamp si P, vamp = -n a / sqrt(1 - e^2), P = e cw + cwf
+        const double cwf = (c.cw * ld_cx - c.sw * ld_sx) * id1, Pq = c.e * c.cw + cwf;
+        const double vamp = -c.n * c.aor * c.isq1me2;
+        const double vampbar = vzbar * c.si * Pq, Pbar = vzbar * vamp * c.si;
+        double sibar = vzbar * vamp * Pq;
+        nbar += vampbar * (-c.aor * c.isq1me2);
+        double aorbar = vampbar * (-c.n * c.isq1me2);
+        // d(1/sqrt(1-e^2))/de = e / (1-e^2)^(3/2)
+        double ebar = vampbar * (-c.n * c.aor) * c.e * c.isq1me2 * c.isq1me2 * c.isq1me2 + Pbar * c.cw;
+        double cwbar = Pbar * c.e, swbar = 0.0;
+        // cwf = (cw cx - sw sx) / den
+        const double Nbar = Pbar * id1;
+        denbar -= Pbar * cwf * id1;
+        cwbar += Nbar * ld_cx; swbar -= Nbar * ld_sx;
+        double cxbar1 = Nbar * c.cw, sxbar1 = -Nbar * c.sw;
+        // z = -si y1 ;  y1 = -a (sw cx + cw sx)
+        const double y1 = -c.aor * (c.sw * ld_cx + c.cw * ld_sx);
+        sibar -= zbar * y1;
+        const double y1bar = -zbar * c.si;
+        aorbar -= y1bar * (c.sw * ld_cx + c.cw * ld_sx);
+        swbar -= y1bar * c.aor * ld_cx; cwbar -= y1bar * c.aor * ld_sx;
+        cxbar1 -= y1bar * c.aor * c.sw; sxbar1 -= y1bar * c.aor * c.cw;
+        // first solve: cx = cos E - e, sx = sqrt(1-e^2) sin E, den = 1 - e cos E
+        const double sinE1 = ld_sx * c.isq1me2, cosE1 = ld_cx + c.e;
+        const double Ebar1 = -cxbar1 * sinE1 + sxbar1 * c.sq1me2 * cosE1 + denbar * c.e * sinE1;
+        ebar += -cxbar1 - sxbar1 * c.e * c.isq1me2 * sinE1 - denbar * cosE1;
+        const double Mbar1 = Ebar1 * id1;
+        ebar += Mbar1 * sinE1;
+        nbar += Mbar1 * (ld_t - c.tp);
+        acc.add(G_TP, -Mbar1 * c.n);
+        acc.add(G_N, nbar);
+        acc.add(G_ECC, ebar);
+        acc.add(G_COSW, cwbar);
+        acc.add(G_SINW, swbar);
+        acc.add(G_AOR, aorbar);
+        acc.add(G_SINI, sibar);
+      }
     }
   }
   return F;
@@ -1226,13 +1331,13 @@ __global__ __launch_bounds__(kBlock) void transit_vjp_reduce_kernel(
   const int64_t draw = blockIdx.x;
   const int ng_draw = n_planet * kNG + 7;
   const int s = threadIdx.x;
-  {
-    // record slots that carry no gradient (SINI, T0, PERIOD, the windows) read 0
-    const int p = s / EXO_NPAR, slot = s % EXO_NPAR;
+  for (int q = s; q < n_planet * EXO_NPAR; q += kBlock) {
+    // record slots that carry no gradient (T0, PERIOD, the windows, the reserved ones) read 0
+    const int p = q / EXO_NPAR, slot = q % EXO_NPAR;
     const bool carried = slot == EXO_P_N || slot == EXO_P_TP || slot == EXO_P_ECC || slot == EXO_P_COSW ||
                          slot == EXO_P_SINW || slot == EXO_P_COSI || slot == EXO_P_AOR || slot == EXO_P_ROR ||
-                         slot == EXO_P_FRATIO;
-    if (p < n_planet && !carried) gparams[(draw * n_planet + p) * EXO_NPAR + slot] = 0.0;
+                         slot == EXO_P_FRATIO || slot == EXO_P_SINI || slot == EXO_P_CLIGHT;
+    if (!carried) gparams[(draw * n_planet + p) * EXO_NPAR + slot] = 0.0;
   }
   if (s >= ng_draw) return;
   const double* __restrict__ src = partial + draw * nblk * (int64_t)ng_draw + s;
@@ -1242,7 +1347,7 @@ __global__ __launch_bounds__(kBlock) void transit_vjp_reduce_kernel(
     const int p = s / kNG, k = s % kNG;
     // compact slot -> EXO_P_* slot
     const int map[kNG] = {EXO_P_N, EXO_P_TP, EXO_P_ECC, EXO_P_COSW, EXO_P_SINW,
-                          EXO_P_COSI, EXO_P_AOR, EXO_P_ROR, EXO_P_FRATIO, -1};
+                          EXO_P_COSI, EXO_P_AOR, EXO_P_ROR, EXO_P_FRATIO, -1, EXO_P_SINI, EXO_P_CLIGHT};
     if (map[k] >= 0) gparams[(draw * n_planet + p) * EXO_NPAR + map[k]] = v;
   } else {
     const int k = s - n_planet * kNG;
@@ -1422,7 +1527,7 @@ struct FillCursor {
   }
 };
 
-template <bool GRAD, bool SECONDARY>
+template <bool GRAD, bool SECONDARY, bool LDELAY = false>
 __global__ __launch_bounds__(kBlock, EXO_HEAVY_MIN_WAVES) void transit_runs_kernel(
     const double* __restrict__ t, int64_t n_cad, const double* __restrict__ texp, int64_t n_texp,
     const double* __restrict__ stencil_dt, const double* __restrict__ stencil_w, int n_sub,
@@ -1541,7 +1646,7 @@ __global__ __launch_bounds__(kBlock, EXO_HEAVY_MIN_WAVES) void transit_runs_kern
           for (int k = 0; k < n_sub; ++k) {
             const double tt = fma(te, sh.sdt[k], cur.tv);
             const double gw = cur.g * sh.sw[k];
-            const double F = eval_sample<GRAD, SECONDARY>(tt, c, cld, gw, acc);
+            const double F = eval_sample<GRAD, SECONDARY, LDELAY>(tt, c, cld, gw, acc);
             f = fma(sh.sw[k], F, f);
             if (GRAD) acc.add(kNG + 6, gw * F);
           }
@@ -1570,13 +1675,13 @@ __global__ __launch_bounds__(kBlock) void transit_finish_kernel(
   const int ng_draw = n_planet * kNG + 7;
   const int s = threadIdx.x;
   if (partial) {
-    {
-      // record slots that carry no gradient (SINI, T0, PERIOD, the windows) read 0
-      const int p = s / EXO_NPAR, slot = s % EXO_NPAR;
+    for (int q = s; q < n_planet * EXO_NPAR; q += kBlock) {
+      // record slots that carry no gradient (T0, PERIOD, the windows, the reserved ones) read 0
+      const int p = q / EXO_NPAR, slot = q % EXO_NPAR;
       const bool carried = slot == EXO_P_N || slot == EXO_P_TP || slot == EXO_P_ECC || slot == EXO_P_COSW ||
                            slot == EXO_P_SINW || slot == EXO_P_COSI || slot == EXO_P_AOR || slot == EXO_P_ROR ||
-                           slot == EXO_P_FRATIO;
-      if (p < n_planet && !carried) gparams[(draw * n_planet + p) * EXO_NPAR + slot] = 0.0;
+                           slot == EXO_P_FRATIO || slot == EXO_P_SINI || slot == EXO_P_CLIGHT;
+      if (!carried) gparams[(draw * n_planet + p) * EXO_NPAR + slot] = 0.0;
     }
     if (s < ng_draw) {
       const double* __restrict__ src = partial + draw * nblk * (int64_t)ng_draw + s;
@@ -1585,7 +1690,7 @@ __global__ __launch_bounds__(kBlock) void transit_finish_kernel(
       if (s < n_planet * kNG) {
         const int p = s / kNG, k = s % kNG;
         const int map[kNG] = {EXO_P_N, EXO_P_TP, EXO_P_ECC, EXO_P_COSW, EXO_P_SINW,
-                              EXO_P_COSI, EXO_P_AOR, EXO_P_ROR, EXO_P_FRATIO, -1};
+                              EXO_P_COSI, EXO_P_AOR, EXO_P_ROR, EXO_P_FRATIO, -1, EXO_P_SINI, EXO_P_CLIGHT};
         if (map[k] >= 0) gparams[(draw * n_planet + p) * EXO_NPAR + map[k]] = v;
       } else {
         const int k = s - n_planet * kNG;
@@ -1883,7 +1988,13 @@ inline int launch_runs_sweep(const double* t, int64_t n_cad, const double* texp,
   double* vals = (flux || sparse) ? w.vals : nullptr;
   double* fill = sparse ? nullptr : flux;
   const dim3 hgrid((unsigned)w.hb, (unsigned)n_draw);
+  const bool ldelay = flags & EXO_FLAG_LIGHT_DELAY;
 #define EXO_LAUNCH_RUNS(G, SEC)                                                                                       \
+  if (ldelay)                                                                                                         \
+    hipLaunchKernelGGL((transit_runs_kernel<G, SEC, true>), hgrid, block, 0, st, t, n_cad, texp, n_texp, stencil_dt,  \
+                       stencil_w, (int)n_sub, params, ld, (int)n_planet, flags, n_ev, w.rl, gflux, vals,              \
+                       fill ? w.vcad : nullptr, fill, grad ? w.partial : nullptr);                                    \
+  else                                                                                                                \
   hipLaunchKernelGGL((transit_runs_kernel<G, SEC>), hgrid, block, 0, st, t, n_cad, texp, n_texp, stencil_dt, stencil_w, \
                      (int)n_sub, params, ld, (int)n_planet, flags, n_ev, w.rl, gflux, vals, fill ? w.vcad : nullptr, fill,        \
                      grad ? w.partial : nullptr)
@@ -1988,7 +2099,7 @@ static int transit_fwd(const double* t, int64_t n_cad, const double* texp, int64
     if (ev_stop) (void)hipEventRecord((hipEvent_t)ev_stop, st);
     return rc;
   }
-  if (flags & EXO_FLAG_SPARSE) return EXO_ERR_INVALID_ARGUMENT;   // the list path has no sparse output
+  if (flags & (EXO_FLAG_SPARSE | EXO_FLAG_LIGHT_DELAY)) return EXO_ERR_INVALID_ARGUMENT;   // run-enumeration path only
   int bpd, tpb;
   transit_geometry(n_cad, n_draw, &bpd, &tpb);
   const Workspace w = carve(workspace, n_draw, bpd, tpb, n_planet);
@@ -2054,7 +2165,7 @@ static int transit_vjp(const double* t, int64_t n_cad, const double* texp, int64
     if (ev_stop) (void)hipEventRecord((hipEvent_t)ev_stop, st);
     return rc;
   }
-  if (flags & EXO_FLAG_SPARSE) return EXO_ERR_INVALID_ARGUMENT;   // the list path has no sparse output
+  if (flags & (EXO_FLAG_SPARSE | EXO_FLAG_LIGHT_DELAY)) return EXO_ERR_INVALID_ARGUMENT;   // run-enumeration path only
   int bpd, tpb;
   transit_geometry(n_cad, n_draw, &bpd, &tpb);
   const Workspace w = carve(workspace, n_draw, bpd, tpb, n_planet);

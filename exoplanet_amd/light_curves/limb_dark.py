@@ -131,19 +131,32 @@ class LimbDarkLightCurve:
             stencil = exposure_stencil(oversample, order)   # raises for order > 2 like the reference
         else:
             stencil = None
-        if isinstance(orbit, KeplerianOrbit) and not light_delay and (
-                type(orbit)._warp_times is KeplerianOrbit._warp_times or hasattr(orbit, "kernel_ttv")):
+        if light_delay and use_in_transit:
+            # keplerian.py:720-723: the reference's in_transit refuses light delay
+            raise NotImplementedError("Light travel time delay not yet implemented for `in_transit`")
+        keplerian = isinstance(orbit, KeplerianOrbit) and type(orbit)._warp_times is KeplerianOrbit._warp_times
+        if keplerian and light_delay and self._fusable_delay(orbit, t, texp):
+            # second Kepler solve in the same kernel (EXO_FLAG_LIGHT_DELAY)
+            return self._fused(orbit, r, t, texp, stencil, use_in_transit, light_delay=True)
+        if isinstance(orbit, KeplerianOrbit) and not light_delay and (keplerian or hasattr(orbit, "kernel_ttv")):
             return self._fused(orbit, r, t, texp, stencil, use_in_transit)
         return self._composed(orbit, r, t, texp, stencil, use_in_transit, light_delay)
 
+    @staticmethod
+    def _fusable_delay(orbit, t, texp):
+        """the light-delay kernels take a scalar (or no) exposure time and no sky rotation beyond what the
+        flux needs; anything else stays on the composed path"""
+        scalar_texp = texp is None or as_tensor(texp).numel() == 1
+        return scalar_texp and as_tensor(t).dim() == 1
+
     # ---- hot path: one packing kernel + the fused light-curve kernels, nothing O(N) in torch
-    def _fused(self, orbit, r, t, texp, stencil, use_in_transit, secondary=None):
+    def _fused(self, orbit, r, t, texp, stencil, use_in_transit, secondary=None, light_delay=False):
         t = as_tensor(t, r if isinstance(r, torch.Tensor) else self.u1)
         if t.dim() != 1:
             raise ValueError("t must be a vector of times")
         sec = None if secondary is None else ((secondary[0].u1, secondary[0].u2), secondary[1])
         rec, ld, batch, flags = orbit.kernel_inputs(r, (self.u1, self.u2), use_in_transit=use_in_transit,
-                                                    secondary=sec)
+                                                    secondary=sec, light_delay=light_delay)
         t = t.to(rec.device)
         kw = {}
         if hasattr(orbit, "kernel_ttv"):

@@ -34,13 +34,16 @@ class SecondaryEclipseLightCurve:
             raise ValueError("missing required argument 'r'")
         if t is None:
             raise ValueError("missing required argument 't'")
-        fused = (isinstance(orbit, KeplerianOrbit) and not light_delay
-                 and type(orbit)._warp_times is KeplerianOrbit._warp_times)
+        fused = (isinstance(orbit, KeplerianOrbit) and type(orbit)._warp_times is KeplerianOrbit._warp_times
+                 and (not light_delay or self.primary._fusable_delay(orbit, t, texp)))
         if fused:
-            use_in_transit = True if use_in_transit is None else use_in_transit
+            use_in_transit = (not light_delay) if use_in_transit is None else use_in_transit
+            if light_delay and use_in_transit:
+                raise NotImplementedError("Light travel time delay not yet implemented for `in_transit`")
             stencil = exposure_stencil(oversample, order) if texp is not None else None
             return self.primary._fused(orbit, r, t, texp, stencil, use_in_transit,
-                                       secondary=(self.secondary, self.surface_brightness_ratio))
+                                       secondary=(self.secondary, self.surface_brightness_ratio),
+                                       light_delay=light_delay)
         # composed path: exactly the reference's two-orbit blend (secondary_eclipse.py:45-70)
         r = _vec(r)
         orbit2 = orbit._flip(r)

@@ -19,15 +19,16 @@ import torch
 
 from . import _lib
 
-NPAR = 16
+NPAR = 20
 (P_N, P_TP, P_ECC, P_COSW, P_SINW, P_COSI, P_SINI, P_AOR, P_ROR, P_T0, P_PERIOD, P_TS, P_TE,
- P_FRATIO, P_TS2, P_TE2) = range(16)
+ P_FRATIO, P_TS2, P_TE2, P_CLIGHT) = range(17)
 FLAG_PER_PLANET = 1
 FLAG_WINDOW = 2
 FLAG_SECONDARY = 4
 PACK_CIRCULAR = 8
 FLAG_EXACT_SCAN = 16
 FLAG_SPARSE = 32
+FLAG_LIGHT_DELAY = 64
 NIN = 10
 (IN_PERIOD, IN_T0, IN_B, IN_ECC, IN_OMEGA, IN_R, IN_MSTAR, IN_RSTAR, IN_MPLANET, IN_SBR) = range(10)
 MAX_PLANETS = 16
@@ -266,7 +267,7 @@ def _vjp(t, texp, n_texp, sdt, sw, n_sub, params, ld, D, P, flags, gflux, want_f
     gparams = torch.empty_like(params)
     gld = torch.empty_like(ld)
     dot = torch.empty(D, dtype=torch.float64, device=t.device)
-    flux = torch.empty(shape, dtype=torch.float64, device=t.device) if want_flux else None
+    flux = torch.empty(shape, dtype=torch.float64, device=t.device) if (want_flux and not flags & FLAG_SPARSE) else None
     gshift = torch.empty_like(shift) if n_edge else None
     with torch.cuda.device(t.device):
         if n_edge:
@@ -285,13 +286,20 @@ def _vjp(t, texp, n_texp, sdt, sw, n_sub, params, ld, D, P, flags, gflux, want_f
                                                 events[0], events[1]),
                 "exo_transit_flux_vjp_f64",
             )
+    if flags & FLAG_SPARSE:
+        # the sweep's output lives in its workspace (include/exoplanet_amd.h, EXO_FLAG_SPARSE)
+        import ctypes
+
+        lay = (ctypes.c_int64 * 5)()
+        _lib.check(lib.exo_transit_flux_sparse_layout(N, D, P, lay), "exo_transit_flux_sparse_layout")
+        flux = SparseFlux(ws, list(lay), N, D, P, 2 if flags & FLAG_SECONDARY else 1)
     return flux, gparams, gld, dot, gshift
 
 
 def transit_flux(t, params, ld, texp=None, stencil_dt=None, stencil_w=None, flags=0, ttv=None):
     """Fused light curve for ``n_draw`` parameter sets.
 
-    t (n_cad,), params (n_draw, n_planet, 16) (slot meaning: include/exoplanet_amd.h),
+    t (n_cad,), params (n_draw, n_planet, 20) (slot meaning: include/exoplanet_amd.h),
     ld (n_draw, 3|6).  Returns (n_draw, n_cad) or, with FLAG_PER_PLANET,
     (n_draw, n_cad, n_planet).  Differentiable w.r.t. ``params`` and ``ld``.
     ``ttv = (edges (n_draw, n_planet, E), shift (n_draw, n_planet, E + 1))``: transit-timing
@@ -331,8 +339,11 @@ class _TransitFluxDot(torch.autograd.Function):
         flux, gparams, gld, dot, gshift = _vjp(t, texp, n_texp, sdt, sw, n_sub, params, ld, D, P, flags, gflux, True,
                                                events, ttv=ttv)
         ctx.save_for_backward(gparams, gld, gshift)
-        ctx.mark_non_differentiable(flux)
         ctx.set_materialize_grads(False)  # never build a (D, N) zero cotangent for the detached flux
+        if isinstance(flux, SparseFlux):
+            _TransitFluxDot._sparse = flux   # (not a tensor: handed over beside the autograd outputs)
+            return torch.empty(0, dtype=torch.float64, device=dot.device), dot
+        ctx.mark_non_differentiable(flux)
         return flux, dot
 
     @staticmethod
@@ -349,10 +360,15 @@ def transit_flux_dot(t, params, ld, gflux, texp=None, stencil_dt=None, stencil_w
     """One-sweep value + gradient for a cotangent known in advance: returns
     ``(flux, L)`` with ``L[d] = (gflux[d] * flux[d]).sum()``; ``L`` is
     differentiable w.r.t. ``params`` and ``ld`` (and the ``ttv`` shift table);
-    flux itself is returned detached."""
+    flux itself is returned detached.  With ``flags | FLAG_SPARSE`` no dense flux array is written:
+    the first return value is a :class:`SparseFlux` (runs of cadences + their values)."""
     edges, shift = (None, None) if ttv is None else ttv
-    return _TransitFluxDot.apply(t, texp, stencil_dt, stencil_w, params, ld, gflux, int(flags), events,
-                                 None if edges is None else edges.detach(), shift)
+    out = _TransitFluxDot.apply(t, texp, stencil_dt, stencil_w, params, ld, gflux, int(flags), events,
+                                None if edges is None else edges.detach(), shift)
+    if int(flags) & FLAG_SPARSE:
+        sp, _TransitFluxDot._sparse = _TransitFluxDot._sparse, None
+        return sp, out[1]
+    return out
 
 
 class SparseFlux:
@@ -514,7 +530,7 @@ class _PackRecords(torch.autograd.Function):
 
 def pack_records(orbit_in, ld_in, flags=0):
     """(period, t0, b, ecc, omega, r, m_star, r_star, m_planet, sbr) per (draw, planet) and
-    (u1, u2[, u1s, u2s]) per draw -> kernel records (n_draw, n_planet, 16) and Green's-basis
+    (u1, u2[, u1s, u2s]) per draw -> kernel records (n_draw, n_planet, 20) and Green's-basis
     limb-darkening coefficients (n_draw, 3|6): KeplerianOrbit.__init__ + get_cl + windows in
     one kernel, differentiable.  Slot order: include/exoplanet_amd.h EXO_IN_*."""
     return _PackRecords.apply(orbit_in, ld_in, int(flags))

@@ -513,15 +513,17 @@ class KeplerianOrbit:
                           m_planet=self.m_star, r_star=r_planet)
 
     # ------------------------------------------------------------------ fused-kernel records
-    def kernel_inputs(self, r, u, use_in_transit=False, secondary=None):
+    def kernel_inputs(self, r, u, use_in_transit=False, secondary=None, light_delay=False):
         """Everything the fused light-curve kernels need, differentiable w.r.t. every
-        orbit / limb-darkening parameter: ``(records (D,P,16), ld (D,3|6), batch_shape, flags)``.
+        orbit / limb-darkening parameter: ``(records (D,P,20), ld (D,3|6), batch_shape, flags)``.
+        ``light_delay``: the kernels evaluate every sample at its retarded time (keplerian.py:411-470).
 
         ``u = (u1, u2)``; ``secondary = ((u1s, u2s), sbr)`` adds the occultation.  For the
         standard transit parameterisation (period, t0, b[, ecc, omega], r, [m_star, r_star],
         m_planet) this is ONE packing kernel (ops.pack_records); any other
         parameterisation runs the attribute algebra in torch."""
         flags = (ops.FLAG_WINDOW if use_in_transit else 0) | (ops.FLAG_SECONDARY if secondary is not None else 0)
+        flags |= ops.FLAG_LIGHT_DELAY if light_delay else 0
         if self._standard:
             A = self._args
             like = next((x for x in list(A.values()) + [r] if isinstance(x, torch.Tensor)), None)
@@ -547,7 +549,7 @@ class KeplerianOrbit:
                 orbit_in = orbit_in.expand(ld_in.shape[0], -1, -1)
                 batch = (ld_in.shape[0],)
             rec, ld = ops.pack_records(orbit_in.contiguous(), ld_in.contiguous(),
-                                       flags | (ops.PACK_CIRCULAR if circular else 0))
+                                       (flags & ~ops.FLAG_LIGHT_DELAY) | (ops.PACK_CIRCULAR if circular else 0))
             return rec, ld, batch, flags
         from ..light_curves.limb_dark import get_cl  # local import: light_curves imports this module
 
@@ -568,7 +570,7 @@ class KeplerianOrbit:
         """Pack the per-(draw, planet) parameter records of the fused transit
         kernel (layout: include/exoplanet_amd.h, EXO_P_*) from the orbit's attributes, in
         torch (any parameterisation).  Differentiable with respect to every orbit
-        parameter; returns (D, P, 16) and the batch shape."""
+        parameter; returns (D, P, 20) and the batch shape."""
         shape = self.shape
         z = torch.zeros(shape, dtype=torch.float64, device=self.a.device)
         r = _vec(r, self.a) + z
@@ -581,7 +583,10 @@ class KeplerianOrbit:
         cols[ops.P_COSW] = cw + z
         cols[ops.P_SINW] = sw + z
         cols[ops.P_COSI] = self.cos_incl + z
-        cols[ops.P_SINI] = self.sin_incl + z
+        # |cos i| > 1 (b beyond the orbit's largest impact parameter): sin(acos(.)) is NaN and the
+        # reference's `switch(los > 0, lc, 0)` makes the flux 0 (limb_dark.py:252); sin i = 0 does the same
+        # here -- as the packing kernel does for the standard parameterisation
+        cols[ops.P_SINI] = torch.where((self.cos_incl + z).abs() > 1.0, z, self.sin_incl + z)
         cols[ops.P_AOR] = self.a / self.r_star + z
         cols[ops.P_ROR] = r / self.r_star
         cols[ops.P_T0] = (self.t0 + z).detach()
@@ -589,6 +594,9 @@ class KeplerianOrbit:
         cols[ops.P_TS], cols[ops.P_TE] = -inf, inf
         cols[ops.P_FRATIO] = z
         cols[ops.P_TS2], cols[ops.P_TE2] = -inf, inf
+        cols[ops.P_CLIGHT] = c_light / self.r_star + z          # read by light-delay sweeps only
+        for k in range(ops.P_CLIGHT + 1, ops.NPAR):
+            cols[k] = z                                         # reserved
         if secondary_sbr is not None:
             sbr = as_tensor(secondary_sbr, self.a)
             sbr = sbr.unsqueeze(-1) if sbr.dim() >= 1 else sbr

@@ -78,7 +78,7 @@ int exo_contact_points_f64(const double* a, const double* e, const double* cosw,
  * of the stellar radius (the O(P) algebra that produces them stays on the host
  * side, in autograd):
  * ------------------------------------------------------------------------- */
-#define EXO_NPAR 16
+#define EXO_NPAR 20
 #define EXO_P_N 0       /* mean motion 2 pi / period            keplerian.py:146     */
 #define EXO_P_TP 1      /* t_periastron = t0 - M0/n             keplerian.py:277     */
 #define EXO_P_ECC 2     /* eccentricity (0 for ecc=None)                              */
@@ -95,6 +95,9 @@ int exo_contact_points_f64(const double* a, const double* e, const double* cosw,
 #define EXO_P_FRATIO 13 /* secondary: sbr * ror^2                secondary_eclipse.py:68 */
 #define EXO_P_TS2 14    /* secondary-eclipse window start - t0 (may exceed +-P/2)    */
 #define EXO_P_TE2 15    /* secondary-eclipse window end   - t0                        */
+#define EXO_P_CLIGHT 16 /* speed of light in stellar radii per day (constants.py:36 / R_star): only read
+                           with EXO_FLAG_LIGHT_DELAY                                  */
+/* slots 17 .. 19: reserved, written as 0 by the packing kernel, not read */
 
 /* flags */
 #define EXO_FLAG_PER_PLANET 1u /* flux is [n_draw][n_cad][n_planet] instead of summed [n_draw][n_cad] */
@@ -110,6 +113,12 @@ int exo_contact_points_f64(const double* a, const double* e, const double* cosw,
                                    touched (pass NULL); the output is the runs of cadences in which a planet can
                                    overlap the disk and a compact value array, both inside `workspace`
                                    (exo_transit_flux_sparse_layout); every other cadence has flux exactly 0.  */
+
+#define EXO_FLAG_LIGHT_DELAY 64u /* light-travel delay (keplerian.py:411-470, _get_retarded_position with z0 = 0):
+                                   a body is seen where it was at t - delay, the delay from its line-of-sight
+                                   position, velocity and acceleration at t; a second Kepler solve per sample, in
+                                   the same kernel.  Needs slot EXO_P_CLIGHT and the VALUE of EXO_P_SINI (both get
+                                   cotangents then).  Run-enumeration sweeps only (see EXO_FLAG_SPARSE).        */
 
 #define EXO_MAX_PLANETS 16
 #define EXO_MAX_SUBEXP 63
@@ -166,7 +175,7 @@ int exo_transit_flux_fwd_ev_f64(const double* t, int64_t n_cad, const double* te
                                 int64_t workspace_bytes, void* stream, void* ev_start, void* ev_stop);
 
 /* Reverse (recompute-forward): given gflux (same shape as flux) accumulate
- *   gparams [n_draw][n_planet][EXO_NPAR]  (slots SINI, T0, PERIOD, TS.. are 0)
+ *   gparams [n_draw][n_planet][EXO_NPAR]  (slots T0, PERIOD, TS.. are 0; SINI, CLIGHT too without EXO_FLAG_LIGHT_DELAY)
  *   gld     [n_draw][3 or 6]
  * and, if flux_out != NULL, also write the forward value in the same pass
  * (value + gradient in one sweep over t: 24 B per (draw, cadence)); if

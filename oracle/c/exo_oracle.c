@@ -201,7 +201,7 @@ void oracle_quad_sv(const double* b, const double* r, double* s, double* dsdb, d
 
 /* ------------------------------------------------------------------ fused transit */
 enum { P_N = 0, P_TP, P_ECC, P_COSW, P_SINW, P_COSI, P_SINI, P_AOR, P_ROR, P_T0, P_PERIOD, P_TS, P_TE,
-       P_FRATIO, P_TS2, P_TE2, NPAR };
+       P_FRATIO, P_TS2, P_TE2, P_CLIGHT, P_RES1, P_RES2, P_RES3, NPAR };   /* include/exoplanet_amd.h: EXO_NPAR = 20 */
 #define FLAG_PER_PLANET 1u
 #define FLAG_WINDOW 2u
 #define FLAG_SECONDARY 4u

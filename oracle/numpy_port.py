@@ -773,9 +773,9 @@ class SecondaryEclipseLightCurve:
 # built from the pieces above; forward-mode Jacobian (the kernel is reverse-mode,
 # so the two derivations are independent).
 # =============================================================================
-NPAR = 16
+NPAR = 20
 (P_N, P_TP, P_ECC, P_COSW, P_SINW, P_COSI, P_SINI, P_AOR, P_ROR, P_T0, P_PERIOD, P_TS, P_TE,
- P_FRATIO, P_TS2, P_TE2) = range(16)
+ P_FRATIO, P_TS2, P_TE2, P_CLIGHT) = range(17)   # slots 17..19 reserved (include/exoplanet_amd.h)
 GRAD_SLOTS = (P_N, P_TP, P_ECC, P_COSW, P_SINW, P_COSI, P_AOR, P_ROR, P_FRATIO)
 
 
