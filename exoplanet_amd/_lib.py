@@ -77,6 +77,10 @@ _SIGNATURES = {
         [_c_dp, _c_dp, _c_dp, _c_dp, _i64, _i64, _c_dp, _i32, _c_dp, _i32, _c_dp, _i64, _c_dp, _c_dp, _i64, _i32,
          _c_dp, _c_dp, _c_dp, _c_dp, _c_dp, _c_dp],
     ),
+    "exo_celerite_dot_tril_f64": (ctypes.c_int, [_c_dp, _c_dp, _i64, _i64, _c_dp, _i32, _c_dp, _i32, _c_dp, _i64, _c_dp, _c_dp,
+                                                 _c_dp]),
+    "exo_celerite_predict_f64": (ctypes.c_int, [_c_dp, _i64, _c_dp, _c_dp, _i32, _c_dp, _i32, _c_dp, _i64, _c_dp, _i64, _c_dp,
+                                                _c_dp]),
     "exo_radial_velocity_fwd_f64": (ctypes.c_int, [_c_dp, _i64, _c_dp, _i64, _i32, _c_dp, _c_dp]),
     "exo_radial_velocity_vjp_f64": (ctypes.c_int, [_c_dp, _i64, _c_dp, _i64, _i32, _c_dp, _c_dp, _c_dp]),
     "exo_pack_records_f64": (ctypes.c_int, [_c_dp, _c_dp, _i64, _i32, _u32, _c_dp, _c_dp, _c_dp]),

@@ -1269,6 +1269,26 @@ __global__ __launch_bounds__(kWave) void celerite_chunk_gcoef_kernel(int64_t n, 
   gcoef_lane(cf, n, n_draw, state, cg, gdiag_sum, gcoef_real, gcoef_complex, draw, (int)(e - draw * J));
 }
 
+// O(N) companions (exo_celerite_core.hpp): one lane per draw
+template <int J>
+__global__ __launch_bounds__(kWave) void celerite_dot_tril_kernel(const double* __restrict__ t,
+                                                                  const double* __restrict__ diag, int64_t n_diag, int64_t n,
+                                                                  Coefs cf, int64_t n_draw, const double* __restrict__ x,
+                                                                  double* __restrict__ z) {
+  const int64_t draw = (int64_t)blockIdx.x * kWave + threadIdx.x;
+  if (draw >= n_draw) return;
+  dot_tril_lane<J>(t, diag, n_diag, n, cf, x, z, draw);
+}
+template <int J>
+__global__ __launch_bounds__(kWave) void celerite_predict_kernel(const double* __restrict__ t, int64_t n,
+                                                                 const double* __restrict__ alpha, Coefs cf, int64_t n_draw,
+                                                                 const double* __restrict__ tq, int64_t m,
+                                                                 double* __restrict__ mu) {
+  const int64_t draw = (int64_t)blockIdx.x * kWave + threadIdx.x;
+  if (draw >= n_draw) return;
+  predict_lane<J>(t, n, alpha, cf, tq, m, mu, draw);
+}
+
 inline int launch_status() { return hipGetLastError() == hipSuccess ? EXO_OK : EXO_ERR_LAUNCH; }
 
 inline bool gp_args_ok(int64_t n, int64_t n_diag, int32_t n_real, int32_t n_complex, int64_t n_draw, int32_t n_chunks) {
@@ -1485,6 +1505,34 @@ int exo_celerite_loglike_obs_vjp_f64(const double* t, const double* obs, const d
   return celerite_vjp(t, Series{model, obs}, diag, n_diag, n, Coefs{coef_real, coef_complex, pair_kind, n_real, n_complex},
                       n_draw, gloglike, state, state_doubles, n_chunks, gmodel, -1.0, gdiag, gdiag_sum, gcoef_real,
                       gcoef_complex, stream);
+}
+
+int exo_celerite_dot_tril_f64(const double* t, const double* diag, int64_t n_diag, int64_t n, const double* coef_real,
+                              int32_t n_real, const double* coef_complex, int32_t n_complex, const int32_t* pair_kind,
+                              int64_t n_draw, const double* x, double* z, void* stream) {
+  if (n_draw == 0) return EXO_OK;
+  if (!gp_args_ok(n, n_diag, n_real, n_complex, n_draw, 0) || !t || !diag || !x || !z || (n_real > 0 && !coef_real) ||
+      (n_complex > 0 && !coef_complex))
+    return EXO_ERR_INVALID_ARGUMENT;
+  const Coefs cf{coef_real, coef_complex, pair_kind, n_real, n_complex};
+  const dim3 grid((unsigned)((n_draw + kWave - 1) / kWave)), block(kWave);
+  EXO_GP_DISPATCH(cf.J(), hipLaunchKernelGGL((celerite_dot_tril_kernel<JJ>), grid, block, 0, (hipStream_t)stream, t, diag,
+                                             n_diag, n, cf, n_draw, x, z))
+  return launch_status();
+}
+
+int exo_celerite_predict_f64(const double* t, int64_t n, const double* alpha, const double* coef_real, int32_t n_real,
+                             const double* coef_complex, int32_t n_complex, const int32_t* pair_kind, int64_t n_draw,
+                             const double* tq, int64_t m, double* mu, void* stream) {
+  if (n_draw == 0 || m == 0) return EXO_OK;
+  if (!gp_args_ok(n, 1, n_real, n_complex, n_draw, 0) || m < 0 || !t || !alpha || !tq || !mu ||
+      (n_real > 0 && !coef_real) || (n_complex > 0 && !coef_complex))
+    return EXO_ERR_INVALID_ARGUMENT;
+  const Coefs cf{coef_real, coef_complex, pair_kind, n_real, n_complex};
+  const dim3 grid((unsigned)((n_draw + kWave - 1) / kWave)), block(kWave);
+  EXO_GP_DISPATCH(cf.J(), hipLaunchKernelGGL((celerite_predict_kernel<JJ>), grid, block, 0, (hipStream_t)stream, t, n, alpha,
+                                             cf, n_draw, tq, m, mu))
+  return launch_status();
 }
 
 }  // extern "C"

@@ -1245,6 +1245,111 @@ EXO_HD void chunk1_vjp_lane(const double* EXO_RESTRICT t, Series rs, const doubl
   state[ws.gpart(c, 4 * J, draw)] = r.gasum;
 }
 
+// ---------------------------------------------------------------------------------------------
+// O(N) companions of the likelihood (celerite2's GaussianProcess.dot_tril / predict): sequential in
+// time, one lane per draw with every state index in its registers.  Not on the per-step path --
+// they serve posterior predictions and prior / posterior samples.
+// ---------------------------------------------------------------------------------------------
+// z = L x with K + diag = L L^T:  L = (I + strict_tril(U W^T o P)) D^(1/2), so with y = sqrt(d) o x
+//   F_n = P_{n-1} o (F_{n-1} + W_{n-1} y_{n-1}) ;  z_n = y_n + U_n . F_n
+// (the recurrence of solve_lower with the sign flipped); the factorisation (S, d, W) runs beside it.
+template <int J>
+EXO_HD void dot_tril_lane(const double* EXO_RESTRICT t, const double* EXO_RESTRICT diag, int64_t n_diag, int64_t n,
+                          const Coefs& cf, const double* EXO_RESTRICT x, double* EXO_RESTRICT z, int64_t draw) {
+  DrawCoef<J> co;
+  co.init(cf, draw);
+  const double asum = co.asum();
+  const double* EXO_RESTRICT dg = diag + (n_diag == 1 ? 0 : draw * n);
+  const double* EXO_RESTRICT xr = x + draw * n;
+  double* EXO_RESTRICT zr = z + draw * n;
+  Fwd<J> f;
+  double G[J];   // the F of the dot recurrence (f.F belongs to the unused solve_lower chain)
+#pragma unroll
+  for (int j = 0; j < J; ++j) { f.F[j] = f.W[j] = f.U[j] = f.V[j] = 0.0; G[j] = 0.0; }
+#pragma unroll
+  for (int k = 0; k < J * (J + 1) / 2; ++k) f.S.v[k] = 0.0;
+  Phi<J> phi;
+  double tprev = t[0], yprev = 0.0;
+#pragma unroll 1
+  for (int64_t i = 0; i < n; ++i) {
+    const double ti = t[i];
+    if (i > 0) {
+      phi.set(co, ti - tprev);
+      tprev = ti;
+#pragma unroll
+      for (int j = 0; j < J; ++j) G[j] = phi.v[j] * fma(f.W[j], yprev, G[j]);
+      f.advance(phi.v);
+    }
+    co.uv(ti, f.U, f.V);
+    f.measure(0.0, dg[i] + asum);
+    const double y = sqrt(f.d > 0.0 ? f.d : __builtin_nan("")) * xr[i];   // not positive definite: NaN from here on
+    double acc = y;
+#pragma unroll
+    for (int j = 0; j < J; ++j) acc = fma(f.U[j], G[j], acc);
+    zr[i] = acc;
+    yprev = y;
+  }
+}
+
+// mu[m] = sum_n k(|tq_m - t_n|) alpha_n for sorted data times t and sorted query times tq, in O(N + M):
+//   k(tq - t_n) = sum_j U_j(tq) V_j(t_n) e^{-c_j (tq - t_n)}   for t_n <= tq   (F sweeps forward)
+//   k(t_n - tq) = sum_j V_j(tq) U_j(t_n) e^{-c_j (t_n - tq)}   for t_n >  tq   (G sweeps backward)
+template <int J>
+EXO_HD void predict_lane(const double* EXO_RESTRICT t, int64_t n, const double* EXO_RESTRICT alpha, const Coefs& cf,
+                         const double* EXO_RESTRICT tq, int64_t m, double* EXO_RESTRICT mu, int64_t draw) {
+  DrawCoef<J> co;
+  co.init(cf, draw);
+  const double* EXO_RESTRICT al = alpha + draw * n;
+  double* EXO_RESTRICT out = mu + draw * m;
+  double F[J], U[J], V[J];
+#pragma unroll
+  for (int j = 0; j < J; ++j) F[j] = U[j] = V[j] = 0.0;
+  // forward: data points at or before the query time
+  int64_t i = 0;
+  double tcur = n > 0 ? t[0] : 0.0;
+#pragma unroll 1
+  for (int64_t q = 0; q < m; ++q) {
+    const double tm = tq[q];
+    while (i < n && t[i] <= tm) {
+      const double ti = t[i];
+      co.uv(ti, U, V);
+#pragma unroll
+      for (int j = 0; j < J; ++j) F[j] = fma(F[j], exp(-co.k[j].c * (ti - tcur)), V[j] * al[i]);
+      tcur = ti;
+      ++i;
+    }
+    co.uv(tm, U, V);
+    double acc = 0.0;
+#pragma unroll
+    for (int j = 0; j < J; ++j) acc = fma(U[j] * exp(-co.k[j].c * (tm - tcur)), F[j], acc);
+    out[q] = (i > 0) ? acc : 0.0;
+  }
+  // backward: data points after the query time
+#pragma unroll
+  for (int j = 0; j < J; ++j) F[j] = 0.0;
+  i = n - 1;
+  tcur = n > 0 ? t[n - 1] : 0.0;
+#pragma unroll 1
+  for (int64_t q = m - 1; q >= 0; --q) {
+    const double tm = tq[q];
+    while (i >= 0 && t[i] > tm) {
+      const double ti = t[i];
+      co.uv(ti, U, V);
+#pragma unroll
+      for (int j = 0; j < J; ++j) F[j] = fma(F[j], exp(-co.k[j].c * (tcur - ti)), U[j] * al[i]);
+      tcur = ti;
+      --i;
+    }
+    if (i < n - 1) {
+      co.uv(tm, U, V);
+      double acc = 0.0;
+#pragma unroll
+      for (int j = 0; j < J; ++j) acc = fma(V[j] * exp(-co.k[j].c * (tcur - tm)), F[j], acc);
+      out[q] += acc;
+    }
+  }
+}
+
 // coefficient cotangents of one (draw, state index) from the totals over the chunks (left in chunk
 // 0's slots): the same combination as the tail of celerite_vjp_kernel
 EXO_HD void gcoef_lane(const Coefs& cf, int64_t n, int64_t n_draw, const double* EXO_RESTRICT state, const ChunkGeom& cg,

@@ -246,11 +246,55 @@ class GaussianProcess:
         alpha = -g
         return alpha[0] if squeeze else alpha
 
-    def predict(self, y, t=None, *, include_mean=True, block=4096):
+    def dot_tril(self, x):
+        """``L x`` with ``K + diag = L L^T`` (celerite2's ``GaussianProcess.dot_tril``), per draw, detached:
+        ``x`` (N,) or (D, N).  O(N) recurrence on the device."""
+        if self._t is None:
+            raise RuntimeError("you must call 'compute' first")
+        t = self._t
+        real, cplx, kind, D, batched = self._coefficients()
+        x = as_tensor(x, t).detach()
+        squeeze = x.dim() == 1 and not batched and self._diag.shape[0] == 1
+        D = max(D, x.shape[0] if x.dim() == 2 else 1, self._diag.shape[0])
+        x = _dev(x.expand(D, t.shape[0]), "x")
+        real = _dev(real.detach().expand(D, real.shape[1], 2), "coef_real")
+        cplx = _dev(cplx.detach().expand(D, cplx.shape[1], 4), "coef_complex")
+        kind = None if kind is None else kind.expand(D, kind.shape[1]).contiguous()
+        diag = _dev(self._diag.detach(), "diag")
+        z = torch.empty_like(x)
+        lib = _lib.load()
+        with torch.cuda.device(t.device):
+            _lib.check(lib.exo_celerite_dot_tril_f64(_ptr(t), _ptr(diag), diag.shape[0], t.shape[0], _ptr(real), real.shape[1],
+                                                     _ptr(cplx), cplx.shape[1], _ptr(kind), D, _ptr(x), _ptr(z), _stream(t)),
+                       "exo_celerite_dot_tril_f64")
+        return z[0] if squeeze else z
+
+    def sample(self, size=None, include_mean=True, generator=None):
+        """draws from the prior N(mean, K + diag) at the data times (celerite2's ``GaussianProcess.sample``):
+        ``size`` draws per parameter draw -> (size, [D,] N); None -> ([D,] N)"""
+        t = self._t
+        if t is None:
+            raise RuntimeError("you must call 'compute' first")
+        _, _, _, D, batched = self._coefficients()
+        D = max(D, self._diag.shape[0])
+        n_s = 1 if size is None else int(size)
+        out = []
+        for _ in range(n_s):
+            x = torch.randn(D, t.shape[0], dtype=torch.float64, device=t.device, generator=generator)
+            z = self.dot_tril(x if (batched or D > 1) else x[0])
+            if include_mean:
+                m = self.mean(t) if callable(self.mean) else as_tensor(self.mean, t)
+                if isinstance(m, torch.Tensor) and m.dim() == 1 and m.shape[0] != t.shape[0]:
+                    m = m.unsqueeze(-1)
+                z = z + (m.detach() if isinstance(m, torch.Tensor) else m)
+            out.append(z)
+        return out[0] if size is None else torch.stack(out)
+
+    def predict(self, y, t=None, *, include_mean=True):
         """Conditional mean of the process given ``y`` (celerite2's ``GaussianProcess.predict``
         without the variance), detached.  At the data times (``t=None``) it is
-        ``y - diag * alpha``; at other times ``K(t, t_data) alpha`` is formed densely in blocks
-        of ``block`` prediction times (O(N M): meant for plots, not for the sampling loop)."""
+        ``y - diag * alpha``; at other times ``K(t, t_data) alpha`` by the O(N + M) forward / backward
+        recurrences of exo_celerite_predict_f64 (``t`` sorted)."""
         tt, mean, resid, real, cplx, squeeze, _, kind = self._prepare(y)
         alpha = self.apply_inverse(y)
         alpha2 = alpha if alpha.dim() == 2 else alpha.unsqueeze(0)
@@ -261,24 +305,18 @@ class GaussianProcess:
             tq = as_tensor(t, tt)
             if tq.dim() != 1:
                 raise ValueError("dimension mismatch: t must be 1-D")
-            out = []
-            re, cx = real.detach(), cplx.detach()
-            for i0 in range(0, tq.shape[0], block):
-                tau = (tq[i0:i0 + block, None] - tt[None, :]).abs()        # (M, N)
-                rows = []
-                for d in range(alpha2.shape[0]):                           # plots: a handful of draws
-                    kv = torch.zeros_like(tau)
-                    for j in range(re.shape[1]):
-                        kv = kv + re[d, j, 0] * torch.exp(-re[d, j, 1] * tau)
-                    for j in range(cx.shape[1]):
-                        a, b, c, dd = cx[d, j]
-                        if kind is not None and int(kind[d, j]) == 1:      # the slot holds two real terms
-                            kv = kv + a * torch.exp(-b * tau) + c * torch.exp(-dd * tau)
-                        else:
-                            kv = kv + torch.exp(-c * tau) * (a * torch.cos(dd * tau) + b * torch.sin(dd * tau))
-                    rows.append(kv @ alpha2[d])
-                out.append(torch.stack(rows))
-            mu = torch.cat(out, dim=-1)
+            if tq.numel() > 1 and bool((tq[1:] < tq[:-1]).any()):
+                raise ValueError("the input coordinates must be sorted")
+            tq = _dev(tq.detach(), "t")
+            D = alpha2.shape[0]
+            al = _dev(alpha2.detach(), "alpha")
+            re, cx = _dev(real.detach(), "coef_real"), _dev(cplx.detach(), "coef_complex")
+            mu = torch.empty(D, tq.shape[0], dtype=torch.float64, device=tt.device)
+            lib = _lib.load()
+            with torch.cuda.device(tt.device):
+                _lib.check(lib.exo_celerite_predict_f64(_ptr(tt), tt.shape[0], _ptr(al), _ptr(re), re.shape[1], _ptr(cx),
+                                                        cx.shape[1], _ptr(kind), D, _ptr(tq), tq.shape[0], _ptr(mu),
+                                                        _stream(tt)), "exo_celerite_predict_f64")
         if include_mean:
             m = self.mean(tq) if callable(self.mean) else as_tensor(self.mean, tt)
             if isinstance(m, torch.Tensor) and m.dim() == 1 and m.shape[0] != tq.shape[0]:

@@ -335,6 +335,26 @@ int exo_celerite_loglike_obs_vjp_f64(const double* t, const double* obs, const d
                                      double* gcoef_complex, void* stream);
 
 /* ---------------------------------------------------------------------------
+ * O(N) companions of the likelihood (celerite2's GaussianProcess.dot_tril and the kernel product of
+ * GaussianProcess.predict; the reference's docs pair it with celerite2: docs/index.rst:14,48-49):
+ *   dot_tril: z[d] = L x[d] with K + diag = L L^T (prior samples: x ~ N(0, I));  NaN from the first
+ *             cadence at which the matrix is not positive definite
+ *   predict:  mu[d][m] = sum_n k(|tq[m] - t[n]|) alpha[d][n], t and tq sorted, in O(N + M) by one
+ *             forward and one backward sweep -- the conditional mean at new times is this with
+ *             alpha = (K + diag)^-1 (y - mean) = -d loglike / d resid
+ * Sequential in time, one lane per draw: utilities, not part of the per-step path.  Coefficients,
+ * pair kinds and diag as for exo_celerite_loglike_fwd_f64.
+ * ------------------------------------------------------------------------- */
+int exo_celerite_dot_tril_f64(const double* t, const double* diag, int64_t n_diag, int64_t n,
+                              const double* coef_real, int32_t n_real, const double* coef_complex,
+                              int32_t n_complex, const int32_t* pair_kind, int64_t n_draw, const double* x,
+                              double* z, void* stream);
+int exo_celerite_predict_f64(const double* t, int64_t n, const double* alpha, const double* coef_real,
+                             int32_t n_real, const double* coef_complex, int32_t n_complex,
+                             const int32_t* pair_kind, int64_t n_draw, const double* tq, int64_t m,
+                             double* mu, void* stream);
+
+/* ---------------------------------------------------------------------------
  * Record packing: the O(planets) algebra of KeplerianOrbit.__init__
  * (src/exoplanet/orbits/keplerian.py:133-281,849-934), get_cl
  * (src/exoplanet/light_curves/limb_dark.py:11-18), the in-transit windows

@@ -120,4 +120,34 @@ int harness_gp_vjp(const double* t, const double* y, const double* obs, const do
   return cg.C;
 }
 
+int harness_gp_dot_tril(const double* t, const double* diag, int64_t n_diag, int64_t n, const double* real, int32_t n_real,
+                        const double* cplx, int32_t n_complex, const int32_t* kind, int64_t n_draw, const double* x,
+                        double* z) {
+  const gp::Coefs cf{real, cplx, kind, n_real, n_complex};
+  for (int64_t d = 0; d < n_draw; ++d) switch (cf.J()) {
+      case 1: gp::dot_tril_lane<1>(t, diag, n_diag, n, cf, x, z, d); break;
+      case 2: gp::dot_tril_lane<2>(t, diag, n_diag, n, cf, x, z, d); break;
+      case 3: gp::dot_tril_lane<3>(t, diag, n_diag, n, cf, x, z, d); break;
+      case 4: gp::dot_tril_lane<4>(t, diag, n_diag, n, cf, x, z, d); break;
+      case 6: gp::dot_tril_lane<6>(t, diag, n_diag, n, cf, x, z, d); break;
+      default: return -1;
+    }
+  return 0;
+}
+
+int harness_gp_predict(const double* t, int64_t n, const double* alpha, const double* real, int32_t n_real,
+                       const double* cplx, int32_t n_complex, const int32_t* kind, int64_t n_draw, const double* tq,
+                       int64_t m, double* mu) {
+  const gp::Coefs cf{real, cplx, kind, n_real, n_complex};
+  for (int64_t d = 0; d < n_draw; ++d) switch (cf.J()) {
+      case 1: gp::predict_lane<1>(t, n, alpha, cf, tq, m, mu, d); break;
+      case 2: gp::predict_lane<2>(t, n, alpha, cf, tq, m, mu, d); break;
+      case 3: gp::predict_lane<3>(t, n, alpha, cf, tq, m, mu, d); break;
+      case 4: gp::predict_lane<4>(t, n, alpha, cf, tq, m, mu, d); break;
+      case 6: gp::predict_lane<6>(t, n, alpha, cf, tq, m, mu, d); break;
+      default: return -1;
+    }
+  return 0;
+}
+
 }  // extern "C"

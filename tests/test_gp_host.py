@@ -205,3 +205,36 @@ def test_lane_pipeline_long_series_vs_c_port(harness):
         np.testing.assert_allclose(g["y"][d], gw["y"], rtol=1e-7, atol=1e-9 * np.abs(gw["y"]).max())
         for q, key in enumerate(("ac", "bc", "cc", "dc")):
             np.testing.assert_allclose(g["cplx"][d, 0, q], gw[key][0], rtol=2e-6)
+
+
+def _kernel(tau, c):
+    return P.celerite_kernel(tau, *c)
+
+
+@pytest.mark.parametrize("n_real,n_complex", [(1, 0), (0, 1), (1, 1), (0, 3)])
+def test_dot_tril_and_predict_vs_dense(harness, n_real, n_complex):
+    """z = L x (K + diag = L L^T) and the conditional mean kernel product K(tq, t) alpha, O(N)
+    recurrences against dense linear algebra"""
+    rng = np.random.default_rng(50 + n_real + 3 * n_complex)
+    n, D, m = 150, 2, 97
+    t = np.sort(rng.uniform(0, 30, n))
+    diag = rng.uniform(0.05, 0.3, (D, n))
+    x = rng.normal(size=(D, n))
+    alpha = rng.normal(size=(D, n))
+    tq = np.sort(np.concatenate([rng.uniform(-3, 33, m - 3), t[[0, 40, n - 1]]]))      # outside the data, and ON data points
+    terms = [rand_terms(rng, n_real, n_complex) for _ in range(D)]
+    real = np.ascontiguousarray(np.stack([np.stack([c[0], c[1]], -1) for c in terms]).reshape(D, n_real, 2))
+    cplx = np.ascontiguousarray(np.stack([np.stack([c[2], c[3], c[4], c[5]], -1) for c in terms]).reshape(D, n_complex, 4))
+    z = np.empty((D, n))
+    mu = np.empty((D, m))
+    i64 = ctypes.c_int64
+    assert harness.harness_gp_dot_tril(_p(t), _p(diag), i64(D), i64(n), _p(real), n_real, _p(cplx), n_complex, None, i64(D),
+                                       _p(np.ascontiguousarray(x)), _p(z)) == 0
+    assert harness.harness_gp_predict(_p(t), i64(n), _p(np.ascontiguousarray(alpha)), _p(real), n_real, _p(cplx), n_complex,
+                                      None, i64(D), _p(np.ascontiguousarray(tq)), i64(m), _p(mu)) == 0
+    for d in range(D):
+        K = _kernel(t[:, None] - t[None, :], terms[d]) + np.diag(diag[d])
+        L = np.linalg.cholesky(K)
+        np.testing.assert_allclose(z[d], L @ x[d], rtol=1e-9, atol=1e-11)
+        Ks = _kernel(tq[:, None] - t[None, :], terms[d])
+        np.testing.assert_allclose(mu[d], Ks @ alpha[d], rtol=1e-10, atol=1e-11)

@@ -187,3 +187,42 @@ def test_predict_and_apply_inverse_vs_dense(dev):
     np.testing.assert_allclose(gp.predict(T(y, dev), t=T(ts, dev)).cpu().numpy(), 1.0 + Ks @ alpha, rtol=1e-8, atol=1e-9)
     np.testing.assert_allclose(gp.predict(T(y, dev), t=T(ts, dev), include_mean=False).cpu().numpy(), Ks @ alpha,
                                rtol=1e-8, atol=1e-9)
+
+
+def test_dot_tril_sample_and_predict_batch(dev):
+    """GaussianProcess.dot_tril (= L x, K + diag = L L^T) against the dense Cholesky factor for a batch of
+    draws that straddles Q = 1/2, O(N + M) predict at new times against the dense kernel product, and the
+    shapes / reproducibility of sample()"""
+    import exoplanet_amd as xo
+    from exoplanet_amd.gp import terms
+
+    rng = np.random.default_rng(23)
+    N, D = 400, 3
+    t = np.sort(rng.uniform(0, 30, N))
+    Qs, rhos, sig = np.array([0.3, 0.9, 4.0]), np.array([3.0, 5.0, 2.0]), 0.7
+    kernel = terms.SHOTerm(sigma=T(np.full(D, sig), dev), rho=T(rhos, dev), Q=T(Qs, dev))
+    gp = xo.gp.GaussianProcess(kernel, t=T(t, dev), yerr=0.3)
+    x = rng.normal(size=(D, N))
+    z = gp.dot_tril(T(x, dev)).cpu().numpy()
+    y = rng.normal(size=N)
+    ts = np.sort(rng.uniform(-2, 32, 211))
+    mu = gp.predict(T(y, dev), t=T(ts, dev)).cpu().numpy()
+    for d in range(D):
+        co = P.sho_coefficients(*P.sho_from_sigma_rho(sig, rhos[d], Qs[d]), Qs[d])
+        K = P.celerite_kernel(t[:, None] - t[None, :], *co) + 0.09 * np.eye(N)
+        np.testing.assert_allclose(z[d], np.linalg.cholesky(K) @ x[d], rtol=1e-8, atol=1e-10)
+        alpha = np.linalg.solve(K, y)
+        np.testing.assert_allclose(mu[d], P.celerite_kernel(ts[:, None] - t[None, :], *co) @ alpha, rtol=1e-7, atol=1e-9)
+    g = torch.Generator(device=dev).manual_seed(5)
+    s1 = gp.sample(size=4, generator=g)
+    g.manual_seed(5)
+    s2 = gp.sample(size=4, generator=g)
+    assert s1.shape == (4, D, N) and torch.equal(s1, s2) and bool(torch.isfinite(s1).all())
+    # sample covariance of many prior draws ~ K (one draw of the batch, a few lags)
+    g.manual_seed(6)
+    big = gp.sample(size=2000, generator=g)[:, 1].cpu().numpy()
+    co = P.sho_coefficients(*P.sho_from_sigma_rho(sig, rhos[1], Qs[1]), Qs[1])
+    for lag in (0, 3, 10):
+        emp = np.mean(big[:, 100] * big[:, 100 + lag])
+        want = P.celerite_kernel(np.array([t[100 + lag] - t[100]]), *co)[0] + (0.09 if lag == 0 else 0.0)
+        assert abs(emp - want) < 5 * np.sqrt(2.0 / 2000) * (sig**2 + 0.09)      # five standard errors
