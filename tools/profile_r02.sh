@@ -1,0 +1,45 @@
+#!/bin/bash
+# Round-2 measurement record for profiles/: un-profiled bench line, rocprofv3 kernel stats of the same
+# command (eager launches so that every kernel is a dispatch), and the HBM traffic of the sweep from two
+# SEPARATE PMC passes (FETCH_SIZE, WRITE_SIZE; --pmc only with --kernel-trace, as gpurun requires).
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+tag=${1:-r02_record}
+out=$R/gpurun_out/$tag
+mkdir -p $out
+cd /tmp && export TMPDIR=/tmp
+CMD="python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extras --no-stats --no-graph"
+python $R/bench.py --steps 20 --warmup 5 > $out/bench.json 2> $out/bench.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o p -- $CMD > $out/bench_traced.json 2> $out/bench_traced.err
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/pmc_fetch -o fetch -- $CMD > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/pmc_write -o write -- $CMD > /dev/null 2>&1
+python - <<PY
+import csv, glob, json, collections
+out = "$out"
+res = {"source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes (each with --kernel-trace), "
+                 "bench.py --steps 20 --warmup 3 --no-graph --no-extras --draws-per-gpu 1024; KiB per dispatch, mean",
+       "draws": 1024, "n_cad": 150000, "kernels": {},
+       "correction": "gfx950: FETCH_SIZE counts half the bytes of a wide coalesced read stream -> traffic = "
+                     "(2*fetch + write) KiB (MI355X_MICROARCH.md, HBM section)"}
+for sub, name, cname, key in (("pmc_fetch", "fetch", "FETCH_SIZE", "fetch_kib"), ("pmc_write", "write", "WRITE_SIZE", "write_kib")):
+    fs = glob.glob(f"{out}/{sub}/**/*counter_collection.csv", recursive=True)
+    agg = collections.defaultdict(list)
+    for f in fs:
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] == cname and "transit" in r["Kernel_Name"]:
+                k = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("(anonymous namespace)::", "").strip()
+                agg[k].append(float(r["Counter_Value"]))
+    for k, v in agg.items():
+        res["kernels"].setdefault(k, {})[key] = sum(v) / len(v)
+        res["kernels"][k]["dispatches_" + name] = len(v)
+for k in res["kernels"].values():
+    k.setdefault("fetch_kib", 0.0); k.setdefault("write_kib", 0.0)
+json.dump(res, open(f"{out}/pmc.json", "w"), indent=1)
+print(json.dumps(res["kernels"], indent=1))
+f = glob.glob(f"{out}/trace/**/*kernel_stats.csv", recursive=True)
+rows = list(csv.DictReader(open(f[0])))
+lines = ["%-86s %6s %10s %8s" % ("kernel", "calls", "avg_us", "pct")]
+for r in rows[:14]:
+    lines.append("%-86s %6s %10.1f %8.2f" % (r["Name"][:86], r["Calls"], float(r["AverageNs"]) / 1e3, float(r["Percentage"])))
+open(f"{out}/kernel_stats.txt", "w").write("\n".join(lines) + "\n")
+print("\n".join(lines))
+PY
