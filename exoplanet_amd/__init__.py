@@ -3,7 +3,7 @@ exoplanet-dev/exoplanet (Kepler solve -> limb-darkened transit flux -> celerite
 GP log-likelihood, value + gradient), as HIP kernels behind the reference's own
 operator interface.  See DESIGN.md."""
 from . import ops  # noqa: F401
-from . import orbits, light_curves, gp, graph  # noqa: F401
+from . import orbits, light_curves, gp, graph, sampling  # noqa: F401
 from .light_curves import LimbDarkLightCurve, SecondaryEclipseLightCurve  # noqa: F401
 from .orbits import KeplerianOrbit  # noqa: F401
 from .graph import GraphedStep  # noqa: F401

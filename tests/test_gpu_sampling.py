@@ -1,0 +1,55 @@
+"""GPU: the HMC driver on the real hot path -- C2-like transit likelihood of a batch of chains --
+with the leapfrog trajectory replayed as one hipGraph: graph replay == eager trajectory, and the
+chains move towards the parameters the data were generated with."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_hmc_on_the_transit_likelihood_graph_vs_eager(dev):
+    import exoplanet_amd as xo
+    from exoplanet_amd.sampling import HMC
+
+    rng = np.random.default_rng(51)
+    N, D = 8000, 16
+    t = torch.arange(N, dtype=torch.float64, device=dev) * (2.0 / 1440.0)
+    truth = dict(period=3.5, t0=1.0, b=0.3, r=0.1)
+    with torch.no_grad():
+        f0 = xo.LimbDarkLightCurve(0.3, 0.2).get_light_curve(
+            orbit=xo.KeplerianOrbit(period=torch.tensor(truth["period"], device=dev, dtype=torch.float64),
+                                    t0=torch.tensor(truth["t0"], device=dev, dtype=torch.float64),
+                                    b=torch.tensor(truth["b"], device=dev, dtype=torch.float64)),
+            r=torch.tensor(truth["r"], device=dev, dtype=torch.float64), t=t)[:, 0]
+    sigma = 5e-4
+    y = f0 + sigma * torch.as_tensor(rng.normal(size=N), device=dev)
+
+    def logp(t0, r):          # (D, 1) each: white-noise likelihood of every chain's light curve
+        orbit = xo.KeplerianOrbit(period=3.5, t0=t0, b=0.3)
+        f = xo.LimbDarkLightCurve(0.3, 0.2).get_light_curve(orbit=orbit, r=r, t=t).sum(-1)
+        return -0.5 * (((y - f) / sigma) ** 2).sum(-1)
+
+    def start():
+        g = np.random.default_rng(52)
+        return [torch.tensor(1.0 + 2e-3 * g.normal(size=(D, 1)), dtype=torch.float64, device=dev),
+                torch.tensor(0.1 * (1 + 0.05 * g.normal(size=(D, 1))), dtype=torch.float64, device=dev)]
+
+    mass = [1.0 / (2e-4) ** 2, 1.0 / (5e-4) ** 2]
+    out = {}
+    for mode in (True, False):
+        gen = torch.Generator(device=dev).manual_seed(9)
+        hmc = HMC(logp, start(), step_size=0.25, n_leapfrog=4, mass=mass, graph=mode, generator=gen)
+        assert (hmc._graph is not None) == mode
+        lp_first = None
+        for it in range(25):
+            hmc.step()
+            if it == 0:
+                lp_first = hmc.last_logp.clone()
+        out[mode] = (hmc.params[0].clone(), hmc.params[1].clone(), hmc.last_logp.clone(), hmc.accept_rate().clone(), lp_first)
+    for a, b in zip(out[True], out[False]):
+        assert torch.allclose(a, b, rtol=1e-9, atol=1e-12)
+    t0s, rs, lp, rate, lp_first = out[True]
+    assert float(rate.mean()) > 0.5
+    assert float(lp.mean()) > float(lp_first.mean())                     # the chains climb
+    assert abs(float(t0s.mean()) - truth["t0"]) < 1e-3 and abs(float(rs.mean()) - truth["r"]) < 8e-3
