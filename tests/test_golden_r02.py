@@ -1,0 +1,66 @@
+"""CPU: the round-2 fixtures (oracle/make_golden_r02.py) against the oracle's ports and the
+host-compiled one-lane GP pipeline.
+
+  lightcurves_mp.npz  end-to-end mpmath light curves of the BASELINE C4 (4 planets, per-planet flux)
+                      and C5 (long cadence, 7 sub-exposures, transit + occultation) systems -- from
+                      oracle/mp_lightcurve.py, which shares no code with the numpy / C ports;
+  gp_large.npz        long-double dense-Cholesky log-likelihood and gradients at N = 500 and 2000."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+from oracle import c_port as C
+from oracle import numpy_port as P
+from oracle.make_golden_r02 import C4, C5
+from test_gp_host import harness, run  # noqa: F401  (fixture + driver of the host-compiled pipeline)
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_c4_c5_light_curves_numpy_port_vs_mpmath():
+    g = np.load(os.path.join(GOLD, "lightcurves_mp.npz"))
+    t, want = g["c4_t"], g["c4_flux"]
+    assert want.shape == (2048, 4) and np.all(want.min(0) < -5e-4)        # every planet transits in its stretch
+    orbit = P.KeplerianOrbit(period=np.array(C4["period"]), t0=np.array(C4["t0"]), b=np.array(C4["b"]),
+                             ecc=np.array(C4["ecc"]), omega=np.array(C4["omega"]))
+    for uit in (None, False):
+        got = P.LimbDarkLightCurve(*C4["u"]).get_light_curve(orbit=orbit, r=np.array(C4["r"]), t=t, use_in_transit=uit)
+        np.testing.assert_allclose(got, want, rtol=0, atol=2e-15)
+    t5, want5 = g["c5_t"], g["c5_flux"]
+    assert want5.min() < -5e-3 and np.sum((want5 < -1e-5) & (want5 > -1e-3)) > 20     # transits and occultations
+    o5 = P.KeplerianOrbit(period=C5["period"], t0=C5["t0"], b=C5["b"], ecc=C5["ecc"], omega=C5["omega"])
+    got5 = P.SecondaryEclipseLightCurve(C5["u_p"], C5["u_s"], C5["sbr"]).get_light_curve(
+        orbit=o5, r=C5["r"], t=t5, texp=C5["texp"], oversample=C5["oversample"], order=C5["order"])
+    np.testing.assert_allclose(got5[:, 0], want5, rtol=0, atol=2e-15)
+
+
+@pytest.mark.parametrize("key", ["n500_q03", "n500_q07", "n500_q3", "n2000_q07"])
+def test_gp_large_ports_vs_long_double(key):
+    g = np.load(os.path.join(GOLD, "gp_large.npz"))
+    co = tuple(g[f"{key}_{nm}"] for nm in ("ar", "cr", "ac", "bc", "cc", "dc"))
+    t, y, diag, want = g[f"{key}_t"], g[f"{key}_y"], g[f"{key}_diag"], float(g[f"{key}_loglike"])
+    assert abs(P.celerite_loglike(t, y, diag, co) - want) <= 2e-13 * abs(want)
+    ll, gr = C.celerite(t, y, diag, co, grad=True)
+    assert abs(ll - want) <= 2e-13 * abs(want)
+    np.testing.assert_allclose(gr["y"], g[f"{key}_gy"], rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(gr["diag"], g[f"{key}_gdiag"], rtol=1e-8, atol=1e-10)
+    for nm in ("ar", "cr", "ac", "bc", "cc", "dc"):
+        if co[("ar", "cr", "ac", "bc", "cc", "dc").index(nm)].size:
+            np.testing.assert_allclose(gr[nm], g[f"{key}_g{nm}"], rtol=2e-8, atol=1e-9)
+
+
+@pytest.mark.parametrize("key", ["n500_q07", "n500_q3", "n2000_q07"])
+def test_gp_large_host_compiled_lane_pipeline(harness, key):  # noqa: F811
+    """the time-parallel, checkpointed one-lane pipeline (the code the GPU runs) at N = 500 / 2000"""
+    g = np.load(os.path.join(GOLD, "gp_large.npz"))
+    t, y, diag, want = g[f"{key}_t"], g[f"{key}_y"], g[f"{key}_diag"], float(g[f"{key}_loglike"])
+    cplx = np.stack([g[f"{key}_{nm}"] for nm in ("ac", "bc", "cc", "dc")], -1)[None]
+    ll, flags, C_used, gr = run(harness, t, y[None], diag[None], np.zeros((1, 0, 2)), cplx, gll=np.ones(1))
+    assert flags[0] == 0 and C_used >= 8
+    assert abs(ll[0] - want) <= 2e-13 * abs(want)
+    np.testing.assert_allclose(gr["y"][0], g[f"{key}_gy"], rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(gr["diag"][0], g[f"{key}_gdiag"], rtol=1e-8, atol=1e-9)
+    for q, nm in enumerate(("ac", "bc", "cc", "dc")):
+        np.testing.assert_allclose(gr["cplx"][0, 0, q], g[f"{key}_g{nm}"][0], rtol=5e-8)

@@ -70,3 +70,50 @@ def test_gp_golden(dev):
         ll = celerite_loglike(T(g[f"{tag}_t"], dev), T(g[f"{tag}_y"][None], dev), T(g[f"{tag}_diag"][None], dev),
                               T(real, dev), T(cplx, dev))
         assert abs(ll.item() - float(g[f"{tag}_loglike"])) < 1e-12 * abs(float(g[f"{tag}_loglike"]))
+
+
+def test_c4_c5_light_curves_vs_mpmath_end_to_end(dev):
+    """BASELINE C4 (4 planets, per-planet flux) and C5 (7 sub-exposures, transit + occultation) at 2048
+    cadences against fixtures generated END TO END in mpmath (oracle/mp_lightcurve.py: the reference's
+    formulas restated directly, no code shared with the numpy / C ports or the kernels)"""
+    import exoplanet_amd as xo
+    from oracle.make_golden_r02 import C4, C5
+
+    g = np.load(os.path.join(GOLD, "lightcurves_mp.npz"))
+    orbit = xo.KeplerianOrbit(period=T(C4["period"], dev), t0=T(C4["t0"], dev), b=T(C4["b"], dev), ecc=T(C4["ecc"], dev),
+                              omega=T(C4["omega"], dev))
+    for uit in (None, False):
+        got = xo.LimbDarkLightCurve(*C4["u"]).get_light_curve(orbit=orbit, r=T(C4["r"], dev), t=T(g["c4_t"], dev),
+                                                              use_in_transit=uit)
+        np.testing.assert_allclose(got.cpu().numpy(), g["c4_flux"], rtol=0, atol=1e-13)
+    o5 = xo.KeplerianOrbit(period=C5["period"], t0=C5["t0"], b=C5["b"], ecc=C5["ecc"], omega=C5["omega"])
+    for uit in (None, False):
+        got5 = xo.SecondaryEclipseLightCurve(C5["u_p"], C5["u_s"], C5["sbr"]).get_light_curve(
+            orbit=o5, r=C5["r"], t=T(g["c5_t"], dev), texp=C5["texp"], oversample=C5["oversample"], order=C5["order"],
+            use_in_transit=uit)
+        np.testing.assert_allclose(got5.cpu().numpy()[:, 0], g["c5_flux"], rtol=0, atol=1e-13)
+
+
+@pytest.mark.parametrize("key", ["n500_q03", "n500_q07", "n500_q3", "n2000_q07"])
+def test_gp_large_golden(dev, key):
+    """log-likelihood AND gradients at N = 500 / 2000 against long-double dense Cholesky"""
+    from exoplanet_amd.gp import celerite_loglike
+
+    g = np.load(os.path.join(GOLD, "gp_large.npz"))
+    real = np.stack([g[f"{key}_ar"], g[f"{key}_cr"]], -1)[None]
+    cplx = np.stack([g[f"{key}_ac"], g[f"{key}_bc"], g[f"{key}_cc"], g[f"{key}_dc"]], -1)[None]
+    want = float(g[f"{key}_loglike"])
+    for n_chunks in (None, 1):
+        yt, dt = T(g[f"{key}_y"][None], dev).requires_grad_(True), T(g[f"{key}_diag"][None], dev).requires_grad_(True)
+        rt, ct = T(real, dev).requires_grad_(True), T(cplx, dev).requires_grad_(True)
+        ll = celerite_loglike(T(g[f"{key}_t"], dev), yt, dt, rt, ct, n_chunks=n_chunks)
+        assert abs(ll.item() - want) <= 2e-12 * abs(want)
+        ll.sum().backward()
+        np.testing.assert_allclose(yt.grad.cpu().numpy()[0], g[f"{key}_gy"], rtol=1e-7, atol=1e-9)
+        np.testing.assert_allclose(dt.grad.cpu().numpy()[0], g[f"{key}_gdiag"], rtol=1e-7, atol=1e-8)
+        for q, nm in enumerate(("ar", "cr")):
+            if real.shape[1]:
+                np.testing.assert_allclose(rt.grad.cpu().numpy()[0, :, q], g[f"{key}_g{nm}"], rtol=1e-6, atol=1e-8)
+        for q, nm in enumerate(("ac", "bc", "cc", "dc")):
+            if cplx.shape[1]:
+                np.testing.assert_allclose(ct.grad.cpu().numpy()[0, :, q], g[f"{key}_g{nm}"], rtol=1e-6, atol=1e-8)
