@@ -670,14 +670,15 @@ struct LaneDelta {
 template <int J>
 __global__ __launch_bounds__(kWave) void celerite_elem_lg_kernel(
     const double* __restrict__ t, Series rs, const double* __restrict__ diag, int64_t n_diag,
-    int64_t n, Coefs cf, int64_t n_draw, double* __restrict__ state, ChunkGeom cg) {
+    int64_t n, Coefs cf, int64_t n_draw, double* __restrict__ state, ChunkGeom cg, int64_t flag_at) {
   constexpr int G = Group<J>::G;
   const int j = threadIdx.x & (G - 1);
   const int64_t lane_draw = ((int64_t)blockIdx.x * kWave + threadIdx.x) / G;
   const bool live_draw = lane_draw < n_draw;
   const int64_t draw = live_draw ? lane_draw : n_draw - 1;
   const int c = blockIdx.y;
-  const int64_t n0 = c * cg.L, n1 = (n0 + cg.L < n) ? n0 + cg.L : n;
+  const bool empty = c * cg.L >= n;   // a fine chunk past the end of the series: the identity element
+  const int64_t n0 = empty ? n - 1 : c * cg.L, n1 = empty ? n0 : ((n0 + cg.L < n) ? n0 + cg.L : n);
   const LaneCoef k = lane_coef(cf, draw, j, J);
   const bool live = k.live;
   const ChunkWs ws = chunk_ws(n, n_draw, J, cg);
@@ -749,7 +750,7 @@ __global__ __launch_bounds__(kWave) void celerite_elem_lg_kernel(
     }
   }
   if (!live_draw || !live) return;
-  if (!ok && j == 0) state[ws.off_flag() + draw] = 1.0;
+  if (!ok && j == 0) state[(flag_at >= 0 ? flag_at : ws.off_flag()) + draw] = 1.0;
   const int E1 = J * J, E2 = J * J + J, E3 = 2 * J * J + J, E4 = 2 * J * J + 2 * J;
 #pragma unroll
   for (int l = 0; l < J; ++l) {
@@ -1148,6 +1149,130 @@ __global__ __launch_bounds__(kWave) void celerite_chunk_vjp_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------
+// Composition of two consecutive filtering elements (Sarkka & Garcia-Fernandez 2021, Lemma 8; el1
+// first):  with M = I + C1 J2,  X1 = M^-1 A1,  x2 = M^-1 (b1 + C1 eta2),  X3 = M^-1 C1,  N = I - J2 X3
+//     A = A2 X1        b = A2 x2 + b2        C = A2 X3 A2^T + C2
+//     eta = A1^T N (eta2 - J2 b1) + eta1     J = A1^T N J2 A1 + J1
+// (checked in numpy against the element of the joined run, tools / DESIGN.md 3.5).  The slow element
+// kernel is run on chunks 2^fine times shorter -- that many times more lanes -- and the elements are
+// composed pairwise back up.  One wave per (draw, pair): the matrices live in LDS padded to 8 x 8 and
+// lane (j, l) owns entry (j, l) of every product; Gauss-Jordan with partial pivoting for the solve.
+// ---------------------------------------------------------------------------------------------
+struct ComposeLds {
+  double m[13][64];   // A1 C1 J1 A2 C2 J2 M R1 R3 T T2 T3 tmp
+  double v[8][8];     // b1 eta1 b2 eta2 r2 v w tmp
+};
+__global__ __launch_bounds__(256) void celerite_compose_kernel(int J, int64_t n_draw, double* __restrict__ state,
+                                                               int64_t src_base, int C_src, int64_t dst_base, int C_dst) {
+  __shared__ ComposeLds lds[4];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane >> 3, l = lane & 7;
+  const int64_t item = (int64_t)blockIdx.x * 4 + wave;          // (pair, draw), draws fastest
+  const bool live_item = item < (int64_t)C_dst * n_draw;
+  const int64_t it = live_item ? item : 0;
+  const int c = (int)(it / n_draw);
+  const int64_t draw = it - (int64_t)c * n_draw;
+  ComposeLds& S = lds[wave];
+  enum { A1 = 0, C1, J1, A2, C2, J2, MM, R1, R3, TT, T2, T3, TMP };
+  enum { B1 = 0, E1, B2, E2, RR2, VV, WW, VT };
+  const int E = 3 * J * J + 2 * J, oA = 0, ob = J * J, oC = J * J + J, oeta = 2 * J * J + J, oJ = 2 * J * J + 2 * J;
+  const bool in = j < J && l < J;
+  auto src = [&](int cc, int e) -> double { return state[src_base + ((int64_t)cc * E + e) * n_draw + draw]; };
+  // load: a missing second element (odd count) is the identity
+  const int c1 = 2 * c, c2 = 2 * c + 1;
+  const bool has2 = c2 < C_src;
+  S.m[A1][lane] = in ? src(c1, oA + j * J + l) : 0.0;
+  S.m[C1][lane] = in ? src(c1, oC + j * J + l) : 0.0;
+  S.m[J1][lane] = in ? src(c1, oJ + j * J + l) : 0.0;
+  S.m[A2][lane] = in ? (has2 ? src(c2, oA + j * J + l) : (j == l ? 1.0 : 0.0)) : 0.0;
+  S.m[C2][lane] = (in && has2) ? src(c2, oC + j * J + l) : 0.0;
+  S.m[J2][lane] = (in && has2) ? src(c2, oJ + j * J + l) : 0.0;
+  if (l == 0) {
+    S.v[B1][j] = j < J ? src(c1, ob + j) : 0.0;
+    S.v[E1][j] = j < J ? src(c1, oeta + j) : 0.0;
+    S.v[B2][j] = (j < J && has2) ? src(c2, ob + j) : 0.0;
+    S.v[E2][j] = (j < J && has2) ? src(c2, oeta + j) : 0.0;
+  }
+  __syncthreads();
+  // dst[j][l] = sum_k X[j][k] Y[k][l]  (transposes by index)
+  auto mm = [&](int X, bool tx, int Y, bool ty) -> double {
+    double acc = 0.0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc = fma(tx ? S.m[X][k * 8 + j] : S.m[X][j * 8 + k], ty ? S.m[Y][l * 8 + k] : S.m[Y][k * 8 + l], acc);
+    return acc;
+  };
+  auto mv = [&](int X, bool tx, int V) -> double {   // (X v)_j, computed by every lane of row j
+    double acc = 0.0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc = fma(tx ? S.m[X][k * 8 + j] : S.m[X][j * 8 + k], S.v[V][k], acc);
+    return acc;
+  };
+  // M = I + C1 J2 ;  right-hand sides R1 = A1, r2 = b1 + C1 eta2, R3 = C1
+  {
+    const double m = mm(C1, false, J2, false) + (j == l ? 1.0 : 0.0);
+    const double r2 = S.v[B1][j] + mv(C1, false, E2);
+    S.m[MM][lane] = m;
+    S.m[R1][lane] = S.m[A1][lane];
+    S.m[R3][lane] = S.m[C1][lane];
+    if (l == 0) S.v[RR2][j] = r2;
+  }
+  __syncthreads();
+  // Gauss-Jordan with partial pivoting (padded rows / columns are the identity: never chosen, never changed)
+  for (int k = 0; k < J; ++k) {
+    int piv = k;
+    double best = fabs(S.m[MM][k * 8 + k]);
+    for (int i = k + 1; i < J; ++i) {
+      const double a = fabs(S.m[MM][i * 8 + k]);
+      if (a > best) { best = a; piv = i; }
+    }
+    // swap rows k and piv
+    const int srcrow = j == k ? piv : (j == piv ? k : j);
+    const double m0 = S.m[MM][srcrow * 8 + l], a0 = S.m[R1][srcrow * 8 + l], c0 = S.m[R3][srcrow * 8 + l];
+    const double r0 = S.v[RR2][srcrow];
+    __syncthreads();
+    S.m[MM][lane] = m0; S.m[R1][lane] = a0; S.m[R3][lane] = c0;
+    if (l == 0) S.v[RR2][j] = r0;
+    __syncthreads();
+    const double ip = 1.0 / S.m[MM][k * 8 + k];
+    const double f = j == k ? 0.0 : S.m[MM][j * 8 + k];                 // multiple of (scaled) row k taken off row j
+    const double mk = S.m[MM][k * 8 + l] * ip, ak = S.m[R1][k * 8 + l] * ip, ck = S.m[R3][k * 8 + l] * ip;
+    const double rk = S.v[RR2][k] * ip;
+    const double mj = S.m[MM][lane], aj = S.m[R1][lane], cj = S.m[R3][lane], rj = S.v[RR2][j];
+    __syncthreads();
+    S.m[MM][lane] = j == k ? mk : fma(-f, mk, mj);
+    S.m[R1][lane] = j == k ? ak : fma(-f, ak, aj);
+    S.m[R3][lane] = j == k ? ck : fma(-f, ck, cj);
+    if (l == 0) S.v[RR2][j] = j == k ? rk : fma(-f, rk, rj);
+    __syncthreads();
+  }
+  // now R1 = X1, r2 = x2, R3 = X3
+  const double A_new = mm(A2, false, R1, false);
+  const double b_new = mv(A2, false, RR2) + S.v[B2][j];
+  S.m[TT][lane] = mm(A2, false, R3, false);                 // A2 X3
+  S.m[T2][lane] = (j == l ? 1.0 : 0.0) - mm(J2, false, R3, false);   // N = I - J2 X3
+  if (l == 0) S.v[VV][j] = S.v[E2][j] - mv(J2, false, B1);  // eta2 - J2 b1
+  __syncthreads();
+  const double C_new = mm(TT, false, A2, true) + S.m[C2][lane];
+  S.m[T3][lane] = mm(T2, false, J2, false);                 // N J2
+  if (l == 0) S.v[WW][j] = mv(T2, false, VV);               // N (eta2 - J2 b1)
+  __syncthreads();
+  S.m[TMP][lane] = mm(T3, false, A1, false);                // N J2 A1
+  const double eta_new = mv(A1, true, WW) + S.v[E1][j];
+  __syncthreads();
+  const double J_new = mm(A1, true, TMP, false) + S.m[J1][lane];
+  // symmetrise C and J through LDS
+  S.m[TT][lane] = C_new;
+  S.m[T2][lane] = J_new;
+  __syncthreads();
+  if (live_item && in) {
+    auto dst = [&](int e) -> double& { return state[dst_base + ((int64_t)c * E + e) * n_draw + draw]; };
+    dst(oA + j * J + l) = A_new;
+    dst(oC + j * J + l) = 0.5 * (C_new + S.m[TT][l * 8 + j]);
+    dst(oJ + j * J + l) = 0.5 * (J_new + S.m[T2][l * 8 + j]);
+    if (l == 0) { dst(ob + j) = b_new; dst(oeta + j) = eta_new; }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // One lane per draw / per (draw, chunk): thin wrappers over exo_celerite_core.hpp (the same
 // functions the host harness of tests/ runs lane by lane).  Lanes of a wave are consecutive draws,
 // the chunk is blockIdx.y: every access to the chunk workspace and to the checkpoints is coalesced.
@@ -1162,11 +1287,11 @@ template <int J, int NR>
 __global__ __launch_bounds__(kWave) void celerite_elem_kernel(const double* __restrict__ t, Series rs,
                                                               const double* __restrict__ diag, int64_t n_diag, int64_t n,
                                                               Coefs cf, int64_t n_draw, double* __restrict__ state,
-                                                              ChunkGeom cg) {
+                                                              ChunkGeom cg, int64_t flag_at) {
   const int64_t draw = (int64_t)blockIdx.x * kWave + threadIdx.x;
   if (draw >= n_draw) return;
   if (layout_vote<J>(cf, draw) != NR) return;
-  elem_lane<J, NR>(t, rs, diag, n_diag, n, cf, n_draw, state, cg, draw, (int)blockIdx.y);
+  elem_lane<J, NR>(t, rs, diag, n_diag, n, cf, n_draw, state, cg, draw, (int)blockIdx.y, flag_at);
 }
 
 // (B) the state entering every chunk: C - 1 element applications per draw
@@ -1382,12 +1507,24 @@ static int celerite_fwd(const double* t, Series resid, const double* diag, int64
 #ifndef EXO_ELEM_LG_MIN_J
 #define EXO_ELEM_LG_MIN_J 7
 #endif
+      // the elements are built at the finest level (ChunkGeom::fine: 2^fine times more, shorter chunks) and
+      // composed pairwise up to the chunks the scans and the chunk kernels work on
+      const ChunkGeom cge = cg.fine ? fine_geom(n, n_draw, J, cg, cg.fine) : cg;
+      const int64_t flag_at = ws.off_flag();
+      const dim3 egrid_f(per_draw.x, (unsigned)cge.C), cgrid_f(grid.x, (unsigned)cge.C);
       if (J >= EXO_ELEM_LG_MIN_J) {   // the one-lane element kernel is as fast up to J = 6 and does not fit beyond
-        EXO_GP_DISPATCH(J, hipLaunchKernelGGL((celerite_elem_lg_kernel<JJ>), cgrid, block, 0, st, t, resid, diag, n_diag,
-                                              n, cf, n_draw, state, cg))
+        EXO_GP_DISPATCH(J, hipLaunchKernelGGL((celerite_elem_lg_kernel<JJ>), cgrid_f, block, 0, st, t, resid, diag, n_diag,
+                                              n, cf, n_draw, state, cge, flag_at))
       } else {
-        EXO_GP_LAYOUTS(J, cf, hipLaunchKernelGGL((celerite_elem_kernel<JJ, NR>), egrid, block, 0, st, t, resid, diag, n_diag,
-                                                 n, cf, n_draw, state, cg))
+        EXO_GP_LAYOUTS(J, cf, hipLaunchKernelGGL((celerite_elem_kernel<JJ, NR>), egrid_f, block, 0, st, t, resid, diag,
+                                                 n_diag, n, cf, n_draw, state, cge, flag_at))
+      }
+      for (int f = cg.fine; f >= 1; --f) {
+        const int C_src = cg.C << f, C_dst = cg.C << (f - 1);
+        const int64_t src_base = ws.off_fine(f), dst_base = f > 1 ? ws.off_fine(f - 1) : ws.elem(0, 0, 0);
+        const int64_t items = (int64_t)C_dst * n_draw;
+        hipLaunchKernelGGL(celerite_compose_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, st, J, n_draw, state,
+                           src_base, C_src, dst_base, C_dst);
       }
       // after the element kernel: it may flag more draws (measurement variance too small)
       hipLaunchKernelGGL(celerite_prep_flagged_kernel, dim3(8, (unsigned)n_draw), dim3(256), 0, st, t, n, cf, n_draw, J,

@@ -155,6 +155,8 @@ struct ChunkGeom {
   int64_t L;    // cadences per chunk (the last may be shorter); a multiple of kCkptB on the one-lane path
   int64_t base; // first double of the chunk workspace inside `state`
   int lane;     // 1: one-lane chunk kernels with a checkpointed factorisation; 0: lane-group kernels, full factorisation
+  int fine;     // levels of pairwise element composition: the elements are BUILT for C << fine chunks of L >> fine
+                // cadences (that many times more lanes for the element kernel) and composed back up (0: built directly)
 };
 
 // chunk workspace, all [chunk][quantity][draw] (a lane is a draw: coalesced)
@@ -184,7 +186,18 @@ struct ChunkWs {
   EXO_HDH int64_t off_ckpt() const { return off_flag() + n_draw; }
   // checkpoint of global block g (cadences [g kCkptB, (g + 1) kCkptB)): k < J: F_k; then packed S
   EXO_HDH int64_t ckpt(int64_t g, int k, int64_t draw) const { return off_ckpt() + (g * K() + k) * n_draw + draw; }
-  EXO_HDH int64_t total() const { return off_ckpt() + n_blk * K() * n_draw - base; }
+  // elements of the finer levels (ChunkGeom::fine): level f has C << f chunks; level `fine` is built, f = 0 is elem()
+  int fine;
+  EXO_HDH int64_t off_fine(int f) const {   // f = 1 .. fine
+    int64_t o = off_ckpt() + n_blk * K() * n_draw;
+    for (int g = fine; g > f; --g) o += ((int64_t)C << g) * E() * n_draw;
+    return o;
+  }
+  EXO_HDH int64_t total() const {
+    int64_t o = off_ckpt() + n_blk * K() * n_draw;
+    for (int g = 1; g <= fine; ++g) o += ((int64_t)C << g) * E() * n_draw;
+    return o - base;
+  }
 };
 
 // the series and the measurement variance of one block of four cadences [b0, b0 + 4) clipped to n1.
@@ -222,8 +235,9 @@ EXO_HDH int64_t seq_state_doubles(int64_t n, int64_t n_draw, int J) {
 
 // How a series is cut.  n_chunks = 0: the default plan; 1: sequential; > 1: forced.  A pure
 // function of its arguments: the forward and the reverse call of a pair compute the same plan.
+constexpr int kFineLevels = 2;   // J > 2: elements built for 4 x finer chunks, composed pairwise twice
 EXO_HDH ChunkGeom chunk_plan(int64_t n, int64_t n_draw, int J, int32_t n_chunks) {
-  ChunkGeom g{1, n, seq_state_doubles(n, n_draw, J), 0};
+  ChunkGeom g{1, n, seq_state_doubles(n, n_draw, J), 0, 0};
   if (J > kChunkMaxJ || J < 1 || n < 64) return g;
   const bool lane = J <= kLaneMaxJ;
   int64_t C;
@@ -245,14 +259,26 @@ EXO_HDH ChunkGeom chunk_plan(int64_t n, int64_t n_draw, int J, int32_t n_chunks)
   if (C < 2) return g;
   g.L = (n + C - 1) / C;
   if (lane) g.L = (g.L + kCkptB - 1) / kCkptB * kCkptB;
+  else g.L = (g.L + (1 << kFineLevels) - 1) >> kFineLevels << kFineLevels;   // whole fine chunks
   g.C = (int)((n + g.L - 1) / g.L);
   if (g.C < 2) { g.C = 1; g.L = n; return g; }
   g.lane = lane ? 1 : 0;
+  g.fine = lane ? 0 : kFineLevels;
   return g;
 }
 
 EXO_HDH ChunkWs chunk_ws(int64_t n, int64_t n_draw, int J, const ChunkGeom& g) {
-  return ChunkWs{n_draw, J, g.C, g.base, g.lane ? (n + kCkptB - 1) / kCkptB : 0};
+  return ChunkWs{n_draw, J, g.C, g.base, g.lane ? (n + kCkptB - 1) / kCkptB : 0, g.fine};
+}
+// the geometry the element kernels see when they build level f: C << f chunks of L >> f cadences, elem()
+// addressing that level's array; flags stay where the coarse geometry has them (flag_at)
+EXO_HDH ChunkGeom fine_geom(int64_t n, int64_t n_draw, int J, const ChunkGeom& g, int f) {
+  ChunkGeom q = g;
+  q.C = g.C << f;
+  q.L = g.L >> f;
+  q.base = chunk_ws(n, n_draw, J, g).off_fine(f);
+  q.fine = 0;
+  return q;
 }
 
 // symmetric J x J in packed upper-triangular storage
@@ -426,11 +452,14 @@ EXO_HD void with_layout(const Coefs& cf, int64_t draw, F&& f) {
 }
 
 // (A) the filtering element of one (draw, chunk)
+// (flag_at: where the draw flags live when cg is a fine geometry, -1: cg's own)
 template <int J, int NR = -1>
 EXO_HD void elem_lane(const double* EXO_RESTRICT t, Series rs, const double* EXO_RESTRICT diag, int64_t n_diag,
                       int64_t n, const Coefs& cf, int64_t n_draw, double* EXO_RESTRICT state, const ChunkGeom& cg,
-                      int64_t draw, int c) {
-  const int64_t n0 = c * cg.L, n1 = (n0 + cg.L < n) ? n0 + cg.L : n;
+                      int64_t draw, int c, int64_t flag_at = -1) {
+  // (a chunk past the end of the series -- fine chunks of a short last chunk -- has no cadence: the identity element)
+  const bool empty = c * cg.L >= n;
+  const int64_t n0 = empty ? n - 1 : c * cg.L, n1 = empty ? n0 : ((n0 + cg.L < n) ? n0 + cg.L : n);
   const ChunkWs ws = chunk_ws(n, n_draw, J, cg);
   DeltaCoef<J, NR> dc;
   dc.init(cf, draw);
@@ -530,7 +559,7 @@ EXO_HD void elem_lane(const double* EXO_RESTRICT t, Series rs, const double* EXO
    }
    cur = nxt;
   }
-  if (!ok) state[ws.off_flag() + draw] = 1.0;
+  if (!ok) state[(flag_at >= 0 ? flag_at : ws.off_flag()) + draw] = 1.0;
   int e = 0;
 #pragma unroll
   for (int j = 0; j < J; ++j)
