@@ -1,4 +1,5 @@
-"""PyTensor Ops over the exoplanet_amd kernels -- the object the reference imports as
+"""EXPERIMENTAL (never executed here: PyTensor is not in this image; not imported by the package).
+PyTensor Ops over the exoplanet_amd kernels -- the object the reference imports as
 ``exoplanet.compat.ops`` (``from exoplanet_core.pymc import ops``, compat.py:27,56).
 
 The reference touches exactly three callables on it:
