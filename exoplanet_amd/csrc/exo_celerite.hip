@@ -1149,48 +1149,94 @@ __global__ __launch_bounds__(kWave) void celerite_chunk_vjp_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------
-// Composition of two consecutive filtering elements (Sarkka & Garcia-Fernandez 2021, Lemma 8; el1
-// first):  with M = I + C1 J2,  X1 = M^-1 A1,  x2 = M^-1 (b1 + C1 eta2),  X3 = M^-1 C1,  N = I - J2 X3
+// Composition of two consecutive elements, and the scans over the chunks as trees of compositions.
+//
+// Filtering elements (Sarkka & Garcia-Fernandez 2021, Lemma 8; element 1 acts first):  with M = I + C1 J2,
+// X1 = M^-1 A1,  x2 = M^-1 (b1 + C1 eta2),  X3 = M^-1 C1,  N = I - J2 X3
 //     A = A2 X1        b = A2 x2 + b2        C = A2 X3 A2^T + C2
 //     eta = A1^T N (eta2 - J2 b1) + eta1     J = A1^T N J2 A1 + J1
-// (checked in numpy against the element of the joined run, tools / DESIGN.md 3.5).  The slow element
-// kernel is run on chunks 2^fine times shorter -- that many times more lanes -- and the elements are
-// composed pairwise back up.  One wave per (draw, pair): the matrices live in LDS padded to 8 x 8 and
-// lane (j, l) owns entry (j, l) of every product; Gauss-Jordan with partial pivoting for the solve.
+// A STATE (F, P) is the element (A = 0, b = F, C = P, eta = 0, J = 0): applying an element to a state is the same
+// composition, of which only b and C are kept.
+// Adjoint elements (badj_prep: Abar in the A slot, g in b, local Fbar in eta, local Pbar in C) act on an adjoint
+// state (Fbar, Pbar) as  Fbar' = lF + Abar^T Fbar,  Pbar' = lP + Abar^T Pbar Abar + sym(Abar^T Fbar g^T);  1 first:
+//     Abar = Abar1 Abar2    g = g2 + Abar2^T g1    lF = lF2 + Abar2^T lF1
+//     lP = lP2 + Abar2^T lP1 Abar2 + sym(Abar2^T lF1 g2^T)
+// and a state is the element (Abar = 0, g = 0, lF = Fbar, lP = Pbar).  (Both laws checked in numpy against the
+// element of the joined run / the chained maps before they went to the device.)
+//
+// Uses: (i) the slow element kernel is run on chunks 2^fine times shorter -- that many times more lanes -- and the
+// elements are composed pairwise back up; (ii) the scans (B), (B') as trees: positions p = 0 .. C - 1 (forward:
+// chunk p; adjoint: chunk C - 1 - p), element p takes the state at p to p + 1.  UP: level f + 1 element i = elements
+// 2i, 2i + 1 of level f composed, until one position is left, which holds the initial state; DOWN: state 2i of level
+// f = state i of level f + 1, state 2i + 1 = element 2i of level f applied to it.  2 log2 C short launches instead of
+// C dependent steps of one wave.
+// One wave per item (a block): the matrices live in LDS padded to 8 x 8 and lane (j, l) owns entry (j, l) of every
+// product; Gauss-Jordan with partial pivoting for the solve.
 // ---------------------------------------------------------------------------------------------
+struct TreeOp {
+  int J;
+  int64_t n_draw;
+  int64_t src_elem;    // elements read (UP: the pairs; DOWN: the child level's)
+  int src_n;           //   positions p >= src_n hold the identity
+  int src_rev;         //   position p is stored at index src_len - 1 - p (adjoint scan, level 0)
+  int src_len;
+  int64_t dst_elem;    // UP: elements written, [0, n_item)
+  int64_t par_state;   // DOWN: parent states, [0, n_item)
+  int64_t dst_state;   // DOWN: child states, positions [0, dst_n), stored like src (dst_rev, dst_len)
+  int dst_n, dst_rev, dst_len;
+  double psign;        // DOWN: the sign the matrix part of the child states is stored with
+  int n_item;
+};
 struct ComposeLds {
   double m[13][64];   // A1 C1 J1 A2 C2 J2 M R1 R3 T T2 T3 tmp
   double v[8][8];     // b1 eta1 b2 eta2 r2 v w tmp
 };
-__global__ __launch_bounds__(256) void celerite_compose_kernel(int J, int64_t n_draw, double* __restrict__ state,
-                                                               int64_t src_base, int C_src, int64_t dst_base, int C_dst) {
-  __shared__ ComposeLds lds[4];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane >> 3, l = lane & 7;
-  const int64_t item = (int64_t)blockIdx.x * 4 + wave;          // (pair, draw), draws fastest
-  const bool live_item = item < (int64_t)C_dst * n_draw;
-  const int64_t it = live_item ? item : 0;
-  const int c = (int)(it / n_draw);
-  const int64_t draw = it - (int64_t)c * n_draw;
-  ComposeLds& S = lds[wave];
+template <bool ADJ, bool DOWN>
+__global__ __launch_bounds__(kWave) void celerite_tree_kernel(TreeOp op, double* __restrict__ state) {
+  __shared__ ComposeLds S;
+  const int lane = threadIdx.x, j = lane >> 3, l = lane & 7;
+  const int64_t item = blockIdx.x;                       // (index, draw), draws fastest
+  const int J = op.J;
+  const int64_t n_draw = op.n_draw;
+  const int c = (int)(item / n_draw);
+  const int64_t draw = item - (int64_t)c * n_draw;
   enum { A1 = 0, C1, J1, A2, C2, J2, MM, R1, R3, TT, T2, T3, TMP };
   enum { B1 = 0, E1, B2, E2, RR2, VV, WW, VT };
-  const int E = 3 * J * J + 2 * J, oA = 0, ob = J * J, oC = J * J + J, oeta = 2 * J * J + J, oJ = 2 * J * J + 2 * J;
+  const int E = 3 * J * J + 2 * J, Bq = J + J * J;
+  const int oA = 0, ob = J * J, oC = J * J + J, oeta = 2 * J * J + J, oJ = 2 * J * J + 2 * J;
   const bool in = j < J && l < J;
-  auto src = [&](int cc, int e) -> double { return state[src_base + ((int64_t)cc * E + e) * n_draw + draw]; };
-  // load: a missing second element (odd count) is the identity
-  const int c1 = 2 * c, c2 = 2 * c + 1;
-  const bool has2 = c2 < C_src;
-  S.m[A1][lane] = in ? src(c1, oA + j * J + l) : 0.0;
-  S.m[C1][lane] = in ? src(c1, oC + j * J + l) : 0.0;
-  S.m[J1][lane] = in ? src(c1, oJ + j * J + l) : 0.0;
-  S.m[A2][lane] = in ? (has2 ? src(c2, oA + j * J + l) : (j == l ? 1.0 : 0.0)) : 0.0;
-  S.m[C2][lane] = (in && has2) ? src(c2, oC + j * J + l) : 0.0;
-  S.m[J2][lane] = (in && has2) ? src(c2, oJ + j * J + l) : 0.0;
+  auto src = [&](int pos, int e) -> double {
+    const int idx = op.src_rev ? op.src_len - 1 - pos : pos;
+    return state[op.src_elem + ((int64_t)idx * E + e) * n_draw + draw];
+  };
+  auto par = [&](int k) -> double { return state[op.par_state + ((int64_t)c * Bq + k) * n_draw + draw]; };
+  // ---- load: element 1 (or the parent state as an element), element 2; missing elements are the identity
+  const int p1 = DOWN ? -1 : 2 * c, p2 = DOWN ? 2 * c : 2 * c + 1;
+  const bool has1 = !DOWN && p1 < op.src_n, has2 = p2 < op.src_n;
+  const double idm = (j == l && in) ? 1.0 : 0.0;
+  if (DOWN) {
+    const double pm = in ? par(J + j * J + l) : 0.0;
+    S.m[A1][lane] = 0.0; S.m[C1][lane] = pm; S.m[J1][lane] = 0.0;
+    if (l == 0) {
+      const double pv = j < J ? par(j) : 0.0;
+      S.v[B1][j] = ADJ ? 0.0 : pv;
+      S.v[E1][j] = ADJ ? pv : 0.0;
+    }
+  } else {
+    S.m[A1][lane] = in ? (has1 ? src(p1, oA + j * J + l) : idm) : 0.0;
+    S.m[C1][lane] = (in && has1) ? src(p1, oC + j * J + l) : 0.0;
+    S.m[J1][lane] = (in && has1 && !ADJ) ? src(p1, oJ + j * J + l) : 0.0;
+    if (l == 0) {
+      S.v[B1][j] = (j < J && has1) ? src(p1, ob + j) : 0.0;
+      S.v[E1][j] = (j < J && has1) ? src(p1, oeta + j) : 0.0;
+    }
+  }
+  S.m[A2][lane] = in ? (has2 ? src(p2, oA + j * J + l) : idm) : 0.0;
+  S.m[C2][lane] = (in && has2) ? src(p2, oC + j * J + l) : 0.0;
+  S.m[J2][lane] = (in && has2 && !ADJ) ? src(p2, oJ + j * J + l) : 0.0;
   if (l == 0) {
-    S.v[B1][j] = j < J ? src(c1, ob + j) : 0.0;
-    S.v[E1][j] = j < J ? src(c1, oeta + j) : 0.0;
-    S.v[B2][j] = (j < J && has2) ? src(c2, ob + j) : 0.0;
-    S.v[E2][j] = (j < J && has2) ? src(c2, oeta + j) : 0.0;
+    S.v[B2][j] = (j < J && has2) ? src(p2, ob + j) : 0.0;
+    S.v[E2][j] = (j < J && has2) ? src(p2, oeta + j) : 0.0;
   }
   __syncthreads();
   // dst[j][l] = sum_k X[j][k] Y[k][l]  (transposes by index)
@@ -1206,70 +1252,114 @@ __global__ __launch_bounds__(256) void celerite_compose_kernel(int J, int64_t n_
     for (int k = 0; k < 8; ++k) acc = fma(tx ? S.m[X][k * 8 + j] : S.m[X][j * 8 + k], S.v[V][k], acc);
     return acc;
   };
-  // M = I + C1 J2 ;  right-hand sides R1 = A1, r2 = b1 + C1 eta2, R3 = C1
-  {
-    const double m = mm(C1, false, J2, false) + (j == l ? 1.0 : 0.0);
-    const double r2 = S.v[B1][j] + mv(C1, false, E2);
-    S.m[MM][lane] = m;
-    S.m[R1][lane] = S.m[A1][lane];
-    S.m[R3][lane] = S.m[C1][lane];
-    if (l == 0) S.v[RR2][j] = r2;
-  }
-  __syncthreads();
-  // Gauss-Jordan with partial pivoting (padded rows / columns are the identity: never chosen, never changed)
-  for (int k = 0; k < J; ++k) {
-    int piv = k;
-    double best = fabs(S.m[MM][k * 8 + k]);
-    for (int i = k + 1; i < J; ++i) {
-      const double a = fabs(S.m[MM][i * 8 + k]);
-      if (a > best) { best = a; piv = i; }
+  // (DOWN: element 1 is a state -- A1 = 0, J1 = 0 and, forward, eta1 = 0 -- and only the state part of the result
+  // is kept: the products that feed nothing else are skipped)
+  double A_new = 0.0, b_new, C_new, eta_new = 0.0, J_new = 0.0;
+  if (ADJ) {
+    S.m[TT][lane] = mm(C1, false, A2, false);                 // lP1 Abar2
+    if (l == 0) S.v[VV][j] = mv(A2, true, E1);                // Abar2^T lF1
+    if (!DOWN) A_new = mm(A1, false, A2, false);
+    b_new = S.v[B2][j] + mv(A2, true, B1);
+    __syncthreads();
+    eta_new = S.v[E2][j] + S.v[VV][j];
+    C_new = S.m[C2][lane] + mm(A2, true, TT, false) + 0.5 * (S.v[VV][j] * S.v[B2][l] + S.v[B2][j] * S.v[VV][l]);
+    __syncthreads();
+  } else {
+    // M = I + C1 J2 ;  right-hand sides R1 = A1, r2 = b1 + C1 eta2, R3 = C1
+    {
+      const double m = mm(C1, false, J2, false) + (j == l ? 1.0 : 0.0);
+      const double r2 = S.v[B1][j] + mv(C1, false, E2);
+      S.m[MM][lane] = m;
+      S.m[R1][lane] = S.m[A1][lane];
+      S.m[R3][lane] = S.m[C1][lane];
+      if (l == 0) S.v[RR2][j] = r2;
     }
-    // swap rows k and piv
-    const int srcrow = j == k ? piv : (j == piv ? k : j);
-    const double m0 = S.m[MM][srcrow * 8 + l], a0 = S.m[R1][srcrow * 8 + l], c0 = S.m[R3][srcrow * 8 + l];
-    const double r0 = S.v[RR2][srcrow];
     __syncthreads();
-    S.m[MM][lane] = m0; S.m[R1][lane] = a0; S.m[R3][lane] = c0;
-    if (l == 0) S.v[RR2][j] = r0;
+    // Gauss-Jordan with partial pivoting (padded rows / columns are the identity: never chosen, never changed)
+    for (int k = 0; k < J; ++k) {
+      int piv = k;
+      double best = fabs(S.m[MM][k * 8 + k]);
+      for (int i = k + 1; i < J; ++i) {
+        const double a = fabs(S.m[MM][i * 8 + k]);
+        if (a > best) { best = a; piv = i; }
+      }
+      // rows k and piv swapped on the way in; row k scaled, its multiples taken off the others
+      const int srow = j == k ? piv : (j == piv ? k : j);
+      const double ip = 1.0 / S.m[MM][piv * 8 + k];
+      const double mk = S.m[MM][piv * 8 + l] * ip, ak = S.m[R1][piv * 8 + l] * ip, ck = S.m[R3][piv * 8 + l] * ip;
+      const double rk = S.v[RR2][piv] * ip;
+      const double f = j == k ? 0.0 : S.m[MM][srow * 8 + k];
+      const double mj = S.m[MM][srow * 8 + l], aj = S.m[R1][srow * 8 + l], cj = S.m[R3][srow * 8 + l], rj = S.v[RR2][srow];
+      __syncthreads();
+      S.m[MM][lane] = j == k ? mk : fma(-f, mk, mj);
+      if (!DOWN) S.m[R1][lane] = j == k ? ak : fma(-f, ak, aj);
+      S.m[R3][lane] = j == k ? ck : fma(-f, ck, cj);
+      if (l == 0) S.v[RR2][j] = j == k ? rk : fma(-f, rk, rj);
+      __syncthreads();
+    }
+    // now R1 = X1, r2 = x2, R3 = X3
+    if (!DOWN) A_new = mm(A2, false, R1, false);
+    b_new = mv(A2, false, RR2) + S.v[B2][j];
+    S.m[TT][lane] = mm(A2, false, R3, false);                          // A2 X3
+    if (!DOWN) {
+      S.m[T2][lane] = (j == l ? 1.0 : 0.0) - mm(J2, false, R3, false);   // N = I - J2 X3
+      if (l == 0) S.v[VV][j] = S.v[E2][j] - mv(J2, false, B1);           // eta2 - J2 b1
+    }
     __syncthreads();
-    const double ip = 1.0 / S.m[MM][k * 8 + k];
-    const double f = j == k ? 0.0 : S.m[MM][j * 8 + k];                 // multiple of (scaled) row k taken off row j
-    const double mk = S.m[MM][k * 8 + l] * ip, ak = S.m[R1][k * 8 + l] * ip, ck = S.m[R3][k * 8 + l] * ip;
-    const double rk = S.v[RR2][k] * ip;
-    const double mj = S.m[MM][lane], aj = S.m[R1][lane], cj = S.m[R3][lane], rj = S.v[RR2][j];
-    __syncthreads();
-    S.m[MM][lane] = j == k ? mk : fma(-f, mk, mj);
-    S.m[R1][lane] = j == k ? ak : fma(-f, ak, aj);
-    S.m[R3][lane] = j == k ? ck : fma(-f, ck, cj);
-    if (l == 0) S.v[RR2][j] = j == k ? rk : fma(-f, rk, rj);
-    __syncthreads();
+    C_new = mm(TT, false, A2, true) + S.m[C2][lane];
+    if (!DOWN) {
+      S.m[T3][lane] = mm(T2, false, J2, false);                          // N J2
+      if (l == 0) S.v[WW][j] = mv(T2, false, VV);                        // N (eta2 - J2 b1)
+      __syncthreads();
+      S.m[TMP][lane] = mm(T3, false, A1, false);                         // N J2 A1
+      eta_new = mv(A1, true, WW) + S.v[E1][j];
+      __syncthreads();
+      J_new = mm(A1, true, TMP, false) + S.m[J1][lane];
+    }
   }
-  // now R1 = X1, r2 = x2, R3 = X3
-  const double A_new = mm(A2, false, R1, false);
-  const double b_new = mv(A2, false, RR2) + S.v[B2][j];
-  S.m[TT][lane] = mm(A2, false, R3, false);                 // A2 X3
-  S.m[T2][lane] = (j == l ? 1.0 : 0.0) - mm(J2, false, R3, false);   // N = I - J2 X3
-  if (l == 0) S.v[VV][j] = S.v[E2][j] - mv(J2, false, B1);  // eta2 - J2 b1
-  __syncthreads();
-  const double C_new = mm(TT, false, A2, true) + S.m[C2][lane];
-  S.m[T3][lane] = mm(T2, false, J2, false);                 // N J2
-  if (l == 0) S.v[WW][j] = mv(T2, false, VV);               // N (eta2 - J2 b1)
-  __syncthreads();
-  S.m[TMP][lane] = mm(T3, false, A1, false);                // N J2 A1
-  const double eta_new = mv(A1, true, WW) + S.v[E1][j];
-  __syncthreads();
-  const double J_new = mm(A1, true, TMP, false) + S.m[J1][lane];
   // symmetrise C and J through LDS
   S.m[TT][lane] = C_new;
   S.m[T2][lane] = J_new;
   __syncthreads();
-  if (live_item && in) {
-    auto dst = [&](int e) -> double& { return state[dst_base + ((int64_t)c * E + e) * n_draw + draw]; };
+  const double C_sym = 0.5 * (C_new + S.m[TT][l * 8 + j]), J_sym = 0.5 * (J_new + S.m[T2][l * 8 + j]);
+  if (!in) return;
+  if (!DOWN) {
+    auto dst = [&](int e) -> double& { return state[op.dst_elem + ((int64_t)c * E + e) * n_draw + draw]; };
     dst(oA + j * J + l) = A_new;
-    dst(oC + j * J + l) = 0.5 * (C_new + S.m[TT][l * 8 + j]);
-    dst(oJ + j * J + l) = 0.5 * (J_new + S.m[T2][l * 8 + j]);
+    dst(oC + j * J + l) = C_sym;
+    if (!ADJ) dst(oJ + j * J + l) = J_sym;
     if (l == 0) { dst(ob + j) = b_new; dst(oeta + j) = eta_new; }
+  } else {
+    auto dst = [&](int pos, int k) -> double& {
+      const int idx = op.dst_rev ? op.dst_len - 1 - pos : pos;
+      return state[op.dst_state + ((int64_t)idx * Bq + k) * n_draw + draw];
+    };
+    dst(2 * c, J + j * J + l) = op.psign * S.m[C1][lane];
+    if (l == 0) dst(2 * c, j) = ADJ ? S.v[E1][j] : S.v[B1][j];
+    if (2 * c + 1 < op.dst_n) {
+      dst(2 * c + 1, J + j * J + l) = op.psign * C_sym;
+      if (l == 0) dst(2 * c + 1, j) = ADJ ? eta_new : b_new;
+    }
   }
+}
+
+// the state the forward scan starts from: F = 0, P = Delta(t_0) (S_0 = 0)
+template <int J>
+__global__ __launch_bounds__(kWave) void celerite_scan_init_kernel(const double* __restrict__ t, Coefs cf, int64_t n_draw,
+                                                                   double* __restrict__ dst) {
+  constexpr int G = Group<J>::G;
+  const int j = threadIdx.x & (G - 1);
+  const int64_t draw = ((int64_t)blockIdx.x * kWave + threadIdx.x) / G;
+  if (draw >= n_draw) return;
+  const LaneCoef k = lane_coef(cf, draw, j, J);
+  if (!k.live) return;
+  const LaneDelta ld(k);
+  double U_, V_, cs, sn, Prow[J];
+  lane_uv(k, t[0], &U_, &V_, &cs, &sn);
+  ld.row<J>(k, j, cs, sn, Prow);
+  dst[(int64_t)j * n_draw + draw] = 0.0;
+#pragma unroll
+  for (int l = 0; l < J; ++l) dst[(int64_t)(J + j * J + l) * n_draw + draw] = Prow[l];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1520,16 +1610,41 @@ static int celerite_fwd(const double* t, Series resid, const double* diag, int64
                                                  n_diag, n, cf, n_draw, state, cge, flag_at))
       }
       for (int f = cg.fine; f >= 1; --f) {
-        const int C_src = cg.C << f, C_dst = cg.C << (f - 1);
-        const int64_t src_base = ws.off_fine(f), dst_base = f > 1 ? ws.off_fine(f - 1) : ws.elem(0, 0, 0);
-        const int64_t items = (int64_t)C_dst * n_draw;
-        hipLaunchKernelGGL(celerite_compose_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, st, J, n_draw, state,
-                           src_base, C_src, dst_base, C_dst);
+        TreeOp op{};
+        op.J = J; op.n_draw = n_draw;
+        op.src_elem = ws.off_fine(f); op.src_n = op.src_len = cg.C << f;
+        op.dst_elem = f > 1 ? ws.off_fine(f - 1) : ws.elem(0, 0, 0);
+        op.n_item = cg.C << (f - 1);
+        hipLaunchKernelGGL((celerite_tree_kernel<false, false>), dim3((unsigned)(op.n_item * n_draw)), block, 0, st, op, state);
       }
       // after the element kernel: it may flag more draws (measurement variance too small)
       hipLaunchKernelGGL(celerite_prep_flagged_kernel, dim3(8, (unsigned)n_draw), dim3(256), 0, st, t, n, cf, n_draw, J,
                          state, state + ws.off_flag());
-      if (J >= 3) {
+      if (cg.tree) {
+        // (B) as a tree: compose up to one position, seed it with the initial state, apply back down
+        const int top = ws.tree_top();
+        TreeOp op{};
+        op.J = J; op.n_draw = n_draw;
+        auto level_elems = [&](int f) {
+          op.src_elem = f == 0 ? ws.elem(0, 0, 0) : ws.tree_elem(f);
+          op.src_n = f == 0 ? cg.C - 1 : ws.tree_npos(f);   // the last chunk's element takes no state anywhere
+          op.src_rev = 0; op.src_len = ws.tree_npos(f);
+        };
+        for (int f = 0; f + 1 < top; ++f) {
+          level_elems(f);
+          op.dst_elem = ws.tree_elem(f + 1); op.n_item = ws.tree_npos(f + 1);
+          hipLaunchKernelGGL((celerite_tree_kernel<false, false>), dim3((unsigned)(op.n_item * n_draw)), block, 0, st, op, state);
+        }
+        EXO_GP_DISPATCH(J, hipLaunchKernelGGL((celerite_scan_init_kernel<JJ>), grid, block, 0, st, t, cf, n_draw,
+                                              state + ws.tree_state(top)))
+        for (int f = top - 1; f >= 0; --f) {
+          level_elems(f);
+          op.par_state = ws.tree_state(f + 1); op.n_item = ws.tree_npos(f + 1);
+          op.dst_state = f == 0 ? ws.bnd(1, 0, 0, 0) : ws.tree_state(f);
+          op.dst_n = op.dst_len = ws.tree_npos(f); op.dst_rev = 0; op.psign = 1.0;
+          hipLaunchKernelGGL((celerite_tree_kernel<false, true>), dim3((unsigned)(op.n_item * n_draw)), block, 0, st, op, state);
+        }
+      } else if (J >= 3) {
         EXO_GP_DISPATCH(J, hipLaunchKernelGGL((celerite_bscan_lg_kernel<JJ>), grid, block, 0, st, t, cf, n, n_draw, state,
                                               cg))
       } else {
@@ -1581,7 +1696,33 @@ static int celerite_vjp(const double* t, Series resid, const double* diag, int64
         egrid(per_draw.x, (unsigned)cg.C);
     EXO_GP_DISPATCH(J, hipLaunchKernelGGL((celerite_badj_prep_kernel<JJ>), dim3(per_draw.x, (unsigned)(cg.C - 1)), block,
                                           0, st, gloglike, n, n_draw, wstate, cg))
-    EXO_GP_DISPATCH(J, hipLaunchKernelGGL((celerite_bscan_vjp_kernel<JJ>), per_draw, block, 0, st, n, n_draw, wstate, cg))
+    if (cg.tree) {
+      // (B') as a tree over positions p = C - 1 - chunk: adjoint elements of chunks C - 1 .. 1, zero initial adjoint
+      const int top = ws.tree_top();
+      TreeOp op{};
+      op.J = J; op.n_draw = n_draw;
+      auto level_elems = [&](int f) {
+        op.src_elem = f == 0 ? ws.elem(0, 0, 0) : ws.tree_elem(f);
+        op.src_n = f == 0 ? cg.C - 1 : ws.tree_npos(f);
+        op.src_rev = f == 0 ? 1 : 0; op.src_len = ws.tree_npos(f);
+      };
+      for (int f = 0; f + 1 < top; ++f) {
+        level_elems(f);
+        op.dst_elem = ws.tree_elem(f + 1); op.n_item = ws.tree_npos(f + 1);
+        hipLaunchKernelGGL((celerite_tree_kernel<true, false>), dim3((unsigned)(op.n_item * n_draw)), block, 0, st, op, wstate);
+      }
+      if (hipMemsetAsync(wstate + ws.tree_state(top), 0, sizeof(double) * ws.B() * n_draw, st) != hipSuccess)
+        return EXO_ERR_LAUNCH;
+      for (int f = top - 1; f >= 0; --f) {
+        level_elems(f);
+        op.par_state = ws.tree_state(f + 1); op.n_item = ws.tree_npos(f + 1);
+        op.dst_state = f == 0 ? ws.bnd(2, 0, 0, 0) : ws.tree_state(f);
+        op.dst_n = op.dst_len = ws.tree_npos(f); op.dst_rev = f == 0 ? 1 : 0; op.psign = f == 0 ? -1.0 : 1.0;
+        hipLaunchKernelGGL((celerite_tree_kernel<true, true>), dim3((unsigned)(op.n_item * n_draw)), block, 0, st, op, wstate);
+      }
+    } else {
+      EXO_GP_DISPATCH(J, hipLaunchKernelGGL((celerite_bscan_vjp_kernel<JJ>), per_draw, block, 0, st, n, n_draw, wstate, cg))
+    }
     if (cg.lane) {
       EXO_GP_LAYOUTS(J, cf, hipLaunchKernelGGL((celerite_chunk1_vjp_kernel<(JJ <= kLaneMaxJ ? JJ : 1), NR>), egrid, block, 0,
                                                st, t, resid, diag, n_diag, n, cf, n_draw, gloglike, wstate, cg, gresid,

@@ -157,6 +157,7 @@ struct ChunkGeom {
   int lane;     // 1: one-lane chunk kernels with a checkpointed factorisation; 0: lane-group kernels, full factorisation
   int fine;     // levels of pairwise element composition: the elements are BUILT for C << fine chunks of L >> fine
                 // cadences (that many times more lanes for the element kernel) and composed back up (0: built directly)
+  int tree;     // 1: the scans over the chunks (B), (B') are trees of element compositions (lane-group path), 0: serial
 };
 
 // chunk workspace, all [chunk][quantity][draw] (a lane is a draw: coalesced)
@@ -193,9 +194,33 @@ struct ChunkWs {
     for (int g = fine; g > f; --g) o += ((int64_t)C << g) * E() * n_draw;
     return o;
   }
-  EXO_HDH int64_t total() const {
+  EXO_HDH int64_t off_tree() const {
     int64_t o = off_ckpt() + n_blk * K() * n_draw;
     for (int g = 1; g <= fine; ++g) o += ((int64_t)C << g) * E() * n_draw;
+    return o;
+  }
+  // scan tree (ChunkGeom::tree): level f = 1 .. tree_top() has tree_npos(f) positions, each an element and a state
+  // (vector + matrix); level 0 is elem() / bnd(); the top level is one position
+  int tree;
+  EXO_HDH int tree_npos(int f) const {
+    int p = C;
+    for (int g = 0; g < f; ++g) p = (p + 1) / 2;
+    return p;
+  }
+  EXO_HDH int tree_top() const {
+    int f = 0;
+    while (tree_npos(f) > 1) ++f;
+    return f;
+  }
+  EXO_HDH int64_t tree_elem(int f) const {   // f >= 1
+    int64_t o = off_tree();
+    for (int g = 1; g < f; ++g) o += (int64_t)tree_npos(g) * (E() + B()) * n_draw;
+    return o;
+  }
+  EXO_HDH int64_t tree_state(int f) const { return tree_elem(f) + (int64_t)tree_npos(f) * E() * n_draw; }
+  EXO_HDH int64_t total() const {
+    int64_t o = off_tree();
+    if (tree) o = tree_elem(tree_top() + 1);
     return o - base;
   }
 };
@@ -235,9 +260,9 @@ EXO_HDH int64_t seq_state_doubles(int64_t n, int64_t n_draw, int J) {
 
 // How a series is cut.  n_chunks = 0: the default plan; 1: sequential; > 1: forced.  A pure
 // function of its arguments: the forward and the reverse call of a pair compute the same plan.
-constexpr int kFineLevels = 2;   // J > 2: elements built for 4 x finer chunks, composed pairwise twice
+constexpr int kFineLevels = 1;   // J > 2: elements built for 2 x finer chunks, composed pairwise once
 EXO_HDH ChunkGeom chunk_plan(int64_t n, int64_t n_draw, int J, int32_t n_chunks) {
-  ChunkGeom g{1, n, seq_state_doubles(n, n_draw, J), 0, 0};
+  ChunkGeom g{1, n, seq_state_doubles(n, n_draw, J), 0, 0, 0};
   if (J > kChunkMaxJ || J < 1 || n < 64) return g;
   const bool lane = J <= kLaneMaxJ;
   int64_t C;
@@ -250,8 +275,9 @@ EXO_HDH ChunkGeom chunk_plan(int64_t n, int64_t n_draw, int J, int32_t n_chunks)
     if (C < 4) C = 4;
   } else {
     const int G = J <= 1 ? 1 : (J <= 2 ? 2 : (J <= 4 ? 4 : 8));
-    // ~2 waves per SIMD for the lane-group chunk kernels
-    C = (64 * 2048) / (n_draw * G);
+    // ~4 waves per SIMD offered to the lane-group chunk kernels (they fit 3): the scans over the chunks are
+    // trees, so more chunks cost them little
+    C = (64 * 4096) / (n_draw * G);
     if (C > 512) C = 512;
     if (C < 4) C = 1;
   }
@@ -264,11 +290,12 @@ EXO_HDH ChunkGeom chunk_plan(int64_t n, int64_t n_draw, int J, int32_t n_chunks)
   if (g.C < 2) { g.C = 1; g.L = n; return g; }
   g.lane = lane ? 1 : 0;
   g.fine = lane ? 0 : kFineLevels;
+  g.tree = lane ? 0 : 1;
   return g;
 }
 
 EXO_HDH ChunkWs chunk_ws(int64_t n, int64_t n_draw, int J, const ChunkGeom& g) {
-  return ChunkWs{n_draw, J, g.C, g.base, g.lane ? (n + kCkptB - 1) / kCkptB : 0, g.fine};
+  return ChunkWs{n_draw, J, g.C, g.base, g.lane ? (n + kCkptB - 1) / kCkptB : 0, g.fine, g.tree};
 }
 // the geometry the element kernels see when they build level f: C << f chunks of L >> f cadences, elem()
 // addressing that level's array; flags stay where the coarse geometry has them (flag_at)
@@ -278,6 +305,7 @@ EXO_HDH ChunkGeom fine_geom(int64_t n, int64_t n_draw, int J, const ChunkGeom& g
   q.L = g.L >> f;
   q.base = chunk_ws(n, n_draw, J, g).off_fine(f);
   q.fine = 0;
+  q.tree = 0;
   return q;
 }
 
