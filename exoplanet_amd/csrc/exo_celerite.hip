@@ -935,7 +935,11 @@ __global__ __launch_bounds__(kWave) void celerite_chunk_fwd_kernel(
     const double ti = t[i], dt = ti - tprev;
     tprev = ti;
     double Uj, Vj, cs_, sn_;
+#ifdef EXO_EXP_NOTRIG
+    Uj = k.a + 1e-9 * ti; Vj = 1.0;
+#else
     lane_uv(k, ti, &Uj, &Vj, &cs_, &sn_);
+#endif
     if (dt != dt_prev) {   // wave-uniform: evenly sampled series reuse P
       Pj = k.live ? exp(-k.c * dt) : 0.0;
       dt_prev = dt;
@@ -966,10 +970,12 @@ __global__ __launch_bounds__(kWave) void celerite_chunk_fwd_kernel(
     int lexp;
     lman = frexp(lman * (d > 0.0 ? d : 1.0), &lexp);
     lsum += lexp;
+#ifndef EXO_EXP_NOSTORE
     if (store) {
       if (j == 0) *reinterpret_cast<double2*>(p_scal) = double2{d, z};
       store_record<J>(p_vec, six.piece(), Wj, Fj, Srow);
     }
+#endif
     p_vec += rstride; p_scal += 2 * n_draw;
   }
   if (live_draw && j == 0) {
@@ -1538,7 +1544,7 @@ int64_t exo_celerite_state_doubles(int64_t n, int64_t n_draw, int32_t n_real, in
     case 8: { constexpr int JJ = 8; CALL; } break; \
     default: return EXO_ERR_INVALID_ARGUMENT;      \
   }
-static_assert(kLaneMaxJ == 2, "EXO_GP_LAYOUTS lists the layouts of the one-lane path (J <= 2)");
+static_assert(kLaneMaxJ >= 2, "EXO_GP_LAYOUTS lists compile-time layouts for J <= 2; J > 2 takes run-time flags");
 // CALL with `JJ` and `NR` for every layout variant the draws of a call may need (layout_vote):
 // J = 1: one real term; J = 2: two real terms or one pair slot -- complex, or, with per-draw kinds,
 // either (three launches: waves return at once from the variants they did not vote for); J > 2:

@@ -290,7 +290,7 @@ EXO_HDH ChunkGeom chunk_plan(int64_t n, int64_t n_draw, int J, int32_t n_chunks)
   if (g.C < 2) { g.C = 1; g.L = n; return g; }
   g.lane = lane ? 1 : 0;
   g.fine = lane ? 0 : kFineLevels;
-  g.tree = lane ? 0 : 1;
+  g.tree = J >= 3 ? 1 : 0;   // the tree kernels work on 8 x 8 tiles in LDS: not worth it for 2 x 2
   return g;
 }
 
@@ -376,14 +376,17 @@ struct DeltaCoef {
 template <int J, int NR = -1>
 struct DrawCoef {
   LaneCoef k[J];
-  // rotation of a pair's (cos, sin) by d dt, for the step size dt_rot (see uv_step)
-  double rc[J], rs[J], dt_rot, dt_last;
+  // the REFERENCE STEP dt_ref of the stretch being walked (see step / rot_uv): a pair's rotation (cos, sin)(d dt_ref),
+  // the propagators exp(-c dt_ref); dt_miss: the last step that was not near the reference
+  double rc[J], rs[J], ph[J], dt_ref, dt_miss;
+  bool near_ok;
   EXO_HD bool is_real(int j) const { return NR < 0 ? k[j].real : j < NR; }
   EXO_HD bool is_first(int j) const { return NR < 0 ? (!k[j].real && !k[j].odd) : (j >= NR && ((j - NR) & 1) == 0); }
   EXO_HD void init(const Coefs& co, int64_t draw) {
 #pragma unroll
-    for (int j = 0; j < J; ++j) { k[j] = lane_coef(co, draw, j, J); rc[j] = 1.0; rs[j] = 0.0; }
-    dt_rot = dt_last = -1.0;
+    for (int j = 0; j < J; ++j) { k[j] = lane_coef(co, draw, j, J); rc[j] = 1.0; rs[j] = 0.0; ph[j] = 1.0; }
+    dt_ref = dt_miss = -1.0;
+    near_ok = false;
   }
   EXO_HD void uv(double t, double* U, double* V) const {
 #pragma unroll
@@ -410,33 +413,71 @@ struct DrawCoef {
       }
     }
   }
-  // (U, V) at time t, one step dt after the cadence whose V is Vp: on an evenly sampled stretch the
-  // pair's (cos, sin) is ROTATED by d dt (four multiply-adds instead of a 45-instruction sincos).
-  // The rotation for a step size is set up the second time in a row that step size is seen, so an
-  // unevenly sampled series pays one exact evaluation per cadence, as before.  Every kernel of the
-  // one-lane path restarts from the exact values at the same cadences (the first of each block of
-  // four, counted from the chunk start); three rotations in a row drift by ~3e-16, and kernels that
-  // reach a cadence with different step histories may differ there by that much.
-  EXO_HD void uv_step(double t, double dt, const double* Vp, double* U, double* V) {
-    if (dt != dt_rot) {   // wave-uniform on evenly sampled series
-      if (dt == dt_last) {
+  // Steps of an (almost) evenly sampled stretch.  Time stamps that are "evenly sampled" differ from step to step in
+  // their last bits (t_i = i dt rounds each product: two thirds of consecutive steps of such a series are not
+  // bitwise equal), and real ones by the barycentric correction (~1e-9 of the step from one cadence to the next), so
+  // "same step as before" cannot be a bitwise test.  The first step of a stretch becomes the reference: its
+  // propagators exp(-c dt_ref) and pair rotations (cos, sin)(d dt_ref) are evaluated once, and a step within 2^-20
+  // of it takes them CORRECTED for the difference del = dt - dt_ref to second order,
+  //     exp(-c dt) = ph (1 - x + x^2 / 2),  x = c del;      R(d dt) = R(d del) R(d dt_ref),  R(e) ~ (1 - e^2/2, e),
+  // exact to (|c|, |d|) |del| cubed / 6 <= 1e-16 when max(|c|, |d|) dt_ref <= 8 (near_ok).  Any other step (a gap)
+  // is evaluated exactly and leaves the reference alone; two such steps of the same size in a row re-reference.
+  EXO_HD void set_ref(double dt) {
+    dt_ref = dt;
+    double big = 0.0;
 #pragma unroll
-        for (int j = 0; j < J; ++j)
-          if (!is_real(j) && is_first(j)) exo::sincos_any(k[j].d * dt, &rs[j], &rc[j]);
-        dt_rot = dt;
+    for (int j = 0; j < J; ++j) {
+      ph[j] = exp(-k[j].c * dt);
+      big = fmax(big, fabs(k[j].c));
+      if (!is_real(j) && is_first(j)) {
+        exo::sincos_any(k[j].d * dt, &rs[j], &rc[j]);
+        big = fmax(big, fabs(k[j].d));
       }
-      dt_last = dt;
-      uv(t, U, V);
-      return;
     }
+    near_ok = big * dt <= 8.0 && dt > 0.0;
+  }
+  // propagators of the step dt into phi; true: the step is near the reference (rot_uv may follow)
+  // (track = false: a step that was already seen -- the reverse pass asks for a step's propagators again -- does not
+  // count towards re-referencing)
+  EXO_HD bool step(double dt, double* phi, bool track = true) {
+    constexpr double kTol = 9.5367431640625e-07;   // 2^-20
+    if (dt_ref < 0.0) set_ref(dt);
+    bool near = near_ok && fabs(dt - dt_ref) <= kTol * dt_ref;
+    if (!near && track) {
+      if (dt_miss > 0.0 && fabs(dt - dt_miss) <= kTol * dt_miss) {
+        set_ref(dt);
+        near = near_ok;
+      }
+      dt_miss = dt;
+    }
+    if (near) {
+      const double del = dt - dt_ref;
+#pragma unroll
+      for (int j = 0; j < J; ++j) {
+        const double x = k[j].c * del;
+        phi[j] = ph[j] * fma(x, fma(0.5, x, -1.0), 1.0);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < J; ++j) phi[j] = exp(-k[j].c * dt);
+    }
+    return near;
+  }
+  // (U, V) one near-reference step dt after the cadence whose V is Vp: the pair's (cos, sin) rotated by d dt
+  // (a dozen multiply-adds instead of a 45-instruction sincos).  The kernels restart from the exact values at the
+  // first cadence of every block of four (counted from the chunk start): three rotations in a row drift by ~3e-16.
+  EXO_HD void rot_uv(double dt, const double* Vp, double* U, double* V) const {
+    const double del = dt - dt_ref;
 #pragma unroll
     for (int j = 0; j < J; ++j) {
       if (is_real(j)) {
         V[j] = 1.0;
       } else if (is_first(j) && j + 1 < J) {
         const double cs = Vp[j], sn = Vp[j + 1];
-        V[j] = fma(cs, rc[j], -sn * rs[j]);
-        V[j + 1] = fma(sn, rc[j], cs * rs[j]);
+        const double c1 = fma(cs, rc[j], -sn * rs[j]), s1 = fma(sn, rc[j], cs * rs[j]);
+        const double e = k[j].d * del, h = fma(-0.5 * e, e, 1.0);
+        V[j] = fma(-e, s1, c1 * h);
+        V[j + 1] = fma(e, c1, s1 * h);
       }
     }
     u_from_v(V, U);
@@ -508,7 +549,7 @@ EXO_HD void elem_lane(const double* EXO_RESTRICT t, Series rs, const double* EXO
   double U[J], V[J], phi[J];
 #pragma unroll
   for (int j = 0; j < J; ++j) { U[j] = V[j] = 0.0; phi[j] = 1.0; }
-  double ti = t[n0], dt_prev = -1.0;
+  double ti = t[n0];
   co.uv(ti, U, V);
   dc.eval(V, Dl);
   // Conditioning.  The element is in information form (1 / diag) and lives in celerite's rotating
@@ -560,13 +601,9 @@ EXO_HD void elem_lane(const double* EXO_RESTRICT t, Series rs, const double* EXO
       double Vn[J];
       const double tn = t[i + 1], dt = tn - ti;
       ti = tn;
-      if (dt != dt_prev) {   // evenly sampled series reuse the propagators
-#pragma unroll
-        for (int j = 0; j < J; ++j) phi[j] = exp(-co.k[j].c * dt);
-        dt_prev = dt;
-      }
+      const bool near = co.step(dt, phi);
       // exact at the first cadence of every block of four (counted from the chunk start), rotated in between
-      if (((i + 1 - n0) & 3) == 0) co.uv(tn, U, Vn); else co.uv_step(tn, dt, V, U, Vn);
+      if (((i + 1 - n0) & 3) == 0 || !near) co.uv(tn, U, Vn); else co.rot_uv(dt, V, U, Vn);
 #pragma unroll
       for (int j = 0; j < J; ++j) V[j] = Vn[j];
       Sym<J> Dn;
@@ -991,7 +1028,7 @@ EXO_HD void chunk1_fwd_lane(const double* EXO_RESTRICT t, Series rs, const doubl
       for (int l = j; l < J; ++l) f.S(j, l) = Dl(j, l) - state[ws.bnd(1, c, J + j * J + l, draw)];
     }
   }
-  Phi<J> phi;
+  double phi[J];
   double tprev = t[n0];
   double acc = 0.0, lman = 1.0;
   int64_t lsum = 0;
@@ -1008,16 +1045,16 @@ EXO_HD void chunk1_fwd_lane(const double* EXO_RESTRICT t, Series rs, const doubl
       if (i < n1) {
         if (i > n0) {   // (the entering state is already at n0)
           const double ti = t[i], dt = ti - tprev;
-          phi.set(co, dt);
+          const bool near = co.step(dt, phi);
           tprev = ti;
-          f.advance(phi.v);
-          if (q == 0) {
+          f.advance(phi);
+          if (q == 0 || !near) {
             co.uv(ti, f.U, f.V);
           } else {
             double Vp[J];
 #pragma unroll
             for (int j = 0; j < J; ++j) Vp[j] = f.V[j];
-            co.uv_step(ti, dt, Vp, f.U, f.V);
+            co.rot_uv(dt, Vp, f.U, f.V);
           }
         }
         if (q == 0 && save) {   // checkpoint: the state AT the block's first cadence (after the step into it)
@@ -1169,7 +1206,8 @@ EXO_HD void chunk1_vjp_lane(const double* EXO_RESTRICT t, Series rs, const doubl
     for (int l = 0; l < J; ++l) r.Sb[j][l] = state[ws.bnd(2, c, J + j * J + l, draw)];
   }
   r.db = r.zb = r.gasum = 0.0;
-  Phi<J> phi;
+  double phi[J];
+  if (n0 + 1 < n) co.set_ref(t[n0 + 1] - t[n0]);   // the forward kernel's reference: its first step
   // blocks last to first; `pend`: the step from this block's last cadence into cadence `next` (the
   // first cadence of the block after it, or of the next chunk) still has to be reversed
   const int64_t nb = (n1 - n0 + kCkptB - 1) / kCkptB;
@@ -1213,13 +1251,17 @@ EXO_HD void chunk1_vjp_lane(const double* EXO_RESTRICT t, Series rs, const doubl
           tt[q] = ti;
           if (q > 0) {
             const double dt = ti - tprev;
-            phi.set(co, dt);
+            const bool near = co.step(dt, phi);
             tprev = ti;
-            f.advance(phi.v);
-            double Vp[J];
+            f.advance(phi);
+            if (near) {
+              double Vp[J];
 #pragma unroll
-            for (int j = 0; j < J; ++j) Vp[j] = f.V[j];
-            co.uv_step(ti, dt, Vp, f.U, f.V);
+              for (int j = 0; j < J; ++j) Vp[j] = f.V[j];
+              co.rot_uv(dt, Vp, f.U, f.V);
+            } else {
+              co.uv(ti, f.U, f.V);
+            }
           } else {
             co.uv(ti, f.U, f.V);
           }
@@ -1257,8 +1299,8 @@ EXO_HD void chunk1_vjp_lane(const double* EXO_RESTRICT t, Series rs, const doubl
             W[j] = (st[q].V[j] - uj) * id;
           }
           const double dt = t[i + 1] - tt[q];
-          phi.set(co, dt);
-          r.propagate(st[q], W, phi.v, dt);
+          co.step(dt, phi, false);
+          r.propagate(st[q], W, phi, dt);
         }
         r.measure(co, st[q], tt[q], gL, W, &zbar[q], &dbar[q]);
         if (q > 0) {
@@ -1277,8 +1319,8 @@ EXO_HD void chunk1_vjp_lane(const double* EXO_RESTRICT t, Series rs, const doubl
             Wp[j] = (st[q - 1].V[j] - uj) * id;
           }
           const double dt = tt[q] - tt[q - 1];
-          phi.set(co, dt);
-          r.propagate(st[q - 1], Wp, phi.v, dt);
+          co.step(dt, phi, false);
+          r.propagate(st[q - 1], Wp, phi, dt);
         }
       }
     }

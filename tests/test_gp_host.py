@@ -207,6 +207,36 @@ def test_lane_pipeline_long_series_vs_c_port(harness):
             np.testing.assert_allclose(g["cplx"][d, 0, q], gw[key][0], rtol=2e-6)
 
 
+def test_lane_pipeline_reference_step_regimes(harness):
+    """the reference-step shortcut of the one-lane kernels (DrawCoef::step / rot_uv): steps that differ in their last
+    bits, barycentric-like drift of the step (1e-7 per cadence), gaps, a change of cadence half way (20 s -> 2 min),
+    and a term too fast for the shortcut (d dt > 8) -- all against the C port's exact recurrences"""
+    rng = np.random.default_rng(18)
+    n, D = 6_000, 2
+    dt = np.full(n, 2.0 / 1440.0) * (1 + 1e-7 * np.sin(np.arange(n) / 300.0))
+    dt[n // 2:] *= 6.0                          # cadence change
+    dt[[700, 701, 2500, 4100]] += (0.3, 0.02, 1.7, 0.5)   # gaps
+    t = 1325.0 + np.cumsum(dt)
+    base = P.sho_coefficients(*P.sho_from_sigma_rho(1e-3, 0.7, 3.0), 3.0)
+    fast = P.sho_coefficients(*P.sho_from_sigma_rho(5e-4, 2e-4, 2.0), 2.0)      # d dt ~ 30: exact path
+    y = 5e-4 * rng.normal(size=(D, n))
+    diag = np.full((1, n), 2.5e-7)
+    gll = np.ones(D)
+    for co in (base, fast):
+        cplx = np.repeat(np.stack(co[2:], -1)[None], D, 0) * (1 + 1e-3 * rng.normal(size=(D, 1, 4)))
+        cplx[:, :, 1] = np.minimum(np.abs(cplx[:, :, 1]), cplx[:, :, 0] * cplx[:, :, 2] / cplx[:, :, 3])
+        ll, flags, C_used, g = run(harness, t, y, diag, np.zeros((D, 0, 2)), cplx, gll=gll, n_chunks=24)
+        assert np.all(flags == 0)
+        for d in range(D):
+            z = np.zeros(0)
+            coeffs = (z, z, cplx[d, :, 0], cplx[d, :, 1], cplx[d, :, 2], cplx[d, :, 3])
+            want, gw = C.celerite(t, y[d], diag[0], coeffs, grad=True)
+            assert abs(ll[d] - want) <= 1e-12 * abs(want)
+            np.testing.assert_allclose(g["y"][d], gw["y"], rtol=1e-7, atol=1e-9 * np.abs(gw["y"]).max())
+            for q, key in enumerate(("ac", "bc", "cc", "dc")):
+                np.testing.assert_allclose(g["cplx"][d, 0, q], gw[key][0], rtol=2e-6)
+
+
 def _kernel(tau, c):
     return P.celerite_kernel(tau, *c)
 
