@@ -144,13 +144,21 @@ def make_leaves(n_draw, seed, dev):
     return leaves
 
 
-def step(xo, ops, leaves, t, gbar, events=(None, None), use_in_transit=False):
-    """one pass of the hot path over the batch: returns (flux, L[d], grads of the leaves)"""
+_ONES = {}
+
+
+def step(xo, ops, leaves, t, gbar, events=(None, None), use_in_transit=False, **kw):
+    """one pass of the hot path over the batch: returns (flux, L[d], grads of the leaves).  The leaves go to the
+    kernels as they are (KeplerianOrbit.flux_dot: column-form packing kernel -> sweep -> packing VJP with the
+    cotangent of L folded in); the cotangent of L is a constant vector of ones (d sum(L) / d leaves)."""
     orbit = xo.KeplerianOrbit(period=leaves["period"], t0=leaves["t0"], b=leaves["b"], ecc=leaves["ecc"],
                               omega=leaves["omega"])
-    rec, ld, _, flags = orbit.kernel_inputs(leaves["r"], (leaves["u1"], leaves["u2"]), use_in_transit=use_in_transit)
-    flux, L = ops.transit_flux_dot(t, rec, ld, gbar, flags=flags, events=events)
-    grads = torch.autograd.grad(L.sum(), list(leaves.values()))
+    flux, L = orbit.flux_dot(leaves["r"], (leaves["u1"], leaves["u2"]), t, gbar, use_in_transit=use_in_transit,
+                             events=events, **kw)
+    key = (L.shape[0], L.device)
+    if key not in _ONES:
+        _ONES[key] = torch.ones(L.shape[0], dtype=L.dtype, device=L.device)
+    grads = torch.autograd.grad(L, list(leaves.values()), grad_outputs=_ONES[key])
     return flux, L, grads
 
 
@@ -370,11 +378,8 @@ def extra_c4(xo, dev, D=64):
     from exoplanet_amd import ops
 
     def one(*vals):
-        Lv = dict(zip(names, vals))
-        orbit = xo.KeplerianOrbit(period=Lv["period"], t0=Lv["t0"], b=Lv["b"], ecc=Lv["ecc"], omega=Lv["omega"])
-        rec, ld, _, flags = orbit.kernel_inputs(Lv["r"], (Lv["u1"], Lv["u2"]), use_in_transit=False)
-        flux, L = ops.transit_flux_dot(t, rec, ld, gbar, flags=flags)
-        return (L.detach(),) + torch.autograd.grad(L.sum(), vals)
+        _, L, grads = step(xo, ops, dict(zip(names, vals)), t, gbar)
+        return (L.detach(),) + grads
 
     q, how = graphed(xo, one, list(leaves.values()), dev, 40)
     gbps = SURVEY_BYTES_PER_UNIT * D * n / (q["median_ms"] * 1e-3) / 1e9
@@ -573,8 +578,9 @@ def main():
                             f"cadence classified on the device, {100.0 * n_active / (D * N_CAD):.2f} % solved",
                 "n_cadences": N_CAD, "draws_per_gpu": D, "global_draws": n_global,
                 "parallelism": f"draws sharded over {world} GPU(s); one collective of per-draw scalars per step",
-                "step": "leaf params -> record-packing kernel (orbit algebra + get_cl) -> window + run-enumeration + "
-                        "heavy + finish kernels (value+VJP, one sweep) -> packing VJP kernel -> leaf gradients"
+                "step": "leaf params (separate tensors, read in place) -> record-packing kernel (orbit algebra + "
+                        "get_cl) -> window + run-enumeration + heavy + finish kernels (value+VJP, one sweep) -> packing "
+                        "VJP kernel (cotangent of L folded in) -> leaf gradients: six launches"
                         + ("; replayed as one hipGraph" if graph is not None else "; eager launches"),
             },
             "timing": timing,
@@ -646,11 +652,8 @@ def main():
             names = list(leaves)
 
             def sp_step(*vals):
-                Lv = dict(zip(names, vals))
-                orbit = xo.KeplerianOrbit(period=Lv["period"], t0=Lv["t0"], b=Lv["b"], ecc=Lv["ecc"], omega=Lv["omega"])
-                rec, ld, _, flags = orbit.kernel_inputs(Lv["r"], (Lv["u1"], Lv["u2"]), use_in_transit=False)
-                _, L = ops.transit_flux_dot(t, rec, ld, gbar, flags=flags | ops.FLAG_SPARSE)
-                return (L.detach(),) + torch.autograd.grad(L.sum(), vals)
+                _, L, grads = step(xo, ops, dict(zip(names, vals)), t, gbar, sparse=True)
+                return (L.detach(),) + grads
 
             q, how = graphed(xo, sp_step, list(leaves.values()), dev, 50)
             return {"evals_per_s": D / (q["median_ms"] * 1e-3), **q, "launch": how,
@@ -662,11 +665,8 @@ def main():
             names = list(leaves)
 
             def ld_step(*vals):
-                Lv = dict(zip(names, vals))
-                orbit = xo.KeplerianOrbit(period=Lv["period"], t0=Lv["t0"], b=Lv["b"], ecc=Lv["ecc"], omega=Lv["omega"])
-                rec, ld, _, flags = orbit.kernel_inputs(Lv["r"], (Lv["u1"], Lv["u2"]), use_in_transit=False, light_delay=True)
-                _, L = ops.transit_flux_dot(t, rec, ld, gbar, flags=flags)
-                return (L.detach(),) + torch.autograd.grad(L.sum(), vals)
+                _, L, grads = step(xo, ops, dict(zip(names, vals)), t, gbar, light_delay=True)
+                return (L.detach(),) + grads
 
             q, how = graphed(xo, ld_step, list(leaves.values()), dev, 50)
             return {"evals_per_s": D / (q["median_ms"] * 1e-3), **q, "launch": how,

@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # EXOPLANET_AMD_LIB selects another in-tree build of the same ABI (A/B measurements)
 LIB_PATH = os.environ.get("EXOPLANET_AMD_LIB") or os.path.join(_HERE, "lib", "libexoplanet_amd.so")
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 _c_dp = ctypes.c_void_p  # device pointers travel as integers
 _i64 = ctypes.c_int64
@@ -85,6 +85,11 @@ _SIGNATURES = {
     "exo_radial_velocity_vjp_f64": (ctypes.c_int, [_c_dp, _i64, _c_dp, _i64, _i32, _c_dp, _c_dp, _c_dp]),
     "exo_pack_records_f64": (ctypes.c_int, [_c_dp, _c_dp, _i64, _i32, _u32, _c_dp, _c_dp, _c_dp]),
     "exo_pack_records_vjp_f64": (ctypes.c_int, [_c_dp, _c_dp, _i64, _i32, _u32, _c_dp, _c_dp, _c_dp, _c_dp, _c_dp]),
+    # cols, draw_stride, planet_stride, defaults, ld_cols, ld_draw_stride (host arrays), n_draw, n_planet, flags, ...
+    "exo_pack_records_cols_f64": (ctypes.c_int, [_c_dp, _c_dp, _c_dp, _c_dp, _c_dp, _c_dp, _i64, _i32, _u32, _c_dp, _c_dp,
+                                                 _c_dp]),
+    "exo_pack_records_cols_vjp_f64": (ctypes.c_int, [_c_dp, _c_dp, _c_dp, _c_dp, _c_dp, _c_dp, _i64, _i32, _u32, _c_dp,
+                                                     _c_dp, _c_dp, _c_dp, _c_dp, _c_dp]),
 }
 
 _ERRORS = {1: "invalid argument", 2: "kernel launch failed", 3: "workspace too small"}

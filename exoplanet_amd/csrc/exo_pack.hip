@@ -52,16 +52,54 @@ __device__ __forceinline__ Derived derive(const double* in, bool circular) {
   return d;
 }
 
-__global__ __launch_bounds__(64) void pack_kernel(const double* __restrict__ orbit_in,
-                                                  const double* __restrict__ ld_in, int64_t n_draw, int n_planet,
-                                                  uint32_t flags, double* __restrict__ params,
-                                                  double* __restrict__ ld) {
+// Where the inputs come from / the input cotangents go.  Packed: the (n_draw, n_planet, EXO_NIN) and (n_draw, 2|4)
+// arrays of exo_pack_records_f64.  Cols: every input its own device array read with per-column strides (0 =
+// broadcast) or absent (a default value) -- a caller whose parameters are separate tensors needs no packing pass,
+// and no unpacking pass for the cotangents, which are written densely, one (n_draw, n_planet) array per column.
+struct PackedSrc {
+  const double* orbit_in;
+  const double* ld_in;
+  __device__ __forceinline__ void load(int64_t i, int64_t, int, double* in) const {
+#pragma unroll
+    for (int k = 0; k < EXO_NIN; ++k) in[k] = orbit_in[i * EXO_NIN + k];
+  }
+  __device__ __forceinline__ double ld(int64_t draw, int k, int nld) const { return ld_in[draw * nld + k]; }
+};
+struct PackedDst {
+  double* gorbit_in;
+  double* gld_in;
+  __device__ __forceinline__ void store(int64_t i, int k, double v) const { gorbit_in[i * EXO_NIN + k] = v; }
+  __device__ __forceinline__ void store_ld(int64_t draw, int k, int nld, double v) const { gld_in[draw * nld + k] = v; }
+};
+struct ColsSrc {
+  const double* ptr[EXO_NIN];
+  int64_t ds[EXO_NIN], ps[EXO_NIN];
+  double def[EXO_NIN];
+  const double* ldp[4];
+  int64_t lds[4];
+  __device__ __forceinline__ void load(int64_t, int64_t draw, int planet, double* in) const {
+#pragma unroll
+    for (int k = 0; k < EXO_NIN; ++k) in[k] = ptr[k] ? ptr[k][draw * ds[k] + planet * ps[k]] : def[k];
+  }
+  __device__ __forceinline__ double ld(int64_t draw, int k, int) const { return ldp[k][draw * lds[k]]; }
+};
+struct ColsDst {
+  double* ptr[EXO_NIN];
+  double* ldp[4];
+  __device__ __forceinline__ void store(int64_t i, int k, double v) const { if (ptr[k]) ptr[k][i] = v; }
+  __device__ __forceinline__ void store_ld(int64_t draw, int k, int, double v) const { if (ldp[k]) ldp[k][draw] = v; }
+};
+
+template <class Src>
+__global__ __launch_bounds__(64) void pack_kernel(Src src, int64_t n_draw, int n_planet, uint32_t flags,
+                                                  double* __restrict__ params, double* __restrict__ ld) {
   const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
   const bool circular = flags & EXO_PACK_CIRCULAR, secondary = flags & EXO_FLAG_SECONDARY;
   const bool window = flags & EXO_FLAG_WINDOW;
   const double inf = __builtin_inf();
   if (i < n_draw * n_planet) {
-    const double* in = orbit_in + i * EXO_NIN;
+    double in[EXO_NIN];
+    src.load(i, i / n_planet, (int)(i % n_planet), in);
     double* o = params + i * EXO_NPAR;
     const Derived d = derive(in, circular);
     const double e = circular ? 0.0 : in[EXO_IN_ECC];
@@ -127,7 +165,7 @@ __global__ __launch_bounds__(64) void pack_kernel(const double* __restrict__ orb
   if (i < n_draw) {
     const int nset = secondary ? 2 : 1;
     for (int s = 0; s < nset; ++s) {
-      const double u1 = ld_in[i * 2 * nset + 2 * s], u2 = ld_in[i * 2 * nset + 2 * s + 1];
+      const double u1 = src.ld(i, 2 * s, 2 * nset), u2 = src.ld(i, 2 * s + 1, 2 * nset);
       const double c0 = 1.0 - u1 - 1.5 * u2, c1 = u1 + 2.0 * u2, c2 = -0.25 * u2;
       const double inorm = 1.0 / (kPi * (c0 + c1 * (1.0 / 1.5)));
       double* o = ld + i * 3 * nset + 3 * s;
@@ -136,18 +174,21 @@ __global__ __launch_bounds__(64) void pack_kernel(const double* __restrict__ orb
   }
 }
 
-__global__ __launch_bounds__(64) void pack_vjp_kernel(const double* __restrict__ orbit_in,
-                                                      const double* __restrict__ ld_in, int64_t n_draw,
-                                                      int n_planet, uint32_t flags,
+// gscale (optional, per draw): the record cotangents are multiplied by it as they are read -- the chain rule through
+// a per-draw scalar (L[d] = sum_n gbar[d, n] flux[d, n], cotangent gL[d]) without a pass of its own
+template <class Src, class Dst>
+__global__ __launch_bounds__(64) void pack_vjp_kernel(Src src, int64_t n_draw, int n_planet, uint32_t flags,
                                                       const double* __restrict__ gparams,
                                                       const double* __restrict__ gld,
-                                                      double* __restrict__ gorbit_in, double* __restrict__ gld_in) {
+                                                      const double* __restrict__ gscale, Dst dst) {
   const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
   const bool circular = flags & EXO_PACK_CIRCULAR, secondary = flags & EXO_FLAG_SECONDARY;
   if (i < n_draw * n_planet) {
-    const double* in = orbit_in + i * EXO_NIN;
-    const double* g = gparams + i * EXO_NPAR;
-    double* o = gorbit_in + i * EXO_NIN;
+    double in[EXO_NIN], g[EXO_NPAR], o[EXO_NIN];
+    src.load(i, i / n_planet, (int)(i % n_planet), in);
+    const double sc = gscale ? gscale[i / n_planet] : 1.0;
+#pragma unroll
+    for (int k = 0; k < EXO_NPAR; ++k) g[k] = sc * gparams[i * EXO_NPAR + k];
     const Derived d = derive(in, circular);
     const double e = circular ? 0.0 : in[EXO_IN_ECC];
     const double P = in[EXO_IN_PERIOD], Rs = in[EXO_IN_RSTAR], r = in[EXO_IN_R], b = in[EXO_IN_B];
@@ -203,18 +244,21 @@ __global__ __launch_bounds__(64) void pack_vjp_kernel(const double* __restrict__
     Msb += ab * d.a / (3.0 * d.mtot);
     o[EXO_IN_PERIOD] = Pb; o[EXO_IN_T0] = t0b; o[EXO_IN_B] = bb; o[EXO_IN_ECC] = eb; o[EXO_IN_OMEGA] = wb;
     o[EXO_IN_R] = rb; o[EXO_IN_MSTAR] = Msb; o[EXO_IN_RSTAR] = Rsb; o[EXO_IN_MPLANET] = Msb;
+#pragma unroll
+    for (int k = 0; k < EXO_NIN; ++k) dst.store(i, k, o[k]);
   }
   if (i < n_draw) {
     const int nset = secondary ? 2 : 1;
+    const double sc = gscale ? gscale[i] : 1.0;
     for (int s = 0; s < nset; ++s) {
-      const double u1 = ld_in[i * 2 * nset + 2 * s], u2 = ld_in[i * 2 * nset + 2 * s + 1];
-      const double* g = gld + i * 3 * nset + 3 * s;
+      const double u1 = src.ld(i, 2 * s, 2 * nset), u2 = src.ld(i, 2 * s + 1, 2 * nset);
+      const double g[3] = {sc * gld[i * 3 * nset + 3 * s], sc * gld[i * 3 * nset + 3 * s + 1], sc * gld[i * 3 * nset + 3 * s + 2]};
       const double c0 = 1.0 - u1 - 1.5 * u2, c1 = u1 + 2.0 * u2, c2 = -0.25 * u2;
       const double nrm = kPi * (c0 + c1 * (1.0 / 1.5)), inorm = 1.0 / nrm;
       // c_k = C_k / nrm :  dC/du1 = (-1, 1, 0), dC/du2 = (-1.5, 2, -0.25), dnrm/du1 = pi(-1 + 2/3), dnrm/du2 = pi(-1.5 + 4/3)
       const double dot = (g[0] * c0 + g[1] * c1 + g[2] * c2) * inorm * inorm;
-      gld_in[i * 2 * nset + 2 * s] = (-g[0] + g[1]) * inorm - dot * kPi * (-1.0 + 2.0 / 3.0);
-      gld_in[i * 2 * nset + 2 * s + 1] = (-1.5 * g[0] + 2.0 * g[1] - 0.25 * g[2]) * inorm - dot * kPi * (-1.5 + 4.0 / 3.0);
+      dst.store_ld(i, 2 * s, 2 * nset, (-g[0] + g[1]) * inorm - dot * kPi * (-1.0 + 2.0 / 3.0));
+      dst.store_ld(i, 2 * s + 1, 2 * nset, (-1.5 * g[0] + 2.0 * g[1] - 0.25 * g[2]) * inorm - dot * kPi * (-1.5 + 4.0 / 3.0));
     }
   }
 }
@@ -231,8 +275,8 @@ int exo_pack_records_f64(const double* orbit_in, const double* ld_in, int64_t n_
   if (n_draw == 0) return EXO_OK;
   if (!orbit_in || !ld_in || !params || !ld) return EXO_ERR_INVALID_ARGUMENT;
   const int64_t n = n_draw * n_planet;
-  hipLaunchKernelGGL(pack_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, (hipStream_t)stream, orbit_in, ld_in,
-                     n_draw, n_planet, flags, params, ld);
+  hipLaunchKernelGGL(pack_kernel<PackedSrc>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, (hipStream_t)stream,
+                     PackedSrc{orbit_in, ld_in}, n_draw, n_planet, flags, params, ld);
   return launch_status();
 }
 
@@ -243,8 +287,60 @@ int exo_pack_records_vjp_f64(const double* orbit_in, const double* ld_in, int64_
   if (n_draw == 0) return EXO_OK;
   if (!orbit_in || !ld_in || !gparams || !gld || !gorbit_in || !gld_in) return EXO_ERR_INVALID_ARGUMENT;
   const int64_t n = n_draw * n_planet;
-  hipLaunchKernelGGL(pack_vjp_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, (hipStream_t)stream, orbit_in,
-                     ld_in, n_draw, n_planet, flags, gparams, gld, gorbit_in, gld_in);
+  hipLaunchKernelGGL((pack_vjp_kernel<PackedSrc, PackedDst>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0,
+                     (hipStream_t)stream, PackedSrc{orbit_in, ld_in}, n_draw, n_planet, flags, gparams, gld,
+                     (const double*)nullptr, PackedDst{gorbit_in, gld_in});
+  return launch_status();
+}
+
+static bool cols_src(const double* const* cols, const int64_t* draw_stride, const int64_t* planet_stride,
+                     const double* defaults, const double* const* ld_cols, const int64_t* ld_draw_stride, uint32_t flags,
+                     ColsSrc* s) {
+  if (!cols || !draw_stride || !planet_stride || !defaults || !ld_cols || !ld_draw_stride) return false;
+  for (int k = 0; k < EXO_NIN; ++k) {
+    s->ptr[k] = cols[k]; s->ds[k] = draw_stride[k]; s->ps[k] = planet_stride[k]; s->def[k] = defaults[k];
+  }
+  const int nld = (flags & EXO_FLAG_SECONDARY) ? 4 : 2;
+  for (int k = 0; k < 4; ++k) {
+    s->ldp[k] = k < nld ? ld_cols[k] : nullptr;
+    s->lds[k] = k < nld ? ld_draw_stride[k] : 0;
+    if (k < nld && !ld_cols[k]) return false;
+  }
+  return true;
+}
+
+int exo_pack_records_cols_f64(const double* const* cols, const int64_t* draw_stride, const int64_t* planet_stride,
+                              const double* defaults, const double* const* ld_cols, const int64_t* ld_draw_stride,
+                              int64_t n_draw, int32_t n_planet, uint32_t flags, double* params, double* ld, void* stream) {
+  if (n_draw < 0 || n_planet < 1 || n_planet > EXO_MAX_PLANETS) return EXO_ERR_INVALID_ARGUMENT;
+  if (n_draw == 0) return EXO_OK;
+  ColsSrc src;
+  if (!params || !ld || !cols_src(cols, draw_stride, planet_stride, defaults, ld_cols, ld_draw_stride, flags, &src))
+    return EXO_ERR_INVALID_ARGUMENT;
+  const int64_t n = n_draw * n_planet;
+  hipLaunchKernelGGL(pack_kernel<ColsSrc>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, (hipStream_t)stream, src, n_draw,
+                     n_planet, flags, params, ld);
+  return launch_status();
+}
+
+int exo_pack_records_cols_vjp_f64(const double* const* cols, const int64_t* draw_stride, const int64_t* planet_stride,
+                                  const double* defaults, const double* const* ld_cols, const int64_t* ld_draw_stride,
+                                  int64_t n_draw, int32_t n_planet, uint32_t flags, const double* gparams,
+                                  const double* gld, const double* gscale, double* const* gcols, double* const* gld_cols,
+                                  void* stream) {
+  if (n_draw < 0 || n_planet < 1 || n_planet > EXO_MAX_PLANETS) return EXO_ERR_INVALID_ARGUMENT;
+  if (n_draw == 0) return EXO_OK;
+  ColsSrc src;
+  if (!gparams || !gld || !gcols || !gld_cols ||
+      !cols_src(cols, draw_stride, planet_stride, defaults, ld_cols, ld_draw_stride, flags, &src))
+    return EXO_ERR_INVALID_ARGUMENT;
+  ColsDst dst;
+  for (int k = 0; k < EXO_NIN; ++k) dst.ptr[k] = gcols[k];
+  const int nld = (flags & EXO_FLAG_SECONDARY) ? 4 : 2;
+  for (int k = 0; k < 4; ++k) dst.ldp[k] = k < nld ? gld_cols[k] : nullptr;
+  const int64_t n = n_draw * n_planet;
+  hipLaunchKernelGGL((pack_vjp_kernel<ColsSrc, ColsDst>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0,
+                     (hipStream_t)stream, src, n_draw, n_planet, flags, gparams, gld, gscale, dst);
   return launch_status();
 }
 

@@ -2020,7 +2020,7 @@ inline bool transit_args_ok(int64_t n_cad, int64_t n_texp, int32_t n_sub, int64_
 
 extern "C" {
 
-int32_t exo_abi_version(void) { return 7; }
+int32_t exo_abi_version(void) { return 8; }
 
 int exo_kepler_f64(const double* M, const double* ecc, double* sinf, double* cosf, int64_t n, void* stream) {
   if (n < 0 || (n > 0 && (!M || !ecc || !sinf || !cosf))) return EXO_ERR_INVALID_ARGUMENT;

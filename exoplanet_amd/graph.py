@@ -10,7 +10,11 @@ Requirements (those of torch.cuda.graphs): every tensor ``fn`` touches lives on 
 already (Python scalars are fine: they become fill kernels), shapes never change, and
 ``fn`` does no host synchronisation (no ``.item()``, no data-dependent Python branches).
 The exoplanet_amd ops satisfy this: they launch on the current stream and take their
-scratch from torch's allocator.
+scratch from torch's allocator.  One more, when ``fn`` differentiates with respect to the inputs:
+no autograd graph built from the same leaves OUTSIDE the capture may still be alive (e.g. a
+non-detached result of an eager call of ``fn``) -- the engine would synchronise with the stream that
+graph was built on, which a capturing stream cannot do (on ROCm 7.2 that ends the capture with a crash,
+not an error): detach what you keep.
 """
 import torch
 

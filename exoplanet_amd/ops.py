@@ -528,6 +528,138 @@ class _PackRecords(torch.autograd.Function):
         return go, gl, None
 
 
+class _OrbitFluxDot(torch.autograd.Function):
+    """Record packing (column form: every constructor argument its own tensor), the one-sweep value + VJP light
+    curve, and -- backward -- the packing VJP with the cotangent of L folded in (``gscale``): the whole
+    user-level step of a standard-parameterisation orbit is the sweep plus TWO small kernels, where the
+    composition pack_records -> transit_flux_dot costs seven (two concatenations, the pack, two scalings of
+    the saved cotangents, the pack VJP, and whatever produced the cotangent of L)."""
+
+    @staticmethod
+    def forward(ctx, t, gflux, texp, stencil_dt, stencil_w, flags, pack_flags, events, n_ld, *cols):
+        import ctypes
+
+        t = _dev(t, "t")
+        ocols, lcols = list(cols[:NIN]), list(cols[NIN:NIN + n_ld])
+        D = P = 1
+        for c in ocols:
+            if c is not None:
+                if c.dim() > 2:
+                    raise ValueError("orbit parameters may carry at most one draw dimension here")
+                P = max(P, c.shape[-1] if c.dim() >= 1 else 1)
+                D = max(D, c.shape[0] if c.dim() == 2 else 1)
+        for c in lcols:
+            if c.dim() > 1:
+                raise ValueError("limb-darkening coefficients may carry at most one draw dimension")
+            D = max(D, c.shape[0] if c.dim() == 1 else 1)
+        vp, i64 = ctypes.c_void_p, ctypes.c_int64
+        cp, ds, ps, df = (vp * NIN)(), (i64 * NIN)(), (i64 * NIN)(), (ctypes.c_double * NIN)(*_PACK_DEFAULTS)
+        keep = []
+        for k, c in enumerate(ocols):
+            if c is None:
+                continue
+            c = _dev(c.detach(), "orbit parameter")
+            v = c.reshape(1, 1) if c.dim() == 0 else (c.unsqueeze(0) if c.dim() == 1 else c)
+            v = v.expand(D, P)
+            keep.append(v)
+            cp[k], ds[k], ps[k] = v.data_ptr(), v.stride(0), v.stride(1)
+        lp, ls = (vp * 4)(), (i64 * 4)()
+        for k, c in enumerate(lcols):
+            c = _dev(c.detach(), "limb-darkening coefficient")
+            v = (c.reshape(1) if c.dim() == 0 else c).expand(D)
+            keep.append(v)
+            lp[k], ls[k] = v.data_ptr(), v.stride(0)
+        nset = n_ld // 2
+        params = torch.empty(D, P, NPAR, dtype=torch.float64, device=t.device)
+        ld = torch.empty(D, 3 * nset, dtype=torch.float64, device=t.device)
+        lib = _lib.load()
+        with torch.cuda.device(t.device):
+            _lib.check(lib.exo_pack_records_cols_f64(cp, ds, ps, df, lp, ls, D, P, pack_flags, _ptr(params), _ptr(ld),
+                                                     _stream(t)), "exo_pack_records_cols_f64")
+        t_, texp_, n_texp, sdt, sw, n_sub, params, ld, D, P = _transit_args(t, texp, stencil_dt, stencil_w, params, ld, flags)
+        flux, gparams, gld, dot, _ = _vjp(t_, texp_, n_texp, sdt, sw, n_sub, params, ld, D, P, flags, gflux, True, events)
+        ctx.save_for_backward(gparams, gld, *keep)
+        ctx.meta = (D, P, pack_flags, n_ld, [c is not None for c in ocols], [None if c is None else tuple(c.shape) for c in cols])
+        ctx.set_materialize_grads(False)
+        if isinstance(flux, SparseFlux):
+            _OrbitFluxDot._sparse = flux
+            return torch.empty(0, dtype=torch.float64, device=dot.device), dot
+        ctx.mark_non_differentiable(flux)
+        return flux, dot
+
+    @staticmethod
+    def backward(ctx, _gflux_unused, gdot):
+        import ctypes
+
+        D, P, pack_flags, n_ld, present, shapes = ctx.meta
+        nfix = 9
+        if gdot is None:
+            return (None,) * (nfix + len(shapes))
+        gparams, gld, *keep = ctx.saved_tensors
+        vp, i64 = ctypes.c_void_p, ctypes.c_int64
+        cp, ds, ps, df = (vp * NIN)(), (i64 * NIN)(), (i64 * NIN)(), (ctypes.c_double * NIN)(*_PACK_DEFAULTS)
+        it = iter(keep)
+        for k in range(NIN):
+            if present[k]:
+                v = next(it)
+                cp[k], ds[k], ps[k] = v.data_ptr(), v.stride(0), v.stride(1)
+        lp, ls = (vp * 4)(), (i64 * 4)()
+        for k in range(n_ld):
+            v = next(it)
+            lp[k], ls[k] = v.data_ptr(), v.stride(0)
+        dev = gparams.device
+        gcp, glp = (vp * NIN)(), (vp * 4)()
+        outs = [None] * len(shapes)
+        for k in range(NIN):
+            if present[k] and ctx.needs_input_grad[nfix + k]:
+                outs[k] = torch.empty(D, P, dtype=torch.float64, device=dev)
+                gcp[k] = outs[k].data_ptr()
+        for k in range(n_ld):
+            if ctx.needs_input_grad[nfix + NIN + k]:
+                outs[NIN + k] = torch.empty(D, dtype=torch.float64, device=dev)
+                glp[k] = outs[NIN + k].data_ptr()
+        gdot = _dev(gdot, "gdot")
+        lib = _lib.load()
+        with torch.cuda.device(dev):
+            _lib.check(lib.exo_pack_records_cols_vjp_f64(cp, ds, ps, df, lp, ls, D, P, pack_flags, _ptr(gparams), _ptr(gld),
+                                                         _ptr(gdot), gcp, glp, _stream(gparams)),
+                       "exo_pack_records_cols_vjp_f64")
+        # dense (D, P) / (D,) cotangents back to the shapes the caller passed (sums over what was broadcast)
+        grads = [None if g is None else (g.reshape(shp) if g.numel() == _numel(shp) else g.sum_to_size(_bshape(shp, g.dim())).reshape(shp))
+                 for g, shp in zip(outs, shapes)]
+        return (None,) * nfix + tuple(grads)
+
+
+_PACK_DEFAULTS = (float("nan"), 0.0, 0.0, 0.0, 0.0, float("nan"), 1.0, 1.0, 0.0, 0.0)   # EXO_IN_* order; period, r: required
+
+
+def _numel(shape):
+    n = 1
+    for s in shape:
+        n *= s
+    return n
+
+
+def _bshape(shape, ndim):
+    """`shape` left-padded with ones to `ndim` dimensions (what sum_to_size reduces to)"""
+    return (1,) * (ndim - len(shape)) + tuple(shape)
+
+
+def orbit_flux_dot(t, gflux, orbit_cols, ld_cols, flags=0, pack_flags=0, texp=None, stencil_dt=None, stencil_w=None,
+                   events=(None, None)):
+    """``transit_flux_dot(t, *pack_records(stack(orbit_cols), stack(ld_cols)), gflux)`` without the stacking, the
+    intermediate autograd nodes and the separate scaling of the cotangents: ``orbit_cols`` are the EXO_IN_* inputs
+    (period, t0, b, ecc, omega, r, m_star, r_star, m_planet, sbr), each a tensor of shape (), (P,), (D, 1) or (D, P)
+    -- or None for the constructor default -- and ``ld_cols`` are (u1, u2[, u1s, u2s]) of shape () or (D,).
+    Returns ``(flux, L)`` like :func:`transit_flux_dot`; L is differentiable w.r.t. every column."""
+    out = _OrbitFluxDot.apply(t, gflux, texp, stencil_dt, stencil_w, int(flags), int(pack_flags), events, len(ld_cols),
+                              *orbit_cols, *ld_cols)
+    if int(flags) & FLAG_SPARSE:
+        sp, _OrbitFluxDot._sparse = _OrbitFluxDot._sparse, None
+        return sp, out[1]
+    return out
+
+
 def pack_records(orbit_in, ld_in, flags=0):
     """(period, t0, b, ecc, omega, r, m_star, r_star, m_planet, sbr) per (draw, planet) and
     (u1, u2[, u1s, u2s]) per draw -> kernel records (n_draw, n_planet, 20) and Green's-basis

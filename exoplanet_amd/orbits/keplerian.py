@@ -566,6 +566,36 @@ class KeplerianOrbit:
         ld = c.to(rec.device).expand(batch + (c.shape[-1],)).reshape(D, c.shape[-1])
         return rec.contiguous(), ld.contiguous(), batch, flags
 
+    def flux_dot(self, r, u, t, weights, use_in_transit=False, secondary=None, light_delay=False, texp=None,
+                 stencil=None, sparse=False, events=(None, None)):
+        """``(flux, L)`` with ``L[d] = sum_n weights[d, n] flux[d, n]``, L differentiable with respect to every
+        orbit / limb-darkening parameter: value and gradient of a light-curve likelihood whose cotangent is known
+        up front, in ONE sweep over the cadences (ops.transit_flux_dot).  For the standard parameterisation with
+        at most one draw dimension the parameter tensors go to the kernels as they are (ops.orbit_flux_dot: no
+        stacking pass, the cotangent of L folded into the packing VJP); otherwise kernel_inputs + transit_flux_dot.
+        ``stencil = (dt, w)``: exposure-time integration (limb_dark.exposure_stencil)."""
+        sdt, sw = (None, None) if stencil is None else stencil
+        flags = (ops.FLAG_WINDOW if use_in_transit else 0) | (ops.FLAG_SECONDARY if secondary is not None else 0)
+        flags |= (ops.FLAG_LIGHT_DELAY if light_delay else 0) | (ops.FLAG_SPARSE if sparse else 0)
+        if self._standard:
+            A = self._args
+            like = next((x for x in list(A.values()) + [r] if isinstance(x, torch.Tensor)), None)
+            opt = lambda x: None if x is None else _vec(x, like)  # noqa: E731
+            sbr = None
+            if secondary is not None:
+                sbr = as_tensor(secondary[1], like)
+                sbr = sbr.unsqueeze(-1) if sbr.dim() >= 1 else sbr.reshape(1)
+            cols = [opt(A["period"]), opt(A["t0"]), opt(A["b"]), opt(A["ecc"]), opt(A["omega"]), opt(r), opt(A["m_star"]),
+                    opt(A["r_star"]), opt(A["m_planet"]), sbr]
+            us = [as_tensor(x, like) for x in list(u) + (list(secondary[0]) if secondary is not None else [])]
+            if all(c is None or c.dim() <= 2 for c in cols) and all(x.dim() <= 1 for x in us):
+                pack_flags = (flags & (ops.FLAG_WINDOW | ops.FLAG_SECONDARY)) | (ops.PACK_CIRCULAR if A["ecc"] is None else 0)
+                return ops.orbit_flux_dot(t, weights, cols, us, flags=flags, pack_flags=pack_flags, texp=texp,
+                                          stencil_dt=sdt, stencil_w=sw, events=events)
+        rec, ld, _, fl = self.kernel_inputs(r, u, use_in_transit=use_in_transit, secondary=secondary, light_delay=light_delay)
+        return ops.transit_flux_dot(t, rec, ld, weights, texp=texp, stencil_dt=sdt, stencil_w=sw,
+                                    flags=fl | (ops.FLAG_SPARSE if sparse else 0), events=events)
+
     def kernel_records(self, r, use_in_transit=False, secondary_sbr=None):
         """Pack the per-(draw, planet) parameter records of the fused transit
         kernel (layout: include/exoplanet_amd.h, EXO_P_*) from the orbit's attributes, in

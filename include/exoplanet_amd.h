@@ -388,6 +388,25 @@ int exo_pack_records_f64(const double* orbit_in, const double* ld_in, int64_t n_
 int exo_pack_records_vjp_f64(const double* orbit_in, const double* ld_in, int64_t n_draw,
                              int32_t n_planet, uint32_t flags, const double* gparams,
                              const double* gld, double* gorbit_in, double* gld_in, void* stream);
+/* Column form of the two calls above, for callers whose parameters are separate arrays (one tensor per
+ * constructor argument of KeplerianOrbit): no packing pass in front, no unpacking pass behind.
+ *   cols, draw_stride, planet_stride, defaults   HOST arrays of EXO_NIN entries: input k of (draw, planet) is
+ *       cols[k][draw * draw_stride[k] + planet * planet_stride[k]]  (device memory; stride 0 = broadcast), or
+ *       defaults[k] where cols[k] is NULL (the reference's constructor defaults: m_star = r_star = 1, m_planet = 0)
+ *   ld_cols, ld_draw_stride   HOST arrays of 2 (u1, u2) or, with EXO_FLAG_SECONDARY, 4 device pointers / strides
+ * Reverse: gscale (optional, [n_draw]) multiplies the record cotangents as they are read -- the chain rule through
+ * a per-draw scalar such as L[d] = sum_n gbar[d][n] flux[d][n] without a pass of its own; gcols[k] / gld_cols[k]
+ * (HOST arrays; NULL entry = not wanted) receive the cotangents DENSELY, [n_draw][n_planet] / [n_draw] doubles each:
+ * the caller sums over whatever it broadcast.                                                                  */
+int exo_pack_records_cols_f64(const double* const* cols, const int64_t* draw_stride, const int64_t* planet_stride,
+                              const double* defaults, const double* const* ld_cols, const int64_t* ld_draw_stride,
+                              int64_t n_draw, int32_t n_planet, uint32_t flags, double* params, double* ld,
+                              void* stream);
+int exo_pack_records_cols_vjp_f64(const double* const* cols, const int64_t* draw_stride, const int64_t* planet_stride,
+                                  const double* defaults, const double* const* ld_cols, const int64_t* ld_draw_stride,
+                                  int64_t n_draw, int32_t n_planet, uint32_t flags, const double* gparams,
+                                  const double* gld, const double* gscale, double* const* gcols,
+                                  double* const* gld_cols, void* stream);
 
 #ifdef __cplusplus
 }
