@@ -1667,7 +1667,9 @@ __global__ __launch_bounds__(kBlock, EXO_HEAVY_MIN_WAVES) void transit_runs_kern
 // Last kernel of a sweep on the run-enumeration path, one block per draw: (GRAD) block partials ->
 // gparams, gld, sum(gflux * flux), in block order; (dense output) the runs' values to their cadences,
 // planet by planet (summed flux: a later planet adds to what the earlier ones left).
-__global__ __launch_bounds__(kBlock) void transit_finish_kernel(
+// (1024 threads per block for batches of at most 256 draws: the scatter of a draw's values is one block's work, and
+// with few draws the loads it keeps in flight are what bounds it -- C4 at 64 draws: 34 -> 10 us)
+__global__ __launch_bounds__(1024) void transit_finish_kernel(
     const double* __restrict__ partial, int nblk, int n_planet, bool secondary, double* __restrict__ gparams,
     double* __restrict__ gld, double* __restrict__ flux_dot, int64_t n_cad, uint32_t flags, int n_ev, RunLists rl,
     const double* __restrict__ vals, const int32_t* __restrict__ vcad, double* __restrict__ flux) {
@@ -1675,7 +1677,7 @@ __global__ __launch_bounds__(kBlock) void transit_finish_kernel(
   const int ng_draw = n_planet * kNG + 7;
   const int s = threadIdx.x;
   if (partial) {
-    for (int q = s; q < n_planet * EXO_NPAR; q += kBlock) {
+    for (int q = s; q < n_planet * EXO_NPAR; q += (int)blockDim.x) {
       // record slots that carry no gradient (T0, PERIOD, the windows, the reserved ones) read 0
       const int p = q / EXO_NPAR, slot = q % EXO_NPAR;
       const bool carried = slot == EXO_P_N || slot == EXO_P_TP || slot == EXO_P_ECC || slot == EXO_P_COSW ||
@@ -1712,12 +1714,13 @@ __global__ __launch_bounds__(kBlock) void transit_finish_kernel(
     }
     const double* __restrict__ src = vals + vbase;
     const int32_t* __restrict__ cad = vcad + vbase;
-    for (int e0 = threadIdx.x; e0 < total; e0 += 4 * kBlock) {
+    const int nthr = (int)blockDim.x;
+    for (int e0 = threadIdx.x; e0 < total; e0 += 4 * nthr) {
       double v[4];
       int i[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const int e = e0 + u * kBlock;
+        const int e = e0 + u * nthr;
         v[u] = e < total ? src[e] : 0.0;
         i[u] = e < total ? cad[e] : -1;
       }
@@ -1922,9 +1925,15 @@ inline ScanPlan scan_plan(uint32_t flags, int bpd, int64_t n_draw, int n_planet,
 }
 
 // ---- run-enumeration path -------------------------------------------------------------------------
-// heavy blocks per draw: ~1024 blocks in all
+// heavy blocks per draw.  A round of a block (256 cadences through eval_sample) takes ~8 us whatever its fill, 512
+// blocks are resident at once (two per CU), and every (planet, inside / limb) segment of a block ends in a partly
+// filled round: one generation of fuller blocks beats two generations of emptier ones (C4 at 64 draws: 11 round
+// times at 8 blocks per draw against 18 at 16).
+#ifndef EXO_RUNS_TARGET_BLOCKS
+#define EXO_RUNS_TARGET_BLOCKS 512
+#endif
 inline int runs_blocks_per_draw(int64_t n_draw) {
-  int64_t hb = (EXO_HEAVY_TARGET_BLOCKS + n_draw - 1) / n_draw;
+  int64_t hb = (EXO_RUNS_TARGET_BLOCKS + n_draw - 1) / n_draw;
   return (int)(hb < 1 ? 1 : (hb > 64 ? 64 : hb));
 }
 inline int runs_r_max(int64_t n_cad) { return (int)(n_cad < kRunMax ? (n_cad < 16 ? 16 : n_cad) : kRunMax); }
@@ -2006,7 +2015,8 @@ inline int launch_runs_sweep(const double* t, int64_t n_cad, const double* texp,
 #undef EXO_LAUNCH_RUNS
   if (launch_status() != EXO_OK) return EXO_ERR_LAUNCH;
   if (grad || fill)
-    hipLaunchKernelGGL(transit_finish_kernel, dim3((unsigned)n_draw), block, 0, st, grad ? w.partial : nullptr, w.hb,
+    hipLaunchKernelGGL(transit_finish_kernel, dim3((unsigned)n_draw), dim3(n_draw <= 256 ? 1024 : kBlock), 0, st,
+                       grad ? w.partial : nullptr, w.hb,
                        (int)n_planet, secondary, gparams, gld, flux_dot, n_cad, flags, n_ev, w.rl, vals, w.vcad, fill);
   return launch_status();
 }
