@@ -197,6 +197,32 @@ def cpu_model():
     return platform.processor() or "unknown"
 
 
+def usable_cpus():
+    """(threads this process can actually run at once, how that was decided): the affinity mask, capped by the
+    cgroup CPU quota -- the GPU boxes show 256 logical cores but grant 16 cores' worth of time (cpu.max), and 256
+    OpenMP threads on that only measure the throttling"""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    why = f"affinity mask: {n} of {os.cpu_count()} logical cores"
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]          # cgroup v2
+        quota = None if q == "max" else float(q) / float(per)
+    except (OSError, ValueError):
+        try:                                                                  # cgroup v1
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            quota = q / per if q > 0 else None
+        except (OSError, ValueError):
+            pass
+    if quota is not None and quota < n:
+        n = max(1, int(quota))
+        why = f"cgroup CPU quota: {quota:g} cores' worth of time on {os.cpu_count()} logical cores"
+    return n, why
+
+
 def cpu_baseline(budget_s=24.0):
     """oracle/c on the host cores of this box, on a bounded sample of the C2 workload:
     (i) 1 core, every cadence evaluated (what the reference does with use_in_transit=False);
@@ -213,7 +239,8 @@ def cpu_baseline(budget_s=24.0):
     except Exception:
         pass
     lib = C.lib()
-    n_threads = int(os.environ.get("EXO_BENCH_CPU_THREADS", os.cpu_count() or 1))
+    usable, usable_why = usable_cpus()
+    n_threads = int(os.environ.get("EXO_BENCH_CPU_THREADS", usable))
     rng = np.random.default_rng(2)
     t = np.arange(N_CAD) * CADENCE
     orbit = P.KeplerianOrbit(period=3.5, t0=1.0, b=0.3, ecc=0.3, omega=1.1)
@@ -268,9 +295,10 @@ def cpu_baseline(budget_s=24.0):
     return {"value": one["evals_per_s"], "unit": "evals/s", "cores": 1, "kind": "port",
             "sample": f"{one['evals']} evaluations (value+VJP, every cadence solved) of the {N_CAD}-cadence C2 "
                       f"system, oracle/c scalar port, {one['seconds']:.1f} s on 1 of {os.cpu_count()} host cores; "
-                      "legs: the same on all cores (OpenMP, one draw per thread) and with the reference's "
-                      "default in-transit selection",
-            "cpu_model": cpu_model(), "host_cores": os.cpu_count(), "legs": legs,
+                      f"legs: the same on all {n_threads} usable cores ({usable_why}; OpenMP, one draw per thread) and "
+                      "with the reference's default in-transit selection",
+            "cpu_model": cpu_model(), "host_cores": os.cpu_count(), "usable_cores": usable, "usable_cores_from": usable_why,
+            "legs": legs,
             "note": "the reference's own Ops (exoplanet_core, celerite2) are not installable here: kind = port"}
 
 

@@ -446,6 +446,8 @@ def transit_flux_sparse(t, params, ld, gflux=None, texp=None, stencil_dt=None, s
 # radial velocity
 # ------------------------------------------------------------------------------
 RV_NPAR = 6
+OV_NPAR = 10          # include/exoplanet_amd.h EXO_OV_*
+OV_VELOCITY = 1
 RV_N, RV_TP, RV_ECC, RV_COSW, RV_SINW, RV_AMP = range(6)
 
 
@@ -478,6 +480,46 @@ class _RadialVelocity(torch.autograd.Function):
             _lib.check(lib.exo_radial_velocity_vjp_f64(_ptr(t), t.numel(), _ptr(params), D, P, _ptr(grv),
                                                        _ptr(gparams), _stream(t)), "exo_radial_velocity_vjp_f64")
         return None, gparams
+
+
+class _OrbitVector(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, t, params, flags):
+        t = _dev(t, "t")
+        params = _dev(params, "params")
+        if t.dim() != 1:
+            raise ValueError("t must be 1-D (n_cad,)")
+        if params.dim() != 3 or params.shape[-1] != OV_NPAR:
+            raise ValueError(f"params must be (n_draw, n_planet, {OV_NPAR})")
+        D, P, _ = params.shape
+        out = torch.empty(D, t.numel(), P, 3, dtype=torch.float64, device=t.device)
+        lib = _lib.load()
+        with torch.cuda.device(t.device):
+            _lib.check(lib.exo_orbit_vector_fwd_f64(_ptr(t), t.numel(), _ptr(params), D, P, flags, _ptr(out), _stream(t)),
+                       "exo_orbit_vector_fwd_f64")
+        ctx.save_for_backward(t, params)
+        ctx.flags = flags
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        t, params = ctx.saved_tensors
+        D, P, _ = params.shape
+        gout = _dev(gout, "gout")
+        gparams = torch.empty_like(params)
+        lib = _lib.load()
+        with torch.cuda.device(t.device):
+            _lib.check(lib.exo_orbit_vector_vjp_f64(_ptr(t), t.numel(), _ptr(params), D, P, ctx.flags, _ptr(gout),
+                                                    _ptr(gparams), _stream(t)), "exo_orbit_vector_vjp_f64")
+        return None, gparams, None
+
+
+def orbit_vector(t, params, velocity=False):
+    """Position (or, ``velocity=True``, velocity) vectors in the observer frame for ``n_draw`` parameter sets, one
+    fused launch each way: t (n_cad,), params (n_draw, n_planet, 10) with slots EXO_OV_* (n, t_periastron, ecc,
+    cos / sin omega, cos / sin incl, amplitude, cos / sin Omega) -> (n_draw, n_cad, n_planet, 3) = (X, Y, Z).
+    Differentiable with respect to ``params``.  (keplerian.py:380-409, :572-578, :283-322)"""
+    return _OrbitVector.apply(t, params, OV_VELOCITY if velocity else 0)
 
 
 def radial_velocity(t, params):

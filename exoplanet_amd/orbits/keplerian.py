@@ -319,9 +319,32 @@ class KeplerianOrbit:
         e = self.ecc.unsqueeze(-2) + torch.zeros_like(M)
         return ops.kepler(M.contiguous(), e.contiguous())
 
+    def _fused_vector(self, amp, t, velocity):
+        """(X, Y, Z) through ops.orbit_vector -- one launch each way instead of the solve, the radius, three
+        rotations and their broadcasts as ~40 launch-bound torch kernels -- or None when the times are not a
+        1-D device tensor / the orbit warps its times (TTV-type subclasses take the composed path)."""
+        if type(self)._warp_times is not KeplerianOrbit._warp_times:
+            return None
+        if not (isinstance(t, torch.Tensor) and t.dim() == 1 and t.is_cuda and t.dtype == torch.float64):
+            return None
+        e, cw, sw = self._ew()
+        one, zero = torch.ones_like(self.n), torch.zeros_like(self.n)
+        cO, sO = (one, zero) if self.Omega is None else (self.cos_Omega, self.sin_Omega)
+        cols = torch.broadcast_tensors(self.n, self.t_periastron, e, cw, sw, self.cos_incl, self.sin_incl, amp, cO, sO)
+        shape = cols[0].shape
+        params = torch.stack(cols, dim=-1).reshape(-1, shape[-1], ops.OV_NPAR).contiguous()
+        out = ops.orbit_vector(t, params, velocity=velocity)
+        out = out.reshape(tuple(shape[:-1]) + (t.shape[0], shape[-1], 3))
+        return out[..., 0], out[..., 1], out[..., 2]
+
     def _get_position(self, a, t, parallax=None, light_delay=False, _pad=True):
         if light_delay:
             return self._get_retarded_position(a, t, parallax=None, _pad=_pad)
+        if _pad:
+            amp = a if parallax is None else a * parallax * au_per_R_sun
+            fused = self._fused_vector(amp, t, velocity=False)
+            if fused is not None:
+                return fused
         sinf, cosf = self._get_true_anomaly(t, _pad=_pad)
         a = a.unsqueeze(-2)
         if self.ecc is None:
@@ -379,6 +402,9 @@ class KeplerianOrbit:
 
     # ------------------------------------------------------------------ velocities ("next" row f-3)
     def _get_velocity(self, m, t):
+        fused = self._fused_vector(self.K0 * m, t, velocity=True)
+        if fused is not None:
+            return fused
         sinf, cosf = self._get_true_anomaly(t)
         K = (self.K0 * m).unsqueeze(-2)
         if self.ecc is None:
@@ -403,7 +429,7 @@ class KeplerianOrbit:
         t = as_tensor(t, next((x for x in self._args.values() if isinstance(x, torch.Tensor)), None))
         if type(self)._warp_times is KeplerianOrbit._warp_times and t.dim() == 1 and t.is_cuda:
             # one fused launch (and one for the reverse pass): amplitude x (cos w cos f - sin w sin f + e cos w)
-            # with the caller's K, or -- the z-velocity of the star written out (keplerian.py:599-606 through
+            # with the caller's K, or -- the z-velocity of the star written out (keplerian.py:572-578 through
             # :283-322) -- conv sin(incl) K0 m_planet
             if K is not None and self._standard and not self._ready:
                 # standard parameterisation: (n, t_periastron, e, cos w, sin w) straight from the record-

@@ -237,7 +237,7 @@ int exo_transit_flux_ttv_vjp_f64(const double* t, int64_t n_cad, const double* t
  * for n_draw parameter sets:   rv[d][n][p] = AMP (COSW cos f - SINW sin f + ECC COSW),
  * f the true anomaly at mean anomaly (t_n - TP) N.  Per-(draw, planet) record, EXO_RV_NPAR
  * doubles; AMP is the caller's K (keplerian.py:660-669; ECC = 0, COSW = 1, SINW = 0 for a
- * circular orbit, :658-659) or, for the mass-based form (:671-676, with :599-606 and :283-322),
+ * circular orbit, :658-659) or, for the mass-based form (:671-676, with :572-578 and :283-322),
  * conv sin(incl) K0 m_planet.  rv / grv are [n_draw][n_cad][n_planet] (the reference returns
  * one column per planet); gparams [n_draw][n_planet][EXO_RV_NPAR].
  * ------------------------------------------------------------------------- */
@@ -252,6 +252,37 @@ int exo_radial_velocity_fwd_f64(const double* t, int64_t n_cad, const double* pa
                                 int32_t n_planet, double* rv, void* stream);
 int exo_radial_velocity_vjp_f64(const double* t, int64_t n_cad, const double* params, int64_t n_draw,
                                 int32_t n_planet, const double* grv, double* gparams, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * Position / velocity vectors in the observer frame from the same solve.  Replaces, for n_draw parameter sets, the
+ * sub-graph behind
+ *   KeplerianOrbit.get_{star,planet,relative}_position   (src/exoplanet/orbits/keplerian.py:472-542 -> :380-409)
+ *   KeplerianOrbit.get_{star,planet,relative}_velocity   (keplerian.py:580-631 -> :572-578)
+ *   KeplerianOrbit.get_relative_angles                   (keplerian.py:544-570: rho, theta from X, Y)
+ * In the orbital plane  position: (u, v) = (1 - e^2) / (1 + e cos f) (cos f, sin f);  with EXO_OV_VELOCITY:
+ * (u, v) = (-sin f, cos f + e);  then _rotate_vector (keplerian.py:283-322) and the amplitude:
+ *   x1 = COSW u - SINW v, y1 = SINW u + COSW v;  x2 = x1, y2 = COSI y1, Z = -SINI y1;
+ *   X = COSO x2 - SINO y2, Y = SINO x2 + COSO y2;   out[d][n][p] = AMP (X, Y, Z)
+ * AMP: a_star / a_planet / -a (times parallax au_per_R_sun, keplerian.py:404-406) for positions, K0 m for velocities;
+ * COSO = 1, SINO = 0 when the orbit has no Omega; ECC = 0, COSW = 1, SINW = 0 when circular.
+ * out / gout [n_draw][n_cad][n_planet][3]; params / gparams [n_draw][n_planet][EXO_OV_NPAR].
+ * ------------------------------------------------------------------------- */
+#define EXO_OV_NPAR 10
+#define EXO_OV_N 0
+#define EXO_OV_TP 1
+#define EXO_OV_ECC 2    /* NaN result outside [0, 1) */
+#define EXO_OV_COSW 3
+#define EXO_OV_SINW 4
+#define EXO_OV_COSI 5
+#define EXO_OV_SINI 6
+#define EXO_OV_AMP 7
+#define EXO_OV_COSO 8
+#define EXO_OV_SINO 9
+#define EXO_OV_VELOCITY 1u
+int exo_orbit_vector_fwd_f64(const double* t, int64_t n_cad, const double* params, int64_t n_draw, int32_t n_planet,
+                             uint32_t flags, double* out, void* stream);
+int exo_orbit_vector_vjp_f64(const double* t, int64_t n_cad, const double* params, int64_t n_draw, int32_t n_planet,
+                             uint32_t flags, const double* gout, double* gparams, void* stream);
 
 /* ---------------------------------------------------------------------------
  * celerite GP log-likelihood, value + VJP, for n_draw independent (kernel,

@@ -407,6 +407,7 @@ class KeplerianOrbit:
         self.n = 2 * np.pi / period                                   # :146
         self.a_star = a * m_planet / self.m_total                     # :147
         self.a_planet = -a * m_star / self.m_total                    # :148
+        self.K0 = self.n * a / self.m_total                           # :172 (divided by sqrt(1 - e^2) below, :213)
         self.Omega = A(Omega)
         if ecc is None:                                               # :182-185
             self.ecc = None
@@ -424,6 +425,7 @@ class KeplerianOrbit:
                                 np.sqrt(1 + self.ecc) * opsw)
             self.M0 = E0 - self.ecc * np.sin(E0)
             ome2 = 1 - self.ecc ** 2
+            self.K0 = self.K0 / np.sqrt(ome2)                         # :213
             incl_factor = (1 + self.ecc * self.sin_omega) / ome2
         self.dcosidb = incl_factor * self.r_star / self.a             # :217-219
         if b is not None:                                             # :221-228
@@ -515,7 +517,7 @@ class KeplerianOrbit:
             return np.sin(M), np.cos(M)
         return kepler(M, self.ecc + np.zeros_like(M))
 
-    def _get_position(self, a, t, light_delay=False, _pad=True):
+    def _get_position(self, a, t, light_delay=False, _pad=True, parallax=None):
         """reference: keplerian.py:380-409 (and :411-470 for light_delay)"""
         t = np.asarray(t, dtype=np.float64)
         if light_delay:
@@ -525,6 +527,8 @@ class KeplerianOrbit:
             r = a
         else:
             r = a * (1.0 - self.ecc ** 2) / (1 + self.ecc * cosf)
+        if parallax is not None:                                      # :404-406
+            r = r * parallax * au_per_R_sun
         return self._rotate_vector(r * cosf, r * sinf)
 
     def _get_retarded_position(self, a, t, z0=0.0, _pad=True):
@@ -555,6 +559,39 @@ class KeplerianOrbit:
     def get_relative_position(self, t, light_delay=False):
         """reference: keplerian.py:517-542"""
         return tuple(np.squeeze(x) for x in self._get_position(-self.a, t, light_delay=light_delay))
+
+    def get_planet_position(self, t, parallax=None):
+        """reference: keplerian.py:472-490"""
+        return tuple(np.squeeze(x) for x in self._get_position(self.a_planet, t, parallax=parallax))
+
+    def get_star_position(self, t, parallax=None):
+        """reference: keplerian.py:492-515"""
+        return tuple(np.squeeze(x) for x in self._get_position(self.a_star, t, parallax=parallax))
+
+    def get_relative_angles(self, t, parallax=None):
+        """reference: keplerian.py:544-570"""
+        X, Y, Z = self._get_position(-self.a, t, parallax=parallax)
+        return np.squeeze(np.sqrt(X ** 2 + Y ** 2)), np.squeeze(np.arctan2(Y, X))
+
+    def _get_velocity(self, m, t):
+        """reference: keplerian.py:572-578"""
+        sinf, cosf = self._get_true_anomaly(np.asarray(t, dtype=np.float64))
+        K = self.K0 * m
+        if self.ecc is None:
+            return self._rotate_vector(-K * sinf, K * cosf)
+        return self._rotate_vector(-K * sinf, K * (cosf + self.ecc))
+
+    def get_planet_velocity(self, t):
+        """reference: keplerian.py:580-593"""
+        return tuple(np.squeeze(x) for x in self._get_velocity(-self.m_star, t))
+
+    def get_star_velocity(self, t):
+        """reference: keplerian.py:595-612"""
+        return tuple(np.squeeze(x) for x in self._get_velocity(self.m_planet, t))
+
+    def get_relative_velocity(self, t):
+        """reference: keplerian.py:614-631"""
+        return tuple(np.squeeze(x) for x in self._get_velocity(-self.m_total, t))
 
     def in_transit(self, t, r=0.0, texp=None):
         """reference: keplerian.py:708-777"""
@@ -976,7 +1013,7 @@ RV_N, RV_TP, RV_ECC, RV_COSW, RV_SINW, RV_AMP = range(6)
 
 def radial_velocity(t, params, jac=False):
     """rv [D, N, P] = amp (cos w cos f - sin w sin f + e cos w) (keplerian.py:660-669; the mass-based
-    form :671-676 is the same function of f with amp = conv sin(i) K0 m_planet, from :599-606 and
+    form :671-676 is the same function of f with amp = conv sin(i) K0 m_planet, from :572-578 and
     :283-322).  params [D, P, 6] = (n, t_periastron, e, cos w, sin w, amp).  With jac: also
     d rv / d params [D, N, P, 6]."""
     t = np.asarray(t, dtype=np.float64)

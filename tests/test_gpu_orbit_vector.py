@@ -1,0 +1,98 @@
+"""GPU: the fused position / velocity op (exo_orbit_vector_*; keplerian.py:380-409, :572-578, :283-322) against the
+numpy restatement of the reference (values) and against the composed torch path it replaces (gradients of every
+orbit parameter), through the public KeplerianOrbit methods: get_{star,planet,relative}_{position,velocity},
+get_relative_angles."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import numpy_port as P
+
+pytestmark = pytest.mark.gpu
+
+BASE = dict(period=np.array([3.5, 17.9]), t0=np.array([1.0, 2.3]), incl=np.array([1.45, 1.2]), ecc=np.array([0.3, 0.7]),
+            omega=np.array([1.1, -2.4]), Omega=np.array([0.4, 2.9]), m_planet=np.array([1e-3, 3e-4]), m_star=1.1, r_star=0.9)
+
+
+def _orbits(dev, D, rng, circular=False, with_Omega=True):
+    """(torch orbit with leaves carrying a draw dimension, list of numpy orbits per draw, leaves)"""
+    import exoplanet_amd as xo
+
+    kw_np = []
+    leaves = {}
+    names = ["period", "t0", "incl", "m_planet"] + ([] if circular else ["ecc", "omega"]) + (["Omega"] if with_Omega else [])
+    vals = {k: BASE[k][None, :] * (1 + 1e-2 * rng.normal(size=(D, 2))) for k in names}
+    for d in range(D):
+        kw = {k: vals[k][d] for k in names}
+        kw_np.append(P.KeplerianOrbit(m_star=BASE["m_star"], r_star=BASE["r_star"], **kw))
+    for k in names:
+        leaves[k] = torch.tensor(vals[k], dtype=torch.float64, device=dev, requires_grad=True)
+    make = lambda: xo.KeplerianOrbit(m_star=BASE["m_star"], r_star=BASE["r_star"], **leaves)  # noqa: E731
+    return make, kw_np, leaves
+
+
+METHODS = ["get_star_position", "get_planet_position", "get_relative_position", "get_star_velocity",
+           "get_planet_velocity", "get_relative_velocity"]
+
+
+@pytest.mark.parametrize("circular,with_Omega", [(False, True), (False, False), (True, True)])
+def test_vectors_match_numpy_port_and_composed_gradients(circular, with_Omega):
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(31)
+    D, N = 3, 257
+    tn = np.sort(rng.uniform(-5.0, 60.0, N))
+    t = torch.tensor(tn, dtype=torch.float64, device=dev)
+    make, np_orbits, leaves = _orbits(dev, D, rng, circular, with_Omega)
+    for name in METHODS:
+        fused = getattr(make(), name)(t)
+        composed_orbit = make()
+        composed_orbit._fused_vector = lambda *a, **k: None      # the torch path the op replaces
+        composed = getattr(composed_orbit, name)(t)
+        w = [torch.randn_like(x) for x in fused]
+        for k in range(3):
+            for d in range(D):
+                want = getattr(np_orbits[d], name)(tn)[k]
+                got = fused[k][d].detach().cpu().numpy()
+                scale = np.abs(want).max()
+                assert np.abs(got - want).max() <= 2e-13 * scale, (name, k, d)
+        gf = torch.autograd.grad(sum((a * b).sum() for a, b in zip(fused, w)), list(leaves.values()))
+        gc = torch.autograd.grad(sum((a * b).sum() for a, b in zip(composed, w)), list(leaves.values()))
+        for key, a, b in zip(leaves, gf, gc):
+            assert float((a - b).abs().max()) <= 1e-10 * float(b.abs().max()) + 1e-300, (name, key)
+
+
+def test_relative_angles_and_parallax():
+    """astrometry (keplerian.py:544-570): separation and position angle in arcseconds with a parallax"""
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(32)
+    D, N = 2, 64
+    tn = np.sort(rng.uniform(0.0, 400.0, N))
+    t = torch.tensor(tn, dtype=torch.float64, device=dev)
+    make, np_orbits, leaves = _orbits(dev, D, rng)
+    plx = 0.027
+    rho, theta = make().get_relative_angles(t, parallax=plx)
+    for d in range(D):
+        wr, wt = np_orbits[d].get_relative_angles(tn, parallax=plx)
+        assert np.abs(rho[d].detach().cpu().numpy() - wr).max() <= 2e-13 * np.abs(wr).max()
+        dth = np.angle(np.exp(1j * (theta[d].detach().cpu().numpy() - wt)))
+        assert np.abs(dth).max() <= 1e-12
+    g = torch.autograd.grad(rho.sum() + theta.cos().sum(), list(leaves.values()))
+    assert all(torch.isfinite(x).all() for x in g)
+
+
+def test_op_level_contract():
+    """NaN outside 0 <= e < 1 (the Kepler op's contract), shapes, empty batches, argument checks"""
+    from exoplanet_amd import ops
+
+    dev = torch.device("cuda:0")
+    t = torch.linspace(0, 10, 50, dtype=torch.float64, device=dev)
+    rec = torch.tensor([[[2.0, 0.3, 0.2, 0.8, 0.6, 0.1, 0.99, 10.0, 1.0, 0.0],
+                         [2.0, 0.3, 1.2, 0.8, 0.6, 0.1, 0.99, 10.0, 1.0, 0.0]]], dtype=torch.float64, device=dev)
+    out = ops.orbit_vector(t, rec)
+    assert out.shape == (1, 50, 2, 3)
+    assert torch.isfinite(out[:, :, 0]).all() and torch.isnan(out[:, :, 1]).all()
+    assert ops.orbit_vector(t, rec[:0]).shape == (0, 50, 2, 3)
+    with pytest.raises(ValueError):
+        ops.orbit_vector(t, rec[..., :6])
+    with pytest.raises(ValueError):
+        ops.orbit_vector(t[None], rec)

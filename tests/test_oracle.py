@@ -330,3 +330,28 @@ def test_radial_velocity_is_minus_the_stars_z_velocity():
         dn[0, :, k] -= step
         fd = (P.radial_velocity(t, up) - P.radial_velocity(t, dn)) / (2 * step)
         np.testing.assert_allclose(J[..., k], fd, rtol=1e-5, atol=1e-6 * np.abs(fd).max())
+
+
+def test_oracle_velocities_are_time_derivatives_of_positions():
+    """the property the reference's own test asserts (tests/orbits/keplerian_test.py:91-131, same system): star, planet
+    and relative velocities equal d(position)/dt -- here by central differences of the numpy restatement; plus
+    get_relative_angles = polar form of the sky-plane relative position (keplerian.py:544-570)"""
+    t = np.linspace(0, 100, 1000)
+    orbit = P.KeplerianOrbit(m_star=1.3, r_star=1.0, t0=0.5, period=100.0, ecc=0.1, omega=0.5, Omega=1.0, incl=0.25 * np.pi,
+                             m_planet=0.1)
+    h = 1e-4
+    for pos, vel in (("get_star_position", "get_star_velocity"), ("get_planet_position", "get_planet_velocity"),
+                     ("get_relative_position", "get_relative_velocity")):
+        v = getattr(orbit, vel)(t)
+        hi, lo = getattr(orbit, pos)(t + h), getattr(orbit, pos)(t - h)
+        for k in range(3):
+            fd = (hi[k] - lo[k]) / (2 * h)
+            assert np.allclose(v[k], fd, rtol=1e-6, atol=1e-8 * np.abs(fd).max()), (pos, k)
+    X, Y, _ = orbit.get_relative_position(t)
+    rho, theta = orbit.get_relative_angles(t, parallax=0.05)
+    assert np.allclose(rho, np.hypot(X, Y) * 0.05 * P.au_per_R_sun, rtol=1e-14)
+    assert np.allclose(theta, np.arctan2(Y, X), rtol=0, atol=1e-14)
+    # barycentre: m_star x_star + m_planet x_planet = 0
+    xs, xp = orbit.get_star_position(t), orbit.get_planet_position(t)
+    for k in range(3):
+        assert np.abs(1.3 * xs[k] + 0.1 * xp[k]).max() <= 1e-12 * np.abs(xp[k]).max()
