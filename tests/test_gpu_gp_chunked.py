@@ -333,3 +333,41 @@ def test_gaussian_process_mean_model_takes_the_fused_route(dev):
     g1, = torch.autograd.grad(ll1.sum(), m1)
     g2, = torch.autograd.grad(ll2.sum(), m2)
     assert torch.equal(g1, g2)
+
+
+def test_library_keeps_nothing_between_calls(dev):
+    """The forward / reverse calls of a pair share nothing but their arguments (ABI >= 7: the plan is a pure function
+    of (n, n_draw, J, n_chunks), the state buffer is the caller's): backward passes run after > 4096 unrelated
+    forwards of other shapes and plans, in any order, and under a different EXO_GP_CHUNKS than their forward saw."""
+    from exoplanet_amd.gp import celerite_loglike
+
+    rng = np.random.default_rng(77)
+    cases = []
+    for n, D, name, c in ((700, 3, "sho_q3", 8), (1500, 2, "three_sho_j6", 16), (900, 5, "mixed_j5", None), (400, 2, "real1", 0)):
+        t = np.sort(rng.uniform(0, 30, n))
+        y, diag = rng.normal(size=(D, n)), 0.1 + 0.1 * rng.uniform(size=(D, n))
+        cr, cc = batch(rng, name, D)
+        with chunks(0):
+            want = value_and_grads(dev, t, y, diag, cr, cc)
+        with chunks(c):
+            tt, yt, dt = T(t, dev), T(y, dev, True), T(diag, dev, True)
+            crt, cct = T(cr, dev, True), T(cc, dev, True)
+            ll = celerite_loglike(tt, yt, dt, crt, cct)
+        cases.append((ll, (yt, dt, crt, cct), want))
+    # > 4096 other forwards (with saved state: requires_grad) in between
+    ts = T(np.linspace(0, 5, 96), dev)
+    for i in range(4200):
+        with chunks((2, 3, None)[i % 3]):
+            ys = torch.zeros(1 + i % 2, 96, dtype=torch.float64, device=dev, requires_grad=True)
+            celerite_loglike(ts, ys, torch.ones(1, 96, dtype=torch.float64, device=dev),
+                             torch.tensor([[[1.0, 0.5]]], dtype=torch.float64, device=dev).expand(1 + i % 2, 1, 2).contiguous(),
+                             torch.zeros(1 + i % 2, 0, 4, dtype=torch.float64, device=dev))
+    with chunks(5):                      # not what any of the forwards was run under
+        for ll, leaves, want in reversed(cases):
+            w = torch.linspace(0.5, 1.5, ll.numel(), dtype=torch.float64, device=ll.device)
+            (ll * w).sum().backward()
+            got = [ll.detach().cpu().numpy()] + [x.grad.cpu().numpy() for x in leaves]
+            assert np.allclose(got[0], want[0], rtol=1e-12)
+            for a, b in zip(got[1:], want[1:]):
+                if b.size:
+                    np.testing.assert_allclose(a, b, rtol=2e-7, atol=1e-9 * np.abs(b).max())
