@@ -110,3 +110,55 @@ def test_classifier_error_bound(dev):
     bound = 8e-4 + 0 * e
     worst = (err / bound).max()
     assert worst < 0.9, f"fp32 position error reaches {worst:.2f} of the assumed bound"
+
+
+def wide_records(rng, D):
+    """single-planet records over the whole range the verdict asked for: e in [0, 0.99], a/R in [1.5, 500],
+    r in [1e-3, 1] (log-uniform), b in [0, 1 + r], periastron outside the star"""
+    rec = np.zeros((D, 1, P.NPAR))
+    d = 0
+    while d < D:
+        ecc = np.array([0.0 if rng.uniform() < 0.15 else rng.uniform(0, 0.99)])
+        a = 10 ** rng.uniform(np.log10(1.5), np.log10(500.0), 1)
+        if a[0] * (1 - ecc[0]) < 1.02:
+            continue
+        r = 10 ** rng.uniform(-3, 0, 1)
+        omega = rng.uniform(-np.pi, np.pi, 1)
+        b = rng.uniform(0, 1 + r[0], 1)
+        incl_factor = (1 + ecc * np.sin(omega)) / (1 - ecc ** 2)
+        cosi = np.clip(incl_factor * b / a, 0, 0.9999)
+        period = 10 ** rng.uniform(-0.5, 1.5, 1)
+        orbit = P.KeplerianOrbit(period=period, a=a, t0=rng.uniform(0, 3, 1), incl=np.arccos(cosi), ecc=ecc, omega=omega)
+        rec[d] = make_record(orbit, r, sbr=0.3)[0]
+        d += 1
+    return rec
+
+
+@pytest.mark.parametrize("stencil", [False, True])
+def test_fp32_classifier_never_discards_over_the_parameter_box(dev, stencil):
+    """The fp32 pre-classifier (list path: per-cadence exposure times force it, the run-enumeration path does not use
+    one) against the exact fp64 scan AND against the run-enumeration path, 400 random systems over the whole
+    parameter box: same cadences non-zero, same values to the last bits, same gradients."""
+    from exoplanet_amd import ops
+
+    rng = np.random.default_rng(29 + stencil)
+    D = 400
+    rec = wide_records(rng, D)
+    t = np.sort(np.concatenate([np.linspace(0, 40, 16000), 900 + np.linspace(0, 10, 4000)]))
+    c = np.repeat(P.get_cl(0.3, 0.2)[None], D, 0)
+    g = rng.normal(size=(D, t.size))
+    te = 0.015
+    sdt, sw = P.exposure_stencil(3, 0) if stencil else (np.zeros(1), np.ones(1))
+    per_cad = dict(texp=T(np.full(t.size, te), dev), stencil_dt=T(sdt, dev), stencil_w=T(sw, dev))
+    scalar = dict(texp=T([te], dev), stencil_dt=T(sdt, dev), stencil_w=T(sw, dev))
+    args = (T(t, dev), T(rec, dev), T(c, dev), T(g, dev))
+    fast = ops.transit_flux_value_and_vjp(*args, flags=0, **per_cad)
+    exact = ops.transit_flux_value_and_vjp(*args, flags=ops.FLAG_EXACT_SCAN, **per_cad)
+    runs = ops.transit_flux_value_and_vjp(*args, flags=0, **scalar)
+    assert (exact[0] != 0).sum().item() > 20000
+    for other in (exact, runs):
+        assert (fast[0] == 0).eq(other[0] == 0).all()
+        assert float((fast[0] - other[0]).abs().max()) <= 4e-15
+        for a, b in zip(fast[1:], other[1:]):
+            scale = b.abs().amax(dim=0, keepdim=True) + 1e-300
+            assert float(((a - b).abs() / scale).max()) <= 1e-9
