@@ -455,6 +455,80 @@ def extra_c5(xo, dev, D=128):
                     "curve (7 sub-exposures) + 3-term GP, value + gradient"}
 
 
+def extra_astrometry(xo, dev, D=1024, n_epoch=64):
+    """8f row 3: relative astrometry (separation, position angle) + star velocities of a two-planet system at a few
+    dozen epochs, value + gradient of every orbit parameter: the fused position / velocity op against the composed
+    torch path it replaces"""
+    rng = np.random.default_rng(6)
+    t = torch.tensor(np.sort(rng.uniform(0.0, 800.0, n_epoch)), dtype=torch.float64, device=dev)
+    base = dict(period=[350.0, 97.0], t0=[10.0, 31.0], incl=[1.1, 1.3], ecc=[0.2, 0.5], omega=[0.3, -1.9], Omega=[0.4, 2.0],
+                m_planet=[1e-3, 4e-4])
+    leaves = {k: torch.tensor(np.asarray(v)[None, :] * (1 + 1e-3 * rng.normal(size=(D, 2))), dtype=torch.float64, device=dev,
+                              requires_grad=True) for k, v in base.items()}
+    names = list(leaves)
+    w = [torch.randn(D, n_epoch, 2, dtype=torch.float64, device=dev) for _ in range(5)]
+
+    def make(fused):
+        def one(*vals):
+            orbit = xo.KeplerianOrbit(m_star=1.0, r_star=1.0, **dict(zip(names, vals)))
+            if not fused:
+                orbit._fused_vector = lambda *a, **k: None
+            rho, theta = orbit.get_relative_angles(t, parallax=0.05)
+            vx, vy, vz = orbit.get_star_velocity(t)
+            L = (rho * w[0] + theta * w[1] + vx * w[2] + vy * w[3] + vz * w[4]).sum((-1, -2))
+            return (L.detach(),) + torch.autograd.grad(L.sum(), vals)
+        return one
+
+    out = {}
+    for tag, fused in (("fused", True), ("composed", False)):
+        q, how = graphed(xo, make(fused), list(leaves.values()), dev, 30)
+        out[tag] = {"median_ms": q["median_ms"], "launch": how}
+    out["draws"], out["n_epoch"], out["n_planet"] = D, n_epoch, 2
+    out["note"] = ("astrometry + star velocities of 2 planets at %d epochs, %d draws, value + gradients of 7 x 2 leaves: "
+                   "exo_orbit_vector_* (one launch each way per quantity) vs ops.kepler + torch algebra" % (n_epoch, D))
+    return out
+
+
+def extra_hmc(xo, ops, dev, D=1024, n_leapfrog=8, dense=False):
+    """8f row 4: one HMC trajectory (n_leapfrog value + gradient evaluations of the C2 likelihood and the position /
+    momentum updates between them) for D chains, replayed as one hipGraph"""
+    rng = np.random.default_rng(8)
+    t = torch.arange(N_CAD, dtype=torch.float64, device=dev) * CADENCE
+    lv = make_leaves(D, 11, dev)
+    names = [k for k in lv if k not in ("u1", "u2")]
+    u1, u2 = lv["u1"].detach(), lv["u2"].detach()
+    with torch.no_grad():
+        one = lambda v: torch.tensor([v], dtype=torch.float64, device=dev)  # noqa: E731
+        orbit = xo.KeplerianOrbit(period=one(3.5), t0=one(1.0), b=one(0.3), ecc=one(0.3), omega=one(1.1))
+        truth = xo.LimbDarkLightCurve(0.3, 0.2).get_light_curve(orbit=orbit, r=one(0.1), t=t).sum(-1).reshape(-1)
+    obs = truth + 1e-4 * torch.randn(N_CAD, dtype=torch.float64, device=dev)
+    ivar = 1e8
+
+    def logp(*vals):
+        # Gaussian log-likelihood of the observed light curve (white noise): one call on the sparse light curve
+        Lv = dict(zip(names, vals))
+        orbit = xo.KeplerianOrbit(period=Lv["period"], t0=Lv["t0"], b=Lv["b"], ecc=Lv["ecc"], omega=Lv["omega"])
+        if dense:
+            flux = xo.LimbDarkLightCurve(u1, u2).get_light_curve(orbit=orbit, r=Lv["r"], t=t).sum(-1)
+            return -0.5 * ivar * ((flux - obs) ** 2).sum(-1)
+        return xo.LimbDarkLightCurve(u1, u2).white_noise_log_likelihood(orbit=orbit, r=Lv["r"], t=t, y=obs, yerr=ivar ** -0.5)
+
+    params = [lv[k].detach().clone() for k in names]
+    hmc = xo.HMC(logp, params, step_size=1e-6, n_leapfrog=n_leapfrog)
+    for _ in range(3):
+        hmc.step()
+    torch.cuda.synchronize(dev)
+    q = stats_loop(lambda _: hmc.step(), dev, 30)
+    evals = D * (n_leapfrog + 1)
+    return {"trajectories_per_s": D / (q["median_ms"] * 1e-3), "evals_per_s": evals / (q["median_ms"] * 1e-3), **q,
+            "chains": D, "n_leapfrog": n_leapfrog,
+            "note": "exoplanet_amd.HMC: %d chains, %d leapfrog steps per trajectory = %d value+gradient evaluations of the "
+                    "C2 white-noise likelihood (LimbDarkLightCurve.white_noise_log_likelihood: exo_transit_chi2_vjp_f64 on the "
+                    "sparse light curve; `dense_ms`: the same through get_light_curve and torch passes over (chains, "
+                    "cadences) arrays), one hipGraph replay per trajectory + momentum draw and accept / reject on the device"
+                    % (D, n_leapfrog, n_leapfrog + 1)}
+
+
 def extra_ttv(xo, ops, leaves, t, gbar, dev, D):
     n_tr = int((float(t[-1]) - 1.0) / 3.5) + 1
     offs = torch.tensor(0.01 * np.random.default_rng(7).normal(size=(D, n_tr)), dtype=torch.float64, device=dev,
@@ -713,6 +787,14 @@ def main():
         torch.cuda.empty_cache()
         leg("c4_four_planets_64_draws", lambda: extra_c4(xo, dev))
         leg("c5_secondary_eclipse_3term_gp_128_chains", lambda: extra_c5(xo, dev))
+        torch.cuda.empty_cache()
+        leg("astrometry_and_velocities", lambda: extra_astrometry(xo, dev))
+        def hmc_leg():
+            res = extra_hmc(xo, ops, dev)
+            res["dense_ms"] = extra_hmc(xo, ops, dev, dense=True)["median_ms"]
+            return res
+
+        leg("hmc_trajectory_c2", hmc_leg)
         torch.cuda.empty_cache()
         leg("ops", lambda: extra_ops(ops, dev))
         if rank == 0:

@@ -85,6 +85,10 @@ _SIGNATURES = {
     "exo_radial_velocity_vjp_f64": (ctypes.c_int, [_c_dp, _i64, _c_dp, _i64, _i32, _c_dp, _c_dp, _c_dp]),
     "exo_orbit_vector_fwd_f64": (ctypes.c_int, [_c_dp, _i64, _c_dp, _i64, _i32, _u32, _c_dp, _c_dp]),
     "exo_orbit_vector_vjp_f64": (ctypes.c_int, [_c_dp, _i64, _c_dp, _i64, _i32, _u32, _c_dp, _c_dp, _c_dp]),
+    # t, n_cad, texp, n_texp, stencil_dt, stencil_w, n_sub, params, ld, n_draw, n_planet, flags, obs, ivar, n_ivar,
+    # chi2, gparams, gld, workspace, workspace_bytes, stream
+    "exo_transit_chi2_vjp_f64": (ctypes.c_int, [_c_dp, _i64, _c_dp, _i64, _c_dp, _c_dp, _i32, _c_dp, _c_dp, _i64, _i32, _u32,
+                                                _c_dp, _c_dp, _i64, _c_dp, _c_dp, _c_dp, _c_dp, _i64, _c_dp]),
     "exo_pack_records_f64": (ctypes.c_int, [_c_dp, _c_dp, _i64, _i32, _u32, _c_dp, _c_dp, _c_dp]),
     "exo_pack_records_vjp_f64": (ctypes.c_int, [_c_dp, _c_dp, _i64, _i32, _u32, _c_dp, _c_dp, _c_dp, _c_dp, _c_dp]),
     # cols, draw_stride, planet_stride, defaults, ld_cols, ld_draw_stride (host arrays), n_draw, n_planet, flags, ...

@@ -1532,8 +1532,8 @@ __global__ __launch_bounds__(kBlock, EXO_HEAVY_MIN_WAVES) void transit_runs_kern
     const double* __restrict__ t, int64_t n_cad, const double* __restrict__ texp, int64_t n_texp,
     const double* __restrict__ stencil_dt, const double* __restrict__ stencil_w, int n_sub,
     const double* __restrict__ params, const double* __restrict__ ld, int n_planet, uint32_t flags, int n_ev, RunLists rl,
-    const double* __restrict__ gflux, double* __restrict__ vals, int32_t* __restrict__ vcad, double* __restrict__ fill,
-    double* __restrict__ partial) {
+    const double* __restrict__ gflux, const double* __restrict__ gsparse, double* __restrict__ vals,
+    int32_t* __restrict__ vcad, double* __restrict__ fill, double* __restrict__ partial) {
   __shared__ Shared sh;
   __shared__ Run s_run[kSeg];
   __shared__ int s_in[kSeg + 1], s_all[kSeg + 1];
@@ -1632,7 +1632,11 @@ __global__ __launch_bounds__(kBlock, EXO_HEAVY_MIN_WAVES) void transit_runs_kern
           Item it{0, 0, 0.0, 0.0};   // lanes past the end of the batch: cadence 0 with a zero cotangent
           if (j < total) locate(j, it.i, it.v);
           it.tv = t[it.i];
-          if (GRAD && j < total) it.g = per_planet ? gflux[(draw * n_cad + it.i) * n_planet + p] : gflux[draw * n_cad + it.i];
+          // the cotangent of the cadence's flux: dense [draw][cadence] (x planet), or -- gsparse -- at the value's own
+          // position in the value array (transit_residual_kernel wrote it there)
+          if (GRAD && j < total)
+            it.g = gsparse ? gsparse[vbase + it.v]
+                           : (per_planet ? gflux[(draw * n_cad + it.i) * n_planet + p] : gflux[draw * n_cad + it.i]);
           return it;
         };
         Item nxt = load_item(threadIdx.x);
@@ -1664,6 +1668,76 @@ __global__ __launch_bounds__(kBlock, EXO_HEAVY_MIN_WAVES) void transit_runs_kern
   fc.issue(1 << 30);   // whatever is left of the fill (all of it for a block without work)
 }
 
+// White-noise likelihood on the sparse output (exo_transit_chi2_vjp_f64), between the value sweep and the gradient
+// sweep: for every value (cadence i of a run of list l = (planet, event) of the draw) the draw's TOTAL flux at i --
+// its own value plus whatever the draw's other lists hold for that cadence (simultaneous transits: a binary search
+// over each other list's runs) -- the residual r = total - obs[i], the cotangent 2 w_i r of the flux at i (written at
+// the value's own position, where the gradient sweep reads it) and the draw's chi^2 relative to an empty light curve,
+//     sum over solved cadences of  w_i ((total_i - obs_i)^2 - obs_i^2),
+// each cadence counted once (by the first list that holds it).  Block partials in a fixed order (bit-reproducible).
+constexpr int kResidualBlocks = 16;   // per draw
+__global__ __launch_bounds__(kBlock) void transit_residual_kernel(int64_t n_cad, int n_planet, int n_ev, RunLists rl,
+                                                                  const double* __restrict__ vals,
+                                                                  const int32_t* __restrict__ vcad,
+                                                                  const double* __restrict__ obs,
+                                                                  const double* __restrict__ ivar, int64_t n_ivar,
+                                                                  double* __restrict__ gvals,
+                                                                  double* __restrict__ chi2_part) {
+  __shared__ double red[kBlock];
+  const int64_t draw = blockIdx.y;
+  const int nb = gridDim.x, n_lists = n_planet * n_ev;
+  double acc = 0.0;
+  // value of list l2 at cadence i (0 if none of its runs holds it); `hit` says whether one does
+  auto lookup = [&](int l2, int i, bool& hit) -> double {
+    const int64_t list = draw * n_lists + l2;
+    const int K = rl.nrun[list];
+    const Run* __restrict__ runs = rl.runs + list * rl.r_max;
+    int lo = 0, hi = K;                       // first run with run.lo > i
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (runs[mid].lo <= i) lo = mid + 1; else hi = mid;
+    }
+    hit = false;
+    if (lo == 0) return 0.0;
+    const Run r = runs[lo - 1];
+    if (i >= r.hi) return 0.0;
+    hit = true;
+    const int p2 = l2 / n_ev, ev2 = l2 - p2 * n_ev;
+    int64_t base = ((int64_t)draw * n_planet + p2) * n_cad;
+    if (ev2 > 0) { const int64_t l0 = list - ev2; base += rl.pre_all[l0 * (rl.r_max + 1) + rl.nrun[l0]]; }
+    return vals[base + rl.pre_all[list * (rl.r_max + 1) + lo - 1] + (i - r.lo)];
+  };
+  for (int l = 0; l < n_lists; ++l) {
+    const int64_t list = draw * n_lists + l;
+    const int p = l / n_ev, ev = l - p * n_ev;
+    int64_t vbase = ((int64_t)draw * n_planet + p) * n_cad;
+    if (ev > 0) { const int64_t l0 = list - ev; vbase += rl.pre_all[l0 * (rl.r_max + 1) + rl.nrun[l0]]; }
+    const int total = rl.pre_all[list * (rl.r_max + 1) + rl.nrun[list]];
+    for (int e = blockIdx.x * kBlock + threadIdx.x; e < total; e += nb * kBlock) {
+      const int i = vcad[vbase + e];
+      double tot = vals[vbase + e];
+      bool first = true;
+      for (int l2 = 0; l2 < n_lists; ++l2) {
+        if (l2 == l) continue;
+        bool hit;
+        tot += lookup(l2, i, hit);
+        first = first && !(hit && l2 < l);
+      }
+      const double o = obs[i], w = ivar[n_ivar == 1 ? 0 : i];
+      const double r = tot - o;
+      gvals[vbase + e] = 2.0 * w * r;
+      if (first) acc += w * (r * r - o * o);
+    }
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int m = kBlock / 2; m > 0; m >>= 1) {
+    if ((int)threadIdx.x < m) red[threadIdx.x] += red[threadIdx.x + m];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) chi2_part[draw * nb + blockIdx.x] = red[0];
+}
+
 // Last kernel of a sweep on the run-enumeration path, one block per draw: (GRAD) block partials ->
 // gparams, gld, sum(gflux * flux), in block order; (dense output) the runs' values to their cadences,
 // planet by planet (summed flux: a later planet adds to what the earlier ones left).
@@ -1672,8 +1746,14 @@ __global__ __launch_bounds__(kBlock, EXO_HEAVY_MIN_WAVES) void transit_runs_kern
 __global__ __launch_bounds__(1024) void transit_finish_kernel(
     const double* __restrict__ partial, int nblk, int n_planet, bool secondary, double* __restrict__ gparams,
     double* __restrict__ gld, double* __restrict__ flux_dot, int64_t n_cad, uint32_t flags, int n_ev, RunLists rl,
-    const double* __restrict__ vals, const int32_t* __restrict__ vcad, double* __restrict__ flux) {
+    const double* __restrict__ vals, const int32_t* __restrict__ vcad, double* __restrict__ flux,
+    const double* __restrict__ chi2_part, int n_chi2_part, double* __restrict__ chi2_out) {
   const int64_t draw = blockIdx.x;
+  if (chi2_out && threadIdx.x == blockDim.x - 1) {   // block partials of transit_residual_kernel, in block order
+    double v = 0.0;
+    for (int b = 0; b < n_chi2_part; ++b) v += chi2_part[draw * n_chi2_part + b];
+    chi2_out[draw] = v;
+  }
   const int ng_draw = n_planet * kNG + 7;
   const int s = threadIdx.x;
   if (partial) {
@@ -1945,7 +2025,9 @@ struct RunWs {
   int32_t* sorted;
   RunLists rl;
   double* vals;
-  int32_t* vcad;   // cadence of every value (dense output only)
+  int32_t* vcad;   // cadence of every value (dense output, chi^2)
+  double* gvals;   // chi^2: cotangent of every value
+  double* chi2_part;
   int hb, n_sorted;
   int64_t off_nrun, off_runs, off_pre_all, off_vals;   // byte offsets (exo_transit_flux_sparse_layout)
   int64_t bytes;
@@ -1968,6 +2050,8 @@ inline RunWs carve_runs(void* base, int64_t n_cad, int64_t n_draw, int n_planet)
   w.off_pre_all = off; w.rl.pre_all = (int32_t*)(p + off); off = up16(off + 4 * n_list * (int64_t)(w.rl.r_max + 1));
   w.off_vals = off; w.vals = (double*)(p + off); off = up16(off + 8 * n_draw * n_planet * n_cad);
   w.vcad = (int32_t*)(p + off); off = up16(off + 4 * n_draw * n_planet * n_cad);
+  w.gvals = (double*)(p + off); off = up16(off + 8 * n_draw * n_planet * n_cad);
+  w.chi2_part = (double*)(p + off); off = up16(off + 8 * n_draw * kResidualBlocks);
   w.bytes = off;
   return w;
 }
@@ -1977,12 +2061,36 @@ inline bool runs_path(bool has_ttv, int64_t n_texp, uint32_t flags) {
   return !has_ttv && n_texp <= 1 && !(flags & EXO_FLAG_EXACT_SCAN);
 }
 
-// launches of one sweep on the run-enumeration path; gflux == nullptr: forward only
+// launches of one sweep on the run-enumeration path; gflux == nullptr: forward only.
+// chi2 (obs != nullptr): value sweep into the sparse output, residuals + cotangents on it, gradient sweep reading them.
+struct Chi2Args {
+  const double* obs;
+  const double* ivar;
+  int64_t n_ivar;
+  double* chi2;
+};
+template <bool G, bool SEC>
+inline void launch_runs_kernel(bool ldelay, dim3 hgrid, hipStream_t st, const double* t, int64_t n_cad, const double* texp,
+                               int64_t n_texp, const double* stencil_dt, const double* stencil_w, int32_t n_sub,
+                               const double* params, const double* ld, int32_t n_planet, uint32_t flags, int n_ev,
+                               const RunLists& rl, const double* gflux, const double* gsparse, double* vals, int32_t* vcad,
+                               double* fill, double* partial) {
+  if (ldelay)
+    hipLaunchKernelGGL((transit_runs_kernel<G, SEC, true>), hgrid, dim3(kBlock), 0, st, t, n_cad, texp, n_texp, stencil_dt,
+                       stencil_w, (int)n_sub, params, ld, (int)n_planet, flags, n_ev, rl, gflux, gsparse, vals, vcad, fill,
+                       partial);
+  else
+    hipLaunchKernelGGL((transit_runs_kernel<G, SEC, false>), hgrid, dim3(kBlock), 0, st, t, n_cad, texp, n_texp, stencil_dt,
+                       stencil_w, (int)n_sub, params, ld, (int)n_planet, flags, n_ev, rl, gflux, gsparse, vals, vcad, fill,
+                       partial);
+}
 inline int launch_runs_sweep(const double* t, int64_t n_cad, const double* texp, int64_t n_texp, const double* stencil_dt,
                              const double* stencil_w, int32_t n_sub, const double* params, const double* ld,
                              int64_t n_draw, int32_t n_planet, uint32_t flags, const double* gflux, double* flux,
-                             double* gparams, double* gld, double* flux_dot, const RunWs& w, hipStream_t st) {
-  const bool secondary = flags & EXO_FLAG_SECONDARY, sparse = flags & EXO_FLAG_SPARSE, grad = gflux != nullptr;
+                             double* gparams, double* gld, double* flux_dot, const RunWs& w, hipStream_t st,
+                             const Chi2Args* chi2 = nullptr) {
+  const bool secondary = flags & EXO_FLAG_SECONDARY, sparse = (flags & EXO_FLAG_SPARSE) || chi2;
+  const bool grad = gflux != nullptr || chi2;
   const int n_ev = secondary ? 2 : 1;
   const dim3 block(kBlock);
   {
@@ -1998,26 +2106,30 @@ inline int launch_runs_sweep(const double* t, int64_t n_cad, const double* texp,
   double* fill = sparse ? nullptr : flux;
   const dim3 hgrid((unsigned)w.hb, (unsigned)n_draw);
   const bool ldelay = flags & EXO_FLAG_LIGHT_DELAY;
-#define EXO_LAUNCH_RUNS(G, SEC)                                                                                       \
-  if (ldelay)                                                                                                         \
-    hipLaunchKernelGGL((transit_runs_kernel<G, SEC, true>), hgrid, block, 0, st, t, n_cad, texp, n_texp, stencil_dt,  \
-                       stencil_w, (int)n_sub, params, ld, (int)n_planet, flags, n_ev, w.rl, gflux, vals,              \
-                       fill ? w.vcad : nullptr, fill, grad ? w.partial : nullptr);                                    \
-  else                                                                                                                \
-  hipLaunchKernelGGL((transit_runs_kernel<G, SEC>), hgrid, block, 0, st, t, n_cad, texp, n_texp, stencil_dt, stencil_w, \
-                     (int)n_sub, params, ld, (int)n_planet, flags, n_ev, w.rl, gflux, vals, fill ? w.vcad : nullptr, fill,        \
-                     grad ? w.partial : nullptr)
-  if (grad) {
-    if (secondary) EXO_LAUNCH_RUNS(true, true); else EXO_LAUNCH_RUNS(true, false);
+#define EXO_LAUNCH_RUNS(G, GFLUX, GSP, VALS, VCAD, FILL, PARTIAL)                                                         \
+  if (secondary)                                                                                                          \
+    launch_runs_kernel<G, true>(ldelay, hgrid, st, t, n_cad, texp, n_texp, stencil_dt, stencil_w, n_sub, params, ld,      \
+                                n_planet, flags, n_ev, w.rl, GFLUX, GSP, VALS, VCAD, FILL, PARTIAL);                       \
+  else                                                                                                                    \
+    launch_runs_kernel<G, false>(ldelay, hgrid, st, t, n_cad, texp, n_texp, stencil_dt, stencil_w, n_sub, params, ld,     \
+                                 n_planet, flags, n_ev, w.rl, GFLUX, GSP, VALS, VCAD, FILL, PARTIAL)
+  if (chi2) {
+    EXO_LAUNCH_RUNS(false, nullptr, nullptr, w.vals, w.vcad, nullptr, nullptr);
+    hipLaunchKernelGGL(transit_residual_kernel, dim3(kResidualBlocks, (unsigned)n_draw), block, 0, st, n_cad, (int)n_planet,
+                       n_ev, w.rl, w.vals, w.vcad, chi2->obs, chi2->ivar, chi2->n_ivar, w.gvals, w.chi2_part);
+    EXO_LAUNCH_RUNS(true, nullptr, w.gvals, nullptr, nullptr, nullptr, w.partial);
+  } else if (grad) {
+    EXO_LAUNCH_RUNS(true, gflux, nullptr, vals, fill ? w.vcad : nullptr, fill, w.partial);
   } else {
-    if (secondary) EXO_LAUNCH_RUNS(false, true); else EXO_LAUNCH_RUNS(false, false);
+    EXO_LAUNCH_RUNS(false, nullptr, nullptr, vals, fill ? w.vcad : nullptr, fill, nullptr);
   }
 #undef EXO_LAUNCH_RUNS
   if (launch_status() != EXO_OK) return EXO_ERR_LAUNCH;
   if (grad || fill)
     hipLaunchKernelGGL(transit_finish_kernel, dim3((unsigned)n_draw), dim3(n_draw <= 256 ? 1024 : kBlock), 0, st,
-                       grad ? w.partial : nullptr, w.hb,
-                       (int)n_planet, secondary, gparams, gld, flux_dot, n_cad, flags, n_ev, w.rl, vals, w.vcad, fill);
+                       grad ? w.partial : nullptr, w.hb, (int)n_planet, secondary, gparams, gld, flux_dot, n_cad, flags, n_ev,
+                       w.rl, chi2 ? nullptr : vals, w.vcad, fill, chi2 ? w.chi2_part : nullptr, kResidualBlocks,
+                       chi2 ? chi2->chi2 : nullptr);
   return launch_status();
 }
 
@@ -2277,6 +2389,26 @@ int exo_transit_flux_ttv_vjp_f64(const double* t, int64_t n_cad, const double* t
   return transit_vjp(t, n_cad, texp, n_texp, stencil_dt, stencil_w, n_sub, params, ld, n_draw, n_planet, flags,
                      Ttv{ttv_edges, ttv_shift, gshift, n_edge}, gflux, flux_out, gparams, gld, flux_dot, workspace,
                      workspace_bytes, stream, nullptr, nullptr);
+}
+
+int exo_transit_chi2_vjp_f64(const double* t, int64_t n_cad, const double* texp, int64_t n_texp, const double* stencil_dt,
+                             const double* stencil_w, int32_t n_sub, const double* params, const double* ld,
+                             int64_t n_draw, int32_t n_planet, uint32_t flags, const double* obs, const double* ivar,
+                             int64_t n_ivar, double* chi2, double* gparams, double* gld, void* workspace,
+                             int64_t workspace_bytes, void* stream) {
+  if (!transit_args_ok(n_cad, n_texp, n_sub, n_draw, n_planet) || (n_ivar != 1 && n_ivar != n_cad))
+    return EXO_ERR_INVALID_ARGUMENT;
+  if (flags & (EXO_FLAG_PER_PLANET | EXO_FLAG_SPARSE | EXO_FLAG_EXACT_SCAN)) return EXO_ERR_INVALID_ARGUMENT;
+  if (n_draw == 0) return EXO_OK;
+  if (!params || !ld || !chi2 || !gparams || !gld || (n_cad > 0 && (!t || !obs || !ivar)) ||
+      (n_texp > 0 && (!texp || !stencil_dt || !stencil_w)))
+    return EXO_ERR_INVALID_ARGUMENT;
+  if (!runs_path(false, n_texp, flags)) return EXO_ERR_INVALID_ARGUMENT;   // one exposure time (or none) for all cadences
+  const RunWs rw = carve_runs(workspace, n_cad, n_draw, n_planet);
+  if (!workspace || workspace_bytes < rw.bytes) return EXO_ERR_WORKSPACE;
+  const Chi2Args c2{obs, ivar, n_ivar, chi2};
+  return launch_runs_sweep(t, n_cad, texp, n_texp, stencil_dt, stencil_w, n_sub, params, ld, n_draw, n_planet, flags, nullptr,
+                           nullptr, gparams, gld, nullptr, rw, (hipStream_t)stream, &c2);
 }
 
 }  // extern "C"

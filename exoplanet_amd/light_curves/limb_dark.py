@@ -178,6 +178,32 @@ class LimbDarkLightCurve:
         flux = ops.transit_flux(t.detach(), rec, ld, flags=flags | ops.FLAG_PER_PLANET, **kw)
         return flux.reshape(tuple(batch) + (t.shape[0], rec.shape[1]))
 
+    def white_noise_log_likelihood(self, orbit=None, r=None, t=None, y=None, yerr=None, mean=0.0, texp=None, oversample=7,
+                                   order=0, use_in_transit=False, light_delay=False):
+        """Gaussian log-likelihood (one value per draw) of the observed series ``y`` with independent errors ``yerr``
+        given ``mean + sum over planets of get_light_curve(...)`` -- what the reference's tutorials write as
+        ``pm.Normal("obs", mu=mean + pt.sum(light_curves, axis=-1), sigma=yerr, observed=y)`` -- for a KeplerianOrbit
+        with sorted times and one exposure time: value and gradient in ONE call on the sparse light curve
+        (ops.transit_chi2), no (draws, cadences) array anywhere.  ``mean``: a number or a (draws, 1) tensor is NOT
+        supported here (it would make the residual per draw): pass a scalar and model offsets in ``y``."""
+        from ..orbits.keplerian import KeplerianOrbit
+
+        if orbit is None or r is None or t is None or y is None or yerr is None:
+            raise ValueError("orbit, r, t, y and yerr are required")
+        if not isinstance(orbit, KeplerianOrbit) or type(orbit)._warp_times is not KeplerianOrbit._warp_times:
+            raise NotImplementedError("white_noise_log_likelihood needs a KeplerianOrbit (no timing variations)")
+        t = as_tensor(t, r if isinstance(r, torch.Tensor) else self.u1)
+        rec, ld, batch, flags = orbit.kernel_inputs(r, (self.u1, self.u2), use_in_transit=use_in_transit,
+                                                    light_delay=light_delay)
+        t = t.to(rec.device)
+        kw = {}
+        if texp is not None:
+            dt, w = exposure_stencil(oversample, order)
+            kw.update(texp=as_tensor(texp, t).reshape(-1).detach(), stencil_dt=_on_device(dt, t.device),
+                      stencil_w=_on_device(w, t.device))
+        ll = ops.white_noise_loglike(t.detach(), rec, ld, as_tensor(y, t).to(rec.device), yerr, mean=mean, flags=flags, **kw)
+        return ll.reshape(tuple(batch)) if batch else ll.reshape(())
+
     # ---- generic orbit objects: ops.quad_solution_vector on their positions
     def _composed(self, orbit, r, t, texp, stencil, use_in_transit, light_delay):
         t = as_tensor(t)

@@ -156,6 +156,24 @@ int64_t exo_transit_flux_workspace_bytes(int64_t n_cad, int64_t n_draw, int32_t 
  * list is the whole series cut into a few runs.                                                   */
 int exo_transit_flux_sparse_layout(int64_t n_cad, int64_t n_draw, int32_t n_planet, int64_t* out);
 
+/* White-noise Gaussian likelihood of ONE observed series against the light curves of n_draw parameter sets, value and
+ * gradient, without a dense flux array -- what a sampler step needs when there is no correlated-noise model (the
+ * reference's `pm.Normal("obs", mu=light_curve, sigma=yerr, observed=y)`, docs/tutorials: the (draw, cadence) arrays of
+ * flux, residual and their cotangents never exist).  With f[d][n] the summed flux of draw d (exactly 0 outside the runs
+ * of the sparse output, see EXO_FLAG_SPARSE), w_n = ivar[n_ivar == 1 ? 0 : n]:
+ *   chi2[d]   = sum over the cadences n solved for draw d of  w_n ((f[d][n] - obs[n])^2 - obs[n]^2)
+ *             = sum_n w_n (f[d][n] - obs[n])^2  -  sum_n w_n obs[n]^2      (the second sum is the caller's constant)
+ *   gparams, gld = d chi2[d] / d (params, ld)
+ * Three sweeps' worth of launches in one call: values into the sparse output, residuals and cotangents on it (a draw's
+ * planets may transit at once: every value sees the draw's total flux at its cadence), gradient sweep.  Sorted t, one
+ * exposure time (or none), no timing tables (EXO_ERR_INVALID_ARGUMENT otherwise); flags: EXO_FLAG_SECONDARY,
+ * EXO_FLAG_WINDOW, EXO_FLAG_LIGHT_DELAY.  Bit-reproducible.                                                          */
+int exo_transit_chi2_vjp_f64(const double* t, int64_t n_cad, const double* texp, int64_t n_texp, const double* stencil_dt,
+                             const double* stencil_w, int32_t n_sub, const double* params, const double* ld,
+                             int64_t n_draw, int32_t n_planet, uint32_t flags, const double* obs, const double* ivar,
+                             int64_t n_ivar, double* chi2, double* gparams, double* gld, void* workspace,
+                             int64_t workspace_bytes, void* stream);
+
 /* Diagnostic for the scan kernel's conservative fp32 cadence classifier: the fp32
  * estimate of (cos E - e, sqrt(1-e^2) sin E) for mean anomaly M (fp64 phase) and
  * eccentricity ecc, widened back to double.  The classifier's safety margin assumes

@@ -1,0 +1,143 @@
+"""GPU: the one-call white-noise likelihood on the sparse light curve (exo_transit_chi2_vjp_f64) against the same
+quantity assembled from the C port's DENSE light curve and its VJP: single planet, three planets with simultaneous
+transits, exposure stencil + secondary eclipse, per-cadence weights, the contact-window flag."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import c_port as C
+from oracle import numpy_port as P
+from test_gpu_transit import make_record
+
+pytestmark = pytest.mark.gpu
+
+
+def T(a, dev):
+    return torch.as_tensor(np.asarray(a, dtype=np.float64), device=dev)
+
+
+def oracle_chi2(t, rec, c, obs, ivar, **kw):
+    """chi2 over ALL cadences minus the empty-light-curve constant, and its gradient, from the dense C port"""
+    D = rec.shape[0]
+    flux, _, _ = C.transit(t, rec, c, None, **kw)
+    w = np.broadcast_to(ivar, t.shape)
+    chi2 = (w * ((flux - obs) ** 2 - obs ** 2)).sum(-1)
+    _, gp, gl = C.transit(t, rec, c, 2.0 * w * (flux - obs), **kw)
+    return flux, chi2, gp, gl
+
+
+CASES = {
+    "one_planet": dict(P=1, secondary=False, texp=None, per_cad_ivar=False, window=False),
+    "three_planets_overlapping": dict(P=3, secondary=False, texp=None, per_cad_ivar=True, window=False),
+    "secondary_texp": dict(P=2, secondary=True, texp=0.02, per_cad_ivar=True, window=False),
+    "window": dict(P=2, secondary=False, texp=None, per_cad_ivar=False, window=True),
+}
+
+
+@pytest.mark.parametrize("case", list(CASES))
+def test_chi2_matches_dense_oracle(dev, case):
+    from exoplanet_amd import ops
+
+    cfg = CASES[case]
+    rng = np.random.default_rng(41)
+    D, Pn, N = 5, cfg["P"], 6000
+    t = np.linspace(0.0, 30.0, N)
+    # commensurate periods and aligned t0: planets transit at the same time again and again
+    period = np.array([3.0, 6.0, 4.5])[:Pn]
+    t0 = np.array([1.5, 1.5, 1.52])[:Pn]
+    rec = np.zeros((D, Pn, P.NPAR))
+    for d in range(D):
+        orbit = P.KeplerianOrbit(period=period * (1 + 1e-4 * rng.normal(size=Pn)), t0=t0 + 1e-3 * rng.normal(size=Pn),
+                                 b=rng.uniform(0, 0.8, Pn), ecc=rng.uniform(0, 0.4, Pn), omega=rng.uniform(-3, 3, Pn))
+        rec[d] = make_record(orbit, rng.uniform(0.03, 0.12, Pn), sbr=0.4, window=cfg["window"])[0]
+    c = np.repeat(np.concatenate([P.get_cl(0.3, 0.2), P.get_cl(0.4, 0.1)])[None], D, 0) * (1 + 1e-2 * rng.normal(size=(D, 6)))
+    c = c if cfg["secondary"] else np.ascontiguousarray(c[:, :3])
+    kw_o, kw_g = dict(secondary=cfg["secondary"], window=cfg["window"]), {}
+    if cfg["texp"] is not None:
+        sdt, sw = P.exposure_stencil(5, 0)
+        kw_o.update(texp=cfg["texp"], stencil_dt=sdt, stencil_w=sw)
+        kw_g = dict(texp=T([cfg["texp"]], dev), stencil_dt=T(sdt, dev), stencil_w=T(sw, dev))
+    truth, _, _ = C.transit(t, rec[:1], c[:1], None, **kw_o)
+    obs = truth[0] + 3e-4 * rng.normal(size=N)
+    ivar = (1.0 / (3e-4 * (1 + 0.3 * rng.uniform(size=N))) ** 2) if cfg["per_cad_ivar"] else np.array([1.0 / 9e-8])
+    flux, want, gp, gl = oracle_chi2(t, rec, c, obs, ivar, **kw_o)
+    if Pn > 1:
+        both = sum((make != 0).astype(int) for make in [C.transit(t, rec[:, p:p + 1], c, None, **kw_o)[0] for p in range(Pn)])
+        assert (both > 1).sum() > 50, "no simultaneous transits in the test system"
+    flags = (ops.FLAG_SECONDARY if cfg["secondary"] else 0) | (ops.FLAG_WINDOW if cfg["window"] else 0)
+    rt, ct = T(rec, dev).requires_grad_(True), T(c, dev).requires_grad_(True)
+    chi2 = ops.transit_chi2(T(t, dev), rt, ct, T(obs, dev), T(ivar, dev), flags=flags, **kw_g)
+    got = chi2.detach().cpu().numpy()
+    scale = (np.broadcast_to(ivar, t.shape) * obs ** 2).sum()          # the size of the sums the difference is taken from
+    assert np.abs(got - want).max() <= 1e-12 * scale
+    wgt = T(rng.normal(size=D), dev)
+    (chi2 * wgt).sum().backward()
+    wn = wgt.cpu().numpy()
+    np.testing.assert_allclose(rt.grad.cpu().numpy(), wn[:, None, None] * gp, rtol=2e-9, atol=1e-9 * np.abs(gp).max())
+    np.testing.assert_allclose(ct.grad.cpu().numpy(), wn[:, None] * gl, rtol=2e-9, atol=1e-9 * np.abs(gl).max())
+
+
+def test_white_noise_loglike_and_argument_checks(dev):
+    from exoplanet_amd import ops
+
+    rng = np.random.default_rng(43)
+    N, D = 3000, 3
+    t = np.linspace(0, 12, N)
+    orbit = P.KeplerianOrbit(period=np.array([3.5]), t0=np.array([1.0]), b=np.array([0.3]), ecc=np.array([0.2]), omega=np.array([0.5]))
+    rec = np.repeat(make_record(orbit, np.array([0.1])), D, 0) * (1 + 1e-3 * rng.normal(size=(D, 1, P.NPAR)))
+    c = np.repeat(P.get_cl(0.3, 0.2)[None], D, 0)
+    flux, _, _ = C.transit(t, rec, c, None)
+    y = 1.0 + flux[0] + 2e-4 * rng.normal(size=N)
+    yerr = 2e-4
+    want = -0.5 * (((y - 1.0 - flux) / yerr) ** 2).sum(-1) - N * np.log(yerr * np.sqrt(2 * np.pi))
+    got = ops.white_noise_loglike(T(t, dev), T(rec, dev), T(c, dev), T(y, dev), yerr, mean=1.0)
+    assert np.abs(got.cpu().numpy() - want).max() <= 1e-10 * np.abs(want).max()
+    with pytest.raises(ValueError):
+        ops.transit_chi2(T(t, dev), T(rec, dev), T(c, dev), T(y[:-1], dev), T([1.0], dev))
+    with pytest.raises(ValueError):
+        ops.transit_chi2(T(t, dev), T(rec, dev), T(c, dev), T(y, dev), T(np.ones(7), dev))
+    with pytest.raises(RuntimeError):   # per-cadence exposure times: not on the run-enumeration path
+        sdt, sw = P.exposure_stencil(3, 0)
+        ops.transit_chi2(T(t, dev), T(rec, dev), T(c, dev), T(y, dev), T([1.0], dev), texp=T(np.full(N, 0.01), dev),
+                         stencil_dt=T(sdt, dev), stencil_w=T(sw, dev))
+
+
+def test_light_curve_level_likelihood_in_a_graph(dev):
+    """LimbDarkLightCurve.white_noise_log_likelihood == the same likelihood from get_light_curve + torch, values and
+    gradients of every leaf, eagerly and replayed as a hipGraph"""
+    import exoplanet_amd as xo
+
+    rng = np.random.default_rng(47)
+    D, N = 6, 8000
+    t = torch.linspace(0.0, 20.0, N, dtype=torch.float64, device=dev)
+    mk = lambda v: torch.tensor(v * (1 + 1e-3 * rng.normal(size=(D, 1))), dtype=torch.float64, device=dev, requires_grad=True)  # noqa: E731
+    L = dict(period=mk(3.5), t0=mk(1.0), b=mk(0.3), ecc=mk(0.2), omega=mk(1.1), r=mk(0.1))
+    names = list(L)
+    u = (0.3, 0.2)
+    with torch.no_grad():
+        orbit = xo.KeplerianOrbit(**{k: v[:1] for k, v in L.items() if k != "r"})
+        y = 1.0 + xo.LimbDarkLightCurve(*u).get_light_curve(orbit=orbit, r=L["r"][:1], t=t, texp=0.01).sum(-1).reshape(-1)
+        y = y + 2e-4 * torch.randn(N, dtype=torch.float64, device=dev)
+    yerr = 2e-4
+
+    def fused(*vals):
+        Lv = dict(zip(names, vals))
+        orbit = xo.KeplerianOrbit(**{k: v for k, v in Lv.items() if k != "r"})
+        ll = xo.LimbDarkLightCurve(*u).white_noise_log_likelihood(orbit=orbit, r=Lv["r"], t=t, y=y, yerr=yerr, mean=1.0, texp=0.01)
+        return (ll.detach(),) + torch.autograd.grad(ll.sum(), vals)
+
+    def dense(*vals):
+        Lv = dict(zip(names, vals))
+        orbit = xo.KeplerianOrbit(**{k: v for k, v in Lv.items() if k != "r"})
+        f = xo.LimbDarkLightCurve(*u).get_light_curve(orbit=orbit, r=Lv["r"], t=t, texp=0.01).sum(-1)
+        ll = -0.5 * (((y - 1.0 - f) / yerr) ** 2).sum(-1) - N * np.log(yerr * np.sqrt(2 * np.pi))
+        return (ll.detach(),) + torch.autograd.grad(ll.sum(), vals)
+
+    a, b = fused(*L.values()), dense(*L.values())
+    assert float((a[0] - b[0]).abs().max()) <= 1e-10 * float(b[0].abs().max())
+    for x, z in zip(a[1:], b[1:]):
+        assert float((x - z).abs().max()) <= 1e-8 * float(z.abs().max())
+    g = xo.GraphedStep(fused, *L.values())
+    out = g()
+    for x, z in zip(out, a):
+        assert float((x - z).abs().max()) <= 1e-12 * float(z.abs().max())
