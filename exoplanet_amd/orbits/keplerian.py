@@ -327,6 +327,8 @@ class KeplerianOrbit:
             return None
         if not (isinstance(t, torch.Tensor) and t.dim() == 1 and t.is_cuda and t.dtype == torch.float64):
             return None
+        if t.requires_grad:      # the op has no cotangent for the times (keplerian_test.py:91-131 differentiates them)
+            return None
         e, cw, sw = self._ew()
         one, zero = torch.ones_like(self.n), torch.zeros_like(self.n)
         cO, sO = (one, zero) if self.Omega is None else (self.cos_Omega, self.sin_Omega)

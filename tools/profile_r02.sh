@@ -13,7 +13,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o p -- $CMD 
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/pmc_fetch -o fetch -- $CMD > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/pmc_write -o write -- $CMD > /dev/null 2>&1
 python - <<PY
-import csv, glob, json, collections
+import csv, glob, json, collections, re
 out = "$out"
 res = {"source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes (each with --kernel-trace), "
                  "bench.py --steps 20 --warmup 3 --no-graph --no-extras --draws-per-gpu 1024; KiB per dispatch, mean",
@@ -26,7 +26,7 @@ for sub, name, cname, key in (("pmc_fetch", "fetch", "FETCH_SIZE", "fetch_kib"),
     for f in fs:
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] == cname and "transit" in r["Kernel_Name"]:
-                k = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("(anonymous namespace)::", "").strip()
+                k = re.search(r"transit_\w+(?:<[^>]*>)?", r["Kernel_Name"]).group(0)
                 agg[k].append(float(r["Counter_Value"]))
     for k, v in agg.items():
         res["kernels"].setdefault(k, {})[key] = sum(v) / len(v)
