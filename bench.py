@@ -121,9 +121,14 @@ def measured_traffic(n_draw):
     this run's draw count.  A cross-reference, not a live measurement: None if the file is absent
     or was taken on another kernel generation."""
     try:
+        import hashlib
+
         p = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc.json")))
-        tot = sum(2.0 * k["fetch_kib"] + k["write_kib"] for k in p["kernels"].values())
-        return {"bytes": tot * 1024.0 * n_draw / p["draws"], "source": "profiles/r02_pmc.json",
+        src = os.path.join(ROOT, "exoplanet_amd", "csrc", "exo_transit.hip")
+        if p.get("kernel_source_sha256") != hashlib.sha256(open(src, "rb").read()).hexdigest():
+            return None                      # the counters were taken on other kernels: say nothing rather than something stale
+        tot = sum(2.0 * k["fetch_kib"] + k["write_kib"] for k in p["kernels"].values() if k.get("dispatches_fetch", 0) > 5)
+        return {"bytes": tot * 1024.0 * n_draw / p["draws"], "source": "profiles/r02_pmc.json (same exo_transit.hip)",
                 "draws_profiled": p["draws"]}
     except Exception:
         return None

@@ -116,7 +116,8 @@ __global__ __launch_bounds__(kRvBlock) void rv_vjp_kernel(const double* __restri
 // :572-578 _get_velocity, :283-322 _rotate_vector): what get_{star,planet,relative}_{position,velocity} and
 // get_relative_angles (astrometry, :544-570) are made of.  In the orbital plane
 //     position:  (u, v) = (1 - e^2) / (1 + e cos f) (cos f, sin f)        velocity:  (u, v) = (-sin f, cos f + e)
-// times an amplitude (a_star, a_planet, -a [x parallax au_per_R_sun]; K0 m), then the three rotations
+//     acceleration (:679-706):  (u, v) = -(1 + e cos f)^2 / (1 - e^2) (cos f, sin f)
+// times an amplitude (a_star, a_planet, -a [x parallax au_per_R_sun]; K0 m; (K0 m)^2 / a), then the three rotations
 //     x1 = cw u - sw v,  y1 = sw u + cw v;   x2 = x1,  y2 = ci y1,  Z = -si y1;   X = cO x2 - sO y2,  Y = sO x2 + cO y2.
 // An astrometric or imaging series is tens of epochs: as for the radial velocities, the composed path's launch-bound
 // torch kernels (solve, radius, three rotations, broadcasts, and their reverse: ~40) are the cost; here one launch
@@ -129,7 +130,7 @@ struct OvSample {
   double X, Y, Z;       // unit amplitude
 };
 
-template <bool VELOCITY>
+template <int MODE>
 __device__ __forceinline__ OvSample ov_sample(double t, const double* __restrict__ p) {
   const double e = p[EXO_OV_ECC];
   const bool ok = (e >= 0.0) && (e < 1.0);
@@ -141,8 +142,11 @@ __device__ __forceinline__ OvSample ov_sample(double t, const double* __restrict
   OvSample s;
   s.sinf = ok ? 2.0 * kh.X * kh.Y * iden : nan;
   s.cosf = ok ? (X2 - Y2) * iden : nan;
-  if (VELOCITY) {
+  if (MODE == 1) {
     s.u = -s.sinf; s.v = s.cosf + e;
+  } else if (MODE == 2) {
+    const double q = 1.0 + e * s.cosf, g = q * q / (1.0 - e * e);
+    s.u = -g * s.cosf; s.v = -g * s.sinf;
   } else {
     const double rho = (1.0 - e * e) / (1.0 + e * s.cosf);
     s.u = rho * s.cosf; s.v = rho * s.sinf;
@@ -157,7 +161,7 @@ __device__ __forceinline__ OvSample ov_sample(double t, const double* __restrict
   return s;
 }
 
-template <bool VELOCITY>
+template <int MODE>
 __global__ __launch_bounds__(kRvBlock) void ov_fwd_kernel(const double* __restrict__ t, int64_t n_cad,
                                                           const double* __restrict__ params, int64_t n_draw,
                                                           int n_planet, double* __restrict__ out) {
@@ -168,13 +172,13 @@ __global__ __launch_bounds__(kRvBlock) void ov_fwd_kernel(const double* __restri
     const int64_t dn = i / n_planet;
     const int64_t n = dn % n_cad, d = dn / n_cad;
     const double* __restrict__ rec = params + (d * n_planet + p) * EXO_OV_NPAR;
-    const OvSample s = ov_sample<VELOCITY>(t[n], rec);
+    const OvSample s = ov_sample<MODE>(t[n], rec);
     const double a = rec[EXO_OV_AMP];
     out[3 * i] = a * s.X; out[3 * i + 1] = a * s.Y; out[3 * i + 2] = a * s.Z;
   }
 }
 
-template <bool VELOCITY>
+template <int MODE>
 __global__ __launch_bounds__(kRvBlock) void ov_vjp_kernel(const double* __restrict__ t, int64_t n_cad,
                                                           const double* __restrict__ params, int n_planet,
                                                           const double* __restrict__ gout,
@@ -193,7 +197,7 @@ __global__ __launch_bounds__(kRvBlock) void ov_vjp_kernel(const double* __restri
   for (int k = 0; k < EXO_OV_NPAR; ++k) acc[k] = 0.0;
   for (int64_t n = threadIdx.x; n < n_cad; n += kRvBlock) {
     const double tn = t[n];
-    const OvSample s = ov_sample<VELOCITY>(tn, rec);
+    const OvSample s = ov_sample<MODE>(tn, rec);
     const double* __restrict__ g = gout + 3 * ((d * n_cad + n) * n_planet + p);
     const double gX0 = g[0], gY0 = g[1], gZ0 = g[2];
     acc[EXO_OV_AMP] += gX0 * s.X + gY0 * s.Y + gZ0 * s.Z;
@@ -211,9 +215,15 @@ __global__ __launch_bounds__(kRvBlock) void ov_vjp_kernel(const double* __restri
     // d f / d e = (2 + e cos f) sin f / (1 - e^2)
     const double q = 1.0 + e * s.cosf;
     double gf, ge;
-    if (VELOCITY) {
+    if (MODE == 1) {
       gf = -gu * s.cosf - gv * s.sinf;
       ge = gv;
+    } else if (MODE == 2) {
+      const double g = q * q * iome2;
+      const double g_f = -2.0 * q * e * s.sinf * iome2;                                 // d g / d f
+      const double g_e = 2.0 * q * (s.cosf * ome2 + e * q) * iome2 * iome2;             // d g / d e at fixed f
+      gf = -gu * (g_f * s.cosf - g * s.sinf) - gv * (g_f * s.sinf + g * s.cosf);
+      ge = -(gu * s.cosf + gv * s.sinf) * g_e;
     } else {
       const double iq = 1.0 / q, rho = ome2 * iq;
       const double rho_f = rho * e * s.sinf * iq;                                // d rho / d f
@@ -280,31 +290,37 @@ int exo_radial_velocity_vjp_f64(const double* t, int64_t n_cad, const double* pa
 
 int exo_orbit_vector_fwd_f64(const double* t, int64_t n_cad, const double* params, int64_t n_draw, int32_t n_planet,
                              uint32_t flags, double* out, void* stream) {
-  if (!rv_args_ok(n_cad, n_draw, n_planet) || (flags & ~EXO_OV_VELOCITY)) return EXO_ERR_INVALID_ARGUMENT;
+  if (!rv_args_ok(n_cad, n_draw, n_planet) || flags > EXO_OV_ACCELERATION) return EXO_ERR_INVALID_ARGUMENT;
   const int64_t total = n_draw * n_cad * n_planet;
   if (total == 0) return EXO_OK;
   if (!t || !params || !out) return EXO_ERR_INVALID_ARGUMENT;
   int64_t blocks = (total + kRvBlock - 1) / kRvBlock;
   if (blocks > 65536) blocks = 65536;
-  if (flags & EXO_OV_VELOCITY)
-    hipLaunchKernelGGL(ov_fwd_kernel<true>, dim3((unsigned)blocks), dim3(kRvBlock), 0, (hipStream_t)stream, t, n_cad, params,
+  if (flags == EXO_OV_VELOCITY)
+    hipLaunchKernelGGL(ov_fwd_kernel<1>, dim3((unsigned)blocks), dim3(kRvBlock), 0, (hipStream_t)stream, t, n_cad, params,
+                       n_draw, n_planet, out);
+  else if (flags == EXO_OV_ACCELERATION)
+    hipLaunchKernelGGL(ov_fwd_kernel<2>, dim3((unsigned)blocks), dim3(kRvBlock), 0, (hipStream_t)stream, t, n_cad, params,
                        n_draw, n_planet, out);
   else
-    hipLaunchKernelGGL(ov_fwd_kernel<false>, dim3((unsigned)blocks), dim3(kRvBlock), 0, (hipStream_t)stream, t, n_cad, params,
+    hipLaunchKernelGGL(ov_fwd_kernel<0>, dim3((unsigned)blocks), dim3(kRvBlock), 0, (hipStream_t)stream, t, n_cad, params,
                        n_draw, n_planet, out);
   return hipGetLastError() == hipSuccess ? EXO_OK : EXO_ERR_LAUNCH;
 }
 
 int exo_orbit_vector_vjp_f64(const double* t, int64_t n_cad, const double* params, int64_t n_draw, int32_t n_planet,
                              uint32_t flags, const double* gout, double* gparams, void* stream) {
-  if (!rv_args_ok(n_cad, n_draw, n_planet) || (flags & ~EXO_OV_VELOCITY)) return EXO_ERR_INVALID_ARGUMENT;
+  if (!rv_args_ok(n_cad, n_draw, n_planet) || flags > EXO_OV_ACCELERATION) return EXO_ERR_INVALID_ARGUMENT;
   if (n_draw == 0) return EXO_OK;
   if (!params || !gparams || (n_cad > 0 && (!t || !gout))) return EXO_ERR_INVALID_ARGUMENT;
-  if (flags & EXO_OV_VELOCITY)
-    hipLaunchKernelGGL(ov_vjp_kernel<true>, dim3((unsigned)(n_draw * n_planet)), dim3(kRvBlock), 0, (hipStream_t)stream, t,
+  if (flags == EXO_OV_VELOCITY)
+    hipLaunchKernelGGL(ov_vjp_kernel<1>, dim3((unsigned)(n_draw * n_planet)), dim3(kRvBlock), 0, (hipStream_t)stream, t,
+                       n_cad, params, n_planet, gout, gparams);
+  else if (flags == EXO_OV_ACCELERATION)
+    hipLaunchKernelGGL(ov_vjp_kernel<2>, dim3((unsigned)(n_draw * n_planet)), dim3(kRvBlock), 0, (hipStream_t)stream, t,
                        n_cad, params, n_planet, gout, gparams);
   else
-    hipLaunchKernelGGL(ov_vjp_kernel<false>, dim3((unsigned)(n_draw * n_planet)), dim3(kRvBlock), 0, (hipStream_t)stream, t,
+    hipLaunchKernelGGL(ov_vjp_kernel<0>, dim3((unsigned)(n_draw * n_planet)), dim3(kRvBlock), 0, (hipStream_t)stream, t,
                        n_cad, params, n_planet, gout, gparams);
   return hipGetLastError() == hipSuccess ? EXO_OK : EXO_ERR_LAUNCH;
 }

@@ -521,6 +521,7 @@ def transit_flux_sparse(t, params, ld, gflux=None, texp=None, stencil_dt=None, s
 RV_NPAR = 6
 OV_NPAR = 10          # include/exoplanet_amd.h EXO_OV_*
 OV_VELOCITY = 1
+OV_ACCELERATION = 2
 RV_N, RV_TP, RV_ECC, RV_COSW, RV_SINW, RV_AMP = range(6)
 
 
@@ -587,12 +588,12 @@ class _OrbitVector(torch.autograd.Function):
         return None, gparams, None
 
 
-def orbit_vector(t, params, velocity=False):
-    """Position (or, ``velocity=True``, velocity) vectors in the observer frame for ``n_draw`` parameter sets, one
+def orbit_vector(t, params, velocity=False, acceleration=False):
+    """Position (or, ``velocity=True`` / ``acceleration=True``, velocity / acceleration) vectors in the observer frame for ``n_draw`` parameter sets, one
     fused launch each way: t (n_cad,), params (n_draw, n_planet, 10) with slots EXO_OV_* (n, t_periastron, ecc,
     cos / sin omega, cos / sin incl, amplitude, cos / sin Omega) -> (n_draw, n_cad, n_planet, 3) = (X, Y, Z).
     Differentiable with respect to ``params``.  (keplerian.py:380-409, :572-578, :283-322)"""
-    return _OrbitVector.apply(t, params, OV_VELOCITY if velocity else 0)
+    return _OrbitVector.apply(t, params, OV_ACCELERATION if acceleration else (OV_VELOCITY if velocity else 0))
 
 
 def radial_velocity(t, params):

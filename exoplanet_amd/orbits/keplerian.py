@@ -319,7 +319,7 @@ class KeplerianOrbit:
         e = self.ecc.unsqueeze(-2) + torch.zeros_like(M)
         return ops.kepler(M.contiguous(), e.contiguous())
 
-    def _fused_vector(self, amp, t, velocity):
+    def _fused_vector(self, amp, t, velocity, acceleration=False):
         """(X, Y, Z) through ops.orbit_vector -- one launch each way instead of the solve, the radius, three
         rotations and their broadcasts as ~40 launch-bound torch kernels -- or None when the times are not a
         1-D device tensor / the orbit warps its times (TTV-type subclasses take the composed path)."""
@@ -335,7 +335,7 @@ class KeplerianOrbit:
         cols = torch.broadcast_tensors(self.n, self.t_periastron, e, cw, sw, self.cos_incl, self.sin_incl, amp, cO, sO)
         shape = cols[0].shape
         params = torch.stack(cols, dim=-1).reshape(-1, shape[-1], ops.OV_NPAR).contiguous()
-        out = ops.orbit_vector(t, params, velocity=velocity)
+        out = ops.orbit_vector(t, params, velocity=velocity, acceleration=acceleration)
         out = out.reshape(tuple(shape[:-1]) + (t.shape[0], shape[-1], 3))
         return out[..., 0], out[..., 1], out[..., 2]
 
@@ -463,6 +463,9 @@ class KeplerianOrbit:
         return -m_per_s_per_Rsun_per_day * self.get_star_velocity(t)[2]
 
     def _get_acceleration(self, a, m, t):
+        fused = self._fused_vector((self.K0 * m) ** 2 / a, t, velocity=False, acceleration=True)
+        if fused is not None:
+            return fused
         sinf, cosf = self._get_true_anomaly(t)
         K = (self.K0 * m).unsqueeze(-2)
         a = a.unsqueeze(-2)

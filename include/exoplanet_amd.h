@@ -277,11 +277,14 @@ int exo_radial_velocity_vjp_f64(const double* t, int64_t n_cad, const double* pa
  *   KeplerianOrbit.get_{star,planet,relative}_position   (src/exoplanet/orbits/keplerian.py:472-542 -> :380-409)
  *   KeplerianOrbit.get_{star,planet,relative}_velocity   (keplerian.py:580-631 -> :572-578)
  *   KeplerianOrbit.get_relative_angles                   (keplerian.py:544-570: rho, theta from X, Y)
- * In the orbital plane  position: (u, v) = (1 - e^2) / (1 + e cos f) (cos f, sin f);  with EXO_OV_VELOCITY:
- * (u, v) = (-sin f, cos f + e);  then _rotate_vector (keplerian.py:283-322) and the amplitude:
+ *   KeplerianOrbit.get_{star,planet,relative}_acceleration   (keplerian.py:679-706)
+ * In the orbital plane  position (flags = 0): (u, v) = (1 - e^2) / (1 + e cos f) (cos f, sin f);  flags =
+ * EXO_OV_VELOCITY: (u, v) = (-sin f, cos f + e);  flags = EXO_OV_ACCELERATION: (u, v) = -(1 + e cos f)^2 / (1 - e^2)
+ * (cos f, sin f);  then _rotate_vector (keplerian.py:283-322) and the amplitude:
  *   x1 = COSW u - SINW v, y1 = SINW u + COSW v;  x2 = x1, y2 = COSI y1, Z = -SINI y1;
  *   X = COSO x2 - SINO y2, Y = SINO x2 + COSO y2;   out[d][n][p] = AMP (X, Y, Z)
- * AMP: a_star / a_planet / -a (times parallax au_per_R_sun, keplerian.py:404-406) for positions, K0 m for velocities;
+ * AMP: a_star / a_planet / -a (times parallax au_per_R_sun, keplerian.py:404-406) for positions, K0 m for velocities,
+ * (K0 m)^2 / a for accelerations;
  * COSO = 1, SINO = 0 when the orbit has no Omega; ECC = 0, COSW = 1, SINW = 0 when circular.
  * out / gout [n_draw][n_cad][n_planet][3]; params / gparams [n_draw][n_planet][EXO_OV_NPAR].
  * ------------------------------------------------------------------------- */
@@ -297,6 +300,7 @@ int exo_radial_velocity_vjp_f64(const double* t, int64_t n_cad, const double* pa
 #define EXO_OV_COSO 8
 #define EXO_OV_SINO 9
 #define EXO_OV_VELOCITY 1u
+#define EXO_OV_ACCELERATION 2u
 int exo_orbit_vector_fwd_f64(const double* t, int64_t n_cad, const double* params, int64_t n_draw, int32_t n_planet,
                              uint32_t flags, double* out, void* stream);
 int exo_orbit_vector_vjp_f64(const double* t, int64_t n_cad, const double* params, int64_t n_draw, int32_t n_planet,

@@ -593,6 +593,28 @@ class KeplerianOrbit:
         """reference: keplerian.py:614-631"""
         return tuple(np.squeeze(x) for x in self._get_velocity(-self.m_total, t))
 
+    def _get_acceleration(self, a, m, t):
+        """reference: keplerian.py:679-688"""
+        sinf, cosf = self._get_true_anomaly(np.asarray(t, dtype=np.float64))
+        K = self.K0 * m
+        if self.ecc is None:
+            factor = -(K ** 2) / a
+        else:
+            factor = K ** 2 * (self.ecc * cosf + 1) ** 2 / (a * (self.ecc ** 2 - 1))
+        return self._rotate_vector(factor * cosf, factor * sinf)
+
+    def get_planet_acceleration(self, t):
+        """reference: keplerian.py:690-694"""
+        return tuple(np.squeeze(x) for x in self._get_acceleration(self.a_planet, -self.m_star, t))
+
+    def get_star_acceleration(self, t):
+        """reference: keplerian.py:696-700"""
+        return tuple(np.squeeze(x) for x in self._get_acceleration(self.a_star, self.m_planet, t))
+
+    def get_relative_acceleration(self, t):
+        """reference: keplerian.py:702-706"""
+        return tuple(np.squeeze(x) for x in self._get_acceleration(-self.a, -self.m_total, t))
+
     def in_transit(self, t, r=0.0, texp=None):
         """reference: keplerian.py:708-777"""
         t = np.asarray(t, dtype=np.float64)

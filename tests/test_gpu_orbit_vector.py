@@ -32,7 +32,8 @@ def _orbits(dev, D, rng, circular=False, with_Omega=True):
 
 
 METHODS = ["get_star_position", "get_planet_position", "get_relative_position", "get_star_velocity",
-           "get_planet_velocity", "get_relative_velocity"]
+           "get_planet_velocity", "get_relative_velocity", "get_star_acceleration", "get_planet_acceleration",
+           "get_relative_acceleration"]
 
 
 @pytest.mark.parametrize("circular,with_Omega", [(False, True), (False, False), (True, True)])

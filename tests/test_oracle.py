@@ -347,6 +347,13 @@ def test_oracle_velocities_are_time_derivatives_of_positions():
         for k in range(3):
             fd = (hi[k] - lo[k]) / (2 * h)
             assert np.allclose(v[k], fd, rtol=1e-6, atol=1e-8 * np.abs(fd).max()), (pos, k)
+    for vel, acc in (("get_star_velocity", "get_star_acceleration"), ("get_planet_velocity", "get_planet_acceleration"),
+                     ("get_relative_velocity", "get_relative_acceleration")):   # keplerian_test.py:158-196
+        a = getattr(orbit, acc)(t)
+        hi, lo = getattr(orbit, vel)(t + h), getattr(orbit, vel)(t - h)
+        for k in range(3):
+            fd = (hi[k] - lo[k]) / (2 * h)
+            assert np.allclose(a[k], fd, rtol=1e-6, atol=1e-8 * np.abs(fd).max()), (acc, k)
     X, Y, _ = orbit.get_relative_position(t)
     rho, theta = orbit.get_relative_angles(t, parallax=0.05)
     assert np.allclose(rho, np.hypot(X, Y) * 0.05 * P.au_per_R_sun, rtol=1e-14)
