@@ -260,7 +260,10 @@ EXO_HDH int64_t seq_state_doubles(int64_t n, int64_t n_draw, int J) {
 
 // How a series is cut.  n_chunks = 0: the default plan; 1: sequential; > 1: forced.  A pure
 // function of its arguments: the forward and the reverse call of a pair compute the same plan.
-constexpr int kFineLevels = 1;   // J > 2: elements built for 2 x finer chunks, composed pairwise once
+#ifndef EXO_FINE_LEVELS
+#define EXO_FINE_LEVELS 1
+#endif
+constexpr int kFineLevels = EXO_FINE_LEVELS;   // J > 2: elements built for 2 x finer chunks, composed pairwise once
 EXO_HDH ChunkGeom chunk_plan(int64_t n, int64_t n_draw, int J, int32_t n_chunks) {
   ChunkGeom g{1, n, seq_state_doubles(n, n_draw, J), 0, 0, 0};
   if (J > kChunkMaxJ || J < 1 || n < 64) return g;
