@@ -28,7 +28,10 @@
 namespace gp {
 
 constexpr double kHalfLog2Pi = 0.91893853320467274178;
-constexpr int kCkptB = 4;   // cadences per checkpoint block of the one-lane chunk kernels
+constexpr int kCkptB = 4;   // cadences per block of the one-lane chunk kernels (series rows move four at a time)
+// cadences per CHECKPOINT: the whole block for J <= 2; half a block for wider states -- the reverse kernel keeps the
+// recomputed states of a span in registers (J (J + 1) / 2 + 2 J + 2 doubles each), and four of them do not fit at J > 2
+EXO_HDH constexpr int ckpt_span(int J) { return J > 2 ? 2 : 4; }
 
 // Term coefficients of a batch of draws, celerite2's Term.get_coefficients() form:
 //   real  [n_draw][n_real][2]     (a, c)
@@ -185,7 +188,7 @@ struct ChunkWs {
   }
   EXO_HDH int64_t off_flag() const { return off_gpart() + (int64_t)C * (4 * J + 1) * n_draw; }
   EXO_HDH int64_t off_ckpt() const { return off_flag() + n_draw; }
-  // checkpoint of global block g (cadences [g kCkptB, (g + 1) kCkptB)): k < J: F_k; then packed S
+  // checkpoint g = the state at cadence g ckpt_span(J): k < J: F_k; then packed S
   EXO_HDH int64_t ckpt(int64_t g, int k, int64_t draw) const { return off_ckpt() + (g * K() + k) * n_draw + draw; }
   // elements of the finer levels (ChunkGeom::fine): level f has C << f chunks; level `fine` is built, f = 0 is elem()
   int fine;
@@ -249,7 +252,7 @@ EXO_HD void load_block(const SeriesRow& y, const double* EXO_RESTRICT dg, int64_
 
 constexpr int kChunkMaxJ = 8;   // = EXO_GP_MAX_J (J = 7, 8: lane-group element kernel, one-lane scan kernels spill)
 #ifndef EXO_LANE_MAX_J
-#define EXO_LANE_MAX_J 2
+#define EXO_LANE_MAX_J 6
 #endif
 constexpr int kLaneMaxJ = EXO_LANE_MAX_J;   // one-lane chunk kernels up to this state width (registers: DESIGN.md 4)
 
@@ -298,7 +301,7 @@ EXO_HDH ChunkGeom chunk_plan(int64_t n, int64_t n_draw, int J, int32_t n_chunks)
 }
 
 EXO_HDH ChunkWs chunk_ws(int64_t n, int64_t n_draw, int J, const ChunkGeom& g) {
-  return ChunkWs{n_draw, J, g.C, g.base, g.lane ? (n + kCkptB - 1) / kCkptB : 0, g.fine, g.tree};
+  return ChunkWs{n_draw, J, g.C, g.base, g.lane ? (n + ckpt_span(J) - 1) / ckpt_span(J) : 0, g.fine, g.tree};
 }
 // the geometry the element kernels see when they build level f: C << f chunks of L >> f cadences, elem()
 // addressing that level's array; flags stay where the coarse geometry has them (flag_at)
@@ -360,16 +363,20 @@ struct DeltaCoef {
   EXO_HD void eval(const double* V, Sym<J>& D) const {
 #pragma unroll
     for (int k = 0; k < J * (J + 1) / 2; ++k) D.v[k] = 0.0;
+    // (every store below is unconditional, at a compile-time index, with the layout deciding the VALUE: with run-time
+    // layouts the compiler merges the branches' stores into one with a run-time index, and an array indexed at run
+    // time lives in scratch memory -- all of it, for the whole kernel: what made the one-lane kernels crawl at J > 2)
+    double next_dd = 0.0;   // the pair's second diagonal entry, handed over by its first index
 #pragma unroll
     for (int j = 0; j < J; ++j) {
-      if (is_real(j)) {
-        D(j, j) = p[j];
-      } else if (is_first(j) && j + 1 < J) {
-        const double cs = V[j], sn = V[j + 1];
-        D(j, j) = p[j] * cs * cs + 2.0 * q[j] * cs * sn + r[j] * sn * sn;
-        D(j, j + 1) = (p[j] - r[j]) * cs * sn + q[j] * (sn * sn - cs * cs);
-        D(j + 1, j + 1) = p[j] * sn * sn - 2.0 * q[j] * cs * sn + r[j] * cs * cs;
-      }
+      const bool re = is_real(j), fi = !re && is_first(j) && j + 1 < J;
+      const double cs = V[j], sn = V[j + 1 < J ? j + 1 : j];
+      const double dd = p[j] * cs * cs + 2.0 * q[j] * cs * sn + r[j] * sn * sn;
+      const double od = (p[j] - r[j]) * cs * sn + q[j] * (sn * sn - cs * cs);
+      const double d2 = p[j] * sn * sn - 2.0 * q[j] * cs * sn + r[j] * cs * cs;
+      D(j, j) = re ? p[j] : (fi ? dd : next_dd);
+      if (j + 1 < J) D(j, j + 1) = fi ? od : 0.0;
+      next_dd = fi ? d2 : 0.0;
     }
   }
 };
@@ -391,29 +398,39 @@ struct DrawCoef {
     dt_ref = dt_miss = -1.0;
     near_ok = false;
   }
+  // (stores unconditional at compile-time indices, see DeltaCoef::eval; a pair's second index gets its values from the
+  // first through `nu`, `nv`)
   EXO_HD void uv(double t, double* U, double* V) const {
+    double nu = 0.0, nv = 0.0;
+    bool carry = false;
 #pragma unroll
     for (int j = 0; j < J; ++j) {
+      double uj = carry ? nu : U[j], vj = carry ? nv : V[j];
+      carry = false;
       if (is_real(j)) {
-        U[j] = k[j].a; V[j] = 1.0;
+        uj = k[j].a; vj = 1.0;
       } else if (is_first(j)) {
         double sn, cs;
         exo::sincos_any(k[j].d * t, &sn, &cs);
-        U[j] = k[j].a * cs + k[j].b * sn; V[j] = cs;
-        if (j + 1 < J) { U[j + 1] = k[j].a * sn - k[j].b * cs; V[j + 1] = sn; }
+        uj = k[j].a * cs + k[j].b * sn; vj = cs;
+        nu = k[j].a * sn - k[j].b * cs; nv = sn;
+        carry = true;
       }
+      U[j] = uj; V[j] = vj;
     }
   }
   // U from V alone (V of a pair is (cos, sin)): the reverse pass keeps V and rebuilds U
   EXO_HD void u_from_v(const double* V, double* U) const {
+    double nu = 0.0;
+    bool carry = false;
 #pragma unroll
     for (int j = 0; j < J; ++j) {
-      if (is_real(j)) {
-        U[j] = k[j].a;
-      } else if (is_first(j) && j + 1 < J) {
-        U[j] = k[j].a * V[j] + k[j].b * V[j + 1];
-        U[j + 1] = k[j].a * V[j + 1] - k[j].b * V[j];
-      }
+      const bool re = is_real(j), fi = !re && is_first(j) && j + 1 < J;
+      const double vn = V[j + 1 < J ? j + 1 : j];
+      const double uj = re ? k[j].a : (fi ? k[j].a * V[j] + k[j].b * vn : (carry ? nu : U[j]));
+      nu = k[j].a * vn - k[j].b * V[j];
+      carry = fi;
+      U[j] = uj;
     }
   }
   // Steps of an (almost) evenly sampled stretch.  Time stamps that are "evenly sampled" differ from step to step in
@@ -432,10 +449,12 @@ struct DrawCoef {
     for (int j = 0; j < J; ++j) {
       ph[j] = exp(-k[j].c * dt);
       big = fmax(big, fabs(k[j].c));
+      double sn = rs[j], cs = rc[j];
       if (!is_real(j) && is_first(j)) {
-        exo::sincos_any(k[j].d * dt, &rs[j], &rc[j]);
+        exo::sincos_any(k[j].d * dt, &sn, &cs);
         big = fmax(big, fabs(k[j].d));
       }
+      rs[j] = sn; rc[j] = cs;
     }
     near_ok = big * dt <= 8.0 && dt > 0.0;
   }
@@ -471,17 +490,18 @@ struct DrawCoef {
   // first cadence of every block of four (counted from the chunk start): three rotations in a row drift by ~3e-16.
   EXO_HD void rot_uv(double dt, const double* Vp, double* U, double* V) const {
     const double del = dt - dt_ref;
+    double nv = 0.0;
+    bool carry = false;
 #pragma unroll
     for (int j = 0; j < J; ++j) {
-      if (is_real(j)) {
-        V[j] = 1.0;
-      } else if (is_first(j) && j + 1 < J) {
-        const double cs = Vp[j], sn = Vp[j + 1];
-        const double c1 = fma(cs, rc[j], -sn * rs[j]), s1 = fma(sn, rc[j], cs * rs[j]);
-        const double e = k[j].d * del, h = fma(-0.5 * e, e, 1.0);
-        V[j] = fma(-e, s1, c1 * h);
-        V[j + 1] = fma(e, c1, s1 * h);
-      }
+      const bool re = is_real(j), fi = !re && is_first(j) && j + 1 < J;
+      const double cs = Vp[j], sn = Vp[j + 1 < J ? j + 1 : j];
+      const double c1 = fma(cs, rc[j], -sn * rs[j]), s1 = fma(sn, rc[j], cs * rs[j]);
+      const double e = k[j].d * del, h = fma(-0.5 * e, e, 1.0);
+      const double vj = re ? 1.0 : (fi ? fma(-e, s1, c1 * h) : (carry ? nv : V[j]));
+      nv = fma(e, c1, s1 * h);
+      carry = fi;
+      V[j] = vj;
     }
     u_from_v(V, U);
   }
@@ -1060,8 +1080,8 @@ EXO_HD void chunk1_fwd_lane(const double* EXO_RESTRICT t, Series rs, const doubl
             co.rot_uv(dt, Vp, f.U, f.V);
           }
         }
-        if (q == 0 && save) {   // checkpoint: the state AT the block's first cadence (after the step into it)
-          const int64_t g = b0 / kCkptB;
+        if (q % ckpt_span(J) == 0 && save) {   // checkpoint: the state AT the span's first cadence (after the step into it)
+          const int64_t g = i / ckpt_span(J);
 #pragma unroll
           for (int j = 0; j < J; ++j) state[ws.ckpt(g, j, draw)] = f.F[j];
 #pragma unroll
@@ -1135,17 +1155,16 @@ struct Rev {
       Ub[j] += acc_u;
     }
     // coefficient cotangents: a real term's U = a; a complex pair's (a, b, d) collect on its first index
+    // (accumulators updated unconditionally, the layout deciding the increment: see DeltaCoef::eval)
 #pragma unroll
     for (int j = 0; j < J; ++j) {
-      if (co.is_real(j)) {
-        ga[j] += Ub[j];
-      } else if (co.is_first(j) && j + 1 < J) {
-        const double cs = s.V[j], sn = s.V[j + 1];
-        const double a = co.k[j].a, b = co.k[j].b;
-        ga[j] += Ub[j] * cs + Ub[j + 1] * sn;
-        gb[j] += Ub[j] * sn - Ub[j + 1] * cs;
-        gd[j] += ti * (Ub[j] * (-a * sn + b * cs) + Ub[j + 1] * (a * cs + b * sn) - Vb[j] * sn + Vb[j + 1] * cs);
-      }
+      const bool re = co.is_real(j), fi = !re && co.is_first(j) && j + 1 < J;
+      const int jn = j + 1 < J ? j + 1 : j;
+      const double cs = s.V[j], sn = s.V[jn];
+      const double a = co.k[j].a, b = co.k[j].b;
+      ga[j] += re ? Ub[j] : (fi ? Ub[j] * cs + Ub[jn] * sn : 0.0);
+      gb[j] += fi ? Ub[j] * sn - Ub[jn] * cs : 0.0;
+      gd[j] += fi ? ti * (Ub[j] * (-a * sn + b * cs) + Ub[jn] * (a * cs + b * sn) - Vb[j] * sn + Vb[jn] * cs) : 0.0;
     }
   }
 
@@ -1345,6 +1364,300 @@ EXO_HD void chunk1_vjp_lane(const double* EXO_RESTRICT t, Series rs, const doubl
     state[ws.gpart(c, 4 * j + 3, draw)] = r.gd[j];
   }
   state[ws.gpart(c, 4 * J, draw)] = r.gasum;
+}
+
+// (C') reverse for wide states (J > 2): the same adjoint with the (symmetrised) adjoint of S PACKED, and
+// (chunkp_vjp_lane) two checkpoints per block.  Hand-derived adjoint of the two recurrences (same algebra as celerite_vjp_kernel
+// of exo_celerite.hip, one lane holding every state index): Sb is the SYMMETRISED adjoint of S.
+template <int J, int NR = -1>
+struct RevP {
+  Sym<J> Sb;   // (symmetrised adjoint of S: packed)
+  double Fb[J], Wb[J];
+  double db, zb;
+  // coefficient cotangents: 4 J + 1 accumulators OUTSIDE the register file -- on the device a column of shared
+  // memory per lane (slot k at g[k * gs]), on the host a plain array (gs = 1): k = 4 j + {a, b, c, d}; 4 J = sum of dbar
+  double* g;
+  int gs;
+  EXO_HD void gadd(int k, double v) { g[k * gs] += v; }
+
+  // measurement half of cadence i: adjoints of (d, z, W) of this cadence -> (S, F) of this cadence
+  // and the coefficient cotangents through U, V.  W = (V - S U) / d is rebuilt (the step keeps V).
+  // Returns zbar (d loglike / d y_i) and dbar (d loglike / d diag_i).
+  EXO_HD void measure(const DrawCoef<J, NR>& co, const Step<J>& s, double ti, double gL, double* W_out, double* zbar_out,
+                      double* dbar_out) {
+    double U[J], u[J], W[J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) U[j] = 0.0;
+    co.u_from_v(s.V, U);
+    const double id = exo::fast_rcp(s.d);
+    double wdot = 0.0;
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      double uj = 0.0;
+#pragma unroll
+      for (int l = 0; l < J; ++l) uj = fma(s.S(j, l), U[l], uj);
+      u[j] = uj;
+      W[j] = (s.V[j] - uj) * id;
+      W_out[j] = W[j];
+      wdot = fma(Wb[j], W[j], wdot);
+    }
+    const double zbar = zb - gL * s.z * id;
+    const double dbar = db + gL * (0.5 * s.z * s.z * id * id - 0.5 * id) - wdot * id;
+    *zbar_out = zbar;
+    *dbar_out = dbar;
+    gadd(4 * J, dbar);
+    double Ub[J], Vb[J], ub[J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      Ub[j] = fma(-dbar, u[j], -zbar * s.F[j]);
+      Fb[j] = fma(-zbar, U[j], Fb[j]);
+      Vb[j] = Wb[j] * id;
+      ub[j] = -Vb[j] - dbar * U[j];
+    }
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      double acc_u = 0.0;
+#pragma unroll
+      for (int l = 0; l < J; ++l) {
+        if (l >= j) Sb(j, l) = fma(0.5, fma(ub[j], U[l], ub[l] * U[j]), Sb(j, l));   // symmetrised  ub U^T
+        acc_u = fma(s.S(j, l), ub[l], acc_u);                                        // (S^T ub)_j, S symmetric
+      }
+      Ub[j] += acc_u;
+    }
+    // coefficient cotangents: a real term's U = a; a complex pair's (a, b, d) collect on its first index
+    // (accumulators updated unconditionally, the layout deciding the increment: see DeltaCoef::eval)
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      const bool re = co.is_real(j), fi = !re && co.is_first(j) && j + 1 < J;
+      const int jn = j + 1 < J ? j + 1 : j;
+      const double cs = s.V[j], sn = s.V[jn];
+      const double a = co.k[j].a, b = co.k[j].b;
+      gadd(4 * j + 0, re ? Ub[j] : (fi ? Ub[j] * cs + Ub[jn] * sn : 0.0));
+      gadd(4 * j + 1, fi ? Ub[j] * sn - Ub[jn] * cs : 0.0);
+      gadd(4 * j + 3, fi ? ti * (Ub[j] * (-a * sn + b * cs) + Ub[jn] * (a * cs + b * sn) - Vb[j] * sn + Vb[jn] * cs) : 0.0);
+    }
+  }
+
+  // reverse of the step p -> n (p = n - 1):  F_n = P o (F_p + W_p z_p),  S_n = P P^T o (S_p + d_p W_p W_p^T);
+  // on entry Sb, Fb are the adjoints of S_n, F_n; on exit those of S_p, F_p, and Wb, db, zb those of
+  // W_p, d_p, z_p.  Wp = W of cadence p.
+  EXO_HD void propagate(const Step<J>& p, const double* Wp, const double* phi, double dt) {
+    double Gb[J], Pb[J], Wbn[J];
+    double zbn = 0.0, dbn = 0.0;
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      const double Gj = fma(Wp[j], p.z, p.F[j]);
+      Pb[j] = Fb[j] * Gj;
+      Gb[j] = Fb[j] * phi[j];
+      Wbn[j] = Gb[j] * p.z;
+      zbn = fma(Gb[j], Wp[j], zbn);
+    }
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      double psum = 0.0, wsum = 0.0;
+#pragma unroll
+      for (int l = 0; l < J; ++l) {
+        const double T = fma(p.d * Wp[j], Wp[l], p.S(j, l));
+        const double sb = Sb(j, l);                        // (still the adjoint of S_n: updated below, once per pair)
+        const double Tb = sb * phi[j] * phi[l];            // adjoint of T (symmetric)
+        psum = fma(2.0 * sb * T, phi[l], psum);
+        wsum = fma(Tb, Wp[l], wsum);
+      }
+      Pb[j] += psum;
+      Wbn[j] = fma(2.0 * p.d, wsum, Wbn[j]);
+      dbn = fma(wsum, Wp[j], dbn);
+      gadd(4 * j + 2, -dt * phi[j] * Pb[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < J; ++j)
+#pragma unroll
+      for (int l = j; l < J; ++l) Sb(j, l) *= phi[j] * phi[l];   // becomes the adjoint of S_p
+    db = dbn; zb = zbn;
+#pragma unroll
+    for (int j = 0; j < J; ++j) { Fb[j] = Gb[j]; Wb[j] = Wbn[j]; }
+  }
+};
+
+// gsign: +1 writes d loglike / d resid; -1 writes d loglike / d model (obs - model series)
+template <int J, int NR = -1>
+EXO_HD void chunkp_vjp_lane(const double* EXO_RESTRICT t, Series rs, const double* EXO_RESTRICT diag, int64_t n_diag,
+                            int64_t n, const Coefs& cf, int64_t n_draw, const double* EXO_RESTRICT gloglike,
+                            double* EXO_RESTRICT state, const ChunkGeom& cg, double* EXO_RESTRICT gresid,
+                            double* EXO_RESTRICT gdiag, double gsign, int64_t draw, int c, double* gacc, int gstride) {
+  const int64_t n0 = c * cg.L, n1 = (n0 + cg.L < n) ? n0 + cg.L : n;
+  const ChunkWs ws = chunk_ws(n, n_draw, J, cg);
+  DrawCoef<J, NR> co;
+  co.init(cf, draw);
+  const double asum = co.asum();
+  const SeriesRow y{rs.y + draw * n, rs.obs};
+  const double* EXO_RESTRICT dg = diag + (n_diag == 1 ? 0 : draw * n);
+  const double gL = gloglike[draw];
+  RevP<J, NR> r;
+#pragma unroll
+  for (int j = 0; j < J; ++j) {
+    r.Fb[j] = state[ws.bnd(2, c, j, draw)];
+    r.Wb[j] = 0.0;
+#pragma unroll
+    for (int l = j; l < J; ++l)   // (the adjoint scan leaves a symmetric matrix)
+      r.Sb(j, l) = 0.5 * (state[ws.bnd(2, c, J + j * J + l, draw)] + state[ws.bnd(2, c, J + l * J + j, draw)]);
+  }
+  r.db = r.zb = 0.0;
+  r.g = gacc; r.gs = gstride;
+#pragma unroll
+  for (int k = 0; k < 4 * J + 1; ++k) gacc[k * gstride] = 0.0;
+  double phi[J];
+  if (n0 + 1 < n) co.set_ref(t[n0 + 1] - t[n0]);   // the forward kernel's reference: its first step
+  // blocks last to first; `pend`: the step from this block's last cadence into cadence `next` (the
+  // first cadence of the block after it, or of the next chunk) still has to be reversed
+  const int64_t nb = (n1 - n0 + kCkptB - 1) / kCkptB;
+  bool pend = n1 < n;
+  constexpr int kK = J + J * (J + 1) / 2;
+  constexpr int kSpan = ckpt_span(J), kSub = kCkptB / kSpan;   // cadences per checkpoint, checkpoints per block
+  constexpr bool kAhead = kSub == 1;   // the next block's checkpoint is loaded ahead only where the registers allow
+  // inputs of a block: its checkpoint(s) (F, packed S) and its cadences of the series
+  BlockIn cur, nxt;
+  double ck[kK], ck_nxt[kAhead ? kK : 1];
+  auto load_ckpt = [&](int64_t i0, double* dst) {   // the checkpoint at cadence i0 (a multiple of kSpan from the chunk start)
+    const int64_t g = i0 / kSpan;
+#pragma unroll
+    for (int k = 0; k < kK; ++k) dst[k] = state[ws.ckpt(g, k, draw)];
+  };
+  load_block(y, dg, n_diag, n0 + (nb - 1) * kCkptB, n1, cur);
+  if (kAhead) {
+    load_ckpt(n0 + (nb - 1) * kCkptB, ck);
+#pragma unroll
+    for (int k = 0; k < (kAhead ? kK : 1); ++k) ck_nxt[k] = ck[k];
+  }
+  nxt = cur;
+#pragma unroll 1
+  for (int64_t bi = nb - 1; bi >= 0; --bi) {
+    const int64_t b0 = n0 + bi * kCkptB;
+    const int len = (int)((n1 - b0 < kCkptB) ? n1 - b0 : kCkptB);
+    if (bi > 0) {   // the block before this one: in flight while this one is worked through
+      load_block(y, dg, n_diag, b0 - kCkptB, n1, nxt);
+      if (kAhead) load_ckpt(b0 - kCkptB, ck_nxt);
+    }
+    double zbar[kCkptB], dbar[kCkptB];
+#pragma unroll
+    for (int q = 0; q < kCkptB; ++q) zbar[q] = dbar[q] = 0.0;
+    // the block's spans, last to first: recompute a span forward from its checkpoint, keeping every cadence's state,
+    // then walk it backwards
+#pragma unroll
+    for (int h = kSub - 1; h >= 0; --h) {
+      const int q0 = h * kSpan;                                  // first cadence of the span, within the block
+      const int slen = (len - q0 < kSpan) ? len - q0 : kSpan;    // its cadences that exist (<= 0: none)
+      if (slen > 0) {
+        if (!kAhead) load_ckpt(b0 + q0, ck);
+        Step<J> st[kSpan];
+        double tt[kSpan];
+        {
+          Fwd<J> f;
+#pragma unroll
+          for (int j = 0; j < J; ++j) { f.F[j] = ck[j]; f.U[j] = f.V[j] = f.W[j] = 0.0; }
+#pragma unroll
+          for (int k = 0; k < J * (J + 1) / 2; ++k) f.S.v[k] = ck[J + k];
+          double tprev = t[b0 + q0];
+#pragma unroll
+          for (int ql = 0; ql < kSpan; ++ql) {
+            if (ql < slen) {
+              const double ti = t[b0 + q0 + ql];
+              tt[ql] = ti;
+              if (ql > 0) {
+                const double dt = ti - tprev;
+                const bool near = co.step(dt, phi);
+                tprev = ti;
+                f.advance(phi);
+                if (near) {
+                  double Vp[J];
+#pragma unroll
+                  for (int j = 0; j < J; ++j) Vp[j] = f.V[j];
+                  co.rot_uv(dt, Vp, f.U, f.V);
+                } else {
+                  co.uv(ti, f.U, f.V);
+                }
+              } else {
+                co.uv(ti, f.U, f.V);
+              }
+              f.measure(cur.y[q0 + ql], cur.g[q0 + ql] + asum);
+              st[ql].S = f.S;
+              st[ql].d = f.d; st[ql].z = f.z;
+#pragma unroll
+              for (int j = 0; j < J; ++j) { st[ql].F[j] = f.F[j]; st[ql].V[j] = f.V[j]; }
+            } else {
+              tt[ql] = 0.0;
+              st[ql] = st[ql > 0 ? ql - 1 : 0];
+            }
+          }
+        }
+#pragma unroll
+        for (int ql = kSpan - 1; ql >= 0; --ql) {
+          if (ql < slen) {
+            const int q = q0 + ql;
+            const int64_t i = b0 + q;
+            double W[J];
+            // the step from cadence i into cadence i + 1 when that is the first cadence of the span / block / chunk
+            // after this one (already walked): W of cadence i from its saved state
+            if (ql == slen - 1 && (q == len - 1 ? pend : true)) {
+              double U[J];
+#pragma unroll
+              for (int j = 0; j < J; ++j) U[j] = 0.0;
+              co.u_from_v(st[ql].V, U);
+              const double id = exo::fast_rcp(st[ql].d);
+#pragma unroll
+              for (int j = 0; j < J; ++j) {
+                double uj = 0.0;
+#pragma unroll
+                for (int l = 0; l < J; ++l) uj = fma(st[ql].S(j, l), U[l], uj);
+                W[j] = (st[ql].V[j] - uj) * id;
+              }
+              const double dt = t[i + 1] - tt[ql];
+              co.step(dt, phi, false);
+              r.propagate(st[ql], W, phi, dt);
+            }
+            r.measure(co, st[ql], tt[ql], gL, W, &zbar[q], &dbar[q]);
+            if (ql > 0) {
+              // reverse of the step (i - 1) -> i inside the span: W of cadence i - 1 is rebuilt inside the next
+              // measure() as well; the few operations are cheaper than a register per state index
+              double U[J], Wp[J];
+#pragma unroll
+              for (int j = 0; j < J; ++j) U[j] = 0.0;
+              co.u_from_v(st[ql - 1].V, U);
+              const double id = exo::fast_rcp(st[ql - 1].d);
+#pragma unroll
+              for (int j = 0; j < J; ++j) {
+                double uj = 0.0;
+#pragma unroll
+                for (int l = 0; l < J; ++l) uj = fma(st[ql - 1].S(j, l), U[l], uj);
+                Wp[j] = (st[ql - 1].V[j] - uj) * id;
+              }
+              const double dt = tt[ql] - tt[ql - 1];
+              co.step(dt, phi, false);
+              r.propagate(st[ql - 1], Wp, phi, dt);
+            }
+          }
+        }
+      }
+    }
+    pend = true;   // the step from the previous block's last cadence into b0
+    // gresid / gdiag are [draw][cadence]: the block's cadences are consecutive doubles of one row
+#pragma unroll
+    for (int q = 0; q < kCkptB; ++q) zbar[q] *= gsign;
+    row_store4(gresid + draw * n, b0, len, zbar);
+    if (gdiag) row_store4(gdiag + draw * n, b0, len, dbar);
+    cur = nxt;
+    if (kAhead) {
+#pragma unroll
+      for (int k = 0; k < (kAhead ? kK : 1); ++k) ck[k] = ck_nxt[k];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < J; ++j) {
+    state[ws.gpart(c, 4 * j + 0, draw)] = gacc[(4 * j + 0) * gstride];
+    state[ws.gpart(c, 4 * j + 1, draw)] = gacc[(4 * j + 1) * gstride];
+    state[ws.gpart(c, 4 * j + 2, draw)] = gacc[(4 * j + 2) * gstride];
+    state[ws.gpart(c, 4 * j + 3, draw)] = gacc[(4 * j + 3) * gstride];
+  }
+  state[ws.gpart(c, 4 * J, draw)] = gacc[4 * J * gstride];
 }
 
 // ---------------------------------------------------------------------------------------------

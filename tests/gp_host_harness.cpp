@@ -5,7 +5,7 @@
 // exoplanet_amd/ loads this.  On the GPU the same functions run one lane per (draw, chunk).
 #define EXO_HOST_BUILD 1
 #ifndef EXO_LANE_MAX_J
-#define EXO_LANE_MAX_J 4
+#define EXO_LANE_MAX_J 6
 #endif
 #include "../exoplanet_amd/csrc/exo_celerite_core.hpp"
 
@@ -55,8 +55,13 @@ void run_vjp(const double* t, gp::Series rs, const double* diag, int64_t n_diag,
   for (int c = 0; c < cg.C; ++c)
     for (int64_t d = 0; d < n_draw; ++d)
       gp::with_layout<J>(cf, d, [&](auto nr) {
-        gp::chunk1_vjp_lane<J, decltype(nr)::value>(t, rs, diag, n_diag, n, cf, n_draw, gloglike, state, cg, gresid, gdiag,
-                                                    gsign, d, c);
+        if constexpr (J > 2) {   // as the device wrapper (celerite_chunk1_vjp_kernel) dispatches
+          double gacc[4 * J + 1];
+          gp::chunkp_vjp_lane<J, decltype(nr)::value>(t, rs, diag, n_diag, n, cf, n_draw, gloglike, state, cg, gresid, gdiag,
+                                                      gsign, d, c, gacc, 1);
+        } else
+          gp::chunk1_vjp_lane<J, decltype(nr)::value>(t, rs, diag, n_diag, n, cf, n_draw, gloglike, state, cg, gresid, gdiag,
+                                                      gsign, d, c);
       });
   for (int64_t d = 0; d < n_draw; ++d)
     for (int k = 0; k < 4 * J + 1; ++k) {
@@ -93,6 +98,8 @@ int harness_gp_fwd(const double* t, const double* y, const double* obs, const do
     case 2: run_fwd<2>(t, rs, diag, n_diag, n, cf, n_draw, loglike, state, cg); break;
     case 3: run_fwd<3>(t, rs, diag, n_diag, n, cf, n_draw, loglike, state, cg); break;
     case 4: run_fwd<4>(t, rs, diag, n_diag, n, cf, n_draw, loglike, state, cg); break;
+    case 5: run_fwd<5>(t, rs, diag, n_diag, n, cf, n_draw, loglike, state, cg); break;
+    case 6: run_fwd<6>(t, rs, diag, n_diag, n, cf, n_draw, loglike, state, cg); break;
     default: return -1;
   }
   const gp::ChunkWs ws = gp::chunk_ws(n, n_draw, J, cg);
@@ -115,6 +122,8 @@ int harness_gp_vjp(const double* t, const double* y, const double* obs, const do
     case 2: run_vjp<2>(t, rs, diag, n_diag, n, cf, n_draw, gloglike, state, cg, gresid, gdiag, gsign, gdiag_sum, gcr, gcc); break;
     case 3: run_vjp<3>(t, rs, diag, n_diag, n, cf, n_draw, gloglike, state, cg, gresid, gdiag, gsign, gdiag_sum, gcr, gcc); break;
     case 4: run_vjp<4>(t, rs, diag, n_diag, n, cf, n_draw, gloglike, state, cg, gresid, gdiag, gsign, gdiag_sum, gcr, gcc); break;
+    case 5: run_vjp<5>(t, rs, diag, n_diag, n, cf, n_draw, gloglike, state, cg, gresid, gdiag, gsign, gdiag_sum, gcr, gcc); break;
+    case 6: run_vjp<6>(t, rs, diag, n_diag, n, cf, n_draw, gloglike, state, cg, gresid, gdiag, gsign, gdiag_sum, gcr, gcc); break;
     default: return -1;
   }
   return cg.C;
@@ -129,6 +138,7 @@ int harness_gp_dot_tril(const double* t, const double* diag, int64_t n_diag, int
       case 2: gp::dot_tril_lane<2>(t, diag, n_diag, n, cf, x, z, d); break;
       case 3: gp::dot_tril_lane<3>(t, diag, n_diag, n, cf, x, z, d); break;
       case 4: gp::dot_tril_lane<4>(t, diag, n_diag, n, cf, x, z, d); break;
+      case 5: gp::dot_tril_lane<5>(t, diag, n_diag, n, cf, x, z, d); break;
       case 6: gp::dot_tril_lane<6>(t, diag, n_diag, n, cf, x, z, d); break;
       default: return -1;
     }
@@ -144,6 +154,7 @@ int harness_gp_predict(const double* t, int64_t n, const double* alpha, const do
       case 2: gp::predict_lane<2>(t, n, alpha, cf, tq, m, mu, d); break;
       case 3: gp::predict_lane<3>(t, n, alpha, cf, tq, m, mu, d); break;
       case 4: gp::predict_lane<4>(t, n, alpha, cf, tq, m, mu, d); break;
+      case 5: gp::predict_lane<5>(t, n, alpha, cf, tq, m, mu, d); break;
       case 6: gp::predict_lane<6>(t, n, alpha, cf, tq, m, mu, d); break;
       default: return -1;
     }

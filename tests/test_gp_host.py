@@ -82,7 +82,7 @@ def rand_terms(rng, n_real, n_complex):
     return ar, cr, ac, bc, cc, dc
 
 
-@pytest.mark.parametrize("n_real,n_complex", [(1, 0), (2, 0), (0, 1), (1, 1), (0, 2), (3, 0), (2, 1)])
+@pytest.mark.parametrize("n_real,n_complex", [(1, 0), (2, 0), (0, 1), (1, 1), (0, 2), (3, 0), (2, 1), (1, 2), (0, 3), (2, 2)])
 def test_lane_pipeline_vs_dense(harness, n_real, n_complex):
     rng = np.random.default_rng(10 * n_real + n_complex)
     n, D = 203, 3          # not a multiple of the checkpoint block or of the chunk length
