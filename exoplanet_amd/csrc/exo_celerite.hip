@@ -762,129 +762,6 @@ __global__ __launch_bounds__(kWave) void celerite_elem_lg_kernel(
   state[ws.elem(c, E3 + j, draw)] = etaj;
 }
 
-// (B) in lane-group form (a draw on G lanes, lane j owns row j of P, A, Cm, Jm): the same chain as
-// celerite_bscan_kernel with the J x J algebra of every step spread over the draw's lanes --
-// products through DPP broadcasts, the solve as Gauss-Jordan with partial pivoting, the pivot row
-// travelling by ds_bpermute.  One lane per draw issues ~2900 instructions per chunk at J = 6 and is
-// bound by exactly that; here a lane issues about a third.
-template <int J>
-__global__ __launch_bounds__(kWave) void celerite_bscan_lg_kernel(const double* __restrict__ t,
-                                                                  Coefs cf, int64_t n, int64_t n_draw,
-                                                                  double* __restrict__ state, ChunkGeom cg) {
-  constexpr int G = Group<J>::G;
-  const int j = threadIdx.x & (G - 1);
-  const int gbase = (int)threadIdx.x - j;   // first lane of this draw's group
-  const int64_t lane_draw = ((int64_t)blockIdx.x * kWave + threadIdx.x) / G;
-  const bool live_draw = lane_draw < n_draw;
-  const int64_t draw = live_draw ? lane_draw : n_draw - 1;
-  const LaneCoef k = lane_coef(cf, draw, j, J);
-  const bool live = k.live;
-  const int jj = live ? j : 0;
-  const bool store = live_draw && live;
-  const ChunkWs ws = chunk_ws(n, n_draw, J, cg);
-  const LaneDelta ld(k);
-  double mj = 0.0, Prow[J];
-  {
-    double U_, V_, cs, sn;
-    lane_uv(k, t[0], &U_, &V_, &cs, &sn);
-    ld.row<J>(k, j, cs, sn, Prow);   // S_0 = 0
-  }
-  const int E1 = J * J, E2 = J * J + J, E3 = 2 * J * J + J, E4 = 2 * J * J + 2 * J;   // b, Cm, eta, Jm offsets
-  // element rows of the next chunk are fetched while this one is applied: the loads (and this
-  // chunk's boundary stores) are issued ahead of the arithmetic that hides them
-  double nA[J], nCm[J], nJm[J], nb = 0.0, neta = 0.0;
-  auto fetch = [&](int c) {
-#pragma unroll
-    for (int l = 0; l < J; ++l) {
-      nA[l] = live ? state[ws.elem(c, jj * J + l, draw)] : 0.0;
-      nCm[l] = live ? state[ws.elem(c, E2 + jj * J + l, draw)] : 0.0;
-      nJm[l] = live ? state[ws.elem(c, E4 + jj * J + l, draw)] : 0.0;
-    }
-    nb = live ? state[ws.elem(c, E1 + jj, draw)] : 0.0;
-    neta = live ? state[ws.elem(c, E3 + jj, draw)] : 0.0;
-  };
-  if (cg.C > 1) fetch(0);
-#pragma unroll 1
-  for (int c = 0; c < cg.C; ++c) {
-    double Arow[J], Cmrow[J], Jmrow[J];
-#pragma unroll
-    for (int l = 0; l < J; ++l) { Arow[l] = nA[l]; Cmrow[l] = nCm[l]; Jmrow[l] = nJm[l]; }
-    const double bj = nb, etaj = neta;
-    if (c + 2 < cg.C) fetch(c + 1);
-    // the state entering chunk c as (F, P); the chunk kernel turns P into S = Delta - P itself
-    if (store) {
-      state[ws.bnd(1, c, j, draw)] = mj;
-#pragma unroll
-      for (int l = 0; l < J; ++l) state[ws.bnd(1, c, J + j * J + l, draw)] = Prow[l];
-    }
-    if (c + 1 == cg.C) break;
-    // row j of X = I + P Jm and of the right-hand sides [P | F + P eta]
-    double Xr[J], R[J + 1];
-    double pe = mj;
-#pragma unroll
-    for (int l = 0; l < J; ++l) { Xr[l] = (l == j) ? 1.0 : 0.0; R[l] = Prow[l]; }
-#pragma unroll
-    for (int kk = 0; kk < J; ++kk) {
-      pe = fma(Prow[kk], group_get<G>(etaj, kk), pe);
-#pragma unroll
-      for (int l = 0; l < J; ++l) Xr[l] = fma(Prow[kk], group_get<G>(Jmrow[l], kk), Xr[l]);
-    }
-    R[J] = pe;
-    // Gauss-Jordan, partial pivoting over the rows (= lanes) not used yet
-    bool used = !live;
-    int myvar = -1;
-    double diag = 1.0;
-#pragma unroll
-    for (int kk = 0; kk < J; ++kk) {
-      double best = used ? -1.0 : fabs(Xr[kk]);
-      int who = j;
-#pragma unroll
-      for (int M = 1; M < G; M <<= 1) {
-        const double ov = __shfl_xor(best, M, 64);
-        const int ow = __shfl_xor(who, M, 64);
-        const bool take = (ov > best) || (ov == best && ow < who);
-        best = take ? ov : best;
-        who = take ? ow : who;
-      }
-      const int src = gbase + who;
-      const double piv = __shfl(Xr[kk], src, 64);
-      const double ipiv = 1.0 / piv;
-      const bool me = (j == who);
-      const double f = me ? 0.0 : Xr[kk] * ipiv;
-#pragma unroll
-      for (int l = kk + 1; l < J; ++l) Xr[l] = fma(-f, __shfl(Xr[l], src, 64), Xr[l]);
-#pragma unroll
-      for (int l = 0; l <= J; ++l) R[l] = fma(-f, __shfl(R[l], src, 64), R[l]);
-      if (me) { used = true; myvar = kk; diag = piv; } else { Xr[kk] = 0.0; }
-    }
-    // the lane that pivoted on column kk holds solution row kk; bring row j to lane j
-    const double idiag = 1.0 / diag;
-    int from = j;
-#pragma unroll
-    for (int l = 0; l < J; ++l) from = (group_get_int<G>(myvar, l) == j) ? l : from;
-    double Z[J + 1];
-#pragma unroll
-    for (int l = 0; l <= J; ++l) Z[l] = __shfl(R[l] * idiag, gbase + from, 64);
-    // F' = A ym + b ;  P' = A (YP) A^T + Cm
-    double mnew = bj, AY[J], Pn[J];
-#pragma unroll
-    for (int l = 0; l < J; ++l) { AY[l] = 0.0; Pn[l] = Cmrow[l]; }
-#pragma unroll
-    for (int kk = 0; kk < J; ++kk) {
-      mnew = fma(Arow[kk], group_get<G>(Z[J], kk), mnew);
-#pragma unroll
-      for (int l = 0; l < J; ++l) AY[l] = fma(Arow[kk], group_get<G>(Z[l], kk), AY[l]);
-    }
-#pragma unroll
-    for (int l = 0; l < J; ++l)
-#pragma unroll
-      for (int kk = 0; kk < J; ++kk) Pn[l] = fma(AY[kk], group_get<G>(Arow[kk], l), Pn[l]);
-    mj = live ? mnew : 0.0;
-#pragma unroll
-    for (int l = 0; l < J; ++l) Prow[l] = live ? Pn[l] : 0.0;
-  }
-}
-
 // (C) the ordinary recurrences inside every chunk, from the entering state: same lane layout as
 // celerite_fwd_kernel (a draw on G lanes), one wave per (64 / G draws, chunk).  With C x more
 // waves than the sequential kernel the loads are hidden by occupancy: no prefetch ring.
@@ -1155,50 +1032,22 @@ __global__ __launch_bounds__(kWave) void celerite_chunk_vjp_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------
-// Composition of two consecutive elements, and the scans over the chunks as trees of compositions.
-//
-// Filtering elements (Sarkka & Garcia-Fernandez 2021, Lemma 8; element 1 acts first):  with M = I + C1 J2,
-// X1 = M^-1 A1,  x2 = M^-1 (b1 + C1 eta2),  X3 = M^-1 C1,  N = I - J2 X3
+// The scans over the chunks as trees of element compositions (exo_celerite_core.hpp, "The scans (B), (B') as TREES").
+// Everything runs one lane per item (celerite_tree_kernel below) except composing two FILTERING elements at J >= 3:
+//     M = I + C1 J2,  X1 = M^-1 A1,  x2 = M^-1 (b1 + C1 eta2),  X3 = M^-1 C1,  N = I - J2 X3
 //     A = A2 X1        b = A2 x2 + b2        C = A2 X3 A2^T + C2
 //     eta = A1^T N (eta2 - J2 b1) + eta1     J = A1^T N J2 A1 + J1
-// A STATE (F, P) is the element (A = 0, b = F, C = P, eta = 0, J = 0): applying an element to a state is the same
-// composition, of which only b and C are kept.
-// Adjoint elements (badj_prep: Abar in the A slot, g in b, local Fbar in eta, local Pbar in C) act on an adjoint
-// state (Fbar, Pbar) as  Fbar' = lF + Abar^T Fbar,  Pbar' = lP + Abar^T Pbar Abar + sym(Abar^T Fbar g^T);  1 first:
-//     Abar = Abar1 Abar2    g = g2 + Abar2^T g1    lF = lF2 + Abar2^T lF1
-//     lP = lP2 + Abar2^T lP1 Abar2 + sym(Abar2^T lF1 g2^T)
-// and a state is the element (Abar = 0, g = 0, lF = Fbar, lP = Pbar).  (Both laws checked in numpy against the
-// element of the joined run / the chained maps before they went to the device.)
-//
-// Uses: (i) the slow element kernel is run on chunks 2^fine times shorter -- that many times more lanes -- and the
-// elements are composed pairwise back up; (ii) the scans (B), (B') as trees: positions p = 0 .. C - 1 (forward:
-// chunk p; adjoint: chunk C - 1 - p), element p takes the state at p to p + 1.  UP: level f + 1 element i = elements
-// 2i, 2i + 1 of level f composed, until one position is left, which holds the initial state; DOWN: state 2i of level
-// f = state i of level f + 1, state 2i + 1 = element 2i of level f applied to it.  2 log2 C short launches instead of
-// C dependent steps of one wave.
-// One wave per item (a block): the matrices live in LDS padded to 8 x 8 and lane (j, l) owns entry (j, l) of every
-// product; Gauss-Jordan with partial pivoting for the solve.
+// keeps ~5 J x J matrices alive around the solve -- one lane spills 2 KB at J = 6 and takes 76 us per level whatever
+// its size.  Here: one wave per composition (a block), the matrices in LDS padded to 8 x 8, lane (j, l) owning entry
+// (j, l) of every product, Gauss-Jordan with partial pivoting for the solve.  LDS-bandwidth-bound (~230 reads of
+// 512 B per composition), ~40 us per level at 128 chains x 512 chunks.  Also used where the J > 2 lane-group path
+// builds its elements on half chunks and composes them pairwise (ChunkGeom::fine).
 // ---------------------------------------------------------------------------------------------
-struct TreeOp {
-  int J;
-  int64_t n_draw;
-  int64_t src_elem;    // elements read (UP: the pairs; DOWN: the child level's)
-  int src_n;           //   positions p >= src_n hold the identity
-  int src_rev;         //   position p is stored at index src_len - 1 - p (adjoint scan, level 0)
-  int src_len;
-  int64_t dst_elem;    // UP: elements written, [0, n_item)
-  int64_t par_state;   // DOWN: parent states, [0, n_item)
-  int64_t dst_state;   // DOWN: child states, positions [0, dst_n), stored like src (dst_rev, dst_len)
-  int dst_n, dst_rev, dst_len;
-  double psign;        // DOWN: the sign the matrix part of the child states is stored with
-  int n_item;
-};
 struct ComposeLds {
   double m[13][64];   // A1 C1 J1 A2 C2 J2 M R1 R3 T T2 T3 tmp
   double v[8][8];     // b1 eta1 b2 eta2 r2 v w tmp
 };
-template <bool ADJ, bool DOWN>
-__global__ __launch_bounds__(kWave) void celerite_tree_kernel(TreeOp op, double* __restrict__ state) {
+__global__ __launch_bounds__(kWave) void celerite_compose_lds_kernel(TreeOp op, double* __restrict__ state) {
   __shared__ ComposeLds S;
   const int lane = threadIdx.x, j = lane >> 3, l = lane & 7;
   const int64_t item = blockIdx.x;                       // (index, draw), draws fastest
@@ -1208,39 +1057,26 @@ __global__ __launch_bounds__(kWave) void celerite_tree_kernel(TreeOp op, double*
   const int64_t draw = item - (int64_t)c * n_draw;
   enum { A1 = 0, C1, J1, A2, C2, J2, MM, R1, R3, TT, T2, T3, TMP };
   enum { B1 = 0, E1, B2, E2, RR2, VV, WW, VT };
-  const int E = 3 * J * J + 2 * J, Bq = J + J * J;
+  const int E = 3 * J * J + 2 * J;
   const int oA = 0, ob = J * J, oC = J * J + J, oeta = 2 * J * J + J, oJ = 2 * J * J + 2 * J;
   const bool in = j < J && l < J;
   auto src = [&](int pos, int e) -> double {
     const int idx = op.src_rev ? op.src_len - 1 - pos : pos;
     return state[op.src_elem + ((int64_t)idx * E + e) * n_draw + draw];
   };
-  auto par = [&](int k) -> double { return state[op.par_state + ((int64_t)c * Bq + k) * n_draw + draw]; };
-  // ---- load: element 1 (or the parent state as an element), element 2; missing elements are the identity
-  const int p1 = DOWN ? -1 : 2 * c, p2 = DOWN ? 2 * c : 2 * c + 1;
-  const bool has1 = !DOWN && p1 < op.src_n, has2 = p2 < op.src_n;
+  // ---- load the two elements; missing ones are the identity
+  const int p1 = 2 * c, p2 = 2 * c + 1;
+  const bool has1 = p1 < op.src_n, has2 = p2 < op.src_n;
   const double idm = (j == l && in) ? 1.0 : 0.0;
-  if (DOWN) {
-    const double pm = in ? par(J + j * J + l) : 0.0;
-    S.m[A1][lane] = 0.0; S.m[C1][lane] = pm; S.m[J1][lane] = 0.0;
-    if (l == 0) {
-      const double pv = j < J ? par(j) : 0.0;
-      S.v[B1][j] = ADJ ? 0.0 : pv;
-      S.v[E1][j] = ADJ ? pv : 0.0;
-    }
-  } else {
-    S.m[A1][lane] = in ? (has1 ? src(p1, oA + j * J + l) : idm) : 0.0;
-    S.m[C1][lane] = (in && has1) ? src(p1, oC + j * J + l) : 0.0;
-    S.m[J1][lane] = (in && has1 && !ADJ) ? src(p1, oJ + j * J + l) : 0.0;
-    if (l == 0) {
-      S.v[B1][j] = (j < J && has1) ? src(p1, ob + j) : 0.0;
-      S.v[E1][j] = (j < J && has1) ? src(p1, oeta + j) : 0.0;
-    }
-  }
+  S.m[A1][lane] = in ? (has1 ? src(p1, oA + j * J + l) : idm) : 0.0;
+  S.m[C1][lane] = (in && has1) ? src(p1, oC + j * J + l) : 0.0;
+  S.m[J1][lane] = (in && has1) ? src(p1, oJ + j * J + l) : 0.0;
   S.m[A2][lane] = in ? (has2 ? src(p2, oA + j * J + l) : idm) : 0.0;
   S.m[C2][lane] = (in && has2) ? src(p2, oC + j * J + l) : 0.0;
-  S.m[J2][lane] = (in && has2 && !ADJ) ? src(p2, oJ + j * J + l) : 0.0;
+  S.m[J2][lane] = (in && has2) ? src(p2, oJ + j * J + l) : 0.0;
   if (l == 0) {
+    S.v[B1][j] = (j < J && has1) ? src(p1, ob + j) : 0.0;
+    S.v[E1][j] = (j < J && has1) ? src(p1, oeta + j) : 0.0;
     S.v[B2][j] = (j < J && has2) ? src(p2, ob + j) : 0.0;
     S.v[E2][j] = (j < J && has2) ? src(p2, oeta + j) : 0.0;
   }
@@ -1258,95 +1094,75 @@ __global__ __launch_bounds__(kWave) void celerite_tree_kernel(TreeOp op, double*
     for (int k = 0; k < 8; ++k) acc = fma(tx ? S.m[X][k * 8 + j] : S.m[X][j * 8 + k], S.v[V][k], acc);
     return acc;
   };
-  // (DOWN: element 1 is a state -- A1 = 0, J1 = 0 and, forward, eta1 = 0 -- and only the state part of the result
-  // is kept: the products that feed nothing else are skipped)
-  double A_new = 0.0, b_new, C_new, eta_new = 0.0, J_new = 0.0;
-  if (ADJ) {
-    S.m[TT][lane] = mm(C1, false, A2, false);                 // lP1 Abar2
-    if (l == 0) S.v[VV][j] = mv(A2, true, E1);                // Abar2^T lF1
-    if (!DOWN) A_new = mm(A1, false, A2, false);
-    b_new = S.v[B2][j] + mv(A2, true, B1);
-    __syncthreads();
-    eta_new = S.v[E2][j] + S.v[VV][j];
-    C_new = S.m[C2][lane] + mm(A2, true, TT, false) + 0.5 * (S.v[VV][j] * S.v[B2][l] + S.v[B2][j] * S.v[VV][l]);
-    __syncthreads();
-  } else {
-    // M = I + C1 J2 ;  right-hand sides R1 = A1, r2 = b1 + C1 eta2, R3 = C1
-    {
-      const double m = mm(C1, false, J2, false) + (j == l ? 1.0 : 0.0);
-      const double r2 = S.v[B1][j] + mv(C1, false, E2);
-      S.m[MM][lane] = m;
-      S.m[R1][lane] = S.m[A1][lane];
-      S.m[R3][lane] = S.m[C1][lane];
-      if (l == 0) S.v[RR2][j] = r2;
-    }
-    __syncthreads();
-    // Gauss-Jordan with partial pivoting (padded rows / columns are the identity: never chosen, never changed)
-    for (int k = 0; k < J; ++k) {
-      int piv = k;
-      double best = fabs(S.m[MM][k * 8 + k]);
-      for (int i = k + 1; i < J; ++i) {
-        const double a = fabs(S.m[MM][i * 8 + k]);
-        if (a > best) { best = a; piv = i; }
-      }
-      // rows k and piv swapped on the way in; row k scaled, its multiples taken off the others
-      const int srow = j == k ? piv : (j == piv ? k : j);
-      const double ip = 1.0 / S.m[MM][piv * 8 + k];
-      const double mk = S.m[MM][piv * 8 + l] * ip, ak = S.m[R1][piv * 8 + l] * ip, ck = S.m[R3][piv * 8 + l] * ip;
-      const double rk = S.v[RR2][piv] * ip;
-      const double f = j == k ? 0.0 : S.m[MM][srow * 8 + k];
-      const double mj = S.m[MM][srow * 8 + l], aj = S.m[R1][srow * 8 + l], cj = S.m[R3][srow * 8 + l], rj = S.v[RR2][srow];
-      __syncthreads();
-      S.m[MM][lane] = j == k ? mk : fma(-f, mk, mj);
-      if (!DOWN) S.m[R1][lane] = j == k ? ak : fma(-f, ak, aj);
-      S.m[R3][lane] = j == k ? ck : fma(-f, ck, cj);
-      if (l == 0) S.v[RR2][j] = j == k ? rk : fma(-f, rk, rj);
-      __syncthreads();
-    }
-    // now R1 = X1, r2 = x2, R3 = X3
-    if (!DOWN) A_new = mm(A2, false, R1, false);
-    b_new = mv(A2, false, RR2) + S.v[B2][j];
-    S.m[TT][lane] = mm(A2, false, R3, false);                          // A2 X3
-    if (!DOWN) {
-      S.m[T2][lane] = (j == l ? 1.0 : 0.0) - mm(J2, false, R3, false);   // N = I - J2 X3
-      if (l == 0) S.v[VV][j] = S.v[E2][j] - mv(J2, false, B1);           // eta2 - J2 b1
-    }
-    __syncthreads();
-    C_new = mm(TT, false, A2, true) + S.m[C2][lane];
-    if (!DOWN) {
-      S.m[T3][lane] = mm(T2, false, J2, false);                          // N J2
-      if (l == 0) S.v[WW][j] = mv(T2, false, VV);                        // N (eta2 - J2 b1)
-      __syncthreads();
-      S.m[TMP][lane] = mm(T3, false, A1, false);                         // N J2 A1
-      eta_new = mv(A1, true, WW) + S.v[E1][j];
-      __syncthreads();
-      J_new = mm(A1, true, TMP, false) + S.m[J1][lane];
-    }
+  // M = I + C1 J2 ;  right-hand sides R1 = A1, r2 = b1 + C1 eta2, R3 = C1
+  {
+    const double m = mm(C1, false, J2, false) + (j == l ? 1.0 : 0.0);
+    const double r2 = S.v[B1][j] + mv(C1, false, E2);
+    S.m[MM][lane] = m;
+    S.m[R1][lane] = S.m[A1][lane];
+    S.m[R3][lane] = S.m[C1][lane];
+    if (l == 0) S.v[RR2][j] = r2;
   }
+  __syncthreads();
+  // Gauss-Jordan with partial pivoting (padded rows / columns are the identity: never chosen, never changed)
+  for (int k = 0; k < J; ++k) {
+    int piv = k;
+    double best = fabs(S.m[MM][k * 8 + k]);
+    for (int i = k + 1; i < J; ++i) {
+      const double a = fabs(S.m[MM][i * 8 + k]);
+      if (a > best) { best = a; piv = i; }
+    }
+    // rows k and piv swapped on the way in; row k scaled, its multiples taken off the others
+    const int srow = j == k ? piv : (j == piv ? k : j);
+    const double ip = 1.0 / S.m[MM][piv * 8 + k];
+    const double mk = S.m[MM][piv * 8 + l] * ip, ak = S.m[R1][piv * 8 + l] * ip, ck = S.m[R3][piv * 8 + l] * ip;
+    const double rk = S.v[RR2][piv] * ip;
+    const double f = j == k ? 0.0 : S.m[MM][srow * 8 + k];
+    const double mj = S.m[MM][srow * 8 + l], aj = S.m[R1][srow * 8 + l], cj = S.m[R3][srow * 8 + l], rj = S.v[RR2][srow];
+    __syncthreads();
+    S.m[MM][lane] = j == k ? mk : fma(-f, mk, mj);
+    S.m[R1][lane] = j == k ? ak : fma(-f, ak, aj);
+    S.m[R3][lane] = j == k ? ck : fma(-f, ck, cj);
+    if (l == 0) S.v[RR2][j] = j == k ? rk : fma(-f, rk, rj);
+    __syncthreads();
+  }
+  // now R1 = X1, r2 = x2, R3 = X3
+  const double A_new = mm(A2, false, R1, false);
+  const double b_new = mv(A2, false, RR2) + S.v[B2][j];
+  S.m[TT][lane] = mm(A2, false, R3, false);                          // A2 X3
+  S.m[T2][lane] = (j == l ? 1.0 : 0.0) - mm(J2, false, R3, false);   // N = I - J2 X3
+  if (l == 0) S.v[VV][j] = S.v[E2][j] - mv(J2, false, B1);           // eta2 - J2 b1
+  __syncthreads();
+  const double C_new = mm(TT, false, A2, true) + S.m[C2][lane];
+  S.m[T3][lane] = mm(T2, false, J2, false);                          // N J2
+  if (l == 0) S.v[WW][j] = mv(T2, false, VV);                        // N (eta2 - J2 b1)
+  __syncthreads();
+  S.m[TMP][lane] = mm(T3, false, A1, false);                         // N J2 A1
+  const double eta_new = mv(A1, true, WW) + S.v[E1][j];
+  __syncthreads();
+  const double J_new = mm(A1, true, TMP, false) + S.m[J1][lane];
   // symmetrise C and J through LDS
   S.m[TT][lane] = C_new;
   S.m[T2][lane] = J_new;
   __syncthreads();
   const double C_sym = 0.5 * (C_new + S.m[TT][l * 8 + j]), J_sym = 0.5 * (J_new + S.m[T2][l * 8 + j]);
   if (!in) return;
-  if (!DOWN) {
-    auto dst = [&](int e) -> double& { return state[op.dst_elem + ((int64_t)c * E + e) * n_draw + draw]; };
-    dst(oA + j * J + l) = A_new;
-    dst(oC + j * J + l) = C_sym;
-    if (!ADJ) dst(oJ + j * J + l) = J_sym;
-    if (l == 0) { dst(ob + j) = b_new; dst(oeta + j) = eta_new; }
-  } else {
-    auto dst = [&](int pos, int k) -> double& {
-      const int idx = op.dst_rev ? op.dst_len - 1 - pos : pos;
-      return state[op.dst_state + ((int64_t)idx * Bq + k) * n_draw + draw];
-    };
-    dst(2 * c, J + j * J + l) = op.psign * S.m[C1][lane];
-    if (l == 0) dst(2 * c, j) = ADJ ? S.v[E1][j] : S.v[B1][j];
-    if (2 * c + 1 < op.dst_n) {
-      dst(2 * c + 1, J + j * J + l) = op.psign * C_sym;
-      if (l == 0) dst(2 * c + 1, j) = ADJ ? eta_new : b_new;
-    }
-  }
+  auto dst = [&](int e) -> double& { return state[op.dst_elem + ((int64_t)c * E + e) * n_draw + draw]; };
+  dst(oA + j * J + l) = A_new;
+  dst(oC + j * J + l) = C_sym;
+  dst(oJ + j * J + l) = J_sym;
+  if (l == 0) { dst(ob + j) = b_new; dst(oeta + j) = eta_new; }
+}
+
+// The same items, ONE LANE each (tree_item_lane, exo_celerite_core.hpp): (index, draw) pairs with draws fastest, so that
+// the [index][quantity][draw] arrays are read and written coalesced.  An item touches ~3 J^2 doubles once; whatever
+// spills costs a few loads, and a wave carries 64 items where the LDS kernel above carries one.
+template <int J, bool ADJ, bool DOWN>
+__global__ __launch_bounds__(kWave) void celerite_tree_kernel(TreeOp op, double* __restrict__ state) {
+  const int64_t item = (int64_t)blockIdx.x * kWave + threadIdx.x;
+  if (item >= (int64_t)op.n_item * op.n_draw) return;
+  const int c = (int)(item / op.n_draw);
+  tree_item_lane<J, ADJ, DOWN>(op, state, c, item - (int64_t)c * op.n_draw);
 }
 
 // the state the forward scan starts from: F = 0, P = Delta(t_0) (S_0 = 0)
@@ -1390,16 +1206,8 @@ __global__ __launch_bounds__(kWave) void celerite_elem_kernel(const double* __re
   elem_lane<J, NR>(t, rs, diag, n_diag, n, cf, n_draw, state, cg, draw, (int)blockIdx.y, flag_at);
 }
 
-// (B) the state entering every chunk: C - 1 element applications per draw
-template <int J>
-__global__ __launch_bounds__(kWave) void celerite_bscan_kernel(const double* __restrict__ t, Coefs cf, int64_t n,
-                                                               int64_t n_draw, double* __restrict__ state, ChunkGeom cg) {
-  const int64_t draw = (int64_t)blockIdx.x * kWave + threadIdx.x;
-  if (draw >= n_draw) return;
-  bscan_lane<J>(t, cf, n, n_draw, state, cg, draw);
-}
-
-// (B') part 1 (all chunks in parallel; chunk 0's entering adjoint is never needed) and part 2 (the chain)
+// (B), (B'): the scans over the chunks are trees of compositions (celerite_tree_kernel, celerite_compose_lds_kernel above).
+// (B') part 1: the adjoint elements, all chunks in parallel (chunk 0's entering adjoint is never needed)
 template <int J>
 __global__ __launch_bounds__(kWave) void celerite_badj_prep_kernel(const double* __restrict__ gloglike, int64_t n,
                                                                    int64_t n_draw, double* __restrict__ state,
@@ -1407,13 +1215,6 @@ __global__ __launch_bounds__(kWave) void celerite_badj_prep_kernel(const double*
   const int64_t draw = (int64_t)blockIdx.x * kWave + threadIdx.x;
   if (draw >= n_draw) return;
   badj_prep_lane<J>(gloglike, n, n_draw, state, cg, draw, (int)blockIdx.y + 1);
-}
-template <int J>
-__global__ __launch_bounds__(kWave) void celerite_bscan_vjp_kernel(int64_t n, int64_t n_draw, double* __restrict__ state,
-                                                                   ChunkGeom cg) {
-  const int64_t draw = (int64_t)blockIdx.x * kWave + threadIdx.x;
-  if (draw >= n_draw) return;
-  bscan_vjp_lane<J>(n, n_draw, state, cg, draw);
 }
 
 // (C) / (C') with a checkpointed factorisation, J <= kLaneMaxJ
@@ -1541,6 +1342,18 @@ int64_t exo_celerite_state_doubles(int64_t n, int64_t n_draw, int32_t n_real, in
   return base + chunk_ws(n, n_draw, (int)J, cg).total();
 }
 
+#define EXO_GP_DISPATCH_VOID(J_, CALL) \
+  switch (J_) {                        \
+    case 1: { constexpr int JJ = 1; CALL; } break; \
+    case 2: { constexpr int JJ = 2; CALL; } break; \
+    case 3: { constexpr int JJ = 3; CALL; } break; \
+    case 4: { constexpr int JJ = 4; CALL; } break; \
+    case 5: { constexpr int JJ = 5; CALL; } break; \
+    case 6: { constexpr int JJ = 6; CALL; } break; \
+    case 7: { constexpr int JJ = 7; CALL; } break; \
+    case 8: { constexpr int JJ = 8; CALL; } break; \
+    default: break;                                \
+  }
 #define EXO_GP_DISPATCH(J_, CALL) \
   switch (J_) {                   \
     case 1: { constexpr int JJ = 1; CALL; } break; \
@@ -1630,41 +1443,33 @@ static int celerite_fwd(const double* t, Series resid, const double* diag, int64
         op.src_elem = ws.off_fine(f); op.src_n = op.src_len = cg.C << f;
         op.dst_elem = f > 1 ? ws.off_fine(f - 1) : ws.elem(0, 0, 0);
         op.n_item = cg.C << (f - 1);
-        hipLaunchKernelGGL((celerite_tree_kernel<false, false>), dim3((unsigned)(op.n_item * n_draw)), block, 0, st, op, state);
+        hipLaunchKernelGGL(celerite_compose_lds_kernel, dim3((unsigned)(op.n_item * n_draw)), block, 0, st, op, state);
       }
       // after the element kernel: it may flag more draws (measurement variance too small)
       hipLaunchKernelGGL(celerite_prep_flagged_kernel, dim3(8, (unsigned)n_draw), dim3(256), 0, st, t, n, cf, n_draw, J,
                          state, state + ws.off_flag());
-      if (cg.tree) {
+      {
         // (B) as a tree: compose up to one position, seed it with the initial state, apply back down
-        const int top = ws.tree_top();
-        TreeOp op{};
-        op.J = J; op.n_draw = n_draw;
-        auto level_elems = [&](int f) {
-          op.src_elem = f == 0 ? ws.elem(0, 0, 0) : ws.tree_elem(f);
-          op.src_n = f == 0 ? cg.C - 1 : ws.tree_npos(f);   // the last chunk's element takes no state anywhere
-          op.src_rev = 0; op.src_len = ws.tree_npos(f);
-        };
-        for (int f = 0; f + 1 < top; ++f) {
-          level_elems(f);
-          op.dst_elem = ws.tree_elem(f + 1); op.n_item = ws.tree_npos(f + 1);
-          hipLaunchKernelGGL((celerite_tree_kernel<false, false>), dim3((unsigned)(op.n_item * n_draw)), block, 0, st, op, state);
-        }
-        EXO_GP_DISPATCH(J, hipLaunchKernelGGL((celerite_scan_init_kernel<JJ>), grid, block, 0, st, t, cf, n_draw,
-                                              state + ws.tree_state(top)))
-        for (int f = top - 1; f >= 0; --f) {
-          level_elems(f);
-          op.par_state = ws.tree_state(f + 1); op.n_item = ws.tree_npos(f + 1);
-          op.dst_state = f == 0 ? ws.bnd(1, 0, 0, 0) : ws.tree_state(f);
-          op.dst_n = op.dst_len = ws.tree_npos(f); op.dst_rev = 0; op.psign = 1.0;
-          hipLaunchKernelGGL((celerite_tree_kernel<false, true>), dim3((unsigned)(op.n_item * n_draw)), block, 0, st, op, state);
-        }
-      } else if (J >= 3) {
-        EXO_GP_DISPATCH(J, hipLaunchKernelGGL((celerite_bscan_lg_kernel<JJ>), grid, block, 0, st, t, cf, n, n_draw, state,
-                                              cg))
-      } else {
-        EXO_GP_DISPATCH(J, hipLaunchKernelGGL((celerite_bscan_kernel<JJ>), per_draw, block, 0, st, t, cf, n, n_draw, state,
-                                              cg))
+        int rc = EXO_OK;
+        tree_scan(ws, cg, J, n_draw, false,
+                  [&](const TreeOp& op, bool down) {
+                    const dim3 tgrid((unsigned)(((int64_t)op.n_item * n_draw + kWave - 1) / kWave));
+                    if (down) {
+                      EXO_GP_DISPATCH_VOID(J, hipLaunchKernelGGL((celerite_tree_kernel<JJ, false, true>), tgrid, block, 0, st, op, state))
+                    } else if (J >= 3) {
+                      // composing two filtering elements keeps ~5 J x J matrices alive around the solve: one lane per
+                      // item spills 2 KB at J = 6 and crawls (76 us per level); a wave per item with the tiles in LDS
+                      hipLaunchKernelGGL(celerite_compose_lds_kernel, dim3((unsigned)(op.n_item * n_draw)), block, 0,
+                                         st, op, state);
+                    } else {
+                      EXO_GP_DISPATCH_VOID(J, hipLaunchKernelGGL((celerite_tree_kernel<JJ, false, false>), tgrid, block, 0, st, op, state))
+                    }
+                  },
+                  [&]() {
+                    EXO_GP_DISPATCH_VOID(J, hipLaunchKernelGGL((celerite_scan_init_kernel<JJ>), grid, block, 0, st, t, cf, n_draw,
+                                                               state + ws.tree_state(ws.tree_top())))
+                  });
+        if (rc != EXO_OK) return rc;
       }
       if (cg.lane) {
         EXO_GP_LAYOUTS(J, cf, hipLaunchKernelGGL((celerite_chunk1_fwd_kernel<(JJ <= kLaneMaxJ ? JJ : 1), NR>), egrid, block, 0,
@@ -1711,32 +1516,22 @@ static int celerite_vjp(const double* t, Series resid, const double* diag, int64
         egrid(per_draw.x, (unsigned)cg.C);
     EXO_GP_DISPATCH(J, hipLaunchKernelGGL((celerite_badj_prep_kernel<JJ>), dim3(per_draw.x, (unsigned)(cg.C - 1)), block,
                                           0, st, gloglike, n, n_draw, wstate, cg))
-    if (cg.tree) {
+    {
       // (B') as a tree over positions p = C - 1 - chunk: adjoint elements of chunks C - 1 .. 1, zero initial adjoint
-      const int top = ws.tree_top();
-      TreeOp op{};
-      op.J = J; op.n_draw = n_draw;
-      auto level_elems = [&](int f) {
-        op.src_elem = f == 0 ? ws.elem(0, 0, 0) : ws.tree_elem(f);
-        op.src_n = f == 0 ? cg.C - 1 : ws.tree_npos(f);
-        op.src_rev = f == 0 ? 1 : 0; op.src_len = ws.tree_npos(f);
-      };
-      for (int f = 0; f + 1 < top; ++f) {
-        level_elems(f);
-        op.dst_elem = ws.tree_elem(f + 1); op.n_item = ws.tree_npos(f + 1);
-        hipLaunchKernelGGL((celerite_tree_kernel<true, false>), dim3((unsigned)(op.n_item * n_draw)), block, 0, st, op, wstate);
-      }
-      if (hipMemsetAsync(wstate + ws.tree_state(top), 0, sizeof(double) * ws.B() * n_draw, st) != hipSuccess)
-        return EXO_ERR_LAUNCH;
-      for (int f = top - 1; f >= 0; --f) {
-        level_elems(f);
-        op.par_state = ws.tree_state(f + 1); op.n_item = ws.tree_npos(f + 1);
-        op.dst_state = f == 0 ? ws.bnd(2, 0, 0, 0) : ws.tree_state(f);
-        op.dst_n = op.dst_len = ws.tree_npos(f); op.dst_rev = f == 0 ? 1 : 0; op.psign = f == 0 ? -1.0 : 1.0;
-        hipLaunchKernelGGL((celerite_tree_kernel<true, true>), dim3((unsigned)(op.n_item * n_draw)), block, 0, st, op, wstate);
-      }
-    } else {
-      EXO_GP_DISPATCH(J, hipLaunchKernelGGL((celerite_bscan_vjp_kernel<JJ>), per_draw, block, 0, st, n, n_draw, wstate, cg))
+      bool ok = true;
+      tree_scan(ws, cg, J, n_draw, true,
+                [&](const TreeOp& op, bool down) {
+                  const dim3 tgrid((unsigned)(((int64_t)op.n_item * n_draw + kWave - 1) / kWave));
+                  if (down) {
+                    EXO_GP_DISPATCH_VOID(J, hipLaunchKernelGGL((celerite_tree_kernel<JJ, true, true>), tgrid, block, 0, st, op, wstate))
+                  } else {
+                    EXO_GP_DISPATCH_VOID(J, hipLaunchKernelGGL((celerite_tree_kernel<JJ, true, false>), tgrid, block, 0, st, op, wstate))
+                  }
+                },
+                [&]() {
+                  ok = hipMemsetAsync(wstate + ws.tree_state(ws.tree_top()), 0, sizeof(double) * ws.B() * n_draw, st) == hipSuccess;
+                });
+      if (!ok) return EXO_ERR_LAUNCH;
     }
     if (cg.lane) {
       EXO_GP_LAYOUTS(J, cf, hipLaunchKernelGGL((celerite_chunk1_vjp_kernel<(JJ <= kLaneMaxJ ? JJ : 1), NR>), egrid, block, 0,

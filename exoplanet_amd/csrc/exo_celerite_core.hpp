@@ -296,7 +296,7 @@ EXO_HDH ChunkGeom chunk_plan(int64_t n, int64_t n_draw, int J, int32_t n_chunks)
   if (g.C < 2) { g.C = 1; g.L = n; return g; }
   g.lane = lane ? 1 : 0;
   g.fine = lane ? 0 : kFineLevels;
-  g.tree = J >= 3 ? 1 : 0;   // the tree kernels work on 8 x 8 tiles in LDS: not worth it for 2 x 2
+  g.tree = 1;   // the scans over the chunks as trees of compositions (one lane each)
   return g;
 }
 
@@ -951,6 +951,367 @@ EXO_HD void bscan_vjp_lane(int64_t n, int64_t n_draw, double* EXO_RESTRICT state
 #pragma unroll
       for (int l = 0; l < J; ++l) Pb[j][l] = 0.5 * (Pbn[j][l] + Pbn[l][j]);
     }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// The scans (B), (B') as TREES of element compositions, one lane per composition.
+//
+// Filtering elements (Sarkka & Garcia-Fernandez 2021, Lemma 8; element 1 acts first):  with M = I + C1 J2,
+// X1 = M^-1 A1,  x2 = M^-1 (b1 + C1 eta2),  X3 = M^-1 C1,  N = I - J2 X3
+//     A = A2 X1        b = A2 x2 + b2        C = A2 X3 A2^T + C2
+//     eta = A1^T N (eta2 - J2 b1) + eta1     J = A1^T N J2 A1 + J1
+// and applying an element to a STATE (F, P) is bscan_lane's step.  Adjoint elements (badj_prep_lane: Abar in the A
+// slot, g in b, local Fbar in eta, local Pbar in Cm) act on an adjoint state (Fbar, Pbar) as bscan_vjp_lane's step,
+//     Fbar' = lF + Abar^T Fbar,   Pbar' = lP + Abar^T Pbar Abar + sym(Abar^T Fbar g^T),
+// and compose (1 first) to
+//     Abar = Abar1 Abar2    g = g2 + Abar2^T g1    lF = lF2 + Abar2^T lF1    lP = lP2 + Abar2^T lP1 Abar2 + sym(Abar2^T lF1 g2^T).
+// Positions p = 0 .. C - 1 (forward: chunk p; adjoint: chunk C - 1 - p); element p takes the state at p to p + 1.
+// UP: level f + 1 element i = elements 2i, 2i + 1 of level f composed, until one position is left, which holds the
+// initial state; DOWN: state 2i of level f = state i of level f + 1, state 2i + 1 = element 2i of level f applied to it.
+// 2 log2 C short launches with (positions x draws) lanes each instead of C dependent steps of one lane per draw.
+// An item runs once, not in a loop: its ~3 J^2 doubles may spill without consequence (cf. badj_prep_lane).
+// ---------------------------------------------------------------------------------------------
+struct TreeOp {
+  int J;
+  int64_t n_draw;
+  int64_t src_elem;    // elements read (UP: the pairs; DOWN: the child level's)
+  int src_n;           //   positions p >= src_n hold the identity
+  int src_rev;         //   position p is stored at index src_len - 1 - p (adjoint scan, level 0)
+  int src_len;
+  int64_t dst_elem;    // UP: elements written, [0, n_item)
+  int64_t par_state;   // DOWN: parent states, [0, n_item)
+  int64_t dst_state;   // DOWN: child states, positions [0, dst_n), stored like src (dst_rev, dst_len)
+  int dst_n, dst_rev, dst_len;
+  double psign;        // DOWN: the sign the matrix part of the child states is stored with
+  int n_item;
+};
+
+// element `pos` of a level ([index][A, b, Cm, eta, Jm][draw]); identity past the end
+template <int J>
+EXO_HD void tree_load_elem(const double* EXO_RESTRICT state, const TreeOp& op, int pos, int64_t draw, Elem<J>& el) {
+  const bool has = pos >= 0 && pos < op.src_n;
+  const int idx = op.src_rev ? op.src_len - 1 - pos : pos;
+  const int64_t E = 3 * J * J + 2 * J;
+  const double* EXO_RESTRICT p = state + op.src_elem + ((int64_t)(has ? idx : 0) * E) * op.n_draw + draw;
+  int e = 0;
+#pragma unroll
+  for (int j = 0; j < J; ++j)
+#pragma unroll
+    for (int l = 0; l < J; ++l) { const double v = p[(e++) * op.n_draw]; el.A[j][l] = has ? v : (j == l ? 1.0 : 0.0); }
+#pragma unroll
+  for (int j = 0; j < J; ++j) { const double v = p[(e++) * op.n_draw]; el.b[j] = has ? v : 0.0; }
+#pragma unroll
+  for (int j = 0; j < J; ++j)
+#pragma unroll
+    for (int l = 0; l < J; ++l) { const double v = p[(e++) * op.n_draw]; el.Cm[j][l] = has ? v : 0.0; }
+#pragma unroll
+  for (int j = 0; j < J; ++j) { const double v = p[(e++) * op.n_draw]; el.eta[j] = has ? v : 0.0; }
+#pragma unroll
+  for (int j = 0; j < J; ++j)
+#pragma unroll
+    for (int l = 0; l < J; ++l) { const double v = p[(e++) * op.n_draw]; el.Jm[j][l] = has ? v : 0.0; }
+}
+
+// one item of a level: UP -- dst element c = src elements 2c, 2c + 1 composed; DOWN -- child states 2c, 2c + 1 from
+// parent state c and child element 2c
+template <int J, bool ADJ, bool DOWN>
+EXO_HD void tree_item_lane(const TreeOp& op, double* EXO_RESTRICT state, int c, int64_t draw) {
+  const int64_t nd = op.n_draw;
+  const int Bq = J + J * J, E = 3 * J * J + 2 * J;
+  if (DOWN) {
+    double m[J], P[J][J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      m[j] = state[op.par_state + ((int64_t)c * Bq + j) * nd + draw];
+#pragma unroll
+      for (int l = 0; l < J; ++l) P[j][l] = state[op.par_state + ((int64_t)c * Bq + J + j * J + l) * nd + draw];
+    }
+    auto put = [&](int pos, const double* mv, const double (*Pv)[J]) {
+      const int idx = op.dst_rev ? op.dst_len - 1 - pos : pos;
+      double* EXO_RESTRICT q = state + op.dst_state + ((int64_t)idx * Bq) * nd + draw;
+#pragma unroll
+      for (int j = 0; j < J; ++j) {
+        q[(int64_t)j * nd] = mv[j];
+#pragma unroll
+        for (int l = 0; l < J; ++l) q[(int64_t)(J + j * J + l) * nd] = op.psign * Pv[j][l];
+      }
+    };
+    put(2 * c, m, P);
+    if (2 * c + 1 >= op.dst_n) return;
+    Elem<J> el;
+    tree_load_elem<J>(state, op, 2 * c, draw, el);
+    double m2[J], P2[J][J];
+    if (ADJ) {
+      // x = Abar^T Fbar ;  Fbar' = lF + x ;  Pbar' = lP + Abar^T Pbar Abar + sym(x g^T)
+      double x[J], T[J][J];
+#pragma unroll
+      for (int j = 0; j < J; ++j) {
+        double xj = 0.0;
+#pragma unroll
+        for (int l = 0; l < J; ++l) {
+          xj = fma(el.A[l][j], m[l], xj);
+          double tv = 0.0;
+#pragma unroll
+          for (int k = 0; k < J; ++k) tv = fma(P[j][k], el.A[k][l], tv);
+          T[j][l] = tv;
+        }
+        x[j] = xj;
+      }
+#pragma unroll
+      for (int j = 0; j < J; ++j) {
+        m2[j] = el.eta[j] + x[j];
+#pragma unroll
+        for (int l = 0; l < J; ++l) {
+          double cong = el.Cm[j][l];
+#pragma unroll
+          for (int k = 0; k < J; ++k) cong = fma(el.A[k][j], T[k][l], cong);
+          P2[j][l] = cong + 0.5 * (x[j] * el.b[l] + el.b[j] * x[l]);
+        }
+      }
+    } else {
+      // X = I + P Jm ;  solve X [YP | ym] = [P | F + P eta] ;  F' = A ym + b ;  P' = A (YP) A^T + Cm
+      double X[J][J], Bm[J][J + 1];
+#pragma unroll
+      for (int j = 0; j < J; ++j) {
+        double pe = m[j];
+#pragma unroll
+        for (int l = 0; l < J; ++l) {
+          double xv = (j == l) ? 1.0 : 0.0;
+#pragma unroll
+          for (int k = 0; k < J; ++k) xv = fma(P[j][k], el.Jm[k][l], xv);
+          X[j][l] = xv;
+          Bm[j][l] = P[j][l];
+          pe = fma(P[j][l], el.eta[l], pe);
+        }
+        Bm[j][J] = pe;
+      }
+      solve_inplace<J, J + 1>(X, Bm);
+      double AY[J][J];
+#pragma unroll
+      for (int j = 0; j < J; ++j) {
+        double mj = el.b[j];
+#pragma unroll
+        for (int l = 0; l < J; ++l) {
+          mj = fma(el.A[j][l], Bm[l][J], mj);
+          double v = 0.0;
+#pragma unroll
+          for (int k = 0; k < J; ++k) v = fma(el.A[j][k], Bm[k][l], v);
+          AY[j][l] = v;
+        }
+        m2[j] = mj;
+      }
+#pragma unroll
+      for (int j = 0; j < J; ++j)
+#pragma unroll
+        for (int l = 0; l < J; ++l) {
+          double v = el.Cm[j][l];
+#pragma unroll
+          for (int k = 0; k < J; ++k) v = fma(AY[j][k], el.A[l][k], v);
+          P2[j][l] = v;
+        }
+    }
+    double Ps[J][J];
+#pragma unroll
+    for (int j = 0; j < J; ++j)
+#pragma unroll
+      for (int l = 0; l < J; ++l) Ps[j][l] = 0.5 * (P2[j][l] + P2[l][j]);
+    put(2 * c + 1, m2, Ps);
+    return;
+  }
+  // ---- UP
+  Elem<J> e1, e2, out;
+  tree_load_elem<J>(state, op, 2 * c, draw, e1);
+  tree_load_elem<J>(state, op, 2 * c + 1, draw, e2);
+  if (ADJ) {
+    double v[J];   // Abar2^T lF1
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      double gj = e2.b[j], vj = 0.0;
+#pragma unroll
+      for (int l = 0; l < J; ++l) {
+        gj = fma(e2.A[l][j], e1.b[l], gj);
+        vj = fma(e2.A[l][j], e1.eta[l], vj);
+        double a = 0.0;
+#pragma unroll
+        for (int k = 0; k < J; ++k) a = fma(e1.A[j][k], e2.A[k][l], a);
+        out.A[j][l] = a;
+      }
+      out.b[j] = gj;
+      v[j] = vj;
+      out.eta[j] = e2.eta[j] + vj;
+    }
+    double T[J][J];   // lP1 Abar2
+#pragma unroll
+    for (int j = 0; j < J; ++j)
+#pragma unroll
+      for (int l = 0; l < J; ++l) {
+        double tv = 0.0;
+#pragma unroll
+        for (int k = 0; k < J; ++k) tv = fma(e1.Cm[j][k], e2.A[k][l], tv);
+        T[j][l] = tv;
+      }
+#pragma unroll
+    for (int j = 0; j < J; ++j)
+#pragma unroll
+      for (int l = 0; l < J; ++l) {
+        double cv = e2.Cm[j][l] + 0.5 * (v[j] * e2.b[l] + e2.b[j] * v[l]);
+#pragma unroll
+        for (int k = 0; k < J; ++k) cv = fma(e2.A[k][j], T[k][l], cv);
+        out.Cm[j][l] = cv;
+        out.Jm[j][l] = 0.0;
+      }
+  } else {
+    double M[J][J], R[J][2 * J + 1];   // right-hand sides [A1 | C1 | b1 + C1 eta2]
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      double r2 = e1.b[j];
+#pragma unroll
+      for (int l = 0; l < J; ++l) {
+        double mv = (j == l) ? 1.0 : 0.0;
+#pragma unroll
+        for (int k = 0; k < J; ++k) mv = fma(e1.Cm[j][k], e2.Jm[k][l], mv);
+        M[j][l] = mv;
+        R[j][l] = e1.A[j][l];
+        R[j][J + l] = e1.Cm[j][l];
+        r2 = fma(e1.Cm[j][l], e2.eta[l], r2);
+      }
+      R[j][2 * J] = r2;
+    }
+    solve_inplace<J, 2 * J + 1>(M, R);   // R = [X1 | X3 | x2]
+    double AX3[J][J], Nm[J][J], w[J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      double bj = e2.b[j], wj = e2.eta[j];
+#pragma unroll
+      for (int l = 0; l < J; ++l) {
+        bj = fma(e2.A[j][l], R[l][2 * J], bj);
+        wj = fma(-e2.Jm[j][l], e1.b[l], wj);
+        double a = 0.0, ax = 0.0, nv = (j == l) ? 1.0 : 0.0;
+#pragma unroll
+        for (int k = 0; k < J; ++k) {
+          a = fma(e2.A[j][k], R[k][l], a);
+          ax = fma(e2.A[j][k], R[k][J + l], ax);
+          nv = fma(-e2.Jm[j][k], R[k][J + l], nv);
+        }
+        out.A[j][l] = a;
+        AX3[j][l] = ax;
+        Nm[j][l] = nv;
+      }
+      out.b[j] = bj;
+      w[j] = wj;      // eta2 - J2 b1
+    }
+    double Nw[J], NJ[J][J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      double nw = 0.0;
+#pragma unroll
+      for (int l = 0; l < J; ++l) {
+        nw = fma(Nm[j][l], w[l], nw);
+        double v = 0.0;
+#pragma unroll
+        for (int k = 0; k < J; ++k) v = fma(Nm[j][k], e2.Jm[k][l], v);
+        NJ[j][l] = v;
+      }
+      Nw[j] = nw;
+    }
+    double NJA[J][J];
+#pragma unroll
+    for (int j = 0; j < J; ++j)
+#pragma unroll
+      for (int l = 0; l < J; ++l) {
+        double v = 0.0;
+#pragma unroll
+        for (int k = 0; k < J; ++k) v = fma(NJ[j][k], e1.A[k][l], v);
+        NJA[j][l] = v;
+      }
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      double ej = e1.eta[j];
+#pragma unroll
+      for (int l = 0; l < J; ++l) {
+        ej = fma(e1.A[l][j], Nw[l], ej);
+        double cv = e2.Cm[j][l], jv = e1.Jm[j][l];
+#pragma unroll
+        for (int k = 0; k < J; ++k) {
+          cv = fma(AX3[j][k], e2.A[l][k], cv);
+          jv = fma(e1.A[k][j], NJA[k][l], jv);
+        }
+        out.Cm[j][l] = cv;
+        out.Jm[j][l] = jv;
+      }
+      out.eta[j] = ej;
+    }
+  }
+  double* EXO_RESTRICT q = state + op.dst_elem + ((int64_t)c * E) * nd + draw;
+  int e = 0;
+#pragma unroll
+  for (int j = 0; j < J; ++j)
+#pragma unroll
+    for (int l = 0; l < J; ++l) q[(int64_t)(e++) * nd] = out.A[j][l];
+#pragma unroll
+  for (int j = 0; j < J; ++j) q[(int64_t)(e++) * nd] = out.b[j];
+#pragma unroll
+  for (int j = 0; j < J; ++j)
+#pragma unroll
+    for (int l = 0; l < J; ++l) q[(int64_t)(e++) * nd] = 0.5 * (out.Cm[j][l] + out.Cm[l][j]);
+#pragma unroll
+  for (int j = 0; j < J; ++j) q[(int64_t)(e++) * nd] = out.eta[j];
+#pragma unroll
+  for (int j = 0; j < J; ++j)
+#pragma unroll
+    for (int l = 0; l < J; ++l) q[(int64_t)(e++) * nd] = ADJ ? 0.0 : 0.5 * (out.Jm[j][l] + out.Jm[l][j]);
+}
+
+// the state the forward scan starts from, (F, P) = (0, Delta(t_0)) (S_0 = 0), as a state record at dst
+template <int J>
+EXO_HD void scan_init_lane(const double* EXO_RESTRICT t, const Coefs& cf, int64_t n_draw, double* EXO_RESTRICT dst, int64_t draw) {
+  DeltaCoef<J> dc;
+  dc.init(cf, draw);
+  DrawCoef<J> co;
+  co.init(cf, draw);
+  double U[J], V[J];
+#pragma unroll
+  for (int j = 0; j < J; ++j) U[j] = V[j] = 0.0;
+  co.uv(t[0], U, V);
+  Sym<J> Dl;
+  dc.eval(V, Dl);
+#pragma unroll
+  for (int j = 0; j < J; ++j) {
+    dst[(int64_t)j * n_draw + draw] = 0.0;
+#pragma unroll
+    for (int l = 0; l < J; ++l) dst[(int64_t)(J + j * J + l) * n_draw + draw] = Dl(j, l);
+  }
+}
+
+// The levels of a scan: `launch(op, down)` is called once per level, in order (UP levels, then -- after `seed()`
+// has put the initial state at ws.tree_state(top) -- the DOWN levels).  adj: the adjoint scan (positions reversed,
+// states into bnd(2, .) with the sign the chunk kernels expect); else the forward scan (states into bnd(1, .)).
+template <class Launch, class Seed>
+EXO_HDH void tree_scan(const ChunkWs& ws, const ChunkGeom& cg, int J, int64_t n_draw, bool adj, Launch&& launch, Seed&& seed) {
+  const int top = ws.tree_top();
+  TreeOp op{};
+  op.J = J; op.n_draw = n_draw; op.psign = 1.0;
+  auto level_elems = [&](int f) {
+    op.src_elem = f == 0 ? ws.elem(0, 0, 0) : ws.tree_elem(f);
+    op.src_n = f == 0 ? cg.C - 1 : ws.tree_npos(f);   // forward: the last chunk's element takes no state anywhere;
+    op.src_rev = (adj && f == 0) ? 1 : 0;              // adjoint: elements of chunks C - 1 .. 1 at positions 0 .. C - 2
+    op.src_len = ws.tree_npos(f);
+  };
+  for (int f = 0; f + 1 < top; ++f) {
+    level_elems(f);
+    op.dst_elem = ws.tree_elem(f + 1); op.n_item = ws.tree_npos(f + 1);
+    launch(op, false);
+  }
+  seed();
+  for (int f = top - 1; f >= 0; --f) {
+    level_elems(f);
+    op.par_state = ws.tree_state(f + 1); op.n_item = ws.tree_npos(f + 1);
+    op.dst_state = f == 0 ? ws.bnd(adj ? 2 : 1, 0, 0, 0) : ws.tree_state(f);
+    op.dst_n = op.dst_len = ws.tree_npos(f);
+    op.dst_rev = (adj && f == 0) ? 1 : 0;
+    op.psign = (adj && f == 0) ? -1.0 : 1.0;
+    launch(op, true);
   }
 }
 

@@ -13,6 +13,8 @@
 
 namespace {
 
+int g_serial_scan = 0;   // 1: the serial reference scans (bscan_lane, bscan_vjp_lane) instead of the trees
+
 template <int J>
 void run_fwd(const double* t, gp::Series rs, const double* diag, int64_t n_diag, int64_t n, const gp::Coefs& cf,
              int64_t n_draw, double* loglike, double* state, const gp::ChunkGeom& cg) {
@@ -27,7 +29,21 @@ void run_fwd(const double* t, gp::Series rs, const double* diag, int64_t n_diag,
       gp::with_layout<J>(cf, d, [&](auto nr) {
         gp::elem_lane<J, decltype(nr)::value>(t, rs, diag, n_diag, n, cf, n_draw, state, cg, d, c);
       });
-  for (int64_t d = 0; d < n_draw; ++d) gp::bscan_lane<J>(t, cf, n, n_draw, state, cg, d);
+  if (cg.tree && !g_serial_scan) {   // the scans as trees of compositions, level by level, as the device launches them
+    gp::tree_scan(ws, cg, J, n_draw, false,
+                  [&](const gp::TreeOp& op, bool down) {
+                    for (int c = 0; c < op.n_item; ++c)
+                      for (int64_t d = 0; d < n_draw; ++d) {
+                        if (down) gp::tree_item_lane<J, false, true>(op, state, c, d);
+                        else gp::tree_item_lane<J, false, false>(op, state, c, d);
+                      }
+                  },
+                  [&]() {
+                    for (int64_t d = 0; d < n_draw; ++d) gp::scan_init_lane<J>(t, cf, n_draw, state + ws.tree_state(ws.tree_top()), d);
+                  });
+  } else {
+    for (int64_t d = 0; d < n_draw; ++d) gp::bscan_lane<J>(t, cf, n, n_draw, state, cg, d);
+  }
   for (int c = 0; c < cg.C; ++c)
     for (int64_t d = 0; d < n_draw; ++d)
       gp::with_layout<J>(cf, d, [&](auto nr) {
@@ -51,7 +67,22 @@ void run_vjp(const double* t, gp::Series rs, const double* diag, int64_t n_diag,
   const gp::ChunkWs ws = gp::chunk_ws(n, n_draw, J, cg);
   for (int c = 1; c < cg.C; ++c)
     for (int64_t d = 0; d < n_draw; ++d) gp::badj_prep_lane<J>(gloglike, n, n_draw, state, cg, d, c);
-  for (int64_t d = 0; d < n_draw; ++d) gp::bscan_vjp_lane<J>(n, n_draw, state, cg, d);
+  if (cg.tree && !g_serial_scan) {
+    gp::tree_scan(ws, cg, J, n_draw, true,
+                  [&](const gp::TreeOp& op, bool down) {
+                    for (int c = 0; c < op.n_item; ++c)
+                      for (int64_t d = 0; d < n_draw; ++d) {
+                        if (down) gp::tree_item_lane<J, true, true>(op, state, c, d);
+                        else gp::tree_item_lane<J, true, false>(op, state, c, d);
+                      }
+                  },
+                  [&]() {
+                    double* dst = state + ws.tree_state(ws.tree_top());
+                    for (int64_t k = 0; k < (int64_t)ws.B() * n_draw; ++k) dst[k] = 0.0;
+                  });
+  } else {
+    for (int64_t d = 0; d < n_draw; ++d) gp::bscan_vjp_lane<J>(n, n_draw, state, cg, d);
+  }
   for (int c = 0; c < cg.C; ++c)
     for (int64_t d = 0; d < n_draw; ++d)
       gp::with_layout<J>(cf, d, [&](auto nr) {
@@ -76,6 +107,9 @@ void run_vjp(const double* t, gp::Series rs, const double* diag, int64_t n_diag,
 }  // namespace
 
 extern "C" {
+
+void harness_set_serial_scan(int v) { g_serial_scan = v; }
+
 
 int64_t harness_gp_state_doubles(int64_t n, int64_t n_draw, int32_t n_real, int32_t n_complex, int32_t n_chunks) {
   const int J = n_real + 2 * n_complex;

@@ -237,6 +237,32 @@ def test_lane_pipeline_reference_step_regimes(harness):
                 np.testing.assert_allclose(g["cplx"][d, 0, q], gw[key][0], rtol=2e-6)
 
 
+def test_tree_scans_equal_serial_scans(harness):
+    """the scans over the chunks as trees of compositions (what the device launches) against the serial
+    element-by-element scans, forward and adjoint, odd and even chunk counts, J = 1 .. 6"""
+    rng = np.random.default_rng(21)
+    for n_real, n_complex, n_chunks in ((1, 0, 5), (0, 1, 8), (2, 1, 7), (0, 3, 13), (1, 2, 2)):
+        n, D = 900, 3
+        t = np.sort(rng.uniform(0, 30, n))
+        y = rng.normal(size=(D, n))
+        diag = 0.1 + 0.1 * rng.uniform(size=(D, n))
+        real = np.stack([10 ** rng.uniform(-1, 0, (D, n_real)), 10 ** rng.uniform(-1, 0.5, (D, n_real))], -1)
+        a = 10 ** rng.uniform(-1, 0, (D, n_complex)); c = 10 ** rng.uniform(-1, 0.3, (D, n_complex))
+        d = 10 ** rng.uniform(-0.5, 0.8, (D, n_complex)); b = rng.uniform(-0.9, 0.9, (D, n_complex)) * a * c / d
+        cplx = np.stack([a, b, c, d], -1)
+        gll = rng.normal(size=D)
+        res = []
+        for serial in (0, 1):
+            harness.harness_set_serial_scan(serial)
+            res.append(run(harness, t, y, diag, real, cplx, gll=gll, n_chunks=n_chunks))
+        harness.harness_set_serial_scan(0)
+        (ll0, _, _, g0), (ll1, _, _, g1) = res
+        assert np.abs(ll0 - ll1).max() <= 1e-12 * np.abs(ll1).max()
+        for k in g0:
+            if g1[k].size:
+                assert np.abs(g0[k] - g1[k]).max() <= 1e-10 * (np.abs(g1[k]).max() + 1e-300), (n_real, n_complex, k)
+
+
 def _kernel(tau, c):
     return P.celerite_kernel(tau, *c)
 

@@ -7,6 +7,7 @@ for v in "$@"; do
 import csv,glob
 f=glob.glob("$R/gpurun_out/abgp_$v/**/*kernel_stats.csv",recursive=True)[0]
 rows=[r for r in csv.DictReader(open(f)) if "celerite" in r["Name"]]
-print("$v", {r["Name"].split("celerite_")[1][:14]: round(float(r["AverageNs"])/1e3) for r in rows[:6]}, "sum ms", round(sum(float(r["TotalDurationNs"]) for r in rows)/3e6,2))
+tree = sum(float(r["TotalDurationNs"]) for r in rows if "tree_kernel" in r["Name"]) / 3e3
+print("$v", {r["Name"].split("celerite_")[1][:14]: round(float(r["AverageNs"])/1e3) for r in rows[:6] if "tree_kernel" not in r["Name"]}, "trees us", round(tree), "sum ms", round(sum(float(r["TotalDurationNs"]) for r in rows)/3e6,2))
 PY
 done
