@@ -1,0 +1,8 @@
+"""the whole C5 user-level step (bench.py extras.c5) eagerly, for rocprofv3 --kernel-trace --stats"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import bench
+import exoplanet_amd as xo
+bench.graphed = lambda xo_, fn, inputs, dev, iters: ([fn(*inputs) for _ in range(5)] and ({"median_ms": 1.0}, "eager"))
+print(bench.extra_c5(xo, torch.device("cuda:0")) if len(sys.argv) < 2 or sys.argv[1] == "c5" else bench.extra_c3(xo, bench.make_leaves(1024, 100, torch.device("cuda:0")), torch.arange(bench.N_CAD, dtype=torch.float64, device="cuda:0") * bench.CADENCE, torch.device("cuda:0"), 1024))
