@@ -11,6 +11,7 @@ import math
 
 import torch
 
+from .. import ops
 from ..orbits.keplerian import as_tensor
 
 __all__ = ["Term", "TermSum", "RealTerm", "ComplexTerm", "SHOTerm", "RotationTerm", "Matern32Term"]
@@ -125,11 +126,35 @@ class SHOTerm(Term):
         if (S0 is None) == (sigma is None):
             raise ValueError("exactly one of S0 and sigma must be given")
         self.eps = eps
-        self.w0 = as_tensor(w0) if w0 is not None else 2 * math.pi / as_tensor(rho)
-        self.Q = as_tensor(Q, self.w0) if Q is not None else 0.5 * self.w0 * as_tensor(tau, self.w0)
-        self.S0 = as_tensor(S0, self.w0) if S0 is not None else as_tensor(sigma, self.w0) ** 2 / (self.w0 * self.Q)
+        # the parameters as given (the fused coefficient op takes any parameterisation) ...
+        freq = as_tensor(w0 if w0 is not None else rho)
+        self._raw = (as_tensor(S0 if S0 is not None else sigma, freq), freq, as_tensor(Q if Q is not None else tau, freq),
+                     (ops.SHO_SIGMA if S0 is None else 0) | (ops.SHO_RHO if w0 is None else 0) | (ops.SHO_TAU if Q is None else 0))
+        self._s0wq = None
+
+    def _derived(self):
+        """(S0, w0, Q), celerite2's attribute names, computed when first asked for (the fused path never does)"""
+        if self._s0wq is None:
+            amp, freq, damp, flags = self._raw
+            w0 = 2 * math.pi / freq if flags & ops.SHO_RHO else freq
+            Q = 0.5 * w0 * damp if flags & ops.SHO_TAU else damp
+            S0 = amp ** 2 / (w0 * Q) if flags & ops.SHO_SIGMA else amp
+            self._s0wq = (S0, w0, Q)
+        return self._s0wq
+
+    S0 = property(lambda self: self._derived()[0])
+    w0 = property(lambda self: self._derived()[1])
+    Q = property(lambda self: self._derived()[2])
 
     def pair_coefficients(self):
+        amp, freq, damp, flags = self._raw
+        if amp.is_cuda and freq.is_cuda and damp.is_cuda:
+            # one launch (and one for the reverse) instead of ~35 elementwise kernels per term and step
+            amp, freq, damp = torch.broadcast_tensors(amp, freq, damp)
+            shape = amp.shape
+            coef, kind = ops.sho_coefficients(amp.reshape(-1), freq.reshape(-1), damp.reshape(-1), flags, self.eps)
+            e = _empty(amp.unsqueeze(-1))
+            return e, e, coef.reshape(shape + (1, 4)), kind.reshape(shape + (1,))
         S0, w0, Q = torch.broadcast_tensors(self.S0, self.w0, self.Q)
         over = Q.detach() < 0.5
         # both parameterisations, each clamped inside its own domain, the draw's regime selects

@@ -644,6 +644,48 @@ class _PackRecords(torch.autograd.Function):
         return go, gl, None
 
 
+SHO_SIGMA, SHO_RHO, SHO_TAU = 1, 2, 4   # include/exoplanet_amd.h EXO_SHO_*
+
+
+class _ShoCoefficients(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, amp, freq, damp, flags, eps):
+        amp, freq, damp = (_dev(x, "SHO parameter").contiguous() for x in (amp, freq, damp))
+        if not (amp.shape == freq.shape == damp.shape) or amp.dim() != 1:
+            raise ValueError("amp, freq, damp must be 1-D tensors of one length")
+        n = amp.numel()
+        coef = torch.empty(n, 4, dtype=torch.float64, device=amp.device)
+        kind = torch.empty(n, dtype=torch.int32, device=amp.device)
+        lib = _lib.load()
+        with torch.cuda.device(amp.device):
+            _lib.check(lib.exo_sho_coefficients_f64(_ptr(amp), _ptr(freq), _ptr(damp), flags, eps, n, _ptr(coef), _ptr(kind),
+                                                    _stream(amp)), "exo_sho_coefficients_f64")
+        ctx.save_for_backward(amp, freq, damp)
+        ctx.flags, ctx.eps = flags, eps
+        ctx.mark_non_differentiable(kind)
+        return coef, kind
+
+    @staticmethod
+    def backward(ctx, gcoef, _gkind):
+        amp, freq, damp = ctx.saved_tensors
+        n = amp.numel()
+        gcoef = _dev(gcoef, "gcoef").contiguous()
+        ga, gf, gd = (torch.empty_like(amp) for _ in range(3))
+        lib = _lib.load()
+        with torch.cuda.device(amp.device):
+            _lib.check(lib.exo_sho_coefficients_vjp_f64(_ptr(amp), _ptr(freq), _ptr(damp), ctx.flags, ctx.eps, n, _ptr(gcoef),
+                                                        _ptr(ga), _ptr(gf), _ptr(gd), _stream(amp)),
+                       "exo_sho_coefficients_vjp_f64")
+        return ga, gf, gd, None, None
+
+
+def sho_coefficients(amp, freq, damp, flags=0, eps=1e-5):
+    """celerite2's SHOTerm in any of its parameterisations (``flags``: SHO_SIGMA | SHO_RHO | SHO_TAU say that ``amp``
+    is sigma rather than S0, ``freq`` the undamped period rho rather than w0, ``damp`` tau rather than Q) -> the
+    term's pair slot ``coef`` (n, 4) and ``kind`` (n,) int32 (1: two real terms, Q < 1/2), one fused launch each way."""
+    return _ShoCoefficients.apply(amp, freq, damp, int(flags), float(eps))
+
+
 class _OrbitFluxDot(torch.autograd.Function):
     """Record packing (column form: every constructor argument its own tensor), the one-sweep value + VJP light
     curve, and -- backward -- the packing VJP with the cotangent of L folded in (``gscale``): the whole

@@ -461,6 +461,25 @@ int exo_pack_records_cols_vjp_f64(const double* const* cols, const int64_t* draw
                                   const double* gld, const double* gscale, double* const* gcols,
                                   double* const* gld_cols, void* stream);
 
+/* ---------------------------------------------------------------------------
+ * celerite2's SHOTerm -> the pair slot of the GP entry points above (one slot per term and draw, two state indices):
+ * the term's parameters in any of celerite2's parameterisations -- amplitude S0 or (EXO_SHO_SIGMA) sigma, frequency w0
+ * or (EXO_SHO_RHO) the undamped period rho, damping Q or (EXO_SHO_TAU) tau -- to coef[n][4] and kind[n]:
+ *   Q >= 1/2: kind 0, one complex term (a, b, c, d) = (S0 w0 Q, a / f, w0 / 2Q, c f),  f = sqrt(max(4 Q^2 - 1, eps))
+ *   Q <  1/2: kind 1, two real terms (a1, c1, a2, c2) = (a (1 + 1/f) / 2, c (1 - f), a (1 - 1/f) / 2, c (1 + f)),
+ *             f = sqrt(max(1 - 4 Q^2, eps))
+ * decided per element on the device (a batch may straddle Q = 1/2).  One launch, and one for the reverse
+ * (gcoef[n][4] -> gamp, gfreq, gdamp[n]); in the reference this algebra is celerite2's Python, in torch ~35 kernels.
+ * ------------------------------------------------------------------------- */
+#define EXO_SHO_SIGMA 1u
+#define EXO_SHO_RHO 2u
+#define EXO_SHO_TAU 4u
+int exo_sho_coefficients_f64(const double* amp, const double* freq, const double* damp, uint32_t flags, double eps,
+                             int64_t n, double* coef, int32_t* kind, void* stream);
+int exo_sho_coefficients_vjp_f64(const double* amp, const double* freq, const double* damp, uint32_t flags, double eps,
+                                 int64_t n, const double* gcoef, double* gamp, double* gfreq, double* gdamp,
+                                 void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -226,3 +226,38 @@ def test_dot_tril_sample_and_predict_batch(dev):
         emp = np.mean(big[:, 100] * big[:, 100 + lag])
         want = P.celerite_kernel(np.array([t[100 + lag] - t[100]]), *co)[0] + (0.09 if lag == 0 else 0.0)
         assert abs(emp - want) < 5 * np.sqrt(2.0 / 2000) * (sig**2 + 0.09)      # five standard errors
+
+
+def test_sho_coefficients_fused_op_matches_torch(dev):
+    """exo_sho_coefficients_*: every parameterisation of celerite2's SHOTerm, a batch straddling Q = 1/2 and touching
+    the clamp, against the torch algebra (values, kinds, gradients of the three parameters)"""
+    from exoplanet_amd import ops
+    from exoplanet_amd.gp import terms
+
+    rng = np.random.default_rng(61)
+    n = 257
+    for flags in range(8):
+        amp = T(10 ** rng.uniform(-2, 0, n), dev, True)
+        if flags & ops.SHO_RHO:
+            freq = T(10 ** rng.uniform(-1, 1.5, n), dev, True)
+        else:
+            freq = T(10 ** rng.uniform(-0.5, 1.5, n), dev, True)
+        q = np.concatenate([rng.uniform(0.05, 0.499, n // 3), rng.uniform(0.5, 5, n // 3), 0.5 + 1e-7 * rng.normal(size=n - 2 * (n // 3))])
+        if flags & ops.SHO_TAU:
+            w0 = (2 * np.pi / freq.detach().cpu().numpy()) if flags & ops.SHO_RHO else freq.detach().cpu().numpy()
+            damp = T(2 * q / w0, dev, True)
+        else:
+            damp = T(q, dev, True)
+        coef, kind = ops.sho_coefficients(amp, freq, damp, flags)
+        kw = {("sigma" if flags & ops.SHO_SIGMA else "S0"): amp, ("rho" if flags & ops.SHO_RHO else "w0"): freq,
+              ("tau" if flags & ops.SHO_TAU else "Q"): damp}
+        term = terms.SHOTerm(**kw)
+        term._raw = tuple(x.cpu() if isinstance(x, torch.Tensor) else x for x in term._raw)   # host copies: the torch algebra
+        _, _, want, wkind = term.pair_coefficients()
+        assert torch.equal(kind.cpu(), wkind.reshape(-1).cpu())
+        np.testing.assert_allclose(coef.detach().cpu().numpy(), want.detach().reshape(n, 4).cpu().numpy(), rtol=1e-12, atol=0)   # (a (1 - 1/f) / 2 cancels near f = 1)
+        w = T(rng.normal(size=(n, 4)), dev)
+        g1 = torch.autograd.grad((coef * w).sum(), (amp, freq, damp))
+        g2 = torch.autograd.grad((want.reshape(n, 4).to(dev) * w).sum(), (amp, freq, damp))
+        for a, b in zip(g1, g2):
+            np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=1e-10, atol=1e-12 * float(b.abs().max()))
