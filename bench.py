@@ -376,8 +376,8 @@ def extra_c3(xo, leaves, t, dev, D):
         Lv = dict(zip(names, vals[:len(names)]))
         sigma, rho, Q = vals[len(names):]
         orbit = xo.KeplerianOrbit(period=Lv["period"], t0=Lv["t0"], b=Lv["b"], ecc=Lv["ecc"], omega=Lv["omega"])
-        lc = xo.LimbDarkLightCurve(Lv["u1"], Lv["u2"]).get_light_curve(orbit=orbit, r=Lv["r"], t=t)
-        gp = xo.gp.GaussianProcess(xo.gp.terms.SHOTerm(sigma=sigma, rho=rho, Q=Q), t=t, yerr=5e-4, mean=lc.sum(-1))
+        lc = xo.LimbDarkLightCurve(Lv["u1"], Lv["u2"]).get_light_curve(orbit=orbit, r=Lv["r"], t=t, total=True)
+        gp = xo.gp.GaussianProcess(xo.gp.terms.SHOTerm(sigma=sigma, rho=rho, Q=Q), t=t, yerr=5e-4, mean=lc)
         ll = gp.log_likelihood(yobs)
         return (ll.detach(),) + torch.autograd.grad(ll.sum(), vals)
 
@@ -443,10 +443,10 @@ def extra_c5(xo, dev, D=128):
         Lv = dict(zip(names, vals))
         orbit = xo.KeplerianOrbit(period=Lv["period"], t0=Lv["t0"], b=Lv["b"], ecc=Lv["ecc"], omega=Lv["omega"])
         lc = xo.SecondaryEclipseLightCurve((0.3, 0.2), (0.4, 0.1), Lv["sbr"]).get_light_curve(
-            orbit=orbit, r=Lv["r"], t=t, texp=texp, oversample=7)
+            orbit=orbit, r=Lv["r"], t=t, texp=texp, oversample=7, total=True)
         kern = (T.SHOTerm(sigma=Lv["s1"], rho=20.0 * ones, Q=2.0 * ones) + T.SHOTerm(sigma=Lv["s2"], rho=10.0 * ones, Q=ones)
                 + T.SHOTerm(sigma=Lv["s3"], rho=2.0 * ones, Q=0.7071 * ones))
-        gp = xo.gp.GaussianProcess(kern, t=t, yerr=3e-4, mean=lc.sum(-1))
+        gp = xo.gp.GaussianProcess(kern, t=t, yerr=3e-4, mean=lc)
         ll = gp.log_likelihood(yobs)
         return (ll.detach(),) + torch.autograd.grad(ll.sum(), vals)
 

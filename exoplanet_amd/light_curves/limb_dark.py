@@ -117,9 +117,12 @@ class LimbDarkLightCurve:
 
     # ------------------------------------------------------------------
     def get_light_curve(self, orbit=None, r=None, t=None, texp=None, oversample=7, order=0,
-                        use_in_transit=None, light_delay=False):
+                        use_in_transit=None, light_delay=False, total=False):
         """Relative flux ``(n_cadence, n_planet)``; arguments as in the reference
-        (limb_dark.py:99-153).  ``use_in_transit`` defaults to ``not light_delay``."""
+        (limb_dark.py:99-153).  ``use_in_transit`` defaults to ``not light_delay``.
+        ``total=True`` (not in the reference): the sum over the planets, ``(n_cadence,)`` -- what the tutorials
+        write as ``pt.sum(light_curves, axis=-1)`` -- formed inside the kernels; as a separate torch reduction it is a
+        pass over the (draws, cadences) array of its own (0.5 ms of a 5.3 ms C3 step)."""
         if orbit is None:
             raise ValueError("missing required argument 'orbit'")
         if r is None:
@@ -137,10 +140,11 @@ class LimbDarkLightCurve:
         keplerian = isinstance(orbit, KeplerianOrbit) and type(orbit)._warp_times is KeplerianOrbit._warp_times
         if keplerian and light_delay and self._fusable_delay(orbit, t, texp):
             # second Kepler solve in the same kernel (EXO_FLAG_LIGHT_DELAY)
-            return self._fused(orbit, r, t, texp, stencil, use_in_transit, light_delay=True)
+            return self._fused(orbit, r, t, texp, stencil, use_in_transit, light_delay=True, total=total)
         if isinstance(orbit, KeplerianOrbit) and not light_delay and (keplerian or hasattr(orbit, "kernel_ttv")):
-            return self._fused(orbit, r, t, texp, stencil, use_in_transit)
-        return self._composed(orbit, r, t, texp, stencil, use_in_transit, light_delay)
+            return self._fused(orbit, r, t, texp, stencil, use_in_transit, total=total)
+        lc = self._composed(orbit, r, t, texp, stencil, use_in_transit, light_delay)
+        return lc.sum(-1) if total else lc
 
     @staticmethod
     def _fusable_delay(orbit, t, texp):
@@ -150,7 +154,7 @@ class LimbDarkLightCurve:
         return scalar_texp and as_tensor(t).dim() == 1
 
     # ---- hot path: one packing kernel + the fused light-curve kernels, nothing O(N) in torch
-    def _fused(self, orbit, r, t, texp, stencil, use_in_transit, secondary=None, light_delay=False):
+    def _fused(self, orbit, r, t, texp, stencil, use_in_transit, secondary=None, light_delay=False, total=False):
         t = as_tensor(t, r if isinstance(r, torch.Tensor) else self.u1)
         if t.dim() != 1:
             raise ValueError("t must be a vector of times")
@@ -175,6 +179,9 @@ class LimbDarkLightCurve:
             dt, w = stencil
             kw.update(texp=as_tensor(texp, t).reshape(-1).detach(), stencil_dt=_on_device(dt, t.device),
                       stencil_w=_on_device(w, t.device))
+        if total:
+            flux = ops.transit_flux(t.detach(), rec, ld, flags=flags, **kw)
+            return flux.reshape(tuple(batch) + (t.shape[0],))
         flux = ops.transit_flux(t.detach(), rec, ld, flags=flags | ops.FLAG_PER_PLANET, **kw)
         return flux.reshape(tuple(batch) + (t.shape[0], rec.shape[1]))
 

@@ -238,3 +238,28 @@ def test_graphed_step_matches_eager(dev):
         for a, b in zip(out, want):
             assert torch.allclose(a, b, rtol=1e-12, atol=1e-14)
         assert out[0].min().item() < -1e-3
+
+
+def test_total_light_curve_is_the_sum_over_planets(dev):
+    """get_light_curve(total=True) == get_light_curve(...).sum(-1) (values and gradients), transit and secondary"""
+    import exoplanet_amd as xo
+
+    rng = np.random.default_rng(71)
+    D = 4
+    t = torch.linspace(0, 20, 4000, dtype=torch.float64, device=dev)
+    mk = lambda v: torch.tensor(np.asarray(v)[None, :] * (1 + 1e-3 * rng.normal(size=(D, len(v)))), dtype=torch.float64,  # noqa: E731
+                                device=dev, requires_grad=True)
+    L = dict(period=mk([3.0, 6.1]), t0=mk([1.5, 1.6]), b=mk([0.2, 0.4]), ecc=mk([0.1, 0.3]), omega=mk([0.5, -1.0]))
+    r = mk([0.08, 0.05])
+    for lcobj, kw in ((xo.LimbDarkLightCurve(0.3, 0.2), {}), (xo.LimbDarkLightCurve(0.3, 0.2), dict(texp=0.02, oversample=3)),
+                      (xo.SecondaryEclipseLightCurve((0.3, 0.2), (0.4, 0.1), 0.3), {})):
+        orbit = xo.KeplerianOrbit(**L)
+        a = lcobj.get_light_curve(orbit=orbit, r=r, t=t, total=True, **kw)
+        b = lcobj.get_light_curve(orbit=xo.KeplerianOrbit(**L), r=r, t=t, **kw).sum(-1)
+        assert a.shape == b.shape == (D, t.numel())
+        assert float((a - b).abs().max()) <= 4e-15
+        w = torch.randn_like(a)
+        ga = torch.autograd.grad((a * w).sum(), list(L.values()) + [r])
+        gb = torch.autograd.grad((b * w).sum(), list(L.values()) + [r])
+        for x, y in zip(ga, gb):
+            assert float((x - y).abs().max()) <= 1e-10 * float(y.abs().max())
