@@ -1232,8 +1232,11 @@ __global__ __launch_bounds__(kWave) void celerite_chunk1_fwd_kernel(const double
 #ifndef EXO_VJP1_WAVES
 #define EXO_VJP1_WAVES 2
 #endif
+#ifndef EXO_VJPP_WAVES
+#define EXO_VJPP_WAVES 2
+#endif
 template <int J, int NR>
-__global__ __launch_bounds__(kWave, (J <= 2 ? EXO_VJP1_WAVES : 1)) void celerite_chunk1_vjp_kernel(const double* __restrict__ t, Series rs,
+__global__ __launch_bounds__(kWave, (J < EXO_SPAN2_MIN_J ? EXO_VJP1_WAVES : (J <= 2 ? EXO_VJPP_WAVES : 1))) void celerite_chunk1_vjp_kernel(const double* __restrict__ t, Series rs,
                                                                     const double* __restrict__ diag, int64_t n_diag,
                                                                     int64_t n, Coefs cf, int64_t n_draw,
                                                                     const double* __restrict__ gloglike,
@@ -1243,7 +1246,7 @@ __global__ __launch_bounds__(kWave, (J <= 2 ? EXO_VJP1_WAVES : 1)) void celerite
   const int64_t draw = (int64_t)blockIdx.x * kWave + threadIdx.x;
   if (draw >= n_draw) return;
   if (layout_vote<J>(cf, draw) != NR) return;
-  if constexpr (J > 2) {   // wide states: packed adjoint, two checkpoints per block, cotangent accumulators in LDS columns
+  if constexpr (J >= EXO_SPAN2_MIN_J) {   // wide states: packed adjoint, two checkpoints per block, cotangent accumulators in LDS columns
     __shared__ double gacc[4 * J + 1][kWave];
     chunkp_vjp_lane<J, NR>(t, rs, diag, n_diag, n, cf, n_draw, gloglike, state, cg, gresid, gdiag, gsign, draw, (int)blockIdx.y,
                            &gacc[0][threadIdx.x], kWave);

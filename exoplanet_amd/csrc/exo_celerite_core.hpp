@@ -31,7 +31,10 @@ constexpr double kHalfLog2Pi = 0.91893853320467274178;
 constexpr int kCkptB = 4;   // cadences per block of the one-lane chunk kernels (series rows move four at a time)
 // cadences per CHECKPOINT: the whole block for J <= 2; half a block for wider states -- the reverse kernel keeps the
 // recomputed states of a span in registers (J (J + 1) / 2 + 2 J + 2 doubles each), and four of them do not fit at J > 2
-EXO_HDH constexpr int ckpt_span(int J) { return J > 2 ? 2 : 4; }
+#ifndef EXO_SPAN2_MIN_J
+#define EXO_SPAN2_MIN_J 3
+#endif
+EXO_HDH constexpr int ckpt_span(int J) { return J >= EXO_SPAN2_MIN_J ? 2 : 4; }
 
 // Term coefficients of a batch of draws, celerite2's Term.get_coefficients() form:
 //   real  [n_draw][n_real][2]     (a, c)
