@@ -141,3 +141,43 @@ def test_light_curve_level_likelihood_in_a_graph(dev):
     out = g()
     for x, z in zip(out, a):
         assert float((x - z).abs().max()) <= 1e-12 * float(z.abs().max())
+
+
+def test_chi2_with_light_delay_and_flux_dot_with_exposure(dev):
+    """the one-call likelihood with the fused light-travel delay, and flux_dot with an exposure stencil, against the
+    dense light curve of the same public API (values and gradients)"""
+    import exoplanet_amd as xo
+
+    rng = np.random.default_rng(53)
+    D, N = 4, 6000
+    t = torch.linspace(0.0, 15.0, N, dtype=torch.float64, device=dev)
+    mk = lambda v: torch.tensor(v * (1 + 1e-3 * rng.normal(size=(D, 1))), dtype=torch.float64, device=dev, requires_grad=True)  # noqa: E731
+    L = dict(period=mk(3.5), t0=mk(1.0), b=mk(0.3), ecc=mk(0.2), omega=mk(1.1), r=mk(0.1))
+    y = 1.0 + 2e-4 * torch.randn(N, dtype=torch.float64, device=dev)
+    lcobj = xo.LimbDarkLightCurve(0.3, 0.2)
+
+    def orbit():
+        return xo.KeplerianOrbit(**{k: v for k, v in L.items() if k != "r"})
+
+    ll = lcobj.white_noise_log_likelihood(orbit=orbit(), r=L["r"], t=t, y=y, yerr=2e-4, mean=1.0, light_delay=True)
+    f = lcobj.get_light_curve(orbit=orbit(), r=L["r"], t=t, light_delay=True, use_in_transit=False, total=True)
+    want = -0.5 * (((y - 1.0 - f) / 2e-4) ** 2).sum(-1) - N * np.log(2e-4 * np.sqrt(2 * np.pi))
+    assert float((ll - want).abs().max()) <= 1e-10 * float(want.abs().max())
+    ga = torch.autograd.grad(ll.sum(), list(L.values()))
+    gb = torch.autograd.grad(want.sum(), list(L.values()))
+    for a, b in zip(ga, gb):
+        assert float((a - b).abs().max()) <= 1e-8 * float(b.abs().max())
+    # flux_dot with exposure-time integration
+    from exoplanet_amd.light_curves.limb_dark import exposure_stencil
+    sdt, sw = exposure_stencil(5, 0)
+    w = torch.randn(D, N, dtype=torch.float64, device=dev)
+    T_ = lambda a: torch.as_tensor(np.asarray(a, dtype=np.float64), device=dev)  # noqa: E731
+    flux, dot = orbit().flux_dot(L["r"], (0.3, 0.2), t, w, texp=T_([0.02]), stencil=(T_(sdt), T_(sw)))
+    f2 = lcobj.get_light_curve(orbit=orbit(), r=L["r"], t=t, texp=0.02, oversample=5, use_in_transit=False, total=True)
+    assert float((flux - f2).abs().max()) <= 4e-15
+    d2 = (f2 * w).sum(-1)
+    assert float((dot - d2).abs().max()) <= 1e-12 * float(d2.abs().max())
+    ga = torch.autograd.grad(dot.sum(), list(L.values()))
+    gb = torch.autograd.grad(d2.sum(), list(L.values()))
+    for a, b in zip(ga, gb):
+        assert float((a - b).abs().max()) <= 1e-9 * float(b.abs().max())
