@@ -8,7 +8,8 @@
  * maintainer would add on the reference side is shown in INTEGRATION.md.
  *
  * Conventions
- *   - all pointers are DEVICE pointers (HBM), float64, C-contiguous;
+ *   - all pointers are DEVICE pointers (HBM), float64, C-contiguous (the column-form packing entry points take
+ *     HOST arrays of device pointers and say so);
  *   - `stream` is a hipStream_t passed as void* (NULL = the null stream);
  *     calls are asynchronous and stream-ordered, nothing is allocated inside;
  *   - return value: 0 = launched, EXO_ERR_* otherwise (no exceptions cross the
