@@ -528,8 +528,8 @@ def extra_hmc(xo, ops, dev, D=1024, n_leapfrog=8, dense=False):
     return {"trajectories_per_s": D / (q["median_ms"] * 1e-3), "evals_per_s": evals / (q["median_ms"] * 1e-3), **q,
             "chains": D, "n_leapfrog": n_leapfrog,
             "note": "exoplanet_amd.HMC: %d chains, %d leapfrog steps per trajectory = %d value+gradient evaluations of the "
-                    "C2 white-noise likelihood (LimbDarkLightCurve.white_noise_log_likelihood: exo_transit_chi2_vjp_f64 on the "
-                    "sparse light curve; `dense_ms`: the same through get_light_curve and torch passes over (chains, "
+                    "C2 white-noise likelihood (LimbDarkLightCurve.white_noise_log_likelihood: exo_transit_chi2_vjp_f64, one "
+                    "evaluation per solved cadence; `dense_ms`: the same through get_light_curve and torch passes over (chains, "
                     "cadences) arrays), one hipGraph replay per trajectory + momentum draw and accept / reject on the device"
                     % (D, n_leapfrog, n_leapfrog + 1)}
 
@@ -788,6 +788,23 @@ def main():
                             "its retarded time -- a second Kepler solve and the reverse sweep through the delay, in the "
                             "same kernel; dense output"}
 
+        def likelihood():
+            names = list(leaves)
+            obs = 1e-4 * torch.randn(N_CAD, dtype=torch.float64, device=dev)
+
+            def ll_step(*vals):
+                Lv = dict(zip(names, vals))
+                orbit = xo.KeplerianOrbit(period=Lv["period"], t0=Lv["t0"], b=Lv["b"], ecc=Lv["ecc"], omega=Lv["omega"])
+                ll = xo.LimbDarkLightCurve(Lv["u1"], Lv["u2"]).white_noise_log_likelihood(orbit=orbit, r=Lv["r"], t=t, y=obs, yerr=1e-4)
+                return (ll.detach(),) + torch.autograd.grad(ll.sum(), vals)
+
+            q, how = graphed(xo, ll_step, list(leaves.values()), dev, 50)
+            return {"evals_per_s": D / (q["median_ms"] * 1e-3), **q, "launch": how,
+                    "note": "C2 as a white-noise likelihood, value + gradient of every leaf (exo_transit_chi2_vjp_f64: one planet, "
+                            "one sample per cadence -> ONE evaluation per solved cadence, the cotangent 2 w (F - obs) formed "
+                            "inside it; no (draw, cadence) array exists)"}
+
+        leg("c2_white_noise_likelihood", likelihood)
         leg("c2_sparse_output", sparse_output)
         leg("c2_light_delay", light_delay)
         leg("in_transit_only", in_transit)

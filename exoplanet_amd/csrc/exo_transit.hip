@@ -382,9 +382,12 @@ struct GradAcc {
 // is the transit of the flipped orbit (keplerian.py:779-804), whose relative position, velocity and
 // acceleration are the negatives: sigma = -1 below.  The reverse sweep takes the cotangent of the
 // retarded time (-n Mbar of the second solve) back through D and the first solve by hand.
-template <bool GRAD, bool SECONDARY, bool LDELAY = false>
+// CHI2 (one planet, no occultation, no exposure stencil: the sample IS the cadence's flux): `gw` carries the observed
+// value and c2w its weight on the way in; the cotangent of F is formed once F is known, 2 w (F - obs), so the value
+// and the gradient of a white-noise misfit take ONE evaluation per cadence.
+template <bool GRAD, bool SECONDARY, bool LDELAY = false, bool CHI2 = false>
 __device__ __forceinline__ double eval_sample(double tt, const PlanetS& c, const double* cld,
-                                              double gw, const GradAcc& acc) {
+                                              double gw, const GradAcc& acc, double c2w = 0.0) {
   // saved by the delay computation for its reverse sweep
   double ld_cx = 0, ld_sx = 0, ld_den = 0, ld_z = 0, ld_vz = 0, ld_az = 0, ld_w = 0, ld_s = 0, ld_D = 0, ld_sig = 1, ld_t = tt;
   if (LDELAY) {
@@ -448,6 +451,7 @@ __device__ __forceinline__ double eval_sample(double tt, const PlanetS& c, const
   } else {
     F = act ? Fq : 0.0;
   }
+  if (CHI2) gw = 2.0 * c2w * (F - gw);
   if (GRAD) {
     if (act) {
       const double gq = gw * wq;
@@ -1527,13 +1531,15 @@ struct FillCursor {
   }
 };
 
-template <bool GRAD, bool SECONDARY, bool LDELAY = false>
+// CHI2 (one planet, one sample per cadence): gflux is the observed series [n_cad], gsparse its weights ([1] or [n_cad],
+// `chi2_nw` says which); the "sum(gflux * flux)" slot of the partials carries sum w ((F - obs)^2 - obs^2) instead.
+template <bool GRAD, bool SECONDARY, bool LDELAY = false, bool CHI2 = false>
 __global__ __launch_bounds__(kBlock, EXO_HEAVY_MIN_WAVES) void transit_runs_kernel(
     const double* __restrict__ t, int64_t n_cad, const double* __restrict__ texp, int64_t n_texp,
     const double* __restrict__ stencil_dt, const double* __restrict__ stencil_w, int n_sub,
     const double* __restrict__ params, const double* __restrict__ ld, int n_planet, uint32_t flags, int n_ev, RunLists rl,
     const double* __restrict__ gflux, const double* __restrict__ gsparse, double* __restrict__ vals,
-    int32_t* __restrict__ vcad, double* __restrict__ fill, double* __restrict__ partial) {
+    int32_t* __restrict__ vcad, double* __restrict__ fill, double* __restrict__ partial, int64_t chi2_nw = 0) {
   __shared__ Shared sh;
   __shared__ Run s_run[kSeg];
   __shared__ int s_in[kSeg + 1], s_all[kSeg + 1];
@@ -1610,7 +1616,7 @@ __global__ __launch_bounds__(kBlock, EXO_HEAVY_MIN_WAVES) void transit_runs_kern
         const int tin = s_in[m] - in0, total = s_all[m] - all0;
         // dense index j of the batch -> cadence i and position v in the value array: "inside" parts of all
         // runs first, then the limb parts, so that a wave's vote on the arc geometry is nearly unanimous
-        struct Item { int i, v; double tv, g; };
+        struct Item { int i, v; double tv, g, w; };
         auto locate = [&](int j, int& i, int& v) {
           const bool in = j < tin;
           const int jj = in ? j : j - tin;
@@ -1629,12 +1635,14 @@ __global__ __launch_bounds__(kBlock, EXO_HEAVY_MIN_WAVES) void transit_runs_kern
           v = s_all[q] + (i - r.lo);
         };
         auto load_item = [&](int j) -> Item {
-          Item it{0, 0, 0.0, 0.0};   // lanes past the end of the batch: cadence 0 with a zero cotangent
+          Item it{0, 0, 0.0, 0.0, 0.0};   // lanes past the end of the batch: cadence 0 with a zero cotangent
           if (j < total) locate(j, it.i, it.v);
           it.tv = t[it.i];
           // the cotangent of the cadence's flux: dense [draw][cadence] (x planet), or -- gsparse -- at the value's own
           // position in the value array (transit_residual_kernel wrote it there)
-          if (GRAD && j < total)
+          if (CHI2) {
+            if (j < total) { it.g = gflux[it.i]; it.w = gsparse[chi2_nw == 1 ? 0 : it.i]; }
+          } else if (GRAD && j < total)
             it.g = gsparse ? gsparse[vbase + it.v]
                            : (per_planet ? gflux[(draw * n_cad + it.i) * n_planet + p] : gflux[draw * n_cad + it.i]);
           return it;
@@ -1650,9 +1658,14 @@ __global__ __launch_bounds__(kBlock, EXO_HEAVY_MIN_WAVES) void transit_runs_kern
           for (int k = 0; k < n_sub; ++k) {
             const double tt = fma(te, sh.sdt[k], cur.tv);
             const double gw = cur.g * sh.sw[k];
-            const double F = eval_sample<GRAD, SECONDARY, LDELAY>(tt, c, cld, gw, acc);
+            const double F = eval_sample<GRAD, SECONDARY, LDELAY, CHI2>(tt, c, cld, CHI2 ? cur.g : gw, acc, cur.w);
             f = fma(sh.sw[k], F, f);
-            if (GRAD) acc.add(kNG + 6, gw * F);
+            if (CHI2) {
+              const double r = F - cur.g;
+              acc.add(kNG + 6, cur.w * (r * r - cur.g * cur.g));
+            } else if (GRAD) {
+              acc.add(kNG + 6, gw * F);
+            }
           }
           if (vals && has) {
             vals[vbase + cur.v] = f;
@@ -2113,6 +2126,23 @@ inline int launch_runs_sweep(const double* t, int64_t n_cad, const double* texp,
   else                                                                                                                    \
     launch_runs_kernel<G, false>(ldelay, hgrid, st, t, n_cad, texp, n_texp, stencil_dt, stencil_w, n_sub, params, ld,     \
                                  n_planet, flags, n_ev, w.rl, GFLUX, GSP, VALS, VCAD, FILL, PARTIAL)
+  if (chi2 && n_planet == 1 && !secondary && n_sub == 1) {
+    // one planet, one sample per cadence: the cotangent of a cadence's flux needs nothing but that flux -- value and
+    // gradient in ONE evaluation per solved cadence (the misfit comes out of the "dot" slot of the partials)
+    if (ldelay)
+      hipLaunchKernelGGL((transit_runs_kernel<true, false, true, true>), hgrid, block, 0, st, t, n_cad, texp, n_texp, stencil_dt,
+                         stencil_w, (int)n_sub, params, ld, (int)n_planet, flags, n_ev, w.rl, chi2->obs, chi2->ivar, nullptr,
+                         nullptr, nullptr, w.partial, chi2->n_ivar);
+    else
+      hipLaunchKernelGGL((transit_runs_kernel<true, false, false, true>), hgrid, block, 0, st, t, n_cad, texp, n_texp, stencil_dt,
+                         stencil_w, (int)n_sub, params, ld, (int)n_planet, flags, n_ev, w.rl, chi2->obs, chi2->ivar, nullptr,
+                         nullptr, nullptr, w.partial, chi2->n_ivar);
+    if (launch_status() != EXO_OK) return EXO_ERR_LAUNCH;
+    hipLaunchKernelGGL(transit_finish_kernel, dim3((unsigned)n_draw), dim3(n_draw <= 256 ? 1024 : kBlock), 0, st, w.partial, w.hb,
+                       (int)n_planet, secondary, gparams, gld, chi2->chi2, n_cad, flags, n_ev, w.rl, nullptr, w.vcad, nullptr,
+                       nullptr, 0, nullptr);
+    return launch_status();
+  }
   if (chi2) {
     EXO_LAUNCH_RUNS(false, nullptr, nullptr, w.vals, w.vcad, nullptr, nullptr);
     hipLaunchKernelGGL(transit_residual_kernel, dim3(kResidualBlocks, (unsigned)n_draw), block, 0, st, n_cad, (int)n_planet,
