@@ -165,8 +165,10 @@ int exo_transit_flux_sparse_layout(int64_t n_cad, int64_t n_draw, int32_t n_plan
  *   chi2[d]   = sum over the cadences n solved for draw d of  w_n ((f[d][n] - obs[n])^2 - obs[n]^2)
  *             = sum_n w_n (f[d][n] - obs[n])^2  -  sum_n w_n obs[n]^2      (the second sum is the caller's constant)
  *   gparams, gld = d chi2[d] / d (params, ld)
- * Three sweeps' worth of launches in one call: values into the sparse output, residuals and cotangents on it (a draw's
- * planets may transit at once: every value sees the draw's total flux at its cadence), gradient sweep.  Sorted t, one
+ * One planet without occultation or exposure stencil: ONE evaluation per solved cadence (the cotangent 2 w (f - obs) is
+ * formed inside it).  Otherwise three sweeps' worth of launches in one call: values into the sparse output, residuals and
+ * cotangents on it (a draw's planets may transit at once: every value sees the draw's total flux at its cadence),
+ * gradient sweep.  Sorted t, one
  * exposure time (or none), no timing tables (EXO_ERR_INVALID_ARGUMENT otherwise); flags: EXO_FLAG_SECONDARY,
  * EXO_FLAG_WINDOW, EXO_FLAG_LIGHT_DELAY.  Bit-reproducible.                                                          */
 int exo_transit_chi2_vjp_f64(const double* t, int64_t n_cad, const double* texp, int64_t n_texp, const double* stencil_dt,
