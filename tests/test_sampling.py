@@ -54,3 +54,34 @@ def test_hmc_rejects_invalid_proposals_and_conserves_energy():
     hmc2 = HMC(lambda x: -0.5 * (x ** 2).sum(-1), [torch.zeros(D, 2, dtype=torch.float64)], step_size=1e-3, n_leapfrog=3,
                generator=torch.Generator().manual_seed(4))
     assert all(bool(hmc2.step().all()) for _ in range(20))
+
+
+def test_warmup_adapts_step_sizes_and_masses():
+    """dual averaging brings every chain's acceptance rate to the target; the pooled mass adaptation finds the scales
+    of a badly scaled Gaussian (1e-2 .. 1e2) from a unit mass matrix"""
+    torch.manual_seed(5)
+    D = 96
+    sd = torch.tensor([1e-2, 1.0, 1e2], dtype=torch.float64)
+    logp = lambda x: (-0.5 * (x / sd) ** 2).sum(-1)  # noqa: E731
+    x = torch.randn(D, 3, dtype=torch.float64) * sd
+    hmc = HMC(logp, [x], step_size=1.0, n_leapfrog=8, generator=torch.Generator().manual_seed(6))
+    eps = hmc.warmup(600, target_accept=0.8, adapt_mass=True)
+    assert eps.shape == (D,) and bool((eps > 0).all())
+    got = (1.0 / hmc.mass[0][0]).sqrt()
+    assert torch.all((got / sd - 1).abs() < 0.3), got
+    xs = []
+    for _ in range(300):
+        hmc.step()
+        xs.append(hmc.params[0].clone())
+    rate = hmc.accept_rate()
+    assert 0.65 < float(rate.mean()) < 0.95 and float(rate.min()) > 0.4
+    xs = torch.stack(xs).reshape(-1, 3)
+    assert torch.all((xs.std(0) / sd - 1).abs() < 0.15)
+    # without mass adaptation: step sizes only (the stiffest direction sets them)
+    hmc2 = HMC(logp, [torch.randn(D, 3, dtype=torch.float64) * sd], step_size=1.0, n_leapfrog=4,
+               generator=torch.Generator().manual_seed(7))
+    eps2 = hmc2.warmup(300)
+    assert float(eps2.median()) < 0.05
+    for _ in range(100):
+        hmc2.step()
+    assert 0.6 < float(hmc2.accept_rate().mean()) < 0.97
