@@ -412,6 +412,8 @@ def _const(value, device):
     """a one-element float64 device tensor holding ``value`` (cached per device: created once, outside any capture)"""
     key = (float(value), str(device))
     if key not in _CONSTS:
+        if len(_CONSTS) >= 256:      # a handful of error bars in practice: never let a sweep over values grow it
+            _CONSTS.clear()
         _CONSTS[key] = torch.tensor([float(value)], dtype=torch.float64, device=device)
     return _CONSTS[key]
 
