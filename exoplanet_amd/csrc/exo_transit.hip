@@ -719,6 +719,21 @@ struct TtvGrad {
       }
     }
   }
+  // Run-enumeration path, a list whose runs carry their bins: the wave's sums go to its own row of a [wave][run]
+  // table in LDS (q = the lane's run within the batch; a wave holds cadences of one or two runs)
+  __device__ __forceinline__ void flush_runs(int q, double* __restrict__ tab, int row_len) const {
+    const double d = take();
+    unsigned long long todo = __ballot(d != 0.0);
+    while (todo) {
+      const int first = __builtin_amdgcn_readfirstlane(__ffsll((long long)todo) - 1);
+      const int q0 = __builtin_amdgcn_readlane(q, first);
+      const bool mine = q == q0;
+      const double sum = wave_sum_last(mine ? d : 0.0);
+      todo &= ~__ballot(mine);
+      const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+      if ((threadIdx.x & 63) == 63) tab[w * row_len + q0] += sum;
+    }
+  }
   // block-wide, between planets: bins -> output table
   __device__ __forceinline__ void drain() const {
     __syncthreads();
@@ -1389,8 +1404,31 @@ struct RunLists {
   Run* runs;         // [n_list][r_max]
   int32_t* pre_in;   // [n_list][r_max + 1]      exclusive prefix sums of b - a
   int32_t* pre_all;  // [n_list][r_max + 1]      exclusive prefix sums of hi - lo (= position in the value array)
+  int32_t* rbin;     // [n_list][r_max]          timing tables: the bin every cadence AND sub-exposure of the run falls
+                     //                          in, or -1 (looked up sample by sample)
+  double* grun;      // [n_list][r_max]          timing tables, reverse sweep: d(sum)/d(shift) collected run by run
   int r_max;
 };
+
+// exclusive prefix sums of the run lengths a list's wave left in s_len: a lane takes a contiguous share of the runs
+__device__ __forceinline__ void enum_prefix(int (*s_len)[kRunMax + 1], int K, int lane, int32_t* __restrict__ pin,
+                                            int32_t* __restrict__ pall, int32_t* __restrict__ nrun_dst) {
+  const int per = (K + 63) / 64, k0 = lane * per, k1 = (k0 + per < K) ? k0 + per : K;
+  int sum_in = 0, sum_all = 0;
+  for (int k = k0; k < k1; ++k) { sum_in += s_len[0][k]; sum_all += s_len[1][k]; }
+  int ex_in = sum_in, ex_all = sum_all;
+#pragma unroll
+  for (int m = 1; m < 64; m <<= 1) {
+    const int o_in = __shfl_up(ex_in, m, 64), o_all = __shfl_up(ex_all, m, 64);
+    if (lane >= m) { ex_in += o_in; ex_all += o_all; }
+  }
+  int run_in = ex_in - sum_in, run_all = ex_all - sum_all;
+  for (int k = k0; k < k1; ++k) {
+    pin[k] = run_in; pall[k] = run_all;
+    run_in += s_len[0][k]; run_all += s_len[1][k];
+  }
+  if (lane == 63) { pin[K] = ex_in; pall[K] = ex_all; *nrun_dst = K; }
+}
 
 // One wave per list (draw, planet, event: 0 = transits, 1 = occultations).
 __global__ __launch_bounds__(64) void transit_enum_kernel(const double* __restrict__ t, int64_t n_cad,
@@ -1490,22 +1528,154 @@ __global__ __launch_bounds__(64) void transit_enum_kernel(const double* __restri
     }
   }
   __syncthreads();
-  // exclusive prefix sums: a lane takes a contiguous share of the runs
-  const int per = (K + 63) / 64, k0 = lane * per, k1 = (k0 + per < K) ? k0 + per : K;
-  int sum_in = 0, sum_all = 0;
-  for (int k = k0; k < k1; ++k) { sum_in += s_len[0][k]; sum_all += s_len[1][k]; }
-  int ex_in = sum_in, ex_all = sum_all;
+  enum_prefix(s_len, K, lane, pin, pall, rl.nrun + list);
+}
+
+// The same with timing tables (one list per (draw, planet): transits only).  Within a timing bin the warp is a plain
+// shift, so the windows of bin k are periodic in t - shift[k]: every bin's windows are enumerated on their own.  A
+// list is TRUSTED when each of its windows, widened by the exposure's reach, lies strictly inside its bin -- then every
+// cadence of a run and every one of its sub-exposures shares the run's bin (rbin), no sample needs a table lookup and
+// d/d(shift) can be collected run by run.  Anything else (a transit across a bin edge, more bins or windows than the
+// tables hold, unsorted times) degenerates to "every cadence", each sample looking its own bin up (rbin = -1).
+__global__ __launch_bounds__(64) void transit_enum_ttv_kernel(const double* __restrict__ t, int64_t n_cad,
+                                                              const double* __restrict__ texp, int64_t n_texp,
+                                                              const double* __restrict__ stencil_dt, int n_sub,
+                                                              uint32_t flags, const double* __restrict__ windows,
+                                                              const int32_t* __restrict__ sorted, int n_sorted,
+                                                              RunLists rl, Ttv ttv) {
+  __shared__ int s_len[2][kRunMax + 1];
+  __shared__ int s_first[kRunMax + 2], s_mlo[kRunMax + 1];
+  const int64_t list = blockIdx.x;
+  const int lane = threadIdx.x;
+  const double* wv = windows + kWin * list;
+  const double nrev = wv[0], c0 = wv[1], hin = wv[5];
+  double reach = 0.0;
+  if (stencil_dt)
+    for (int k = 0; k < n_sub; ++k) reach = fmax(reach, fabs(stencil_dt[k]));
+  const double span = (flags & EXO_FLAG_WINDOW) ? 0.5 : reach;
+  const double te = n_texp ? texp[0] : 0.0;
+  const double h0 = wv[3] + fabs(te) * span * fabs(nrev);
+  bool srt = true;
+  for (int i = lane; i < n_sorted; i += 64) srt = srt && (sorted[i] != 0);
+  srt = __all(srt);
+  const TtvRow row(ttv, list);
+  const int nfin = row.bin(__builtin_inf());   // (the padding is +inf)
+  const double t_first = t[0], t_last = t[n_cad - 1];
+  const double inf = __builtin_inf();
+  bool full = !srt || !(nrev > 0.0) || !(h0 < 0.5) || (nfin + 1 > kRunMax) || !(t_first == t_first) ||
+              !(t_last == t_last) || !(fabs(t_first) < inf) || !(fabs(t_last) < inf);
+  const double hw_t = h0 / nrev, r_t = n_texp ? fabs(te) * reach : 0.0;
+  int K = 0;
+  if (!full) {
+    bool bad = false;
+    int base = 0;
+    for (int k0 = 0; k0 <= nfin; k0 += 64) {
+      const int k = k0 + lane;
+      int cnt = 0, mlo = 0;
+      if (k <= nfin) {
+        const double lo_t = k > 0 ? row.edges[k - 1] : -inf, hi_t = k < nfin ? row.edges[k] : inf;   // the bin: (lo_t, hi_t]
+        const double sh = row.shift[k];
+        const double lo_c = fmax(lo_t, t_first), hi_c = fmin(hi_t, t_last);
+        if (lo_c <= hi_c) {
+          const double x_lo = fma(lo_c - sh, nrev, c0), x_hi = fma(hi_c - sh, nrev, c0);
+          if (!(fabs(x_lo) < 1e9) || !(fabs(x_hi) < 1e9)) {
+            bad = true;
+          } else {
+            const double a = ceil(x_lo - h0), b = floor(x_hi + h0);
+            if (b >= a) {
+              const double n = b - a + 1.0;
+              if (n > (double)rl.r_max) {
+                bad = true;
+              } else {
+                cnt = (int)n;
+                mlo = (int)a;
+              }
+              // the bin's first and last window, the exposure's reach included, strictly inside it
+              const double tc_a = (a - c0) / nrev + sh, tc_b = (b - c0) / nrev + sh;
+              const double slack = 1e-9 * (fabs(tc_a) + fabs(tc_b) + 1.0);
+              if (!(tc_a - hw_t - r_t - slack > lo_t) || !(tc_b + hw_t + r_t + slack < hi_t)) bad = true;
+            }
+          }
+        } else if (!(lo_c == lo_c) || !(hi_c == hi_c)) {
+          bad = true;
+        }
+      }
+      int ex = cnt;
 #pragma unroll
-  for (int m = 1; m < 64; m <<= 1) {
-    const int o_in = __shfl_up(ex_in, m, 64), o_all = __shfl_up(ex_all, m, 64);
-    if (lane >= m) { ex_in += o_in; ex_all += o_all; }
+      for (int m = 1; m < 64; m <<= 1) {
+        const int o = __shfl_up(ex, m, 64);
+        if (lane >= m) ex += o;
+      }
+      if (k <= nfin) { s_first[k] = base + ex - cnt; s_mlo[k] = mlo; }
+      base += __shfl(ex, 63, 64);
+      if (base > rl.r_max) bad = true;
+    }
+    K = base;
+    full = __any(bad) || K > rl.r_max;
   }
-  int run_in = ex_in - sum_in, run_all = ex_all - sum_all;
-  for (int k = k0; k < k1; ++k) {
-    pin[k] = run_in; pall[k] = run_all;
-    run_in += s_len[0][k]; run_all += s_len[1][k];
+  Run* __restrict__ runs = rl.runs + list * rl.r_max;
+  int32_t* __restrict__ rbin = rl.rbin + list * rl.r_max;
+  int32_t* __restrict__ pin = rl.pre_in + list * (rl.r_max + 1);
+  int32_t* __restrict__ pall = rl.pre_all + list * (rl.r_max + 1);
+  __syncthreads();
+  if (full) {
+    int64_t piece = (n_cad + rl.r_max - 1) / rl.r_max;
+    piece = piece < 1024 ? 1024 : piece;
+    K = (int)((n_cad + piece - 1) / piece);
+    for (int k = lane; k < K; k += 64) {
+      const int64_t lo = k * piece, hi = (lo + piece < n_cad) ? lo + piece : n_cad;
+      runs[k] = Run{(int32_t)lo, (int32_t)lo, (int32_t)lo, (int32_t)hi};
+      rbin[k] = -1;
+      s_len[0][k] = 0;
+      s_len[1][k] = (int)(hi - lo);
+    }
+  } else {
+    const double t_rate = (t_last - t_first) / (double)(n_cad > 1 ? n_cad - 1 : 1);
+    for (int r = lane; r < K; r += 64) {
+      int lo_k = 0, hi_k = nfin + 1;     // the run's bin: the last one whose first run is <= r
+      while (hi_k - lo_k > 1) {
+        const int mid = (lo_k + hi_k) >> 1;
+        if (s_first[mid] <= r) lo_k = mid; else hi_k = mid;
+      }
+      const int k = lo_k;
+      const double kc = (double)(s_mlo[k] + (r - s_first[k]));
+      const double sh = row.shift[k], off = -sh * nrev;
+      // first i in [lo, hi) whose warped phase is >= thr (strict: > thr), guessed from the mean sampling rate first
+      auto first_not = [&](double thr, bool strict, int lo, int hi) {
+        if (t_rate > 0.0 && hi > lo) {
+          const double gq = ceil(((thr - c0) / nrev + sh - t_first) / t_rate);
+          const int g = gq < (double)lo ? lo : (gq > (double)hi ? hi : (int)gq);
+          const double xa = g > lo ? fma(t[g - 1], nrev, c0) + off : 0.0, xb = g < hi ? fma(t[g], nrev, c0) + off : 0.0;
+          const bool left_before = g == lo || (strict ? (xa <= thr) : (xa < thr));
+          const bool here_not = g == hi || !(strict ? (xb <= thr) : (xb < thr));
+          if (left_before && here_not) return g;
+        }
+        while (lo < hi) {
+          const int mid = (lo + hi) >> 1;
+          const double xi = fma(t[mid], nrev, c0) + off;
+          const bool before = strict ? (xi <= thr) : (xi < thr);
+          lo = before ? mid + 1 : lo;
+          hi = before ? hi : mid;
+        }
+        return lo;
+      };
+      Run q;
+      q.lo = first_not(kc - h0, false, 0, (int)n_cad);
+      q.hi = first_not(kc + h0, true, q.lo, (int)n_cad);
+      if (hin > 0.0) {
+        q.a = first_not(kc - hin, false, q.lo, q.hi);
+        q.b = first_not(kc + hin, true, q.a, q.hi);
+      } else {
+        q.a = q.b = q.lo;
+      }
+      runs[r] = q;
+      rbin[r] = k;
+      s_len[0][r] = q.b - q.a;
+      s_len[1][r] = q.hi - q.lo;
+    }
   }
-  if (lane == 63) { pin[K] = ex_in; pall[K] = ex_all; rl.nrun[list] = K; }
+  __syncthreads();
+  enum_prefix(s_len, K, lane, pin, pall, rl.nrun + list);
 }
 
 // this wave's share of a block's zero-fill: 1 KB pieces (64 lanes x 16 B, non-temporal), a few per round
@@ -1533,16 +1703,23 @@ struct FillCursor {
 
 // CHI2 (one planet, one sample per cadence): gflux is the observed series [n_cad], gsparse its weights ([1] or [n_cad],
 // `chi2_nw` says which); the "sum(gflux * flux)" slot of the partials carries sum w ((F - obs)^2 - obs^2) instead.
-template <bool GRAD, bool SECONDARY, bool LDELAY = false, bool CHI2 = false>
+// TTV (one event per planet): `ttv` holds the timing tables; a trusted list's runs carry their bin (rl.rbin), its
+// samples are shifted by the run's shift and d/d(shift) is summed run by run (wave partials in LDS, combined in a fixed
+// order into rl.grun: bit-reproducible); the samples of any other list look their bins up and add to gshift atomically.
+template <bool GRAD, bool SECONDARY, bool LDELAY = false, bool CHI2 = false, bool TTV = false>
 __global__ __launch_bounds__(kBlock, EXO_HEAVY_MIN_WAVES) void transit_runs_kernel(
     const double* __restrict__ t, int64_t n_cad, const double* __restrict__ texp, int64_t n_texp,
     const double* __restrict__ stencil_dt, const double* __restrict__ stencil_w, int n_sub,
     const double* __restrict__ params, const double* __restrict__ ld, int n_planet, uint32_t flags, int n_ev, RunLists rl,
     const double* __restrict__ gflux, const double* __restrict__ gsparse, double* __restrict__ vals,
-    int32_t* __restrict__ vcad, double* __restrict__ fill, double* __restrict__ partial, int64_t chi2_nw = 0) {
+    int32_t* __restrict__ vcad, double* __restrict__ fill, double* __restrict__ partial, int64_t chi2_nw = 0,
+    Ttv ttv = Ttv{nullptr, nullptr, nullptr, 0}) {
   __shared__ Shared sh;
   __shared__ Run s_run[kSeg];
   __shared__ int s_in[kSeg + 1], s_all[kSeg + 1];
+  __shared__ int s_bin[TTV ? kSeg : 1];
+  __shared__ double s_shift[TTV ? kSeg : 1];
+  __shared__ double s_grun[(TTV && GRAD) ? kWaves : 1][(TTV && GRAD) ? kSeg : 1];
   __shared__ int s_rounds[2 * EXO_MAX_PLANETS];
   __shared__ double lds_acc[kNG + 7][kBlock];
   const int64_t draw = blockIdx.y;
@@ -1595,6 +1772,9 @@ __global__ __launch_bounds__(kBlock, EXO_HEAVY_MIN_WAVES) void transit_runs_kern
       for (int s = 0; s < kNG; ++s) lds_acc[s][threadIdx.x] = 0.0;
     }
     int64_t vbase = (draw * n_planet + p) * n_cad;   // the planet's values: transits first, occultations behind them
+    const TtvRow row(ttv, TTV ? draw * n_planet + p : 0);
+    double* __restrict__ grow = (TTV && GRAD) ? ttv.gshift + (draw * n_planet + p) * (int64_t)(ttv.n_edge + 1) : nullptr;
+    const TtvGrad tgrad{(GRAD && TTV) ? &lds_acc[0][threadIdx.x] : nullptr, grow, nullptr};
     for (int ev = 0; ev < n_ev; ++ev) {
       const int64_t list = (draw * n_planet + p) * n_ev + ev;
       const int K = rl.nrun[list];
@@ -1610,14 +1790,24 @@ __global__ __launch_bounds__(kBlock, EXO_HEAVY_MIN_WAVES) void transit_runs_kern
           s_in[q] = pin[kb + q];
           s_all[q] = pall[kb + q];
           if (q < m) s_run[q] = runs[kb + q];
+          if (TTV && q < m) {
+            const int kq = rl.rbin[list * rl.r_max + kb + q];
+            s_bin[q] = kq;
+            s_shift[q] = kq >= 0 ? row.shift[kq] : 0.0;
+            if (GRAD) {
+#pragma unroll
+              for (int w = 0; w < kWaves; ++w) s_grun[w][q] = 0.0;
+            }
+          }
         }
         __syncthreads();
+        const bool trusted = TTV && s_bin[0] >= 0;   // (all runs of a list or none)
         const int in0 = s_in[0], all0 = s_all[0];
         const int tin = s_in[m] - in0, total = s_all[m] - all0;
         // dense index j of the batch -> cadence i and position v in the value array: "inside" parts of all
         // runs first, then the limb parts, so that a wave's vote on the arc geometry is nearly unanimous
-        struct Item { int i, v; double tv, g, w; };
-        auto locate = [&](int j, int& i, int& v) {
+        struct Item { int i, v, q; double tv, g, w; };
+        auto locate = [&](int j, int& i, int& v, int& qrun) {
           const bool in = j < tin;
           const int jj = in ? j : j - tin;
           int q = 0;
@@ -1633,10 +1823,11 @@ __global__ __launch_bounds__(kBlock, EXO_HEAVY_MIN_WAVES) void transit_runs_kern
           const int off = jj - (in ? s_in[q] - in0 : (s_all[q] - all0) - (s_in[q] - in0));
           i = in ? r.a + off : ((off < r.a - r.lo) ? r.lo + off : r.b + (off - (r.a - r.lo)));
           v = s_all[q] + (i - r.lo);
+          qrun = q;
         };
         auto load_item = [&](int j) -> Item {
-          Item it{0, 0, 0.0, 0.0, 0.0};   // lanes past the end of the batch: cadence 0 with a zero cotangent
-          if (j < total) locate(j, it.i, it.v);
+          Item it{0, 0, 0, 0.0, 0.0, 0.0};   // lanes past the end of the batch: cadence 0 with a zero cotangent
+          if (j < total) locate(j, it.i, it.v, it.q);
           it.tv = t[it.i];
           // the cotangent of the cadence's flux: dense [draw][cadence] (x planet), or -- gsparse -- at the value's own
           // position in the value array (transit_residual_kernel wrote it there)
@@ -1655,8 +1846,18 @@ __global__ __launch_bounds__(kBlock, EXO_HEAVY_MIN_WAVES) void transit_runs_kern
           if (j0 + kBlock < total) nxt = load_item(j + kBlock);   // in flight while this round computes
           fc.issue(per_round);
           double f = 0.0;
+          const double dsh = TTV ? s_shift[TTV ? cur.q : 0] : 0.0;
           for (int k = 0; k < n_sub; ++k) {
-            const double tt = fma(te, sh.sdt[k], cur.tv);
+            double tt = fma(te, sh.sdt[k], cur.tv);
+            int ks = 0;
+            if (TTV) {
+              double sh_k = dsh;
+              if (!trusted) {
+                ks = row.bin(tt);
+                sh_k = row.shift[ks];
+              }
+              tt -= sh_k;
+            }
             const double gw = cur.g * sh.sw[k];
             const double F = eval_sample<GRAD, SECONDARY, LDELAY, CHI2>(tt, c, cld, CHI2 ? cur.g : gw, acc, cur.w);
             f = fma(sh.sw[k], F, f);
@@ -1666,14 +1867,30 @@ __global__ __launch_bounds__(kBlock, EXO_HEAVY_MIN_WAVES) void transit_runs_kern
             } else if (GRAD) {
               acc.add(kNG + 6, gw * F);
             }
+            if (TTV && GRAD && !trusted) tgrad.flush_lane(ks);
           }
+          if (TTV && GRAD && trusted) tgrad.flush_runs(cur.q, &s_grun[0][0], kSeg);
           if (vals && has) {
             vals[vbase + cur.v] = f;
             if (vcad) vcad[vbase + cur.v] = cur.i;   // (dense output: where the last kernel puts it)
           }
         }
+        if (TTV && GRAD && trusted) {
+          __syncthreads();   // the waves' tables of this batch, in wave order
+          for (int q = threadIdx.x; q < m; q += kBlock) {
+            double v = s_grun[0][q];
+#pragma unroll
+            for (int w = 1; w < kWaves; ++w) v += s_grun[(TTV && GRAD) ? w : 0][q];
+            rl.grun[list * rl.r_max + kb + q] = v;
+          }
+        }
       }
       vbase += pall[K];
+    }
+    if (GRAD && TTV) {
+      // every sample's t_periastron term went to its bin; the planet's total is in G_PAD
+      lds_acc[G_TP][threadIdx.x] = lds_acc[G_PAD][threadIdx.x];
+      lds_acc[G_PAD][threadIdx.x] = 0.0;
     }
     if (GRAD) reduce_columns(lds_acc, sh.red, 0, kNG, pout + p * kNG);
   }
@@ -1760,8 +1977,31 @@ __global__ __launch_bounds__(1024) void transit_finish_kernel(
     const double* __restrict__ partial, int nblk, int n_planet, bool secondary, double* __restrict__ gparams,
     double* __restrict__ gld, double* __restrict__ flux_dot, int64_t n_cad, uint32_t flags, int n_ev, RunLists rl,
     const double* __restrict__ vals, const int32_t* __restrict__ vcad, double* __restrict__ flux,
-    const double* __restrict__ chi2_part, int n_chi2_part, double* __restrict__ chi2_out) {
+    const double* __restrict__ chi2_part, int n_chi2_part, double* __restrict__ chi2_out,
+    Ttv ttv = Ttv{nullptr, nullptr, nullptr, 0}) {
   const int64_t draw = blockIdx.x;
+  if (ttv.gshift) {
+    // timing tables, lists whose runs carry their bins: the runs' sums to their bins, in run order (the bins of a
+    // list's runs ascend); the samples of any other list added to gshift themselves
+    for (int p = 0; p < n_planet; ++p) {
+      const int64_t list = draw * n_planet + p;
+      const int K = rl.nrun[list];
+      const int32_t* __restrict__ rbin = rl.rbin + list * rl.r_max;
+      if (K == 0 || rbin[0] < 0) continue;
+      const double* __restrict__ grun = rl.grun + list * rl.r_max;
+      double* __restrict__ dst = ttv.gshift + list * (int64_t)(ttv.n_edge + 1);
+      for (int k = threadIdx.x; k <= ttv.n_edge; k += (int)blockDim.x) {
+        int lo = 0, hi = K;   // first run of a bin >= k
+        while (lo < hi) {
+          const int mid = (lo + hi) >> 1;
+          if (rbin[mid] < k) lo = mid + 1; else hi = mid;
+        }
+        double v = 0.0;
+        for (int r = lo; r < K && rbin[r] == k; ++r) v += grun[r];
+        dst[k] = v;
+      }
+    }
+  }
   if (chi2_out && threadIdx.x == blockDim.x - 1) {   // block partials of transit_residual_kernel, in block order
     double v = 0.0;
     for (int b = 0; b < n_chi2_part; ++b) v += chi2_part[draw * n_chi2_part + b];
@@ -2061,6 +2301,8 @@ inline RunWs carve_runs(void* base, int64_t n_cad, int64_t n_draw, int n_planet)
   w.off_runs = off; w.rl.runs = (Run*)(p + off); off = up16(off + (int64_t)sizeof(Run) * n_list * w.rl.r_max);
   w.rl.pre_in = (int32_t*)(p + off); off = up16(off + 4 * n_list * (int64_t)(w.rl.r_max + 1));
   w.off_pre_all = off; w.rl.pre_all = (int32_t*)(p + off); off = up16(off + 4 * n_list * (int64_t)(w.rl.r_max + 1));
+  w.rl.rbin = (int32_t*)(p + off); off = up16(off + 4 * n_draw * n_planet * (int64_t)w.rl.r_max);
+  w.rl.grun = (double*)(p + off); off = up16(off + 8 * n_draw * n_planet * (int64_t)w.rl.r_max);
   w.off_vals = off; w.vals = (double*)(p + off); off = up16(off + 8 * n_draw * n_planet * n_cad);
   w.vcad = (int32_t*)(p + off); off = up16(off + 4 * n_draw * n_planet * n_cad);
   w.gvals = (double*)(p + off); off = up16(off + 8 * n_draw * n_planet * n_cad);
@@ -2071,7 +2313,8 @@ inline RunWs carve_runs(void* base, int64_t n_cad, int64_t n_draw, int n_planet)
 // which sweeps take the run-enumeration path (the list path keeps timing tables, per-cadence exposure
 // times and the exact fp64 scan that the tests compare against)
 inline bool runs_path(bool has_ttv, int64_t n_texp, uint32_t flags) {
-  return !has_ttv && n_texp <= 1 && !(flags & EXO_FLAG_EXACT_SCAN);
+  if (has_ttv && (flags & (EXO_FLAG_SECONDARY | EXO_FLAG_LIGHT_DELAY))) return false;
+  return n_texp <= 1 && !(flags & EXO_FLAG_EXACT_SCAN);
 }
 
 // launches of one sweep on the run-enumeration path; gflux == nullptr: forward only.
@@ -2101,7 +2344,7 @@ inline int launch_runs_sweep(const double* t, int64_t n_cad, const double* texp,
                              const double* stencil_w, int32_t n_sub, const double* params, const double* ld,
                              int64_t n_draw, int32_t n_planet, uint32_t flags, const double* gflux, double* flux,
                              double* gparams, double* gld, double* flux_dot, const RunWs& w, hipStream_t st,
-                             const Chi2Args* chi2 = nullptr) {
+                             const Chi2Args* chi2 = nullptr, const Ttv* ttv = nullptr) {
   const bool secondary = flags & EXO_FLAG_SECONDARY, sparse = (flags & EXO_FLAG_SPARSE) || chi2;
   const bool grad = gflux != nullptr || chi2;
   const int n_ev = secondary ? 2 : 1;
@@ -2111,8 +2354,13 @@ inline int launch_runs_sweep(const double* t, int64_t n_cad, const double* texp,
     hipLaunchKernelGGL(transit_window_kernel, dim3((unsigned)((n_rec + kBlock - 1) / kBlock + w.n_sorted)), block, 0, st,
                        params, n_rec, flags, w.windows, t, n_cad, w.sorted);
   }
-  hipLaunchKernelGGL(transit_enum_kernel, dim3((unsigned)(n_draw * n_planet * n_ev)), dim3(64), 0, st, t, n_cad, texp, n_texp,
-                     stencil_dt, (int)n_sub, flags, w.windows, w.sorted, w.n_sorted, n_ev, w.rl);
+  const bool has_ttv = ttv && ttv->edges;
+  if (has_ttv)
+    hipLaunchKernelGGL(transit_enum_ttv_kernel, dim3((unsigned)(n_draw * n_planet)), dim3(64), 0, st, t, n_cad, texp, n_texp,
+                       stencil_dt, (int)n_sub, flags, w.windows, w.sorted, w.n_sorted, w.rl, *ttv);
+  else
+    hipLaunchKernelGGL(transit_enum_kernel, dim3((unsigned)(n_draw * n_planet * n_ev)), dim3(64), 0, st, t, n_cad, texp,
+                       n_texp, stencil_dt, (int)n_sub, flags, w.windows, w.sorted, w.n_sorted, n_ev, w.rl);
   if (launch_status() != EXO_OK) return EXO_ERR_LAUNCH;
   // the values are kept when somebody reads them: the dense output's last kernel, or the caller (sparse)
   double* vals = (flux || sparse) ? w.vals : nullptr;
@@ -2143,7 +2391,17 @@ inline int launch_runs_sweep(const double* t, int64_t n_cad, const double* texp,
                        nullptr, 0, nullptr);
     return launch_status();
   }
-  if (chi2) {
+  if (has_ttv) {
+    // (transits only, no light delay: runs_path)
+    if (grad)
+      hipLaunchKernelGGL((transit_runs_kernel<true, false, false, false, true>), hgrid, block, 0, st, t, n_cad, texp, n_texp,
+                         stencil_dt, stencil_w, (int)n_sub, params, ld, (int)n_planet, flags, n_ev, w.rl, gflux, nullptr, vals,
+                         fill ? w.vcad : nullptr, fill, w.partial, (int64_t)0, *ttv);
+    else
+      hipLaunchKernelGGL((transit_runs_kernel<false, false, false, false, true>), hgrid, block, 0, st, t, n_cad, texp, n_texp,
+                         stencil_dt, stencil_w, (int)n_sub, params, ld, (int)n_planet, flags, n_ev, w.rl, nullptr, nullptr, vals,
+                         fill ? w.vcad : nullptr, fill, nullptr, (int64_t)0, *ttv);
+  } else if (chi2) {
     EXO_LAUNCH_RUNS(false, nullptr, nullptr, w.vals, w.vcad, nullptr, nullptr);
     hipLaunchKernelGGL(transit_residual_kernel, dim3(kResidualBlocks, (unsigned)n_draw), block, 0, st, n_cad, (int)n_planet,
                        n_ev, w.rl, w.vals, w.vcad, chi2->obs, chi2->ivar, chi2->n_ivar, w.gvals, w.chi2_part);
@@ -2159,7 +2417,7 @@ inline int launch_runs_sweep(const double* t, int64_t n_cad, const double* texp,
     hipLaunchKernelGGL(transit_finish_kernel, dim3((unsigned)n_draw), dim3(n_draw <= 256 ? 1024 : kBlock), 0, st,
                        grad ? w.partial : nullptr, w.hb, (int)n_planet, secondary, gparams, gld, flux_dot, n_cad, flags, n_ev,
                        w.rl, chi2 ? nullptr : vals, w.vcad, fill, chi2 ? w.chi2_part : nullptr, kResidualBlocks,
-                       chi2 ? chi2->chi2 : nullptr);
+                       chi2 ? chi2->chi2 : nullptr, (has_ttv && grad) ? *ttv : Ttv{nullptr, nullptr, nullptr, 0});
   return launch_status();
 }
 
@@ -2247,7 +2505,7 @@ static int transit_fwd(const double* t, int64_t n_cad, const double* texp, int64
     if (!workspace || workspace_bytes < rw.bytes) return EXO_ERR_WORKSPACE;
     if (ev_start) (void)hipEventRecord((hipEvent_t)ev_start, st);
     const int rc = launch_runs_sweep(t, n_cad, texp, n_texp, stencil_dt, stencil_w, n_sub, params, ld, n_draw, n_planet,
-                                     flags, nullptr, flux, nullptr, nullptr, nullptr, rw, st);
+                                     flags, nullptr, flux, nullptr, nullptr, nullptr, rw, st, nullptr, &ttv);
     if (ev_stop) (void)hipEventRecord((hipEvent_t)ev_stop, st);
     return rc;
   }
@@ -2313,7 +2571,7 @@ static int transit_vjp(const double* t, int64_t n_cad, const double* texp, int64
     if (!workspace || workspace_bytes < rw.bytes) return EXO_ERR_WORKSPACE;
     if (ev_start) (void)hipEventRecord((hipEvent_t)ev_start, st);
     const int rc = launch_runs_sweep(t, n_cad, texp, n_texp, stencil_dt, stencil_w, n_sub, params, ld, n_draw, n_planet,
-                                     flags, gflux, flux_out, gparams, gld, flux_dot, rw, st);
+                                     flags, gflux, flux_out, gparams, gld, flux_dot, rw, st, nullptr, &ttv);
     if (ev_stop) (void)hipEventRecord((hipEvent_t)ev_stop, st);
     return rc;
   }
