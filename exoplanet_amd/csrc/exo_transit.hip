@@ -82,7 +82,9 @@ __device__ double mean_anomaly_of(double f, double e, double se, double pe) {
 // Where can the planet overlap the disk at all?  Sky-plane separation (units of R*) is
 //   rho sqrt(cos^2(w+f) + cos^2 i sin^2(w+f)) >= (a/R)(1-e) |cos(w+f)|,
 // so b < 1 + r needs |cos(w+f)| < q = (1+r) / ((a/R)(1-e)) and, for the planet to be in
-// front, sin(w+f) sin i > 0: f within asin(q) of the conjunction f_c = +-pi/2 - w.  Mapped
+// front, sin(w+f) sin i > 0: f within asin(q) of the conjunction f_c = +-pi/2 - w -- a first bound,
+// then tightened side by side to the contacts with the inclination and the distance actually reached
+// (below: never inside them).  Mapped
 // through E(f), M(E) (closed forms in this direction) that is a window of mean anomaly; the
 // occultation window is the same about f_c + pi.  One thread per (draw, planet), run ahead of
 // the scan kernel (libm's fp64 trigonometry would cost the scan kernel half its occupancy);
@@ -103,12 +105,16 @@ __device__ double mean_anomaly_of(double f, double e, double se, double pe) {
 // evaluated.
 // (Blocks past the records' -- the run-enumeration path launches n_sorted more -- check that t is
 // non-decreasing: one flag per kSortBlock cadences, the pair straddling the block's end included.)
+#ifndef EXO_WINDOW_REFINE
+#define EXO_WINDOW_REFINE 1   // (0: the first bound only -- A/B builds)
+#endif
 constexpr int kSortBlock = 4096;
+constexpr int kWinLanes = 4;   // threads per record: (event, side of the conjunction)
 __global__ __launch_bounds__(kBlock) void transit_window_kernel(const double* __restrict__ params, int64_t n_rec,
                                                                 uint32_t flags, double* __restrict__ out,
                                                                 const double* __restrict__ t = nullptr, int64_t n_cad = 0,
                                                                 int32_t* __restrict__ sorted = nullptr) {
-  const int n_rec_blocks = (int)((n_rec + kBlock - 1) / kBlock);
+  const int n_rec_blocks = (int)((n_rec * kWinLanes + kBlock - 1) / kBlock);
   if ((int)blockIdx.x >= n_rec_blocks) {
     const int sb = blockIdx.x - n_rec_blocks;
     const int64_t b0 = (int64_t)sb * kSortBlock;
@@ -118,12 +124,15 @@ __global__ __launch_bounds__(kBlock) void transit_window_kernel(const double* __
     if (threadIdx.x == 0) sorted[sb] = all;
     return;
   }
-  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (i >= n_rec) return;
+  const int64_t gid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const int64_t i = gid / kWinLanes;
+  const int sub = (int)(gid - i * kWinLanes), k = sub >> 1, sd = sub & 1;   // event (0 transit, 1 occultation), side
+  if (i >= n_rec) return;   // (whole groups of four: the shuffles below stay within a record)
   const double* p = params + i * EXO_NPAR;
   const double e = p[EXO_P_ECC], cw = p[EXO_P_COSW], sw = p[EXO_P_SINW];
   double* o = out + kWin * i;
   if (flags & EXO_FLAG_WINDOW) {
+    if (sub != 0) return;
     const double ip = 1.0 / p[EXO_P_PERIOD];
     const double ts = p[EXO_P_TS], te = p[EXO_P_TE], ts2 = p[EXO_P_TS2], te2 = p[EXO_P_TE2];
     const bool fin = (fabs(ts) < __builtin_inf()) && (fabs(te) < __builtin_inf());
@@ -139,11 +148,11 @@ __global__ __launch_bounds__(kBlock) void transit_window_kernel(const double* __
     // b = impact parameter at the conjunction
     const double wn_ = sqrt(cw * cw + sw * sw), r_ = fabs(p[EXO_P_ROR]);
     const double sinw_ = wn_ > 0.0 ? sw / wn_ : 0.0;
-    for (int k = 0; k < 2; ++k) {
-      const double bk = fabs(p[EXO_P_AOR] * p[EXO_P_COSI]) * (1.0 - e * e) / (1.0 + (k ? -e : e) * sinw_);
+    for (int q = 0; q < 2; ++q) {
+      const double bk = fabs(p[EXO_P_AOR] * p[EXO_P_COSI]) * (1.0 - e * e) / (1.0 + (q ? -e : e) * sinw_);
       const double in2 = (1.0 - r_) * (1.0 - r_) - bk * bk, out2 = (1.0 + r_) * (1.0 + r_) - bk * bk;
-      const double h = o[3 + k];
-      o[5 + k] = (r_ < 1.0 && in2 > 0.0 && out2 > 0.0 && h < __builtin_inf()) ? 0.95 * h * sqrt(in2 / out2) : 0.0;
+      const double h = o[3 + q];
+      o[5 + q] = (r_ < 1.0 && in2 > 0.0 && out2 > 0.0 && h < __builtin_inf()) ? 0.95 * h * sqrt(in2 / out2) : 0.0;
     }
     if (flags & EXO_FLAG_LIGHT_DELAY) {   // as below: the retarded time differs from t by at most this
       const double vmax = fabs(p[EXO_P_N] * p[EXO_P_AOR]) * (1.0 + e) / sqrt(1.0 - e * e);
@@ -153,43 +162,89 @@ __global__ __launch_bounds__(kBlock) void transit_window_kernel(const double* __
     }
     return;
   }
+  // Four threads per record -- (event, side) -- each with the short serial chain of its own contact (libm's fp64
+  // trigonometry, a dozen calls one after the other: as one thread per record this kernel took 19 us of a 320 us
+  // sweep); the occultation's pair only works when the sweep has occultations.
   const double nrev = p[EXO_P_N] * (0.5 / exo::kPi);
-  o[0] = nrev;
-  o[1] = -p[EXO_P_TP] * nrev;
-  o[2] = 0.0;
-  o[3] = o[4] = __builtin_inf();
-  o[5] = o[6] = 0.0;
-  if (!(e >= 0.0 && e < 1.0)) return;  // NaN everywhere: every cadence must reach the heavy kernel
   const double wn = sqrt(cw * cw + sw * sw);
   const double q = (1.0 + fabs(p[EXO_P_ROR])) / (fabs(p[EXO_P_AOR]) * (1.0 - e) * wn);
-  if (!(q < 0.999)) return;
-  const double se = sqrt(1.0 - e), pe = sqrt(1.0 + e);
-  const double delta = asin(q) * (1.0 + 1e-6) + 1e-6;
-  const double fc = (p[EXO_P_SINI] < 0.0 ? -0.5 : 0.5) * exo::kPi - atan2(sw, cw);
-  double mid[2];
-  for (int k = 0; k < 2; ++k) {
-    const double f0 = fc + k * exo::kPi;
-    const double lo = mean_anomaly_of(f0 - delta, e, se, pe), hi = mean_anomaly_of(f0 + delta, e, se, pe);
-    mid[k] = 0.5 * (lo + hi) * (0.5 / exo::kPi);
-    o[3 + k] = 0.5 * (hi - lo) * (0.5 / exo::kPi) * (1.0 + 1e-5) + 1e-6;
+  const bool bounded = (e >= 0.0 && e < 1.0) && (q < 0.999);   // else NaN everywhere / no bound: every cadence goes on
+  const bool want = bounded && (k == 0 || (flags & EXO_FLAG_SECONDARY));
+  double m_edge = 0.0, m_in = 0.0;   // this side's contact and inner point, revolutions of mean anomaly
+  bool has_in = false;
+  if (want) {
+    const double se = sqrt(1.0 - e), pe = sqrt(1.0 + e);
+    const double delta0 = asin(q);
+    const double f0 = (p[EXO_P_SINI] < 0.0 ? -0.5 : 0.5) * exo::kPi - atan2(sw, cw) + k * exo::kPi;
+    const double si2 = p[EXO_P_SINI] * p[EXO_P_SINI], ci2 = p[EXO_P_COSI] * p[EXO_P_COSI];
+    const double lim = 1.0 + fabs(p[EXO_P_ROR]), semi = fabs(p[EXO_P_AOR]) * (1.0 - e * e);
+    const double sgn = sd ? 1.0 : -1.0;
+    // The bound above is that of an edge-on orbit at its periastron distance.  At phase angle phi from the
+    // conjunction the sky-plane separation is dist(f) sqrt(cos^2 i + sin^2 i sin^2 phi): the disks overlap only where
+    // phi <= G(phi) = asin sqrt(((1 + r)^2 / dist(f0 +- phi)^2 - cos^2 i) / sin^2 i).  Each side of the conjunction on
+    // its own, from the upper bound ub = delta0, never below the contact:
+    //   dist falling away from the conjunction (G rising): ub <- G(ub);
+    //   dist rising (G falling): lb = G(ub) is a lower bound of the contact, so G(lb) an upper one;
+    //   an apsis inside the half-window: G at the smallest distance in it.
+    // Three rounds leave the window within ~0.1 % of the contacts (C2: it was 6.8 % wider than them); a planet that
+    // never reaches the disk (b > 1 + r) keeps only the safety margin.
+    double ub = delta0;
+    if (EXO_WINDOW_REFINE && si2 > 1e-12) {
+      auto ang = [&](double dist) {
+        const double S = (lim * lim / (dist * dist) - ci2) / si2;
+        return S <= 0.0 ? 0.0 : (S < 1.0 ? asin(sqrt(S)) : delta0);   // (NaN: no information)
+      };
+      auto dist_at = [&](double f) { return semi / (1.0 + e * cos(f)); };
+      const double d_c = dist_at(f0);
+      for (int it = 0; it < 3; ++it) {
+        const double f_end = f0 + sgn * ub;
+        const double lo_f = fmin(f0, f_end), hi_f = fmax(f0, f_end);
+        const bool apsis = floor(hi_f * (1.0 / exo::kPi)) >= ceil(lo_f * (1.0 / exo::kPi));
+        const bool peri = floor(hi_f * (0.5 / exo::kPi)) >= ceil(lo_f * (0.5 / exo::kPi));
+        const double d_end = dist_at(f_end);
+        if (!apsis && d_end >= d_c) {
+          const double lb = fmin(ang(d_end), ub);
+          ub = fmin(ub, ang(dist_at(f0 + sgn * lb)));
+        } else {
+          ub = fmin(ub, ang(peri ? semi / (1.0 + e) : fmin(d_end, d_c)));
+        }
+      }
+    }
+    m_edge = mean_anomaly_of(f0 + sgn * (ub * (1.0 + 1e-6) + 1e-6), e, se, pe) * (0.5 / exo::kPi);
     // inner part: |sky-plane x| < sqrt((1-r)^2 - b^2) at the conjunction's star-planet distance
     const double sinw = sw / wn, r = fabs(p[EXO_P_ROR]);
     const double dist = fabs(p[EXO_P_AOR]) * (1.0 - e * e) / (1.0 + (k ? -e : e) * sinw);
     const double bk = dist * fabs(p[EXO_P_COSI]);
     const double in2 = (1.0 - r) * (1.0 - r) - bk * bk;
-    if (r < 1.0 && in2 > 0.0 && dist > 0.0) {
-      const double din = asin(fmin(0.95 * sqrt(in2) / dist, 1.0));
-      o[5 + k] = 0.5 * (mean_anomaly_of(f0 + din, e, se, pe) - mean_anomaly_of(f0 - din, e, se, pe)) * (0.5 / exo::kPi);
-    }
+    has_in = r < 1.0 && in2 > 0.0 && dist > 0.0;
+    if (has_in) m_in = mean_anomaly_of(f0 + sgn * asin(fmin(0.95 * sqrt(in2) / dist, 1.0)), e, se, pe) * (0.5 / exo::kPi);
   }
-  o[1] = -fma(p[EXO_P_TP], nrev, mid[0]);
-  o[2] = mid[0] - mid[1];
+  // the other side's numbers (lanes 4j .. 4j + 3 hold one record: no record straddles a wave)
+  const double o_edge = __shfl_xor(m_edge, 1, 64), o_in = __shfl_xor(m_in, 1, 64);
+  const double lo = sd ? o_edge : m_edge, hi = sd ? m_edge : o_edge;
+  const double mid = 0.5 * (lo + hi);
+  const double half = want ? 0.5 * (hi - lo) * (1.0 + 1e-5) + 1e-6 : __builtin_inf();
+  // (about the window's centre, which the two contacts set: the smaller of the two sides)
+  const double in_lo = sd ? o_in : m_in, in_hi = sd ? m_in : o_in;
+  const double inner = (want && has_in) ? fmax(fmin(in_hi - mid, mid - in_lo), 0.0) : 0.0;
+  const double mid_other = __shfl_xor(mid, 2, 64);   // the other event's centre
+  double wd = 0.0;
   if (flags & EXO_FLAG_LIGHT_DELAY) {
     // the body is seen where it was up to |z|max / (c - |vz|max) earlier or later: widen by that much
     const double vmax = fabs(p[EXO_P_N] * p[EXO_P_AOR]) * (1.0 + e) / sqrt(1.0 - e * e);
     const double dmax = fabs(p[EXO_P_AOR]) * (1.0 + e) / (fabs(p[EXO_P_CLIGHT]) - vmax);
-    const double wd = (dmax >= 0.0 ? dmax : __builtin_inf()) * fabs(nrev) * 1.05;   // (NaN or v >= c: no window)
-    o[3] += wd; o[4] += wd;
+    wd = (dmax >= 0.0 ? dmax : __builtin_inf()) * fabs(nrev) * 1.05;   // (NaN or v >= c: no window)
+  }
+  if (sd != 0) return;
+  if (k == 0) {
+    o[0] = nrev;
+    o[1] = bounded ? -fma(p[EXO_P_TP], nrev, mid) : -p[EXO_P_TP] * nrev;
+    o[2] = (bounded && (flags & EXO_FLAG_SECONDARY)) ? mid - mid_other : 0.0;
+    o[3] = half + wd;
+    o[5] = inner;
+  } else {
+    o[4] = half + wd;
+    o[6] = inner;
   }
 }
 
@@ -2236,7 +2291,7 @@ inline void launch_windows(const double* params, int64_t n_draw, int n_planet, u
                            hipStream_t st) {
   if ((flags & EXO_FLAG_EXACT_SCAN) && !(flags & EXO_FLAG_WINDOW)) return;
   const int64_t n_rec = n_draw * n_planet;
-  hipLaunchKernelGGL(transit_window_kernel, dim3((unsigned)((n_rec + kBlock - 1) / kBlock)), dim3(kBlock), 0, st,
+  hipLaunchKernelGGL(transit_window_kernel, dim3((unsigned)((n_rec * kWinLanes + kBlock - 1) / kBlock)), dim3(kBlock), 0, st,
                      params, n_rec, flags, windows);
 }
 
@@ -2351,7 +2406,7 @@ inline int launch_runs_sweep(const double* t, int64_t n_cad, const double* texp,
   const dim3 block(kBlock);
   {
     const int64_t n_rec = n_draw * n_planet;
-    hipLaunchKernelGGL(transit_window_kernel, dim3((unsigned)((n_rec + kBlock - 1) / kBlock + w.n_sorted)), block, 0, st,
+    hipLaunchKernelGGL(transit_window_kernel, dim3((unsigned)((n_rec * kWinLanes + kBlock - 1) / kBlock + w.n_sorted)), block, 0, st,
                        params, n_rec, flags, w.windows, t, n_cad, w.sorted);
   }
   const bool has_ttv = ttv && ttv->edges;

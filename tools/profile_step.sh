@@ -8,7 +8,7 @@ rows=list(csv.DictReader(open(f)))
 tot=sum(float(r["TotalDurationNs"]) for r in rows)
 gp=sum(float(r["TotalDurationNs"]) for r in rows if "celerite" in r["Name"])
 tr=sum(float(r["TotalDurationNs"]) for r in rows if "transit" in r["Name"] or "pack" in r["Name"])
-print("per step (5 steps): total %.3f ms, celerite %.3f, transit+pack %.3f, other (torch) %.3f" % (tot/5e6, gp/5e6, tr/5e6, (tot-gp-tr)/5e6))
+print("per step (5 steps, CFG=$CFG): total %.3f ms, celerite %.3f, transit+pack %.3f, other (torch) %.3f" % (tot/5e6, gp/5e6, tr/5e6, (tot-gp-tr)/5e6))
 for r in rows[:14]:
     print("%-70s calls %4s total/step %8.1f us" % (r["Name"][:70], r["Calls"], float(r["TotalDurationNs"])/5e3))
 PY
