@@ -1756,6 +1756,126 @@ struct FillCursor {
   }
 };
 
+// Last kernel of a sweep on the run-enumeration path, one block per draw: (GRAD) block partials ->
+// gparams, gld, sum(gflux * flux), in block order; (dense output) the runs' values to their cadences,
+// planet by planet (summed flux: a later planet adds to what the earlier ones left).
+// (1024 threads per block for batches of at most 256 draws: the scatter of a draw's values is one block's work, and
+// with few draws the loads it keeps in flight are what bounds it -- C4 at 64 draws: 34 -> 10 us)
+// (also the tail of transit_runs_kernel when a draw is one block's work -- no restrict on what that kernel wrote)
+__device__ __forceinline__ void finish_draw(
+    int64_t draw, const double* partial, int nblk, int n_planet, bool secondary, double* __restrict__ gparams,
+    double* __restrict__ gld, double* __restrict__ flux_dot, int64_t n_cad, uint32_t flags, int n_ev, const RunLists& rl,
+    const double* vals, const int32_t* vcad, double* flux,
+    const double* __restrict__ chi2_part, int n_chi2_part, double* __restrict__ chi2_out, const Ttv& ttv) {
+  if (ttv.gshift) {
+    // timing tables, lists whose runs carry their bins: the runs' sums to their bins, in run order (the bins of a
+    // list's runs ascend); the samples of any other list added to gshift themselves
+    for (int p = 0; p < n_planet; ++p) {
+      const int64_t list = draw * n_planet + p;
+      const int K = rl.nrun[list];
+      const int32_t* __restrict__ rbin = rl.rbin + list * rl.r_max;
+      if (K == 0 || rbin[0] < 0) continue;
+      const double* grun = rl.grun + list * rl.r_max;
+      double* __restrict__ dst = ttv.gshift + list * (int64_t)(ttv.n_edge + 1);
+      for (int k = threadIdx.x; k <= ttv.n_edge; k += (int)blockDim.x) {
+        int lo = 0, hi = K;   // first run of a bin >= k
+        while (lo < hi) {
+          const int mid = (lo + hi) >> 1;
+          if (rbin[mid] < k) lo = mid + 1; else hi = mid;
+        }
+        double v = 0.0;
+        for (int r = lo; r < K && rbin[r] == k; ++r) v += grun[r];
+        dst[k] = v;
+      }
+    }
+  }
+  if (chi2_out && threadIdx.x == blockDim.x - 1) {   // block partials of transit_residual_kernel, in block order
+    double v = 0.0;
+    for (int b = 0; b < n_chi2_part; ++b) v += chi2_part[draw * n_chi2_part + b];
+    chi2_out[draw] = v;
+  }
+  const int ng_draw = n_planet * kNG + 7;
+  const int s = threadIdx.x;
+  if (partial) {
+    for (int q = s; q < n_planet * EXO_NPAR; q += (int)blockDim.x) {
+      // record slots that carry no gradient (T0, PERIOD, the windows, the reserved ones) read 0
+      const int p = q / EXO_NPAR, slot = q % EXO_NPAR;
+      const bool carried = slot == EXO_P_N || slot == EXO_P_TP || slot == EXO_P_ECC || slot == EXO_P_COSW ||
+                           slot == EXO_P_SINW || slot == EXO_P_COSI || slot == EXO_P_AOR || slot == EXO_P_ROR ||
+                           slot == EXO_P_FRATIO || slot == EXO_P_SINI || slot == EXO_P_CLIGHT;
+      if (!carried) gparams[(draw * n_planet + p) * EXO_NPAR + slot] = 0.0;
+    }
+    if (s < ng_draw) {
+      const double* src = partial + draw * nblk * (int64_t)ng_draw + s;
+      double v = 0.0;
+      for (int b = 0; b < nblk; ++b) v += src[(int64_t)b * ng_draw];
+      if (s < n_planet * kNG) {
+        const int p = s / kNG, k = s % kNG;
+        const int map[kNG] = {EXO_P_N, EXO_P_TP, EXO_P_ECC, EXO_P_COSW, EXO_P_SINW,
+                              EXO_P_COSI, EXO_P_AOR, EXO_P_ROR, EXO_P_FRATIO, -1, EXO_P_SINI, EXO_P_CLIGHT};
+        if (map[k] >= 0) gparams[(draw * n_planet + p) * EXO_NPAR + map[k]] = v;
+      } else {
+        const int k = s - n_planet * kNG;
+        const int nld = secondary ? 6 : 3;
+        if (k < nld) gld[draw * nld + k] = v;
+        if (k == 6 && flux_dot) flux_dot[draw] = v;
+      }
+    }
+  }
+  if (!flux || !vals) return;
+  // a thread per value: value and cadence arrays are read contiguously, four loads in flight per thread
+  const bool per_planet = flags & EXO_FLAG_PER_PLANET;
+  for (int p = 0; p < n_planet; ++p) {
+    const int64_t vbase = (draw * n_planet + p) * n_cad;
+    int total = 0;
+    for (int ev = 0; ev < n_ev; ++ev) {
+      const int64_t list = (draw * n_planet + p) * n_ev + ev;
+      total += rl.pre_all[list * (rl.r_max + 1) + rl.nrun[list]];
+    }
+    const double* src = vals + vbase;
+    const int32_t* cad = vcad + vbase;
+    const int nthr = (int)blockDim.x;
+    for (int e0 = threadIdx.x; e0 < total; e0 += 4 * nthr) {
+      double v[4];
+      int i[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int e = e0 + u * nthr;
+        v[u] = e < total ? src[e] : 0.0;
+        i[u] = e < total ? cad[e] : -1;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (i[u] < 0) continue;
+        if (per_planet) {
+          flux[(draw * n_cad + i[u]) * n_planet + p] = v[u];
+        } else {
+          double* dst = flux + draw * n_cad + i[u];
+          *dst = (p == 0) ? v[u] : (*dst + v[u]);   // (a planet's transits and occultations never share a cadence)
+        }
+      }
+    }
+    if (!per_planet && p + 1 < n_planet) __syncthreads();   // planets in order: bit-reproducible sums
+  }
+}
+
+__global__ __launch_bounds__(1024) void transit_finish_kernel(
+    const double* __restrict__ partial, int nblk, int n_planet, bool secondary, double* __restrict__ gparams,
+    double* __restrict__ gld, double* __restrict__ flux_dot, int64_t n_cad, uint32_t flags, int n_ev, RunLists rl,
+    const double* __restrict__ vals, const int32_t* __restrict__ vcad, double* __restrict__ flux,
+    const double* __restrict__ chi2_part, int n_chi2_part, double* __restrict__ chi2_out,
+    Ttv ttv = Ttv{nullptr, nullptr, nullptr, 0}) {
+  finish_draw(blockIdx.x, partial, nblk, n_planet, secondary, gparams, gld, flux_dot, n_cad, flags, n_ev, rl, vals, vcad, flux,
+              chi2_part, n_chi2_part, chi2_out, ttv);
+}
+
+struct FinishArgs {
+  double* gparams;
+  double* gld;
+  double* flux_dot;
+  int fold;   // the runs kernel finishes its draw itself (one block per draw)
+};
+
 // CHI2 (one planet, one sample per cadence): gflux is the observed series [n_cad], gsparse its weights ([1] or [n_cad],
 // `chi2_nw` says which); the "sum(gflux * flux)" slot of the partials carries sum w ((F - obs)^2 - obs^2) instead.
 // TTV (one event per planet): `ttv` holds the timing tables; a trusted list's runs carry their bin (rl.rbin), its
@@ -1768,7 +1888,7 @@ __global__ __launch_bounds__(kBlock, EXO_HEAVY_MIN_WAVES) void transit_runs_kern
     const double* __restrict__ params, const double* __restrict__ ld, int n_planet, uint32_t flags, int n_ev, RunLists rl,
     const double* __restrict__ gflux, const double* __restrict__ gsparse, double* __restrict__ vals,
     int32_t* __restrict__ vcad, double* __restrict__ fill, double* __restrict__ partial, int64_t chi2_nw = 0,
-    Ttv ttv = Ttv{nullptr, nullptr, nullptr, 0}) {
+    Ttv ttv = Ttv{nullptr, nullptr, nullptr, 0}, FinishArgs fin = FinishArgs{nullptr, nullptr, nullptr, 0}) {
   __shared__ Shared sh;
   __shared__ Run s_run[kSeg];
   __shared__ int s_in[kSeg + 1], s_all[kSeg + 1];
@@ -1951,6 +2071,14 @@ __global__ __launch_bounds__(kBlock, EXO_HEAVY_MIN_WAVES) void transit_runs_kern
   }
   if (GRAD) reduce_columns(lds_acc, sh.red, kNG, 7, pout + n_planet * kNG);
   fc.issue(1 << 30);   // whatever is left of the fill (all of it for a block without work)
+  if (fin.fold) {
+    // the draw was this block's work alone: partials -> gradients, values -> their cadences right here (what
+    // transit_finish_kernel does otherwise: one launch and ~12 us less per sweep)
+    __syncthreads();   // (partials, fill, values and run sums: written, and visible to the block)
+    finish_draw(draw, GRAD ? partial : nullptr, 1, n_planet, SECONDARY, fin.gparams, fin.gld, fin.flux_dot, n_cad, flags, n_ev,
+                rl, vals, vcad, fill, nullptr, 0, nullptr,
+                (TTV && GRAD) ? ttv : Ttv{nullptr, nullptr, nullptr, 0});
+  }
 }
 
 // White-noise likelihood on the sparse output (exo_transit_chi2_vjp_f64), between the value sweep and the gradient
@@ -2021,110 +2149,6 @@ __global__ __launch_bounds__(kBlock) void transit_residual_kernel(int64_t n_cad,
     __syncthreads();
   }
   if (threadIdx.x == 0) chi2_part[draw * nb + blockIdx.x] = red[0];
-}
-
-// Last kernel of a sweep on the run-enumeration path, one block per draw: (GRAD) block partials ->
-// gparams, gld, sum(gflux * flux), in block order; (dense output) the runs' values to their cadences,
-// planet by planet (summed flux: a later planet adds to what the earlier ones left).
-// (1024 threads per block for batches of at most 256 draws: the scatter of a draw's values is one block's work, and
-// with few draws the loads it keeps in flight are what bounds it -- C4 at 64 draws: 34 -> 10 us)
-__global__ __launch_bounds__(1024) void transit_finish_kernel(
-    const double* __restrict__ partial, int nblk, int n_planet, bool secondary, double* __restrict__ gparams,
-    double* __restrict__ gld, double* __restrict__ flux_dot, int64_t n_cad, uint32_t flags, int n_ev, RunLists rl,
-    const double* __restrict__ vals, const int32_t* __restrict__ vcad, double* __restrict__ flux,
-    const double* __restrict__ chi2_part, int n_chi2_part, double* __restrict__ chi2_out,
-    Ttv ttv = Ttv{nullptr, nullptr, nullptr, 0}) {
-  const int64_t draw = blockIdx.x;
-  if (ttv.gshift) {
-    // timing tables, lists whose runs carry their bins: the runs' sums to their bins, in run order (the bins of a
-    // list's runs ascend); the samples of any other list added to gshift themselves
-    for (int p = 0; p < n_planet; ++p) {
-      const int64_t list = draw * n_planet + p;
-      const int K = rl.nrun[list];
-      const int32_t* __restrict__ rbin = rl.rbin + list * rl.r_max;
-      if (K == 0 || rbin[0] < 0) continue;
-      const double* __restrict__ grun = rl.grun + list * rl.r_max;
-      double* __restrict__ dst = ttv.gshift + list * (int64_t)(ttv.n_edge + 1);
-      for (int k = threadIdx.x; k <= ttv.n_edge; k += (int)blockDim.x) {
-        int lo = 0, hi = K;   // first run of a bin >= k
-        while (lo < hi) {
-          const int mid = (lo + hi) >> 1;
-          if (rbin[mid] < k) lo = mid + 1; else hi = mid;
-        }
-        double v = 0.0;
-        for (int r = lo; r < K && rbin[r] == k; ++r) v += grun[r];
-        dst[k] = v;
-      }
-    }
-  }
-  if (chi2_out && threadIdx.x == blockDim.x - 1) {   // block partials of transit_residual_kernel, in block order
-    double v = 0.0;
-    for (int b = 0; b < n_chi2_part; ++b) v += chi2_part[draw * n_chi2_part + b];
-    chi2_out[draw] = v;
-  }
-  const int ng_draw = n_planet * kNG + 7;
-  const int s = threadIdx.x;
-  if (partial) {
-    for (int q = s; q < n_planet * EXO_NPAR; q += (int)blockDim.x) {
-      // record slots that carry no gradient (T0, PERIOD, the windows, the reserved ones) read 0
-      const int p = q / EXO_NPAR, slot = q % EXO_NPAR;
-      const bool carried = slot == EXO_P_N || slot == EXO_P_TP || slot == EXO_P_ECC || slot == EXO_P_COSW ||
-                           slot == EXO_P_SINW || slot == EXO_P_COSI || slot == EXO_P_AOR || slot == EXO_P_ROR ||
-                           slot == EXO_P_FRATIO || slot == EXO_P_SINI || slot == EXO_P_CLIGHT;
-      if (!carried) gparams[(draw * n_planet + p) * EXO_NPAR + slot] = 0.0;
-    }
-    if (s < ng_draw) {
-      const double* __restrict__ src = partial + draw * nblk * (int64_t)ng_draw + s;
-      double v = 0.0;
-      for (int b = 0; b < nblk; ++b) v += src[(int64_t)b * ng_draw];
-      if (s < n_planet * kNG) {
-        const int p = s / kNG, k = s % kNG;
-        const int map[kNG] = {EXO_P_N, EXO_P_TP, EXO_P_ECC, EXO_P_COSW, EXO_P_SINW,
-                              EXO_P_COSI, EXO_P_AOR, EXO_P_ROR, EXO_P_FRATIO, -1, EXO_P_SINI, EXO_P_CLIGHT};
-        if (map[k] >= 0) gparams[(draw * n_planet + p) * EXO_NPAR + map[k]] = v;
-      } else {
-        const int k = s - n_planet * kNG;
-        const int nld = secondary ? 6 : 3;
-        if (k < nld) gld[draw * nld + k] = v;
-        if (k == 6 && flux_dot) flux_dot[draw] = v;
-      }
-    }
-  }
-  if (!flux || !vals) return;
-  // a thread per value: value and cadence arrays are read contiguously, four loads in flight per thread
-  const bool per_planet = flags & EXO_FLAG_PER_PLANET;
-  for (int p = 0; p < n_planet; ++p) {
-    const int64_t vbase = (draw * n_planet + p) * n_cad;
-    int total = 0;
-    for (int ev = 0; ev < n_ev; ++ev) {
-      const int64_t list = (draw * n_planet + p) * n_ev + ev;
-      total += rl.pre_all[list * (rl.r_max + 1) + rl.nrun[list]];
-    }
-    const double* __restrict__ src = vals + vbase;
-    const int32_t* __restrict__ cad = vcad + vbase;
-    const int nthr = (int)blockDim.x;
-    for (int e0 = threadIdx.x; e0 < total; e0 += 4 * nthr) {
-      double v[4];
-      int i[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int e = e0 + u * nthr;
-        v[u] = e < total ? src[e] : 0.0;
-        i[u] = e < total ? cad[e] : -1;
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        if (i[u] < 0) continue;
-        if (per_planet) {
-          flux[(draw * n_cad + i[u]) * n_planet + p] = v[u];
-        } else {
-          double* dst = flux + draw * n_cad + i[u];
-          *dst = (p == 0) ? v[u] : (*dst + v[u]);   // (a planet's transits and occultations never share a cadence)
-        }
-      }
-    }
-    if (!per_planet && p + 1 < n_planet) __syncthreads();   // planets in order: bit-reproducible sums
-  }
 }
 
 // ---------------------------------------------------------------------------
@@ -2317,6 +2341,9 @@ inline ScanPlan scan_plan(uint32_t flags, int bpd, int64_t n_draw, int n_planet,
 // blocks are resident at once (two per CU), and every (planet, inside / limb) segment of a block ends in a partly
 // filled round: one generation of fuller blocks beats two generations of emptier ones (C4 at 64 draws: 11 round
 // times at 8 blocks per draw against 18 at 16).
+#ifndef EXO_RUNS_FOLD_FINISH
+#define EXO_RUNS_FOLD_FINISH 1   // (0: always the separate last kernel -- A/B builds)
+#endif
 #ifndef EXO_RUNS_TARGET_BLOCKS
 #define EXO_RUNS_TARGET_BLOCKS 512
 #endif
@@ -2385,15 +2412,16 @@ inline void launch_runs_kernel(bool ldelay, dim3 hgrid, hipStream_t st, const do
                                int64_t n_texp, const double* stencil_dt, const double* stencil_w, int32_t n_sub,
                                const double* params, const double* ld, int32_t n_planet, uint32_t flags, int n_ev,
                                const RunLists& rl, const double* gflux, const double* gsparse, double* vals, int32_t* vcad,
-                               double* fill, double* partial) {
+                               double* fill, double* partial, const FinishArgs& fin) {
+  const Ttv no_ttv{nullptr, nullptr, nullptr, 0};
   if (ldelay)
     hipLaunchKernelGGL((transit_runs_kernel<G, SEC, true>), hgrid, dim3(kBlock), 0, st, t, n_cad, texp, n_texp, stencil_dt,
                        stencil_w, (int)n_sub, params, ld, (int)n_planet, flags, n_ev, rl, gflux, gsparse, vals, vcad, fill,
-                       partial);
+                       partial, (int64_t)0, no_ttv, fin);
   else
     hipLaunchKernelGGL((transit_runs_kernel<G, SEC, false>), hgrid, dim3(kBlock), 0, st, t, n_cad, texp, n_texp, stencil_dt,
                        stencil_w, (int)n_sub, params, ld, (int)n_planet, flags, n_ev, rl, gflux, gsparse, vals, vcad, fill,
-                       partial);
+                       partial, (int64_t)0, no_ttv, fin);
 }
 inline int launch_runs_sweep(const double* t, int64_t n_cad, const double* texp, int64_t n_texp, const double* stencil_dt,
                              const double* stencil_w, int32_t n_sub, const double* params, const double* ld,
@@ -2422,25 +2450,30 @@ inline int launch_runs_sweep(const double* t, int64_t n_cad, const double* texp,
   double* fill = sparse ? nullptr : flux;
   const dim3 hgrid((unsigned)w.hb, (unsigned)n_draw);
   const bool ldelay = flags & EXO_FLAG_LIGHT_DELAY;
-#define EXO_LAUNCH_RUNS(G, GFLUX, GSP, VALS, VCAD, FILL, PARTIAL)                                                         \
+  // a draw that is one block's work is finished by that block (gradients from its partials, values to their cadences):
+  // no transit_finish_kernel launch
+  const bool fold = w.hb == 1 && EXO_RUNS_FOLD_FINISH;
+  const FinishArgs fin{gparams, gld, chi2 ? chi2->chi2 : flux_dot, fold ? 1 : 0}, no_fin{nullptr, nullptr, nullptr, 0};
+#define EXO_LAUNCH_RUNS(G, GFLUX, GSP, VALS, VCAD, FILL, PARTIAL, FIN)                                                    \
   if (secondary)                                                                                                          \
     launch_runs_kernel<G, true>(ldelay, hgrid, st, t, n_cad, texp, n_texp, stencil_dt, stencil_w, n_sub, params, ld,      \
-                                n_planet, flags, n_ev, w.rl, GFLUX, GSP, VALS, VCAD, FILL, PARTIAL);                       \
+                                n_planet, flags, n_ev, w.rl, GFLUX, GSP, VALS, VCAD, FILL, PARTIAL, FIN);                  \
   else                                                                                                                    \
     launch_runs_kernel<G, false>(ldelay, hgrid, st, t, n_cad, texp, n_texp, stencil_dt, stencil_w, n_sub, params, ld,     \
-                                 n_planet, flags, n_ev, w.rl, GFLUX, GSP, VALS, VCAD, FILL, PARTIAL)
+                                 n_planet, flags, n_ev, w.rl, GFLUX, GSP, VALS, VCAD, FILL, PARTIAL, FIN)
   if (chi2 && n_planet == 1 && !secondary && n_sub == 1) {
     // one planet, one sample per cadence: the cotangent of a cadence's flux needs nothing but that flux -- value and
     // gradient in ONE evaluation per solved cadence (the misfit comes out of the "dot" slot of the partials)
     if (ldelay)
       hipLaunchKernelGGL((transit_runs_kernel<true, false, true, true>), hgrid, block, 0, st, t, n_cad, texp, n_texp, stencil_dt,
                          stencil_w, (int)n_sub, params, ld, (int)n_planet, flags, n_ev, w.rl, chi2->obs, chi2->ivar, nullptr,
-                         nullptr, nullptr, w.partial, chi2->n_ivar);
+                         nullptr, nullptr, w.partial, chi2->n_ivar, Ttv{nullptr, nullptr, nullptr, 0}, fin);
     else
       hipLaunchKernelGGL((transit_runs_kernel<true, false, false, true>), hgrid, block, 0, st, t, n_cad, texp, n_texp, stencil_dt,
                          stencil_w, (int)n_sub, params, ld, (int)n_planet, flags, n_ev, w.rl, chi2->obs, chi2->ivar, nullptr,
-                         nullptr, nullptr, w.partial, chi2->n_ivar);
+                         nullptr, nullptr, w.partial, chi2->n_ivar, Ttv{nullptr, nullptr, nullptr, 0}, fin);
     if (launch_status() != EXO_OK) return EXO_ERR_LAUNCH;
+    if (fold) return EXO_OK;
     hipLaunchKernelGGL(transit_finish_kernel, dim3((unsigned)n_draw), dim3(n_draw <= 256 ? 1024 : kBlock), 0, st, w.partial, w.hb,
                        (int)n_planet, secondary, gparams, gld, chi2->chi2, n_cad, flags, n_ev, w.rl, nullptr, w.vcad, nullptr,
                        nullptr, 0, nullptr);
@@ -2451,24 +2484,25 @@ inline int launch_runs_sweep(const double* t, int64_t n_cad, const double* texp,
     if (grad)
       hipLaunchKernelGGL((transit_runs_kernel<true, false, false, false, true>), hgrid, block, 0, st, t, n_cad, texp, n_texp,
                          stencil_dt, stencil_w, (int)n_sub, params, ld, (int)n_planet, flags, n_ev, w.rl, gflux, nullptr, vals,
-                         fill ? w.vcad : nullptr, fill, w.partial, (int64_t)0, *ttv);
+                         fill ? w.vcad : nullptr, fill, w.partial, (int64_t)0, *ttv, fin);
     else
       hipLaunchKernelGGL((transit_runs_kernel<false, false, false, false, true>), hgrid, block, 0, st, t, n_cad, texp, n_texp,
                          stencil_dt, stencil_w, (int)n_sub, params, ld, (int)n_planet, flags, n_ev, w.rl, nullptr, nullptr, vals,
-                         fill ? w.vcad : nullptr, fill, nullptr, (int64_t)0, *ttv);
+                         fill ? w.vcad : nullptr, fill, nullptr, (int64_t)0, *ttv, fin);
   } else if (chi2) {
-    EXO_LAUNCH_RUNS(false, nullptr, nullptr, w.vals, w.vcad, nullptr, nullptr);
+    EXO_LAUNCH_RUNS(false, nullptr, nullptr, w.vals, w.vcad, nullptr, nullptr, no_fin);
     hipLaunchKernelGGL(transit_residual_kernel, dim3(kResidualBlocks, (unsigned)n_draw), block, 0, st, n_cad, (int)n_planet,
                        n_ev, w.rl, w.vals, w.vcad, chi2->obs, chi2->ivar, chi2->n_ivar, w.gvals, w.chi2_part);
-    EXO_LAUNCH_RUNS(true, nullptr, w.gvals, nullptr, nullptr, nullptr, w.partial);
+    EXO_LAUNCH_RUNS(true, nullptr, w.gvals, nullptr, nullptr, nullptr, w.partial, no_fin);
   } else if (grad) {
-    EXO_LAUNCH_RUNS(true, gflux, nullptr, vals, fill ? w.vcad : nullptr, fill, w.partial);
+    EXO_LAUNCH_RUNS(true, gflux, nullptr, vals, fill ? w.vcad : nullptr, fill, w.partial, fin);
   } else {
-    EXO_LAUNCH_RUNS(false, nullptr, nullptr, vals, fill ? w.vcad : nullptr, fill, nullptr);
+    EXO_LAUNCH_RUNS(false, nullptr, nullptr, vals, fill ? w.vcad : nullptr, fill, nullptr, fin);
   }
 #undef EXO_LAUNCH_RUNS
   if (launch_status() != EXO_OK) return EXO_ERR_LAUNCH;
-  if (grad || fill)
+  const bool three_sweeps = chi2 && !has_ttv;   // (the single-pass likelihood returned above)
+  if ((grad || fill) && (!fold || three_sweeps))
     hipLaunchKernelGGL(transit_finish_kernel, dim3((unsigned)n_draw), dim3(n_draw <= 256 ? 1024 : kBlock), 0, st,
                        grad ? w.partial : nullptr, w.hb, (int)n_planet, secondary, gparams, gld, flux_dot, n_cad, flags, n_ev,
                        w.rl, chi2 ? nullptr : vals, w.vcad, fill, chi2 ? w.chi2_part : nullptr, kResidualBlocks,
