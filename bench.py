@@ -693,15 +693,16 @@ def main():
                 "n_cadences": N_CAD, "draws_per_gpu": D, "global_draws": n_global,
                 "parallelism": f"draws sharded over {world} GPU(s); one collective of per-draw scalars per step",
                 "step": "leaf params (separate tensors, read in place) -> record-packing kernel (orbit algebra + "
-                        "get_cl) -> window + run-enumeration + heavy + finish kernels (value+VJP, one sweep) -> packing "
-                        "VJP kernel (cotangent of L folded in) -> leaf gradients: six launches"
+                        "get_cl) -> window + run-enumeration + heavy kernels (value+VJP, one sweep; the heavy kernel's blocks "
+                        "finish their own draws at >= 512 draws, a separate finish kernel below that) -> packing "
+                        "VJP kernel (cotangent of L folded in) -> leaf gradients: five launches (six below 512 draws)"
                         + ("; replayed as one hipGraph" if graph is not None else "; eager launches"),
             },
             "timing": timing,
             "roofline": {
                 "bound": "hbm",
-                "kernel": "transit_sorted_kernel + transit_window_kernel + transit_enum_kernel + transit_runs_kernel + "
-                          "transit_finish_kernel (one sweep)",
+                "kernel": "transit_window_kernel (+ sortedness flags) + transit_enum_kernel + transit_runs_kernel "
+                          "[+ transit_finish_kernel below 512 draws] (one sweep)",
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic["bytes"] if traffic else None,
                 "traffic_source": traffic["source"] if traffic else None,
@@ -716,7 +717,8 @@ def main():
                                             "against the bytes the design must move"},
                 "note": "achieved = algorithmic_bytes_per_launch / mean hipEvent time of the launches of one sweep "
                         "(sortedness flags, window constants, run enumeration, heavy = solved cadences + zero-fill of "
-                        "the dense flux, finish = values to their cadences + block partials), eager launches on the "
+                        "the dense flux, then -- in the same kernel when a draw is one block's work, else in a last small one -- "
+                        "values to their cadences + block partials), eager launches on the "
                         "same inputs as the timed graph.  The heavy kernel is where the time goes: fp64 VALU issue "
                         "(~1e3 flop per solved cadence) with the store stream of the dense output interleaved; "
                         "rocprof per-kernel averages and PMC traffic: profiles/",
