@@ -113,8 +113,11 @@ constexpr int kWinLanes = 4;   // threads per record: (event, side of the conjun
 __global__ __launch_bounds__(kBlock) void transit_window_kernel(const double* __restrict__ params, int64_t n_rec,
                                                                 uint32_t flags, double* __restrict__ out,
                                                                 const double* __restrict__ t = nullptr, int64_t n_cad = 0,
-                                                                int32_t* __restrict__ sorted = nullptr) {
+                                                                int32_t* __restrict__ sorted = nullptr,
+                                                                int32_t* __restrict__ done = nullptr, int64_t n_done = 0) {
   const int n_rec_blocks = (int)((n_rec * kWinLanes + kBlock - 1) / kBlock);
+  // (the per-draw block counters of the sweep that follows: transit_runs_kernel)
+  if (done && (int64_t)blockIdx.x * kBlock + threadIdx.x < n_done) done[(int64_t)blockIdx.x * kBlock + threadIdx.x] = 0;
   if ((int)blockIdx.x >= n_rec_blocks) {
     const int sb = blockIdx.x - n_rec_blocks;
     const int64_t b0 = (int64_t)sb * kSortBlock;
@@ -1873,7 +1876,8 @@ struct FinishArgs {
   double* gparams;
   double* gld;
   double* flux_dot;
-  int fold;   // the runs kernel finishes its draw itself (one block per draw)
+  int fold;        // the runs kernel finishes its draws itself: no transit_finish_kernel launch
+  int32_t* done;   // [n_draw] blocks of the draw that are through (zeroed by transit_window_kernel)
 };
 
 // CHI2 (one planet, one sample per cadence): gflux is the observed series [n_cad], gsparse its weights ([1] or [n_cad],
@@ -1888,7 +1892,7 @@ __global__ __launch_bounds__(kBlock, EXO_HEAVY_MIN_WAVES) void transit_runs_kern
     const double* __restrict__ params, const double* __restrict__ ld, int n_planet, uint32_t flags, int n_ev, RunLists rl,
     const double* __restrict__ gflux, const double* __restrict__ gsparse, double* __restrict__ vals,
     int32_t* __restrict__ vcad, double* __restrict__ fill, double* __restrict__ partial, int64_t chi2_nw = 0,
-    Ttv ttv = Ttv{nullptr, nullptr, nullptr, 0}, FinishArgs fin = FinishArgs{nullptr, nullptr, nullptr, 0}) {
+    Ttv ttv = Ttv{nullptr, nullptr, nullptr, 0}, FinishArgs fin = FinishArgs{nullptr, nullptr, nullptr, 0, nullptr}) {
   __shared__ Shared sh;
   __shared__ Run s_run[kSeg];
   __shared__ int s_in[kSeg + 1], s_all[kSeg + 1];
@@ -2072,10 +2076,22 @@ __global__ __launch_bounds__(kBlock, EXO_HEAVY_MIN_WAVES) void transit_runs_kern
   if (GRAD) reduce_columns(lds_acc, sh.red, kNG, 7, pout + n_planet * kNG);
   fc.issue(1 << 30);   // whatever is left of the fill (all of it for a block without work)
   if (fin.fold) {
-    // the draw was this block's work alone: partials -> gradients, values -> their cadences right here (what
-    // transit_finish_kernel does otherwise: one launch and ~12 us less per sweep)
-    __syncthreads();   // (partials, fill, values and run sums: written, and visible to the block)
-    finish_draw(draw, GRAD ? partial : nullptr, 1, n_planet, SECONDARY, fin.gparams, fin.gld, fin.flux_dot, n_cad, flags, n_ev,
+    // The last block of a draw to get here finishes the draw: partials -> gradients (in block order, whoever is
+    // last), values -> their cadences -- what transit_finish_kernel does otherwise, without its launch.  A draw that
+    // is one block's work needs no hand-shake; otherwise every thread publishes its stores (partials, values, zero
+    // fill, run sums), the block counts itself in, and the block that completes the count reads what the others left.
+    __shared__ int s_last;
+    if (hb > 1) {
+      __threadfence();
+      __syncthreads();
+      if (threadIdx.x == 0) s_last = (atomicAdd(fin.done + draw, 1) == hb - 1) ? 1 : 0;
+      __syncthreads();
+      if (!s_last) return;
+      __threadfence();
+    } else {
+      __syncthreads();
+    }
+    finish_draw(draw, GRAD ? partial : nullptr, hb, n_planet, SECONDARY, fin.gparams, fin.gld, fin.flux_dot, n_cad, flags, n_ev,
                 rl, vals, vcad, fill, nullptr, 0, nullptr,
                 (TTV && GRAD) ? ttv : Ttv{nullptr, nullptr, nullptr, 0});
   }
@@ -2342,7 +2358,10 @@ inline ScanPlan scan_plan(uint32_t flags, int bpd, int64_t n_draw, int n_planet,
 // filled round: one generation of fuller blocks beats two generations of emptier ones (C4 at 64 draws: 11 round
 // times at 8 blocks per draw against 18 at 16).
 #ifndef EXO_RUNS_FOLD_FINISH
-#define EXO_RUNS_FOLD_FINISH 1   // (0: always the separate last kernel -- A/B builds)
+// 1: draws that are one block's work are finished by that block; 0: never; 2: shared draws too, by the last block to
+// arrive (fence + counter) -- measured and NOT used: the device-scope release each block then needs writes the L2's
+// dirty zero-fill lines back before it returns (heavy kernel 54 -> 147 us at 128 draws, 102 -> 225 us on C4 at 64)
+#define EXO_RUNS_FOLD_FINISH 1
 #endif
 #ifndef EXO_RUNS_TARGET_BLOCKS
 #define EXO_RUNS_TARGET_BLOCKS 512
@@ -2363,6 +2382,7 @@ struct RunWs {
   int32_t* vcad;   // cadence of every value (dense output, chi^2)
   double* gvals;   // chi^2: cotangent of every value
   double* chi2_part;
+  int32_t* done;   // [n_draw] blocks of a draw that are through with it
   int hb, n_sorted;
   int64_t off_nrun, off_runs, off_pre_all, off_vals;   // byte offsets (exo_transit_flux_sparse_layout)
   int64_t bytes;
@@ -2389,6 +2409,7 @@ inline RunWs carve_runs(void* base, int64_t n_cad, int64_t n_draw, int n_planet)
   w.vcad = (int32_t*)(p + off); off = up16(off + 4 * n_draw * n_planet * n_cad);
   w.gvals = (double*)(p + off); off = up16(off + 8 * n_draw * n_planet * n_cad);
   w.chi2_part = (double*)(p + off); off = up16(off + 8 * n_draw * kResidualBlocks);
+  w.done = (int32_t*)(p + off); off = up16(off + 4 * n_draw);
   w.bytes = off;
   return w;
 }
@@ -2435,7 +2456,7 @@ inline int launch_runs_sweep(const double* t, int64_t n_cad, const double* texp,
   {
     const int64_t n_rec = n_draw * n_planet;
     hipLaunchKernelGGL(transit_window_kernel, dim3((unsigned)((n_rec * kWinLanes + kBlock - 1) / kBlock + w.n_sorted)), block, 0, st,
-                       params, n_rec, flags, w.windows, t, n_cad, w.sorted);
+                       params, n_rec, flags, w.windows, t, n_cad, w.sorted, w.done, n_draw);
   }
   const bool has_ttv = ttv && ttv->edges;
   if (has_ttv)
@@ -2452,8 +2473,8 @@ inline int launch_runs_sweep(const double* t, int64_t n_cad, const double* texp,
   const bool ldelay = flags & EXO_FLAG_LIGHT_DELAY;
   // a draw that is one block's work is finished by that block (gradients from its partials, values to their cadences):
   // no transit_finish_kernel launch
-  const bool fold = w.hb == 1 && EXO_RUNS_FOLD_FINISH;
-  const FinishArgs fin{gparams, gld, chi2 ? chi2->chi2 : flux_dot, fold ? 1 : 0}, no_fin{nullptr, nullptr, nullptr, 0};
+  const bool fold = EXO_RUNS_FOLD_FINISH == 2 || (EXO_RUNS_FOLD_FINISH == 1 && w.hb == 1);
+  const FinishArgs fin{gparams, gld, chi2 ? chi2->chi2 : flux_dot, fold ? 1 : 0, w.done}, no_fin{nullptr, nullptr, nullptr, 0, nullptr};
 #define EXO_LAUNCH_RUNS(G, GFLUX, GSP, VALS, VCAD, FILL, PARTIAL, FIN)                                                    \
   if (secondary)                                                                                                          \
     launch_runs_kernel<G, true>(ldelay, hgrid, st, t, n_cad, texp, n_texp, stencil_dt, stencil_w, n_sub, params, ld,      \
