@@ -494,7 +494,7 @@ def extra_astrometry(xo, dev, D=1024, n_epoch=64):
     return out
 
 
-def extra_hmc(xo, ops, dev, D=1024, n_leapfrog=8, dense=False):
+def extra_hmc(xo, ops, dev, D=1024, n_leapfrog=8, dense=False, nuts=False):
     """8f row 4: one HMC trajectory (n_leapfrog value + gradient evaluations of the C2 likelihood and the position /
     momentum updates between them) for D chains, replayed as one hipGraph"""
     rng = np.random.default_rng(8)
@@ -519,6 +519,22 @@ def extra_hmc(xo, ops, dev, D=1024, n_leapfrog=8, dense=False):
         return xo.LimbDarkLightCurve(u1, u2).white_noise_log_likelihood(orbit=orbit, r=Lv["r"], t=t, y=obs, yerr=ivar ** -0.5)
 
     params = [lv[k].detach().clone() for k in names]
+    if nuts:
+        # (unit masses and a step size far below the posterior's scales: every tree grows to the depth limit, i.e. the
+        # leg times 2**4 - 1 = 15 leaves per transition and the tree bookkeeping around them, not a tuned sampler)
+        smp = xo.NUTS(logp, params, step_size=1e-9, max_depth=4)
+        for _ in range(2):
+            smp.step()
+        torch.cuda.synchronize(dev)
+        n0 = smp.n_leapfrog
+        q = stats_loop(lambda _: smp.step(), dev, 10)
+        leaves = (smp.n_leapfrog - n0) / 10.0
+        return {"transitions_per_s": D / (q["median_ms"] * 1e-3), "evals_per_s": D * leaves / (q["median_ms"] * 1e-3), **q,
+                "chains": D, "leaves_per_transition": leaves, "ms_per_leaf": q["median_ms"] / leaves,
+                "mean_depth": float(smp.mean_depth().mean()),
+                "note": "exoplanet_amd.NUTS: %d chains in lockstep, one batched value+gradient evaluation of the C2 white-noise "
+                        "likelihood per leaf (leapfrog step replayed as a hipGraph), tree bookkeeping (multinomial sampling, "
+                        "checkpointed turning checks, masks) as torch ops on the device, one host synchronisation per doubling" % D}
     hmc = xo.HMC(logp, params, step_size=1e-6, n_leapfrog=n_leapfrog)
     for _ in range(3):
         hmc.step()
@@ -820,12 +836,16 @@ def main():
         leg("c5_secondary_eclipse_3term_gp_128_chains", lambda: extra_c5(xo, dev))
         torch.cuda.empty_cache()
         leg("astrometry_and_velocities", lambda: extra_astrometry(xo, dev))
+        def nuts_leg():
+            return extra_hmc(xo, ops, dev, nuts=True)
+
         def hmc_leg():
             res = extra_hmc(xo, ops, dev)
             res["dense_ms"] = extra_hmc(xo, ops, dev, dense=True)["median_ms"]
             return res
 
         leg("hmc_trajectory_c2", hmc_leg)
+        leg("nuts_transition_c2", nuts_leg)
         torch.cuda.empty_cache()
         leg("ops", lambda: extra_ops(ops, dev))
         if rank == 0:

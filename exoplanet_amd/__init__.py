@@ -7,6 +7,6 @@ from . import orbits, light_curves, gp, graph, sampling  # noqa: F401
 from .light_curves import LimbDarkLightCurve, SecondaryEclipseLightCurve  # noqa: F401
 from .orbits import KeplerianOrbit  # noqa: F401
 from .graph import GraphedStep  # noqa: F401
-from .sampling import HMC  # noqa: F401
+from .sampling import HMC, NUTS  # noqa: F401
 
 __version__ = "0.1.0"

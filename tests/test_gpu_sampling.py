@@ -53,3 +53,45 @@ def test_hmc_on_the_transit_likelihood_graph_vs_eager(dev):
     assert float(rate.mean()) > 0.5
     assert float(lp.mean()) > float(lp_first.mean())                     # the chains climb
     assert abs(float(t0s.mean()) - truth["t0"]) < 1e-3 and abs(float(rs.mean()) - truth["r"]) < 8e-3
+
+
+def test_nuts_on_the_white_noise_likelihood_graph_vs_eager(dev):
+    """NUTS over the fused white-noise likelihood (exo_transit_chi2_vjp_f64): the leapfrog step replayed as a hipGraph
+    gives the chains the eager step gives, and they settle on the generating parameters"""
+    import exoplanet_amd as xo
+    from exoplanet_amd.sampling import NUTS
+
+    rng = np.random.default_rng(61)
+    N, D = 8000, 24
+    t = torch.arange(N, dtype=torch.float64, device=dev) * (2.0 / 1440.0)
+    T = lambda v: torch.tensor(v, dtype=torch.float64, device=dev)   # noqa: E731
+    with torch.no_grad():
+        f0 = xo.LimbDarkLightCurve(0.3, 0.2).get_light_curve(orbit=xo.KeplerianOrbit(period=T(3.5), t0=T(1.0), b=T(0.3)),
+                                                             r=T(0.1), t=t)[:, 0]
+    sigma = 5e-4
+    y = f0 + sigma * torch.as_tensor(rng.normal(size=N), device=dev)
+    lc = xo.LimbDarkLightCurve(0.3, 0.2)
+
+    def logp(t0, r):
+        orbit = xo.KeplerianOrbit(period=3.5, t0=t0, b=0.3)
+        return lc.white_noise_log_likelihood(orbit=orbit, r=r, t=t, y=y, yerr=sigma)
+
+    def start():
+        g = np.random.default_rng(62)
+        return [torch.tensor(1.0 + 2e-3 * g.normal(size=(D, 1)), dtype=torch.float64, device=dev),
+                torch.tensor(0.1 * (1 + 0.05 * g.normal(size=(D, 1))), dtype=torch.float64, device=dev)]
+
+    mass = [1.0 / (2e-4) ** 2, 1.0 / (5e-4) ** 2]
+    out = {}
+    for mode in (True, False):
+        nuts = NUTS(logp, start(), step_size=0.3, max_depth=5, mass=mass, graph=mode,
+                    generator=torch.Generator(device=dev).manual_seed(9))
+        assert (nuts._graph is not None) == mode
+        for it in range(20):
+            nuts.step()
+        out[mode] = (nuts.params[0].clone(), nuts.params[1].clone(), nuts.last_logp.clone(), nuts.mean_depth().clone())
+    for a, b in zip(out[True], out[False]):
+        assert torch.allclose(a, b, rtol=1e-8, atol=1e-11)
+    t0s, rs, lp, depth = out[True]
+    assert 1.0 <= float(depth.mean()) <= 5.0
+    assert abs(float(t0s.mean()) - 1.0) < 1e-3 and abs(float(rs.mean()) - 0.1) < 8e-3

@@ -1,10 +1,10 @@
-"""CPU: the batched HMC driver (exoplanet_amd/sampling.py) is device-agnostic; its logic -- leapfrog,
-per-chain Metropolis step, in-place update of the chains -- is checked here on a Gaussian target.
-On a GPU the same class replays the trajectory as a hipGraph (tests/test_gpu_sampling.py)."""
+"""CPU: the batched HMC / NUTS drivers (exoplanet_amd/sampling.py) are device-agnostic; their logic -- leapfrog,
+per-chain Metropolis step or tree building, in-place update of the chains, warm-up -- is checked here on targets with
+known moments.  On a GPU the same classes replay their leapfrog steps as hipGraphs (tests/test_gpu_sampling.py)."""
 import numpy as np
 import torch
 
-from exoplanet_amd.sampling import HMC
+from exoplanet_amd.sampling import HMC, NUTS, _ckpt_range
 
 
 def test_hmc_samples_a_gaussian():
@@ -85,3 +85,84 @@ def test_warmup_adapts_step_sizes_and_masses():
     for _ in range(100):
         hmc2.step()
     assert 0.6 < float(hmc2.accept_rate().mean()) < 0.97
+
+
+def test_nuts_checkpoint_slots():
+    """leaf n (odd) closes the sub-trees of 2, 4, ... leaves that end at it -- one per trailing 1 bit -- whose first
+    leaves sit in consecutive checkpoint slots; brute force over every aligned sub-tree of a 64-leaf tree"""
+    first_slot = {}                      # first leaf (even) -> slot it was stored in
+    for n in range(64):
+        if n % 2 == 0:
+            first_slot[n] = bin(n >> 1).count("1")
+            continue
+        lo, hi = _ckpt_range(n)
+        want = []
+        size = 2
+        while (n + 1) % size == 0 and size <= 64:
+            want.append(first_slot[n + 1 - size])      # slots are reused: the value must be that sub-tree's first leaf's
+            size *= 2
+        assert list(range(hi, lo - 1, -1)) == want, (n, lo, hi, want)
+    assert _ckpt_range(7) == (0, 2) and _ckpt_range(11) == (1, 2) and _ckpt_range(1) == (0, 0)
+
+
+def test_nuts_samples_correlated_and_skewed_targets():
+    """a correlated Gaussian (rho = 0.9, unit masses) and log of a Gamma(2.5) variate: covariance, mean, variance and
+    third central moment against the closed forms (digamma, trigamma, tetragamma)"""
+    from scipy.special import digamma, polygamma
+
+    D, rho, k = 384, 0.9, 2.5
+
+    def logp(x, y):
+        a, b = x[:, 0], x[:, 1]
+        return -(a * a - 2 * rho * a * b + b * b) / (2 * (1 - rho * rho)) + (k * y[:, 0] - torch.exp(y[:, 0]))
+
+    torch.manual_seed(0)
+    x, y = torch.randn(D, 2, dtype=torch.float64), torch.zeros(D, 1, dtype=torch.float64)
+    nuts = NUTS(logp, [x, y], step_size=0.1, max_depth=6, generator=torch.Generator().manual_seed(3))
+    eps = nuts.warmup(80)
+    assert eps.shape == (D,) and 0.1 < float(eps.mean()) < 1.0
+    dx, dy = [], []
+    for _ in range(250):
+        depth = nuts.step()
+        assert depth.shape == (D,) and 1 <= float(depth.min()) and float(depth.max()) <= 6
+        dx.append(nuts.params[0].clone()); dy.append(nuts.params[1].clone())
+    assert float(nuts.n_divergent.sum()) == 0
+    assert 0.6 < float(nuts.last_accept_prob.mean()) <= 1.0
+    assert 1.5 < float(nuts.mean_depth().mean()) < 5
+    dx, dy = torch.stack(dx).reshape(-1, 2), torch.stack(dy).reshape(-1)
+    cov = torch.cov(dx.T)
+    assert abs(float(cov[0, 0]) - 1) < 0.05 and abs(float(cov[1, 1]) - 1) < 0.05 and abs(float(cov[0, 1]) - rho) < 0.05
+    assert abs(float(dy.mean()) - digamma(k)) < 0.02
+    assert abs(float(dy.var()) / polygamma(1, k) - 1) < 0.05
+    assert abs(float(((dy - dy.mean()) ** 3).mean()) / polygamma(2, k) - 1) < 0.15
+    # the chains' own tensors were updated in place
+    assert torch.equal(nuts.params[0], x)
+
+
+def test_nuts_walls_divergences_and_depth_limit():
+    D = 16
+
+    def logp(x):             # a wall at |x| > 1.5: -inf beyond it (such leaves diverge and end the tree)
+        lp = -0.5 * x[:, 0] ** 2
+        return torch.where(x[:, 0].abs() > 1.5, torch.full_like(lp, -float("inf")), lp)
+
+    nuts = NUTS(logp, [torch.zeros(D, 1, dtype=torch.float64)], step_size=0.3, max_depth=5,
+                generator=torch.Generator().manual_seed(3))
+    for _ in range(60):
+        nuts.step()
+        assert bool((nuts.params[0].abs() <= 1.5).all()) and bool(torch.isfinite(nuts.last_logp).all())
+    assert float(nuts.n_divergent.sum()) > 0
+    # tiny steps on a wide Gaussian: no U-turn within the depth limit -- every tree has exactly max_depth doublings,
+    # 2**max_depth - 1 leapfrog steps, and (energy conserved) every leaf is accepted
+    nuts2 = NUTS(lambda x: -0.5 * (x ** 2).sum(-1), [torch.zeros(D, 2, dtype=torch.float64)], step_size=1e-3, max_depth=4,
+                 generator=torch.Generator().manual_seed(4))
+    d = nuts2.step()
+    assert bool((d == 4).all()) and nuts2.n_leapfrog == 15 and float(nuts2.last_accept_prob.min()) > 0.999
+    # same seed, same chain
+    a = NUTS(lambda x: -0.5 * (x ** 2).sum(-1), [torch.ones(D, 2, dtype=torch.float64)], step_size=0.4, max_depth=6,
+             generator=torch.Generator().manual_seed(8))
+    b = NUTS(lambda x: -0.5 * (x ** 2).sum(-1), [torch.ones(D, 2, dtype=torch.float64)], step_size=0.4, max_depth=6,
+             generator=torch.Generator().manual_seed(8))
+    for _ in range(5):
+        a.step(); b.step()
+    assert torch.equal(a.params[0], b.params[0])
