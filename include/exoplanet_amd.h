@@ -231,8 +231,12 @@ int exo_transit_flux_vjp_ev_f64(const double* t, int64_t n_cad, const double* te
  * and a time t acts as t - ttv_shift[k(t)]: mean anomaly (t - shift - TP) N, window
  * phase t - shift - T0.  The reverse sweep adds
  *   gshift    [n_draw][n_planet][n_edge + 1]  d sum(gflux * flux) / d ttv_shift
- * (hardware fp64 atomics, one per wave and cadence run: the last bits of gshift depend
- * on scheduling; everything else is as reproducible as without timing variations).
+ * Sorted times, one exposure time (or none), no occultations: the windows are enumerated per
+ * timing bin (run-enumeration sweep; EXO_FLAG_SPARSE is accepted), and gshift is summed run by
+ * run in a fixed order -- bit-reproducible -- unless a transit lies across a bin edge (that
+ * list's samples look their bins up one by one).  Otherwise, and for such lists: hardware fp64
+ * atomics, one per wave and cadence run -- the last bits of gshift depend on scheduling;
+ * everything else is as reproducible as without timing variations.
  * EXO_FLAG_WINDOW: the caller's windows are tested on the warped mid-exposure time
  * (keplerian.py:729-731 with ttv.py:181-187).
  * ------------------------------------------------------------------------- */
