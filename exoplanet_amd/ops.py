@@ -487,12 +487,16 @@ class SparseFlux:
 
 
 @torch.no_grad()
-def transit_flux_sparse(t, params, ld, gflux=None, texp=None, stencil_dt=None, stencil_w=None, flags=0):
+def transit_flux_sparse(t, params, ld, gflux=None, texp=None, stencil_dt=None, stencil_w=None, flags=0, ttv=None):
     """Sparse sweep: no dense flux array is written.  Returns a :class:`SparseFlux`, and with
-    ``gflux`` (dense cotangent, read only at the solved cadences) also (gparams, gld, dot).
-    Needs sorted times, a scalar (or no) exposure time and no FLAG_EXACT_SCAN."""
+    ``gflux`` (dense cotangent, read only at the solved cadences) also (gparams, gld, dot[, gshift]).
+    Needs sorted times, a scalar (or no) exposure time and no FLAG_EXACT_SCAN; ``ttv = (edges, shift)``:
+    timing tables (transits only)."""
     flags = int(flags) | FLAG_SPARSE
     t, texp, n_texp, sdt, sw, n_sub, params, ld, D, P = _transit_args(t, texp, stencil_dt, stencil_w, params, ld, flags)
+    edges, shift, n_edge = _ttv_args(ttv, D, P)
+    if n_edge and flags & FLAG_SECONDARY:
+        raise ValueError("the sparse sweep takes timing tables for transits only")
     N = t.numel()
     lib = _lib.load()
     nbytes = lib.exo_transit_flux_workspace_bytes(N, D, P)
@@ -504,13 +508,27 @@ def transit_flux_sparse(t, params, ld, gflux=None, texp=None, stencil_dt=None, s
     n_ev = 2 if flags & FLAG_SECONDARY else 1
     with torch.cuda.device(t.device):
         if gflux is None:
-            _lib.check(lib.exo_transit_flux_fwd_f64(_ptr(t), N, _ptr(texp), n_texp, _ptr(sdt), _ptr(sw), n_sub, _ptr(params),
-                                                    _ptr(ld), D, P, flags, 0, _ptr(ws), nbytes, _stream(t)),
-                       "exo_transit_flux_fwd_f64")
+            if n_edge:
+                _lib.check(lib.exo_transit_flux_ttv_fwd_f64(_ptr(t), N, _ptr(texp), n_texp, _ptr(sdt), _ptr(sw), n_sub,
+                                                            _ptr(params), _ptr(ld), D, P, flags, _ptr(edges), _ptr(shift),
+                                                            n_edge, 0, _ptr(ws), nbytes, _stream(t)),
+                           "exo_transit_flux_ttv_fwd_f64")
+            else:
+                _lib.check(lib.exo_transit_flux_fwd_f64(_ptr(t), N, _ptr(texp), n_texp, _ptr(sdt), _ptr(sw), n_sub, _ptr(params),
+                                                        _ptr(ld), D, P, flags, 0, _ptr(ws), nbytes, _stream(t)),
+                           "exo_transit_flux_fwd_f64")
             return SparseFlux(ws, list(lay), N, D, P, n_ev)
         gflux = _dev(gflux, "gflux")
         gparams, gld = torch.empty_like(params), torch.empty_like(ld)
         dot = torch.empty(D, dtype=torch.float64, device=t.device)
+        if n_edge:
+            gshift = torch.empty_like(shift)
+            _lib.check(lib.exo_transit_flux_ttv_vjp_f64(_ptr(t), N, _ptr(texp), n_texp, _ptr(sdt), _ptr(sw), n_sub,
+                                                        _ptr(params), _ptr(ld), D, P, flags, _ptr(edges), _ptr(shift),
+                                                        n_edge, _ptr(gflux), 0, _ptr(gparams), _ptr(gld), _ptr(gshift),
+                                                        _ptr(dot), _ptr(ws), nbytes, _stream(t)),
+                       "exo_transit_flux_ttv_vjp_f64")
+            return SparseFlux(ws, list(lay), N, D, P, n_ev), gparams, gld, dot, gshift
         _lib.check(lib.exo_transit_flux_vjp_f64(_ptr(t), N, _ptr(texp), n_texp, _ptr(sdt), _ptr(sw), n_sub, _ptr(params),
                                                 _ptr(ld), D, P, flags, _ptr(gflux), 0, _ptr(gparams), _ptr(gld), _ptr(dot),
                                                 _ptr(ws), nbytes, _stream(t)), "exo_transit_flux_vjp_f64")

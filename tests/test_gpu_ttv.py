@@ -427,3 +427,29 @@ def test_one_bin_covering_many_transits(dev):
     c = P.get_cl(0.3, 0.2)[None]
     check(dev, t, rec, c, (edges, shift))
     check(dev, t, rec, c, (edges, shift), texp=0.02, order=1)
+
+
+def test_sparse_output_with_timing_tables(dev):
+    """EXO_FLAG_SPARSE through the timing-table entry points: the runs + values are the dense flux at the same cadences,
+    zero elsewhere; same gradients, gshift included"""
+    from exoplanet_amd import ops
+
+    rec, tables = case_records(draws=4)
+    D = rec.shape[0]
+    c = T(np.repeat(P.get_cl(0.3, 0.2)[None], D, 0), dev)
+    t = T(np.linspace(-3.0, 84.0, 12001), dev)
+    g = T(np.random.default_rng(9).normal(size=(D, 12001)), dev)
+    ttv = (T(tables[0], dev), T(tables[1], dev))
+    sdt, sw = P.exposure_stencil(3, 0)
+    for kw in ({}, dict(texp=T(np.array([0.03]), dev), stencil_dt=T(sdt, dev), stencil_w=T(sw, dev))):
+        f, gp, gl, gs = ops.transit_flux_value_and_vjp(t, T(rec, dev), c, g, ttv=ttv, **kw)
+        sp = ops.transit_flux_sparse(t, T(rec, dev), c, ttv=ttv, **kw)
+        dense = sp.to_dense(per_planet=False)
+        assert np.array_equal(dense, npy(f))
+        sp2, gp2, gl2, dot, gs2 = ops.transit_flux_sparse(t, T(rec, dev), c, gflux=g, ttv=ttv, **kw)
+        assert np.array_equal(sp2.to_dense(per_planet=False), npy(f))
+        assert torch.equal(gp2, gp) and torch.equal(gl2, gl) and torch.equal(gs2, gs)
+        np.testing.assert_allclose(npy(dot), (npy(g) * npy(f)).sum(-1), rtol=1e-10, atol=1e-14)
+        assert 0 < sp.n_solved() < 0.2 * D * 12001 * 2
+    with pytest.raises(ValueError):
+        ops.transit_flux_sparse(t, T(rec, dev), c, ttv=ttv, flags=ops.FLAG_SECONDARY)
