@@ -1286,3 +1286,44 @@ def celerite_loglike(t, y, diag, coeffs):
         z = y[n] - U[n] @ F
         acc += z * z / d + np.log(d)
     return -0.5 * acc - 0.5 * N * np.log(2 * np.pi)
+
+
+# ---------------------------------------------------------------------------------------------
+# Not a reference function: the conjunction-window bound of the HIP path (exoplanet_amd/csrc/exo_transit.hip,
+# transit_window_kernel), restated so that its defining property -- the window holds every true anomaly at which
+# the disks can overlap -- can be checked on the CPU against brute force (tests/test_window_bound.py).  The
+# reference has no counterpart: its in_transit (keplerian.py:708-777) solves for the contacts themselves.
+# ---------------------------------------------------------------------------------------------
+def conjunction_window(e, omega, cosi, sini, aor, ror, event=0, rounds=3):
+    """(f0, d_lo, d_hi): overlap of the disks (separation < 1 + ror, body on the near / far side for event 0 / 1)
+    is only possible for true anomalies in [f0 - d_lo, f0 + d_hi]; None if the first bound does not exist"""
+    lim = 1.0 + abs(ror)
+    q = lim / (abs(aor) * (1.0 - e))
+    if not (0.0 <= e < 1.0) or not q < 0.999:
+        return None
+    delta0 = np.arcsin(q)
+    f0 = (-0.5 if sini < 0 else 0.5) * np.pi - omega + event * np.pi
+    semi = abs(aor) * (1.0 - e * e)
+    si2, ci2 = sini * sini, cosi * cosi
+    out = []
+    for sgn in (-1.0, 1.0):
+        ub = delta0
+        if si2 > 1e-12:
+            def ang(dist):
+                S = (lim * lim / (dist * dist) - ci2) / si2
+                return 0.0 if S <= 0 else (np.arcsin(np.sqrt(S)) if S < 1 else delta0)
+            dist_at = lambda f: semi / (1.0 + e * np.cos(f))  # noqa: E731
+            d_c = dist_at(f0)
+            for _ in range(rounds):
+                f_end = f0 + sgn * ub
+                lo, hi = min(f0, f_end), max(f0, f_end)
+                apsis = np.floor(hi / np.pi) >= np.ceil(lo / np.pi)
+                peri = np.floor(hi / (2 * np.pi)) >= np.ceil(lo / (2 * np.pi))
+                d_end = dist_at(f_end)
+                if not apsis and d_end >= d_c:
+                    lb = min(ang(d_end), ub)
+                    ub = min(ub, ang(dist_at(f0 + sgn * lb)))
+                else:
+                    ub = min(ub, ang(semi / (1.0 + e) if peri else min(d_end, d_c)))
+        out.append(ub * (1.0 + 1e-6) + 1e-6)
+    return f0, out[0], out[1]
