@@ -130,3 +130,46 @@ def test_short_and_odd_series(dev):
         assert same_flux(a[0], b[0]), N
         for x, y in zip(a[1:], b[1:]):
             assert float((x - y).abs().max()) <= 1e-11 * float(x.abs().max()) + 1e-300
+
+
+@pytest.mark.parametrize("planets", [1, 2])
+def test_folded_finish_equals_the_separate_last_kernel(dev, planets):
+    """batches of >= 512 draws: a draw is one block's work and that block finishes it (gradients from its partials,
+    values to their cadences); smaller batches share a draw among several blocks and a last kernel finishes it.  The
+    same draws through both: the same flux (up to the wave-vote rounding, zero at the same cadences), gradients equal to
+    summation order -- dense, per-planet, forward-only, with timing tables."""
+    from exoplanet_amd import ops
+    from test_gpu_ttv import case_records
+
+    rng = np.random.default_rng(77)
+    D, N, k = 640, 3001, 6
+    t = np.arange(N) * (30.0 / 1440.0) + 0.1
+    rec, c = system(rng, D, 3 if planets == 2 else 1)
+    g = rng.normal(size=(D, N))
+    sub = slice(100, 100 + k)
+    for flags in (0, ops.FLAG_PER_PLANET):
+        gg = np.repeat(g[..., None], rec.shape[1], -1) if flags else g
+        big = ops.transit_flux_value_and_vjp(T(t, dev), T(rec, dev), T(c, dev), T(gg, dev), flags=flags)
+        small = ops.transit_flux_value_and_vjp(T(t, dev), T(rec[sub], dev), T(c[sub], dev), T(gg[sub], dev), flags=flags)
+        assert float(big[0].min()) < -1e-3
+        assert same_flux(big[0][sub], small[0])
+        for a, b in zip(big[1:], small[1:]):
+            assert float((a[sub] - b).abs().max()) <= 1e-12 * float(b.abs().max())
+        f_big = ops.transit_flux(T(t, dev), T(rec, dev), T(c, dev), flags=flags)
+        assert torch.equal(f_big, big[0])
+    # timing tables (two planets, their own tables per draw)
+    recs, tables = case_records(draws=8)
+    reps = 80
+    rec_t = np.tile(recs, (reps, 1, 1))
+    ed, sh = np.tile(tables[0], (reps, 1, 1)), np.tile(tables[1], (reps, 1, 1))
+    Dt = rec_t.shape[0]
+    ct = np.repeat(P.get_cl(0.3, 0.2)[None], Dt, 0)
+    tt = np.linspace(-3.0, 84.0, 4001)
+    gt = rng.normal(size=(Dt, tt.size))
+    big = ops.transit_flux_value_and_vjp(T(tt, dev), T(rec_t, dev), T(ct, dev), T(gt, dev), ttv=(T(ed, dev), T(sh, dev)))
+    small = ops.transit_flux_value_and_vjp(T(tt, dev), T(rec_t[:8], dev), T(ct[:8], dev), T(gt[:8], dev),
+                                           ttv=(T(ed[:8], dev), T(sh[:8], dev)))
+    assert Dt >= 512 and float(big[0].min()) < -1e-3
+    assert same_flux(big[0][:8], small[0])
+    for a, b in zip(big[1:], small[1:]):
+        assert float((a[:8] - b).abs().max()) <= 1e-12 * float(b.abs().max())
