@@ -566,8 +566,21 @@ def extra_ttv(xo, ops, leaves, t, gbar, dev, D):
         return (dot.detach(),) + torch.autograd.grad(dot.sum(), vals)
 
     q, how = graphed(xo, ttv_step, list(leaves.values()) + [offs], dev, 30)
+    # the same orbit as a white-noise likelihood (exo_transit_chi2_ttv_vjp_f64): no (draw, cadence) array
+    obs = 1e-4 * torch.randn(t.numel(), dtype=torch.float64, device=dev)
+
+    def ttv_like(*vals):
+        Lv = dict(zip(tnames, vals))
+        orb = xo.orbits.TTVOrbit(period=Lv["period"], t0=Lv["t0"], b=Lv["b"], ecc=Lv["ecc"], omega=Lv["omega"],
+                                 ttvs=[Lv["ttvs"]])
+        ll = xo.LimbDarkLightCurve(Lv["u1"], Lv["u2"]).white_noise_log_likelihood(orbit=orb, r=Lv["r"], t=t, y=obs, yerr=1e-4)
+        return (ll.detach(),) + torch.autograd.grad(ll.sum(), vals)
+
+    ql, _ = graphed(xo, ttv_like, list(leaves.values()) + [offs], dev, 30)
     return {"evals_per_s": D / (q["median_ms"] * 1e-3), **q, "transits": n_tr, "launch": how,
-            "note": "C2 step with a TTVOrbit (timing tables in the fused kernels, gradients to every per-transit offset)"}
+            "likelihood": {"evals_per_s": D / (ql["median_ms"] * 1e-3), "median_ms": ql["median_ms"]},
+            "note": "C2 step with a TTVOrbit (timing tables in the fused kernels, gradients to every per-transit offset); "
+                    "`likelihood`: the same orbit through white_noise_log_likelihood (one evaluation per solved cadence)"}
 
 
 def main():

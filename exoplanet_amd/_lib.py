@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # EXOPLANET_AMD_LIB selects another in-tree build of the same ABI (A/B measurements)
 LIB_PATH = os.environ.get("EXOPLANET_AMD_LIB") or os.path.join(_HERE, "lib", "libexoplanet_amd.so")
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 _c_dp = ctypes.c_void_p  # device pointers travel as integers
 _i64 = ctypes.c_int64
@@ -89,6 +89,10 @@ _SIGNATURES = {
     # chi2, gparams, gld, workspace, workspace_bytes, stream
     "exo_transit_chi2_vjp_f64": (ctypes.c_int, [_c_dp, _i64, _c_dp, _i64, _c_dp, _c_dp, _i32, _c_dp, _c_dp, _i64, _i32, _u32,
                                                 _c_dp, _c_dp, _i64, _c_dp, _c_dp, _c_dp, _c_dp, _i64, _c_dp]),
+    # ..., flags, ttv_edges, ttv_shift, n_edge, obs, ivar, n_ivar, chi2, gparams, gld, gshift, workspace, workspace_bytes, stream
+    "exo_transit_chi2_ttv_vjp_f64": (ctypes.c_int, [_c_dp, _i64, _c_dp, _i64, _c_dp, _c_dp, _i32, _c_dp, _c_dp, _i64, _i32, _u32,
+                                                    _c_dp, _c_dp, _i32, _c_dp, _c_dp, _i64, _c_dp, _c_dp, _c_dp, _c_dp, _c_dp,
+                                                    _i64, _c_dp]),
     "exo_sho_coefficients_f64": (ctypes.c_int, [_c_dp, _c_dp, _c_dp, _u32, ctypes.c_double, _i64, _c_dp, _c_dp, _c_dp]),
     "exo_sho_coefficients_vjp_f64": (ctypes.c_int, [_c_dp, _c_dp, _c_dp, _u32, ctypes.c_double, _i64, _c_dp, _c_dp, _c_dp,
                                                     _c_dp, _c_dp]),

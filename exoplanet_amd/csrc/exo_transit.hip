@@ -2485,7 +2485,11 @@ inline int launch_runs_sweep(const double* t, int64_t n_cad, const double* texp,
   if (chi2 && n_planet == 1 && !secondary && n_sub == 1) {
     // one planet, one sample per cadence: the cotangent of a cadence's flux needs nothing but that flux -- value and
     // gradient in ONE evaluation per solved cadence (the misfit comes out of the "dot" slot of the partials)
-    if (ldelay)
+    if (has_ttv)
+      hipLaunchKernelGGL((transit_runs_kernel<true, false, false, true, true>), hgrid, block, 0, st, t, n_cad, texp, n_texp,
+                         stencil_dt, stencil_w, (int)n_sub, params, ld, (int)n_planet, flags, n_ev, w.rl, chi2->obs, chi2->ivar,
+                         nullptr, nullptr, nullptr, w.partial, chi2->n_ivar, *ttv, fin);
+    else if (ldelay)
       hipLaunchKernelGGL((transit_runs_kernel<true, false, true, true>), hgrid, block, 0, st, t, n_cad, texp, n_texp, stencil_dt,
                          stencil_w, (int)n_sub, params, ld, (int)n_planet, flags, n_ev, w.rl, chi2->obs, chi2->ivar, nullptr,
                          nullptr, nullptr, w.partial, chi2->n_ivar, Ttv{nullptr, nullptr, nullptr, 0}, fin);
@@ -2497,10 +2501,20 @@ inline int launch_runs_sweep(const double* t, int64_t n_cad, const double* texp,
     if (fold) return EXO_OK;
     hipLaunchKernelGGL(transit_finish_kernel, dim3((unsigned)n_draw), dim3(n_draw <= 256 ? 1024 : kBlock), 0, st, w.partial, w.hb,
                        (int)n_planet, secondary, gparams, gld, chi2->chi2, n_cad, flags, n_ev, w.rl, nullptr, w.vcad, nullptr,
-                       nullptr, 0, nullptr);
+                       nullptr, 0, nullptr, has_ttv ? *ttv : Ttv{nullptr, nullptr, nullptr, 0});
     return launch_status();
   }
-  if (has_ttv) {
+  if (has_ttv && chi2) {
+    // value sweep into the sparse output, residuals + cotangents on it, gradient sweep reading them (gshift included)
+    hipLaunchKernelGGL((transit_runs_kernel<false, false, false, false, true>), hgrid, block, 0, st, t, n_cad, texp, n_texp,
+                       stencil_dt, stencil_w, (int)n_sub, params, ld, (int)n_planet, flags, n_ev, w.rl, nullptr, nullptr, w.vals,
+                       w.vcad, nullptr, nullptr, (int64_t)0, *ttv, no_fin);
+    hipLaunchKernelGGL(transit_residual_kernel, dim3(kResidualBlocks, (unsigned)n_draw), block, 0, st, n_cad, (int)n_planet,
+                       n_ev, w.rl, w.vals, w.vcad, chi2->obs, chi2->ivar, chi2->n_ivar, w.gvals, w.chi2_part);
+    hipLaunchKernelGGL((transit_runs_kernel<true, false, false, false, true>), hgrid, block, 0, st, t, n_cad, texp, n_texp,
+                       stencil_dt, stencil_w, (int)n_sub, params, ld, (int)n_planet, flags, n_ev, w.rl, nullptr, w.gvals, nullptr,
+                       nullptr, nullptr, w.partial, (int64_t)0, *ttv, no_fin);
+  } else if (has_ttv) {
     // (transits only, no light delay: runs_path)
     if (grad)
       hipLaunchKernelGGL((transit_runs_kernel<true, false, false, false, true>), hgrid, block, 0, st, t, n_cad, texp, n_texp,
@@ -2522,7 +2536,7 @@ inline int launch_runs_sweep(const double* t, int64_t n_cad, const double* texp,
   }
 #undef EXO_LAUNCH_RUNS
   if (launch_status() != EXO_OK) return EXO_ERR_LAUNCH;
-  const bool three_sweeps = chi2 && !has_ttv;   // (the single-pass likelihood returned above)
+  const bool three_sweeps = chi2 != nullptr;   // (the single-pass likelihood returned above)
   if ((grad || fill) && (!fold || three_sweeps))
     hipLaunchKernelGGL(transit_finish_kernel, dim3((unsigned)n_draw), dim3(n_draw <= 256 ? 1024 : kBlock), 0, st,
                        grad ? w.partial : nullptr, w.hb, (int)n_planet, secondary, gparams, gld, flux_dot, n_cad, flags, n_ev,
@@ -2540,7 +2554,7 @@ inline bool transit_args_ok(int64_t n_cad, int64_t n_texp, int32_t n_sub, int64_
 
 extern "C" {
 
-int32_t exo_abi_version(void) { return 8; }
+int32_t exo_abi_version(void) { return 9; }
 
 int exo_kepler_f64(const double* M, const double* ecc, double* sinf, double* cosf, int64_t n, void* stream) {
   if (n < 0 || (n > 0 && (!M || !ecc || !sinf || !cosf))) return EXO_ERR_INVALID_ARGUMENT;
@@ -2807,6 +2821,31 @@ int exo_transit_chi2_vjp_f64(const double* t, int64_t n_cad, const double* texp,
   const Chi2Args c2{obs, ivar, n_ivar, chi2};
   return launch_runs_sweep(t, n_cad, texp, n_texp, stencil_dt, stencil_w, n_sub, params, ld, n_draw, n_planet, flags, nullptr,
                            nullptr, gparams, gld, nullptr, rw, (hipStream_t)stream, &c2);
+}
+
+int exo_transit_chi2_ttv_vjp_f64(const double* t, int64_t n_cad, const double* texp, int64_t n_texp, const double* stencil_dt,
+                                 const double* stencil_w, int32_t n_sub, const double* params, const double* ld,
+                                 int64_t n_draw, int32_t n_planet, uint32_t flags, const double* ttv_edges,
+                                 const double* ttv_shift, int32_t n_edge, const double* obs, const double* ivar,
+                                 int64_t n_ivar, double* chi2, double* gparams, double* gld, double* gshift, void* workspace,
+                                 int64_t workspace_bytes, void* stream) {
+  if (!transit_args_ok(n_cad, n_texp, n_sub, n_draw, n_planet) || (n_ivar != 1 && n_ivar != n_cad) || n_cad < 1)
+    return EXO_ERR_INVALID_ARGUMENT;
+  if (flags & (EXO_FLAG_PER_PLANET | EXO_FLAG_SPARSE | EXO_FLAG_EXACT_SCAN | EXO_FLAG_SECONDARY | EXO_FLAG_LIGHT_DELAY))
+    return EXO_ERR_INVALID_ARGUMENT;
+  if (!ttv_args_ok(ttv_edges, ttv_shift, n_edge) || !gshift) return EXO_ERR_INVALID_ARGUMENT;
+  if (n_draw == 0) return EXO_OK;
+  if (!params || !ld || !chi2 || !gparams || !gld || !t || !obs || !ivar || (n_texp > 0 && (!texp || !stencil_dt || !stencil_w)))
+    return EXO_ERR_INVALID_ARGUMENT;
+  if (!runs_path(true, n_texp, flags)) return EXO_ERR_INVALID_ARGUMENT;   // one exposure time (or none) for all cadences
+  const RunWs rw = carve_runs(workspace, n_cad, n_draw, n_planet);
+  if (!workspace || workspace_bytes < rw.bytes) return EXO_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(gshift, 0, sizeof(double) * n_draw * n_planet * (n_edge + 1), st) != hipSuccess) return EXO_ERR_LAUNCH;
+  const Chi2Args c2{obs, ivar, n_ivar, chi2};
+  const Ttv ttv{ttv_edges, ttv_shift, gshift, n_edge};
+  return launch_runs_sweep(t, n_cad, texp, n_texp, stencil_dt, stencil_w, n_sub, params, ld, n_draw, n_planet, flags, nullptr,
+                           nullptr, gparams, gld, nullptr, rw, st, &c2, &ttv);
 }
 
 }  // extern "C"

@@ -190,15 +190,18 @@ class LimbDarkLightCurve:
         """Gaussian log-likelihood (one value per draw) of the observed series ``y`` with independent errors ``yerr``
         given ``mean + sum over planets of get_light_curve(...)`` -- what the reference's tutorials write as
         ``pm.Normal("obs", mu=mean + pt.sum(light_curves, axis=-1), sigma=yerr, observed=y)`` -- for a KeplerianOrbit
-        with sorted times and one exposure time: value and gradient in ONE call on the sparse light curve
+        or a TTVOrbit (gradients to its transit times / offsets included) with sorted times and one exposure time: value and gradient in ONE call on the sparse light curve
         (ops.transit_chi2), no (draws, cadences) array anywhere.  ``mean``: a number or a (draws, 1) tensor is NOT
         supported here (it would make the residual per draw): pass a scalar and model offsets in ``y``."""
         from ..orbits.keplerian import KeplerianOrbit
 
         if orbit is None or r is None or t is None or y is None or yerr is None:
             raise ValueError("orbit, r, t, y and yerr are required")
-        if not isinstance(orbit, KeplerianOrbit) or type(orbit)._warp_times is not KeplerianOrbit._warp_times:
-            raise NotImplementedError("white_noise_log_likelihood needs a KeplerianOrbit (no timing variations)")
+        has_ttv = hasattr(orbit, "kernel_ttv")
+        if not isinstance(orbit, KeplerianOrbit) or (type(orbit)._warp_times is not KeplerianOrbit._warp_times and not has_ttv):
+            raise NotImplementedError("white_noise_log_likelihood needs a KeplerianOrbit or a TTVOrbit")
+        if has_ttv and light_delay:
+            raise NotImplementedError("white_noise_log_likelihood: no light delay together with timing variations")
         t = as_tensor(t, r if isinstance(r, torch.Tensor) else self.u1)
         rec, ld, batch, flags = orbit.kernel_inputs(r, (self.u1, self.u2), use_in_transit=use_in_transit,
                                                     light_delay=light_delay)
@@ -208,6 +211,16 @@ class LimbDarkLightCurve:
             dt, w = exposure_stencil(oversample, order)
             kw.update(texp=as_tensor(texp, t).reshape(-1).detach(), stencil_dt=_on_device(dt, t.device),
                       stencil_w=_on_device(w, t.device))
+        if has_ttv:
+            # timing tables and records share one draw batch (as in get_light_curve)
+            edges, shift = orbit.kernel_ttv()
+            full = torch.broadcast_shapes(edges.shape[:-2], tuple(batch))
+            P = rec.shape[1]
+            rec = rec.reshape(tuple(batch) + rec.shape[1:]).expand(full + rec.shape[1:]).reshape(-1, P, rec.shape[2])
+            ld = ld.reshape(tuple(batch) + ld.shape[1:]).expand(full + ld.shape[1:]).reshape(-1, ld.shape[1])
+            kw["ttv"] = (edges.expand(full + edges.shape[-2:]).reshape(-1, P, edges.shape[-1]).contiguous(),
+                         shift.expand(full + shift.shape[-2:]).reshape(-1, P, shift.shape[-1]).contiguous())
+            rec, ld, batch = rec.contiguous(), ld.contiguous(), full
         ll = ops.white_noise_loglike(t.detach(), rec, ld, as_tensor(y, t).to(rec.device), yerr, mean=mean, flags=flags, **kw)
         return ll.reshape(tuple(batch)) if batch else ll.reshape(())
 

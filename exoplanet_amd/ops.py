@@ -376,8 +376,9 @@ class _TransitChi2(torch.autograd.Function):
     same call, like transit_flux_dot -- its gradient with respect to params and ld (exo_transit_chi2_vjp_f64)."""
 
     @staticmethod
-    def forward(ctx, t, texp, stencil_dt, stencil_w, params, ld, obs, ivar, flags):
+    def forward(ctx, t, texp, stencil_dt, stencil_w, params, ld, obs, ivar, flags, ttv_edges, ttv_shift):
         t, texp, n_texp, sdt, sw, n_sub, params, ld, D, P = _transit_args(t, texp, stencil_dt, stencil_w, params, ld, flags)
+        edges, shift, n_edge = _ttv_args(None if ttv_edges is None else (ttv_edges, ttv_shift), D, P)
         N = t.numel()
         obs = _dev(obs, "obs")
         ivar = _dev(ivar, "ivar").reshape(-1)
@@ -391,18 +392,28 @@ class _TransitChi2(torch.autograd.Function):
         chi2 = torch.empty(D, dtype=torch.float64, device=t.device)
         gparams = torch.empty_like(params)
         gld = torch.empty_like(ld)
+        gshift = torch.empty_like(shift) if n_edge else None
         with torch.cuda.device(t.device):
-            _lib.check(lib.exo_transit_chi2_vjp_f64(_ptr(t), N, _ptr(texp), n_texp, _ptr(sdt), _ptr(sw), n_sub, _ptr(params),
-                                                    _ptr(ld), D, P, flags, _ptr(obs), _ptr(ivar), ivar.numel(), _ptr(chi2),
-                                                    _ptr(gparams), _ptr(gld), _ptr(ws), nbytes, _stream(t)),
-                       "exo_transit_chi2_vjp_f64")
-        ctx.save_for_backward(gparams, gld)
+            if n_edge:
+                _lib.check(lib.exo_transit_chi2_ttv_vjp_f64(_ptr(t), N, _ptr(texp), n_texp, _ptr(sdt), _ptr(sw), n_sub,
+                                                            _ptr(params), _ptr(ld), D, P, flags, _ptr(edges), _ptr(shift),
+                                                            n_edge, _ptr(obs), _ptr(ivar), ivar.numel(), _ptr(chi2),
+                                                            _ptr(gparams), _ptr(gld), _ptr(gshift), _ptr(ws), nbytes,
+                                                            _stream(t)), "exo_transit_chi2_ttv_vjp_f64")
+                ctx.save_for_backward(gparams, gld, gshift)
+            else:
+                _lib.check(lib.exo_transit_chi2_vjp_f64(_ptr(t), N, _ptr(texp), n_texp, _ptr(sdt), _ptr(sw), n_sub, _ptr(params),
+                                                        _ptr(ld), D, P, flags, _ptr(obs), _ptr(ivar), ivar.numel(), _ptr(chi2),
+                                                        _ptr(gparams), _ptr(gld), _ptr(ws), nbytes, _stream(t)),
+                           "exo_transit_chi2_vjp_f64")
+                ctx.save_for_backward(gparams, gld)
         return chi2
 
     @staticmethod
     def backward(ctx, gchi2):
-        gparams, gld = ctx.saved_tensors
-        return (None, None, None, None, gchi2[:, None, None] * gparams, gchi2[:, None] * gld, None, None, None)
+        gparams, gld, *rest = ctx.saved_tensors
+        gshift = gchi2[:, None, None] * rest[0] if rest else None
+        return (None, None, None, None, gchi2[:, None, None] * gparams, gchi2[:, None] * gld, None, None, None, None, gshift)
 
 
 _CONSTS = {}
@@ -418,17 +429,19 @@ def _const(value, device):
     return _CONSTS[key]
 
 
-def transit_chi2(t, params, ld, obs, ivar, texp=None, stencil_dt=None, stencil_w=None, flags=0):
+def transit_chi2(t, params, ld, obs, ivar, texp=None, stencil_dt=None, stencil_w=None, flags=0, ttv=None):
     """White-noise misfit of ONE observed series ``obs`` (n_cad,) against the light curves of ``n_draw`` parameter
     sets, relative to an empty light curve, without any (n_draw, n_cad) array:
     ``chi2[d] = sum_n ivar_n ((flux[d, n] - obs[n])**2 - obs[n]**2)`` -- the sum runs over the cadences in which a
     planet of draw d can overlap the disk, everything else cancels.  Differentiable w.r.t. ``params`` and ``ld``
     (the gradient is computed in the same call).  ``ivar``: scalar or (n_cad,).  The Gaussian log-likelihood is
-    ``-0.5 * (chi2 + (ivar * obs**2).sum()) + 0.5 * log(ivar / 2 pi).sum()``: :func:`white_noise_loglike`."""
-    return _TransitChi2.apply(t, texp, stencil_dt, stencil_w, params, ld, obs, ivar, int(flags))
+    ``-0.5 * (chi2 + (ivar * obs**2).sum()) + 0.5 * log(ivar / 2 pi).sum()``: :func:`white_noise_loglike`.
+    ``ttv = (edges, shift)``: timing tables (transits only); differentiable w.r.t. ``shift`` as well."""
+    edges, shift = (None, None) if ttv is None else ttv
+    return _TransitChi2.apply(t, texp, stencil_dt, stencil_w, params, ld, obs, ivar, int(flags), edges, shift)
 
 
-def white_noise_loglike(t, params, ld, y, yerr, mean=0.0, texp=None, stencil_dt=None, stencil_w=None, flags=0):
+def white_noise_loglike(t, params, ld, y, yerr, mean=0.0, texp=None, stencil_dt=None, stencil_w=None, flags=0, ttv=None):
     """Gaussian log-likelihood (n_draw,) of the observed series ``y`` with independent errors ``yerr`` (scalar or
     per cadence) given ``mean + light curve`` -- the reference's ``pm.Normal("obs", mu=mean + lc, sigma=yerr,
     observed=y)`` for a batch of parameter sets, value and gradient in one call (:func:`transit_chi2`)."""
@@ -439,7 +452,7 @@ def white_noise_loglike(t, params, ld, y, yerr, mean=0.0, texp=None, stencil_dt=
         yerr = _dev(yerr, "yerr")
         ivar = (1.0 / (yerr * yerr)).reshape(-1)
     obs = y - mean
-    chi2 = transit_chi2(t, params, ld, obs, ivar, texp=texp, stencil_dt=stencil_dt, stencil_w=stencil_w, flags=flags)
+    chi2 = transit_chi2(t, params, ld, obs, ivar, texp=texp, stencil_dt=stencil_dt, stencil_w=stencil_w, flags=flags, ttv=ttv)
     n = y.numel()
     const = (ivar * obs * obs).sum() if ivar.numel() == n else ivar[0] * (obs * obs).sum()
     lognorm = torch.log(ivar / (2.0 * torch.pi)).sum() * (1.0 if ivar.numel() == n else float(n))

@@ -177,6 +177,18 @@ int exo_transit_chi2_vjp_f64(const double* t, int64_t n_cad, const double* texp,
                              int64_t n_ivar, double* chi2, double* gparams, double* gld, void* workspace,
                              int64_t workspace_bytes, void* stream);
 
+/* The same likelihood for an orbit with transit-timing variations (tables as for exo_transit_flux_ttv_vjp_f64, which
+ * see; transits only, no light delay: EXO_FLAG_WINDOW is the one flag), plus
+ *   gshift [n_draw][n_planet][n_edge + 1] = d chi2[d] / d ttv_shift
+ * -- the gradient of a timing fit (TTVOrbit with `ttvs` or `transit_times` as parameters: ttv.py:71-156) without a
+ * (draw, cadence) array.  n_cad >= 1.  One planet and no exposure stencil: one evaluation per solved cadence. */
+int exo_transit_chi2_ttv_vjp_f64(const double* t, int64_t n_cad, const double* texp, int64_t n_texp, const double* stencil_dt,
+                                 const double* stencil_w, int32_t n_sub, const double* params, const double* ld,
+                                 int64_t n_draw, int32_t n_planet, uint32_t flags, const double* ttv_edges,
+                                 const double* ttv_shift, int32_t n_edge, const double* obs, const double* ivar,
+                                 int64_t n_ivar, double* chi2, double* gparams, double* gld, double* gshift, void* workspace,
+                                 int64_t workspace_bytes, void* stream);
+
 /* Diagnostic for the scan kernel's conservative fp32 cadence classifier: the fp32
  * estimate of (cos E - e, sqrt(1-e^2) sin E) for mean anomaly M (fp64 phase) and
  * eccentricity ecc, widened back to double.  The classifier's safety margin assumes

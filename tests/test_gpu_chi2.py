@@ -181,3 +181,83 @@ def test_chi2_with_light_delay_and_flux_dot_with_exposure(dev):
     gb = torch.autograd.grad(d2.sum(), list(L.values()))
     for a, b in zip(ga, gb):
         assert float((a - b).abs().max()) <= 1e-9 * float(b.abs().max())
+
+
+@pytest.mark.parametrize("planets,texp", [(1, None), (2, None), (2, 0.03)])
+def test_chi2_with_timing_tables_matches_the_dense_sweep(dev, planets, texp):
+    """exo_transit_chi2_ttv_vjp_f64 -- one evaluation per solved cadence for one planet without a stencil, three sweeps
+    otherwise -- against chi^2 assembled from the dense timing-table sweep (itself checked against the oracle in
+    tests/test_gpu_ttv.py): value, gradients of records / limb darkening / per-transit shifts; the oracle's numpy
+    evaluation for the shifts as well"""
+    from exoplanet_amd import ops
+    from test_gpu_ttv import case_records, single_planet_draws
+
+    rng = np.random.default_rng(43)
+    rec, tables = single_planet_draws(6) if planets == 1 else case_records(draws=4)
+    D, N = rec.shape[0], 9001
+    t = np.linspace(-3.0, 84.0, N)
+    c = np.stack([P.get_cl(0.3 + 0.02 * d, 0.2 - 0.01 * d) for d in range(D)])     # (normalised: zero flux off the disk)
+    kw_g, kw_o = {}, {}
+    if texp is not None:
+        sdt, sw = P.exposure_stencil(5, 0)
+        kw_g = dict(texp=T([texp], dev), stencil_dt=T(sdt, dev), stencil_w=T(sw, dev))
+        kw_o = dict(texp=texp, stencil_dt=sdt, stencil_w=sw)
+    ttv = (T(tables[0], dev), T(tables[1], dev))
+    truth = ops.transit_flux(T(t, dev), T(rec[:1], dev), T(c[:1], dev), ttv=(ttv[0][:1], ttv[1][:1]), **kw_g)[0].cpu().numpy()
+    obs = truth + 3e-4 * rng.normal(size=N)
+    ivar = 1.0 / (3e-4 * (1 + 0.3 * rng.uniform(size=N))) ** 2
+    # dense composition: flux, then chi^2 and its cotangent in torch, VJP through the dense sweep
+    flux = ops.transit_flux(T(t, dev), T(rec, dev), T(c, dev), ttv=ttv, **kw_g)
+    w, o = T(ivar, dev), T(obs, dev)
+    want = (w * ((flux - o) ** 2 - o ** 2)).sum(-1)
+    _, gp, gl, gs = ops.transit_flux_value_and_vjp(T(t, dev), T(rec, dev), T(c, dev), 2.0 * w * (flux - o), ttv=ttv, **kw_g)
+    rt, ct, st = T(rec, dev).requires_grad_(True), T(c, dev).requires_grad_(True), ttv[1].clone().requires_grad_(True)
+    chi2 = ops.transit_chi2(T(t, dev), rt, ct, o, w, ttv=(ttv[0], st), **kw_g)
+    scale = float((w * o * o).sum())
+    assert float((chi2.detach() - want).abs().max()) <= 1e-12 * scale
+    wgt = T(rng.normal(size=D), dev)
+    (chi2 * wgt).sum().backward()
+    for got, ref, shape in ((rt.grad, gp, (D, 1, 1)), (ct.grad, gl, (D, 1)), (st.grad, gs, (D, 1, 1))):
+        ref = wgt.reshape(shape) * ref
+        assert float(ref.abs().max()) > 0
+        assert float((got - ref).abs().max()) <= 2e-9 * float(ref.abs().max())
+    # the shifts' gradient against the oracle's dense evaluation
+    f_o, _, _, gs_o = P.transit_flux_vjp(t, rec, c, 2.0 * ivar * (flux.cpu().numpy() - obs), ttv=tables, **kw_o)
+    assert np.abs(f_o - flux.cpu().numpy()).max() < 2e-13
+    assert np.abs(gs.cpu().numpy() - gs_o).max() <= 1e-8 * np.abs(gs_o).max()
+    # twice the same bits (no atomics on this path)
+    chi2b = ops.transit_chi2(T(t, dev), rt, ct, o, w, ttv=(ttv[0], st), **kw_g)
+    assert torch.equal(chi2b, chi2)
+
+
+def test_white_noise_log_likelihood_of_a_ttv_orbit(dev):
+    """user level: LimbDarkLightCurve.white_noise_log_likelihood with a TTVOrbit = the Gaussian log-likelihood of
+    get_light_curve's model, gradients to the per-transit offsets included; a batch of draws"""
+    import exoplanet_amd as xo
+
+    rng = np.random.default_rng(44)
+    D, N = 5, 6000
+    t = torch.linspace(0.0, 40.0, N, dtype=torch.float64, device=dev)
+    n_tr = 12
+    mk = lambda v: torch.tensor(v * (1 + 1e-3 * rng.normal(size=(D, 1))), dtype=torch.float64, device=dev, requires_grad=True)  # noqa: E731
+    leaves = dict(period=mk(3.3), t0=mk(0.9), b=mk(0.3), r=mk(0.08))
+    ttvs = torch.tensor(0.01 * rng.normal(size=(D, n_tr)), dtype=torch.float64, device=dev, requires_grad=True)
+    y = torch.tensor(3e-4 * rng.normal(size=N), dtype=torch.float64, device=dev)
+    lc = xo.LimbDarkLightCurve(0.3, 0.2)
+
+    def orbit():
+        return xo.orbits.TTVOrbit(period=leaves["period"], t0=leaves["t0"], b=leaves["b"], ttvs=[ttvs])
+
+    sigma = 3e-4
+    ll = lc.white_noise_log_likelihood(orbit=orbit(), r=leaves["r"], t=t, y=y, yerr=sigma)
+    assert ll.shape == (D,)
+    model = lc.get_light_curve(orbit=orbit(), r=leaves["r"], t=t).sum(-1)
+    want = (-0.5 * ((y - model) / sigma) ** 2).sum(-1) - N * np.log(sigma * np.sqrt(2 * np.pi))
+    assert torch.allclose(ll, want, rtol=1e-11, atol=1e-7)
+    names = list(leaves) + ["ttvs"]
+    vals = list(leaves.values()) + [ttvs]
+    g1 = torch.autograd.grad(ll.sum(), vals)
+    g2 = torch.autograd.grad(want.sum(), vals)
+    for n, a, b in zip(names, g1, g2):
+        assert float(b.abs().max()) > 0, n
+        assert float((a - b).abs().max()) <= 1e-8 * float(b.abs().max()), n
