@@ -93,6 +93,11 @@ _SIGNATURES = {
     "exo_transit_chi2_ttv_vjp_f64": (ctypes.c_int, [_c_dp, _i64, _c_dp, _i64, _c_dp, _c_dp, _i32, _c_dp, _c_dp, _i64, _i32, _u32,
                                                     _c_dp, _c_dp, _i32, _c_dp, _c_dp, _i64, _c_dp, _c_dp, _c_dp, _c_dp, _c_dp,
                                                     _i64, _c_dp]),
+    # period, ds, ps, t0, ds, ps, ttv (host), ttv_ds (host), n_transit (host), n_draw, n_planet, n_edge, edges, shift, stream
+    "exo_ttv_tables_f64": (ctypes.c_int, [_c_dp, _i64, _i64, _c_dp, _i64, _i64, _c_dp, _c_dp, _c_dp, _i64, _i32, _i32, _c_dp,
+                                          _c_dp, _c_dp]),
+    "exo_ttv_tables_vjp_f64": (ctypes.c_int, [_c_dp, _i64, _i64, _c_dp, _i64, _i64, _c_dp, _c_dp, _c_dp, _i64, _i32, _i32, _c_dp,
+                                              _c_dp, _c_dp, _c_dp]),
     "exo_sho_coefficients_f64": (ctypes.c_int, [_c_dp, _c_dp, _c_dp, _u32, ctypes.c_double, _i64, _c_dp, _c_dp, _c_dp]),
     "exo_sho_coefficients_vjp_f64": (ctypes.c_int, [_c_dp, _c_dp, _c_dp, _u32, ctypes.c_double, _i64, _c_dp, _c_dp, _c_dp,
                                                     _c_dp, _c_dp]),

@@ -457,3 +457,136 @@ int exo_sho_coefficients_vjp_f64(const double* amp, const double* freq, const do
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------
+// Timing tables of a TTVOrbit whose transits are all labelled and given as offsets from the linear ephemeris
+// (reference: orbits/ttv.py:99-170 with `ttvs`): transit k of planet p of a draw happens at
+//     tt_k = t0 + period k + ttv_k,        k = 0 .. n_p - 1,
+// the bin edges are the midpoints between neighbours closed by half a period either side (ttv.py:158-166, padded
+// with +inf to a common width), and bin j belongs to transit max(0, min(j - 1, n_p - 1)) (ttv.py:167-170); the
+// kernels take shift = transit time of the bin - t0 = period k + ttv_k (include/exoplanet_amd.h).  In torch this
+// was ~25 small kernels forward and ~30 in the reverse pass per step; here one launch each way.
+// One thread per (draw, planet, bin).
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+struct TtvSrc {
+  const double* period; int64_t period_ds, period_ps;
+  const double* t0; int64_t t0_ds, t0_ps;
+  const double* ttv[EXO_MAX_PLANETS]; int64_t ttv_ds[EXO_MAX_PLANETS]; int32_t n[EXO_MAX_PLANETS];
+};
+struct TtvGradDst {
+  double* gttv[EXO_MAX_PLANETS];   // [n_draw][n_p] each, dense (NULL: not wanted)
+  double* gperiod;                 // [n_draw][n_planet] dense (NULL: not wanted)
+};
+
+__global__ __launch_bounds__(64) void ttv_tables_kernel(TtvSrc s, int64_t n_draw, int n_planet, int n_edge,
+                                                        double* __restrict__ edges, double* __restrict__ shift) {
+  const int64_t gid = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  const int per = n_edge + 1;                       // bins of one (draw, planet)
+  const int64_t rec = gid / per;
+  const int j = (int)(gid - rec * per);
+  if (rec >= n_draw * n_planet) return;
+  const int64_t d = rec / n_planet;
+  const int p = (int)(rec - d * n_planet);
+  const int n = s.n[p];
+  const double P = s.period[d * s.period_ds + p * s.period_ps], t0 = s.t0[d * s.t0_ds + p * s.t0_ps];
+  const double* __restrict__ ttv = s.ttv[p] + d * s.ttv_ds[p];
+  auto off = [&](int k) { return fma(P, (double)k, ttv[k]); };   // transit time - t0
+  const int k = j - 1 < 0 ? 0 : (j - 1 < n ? j - 1 : n - 1);    // the transit bin j belongs to
+  shift[rec * per + j] = off(k);
+  if (j < n_edge) {
+    double e;
+    if (j == 0) e = t0 + off(0) - 0.5 * P;
+    else if (j < n) e = 0.5 * ((t0 + off(j - 1)) + (t0 + off(j)));
+    else if (j == n) e = t0 + off(n - 1) + 0.5 * P;
+    else e = __builtin_inf();
+    edges[rec * n_edge + j] = e;
+  }
+}
+
+// reverse: the cotangent of shift back to the offsets and the periods (the edges carry none: searchsorted, ttv.py:174).
+// One thread per (draw, planet, transit); the thread of transit 0 also sums the period's.
+__global__ __launch_bounds__(64) void ttv_tables_vjp_kernel(TtvSrc s, int64_t n_draw, int n_planet, int n_edge, int width,
+                                                            const double* __restrict__ gshift, TtvGradDst dst) {
+  const int64_t gid = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  const int64_t rec = gid / width;
+  const int k = (int)(gid - rec * width);
+  if (rec >= n_draw * n_planet) return;
+  const int64_t d = rec / n_planet;
+  const int p = (int)(rec - d * n_planet);
+  const int n = s.n[p], per = n_edge + 1;
+  const double* __restrict__ g = gshift + rec * per;
+  auto gtt = [&](int q) {
+    double v = g[q + 1];
+    if (q == 0) v += g[0];
+    if (q == n - 1)
+      for (int j = n + 1; j < per; ++j) v += g[j];
+    return v;
+  };
+  if (k < n && dst.gttv[p]) dst.gttv[p][d * n + k] = gtt(k);
+  if (k == 0 && dst.gperiod) {
+    double acc = 0.0;
+    for (int q = 0; q < n; ++q) acc = fma((double)q, gtt(q), acc);
+    dst.gperiod[rec] = acc;
+  }
+}
+
+static bool ttv_src(const double* period, int64_t period_ds, int64_t period_ps, const double* t0, int64_t t0_ds, int64_t t0_ps,
+                    const double* const* ttv, const int64_t* ttv_ds, const int32_t* n_transit, int32_t n_planet,
+                    int32_t n_edge, TtvSrc* s) {
+  if (!period || !t0 || !ttv || !ttv_ds || !n_transit || n_planet < 1 || n_planet > EXO_MAX_PLANETS) return false;
+  s->period = period; s->period_ds = period_ds; s->period_ps = period_ps;
+  s->t0 = t0; s->t0_ds = t0_ds; s->t0_ps = t0_ps;
+  int width = 0;
+  for (int p = 0; p < n_planet; ++p) {
+    if (!ttv[p] || n_transit[p] < 1) return false;
+    s->ttv[p] = ttv[p]; s->ttv_ds[p] = ttv_ds[p]; s->n[p] = n_transit[p];
+    width = n_transit[p] > width ? n_transit[p] : width;
+  }
+  return n_edge == width + 1;
+}
+
+}  // namespace
+
+extern "C" {
+
+int exo_ttv_tables_f64(const double* period, int64_t period_draw_stride, int64_t period_planet_stride, const double* t0,
+                       int64_t t0_draw_stride, int64_t t0_planet_stride, const double* const* ttv,
+                       const int64_t* ttv_draw_stride, const int32_t* n_transit, int64_t n_draw, int32_t n_planet,
+                       int32_t n_edge, double* edges, double* shift, void* stream) {
+  if (n_draw < 0) return EXO_ERR_INVALID_ARGUMENT;
+  TtvSrc s;
+  if (!ttv_src(period, period_draw_stride, period_planet_stride, t0, t0_draw_stride, t0_planet_stride, ttv, ttv_draw_stride,
+               n_transit, n_planet, n_edge, &s))
+    return EXO_ERR_INVALID_ARGUMENT;
+  if (n_draw == 0) return EXO_OK;
+  if (!edges || !shift) return EXO_ERR_INVALID_ARGUMENT;
+  const int64_t n = n_draw * n_planet * (int64_t)(n_edge + 1);
+  hipLaunchKernelGGL(ttv_tables_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, (hipStream_t)stream, s, n_draw,
+                     (int)n_planet, (int)n_edge, edges, shift);
+  return launch_status();
+}
+
+int exo_ttv_tables_vjp_f64(const double* period, int64_t period_draw_stride, int64_t period_planet_stride, const double* t0,
+                           int64_t t0_draw_stride, int64_t t0_planet_stride, const double* const* ttv,
+                           const int64_t* ttv_draw_stride, const int32_t* n_transit, int64_t n_draw, int32_t n_planet,
+                           int32_t n_edge, const double* gshift, double* const* gttv, double* gperiod, void* stream) {
+  if (n_draw < 0) return EXO_ERR_INVALID_ARGUMENT;
+  TtvSrc s;
+  if (!ttv_src(period, period_draw_stride, period_planet_stride, t0, t0_draw_stride, t0_planet_stride, ttv, ttv_draw_stride,
+               n_transit, n_planet, n_edge, &s))
+    return EXO_ERR_INVALID_ARGUMENT;
+  if (n_draw == 0) return EXO_OK;
+  if (!gshift || !gttv) return EXO_ERR_INVALID_ARGUMENT;
+  TtvGradDst dst;
+  for (int p = 0; p < EXO_MAX_PLANETS; ++p) dst.gttv[p] = p < n_planet ? gttv[p] : nullptr;
+  dst.gperiod = gperiod;
+  const int width = n_edge - 1;
+  const int64_t n = n_draw * n_planet * (int64_t)width;
+  hipLaunchKernelGGL(ttv_tables_vjp_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, (hipStream_t)stream, s, n_draw,
+                     (int)n_planet, (int)n_edge, width, gshift, dst);
+  return launch_status();
+}
+
+}  // extern "C"

@@ -549,6 +549,77 @@ def transit_flux_sparse(t, params, ld, gflux=None, texp=None, stencil_dt=None, s
 
 
 # ------------------------------------------------------------------------------
+# timing tables of a TTVOrbit given O-C offsets
+# ------------------------------------------------------------------------------
+class _TtvTables(torch.autograd.Function):
+    """(edges, shift) of exo_ttv_tables_f64 from period (D|1, P), t0 (D|1, P) and one (D|1, n_p) tensor of offsets per
+    planet; differentiable in the offsets and the period (the edges carry no gradient, t0 none through the tables)"""
+
+    @staticmethod
+    def forward(ctx, period, t0, n_draw, *ttvs):
+        import ctypes
+
+        period, t0 = _dev(period.detach(), "period"), _dev(t0.detach(), "t0")
+        ttvs = [_dev(x.detach(), "ttvs") for x in ttvs]
+        P, D = len(ttvs), int(n_draw)
+        counts = [int(x.shape[-1]) for x in ttvs]
+        n_edge = max(counts) + 1
+        edges = torch.empty(D, P, n_edge, dtype=torch.float64, device=period.device)
+        shift = torch.empty(D, P, n_edge + 1, dtype=torch.float64, device=period.device)
+        args = _TtvTables._args(period, t0, ttvs, counts)
+        lib = _lib.load()
+        with torch.cuda.device(period.device):
+            _lib.check(lib.exo_ttv_tables_f64(*args, D, P, n_edge, _ptr(edges), _ptr(shift), _stream(period)), "exo_ttv_tables_f64")
+        ctx.save_for_backward(period, t0, *ttvs)
+        ctx.meta = (D, P, n_edge, counts)
+        ctx.mark_non_differentiable(edges)
+        return edges, shift
+
+    @staticmethod
+    def _args(period, t0, ttvs, counts):
+        import ctypes
+
+        def strides(x):      # (rows, P) -> element strides of (draw, planet); one row: broadcast over draws
+            return (x.stride(0) if x.shape[0] > 1 else 0, x.stride(1) if x.shape[1] > 1 else 0)
+
+        P = len(ttvs)
+        tp = (ctypes.c_void_p * P)(*[x.data_ptr() for x in ttvs])
+        td = (ctypes.c_int64 * P)(*[(x.stride(0) if x.shape[0] > 1 else 0) for x in ttvs])
+        tn = (ctypes.c_int32 * P)(*counts)
+        return (_ptr(period), *strides(period), _ptr(t0), *strides(t0), tp, td, tn)
+
+    @staticmethod
+    def backward(ctx, _gedges, gshift):
+        import ctypes
+
+        period, t0, *ttvs = ctx.saved_tensors
+        D, P, n_edge, counts = ctx.meta
+        if gshift is None:
+            return (None,) * (3 + P)
+        gshift = _dev(gshift, "gshift")
+        need_p = ctx.needs_input_grad[0]
+        gper = torch.empty(D, P, dtype=torch.float64, device=gshift.device) if need_p else None
+        gt = [torch.empty(D, n, dtype=torch.float64, device=gshift.device) if ctx.needs_input_grad[3 + p] else None
+              for p, n in enumerate(counts)]
+        gp = (ctypes.c_void_p * P)(*[_ptr(x) for x in gt])
+        lib = _lib.load()
+        with torch.cuda.device(gshift.device):
+            _lib.check(lib.exo_ttv_tables_vjp_f64(*_TtvTables._args(period, t0, ttvs, counts), D, P, n_edge, _ptr(gshift), gp,
+                                                  _ptr(gper), _stream(gshift)), "exo_ttv_tables_vjp_f64")
+        if gper is not None:
+            gper = gper.sum_to_size(period.shape)
+        gt = [None if g is None else g.sum_to_size(x.shape) for g, x in zip(gt, ttvs)]
+        return (gper, None, None, *gt)
+
+
+def ttv_tables(period, t0, ttvs, n_draw):
+    """Timing tables ``(edges (D, P, E), shift (D, P, E + 1))`` of a TTVOrbit whose transits are all labelled and given as
+    offsets from the linear ephemeris: ``period``, ``t0`` (1 | D, P), ``ttvs`` a list of (1 | D, n_p) tensors.  One
+    launch each way (exo_ttv_tables_f64); differentiable in ``ttvs`` and ``period``."""
+    return _TtvTables.apply(period, t0, int(n_draw), *ttvs)
+
+
+# ------------------------------------------------------------------------------
 # radial velocity
 # ------------------------------------------------------------------------------
 RV_NPAR = 6

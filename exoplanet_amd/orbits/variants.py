@@ -114,6 +114,7 @@ class TTVOrbit(KeplerianOrbit):
             self._inds = host
             self._counts = [int(h.max()) + 1 for h in host]
             self.transit_inds = [_device_index(h, dev) for h in host]
+        self._given = "ttvs" if ttvs is not None else "transit_times"
         if ttvs is not None:
             self.ttvs = given
         else:
@@ -134,6 +135,23 @@ class TTVOrbit(KeplerianOrbit):
         t0, period = self._ephemeris()
         if ttvs is not None:
             self.ttv_period = period
+        # transit_times (with `ttvs`), all_transit_times and the lookup table are built on first use (__getattr__): a
+        # fused light-curve call of the common case -- offsets for every transit -- never needs them (kernel_ttv)
+        self._tables_ready = False
+
+    _TABLE_ATTRS = ("transit_times", "all_transit_times", "_table")
+
+    def __getattr__(self, name):
+        if name in TTVOrbit._TABLE_ATTRS and not self.__dict__.get("_tables_ready", True):
+            self._build_tables()
+            return self.__dict__[name]
+        return super().__getattr__(name)
+
+    def _build_tables(self):
+        self._tables_ready = True
+        dev = self.ttvs[0].device
+        t0, period = self._ephemeris()
+        if "transit_times" not in self.__dict__:
             self.transit_times = [t0[..., p:p + 1] + period[..., p:p + 1] * ix + dv
                                   for p, (ix, dv) in enumerate(zip(self.transit_inds, self.ttvs))]
         # fill unobserved transit numbers with the linear ephemeris (ttv.py:141-147)
@@ -177,10 +195,37 @@ class TTVOrbit(KeplerianOrbit):
         per_planet = t.unsqueeze(0).expand((P,) + tuple(t.shape)) if _pad else t.movedim(-1, 0)
         return (per_planet - self._table.nearest(per_planet)).movedim(0, -1)
 
+    def _fused_tables(self):
+        """the common case -- offsets `ttvs` for every transit, at most one draw dimension, ROCm tensors -- in one launch
+        (ops.ttv_tables: exo_ttv_tables_f64) instead of the torch construction; None when it does not apply"""
+        from .. import ops
+
+        if self._given != "ttvs" or any(h is not None for h in self._inds):
+            return None
+        t0, period = self._ephemeris()
+        parts = list(self.ttvs) + [t0, period]
+        if not all(isinstance(x, torch.Tensor) and x.is_cuda and x.dtype == torch.float64 for x in parts):
+            return None
+        if any(x.dim() > 2 for x in parts):
+            return None
+        as2 = lambda x: x if x.dim() == 2 else x.unsqueeze(0)  # noqa: E731
+        rows = [as2(x) for x in parts]
+        D = max(x.shape[0] for x in rows)
+        if any(x.shape[0] not in (1, D) for x in rows):
+            return None
+        P = len(self.ttvs)
+        per, ref = rows[-1].expand(-1, P) if rows[-1].shape[1] == 1 else rows[-1], rows[-2].expand(-1, P) if rows[-2].shape[1] == 1 else rows[-2]
+        edges, shift = ops.ttv_tables(per, ref, rows[:P], D)
+        batched = any(x.dim() == 2 for x in parts)
+        return (edges, shift) if batched else (edges[0], shift[0])
+
     def kernel_ttv(self):
         """the fused kernels' timing tables (include/exoplanet_amd.h): bin edges ``batch + (P, E)``
         (no gradient, like the reference's searchsorted) and per-bin shifts ``batch + (P, E + 1)``
         = transit time of the bin - t0, differentiable"""
+        fused = self._fused_tables()
+        if fused is not None:
+            return fused
         centres = self._table.centres
         t0, _ = self._ephemeris()
         shape = torch.broadcast_shapes(centres.shape[:-1], t0.shape)

@@ -480,6 +480,25 @@ int exo_pack_records_cols_vjp_f64(const double* const* cols, const int64_t* draw
                                   const double* gld, const double* gscale, double* const* gcols,
                                   double* const* gld_cols, void* stream);
 
+/* Timing tables of a TTVOrbit whose transits are all labelled and given as offsets `ttvs` from the linear ephemeris
+ * (orbits/ttv.py:99-170): transit k of planet p of a draw at tt_k = t0 + period k + ttv_k, k < n_transit[p];
+ *   edges [n_draw][n_planet][n_edge]      tt_0 - period/2, midpoints of neighbours, tt_last + period/2, then +inf
+ *                                         (ttv.py:158-166); n_edge = max_p n_transit[p] + 1
+ *   shift [n_draw][n_planet][n_edge + 1]  bin j -> transit max(0, min(j - 1, n - 1)) (ttv.py:167-170): period k + ttv_k
+ * -- the tables the exo_transit_*_ttv_* entry points take.  period, t0: device arrays read at
+ * [draw * draw_stride + planet * planet_stride] (strides in elements, 0 = broadcast); ttv, ttv_draw_stride, n_transit:
+ * HOST arrays [n_planet] of device pointers (row of a draw: n_transit[p] contiguous doubles), draw strides, counts.
+ * Reverse: gshift -> gttv[p] [n_draw][n_transit[p]] and gperiod [n_draw][n_planet], dense, either may be NULL (per
+ * planet for gttv); the edges carry no gradient (searchsorted, ttv.py:174) and t0 none through the tables.       */
+int exo_ttv_tables_f64(const double* period, int64_t period_draw_stride, int64_t period_planet_stride, const double* t0,
+                       int64_t t0_draw_stride, int64_t t0_planet_stride, const double* const* ttv,
+                       const int64_t* ttv_draw_stride, const int32_t* n_transit, int64_t n_draw, int32_t n_planet,
+                       int32_t n_edge, double* edges, double* shift, void* stream);
+int exo_ttv_tables_vjp_f64(const double* period, int64_t period_draw_stride, int64_t period_planet_stride, const double* t0,
+                           int64_t t0_draw_stride, int64_t t0_planet_stride, const double* const* ttv,
+                           const int64_t* ttv_draw_stride, const int32_t* n_transit, int64_t n_draw, int32_t n_planet,
+                           int32_t n_edge, const double* gshift, double* const* gttv, double* gperiod, void* stream);
+
 /* ---------------------------------------------------------------------------
  * celerite2's SHOTerm -> the pair slot of the GP entry points above (one slot per term and draw, two state indices):
  * the term's parameters in any of celerite2's parameterisations -- amplitude S0 or (EXO_SHO_SIGMA) sigma, frequency w0

@@ -453,3 +453,53 @@ def test_sparse_output_with_timing_tables(dev):
         assert 0 < sp.n_solved() < 0.2 * D * 12001 * 2
     with pytest.raises(ValueError):
         ops.transit_flux_sparse(t, T(rec, dev), c, ttv=ttv, flags=ops.FLAG_SECONDARY)
+
+
+@pytest.mark.parametrize("batched", [True, False])
+def test_fused_table_construction_equals_the_torch_construction(dev, batched):
+    """TTVOrbit.kernel_ttv: offsets for every transit go through exo_ttv_tables_f64 (one launch each way); the same
+    tables and the same gradients (offsets, period) as the torch construction of ttv.py:99-170"""
+    import exoplanet_amd as xo
+
+    rng = np.random.default_rng(71)
+    D = 5
+    shape = (D, 1) if batched else ()
+    mk = lambda v, s: torch.tensor(v * (1 + 1e-3 * rng.normal(size=s)), dtype=torch.float64, device=dev, requires_grad=True)  # noqa: E731
+    period = mk(np.array([3.3, 7.1]), (D, 2) if batched else (2,))
+    t0 = mk(np.array([0.9, 2.2]), (2,))                       # shared by the draws
+    b = torch.tensor([0.3, 0.1], dtype=torch.float64, device=dev)
+    ttvs = [torch.tensor(0.01 * rng.normal(size=((D, n) if batched else (n,))), dtype=torch.float64, device=dev, requires_grad=True)
+            for n in (12, 5)]
+    wgt_e = wgt_s = None
+    out = {}
+    for fused in (True, False):
+        orb = xo.orbits.TTVOrbit(period=period, t0=t0, b=b, ttvs=ttvs)
+        if not fused:
+            orb._fused_tables = lambda: None
+        edges, shift = orb.kernel_ttv()
+        if wgt_s is None:
+            wgt_s = torch.tensor(rng.normal(size=tuple(shift.shape)), dtype=torch.float64, device=dev)
+        grads = torch.autograd.grad((shift * wgt_s).sum(), [period] + ttvs, allow_unused=True)
+        out[fused] = (edges.detach(), shift.detach(), grads)
+        assert not edges.requires_grad
+    (e1, s1, g1), (e0, s0, g0) = out[True], out[False]
+    assert e1.shape == e0.shape and s1.shape == s0.shape
+    assert torch.equal(torch.isinf(e1), torch.isinf(e0))
+    fin = torch.isfinite(e0)
+    assert float((e1[fin] - e0[fin]).abs().max()) <= 1e-13 * 100.0
+    assert float((s1 - s0).abs().max()) <= 1e-13 * 100.0
+    for a, b_ in zip(g1, g0):
+        assert a.shape == b_.shape
+        assert float((a - b_).abs().max()) <= 1e-12 * float(b_.abs().max())
+    # and the light curve through both: the same flux
+    t = torch.linspace(0.0, 38.0, 4000, dtype=torch.float64, device=dev)
+    lcs = []
+    for fused in (True, False):
+        orb = xo.orbits.TTVOrbit(period=period, t0=t0, b=b, ttvs=ttvs)
+        if not fused:
+            orb._fused_tables = lambda: None
+        lcs.append(xo.LimbDarkLightCurve(0.3, 0.2).get_light_curve(orbit=orb, r=torch.tensor([0.08, 0.05], dtype=torch.float64, device=dev), t=t))
+    assert float(lcs[0].min()) < -1e-3 and float((lcs[0] - lcs[1]).abs().max()) <= 1e-12
+    # the public attributes are still there, built on first use
+    orb = xo.orbits.TTVOrbit(period=period, t0=t0, b=b, ttvs=ttvs)
+    assert len(orb.transit_times) == 2 and orb.all_transit_times[0].shape[-1] == 12
