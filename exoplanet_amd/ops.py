@@ -922,6 +922,100 @@ def orbit_flux_dot(t, gflux, orbit_cols, ld_cols, flags=0, pack_flags=0, texp=No
     return out
 
 
+class _PackCols(torch.autograd.Function):
+    """exo_pack_records_cols_f64 on its own: every constructor argument its own tensor (shape (), (P,), (D, 1) or
+    (D, P); None = the constructor default), limb-darkening coefficients () or (D,) -> records (D, P, 20), ld (D, 3|6).
+    No stacking pass forward, one packing-VJP launch in the reverse pass (the composition stack -> pack_records costs
+    a concatenation each way plus a slice and a reduction per broadcast column)."""
+
+    @staticmethod
+    def forward(ctx, pack_flags, n_ld, n_draw, *cols):
+        import ctypes
+
+        ocols, lcols = list(cols[:NIN]), list(cols[NIN:NIN + n_ld])
+        ref = next(c for c in ocols + lcols if c is not None)
+        D, P = int(n_draw), 1
+        for c in ocols:
+            if c is not None:
+                if c.dim() > 2:
+                    raise ValueError("orbit parameters may carry at most one draw dimension here")
+                P = max(P, c.shape[-1] if c.dim() >= 1 else 1)
+        vp, i64 = ctypes.c_void_p, ctypes.c_int64
+        cp, ds, ps, df = (vp * NIN)(), (i64 * NIN)(), (i64 * NIN)(), (ctypes.c_double * NIN)(*_PACK_DEFAULTS)
+        keep = []
+        for k, c in enumerate(ocols):
+            if c is None:
+                continue
+            c = _dev(c.detach(), "orbit parameter")
+            v = c.reshape(1, 1) if c.dim() == 0 else (c.unsqueeze(0) if c.dim() == 1 else c)
+            v = v.expand(D, P)
+            keep.append(v)
+            cp[k], ds[k], ps[k] = v.data_ptr(), v.stride(0), v.stride(1)
+        lp, ls = (vp * 4)(), (i64 * 4)()
+        for k, c in enumerate(lcols):
+            c = _dev(c.detach(), "limb-darkening coefficient")
+            v = (c.reshape(1) if c.dim() == 0 else c).expand(D)
+            keep.append(v)
+            lp[k], ls[k] = v.data_ptr(), v.stride(0)
+        nset = n_ld // 2
+        params = torch.empty(D, P, NPAR, dtype=torch.float64, device=ref.device)
+        ld = torch.empty(D, 3 * nset, dtype=torch.float64, device=ref.device)
+        lib = _lib.load()
+        with torch.cuda.device(ref.device):
+            _lib.check(lib.exo_pack_records_cols_f64(cp, ds, ps, df, lp, ls, D, P, pack_flags, _ptr(params), _ptr(ld),
+                                                     _stream(params)), "exo_pack_records_cols_f64")
+        ctx.save_for_backward(*keep)
+        ctx.meta = (D, P, pack_flags, n_ld, [c is not None for c in ocols], [None if c is None else tuple(c.shape) for c in cols])
+        return params, ld
+
+    @staticmethod
+    def backward(ctx, gparams, gld):
+        import ctypes
+
+        D, P, pack_flags, n_ld, present, shapes = ctx.meta
+        nfix = 3
+        keep = ctx.saved_tensors
+        dev = keep[0].device
+        gparams = torch.zeros(D, P, NPAR, dtype=torch.float64, device=dev) if gparams is None else _dev(gparams, "gparams")
+        gld = torch.zeros(D, 3 * (n_ld // 2), dtype=torch.float64, device=dev) if gld is None else _dev(gld, "gld")
+        vp, i64 = ctypes.c_void_p, ctypes.c_int64
+        cp, ds, ps, df = (vp * NIN)(), (i64 * NIN)(), (i64 * NIN)(), (ctypes.c_double * NIN)(*_PACK_DEFAULTS)
+        it = iter(keep)
+        for k in range(NIN):
+            if present[k]:
+                v = next(it)
+                cp[k], ds[k], ps[k] = v.data_ptr(), v.stride(0), v.stride(1)
+        lp, ls = (vp * 4)(), (i64 * 4)()
+        for k in range(n_ld):
+            v = next(it)
+            lp[k], ls[k] = v.data_ptr(), v.stride(0)
+        gcp, glp = (vp * NIN)(), (vp * 4)()
+        outs = [None] * len(shapes)
+        for k in range(NIN):
+            if present[k] and ctx.needs_input_grad[nfix + k]:
+                outs[k] = torch.empty(D, P, dtype=torch.float64, device=dev)
+                gcp[k] = outs[k].data_ptr()
+        for k in range(n_ld):
+            if ctx.needs_input_grad[nfix + NIN + k]:
+                outs[NIN + k] = torch.empty(D, dtype=torch.float64, device=dev)
+                glp[k] = outs[NIN + k].data_ptr()
+        lib = _lib.load()
+        with torch.cuda.device(dev):
+            _lib.check(lib.exo_pack_records_cols_vjp_f64(cp, ds, ps, df, lp, ls, D, P, pack_flags, _ptr(gparams), _ptr(gld),
+                                                         0, gcp, glp, _stream(gparams)), "exo_pack_records_cols_vjp_f64")
+        grads = [None if g is None else (g.reshape(shp) if g.numel() == _numel(shp) else g.sum_to_size(_bshape(shp, g.dim())).reshape(shp))
+                 for g, shp in zip(outs, shapes)]
+        return (None,) * nfix + tuple(grads)
+
+
+def pack_records_cols(orbit_cols, ld_cols, n_draw, pack_flags=0):
+    """:func:`pack_records` without the stacking: ``orbit_cols`` are the EXO_IN_* inputs (period, t0, b, ecc, omega, r,
+    m_star, r_star, m_planet, sbr), each a tensor of shape (), (P,), (D, 1) or (D, P) -- or None for the constructor
+    default -- and ``ld_cols`` (u1, u2[, u1s, u2s]) of shape () or (D,).  Returns records (D, P, 20) and ld (D, 3|6),
+    differentiable w.r.t. every column (one launch each way)."""
+    return _PackCols.apply(int(pack_flags), len(ld_cols), int(n_draw), *orbit_cols, *ld_cols)
+
+
 def pack_records(orbit_in, ld_in, flags=0):
     """(period, t0, b, ecc, omega, r, m_star, r_star, m_planet, sbr) per (draw, planet) and
     (u1, u2[, u1s, u2s]) per draw -> kernel records (n_draw, n_planet, 20) and Green's-basis

@@ -560,6 +560,10 @@ class KeplerianOrbit:
             like = next((x for x in list(A.values()) + [r] if isinstance(x, torch.Tensor)), None)
             V = lambda x, default: _vec(default if x is None else x, like)  # noqa: E731
             circular = A["ecc"] is None
+            pack_flags = (flags & ~ops.FLAG_LIGHT_DELAY) | (ops.PACK_CIRCULAR if circular else 0)
+            fast = self._kernel_inputs_cols(r, u, secondary, pack_flags, like)
+            if fast is not None:
+                return fast + (flags,)
             # the surface-brightness ratio is a per-light-curve scalar (like u): a 1-D value is per draw
             sbr = as_tensor(secondary[1] if secondary is not None else 0.0, like)
             sbr = sbr.unsqueeze(-1) if sbr.dim() >= 1 else sbr.reshape(1)
@@ -596,6 +600,33 @@ class KeplerianOrbit:
             D = c.shape[0]
         ld = c.to(rec.device).expand(batch + (c.shape[-1],)).reshape(D, c.shape[-1])
         return rec.contiguous(), ld.contiguous(), batch, flags
+
+    def _kernel_inputs_cols(self, r, u, secondary, pack_flags, like):
+        """kernel_inputs of the standard parameterisation with at most one draw dimension on ROCm tensors: the
+        constructor arguments go to the packing kernel as they are (ops.pack_records_cols: no stacking, one launch each
+        way); None when that form does not apply"""
+        A = self._args
+        opt = lambda x: None if x is None else _vec(x, like)  # noqa: E731
+        sbr = None
+        if secondary is not None:
+            sbr = as_tensor(secondary[1], like)
+            sbr = sbr.unsqueeze(-1) if sbr.dim() >= 1 else sbr.reshape(1)
+        cols = [opt(A["period"]), opt(A["t0"]), opt(A["b"]), opt(A["ecc"]), opt(A["omega"]), opt(r), opt(A["m_star"]),
+                opt(A["r_star"]), opt(A["m_planet"]), sbr]
+        us = [as_tensor(x, like) for x in list(u) + (list(secondary[0]) if secondary is not None else [])]
+        every = [c for c in cols if c is not None] + us
+        if not all(x.is_cuda and x.dtype == torch.float64 for x in every):
+            return None
+        if any(c.dim() > 2 for c in cols if c is not None) or any(x.dim() > 1 for x in us):
+            return None
+        draws = {c.shape[0] for c in cols if c is not None and c.dim() == 2} | {x.shape[0] for x in us if x.dim() == 1}
+        draws.discard(1)
+        if len(draws) > 1:
+            return None
+        batched = any(c.dim() == 2 for c in cols if c is not None) or any(x.dim() == 1 for x in us)
+        D = draws.pop() if draws else 1
+        rec, ld = ops.pack_records_cols(cols, us, D, pack_flags)
+        return rec, ld, ((D,) if batched else ())
 
     def flux_dot(self, r, u, t, weights, use_in_transit=False, secondary=None, light_delay=False, texp=None,
                  stencil=None, sparse=False, events=(None, None)):

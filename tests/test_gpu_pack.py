@@ -88,3 +88,34 @@ def test_light_curve_through_both_paths(dev):
                                                              use_in_transit=False)
         np.testing.assert_allclose(a.cpu().numpy(), want, rtol=0, atol=1e-13)
         np.testing.assert_allclose(b.cpu().numpy(), want, rtol=0, atol=1e-13)
+
+
+def test_column_form_equals_the_stacked_form_for_mixed_shapes(dev):
+    """ops.pack_records_cols: columns of shape (), (P,), (D, 1), (D, P), defaults left out, limb darkening () or (D,):
+    the records and every gradient of pack_records on the stacked, broadcast inputs"""
+    from exoplanet_amd import ops
+
+    rng = np.random.default_rng(13)
+    D, Pn = 4, 3
+    mk = lambda v, shape: torch.tensor(np.asarray(v) * (1 + 0.02 * rng.normal(size=shape)), dtype=torch.float64, device=dev,  # noqa: E731
+                                       requires_grad=True)
+    cols = dict(period=mk([3.5, 8.1, 12.3], (Pn,)), t0=mk(1.0, ()), b=mk(0.3, (D, 1)), ecc=mk([0.1, 0.2, 0.3], (D, Pn)),
+                omega=mk([1.1, -0.7, 0.2], (Pn,)), r=mk([0.1, 0.06, 0.04], (D, Pn)), m_star=None, r_star=mk(0.9, ()),
+                m_planet=None, sbr=None)
+    u1, u2 = mk(0.3, ()), mk(0.2, (D,))
+    rec, ld = ops.pack_records_cols(list(cols.values()), [u1, u2], D)
+    defaults = dict(m_star=1.0, m_planet=0.0, sbr=0.0)
+    full = [(torch.full((), defaults[k], dtype=torch.float64, device=dev) if v is None else v) for k, v in cols.items()]
+    full = [x.reshape((1,) * (2 - x.dim()) + tuple(x.shape)).expand(D, Pn) for x in full]
+    orbit_in = torch.stack(full, dim=-1).contiguous()
+    ld_in = torch.stack([u1.expand(D), u2], dim=-1).contiguous()
+    rec2, ld2 = ops.pack_records(orbit_in, ld_in, 0)
+    assert rec.shape == (D, Pn, ops.NPAR) and torch.equal(rec, rec2) and torch.equal(ld, ld2)
+    wr, wl = torch.randn_like(rec), torch.randn_like(ld)
+    wr[~torch.isfinite(rec)] = 0.0
+    leaves_ = [v for v in cols.values() if v is not None] + [u1, u2]
+    g1 = torch.autograd.grad((torch.nan_to_num(rec, posinf=0.0, neginf=0.0) * wr).sum() + (ld * wl).sum(), leaves_, allow_unused=True)
+    g2 = torch.autograd.grad((torch.nan_to_num(rec2, posinf=0.0, neginf=0.0) * wr).sum() + (ld2 * wl).sum(), leaves_, allow_unused=True)
+    for x, a, b in zip(leaves_, g1, g2):
+        assert a.shape == x.shape
+        assert float((a - b).abs().max()) <= 1e-12 * max(float(b.abs().max()), 1e-30)
