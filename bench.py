@@ -522,7 +522,7 @@ def extra_hmc(xo, ops, dev, D=1024, n_leapfrog=8, dense=False, nuts=False):
     if nuts:
         # (unit masses and a step size far below the posterior's scales: every tree grows to the depth limit, i.e. the
         # leg times 2**4 - 1 = 15 leaves per transition and the tree bookkeeping around them, not a tuned sampler)
-        smp = xo.NUTS(logp, params, step_size=1e-9, max_depth=4, generator=torch.Generator(device=dev).manual_seed(12))
+        smp = xo.NUTS(logp, params, step_size=1e-11, max_depth=4, generator=torch.Generator(device=dev).manual_seed(12))
         for _ in range(2):
             smp.step()
         torch.cuda.synchronize(dev)
