@@ -506,30 +506,32 @@ __global__ __launch_bounds__(64) void ttv_tables_kernel(TtvSrc s, int64_t n_draw
 }
 
 // reverse: the cotangent of shift back to the offsets and the periods (the edges carry none: searchsorted, ttv.py:174).
-// One thread per (draw, planet, transit); the thread of transit 0 also sums the period's.
-__global__ __launch_bounds__(64) void ttv_tables_vjp_kernel(TtvSrc s, int64_t n_draw, int n_planet, int n_edge, int width,
+// One wave per (draw, planet): a lane per transit (strided), the period's sum over the wave in a fixed order.
+__global__ __launch_bounds__(64) void ttv_tables_vjp_kernel(TtvSrc s, int64_t n_draw, int n_planet, int n_edge,
                                                             const double* __restrict__ gshift, TtvGradDst dst) {
-  const int64_t gid = (int64_t)blockIdx.x * 64 + threadIdx.x;
-  const int64_t rec = gid / width;
-  const int k = (int)(gid - rec * width);
-  if (rec >= n_draw * n_planet) return;
+  const int64_t rec = blockIdx.x;
+  const int lane = threadIdx.x;
   const int64_t d = rec / n_planet;
   const int p = (int)(rec - d * n_planet);
   const int n = s.n[p], per = n_edge + 1;
   const double* __restrict__ g = gshift + rec * per;
-  auto gtt = [&](int q) {
-    double v = g[q + 1];
-    if (q == 0) v += g[0];
-    if (q == n - 1)
-      for (int j = n + 1; j < per; ++j) v += g[j];
-    return v;
-  };
-  if (k < n && dst.gttv[p]) dst.gttv[p][d * n + k] = gtt(k);
-  if (k == 0 && dst.gperiod) {
-    double acc = 0.0;
-    for (int q = 0; q < n; ++q) acc = fma((double)q, gtt(q), acc);
-    dst.gperiod[rec] = acc;
+  // the bins past the last transit belong to it: their sum, lanes strided, combined below
+  double tail = 0.0;
+  for (int j = n + 1 + lane; j < per; j += 64) tail += g[j];
+  double acc = 0.0;
+  for (int k = lane; k < n; k += 64) {
+    double v = g[k + 1];
+    if (k == 0) v += g[0];
+    if (dst.gttv[p]) dst.gttv[p][d * n + k] = v;       // (transit n - 1 gets the tail added by its lane below)
+    acc = fma((double)k, v, acc);
   }
+#pragma unroll
+  for (int m = 32; m > 0; m >>= 1) {
+    tail += __shfl_xor(tail, m, 64);
+    acc += __shfl_xor(acc, m, 64);
+  }
+  if (lane == (n - 1) % 64 && dst.gttv[p]) dst.gttv[p][d * n + (n - 1)] += tail;
+  if (lane == 0 && dst.gperiod) dst.gperiod[rec] = fma((double)(n - 1), tail, acc);
 }
 
 static bool ttv_src(const double* period, int64_t period_ds, int64_t period_ps, const double* t0, int64_t t0_ds, int64_t t0_ps,
@@ -582,10 +584,8 @@ int exo_ttv_tables_vjp_f64(const double* period, int64_t period_draw_stride, int
   TtvGradDst dst;
   for (int p = 0; p < EXO_MAX_PLANETS; ++p) dst.gttv[p] = p < n_planet ? gttv[p] : nullptr;
   dst.gperiod = gperiod;
-  const int width = n_edge - 1;
-  const int64_t n = n_draw * n_planet * (int64_t)width;
-  hipLaunchKernelGGL(ttv_tables_vjp_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, (hipStream_t)stream, s, n_draw,
-                     (int)n_planet, (int)n_edge, width, gshift, dst);
+  hipLaunchKernelGGL(ttv_tables_vjp_kernel, dim3((unsigned)(n_draw * n_planet)), dim3(64), 0, (hipStream_t)stream, s, n_draw,
+                     (int)n_planet, (int)n_edge, gshift, dst);
   return launch_status();
 }
 
