@@ -264,13 +264,14 @@ class NUTS(_ChainSampler):
         w1 = lambda m, a, b: torch.where(m.unsqueeze(1), a, b)  # noqa: E731
         p0 = torch.randn(q0.shape, dtype=q0.dtype, device=q0.device, generator=self.generator) * torch.sqrt(self._mflat)
         H0 = -lp0 + kin(p0)
-        H0 = torch.where(torch.isfinite(H0), H0, torch.full_like(H0, float("inf")))
+        valid = torch.isfinite(H0)                         # a chain outside the support (or at a NaN) stays where it is
+        H0 = torch.where(valid, H0, torch.zeros_like(H0))
         ql, pl, gl = q0, p0, g0                            # the trajectory's ends
         qr, pr, gr = q0, p0, g0
         p_sum = p0
         log_w = torch.zeros_like(H0)                       # log of the tree's total weight, relative to exp(-H0)
         prop_q, prop_lp, prop_g = q0, lp0, g0
-        active = torch.ones(self.D, dtype=torch.bool, device=H0.device)
+        active = valid
         depth = torch.zeros_like(H0)
         diverged = torch.zeros_like(active)
         acc_sum, acc_n = torch.zeros_like(H0), torch.zeros_like(H0)

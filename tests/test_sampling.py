@@ -166,3 +166,20 @@ def test_nuts_walls_divergences_and_depth_limit():
     for _ in range(5):
         a.step(); b.step()
     assert torch.equal(a.params[0], b.params[0])
+
+
+def test_nuts_chain_outside_the_support_stays_put():
+    D = 6
+
+    def logp(x):
+        lp = -0.5 * x[:, 0] ** 2
+        return torch.where(x[:, 0] > 2.0, torch.full_like(lp, -float("inf")), lp)
+
+    x = torch.zeros(D, 1, dtype=torch.float64)
+    x[0, 0] = 5.0                                # outside: log-density -inf from the start
+    nuts = NUTS(logp, [x], step_size=0.5, max_depth=4, generator=torch.Generator().manual_seed(2))
+    for _ in range(10):
+        d = nuts.step()
+        assert float(nuts.params[0][0, 0]) == 5.0 and float(d[0]) == 0
+        assert bool(torch.isfinite(nuts.params[0]).all()) and bool((nuts.params[0][1:, 0] <= 2.0).all())
+    assert float(nuts.params[0][1:].abs().max()) > 0       # the others move
