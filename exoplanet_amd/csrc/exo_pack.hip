@@ -590,3 +590,138 @@ int exo_ttv_tables_vjp_f64(const double* period, int64_t period_draw_stride, int
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------
+// NUTS, one leaf of the sub-tree a batch of chains is building (exoplanet_amd/sampling.py, NUTS._leaf_update restated:
+// that torch version is what runs on the CPU and what tests/test_gpu_sampling.py checks this against).  The tree state
+// lives in (chains, parameters) arrays on the device; per leaf the torch version is ~35 small launches, here two:
+//   begin:  half kick and drift of the moving end            p_half = p + eps g / 2,  q' = q + eps p_half / m
+//   update: second half kick with the gradient at q', energy error, divergence, multinomial candidate, momentum sums,
+//           checkpoint write (even leaves) / turning checks (odd leaves), which chains go on.
+// One thread per chain (a chain's row is a few to a few dozen doubles).
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+struct NutsLeaf {
+  double *qe, *pe, *ge;              // [D][n]   the moving end of the sub-tree
+  const double* eps;                 // [D]      signed step size
+  uint8_t* on;                       // [D]      still adding leaves (torch.bool)
+  const double* H0;                  // [D]
+  double *logw, *psum, *sq, *sg, *slp;
+  uint8_t *turn, *div;
+  double *acc, *accn;
+  double *ckp, *cks;                 // [S][D][n] checkpoints: momentum of a sub-sub-tree's first leaf, momentum sum up to it
+  const double* u;                   // [D]      uniform random numbers of this leaf
+  const uint8_t *wsel, *csel;        // [S]      slot written (even leaf) / slots checked (odd leaf)
+  const double* mass;                // [D][n]
+  double *qn, *ph;                   // [D][n]   scratch: position and half-kicked momentum of the new leaf
+  const double *gn, *lpn;            // [D][n], [D]  gradient and log-density at qn
+  int64_t D;
+  int n, S;
+  double max_energy_error;
+};
+
+__global__ __launch_bounds__(64) void nuts_leaf_begin_kernel(NutsLeaf a) {
+  const int64_t d = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  if (d >= a.D) return;
+  const double e = a.eps[d];
+  for (int i = 0; i < a.n; ++i) {
+    const int64_t k = d * a.n + i;
+    const double ph = fma(0.5 * e, a.ge[k], a.pe[k]);
+    a.ph[k] = ph;
+    a.qn[k] = fma(e, ph / a.mass[k], a.qe[k]);
+  }
+}
+
+__device__ __forceinline__ double log_add_exp(double x, double y) {
+  const double m = fmax(x, y);
+  if (!(m > -__builtin_inf())) return m;       // both -inf (or NaN)
+  return m + log1p(exp(-fabs(x - y)));
+}
+
+__global__ __launch_bounds__(64) void nuts_leaf_update_kernel(NutsLeaf a) {
+  const int64_t d = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  if (d >= a.D || !a.on[d]) return;              // (a chain that has stopped carries its state along unchanged)
+  const int n = a.n;
+  const int64_t row = d * n, plane = a.D * (int64_t)n;
+  const double e = a.eps[d];
+  double kin = 0.0;
+  for (int i = 0; i < n; ++i) {
+    const double pn = fma(0.5 * e, a.gn[row + i], a.ph[row + i]);
+    kin += 0.5 * pn * pn / a.mass[row + i];
+    a.pe[row + i] = pn;
+    a.qe[row + i] = a.qn[row + i];
+    a.ge[row + i] = a.gn[row + i];
+  }
+  const double lp = a.lpn[d];
+  double dH = -lp + kin - a.H0[d];
+  if (dH != dH) dH = __builtin_inf();
+  const bool div = dH > a.max_energy_error;
+  a.acc[d] += exp(fmin(-dH, 0.0));
+  a.accn[d] += 1.0;
+  bool turn = false;
+  if (!div) {
+    // multinomial sampling within the sub-tree: the new leaf replaces the candidate with probability w / W
+    const double new_logw = log_add_exp(a.logw[d], -dH);
+    if (log(a.u[d]) < (-dH - new_logw)) {
+      for (int i = 0; i < n; ++i) { a.sq[row + i] = a.qn[row + i]; a.sg[row + i] = a.gn[row + i]; }
+      a.slp[d] = lp;
+    }
+    a.logw[d] = new_logw;
+    for (int i = 0; i < n; ++i) a.psum[row + i] += a.pe[row + i];
+    // turning checks against the checkpoints named by csel, then this leaf's own checkpoint (wsel)
+    for (int s = 0; s < a.S; ++s) {
+      if (!a.csel[s]) continue;
+      const double* __restrict__ cp = a.ckp + s * plane + row;
+      const double* __restrict__ cs = a.cks + s * plane + row;
+      double left = 0.0, right = 0.0;
+      for (int i = 0; i < n; ++i) {
+        const double pn = a.pe[row + i];
+        const double rho = ((a.psum[row + i] - cs[i] + cp[i]) - 0.5 * (cp[i] + pn)) / a.mass[row + i];
+        left = fma(cp[i], rho, left);
+        right = fma(pn, rho, right);
+      }
+      turn = turn || (left <= 0.0) || (right <= 0.0);
+    }
+    for (int s = 0; s < a.S; ++s) {
+      if (!a.wsel[s]) continue;
+      for (int i = 0; i < n; ++i) {
+        a.ckp[s * plane + row + i] = a.pe[row + i];
+        a.cks[s * plane + row + i] = a.psum[row + i];
+      }
+    }
+  }
+  if (turn) a.turn[d] = 1;
+  if (div) a.div[d] = 1;
+  a.on[d] = (!div && !turn) ? 1 : 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+// ptrs: 24 device pointers in the order of NutsLeaf's pointer members (qe, pe, ge, eps, on, H0, logw, psum, sq, sg, slp,
+// turn, div, acc, accn, ckp, cks, u, wsel, csel, mass, qn, ph, gn) followed by lpn: 25 in all; phase 0 = begin, 1 = update
+int exo_nuts_leaf_f64(const void* const* ptrs, int64_t n_chain, int32_t n_param, int32_t n_slot, double max_energy_error,
+                      int32_t phase, void* stream) {
+  if (!ptrs || n_chain < 0 || n_param < 1 || n_slot < 1 || (phase != 0 && phase != 1)) return EXO_ERR_INVALID_ARGUMENT;
+  if (n_chain == 0) return EXO_OK;
+  for (int k = 0; k < 25; ++k)
+    if (!ptrs[k]) return EXO_ERR_INVALID_ARGUMENT;
+  NutsLeaf a;
+  int k = 0;
+  a.qe = (double*)ptrs[k++]; a.pe = (double*)ptrs[k++]; a.ge = (double*)ptrs[k++]; a.eps = (const double*)ptrs[k++];
+  a.on = (uint8_t*)ptrs[k++]; a.H0 = (const double*)ptrs[k++]; a.logw = (double*)ptrs[k++]; a.psum = (double*)ptrs[k++];
+  a.sq = (double*)ptrs[k++]; a.sg = (double*)ptrs[k++]; a.slp = (double*)ptrs[k++]; a.turn = (uint8_t*)ptrs[k++];
+  a.div = (uint8_t*)ptrs[k++]; a.acc = (double*)ptrs[k++]; a.accn = (double*)ptrs[k++]; a.ckp = (double*)ptrs[k++];
+  a.cks = (double*)ptrs[k++]; a.u = (const double*)ptrs[k++]; a.wsel = (const uint8_t*)ptrs[k++];
+  a.csel = (const uint8_t*)ptrs[k++]; a.mass = (const double*)ptrs[k++]; a.qn = (double*)ptrs[k++]; a.ph = (double*)ptrs[k++];
+  a.gn = (const double*)ptrs[k++]; a.lpn = (const double*)ptrs[k++];
+  a.D = n_chain; a.n = n_param; a.S = n_slot; a.max_energy_error = max_energy_error;
+  const dim3 grid((unsigned)((n_chain + 63) / 64)), block(64);
+  if (phase == 0) hipLaunchKernelGGL(nuts_leaf_begin_kernel, grid, block, 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(nuts_leaf_update_kernel, grid, block, 0, (hipStream_t)stream, a);
+  return launch_status();
+}
+
+}  // extern "C"

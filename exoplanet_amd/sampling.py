@@ -220,10 +220,42 @@ class NUTS(_ChainSampler):
         self._shapes = [tuple(p.shape) for p in self.params]
         self._sizes = [int(p[0].numel()) for p in self.params]
         self._mflat = self._flat(self.mass)
+        # control rows of the iterative tree building: leaf n of a sub-tree stores its momentum in slot wsel (n even) or
+        # closes the sub-sub-trees whose first leaves sit in the slots csel (n odd)
+        S = max(self.max_depth - 1, 1)
+        n_leaf = 2 ** (self.max_depth - 1)
+        W = torch.zeros(n_leaf, S, dtype=torch.bool)
+        C = torch.zeros(n_leaf, S, dtype=torch.bool)
+        for n in range(n_leaf):
+            if n % 2 == 0:
+                W[n, bin(n >> 1).count("1")] = True
+            else:
+                lo, hi = _ckpt_range(n)
+                C[n, lo:hi + 1] = True
+        self._W, self._C = W.to(dev), C.to(dev)
+        q = self._flat(self.params)
+        zq, zd = torch.zeros_like(q), torch.zeros(self.D, dtype=q.dtype, device=dev)
+        zb = torch.zeros(self.D, dtype=torch.bool, device=dev)
+        # the state of the sub-tree being built (static buffers: the captured leaf update works on them in place)
+        self._st = dict(qe=q.clone(), pe=zq.clone(), ge=zq.clone(), eps=self.eps.clone(), on=zb.clone(), H0=zd.clone(),
+                        logw=zd.clone(), psum=zq.clone(), sq=zq.clone(), sg=zq.clone(), slp=zd.clone(), turn=zb.clone(),
+                        div=zb.clone(), acc=zd.clone(), accn=zd.clone(), ckp=torch.zeros((S,) + tuple(q.shape), dtype=q.dtype, device=dev),
+                        cks=torch.zeros((S,) + tuple(q.shape), dtype=q.dtype, device=dev), u=zd.clone() + 0.5,
+                        wsel=self._W[0].clone(), csel=self._C[0].clone())
+        self._native = None
+        if self.params[0].is_cuda:
+            # on the device a leaf is two launches around the likelihood (exo_nuts_leaf_f64) instead of ~35 torch ones
+            import ctypes
+
+            st = self._st
+            st.update(qn=zq.clone(), ph=zq.clone(), gn=zq.clone(), lpn=zd.clone())
+            order = ("qe", "pe", "ge", "eps", "on", "H0", "logw", "psum", "sq", "sg", "slp", "turn", "div", "acc", "accn", "ckp",
+                     "cks", "u", "wsel", "csel")
+            ptrs = [st[k].data_ptr() for k in order] + [self._mflat.data_ptr()] + [st[k].data_ptr() for k in ("qn", "ph", "gn", "lpn")]
+            self._native = ((ctypes.c_void_p * len(ptrs))(*ptrs), int(q.shape[1]), S)
         self._graph = None
         if graph and self.params[0].is_cuda:
-            q = self._flat(self.params)
-            self._graph = GraphedStep(self._leaf, q, torch.zeros_like(q), torch.zeros_like(q), self.eps.clone())
+            self._graph = GraphedStep(lambda *a: self._leaf_update(), *self._st.values())
 
     def _flat(self, parts):
         return torch.cat([x.reshape(self.D, -1) for x in parts], dim=1)
@@ -253,6 +285,57 @@ class NUTS(_ChainSampler):
         rho = (p_sum - 0.5 * (p_left + p_right)) / self._mflat
         return ((p_left * rho).sum(1) <= 0) | ((p_right * rho).sum(1) <= 0)
 
+    def _leaf_update(self):
+        """one leaf of the sub-tree in `self._st`, in place: leapfrog step of the moving end, energy error, divergence,
+        multinomial candidate, momentum sums, checkpoint write (even leaves) or turning checks (odd leaves) -- the slots
+        come as the masks `wsel` / `csel` -- and the chains that go on.  Eager, or captured once and replayed per leaf."""
+        st = self._st
+        if self._native is not None:
+            from . import _lib
+
+            ptrs, n, S = self._native
+            lib = _lib.load()
+            stream = torch.cuda.current_stream(st["qe"].device).cuda_stream
+            with torch.cuda.device(st["qe"].device):
+                _lib.check(lib.exo_nuts_leaf_f64(ptrs, self.D, n, S, self.max_energy_error, 0, stream), "exo_nuts_leaf_f64")
+                lp, g = self._value_and_grad_flat(st["qn"])
+                st["gn"].copy_(g); st["lpn"].copy_(lp)
+                _lib.check(lib.exo_nuts_leaf_f64(ptrs, self.D, n, S, self.max_energy_error, 1, stream), "exo_nuts_leaf_f64")
+            return st["on"]
+        qn, pn, gn, lpn = self._leaf(st["qe"], st["pe"], st["ge"], st["eps"])
+        with torch.no_grad():
+            on = st["on"]
+            dH = -lpn + (0.5 * pn * pn / self._mflat).sum(1) - st["H0"]
+            dH = torch.where(torch.isnan(dH), torch.full_like(dH, float("inf")), dH)
+            div = on & (dH > self.max_energy_error)
+            ok = on & ~div
+            m1 = on.unsqueeze(1)
+            qe, pe, ge = torch.where(m1, qn, st["qe"]), torch.where(m1, pn, st["pe"]), torch.where(m1, gn, st["ge"])
+            acc = st["acc"] + torch.where(on, torch.exp(torch.clamp(-dH, max=0.0)), torch.zeros_like(dH))
+            accn = st["accn"] + on.to(dH.dtype)
+            # multinomial sampling within the sub-tree: the new leaf replaces the candidate with probability w / W
+            new_logw = torch.logaddexp(st["logw"], -dH)
+            take = ok & (torch.log(st["u"]) < (-dH - new_logw))
+            t1 = take.unsqueeze(1)
+            sq, sg = torch.where(t1, qn, st["sq"]), torch.where(t1, gn, st["sg"])
+            slp = torch.where(take, lpn, st["slp"])
+            logw = torch.where(ok, new_logw, st["logw"])
+            psum = torch.where(ok.unsqueeze(1), st["psum"] + pn, st["psum"])
+            # turning checks against the checkpoints named by csel (as they were before this leaf's own write)
+            ckp, cks = st["ckp"], st["cks"]
+            inner = psum.unsqueeze(0) - cks + ckp
+            rho = (inner - 0.5 * (ckp + pn.unsqueeze(0))) / self._mflat
+            t = ((ckp * rho).sum(-1) <= 0) | ((pn.unsqueeze(0) * rho).sum(-1) <= 0)
+            turn = st["turn"] | (t & st["csel"].unsqueeze(1) & ok.unsqueeze(0)).any(0)
+            wm = (st["wsel"].unsqueeze(1) & ok.unsqueeze(0)).unsqueeze(-1)
+            ckp2, cks2 = torch.where(wm, pn.unsqueeze(0), ckp), torch.where(wm, psum.unsqueeze(0), cks)
+            sdiv = st["div"] | div
+            on2 = on & ~div & ~turn
+            for k, v in (("qe", qe), ("pe", pe), ("ge", ge), ("acc", acc), ("accn", accn), ("sq", sq), ("sg", sg), ("slp", slp),
+                         ("logw", logw), ("psum", psum), ("turn", turn), ("ckp", ckp2), ("cks", cks2), ("div", sdiv), ("on", on2)):
+                st[k].copy_(v)
+        return st["on"]
+
     @torch.no_grad()
     def step(self):
         self._mflat.copy_(self._flat(self.mass))         # (warm-up may have changed the masses; captured graphs read this)
@@ -275,48 +358,30 @@ class NUTS(_ChainSampler):
         depth = torch.zeros_like(H0)
         diverged = torch.zeros_like(active)
         acc_sum, acc_n = torch.zeros_like(H0), torch.zeros_like(H0)
-        ninf = torch.full_like(H0, float("-inf"))
-        zeros = torch.zeros_like(p0)
         for j in range(self.max_depth):
             going_right = self._rand() < 0.5
             eps_s = torch.where(going_right, self.eps, -self.eps)
             qe, pe, ge = w1(going_right, qr, ql), w1(going_right, pr, pl), w1(going_right, gr, gl)
-            sub_on = active                                  # still adding leaves to this sub-tree
-            sub_turn = torch.zeros_like(active)
-            sub_div = torch.zeros_like(active)
-            sub_logw = ninf
-            sub_psum = zeros
-            sub_q, sub_lp, sub_g = qe, lp0, ge
-            n_slots = max(j, 1)
-            ck_p, ck_sum = [zeros] * n_slots, [zeros] * n_slots
+            # the sub-tree's state (static buffers); its random numbers for all leaves at once
+            U = torch.rand(2 ** j, self.D, dtype=H0.dtype, device=H0.device, generator=self.generator)
+            st = self._st
+            for k, v in (("qe", qe), ("pe", pe), ("ge", ge), ("eps", eps_s), ("on", active), ("H0", H0), ("sq", qe), ("sg", ge),
+                         ("slp", lp0), ("acc", acc_sum), ("accn", acc_n)):
+                st[k].copy_(v)
+            st["logw"].fill_(float("-inf"))
+            st["psum"].zero_(); st["turn"].zero_(); st["div"].zero_()
             for n in range(2 ** j):
-                out = self._graph(qe, pe, ge, eps_s) if self._graph is not None else self._leaf(qe, pe, ge, eps_s)
-                self.n_leapfrog += 1
-                qn, pn, gn, lpn = out
-                dH = -lpn + kin(pn) - H0
-                dH = torch.where(torch.isnan(dH), torch.full_like(dH, float("inf")), dH)
-                div = sub_on & (dH > self.max_energy_error)
-                ok = sub_on & ~div
-                qe, pe, ge = w1(sub_on, qn, qe), w1(sub_on, pn, pe), w1(sub_on, gn, ge)
-                acc_sum = acc_sum + torch.where(sub_on, torch.exp(torch.clamp(-dH, max=0.0)), torch.zeros_like(dH))
-                acc_n = acc_n + sub_on.to(acc_n.dtype)
-                # multinomial sampling within the sub-tree: the new leaf replaces the candidate with probability w / W
-                new_logw = torch.logaddexp(sub_logw, -dH)
-                take = ok & (torch.log(self._rand()) < (-dH - new_logw))
-                sub_q, sub_g = w1(take, qn, sub_q), w1(take, gn, sub_g)
-                sub_lp = torch.where(take, lpn, sub_lp)
-                sub_logw = torch.where(ok, new_logw, sub_logw)
-                sub_psum = w1(ok, sub_psum + pn, sub_psum)
-                if n % 2 == 0:
-                    slot = bin(n >> 1).count("1")
-                    ck_p[slot] = w1(ok, pn, ck_p[slot])
-                    ck_sum[slot] = w1(ok, sub_psum, ck_sum[slot])
+                st["u"].copy_(U[n]); st["wsel"].copy_(self._W[n]); st["csel"].copy_(self._C[n])
+                if self._graph is not None:
+                    self._graph()
                 else:
-                    lo, hi = _ckpt_range(n)
-                    for i in range(hi, lo - 1, -1):
-                        sub_turn = sub_turn | (ok & self._turning(ck_p[i], pn, sub_psum - ck_sum[i] + ck_p[i]))
-                sub_div = sub_div | div
-                sub_on = sub_on & ~div & ~sub_turn
+                    self._leaf_update()
+                self.n_leapfrog += 1
+            # (read before the next doubling rewrites the buffers: everything below makes new tensors)
+            qe, pe, ge = st["qe"], st["pe"], st["ge"]
+            sub_turn, sub_div, sub_logw, sub_psum = st["turn"], st["div"], st["logw"], st["psum"]
+            sub_q, sub_lp, sub_g = st["sq"], st["slp"], st["sg"]
+            acc_sum, acc_n = st["acc"].clone(), st["accn"].clone()
             grown = active & ~sub_turn & ~sub_div               # the sub-tree is valid: it joins the tree
             # biased progressive sampling between the old tree and the new half
             take = grown & (torch.log(self._rand()) < (sub_logw - log_w))
