@@ -43,6 +43,8 @@ class _ChainSampler:
                      for p, m in zip(self.params, mass or [None] * len(self.params))]
         self.generator = generator
         self.n_steps = 0
+        self._shapes = [tuple(p.shape) for p in self.params]
+        self._sizes = [int(p[0].numel()) for p in self.params]
 
     # one value + gradient evaluation of all chains
     def _value_and_grad(self, q):
@@ -54,6 +56,21 @@ class _ChainSampler:
 
     def _kinetic(self, p):
         return sum((0.5 * pi * pi / mi).reshape(self.D, -1).sum(-1) for pi, mi in zip(p, self.mass))
+
+    # all parameter blocks of a chain side by side in ONE (D, n) array: an update of positions or momenta is one launch
+    # whatever the number of blocks; logp_fn sees views of it
+    def _flat(self, parts):
+        return torch.cat([x.reshape(self.D, -1) for x in parts], dim=1)
+
+    def _parts(self, flat):
+        return [x.reshape(shp) for x, shp in zip(torch.split(flat, self._sizes, dim=1), self._shapes)]
+
+    def _value_and_grad_flat(self, q):
+        with torch.enable_grad():
+            parts = self._parts(q.detach().requires_grad_(True))
+            lp = self.logp_fn(*parts)
+            grads = torch.autograd.grad(lp.sum(), parts)
+        return lp.detach(), self._flat([g.detach() for g in grads])
 
     def _momenta(self):
         return [torch.randn(q.shape, dtype=q.dtype, device=q.device, generator=self.generator) * torch.sqrt(m)
@@ -124,43 +141,38 @@ class HMC(_ChainSampler):
             raise ValueError("need step_size > 0 and n_leapfrog >= 1")
         self._setup(logp_fn, params, step_size, mass, generator)
         self.n_accept = torch.zeros(self.D, dtype=torch.float64, device=self.params[0].device)
+        self._mflat = self._flat(self.mass)
         self._graph = None
         if graph and self.params[0].is_cuda:
-            k = len(self.params)
-            # static inputs: positions, momenta; static outputs: proposal, its momenta, both log-densities
-            q0 = [p.clone() for p in self.params]
-            p0 = [torch.zeros_like(p) for p in self.params]
-            self._graph = GraphedStep(lambda *a: self._trajectory(list(a[:k]), list(a[k:])), *q0, *p0)
+            # static inputs: positions, momenta (flat); static outputs: proposal, its momenta, both log-densities
+            q0 = self._flat(self.params)
+            self._graph = GraphedStep(self._trajectory, q0, torch.zeros_like(q0))
 
     def _trajectory(self, q, p):
-        """leapfrog: (q, p) -> (q', p', logp(q), logp(q'))"""
-        lp0, g = self._value_and_grad(q)
-        q = [x.clone() for x in q]
-        p = [x.clone() for x in p]
+        """leapfrog on the flat (D, n) arrays: (q, p) -> (q', p', logp(q), logp(q'))"""
+        lp0, g = self._value_and_grad_flat(q)
         lp = lp0
-        eps = [self.eps.reshape((self.D,) + (1,) * (x.dim() - 1)) for x in q]
+        e = self.eps.unsqueeze(1)
         for _ in range(self.L):
-            p = [pi + 0.5 * ei * gi for pi, gi, ei in zip(p, g, eps)]
-            q = [qi + ei * pi / mi for qi, pi, mi, ei in zip(q, p, self.mass, eps)]
-            lp, g = self._value_and_grad(q)
-            p = [pi + 0.5 * ei * gi for pi, gi, ei in zip(p, g, eps)]
-        return tuple(q) + tuple(p) + (lp0, lp)
+            p = p + 0.5 * e * g
+            q = q + e * p / self._mflat
+            lp, g = self._value_and_grad_flat(q)
+            p = p + 0.5 * e * g
+        return q, p, lp0, lp
 
     @torch.no_grad()
     def step(self):
-        k = len(self.params)
-        p0 = self._momenta()
-        if self._graph is not None:
-            out = self._graph(*self.params, *p0)
-        else:
-            out = self._trajectory(self.params, p0)
-        q1, p1, lp0, lp1 = list(out[:k]), list(out[k:2 * k]), out[2 * k], out[2 * k + 1]
-        dH = (lp1 - self._kinetic(p1)) - (lp0 - self._kinetic(p0))       # -(H1 - H0)
+        self._mflat.copy_(self._flat(self.mass))          # (warm-up may have changed the masses; the captured graph reads this)
+        q0 = self._flat(self.params)
+        p0 = torch.randn(q0.shape, dtype=q0.dtype, device=q0.device, generator=self.generator) * torch.sqrt(self._mflat)
+        q1, p1, lp0, lp1 = self._graph(q0, p0) if self._graph is not None else self._trajectory(q0, p0)
+        kin = lambda p: (0.5 * p * p / self._mflat).sum(1)  # noqa: E731
+        dH = (lp1 - kin(p1)) - (lp0 - kin(p0))                           # -(H1 - H0)
         u = self._rand()
         accept = torch.log(u) < dH                                        # NaN / -inf proposals are rejected
-        for q, qn in zip(self.params, q1):
-            m = accept.reshape((self.D,) + (1,) * (q.dim() - 1))
-            q.copy_(torch.where(m, qn, q))
+        qnew = torch.where(accept.unsqueeze(1), q1, q0)
+        for x, y in zip(self.params, self._parts(qnew)):
+            x.copy_(y)
         self.n_steps += 1
         self.n_accept += accept.to(self.n_accept.dtype)
         self.last_logp = torch.where(accept, lp1, lp0)
@@ -217,8 +229,6 @@ class NUTS(_ChainSampler):
         self._lp = self._g = None    # log-density and gradient at the current positions
         # the tree lives on ONE (D, n) array per quantity -- all parameter blocks of a chain side by side -- so that a
         # mask, a dot product or a checkpoint is one launch whatever the number of blocks; logp_fn sees views of it
-        self._shapes = [tuple(p.shape) for p in self.params]
-        self._sizes = [int(p[0].numel()) for p in self.params]
         self._mflat = self._flat(self.mass)
         # control rows of the iterative tree building: leaf n of a sub-tree stores its momentum in slot wsel (n even) or
         # closes the sub-sub-trees whose first leaves sit in the slots csel (n odd)
@@ -256,19 +266,6 @@ class NUTS(_ChainSampler):
         self._graph = None
         if graph and self.params[0].is_cuda:
             self._graph = GraphedStep(lambda *a: self._leaf_update(), *self._st.values())
-
-    def _flat(self, parts):
-        return torch.cat([x.reshape(self.D, -1) for x in parts], dim=1)
-
-    def _parts(self, flat):
-        return [x.reshape(shp) for x, shp in zip(torch.split(flat, self._sizes, dim=1), self._shapes)]
-
-    def _value_and_grad_flat(self, q):
-        with torch.enable_grad():
-            parts = self._parts(q.detach().requires_grad_(True))
-            lp = self.logp_fn(*parts)
-            grads = torch.autograd.grad(lp.sum(), parts)
-        return lp.detach(), self._flat([g.detach() for g in grads])
 
     def _leaf(self, q, p, g, eps):
         """one leapfrog step of every chain with its own signed step size: (q, p, grad) -> (q', p', grad', logp')"""
