@@ -417,6 +417,7 @@ class _TransitChi2(torch.autograd.Function):
 
 
 _CONSTS = {}
+_WN_CACHE = {}     # white_noise_loglike: (series, error bars, mean) -> residuals, weights, constants
 
 
 def _const(value, device):
@@ -446,16 +447,33 @@ def white_noise_loglike(t, params, ld, y, yerr, mean=0.0, texp=None, stencil_dt=
     per cadence) given ``mean + light curve`` -- the reference's ``pm.Normal("obs", mu=mean + lc, sigma=yerr,
     observed=y)`` for a batch of parameter sets, value and gradient in one call (:func:`transit_chi2`)."""
     y = _dev(y, "y")
-    if isinstance(yerr, (int, float)):
-        ivar = _const(1.0 / (float(yerr) * float(yerr)), y.device)      # cached: no upload inside a hipGraph capture
-    else:
-        yerr = _dev(yerr, "yerr")
-        ivar = (1.0 / (yerr * yerr)).reshape(-1)
-    obs = y - mean
+    # what depends on the data alone (residual series, weights, the two constants of the likelihood) is computed once per
+    # (y, yerr, mean): a sampler calls this thousands of times with the same series
+    key = None
+    if isinstance(mean, (int, float)) and not y.requires_grad and (isinstance(yerr, (int, float)) or not yerr.requires_grad):
+        # (keyed by the tensor OBJECTS, which the entry keeps alive -- an address alone could be handed to another series)
+        key = (id(y), y._version, float(mean),
+               float(yerr) if isinstance(yerr, (int, float)) else (id(yerr), yerr._version))
+    hit = _WN_CACHE.get(key) if key is not None else None
+    if hit is not None and not (hit[4] is y and (isinstance(yerr, (int, float)) or hit[5] is yerr)):
+        hit = None
+    if hit is None:
+        if isinstance(yerr, (int, float)):
+            ivar = _const(1.0 / (float(yerr) * float(yerr)), y.device)      # cached: no upload inside a hipGraph capture
+        else:
+            yerr = _dev(yerr, "yerr")
+            ivar = (1.0 / (yerr * yerr)).reshape(-1)
+        obs = y - mean
+        n = y.numel()
+        const = (ivar * obs * obs).sum() if ivar.numel() == n else ivar[0] * (obs * obs).sum()
+        lognorm = torch.log(ivar / (2.0 * torch.pi)).sum() * (1.0 if ivar.numel() == n else float(n))
+        hit = (obs, ivar, const, lognorm, y, yerr)
+        if key is not None:
+            if len(_WN_CACHE) >= 16:
+                _WN_CACHE.clear()
+            _WN_CACHE[key] = hit
+    obs, ivar, const, lognorm = hit[:4]
     chi2 = transit_chi2(t, params, ld, obs, ivar, texp=texp, stencil_dt=stencil_dt, stencil_w=stencil_w, flags=flags, ttv=ttv)
-    n = y.numel()
-    const = (ivar * obs * obs).sum() if ivar.numel() == n else ivar[0] * (obs * obs).sum()
-    lognorm = torch.log(ivar / (2.0 * torch.pi)).sum() * (1.0 if ivar.numel() == n else float(n))
     return -0.5 * (chi2 + const) + 0.5 * lognorm
 
 

@@ -92,6 +92,24 @@ def test_white_noise_loglike_and_argument_checks(dev):
     want = -0.5 * (((y - 1.0 - flux) / yerr) ** 2).sum(-1) - N * np.log(yerr * np.sqrt(2 * np.pi))
     got = ops.white_noise_loglike(T(t, dev), T(rec, dev), T(c, dev), T(y, dev), yerr, mean=1.0)
     assert np.abs(got.cpu().numpy() - want).max() <= 1e-10 * np.abs(want).max()
+    # the data-only terms are cached per (series, error bars, mean): same object again -> same value; the series changed
+    # in place, another mean, per-cadence error bars -> recomputed
+    yt = T(y, dev)
+    a1 = ops.white_noise_loglike(T(t, dev), T(rec, dev), T(c, dev), yt, yerr, mean=1.0)
+    a2 = ops.white_noise_loglike(T(t, dev), T(rec, dev), T(c, dev), yt, yerr, mean=1.0)
+    assert torch.equal(a1, a2) and np.abs(a1.cpu().numpy() - want).max() <= 1e-10 * np.abs(want).max()
+    yt.add_(3e-4)
+    want2 = -0.5 * (((y + 3e-4 - 1.0 - flux) / yerr) ** 2).sum(-1) - N * np.log(yerr * np.sqrt(2 * np.pi))
+    a3 = ops.white_noise_loglike(T(t, dev), T(rec, dev), T(c, dev), yt, yerr, mean=1.0)
+    assert np.abs(a3.cpu().numpy() - want2).max() <= 1e-10 * np.abs(want2).max()
+    a4 = ops.white_noise_loglike(T(t, dev), T(rec, dev), T(c, dev), yt, yerr, mean=1.0 + 3e-4)
+    assert np.abs(a4.cpu().numpy() - want).max() <= 1e-9 * np.abs(want).max()
+    errs = yerr * (1 + 0.2 * rng.uniform(size=N))
+    want5 = -0.5 * (((y + 3e-4 - 1.0 - flux) / errs) ** 2).sum(-1) - np.log(errs * np.sqrt(2 * np.pi)).sum()
+    et = T(errs, dev)
+    for _ in range(2):
+        a5 = ops.white_noise_loglike(T(t, dev), T(rec, dev), T(c, dev), yt, et, mean=1.0)
+        assert np.abs(a5.cpu().numpy() - want5).max() <= 1e-10 * np.abs(want5).max()
     with pytest.raises(ValueError):
         ops.transit_chi2(T(t, dev), T(rec, dev), T(c, dev), T(y[:-1], dev), T([1.0], dev))
     with pytest.raises(ValueError):
