@@ -110,13 +110,30 @@ __device__ double mean_anomaly_of(double f, double e, double se, double pe) {
 #endif
 constexpr int kSortBlock = 4096;
 constexpr int kWinLanes = 4;   // threads per record: (event, side of the conjunction)
-// The record of one (draw, planet), by the four lanes sub = 0..3 of a wave that hold it (sub = lane & 3: the
-// shuffles stay inside the group); p: its parameter record, o: where the kWin doubles go (global or LDS).
-__device__ __forceinline__ void window_record(const double* __restrict__ p, uint32_t flags, int sub, double* __restrict__ o) {
-  const int k = sub >> 1, sd = sub & 1;   // event (0 transit, 1 occultation), side
-
+__global__ __launch_bounds__(kBlock) void transit_window_kernel(const double* __restrict__ params, int64_t n_rec,
+                                                                uint32_t flags, double* __restrict__ out,
+                                                                const double* __restrict__ t = nullptr, int64_t n_cad = 0,
+                                                                int32_t* __restrict__ sorted = nullptr,
+                                                                int32_t* __restrict__ done = nullptr, int64_t n_done = 0) {
+  const int n_rec_blocks = (int)((n_rec * kWinLanes + kBlock - 1) / kBlock);
+  // (the per-draw block counters of the sweep that follows: transit_runs_kernel)
+  if (done && (int64_t)blockIdx.x * kBlock + threadIdx.x < n_done) done[(int64_t)blockIdx.x * kBlock + threadIdx.x] = 0;
+  if ((int)blockIdx.x >= n_rec_blocks) {
+    const int sb = blockIdx.x - n_rec_blocks;
+    const int64_t b0 = (int64_t)sb * kSortBlock;
+    bool ok = true;
+    for (int64_t k = b0 + threadIdx.x; k < b0 + kSortBlock && k + 1 < n_cad; k += kBlock) ok = ok && (t[k] <= t[k + 1]);   // NaN: not sorted
+    const int all = __syncthreads_and(ok ? 1 : 0);
+    if (threadIdx.x == 0) sorted[sb] = all;
+    return;
+  }
+  const int64_t gid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const int64_t i = gid / kWinLanes;
+  const int sub = (int)(gid - i * kWinLanes), k = sub >> 1, sd = sub & 1;   // event (0 transit, 1 occultation), side
+  if (i >= n_rec) return;   // (whole groups of four: the shuffles below stay within a record)
+  const double* p = params + i * EXO_NPAR;
   const double e = p[EXO_P_ECC], cw = p[EXO_P_COSW], sw = p[EXO_P_SINW];
-
+  double* o = out + kWin * i;
   if (flags & EXO_FLAG_WINDOW) {
     if (sub != 0) return;
     const double ip = 1.0 / p[EXO_P_PERIOD];
@@ -232,30 +249,6 @@ __device__ __forceinline__ void window_record(const double* __restrict__ p, uint
     o[4] = half + wd;
     o[6] = inner;
   }
-}
-
-__global__ __launch_bounds__(kBlock) void transit_window_kernel(const double* __restrict__ params, int64_t n_rec,
-                                                                uint32_t flags, double* __restrict__ out,
-                                                                const double* __restrict__ t = nullptr, int64_t n_cad = 0,
-                                                                int32_t* __restrict__ sorted = nullptr,
-                                                                int32_t* __restrict__ done = nullptr, int64_t n_done = 0) {
-  const int n_rec_blocks = (int)((n_rec * kWinLanes + kBlock - 1) / kBlock);
-  // (the per-draw block counters of the sweep that follows: transit_runs_kernel)
-  if (done && (int64_t)blockIdx.x * kBlock + threadIdx.x < n_done) done[(int64_t)blockIdx.x * kBlock + threadIdx.x] = 0;
-  if ((int)blockIdx.x >= n_rec_blocks) {
-    const int sb = blockIdx.x - n_rec_blocks;
-    const int64_t b0 = (int64_t)sb * kSortBlock;
-    bool ok = true;
-    for (int64_t k = b0 + threadIdx.x; k < b0 + kSortBlock && k + 1 < n_cad; k += kBlock) ok = ok && (t[k] <= t[k + 1]);   // NaN: not sorted
-    const int all = __syncthreads_and(ok ? 1 : 0);
-    if (threadIdx.x == 0) sorted[sb] = all;
-    return;
-  }
-  const int64_t gid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  const int64_t i = gid / kWinLanes;
-  const int sub = (int)(gid - i * kWinLanes);
-  if (i >= n_rec) return;   // (whole groups of four: the shuffles below stay within a record)
-  window_record(params + i * EXO_NPAR, flags, sub, out + kWin * i);
 }
 
 // ---------------------------------------------------------------------------
@@ -1495,100 +1488,6 @@ __device__ __forceinline__ void enum_prefix(int (*s_len)[kRunMax + 1], int K, in
   if (lane == 63) { pin[K] = ex_in; pall[K] = ex_all; *nrun_dst = K; }
 }
 
-// What the runs of one list (draw, planet, event) follow from, in closed form: its windows are the integers of
-// phase x = t nrev + c0 + off, run k is window kmin + k, half-width h (inner part hin); or -- `full` -- the list
-// degenerates to every cadence in K pieces of `piece` cadences.
-struct ListGeom {
-  double nrev, c0, off, h, hin, x_first, x_rate, kmin;
-  int64_t piece;
-  int K;
-  bool full;
-};
-// wv: the record of transit_window_kernel; widen: exposure half-span in revolutions; sorted: t is non-decreasing
-__device__ __forceinline__ ListGeom list_geom(const double* wv, int ev, int n_ev, double widen, bool sorted,
-                                              const double* __restrict__ t, int64_t n_cad, int r_max) {
-  ListGeom g;
-  const double nrev = wv[0], c0 = wv[1], dmid = wv[2];
-  const double h0 = wv[3] + widen, h1 = wv[4] + widen;
-  // the list degenerates to "every cadence" unless its windows are bounded, periodic in t and disjoint
-  // (the decision is the same for both events of a planet: it only uses what they share)
-  const double x_first = fma(t[0], nrev, c0), x_last = fma(t[n_cad - 1], nrev, c0);
-  bool full = !sorted || !(nrev > 0.0) || !(x_first == x_first) || !(x_last == x_last) || !(fabs(x_first) < 1e15) ||
-              !(fabs(x_last) < 1e15) || !(h0 < 0.5);
-  if (n_ev == 2) {
-    const double sep = fabs(frac_rev(dmid));   // transit and occultation centres, in revolutions
-    full = full || !(h1 < 0.5) || !(h0 + h1 < sep);
-  }
-  double kmin[2] = {0.0, 0.0}, kcnt[2] = {0.0, 0.0};
-  if (!full) {
-    for (int e = 0; e < n_ev; ++e) {
-      const double off = e ? dmid : 0.0, h = e ? h1 : h0;
-      kmin[e] = ceil((x_first + off) - h);
-      kcnt[e] = floor((x_last + off) + h) - kmin[e] + 1.0;
-      full = full || (kcnt[e] > (double)r_max);
-    }
-  }
-  g.nrev = nrev; g.c0 = c0; g.off = ev ? dmid : 0.0; g.h = ev ? h1 : h0; g.hin = wv[5 + ev];
-  g.x_first = x_first;
-  g.x_rate = (x_last - x_first) / (double)(n_cad > 1 ? n_cad - 1 : 1);
-  g.kmin = kmin[ev];
-  g.full = full;
-  // every cadence, as pieces of >= 1024 (the heavy blocks of a draw share a list run by run)
-  int64_t piece = (n_cad + r_max - 1) / r_max;
-  g.piece = piece < 1024 ? 1024 : piece;
-  if (full) g.K = ev == 0 ? (int)((n_cad + g.piece - 1) / g.piece) : 0;
-  else g.K = kcnt[ev] > 0.0 ? (int)kcnt[ev] : 0;
-  return g;
-}
-// run k of the list
-__device__ __forceinline__ Run list_run(const ListGeom& g, const double* __restrict__ t, int64_t n_cad, int k) {
-  if (g.full) {
-    const int64_t lo = k * g.piece, hi = (lo + g.piece < n_cad) ? lo + g.piece : n_cad;
-    return Run{(int32_t)lo, (int32_t)lo, (int32_t)lo, (int32_t)hi};
-  }
-  const double nrev = g.nrev, c0 = g.c0, off = g.off;
-  // first i in [lo, hi) with x_i >= thr (strict: > thr).  Series are nearly always evenly sampled:
-  // the position guessed from the mean sampling rate is confirmed by its two neighbours (two
-  // independent loads instead of a chain of log2(n) dependent ones); anything else is searched for.
-  auto first_not = [&](double thr, bool strict, int lo, int hi) {
-    if (g.x_rate > 0.0 && hi > lo) {
-      const double gq = ceil((thr - off - g.x_first) / g.x_rate);
-      const int q = gq < (double)lo ? lo : (gq > (double)hi ? hi : (int)gq);
-      const double xa = q > lo ? fma(t[q - 1], nrev, c0) + off : 0.0, xb = q < hi ? fma(t[q], nrev, c0) + off : 0.0;
-      const bool left_before = q == lo || (strict ? (xa <= thr) : (xa < thr));
-      const bool here_not = q == hi || !(strict ? (xb <= thr) : (xb < thr));
-      if (left_before && here_not) return q;
-    }
-    while (lo < hi) {
-      const int mid = (lo + hi) >> 1;
-      const double xi = fma(t[mid], nrev, c0) + off;
-      const bool before = strict ? (xi <= thr) : (xi < thr);
-      lo = before ? mid + 1 : lo;
-      hi = before ? hi : mid;
-    }
-    return lo;
-  };
-  const double kc = g.kmin + (double)k;
-  Run r;
-  r.lo = first_not(kc - g.h, false, 0, (int)n_cad);
-  r.hi = first_not(kc + g.h, true, r.lo, (int)n_cad);
-  if (g.hin > 0.0) {
-    r.a = first_not(kc - g.hin, false, r.lo, r.hi);
-    r.b = first_not(kc + g.hin, true, r.a, r.hi);
-  } else {
-    r.a = r.b = r.lo;
-  }
-  return r;
-}
-// the windows are widened by the half-span of the exposure stencil; the reference widens its
-// contact windows by texp / 2 whatever the stencil (keplerian.py:765-769).  In units of |texp|.
-__device__ __forceinline__ double exposure_span(uint32_t flags, const double* __restrict__ stencil_dt, int n_sub) {
-  double span = (flags & EXO_FLAG_WINDOW) ? 0.5 : 0.0;
-  if (!(flags & EXO_FLAG_WINDOW) && stencil_dt)
-    for (int k = 0; k < n_sub; ++k) span = fmax(span, fabs(stencil_dt[k]));
-  return span;
-}
-
 // One wave per list (draw, planet, event: 0 = transits, 1 = occultations).
 __global__ __launch_bounds__(64) void transit_enum_kernel(const double* __restrict__ t, int64_t n_cad,
                                                           const double* __restrict__ texp, int64_t n_texp,
@@ -1600,21 +1499,91 @@ __global__ __launch_bounds__(64) void transit_enum_kernel(const double* __restri
   const int64_t list = blockIdx.x, rec = list / n_ev;
   const int ev = (int)(list - rec * n_ev), lane = threadIdx.x;
   const double* wv = windows + kWin * rec;
+  const double nrev = wv[0], c0 = wv[1], dmid = wv[2];
+  // the windows are widened by the half-span of the exposure stencil; the reference widens its
+  // contact windows by texp / 2 whatever the stencil (keplerian.py:765-769)
+  double span = (flags & EXO_FLAG_WINDOW) ? 0.5 : 0.0;
+  if (!(flags & EXO_FLAG_WINDOW) && stencil_dt)
+    for (int k = 0; k < n_sub; ++k) span = fmax(span, fabs(stencil_dt[k]));
   const double te = n_texp ? texp[0] : 0.0;
-  const double widen = fabs(te) * exposure_span(flags, stencil_dt, n_sub) * fabs(wv[0]);
+  const double widen = fabs(te) * span * fabs(nrev);
+  const double h0 = wv[3] + widen, h1 = wv[4] + widen;
   bool srt = true;
   for (int i = lane; i < n_sorted; i += 64) srt = srt && (sorted[i] != 0);
   srt = __all(srt);
-  const ListGeom g = list_geom(wv, ev, n_ev, widen, srt, t, n_cad, rl.r_max);
+  // the list degenerates to "every cadence" unless its windows are bounded, periodic in t and disjoint
+  // (the decision is the same for both events of a planet: it only uses what they share)
+  const double x_first = fma(t[0], nrev, c0), x_last = fma(t[n_cad - 1], nrev, c0);
+  bool full = !srt || !(nrev > 0.0) || !(x_first == x_first) || !(x_last == x_last) || !(fabs(x_first) < 1e15) ||
+              !(fabs(x_last) < 1e15) || !(h0 < 0.5);
+  if (n_ev == 2) {
+    const double sep = fabs(frac_rev(dmid));   // transit and occultation centres, in revolutions
+    full = full || !(h1 < 0.5) || !(h0 + h1 < sep);
+  }
+  double kmin[2] = {0.0, 0.0}, kcnt[2] = {0.0, 0.0};
+  if (!full) {
+    for (int e = 0; e < n_ev; ++e) {
+      const double off = e ? dmid : 0.0, h = e ? h1 : h0;
+      kmin[e] = ceil((x_first + off) - h);
+      kcnt[e] = floor((x_last + off) + h) - kmin[e] + 1.0;
+      full = full || (kcnt[e] > (double)rl.r_max);
+    }
+  }
   Run* __restrict__ runs = rl.runs + list * rl.r_max;
   int32_t* __restrict__ pin = rl.pre_in + list * (rl.r_max + 1);
   int32_t* __restrict__ pall = rl.pre_all + list * (rl.r_max + 1);
-  const int K = g.K;
-  for (int k = lane; k < K; k += 64) {
-    const Run r = list_run(g, t, n_cad, k);
-    runs[k] = r;
-    s_len[0][k] = r.b - r.a;
-    s_len[1][k] = r.hi - r.lo;
+  int K;
+  if (full) {
+    // every cadence, as pieces of >= 1024 (the heavy blocks of a draw share a list run by run)
+    int64_t piece = (n_cad + rl.r_max - 1) / rl.r_max;
+    piece = piece < 1024 ? 1024 : piece;
+    K = ev == 0 ? (int)((n_cad + piece - 1) / piece) : 0;
+    for (int k = lane; k < K; k += 64) {
+      const int64_t lo = k * piece, hi = (lo + piece < n_cad) ? lo + piece : n_cad;
+      runs[k] = Run{(int32_t)lo, (int32_t)lo, (int32_t)lo, (int32_t)hi};
+      s_len[0][k] = 0;
+      s_len[1][k] = (int)(hi - lo);
+    }
+  } else {
+    K = kcnt[ev] > 0.0 ? (int)kcnt[ev] : 0;
+    const double off = ev ? dmid : 0.0, h = ev ? h1 : h0, hin = wv[5 + ev];
+    // first i in [lo, hi) with x_i >= thr (strict: > thr).  Series are nearly always evenly sampled:
+    // the position guessed from the mean sampling rate is confirmed by its two neighbours (two
+    // independent loads instead of a chain of log2(n) dependent ones); anything else is searched for.
+    const double x_rate = (x_last - x_first) / (double)(n_cad > 1 ? n_cad - 1 : 1);
+    auto first_not = [&](double thr, bool strict, int lo, int hi) {
+      if (x_rate > 0.0 && hi > lo) {
+        const double gq = ceil((thr - off - x_first) / x_rate);
+        int g = gq < (double)lo ? lo : (gq > (double)hi ? hi : (int)gq);
+        const double xa = g > lo ? fma(t[g - 1], nrev, c0) + off : 0.0, xb = g < hi ? fma(t[g], nrev, c0) + off : 0.0;
+        const bool left_before = g == lo || (strict ? (xa <= thr) : (xa < thr));
+        const bool here_not = g == hi || !(strict ? (xb <= thr) : (xb < thr));
+        if (left_before && here_not) return g;
+      }
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        const double xi = fma(t[mid], nrev, c0) + off;
+        const bool before = strict ? (xi <= thr) : (xi < thr);
+        lo = before ? mid + 1 : lo;
+        hi = before ? hi : mid;
+      }
+      return lo;
+    };
+    for (int k = lane; k < K; k += 64) {
+      const double kc = kmin[ev] + (double)k;
+      Run r;
+      r.lo = first_not(kc - h, false, 0, (int)n_cad);
+      r.hi = first_not(kc + h, true, r.lo, (int)n_cad);
+      if (hin > 0.0) {
+        r.a = first_not(kc - hin, false, r.lo, r.hi);
+        r.b = first_not(kc + hin, true, r.a, r.hi);
+      } else {
+        r.a = r.b = r.lo;
+      }
+      runs[k] = r;
+      s_len[0][k] = r.b - r.a;
+      s_len[1][k] = r.hi - r.lo;
+    }
   }
   __syncthreads();
   enum_prefix(s_len, K, lane, pin, pall, rl.nrun + list);
@@ -1909,7 +1878,6 @@ struct FinishArgs {
   double* flux_dot;
   int fold;        // the runs kernel finishes its draws itself: no transit_finish_kernel launch
   int32_t* done;   // [n_draw] blocks of the draw that are through (zeroed by transit_window_kernel)
-  int inl;         // the runs kernel works the windows and the runs out itself (EXO_FLAG_SORTED: no window / enumeration launch)
 };
 
 // CHI2 (one planet, one sample per cadence): gflux is the observed series [n_cad], gsparse its weights ([1] or [n_cad],
@@ -1924,7 +1892,7 @@ __global__ __launch_bounds__(kBlock, EXO_HEAVY_MIN_WAVES) void transit_runs_kern
     const double* __restrict__ params, const double* __restrict__ ld, int n_planet, uint32_t flags, int n_ev, RunLists rl,
     const double* __restrict__ gflux, const double* __restrict__ gsparse, double* __restrict__ vals,
     int32_t* __restrict__ vcad, double* __restrict__ fill, double* __restrict__ partial, int64_t chi2_nw = 0,
-    Ttv ttv = Ttv{nullptr, nullptr, nullptr, 0}, FinishArgs fin = FinishArgs{nullptr, nullptr, nullptr, 0, nullptr, 0}) {
+    Ttv ttv = Ttv{nullptr, nullptr, nullptr, 0}, FinishArgs fin = FinishArgs{nullptr, nullptr, nullptr, 0, nullptr}) {
   __shared__ Shared sh;
   __shared__ Run s_run[kSeg];
   __shared__ int s_in[kSeg + 1], s_all[kSeg + 1];
@@ -1933,123 +1901,25 @@ __global__ __launch_bounds__(kBlock, EXO_HEAVY_MIN_WAVES) void transit_runs_kern
   __shared__ double s_grun[(TTV && GRAD) ? kWaves : 1][(TTV && GRAD) ? kSeg : 1];
   __shared__ int s_rounds[2 * EXO_MAX_PLANETS];
   __shared__ double lds_acc[kNG + 7][kBlock];
-  // inline enumeration (fin.inl; never with timing tables): the draw's window records, what its lists follow from, the
-  // prefix sums at this block's batch boundaries, the lists' totals
-  constexpr int kInlLists = TTV ? 1 : 2 * EXO_MAX_PLANETS, kInlBatches = kRunMax / kSeg + 2;
-  __shared__ double s_win[TTV ? 1 : EXO_MAX_PLANETS][kWin + 1];
-  __shared__ ListGeom s_geom[kInlLists];
-  __shared__ int s_base[kInlLists][2][kInlBatches];
-  __shared__ int s_total[kInlLists];
-  __shared__ int s_wsum[2][kWaves];
   const int64_t draw = blockIdx.y;
   const int hb = gridDim.x, bx = blockIdx.x;
   stage_constants(sh, params, ld, stencil_dt, stencil_w, n_sub, n_planet, draw, SECONDARY);
   const bool per_planet = flags & EXO_FLAG_PER_PLANET;
   const int n_lists = n_planet * n_ev;
-  const bool inl = !TTV && fin.inl;
   // this block's slice of every list, and the rounds of 256 cadences it will take in all
   auto slice = [&](int K, int& k0, int& k1) {
     k0 = (int)((int64_t)K * bx / hb);
     k1 = (int)((int64_t)K * (bx + 1) / hb);
   };
-  // runs kb .. kb + m - 1 of a list into the LDS tables, with their prefix sums continued from (base_in, base_all):
-  // what the batch staging below otherwise loads from the tables of transit_enum_kernel.  Two runs per thread.
-  auto enum_batch = [&](const ListGeom& g, int kb, int m, int base_in, int base_all) {
-    int li[2] = {0, 0}, la[2] = {0, 0};
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int q = 2 * (int)threadIdx.x + u;
-      if (q < m) {
-        const Run r = list_run(g, t, n_cad, kb + q);
-        s_run[q] = r;
-        li[u] = r.b - r.a;
-        la[u] = r.hi - r.lo;
-      }
-    }
-    int sc_in = li[0] + li[1], sc_all = la[0] + la[1];
-    const int lane = threadIdx.x & 63, wv_ = threadIdx.x >> 6;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const int o_in = __shfl_up(sc_in, d, 64), o_all = __shfl_up(sc_all, d, 64);
-      if (lane >= d) { sc_in += o_in; sc_all += o_all; }
-    }
-    if (lane == 63) { s_wsum[0][wv_] = sc_in; s_wsum[1][wv_] = sc_all; }
-    __syncthreads();
-    int off_in = base_in, off_all = base_all, tot_in = base_in, tot_all = base_all;
-#pragma unroll
-    for (int w = 0; w < kWaves; ++w) {
-      if (w < wv_) { off_in += s_wsum[0][w]; off_all += s_wsum[1][w]; }
-      tot_in += s_wsum[0][w]; tot_all += s_wsum[1][w];
-    }
-    const int q0 = 2 * (int)threadIdx.x;
-    const int ex_in = off_in + sc_in - (li[0] + li[1]), ex_all = off_all + sc_all - (la[0] + la[1]);
-    if (q0 < m) { s_in[q0] = ex_in; s_all[q0] = ex_all; }
-    if (q0 + 1 < m) { s_in[q0 + 1] = ex_in + li[0]; s_all[q0 + 1] = ex_all + la[0]; }
-    if (threadIdx.x == 0) { s_in[m] = tot_in; s_all[m] = tot_all; }
-    __syncthreads();
-  };
-  if (inl) {
-    if ((int)threadIdx.x < kWinLanes * n_planet)
-      window_record(params + (draw * n_planet + (threadIdx.x >> 2)) * EXO_NPAR, flags, (int)(threadIdx.x & 3),
-                    &s_win[TTV ? 0 : (threadIdx.x >> 2)][0]);
-    __syncthreads();
-    if ((int)threadIdx.x < n_lists) {
-      const int p = threadIdx.x / n_ev, ev = threadIdx.x - p * n_ev;
-      const double* wv = &s_win[TTV ? 0 : p][0];
-      const double te_ = n_texp ? texp[0] : 0.0;
-      const double widen = fabs(te_) * exposure_span(flags, stencil_dt, n_sub) * fabs(wv[0]);
-      s_geom[TTV ? 0 : threadIdx.x] = list_geom(wv, ev, n_ev, widen, true, t, n_cad, rl.r_max);
-    }
-    __syncthreads();
-    // every list once through, batch by batch: the prefix sums where this block's batches begin and end, the list's
-    // total and -- first block of the draw -- the tables other kernels and the caller read (finish, residuals, sparse)
-    for (int l = 0; l < n_lists; ++l) {
-      const ListGeom g = s_geom[TTV ? 0 : l];
-      const int64_t list = draw * n_lists + l;
-      const int K = g.K;
-      int k0, k1;
-      slice(K, k0, k1);
-      int base_in = 0, base_all = 0;
-      if (K == 0 && threadIdx.x == 0) {
-        s_total[TTV ? 0 : l] = 0;
-        s_base[TTV ? 0 : l][0][0] = s_base[TTV ? 0 : l][1][0] = 0;
-        if (bx == 0) { rl.pre_in[list * (rl.r_max + 1)] = 0; rl.pre_all[list * (rl.r_max + 1)] = 0; }
-      }
-      for (int b0 = 0; b0 < K; b0 += kSeg) {
-        const int m = (b0 + kSeg < K) ? kSeg : K - b0;
-        enum_batch(g, b0, m, base_in, base_all);
-        // (thread i: the boundary kb = k0 + i kSeg of this block's batches, the last one being k1)
-        if ((int)threadIdx.x < kInlBatches) {
-          int kb = k0 + (int)threadIdx.x * kSeg;
-          kb = kb < k1 ? kb : k1;
-          const bool here = kb >= b0 && (kb < b0 + m || (kb == K && b0 + m == K));
-          if (here) { s_base[TTV ? 0 : l][0][threadIdx.x] = s_in[kb - b0]; s_base[TTV ? 0 : l][1][threadIdx.x] = s_all[kb - b0]; }
-        }
-        if (bx == 0) {
-          for (int q = threadIdx.x; q <= m; q += kBlock) {
-            rl.pre_in[list * (rl.r_max + 1) + b0 + q] = s_in[q];
-            rl.pre_all[list * (rl.r_max + 1) + b0 + q] = s_all[q];
-            if (q < m) rl.runs[list * rl.r_max + b0 + q] = s_run[q];
-          }
-        }
-        base_in = s_in[m]; base_all = s_all[m];
-        if (threadIdx.x == 0 && b0 + m == K) s_total[TTV ? 0 : l] = base_all;
-        __syncthreads();
-      }
-      if (bx == 0 && threadIdx.x == 0) rl.nrun[list] = K;
-    }
-    __syncthreads();
-  }
   if ((int)threadIdx.x < n_lists) {
     const int64_t list = draw * n_lists + threadIdx.x;
     int k0, k1;
-    slice(inl ? s_geom[TTV ? 0 : threadIdx.x].K : rl.nrun[list], k0, k1);
+    slice(rl.nrun[list], k0, k1);
     const int32_t* pall = rl.pre_all + list * (rl.r_max + 1);
-    int rounds = 0, bi = 0;
-    for (int kb = k0; kb < k1; kb += kSeg, ++bi) {
+    int rounds = 0;
+    for (int kb = k0; kb < k1; kb += kSeg) {
       const int ke = (kb + kSeg < k1) ? kb + kSeg : k1;
-      const int len = inl ? s_base[TTV ? 0 : threadIdx.x][1][bi + 1] - s_base[TTV ? 0 : threadIdx.x][1][bi] : pall[ke] - pall[kb];
-      rounds += (len + kBlock - 1) / kBlock;
+      rounds += (pall[ke] - pall[kb] + kBlock - 1) / kBlock;
     }
     s_rounds[threadIdx.x] = rounds;
   }
@@ -2086,19 +1956,16 @@ __global__ __launch_bounds__(kBlock, EXO_HEAVY_MIN_WAVES) void transit_runs_kern
     const TtvGrad tgrad{(GRAD && TTV) ? &lds_acc[0][threadIdx.x] : nullptr, grow, nullptr};
     for (int ev = 0; ev < n_ev; ++ev) {
       const int64_t list = (draw * n_planet + p) * n_ev + ev;
-      const int l_ = TTV ? 0 : p * n_ev + ev;
-      const int K = inl ? s_geom[l_].K : rl.nrun[list];
+      const int K = rl.nrun[list];
       const Run* __restrict__ runs = rl.runs + list * rl.r_max;
       const int32_t* __restrict__ pin = rl.pre_in + list * (rl.r_max + 1);
       const int32_t* __restrict__ pall = rl.pre_all + list * (rl.r_max + 1);
       int k0, k1;
       slice(K, k0, k1);
-      int bi = 0;
-      for (int kb = k0; kb < k1; kb += kSeg, ++bi) {
+      for (int kb = k0; kb < k1; kb += kSeg) {
         const int m = (kb + kSeg < k1) ? kSeg : k1 - kb;
         __syncthreads();   // (the previous batch is done with the tables)
-        if (inl) enum_batch(s_geom[l_], kb, m, s_base[l_][0][bi], s_base[l_][1][bi]);
-        for (int q = threadIdx.x; q <= m && !inl; q += kBlock) {
+        for (int q = threadIdx.x; q <= m; q += kBlock) {
           s_in[q] = pin[kb + q];
           s_all[q] = pall[kb + q];
           if (q < m) s_run[q] = runs[kb + q];
@@ -2197,7 +2064,7 @@ __global__ __launch_bounds__(kBlock, EXO_HEAVY_MIN_WAVES) void transit_runs_kern
           }
         }
       }
-      vbase += inl ? s_total[l_] : pall[K];
+      vbase += pall[K];
     }
     if (GRAD && TTV) {
       // every sample's t_periastron term went to its bin; the planet's total is in G_PAD
@@ -2496,9 +2363,6 @@ inline ScanPlan scan_plan(uint32_t flags, int bpd, int64_t n_draw, int n_planet,
 // dirty zero-fill lines back before it returns (heavy kernel 54 -> 147 us at 128 draws, 102 -> 225 us on C4 at 64)
 #define EXO_RUNS_FOLD_FINISH 1
 #endif
-#ifndef EXO_RUNS_INLINE_ENUM
-#define EXO_RUNS_INLINE_ENUM 1   // (0: EXO_FLAG_SORTED sweeps launch the window and enumeration kernels like any other)
-#endif
 #ifndef EXO_RUNS_TARGET_BLOCKS
 #define EXO_RUNS_TARGET_BLOCKS 512
 #endif
@@ -2589,17 +2453,13 @@ inline int launch_runs_sweep(const double* t, int64_t n_cad, const double* texp,
   const bool grad = gflux != nullptr || chi2;
   const int n_ev = secondary ? 2 : 1;
   const dim3 block(kBlock);
-  const bool has_ttv = ttv && ttv->edges;
-  // EXO_FLAG_SORTED (the caller vouches for non-decreasing times): nothing to check, and -- without timing tables -- the
-  // heavy kernel's blocks work out their draw's windows and runs themselves: no window / enumeration launch
-  const bool inl = (flags & EXO_FLAG_SORTED) && !has_ttv && EXO_RUNS_INLINE_ENUM;
-  if (!inl) {
+  {
     const int64_t n_rec = n_draw * n_planet;
     hipLaunchKernelGGL(transit_window_kernel, dim3((unsigned)((n_rec * kWinLanes + kBlock - 1) / kBlock + w.n_sorted)), block, 0, st,
                        params, n_rec, flags, w.windows, t, n_cad, w.sorted, w.done, n_draw);
   }
-  if (inl) {
-  } else if (has_ttv)
+  const bool has_ttv = ttv && ttv->edges;
+  if (has_ttv)
     hipLaunchKernelGGL(transit_enum_ttv_kernel, dim3((unsigned)(n_draw * n_planet)), dim3(64), 0, st, t, n_cad, texp, n_texp,
                        stencil_dt, (int)n_sub, flags, w.windows, w.sorted, w.n_sorted, w.rl, *ttv);
   else
@@ -2614,8 +2474,7 @@ inline int launch_runs_sweep(const double* t, int64_t n_cad, const double* texp,
   // a draw that is one block's work is finished by that block (gradients from its partials, values to their cadences):
   // no transit_finish_kernel launch
   const bool fold = EXO_RUNS_FOLD_FINISH == 2 || (EXO_RUNS_FOLD_FINISH == 1 && w.hb == 1);
-  const FinishArgs fin{gparams, gld, chi2 ? chi2->chi2 : flux_dot, fold ? 1 : 0, w.done, inl ? 1 : 0},
-      no_fin{nullptr, nullptr, nullptr, 0, nullptr, inl ? 1 : 0};
+  const FinishArgs fin{gparams, gld, chi2 ? chi2->chi2 : flux_dot, fold ? 1 : 0, w.done}, no_fin{nullptr, nullptr, nullptr, 0, nullptr};
 #define EXO_LAUNCH_RUNS(G, GFLUX, GSP, VALS, VCAD, FILL, PARTIAL, FIN)                                                    \
   if (secondary)                                                                                                          \
     launch_runs_kernel<G, true>(ldelay, hgrid, st, t, n_cad, texp, n_texp, stencil_dt, stencil_w, n_sub, params, ld,      \

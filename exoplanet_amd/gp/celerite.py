@@ -129,16 +129,26 @@ def celerite_loglike(t, resid, diag, coef_real, coef_complex, obs=None, pair_kin
                                   None if pair_kind is None else pair_kind.detach(), n_chunks)
 
 
+_SORTED = {}
 
 
 def _known_sorted(t):
-    """True if ``t`` is non-decreasing (ops.known_sorted: looked at once per tensor and version).  Inside a hipGraph
-    capture an unseen tensor cannot be looked at: the warm-up runs before the capture did."""
-    from ..ops import known_sorted
-
-    if t.is_cuda and torch.cuda.is_current_stream_capturing():
-        return True
-    return known_sorted(t)
+    """True if ``t`` is non-decreasing.  A device tensor is looked at once (one host
+    synchronisation) and remembered by (storage, length, version): a sampler calls ``compute`` with
+    the same time array every step, and a step that is being captured into a hipGraph must not
+    synchronise."""
+    if not t.is_cuda:
+        return not bool((t[1:] < t[:-1]).any())
+    key = (t.data_ptr(), t.numel(), t._version, str(t.device))
+    ok = _SORTED.get(key)
+    if ok is None:
+        if torch.cuda.is_current_stream_capturing():
+            return True   # cannot look during a capture; the warm-up runs before it did
+        ok = not bool((t[1:] < t[:-1]).any())
+        if len(_SORTED) > 64:
+            _SORTED.clear()
+        _SORTED[key] = ok
+    return ok
 
 
 class GaussianProcess:

@@ -29,7 +29,6 @@ PACK_CIRCULAR = 8
 FLAG_EXACT_SCAN = 16
 FLAG_SPARSE = 32
 FLAG_LIGHT_DELAY = 64
-FLAG_SORTED = 128
 NIN = 10
 (IN_PERIOD, IN_T0, IN_B, IN_ECC, IN_OMEGA, IN_R, IN_MSTAR, IN_RSTAR, IN_MPLANET, IN_SBR) = range(10)
 MAX_PLANETS = 16
@@ -55,34 +54,6 @@ def _dev(x, name):
 
 def _ptr(x):
     return 0 if x is None else x.data_ptr()
-
-
-_SORTED = {}
-
-
-def known_sorted(t):
-    """True if ``t`` is non-decreasing (and free of NaN).  A device tensor is looked at once (one host synchronisation)
-    and remembered by object and version -- the entry keeps the tensor alive, so its address cannot be handed to another
-    series: a sampler calls with the same time array every step, and a step that is being captured into a hipGraph must
-    not synchronise.  Inside a capture an unseen tensor is NOT vouched for (False)."""
-    if not t.is_cuda:
-        return bool((t[1:] >= t[:-1]).all())
-    key = (id(t), t._version)
-    hit = _SORTED.get(key)
-    if hit is not None and hit[1] is t:
-        return hit[0]
-    if torch.cuda.is_current_stream_capturing():
-        return False
-    ok = bool((t[1:] >= t[:-1]).all()) if t.numel() > 1 else True
-    if len(_SORTED) > 64:
-        _SORTED.clear()
-    _SORTED[key] = (ok, t)
-    return ok
-
-
-def _sorted_flag(t):
-    """FLAG_SORTED if the time array is known to be sorted: the sweeps then skip their own check and two launches"""
-    return FLAG_SORTED if (t.numel() > 0 and known_sorted(t)) else 0
 
 
 # ------------------------------------------------------------------------------
@@ -251,7 +222,6 @@ class _TransitFlux(torch.autograd.Function):
         N = t.numel()
         shape = (D, N, P) if flags & FLAG_PER_PLANET else (D, N)
         flux = torch.empty(shape, dtype=torch.float64, device=t.device)
-        flags = flags | _sorted_flag(t)
         lib = _lib.load()
         nbytes = lib.exo_transit_flux_workspace_bytes(N, D, P)
         ws = torch.empty(max(nbytes // 8 + 1, 1), dtype=torch.float64, device=t.device)
@@ -286,7 +256,6 @@ class _TransitFlux(torch.autograd.Function):
 
 def _vjp(t, texp, n_texp, sdt, sw, n_sub, params, ld, D, P, flags, gflux, want_flux, events=(None, None), ttv=None):
     N = t.numel()
-    flags = flags | _sorted_flag(t)
     gflux = _dev(gflux, "gflux")
     shape = (D, N, P) if flags & FLAG_PER_PLANET else (D, N)
     if tuple(gflux.shape) != shape:
@@ -411,7 +380,6 @@ class _TransitChi2(torch.autograd.Function):
         t, texp, n_texp, sdt, sw, n_sub, params, ld, D, P = _transit_args(t, texp, stencil_dt, stencil_w, params, ld, flags)
         edges, shift, n_edge = _ttv_args(None if ttv_edges is None else (ttv_edges, ttv_shift), D, P)
         N = t.numel()
-        flags = flags | _sorted_flag(t)
         obs = _dev(obs, "obs")
         ivar = _dev(ivar, "ivar").reshape(-1)
         if tuple(obs.shape) != (N,):
@@ -560,7 +528,6 @@ def transit_flux_sparse(t, params, ld, gflux=None, texp=None, stencil_dt=None, s
     edges, shift, n_edge = _ttv_args(ttv, D, P)
     if n_edge and flags & FLAG_SECONDARY:
         raise ValueError("the sparse sweep takes timing tables for transits only")
-    flags = flags | _sorted_flag(t)
     N = t.numel()
     lib = _lib.load()
     nbytes = lib.exo_transit_flux_workspace_bytes(N, D, P)

@@ -120,10 +120,6 @@ int exo_contact_points_f64(const double* a, const double* e, const double* cosw,
                                    position, velocity and acceleration at t; a second Kepler solve per sample, in
                                    the same kernel.  Needs slot EXO_P_CLIGHT and the VALUE of EXO_P_SINI (both get
                                    cotangents then).  Run-enumeration sweeps only (see EXO_FLAG_SPARSE).        */
-#define EXO_FLAG_SORTED 128u     /* the caller vouches that t is non-decreasing (and free of NaN): the sweep does not
-                                   check it, and -- run-enumeration sweeps without timing tables -- the heavy kernel
-                                   works out each draw's windows and runs itself: two launches fewer per sweep, same
-                                   results bit for bit.  With unsorted t under this flag cadences are missed.      */
 
 #define EXO_MAX_PLANETS 16
 #define EXO_MAX_SUBEXP 63

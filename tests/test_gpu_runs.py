@@ -173,57 +173,3 @@ def test_folded_finish_equals_the_separate_last_kernel(dev, planets):
     assert same_flux(big[0][:8], small[0])
     for a, b in zip(big[1:], small[1:]):
         assert float((a[:8] - b).abs().max()) <= 1e-12 * float(b.abs().max())
-
-
-@pytest.mark.parametrize("case", ["one_planet", "three_planets_secondary", "many_windows", "unbounded_window", "big_batch"])
-def test_sorted_flag_inline_enumeration_is_bit_identical(dev, case, monkeypatch):
-    """EXO_FLAG_SORTED: the heavy kernel works out windows and runs itself (no window / enumeration launch).  Same run
-    tables, same batches, same waves as with the two kernels in front: identical bits everywhere -- dense flux,
-    gradients, sparse output and its tables, the white-noise likelihood; lists of more than 512 windows (several
-    batches), a list that degenerates to every cadence, draws shared by several blocks and draws of one block"""
-    from exoplanet_amd import ops
-
-    rng = np.random.default_rng(91)
-    secondary = case == "three_planets_secondary"
-    D, N = (600, 4001) if case == "big_batch" else (5, 30_011)
-    t = np.arange(N) * (10.0 / 1440.0) + 0.25
-    rec, c = system(rng, D, 3 if secondary else 1, secondary)
-    if case == "many_windows":                      # ~1400 transits in the series: three batches of runs per list
-        orbit = P.KeplerianOrbit(period=0.15, t0=0.05, b=0.2)
-        rec = np.repeat(make_record(orbit, np.array([0.1])), D, 0) * (1 + 1e-4 * rng.normal(size=(D, 1, P.NPAR)))
-    if case == "unbounded_window":                  # a/R so small that the first bound does not exist: every cadence
-        orbit = P.KeplerianOrbit(period=1.3, t0=0.4, b=0.1)
-        rec = np.repeat(make_record(orbit, np.array([0.3])), D, 0)
-        rec[..., P.P_AOR] = 1.25                   # (1 + r) / (a/R) > 1
-        t = t[:3001]
-        N = t.size
-    flags = ops.FLAG_SECONDARY if secondary else 0
-    g = rng.normal(size=(D, N))
-    obs = 2e-4 * rng.normal(size=N)
-    ivar = np.array([1.0 / 4e-8])
-    sdt, sw = P.exposure_stencil(3, 0)
-    out = {}
-    for inline in (True, False):
-        if not inline:
-            monkeypatch.setattr(ops, "_sorted_flag", lambda t_: 0)
-        tt = T(t, dev)
-        assert bool(ops._sorted_flag(tt)) == inline
-        res = []
-        for kw in ({}, dict(texp=T([0.01], dev), stencil_dt=T(sdt, dev), stencil_w=T(sw, dev))):
-            res += list(ops.transit_flux_value_and_vjp(tt, T(rec, dev), T(c, dev), T(g, dev), flags=flags, **kw))
-            res.append(ops.transit_flux(tt, T(rec, dev), T(c, dev), flags=flags, **kw))
-            sp, gp, gl, dot = ops.transit_flux_sparse(tt, T(rec, dev), T(c, dev), gflux=T(g, dev), flags=flags, **kw)
-            res += [gp, gl, dot, sp.nrun.clone(), torch.as_tensor(sp.to_dense(per_planet=True)), torch.tensor(float(sp.n_solved()))]
-            K = int(sp.nrun.max())
-            rt, ct = T(rec, dev).requires_grad_(True), T(c, dev).requires_grad_(True)
-            chi2 = ops.transit_chi2(tt, rt, ct, T(obs, dev), T(ivar, dev), flags=flags, **kw)
-            chi2.sum().backward()
-            res += [chi2.detach(), rt.grad, ct.grad]
-        out[inline] = res
-        if case == "many_windows":
-            assert K > 1024
-        if case == "unbounded_window":
-            assert sp.n_solved() == D * N
-    assert float(out[True][0].min()) < -1e-4
-    for i, (a, b) in enumerate(zip(out[True], out[False])):
-        assert a.shape == b.shape and torch.equal(torch.nan_to_num(a.double()), torch.nan_to_num(b.double())), (case, i)
