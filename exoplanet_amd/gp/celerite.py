@@ -133,21 +133,22 @@ _SORTED = {}
 
 
 def _known_sorted(t):
-    """True if ``t`` is non-decreasing.  A device tensor is looked at once (one host
-    synchronisation) and remembered by (storage, length, version): a sampler calls ``compute`` with
-    the same time array every step, and a step that is being captured into a hipGraph must not
-    synchronise."""
+    """True if ``t`` is non-decreasing.  A device tensor is looked at once (one host synchronisation) and remembered
+    by object and version -- the entry keeps the tensor alive, so its address cannot be handed to another series
+    meanwhile: a sampler calls ``compute`` with the same time array every step, and a step that is being captured
+    into a hipGraph must not synchronise."""
     if not t.is_cuda:
         return not bool((t[1:] < t[:-1]).any())
-    key = (t.data_ptr(), t.numel(), t._version, str(t.device))
-    ok = _SORTED.get(key)
-    if ok is None:
-        if torch.cuda.is_current_stream_capturing():
-            return True   # cannot look during a capture; the warm-up runs before it did
-        ok = not bool((t[1:] < t[:-1]).any())
-        if len(_SORTED) > 64:
-            _SORTED.clear()
-        _SORTED[key] = ok
+    key = (id(t), t._version)
+    hit = _SORTED.get(key)
+    if hit is not None and hit[1] is t:
+        return hit[0]
+    if torch.cuda.is_current_stream_capturing():
+        return True   # cannot look during a capture; the warm-up runs before it did
+    ok = not bool((t[1:] < t[:-1]).any())
+    if len(_SORTED) > 64:
+        _SORTED.clear()
+    _SORTED[key] = (ok, t)
     return ok
 
 
