@@ -98,7 +98,7 @@ _SIGNATURES = {
                                           _c_dp, _c_dp]),
     "exo_ttv_tables_vjp_f64": (ctypes.c_int, [_c_dp, _i64, _i64, _c_dp, _i64, _i64, _c_dp, _c_dp, _c_dp, _i64, _i32, _i32, _c_dp,
                                               _c_dp, _c_dp, _c_dp]),
-    "exo_nuts_leaf_f64": (ctypes.c_int, [_c_dp, _i64, _i32, _i32, ctypes.c_double, _i32, _c_dp]),
+    "exo_nuts_f64": (ctypes.c_int, [_c_dp, _i64, _i32, _i32, ctypes.c_double, _i32, _c_dp]),
     "exo_sho_coefficients_f64": (ctypes.c_int, [_c_dp, _c_dp, _c_dp, _u32, ctypes.c_double, _i64, _c_dp, _c_dp, _c_dp]),
     "exo_sho_coefficients_vjp_f64": (ctypes.c_int, [_c_dp, _c_dp, _c_dp, _u32, ctypes.c_double, _i64, _c_dp, _c_dp, _c_dp,
                                                     _c_dp, _c_dp]),

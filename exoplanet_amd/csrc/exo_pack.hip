@@ -592,37 +592,91 @@ int exo_ttv_tables_vjp_f64(const double* period, int64_t period_draw_stride, int
 }  // extern "C"
 
 // ---------------------------------------------------------------------------------------------
-// NUTS, one leaf of the sub-tree a batch of chains is building (exoplanet_amd/sampling.py, NUTS._leaf_update restated:
-// that torch version is what runs on the CPU and what tests/test_gpu_sampling.py checks this against).  The tree state
-// lives in (chains, parameters) arrays on the device; per leaf the torch version is ~35 small launches, here two:
-//   begin:  half kick and drift of the moving end            p_half = p + eps g / 2,  q' = q + eps p_half / m
-//   update: second half kick with the gradient at q', energy error, divergence, multinomial candidate, momentum sums,
-//           checkpoint write (even leaves) / turning checks (odd leaves), which chains go on.
-// One thread per chain (a chain's row is a few to a few dozen doubles).
+// NUTS on (chains, parameters) arrays that stay on the device (exoplanet_amd/sampling.py: NUTS.step restated -- that
+// torch version is what runs on the CPU and what tests/test_gpu_sampling.py checks this against).  A transition grows
+// every chain's trajectory by doublings; a doubling is
+//   phase 2  begin:  each chain draws its direction, the sub-tree starts at that end of its trajectory
+//   per leaf phase 0: half kick and drift of the moving end     p_half = p + eps g / 2,  q' = q + eps p_half / m
+//            (the caller evaluates log-density and gradient at q')
+//            phase 1: second half kick, energy error, divergence, multinomial candidate, momentum sums, checkpoint
+//            write (even leaves) / generalised turning checks (odd leaves), which chains go on
+//   phase 3  merge:  a valid sub-tree joins the trajectory (biased progressive sampling of the proposal, the new end,
+//            momentum sum, weights, the trajectory's own turning check)
+// -- four launches of these kernels where the torch statement is ~35 per leaf and ~45 per doubling.  One thread per
+// chain (a chain's row is a few to a few dozen doubles).  The leaf index lives on the device (phase 0 counts it up),
+// so that the captured graph of a leaf needs nothing from the host; the random numbers of a doubling are one
+// [2 + leaves][chains] array: row 0 directions, row 1 the merge, row 2 + n leaf n.
 // ---------------------------------------------------------------------------------------------
 namespace {
 
-struct NutsLeaf {
-  double *qe, *pe, *ge;              // [D][n]   the moving end of the sub-tree
-  const double* eps;                 // [D]      signed step size
+struct NutsTree {
+  // the sub-tree being built
+  double *qe, *pe, *ge;              // [D][n]   its moving end
+  double* eps;                       // [D]      signed step size
   uint8_t* on;                       // [D]      still adding leaves (torch.bool)
   const double* H0;                  // [D]
   double *logw, *psum, *sq, *sg, *slp;
   uint8_t *turn, *div;
   double *acc, *accn;
   double *ckp, *cks;                 // [S][D][n] checkpoints: momentum of a sub-sub-tree's first leaf, momentum sum up to it
-  const double* u;                   // [D]      uniform random numbers of this leaf
-  const uint8_t *wsel, *csel;        // [S]      slot written (even leaf) / slots checked (odd leaf)
   const double* mass;                // [D][n]
   double *qn, *ph;                   // [D][n]   scratch: position and half-kicked momentum of the new leaf
   const double *gn, *lpn;            // [D][n], [D]  gradient and log-density at qn
+  // the trajectory
+  double *ql, *pl, *gl, *qr, *pr, *gr, *tsum;   // [D][n] its ends, the sum of its momenta
+  double* logW;                      // [D]
+  double *propq, *propg, *proplp;    // the proposal
+  uint8_t *active, *diverged, *going;
+  double* depth;
+  const double* eps_abs;             // [D]
+  const double* R;                   // [2 + leaves][D] uniform random numbers of the doubling
+  int32_t* leaf;                     // [1] index of the current leaf within the sub-tree
   int64_t D;
   int n, S;
   double max_energy_error;
 };
+constexpr int kNutsPtrs = 40;
 
-__global__ __launch_bounds__(64) void nuts_leaf_begin_kernel(NutsLeaf a) {
+__device__ __forceinline__ double log_add_exp(double x, double y) {
+  const double m = fmax(x, y);
+  if (!(m > -__builtin_inf())) return m;       // both -inf (or NaN)
+  return m + log1p(exp(-fabs(x - y)));
+}
+// generalised U-turn: the ends no longer move apart along rho = sum of momenta - half of each end
+__device__ __forceinline__ bool nuts_turning(const double* pl, const double* pr, const double* sum, const double* mass, int n) {
+  double left = 0.0, right = 0.0;
+  for (int i = 0; i < n; ++i) {
+    const double rho = (sum[i] - 0.5 * (pl[i] + pr[i])) / mass[i];
+    left = fma(pl[i], rho, left);
+    right = fma(pr[i], rho, right);
+  }
+  return (left <= 0.0) || (right <= 0.0);
+}
+
+__global__ __launch_bounds__(64) void nuts_begin_doubling_kernel(NutsTree a) {
   const int64_t d = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  if (d == 0) *a.leaf = -1;
+  if (d >= a.D) return;
+  const bool right = a.R[d] < 0.5;
+  a.going[d] = right ? 1 : 0;
+  a.eps[d] = right ? a.eps_abs[d] : -a.eps_abs[d];
+  const int64_t row = d * a.n;
+  const double *q = right ? a.qr : a.ql, *p = right ? a.pr : a.pl, *g = right ? a.gr : a.gl;
+  for (int i = 0; i < a.n; ++i) {
+    a.qe[row + i] = q[row + i]; a.pe[row + i] = p[row + i]; a.ge[row + i] = g[row + i];
+    a.sq[row + i] = q[row + i]; a.sg[row + i] = g[row + i];
+    a.psum[row + i] = 0.0;
+  }
+  a.slp[d] = a.proplp[d];
+  a.on[d] = a.active[d];
+  a.logw[d] = -__builtin_inf();
+  a.turn[d] = 0;
+  a.div[d] = 0;
+}
+
+__global__ __launch_bounds__(64) void nuts_leaf_begin_kernel(NutsTree a) {
+  const int64_t d = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  if (d == 0) *a.leaf += 1;                      // (nothing in this launch reads it)
   if (d >= a.D) return;
   const double e = a.eps[d];
   for (int i = 0; i < a.n; ++i) {
@@ -633,16 +687,10 @@ __global__ __launch_bounds__(64) void nuts_leaf_begin_kernel(NutsLeaf a) {
   }
 }
 
-__device__ __forceinline__ double log_add_exp(double x, double y) {
-  const double m = fmax(x, y);
-  if (!(m > -__builtin_inf())) return m;       // both -inf (or NaN)
-  return m + log1p(exp(-fabs(x - y)));
-}
-
-__global__ __launch_bounds__(64) void nuts_leaf_update_kernel(NutsLeaf a) {
+__global__ __launch_bounds__(64) void nuts_leaf_update_kernel(NutsTree a) {
   const int64_t d = (int64_t)blockIdx.x * 64 + threadIdx.x;
   if (d >= a.D || !a.on[d]) return;              // (a chain that has stopped carries its state along unchanged)
-  const int n = a.n;
+  const int n = a.n, leaf = *a.leaf;
   const int64_t row = d * n, plane = a.D * (int64_t)n;
   const double e = a.eps[d];
   double kin = 0.0;
@@ -663,31 +711,34 @@ __global__ __launch_bounds__(64) void nuts_leaf_update_kernel(NutsLeaf a) {
   if (!div) {
     // multinomial sampling within the sub-tree: the new leaf replaces the candidate with probability w / W
     const double new_logw = log_add_exp(a.logw[d], -dH);
-    if (log(a.u[d]) < (-dH - new_logw)) {
+    if (log(a.R[(int64_t)(2 + leaf) * a.D + d]) < (-dH - new_logw)) {
       for (int i = 0; i < n; ++i) { a.sq[row + i] = a.qn[row + i]; a.sg[row + i] = a.gn[row + i]; }
       a.slp[d] = lp;
     }
     a.logw[d] = new_logw;
     for (int i = 0; i < n; ++i) a.psum[row + i] += a.pe[row + i];
-    // turning checks against the checkpoints named by csel, then this leaf's own checkpoint (wsel)
-    for (int s = 0; s < a.S; ++s) {
-      if (!a.csel[s]) continue;
-      const double* __restrict__ cp = a.ckp + s * plane + row;
-      const double* __restrict__ cs = a.cks + s * plane + row;
-      double left = 0.0, right = 0.0;
-      for (int i = 0; i < n; ++i) {
-        const double pn = a.pe[row + i];
-        const double rho = ((a.psum[row + i] - cs[i] + cp[i]) - 0.5 * (cp[i] + pn)) / a.mass[row + i];
-        left = fma(cp[i], rho, left);
-        right = fma(pn, rho, right);
+    // Leaf `leaf` of the sub-tree: even -- its momentum and the sum so far go to checkpoint slot popcount(leaf >> 1);
+    // odd -- it closes the sub-sub-trees of 2, 4, ... leaves that end here, one per trailing 1 bit, whose first
+    // leaves sit in the slots hi, hi - 1, ...
+    const int hi = __popc((unsigned)(leaf >> 1));
+    if (leaf & 1) {
+      const int ones = __ffs(~(unsigned)leaf) - 1;          // trailing 1 bits
+      for (int s = hi; s > hi - ones; --s) {
+        const double* __restrict__ cp = a.ckp + s * plane + row;
+        const double* __restrict__ cs = a.cks + s * plane + row;
+        double left = 0.0, right = 0.0;
+        for (int i = 0; i < n; ++i) {
+          const double pn = a.pe[row + i];
+          const double rho = ((a.psum[row + i] - cs[i] + cp[i]) - 0.5 * (cp[i] + pn)) / a.mass[row + i];
+          left = fma(cp[i], rho, left);
+          right = fma(pn, rho, right);
+        }
+        turn = turn || (left <= 0.0) || (right <= 0.0);
       }
-      turn = turn || (left <= 0.0) || (right <= 0.0);
-    }
-    for (int s = 0; s < a.S; ++s) {
-      if (!a.wsel[s]) continue;
+    } else {
       for (int i = 0; i < n; ++i) {
-        a.ckp[s * plane + row + i] = a.pe[row + i];
-        a.cks[s * plane + row + i] = a.psum[row + i];
+        a.ckp[hi * plane + row + i] = a.pe[row + i];
+        a.cks[hi * plane + row + i] = a.psum[row + i];
       }
     }
   }
@@ -696,31 +747,56 @@ __global__ __launch_bounds__(64) void nuts_leaf_update_kernel(NutsLeaf a) {
   a.on[d] = (!div && !turn) ? 1 : 0;
 }
 
+__global__ __launch_bounds__(64) void nuts_merge_kernel(NutsTree a) {
+  const int64_t d = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  if (d >= a.D || !a.active[d]) return;
+  const int n = a.n;
+  const int64_t row = d * n;
+  a.depth[d] += 1.0;
+  if (a.div[d]) a.diverged[d] = 1;
+  if (a.turn[d] || a.div[d]) { a.active[d] = 0; return; }      // the sub-tree is not valid: the trajectory ends as it was
+  // biased progressive sampling between the old trajectory and the new half
+  if (log(a.R[a.D + d]) < (a.logw[d] - a.logW[d])) {
+    for (int i = 0; i < n; ++i) { a.propq[row + i] = a.sq[row + i]; a.propg[row + i] = a.sg[row + i]; }
+    a.proplp[d] = a.slp[d];
+  }
+  double *q = a.going[d] ? a.qr : a.ql, *p = a.going[d] ? a.pr : a.pl, *g = a.going[d] ? a.gr : a.gl;
+  for (int i = 0; i < n; ++i) {
+    q[row + i] = a.qe[row + i]; p[row + i] = a.pe[row + i]; g[row + i] = a.ge[row + i];
+    a.tsum[row + i] += a.psum[row + i];
+  }
+  a.logW[d] = log_add_exp(a.logW[d], a.logw[d]);
+  a.active[d] = nuts_turning(a.pl + row, a.pr + row, a.tsum + row, a.mass + row, n) ? 0 : 1;
+}
+
 }  // namespace
 
 extern "C" {
 
-// ptrs: 24 device pointers in the order of NutsLeaf's pointer members (qe, pe, ge, eps, on, H0, logw, psum, sq, sg, slp,
-// turn, div, acc, accn, ckp, cks, u, wsel, csel, mass, qn, ph, gn) followed by lpn: 25 in all; phase 0 = begin, 1 = update
-int exo_nuts_leaf_f64(const void* const* ptrs, int64_t n_chain, int32_t n_param, int32_t n_slot, double max_energy_error,
-                      int32_t phase, void* stream) {
-  if (!ptrs || n_chain < 0 || n_param < 1 || n_slot < 1 || (phase != 0 && phase != 1)) return EXO_ERR_INVALID_ARGUMENT;
+// ptrs: kNutsPtrs device pointers in the order of NutsTree's pointer members
+int exo_nuts_f64(const void* const* ptrs, int64_t n_chain, int32_t n_param, int32_t n_slot, double max_energy_error,
+                 int32_t phase, void* stream) {
+  if (!ptrs || n_chain < 0 || n_param < 1 || n_slot < 1 || phase < 0 || phase > 3) return EXO_ERR_INVALID_ARGUMENT;
   if (n_chain == 0) return EXO_OK;
-  for (int k = 0; k < 25; ++k)
+  for (int k = 0; k < kNutsPtrs; ++k)
     if (!ptrs[k]) return EXO_ERR_INVALID_ARGUMENT;
-  NutsLeaf a;
+  NutsTree a;
   int k = 0;
-  a.qe = (double*)ptrs[k++]; a.pe = (double*)ptrs[k++]; a.ge = (double*)ptrs[k++]; a.eps = (const double*)ptrs[k++];
-  a.on = (uint8_t*)ptrs[k++]; a.H0 = (const double*)ptrs[k++]; a.logw = (double*)ptrs[k++]; a.psum = (double*)ptrs[k++];
-  a.sq = (double*)ptrs[k++]; a.sg = (double*)ptrs[k++]; a.slp = (double*)ptrs[k++]; a.turn = (uint8_t*)ptrs[k++];
-  a.div = (uint8_t*)ptrs[k++]; a.acc = (double*)ptrs[k++]; a.accn = (double*)ptrs[k++]; a.ckp = (double*)ptrs[k++];
-  a.cks = (double*)ptrs[k++]; a.u = (const double*)ptrs[k++]; a.wsel = (const uint8_t*)ptrs[k++];
-  a.csel = (const uint8_t*)ptrs[k++]; a.mass = (const double*)ptrs[k++]; a.qn = (double*)ptrs[k++]; a.ph = (double*)ptrs[k++];
-  a.gn = (const double*)ptrs[k++]; a.lpn = (const double*)ptrs[k++];
+  auto dp = [&]() { return (double*)ptrs[k++]; };
+  auto bp = [&]() { return (uint8_t*)ptrs[k++]; };
+  a.qe = dp(); a.pe = dp(); a.ge = dp(); a.eps = dp(); a.on = bp(); a.H0 = dp(); a.logw = dp(); a.psum = dp(); a.sq = dp();
+  a.sg = dp(); a.slp = dp(); a.turn = bp(); a.div = bp(); a.acc = dp(); a.accn = dp(); a.ckp = dp(); a.cks = dp();
+  a.mass = dp(); a.qn = dp(); a.ph = dp(); a.gn = dp(); a.lpn = dp();
+  a.ql = dp(); a.pl = dp(); a.gl = dp(); a.qr = dp(); a.pr = dp(); a.gr = dp(); a.tsum = dp(); a.logW = dp();
+  a.propq = dp(); a.propg = dp(); a.proplp = dp(); a.active = bp(); a.diverged = bp(); a.going = bp(); a.depth = dp();
+  a.eps_abs = dp(); a.R = dp(); a.leaf = (int32_t*)ptrs[k++];
   a.D = n_chain; a.n = n_param; a.S = n_slot; a.max_energy_error = max_energy_error;
   const dim3 grid((unsigned)((n_chain + 63) / 64)), block(64);
-  if (phase == 0) hipLaunchKernelGGL(nuts_leaf_begin_kernel, grid, block, 0, (hipStream_t)stream, a);
-  else hipLaunchKernelGGL(nuts_leaf_update_kernel, grid, block, 0, (hipStream_t)stream, a);
+  hipStream_t st = (hipStream_t)stream;
+  if (phase == 0) hipLaunchKernelGGL(nuts_leaf_begin_kernel, grid, block, 0, st, a);
+  else if (phase == 1) hipLaunchKernelGGL(nuts_leaf_update_kernel, grid, block, 0, st, a);
+  else if (phase == 2) hipLaunchKernelGGL(nuts_begin_doubling_kernel, grid, block, 0, st, a);
+  else hipLaunchKernelGGL(nuts_merge_kernel, grid, block, 0, st, a);
   return launch_status();
 }
 

@@ -230,42 +230,48 @@ class NUTS(_ChainSampler):
         # the tree lives on ONE (D, n) array per quantity -- all parameter blocks of a chain side by side -- so that a
         # mask, a dot product or a checkpoint is one launch whatever the number of blocks; logp_fn sees views of it
         self._mflat = self._flat(self.mass)
-        # control rows of the iterative tree building: leaf n of a sub-tree stores its momentum in slot wsel (n even) or
-        # closes the sub-sub-trees whose first leaves sit in the slots csel (n odd)
-        S = max(self.max_depth - 1, 1)
-        n_leaf = 2 ** (self.max_depth - 1)
-        W = torch.zeros(n_leaf, S, dtype=torch.bool)
-        C = torch.zeros(n_leaf, S, dtype=torch.bool)
-        for n in range(n_leaf):
-            if n % 2 == 0:
-                W[n, bin(n >> 1).count("1")] = True
-            else:
-                lo, hi = _ckpt_range(n)
-                C[n, lo:hi + 1] = True
-        self._W, self._C = W.to(dev), C.to(dev)
+        S = self._S = max(self.max_depth - 1, 1)
         q = self._flat(self.params)
         zq, zd = torch.zeros_like(q), torch.zeros(self.D, dtype=q.dtype, device=dev)
         zb = torch.zeros(self.D, dtype=torch.bool, device=dev)
-        # the state of the sub-tree being built (static buffers: the captured leaf update works on them in place)
+        n_rows = 2 + 2 ** (self.max_depth - 1)
+        # static buffers: the sub-tree being built, the trajectory, the doubling's random numbers (row 0 directions, row 1
+        # the merge, row 2 + k leaf k), the index of the current leaf
         self._st = dict(qe=q.clone(), pe=zq.clone(), ge=zq.clone(), eps=self.eps.clone(), on=zb.clone(), H0=zd.clone(),
                         logw=zd.clone(), psum=zq.clone(), sq=zq.clone(), sg=zq.clone(), slp=zd.clone(), turn=zb.clone(),
-                        div=zb.clone(), acc=zd.clone(), accn=zd.clone(), ckp=torch.zeros((S,) + tuple(q.shape), dtype=q.dtype, device=dev),
-                        cks=torch.zeros((S,) + tuple(q.shape), dtype=q.dtype, device=dev), u=zd.clone() + 0.5,
-                        wsel=self._W[0].clone(), csel=self._C[0].clone())
+                        div=zb.clone(), acc=zd.clone(), accn=zd.clone(),
+                        ckp=torch.zeros((S,) + tuple(q.shape), dtype=q.dtype, device=dev),
+                        cks=torch.zeros((S,) + tuple(q.shape), dtype=q.dtype, device=dev),
+                        qn=zq.clone(), ph=zq.clone(), gn=zq.clone(), lpn=zd.clone(),
+                        ql=zq.clone(), pl=zq.clone(), gl=zq.clone(), qr=zq.clone(), pr=zq.clone(), gr=zq.clone(), tsum=zq.clone(),
+                        logW=zd.clone(), propq=zq.clone(), propg=zq.clone(), proplp=zd.clone(), active=zb.clone(),
+                        diverged=zb.clone(), going=zb.clone(), depth=zd.clone(),
+                        R=torch.full((n_rows, self.D), 0.5, dtype=q.dtype, device=dev),
+                        leaf=torch.zeros(1, dtype=torch.int32, device=dev))
         self._native = None
         if self.params[0].is_cuda:
-            # on the device a leaf is two launches around the likelihood (exo_nuts_leaf_f64) instead of ~35 torch ones
+            # on the device the tree is built by four kernels around the likelihood (exo_nuts_f64)
             import ctypes
 
             st = self._st
-            st.update(qn=zq.clone(), ph=zq.clone(), gn=zq.clone(), lpn=zd.clone())
             order = ("qe", "pe", "ge", "eps", "on", "H0", "logw", "psum", "sq", "sg", "slp", "turn", "div", "acc", "accn", "ckp",
-                     "cks", "u", "wsel", "csel")
-            ptrs = [st[k].data_ptr() for k in order] + [self._mflat.data_ptr()] + [st[k].data_ptr() for k in ("qn", "ph", "gn", "lpn")]
+                     "cks", None, "qn", "ph", "gn", "lpn", "ql", "pl", "gl", "qr", "pr", "gr", "tsum", "logW", "propq", "propg",
+                     "proplp", "active", "diverged", "going", "depth", "eps_abs", "R", "leaf")
+            ptrs = [self._mflat.data_ptr() if k is None else (self.eps.data_ptr() if k == "eps_abs" else st[k].data_ptr())
+                    for k in order]
             self._native = ((ctypes.c_void_p * len(ptrs))(*ptrs), int(q.shape[1]), S)
         self._graph = None
         if graph and self.params[0].is_cuda:
-            self._graph = GraphedStep(lambda *a: self._leaf_update(), *self._st.values())
+            self._graph = GraphedStep(lambda *a: self._leaf_update(), *[v for v in self._st.values()])
+
+    def _phase(self, phase):
+        from . import _lib
+
+        ptrs, n, S = self._native
+        dev = self._st["qe"].device
+        with torch.cuda.device(dev):
+            _lib.check(_lib.load().exo_nuts_f64(ptrs, self.D, n, S, self.max_energy_error, phase,
+                                                torch.cuda.current_stream(dev).cuda_stream), "exo_nuts_f64")
 
     def _leaf(self, q, p, g, eps):
         """one leapfrog step of every chain with its own signed step size: (q, p, grad) -> (q', p', grad', logp')"""
@@ -282,23 +288,35 @@ class NUTS(_ChainSampler):
         rho = (p_sum - 0.5 * (p_left + p_right)) / self._mflat
         return ((p_left * rho).sum(1) <= 0) | ((p_right * rho).sum(1) <= 0)
 
-    def _leaf_update(self):
-        """one leaf of the sub-tree in `self._st`, in place: leapfrog step of the moving end, energy error, divergence,
-        multinomial candidate, momentum sums, checkpoint write (even leaves) or turning checks (odd leaves) -- the slots
-        come as the masks `wsel` / `csel` -- and the chains that go on.  Eager, or captured once and replayed per leaf."""
+    # ---- the three steps of a doubling, on the static buffers: native kernels on the device, torch otherwise --------
+    def _begin_doubling(self):
         st = self._st
         if self._native is not None:
-            from . import _lib
+            return self._phase(2)
+        w1 = lambda m, a, b: torch.where(m.unsqueeze(1), a, b)  # noqa: E731
+        right = st["R"][0] < 0.5
+        st["going"].copy_(right)
+        st["eps"].copy_(torch.where(right, self.eps, -self.eps))
+        qe, pe, ge = w1(right, st["qr"], st["ql"]), w1(right, st["pr"], st["pl"]), w1(right, st["gr"], st["gl"])
+        for k, v in (("qe", qe), ("pe", pe), ("ge", ge), ("sq", qe), ("sg", ge), ("slp", st["proplp"]), ("on", st["active"])):
+            st[k].copy_(v)
+        st["logw"].fill_(float("-inf"))
+        st["psum"].zero_(); st["turn"].zero_(); st["div"].zero_()
+        st["leaf"].fill_(-1)
 
-            ptrs, n, S = self._native
-            lib = _lib.load()
-            stream = torch.cuda.current_stream(st["qe"].device).cuda_stream
-            with torch.cuda.device(st["qe"].device):
-                _lib.check(lib.exo_nuts_leaf_f64(ptrs, self.D, n, S, self.max_energy_error, 0, stream), "exo_nuts_leaf_f64")
-                lp, g = self._value_and_grad_flat(st["qn"])
-                st["gn"].copy_(g); st["lpn"].copy_(lp)
-                _lib.check(lib.exo_nuts_leaf_f64(ptrs, self.D, n, S, self.max_energy_error, 1, stream), "exo_nuts_leaf_f64")
+    def _leaf_update(self):
+        """one leaf of the sub-tree, in place: leapfrog step of the moving end, energy error, divergence, multinomial
+        candidate, momentum sums, checkpoint write (even leaves) or turning checks (odd leaves), the chains that go on.
+        Eager, or captured once and replayed per leaf (the leaf's index is counted on the device)."""
+        st = self._st
+        if self._native is not None:
+            self._phase(0)
+            lp, g = self._value_and_grad_flat(st["qn"])
+            st["gn"].copy_(g); st["lpn"].copy_(lp)
+            self._phase(1)
             return st["on"]
+        st["leaf"].add_(1)
+        n = int(st["leaf"])                       # (the torch statement runs on the CPU: reading the index costs nothing)
         qn, pn, gn, lpn = self._leaf(st["qe"], st["pe"], st["ge"], st["eps"])
         with torch.no_grad():
             on = st["on"]
@@ -312,99 +330,91 @@ class NUTS(_ChainSampler):
             accn = st["accn"] + on.to(dH.dtype)
             # multinomial sampling within the sub-tree: the new leaf replaces the candidate with probability w / W
             new_logw = torch.logaddexp(st["logw"], -dH)
-            take = ok & (torch.log(st["u"]) < (-dH - new_logw))
+            take = ok & (torch.log(st["R"][2 + n]) < (-dH - new_logw))
             t1 = take.unsqueeze(1)
             sq, sg = torch.where(t1, qn, st["sq"]), torch.where(t1, gn, st["sg"])
             slp = torch.where(take, lpn, st["slp"])
             logw = torch.where(ok, new_logw, st["logw"])
             psum = torch.where(ok.unsqueeze(1), st["psum"] + pn, st["psum"])
-            # turning checks against the checkpoints named by csel (as they were before this leaf's own write)
-            ckp, cks = st["ckp"], st["cks"]
-            inner = psum.unsqueeze(0) - cks + ckp
-            rho = (inner - 0.5 * (ckp + pn.unsqueeze(0))) / self._mflat
-            t = ((ckp * rho).sum(-1) <= 0) | ((pn.unsqueeze(0) * rho).sum(-1) <= 0)
-            turn = st["turn"] | (t & st["csel"].unsqueeze(1) & ok.unsqueeze(0)).any(0)
-            wm = (st["wsel"].unsqueeze(1) & ok.unsqueeze(0)).unsqueeze(-1)
-            ckp2, cks2 = torch.where(wm, pn.unsqueeze(0), ckp), torch.where(wm, psum.unsqueeze(0), cks)
+            turn = st["turn"]
+            if n % 2 == 0:                        # its momentum and the sum so far: checkpoint of the sub-sub-trees that start here
+                slot = bin(n >> 1).count("1")
+                wm = ok.unsqueeze(1)
+                st["ckp"][slot].copy_(torch.where(wm, pn, st["ckp"][slot]))
+                st["cks"][slot].copy_(torch.where(wm, psum, st["cks"][slot]))
+            else:                                 # it closes the sub-sub-trees of 2, 4, ... leaves that end here
+                lo, hi = _ckpt_range(n)
+                for i in range(hi, lo - 1, -1):
+                    inner = psum - st["cks"][i] + st["ckp"][i]
+                    turn = turn | (ok & self._turning(st["ckp"][i], pn, inner))
             sdiv = st["div"] | div
             on2 = on & ~div & ~turn
             for k, v in (("qe", qe), ("pe", pe), ("ge", ge), ("acc", acc), ("accn", accn), ("sq", sq), ("sg", sg), ("slp", slp),
-                         ("logw", logw), ("psum", psum), ("turn", turn), ("ckp", ckp2), ("cks", cks2), ("div", sdiv), ("on", on2)):
+                         ("logw", logw), ("psum", psum), ("turn", turn), ("div", sdiv), ("on", on2)):
                 st[k].copy_(v)
         return st["on"]
 
+    def _merge(self):
+        st = self._st
+        if self._native is not None:
+            return self._phase(3)
+        w1 = lambda m, a, b: torch.where(m.unsqueeze(1), a, b)  # noqa: E731
+        active, right = st["active"].clone(), st["going"]
+        grown = active & ~st["turn"] & ~st["div"]               # the sub-tree is valid: it joins the trajectory
+        # biased progressive sampling between the old trajectory and the new half
+        take = grown & (torch.log(st["R"][1]) < (st["logw"] - st["logW"]))
+        st["propq"].copy_(w1(take, st["sq"], st["propq"])); st["propg"].copy_(w1(take, st["sg"], st["propg"]))
+        st["proplp"].copy_(torch.where(take, st["slp"], st["proplp"]))
+        g_r, g_l = grown & right, grown & ~right
+        for end, m in (("r", g_r), ("l", g_l)):
+            for a, b in (("q", "qe"), ("p", "pe"), ("g", "ge")):
+                st[a + end].copy_(w1(m, st[b], st[a + end]))
+        st["tsum"].copy_(w1(grown, st["tsum"] + st["psum"], st["tsum"]))
+        st["logW"].copy_(torch.where(grown, torch.logaddexp(st["logW"], st["logw"]), st["logW"]))
+        st["depth"].add_(active.to(st["depth"].dtype))
+        st["diverged"].copy_(st["diverged"] | (active & st["div"]))
+        st["active"].copy_(grown & ~self._turning(st["pl"], st["pr"], st["tsum"]))
+
     @torch.no_grad()
     def step(self):
+        st = self._st
         self._mflat.copy_(self._flat(self.mass))         # (warm-up may have changed the masses; captured graphs read this)
         q0 = self._flat(self.params)
         if self._lp is None:
             self._lp, self._g = self._value_and_grad_flat(q0)
         lp0, g0 = self._lp, self._g
-        kin = lambda p: (0.5 * p * p / self._mflat).sum(1)  # noqa: E731
-        w1 = lambda m, a, b: torch.where(m.unsqueeze(1), a, b)  # noqa: E731
         p0 = torch.randn(q0.shape, dtype=q0.dtype, device=q0.device, generator=self.generator) * torch.sqrt(self._mflat)
-        H0 = -lp0 + kin(p0)
+        H0 = -lp0 + (0.5 * p0 * p0 / self._mflat).sum(1)
         valid = torch.isfinite(H0)                         # a chain outside the support (or at a NaN) stays where it is
-        H0 = torch.where(valid, H0, torch.zeros_like(H0))
-        ql, pl, gl = q0, p0, g0                            # the trajectory's ends
-        qr, pr, gr = q0, p0, g0
-        p_sum = p0
-        log_w = torch.zeros_like(H0)                       # log of the tree's total weight, relative to exp(-H0)
-        prop_q, prop_lp, prop_g = q0, lp0, g0
-        active = valid
-        depth = torch.zeros_like(H0)
-        diverged = torch.zeros_like(active)
-        acc_sum, acc_n = torch.zeros_like(H0), torch.zeros_like(H0)
+        for k, v in (("ql", q0), ("qr", q0), ("pl", p0), ("pr", p0), ("gl", g0), ("gr", g0), ("tsum", p0), ("propq", q0),
+                     ("propg", g0), ("proplp", lp0), ("active", valid), ("H0", torch.where(valid, H0, torch.zeros_like(H0)))):
+            st[k].copy_(v)
+        for k in ("logW", "depth", "diverged", "acc", "accn"):   # (logW: log of the trajectory's weight relative to exp(-H0))
+            st[k].zero_()
         for j in range(self.max_depth):
-            going_right = self._rand() < 0.5
-            eps_s = torch.where(going_right, self.eps, -self.eps)
-            qe, pe, ge = w1(going_right, qr, ql), w1(going_right, pr, pl), w1(going_right, gr, gl)
-            # the sub-tree's state (static buffers); its random numbers for all leaves at once
-            U = torch.rand(2 ** j, self.D, dtype=H0.dtype, device=H0.device, generator=self.generator)
-            st = self._st
-            for k, v in (("qe", qe), ("pe", pe), ("ge", ge), ("eps", eps_s), ("on", active), ("H0", H0), ("sq", qe), ("sg", ge),
-                         ("slp", lp0), ("acc", acc_sum), ("accn", acc_n)):
-                st[k].copy_(v)
-            st["logw"].fill_(float("-inf"))
-            st["psum"].zero_(); st["turn"].zero_(); st["div"].zero_()
-            for n in range(2 ** j):
-                st["u"].copy_(U[n]); st["wsel"].copy_(self._W[n]); st["csel"].copy_(self._C[n])
+            # the doubling's random numbers: directions, the merge, one row per leaf
+            torch.rand(2 + 2 ** j, self.D, dtype=q0.dtype, device=q0.device, generator=self.generator, out=st["R"][:2 + 2 ** j])
+            self._begin_doubling()
+            for _ in range(2 ** j):
                 if self._graph is not None:
                     self._graph()
                 else:
                     self._leaf_update()
                 self.n_leapfrog += 1
-            # (read before the next doubling rewrites the buffers: everything below makes new tensors)
-            qe, pe, ge = st["qe"], st["pe"], st["ge"]
-            sub_turn, sub_div, sub_logw, sub_psum = st["turn"], st["div"], st["logw"], st["psum"]
-            sub_q, sub_lp, sub_g = st["sq"], st["slp"], st["sg"]
-            acc_sum, acc_n = st["acc"].clone(), st["accn"].clone()
-            grown = active & ~sub_turn & ~sub_div               # the sub-tree is valid: it joins the tree
-            # biased progressive sampling between the old tree and the new half
-            take = grown & (torch.log(self._rand()) < (sub_logw - log_w))
-            prop_q, prop_g = w1(take, sub_q, prop_q), w1(take, sub_g, prop_g)
-            prop_lp = torch.where(take, sub_lp, prop_lp)
-            g_r, g_l = grown & going_right, grown & ~going_right
-            qr, pr, gr = w1(g_r, qe, qr), w1(g_r, pe, pr), w1(g_r, ge, gr)
-            ql, pl, gl = w1(g_l, qe, ql), w1(g_l, pe, pl), w1(g_l, ge, gl)
-            p_sum = w1(grown, p_sum + sub_psum, p_sum)
-            log_w = torch.where(grown, torch.logaddexp(log_w, sub_logw), log_w)
-            depth = depth + active.to(depth.dtype)
-            diverged = diverged | (active & sub_div)
-            active = grown & ~self._turning(pl, pr, p_sum)
-            if j + 1 < self.max_depth and not bool(active.any()):   # (the one host synchronisation per doubling)
+            self._merge()
+            if j + 1 < self.max_depth and not bool(st["active"].any()):   # (the one host synchronisation per doubling)
                 break
-        for x, y in zip(self.params, self._parts(prop_q)):
+        for x, y in zip(self.params, self._parts(st["propq"])):
             x.copy_(y)
-        self._lp, self._g = prop_lp, prop_g.clone()
+        self._lp, self._g = st["proplp"].clone(), st["propg"].clone()
         self.n_steps += 1
-        self.last_logp = prop_lp
-        self.last_depth = depth
-        self.last_diverged = diverged
-        self.last_accept_prob = acc_sum / torch.clamp(acc_n, min=1.0)
-        self.n_divergent += diverged.to(self.n_divergent.dtype)
-        self.sum_depth += depth
-        return depth
+        self.last_logp = self._lp
+        self.last_depth = st["depth"].clone()
+        self.last_diverged = st["diverged"].clone()
+        self.last_accept_prob = st["acc"] / torch.clamp(st["accn"], min=1.0)
+        self.n_divergent += self.last_diverged.to(self.n_divergent.dtype)
+        self.sum_depth += self.last_depth
+        return self.last_depth
 
     def _reset_statistics(self):
         self.n_steps = 0

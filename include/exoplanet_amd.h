@@ -480,16 +480,22 @@ int exo_pack_records_cols_vjp_f64(const double* const* cols, const int64_t* draw
                                   const double* gld, const double* gscale, double* const* gcols,
                                   double* const* gld_cols, void* stream);
 
-/* One leaf of the No-U-Turn sub-tree that a batch of chains is building (exoplanet_amd/sampling.py: NUTS; the
- * reference hands its models to PyMC's NUTS, docs/tutorials/data-and-models.md:289) on (chains, parameters) arrays
- * that stay on the device.  phase 0: half kick and drift of the sub-tree's moving end into the scratch rows qn, ph
- * (the caller then evaluates log-density and gradient at qn into lpn, gn); phase 1: second half kick, energy error,
- * divergence, multinomial candidate, momentum sums, checkpoint write / generalised turning checks, which chains go on.
- * ptrs: HOST array of 25 device pointers -- qe, pe, ge [D][n]; eps [D]; on [D] (bytes); H0 [D]; logw [D]; psum, sq,
- * sg [D][n]; slp [D]; turn, div [D] (bytes); acc, accn [D]; ckp, cks [n_slot][D][n]; u [D]; wsel, csel [n_slot]
- * (bytes); mass [D][n]; qn, ph, gn [D][n]; lpn [D].                                                                */
-int exo_nuts_leaf_f64(const void* const* ptrs, int64_t n_chain, int32_t n_param, int32_t n_slot, double max_energy_error,
-                      int32_t phase, void* stream);
+/* The No-U-Turn sampler's tree building for a batch of chains (exoplanet_amd/sampling.py: NUTS; the reference hands
+ * its models to PyMC's NUTS, docs/tutorials/data-and-models.md:289) on (chains, parameters) arrays that stay on the
+ * device.  A transition grows every chain's trajectory by doublings; per doubling
+ *   phase 2: every chain draws its direction, the sub-tree starts at that end of its trajectory;
+ *   per leaf, phase 0: half kick and drift of the sub-tree's moving end into the scratch rows qn, ph (the caller then
+ *            evaluates log-density and gradient at qn into lpn, gn), phase 1: second half kick, energy error,
+ *            divergence, multinomial candidate, momentum sums, checkpoint write / generalised turning checks, which
+ *            chains go on (the leaf index is kept on the device: a captured leaf needs nothing from the host);
+ *   phase 3: a valid sub-tree joins the trajectory (proposal, new end, sums, weights, the trajectory's turning check).
+ * ptrs: HOST array of 40 device pointers -- sub-tree: qe, pe, ge [D][n]; eps [D]; on [D] (bytes); H0, logw [D]; psum,
+ * sq, sg [D][n]; slp [D]; turn, div [D] (bytes); acc, accn [D]; ckp, cks [n_slot][D][n]; then mass, qn, ph, gn [D][n];
+ * lpn [D]; trajectory: ql, pl, gl, qr, pr, gr, tsum [D][n]; logW [D]; propq, propg [D][n]; proplp [D]; active,
+ * diverged, going [D] (bytes); depth [D]; eps_abs [D]; R [2 + leaves][D] (uniform random numbers of the doubling: row 0
+ * directions, row 1 the merge, row 2 + k leaf k); leaf (int32 [1]).                                               */
+int exo_nuts_f64(const void* const* ptrs, int64_t n_chain, int32_t n_param, int32_t n_slot, double max_energy_error,
+                 int32_t phase, void* stream);
 
 /* Timing tables of a TTVOrbit whose transits are all labelled and given as offsets `ttvs` from the linear ephemeris
  * (orbits/ttv.py:99-170): transit k of planet p of a draw at tt_k = t0 + period k + ttv_k, k < n_transit[p];

@@ -97,58 +97,41 @@ def test_nuts_on_the_white_noise_likelihood_graph_vs_eager(dev):
     assert abs(float(t0s.mean()) - 1.0) < 1e-3 and abs(float(rs.mean()) - 0.1) < 8e-3
 
 
-def test_native_leaf_update_equals_the_torch_leaf_update(dev):
-    """exo_nuts_leaf_f64 (two launches per leaf) against NUTS._leaf_update's torch statement of the same update, leaf by
-    leaf through several doublings on a correlated Gaussian: every array of the sub-tree state after every leaf"""
+def test_native_tree_building_equals_the_torch_statement(dev):
+    """exo_nuts_f64 (begin / leaf / merge kernels, leaf index on the device) against the torch statement of the same
+    tree building in NUTS: the same chains, depths, divergences and acceptance statistics transition after transition
+    on a correlated Gaussian with a wall (both read the same random numbers; every decision is the same)"""
     from exoplanet_amd.sampling import NUTS
 
-    torch.manual_seed(3)
     D = 97
     A = torch.tensor([[1.0, 0.6, 0.0], [0.6, 2.0, -0.3], [0.0, -0.3, 0.5]], dtype=torch.float64, device=dev)
 
     def logp(x, y):
         z = torch.cat([x, y], dim=1)
-        return -0.5 * ((z @ A) * z).sum(-1)
+        lp = -0.5 * ((z @ A) * z).sum(-1)
+        return torch.where(z[:, 0] > 2.5, torch.full_like(lp, -float("inf")), lp)      # a wall: divergences
 
-    def make(native):
+    def make(native, graph):
         x = torch.linspace(-1, 1, 2 * D, dtype=torch.float64, device=dev).reshape(D, 2).clone()
         y = torch.linspace(0.5, -0.5, D, dtype=torch.float64, device=dev).reshape(D, 1).clone()
-        s = NUTS(logp, [x, y], step_size=0.35, max_depth=5, graph=False, mass=[torch.tensor([1.0, 2.0], device=dev), 0.7],
+        s = NUTS(logp, [x, y], step_size=0.45, max_depth=5, graph=graph, mass=[torch.tensor([1.0, 2.0], device=dev), 0.7],
                  generator=torch.Generator(device=dev).manual_seed(5))
         if not native:
             s._native = None
         return s
 
-    a, b = make(True), make(False)
-    assert a._native is not None
-    # walk both through the same doublings by hand: identical controls and random numbers
-    for s in (a, b):
-        s._mflat.copy_(s._flat(s.mass))
-    q0 = a._flat(a.params)
-    lp0, g0 = a._value_and_grad_flat(q0)
-    gen = torch.Generator(device=dev).manual_seed(11)
-    p0 = torch.randn(q0.shape, dtype=torch.float64, device=dev, generator=gen)
-    H0 = -lp0 + (0.5 * p0 * p0 / a._mflat).sum(1)
-    for j in range(4):
-        eps_s = torch.where(torch.rand(D, device=dev, generator=gen) < 0.5, a.eps, -a.eps)
-        U = torch.rand(2 ** j, D, dtype=torch.float64, device=dev, generator=gen)
-        for s in (a, b):
-            st = s._st
-            for k, v in (("qe", q0), ("pe", p0), ("ge", g0), ("eps", eps_s), ("H0", H0), ("sq", q0), ("sg", g0), ("slp", lp0)):
-                st[k].copy_(v)
-            st["on"].fill_(True); st["logw"].fill_(float("-inf"))
-            for k in ("psum", "turn", "div", "acc", "accn"):
-                st[k].zero_()
-        for n in range(2 ** j):
-            for s in (a, b):
-                s._st["u"].copy_(U[n]); s._st["wsel"].copy_(s._W[n]); s._st["csel"].copy_(s._C[n])
-                s._leaf_update()
-            for k in ("qe", "pe", "ge", "on", "logw", "psum", "sq", "sg", "slp", "turn", "div", "acc", "accn"):
-                x, y = a._st[k], b._st[k]
-                if x.dtype == torch.bool:
-                    assert torch.equal(x, y), (j, n, k)
-                else:
-                    fin = torch.isfinite(y)
-                    assert torch.equal(torch.isfinite(x), fin), (j, n, k)
-                    assert float((x[fin] - y[fin]).abs().max()) <= 1e-12 * (1 + float(y[fin].abs().max())), (j, n, k)
-    assert bool(a._st["turn"].any()) and bool((~a._st["turn"]).any())      # some chains turned inside the sub-tree, some not
+    a, b, c = make(True, False), make(False, False), make(True, True)
+    assert a._native is not None and c._graph is not None
+    depths = []
+    for it in range(25):
+        da, db, dc = a.step(), b.step(), c.step()
+        assert torch.equal(da, db) and torch.equal(da, dc), it
+        assert torch.equal(a.last_diverged, b.last_diverged)
+        for s2 in (b, c):
+            for x, y in zip(a.params, s2.params):
+                assert torch.allclose(x, y, rtol=1e-10, atol=1e-12), it
+            assert torch.allclose(a.last_accept_prob, s2.last_accept_prob, rtol=1e-10, atol=1e-12)
+            assert torch.allclose(a.last_logp, s2.last_logp, rtol=1e-10, atol=1e-10)
+        depths.append(float(da.mean()))
+    assert a.n_leapfrog == b.n_leapfrog == c.n_leapfrog
+    assert 1.5 < np.mean(depths) < 5 and float(a.n_divergent.sum()) > 0 and float(da.max()) >= 3
