@@ -120,3 +120,42 @@ def test_ops_reject_host_tensors():
                lambda: ops.transit_flux(x, torch.zeros(1, 1, 16, dtype=torch.float64), torch.zeros(1, 3, dtype=torch.float64))):
         with pytest.raises(RuntimeError, match="no CPU fallback"):
             fn()
+
+
+def test_round_two_entry_points_reject_bad_arguments(lib):
+    """the timing-table likelihood, the table construction and the sampler kernels check their arguments on the host,
+    before any launch"""
+    import ctypes
+
+    from exoplanet_amd import ops
+
+    INVALID = 1
+    # white-noise likelihood with timing tables: flags it cannot take, missing tables, missing gshift, empty series
+    base = [8, 10, None, 0, None, None, 1, 8, 8, 1, 1]
+    for bad in (ops.FLAG_SECONDARY, ops.FLAG_LIGHT_DELAY, ops.FLAG_SPARSE, ops.FLAG_PER_PLANET, ops.FLAG_EXACT_SCAN):
+        assert lib.exo_transit_chi2_ttv_vjp_f64(*base, bad, 8, 8, 3, 8, 8, 1, 8, 8, 8, 8, 8, 1 << 30, None) == INVALID
+    assert lib.exo_transit_chi2_ttv_vjp_f64(*base, 0, None, 8, 3, 8, 8, 1, 8, 8, 8, 8, 8, 1 << 30, None) == INVALID
+    assert lib.exo_transit_chi2_ttv_vjp_f64(*base, 0, 8, 8, 3, 8, 8, 1, 8, 8, 8, None, 8, 1 << 30, None) == INVALID
+    empty = [8, 0, None, 0, None, None, 1, 8, 8, 1, 1]
+    assert lib.exo_transit_chi2_ttv_vjp_f64(*empty, 0, 8, 8, 3, 8, 8, 1, 8, 8, 8, 8, 8, 1 << 30, None) == INVALID
+    assert lib.exo_transit_chi2_ttv_vjp_f64(*base, 0, 8, 8, 3, 8, 8, 5, 8, 8, 8, 8, 8, 1 << 30, None) == INVALID   # n_ivar
+    # table construction: n_edge must be the widest row + 1, every planet needs offsets and at least one transit
+    ptr = (ctypes.c_void_p * 2)(8, 8)
+    ds = (ctypes.c_int64 * 2)(0, 0)
+    cnt = (ctypes.c_int32 * 2)(5, 3)
+    assert lib.exo_ttv_tables_f64(8, 0, 1, 8, 0, 1, ptr, ds, cnt, 4, 2, 5, 8, 8, None) == INVALID          # n_edge != 6
+    assert lib.exo_ttv_tables_f64(8, 0, 1, 8, 0, 1, ptr, ds, cnt, 0, 2, 6, None, None, None) == 0          # no draws
+    assert lib.exo_ttv_tables_f64(8, 0, 1, 8, 0, 1, ptr, ds, cnt, 4, 2, 6, None, 8, None) == INVALID        # no output
+    cnt0 = (ctypes.c_int32 * 2)(5, 0)
+    assert lib.exo_ttv_tables_f64(8, 0, 1, 8, 0, 1, ptr, ds, cnt0, 4, 2, 6, 8, 8, None) == INVALID
+    hole = (ctypes.c_void_p * 2)(8, None)
+    assert lib.exo_ttv_tables_vjp_f64(8, 0, 1, 8, 0, 1, hole, ds, cnt, 4, 2, 6, 8, ptr, 8, None) == INVALID
+    assert lib.exo_ttv_tables_vjp_f64(8, 0, 1, 8, 0, 1, ptr, ds, cnt, 4, 2, 6, None, ptr, 8, None) == INVALID
+    # sampler kernels: forty pointers, a known phase
+    full = (ctypes.c_void_p * 40)(*([8] * 40))
+    assert lib.exo_nuts_f64(None, 4, 3, 2, 1000.0, 0, None) == INVALID
+    assert lib.exo_nuts_f64(full, 4, 3, 2, 1000.0, 4, None) == INVALID
+    assert lib.exo_nuts_f64(full, 4, 0, 2, 1000.0, 0, None) == INVALID
+    assert lib.exo_nuts_f64(full, 0, 3, 2, 1000.0, 0, None) == 0                                           # no chains
+    gap = (ctypes.c_void_p * 40)(*([8] * 39 + [None]))
+    assert lib.exo_nuts_f64(gap, 4, 3, 2, 1000.0, 1, None) == INVALID
