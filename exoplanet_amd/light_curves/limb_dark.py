@@ -203,6 +203,9 @@ class LimbDarkLightCurve:
         if has_ttv and light_delay:
             raise NotImplementedError("white_noise_log_likelihood: no light delay together with timing variations")
         t = as_tensor(t, r if isinstance(r, torch.Tensor) else self.u1)
+        fused = self._loglike_from_columns(orbit, r, t, y, yerr, mean, texp, oversample, order, use_in_transit, light_delay, has_ttv)
+        if fused is not None:
+            return fused
         rec, ld, batch, flags = orbit.kernel_inputs(r, (self.u1, self.u2), use_in_transit=use_in_transit,
                                                     light_delay=light_delay)
         t = t.to(rec.device)
@@ -223,6 +226,40 @@ class LimbDarkLightCurve:
             rec, ld, batch = rec.contiguous(), ld.contiguous(), full
         ll = ops.white_noise_loglike(t.detach(), rec, ld, as_tensor(y, t).to(rec.device), yerr, mean=mean, flags=flags, **kw)
         return ll.reshape(tuple(batch)) if batch else ll.reshape(())
+
+    def _loglike_from_columns(self, orbit, r, t, y, yerr, mean, texp, oversample, order, use_in_transit, light_delay, has_ttv):
+        """white_noise_log_likelihood of the standard parameterisation with the constructor arguments handed to the
+        kernels as they are (ops.orbit_white_noise_loglike: packing, misfit + gradient, packing VJP with the
+        likelihood's cotangent folded in); None when that form does not apply"""
+        if not getattr(orbit, "_standard", False) or not t.is_cuda or not isinstance(mean, (int, float)):
+            return None
+        A = orbit._args
+        like = next((x for x in list(A.values()) + [r] if isinstance(x, torch.Tensor)), None)
+        got = orbit._standard_cols(r, (self.u1, self.u2), None, like)
+        if got is None:
+            return None
+        cols, us, D, batched = got
+        kw = {}
+        if has_ttv:
+            edges, shift = orbit.kernel_ttv()
+            if edges.dim() > 3:
+                return None
+            Dt = edges.shape[0] if edges.dim() == 3 else 1
+            if Dt != 1 and D != 1 and Dt != D:
+                return None
+            D = max(D, Dt)
+            batched = batched or edges.dim() == 3
+            P = edges.shape[-2]
+            kw["ttv"] = (edges.expand((D,) + tuple(edges.shape[-2:])).contiguous(), shift.expand((D,) + tuple(shift.shape[-2:])).contiguous())
+        if texp is not None:
+            dt, w = exposure_stencil(oversample, order)
+            kw.update(texp=as_tensor(texp, t).reshape(-1).detach(), stencil_dt=_on_device(dt, t.device),
+                      stencil_w=_on_device(w, t.device))
+        flags = (ops.FLAG_WINDOW if use_in_transit else 0) | (ops.FLAG_LIGHT_DELAY if light_delay else 0)
+        pack_flags = (flags & ops.FLAG_WINDOW) | (ops.PACK_CIRCULAR if A["ecc"] is None else 0)
+        yt = as_tensor(y, t).to(t.device)
+        ll = ops.orbit_white_noise_loglike(t.detach(), yt, yerr, cols, us, D, mean=mean, flags=flags, pack_flags=pack_flags, **kw)
+        return ll if batched else ll.reshape(())
 
     # ---- generic orbit objects: ops.quad_solution_vector on their positions
     def _composed(self, orbit, r, t, texp, stencil, use_in_transit, light_delay):

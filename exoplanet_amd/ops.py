@@ -442,11 +442,9 @@ def transit_chi2(t, params, ld, obs, ivar, texp=None, stencil_dt=None, stencil_w
     return _TransitChi2.apply(t, texp, stencil_dt, stencil_w, params, ld, obs, ivar, int(flags), edges, shift)
 
 
-def white_noise_loglike(t, params, ld, y, yerr, mean=0.0, texp=None, stencil_dt=None, stencil_w=None, flags=0, ttv=None):
-    """Gaussian log-likelihood (n_draw,) of the observed series ``y`` with independent errors ``yerr`` (scalar or
-    per cadence) given ``mean + light curve`` -- the reference's ``pm.Normal("obs", mu=mean + lc, sigma=yerr,
-    observed=y)`` for a batch of parameter sets, value and gradient in one call (:func:`transit_chi2`)."""
-    y = _dev(y, "y")
+def _white_noise_terms(y, yerr, mean):
+    """(y - mean, weights, sum w (y - mean)^2, sum log(w / 2 pi), and the likelihood's constant term (the last minus the
+    one before, halved)) of a white-noise likelihood"""
     # what depends on the data alone (residual series, weights, the two constants of the likelihood) is computed once per
     # (y, yerr, mean): a sampler calls this thousands of times with the same series
     key = None
@@ -467,12 +465,19 @@ def white_noise_loglike(t, params, ld, y, yerr, mean=0.0, texp=None, stencil_dt=
         n = y.numel()
         const = (ivar * obs * obs).sum() if ivar.numel() == n else ivar[0] * (obs * obs).sum()
         lognorm = torch.log(ivar / (2.0 * torch.pi)).sum() * (1.0 if ivar.numel() == n else float(n))
-        hit = (obs, ivar, const, lognorm, y, yerr)
+        hit = (obs, ivar, const, lognorm, y, yerr, 0.5 * (lognorm - const))
         if key is not None:
             if len(_WN_CACHE) >= 16:
                 _WN_CACHE.clear()
             _WN_CACHE[key] = hit
-    obs, ivar, const, lognorm = hit[:4]
+    return hit[:4] + (hit[6],)
+
+
+def white_noise_loglike(t, params, ld, y, yerr, mean=0.0, texp=None, stencil_dt=None, stencil_w=None, flags=0, ttv=None):
+    """Gaussian log-likelihood (n_draw,) of the observed series ``y`` with independent errors ``yerr`` (scalar or
+    per cadence) given ``mean + light curve`` -- the reference's ``pm.Normal("obs", mu=mean + lc, sigma=yerr,
+    observed=y)`` for a batch of parameter sets, value and gradient in one call (:func:`transit_chi2`)."""
+    obs, ivar, const, lognorm, _ = _white_noise_terms(_dev(y, "y"), yerr, mean)
     chi2 = transit_chi2(t, params, ld, obs, ivar, texp=texp, stencil_dt=stencil_dt, stencil_w=stencil_w, flags=flags, ttv=ttv)
     return -0.5 * (chi2 + const) + 0.5 * lognorm
 
@@ -940,6 +945,84 @@ def orbit_flux_dot(t, gflux, orbit_cols, ld_cols, flags=0, pack_flags=0, texp=No
     return out
 
 
+def _pack_cols_forward(cols, n_ld, n_draw, pack_flags):
+    """exo_pack_records_cols_f64 on a list of NIN orbit columns (None = constructor default) + n_ld limb-darkening
+    columns: (params (D, P, 20), ld (D, 3|6), the expanded views to keep for the reverse call, meta)"""
+    import ctypes
+
+    ocols, lcols = list(cols[:NIN]), list(cols[NIN:NIN + n_ld])
+    ref = next(c for c in ocols + lcols if c is not None)
+    D, P = int(n_draw), 1
+    for c in ocols:
+        if c is not None:
+            if c.dim() > 2:
+                raise ValueError("orbit parameters may carry at most one draw dimension here")
+            P = max(P, c.shape[-1] if c.dim() >= 1 else 1)
+    vp, i64 = ctypes.c_void_p, ctypes.c_int64
+    cp, ds, ps, df = (vp * NIN)(), (i64 * NIN)(), (i64 * NIN)(), (ctypes.c_double * NIN)(*_PACK_DEFAULTS)
+    keep = []
+    for k, c in enumerate(ocols):
+        if c is None:
+            continue
+        c = _dev(c.detach(), "orbit parameter")
+        v = c.reshape(1, 1) if c.dim() == 0 else (c.unsqueeze(0) if c.dim() == 1 else c)
+        v = v.expand(D, P)
+        keep.append(v)
+        cp[k], ds[k], ps[k] = v.data_ptr(), v.stride(0), v.stride(1)
+    lp, ls = (vp * 4)(), (i64 * 4)()
+    for k, c in enumerate(lcols):
+        c = _dev(c.detach(), "limb-darkening coefficient")
+        v = (c.reshape(1) if c.dim() == 0 else c).expand(D)
+        keep.append(v)
+        lp[k], ls[k] = v.data_ptr(), v.stride(0)
+    nset = n_ld // 2
+    params = torch.empty(D, P, NPAR, dtype=torch.float64, device=ref.device)
+    ld = torch.empty(D, 3 * nset, dtype=torch.float64, device=ref.device)
+    lib = _lib.load()
+    with torch.cuda.device(ref.device):
+        _lib.check(lib.exo_pack_records_cols_f64(cp, ds, ps, df, lp, ls, D, P, pack_flags, _ptr(params), _ptr(ld),
+                                                 _stream(params)), "exo_pack_records_cols_f64")
+    meta = (D, P, pack_flags, n_ld, [c is not None for c in ocols], [None if c is None else tuple(c.shape) for c in cols])
+    return params, ld, keep, meta
+
+
+def _pack_cols_backward(keep, meta, gparams, gld, gscale, needs):
+    """exo_pack_records_cols_vjp_f64: cotangents of (params, ld), optionally scaled per draw by ``gscale``, back to the
+    columns' own shapes; ``needs[k]``: whether column k wants one"""
+    import ctypes
+
+    D, P, pack_flags, n_ld, present, shapes = meta
+    dev = keep[0].device
+    vp, i64 = ctypes.c_void_p, ctypes.c_int64
+    cp, ds, ps, df = (vp * NIN)(), (i64 * NIN)(), (i64 * NIN)(), (ctypes.c_double * NIN)(*_PACK_DEFAULTS)
+    it = iter(keep)
+    for k in range(NIN):
+        if present[k]:
+            v = next(it)
+            cp[k], ds[k], ps[k] = v.data_ptr(), v.stride(0), v.stride(1)
+    lp, ls = (vp * 4)(), (i64 * 4)()
+    for k in range(n_ld):
+        v = next(it)
+        lp[k], ls[k] = v.data_ptr(), v.stride(0)
+    gcp, glp = (vp * NIN)(), (vp * 4)()
+    outs = [None] * len(shapes)
+    for k in range(NIN):
+        if present[k] and needs[k]:
+            outs[k] = torch.empty(D, P, dtype=torch.float64, device=dev)
+            gcp[k] = outs[k].data_ptr()
+    for k in range(n_ld):
+        if needs[NIN + k]:
+            outs[NIN + k] = torch.empty(D, dtype=torch.float64, device=dev)
+            glp[k] = outs[NIN + k].data_ptr()
+    lib = _lib.load()
+    with torch.cuda.device(dev):
+        _lib.check(lib.exo_pack_records_cols_vjp_f64(cp, ds, ps, df, lp, ls, D, P, pack_flags, _ptr(gparams), _ptr(gld),
+                                                     _ptr(gscale), gcp, glp, _stream(gparams)), "exo_pack_records_cols_vjp_f64")
+    # dense (D, P) / (D,) cotangents back to the shapes the caller passed (sums over what was broadcast)
+    return [None if g is None else (g.reshape(shp) if g.numel() == _numel(shp) else g.sum_to_size(_bshape(shp, g.dim())).reshape(shp))
+            for g, shp in zip(outs, shapes)]
+
+
 class _PackCols(torch.autograd.Function):
     """exo_pack_records_cols_f64 on its own: every constructor argument its own tensor (shape (), (P,), (D, 1) or
     (D, P); None = the constructor default), limb-darkening coefficients () or (D,) -> records (D, P, 20), ld (D, 3|6).
@@ -948,82 +1031,81 @@ class _PackCols(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, pack_flags, n_ld, n_draw, *cols):
-        import ctypes
-
-        ocols, lcols = list(cols[:NIN]), list(cols[NIN:NIN + n_ld])
-        ref = next(c for c in ocols + lcols if c is not None)
-        D, P = int(n_draw), 1
-        for c in ocols:
-            if c is not None:
-                if c.dim() > 2:
-                    raise ValueError("orbit parameters may carry at most one draw dimension here")
-                P = max(P, c.shape[-1] if c.dim() >= 1 else 1)
-        vp, i64 = ctypes.c_void_p, ctypes.c_int64
-        cp, ds, ps, df = (vp * NIN)(), (i64 * NIN)(), (i64 * NIN)(), (ctypes.c_double * NIN)(*_PACK_DEFAULTS)
-        keep = []
-        for k, c in enumerate(ocols):
-            if c is None:
-                continue
-            c = _dev(c.detach(), "orbit parameter")
-            v = c.reshape(1, 1) if c.dim() == 0 else (c.unsqueeze(0) if c.dim() == 1 else c)
-            v = v.expand(D, P)
-            keep.append(v)
-            cp[k], ds[k], ps[k] = v.data_ptr(), v.stride(0), v.stride(1)
-        lp, ls = (vp * 4)(), (i64 * 4)()
-        for k, c in enumerate(lcols):
-            c = _dev(c.detach(), "limb-darkening coefficient")
-            v = (c.reshape(1) if c.dim() == 0 else c).expand(D)
-            keep.append(v)
-            lp[k], ls[k] = v.data_ptr(), v.stride(0)
-        nset = n_ld // 2
-        params = torch.empty(D, P, NPAR, dtype=torch.float64, device=ref.device)
-        ld = torch.empty(D, 3 * nset, dtype=torch.float64, device=ref.device)
-        lib = _lib.load()
-        with torch.cuda.device(ref.device):
-            _lib.check(lib.exo_pack_records_cols_f64(cp, ds, ps, df, lp, ls, D, P, pack_flags, _ptr(params), _ptr(ld),
-                                                     _stream(params)), "exo_pack_records_cols_f64")
+        params, ld, keep, ctx.meta = _pack_cols_forward(cols, n_ld, n_draw, pack_flags)
         ctx.save_for_backward(*keep)
-        ctx.meta = (D, P, pack_flags, n_ld, [c is not None for c in ocols], [None if c is None else tuple(c.shape) for c in cols])
         return params, ld
 
     @staticmethod
     def backward(ctx, gparams, gld):
-        import ctypes
-
-        D, P, pack_flags, n_ld, present, shapes = ctx.meta
-        nfix = 3
+        D, P, _, n_ld = ctx.meta[:4]
         keep = ctx.saved_tensors
         dev = keep[0].device
         gparams = torch.zeros(D, P, NPAR, dtype=torch.float64, device=dev) if gparams is None else _dev(gparams, "gparams")
         gld = torch.zeros(D, 3 * (n_ld // 2), dtype=torch.float64, device=dev) if gld is None else _dev(gld, "gld")
-        vp, i64 = ctypes.c_void_p, ctypes.c_int64
-        cp, ds, ps, df = (vp * NIN)(), (i64 * NIN)(), (i64 * NIN)(), (ctypes.c_double * NIN)(*_PACK_DEFAULTS)
-        it = iter(keep)
-        for k in range(NIN):
-            if present[k]:
-                v = next(it)
-                cp[k], ds[k], ps[k] = v.data_ptr(), v.stride(0), v.stride(1)
-        lp, ls = (vp * 4)(), (i64 * 4)()
-        for k in range(n_ld):
-            v = next(it)
-            lp[k], ls[k] = v.data_ptr(), v.stride(0)
-        gcp, glp = (vp * NIN)(), (vp * 4)()
-        outs = [None] * len(shapes)
-        for k in range(NIN):
-            if present[k] and ctx.needs_input_grad[nfix + k]:
-                outs[k] = torch.empty(D, P, dtype=torch.float64, device=dev)
-                gcp[k] = outs[k].data_ptr()
-        for k in range(n_ld):
-            if ctx.needs_input_grad[nfix + NIN + k]:
-                outs[NIN + k] = torch.empty(D, dtype=torch.float64, device=dev)
-                glp[k] = outs[NIN + k].data_ptr()
+        return (None,) * 3 + tuple(_pack_cols_backward(keep, ctx.meta, gparams, gld, None, ctx.needs_input_grad[3:]))
+
+
+class _OrbitLoglike(torch.autograd.Function):
+    """The white-noise log-likelihood of a batch of standard-parameterisation orbits straight from the constructor
+    arguments: column-form packing, the one-call misfit + gradient (exo_transit_chi2[_ttv]_vjp_f64), and -- backward --
+    the packing VJP with the likelihood's cotangent folded in (gscale = -gll / 2).  Seven launches for value and
+    gradient where pack_records_cols -> transit_chi2 -> torch algebra takes eleven."""
+
+    @staticmethod
+    def forward(ctx, t, texp, stencil_dt, stencil_w, obs, ivar, cterm, flags, pack_flags, n_ld, n_draw, ttv_edges, ttv_shift,
+                *cols):
+        params, ld, keep, meta = _pack_cols_forward(cols, n_ld, n_draw, pack_flags)
+        t, texp, n_texp, sdt, sw, n_sub, params, ld, D, P = _transit_args(t, texp, stencil_dt, stencil_w, params, ld, flags)
+        edges, shift, n_edge = _ttv_args(None if ttv_edges is None else (ttv_edges, ttv_shift), D, P)
+        N = t.numel()
         lib = _lib.load()
-        with torch.cuda.device(dev):
-            _lib.check(lib.exo_pack_records_cols_vjp_f64(cp, ds, ps, df, lp, ls, D, P, pack_flags, _ptr(gparams), _ptr(gld),
-                                                         0, gcp, glp, _stream(gparams)), "exo_pack_records_cols_vjp_f64")
-        grads = [None if g is None else (g.reshape(shp) if g.numel() == _numel(shp) else g.sum_to_size(_bshape(shp, g.dim())).reshape(shp))
-                 for g, shp in zip(outs, shapes)]
-        return (None,) * nfix + tuple(grads)
+        nbytes = lib.exo_transit_flux_workspace_bytes(N, D, P)
+        ws = torch.empty(max(nbytes // 8 + 1, 1), dtype=torch.float64, device=t.device)
+        chi2 = torch.empty(D, dtype=torch.float64, device=t.device)
+        gparams, gld = torch.empty_like(params), torch.empty_like(ld)
+        gshift = torch.empty_like(shift) if n_edge else None
+        with torch.cuda.device(t.device):
+            if n_edge:
+                _lib.check(lib.exo_transit_chi2_ttv_vjp_f64(_ptr(t), N, _ptr(texp), n_texp, _ptr(sdt), _ptr(sw), n_sub,
+                                                            _ptr(params), _ptr(ld), D, P, flags, _ptr(edges), _ptr(shift),
+                                                            n_edge, _ptr(obs), _ptr(ivar), ivar.numel(), _ptr(chi2),
+                                                            _ptr(gparams), _ptr(gld), _ptr(gshift), _ptr(ws), nbytes,
+                                                            _stream(t)), "exo_transit_chi2_ttv_vjp_f64")
+            else:
+                _lib.check(lib.exo_transit_chi2_vjp_f64(_ptr(t), N, _ptr(texp), n_texp, _ptr(sdt), _ptr(sw), n_sub, _ptr(params),
+                                                        _ptr(ld), D, P, flags, _ptr(obs), _ptr(ivar), ivar.numel(), _ptr(chi2),
+                                                        _ptr(gparams), _ptr(gld), _ptr(ws), nbytes, _stream(t)),
+                           "exo_transit_chi2_vjp_f64")
+        ctx.meta = meta
+        ctx.n_keep = len(keep)
+        ctx.save_for_backward(gparams, gld, *keep, *([gshift] if n_edge else []))
+        return torch.add(cterm, chi2, alpha=-0.5)
+
+    @staticmethod
+    def backward(ctx, gll):
+        saved = ctx.saved_tensors
+        gparams, gld, keep = saved[0], saved[1], saved[2:2 + ctx.n_keep]
+        gscale = -0.5 * _dev(gll, "gll")
+        nfix = 13
+        grads = _pack_cols_backward(keep, ctx.meta, gparams, gld, gscale, ctx.needs_input_grad[nfix:])
+        gshift = gscale[:, None, None] * saved[2 + ctx.n_keep] if len(saved) > 2 + ctx.n_keep else None
+        return (None,) * 11 + (None, gshift) + tuple(grads)
+
+
+def orbit_white_noise_loglike(t, y, yerr, orbit_cols, ld_cols, n_draw, mean=0.0, flags=0, pack_flags=0, texp=None,
+                              stencil_dt=None, stencil_w=None, ttv=None):
+    """:func:`white_noise_loglike` for orbits in the standard parameterisation given column by column (the EXO_IN_*
+    inputs of :func:`pack_records_cols`): Gaussian log-likelihood (n_draw,), differentiable w.r.t. every column and the
+    timing shifts, value and gradient in seven launches."""
+    t = _dev(t, "t")
+    obs, ivar, _, _, cterm = _white_noise_terms(_dev(y, "y"), yerr, mean)
+    if tuple(obs.shape) != (t.numel(),):
+        raise ValueError("y must have shape (n_cad,)")
+    if ivar.numel() not in (1, t.numel()):
+        raise ValueError("yerr must be a scalar or have one entry per cadence")
+    edges, shift = (None, None) if ttv is None else ttv
+    return _OrbitLoglike.apply(t, texp, stencil_dt, stencil_w, obs, ivar, cterm, int(flags), int(pack_flags),
+                               len(ld_cols), int(n_draw), edges, shift, *orbit_cols, *ld_cols)
 
 
 def pack_records_cols(orbit_cols, ld_cols, n_draw, pack_flags=0):

@@ -601,10 +601,10 @@ class KeplerianOrbit:
         ld = c.to(rec.device).expand(batch + (c.shape[-1],)).reshape(D, c.shape[-1])
         return rec.contiguous(), ld.contiguous(), batch, flags
 
-    def _kernel_inputs_cols(self, r, u, secondary, pack_flags, like):
-        """kernel_inputs of the standard parameterisation with at most one draw dimension on ROCm tensors: the
-        constructor arguments go to the packing kernel as they are (ops.pack_records_cols: no stacking, one launch each
-        way); None when that form does not apply"""
+    def _standard_cols(self, r, u, secondary, like):
+        """the constructor arguments of the standard parameterisation as the packing kernel's columns -- ``(orbit
+        columns, limb-darkening columns, draws, batched?)`` -- when they are ROCm float64 tensors with at most one draw
+        dimension (then they go to the kernels as they are); None otherwise"""
         A = self._args
         opt = lambda x: None if x is None else _vec(x, like)  # noqa: E731
         sbr = None
@@ -624,7 +624,15 @@ class KeplerianOrbit:
         if len(draws) > 1:
             return None
         batched = any(c.dim() == 2 for c in cols if c is not None) or any(x.dim() == 1 for x in us)
-        D = draws.pop() if draws else 1
+        return cols, us, (draws.pop() if draws else 1), batched
+
+    def _kernel_inputs_cols(self, r, u, secondary, pack_flags, like):
+        """kernel_inputs of the standard parameterisation through ops.pack_records_cols (no stacking, one launch each
+        way); None when that form does not apply"""
+        got = self._standard_cols(r, u, secondary, like)
+        if got is None:
+            return None
+        cols, us, D, batched = got
         rec, ld = ops.pack_records_cols(cols, us, D, pack_flags)
         return rec, ld, ((D,) if batched else ())
 
