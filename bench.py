@@ -167,21 +167,37 @@ def step(xo, ops, leaves, t, gbar, events=(None, None), use_in_transit=False, **
     return flux, L, grads
 
 
-def exchange_step(exchange, L_local):
+def exchange_step(exchange, L_local, pipelined=False):
     """the multi-GPU part of a step: one collective, every rank ends up with all per-draw scalars.
+    ``pipelined``: the collective is issued asynchronously from a private copy of the rank's scalars and overlaps the
+    next step's kernels (LoglikeExchange.start); the caller ends the loop with ``exchange.finish()``.
     (tests/test_distributed.py drives this function on CPU under gloo, world size 2.)"""
+    if pipelined and not _SYNC_EXCHANGE[0]:
+        try:
+            return exchange.start(L_local)
+        except RuntimeError as e:      # (a backend without asynchronous collectives: say so once, go on synchronously)
+            print(f"bench.py: asynchronous exchange failed ({e}); using the synchronous collective", file=sys.stderr)
+            _SYNC_EXCHANGE[0] = True
     return exchange(L_local)
 
 
-def time_steps(fn, steps, warmup, dist, dev):
+_SYNC_EXCHANGE = [os.environ.get("EXO_BENCH_SYNC_EXCHANGE") == "1"]
+
+
+def time_steps(fn, steps, warmup, dist, dev, drain=None):
+    """``drain``: called after the last step, inside the timed region (collectives still in flight are waited for)"""
     for _ in range(warmup):
         fn(-1)
+    if drain is not None:
+        drain()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     for i in range(steps):
         fn(i)
+    if drain is not None:
+        drain()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize(dev)
@@ -636,7 +652,7 @@ def main():
         evs = events.handles(i) if (ev and i >= 0) else (None, None)
         flux, L, grads = step(xo, ops, leaves, t, gbar, events=evs)
         if exchange is not None:
-            exchange_step(exchange, L)
+            exchange_step(exchange, L, pipelined=True)
         return flux, L, grads
 
     # The step is a dozen short launches (packing kernel, window, scan, heavy, reduce, packing VJP and
@@ -653,7 +669,7 @@ def main():
     def one_graph(i):
         graph()
         if exchange is not None:
-            exchange_step(exchange, static["L"])
+            exchange_step(exchange, static["L"], pipelined=True)
 
     run = one_graph if graph is not None else (lambda i: one(i, ev=False))
     # setup, outside the contract's W + K steps: bring clocks, caches and the allocator to the state a sampler runs
@@ -662,7 +678,8 @@ def main():
     for _ in range(SETUP_STEPS):
         run(-1)
     torch.cuda.synchronize(dev)
-    wall = time_steps(run, args.steps, args.warmup, dist, dev)
+    drain = exchange.finish if exchange is not None else None
+    wall = time_steps(run, args.steps, args.warmup, dist, dev, drain=drain)
     wall_t = torch.tensor([wall], dtype=torch.float64, device=dev)
     if dist is not None:
         dist.all_reduce(wall_t, op=dist.ReduceOp.MAX)
@@ -673,6 +690,8 @@ def main():
         # max-over-ranks step time above, so it is the same on every rank
         n_stat = int(min(6000, max(100, np.ceil(2.0 / max(wall / args.steps, 1e-6)))))
         timing = stats_loop(run, dev, n_stat)
+        if exchange is not None:
+            exchange.finish()
         if dist is not None:
             dist.barrier()
     # hipEvents cannot bracket a node inside a replayed graph: time the kernels of the sweep over
@@ -720,7 +739,9 @@ def main():
                             "transit, 150000 cadences, value+grad, use_in_transit=False: dense flux output, every "
                             f"cadence classified on the device, {100.0 * n_active / (D * N_CAD):.2f} % solved",
                 "n_cadences": N_CAD, "draws_per_gpu": D, "global_draws": n_global,
-                "parallelism": f"draws sharded over {world} GPU(s); one collective of per-draw scalars per step",
+                "parallelism": f"draws sharded over {world} GPU(s); one collective of per-draw scalars per step, issued "
+                               "asynchronously from a private copy (double-buffered): it overlaps the next step's kernels and "
+                               "is waited for inside the timed region",
                 "step": "leaf params (separate tensors, read in place) -> record-packing kernel (orbit algebra + "
                         "get_cl) -> window + run-enumeration + heavy kernels (value+VJP, one sweep; the heavy kernel's blocks "
                         "finish their own draws at >= 512 draws, a separate finish kernel below that) -> packing "

@@ -49,7 +49,8 @@ class LoglikeExchange:
     scalars.  The output buffer is allocated once; a call issues exactly ONE collective and no
     other device work when the shards are equal (``all_gather_into_tensor`` straight from the
     caller's tensor -- e.g. the static output of a replayed hipGraph); ragged shards fall back
-    to "own slice of a zero vector + all-reduce(SUM)".  Rank and world size are those of
+    to "own slice of a zero vector + all-reduce(SUM)".  ``start`` / ``finish`` are the pipelined
+    form of the same exchange: the collective of a step overlaps the kernels of the next one.  Rank and world size are those of
     ``group``.  A single process (or an uninitialised process group) just copies."""
 
     def __init__(self, n_draw, device, dtype=torch.float64, group=None):
@@ -59,6 +60,46 @@ class LoglikeExchange:
         self.lo, self.hi = shard_bounds(self.n_draw, self.rank, self.world)
         self.equal = self.n_draw % self.world == 0
         self.out = torch.zeros(self.n_draw, dtype=dtype, device=device)
+        # pipelined form (start / finish): two private copies of the rank's slice, two outputs, the collectives in flight
+        self._stage = [torch.zeros(self.hi - self.lo, dtype=dtype, device=device) for _ in range(2)]
+        self._outs = [torch.zeros(self.n_draw, dtype=dtype, device=device) for _ in range(2)]
+        self._work = [None, None]
+        self._k = 0
+        self._last = None
+
+    def start(self, local):
+        """The same collective, PIPELINED: it is issued asynchronously from a private copy of ``local`` and may still be
+        in flight while the next step's kernels run -- nothing in a step depends on the other ranks' scalars, a sampler
+        reads them for adaptation and logging.  ``local`` may be overwritten as soon as this returns (e.g. the static
+        output of a replayed hipGraph).  Two buffers alternate; a ``start`` waits for the collective issued two steps
+        earlier.  ``finish()`` waits for everything and returns the vector of the LATEST step."""
+        local = local.detach()
+        if local.shape != (self.hi - self.lo,):
+            raise ValueError(f"rank owns draws [{self.lo},{self.hi}) but got a tensor of shape {tuple(local.shape)}")
+        k = self._k
+        self._k ^= 1
+        if self._work[k] is not None:
+            self._work[k].wait()
+            self._work[k] = None
+        stage, out = self._stage[k], self._outs[k]
+        stage.copy_(local)
+        if self.world == 1:
+            out.copy_(stage)
+        elif self.equal:
+            self._work[k] = dist.all_gather_into_tensor(out, stage, group=self.group, async_op=True)
+        else:
+            out.zero_()
+            out[self.lo:self.hi] = stage
+            self._work[k] = dist.all_reduce(out, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self._last = k
+
+    def finish(self):
+        """wait for the collectives in flight; the full vector of the most recent ``start`` (None if there was none)"""
+        for k in (0, 1):
+            if self._work[k] is not None:
+                self._work[k].wait()
+                self._work[k] = None
+        return None if self._last is None else self._outs[self._last]
 
     def __call__(self, local):
         local = local.detach()

@@ -131,6 +131,16 @@ def _worker_bench_exchange(rank, world, port, n_global, out_dir):
             assert torch.equal(full, want), (rank, it, full, want)
         with pytest.raises(ValueError):
             ex(torch.zeros(hi - lo + 1, dtype=torch.float64))
+        # the pipelined form: the source may be overwritten right after start(); finish() returns the latest step's vector
+        assert ex.finish() is None
+        src = torch.zeros(hi - lo, dtype=torch.float64)
+        for it in range(5):
+            src.copy_(torch.arange(lo, hi, dtype=torch.float64) * (it + 2) - 0.5)
+            bench.exchange_step(ex, src, pipelined=True)
+            src.fill_(float("nan"))                      # (what the next graph replay does to its static output)
+        assert torch.equal(ex.finish(), torch.arange(n_global, dtype=torch.float64) * 6 - 0.5)
+        with pytest.raises(ValueError):
+            ex.start(torch.zeros(hi - lo + 1, dtype=torch.float64))
         # a group with the ranks in reverse order: position in the group != global rank
         grp = dist.new_group(ranks=list(range(world))[::-1])
         glo, ghi = shard_bounds(n_global, group=grp)
