@@ -249,7 +249,6 @@ class LimbDarkLightCurve:
                 return None
             D = max(D, Dt)
             batched = batched or edges.dim() == 3
-            P = edges.shape[-2]
             kw["ttv"] = (edges.expand((D,) + tuple(edges.shape[-2:])).contiguous(), shift.expand((D,) + tuple(shift.shape[-2:])).contiguous())
         if texp is not None:
             dt, w = exposure_stencil(oversample, order)

@@ -132,9 +132,8 @@ class TTVOrbit(KeplerianOrbit):
         super().__init__(*args, **kwargs)
         # (the base class's `_standard` stands: the fused kernels take the ordinary records plus the
         # timing tables, so the standard parameterisation still goes through the packing kernel)
-        t0, period = self._ephemeris()
         if ttvs is not None:
-            self.ttv_period = period
+            self.ttv_period = self._ephemeris()[1]
         # transit_times (with `ttvs`), all_transit_times and the lookup table are built on first use (__getattr__): a
         # fused light-curve call of the common case -- offsets for every transit -- never needs them (kernel_ttv)
         self._tables_ready = False
