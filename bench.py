@@ -5,7 +5,7 @@ Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it
 is launched under torch.distributed.run, one rank per GPU (RCCL).  Rank 0
 prints ONE JSON line.
 
-Workload = BASELINE.json configs[1] ("C2"): single planet, e = 0.3,
+Default workload = BASELINE.json configs[1] ("C2"): single planet, e = 0.3,
 omega = 1.1, P = 3.5 d, t0 = 1, b = 0.3, r = 0.1, (u1, u2) = (0.3, 0.2), 150 000
 two-minute cadences, float64, cotangent gbar ~ N(0,1), use_in_transit=False: the
 output is the DENSE flux array [draws][150 000]; every cadence is classified on
@@ -19,11 +19,20 @@ pass of the hot path over a batch of `--draws-per-gpu` draws (base parameters x
 algebra + get_cl) -> window + run-enumeration + heavy + finish kernels (value +
 VJP in one sweep; the heavy kernel zero-fills the dense flux array while it
 solves) -> packing VJP -> leaf gradients, replayed as one hipGraph.  With N > 1
-ranks each own their draws and exchange only the per-draw scalar sum(gbar*flux):
-ONE collective per step (exoplanet_amd.distributed.LoglikeExchange).  Default is
-weak scaling (fixed draws per GPU); `--global-draws G` fixes the total instead
-(BASELINE C4 / C5: 512 / 1024 draws over 8 GPUs) and reports "strong".
-Inputs are resident in HBM before the timed region.
+ranks each own their draws and exchange only the per-draw scalar (sum(gbar*flux),
+or the log-likelihood of a GP config): ONE collective per step
+(exoplanet_amd.distributed.LoglikeExchange), whose result -- the full vector of the
+previous step -- is consumed inside the timed loop.
+
+`--config c2|c3|c4|c5` selects the BASELINE config whose step is timed (`workload_c2` ..
+`workload_c5` below build exactly the step each `extras` leg reports, and
+tests/test_gpu_timed_config.py holds those same steps to the oracle):
+  c2 (default)  weak scaling, `--draws-per-gpu` draws on every GPU;
+  c3            C2 + SHO-term celerite GP log-likelihood, weak scaling;
+  c4            4 planets, 200 000 cadences, `--global-draws` (default 512) draws sharded over the GPUs: strong scaling;
+  c5            65 000 long cadences x 7 sub-exposures, secondary eclipse, 3-term GP (J = 6),
+                `--global-draws` (default 1024) chains sharded over the GPUs: strong scaling.
+`--global-draws G` fixes the total for any config.  Inputs are resident in HBM before the timed region.
 
 Timing: `value` comes from EXACTLY --steps steps between barrier + synchronize
 on both sides (max over ranks).  Independently of --steps, `timing` reports
@@ -167,10 +176,156 @@ def step(xo, ops, leaves, t, gbar, events=(None, None), use_in_transit=False, **
     return flux, L, grads
 
 
+# ------------------------------------------------------------------------------------------
+# The BASELINE configs as steps: what `--config` times, what the `extras` legs report, and what
+# tests/test_gpu_timed_config.py checks against the oracle -- one definition each.
+# ------------------------------------------------------------------------------------------
+class Workload:
+    """One BASELINE config on one rank: `fn(*leaves)` is a value + gradient step over `D` draws; its output
+    `scalar_index` is the per-draw scalar the ranks exchange (sum(gbar * flux) or the log-likelihood), outputs after
+    `grads_from` are the leaf gradients in the order of `names`."""
+
+    def __init__(self, key, label, D, n_cad, names, leaves, fn, scalar_index, grads_from, survey_bytes_per_unit, data, step_text):
+        self.key, self.label, self.D, self.n_cad = key, label, D, n_cad
+        self.names, self.leaves, self.fn = names, leaves, fn
+        self.scalar_index, self.grads_from = scalar_index, grads_from
+        self.survey_bytes_per_unit = survey_bytes_per_unit
+        self.data = data          # the fixed inputs (t, gbar / yobs, ...), for the parity tests
+        self.step_text = step_text
+
+
+def workload_c2(xo, ops, dev, D, rank=0, events=None):
+    """BASELINE configs[1] (module docstring).  `events`: a HipEvents object -> `fn.eager(i)` records pair i around the sweep."""
+    t = torch.arange(N_CAD, dtype=torch.float64, device=dev) * CADENCE
+    gbar = torch.as_tensor(np.random.default_rng(2 + rank).normal(size=(D, N_CAD)), device=dev)
+    leaves = make_leaves(D, 100 + rank, dev)
+    names = list(leaves)
+
+    def fn(*vals):
+        flux, L, grads = step(xo, ops, dict(zip(names, vals)), t, gbar)
+        return (flux, L) + tuple(grads)
+
+    return Workload("c2", "BASELINE configs[1] (C2): single planet e=0.3 Kepler solve + quadratic limb-darkened transit, "
+                    "150000 cadences, value+grad, use_in_transit=False: dense flux output", D, N_CAD, names,
+                    list(leaves.values()), fn, 1, 2, SURVEY_BYTES_PER_UNIT, dict(t=t, gbar=gbar, leaves=leaves),
+                    "leaf params (separate tensors, read in place) -> record-packing kernel (orbit algebra + get_cl) -> window + "
+                    "run-enumeration + heavy kernels (value+VJP, one sweep; the heavy kernel's blocks finish their own draws at "
+                    ">= 512 draws, a separate finish kernel below that) -> packing VJP kernel (cotangent of L folded in) -> leaf "
+                    "gradients: five launches (six below 512 draws)")
+
+
+C3_HYPER = (1e-3, 5.0, 0.7071)       # SHOTerm(sigma, rho, Q) of SURVEY.md 8d C3
+
+
+def workload_c3(xo, ops, dev, D, rank=0):
+    """BASELINE configs[2] (C3): the C2 light curve + a celerite SHO-term GP log-likelihood on the residual; value +
+    gradient w.r.t. the orbit / limb-darkening leaves and the kernel hyper-parameters (sigma, rho, Q) per draw"""
+    t = torch.arange(N_CAD, dtype=torch.float64, device=dev) * CADENCE
+    yobs = torch.as_tensor(5e-4 * np.random.default_rng(3).normal(size=N_CAD), device=dev)     # (the data: same on every rank)
+    leaves = make_leaves(D, 100 + rank, dev)
+    for k, v in zip(("sigma", "rho", "Q"), C3_HYPER):
+        leaves[k] = torch.full((D,), v, dtype=torch.float64, device=dev, requires_grad=True)
+    names = list(leaves)
+
+    def fn(*vals):
+        Lv = dict(zip(names, vals))
+        orbit = xo.KeplerianOrbit(period=Lv["period"], t0=Lv["t0"], b=Lv["b"], ecc=Lv["ecc"], omega=Lv["omega"])
+        lc = xo.LimbDarkLightCurve(Lv["u1"], Lv["u2"]).get_light_curve(orbit=orbit, r=Lv["r"], t=t, total=True)
+        gp = xo.gp.GaussianProcess(xo.gp.terms.SHOTerm(sigma=Lv["sigma"], rho=Lv["rho"], Q=Lv["Q"]), t=t, yerr=5e-4, mean=lc)
+        ll = gp.log_likelihood(yobs)
+        return (ll.detach(),) + torch.autograd.grad(ll.sum(), vals)
+
+    J = 2
+    return Workload("c3", "BASELINE configs[2] (C3): the C2 system + celerite SHOTerm GP log-likelihood (J = 2) on the residual, "
+                    "150000 cadences, value+grad of every leaf incl. (sigma, rho, Q) per draw", D, N_CAD, names,
+                    list(leaves.values()), fn, 0, 1, 48 + 16 * (1 + J + J * J), dict(t=t, yobs=yobs, yerr=5e-4, leaves=leaves),
+                    "packing -> light-curve sweep (summed flux) -> SHO coefficients -> celerite in parallel over time (elements, "
+                    "scan trees, chunk recurrences) -> its reverse -> light-curve VJP sweep -> packing VJP")
+
+
+C4_BASE = dict(period=[3.5, 7.9, 13.1, 29.7], t0=[1.0, 2.3, 5.1, 11.7], b=[0.3, 0.1, 0.5, 0.2],
+               ecc=[0.05, 0.1, 0.2, 0.3], omega=[1.1, -0.4, 2.0, 0.3], r=[0.1, 0.05, 0.07, 0.03])
+C4_NCAD = 200_000
+
+
+def workload_c4(xo, ops, dev, D, rank=0):
+    """BASELINE configs[3] (C4): 4 planets, 200 000 cadences, dense summed flux, value + gradient of all 4 x 6 + 2 leaves
+    per draw; D = this rank's share of the 512 draws (64 on each of 8 GPUs)"""
+    rng = np.random.default_rng(4 + 1000 * rank)
+    n = C4_NCAD
+    t = torch.arange(n, dtype=torch.float64, device=dev) * CADENCE
+    leaves = {}
+    for k, v in C4_BASE.items():
+        x = np.asarray(v)[None, :] * (1 + 1e-3 * rng.normal(size=(D, 4)))
+        if k == "ecc":
+            x = np.clip(x, 0.0, 0.95)
+        leaves[k] = torch.tensor(x, dtype=torch.float64, device=dev, requires_grad=True)
+    leaves["u1"] = torch.full((D,), 0.3, dtype=torch.float64, device=dev, requires_grad=True)
+    leaves["u2"] = torch.full((D,), 0.2, dtype=torch.float64, device=dev, requires_grad=True)
+    gbar = torch.as_tensor(rng.normal(size=(D, n)), device=dev)
+    names = list(leaves)
+
+    def fn(*vals):
+        flux, L, grads = step(xo, ops, dict(zip(names, vals)), t, gbar)
+        return (flux, L) + tuple(grads)
+
+    return Workload("c4", "BASELINE configs[3] (C4): 4-planet system, 200000 cadences, value+grad, dense summed flux", D, n, names,
+                    list(leaves.values()), fn, 1, 2, SURVEY_BYTES_PER_UNIT, dict(t=t, gbar=gbar, leaves=leaves),
+                    "as C2, four planets per draw in one sweep")
+
+
+C5_BASE = dict(period=2.7, t0=0.4, b=0.2, ecc=0.1, omega=0.7, r=0.08)
+C5_NCAD, C5_TEXP = 65_000, 29.4 / 1440.0
+C5_TERMS = ((4e-4, 20.0, 2.0), (3e-4, 10.0, 1.0), (2e-4, 2.0, 0.7071))      # (sigma, rho, Q) of the three SHO terms
+C5_LD = ((0.3, 0.2), (0.4, 0.1))
+C5_YERR = 3e-4
+
+
+def workload_c5(xo, ops, dev, D, rank=0):
+    """BASELINE configs[4] (C5): 65 000 long cadences, exposure stencil x 7, secondary eclipse, three SHO terms (J = 6);
+    D = this rank's share of the 1024 chains (128 on each of 8 GPUs)"""
+    rng = np.random.default_rng(5 + 1000 * rank)
+    n, texp = C5_NCAD, C5_TEXP
+    t = torch.arange(n, dtype=torch.float64, device=dev) * texp
+    mk = lambda v: torch.tensor(v * (1 + 1e-3 * rng.normal(size=(D, 1))), dtype=torch.float64, device=dev,  # noqa: E731
+                                requires_grad=True)
+    leaves = {k: mk(v) for k, v in C5_BASE.items()}
+    vec = lambda v: torch.full((D,), v, dtype=torch.float64, device=dev, requires_grad=True)  # noqa: E731
+    leaves.update(sbr=vec(0.3), s1=vec(C5_TERMS[0][0]), s2=vec(C5_TERMS[1][0]), s3=vec(C5_TERMS[2][0]))
+    yobs = torch.as_tensor(3e-4 * np.random.default_rng(5).normal(size=n), device=dev)       # (the data: same on every rank)
+    ones = torch.ones(D, dtype=torch.float64, device=dev)
+    names = list(leaves)
+    T = xo.gp.terms
+
+    def fn(*vals):
+        Lv = dict(zip(names, vals))
+        orbit = xo.KeplerianOrbit(period=Lv["period"], t0=Lv["t0"], b=Lv["b"], ecc=Lv["ecc"], omega=Lv["omega"])
+        lc = xo.SecondaryEclipseLightCurve(C5_LD[0], C5_LD[1], Lv["sbr"]).get_light_curve(
+            orbit=orbit, r=Lv["r"], t=t, texp=texp, oversample=7, total=True)
+        kern = (T.SHOTerm(sigma=Lv["s1"], rho=C5_TERMS[0][1] * ones, Q=C5_TERMS[0][2] * ones)
+                + T.SHOTerm(sigma=Lv["s2"], rho=C5_TERMS[1][1] * ones, Q=C5_TERMS[1][2] * ones)
+                + T.SHOTerm(sigma=Lv["s3"], rho=C5_TERMS[2][1] * ones, Q=C5_TERMS[2][2] * ones))
+        gp = xo.gp.GaussianProcess(kern, t=t, yerr=C5_YERR, mean=lc)
+        ll = gp.log_likelihood(yobs)
+        return (ll.detach(),) + torch.autograd.grad(ll.sum(), vals)
+
+    J = 6
+    return Workload("c5", "BASELINE configs[4] (C5): 65000 Kepler long cadences, exposure stencil x 7, SecondaryEclipseLightCurve + "
+                    "3-term celerite GP (J = 6), value+grad", D, n, names, list(leaves.values()), fn, 0, 1,
+                    48 + 16 * (1 + J + J * J), dict(t=t, yobs=yobs, yerr=C5_YERR, texp=texp, leaves=leaves),
+                    "packing -> secondary-eclipse light-curve sweep (7 sub-exposures, transit + occultation) -> SHO coefficients "
+                    "x 3 -> celerite (J = 6) in parallel over time -> reverse -> light-curve VJP sweep -> packing VJP")
+
+
+WORKLOADS = {"c2": workload_c2, "c3": workload_c3, "c4": workload_c4, "c5": workload_c5}
+DEFAULT_GLOBAL_DRAWS = {"c4": 512, "c5": 1024}       # BASELINE.json states C4 / C5 as totals over 8 GPUs
+
+
 def exchange_step(exchange, L_local, pipelined=False):
     """the multi-GPU part of a step: one collective, every rank ends up with all per-draw scalars.
     ``pipelined``: the collective is issued asynchronously from a private copy of the rank's scalars and overlaps the
-    next step's kernels (LoglikeExchange.start); the caller ends the loop with ``exchange.finish()``.
+    next step's kernels (LoglikeExchange.start): the return value is then the PREVIOUS step's full vector (None on the
+    first call), and the caller ends the loop with ``exchange.finish()``.
     (tests/test_distributed.py drives this function on CPU under gloo, world size 2.)"""
     if pipelined and not _SYNC_EXCHANGE[0]:
         try:
@@ -179,6 +334,40 @@ def exchange_step(exchange, L_local, pipelined=False):
             print(f"bench.py: asynchronous exchange failed ({e}); using the synchronous collective", file=sys.stderr)
             _SYNC_EXCHANGE[0] = True
     return exchange(L_local)
+
+
+def make_runner(step_fn, scalar_index, exchange, consume):
+    """(run(i), drain()) of the timed loop for ANY config: one step of the rank's shard, then -- with several ranks -- the
+    step's ONE collective of per-draw scalars, whose previous result is consumed; `drain` waits for the collective still
+    in flight and consumes it (called inside the timed region).  tests/test_distributed.py drives this on CPU (gloo,
+    world size 2) with a stand-in step."""
+    def run(i):
+        out = step_fn()
+        if exchange is not None:
+            consume(exchange_step(exchange, out[scalar_index], pipelined=True))
+
+    def drain():
+        if exchange is not None:
+            consume(exchange.finish())
+
+    return run, drain
+
+
+class ExchangeConsumer:
+    """what a sampler does with the exchanged vector, reduced to its cost: every step's full (n_global,) vector is
+    folded into running sums (cross-chain mean / second moment for adaptation and logging) on the device -- one small
+    kernel per step, inside the timed region, so the timed step covers an exchange whose result is USED"""
+
+    def __init__(self, n_global, dev):
+        self.acc = torch.zeros(2, n_global, dtype=torch.float64, device=dev)
+        self.steps = 0
+
+    def __call__(self, full):
+        if full is None:
+            return
+        self.acc[0].add_(full)
+        self.acc[1].addcmul_(full, full)
+        self.steps += 1
 
 
 _SYNC_EXCHANGE = [os.environ.get("EXO_BENCH_SYNC_EXCHANGE") == "1"]
@@ -244,12 +433,16 @@ def usable_cpus():
     return n, why
 
 
-def cpu_baseline(budget_s=24.0):
-    """oracle/c on the host cores of this box, on a bounded sample of the C2 workload:
-    (i) 1 core, every cadence evaluated (what the reference does with use_in_transit=False);
-    (ii) 1 core, in-transit cadences only (the reference's default use_in_transit=True);
-    (iii) all cores, one draw per thread (PyMC's one process per chain on every core), every cadence;
-    (iv) all cores, in-transit only."""
+def cpu_baseline(budget_s=27.0, config="c2"):
+    """oracle/c on the host cores of this box, on a bounded sample of the workload.  C2 (the headline):
+    (i) 1 core, in-transit cadences only (the reference's default use_in_transit=True, and what the GPU sweep solves:
+        the like-for-like leg = `value`);
+    (ii) 1 core, every cadence evaluated (what the reference does with use_in_transit=False);
+    (iii) / (iv) the same on all usable cores, one draw per thread (PyMC's one process per chain on every core).
+    Then one leg each (1 core, all cores) for C3, C4 and C5: light curve value + VJP [+ celerite log-likelihood +
+    gradient] per evaluation, the configs the `extras` legs time on the GPU."""
+    from concurrent.futures import ThreadPoolExecutor
+
     from oracle import c_port as C
     from oracle import numpy_port as P
 
@@ -263,61 +456,129 @@ def cpu_baseline(budget_s=24.0):
     usable, usable_why = usable_cpus()
     n_threads = int(os.environ.get("EXO_BENCH_CPU_THREADS", usable))
     rng = np.random.default_rng(2)
-    t = np.arange(N_CAD) * CADENCE
-    orbit = P.KeplerianOrbit(period=3.5, t0=1.0, b=0.3, ecc=0.3, omega=1.1)
 
-    def records(n_draw, window):
-        ts, te = (-np.inf, np.inf)
-        rec = np.zeros((n_draw, 1, P.NPAR))
-        rec[:, 0, [P.P_N, P.P_TP, P.P_ECC, P.P_COSW, P.P_SINW, P.P_COSI, P.P_SINI, P.P_AOR, P.P_ROR]] = [
-            orbit.n[0], orbit.t_periastron[0], 0.3, np.cos(1.1), np.sin(1.1), orbit.cos_incl[0], orbit.sin_incl[0],
-            orbit.a[0], 0.1]
-        if window:   # first / fourth contact relative to t0 (keplerian.py:744-763)
-            Ml, Mr, flag = P.contact_points(orbit.a, orbit.ecc, orbit.cos_omega, orbit.sin_omega, orbit.cos_incl,
-                                            orbit.sin_incl, orbit.r_star + 0.1)
-            assert np.all(flag == 0)
-            hp = 0.5 * orbit.period
-            ts = float(np.ravel(np.mod((Ml - orbit.M0) / orbit.n + hp, orbit.period) - hp)[0])
-            te = float(np.ravel(np.mod((Mr - orbit.M0) / orbit.n + hp, orbit.period) - hp)[0])
-            ts = ts - 3.5 if ts > 0 else ts
-            te = te + 3.5 if te < 0 else te
-        rec[:, 0, [P.P_T0, P.P_PERIOD, P.P_TS, P.P_TE, P.P_TS2, P.P_TE2]] = [1.0, 3.5, ts, te, -np.inf, np.inf]
-        rec[:, 0, P.P_ROR] *= 1 + 1e-3 * rng.normal(size=n_draw)
+    def contact_window(orbit, r):
+        """first / fourth contact relative to t0 (keplerian.py:744-763)"""
+        Ml, Mr, flag = P.contact_points(orbit.a, orbit.ecc, orbit.cos_omega, orbit.sin_omega, orbit.cos_incl,
+                                        orbit.sin_incl, orbit.r_star + r)
+        assert np.all(flag == 0)
+        hp = 0.5 * orbit.period
+        ts = np.mod((Ml - orbit.M0) / orbit.n + hp, orbit.period) - hp
+        te = np.mod((Mr - orbit.M0) / orbit.n + hp, orbit.period) - hp
+        return np.where(ts > 0, ts - orbit.period, ts), np.where(te < 0, te + orbit.period, te)
+
+    def records(orbit, r, n_draw, window, sbr=None):
+        Pn = orbit.a.size
+        rec = np.zeros((n_draw, Pn, P.NPAR))
+        rec[:, :, P.P_N], rec[:, :, P.P_TP], rec[:, :, P.P_ECC] = orbit.n, orbit.t_periastron, orbit.ecc
+        rec[:, :, P.P_COSW], rec[:, :, P.P_SINW] = orbit.cos_omega, orbit.sin_omega
+        rec[:, :, P.P_COSI], rec[:, :, P.P_SINI] = orbit.cos_incl, orbit.sin_incl
+        rec[:, :, P.P_AOR], rec[:, :, P.P_ROR] = orbit.a / orbit.r_star, r / orbit.r_star
+        rec[:, :, P.P_T0], rec[:, :, P.P_PERIOD] = orbit.t0, orbit.period
+        ts, te = contact_window(orbit, r) if window else (-np.inf, np.inf)
+        rec[:, :, P.P_TS], rec[:, :, P.P_TE], rec[:, :, P.P_TS2], rec[:, :, P.P_TE2] = ts, te, -np.inf, np.inf
+        if sbr is not None:
+            rec[:, :, P.P_FRATIO] = sbr * (r / orbit.r_star) ** 2
+        rec[:, :, P.P_ROR] *= 1 + 1e-3 * rng.normal(size=(n_draw, Pn))
         return rec
 
-    def leg(n_draw, threads, window, seconds):
-        lib.oracle_set_threads(int(threads))
-        rec = records(n_draw, window)
-        c = np.repeat(P.get_cl(0.3, 0.2)[None], n_draw, 0)
-        g = rng.normal(size=(n_draw, N_CAD))
-        C.transit(t, rec, c, g, window=window)  # warm
+    def timed(call, n_per_call, seconds):
+        call()  # warm
         n, t0 = 0, time.perf_counter()
         while time.perf_counter() - t0 < seconds:
-            C.transit(t, rec, c, g, window=window)
-            n += n_draw
+            call()
+            n += n_per_call
         dt = time.perf_counter() - t0
-        return {"evals_per_s": n / dt, "evals": n, "seconds": dt, "threads": int(threads),
-                "semantics": "in-transit cadences only (use_in_transit=True)" if window else
-                             "every cadence solved (use_in_transit=False)"}
+        return {"evals_per_s": n / dt, "evals": n, "seconds": dt}
 
-    share = budget_s / 4.0
-    legs = {"one_core_every_cadence": leg(1, 1, False, share)}
-    try:
-        legs["one_core_in_transit"] = leg(1, 1, True, share)
-    except Exception as exc:      # window helper missing in the oracle: report, do not die
-        legs["one_core_in_transit"] = {"error": repr(exc)[:160]}
-    legs["all_cores_every_cadence"] = leg(n_threads, n_threads, False, share)
-    try:
-        legs["all_cores_in_transit"] = leg(4 * n_threads, n_threads, True, share)
-    except Exception as exc:
-        legs["all_cores_in_transit"] = {"error": repr(exc)[:160]}
+    def c2_leg(n_draw, threads, window, seconds):
+        lib.oracle_set_threads(int(threads))
+        t = np.arange(N_CAD) * CADENCE
+        orbit = P.KeplerianOrbit(period=3.5, t0=1.0, b=0.3, ecc=0.3, omega=1.1)
+        rec = records(orbit, np.array([0.1]), n_draw, window)
+        c = np.repeat(P.get_cl(0.3, 0.2)[None], n_draw, 0)
+        g = rng.normal(size=(n_draw, N_CAD))
+        out = timed(lambda: C.transit(t, rec, c, g, window=window), n_draw, seconds)
+        out.update(threads=int(threads), semantics="in-transit cadences only (use_in_transit=True)" if window else
+                   "every cadence solved (use_in_transit=False)")
+        return out
+
+    def gp_config_leg(which, threads, seconds):
+        """C3 / C5: light curve value + VJP, then celerite log-likelihood + gradient of the residual, per draw; `threads`
+        draws at once (the C port's light curve is OpenMP over draws; the celerite calls run in a thread pool: ctypes
+        releases the GIL)"""
+        lib.oracle_set_threads(int(threads))
+        n_draw = int(threads)
+        if which == "c3":
+            n, kw, sec = N_CAD, {}, False
+            t = np.arange(n) * CADENCE
+            orbit = P.KeplerianOrbit(period=3.5, t0=1.0, b=0.3, ecc=0.3, omega=1.1)
+            rec = records(orbit, np.array([0.1]), n_draw, True)
+            c = np.repeat(P.get_cl(0.3, 0.2)[None], n_draw, 0)
+            parts = [P.sho_coefficients(*P.sho_from_sigma_rho(*C3_HYPER), C3_HYPER[2])]
+            yerr = 5e-4
+        else:
+            n, sec = C5_NCAD, True
+            t = np.arange(n) * C5_TEXP
+            orbit = P.KeplerianOrbit(**{k: v for k, v in C5_BASE.items() if k != "r"})
+            rec = records(orbit, np.array([C5_BASE["r"]]), n_draw, True, sbr=0.3)
+            c = np.repeat(np.concatenate([P.get_cl(*C5_LD[0]), P.get_cl(*C5_LD[1])])[None], n_draw, 0)
+            sdt, sw = P.exposure_stencil(7, 0)
+            kw = dict(texp=C5_TEXP, stencil_dt=sdt, stencil_w=sw, secondary=True)
+            parts = [P.sho_coefficients(*P.sho_from_sigma_rho(sg, rho, q), q) for sg, rho, q in C5_TERMS]
+            yerr = C5_YERR
+        co = tuple(np.concatenate(x) for x in zip(*parts))
+        y = yerr * rng.normal(size=n)
+        diag = np.full(n, yerr * yerr)
+        pool = ThreadPoolExecutor(max_workers=n_draw)
+
+        def call():
+            f, gp, gl = C.transit(t, rec, c, None, window=not sec, want_flux=True, **kw)
+            res = list(pool.map(lambda d: C.celerite(t, y - f[d], diag, co, grad=True), range(n_draw)))
+            gres = np.stack([-r[1]["y"] for r in res])
+            C.transit(t, rec, c, gres, window=not sec, want_flux=False, **kw)
+
+        out = timed(call, n_draw, seconds)
+        pool.shutdown()
+        out.update(threads=int(threads), semantics="light curve (in-transit cadences only) + celerite log-likelihood, value + "
+                   "gradient" if not sec else "secondary-eclipse light curve (every cadence, 7 sub-exposures) + 3-term celerite "
+                   "log-likelihood, value + gradient")
+        return out
+
+    def c4_leg(threads, seconds):
+        lib.oracle_set_threads(int(threads))
+        n_draw = int(threads)
+        t = np.arange(C4_NCAD) * CADENCE
+        orbit = P.KeplerianOrbit(**{k: np.array(v) for k, v in C4_BASE.items() if k != "r"})
+        rec = records(orbit, np.array(C4_BASE["r"]), n_draw, True)
+        c = np.repeat(P.get_cl(0.3, 0.2)[None], n_draw, 0)
+        g = rng.normal(size=(n_draw, C4_NCAD))
+        out = timed(lambda: C.transit(t, rec, c, g, window=True), n_draw, seconds)
+        out.update(threads=int(threads), semantics="4 planets, in-transit cadences only, value + VJP")
+        return out
+
+    def guarded(fn, *a):
+        try:
+            return fn(*a)
+        except Exception as exc:      # a leg must not take the record down with it
+            return {"error": repr(exc)[:200]}
+
+    share = budget_s / 10.0
+    legs = {"one_core_in_transit": guarded(c2_leg, 1, 1, True, share),
+            "one_core_every_cadence": guarded(c2_leg, 1, 1, False, share),
+            "all_cores_in_transit": guarded(c2_leg, 4 * n_threads, n_threads, True, share),
+            "all_cores_every_cadence": guarded(c2_leg, n_threads, n_threads, False, share),
+            "c3_one_core": guarded(gp_config_leg, "c3", 1, share), "c3_all_cores": guarded(gp_config_leg, "c3", n_threads, share),
+            "c4_one_core": guarded(c4_leg, 1, share), "c4_all_cores": guarded(c4_leg, n_threads, share),
+            "c5_one_core": guarded(gp_config_leg, "c5", 1, share), "c5_all_cores": guarded(gp_config_leg, "c5", n_threads, share)}
     lib.oracle_set_threads(1)
-    one = legs["one_core_every_cadence"]
-    return {"value": one["evals_per_s"], "unit": "evals/s", "cores": 1, "kind": "port",
-            "sample": f"{one['evals']} evaluations (value+VJP, every cadence solved) of the {N_CAD}-cadence C2 "
-                      f"system, oracle/c scalar port, {one['seconds']:.1f} s on 1 of {os.cpu_count()} host cores; "
-                      f"legs: the same on all {n_threads} usable cores ({usable_why}; OpenMP, one draw per thread) and "
-                      "with the reference's default in-transit selection",
+    head = {"c2": "one_core_in_transit", "c3": "c3_one_core", "c4": "c4_one_core", "c5": "c5_one_core"}[config]
+    one = legs[head]
+    return {"value": one.get("evals_per_s"), "unit": "evals/s", "cores": 1, "kind": "port", "leg": head,
+            "sample": f"{one.get('evals')} evaluations (value+VJP; {one.get('semantics')}) of the {config.upper()} workload, oracle/c "
+                      f"scalar port, {one.get('seconds', 0):.1f} s on 1 of {os.cpu_count()} host cores -- the like-for-like leg: "
+                      "the GPU sweep solves only the cadences inside its conjunction windows too.  `legs`: every-cadence "
+                      f"semantics, all {n_threads} usable cores ({usable_why}; one draw per thread), and C3 / C4 / C5",
             "cpu_model": cpu_model(), "host_cores": os.cpu_count(), "usable_cores": usable, "usable_cores_from": usable_why,
             "legs": legs,
             "note": "the reference's own Ops (exoplanet_core, celerite2) are not installable here: kind = port"}
@@ -381,99 +642,80 @@ def graphed(xo, fn, inputs, dev, iters):
         return q, f"eager launches (capture failed: {repr(exc)[:120]})"
 
 
-def extra_c3(xo, leaves, t, dev, D):
-    """BASELINE configs[2] (C3): the C2 light curve + a celerite SHO-term GP log-likelihood on the
-    residual; value + gradient w.r.t. the orbit / limb-darkening leaves and the kernel hyper-parameters"""
-    yobs = 5e-4 * torch.randn(N_CAD, dtype=torch.float64, device=dev)
-    names = list(leaves)
-    hyper = [torch.full((D,), v, dtype=torch.float64, device=dev, requires_grad=True) for v in (1e-3, 5.0, 0.7071)]
-
-    def one(*vals):
-        Lv = dict(zip(names, vals[:len(names)]))
-        sigma, rho, Q = vals[len(names):]
-        orbit = xo.KeplerianOrbit(period=Lv["period"], t0=Lv["t0"], b=Lv["b"], ecc=Lv["ecc"], omega=Lv["omega"])
-        lc = xo.LimbDarkLightCurve(Lv["u1"], Lv["u2"]).get_light_curve(orbit=orbit, r=Lv["r"], t=t, total=True)
-        gp = xo.gp.GaussianProcess(xo.gp.terms.SHOTerm(sigma=sigma, rho=rho, Q=Q), t=t, yerr=5e-4, mean=lc)
-        ll = gp.log_likelihood(yobs)
-        return (ll.detach(),) + torch.autograd.grad(ll.sum(), vals)
-
-    q, how = graphed(xo, one, list(leaves.values()) + hyper, dev, 12)
-    J = 2
-    bpu = 48 + 16 * (1 + J + J * J)
-    gbps = bpu * D * N_CAD / (q["median_ms"] * 1e-3) / 1e9
-    return {"evals_per_s": D / (q["median_ms"] * 1e-3), **q, "draws": D, "launch": how,
-            "survey_8d_bytes_per_unit": bpu, "survey_8d_GBps": gbps, "survey_8d_frac_of_hbm_peak": gbps / HBM_PEAK_GBS,
-            "note": "C3: C2 light curve + SHO-term celerite GP on the residual (recurrences in parallel over "
-                    "time), value + gradient of every leaf incl. (sigma, rho, Q) per draw"}
+def extra_config(xo, ops, dev, key, D, iters):
+    """one of the BASELINE configs at a per-GPU size, as the very step `--config` times (hipGraph replay)"""
+    w = WORKLOADS[key](xo, ops, dev, D)
+    q, how = graphed(xo, w.fn, w.leaves, dev, iters)
+    gbps = w.survey_bytes_per_unit * D * w.n_cad / (q["median_ms"] * 1e-3) / 1e9
+    out = {"evals_per_s": D / (q["median_ms"] * 1e-3), **q, "draws": D, "n_cadences": w.n_cad, "launch": how,
+           "survey_8d_bytes_per_unit": w.survey_bytes_per_unit, "survey_8d_GBps": gbps,
+           "survey_8d_frac_of_hbm_peak": gbps / HBM_PEAK_GBS, "note": w.label + "; step: " + w.step_text,
+           "same_step_as": f"bench.py --config {key} --global-draws {D}"}
+    del w
+    torch.cuda.empty_cache()
+    return out
 
 
-def extra_c4(xo, dev, D=64):
-    """BASELINE configs[3] (C4) at its per-GPU size: 4 planets, 200 000 cadences, 64 draws"""
-    rng = np.random.default_rng(4)
-    n = 200_000
-    t = torch.arange(n, dtype=torch.float64, device=dev) * CADENCE
-    base = dict(period=[3.5, 7.9, 13.1, 29.7], t0=[1.0, 2.3, 5.1, 11.7], b=[0.3, 0.1, 0.5, 0.2],
-                ecc=[0.05, 0.1, 0.2, 0.3], omega=[1.1, -0.4, 2.0, 0.3], r=[0.1, 0.05, 0.07, 0.03])
-    leaves = {}
-    for k, v in base.items():
-        x = np.asarray(v)[None, :] * (1 + 1e-3 * rng.normal(size=(D, 4)))
-        if k == "ecc":
-            x = np.clip(x, 0.0, 0.95)
-        leaves[k] = torch.tensor(x, dtype=torch.float64, device=dev, requires_grad=True)
-    leaves["u1"] = torch.full((D,), 0.3, dtype=torch.float64, device=dev, requires_grad=True)
-    leaves["u2"] = torch.full((D,), 0.2, dtype=torch.float64, device=dev, requires_grad=True)
-    gbar = torch.randn(D, n, dtype=torch.float64, device=dev)
-    names = list(leaves)
-    from exoplanet_amd import ops
-
-    def one(*vals):
-        _, L, grads = step(xo, ops, dict(zip(names, vals)), t, gbar)
+def sparse_step_fn(xo, ops, names, t, gbar):
+    """the C2 step with EXO_FLAG_SPARSE (`extras.c2_sparse_output`): (L, *leaf gradients); no dense flux array"""
+    def fn(*vals):
+        _, L, grads = step(xo, ops, dict(zip(names, vals)), t, gbar, sparse=True)
         return (L.detach(),) + grads
-
-    q, how = graphed(xo, one, list(leaves.values()), dev, 40)
-    gbps = SURVEY_BYTES_PER_UNIT * D * n / (q["median_ms"] * 1e-3) / 1e9
-    return {"evals_per_s": D / (q["median_ms"] * 1e-3), **q, "draws": D, "n_cadences": n, "n_planets": 4,
-            "launch": how, "survey_8d_GBps": gbps, "survey_8d_frac_of_hbm_peak": gbps / HBM_PEAK_GBS,
-            "note": "C4 at the per-GPU size of its 8-GPU statement (512 draws / 8): dense summed flux, value + "
-                    "gradient of all 4 x 6 + 2 leaves per draw"}
+    return fn
 
 
-def extra_c5(xo, dev, D=128):
-    """BASELINE configs[4] (C5) at its per-GPU size: 65 000 long cadences, exposure stencil x 7,
-    secondary eclipse, three SHO terms (J = 6), 128 chains"""
-    rng = np.random.default_rng(5)
-    n = 65_000
-    texp = 29.4 / 1440.0
-    t = torch.arange(n, dtype=torch.float64, device=dev) * texp
-    mk = lambda v: torch.tensor(v * (1 + 1e-3 * rng.normal(size=(D, 1))), dtype=torch.float64, device=dev,  # noqa: E731
-                                requires_grad=True)
-    leaves = {k: mk(v) for k, v in dict(period=2.7, t0=0.4, b=0.2, ecc=0.1, omega=0.7, r=0.08).items()}
-    vec = lambda v: torch.full((D,), v, dtype=torch.float64, device=dev, requires_grad=True)  # noqa: E731
-    leaves.update(sbr=vec(0.3), s1=vec(4e-4), s2=vec(3e-4), s3=vec(2e-4))
-    yobs = 3e-4 * torch.randn(n, dtype=torch.float64, device=dev)
-    ones = torch.ones(D, dtype=torch.float64, device=dev)
-    names = list(leaves)
-    T = xo.gp.terms
-
-    def one(*vals):
+def likelihood_step_fn(xo, names, t, obs, yerr):
+    """C2 as a white-noise likelihood (`extras.c2_white_noise_likelihood`): (ll, *leaf gradients)"""
+    def fn(*vals):
         Lv = dict(zip(names, vals))
         orbit = xo.KeplerianOrbit(period=Lv["period"], t0=Lv["t0"], b=Lv["b"], ecc=Lv["ecc"], omega=Lv["omega"])
-        lc = xo.SecondaryEclipseLightCurve((0.3, 0.2), (0.4, 0.1), Lv["sbr"]).get_light_curve(
-            orbit=orbit, r=Lv["r"], t=t, texp=texp, oversample=7, total=True)
-        kern = (T.SHOTerm(sigma=Lv["s1"], rho=20.0 * ones, Q=2.0 * ones) + T.SHOTerm(sigma=Lv["s2"], rho=10.0 * ones, Q=ones)
-                + T.SHOTerm(sigma=Lv["s3"], rho=2.0 * ones, Q=0.7071 * ones))
-        gp = xo.gp.GaussianProcess(kern, t=t, yerr=3e-4, mean=lc)
-        ll = gp.log_likelihood(yobs)
+        ll = xo.LimbDarkLightCurve(Lv["u1"], Lv["u2"]).white_noise_log_likelihood(orbit=orbit, r=Lv["r"], t=t, y=obs, yerr=yerr)
         return (ll.detach(),) + torch.autograd.grad(ll.sum(), vals)
+    return fn
 
-    q, how = graphed(xo, one, list(leaves.values()), dev, 12)
-    J = 6
-    bpu = 48 + 16 * (1 + J + J * J)
-    gbps = bpu * D * n / (q["median_ms"] * 1e-3) / 1e9
-    return {"evals_per_s": D / (q["median_ms"] * 1e-3), **q, "draws": D, "n_cadences": n, "launch": how,
-            "survey_8d_bytes_per_unit": bpu, "survey_8d_GBps": gbps, "survey_8d_frac_of_hbm_peak": gbps / HBM_PEAK_GBS,
-            "note": "C5 at the per-GPU size of its 8-GPU statement (1024 chains / 8): secondary-eclipse light "
-                    "curve (7 sub-exposures) + 3-term GP, value + gradient"}
+
+def extra_gp_conditioning(xo, ops, dev, D):
+    """The celerite log-likelihood alone (value + gradient of the hyper-parameters and of the series) at the C3 shape for
+    kernels of increasing difficulty for the time-parallel form: the clean SHO term; 1 % of the draws within 1 % of
+    critical damping; a Matern-3/2 term (celerite2's eps = 0.01 approximation: b / a = 100); a RotationTerm whose
+    second mode sits near Q = 1/2 -- the cases DESIGN.md 3.5 used to send to the sequential kernels."""
+    T = xo.gp.terms
+    t = torch.arange(N_CAD, dtype=torch.float64, device=dev) * CADENCE
+    y = torch.as_tensor(5e-4 * np.random.default_rng(3).normal(size=N_CAD), device=dev)
+    model = torch.zeros(D, N_CAD, dtype=torch.float64, device=dev, requires_grad=True)
+    full = lambda v: torch.full((D,), v, dtype=torch.float64, device=dev, requires_grad=True)  # noqa: E731
+    Qmix = np.full(D, 0.7071)
+    Qmix[: max(1, D // 100): 2] = 0.505
+    Qmix[1: max(2, D // 100): 2] = 0.495
+    cases = {
+        "sho_clean": ([full(1e-3), full(5.0), full(0.7071)], lambda s, r, q: T.SHOTerm(sigma=s, rho=r, Q=q)),
+        "sho_1pct_near_critical": ([full(1e-3), full(5.0), torch.tensor(Qmix, device=dev, requires_grad=True)],
+                                   lambda s, r, q: T.SHOTerm(sigma=s, rho=r, Q=q)),
+        "matern32": ([full(1e-3), full(5.0)], lambda s, r: T.Matern32Term(sigma=s, rho=r)),
+        "rotation_term": ([full(1e-3), full(5.0), full(0.02), full(0.5), full(0.5)],
+                          lambda s, p, q0, dq, f: T.RotationTerm(sigma=s, period=p, Q0=q0, dQ=dq, f=f)),
+    }
+    out = {}
+    for name, (hyper, build) in cases.items():
+        def fn(m, *h):
+            gp = xo.gp.GaussianProcess(build(*h), t=t, yerr=5e-4, mean=m)
+            ll = gp.log_likelihood(y)
+            return (ll.detach(),) + torch.autograd.grad(ll.sum(), (m,) + h)
+        try:
+            q, how = graphed(xo, fn, [model] + hyper, dev, 8)
+            out[name] = {"median_ms": q["median_ms"], "launch": how}
+        except Exception as exc:
+            out[name] = {"error": repr(exc)[:200]}
+        torch.cuda.synchronize(dev)
+    if "median_ms" in out.get("sho_clean", {}):
+        for k, v in out.items():
+            if "median_ms" in v:
+                v["over_clean"] = v["median_ms"] / out["sho_clean"]["median_ms"]
+    out["draws"], out["n_cadences"] = D, N_CAD
+    out["note"] = ("GP log-likelihood + gradients alone (no light curve); `over_clean` = step time relative to the clean SHO "
+                   "batch: the cost of ill-conditioned draws in a batch (round 2: ~45x when a draw fell back to the sequential "
+                   "kernels)")
+    return out
 
 
 def extra_astrometry(xo, dev, D=1024, n_epoch=64):
@@ -599,14 +841,31 @@ def extra_ttv(xo, ops, leaves, t, gbar, dev, D):
                     "`likelihood`: the same orbit through white_noise_log_likelihood (one evaluation per solved cadence)"}
 
 
+def load_counters():
+    """This round's committed counter record (profiles/r03_counters.json: rocprofv3 --pmc passes, tools/profile_r03.sh),
+    quoted only when it was taken on the kernel sources this run executes (sha256 of the .hip / .hpp files)."""
+    try:
+        import hashlib
+
+        p = json.load(open(os.path.join(ROOT, "profiles", "r03_counters.json")))
+        h = hashlib.sha256()
+        for f in sorted(p["kernel_sources"]):
+            h.update(open(os.path.join(ROOT, "exoplanet_amd", "csrc", f), "rb").read())
+        return p if h.hexdigest() == p["kernel_sources_sha256"] else None
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", choices=sorted(WORKLOADS), default="c2", help="the BASELINE config whose step is timed")
     ap.add_argument("--draws-per-gpu", type=int, default=1024)
     ap.add_argument("--global-draws", type=int, default=0,
-                    help="fix the TOTAL number of draws (strong scaling: BASELINE C4 = 512, C5 = 1024 over 8 GPUs)")
+                    help="fix the TOTAL number of draws (strong scaling); default for --config c4 / c5: 512 / 1024, "
+                         "as BASELINE.json states them over 8 GPUs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch the step eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-extras", action="store_true")
@@ -637,49 +896,36 @@ def main():
     from exoplanet_amd.distributed import LoglikeExchange, shard_bounds
 
     _lib.load()  # fail loudly if the HIP library is missing
-    if args.global_draws:
-        lo, hi = shard_bounds(args.global_draws, rank, world)
-        D, n_global, scaling = hi - lo, args.global_draws, "strong"
+    cfg = args.config
+    global_draws = args.global_draws or DEFAULT_GLOBAL_DRAWS.get(cfg, 0)
+    if global_draws:
+        lo, hi = shard_bounds(global_draws, rank, world)
+        D, n_global, scaling = hi - lo, global_draws, "strong"
     else:
         D, n_global, scaling = args.draws_per_gpu, world * args.draws_per_gpu, "weak"
-    t = torch.arange(N_CAD, dtype=torch.float64, device=dev) * CADENCE
-    gbar = torch.as_tensor(np.random.default_rng(2 + rank).normal(size=(D, N_CAD)), device=dev)
-    leaves = make_leaves(D, 100 + rank, dev)
-    exchange = LoglikeExchange(n_global, dev) if dist is not None else None
     events = HipEvents(max(args.steps, 20))
+    wl = WORKLOADS[cfg](xo, ops, dev, D, rank)
+    leaves = dict(zip(wl.names, wl.leaves))
+    N = wl.n_cad
+    exchange = LoglikeExchange(n_global, dev) if dist is not None else None
+    consume = ExchangeConsumer(n_global, dev) if exchange is not None else None
 
-    def one(i, ev=True):
-        evs = events.handles(i) if (ev and i >= 0) else (None, None)
-        flux, L, grads = step(xo, ops, leaves, t, gbar, events=evs)
-        if exchange is not None:
-            exchange_step(exchange, L, pipelined=True)
-        return flux, L, grads
-
-    # The step is a dozen short launches (packing kernel, window, scan, heavy, reduce, packing VJP and
-    # a few tensor-shuffling torch kernels): launch-bound when issued eagerly, so the timed region
-    # replays it as ONE hipGraph; the collective -- exactly one call, straight from the graph's static
-    # output -- stays outside the graph.
+    # The step is a handful of short launches: launch-bound when issued eagerly, so the timed region replays it as ONE
+    # hipGraph; the collective -- exactly one call, from the graph's static output -- stays outside the graph, and the
+    # full vector it hands back (the previous step's) is folded into the running cross-chain sums.
     graph = None
-    static = {}
     if not args.no_graph:
-        names = list(leaves)
-        graph = xo.GraphedStep(lambda *vals: step(xo, ops, dict(zip(names, vals)), t, gbar), *leaves.values())
-        static["flux"], static["L"], static["grads"] = graph.outputs
+        graph = xo.GraphedStep(wl.fn, *wl.leaves)
 
-    def one_graph(i):
-        graph()
-        if exchange is not None:
-            exchange_step(exchange, static["L"], pipelined=True)
+    run, drain = make_runner(graph if graph is not None else (lambda: wl.fn(*wl.leaves)), wl.scalar_index, exchange, consume)
 
-    run = one_graph if graph is not None else (lambda i: one(i, ev=False))
     # setup, outside the contract's W + K steps: bring clocks, caches and the allocator to the state a sampler runs
     # in (a few hundred steps, ~0.1 s; the same count on every rank)
-    SETUP_STEPS = 300
+    SETUP_STEPS = 300 if cfg in ("c2", "c4") else 30
     for _ in range(SETUP_STEPS):
         run(-1)
     torch.cuda.synchronize(dev)
-    drain = exchange.finish if exchange is not None else None
-    wall = time_steps(run, args.steps, args.warmup, dist, dev, drain=drain)
+    wall = time_steps(run, args.steps, args.warmup, dist, dev, drain=drain if exchange is not None else None)
     wall_t = torch.tensor([wall], dtype=torch.float64, device=dev)
     if dist is not None:
         dist.all_reduce(wall_t, op=dist.ReduceOp.MAX)
@@ -690,38 +936,42 @@ def main():
         # max-over-ranks step time above, so it is the same on every rank
         n_stat = int(min(6000, max(100, np.ceil(2.0 / max(wall / args.steps, 1e-6)))))
         timing = stats_loop(run, dev, n_stat)
-        if exchange is not None:
-            exchange.finish()
+        drain()
         if dist is not None:
             dist.barrier()
-    # hipEvents cannot bracket a node inside a replayed graph: time the kernels of the sweep over
-    # directly launched steps on the same inputs (events recorded by the C ABI on the launch stream)
-    n_ev = len(events.pairs)
-    for i in range(n_ev):
-        one(i)
-    torch.cuda.synchronize(dev)
-    kernel_ms, per_launch = events.mean_ms()
-    # cadences the sweep solves = the runs of the conjunction windows (one sparse sweep, outside any timing)
-    with torch.no_grad():
-        orbit0 = xo.KeplerianOrbit(period=leaves["period"], t0=leaves["t0"], b=leaves["b"], ecc=leaves["ecc"],
-                                   omega=leaves["omega"])
-        rec0, ld0, _, flags0 = orbit0.kernel_inputs(leaves["r"], (leaves["u1"], leaves["u2"]), use_in_transit=False)
-        n_active = ops.transit_flux_sparse(t, rec0.detach(), ld0.detach(), flags=flags0).n_solved()
+
+    light_curve_only = cfg in ("c2", "c4")
+    kernel_ms = per_launch = n_active = None
+    if light_curve_only:
+        # hipEvents cannot bracket a node inside a replayed graph: time the kernels of the sweep over
+        # directly launched steps on the same inputs (events recorded by the C ABI on the launch stream)
+        n_ev = len(events.pairs)
+        t_dev, gbar = wl.data["t"], wl.data["gbar"]
+        for i in range(n_ev):
+            step(xo, ops, leaves, t_dev, gbar, events=events.handles(i))
+        torch.cuda.synchronize(dev)
+        kernel_ms, per_launch = events.mean_ms()
+        # cadences the sweep solves = the runs of the conjunction windows (one sparse sweep, outside any timing)
+        with torch.no_grad():
+            orbit0 = xo.KeplerianOrbit(period=leaves["period"], t0=leaves["t0"], b=leaves["b"], ecc=leaves["ecc"],
+                                       omega=leaves["omega"])
+            rec0, ld0, _, flags0 = orbit0.kernel_inputs(leaves["r"], (leaves["u1"], leaves["u2"]), use_in_transit=False)
+            n_active = ops.transit_flux_sparse(t_dev, rec0.detach(), ld0.detach(), flags=flags0).n_solved()
+    else:
+        # GP configs: the step is a chain of ~20 kernels; the whole replayed step is timed with events on the stream it
+        # is replayed on (per-kernel averages and counters: profiles/r03_*)
+        q = time_events(lambda: run(-1), dev, 20)
+        drain()
+        kernel_ms = q["median_ms"]
 
     out = None
     if rank == 0:
         evals = n_global * args.steps
-        # bytes this design must move per sweep: the dense flux array once (zeros); for every solved
-        # cadence t and gbar in, its flux out to the run-ordered value array, back in and out to its
-        # place in the flux array (the binary searches of the windows are a few MB)
-        req = {"flux_zero_fill": 8 * D * N_CAD, "t_and_gbar_solved": 16 * n_active,
-               "value_and_cadence_arrays_write_read": 24 * n_active, "flux_write_solved": 8 * n_active}
-        req_bytes = sum(req.values())
-        achieved = req_bytes / (kernel_ms * 1e-3) / 1e9
-        survey_bytes = SURVEY_BYTES_PER_UNIT * D * N_CAD
-        traffic = measured_traffic(D)
+        survey_bytes = wl.survey_bytes_per_unit * D * N
+        counters = load_counters()
         out = {
-            "metric": "light-curve evals/sec (value+grad) at 150k cadences",
+            "metric": "light-curve evals/sec (value+grad) at 150k cadences" if cfg == "c2" else
+                      f"evals/sec (value+grad) of BASELINE config {cfg.upper()} ({N} cadences)",
             "value": evals / wall,
             "unit": "evals/s",
             "n_gpus": world,
@@ -735,50 +985,80 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": "BASELINE configs[1] (C2): single planet e=0.3 Kepler solve + quadratic limb-darkened "
-                            "transit, 150000 cadences, value+grad, use_in_transit=False: dense flux output, every "
-                            f"cadence classified on the device, {100.0 * n_active / (D * N_CAD):.2f} % solved",
-                "n_cadences": N_CAD, "draws_per_gpu": D, "global_draws": n_global,
+                "workload": wl.label + (f", every cadence classified on the device, {100.0 * n_active / (D * N):.2f} % solved"
+                                        if n_active is not None else ""),
+                "n_cadences": N, "draws_per_gpu": D, "global_draws": n_global,
                 "parallelism": f"draws sharded over {world} GPU(s); one collective of per-draw scalars per step, issued "
-                               "asynchronously from a private copy (double-buffered): it overlaps the next step's kernels and "
-                               "is waited for inside the timed region",
-                "step": "leaf params (separate tensors, read in place) -> record-packing kernel (orbit algebra + "
-                        "get_cl) -> window + run-enumeration + heavy kernels (value+VJP, one sweep; the heavy kernel's blocks "
-                        "finish their own draws at >= 512 draws, a separate finish kernel below that) -> packing "
-                        "VJP kernel (cotangent of L folded in) -> leaf gradients: five launches (six below 512 draws)"
-                        + ("; replayed as one hipGraph" if graph is not None else "; eager launches"),
+                               "asynchronously from a private copy (double-buffered): it overlaps the next step's kernels, "
+                               "is waited for inside the timed region, and the previous step's full vector is consumed there "
+                               "(running cross-chain sums)",
+                "step": wl.step_text + ("; replayed as one hipGraph" if graph is not None else "; eager launches"),
             },
             "timing": timing,
-            "roofline": {
+        }
+        if light_curve_only:
+            # bytes this design must move per sweep: the dense flux array once (zeros); for every solved
+            # cadence t and gbar in, its flux out to the run-ordered value array, back in and out to its
+            # place in the flux array (the binary searches of the windows are a few MB)
+            req = {"flux_zero_fill": 8 * D * N, "t_and_gbar_solved": 16 * n_active,
+                   "value_and_cadence_arrays_write_read": 24 * n_active, "flux_write_solved": 8 * n_active}
+            req_bytes = sum(req.values())
+            achieved = req_bytes / (kernel_ms * 1e-3) / 1e9
+            roof = {
                 "bound": "hbm",
-                "kernel": "transit_window_kernel (+ sortedness flags) + transit_enum_kernel + transit_runs_kernel "
-                          "[+ transit_finish_kernel below 512 draws] (one sweep)",
+                "kernel": "transit_runs_kernel (dominant; the sweep = transit_window_kernel + transit_enum_kernel + "
+                          "transit_runs_kernel [+ transit_finish_kernel below 512 draws])",
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic["bytes"] if traffic else None,
-                "traffic_source": traffic["source"] if traffic else None,
+                "frac_definition": "bytes this design must move per sweep / live hipEvent time of the sweep / 8 TB/s",
+                "traffic": None,
                 "algorithmic_bytes_per_launch": req_bytes, "algorithmic_bytes_breakdown": req,
                 "active_cadences_per_launch": n_active, "kernel_ms": kernel_ms,
                 "kernel_ms_quantiles": quantiles(per_launch),
-                "survey_8d_count": {"bytes_per_unit": SURVEY_BYTES_PER_UNIT, "bytes_per_launch": survey_bytes,
+                "survey_8d_count": {"bytes_per_unit": wl.survey_bytes_per_unit, "bytes_per_launch": survey_bytes,
                                     "GBps": survey_bytes / (kernel_ms * 1e-3) / 1e9,
-                                    "note": "SURVEY.md 8d charges t + gbar + flux = 24 B to EVERY (draw, cadence); "
-                                            "this design finds the cadences to solve by binary search and reads t, gbar "
-                                            "only there, so this figure is not a fraction of anything: `frac` above is "
-                                            "against the bytes the design must move"},
-                "note": "achieved = algorithmic_bytes_per_launch / mean hipEvent time of the launches of one sweep "
-                        "(sortedness flags, window constants, run enumeration, heavy = solved cadences + zero-fill of "
-                        "the dense flux, then -- in the same kernel when a draw is one block's work, else in a last small one -- "
-                        "values to their cadences + block partials), eager launches on the "
-                        "same inputs as the timed graph.  The heavy kernel is where the time goes: fp64 VALU issue "
-                        "(~1e3 flop per solved cadence) with the store stream of the dense output interleaved; "
-                        "rocprof per-kernel averages and PMC traffic: profiles/",
-            },
-        }
+                                    "note": "SURVEY.md 8d charges t + gbar + flux = 24 B to EVERY (draw, cadence); this design "
+                                            "finds the cadences to solve by binary search and reads t, gbar only there "
+                                            "(8f row 1, compaction, folded into the sweep): bytes NOT moved, so this figure is "
+                                            "not a fraction of anything"},
+            }
+            c = (counters or {}).get(cfg) if counters else None
+            if c and c.get("draws") == D:
+                # counter-derived figures of the SAME kernels (profiles/r03_counters.json, committed; FETCH x 2 on gfx950)
+                tr = c["traffic_bytes_per_sweep"]
+                dom = c["dominant_kernel"]
+                roof["traffic"] = tr
+                roof["traffic_source"] = c["source"]
+                roof["frac"] = dom["traffic_bytes"] / (dom["rocprof_avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS
+                roof["frac_definition"] = ("HBM bytes of the dominant kernel from the PMC counters (FETCH_SIZE x 2 + WRITE_SIZE, "
+                                           "separate passes) / its rocprofv3 --kernel-trace average / 8 TB/s -- all three in "
+                                           "profiles/r03_counters.json; `achieved` stays the live figure by required bytes")
+                roof["frac_by_required_bytes_live"] = achieved / HBM_PEAK_GBS
+                roof["traffic_over_required_bytes"] = tr / req_bytes
+                roof["traffic_over_survey_8d_bytes"] = tr / survey_bytes
+                roof["valu"] = c.get("valu")
+            out["roofline"] = roof
+        else:
+            achieved = survey_bytes / (kernel_ms * 1e-3) / 1e9
+            c = (counters or {}).get(cfg) if counters else None
+            out["roofline"] = {
+                "bound": "hbm", "kernel": "whole replayed step (celerite element / scan-tree / chunk kernels + two light-curve "
+                                          "sweeps + packing); per-kernel: profiles/r03_*",
+                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "frac_definition": f"SURVEY.md 8d count ({wl.survey_bytes_per_unit} B per (draw, cadence): the saved forward "
+                                   "state written and re-read) / median event time of one replayed step / 8 TB/s.  The J <= 6 "
+                                   "kernels keep CHECKPOINTS and recompute (DESIGN.md section 2), so they move far fewer bytes "
+                                   "than this count: see `traffic` and `valu` for what the counters say",
+                "traffic": c["traffic_bytes_per_step"] if c and c.get("draws") == D else None,
+                "traffic_source": c["source"] if c and c.get("draws") == D else None,
+                "valu": c.get("valu") if c and c.get("draws") == D else None,
+                "algorithmic_bytes_per_launch": survey_bytes, "kernel_ms": kernel_ms,
+            }
 
     # the extra legs are single-GPU diagnostics: under torch.distributed.run they would only add
     # barriers that every rank has to reach (an exception on one rank would hang the others)
-    if not args.no_extras and world == 1 and dist is None:
+    if not args.no_extras and world == 1 and dist is None and cfg == "c2":
         extras = {}
+        t, gbar = wl.data["t"], wl.data["gbar"]
 
         def leg(name, fn):
             try:
@@ -815,13 +1095,7 @@ def main():
             return res
 
         def sparse_output():
-            names = list(leaves)
-
-            def sp_step(*vals):
-                _, L, grads = step(xo, ops, dict(zip(names, vals)), t, gbar, sparse=True)
-                return (L.detach(),) + grads
-
-            q, how = graphed(xo, sp_step, list(leaves.values()), dev, 50)
+            q, how = graphed(xo, sparse_step_fn(xo, ops, list(leaves), t, gbar), list(leaves.values()), dev, 50)
             return {"evals_per_s": D / (q["median_ms"] * 1e-3), **q, "launch": how,
                     "note": "the same C2 step with EXO_FLAG_SPARSE: the output is the runs of cadences in which the planet "
                             "can overlap the disk plus their flux values (every other cadence is exactly 0) -- no 1.23 GB "
@@ -841,16 +1115,8 @@ def main():
                             "same kernel; dense output"}
 
         def likelihood():
-            names = list(leaves)
-            obs = 1e-4 * torch.randn(N_CAD, dtype=torch.float64, device=dev)
-
-            def ll_step(*vals):
-                Lv = dict(zip(names, vals))
-                orbit = xo.KeplerianOrbit(period=Lv["period"], t0=Lv["t0"], b=Lv["b"], ecc=Lv["ecc"], omega=Lv["omega"])
-                ll = xo.LimbDarkLightCurve(Lv["u1"], Lv["u2"]).white_noise_log_likelihood(orbit=orbit, r=Lv["r"], t=t, y=obs, yerr=1e-4)
-                return (ll.detach(),) + torch.autograd.grad(ll.sum(), vals)
-
-            q, how = graphed(xo, ll_step, list(leaves.values()), dev, 50)
+            obs = torch.as_tensor(1e-4 * np.random.default_rng(12).normal(size=N_CAD), device=dev)
+            q, how = graphed(xo, likelihood_step_fn(xo, list(leaves), t, obs, 1e-4), list(leaves.values()), dev, 50)
             return {"evals_per_s": D / (q["median_ms"] * 1e-3), **q, "launch": how,
                     "note": "C2 as a white-noise likelihood, value + gradient of every leaf (exo_transit_chi2_vjp_f64: one planet, "
                             "one sample per cadence -> ONE evaluation per solved cadence, the cotangent 2 w (F - obs) formed "
@@ -863,11 +1129,13 @@ def main():
         leg("op_level_every_cadence", op_level)
         leg("c2_small_batches", small_batch)
         leg("c2_with_transit_timing_variations", lambda: extra_ttv(xo, ops, leaves, t, gbar, dev, D))
-        leg("c3_light_curve_plus_sho_gp", lambda: extra_c3(xo, leaves, t, dev, D))
-        del gbar
+        del gbar, wl, graph
         torch.cuda.empty_cache()
-        leg("c4_four_planets_64_draws", lambda: extra_c4(xo, dev))
-        leg("c5_secondary_eclipse_3term_gp_128_chains", lambda: extra_c5(xo, dev))
+        leg("c3_light_curve_plus_sho_gp", lambda: extra_config(xo, ops, dev, "c3", D, 12))
+        leg("c3_gp_conditioning", lambda: extra_gp_conditioning(xo, ops, dev, D))
+        torch.cuda.empty_cache()
+        leg("c4_four_planets_64_draws", lambda: extra_config(xo, ops, dev, "c4", 64, 40))
+        leg("c5_secondary_eclipse_3term_gp_128_chains", lambda: extra_config(xo, ops, dev, "c5", 128, 12))
         torch.cuda.empty_cache()
         leg("astrometry_and_velocities", lambda: extra_astrometry(xo, dev))
         def nuts_leg():
@@ -887,7 +1155,7 @@ def main():
 
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
+            out["cpu_baseline"] = cpu_baseline(config=cfg)
         else:
             out["cpu_baseline"] = None
     if dist is not None:

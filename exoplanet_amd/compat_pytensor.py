@@ -70,9 +70,20 @@ class KeplerOp(Op):
         return [bM, be]
 
     def R_op(self, inputs, eval_points):
-        if eval_points[0] is None:
-            return eval_points
-        return self.grad(inputs, eval_points)
+        """forward mode (a JVP, not the transposed product `grad` computes): tangents (dM, de) of the inputs ->
+        tangents of (sin f, cos f) through df = f_M dM + f_e de"""
+        M, e = inputs
+        dM, de = eval_points
+        if dM is None and de is None:
+            return [None, None]
+        sinf, cosf = self(M, e)
+        ome2 = 1 - e**2
+        df = pt.zeros_like(M)
+        if dM is not None:
+            df = df + dM * (1 + e * cosf) ** 2 / ome2**1.5
+        if de is not None:
+            df = df + de * (2 + e * cosf) * sinf / ome2
+        return [cosf * df, -sinf * df]
 
 
 class QuadSolutionVectorOp(Op):

@@ -1455,7 +1455,10 @@ struct Run {
   int32_t lo, a, b, hi;   // cadences [lo, a) and [b, hi): may touch the limb; [a, b): small disk wholly inside (a hint)
 };
 constexpr int kRunMax = 4096;     // windows per list
-constexpr int kSeg = 512;         // runs of one list a heavy block holds in LDS at a time
+#ifndef EXO_RUN_SEG
+#define EXO_RUN_SEG 512
+#endif
+constexpr int kSeg = EXO_RUN_SEG;  // runs of one list a heavy block holds in LDS at a time (a power of two)
 
 struct RunLists {
   int32_t* nrun;     // [n_list]                 windows of list = (draw, planet, event)

@@ -50,7 +50,8 @@ class LoglikeExchange:
     other device work when the shards are equal (``all_gather_into_tensor`` straight from the
     caller's tensor -- e.g. the static output of a replayed hipGraph); ragged shards fall back
     to "own slice of a zero vector + all-reduce(SUM)".  ``start`` / ``finish`` are the pipelined
-    form of the same exchange: the collective of a step overlaps the kernels of the next one.  Rank and world size are those of
+    form of the same exchange: the collective of a step overlaps the kernels of the next one, and every ``start``
+    hands back the previous step's completed vector.  Rank and world size are those of
     ``group``.  A single process (or an uninitialised process group) just copies."""
 
     def __init__(self, n_draw, device, dtype=torch.float64, group=None):
@@ -59,28 +60,40 @@ class LoglikeExchange:
         self.n_draw = int(n_draw)
         self.lo, self.hi = shard_bounds(self.n_draw, self.rank, self.world)
         self.equal = self.n_draw % self.world == 0
-        self.out = torch.zeros(self.n_draw, dtype=dtype, device=device)
-        # pipelined form (start / finish): two private copies of the rank's slice, two outputs, the collectives in flight
-        self._stage = [torch.zeros(self.hi - self.lo, dtype=dtype, device=device) for _ in range(2)]
-        self._outs = [torch.zeros(self.n_draw, dtype=dtype, device=device) for _ in range(2)]
+        self.device, self.dtype = device, dtype
+        self.out = torch.empty(self.n_draw, dtype=dtype, device=device)
+        # pipelined form (start / finish): two private copies of the rank's slice, two outputs, the collectives in
+        # flight -- allocated by the first start(), a synchronous exchange never pays for them
+        self._stage = self._outs = None
         self._work = [None, None]
-        self._k = 0
         self._last = None
+
+    def _wait(self, k):
+        if self._work[k] is not None:
+            self._work[k].wait()       # (RCCL: the current stream waits for the collective; no host block)
+            self._work[k] = None
 
     def start(self, local):
         """The same collective, PIPELINED: it is issued asynchronously from a private copy of ``local`` and may still be
         in flight while the next step's kernels run -- nothing in a step depends on the other ranks' scalars, a sampler
         reads them for adaptation and logging.  ``local`` may be overwritten as soon as this returns (e.g. the static
-        output of a replayed hipGraph).  Two buffers alternate; a ``start`` waits for the collective issued two steps
-        earlier.  ``finish()`` waits for everything and returns the vector of the LATEST step."""
+        output of a replayed hipGraph).  RETURNS the completed full vector of the PREVIOUS ``start`` (None on the first
+        call): the consumer of step k's scalars runs one step behind, which is what lets the collective overlap.  That
+        vector is valid until the next ``start`` returns -- use it (or copy it) before then; two buffers alternate.
+        ``finish()`` waits for the collective still in flight and returns the vector of the LATEST step."""
         local = local.detach()
         if local.shape != (self.hi - self.lo,):
             raise ValueError(f"rank owns draws [{self.lo},{self.hi}) but got a tensor of shape {tuple(local.shape)}")
-        k = self._k
-        self._k ^= 1
-        if self._work[k] is not None:
-            self._work[k].wait()
-            self._work[k] = None
+        if self._stage is None:
+            self._stage = [torch.empty(self.hi - self.lo, dtype=self.dtype, device=self.device) for _ in range(2)]
+            self._outs = [torch.empty(self.n_draw, dtype=self.dtype, device=self.device) for _ in range(2)]
+        prev = self._last
+        prev_out = None
+        if prev is not None:
+            self._wait(prev)
+            prev_out = self._outs[prev]
+        k = 0 if prev is None else 1 - prev
+        self._wait(k)                  # (issued two steps ago and already waited for when it was handed out: a no-op)
         stage, out = self._stage[k], self._outs[k]
         stage.copy_(local)
         if self.world == 1:
@@ -92,13 +105,12 @@ class LoglikeExchange:
             out[self.lo:self.hi] = stage
             self._work[k] = dist.all_reduce(out, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         self._last = k
+        return prev_out
 
     def finish(self):
         """wait for the collectives in flight; the full vector of the most recent ``start`` (None if there was none)"""
         for k in (0, 1):
-            if self._work[k] is not None:
-                self._work[k].wait()
-                self._work[k] = None
+            self._wait(k)
         return None if self._last is None else self._outs[self._last]
 
     def __call__(self, local):

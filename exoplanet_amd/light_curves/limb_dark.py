@@ -191,12 +191,26 @@ class LimbDarkLightCurve:
         given ``mean + sum over planets of get_light_curve(...)`` -- what the reference's tutorials write as
         ``pm.Normal("obs", mu=mean + pt.sum(light_curves, axis=-1), sigma=yerr, observed=y)`` -- for a KeplerianOrbit
         or a TTVOrbit (gradients to its transit times / offsets included) with sorted times and one exposure time: value and gradient in ONE call on the sparse light curve
-        (ops.transit_chi2), no (draws, cadences) array anywhere.  ``mean``: a number or a (draws, 1) tensor is NOT
-        supported here (it would make the residual per draw): pass a scalar and model offsets in ``y``."""
+        (ops.transit_chi2), no (draws, cadences) array anywhere.  ``yerr``: a number, one value per cadence, or PER DRAW
+        (a 0-d or (draws, 1) tensor, differentiable: a jitter term sampled per chain costs nothing extra).  Whatever
+        the fused form cannot differentiate -- a per-cadence ``yerr``, a ``mean`` or a ``y`` that requires grad, a
+        ``mean`` per draw -- takes the dense light curve (``get_light_curve(total=True)``) and torch: slower, never a
+        partial gradient."""
         from ..orbits.keplerian import KeplerianOrbit
 
         if orbit is None or r is None or t is None or y is None or yerr is None:
             raise ValueError("orbit, r, t, y and yerr are required")
+        needs = lambda x: isinstance(x, torch.Tensor) and x.requires_grad and torch.is_grad_enabled()  # noqa: E731
+        n_cad = as_tensor(t).numel()
+        per_draw = ops.per_draw_yerr(yerr, n_cad) is not None
+        if needs(y) or needs(mean) or (needs(yerr) and not per_draw) or (isinstance(mean, torch.Tensor) and mean.numel() > 1):
+            lc = self.get_light_curve(orbit=orbit, r=r, t=t, texp=texp, oversample=oversample, order=order,
+                                      use_in_transit=use_in_transit, light_delay=light_delay, total=True)
+            resid = as_tensor(y, lc).to(lc.device) - mean - lc
+            w = as_tensor(yerr, lc).to(lc.device) ** -2
+            lognorm = torch.log(w / (2.0 * math.pi))
+            lognorm = lognorm.sum(-1) if (lognorm.dim() and lognorm.shape[-1] == n_cad) else lognorm.reshape(lognorm.shape[:-1] if lognorm.dim() else ()) * float(n_cad)
+            return -0.5 * (w * resid * resid).sum(-1) + 0.5 * lognorm
         has_ttv = hasattr(orbit, "kernel_ttv")
         if not isinstance(orbit, KeplerianOrbit) or (type(orbit)._warp_times is not KeplerianOrbit._warp_times and not has_ttv):
             raise NotImplementedError("white_noise_log_likelihood needs a KeplerianOrbit or a TTVOrbit")

@@ -287,13 +287,17 @@ def _vjp(t, texp, n_texp, sdt, sw, n_sub, params, ld, D, P, flags, gflux, want_f
                 "exo_transit_flux_vjp_f64",
             )
     if flags & FLAG_SPARSE:
-        # the sweep's output lives in its workspace (include/exoplanet_amd.h, EXO_FLAG_SPARSE)
-        import ctypes
-
-        lay = (ctypes.c_int64 * 5)()
-        _lib.check(lib.exo_transit_flux_sparse_layout(N, D, P, lay), "exo_transit_flux_sparse_layout")
-        flux = SparseFlux(ws, list(lay), N, D, P, 2 if flags & FLAG_SECONDARY else 1)
+        flux = _sparse_from_ws(ws, N, D, P, flags)
     return flux, gparams, gld, dot, gshift
+
+
+def _sparse_from_ws(ws, N, D, P, flags):
+    """the sweep's output lives in its workspace (include/exoplanet_amd.h, EXO_FLAG_SPARSE)"""
+    import ctypes
+
+    lay = (ctypes.c_int64 * 5)()
+    _lib.check(_lib.load().exo_transit_flux_sparse_layout(N, D, P, lay), "exo_transit_flux_sparse_layout")
+    return SparseFlux(ws, list(lay), N, D, P, 2 if flags & FLAG_SECONDARY else 1)
 
 
 def transit_flux(t, params, ld, texp=None, stencil_dt=None, stencil_w=None, flags=0, ttv=None):
@@ -341,8 +345,7 @@ class _TransitFluxDot(torch.autograd.Function):
         ctx.save_for_backward(gparams, gld, gshift)
         ctx.set_materialize_grads(False)  # never build a (D, N) zero cotangent for the detached flux
         if isinstance(flux, SparseFlux):
-            _TransitFluxDot._sparse = flux   # (not a tensor: handed over beside the autograd outputs)
-            return torch.empty(0, dtype=torch.float64, device=dot.device), dot
+            flux = flux._ws      # the workspace travels as a (non-differentiable) output; the wrapper rebuilds the views
         ctx.mark_non_differentiable(flux)
         return flux, dot
 
@@ -366,8 +369,7 @@ def transit_flux_dot(t, params, ld, gflux, texp=None, stencil_dt=None, stencil_w
     out = _TransitFluxDot.apply(t, texp, stencil_dt, stencil_w, params, ld, gflux, int(flags), events,
                                 None if edges is None else edges.detach(), shift)
     if int(flags) & FLAG_SPARSE:
-        sp, _TransitFluxDot._sparse = _TransitFluxDot._sparse, None
-        return sp, out[1]
+        return _sparse_from_ws(out[0], t.numel(), params.shape[0], params.shape[1], int(flags)), out[1]
     return out
 
 
@@ -377,6 +379,11 @@ class _TransitChi2(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, t, texp, stencil_dt, stencil_w, params, ld, obs, ivar, flags, ttv_edges, ttv_shift):
+        if ctx.needs_input_grad[6] or ctx.needs_input_grad[7]:
+            # (the kernels never hold the per-cadence residuals of every draw; see white_noise_loglike for what is offered)
+            raise NotImplementedError(
+                "transit_chi2 is not differentiable with respect to obs / ivar: per-draw error bars go through "
+                "white_noise_loglike(yerr=(n_draw, 1) tensor), anything else through get_light_curve(total=True) and torch")
         t, texp, n_texp, sdt, sw, n_sub, params, ld, D, P = _transit_args(t, texp, stencil_dt, stencil_w, params, ld, flags)
         edges, shift, n_edge = _ttv_args(None if ttv_edges is None else (ttv_edges, ttv_shift), D, P)
         N = t.numel()
@@ -473,12 +480,54 @@ def _white_noise_terms(y, yerr, mean):
     return hit[:4] + (hit[6],)
 
 
+def per_draw_yerr(yerr, n_cad):
+    """``yerr`` as a per-draw error bar: a tensor that broadcasts against a (n_draw, n_cad) light curve along the
+    draws only -- 0-d, or last dimension 1 -- flattened to (n_draw | 1,); None for anything else (a number, a
+    per-cadence vector)."""
+    if not isinstance(yerr, torch.Tensor):
+        return None
+    if yerr.dim() == 0 or yerr.shape[-1] == 1 or (yerr.numel() == 1 and n_cad != 1):
+        return yerr.reshape(-1)
+    return None
+
+
+def _check_data_terms(y, yerr, mean):
+    """the data-side terms of the white-noise likelihood carry no gradient through the fused kernels: refuse rather than
+    return a partial gradient (jitter per chain: a (n_draw, 1) ``yerr``; anything else: the dense light curve + torch)"""
+    for name, x in (("y", y), ("yerr", yerr), ("mean", mean)):
+        if isinstance(x, torch.Tensor) and x.requires_grad and torch.is_grad_enabled():
+            raise NotImplementedError(
+                f"white-noise likelihood: `{name}` requires grad, and the fused kernels differentiate only the orbit / "
+                "limb-darkening parameters (plus per-draw error bars, yerr of shape (n_draw, 1)); use "
+                "LimbDarkLightCurve.white_noise_log_likelihood (it falls back to the dense light curve) or "
+                "get_light_curve(total=True) with torch")
+
+
+def _scaled_loglike(unit_fn, y, yerr_d, mean):
+    """log-likelihood for per-draw error bars from the unit-weight misfit: with w_d = 1 / yerr_d^2,
+    ll_d = -w_d / 2 (chi2_1[d] + sum obs^2) + n / 2 log(w_d / 2 pi) -- differentiable in yerr_d through torch, in
+    everything else through the kernels' own gradient; ``unit_fn(obs, one)`` returns chi2 at unit weights"""
+    _check_data_terms(y, None, mean)
+    obs, one, s2, _, _ = _white_noise_terms(y, 1.0, mean)
+    w = 1.0 / (yerr_d * yerr_d)
+    n = float(y.numel())
+    return -0.5 * w * (unit_fn(obs, one) + s2) + 0.5 * n * torch.log(w / (2.0 * torch.pi))
+
+
 def white_noise_loglike(t, params, ld, y, yerr, mean=0.0, texp=None, stencil_dt=None, stencil_w=None, flags=0, ttv=None):
-    """Gaussian log-likelihood (n_draw,) of the observed series ``y`` with independent errors ``yerr`` (scalar or
-    per cadence) given ``mean + light curve`` -- the reference's ``pm.Normal("obs", mu=mean + lc, sigma=yerr,
-    observed=y)`` for a batch of parameter sets, value and gradient in one call (:func:`transit_chi2`)."""
-    obs, ivar, const, lognorm, _ = _white_noise_terms(_dev(y, "y"), yerr, mean)
-    chi2 = transit_chi2(t, params, ld, obs, ivar, texp=texp, stencil_dt=stencil_dt, stencil_w=stencil_w, flags=flags, ttv=ttv)
+    """Gaussian log-likelihood (n_draw,) of the observed series ``y`` with independent errors ``yerr`` (a number, a
+    per-cadence vector, or PER DRAW: a 0-d / (n_draw, 1) tensor, differentiable -- a jitter term sampled per chain)
+    given ``mean + light curve`` -- the reference's ``pm.Normal("obs", mu=mean + lc, sigma=yerr, observed=y)`` for a
+    batch of parameter sets, value and gradient in one call (:func:`transit_chi2`).  ``y``, a per-cadence ``yerr`` and
+    ``mean`` are data here: a tensor among them that requires grad is refused, not silently dropped."""
+    y = _dev(y, "y")
+    kw = dict(texp=texp, stencil_dt=stencil_dt, stencil_w=stencil_w, flags=flags, ttv=ttv)
+    yd = per_draw_yerr(yerr, y.numel())
+    if yd is not None:
+        return _scaled_loglike(lambda obs, one: transit_chi2(t, params, ld, obs, one, **kw), y, _dev(yd, "yerr"), mean)
+    _check_data_terms(y, yerr, mean)
+    obs, ivar, const, lognorm, _ = _white_noise_terms(y, yerr, mean)
+    chi2 = transit_chi2(t, params, ld, obs, ivar, **kw)
     return -0.5 * (chi2 + const) + 0.5 * lognorm
 
 
@@ -867,13 +916,14 @@ class _OrbitFluxDot(torch.autograd.Function):
         ctx.meta = (D, P, pack_flags, n_ld, [c is not None for c in ocols], [None if c is None else tuple(c.shape) for c in cols])
         ctx.set_materialize_grads(False)
         if isinstance(flux, SparseFlux):
-            _OrbitFluxDot._sparse = flux
-            return torch.empty(0, dtype=torch.float64, device=dot.device), dot
+            shape = torch.tensor([D, P], dtype=torch.int64)      # (host tensor: the wrapper needs the batch the columns implied)
+            ctx.mark_non_differentiable(flux._ws, shape)
+            return flux._ws, dot, shape
         ctx.mark_non_differentiable(flux)
         return flux, dot
 
     @staticmethod
-    def backward(ctx, _gflux_unused, gdot):
+    def backward(ctx, _gflux_unused, gdot, *_shape_unused):
         import ctypes
 
         D, P, pack_flags, n_ld, present, shapes = ctx.meta
@@ -940,8 +990,8 @@ def orbit_flux_dot(t, gflux, orbit_cols, ld_cols, flags=0, pack_flags=0, texp=No
     out = _OrbitFluxDot.apply(t, gflux, texp, stencil_dt, stencil_w, int(flags), int(pack_flags), events, len(ld_cols),
                               *orbit_cols, *ld_cols)
     if int(flags) & FLAG_SPARSE:
-        sp, _OrbitFluxDot._sparse = _OrbitFluxDot._sparse, None
-        return sp, out[1]
+        D, P = (int(x) for x in out[2])
+        return _sparse_from_ws(out[0], t.numel(), D, P, int(flags)), out[1]
     return out
 
 
@@ -1098,14 +1148,25 @@ def orbit_white_noise_loglike(t, y, yerr, orbit_cols, ld_cols, n_draw, mean=0.0,
     inputs of :func:`pack_records_cols`): Gaussian log-likelihood (n_draw,), differentiable w.r.t. every column and the
     timing shifts, value and gradient in seven launches."""
     t = _dev(t, "t")
-    obs, ivar, _, _, cterm = _white_noise_terms(_dev(y, "y"), yerr, mean)
-    if tuple(obs.shape) != (t.numel(),):
+    y = _dev(y, "y")
+    if tuple(y.shape) != (t.numel(),):
         raise ValueError("y must have shape (n_cad,)")
-    if ivar.numel() not in (1, t.numel()):
-        raise ValueError("yerr must be a scalar or have one entry per cadence")
     edges, shift = (None, None) if ttv is None else ttv
-    return _OrbitLoglike.apply(t, texp, stencil_dt, stencil_w, obs, ivar, cterm, int(flags), int(pack_flags),
-                               len(ld_cols), int(n_draw), edges, shift, *orbit_cols, *ld_cols)
+
+    def run(obs, ivar, cterm):
+        return _OrbitLoglike.apply(t, texp, stencil_dt, stencil_w, obs, ivar, cterm, int(flags), int(pack_flags),
+                                   len(ld_cols), int(n_draw), edges, shift, *orbit_cols, *ld_cols)
+
+    yd = per_draw_yerr(yerr, y.numel())
+    if yd is not None:
+        # (_OrbitLoglike returns cterm - chi2 / 2: with cterm = 0 the unit-weight misfit is -2 x that)
+        zero = _const(0.0, t.device)
+        return _scaled_loglike(lambda obs, one: -2.0 * run(obs, one, zero), y, _dev(yd, "yerr"), mean)
+    _check_data_terms(y, yerr, mean)
+    obs, ivar, _, _, cterm = _white_noise_terms(y, yerr, mean)
+    if ivar.numel() not in (1, t.numel()):
+        raise ValueError("yerr must be a number, one entry per cadence, or per draw: (n_draw, 1)")
+    return run(obs, ivar, cterm)
 
 
 def pack_records_cols(orbit_cols, ld_cols, n_draw, pack_flags=0):

@@ -380,6 +380,13 @@ def _contact_one(a, e, cosw, sinw, cosi, sini, L):
 # =============================================================================
 # Python glue, restated from the reference's own source
 # =============================================================================
+def get_aor_from_transit_duration(duration, period, b, ror=None):
+    """reference: src/exoplanet/orbits/keplerian.py:822-846 (the value; the Jacobian is a derivative of it)"""
+    ror = 0.0 if ror is None else ror
+    phi = np.pi * duration / period
+    return np.sqrt((1 + ror) ** 2 - b ** 2 * np.cos(phi) ** 2) / np.sin(phi)
+
+
 def get_cl(u1, u2):
     """reference: src/exoplanet/light_curves/limb_dark.py:11-18"""
     c0 = 1 - u1 - 1.5 * u2
@@ -395,10 +402,18 @@ class KeplerianOrbit:
     :779-804 (_flip), :849-934 (_get_consistent_inputs).  Subset used by the
     hot path: no units, no Jacobian bookkeeping."""
 
-    def __init__(self, period=None, a=None, t0=None, t_periastron=None, incl=None, b=None,
+    def __init__(self, period=None, a=None, t0=None, t_periastron=None, incl=None, b=None, duration=None,
                  ecc=None, omega=None, Omega=None, m_planet=0.0, m_star=None, r_star=None,
-                 rho_star=None):
+                 rho_star=None, ror=None):
         A = lambda x: None if x is None else np.atleast_1d(np.asarray(x, dtype=np.float64))
+        if ecc is None and duration is not None:                      # :112-131 (circular orbit from its duration)
+            if r_star is None:
+                r_star = 1.0
+            if b is None:
+                raise ValueError("'b' must be provided for a circular orbit with a 'duration'")
+            aor = get_aor_from_transit_duration(A(duration), A(period), A(b), ror=A(ror))
+            a = A(r_star) * aor
+            duration = None
         a, period, rho_star, r_star, m_star, m_planet = self._consistent(
             A(a), A(period), A(rho_star), A(r_star), A(m_star), A(m_planet))
         self.a, self.period, self.rho_star = a, period, rho_star
@@ -429,7 +444,7 @@ class KeplerianOrbit:
             incl_factor = (1 + self.ecc * self.sin_omega) / ome2
         self.dcosidb = incl_factor * self.r_star / self.a             # :217-219
         if b is not None:                                             # :221-228
-            if incl is not None:
+            if incl is not None or duration is not None:
                 raise ValueError("only one of 'incl', 'b', and 'duration' can be given")
             self.b = A(b) + np.zeros_like(self.a)
             self.cos_incl = self.dcosidb * self.b
@@ -438,6 +453,16 @@ class KeplerianOrbit:
             self.incl = A(incl) + np.zeros_like(self.a)
             self.cos_incl = np.cos(self.incl)
             self.b = self.cos_incl / self.dcosidb
+        elif duration is not None:                                    # :237-260 (eccentric orbit from its duration)
+            self.duration = A(duration)
+            c2 = np.sin(np.pi * self.duration * incl_factor / self.period) ** 2
+            aor = self.a_planet / self.r_star
+            esinw = self.ecc * self.sin_omega
+            self.b = np.sqrt((aor ** 2 * c2 - 1) / (c2 * esinw ** 2 + 2 * c2 * esinw + c2 - self.ecc ** 4
+                                                    + 2 * self.ecc ** 2 - 1))
+            self.b = self.b * (1 - self.ecc ** 2)
+            self.cos_incl = self.dcosidb * self.b
+            self.incl = np.arccos(self.cos_incl)
         else:                                                         # :261-265
             zla = np.zeros_like(self.a)
             self.incl = 0.5 * np.pi + zla

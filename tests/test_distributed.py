@@ -134,11 +134,23 @@ def _worker_bench_exchange(rank, world, port, n_global, out_dir):
         # the pipelined form: the source may be overwritten right after start(); finish() returns the latest step's vector
         assert ex.finish() is None
         src = torch.zeros(hi - lo, dtype=torch.float64)
+        consume = bench.ExchangeConsumer(n_global, torch.device("cpu"))
         for it in range(5):
             src.copy_(torch.arange(lo, hi, dtype=torch.float64) * (it + 2) - 0.5)
-            bench.exchange_step(ex, src, pipelined=True)
+            prev = bench.exchange_step(ex, src, pipelined=True)
             src.fill_(float("nan"))                      # (what the next graph replay does to its static output)
-        assert torch.equal(ex.finish(), torch.arange(n_global, dtype=torch.float64) * 6 - 0.5)
+            # every start() hands back the PREVIOUS step's completed vector: a consumer sees each step once
+            if it == 0:
+                assert prev is None
+            else:
+                assert torch.equal(prev, torch.arange(n_global, dtype=torch.float64) * (it + 1) - 0.5), (rank, it, prev)
+            consume(prev)
+        last = ex.finish()
+        assert torch.equal(last, torch.arange(n_global, dtype=torch.float64) * 6 - 0.5)
+        consume(last)
+        assert consume.steps == 5
+        want_sum = sum(torch.arange(n_global, dtype=torch.float64) * (it + 2) - 0.5 for it in range(5))
+        assert torch.allclose(consume.acc[0], want_sum, rtol=1e-14)
         with pytest.raises(ValueError):
             ex.start(torch.zeros(hi - lo + 1, dtype=torch.float64))
         # a group with the ranks in reverse order: position in the group != global rank
@@ -166,3 +178,56 @@ def test_exchange_single_process():
     ex = LoglikeExchange(5, torch.device("cpu"))
     x = torch.arange(5, dtype=torch.float64)
     assert torch.equal(ex(x), x) and ex(x) is ex.out
+
+
+def _worker_runner(rank, world, port, n_global, out_dir):
+    """bench.py's timed loop (make_runner + time_steps) for a strong-scaling config under gloo: a stand-in step whose
+    per-draw scalar is known in closed form, ragged and equal shards; every step's full vector reaches the consumer
+    exactly once, in order, on every rank"""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import bench
+        from exoplanet_amd.distributed import LoglikeExchange, shard_bounds
+
+        lo, hi = shard_bounds(n_global, rank, world)       # what main() does with --global-draws
+        ex = LoglikeExchange(n_global, torch.device("cpu"))
+        consume = bench.ExchangeConsumer(n_global, torch.device("cpu"))
+        state = {"k": 0}
+        static = torch.zeros(hi - lo, dtype=torch.float64)     # (a replayed graph's static output: overwritten every step)
+
+        def step_fn():
+            state["k"] += 1
+            static.copy_(torch.arange(lo, hi, dtype=torch.float64) + 100.0 * state["k"])
+            return (None, static)
+
+        run, drain = bench.make_runner(step_fn, 1, ex, consume)
+        K = 7
+        for i in range(K):
+            run(i)
+        drain()
+        assert consume.steps == K
+        want = K * torch.arange(n_global, dtype=torch.float64) + 100.0 * sum(range(1, K + 1))
+        assert torch.equal(consume.acc[0], want), (rank, consume.acc[0], want)
+        np.save(os.path.join(out_dir, f"ok_{rank}.npy"), np.ones(1))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_global", [64, 7])
+def test_bench_runner_world2(tmp_path, n_global):
+    port = _free_port()
+    mp.spawn(_worker_runner, args=(2, port, n_global, str(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / "ok_0.npy").exists() and (tmp_path / "ok_1.npy").exists()
+
+
+def test_bench_config_table():
+    """--config: every BASELINE GPU config has a builder; C4 / C5 default to their 8-GPU totals"""
+    import bench
+
+    assert sorted(bench.WORKLOADS) == ["c2", "c3", "c4", "c5"]
+    assert bench.DEFAULT_GLOBAL_DRAWS == {"c4": 512, "c5": 1024}
+    from exoplanet_amd.distributed import shard_bounds
+    assert [shard_bounds(512, r, 8)[1] - shard_bounds(512, r, 8)[0] for r in range(8)] == [64] * 8
+    assert [shard_bounds(1024, r, 8)[1] - shard_bounds(1024, r, 8)[0] for r in range(8)] == [128] * 8
