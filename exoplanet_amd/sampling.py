@@ -99,11 +99,15 @@ class _ChainSampler:
         s1 = [torch.zeros_like(q[0]) for q in self.params]
         s2 = [torch.zeros_like(q[0]) for q in self.params]
         n_acc = 0
+        log_eps0 = torch.log(self.eps)
         for it in range(n_steps):
             self.step()
             m += 1
-            Hbar = (1.0 - 1.0 / (m + t0)) * Hbar + (target_accept - self.last_accept_prob) / (m + t0)
-            log_eps = mu - (m ** 0.5 / gamma) * Hbar
+            # a chain that made no move this step for a reason that is not its step size (it sits outside the support:
+            # no valid leaf) reports the target itself -- its step size is left alone instead of being driven to zero
+            acc = torch.where(self.last_adapt_ok, self.last_accept_prob, torch.full_like(self.last_accept_prob, target_accept))
+            Hbar = (1.0 - 1.0 / (m + t0)) * Hbar + (target_accept - acc) / (m + t0)
+            log_eps = torch.clamp(mu - (m ** 0.5 / gamma) * Hbar, min=log_eps0 - 30.0, max=log_eps0 + 30.0)
             w = m ** (-kappa)
             log_eps_bar = w * log_eps + (1.0 - w) * log_eps_bar
             self.eps.copy_(torch.exp(log_eps))
@@ -178,6 +182,7 @@ class HMC(_ChainSampler):
         self.last_logp = torch.where(accept, lp1, lp0)
         # acceptance probability min(1, exp(-dH)) of every chain (NaN proposals: 0): what step-size adaptation feeds on
         self.last_accept_prob = torch.nan_to_num(torch.exp(torch.clamp(dH, max=0.0)), nan=0.0)
+        self.last_adapt_ok = torch.isfinite(lp0)           # (a chain outside the support says nothing about its step size)
         return accept
 
     def _reset_statistics(self):
@@ -412,6 +417,7 @@ class NUTS(_ChainSampler):
         self.last_depth = st["depth"].clone()
         self.last_diverged = st["diverged"].clone()
         self.last_accept_prob = st["acc"] / torch.clamp(st["accn"], min=1.0)
+        self.last_adapt_ok = st["accn"] > 0                # (no leaf at all: the chain started outside the support)
         self.n_divergent += self.last_diverged.to(self.n_divergent.dtype)
         self.sum_depth += self.last_depth
         return self.last_depth

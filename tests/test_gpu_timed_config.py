@@ -439,11 +439,15 @@ def test_duration_orbit_on_the_hip_path(dev):
     assert (want[inside] < 0).all() and (want[np.abs(t) > 0.5 * duration + 1e-3] == 0).all()
     x, y, z = orbit.get_planet_position(torch.tensor([-0.5 * duration, 0.5 * duration, period + 0.5 * duration], device=dev))
     assert np.allclose(npy(torch.sqrt(x ** 2 + y ** 2)).ravel(), r_star * (1 + ror))      # (the reference's own tolerance)
+    # d flux / d duration is singular (~ 1 / sqrt) at the contact points: central differences of the oracle are held
+    # tightly on the cadences away from them, loosely on all
     w = np.random.default_rng(3).normal(size=want.shape)
-    (g,) = torch.autograd.grad((lc * torch.as_tensor(w, device=dev)).sum(), dv)
-    h = 1e-6
-    fd = ((oracle(duration + h) - oracle(duration - h)) * w).sum() / (2 * h)
-    assert abs(float(g) - fd) <= 1e-5 * abs(fd)
+    away = (np.abs(np.abs(t) - 0.5 * duration) > 6e-3)[:, None]
+    for ww, tol in ((w * away, 1e-5), (w, 1e-2)):
+        (g,) = torch.autograd.grad((lc * torch.as_tensor(ww, device=dev)).sum(), dv, retain_graph=True)
+        h = 1e-6
+        fd = ((oracle(duration + h) - oracle(duration - h)) * ww).sum() / (2 * h)
+        assert abs(float(g) - fd) <= tol * abs(fd), (float(g), fd)
     # the eccentric branch: duration -> b (keplerian.py:237-260), then the same kernels
     kw = dict(period=5.0, t0=0.2, ecc=0.3, omega=0.7, duration=0.11)
     t2 = np.linspace(-0.1, 0.5, 3001)

@@ -183,3 +183,23 @@ def test_nuts_chain_outside_the_support_stays_put():
         assert float(nuts.params[0][0, 0]) == 5.0 and float(d[0]) == 0
         assert bool(torch.isfinite(nuts.params[0]).all()) and bool((nuts.params[0][1:, 0] <= 2.0).all())
     assert float(nuts.params[0][1:].abs().max()) > 0       # the others move
+
+
+def test_warmup_leaves_chains_outside_the_support_alone():
+    """a chain that starts outside the support never has a valid leaf; its acceptance statistic says nothing
+    about its step size, so dual averaging must not drive that step size to zero"""
+    D = 6
+
+    def logp(x):
+        lp = -0.5 * (x ** 2).sum(-1)
+        return torch.where(x[:, 0] > 5.0, torch.full_like(lp, -float("inf")), lp)
+
+    for cls, kw in ((NUTS, dict(max_depth=4)), (HMC, dict(n_leapfrog=4))):
+        x = torch.zeros(D, 2, dtype=torch.float64)
+        x[0, 0] = 9.0                                     # outside the support
+        smp = cls(logp, [x], step_size=0.5, generator=torch.Generator().manual_seed(2), **kw)
+        eps = smp.warmup(60, target_accept=0.8)
+        if cls is NUTS:
+            assert float(smp.params[0][0, 0]) == 9.0     # it stays where it is (HMC may step back inside: -inf -> finite is accepted)
+        assert torch.isfinite(eps).all() and float(eps[0]) > 1e-3, eps      # and keeps a usable step size
+        assert torch.all(eps[1:] > 0.1) and torch.all(eps[1:] < 5.0)
