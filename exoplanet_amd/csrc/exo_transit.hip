@@ -423,9 +423,15 @@ struct PlanetS {
 // ([slot][thread]: consecutive threads hit consecutive banks).  They are touched only
 // by samples that overlap the disk, and keeping 17 doubles out of the register file is
 // what lets two waves share a SIMD next to the elliptic-integral code.
+// `add` is the LDS's own fp64 adder (ds_add_f64, no return value): one instruction, nothing to wait for -- as a
+// read-modify-write in the wave (ds_read, wait ~100 cycles, v_add, ds_write) the dozen accumulations of a sample cost
+// the kernel more stalled cycles than the arithmetic of its Kepler solve.  A column belongs to one thread and the LDS
+// executes a wave's operations in order: the sums are those of the sequential loop, bit for bit, run after run.
 struct GradAcc {
   double* col;  // &lds[0][threadIdx.x]
-  __device__ __forceinline__ void add(int slot, double v) const { col[slot * kBlock] += v; }
+  __device__ __forceinline__ void add(int slot, double v) const {
+    __hip_atomic_fetch_add(col + slot * kBlock, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+  }
 };
 
 // One (cadence, sub-exposure, planet) sample.  Returns the flux contribution F
@@ -466,7 +472,11 @@ __device__ __forceinline__ double eval_sample(double tt, const PlanetS& c, const
     tt -= ld_D;
   }
   const double M = (tt - c.tp) * c.n;
+#ifdef EXO_STUB_KEPLER   // (instruction-count builds: tools/transit_breakdown.sh; results are meaningless)
+  exo::KeplerHalf kh; kh.X = c.se * 0.6 + 1e-3 * M; kh.Y = c.pe * 0.01; kh.sh = 0.1; kh.ch = 0.9;
+#else
   const exo::KeplerHalf kh = exo::kepler_half(M, c.e, c.se, c.pe);
+#endif
   const double X2 = kh.X * kh.X, Y2 = kh.Y * kh.Y;
   const double cx = X2 - Y2;            // (1 - e cos E) cos f = cos E - e
   const double sx = 2.0 * kh.X * kh.Y;  // (1 - e cos E) sin f = sqrt(1-e^2) sin E
@@ -497,7 +507,11 @@ __device__ __forceinline__ double eval_sample(double tt, const PlanetS& c, const
   const double bq = occ ? b * c.iror : b;
   const double rq = occ ? c.iror : c.ror;
   exo::SV sv;
+#ifdef EXO_STUB_SV
+  sv.s0 = bq; sv.s1 = rq; sv.s2 = bq * rq; sv.db0 = sv.db1 = sv.db2 = bq; sv.dr0 = sv.dr1 = sv.dr2 = rq;
+#else
   exo::quad_sv<GRAD>(act ? bq : 2.0 + rq, rq, sv);
+#endif
   const double* cc = occ ? cld + 3 : cld;
   const double Fq = fma(sv.s0, cc[0], fma(sv.s1, cc[1], sv.s2 * cc[2])) - 1.0;
   double F;
@@ -1456,7 +1470,7 @@ struct Run {
 };
 constexpr int kRunMax = 4096;     // windows per list
 #ifndef EXO_RUN_SEG
-#define EXO_RUN_SEG 512
+#define EXO_RUN_SEG 256
 #endif
 constexpr int kSeg = EXO_RUN_SEG;  // runs of one list a heavy block holds in LDS at a time (a power of two)
 
@@ -1739,26 +1753,44 @@ __global__ __launch_bounds__(64) void transit_enum_ttv_kernel(const double* __re
   enum_prefix(s_len, K, lane, pin, pall, rl.nrun + list);
 }
 
-// this wave's share of a block's zero-fill: 1 KB pieces (64 lanes x 16 B, non-temporal), a few per round
+// this wave's share of a block's zero-fill: 1 KB pieces (64 lanes x 16 B, non-temporal), a few per round.
+// Everything that steers the stream is WAVE-UNIFORM and lives in scalar registers -- the piece pointer, the count of
+// pieces left -- and a store is `global_store_dwordx4 v_lane_offset, v_zero, s[piece]` with no vector arithmetic at
+// all (round 2 carried the cursor per lane: 64-bit vector adds, two vector compares and four moves of the zero per
+// store, ~200 vector instructions per round of a 1024-draw sweep -- a sixth of the kernel's VALU work).
 struct FillCursor {
   typedef double v2d __attribute__((ext_vector_type(2)));
-  v2d* __restrict__ q2;
-  int64_t n2, next;   // 16-B units in the block's share; this wave's next piece
-  __device__ __forceinline__ FillCursor(double* dst, int64_t n) : q2(nullptr), n2(0), next(threadIdx.x >> 6) {
+  char* base;      // the block's 16-B aligned share (block-uniform: derived from kernel arguments and block indices)
+  int64_t off;     // byte offset of this wave's next full piece (wave-uniform)
+  int left;        // full pieces this wave still owes (wave-uniform)
+  uint32_t loff;   // lane * 16
+  v2d zero;
+  __device__ __forceinline__ FillCursor(double* dst, int64_t n) : base(nullptr), off(0), left(0), loff((threadIdx.x & 63) * 16) {
+    zero = v2d{0.0, 0.0};
+    asm volatile("" : "+v"(zero));   // (an opaque value: kept in four registers, not re-materialised before every store)
     if (!dst || n <= 0) return;
     const int64_t head = (reinterpret_cast<uintptr_t>(dst) & 8) ? 1 : 0;
     if (threadIdx.x == 0 && head) dst[0] = 0.0;
     if (threadIdx.x == 0 && ((n - head) & 1)) dst[n - 1] = 0.0;
-    q2 = reinterpret_cast<v2d*>(dst + head);
-    n2 = (n - head) >> 1;
+    v2d* q2 = reinterpret_cast<v2d*>(dst + head);
+    const int64_t n2 = (n - head) >> 1;            // 16-B units
+    const int64_t nfull = n2 >> 6;                 // full 1-KB pieces; the partial one goes now
+    const int rem = (int)(n2 & 63);
+    if ((int)threadIdx.x < rem) __builtin_nontemporal_store(zero, q2 + (nfull << 6) + threadIdx.x);
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    left = nfull > w ? (int)((nfull - w + kWaves - 1) / kWaves) : 0;
+    left = __builtin_amdgcn_readfirstlane(left);
+    base = reinterpret_cast<char*>(q2);
+    off = (int64_t)w * 1024;
   }
-  __device__ __forceinline__ int64_t pieces() const { return (n2 + 63) >> 6; }
-  __device__ __forceinline__ void issue(int count) {
-    const v2d z = {0.0, 0.0};
-    for (int s = 0; s < count && next * 64 < n2; ++s, next += kWaves) {
-      const int64_t k = next * 64 + (threadIdx.x & 63);
-      if (k < n2) __builtin_nontemporal_store(z, q2 + k);
+  __device__ __forceinline__ int pieces_left() const { return left; }
+  __device__ __forceinline__ void issue(int count) {   // `count`: wave-uniform
+    const int k = count < left ? count : left;
+    for (int s = 0; s < k; ++s) {
+      __builtin_nontemporal_store(zero, reinterpret_cast<v2d*>(base + off + loff));
+      off += kWaves * 1024;
     }
+    left -= k;
   }
 };
 
@@ -1888,8 +1920,19 @@ struct FinishArgs {
 // TTV (one event per planet): `ttv` holds the timing tables; a trusted list's runs carry their bin (rl.rbin), its
 // samples are shifted by the run's shift and d/d(shift) is summed run by run (wave partials in LDS, combined in a fixed
 // order into rl.grun: bit-reproducible); the samples of any other list look their bins up and add to gshift atomically.
+// Occupancy: THREE blocks per CU (three waves per SIMD: 168 registers, <= 53 KB of LDS per block).  The fp64 work of
+// a sample is one long dependency chain (8 cycles per dependent operation against 4 of issue); a third wave per SIMD is
+// worth ~1.2x of two.  It fits because (a) this translation unit is built with -mllvm -disable-machine-licm
+// (__graft_entry__.py): hoisted out of the cadence loop, the ~60 fp64 constants of the polynomials sat in ~110 vector
+// registers for the whole kernel (256 registers + scratch, two waves); re-materialised where they are used the kernel
+// needs 168; (b) kSeg = 256 runs per batch keeps the LDS under a third of the CU's.  Variants whose LDS does not fit
+// three blocks (timing tables) get the registers of two waves from the compiler; so do the light-delay variants (two
+// Kepler solves alive at once: 250 B of scratch at 168 registers, measured slower than two waves without).
+#ifndef EXO_RUNS_MIN_WAVES
+#define EXO_RUNS_MIN_WAVES 3
+#endif
 template <bool GRAD, bool SECONDARY, bool LDELAY = false, bool CHI2 = false, bool TTV = false>
-__global__ __launch_bounds__(kBlock, EXO_HEAVY_MIN_WAVES) void transit_runs_kernel(
+__global__ __launch_bounds__(kBlock, LDELAY ? 2 : EXO_RUNS_MIN_WAVES) void transit_runs_kernel(
     const double* __restrict__ t, int64_t n_cad, const double* __restrict__ texp, int64_t n_texp,
     const double* __restrict__ stencil_dt, const double* __restrict__ stencil_w, int n_sub,
     const double* __restrict__ params, const double* __restrict__ ld, int n_planet, uint32_t flags, int n_ev, RunLists rl,
@@ -1898,7 +1941,8 @@ __global__ __launch_bounds__(kBlock, EXO_HEAVY_MIN_WAVES) void transit_runs_kern
     Ttv ttv = Ttv{nullptr, nullptr, nullptr, 0}, FinishArgs fin = FinishArgs{nullptr, nullptr, nullptr, 0, nullptr}) {
   __shared__ Shared sh;
   __shared__ Run s_run[kSeg];
-  __shared__ int s_in[kSeg + 1], s_all[kSeg + 1];
+  __shared__ int2 s_pre[kSeg + 1];   // positions of a batch's runs among its "inside" items (.x) and its limb items (.y)
+  __shared__ int s_all[kSeg + 1];    // position of a run's first cadence in the value array
   __shared__ int s_bin[TTV ? kSeg : 1];
   __shared__ double s_shift[TTV ? kSeg : 1];
   __shared__ double s_grun[(TTV && GRAD) ? kWaves : 1][(TTV && GRAD) ? kSeg : 1];
@@ -1933,8 +1977,8 @@ __global__ __launch_bounds__(kBlock, EXO_HEAVY_MIN_WAVES) void transit_runs_kern
   const int64_t npl = per_planet ? n_planet : 1, n_fill = n_cad * npl;
   const int64_t f0 = n_fill * bx / hb, f1 = n_fill * (bx + 1) / hb;
   FillCursor fc(fill ? fill + draw * n_fill + f0 : nullptr, f1 - f0);
-  const int64_t my_pieces = (fc.pieces() + kWaves - 1 - (threadIdx.x >> 6)) / kWaves;   // pieces wave, wave + 4, ...
-  const int per_round = total_rounds > 0 ? (int)((my_pieces + total_rounds - 1) / total_rounds) : 0;
+  const int per_round =
+      __builtin_amdgcn_readfirstlane(total_rounds > 0 ? (fc.pieces_left() + total_rounds - 1) / total_rounds : 0);   // (wave-uniform)
 
   const int ng_draw = n_planet * kNG + 7;
   double* __restrict__ pout = GRAD ? partial + ((int64_t)draw * hb + bx) * ng_draw : nullptr;
@@ -1947,6 +1991,7 @@ __global__ __launch_bounds__(kBlock, EXO_HEAVY_MIN_WAVES) void transit_runs_kern
 #pragma unroll
   for (int k = 0; k < 6; ++k) cld[k] = uniform((SECONDARY || k < 3) ? sh.c[k] : 0.0);
   const double te = (n_texp == 0) ? 0.0 : texp[0];
+  const double sdt0 = uniform(sh.sdt[0]), sw0 = uniform(sh.sw[0]);
   for (int p = 0; p < n_planet; ++p) {
     const PlanetS c(sh.pc[p]);
     if (GRAD && p > 0) {
@@ -1968,9 +2013,11 @@ __global__ __launch_bounds__(kBlock, EXO_HEAVY_MIN_WAVES) void transit_runs_kern
       for (int kb = k0; kb < k1; kb += kSeg) {
         const int m = (kb + kSeg < k1) ? kSeg : k1 - kb;
         __syncthreads();   // (the previous batch is done with the tables)
+        const int in0 = pin[kb], all0 = pall[kb];
         for (int q = threadIdx.x; q <= m; q += kBlock) {
-          s_in[q] = pin[kb + q];
-          s_all[q] = pall[kb + q];
+          const int pi = pin[kb + q] - in0, pa = pall[kb + q];
+          s_pre[q] = make_int2(pi, (pa - all0) - pi);
+          s_all[q] = pa;
           if (q < m) s_run[q] = runs[kb + q];
           if (TTV && q < m) {
             const int kq = rl.rbin[list * rl.r_max + kb + q];
@@ -1984,25 +2031,48 @@ __global__ __launch_bounds__(kBlock, EXO_HEAVY_MIN_WAVES) void transit_runs_kern
         }
         __syncthreads();
         const bool trusted = TTV && s_bin[0] >= 0;   // (all runs of a list or none)
-        const int in0 = s_in[0], all0 = s_all[0];
-        const int tin = s_in[m] - in0, total = s_all[m] - all0;
+        const int tin = s_pre[m].x, total = tin + s_pre[m].y;
         // dense index j of the batch -> cadence i and position v in the value array: "inside" parts of all
-        // runs first, then the limb parts, so that a wave's vote on the arc geometry is nearly unanimous
+        // runs first, then the limb parts, so that a wave's vote on the arc geometry is nearly unanimous.
+        // Which run?  Transits recur: the runs of a list are nearly equally long, so position x runs / items is
+        // the run or a neighbour of it; a wave steps its lanes to the right run (a vote per step) and only an uneven
+        // list -- gaps in the series, the every-cadence fallback -- pays for a binary search (round 2 paid for one per
+        // item: ~100 of the kernel's ~1100 vector instructions per cadence).
+        const float g_in = tin > 0 ? (float)m / (float)tin : 0.0f;
+        const float g_lim = total > tin ? (float)m / (float)(total - tin) : 0.0f;
         struct Item { int i, v, q; double tv, g, w; };
         auto locate = [&](int j, int& i, int& v, int& qrun) {
+#ifdef EXO_STUB_LOCATE
+          { const Run r0 = s_run[0]; i = r0.lo + (j & 31); v = s_all[0] + (j & 31); qrun = 0; return; }
+#endif
           const bool in = j < tin;
           const int jj = in ? j : j - tin;
-          int q = 0;
+          int q = (int)((float)jj * (in ? g_in : g_lim));
+          q = q < m - 1 ? q : m - 1;
+          int2 pa = s_pre[q], pb = s_pre[q + 1];
+          int lo = in ? pa.x : pa.y, hi = in ? pb.x : pb.y;
+          int tries = 0;
+          while (EXO_WAVE_ANY((jj < lo) | (jj >= hi))) {
+            if (++tries > 4) {
+              q = 0;
 #pragma unroll
-          for (int step = kSeg / 2; step > 0; step >>= 1) {
-            const int c2 = q + step;
-            if (c2 < m) {
-              const int pv = in ? s_in[c2] - in0 : (s_all[c2] - all0) - (s_in[c2] - in0);
-              q = (jj >= pv) ? c2 : q;
+              for (int step = kSeg / 2; step > 0; step >>= 1) {
+                const int c2 = q + step;
+                if (c2 < m) {
+                  const int2 pc = s_pre[c2];
+                  q = (jj >= (in ? pc.x : pc.y)) ? c2 : q;
+                }
+              }
+              pa = s_pre[q];
+              lo = in ? pa.x : pa.y;
+              break;
             }
+            q += (jj < lo) ? -1 : ((jj >= hi) ? 1 : 0);
+            pa = s_pre[q]; pb = s_pre[q + 1];
+            lo = in ? pa.x : pa.y; hi = in ? pb.x : pb.y;
           }
           const Run r = s_run[q];
-          const int off = jj - (in ? s_in[q] - in0 : (s_all[q] - all0) - (s_in[q] - in0));
+          const int off = jj - lo;
           i = in ? r.a + off : ((off < r.a - r.lo) ? r.lo + off : r.b + (off - (r.a - r.lo)));
           v = s_all[q] + (i - r.lo);
           qrun = q;
@@ -2030,7 +2100,10 @@ __global__ __launch_bounds__(kBlock, EXO_HEAVY_MIN_WAVES) void transit_runs_kern
           double f = 0.0;
           const double dsh = TTV ? s_shift[TTV ? cur.q : 0] : 0.0;
           for (int k = 0; k < n_sub; ++k) {
-            double tt = fma(te, sh.sdt[k], cur.tv);
+            // (the first sub-exposure's offset and weight sit in scalar registers: without an exposure time there is
+            // no LDS read -- and no wait for one -- at the top of a round)
+            const double sdt_k = (k == 0) ? sdt0 : sh.sdt[k], sw_k = (k == 0) ? sw0 : sh.sw[k];
+            double tt = fma(te, sdt_k, cur.tv);
             int ks = 0;
             if (TTV) {
               double sh_k = dsh;
@@ -2040,9 +2113,9 @@ __global__ __launch_bounds__(kBlock, EXO_HEAVY_MIN_WAVES) void transit_runs_kern
               }
               tt -= sh_k;
             }
-            const double gw = cur.g * sh.sw[k];
+            const double gw = cur.g * sw_k;
             const double F = eval_sample<GRAD, SECONDARY, LDELAY, CHI2>(tt, c, cld, CHI2 ? cur.g : gw, acc, cur.w);
-            f = fma(sh.sw[k], F, f);
+            f = fma(sw_k, F, f);
             if (CHI2) {
               const double r = F - cur.g;
               acc.add(kNG + 6, cur.w * (r * r - cur.g * cur.g));

@@ -40,9 +40,10 @@ def c2_inputs(D, seed=100):
 
 
 out = {"lib": os.environ.get("EXOPLANET_AMD_LIB", "product")}
+QUICK = "--quick" in sys.argv      # C2 at 1024 draws only (for alternating A/B/A/B runs: boxes and clocks drift)
 N = 150_000
 t = torch.arange(N, dtype=torch.float64, device=dev) * CAD
-for D in (1024, 128):
+for D in ((1024,) if QUICK else (1024, 128)):
     rec, ld, flags = c2_inputs(D)
     g = torch.randn(D, N, dtype=torch.float64, device=dev, generator=torch.Generator(device=dev).manual_seed(1))
     obs = 1e-4 * torch.randn(N, dtype=torch.float64, device=dev, generator=torch.Generator(device=dev).manual_seed(2))
@@ -58,6 +59,9 @@ for D in (1024, 128):
     out[tag + "_check"] = [float(f.sum()), float(gp.abs().sum()), float(gl.abs().sum()), float(ops.transit_chi2(t, rec, ld, obs, w, flags=flags).sum())]
     del g, f
 torch.cuda.empty_cache()
+if QUICK:
+    print(json.dumps(out))
+    sys.exit(0)
 # C4: 4 planets, 200 000 cadences, 64 draws
 rng = np.random.default_rng(4)
 n4, D4 = 200_000, 64
