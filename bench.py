@@ -692,6 +692,8 @@ def extra_gp_conditioning(xo, ops, dev, D):
         "sho_1pct_near_critical": ([full(1e-3), full(5.0), torch.tensor(Qmix, device=dev, requires_grad=True)],
                                    lambda s, r, q: T.SHOTerm(sigma=s, rho=r, Q=q)),
         "matern32": ([full(1e-3), full(5.0)], lambda s, r: T.Matern32Term(sigma=s, rho=r)),
+        "two_sho_clean": ([full(1e-3), full(5.0), full(7e-4), full(2.5)],
+                          lambda s1, r1, s2, r2: T.SHOTerm(sigma=s1, rho=r1, Q=1.2) + T.SHOTerm(sigma=s2, rho=r2, Q=1.5)),
         "rotation_term": ([full(1e-3), full(5.0), full(0.02), full(0.5), full(0.5)],
                           lambda s, p, q0, dq, f: T.RotationTerm(sigma=s, period=p, Q0=q0, dQ=dq, f=f)),
     }
@@ -707,14 +709,16 @@ def extra_gp_conditioning(xo, ops, dev, D):
         except Exception as exc:
             out[name] = {"error": repr(exc)[:200]}
         torch.cuda.synchronize(dev)
-    if "median_ms" in out.get("sho_clean", {}):
-        for k, v in out.items():
-            if "median_ms" in v:
-                v["over_clean"] = v["median_ms"] / out["sho_clean"]["median_ms"]
+    for k, ref in (("sho_1pct_near_critical", "sho_clean"), ("matern32", "sho_clean"), ("rotation_term", "two_sho_clean")):
+        if "median_ms" in out.get(k, {}) and "median_ms" in out.get(ref, {}):
+            out[k]["over_clean"] = out[k]["median_ms"] / out[ref]["median_ms"]      # against a clean batch of the same J
+            out[k]["clean_reference"] = ref
     out["draws"], out["n_cadences"] = D, N_CAD
-    out["note"] = ("GP log-likelihood + gradients alone (no light curve); `over_clean` = step time relative to the clean SHO "
-                   "batch: the cost of ill-conditioned draws in a batch (round 2: ~45x when a draw fell back to the sequential "
-                   "kernels)")
+    out["note"] = ("GP log-likelihood + gradients alone (no light curve); `over_clean` = step time relative to a clean batch of "
+                   "the same state width (J = 2: sho_clean; J = 4: two_sho_clean): the cost of over-damped / nearly critically "
+                   "damped / Matern-type draws in a batch.  Round 2: 53x (207 ms against 3.9) as soon as ONE draw had Q < 1/2; "
+                   "now every such draw stays on the time-parallel path (joint state covariance of the over-damped pair, "
+                   "conditioning threshold 1e8), and a batch of mixed kinds pays for the second kernel variant only")
     return out
 
 

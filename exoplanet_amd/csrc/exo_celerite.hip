@@ -691,7 +691,7 @@ __global__ __launch_bounds__(kWave) void celerite_elem_lg_kernel(
   if (G >= 2) ba2 = fmax(ba2, xor_get<1>(ba2));
   if (G >= 4) ba2 = fmax(ba2, xor_get<2>(ba2));
   if (G >= 8) ba2 = fmax(ba2, xor_get<4>(ba2));
-  const double rmin = (1.0 + ba2) * asum * 1e-5;
+  const double rmin = (1.0 + ba2) * asum * (1.0 / EXO_GP_COND_MAX);
   bool ok = true;
 
   // lane j holds COLUMN j of A (so that (A^T U)_j is a local dot product: no butterfly) and rows j of
@@ -1173,6 +1173,12 @@ __global__ __launch_bounds__(kWave) void celerite_scan_init_kernel(const double*
   const int j = threadIdx.x & (G - 1);
   const int64_t draw = ((int64_t)blockIdx.x * kWave + threadIdx.x) / G;
   if (draw >= n_draw) return;
+  if (J <= kLaneMaxJ) {
+    // the one-lane path's own Delta (DeltaCoef: joint covariance of an over-damped SHO's pair of real terms included);
+    // LaneDelta below serves the lane-group kernels (J = 7, 8), where such pairs stay flagged
+    if (j == 0) scan_init_lane<J>(t, cf, n_draw, dst, draw);
+    return;
+  }
   const LaneCoef k = lane_coef(cf, draw, j, J);
   if (!k.live) return;
   const LaneDelta ld(k);

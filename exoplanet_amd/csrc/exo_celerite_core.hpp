@@ -254,6 +254,10 @@ EXO_HD void load_block(const SeriesRow& y, const double* EXO_RESTRICT dg, int64_
 }
 
 constexpr int kChunkMaxJ = 8;   // = EXO_GP_MAX_J (J = 7, 8: lane-group element kernel, one-lane scan kernels spill)
+// conditioning score above which a draw leaves the time-parallel path (elem_lane: how it was calibrated)
+#ifndef EXO_GP_COND_MAX
+#define EXO_GP_COND_MAX 1e8
+#endif
 #ifndef EXO_LANE_MAX_J
 #define EXO_LANE_MAX_J 6
 #endif
@@ -343,8 +347,20 @@ struct DeltaCoef {
   bool valid;
   EXO_HD bool is_real(int j) const { return NR < 0 ? real[j] : j < NR; }
   EXO_HD bool is_first(int j) const { return NR < 0 ? first[j] : (j >= NR && ((j - NR) & 1) == 0); }
-  EXO_HD void init(const Coefs& co, int64_t draw) {
+  // Two real terms that share a pair slot (kind 1: an SHO term with Q < 1/2) and are NOT both positive -- the
+  // over-damped oscillator's a2 = S0 w0 Q (1 - 1 / f) / 2 < 0 -- have no covariance of their own (1 / a2 < 0), but the
+  // pair has a joint one: the process z' = -diag(c) z + g w (one noise input), observed through (1, 1), has the
+  // stationary covariance Pi_ij = g_i g_j / (c_i + c_j) and the kernel sum_i a_i exp(-c_i tau) with a_i = sum_j Pi_ij.
+  // With x = Pi_11, y = Pi_22, z = Pi_12:  a1 = x + z, a2 = y + z, z^2 = k x y, k = 4 c1 c2 / (c1 + c2)^2, i.e.
+  //     (1 - k) z^2 + k (a1 + a2) z - k a1 a2 = 0,     z = the root that leaves x = a1 - z, y = a2 - z >= 0
+  // (the discriminant vanishes exactly for an SHO term: the only admissible member, as for the complex pair), and in
+  // celerite's scaling (U = a, V = 1) Delta = [[x / a1^2, z / (a1 a2)], [., y / a2^2]]: Delta U = V, and the process
+  // noise Delta - phi Delta phi is positive semi-definite.  Round 2 sent every such draw -- every chain whose Q
+  // crosses 1/2 -- to the sequential kernels: ~50x the step time of the whole batch.
+  EXO_HD void init(const Coefs& co, int64_t draw, bool allow_coupled = (J <= EXO_LANE_MAX_J)) {
     valid = true;
+    double a1 = 0.0, c1 = 0.0;
+    bool ok1 = true;
 #pragma unroll
     for (int j = 0; j < J; ++j) {
       const LaneCoef k = lane_coef(co, draw, j, J);
@@ -352,7 +368,26 @@ struct DeltaCoef {
       first[j] = !k.real && !k.odd;
       if (is_real(j)) {
         p[j] = 1.0 / k.a; q[j] = 0.0; r[j] = 0.0;
-        valid = valid && (k.a > 0.0) && (k.c >= 0.0) && (k.a < INFINITY) && (k.c < INFINITY);
+        const bool ok = (k.a > 0.0) && (k.c >= 0.0) && (k.a < INFINITY) && (k.c < INFINITY);
+        const bool pair1 = k.slot >= 0 && (k.slot & 2) == 0, pair2 = k.slot >= 0 && (k.slot & 2) != 0;
+        if (pair1) {          // (decided with its partner)
+          a1 = k.a; c1 = k.c; ok1 = ok;
+        } else if (pair2 && j > 0 && !(ok1 && ok)) {
+          const double a2 = k.a, c2 = k.c, cs = c1 + c2, kk = 4.0 * c1 * c2 / (cs * cs), omk = (c1 - c2) * (c1 - c2) / (cs * cs);
+          const double sa = a1 + a2, disc = kk * kk * sa * sa + 4.0 * omk * kk * a1 * a2;
+          const double z = -(kk * sa + sqrt(fmax(disc, 0.0))) / (2.0 * omk);
+          const double x = a1 - z, y = a2 - z;
+          const bool okc = allow_coupled && (c1 > 0.0) && (c2 > 0.0) && (omk > 0.0) && (sa > 0.0) && (x >= 0.0) && (y >= 0.0) &&
+                           (disc >= -1e-9 * kk * kk * sa * sa) && (x < INFINITY) && (y < INFINITY) && (c1 < INFINITY) && (c2 < INFINITY);
+          p[j > 0 ? j - 1 : 0] = x / (a1 * a1);
+          q[j > 0 ? j - 1 : 0] = z / (a1 * a2);
+          p[j] = y / (a2 * a2);
+          valid = valid && okc;
+        } else if (pair2) {
+          valid = valid && ok1 && ok;
+        } else {
+          valid = valid && ok;
+        }
       } else {
         const double a = k.a, b = k.b, c = k.c, d = k.d;
         const double h = 1.0 / (a * a + b * b);
@@ -378,7 +413,7 @@ struct DeltaCoef {
       const double od = (p[j] - r[j]) * cs * sn + q[j] * (sn * sn - cs * cs);
       const double d2 = p[j] * sn * sn - 2.0 * q[j] * cs * sn + r[j] * cs * cs;
       D(j, j) = re ? p[j] : (fi ? dd : next_dd);
-      if (j + 1 < J) D(j, j + 1) = fi ? od : 0.0;
+      if (j + 1 < J) D(j, j + 1) = fi ? od : (re ? q[j] : 0.0);   // (a real index: 0, or the coupling of a joint pair)
       next_dd = fi ? d2 : 0.0;
     }
   }
@@ -580,19 +615,31 @@ EXO_HD void elem_lane(const double* EXO_RESTRICT t, Series rs, const double* EXO
   dc.eval(V, Dl);
   // Conditioning.  The element is in information form (1 / diag) and lives in celerite's rotating
   // frame, where a complex term's state covariance Delta0 has condition number ~ 4 (b / a)^2: the
-  // J x J solves of the scans lose about  kappa = (1 + max (b/a)^2) sum(a) / min(diag)  times 1e-13
-  // in the gradients (measured against the sequential kernels over random kernels,
-  // tools/gp_cond_scan.py: 1e-9 at kappa = 1e4, 2e-8 at 1e5, 1e-4 at 1e7).  Draws with kappa > 1e5
-  // -- celerite2's Matern-3/2 term (b / a = 100 w0), an SHO term within a few per cent of critical
-  // damping, a signal 1e5 times the white noise, diag = 0 -- are flagged here and redone by the
-  // sequential kernels.  (A whitened state basis would lift the (b / a)^2 factor: DESIGN.md 8.)
-  double asum = 0.0, ba2 = 0.0;
+  // J x J solves of the scans lose accuracy with  kappa = (1 + max (b/a)^2) sum(a) / min(diag).
+  // Measured at the benchmarked sizes against the sequential kernels with the flag off (tools/gp_cond_scale.py,
+  // N = 150 000, SHO terms from Q = 4 to within 1e-4 of critical damping on either side, celerite2's Matern-3/2
+  // term, signal / noise variance 4 .. 1e6): every gradient agrees to <= 3e-7 up to kappa = 5e7, 1e-6 .. 3e-6 at
+  // 5e8 .. 1e9, 3e-5 at 5e9; against the long-double dense definition at N = 500 (tests/golden/gp_hard.npz):
+  // <= 1e-6 in all seven hard regimes.  Draws with kappa > EXO_GP_COND_MAX = 1e8 -- a signal 1e8 times the
+  // white noise, diag = 0 -- are flagged here and redone by the sequential kernels.  (Round 2 drew the line at 1e5
+  // from a scan over random kernels in which other extremes dominated the disagreement, and so sent celerite2's
+  // Matern-3/2 term and every nearly critically damped SHO term to the ~50x slower sequential path.)
+  double asum = 0.0, ba2 = 0.0, a_first = 0.0;
 #pragma unroll
   for (int j = 0; j < J; ++j) {
     asum += (co.is_real(j) || co.is_first(j)) ? fabs(co.k[j].a) : 0.0;
     if (!co.is_real(j) && co.is_first(j)) ba2 = fmax(ba2, (co.k[j].b * co.k[j].b) / (co.k[j].a * co.k[j].a));
+    // a joint pair of real terms (DeltaCoef::init): (|a1| + |a2|) / (a1 + a2) = 1 / f plays the part of b / a = 1 / f
+    if (co.is_real(j) && co.k[j].slot >= 0) {
+      if ((co.k[j].slot & 2) == 0) {
+        a_first = co.k[j].a;
+      } else if (!(a_first > 0.0 && co.k[j].a > 0.0)) {
+        const double w = (fabs(a_first) + fabs(co.k[j].a)) / (a_first + co.k[j].a);
+        ba2 = fmax(ba2, w * w);
+      }
+    }
   }
-  const double rmin = (1.0 + ba2) * asum * 1e-5;
+  const double rmin = (1.0 + ba2) * asum * (1.0 / EXO_GP_COND_MAX);
   bool ok = true;
   BlockIn cur, nxt;
   load_block(y, dg, n_diag, n0, n1, cur);

@@ -171,6 +171,55 @@ def test_lane_pipeline_mixed_pair_kinds(harness):
                 np.testing.assert_allclose(g["cplx"][d, 0, q], gll[d] * gw[key][0], rtol=1e-7, atol=1e-8)
 
 
+@pytest.mark.parametrize("n_extra", [0, 1, 2])
+def test_lane_pipeline_takes_overdamped_sho_pairs(harness, n_extra):
+    """An SHO term with Q < 1/2 is two real terms, one of NEGATIVE amplitude: as a pair slot of kind 1 the time-parallel
+    path takes it with the pair's joint state covariance (DeltaCoef::init) -- not flagged, log-likelihood and every
+    gradient equal to the dense definition -- from deep over-damping to within 1 % of critical damping, alone (J = 2)
+    and next to other terms (J = 4, 6: an under-damped SHO, a plain real pair)."""
+    rng = np.random.default_rng(40 + n_extra)
+    n = 230
+    t = np.sort(rng.uniform(0, 40, n))
+    t[100:] += 2.5
+    Qs = [0.05, 0.2, 0.35, 0.45, 0.49, 0.495]
+    D = len(Qs)
+    y = rng.normal(size=(D, n))
+    diag = rng.uniform(0.05, 0.3, (D, n))
+    n_slot = 1 + n_extra
+    cplx = np.zeros((D, n_slot, 4))
+    kind = np.zeros((D, n_slot), dtype=np.int32)
+    terms = []
+    for d, Q in enumerate(Qs):
+        ar, cr, *_ = P.sho_coefficients(rng.uniform(0.5, 1.5), rng.uniform(0.8, 2.0), Q)
+        assert ar.size == 2 and ar.min() < 0          # the over-damped pair
+        cplx[d, 0] = [ar[0], cr[0], ar[1], cr[1]]
+        kind[d, 0] = 1
+        tr = [ar, cr, np.zeros(0), np.zeros(0), np.zeros(0), np.zeros(0)]
+        if n_extra >= 1:                               # an under-damped SHO in the next slot
+            c = P.sho_coefficients(0.7, 1.1, 2.0)
+            cplx[d, 1] = [c[2][0], c[3][0], c[4][0], c[5][0]]
+            tr = [tr[0], tr[1]] + [c[k] for k in (2, 3, 4, 5)]
+        if n_extra >= 2:                               # two positive real terms sharing a slot (independent, as before)
+            a2, c2, *_ = rand_terms(rng, 2, 0)
+            cplx[d, 2] = [a2[0], c2[0], a2[1], c2[1]]
+            kind[d, 2] = 1
+            tr[0], tr[1] = np.concatenate([tr[0], a2]), np.concatenate([tr[1], c2])
+        terms.append(tuple(tr))
+    gll = rng.normal(size=D)
+    for n_chunks in (0, 6):
+        ll, flags, _, g = run(harness, t, y, diag, np.zeros((D, 0, 2)), cplx, kind=kind, n_chunks=n_chunks, gll=gll)
+        assert np.all(flags == 0), flags
+        for d in range(D):
+            want, gw = P.gp_loglike_dense(t, y[d], diag[d], terms[d])
+            assert abs(ll[d] - want) <= 1e-10 * abs(want), (Qs[d], ll[d], want)
+            tol = 1e-6 if Qs[d] > 0.48 else 1e-7      # (within 2 % of critical damping a1 ~ -a2 ~ 1 / f: conditioning)
+            np.testing.assert_allclose(g["y"][d], gll[d] * gw["y"], rtol=tol, atol=1e-9)
+            got = g["cplx"][d, 0]
+            sc = np.abs(gll[d] * gw["ar"][:2]).max()
+            np.testing.assert_allclose(got[[0, 2]], gll[d] * gw["ar"][:2], rtol=tol, atol=tol * sc)
+            np.testing.assert_allclose(got[[1, 3]], gll[d] * gw["cr"][:2], rtol=tol, atol=tol * np.abs(gll[d] * gw["cr"][:2]).max())
+
+
 def test_lane_pipeline_flags_what_it_cannot_take(harness):
     """the negative-amplitude real term of an over-damped SHO is outside the filter form: flagged
     (the library then redoes the draw with the sequential kernels)"""

@@ -173,11 +173,11 @@ def test_no_white_noise_falls_back(dev):
             assert np.abs(g - w).max() / (np.abs(w).max() + 1e-300) < 2e-9
 
 
-def test_ill_conditioned_terms_stay_sequential(dev):
-    """celerite2's Matern-3/2 term is a complex term with b / a = 100 w0: in celerite's rotating
-    frame its state covariance has a condition number ~ 4 (b/a)^2, and the J x J solves of the
-    chunk scans would lose that many digits.  The element kernel's conditioning score sends such
-    draws (and signals > 1e5 x the white noise) to the sequential kernels: identical numbers."""
+def test_conditioning_score_decides_the_path(dev):
+    """The element kernel's conditioning score kappa = (1 + max (b/a)^2) sum(a) / min(diag) sends a draw to the
+    sequential kernels above EXO_GP_COND_MAX = 1e8 (round 3; 1e5 in round 2): celerite2's Matern-3/2 term
+    (b / a = w0 / eps = 58 here) and an SHO term at a signal 1e6 x the noise now stay on the time-parallel path (close
+    to the sequential numbers, not identical), a signal 1e10 x the noise does not (identical numbers)."""
     import exoplanet_amd as xo
     from exoplanet_amd.gp import terms
 
@@ -198,15 +198,16 @@ def test_ill_conditioned_terms_stay_sequential(dev):
                 out.append([x.detach().cpu().numpy() for x in (ll,) + g])
         return out
 
-    seq, par = both(lambda: terms.Matern32Term(sigma=sig, rho=rho), 0.05)
-    for a, b in zip(seq, par):
-        np.testing.assert_array_equal(a, b)
-    # a well-conditioned term at the same noise level takes the time-parallel path: close, not identical
-    seq, par = both(lambda: terms.SHOTerm(sigma=sig, rho=rho, Q=0.8), 0.05)
-    assert not np.array_equal(seq[0], par[0])
-    np.testing.assert_allclose(par[0], seq[0], rtol=1e-12)
-    # ... until the noise is 1e-6 of the signal
-    seq, par = both(lambda: terms.SHOTerm(sigma=sig, rho=rho, Q=0.8), 5e-4)
+    def close(seq, par, rtol_ll, rtol_g):
+        assert not np.array_equal(seq[0], par[0])              # two different algorithms ...
+        np.testing.assert_allclose(par[0], seq[0], rtol=rtol_ll)   # ... one answer
+        for a, b in zip(seq[1:], par[1:]):
+            assert np.abs(a - b).max() <= rtol_g * np.abs(a).max()
+
+    close(*both(lambda: terms.Matern32Term(sigma=sig, rho=rho), 0.05), 1e-11, 1e-7)      # kappa ~ 3e5
+    close(*both(lambda: terms.SHOTerm(sigma=sig, rho=rho, Q=0.8), 0.05), 1e-12, 1e-9)
+    close(*both(lambda: terms.SHOTerm(sigma=sig, rho=rho, Q=0.8), 5e-4), 1e-9, 1e-6)     # signal 1e6 x the noise
+    seq, par = both(lambda: terms.SHOTerm(sigma=sig, rho=rho, Q=0.8), 5e-6)              # 1e10 x: flagged
     for a, b in zip(seq, par):
         np.testing.assert_array_equal(a, b)
 
