@@ -1,1 +1,2 @@
-python -m pytest tests/test_gpu_gp.py tests/test_gpu_gp_chunked.py tests/test_gpu_gp_lane.py tests/test_gpu_golden.py -x -q -m gpu 2>&1 | grep -E "^E  |^>|passed|failed" | head -12
+bash tools/profile_r03.sh > gpurun_out/r03_log.txt 2>&1
+tail -60 gpurun_out/r03_log.txt
