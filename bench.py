@@ -355,18 +355,17 @@ def make_runner(step_fn, scalar_index, exchange, consume):
 
 class ExchangeConsumer:
     """what a sampler does with the exchanged vector, reduced to its cost: every step's full (n_global,) vector is
-    folded into running sums (cross-chain mean / second moment for adaptation and logging) on the device -- one small
+    folded into a running sum (cross-chain mean log-likelihood for adaptation and logging) on the device -- ONE small
     kernel per step, inside the timed region, so the timed step covers an exchange whose result is USED"""
 
     def __init__(self, n_global, dev):
-        self.acc = torch.zeros(2, n_global, dtype=torch.float64, device=dev)
+        self.acc = torch.zeros(n_global, dtype=torch.float64, device=dev)
         self.steps = 0
 
     def __call__(self, full):
         if full is None:
             return
-        self.acc[0].add_(full)
-        self.acc[1].addcmul_(full, full)
+        self.acc.add_(full)
         self.steps += 1
 
 
@@ -911,7 +910,7 @@ def main():
     wl = WORKLOADS[cfg](xo, ops, dev, D, rank)
     leaves = dict(zip(wl.names, wl.leaves))
     N = wl.n_cad
-    exchange = LoglikeExchange(n_global, dev) if dist is not None else None
+    exchange = LoglikeExchange(n_global, dev, force_collective=os.environ.get("EXO_BENCH_FORCE_DIST") == "1") if dist is not None else None
     consume = ExchangeConsumer(n_global, dev) if exchange is not None else None
 
     # The step is a handful of short launches: launch-bound when issued eagerly, so the timed region replays it as ONE

@@ -54,9 +54,12 @@ class LoglikeExchange:
     hands back the previous step's completed vector.  Rank and world size are those of
     ``group``.  A single process (or an uninitialised process group) just copies."""
 
-    def __init__(self, n_draw, device, dtype=torch.float64, group=None):
+    def __init__(self, n_draw, device, dtype=torch.float64, group=None, force_collective=False):
+        """``force_collective``: issue the collective even in a group of ONE rank (instead of a copy) -- how a 1-GPU box
+        exercises and traces the RCCL path (bench.py, EXO_BENCH_FORCE_DIST=1)"""
         self.group = group
         self.rank, self.world = _rank_world(group)
+        self._force = bool(force_collective) and dist.is_initialized()
         self.n_draw = int(n_draw)
         self.lo, self.hi = shard_bounds(self.n_draw, self.rank, self.world)
         self.equal = self.n_draw % self.world == 0
@@ -96,7 +99,7 @@ class LoglikeExchange:
         self._wait(k)                  # (issued two steps ago and already waited for when it was handed out: a no-op)
         stage, out = self._stage[k], self._outs[k]
         stage.copy_(local)
-        if self.world == 1:
+        if self.world == 1 and not self._force:
             out.copy_(stage)
         elif self.equal:
             self._work[k] = dist.all_gather_into_tensor(out, stage, group=self.group, async_op=True)
@@ -117,7 +120,7 @@ class LoglikeExchange:
         local = local.detach()
         if local.shape != (self.hi - self.lo,):
             raise ValueError(f"rank owns draws [{self.lo},{self.hi}) but got a tensor of shape {tuple(local.shape)}")
-        if self.world == 1:
+        if self.world == 1 and not self._force:
             self.out.copy_(local)
         elif self.equal:
             dist.all_gather_into_tensor(self.out, local.contiguous(), group=self.group)

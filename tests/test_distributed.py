@@ -150,7 +150,7 @@ def _worker_bench_exchange(rank, world, port, n_global, out_dir):
         consume(last)
         assert consume.steps == 5
         want_sum = sum(torch.arange(n_global, dtype=torch.float64) * (it + 2) - 0.5 for it in range(5))
-        assert torch.allclose(consume.acc[0], want_sum, rtol=1e-14)
+        assert torch.allclose(consume.acc, want_sum, rtol=1e-14)
         with pytest.raises(ValueError):
             ex.start(torch.zeros(hi - lo + 1, dtype=torch.float64))
         # a group with the ranks in reverse order: position in the group != global rank
@@ -209,7 +209,7 @@ def _worker_runner(rank, world, port, n_global, out_dir):
         drain()
         assert consume.steps == K
         want = K * torch.arange(n_global, dtype=torch.float64) + 100.0 * sum(range(1, K + 1))
-        assert torch.equal(consume.acc[0], want), (rank, consume.acc[0], want)
+        assert torch.equal(consume.acc, want), (rank, consume.acc, want)
         np.save(os.path.join(out_dir, f"ok_{rank}.npy"), np.ones(1))
     finally:
         dist.destroy_process_group()
