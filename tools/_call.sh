@@ -1,9 +1,9 @@
-mkdir -p gpurun_out/r3p
-cd /tmp && export TMPDIR=/tmp
-EXO_BENCH_FORCE_DIST=1 rocprofv3 --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/r3p/trace -o p -- python $GRAFT_REPO_ROOT/bench.py --steps 40 --warmup 5 --no-extras --no-cpu-baseline --no-stats > $GRAFT_REPO_ROOT/gpurun_out/r3p/bench_forced.json 2> $GRAFT_REPO_ROOT/gpurun_out/r3p/bench_forced.err
-cd $GRAFT_REPO_ROOT
-python tools/trace_overlap.py gpurun_out/r3p/trace gpurun_out/r3p/r03_forced_dist_overlap.txt
-tail -c 300 gpurun_out/r3p/bench_forced.json
-rm -rf gpurun_out/r3p/trace
-EXO_BENCH_FORCE_DIST=1 python bench.py --steps 50 --no-extras --no-cpu-baseline --no-stats 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().split('\n')[-1]); print('forced dist ms_per_step', d['ms_per_step'])"
-python bench.py --steps 50 --no-extras --no-cpu-baseline --no-stats 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().split('\n')[-1]); print('plain ms_per_step', d['ms_per_step'])"
+mkdir -p gpurun_out/r3q
+R=$GRAFT_REPO_ROOT
+for r in 1 2; do
+for v in base gp_span2w2 gp_span2w3; do for ch in 0 384 192; do
+    if [ "$v" = base ]; then unset EXOPLANET_AMD_LIB; else export EXOPLANET_AMD_LIB=$R/tests/_build/variants/$v.so; fi
+    a=$(EXO_GP_CHUNKS=$ch python $R/bench.py --config c3 --steps 10 --warmup 2 --no-cpu-baseline --no-stats 2>/dev/null | python -c "import json,sys; print('%.3f'%json.loads(sys.stdin.read().strip().split('\n')[-1])['ms_per_step'])")
+    echo "$v chunks=$ch c3_ms=$a"
+done; done; done > gpurun_out/r3q/ab.txt 2>&1
+cat gpurun_out/r3q/ab.txt
