@@ -1380,17 +1380,69 @@ static_assert(kLaneMaxJ >= 2, "EXO_GP_LAYOUTS lists compile-time layouts for J <
 // J = 1: one real term; J = 2: two real terms or one pair slot -- complex, or, with per-draw kinds,
 // either (three launches: waves return at once from the variants they did not vote for); J > 2:
 // run-time flags.
-#define EXO_GP_LAYOUTS(J_, CF, CALL)                                                    \
+// J = 2 with per-draw pair kinds (a batch of SHO terms that straddles Q = 1/2): the three layout variants in ONE launch.
+// blockIdx.z picks the variant; a wave runs the one it voted for and leaves the other two at once.  Launched one after the
+// other (round 2), each variant cost its full single-wave latency however few waves took it: a batch with 1 % of its draws
+// on the other side of Q = 1/2 paid twice the clean batch's time.  The layouts keep their own code (compile-time NR); the
+// kernel's registers are those of the widest variant -- the same waves per SIMD as each alone (145 / 118 / 159, 113 / 100 /
+// 124, 217 / 186 / 239 registers for element / forward / reverse).
+__global__ __launch_bounds__(kWave) void celerite_elem_mixed_kernel(const double* __restrict__ t, Series rs,
+                                                                    const double* __restrict__ diag, int64_t n_diag, int64_t n,
+                                                                    Coefs cf, int64_t n_draw, double* __restrict__ state,
+                                                                    ChunkGeom cg, int64_t flag_at) {
+  const int64_t draw = (int64_t)blockIdx.x * kWave + threadIdx.x;
+  if (draw >= n_draw) return;
+  const int nr = layout_vote<2>(cf, draw);
+  const int c = (int)blockIdx.y;
+  if (blockIdx.z == 0) {
+    if (nr == 0) elem_lane<2, 0>(t, rs, diag, n_diag, n, cf, n_draw, state, cg, draw, c, flag_at);
+  } else if (blockIdx.z == 1) {
+    if (nr == 2) elem_lane<2, 2>(t, rs, diag, n_diag, n, cf, n_draw, state, cg, draw, c, flag_at);
+  } else {
+    if (nr == -1) elem_lane<2, -1>(t, rs, diag, n_diag, n, cf, n_draw, state, cg, draw, c, flag_at);
+  }
+}
+__global__ __launch_bounds__(kWave) void celerite_chunk1_fwd_mixed_kernel(const double* __restrict__ t, Series rs,
+                                                                          const double* __restrict__ diag, int64_t n_diag,
+                                                                          int64_t n, Coefs cf, int64_t n_draw,
+                                                                          double* __restrict__ state, ChunkGeom cg) {
+  const int64_t draw = (int64_t)blockIdx.x * kWave + threadIdx.x;
+  if (draw >= n_draw) return;
+  const int nr = layout_vote<2>(cf, draw);
+  const int c = (int)blockIdx.y;
+  if (blockIdx.z == 0) {
+    if (nr == 0) chunk1_fwd_lane<2, 0>(t, rs, diag, n_diag, n, cf, n_draw, state, cg, draw, c, true);
+  } else if (blockIdx.z == 1) {
+    if (nr == 2) chunk1_fwd_lane<2, 2>(t, rs, diag, n_diag, n, cf, n_draw, state, cg, draw, c, true);
+  } else {
+    if (nr == -1) chunk1_fwd_lane<2, -1>(t, rs, diag, n_diag, n, cf, n_draw, state, cg, draw, c, true);
+  }
+}
+__global__ __launch_bounds__(kWave, EXO_VJP1_WAVES) void celerite_chunk1_vjp_mixed_kernel(
+    const double* __restrict__ t, Series rs, const double* __restrict__ diag, int64_t n_diag, int64_t n, Coefs cf, int64_t n_draw,
+    const double* __restrict__ gloglike, double* __restrict__ state, ChunkGeom cg, double* __restrict__ gresid,
+    double* __restrict__ gdiag, double gsign) {
+  static_assert(2 < EXO_SPAN2_MIN_J, "the mixed reverse kernel is the J = 2 register-resident form (chunk1_vjp_lane)");
+  const int64_t draw = (int64_t)blockIdx.x * kWave + threadIdx.x;
+  if (draw >= n_draw) return;
+  const int nr = layout_vote<2>(cf, draw);
+  const int c = (int)blockIdx.y;
+  if (blockIdx.z == 0) {
+    if (nr == 0) chunk1_vjp_lane<2, 0>(t, rs, diag, n_diag, n, cf, n_draw, gloglike, state, cg, gresid, gdiag, gsign, draw, c);
+  } else if (blockIdx.z == 1) {
+    if (nr == 2) chunk1_vjp_lane<2, 2>(t, rs, diag, n_diag, n, cf, n_draw, gloglike, state, cg, gresid, gdiag, gsign, draw, c);
+  } else {
+    if (nr == -1) chunk1_vjp_lane<2, -1>(t, rs, diag, n_diag, n, cf, n_draw, gloglike, state, cg, gresid, gdiag, gsign, draw, c);
+  }
+}
+
+#define EXO_GP_LAYOUTS(J_, CF, CALL, MIXED)                                             \
   switch (J_) {                                                                         \
     case 1: { constexpr int JJ = 1, NR = 1; CALL; } break;                              \
     case 2:                                                                             \
       if ((CF).n_real == 2) { constexpr int JJ = 2, NR = 2; CALL; }                     \
       else if (!(CF).kind) { constexpr int JJ = 2, NR = 0; CALL; }                      \
-      else {                                                                            \
-        { constexpr int JJ = 2, NR = 0; CALL; }                                         \
-        { constexpr int JJ = 2, NR = 2; CALL; }                                         \
-        { constexpr int JJ = 2, NR = -1; CALL; }                                        \
-      }                                                                                 \
+      else { MIXED; }   /* per-draw kinds: the three variants in one launch */          \
       break;                                                                            \
     case 3: { constexpr int JJ = 3, NR = -1; CALL; } break;                             \
     case 4: { constexpr int JJ = 4, NR = -1; CALL; } break;                             \
@@ -1444,7 +1496,9 @@ static int celerite_fwd(const double* t, Series resid, const double* diag, int64
                                               n, cf, n_draw, state, cge, flag_at))
       } else {
         EXO_GP_LAYOUTS(J, cf, hipLaunchKernelGGL((celerite_elem_kernel<JJ, NR>), egrid_f, block, 0, st, t, resid, diag,
-                                                 n_diag, n, cf, n_draw, state, cge, flag_at))
+                                                 n_diag, n, cf, n_draw, state, cge, flag_at),
+                       hipLaunchKernelGGL(celerite_elem_mixed_kernel, dim3(egrid_f.x, egrid_f.y, 3), block, 0, st, t, resid, diag,
+                                          n_diag, n, cf, n_draw, state, cge, flag_at))
       }
       for (int f = cg.fine; f >= 1; --f) {
         TreeOp op{};
@@ -1482,7 +1536,9 @@ static int celerite_fwd(const double* t, Series resid, const double* diag, int64
       }
       if (cg.lane) {
         EXO_GP_LAYOUTS(J, cf, hipLaunchKernelGGL((celerite_chunk1_fwd_kernel<(JJ <= kLaneMaxJ ? JJ : 1), NR>), egrid, block, 0,
-                                                 st, t, resid, diag, n_diag, n, cf, n_draw, state, cg))
+                                                 st, t, resid, diag, n_diag, n, cf, n_draw, state, cg),
+                       hipLaunchKernelGGL(celerite_chunk1_fwd_mixed_kernel, dim3(egrid.x, egrid.y, 3), block, 0, st, t, resid, diag,
+                                          n_diag, n, cf, n_draw, state, cg))
       } else {
         EXO_GP_DISPATCH(J, hipLaunchKernelGGL((celerite_chunk_fwd_kernel<JJ>), cgrid, block, 0, st, t, resid, diag, n_diag,
                                               n, cf, n_draw, state, cg))
@@ -1545,7 +1601,9 @@ static int celerite_vjp(const double* t, Series resid, const double* diag, int64
     if (cg.lane) {
       EXO_GP_LAYOUTS(J, cf, hipLaunchKernelGGL((celerite_chunk1_vjp_kernel<(JJ <= kLaneMaxJ ? JJ : 1), NR>), egrid, block, 0,
                                                st, t, resid, diag, n_diag, n, cf, n_draw, gloglike, wstate, cg, gresid,
-                                               gdiag, gsign))
+                                               gdiag, gsign),
+                     hipLaunchKernelGGL(celerite_chunk1_vjp_mixed_kernel, dim3(egrid.x, egrid.y, 3), block, 0, st, t, resid, diag,
+                                        n_diag, n, cf, n_draw, gloglike, wstate, cg, gresid, gdiag, gsign))
     } else {
       EXO_GP_DISPATCH(J, hipLaunchKernelGGL((celerite_chunk_vjp_kernel<JJ>), cgrid, block, 0, st, t, n, cf, n_draw,
                                             gloglike, wstate, cg, gresid, gdiag, gsign))

@@ -1,9 +1,13 @@
-mkdir -p gpurun_out/r3q
-R=$GRAFT_REPO_ROOT
-for r in 1 2; do
-for v in base gp_span2w2 gp_span2w3; do for ch in 0 384 192; do
-    if [ "$v" = base ]; then unset EXOPLANET_AMD_LIB; else export EXOPLANET_AMD_LIB=$R/tests/_build/variants/$v.so; fi
-    a=$(EXO_GP_CHUNKS=$ch python $R/bench.py --config c3 --steps 10 --warmup 2 --no-cpu-baseline --no-stats 2>/dev/null | python -c "import json,sys; print('%.3f'%json.loads(sys.stdin.read().strip().split('\n')[-1])['ms_per_step'])")
-    echo "$v chunks=$ch c3_ms=$a"
-done; done; done > gpurun_out/r3q/ab.txt 2>&1
-cat gpurun_out/r3q/ab.txt
+mkdir -p gpurun_out/r3r
+python -m pytest tests/test_gpu_gp.py tests/test_gpu_gp_chunked.py tests/test_gpu_gp_lane.py tests/test_gpu_golden.py tests/test_gpu_fullsize.py -x -q -m gpu 2>&1 | grep -E "^E  |^>|passed|failed" | head
+python - <<'PY' > gpurun_out/r3r/gp_cond_leg.json 2>gpurun_out/r3r/gp_cond_leg.err
+import json, torch, sys
+sys.path.insert(0, '.')
+import bench, exoplanet_amd as xo
+from exoplanet_amd import ops
+print(json.dumps(bench.extra_gp_conditioning(xo, ops, torch.device('cuda:0'), 1024)))
+PY
+python -c "
+import json
+d=json.load(open('gpurun_out/r3r/gp_cond_leg.json'))
+print({k:(round(v['median_ms'],3), round(v.get('over_clean',0),2)) for k,v in d.items() if isinstance(v,dict) and 'median_ms' in v})"
