@@ -146,7 +146,7 @@ def _known_sorted(t):
     if torch.cuda.is_current_stream_capturing():
         return True   # cannot look during a capture; the warm-up runs before it did
     ok = not bool((t[1:] < t[:-1]).any())
-    if len(_SORTED) > 64:
+    if len(_SORTED) >= 8:      # (an entry keeps its time array alive: a handful of series, not dozens -- ADVICE r2)
         _SORTED.clear()
     _SORTED[key] = (ok, t)
     return ok

@@ -474,7 +474,7 @@ def _white_noise_terms(y, yerr, mean):
         lognorm = torch.log(ivar / (2.0 * torch.pi)).sum() * (1.0 if ivar.numel() == n else float(n))
         hit = (obs, ivar, const, lognorm, y, yerr, 0.5 * (lognorm - const))
         if key is not None:
-            if len(_WN_CACHE) >= 16:
+            if len(_WN_CACHE) >= 4:      # (an entry keeps y, its residuals and weights alive: a few series at most)
                 _WN_CACHE.clear()
             _WN_CACHE[key] = hit
     return hit[:4] + (hit[6],)
