@@ -717,7 +717,7 @@ def extra_gp_conditioning(xo, ops, dev, D):
                    "the same state width (J = 2: sho_clean; J = 4: two_sho_clean): the cost of over-damped / nearly critically "
                    "damped / Matern-type draws in a batch.  Round 2: 53x (207 ms against 3.9) as soon as ONE draw had Q < 1/2; "
                    "now every such draw stays on the time-parallel path (joint state covariance of the over-damped pair, "
-                   "conditioning threshold 1e8); the three layout variants of a mixed batch share one launch, and the step waits for the "
+                   "conditioning threshold 1e7 at J <= 2); the three layout variants of a mixed batch share one launch, and the step waits for the "
                    "one wave of mixed kinds on the run-time layout")
     return out
 

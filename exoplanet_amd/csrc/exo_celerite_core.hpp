@@ -254,9 +254,13 @@ EXO_HD void load_block(const SeriesRow& y, const double* EXO_RESTRICT dg, int64_
 }
 
 constexpr int kChunkMaxJ = 8;   // = EXO_GP_MAX_J (J = 7, 8: lane-group element kernel, one-lane scan kernels spill)
-// conditioning score above which a draw leaves the time-parallel path (elem_lane: how it was calibrated)
+// conditioning score above which a draw leaves the time-parallel path (elem_lane: how it was calibrated):
+// EXO_GP_COND_MAX_J2 for state widths J <= 2, EXO_GP_COND_MAX for wider states
 #ifndef EXO_GP_COND_MAX
-#define EXO_GP_COND_MAX 1e8
+#define EXO_GP_COND_MAX 1e5
+#endif
+#ifndef EXO_GP_COND_MAX_J2
+#define EXO_GP_COND_MAX_J2 1e7
 #endif
 #ifndef EXO_LANE_MAX_J
 #define EXO_LANE_MAX_J 6
@@ -615,15 +619,20 @@ EXO_HD void elem_lane(const double* EXO_RESTRICT t, Series rs, const double* EXO
   dc.eval(V, Dl);
   // Conditioning.  The element is in information form (1 / diag) and lives in celerite's rotating
   // frame, where a complex term's state covariance Delta0 has condition number ~ 4 (b / a)^2: the
-  // J x J solves of the scans lose accuracy with  kappa = (1 + max (b/a)^2) sum(a) / min(diag).
-  // Measured at the benchmarked sizes against the sequential kernels with the flag off (tools/gp_cond_scale.py,
-  // N = 150 000, SHO terms from Q = 4 to within 1e-4 of critical damping on either side, celerite2's Matern-3/2
-  // term, signal / noise variance 4 .. 1e6): every gradient agrees to <= 3e-7 up to kappa = 5e7, 1e-6 .. 3e-6 at
-  // 5e8 .. 1e9, 3e-5 at 5e9; against the long-double dense definition at N = 500 (tests/golden/gp_hard.npz):
-  // <= 1e-6 in all seven hard regimes.  Draws with kappa > EXO_GP_COND_MAX = 1e8 -- a signal 1e8 times the
-  // white noise, diag = 0 -- are flagged here and redone by the sequential kernels.  (Round 2 drew the line at 1e5
-  // from a scan over random kernels in which other extremes dominated the disagreement, and so sent celerite2's
-  // Matern-3/2 term and every nearly critically damped SHO term to the ~50x slower sequential path.)
+  // J x J solves of the scans lose accuracy with  kappa = (1 + max (b/a)^2) sum(a) / min(diag)  -- and with the state
+  // width and the spread of the terms' time scales.  Two measurements with the flag off set the thresholds:
+  //  * the benchmarked shapes (tools/gp_cond_scale.py: N = 150 000, J = 2, SHO terms from Q = 4 to within 1e-4 of
+  //    critical damping on either side, celerite2's Matern-3/2 term, signal / noise variance 4 .. 1e6): every gradient
+  //    within 3e-7 of the sequential kernels up to kappa = 5e7; within 1e-6 of the long-double dense definition in
+  //    the seven regimes of tests/golden/gp_hard.npz;
+  //  * 9 600 draws of RANDOM kernels (tools/gp_cond_bins.py: J = 1 .. 6, decay and oscillation rates from 1e-3 to 30
+  //    per sample within one kernel, gaps): worst gradient disagreement per decade of kappa -- J <= 2: 2e-6 (1e5),
+  //    8e-6 (1e6), 5e-2 (1e7); J = 3: 1e-7, 4e-5, 2e-4; J = 4 .. 6: 1e-5 .. 7e-5 (1e5), 4e-4 .. 5e-3 (1e6); medians
+  //    1e-11 .. 1e-9 throughout: the tail is kernels whose terms differ by four decades in time scale, and it is
+  //    heavy for wide states.
+  // Hence: a draw is flagged -- redone by the sequential kernels -- above kappa = 1e7 for J <= 2 (round 2: 1e5; an SHO
+  // term within 1e-4 of critical damping, Matern-3/2, a signal 1e6 x the noise stay on this path) and above 1e5 for
+  // wider states (as in round 2).  diag = 0 is flagged whatever J.
   double asum = 0.0, ba2 = 0.0, a_first = 0.0;
 #pragma unroll
   for (int j = 0; j < J; ++j) {
@@ -639,7 +648,7 @@ EXO_HD void elem_lane(const double* EXO_RESTRICT t, Series rs, const double* EXO
       }
     }
   }
-  const double rmin = (1.0 + ba2) * asum * (1.0 / EXO_GP_COND_MAX);
+  const double rmin = (1.0 + ba2) * asum * (1.0 / (J <= 2 ? EXO_GP_COND_MAX_J2 : EXO_GP_COND_MAX));
   bool ok = true;
   BlockIn cur, nxt;
   load_block(y, dg, n_diag, n0, n1, cur);

@@ -175,7 +175,7 @@ def test_no_white_noise_falls_back(dev):
 
 def test_conditioning_score_decides_the_path(dev):
     """The element kernel's conditioning score kappa = (1 + max (b/a)^2) sum(a) / min(diag) sends a draw to the
-    sequential kernels above EXO_GP_COND_MAX = 1e8 (round 3; 1e5 in round 2): celerite2's Matern-3/2 term
+    sequential kernels above 1e7 for J <= 2 (round 3; 1e5 in round 2, and still for wider states): celerite2's Matern-3/2 term
     (b / a = w0 / eps = 58 here) and an SHO term at a signal 1e6 x the noise now stay on the time-parallel path (close
     to the sequential numbers, not identical), a signal 1e10 x the noise does not (identical numbers)."""
     import exoplanet_amd as xo
