@@ -72,13 +72,6 @@ struct Shared {
 };
 
 // mean anomaly of true anomaly f, continuous and increasing over all f
-__device__ double mean_anomaly_of(double f, double e, double se, double pe) {
-  const double k = rint(f * (0.5 / exo::kPi));
-  const double h = 0.5 * fma(-k, 2.0 * exo::kPi, f);
-  const double E = 2.0 * atan2(se * sin(h), pe * cos(h));
-  return fma(k, 2.0 * exo::kPi, E - e * sin(E));
-}
-
 // Where can the planet overlap the disk at all?  Sky-plane separation (units of R*) is
 //   rho sqrt(cos^2(w+f) + cos^2 i sin^2(w+f)) >= (a/R)(1-e) |cos(w+f)|,
 // so b < 1 + r needs |cos(w+f)| < q = (1+r) / ((a/R)(1-e)) and, for the planet to be in
@@ -109,7 +102,7 @@ __device__ double mean_anomaly_of(double f, double e, double se, double pe) {
 #define EXO_WINDOW_REFINE 1   // (0: the first bound only -- A/B builds)
 #endif
 constexpr int kSortBlock = 4096;
-constexpr int kWinLanes = 4;   // threads per record: (event, side of the conjunction)
+constexpr int kWinLanes = 8;   // threads per record: (event, side of the conjunction, contact | inner point)
 __global__ __launch_bounds__(kBlock) void transit_window_kernel(const double* __restrict__ params, int64_t n_rec,
                                                                 uint32_t flags, double* __restrict__ out,
                                                                 const double* __restrict__ t = nullptr, int64_t n_cad = 0,
@@ -129,8 +122,8 @@ __global__ __launch_bounds__(kBlock) void transit_window_kernel(const double* __
   }
   const int64_t gid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   const int64_t i = gid / kWinLanes;
-  const int sub = (int)(gid - i * kWinLanes), k = sub >> 1, sd = sub & 1;   // event (0 transit, 1 occultation), side
-  if (i >= n_rec) return;   // (whole groups of four: the shuffles below stay within a record)
+  const int sub = (int)(gid - i * kWinLanes), which = sub >> 2, k = (sub >> 1) & 1, sd = sub & 1;   // point, event (0 transit, 1 occultation), side
+  if (i >= n_rec) return;   // (whole groups of eight: the shuffles below stay within a record)
   const double* p = params + i * EXO_NPAR;
   const double e = p[EXO_P_ECC], cw = p[EXO_P_COSW], sw = p[EXO_P_SINW];
   double* o = out + kWin * i;
@@ -165,64 +158,92 @@ __global__ __launch_bounds__(kBlock) void transit_window_kernel(const double* __
     }
     return;
   }
-  // Four threads per record -- (event, side) -- each with the short serial chain of its own contact (libm's fp64
-  // trigonometry, a dozen calls one after the other: as one thread per record this kernel took 19 us of a 320 us
-  // sweep); the occultation's pair only works when the sweep has occultations.
+  // Eight threads per record -- (event, side, contact | inner point) -- each with the short serial chain of its own
+  // point.  No forward trigonometry: the conjunction's true anomaly f0 = +-pi/2 - w (+ pi) has cos f0 = +-sin w,
+  // sin f0 = +-cos w; every angle of the refinement is carried as its sine (all lie in [0, pi/2)) and composed with f0
+  // by the addition formulas; distances enter as 1 / dist = (1 + e cos f) / (a (1 - e^2)).  What is left is one atan2
+  // for w, one asin for the angle reached and one atan2 for E(f).  (One thread per record with libm's sin / cos / asin
+  // in the loop: 19 us of a 320 us sweep; four threads: 11.6 us; this form: see DESIGN.md 4.)
   const double nrev = p[EXO_P_N] * (0.5 / exo::kPi);
   const double wn = sqrt(cw * cw + sw * sw);
   const double q = (1.0 + fabs(p[EXO_P_ROR])) / (fabs(p[EXO_P_AOR]) * (1.0 - e) * wn);
   const bool bounded = (e >= 0.0 && e < 1.0) && (q < 0.999);   // else NaN everywhere / no bound: every cadence goes on
   const bool want = bounded && (k == 0 || (flags & EXO_FLAG_SECONDARY));
-  double m_edge = 0.0, m_in = 0.0;   // this side's contact and inner point, revolutions of mean anomaly
+  double m_pt = 0.0;       // this thread's point (contact or inner point of its side), revolutions of mean anomaly
   bool has_in = false;
   if (want) {
     const double se = sqrt(1.0 - e), pe = sqrt(1.0 + e);
-    const double delta0 = asin(q);
-    const double f0 = (p[EXO_P_SINI] < 0.0 ? -0.5 : 0.5) * exo::kPi - atan2(sw, cw) + k * exo::kPi;
+    const double s0 = p[EXO_P_SINI] < 0.0 ? -1.0 : 1.0, sk = k ? -1.0 : 1.0;
+    const double sinw = sw / wn, cosw = cw / wn;
+    const double cf0 = sk * s0 * sinw, sf0 = sk * s0 * cosw;
+    const double f0 = 0.5 * s0 * exo::kPi - atan2(sw, cw) + k * exo::kPi;
     const double si2 = p[EXO_P_SINI] * p[EXO_P_SINI], ci2 = p[EXO_P_COSI] * p[EXO_P_COSI];
     const double lim = 1.0 + fabs(p[EXO_P_ROR]), semi = fabs(p[EXO_P_AOR]) * (1.0 - e * e);
     const double sgn = sd ? 1.0 : -1.0;
-    // The bound above is that of an edge-on orbit at its periastron distance.  At phase angle phi from the
-    // conjunction the sky-plane separation is dist(f) sqrt(cos^2 i + sin^2 i sin^2 phi): the disks overlap only where
-    // phi <= G(phi) = asin sqrt(((1 + r)^2 / dist(f0 +- phi)^2 - cos^2 i) / sin^2 i).  Each side of the conjunction on
-    // its own, from the upper bound ub = delta0, never below the contact:
-    //   dist falling away from the conjunction (G rising): ub <- G(ub);
-    //   dist rising (G falling): lb = G(ub) is a lower bound of the contact, so G(lb) an upper one;
-    //   an apsis inside the half-window: G at the smallest distance in it.
-    // Three rounds leave the window within ~0.1 % of the contacts (C2: it was 6.8 % wider than them); a planet that
-    // never reaches the disk (b > 1 + r) keeps only the safety margin.
-    double ub = delta0;
-    if (EXO_WINDOW_REFINE && si2 > 1e-12) {
-      auto ang = [&](double dist) {
-        const double S = (lim * lim / (dist * dist) - ci2) / si2;
-        return S <= 0.0 ? 0.0 : (S < 1.0 ? asin(sqrt(S)) : delta0);   // (NaN: no information)
-      };
-      auto dist_at = [&](double f) { return semi / (1.0 + e * cos(f)); };
-      const double d_c = dist_at(f0);
-      for (int it = 0; it < 3; ++it) {
-        const double f_end = f0 + sgn * ub;
-        const double lo_f = fmin(f0, f_end), hi_f = fmax(f0, f_end);
-        const bool apsis = floor(hi_f * (1.0 / exo::kPi)) >= ceil(lo_f * (1.0 / exo::kPi));
-        const bool peri = floor(hi_f * (0.5 / exo::kPi)) >= ceil(lo_f * (0.5 / exo::kPi));
-        const double d_end = dist_at(f_end);
-        if (!apsis && d_end >= d_c) {
-          const double lb = fmin(ang(d_end), ub);
-          ub = fmin(ub, ang(dist_at(f0 + sgn * lb)));
-        } else {
-          ub = fmin(ub, ang(peri ? semi / (1.0 + e) : fmin(d_end, d_c)));
+    double sphi;   // sine of the angle from the conjunction to this thread's point
+    if (which == 0) {
+      // The bound above is that of an edge-on orbit at its periastron distance.  At phase angle phi from the
+      // conjunction the sky-plane separation is dist(f) sqrt(cos^2 i + sin^2 i sin^2 phi): the disks overlap only where
+      // phi <= G(phi) = asin sqrt(((1 + r)^2 / dist(f0 +- phi)^2 - cos^2 i) / sin^2 i).  Each side of the conjunction on
+      // its own, from the upper bound ub = asin q, never below the contact:
+      //   dist falling away from the conjunction (G rising): ub <- G(ub);
+      //   dist rising (G falling): lb = G(ub) is a lower bound of the contact, so G(lb) an upper one;
+      //   an apsis inside the half-window: G at the smallest distance in it.
+      // Three rounds leave the window within ~0.1 % of the contacts (C2: it was 6.8 % wider than them); a planet that
+      // never reaches the disk (b > 1 + r) keeps only the safety margin.
+      double su = q;
+      if (EXO_WINDOW_REFINE && si2 > 1e-12) {
+        const double isemi = 1.0 / semi, isi2 = 1.0 / si2, lim2 = lim * lim;
+        auto sin_ang = [&](double u) {   // u = 1 / dist
+          const double S = (lim2 * u * u - ci2) * isi2;
+          return S <= 0.0 ? 0.0 : (S < 1.0 ? sqrt(S) : q);   // (NaN: no information)
+        };
+        auto u_at = [&](double sa) {     // 1 / dist at f0 + sgn * asin(sa)
+          return fma(e, cf0 * sqrt(1.0 - sa * sa) - sgn * sf0 * sa, 1.0) * isemi;
+        };
+        const double u_c = fma(e, cf0, 1.0) * isemi;
+        for (int it = 0; it < 3; ++it) {
+          // an apsis (f = m pi) in [f0, f_end] <=> sin f changes sign over it (the interval is shorter than pi / 2);
+          // it is the periastron <=> cos f0 > 0
+          const double s_end = sf0 * sqrt(1.0 - su * su) + sgn * cf0 * su;
+          const bool apsis = sf0 * s_end <= 0.0;
+          const double u_end = u_at(su);
+          if (!apsis && u_end <= u_c) {
+            const double lb = fmin(sin_ang(u_end), su);
+            su = fmin(su, sin_ang(u_at(lb)));
+          } else {
+            su = fmin(su, sin_ang((apsis && cf0 > 0.0) ? (1.0 + e) * isemi : fmax(u_end, u_c)));
+          }
         }
       }
+      sphi = su;
+    } else {
+      // inner part: |sky-plane x| < sqrt((1-r)^2 - b^2) at the conjunction's star-planet distance
+      const double r = fabs(p[EXO_P_ROR]);
+      const double dist = fabs(p[EXO_P_AOR]) * (1.0 - e * e) / (1.0 + (k ? -e : e) * sinw);
+      const double bk = dist * fabs(p[EXO_P_COSI]);
+      const double in2 = (1.0 - r) * (1.0 - r) - bk * bk;
+      has_in = r < 1.0 && in2 > 0.0 && dist > 0.0;
+      sphi = has_in ? fmin(0.95 * sqrt(in2) / dist, 1.0) : 0.0;
     }
-    m_edge = mean_anomaly_of(f0 + sgn * (ub * (1.0 + 1e-6) + 1e-6), e, se, pe) * (0.5 / exo::kPi);
-    // inner part: |sky-plane x| < sqrt((1-r)^2 - b^2) at the conjunction's star-planet distance
-    const double sinw = sw / wn, r = fabs(p[EXO_P_ROR]);
-    const double dist = fabs(p[EXO_P_AOR]) * (1.0 - e * e) / (1.0 + (k ? -e : e) * sinw);
-    const double bk = dist * fabs(p[EXO_P_COSI]);
-    const double in2 = (1.0 - r) * (1.0 - r) - bk * bk;
-    has_in = r < 1.0 && in2 > 0.0 && dist > 0.0;
-    if (has_in) m_in = mean_anomaly_of(f0 + sgn * asin(fmin(0.95 * sqrt(in2) / dist, 1.0)), e, se, pe) * (0.5 / exo::kPi);
+    // the point's true anomaly f = f0 + sgn (phi (1 + 1e-6) + 1e-6) for a contact, f0 + sgn phi for an inner point:
+    // its angle for the revolution count, its sine and cosine by the addition formulas (the margin: a rotation by
+    // delta <= 2.6e-6, second order)
+    const double phi = asin(sphi), cphi = sqrt(fmax(1.0 - sphi * sphi, 0.0));
+    const double delta = which == 0 ? fma(phi, 1e-6, 1e-6) : 0.0;
+    const double c1 = cf0 * cphi - sgn * sf0 * sphi, s1 = sf0 * cphi + sgn * cf0 * sphi;
+    const double hd = 1.0 - 0.5 * delta * delta;
+    const double cf = c1 * hd - sgn * delta * s1, sf = s1 * hd + sgn * delta * c1;
+    // E(f) = f - 2 atan(beta sin f / (1 + beta cos f)), beta = e / (1 + sqrt(1 - e^2)): continuous in f, no wrap
+    const double rt = se * pe, beta = e / (1.0 + rt);
+    const double E = (f0 + sgn * (phi + delta)) - 2.0 * atan2(beta * sf, fma(beta, cf, 1.0));
+    m_pt = (E - e * (rt * sf / fma(e, cf, 1.0))) * (0.5 / exo::kPi);
   }
-  // the other side's numbers (lanes 4j .. 4j + 3 hold one record: no record straddles a wave)
+  // the record's other numbers (lanes 8j .. 8j + 7 hold one record: no record straddles a wave)
+  const double m_other = __shfl_xor(m_pt, 4, 64);    // (every shuffle outside the branches: all eight lanes take part)
+  const int in_other = __shfl_xor((int)has_in, 4, 64);
+  const double m_edge = which ? m_other : m_pt, m_in = which ? m_pt : m_other;
+  has_in = has_in || in_other != 0;
   const double o_edge = __shfl_xor(m_edge, 1, 64), o_in = __shfl_xor(m_in, 1, 64);
   const double lo = sd ? o_edge : m_edge, hi = sd ? m_edge : o_edge;
   const double mid = 0.5 * (lo + hi);
@@ -238,7 +259,7 @@ __global__ __launch_bounds__(kBlock) void transit_window_kernel(const double* __
     const double dmax = fabs(p[EXO_P_AOR]) * (1.0 + e) / (fabs(p[EXO_P_CLIGHT]) - vmax);
     wd = (dmax >= 0.0 ? dmax : __builtin_inf()) * fabs(nrev) * 1.05;   // (NaN or v >= c: no window)
   }
-  if (sd != 0) return;
+  if (sd != 0 || which != 0) return;
   if (k == 0) {
     o[0] = nrev;
     o[1] = bounded ? -fma(p[EXO_P_TP], nrev, mid) : -p[EXO_P_TP] * nrev;
@@ -1861,39 +1882,67 @@ __device__ __forceinline__ void finish_draw(
     }
   }
   if (!flux || !vals) return;
-  // a thread per value: value and cadence arrays are read contiguously, four loads in flight per thread
+  // a thread per value: value and cadence arrays are read contiguously, four loads in flight per thread.  Summed flux of
+  // several planets: planet 0 stores, every later planet ADDS with the hardware's fp64 atomic (no load of the target:
+  // read-modify-write in the thread made each planet a load and a store round trip, C4 at 64 draws 15.8 us) behind a
+  // block barrier -- planets in order, so the sums stay bit-reproducible (a planet's transits and occultations never
+  // share a cadence) -- and the next batch of values is loaded before the current one is written.
   const bool per_planet = flags & EXO_FLAG_PER_PLANET;
-  for (int p = 0; p < n_planet; ++p) {
-    const int64_t vbase = (draw * n_planet + p) * n_cad;
+  const int nthr = (int)blockDim.x;
+  auto total_of = [&](int p) {
     int total = 0;
     for (int ev = 0; ev < n_ev; ++ev) {
       const int64_t list = (draw * n_planet + p) * n_ev + ev;
       total += rl.pre_all[list * (rl.r_max + 1) + rl.nrun[list]];
     }
-    const double* src = vals + vbase;
-    const int32_t* cad = vcad + vbase;
-    const int nthr = (int)blockDim.x;
-    for (int e0 = threadIdx.x; e0 < total; e0 += 4 * nthr) {
-      double v[4];
-      int i[4];
+    return total;
+  };
+  auto load = [&](int p, int cb, int total, double* v, int* i) {
+    const int64_t vbase = (draw * n_planet + p) * n_cad;
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int e = e0 + u * nthr;
-        v[u] = e < total ? src[e] : 0.0;
-        i[u] = e < total ? cad[e] : -1;
-      }
+    for (int u = 0; u < 4; ++u) {
+      const int e = cb + (int)threadIdx.x + u * nthr;
+      v[u] = e < total ? vals[vbase + e] : 0.0;
+      i[u] = e < total ? vcad[vbase + e] : -1;
+    }
+  };
+  // batches (planet, first value) in order; `advance` steps to the next non-empty one
+  int pl = 0, cb = -4 * nthr, total = total_of(0);
+  auto advance = [&](int& p, int& c, int& tot) {
+    c += 4 * nthr;
+    while (p < n_planet && c >= tot) {
+      ++p; c = 0;
+      tot = p < n_planet ? total_of(p) : 0;
+    }
+  };
+  advance(pl, cb, total);
+  if (pl >= n_planet) return;
+  double v[4];
+  int i[4];
+  load(pl, cb, total, v, i);
+  for (;;) {
+    int np = pl, ncb = cb, ntotal = total;
+    advance(np, ncb, ntotal);
+    const bool more = np < n_planet;
+    double nv[4] = {0.0, 0.0, 0.0, 0.0};
+    int ni[4] = {-1, -1, -1, -1};
+    if (more) load(np, ncb, ntotal, nv, ni);
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        if (i[u] < 0) continue;
-        if (per_planet) {
-          flux[(draw * n_cad + i[u]) * n_planet + p] = v[u];
-        } else {
-          double* dst = flux + draw * n_cad + i[u];
-          *dst = (p == 0) ? v[u] : (*dst + v[u]);   // (a planet's transits and occultations never share a cadence)
-        }
+    for (int u = 0; u < 4; ++u) {
+      if (i[u] < 0) continue;
+      if (per_planet) {
+        flux[(draw * n_cad + i[u]) * n_planet + pl] = v[u];
+      } else if (pl == 0) {
+        flux[draw * n_cad + i[u]] = v[u];
+      } else {
+        unsafeAtomicAdd(flux + draw * n_cad + i[u], v[u]);
       }
     }
-    if (!per_planet && p + 1 < n_planet) __syncthreads();   // planets in order: bit-reproducible sums
+    if (!more) break;
+    if (!per_planet && np != pl) __syncthreads();   // planets in order
+    pl = np; cb = ncb; total = ntotal;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { v[u] = nv[u]; i[u] = ni[u]; }
   }
 }
 
