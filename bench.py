@@ -214,6 +214,9 @@ def workload_c2(xo, ops, dev, D, rank=0, events=None):
                     "gradients: five launches (six below 512 draws)")
 
 
+# the light curve that is the mean of a GP travels between the two ops as a [cadence][draw] array (get_light_curve's
+# cadence_major: same values, the layout the celerite kernels read with contiguous accesses); EXO_BENCH_ROW_MAJOR=1: A/B
+GP_MEAN_CADENCE_MAJOR = os.environ.get("EXO_BENCH_ROW_MAJOR", "0") != "1"
 C3_HYPER = (1e-3, 5.0, 0.7071)       # SHOTerm(sigma, rho, Q) of SURVEY.md 8d C3
 
 
@@ -230,7 +233,8 @@ def workload_c3(xo, ops, dev, D, rank=0):
     def fn(*vals):
         Lv = dict(zip(names, vals))
         orbit = xo.KeplerianOrbit(period=Lv["period"], t0=Lv["t0"], b=Lv["b"], ecc=Lv["ecc"], omega=Lv["omega"])
-        lc = xo.LimbDarkLightCurve(Lv["u1"], Lv["u2"]).get_light_curve(orbit=orbit, r=Lv["r"], t=t, total=True)
+        lc = xo.LimbDarkLightCurve(Lv["u1"], Lv["u2"]).get_light_curve(orbit=orbit, r=Lv["r"], t=t, total=True,
+                                                                      cadence_major=GP_MEAN_CADENCE_MAJOR)
         gp = xo.gp.GaussianProcess(xo.gp.terms.SHOTerm(sigma=Lv["sigma"], rho=Lv["rho"], Q=Lv["Q"]), t=t, yerr=5e-4, mean=lc)
         ll = gp.log_likelihood(yobs)
         return (ll.detach(),) + torch.autograd.grad(ll.sum(), vals)
@@ -301,7 +305,7 @@ def workload_c5(xo, ops, dev, D, rank=0):
         Lv = dict(zip(names, vals))
         orbit = xo.KeplerianOrbit(period=Lv["period"], t0=Lv["t0"], b=Lv["b"], ecc=Lv["ecc"], omega=Lv["omega"])
         lc = xo.SecondaryEclipseLightCurve(C5_LD[0], C5_LD[1], Lv["sbr"]).get_light_curve(
-            orbit=orbit, r=Lv["r"], t=t, texp=texp, oversample=7, total=True)
+            orbit=orbit, r=Lv["r"], t=t, texp=texp, oversample=7, total=True, cadence_major=GP_MEAN_CADENCE_MAJOR)
         kern = (T.SHOTerm(sigma=Lv["s1"], rho=C5_TERMS[0][1] * ones, Q=C5_TERMS[0][2] * ones)
                 + T.SHOTerm(sigma=Lv["s2"], rho=C5_TERMS[1][1] * ones, Q=C5_TERMS[1][2] * ones)
                 + T.SHOTerm(sigma=Lv["s3"], rho=C5_TERMS[2][1] * ones, Q=C5_TERMS[2][2] * ones))

@@ -77,6 +77,16 @@ _SIGNATURES = {
         [_c_dp, _c_dp, _c_dp, _c_dp, _i64, _i64, _c_dp, _i32, _c_dp, _i32, _c_dp, _i64, _c_dp, _c_dp, _i64, _i32,
          _c_dp, _c_dp, _c_dp, _c_dp, _c_dp, _c_dp],
     ),
+    # the same pair with model / gmodel CADENCE-MAJOR ([n][n_draw])
+    "exo_celerite_loglike_obs_fwd_cm_f64": (
+        ctypes.c_int,
+        [_c_dp, _c_dp, _c_dp, _c_dp, _i64, _i64, _c_dp, _i32, _c_dp, _i32, _c_dp, _i64, _c_dp, _c_dp, _i64, _i32, _c_dp],
+    ),
+    "exo_celerite_loglike_obs_vjp_cm_f64": (
+        ctypes.c_int,
+        [_c_dp, _c_dp, _c_dp, _c_dp, _i64, _i64, _c_dp, _i32, _c_dp, _i32, _c_dp, _i64, _c_dp, _c_dp, _i64, _i32,
+         _c_dp, _c_dp, _c_dp, _c_dp, _c_dp, _c_dp],
+    ),
     "exo_celerite_dot_tril_f64": (ctypes.c_int, [_c_dp, _c_dp, _i64, _i64, _c_dp, _i32, _c_dp, _i32, _c_dp, _i64, _c_dp, _c_dp,
                                                  _c_dp]),
     "exo_celerite_predict_f64": (ctypes.c_int, [_c_dp, _i64, _c_dp, _c_dp, _i32, _c_dp, _i32, _c_dp, _i64, _c_dp, _i64, _c_dp,

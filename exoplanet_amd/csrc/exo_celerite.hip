@@ -224,7 +224,7 @@ __global__ __launch_bounds__(kWave) void celerite_fwd_kernel(
   // a_n = diag_n + sum of the a coefficients (first index of each term)
   const double asum = group_sum<G>((k.live && !k.odd) ? k.a : 0.0);
   const StateIdx six{n, n_draw, J};
-  const SeriesRow y{rs.y + draw * n, rs.obs};
+  const SeriesRow y(rs, draw, n);
   const double* __restrict__ dg = diag + (n_diag == 1 ? 0 : draw * n);
 
   double Srow[J], Wall[J], Uall[J], Pall[J];
@@ -360,7 +360,7 @@ __global__ __launch_bounds__(kWave) void celerite_vjp_kernel(
     int64_t n_draw, const double* __restrict__ gloglike, const double* __restrict__ state,
     double* __restrict__ gresid, double* __restrict__ gdiag, double* __restrict__ gdiag_sum,
     double* __restrict__ gcoef_real, double* __restrict__ gcoef_complex, const double* __restrict__ only_flagged,
-    double gsign) {
+    double gsign, int64_t gcm) {   // gcm: Series::cm of the series this is the cotangent of
   constexpr int G = Group<J>::G;
   const int j = threadIdx.x & (G - 1);
   const int64_t lane_draw = ((int64_t)blockIdx.x * kWave + threadIdx.x) / G;
@@ -457,7 +457,7 @@ __global__ __launch_bounds__(kWave) void celerite_vjp_kernel(
     const double wdot = group_sum<G>(Wb * W_n);
     const double dbar = db + gL * (0.5 * z_n * z_n * id * id - 0.5 * id) - wdot * id;
     if (lead) {
-      gresid[draw * n + i] = gsign * zbar;
+      gresid[gcm ? i * gcm + draw : draw * n + i] = gsign * zbar;
       if (gdiag) gdiag[draw * n + i] = dbar;
     }
     gasum += dbar;
@@ -532,7 +532,7 @@ __global__ __launch_bounds__(kWave) void celerite_vjp_kernel(
     const double wdot = group_sum<G>(Wb * W_n);
     const double dbar = db + gL * (0.5 * z_n * z_n * id * id - 0.5 * id) - wdot * id;
     if (lead) {
-      gresid[draw * n] = gsign * zbar;
+      gresid[gcm ? draw : draw * n] = gsign * zbar;
       if (gdiag) gdiag[draw * n] = dbar;
     }
     gasum += dbar;
@@ -683,7 +683,7 @@ __global__ __launch_bounds__(kWave) void celerite_elem_lg_kernel(
   const bool live = k.live;
   const ChunkWs ws = chunk_ws(n, n_draw, J, cg);
   const LaneDelta ld(k);
-  const SeriesRow y{rs.y + draw * n, rs.obs};
+  const SeriesRow y(rs, draw, n);
   const double* __restrict__ dg = diag + (n_diag == 1 ? 0 : draw * n);
   // conditioning score (see celerite_elem_kernel)
   const double asum = group_sum<G>((live && !k.odd) ? fabs(k.a) : 0.0);
@@ -783,7 +783,7 @@ __global__ __launch_bounds__(kWave) void celerite_chunk_fwd_kernel(
   const double asum = group_sum<G>((k.live && !k.odd) ? k.a : 0.0);
   const StateIdx six{n, n_draw, J};
   const ChunkWs ws = chunk_ws(n, n_draw, J, cg);
-  const SeriesRow y{rs.y + draw * n, rs.obs};
+  const SeriesRow y(rs, draw, n);
   const double* __restrict__ dg = diag + (n_diag == 1 ? 0 : draw * n);
   const int jj = k.live ? j : 0;
 
@@ -869,7 +869,7 @@ template <int J>
 __global__ __launch_bounds__(kWave) void celerite_chunk_vjp_kernel(
     const double* __restrict__ t, int64_t n, Coefs cf, int64_t n_draw, const double* __restrict__ gloglike,
     double* __restrict__ state, ChunkGeom cg, double* __restrict__ gresid, double* __restrict__ gdiag,
-    double gsign) {
+    double gsign, int64_t gcm) {
   constexpr int G = Group<J>::G;
   const int j = threadIdx.x & (G - 1);
   const int64_t lane_draw = ((int64_t)blockIdx.x * kWave + threadIdx.x) / G;
@@ -966,6 +966,7 @@ __global__ __launch_bounds__(kWave) void celerite_chunk_vjp_kernel(
     // different 64-B line for every draw of the wave.  The G lanes of a draw (zbar, dbar are the
     // same on all of them) each keep 8 / G consecutive cadences of an aligned block of 8 and the
     // block is written when it is complete (measured: 2.9x write amplification without this).
+    if (gcm && live_draw && j == 0) gresid[i * gcm + draw] = gsign * zbar;   // cadence-major: the wave's draws are neighbours
     {
       const int owner = (int)(i & 7) / kPer, slot = (int)(i & 7) % kPer;
       if (live_draw && j == owner) {
@@ -979,7 +980,7 @@ __global__ __launch_bounds__(kWave) void celerite_chunk_vjp_kernel(
 #pragma unroll
         for (int q = 0; q < kPer; ++q)
           if ((have >> q) & 1u) {
-            gresid[at + q] = gsign * buf_r[q];
+            if (!gcm) gresid[at + q] = gsign * buf_r[q];
             if (gdiag) gdiag[at + q] = buf_d[q];
           }
         have = 0u;
@@ -1402,7 +1403,8 @@ __global__ __launch_bounds__(kWave) void celerite_elem_mixed_kernel(const double
     if (nr == -1) elem_lane<2, -1>(t, rs, diag, n_diag, n, cf, n_draw, state, cg, draw, c, flag_at);
   }
 }
-__global__ __launch_bounds__(kWave) void celerite_chunk1_fwd_mixed_kernel(const double* __restrict__ t, Series rs,
+// (four waves per SIMD asked for: the three inlined layouts sit at 129 registers otherwise, and the plan offers four)
+__global__ __launch_bounds__(kWave, 4) void celerite_chunk1_fwd_mixed_kernel(const double* __restrict__ t, Series rs,
                                                                           const double* __restrict__ diag, int64_t n_diag,
                                                                           int64_t n, Coefs cf, int64_t n_draw,
                                                                           double* __restrict__ state, ChunkGeom cg) {
@@ -1606,7 +1608,7 @@ static int celerite_vjp(const double* t, Series resid, const double* diag, int64
                                         n_diag, n, cf, n_draw, gloglike, wstate, cg, gresid, gdiag, gsign))
     } else {
       EXO_GP_DISPATCH(J, hipLaunchKernelGGL((celerite_chunk_vjp_kernel<JJ>), cgrid, block, 0, st, t, n, cf, n_draw,
-                                            gloglike, wstate, cg, gresid, gdiag, gsign))
+                                            gloglike, wstate, cg, gresid, gdiag, gsign, resid.cm))
     }
     hipLaunchKernelGGL(celerite_chunk_gsum_kernel, dim3((unsigned)n_draw, (unsigned)(4 * J + 1)), block, 0, st, n, n_draw,
                        J, wstate, cg);
@@ -1617,7 +1619,7 @@ static int celerite_vjp(const double* t, Series resid, const double* diag, int64
   }
   EXO_GP_DISPATCH(J, hipLaunchKernelGGL((celerite_vjp_kernel<JJ>), grid, block, 0, st, t, diag, n_diag, n, cf, n_draw,
                                         gloglike, state, gresid, gdiag, gdiag_sum, gcoef_real, gcoef_complex,
-                                        only_flagged, gsign))
+                                        only_flagged, gsign, resid.cm))
   return launch_status();
 }
 
@@ -1625,7 +1627,7 @@ int exo_celerite_loglike_fwd_f64(const double* t, const double* resid, const dou
                                  int64_t n, const double* coef_real, int32_t n_real, const double* coef_complex,
                                  int32_t n_complex, const int32_t* pair_kind, int64_t n_draw, double* loglike,
                                  double* state, int64_t state_doubles, int32_t n_chunks, void* stream) {
-  return celerite_fwd(t, Series{resid, nullptr}, diag, n_diag, n, Coefs{coef_real, coef_complex, pair_kind, n_real, n_complex},
+  return celerite_fwd(t, Series{resid, nullptr, 0}, diag, n_diag, n, Coefs{coef_real, coef_complex, pair_kind, n_real, n_complex},
                       n_draw, loglike, state, state_doubles, n_chunks, stream);
 }
 
@@ -1635,7 +1637,7 @@ int exo_celerite_loglike_vjp_f64(const double* t, const double* resid, const dou
                                  const double* state, int64_t state_doubles, int32_t n_chunks, double* gresid,
                                  double* gdiag, double* gdiag_sum, double* gcoef_real, double* gcoef_complex,
                                  void* stream) {
-  return celerite_vjp(t, Series{resid, nullptr}, diag, n_diag, n, Coefs{coef_real, coef_complex, pair_kind, n_real, n_complex},
+  return celerite_vjp(t, Series{resid, nullptr, 0}, diag, n_diag, n, Coefs{coef_real, coef_complex, pair_kind, n_real, n_complex},
                       n_draw, gloglike, state, state_doubles, n_chunks, gresid, 1.0, gdiag, gdiag_sum, gcoef_real,
                       gcoef_complex, stream);
 }
@@ -1646,7 +1648,7 @@ int exo_celerite_loglike_obs_fwd_f64(const double* t, const double* obs, const d
                                      int64_t n_draw, double* loglike, double* state, int64_t state_doubles,
                                      int32_t n_chunks, void* stream) {
   if (n_draw > 0 && !obs) return EXO_ERR_INVALID_ARGUMENT;
-  return celerite_fwd(t, Series{model, obs}, diag, n_diag, n, Coefs{coef_real, coef_complex, pair_kind, n_real, n_complex},
+  return celerite_fwd(t, Series{model, obs, 0}, diag, n_diag, n, Coefs{coef_real, coef_complex, pair_kind, n_real, n_complex},
                       n_draw, loglike, state, state_doubles, n_chunks, stream);
 }
 
@@ -1657,9 +1659,32 @@ int exo_celerite_loglike_obs_vjp_f64(const double* t, const double* obs, const d
                                      int64_t state_doubles, int32_t n_chunks, double* gmodel, double* gdiag,
                                      double* gdiag_sum, double* gcoef_real, double* gcoef_complex, void* stream) {
   if (n_draw > 0 && !obs) return EXO_ERR_INVALID_ARGUMENT;
-  return celerite_vjp(t, Series{model, obs}, diag, n_diag, n, Coefs{coef_real, coef_complex, pair_kind, n_real, n_complex},
+  return celerite_vjp(t, Series{model, obs, 0}, diag, n_diag, n, Coefs{coef_real, coef_complex, pair_kind, n_real, n_complex},
                       n_draw, gloglike, state, state_doubles, n_chunks, gmodel, -1.0, gdiag, gdiag_sum, gcoef_real,
                       gcoef_complex, stream);
+}
+
+int exo_celerite_loglike_obs_fwd_cm_f64(const double* t, const double* obs, const double* model_cm, const double* diag,
+                                        int64_t n_diag, int64_t n, const double* coef_real, int32_t n_real,
+                                        const double* coef_complex, int32_t n_complex, const int32_t* pair_kind,
+                                        int64_t n_draw, double* loglike, double* state, int64_t state_doubles,
+                                        int32_t n_chunks, void* stream) {
+  if (n_draw > 0 && !obs) return EXO_ERR_INVALID_ARGUMENT;
+  return celerite_fwd(t, Series{model_cm, obs, n_draw}, diag, n_diag, n,
+                      Coefs{coef_real, coef_complex, pair_kind, n_real, n_complex}, n_draw, loglike, state, state_doubles,
+                      n_chunks, stream);
+}
+
+int exo_celerite_loglike_obs_vjp_cm_f64(const double* t, const double* obs, const double* model_cm, const double* diag,
+                                        int64_t n_diag, int64_t n, const double* coef_real, int32_t n_real,
+                                        const double* coef_complex, int32_t n_complex, const int32_t* pair_kind,
+                                        int64_t n_draw, const double* gloglike, const double* state,
+                                        int64_t state_doubles, int32_t n_chunks, double* gmodel_cm, double* gdiag,
+                                        double* gdiag_sum, double* gcoef_real, double* gcoef_complex, void* stream) {
+  if (n_draw > 0 && !obs) return EXO_ERR_INVALID_ARGUMENT;
+  return celerite_vjp(t, Series{model_cm, obs, n_draw}, diag, n_diag, n,
+                      Coefs{coef_real, coef_complex, pair_kind, n_real, n_complex}, n_draw, gloglike, state, state_doubles,
+                      n_chunks, gmodel_cm, -1.0, gdiag, gdiag_sum, gcoef_real, gcoef_complex, stream);
 }
 
 int exo_celerite_dot_tril_f64(const double* t, const double* diag, int64_t n_diag, int64_t n, const double* coef_real,

@@ -112,6 +112,8 @@ EXO_HD void lane_uv(const LaneCoef& k, double t, double* U, double* V, double* c
 struct Series {
   const double* y;
   const double* obs;
+  int64_t cm;   // 0: y is [draw][cadence]; else CADENCE-MAJOR, [cadence][cm] with cm = n_draw (the reverse pass writes the
+                // cotangent of the series in the same layout)
 };
 // A lane owns one ROW of a [draw][cadence] array: consecutive lanes are n cadences apart, so every
 // load instruction of a wave touches 64 different cache lines, and cadence-by-cadence 8-byte
@@ -119,6 +121,9 @@ struct Series {
 // measured 1.6 ms for the forward chunk kernel of C3, 9.8 GB through L2 for 1.2 GB of data).  The
 // chunk kernels therefore move a row kCkptB = 4 cadences at a time, as two 16-byte accesses per
 // lane whenever the row is 16-byte aligned there.
+// CADENCE-MAJOR arrays ([cadence][draw]: what the light-curve sweep writes under EXO_FLAG_CADENCE_MAJOR) need none of
+// that: the lanes of a wave are consecutive draws, every access of a wave is 512 contiguous bytes (C3: the forward
+// chunk kernel 0.86 -> 0.64 ms, the reverse one 2.02 -> 1.54 ms against the 16-byte row accesses).
 struct alignas(16) D2 {
   double x, y;
 };
@@ -142,16 +147,42 @@ EXO_HD void row_store4(double* EXO_RESTRICT row, int64_t i, int len, const doubl
   }
 }
 
+// one draw's series: element i at y[i * stride] (stride 1: a row; n_draw: a column of a cadence-major array)
 struct SeriesRow {
   const double* EXO_RESTRICT y;
   const double* EXO_RESTRICT obs;
-  EXO_HD double operator[](int64_t i) const { return obs ? obs[i] - y[i] : y[i]; }
+  int64_t stride;
+  EXO_HD SeriesRow(const Series& rs, int64_t draw, int64_t n)
+      : y(rs.y + (rs.cm ? draw : draw * n)), obs(rs.obs), stride(rs.cm ? rs.cm : 1) {}
+  EXO_HD double operator[](int64_t i) const { return obs ? obs[i] - y[i * stride] : y[i * stride]; }
   // cadences i .. i + 3 (the first `len` of them exist)
   EXO_HD void load4(int64_t i, int len, double* v) const {
-    row_load4(y, i, len, v);
+    if (stride == 1) {
+      row_load4(y, i, len, v);
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v[q] = q < len ? y[(i + q) * stride] : 0.0;
+    }
     if (obs) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) v[q] = (q < len ? obs[i + q] : 0.0) - v[q];
+    }
+  }
+};
+// one draw's cotangent of the series, in the layout of the series
+struct GradRow {
+  double* EXO_RESTRICT g;
+  int64_t stride;
+  EXO_HD GradRow(double* gresid, const Series& rs, int64_t draw, int64_t n)
+      : g(gresid + (rs.cm ? draw : draw * n)), stride(rs.cm ? rs.cm : 1) {}
+  EXO_HD void store(int64_t i, double v) const { g[i * stride] = v; }
+  EXO_HD void store4(int64_t i, int len, const double* v) const {
+    if (stride == 1) {
+      row_store4(g, i, len, v);
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (q < len) g[(i + q) * stride] = v[q];
     }
   }
 };
@@ -599,7 +630,7 @@ EXO_HD void elem_lane(const double* EXO_RESTRICT t, Series rs, const double* EXO
   dc.init(cf, draw);
   DrawCoef<J, NR> co;
   co.init(cf, draw);
-  const SeriesRow y{rs.y + draw * n, rs.obs};
+  const SeriesRow y(rs, draw, n);
   const double* EXO_RESTRICT dg = diag + (n_diag == 1 ? 0 : draw * n);
   double A[J][J], b[J], eta[J];
   Sym<J> Cm, Jm, Dl;
@@ -1452,7 +1483,7 @@ EXO_HD void chunk1_fwd_lane(const double* EXO_RESTRICT t, Series rs, const doubl
   DrawCoef<J, NR> co;
   co.init(cf, draw);
   const double asum = co.asum();
-  const SeriesRow y{rs.y + draw * n, rs.obs};
+  const SeriesRow y(rs, draw, n);
   const double* EXO_RESTRICT dg = diag + (n_diag == 1 ? 0 : draw * n);
   Fwd<J> f;
 #pragma unroll
@@ -1635,7 +1666,7 @@ EXO_HD void chunk1_vjp_lane(const double* EXO_RESTRICT t, Series rs, const doubl
   DrawCoef<J, NR> co;
   co.init(cf, draw);
   const double asum = co.asum();
-  const SeriesRow y{rs.y + draw * n, rs.obs};
+  const SeriesRow y(rs, draw, n);
   const double* EXO_RESTRICT dg = diag + (n_diag == 1 ? 0 : draw * n);
   const double gL = gloglike[draw];
   Rev<J, NR> r;
@@ -1767,10 +1798,11 @@ EXO_HD void chunk1_vjp_lane(const double* EXO_RESTRICT t, Series rs, const doubl
       }
     }
     pend = true;   // the step from the previous block's last cadence into b0
-    // gresid / gdiag are [draw][cadence]: the block's cadences are consecutive doubles of one row
+    // gresid / gdiag are [draw][cadence]: the block's cadences are consecutive doubles of one row (gresid cadence-major
+    // with the series: GradRow)
 #pragma unroll
     for (int q = 0; q < kCkptB; ++q) zbar[q] *= gsign;
-    row_store4(gresid + draw * n, b0, len, zbar);
+    GradRow(gresid, rs, draw, n).store4(b0, len, zbar);
     if (gdiag) row_store4(gdiag + draw * n, b0, len, dbar);
     cur = nxt;
 #pragma unroll
@@ -1909,7 +1941,7 @@ EXO_HD void chunkp_vjp_lane(const double* EXO_RESTRICT t, Series rs, const doubl
   DrawCoef<J, NR> co;
   co.init(cf, draw);
   const double asum = co.asum();
-  const SeriesRow y{rs.y + draw * n, rs.obs};
+  const SeriesRow y(rs, draw, n);
   const double* EXO_RESTRICT dg = diag + (n_diag == 1 ? 0 : draw * n);
   const double gL = gloglike[draw];
   RevP<J, NR> r;
@@ -2059,10 +2091,11 @@ EXO_HD void chunkp_vjp_lane(const double* EXO_RESTRICT t, Series rs, const doubl
       }
     }
     pend = true;   // the step from the previous block's last cadence into b0
-    // gresid / gdiag are [draw][cadence]: the block's cadences are consecutive doubles of one row
+    // gresid / gdiag are [draw][cadence]: the block's cadences are consecutive doubles of one row (gresid cadence-major
+    // with the series: GradRow)
 #pragma unroll
     for (int q = 0; q < kCkptB; ++q) zbar[q] *= gsign;
-    row_store4(gresid + draw * n, b0, len, zbar);
+    GradRow(gresid, rs, draw, n).store4(b0, len, zbar);
     if (gdiag) row_store4(gdiag + draw * n, b0, len, dbar);
     cur = nxt;
     if (kAhead) {

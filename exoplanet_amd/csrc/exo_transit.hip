@@ -1825,7 +1825,8 @@ __device__ __forceinline__ void finish_draw(
     int64_t draw, const double* partial, int nblk, int n_planet, bool secondary, double* __restrict__ gparams,
     double* __restrict__ gld, double* __restrict__ flux_dot, int64_t n_cad, uint32_t flags, int n_ev, const RunLists& rl,
     const double* vals, const int32_t* vcad, double* flux,
-    const double* __restrict__ chi2_part, int n_chi2_part, double* __restrict__ chi2_out, const Ttv& ttv) {
+    const double* __restrict__ chi2_part, int n_chi2_part, double* __restrict__ chi2_out, const Ttv& ttv,
+    int64_t cm_draws = 0) {   // cm_draws: 0, or n_draw -- the summed flux is cadence-major, [n_cad][n_draw]
   if (ttv.gshift) {
     // timing tables, lists whose runs carry their bins: the runs' sums to their bins, in run order (the bins of a
     // list's runs ascend); the samples of any other list added to gshift themselves
@@ -1889,14 +1890,18 @@ __device__ __forceinline__ void finish_draw(
   // share a cadence) -- and the next batch of values is loaded before the current one is written.
   const bool per_planet = flags & EXO_FLAG_PER_PLANET;
   const int nthr = (int)blockDim.x;
-  auto total_of = [&](int p) {
+  // the planets' value counts, all at once (two dependent loads each: one after the other they were the kernel)
+  __shared__ int s_total[EXO_MAX_PLANETS];
+  if ((int)threadIdx.x < n_planet) {
     int total = 0;
     for (int ev = 0; ev < n_ev; ++ev) {
-      const int64_t list = (draw * n_planet + p) * n_ev + ev;
+      const int64_t list = (draw * n_planet + threadIdx.x) * n_ev + ev;
       total += rl.pre_all[list * (rl.r_max + 1) + rl.nrun[list]];
     }
-    return total;
-  };
+    s_total[threadIdx.x] = total;
+  }
+  __syncthreads();
+  auto total_of = [&](int p) { return s_total[p]; };
   auto load = [&](int p, int cb, int total, double* v, int* i) {
     const int64_t vbase = (draw * n_planet + p) * n_cad;
 #pragma unroll
@@ -1932,10 +1937,9 @@ __device__ __forceinline__ void finish_draw(
       if (i[u] < 0) continue;
       if (per_planet) {
         flux[(draw * n_cad + i[u]) * n_planet + pl] = v[u];
-      } else if (pl == 0) {
-        flux[draw * n_cad + i[u]] = v[u];
       } else {
-        unsafeAtomicAdd(flux + draw * n_cad + i[u], v[u]);
+        double* dst = cm_draws ? flux + (int64_t)i[u] * cm_draws + draw : flux + draw * n_cad + i[u];
+        if (pl == 0) *dst = v[u]; else unsafeAtomicAdd(dst, v[u]);
       }
     }
     if (!more) break;
@@ -1953,7 +1957,8 @@ __global__ __launch_bounds__(1024) void transit_finish_kernel(
     const double* __restrict__ chi2_part, int n_chi2_part, double* __restrict__ chi2_out,
     Ttv ttv = Ttv{nullptr, nullptr, nullptr, 0}) {
   finish_draw(blockIdx.x, partial, nblk, n_planet, secondary, gparams, gld, flux_dot, n_cad, flags, n_ev, rl, vals, vcad, flux,
-              chi2_part, n_chi2_part, chi2_out, ttv);
+              chi2_part, n_chi2_part, chi2_out, ttv,
+              ((flags & EXO_FLAG_CADENCE_MAJOR) && !(flags & EXO_FLAG_PER_PLANET)) ? (int64_t)gridDim.x : 0);
 }
 
 struct FinishArgs {
@@ -2136,7 +2141,9 @@ __global__ __launch_bounds__(kBlock, LDELAY ? 2 : EXO_RUNS_MIN_WAVES) void trans
             if (j < total) { it.g = gflux[it.i]; it.w = gsparse[chi2_nw == 1 ? 0 : it.i]; }
           } else if (GRAD && j < total)
             it.g = gsparse ? gsparse[vbase + it.v]
-                           : (per_planet ? gflux[(draw * n_cad + it.i) * n_planet + p] : gflux[draw * n_cad + it.i]);
+                           : (per_planet ? gflux[(draw * n_cad + it.i) * n_planet + p]
+                                         : ((flags & EXO_FLAG_CADENCE_MAJOR) ? gflux[(int64_t)it.i * gridDim.y + draw]
+                                                                             : gflux[draw * n_cad + it.i]));
           return it;
         };
         Item nxt = load_item(threadIdx.x);
@@ -2598,7 +2605,9 @@ inline int launch_runs_sweep(const double* t, int64_t n_cad, const double* texp,
   const bool ldelay = flags & EXO_FLAG_LIGHT_DELAY;
   // a draw that is one block's work is finished by that block (gradients from its partials, values to their cadences):
   // no transit_finish_kernel launch
-  const bool fold = EXO_RUNS_FOLD_FINISH == 2 || (EXO_RUNS_FOLD_FINISH == 1 && w.hb == 1);
+  // (not with a cadence-major flux: a draw's values land in lines other blocks zero-fill -- after the sweep, then)
+  const bool cmaj = flags & EXO_FLAG_CADENCE_MAJOR;
+  const bool fold = !(cmaj && flux) && (EXO_RUNS_FOLD_FINISH == 2 || (EXO_RUNS_FOLD_FINISH == 1 && w.hb == 1));
   const FinishArgs fin{gparams, gld, chi2 ? chi2->chi2 : flux_dot, fold ? 1 : 0, w.done}, no_fin{nullptr, nullptr, nullptr, 0, nullptr};
 #define EXO_LAUNCH_RUNS(G, GFLUX, GSP, VALS, VCAD, FILL, PARTIAL, FIN)                                                    \
   if (secondary)                                                                                                          \
@@ -2749,6 +2758,7 @@ static int transit_fwd(const double* t, int64_t n_cad, const double* texp, int64
     return EXO_ERR_INVALID_ARGUMENT;
   const bool has_ttv = ttv.edges != nullptr;
   hipStream_t st = (hipStream_t)stream;
+  if ((flags & EXO_FLAG_CADENCE_MAJOR) && (flags & EXO_FLAG_PER_PLANET)) return EXO_ERR_INVALID_ARGUMENT;
   if (runs_path(has_ttv, n_texp, flags)) {
     const RunWs rw = carve_runs(workspace, n_cad, n_draw, n_planet);
     if (!workspace || workspace_bytes < rw.bytes) return EXO_ERR_WORKSPACE;
@@ -2758,7 +2768,7 @@ static int transit_fwd(const double* t, int64_t n_cad, const double* texp, int64
     if (ev_stop) (void)hipEventRecord((hipEvent_t)ev_stop, st);
     return rc;
   }
-  if (flags & (EXO_FLAG_SPARSE | EXO_FLAG_LIGHT_DELAY)) return EXO_ERR_INVALID_ARGUMENT;   // run-enumeration path only
+  if (flags & (EXO_FLAG_SPARSE | EXO_FLAG_LIGHT_DELAY | EXO_FLAG_CADENCE_MAJOR)) return EXO_ERR_INVALID_ARGUMENT;   // run-enumeration path only
   int bpd, tpb;
   transit_geometry(n_cad, n_draw, &bpd, &tpb);
   const Workspace w = carve(workspace, n_draw, bpd, tpb, n_planet);
@@ -2815,6 +2825,7 @@ static int transit_vjp(const double* t, int64_t n_cad, const double* texp, int64
                ? EXO_OK : EXO_ERR_LAUNCH;
   }
   if (n_planet * kNG + 7 > kBlock) return EXO_ERR_INVALID_ARGUMENT;
+  if ((flags & EXO_FLAG_CADENCE_MAJOR) && (flags & EXO_FLAG_PER_PLANET)) return EXO_ERR_INVALID_ARGUMENT;
   if (runs_path(has_ttv, n_texp, flags)) {
     const RunWs rw = carve_runs(workspace, n_cad, n_draw, n_planet);
     if (!workspace || workspace_bytes < rw.bytes) return EXO_ERR_WORKSPACE;
@@ -2824,7 +2835,7 @@ static int transit_vjp(const double* t, int64_t n_cad, const double* texp, int64
     if (ev_stop) (void)hipEventRecord((hipEvent_t)ev_stop, st);
     return rc;
   }
-  if (flags & (EXO_FLAG_SPARSE | EXO_FLAG_LIGHT_DELAY)) return EXO_ERR_INVALID_ARGUMENT;   // run-enumeration path only
+  if (flags & (EXO_FLAG_SPARSE | EXO_FLAG_LIGHT_DELAY | EXO_FLAG_CADENCE_MAJOR)) return EXO_ERR_INVALID_ARGUMENT;   // run-enumeration path only
   int bpd, tpb;
   transit_geometry(n_cad, n_draw, &bpd, &tpb);
   const Workspace w = carve(workspace, n_draw, bpd, tpb, n_planet);

@@ -4,7 +4,7 @@ import os
 import torch
 
 from .. import _lib
-from ..ops import _dev, _ptr, _stream
+from ..ops import _dev, _ptr, _stream, is_cadence_major
 from ..orbits.keplerian import as_tensor
 from .terms import Term
 
@@ -28,7 +28,9 @@ class _CeleriteLogLike(torch.autograd.Function):
     @staticmethod
     def forward(ctx, t, resid, diag, coef_real, coef_complex, obs, pair_kind, n_chunks):
         t = _dev(t, "t")
-        resid = _dev(resid, "resid")
+        cm = obs is not None and is_cadence_major(resid)
+        if not cm:
+            resid = _dev(resid, "resid")
         if obs is not None:
             obs = _dev(obs, "obs")
             if obs.shape != t.shape:
@@ -75,17 +77,18 @@ class _CeleriteLogLike(torch.autograd.Function):
                     "exo_celerite_loglike_fwd_f64",
                 )
             else:
+                fn = lib.exo_celerite_loglike_obs_fwd_cm_f64 if cm else lib.exo_celerite_loglike_obs_fwd_f64
                 _lib.check(
-                    lib.exo_celerite_loglike_obs_fwd_f64(_ptr(t), _ptr(obs), _ptr(resid), _ptr(diag), diag.shape[0], N,
-                                                         _ptr(coef_real), n_real, _ptr(coef_complex), n_complex,
-                                                         _ptr(pair_kind), D, _ptr(loglike), _ptr(state), nstate,
-                                                         n_chunks, _stream(t)),
-                    "exo_celerite_loglike_obs_fwd_f64",
+                    fn(_ptr(t), _ptr(obs), _ptr(resid), _ptr(diag), diag.shape[0], N, _ptr(coef_real), n_real,
+                       _ptr(coef_complex), n_complex, _ptr(pair_kind), D, _ptr(loglike), _ptr(state), nstate, n_chunks,
+                       _stream(t)),
+                    "exo_celerite_loglike_obs_fwd_cm_f64" if cm else "exo_celerite_loglike_obs_fwd_f64",
                 )
         if need_grad:
             # the series itself is saved too: the reverse pass of the checkpointed path recomputes from it
             ctx.save_for_backward(t, resid, diag, coef_real, coef_complex, state, obs, pair_kind)
             ctx.dims = (D, N, n_real, n_complex, nstate, n_chunks)
+            ctx.cm = cm
         return loglike
 
     @staticmethod
@@ -94,7 +97,10 @@ class _CeleriteLogLike(torch.autograd.Function):
         D, N, n_real, n_complex, nstate, n_chunks = ctx.dims
         gll = _dev(gll, "gloglike")
         lib = _lib.load()
-        gresid = torch.empty(D, N, dtype=torch.float64, device=t.device)
+        if ctx.cm:     # the cotangent of a cadence-major model in the model's layout
+            gresid = torch.empty(N, D, dtype=torch.float64, device=t.device).t()
+        else:
+            gresid = torch.empty(D, N, dtype=torch.float64, device=t.device)
         want_diag = ctx.needs_input_grad[2]
         shared_diag = diag.shape[0] == 1
         gdiag = torch.empty(D, N, dtype=torch.float64, device=t.device) if want_diag else None
@@ -106,6 +112,9 @@ class _CeleriteLogLike(torch.autograd.Function):
                     _stream(t))
             if obs is None:
                 _lib.check(lib.exo_celerite_loglike_vjp_f64(_ptr(t), _ptr(resid), *tail), "exo_celerite_loglike_vjp_f64")
+            elif ctx.cm:
+                _lib.check(lib.exo_celerite_loglike_obs_vjp_cm_f64(_ptr(t), _ptr(obs), _ptr(resid), *tail),
+                           "exo_celerite_loglike_obs_vjp_cm_f64")
             else:
                 _lib.check(lib.exo_celerite_loglike_obs_vjp_f64(_ptr(t), _ptr(obs), _ptr(resid), *tail),
                            "exo_celerite_loglike_obs_vjp_f64")
@@ -223,7 +232,9 @@ class GaussianProcess:
         real, cplx, kind, D, batched = self._coefficients()
         squeeze = resid.dim() == 1 and not batched and self._diag.shape[0] == 1
         D = max(D, resid.shape[0] if resid.dim() == 2 else 1, self._diag.shape[0])
-        resid = resid.expand(D, t.shape[0]).contiguous()
+        resid = resid.expand(D, t.shape[0])
+        if not (obs is not None and is_cadence_major(resid)):   # (a cadence-major model goes to the kernels as it is)
+            resid = resid.contiguous()
         real = real.expand(D, real.shape[1], 2).contiguous()
         cplx = cplx.expand(D, cplx.shape[1], 4).contiguous()
         if kind is not None:

@@ -117,12 +117,17 @@ class LimbDarkLightCurve:
 
     # ------------------------------------------------------------------
     def get_light_curve(self, orbit=None, r=None, t=None, texp=None, oversample=7, order=0,
-                        use_in_transit=None, light_delay=False, total=False):
+                        use_in_transit=None, light_delay=False, total=False, cadence_major=False):
         """Relative flux ``(n_cadence, n_planet)``; arguments as in the reference
         (limb_dark.py:99-153).  ``use_in_transit`` defaults to ``not light_delay``.
         ``total=True`` (not in the reference): the sum over the planets, ``(n_cadence,)`` -- what the tutorials
         write as ``pt.sum(light_curves, axis=-1)`` -- formed inside the kernels; as a separate torch reduction it is a
-        pass over the (draws, cadences) array of its own (0.5 ms of a 5.3 ms C3 step)."""
+        pass over the (draws, cadences) array of its own (0.5 ms of a 5.3 ms C3 step).
+        ``cadence_major=True`` (with ``total``, a batch of draws): the (draws, cadences) result is the transposed view of
+        a (cadences, draws) array -- same shape, same values, draws innermost in memory.  That is the layout the
+        celerite kernels read a mean model in (and write its cotangent in) with contiguous accesses: pass the result
+        as the ``mean`` of a ``GaussianProcess`` (C3: 4.3 -> 3.6 ms per value + gradient).  Ignored where the fused
+        sweep does not offer it (per-cadence exposure times, occultations or light delay together with timing tables)."""
         if orbit is None:
             raise ValueError("missing required argument 'orbit'")
         if r is None:
@@ -140,9 +145,10 @@ class LimbDarkLightCurve:
         keplerian = isinstance(orbit, KeplerianOrbit) and type(orbit)._warp_times is KeplerianOrbit._warp_times
         if keplerian and light_delay and self._fusable_delay(orbit, t, texp):
             # second Kepler solve in the same kernel (EXO_FLAG_LIGHT_DELAY)
-            return self._fused(orbit, r, t, texp, stencil, use_in_transit, light_delay=True, total=total)
+            return self._fused(orbit, r, t, texp, stencil, use_in_transit, light_delay=True, total=total,
+                               cadence_major=cadence_major)
         if isinstance(orbit, KeplerianOrbit) and not light_delay and (keplerian or hasattr(orbit, "kernel_ttv")):
-            return self._fused(orbit, r, t, texp, stencil, use_in_transit, total=total)
+            return self._fused(orbit, r, t, texp, stencil, use_in_transit, total=total, cadence_major=cadence_major)
         lc = self._composed(orbit, r, t, texp, stencil, use_in_transit, light_delay)
         return lc.sum(-1) if total else lc
 
@@ -154,7 +160,8 @@ class LimbDarkLightCurve:
         return scalar_texp and as_tensor(t).dim() == 1
 
     # ---- hot path: one packing kernel + the fused light-curve kernels, nothing O(N) in torch
-    def _fused(self, orbit, r, t, texp, stencil, use_in_transit, secondary=None, light_delay=False, total=False):
+    def _fused(self, orbit, r, t, texp, stencil, use_in_transit, secondary=None, light_delay=False, total=False,
+               cadence_major=False):
         t = as_tensor(t, r if isinstance(r, torch.Tensor) else self.u1)
         if t.dim() != 1:
             raise ValueError("t must be a vector of times")
@@ -180,8 +187,13 @@ class LimbDarkLightCurve:
             kw.update(texp=as_tensor(texp, t).reshape(-1).detach(), stencil_dt=_on_device(dt, t.device),
                       stencil_w=_on_device(w, t.device))
         if total:
-            flux = ops.transit_flux(t.detach(), rec, ld, flags=flags, **kw)
-            return flux.reshape(tuple(batch) + (t.shape[0],))
+            # cadence-major output: run-enumeration sweeps only (one exposure time at most; timing tables without
+            # occultations / light delay), a one-dimensional batch of more than one draw
+            n_texp = kw["texp"].numel() if "texp" in kw else 0
+            cm = (cadence_major and len(tuple(batch)) == 1 and rec.shape[0] > 1 and n_texp <= 1
+                  and not ("ttv" in kw and (secondary is not None or light_delay)))
+            flux = ops.transit_flux(t.detach(), rec, ld, flags=flags | (ops.FLAG_CADENCE_MAJOR if cm else 0), **kw)
+            return flux if cm else flux.reshape(tuple(batch) + (t.shape[0],))
         flux = ops.transit_flux(t.detach(), rec, ld, flags=flags | ops.FLAG_PER_PLANET, **kw)
         return flux.reshape(tuple(batch) + (t.shape[0], rec.shape[1]))
 

@@ -29,6 +29,7 @@ PACK_CIRCULAR = 8
 FLAG_EXACT_SCAN = 16
 FLAG_SPARSE = 32
 FLAG_LIGHT_DELAY = 64
+FLAG_CADENCE_MAJOR = 128   # summed dense flux / its cotangent as [cadence][draw] arrays (include/exoplanet_amd.h)
 NIN = 10
 (IN_PERIOD, IN_T0, IN_B, IN_ECC, IN_OMEGA, IN_R, IN_MSTAR, IN_RSTAR, IN_MPLANET, IN_SBR) = range(10)
 MAX_PLANETS = 16
@@ -54,6 +55,14 @@ def _dev(x, name):
 
 def _ptr(x):
     return 0 if x is None else x.data_ptr()
+
+
+def is_cadence_major(x):
+    """a (D, N) float64 device tensor laid out [cadence][draw] -- the transposed view of a contiguous (N, D) array: what
+    the light-curve sweep returns under FLAG_CADENCE_MAJOR and what the celerite kernels read (and write the cotangent
+    of) with every wave's accesses contiguous, a lane being a draw"""
+    return (torch.is_tensor(x) and x.is_cuda and x.dtype == torch.float64 and x.dim() == 2 and x.shape[0] > 1
+            and x.stride() == (1, x.shape[0]))
 
 
 # ------------------------------------------------------------------------------
@@ -221,7 +230,12 @@ class _TransitFlux(torch.autograd.Function):
         edges, shift, n_edge = _ttv_args(None if ttv_edges is None else (ttv_edges, ttv_shift), D, P)
         N = t.numel()
         shape = (D, N, P) if flags & FLAG_PER_PLANET else (D, N)
-        flux = torch.empty(shape, dtype=torch.float64, device=t.device)
+        if flags & FLAG_CADENCE_MAJOR:
+            if flags & FLAG_PER_PLANET:
+                raise ValueError("FLAG_CADENCE_MAJOR is a layout of the summed flux")
+            flux = torch.empty((N, D), dtype=torch.float64, device=t.device).t()     # (D, N), draws innermost
+        else:
+            flux = torch.empty(shape, dtype=torch.float64, device=t.device)
         lib = _lib.load()
         nbytes = lib.exo_transit_flux_workspace_bytes(N, D, P)
         ws = torch.empty(max(nbytes // 8 + 1, 1), dtype=torch.float64, device=t.device)
@@ -256,10 +270,17 @@ class _TransitFlux(torch.autograd.Function):
 
 def _vjp(t, texp, n_texp, sdt, sw, n_sub, params, ld, D, P, flags, gflux, want_flux, events=(None, None), ttv=None):
     N = t.numel()
-    gflux = _dev(gflux, "gflux")
     shape = (D, N, P) if flags & FLAG_PER_PLANET else (D, N)
-    if tuple(gflux.shape) != shape:
+    if isinstance(gflux, torch.Tensor) and tuple(gflux.shape) != shape:
         raise ValueError(f"gflux must have shape {shape}")
+    # the cotangent as it comes: cadence-major (the celerite kernels' gradient of a cadence-major model) or rows
+    if is_cadence_major(gflux) and not flags & FLAG_PER_PLANET:
+        flags |= FLAG_CADENCE_MAJOR
+    elif flags & FLAG_CADENCE_MAJOR and want_flux:
+        gflux = _dev(gflux, "gflux").t().contiguous().t()
+    else:
+        flags &= ~FLAG_CADENCE_MAJOR
+        gflux = _dev(gflux, "gflux")
     edges, shift, n_edge = _ttv_args(ttv, D, P)
     lib = _lib.load()
     nbytes = lib.exo_transit_flux_workspace_bytes(N, D, P)
@@ -267,7 +288,10 @@ def _vjp(t, texp, n_texp, sdt, sw, n_sub, params, ld, D, P, flags, gflux, want_f
     gparams = torch.empty_like(params)
     gld = torch.empty_like(ld)
     dot = torch.empty(D, dtype=torch.float64, device=t.device)
-    flux = torch.empty(shape, dtype=torch.float64, device=t.device) if (want_flux and not flags & FLAG_SPARSE) else None
+    flux = None
+    if want_flux and not flags & FLAG_SPARSE:
+        flux = (torch.empty((N, D), dtype=torch.float64, device=t.device).t() if flags & FLAG_CADENCE_MAJOR
+                else torch.empty(shape, dtype=torch.float64, device=t.device))
     gshift = torch.empty_like(shift) if n_edge else None
     with torch.cuda.device(t.device):
         if n_edge:

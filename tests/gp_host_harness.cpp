@@ -118,6 +118,10 @@ int64_t harness_gp_state_doubles(int64_t n, int64_t n_draw, int32_t n_real, int3
   return cg.base + gp::chunk_ws(n, n_draw, J, cg).total();
 }
 
+// the layout of y / gresid for the calls that follow: 0 = [draw][cadence], 1 = cadence-major [cadence][draw]
+static int g_cadence_major = 0;
+void harness_gp_set_cadence_major(int on) { g_cadence_major = on; }
+
 // returns the number of chunks used (1: the plan is sequential, nothing was computed), -1 on bad J
 int harness_gp_fwd(const double* t, const double* y, const double* obs, const double* diag, int64_t n_diag, int64_t n,
                    const double* real, int32_t n_real, const double* cplx, int32_t n_complex, const int32_t* kind,
@@ -126,7 +130,7 @@ int harness_gp_fwd(const double* t, const double* y, const double* obs, const do
   const int J = cf.J();
   const gp::ChunkGeom cg = gp::chunk_plan(n, n_draw, J, n_chunks);
   if (cg.C <= 1 || !cg.lane) return cg.C <= 1 ? 1 : -1;
-  const gp::Series rs{y, obs};
+  const gp::Series rs{y, obs, g_cadence_major ? n_draw : 0};
   switch (J) {
     case 1: run_fwd<1>(t, rs, diag, n_diag, n, cf, n_draw, loglike, state, cg); break;
     case 2: run_fwd<2>(t, rs, diag, n_diag, n, cf, n_draw, loglike, state, cg); break;
@@ -149,7 +153,7 @@ int harness_gp_vjp(const double* t, const double* y, const double* obs, const do
   const int J = cf.J();
   const gp::ChunkGeom cg = gp::chunk_plan(n, n_draw, J, n_chunks);
   if (cg.C <= 1 || !cg.lane) return cg.C <= 1 ? 1 : -1;
-  const gp::Series rs{y, obs};
+  const gp::Series rs{y, obs, g_cadence_major ? n_draw : 0};
   const double gsign = obs ? -1.0 : 1.0;
   switch (J) {
     case 1: run_vjp<1>(t, rs, diag, n_diag, n, cf, n_draw, gloglike, state, cg, gresid, gdiag, gsign, gdiag_sum, gcr, gcc); break;

@@ -38,14 +38,18 @@ def _p(a):
     return None if a is None else a.ctypes.data_as(_dp)
 
 
-def run(lib, t, y, diag, real, cplx, kind=None, obs=None, n_chunks=0, gll=None):
-    """-> loglike (D,), flags (D,), and with gll: dict of gradients"""
+def run(lib, t, y, diag, real, cplx, kind=None, obs=None, n_chunks=0, gll=None, cadence_major=False):
+    """-> loglike (D,), flags (D,), and with gll: dict of gradients.  cadence_major: the kernels are handed y (and write its
+    cotangent) as [cadence][draw] arrays (Series::cm)"""
     t = np.ascontiguousarray(t, dtype=np.float64)
     y = np.ascontiguousarray(y, dtype=np.float64)
     diag = np.ascontiguousarray(diag, dtype=np.float64)
     real = np.ascontiguousarray(real, dtype=np.float64)
     cplx = np.ascontiguousarray(cplx, dtype=np.float64)
     D, n = y.shape
+    if cadence_major:
+        y = np.ascontiguousarray(y.T)
+    lib.harness_gp_set_cadence_major(1 if cadence_major else 0)
     n_real, n_complex = real.shape[1], cplx.shape[1]
     kind_p = None
     if kind is not None:
@@ -68,6 +72,8 @@ def run(lib, t, y, diag, real, cplx, kind=None, obs=None, n_chunks=0, gll=None):
     rc = lib.harness_gp_vjp(*args, _p(gll), _p(state), _p(g["y"]), _p(g["diag"]), _p(g["diag_sum"]), _p(g["real"]),
                             _p(g["cplx"]))
     assert rc == C_used
+    if cadence_major:
+        g["y"] = np.ascontiguousarray(g["y"].reshape(n, D).T)
     return ll, flags, C_used, g
 
 
@@ -343,3 +349,25 @@ def test_dot_tril_and_predict_vs_dense(harness, n_real, n_complex):
         np.testing.assert_allclose(z[d], L @ x[d], rtol=1e-9, atol=1e-11)
         Ks = _kernel(tq[:, None] - t[None, :], terms[d])
         np.testing.assert_allclose(mu[d], Ks @ alpha[d], rtol=1e-10, atol=1e-11)
+
+
+@pytest.mark.parametrize("n_real,n_complex", [(0, 1), (2, 1), (0, 3)])
+def test_cadence_major_series_is_the_same_arithmetic(harness, n_real, n_complex):
+    """the series as a [cadence][draw] array (what the light-curve sweep writes under EXO_FLAG_CADENCE_MAJOR): same bits
+    as the [draw][cadence] rows, with and without an observed series subtracted on the fly"""
+    rng = np.random.default_rng(77 + n_real)
+    n, D = 331, 5
+    t = np.sort(rng.uniform(0, 60, n))
+    diag = rng.uniform(0.05, 0.3, (1, n))
+    y = rng.normal(size=(D, n))
+    obs = rng.normal(size=n)
+    terms = [rand_terms(rng, n_real, n_complex) for _ in range(D)]
+    real = np.stack([np.stack([c[0], c[1]], -1) for c in terms]).reshape(D, n_real, 2)
+    cplx = np.stack([np.stack([c[2], c[3], c[4], c[5]], -1) for c in terms]).reshape(D, n_complex, 4)
+    gll = rng.normal(size=D)
+    for o in (None, obs):
+        a = run(harness, t, y, diag, real, cplx, obs=o, gll=gll)
+        b = run(harness, t, y, diag, real, cplx, obs=o, gll=gll, cadence_major=True)
+        assert np.array_equal(a[0], b[0])
+        for k in a[3]:
+            assert np.array_equal(a[3][k], b[3][k]), k

@@ -1,0 +1,128 @@
+"""GPU: the cadence-major layout of the dense summed flux and of the celerite kernels' series (EXO_FLAG_CADENCE_MAJOR,
+exo_celerite_loglike_obs_*_cm_f64): the same arithmetic on [cadence][draw] arrays -- bit-identical values and gradients
+to the [draw][cadence] path, for the light-curve sweeps, the celerite likelihood (time-parallel, sequential and flagged
+draws) and the two chained as a mean model (the C3 / C5 shapes of bench.py)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a ROCm device")
+    return torch.device("cuda:0")
+
+
+def _system(dev, D, n_planet, seed=3, secondary=False):
+    import exoplanet_amd as xo
+
+    rng = np.random.default_rng(seed)
+    base = dict(period=[3.5, 7.9][:n_planet], t0=[1.0, 2.3][:n_planet], b=[0.3, 0.1][:n_planet], ecc=[0.3, 0.1][:n_planet],
+                omega=[1.1, -0.4][:n_planet])
+    L = {k: torch.tensor(np.asarray(v)[None] * (1 + 1e-3 * rng.normal(size=(D, n_planet))), dtype=torch.float64, device=dev,
+                         requires_grad=True) for k, v in base.items()}
+    r = torch.tensor(np.asarray([0.1, 0.05][:n_planet])[None] * (1 + 1e-3 * rng.normal(size=(D, n_planet))),
+                     dtype=torch.float64, device=dev, requires_grad=True)
+    orbit = lambda: xo.KeplerianOrbit(**L)  # noqa: E731
+    return xo, L, r, orbit
+
+
+@pytest.mark.parametrize("n_planet,texp,D", [(1, None, 5), (2, 0.02, 70), (1, 0.02, 600)])
+def test_light_curve_cadence_major(dev, n_planet, texp, D):
+    xo, L, r, orbit = _system(dev, D, n_planet)
+    N = 20_011
+    t = torch.arange(N, dtype=torch.float64, device=dev) * (2.0 / 1440.0)
+    star = xo.LimbDarkLightCurve(0.3, 0.2)
+    g = torch.randn(D, N, dtype=torch.float64, device=dev, generator=torch.Generator(device=dev).manual_seed(5))
+    out = {}
+    for cm in (False, True):
+        lc = star.get_light_curve(orbit=orbit(), r=r, t=t, texp=texp, total=True, cadence_major=cm)
+        assert lc.shape == (D, N)
+        assert lc.stride() == ((1, D) if cm else (N, 1))
+        gg = g.t().contiguous().t() if cm else g          # the cotangent in the layout of the flux
+        leaves = list(L.values()) + [r]
+        grads = torch.autograd.grad((lc * gg).sum(), leaves)
+        out[cm] = (lc.detach().contiguous(), [x.clone() for x in grads])
+    assert torch.equal(out[False][0], out[True][0])
+    assert (out[True][0] != 0).any()
+    for a, b in zip(out[False][1], out[True][1]):
+        assert torch.equal(a, b)
+    # a row-major cotangent for a cadence-major flux (and the other way round) is taken as it comes
+    lc = star.get_light_curve(orbit=orbit(), r=r, t=t, texp=texp, total=True, cadence_major=True)
+    (gr,) = torch.autograd.grad((lc * g).sum(), [r])
+    assert torch.equal(gr, out[False][1][-1])
+
+
+def _terms(dev, D, which, rng):
+    import exoplanet_amd as xo
+
+    T = xo.gp.terms
+    v = lambda x: torch.tensor(x * (1 + 0.05 * rng.normal(size=D)), dtype=torch.float64, device=dev, requires_grad=True)  # noqa: E731
+    if which == "sho":
+        p = dict(sigma=v(0.7), rho=v(3.0), Q=v(2.0))
+        return T.SHOTerm(**p), list(p.values())
+    if which == "sho3":
+        ps = [dict(sigma=v(0.7), rho=v(20.0), Q=v(2.0)), dict(sigma=v(0.5), rho=v(10.0), Q=v(1.0)),
+              dict(sigma=v(0.3), rho=v(2.0), Q=v(0.7071))]
+        return T.SHOTerm(**ps[0]) + T.SHOTerm(**ps[1]) + T.SHOTerm(**ps[2]), [x for p in ps for x in p.values()]
+    if which == "mixed":       # draws on both sides of critical damping: pair kinds per draw, one of them ill-conditioned
+        q = torch.tensor(np.where(np.arange(D) % 3 == 0, 0.3, 2.0), dtype=torch.float64, device=dev, requires_grad=True)
+        p = dict(sigma=v(0.7), rho=v(3.0), Q=q)
+        return T.SHOTerm(**p), list(p.values())
+    raise ValueError(which)
+
+
+@pytest.mark.parametrize("which,N,D", [("sho", 3001, 70), ("sho3", 2000, 9), ("mixed", 1500, 66), ("sho", 40, 3)])
+def test_gp_with_cadence_major_mean(dev, which, N, D):
+    """GaussianProcess.log_likelihood with a (D, N) mean model in either layout: same bits, gradient of the mean in the
+    layout of the mean"""
+    import exoplanet_amd as xo
+
+    rng = np.random.default_rng(11)
+    t = torch.tensor(np.sort(rng.uniform(0, 80, N)), dtype=torch.float64, device=dev)
+    y = torch.tensor(rng.normal(size=N), dtype=torch.float64, device=dev)
+    mean_rows = torch.tensor(0.1 * rng.normal(size=(D, N)), dtype=torch.float64, device=dev)
+    out = {}
+    for cm in (False, True):
+        kern, leaves = _terms(dev, D, which, np.random.default_rng(12))
+        mean = (mean_rows.t().contiguous().t() if cm else mean_rows.clone()).requires_grad_(True)
+        if which == "mixed" and cm:    # one draw too ill-conditioned for the time-parallel path: redone by the sequential kernels
+            pass
+        gp = xo.gp.GaussianProcess(kern, t=t, yerr=0.3 if which != "mixed" else 1e-3, mean=mean)
+        ll = gp.log_likelihood(y)
+        w = torch.linspace(0.5, 1.5, D, dtype=torch.float64, device=dev)
+        grads = torch.autograd.grad((ll * w).sum(), leaves + [mean])
+        if cm:
+            assert grads[-1].stride() == (1, D)
+        out[cm] = (ll.detach().clone(), [g.contiguous().clone() for g in grads])
+    assert torch.isfinite(out[True][0]).all()
+    assert torch.equal(out[False][0], out[True][0])
+    for a, b in zip(out[False][1], out[True][1]):
+        assert torch.equal(a, b)
+
+
+def test_light_curve_into_gp_cadence_major(dev):
+    """the two chained -- a batch of light curves as the mean of a celerite GP (bench.py's C3) -- against the row layout and
+    against the oracle's dense statement for one draw"""
+    import exoplanet_amd as xo
+
+    D, N = 130, 6000
+    xo_, L, r, orbit = _system(dev, D, 1, seed=9)
+    rng = np.random.default_rng(2)
+    t = torch.arange(N, dtype=torch.float64, device=dev) * (2.0 / 1440.0)
+    y = torch.tensor(1e-3 * rng.normal(size=N), dtype=torch.float64, device=dev)
+    star = xo.LimbDarkLightCurve(0.3, 0.2)
+    res = {}
+    for cm in (False, True):
+        kern, kl = _terms(dev, D, "sho", np.random.default_rng(4))
+        lc = star.get_light_curve(orbit=orbit(), r=r, t=t, texp=0.01, total=True, cadence_major=cm)
+        gp = xo.gp.GaussianProcess(kern, t=t, yerr=1e-3, mean=lc)
+        ll = gp.log_likelihood(y)
+        leaves = list(L.values()) + [r] + kl
+        res[cm] = (ll.detach().clone(), [g.clone() for g in torch.autograd.grad(ll.sum(), leaves)])
+    assert torch.equal(res[False][0], res[True][0])
+    for a, b in zip(res[False][1], res[True][1]):
+        assert torch.equal(a, b)
