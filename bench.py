@@ -298,6 +298,7 @@ def workload_c5(xo, ops, dev, D, rank=0):
     leaves.update(sbr=vec(0.3), s1=vec(C5_TERMS[0][0]), s2=vec(C5_TERMS[1][0]), s3=vec(C5_TERMS[2][0]))
     yobs = torch.as_tensor(3e-4 * np.random.default_rng(5).normal(size=n), device=dev)       # (the data: same on every rank)
     ones = torch.ones(D, dtype=torch.float64, device=dev)
+    fixed = [(rho * ones, Q * ones) for _, rho, Q in C5_TERMS]     # (rho, Q) of the three terms: fixed, per chain
     names = list(leaves)
     T = xo.gp.terms
 
@@ -306,9 +307,8 @@ def workload_c5(xo, ops, dev, D, rank=0):
         orbit = xo.KeplerianOrbit(period=Lv["period"], t0=Lv["t0"], b=Lv["b"], ecc=Lv["ecc"], omega=Lv["omega"])
         lc = xo.SecondaryEclipseLightCurve(C5_LD[0], C5_LD[1], Lv["sbr"]).get_light_curve(
             orbit=orbit, r=Lv["r"], t=t, texp=texp, oversample=7, total=True, cadence_major=GP_MEAN_CADENCE_MAJOR)
-        kern = (T.SHOTerm(sigma=Lv["s1"], rho=C5_TERMS[0][1] * ones, Q=C5_TERMS[0][2] * ones)
-                + T.SHOTerm(sigma=Lv["s2"], rho=C5_TERMS[1][1] * ones, Q=C5_TERMS[1][2] * ones)
-                + T.SHOTerm(sigma=Lv["s3"], rho=C5_TERMS[2][1] * ones, Q=C5_TERMS[2][2] * ones))
+        kern = (T.SHOTerm(sigma=Lv["s1"], rho=fixed[0][0], Q=fixed[0][1]) + T.SHOTerm(sigma=Lv["s2"], rho=fixed[1][0], Q=fixed[1][1])
+                + T.SHOTerm(sigma=Lv["s3"], rho=fixed[2][0], Q=fixed[2][1]))
         gp = xo.gp.GaussianProcess(kern, t=t, yerr=C5_YERR, mean=lc)
         ll = gp.log_likelihood(yobs)
         return (ll.detach(),) + torch.autograd.grad(ll.sum(), vals)

@@ -139,6 +139,7 @@ def celerite_loglike(t, resid, diag, coef_real, coef_complex, obs=None, pair_kin
 
 
 _SORTED = {}
+_CONST_VAR = {}   # (n, device, yerr) -> the variance vector of a scalar error bar (a handful of series at most)
 
 
 def _known_sorted(t):
@@ -189,7 +190,17 @@ class GaussianProcess:
         elif yerr is not None:
             if diag is not None:
                 raise ValueError("only one of 'diag' and 'yerr' can be provided")
-            var = as_tensor(yerr, t) ** 2 + torch.zeros_like(t)
+            if isinstance(yerr, (int, float)):
+                # one error bar for the whole series: the same constant vector for every object built on these times --
+                # made once (a sampler builds a GaussianProcess per evaluation: three small kernels each time otherwise)
+                key = (t.shape[0], str(t.device), float(yerr))
+                var = _CONST_VAR.get(key)
+                if var is None:
+                    if len(_CONST_VAR) >= 8:
+                        _CONST_VAR.clear()
+                    var = _CONST_VAR[key] = torch.full_like(t, float(yerr) ** 2)
+            else:
+                var = as_tensor(yerr, t) ** 2 + torch.zeros_like(t)
         else:
             var = as_tensor(diag, t) + torch.zeros_like(t)
         if var.shape[-1] != t.shape[0]:

@@ -100,7 +100,16 @@ class LimbDarkLightCurve:
         else:
             self.u1 = as_tensor(u1)
             self.u2 = as_tensor(u2, self.u1)
-        self.c = get_cl(self.u1, self.u2)
+        self._c = None
+
+    @property
+    def c(self):
+        """Green's-basis coefficients (limb_dark.py:66: the reference builds them in the constructor, as a node of a lazy
+        graph).  Here on first use: the fused paths never read them -- the packing kernel forms its own from (u1, u2) --
+        and eleven small torch kernels per light-curve object were a quarter of a sampler's likelihood step."""
+        if self._c is None:
+            self._c = get_cl(self.u1, self.u2)
+        return self._c
 
     def get_ror_from_approx_transit_depth(self, delta, b, jac=False):
         """radius ratio for an approximate depth in the small-planet limit (limb_dark.py:70-97)"""
