@@ -69,7 +69,11 @@ class _ChainSampler:
         with torch.enable_grad():
             parts = self._parts(q.detach().requires_grad_(True))
             lp = self.logp_fn(*parts)
-            grads = torch.autograd.grad(lp.sum(), parts)
+            # d(sum of the chains' log-densities): a unit cotangent kept from call to call (no reduction kernel, no fill)
+            ones = getattr(self, "_unit", None)
+            if ones is None or ones.shape != lp.shape or ones.device != lp.device:
+                ones = self._unit = torch.ones_like(lp).detach()
+            grads = torch.autograd.grad(lp, parts, grad_outputs=ones)
         return lp.detach(), self._flat([g.detach() for g in grads])
 
     def _momenta(self):
@@ -157,11 +161,14 @@ class HMC(_ChainSampler):
         lp0, g = self._value_and_grad_flat(q)
         lp = lp0
         e = self.eps.unsqueeze(1)
-        for _ in range(self.L):
-            p = p + 0.5 * e * g
-            q = q + e * p / self._mflat
+        eh, em = 0.5 * e, e / self._mflat
+        # (the closing half step of one leapfrog step and the opening half step of the next use the same gradient: one
+        # fused multiply-add each for p and q per step -- every elementwise kernel here is a launch between two likelihoods)
+        p = torch.addcmul(p, eh, g)
+        for i in range(self.L):
+            q = torch.addcmul(q, em, p)
             lp, g = self._value_and_grad_flat(q)
-            p = p + 0.5 * e * g
+            p = torch.addcmul(p, e if i + 1 < self.L else eh, g)
         return q, p, lp0, lp
 
     @torch.no_grad()
