@@ -685,7 +685,8 @@ def extra_gp_conditioning(xo, ops, dev, D):
     T = xo.gp.terms
     t = torch.arange(N_CAD, dtype=torch.float64, device=dev) * CADENCE
     y = torch.as_tensor(5e-4 * np.random.default_rng(3).normal(size=N_CAD), device=dev)
-    model = torch.zeros(D, N_CAD, dtype=torch.float64, device=dev, requires_grad=True)
+    # (the mean model draws-innermost, as the C3 step hands it over: get_light_curve(cadence_major=True))
+    model = torch.zeros(N_CAD, D, dtype=torch.float64, device=dev).t().requires_grad_(True)
     full = lambda v: torch.full((D,), v, dtype=torch.float64, device=dev, requires_grad=True)  # noqa: E731
     Qmix = np.full(D, 0.7071)
     Qmix[: max(1, D // 100): 2] = 0.505
