@@ -1438,13 +1438,21 @@ __global__ __launch_bounds__(kWave, EXO_VJP1_WAVES) void celerite_chunk1_vjp_mix
   }
 }
 
+#ifndef EXO_GP_MIXED_ONE_LAUNCH
+#define EXO_GP_MIXED_ONE_LAUNCH 1
+#endif
 #define EXO_GP_LAYOUTS(J_, CF, CALL, MIXED)                                             \
   switch (J_) {                                                                         \
     case 1: { constexpr int JJ = 1, NR = 1; CALL; } break;                              \
     case 2:                                                                             \
       if ((CF).n_real == 2) { constexpr int JJ = 2, NR = 2; CALL; }                     \
       else if (!(CF).kind) { constexpr int JJ = 2, NR = 0; CALL; }                      \
-      else { MIXED; }   /* per-draw kinds: the three variants in one launch */          \
+      else if (EXO_GP_MIXED_ONE_LAUNCH) { MIXED; }   /* per-draw kinds: the three variants in one launch */ \
+      else {            /* ... or one after the other: a wave returns at once from the variants it did not vote for */ \
+        { constexpr int JJ = 2, NR = 0; CALL; }                                         \
+        { constexpr int JJ = 2, NR = 2; CALL; }                                         \
+        { constexpr int JJ = 2, NR = -1; CALL; }                                        \
+      }                                                                                 \
       break;                                                                            \
     case 3: { constexpr int JJ = 3, NR = -1; CALL; } break;                             \
     case 4: { constexpr int JJ = 4, NR = -1; CALL; } break;                             \

@@ -126,3 +126,38 @@ def test_light_curve_into_gp_cadence_major(dev):
     assert torch.equal(res[False][0], res[True][0])
     for a, b in zip(res[False][1], res[True][1]):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("kind", ["ttv", "light_delay"])
+def test_cadence_major_on_the_other_sweeps(dev, kind):
+    """timing tables (transit_enum_ttv_kernel + the table variant of the sweep) and light-travel delay (its own variant):
+    the cadence-major flux and gradients are those of the row layout, bit for bit"""
+    import exoplanet_amd as xo
+
+    D, N = 70, 12_007
+    xo_, L, r, orbit = _system(dev, D, 1, seed=21)
+    t = torch.arange(N, dtype=torch.float64, device=dev) * (2.0 / 1440.0)
+    star = xo.LimbDarkLightCurve(0.3, 0.2)
+    extra = []
+    if kind == "ttv":
+        n_tr = int(float(t[-1]) / 3.5) + 2
+        offs = torch.tensor(0.01 * np.random.default_rng(1).normal(size=(D, n_tr)), dtype=torch.float64, device=dev,
+                            requires_grad=True)
+        extra = [offs]
+        make = lambda: xo.orbits.TTVOrbit(ttvs=[offs], **L)  # noqa: E731
+        kw = {}
+    else:
+        make = orbit
+        kw = dict(light_delay=True)
+    g = torch.randn(D, N, dtype=torch.float64, device=dev, generator=torch.Generator(device=dev).manual_seed(3))
+    out = {}
+    for cm in (False, True):
+        lc = star.get_light_curve(orbit=make(), r=r, t=t, total=True, cadence_major=cm, **kw)
+        assert lc.stride() == ((1, D) if cm else (N, 1))
+        gg = g.t().contiguous().t() if cm else g
+        grads = torch.autograd.grad((lc * gg).sum(), list(L.values()) + [r] + extra)
+        out[cm] = (lc.detach().contiguous(), [x.clone() for x in grads])
+    assert (out[True][0] != 0).any()
+    assert torch.equal(out[False][0], out[True][0])
+    for a, b in zip(out[False][1], out[True][1]):
+        assert torch.equal(a, b)
