@@ -103,43 +103,24 @@ struct Shared {
 #endif
 constexpr int kSortBlock = 4096;
 constexpr int kWinLanes = 8;   // threads per record: (event, side of the conjunction, contact | inner point)
-__global__ __launch_bounds__(kBlock) void transit_window_kernel(const double* __restrict__ params, int64_t n_rec,
-                                                                uint32_t flags, double* __restrict__ out,
-                                                                const double* __restrict__ t = nullptr, int64_t n_cad = 0,
-                                                                int32_t* __restrict__ sorted = nullptr,
-                                                                int32_t* __restrict__ done = nullptr, int64_t n_done = 0) {
-  const int n_rec_blocks = (int)((n_rec * kWinLanes + kBlock - 1) / kBlock);
-  // (the per-draw block counters of the sweep that follows: transit_runs_kernel)
-  if (done && (int64_t)blockIdx.x * kBlock + threadIdx.x < n_done) done[(int64_t)blockIdx.x * kBlock + threadIdx.x] = 0;
-  if ((int)blockIdx.x >= n_rec_blocks) {
-    const int sb = blockIdx.x - n_rec_blocks;
-    const int64_t b0 = (int64_t)sb * kSortBlock;
-    bool ok = true;
-    for (int64_t k = b0 + threadIdx.x; k < b0 + kSortBlock && k + 1 < n_cad; k += kBlock) ok = ok && (t[k] <= t[k + 1]);   // NaN: not sorted
-    const int all = __syncthreads_and(ok ? 1 : 0);
-    if (threadIdx.x == 0) sorted[sb] = all;
-    return;
-  }
-  const int64_t gid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  const int64_t i = gid / kWinLanes;
-  const int sub = (int)(gid - i * kWinLanes), which = sub >> 2, k = (sub >> 1) & 1, sd = sub & 1;   // point, event (0 transit, 1 occultation), side
-  if (i >= n_rec) return;   // (whole groups of eight: the shuffles below stay within a record)
-  const double* p = params + i * EXO_NPAR;
+// The window of one record on EIGHT lanes (sub = 0 .. 7: (point, event, side); all eight must call it together: shuffles).
+// On return: with EXO_FLAG_WINDOW every lane holds all seven numbers; otherwise lane sub = 0 holds w[0..3] and w[5] (the
+// transit's), lane sub = 2 holds w[4] and w[6] (the occultation's).
+__device__ __forceinline__ void window_lanes(const double* __restrict__ p, uint32_t flags, int sub, double* w) {
+  const int which = sub >> 2, k = (sub >> 1) & 1, sd = sub & 1;   // point, event (0 transit, 1 occultation), side
   const double e = p[EXO_P_ECC], cw = p[EXO_P_COSW], sw = p[EXO_P_SINW];
-  double* o = out + kWin * i;
-  if (flags & EXO_FLAG_WINDOW) {
-    if (sub != 0) return;
+  if (flags & EXO_FLAG_WINDOW) {   // (every lane: a dozen operations, and then every lane holds all seven)
     const double ip = 1.0 / p[EXO_P_PERIOD];
     const double ts = p[EXO_P_TS], te = p[EXO_P_TE], ts2 = p[EXO_P_TS2], te2 = p[EXO_P_TE2];
     const bool fin = (fabs(ts) < __builtin_inf()) && (fabs(te) < __builtin_inf());
     const bool fin2 = (fabs(ts2) < __builtin_inf()) && (fabs(te2) < __builtin_inf());
     const double mid = fin ? 0.5 * (ts + te) : 0.0, mid2 = fin2 ? 0.5 * (ts2 + te2) : 0.0;
-    o[0] = ip;
-    o[1] = -(p[EXO_P_T0] + mid) * ip;
-    o[2] = (mid - mid2) * ip;
+    w[0] = ip;
+    w[1] = -(p[EXO_P_T0] + mid) * ip;
+    w[2] = (mid - mid2) * ip;
     // a hair wider than the reference's closed interval: a cadence exactly at a contact has zero flux
-    o[3] = fin ? fma(0.5 * (te - ts) * ip, 1.0 + 1e-12, 1e-14) : __builtin_inf();
-    o[4] = fin2 ? fma(0.5 * (te2 - ts2) * ip, 1.0 + 1e-12, 1e-14) : __builtin_inf();
+    w[3] = fin ? fma(0.5 * (te - ts) * ip, 1.0 + 1e-12, 1e-14) : __builtin_inf();
+    w[4] = fin2 ? fma(0.5 * (te2 - ts2) * ip, 1.0 + 1e-12, 1e-14) : __builtin_inf();
     // inner parts: chord ratio sqrt((1-r)^2 - b^2) / sqrt((1+r)^2 - b^2) of the contact window,
     // b = impact parameter at the conjunction
     const double wn_ = sqrt(cw * cw + sw * sw), r_ = fabs(p[EXO_P_ROR]);
@@ -147,16 +128,16 @@ __global__ __launch_bounds__(kBlock) void transit_window_kernel(const double* __
     for (int q = 0; q < 2; ++q) {
       const double bk = fabs(p[EXO_P_AOR] * p[EXO_P_COSI]) * (1.0 - e * e) / (1.0 + (q ? -e : e) * sinw_);
       const double in2 = (1.0 - r_) * (1.0 - r_) - bk * bk, out2 = (1.0 + r_) * (1.0 + r_) - bk * bk;
-      const double h = o[3 + q];
-      o[5 + q] = (r_ < 1.0 && in2 > 0.0 && out2 > 0.0 && h < __builtin_inf()) ? 0.95 * h * sqrt(in2 / out2) : 0.0;
+      const double h = w[3 + q];
+      w[5 + q] = (r_ < 1.0 && in2 > 0.0 && out2 > 0.0 && h < __builtin_inf()) ? 0.95 * h * sqrt(in2 / out2) : 0.0;
     }
     if (flags & EXO_FLAG_LIGHT_DELAY) {   // as below: the retarded time differs from t by at most this
       const double vmax = fabs(p[EXO_P_N] * p[EXO_P_AOR]) * (1.0 + e) / sqrt(1.0 - e * e);
       const double dmax = fabs(p[EXO_P_AOR]) * (1.0 + e) / (fabs(p[EXO_P_CLIGHT]) - vmax);
       const double wd = (dmax >= 0.0 ? dmax : __builtin_inf()) * ip * 1.05;
-      o[3] += wd; o[4] += wd;
+      w[3] += wd; w[4] += wd;
     }
-    return;
+    return;     // (flag-uniform: every lane of the launch takes this branch or none does)
   }
   // Eight threads per record -- (event, side, contact | inner point) -- each with the short serial chain of its own
   // point.  No forward trigonometry: the conjunction's true anomaly f0 = +-pi/2 - w (+ pi) has cos f0 = +-sin w,
@@ -259,16 +240,51 @@ __global__ __launch_bounds__(kBlock) void transit_window_kernel(const double* __
     const double dmax = fabs(p[EXO_P_AOR]) * (1.0 + e) / (fabs(p[EXO_P_CLIGHT]) - vmax);
     wd = (dmax >= 0.0 ? dmax : __builtin_inf()) * fabs(nrev) * 1.05;   // (NaN or v >= c: no window)
   }
-  if (sd != 0 || which != 0) return;
+  // (valid on the lanes with sd == 0, which == 0: event 0 -> w[0..3], w[5]; event 1 -> w[4], w[6])
   if (k == 0) {
-    o[0] = nrev;
-    o[1] = bounded ? -fma(p[EXO_P_TP], nrev, mid) : -p[EXO_P_TP] * nrev;
-    o[2] = (bounded && (flags & EXO_FLAG_SECONDARY)) ? mid - mid_other : 0.0;
-    o[3] = half + wd;
-    o[5] = inner;
+    w[0] = nrev;
+    w[1] = bounded ? -fma(p[EXO_P_TP], nrev, mid) : -p[EXO_P_TP] * nrev;
+    w[2] = (bounded && (flags & EXO_FLAG_SECONDARY)) ? mid - mid_other : 0.0;
+    w[3] = half + wd;
+    w[5] = inner;
   } else {
-    o[4] = half + wd;
-    o[6] = inner;
+    w[4] = half + wd;
+    w[6] = inner;
+  }
+}
+
+
+__global__ __launch_bounds__(kBlock) void transit_window_kernel(const double* __restrict__ params, int64_t n_rec,
+                                                                uint32_t flags, double* __restrict__ out,
+                                                                const double* __restrict__ t = nullptr, int64_t n_cad = 0,
+                                                                int32_t* __restrict__ sorted = nullptr,
+                                                                int32_t* __restrict__ done = nullptr, int64_t n_done = 0) {
+  const int n_rec_blocks = (int)((n_rec * kWinLanes + kBlock - 1) / kBlock);
+  // (the per-draw block counters of the sweep that follows: transit_runs_kernel)
+  if (done && (int64_t)blockIdx.x * kBlock + threadIdx.x < n_done) done[(int64_t)blockIdx.x * kBlock + threadIdx.x] = 0;
+  if ((int)blockIdx.x >= n_rec_blocks) {
+    const int sb = blockIdx.x - n_rec_blocks;
+    const int64_t b0 = (int64_t)sb * kSortBlock;
+    bool ok = true;
+    for (int64_t k = b0 + threadIdx.x; k < b0 + kSortBlock && k + 1 < n_cad; k += kBlock) ok = ok && (t[k] <= t[k + 1]);   // NaN: not sorted
+    const int all = __syncthreads_and(ok ? 1 : 0);
+    if (threadIdx.x == 0) sorted[sb] = all;
+    return;
+  }
+  const int64_t gid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const int64_t i = gid / kWinLanes;
+  const int sub = (int)(gid - i * kWinLanes);
+  if (i >= n_rec) return;   // (whole groups of eight: the shuffles below stay within a record)
+  double w[kWin] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  window_lanes(params + i * EXO_NPAR, flags, sub, w);
+  double* o = out + kWin * i;
+  if (flags & EXO_FLAG_WINDOW) {
+    if (sub == 0)
+      for (int q = 0; q < kWin; ++q) o[q] = w[q];
+  } else if (sub == 0) {
+    o[0] = w[0]; o[1] = w[1]; o[2] = w[2]; o[3] = w[3]; o[5] = w[5];
+  } else if (sub == 2) {
+    o[4] = w[4]; o[6] = w[6];
   }
 }
 
@@ -1527,16 +1543,36 @@ __device__ __forceinline__ void enum_prefix(int (*s_len)[kRunMax + 1], int K, in
 }
 
 // One wave per list (draw, planet, event: 0 = transits, 1 = occultations).
+// FUSED (EXO_FLAG_SORTED_TIMES: the caller vouches for non-decreasing times, so nothing has to be checked before the
+// searches): the wave works its record's conjunction windows out itself -- every group of eight lanes the same record, lane 0
+// and lane 2 hold the result -- and the list of event 0 leaves them in `windows_out` for the sweep: no transit_window_kernel
+// launch (each of these short kernels is ~5 us of dispatch and dependent memory round trips before its first useful cycle).
+template <bool FUSED>
 __global__ __launch_bounds__(64) void transit_enum_kernel(const double* __restrict__ t, int64_t n_cad,
                                                           const double* __restrict__ texp, int64_t n_texp,
                                                           const double* __restrict__ stencil_dt, int n_sub, uint32_t flags,
                                                           const double* __restrict__ windows,
                                                           const int32_t* __restrict__ sorted, int n_sorted, int n_ev,
-                                                          RunLists rl) {
+                                                          RunLists rl, const double* __restrict__ params = nullptr,
+                                                          double* __restrict__ windows_out = nullptr) {
   __shared__ int s_len[2][kRunMax + 1];
   const int64_t list = blockIdx.x, rec = list / n_ev;
   const int ev = (int)(list - rec * n_ev), lane = threadIdx.x;
-  const double* wv = windows + kWin * rec;
+  double wv[kWin];
+  if (FUSED) {
+    double w[kWin] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    window_lanes(params + rec * EXO_NPAR, flags, lane & 7, w);
+    const bool every = flags & EXO_FLAG_WINDOW;   // (every lane holds all seven)
+#pragma unroll
+    for (int q = 0; q < kWin; ++q) wv[q] = __shfl(w[q], (!every && (q == 4 || q == 6)) ? 2 : 0, 64);
+    if (ev == 0 && lane == 0) {
+#pragma unroll
+      for (int q = 0; q < kWin; ++q) windows_out[kWin * rec + q] = wv[q];
+    }
+  } else {
+#pragma unroll
+    for (int q = 0; q < kWin; ++q) wv[q] = windows[kWin * rec + q];
+  }
   const double nrev = wv[0], c0 = wv[1], dmid = wv[2];
   // the windows are widened by the half-span of the exposure stencil; the reference widens its
   // contact windows by texp / 2 whatever the stencil (keplerian.py:765-769)
@@ -1547,8 +1583,10 @@ __global__ __launch_bounds__(64) void transit_enum_kernel(const double* __restri
   const double widen = fabs(te) * span * fabs(nrev);
   const double h0 = wv[3] + widen, h1 = wv[4] + widen;
   bool srt = true;
-  for (int i = lane; i < n_sorted; i += 64) srt = srt && (sorted[i] != 0);
-  srt = __all(srt);
+  if (!FUSED) {
+    for (int i = lane; i < n_sorted; i += 64) srt = srt && (sorted[i] != 0);
+    srt = __all(srt);
+  }
   // the list degenerates to "every cadence" unless its windows are bounded, periodic in t and disjoint
   // (the decision is the same for both events of a planet: it only uses what they share)
   const double x_first = fma(t[0], nrev, c0), x_last = fma(t[n_cad - 1], nrev, c0);
@@ -2585,17 +2623,23 @@ inline int launch_runs_sweep(const double* t, int64_t n_cad, const double* texp,
   const bool grad = gflux != nullptr || chi2;
   const int n_ev = secondary ? 2 : 1;
   const dim3 block(kBlock);
-  {
+  const bool has_ttv = ttv && ttv->edges;
+  // sorted times on the caller's word and no fence counters to clear: windows and runs in ONE launch
+  const bool fused_enum = (flags & EXO_FLAG_SORTED_TIMES) && !has_ttv && EXO_RUNS_FOLD_FINISH != 2;
+  if (!fused_enum) {
     const int64_t n_rec = n_draw * n_planet;
     hipLaunchKernelGGL(transit_window_kernel, dim3((unsigned)((n_rec * kWinLanes + kBlock - 1) / kBlock + w.n_sorted)), block, 0, st,
                        params, n_rec, flags, w.windows, t, n_cad, w.sorted, w.done, n_draw);
   }
-  const bool has_ttv = ttv && ttv->edges;
-  if (has_ttv)
+  if (fused_enum)
+    hipLaunchKernelGGL(transit_enum_kernel<true>, dim3((unsigned)(n_draw * n_planet * n_ev)), dim3(64), 0, st, t, n_cad, texp,
+                       n_texp, stencil_dt, (int)n_sub, flags, (const double*)nullptr, (const int32_t*)nullptr, 0, n_ev, w.rl,
+                       params, w.windows);
+  else if (has_ttv)
     hipLaunchKernelGGL(transit_enum_ttv_kernel, dim3((unsigned)(n_draw * n_planet)), dim3(64), 0, st, t, n_cad, texp, n_texp,
                        stencil_dt, (int)n_sub, flags, w.windows, w.sorted, w.n_sorted, w.rl, *ttv);
   else
-    hipLaunchKernelGGL(transit_enum_kernel, dim3((unsigned)(n_draw * n_planet * n_ev)), dim3(64), 0, st, t, n_cad, texp,
+    hipLaunchKernelGGL(transit_enum_kernel<false>, dim3((unsigned)(n_draw * n_planet * n_ev)), dim3(64), 0, st, t, n_cad, texp,
                        n_texp, stencil_dt, (int)n_sub, flags, w.windows, w.sorted, w.n_sorted, n_ev, w.rl);
   if (launch_status() != EXO_OK) return EXO_ERR_LAUNCH;
   // the values are kept when somebody reads them: the dense output's last kernel, or the caller (sparse)

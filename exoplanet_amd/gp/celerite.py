@@ -138,28 +138,14 @@ def celerite_loglike(t, resid, diag, coef_real, coef_complex, obs=None, pair_kin
                                   None if pair_kind is None else pair_kind.detach(), n_chunks)
 
 
-_SORTED = {}
 _CONST_VAR = {}   # (n, device, yerr) -> the variance vector of a scalar error bar (a handful of series at most)
 
 
 def _known_sorted(t):
-    """True if ``t`` is non-decreasing.  A device tensor is looked at once (one host synchronisation) and remembered
-    by object and version -- the entry keeps the tensor alive, so its address cannot be handed to another series
-    meanwhile: a sampler calls ``compute`` with the same time array every step, and a step that is being captured
-    into a hipGraph must not synchronise."""
-    if not t.is_cuda:
-        return not bool((t[1:] < t[:-1]).any())
-    key = (id(t), t._version)
-    hit = _SORTED.get(key)
-    if hit is not None and hit[1] is t:
-        return hit[0]
-    if torch.cuda.is_current_stream_capturing():
-        return True   # cannot look during a capture; the warm-up runs before it did
-    ok = not bool((t[1:] < t[:-1]).any())
-    if len(_SORTED) >= 8:      # (an entry keeps its time array alive: a handful of series, not dozens -- ADVICE r2)
-        _SORTED.clear()
-    _SORTED[key] = (ok, t)
-    return ok
+    """ops.known_sorted: looked at once per (storage, version); inside a hipGraph capture an unseen tensor passes"""
+    from ..ops import known_sorted
+
+    return known_sorted(t, unknown=True)
 
 
 class GaussianProcess:

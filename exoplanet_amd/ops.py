@@ -15,6 +15,8 @@ the time array and the flux array; ``ttv=`` for a TTVOrbit's timing tables),
 run hand-written HIP kernels through the C ABI (include/exoplanet_amd.h); each
 has value + gradient (torch.autograd).  There is no CPU / eager fallback.
 """
+import os
+
 import torch
 
 from . import _lib
@@ -30,10 +32,43 @@ FLAG_EXACT_SCAN = 16
 FLAG_SPARSE = 32
 FLAG_LIGHT_DELAY = 64
 FLAG_CADENCE_MAJOR = 128   # summed dense flux / its cotangent as [cadence][draw] arrays (include/exoplanet_amd.h)
+FLAG_SORTED_TIMES = 256    # t has been checked to be non-decreasing (known_sorted): windows and runs in one launch
 NIN = 10
 (IN_PERIOD, IN_T0, IN_B, IN_ECC, IN_OMEGA, IN_R, IN_MSTAR, IN_RSTAR, IN_MPLANET, IN_SBR) = range(10)
 MAX_PLANETS = 16
 MAX_SUBEXP = 63
+
+
+_SORTED = {}
+
+
+def known_sorted(t, unknown=True):
+    """True if ``t`` is non-decreasing.  A device tensor is looked at once (one host synchronisation) and remembered
+    by storage and version -- the entry keeps the tensor alive, so its address cannot be handed to another series
+    meanwhile: a sampler evaluates on the same time array every step, and a step that is being captured into a hipGraph
+    must not synchronise (``unknown``: the answer then, for a tensor never looked at)."""
+    if not t.is_cuda:
+        return not bool((t[1:] < t[:-1]).any())
+    # (by storage address, extent and version: `t.detach()` is a new object on the same storage with the same version
+    # counter; the entry holds a tensor on that storage, so the address is not reused while it is here)
+    key = (t.data_ptr(), t.numel(), t.stride(0) if t.dim() else 0, t._version)
+    hit = _SORTED.get(key)
+    if hit is not None:
+        return hit[0]
+    if torch.cuda.is_current_stream_capturing():
+        return unknown   # cannot look during a capture; the warm-up runs before it did
+    ok = not bool((t[1:] < t[:-1]).any())
+    if len(_SORTED) >= 8:      # (an entry keeps its time array alive: a handful of series, not dozens -- ADVICE r2)
+        _SORTED.clear()
+    _SORTED[key] = (ok, t)
+    return ok
+
+
+def _sorted_flag(t):
+    """FLAG_SORTED_TIMES when the sweep may skip its own check of ``t`` (never on a guess)"""
+    if os.environ.get("EXO_CHECK_SORTED_ON_DEVICE") == "1":     # (A/B: the sweep's own check, every call)
+        return 0
+    return FLAG_SORTED_TIMES if (t.numel() > 1 and known_sorted(t, unknown=False)) else 0
 
 
 def _stream(t):
@@ -227,6 +262,7 @@ class _TransitFlux(torch.autograd.Function):
     def forward(ctx, t, texp, stencil_dt, stencil_w, params, ld, flags, ttv_edges, ttv_shift):
         t, texp, n_texp, sdt, sw, n_sub, params, ld, D, P = _transit_args(
             t, texp, stencil_dt, stencil_w, params, ld, flags)
+        flags |= _sorted_flag(t)
         edges, shift, n_edge = _ttv_args(None if ttv_edges is None else (ttv_edges, ttv_shift), D, P)
         N = t.numel()
         shape = (D, N, P) if flags & FLAG_PER_PLANET else (D, N)
@@ -270,6 +306,7 @@ class _TransitFlux(torch.autograd.Function):
 
 def _vjp(t, texp, n_texp, sdt, sw, n_sub, params, ld, D, P, flags, gflux, want_flux, events=(None, None), ttv=None):
     N = t.numel()
+    flags |= _sorted_flag(t)
     shape = (D, N, P) if flags & FLAG_PER_PLANET else (D, N)
     if isinstance(gflux, torch.Tensor) and tuple(gflux.shape) != shape:
         raise ValueError(f"gflux must have shape {shape}")
@@ -409,6 +446,7 @@ class _TransitChi2(torch.autograd.Function):
                 "transit_chi2 is not differentiable with respect to obs / ivar: per-draw error bars go through "
                 "white_noise_loglike(yerr=(n_draw, 1) tensor), anything else through get_light_curve(total=True) and torch")
         t, texp, n_texp, sdt, sw, n_sub, params, ld, D, P = _transit_args(t, texp, stencil_dt, stencil_w, params, ld, flags)
+        flags |= _sorted_flag(t)
         edges, shift, n_edge = _ttv_args(None if ttv_edges is None else (ttv_edges, ttv_shift), D, P)
         N = t.numel()
         obs = _dev(obs, "obs")
@@ -603,6 +641,7 @@ def transit_flux_sparse(t, params, ld, gflux=None, texp=None, stencil_dt=None, s
     timing tables (transits only)."""
     flags = int(flags) | FLAG_SPARSE
     t, texp, n_texp, sdt, sw, n_sub, params, ld, D, P = _transit_args(t, texp, stencil_dt, stencil_w, params, ld, flags)
+    flags |= _sorted_flag(t)
     edges, shift, n_edge = _ttv_args(ttv, D, P)
     if n_edge and flags & FLAG_SECONDARY:
         raise ValueError("the sparse sweep takes timing tables for transits only")
@@ -1130,6 +1169,7 @@ class _OrbitLoglike(torch.autograd.Function):
                 *cols):
         params, ld, keep, meta = _pack_cols_forward(cols, n_ld, n_draw, pack_flags)
         t, texp, n_texp, sdt, sw, n_sub, params, ld, D, P = _transit_args(t, texp, stencil_dt, stencil_w, params, ld, flags)
+        flags |= _sorted_flag(t)
         edges, shift, n_edge = _ttv_args(None if ttv_edges is None else (ttv_edges, ttv_shift), D, P)
         N = t.numel()
         lib = _lib.load()

@@ -127,6 +127,11 @@ int exo_contact_points_f64(const double* a, const double* e, const double* cosw,
                                       Run-enumeration sweeps only (see EXO_FLAG_SPARSE); not with
                                       EXO_FLAG_PER_PLANET (EXO_ERR_INVALID_ARGUMENT).                            */
 
+#define EXO_FLAG_SORTED_TIMES 256u /* the caller has CHECKED that t is non-decreasing (the sweep otherwise checks it on
+                                     the device, every call, in a launch of its own before the searches): windows and runs
+                                     then come out of one launch.  With unsorted times under this flag the results are
+                                     undefined; without it unsorted times are merely slow (every cadence solved).     */
+
 #define EXO_MAX_PLANETS 16
 #define EXO_MAX_SUBEXP 63
 
