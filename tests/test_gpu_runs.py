@@ -173,3 +173,35 @@ def test_folded_finish_equals_the_separate_last_kernel(dev, planets):
     assert same_flux(big[0][:8], small[0])
     for a, b in zip(big[1:], small[1:]):
         assert float((a[:8] - b).abs().max()) <= 1e-12 * float(b.abs().max())
+
+
+@pytest.mark.parametrize("planets,secondary,window", [(1, False, False), (3, False, False), (1, True, False), (3, False, True)])
+def test_windows_and_runs_in_one_launch(dev, planets, secondary, window, monkeypatch):
+    """EXO_FLAG_SORTED_TIMES (set by the torch layer once it has looked at the time array): the enumeration kernel works the
+    windows out itself -- the same runs, the same values, the same gradients as with the device's own check and the
+    window kernel in front, bit for bit; an unsorted array never gets the flag"""
+    from exoplanet_amd import ops
+
+    rng = np.random.default_rng(7 + planets)
+    D, N = 9, 20_011
+    t = T(np.arange(N) * (2.0 / 1440.0) + 0.25, dev)
+    rec, c = system(rng, D, planets, secondary, window=window)
+    flags = (ops.FLAG_SECONDARY if secondary else 0) | (ops.FLAG_WINDOW if window else 0)
+    dt, w = P.exposure_stencil(5, 1)
+    kw = dict(texp=T([0.02], dev), stencil_dt=T(dt, dev), stencil_w=T(w, dev))
+    g = T(rng.normal(size=(D, N)), dev)
+    out = {}
+    for on_device in ("1", "0"):
+        monkeypatch.setenv("EXO_CHECK_SORTED_ON_DEVICE", on_device)
+        assert ops._sorted_flag(t) == (0 if on_device == "1" else ops.FLAG_SORTED_TIMES)
+        sp, gp, gl, dot = ops.transit_flux_sparse(t, T(rec, dev), T(c, dev), gflux=g, flags=flags, **kw)
+        f, gp2, gl2 = ops.transit_flux_value_and_vjp(t, T(rec, dev), T(c, dev), g, flags=flags, **kw)
+        out[on_device] = (sp.to_dense(), sp.n_solved(), gp.clone(), gl.clone(), dot.clone(), f.clone(), gp2.clone())
+    a, b = out["1"], out["0"]
+    assert a[1] == b[1] and np.array_equal(a[0], b[0])
+    for x, y in zip(a[2:], b[2:]):
+        assert torch.equal(x, y)
+    monkeypatch.setenv("EXO_CHECK_SORTED_ON_DEVICE", "0")
+    tu = t.clone()
+    tu[100], tu[101] = t[101], t[100]
+    assert ops._sorted_flag(tu) == 0
