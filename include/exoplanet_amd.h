@@ -9,7 +9,9 @@
  *
  * Conventions
  *   - all pointers are DEVICE pointers (HBM), float64, C-contiguous (the column-form packing entry points take
- *     HOST arrays of device pointers and say so);
+ *     HOST arrays of device pointers and say so); ordinary hipMalloc memory (coarse-grained): the summed flux of
+ *     several planets and the cotangents of timing shifts are accumulated with the hardware's fp64 atomics, which
+ *     fine-grained / host-mapped allocations do not offer;
  *   - `stream` is a hipStream_t passed as void* (NULL = the null stream);
  *     calls are asynchronous and stream-ordered, nothing is allocated inside;
  *   - return value: 0 = launched, EXO_ERR_* otherwise (no exceptions cross the
