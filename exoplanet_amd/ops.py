@@ -310,15 +310,18 @@ def _vjp(t, texp, n_texp, sdt, sw, n_sub, params, ld, D, P, flags, gflux, want_f
     shape = (D, N, P) if flags & FLAG_PER_PLANET else (D, N)
     if isinstance(gflux, torch.Tensor) and tuple(gflux.shape) != shape:
         raise ValueError(f"gflux must have shape {shape}")
-    # the cotangent as it comes: cadence-major (the celerite kernels' gradient of a cadence-major model) or rows
-    if is_cadence_major(gflux) and not flags & FLAG_PER_PLANET:
+    edges, shift, n_edge = _ttv_args(ttv, D, P)
+    # the cotangent as it comes: cadence-major (the celerite kernels' gradient of a cadence-major model) or rows.  Only the
+    # run-enumeration sweeps read it cadence-major (include/exoplanet_amd.h): anything else gets rows
+    cm_sweep = (n_texp <= 1 and not flags & (FLAG_EXACT_SCAN | FLAG_PER_PLANET)
+                and not (n_edge and flags & (FLAG_SECONDARY | FLAG_LIGHT_DELAY)))
+    if is_cadence_major(gflux) and cm_sweep:
         flags |= FLAG_CADENCE_MAJOR
-    elif flags & FLAG_CADENCE_MAJOR and want_flux:
+    elif flags & FLAG_CADENCE_MAJOR and want_flux and cm_sweep:
         gflux = _dev(gflux, "gflux").t().contiguous().t()
     else:
         flags &= ~FLAG_CADENCE_MAJOR
         gflux = _dev(gflux, "gflux")
-    edges, shift, n_edge = _ttv_args(ttv, D, P)
     lib = _lib.load()
     nbytes = lib.exo_transit_flux_workspace_bytes(N, D, P)
     ws = torch.empty(max(nbytes // 8 + 1, 1), dtype=torch.float64, device=t.device)

@@ -161,3 +161,22 @@ def test_cadence_major_on_the_other_sweeps(dev, kind):
     assert torch.equal(out[False][0], out[True][0])
     for a, b in zip(out[False][1], out[True][1]):
         assert torch.equal(a, b)
+
+
+def test_cadence_major_cotangent_where_the_sweep_wants_rows(dev):
+    """a cadence-major cotangent handed to a sweep that only reads rows (per-cadence exposure times: the list path) is
+    converted, not refused"""
+    import exoplanet_amd as xo
+
+    D, N = 6, 3001
+    xo_, L, r, orbit = _system(dev, D, 1, seed=5)
+    t = torch.arange(N, dtype=torch.float64, device=dev) * (2.0 / 1440.0)
+    texp = torch.full((N,), 0.02, dtype=torch.float64, device=dev)
+    star = xo.LimbDarkLightCurve(0.3, 0.2)
+    g = torch.randn(D, N, dtype=torch.float64, device=dev, generator=torch.Generator(device=dev).manual_seed(8))
+    lc = star.get_light_curve(orbit=orbit(), r=r, t=t, texp=texp, total=True, cadence_major=True)
+    assert lc.stride() == (N, 1)               # (not offered here: rows)
+    (a,) = torch.autograd.grad((lc * g).sum(), [r])
+    lc = star.get_light_curve(orbit=orbit(), r=r, t=t, texp=texp, total=True)
+    (b,) = torch.autograd.grad(lc, [r], grad_outputs=g.t().contiguous().t())
+    assert torch.equal(a, b)
