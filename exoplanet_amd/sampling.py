@@ -59,13 +59,14 @@ class _ChainSampler:
 
     # all parameter blocks of a chain side by side in ONE (D, n) array: an update of positions or momenta is one launch
     # whatever the number of blocks; logp_fn sees views of it
-    def _flat(self, parts):
-        return torch.cat([x.reshape(self.D, -1) for x in parts], dim=1)
+    def _flat(self, parts, out=None):
+        return torch.cat([x.reshape(self.D, -1) for x in parts], dim=1, out=out)
 
     def _parts(self, flat):
         return [x.reshape(shp) for x, shp in zip(torch.split(flat, self._sizes, dim=1), self._shapes)]
 
-    def _value_and_grad_flat(self, q):
+    def _value_and_grad_flat(self, q, grad_out=None):
+        """(logp (D,), its gradient as a flat (D, n) array); ``grad_out``: write the gradient there (no copy afterwards)"""
         with torch.enable_grad():
             parts = self._parts(q.detach().requires_grad_(True))
             lp = self.logp_fn(*parts)
@@ -74,7 +75,7 @@ class _ChainSampler:
             if ones is None or ones.shape != lp.shape or ones.device != lp.device:
                 ones = self._unit = torch.ones_like(lp).detach()
             grads = torch.autograd.grad(lp, parts, grad_outputs=ones)
-        return lp.detach(), self._flat([g.detach() for g in grads])
+        return lp.detach(), self._flat([g.detach() for g in grads], out=grad_out)
 
     def _momenta(self):
         return [torch.randn(q.shape, dtype=q.dtype, device=q.device, generator=self.generator) * torch.sqrt(m)
@@ -323,8 +324,8 @@ class NUTS(_ChainSampler):
         st = self._st
         if self._native is not None:
             self._phase(0)
-            lp, g = self._value_and_grad_flat(st["qn"])
-            st["gn"].copy_(g); st["lpn"].copy_(lp)
+            lp, _ = self._value_and_grad_flat(st["qn"], grad_out=st["gn"])     # (the gradient lands in the leaf's buffer)
+            st["lpn"].copy_(lp)
             self._phase(1)
             return st["on"]
         st["leaf"].add_(1)
