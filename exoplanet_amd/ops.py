@@ -42,33 +42,34 @@ MAX_SUBEXP = 63
 _SORTED = {}
 
 
-def known_sorted(t, unknown=True):
+def known_sorted(t, unknown=True, nan_ok=True):
     """True if ``t`` is non-decreasing.  A device tensor is looked at once (one host synchronisation) and remembered
     by storage and version -- the entry keeps the tensor alive, so its address cannot be handed to another series
     meanwhile: a sampler evaluates on the same time array every step, and a step that is being captured into a hipGraph
-    must not synchronise (``unknown``: the answer then, for a tensor never looked at)."""
+    must not synchronise (``unknown``: the answer then, for a tensor never looked at).  ``nan_ok=False``: every
+    neighbouring pair must compare as ordered -- a NaN among the times makes the answer False (what the sweep's own
+    device check says: it then solves every cadence instead of searching)."""
     if not t.is_cuda:
-        return not bool((t[1:] < t[:-1]).any())
+        return bool((t[1:] >= t[:-1]).all()) if not nan_ok else not bool((t[1:] < t[:-1]).any())
     # (by storage address, extent and version: `t.detach()` is a new object on the same storage with the same version
     # counter; the entry holds a tensor on that storage, so the address is not reused while it is here)
     key = (t.data_ptr(), t.numel(), t.stride(0) if t.dim() else 0, t._version)
     hit = _SORTED.get(key)
-    if hit is not None:
-        return hit[0]
-    if torch.cuda.is_current_stream_capturing():
-        return unknown   # cannot look during a capture; the warm-up runs before it did
-    ok = not bool((t[1:] < t[:-1]).any())
-    if len(_SORTED) >= 8:      # (an entry keeps its time array alive: a handful of series, not dozens -- ADVICE r2)
-        _SORTED.clear()
-    _SORTED[key] = (ok, t)
-    return ok
+    if hit is None:
+        if torch.cuda.is_current_stream_capturing():
+            return unknown   # cannot look during a capture; the warm-up runs before it did
+        both = torch.stack([~(t[1:] < t[:-1]).any(), (t[1:] >= t[:-1]).all()]).cpu()     # one synchronisation
+        if len(_SORTED) >= 8:      # (an entry keeps its time array alive: a handful of series, not dozens -- ADVICE r2)
+            _SORTED.clear()
+        hit = _SORTED[key] = (bool(both[0]), bool(both[1]), t)
+    return hit[0] if nan_ok else hit[1]
 
 
 def _sorted_flag(t):
-    """FLAG_SORTED_TIMES when the sweep may skip its own check of ``t`` (never on a guess)"""
+    """FLAG_SORTED_TIMES when the sweep may skip its own check of ``t`` (never on a guess, never with a NaN among the times)"""
     if os.environ.get("EXO_CHECK_SORTED_ON_DEVICE") == "1":     # (A/B: the sweep's own check, every call)
         return 0
-    return FLAG_SORTED_TIMES if (t.numel() > 1 and known_sorted(t, unknown=False)) else 0
+    return FLAG_SORTED_TIMES if (t.numel() > 1 and known_sorted(t, unknown=False, nan_ok=False)) else 0
 
 
 def _stream(t):

@@ -205,3 +205,24 @@ def test_windows_and_runs_in_one_launch(dev, planets, secondary, window, monkeyp
     tu = t.clone()
     tu[100], tu[101] = t[101], t[100]
     assert ops._sorted_flag(tu) == 0
+
+
+def test_a_nan_among_the_times_never_gets_the_sorted_flag(dev):
+    """the torch layer's look at the time array says "unordered" for a NaN, as the device's own check does: the sweep then
+    solves every cadence, and the finite cadences keep their flux"""
+    from exoplanet_amd import ops
+
+    rng = np.random.default_rng(3)
+    D, N = 4, 5003
+    tt = np.arange(N) * (2.0 / 1440.0) + 0.25
+    rec, c = system(rng, D)
+    f_ref = ops.transit_flux(T(tt, dev), T(rec, dev), T(c, dev))
+    tn = tt.copy()
+    tn[777] = np.nan
+    t = T(tn, dev)
+    assert ops._sorted_flag(t) == 0 and ops.known_sorted(t) and not ops.known_sorted(t, nan_ok=False)
+    f = ops.transit_flux(t, T(rec, dev), T(c, dev))
+    keep = np.ones(N, bool)
+    keep[777] = False
+    assert same_flux(f[:, keep], f_ref[:, keep])
+    assert float(f_ref.min()) < -1e-3
