@@ -196,7 +196,7 @@ class Workload:
 
 def workload_c2(xo, ops, dev, D, rank=0, events=None):
     """BASELINE configs[1] (module docstring).  `events`: a HipEvents object -> `fn.eager(i)` records pair i around the sweep."""
-    t = torch.arange(N_CAD, dtype=torch.float64, device=dev) * CADENCE
+    t = ops.vouch_sorted(torch.arange(N_CAD, dtype=torch.float64, device=dev) * CADENCE)   # (a fixed series: the caller's word)
     gbar = torch.as_tensor(np.random.default_rng(2 + rank).normal(size=(D, N_CAD)), device=dev)
     leaves = make_leaves(D, 100 + rank, dev)
     names = list(leaves)
@@ -223,7 +223,7 @@ C3_HYPER = (1e-3, 5.0, 0.7071)       # SHOTerm(sigma, rho, Q) of SURVEY.md 8d C3
 def workload_c3(xo, ops, dev, D, rank=0):
     """BASELINE configs[2] (C3): the C2 light curve + a celerite SHO-term GP log-likelihood on the residual; value +
     gradient w.r.t. the orbit / limb-darkening leaves and the kernel hyper-parameters (sigma, rho, Q) per draw"""
-    t = torch.arange(N_CAD, dtype=torch.float64, device=dev) * CADENCE
+    t = ops.vouch_sorted(torch.arange(N_CAD, dtype=torch.float64, device=dev) * CADENCE)   # (a fixed series: the caller's word)
     yobs = torch.as_tensor(5e-4 * np.random.default_rng(3).normal(size=N_CAD), device=dev)     # (the data: same on every rank)
     leaves = make_leaves(D, 100 + rank, dev)
     for k, v in zip(("sigma", "rho", "Q"), C3_HYPER):
@@ -257,7 +257,7 @@ def workload_c4(xo, ops, dev, D, rank=0):
     per draw; D = this rank's share of the 512 draws (64 on each of 8 GPUs)"""
     rng = np.random.default_rng(4 + 1000 * rank)
     n = C4_NCAD
-    t = torch.arange(n, dtype=torch.float64, device=dev) * CADENCE
+    t = ops.vouch_sorted(torch.arange(n, dtype=torch.float64, device=dev) * CADENCE)
     leaves = {}
     for k, v in C4_BASE.items():
         x = np.asarray(v)[None, :] * (1 + 1e-3 * rng.normal(size=(D, 4)))
@@ -290,7 +290,7 @@ def workload_c5(xo, ops, dev, D, rank=0):
     D = this rank's share of the 1024 chains (128 on each of 8 GPUs)"""
     rng = np.random.default_rng(5 + 1000 * rank)
     n, texp = C5_NCAD, C5_TEXP
-    t = torch.arange(n, dtype=torch.float64, device=dev) * texp
+    t = ops.vouch_sorted(torch.arange(n, dtype=torch.float64, device=dev) * texp)
     mk = lambda v: torch.tensor(v * (1 + 1e-3 * rng.normal(size=(D, 1))), dtype=torch.float64, device=dev,  # noqa: E731
                                 requires_grad=True)
     leaves = {k: mk(v) for k, v in C5_BASE.items()}
@@ -683,7 +683,7 @@ def extra_gp_conditioning(xo, ops, dev, D):
     critical damping; a Matern-3/2 term (celerite2's eps = 0.01 approximation: b / a = 100); a RotationTerm whose
     second mode sits near Q = 1/2 -- the cases DESIGN.md 3.5 used to send to the sequential kernels."""
     T = xo.gp.terms
-    t = torch.arange(N_CAD, dtype=torch.float64, device=dev) * CADENCE
+    t = ops.vouch_sorted(torch.arange(N_CAD, dtype=torch.float64, device=dev) * CADENCE)   # (a fixed series: the caller's word)
     y = torch.as_tensor(5e-4 * np.random.default_rng(3).normal(size=N_CAD), device=dev)
     # (the mean model draws-innermost, as the C3 step hands it over: get_light_curve(cadence_major=True))
     model = torch.zeros(N_CAD, D, dtype=torch.float64, device=dev).t().requires_grad_(True)
@@ -765,7 +765,7 @@ def extra_hmc(xo, ops, dev, D=1024, n_leapfrog=8, dense=False, nuts=False):
     """8f row 4: one HMC trajectory (n_leapfrog value + gradient evaluations of the C2 likelihood and the position /
     momentum updates between them) for D chains, replayed as one hipGraph"""
     rng = np.random.default_rng(8)
-    t = torch.arange(N_CAD, dtype=torch.float64, device=dev) * CADENCE
+    t = ops.vouch_sorted(torch.arange(N_CAD, dtype=torch.float64, device=dev) * CADENCE)   # (a fixed series: the caller's word)
     lv = make_leaves(D, 11, dev)
     names = [k for k in lv if k not in ("u1", "u2")]
     u1, u2 = lv["u1"].detach(), lv["u2"].detach()
@@ -865,6 +865,17 @@ def load_counters():
         return None
 
 
+def launcher_argv(n_gpus, argv):
+    """The command `python bench.py --gpus N ...` turns itself into when it was not started by a launcher."""
+    import socket
+
+    with socket.socket() as sk:          # a free port now is a free port a moment later, near enough, on a private box
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(argv[0])] + list(argv[1:])
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -884,9 +895,16 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world == 1 and args.gpus > 1:
+        # `python bench.py --gpus N` called directly (the form of the driver's recorded command): become the launcher --
+        # one rank per GPU of this node under torch.distributed.run, rendezvous on the loopback address (the container's
+        # hostname may not resolve), the same argument list
+        if "WORLD_SIZE" in os.environ or os.environ.get("EXO_BENCH_NO_REEXEC") == "1":
+            raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={os.environ.get('WORLD_SIZE')}: launch with "
+                             "torch.distributed.run --nproc-per-node N")
+        os.execv(sys.executable, launcher_argv(args.gpus, sys.argv))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+        raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE={world}")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None

@@ -1586,6 +1586,13 @@ __global__ __launch_bounds__(64) void transit_enum_kernel(const double* __restri
   if (!FUSED) {
     for (int i = lane; i < n_sorted; i += 64) srt = srt && (sorted[i] != 0);
     srt = __all(srt);
+  } else {
+    // the caller's word covers the order of NEIGHBOURING cadences; the series as a whole is looked at here, coarsely: 65
+    // evenly spaced cadences must ascend (a NaN fails), else the list is "every cadence".  What this catches is a time
+    // buffer refilled with another, unordered series under a flag that was baked into a captured launch; two swapped
+    // neighbours it cannot see (that is what the unflagged sweep's own check is for).  Two independent loads per lane.
+    const int64_t i0 = (n_cad - 1) * lane / 64, i1 = (n_cad - 1) * (lane + 1) / 64;
+    srt = __all(t[i0] <= t[i1]);
   }
   // the list degenerates to "every cadence" unless its windows are bounded, periodic in t and disjoint
   // (the decision is the same for both events of a planet: it only uses what they share)
@@ -2723,6 +2730,10 @@ inline int launch_runs_sweep(const double* t, int64_t n_cad, const double* texp,
   return launch_status();
 }
 
+// every flag bit a sweep knows; anything else is a newer header talking to this library (ABI 10: refused, not ignored --
+// a layout flag this build does not know would otherwise come back as a silently different array)
+inline bool sweep_flags_ok(uint32_t flags) { return (flags & ~(uint32_t)EXO_FLAG_SWEEP_ALL) == 0; }
+
 inline bool transit_args_ok(int64_t n_cad, int64_t n_texp, int32_t n_sub, int64_t n_draw, int32_t n_planet) {
   return n_cad >= 0 && n_draw >= 0 && n_draw <= 65535 && n_planet >= 1 && n_planet <= EXO_MAX_PLANETS &&
          n_sub >= 1 && n_sub <= EXO_MAX_SUBEXP && (n_texp == 0 || n_texp == 1 || n_texp == n_cad);
@@ -2732,7 +2743,7 @@ inline bool transit_args_ok(int64_t n_cad, int64_t n_texp, int32_t n_sub, int64_
 
 extern "C" {
 
-int32_t exo_abi_version(void) { return 9; }
+int32_t exo_abi_version(void) { return EXO_ABI_VERSION; }
 
 int exo_kepler_f64(const double* M, const double* ecc, double* sinf, double* cosf, int64_t n, void* stream) {
   if (n < 0 || (n > 0 && (!M || !ecc || !sinf || !cosf))) return EXO_ERR_INVALID_ARGUMENT;
@@ -2796,7 +2807,7 @@ static int transit_fwd(const double* t, int64_t n_cad, const double* texp, int64
                        const double* stencil_w, int32_t n_sub, const double* params, const double* ld,
                        int64_t n_draw, int32_t n_planet, uint32_t flags, const Ttv& ttv, double* flux,
                        void* workspace, int64_t workspace_bytes, void* stream, void* ev_start, void* ev_stop) {
-  if (!transit_args_ok(n_cad, n_texp, n_sub, n_draw, n_planet)) return EXO_ERR_INVALID_ARGUMENT;
+  if (!transit_args_ok(n_cad, n_texp, n_sub, n_draw, n_planet) || !sweep_flags_ok(flags)) return EXO_ERR_INVALID_ARGUMENT;
   if (n_cad == 0 || n_draw == 0) return EXO_OK;
   if (!t || !params || !ld || (!flux && !(flags & EXO_FLAG_SPARSE)) || (n_texp > 0 && (!texp || !stencil_dt || !stencil_w)))
     return EXO_ERR_INVALID_ARGUMENT;
@@ -2850,7 +2861,7 @@ static int transit_vjp(const double* t, int64_t n_cad, const double* texp, int64
                        int64_t n_draw, int32_t n_planet, uint32_t flags, const Ttv& ttv, const double* gflux,
                        double* flux_out, double* gparams, double* gld, double* flux_dot, void* workspace,
                        int64_t workspace_bytes, void* stream, void* ev_start, void* ev_stop) {
-  if (!transit_args_ok(n_cad, n_texp, n_sub, n_draw, n_planet)) return EXO_ERR_INVALID_ARGUMENT;
+  if (!transit_args_ok(n_cad, n_texp, n_sub, n_draw, n_planet) || !sweep_flags_ok(flags)) return EXO_ERR_INVALID_ARGUMENT;
   if (n_draw == 0) return EXO_OK;
   if (!params || !ld || !gparams || !gld || (n_cad > 0 && (!t || !gflux)) ||
       (n_texp > 0 && (!texp || !stencil_dt || !stencil_w)))
@@ -2988,7 +2999,7 @@ int exo_transit_chi2_vjp_f64(const double* t, int64_t n_cad, const double* texp,
                              int64_t n_draw, int32_t n_planet, uint32_t flags, const double* obs, const double* ivar,
                              int64_t n_ivar, double* chi2, double* gparams, double* gld, void* workspace,
                              int64_t workspace_bytes, void* stream) {
-  if (!transit_args_ok(n_cad, n_texp, n_sub, n_draw, n_planet) || (n_ivar != 1 && n_ivar != n_cad))
+  if (!transit_args_ok(n_cad, n_texp, n_sub, n_draw, n_planet) || (n_ivar != 1 && n_ivar != n_cad) || !sweep_flags_ok(flags))
     return EXO_ERR_INVALID_ARGUMENT;
   if (flags & (EXO_FLAG_PER_PLANET | EXO_FLAG_SPARSE | EXO_FLAG_EXACT_SCAN)) return EXO_ERR_INVALID_ARGUMENT;
   if (n_draw == 0) return EXO_OK;
@@ -3009,7 +3020,8 @@ int exo_transit_chi2_ttv_vjp_f64(const double* t, int64_t n_cad, const double* t
                                  const double* ttv_shift, int32_t n_edge, const double* obs, const double* ivar,
                                  int64_t n_ivar, double* chi2, double* gparams, double* gld, double* gshift, void* workspace,
                                  int64_t workspace_bytes, void* stream) {
-  if (!transit_args_ok(n_cad, n_texp, n_sub, n_draw, n_planet) || (n_ivar != 1 && n_ivar != n_cad) || n_cad < 1)
+  if (!transit_args_ok(n_cad, n_texp, n_sub, n_draw, n_planet) || (n_ivar != 1 && n_ivar != n_cad) || n_cad < 1 ||
+      !sweep_flags_ok(flags))
     return EXO_ERR_INVALID_ARGUMENT;
   if (flags & (EXO_FLAG_PER_PLANET | EXO_FLAG_SPARSE | EXO_FLAG_EXACT_SCAN | EXO_FLAG_SECONDARY | EXO_FLAG_LIGHT_DELAY))
     return EXO_ERR_INVALID_ARGUMENT;

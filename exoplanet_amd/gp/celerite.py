@@ -138,7 +138,7 @@ def celerite_loglike(t, resid, diag, coef_real, coef_complex, obs=None, pair_kin
                                   None if pair_kind is None else pair_kind.detach(), n_chunks)
 
 
-_CONST_VAR = {}   # (n, device, yerr) -> the variance vector of a scalar error bar (a handful of series at most)
+_CONST_VAR = {}   # (n, device, dtype, yerr) -> the variance vector of a scalar error bar (a handful of series at most)
 
 
 def _known_sorted(t):
@@ -179,12 +179,18 @@ class GaussianProcess:
             if isinstance(yerr, (int, float)):
                 # one error bar for the whole series: the same constant vector for every object built on these times --
                 # made once (a sampler builds a GaussianProcess per evaluation: three small kernels each time otherwise)
-                key = (t.shape[0], str(t.device), float(yerr))
+                # (a bool is an int to isinstance: as an error bar it is a mistake, caught by the float() below all the same)
+                # SHARED and read-only: every object on this key holds the same tensor as `_diag` -- never written in
+                # place by this package; a caller who wants to edit a GP's diagonal passes `diag=`.  Not made
+                # during a hipGraph capture: that tensor would live in the graph's private pool, filled on replay only.
+                key = (t.shape[0], str(t.device), str(t.dtype), float(yerr))
                 var = _CONST_VAR.get(key)
                 if var is None:
-                    if len(_CONST_VAR) >= 8:
-                        _CONST_VAR.clear()
-                    var = _CONST_VAR[key] = torch.full_like(t, float(yerr) ** 2)
+                    var = torch.full_like(t, float(yerr) ** 2)
+                    if not (t.is_cuda and torch.cuda.is_current_stream_capturing()):
+                        if len(_CONST_VAR) >= 8:
+                            _CONST_VAR.clear()
+                        _CONST_VAR[key] = var
             else:
                 var = as_tensor(yerr, t) ** 2 + torch.zeros_like(t)
         else:

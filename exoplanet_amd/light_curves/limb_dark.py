@@ -80,6 +80,17 @@ def quad_limbdark_light_curve(c, b, r):
     return (s * c).sum(-1) - 1.0
 
 
+def _batch_shape(ll, batch, batched):
+    """the per-draw log-likelihoods in the orbit's batch shape; ONE system with several per-draw error bars (yerr of shape
+    (n_draw, 1): a jitter chain per entry) keeps yerr's draws -- ADVICE r3: that case used to die in reshape(())"""
+    n = 1
+    for b in batch:
+        n *= int(b)
+    if ll.numel() == n:
+        return ll.reshape(tuple(batch)) if batched else ll.reshape(())
+    return ll.reshape(-1)
+
+
 class LimbDarkLightCurve:
     """A quadratically limb darkened light curve.
 
@@ -260,7 +271,7 @@ class LimbDarkLightCurve:
                          shift.expand(full + shift.shape[-2:]).reshape(-1, P, shift.shape[-1]).contiguous())
             rec, ld, batch = rec.contiguous(), ld.contiguous(), full
         ll = ops.white_noise_loglike(t.detach(), rec, ld, as_tensor(y, t).to(rec.device), yerr, mean=mean, flags=flags, **kw)
-        return ll.reshape(tuple(batch)) if batch else ll.reshape(())
+        return _batch_shape(ll, batch, bool(batch))
 
     def _loglike_from_columns(self, orbit, r, t, y, yerr, mean, texp, oversample, order, use_in_transit, light_delay, has_ttv):
         """white_noise_log_likelihood of the standard parameterisation with the constructor arguments handed to the
@@ -293,7 +304,7 @@ class LimbDarkLightCurve:
         pack_flags = (flags & ops.FLAG_WINDOW) | (ops.PACK_CIRCULAR if A["ecc"] is None else 0)
         yt = as_tensor(y, t).to(t.device)
         ll = ops.orbit_white_noise_loglike(t.detach(), yt, yerr, cols, us, D, mean=mean, flags=flags, pack_flags=pack_flags, **kw)
-        return ll if batched else ll.reshape(())
+        return ll if batched else _batch_shape(ll, (), False)
 
     # ---- generic orbit objects: ops.quad_solution_vector on their positions
     def _composed(self, orbit, r, t, texp, stencil, use_in_transit, light_delay):

@@ -40,6 +40,34 @@ MAX_SUBEXP = 63
 
 
 _SORTED = {}
+_VOUCHED = {}
+
+
+def _series_key(t):
+    return (t.data_ptr(), t.numel(), t.stride(0) if t.dim() else 0)
+
+
+def vouch_sorted(t):
+    """The caller's word that the device tensor ``t`` is non-decreasing (no NaN) and STAYS so for as long as this buffer is
+    a time array -- whatever is written into it later, by whatever means.  The sweeps then carry FLAG_SORTED_TIMES
+    (windows and runs in one launch) also where the torch layer cannot see for itself: inside a hipGraph capture, whose
+    launches keep their flags at every replay.  The array is looked at once, now (one host synchronisation; not during a
+    capture); ValueError if it is not sorted.  A sampler's time array is the use: fixed for the whole run.
+    ``release_sorted(t)`` takes the word back."""
+    if not (torch.is_tensor(t) and t.is_cuda):
+        raise RuntimeError("vouch_sorted: a device tensor, please")
+    if torch.cuda.is_current_stream_capturing():
+        raise RuntimeError("vouch_sorted looks at the array (a host synchronisation): call it before the capture")
+    if t.numel() > 1 and not bool((t[1:] >= t[:-1]).all()):
+        raise ValueError("vouch_sorted: the times are not non-decreasing (or hold a NaN)")
+    if len(_VOUCHED) >= 16:
+        _VOUCHED.clear()
+    _VOUCHED[_series_key(t)] = t        # (keeps the storage alive: the address cannot pass to another series meanwhile)
+    return t
+
+
+def release_sorted(t):
+    _VOUCHED.pop(_series_key(t), None)
 
 
 def known_sorted(t, unknown=True, nan_ok=True):
@@ -48,12 +76,18 @@ def known_sorted(t, unknown=True, nan_ok=True):
     meanwhile: a sampler evaluates on the same time array every step, and a step that is being captured into a hipGraph
     must not synchronise (``unknown``: the answer then, for a tensor never looked at).  ``nan_ok=False``: every
     neighbouring pair must compare as ordered -- a NaN among the times makes the answer False (what the sweep's own
-    device check says: it then solves every cadence instead of searching)."""
+    device check says: it then solves every cadence instead of searching).  A tensor without a version counter
+    (inference mode) is ``unknown``.  The version counter sees torch's own in-place writes only: a buffer that is
+    written behind torch's back (``t.data.copy_``, DLPack / ctypes consumers) must not rely on this cache -- see
+    ``vouch_sorted`` and INTEGRATION.md."""
     if not t.is_cuda:
         return bool((t[1:] >= t[:-1]).all()) if not nan_ok else not bool((t[1:] < t[:-1]).any())
     # (by storage address, extent and version: `t.detach()` is a new object on the same storage with the same version
     # counter; the entry holds a tensor on that storage, so the address is not reused while it is here)
-    key = (t.data_ptr(), t.numel(), t.stride(0) if t.dim() else 0, t._version)
+    try:
+        key = _series_key(t) + (t._version,)
+    except RuntimeError:                 # inference tensors do not track versions
+        return unknown
     hit = _SORTED.get(key)
     if hit is None:
         if torch.cuda.is_current_stream_capturing():
@@ -66,10 +100,19 @@ def known_sorted(t, unknown=True, nan_ok=True):
 
 
 def _sorted_flag(t):
-    """FLAG_SORTED_TIMES when the sweep may skip its own check of ``t`` (never on a guess, never with a NaN among the times)"""
+    """FLAG_SORTED_TIMES when the sweep may skip its own check of ``t``: never on a guess, never with a NaN among the times,
+    and -- ADVICE r3 -- never baked into a captured launch on the strength of the version cache (a replay runs on whatever
+    the buffer holds THEN; the cache saw what it held at capture): inside a capture only a series the caller vouched for
+    (``vouch_sorted``) gets the flag, everything else keeps the device's own check, every replay."""
     if os.environ.get("EXO_CHECK_SORTED_ON_DEVICE") == "1":     # (A/B: the sweep's own check, every call)
         return 0
-    return FLAG_SORTED_TIMES if (t.numel() > 1 and known_sorted(t, unknown=False, nan_ok=False)) else 0
+    if t.numel() <= 1:
+        return 0
+    if _series_key(t) in _VOUCHED:
+        return FLAG_SORTED_TIMES
+    if torch.cuda.is_current_stream_capturing():
+        return 0
+    return FLAG_SORTED_TIMES if known_sorted(t, unknown=False, nan_ok=False) else 0
 
 
 def _stream(t):
@@ -577,7 +620,12 @@ def _scaled_loglike(unit_fn, y, yerr_d, mean):
     obs, one, s2, _, _ = _white_noise_terms(y, 1.0, mean)
     w = 1.0 / (yerr_d * yerr_d)
     n = float(y.numel())
-    return -0.5 * w * (unit_fn(obs, one) + s2) + 0.5 * n * torch.log(w / (2.0 * torch.pi))
+    chi2 = unit_fn(obs, one)
+    if chi2.numel() != 1 and yerr_d.numel() not in (1, chi2.numel()):
+        raise ValueError(f"white-noise likelihood: yerr holds {yerr_d.numel()} per-draw error bars, the parameters "
+                         f"{chi2.numel()} draws -- one error bar, one per draw, or one system with many error bars")
+    # (one system, many error bars -- a jitter chain per entry of yerr: the result has yerr's draws)
+    return -0.5 * w * (chi2 + s2) + 0.5 * n * torch.log(w / (2.0 * torch.pi))
 
 
 def white_noise_loglike(t, params, ld, y, yerr, mean=0.0, texp=None, stencil_dt=None, stencil_w=None, flags=0, ttv=None):

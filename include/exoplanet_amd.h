@@ -33,7 +33,9 @@ extern "C" {
 #define EXO_ERR_LAUNCH 2
 #define EXO_ERR_WORKSPACE 3
 
-/* ABI version, bumped whenever a signature or a layout below changes. */
+/* ABI version, bumped whenever a signature, a layout or the set of flags below changes (10: EXO_FLAG_CADENCE_MAJOR,
+ * EXO_FLAG_SORTED_TIMES, the *_cm_f64 entry points; flag bits a build does not know are EXO_ERR_INVALID_ARGUMENT). */
+#define EXO_ABI_VERSION 10
 int32_t exo_abi_version(void);
 
 /* ---------------------------------------------------------------------------
@@ -131,8 +133,16 @@ int exo_contact_points_f64(const double* a, const double* e, const double* cosw,
 
 #define EXO_FLAG_SORTED_TIMES 256u /* the caller has CHECKED that t is non-decreasing (the sweep otherwise checks it on
                                      the device, every call, in a launch of its own before the searches): windows and runs
-                                     then come out of one launch.  With unsorted times under this flag the results are
-                                     undefined; without it unsorted times are merely slow (every cadence solved).     */
+                                     then come out of one launch.  The word is taken for NEIGHBOURING cadences only: the
+                                     launch still looks at 65 evenly spaced cadences, and a series that does not ascend
+                                     through them (a NaN included) is swept cadence by cadence, as without the flag.
+                                     Disorder finer than that under this flag gives undefined results; without the flag
+                                     unsorted times are merely slow (every cadence solved).  A flag is part of a captured
+                                     launch: it must hold for whatever the time buffer contains at every replay.       */
+
+/* a sweep called with a flag bit outside this set returns EXO_ERR_INVALID_ARGUMENT */
+#define EXO_FLAG_SWEEP_ALL (EXO_FLAG_PER_PLANET | EXO_FLAG_WINDOW | EXO_FLAG_SECONDARY | EXO_FLAG_EXACT_SCAN | \
+                            EXO_FLAG_SPARSE | EXO_FLAG_LIGHT_DELAY | EXO_FLAG_CADENCE_MAJOR | EXO_FLAG_SORTED_TIMES)
 
 #define EXO_MAX_PLANETS 16
 #define EXO_MAX_SUBEXP 63

@@ -231,3 +231,38 @@ def test_bench_config_table():
     from exoplanet_amd.distributed import shard_bounds
     assert [shard_bounds(512, r, 8)[1] - shard_bounds(512, r, 8)[0] for r in range(8)] == [64] * 8
     assert [shard_bounds(1024, r, 8)[1] - shard_bounds(1024, r, 8)[0] for r in range(8)] == [128] * 8
+
+
+def test_bench_turns_itself_into_the_launcher(monkeypatch):
+    """`python bench.py --gpus N` without WORLD_SIZE (the form of the driver's recorded command) re-executes itself under
+    torch.distributed.run on the loopback address with the same arguments (it used to exit)"""
+    import sys
+
+    import bench
+
+    argv = bench.launcher_argv(4, ["bench.py", "--gpus", "4", "--steps", "7", "--config", "c5"])
+    assert argv[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nnodes=1" in argv and "--nproc-per-node=4" in argv
+    assert argv[argv.index("--master-addr") + 1] == "127.0.0.1"
+    assert 0 < int(argv[argv.index("--master-port") + 1]) < 65536
+    k = argv.index(os.path.abspath("bench.py"))
+    assert argv[k + 1:] == ["--gpus", "4", "--steps", "7", "--config", "c5"]
+    # main() hands over before it touches a GPU
+    seen = {}
+
+    def fake_execv(path, args):
+        seen["path"], seen["args"] = path, args
+        raise SystemExit(0)
+
+    monkeypatch.setattr(os, "execv", fake_execv)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.delenv("EXO_BENCH_NO_REEXEC", raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2", "--steps", "3"])
+    with pytest.raises(SystemExit):
+        bench.main()
+    assert seen["path"] == sys.executable and "--nproc-per-node=2" in seen["args"]
+    # a launcher that set WORLD_SIZE=1 for --gpus 2 is a mistake, not a reason to spawn again
+    monkeypatch.setenv("WORLD_SIZE", "1")
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert "WORLD_SIZE" in str(e.value)

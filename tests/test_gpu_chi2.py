@@ -279,3 +279,47 @@ def test_white_noise_log_likelihood_of_a_ttv_orbit(dev):
     for n, a, b in zip(names, g1, g2):
         assert float(b.abs().max()) > 0, n
         assert float((a - b).abs().max()) <= 1e-8 * float(b.abs().max()), n
+
+
+def test_one_system_many_jitter_chains_and_mismatched_error_bars(dev):
+    """an UNBATCHED orbit with a (n_draw, 1) error bar ("one system, many jitter chains") returns yerr's draws --
+    through both forms of white_noise_log_likelihood (constructor columns and records) -- with the gradient of every
+    chain's error bar; a yerr whose draw count matches neither 1 nor the parameter batch is a clear ValueError"""
+    import exoplanet_amd as xo
+
+    rng = np.random.default_rng(5)
+    N, K = 4000, 7
+    t = np.linspace(0.0, 12.0, N)
+    td = T(t, dev)
+    want_f = P.LimbDarkLightCurve(0.3, 0.2).get_light_curve(
+        orbit=P.KeplerianOrbit(period=3.5, t0=1.0, b=0.3, ecc=0.2, omega=0.4), r=0.1, t=t, use_in_transit=False)[:, 0]
+    assert want_f.min() < -1e-3
+    y = want_f + 2e-4 * rng.normal(size=N)
+    s = 2e-4 * (1 + 0.3 * rng.uniform(size=(K, 1)))
+    r2 = ((y - want_f) ** 2).sum()
+    want_ll = -0.5 * r2 / s[:, 0] ** 2 - N * np.log(s[:, 0]) - 0.5 * N * np.log(2 * np.pi)
+    want_g = r2 / s[:, 0] ** 3 - N / s[:, 0]
+    for standard in (True, False):
+        yerr = T(s, dev).requires_grad_(True)
+        kw = dict(period=3.5, t0=1.0, b=0.3, ecc=0.2, omega=0.4)
+        if not standard:                      # a parameterisation the column form does not take: the record form
+            kw["rho_star"] = 1.3
+        orbit = xo.KeplerianOrbit(**kw)
+        if not standard:
+            po = P.KeplerianOrbit(**kw)
+            f2 = P.LimbDarkLightCurve(0.3, 0.2).get_light_curve(orbit=po, r=0.1, t=t, use_in_transit=False)[:, 0]
+            rr = ((y - f2) ** 2).sum()
+            w_ll = -0.5 * rr / s[:, 0] ** 2 - N * np.log(s[:, 0]) - 0.5 * N * np.log(2 * np.pi)
+            w_g = rr / s[:, 0] ** 3 - N / s[:, 0]
+        else:
+            w_ll, w_g = want_ll, want_g
+        ll = xo.LimbDarkLightCurve(0.3, 0.2).white_noise_log_likelihood(orbit=orbit, r=0.1, t=td, y=T(y, dev), yerr=yerr)
+        assert ll.shape == (K,)
+        (g,) = torch.autograd.grad(ll.sum(), yerr)
+        assert np.abs(ll.detach().cpu().numpy() - w_ll).max() <= 1e-9 * np.abs(w_ll).max()
+        assert np.abs(g.cpu().numpy()[:, 0] - w_g).max() <= 1e-8 * np.abs(w_g).max()
+    # a batch of 3 parameter sets with 7 error bars: neither one per draw nor one for all
+    orbit3 = xo.KeplerianOrbit(period=T([3.5, 3.6, 3.7], dev).reshape(3, 1), t0=1.0, b=0.3)
+    with pytest.raises(ValueError, match="error bars"):
+        xo.LimbDarkLightCurve(0.3, 0.2).white_noise_log_likelihood(orbit=orbit3, r=T([[0.1]] * 3, dev), t=td, y=T(y, dev),
+                                                                    yerr=T(s, dev))

@@ -226,3 +226,56 @@ def test_a_nan_among_the_times_never_gets_the_sorted_flag(dev):
     keep[777] = False
     assert same_flux(f[:, keep], f_ref[:, keep])
     assert float(f_ref.min()) < -1e-3
+
+
+def test_sorted_flag_policy_and_the_device_guard(dev):
+    """(i) inside a hipGraph capture the flag is only set for a series the caller vouched for -- a captured
+    step whose time buffer is REFILLED with an unsorted series before a replay still gives the right light curve (the
+    device's own check runs at every replay); (ii) with the flag forced on an unordered series, the launch's own coarse
+    look (65 evenly spaced cadences) sends the sweep to "every cadence": right results, not undefined ones; (iii) a
+    tensor without a version counter never gets the flag; (iv) unknown flag bits are refused"""
+    import exoplanet_amd as xo
+    from exoplanet_amd import ops, _lib
+
+    rng = np.random.default_rng(11)
+    D, N = 6, 30_000
+    tt = np.arange(N) * (2.0 / 1440.0) + 0.25
+    perm = rng.permutation(N)
+    rec, c = system(rng, D)
+    recd, cd = T(rec, dev), T(c, dev)
+    want = ops.transit_flux(T(tt, dev), recd, cd, flags=ops.FLAG_EXACT_SCAN)       # list path: no searches at all
+    assert float(want.min()) < -1e-3
+    # (i) capture on a sorted buffer nobody vouched for, refill it with a permutation, replay
+    tbuf = T(tt, dev)
+    assert ops._sorted_flag(tbuf) == ops.FLAG_SORTED_TIMES          # eager: looked at, remembered
+    step = xo.GraphedStep(lambda r: ops.transit_flux(tbuf, r, cd), recd)
+    assert same_flux(step().clone(), want)
+    tbuf.data.copy_(T(tt[perm], dev))                               # behind the version counter's back
+    got = step().clone()
+    assert same_flux(got, want[:, torch.as_tensor(perm, device=dev)])
+    # a vouched-for series carries the flag into a capture
+    tv = ops.vouch_sorted(T(tt, dev))
+    seen = []
+    g2 = xo.GraphedStep(lambda r: (seen.append(ops._sorted_flag(tv)), ops.transit_flux(tv, r, cd))[1], recd)
+    assert seen[-1] == ops.FLAG_SORTED_TIMES and same_flux(g2().clone(), want)
+    ops.release_sorted(tv)
+    with pytest.raises(ValueError):
+        ops.vouch_sorted(T(tt[perm], dev))
+    # (ii) the flag forced onto an unordered series: the launch's own look at it degrades the sweep, results stay right
+    tp = T(tt[perm], dev)
+    assert ops._sorted_flag(tp) == 0
+    forced = ops.transit_flux(tp, recd, cd, flags=ops.FLAG_SORTED_TIMES)
+    assert same_flux(forced, want[:, torch.as_tensor(perm, device=dev)])
+    # (iii) inference tensors have no version counter
+    with torch.inference_mode():
+        ti = T(tt, dev) + 0.0
+    assert ops._sorted_flag(ti) == 0
+    # (iv) a flag bit this build does not know
+    lib = _lib.load()
+    flux = torch.empty(D, N, dtype=torch.float64, device=dev)
+    nbytes = lib.exo_transit_flux_workspace_bytes(N, D, 1)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    rc = lib.exo_transit_flux_fwd_f64(tbuf.data_ptr(), N, 0, 0, 0, 0, 1, recd.data_ptr(), cd.data_ptr(), D, 1, 1 << 12,
+                                      flux.data_ptr(), ws.data_ptr(), nbytes, 0)
+    assert rc == 1      # EXO_ERR_INVALID_ARGUMENT
+    assert lib.exo_abi_version() == 10

@@ -7,8 +7,9 @@ are held to the oracle's C port (oracle/c, OpenMP over draws) DIRECTLY:
 * C2, D = 1024 draws x 150 000 cadences (one block per draw: the heavy kernel finishes its own draws; `flux_dot` with the
   column-form packing VJP): the dense flux of EVERY draw, the per-draw scalar, all 8 leaf gradients of every draw;
 * the same batch through the sparse step and the white-noise-likelihood step (what the sampler legs run);
-* C4 at 64 draws, C5 at 128 chains (light curve of every chain; log-likelihood and gradients of >= 8 chains),
-  C3 at 1024 draws (log-likelihood and gradients of >= 8 draws);
+* C4 at 64 draws, C5 at 128 chains (light curve of every chain; log-likelihood and gradients of >= 8 chains) -- the per-GPU
+  shares of an 8-GPU run -- AND at 512 draws / 1024 chains, the shapes `bench.py --config c4|c5 --gpus 1` times;
+  C3 at 1024 draws (log-likelihood of EVERY draw, gradients of >= 8 draws);
 * C1's exact size (10 000 cadences, circular) and a `duration=` orbit, end to end on the HIP path.
 
 Leaf gradients of the oracle: its record / limb-darkening cotangents (C port) chained through the Jacobian of the numpy
@@ -238,14 +239,16 @@ def test_c2_per_draw_jitter_gradient(dev, c2):
 # ---------------------------------------------------------------------------------------------------
 # C4 at 64 draws
 # ---------------------------------------------------------------------------------------------------
-def test_c4_timed_step_vs_oracle(dev):
-    """`bench.py --config c4` on one of eight GPUs / `extras.c4_four_planets_64_draws`: 4 planets, 200 000 cadences, 64
-    draws, hipGraph replay; flux of every draw, per-draw scalar, all 4 x 6 + 2 leaf gradients per draw"""
+@pytest.mark.parametrize("D", [64, 512])
+def test_c4_timed_step_vs_oracle(dev, D):
+    """`bench.py --config c4` on one of eight GPUs / `extras.c4_four_planets_64_draws` (64 draws) and on ONE GPU
+    (`--config c4 --gpus 1`: all 512 draws of BASELINE's total -- the single-GPU point of the strong-scaling curve, where a
+    block finishes its own draw): 4 planets, 200 000 cadences, hipGraph replay; flux of every draw, per-draw scalar, all
+    4 x 6 + 2 leaf gradients per draw"""
     import bench
     import exoplanet_amd as xo
     from exoplanet_amd import ops
 
-    D = 64
     wl = bench.workload_c4(xo, ops, dev, D, rank=0)
     oracle_threads()
     lv = dict(zip(wl.names, wl.leaves))
@@ -298,7 +301,7 @@ def gp_oracle_draw(t, y, diag, flux, terms, wrt):
 def test_c3_timed_step_vs_oracle(dev):
     """`extras.c3_light_curve_plus_sho_gp` / `bench.py --config c3` at D = 1024: the replayed step's log-likelihood and
     every leaf gradient (8 orbit / limb-darkening leaves + sigma, rho, Q) for 8 draws spread over the batch against the C
-    port (light curve -> celerite -> back), and the log-likelihood finite and distinct for all 1024"""
+    port (light curve -> celerite -> back), and the log-likelihood of ALL 1024 draws against it"""
     import bench
     import exoplanet_amd as xo
     from exoplanet_amd import ops
@@ -311,14 +314,24 @@ def test_c3_timed_step_vs_oracle(dev):
     torch.cuda.synchronize()
     ll, grads = npy(out[0]), dict(zip(wl.names, out[1:]))
     assert np.isfinite(ll).all() and np.unique(ll).size > D // 2
-    rows = np.array([0, 1, 2, 3, 500, 777, 1022, 1023])
     lv = dict(zip(wl.names, wl.leaves))
-    vals = {k: npy(lv[k]).reshape(D, 1)[rows] for k in ORBIT_KEYS + ("r",)}
-    u1, u2 = npy(lv["u1"])[rows], npy(lv["u2"])[rows]
-    rec, c = records(vals), np.stack(P.get_cl(u1, u2), -1)
     t, y = npy(wl.data["t"]), npy(wl.data["yobs"])
     diag = np.full(N, wl.data["yerr"] ** 2)
-    flux, _, _ = C.transit(t, rec, c, None)
+    # EVERY draw's log-likelihood against the C port (8 of 1024 were compared): light curve of all 1024 draws
+    # (OpenMP over draws), then one sequential celerite pass per draw on a thread pool (ctypes releases the GIL)
+    all_vals = {k: npy(lv[k]).reshape(D, 1) for k in ORBIT_KEYS + ("r",)}
+    all_flux, _, _ = C.transit(t, records(all_vals), np.stack(P.get_cl(npy(lv["u1"]), npy(lv["u2"])), -1), None)
+    hyper = [(float(a), float(b), float(q)) for a, b, q in zip(npy(lv["sigma"]), npy(lv["rho"]), npy(lv["Q"]))]
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max(1, oracle_threads())) as pool:
+        all_ll = np.array(list(pool.map(lambda d: C.celerite(t, y - all_flux[d], diag, sho_coeffs([hyper[d]])), range(D))))
+    assert np.abs(ll - all_ll).max() <= 1e-10 * np.abs(all_ll).max(), np.abs(ll - all_ll).max() / np.abs(all_ll).max()
+    rows = np.array([0, 1, 2, 3, 500, 777, 1022, 1023])
+    vals = {k: v[rows] for k, v in all_vals.items()}
+    u1, u2 = npy(lv["u1"])[rows], npy(lv["u2"])[rows]
+    rec, c = records(vals), np.stack(P.get_cl(u1, u2), -1)
+    flux = all_flux[rows]
+    del all_flux
     want_ll, gflux, gh = [], [], []
     for i, d in enumerate(rows):
         terms = [(float(npy(lv["sigma"])[d]), float(npy(lv["rho"])[d]), float(npy(lv["Q"])[d]))]
@@ -333,15 +346,17 @@ def test_c3_timed_step_vs_oracle(dev):
     assert_grads(grads, want, wl.names, rel=2e-6, rows=rows)
 
 
-def test_c5_timed_step_vs_oracle(dev):
-    """`extras.c5_secondary_eclipse_3term_gp_128_chains` / `bench.py --config c5` on one of eight GPUs: 128 chains, 65 000
-    long cadences x 7 sub-exposures, transit + occultation, three SHO terms (J = 6).  The light curve of EVERY chain
-    against the C port; the replayed step's log-likelihood and all 10 leaf gradients for 8 chains"""
+@pytest.mark.parametrize("D", [128, 1024])
+def test_c5_timed_step_vs_oracle(dev, D):
+    """`extras.c5_secondary_eclipse_3term_gp_128_chains` / `bench.py --config c5` on one of eight GPUs (128 chains) and on
+    ONE GPU (`--config c5 --gpus 1`: all 1024 chains -- another chunk plan, and the light-curve blocks finish their own
+    draws): 65 000 long cadences x 7 sub-exposures, transit + occultation, three SHO terms (J = 6).  The light curve of
+    EVERY chain against the C port; the replayed step's log-likelihood and all 10 leaf gradients for 8 chains"""
     import bench
     import exoplanet_amd as xo
     from exoplanet_amd import ops
 
-    D, N = 128, bench.C5_NCAD
+    N = bench.C5_NCAD
     wl = bench.workload_c5(xo, ops, dev, D, rank=0)
     oracle_threads()
     lv = dict(zip(wl.names, wl.leaves))
@@ -364,7 +379,7 @@ def test_c5_timed_step_vs_oracle(dev):
     torch.cuda.synchronize()
     ll, grads = npy(out[0]), dict(zip(wl.names, out[1:]))
     assert np.isfinite(ll).all()
-    rows = np.array([0, 1, 2, 63, 64, 100, 126, 127])
+    rows = np.array([0, 1, 2, 63, 64, 100, 126, 127]) if D == 128 else np.array([0, 1, 127, 128, 511, 512, 1000, 1023])
     diag = np.full(N, wl.data["yerr"] ** 2)
     want_ll, gflux, gh = [], [], []
     for d in rows:
