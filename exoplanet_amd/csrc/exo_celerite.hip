@@ -35,6 +35,7 @@
 
 #include "../../include/exoplanet_amd.h"
 #include "exo_celerite_core.hpp"
+#include "exo_celerite_group.hpp"
 #include "exo_math.hpp"
 
 namespace {
@@ -1166,6 +1167,77 @@ __global__ __launch_bounds__(kWave) void celerite_tree_kernel(TreeOp op, double*
   tree_item_lane<J, ADJ, DOWN>(op, state, c, item - (int64_t)c * op.n_draw);
 }
 
+// A draw's WHOLE scan in one launch (exo_celerite_group.hpp): one block per draw walks the UP levels, seeds the top state,
+// walks the DOWN levels, a block barrier between levels.  Items of J >= 3 on groups of eight lanes (32 per block), items of
+// J <= 2 one lane each.  Blocks are dealt to the XCDs so that the 16 draws sharing a 128-B line of the [..][draw] arrays
+// run on ONE XCD (blockIdx.x % 8 is the XCD of a block): each line crosses the fabric once instead of up to 8 times.
+#ifndef EXO_GP_FUSED_SCAN
+#define EXO_GP_FUSED_SCAN 0
+#endif
+#ifndef EXO_GP_GROUP_TREES
+#define EXO_GP_GROUP_TREES 1
+#endif
+constexpr int kScanBlock = 256;
+// One level of a scan, items of J >= 3 on groups of eight lanes (tree_item_group): a block is 32 groups = 32 CONSECUTIVE
+// DRAWS of one item (draws fastest), so that each of an item's ~100 strided accesses covers, per row, 64 contiguous bytes of
+// eight draws (one lane per (item, draw) -- celerite_tree_kernel -- is fully coalesced but spills 2 KB per lane at J = 6; a
+// block per draw -- the fused kernel below -- touches 64 lines per instruction and is SLOWER than the 34 launches it replaces).
+template <int J, bool ADJ, bool DOWN>
+__global__ __launch_bounds__(kScanBlock) void celerite_tree_group_kernel(TreeOp op, double* state) {
+  __shared__ double lds[(kScanBlock / 8) * GroupLds<J>::S];
+  const int tid = threadIdx.x;
+  const int64_t unit = (int64_t)blockIdx.x * (kScanBlock / 8) + (tid >> 3);
+  if (unit >= (int64_t)op.n_item * op.n_draw) return;     // (whole groups leave; nothing below needs a block barrier)
+  Grp<J> g;
+  g.lds = lds + (tid >> 3) * GroupLds<J>::S;
+  g.r = tid & 7;
+  g.live = g.r < J;
+  const int c = (int)(unit / op.n_draw);
+  tree_item_group<J, ADJ, DOWN>(op, state, c, unit - (int64_t)c * op.n_draw, g);
+}
+
+template <int J, bool ADJ>
+__global__ __launch_bounds__(kScanBlock) void celerite_scan_fused_kernel(ChunkWs ws, double* state, const double* __restrict__ t,
+                                                                        Coefs cf, int64_t n_draw) {
+  constexpr bool kGroup = J >= 3;
+  __shared__ double lds[kGroup ? (kScanBlock / 8) * GroupLds<J>::S : 2];
+  const int per = (int)((n_draw + 7) / 8);
+  const int64_t draw = (int64_t)(blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  if (draw >= n_draw) return;
+  const int tid = threadIdx.x;
+  Grp<J> g;
+  g.lds = lds + (kGroup ? (tid >> 3) * GroupLds<J>::S : 0);
+  g.r = tid & 7;
+  g.live = g.r < J;
+  const int unit = kGroup ? (tid >> 3) : tid, n_unit = kGroup ? kScanBlock / 8 : kScanBlock;
+  const int top = ws.tree_top();
+  // (the level's TreeOp is worked out here, in scalar registers: a table of them as a kernel argument, indexed by the
+  // level, is copied to 600 vector registers and scratch)
+  for (int f = 0; f + 1 < top; ++f) {
+    const TreeOp op = scan_level_op(ws, J, ADJ, f, false);
+    for (int c = unit; c < op.n_item; c += n_unit) {
+      if constexpr (kGroup) tree_item_group<J, ADJ, false>(op, state, c, draw, g);
+      else tree_item_lane<J, ADJ, false>(op, state, c, draw);
+    }
+    __syncthreads();
+  }
+  const int64_t seed = ws.tree_state(top);
+  if (ADJ) {
+    for (int k = tid; k < J + J * J; k += kScanBlock) state[seed + (int64_t)k * n_draw + draw] = 0.0;
+  } else if (tid == 0) {
+    scan_init_lane<J>(t, cf, n_draw, state + seed, draw);
+  }
+  __syncthreads();
+  for (int f = top - 1; f >= 0; --f) {
+    const TreeOp op = scan_level_op(ws, J, ADJ, f, true);
+    for (int c = unit; c < op.n_item; c += n_unit) {
+      if constexpr (kGroup) tree_item_group<J, ADJ, true>(op, state, c, draw, g);
+      else tree_item_lane<J, ADJ, true>(op, state, c, draw);
+    }
+    __syncthreads();
+  }
+}
+
 // the state the forward scan starts from: F = 0, P = Delta(t_0) (S_0 = 0)
 template <int J>
 __global__ __launch_bounds__(kWave) void celerite_scan_init_kernel(const double* __restrict__ t, Coefs cf, int64_t n_draw,
@@ -1364,6 +1436,16 @@ int64_t exo_celerite_state_doubles(int64_t n, int64_t n_draw, int32_t n_real, in
     case 8: { constexpr int JJ = 8; CALL; } break; \
     default: break;                                \
   }
+#define EXO_GP_DISPATCH_GROUP(J_, CALL) \
+  switch (J_) {                         \
+    case 3: { constexpr int JJ = 3; CALL; } break; \
+    case 4: { constexpr int JJ = 4; CALL; } break; \
+    case 5: { constexpr int JJ = 5; CALL; } break; \
+    case 6: { constexpr int JJ = 6; CALL; } break; \
+    case 7: { constexpr int JJ = 7; CALL; } break; \
+    case 8: { constexpr int JJ = 8; CALL; } break; \
+    default: break;                                \
+  }
 #define EXO_GP_DISPATCH(J_, CALL) \
   switch (J_) {                   \
     case 1: { constexpr int JJ = 1; CALL; } break; \
@@ -1521,13 +1603,25 @@ static int celerite_fwd(const double* t, Series resid, const double* diag, int64
       // after the element kernel: it may flag more draws (measurement variance too small)
       hipLaunchKernelGGL(celerite_prep_flagged_kernel, dim3(8, (unsigned)n_draw), dim3(256), 0, st, t, n, cf, n_draw, J,
                          state, state + ws.off_flag());
-      {
+      if (EXO_GP_FUSED_SCAN) {
+        // (B) as a tree, all of it in one launch: compose up to one position, seed it with the initial state, apply back down
+        const dim3 sgrid((unsigned)(8 * ((n_draw + 7) / 8)));
+        EXO_GP_DISPATCH(J, hipLaunchKernelGGL((celerite_scan_fused_kernel<JJ, false>), sgrid, dim3(kScanBlock), 0, st, ws, state, t,
+                                              cf, n_draw))
+      } else {
         // (B) as a tree: compose up to one position, seed it with the initial state, apply back down
         int rc = EXO_OK;
         tree_scan(ws, cg, J, n_draw, false,
                   [&](const TreeOp& op, bool down) {
                     const dim3 tgrid((unsigned)(((int64_t)op.n_item * n_draw + kWave - 1) / kWave));
-                    if (down) {
+                    const dim3 ggrid((unsigned)(((int64_t)op.n_item * n_draw + kScanBlock / 8 - 1) / (kScanBlock / 8)));
+                    if (EXO_GP_GROUP_TREES && J >= 3) {
+                      if (down) {
+                        EXO_GP_DISPATCH_GROUP(J, hipLaunchKernelGGL((celerite_tree_group_kernel<JJ, false, true>), ggrid, dim3(kScanBlock), 0, st, op, state))
+                      } else {
+                        EXO_GP_DISPATCH_GROUP(J, hipLaunchKernelGGL((celerite_tree_group_kernel<JJ, false, false>), ggrid, dim3(kScanBlock), 0, st, op, state))
+                      }
+                    } else if (down) {
                       EXO_GP_DISPATCH_VOID(J, hipLaunchKernelGGL((celerite_tree_kernel<JJ, false, true>), tgrid, block, 0, st, op, state))
                     } else if (J >= 3) {
                       // composing two filtering elements keeps ~5 J x J matrices alive around the solve: one lane per
@@ -1591,13 +1685,25 @@ static int celerite_vjp(const double* t, Series resid, const double* diag, int64
         egrid(per_draw.x, (unsigned)cg.C);
     EXO_GP_DISPATCH(J, hipLaunchKernelGGL((celerite_badj_prep_kernel<JJ>), dim3(per_draw.x, (unsigned)(cg.C - 1)), block,
                                           0, st, gloglike, n, n_draw, wstate, cg))
-    {
+    if (EXO_GP_FUSED_SCAN) {
+      // (B') as a tree over positions p = C - 1 - chunk, one launch: adjoint elements of chunks C - 1 .. 1, zero initial adjoint
+      const dim3 sgrid((unsigned)(8 * ((n_draw + 7) / 8)));
+      EXO_GP_DISPATCH(J, hipLaunchKernelGGL((celerite_scan_fused_kernel<JJ, true>), sgrid, dim3(kScanBlock), 0, st, ws, wstate, t,
+                                            cf, n_draw))
+    } else {
       // (B') as a tree over positions p = C - 1 - chunk: adjoint elements of chunks C - 1 .. 1, zero initial adjoint
       bool ok = true;
       tree_scan(ws, cg, J, n_draw, true,
                 [&](const TreeOp& op, bool down) {
                   const dim3 tgrid((unsigned)(((int64_t)op.n_item * n_draw + kWave - 1) / kWave));
-                  if (down) {
+                  const dim3 ggrid((unsigned)(((int64_t)op.n_item * n_draw + kScanBlock / 8 - 1) / (kScanBlock / 8)));
+                  if (EXO_GP_GROUP_TREES && J >= 3) {
+                    if (down) {
+                      EXO_GP_DISPATCH_GROUP(J, hipLaunchKernelGGL((celerite_tree_group_kernel<JJ, true, true>), ggrid, dim3(kScanBlock), 0, st, op, wstate))
+                    } else {
+                      EXO_GP_DISPATCH_GROUP(J, hipLaunchKernelGGL((celerite_tree_group_kernel<JJ, true, false>), ggrid, dim3(kScanBlock), 0, st, op, wstate))
+                    }
+                  } else if (down) {
                     EXO_GP_DISPATCH_VOID(J, hipLaunchKernelGGL((celerite_tree_kernel<JJ, true, true>), tgrid, block, 0, st, op, wstate))
                   } else {
                     EXO_GP_DISPATCH_VOID(J, hipLaunchKernelGGL((celerite_tree_kernel<JJ, true, false>), tgrid, block, 0, st, op, wstate))

@@ -1377,32 +1377,39 @@ EXO_HD void scan_init_lane(const double* EXO_RESTRICT t, const Coefs& cf, int64_
 // The levels of a scan: `launch(op, down)` is called once per level, in order (UP levels, then -- after `seed()`
 // has put the initial state at ws.tree_state(top) -- the DOWN levels).  adj: the adjoint scan (positions reversed,
 // states into bnd(2, .) with the sign the chunk kernels expect); else the forward scan (states into bnd(1, .)).
-template <class Launch, class Seed>
-EXO_HDH void tree_scan(const ChunkWs& ws, const ChunkGeom& cg, int J, int64_t n_draw, bool adj, Launch&& launch, Seed&& seed) {
-  const int top = ws.tree_top();
+// level f of a scan as a TreeOp: UP -- elements of level f composed into level f + 1 (f = 0 .. top - 2); DOWN -- states of
+// level f from those of level f + 1 and the elements of level f (f = top - 1 .. 0).  adj: the adjoint scan (positions
+// reversed, states into bnd(2, .) with the sign the chunk kernels expect); else the forward scan (states into bnd(1, .)).
+// A pure function of the plan: the host loop below and the one-launch scan kernel (exo_celerite_group.hpp) both call it.
+EXO_HDH TreeOp scan_level_op(const ChunkWs& ws, int J, bool adj, int f, bool down) {
   TreeOp op{};
-  op.J = J; op.n_draw = n_draw; op.psign = 1.0;
-  auto level_elems = [&](int f) {
-    op.src_elem = f == 0 ? ws.elem(0, 0, 0) : ws.tree_elem(f);
-    op.src_n = f == 0 ? cg.C - 1 : ws.tree_npos(f);   // forward: the last chunk's element takes no state anywhere;
-    op.src_rev = (adj && f == 0) ? 1 : 0;              // adjoint: elements of chunks C - 1 .. 1 at positions 0 .. C - 2
-    op.src_len = ws.tree_npos(f);
-  };
-  for (int f = 0; f + 1 < top; ++f) {
-    level_elems(f);
-    op.dst_elem = ws.tree_elem(f + 1); op.n_item = ws.tree_npos(f + 1);
-    launch(op, false);
-  }
-  seed();
-  for (int f = top - 1; f >= 0; --f) {
-    level_elems(f);
-    op.par_state = ws.tree_state(f + 1); op.n_item = ws.tree_npos(f + 1);
+  op.J = J; op.n_draw = ws.n_draw; op.psign = 1.0;
+  op.src_elem = f == 0 ? ws.elem(0, 0, 0) : ws.tree_elem(f);
+  op.src_n = f == 0 ? ws.C - 1 : ws.tree_npos(f);   // forward: the last chunk's element takes no state anywhere;
+  op.src_rev = (adj && f == 0) ? 1 : 0;              // adjoint: elements of chunks C - 1 .. 1 at positions 0 .. C - 2
+  op.src_len = ws.tree_npos(f);
+  op.n_item = ws.tree_npos(f + 1);
+  if (!down) {
+    op.dst_elem = ws.tree_elem(f + 1);
+  } else {
+    op.par_state = ws.tree_state(f + 1);
     op.dst_state = f == 0 ? ws.bnd(adj ? 2 : 1, 0, 0, 0) : ws.tree_state(f);
     op.dst_n = op.dst_len = ws.tree_npos(f);
     op.dst_rev = (adj && f == 0) ? 1 : 0;
     op.psign = (adj && f == 0) ? -1.0 : 1.0;
-    launch(op, true);
   }
+  return op;
+}
+
+// The levels of a scan: `launch(op, down)` is called once per level, in order (UP levels, then -- after `seed()`
+// has put the initial state at ws.tree_state(top) -- the DOWN levels).
+template <class Launch, class Seed>
+EXO_HDH void tree_scan(const ChunkWs& ws, const ChunkGeom& cg, int J, int64_t n_draw, bool adj, Launch&& launch, Seed&& seed) {
+  (void)cg; (void)n_draw;
+  const int top = ws.tree_top();
+  for (int f = 0; f + 1 < top; ++f) launch(scan_level_op(ws, J, adj, f, false), false);
+  seed();
+  for (int f = top - 1; f >= 0; --f) launch(scan_level_op(ws, J, adj, f, true), true);
 }
 
 // ---------------------------------------------------------------------------------------------
