@@ -1182,8 +1182,11 @@ constexpr int kScanBlock = 256;
 // DRAWS of one item (draws fastest), so that each of an item's ~100 strided accesses covers, per row, 64 contiguous bytes of
 // eight draws (one lane per (item, draw) -- celerite_tree_kernel -- is fully coalesced but spills 2 KB per lane at J = 6; a
 // block per draw -- the fused kernel below -- touches 64 lines per instruction and is SLOWER than the 34 launches it replaces).
+#ifndef EXO_GROUP_WAVES
+#define EXO_GROUP_WAVES 1
+#endif
 template <int J, bool ADJ, bool DOWN>
-__global__ __launch_bounds__(kScanBlock) void celerite_tree_group_kernel(TreeOp op, double* state) {
+__global__ __launch_bounds__(kScanBlock, EXO_GROUP_WAVES) void celerite_tree_group_kernel(TreeOp op, double* state) {
   __shared__ double lds[(kScanBlock / 8) * GroupLds<J>::S];
   const int tid = threadIdx.x;
   const int64_t unit = (int64_t)blockIdx.x * (kScanBlock / 8) + (tid >> 3);

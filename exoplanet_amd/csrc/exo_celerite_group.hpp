@@ -10,8 +10,8 @@
 // of LDS and read back row by row, every lane of the group the same address (a broadcast: 16-B reads, no conflict
 // between the eight groups of a wave: their strips start 8 banks apart).  A wave carries eight items, needs no block
 // barrier inside an item (LDS operations of one wave execute in order), and one composition costs ~50 LDS instructions
-// where the tile kernel spent 230.  The J x J solves are Gauss-Jordan with partial pivoting without moving rows: the
-// pivot lane publishes its row, every other lane eliminates, the rows are brought into order once at the end.
+// where the tile kernel spent 230.  The J x J solves are Gauss-Jordan with partial pivoting without moving rows: every
+// lane publishes its row, reads the pivot's and eliminates; the rows are brought into order once at the end.
 //
 // celerite_scan_fused_kernel: one BLOCK per draw walks all UP levels, seeds the top, walks all DOWN levels, a block
 // barrier between levels (the levels live in global memory, as before: a block's own stores are visible to it after
@@ -26,8 +26,11 @@ struct GroupLds {
   static constexpr int RS = (J + 1) & ~1;          // row stride: 16-B aligned rows
   static constexpr int W = 3 * J + 1;              // widest Gauss-Jordan row: [M | A1 | C1 | r2]
   static constexpr int WS = (W + 1) & ~1;
-  static constexpr int kMat = 4, kVec = 5;
-  static constexpr int raw = kMat * J * RS + WS + kVec * 8;
+  static constexpr int kVec = 5;
+  // matrix slots 0 .. 2 live through a solve (the operands staged before it); the rows of the solve share their strip with
+  // slots 3 .. 5, which are only written after it
+  static constexpr int kGj = (J * WS > 3 * J * RS) ? J * WS : 3 * J * RS;
+  static constexpr int raw = 3 * J * RS + kGj + kVec * 8;
   // strips of consecutive groups start 8 banks (4 doubles) apart modulo the 64 banks: S = 4 (mod 32)
   static constexpr int S = ((raw - 4 + 31) / 32) * 32 + 4;
 };
@@ -40,31 +43,27 @@ struct Grp {
   int r;           // row owned (lane & 7); rows >= J idle
   bool live;
   __device__ __forceinline__ double* mat(int s) const { return lds + s * (J * L::RS); }
-  __device__ __forceinline__ double* gj() const { return lds + L::kMat * J * L::RS; }
-  __device__ __forceinline__ double* vec(int s) const { return lds + L::kMat * J * L::RS + L::WS + s * 8; }
-  // products are kept apart in the instruction stream: left to itself the scheduler starts the LDS reads of three or four
-  // of them at once (72 registers each) and the composition item needs 600 registers
-  static __device__ __forceinline__ void apart() { __builtin_amdgcn_sched_barrier(0); }
-  static __device__ __forceinline__ void fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+  __device__ __forceinline__ double* gj() const { return lds + 3 * J * L::RS; }
+  __device__ __forceinline__ double* vec(int s) const { return lds + 3 * J * L::RS + L::kGj + s * 8; }
+  // LDS operations of one wave execute in program order: what a lane has written is there for the other lanes of its
+  // group as soon as the instruction stream says so.  sync() only keeps the COMPILER from moving reads above the
+  // writes they depend on (or writes above reads of what they replace); it costs no cycles of its own -- what costs is
+  // the round trip write -> read -> arithmetic -> write, so the items below stage as much as they can per exchange.
+  static __device__ __forceinline__ void sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
 
-  // publish my row of a matrix / my entry of a vector
+  // publish my row of a matrix / my entry of a vector (no sync: the caller batches)
   __device__ __forceinline__ void put_rows(int s, const double (&a)[J]) const {
-    fence();
     if (live) {
       double* p = mat(s) + r * L::RS;
 #pragma unroll
       for (int l = 0; l < J; ++l) p[l] = a[l];
     }
-    fence();
   }
   __device__ __forceinline__ void put_vec(int s, double v) const {
-    fence();
     if (live) vec(s)[r] = v;
-    fence();
   }
   // row r of (a . B):  sum_k a[k] B[k][l]
   __device__ __forceinline__ void mm(const double (&a)[J], int sB, double (&c)[J]) const {
-    apart();
     const double* B = mat(sB);
 #pragma unroll
     for (int l = 0; l < J; ++l) c[l] = 0.0;
@@ -72,11 +71,9 @@ struct Grp {
     for (int k = 0; k < J; ++k)
 #pragma unroll
       for (int l = 0; l < J; ++l) c[l] = fma(a[k], B[k * L::RS + l], c[l]);
-    apart();
   }
   // row r of (a . B^T):  sum_k a[k] B[l][k]
   __device__ __forceinline__ void mm_t(const double (&a)[J], int sB, double (&c)[J]) const {
-    apart();
     const double* B = mat(sB);
 #pragma unroll
     for (int l = 0; l < J; ++l) {
@@ -85,11 +82,9 @@ struct Grp {
       for (int k = 0; k < J; ++k) v = fma(a[k], B[l * L::RS + k], v);
       c[l] = v;
     }
-    apart();
   }
   // row r of (A^T . B):  sum_k A[k][r] B[k][l]
   __device__ __forceinline__ void tmm(int sA, int sB, double (&c)[J]) const {
-    apart();
     const double* A = mat(sA);
     const double* B = mat(sB);
     const int rr = live ? r : 0;
@@ -101,7 +96,6 @@ struct Grp {
 #pragma unroll
       for (int l = 0; l < J; ++l) c[l] = fma(a, B[k * L::RS + l], c[l]);
     }
-    apart();
   }
   // a . v  and  (A^T v)_r
   __device__ __forceinline__ double mv(const double (&a)[J], int sV) const {
@@ -125,78 +119,78 @@ struct Grp {
 #pragma unroll
     for (int k = 0; k < J; ++k) v[k] = p[k];
   }
-  // my row of (X + X^T) / 2 (through matrix slot s)
-  __device__ __forceinline__ void symmetrise(int s, double (&a)[J]) const {
-    put_rows(s, a);
+  // my row of (X + X^T) / 2 for a matrix whose rows were put into slot s (and synced) by the caller
+  __device__ __forceinline__ void sym_from(int s, double (&a)[J]) const {
     const double* X = mat(s);
     const int rr = live ? r : 0;
 #pragma unroll
     for (int l = 0; l < J; ++l) a[l] = 0.5 * (a[l] + X[l * L::RS + rr]);
   }
   // Solve M Z = R in place (my row of M, my row of the NB right-hand sides; on return my row of Z): Gauss-Jordan with
-  // partial pivoting, rows stay where they are -- lane p(k), the pivot of step k, ends up with the row of unknown k --
-  // and one pass through LDS at the end brings them into order.
+  // partial pivoting.  ONE exchange per step: every lane publishes its whole row [M | R]; every lane then reads column k
+  // (the pivot search, the same answer in all lanes) and the pivot's row, and eliminates.  Rows stay where they are --
+  // lane p(k), the pivot of step k, ends up with the row of unknown k -- and one more exchange at the end brings them
+  // into order.  (A step's writes follow the previous step's reads in the instruction stream: in order, as LDS is.)
   template <int NB>
   __device__ __forceinline__ void solve(double (&M)[J], double (&R)[NB]) const {
     static_assert(J + NB <= L::WS, "Gauss-Jordan row does not fit its strip");
     unsigned done = 0u;
     int mine = -1;                 // the unknown my row solves for
-    double* col = vec(L::kVec - 1);
-    double* row = gj();
 #pragma unroll
     for (int k = 0; k < J; ++k) {
-      fence();
-      if (live) col[r] = M[k];
-      fence();
+      double* rows = gj();
+      sync();
+      if (live) {
+        double* p = rows + r * L::WS;
+        // (columns < k of M are settled -- 0, or 1 in a pivot's own column -- and are not read again)
+#pragma unroll
+        for (int l = k; l < J; ++l) p[l] = M[l];
+#pragma unroll
+        for (int l = 0; l < NB; ++l) p[J + l] = R[l];
+      }
+      sync();
       int piv = 0;
       double best = -1.0;
 #pragma unroll
       for (int i = 0; i < J; ++i) {
-        const double a = ((done >> i) & 1u) ? -1.0 : fabs(col[i]);
+        const double a = ((done >> i) & 1u) ? -1.0 : fabs(rows[i * L::WS + k]);
         const bool better = a > best;          // (first of equals: as solve_inplace; a NaN never wins)
         best = better ? a : best;
         piv = better ? i : piv;
       }
       done |= 1u << piv;
       const bool is_piv = live && r == piv;
-      if (is_piv) {
-        mine = k;
-        const double ip = 1.0 / M[k];
-#pragma unroll
-        for (int l = 0; l < J; ++l) M[l] *= ip;
-#pragma unroll
-        for (int l = 0; l < NB; ++l) R[l] *= ip;
-#pragma unroll
-        for (int l = 0; l < J; ++l) row[l] = M[l];
-#pragma unroll
-        for (int l = 0; l < NB; ++l) row[J + l] = R[l];
-      }
-      fence();
+      mine = is_piv ? k : mine;
+      const double* prow = rows + piv * L::WS;
+      const double ip = 1.0 / prow[k];
+      // the pivot's own row is scaled; every other row loses its multiple of the scaled pivot row
       const double f = is_piv ? 0.0 : M[k];
 #pragma unroll
-      for (int l = 0; l < J; ++l) M[l] = fma(-f, row[l], M[l]);
+      for (int l = k; l < J; ++l) {
+        const double pv = prow[l] * ip;
+        M[l] = is_piv ? pv : fma(-f, pv, M[l]);
+      }
 #pragma unroll
-      for (int l = 0; l < NB; ++l) R[l] = fma(-f, row[J + l], R[l]);
+      for (int l = 0; l < NB; ++l) {
+        const double pv = prow[J + l] * ip;
+        R[l] = is_piv ? pv : fma(-f, pv, R[l]);
+      }
     }
-    // rows into order: the lane that solved for unknown k hands its right-hand sides to lane k (NB <= 2 J + 1 doubles per
-    // row: through the matrix slots 0 .. 2 and the Gauss-Jordan strip, a row at a time would alias -- use a strip of
-    // NB-wide rows laid over slots 0 .. 3, which the callers have finished with when they solve)
-    fence();
-    static_assert(J * ((NB + 1) & ~1) <= L::kMat * J * L::RS, "permutation strip");
-    constexpr int PS = (NB + 1) & ~1;
-    double* perm = mat(0);
+    // rows into order: the lane that solved for unknown k hands its right-hand sides to lane k
+    double* rows = gj();
+    sync();
     if (live) {
-      double* p = perm + (mine < 0 ? r : mine) * PS;
+      double* p = rows + (mine < 0 ? r : mine) * L::WS;
 #pragma unroll
       for (int l = 0; l < NB; ++l) p[l] = R[l];
     }
-    fence();
+    sync();
     {
-      const double* p = perm + (live ? r : 0) * PS;
+      const double* p = rows + (live ? r : 0) * L::WS;
 #pragma unroll
       for (int l = 0; l < NB; ++l) R[l] = p[l];
     }
-    fence();
+    sync();
   }
 };
 
@@ -251,7 +245,9 @@ __device__ __forceinline__ void group_put_state(double* state, const TreeOp& op,
   for (int l = 0; l < J; ++l) q[(int64_t)(J + r * J + l) * nd] = op.psign * P[l];
 }
 
-// one item of a level on eight lanes: the same arithmetic as tree_item_lane<J, ADJ, DOWN> (exo_celerite_core.hpp)
+// one item of a level on eight lanes: the same arithmetic as tree_item_lane<J, ADJ, DOWN> (exo_celerite_core.hpp).
+// Everything an exchange can carry is staged at once: composing two filtering elements is 4 exchanges + the 7 of its
+// solve, applying one to a state 3 + 7, the adjoint items 3 each.
 template <int J, bool ADJ, bool DOWN>
 __device__ __forceinline__ void tree_item_group(const TreeOp& op, double* state, int c, int64_t draw, const Grp<J>& g) {
   const int64_t nd = op.n_draw;
@@ -277,12 +273,14 @@ __device__ __forceinline__ void tree_item_group(const TreeOp& op, double* state,
       // x = Abar^T Fbar ;  Fbar' = lF + x ;  Pbar' = lP + Abar^T Pbar Abar + sym(x g^T)
       g.put_rows(0, el.A);
       g.put_vec(0, m);
+      g.put_vec(2, el.b);
+      g.sync();
       const double x = g.tmv(0, 0);
       double T[J];
       g.mm(P, 0, T);
       g.put_rows(1, T);
       g.put_vec(1, x);
-      g.put_vec(2, el.b);
+      g.sync();
       g.tmm(0, 1, P2);
       double xa[J], ba[J];
       g.get_vec(1, xa);
@@ -293,7 +291,9 @@ __device__ __forceinline__ void tree_item_group(const TreeOp& op, double* state,
     } else {
       // X = I + P Jm ;  solve X [YP | ym] = [P | F + P eta] ;  F' = A ym + b ;  P' = A (YP) A^T + Cm
       g.put_rows(0, el.Jm);
+      g.put_rows(2, el.A);
       g.put_vec(0, el.eta);
+      g.sync();
       double X[J], Bm[J + 1];
       g.mm(P, 0, X);
 #pragma unroll
@@ -307,15 +307,17 @@ __device__ __forceinline__ void tree_item_group(const TreeOp& op, double* state,
       for (int l = 0; l < J; ++l) YP[l] = Bm[l];
       g.put_rows(1, YP);
       g.put_vec(1, Bm[J]);
+      g.sync();
       double AY[J];
       g.mm(el.A, 1, AY);
       m2 = el.b + g.mv(el.A, 1);
-      g.put_rows(2, el.A);
       g.mm_t(AY, 2, P2);
 #pragma unroll
       for (int l = 0; l < J; ++l) P2[l] += el.Cm[l];
     }
-    g.symmetrise(3, P2);
+    g.put_rows(3, P2);
+    g.sync();
+    g.sym_from(3, P2);
     group_put_state<J>(state, op, 2 * c + 1, draw, g, r, m2, P2);
     return;
   }
@@ -329,6 +331,8 @@ __device__ __forceinline__ void tree_item_group(const TreeOp& op, double* state,
     g.put_rows(0, e2.A);
     g.put_vec(0, e1.b);
     g.put_vec(1, e1.eta);
+    g.put_vec(3, e2.b);
+    g.sync();
     g.mm(e1.A, 0, oA);
     ob = e2.b + g.tmv(0, 0);
     const double v = g.tmv(0, 1);
@@ -337,7 +341,7 @@ __device__ __forceinline__ void tree_item_group(const TreeOp& op, double* state,
     g.mm(e1.Cm, 0, T);
     g.put_rows(1, T);
     g.put_vec(2, v);
-    g.put_vec(3, e2.b);
+    g.sync();
     g.tmm(0, 1, oC);
     double va[J], ba[J];
     g.get_vec(2, va);
@@ -347,13 +351,18 @@ __device__ __forceinline__ void tree_item_group(const TreeOp& op, double* state,
       oC[l] = e2.Cm[l] + oC[l] + 0.5 * (v * ba[l] + e2.b * va[l]);
       oJ[l] = 0.0;
     }
-    g.symmetrise(2, oC);
+    g.put_rows(2, oC);
+    g.sync();
+    g.sym_from(2, oC);
   } else {
     // M = I + C1 J2 ;  M [X1 | X3 | x2] = [A1 | C1 | b1 + C1 eta2] ;  N = I - J2 X3
     // A = A2 X1 ;  b = A2 x2 + b2 ;  C = A2 X3 A2^T + C2 ;  eta = A1^T N (eta2 - J2 b1) + eta1 ;  J = A1^T N J2 A1 + J1
     g.put_rows(0, e2.Jm);
+    g.put_rows(1, e2.A);
+    g.put_rows(2, e1.A);
     g.put_vec(0, e2.eta);
     g.put_vec(1, e1.b);
+    g.sync();
     double M[J], R[2 * J + 1];
     g.mm(e1.Cm, 0, M);
 #pragma unroll
@@ -362,40 +371,41 @@ __device__ __forceinline__ void tree_item_group(const TreeOp& op, double* state,
     for (int l = 0; l < J; ++l) { R[l] = e1.A[l]; R[J + l] = e1.Cm[l]; }
     R[2 * J] = e1.b + g.mv(e1.Cm, 0);
     const double vv = e2.eta - g.mv(e2.Jm, 1);      // (eta2 - J2 b1)_r
-    g.template solve<2 * J + 1>(M, R);              // (slots 0 .. 3 are free again)
+    g.template solve<2 * J + 1>(M, R);
     double X1[J], X3[J];
 #pragma unroll
     for (int l = 0; l < J; ++l) { X1[l] = R[l]; X3[l] = R[J + l]; }
-    g.put_rows(0, X1);
-    g.put_rows(1, X3);
-    g.put_vec(0, R[2 * J]);
-    g.mm(e2.A, 0, oA);
-    ob = e2.b + g.mv(e2.A, 0);
+    g.put_rows(3, X1);
+    g.put_rows(4, X3);
+    g.put_vec(2, R[2 * J]);
+    g.put_vec(3, vv);
+    g.sync();
+    g.mm(e2.A, 3, oA);
+    ob = e2.b + g.mv(e2.A, 2);
     double T[J], N[J];
-    g.mm(e2.A, 1, T);                               // A2 X3
-    g.mm(e2.Jm, 1, N);
+    g.mm(e2.A, 4, T);                               // A2 X3
+    g.mm(e2.Jm, 4, N);
 #pragma unroll
     for (int l = 0; l < J; ++l) N[l] = ((g.live && l == r) ? 1.0 : 0.0) - N[l];
-    g.put_rows(2, e2.A);
-    g.mm_t(T, 2, oC);
+    g.mm_t(T, 1, oC);
 #pragma unroll
     for (int l = 0; l < J; ++l) oC[l] += e2.Cm[l];
-    g.put_rows(0, e2.Jm);
-    g.put_vec(1, vv);
-    double T3[J];
+    double T3[J], TMP[J];
     g.mm(N, 0, T3);                                 // N J2
-    const double w = g.mv(N, 1);                    // N (eta2 - J2 b1)
-    g.put_rows(1, e1.A);
-    g.put_vec(2, w);
-    double TMP[J];
-    g.mm(T3, 1, TMP);                               // N J2 A1
-    oeta = e1.eta + g.tmv(1, 2);
-    g.put_rows(2, TMP);
-    g.tmm(1, 2, oJ);
+    const double w = g.mv(N, 3);                    // N (eta2 - J2 b1)
+    g.mm(T3, 2, TMP);                               // N J2 A1
+    g.put_rows(5, TMP);
+    g.put_vec(4, w);
+    g.put_rows(3, oC);
+    g.sync();
+    oeta = e1.eta + g.tmv(2, 4);
+    g.tmm(2, 5, oJ);
 #pragma unroll
     for (int l = 0; l < J; ++l) oJ[l] += e1.Jm[l];
-    g.symmetrise(0, oC);
-    g.symmetrise(3, oJ);
+    g.sym_from(3, oC);
+    g.put_rows(4, oJ);
+    g.sync();
+    g.sym_from(4, oJ);
   }
   group_store_elem<J, ADJ>(state, op, c, draw, g, r, oA, ob, oC, oeta, oJ);
 }
