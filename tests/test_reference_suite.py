@@ -127,3 +127,30 @@ def test_vector_limb_darkening_is_deprecated():
     with pytest.warns(DeprecationWarning):
         with pytest.raises(AssertionError):
             xo.LimbDarkLightCurve(torch.tensor([0.3], dtype=torch.float64))
+
+
+def test_jacobians_all_five_entries():
+    """tests/orbits/keplerian_test.py:664-699 (`test_jacobians`), all five entries with the reference's numbers: the
+    hand-written Jacobians of the duration parameterisation (a, a_planet, a_star, rho_star) and d cos(i) / d b against
+    autograd through the same constructor"""
+    from oracle import numpy_port as P
+
+    duration, period, b, ror, r_star = 0.12, 10.1235, 0.34, 0.06, 0.7
+    dv = torch.tensor(duration, dtype=torch.float64, requires_grad=True)
+    orbit = xo.KeplerianOrbit(period=period, t0=0.0, b=b, duration=dv, r_star=r_star, ror=ror)
+    for name in ("a", "a_planet", "a_star", "rho_star"):
+        (g,) = torch.autograd.grad(getattr(orbit, name).sum(), dv, retain_graph=True)
+        jac = orbit.jacobians["duration"][name]
+        assert np.allclose(float(jac.sum()), float(g)), name
+    assert float(orbit.jacobians["duration"]["a"].sum()) != 0.0 and float(orbit.jacobians["duration"]["rho_star"].sum()) != 0.0
+    # (m_planet = 0: a_star and its Jacobian vanish identically, as in the reference's case)
+    bv = torch.tensor(b, dtype=torch.float64, requires_grad=True)
+    orbit2 = xo.KeplerianOrbit(period=period, t0=0.0, b=bv, a=orbit.a.detach(), r_star=r_star, ror=ror)
+    (g,) = torch.autograd.grad(orbit2.cos_incl.sum(), bv)
+    assert np.allclose(float(orbit2.jacobians["b"]["cos_incl"].sum()), float(g))
+    # the same against the oracle's restatement of the constructor (central differences)
+    h = 1e-6
+    for name in ("a", "rho_star"):
+        f = lambda d: float(np.sum(getattr(P.KeplerianOrbit(period=period, t0=0.0, b=b, duration=d, r_star=r_star, ror=ror), name)))  # noqa: E731
+        fd = (f(duration + h) - f(duration - h)) / (2 * h)
+        assert abs(float(orbit.jacobians["duration"][name].sum()) - fd) <= 1e-6 * abs(fd), name
