@@ -513,7 +513,7 @@ __global__ __launch_bounds__(kWave) void celerite_vjp_kernel(
       if (k.live && !k.real && !k.odd) {
         ga += Ub * cs + Ub_o * sn;
         gb += Ub * sn - Ub_o * cs;
-        gd += ti * (Ub * (-k.a * sn + k.b * cs) + Ub_o * (k.a * cs + k.b * sn) - Vb * sn + Vb_o * cs);
+        gd += (ti - k.t0) * (Ub * (-k.a * sn + k.b * cs) + Ub_o * (k.a * cs + k.b * sn) - Vb * sn + Vb_o * cs);
       }
     }
     // shift to cadence n-1
@@ -543,7 +543,7 @@ __global__ __launch_bounds__(kWave) void celerite_vjp_kernel(
     const double cs = k.odd ? Vo : Vj, sn = k.odd ? Vj : Vo;
     const double Vb = Wb * id;
     const double Vb_o = __shfl(Vb, partner, 64);
-    if (k.live && !k.real && !k.odd) gd += t0 * (-Vb * sn + Vb_o * cs);
+    if (k.live && !k.real && !k.odd) gd += (t0 - k.t0) * (-Vb * sn + Vb_o * cs);   // (phases from Coefs::origin, as everywhere)
   }
   // the decay rate of a complex pair is shared by its two state indices
   const double gc_o = __shfl(gc, partner, 64);
@@ -1012,7 +1012,7 @@ __global__ __launch_bounds__(kWave) void celerite_chunk_vjp_kernel(
       if (k.live && !k.real && !k.odd) {
         ga += Ub * cs + Ub_o * sn;
         gb += Ub * sn - Ub_o * cs;
-        gd += ti * (Ub * (-k.a * sn + k.b * cs) + Ub_o * (k.a * cs + k.b * sn) - Vb * sn + Vb_o * cs);
+        gd += (ti - k.t0) * (Ub * (-k.a * sn + k.b * cs) + Ub_o * (k.a * cs + k.b * sn) - Vb * sn + Vb_o * cs);
       }
     }
     if (i == n0) break;
@@ -1552,6 +1552,7 @@ static int celerite_fwd(const double* t, Series resid, const double* diag, int64
                         int64_t n_draw, double* loglike, double* state, int64_t state_doubles, int32_t n_chunks,
                         void* stream) {
   if (n_draw == 0) return EXO_OK;
+  cf.origin = n > 0 ? t : nullptr;   // phases from the first time stamp (Coefs::origin)
   if (!gp_args_ok(n, n_diag, cf.n_real, cf.n_complex, n_draw, n_chunks) || !t || !resid.y || !diag || !loglike ||
       (cf.n_real > 0 && !cf.real) || (cf.n_complex > 0 && !cf.cplx))
     return EXO_ERR_INVALID_ARGUMENT;
@@ -1669,6 +1670,7 @@ static int celerite_vjp(const double* t, Series resid, const double* diag, int64
                         int32_t n_chunks, double* gresid, double gsign, double* gdiag, double* gdiag_sum,
                         double* gcoef_real, double* gcoef_complex, void* stream) {
   if (n_draw == 0) return EXO_OK;
+  cf.origin = n > 0 ? t : nullptr;   // (the forward call's)
   if (!gp_args_ok(n, n_diag, cf.n_real, cf.n_complex, n_draw, n_chunks) || !t || !resid.y || !diag || !gloglike ||
       !state || !gresid || (cf.n_real > 0 && (!cf.real || !gcoef_real)) ||
       (cf.n_complex > 0 && (!cf.cplx || !gcoef_complex)))
@@ -1811,7 +1813,7 @@ int exo_celerite_dot_tril_f64(const double* t, const double* diag, int64_t n_dia
   if (!gp_args_ok(n, n_diag, n_real, n_complex, n_draw, 0) || !t || !diag || !x || !z || (n_real > 0 && !coef_real) ||
       (n_complex > 0 && !coef_complex))
     return EXO_ERR_INVALID_ARGUMENT;
-  const Coefs cf{coef_real, coef_complex, pair_kind, n_real, n_complex};
+  const Coefs cf{coef_real, coef_complex, pair_kind, n_real, n_complex, n > 0 ? t : nullptr};
   const dim3 grid((unsigned)((n_draw + kWave - 1) / kWave)), block(kWave);
   EXO_GP_DISPATCH(cf.J(), hipLaunchKernelGGL((celerite_dot_tril_kernel<JJ>), grid, block, 0, (hipStream_t)stream, t, diag,
                                              n_diag, n, cf, n_draw, x, z))
@@ -1825,7 +1827,7 @@ int exo_celerite_predict_f64(const double* t, int64_t n, const double* alpha, co
   if (!gp_args_ok(n, 1, n_real, n_complex, n_draw, 0) || m < 0 || !t || !alpha || !tq || !mu ||
       (n_real > 0 && !coef_real) || (n_complex > 0 && !coef_complex))
     return EXO_ERR_INVALID_ARGUMENT;
-  const Coefs cf{coef_real, coef_complex, pair_kind, n_real, n_complex};
+  const Coefs cf{coef_real, coef_complex, pair_kind, n_real, n_complex, n > 0 ? t : nullptr};
   const dim3 grid((unsigned)((n_draw + kWave - 1) / kWave)), block(kWave);
   EXO_GP_DISPATCH(cf.J(), hipLaunchKernelGGL((celerite_predict_kernel<JJ>), grid, block, 0, (hipStream_t)stream, t, n, alpha,
                                              cf, n_draw, tq, m, mu))

@@ -48,6 +48,11 @@ struct Coefs {
   const double* cplx;
   const int32_t* kind;
   int n_real, n_complex;
+  // the time the phases d (t - *origin) of the complex terms are counted from (nullptr: 0).  The likelihood sees phase
+  // differences only, so any origin gives the same numbers in exact arithmetic; in double precision d t at t ~ 2 457 000 d
+  // has lost nine digits before the cosine is taken (round 4: the entry points point this at the series' first time stamp;
+  // every kernel of a call reads the same one, the states they exchange live in the same rotating frame)
+  const double* origin = nullptr;
   EXO_HDH int J() const { return n_real + 2 * n_complex; }
 };
 
@@ -56,6 +61,7 @@ struct Coefs {
 // (-1: its own row of gcoef_real; >= 0: doubles slot, slot + 1 of the draw's pair-slot block)
 struct LaneCoef {
   double a, b, c, d;
+  double t0;      // Coefs::origin's value
   bool real, odd, live;
   int slot;
 };
@@ -67,6 +73,7 @@ EXO_HD LaneCoef lane_coef(const Coefs& co, int64_t draw, int j, int J) {
   k.odd = false;
   k.slot = -1;
   k.a = k.b = k.c = k.d = 0.0;
+  k.t0 = co.origin ? *co.origin : 0.0;
   if (!k.live) return k;
   if (k.real) {
     const double* p = co.real + (draw * co.n_real + j) * 2;
@@ -100,7 +107,7 @@ EXO_HD void lane_uv(const LaneCoef& k, double t, double* U, double* V, double* c
     return;
   }
   double s, c;
-  exo::sincos_any(k.d * t, &s, &c);   // branch-free, no large-argument path: half the instructions and registers of libm's
+  exo::sincos_any(k.d * (t - k.t0), &s, &c);   // branch-free, no large-argument path: half the instructions and registers of libm's
   *cs = c; *sn = s;
   *U = k.odd ? (k.a * s - k.b * c) : (k.a * c + k.b * s);
   *V = k.odd ? s : c;
@@ -484,7 +491,7 @@ struct DrawCoef {
         uj = k[j].a; vj = 1.0;
       } else if (is_first(j)) {
         double sn, cs;
-        exo::sincos_any(k[j].d * t, &sn, &cs);
+        exo::sincos_any(k[j].d * (t - k[j].t0), &sn, &cs);
         uj = k[j].a * cs + k[j].b * sn; vj = cs;
         nu = k[j].a * sn - k[j].b * cs; nv = sn;
         carry = true;
@@ -664,6 +671,13 @@ EXO_HD void elem_lane(const double* EXO_RESTRICT t, Series rs, const double* EXO
   // Hence: a draw is flagged -- redone by the sequential kernels -- above kappa = 1e7 for J <= 2 (round 2: 1e5; an SHO
   // term within 1e-4 of critical damping, Matern-3/2, a signal 1e6 x the noise stay on this path) and above 1e5 for
   // wider states (as in round 2).  diag = 0 is flagged whatever J.
+  // ROUND 4: that tail was ONE gradient -- d loglike / d(oscillation rate of a complex term), whose cancellation across
+  // chunk boundaries the absolute-time form could not keep (phase_flux); with the flux form the same scan (tools/gp_cond_bins.py,
+  // 11 520 draws, flags off, worst disagreement with the sequential kernels per decade of kappa starting at 1e4 / 1e5 / 1e6 /
+  // 1e7) reads  J <= 2: 1e-9, 2e-8, 7e-8, 1e-5;  J = 3: 2e-8, 3e-7, 2e-5, 2e-3;  J = 4: 6e-8, 5e-7, 7e-5;  J = 5, 6: 2e-8,
+  // 1e-5 (one draw; median 3e-11), 3e-4 -- what is left is conditioning proper (every gradient, the log-likelihood at 1e-9).
+  // The thresholds stay where they were and now have a decade of margin under the stated 1e-6:
+  // tests/golden/gp_tail.npz and tests/test_gpu_golden.py pin it.
   double asum = 0.0, ba2 = 0.0, a_first = 0.0;
 #pragma unroll
   for (int j = 0; j < J; ++j) {
@@ -760,6 +774,27 @@ EXO_HD void elem_lane(const double* EXO_RESTRICT t, Series rs, const double* EXO
 // solve X Z = B (J x J, NB right-hand sides) in place by Gaussian elimination with partial pivoting
 template <int J, int NB>
 EXO_HD void solve_inplace(double (&X)[J][J], double (&B)[J][NB]) {
+#if defined(EXO_HOST_BUILD) && defined(EXO_SOLVE_LD)
+  // (host experiments, tools/gp_host_lab.py: is the rounding of these J x J solves what the conditioning tail is made of?)
+  {
+    long double Xl[J][J], Bl[J][NB];
+    for (int i = 0; i < J; ++i) { for (int l = 0; l < J; ++l) Xl[i][l] = X[i][l]; for (int l = 0; l < NB; ++l) Bl[i][l] = B[i][l]; }
+    for (int k = 0; k < J; ++k) {
+      int piv = k;
+      for (int i = k + 1; i < J; ++i) if (fabsl(Xl[i][k]) > fabsl(Xl[piv][k])) piv = i;
+      for (int l = 0; l < J; ++l) { long double tmp = Xl[k][l]; Xl[k][l] = Xl[piv][l]; Xl[piv][l] = tmp; }
+      for (int l = 0; l < NB; ++l) { long double tmp = Bl[k][l]; Bl[k][l] = Bl[piv][l]; Bl[piv][l] = tmp; }
+      for (int i = 0; i < J; ++i) {
+        if (i == k) continue;
+        const long double f = Xl[i][k] / Xl[k][k];
+        for (int l = 0; l < J; ++l) Xl[i][l] -= f * Xl[k][l];
+        for (int l = 0; l < NB; ++l) Bl[i][l] -= f * Bl[k][l];
+      }
+    }
+    for (int i = 0; i < J; ++i) for (int l = 0; l < NB; ++l) B[i][l] = (double)(Bl[i][l] / Xl[i][i]);
+    return;
+  }
+#endif
 #pragma unroll
   for (int k = 0; k < J; ++k) {
     int piv = k;
@@ -1560,6 +1595,30 @@ EXO_HD void chunk1_fwd_lane(const double* EXO_RESTRICT t, Series rs, const doubl
   state[ws.part(c, 2, draw)] = bad ? 1.0 : 0.0;
 }
 
+// d loglike / d(d_pair), the oscillation rate of a complex pair, ACROSS CHUNKS (round 4).  The recurrences carry absolute
+// phases d t_i, so the cotangent of d is sum_i t_i g_i, g_i the phase cotangent of cadence i -- and, the likelihood
+// depending on phase DIFFERENCES only, sum_i g_i = 0: the sum is a small difference of terms of size t |g|.  In one
+// sequential sweep that cancellation is consistent to rounding.  Across chunks it is not: every chunk's reverse sweep
+// starts from an adjoint the scans supplied and runs on a state the scans supplied, each right to kappa x 1e-16 on its own,
+// and t_c x (that mismatch) stayed behind -- the conditioning tail of tools/gp_cond_bins.py was THIS term (every other
+// gradient agreed to 1e-10; the error grew with the number of chunks and with the origin of the time axis: 100 spans away,
+// BTJD-style time stamps, it reached 1e-3).  Summed by parts the cotangent is  - sum_i (t_{i+1} - t_i) Phi_i  with the phase
+// FLUX across the link (i, i + 1), Phi_i = sum_{i' <= i} g_i': local time differences only.  A chunk's reverse sweep walks
+// its links last to first, Phi_{i-1} = Phi_i - g_i, and STARTS from the flux across its end boundary taken not from any
+// sum but from what it is: shifting every earlier phase by eps turns the pair's components of the state entering the next
+// chunk by eps -- F -> R F, S -> R S R^T -- hence
+//     Phi = Fbar^T G F + < Sbar, G S + S G^T >,   G = [[0, -1], [1, 0]] on the pair,
+// with the entering state (the next chunk's first checkpoint) and its adjoint (what the adjoint scan hands this chunk).
+template <int J, class CoefT, class SbT>
+EXO_HD double phase_flux(const CoefT& co, int j, const double* F, const Sym<J>& S, const double* Fb, const SbT& Sb) {
+  const int jn = j + 1 < J ? j + 1 : j;
+  double acc = Fb[jn] * F[j] - Fb[j] * F[jn];
+#pragma unroll
+  for (int l = 0; l < J; ++l) acc = fma(2.0, Sb(jn, l) * S(j, l) - Sb(j, l) * S(jn, l), acc);
+  (void)co;
+  return acc;
+}
+
 // (C') reverse.  Hand-derived adjoint of the two recurrences (same algebra as celerite_vjp_kernel
 // of exo_celerite.hip, one lane holding every state index): Sb is the SYMMETRISED adjoint of S.
 template <int J, int NR = -1>
@@ -1567,11 +1626,13 @@ struct Rev {
   double Sb[J][J], Fb[J], Wb[J];
   double db, zb, gasum;
   double ga[J], gb[J], gc[J], gd[J];
+  double flux[J];   // phase flux across the link behind the cadence being reversed (phase_flux), per pair (first index)
 
   // measurement half of cadence i: adjoints of (d, z, W) of this cadence -> (S, F) of this cadence
   // and the coefficient cotangents through U, V.  W = (V - S U) / d is rebuilt (the step keeps V).
   // Returns zbar (d loglike / d y_i) and dbar (d loglike / d diag_i).
-  EXO_HD void measure(const DrawCoef<J, NR>& co, const Step<J>& s, double ti, double gL, double* W_out, double* zbar_out,
+  // dt_next: t_{i+1} - t_i, the link behind this cadence (0: the series ends here)
+  EXO_HD void measure(const DrawCoef<J, NR>& co, const Step<J>& s, double dt_next, double gL, double* W_out, double* zbar_out,
                       double* dbar_out) {
     double U[J], u[J], W[J];
 #pragma unroll
@@ -1622,7 +1683,10 @@ struct Rev {
       const double a = co.k[j].a, b = co.k[j].b;
       ga[j] += re ? Ub[j] : (fi ? Ub[j] * cs + Ub[jn] * sn : 0.0);
       gb[j] += fi ? Ub[j] * sn - Ub[jn] * cs : 0.0;
-      gd[j] += fi ? ti * (Ub[j] * (-a * sn + b * cs) + Ub[jn] * (a * cs + b * sn) - Vb[j] * sn + Vb[jn] * cs) : 0.0;
+      // d: the link behind this cadence carries the flux so far; this cadence's phase cotangent leaves it (phase_flux)
+      const double gph = fi ? Ub[j] * (-a * sn + b * cs) + Ub[jn] * (a * cs + b * sn) - Vb[j] * sn + Vb[jn] * cs : 0.0;
+      gd[j] = fma(-dt_next, flux[j], gd[j]);
+      flux[j] -= gph;
     }
   }
 
@@ -1687,6 +1751,23 @@ EXO_HD void chunk1_vjp_lane(const double* EXO_RESTRICT t, Series rs, const doubl
   }
   r.db = r.zb = r.gasum = 0.0;
   double phi[J];
+  {
+    // the phase flux across the chunk's end boundary: the state entering the next chunk (its first checkpoint) against the
+    // adjoint the scan handed over (phase_flux); nothing flows out of the series' end
+    double ckn[J + J * (J + 1) / 2];
+#pragma unroll
+    for (int k = 0; k < J + J * (J + 1) / 2; ++k) ckn[k] = (n1 < n) ? state[ws.ckpt(n1 / kCkptB, k, draw)] : 0.0;
+    Sym<J> Sn;
+#pragma unroll
+    for (int k = 0; k < J * (J + 1) / 2; ++k) Sn.v[k] = ckn[J + k];
+    auto SbAt = [&](int a, int b) { return r.Sb[a][b]; };
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      const bool fi = !co.is_real(j) && co.is_first(j) && j + 1 < J;
+      const double fl = phase_flux<J>(co, j, ckn, Sn, r.Fb, SbAt);
+      r.flux[j] = fi ? fl : 0.0;
+    }
+  }
   if (n0 + 1 < n) co.set_ref(t[n0 + 1] - t[n0]);   // the forward kernel's reference: its first step
   // blocks last to first; `pend`: the step from this block's last cadence into cadence `next` (the
   // first cadence of the block after it, or of the next chunk) still has to be reversed
@@ -1782,7 +1863,7 @@ EXO_HD void chunk1_vjp_lane(const double* EXO_RESTRICT t, Series rs, const doubl
           co.step(dt, phi, false);
           r.propagate(st[q], W, phi, dt);
         }
-        r.measure(co, st[q], tt[q], gL, W, &zbar[q], &dbar[q]);
+        r.measure(co, st[q], (q + 1 < len) ? tt[q + 1] - tt[q] : (pend ? t[i + 1] - tt[q] : 0.0), gL, W, &zbar[q], &dbar[q]);
         if (q > 0) {
           // reverse of the step (i - 1) -> i: W of cadence i - 1 is rebuilt inside the next
           // measure() as well; the few operations are cheaper than a register per state index
@@ -1833,6 +1914,7 @@ struct RevP {
   Sym<J> Sb;   // (symmetrised adjoint of S: packed)
   double Fb[J], Wb[J];
   double db, zb;
+  double flux[J];   // phase flux across the link behind the cadence being reversed (phase_flux), per pair (first index)
   // coefficient cotangents: 4 J + 1 accumulators OUTSIDE the register file -- on the device a column of shared
   // memory per lane (slot k at g[k * gs]), on the host a plain array (gs = 1): k = 4 j + {a, b, c, d}; 4 J = sum of dbar
   double* g;
@@ -1842,7 +1924,7 @@ struct RevP {
   // measurement half of cadence i: adjoints of (d, z, W) of this cadence -> (S, F) of this cadence
   // and the coefficient cotangents through U, V.  W = (V - S U) / d is rebuilt (the step keeps V).
   // Returns zbar (d loglike / d y_i) and dbar (d loglike / d diag_i).
-  EXO_HD void measure(const DrawCoef<J, NR>& co, const Step<J>& s, double ti, double gL, double* W_out, double* zbar_out,
+  EXO_HD void measure(const DrawCoef<J, NR>& co, const Step<J>& s, double dt_next, double gL, double* W_out, double* zbar_out,
                       double* dbar_out) {
     double U[J], u[J], W[J];
 #pragma unroll
@@ -1893,7 +1975,9 @@ struct RevP {
       const double a = co.k[j].a, b = co.k[j].b;
       gadd(4 * j + 0, re ? Ub[j] : (fi ? Ub[j] * cs + Ub[jn] * sn : 0.0));
       gadd(4 * j + 1, fi ? Ub[j] * sn - Ub[jn] * cs : 0.0);
-      gadd(4 * j + 3, fi ? ti * (Ub[j] * (-a * sn + b * cs) + Ub[jn] * (a * cs + b * sn) - Vb[j] * sn + Vb[jn] * cs) : 0.0);
+      const double gph = fi ? Ub[j] * (-a * sn + b * cs) + Ub[jn] * (a * cs + b * sn) - Vb[j] * sn + Vb[jn] * cs : 0.0;
+      gadd(4 * j + 3, -dt_next * flux[j]);     // (the link behind this cadence carries the flux so far: phase_flux)
+      flux[j] -= gph;
     }
   }
 
@@ -1965,6 +2049,22 @@ EXO_HD void chunkp_vjp_lane(const double* EXO_RESTRICT t, Series rs, const doubl
 #pragma unroll
   for (int k = 0; k < 4 * J + 1; ++k) gacc[k * gstride] = 0.0;
   double phi[J];
+  {
+    // the phase flux across the chunk's end boundary (phase_flux): the next chunk's first checkpoint against the adjoint the
+    // scan handed over
+    double ckn[J + J * (J + 1) / 2];
+#pragma unroll
+    for (int k = 0; k < J + J * (J + 1) / 2; ++k) ckn[k] = (n1 < n) ? state[ws.ckpt(n1 / ckpt_span(J), k, draw)] : 0.0;
+    Sym<J> Sn;
+#pragma unroll
+    for (int k = 0; k < J * (J + 1) / 2; ++k) Sn.v[k] = ckn[J + k];
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      const bool fi = !co.is_real(j) && co.is_first(j) && j + 1 < J;
+      const double fl = phase_flux<J>(co, j, ckn, Sn, r.Fb, r.Sb);
+      r.flux[j] = fi ? fl : 0.0;
+    }
+  }
   if (n0 + 1 < n) co.set_ref(t[n0 + 1] - t[n0]);   // the forward kernel's reference: its first step
   // blocks last to first; `pend`: the step from this block's last cadence into cadence `next` (the
   // first cadence of the block after it, or of the next chunk) still has to be reversed
@@ -2073,7 +2173,8 @@ EXO_HD void chunkp_vjp_lane(const double* EXO_RESTRICT t, Series rs, const doubl
               co.step(dt, phi, false);
               r.propagate(st[ql], W, phi, dt);
             }
-            r.measure(co, st[ql], tt[ql], gL, W, &zbar[q], &dbar[q]);
+            r.measure(co, st[ql], (ql + 1 < slen) ? tt[ql + 1] - tt[ql] : ((i + 1 < n) ? t[i + 1] - tt[ql] : 0.0), gL, W, &zbar[q],
+                      &dbar[q]);
             if (ql > 0) {
               // reverse of the step (i - 1) -> i inside the span: W of cadence i - 1 is rebuilt inside the next
               // measure() as well; the few operations are cheaper than a register per state index

@@ -126,7 +126,7 @@ void harness_gp_set_cadence_major(int on) { g_cadence_major = on; }
 int harness_gp_fwd(const double* t, const double* y, const double* obs, const double* diag, int64_t n_diag, int64_t n,
                    const double* real, int32_t n_real, const double* cplx, int32_t n_complex, const int32_t* kind,
                    int64_t n_draw, int32_t n_chunks, double* loglike, double* state, double* flags) {
-  const gp::Coefs cf{real, cplx, kind, n_real, n_complex};
+  const gp::Coefs cf{real, cplx, kind, n_real, n_complex, n > 0 ? t : nullptr};   // (as the device entry points)
   const int J = cf.J();
   const gp::ChunkGeom cg = gp::chunk_plan(n, n_draw, J, n_chunks);
   if (cg.C <= 1 || !cg.lane) return cg.C <= 1 ? 1 : -1;
@@ -149,7 +149,7 @@ int harness_gp_vjp(const double* t, const double* y, const double* obs, const do
                    const double* real, int32_t n_real, const double* cplx, int32_t n_complex, const int32_t* kind,
                    int64_t n_draw, int32_t n_chunks, const double* gloglike, double* state, double* gresid,
                    double* gdiag, double* gdiag_sum, double* gcr, double* gcc) {
-  const gp::Coefs cf{real, cplx, kind, n_real, n_complex};
+  const gp::Coefs cf{real, cplx, kind, n_real, n_complex, n > 0 ? t : nullptr};   // (as the device entry points)
   const int J = cf.J();
   const gp::ChunkGeom cg = gp::chunk_plan(n, n_draw, J, n_chunks);
   if (cg.C <= 1 || !cg.lane) return cg.C <= 1 ? 1 : -1;
@@ -170,7 +170,7 @@ int harness_gp_vjp(const double* t, const double* y, const double* obs, const do
 int harness_gp_dot_tril(const double* t, const double* diag, int64_t n_diag, int64_t n, const double* real, int32_t n_real,
                         const double* cplx, int32_t n_complex, const int32_t* kind, int64_t n_draw, const double* x,
                         double* z) {
-  const gp::Coefs cf{real, cplx, kind, n_real, n_complex};
+  const gp::Coefs cf{real, cplx, kind, n_real, n_complex, n > 0 ? t : nullptr};   // (as the device entry points)
   for (int64_t d = 0; d < n_draw; ++d) switch (cf.J()) {
       case 1: gp::dot_tril_lane<1>(t, diag, n_diag, n, cf, x, z, d); break;
       case 2: gp::dot_tril_lane<2>(t, diag, n_diag, n, cf, x, z, d); break;
@@ -186,7 +186,7 @@ int harness_gp_dot_tril(const double* t, const double* diag, int64_t n_diag, int
 int harness_gp_predict(const double* t, int64_t n, const double* alpha, const double* real, int32_t n_real,
                        const double* cplx, int32_t n_complex, const int32_t* kind, int64_t n_draw, const double* tq,
                        int64_t m, double* mu) {
-  const gp::Coefs cf{real, cplx, kind, n_real, n_complex};
+  const gp::Coefs cf{real, cplx, kind, n_real, n_complex, n > 0 ? t : nullptr};   // (as the device entry points)
   for (int64_t d = 0; d < n_draw; ++d) switch (cf.J()) {
       case 1: gp::predict_lane<1>(t, n, alpha, cf, tq, m, mu, d); break;
       case 2: gp::predict_lane<2>(t, n, alpha, cf, tq, m, mu, d); break;

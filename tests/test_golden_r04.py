@@ -1,0 +1,60 @@
+"""CPU: the random-kernel conditioning tail (tests/golden/gp_tail.npz, oracle/make_golden_r04.py: long-double dense
+log-likelihood + gradients of 17 random kernels, J = 2 .. 6, conditioning scores 1e3 .. 3e6) against
+* the C port's sequential recurrences (what celerite2's own algorithm delivers there), and
+* the HOST-COMPILED time-parallel lane pipeline -- the code the GPU runs -- at the series' own time stamps AND with the
+  origin 2 457 000 days away (BJD-style stamps; the dense definition sees time differences only): every gradient to 1e-6,
+  none of the draws flagged.  The gradient with respect to a complex term's oscillation rate used to be the whole tail
+  and grew with the origin (exo_celerite_core.hpp, phase_flux): 1e-3 at 100 spans.
+
+reference: celerite2 is a dependency of the reference (setup.py:36), not in its tree; BASELINE.md section 3 states the
+tolerance (gradients 1e-6 relative)."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import c_port as C
+from test_gp_host import harness, run  # noqa: F401
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+G = np.load(os.path.join(GOLD, "gp_tail.npz"))
+KEYS = [str(k) for k in G["names"]]
+NAMES = ("ar", "cr", "ac", "bc", "cc", "dc")
+
+
+def case(key):
+    co = tuple(G[f"{key}_{nm}"] for nm in NAMES)
+    return G[f"{key}_t"], G[f"{key}_y"], G[f"{key}_diag"], co, float(G[f"{key}_loglike"])
+
+
+def worst(got, key):
+    e = 0.0
+    for nm, v in got.items():
+        w = G[f"{key}_g{nm}"]
+        if w.size:
+            e = max(e, float(np.abs(v - w).max() / np.abs(w).max()))
+    return e
+
+
+@pytest.mark.parametrize("key", KEYS)
+def test_gp_tail_c_port_vs_long_double(key):
+    t, y, diag, co, want = case(key)
+    ll, gr = C.celerite(t, y, diag, co, grad=True)
+    assert abs(ll - want) <= 1e-9 * abs(want)
+    assert worst({"y": gr["y"], "diag": gr["diag"], **{nm: gr[nm] for nm in NAMES}}, key) <= 1e-6
+
+
+@pytest.mark.parametrize("origin", [0.0, 2457000.0])
+@pytest.mark.parametrize("key", KEYS)
+def test_gp_tail_host_compiled_lane_pipeline(harness, key, origin):  # noqa: F811
+    t, y, diag, co, want = case(key)
+    ar, cr, ac, bc, cc, dc = co
+    real = np.stack([ar, cr], -1)[None]
+    cplx = np.stack([ac, bc, cc, dc], -1)[None]
+    ll, flags, C_used, gr = run(harness, t + origin, y[None], diag[None], real, cplx, gll=np.ones(1))
+    assert flags[0] == 0 and C_used >= 8
+    assert abs(ll[0] - want) <= 1e-9 * abs(want)
+    got = {"y": gr["y"][0], "diag": gr["diag"][0], "ar": gr["real"][0, :, 0], "cr": gr["real"][0, :, 1]}
+    got.update({nm: gr["cplx"][0, :, q] for q, nm in enumerate(("ac", "bc", "cc", "dc"))})
+    assert np.array_equal((t + origin) - origin, t)       # (the fixture's stamps sit on a 2^-20 d grid: the shift is exact)
+    assert worst(got, key) <= 1e-6, worst(got, key)

@@ -202,3 +202,87 @@ def test_overdamped_draws_stay_on_the_time_parallel_path(dev):
         del os.environ["EXO_GP_CHUNKS"]
     assert torch.allclose(ll, ll_seq, rtol=1e-11)
     assert float((gm - gm_seq).abs().max()) <= 1e-7 * float(gm_seq.abs().max())
+
+
+_TAIL = np.load(os.path.join(GOLD, "gp_tail.npz"))
+
+
+@pytest.mark.parametrize("origin", [0.0, 2457000.0])
+@pytest.mark.parametrize("key", [str(k) for k in _TAIL["names"]])
+def test_gp_tail_golden(dev, key, origin):
+    """random kernels of the conditioning tail (oracle/make_golden_r04.py: J = 2 .. 6, conditioning
+    scores 1e3 .. 3e6, decay / oscillation rates 1e-3 .. 30 per sample, gaps) on the TIME-PARALLEL path and on the
+    sequential kernels, at the series' own time stamps and 2 457 000 days away from them (the stamps sit on a 2^-20 d grid:
+    the shift is exact) -- log-likelihood to 1e-9, EVERY gradient to the stated 1e-6 against the long-double dense
+    definition, no draw flagged.  What used to fail: d loglike / d(oscillation rate) across chunk boundaries
+    (exo_celerite_core.hpp, phase_flux) and cos(d t) at BJD-sized t (Coefs::origin)"""
+    from exoplanet_amd.gp import celerite_loglike
+
+    g = _TAIL
+    real = np.stack([g[f"{key}_ar"], g[f"{key}_cr"]], -1)[None]
+    cplx = np.stack([g[f"{key}_ac"], g[f"{key}_bc"], g[f"{key}_cc"], g[f"{key}_dc"]], -1)[None]
+    want = float(g[f"{key}_loglike"])
+    t = g[f"{key}_t"] + origin
+    assert np.array_equal(t - origin, g[f"{key}_t"])
+    for n_chunks in (None, 1):
+        yt, dt = T(g[f"{key}_y"][None], dev).requires_grad_(True), T(g[f"{key}_diag"][None], dev).requires_grad_(True)
+        rt, ct = T(real, dev).requires_grad_(True), T(cplx, dev).requires_grad_(True)
+        ll = celerite_loglike(T(t, dev), yt, dt, rt, ct, n_chunks=n_chunks)
+        assert abs(ll.item() - want) <= 1e-9 * abs(want), (n_chunks, ll.item(), want)
+        ll.sum().backward()
+        worst = 0.0
+        for got, nm in ((yt.grad[0], "gy"), (dt.grad[0], "gdiag"), (rt.grad[0, :, 0], "gar"), (rt.grad[0, :, 1], "gcr"),
+                        (ct.grad[0, :, 0], "gac"), (ct.grad[0, :, 1], "gbc"), (ct.grad[0, :, 2], "gcc"), (ct.grad[0, :, 3], "gdc")):
+            w = g[f"{key}_{nm}"]
+            if w.size:
+                worst = max(worst, float(np.abs(got.cpu().numpy() - w).max() / np.abs(w).max()))
+        assert worst <= 1e-6, (n_chunks, worst)
+
+
+def test_random_kernels_time_parallel_vs_sequential_kernels(dev):
+    """the scan of tools/gp_cond_bins.py as a test, flags ON (the product's thresholds: kappa <= 1e7 for J <= 2, 1e5 for wider
+    states): 12 seeded batches of 32 random kernels each, N up to 4000 -- many chunks of 32 cadences, the worst case for the
+    boundary terms -- with the time axis starting at 1500 d.  Every draw's every gradient from the default path within 1e-6 of
+    the sequential kernels' (themselves held to the long-double definition above), whatever its conditioning score"""
+    from exoplanet_amd.gp import celerite_loglike
+
+    rng = np.random.default_rng(2027)
+    worst, n_draws = 0.0, 0
+    for case in range(12):
+        n_real = int(rng.integers(0, 4))
+        n_cplx = int(rng.integers(1, (6 - n_real) // 2 + 1))
+        N, D = int(rng.integers(300, 4000)), 32
+        span = 10 ** rng.uniform(0, 3)
+        t = np.sort(rng.uniform(0, span, N)) + 1500.0
+        if rng.uniform() < 0.3:
+            t[N // 2:] += span * rng.uniform(0.5, 20)
+        dtm = span / N
+        cr = np.zeros((D, n_real, 2)); cc = np.zeros((D, n_cplx, 4))
+        for d in range(D):
+            for j in range(n_real):
+                cr[d, j] = [10 ** rng.uniform(-2, 1), 10 ** rng.uniform(-3, 2) / dtm]
+            for j in range(n_cplx):
+                a = 10 ** rng.uniform(-2, 1); c = 10 ** rng.uniform(-3, 1.5) / dtm; dd = 10 ** rng.uniform(-2, 1.5) / dtm
+                b = rng.uniform(-1, 1) * a * c / dd
+                if rng.uniform() < 0.5:
+                    b = np.sign(b) * min(abs(b), a * 10 ** rng.uniform(-1, 3))
+                cc[d, j] = [a, b, c, dd]
+        amp2 = cr[..., 0].sum(-1) + cc[..., 0].sum(-1)
+        diag = (10 ** rng.uniform(-7, 0, size=(D, 1)) * amp2[:, None]) * (1 + 0.3 * rng.uniform(size=(D, N)))
+        y = np.sqrt(amp2)[:, None] * rng.normal(size=(D, N))
+        res = []
+        for chunks in (1, None):
+            yt, dgt, crt, cct = (T(a, dev).requires_grad_(True) for a in (y, diag, cr, cc))
+            ll = celerite_loglike(T(t, dev), yt, dgt, crt, cct, n_chunks=chunks)
+            torch.where(torch.isfinite(ll), ll, torch.zeros_like(ll)).sum().backward()
+            res.append([x.detach().cpu().numpy() for x in (ll, yt.grad, dgt.grad, crt.grad, cct.grad)])
+        want, got = res
+        ok = np.isfinite(want[0])
+        assert np.array_equal(ok, np.isfinite(got[0]))
+        assert np.abs(got[0][ok] - want[0][ok]).max() <= 1e-8 * np.abs(want[0][ok]).max()
+        for gg, ww in zip(got[1:], want[1:]):
+            if ww.size:
+                for d in np.nonzero(ok)[0]:
+                    worst = max(worst, float(np.abs(gg[d] - ww[d]).max() / (np.abs(ww[d]).max() + 1e-300)))
+        n_draws += int(ok.sum())
+    assert n_draws > 300 and worst <= 1e-6, (n_draws, worst)
