@@ -1284,7 +1284,10 @@ __global__ __launch_bounds__(kWave) void celerite_elem_kernel(const double* __re
                                                               ChunkGeom cg, int64_t flag_at) {
   const int64_t draw = (int64_t)blockIdx.x * kWave + threadIdx.x;
   if (draw >= n_draw) return;
-  if (layout_vote<J>(cf, draw) != NR) return;
+  const int vote = layout_vote<J>(cf, draw);
+  if constexpr (J > 2 && NR == -1 && EXO_GP_WIDE_COMPLEX_LAYOUT) {   // a wave of all-complex draws takes the compile-time layout
+    if (vote == 0) { elem_lane<J, 0>(t, rs, diag, n_diag, n, cf, n_draw, state, cg, draw, (int)blockIdx.y, flag_at); return; }
+  } else if (vote != NR) return;
   elem_lane<J, NR>(t, rs, diag, n_diag, n, cf, n_draw, state, cg, draw, (int)blockIdx.y, flag_at);
 }
 
@@ -1307,7 +1310,10 @@ __global__ __launch_bounds__(kWave) void celerite_chunk1_fwd_kernel(const double
                                                                     double* __restrict__ state, ChunkGeom cg) {
   const int64_t draw = (int64_t)blockIdx.x * kWave + threadIdx.x;
   if (draw >= n_draw) return;
-  if (layout_vote<J>(cf, draw) != NR) return;
+  const int vote = layout_vote<J>(cf, draw);
+  if constexpr (J > 2 && NR == -1 && EXO_GP_WIDE_COMPLEX_LAYOUT) {
+    if (vote == 0) { chunk1_fwd_lane<J, 0>(t, rs, diag, n_diag, n, cf, n_draw, state, cg, draw, (int)blockIdx.y, true); return; }
+  } else if (vote != NR) return;
   chunk1_fwd_lane<J, NR>(t, rs, diag, n_diag, n, cf, n_draw, state, cg, draw, (int)blockIdx.y, true);
 }
 // (two waves per SIMD asked for: the J = 2 complex-term variant sits at 254 + 4 registers otherwise -- one wave)
@@ -1327,9 +1333,17 @@ __global__ __launch_bounds__(kWave, (J < EXO_SPAN2_MIN_J ? EXO_VJP1_WAVES : (J <
                                                                     double gsign) {
   const int64_t draw = (int64_t)blockIdx.x * kWave + threadIdx.x;
   if (draw >= n_draw) return;
-  if (layout_vote<J>(cf, draw) != NR) return;
+  const int vote = layout_vote<J>(cf, draw);
+  if (!(J > 2 && NR == -1 && EXO_GP_WIDE_COMPLEX_LAYOUT) && vote != NR) return;
   if constexpr (J >= EXO_SPAN2_MIN_J) {   // wide states: packed adjoint, two checkpoints per block, cotangent accumulators in LDS columns
     __shared__ double gacc[4 * J + 1][kWave];
+    if constexpr (J > 2 && NR == -1 && EXO_GP_WIDE_COMPLEX_LAYOUT) {
+      if (vote == 0) {
+        chunkp_vjp_lane<J, 0>(t, rs, diag, n_diag, n, cf, n_draw, gloglike, state, cg, gresid, gdiag, gsign, draw, (int)blockIdx.y,
+                              &gacc[0][threadIdx.x], kWave);
+        return;
+      }
+    }
     chunkp_vjp_lane<J, NR>(t, rs, diag, n_diag, n, cf, n_draw, gloglike, state, cg, gresid, gdiag, gsign, draw, (int)blockIdx.y,
                            &gacc[0][threadIdx.x], kWave);
   } else

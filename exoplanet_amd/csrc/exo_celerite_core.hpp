@@ -597,6 +597,9 @@ struct DrawCoef {
 // called with NR = the number of leading real terms when every lane of the wave has the layout
 // "NR real terms, then complex pairs", and with NR = -1 (run-time flags) otherwise.  J <= 2: the
 // layouts are R (J = 1); R R or one complex pair (J = 2; R R also for a pair slot of kind 1).
+#ifndef EXO_GP_WIDE_COMPLEX_LAYOUT
+#define EXO_GP_WIDE_COMPLEX_LAYOUT 1   // 0: wide states always take the run-time layout (A/B)
+#endif
 template <int J>
 EXO_HD int layout_vote(const Coefs& cf, int64_t draw) {
   if (J == 1) return 1;
@@ -604,6 +607,15 @@ EXO_HD int layout_vote(const Coefs& cf, int64_t draw) {
     const bool rr = cf.n_real == 2 || (cf.kind != nullptr && cf.kind[draw] != 0);   // (n_complex = 1: one slot per draw)
     if (EXO_WAVE_ALL(!rr)) return 0;
     if (EXO_WAVE_ALL(rr)) return 2;
+  }
+  if (EXO_GP_WIDE_COMPLEX_LAYOUT && J > 2 && (J % 2) == 0 && cf.n_real == 0) {
+    // wide states made of pair slots only (sums of SHO terms: C5 is three of them): when every slot of every draw of the
+    // wave is a COMPLEX term the layout is the compile-time "no real terms" one (round 4) -- the per-index selects and flags of
+    // the run-time layout are a quarter of the instructions of the J = 6 kernels
+    bool allc = true;
+    if (cf.kind != nullptr)
+      for (int q = 0; q < J / 2; ++q) allc = allc && (cf.kind[draw * (J / 2) + q] == 0);
+    if (EXO_WAVE_ALL(allc)) return 0;
   }
   return -1;
 }
@@ -618,6 +630,8 @@ EXO_HD void with_layout(const Coefs& cf, int64_t draw, F&& f) {
     f(std::integral_constant<int, J == 2 ? 0 : -1>{});
   } else if (J == 2 && nr == 2) {
     f(std::integral_constant<int, J == 2 ? 2 : -1>{});
+  } else if (J > 2 && nr == 0) {
+    f(std::integral_constant<int, (J > 2) ? 0 : -1>{});
   } else {
     f(std::integral_constant<int, -1>{});
   }

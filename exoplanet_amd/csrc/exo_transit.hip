@@ -2,18 +2,36 @@
 // part of the hot path (gfx950, wave64, fp64 VALU; no MFMA -- nothing here is a
 // dense contraction).
 //
-// One light-curve sweep (value, or value + VJP) is four launches:
-//   transit_window_kernel   per (draw, planet): where in mean anomaly an overlap is possible
-//   transit_scan_kernel     classify blocks: which cadences can overlap the disk -> per-wave work
-//                           lists (inside / limb);  fill blocks: flux = 0 everywhere
-//   transit_heavy_kernel    the listed cadences, dense: Kepler solve, solution vector, flux and
-//                           (GRAD) the reverse sweep into per-block gradient partials
-//   transit_vjp_reduce_kernel   block partials -> gparams, gld, sum(gflux * flux)
-// Work units: a (draw, run of tiles_per_block tiles of 512 consecutive cadences); a lane owns
-// cadences (sub-exposures and planets are register loops), so a wave is a run of consecutive
-// cadences: transits are contiguous in time and whole waves are in / out of transit except at
-// the edges.  Per-(draw, planet) constants are derived once per block, staged in LDS and, in the
-// heavy kernel, pinned to scalar registers.
+// TWO paths through this file (runs_path() decides; section "Run-enumeration path" below has the details):
+//
+// * RUN ENUMERATION (sorted times, one exposure time -- or none -- for all cadences, no EXO_FLAG_EXACT_SCAN; timing tables
+//   allowed when the sweep has transits only and no light delay): what every BASELINE config and every sampler leg takes.
+//   A sweep (value, or value + VJP) is two launches, three when a draw is shared by several blocks:
+//     transit_enum_kernel<true>   one wave per list (draw, planet, event): the record's conjunction windows (closed form,
+//                                 refined to the contacts) and, by binary search in t, the RUN of cadences of every window,
+//                                 with prefix sums -- caller vouched for sorted times (EXO_FLAG_SORTED_TIMES); otherwise
+//                                 transit_window_kernel (+ sortedness blocks) and transit_enum_kernel<false>
+//                                 (timing tables: transit_enum_ttv_kernel, a bin's windows periodic in t - shift[bin])
+//     transit_runs_kernel         the solved cadences of the runs, dense, in full fp64 (eval_sample: Kepler solve, solution
+//                                 vector, flux, reverse sweep into LDS gradient columns), values to a run-ordered array; the
+//                                 dense output's zero fill is interleaved with the arithmetic (FillCursor); a block that owns
+//                                 its draw (>= 512 draws) also finishes it; EXO_FLAG_SPARSE: runs + values ARE the output;
+//                                 chi2 variants: the white-noise likelihood with its gradient, no (draw, cadence) array
+//     transit_finish_kernel       (draws shared by several blocks, cadence-major flux, the three-sweep chi2) block partials ->
+//                                 gparams / gld / sum(gflux flux); the runs' values to their cadences
+//
+// * LIST PATH (per-cadence exposure times, EXO_FLAG_EXACT_SCAN, timing tables together with occultations or light delay):
+//   four launches, every cadence classified:
+//     transit_window_kernel       per (draw, planet): where in mean anomaly an overlap is possible
+//     transit_scan_kernel         classify blocks: which cadences can overlap the disk -> per-wave work lists (inside / limb);
+//                                 fill blocks: flux = 0 everywhere
+//     transit_heavy_kernel        the listed cadences, dense: the same eval_sample; per-block gradient partials
+//     transit_vjp_reduce_kernel   block partials -> gparams, gld, sum(gflux flux)
+//   Work units: a (draw, run of tiles_per_block tiles of 512 consecutive cadences); a lane owns cadences (sub-exposures and
+//   planets are register loops), so a wave is a run of consecutive cadences: transits are contiguous in time and whole waves
+//   are in / out of transit except at the edges.
+// Per-(draw, planet) constants are derived once per block, staged in LDS and, in the heavy / runs kernels, pinned to scalar
+// registers.
 //
 // Reference lines restated by the fused kernel (all under /root/reference/src/exoplanet):
 //   orbits/keplerian.py:324-334   M = (t - t0 - tref) n ; kepler(M, e)
