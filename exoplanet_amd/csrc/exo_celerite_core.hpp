@@ -31,6 +31,12 @@ constexpr double kHalfLog2Pi = 0.91893853320467274178;
 constexpr int kCkptB = 4;   // cadences per block of the one-lane chunk kernels (series rows move four at a time)
 // cadences per CHECKPOINT: the whole block for J <= 2; half a block for wider states -- the reverse kernel keeps the
 // recomputed states of a span in registers (J (J + 1) / 2 + 2 J + 2 doubles each), and four of them do not fit at J > 2
+// the polish passes (chunk1_fwd_lane): a laboratory result so far -- compiled into the host harness (tests/gp_host_harness.cpp,
+// tools/gp_host_lab.py), not into the device kernels: one Jacobi sweep takes the MEDIAN error of ill-conditioned draws down
+// 10-100 x but the worst kernels only 3-10 x per four sweeps
+#ifndef EXO_GP_POLISH
+#define EXO_GP_POLISH 0
+#endif
 #ifndef EXO_SPAN2_MIN_J
 #define EXO_SPAN2_MIN_J 3
 #endif
@@ -262,11 +268,18 @@ struct ChunkWs {
     return o;
   }
   EXO_HDH int64_t tree_state(int f) const { return tree_elem(f) + (int64_t)tree_npos(f) * E() * n_draw; }
-  EXO_HDH int64_t total() const {
+  EXO_HDH int64_t off_polish() const {
     int64_t o = off_tree();
     if (tree) o = tree_elem(tree_top() + 1);
-    return o - base;
+    return o;
   }
+  // polish (round 4): q = 0 the state a chunk's forward recurrences LEAVE for the next chunk (F, packed S at that chunk's
+  // first cadence), q = 1 the adjoint of the state a chunk's reverse recurrences were ENTERED with (Fbar, packed Sbar);
+  // q = 2, 3: the same from a polish pass (its lanes read pass 0's while they write)
+  EXO_HDH int64_t polish(int q, int c, int k, int64_t draw) const {
+    return off_polish() + (((int64_t)q * C + c) * K() + k) * n_draw + draw;
+  }
+  EXO_HDH int64_t total() const { return off_polish() + (EXO_GP_POLISH ? (int64_t)4 * C * K() * n_draw : 0) - base; }
 };
 
 // the series and the measurement variance of one block of four cadences [b0, b0 + 4) clipped to n1.
@@ -1533,7 +1546,14 @@ struct Phi {
 template <int J, int NR = -1>
 EXO_HD void chunk1_fwd_lane(const double* EXO_RESTRICT t, Series rs, const double* EXO_RESTRICT diag, int64_t n_diag,
                             int64_t n, const Coefs& cf, int64_t n_draw, double* EXO_RESTRICT state, const ChunkGeom& cg,
-                            int64_t draw, int c, bool save) {
+                            int64_t draw, int c, bool save, int polish = 0) {
+  // POLISH (round 4).  The scans hand every chunk the state it is entered with, right to kappa x 1e-16 -- which for a
+  // conditioning score kappa of 1e5 .. 1e8 is what the gradients' tail was made of, and why such draws were REDONE by the
+  // sequential kernels (~50 x the step, for the whole batch).  But the recurrences of a chunk forget the state they
+  // were entered with (the filter is a contraction: the better the data, the faster), so the state they LEAVE for the
+  // next chunk is far more accurate than the one they were given: pass 0 stores it (ChunkWs::polish), and a second pass
+  // over the draws that need it -- polish = 1 -- enters every chunk with what its predecessor left.  One Jacobi sweep of
+  // the exact recurrences, all chunks at once; the scans have become the initial guess.
   const int64_t n0 = c * cg.L, n1 = (n0 + cg.L < n) ? n0 + cg.L : n;
   const ChunkWs ws = chunk_ws(n, n_draw, J, cg);
   DrawCoef<J, NR> co;
@@ -1544,7 +1564,13 @@ EXO_HD void chunk1_fwd_lane(const double* EXO_RESTRICT t, Series rs, const doubl
   Fwd<J> f;
 #pragma unroll
   for (int j = 0; j < J; ++j) { f.U[j] = f.V[j] = f.W[j] = 0.0; }
-  {
+  if (EXO_GP_POLISH && polish && c > 0) {
+    co.uv(t[n0], f.U, f.V);
+#pragma unroll
+    for (int j = 0; j < J; ++j) f.F[j] = state[ws.polish((polish & 1) ? 0 : 2, c - 1, j, draw)];
+#pragma unroll
+    for (int k = 0; k < J * (J + 1) / 2; ++k) f.S.v[k] = state[ws.polish((polish & 1) ? 0 : 2, c - 1, J + k, draw)];
+  } else {
     // entering state from (B) as (F, P): S = Delta_{n0} - P
     DeltaCoef<J, NR> dc;
     dc.init(cf, draw);
@@ -1607,6 +1633,18 @@ EXO_HD void chunk1_fwd_lane(const double* EXO_RESTRICT t, Series rs, const doubl
   state[ws.part(c, 0, draw)] = acc;
   state[ws.part(c, 1, draw)] = log(lman) + (double)lsum * 0.69314718055994530942;
   state[ws.part(c, 2, draw)] = bad ? 1.0 : 0.0;
+  if (EXO_GP_POLISH && save && n1 < n) {
+    // what this chunk leaves for the next one: the step from its last cadence into cadence n1 (ChunkWs::polish; a polish
+    // pass reads pass 0's values and writes to the other half of the double buffer `polish & 1` selects -- see the callers)
+    const double dt = t[n1] - tprev;
+    co.step(dt, phi);
+    f.advance(phi);
+    const int slot = (polish & 1) ? 2 : 0;   // (two buffers alternate: the lanes of a pass read the pass before while they write)
+#pragma unroll
+    for (int j = 0; j < J; ++j) state[ws.polish(slot, c, j, draw)] = f.F[j];
+#pragma unroll
+    for (int k = 0; k < J * (J + 1) / 2; ++k) state[ws.polish(slot, c, J + k, draw)] = f.S.v[k];
+  }
 }
 
 // d loglike / d(d_pair), the oscillation rate of a complex pair, ACROSS CHUNKS (round 4).  The recurrences carry absolute
@@ -1745,7 +1783,9 @@ template <int J, int NR = -1>
 EXO_HD void chunk1_vjp_lane(const double* EXO_RESTRICT t, Series rs, const double* EXO_RESTRICT diag, int64_t n_diag,
                             int64_t n, const Coefs& cf, int64_t n_draw, const double* EXO_RESTRICT gloglike,
                             double* EXO_RESTRICT state, const ChunkGeom& cg, double* EXO_RESTRICT gresid,
-                            double* EXO_RESTRICT gdiag, double gsign, int64_t draw, int c) {
+                            double* EXO_RESTRICT gdiag, double gsign, int64_t draw, int c, int polish = 0) {
+  // (polish: the adjoint this chunk is entered with is what the NEXT chunk's reverse recurrences left in pass 0 -- the
+  // adjoint of the state entering it -- instead of the adjoint scan's: chunk1_fwd_lane has the reasoning)
   const int64_t n0 = c * cg.L, n1 = (n0 + cg.L < n) ? n0 + cg.L : n;
   const ChunkWs ws = chunk_ws(n, n_draw, J, cg);
   DrawCoef<J, NR> co;
@@ -1755,13 +1795,16 @@ EXO_HD void chunk1_vjp_lane(const double* EXO_RESTRICT t, Series rs, const doubl
   const double* EXO_RESTRICT dg = diag + (n_diag == 1 ? 0 : draw * n);
   const double gL = gloglike[draw];
   Rev<J, NR> r;
+  const bool from_next = EXO_GP_POLISH && polish && n1 < n;
 #pragma unroll
   for (int j = 0; j < J; ++j) {
-    r.Fb[j] = state[ws.bnd(2, c, j, draw)];
+    r.Fb[j] = from_next ? state[ws.polish((polish & 1) ? 1 : 3, c + 1, j, draw)] : state[ws.bnd(2, c, j, draw)];
     r.Wb[j] = 0.0;
     r.ga[j] = r.gb[j] = r.gc[j] = r.gd[j] = 0.0;
 #pragma unroll
-    for (int l = 0; l < J; ++l) r.Sb[j][l] = state[ws.bnd(2, c, J + j * J + l, draw)];
+    for (int l = 0; l < J; ++l)
+      r.Sb[j][l] = from_next ? state[ws.polish((polish & 1) ? 1 : 3, c + 1, J + Sym<J>::idx(j, l), draw)]
+                             : state[ws.bnd(2, c, J + j * J + l, draw)];
   }
   r.db = r.zb = r.gasum = 0.0;
   double phi[J];
@@ -1918,6 +1961,15 @@ EXO_HD void chunk1_vjp_lane(const double* EXO_RESTRICT t, Series rs, const doubl
     state[ws.gpart(c, 4 * j + 3, draw)] = r.gd[j];
   }
   state[ws.gpart(c, 4 * J, draw)] = r.gasum;
+  if (EXO_GP_POLISH && c > 0) {   // the adjoint of the state this chunk was entered with: what a polish pass enters the previous chunk with
+    const int slot = (polish & 1) ? 3 : 1;
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      state[ws.polish(slot, c, j, draw)] = r.Fb[j];
+#pragma unroll
+      for (int l = j; l < J; ++l) state[ws.polish(slot, c, J + Sym<J>::idx(j, l), draw)] = 0.5 * (r.Sb[j][l] + r.Sb[l][j]);
+    }
+  }
 }
 
 // (C') reverse for wide states (J > 2): the same adjoint with the (symmetrised) adjoint of S PACKED, and
@@ -2040,7 +2092,8 @@ template <int J, int NR = -1>
 EXO_HD void chunkp_vjp_lane(const double* EXO_RESTRICT t, Series rs, const double* EXO_RESTRICT diag, int64_t n_diag,
                             int64_t n, const Coefs& cf, int64_t n_draw, const double* EXO_RESTRICT gloglike,
                             double* EXO_RESTRICT state, const ChunkGeom& cg, double* EXO_RESTRICT gresid,
-                            double* EXO_RESTRICT gdiag, double gsign, int64_t draw, int c, double* gacc, int gstride) {
+                            double* EXO_RESTRICT gdiag, double gsign, int64_t draw, int c, double* gacc, int gstride,
+                            int polish = 0) {
   const int64_t n0 = c * cg.L, n1 = (n0 + cg.L < n) ? n0 + cg.L : n;
   const ChunkWs ws = chunk_ws(n, n_draw, J, cg);
   DrawCoef<J, NR> co;
@@ -2050,13 +2103,15 @@ EXO_HD void chunkp_vjp_lane(const double* EXO_RESTRICT t, Series rs, const doubl
   const double* EXO_RESTRICT dg = diag + (n_diag == 1 ? 0 : draw * n);
   const double gL = gloglike[draw];
   RevP<J, NR> r;
+  const bool from_next = EXO_GP_POLISH && polish && n1 < n;   // (polish: entered with what the next chunk's reverse recurrences left, chunk1_fwd_lane)
 #pragma unroll
   for (int j = 0; j < J; ++j) {
-    r.Fb[j] = state[ws.bnd(2, c, j, draw)];
+    r.Fb[j] = from_next ? state[ws.polish((polish & 1) ? 1 : 3, c + 1, j, draw)] : state[ws.bnd(2, c, j, draw)];
     r.Wb[j] = 0.0;
 #pragma unroll
     for (int l = j; l < J; ++l)   // (the adjoint scan leaves a symmetric matrix)
-      r.Sb(j, l) = 0.5 * (state[ws.bnd(2, c, J + j * J + l, draw)] + state[ws.bnd(2, c, J + l * J + j, draw)]);
+      r.Sb(j, l) = from_next ? state[ws.polish((polish & 1) ? 1 : 3, c + 1, J + Sym<J>::idx(j, l), draw)]
+                             : 0.5 * (state[ws.bnd(2, c, J + j * J + l, draw)] + state[ws.bnd(2, c, J + l * J + j, draw)]);
   }
   r.db = r.zb = 0.0;
   r.g = gacc; r.gs = gstride;
@@ -2224,6 +2279,13 @@ EXO_HD void chunkp_vjp_lane(const double* EXO_RESTRICT t, Series rs, const doubl
 #pragma unroll
       for (int k = 0; k < (kAhead ? kK : 1); ++k) ck[k] = ck_nxt[k];
     }
+  }
+  if (EXO_GP_POLISH && c > 0) {   // the adjoint of the state this chunk was entered with (ChunkWs::polish)
+    const int slot = (polish & 1) ? 3 : 1;
+#pragma unroll
+    for (int j = 0; j < J; ++j) state[ws.polish(slot, c, j, draw)] = r.Fb[j];
+#pragma unroll
+    for (int k = 0; k < J * (J + 1) / 2; ++k) state[ws.polish(slot, c, J + k, draw)] = r.Sb.v[k];
   }
 #pragma unroll
   for (int j = 0; j < J; ++j) {

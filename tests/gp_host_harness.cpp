@@ -4,6 +4,7 @@
 // is checked against the oracle on a machine without a GPU.  Not part of the product; nothing in
 // exoplanet_amd/ loads this.  On the GPU the same functions run one lane per (draw, chunk).
 #define EXO_HOST_BUILD 1
+#define EXO_GP_POLISH 1   // (the polish passes are a host-side experiment: exo_celerite_core.hpp)
 #ifndef EXO_LANE_MAX_J
 #define EXO_LANE_MAX_J 6
 #endif
@@ -14,6 +15,8 @@
 namespace {
 
 int g_serial_scan = 0;   // 1: the serial reference scans (bscan_lane, bscan_vjp_lane) instead of the trees
+int g_polish = 0;        // 1: a polish pass over every draw after the chunk recurrences (forward and reverse), as the
+                         //    device runs it for the draws whose conditioning asks for it
 
 template <int J>
 void run_fwd(const double* t, gp::Series rs, const double* diag, int64_t n_diag, int64_t n, const gp::Coefs& cf,
@@ -44,11 +47,12 @@ void run_fwd(const double* t, gp::Series rs, const double* diag, int64_t n_diag,
   } else {
     for (int64_t d = 0; d < n_draw; ++d) gp::bscan_lane<J>(t, cf, n, n_draw, state, cg, d);
   }
-  for (int c = 0; c < cg.C; ++c)
-    for (int64_t d = 0; d < n_draw; ++d)
-      gp::with_layout<J>(cf, d, [&](auto nr) {
-        gp::chunk1_fwd_lane<J, decltype(nr)::value>(t, rs, diag, n_diag, n, cf, n_draw, state, cg, d, c, true);
-      });
+  for (int pass = 0; pass <= g_polish; ++pass)
+    for (int c = 0; c < cg.C; ++c)
+      for (int64_t d = 0; d < n_draw; ++d)
+        gp::with_layout<J>(cf, d, [&](auto nr) {
+          gp::chunk1_fwd_lane<J, decltype(nr)::value>(t, rs, diag, n_diag, n, cf, n_draw, state, cg, d, c, true, pass);
+        });
   for (int64_t d = 0; d < n_draw; ++d) {
     double acc = 0.0, logdet = 0.0, bad = 0.0;
     for (int c = 0; c < cg.C; ++c) {
@@ -83,16 +87,17 @@ void run_vjp(const double* t, gp::Series rs, const double* diag, int64_t n_diag,
   } else {
     for (int64_t d = 0; d < n_draw; ++d) gp::bscan_vjp_lane<J>(n, n_draw, state, cg, d);
   }
+  for (int pass = 0; pass <= g_polish; ++pass)
   for (int c = 0; c < cg.C; ++c)
     for (int64_t d = 0; d < n_draw; ++d)
       gp::with_layout<J>(cf, d, [&](auto nr) {
         if constexpr (J > 2) {   // as the device wrapper (celerite_chunk1_vjp_kernel) dispatches
           double gacc[4 * J + 1];
           gp::chunkp_vjp_lane<J, decltype(nr)::value>(t, rs, diag, n_diag, n, cf, n_draw, gloglike, state, cg, gresid, gdiag,
-                                                      gsign, d, c, gacc, 1);
+                                                      gsign, d, c, gacc, 1, pass);
         } else
           gp::chunk1_vjp_lane<J, decltype(nr)::value>(t, rs, diag, n_diag, n, cf, n_draw, gloglike, state, cg, gresid, gdiag,
-                                                      gsign, d, c);
+                                                      gsign, d, c, pass);
       });
   for (int64_t d = 0; d < n_draw; ++d)
     for (int k = 0; k < 4 * J + 1; ++k) {
@@ -109,6 +114,7 @@ void run_vjp(const double* t, gp::Series rs, const double* diag, int64_t n_diag,
 extern "C" {
 
 void harness_set_serial_scan(int v) { g_serial_scan = v; }
+void harness_set_polish(int v) { g_polish = v; }
 
 
 int64_t harness_gp_state_doubles(int64_t n, int64_t n_draw, int32_t n_real, int32_t n_complex, int32_t n_chunks) {
