@@ -47,7 +47,20 @@ void run_fwd(const double* t, gp::Series rs, const double* diag, int64_t n_diag,
   } else {
     for (int64_t d = 0; d < n_draw; ++d) gp::bscan_lane<J>(t, cf, n, n_draw, state, cg, d);
   }
-  for (int pass = 0; pass <= g_polish; ++pass)
+  if (g_polish < 0 && ((-g_polish) & 1)) {
+    // experiment: the chunks ONE AFTER THE OTHER, each entered with what its predecessor just left -- the sequential algorithm
+    // in chunk-sized steps (exact boundary states): what the accuracy would be if the scans were perfect
+    for (int c = 0; c < cg.C; ++c) {
+      for (int64_t d = 0; d < n_draw; ++d)
+        gp::with_layout<J>(cf, d, [&](auto nr) {
+          gp::chunk1_fwd_lane<J, decltype(nr)::value>(t, rs, diag, n_diag, n, cf, n_draw, state, cg, d, c, true, c > 0 ? 1 : 0);
+        });
+      if (c > 0)
+        for (int k = 0; k < ws.K(); ++k)
+          for (int64_t d = 0; d < n_draw; ++d) state[ws.polish(0, c, k, d)] = state[ws.polish(2, c, k, d)];
+    }
+  } else
+  for (int pass = 0; pass <= (g_polish > 0 ? g_polish : 0); ++pass)
     for (int c = 0; c < cg.C; ++c)
       for (int64_t d = 0; d < n_draw; ++d)
         gp::with_layout<J>(cf, d, [&](auto nr) {
@@ -87,18 +100,25 @@ void run_vjp(const double* t, gp::Series rs, const double* diag, int64_t n_diag,
   } else {
     for (int64_t d = 0; d < n_draw; ++d) gp::bscan_vjp_lane<J>(n, n_draw, state, cg, d);
   }
-  for (int pass = 0; pass <= g_polish; ++pass)
-  for (int c = 0; c < cg.C; ++c)
+  const bool seq_adj = g_polish < 0 && ((-g_polish) & 2);   // experiment: exact adjoint boundary states (chunks last to first)
+  for (int pass = 0; pass <= (g_polish > 0 ? g_polish : 0); ++pass)
+  for (int cc = 0; cc < cg.C; ++cc) {
+    const int c = seq_adj ? cg.C - 1 - cc : cc;
+    if (seq_adj && c + 1 < cg.C && c + 1 < cg.C - 0 && cc > 1)
+      for (int k = 0; k < ws.K(); ++k)
+        for (int64_t d = 0; d < n_draw; ++d) state[ws.polish(1, c + 1, k, d)] = state[ws.polish(3, c + 1, k, d)];
+    const int lane_pass = seq_adj ? (cc > 0 ? 1 : 0) : pass;
     for (int64_t d = 0; d < n_draw; ++d)
       gp::with_layout<J>(cf, d, [&](auto nr) {
         if constexpr (J > 2) {   // as the device wrapper (celerite_chunk1_vjp_kernel) dispatches
           double gacc[4 * J + 1];
           gp::chunkp_vjp_lane<J, decltype(nr)::value>(t, rs, diag, n_diag, n, cf, n_draw, gloglike, state, cg, gresid, gdiag,
-                                                      gsign, d, c, gacc, 1, pass);
+                                                      gsign, d, c, gacc, 1, lane_pass);
         } else
           gp::chunk1_vjp_lane<J, decltype(nr)::value>(t, rs, diag, n_diag, n, cf, n_draw, gloglike, state, cg, gresid, gdiag,
-                                                      gsign, d, c, pass);
+                                                      gsign, d, c, lane_pass);
       });
+  }
   for (int64_t d = 0; d < n_draw; ++d)
     for (int k = 0; k < 4 * J + 1; ++k) {
       double v = 0.0;
@@ -115,6 +135,15 @@ extern "C" {
 
 void harness_set_serial_scan(int v) { g_serial_scan = v; }
 void harness_set_polish(int v) { g_polish = v; }
+// (experiments: where the checkpoints -- the states (F, packed S) entering every ckpt_span(J)-th cadence -- live in `state`)
+int64_t harness_gp_ckpt_layout(int64_t n, int64_t n_draw, int32_t n_real, int32_t n_complex, int32_t n_chunks, int64_t* K,
+                               int64_t* span, int64_t* L) {
+  const int J = n_real + 2 * n_complex;
+  const gp::ChunkGeom cg = gp::chunk_plan(n, n_draw, J, n_chunks);
+  const gp::ChunkWs ws = gp::chunk_ws(n, n_draw, J, cg);
+  *K = ws.K(); *span = gp::ckpt_span(J); *L = cg.L;
+  return ws.off_ckpt();
+}
 
 
 int64_t harness_gp_state_doubles(int64_t n, int64_t n_draw, int32_t n_real, int32_t n_complex, int32_t n_chunks) {
