@@ -97,6 +97,10 @@ _SIGNATURES = {
     "exo_orbit_vector_vjp_f64": (ctypes.c_int, [_c_dp, _i64, _c_dp, _i64, _i32, _u32, _c_dp, _c_dp, _c_dp]),
     # t, n_cad, texp, n_texp, stencil_dt, stencil_w, n_sub, params, ld, n_draw, n_planet, flags, obs, ivar, n_ivar,
     # chi2, gparams, gld, workspace, workspace_bytes, stream
+    "exo_transit_flux_jac_doubles": (_i64, [_i64, _i64, _i32]),
+    "exo_transit_flux_fwd_jac_f64": (ctypes.c_int, [_c_dp, _i64, _c_dp, _i64, _c_dp, _c_dp, _i32, _c_dp, _c_dp, _i64, _i32, _u32,
+                                                    _c_dp, _c_dp, _i64, _c_dp, _i64, _c_dp]),
+    "exo_transit_flux_jac_vjp_f64": (ctypes.c_int, [_c_dp, _i64, _i64, _i32, _u32, _c_dp, _c_dp, _i64, _c_dp, _c_dp, _c_dp, _c_dp]),
     "exo_transit_chi2_vjp_f64": (ctypes.c_int, [_c_dp, _i64, _c_dp, _i64, _c_dp, _c_dp, _i32, _c_dp, _c_dp, _i64, _i32, _u32,
                                                 _c_dp, _c_dp, _i64, _c_dp, _c_dp, _c_dp, _c_dp, _i64, _c_dp]),
     # ..., flags, ttv_edges, ttv_shift, n_edge, obs, ivar, n_ivar, chi2, gparams, gld, gshift, workspace, workspace_bytes, stream

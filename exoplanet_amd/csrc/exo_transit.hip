@@ -2048,7 +2048,17 @@ struct FinishArgs {
 #ifndef EXO_RUNS_MIN_WAVES
 #define EXO_RUNS_MIN_WAVES 3
 #endif
-template <bool GRAD, bool SECONDARY, bool LDELAY = false, bool CHI2 = false, bool TTV = false>
+// JAC (round 4; GRAD with a UNIT cotangent, value sweep of exo_transit_flux_fwd_jac_f64): a light curve that is the mean of a GP
+// is swept before its cotangent exists, and used to be swept AGAIN for the gradient once it did.  The cotangent enters
+// linearly -- gparams = sum over cadences of g x dF / dparams -- so this sweep leaves, next to every solved cadence's value, its
+// sixteen derivatives (ten record slots, six limb-darkening coefficients: kJac doubles at `partial`, which is the Jacobian
+// array here) and the second sweep becomes a contraction (transit_jac_vjp_kernel).  With an exposure stencil a cadence is
+// n_sub Kepler solves and still one row of sixteen: C5 (7 sub-exposures) 238 us -> a few.
+constexpr int kJac = 16;
+__device__ __forceinline__ int jac_slot(int s) {   // LDS gradient column -> position in the row (-1: not kept)
+  return s < G_PAD ? s : (s == G_SINI ? 9 : (s >= kNG && s < kNG + 6 ? 10 + (s - kNG) : -1));
+}
+template <bool GRAD, bool SECONDARY, bool LDELAY = false, bool CHI2 = false, bool TTV = false, bool JAC = false>
 __global__ __launch_bounds__(kBlock, LDELAY ? 2 : EXO_RUNS_MIN_WAVES) void transit_runs_kernel(
     const double* __restrict__ t, int64_t n_cad, const double* __restrict__ texp, int64_t n_texp,
     const double* __restrict__ stencil_dt, const double* __restrict__ stencil_w, int n_sub,
@@ -2097,8 +2107,10 @@ __global__ __launch_bounds__(kBlock, LDELAY ? 2 : EXO_RUNS_MIN_WAVES) void trans
   const int per_round =
       __builtin_amdgcn_readfirstlane(total_rounds > 0 ? (fc.pieces_left() + total_rounds - 1) / total_rounds : 0);   // (wave-uniform)
 
+  static_assert(!JAC || (GRAD && !LDELAY && !CHI2 && !TTV), "the Jacobian sweep is the plain value + gradient evaluation");
   const int ng_draw = n_planet * kNG + 7;
-  double* __restrict__ pout = GRAD ? partial + ((int64_t)draw * hb + bx) * ng_draw : nullptr;
+  double* __restrict__ pout = (GRAD && !JAC) ? partial + ((int64_t)draw * hb + bx) * ng_draw : nullptr;
+  double* __restrict__ jac = JAC ? partial : nullptr;
   const GradAcc acc{GRAD ? &lds_acc[0][threadIdx.x] : nullptr};
   if (GRAD) {
 #pragma unroll
@@ -2200,7 +2212,9 @@ __global__ __launch_bounds__(kBlock, LDELAY ? 2 : EXO_RUNS_MIN_WAVES) void trans
           it.tv = t[it.i];
           // the cotangent of the cadence's flux: dense [draw][cadence] (x planet), or -- gsparse -- at the value's own
           // position in the value array (transit_residual_kernel wrote it there)
-          if (CHI2) {
+          if (JAC) {
+            it.g = (j < total) ? 1.0 : 0.0;   // unit cotangent: the row of derivatives itself
+          } else if (CHI2) {
             if (j < total) { it.g = gflux[it.i]; it.w = gsparse[chi2_nw == 1 ? 0 : it.i]; }
           } else if (GRAD && j < total)
             it.g = gsparse ? gsparse[vbase + it.v]
@@ -2238,12 +2252,30 @@ __global__ __launch_bounds__(kBlock, LDELAY ? 2 : EXO_RUNS_MIN_WAVES) void trans
             if (CHI2) {
               const double r = F - cur.g;
               acc.add(kNG + 6, cur.w * (r * r - cur.g * cur.g));
-            } else if (GRAD) {
+            } else if (GRAD && !JAC) {
               acc.add(kNG + 6, gw * F);
             }
             if (TTV && GRAD && !trusted) tgrad.flush_lane(ks);
           }
           if (TTV && GRAD && trusted) tgrad.flush_runs(cur.q, &s_grun[0][0], kSeg);
+          if (JAC) {
+            // this cadence's row: the thread's gradient columns hold sum_k w_k dF_k / d(slot); out they go, and back to zero
+            double row[kJac];
+#pragma unroll
+            for (int q = 0; q < kJac; ++q) row[q] = 0.0;
+#pragma unroll
+            for (int sl = 0; sl < kNG + 6; ++sl) {
+              if (jac_slot(sl) >= 0) {
+                row[jac_slot(sl)] = lds_acc[sl][threadIdx.x];
+                lds_acc[sl][threadIdx.x] = 0.0;
+              }
+            }
+            if (has) {
+              double2* __restrict__ dst = reinterpret_cast<double2*>(jac + (vbase + cur.v) * kJac);
+#pragma unroll
+              for (int q = 0; q < kJac / 2; ++q) dst[q] = make_double2(row[2 * q], row[2 * q + 1]);
+            }
+          }
           if (vals && has) {
             vals[vbase + cur.v] = f;
             if (vcad) vcad[vbase + cur.v] = cur.i;   // (dense output: where the last kernel puts it)
@@ -2266,9 +2298,9 @@ __global__ __launch_bounds__(kBlock, LDELAY ? 2 : EXO_RUNS_MIN_WAVES) void trans
       lds_acc[G_TP][threadIdx.x] = lds_acc[G_PAD][threadIdx.x];
       lds_acc[G_PAD][threadIdx.x] = 0.0;
     }
-    if (GRAD) reduce_columns(lds_acc, sh.red, 0, kNG, pout + p * kNG);
+    if (GRAD && !JAC) reduce_columns(lds_acc, sh.red, 0, kNG, pout + p * kNG);
   }
-  if (GRAD) reduce_columns(lds_acc, sh.red, kNG, 7, pout + n_planet * kNG);
+  if (GRAD && !JAC) reduce_columns(lds_acc, sh.red, kNG, 7, pout + n_planet * kNG);
   fc.issue(1 << 30);   // whatever is left of the fill (all of it for a block without work)
   if (fin.fold) {
     // The last block of a draw to get here finishes the draw: partials -> gradients (in block order, whoever is
@@ -2286,10 +2318,70 @@ __global__ __launch_bounds__(kBlock, LDELAY ? 2 : EXO_RUNS_MIN_WAVES) void trans
     } else {
       __syncthreads();
     }
-    finish_draw(draw, GRAD ? partial : nullptr, hb, n_planet, SECONDARY, fin.gparams, fin.gld, fin.flux_dot, n_cad, flags, n_ev,
+    finish_draw(draw, (GRAD && !JAC) ? partial : nullptr, hb, n_planet, SECONDARY, fin.gparams, fin.gld, fin.flux_dot, n_cad, flags, n_ev,
                 rl, vals, vcad, fill, nullptr, 0, nullptr,
                 (TTV && GRAD) ? ttv : Ttv{nullptr, nullptr, nullptr, 0});
   }
+}
+
+// The second half of the Jacobian route (transit_runs_kernel<.., JAC>): gparams, gld and sum(gflux flux) of a draw from the rows
+// the value sweep left -- one block per draw, the planets in turn, every thread its share of the planet's solved cadences
+// (the cotangent gathered through the cadence index of the value array), a fixed-order sum over the block: bit-reproducible.
+// Output: the draw's partials in the layout of the runs kernel with ONE block per draw (transit_finish_kernel turns them
+// into gparams / gld / flux_dot as it does for the sweep's).
+__global__ __launch_bounds__(kBlock) void transit_jac_vjp_kernel(int64_t n_cad, int n_planet, int n_ev, uint32_t flags,
+                                                                 RunLists rl, const double* __restrict__ vals,
+                                                                 const int32_t* __restrict__ vcad,
+                                                                 const double* __restrict__ jac,
+                                                                 const double* __restrict__ gflux, int64_t n_draw,
+                                                                 double* __restrict__ partial) {
+  __shared__ double red[kJac + 1][kBlock];
+  const int64_t draw = blockIdx.y;
+  const int nb = gridDim.x, bx = blockIdx.x;       // a draw's cadences in nb contiguous shares (as the sweep's blocks share them)
+  const int ng_draw = n_planet * kNG + 7;
+  double* __restrict__ pout = partial + (draw * nb + bx) * ng_draw;
+  const bool cmaj = flags & EXO_FLAG_CADENCE_MAJOR;
+  double keep = 0.0;   // threads 10 .. 15: the running sum over planets of limb-darkening coefficient (thread - 10); thread 16: the dot
+  for (int p = 0; p < n_planet; ++p) {
+    int n_vals = 0;
+    for (int ev = 0; ev < n_ev; ++ev) {
+      const int64_t list = (draw * n_planet + p) * n_ev + ev;
+      n_vals += rl.pre_all[list * (rl.r_max + 1) + rl.nrun[list]];
+    }
+    const int64_t vbase = (draw * n_planet + p) * n_cad;
+    double acc[kJac + 1];
+#pragma unroll
+    for (int q = 0; q <= kJac; ++q) acc[q] = 0.0;
+    const int v0 = (int)((int64_t)n_vals * bx / nb), v1 = (int)((int64_t)n_vals * (bx + 1) / nb);
+    for (int v = v0 + threadIdx.x; v < v1; v += kBlock) {
+      const int64_t i = vcad[vbase + v];
+      const double g = cmaj ? gflux[i * n_draw + draw] : gflux[draw * n_cad + i];
+      const double2* __restrict__ row = reinterpret_cast<const double2*>(jac + (vbase + v) * kJac);
+#pragma unroll
+      for (int q = 0; q < kJac / 2; ++q) {
+        const double2 r2 = row[q];
+        acc[2 * q] = fma(g, r2.x, acc[2 * q]);
+        acc[2 * q + 1] = fma(g, r2.y, acc[2 * q + 1]);
+      }
+      acc[kJac] = fma(g, vals[vbase + v], acc[kJac]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q <= kJac; ++q) red[q][threadIdx.x] = acc[q];
+    __syncthreads();
+    if (threadIdx.x <= kJac) {
+      double v = 0.0;
+      for (int k = 0; k < kBlock; ++k) v += red[threadIdx.x][k];
+      const int q = threadIdx.x;
+      if (q < 10) {
+        pout[p * kNG + (q < 9 ? q : G_SINI)] = v;
+      } else {
+        keep += v;
+      }
+    }
+    if (threadIdx.x < kNG && (threadIdx.x == G_PAD || threadIdx.x == G_CL)) pout[p * kNG + threadIdx.x] = 0.0;
+  }
+  if (threadIdx.x >= 10 && threadIdx.x <= kJac) pout[n_planet * kNG + (threadIdx.x - 10)] = keep;
 }
 
 // White-noise likelihood on the sparse output (exo_transit_chi2_vjp_f64), between the value sweep and the gradient
@@ -2643,7 +2735,7 @@ inline int launch_runs_sweep(const double* t, int64_t n_cad, const double* texp,
                              const double* stencil_w, int32_t n_sub, const double* params, const double* ld,
                              int64_t n_draw, int32_t n_planet, uint32_t flags, const double* gflux, double* flux,
                              double* gparams, double* gld, double* flux_dot, const RunWs& w, hipStream_t st,
-                             const Chi2Args* chi2 = nullptr, const Ttv* ttv = nullptr) {
+                             const Chi2Args* chi2 = nullptr, const Ttv* ttv = nullptr, double* jac = nullptr) {
   const bool secondary = flags & EXO_FLAG_SECONDARY, sparse = (flags & EXO_FLAG_SPARSE) || chi2;
   const bool grad = gflux != nullptr || chi2;
   const int n_ev = secondary ? 2 : 1;
@@ -2734,6 +2826,18 @@ inline int launch_runs_sweep(const double* t, int64_t n_cad, const double* texp,
     EXO_LAUNCH_RUNS(true, nullptr, w.gvals, nullptr, nullptr, nullptr, w.partial, no_fin);
   } else if (grad) {
     EXO_LAUNCH_RUNS(true, gflux, nullptr, vals, fill ? w.vcad : nullptr, fill, w.partial, fin);
+  } else if (jac) {
+    // value sweep that leaves every solved cadence's row of derivatives (transit_runs_kernel<.., JAC>; the cadence index
+    // is written whatever the output: the contraction gathers the cotangent through it)
+    const Ttv no_ttv{nullptr, nullptr, nullptr, 0};
+    if (secondary)
+      hipLaunchKernelGGL((transit_runs_kernel<true, true, false, false, false, true>), hgrid, block, 0, st, t, n_cad, texp, n_texp,
+                         stencil_dt, stencil_w, (int)n_sub, params, ld, (int)n_planet, flags, n_ev, w.rl, nullptr, nullptr, vals,
+                         w.vcad, fill, jac, (int64_t)0, no_ttv, fin);
+    else
+      hipLaunchKernelGGL((transit_runs_kernel<true, false, false, false, false, true>), hgrid, block, 0, st, t, n_cad, texp, n_texp,
+                         stencil_dt, stencil_w, (int)n_sub, params, ld, (int)n_planet, flags, n_ev, w.rl, nullptr, nullptr, vals,
+                         w.vcad, fill, jac, (int64_t)0, no_ttv, fin);
   } else {
     EXO_LAUNCH_RUNS(false, nullptr, nullptr, vals, fill ? w.vcad : nullptr, fill, nullptr, fin);
   }
@@ -3010,6 +3114,53 @@ int exo_transit_flux_ttv_vjp_f64(const double* t, int64_t n_cad, const double* t
   return transit_vjp(t, n_cad, texp, n_texp, stencil_dt, stencil_w, n_sub, params, ld, n_draw, n_planet, flags,
                      Ttv{ttv_edges, ttv_shift, gshift, n_edge}, gflux, flux_out, gparams, gld, flux_dot, workspace,
                      workspace_bytes, stream, nullptr, nullptr);
+}
+
+int64_t exo_transit_flux_jac_doubles(int64_t n_cad, int64_t n_draw, int32_t n_planet) {
+  if (n_cad < 0 || n_draw < 0 || n_planet < 1 || n_planet > EXO_MAX_PLANETS) return -1;
+  return (int64_t)kJac * n_cad * n_draw * n_planet;
+}
+
+int exo_transit_flux_fwd_jac_f64(const double* t, int64_t n_cad, const double* texp, int64_t n_texp, const double* stencil_dt,
+                                 const double* stencil_w, int32_t n_sub, const double* params, const double* ld,
+                                 int64_t n_draw, int32_t n_planet, uint32_t flags, double* flux, double* jac,
+                                 int64_t jac_doubles, void* workspace, int64_t workspace_bytes, void* stream) {
+  if (!transit_args_ok(n_cad, n_texp, n_sub, n_draw, n_planet) || !sweep_flags_ok(flags)) return EXO_ERR_INVALID_ARGUMENT;
+  if (flags & (EXO_FLAG_PER_PLANET | EXO_FLAG_SPARSE | EXO_FLAG_EXACT_SCAN | EXO_FLAG_LIGHT_DELAY)) return EXO_ERR_INVALID_ARGUMENT;
+  if (!runs_path(false, n_texp, flags)) return EXO_ERR_INVALID_ARGUMENT;   // one exposure time (or none) for all cadences
+  if (n_cad == 0 || n_draw == 0) return EXO_OK;
+  if (!t || !params || !ld || !flux || !jac || (n_texp > 0 && (!texp || !stencil_dt || !stencil_w))) return EXO_ERR_INVALID_ARGUMENT;
+  if (jac_doubles < exo_transit_flux_jac_doubles(n_cad, n_draw, n_planet)) return EXO_ERR_WORKSPACE;
+  const RunWs rw = carve_runs(workspace, n_cad, n_draw, n_planet);
+  if (!workspace || workspace_bytes < rw.bytes) return EXO_ERR_WORKSPACE;
+  return launch_runs_sweep(t, n_cad, texp, n_texp, stencil_dt, stencil_w, n_sub, params, ld, n_draw, n_planet, flags, nullptr,
+                           flux, nullptr, nullptr, nullptr, rw, (hipStream_t)stream, nullptr, nullptr, jac);
+}
+
+int exo_transit_flux_jac_vjp_f64(const double* gflux, int64_t n_cad, int64_t n_draw, int32_t n_planet, uint32_t flags,
+                                 const double* jac, void* workspace, int64_t workspace_bytes, double* gparams, double* gld,
+                                 double* flux_dot, void* stream) {
+  if (n_cad < 0 || n_draw < 0 || n_draw > 65535 || n_planet < 1 || n_planet > EXO_MAX_PLANETS || !sweep_flags_ok(flags))
+    return EXO_ERR_INVALID_ARGUMENT;
+  if (flags & (EXO_FLAG_PER_PLANET | EXO_FLAG_SPARSE | EXO_FLAG_EXACT_SCAN | EXO_FLAG_LIGHT_DELAY)) return EXO_ERR_INVALID_ARGUMENT;
+  if (n_draw == 0) return EXO_OK;
+  if (!gparams || !gld || (n_cad > 0 && (!gflux || !jac))) return EXO_ERR_INVALID_ARGUMENT;
+  hipStream_t st = (hipStream_t)stream;
+  const bool secondary = flags & EXO_FLAG_SECONDARY;
+  if (n_cad == 0) {
+    if (hipMemsetAsync(gparams, 0, sizeof(double) * n_draw * n_planet * EXO_NPAR, st) != hipSuccess) return EXO_ERR_LAUNCH;
+    if (flux_dot && hipMemsetAsync(flux_dot, 0, sizeof(double) * n_draw, st) != hipSuccess) return EXO_ERR_LAUNCH;
+    return hipMemsetAsync(gld, 0, sizeof(double) * n_draw * (secondary ? 6 : 3), st) == hipSuccess ? EXO_OK : EXO_ERR_LAUNCH;
+  }
+  const RunWs rw = carve_runs(workspace, n_cad, n_draw, n_planet);   // the workspace of the forward call: runs, values, cadence index
+  if (!workspace || workspace_bytes < rw.bytes) return EXO_ERR_WORKSPACE;
+  const int n_ev = secondary ? 2 : 1;
+  hipLaunchKernelGGL(transit_jac_vjp_kernel, dim3((unsigned)rw.hb, (unsigned)n_draw), dim3(kBlock), 0, st, n_cad, (int)n_planet, n_ev,
+                     flags, rw.rl, rw.vals, rw.vcad, jac, gflux, n_draw, rw.partial);
+  hipLaunchKernelGGL(transit_finish_kernel, dim3((unsigned)n_draw), dim3(kBlock), 0, st, rw.partial, rw.hb, (int)n_planet, secondary,
+                     gparams, gld, flux_dot, n_cad, flags & ~(uint32_t)EXO_FLAG_CADENCE_MAJOR, n_ev, rw.rl, nullptr, nullptr, nullptr,
+                     nullptr, 0, nullptr, Ttv{nullptr, nullptr, nullptr, 0});
+  return launch_status();
 }
 
 int exo_transit_chi2_vjp_f64(const double* t, int64_t n_cad, const double* texp, int64_t n_texp, const double* stencil_dt,

@@ -301,6 +301,14 @@ def _ttv_args(ttv, D, P):
     return edges, shift, int(edges.shape[2])
 
 
+# the Jacobian route of _TransitFlux: on from this many samples per cadence (with one sample a cadence the rows cost as much
+# HBM traffic as the second sweep costs arithmetic: C3 gains nothing), up to this many bytes of rows (EXO_JAC_ROUTE=0: A/B)
+_JAC_ROUTE = [os.environ.get("EXO_JAC_ROUTE", "1") != "0"]
+_JAC_MIN_SUB = 2
+_JAC_MAX_BYTES = 8 << 30
+_JAC_CALLS = [0]        # forward sweeps that took the route (tests look at it)
+
+
 class _TransitFlux(torch.autograd.Function):
     @staticmethod
     def forward(ctx, t, texp, stencil_dt, stencil_w, params, ld, flags, ttv_edges, ttv_shift):
@@ -319,6 +327,25 @@ class _TransitFlux(torch.autograd.Function):
         lib = _lib.load()
         nbytes = lib.exo_transit_flux_workspace_bytes(N, D, P)
         ws = torch.empty(max(nbytes // 8 + 1, 1), dtype=torch.float64, device=t.device)
+        # the Jacobian route (include/exoplanet_amd.h, exo_transit_flux_fwd_jac_f64): when the gradient will be asked for and a
+        # cadence is several samples, the value sweep keeps every solved cadence's row of derivatives and backward() is a
+        # contraction instead of a second sweep
+        n_jac = lib.exo_transit_flux_jac_doubles(N, D, P)
+        use_jac = (_JAC_ROUTE[0] and n_sub >= _JAC_MIN_SUB and not n_edge and n_texp <= 1 and 8 * n_jac <= _JAC_MAX_BYTES
+                   and not flags & (FLAG_PER_PLANET | FLAG_SPARSE | FLAG_EXACT_SCAN | FLAG_LIGHT_DELAY)
+                   and (ctx.needs_input_grad[4] or ctx.needs_input_grad[5]))
+        ctx.jac = None
+        if use_jac:
+            _JAC_CALLS[0] += 1
+            jac = torch.empty(n_jac, dtype=torch.float64, device=t.device)
+            with torch.cuda.device(t.device):
+                _lib.check(lib.exo_transit_flux_fwd_jac_f64(_ptr(t), N, _ptr(texp), n_texp, _ptr(sdt), _ptr(sw), n_sub, _ptr(params),
+                                                            _ptr(ld), D, P, flags, _ptr(flux), _ptr(jac), n_jac, _ptr(ws), nbytes,
+                                                            _stream(t)), "exo_transit_flux_fwd_jac_f64")
+            ctx.jac = (jac, ws, nbytes)
+            ctx.save_for_backward(t, texp, sdt, sw, params, ld, edges, shift)
+            ctx.meta = (n_texp, n_sub, D, P, flags)
+            return flux
         with torch.cuda.device(t.device):
             if n_edge:
                 _lib.check(
@@ -342,6 +369,20 @@ class _TransitFlux(torch.autograd.Function):
     def backward(ctx, gflux):
         t, texp, sdt, sw, params, ld, edges, shift = ctx.saved_tensors
         n_texp, n_sub, D, P, flags = ctx.meta
+        if ctx.jac is not None:
+            jac, ws, nbytes = ctx.jac
+            N = t.numel()
+            if is_cadence_major(gflux):
+                flags |= FLAG_CADENCE_MAJOR
+            else:
+                flags &= ~FLAG_CADENCE_MAJOR
+                gflux = _dev(gflux, "gflux")
+            gparams, gld = torch.empty_like(params), torch.empty_like(ld)
+            with torch.cuda.device(t.device):
+                _lib.check(_lib.load().exo_transit_flux_jac_vjp_f64(_ptr(gflux), N, D, P, flags, _ptr(jac), _ptr(ws), nbytes,
+                                                                    _ptr(gparams), _ptr(gld), 0, _stream(t)),
+                           "exo_transit_flux_jac_vjp_f64")
+            return None, None, None, None, gparams, gld, None, None, None
         ttv = None if edges is None else (edges, shift)
         _, gparams, gld, _, gshift = _vjp(t, texp, n_texp, sdt, sw, n_sub, params, ld, D, P, flags, gflux, False,
                                           ttv=ttv)

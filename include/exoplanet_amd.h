@@ -180,6 +180,26 @@ int64_t exo_transit_flux_workspace_bytes(int64_t n_cad, int64_t n_draw, int32_t 
  * list is the whole series cut into a few runs.                                                   */
 int exo_transit_flux_sparse_layout(int64_t n_cad, int64_t n_draw, int32_t n_planet, int64_t* out);
 
+/* A light curve whose cotangent is not known yet (the mean of a GP: limb_dark.py:99-232 feeding celerite2's
+ * log_likelihood; the cotangent is the GP's gradient with respect to its mean): the forward sweep and, once the cotangent
+ * exists, its VJP WITHOUT a second sweep.  exo_transit_flux_fwd_jac_f64 is exo_transit_flux_fwd_f64 (same arguments, same flux,
+ * bit for bit) that also leaves, for every solved cadence, the sixteen derivatives of its flux -- ten record slots, six
+ * limb-darkening coefficients -- in `jac` (exo_transit_flux_jac_doubles(n_cad, n_draw, n_planet) doubles, caller-owned);
+ * exo_transit_flux_jac_vjp_f64 contracts them with the cotangent (rows or EXO_FLAG_CADENCE_MAJOR, as the flux was) into what
+ * exo_transit_flux_vjp_f64 returns.  `workspace` of the second call is the forward call's, untouched in between (it holds
+ * the runs, the values and their cadences).  Run-enumeration sweeps (see EXO_FLAG_SPARSE) of the summed flux, without timing
+ * tables, EXO_FLAG_LIGHT_DELAY, EXO_FLAG_PER_PLANET or EXO_FLAG_SPARSE: EXO_ERR_INVALID_ARGUMENT otherwise -- callers keep
+ * the two-sweep route for those.  Worth it when a cadence is several samples (an exposure stencil: each of them a Kepler
+ * solve, the row still sixteen doubles); bit-reproducible.                                                              */
+int64_t exo_transit_flux_jac_doubles(int64_t n_cad, int64_t n_draw, int32_t n_planet);
+int exo_transit_flux_fwd_jac_f64(const double* t, int64_t n_cad, const double* texp, int64_t n_texp, const double* stencil_dt,
+                                 const double* stencil_w, int32_t n_sub, const double* params, const double* ld,
+                                 int64_t n_draw, int32_t n_planet, uint32_t flags, double* flux, double* jac,
+                                 int64_t jac_doubles, void* workspace, int64_t workspace_bytes, void* stream);
+int exo_transit_flux_jac_vjp_f64(const double* gflux, int64_t n_cad, int64_t n_draw, int32_t n_planet, uint32_t flags,
+                                 const double* jac, void* workspace, int64_t workspace_bytes, double* gparams, double* gld,
+                                 double* flux_dot, void* stream);
+
 /* White-noise Gaussian likelihood of ONE observed series against the light curves of n_draw parameter sets, value and
  * gradient, without a dense flux array -- what a sampler step needs when there is no correlated-noise model (the
  * reference's `pm.Normal("obs", mu=light_curve, sigma=yerr, observed=y)`, docs/tutorials: the (draw, cadence) arrays of
