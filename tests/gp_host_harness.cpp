@@ -136,6 +136,21 @@ extern "C" {
 void harness_set_serial_scan(int v) { g_serial_scan = v; }
 void harness_set_polish(int v) { g_polish = v; }
 // (experiments: where the checkpoints -- the states (F, packed S) entering every ckpt_span(J)-th cadence -- live in `state`)
+// (experiments: where the filtering elements [chunk][A, b, C, eta, J][draw] live in `state`)
+int64_t harness_gp_elem_offset(int64_t n, int64_t n_draw, int32_t n_real, int32_t n_complex, int32_t n_chunks, int64_t* C) {
+  const int J = n_real + 2 * n_complex;
+  const gp::ChunkGeom cg = gp::chunk_plan(n, n_draw, J, n_chunks);
+  const gp::ChunkWs ws = gp::chunk_ws(n, n_draw, J, cg);
+  *C = cg.C;
+  return ws.elem(0, 0, 0);
+}
+// (experiments: out = {off_bnd, B, off_polish, K, C, L})
+void harness_gp_offsets(int64_t n, int64_t n_draw, int32_t n_real, int32_t n_complex, int32_t n_chunks, int64_t* out) {
+  const int J = n_real + 2 * n_complex;
+  const gp::ChunkGeom cg = gp::chunk_plan(n, n_draw, J, n_chunks);
+  const gp::ChunkWs ws = gp::chunk_ws(n, n_draw, J, cg);
+  out[0] = ws.off_bnd(); out[1] = ws.B(); out[2] = ws.off_polish(); out[3] = ws.K(); out[4] = cg.C; out[5] = cg.L;
+}
 int64_t harness_gp_ckpt_layout(int64_t n, int64_t n_draw, int32_t n_real, int32_t n_complex, int32_t n_chunks, int64_t* K,
                                int64_t* span, int64_t* L) {
   const int J = n_real + 2 * n_complex;
