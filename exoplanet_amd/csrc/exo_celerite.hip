@@ -947,6 +947,22 @@ __global__ __launch_bounds__(kWave) void celerite_chunk_vjp_kernel(
     db = db_prev; zb = zb_prev; Fb = Gb; Wb = Wb_prev;
   };
 
+  // d loglike / d(oscillation rate) as a phase FLUX (exo_celerite_core.hpp, phase_flux): the flux across the chunk's end boundary
+  // from the state entering the next chunk (saved at cadence n1) and the adjoint the scan handed over; a pair's first lane keeps it,
+  // the partner lane supplies the other row
+  double flux = 0.0;
+  if (n1 < n) {
+    double d1, z1, W1, F1, S1[J];
+    load(n1, d1, z1, W1, F1, S1);
+    const double Fb_o = __shfl(Fb, partner, 64), F1_o = __shfl(F1, partner, 64);
+    double acc = Fb_o * F1 - Fb * F1_o;
+#pragma unroll
+    for (int l = 0; l < J; ++l) {
+      const double Sb_o = __shfl(Sb[l], partner, 64), S1_o = __shfl(S1[l], partner, 64);
+      acc = fma(2.0, Sb_o * S1[l] - Sb[l] * S1_o, acc);
+    }
+    flux = (k.live && !k.real && !k.odd) ? acc : 0.0;
+  }
   double d_n, z_n, W_n, F_n, S_n[J];
   load(n1 - 1, d_n, z_n, W_n, F_n, S_n);
   if (n1 < n) propagate_adjoint(n1, d_n, z_n, W_n, F_n, S_n);
@@ -954,6 +970,7 @@ __global__ __launch_bounds__(kWave) void celerite_chunk_vjp_kernel(
   for (int64_t i = n1 - 1; i >= n0; --i) {
     // measurement half of cadence i
     const double ti = t[i];
+    const double dt_next = (i + 1 < n) ? t[i + 1] - ti : 0.0;
     double Uj, Vj, cs, sn;
     lane_uv(k, ti, &Uj, &Vj, &cs, &sn);
     double Uall[J];
@@ -1012,7 +1029,9 @@ __global__ __launch_bounds__(kWave) void celerite_chunk_vjp_kernel(
       if (k.live && !k.real && !k.odd) {
         ga += Ub * cs + Ub_o * sn;
         gb += Ub * sn - Ub_o * cs;
-        gd += (ti - k.t0) * (Ub * (-k.a * sn + k.b * cs) + Ub_o * (k.a * cs + k.b * sn) - Vb * sn + Vb_o * cs);
+        // the link behind this cadence carries the flux so far; this cadence's phase cotangent leaves it
+        gd = fma(-dt_next, flux, gd);
+        flux -= Ub * (-k.a * sn + k.b * cs) + Ub_o * (k.a * cs + k.b * sn) - Vb * sn + Vb_o * cs;
       }
     }
     if (i == n0) break;

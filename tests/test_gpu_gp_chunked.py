@@ -292,6 +292,16 @@ def test_wide_state_takes_the_time_parallel_path(dev):
         co_d = (cr[0, :, 0], cr[0, :, 1], cc[0, :, 0], cc[0, :, 1], cc[0, :, 2], cc[0, :, 3])
         ref, _ = P.gp_loglike_dense(t, y[0], diag[0], co_d)
         assert abs(got[0][0] - ref) < 1e-10 * abs(ref)
+        # round 4: the oscillation-rate gradient as a phase flux, phases from the first stamp -- the lane-group kernels too: the
+        # series 3000 d away (stamps on a 2^-20 d grid: an exact shift) gives the same gradients
+        tq = np.round(t * 2.0 ** 20) / 2.0 ** 20
+        with chunks(11):
+            a = value_and_grads(dev, tq, y, diag, cr, cc)
+            b = value_and_grads(dev, tq + 3000.0, y, diag, cr, cc)
+        np.testing.assert_allclose(b[0], a[0], rtol=1e-12)
+        for g, w in zip(b[1:], a[1:]):
+            if w.size:
+                assert np.abs(g - w).max() / (np.abs(w).max() + 1e-300) < 1e-9
 
 
 @pytest.mark.parametrize("name", ["sho_q3", "real1", "three_sho_j6"])
