@@ -1609,10 +1609,8 @@ __global__ __launch_bounds__(64) void transit_enum_kernel(const double* __restri
     // evenly spaced cadences must ascend (a NaN fails), else the list is "every cadence".  What this catches is a time
     // buffer refilled with another, unordered series under a flag that was baked into a captured launch; two swapped
     // neighbours it cannot see (that is what the unflagged sweep's own check is for).  Two independent loads per lane.
-#ifndef EXO_NO_SORT_GUARD   // (A/B)
     const int64_t i0 = (n_cad - 1) * lane / 64, i1 = (n_cad - 1) * (lane + 1) / 64;
     srt = __all(t[i0] <= t[i1]);
-#endif
   }
   // the list degenerates to "every cadence" unless its windows are bounded, periodic in t and disjoint
   // (the decision is the same for both events of a planet: it only uses what they share)
