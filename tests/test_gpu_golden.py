@@ -240,7 +240,7 @@ def test_gp_tail_golden(dev, key, origin):
 
 
 def test_random_kernels_time_parallel_vs_sequential_kernels(dev):
-    """the scan of tools/gp_cond_bins.py as a test, flags ON (the product's thresholds: kappa <= 1e7 for J <= 2, 1e5 for wider
+    """the scan of tools/gp_cond_bins.py as a test, flags ON (the product's thresholds: kappa <= 1e7 for J <= 2, 3e4 for wider
     states): 12 seeded batches of 32 random kernels each, N up to 4000 -- many chunks of 32 cadences, the worst case for the
     boundary terms -- with the time axis starting at 1500 d.  Every draw's every gradient from the default path within 1e-6 of
     the sequential kernels' (themselves held to the long-double definition above), whatever its conditioning score"""
