@@ -116,6 +116,10 @@ _SIGNATURES = {
     "exo_sho_coefficients_f64": (ctypes.c_int, [_c_dp, _c_dp, _c_dp, _u32, ctypes.c_double, _i64, _c_dp, _c_dp, _c_dp]),
     "exo_sho_coefficients_vjp_f64": (ctypes.c_int, [_c_dp, _c_dp, _c_dp, _u32, ctypes.c_double, _i64, _c_dp, _c_dp, _c_dp,
                                                     _c_dp, _c_dp]),
+    # amp, freq, damp, flags (host arrays), n_terms, eps, n, ...
+    "exo_sho_coefficients_multi_f64": (ctypes.c_int, [_c_dp, _c_dp, _c_dp, _c_dp, _i32, ctypes.c_double, _i64, _c_dp, _c_dp, _c_dp]),
+    "exo_sho_coefficients_multi_vjp_f64": (ctypes.c_int, [_c_dp, _c_dp, _c_dp, _c_dp, _i32, ctypes.c_double, _i64, _c_dp, _c_dp,
+                                                          _c_dp, _c_dp, _c_dp]),
     "exo_pack_records_f64": (ctypes.c_int, [_c_dp, _c_dp, _i64, _i32, _u32, _c_dp, _c_dp, _c_dp]),
     "exo_pack_records_vjp_f64": (ctypes.c_int, [_c_dp, _c_dp, _i64, _i32, _u32, _c_dp, _c_dp, _c_dp, _c_dp, _c_dp]),
     # cols, draw_stride, planet_stride, defaults, ld_cols, ld_draw_stride (host arrays), n_draw, n_planet, flags, ...

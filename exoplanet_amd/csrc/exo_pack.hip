@@ -376,31 +376,32 @@ __device__ __forceinline__ ShoDerived sho_derive(double amp, double freq, double
   return d;
 }
 
-__global__ __launch_bounds__(64) void sho_coef_kernel(const double* __restrict__ amp, const double* __restrict__ freq,
-                                                      const double* __restrict__ damp, uint32_t flags, double eps, int64_t n,
-                                                      double* __restrict__ coef, int32_t* __restrict__ kind) {
-  const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
-  if (i >= n) return;
-  const ShoDerived d = sho_derive(amp[i], freq[i], damp[i], flags, eps);
-  double* o = coef + 4 * i;
+// the terms of a sum, by value in the kernel arguments
+struct ShoTerms {
+  const double* amp[EXO_SHO_MAX_TERMS];
+  const double* freq[EXO_SHO_MAX_TERMS];
+  const double* damp[EXO_SHO_MAX_TERMS];
+  double* gamp[EXO_SHO_MAX_TERMS];
+  double* gfreq[EXO_SHO_MAX_TERMS];
+  double* gdamp[EXO_SHO_MAX_TERMS];
+  uint32_t flags[EXO_SHO_MAX_TERMS];
+  int32_t n_terms;
+};
+
+// one term, one element: coefficients + kind; and the reverse
+__device__ __forceinline__ void sho_coef_one(double am, double fr, double da, uint32_t flags, double eps, double* o, int32_t* kd) {
+  const ShoDerived d = sho_derive(am, fr, da, flags, eps);
   if (d.over) {
     o[0] = 0.5 * d.a * (1.0 + 1.0 / d.f); o[1] = d.c * (1.0 - d.f); o[2] = 0.5 * d.a * (1.0 - 1.0 / d.f); o[3] = d.c * (1.0 + d.f);
   } else {
     o[0] = d.a; o[1] = d.a / d.f; o[2] = d.c; o[3] = d.c * d.f;
   }
-  kind[i] = d.over ? 1 : 0;
+  *kd = d.over ? 1 : 0;
 }
-
-__global__ __launch_bounds__(64) void sho_coef_vjp_kernel(const double* __restrict__ amp, const double* __restrict__ freq,
-                                                          const double* __restrict__ damp, uint32_t flags, double eps,
-                                                          int64_t n, const double* __restrict__ gcoef,
-                                                          double* __restrict__ gamp, double* __restrict__ gfreq,
-                                                          double* __restrict__ gdamp) {
-  const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
-  if (i >= n) return;
-  const double am = amp[i], fr = freq[i], da = damp[i];
+__device__ __forceinline__ void sho_coef_vjp_one(double am, double fr, double da, uint32_t flags, double eps, const double* g,
+                                                 double* g_amp_o, double* g_freq_o, double* g_damp_o) {
   const ShoDerived d = sho_derive(am, fr, da, flags, eps);
-  const double g0 = gcoef[4 * i], g1 = gcoef[4 * i + 1], g2 = gcoef[4 * i + 2], g3 = gcoef[4 * i + 3];
+  const double g0 = g[0], g1 = g[1], g2 = g[2], g3 = g[3];
   double ga, gc, gf, dfdQ;
   if (d.over) {
     ga = 0.5 * g0 * (1.0 + 1.0 / d.f) + 0.5 * g2 * (1.0 - 1.0 / d.f);
@@ -427,8 +428,46 @@ __global__ __launch_bounds__(64) void sho_coef_vjp_kernel(const double* __restri
     g_damp = gQ * 0.5 * d.w0;
     gw0 += gQ * 0.5 * da;
   }
-  const double g_freq = (flags & EXO_SHO_RHO) ? -gw0 * 2.0 * kPi / (fr * fr) : gw0;
-  gamp[i] = g_amp; gfreq[i] = g_freq; gdamp[i] = g_damp;
+  *g_amp_o = g_amp;
+  *g_freq_o = (flags & EXO_SHO_RHO) ? -gw0 * 2.0 * kPi / (fr * fr) : gw0;
+  *g_damp_o = g_damp;
+}
+
+__global__ __launch_bounds__(64) void sho_coef_kernel(const double* __restrict__ amp, const double* __restrict__ freq,
+                                                      const double* __restrict__ damp, uint32_t flags, double eps, int64_t n,
+                                                      double* __restrict__ coef, int32_t* __restrict__ kind) {
+  const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  if (i >= n) return;
+  sho_coef_one(amp[i], freq[i], damp[i], flags, eps, coef + 4 * i, kind + i);
+}
+
+__global__ __launch_bounds__(64) void sho_coef_vjp_kernel(const double* __restrict__ amp, const double* __restrict__ freq,
+                                                          const double* __restrict__ damp, uint32_t flags, double eps,
+                                                          int64_t n, const double* __restrict__ gcoef,
+                                                          double* __restrict__ gamp, double* __restrict__ gfreq,
+                                                          double* __restrict__ gdamp) {
+  const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  if (i >= n) return;
+  sho_coef_vjp_one(amp[i], freq[i], damp[i], flags, eps, gcoef + 4 * i, gamp + i, gfreq + i, gdamp + i);
+}
+
+// gcoef == nullptr: forward (coef, kind written); else reverse (the terms' gamp / gfreq / gdamp written)
+__global__ __launch_bounds__(64) void sho_coef_multi_kernel(ShoTerms s, double eps, int64_t n, double* __restrict__ coef,
+                                                            int32_t* __restrict__ kind, const double* __restrict__ gcoef) {
+  const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  const int k = blockIdx.y;
+  if (i >= n) return;
+  // (the term's pointers are picked with selects over compile-time indices: a struct member indexed at run time is a scratch copy)
+  const double *pa = nullptr, *pf = nullptr, *pd = nullptr;
+  double *ga = nullptr, *gf = nullptr, *gd = nullptr;
+  uint32_t fl = 0u;
+#pragma unroll
+  for (int q = 0; q < EXO_SHO_MAX_TERMS; ++q) {
+    if (q == k) { pa = s.amp[q]; pf = s.freq[q]; pd = s.damp[q]; ga = s.gamp[q]; gf = s.gfreq[q]; gd = s.gdamp[q]; fl = s.flags[q]; }
+  }
+  const int64_t at = i * s.n_terms + k;
+  if (gcoef == nullptr) sho_coef_one(pa[i], pf[i], pd[i], fl, eps, coef + 4 * at, kind + at);
+  else sho_coef_vjp_one(pa[i], pf[i], pd[i], fl, eps, gcoef + 4 * at, ga + i, gf + i, gd + i);
 }
 
 }  // namespace
@@ -454,6 +493,40 @@ int exo_sho_coefficients_vjp_f64(const double* amp, const double* freq, const do
   hipLaunchKernelGGL(sho_coef_vjp_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, (hipStream_t)stream, amp, freq,
                      damp, flags, eps, n, gcoef, gamp, gfreq, gdamp);
   return launch_status();
+}
+
+static int sho_multi(const double* const* amp, const double* const* freq, const double* const* damp, const uint32_t* flags,
+                     int32_t n_terms, double eps, int64_t n, double* coef, int32_t* kind, const double* gcoef, double* const* gamp,
+                     double* const* gfreq, double* const* gdamp, void* stream) {
+  if (n < 0 || n_terms < 1 || n_terms > EXO_SHO_MAX_TERMS || !amp || !freq || !damp || !flags) return EXO_ERR_INVALID_ARGUMENT;
+  if (n == 0) return EXO_OK;
+  ShoTerms s{};
+  s.n_terms = n_terms;
+  for (int k = 0; k < n_terms; ++k) {
+    if (!amp[k] || !freq[k] || !damp[k] || (flags[k] & ~(EXO_SHO_SIGMA | EXO_SHO_RHO | EXO_SHO_TAU))) return EXO_ERR_INVALID_ARGUMENT;
+    s.amp[k] = amp[k]; s.freq[k] = freq[k]; s.damp[k] = damp[k]; s.flags[k] = flags[k];
+    if (gcoef) {
+      if (!gamp || !gfreq || !gdamp || !gamp[k] || !gfreq[k] || !gdamp[k]) return EXO_ERR_INVALID_ARGUMENT;
+      s.gamp[k] = gamp[k]; s.gfreq[k] = gfreq[k]; s.gdamp[k] = gdamp[k];
+    }
+  }
+  if (!gcoef && (!coef || !kind)) return EXO_ERR_INVALID_ARGUMENT;
+  hipLaunchKernelGGL(sho_coef_multi_kernel, dim3((unsigned)((n + 63) / 64), (unsigned)n_terms), dim3(64), 0, (hipStream_t)stream, s,
+                     eps, n, coef, kind, gcoef);
+  return launch_status();
+}
+
+int exo_sho_coefficients_multi_f64(const double* const* amp, const double* const* freq, const double* const* damp,
+                                   const uint32_t* flags, int32_t n_terms, double eps, int64_t n, double* coef, int32_t* kind,
+                                   void* stream) {
+  return sho_multi(amp, freq, damp, flags, n_terms, eps, n, coef, kind, nullptr, nullptr, nullptr, nullptr, stream);
+}
+
+int exo_sho_coefficients_multi_vjp_f64(const double* const* amp, const double* const* freq, const double* const* damp,
+                                       const uint32_t* flags, int32_t n_terms, double eps, int64_t n, const double* gcoef,
+                                       double* const* gamp, double* const* gfreq, double* const* gdamp, void* stream) {
+  if (!gcoef) return EXO_ERR_INVALID_ARGUMENT;
+  return sho_multi(amp, freq, damp, flags, n_terms, eps, n, nullptr, nullptr, gcoef, gamp, gfreq, gdamp, stream);
 }
 
 }  // extern "C"

@@ -57,6 +57,23 @@ class TermSum(Term):
             raise TypeError("terms must be exoplanet_amd.gp.terms.Term instances")
         self.terms = tuple(flat)
 
+    def _fused_sho(self):
+        """a sum of SHO terms on the device: every term's pair slot from ONE launch (ops.sho_coefficients_multi), written where
+        the kernels read it -- per term and step this was two launches, a slice of a concatenation and a strided copy of the
+        cotangent; None when the sum is anything else"""
+        if not (1 < len(self.terms) <= ops.SHO_MAX_TERMS) or not all(type(t) is SHOTerm for t in self.terms):
+            return None
+        raws = [t._raw for t in self.terms]
+        if not all(x.is_cuda for amp, freq, damp, _ in raws for x in (amp, freq, damp)) or len({t.eps for t in self.terms}) != 1:
+            return None
+        shape = torch.broadcast_shapes(*[x.shape for amp, freq, damp, _ in raws for x in (amp, freq, damp)])
+        flat = [(amp.expand(shape).reshape(-1), freq.expand(shape).reshape(-1), damp.expand(shape).reshape(-1), fl)
+                for amp, freq, damp, fl in raws]
+        coef, kind = ops.sho_coefficients_multi(flat, self.terms[0].eps)
+        e = torch.zeros(shape + (0,), dtype=torch.float64, device=coef.device)
+        T = len(self.terms)
+        return e, e, coef.reshape(shape + (T, 4)), kind.reshape(shape + (T,))
+
     def get_coefficients(self):
         parts = [t.get_coefficients() for t in self.terms]
         batch = torch.broadcast_shapes(*[p[0].shape[:-1] for p in parts])
@@ -66,6 +83,9 @@ class TermSum(Term):
         return tuple(out)
 
     def pair_coefficients(self):
+        fused = self._fused_sho()
+        if fused is not None:
+            return fused
         parts = [t.pair_coefficients() for t in self.terms]
         batch = torch.broadcast_shapes(*[p[0].shape[:-1] for p in parts], *[p[2].shape[:-2] for p in parts])
         ar = torch.cat([p[0].expand(batch + (p[0].shape[-1],)) for p in parts], dim=-1)

@@ -995,12 +995,15 @@ class _ShoCoefficients(torch.autograd.Function):
         ctx.save_for_backward(amp, freq, damp)
         ctx.flags, ctx.eps = flags, eps
         ctx.mark_non_differentiable(kind)
+        ctx.set_materialize_grads(False)      # (no zero-filled int32 "gradient" of `kind` per backward call: a launch each)
         return coef, kind
 
     @staticmethod
     def backward(ctx, gcoef, _gkind):
         amp, freq, damp = ctx.saved_tensors
         n = amp.numel()
+        if gcoef is None:
+            return None, None, None, None, None
         gcoef = _dev(gcoef, "gcoef").contiguous()
         ga, gf, gd = (torch.empty_like(amp) for _ in range(3))
         lib = _lib.load()
@@ -1016,6 +1019,64 @@ def sho_coefficients(amp, freq, damp, flags=0, eps=1e-5):
     is sigma rather than S0, ``freq`` the undamped period rho rather than w0, ``damp`` tau rather than Q) -> the
     term's pair slot ``coef`` (n, 4) and ``kind`` (n,) int32 (1: two real terms, Q < 1/2), one fused launch each way."""
     return _ShoCoefficients.apply(amp, freq, damp, int(flags), float(eps))
+
+
+SHO_MAX_TERMS = 8
+
+
+class _ShoCoefficientsMulti(torch.autograd.Function):
+    """several SHO terms in one launch each way (include/exoplanet_amd.h, exo_sho_coefficients_multi_f64): inputs
+    (flags tuple, eps, amp_0, freq_0, damp_0, amp_1, ...) -> coef (n, T, 4), kind (n, T)"""
+
+    @staticmethod
+    def forward(ctx, flags, eps, *cols):
+        import ctypes
+
+        T = len(flags)
+        cols = [_dev(x, "SHO parameter").contiguous() for x in cols]
+        n = cols[0].numel()
+        if len(cols) != 3 * T or not 1 <= T <= SHO_MAX_TERMS or any(c.dim() != 1 or c.numel() != n for c in cols):
+            raise ValueError("three 1-D tensors of one length per term, at most %d terms" % SHO_MAX_TERMS)
+        coef = torch.empty(n, T, 4, dtype=torch.float64, device=cols[0].device)
+        kind = torch.empty(n, T, dtype=torch.int32, device=cols[0].device)
+        vp = ctypes.c_void_p
+        arr = lambda q: (vp * T)(*[cols[3 * k + q].data_ptr() for k in range(T)])  # noqa: E731
+        fl = (ctypes.c_uint32 * T)(*[int(f) for f in flags])
+        with torch.cuda.device(coef.device):
+            _lib.check(_lib.load().exo_sho_coefficients_multi_f64(arr(0), arr(1), arr(2), fl, T, eps, n, _ptr(coef), _ptr(kind),
+                                                                  _stream(coef)), "exo_sho_coefficients_multi_f64")
+        ctx.save_for_backward(*cols)
+        ctx.flags, ctx.eps = tuple(int(f) for f in flags), eps
+        ctx.mark_non_differentiable(kind)
+        ctx.set_materialize_grads(False)
+        return coef, kind
+
+    @staticmethod
+    def backward(ctx, gcoef, _gkind):
+        import ctypes
+
+        cols = ctx.saved_tensors
+        T = len(ctx.flags)
+        if gcoef is None:
+            return (None,) * (2 + 3 * T)
+        n = cols[0].numel()
+        gcoef = _dev(gcoef, "gcoef").contiguous()
+        grads = [torch.empty_like(c) for c in cols]
+        vp = ctypes.c_void_p
+        arr = lambda xs, q: (vp * T)(*[xs[3 * k + q].data_ptr() for k in range(T)])  # noqa: E731
+        fl = (ctypes.c_uint32 * T)(*ctx.flags)
+        with torch.cuda.device(gcoef.device):
+            _lib.check(_lib.load().exo_sho_coefficients_multi_vjp_f64(arr(cols, 0), arr(cols, 1), arr(cols, 2), fl, T, ctx.eps, n,
+                                                                      _ptr(gcoef), arr(grads, 0), arr(grads, 1), arr(grads, 2),
+                                                                      _stream(gcoef)), "exo_sho_coefficients_multi_vjp_f64")
+        return (None, None) + tuple(grads)
+
+
+def sho_coefficients_multi(terms, eps=1e-5):
+    """``terms``: [(amp, freq, damp, flags), ...] of one length n each -> coef (n, T, 4), kind (n, T) int32: a sum of SHO terms
+    in one launch each way (and no concatenation of the terms' slots)"""
+    flat = [x for amp, freq, damp, _ in terms for x in (amp, freq, damp)]
+    return _ShoCoefficientsMulti.apply(tuple(int(f) for *_, f in terms), float(eps), *flat)
 
 
 class _OrbitFluxDot(torch.autograd.Function):

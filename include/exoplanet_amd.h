@@ -599,6 +599,18 @@ int exo_sho_coefficients_vjp_f64(const double* amp, const double* freq, const do
                                  int64_t n, const double* gcoef, double* gamp, double* gfreq, double* gdamp,
                                  void* stream);
 
+/* A SUM of SHO terms (celerite2: term_1 + term_2 + ...), all of it in one launch each way: term k reads its own
+ * amp[k], freq[k], damp[k] (host arrays of n_terms <= EXO_SHO_MAX_TERMS device pointers to n doubles each) under its own
+ * flags[k], and owns slot k of coef[n][n_terms][4] and kind[n][n_terms] -- the pair-slot arrays the celerite entry points
+ * take (no concatenation; the reverse reads gcoef[n][n_terms][4] in place and writes every term's gamp / gfreq / gdamp[n]). */
+#define EXO_SHO_MAX_TERMS 8
+int exo_sho_coefficients_multi_f64(const double* const* amp, const double* const* freq, const double* const* damp,
+                                   const uint32_t* flags, int32_t n_terms, double eps, int64_t n, double* coef, int32_t* kind,
+                                   void* stream);
+int exo_sho_coefficients_multi_vjp_f64(const double* const* amp, const double* const* freq, const double* const* damp,
+                                       const uint32_t* flags, int32_t n_terms, double eps, int64_t n, const double* gcoef,
+                                       double* const* gamp, double* const* gfreq, double* const* gdamp, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
