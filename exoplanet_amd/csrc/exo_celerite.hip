@@ -218,7 +218,7 @@ __global__ __launch_bounds__(kWave) void celerite_fwd_kernel(
   const bool live_draw = lane_draw < n_draw;
   const int64_t draw = live_draw ? lane_draw : n_draw - 1;
   // after the time-parallel path: redo only the draws it could not take (see DeltaCoef)
-  const bool mine = live_draw && (!only_flagged || only_flagged[draw] != 0.0);
+  const bool mine = live_draw && (!only_flagged || only_flagged[draw] >= kFlagSeq);
   if (only_flagged && __ballot(mine) == 0) return;
   const LaneCoef k = lane_coef(cf, draw, j, J);
   const bool store = SAVE && mine && k.live;
@@ -365,7 +365,7 @@ __global__ __launch_bounds__(kWave) void celerite_vjp_kernel(
   constexpr int G = Group<J>::G;
   const int j = threadIdx.x & (G - 1);
   const int64_t lane_draw = ((int64_t)blockIdx.x * kWave + threadIdx.x) / G;
-  const bool live_draw = (lane_draw < n_draw) && (!only_flagged || only_flagged[lane_draw < n_draw ? lane_draw : 0] != 0.0);
+  const bool live_draw = (lane_draw < n_draw) && (!only_flagged || only_flagged[lane_draw < n_draw ? lane_draw : 0] >= kFlagSeq);
   if (only_flagged && __ballot(live_draw) == 0) return;
   const int64_t draw = lane_draw < n_draw ? lane_draw : n_draw - 1;
   const LaneCoef k = lane_coef(cf, draw, j, J);
@@ -604,7 +604,7 @@ __global__ __launch_bounds__(kWave) void celerite_flag_kernel(Coefs cf,
   if (draw >= n_draw) return;
   DeltaCoef<J> dc;
   dc.init(cf, draw);
-  flag[draw] = dc.valid ? 0.0 : 1.0;
+  flag[draw] = dc.valid ? kFlagClean : kFlagSeq;
 }
 
 // pre-pass for the flagged draws only (the sequential kernels read U, V, P from `state`; the
@@ -614,7 +614,7 @@ __global__ __launch_bounds__(256) void celerite_prep_flagged_kernel(const double
                                                                     double* __restrict__ state,
                                                                     const double* __restrict__ flag) {
   const int64_t draw = blockIdx.y;
-  if (flag[draw] == 0.0) return;
+  if (flag[draw] < kFlagSeq) return;   // (clean, or finished on the robust route of the time-parallel path)
   const StateIdx six{n, n_draw, J};
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n * J; e += (int64_t)gridDim.x * 256) {
     const int64_t i = e / J;
@@ -751,7 +751,7 @@ __global__ __launch_bounds__(kWave) void celerite_elem_lg_kernel(
     }
   }
   if (!live_draw || !live) return;
-  if (!ok && j == 0) state[(flag_at >= 0 ? flag_at : ws.off_flag()) + draw] = 1.0;
+  if (!ok && j == 0) state[(flag_at >= 0 ? flag_at : ws.off_flag()) + draw] = kFlagSeq;   // (no robust route on the lane-group path)
   const int E1 = J * J, E2 = J * J + J, E3 = 2 * J * J + J, E4 = 2 * J * J + 2 * J;
 #pragma unroll
   for (int l = 0; l < J; ++l) {
@@ -1369,6 +1369,47 @@ __global__ __launch_bounds__(kWave, (J < EXO_SPAN2_MIN_J ? EXO_VJP1_WAVES : (J <
     chunk1_vjp_lane<J, NR>(t, rs, diag, n_diag, n, cf, n_draw, gloglike, state, cg, gresid, gdiag, gsign, draw, (int)blockIdx.y);
 }
 
+// ---- the ROBUST route (draws flagged kFlagRobust: exo_celerite_core.hpp, chunk_adj_lane) ---------------------------------
+// (B) / (B') once more for those draws alone, as serial chains over the chunks: a draw on one group of eight lanes for
+// J >= 3 (robust_scan_group), on one lane below.  Launched after the trees, whose boundary states of these draws it replaces.
+template <int J, bool ADJ>
+__global__ __launch_bounds__(kWave) void celerite_robust_scan_kernel(const double* __restrict__ t, Coefs cf, int64_t n,
+                                                                     ChunkGeom cg, int64_t n_draw, double* state) {
+  const ChunkWs ws = chunk_ws(n, n_draw, J, cg);
+  if constexpr (J >= 3) {
+    __shared__ double lds[(kWave / 8) * GroupLds<J>::S];
+    const int64_t draw = (int64_t)blockIdx.x * (kWave / 8) + (threadIdx.x >> 3);
+    const bool mine = draw < n_draw && state[ws.off_flag() + (draw < n_draw ? draw : 0)] == kFlagRobust;
+    if (__ballot(mine) == 0) return;
+    if (!mine) return;     // (whole groups leave: the items need no block barrier)
+    Grp<J> g;
+    g.lds = lds + (threadIdx.x >> 3) * GroupLds<J>::S;
+    g.r = threadIdx.x & 7;
+    g.live = g.r < J;
+    robust_scan_group<J, ADJ>(ws, state, draw, g);
+  } else {
+    const int64_t draw = (int64_t)blockIdx.x * kWave + threadIdx.x;
+    if (draw >= n_draw || state[ws.off_flag() + draw] != kFlagRobust) return;
+    if (ADJ) bscan_vjp_lane<J>(n, n_draw, state, cg, draw);
+    else bscan_lane<J>(t, cf, n, n_draw, state, cg, draw);
+  }
+}
+
+// (B') part 1 for those draws: the adjoint scan's inputs from the chunks' own reverse recurrences (chunk_adj_lane), one lane
+// per (draw, chunk >= 1), written over the chunk's element where badj_prep_lane wrote its own
+template <int J>
+__global__ __launch_bounds__(kWave) void celerite_chunk_adj_kernel(const double* __restrict__ t, Series rs,
+                                                                   const double* __restrict__ diag, int64_t n_diag, int64_t n,
+                                                                   Coefs cf, int64_t n_draw, const double* __restrict__ gloglike,
+                                                                   double* __restrict__ state, ChunkGeom cg) {
+  __shared__ double xacc[J * J][kWave];
+  const int64_t draw = (int64_t)blockIdx.x * kWave + threadIdx.x;
+  const ChunkWs ws = chunk_ws(n, n_draw, J, cg);
+  if (draw >= n_draw || state[ws.off_flag() + draw] != kFlagRobust) return;
+  chunk_adj_lane<J, -1>(t, rs, diag, n_diag, n, cf, n_draw, gloglike, state, cg, draw, (int)blockIdx.y + 1, &xacc[0][threadIdx.x],
+                        kWave);
+}
+
 // sum over the wave in a fixed order (xor butterfly), result in every lane
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
@@ -1482,6 +1523,17 @@ int64_t exo_celerite_state_doubles(int64_t n, int64_t n_draw, int32_t n_real, in
     case 8: { constexpr int JJ = 8; CALL; } break; \
     default: break;                                \
   }
+#define EXO_GP_DISPATCH_LANE(J_, CALL) \
+  switch (J_) {                        \
+    case 1: { constexpr int JJ = 1; CALL; } break; \
+    case 2: { constexpr int JJ = 2; CALL; } break; \
+    case 3: { constexpr int JJ = 3; CALL; } break; \
+    case 4: { constexpr int JJ = 4; CALL; } break; \
+    case 5: { constexpr int JJ = 5; CALL; } break; \
+    case 6: { constexpr int JJ = 6; CALL; } break; \
+    default: break;                                \
+  }
+static_assert(kLaneMaxJ <= 6, "EXO_GP_DISPATCH_LANE lists the state widths of the one-lane path");
 #define EXO_GP_DISPATCH(J_, CALL) \
   switch (J_) {                   \
     case 1: { constexpr int JJ = 1; CALL; } break; \
@@ -1676,6 +1728,10 @@ static int celerite_fwd(const double* t, Series resid, const double* diag, int64
         if (rc != EXO_OK) return rc;
       }
       if (cg.lane) {
+        // draws flagged kFlagRobust: their entering states once more, by serial application of the elements
+        const dim3 rgrid((unsigned)(J >= 3 ? (n_draw + kWave / 8 - 1) / (kWave / 8) : per_draw.x));
+        EXO_GP_DISPATCH_LANE(J, hipLaunchKernelGGL((celerite_robust_scan_kernel<JJ, false>), rgrid, block, 0, st, t, cf, n, cg, n_draw,
+                                                   state))
         EXO_GP_LAYOUTS(J, cf, hipLaunchKernelGGL((celerite_chunk1_fwd_kernel<(JJ <= kLaneMaxJ ? JJ : 1), NR>), egrid, block, 0,
                                                  st, t, resid, diag, n_diag, n, cf, n_draw, state, cg),
                        hipLaunchKernelGGL(celerite_chunk1_fwd_mixed_kernel, dim3(egrid.x, egrid.y, 3), block, 0, st, t, resid, diag,
@@ -1753,6 +1809,12 @@ static int celerite_vjp(const double* t, Series resid, const double* diag, int64
       if (!ok) return EXO_ERR_LAUNCH;
     }
     if (cg.lane) {
+      // draws flagged kFlagRobust: the adjoint scan's inputs from the chunks' own recurrences, chained serially
+      const dim3 rgrid((unsigned)(J >= 3 ? (n_draw + kWave / 8 - 1) / (kWave / 8) : per_draw.x));
+      EXO_GP_DISPATCH_LANE(J, hipLaunchKernelGGL((celerite_chunk_adj_kernel<JJ>), dim3(per_draw.x, (unsigned)(cg.C - 1)), block, 0, st, t,
+                                                 resid, diag, n_diag, n, cf, n_draw, gloglike, wstate, cg))
+      EXO_GP_DISPATCH_LANE(J, hipLaunchKernelGGL((celerite_robust_scan_kernel<JJ, true>), rgrid, block, 0, st, t, cf, n, cg, n_draw,
+                                                 wstate))
       EXO_GP_LAYOUTS(J, cf, hipLaunchKernelGGL((celerite_chunk1_vjp_kernel<(JJ <= kLaneMaxJ ? JJ : 1), NR>), egrid, block, 0,
                                                st, t, resid, diag, n_diag, n, cf, n_draw, gloglike, wstate, cg, gresid,
                                                gdiag, gsign),

@@ -313,6 +313,26 @@ constexpr int kChunkMaxJ = 8;   // = EXO_GP_MAX_J (J = 7, 8: lane-group element 
 #ifndef EXO_GP_COND_MAX_J2
 #define EXO_GP_COND_MAX_J2 1e7
 #endif
+// ... and the score up to which such a draw takes the ROBUST route of the time-parallel path (round 4: serial application
+// of the elements + the adjoint scan's inputs from the chunks' own recurrences, chunk_adj_lane) instead of the sequential
+// kernels: tools/gp_lab_robust.py, 2400 random kernels -- every gradient of every draw under 1e8 within 4.5e-7 of the
+// long-double dense definition, 2e-7 worst in [1e8, 1e9), 1e-5 beyond
+#ifndef EXO_GP_COND_ROBUST_MAX
+#define EXO_GP_COND_ROBUST_MAX 1e8
+#endif
+// draw flags (ChunkWs::off_flag): how a draw is finished
+constexpr double kFlagClean = 0.0;    // scans as trees of element compositions
+constexpr double kFlagRobust = 1.0;   // one-lane path only: serial scans, adjoint inputs from the recurrences
+constexpr double kFlagSeq = 2.0;      // redone by the sequential kernels
+// raise a draw's flag (several chunks' lanes may, with different verdicts: the highest stays)
+EXO_HD void flag_raise(double* EXO_RESTRICT flag, double v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  // (non-negative doubles order like their bit patterns)
+  atomicMax(reinterpret_cast<unsigned long long*>(flag), (unsigned long long)__double_as_longlong(v));
+#else
+  if (v > *flag) *flag = v;
+#endif
+}
 #ifndef EXO_LANE_MAX_J
 #define EXO_LANE_MAX_J 6
 #endif
@@ -723,7 +743,8 @@ EXO_HD void elem_lane(const double* EXO_RESTRICT t, Series rs, const double* EXO
     }
   }
   const double rmin = (1.0 + ba2) * asum * (1.0 / (J <= 2 ? EXO_GP_COND_MAX_J2 : EXO_GP_COND_MAX));
-  bool ok = true;
+  const double rmin_seq = (1.0 + ba2) * asum * (1.0 / EXO_GP_COND_ROBUST_MAX);   // below: not even the robust route
+  bool ok = true, ok_robust = true;
   BlockIn cur, nxt;
   load_block(y, dg, n_diag, n0, n1, cur);
 #pragma unroll 1
@@ -735,6 +756,7 @@ EXO_HD void elem_lane(const double* EXO_RESTRICT t, Series rs, const double* EXO
     if (i < n1) {
     const double yi = cur.y[q], R = cur.g[q];
     ok = ok && (R >= rmin) && (R < INFINITY);
+    ok_robust = ok_robust && (R >= rmin_seq) && (R < INFINITY);
     double r[J], cu[J];
     double s = R, zeta = yi;
 #pragma unroll
@@ -780,7 +802,7 @@ EXO_HD void elem_lane(const double* EXO_RESTRICT t, Series rs, const double* EXO
    }
    cur = nxt;
   }
-  if (!ok) state[(flag_at >= 0 ? flag_at : ws.off_flag()) + draw] = 1.0;
+  if (!ok) flag_raise(state + (flag_at >= 0 ? flag_at : ws.off_flag()) + draw, ok_robust ? kFlagRobust : kFlagSeq);
   int e = 0;
 #pragma unroll
   for (int j = 0; j < J; ++j)
@@ -1977,7 +1999,8 @@ EXO_HD void chunk1_vjp_lane(const double* EXO_RESTRICT t, Series rs, const doubl
 // (C') reverse for wide states (J > 2): the same adjoint with the (symmetrised) adjoint of S PACKED, and
 // (chunkp_vjp_lane) two checkpoints per block.  Hand-derived adjoint of the two recurrences (same algebra as celerite_vjp_kernel
 // of exo_celerite.hip, one lane holding every state index): Sb is the SYMMETRISED adjoint of S.
-template <int J, int NR = -1>
+// STATE_ONLY: the adjoints of the recurrence state alone (chunk_adj_lane): no coefficient cotangents, no phase flux
+template <int J, int NR = -1, bool STATE_ONLY = false>
 struct RevP {
   Sym<J> Sb;   // (symmetrised adjoint of S: packed)
   double Fb[J], Wb[J];
@@ -1987,17 +2010,23 @@ struct RevP {
   // memory per lane (slot k at g[k * gs]), on the host a plain array (gs = 1): k = 4 j + {a, b, c, d}; 4 J = sum of dbar
   double* g;
   int gs;
-  EXO_HD void gadd(int k, double v) { g[k * gs] += v; }
+  EXO_HD void gadd(int k, double v) {
+    if (!STATE_ONLY) g[k * gs] += v;
+  }
 
   // measurement half of cadence i: adjoints of (d, z, W) of this cadence -> (S, F) of this cadence
   // and the coefficient cotangents through U, V.  W = (V - S U) / d is rebuilt (the step keeps V).
-  // Returns zbar (d loglike / d y_i) and dbar (d loglike / d diag_i).
+  // Returns zbar (d loglike / d y_i) and dbar (d loglike / d diag_i); U_out (if given): this cadence's U.
   EXO_HD void measure(const DrawCoef<J, NR>& co, const Step<J>& s, double dt_next, double gL, double* W_out, double* zbar_out,
-                      double* dbar_out) {
+                      double* dbar_out, double* U_out = nullptr) {
     double U[J], u[J], W[J];
 #pragma unroll
     for (int j = 0; j < J; ++j) U[j] = 0.0;
     co.u_from_v(s.V, U);
+    if (U_out) {
+#pragma unroll
+      for (int j = 0; j < J; ++j) U_out[j] = U[j];
+    }
     const double id = exo::fast_rcp(s.d);
     double wdot = 0.0;
 #pragma unroll
@@ -2035,6 +2064,7 @@ struct RevP {
     }
     // coefficient cotangents: a real term's U = a; a complex pair's (a, b, d) collect on its first index
     // (accumulators updated unconditionally, the layout deciding the increment: see DeltaCoef::eval)
+    if (STATE_ONLY) return;
 #pragma unroll
     for (int j = 0; j < J; ++j) {
       const bool re = co.is_real(j), fi = !re && co.is_first(j) && j + 1 < J;
@@ -2297,6 +2327,184 @@ EXO_HD void chunkp_vjp_lane(const double* EXO_RESTRICT t, Series rs, const doubl
     state[ws.gpart(c, 4 * j + 3, draw)] = gacc[(4 * j + 3) * gstride];
   }
   state[ws.gpart(c, 4 * J, draw)] = gacc[4 * J * gstride];
+}
+
+// (B'), part 1 by the EXACT RECURRENCES (round 4) -- what badj_prep_lane derives from a chunk's filtering element and the
+// state entering it, taken instead from the chunk's own reverse recurrences, for the draws whose conditioning the element
+// algebra cannot carry (tools/gp_host_lab.py: with the serial forward scan and THIS, every gradient of the random-kernel
+// tail is within 2e-7 of the sequential recurrences up to a score of 1e8; badj_prep_lane's local terms are accurate as
+// arithmetic but 1e7-fold sensitive to their inputs).  The reverse sweep of a chunk is affine in the adjoint it is entered
+// with:  with G_p = Phi_p (I - W_p U_p^T), the closed-loop transition of cadence p and the link behind it,
+//     Fbar_in = X Fbar_out + l_F,      Sbar_in = X Sbar_out X^T + sym(X Fbar_out r^T) + l_S,
+//     X = G_n0^T ... G_(n1-1)^T,       r = R_n0,   R_p = -(z_p / d_p) U_p + G_p^T R_(p+1),
+// and (l_F, l_S) is what the sweep leaves when entered with zero.  One sweep with the state adjoints only (RevP<STATE_ONLY>),
+// X and R riding along (X in a column outside the register file: `xacc`, J J doubles, stride `xs`), written over the
+// chunk's element exactly where badj_prep_lane writes (A <- X^T, b <- -r, eta <- l_F, Cm <- -l_S; P = Delta - S) so that
+// bscan_vjp_lane chains them unchanged.  c >= 1; reads the checkpoints of the forward pass.
+template <int J, int NR = -1>
+EXO_HD void chunk_adj_lane(const double* EXO_RESTRICT t, Series rs, const double* EXO_RESTRICT diag, int64_t n_diag, int64_t n,
+                           const Coefs& cf, int64_t n_draw, const double* EXO_RESTRICT gloglike, double* EXO_RESTRICT state,
+                           const ChunkGeom& cg, int64_t draw, int c, double* xacc, int xs) {
+  const int64_t n0 = c * cg.L, n1 = (n0 + cg.L < n) ? n0 + cg.L : n;
+  const ChunkWs ws = chunk_ws(n, n_draw, J, cg);
+  DrawCoef<J, NR> co;
+  co.init(cf, draw);
+  const double asum = co.asum();
+  const SeriesRow y(rs, draw, n);
+  const double* EXO_RESTRICT dg = diag + (n_diag == 1 ? 0 : draw * n);
+  const double gL = gloglike[draw];
+  RevP<J, NR, true> r;
+  double R[J];
+#pragma unroll
+  for (int j = 0; j < J; ++j) {
+    r.Fb[j] = r.Wb[j] = r.flux[j] = R[j] = 0.0;
+#pragma unroll
+    for (int l = 0; l < J; ++l) xacc[(j * J + l) * xs] = (j == l) ? 1.0 : 0.0;
+  }
+#pragma unroll
+  for (int k = 0; k < J * (J + 1) / 2; ++k) r.Sb.v[k] = 0.0;
+  r.db = r.zb = 0.0;
+  r.g = nullptr; r.gs = 0;
+  double phi[J];
+  if (n0 + 1 < n) co.set_ref(t[n0 + 1] - t[n0]);
+  const int64_t nb = (n1 - n0 + kCkptB - 1) / kCkptB;
+  bool pend = n1 < n;
+  constexpr int kK = J + J * (J + 1) / 2;
+  constexpr int kSpan = ckpt_span(J), kSub = kCkptB / kSpan;
+  BlockIn cur;
+  double ck[kK];
+#pragma unroll 1
+  for (int64_t bi = nb - 1; bi >= 0; --bi) {
+    const int64_t b0 = n0 + bi * kCkptB;
+    const int len = (int)((n1 - b0 < kCkptB) ? n1 - b0 : kCkptB);
+    load_block(y, dg, n_diag, b0, n1, cur);
+#pragma unroll
+    for (int h = kSub - 1; h >= 0; --h) {
+      const int q0 = h * kSpan;
+      const int slen = (len - q0 < kSpan) ? len - q0 : kSpan;
+      if (slen > 0) {
+        {
+          const int64_t g = (b0 + q0) / kSpan;
+#pragma unroll
+          for (int k = 0; k < kK; ++k) ck[k] = state[ws.ckpt(g, k, draw)];
+        }
+        Step<J> st[kSpan];
+        double tt[kSpan];
+        {
+          Fwd<J> f;
+#pragma unroll
+          for (int j = 0; j < J; ++j) { f.F[j] = ck[j]; f.U[j] = f.V[j] = f.W[j] = 0.0; }
+#pragma unroll
+          for (int k = 0; k < J * (J + 1) / 2; ++k) f.S.v[k] = ck[J + k];
+          double tprev = t[b0 + q0];
+#pragma unroll
+          for (int ql = 0; ql < kSpan; ++ql) {
+            if (ql < slen) {
+              const double ti = t[b0 + q0 + ql];
+              tt[ql] = ti;
+              if (ql > 0) {
+                const double dt = ti - tprev;
+                const bool near = co.step(dt, phi);
+                tprev = ti;
+                f.advance(phi);
+                if (near) {
+                  double Vp[J];
+#pragma unroll
+                  for (int j = 0; j < J; ++j) Vp[j] = f.V[j];
+                  co.rot_uv(dt, Vp, f.U, f.V);
+                } else {
+                  co.uv(ti, f.U, f.V);
+                }
+              } else {
+                co.uv(ti, f.U, f.V);
+              }
+              f.measure(cur.y[q0 + ql], cur.g[q0 + ql] + asum);
+              st[ql].S = f.S;
+              st[ql].d = f.d; st[ql].z = f.z;
+#pragma unroll
+              for (int j = 0; j < J; ++j) { st[ql].F[j] = f.F[j]; st[ql].V[j] = f.V[j]; }
+            } else {
+              tt[ql] = 0.0;
+              st[ql] = st[ql > 0 ? ql - 1 : 0];
+            }
+          }
+        }
+#pragma unroll
+        for (int ql = kSpan - 1; ql >= 0; --ql) {
+          if (ql < slen) {
+            const int q = q0 + ql;
+            const int64_t i = b0 + q;
+            double W[J], U[J];
+            const bool link = (i + 1 < n);   // the link behind cadence i; its phi is the one the last co.step call left
+            if (ql == slen - 1 && (q == len - 1 ? pend : true)) {
+#pragma unroll
+              for (int j = 0; j < J; ++j) U[j] = 0.0;
+              co.u_from_v(st[ql].V, U);
+              const double id = exo::fast_rcp(st[ql].d);
+#pragma unroll
+              for (int j = 0; j < J; ++j) {
+                double uj = 0.0;
+#pragma unroll
+                for (int l = 0; l < J; ++l) uj = fma(st[ql].S(j, l), U[l], uj);
+                W[j] = (st[ql].V[j] - uj) * id;
+              }
+              const double dt = t[i + 1] - tt[ql];
+              co.step(dt, phi, false);
+              r.propagate(st[ql], W, phi, dt);
+            }
+            double zbar, dbar;
+            r.measure(co, st[ql], 0.0, gL, W, &zbar, &dbar, U);
+            // X <- G^T X,  R <- c U + G^T R   with  G^T v = Phi v - U (W . Phi v)
+            {
+              const double cz = -st[ql].z * exo::fast_rcp(st[ql].d);
+              double v[J], sdot = 0.0;
+#pragma unroll
+              for (int j = 0; j < J; ++j) { v[j] = link ? phi[j] * R[j] : 0.0; sdot = fma(W[j], v[j], sdot); }
+#pragma unroll
+              for (int j = 0; j < J; ++j) R[j] = fma(cz - sdot, U[j], v[j]);
+#pragma unroll
+              for (int k = 0; k < J; ++k) {
+                sdot = 0.0;
+#pragma unroll
+                for (int j = 0; j < J; ++j) { v[j] = (link ? phi[j] : 1.0) * xacc[(j * J + k) * xs]; sdot = fma(W[j], v[j], sdot); }
+#pragma unroll
+                for (int j = 0; j < J; ++j) xacc[(j * J + k) * xs] = fma(-sdot, U[j], v[j]);
+              }
+            }
+            if (ql > 0) {
+              double Wp[J];
+#pragma unroll
+              for (int j = 0; j < J; ++j) U[j] = 0.0;
+              co.u_from_v(st[ql - 1].V, U);
+              const double id = exo::fast_rcp(st[ql - 1].d);
+#pragma unroll
+              for (int j = 0; j < J; ++j) {
+                double uj = 0.0;
+#pragma unroll
+                for (int l = 0; l < J; ++l) uj = fma(st[ql - 1].S(j, l), U[l], uj);
+                Wp[j] = (st[ql - 1].V[j] - uj) * id;
+              }
+              const double dt = tt[ql] - tt[ql - 1];
+              co.step(dt, phi, false);
+              r.propagate(st[ql - 1], Wp, phi, dt);
+            }
+          }
+        }
+      }
+    }
+    pend = true;
+  }
+  const int oA = 0, ob = J * J, oC = J * J + J, oeta = 2 * J * J + J;
+#pragma unroll
+  for (int j = 0; j < J; ++j) {
+    state[ws.elem(c, ob + j, draw)] = -R[j];
+    state[ws.elem(c, oeta + j, draw)] = r.Fb[j];
+#pragma unroll
+    for (int l = 0; l < J; ++l) {
+      state[ws.elem(c, oA + j * J + l, draw)] = xacc[(l * J + j) * xs];   // Abar = X^T
+      state[ws.elem(c, oC + j * J + l, draw)] = -r.Sb(j, l);
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------

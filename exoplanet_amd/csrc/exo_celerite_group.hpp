@@ -410,4 +410,114 @@ __device__ __forceinline__ void tree_item_group(const TreeOp& op, double* state,
   group_store_elem<J, ADJ>(state, op, c, draw, g, r, oA, ob, oC, oeta, oJ);
 }
 
+// ---- the ROBUST route (exo_celerite_core.hpp, chunk_adj_lane): the scans of ONE draw as serial chains on one group of eight
+// lanes -- C - 1 applications of an element to a state, each the DOWN item of the trees (the same arithmetic as bscan_lane /
+// bscan_vjp_lane), the next element's rows in flight while the current one is applied.  Composing elements is what loses the
+// digits of ill-conditioned draws; applying them one after the other does not.
+template <int J>
+__device__ __forceinline__ void chain_load_elem(const double* state, const ChunkWs& ws, int c, int64_t draw, const Grp<J>& g, int r,
+                                                ElemRow<J>& el, bool want_J) {
+  const int64_t nd = ws.n_draw;
+  const bool has = c >= 0 && c < ws.C;
+  const double* p = state + ws.elem(has ? c : 0, 0, draw);
+  const bool ld = has && g.live;
+#pragma unroll
+  for (int l = 0; l < J; ++l) {
+    el.A[l] = ld ? p[(int64_t)(r * J + l) * nd] : 0.0;
+    el.Cm[l] = ld ? p[(int64_t)(J * J + J + r * J + l) * nd] : 0.0;
+    el.Jm[l] = (ld && want_J) ? p[(int64_t)(2 * J * J + 2 * J + r * J + l) * nd] : 0.0;
+  }
+  el.b = ld ? p[(int64_t)(J * J + r) * nd] : 0.0;
+  el.eta = ld ? p[(int64_t)(2 * J * J + J + r) * nd] : 0.0;
+}
+
+template <int J, bool ADJ>
+__device__ __forceinline__ void robust_scan_group(const ChunkWs& ws, double* state, int64_t draw, const Grp<J>& g) {
+  const int64_t nd = ws.n_draw;
+  const int C = ws.C;
+  int r = g.live ? g.r : 0;
+  double m = 0.0, P[J];
+#pragma unroll
+  for (int l = 0; l < J; ++l) P[l] = 0.0;
+  if (!ADJ) {   // the state entering chunk 0 (the trees hand it down untouched)
+    m = g.live ? state[ws.bnd(1, 0, r, draw)] : 0.0;
+#pragma unroll
+    for (int l = 0; l < J; ++l) P[l] = g.live ? state[ws.bnd(1, 0, J + r * J + l, draw)] : 0.0;
+  } else if (g.live) {   // nothing enters the last chunk from behind
+    state[ws.bnd(2, C - 1, r, draw)] = 0.0;
+#pragma unroll
+    for (int l = 0; l < J; ++l) state[ws.bnd(2, C - 1, J + r * J + l, draw)] = 0.0;
+  }
+  ElemRow<J> el, nx;
+  chain_load_elem<J>(state, ws, ADJ ? C - 1 : 0, draw, g, r, el, !ADJ);
+#pragma unroll 1
+  for (int s = 0; s + 1 < C; ++s) {
+    asm volatile("" : "+v"(r));   // (keeps the ~20 row offsets of the strided loads from being hoisted out of the loop)
+    const int c = ADJ ? C - 1 - s : s;          // the element applied in this step
+    chain_load_elem<J>(state, ws, ADJ ? c - 1 : c + 1, draw, g, r, nx, !ADJ);
+    double m2, P2[J];
+    if (ADJ) {
+      // x = Abar^T Fbar ;  Fbar' = lF + x ;  Pbar' = lP + Abar^T Pbar Abar + sym(x g^T)
+      g.put_rows(0, el.A);
+      g.put_vec(0, m);
+      g.put_vec(2, el.b);
+      g.sync();
+      const double x = g.tmv(0, 0);
+      double T[J];
+      g.mm(P, 0, T);
+      g.put_rows(1, T);
+      g.put_vec(1, x);
+      g.sync();
+      g.tmm(0, 1, P2);
+      double xa[J], ba[J];
+      g.get_vec(1, xa);
+      g.get_vec(2, ba);
+      m2 = el.eta + x;
+#pragma unroll
+      for (int l = 0; l < J; ++l) P2[l] = el.Cm[l] + P2[l] + 0.5 * (x * ba[l] + el.b * xa[l]);
+    } else {
+      // X = I + P Jm ;  solve X [YP | ym] = [P | F + P eta] ;  F' = A ym + b ;  P' = A (YP) A^T + Cm
+      g.put_rows(0, el.Jm);
+      g.put_rows(2, el.A);
+      g.put_vec(0, el.eta);
+      g.sync();
+      double X[J], Bm[J + 1];
+      g.mm(P, 0, X);
+#pragma unroll
+      for (int l = 0; l < J; ++l) X[l] = g.live ? X[l] + (l == r ? 1.0 : 0.0) : 0.0;
+#pragma unroll
+      for (int l = 0; l < J; ++l) Bm[l] = P[l];
+      Bm[J] = m + g.mv(P, 0);
+      g.template solve<J + 1>(X, Bm);
+      double YP[J];
+#pragma unroll
+      for (int l = 0; l < J; ++l) YP[l] = Bm[l];
+      g.put_rows(1, YP);
+      g.put_vec(1, Bm[J]);
+      g.sync();
+      double AY[J];
+      g.mm(el.A, 1, AY);
+      m2 = el.b + g.mv(el.A, 1);
+      g.mm_t(AY, 2, P2);
+#pragma unroll
+      for (int l = 0; l < J; ++l) P2[l] += el.Cm[l];
+    }
+    g.put_rows(3, P2);
+    g.sync();
+    g.sym_from(3, P2);
+    g.sync();      // (the next step's rows go where this one's were read)
+    m = m2;
+#pragma unroll
+    for (int l = 0; l < J; ++l) P[l] = P2[l];
+    if (g.live) {
+      // forward: the state entering chunk c + 1;  adjoint: what chunk c - 1's reverse recurrences start from (Sbar = -Pbar)
+      const int q = ADJ ? 2 : 1, at = ADJ ? c - 1 : c + 1;
+      state[ws.bnd(q, at, r, draw)] = m;
+#pragma unroll
+      for (int l = 0; l < J; ++l) state[ws.bnd(q, at, J + r * J + l, draw)] = ADJ ? -P[l] : P[l];
+    }
+    el = nx;
+  }
+}
+
 }  // namespace gp

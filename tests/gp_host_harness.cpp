@@ -15,6 +15,8 @@
 namespace {
 
 int g_serial_scan = 0;   // 1: the serial reference scans (bscan_lane, bscan_vjp_lane) instead of the trees
+int g_robust_flags = 1;  // draws the element lanes flag kFlagRobust take the robust route (as on the device)
+int g_robust = 0;        // 1: serial forward scan + the adjoint scan's inputs from the chunks' own recurrences (chunk_adj_lane)
 int g_polish = 0;        // 1: a polish pass over every draw after the chunk recurrences (forward and reverse), as the
                          //    device runs it for the draws whose conditioning asks for it
 
@@ -25,14 +27,14 @@ void run_fwd(const double* t, gp::Series rs, const double* diag, int64_t n_diag,
   for (int64_t d = 0; d < n_draw; ++d) {
     gp::DeltaCoef<J> dc;
     dc.init(cf, d);
-    state[ws.off_flag() + d] = dc.valid ? 0.0 : 1.0;
+    state[ws.off_flag() + d] = dc.valid ? gp::kFlagClean : gp::kFlagSeq;
   }
   for (int c = 0; c < cg.C; ++c)
     for (int64_t d = 0; d < n_draw; ++d)
       gp::with_layout<J>(cf, d, [&](auto nr) {
         gp::elem_lane<J, decltype(nr)::value>(t, rs, diag, n_diag, n, cf, n_draw, state, cg, d, c);
       });
-  if (cg.tree && !g_serial_scan) {   // the scans as trees of compositions, level by level, as the device launches them
+  if (cg.tree && !g_serial_scan && !g_robust) {   // the scans as trees of compositions, level by level, as the device launches them
     gp::tree_scan(ws, cg, J, n_draw, false,
                   [&](const gp::TreeOp& op, bool down) {
                     for (int c = 0; c < op.n_item; ++c)
@@ -47,6 +49,10 @@ void run_fwd(const double* t, gp::Series rs, const double* diag, int64_t n_diag,
   } else {
     for (int64_t d = 0; d < n_draw; ++d) gp::bscan_lane<J>(t, cf, n, n_draw, state, cg, d);
   }
+  // the robust route, as the device takes it: draws flagged kFlagRobust get their entering states from the serial scan
+  if (cg.tree && !g_serial_scan && !g_robust && g_robust_flags)
+    for (int64_t d = 0; d < n_draw; ++d)
+      if (state[ws.off_flag() + d] == gp::kFlagRobust) gp::bscan_lane<J>(t, cf, n, n_draw, state, cg, d);
   if (g_polish < 0 && ((-g_polish) & 1)) {
     // experiment: the chunks ONE AFTER THE OTHER, each entered with what its predecessor just left -- the sequential algorithm
     // in chunk-sized steps (exact boundary states): what the accuracy would be if the scans were perfect
@@ -83,8 +89,17 @@ void run_vjp(const double* t, gp::Series rs, const double* diag, int64_t n_diag,
              double* gdiag, double gsign, double* gdiag_sum, double* gcr, double* gcc) {
   const gp::ChunkWs ws = gp::chunk_ws(n, n_draw, J, cg);
   for (int c = 1; c < cg.C; ++c)
-    for (int64_t d = 0; d < n_draw; ++d) gp::badj_prep_lane<J>(gloglike, n, n_draw, state, cg, d, c);
-  if (cg.tree && !g_serial_scan) {
+    for (int64_t d = 0; d < n_draw; ++d) {
+      if (g_robust) {
+        gp::with_layout<J>(cf, d, [&](auto nr) {
+          double x[J * J];
+          gp::chunk_adj_lane<J, decltype(nr)::value>(t, rs, diag, n_diag, n, cf, n_draw, gloglike, state, cg, d, c, x, 1);
+        });
+      } else {
+        gp::badj_prep_lane<J>(gloglike, n, n_draw, state, cg, d, c);
+      }
+    }
+  if (cg.tree && !g_serial_scan && !g_robust) {
     gp::tree_scan(ws, cg, J, n_draw, true,
                   [&](const gp::TreeOp& op, bool down) {
                     for (int c = 0; c < op.n_item; ++c)
@@ -100,6 +115,16 @@ void run_vjp(const double* t, gp::Series rs, const double* diag, int64_t n_diag,
   } else {
     for (int64_t d = 0; d < n_draw; ++d) gp::bscan_vjp_lane<J>(n, n_draw, state, cg, d);
   }
+  if (cg.tree && !g_serial_scan && !g_robust && g_robust_flags)
+    for (int64_t d = 0; d < n_draw; ++d)
+      if (state[ws.off_flag() + d] == gp::kFlagRobust) {
+        for (int c = 1; c < cg.C; ++c)
+          gp::with_layout<J>(cf, d, [&](auto nr) {
+            double x[J * J];
+            gp::chunk_adj_lane<J, decltype(nr)::value>(t, rs, diag, n_diag, n, cf, n_draw, gloglike, state, cg, d, c, x, 1);
+          });
+        gp::bscan_vjp_lane<J>(n, n_draw, state, cg, d);
+      }
   const bool seq_adj = g_polish < 0 && ((-g_polish) & 2);   // experiment: exact adjoint boundary states (chunks last to first)
   for (int pass = 0; pass <= (g_polish > 0 ? g_polish : 0); ++pass)
   for (int cc = 0; cc < cg.C; ++cc) {
@@ -135,6 +160,8 @@ extern "C" {
 
 void harness_set_serial_scan(int v) { g_serial_scan = v; }
 void harness_set_polish(int v) { g_polish = v; }
+void harness_set_robust(int v) { g_robust = v; }
+void harness_set_robust_flags(int v) { g_robust_flags = v; }
 // (experiments: where the checkpoints -- the states (F, packed S) entering every ckpt_span(J)-th cadence -- live in `state`)
 // (experiments: where the filtering elements [chunk][A, b, C, eta, J][draw] live in `state`)
 int64_t harness_gp_elem_offset(int64_t n, int64_t n_draw, int32_t n_real, int32_t n_complex, int32_t n_chunks, int64_t* C) {

@@ -235,7 +235,7 @@ def test_lane_pipeline_flags_what_it_cannot_take(harness):
     ar, cr, *_ = P.sho_coefficients(1.0, 1.3, 0.3)
     real = np.stack([ar, cr], -1)[None]
     ll, flags, _ = run(harness, t, rng.normal(size=(1, n)), np.full((1, n), 0.1), real, np.zeros((1, 0, 4)))
-    assert flags[0] == 1.0
+    assert flags[0] == 2.0     # (kFlagSeq)
 
 
 def test_lane_pipeline_long_series_vs_c_port(harness):

@@ -1,15 +1,8 @@
-#!/usr/bin/env python
-"""the c3_gp_conditioning legs of bench.py alone (clean / 1 % near-critical / Matern): tools/gp_cond_leg.py"""
-import json
-import os
-import sys
-
-import torch
-
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import bench  # noqa: E402
-import exoplanet_amd as xo  # noqa: E402
-from exoplanet_amd import ops  # noqa: E402
-
-r = bench.extra_gp_conditioning(xo, ops, torch.device("cuda:0"), 1024)
-print(json.dumps({k: round(v["median_ms"], 3) for k, v in r.items() if isinstance(v, dict) and "median_ms" in v}))
+import json, sys, torch
+sys.path.insert(0, '.')
+import bench, exoplanet_amd as xo
+from exoplanet_amd import ops
+dev = torch.device('cuda:0')
+out = bench.extra_gp_conditioning(xo, ops, dev, 1024)
+for k, v in out.items():
+    if isinstance(v, dict): print(k, {a: (round(b, 4) if isinstance(b, float) else b) for a, b in v.items() if a != 'note'})

@@ -59,6 +59,7 @@ def main():
     lib = build(name, sys.argv[4:])
     lib.harness_set_serial_scan(int(os.environ.get("LAB_SERIAL", "0")))
     lib.harness_set_polish(int(os.environ.get("LAB_POLISH", "0")))
+    lib.harness_set_robust(int(os.environ.get("LAB_ROBUST", "0")))
     rows = []
     for t, y, diag, cr, cc, dtm in cases(seed, n_cases):
         D = y.shape[0]
