@@ -285,9 +285,11 @@ C5_LD = ((0.3, 0.2), (0.4, 0.1))
 C5_YERR = 3e-4
 
 
-def workload_c5(xo, ops, dev, D, rank=0):
+def workload_c5(xo, ops, dev, D, rank=0, bright=0):
     """BASELINE configs[4] (C5): 65 000 long cadences, exposure stencil x 7, secondary eclipse, three SHO terms (J = 6);
-    D = this rank's share of the 1024 chains (128 on each of 8 GPUs)"""
+    D = this rank's share of the 1024 chains (128 on each of 8 GPUs).  bright (extras only): that many chains with the first
+    term's amplitude at 1000 x the error bars -- a conditioning score of 1e6, above the 3e4 of the scan trees: those chains
+    take the robust route of the time-parallel path (exo_celerite_core.hpp, chunk_adj_lane)"""
     rng = np.random.default_rng(5 + 1000 * rank)
     n, texp = C5_NCAD, C5_TEXP
     t = ops.vouch_sorted(torch.arange(n, dtype=torch.float64, device=dev) * texp)
@@ -296,6 +298,10 @@ def workload_c5(xo, ops, dev, D, rank=0):
     leaves = {k: mk(v) for k, v in C5_BASE.items()}
     vec = lambda v: torch.full((D,), v, dtype=torch.float64, device=dev, requires_grad=True)  # noqa: E731
     leaves.update(sbr=vec(0.3), s1=vec(C5_TERMS[0][0]), s2=vec(C5_TERMS[1][0]), s3=vec(C5_TERMS[2][0]))
+    if bright:
+        s1 = np.full(D, C5_TERMS[0][0])
+        s1[:bright] = 1e3 * C5_YERR
+        leaves["s1"] = torch.tensor(s1, dtype=torch.float64, device=dev, requires_grad=True)
     yobs = torch.as_tensor(3e-4 * np.random.default_rng(5).normal(size=n), device=dev)       # (the data: same on every rank)
     ones = torch.ones(D, dtype=torch.float64, device=dev)
     fixed = [(rho * ones, Q * ones) for _, rho, Q in C5_TERMS]     # (rho, Q) of the three terms: fixed, per chain
@@ -645,9 +651,9 @@ def graphed(xo, fn, inputs, dev, iters):
         return q, f"eager launches (capture failed: {repr(exc)[:120]})"
 
 
-def extra_config(xo, ops, dev, key, D, iters):
+def extra_config(xo, ops, dev, key, D, iters, **kw):
     """one of the BASELINE configs at a per-GPU size, as the very step `--config` times (hipGraph replay)"""
-    w = WORKLOADS[key](xo, ops, dev, D)
+    w = WORKLOADS[key](xo, ops, dev, D, **kw)
     q, how = graphed(xo, w.fn, w.leaves, dev, iters)
     gbps = w.survey_bytes_per_unit * D * w.n_cad / (q["median_ms"] * 1e-3) / 1e9
     out = {"evals_per_s": D / (q["median_ms"] * 1e-3), **q, "draws": D, "n_cadences": w.n_cad, "launch": how,
@@ -898,6 +904,8 @@ def main():
     ap.add_argument("--global-draws", type=int, default=0,
                     help="fix the TOTAL number of draws (strong scaling); default for --config c4 / c5: 512 / 1024, "
                          "as BASELINE.json states them over 8 GPUs")
+    ap.add_argument("--c5-bright", type=int, default=0, help="profiling aid (--config c5): that many chains at a conditioning score of 1e6 "
+                    "(workload_c5); not a BASELINE configuration")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch the step eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-extras", action="store_true")
@@ -943,7 +951,7 @@ def main():
     else:
         D, n_global, scaling = args.draws_per_gpu, world * args.draws_per_gpu, "weak"
     events = HipEvents(max(args.steps, 20))
-    wl = WORKLOADS[cfg](xo, ops, dev, D, rank)
+    wl = WORKLOADS[cfg](xo, ops, dev, D, rank, **({"bright": args.c5_bright} if cfg == "c5" and args.c5_bright else {}))
     leaves = dict(zip(wl.names, wl.leaves))
     N = wl.n_cad
     exchange = LoglikeExchange(n_global, dev, force_collective=os.environ.get("EXO_BENCH_FORCE_DIST") == "1") if dist is not None else None
@@ -1189,6 +1197,18 @@ def main():
         torch.cuda.empty_cache()
         leg("c4_four_planets_64_draws", lambda: extra_config(xo, ops, dev, "c4", 64, 40))
         leg("c5_secondary_eclipse_3term_gp_128_chains", lambda: extra_config(xo, ops, dev, "c5", 128, 12))
+
+        def c5_bright():
+            out = extra_config(xo, ops, dev, "c5", 128, 12, bright=2)
+            clean = extras.get("c5_secondary_eclipse_3term_gp_128_chains", {}).get("median_ms")
+            out["over_clean"] = out["median_ms"] / clean if clean else None
+            out["same_step_as"] = None
+            out["note"] = ("the C5 step at 128 chains with 2 of them (1 %) at a conditioning score of 1e6 (first SHO term 1000 x the error "
+                           "bars): those chains take the robust route of the time-parallel path -- serial scans on a group of eight "
+                           "lanes, the adjoint scan's inputs from the chunks' own reverse recurrences -- instead of the sequential "
+                           "kernels (VERDICT r3 item 2b: <= 2 x the clean step); " + out["note"])
+            return out
+        leg("c5_128_chains_1pct_bright_star_kappa_1e6", c5_bright)
         torch.cuda.empty_cache()
         leg("astrometry_and_velocities", lambda: extra_astrometry(xo, dev))
         def nuts_leg():

@@ -1370,44 +1370,49 @@ __global__ __launch_bounds__(kWave, (J < EXO_SPAN2_MIN_J ? EXO_VJP1_WAVES : (J <
 }
 
 // ---- the ROBUST route (draws flagged kFlagRobust: exo_celerite_core.hpp, chunk_adj_lane) ---------------------------------
-// (B) / (B') once more for those draws alone, as serial chains over the chunks: a draw on one group of eight lanes for
-// J >= 3 (robust_scan_group), on one lane below.  Launched after the trees, whose boundary states of these draws it replaces.
-template <int J, bool ADJ>
+// (B) once more for those draws alone, as a serial chain over the chunks: a draw on one group of eight lanes for J >= 3
+// (robust_fwd_chain_group), on one lane below.  Launched after the trees, whose boundary states of these draws it replaces.
+template <int J>
 __global__ __launch_bounds__(kWave) void celerite_robust_scan_kernel(const double* __restrict__ t, Coefs cf, int64_t n,
                                                                      ChunkGeom cg, int64_t n_draw, double* state) {
   const ChunkWs ws = chunk_ws(n, n_draw, J, cg);
   if constexpr (J >= 3) {
-    __shared__ double lds[(kWave / 8) * GroupLds<J>::S];
+    __shared__ double lds[(kWave / 8) * ChainLds<J>::S];
     const int64_t draw = (int64_t)blockIdx.x * (kWave / 8) + (threadIdx.x >> 3);
     const bool mine = draw < n_draw && state[ws.off_flag() + (draw < n_draw ? draw : 0)] == kFlagRobust;
     if (__ballot(mine) == 0) return;
-    if (!mine) return;     // (whole groups leave: the items need no block barrier)
-    Grp<J> g;
-    g.lds = lds + (threadIdx.x >> 3) * GroupLds<J>::S;
-    g.r = threadIdx.x & 7;
-    g.live = g.r < J;
-    robust_scan_group<J, ADJ>(ws, state, draw, g);
+    if (!mine) return;     // (whole groups leave: nothing below needs a block barrier)
+    robust_fwd_chain_group<J>(ws, state, draw, lds + (threadIdx.x >> 3) * ChainLds<J>::S, (int)(threadIdx.x & 7));
   } else {
     const int64_t draw = (int64_t)blockIdx.x * kWave + threadIdx.x;
     if (draw >= n_draw || state[ws.off_flag() + draw] != kFlagRobust) return;
-    if (ADJ) bscan_vjp_lane<J>(n, n_draw, state, cg, draw);
-    else bscan_lane<J>(t, cf, n, n_draw, state, cg, draw);
+    bscan_lane<J>(t, cf, n, n_draw, state, cg, draw);
   }
 }
 
-// (B') part 1 for those draws: the adjoint scan's inputs from the chunks' own reverse recurrences (chunk_adj_lane), one lane
-// per (draw, chunk >= 1), written over the chunk's element where badj_prep_lane wrote its own
+// (B') part 1 for those draws: the adjoint scan's inputs from the chunks' own reverse recurrences (chunk_adj_lane), written
+// over the chunk's element where badj_prep_lane wrote its own -- launched between that kernel and the adjoint trees, which take
+// them as they are.  A (draw, chunk >= 1) on EIGHT lanes (chunk_adj_lane's roles: the state adjoints, the J columns of X, R):
+// a block is eight consecutive chunks of the robust draws among 64 consecutive ones -- none, almost always: it leaves at once.
 template <int J>
 __global__ __launch_bounds__(kWave) void celerite_chunk_adj_kernel(const double* __restrict__ t, Series rs,
                                                                    const double* __restrict__ diag, int64_t n_diag, int64_t n,
                                                                    Coefs cf, int64_t n_draw, const double* __restrict__ gloglike,
                                                                    double* __restrict__ state, ChunkGeom cg) {
-  __shared__ double xacc[J * J][kWave];
-  const int64_t draw = (int64_t)blockIdx.x * kWave + threadIdx.x;
+  static_assert(J + 2 <= 8, "roles 0 .. J + 1 on the eight lanes of a group");
   const ChunkWs ws = chunk_ws(n, n_draw, J, cg);
-  if (draw >= n_draw || state[ws.off_flag() + draw] != kFlagRobust) return;
-  chunk_adj_lane<J, -1>(t, rs, diag, n_diag, n, cf, n_draw, gloglike, state, cg, draw, (int)blockIdx.y + 1, &xacc[0][threadIdx.x],
-                        kWave);
+  const int64_t d0 = (int64_t)blockIdx.y * kWave, dl = d0 + threadIdx.x;
+  unsigned long long todo = __ballot(dl < n_draw && state[ws.off_flag() + (dl < n_draw ? dl : 0)] == kFlagRobust);
+  const int c = 1 + (int)blockIdx.x * 8 + (int)(threadIdx.x >> 3), role = (int)(threadIdx.x & 7);
+  while (todo) {
+    const int64_t draw = d0 + (__ffsll((long long)todo) - 1);
+    todo &= todo - 1;
+    // (every lane has the same draw: the "vote" is that draw's layout -- the compile-time ones cost a quarter fewer instructions)
+    if (c < cg.C && role <= J + 1)
+      with_layout<J>(cf, draw, [&](auto nr) {
+        chunk_adj_lane<J, decltype(nr)::value>(t, rs, diag, n_diag, n, cf, n_draw, gloglike, state, cg, draw, c, role, nullptr, 0);
+      });
+  }
 }
 
 // sum over the wave in a fixed order (xor butterfly), result in every lane
@@ -1730,7 +1735,7 @@ static int celerite_fwd(const double* t, Series resid, const double* diag, int64
       if (cg.lane) {
         // draws flagged kFlagRobust: their entering states once more, by serial application of the elements
         const dim3 rgrid((unsigned)(J >= 3 ? (n_draw + kWave / 8 - 1) / (kWave / 8) : per_draw.x));
-        EXO_GP_DISPATCH_LANE(J, hipLaunchKernelGGL((celerite_robust_scan_kernel<JJ, false>), rgrid, block, 0, st, t, cf, n, cg, n_draw,
+        EXO_GP_DISPATCH_LANE(J, hipLaunchKernelGGL((celerite_robust_scan_kernel<JJ>), rgrid, block, 0, st, t, cf, n, cg, n_draw,
                                                    state))
         EXO_GP_LAYOUTS(J, cf, hipLaunchKernelGGL((celerite_chunk1_fwd_kernel<(JJ <= kLaneMaxJ ? JJ : 1), NR>), egrid, block, 0,
                                                  st, t, resid, diag, n_diag, n, cf, n_draw, state, cg),
@@ -1779,6 +1784,11 @@ static int celerite_vjp(const double* t, Series resid, const double* diag, int64
         egrid(per_draw.x, (unsigned)cg.C);
     EXO_GP_DISPATCH(J, hipLaunchKernelGGL((celerite_badj_prep_kernel<JJ>), dim3(per_draw.x, (unsigned)(cg.C - 1)), block,
                                           0, st, gloglike, n, n_draw, wstate, cg))
+    if (cg.lane) {
+      // draws flagged kFlagRobust: those inputs once more, from the chunks' own reverse recurrences (chunk_adj_lane)
+      EXO_GP_DISPATCH_LANE(J, hipLaunchKernelGGL((celerite_chunk_adj_kernel<JJ>), dim3((unsigned)((cg.C - 1 + 7) / 8), per_draw.x), block, 0,
+                                                 st, t, resid, diag, n_diag, n, cf, n_draw, gloglike, wstate, cg))
+    }
     if (EXO_GP_FUSED_SCAN) {
       // (B') as a tree over positions p = C - 1 - chunk, one launch: adjoint elements of chunks C - 1 .. 1, zero initial adjoint
       const dim3 sgrid((unsigned)(8 * ((n_draw + 7) / 8)));
@@ -1809,12 +1819,6 @@ static int celerite_vjp(const double* t, Series resid, const double* diag, int64
       if (!ok) return EXO_ERR_LAUNCH;
     }
     if (cg.lane) {
-      // draws flagged kFlagRobust: the adjoint scan's inputs from the chunks' own recurrences, chained serially
-      const dim3 rgrid((unsigned)(J >= 3 ? (n_draw + kWave / 8 - 1) / (kWave / 8) : per_draw.x));
-      EXO_GP_DISPATCH_LANE(J, hipLaunchKernelGGL((celerite_chunk_adj_kernel<JJ>), dim3(per_draw.x, (unsigned)(cg.C - 1)), block, 0, st, t,
-                                                 resid, diag, n_diag, n, cf, n_draw, gloglike, wstate, cg))
-      EXO_GP_DISPATCH_LANE(J, hipLaunchKernelGGL((celerite_robust_scan_kernel<JJ, true>), rgrid, block, 0, st, t, cf, n, cg, n_draw,
-                                                 wstate))
       EXO_GP_LAYOUTS(J, cf, hipLaunchKernelGGL((celerite_chunk1_vjp_kernel<(JJ <= kLaneMaxJ ? JJ : 1), NR>), egrid, block, 0,
                                                st, t, resid, diag, n_diag, n, cf, n_draw, gloglike, wstate, cg, gresid,
                                                gdiag, gsign),

@@ -912,6 +912,56 @@ struct Elem {
   }
 };
 
+// a filtering element applied to the state entering it: (m, P) <- the state it leaves
+template <int J>
+EXO_HD void apply_elem(const Elem<J>& el, double (&m)[J], double (&P)[J][J]) {
+  // X = I + P Jm ;  solve X [YP | ym] = [P | m + P eta]
+  double X[J][J], Bm[J][J + 1];
+#pragma unroll
+  for (int j = 0; j < J; ++j) {
+    double pe = m[j];
+#pragma unroll
+    for (int l = 0; l < J; ++l) {
+      double x = (j == l) ? 1.0 : 0.0;
+#pragma unroll
+      for (int k = 0; k < J; ++k) x = fma(P[j][k], el.Jm[k][l], x);
+      X[j][l] = x;
+      Bm[j][l] = P[j][l];
+      pe = fma(P[j][l], el.eta[l], pe);
+    }
+    Bm[j][J] = pe;
+  }
+  solve_inplace<J, J + 1>(X, Bm);
+  // m' = A ym + b ;  P' = A (YP) A^T + Cm  (symmetrised)
+  double AY[J][J];
+#pragma unroll
+  for (int j = 0; j < J; ++j) {
+    double mj = el.b[j];
+#pragma unroll
+    for (int l = 0; l < J; ++l) {
+      mj = fma(el.A[j][l], Bm[l][J], mj);
+      double v = 0.0;
+#pragma unroll
+      for (int k = 0; k < J; ++k) v = fma(el.A[j][k], Bm[k][l], v);
+      AY[j][l] = v;   // A (YP)
+    }
+    m[j] = mj;
+  }
+#pragma unroll
+  for (int j = 0; j < J; ++j)
+#pragma unroll
+    for (int l = 0; l < J; ++l) {
+      double v = el.Cm[j][l];
+#pragma unroll
+      for (int k = 0; k < J; ++k) v = fma(AY[j][k], el.A[l][k], v);
+      X[j][l] = v;
+    }
+#pragma unroll
+  for (int j = 0; j < J; ++j)
+#pragma unroll
+    for (int l = 0; l < J; ++l) P[j][l] = 0.5 * (X[j][l] + X[l][j]);
+}
+
 // (B) the state entering every chunk of one draw: C - 1 element applications
 template <int J>
 EXO_HD void bscan_lane(const double* EXO_RESTRICT t, const Coefs& cf, int64_t n, int64_t n_draw,
@@ -951,51 +1001,7 @@ EXO_HD void bscan_lane(const double* EXO_RESTRICT t, const Coefs& cf, int64_t n,
     if (c + 1 == cg.C) break;
     Elem<J> el;
     el.load(state, ws, c, draw);
-    // X = I + P Jm ;  solve X [YP | ym] = [P | m + P eta]
-    double X[J][J], Bm[J][J + 1];
-#pragma unroll
-    for (int j = 0; j < J; ++j) {
-      double pe = m[j];
-#pragma unroll
-      for (int l = 0; l < J; ++l) {
-        double x = (j == l) ? 1.0 : 0.0;
-#pragma unroll
-        for (int k = 0; k < J; ++k) x = fma(P[j][k], el.Jm[k][l], x);
-        X[j][l] = x;
-        Bm[j][l] = P[j][l];
-        pe = fma(P[j][l], el.eta[l], pe);
-      }
-      Bm[j][J] = pe;
-    }
-    solve_inplace<J, J + 1>(X, Bm);
-    // m' = A ym + b ;  P' = A (YP) A^T + Cm  (symmetrised)
-    double AY[J][J];
-#pragma unroll
-    for (int j = 0; j < J; ++j) {
-      double mj = el.b[j];
-#pragma unroll
-      for (int l = 0; l < J; ++l) {
-        mj = fma(el.A[j][l], Bm[l][J], mj);
-        double v = 0.0;
-#pragma unroll
-        for (int k = 0; k < J; ++k) v = fma(el.A[j][k], Bm[k][l], v);
-        AY[j][l] = v;   // A (YP)
-      }
-      m[j] = mj;
-    }
-#pragma unroll
-    for (int j = 0; j < J; ++j)
-#pragma unroll
-      for (int l = 0; l < J; ++l) {
-        double v = el.Cm[j][l];
-#pragma unroll
-        for (int k = 0; k < J; ++k) v = fma(AY[j][k], el.A[l][k], v);
-        X[j][l] = v;
-      }
-#pragma unroll
-    for (int j = 0; j < J; ++j)
-#pragma unroll
-      for (int l = 0; l < J; ++l) P[j][l] = 0.5 * (X[j][l] + X[l][j]);
+    apply_elem<J>(el, m, P);
   }
 }
 
@@ -2331,20 +2337,23 @@ EXO_HD void chunkp_vjp_lane(const double* EXO_RESTRICT t, Series rs, const doubl
 
 // (B'), part 1 by the EXACT RECURRENCES (round 4) -- what badj_prep_lane derives from a chunk's filtering element and the
 // state entering it, taken instead from the chunk's own reverse recurrences, for the draws whose conditioning the element
-// algebra cannot carry (tools/gp_host_lab.py: with the serial forward scan and THIS, every gradient of the random-kernel
-// tail is within 2e-7 of the sequential recurrences up to a score of 1e8; badj_prep_lane's local terms are accurate as
-// arithmetic but 1e7-fold sensitive to their inputs).  The reverse sweep of a chunk is affine in the adjoint it is entered
-// with:  with G_p = Phi_p (I - W_p U_p^T), the closed-loop transition of cadence p and the link behind it,
+// algebra cannot carry (tools/gp_host_lab.py, tools/gp_lab_robust.py: with the serial forward scan and THIS, every gradient
+// of the random-kernel tail is within 5e-7 of the long-double dense definition up to a score of 1e8; badj_prep_lane's local
+// terms are accurate as arithmetic but 1e7-fold sensitive to their inputs).  The reverse sweep of a chunk is affine in the
+// adjoint it is entered with:  with G_p = Phi_p (I - W_p U_p^T), the closed-loop transition of cadence p and the link behind it,
 //     Fbar_in = X Fbar_out + l_F,      Sbar_in = X Sbar_out X^T + sym(X Fbar_out r^T) + l_S,
 //     X = G_n0^T ... G_(n1-1)^T,       r = R_n0,   R_p = -(z_p / d_p) U_p + G_p^T R_(p+1),
 // and (l_F, l_S) is what the sweep leaves when entered with zero.  One sweep with the state adjoints only (RevP<STATE_ONLY>),
-// X and R riding along (X in a column outside the register file: `xacc`, J J doubles, stride `xs`), written over the
-// chunk's element exactly where badj_prep_lane writes (A <- X^T, b <- -r, eta <- l_F, Cm <- -l_S; P = Delta - S) so that
-// bscan_vjp_lane chains them unchanged.  c >= 1; reads the checkpoints of the forward pass.
+// the columns of X and R riding along, written over the chunk's element exactly where badj_prep_lane writes (A <- X^T,
+// b <- -r, eta <- l_F, Cm <- -l_S; P = Delta - S): the adjoint scan -- tree or chain -- takes them unchanged.  c >= 1; reads
+// the checkpoints of the forward pass.
+// `role`: the sweep of one (draw, chunk) on up to eight lanes -- all of them recompute the forward recurrences of a span (the
+// same instructions: no time), role 0 walks the state adjoints back, roles 1 .. J one column of X each, role J + 1 the vector
+// R; role < 0: everything on one lane (the host), X in the column `xacc` (J J doubles, stride `xs`).
 template <int J, int NR = -1>
 EXO_HD void chunk_adj_lane(const double* EXO_RESTRICT t, Series rs, const double* EXO_RESTRICT diag, int64_t n_diag, int64_t n,
                            const Coefs& cf, int64_t n_draw, const double* EXO_RESTRICT gloglike, double* EXO_RESTRICT state,
-                           const ChunkGeom& cg, int64_t draw, int c, double* xacc, int xs) {
+                           const ChunkGeom& cg, int64_t draw, int c, int role, double* xacc, int xs) {
   const int64_t n0 = c * cg.L, n1 = (n0 + cg.L < n) ? n0 + cg.L : n;
   const ChunkWs ws = chunk_ws(n, n_draw, J, cg);
   DrawCoef<J, NR> co;
@@ -2353,13 +2362,17 @@ EXO_HD void chunk_adj_lane(const double* EXO_RESTRICT t, Series rs, const double
   const SeriesRow y(rs, draw, n);
   const double* EXO_RESTRICT dg = diag + (n_diag == 1 ? 0 : draw * n);
   const double gL = gloglike[draw];
+  const bool do_state = role <= 0, all = role < 0, is_R = all || role == J + 1, do_vec = role != 0;
   RevP<J, NR, true> r;
-  double R[J];
+  double v[J];   // one column of X (roles 1 .. J), or R
 #pragma unroll
   for (int j = 0; j < J; ++j) {
-    r.Fb[j] = r.Wb[j] = r.flux[j] = R[j] = 0.0;
+    r.Fb[j] = r.Wb[j] = r.flux[j] = 0.0;
+    v[j] = (!is_R && role == j + 1) ? 1.0 : 0.0;
+    if (all) {
 #pragma unroll
-    for (int l = 0; l < J; ++l) xacc[(j * J + l) * xs] = (j == l) ? 1.0 : 0.0;
+      for (int l = 0; l < J; ++l) xacc[(j * J + l) * xs] = (j == l) ? 1.0 : 0.0;
+    }
   }
 #pragma unroll
   for (int k = 0; k < J * (J + 1) / 2; ++k) r.Sb.v[k] = 0.0;
@@ -2371,13 +2384,16 @@ EXO_HD void chunk_adj_lane(const double* EXO_RESTRICT t, Series rs, const double
   bool pend = n1 < n;
   constexpr int kK = J + J * (J + 1) / 2;
   constexpr int kSpan = ckpt_span(J), kSub = kCkptB / kSpan;
-  BlockIn cur;
+  constexpr bool kAheadBlk = J <= 4;   // (the next block's series in flight while this one is worked through: where the registers allow)
+  BlockIn cur, nxt;
   double ck[kK];
+  load_block(y, dg, n_diag, n0 + (nb - 1) * kCkptB, n1, cur);
+  nxt = cur;
 #pragma unroll 1
   for (int64_t bi = nb - 1; bi >= 0; --bi) {
     const int64_t b0 = n0 + bi * kCkptB;
     const int len = (int)((n1 - b0 < kCkptB) ? n1 - b0 : kCkptB);
-    load_block(y, dg, n_diag, b0, n1, cur);
+    if (kAheadBlk && bi > 0) load_block(y, dg, n_diag, b0 - kCkptB, n1, nxt);
 #pragma unroll
     for (int h = kSub - 1; h >= 0; --h) {
       const int q0 = h * kSpan;
@@ -2429,6 +2445,20 @@ EXO_HD void chunk_adj_lane(const double* EXO_RESTRICT t, Series rs, const double
             }
           }
         }
+        // W of a cadence from its saved state
+        auto w_of = [&](const Step<J>& s, double* U, double* W) {
+#pragma unroll
+          for (int j = 0; j < J; ++j) U[j] = 0.0;
+          co.u_from_v(s.V, U);
+          const double id = exo::fast_rcp(s.d);
+#pragma unroll
+          for (int j = 0; j < J; ++j) {
+            double uj = 0.0;
+#pragma unroll
+            for (int l = 0; l < J; ++l) uj = fma(s.S(j, l), U[l], uj);
+            W[j] = (s.V[j] - uj) * id;
+          }
+        };
 #pragma unroll
         for (int ql = kSpan - 1; ql >= 0; --ql) {
           if (ql < slen) {
@@ -2436,74 +2466,71 @@ EXO_HD void chunk_adj_lane(const double* EXO_RESTRICT t, Series rs, const double
             const int64_t i = b0 + q;
             double W[J], U[J];
             const bool link = (i + 1 < n);   // the link behind cadence i; its phi is the one the last co.step call left
+            w_of(st[ql], U, W);
             if (ql == slen - 1 && (q == len - 1 ? pend : true)) {
-#pragma unroll
-              for (int j = 0; j < J; ++j) U[j] = 0.0;
-              co.u_from_v(st[ql].V, U);
-              const double id = exo::fast_rcp(st[ql].d);
-#pragma unroll
-              for (int j = 0; j < J; ++j) {
-                double uj = 0.0;
-#pragma unroll
-                for (int l = 0; l < J; ++l) uj = fma(st[ql].S(j, l), U[l], uj);
-                W[j] = (st[ql].V[j] - uj) * id;
-              }
               const double dt = t[i + 1] - tt[ql];
               co.step(dt, phi, false);
-              r.propagate(st[ql], W, phi, dt);
+              if (do_state) r.propagate(st[ql], W, phi, dt);
             }
-            double zbar, dbar;
-            r.measure(co, st[ql], 0.0, gL, W, &zbar, &dbar, U);
-            // X <- G^T X,  R <- c U + G^T R   with  G^T v = Phi v - U (W . Phi v)
-            {
-              const double cz = -st[ql].z * exo::fast_rcp(st[ql].d);
-              double v[J], sdot = 0.0;
+            if (do_state) {
+              double zbar, dbar, Wm[J];
+              r.measure(co, st[ql], 0.0, gL, Wm, &zbar, &dbar);
+            }
+            if (do_vec) {
+              // X <- G^T X,  R <- c U + G^T R   with  G^T x = Phi x - U (W . Phi x)
+              const double cz = is_R ? -st[ql].z * exo::fast_rcp(st[ql].d) : 0.0;
+              double pv[J], sdot = 0.0;
 #pragma unroll
-              for (int j = 0; j < J; ++j) { v[j] = link ? phi[j] * R[j] : 0.0; sdot = fma(W[j], v[j], sdot); }
+              for (int j = 0; j < J; ++j) { pv[j] = link ? phi[j] * v[j] : (is_R ? 0.0 : v[j]); sdot = fma(W[j], pv[j], sdot); }
 #pragma unroll
-              for (int j = 0; j < J; ++j) R[j] = fma(cz - sdot, U[j], v[j]);
+              for (int j = 0; j < J; ++j) v[j] = fma(cz - sdot, U[j], pv[j]);
+              if (all) {
 #pragma unroll
-              for (int k = 0; k < J; ++k) {
-                sdot = 0.0;
+                for (int k = 0; k < J; ++k) {
+                  sdot = 0.0;
 #pragma unroll
-                for (int j = 0; j < J; ++j) { v[j] = (link ? phi[j] : 1.0) * xacc[(j * J + k) * xs]; sdot = fma(W[j], v[j], sdot); }
+                  for (int j = 0; j < J; ++j) { pv[j] = (link ? phi[j] : 1.0) * xacc[(j * J + k) * xs]; sdot = fma(W[j], pv[j], sdot); }
 #pragma unroll
-                for (int j = 0; j < J; ++j) xacc[(j * J + k) * xs] = fma(-sdot, U[j], v[j]);
+                  for (int j = 0; j < J; ++j) xacc[(j * J + k) * xs] = fma(-sdot, U[j], pv[j]);
+                }
               }
             }
             if (ql > 0) {
               double Wp[J];
-#pragma unroll
-              for (int j = 0; j < J; ++j) U[j] = 0.0;
-              co.u_from_v(st[ql - 1].V, U);
-              const double id = exo::fast_rcp(st[ql - 1].d);
-#pragma unroll
-              for (int j = 0; j < J; ++j) {
-                double uj = 0.0;
-#pragma unroll
-                for (int l = 0; l < J; ++l) uj = fma(st[ql - 1].S(j, l), U[l], uj);
-                Wp[j] = (st[ql - 1].V[j] - uj) * id;
-              }
+              w_of(st[ql - 1], U, Wp);
               const double dt = tt[ql] - tt[ql - 1];
               co.step(dt, phi, false);
-              r.propagate(st[ql - 1], Wp, phi, dt);
+              if (do_state) r.propagate(st[ql - 1], Wp, phi, dt);
             }
           }
         }
       }
     }
     pend = true;
+    if (kAheadBlk) cur = nxt;
+    else if (bi > 0) load_block(y, dg, n_diag, b0 - kCkptB, n1, cur);
   }
   const int oA = 0, ob = J * J, oC = J * J + J, oeta = 2 * J * J + J;
+  if (do_state) {
 #pragma unroll
-  for (int j = 0; j < J; ++j) {
-    state[ws.elem(c, ob + j, draw)] = -R[j];
-    state[ws.elem(c, oeta + j, draw)] = r.Fb[j];
+    for (int j = 0; j < J; ++j) {
+      state[ws.elem(c, oeta + j, draw)] = r.Fb[j];
 #pragma unroll
-    for (int l = 0; l < J; ++l) {
-      state[ws.elem(c, oA + j * J + l, draw)] = xacc[(l * J + j) * xs];   // Abar = X^T
-      state[ws.elem(c, oC + j * J + l, draw)] = -r.Sb(j, l);
+      for (int l = 0; l < J; ++l) state[ws.elem(c, oC + j * J + l, draw)] = -r.Sb(j, l);
     }
+  }
+  if (is_R) {
+#pragma unroll
+    for (int j = 0; j < J; ++j) state[ws.elem(c, ob + j, draw)] = -v[j];
+  } else if (do_vec) {   // column role - 1 of X is row role - 1 of Abar = X^T
+#pragma unroll
+    for (int l = 0; l < J; ++l) state[ws.elem(c, oA + (role - 1) * J + l, draw)] = v[l];
+  }
+  if (all) {
+#pragma unroll
+    for (int j = 0; j < J; ++j)
+#pragma unroll
+      for (int l = 0; l < J; ++l) state[ws.elem(c, oA + j * J + l, draw)] = xacc[(l * J + j) * xs];
   }
 }
 

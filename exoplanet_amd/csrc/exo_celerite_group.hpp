@@ -410,111 +410,183 @@ __device__ __forceinline__ void tree_item_group(const TreeOp& op, double* state,
   group_store_elem<J, ADJ>(state, op, c, draw, g, r, oA, ob, oC, oeta, oJ);
 }
 
-// ---- the ROBUST route (exo_celerite_core.hpp, chunk_adj_lane): the scans of ONE draw as serial chains on one group of eight
-// lanes -- C - 1 applications of an element to a state, each the DOWN item of the trees (the same arithmetic as bscan_lane /
-// bscan_vjp_lane), the next element's rows in flight while the current one is applied.  Composing elements is what loses the
-// digits of ill-conditioned draws; applying them one after the other does not.
-template <int J>
-__device__ __forceinline__ void chain_load_elem(const double* state, const ChunkWs& ws, int c, int64_t draw, const Grp<J>& g, int r,
-                                                ElemRow<J>& el, bool want_J) {
-  const int64_t nd = ws.n_draw;
-  const bool has = c >= 0 && c < ws.C;
-  const double* p = state + ws.elem(has ? c : 0, 0, draw);
-  const bool ld = has && g.live;
-#pragma unroll
-  for (int l = 0; l < J; ++l) {
-    el.A[l] = ld ? p[(int64_t)(r * J + l) * nd] : 0.0;
-    el.Cm[l] = ld ? p[(int64_t)(J * J + J + r * J + l) * nd] : 0.0;
-    el.Jm[l] = (ld && want_J) ? p[(int64_t)(2 * J * J + 2 * J + r * J + l) * nd] : 0.0;
-  }
-  el.b = ld ? p[(int64_t)(J * J + r) * nd] : 0.0;
-  el.eta = ld ? p[(int64_t)(2 * J * J + J + r) * nd] : 0.0;
+// ---- the ROBUST route (exo_celerite_core.hpp, chunk_adj_lane): the forward scan of ONE draw as a serial chain on one group of
+// eight lanes -- C - 1 applications of an element to a state (bscan_lane's arithmetic).  Composing elements is what loses the
+// digits of ill-conditioned draws (one level of composition is enough: tools/gp_host_lab.py, LAB_HYBRID_K); applying them one
+// after the other does not.  Nothing but latency, so the step is built around its exchanges: the element's own matrices are
+// staged in LDS a step AHEAD (two sets of slots), the pivot of a Gauss-Jordan step is found in registers (a DPP butterfly over
+// the eight lanes) and only the pivot's lane publishes its row, the solved rows are never brought into order (they are
+// written to LDS where they belong), and the symmetrisation is folded into the product that consumes the solution: seven
+// write -> read round trips a step (6 + 1) instead of eleven, no IEEE division.
+template <int CTRL>
+__device__ __forceinline__ int grp_dpp_int(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false); }
+template <int CTRL>
+__device__ __forceinline__ double grp_dpp(double v) {
+  return __hiloint2double(grp_dpp_int<CTRL>(__double2hiint(v)), grp_dpp_int<CTRL>(__double2loint(v)));
+}
+// (value, index) of the largest value over the aligned group of eight lanes; of equals the lowest index (solve_inplace's order)
+__device__ __forceinline__ int grp_argmax8(double a, int idx) {
+  auto take = [&](double pa, int pi) {
+    const bool t = (pa > a) | ((pa == a) & (pi < idx));   // (no short circuit: no branch)
+    a = t ? pa : a;
+    idx = t ? pi : idx;
+  };
+  take(grp_dpp<0xB1>(a), grp_dpp_int<0xB1>(idx));   // quad_perm [1, 0, 3, 2]
+  take(grp_dpp<0x4E>(a), grp_dpp_int<0x4E>(idx));   // quad_perm [2, 3, 0, 1]
+  // lane ^ 4: row_shr 4 for the upper quad, row_shl 4 for the lower.  BOTH moves by every lane, then the choice: a move
+  // inside a branch runs with the other quad switched off, and a DPP read of a switched-off lane returns nothing
+  const bool hi = (threadIdx.x & 4) != 0;
+  const double a_dn = grp_dpp<0x114>(a), a_up = grp_dpp<0x104>(a);
+  const int i_dn = grp_dpp_int<0x114>(idx), i_up = grp_dpp_int<0x104>(idx);
+  take(hi ? a_dn : a_up, hi ? i_dn : i_up);
+  return idx;
 }
 
-template <int J, bool ADJ>
-__device__ __forceinline__ void robust_scan_group(const ChunkWs& ws, double* state, int64_t draw, const Grp<J>& g) {
+template <int J>
+struct ChainLds {
+  static constexpr int RS = (J + 1) & ~1;
+  static constexpr int WS = (2 * J + 2) & ~1;                 // a Gauss-Jordan row [M | Y | ym]
+  // two sets of {Jm, A, eta} (this step's and the next one's), the solved rows [Y | ym], the pivot row
+  static constexpr int kSet = 2 * J * RS + 8;
+  static constexpr int raw = 2 * kSet + J * WS + WS;
+  static constexpr int S = ((raw - 4 + 31) / 32) * 32 + 4;    // strips of consecutive groups 8 banks apart (GroupLds)
+};
+
+// my row of element c: plain loads, no predicate (a lane past the state width reads row 0 and never shows what it computes;
+// every `cond ? load : constant` is a branch of its own, and the loads of a step -- there to be IN FLIGHT through the solve --
+// were waited for one branch after the other)
+template <int J>
+__device__ __forceinline__ void chain_load_elem(const double* state, const ChunkWs& ws, int c, int64_t draw, int r, ElemRow<J>& el) {
   const int64_t nd = ws.n_draw;
-  const int C = ws.C;
-  int r = g.live ? g.r : 0;
-  double m = 0.0, P[J];
+  const double* p = state + ws.elem(c < ws.C ? c : ws.C - 1, 0, draw);
 #pragma unroll
-  for (int l = 0; l < J; ++l) P[l] = 0.0;
-  if (!ADJ) {   // the state entering chunk 0 (the trees hand it down untouched)
-    m = g.live ? state[ws.bnd(1, 0, r, draw)] : 0.0;
-#pragma unroll
-    for (int l = 0; l < J; ++l) P[l] = g.live ? state[ws.bnd(1, 0, J + r * J + l, draw)] : 0.0;
-  } else if (g.live) {   // nothing enters the last chunk from behind
-    state[ws.bnd(2, C - 1, r, draw)] = 0.0;
-#pragma unroll
-    for (int l = 0; l < J; ++l) state[ws.bnd(2, C - 1, J + r * J + l, draw)] = 0.0;
+  for (int l = 0; l < J; ++l) {
+    el.A[l] = p[(int64_t)(r * J + l) * nd];
+    el.Cm[l] = p[(int64_t)(J * J + J + r * J + l) * nd];
+    el.Jm[l] = p[(int64_t)(2 * J * J + 2 * J + r * J + l) * nd];
   }
-  ElemRow<J> el, nx;
-  chain_load_elem<J>(state, ws, ADJ ? C - 1 : 0, draw, g, r, el, !ADJ);
-#pragma unroll 1
-  for (int s = 0; s + 1 < C; ++s) {
-    asm volatile("" : "+v"(r));   // (keeps the ~20 row offsets of the strided loads from being hoisted out of the loop)
-    const int c = ADJ ? C - 1 - s : s;          // the element applied in this step
-    chain_load_elem<J>(state, ws, ADJ ? c - 1 : c + 1, draw, g, r, nx, !ADJ);
-    double m2, P2[J];
-    if (ADJ) {
-      // x = Abar^T Fbar ;  Fbar' = lF + x ;  Pbar' = lP + Abar^T Pbar Abar + sym(x g^T)
-      g.put_rows(0, el.A);
-      g.put_vec(0, m);
-      g.put_vec(2, el.b);
-      g.sync();
-      const double x = g.tmv(0, 0);
-      double T[J];
-      g.mm(P, 0, T);
-      g.put_rows(1, T);
-      g.put_vec(1, x);
-      g.sync();
-      g.tmm(0, 1, P2);
-      double xa[J], ba[J];
-      g.get_vec(1, xa);
-      g.get_vec(2, ba);
-      m2 = el.eta + x;
+  el.b = p[(int64_t)(J * J + r) * nd];
+  el.eta = p[(int64_t)(2 * J * J + J + r) * nd];
+}
+
+template <int J>
+__device__ __forceinline__ void robust_fwd_chain_group(const ChunkWs& ws, double* state, int64_t draw, double* lds, int lane8) {
+  using L = ChainLds<J>;
+  const int C = ws.C;
+  const bool live = lane8 < J;
+  int r = live ? lane8 : 0;
+  // LDS operations of one wave execute in order: all that is needed between a lane's write and another lane's read is that the
+  // COMPILER keeps them in order.  (A wavefront-scope fence does that too -- and waits for every global load in flight,
+  // vmcnt(0): the next element's rows, prefetched for exactly that reason, were waited for at the first exchange of a step.)
+  auto sync = [] { asm volatile("" ::: "memory"); __builtin_amdgcn_wave_barrier(); };
+  auto set_J = [&](int q) { return lds + q * L::kSet; };
+  auto set_A = [&](int q) { return lds + q * L::kSet + J * L::RS; };
+  auto set_eta = [&](int q) { return lds + q * L::kSet + 2 * J * L::RS; };
+  double* rowsY = lds + 2 * L::kSet;          // [Y | ym], row k = unknown k
+  double* prow = rowsY + J * L::WS;           // the pivot's row of the current Gauss-Jordan step
+  auto stage = [&](int q, const ElemRow<J>& e) {
+    if (live) {
 #pragma unroll
-      for (int l = 0; l < J; ++l) P2[l] = el.Cm[l] + P2[l] + 0.5 * (x * ba[l] + el.b * xa[l]);
-    } else {
-      // X = I + P Jm ;  solve X [YP | ym] = [P | F + P eta] ;  F' = A ym + b ;  P' = A (YP) A^T + Cm
-      g.put_rows(0, el.Jm);
-      g.put_rows(2, el.A);
-      g.put_vec(0, el.eta);
-      g.sync();
-      double X[J], Bm[J + 1];
-      g.mm(P, 0, X);
-#pragma unroll
-      for (int l = 0; l < J; ++l) X[l] = g.live ? X[l] + (l == r ? 1.0 : 0.0) : 0.0;
-#pragma unroll
-      for (int l = 0; l < J; ++l) Bm[l] = P[l];
-      Bm[J] = m + g.mv(P, 0);
-      g.template solve<J + 1>(X, Bm);
-      double YP[J];
-#pragma unroll
-      for (int l = 0; l < J; ++l) YP[l] = Bm[l];
-      g.put_rows(1, YP);
-      g.put_vec(1, Bm[J]);
-      g.sync();
-      double AY[J];
-      g.mm(el.A, 1, AY);
-      m2 = el.b + g.mv(el.A, 1);
-      g.mm_t(AY, 2, P2);
-#pragma unroll
-      for (int l = 0; l < J; ++l) P2[l] += el.Cm[l];
+      for (int l = 0; l < J; ++l) { set_J(q)[r * L::RS + l] = e.Jm[l]; set_A(q)[r * L::RS + l] = e.A[l]; }
+      set_eta(q)[r] = e.eta;
     }
-    g.put_rows(3, P2);
-    g.sync();
-    g.sym_from(3, P2);
-    g.sync();      // (the next step's rows go where this one's were read)
+  };
+  // the state entering chunk 0 (the trees hand it down untouched)
+  double m = state[ws.bnd(1, 0, r, draw)], P[J];
+#pragma unroll
+  for (int l = 0; l < J; ++l) P[l] = state[ws.bnd(1, 0, J + r * J + l, draw)];
+  ElemRow<J> el, nx;
+  chain_load_elem<J>(state, ws, 0, draw, r, el);
+  stage(0, el);
+  sync();
+#pragma unroll 1
+  for (int c = 0; c + 1 < C; ++c) {
+    asm volatile("" : "+v"(r));   // (keeps the ~20 row offsets of the strided loads from being hoisted out of the loop)
+    const int q = c & 1;
+    chain_load_elem<J>(state, ws, c + 1, draw, r, nx);
+    // X = I + P Jm ;  right-hand sides [P | m + P eta]
+    double M[J], R[J + 1];
+    {
+      const double* Jm = set_J(q);
+#pragma unroll
+      for (int l = 0; l < J; ++l) M[l] = (live && l == r) ? 1.0 : 0.0;
+#pragma unroll
+      for (int k = 0; k < J; ++k)
+#pragma unroll
+        for (int l = 0; l < J; ++l) M[l] = fma(P[k], Jm[k * L::RS + l], M[l]);
+      const double* eta = set_eta(q);
+      double pe = m;
+#pragma unroll
+      for (int k = 0; k < J; ++k) pe = fma(P[k], eta[k], pe);
+#pragma unroll
+      for (int l = 0; l < J; ++l) R[l] = P[l];
+      R[J] = pe;
+    }
+    // Gauss-Jordan with partial pivoting, rows left where they are: `mine` = the unknown this lane's row ends up solving
+    int mine = -1;
+#pragma unroll
+    for (int k = 0; k < J; ++k) {
+      const double a = (live && mine < 0) ? fabs(M[k]) : -1.0;
+      const int piv = grp_argmax8(a == a ? a : -0.5, lane8);
+      const bool is_piv = lane8 == piv;
+      mine = is_piv ? k : mine;
+      sync();            // (the previous step's readers are done with `prow`)
+      if (is_piv) {
+#pragma unroll
+        for (int l = k; l < J; ++l) prow[l] = M[l];
+#pragma unroll
+        for (int l = 0; l <= J; ++l) prow[J + l] = R[l];
+      }
+      sync();
+      const double ip = exo::fast_rcp(prow[k]);
+      const double f = is_piv ? 0.0 : M[k];
+#pragma unroll
+      for (int l = k; l < J; ++l) {
+        const double pv = prow[l] * ip;
+        M[l] = is_piv ? pv : fma(-f, pv, M[l]);
+      }
+#pragma unroll
+      for (int l = 0; l <= J; ++l) {
+        const double pv = prow[J + l] * ip;
+        R[l] = is_piv ? pv : fma(-f, pv, R[l]);
+      }
+    }
+    // the solved rows where they belong: row `mine` of [Y | ym]
+    if (live) {
+      double* p = rowsY + (mine < 0 ? r : mine) * L::WS;
+#pragma unroll
+      for (int l = 0; l <= J; ++l) p[l] = R[l];
+    }
+    // the NEXT step's element into the other set of slots (its loads have been in flight through the solve)
+    stage(q ^ 1, nx);
+    sync();
+    // F' = A ym + b ;  P' = A sym(Y) A^T + Cm
+    double AY[J], m2 = el.b, P2[J];
+#pragma unroll
+    for (int l = 0; l < J; ++l) AY[l] = 0.0;
+#pragma unroll
+    for (int k = 0; k < J; ++k) {
+      m2 = fma(el.A[k], rowsY[k * L::WS + J], m2);
+#pragma unroll
+      for (int l = 0; l < J; ++l) AY[l] = fma(el.A[k], 0.5 * (rowsY[k * L::WS + l] + rowsY[l * L::WS + k]), AY[l]);
+    }
+    {
+      const double* A = set_A(q);
+#pragma unroll
+      for (int l = 0; l < J; ++l) {
+        double v = el.Cm[l];
+#pragma unroll
+        for (int k = 0; k < J; ++k) v = fma(AY[k], A[l * L::RS + k], v);
+        P2[l] = v;
+      }
+    }
     m = m2;
 #pragma unroll
     for (int l = 0; l < J; ++l) P[l] = P2[l];
-    if (g.live) {
-      // forward: the state entering chunk c + 1;  adjoint: what chunk c - 1's reverse recurrences start from (Sbar = -Pbar)
-      const int q = ADJ ? 2 : 1, at = ADJ ? c - 1 : c + 1;
-      state[ws.bnd(q, at, r, draw)] = m;
+    if (live) {   // the state entering chunk c + 1
+      state[ws.bnd(1, c + 1, r, draw)] = m;
 #pragma unroll
-      for (int l = 0; l < J; ++l) state[ws.bnd(q, at, J + r * J + l, draw)] = ADJ ? -P[l] : P[l];
+      for (int l = 0; l < J; ++l) state[ws.bnd(1, c + 1, J + r * J + l, draw)] = P[l];
     }
     el = nx;
   }

@@ -2,7 +2,8 @@
 """Round-4 fixture (TEST INFRASTRUCTURE; see oracle/__init__.py): the celerite log-likelihood and its gradient for RANDOM
 kernels of the kind tools/gp_cond_bins.py scans -- J = 2 .. 6 state indices, decay and oscillation rates from 1e-3 to 30 per
 sample within one kernel, a gap, irregular sampling -- at conditioning scores kappa = (1 + max (b/a)^2) sum(a) / min(diag)
-chosen across the range the time-parallel path keeps (1e3 .. 3e6 for J = 2; 1e3, 2e4 for wider states) and just above it (7e4), from the dense definition in
+chosen across the range the time-parallel path keeps (1e3 .. 3e6 for J = 2; 1e3, 2e4 for wider states), just above it (7e4) and
+across the range of its robust route (1e6 .. 5e7), from the dense definition in
 x87 long double (oracle/make_golden_r02.gp_dense_ld, pinned to mpmath there).  N = 400 cadences each.
 
 What the fixture is for: the gradient with respect to the oscillation rate d of a
@@ -59,6 +60,9 @@ def main():
     # device redoes them with the sequential kernels, the host-compiled lane pipeline is run on them all the same)
     plan = [(0, 1, k) for k in (1e3, 1e5, 3e6, 3e6)] + [(1, 1, k) for k in (1e3, 2e4)] + [(0, 2, k) for k in (1e3, 2e4, 7e4)] \
         + [(1, 2, k) for k in (1e3, 2e4)] + [(2, 2, k) for k in (1e3, 2e4, 7e4)] + [(0, 3, k) for k in (1e3, 2e4, 7e4)]
+    # (round 4, later: the ROBUST route of the time-parallel path takes draws up to a score of 1e8 -- exo_celerite_core.hpp,
+    # chunk_adj_lane; appended, so that the cases above keep their random numbers)
+    plan += [(0, 1, 5e7)] + [(0, 2, k) for k in (1e6, 1e7, 5e7)] + [(2, 2, k) for k in (1e6, 5e7)] + [(0, 3, k) for k in (1e6, 1e7, 5e7)]
     for i, (n_real, n_cplx, kappa) in enumerate(plan):
         t, y, diag, cr, cc = draw_case(rng, n_real, n_cplx, kappa)
         co = (cr[:, 0], cr[:, 1], cc[:, 0], cc[:, 1], cc[:, 2], cc[:, 3])

@@ -16,6 +16,9 @@ namespace {
 
 int g_serial_scan = 0;   // 1: the serial reference scans (bscan_lane, bscan_vjp_lane) instead of the trees
 int g_robust_flags = 1;  // draws the element lanes flag kFlagRobust take the robust route (as on the device)
+int g_adj_roles = 0;     // 1: chunk_adj_lane role by role, as the device's eight lanes run it
+int g_adj_tree = 0;      // experiment (with g_robust): chunk_adj_lane's outputs scanned by the adjoint TREE instead of the serial chain
+int g_hybrid_k = -1;     // experiment (with g_robust): forward scan = k levels of composition, a serial chain at level k, k levels down
 int g_robust = 0;        // 1: serial forward scan + the adjoint scan's inputs from the chunks' own recurrences (chunk_adj_lane)
 int g_polish = 0;        // 1: a polish pass over every draw after the chunk recurrences (forward and reverse), as the
                          //    device runs it for the draws whose conditioning asks for it
@@ -46,6 +49,42 @@ void run_fwd(const double* t, gp::Series rs, const double* diag, int64_t n_diag,
                   [&]() {
                     for (int64_t d = 0; d < n_draw; ++d) gp::scan_init_lane<J>(t, cf, n_draw, state + ws.tree_state(ws.tree_top()), d);
                   });
+  } else if (g_robust && g_hybrid_k >= 0 && cg.tree) {
+    const int top = ws.tree_top();
+    const int k = g_hybrid_k < top ? g_hybrid_k : top - 1;
+    for (int64_t d = 0; d < n_draw; ++d) {
+      for (int f = 0; f < k; ++f) {
+        const gp::TreeOp op = gp::scan_level_op(ws, J, false, f, false);
+        for (int c = 0; c < op.n_item; ++c) gp::tree_item_lane<J, false, false>(op, state, c, d);
+      }
+      // the chain at level k: position p + 1's state from position p's and element p of that level
+      gp::TreeOp op{};
+      op.J = J; op.n_draw = n_draw;
+      op.src_elem = k == 0 ? ws.elem(0, 0, 0) : ws.tree_elem(k);
+      op.src_n = k == 0 ? ws.C - 1 : ws.tree_npos(k);
+      op.src_len = ws.tree_npos(k);
+      const int64_t base = k == 0 ? ws.bnd(1, 0, 0, 0) : ws.tree_state(k);
+      const int Bq = J + J * J;
+      gp::scan_init_lane<J>(t, cf, n_draw, state + base, d);
+      double m[J], P[J][J];
+      for (int j = 0; j < J; ++j) {
+        m[j] = state[base + (int64_t)j * n_draw + d];
+        for (int l = 0; l < J; ++l) P[j][l] = state[base + (int64_t)(J + j * J + l) * n_draw + d];
+      }
+      for (int pos = 0; pos + 1 < ws.tree_npos(k); ++pos) {
+        gp::Elem<J> el;
+        gp::tree_load_elem<J>(state, op, pos, d, el);
+        gp::apply_elem<J>(el, m, P);
+        for (int j = 0; j < J; ++j) {
+          state[base + ((int64_t)(pos + 1) * Bq + j) * n_draw + d] = m[j];
+          for (int l = 0; l < J; ++l) state[base + ((int64_t)(pos + 1) * Bq + J + j * J + l) * n_draw + d] = P[j][l];
+        }
+      }
+      for (int f = k - 1; f >= 0; --f) {
+        const gp::TreeOp dn = gp::scan_level_op(ws, J, false, f, true);
+        for (int c = 0; c < dn.n_item; ++c) gp::tree_item_lane<J, false, true>(dn, state, c, d);
+      }
+    }
   } else {
     for (int64_t d = 0; d < n_draw; ++d) gp::bscan_lane<J>(t, cf, n, n_draw, state, cg, d);
   }
@@ -88,18 +127,28 @@ void run_vjp(const double* t, gp::Series rs, const double* diag, int64_t n_diag,
              int64_t n_draw, const double* gloglike, double* state, const gp::ChunkGeom& cg, double* gresid,
              double* gdiag, double gsign, double* gdiag_sum, double* gcr, double* gcc) {
   const gp::ChunkWs ws = gp::chunk_ws(n, n_draw, J, cg);
+  // (B') part 1: from the element (badj_prep_lane), or -- draws flagged kFlagRobust, as on the device; every draw with
+  // g_robust -- from the chunk's own reverse recurrences (chunk_adj_lane: the device's eight lanes role by role with g_adj_roles)
+  auto robust_draw = [&](int64_t d) {
+    return g_robust || (cg.tree && !g_serial_scan && g_robust_flags && state[ws.off_flag() + d] == gp::kFlagRobust);
+  };
   for (int c = 1; c < cg.C; ++c)
     for (int64_t d = 0; d < n_draw; ++d) {
-      if (g_robust) {
+      if (robust_draw(d)) {
         gp::with_layout<J>(cf, d, [&](auto nr) {
           double x[J * J];
-          gp::chunk_adj_lane<J, decltype(nr)::value>(t, rs, diag, n_diag, n, cf, n_draw, gloglike, state, cg, d, c, x, 1);
+          if (g_adj_roles) {
+            for (int role = 0; role <= J + 1; ++role)
+              gp::chunk_adj_lane<J, decltype(nr)::value>(t, rs, diag, n_diag, n, cf, n_draw, gloglike, state, cg, d, c, role, nullptr, 0);
+          } else {
+            gp::chunk_adj_lane<J, decltype(nr)::value>(t, rs, diag, n_diag, n, cf, n_draw, gloglike, state, cg, d, c, -1, x, 1);
+          }
         });
       } else {
         gp::badj_prep_lane<J>(gloglike, n, n_draw, state, cg, d, c);
       }
     }
-  if (cg.tree && !g_serial_scan && !g_robust) {
+  if (cg.tree && !g_serial_scan && (!g_robust || g_adj_tree)) {   // (the adjoint tree takes the robust draws' inputs as they are)
     gp::tree_scan(ws, cg, J, n_draw, true,
                   [&](const gp::TreeOp& op, bool down) {
                     for (int c = 0; c < op.n_item; ++c)
@@ -115,16 +164,6 @@ void run_vjp(const double* t, gp::Series rs, const double* diag, int64_t n_diag,
   } else {
     for (int64_t d = 0; d < n_draw; ++d) gp::bscan_vjp_lane<J>(n, n_draw, state, cg, d);
   }
-  if (cg.tree && !g_serial_scan && !g_robust && g_robust_flags)
-    for (int64_t d = 0; d < n_draw; ++d)
-      if (state[ws.off_flag() + d] == gp::kFlagRobust) {
-        for (int c = 1; c < cg.C; ++c)
-          gp::with_layout<J>(cf, d, [&](auto nr) {
-            double x[J * J];
-            gp::chunk_adj_lane<J, decltype(nr)::value>(t, rs, diag, n_diag, n, cf, n_draw, gloglike, state, cg, d, c, x, 1);
-          });
-        gp::bscan_vjp_lane<J>(n, n_draw, state, cg, d);
-      }
   const bool seq_adj = g_polish < 0 && ((-g_polish) & 2);   // experiment: exact adjoint boundary states (chunks last to first)
   for (int pass = 0; pass <= (g_polish > 0 ? g_polish : 0); ++pass)
   for (int cc = 0; cc < cg.C; ++cc) {
@@ -161,6 +200,9 @@ extern "C" {
 void harness_set_serial_scan(int v) { g_serial_scan = v; }
 void harness_set_polish(int v) { g_polish = v; }
 void harness_set_robust(int v) { g_robust = v; }
+void harness_set_adj_tree(int v) { g_adj_tree = v; }
+void harness_set_adj_roles(int v) { g_adj_roles = v; }
+void harness_set_hybrid_k(int v) { g_hybrid_k = v; }
 void harness_set_robust_flags(int v) { g_robust_flags = v; }
 // (experiments: where the checkpoints -- the states (F, packed S) entering every ckpt_span(J)-th cadence -- live in `state`)
 // (experiments: where the filtering elements [chunk][A, b, C, eta, J][draw] live in `state`)

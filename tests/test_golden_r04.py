@@ -54,9 +54,35 @@ def test_gp_tail_host_compiled_lane_pipeline(harness, key, origin):  # noqa: F81
     ll, flags, C_used, gr = run(harness, t + origin, y[None], diag[None], real, cplx, gll=np.ones(1))
     J = real.shape[1] + 2 * cplx.shape[1]
     kept = float(G[f"{key}_kappa"]) <= (1e7 if J <= 2 else 3e4)        # (exo_celerite_core.hpp: EXO_GP_COND_MAX_J2, EXO_GP_COND_MAX)
-    assert flags[0] == (0 if kept else 1) and C_used >= 8              # (a flagged draw: the lanes are run all the same)
+    # above the thresholds and up to a score of 1e8 (EXO_GP_COND_ROBUST_MAX): kFlagRobust -- the serial scans and the adjoint
+    # inputs from the chunks' own recurrences, still on the lanes
+    assert flags[0] == (0 if kept else 1) and C_used >= 8
     assert abs(ll[0] - want) <= 1e-9 * abs(want)
     got = {"y": gr["y"][0], "diag": gr["diag"][0], "ar": gr["real"][0, :, 0], "cr": gr["real"][0, :, 1]}
     got.update({nm: gr["cplx"][0, :, q] for q, nm in enumerate(("ac", "bc", "cc", "dc"))})
     assert np.array_equal((t + origin) - origin, t)       # (the fixture's stamps sit on a 2^-20 d grid: the shift is exact)
     assert worst(got, key) <= 1e-6, worst(got, key)
+
+
+def test_robust_route_is_what_holds_the_ill_conditioned_draws(harness):  # noqa: F811
+    """two J = 6 kernels at scores of 5e7 and 1e7: with the trees of element compositions (robust routing switched off) their
+    gradients are off by 3e-5 and 2e-6; with the serial scans and the adjoint inputs from the chunks' own recurrences
+    (chunk_adj_lane) they are within 1e-8 of the long-double definition"""
+    res = {}
+    for on in (0, 1):
+        harness.harness_set_robust_flags(on)
+        try:
+            for key in ("c22", "c24"):
+                t, y, diag, co, want = case(key)
+                ar, cr, ac, bc, cc, dc = co
+                real = np.stack([ar, cr], -1)[None]
+                cplx = np.stack([ac, bc, cc, dc], -1)[None]
+                ll, flags, C_used, gr = run(harness, t, y[None], diag[None], real, cplx, gll=np.ones(1))
+                assert flags[0] == 1 and (not on or abs(ll[0] - want) <= 1e-9 * abs(want))
+                got = {"y": gr["y"][0], "diag": gr["diag"][0], "ar": gr["real"][0, :, 0], "cr": gr["real"][0, :, 1]}
+                got.update({nm: gr["cplx"][0, :, q] for q, nm in enumerate(("ac", "bc", "cc", "dc"))})
+                res[on, key] = worst(got, key)
+        finally:
+            harness.harness_set_robust_flags(1)
+    assert res[0, "c22"] > 1e-6 and res[0, "c24"] > 1e-6, res
+    assert res[1, "c22"] <= 1e-8 and res[1, "c24"] <= 1e-8, res

@@ -214,7 +214,7 @@ def test_gp_tail_golden(dev, key, origin):
     scores 1e3 .. 3e6, decay / oscillation rates 1e-3 .. 30 per sample, gaps) on the TIME-PARALLEL path and on the
     sequential kernels, at the series' own time stamps and 2 457 000 days away from them (the stamps sit on a 2^-20 d grid:
     the shift is exact) -- log-likelihood to 1e-9, EVERY gradient to the stated 1e-6 against the long-double dense
-    definition, no draw flagged.  What used to fail: d loglike / d(oscillation rate) across chunk boundaries
+    definition, no draw handed to the sequential kernels.  What used to fail: d loglike / d(oscillation rate) across chunk boundaries
     (exo_celerite_core.hpp, phase_flux) and cos(d t) at BJD-sized t (Coefs::origin)"""
     from exoplanet_amd.gp import celerite_loglike
 
@@ -224,10 +224,12 @@ def test_gp_tail_golden(dev, key, origin):
     want = float(g[f"{key}_loglike"])
     t = g[f"{key}_t"] + origin
     assert np.array_equal(t - origin, g[f"{key}_t"])
+    lls = []
     for n_chunks in (None, 1):
         yt, dt = T(g[f"{key}_y"][None], dev).requires_grad_(True), T(g[f"{key}_diag"][None], dev).requires_grad_(True)
         rt, ct = T(real, dev).requires_grad_(True), T(cplx, dev).requires_grad_(True)
         ll = celerite_loglike(T(t, dev), yt, dt, rt, ct, n_chunks=n_chunks)
+        lls.append(ll.item())
         assert abs(ll.item() - want) <= 1e-9 * abs(want), (n_chunks, ll.item(), want)
         ll.sum().backward()
         worst = 0.0
@@ -237,6 +239,9 @@ def test_gp_tail_golden(dev, key, origin):
             if w.size:
                 worst = max(worst, float(np.abs(got.cpu().numpy() - w).max() / np.abs(w).max()))
         assert worst <= 1e-6, (n_chunks, worst)
+    # scores up to 1e8 (the fixture's reach 5e7) stay on the time-parallel path -- above the thresholds of its trees on the
+    # ROBUST route (chunk_adj_lane) --: two algorithms, not the sequential kernels' bits twice
+    assert lls[0] != lls[1]
 
 
 def test_random_kernels_time_parallel_vs_sequential_kernels(dev):

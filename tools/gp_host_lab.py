@@ -60,6 +60,8 @@ def main():
     lib.harness_set_serial_scan(int(os.environ.get("LAB_SERIAL", "0")))
     lib.harness_set_polish(int(os.environ.get("LAB_POLISH", "0")))
     lib.harness_set_robust(int(os.environ.get("LAB_ROBUST", "0")))
+    lib.harness_set_adj_tree(int(os.environ.get("LAB_ADJ_TREE", "0")))
+    lib.harness_set_hybrid_k(int(os.environ.get("LAB_HYBRID_K", "-1")))
     rows = []
     for t, y, diag, cr, cc, dtm in cases(seed, n_cases):
         D = y.shape[0]
