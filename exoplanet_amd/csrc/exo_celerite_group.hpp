@@ -424,22 +424,23 @@ template <int CTRL>
 __device__ __forceinline__ double grp_dpp(double v) {
   return __hiloint2double(grp_dpp_int<CTRL>(__double2hiint(v)), grp_dpp_int<CTRL>(__double2loint(v)));
 }
-// (value, index) of the largest value over the aligned group of eight lanes; of equals the lowest index (solve_inplace's order)
-__device__ __forceinline__ int grp_argmax8(double a, int idx) {
-  auto take = [&](double pa, int pi) {
-    const bool t = (pa > a) | ((pa == a) & (pi < idx));   // (no short circuit: no branch)
-    a = t ? pa : a;
-    idx = t ? pi : idx;
+// the lane (0 .. 7) holding the largest a >= 0 of the aligned group of eight lanes; of (nearly) equal values the lowest lane.
+// One 64-bit key per lane -- the bits of a non-negative double order like the number; its three lowest bits give way to
+// 7 - lane -- and a butterfly of maxima: quad_perm [1,0,3,2], [2,3,0,1], then lane ^ 4 (row_shr / row_shl by 4; BOTH moves by
+// every lane, then the choice: inside a branch the other quad is switched off, and a DPP read of a switched-off lane returns
+// nothing).  a < 0 (a row already used, a lane past the state width): never chosen.
+__device__ __forceinline__ int grp_argmax8(double a, int lane8) {
+  unsigned long long key = (a >= 0.0) ? (((unsigned long long)__double_as_longlong(a) & ~7ull) | (unsigned)(7 - lane8)) + 8ull : 0ull;
+  auto mx = [&](unsigned long long o) { key = o > key ? o : key; };
+  auto mv = [](auto tag, unsigned long long k) {
+    constexpr int CTRL = decltype(tag)::value;
+    return ((unsigned long long)(unsigned)grp_dpp_int<CTRL>((int)(k >> 32)) << 32) | (unsigned)grp_dpp_int<CTRL>((int)k);
   };
-  take(grp_dpp<0xB1>(a), grp_dpp_int<0xB1>(idx));   // quad_perm [1, 0, 3, 2]
-  take(grp_dpp<0x4E>(a), grp_dpp_int<0x4E>(idx));   // quad_perm [2, 3, 0, 1]
-  // lane ^ 4: row_shr 4 for the upper quad, row_shl 4 for the lower.  BOTH moves by every lane, then the choice: a move
-  // inside a branch runs with the other quad switched off, and a DPP read of a switched-off lane returns nothing
-  const bool hi = (threadIdx.x & 4) != 0;
-  const double a_dn = grp_dpp<0x114>(a), a_up = grp_dpp<0x104>(a);
-  const int i_dn = grp_dpp_int<0x114>(idx), i_up = grp_dpp_int<0x104>(idx);
-  take(hi ? a_dn : a_up, hi ? i_dn : i_up);
-  return idx;
+  mx(mv(std::integral_constant<int, 0xB1>{}, key));
+  mx(mv(std::integral_constant<int, 0x4E>{}, key));
+  const unsigned long long dn = mv(std::integral_constant<int, 0x114>{}, key), up = mv(std::integral_constant<int, 0x104>{}, key);
+  mx((threadIdx.x & 4) ? dn : up);
+  return 7 - (int)(key & 7ull);
 }
 
 template <int J>
@@ -501,7 +502,6 @@ __device__ __forceinline__ void robust_fwd_chain_group(const ChunkWs& ws, double
   sync();
 #pragma unroll 1
   for (int c = 0; c + 1 < C; ++c) {
-    asm volatile("" : "+v"(r));   // (keeps the ~20 row offsets of the strided loads from being hoisted out of the loop)
     const int q = c & 1;
     chain_load_elem<J>(state, ws, c + 1, draw, r, nx);
     // X = I + P Jm ;  right-hand sides [P | m + P eta]
@@ -527,7 +527,7 @@ __device__ __forceinline__ void robust_fwd_chain_group(const ChunkWs& ws, double
 #pragma unroll
     for (int k = 0; k < J; ++k) {
       const double a = (live && mine < 0) ? fabs(M[k]) : -1.0;
-      const int piv = grp_argmax8(a == a ? a : -0.5, lane8);
+      const int piv = grp_argmax8(a, lane8);   // (a NaN compares false with >= 0: never chosen unless nothing is)
       const bool is_piv = lane8 == piv;
       mine = is_piv ? k : mine;
       sync();            // (the previous step's readers are done with `prow`)
@@ -539,17 +539,13 @@ __device__ __forceinline__ void robust_fwd_chain_group(const ChunkWs& ws, double
       }
       sync();
       const double ip = exo::fast_rcp(prow[k]);
-      const double f = is_piv ? 0.0 : M[k];
+      // every row loses f x the scaled pivot row; the pivot's own row BECOMES it: keep = 0, f = -1 (two exact products
+      // instead of a select per entry)
+      const double f = is_piv ? -1.0 : M[k], keep = is_piv ? 0.0 : 1.0;
 #pragma unroll
-      for (int l = k; l < J; ++l) {
-        const double pv = prow[l] * ip;
-        M[l] = is_piv ? pv : fma(-f, pv, M[l]);
-      }
+      for (int l = k; l < J; ++l) M[l] = fma(-f, prow[l] * ip, keep * M[l]);
 #pragma unroll
-      for (int l = 0; l <= J; ++l) {
-        const double pv = prow[J + l] * ip;
-        R[l] = is_piv ? pv : fma(-f, pv, R[l]);
-      }
+      for (int l = 0; l <= J; ++l) R[l] = fma(-f, prow[J + l] * ip, keep * R[l]);
     }
     // the solved rows where they belong: row `mine` of [Y | ym]
     if (live) {
