@@ -1392,26 +1392,36 @@ __global__ __launch_bounds__(kWave) void celerite_robust_scan_kernel(const doubl
 
 // (B') part 1 for those draws: the adjoint scan's inputs from the chunks' own reverse recurrences (chunk_adj_lane), written
 // over the chunk's element where badj_prep_lane wrote its own -- launched between that kernel and the adjoint trees, which take
-// them as they are.  A (draw, chunk >= 1) on EIGHT lanes (chunk_adj_lane's roles: the state adjoints, the J columns of X, R):
-// a block is eight consecutive chunks of the robust draws among 64 consecutive ones -- none, almost always: it leaves at once.
+// them as they are.  A WAVE per (draw, chunk >= 1): the chunk's reverse sweep in eight pieces, a piece on a group of eight
+// lanes (chunk_adj_lane's roles: the state adjoints, the J columns of X, R), the pieces' records multiplied back together
+// through LDS (adj_combine_lane).  Nothing but latency -- 1.2 ms for a 127-cadence chunk on one lane at J = 6, 0.7 ms on eight
+// lanes by roles, ~0.1 ms in eight pieces.  A block looks at 64 consecutive draws and, almost always, leaves at once.
 template <int J>
 __global__ __launch_bounds__(kWave) void celerite_chunk_adj_kernel(const double* __restrict__ t, Series rs,
                                                                    const double* __restrict__ diag, int64_t n_diag, int64_t n,
                                                                    Coefs cf, int64_t n_draw, const double* __restrict__ gloglike,
                                                                    double* __restrict__ state, ChunkGeom cg) {
   static_assert(J + 2 <= 8, "roles 0 .. J + 1 on the eight lanes of a group");
+  constexpr int kRec = adj_record_doubles<J>(), kPieces = kWave / 8;
+  __shared__ double rec[kPieces * kRec];
   const ChunkWs ws = chunk_ws(n, n_draw, J, cg);
   const int64_t d0 = (int64_t)blockIdx.y * kWave, dl = d0 + threadIdx.x;
   unsigned long long todo = __ballot(dl < n_draw && state[ws.off_flag() + (dl < n_draw ? dl : 0)] == kFlagRobust);
-  const int c = 1 + (int)blockIdx.x * 8 + (int)(threadIdx.x >> 3), role = (int)(threadIdx.x & 7);
+  const int c = 1 + (int)blockIdx.x, piece = (int)(threadIdx.x >> 3), role = (int)(threadIdx.x & 7);
   while (todo) {
     const int64_t draw = d0 + (__ffsll((long long)todo) - 1);
     todo &= todo - 1;
     // (every lane has the same draw: the "vote" is that draw's layout -- the compile-time ones cost a quarter fewer instructions)
-    if (c < cg.C && role <= J + 1)
+    if (role <= J + 1)
       with_layout<J>(cf, draw, [&](auto nr) {
-        chunk_adj_lane<J, decltype(nr)::value>(t, rs, diag, n_diag, n, cf, n_draw, gloglike, state, cg, draw, c, role, nullptr, 0);
+        chunk_adj_lane<J, decltype(nr)::value, false>(t, rs, diag, n_diag, n, cf, n_draw, gloglike, state, cg, draw, c, role, piece,
+                                                      kPieces, rec + piece * kRec, 1);
       });
+    asm volatile("" ::: "memory");   // (one wave: its LDS operations execute in order; the compiler must keep them so)
+    __builtin_amdgcn_wave_barrier();
+    if (threadIdx.x == 0) adj_combine_lane<J>(rec, kRec, 1, kPieces, n, n_draw, state, cg, draw, c);
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
@@ -1786,7 +1796,7 @@ static int celerite_vjp(const double* t, Series resid, const double* diag, int64
                                           0, st, gloglike, n, n_draw, wstate, cg))
     if (cg.lane) {
       // draws flagged kFlagRobust: those inputs once more, from the chunks' own reverse recurrences (chunk_adj_lane)
-      EXO_GP_DISPATCH_LANE(J, hipLaunchKernelGGL((celerite_chunk_adj_kernel<JJ>), dim3((unsigned)((cg.C - 1 + 7) / 8), per_draw.x), block, 0,
+      EXO_GP_DISPATCH_LANE(J, hipLaunchKernelGGL((celerite_chunk_adj_kernel<JJ>), dim3((unsigned)(cg.C - 1), per_draw.x), block, 0,
                                                  st, t, resid, diag, n_diag, n, cf, n_draw, gloglike, wstate, cg))
     }
     if (EXO_GP_FUSED_SCAN) {

@@ -2349,11 +2349,18 @@ EXO_HD void chunkp_vjp_lane(const double* EXO_RESTRICT t, Series rs, const doubl
 // the checkpoints of the forward pass.
 // `role`: the sweep of one (draw, chunk) on up to eight lanes -- all of them recompute the forward recurrences of a span (the
 // same instructions: no time), role 0 walks the state adjoints back, roles 1 .. J one column of X each, role J + 1 the vector
-// R; role < 0: everything on one lane (the host), X in the column `xacc` (J J doubles, stride `xs`).
-template <int J, int NR = -1>
+// R; ALL (the host): everything on one lane.
+// `piece` of `n_pieces`: a reverse sweep is nothing but latency (a wave64 instruction every four cycles whatever the number of
+// lanes at work), and its affine map is a product of the maps of PIECES of the chunk, each swept on its own from a zero
+// adjoint: a chunk's checkpoint blocks are dealt to n_pieces sweeps (one group of eight lanes each on the device) and
+// adj_combine_lane multiplies them back together -- X = X_0 X_1 ..., the plain products of the adjoint scan.  Piece records
+// go to `out` (stride `os`): X row-major, r, l_F, l_S (J J + 2 J + J J doubles).
+template <int J>
+constexpr int adj_record_doubles() { return 2 * J * J + 2 * J; }
+template <int J, int NR = -1, bool ALL = false>
 EXO_HD void chunk_adj_lane(const double* EXO_RESTRICT t, Series rs, const double* EXO_RESTRICT diag, int64_t n_diag, int64_t n,
-                           const Coefs& cf, int64_t n_draw, const double* EXO_RESTRICT gloglike, double* EXO_RESTRICT state,
-                           const ChunkGeom& cg, int64_t draw, int c, int role, double* xacc, int xs) {
+                           const Coefs& cf, int64_t n_draw, const double* EXO_RESTRICT gloglike, const double* EXO_RESTRICT state,
+                           const ChunkGeom& cg, int64_t draw, int c, int role, int piece, int n_pieces, double* out, int os) {
   const int64_t n0 = c * cg.L, n1 = (n0 + cg.L < n) ? n0 + cg.L : n;
   const ChunkWs ws = chunk_ws(n, n_draw, J, cg);
   DrawCoef<J, NR> co;
@@ -2362,17 +2369,21 @@ EXO_HD void chunk_adj_lane(const double* EXO_RESTRICT t, Series rs, const double
   const SeriesRow y(rs, draw, n);
   const double* EXO_RESTRICT dg = diag + (n_diag == 1 ? 0 : draw * n);
   const double gL = gloglike[draw];
-  const bool do_state = role <= 0, all = role < 0, is_R = all || role == J + 1, do_vec = role != 0;
+  constexpr bool all = ALL;
+  const bool do_state = all || role == 0, is_R = all || role == J + 1, do_vec = all || role != 0;
   RevP<J, NR, true> r;
   double v[J];   // one column of X (roles 1 .. J), or R
 #pragma unroll
   for (int j = 0; j < J; ++j) {
     r.Fb[j] = r.Wb[j] = r.flux[j] = 0.0;
     v[j] = (!is_R && role == j + 1) ? 1.0 : 0.0;
-    if (all) {
+  }
+  double Xl[ALL ? J : 1][ALL ? J : 1];   // (ALL: every column of X here)
+  if constexpr (ALL) {
 #pragma unroll
-      for (int l = 0; l < J; ++l) xacc[(j * J + l) * xs] = (j == l) ? 1.0 : 0.0;
-    }
+    for (int j = 0; j < J; ++j)
+#pragma unroll
+      for (int l = 0; l < J; ++l) Xl[j][l] = (j == l) ? 1.0 : 0.0;
   }
 #pragma unroll
   for (int k = 0; k < J * (J + 1) / 2; ++k) r.Sb.v[k] = 0.0;
@@ -2381,19 +2392,21 @@ EXO_HD void chunk_adj_lane(const double* EXO_RESTRICT t, Series rs, const double
   double phi[J];
   if (n0 + 1 < n) co.set_ref(t[n0 + 1] - t[n0]);
   const int64_t nb = (n1 - n0 + kCkptB - 1) / kCkptB;
-  bool pend = n1 < n;
+  // this piece's blocks [bi_lo, bi_hi): whole checkpoint blocks, dealt evenly
+  const int64_t bi_lo = nb * piece / n_pieces, bi_hi = nb * (piece + 1) / n_pieces;
+  bool pend = bi_hi < nb || n1 < n;   // (the link behind a piece's last cadence is the piece's to reverse)
   constexpr int kK = J + J * (J + 1) / 2;
   constexpr int kSpan = ckpt_span(J), kSub = kCkptB / kSpan;
   constexpr bool kAheadBlk = J <= 4;   // (the next block's series in flight while this one is worked through: where the registers allow)
   BlockIn cur, nxt;
   double ck[kK];
-  load_block(y, dg, n_diag, n0 + (nb - 1) * kCkptB, n1, cur);
+  if (bi_hi > bi_lo) load_block(y, dg, n_diag, n0 + (bi_hi - 1) * kCkptB, n1, cur);
   nxt = cur;
 #pragma unroll 1
-  for (int64_t bi = nb - 1; bi >= 0; --bi) {
+  for (int64_t bi = bi_hi - 1; bi >= bi_lo; --bi) {
     const int64_t b0 = n0 + bi * kCkptB;
     const int len = (int)((n1 - b0 < kCkptB) ? n1 - b0 : kCkptB);
-    if (kAheadBlk && bi > 0) load_block(y, dg, n_diag, b0 - kCkptB, n1, nxt);
+    if (kAheadBlk && bi > bi_lo) load_block(y, dg, n_diag, b0 - kCkptB, n1, nxt);
 #pragma unroll
     for (int h = kSub - 1; h >= 0; --h) {
       const int q0 = h * kSpan;
@@ -2484,14 +2497,14 @@ EXO_HD void chunk_adj_lane(const double* EXO_RESTRICT t, Series rs, const double
               for (int j = 0; j < J; ++j) { pv[j] = link ? phi[j] * v[j] : (is_R ? 0.0 : v[j]); sdot = fma(W[j], pv[j], sdot); }
 #pragma unroll
               for (int j = 0; j < J; ++j) v[j] = fma(cz - sdot, U[j], pv[j]);
-              if (all) {
+              if constexpr (ALL) {
 #pragma unroll
                 for (int k = 0; k < J; ++k) {
                   sdot = 0.0;
 #pragma unroll
-                  for (int j = 0; j < J; ++j) { pv[j] = (link ? phi[j] : 1.0) * xacc[(j * J + k) * xs]; sdot = fma(W[j], pv[j], sdot); }
+                  for (int j = 0; j < J; ++j) { pv[j] = (link ? phi[j] : 1.0) * Xl[j][k]; sdot = fma(W[j], pv[j], sdot); }
 #pragma unroll
-                  for (int j = 0; j < J; ++j) xacc[(j * J + k) * xs] = fma(-sdot, U[j], pv[j]);
+                  for (int j = 0; j < J; ++j) Xl[j][k] = fma(-sdot, U[j], pv[j]);
                 }
               }
             }
@@ -2508,29 +2521,107 @@ EXO_HD void chunk_adj_lane(const double* EXO_RESTRICT t, Series rs, const double
     }
     pend = true;
     if (kAheadBlk) cur = nxt;
-    else if (bi > 0) load_block(y, dg, n_diag, b0 - kCkptB, n1, cur);
+    else if (bi > bi_lo) load_block(y, dg, n_diag, b0 - kCkptB, n1, cur);
   }
-  const int oA = 0, ob = J * J, oC = J * J + J, oeta = 2 * J * J + J;
+  // the piece's record: X row-major, r, l_F, l_S
+  const int oX = 0, oR = J * J, oF = J * J + J, oS = J * J + 2 * J;
   if (do_state) {
 #pragma unroll
     for (int j = 0; j < J; ++j) {
-      state[ws.elem(c, oeta + j, draw)] = r.Fb[j];
+      out[(oF + j) * os] = r.Fb[j];
 #pragma unroll
-      for (int l = 0; l < J; ++l) state[ws.elem(c, oC + j * J + l, draw)] = -r.Sb(j, l);
+      for (int l = 0; l < J; ++l) out[(oS + j * J + l) * os] = r.Sb(j, l);
     }
   }
   if (is_R) {
 #pragma unroll
-    for (int j = 0; j < J; ++j) state[ws.elem(c, ob + j, draw)] = -v[j];
-  } else if (do_vec) {   // column role - 1 of X is row role - 1 of Abar = X^T
+    for (int j = 0; j < J; ++j) out[(oR + j) * os] = v[j];
+  } else if (do_vec) {   // column role - 1 of X
 #pragma unroll
-    for (int l = 0; l < J; ++l) state[ws.elem(c, oA + (role - 1) * J + l, draw)] = v[l];
+    for (int j = 0; j < J; ++j) out[(oX + j * J + (role - 1)) * os] = v[j];
   }
-  if (all) {
+  if constexpr (ALL) {
 #pragma unroll
     for (int j = 0; j < J; ++j)
 #pragma unroll
-      for (int l = 0; l < J; ++l) state[ws.elem(c, oA + j * J + l, draw)] = xacc[(l * J + j) * xs];
+      for (int l = 0; l < J; ++l) out[(oX + j * J + l) * os] = Xl[j][l];
+  }
+}
+
+// the pieces of a chunk's reverse sweep multiplied back together, first piece outermost (it is the last to act on an adjoint
+// coming from behind the chunk):  T_a o T_b:  X = X_a X_b,  r = X_a r_b + r_a,  l_F = X_a l_F,b + l_F,a,
+// l_S = X_a l_S,b X_a^T + sym((X_a l_F,b) r_a^T) + l_S,a  -- and the result written over the chunk's element where
+// badj_prep_lane writes (A <- X^T, b <- -r, eta <- l_F, Cm <- -l_S).  rec: n_pieces records of adj_record_doubles<J>() doubles,
+// piece p's entry k at rec[(p * rstride + k) * os].
+template <int J>
+EXO_HD void adj_combine_lane(const double* rec, int rstride, int os, int n_pieces, int64_t n, int64_t n_draw,
+                             double* EXO_RESTRICT state, const ChunkGeom& cg, int64_t draw, int c) {
+  const ChunkWs ws = chunk_ws(n, n_draw, J, cg);
+  const int oX = 0, oR = J * J, oF = J * J + J, oS = J * J + 2 * J;
+  double X[J][J], S[J][J], rr[J], lF[J];
+  {
+    const double* q = rec + (int64_t)(n_pieces - 1) * rstride * os;
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      rr[j] = q[(oR + j) * os]; lF[j] = q[(oF + j) * os];
+#pragma unroll
+      for (int l = 0; l < J; ++l) { X[j][l] = q[(oX + j * J + l) * os]; S[j][l] = q[(oS + j * J + l) * os]; }
+    }
+  }
+#pragma unroll 1
+  for (int p = n_pieces - 2; p >= 0; --p) {
+    const double* q = rec + (int64_t)p * rstride * os;
+    // (X_a is read from its record entry by entry, twice: registers are what this lane is short of)
+    double T[J][J], Xn[J][J], xf[J], xr[J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      double a[J], f = 0.0, g = 0.0;
+#pragma unroll
+      for (int l = 0; l < J; ++l) a[l] = q[(oX + j * J + l) * os];
+#pragma unroll
+      for (int l = 0; l < J; ++l) {
+        f = fma(a[l], lF[l], f);
+        g = fma(a[l], rr[l], g);
+        double tv = 0.0, xv = 0.0;
+#pragma unroll
+        for (int k = 0; k < J; ++k) { tv = fma(a[k], S[k][l], tv); xv = fma(a[k], X[k][l], xv); }
+        T[j][l] = tv;                       // X_a l_S,b
+        Xn[j][l] = xv;                      // X_a X_b
+      }
+      xf[j] = f; xr[j] = g;
+    }
+#pragma unroll
+    for (int l = 0; l < J; ++l) {
+      double a[J];
+#pragma unroll
+      for (int k = 0; k < J; ++k) a[k] = q[(oX + l * J + k) * os];
+      const double ral = q[(oR + l) * os];
+#pragma unroll
+      for (int j = 0; j < J; ++j) {
+        double sv = q[(oS + j * J + l) * os];
+#pragma unroll
+        for (int k = 0; k < J; ++k) sv = fma(T[j][k], a[k], sv);
+        S[j][l] = sv + 0.5 * (xf[j] * ral + q[(oR + j) * os] * xf[l]);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      rr[j] = xr[j] + q[(oR + j) * os];
+      lF[j] = xf[j] + q[(oF + j) * os];
+#pragma unroll
+      for (int l = 0; l < J; ++l) X[j][l] = Xn[j][l];
+    }
+  }
+  const int oA = 0, ob = J * J, oC = J * J + J, oeta = 2 * J * J + J;
+#pragma unroll
+  for (int j = 0; j < J; ++j) {
+    state[ws.elem(c, ob + j, draw)] = -rr[j];
+    state[ws.elem(c, oeta + j, draw)] = lF[j];
+#pragma unroll
+    for (int l = 0; l < J; ++l) {
+      state[ws.elem(c, oA + j * J + l, draw)] = X[l][j];                       // Abar = X^T
+      state[ws.elem(c, oC + j * J + l, draw)] = -0.5 * (S[j][l] + S[l][j]);
+    }
   }
 }
 

@@ -16,6 +16,7 @@ namespace {
 
 int g_serial_scan = 0;   // 1: the serial reference scans (bscan_lane, bscan_vjp_lane) instead of the trees
 int g_robust_flags = 1;  // draws the element lanes flag kFlagRobust take the robust route (as on the device)
+int g_adj_pieces = 8;    // the chunk's reverse sweep in that many pieces (chunk_adj_lane), as the device's eight groups of a wave
 int g_adj_roles = 0;     // 1: chunk_adj_lane role by role, as the device's eight lanes run it
 int g_adj_tree = 0;      // experiment (with g_robust): chunk_adj_lane's outputs scanned by the adjoint TREE instead of the serial chain
 int g_hybrid_k = -1;     // experiment (with g_robust): forward scan = k levels of composition, a serial chain at level k, k levels down
@@ -136,13 +137,18 @@ void run_vjp(const double* t, gp::Series rs, const double* diag, int64_t n_diag,
     for (int64_t d = 0; d < n_draw; ++d) {
       if (robust_draw(d)) {
         gp::with_layout<J>(cf, d, [&](auto nr) {
-          double x[J * J];
-          if (g_adj_roles) {
-            for (int role = 0; role <= J + 1; ++role)
-              gp::chunk_adj_lane<J, decltype(nr)::value>(t, rs, diag, n_diag, n, cf, n_draw, gloglike, state, cg, d, c, role, nullptr, 0);
-          } else {
-            gp::chunk_adj_lane<J, decltype(nr)::value>(t, rs, diag, n_diag, n, cf, n_draw, gloglike, state, cg, d, c, -1, x, 1);
+          constexpr int NR = decltype(nr)::value, kRec = gp::adj_record_doubles<J>();
+          double rec[8][kRec];
+          const int np = g_adj_pieces < 1 ? 1 : (g_adj_pieces > 8 ? 8 : g_adj_pieces);
+          for (int piece = 0; piece < np; ++piece) {
+            if (g_adj_roles) {
+              for (int role = 0; role <= J + 1; ++role)
+                gp::chunk_adj_lane<J, NR, false>(t, rs, diag, n_diag, n, cf, n_draw, gloglike, state, cg, d, c, role, piece, np, rec[piece], 1);
+            } else {
+              gp::chunk_adj_lane<J, NR, true>(t, rs, diag, n_diag, n, cf, n_draw, gloglike, state, cg, d, c, -1, piece, np, rec[piece], 1);
+            }
           }
+          gp::adj_combine_lane<J>(&rec[0][0], kRec, 1, np, n, n_draw, state, cg, d, c);
         });
       } else {
         gp::badj_prep_lane<J>(gloglike, n, n_draw, state, cg, d, c);
@@ -202,6 +208,7 @@ void harness_set_polish(int v) { g_polish = v; }
 void harness_set_robust(int v) { g_robust = v; }
 void harness_set_adj_tree(int v) { g_adj_tree = v; }
 void harness_set_adj_roles(int v) { g_adj_roles = v; }
+void harness_set_adj_pieces(int v) { g_adj_pieces = v; }
 void harness_set_hybrid_k(int v) { g_hybrid_k = v; }
 void harness_set_robust_flags(int v) { g_robust_flags = v; }
 // (experiments: where the checkpoints -- the states (F, packed S) entering every ckpt_span(J)-th cadence -- live in `state`)
