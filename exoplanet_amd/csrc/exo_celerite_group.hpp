@@ -531,21 +531,20 @@ __device__ __forceinline__ void robust_fwd_chain_group(const ChunkWs& ws, double
       const bool is_piv = lane8 == piv;
       mine = is_piv ? k : mine;
       sync();            // (the previous step's readers are done with `prow`)
-      if (is_piv) {
+      if (is_piv) {      // the pivot's lane scales its row and publishes it
+        const double ip = exo::fast_rcp(M[k]);
 #pragma unroll
-        for (int l = k; l < J; ++l) prow[l] = M[l];
+        for (int l = k; l < J; ++l) { M[l] *= ip; prow[l] = M[l]; }
 #pragma unroll
-        for (int l = 0; l <= J; ++l) prow[J + l] = R[l];
+        for (int l = 0; l <= J; ++l) { R[l] *= ip; prow[J + l] = R[l]; }
       }
       sync();
-      const double ip = exo::fast_rcp(prow[k]);
-      // every row loses f x the scaled pivot row; the pivot's own row BECOMES it: keep = 0, f = -1 (two exact products
-      // instead of a select per entry)
-      const double f = is_piv ? -1.0 : M[k], keep = is_piv ? 0.0 : 1.0;
+      // every other row loses its multiple of the scaled pivot row (the pivot's own: f = 0, untouched)
+      const double f = is_piv ? 0.0 : M[k];
 #pragma unroll
-      for (int l = k; l < J; ++l) M[l] = fma(-f, prow[l] * ip, keep * M[l]);
+      for (int l = k; l < J; ++l) M[l] = fma(-f, prow[l], M[l]);
 #pragma unroll
-      for (int l = 0; l <= J; ++l) R[l] = fma(-f, prow[J + l] * ip, keep * R[l]);
+      for (int l = 0; l <= J; ++l) R[l] = fma(-f, prow[J + l], R[l]);
     }
     // the solved rows where they belong: row `mine` of [Y | ym]
     if (live) {
@@ -563,8 +562,9 @@ __device__ __forceinline__ void robust_fwd_chain_group(const ChunkWs& ws, double
 #pragma unroll
     for (int k = 0; k < J; ++k) {
       m2 = fma(el.A[k], rowsY[k * L::WS + J], m2);
+      const double ha = 0.5 * el.A[k];   // A sym(Y) = (A / 2) Y + (A / 2) Y^T
 #pragma unroll
-      for (int l = 0; l < J; ++l) AY[l] = fma(el.A[k], 0.5 * (rowsY[k * L::WS + l] + rowsY[l * L::WS + k]), AY[l]);
+      for (int l = 0; l < J; ++l) AY[l] = fma(ha, rowsY[k * L::WS + l], fma(ha, rowsY[l * L::WS + k], AY[l]));
     }
     {
       const double* A = set_A(q);
