@@ -26,7 +26,9 @@
 //    the lane's registers -- no cross-lane traffic, none of the G-fold duplicated scalar work -- and a
 //    CHECKPOINTED factorisation: the forward pass stores (F, S) every 4 cadences (10 B per (draw,
 //    cadence) at J = 2 instead of 80), the reverse pass recomputes the cadences of a block from its
-//    checkpoint in registers.
+//    checkpoint in registers.  Draws too ill-conditioned for the scans' trees of element compositions (a score up to
+//    1e8) stay on this path by its ROBUST route: the elements applied serially (celerite_robust_scan_kernel), the
+//    adjoint scan fed from the chunks' own reverse recurrences (celerite_chunk_adj_kernel) -- DESIGN.md 3.11.
 // The library keeps no state between calls: how a series is cut is a pure function of the call's
 // arguments (gp::chunk_plan), which the forward and the reverse call of a pair share.
 #include <hip/hip_runtime.h>
@@ -596,7 +598,8 @@ __global__ __launch_bounds__(kWave) void celerite_vjp_kernel(
 // a > 0, |b d| <= a c are flagged and handled by the sequential kernels.
 // ===========================================================================
 
-// which draws the time-parallel path cannot take (DeltaCoef::valid): 1.0 = redo sequentially
+// which draws the time-parallel path cannot take (DeltaCoef::valid): kFlagSeq = redo sequentially (the element kernel adds
+// its own verdicts on the conditioning: kFlagRobust / kFlagSeq, exo_celerite_core.hpp)
 template <int J>
 __global__ __launch_bounds__(kWave) void celerite_flag_kernel(Coefs cf,
                                                               int64_t n_draw, double* __restrict__ flag) {

@@ -715,7 +715,8 @@ EXO_HD void elem_lane(const double* EXO_RESTRICT t, Series rs, const double* EXO
   //    8e-6 (1e6), 5e-2 (1e7); J = 3: 1e-7, 4e-5, 2e-4; J = 4 .. 6: 1e-5 .. 7e-5 (1e5), 4e-4 .. 5e-3 (1e6); medians
   //    1e-11 .. 1e-9 throughout: the tail is kernels whose terms differ by four decades in time scale, and it is
   //    heavy for wide states.
-  // Hence: a draw is flagged -- redone by the sequential kernels -- above kappa = 1e7 for J <= 2 (round 2: 1e5; an SHO
+  // Hence: a draw is flagged -- until round 4 redone by the sequential kernels; now kept on this path by its robust route up
+  // to EXO_GP_COND_ROBUST_MAX (chunk_adj_lane), sequential beyond -- above kappa = 1e7 for J <= 2 (round 2: 1e5; an SHO
   // term within 1e-4 of critical damping, Matern-3/2, a signal 1e6 x the noise stay on this path) and above 1e5 for
   // wider states (as in round 2; 3e4 since round 4, below).  diag = 0 is flagged whatever J.
   // ROUND 4: that tail was ONE gradient -- d loglike / d(oscillation rate of a complex term), whose cancellation across
