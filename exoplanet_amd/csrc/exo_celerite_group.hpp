@@ -49,7 +49,15 @@ struct Grp {
   // group as soon as the instruction stream says so.  sync() only keeps the COMPILER from moving reads above the
   // writes they depend on (or writes above reads of what they replace); it costs no cycles of its own -- what costs is
   // the round trip write -> read -> arithmetic -> write, so the items below stage as much as they can per exchange.
-  static __device__ __forceinline__ void sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+  // (NOT a wavefront-scope fence: that one also waits for every global load and store in flight -- vmcnt(0) -- at each exchange)
+#ifndef EXO_GROUP_FENCE
+#define EXO_GROUP_FENCE 0
+#endif
+  static __device__ __forceinline__ void sync() {
+    if (EXO_GROUP_FENCE) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    else asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+  }
 
   // publish my row of a matrix / my entry of a vector (no sync: the caller batches)
   __device__ __forceinline__ void put_rows(int s, const double (&a)[J]) const {
