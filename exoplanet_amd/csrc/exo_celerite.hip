@@ -1193,6 +1193,21 @@ __global__ __launch_bounds__(kWave) void celerite_tree_kernel(TreeOp op, double*
 // walks the DOWN levels, a block barrier between levels.  Items of J >= 3 on groups of eight lanes (32 per block), items of
 // J <= 2 one lane each.  Blocks are dealt to the XCDs so that the 16 draws sharing a 128-B line of the [..][draw] arrays
 // run on ONE XCD (blockIdx.x % 8 is the XCD of a block): each line crosses the fabric once instead of up to 8 times.
+// The NARROW levels of a scan -- at most EXO_GP_FUSED_TOP positions per draw: one item's latency each, ~7 us, and a launch
+// gap -- can go in ONE launch, a block per draw with a block barrier between levels (celerite_scan_fused_kernel from level
+// f_lo up), the wide levels below keeping their own launches, coalesced over the draws.  Measured (round 4, hipGraph replay) and
+// OFF: C5 at 128 chains 1.90 against 1.91 ms, C3 3.88 against 3.82 (a block per draw: 1024 blocks of mostly idle lanes at J = 2) --
+// inside a graph the launches' gaps are already small, what a narrow level costs is its item's latency, and that stays.
+// (The whole scan in one launch, EXO_GP_FUSED_SCAN, is slower still: the wide levels' traffic, uncoalesced.)
+#ifndef EXO_GP_FUSED_TOP
+#define EXO_GP_FUSED_TOP 0
+#endif
+inline int scan_fused_from(const ChunkWs& ws) {
+  const int top = ws.tree_top();
+  int f = 0;
+  while (f < top && ws.tree_npos(f) > EXO_GP_FUSED_TOP) ++f;
+  return f;     // (== top: nothing is narrow enough)
+}
 #ifndef EXO_GP_FUSED_SCAN
 #define EXO_GP_FUSED_SCAN 0
 #endif
@@ -1221,9 +1236,11 @@ __global__ __launch_bounds__(kScanBlock, EXO_GROUP_WAVES) void celerite_tree_gro
   tree_item_group<J, ADJ, DOWN>(op, state, c, unit - (int64_t)c * op.n_draw, g);
 }
 
+// f_lo: the levels below it (the wide ones) are launches of their own (celerite_tree_group_kernel: coalesced over draws);
+// this kernel walks UP from level f_lo, seeds the top, and comes back DOWN to level f_lo.
 template <int J, bool ADJ>
 __global__ __launch_bounds__(kScanBlock) void celerite_scan_fused_kernel(ChunkWs ws, double* state, const double* __restrict__ t,
-                                                                        Coefs cf, int64_t n_draw) {
+                                                                        Coefs cf, int64_t n_draw, int f_lo) {
   constexpr bool kGroup = J >= 3;
   __shared__ double lds[kGroup ? (kScanBlock / 8) * GroupLds<J>::S : 2];
   const int per = (int)((n_draw + 7) / 8);
@@ -1238,7 +1255,7 @@ __global__ __launch_bounds__(kScanBlock) void celerite_scan_fused_kernel(ChunkWs
   const int top = ws.tree_top();
   // (the level's TreeOp is worked out here, in scalar registers: a table of them as a kernel argument, indexed by the
   // level, is copied to 600 vector registers and scratch)
-  for (int f = 0; f + 1 < top; ++f) {
+  for (int f = f_lo; f + 1 < top; ++f) {
     const TreeOp op = scan_level_op(ws, J, ADJ, f, false);
     for (int c = unit; c < op.n_item; c += n_unit) {
       if constexpr (kGroup) tree_item_group<J, ADJ, false>(op, state, c, draw, g);
@@ -1253,7 +1270,7 @@ __global__ __launch_bounds__(kScanBlock) void celerite_scan_fused_kernel(ChunkWs
     scan_init_lane<J>(t, cf, n_draw, state + seed, draw);
   }
   __syncthreads();
-  for (int f = top - 1; f >= 0; --f) {
+  for (int f = top - 1; f >= f_lo; --f) {
     const TreeOp op = scan_level_op(ws, J, ADJ, f, true);
     for (int c = unit; c < op.n_item; c += n_unit) {
       if constexpr (kGroup) tree_item_group<J, ADJ, true>(op, state, c, draw, g);
@@ -1710,15 +1727,12 @@ static int celerite_fwd(const double* t, Series resid, const double* diag, int64
       // after the element kernel: it may flag more draws (measurement variance too small)
       hipLaunchKernelGGL(celerite_prep_flagged_kernel, dim3(8, (unsigned)n_draw), dim3(256), 0, st, t, n, cf, n_draw, J,
                          state, state + ws.off_flag());
-      if (EXO_GP_FUSED_SCAN) {
-        // (B) as a tree, all of it in one launch: compose up to one position, seed it with the initial state, apply back down
-        const dim3 sgrid((unsigned)(8 * ((n_draw + 7) / 8)));
-        EXO_GP_DISPATCH(J, hipLaunchKernelGGL((celerite_scan_fused_kernel<JJ, false>), sgrid, dim3(kScanBlock), 0, st, ws, state, t,
-                                              cf, n_draw))
-      } else {
-        // (B) as a tree: compose up to one position, seed it with the initial state, apply back down
+      {
+        // (B) as a tree: compose up to one position, seed it with the initial state, apply back down -- the wide levels a launch
+        // each, the narrow ones (scan_fused_from) all in one
         int rc = EXO_OK;
-        tree_scan(ws, cg, J, n_draw, false,
+        const dim3 sgrid((unsigned)(8 * ((n_draw + 7) / 8)));
+        tree_scan_split(ws, J, false, EXO_GP_FUSED_SCAN ? 0 : scan_fused_from(ws),
                   [&](const TreeOp& op, bool down) {
                     const dim3 tgrid((unsigned)(((int64_t)op.n_item * n_draw + kWave - 1) / kWave));
                     const dim3 ggrid((unsigned)(((int64_t)op.n_item * n_draw + kScanBlock / 8 - 1) / (kScanBlock / 8)));
@@ -1742,6 +1756,10 @@ static int celerite_fwd(const double* t, Series resid, const double* diag, int64
                   [&]() {
                     EXO_GP_DISPATCH_VOID(J, hipLaunchKernelGGL((celerite_scan_init_kernel<JJ>), grid, block, 0, st, t, cf, n_draw,
                                                                state + ws.tree_state(ws.tree_top())))
+                  },
+                  [&](int f_lo) {
+                    EXO_GP_DISPATCH_VOID(J, hipLaunchKernelGGL((celerite_scan_fused_kernel<JJ, false>), sgrid, dim3(kScanBlock), 0, st, ws,
+                                                               state, t, cf, n_draw, f_lo))
                   });
         if (rc != EXO_OK) return rc;
       }
@@ -1802,15 +1820,11 @@ static int celerite_vjp(const double* t, Series resid, const double* diag, int64
       EXO_GP_DISPATCH_LANE(J, hipLaunchKernelGGL((celerite_chunk_adj_kernel<JJ>), dim3((unsigned)(cg.C - 1), per_draw.x), block, 0,
                                                  st, t, resid, diag, n_diag, n, cf, n_draw, gloglike, wstate, cg))
     }
-    if (EXO_GP_FUSED_SCAN) {
-      // (B') as a tree over positions p = C - 1 - chunk, one launch: adjoint elements of chunks C - 1 .. 1, zero initial adjoint
-      const dim3 sgrid((unsigned)(8 * ((n_draw + 7) / 8)));
-      EXO_GP_DISPATCH(J, hipLaunchKernelGGL((celerite_scan_fused_kernel<JJ, true>), sgrid, dim3(kScanBlock), 0, st, ws, wstate, t,
-                                            cf, n_draw))
-    } else {
+    {
       // (B') as a tree over positions p = C - 1 - chunk: adjoint elements of chunks C - 1 .. 1, zero initial adjoint
       bool ok = true;
-      tree_scan(ws, cg, J, n_draw, true,
+      const dim3 sgrid((unsigned)(8 * ((n_draw + 7) / 8)));
+      tree_scan_split(ws, J, true, EXO_GP_FUSED_SCAN ? 0 : scan_fused_from(ws),
                 [&](const TreeOp& op, bool down) {
                   const dim3 tgrid((unsigned)(((int64_t)op.n_item * n_draw + kWave - 1) / kWave));
                   const dim3 ggrid((unsigned)(((int64_t)op.n_item * n_draw + kScanBlock / 8 - 1) / (kScanBlock / 8)));
@@ -1828,6 +1842,10 @@ static int celerite_vjp(const double* t, Series resid, const double* diag, int64
                 },
                 [&]() {
                   ok = hipMemsetAsync(wstate + ws.tree_state(ws.tree_top()), 0, sizeof(double) * ws.B() * n_draw, st) == hipSuccess;
+                },
+                [&](int f_lo) {
+                  EXO_GP_DISPATCH_VOID(J, hipLaunchKernelGGL((celerite_scan_fused_kernel<JJ, true>), sgrid, dim3(kScanBlock), 0, st, ws,
+                                                             wstate, t, cf, n_draw, f_lo))
                 });
       if (!ok) return EXO_ERR_LAUNCH;
     }

@@ -1496,13 +1496,19 @@ EXO_HDH TreeOp scan_level_op(const ChunkWs& ws, int J, bool adj, int f, bool dow
 
 // The levels of a scan: `launch(op, down)` is called once per level, in order (UP levels, then -- after `seed()`
 // has put the initial state at ws.tree_state(top) -- the DOWN levels).
+// f_lo < top: the levels from f_lo up -- the remaining UP levels, the seed, the DOWN levels back to f_lo -- are `fused(f_lo)`'s
+// (one launch on the device: celerite_scan_fused_kernel); f_lo >= top: every level its own launch.
+template <class Launch, class Seed, class Fused>
+EXO_HDH void tree_scan_split(const ChunkWs& ws, int J, bool adj, int f_lo, Launch&& launch, Seed&& seed, Fused&& fused) {
+  const int top = ws.tree_top();
+  for (int f = 0; f + 1 < top && f < f_lo; ++f) launch(scan_level_op(ws, J, adj, f, false), false);
+  if (f_lo < top) fused(f_lo); else seed();
+  for (int f = (f_lo < top ? f_lo : top) - 1; f >= 0; --f) launch(scan_level_op(ws, J, adj, f, true), true);
+}
 template <class Launch, class Seed>
 EXO_HDH void tree_scan(const ChunkWs& ws, const ChunkGeom& cg, int J, int64_t n_draw, bool adj, Launch&& launch, Seed&& seed) {
   (void)cg; (void)n_draw;
-  const int top = ws.tree_top();
-  for (int f = 0; f + 1 < top; ++f) launch(scan_level_op(ws, J, adj, f, false), false);
-  seed();
-  for (int f = top - 1; f >= 0; --f) launch(scan_level_op(ws, J, adj, f, true), true);
+  tree_scan_split(ws, J, adj, ws.tree_top(), launch, seed, [](int) {});
 }
 
 // ---------------------------------------------------------------------------------------------
