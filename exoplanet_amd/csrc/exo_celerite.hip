@@ -483,6 +483,26 @@ __global__ __launch_bounds__(kWave) void celerite_vjp_kernel(
       acc_u = fma(S_n[l], uball[l], acc_u);                        // (S_n^T ub)_j, S symmetric
     }
     Ub += acc_u;
+    // d loglike / d(oscillation rate of a complex pair): - sum over the links of dt x (the phase FLUX across the link), the flux
+    // taken from what it is -- Fbar^T G F + < Sbar, G S + S G^T >, G = [[0, -1], [1, 0]] on the pair, the state entering this
+    // cadence against its adjoint (phase_flux, exo_celerite_core.hpp) -- at EVERY link: no sum of phase cotangents weighted with
+    // their distance from the origin (sum_i (t_i - t_0) g_i lost up to 4e-5 on kernels with aliased oscillation rates -- the
+    // sequential recurrences of celerite2's formulation do; tools/gp_seq_dc_check.py).  Lane j of a pair has row j of S and of
+    // Sbar; the partner lane (j ^ 1) supplies its row of Sbar and its own cross term.
+    double flux = 0.0;
+    if (G >= 2) {
+      // the pair's other lane: j + 1 for its first index, j - 1 for its second (an odd number of real terms in front leaves
+      // the pairs on odd lanes: not lane ^ 1) -- both moves by every lane, then the choice (dpp inside a branch: see grp_argmax8)
+      auto other = [&](double v) {
+        const double up = dpp_mov<0x101>(v), dn = dpp_mov<0x111>(v);   // row_shl 1: lane i reads i + 1; row_shr 1: i - 1
+        return k.odd ? dn : up;
+      };
+      double cross = 0.0;
+#pragma unroll
+      for (int l = 0; l < J; ++l) cross = fma(other(Sb[l]), S_n[l], cross);
+      const double cross_o = other(cross), F_o = other(F_n), Fb_o = other(Fb);
+      flux = fma(Fb_o, F_n, -Fb * F_o) + 2.0 * (cross - cross_o);
+    }
     // (2) F_n = P o G, G = F_p + W_p z_p   (1) S_n = P P^T o T, T = S_p + d_p W_p W_p^T
     const double Gj = fma(W_p, z_p, F_p);
     double Pb = Fb * Gj;
@@ -515,7 +535,7 @@ __global__ __launch_bounds__(kWave) void celerite_vjp_kernel(
       if (k.live && !k.real && !k.odd) {
         ga += Ub * cs + Ub_o * sn;
         gb += Ub * sn - Ub_o * cs;
-        gd += (ti - k.t0) * (Ub * (-k.a * sn + k.b * cs) + Ub_o * (k.a * cs + k.b * sn) - Vb * sn + Vb_o * cs);
+        gd = fma(-dt, flux, gd);
       }
     }
     // shift to cadence n-1
@@ -545,7 +565,8 @@ __global__ __launch_bounds__(kWave) void celerite_vjp_kernel(
     const double cs = k.odd ? Vo : Vj, sn = k.odd ? Vj : Vo;
     const double Vb = Wb * id;
     const double Vb_o = __shfl(Vb, partner, 64);
-    if (k.live && !k.real && !k.odd) gd += (t0 - k.t0) * (-Vb * sn + Vb_o * cs);   // (phases from Coefs::origin, as everywhere)
+    // (cadence 0's phase cotangent has no link in front of it: the phases are counted from t_0, Coefs::origin)
+    (void)t0; (void)cs; (void)sn; (void)Vb_o;
   }
   // the decay rate of a complex pair is shared by its two state indices
   const double gc_o = __shfl(gc, partner, 64);
