@@ -1436,7 +1436,8 @@ __global__ __launch_bounds__(kWave) void celerite_robust_scan_kernel(const doubl
 // them as they are.  A WAVE per (draw, chunk >= 1): the chunk's reverse sweep in eight pieces, a piece on a group of eight
 // lanes (chunk_adj_lane's roles: the state adjoints, the J columns of X, R), the pieces' records multiplied back together
 // through LDS (adj_combine_lane).  Nothing but latency -- 1.2 ms for a 127-cadence chunk on one lane at J = 6, 0.7 ms on eight
-// lanes by roles, ~0.1 ms in eight pieces.  A block looks at 64 consecutive draws and, almost always, leaves at once.
+// lanes by roles, ~0.2 ms in eight pieces.  A block looks at its draws' flags and, almost always, leaves at once.
+constexpr int kAdjDraws = 8;
 template <int J>
 __global__ __launch_bounds__(kWave) void celerite_chunk_adj_kernel(const double* __restrict__ t, Series rs,
                                                                    const double* __restrict__ diag, int64_t n_diag, int64_t n,
@@ -1446,8 +1447,11 @@ __global__ __launch_bounds__(kWave) void celerite_chunk_adj_kernel(const double*
   constexpr int kRec = adj_record_doubles<J>(), kPieces = kWave / 8;
   __shared__ double rec[kPieces * kRec];
   const ChunkWs ws = chunk_ws(n, n_draw, J, cg);
-  const int64_t d0 = (int64_t)blockIdx.y * kWave, dl = d0 + threadIdx.x;
-  unsigned long long todo = __ballot(dl < n_draw && state[ws.off_flag() + (dl < n_draw ? dl : 0)] == kFlagRobust);
+  // (a block looks at kAdjDraws consecutive draws: a batch of nothing but such draws works them kAdjDraws deep, a clean batch
+  // pays (C - 1) n_draw / kAdjDraws empty blocks -- ~10 us at the C3 shape)
+  const int64_t d0 = (int64_t)blockIdx.y * kAdjDraws, dl = d0 + threadIdx.x;
+  const bool look = threadIdx.x < kAdjDraws && dl < n_draw;
+  unsigned long long todo = __ballot(look && state[ws.off_flag() + (look ? dl : 0)] == kFlagRobust);
   const int c = 1 + (int)blockIdx.x, piece = (int)(threadIdx.x >> 3), role = (int)(threadIdx.x & 7);
   while (todo) {
     const int64_t draw = d0 + (__ffsll((long long)todo) - 1);
@@ -1838,7 +1842,7 @@ static int celerite_vjp(const double* t, Series resid, const double* diag, int64
                                           0, st, gloglike, n, n_draw, wstate, cg))
     if (cg.lane) {
       // draws flagged kFlagRobust: those inputs once more, from the chunks' own reverse recurrences (chunk_adj_lane)
-      EXO_GP_DISPATCH_LANE(J, hipLaunchKernelGGL((celerite_chunk_adj_kernel<JJ>), dim3((unsigned)(cg.C - 1), per_draw.x), block, 0,
+      EXO_GP_DISPATCH_LANE(J, hipLaunchKernelGGL((celerite_chunk_adj_kernel<JJ>), dim3((unsigned)(cg.C - 1), (unsigned)((n_draw + kAdjDraws - 1) / kAdjDraws)), block, 0,
                                                  st, t, resid, diag, n_diag, n, cf, n_draw, gloglike, wstate, cg))
     }
     {

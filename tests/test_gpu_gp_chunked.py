@@ -388,3 +388,33 @@ def test_library_keeps_nothing_between_calls(dev):
             for a, b in zip(got[1:], want[1:]):
                 if b.size:
                     np.testing.assert_allclose(a, b, rtol=2e-7, atol=1e-9 * np.abs(b).max())
+
+
+@pytest.mark.parametrize("name,D,C", [("three_sho_j6", 13, None), ("mixed_j5", 70, None), ("sho_q3", 9, 11), ("real1", 5, 2)])
+def test_robust_route_whole_batch(dev, name, D, C):
+    """EVERY draw of the batch above the trees' conditioning thresholds (a signal 3e3 .. 3e4 x the error bars: scores of 1e7 ..
+    9e8 / 10 -- under the robust route's 1e8): the serial forward chain and the adjoint inputs from the chunks' own recurrences
+     for a number of draws that fills no block evenly, state widths 2, 5 and 6, forced chunk counts down to two --
+    against the sequential kernels, which since round 4 carry the oscillation-rate gradient as a phase flux too"""
+    rng = np.random.default_rng(21)
+    N = 2100
+    t = np.sort(rng.uniform(0, 80, N))
+    if name not in KERNELS:
+        pytest.skip("kernel not in the table")
+    cr, cc = batch(rng, name, D)
+    amp = cr[..., 0].sum(-1) + cc[..., 0].sum(-1)
+    ba2 = ((cc[..., 1] / cc[..., 0]) ** 2).max(-1) if cc.shape[1] else np.zeros(D)
+    kappa = 10 ** rng.uniform(7.2, 7.9, size=D)          # (J <= 2: above 1e7; wider states: far above 3e4)
+    diag = ((1 + ba2) * amp / kappa)[:, None] * (1 + 0.5 * rng.uniform(size=(D, N)))
+    y = np.sqrt(amp)[:, None] * rng.normal(size=(D, N))
+    with chunks(0):
+        want = value_and_grads(dev, t, y, diag, cr, cc)
+    with chunks(C):
+        got = value_and_grads(dev, t, y, diag, cr, cc)
+    assert not np.array_equal(got[0], want[0])                       # (not the sequential kernels' bits: the route was taken)
+    np.testing.assert_allclose(got[0], want[0], rtol=1e-9)
+    for g, w in zip(got[1:], want[1:]):
+        if w.size:
+            for d in range(D):
+                e = np.abs(g[d] - w[d]).max() / (np.abs(w[d]).max() + 1e-300)
+                assert e <= 1e-6, (d, e)

@@ -104,7 +104,7 @@ except Exception:
 solved = solved or 4.34e6
 lines = []
 for leg, D, N, J in (("c2", 1024, 150_000, 0), ("sparse", 1024, 150_000, 0), ("chi2", 1024, 150_000, 0), ("c3", 1024, 150_000, 2),
-                     ("c4", 64, 200_000, 0), ("c5", 128, 65_000, 6)):
+                     ("c4", 64, 200_000, 0), ("c5", 128, 65_000, 6), ("c5b", 128, 65_000, 6)):
     def units_of(k, D=D, N=N, leg=leg):
         if k.startswith("transit_runs_kernel") and leg in ("c2", "sparse", "chi2"):
             return solved
@@ -132,7 +132,7 @@ for leg, D, N, J in (("c2", 1024, 150_000, 0), ("sparse", 1024, 150_000, 0), ("c
                        "valu_busy_frac": v.get("valu_busy_frac"), "rocprof_avg_us": v["rocprof_avg_us"], "wave_state": v.get("wave_state")}
     entry["valu"] = valu
     rec[leg] = entry
-    lines.append(f"# {leg}: D = {D}, N = {N}" + (f", J = {J}" if J else ""))
+    lines.append(f"# {leg}: D = {D}, N = {N}" + (f", J = {J}" if J else "") + (" -- 2 chains at a conditioning score of 1e6 (robust route)" if leg == "c5b" else ""))
     lines.append("%-64s %6s %10s %12s %10s %8s %8s" % ("kernel", "calls", "avg_us", "traffic_MB", "GB/s", "valu/pk", "busy"))
     for k, v in list(ks.items())[:16]:
         lines.append("%-64s %6d %10.1f %12s %10s %8s %8s" % (
