@@ -739,8 +739,9 @@ def extra_gp_conditioning(xo, ops, dev, D):
                    "the same state width (J = 2: sho_clean; J = 4: two_sho_clean): the cost of over-damped / nearly critically "
                    "damped / Matern-type draws in a batch.  Round 2: 53x (207 ms against 3.9) as soon as ONE draw had Q < 1/2; "
                    "now every such draw stays on the time-parallel path (joint state covariance of the over-damped pair, "
-                   "conditioning threshold 1e7 at J <= 2); the three layout variants of a mixed batch share one launch, and the step waits for the "
-                   "one wave of mixed kinds on the run-time layout.  `*_bright_star_*`: 1 % of the draws at a conditioning score of 1e6 "
+                   "conditioning threshold 1e7 at J <= 2); the lanes of a batch of mixed kinds take the draws kind by kind (a stable partition on the "
+                   "device: no wave of mixed kinds, no run-time layout; what is left of the 1.84x of round 3 is one more round of resident "
+                   "waves for the second kind's wave).  `*_bright_star_*`: 1 % of the draws at a conditioning score of 1e6 "
                    "(J = 2: under the threshold of the scan trees) / 3e5 (J = 4: above the 3e4 of wider states -- those draws take the "
                    "robust route of the time-parallel path, DESIGN.md section 3.11: serial application of the elements forward, the "
                    "adjoint scan fed from the chunks' own reverse recurrences; the sequential kernels that used to redo them cost 27x)")

@@ -1611,6 +1611,56 @@ static_assert(kLaneMaxJ >= 2, "EXO_GP_LAYOUTS lists compile-time layouts for J <
 // J = 1: one real term; J = 2: two real terms or one pair slot -- complex, or, with per-draw kinds,
 // either (three launches: waves return at once from the variants they did not vote for); J > 2:
 // run-time flags.
+// J = 2 with per-draw pair kinds: which draw a lane of the *_mixed_kernel launches works on.  A wave runs ONE layout, the one
+// all its draws share, or the run-time layout (half again as many instructions) -- and the step waits for its slowest wave: a
+// batch with 1 % of its draws on the other side of Q = 1/2 cost 1.84 x a clean one for the sake of ONE mixed wave.  So the
+// lanes take the draws in an order that has no mixed wave: the complex-term draws, padded to whole waves, then the
+// two-real-terms draws (a stable partition: neighbours stay neighbours, the [..][draw] arrays stay coalesced), written into the
+// workspace by one small kernel per forward call (the reverse call finds it there).
+__device__ __forceinline__ int64_t mixed_draw(const double* __restrict__ state, int64_t n, int64_t n_draw, const ChunkGeom& cg) {
+  const ChunkWs ws = chunk_ws(n, n_draw, 2, cg);
+  const int32_t* __restrict__ perm = reinterpret_cast<const int32_t*>(state + ws.off_perm());
+  return perm[(int64_t)blockIdx.x * kWave + threadIdx.x];      // (the launches cover ws.perm_lanes() lanes)
+}
+__global__ __launch_bounds__(1024) void celerite_kind_partition_kernel(const int32_t* __restrict__ kind, int64_t n_draw,
+                                                                       int32_t* __restrict__ perm, int64_t lanes) {
+  __shared__ int s_cnt[2][16];
+  __shared__ int s_base[2];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  for (int64_t i = tid; i < lanes; i += 1024) perm[i] = -1;
+  // the complex-term draws: how many
+  int mine = 0;
+  for (int64_t d = tid; d < n_draw; d += 1024) mine += kind[d] == 0 ? 1 : 0;
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) mine += __shfl_xor(mine, m, 64);
+  if (lane == 0) s_cnt[0][wave] = mine;
+  if (tid < 2) s_base[tid] = 0;
+  __syncthreads();
+  int c0 = 0;
+  for (int w = 0; w < 16; ++w) c0 += s_cnt[0][w];
+  const int64_t off1 = ((int64_t)c0 + 63) / 64 * 64;
+  __syncthreads();
+  for (int64_t d0 = 0; d0 < n_draw; d0 += 1024) {
+    const int64_t d = d0 + tid;
+    const int k = d < n_draw ? (kind[d] == 0 ? 0 : 1) : -1;
+    const unsigned long long m0 = __ballot(k == 0), m1 = __ballot(k == 1), below = (1ull << lane) - 1ull;
+    if (lane == 0) { s_cnt[0][wave] = __popcll(m0); s_cnt[1][wave] = __popcll(m1); }
+    __syncthreads();
+    if (k >= 0) {
+      int pos = s_base[k] + __popcll((k == 0 ? m0 : m1) & below);
+      for (int w = 0; w < wave; ++w) pos += s_cnt[k][w];
+      perm[(k == 0 ? 0 : off1) + pos] = (int32_t)d;
+    }
+    __syncthreads();
+    if (tid < 2) {
+      int tot = 0;
+      for (int w = 0; w < 16; ++w) tot += s_cnt[tid][w];
+      s_base[tid] += tot;
+    }
+    __syncthreads();
+  }
+}
+
 // J = 2 with per-draw pair kinds (a batch of SHO terms that straddles Q = 1/2): the three layout variants in ONE launch.
 // blockIdx.z picks the variant; a wave runs the one it voted for and leaves the other two at once.  Launched one after the
 // other (round 2), each variant cost its full single-wave latency however few waves took it: a batch with 1 % of its draws
@@ -1621,51 +1671,45 @@ __global__ __launch_bounds__(kWave) void celerite_elem_mixed_kernel(const double
                                                                     const double* __restrict__ diag, int64_t n_diag, int64_t n,
                                                                     Coefs cf, int64_t n_draw, double* __restrict__ state,
                                                                     ChunkGeom cg, int64_t flag_at) {
-  const int64_t draw = (int64_t)blockIdx.x * kWave + threadIdx.x;
-  if (draw >= n_draw) return;
+  const int64_t draw = mixed_draw(state, n, n_draw, cg);
+  if (draw < 0) return;
   const int nr = layout_vote<2>(cf, draw);
   const int c = (int)blockIdx.y;
   if (blockIdx.z == 0) {
     if (nr == 0) elem_lane<2, 0>(t, rs, diag, n_diag, n, cf, n_draw, state, cg, draw, c, flag_at);
-  } else if (blockIdx.z == 1) {
-    if (nr == 2) elem_lane<2, 2>(t, rs, diag, n_diag, n, cf, n_draw, state, cg, draw, c, flag_at);
   } else {
-    if (nr == -1) elem_lane<2, -1>(t, rs, diag, n_diag, n, cf, n_draw, state, cg, draw, c, flag_at);
-  }
+    if (nr == 2) elem_lane<2, 2>(t, rs, diag, n_diag, n, cf, n_draw, state, cg, draw, c, flag_at);
+  }   // (no wave is of mixed kinds: mixed_draw)
 }
 // (four waves per SIMD asked for: the three inlined layouts sit at 129 registers otherwise, and the plan offers four)
 __global__ __launch_bounds__(kWave, 4) void celerite_chunk1_fwd_mixed_kernel(const double* __restrict__ t, Series rs,
                                                                           const double* __restrict__ diag, int64_t n_diag,
                                                                           int64_t n, Coefs cf, int64_t n_draw,
                                                                           double* __restrict__ state, ChunkGeom cg) {
-  const int64_t draw = (int64_t)blockIdx.x * kWave + threadIdx.x;
-  if (draw >= n_draw) return;
+  const int64_t draw = mixed_draw(state, n, n_draw, cg);
+  if (draw < 0) return;
   const int nr = layout_vote<2>(cf, draw);
   const int c = (int)blockIdx.y;
   if (blockIdx.z == 0) {
     if (nr == 0) chunk1_fwd_lane<2, 0>(t, rs, diag, n_diag, n, cf, n_draw, state, cg, draw, c, true);
-  } else if (blockIdx.z == 1) {
-    if (nr == 2) chunk1_fwd_lane<2, 2>(t, rs, diag, n_diag, n, cf, n_draw, state, cg, draw, c, true);
   } else {
-    if (nr == -1) chunk1_fwd_lane<2, -1>(t, rs, diag, n_diag, n, cf, n_draw, state, cg, draw, c, true);
-  }
+    if (nr == 2) chunk1_fwd_lane<2, 2>(t, rs, diag, n_diag, n, cf, n_draw, state, cg, draw, c, true);
+  }   // (no wave is of mixed kinds: mixed_draw)
 }
 __global__ __launch_bounds__(kWave, EXO_VJP1_WAVES) void celerite_chunk1_vjp_mixed_kernel(
     const double* __restrict__ t, Series rs, const double* __restrict__ diag, int64_t n_diag, int64_t n, Coefs cf, int64_t n_draw,
     const double* __restrict__ gloglike, double* __restrict__ state, ChunkGeom cg, double* __restrict__ gresid,
     double* __restrict__ gdiag, double gsign) {
   static_assert(2 < EXO_SPAN2_MIN_J, "the mixed reverse kernel is the J = 2 register-resident form (chunk1_vjp_lane)");
-  const int64_t draw = (int64_t)blockIdx.x * kWave + threadIdx.x;
-  if (draw >= n_draw) return;
+  const int64_t draw = mixed_draw(state, n, n_draw, cg);
+  if (draw < 0) return;
   const int nr = layout_vote<2>(cf, draw);
   const int c = (int)blockIdx.y;
   if (blockIdx.z == 0) {
     if (nr == 0) chunk1_vjp_lane<2, 0>(t, rs, diag, n_diag, n, cf, n_draw, gloglike, state, cg, gresid, gdiag, gsign, draw, c);
-  } else if (blockIdx.z == 1) {
-    if (nr == 2) chunk1_vjp_lane<2, 2>(t, rs, diag, n_diag, n, cf, n_draw, gloglike, state, cg, gresid, gdiag, gsign, draw, c);
   } else {
-    if (nr == -1) chunk1_vjp_lane<2, -1>(t, rs, diag, n_diag, n, cf, n_draw, gloglike, state, cg, gresid, gdiag, gsign, draw, c);
-  }
+    if (nr == 2) chunk1_vjp_lane<2, 2>(t, rs, diag, n_diag, n, cf, n_draw, gloglike, state, cg, gresid, gdiag, gsign, draw, c);
+  }   // (no wave is of mixed kinds: mixed_draw)
 }
 
 #ifndef EXO_GP_MIXED_ONE_LAUNCH
@@ -1732,13 +1776,16 @@ static int celerite_fwd(const double* t, Series resid, const double* diag, int64
       const ChunkGeom cge = cg.fine ? fine_geom(n, n_draw, J, cg, cg.fine) : cg;
       const int64_t flag_at = ws.off_flag();
       const dim3 egrid_f(per_draw.x, (unsigned)cge.C), cgrid_f(grid.x, (unsigned)cge.C);
+      if (J == 2 && cf.n_real == 0 && cf.kind && EXO_GP_MIXED_ONE_LAUNCH)   // per-draw pair kinds: no wave of mixed kinds (mixed_draw)
+        hipLaunchKernelGGL(celerite_kind_partition_kernel, dim3(1), dim3(1024), 0, st, cf.kind, n_draw,
+                           reinterpret_cast<int32_t*>(state + ws.off_perm()), ws.perm_lanes());
       if (J >= EXO_ELEM_LG_MIN_J) {   // the one-lane element kernel is as fast up to J = 6 and does not fit beyond
         EXO_GP_DISPATCH(J, hipLaunchKernelGGL((celerite_elem_lg_kernel<JJ>), cgrid_f, block, 0, st, t, resid, diag, n_diag,
                                               n, cf, n_draw, state, cge, flag_at))
       } else {
         EXO_GP_LAYOUTS(J, cf, hipLaunchKernelGGL((celerite_elem_kernel<JJ, NR>), egrid_f, block, 0, st, t, resid, diag,
                                                  n_diag, n, cf, n_draw, state, cge, flag_at),
-                       hipLaunchKernelGGL(celerite_elem_mixed_kernel, dim3(egrid_f.x, egrid_f.y, 3), block, 0, st, t, resid, diag,
+                       hipLaunchKernelGGL(celerite_elem_mixed_kernel, dim3(egrid_f.x + 1, egrid_f.y, 2), block, 0, st, t, resid, diag,
                                           n_diag, n, cf, n_draw, state, cge, flag_at))
       }
       for (int f = cg.fine; f >= 1; --f) {
@@ -1795,7 +1842,7 @@ static int celerite_fwd(const double* t, Series resid, const double* diag, int64
                                                    state))
         EXO_GP_LAYOUTS(J, cf, hipLaunchKernelGGL((celerite_chunk1_fwd_kernel<(JJ <= kLaneMaxJ ? JJ : 1), NR>), egrid, block, 0,
                                                  st, t, resid, diag, n_diag, n, cf, n_draw, state, cg),
-                       hipLaunchKernelGGL(celerite_chunk1_fwd_mixed_kernel, dim3(egrid.x, egrid.y, 3), block, 0, st, t, resid, diag,
+                       hipLaunchKernelGGL(celerite_chunk1_fwd_mixed_kernel, dim3(egrid.x + 1, egrid.y, 2), block, 0, st, t, resid, diag,
                                           n_diag, n, cf, n_draw, state, cg))
       } else {
         EXO_GP_DISPATCH(J, hipLaunchKernelGGL((celerite_chunk_fwd_kernel<JJ>), cgrid, block, 0, st, t, resid, diag, n_diag,
@@ -1878,7 +1925,7 @@ static int celerite_vjp(const double* t, Series resid, const double* diag, int64
       EXO_GP_LAYOUTS(J, cf, hipLaunchKernelGGL((celerite_chunk1_vjp_kernel<(JJ <= kLaneMaxJ ? JJ : 1), NR>), egrid, block, 0,
                                                st, t, resid, diag, n_diag, n, cf, n_draw, gloglike, wstate, cg, gresid,
                                                gdiag, gsign),
-                     hipLaunchKernelGGL(celerite_chunk1_vjp_mixed_kernel, dim3(egrid.x, egrid.y, 3), block, 0, st, t, resid, diag,
+                     hipLaunchKernelGGL(celerite_chunk1_vjp_mixed_kernel, dim3(egrid.x + 1, egrid.y, 2), block, 0, st, t, resid, diag,
                                         n_diag, n, cf, n_draw, gloglike, wstate, cg, gresid, gdiag, gsign))
     } else {
       EXO_GP_DISPATCH(J, hipLaunchKernelGGL((celerite_chunk_vjp_kernel<JJ>), cgrid, block, 0, st, t, n, cf, n_draw,

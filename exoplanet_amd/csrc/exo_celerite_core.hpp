@@ -279,7 +279,11 @@ struct ChunkWs {
   EXO_HDH int64_t polish(int q, int c, int k, int64_t draw) const {
     return off_polish() + (((int64_t)q * C + c) * K() + k) * n_draw + draw;
   }
-  EXO_HDH int64_t total() const { return off_polish() + (EXO_GP_POLISH ? (int64_t)4 * C * K() * n_draw : 0) - base; }
+  // J = 2 with per-draw pair kinds: the order in which the lanes of the chunk kernels take the draws -- the draws of one kind,
+  // padded to whole waves, then those of the other (int32, -1 = no draw): celerite_kind_partition_kernel
+  EXO_HDH int64_t off_perm() const { return off_polish() + (EXO_GP_POLISH ? (int64_t)4 * C * K() * n_draw : 0); }
+  EXO_HDH int64_t perm_lanes() const { return ((n_draw + 63) / 64 + 1) * 64; }
+  EXO_HDH int64_t total() const { return off_perm() + (perm_lanes() + 1) / 2 - base; }
 };
 
 // the series and the measurement variance of one block of four cadences [b0, b0 + 4) clipped to n1.

@@ -86,3 +86,32 @@ def test_robust_route_is_what_holds_the_ill_conditioned_draws(harness):  # noqa:
             harness.harness_set_robust_flags(1)
     assert res[0, "c22"] > 1e-6 and res[0, "c24"] > 1e-6, res
     assert res[1, "c22"] <= 1e-8 and res[1, "c24"] <= 1e-8, res
+
+
+def test_reverse_sweep_in_pieces_and_by_roles(harness):  # noqa: F811
+    """chunk_adj_lane as the device runs it -- a chunk's reverse sweep dealt to eight pieces, each piece role by role (the state
+    adjoints, the columns of X, R), the pieces' affine maps multiplied back together (adj_combine_lane) -- against the one sweep
+    on one lane: the same numbers to rounding, and every gradient at the long-double definition's"""
+    res = {}
+    try:
+        for pieces, roles in ((1, 0), (8, 1), (3, 1)):
+            harness.harness_set_adj_pieces(pieces)
+            harness.harness_set_adj_roles(roles)
+            for key in ("c17", "c20", "c25"):
+                t, y, diag, co, want = case(key)
+                ar, cr, ac, bc, cc, dc = co
+                real = np.stack([ar, cr], -1)[None]
+                cplx = np.stack([ac, bc, cc, dc], -1)[None]
+                ll, flags, C_used, gr = run(harness, t, y[None], diag[None], real, cplx, gll=np.ones(1))
+                assert flags[0] == 1
+                got = {"y": gr["y"][0], "diag": gr["diag"][0], "ar": gr["real"][0, :, 0], "cr": gr["real"][0, :, 1]}
+                got.update({nm: gr["cplx"][0, :, q] for q, nm in enumerate(("ac", "bc", "cc", "dc"))})
+                assert worst(got, key) <= 1e-8
+                res[pieces, roles, key] = np.concatenate([got[k].ravel() for k in sorted(got)])
+    finally:
+        harness.harness_set_adj_pieces(8)
+        harness.harness_set_adj_roles(0)
+    for key in ("c17", "c20", "c25"):
+        ref = res[1, 0, key]
+        for other in ((8, 1), (3, 1)):
+            assert np.abs(res[other + (key,)] - ref).max() <= 1e-9 * np.abs(ref).max()
