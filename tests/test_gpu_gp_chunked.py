@@ -418,3 +418,46 @@ def test_robust_route_whole_batch(dev, name, D, C):
             for d in range(D):
                 e = np.abs(g[d] - w[d]).max() / (np.abs(w[d]).max() + 1e-300)
                 assert e <= 1e-6, (d, e)
+
+
+@pytest.mark.parametrize("D,frac", [(130, 0.5), (64, 0.02), (200, 0.97), (7, 0.4)])
+def test_mixed_pair_kinds_take_the_draws_kind_by_kind(dev, D, frac):
+    """J = 2 with per-draw pair kinds: the chunk kernels' lanes take the draws in the order celerite_kind_partition_kernel
+    leaves in the workspace (complex-term draws, padded to whole waves, then two-real-terms draws) -- batches that fill no wave
+    evenly, one with a single draw of the other kind, against the sequential kernels draw by draw"""
+    from exoplanet_amd.gp import celerite_loglike
+
+    rng = np.random.default_rng(31 + D)
+    N = 1500
+    t = np.sort(rng.uniform(0, 50, N))
+    y = 0.3 * rng.normal(size=(D, N))
+    diag = 0.02 + 0.02 * rng.uniform(size=(D, N))
+    kind = (rng.uniform(size=D) < frac).astype(np.int32)
+    if frac < 0.1:
+        kind[:] = 0
+        kind[D // 2] = 1
+    cplx = np.zeros((D, 1, 4))
+    for d in range(D):
+        sig, rho = 0.6 * (1 + 0.1 * rng.normal()), 4.0 * (1 + 0.1 * rng.normal())
+        if kind[d]:     # two real terms (a1, c1, a2, c2): an over-damped SHO term's
+            Q = rng.uniform(0.2, 0.45)
+            ar, cr, *_ = P.sho_coefficients(*P.sho_from_sigma_rho(sig, rho, Q), Q)
+            cplx[d, 0] = [ar[0], cr[0], ar[1], cr[1]]
+        else:
+            Q = rng.uniform(0.6, 3.0)
+            _, _, ac, bc, cc, dc = P.sho_coefficients(*P.sho_from_sigma_rho(sig, rho, Q), Q)
+            cplx[d, 0] = [ac[0], bc[0], cc[0], dc[0]]
+    kt = torch.as_tensor(kind[:, None], device=dev)
+    res = []
+    for c in (1, None):
+        yt, dt, ct = T(y, dev, True), T(diag, dev, True), T(cplx, dev, True)
+        ll = celerite_loglike(T(t, dev), yt, dt, T(np.zeros((D, 0, 2)), dev), ct, pair_kind=kt, n_chunks=c)
+        w = torch.linspace(0.5, 1.5, D, dtype=torch.float64, device=dev)
+        (ll * w).sum().backward()
+        res.append([x.detach().cpu().numpy() for x in (ll, yt.grad, dt.grad, ct.grad)])
+    want, got = res
+    assert np.isfinite(want[0]).all()
+    np.testing.assert_allclose(got[0], want[0], rtol=1e-11)
+    for g, w_ in zip(got[1:], want[1:]):
+        for d in range(D):
+            assert np.abs(g[d] - w_[d]).max() <= 2e-8 * np.abs(w_[d]).max(), d
