@@ -346,18 +346,21 @@ def test_c3_timed_step_vs_oracle(dev):
     assert_grads(grads, want, wl.names, rel=2e-6, rows=rows)
 
 
-@pytest.mark.parametrize("D", [128, 1024])
-def test_c5_timed_step_vs_oracle(dev, D):
+@pytest.mark.parametrize("D,bright", [(128, 0), (1024, 0), (128, 2)])
+def test_c5_timed_step_vs_oracle(dev, D, bright):
     """`extras.c5_secondary_eclipse_3term_gp_128_chains` / `bench.py --config c5` on one of eight GPUs (128 chains) and on
     ONE GPU (`--config c5 --gpus 1`: all 1024 chains -- another chunk plan, and the light-curve blocks finish their own
     draws): 65 000 long cadences x 7 sub-exposures, transit + occultation, three SHO terms (J = 6).  The light curve of
-    EVERY chain against the C port; the replayed step's log-likelihood and all 10 leaf gradients for 8 chains"""
+    EVERY chain against the C port; the replayed step's log-likelihood and all 10 leaf gradients for 8 chains.
+    bright = 2: `extras.c5_128_chains_1pct_bright_star_kappa_1e6` -- chains 0 and 1 at a conditioning score of 1e6, finished by
+    the ROBUST route of the time-parallel path at the benchmark's own size: 512 chunks, the serial forward
+    chain, the adjoint inputs from the chunks' own recurrences -- both among the chains checked"""
     import bench
     import exoplanet_amd as xo
     from exoplanet_amd import ops
 
     N = bench.C5_NCAD
-    wl = bench.workload_c5(xo, ops, dev, D, rank=0)
+    wl = bench.workload_c5(xo, ops, dev, D, rank=0, bright=bright)
     oracle_threads()
     lv = dict(zip(wl.names, wl.leaves))
     vals = {k: npy(lv[k]).reshape(D, 1) for k in ORBIT_KEYS + ("r",)}
