@@ -1431,6 +1431,68 @@ __global__ __launch_bounds__(kWave) void celerite_robust_scan_kernel(const doubl
   }
 }
 
+// (B) once more for those draws as NEWTON ITERATIONS from the trees' states (exo_celerite_group.hpp, tan_linearise): one block per
+// draw -- it leaves at once unless the draw is flagged kFlagRobust -- walks, per iteration, the level-0 items (tangent elements
+// of the chunks at the current guess, composed pairwise), the levels of the corrections' scan up and down, and the level-0
+// items again (corrections added), a block barrier between levels.  J >= 3; replaces the serial chain above (kept behind
+// EXO_GP_ROBUST_NEWTON = 0: 1.34 ms at C5 against ~0.5).
+#ifndef EXO_GP_ROBUST_NEWTON
+#define EXO_GP_ROBUST_NEWTON 1
+#endif
+// Iterations: until one's corrections were below EXO_GP_NEWTON_TOL of the states (the next guess is then right to the square
+// of that), at most EXO_GP_NEWTON_ITERS (tools/gp_lab_newton.py, 450 chunks, scores of 1e7 .. 1e8: the guess is off by up to
+// 4e-2, one iteration leaves 4e-7, two 8e-9 -- the serial chain's own distance from the long-double definition)
+#ifndef EXO_GP_NEWTON_ITERS
+#define EXO_GP_NEWTON_ITERS 4
+#endif
+#ifndef EXO_GP_NEWTON_TOL
+#define EXO_GP_NEWTON_TOL 1e-8
+#endif
+template <int J>
+__global__ __launch_bounds__(kScanBlock) void celerite_robust_newton_kernel(int64_t n, ChunkGeom cg, int64_t n_draw, double* state) {
+  __shared__ double lds[(kScanBlock / 8) * GroupLds<J>::S];
+  const ChunkWs ws = chunk_ws(n, n_draw, J, cg);
+  const int64_t draw = blockIdx.x;
+  if (state[ws.off_flag() + draw] != kFlagRobust) return;     // (the whole block)
+  const int tid = threadIdx.x, unit = tid >> 3, n_unit = kScanBlock / 8;
+  Grp<J> g;
+  g.lds = lds + unit * GroupLds<J>::S;
+  g.r = tid & 7;
+  g.live = g.r < J;
+  const int top = ws.tree_top(), n1 = ws.tree_npos(1);
+  __shared__ double s_err[kScanBlock / kWave];
+  for (int it = 0; it < EXO_GP_NEWTON_ITERS; ++it) {
+    for (int i = unit; i < n1; i += n_unit) newton_up0<J>(ws, state, i, draw, g);
+    __syncthreads();
+    for (int f = 1; f + 1 < top; ++f) {
+      const TreeOp op = scan_level_op(ws, J, false, f, false);
+      for (int c = unit; c < op.n_item; c += n_unit) newton_item<J, false>(op, state, c, draw, g);
+      __syncthreads();
+    }
+    {   // nothing to correct in front of the first chunk
+      const int64_t seed = ws.tree_state(top);
+      for (int k = tid; k < J + J * J; k += kScanBlock) state[seed + (int64_t)k * n_draw + draw] = 0.0;
+    }
+    __syncthreads();
+    for (int f = top - 1; f >= 1; --f) {
+      const TreeOp op = scan_level_op(ws, J, false, f, true);
+      for (int c = unit; c < op.n_item; c += n_unit) newton_item<J, true>(op, state, c, draw, g);
+      __syncthreads();
+    }
+    double err = 0.0;
+    for (int i = unit; i < n1; i += n_unit) err = fmax(err, newton_down0<J>(ws, state, i, draw, g));
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) err = fmax(err, __shfl_xor(err, m, 64));
+    if ((tid & 63) == 0) s_err[tid >> 6] = err;
+    __syncthreads();
+    double all = 0.0;
+#pragma unroll
+    for (int w = 0; w < kScanBlock / kWave; ++w) all = fmax(all, s_err[w]);
+    __syncthreads();
+    if (!(all >= EXO_GP_NEWTON_TOL)) break;     // (the same verdict in every thread; a NaN ends it too)
+  }
+}
+
 // (B') part 1 for those draws: the adjoint scan's inputs from the chunks' own reverse recurrences (chunk_adj_lane), written
 // over the chunk's element where badj_prep_lane wrote its own -- launched between that kernel and the adjoint trees, which take
 // them as they are.  A WAVE per (draw, chunk >= 1): the chunk's reverse sweep in eight pieces, a piece on a group of eight
@@ -1594,6 +1656,14 @@ int64_t exo_celerite_state_doubles(int64_t n, int64_t n_draw, int32_t n_real, in
     default: break;                                \
   }
 static_assert(kLaneMaxJ <= 6, "EXO_GP_DISPATCH_LANE lists the state widths of the one-lane path");
+#define EXO_GP_DISPATCH_NEWTON(J_, CALL) \
+  switch (J_) {                          \
+    case 3: { constexpr int JJ = 3; CALL; } break; \
+    case 4: { constexpr int JJ = 4; CALL; } break; \
+    case 5: { constexpr int JJ = 5; CALL; } break; \
+    case 6: { constexpr int JJ = 6; CALL; } break; \
+    default: break;                                \
+  }
 #define EXO_GP_DISPATCH(J_, CALL) \
   switch (J_) {                   \
     case 1: { constexpr int JJ = 1; CALL; } break; \
@@ -1838,8 +1908,13 @@ static int celerite_fwd(const double* t, Series resid, const double* diag, int64
       if (cg.lane) {
         // draws flagged kFlagRobust: their entering states once more, by serial application of the elements
         const dim3 rgrid((unsigned)(J >= 3 ? (n_draw + kWave / 8 - 1) / (kWave / 8) : per_draw.x));
-        EXO_GP_DISPATCH_LANE(J, hipLaunchKernelGGL((celerite_robust_scan_kernel<JJ>), rgrid, block, 0, st, t, cf, n, cg, n_draw,
-                                                   state))
+        if (EXO_GP_ROBUST_NEWTON && J >= 3) {
+          EXO_GP_DISPATCH_NEWTON(J, hipLaunchKernelGGL((celerite_robust_newton_kernel<JJ>), dim3((unsigned)n_draw), dim3(kScanBlock), 0, st,
+                                                       n, cg, n_draw, state))
+        } else {
+          EXO_GP_DISPATCH_LANE(J, hipLaunchKernelGGL((celerite_robust_scan_kernel<JJ>), rgrid, block, 0, st, t, cf, n, cg, n_draw,
+                                                     state))
+        }
         EXO_GP_LAYOUTS(J, cf, hipLaunchKernelGGL((celerite_chunk1_fwd_kernel<(JJ <= kLaneMaxJ ? JJ : 1), NR>), egrid, block, 0,
                                                  st, t, resid, diag, n_diag, n, cf, n_draw, state, cg),
                        hipLaunchKernelGGL(celerite_chunk1_fwd_mixed_kernel, dim3(egrid.x + 1, egrid.y, 2), block, 0, st, t, resid, diag,

@@ -596,4 +596,236 @@ __device__ __forceinline__ void robust_fwd_chain_group(const ChunkWs& ws, double
   }
 }
 
+// ---- the ROBUST route's forward scan as NEWTON ITERATIONS (round 4, late).  The states entering the chunks are the fixed
+// point of  x_(c+1) = f_c(x_c)  (f_c: element c applied to a state); the trees of compositions hand over a GUESS that is wrong
+// by up to 4e-2 for ill-conditioned draws; the serial chain above takes C - 1 dependent applications (1.3 ms at C5).  Newton: every
+// f_c and its linearisation at the current guess -- independent, all chunks at once -- and the linear recurrence of the
+// corrections
+//     dm' = G (dm + dP g) + s,   dP' = G dP G^T + R,      G = A (I + P Jm)^-1,  g = eta - Jm ym,  (s, R) = f_c(x_c) - x_(c+1),
+// solved by a scan of PLAIN PRODUCTS (tangent elements compose without a solve: accurate, like the adjoint tree's).  Quadratic:
+// tools/gp_lab_newton.py, 450 chunks, scores up to 1e8: the guess 4e-2, one iteration 4e-7, two 8e-9 (of the serial chain's
+// gradients).  One block per draw walks the levels with block barriers; the tangent elements and states of levels >= 1 live in
+// the forward trees' (finished) arrays in the adjoint elements' slots (A <- G, b <- g, Cm <- R, eta <- s), level 0 is never
+// stored: its items linearise on the fly (twice on the way up, once more on the way down).
+template <int J>
+struct TanRow {
+  double G[J], R[J], g, s;
+};
+
+// my row of the tangent element of chunk `el` at the state (m, P) against the state (mn, Pn) the guess has behind it
+template <int J>
+__device__ __forceinline__ void tan_linearise(const Grp<J>& g, int r, const ElemRow<J>& el, double m, const double (&P)[J], double mn,
+                                              const double (&Pn)[J], TanRow<J>& o) {
+  g.put_rows(0, el.Jm);
+  g.put_rows(2, el.A);
+  g.put_vec(0, el.eta);
+  g.sync();
+  double X[J], B[2 * J + 1];
+  g.mm(P, 0, X);
+#pragma unroll
+  for (int l = 0; l < J; ++l) {
+    X[l] = g.live ? X[l] + (l == r ? 1.0 : 0.0) : 0.0;
+    B[l] = P[l];
+    B[J + 1 + l] = (g.live && l == r) ? 1.0 : 0.0;
+  }
+  B[J] = m + g.mv(P, 0);
+  g.template solve<2 * J + 1>(X, B);          // [Y P | Y (m + P eta) | Y],  Y = (I + P Jm)^-1
+  double YP[J], Y[J];
+#pragma unroll
+  for (int l = 0; l < J; ++l) { YP[l] = B[l]; Y[l] = B[J + 1 + l]; }
+  g.put_rows(1, YP);
+  g.put_rows(3, Y);
+  g.put_vec(1, B[J]);
+  g.sync();
+  double AY[J], P2[J];
+  g.mm(el.A, 1, AY);
+  g.mm(el.A, 3, o.G);
+  const double m2 = el.b + g.mv(el.A, 1);
+  o.g = el.eta - g.mv(el.Jm, 1);
+  g.mm_t(AY, 2, P2);
+#pragma unroll
+  for (int l = 0; l < J; ++l) P2[l] += el.Cm[l];
+  g.put_rows(4, P2);
+  g.sync();
+  g.sym_from(4, P2);
+  o.s = m2 - mn;
+#pragma unroll
+  for (int l = 0; l < J; ++l) o.R[l] = P2[l] - Pn[l];
+  g.sync();
+}
+template <int J>
+__device__ __forceinline__ void tan_identity(const Grp<J>& g, int r, TanRow<J>& o) {
+#pragma unroll
+  for (int l = 0; l < J; ++l) { o.G[l] = (g.live && l == r) ? 1.0 : 0.0; o.R[l] = 0.0; }
+  o.g = o.s = 0.0;
+}
+// b o a (a acts first):  G = G_b G_a,  g = g_a + G_a^T g_b,  s = G_b (s_a + R_a g_b) + s_b,  R = G_b R_a G_b^T + R_b
+template <int J>
+__device__ __forceinline__ void tan_compose(const Grp<J>& g, const TanRow<J>& a, const TanRow<J>& b, TanRow<J>& o) {
+  g.put_rows(0, a.G);
+  g.put_rows(1, a.R);
+  g.put_rows(2, b.G);
+  g.put_vec(0, b.g);
+  g.sync();
+  g.mm(b.G, 0, o.G);
+  o.g = a.g + g.tmv(0, 0);
+  const double w = a.s + g.mv(a.R, 0);
+  double T[J];
+  g.mm(b.G, 1, T);
+  g.put_vec(1, w);
+  g.sync();
+  o.s = b.s + g.mv(b.G, 1);
+  g.mm_t(T, 2, o.R);
+#pragma unroll
+  for (int l = 0; l < J; ++l) o.R[l] += b.R[l];
+  g.sync();
+}
+// the correction (dm, dP) carried across one tangent element
+template <int J>
+__device__ __forceinline__ void tan_apply(const Grp<J>& g, const TanRow<J>& e, double dm, const double (&dP)[J], double& dm2,
+                                          double (&dP2)[J]) {
+  g.put_rows(0, e.G);
+  g.put_vec(0, e.g);
+  g.sync();
+  const double v = dm + g.mv(dP, 0);
+  double T[J];
+  g.mm_t(dP, 0, T);                      // dP G^T
+  g.put_vec(1, v);
+  g.put_rows(1, T);
+  g.sync();
+  dm2 = e.s + g.mv(e.G, 1);
+  g.mm(e.G, 1, dP2);
+#pragma unroll
+  for (int l = 0; l < J; ++l) dP2[l] += e.R[l];
+  g.sync();
+}
+
+// state entering chunk c of the guess: my entry / my row (plain loads: chain_load_elem's reasoning)
+template <int J>
+__device__ __forceinline__ void newton_load_state(const double* state, const ChunkWs& ws, int c, int64_t draw, int r, double& m,
+                                                  double (&P)[J]) {
+  m = state[ws.bnd(1, c, r, draw)];
+#pragma unroll
+  for (int l = 0; l < J; ++l) P[l] = state[ws.bnd(1, c, J + r * J + l, draw)];
+}
+template <int J>
+__device__ __forceinline__ void newton_elem_of_chunk(const double* state, const ChunkWs& ws, int c, int64_t draw, const Grp<J>& g,
+                                                     int r, TanRow<J>& o) {
+  if (c + 1 >= ws.C) { tan_identity<J>(g, r, o); return; }     // (the last chunk's element takes no state anywhere)
+  ElemRow<J> el;
+  chain_load_elem<J>(state, ws, c, draw, r, el);
+  double m, P[J], mn, Pn[J];
+  newton_load_state<J>(state, ws, c, draw, r, m, P);
+  newton_load_state<J>(state, ws, c + 1, draw, r, mn, Pn);
+  tan_linearise<J>(g, r, el, m, P, mn, Pn, o);
+}
+
+// one level-0 item on the way UP: the tangent elements of chunks 2 i and 2 i + 1 composed into position i of level 1
+template <int J>
+__device__ __forceinline__ void newton_up0(const ChunkWs& ws, double* state, int i, int64_t draw, const Grp<J>& g) {
+  int r = g.live ? g.r : 0;
+  asm volatile("" : "+v"(r));
+  TanRow<J> a, b, o;
+  newton_elem_of_chunk<J>(state, ws, 2 * i, draw, g, r, a);
+  newton_elem_of_chunk<J>(state, ws, 2 * i + 1, draw, g, r, b);
+  tan_compose<J>(g, a, b, o);
+  TreeOp op{};
+  op.n_draw = ws.n_draw; op.dst_elem = ws.tree_elem(1);
+  group_store_elem<J, true>(state, op, i, draw, g, r, o.G, o.g, o.R, o.s, o.R);
+}
+// ... and on the way DOWN: the correction entering chunk 2 i (position i of level 1) added to the guess, carried across
+// chunk 2 i's tangent element (taken at the OLD guess, as on the way up), added to chunk 2 i + 1's
+// Returns the size of the corrections it added: max |dP_jl| / sqrt(P_jj P_ll) over my row (what the iteration count goes by).
+template <int J>
+__device__ __forceinline__ double newton_down0(const ChunkWs& ws, double* state, int i, int64_t draw, const Grp<J>& g) {
+  int r = g.live ? g.r : 0;
+  asm volatile("" : "+v"(r));
+  const int64_t nd = ws.n_draw;
+  const int Bq = J + J * J, a = 2 * i;
+  double dm, dP[J];
+  {
+    const double* q = state + ws.tree_state(1) + ((int64_t)i * Bq) * nd + draw;
+    dm = q[(int64_t)r * nd];
+#pragma unroll
+    for (int l = 0; l < J; ++l) dP[l] = q[(int64_t)(J + r * J + l) * nd];
+  }
+  double m, P[J];
+  newton_load_state<J>(state, ws, a, draw, r, m, P);
+  // |dP_jl| against sqrt(P_jj P_ll): the diagonal through the group's LDS strip
+  auto rel_size = [&](const double (&d)[J], const double (&Q)[J]) {
+    double mine = 0.0;
+#pragma unroll
+    for (int l = 0; l < J; ++l) mine = (l == r) ? Q[l] : mine;
+    g.put_vec(2, mine);
+    g.sync();
+    double dd[J], e = 0.0;
+    g.get_vec(2, dd);
+#pragma unroll
+    for (int l = 0; l < J; ++l) {
+      const double sc = fabs(mine * dd[l]);
+      e = fmax(e, sc > 0.0 ? fabs(d[l]) * exo::fast_rcp(sqrt(sc)) : 0.0);
+    }
+    g.sync();
+    return g.live ? e : 0.0;
+  };
+  double err = (a > 0) ? rel_size(dP, P) : 0.0;
+  if (a + 1 < ws.C) {
+    TanRow<J> e;
+    newton_elem_of_chunk<J>(state, ws, a, draw, g, r, e);
+    double dm2, dP2[J], mn, Pn[J];
+    tan_apply<J>(g, e, dm, dP, dm2, dP2);
+    newton_load_state<J>(state, ws, a + 1, draw, r, mn, Pn);
+    err = fmax(err, rel_size(dP2, Pn));
+    if (g.live) {
+      state[ws.bnd(1, a + 1, r, draw)] = mn + dm2;
+#pragma unroll
+      for (int l = 0; l < J; ++l) state[ws.bnd(1, a + 1, J + r * J + l, draw)] = Pn[l] + dP2[l];
+    }
+  }
+  if (g.live && a > 0) {
+    state[ws.bnd(1, a, r, draw)] = m + dm;
+#pragma unroll
+    for (int l = 0; l < J; ++l) state[ws.bnd(1, a, J + r * J + l, draw)] = P[l] + dP[l];
+  }
+  return err;
+}
+// an item of a level f >= 1 of the corrections' scan: tangent elements composed (UP) / a correction handed down and carried
+// across the left child's element (DOWN); records as the trees' (TreeOp: scan_level_op(ws, J, false, f, down))
+template <int J, bool DOWN>
+__device__ __forceinline__ void newton_item(const TreeOp& op, double* state, int c, int64_t draw, const Grp<J>& g) {
+  int r = g.live ? g.r : 0;
+  asm volatile("" : "+v"(r));
+  const int64_t nd = op.n_draw;
+  const int Bq = J + J * J;
+  auto load_tan = [&](int pos, TanRow<J>& o) {
+    ElemRow<J> el;
+    group_load_elem<J>(state, op, pos, draw, g, r, el, false);
+#pragma unroll
+    for (int l = 0; l < J; ++l) { o.G[l] = el.A[l]; o.R[l] = el.Cm[l]; }
+    o.g = el.b; o.s = el.eta;
+  };
+  if (DOWN) {
+    double dm, dP[J];
+    {
+      const double* q = state + op.par_state + ((int64_t)c * Bq) * nd + draw;
+      dm = g.live ? q[(int64_t)r * nd] : 0.0;
+#pragma unroll
+      for (int l = 0; l < J; ++l) dP[l] = g.live ? q[(int64_t)(J + r * J + l) * nd] : 0.0;
+    }
+    group_put_state<J>(state, op, 2 * c, draw, g, r, dm, dP);
+    if (2 * c + 1 >= op.dst_n) return;
+    TanRow<J> e;
+    load_tan(2 * c, e);
+    double dm2, dP2[J];
+    tan_apply<J>(g, e, dm, dP, dm2, dP2);
+    group_put_state<J>(state, op, 2 * c + 1, draw, g, r, dm2, dP2);
+  } else {
+    TanRow<J> a, b, o;
+    load_tan(2 * c, a);
+    load_tan(2 * c + 1, b);
+    tan_compose<J>(g, a, b, o);
+    group_store_elem<J, true>(state, op, c, draw, g, r, o.G, o.g, o.R, o.s, o.R);
+  }
+}
+
 }  // namespace gp

@@ -1,3 +1,6 @@
+#include <vector>
+#include <cstdio>
+#include <cmath>
 // Test harness ONLY: compiles the one-lane celerite pipeline (exo_celerite_core.hpp) for the host
 // (g++) and runs it lane by lane -- filtering elements, scan, checkpointed chunk recurrences, the
 // adjoint scan and the recomputing reverse recurrences -- so that the whole time-parallel algorithm
@@ -16,6 +19,8 @@ namespace {
 
 int g_serial_scan = 0;   // 1: the serial reference scans (bscan_lane, bscan_vjp_lane) instead of the trees
 int g_robust_flags = 1;  // draws the element lanes flag kFlagRobust take the robust route (as on the device)
+int g_newton = -1;        // experiment: >= 0: that many Newton iterations instead of the serial forward scan (newton_scan)
+int g_newton_verbose = 0;
 int g_adj_pieces = 8;    // the chunk's reverse sweep in that many pieces (chunk_adj_lane), as the device's eight groups of a wave
 int g_adj_roles = 0;     // 1: chunk_adj_lane role by role, as the device's eight lanes run it
 int g_adj_tree = 0;      // experiment (with g_robust): chunk_adj_lane's outputs scanned by the adjoint TREE instead of the serial chain
@@ -23,6 +28,113 @@ int g_hybrid_k = -1;     // experiment (with g_robust): forward scan = k levels 
 int g_robust = 0;        // 1: serial forward scan + the adjoint scan's inputs from the chunks' own recurrences (chunk_adj_lane)
 int g_polish = 0;        // 1: a polish pass over every draw after the chunk recurrences (forward and reverse), as the
                          //    device runs it for the draws whose conditioning asks for it
+
+// EXPERIMENT: the states entering the chunks as the fixed point of  x_(c+1) = f_c(x_c)  (f_c: element c applied), by Newton
+// iterations from the trees' (inaccurate) states: every f_c and its linearisation evaluated at the current guess (all chunks
+// at once on a device), the linear recurrence of the corrections  dP' = G dP G^T + r,  dm' = G dm + G dP g + s  solved
+// (here: serially; on a device a scan of plain products, like the adjoint tree).
+template <int J>
+void newton_scan(int64_t n, int64_t n_draw, double* state, const gp::ChunkGeom& cg, int64_t d, int iters) {
+  const gp::ChunkWs ws = gp::chunk_ws(n, n_draw, J, cg);
+  const int C = cg.C;
+  std::vector<double> m((size_t)C * J), P((size_t)C * J * J);
+  for (int c = 0; c < C; ++c)
+    for (int j = 0; j < J; ++j) {
+      m[c * J + j] = state[ws.bnd(1, c, j, d)];
+      for (int l = 0; l < J; ++l) P[(c * J + j) * J + l] = state[ws.bnd(1, c, J + j * J + l, d)];
+    }
+  std::vector<double> G((size_t)C * J * J), gv((size_t)C * J), rP((size_t)C * J * J), rm((size_t)C * J);
+  double last = 0.0;
+  for (int it = 0; it < iters; ++it) {
+    for (int c = 0; c + 1 < C; ++c) {
+      gp::Elem<J> el;
+      el.load(state, ws, c, d);
+      double X[J][J], B[J][2 * J + 1];
+      for (int j = 0; j < J; ++j) {
+        double pe = m[c * J + j];
+        for (int l = 0; l < J; ++l) {
+          double x = (j == l) ? 1.0 : 0.0;
+          for (int k = 0; k < J; ++k) x += P[(c * J + j) * J + k] * el.Jm[k][l];
+          X[j][l] = x;
+          B[j][l] = P[(c * J + j) * J + l];
+          B[j][J + 1 + l] = (j == l) ? 1.0 : 0.0;
+          pe += P[(c * J + j) * J + l] * el.eta[l];
+        }
+        B[j][J] = pe;
+      }
+      gp::solve_inplace<J, 2 * J + 1>(X, B);      // [Y P | Y (m + P eta) | Y]
+      double m2[J], P2[J][J], Gc[J][J], AY[J][J];
+      for (int j = 0; j < J; ++j) {
+        double mj = el.b[j];
+        for (int l = 0; l < J; ++l) {
+          mj += el.A[j][l] * B[l][J];
+          double v = 0.0, gg = 0.0;
+          for (int k = 0; k < J; ++k) { v += el.A[j][k] * B[k][l]; gg += el.A[j][k] * B[k][J + 1 + l]; }
+          AY[j][l] = v; Gc[j][l] = gg;
+        }
+        m2[j] = mj;
+      }
+      for (int j = 0; j < J; ++j)
+        for (int l = 0; l < J; ++l) {
+          double v = el.Cm[j][l];
+          for (int k = 0; k < J; ++k) v += AY[j][k] * el.A[l][k];
+          P2[j][l] = v;
+        }
+      for (int j = 0; j < J; ++j) {
+        double gj = el.eta[j];
+        for (int l = 0; l < J; ++l) gj -= el.Jm[j][l] * B[l][J];
+        gv[c * J + j] = gj;                                   // g = eta - Jm Y (m + P eta)
+        rm[(c + 1) * J + j] = m2[j] - m[(c + 1) * J + j];
+        for (int l = 0; l < J; ++l) {
+          G[(c * J + j) * J + l] = Gc[j][l];
+          rP[((c + 1) * J + j) * J + l] = 0.5 * (P2[j][l] + P2[l][j]) - P[((c + 1) * J + j) * J + l];
+        }
+      }
+    }
+    // corrections, chunk 0's state exact
+    double dP[J][J] = {}, dm[J] = {};
+    last = 0.0;
+    for (int c = 0; c + 1 < C; ++c) {
+      double T[J][J], nP[J][J], nm[J], dg[J];
+      for (int j = 0; j < J; ++j) {
+        dg[j] = 0.0;
+        for (int l = 0; l < J; ++l) dg[j] += dP[j][l] * gv[c * J + l];
+      }
+      for (int j = 0; j < J; ++j) {
+        double v = rm[(c + 1) * J + j];
+        for (int l = 0; l < J; ++l) {
+          v += G[(c * J + j) * J + l] * (dm[l] + dg[l]);
+          double tv = 0.0;
+          for (int k = 0; k < J; ++k) tv += G[(c * J + j) * J + k] * dP[k][l];
+          T[j][l] = tv;
+        }
+        nm[j] = v;
+      }
+      for (int j = 0; j < J; ++j)
+        for (int l = 0; l < J; ++l) {
+          double v = rP[((c + 1) * J + j) * J + l];
+          for (int k = 0; k < J; ++k) v += T[j][k] * G[(c * J + l) * J + k];
+          nP[j][l] = v;
+        }
+      for (int j = 0; j < J; ++j) {
+        dm[j] = nm[j];
+        m[(c + 1) * J + j] += dm[j];
+        for (int l = 0; l < J; ++l) {
+          dP[j][l] = 0.5 * (nP[j][l] + nP[l][j]);
+          P[((c + 1) * J + j) * J + l] += dP[j][l];
+          const double sc = std::fabs(P[((c + 1) * J + j) * J + j] * P[((c + 1) * J + l) * J + l]);
+          if (sc > 0) last = std::fmax(last, std::fabs(dP[j][l]) / std::sqrt(sc));
+        }
+      }
+    }
+    if (g_newton_verbose) fprintf(stderr, "newton draw %lld it %d: max |dP| / sqrt(Pjj Pll) = %.2e\n", (long long)d, it, last);
+  }
+  for (int c = 1; c < C; ++c)
+    for (int j = 0; j < J; ++j) {
+      state[ws.bnd(1, c, j, d)] = m[c * J + j];
+      for (int l = 0; l < J; ++l) state[ws.bnd(1, c, J + j * J + l, d)] = P[(c * J + j) * J + l];
+    }
+}
 
 template <int J>
 void run_fwd(const double* t, gp::Series rs, const double* diag, int64_t n_diag, int64_t n, const gp::Coefs& cf,
@@ -90,9 +202,13 @@ void run_fwd(const double* t, gp::Series rs, const double* diag, int64_t n_diag,
     for (int64_t d = 0; d < n_draw; ++d) gp::bscan_lane<J>(t, cf, n, n_draw, state, cg, d);
   }
   // the robust route, as the device takes it: draws flagged kFlagRobust get their entering states from the serial scan
+  // (experiment, g_newton >= 0: from that many Newton iterations on the chunk-boundary fixed point, started at the trees' states)
   if (cg.tree && !g_serial_scan && !g_robust && g_robust_flags)
     for (int64_t d = 0; d < n_draw; ++d)
-      if (state[ws.off_flag() + d] == gp::kFlagRobust) gp::bscan_lane<J>(t, cf, n, n_draw, state, cg, d);
+      if (state[ws.off_flag() + d] == gp::kFlagRobust) {
+        if (g_newton >= 0) newton_scan<J>(n, n_draw, state, cg, d, g_newton);
+        else gp::bscan_lane<J>(t, cf, n, n_draw, state, cg, d);
+      }
   if (g_polish < 0 && ((-g_polish) & 1)) {
     // experiment: the chunks ONE AFTER THE OTHER, each entered with what its predecessor just left -- the sequential algorithm
     // in chunk-sized steps (exact boundary states): what the accuracy would be if the scans were perfect
@@ -209,6 +325,7 @@ void harness_set_robust(int v) { g_robust = v; }
 void harness_set_adj_tree(int v) { g_adj_tree = v; }
 void harness_set_adj_roles(int v) { g_adj_roles = v; }
 void harness_set_adj_pieces(int v) { g_adj_pieces = v; }
+void harness_set_newton(int v, int verbose) { g_newton = v; g_newton_verbose = verbose; }
 void harness_set_hybrid_k(int v) { g_hybrid_k = v; }
 void harness_set_robust_flags(int v) { g_robust_flags = v; }
 // (experiments: where the checkpoints -- the states (F, packed S) entering every ckpt_span(J)-th cadence -- live in `state`)

@@ -393,7 +393,7 @@ def test_library_keeps_nothing_between_calls(dev):
 @pytest.mark.parametrize("name,D,C", [("three_sho_j6", 13, None), ("mixed_j5", 70, None), ("sho_q3", 9, 11), ("real1", 5, 2)])
 def test_robust_route_whole_batch(dev, name, D, C):
     """EVERY draw of the batch above the trees' conditioning thresholds (a signal 3e3 .. 3e4 x the error bars: scores of 1e7 ..
-    9e8 / 10 -- under the robust route's 1e8): the serial forward chain and the adjoint inputs from the chunks' own recurrences
+    9e8 / 10 -- under the robust route's 1e8): Newton iterations on the entering states and the adjoint inputs from the chunks' own recurrences
      for a number of draws that fills no block evenly, state widths 2, 5 and 6, forced chunk counts down to two --
     against the sequential kernels, which since round 4 carry the oscillation-rate gradient as a phase flux too"""
     rng = np.random.default_rng(21)
@@ -412,7 +412,9 @@ def test_robust_route_whole_batch(dev, name, D, C):
     with chunks(C):
         got = value_and_grads(dev, t, y, diag, cr, cc)
     assert not np.array_equal(got[0], want[0])                       # (not the sequential kernels' bits: the route was taken)
-    np.testing.assert_allclose(got[0], want[0], rtol=1e-9)
+    # (white noise of the signal's variance against error bars 3e3 .. 9e3 times smaller: log-likelihoods of -1e7 .. -8e7 whose
+    # terms carry the conditioning score times the rounding -- two algorithms meet at a few 1e-9 of them)
+    np.testing.assert_allclose(got[0], want[0], rtol=3e-9)
     for g, w in zip(got[1:], want[1:]):
         if w.size:
             for d in range(D):
