@@ -743,7 +743,7 @@ def extra_gp_conditioning(xo, ops, dev, D):
                    "device: no wave of mixed kinds, no run-time layout; what is left of the 1.84x of round 3 is one more round of resident "
                    "waves for the second kind's wave).  `*_bright_star_*`: 1 % of the draws at a conditioning score of 1e6 "
                    "(J = 2: under the threshold of the scan trees) / 3e5 (J = 4: above the 3e4 of wider states -- those draws take the "
-                   "robust route of the time-parallel path, DESIGN.md section 3.11: serial application of the elements forward, the "
+                   "robust route of the time-parallel path, DESIGN.md section 3.11: Newton iterations on the chunks' entering states, the "
                    "adjoint scan fed from the chunks' own reverse recurrences; the sequential kernels that used to redo them cost 27x)")
     return out
 
@@ -1207,8 +1207,8 @@ def main():
             out["over_clean"] = out["median_ms"] / clean if clean else None
             out["same_step_as"] = None
             out["note"] = ("the C5 step at 128 chains with 2 of them (1 %) at a conditioning score of 1e6 (first SHO term 1000 x the error "
-                           "bars): those chains take the robust route of the time-parallel path -- serial scans on a group of eight "
-                           "lanes, the adjoint scan's inputs from the chunks' own reverse recurrences -- instead of the sequential "
+                           "bars): those chains take the robust route of the time-parallel path -- Newton iterations on the states "
+                           "entering the chunks, the adjoint scan's inputs from the chunks' own reverse recurrences -- instead of the sequential "
                            "kernels (VERDICT r3 item 2b: <= 2 x the clean step); " + out["note"])
             return out
         leg("c5_128_chains_1pct_bright_star_kappa_1e6", c5_bright)

@@ -27,7 +27,7 @@
 //    CHECKPOINTED factorisation: the forward pass stores (F, S) every 4 cadences (10 B per (draw,
 //    cadence) at J = 2 instead of 80), the reverse pass recomputes the cadences of a block from its
 //    checkpoint in registers.  Draws too ill-conditioned for the scans' trees of element compositions (a score up to
-//    1e8) stay on this path by its ROBUST route: the elements applied serially (celerite_robust_scan_kernel), the
+//    1e8) stay on this path by its ROBUST route: Newton iterations on the chunks' entering states (celerite_robust_newton_kernel), the
 //    adjoint scan fed from the chunks' own reverse recurrences (celerite_chunk_adj_kernel) -- DESIGN.md 3.11.
 // The library keeps no state between calls: how a series is cut is a pure function of the call's
 // arguments (gp::chunk_plan), which the forward and the reverse call of a pair share.
@@ -1906,7 +1906,8 @@ static int celerite_fwd(const double* t, Series resid, const double* diag, int64
         if (rc != EXO_OK) return rc;
       }
       if (cg.lane) {
-        // draws flagged kFlagRobust: their entering states once more, by serial application of the elements
+        // draws flagged kFlagRobust: their entering states once more -- Newton iterations from the trees' (J <= 2: the elements
+        // applied one after the other)
         const dim3 rgrid((unsigned)(J >= 3 ? (n_draw + kWave / 8 - 1) / (kWave / 8) : per_draw.x));
         if (EXO_GP_ROBUST_NEWTON && J >= 3) {
           EXO_GP_DISPATCH_NEWTON(J, hipLaunchKernelGGL((celerite_robust_newton_kernel<JJ>), dim3((unsigned)n_draw), dim3(kScanBlock), 0, st,

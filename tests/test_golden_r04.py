@@ -115,3 +115,30 @@ def test_reverse_sweep_in_pieces_and_by_roles(harness):  # noqa: F811
         ref = res[1, 0, key]
         for other in ((8, 1), (3, 1)):
             assert np.abs(res[other + (key,)] - ref).max() <= 1e-9 * np.abs(ref).max()
+
+
+def test_newton_iterations_reach_the_serial_chain(harness):  # noqa: F811
+    """the device's forward scan for ill-conditioned draws (exo_celerite_group.hpp, tan_linearise): Newton iterations on the fixed
+    point x_(c+1) = f_c(x_c) of the states entering the chunks, started at the trees' states -- here with the corrections'
+    linear recurrence solved serially (tests/gp_host_harness.cpp, newton_scan).  Zero iterations = the trees' states: well off
+    on these kernels; two iterations: the serial chain's gradients to 1e-8 and the long-double definition's to 1e-8"""
+    res = {}
+    try:
+        for iters in (-1, 0, 2):
+            harness.harness_set_newton(iters, 0)
+            for key in ("c22", "c24"):
+                t, y, diag, co, want = case(key)
+                ar, cr, ac, bc, cc, dc = co
+                real = np.stack([ar, cr], -1)[None]
+                cplx = np.stack([ac, bc, cc, dc], -1)[None]
+                ll, flags, C_used, gr = run(harness, t, y[None], diag[None], real, cplx, gll=np.ones(1))
+                got = {"y": gr["y"][0], "diag": gr["diag"][0], "ar": gr["real"][0, :, 0], "cr": gr["real"][0, :, 1]}
+                got.update({nm: gr["cplx"][0, :, q] for q, nm in enumerate(("ac", "bc", "cc", "dc"))})
+                res[iters, key] = (worst(got, key), np.concatenate([got[k].ravel() for k in sorted(got)]))
+    finally:
+        harness.harness_set_newton(-1, 0)
+    for key in ("c22", "c24"):
+        assert res[0, key][0] > 30 * res[2, key][0]        # the trees' states (with the robust route's adjoint side): 5e-7 / 2e-8
+        assert res[2, key][0] <= 1e-8
+        chain, newton = res[-1, key][1], res[2, key][1]
+        assert np.abs(newton - chain).max() <= 1e-8 * np.abs(chain).max()

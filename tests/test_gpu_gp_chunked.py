@@ -390,16 +390,16 @@ def test_library_keeps_nothing_between_calls(dev):
                     np.testing.assert_allclose(a, b, rtol=2e-7, atol=1e-9 * np.abs(b).max())
 
 
-@pytest.mark.parametrize("name,D,C", [("three_sho_j6", 13, None), ("mixed_j5", 70, None), ("sho_q3", 9, 11), ("real1", 5, 2)])
-def test_robust_route_whole_batch(dev, name, D, C):
+@pytest.mark.parametrize("name,D,C,N", [("three_sho_j6", 13, None, 2100), ("mixed_j5", 70, None, 2100), ("sho_q3", 9, 11, 2100),
+                                        ("real1", 5, 2, 2100), ("three_sho_j6", 5, 500, 16000), ("mixed_j5", 3, 333, 12000)])
+def test_robust_route_whole_batch(dev, name, D, C, N):
     """EVERY draw of the batch above the trees' conditioning thresholds (a signal 3e3 .. 3e4 x the error bars: scores of 1e7 ..
     9e8 / 10 -- under the robust route's 1e8): Newton iterations on the entering states and the adjoint inputs from the chunks' own recurrences
      for a number of draws that fills no block evenly, state widths 2, 5 and 6, forced chunk counts down to two --
     against the sequential kernels, which since round 4 carry the oscillation-rate gradient as a phase flux too"""
     rng = np.random.default_rng(21)
-    N = 2100
-    t = np.sort(rng.uniform(0, 80, N))
-    if name not in KERNELS:
+    t = np.sort(rng.uniform(0, 80 * N / 2100, N))      # (the last two cases: hundreds of chunks -- the depth of the trees whose states the
+    if name not in KERNELS:                            # Newton iterations start from)
         pytest.skip("kernel not in the table")
     cr, cc = batch(rng, name, D)
     amp = cr[..., 0].sum(-1) + cc[..., 0].sum(-1)
