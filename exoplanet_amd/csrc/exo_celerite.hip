@@ -1448,19 +1448,23 @@ __global__ __launch_bounds__(kWave) void celerite_robust_scan_kernel(const doubl
 #ifndef EXO_GP_NEWTON_TOL
 #define EXO_GP_NEWTON_TOL 1e-8
 #endif
+#ifndef EXO_GP_NEWTON_BLOCK
+#define EXO_GP_NEWTON_BLOCK 256   // (512: 64 items at a time, but 256 registers a lane -- scratch at J = 6 -- and 0.54 ms against 0.43)
+#endif
+constexpr int kNewtonBlock = EXO_GP_NEWTON_BLOCK;   // threads of a draw's block: 8 per item of a level
 template <int J>
-__global__ __launch_bounds__(kScanBlock) void celerite_robust_newton_kernel(int64_t n, ChunkGeom cg, int64_t n_draw, double* state) {
-  __shared__ double lds[(kScanBlock / 8) * GroupLds<J>::S];
+__global__ __launch_bounds__(kNewtonBlock) void celerite_robust_newton_kernel(int64_t n, ChunkGeom cg, int64_t n_draw, double* state) {
+  __shared__ double lds[(kNewtonBlock / 8) * GroupLds<J>::S];
   const ChunkWs ws = chunk_ws(n, n_draw, J, cg);
   const int64_t draw = blockIdx.x;
   if (state[ws.off_flag() + draw] != kFlagRobust) return;     // (the whole block)
-  const int tid = threadIdx.x, unit = tid >> 3, n_unit = kScanBlock / 8;
+  const int tid = threadIdx.x, unit = tid >> 3, n_unit = kNewtonBlock / 8;
   Grp<J> g;
   g.lds = lds + unit * GroupLds<J>::S;
   g.r = tid & 7;
   g.live = g.r < J;
   const int top = ws.tree_top(), n1 = ws.tree_npos(1);
-  __shared__ double s_err[kScanBlock / kWave];
+  __shared__ double s_err[kNewtonBlock / kWave];
   for (int it = 0; it < EXO_GP_NEWTON_ITERS; ++it) {
     for (int i = unit; i < n1; i += n_unit) newton_up0<J>(ws, state, i, draw, g);
     __syncthreads();
@@ -1471,7 +1475,7 @@ __global__ __launch_bounds__(kScanBlock) void celerite_robust_newton_kernel(int6
     }
     {   // nothing to correct in front of the first chunk
       const int64_t seed = ws.tree_state(top);
-      for (int k = tid; k < J + J * J; k += kScanBlock) state[seed + (int64_t)k * n_draw + draw] = 0.0;
+      for (int k = tid; k < J + J * J; k += kNewtonBlock) state[seed + (int64_t)k * n_draw + draw] = 0.0;
     }
     __syncthreads();
     for (int f = top - 1; f >= 1; --f) {
@@ -1487,7 +1491,7 @@ __global__ __launch_bounds__(kScanBlock) void celerite_robust_newton_kernel(int6
     __syncthreads();
     double all = 0.0;
 #pragma unroll
-    for (int w = 0; w < kScanBlock / kWave; ++w) all = fmax(all, s_err[w]);
+    for (int w = 0; w < kNewtonBlock / kWave; ++w) all = fmax(all, s_err[w]);
     __syncthreads();
     if (!(all >= EXO_GP_NEWTON_TOL)) break;     // (the same verdict in every thread; a NaN ends it too)
   }
@@ -1910,7 +1914,7 @@ static int celerite_fwd(const double* t, Series resid, const double* diag, int64
         // applied one after the other)
         const dim3 rgrid((unsigned)(J >= 3 ? (n_draw + kWave / 8 - 1) / (kWave / 8) : per_draw.x));
         if (EXO_GP_ROBUST_NEWTON && J >= 3) {
-          EXO_GP_DISPATCH_NEWTON(J, hipLaunchKernelGGL((celerite_robust_newton_kernel<JJ>), dim3((unsigned)n_draw), dim3(kScanBlock), 0, st,
+          EXO_GP_DISPATCH_NEWTON(J, hipLaunchKernelGGL((celerite_robust_newton_kernel<JJ>), dim3((unsigned)n_draw), dim3(kNewtonBlock), 0, st,
                                                        n, cg, n_draw, state))
         } else {
           EXO_GP_DISPATCH_LANE(J, hipLaunchKernelGGL((celerite_robust_scan_kernel<JJ>), rgrid, block, 0, st, t, cf, n, cg, n_draw,
