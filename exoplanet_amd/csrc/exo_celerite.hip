@@ -1465,6 +1465,7 @@ __global__ __launch_bounds__(kNewtonBlock) void celerite_robust_newton_kernel(in
   g.live = g.r < J;
   const int top = ws.tree_top(), n1 = ws.tree_npos(1);
   __shared__ double s_err[kNewtonBlock / kWave];
+  bool converged = false;
   for (int it = 0; it < EXO_GP_NEWTON_ITERS; ++it) {
     for (int i = unit; i < n1; i += n_unit) newton_up0<J>(ws, state, i, draw, g);
     __syncthreads();
@@ -1493,7 +1494,13 @@ __global__ __launch_bounds__(kNewtonBlock) void celerite_robust_newton_kernel(in
 #pragma unroll
     for (int w = 0; w < kNewtonBlock / kWave; ++w) all = fmax(all, s_err[w]);
     __syncthreads();
-    if (!(all >= EXO_GP_NEWTON_TOL)) break;     // (the same verdict in every thread; a NaN ends it too)
+    if (all < EXO_GP_NEWTON_TOL) { converged = true; break; }     // (the same verdict in every thread)
+  }
+  // not there after the last iteration, or a NaN on the way (a guess the iterations could not start from): the elements applied
+  // one after the other -- the serial chain needs no guess -- by the block's first eight lanes
+  if (!converged && tid < 8) {
+    static_assert(ChainLds<J>::S <= (kNewtonBlock / 8) * GroupLds<J>::S, "the chain's strip inside the block's LDS");
+    robust_fwd_chain_group<J>(ws, state, draw, lds, tid);
   }
 }
 
