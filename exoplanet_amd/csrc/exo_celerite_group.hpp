@@ -428,10 +428,6 @@ __device__ __forceinline__ void tree_item_group(const TreeOp& op, double* state,
 // write -> read round trips a step (6 + 1) instead of eleven, no IEEE division.
 template <int CTRL>
 __device__ __forceinline__ int grp_dpp_int(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false); }
-template <int CTRL>
-__device__ __forceinline__ double grp_dpp(double v) {
-  return __hiloint2double(grp_dpp_int<CTRL>(__double2hiint(v)), grp_dpp_int<CTRL>(__double2loint(v)));
-}
 // the lane (0 .. 7) holding the largest a >= 0 of the aligned group of eight lanes; of (nearly) equal values the lowest lane.
 // One 64-bit key per lane -- the bits of a non-negative double order like the number; its three lowest bits give way to
 // 7 - lane -- and a butterfly of maxima: quad_perm [1,0,3,2], [2,3,0,1], then lane ^ 4 (row_shr / row_shl by 4; BOTH moves by
