@@ -1510,7 +1510,7 @@ __global__ __launch_bounds__(kNewtonBlock) void celerite_robust_newton_kernel(in
 // lanes (chunk_adj_lane's roles: the state adjoints, the J columns of X, R), the pieces' records multiplied back together
 // through LDS (adj_combine_lane).  Nothing but latency -- 1.2 ms for a 127-cadence chunk on one lane at J = 6, 0.7 ms on eight
 // lanes by roles, ~0.2 ms in eight pieces.  A block looks at its draws' flags and, almost always, leaves at once.
-constexpr int kAdjDraws = 8;
+constexpr int kAdjDraws = 32;   // (8: 14 us of empty blocks for a clean batch of the C3 shape; 64: a batch of nothing but such draws 64 deep)
 template <int J>
 __global__ __launch_bounds__(kWave) void celerite_chunk_adj_kernel(const double* __restrict__ t, Series rs,
                                                                    const double* __restrict__ diag, int64_t n_diag, int64_t n,
@@ -1521,7 +1521,7 @@ __global__ __launch_bounds__(kWave) void celerite_chunk_adj_kernel(const double*
   __shared__ double rec[kPieces * kRec];
   const ChunkWs ws = chunk_ws(n, n_draw, J, cg);
   // (a block looks at kAdjDraws consecutive draws: a batch of nothing but such draws works them kAdjDraws deep, a clean batch
-  // pays (C - 1) n_draw / kAdjDraws empty blocks -- ~10 us at the C3 shape)
+  // pays (C - 1) n_draw / kAdjDraws empty blocks -- ~5 us at the C3 shape)
   const int64_t d0 = (int64_t)blockIdx.y * kAdjDraws, dl = d0 + threadIdx.x;
   const bool look = threadIdx.x < kAdjDraws && dl < n_draw;
   unsigned long long todo = __ballot(look && state[ws.off_flag() + (look ? dl : 0)] == kFlagRobust);
