@@ -120,6 +120,7 @@ _SIGNATURES = {
     "exo_sho_coefficients_multi_f64": (ctypes.c_int, [_c_dp, _c_dp, _c_dp, _c_dp, _i32, ctypes.c_double, _i64, _c_dp, _c_dp, _c_dp]),
     "exo_sho_coefficients_multi_vjp_f64": (ctypes.c_int, [_c_dp, _c_dp, _c_dp, _c_dp, _i32, ctypes.c_double, _i64, _c_dp, _c_dp,
                                                           _c_dp, _c_dp, _c_dp]),
+    "exo_transit_sparse_scatter_f64": (ctypes.c_int, [_c_dp, _i64, _i64, _i64, _i32, ctypes.c_uint32, _i32, _c_dp, _c_dp]),
     "exo_pack_records_f64": (ctypes.c_int, [_c_dp, _c_dp, _i64, _i32, _u32, _c_dp, _c_dp, _c_dp]),
     "exo_pack_records_vjp_f64": (ctypes.c_int, [_c_dp, _c_dp, _i64, _i32, _u32, _c_dp, _c_dp, _c_dp, _c_dp, _c_dp]),
     # cols, draw_stride, planet_stride, defaults, ld_cols, ld_draw_stride (host arrays), n_draw, n_planet, flags, ...

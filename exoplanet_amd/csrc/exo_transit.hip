@@ -2852,6 +2852,41 @@ inline int launch_runs_sweep(const double* t, int64_t n_cad, const double* texp,
   return launch_status();
 }
 
+// A DENSE flux array kept across steps (exo_transit_sparse_scatter_f64): the summed flux of the cadences in a sparse output's
+// runs written into -- or, CLEAR, zeroed in -- a dense [n_draw][n_cad] array that is otherwise left alone.  A step of a sampler
+// solves the same few per cent of the cadences as the step before it: clear the last step's, write this one's, and the
+// dense result costs the sparse sweep plus two passes over the solved cadences instead of a fill of every cadence (1.2 GB at
+// C2).  A block per draw; a wave per run (its cadences are consecutive: coalesced); planets in order with a block barrier,
+// the first one storing and the later ones adding with the hardware's fp64 atomic -- the dense sweep's own order, so the
+// same bits.
+template <bool CLEAR>
+__global__ __launch_bounds__(kBlock) void transit_scatter_runs_kernel(RunLists rl, const double* __restrict__ vals, int64_t n_cad,
+                                                                      int n_planet, int n_ev, double* __restrict__ flux) {
+  const int64_t draw = blockIdx.x;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, n_wave = kBlock / 64;
+  double* __restrict__ row = flux + draw * n_cad;
+  for (int p = 0; p < n_planet; ++p) {
+    int64_t vbase = (draw * n_planet + p) * n_cad;      // the planet's values: transits first, occultations behind them
+    for (int ev = 0; ev < n_ev; ++ev) {
+      const int64_t list = (draw * n_planet + p) * n_ev + ev;
+      const int K = rl.nrun[list];
+      const Run* __restrict__ runs = rl.runs + list * rl.r_max;
+      const int32_t* __restrict__ pall = rl.pre_all + list * (rl.r_max + 1);
+      for (int k = wave; k < K; k += n_wave) {
+        const int lo = runs[k].lo, len = runs[k].hi - lo;
+        const int64_t v0 = vbase + pall[k];
+        for (int i = lane; i < len; i += 64) {
+          if (CLEAR) row[lo + i] = 0.0;
+          else if (p == 0) row[lo + i] = vals[v0 + i];
+          else unsafeAtomicAdd(row + lo + i, vals[v0 + i]);
+        }
+      }
+      vbase += pall[K];
+    }
+    if (!CLEAR && p + 1 < n_planet) __syncthreads();   // planets in order
+  }
+}
+
 // every flag bit a sweep knows; anything else is a newer header talking to this library (ABI 10: refused, not ignored --
 // a layout flag this build does not know would otherwise come back as a silently different array)
 inline bool sweep_flags_ok(uint32_t flags) { return (flags & ~(uint32_t)EXO_FLAG_SWEEP_ALL) == 0; }
@@ -2922,6 +2957,25 @@ int exo_transit_flux_sparse_layout(int64_t n_cad, int64_t n_draw, int32_t n_plan
   const RunWs r = carve_runs(nullptr, n_cad, n_draw, n_planet);
   out[0] = r.off_nrun; out[1] = r.off_runs; out[2] = r.off_pre_all; out[3] = r.off_vals; out[4] = r.rl.r_max;
   return EXO_OK;
+}
+
+int exo_transit_sparse_scatter_f64(const void* workspace, int64_t workspace_bytes, int64_t n_cad, int64_t n_draw, int32_t n_planet,
+                                   uint32_t flags, int32_t clear, double* flux, void* stream) {
+  if (n_cad < 0 || n_draw < 0 || n_draw > 65535 || n_planet < 1 || n_planet > EXO_MAX_PLANETS ||
+      (flags & ~(uint32_t)EXO_FLAG_SECONDARY))
+    return EXO_ERR_INVALID_ARGUMENT;
+  if (n_cad == 0 || n_draw == 0) return EXO_OK;
+  if (!flux) return EXO_ERR_INVALID_ARGUMENT;
+  const RunWs rw = carve_runs(const_cast<void*>(workspace), n_cad, n_draw, n_planet);
+  if (!workspace || workspace_bytes < rw.bytes) return EXO_ERR_WORKSPACE;
+  const int n_ev = (flags & EXO_FLAG_SECONDARY) ? 2 : 1;
+  if (clear)
+    hipLaunchKernelGGL(transit_scatter_runs_kernel<true>, dim3((unsigned)n_draw), dim3(kBlock), 0, (hipStream_t)stream, rw.rl, rw.vals,
+                       n_cad, (int)n_planet, n_ev, flux);
+  else
+    hipLaunchKernelGGL(transit_scatter_runs_kernel<false>, dim3((unsigned)n_draw), dim3(kBlock), 0, (hipStream_t)stream, rw.rl, rw.vals,
+                       n_cad, (int)n_planet, n_ev, flux);
+  return launch_status();
 }
 
 // forward sweep; ttv.edges == nullptr: no timing variations

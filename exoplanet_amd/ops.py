@@ -727,7 +727,7 @@ class SparseFlux:
 
 
 @torch.no_grad()
-def transit_flux_sparse(t, params, ld, gflux=None, texp=None, stencil_dt=None, stencil_w=None, flags=0, ttv=None):
+def transit_flux_sparse(t, params, ld, gflux=None, texp=None, stencil_dt=None, stencil_w=None, flags=0, ttv=None, ws=None):
     """Sparse sweep: no dense flux array is written.  Returns a :class:`SparseFlux`, and with
     ``gflux`` (dense cotangent, read only at the solved cadences) also (gparams, gld, dot[, gshift]).
     Needs sorted times, a scalar (or no) exposure time and no FLAG_EXACT_SCAN; ``ttv = (edges, shift)``:
@@ -741,7 +741,10 @@ def transit_flux_sparse(t, params, ld, gflux=None, texp=None, stencil_dt=None, s
     N = t.numel()
     lib = _lib.load()
     nbytes = lib.exo_transit_flux_workspace_bytes(N, D, P)
-    ws = torch.empty(max(nbytes // 8 + 1, 1), dtype=torch.float64, device=t.device)
+    if ws is None:
+        ws = torch.empty(max(nbytes // 8 + 1, 1), dtype=torch.float64, device=t.device)
+    elif ws.dtype != torch.float64 or ws.numel() * 8 < nbytes or not ws.is_contiguous() or ws.device != t.device:
+        raise ValueError("ws: a contiguous float64 tensor of at least exo_transit_flux_workspace_bytes on the device of t")
     import ctypes
 
     lay = (ctypes.c_int64 * 5)()
@@ -774,6 +777,45 @@ def transit_flux_sparse(t, params, ld, gflux=None, texp=None, stencil_dt=None, s
                                                 _ptr(ld), D, P, flags, _ptr(gflux), 0, _ptr(gparams), _ptr(gld), _ptr(dot),
                                                 _ptr(ws), nbytes, _stream(t)), "exo_transit_flux_vjp_f64")
     return SparseFlux(ws, list(lay), N, D, P, n_ev), gparams, gld, dot
+
+
+class KeptDenseFlux:
+    """A dense (D, N) flux array KEPT ACROSS STEPS (include/exoplanet_amd.h, exo_transit_sparse_scatter_f64).
+
+    The dense sweep zero-fills every cadence of every draw on every call (1.2 GB at 1024 draws x 150 000 cadences) although a
+    step of a sampler solves the same few per cent of them as the step before.  This object owns the flux array and the
+    sweep's workspace: ``step`` zeroes the cadences the LAST step solved, runs the sparse sweep, and writes the cadences THIS
+    step solved -- after every step ``flux`` holds what ``transit_flux`` / ``transit_flux_vjp`` would have returned, bit for
+    bit, for the price of the sparse sweep.  The state is this object's, not the library's; ``flux`` must not be written by
+    anyone else.  Total flux, run-enumeration sweeps (sorted times, a scalar or no exposure time), no timing tables."""
+
+    def __init__(self, t, n_draw, n_planet, texp=None, stencil_dt=None, stencil_w=None, flags=0):
+        if int(flags) & (FLAG_PER_PLANET | FLAG_CADENCE_MAJOR | FLAG_EXACT_SCAN | FLAG_SPARSE):
+            raise ValueError("KeptDenseFlux: the summed flux in rows, run-enumeration sweeps")
+        self.t = _dev(t, "t")
+        self.texp, self.stencil = texp, (stencil_dt, stencil_w)
+        self.flags = int(flags)
+        self.D, self.P, self.N = int(n_draw), int(n_planet), self.t.numel()
+        self._nbytes = _lib.load().exo_transit_flux_workspace_bytes(self.N, self.D, self.P)
+        # zeroed: a workspace without runs (the first step has nothing to clear), a flux array without a transit
+        self._ws = torch.zeros(max(self._nbytes // 8 + 1, 1), dtype=torch.float64, device=self.t.device)
+        self.flux = torch.zeros(self.D, self.N, dtype=torch.float64, device=self.t.device)
+
+    def _scatter(self, clear):
+        with torch.cuda.device(self.t.device):
+            _lib.check(_lib.load().exo_transit_sparse_scatter_f64(_ptr(self._ws), self._nbytes, self.N, self.D, self.P,
+                                                                  self.flags & FLAG_SECONDARY, 1 if clear else 0, _ptr(self.flux),
+                                                                  _stream(self.t)), "exo_transit_sparse_scatter_f64")
+
+    @torch.no_grad()
+    def step(self, params, ld, gflux=None):
+        """-> flux (D, N) [, gparams, gld, dot with a cotangent ``gflux`` (D, N)]; ``flux`` is this object's array"""
+        if params.shape[0] != self.D or params.shape[1] != self.P:
+            raise ValueError("params: (n_draw, n_planet, NPAR) as this object was made for")
+        self._scatter(True)
+        out = transit_flux_sparse(self.t, params, ld, gflux, self.texp, self.stencil[0], self.stencil[1], self.flags, ws=self._ws)
+        self._scatter(False)
+        return self.flux if gflux is None else (self.flux,) + tuple(out[1:])
 
 
 # ------------------------------------------------------------------------------
