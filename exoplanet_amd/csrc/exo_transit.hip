@@ -2869,19 +2869,25 @@ __global__ __launch_bounds__(kBlock) void transit_scatter_runs_kernel(RunLists r
     int64_t vbase = (draw * n_planet + p) * n_cad;      // the planet's values: transits first, occultations behind them
     for (int ev = 0; ev < n_ev; ++ev) {
       const int64_t list = (draw * n_planet + p) * n_ev + ev;
-      const int K = rl.nrun[list];
+      // (a workspace that is not a sparse output -- never zeroed, never swept -- must not become a wild store: counts and
+      // cadences are held to the arrays' bounds)
+      int K = rl.nrun[list];
+      K = K < 0 ? 0 : (K > rl.r_max ? rl.r_max : K);
       const Run* __restrict__ runs = rl.runs + list * rl.r_max;
       const int32_t* __restrict__ pall = rl.pre_all + list * (rl.r_max + 1);
       for (int k = wave; k < K; k += n_wave) {
-        const int lo = runs[k].lo, len = runs[k].hi - lo;
-        const int64_t v0 = vbase + pall[k];
+        int lo = runs[k].lo, len = runs[k].hi - lo;
+        const int pk = pall[k];
+        if (lo < 0 || len < 0 || (int64_t)lo + len > n_cad || pk < 0 || (int64_t)pk + len > n_cad) continue;
+        const int64_t v0 = vbase + pk;
         for (int i = lane; i < len; i += 64) {
           if (CLEAR) row[lo + i] = 0.0;
           else if (p == 0) row[lo + i] = vals[v0 + i];
           else unsafeAtomicAdd(row + lo + i, vals[v0 + i]);
         }
       }
-      vbase += pall[K];
+      const int tot = pall[K];
+      vbase += (tot < 0 || tot > n_cad) ? 0 : tot;
     }
     if (!CLEAR && p + 1 < n_planet) __syncthreads();   // planets in order
   }
