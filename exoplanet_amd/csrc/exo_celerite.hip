@@ -531,7 +531,7 @@ __global__ __launch_bounds__(kWave) void celerite_vjp_kernel(
       }
     }
     {
-      const double Ub_o = __shfl(Ub, partner, 64), Vb_o = __shfl(Vb, partner, 64);
+      const double Ub_o = __shfl(Ub, partner, 64);
       if (k.live && !k.real && !k.odd) {
         ga += Ub * cs + Ub_o * sn;
         gb += Ub * sn - Ub_o * cs;
@@ -559,14 +559,8 @@ __global__ __launch_bounds__(kWave) void celerite_vjp_kernel(
       if (gdiag) gdiag[draw * n] = dbar;
     }
     gasum += dbar;
-    const double t0 = t[0];
-    double Uj, Vj, Vo, P0;
-    load_uvp(0, Uj, Vj, Vo, P0);
-    const double cs = k.odd ? Vo : Vj, sn = k.odd ? Vj : Vo;
-    const double Vb = Wb * id;
-    const double Vb_o = __shfl(Vb, partner, 64);
-    // (cadence 0's phase cotangent has no link in front of it: the phases are counted from t_0, Coefs::origin)
-    (void)t0; (void)cs; (void)sn; (void)Vb_o;
+    // (cadence 0's phase cotangent has no link in front of it -- the phases are counted from t_0, Coefs::origin -- and its
+    // U, V carry no other parameter: nothing more to collect)
   }
   // the decay rate of a complex pair is shared by its two state indices
   const double gc_o = __shfl(gc, partner, 64);
