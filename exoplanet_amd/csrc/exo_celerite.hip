@@ -1742,7 +1742,11 @@ __global__ __launch_bounds__(1024) void celerite_kind_partition_kernel(const int
 // on the other side of Q = 1/2 paid twice the clean batch's time.  The layouts keep their own code (compile-time NR); the
 // kernel's registers are those of the widest variant -- the same waves per SIMD as each alone (145 / 118 / 159, 113 / 100 /
 // 124, 217 / 186 / 239 registers for element / forward / reverse).
-__global__ __launch_bounds__(kWave) void celerite_elem_mixed_kernel(const double* __restrict__ t, Series rs,
+// (four waves per SIMD without the look-ahead load of the next block: elem_lane's PREFETCH)
+#ifndef EXO_ELEM_MIXED_WAVES
+#define EXO_ELEM_MIXED_WAVES 4
+#endif
+__global__ __launch_bounds__(kWave, EXO_ELEM_MIXED_WAVES) void celerite_elem_mixed_kernel(const double* __restrict__ t, Series rs,
                                                                     const double* __restrict__ diag, int64_t n_diag, int64_t n,
                                                                     Coefs cf, int64_t n_draw, double* __restrict__ state,
                                                                     ChunkGeom cg, int64_t flag_at) {
@@ -1751,9 +1755,9 @@ __global__ __launch_bounds__(kWave) void celerite_elem_mixed_kernel(const double
   const int nr = layout_vote<2>(cf, draw);
   const int c = (int)blockIdx.y;
   if (blockIdx.z == 0) {
-    if (nr == 0) elem_lane<2, 0>(t, rs, diag, n_diag, n, cf, n_draw, state, cg, draw, c, flag_at);
+    if (nr == 0) elem_lane<2, 0, EXO_ELEM_MIXED_WAVES < 4>(t, rs, diag, n_diag, n, cf, n_draw, state, cg, draw, c, flag_at);
   } else {
-    if (nr == 2) elem_lane<2, 2>(t, rs, diag, n_diag, n, cf, n_draw, state, cg, draw, c, flag_at);
+    if (nr == 2) elem_lane<2, 2, EXO_ELEM_MIXED_WAVES < 4>(t, rs, diag, n_diag, n, cf, n_draw, state, cg, draw, c, flag_at);
   }   // (no wave is of mixed kinds: mixed_draw)
 }
 // (four waves per SIMD asked for: the three inlined layouts sit at 129 registers otherwise, and the plan offers four)

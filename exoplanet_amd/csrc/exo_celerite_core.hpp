@@ -676,7 +676,10 @@ EXO_HD void with_layout(const Coefs& cf, int64_t draw, F&& f) {
 
 // (A) the filtering element of one (draw, chunk)
 // (flag_at: where the draw flags live when cg is a fine geometry, -1: cg's own)
-template <int J, int NR = -1>
+// PREFETCH: the next block's series in flight while this one is worked through.  Off for J <= 2 on the device (round 4): its
+// sixteen registers are the difference between three and four waves per SIMD there, and a 1024-draw batch is 4096 waves --
+// 1.33 rounds of resident waves at three per SIMD, one round at four: element kernel 0.90 -> 0.82 ms at C3.
+template <int J, int NR = -1, bool PREFETCH = true>
 EXO_HD void elem_lane(const double* EXO_RESTRICT t, Series rs, const double* EXO_RESTRICT diag, int64_t n_diag,
                       int64_t n, const Coefs& cf, int64_t n_draw, double* EXO_RESTRICT state, const ChunkGeom& cg,
                       int64_t draw, int c, int64_t flag_at = -1) {
@@ -754,7 +757,7 @@ EXO_HD void elem_lane(const double* EXO_RESTRICT t, Series rs, const double* EXO
   load_block(y, dg, n_diag, n0, n1, cur);
 #pragma unroll 1
   for (int64_t b0 = n0; b0 < n1; b0 += 4) {
-   load_block(y, dg, n_diag, b0 + 4, n1, nxt);   // in flight while this block is worked through
+   if (PREFETCH) load_block(y, dg, n_diag, b0 + 4, n1, nxt);   // in flight while this block is worked through
 #pragma unroll
    for (int q = 0; q < 4; ++q) {
     const int64_t i = b0 + q;
@@ -805,7 +808,8 @@ EXO_HD void elem_lane(const double* EXO_RESTRICT t, Series rs, const double* EXO
     }
     }
    }
-   cur = nxt;
+   if (PREFETCH) cur = nxt;
+   else load_block(y, dg, n_diag, b0 + 4, n1, cur);
   }
   if (!ok) flag_raise(state + (flag_at >= 0 ? flag_at : ws.off_flag()) + draw, ok_robust ? kFlagRobust : kFlagSeq);
   int e = 0;
