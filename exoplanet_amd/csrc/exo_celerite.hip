@@ -1330,9 +1330,13 @@ __global__ __launch_bounds__(kWave) void celerite_scan_init_kernel(const double*
 // at run time.  Every variant is a kernel of its own (its own register budget); a wave votes on the
 // layout of its draws (layout_vote) and returns at once from the variants it did not vote for, so the
 // host may launch several variants of one step when pair kinds are given per draw.
+// (J <= 2: four waves per SIMD without the look-ahead load of the next block -- elem_lane's PREFETCH)
+#ifndef EXO_ELEM_MIXED_WAVES
+#define EXO_ELEM_MIXED_WAVES 4
+#endif
 // (A) the filtering element of every (draw, chunk)
 template <int J, int NR>
-__global__ __launch_bounds__(kWave) void celerite_elem_kernel(const double* __restrict__ t, Series rs,
+__global__ __launch_bounds__(kWave, (J <= 2 ? EXO_ELEM_MIXED_WAVES : 1)) void celerite_elem_kernel(const double* __restrict__ t, Series rs,
                                                               const double* __restrict__ diag, int64_t n_diag, int64_t n,
                                                               Coefs cf, int64_t n_draw, double* __restrict__ state,
                                                               ChunkGeom cg, int64_t flag_at) {
@@ -1342,7 +1346,7 @@ __global__ __launch_bounds__(kWave) void celerite_elem_kernel(const double* __re
   if constexpr (J > 2 && NR == -1 && EXO_GP_WIDE_COMPLEX_LAYOUT) {   // a wave of all-complex draws takes the compile-time layout
     if (vote == 0) { elem_lane<J, 0>(t, rs, diag, n_diag, n, cf, n_draw, state, cg, draw, (int)blockIdx.y, flag_at); return; }
   } else if (vote != NR) return;
-  elem_lane<J, NR>(t, rs, diag, n_diag, n, cf, n_draw, state, cg, draw, (int)blockIdx.y, flag_at);
+  elem_lane<J, NR, (J > 2 || EXO_ELEM_MIXED_WAVES < 4)>(t, rs, diag, n_diag, n, cf, n_draw, state, cg, draw, (int)blockIdx.y, flag_at);
 }
 
 // (B), (B'): the scans over the chunks are trees of compositions (celerite_tree_kernel, celerite_compose_lds_kernel above).
@@ -1742,10 +1746,6 @@ __global__ __launch_bounds__(1024) void celerite_kind_partition_kernel(const int
 // on the other side of Q = 1/2 paid twice the clean batch's time.  The layouts keep their own code (compile-time NR); the
 // kernel's registers are those of the widest variant -- the same waves per SIMD as each alone (145 / 118 / 159, 113 / 100 /
 // 124, 217 / 186 / 239 registers for element / forward / reverse).
-// (four waves per SIMD without the look-ahead load of the next block: elem_lane's PREFETCH)
-#ifndef EXO_ELEM_MIXED_WAVES
-#define EXO_ELEM_MIXED_WAVES 4
-#endif
 __global__ __launch_bounds__(kWave, EXO_ELEM_MIXED_WAVES) void celerite_elem_mixed_kernel(const double* __restrict__ t, Series rs,
                                                                     const double* __restrict__ diag, int64_t n_diag, int64_t n,
                                                                     Coefs cf, int64_t n_draw, double* __restrict__ state,
