@@ -1761,7 +1761,10 @@ __global__ __launch_bounds__(kWave, EXO_ELEM_MIXED_WAVES) void celerite_elem_mix
   }   // (no wave is of mixed kinds: mixed_draw)
 }
 // (four waves per SIMD asked for: the three inlined layouts sit at 129 registers otherwise, and the plan offers four)
-__global__ __launch_bounds__(kWave, 4) void celerite_chunk1_fwd_mixed_kernel(const double* __restrict__ t, Series rs,
+#ifndef EXO_FWD_MIXED_WAVES
+#define EXO_FWD_MIXED_WAVES 4
+#endif
+__global__ __launch_bounds__(kWave, EXO_FWD_MIXED_WAVES) void celerite_chunk1_fwd_mixed_kernel(const double* __restrict__ t, Series rs,
                                                                           const double* __restrict__ diag, int64_t n_diag,
                                                                           int64_t n, Coefs cf, int64_t n_draw,
                                                                           double* __restrict__ state, ChunkGeom cg) {

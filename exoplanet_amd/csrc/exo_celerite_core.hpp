@@ -1588,6 +1588,10 @@ struct Phi {
 
 // (C) forward: acc = sum z^2 / d, log det and the "not positive definite" mark of the chunk go to the
 // chunk partials; (F, S) at the first cadence of every checkpoint block goes to the checkpoints.
+#ifndef EXO_FWD_PREFETCH_J2
+#define EXO_FWD_PREFETCH_J2 1     // (0 = no look-ahead load in the J <= 2 forward sweep: measured, no gain at four waves per SIMD -- 707 against
+                                  // 711 us at C3 --, slower at five -- 794: scratch)
+#endif
 template <int J, int NR = -1>
 EXO_HD void chunk1_fwd_lane(const double* EXO_RESTRICT t, Series rs, const double* EXO_RESTRICT diag, int64_t n_diag,
                             int64_t n, const Coefs& cf, int64_t n_draw, double* EXO_RESTRICT state, const ChunkGeom& cg,
@@ -1639,7 +1643,8 @@ EXO_HD void chunk1_fwd_lane(const double* EXO_RESTRICT t, Series rs, const doubl
   load_block(y, dg, n_diag, n0, n1, cur);
 #pragma unroll 1
   for (int64_t b0 = n0; b0 < n1; b0 += kCkptB) {
-    load_block(y, dg, n_diag, b0 + kCkptB, n1, nxt);   // in flight while this block is worked through
+    constexpr bool kAhead = J > 2 || EXO_FWD_PREFETCH_J2;
+    if (kAhead) load_block(y, dg, n_diag, b0 + kCkptB, n1, nxt);   // in flight while this block is worked through
 #pragma unroll
     for (int q = 0; q < kCkptB; ++q) {
       const int64_t i = b0 + q;
@@ -1673,7 +1678,8 @@ EXO_HD void chunk1_fwd_lane(const double* EXO_RESTRICT t, Series rs, const doubl
         lsum += lexp;
       }
     }
-    cur = nxt;
+    if (J > 2 || EXO_FWD_PREFETCH_J2) cur = nxt;
+    else load_block(y, dg, n_diag, b0 + kCkptB, n1, cur);
   }
   state[ws.part(c, 0, draw)] = acc;
   state[ws.part(c, 1, draw)] = log(lman) + (double)lsum * 0.69314718055994530942;
