@@ -1330,20 +1330,32 @@ __global__ __launch_bounds__(kWave) void celerite_scan_init_kernel(const double*
 // at run time.  Every variant is a kernel of its own (its own register budget); a wave votes on the
 // layout of its draws (layout_vote) and returns at once from the variants it did not vote for, so the
 // host may launch several variants of one step when pair kinds are given per draw.
+// J = 4 (two SHO terms, a RotationTerm): the all-complex layout as kernels OF ITS OWN (launched beside the run-time-layout ones;
+// a wave runs the one it voted for).  Inside one kernel -- as J = 6, 8 have it -- the registers are those of the heavier
+// run-time layout: forward 204 against 162 (two waves per SIMD against three), and element / reverse sit 14 / 24 registers above
+// the 256 of TWO waves per SIMD, which they are held to here (EXO_J4_WAVES): a 1024-draw batch is 4096 waves -- four rounds of
+// resident waves at one per SIMD, two at two.
+#ifndef EXO_J4_SPLIT
+#define EXO_J4_SPLIT 1
+#endif
+#ifndef EXO_J4_WAVES
+#define EXO_J4_WAVES 2
+#endif
+constexpr bool split_layouts(int J) { return EXO_J4_SPLIT && J == 4; }
 // (J <= 2: four waves per SIMD without the look-ahead load of the next block -- elem_lane's PREFETCH)
 #ifndef EXO_ELEM_MIXED_WAVES
 #define EXO_ELEM_MIXED_WAVES 4
 #endif
 // (A) the filtering element of every (draw, chunk)
 template <int J, int NR>
-__global__ __launch_bounds__(kWave, (J <= 2 ? EXO_ELEM_MIXED_WAVES : 1)) void celerite_elem_kernel(const double* __restrict__ t, Series rs,
+__global__ __launch_bounds__(kWave, (J <= 2 ? EXO_ELEM_MIXED_WAVES : (split_layouts(J) && NR == 0 ? EXO_J4_WAVES : 1))) void celerite_elem_kernel(const double* __restrict__ t, Series rs,
                                                               const double* __restrict__ diag, int64_t n_diag, int64_t n,
                                                               Coefs cf, int64_t n_draw, double* __restrict__ state,
                                                               ChunkGeom cg, int64_t flag_at) {
   const int64_t draw = (int64_t)blockIdx.x * kWave + threadIdx.x;
   if (draw >= n_draw) return;
   const int vote = layout_vote<J>(cf, draw);
-  if constexpr (J > 2 && NR == -1 && EXO_GP_WIDE_COMPLEX_LAYOUT) {   // a wave of all-complex draws takes the compile-time layout
+  if constexpr (J > 2 && NR == -1 && EXO_GP_WIDE_COMPLEX_LAYOUT && !split_layouts(J)) {   // a wave of all-complex draws takes the compile-time layout
     if (vote == 0) { elem_lane<J, 0>(t, rs, diag, n_diag, n, cf, n_draw, state, cg, draw, (int)blockIdx.y, flag_at); return; }
   } else if (vote != NR) return;
   elem_lane<J, NR, (J > 2 || EXO_ELEM_MIXED_WAVES < 4)>(t, rs, diag, n_diag, n, cf, n_draw, state, cg, draw, (int)blockIdx.y, flag_at);
@@ -1362,14 +1374,14 @@ __global__ __launch_bounds__(kWave) void celerite_badj_prep_kernel(const double*
 
 // (C) / (C') with a checkpointed factorisation, J <= kLaneMaxJ
 template <int J, int NR>
-__global__ __launch_bounds__(kWave) void celerite_chunk1_fwd_kernel(const double* __restrict__ t, Series rs,
+__global__ __launch_bounds__(kWave, (split_layouts(J) && NR == 0 ? 3 : 1)) void celerite_chunk1_fwd_kernel(const double* __restrict__ t, Series rs,
                                                                     const double* __restrict__ diag, int64_t n_diag,
                                                                     int64_t n, Coefs cf, int64_t n_draw,
                                                                     double* __restrict__ state, ChunkGeom cg) {
   const int64_t draw = (int64_t)blockIdx.x * kWave + threadIdx.x;
   if (draw >= n_draw) return;
   const int vote = layout_vote<J>(cf, draw);
-  if constexpr (J > 2 && NR == -1 && EXO_GP_WIDE_COMPLEX_LAYOUT) {
+  if constexpr (J > 2 && NR == -1 && EXO_GP_WIDE_COMPLEX_LAYOUT && !split_layouts(J)) {
     if (vote == 0) { chunk1_fwd_lane<J, 0>(t, rs, diag, n_diag, n, cf, n_draw, state, cg, draw, (int)blockIdx.y, true); return; }
   } else if (vote != NR) return;
   chunk1_fwd_lane<J, NR>(t, rs, diag, n_diag, n, cf, n_draw, state, cg, draw, (int)blockIdx.y, true);
@@ -1382,7 +1394,7 @@ __global__ __launch_bounds__(kWave) void celerite_chunk1_fwd_kernel(const double
 #define EXO_VJPP_WAVES 2
 #endif
 template <int J, int NR>
-__global__ __launch_bounds__(kWave, (J < EXO_SPAN2_MIN_J ? EXO_VJP1_WAVES : (J <= 2 ? EXO_VJPP_WAVES : 1))) void celerite_chunk1_vjp_kernel(const double* __restrict__ t, Series rs,
+__global__ __launch_bounds__(kWave, (J < EXO_SPAN2_MIN_J ? EXO_VJP1_WAVES : (J <= 2 ? EXO_VJPP_WAVES : (split_layouts(J) && NR == 0 ? EXO_J4_WAVES : 1)))) void celerite_chunk1_vjp_kernel(const double* __restrict__ t, Series rs,
                                                                     const double* __restrict__ diag, int64_t n_diag,
                                                                     int64_t n, Coefs cf, int64_t n_draw,
                                                                     const double* __restrict__ gloglike,
@@ -1392,10 +1404,11 @@ __global__ __launch_bounds__(kWave, (J < EXO_SPAN2_MIN_J ? EXO_VJP1_WAVES : (J <
   const int64_t draw = (int64_t)blockIdx.x * kWave + threadIdx.x;
   if (draw >= n_draw) return;
   const int vote = layout_vote<J>(cf, draw);
-  if (!(J > 2 && NR == -1 && EXO_GP_WIDE_COMPLEX_LAYOUT) && vote != NR) return;
+  constexpr bool kBoth = J > 2 && NR == -1 && EXO_GP_WIDE_COMPLEX_LAYOUT && !split_layouts(J);   // (both layouts in this kernel)
+  if (!kBoth && vote != NR) return;
   if constexpr (J >= EXO_SPAN2_MIN_J) {   // wide states: packed adjoint, two checkpoints per block, cotangent accumulators in LDS columns
     __shared__ double gacc[4 * J + 1][kWave];
-    if constexpr (J > 2 && NR == -1 && EXO_GP_WIDE_COMPLEX_LAYOUT) {
+    if constexpr (kBoth) {
       if (vote == 0) {
         chunkp_vjp_lane<J, 0>(t, rs, diag, n_diag, n, cf, n_draw, gloglike, state, cg, gresid, gdiag, gsign, draw, (int)blockIdx.y,
                               &gacc[0][threadIdx.x], kWave);
@@ -1811,7 +1824,10 @@ __global__ __launch_bounds__(kWave, EXO_VJP1_WAVES) void celerite_chunk1_vjp_mix
       }                                                                                 \
       break;                                                                            \
     case 3: { constexpr int JJ = 3, NR = -1; CALL; } break;                             \
-    case 4: { constexpr int JJ = 4, NR = -1; CALL; } break;                             \
+    case 4:                                                                             \
+      if (split_layouts(4) && (CF).n_real == 0) { constexpr int JJ = 4, NR = 0; CALL; }   \
+      { constexpr int JJ = 4, NR = -1; CALL; }                                          \
+      break;                                                                            \
     case 5: { constexpr int JJ = 5, NR = -1; CALL; } break;                             \
     case 6: { constexpr int JJ = 6, NR = -1; CALL; } break;                             \
     case 7: { constexpr int JJ = 7, NR = -1; CALL; } break;                             \
@@ -2125,3 +2141,4 @@ int exo_celerite_predict_f64(const double* t, int64_t n, const double* alpha, co
 }
 
 }  // extern "C"
+
