@@ -599,7 +599,8 @@ int exo_sho_coefficients_vjp_f64(const double* amp, const double* freq, const do
                                  int64_t n, const double* gcoef, double* gamp, double* gfreq, double* gdamp,
                                  void* stream);
 
-/* A dense flux array KEPT ACROSS STEPS.  `workspace` holds the sparse output of an EXO_FLAG_SPARSE sweep (same n_cad, n_draw,
+/* A dense flux array KEPT ACROSS STEPS (the dense light curve a sampler asks LimbDarkLightCurve.get_light_curve for at every step:
+ * src/exoplanet/light_curves/limb_dark.py:163-170, 228-230).  `workspace` holds the sparse output of an EXO_FLAG_SPARSE sweep (same n_cad, n_draw,
  * n_planet; flags: EXO_FLAG_SECONDARY as in that sweep, nothing else).  clear == 0: the summed flux of the cadences in its runs
  * is written into flux[n_draw][n_cad] (planets in order: the bits of the dense sweep), every other entry left alone;
  * clear != 0: those entries are zeroed.  A caller that keeps `flux` and `workspace` from step to step -- zero-initialised
@@ -610,7 +611,8 @@ int exo_sho_coefficients_vjp_f64(const double* amp, const double* freq, const do
 int exo_transit_sparse_scatter_f64(const void* workspace, int64_t workspace_bytes, int64_t n_cad, int64_t n_draw, int32_t n_planet,
                                    uint32_t flags, int32_t clear, double* flux, void* stream);
 
-/* A SUM of SHO terms (celerite2: term_1 + term_2 + ...), all of it in one launch each way: term k reads its own
+/* A SUM of SHO terms (celerite2's terms.TermSum, term_1 + term_2 + ...; celerite2 is a dependency of the reference,
+ * /root/reference/setup.py:36, its terms are what the reference's GP models are built from), all of it in one launch each way: term k reads its own
  * amp[k], freq[k], damp[k] (host arrays of n_terms <= EXO_SHO_MAX_TERMS device pointers to n doubles each) under its own
  * flags[k], and owns slot k of coef[n][n_terms][4] and kind[n][n_terms] -- the pair-slot arrays the celerite entry points
  * take (no concatenation; the reverse reads gcoef[n][n_terms][4] in place and writes every term's gamp / gfreq / gdamp[n]). */
