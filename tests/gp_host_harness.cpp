@@ -21,6 +21,7 @@ int g_serial_scan = 0;   // 1: the serial reference scans (bscan_lane, bscan_vjp
 int g_robust_flags = 1;  // draws the element lanes flag kFlagRobust take the robust route (as on the device)
 int g_newton = -1;        // experiment: >= 0: that many Newton iterations instead of the serial forward scan (newton_scan)
 int g_newton_verbose = 0;
+int g_newton_tree = 0;     // the corrections' recurrence by the device's tree of plain products instead of serially
 int g_adj_pieces = 8;    // the chunk's reverse sweep in that many pieces (chunk_adj_lane), as the device's eight groups of a wave
 int g_adj_roles = 0;     // 1: chunk_adj_lane role by role, as the device's eight lanes run it
 int g_adj_tree = 0;      // experiment (with g_robust): chunk_adj_lane's outputs scanned by the adjoint TREE instead of the serial chain
@@ -90,6 +91,119 @@ void newton_scan(int64_t n, int64_t n_draw, double* state, const gp::ChunkGeom& 
           rP[((c + 1) * J + j) * J + l] = 0.5 * (P2[j][l] + P2[l][j]) - P[((c + 1) * J + j) * J + l];
         }
       }
+    }
+    if (g_newton_tree) {
+      // ... the linear recurrence as the device solves it: tangent elements composed pairwise, level by level, by plain
+      // products (exo_celerite_group.hpp, tan_compose), a zero correction in front of the first chunk handed back down
+      // (tan_apply).  Element c (G, g, s, R) carries a correction from chunk c to chunk c + 1.
+      struct Tan { double G[J][J], g[J], s[J], R[J][J]; };
+      auto compose = [](const Tan& a, const Tan& b) {       // b o a
+        Tan o;
+        for (int j = 0; j < J; ++j) {
+          double gg = a.g[j], w = 0.0;
+          for (int k = 0; k < J; ++k) gg += a.G[k][j] * b.g[k];
+          o.g[j] = gg;
+          (void)w;
+          for (int l = 0; l < J; ++l) {
+            double v = 0.0;
+            for (int k = 0; k < J; ++k) v += b.G[j][k] * a.G[k][l];
+            o.G[j][l] = v;
+          }
+        }
+        double wv[J], T[J][J];
+        for (int j = 0; j < J; ++j) {
+          double v = a.s[j];
+          for (int l = 0; l < J; ++l) v += a.R[j][l] * b.g[l];
+          wv[j] = v;
+        }
+        for (int j = 0; j < J; ++j) {
+          double v = b.s[j];
+          for (int k = 0; k < J; ++k) v += b.G[j][k] * wv[k];
+          o.s[j] = v;
+          for (int l = 0; l < J; ++l) {
+            double tv = 0.0;
+            for (int k = 0; k < J; ++k) tv += b.G[j][k] * a.R[k][l];
+            T[j][l] = tv;
+          }
+        }
+        for (int j = 0; j < J; ++j)
+          for (int l = 0; l < J; ++l) {
+            double v = b.R[j][l];
+            for (int k = 0; k < J; ++k) v += T[j][k] * b.G[l][k];
+            o.R[j][l] = v;
+          }
+        return o;
+      };
+      auto ident = [] {
+        Tan o{};
+        for (int j = 0; j < J; ++j) o.G[j][j] = 1.0;
+        return o;
+      };
+      std::vector<std::vector<Tan>> lev(1);
+      lev[0].resize(C);
+      for (int c = 0; c < C; ++c) {
+        if (c + 1 >= C) { lev[0][c] = ident(); continue; }
+        Tan& e = lev[0][c];
+        for (int j = 0; j < J; ++j) {
+          e.g[j] = gv[c * J + j];
+          e.s[j] = rm[(c + 1) * J + j];
+          for (int l = 0; l < J; ++l) { e.G[j][l] = G[(c * J + j) * J + l]; e.R[j][l] = rP[((c + 1) * J + j) * J + l]; }
+        }
+      }
+      while (lev.back().size() > 1) {
+        const std::vector<Tan>& src = lev.back();
+        std::vector<Tan> dst((src.size() + 1) / 2);
+        for (size_t i = 0; i < dst.size(); ++i) dst[i] = compose(src[2 * i], 2 * i + 1 < src.size() ? src[2 * i + 1] : ident());
+        lev.push_back(dst);
+      }
+      struct St { double dm[J], dP[J][J]; };
+      std::vector<St> cur(1, St{}), nxt;
+      for (int f = (int)lev.size() - 2; f >= 0; --f) {
+        nxt.assign(lev[f].size(), St{});
+        for (size_t i = 0; i < cur.size(); ++i) {
+          nxt[2 * i] = cur[i];
+          if (2 * i + 1 >= lev[f].size()) continue;
+          const Tan& e = lev[f][2 * i];
+          St o;
+          double v[J], T[J][J];
+          for (int j = 0; j < J; ++j) {
+            double x = cur[i].dm[j];
+            for (int l = 0; l < J; ++l) x += cur[i].dP[j][l] * e.g[l];
+            v[j] = x;
+          }
+          for (int j = 0; j < J; ++j) {
+            double x = e.s[j];
+            for (int k = 0; k < J; ++k) x += e.G[j][k] * v[k];
+            o.dm[j] = x;
+            for (int l = 0; l < J; ++l) {
+              double tv = 0.0;
+              for (int k = 0; k < J; ++k) tv += cur[i].dP[j][k] * e.G[l][k];
+              T[j][l] = tv;
+            }
+          }
+          for (int j = 0; j < J; ++j)
+            for (int l = 0; l < J; ++l) {
+              double x = e.R[j][l];
+              for (int k = 0; k < J; ++k) x += e.G[j][k] * T[k][l];
+              o.dP[j][l] = x;
+            }
+          nxt[2 * i + 1] = o;
+        }
+        cur.swap(nxt);
+      }
+      last = 0.0;
+      for (int c = 1; c < C; ++c)
+        for (int j = 0; j < J; ++j) {
+          m[c * J + j] += cur[c].dm[j];
+          for (int l = 0; l < J; ++l) {
+            P[(c * J + j) * J + l] += cur[c].dP[j][l];
+            const double sc = std::fabs(P[(c * J + j) * J + j] * P[(c * J + l) * J + l]);
+            if (sc > 0) last = std::fmax(last, std::fabs(cur[c].dP[j][l]) / std::sqrt(sc));
+          }
+        }
+      if (g_newton_verbose) fprintf(stderr, "newton (tree) draw %lld it %d: max |dP| / sqrt(Pjj Pll) = %.2e\n", (long long)d, it, last);
+      if (last < 1e-8) break;
+      continue;
     }
     // corrections, chunk 0's state exact
     double dP[J][J] = {}, dm[J] = {};
@@ -326,6 +440,7 @@ void harness_set_adj_tree(int v) { g_adj_tree = v; }
 void harness_set_adj_roles(int v) { g_adj_roles = v; }
 void harness_set_adj_pieces(int v) { g_adj_pieces = v; }
 void harness_set_newton(int v, int verbose) { g_newton = v; g_newton_verbose = verbose; }
+void harness_set_newton_tree(int v) { g_newton_tree = v; }
 void harness_set_hybrid_k(int v) { g_hybrid_k = v; }
 void harness_set_robust_flags(int v) { g_robust_flags = v; }
 // (experiments: where the checkpoints -- the states (F, packed S) entering every ckpt_span(J)-th cadence -- live in `state`)

@@ -124,8 +124,11 @@ def test_newton_iterations_reach_the_serial_chain(harness):  # noqa: F811
     on these kernels; two iterations: the serial chain's gradients to 1e-8 and the long-double definition's to 1e-8"""
     res = {}
     try:
-        for iters in (-1, 0, 2):
-            harness.harness_set_newton(iters, 0)
+        for iters in (-1, 0, 2, 104):
+            # (104: up to four iterations, stopped by the size of their corrections, the corrections' recurrence solved by
+            # the device's TREE of plain products -- tan_compose / tan_apply -- instead of serially)
+            harness.harness_set_newton_tree(1 if iters >= 100 else 0)
+            harness.harness_set_newton(iters % 100 if iters >= 0 else iters, 0)
             for key in ("c22", "c24"):
                 t, y, diag, co, want = case(key)
                 ar, cr, ac, bc, cc, dc = co
@@ -137,7 +140,10 @@ def test_newton_iterations_reach_the_serial_chain(harness):  # noqa: F811
                 res[iters, key] = (worst(got, key), np.concatenate([got[k].ravel() for k in sorted(got)]))
     finally:
         harness.harness_set_newton(-1, 0)
+        harness.harness_set_newton_tree(0)
     for key in ("c22", "c24"):
+        assert res[104, key][0] <= 1e-8
+        assert np.abs(res[104, key][1] - res[-1, key][1]).max() <= 1e-8 * np.abs(res[-1, key][1]).max()
         assert res[0, key][0] > 30 * res[2, key][0]        # the trees' states (with the robust route's adjoint side): 5e-7 / 2e-8
         assert res[2, key][0] <= 1e-8
         chain, newton = res[-1, key][1], res[2, key][1]

@@ -12,6 +12,7 @@ import subprocess
 out = os.path.join(R, "tests", "_build", "lab_newton.so")
 subprocess.run(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", out, os.path.join(R, "tests", "gp_host_harness.cpp")], check=True)
 lib = ctypes.CDLL(out); lib.harness_gp_state_doubles.restype = ctypes.c_int64
+lib.harness_set_newton_tree(int(os.environ.get('LAB_NEWTON_TREE', '0')))   # 1: the corrections' recurrence by the tree of plain products
 KS = (0, 1, 2, 3, 4, 6)
 worst = {k: [] for k in KS}
 n_chunks_of = lambda t: max(2, t.size // int(sys.argv[3])) if len(sys.argv) > 3 else 0
