@@ -35,6 +35,27 @@ struct GroupLds {
   static constexpr int S = ((raw - 4 + 31) / 32) * 32 + 4;
 };
 
+template <int CTRL>
+__device__ __forceinline__ int grp_dpp_int(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false); }
+// the lane (0 .. 7) holding the largest a >= 0 of the aligned group of eight lanes; of (nearly) equal values the lowest lane.
+// One 64-bit key per lane -- the bits of a non-negative double order like the number; its three lowest bits give way to
+// 7 - lane -- and a butterfly of maxima: quad_perm [1,0,3,2], [2,3,0,1], then lane ^ 4 (row_shr / row_shl by 4; BOTH moves by
+// every lane, then the choice: inside a branch the other quad is switched off, and a DPP read of a switched-off lane returns
+// nothing).  a < 0 (a row already used, a lane past the state width): never chosen.
+__device__ __forceinline__ int grp_argmax8(double a, int lane8) {
+  unsigned long long key = (a >= 0.0) ? (((unsigned long long)__double_as_longlong(a) & ~7ull) | (unsigned)(7 - lane8)) + 8ull : 0ull;
+  auto mx = [&](unsigned long long o) { key = o > key ? o : key; };
+  auto mv = [](auto tag, unsigned long long k) {
+    constexpr int CTRL = decltype(tag)::value;
+    return ((unsigned long long)(unsigned)grp_dpp_int<CTRL>((int)(k >> 32)) << 32) | (unsigned)grp_dpp_int<CTRL>((int)k);
+  };
+  mx(mv(std::integral_constant<int, 0xB1>{}, key));
+  mx(mv(std::integral_constant<int, 0x4E>{}, key));
+  const unsigned long long dn = mv(std::integral_constant<int, 0x114>{}, key), up = mv(std::integral_constant<int, 0x104>{}, key);
+  mx((threadIdx.x & 4) ? dn : up);
+  return 7 - (int)(key & 7ull);
+}
+
 // the eight lanes of one item
 template <int J>
 struct Grp {
@@ -142,47 +163,33 @@ struct Grp {
   template <int NB>
   __device__ __forceinline__ void solve(double (&M)[J], double (&R)[NB]) const {
     static_assert(J + NB <= L::WS, "Gauss-Jordan row does not fit its strip");
-    unsigned done = 0u;
+    // (round 4, late -- the serial chain's step, robust_fwd_chain_group, carried over: the pivot of a step is found in
+    // registers, a DPP butterfly of 64-bit keys over the eight lanes, instead of every lane publishing its row and reading a
+    // column back; only the pivot's lane scales its row -- by a Newton reciprocal, not an IEEE division -- and publishes it)
+    const int lane8 = (int)(threadIdx.x & 7);
     int mine = -1;                 // the unknown my row solves for
+    double* prow = gj();
 #pragma unroll
     for (int k = 0; k < J; ++k) {
-      double* rows = gj();
-      sync();
-      if (live) {
-        double* p = rows + r * L::WS;
-        // (columns < k of M are settled -- 0, or 1 in a pivot's own column -- and are not read again)
-#pragma unroll
-        for (int l = k; l < J; ++l) p[l] = M[l];
-#pragma unroll
-        for (int l = 0; l < NB; ++l) p[J + l] = R[l];
-      }
-      sync();
-      int piv = 0;
-      double best = -1.0;
-#pragma unroll
-      for (int i = 0; i < J; ++i) {
-        const double a = ((done >> i) & 1u) ? -1.0 : fabs(rows[i * L::WS + k]);
-        const bool better = a > best;          // (first of equals: as solve_inplace; a NaN never wins)
-        best = better ? a : best;
-        piv = better ? i : piv;
-      }
-      done |= 1u << piv;
-      const bool is_piv = live && r == piv;
+      const double a = (live && mine < 0) ? fabs(M[k]) : -1.0;
+      const int piv = grp_argmax8(a, lane8);
+      const bool is_piv = lane8 == piv;
       mine = is_piv ? k : mine;
-      const double* prow = rows + piv * L::WS;
-      const double ip = 1.0 / prow[k];
-      // the pivot's own row is scaled; every other row loses its multiple of the scaled pivot row
+      sync();            // (the previous step's readers are done with the pivot row)
+      if (is_piv) {
+        const double ip = exo::fast_rcp(M[k]);
+#pragma unroll
+        for (int l = k; l < J; ++l) { M[l] *= ip; prow[l] = M[l]; }
+#pragma unroll
+        for (int l = 0; l < NB; ++l) { R[l] *= ip; prow[J + l] = R[l]; }
+      }
+      sync();
+      // every other row loses its multiple of the scaled pivot row (the pivot's own: f = 0, untouched)
       const double f = is_piv ? 0.0 : M[k];
 #pragma unroll
-      for (int l = k; l < J; ++l) {
-        const double pv = prow[l] * ip;
-        M[l] = is_piv ? pv : fma(-f, pv, M[l]);
-      }
+      for (int l = k; l < J; ++l) M[l] = fma(-f, prow[l], M[l]);
 #pragma unroll
-      for (int l = 0; l < NB; ++l) {
-        const double pv = prow[J + l] * ip;
-        R[l] = is_piv ? pv : fma(-f, pv, R[l]);
-      }
+      for (int l = 0; l < NB; ++l) R[l] = fma(-f, prow[J + l], R[l]);
     }
     // rows into order: the lane that solved for unknown k hands its right-hand sides to lane k
     double* rows = gj();
@@ -426,27 +433,6 @@ __device__ __forceinline__ void tree_item_group(const TreeOp& op, double* state,
 // the eight lanes) and only the pivot's lane publishes its row, the solved rows are never brought into order (they are
 // written to LDS where they belong), and the symmetrisation is folded into the product that consumes the solution: seven
 // write -> read round trips a step (6 + 1) instead of eleven, no IEEE division.
-template <int CTRL>
-__device__ __forceinline__ int grp_dpp_int(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false); }
-// the lane (0 .. 7) holding the largest a >= 0 of the aligned group of eight lanes; of (nearly) equal values the lowest lane.
-// One 64-bit key per lane -- the bits of a non-negative double order like the number; its three lowest bits give way to
-// 7 - lane -- and a butterfly of maxima: quad_perm [1,0,3,2], [2,3,0,1], then lane ^ 4 (row_shr / row_shl by 4; BOTH moves by
-// every lane, then the choice: inside a branch the other quad is switched off, and a DPP read of a switched-off lane returns
-// nothing).  a < 0 (a row already used, a lane past the state width): never chosen.
-__device__ __forceinline__ int grp_argmax8(double a, int lane8) {
-  unsigned long long key = (a >= 0.0) ? (((unsigned long long)__double_as_longlong(a) & ~7ull) | (unsigned)(7 - lane8)) + 8ull : 0ull;
-  auto mx = [&](unsigned long long o) { key = o > key ? o : key; };
-  auto mv = [](auto tag, unsigned long long k) {
-    constexpr int CTRL = decltype(tag)::value;
-    return ((unsigned long long)(unsigned)grp_dpp_int<CTRL>((int)(k >> 32)) << 32) | (unsigned)grp_dpp_int<CTRL>((int)k);
-  };
-  mx(mv(std::integral_constant<int, 0xB1>{}, key));
-  mx(mv(std::integral_constant<int, 0x4E>{}, key));
-  const unsigned long long dn = mv(std::integral_constant<int, 0x114>{}, key), up = mv(std::integral_constant<int, 0x104>{}, key);
-  mx((threadIdx.x & 4) ? dn : up);
-  return 7 - (int)(key & 7ull);
-}
-
 template <int J>
 struct ChainLds {
   static constexpr int RS = (J + 1) & ~1;
