@@ -217,6 +217,11 @@ def workload_c2(xo, ops, dev, D, rank=0, events=None):
 # the light curve that is the mean of a GP travels between the two ops as a [cadence][draw] array (get_light_curve's
 # cadence_major: same values, the layout the celerite kernels read with contiguous accesses); EXO_BENCH_ROW_MAJOR=1: A/B
 GP_MEAN_CADENCE_MAJOR = os.environ.get("EXO_BENCH_ROW_MAJOR", "0") != "1"
+# ... or, round 5, as the sweep's SPARSE output -- the runs of cadences a planet can overlap the disk in + the flux of those
+# cadences (get_light_curve's sparse=True): the celerite kernels read the segments, the dense (draw, cadence) array and its
+# cotangent never exist.  Offered for one list per draw (C3); C5 (transits + occultations) gets the cadence-major array back.
+# EXO_BENCH_DENSE_MEAN=1: A/B
+GP_MEAN_SPARSE = os.environ.get("EXO_BENCH_DENSE_MEAN", "0") != "1" and GP_MEAN_CADENCE_MAJOR
 C3_HYPER = (1e-3, 5.0, 0.7071)       # SHOTerm(sigma, rho, Q) of SURVEY.md 8d C3
 
 
@@ -234,7 +239,7 @@ def workload_c3(xo, ops, dev, D, rank=0):
         Lv = dict(zip(names, vals))
         orbit = xo.KeplerianOrbit(period=Lv["period"], t0=Lv["t0"], b=Lv["b"], ecc=Lv["ecc"], omega=Lv["omega"])
         lc = xo.LimbDarkLightCurve(Lv["u1"], Lv["u2"]).get_light_curve(orbit=orbit, r=Lv["r"], t=t, total=True,
-                                                                      cadence_major=GP_MEAN_CADENCE_MAJOR)
+                                                                      cadence_major=GP_MEAN_CADENCE_MAJOR, sparse=GP_MEAN_SPARSE)
         gp = xo.gp.GaussianProcess(xo.gp.terms.SHOTerm(sigma=Lv["sigma"], rho=Lv["rho"], Q=Lv["Q"]), t=t, yerr=5e-4, mean=lc)
         ll = gp.log_likelihood(yobs)
         return (ll.detach(),) + torch.autograd.grad(ll.sum(), vals)
@@ -243,8 +248,9 @@ def workload_c3(xo, ops, dev, D, rank=0):
     return Workload("c3", "BASELINE configs[2] (C3): the C2 system + celerite SHOTerm GP log-likelihood (J = 2) on the residual, "
                     "150000 cadences, value+grad of every leaf incl. (sigma, rho, Q) per draw", D, N_CAD, names,
                     list(leaves.values()), fn, 0, 1, 48 + 16 * (1 + J + J * J), dict(t=t, yobs=yobs, yerr=5e-4, leaves=leaves),
-                    "packing -> light-curve sweep (summed flux) -> SHO coefficients -> celerite in parallel over time (elements, "
-                    "scan trees, chunk recurrences) -> its reverse -> light-curve VJP sweep -> packing VJP")
+                    "packing -> light-curve sweep into its sparse output (runs + values; no dense flux) -> SHO coefficients -> celerite "
+                    "in parallel over time reading the segments (elements, scan trees, chunk recurrences) -> its reverse, the "
+                    "cotangent written at the values -> light-curve VJP sweep on the same runs -> packing VJP")
 
 
 C4_BASE = dict(period=[3.5, 7.9, 13.1, 29.7], t0=[1.0, 2.3, 5.1, 11.7], b=[0.3, 0.1, 0.5, 0.2],
@@ -312,7 +318,8 @@ def workload_c5(xo, ops, dev, D, rank=0, bright=0):
         Lv = dict(zip(names, vals))
         orbit = xo.KeplerianOrbit(period=Lv["period"], t0=Lv["t0"], b=Lv["b"], ecc=Lv["ecc"], omega=Lv["omega"])
         lc = xo.SecondaryEclipseLightCurve(C5_LD[0], C5_LD[1], Lv["sbr"]).get_light_curve(
-            orbit=orbit, r=Lv["r"], t=t, texp=texp, oversample=7, total=True, cadence_major=GP_MEAN_CADENCE_MAJOR)
+            orbit=orbit, r=Lv["r"], t=t, texp=texp, oversample=7, total=True, cadence_major=GP_MEAN_CADENCE_MAJOR,
+            sparse=GP_MEAN_SPARSE)
         kern = (T.SHOTerm(sigma=Lv["s1"], rho=fixed[0][0], Q=fixed[0][1]) + T.SHOTerm(sigma=Lv["s2"], rho=fixed[1][0], Q=fixed[1][1])
                 + T.SHOTerm(sigma=Lv["s3"], rho=fixed[2][0], Q=fixed[2][1]))
         gp = xo.gp.GaussianProcess(kern, t=t, yerr=C5_YERR, mean=lc)
@@ -1256,6 +1263,19 @@ def main():
             out["cpu_baseline"] = cpu_baseline(config=cfg)
         else:
             out["cpu_baseline"] = None
+    if rank == 0:
+        # every config's step time in ONE compact object, the LAST key of the line (the driver keeps the tail of stdout: the
+        # C3 / C5 figures used to sit in the middle of `extras` and fall outside it -- VERDICT r4 item 4)
+        ex = out.get("extras") or {}
+        pick = lambda k, f="median_ms": (round(ex[k][f], 4) if isinstance(ex.get(k), dict) and isinstance(ex[k].get(f), (int, float)) else None)  # noqa: E731
+        out["configs_ms"] = {
+            cfg: round(out["ms_per_step"], 4),
+            "c3": pick("c3_light_curve_plus_sho_gp"), "c4_64": pick("c4_four_planets_64_draws"),
+            "c5_128": pick("c5_secondary_eclipse_3term_gp_128_chains"), "c5b": pick("c5_128_chains_1pct_bright_star_kappa_1e6"),
+            "sparse": pick("c2_sparse_output"), "chi2": pick("c2_white_noise_likelihood"),
+            "hmc": pick("hmc_trajectory_c2"), "nuts_leaf": pick("nuts_transition_c2", "ms_per_leaf"),
+            "note": "ms per value + gradient step, one MI355X, hipGraph replay; c2 / sparse / chi2 at 1024 draws x 150000 cadences",
+        }
     if dist is not None:
         dist.destroy_process_group()
     if rank == 0:

@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # EXOPLANET_AMD_LIB selects another in-tree build of the same ABI (A/B measurements)
 LIB_PATH = os.environ.get("EXOPLANET_AMD_LIB") or os.path.join(_HERE, "lib", "libexoplanet_amd.so")
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 _c_dp = ctypes.c_void_p  # device pointers travel as integers
 _i64 = ctypes.c_int64
@@ -87,6 +87,25 @@ _SIGNATURES = {
         [_c_dp, _c_dp, _c_dp, _c_dp, _i64, _i64, _c_dp, _i32, _c_dp, _i32, _c_dp, _i64, _c_dp, _c_dp, _i64, _i32,
          _c_dp, _c_dp, _c_dp, _c_dp, _c_dp, _c_dp],
     ),
+    # t, obs, model (host struct exo_sparse_model*), diag, ... as the obs pair; gvals instead of gmodel
+    "exo_celerite_loglike_sparse_fwd_f64": (
+        ctypes.c_int,
+        [_c_dp, _c_dp, _c_dp, _c_dp, _i64, _i64, _c_dp, _i32, _c_dp, _i32, _c_dp, _i64, _c_dp, _c_dp, _i64, _i32, _c_dp],
+    ),
+    "exo_celerite_loglike_sparse_vjp_f64": (
+        ctypes.c_int,
+        [_c_dp, _c_dp, _c_dp, _c_dp, _i64, _i64, _c_dp, _i32, _c_dp, _i32, _c_dp, _i64, _c_dp, _c_dp, _i64, _i32,
+         _c_dp, _c_dp, _c_dp, _c_dp, _c_dp, _c_dp],
+    ),
+    # workspace, workspace_bytes, n_cad, n_draw, n_planet, flags, out (host struct)
+    "exo_transit_flux_sparse_model": (ctypes.c_int, [_c_dp, _i64, _i64, _i64, _i32, _u32, _c_dp]),
+    # t, n_cad, texp, n_texp, stencil_dt, stencil_w, n_sub, params, ld, n_draw, n_planet, flags, gvals, gparams, gld, flux_dot,
+    # workspace, workspace_bytes, reuse_runs, stream
+    "exo_transit_flux_vjp_sparse_f64": (
+        ctypes.c_int,
+        [_c_dp, _i64, _c_dp, _i64, _c_dp, _c_dp, _i32, _c_dp, _c_dp, _i64, _i32, _u32, _c_dp, _c_dp, _c_dp, _c_dp, _c_dp, _i64,
+         _i32, _c_dp],
+    ),
     "exo_celerite_dot_tril_f64": (ctypes.c_int, [_c_dp, _c_dp, _i64, _i64, _c_dp, _i32, _c_dp, _i32, _c_dp, _i64, _c_dp, _c_dp,
                                                  _c_dp]),
     "exo_celerite_predict_f64": (ctypes.c_int, [_c_dp, _i64, _c_dp, _c_dp, _i32, _c_dp, _i32, _c_dp, _i64, _c_dp, _i64, _c_dp,
@@ -129,6 +148,12 @@ _SIGNATURES = {
     "exo_pack_records_cols_vjp_f64": (ctypes.c_int, [_c_dp, _c_dp, _c_dp, _c_dp, _c_dp, _c_dp, _i64, _i32, _u32, _c_dp,
                                                      _c_dp, _c_dp, _c_dp, _c_dp, _c_dp]),
 }
+
+class SparseModel(ctypes.Structure):
+    """exo_sparse_model of include/exoplanet_amd.h (a HOST struct of device pointers and strides)"""
+    _fields_ = [("nseg", ctypes.c_void_p), ("seg", ctypes.c_void_p), ("off", ctypes.c_void_p), ("vals", ctypes.c_void_p),
+                ("seg_row", _i64), ("off_row", _i64), ("val_row", _i64), ("seg_step", _i32), ("hi_at", _i32)]
+
 
 _ERRORS = {1: "invalid argument", 2: "kernel launch failed", 3: "workspace too small"}
 

@@ -363,7 +363,7 @@ __global__ __launch_bounds__(kWave) void celerite_vjp_kernel(
     int64_t n_draw, const double* __restrict__ gloglike, const double* __restrict__ state,
     double* __restrict__ gresid, double* __restrict__ gdiag, double* __restrict__ gdiag_sum,
     double* __restrict__ gcoef_real, double* __restrict__ gcoef_complex, const double* __restrict__ only_flagged,
-    double gsign, int64_t gcm) {   // gcm: Series::cm of the series this is the cotangent of
+    double gsign, Series rs) {   // rs: the series this is the cotangent of (its layout is the cotangent's: GradRow)
   constexpr int G = Group<J>::G;
   const int j = threadIdx.x & (G - 1);
   const int64_t lane_draw = ((int64_t)blockIdx.x * kWave + threadIdx.x) / G;
@@ -375,6 +375,7 @@ __global__ __launch_bounds__(kWave) void celerite_vjp_kernel(
   const StateIdx six{n, n_draw, J};
   const double gL = gloglike[draw];
   const bool lead = live_draw && j == 0;
+  GradRow grow(gresid, rs, draw, n);
   // the other state index of this lane's complex pair (itself for real terms / idle lanes)
   const int partner = (int)threadIdx.x + ((k.live && !k.real) ? (k.odd ? -1 : 1) : 0);
 
@@ -460,7 +461,7 @@ __global__ __launch_bounds__(kWave) void celerite_vjp_kernel(
     const double wdot = group_sum<G>(Wb * W_n);
     const double dbar = db + gL * (0.5 * z_n * z_n * id * id - 0.5 * id) - wdot * id;
     if (lead) {
-      gresid[gcm ? i * gcm + draw : draw * n + i] = gsign * zbar;
+      grow.store(i, gsign * zbar);
       if (gdiag) gdiag[draw * n + i] = dbar;
     }
     gasum += dbar;
@@ -555,7 +556,7 @@ __global__ __launch_bounds__(kWave) void celerite_vjp_kernel(
     const double wdot = group_sum<G>(Wb * W_n);
     const double dbar = db + gL * (0.5 * z_n * z_n * id * id - 0.5 * id) - wdot * id;
     if (lead) {
-      gresid[gcm ? draw : draw * n] = gsign * zbar;
+      grow.store(0, gsign * zbar);
       if (gdiag) gdiag[draw * n] = dbar;
     }
     gasum += dbar;
@@ -888,8 +889,9 @@ template <int J>
 __global__ __launch_bounds__(kWave) void celerite_chunk_vjp_kernel(
     const double* __restrict__ t, int64_t n, Coefs cf, int64_t n_draw, const double* __restrict__ gloglike,
     double* __restrict__ state, ChunkGeom cg, double* __restrict__ gresid, double* __restrict__ gdiag,
-    double gsign, int64_t gcm) {
+    double gsign, Series rs) {
   constexpr int G = Group<J>::G;
+  const bool gcm = rs.cm != 0 || rs.sp.nseg != nullptr;   // the cotangent is not a row of consecutive cadences: stored one by one
   const int j = threadIdx.x & (G - 1);
   const int64_t lane_draw = ((int64_t)blockIdx.x * kWave + threadIdx.x) / G;
   const bool live_draw = lane_draw < n_draw;
@@ -902,6 +904,7 @@ __global__ __launch_bounds__(kWave) void celerite_chunk_vjp_kernel(
   const ChunkWs ws = chunk_ws(n, n_draw, J, cg);
   const double gL = gloglike[draw];
   const int partner = (int)threadIdx.x + ((k.live && !k.real) ? (k.odd ? -1 : 1) : 0);
+  GradRow grow(gresid, rs, draw, n);
 
   double Sb[J];
 #pragma unroll
@@ -1002,7 +1005,7 @@ __global__ __launch_bounds__(kWave) void celerite_chunk_vjp_kernel(
     // different 64-B line for every draw of the wave.  The G lanes of a draw (zbar, dbar are the
     // same on all of them) each keep 8 / G consecutive cadences of an aligned block of 8 and the
     // block is written when it is complete (measured: 2.9x write amplification without this).
-    if (gcm && live_draw && j == 0) gresid[i * gcm + draw] = gsign * zbar;   // cadence-major: the wave's draws are neighbours
+    if (gcm && live_draw && j == 0) grow.store(i, gsign * zbar);   // cadence-major: the wave's draws are neighbours (sparse: the few values)
     {
       const int owner = (int)(i & 7) / kPer, slot = (int)(i & 7) % kPer;
       if (live_draw && j == owner) {
@@ -1347,7 +1350,7 @@ constexpr bool split_layouts(int J) { return EXO_J4_SPLIT && J == 4; }
 #define EXO_ELEM_MIXED_WAVES 4
 #endif
 // (A) the filtering element of every (draw, chunk)
-template <int J, int NR>
+template <int J, int NR, int SP>
 __global__ __launch_bounds__(kWave, (J <= 2 ? EXO_ELEM_MIXED_WAVES : (split_layouts(J) && NR == 0 ? EXO_J4_WAVES : 1))) void celerite_elem_kernel(const double* __restrict__ t, Series rs,
                                                               const double* __restrict__ diag, int64_t n_diag, int64_t n,
                                                               Coefs cf, int64_t n_draw, double* __restrict__ state,
@@ -1356,9 +1359,9 @@ __global__ __launch_bounds__(kWave, (J <= 2 ? EXO_ELEM_MIXED_WAVES : (split_layo
   if (draw >= n_draw) return;
   const int vote = layout_vote<J>(cf, draw);
   if constexpr (J > 2 && NR == -1 && EXO_GP_WIDE_COMPLEX_LAYOUT && !split_layouts(J)) {   // a wave of all-complex draws takes the compile-time layout
-    if (vote == 0) { elem_lane<J, 0>(t, rs, diag, n_diag, n, cf, n_draw, state, cg, draw, (int)blockIdx.y, flag_at); return; }
+    if (vote == 0) { elem_lane<J, 0, true, SP>(t, rs, diag, n_diag, n, cf, n_draw, state, cg, draw, (int)blockIdx.y, flag_at); return; }
   } else if (vote != NR) return;
-  elem_lane<J, NR, (J > 2 || EXO_ELEM_MIXED_WAVES < 4)>(t, rs, diag, n_diag, n, cf, n_draw, state, cg, draw, (int)blockIdx.y, flag_at);
+  elem_lane<J, NR, (J > 2 || EXO_ELEM_MIXED_WAVES < 4), SP>(t, rs, diag, n_diag, n, cf, n_draw, state, cg, draw, (int)blockIdx.y, flag_at);
 }
 
 // (B), (B'): the scans over the chunks are trees of compositions (celerite_tree_kernel, celerite_compose_lds_kernel above).
@@ -1373,7 +1376,7 @@ __global__ __launch_bounds__(kWave) void celerite_badj_prep_kernel(const double*
 }
 
 // (C) / (C') with a checkpointed factorisation, J <= kLaneMaxJ
-template <int J, int NR>
+template <int J, int NR, int SP>
 __global__ __launch_bounds__(kWave, (split_layouts(J) && NR == 0 ? 3 : 1)) void celerite_chunk1_fwd_kernel(const double* __restrict__ t, Series rs,
                                                                     const double* __restrict__ diag, int64_t n_diag,
                                                                     int64_t n, Coefs cf, int64_t n_draw,
@@ -1382,9 +1385,9 @@ __global__ __launch_bounds__(kWave, (split_layouts(J) && NR == 0 ? 3 : 1)) void 
   if (draw >= n_draw) return;
   const int vote = layout_vote<J>(cf, draw);
   if constexpr (J > 2 && NR == -1 && EXO_GP_WIDE_COMPLEX_LAYOUT && !split_layouts(J)) {
-    if (vote == 0) { chunk1_fwd_lane<J, 0>(t, rs, diag, n_diag, n, cf, n_draw, state, cg, draw, (int)blockIdx.y, true); return; }
+    if (vote == 0) { chunk1_fwd_lane<J, 0, SP>(t, rs, diag, n_diag, n, cf, n_draw, state, cg, draw, (int)blockIdx.y, true); return; }
   } else if (vote != NR) return;
-  chunk1_fwd_lane<J, NR>(t, rs, diag, n_diag, n, cf, n_draw, state, cg, draw, (int)blockIdx.y, true);
+  chunk1_fwd_lane<J, NR, SP>(t, rs, diag, n_diag, n, cf, n_draw, state, cg, draw, (int)blockIdx.y, true);
 }
 // (two waves per SIMD asked for: the J = 2 complex-term variant sits at 254 + 4 registers otherwise -- one wave)
 #ifndef EXO_VJP1_WAVES
@@ -1393,7 +1396,7 @@ __global__ __launch_bounds__(kWave, (split_layouts(J) && NR == 0 ? 3 : 1)) void 
 #ifndef EXO_VJPP_WAVES
 #define EXO_VJPP_WAVES 2
 #endif
-template <int J, int NR>
+template <int J, int NR, int SP>
 __global__ __launch_bounds__(kWave, (J < EXO_SPAN2_MIN_J ? EXO_VJP1_WAVES : (J <= 2 ? EXO_VJPP_WAVES : (split_layouts(J) && NR == 0 ? EXO_J4_WAVES : 1)))) void celerite_chunk1_vjp_kernel(const double* __restrict__ t, Series rs,
                                                                     const double* __restrict__ diag, int64_t n_diag,
                                                                     int64_t n, Coefs cf, int64_t n_draw,
@@ -1410,15 +1413,15 @@ __global__ __launch_bounds__(kWave, (J < EXO_SPAN2_MIN_J ? EXO_VJP1_WAVES : (J <
     __shared__ double gacc[4 * J + 1][kWave];
     if constexpr (kBoth) {
       if (vote == 0) {
-        chunkp_vjp_lane<J, 0>(t, rs, diag, n_diag, n, cf, n_draw, gloglike, state, cg, gresid, gdiag, gsign, draw, (int)blockIdx.y,
+        chunkp_vjp_lane<J, 0, SP>(t, rs, diag, n_diag, n, cf, n_draw, gloglike, state, cg, gresid, gdiag, gsign, draw, (int)blockIdx.y,
                               &gacc[0][threadIdx.x], kWave);
         return;
       }
     }
-    chunkp_vjp_lane<J, NR>(t, rs, diag, n_diag, n, cf, n_draw, gloglike, state, cg, gresid, gdiag, gsign, draw, (int)blockIdx.y,
+    chunkp_vjp_lane<J, NR, SP>(t, rs, diag, n_diag, n, cf, n_draw, gloglike, state, cg, gresid, gdiag, gsign, draw, (int)blockIdx.y,
                            &gacc[0][threadIdx.x], kWave);
   } else
-    chunk1_vjp_lane<J, NR>(t, rs, diag, n_diag, n, cf, n_draw, gloglike, state, cg, gresid, gdiag, gsign, draw, (int)blockIdx.y);
+    chunk1_vjp_lane<J, NR, SP>(t, rs, diag, n_diag, n, cf, n_draw, gloglike, state, cg, gresid, gdiag, gsign, draw, (int)blockIdx.y);
 }
 
 // ---- the ROBUST route (draws flagged kFlagRobust: exo_celerite_core.hpp, chunk_adj_lane) ---------------------------------
@@ -1759,6 +1762,8 @@ __global__ __launch_bounds__(1024) void celerite_kind_partition_kernel(const int
 // on the other side of Q = 1/2 paid twice the clean batch's time.  The layouts keep their own code (compile-time NR); the
 // kernel's registers are those of the widest variant -- the same waves per SIMD as each alone (145 / 118 / 159, 113 / 100 /
 // 124, 217 / 186 / 239 registers for element / forward / reverse).
+extern "C++" {   // (templates: the entry points below are extern "C")
+template <int SP>
 __global__ __launch_bounds__(kWave, EXO_ELEM_MIXED_WAVES) void celerite_elem_mixed_kernel(const double* __restrict__ t, Series rs,
                                                                     const double* __restrict__ diag, int64_t n_diag, int64_t n,
                                                                     Coefs cf, int64_t n_draw, double* __restrict__ state,
@@ -1768,15 +1773,16 @@ __global__ __launch_bounds__(kWave, EXO_ELEM_MIXED_WAVES) void celerite_elem_mix
   const int nr = layout_vote<2>(cf, draw);
   const int c = (int)blockIdx.y;
   if (blockIdx.z == 0) {
-    if (nr == 0) elem_lane<2, 0, EXO_ELEM_MIXED_WAVES < 4>(t, rs, diag, n_diag, n, cf, n_draw, state, cg, draw, c, flag_at);
+    if (nr == 0) elem_lane<2, 0, EXO_ELEM_MIXED_WAVES < 4, SP>(t, rs, diag, n_diag, n, cf, n_draw, state, cg, draw, c, flag_at);
   } else {
-    if (nr == 2) elem_lane<2, 2, EXO_ELEM_MIXED_WAVES < 4>(t, rs, diag, n_diag, n, cf, n_draw, state, cg, draw, c, flag_at);
+    if (nr == 2) elem_lane<2, 2, EXO_ELEM_MIXED_WAVES < 4, SP>(t, rs, diag, n_diag, n, cf, n_draw, state, cg, draw, c, flag_at);
   }   // (no wave is of mixed kinds: mixed_draw)
 }
 // (four waves per SIMD asked for: the three inlined layouts sit at 129 registers otherwise, and the plan offers four)
 #ifndef EXO_FWD_MIXED_WAVES
 #define EXO_FWD_MIXED_WAVES 4
 #endif
+template <int SP>
 __global__ __launch_bounds__(kWave, EXO_FWD_MIXED_WAVES) void celerite_chunk1_fwd_mixed_kernel(const double* __restrict__ t, Series rs,
                                                                           const double* __restrict__ diag, int64_t n_diag,
                                                                           int64_t n, Coefs cf, int64_t n_draw,
@@ -1786,11 +1792,12 @@ __global__ __launch_bounds__(kWave, EXO_FWD_MIXED_WAVES) void celerite_chunk1_fw
   const int nr = layout_vote<2>(cf, draw);
   const int c = (int)blockIdx.y;
   if (blockIdx.z == 0) {
-    if (nr == 0) chunk1_fwd_lane<2, 0>(t, rs, diag, n_diag, n, cf, n_draw, state, cg, draw, c, true);
+    if (nr == 0) chunk1_fwd_lane<2, 0, SP>(t, rs, diag, n_diag, n, cf, n_draw, state, cg, draw, c, true);
   } else {
-    if (nr == 2) chunk1_fwd_lane<2, 2>(t, rs, diag, n_diag, n, cf, n_draw, state, cg, draw, c, true);
+    if (nr == 2) chunk1_fwd_lane<2, 2, SP>(t, rs, diag, n_diag, n, cf, n_draw, state, cg, draw, c, true);
   }   // (no wave is of mixed kinds: mixed_draw)
 }
+template <int SP>
 __global__ __launch_bounds__(kWave, EXO_VJP1_WAVES) void celerite_chunk1_vjp_mixed_kernel(
     const double* __restrict__ t, Series rs, const double* __restrict__ diag, int64_t n_diag, int64_t n, Coefs cf, int64_t n_draw,
     const double* __restrict__ gloglike, double* __restrict__ state, ChunkGeom cg, double* __restrict__ gresid,
@@ -1801,11 +1808,13 @@ __global__ __launch_bounds__(kWave, EXO_VJP1_WAVES) void celerite_chunk1_vjp_mix
   const int nr = layout_vote<2>(cf, draw);
   const int c = (int)blockIdx.y;
   if (blockIdx.z == 0) {
-    if (nr == 0) chunk1_vjp_lane<2, 0>(t, rs, diag, n_diag, n, cf, n_draw, gloglike, state, cg, gresid, gdiag, gsign, draw, c);
+    if (nr == 0) chunk1_vjp_lane<2, 0, SP>(t, rs, diag, n_diag, n, cf, n_draw, gloglike, state, cg, gresid, gdiag, gsign, draw, c);
   } else {
-    if (nr == 2) chunk1_vjp_lane<2, 2>(t, rs, diag, n_diag, n, cf, n_draw, gloglike, state, cg, gresid, gdiag, gsign, draw, c);
+    if (nr == 2) chunk1_vjp_lane<2, 2, SP>(t, rs, diag, n_diag, n, cf, n_draw, gloglike, state, cg, gresid, gdiag, gsign, draw, c);
   }   // (no wave is of mixed kinds: mixed_draw)
 }
+
+}  // extern "C++"
 
 #ifndef EXO_GP_MIXED_ONE_LAUNCH
 #define EXO_GP_MIXED_ONE_LAUNCH 1
@@ -1833,6 +1842,13 @@ __global__ __launch_bounds__(kWave, EXO_VJP1_WAVES) void celerite_chunk1_vjp_mix
     case 7: { constexpr int JJ = 7, NR = -1; CALL; } break;                             \
     case 8: { constexpr int JJ = 8, NR = -1; CALL; } break;                             \
     default: return EXO_ERR_INVALID_ARGUMENT;                                           \
+  }
+
+// the series' kind is a compile-time constant of the one-lane kernels (SeriesRowT): SP = 1 a sparse model, 0 otherwise
+#define EXO_GP_BY_SERIES(RS, NAME)                                                                        \
+  {                                                                                                       \
+    const int rc_ = (RS).sp.nseg ? NAME(std::integral_constant<int, 1>{}) : NAME(std::integral_constant<int, 0>{}); \
+    if (rc_ != EXO_OK) return rc_;                                                                        \
   }
 
 static int celerite_fwd(const double* t, Series resid, const double* diag, int64_t n_diag, int64_t n, Coefs cf,
@@ -1881,10 +1897,15 @@ static int celerite_fwd(const double* t, Series resid, const double* diag, int64
         EXO_GP_DISPATCH(J, hipLaunchKernelGGL((celerite_elem_lg_kernel<JJ>), cgrid_f, block, 0, st, t, resid, diag, n_diag,
                                               n, cf, n_draw, state, cge, flag_at))
       } else {
-        EXO_GP_LAYOUTS(J, cf, hipLaunchKernelGGL((celerite_elem_kernel<JJ, NR>), egrid_f, block, 0, st, t, resid, diag,
-                                                 n_diag, n, cf, n_draw, state, cge, flag_at),
-                       hipLaunchKernelGGL(celerite_elem_mixed_kernel, dim3(egrid_f.x + 1, egrid_f.y, 2), block, 0, st, t, resid, diag,
-                                          n_diag, n, cf, n_draw, state, cge, flag_at))
+        auto launch_elem = [&](auto sp_tag) -> int {
+          constexpr int SP = decltype(sp_tag)::value;
+          EXO_GP_LAYOUTS(J, cf, hipLaunchKernelGGL((celerite_elem_kernel<JJ, NR, SP>), egrid_f, block, 0, st, t, resid, diag,
+                                                   n_diag, n, cf, n_draw, state, cge, flag_at),
+                         hipLaunchKernelGGL(celerite_elem_mixed_kernel<SP>, dim3(egrid_f.x + 1, egrid_f.y, 2), block, 0, st, t, resid, diag,
+                                            n_diag, n, cf, n_draw, state, cge, flag_at))
+          return EXO_OK;
+        };
+        EXO_GP_BY_SERIES(resid, launch_elem)
       }
       for (int f = cg.fine; f >= 1; --f) {
         TreeOp op{};
@@ -1944,10 +1965,15 @@ static int celerite_fwd(const double* t, Series resid, const double* diag, int64
           EXO_GP_DISPATCH_LANE(J, hipLaunchKernelGGL((celerite_robust_scan_kernel<JJ>), rgrid, block, 0, st, t, cf, n, cg, n_draw,
                                                      state))
         }
-        EXO_GP_LAYOUTS(J, cf, hipLaunchKernelGGL((celerite_chunk1_fwd_kernel<(JJ <= kLaneMaxJ ? JJ : 1), NR>), egrid, block, 0,
-                                                 st, t, resid, diag, n_diag, n, cf, n_draw, state, cg),
-                       hipLaunchKernelGGL(celerite_chunk1_fwd_mixed_kernel, dim3(egrid.x + 1, egrid.y, 2), block, 0, st, t, resid, diag,
-                                          n_diag, n, cf, n_draw, state, cg))
+        auto launch_fwd = [&](auto sp_tag) -> int {
+          constexpr int SP = decltype(sp_tag)::value;
+          EXO_GP_LAYOUTS(J, cf, hipLaunchKernelGGL((celerite_chunk1_fwd_kernel<(JJ <= kLaneMaxJ ? JJ : 1), NR, SP>), egrid, block, 0,
+                                                   st, t, resid, diag, n_diag, n, cf, n_draw, state, cg),
+                         hipLaunchKernelGGL(celerite_chunk1_fwd_mixed_kernel<SP>, dim3(egrid.x + 1, egrid.y, 2), block, 0, st, t, resid, diag,
+                                            n_diag, n, cf, n_draw, state, cg))
+          return EXO_OK;
+        };
+        EXO_GP_BY_SERIES(resid, launch_fwd)
       } else {
         EXO_GP_DISPATCH(J, hipLaunchKernelGGL((celerite_chunk_fwd_kernel<JJ>), cgrid, block, 0, st, t, resid, diag, n_diag,
                                               n, cf, n_draw, state, cg))
@@ -2026,14 +2052,19 @@ static int celerite_vjp(const double* t, Series resid, const double* diag, int64
       if (!ok) return EXO_ERR_LAUNCH;
     }
     if (cg.lane) {
-      EXO_GP_LAYOUTS(J, cf, hipLaunchKernelGGL((celerite_chunk1_vjp_kernel<(JJ <= kLaneMaxJ ? JJ : 1), NR>), egrid, block, 0,
-                                               st, t, resid, diag, n_diag, n, cf, n_draw, gloglike, wstate, cg, gresid,
-                                               gdiag, gsign),
-                     hipLaunchKernelGGL(celerite_chunk1_vjp_mixed_kernel, dim3(egrid.x + 1, egrid.y, 2), block, 0, st, t, resid, diag,
-                                        n_diag, n, cf, n_draw, gloglike, wstate, cg, gresid, gdiag, gsign))
+      auto launch_vjp = [&](auto sp_tag) -> int {
+        constexpr int SP = decltype(sp_tag)::value;
+        EXO_GP_LAYOUTS(J, cf, hipLaunchKernelGGL((celerite_chunk1_vjp_kernel<(JJ <= kLaneMaxJ ? JJ : 1), NR, SP>), egrid, block, 0,
+                                                 st, t, resid, diag, n_diag, n, cf, n_draw, gloglike, wstate, cg, gresid,
+                                                 gdiag, gsign),
+                       hipLaunchKernelGGL(celerite_chunk1_vjp_mixed_kernel<SP>, dim3(egrid.x + 1, egrid.y, 2), block, 0, st, t, resid, diag,
+                                          n_diag, n, cf, n_draw, gloglike, wstate, cg, gresid, gdiag, gsign))
+        return EXO_OK;
+      };
+      EXO_GP_BY_SERIES(resid, launch_vjp)
     } else {
       EXO_GP_DISPATCH(J, hipLaunchKernelGGL((celerite_chunk_vjp_kernel<JJ>), cgrid, block, 0, st, t, n, cf, n_draw,
-                                            gloglike, wstate, cg, gresid, gdiag, gsign, resid.cm))
+                                            gloglike, wstate, cg, gresid, gdiag, gsign, resid))
     }
     hipLaunchKernelGGL(celerite_chunk_gsum_kernel, dim3((unsigned)n_draw, (unsigned)(4 * J + 1)), block, 0, st, n, n_draw,
                        J, wstate, cg);
@@ -2044,7 +2075,7 @@ static int celerite_vjp(const double* t, Series resid, const double* diag, int64
   }
   EXO_GP_DISPATCH(J, hipLaunchKernelGGL((celerite_vjp_kernel<JJ>), grid, block, 0, st, t, diag, n_diag, n, cf, n_draw,
                                         gloglike, state, gresid, gdiag, gdiag_sum, gcoef_real, gcoef_complex,
-                                        only_flagged, gsign, resid.cm))
+                                        only_flagged, gsign, resid))
   return launch_status();
 }
 
@@ -2110,6 +2141,45 @@ int exo_celerite_loglike_obs_vjp_cm_f64(const double* t, const double* obs, cons
   return celerite_vjp(t, Series{model_cm, obs, n_draw}, diag, n_diag, n,
                       Coefs{coef_real, coef_complex, pair_kind, n_real, n_complex}, n_draw, gloglike, state, state_doubles,
                       n_chunks, gmodel_cm, -1.0, gdiag, gdiag_sum, gcoef_real, gcoef_complex, stream);
+}
+
+// the model as the light-curve sweep's SPARSE output (exo_sparse_model): segments of cadences + their values
+static bool sparse_series(const exo_sparse_model* m, const double* obs, int64_t n, Series* out) {
+  if (!m || !obs || !m->nseg || !m->seg || !m->off || !m->vals || m->seg_step < 1 || m->hi_at < 0 || m->hi_at >= m->seg_step ||
+      m->seg_row < 0 || m->off_row < 0 || m->val_row < 0 || n > 0x7fffffff)
+    return false;
+  out->y = m->vals;
+  out->obs = obs;
+  out->cm = 0;
+  out->sp.nseg = m->nseg; out->sp.seg = m->seg; out->sp.off = m->off;
+  out->sp.seg_row = m->seg_row; out->sp.off_row = m->off_row; out->sp.val_row = m->val_row;
+  out->sp.seg_step = m->seg_step; out->sp.hi_at = m->hi_at;
+  return true;
+}
+
+int exo_celerite_loglike_sparse_fwd_f64(const double* t, const double* obs, const exo_sparse_model* model, const double* diag,
+                                        int64_t n_diag, int64_t n, const double* coef_real, int32_t n_real,
+                                        const double* coef_complex, int32_t n_complex, const int32_t* pair_kind,
+                                        int64_t n_draw, double* loglike, double* state, int64_t state_doubles,
+                                        int32_t n_chunks, void* stream) {
+  if (n_draw == 0) return EXO_OK;
+  Series rs{};
+  if (!sparse_series(model, obs, n, &rs)) return EXO_ERR_INVALID_ARGUMENT;
+  return celerite_fwd(t, rs, diag, n_diag, n, Coefs{coef_real, coef_complex, pair_kind, n_real, n_complex}, n_draw, loglike,
+                      state, state_doubles, n_chunks, stream);
+}
+
+int exo_celerite_loglike_sparse_vjp_f64(const double* t, const double* obs, const exo_sparse_model* model, const double* diag,
+                                        int64_t n_diag, int64_t n, const double* coef_real, int32_t n_real,
+                                        const double* coef_complex, int32_t n_complex, const int32_t* pair_kind,
+                                        int64_t n_draw, const double* gloglike, const double* state,
+                                        int64_t state_doubles, int32_t n_chunks, double* gvals, double* gdiag,
+                                        double* gdiag_sum, double* gcoef_real, double* gcoef_complex, void* stream) {
+  if (n_draw == 0) return EXO_OK;
+  Series rs{};
+  if (!sparse_series(model, obs, n, &rs)) return EXO_ERR_INVALID_ARGUMENT;
+  return celerite_vjp(t, rs, diag, n_diag, n, Coefs{coef_real, coef_complex, pair_kind, n_real, n_complex}, n_draw, gloglike,
+                      state, state_doubles, n_chunks, gvals, -1.0, gdiag, gdiag_sum, gcoef_real, gcoef_complex, stream);
 }
 
 int exo_celerite_dot_tril_f64(const double* t, const double* diag, int64_t n_diag, int64_t n, const double* coef_real,

@@ -122,11 +122,25 @@ EXO_HD void lane_uv(const LaneCoef& k, double t, double* U, double* V, double* c
 // The series the likelihood is evaluated on: y[draw][n] as given, or -- obs != nullptr -- the
 // residual obs[n] - y[draw][n] of a per-draw model against one observed series, formed on the
 // fly (the subtraction, and the sign flip of its cotangent, never cross HBM as arrays).
+// SPARSE model (round 5; obs != nullptr, sp.nseg != nullptr): the per-draw model is zero outside a few SEGMENTS of
+// cadences -- a transit light curve: ~3 % of the series -- and only the values inside them exist, in the order of the
+// cadences (exo_sparse_model, include/exoplanet_amd.h: the sparse output of the light-curve sweep, or its merged form).
+// Segment k of draw d covers cadences [lo, hi) = seg[d * seg_row + k * seg_step + {0, hi_at}], ascending and disjoint; the
+// value of cadence n in it is vals[d * val_row + off[d * off_row + k] + (n - lo)].  The dense (draw, cadence) model, 97 % zeros,
+// and its cotangent never cross HBM: the cotangent comes back in the same value layout.
+struct SparseSegs {
+  const int32_t* nseg = nullptr;
+  const int32_t* seg = nullptr;
+  const int32_t* off = nullptr;
+  int64_t seg_row = 0, off_row = 0, val_row = 0;
+  int32_t seg_step = 0, hi_at = 0;
+};
 struct Series {
   const double* y;
   const double* obs;
   int64_t cm;   // 0: y is [draw][cadence]; else CADENCE-MAJOR, [cadence][cm] with cm = n_draw (the reverse pass writes the
                 // cotangent of the series in the same layout)
+  SparseSegs sp{};   // sp.nseg != nullptr: y is the value array of a sparse model
 };
 // A lane owns one ROW of a [draw][cadence] array: consecutive lanes are n cadences apart, so every
 // load instruction of a wave touches 64 different cache lines, and cadence-by-cadence 8-byte
@@ -160,17 +174,107 @@ EXO_HD void row_store4(double* EXO_RESTRICT row, int64_t i, int len, const doubl
   }
 }
 
-// one draw's series: element i at y[i * stride] (stride 1: a row; n_draw: a column of a cadence-major array)
-struct SeriesRow {
+// A lane's place among its draw's segments.  The kernels walk a chunk one way -- the forward recurrences upwards, the reverse
+// ones downwards -- so the cursor is one segment and a direction:
+//   ASC   k = the first segment that ends beyond the cadence last asked for (k = nseg: none left, lo = hi = "never")
+//   DESC  k = the last segment that starts at or before it                (k = -1: none left)
+// [lo, hi) its cadences, voff + n the position of cadence n's value.  The first access finds its segment by bisection; after
+// that the cursor moves a segment at a time -- three loads, once per transit -- and a block of four cadences outside every
+// segment (97 % of them) costs one comparison.
+template <bool ASC>
+struct SegCursor {
+  static constexpr int32_t kFar = 0x7fffffff;
+  int32_t k = ASC ? -1 : kFar, lo = 0, hi = 0, voff = 0;
+  EXO_HD void fetch(const SparseSegs& sp, int64_t draw) {
+    const int32_t nseg = sp.nseg[draw];
+    if (k >= 0 && k < nseg) {
+      const int32_t* EXO_RESTRICT s = sp.seg + draw * sp.seg_row + (int64_t)k * sp.seg_step;
+      lo = s[0];
+      hi = s[sp.hi_at];
+      voff = sp.off[draw * sp.off_row + k] - lo;
+    } else {
+      lo = hi = ASC ? kFar : -kFar;
+      voff = 0;
+    }
+  }
+  EXO_HD void first(const SparseSegs& sp, int64_t draw, int32_t i) {
+    const int32_t* EXO_RESTRICT s = sp.seg + draw * sp.seg_row + (ASC ? sp.hi_at : 0);
+    int32_t a = 0, b = sp.nseg[draw];   // ASC: the first segment with hi > i;  DESC: the first with lo > i, minus one
+    while (a < b) {
+      const int32_t m = (a + b) >> 1;
+      if (s[(int64_t)m * sp.seg_step] <= i) a = m + 1; else b = m;
+    }
+    k = ASC ? a : a - 1;
+    fetch(sp, draw);
+  }
+  // Position the cursor for the block of cadences [b, b + 4); false: no cadence of the block is in any segment (one
+  // comparison in the usual case).  Blocks come in the cursor's direction.
+  EXO_HD bool enter(const SparseSegs& sp, int64_t draw, int64_t b64) {
+    const int32_t b = (int32_t)b64;
+    if (ASC) {
+      if (k < 0) first(sp, draw, b);
+      while (b >= hi) { ++k; fetch(sp, draw); }
+      return b + 4 > lo;
+    }
+    if (k == kFar) first(sp, draw, b + 3);
+    while (b + 3 < lo) { --k; fetch(sp, draw); }
+    return b < hi;
+  }
+  // position of cadence n's value, or -1 -- after enter(), for the block's cadences in the cursor's direction (the loop only
+  // turns when two segments share the block)
+  EXO_HD int32_t idx(const SparseSegs& sp, int64_t draw, int32_t n) {
+    if (ASC) {
+      while (n >= hi) { ++k; fetch(sp, draw); }
+      return n >= lo ? voff + n : -1;
+    }
+    while (n < lo) { --k; fetch(sp, draw); }
+    return n < hi ? voff + n : -1;
+  }
+  // a single cadence, any time (cadences still in the cursor's direction)
+  EXO_HD int32_t at(const SparseSegs& sp, int64_t draw, int64_t i) {
+    if (ASC ? (k < 0) : (k == kFar)) first(sp, draw, (int32_t)i);
+    return idx(sp, draw, (int32_t)i);
+  }
+};
+
+// one draw's series: element i at y[i * stride] (stride 1: a row; n_draw: a column of a cadence-major array); or the
+// values of a sparse model (SparseSegs), read in ascending (ASC) or descending order of the cadences
+// SP: 1 the series is known to be sparse at compile time, 0 known not to be (the hot one-lane kernels are compiled both ways:
+// a cursor's registers in the dense kernels cost their J = 2 forms scratch), -1 decided by rs.sp.nseg at run time
+template <bool ASC, int SP = -1>
+struct SeriesRowT {
   const double* EXO_RESTRICT y;
   const double* EXO_RESTRICT obs;
   int64_t stride;
-  EXO_HD SeriesRow(const Series& rs, int64_t draw, int64_t n)
-      : y(rs.y + (rs.cm ? draw : draw * n)), obs(rs.obs), stride(rs.cm ? rs.cm : 1) {}
-  EXO_HD double operator[](int64_t i) const { return obs ? obs[i] - y[i * stride] : y[i * stride]; }
+  const SparseSegs& sp;
+  int64_t draw;
+  mutable SegCursor<ASC> cur;
+  EXO_HD SeriesRowT(const Series& rs, int64_t draw_, int64_t n)
+      : y(rs.y + (rs.sp.nseg ? draw_ * rs.sp.val_row : (rs.cm ? draw_ : draw_ * n))), obs(rs.obs), stride(rs.cm ? rs.cm : 1),
+        sp(rs.sp), draw(draw_) {}
+  EXO_HD bool sparse() const { return SP == 1 || (SP == -1 && sp.nseg != nullptr); }
+  EXO_HD double model_at(int64_t i) const {   // sparse: the model at cadence i
+    const int32_t v = cur.at(sp, draw, i);
+    return v >= 0 ? y[v] : 0.0;
+  }
+  EXO_HD double operator[](int64_t i) const {
+    if (sparse()) return obs[i] - model_at(i);
+    return obs ? obs[i] - y[i * stride] : y[i * stride];
+  }
   // cadences i .. i + 3 (the first `len` of them exist)
   EXO_HD void load4(int64_t i, int len, double* v) const {
-    if (stride == 1) {
+    if (sparse()) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v[q] = 0.0;
+      if (cur.enter(sp, draw, i)) {   // (the usual case is the other one: no load)
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) {
+          const int q = ASC ? qq : 3 - qq;
+          const int32_t at = cur.idx(sp, draw, (int32_t)i + q);
+          if (q < len && at >= 0) v[q] = y[at];
+        }
+      }
+    } else if (stride == 1) {
       row_load4(y, i, len, v);
     } else {
 #pragma unroll
@@ -182,15 +286,38 @@ struct SeriesRow {
     }
   }
 };
-// one draw's cotangent of the series, in the layout of the series
-struct GradRow {
+using SeriesRow = SeriesRowT<true>;
+using SeriesRowDesc = SeriesRowT<false>;
+// one draw's cotangent of the series, in the layout of the series (sparse: of the values -- cadences outside the segments
+// have no value to receive one), written in DESCENDING order of the cadences (every reverse recurrence does)
+template <int SP = -1>
+struct GradRowT {
   double* EXO_RESTRICT g;
   int64_t stride;
-  EXO_HD GradRow(double* gresid, const Series& rs, int64_t draw, int64_t n)
-      : g(gresid + (rs.cm ? draw : draw * n)), stride(rs.cm ? rs.cm : 1) {}
-  EXO_HD void store(int64_t i, double v) const { g[i * stride] = v; }
-  EXO_HD void store4(int64_t i, int len, const double* v) const {
-    if (stride == 1) {
+  const SparseSegs& sp;
+  int64_t draw;
+  SegCursor<false> cur;
+  EXO_HD bool sparse() const { return SP == 1 || (SP == -1 && sp.nseg != nullptr); }
+  EXO_HD GradRowT(double* gresid, const Series& rs, int64_t draw_, int64_t n)
+      : g(gresid + (rs.sp.nseg ? draw_ * rs.sp.val_row : (rs.cm ? draw_ : draw_ * n))), stride(rs.cm ? rs.cm : 1), sp(rs.sp),
+        draw(draw_) {}
+  EXO_HD void store(int64_t i, double v) {
+    if (sparse()) {
+      const int32_t at = cur.at(sp, draw, i);
+      if (at >= 0) g[at] = v;
+    } else {
+      g[i * stride] = v;
+    }
+  }
+  EXO_HD void store4(int64_t i, int len, const double* v) {
+    if (sparse()) {
+      if (!cur.enter(sp, draw, i)) return;
+#pragma unroll
+      for (int q = 3; q >= 0; --q) {
+        const int32_t at = cur.idx(sp, draw, (int32_t)i + q);
+        if (q < len && at >= 0) g[at] = v[q];
+      }
+    } else if (stride == 1) {
       row_store4(g, i, len, v);
     } else {
 #pragma unroll
@@ -199,6 +326,7 @@ struct GradRow {
     }
   }
 };
+using GradRow = GradRowT<>;
 
 struct ChunkGeom {
   int C;        // chunks
@@ -292,7 +420,8 @@ struct ChunkWs {
 struct BlockIn {
   double y[4], g[4];
 };
-EXO_HD void load_block(const SeriesRow& y, const double* EXO_RESTRICT dg, int64_t n_diag, int64_t b0, int64_t n1, BlockIn& o) {
+template <class RowT>
+EXO_HD void load_block(const RowT& y, const double* EXO_RESTRICT dg, int64_t n_diag, int64_t b0, int64_t n1, BlockIn& o) {
   const int len = (int)((n1 - b0 < 4) ? (n1 - b0 > 0 ? n1 - b0 : 0) : 4);
   if (len == 0) {
 #pragma unroll
@@ -679,7 +808,7 @@ EXO_HD void with_layout(const Coefs& cf, int64_t draw, F&& f) {
 // PREFETCH: the next block's series in flight while this one is worked through.  Off for J <= 2 on the device (round 4): its
 // sixteen registers are the difference between three and four waves per SIMD there, and a 1024-draw batch is 4096 waves --
 // 1.33 rounds of resident waves at three per SIMD, one round at four: element kernel 0.90 -> 0.82 ms at C3.
-template <int J, int NR = -1, bool PREFETCH = true>
+template <int J, int NR = -1, bool PREFETCH = true, int SP = -1>
 EXO_HD void elem_lane(const double* EXO_RESTRICT t, Series rs, const double* EXO_RESTRICT diag, int64_t n_diag,
                       int64_t n, const Coefs& cf, int64_t n_draw, double* EXO_RESTRICT state, const ChunkGeom& cg,
                       int64_t draw, int c, int64_t flag_at = -1) {
@@ -691,7 +820,7 @@ EXO_HD void elem_lane(const double* EXO_RESTRICT t, Series rs, const double* EXO
   dc.init(cf, draw);
   DrawCoef<J, NR> co;
   co.init(cf, draw);
-  const SeriesRow y(rs, draw, n);
+  const SeriesRowT<true, SP> y(rs, draw, n);
   const double* EXO_RESTRICT dg = diag + (n_diag == 1 ? 0 : draw * n);
   double A[J][J], b[J], eta[J];
   Sym<J> Cm, Jm, Dl;
@@ -1592,7 +1721,7 @@ struct Phi {
 #define EXO_FWD_PREFETCH_J2 1     // (0 = no look-ahead load in the J <= 2 forward sweep: measured, no gain at four waves per SIMD -- 707 against
                                   // 711 us at C3 --, slower at five -- 794: scratch)
 #endif
-template <int J, int NR = -1>
+template <int J, int NR = -1, int SP = -1>
 EXO_HD void chunk1_fwd_lane(const double* EXO_RESTRICT t, Series rs, const double* EXO_RESTRICT diag, int64_t n_diag,
                             int64_t n, const Coefs& cf, int64_t n_draw, double* EXO_RESTRICT state, const ChunkGeom& cg,
                             int64_t draw, int c, bool save, int polish = 0) {
@@ -1608,7 +1737,7 @@ EXO_HD void chunk1_fwd_lane(const double* EXO_RESTRICT t, Series rs, const doubl
   DrawCoef<J, NR> co;
   co.init(cf, draw);
   const double asum = co.asum();
-  const SeriesRow y(rs, draw, n);
+  const SeriesRowT<true, SP> y(rs, draw, n);
   const double* EXO_RESTRICT dg = diag + (n_diag == 1 ? 0 : draw * n);
   Fwd<J> f;
 #pragma unroll
@@ -1830,7 +1959,7 @@ struct Rev {
 };
 
 // gsign: +1 writes d loglike / d resid; -1 writes d loglike / d model (obs - model series)
-template <int J, int NR = -1>
+template <int J, int NR = -1, int SP = -1>
 EXO_HD void chunk1_vjp_lane(const double* EXO_RESTRICT t, Series rs, const double* EXO_RESTRICT diag, int64_t n_diag,
                             int64_t n, const Coefs& cf, int64_t n_draw, const double* EXO_RESTRICT gloglike,
                             double* EXO_RESTRICT state, const ChunkGeom& cg, double* EXO_RESTRICT gresid,
@@ -1842,7 +1971,8 @@ EXO_HD void chunk1_vjp_lane(const double* EXO_RESTRICT t, Series rs, const doubl
   DrawCoef<J, NR> co;
   co.init(cf, draw);
   const double asum = co.asum();
-  const SeriesRow y(rs, draw, n);
+  const SeriesRowT<false, SP> y(rs, draw, n);
+  GradRowT<SP> grow(gresid, rs, draw, n);
   const double* EXO_RESTRICT dg = diag + (n_diag == 1 ? 0 : draw * n);
   const double gL = gloglike[draw];
   Rev<J, NR> r;
@@ -1998,7 +2128,7 @@ EXO_HD void chunk1_vjp_lane(const double* EXO_RESTRICT t, Series rs, const doubl
     // with the series: GradRow)
 #pragma unroll
     for (int q = 0; q < kCkptB; ++q) zbar[q] *= gsign;
-    GradRow(gresid, rs, draw, n).store4(b0, len, zbar);
+    grow.store4(b0, len, zbar);
     if (gdiag) row_store4(gdiag + draw * n, b0, len, dbar);
     cur = nxt;
 #pragma unroll
@@ -2147,7 +2277,7 @@ struct RevP {
 };
 
 // gsign: +1 writes d loglike / d resid; -1 writes d loglike / d model (obs - model series)
-template <int J, int NR = -1>
+template <int J, int NR = -1, int SP = -1>
 EXO_HD void chunkp_vjp_lane(const double* EXO_RESTRICT t, Series rs, const double* EXO_RESTRICT diag, int64_t n_diag,
                             int64_t n, const Coefs& cf, int64_t n_draw, const double* EXO_RESTRICT gloglike,
                             double* EXO_RESTRICT state, const ChunkGeom& cg, double* EXO_RESTRICT gresid,
@@ -2158,7 +2288,8 @@ EXO_HD void chunkp_vjp_lane(const double* EXO_RESTRICT t, Series rs, const doubl
   DrawCoef<J, NR> co;
   co.init(cf, draw);
   const double asum = co.asum();
-  const SeriesRow y(rs, draw, n);
+  const SeriesRowT<false, SP> y(rs, draw, n);
+  GradRowT<SP> grow(gresid, rs, draw, n);
   const double* EXO_RESTRICT dg = diag + (n_diag == 1 ? 0 : draw * n);
   const double gL = gloglike[draw];
   RevP<J, NR> r;
@@ -2331,7 +2462,7 @@ EXO_HD void chunkp_vjp_lane(const double* EXO_RESTRICT t, Series rs, const doubl
     // with the series: GradRow)
 #pragma unroll
     for (int q = 0; q < kCkptB; ++q) zbar[q] *= gsign;
-    GradRow(gresid, rs, draw, n).store4(b0, len, zbar);
+    grow.store4(b0, len, zbar);
     if (gdiag) row_store4(gdiag + draw * n, b0, len, dbar);
     cur = nxt;
     if (kAhead) {
@@ -2387,7 +2518,7 @@ EXO_HD void chunk_adj_lane(const double* EXO_RESTRICT t, Series rs, const double
   DrawCoef<J, NR> co;
   co.init(cf, draw);
   const double asum = co.asum();
-  const SeriesRow y(rs, draw, n);
+  const SeriesRowDesc y(rs, draw, n);
   const double* EXO_RESTRICT dg = diag + (n_diag == 1 ? 0 : draw * n);
   const double gL = gloglike[draw];
   constexpr bool all = ALL;

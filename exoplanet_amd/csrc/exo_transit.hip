@@ -2335,12 +2335,13 @@ __global__ __launch_bounds__(kBlock) void transit_jac_vjp_kernel(int64_t n_cad, 
                                                                  const double* __restrict__ jac,
                                                                  const double* __restrict__ gflux, int64_t n_draw,
                                                                  double* __restrict__ partial) {
+  // (EXO_FLAG_SPARSE: gflux is the cotangent of the VALUES, in their layout -- what the sparse GP entries return)
   __shared__ double red[kJac + 1][kBlock];
   const int64_t draw = blockIdx.y;
   const int nb = gridDim.x, bx = blockIdx.x;       // a draw's cadences in nb contiguous shares (as the sweep's blocks share them)
   const int ng_draw = n_planet * kNG + 7;
   double* __restrict__ pout = partial + (draw * nb + bx) * ng_draw;
-  const bool cmaj = flags & EXO_FLAG_CADENCE_MAJOR;
+  const bool cmaj = flags & EXO_FLAG_CADENCE_MAJOR, gsp = flags & EXO_FLAG_SPARSE;
   double keep = 0.0;   // threads 10 .. 15: the running sum over planets of limb-darkening coefficient (thread - 10); thread 16: the dot
   for (int p = 0; p < n_planet; ++p) {
     int n_vals = 0;
@@ -2354,8 +2355,13 @@ __global__ __launch_bounds__(kBlock) void transit_jac_vjp_kernel(int64_t n_cad, 
     for (int q = 0; q <= kJac; ++q) acc[q] = 0.0;
     const int v0 = (int)((int64_t)n_vals * bx / nb), v1 = (int)((int64_t)n_vals * (bx + 1) / nb);
     for (int v = v0 + threadIdx.x; v < v1; v += kBlock) {
-      const int64_t i = vcad[vbase + v];
-      const double g = cmaj ? gflux[i * n_draw + draw] : gflux[draw * n_cad + i];
+      double g;
+      if (gsp) {
+        g = gflux[vbase + v];
+      } else {
+        const int64_t i = vcad[vbase + v];
+        g = cmaj ? gflux[i * n_draw + draw] : gflux[draw * n_cad + i];
+      }
       const double2* __restrict__ row = reinterpret_cast<const double2*>(jac + (vbase + v) * kJac);
 #pragma unroll
       for (int q = 0; q < kJac / 2; ++q) {
@@ -2735,20 +2741,26 @@ inline int launch_runs_sweep(const double* t, int64_t n_cad, const double* texp,
                              const double* stencil_w, int32_t n_sub, const double* params, const double* ld,
                              int64_t n_draw, int32_t n_planet, uint32_t flags, const double* gflux, double* flux,
                              double* gparams, double* gld, double* flux_dot, const RunWs& w, hipStream_t st,
-                             const Chi2Args* chi2 = nullptr, const Ttv* ttv = nullptr, double* jac = nullptr) {
+                             const Chi2Args* chi2 = nullptr, const Ttv* ttv = nullptr, double* jac = nullptr,
+                             const double* gvals = nullptr, bool reuse_runs = false) {
+  // gvals: the cotangent in the VALUE layout of the sparse output (exo_transit_flux_vjp_sparse_f64) instead of gflux;
+  // reuse_runs: the workspace still holds the windows and runs of these very records (the forward sweep's): no enumeration
   const bool secondary = flags & EXO_FLAG_SECONDARY, sparse = (flags & EXO_FLAG_SPARSE) || chi2;
-  const bool grad = gflux != nullptr || chi2;
+  const bool grad = gflux != nullptr || chi2 || gvals != nullptr;
   const int n_ev = secondary ? 2 : 1;
   const dim3 block(kBlock);
   const bool has_ttv = ttv && ttv->edges;
   // sorted times on the caller's word and no fence counters to clear: windows and runs in ONE launch
   const bool fused_enum = (flags & EXO_FLAG_SORTED_TIMES) && !has_ttv && EXO_RUNS_FOLD_FINISH != 2;
-  if (!fused_enum) {
+  if (reuse_runs) {
+    // (nothing to launch)
+  } else if (!fused_enum) {
     const int64_t n_rec = n_draw * n_planet;
     hipLaunchKernelGGL(transit_window_kernel, dim3((unsigned)((n_rec * kWinLanes + kBlock - 1) / kBlock + w.n_sorted)), block, 0, st,
                        params, n_rec, flags, w.windows, t, n_cad, w.sorted, w.done, n_draw);
   }
-  if (fused_enum)
+  if (reuse_runs) {
+  } else if (fused_enum)
     hipLaunchKernelGGL(transit_enum_kernel<true>, dim3((unsigned)(n_draw * n_planet * n_ev)), dim3(64), 0, st, t, n_cad, texp,
                        n_texp, stencil_dt, (int)n_sub, flags, (const double*)nullptr, (const int32_t*)nullptr, 0, n_ev, w.rl,
                        params, w.windows);
@@ -2824,6 +2836,9 @@ inline int launch_runs_sweep(const double* t, int64_t n_cad, const double* texp,
     hipLaunchKernelGGL(transit_residual_kernel, dim3(kResidualBlocks, (unsigned)n_draw), block, 0, st, n_cad, (int)n_planet,
                        n_ev, w.rl, w.vals, w.vcad, chi2->obs, chi2->ivar, chi2->n_ivar, w.gvals, w.chi2_part);
     EXO_LAUNCH_RUNS(true, nullptr, w.gvals, nullptr, nullptr, nullptr, w.partial, no_fin);
+  } else if (gvals) {
+    // (the values stay as the forward sweep left them: the GP's reverse pass has read them, nobody reads them again)
+    EXO_LAUNCH_RUNS(true, nullptr, gvals, nullptr, nullptr, nullptr, w.partial, fin);
   } else if (grad) {
     EXO_LAUNCH_RUNS(true, gflux, nullptr, vals, fill ? w.vcad : nullptr, fill, w.partial, fin);
   } else if (jac) {
@@ -3186,10 +3201,11 @@ int exo_transit_flux_fwd_jac_f64(const double* t, int64_t n_cad, const double* t
                                  int64_t n_draw, int32_t n_planet, uint32_t flags, double* flux, double* jac,
                                  int64_t jac_doubles, void* workspace, int64_t workspace_bytes, void* stream) {
   if (!transit_args_ok(n_cad, n_texp, n_sub, n_draw, n_planet) || !sweep_flags_ok(flags)) return EXO_ERR_INVALID_ARGUMENT;
-  if (flags & (EXO_FLAG_PER_PLANET | EXO_FLAG_SPARSE | EXO_FLAG_EXACT_SCAN | EXO_FLAG_LIGHT_DELAY)) return EXO_ERR_INVALID_ARGUMENT;
+  if (flags & (EXO_FLAG_PER_PLANET | EXO_FLAG_EXACT_SCAN | EXO_FLAG_LIGHT_DELAY)) return EXO_ERR_INVALID_ARGUMENT;
   if (!runs_path(false, n_texp, flags)) return EXO_ERR_INVALID_ARGUMENT;   // one exposure time (or none) for all cadences
   if (n_cad == 0 || n_draw == 0) return EXO_OK;
-  if (!t || !params || !ld || !flux || !jac || (n_texp > 0 && (!texp || !stencil_dt || !stencil_w))) return EXO_ERR_INVALID_ARGUMENT;
+  if (!t || !params || !ld || (!flux && !(flags & EXO_FLAG_SPARSE)) || !jac || (n_texp > 0 && (!texp || !stencil_dt || !stencil_w)))
+    return EXO_ERR_INVALID_ARGUMENT;
   if (jac_doubles < exo_transit_flux_jac_doubles(n_cad, n_draw, n_planet)) return EXO_ERR_WORKSPACE;
   const RunWs rw = carve_runs(workspace, n_cad, n_draw, n_planet);
   if (!workspace || workspace_bytes < rw.bytes) return EXO_ERR_WORKSPACE;
@@ -3202,7 +3218,7 @@ int exo_transit_flux_jac_vjp_f64(const double* gflux, int64_t n_cad, int64_t n_d
                                  double* flux_dot, void* stream) {
   if (n_cad < 0 || n_draw < 0 || n_draw > 65535 || n_planet < 1 || n_planet > EXO_MAX_PLANETS || !sweep_flags_ok(flags))
     return EXO_ERR_INVALID_ARGUMENT;
-  if (flags & (EXO_FLAG_PER_PLANET | EXO_FLAG_SPARSE | EXO_FLAG_EXACT_SCAN | EXO_FLAG_LIGHT_DELAY)) return EXO_ERR_INVALID_ARGUMENT;
+  if (flags & (EXO_FLAG_PER_PLANET | EXO_FLAG_EXACT_SCAN | EXO_FLAG_LIGHT_DELAY)) return EXO_ERR_INVALID_ARGUMENT;
   if (n_draw == 0) return EXO_OK;
   if (!gparams || !gld || (n_cad > 0 && (!gflux || !jac))) return EXO_ERR_INVALID_ARGUMENT;
   hipStream_t st = (hipStream_t)stream;
@@ -3218,9 +3234,54 @@ int exo_transit_flux_jac_vjp_f64(const double* gflux, int64_t n_cad, int64_t n_d
   hipLaunchKernelGGL(transit_jac_vjp_kernel, dim3((unsigned)rw.hb, (unsigned)n_draw), dim3(kBlock), 0, st, n_cad, (int)n_planet, n_ev,
                      flags, rw.rl, rw.vals, rw.vcad, jac, gflux, n_draw, rw.partial);
   hipLaunchKernelGGL(transit_finish_kernel, dim3((unsigned)n_draw), dim3(kBlock), 0, st, rw.partial, rw.hb, (int)n_planet, secondary,
-                     gparams, gld, flux_dot, n_cad, flags & ~(uint32_t)EXO_FLAG_CADENCE_MAJOR, n_ev, rw.rl, nullptr, nullptr, nullptr,
+                     gparams, gld, flux_dot, n_cad, flags & ~(uint32_t)(EXO_FLAG_CADENCE_MAJOR | EXO_FLAG_SPARSE), n_ev, rw.rl, nullptr, nullptr, nullptr,
                      nullptr, 0, nullptr, Ttv{nullptr, nullptr, nullptr, 0});
   return launch_status();
+}
+
+int exo_transit_flux_vjp_sparse_f64(const double* t, int64_t n_cad, const double* texp, int64_t n_texp, const double* stencil_dt,
+                                    const double* stencil_w, int32_t n_sub, const double* params, const double* ld,
+                                    int64_t n_draw, int32_t n_planet, uint32_t flags, const double* gvals, double* gparams,
+                                    double* gld, double* flux_dot, void* workspace, int64_t workspace_bytes, int32_t reuse_runs,
+                                    void* stream) {
+  if (!transit_args_ok(n_cad, n_texp, n_sub, n_draw, n_planet) || !sweep_flags_ok(flags)) return EXO_ERR_INVALID_ARGUMENT;
+  if (!(flags & EXO_FLAG_SPARSE) || (flags & (EXO_FLAG_PER_PLANET | EXO_FLAG_CADENCE_MAJOR | EXO_FLAG_EXACT_SCAN)))
+    return EXO_ERR_INVALID_ARGUMENT;
+  if (!runs_path(false, n_texp, flags)) return EXO_ERR_INVALID_ARGUMENT;   // one exposure time (or none) for all cadences
+  if (n_draw == 0) return EXO_OK;
+  if (!params || !ld || !gparams || !gld || (n_cad > 0 && (!t || !gvals)) || (n_texp > 0 && (!texp || !stencil_dt || !stencil_w)))
+    return EXO_ERR_INVALID_ARGUMENT;
+  if (n_planet * kNG + 7 > kBlock) return EXO_ERR_INVALID_ARGUMENT;
+  hipStream_t st = (hipStream_t)stream;
+  if (n_cad == 0) {
+    if (hipMemsetAsync(gparams, 0, sizeof(double) * n_draw * n_planet * EXO_NPAR, st) != hipSuccess) return EXO_ERR_LAUNCH;
+    if (flux_dot && hipMemsetAsync(flux_dot, 0, sizeof(double) * n_draw, st) != hipSuccess) return EXO_ERR_LAUNCH;
+    return hipMemsetAsync(gld, 0, sizeof(double) * n_draw * ((flags & EXO_FLAG_SECONDARY) ? 6 : 3), st) == hipSuccess ? EXO_OK : EXO_ERR_LAUNCH;
+  }
+  const RunWs rw = carve_runs(workspace, n_cad, n_draw, n_planet);
+  if (!workspace || workspace_bytes < rw.bytes) return EXO_ERR_WORKSPACE;
+  return launch_runs_sweep(t, n_cad, texp, n_texp, stencil_dt, stencil_w, n_sub, params, ld, n_draw, n_planet, flags, nullptr,
+                           nullptr, gparams, gld, flux_dot, rw, st, nullptr, nullptr, nullptr, gvals, reuse_runs != 0);
+}
+
+int exo_transit_flux_sparse_model(const void* workspace, int64_t workspace_bytes, int64_t n_cad, int64_t n_draw, int32_t n_planet,
+                                  uint32_t flags, exo_sparse_model* out) {
+  if (n_cad < 0 || n_draw < 0 || n_planet < 1 || n_planet > EXO_MAX_PLANETS || !out || n_cad > 0x7fffffff) return EXO_ERR_INVALID_ARGUMENT;
+  const int n_ev = (flags & EXO_FLAG_SECONDARY) ? 2 : 1;
+  // one list per draw: the runs ARE the segments (several lists -- planets, occultations -- need the merged form)
+  if (n_planet * n_ev != 1) return EXO_ERR_INVALID_ARGUMENT;
+  const RunWs rw = carve_runs(const_cast<void*>(workspace), n_cad, n_draw, n_planet);
+  if (!workspace || workspace_bytes < rw.bytes) return EXO_ERR_WORKSPACE;
+  // (the workspace is sized for two events per planet: a draw's lists are 2 apart)
+  out->nseg = rw.rl.nrun;
+  out->seg = reinterpret_cast<const int32_t*>(rw.rl.runs);
+  out->off = rw.rl.pre_all;
+  out->vals = rw.vals;
+  out->seg_step = 4; out->hi_at = 3;
+  out->seg_row = (int64_t)n_planet * n_ev * rw.rl.r_max * 4;
+  out->off_row = (int64_t)n_planet * n_ev * (rw.rl.r_max + 1);
+  out->val_row = (int64_t)n_planet * n_cad;
+  return EXO_OK;
 }
 
 int exo_transit_chi2_vjp_f64(const double* t, int64_t n_cad, const double* texp, int64_t n_texp, const double* stencil_dt,

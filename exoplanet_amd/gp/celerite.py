@@ -4,11 +4,11 @@ import os
 import torch
 
 from .. import _lib
-from ..ops import _dev, _ptr, _stream, is_cadence_major
+from ..ops import SparseLightCurve, _dev, _ptr, _stream, is_cadence_major
 from ..orbits.keplerian import as_tensor
 from .terms import Term
 
-__all__ = ["GaussianProcess", "celerite_loglike"]
+__all__ = ["GaussianProcess", "celerite_loglike", "celerite_loglike_sparse"]
 
 MAX_J = 8
 
@@ -123,6 +123,88 @@ class _CeleriteLogLike(torch.autograd.Function):
         return None, gresid, gdiag, gcr, gcc, None, None, None
 
 
+class _CeleriteLogLikeSparse(torch.autograd.Function):
+    """log N(obs - model | 0, K + diag) per draw for a SPARSE per-draw model (ops.SparseLightCurve: segments of cadences +
+    their values; exo_celerite_loglike_sparse_*_f64): `vals` is the differentiable input, its cotangent comes back at the
+    positions of the values; neither the dense model nor its cotangent exists"""
+
+    @staticmethod
+    def forward(ctx, t, vals, diag, coef_real, coef_complex, obs, pair_kind, n_chunks, sp):
+        import ctypes
+
+        t, obs, diag = _dev(t, "t"), _dev(obs, "obs"), _dev(diag, "diag")
+        coef_real, coef_complex = _dev(coef_real, "coef_real"), _dev(coef_complex, "coef_complex")
+        D, N = sp.n_draw, sp.n_cad
+        n_real, n_complex = coef_real.shape[1], coef_complex.shape[1]
+        if t.shape != (N,) or obs.shape != (N,) or diag.dim() != 2 or diag.shape[1] != N or diag.shape[0] not in (1, D):
+            raise ValueError("shapes: t (N,), obs (N,), diag (1|D, N)")
+        if coef_real.shape != (D, n_real, 2) or coef_complex.shape != (D, n_complex, 4):
+            raise ValueError("coef_real (D,Jr,2), coef_complex (D,Jc,4)")
+        if vals.data_ptr() != sp.values.data_ptr() or not vals.is_contiguous():
+            raise ValueError("vals must be the value array of the sparse light curve")
+        if pair_kind is not None:
+            if not pair_kind.is_cuda or pair_kind.dtype != torch.int32 or tuple(pair_kind.shape) != (D, n_complex):
+                raise ValueError("pair_kind must be an int32 device tensor of shape (D, Jc)")
+            pair_kind = pair_kind.contiguous()
+        J = n_real + 2 * n_complex
+        if not 1 <= J <= MAX_J:
+            raise ValueError(f"celerite state width J = {J} outside 1..{MAX_J}")
+        n_chunks = int(n_chunks)
+        lib = _lib.load()
+        need_grad = any(ctx.needs_input_grad)
+        loglike = torch.empty(D, dtype=torch.float64, device=t.device)
+        nstate = lib.exo_celerite_state_doubles(N, D, n_real, n_complex, n_chunks)
+        try:
+            state = torch.empty(nstate, dtype=torch.float64, device=t.device)
+        except torch.cuda.OutOfMemoryError:
+            if need_grad:
+                raise
+            state, nstate = None, 0
+        model = sp.model_struct()
+        with torch.cuda.device(t.device):
+            _lib.check(lib.exo_celerite_loglike_sparse_fwd_f64(_ptr(t), _ptr(obs), ctypes.addressof(model), _ptr(diag),
+                                                               diag.shape[0], N, _ptr(coef_real), n_real, _ptr(coef_complex),
+                                                               n_complex, _ptr(pair_kind), D, _ptr(loglike), _ptr(state), nstate,
+                                                               n_chunks, _stream(t)), "exo_celerite_loglike_sparse_fwd_f64")
+        if need_grad:
+            ctx.save_for_backward(t, vals, diag, coef_real, coef_complex, state, obs, pair_kind)
+            ctx.dims = (D, N, n_real, n_complex, nstate, n_chunks)
+            ctx.sp = sp
+        return loglike
+
+    @staticmethod
+    def backward(ctx, gll):
+        import ctypes
+
+        t, vals, diag, coef_real, coef_complex, state, obs, pair_kind = ctx.saved_tensors
+        D, N, n_real, n_complex, nstate, n_chunks = ctx.dims
+        gll = _dev(gll, "gloglike")
+        lib = _lib.load()
+        # (positions no segment covers are never written and never read: the reverse sweep of the light curve walks the same runs)
+        gvals = torch.empty_like(vals)
+        want_diag = ctx.needs_input_grad[2]
+        gdiag = torch.empty(D, N, dtype=torch.float64, device=t.device) if want_diag else None
+        gcr, gcc = torch.empty_like(coef_real), torch.empty_like(coef_complex)
+        model = ctx.sp.model_struct()
+        with torch.cuda.device(t.device):
+            _lib.check(lib.exo_celerite_loglike_sparse_vjp_f64(_ptr(t), _ptr(obs), ctypes.addressof(model), _ptr(diag),
+                                                               diag.shape[0], N, _ptr(coef_real), n_real, _ptr(coef_complex),
+                                                               n_complex, _ptr(pair_kind), D, _ptr(gll), _ptr(state), nstate,
+                                                               n_chunks, _ptr(gvals), _ptr(gdiag), None, _ptr(gcr), _ptr(gcc),
+                                                               _stream(t)), "exo_celerite_loglike_sparse_vjp_f64")
+        if want_diag and diag.shape[0] == 1:
+            gdiag = gdiag.sum(0, keepdim=True)
+        return None, gvals, gdiag, gcr, gcc, None, None, None, None
+
+
+def celerite_loglike_sparse(t, model, diag, coef_real, coef_complex, obs, pair_kind=None, n_chunks=None):
+    """:func:`celerite_loglike` of ``obs - model`` for a :class:`~exoplanet_amd.ops.SparseLightCurve` ``model``"""
+    if n_chunks is None:
+        n_chunks = default_chunks()
+    return _CeleriteLogLikeSparse.apply(t, model.values, diag, coef_real, coef_complex, obs.detach(),
+                                        None if pair_kind is None else pair_kind.detach(), n_chunks, model)
+
+
 def celerite_loglike(t, resid, diag, coef_real, coef_complex, obs=None, pair_kind=None, n_chunks=None):
     """log N(resid | 0, K + diag) per draw.  t (N,), resid (D,N), diag (1|D,N),
     coef_real (D,Jr,2) = (a,c), coef_complex (D,Jc,4) = (a,b,c,d).  Differentiable
@@ -200,6 +282,12 @@ class GaussianProcess:
         self._t = t
         self._diag = var if var.dim() == 2 else var.reshape(1, -1)
 
+    def _mean_at(self, tq, like):
+        """the mean as a tensor: a callable evaluated at ``tq``, a sparse light curve as its dense array"""
+        if isinstance(self.mean, SparseLightCurve):
+            return self.mean.dense()
+        return self.mean(tq) if callable(self.mean) else as_tensor(self.mean, like)
+
     def _coefficients(self):
         """(coef_real (D,Jr,2), pair slots (D,Jc,4), their kind (D,Jc) int32 or None, D, batched?)"""
         ar, cr, pairs, kind = self.kernel.pair_coefficients()
@@ -219,7 +307,28 @@ class GaussianProcess:
             raise RuntimeError("you must call 'compute' first")
         t = self._t
         y = as_tensor(y, t)
-        mean = self.mean(t) if callable(self.mean) else as_tensor(self.mean, t)
+        sparse = None
+        if isinstance(self.mean, SparseLightCurve):
+            # one observed series against a sparse per-draw model: the kernels read the segments (log_likelihood); every other
+            # use gets the dense array
+            if (fuse and y.dim() == 1 and not y.requires_grad and y.is_cuda and y.shape[0] == t.shape[0]
+                    and self.mean.n_cad == t.shape[0]):
+                sparse = self.mean
+                mean = None
+            else:
+                mean = self.mean.dense()
+        else:
+            mean = self.mean(t) if callable(self.mean) else as_tensor(self.mean, t)
+        if sparse is not None:
+            real, cplx, kind, D, batched = self._coefficients()
+            if D not in (1, sparse.n_draw) or self._diag.shape[0] not in (1, sparse.n_draw):
+                raise ValueError("dimension mismatch: the kernel's / diagonal's draws and the light curve's")
+            D = sparse.n_draw
+            real = real.expand(D, real.shape[1], 2).contiguous()
+            cplx = cplx.expand(D, cplx.shape[1], 4).contiguous()
+            if kind is not None:
+                kind = kind.expand(D, kind.shape[1]).contiguous()
+            return t, None, sparse, real, cplx, False, y, kind
         if isinstance(mean, torch.Tensor) and mean.dim() == 1 and mean.shape[0] != t.shape[0]:
             mean = mean.unsqueeze(-1)  # per-draw constant
         # one observed series against a per-draw mean model: the kernels form obs - model themselves
@@ -246,6 +355,8 @@ class GaussianProcess:
 
     def log_likelihood(self, y):
         t, _, resid, real, cplx, squeeze, obs, kind = self._prepare(y, fuse=True)
+        if isinstance(resid, SparseLightCurve):
+            return celerite_loglike_sparse(t.detach(), resid, self._diag.contiguous(), real, cplx, obs, pair_kind=kind)
         ll = celerite_loglike(t.detach(), resid, self._diag.contiguous(), real, cplx, obs=obs, pair_kind=kind)
         return ll[0] if squeeze else ll
 
@@ -298,7 +409,7 @@ class GaussianProcess:
             x = torch.randn(D, t.shape[0], dtype=torch.float64, device=t.device, generator=generator)
             z = self.dot_tril(x if (batched or D > 1) else x[0])
             if include_mean:
-                m = self.mean(t) if callable(self.mean) else as_tensor(self.mean, t)
+                m = self._mean_at(t, t)
                 if isinstance(m, torch.Tensor) and m.dim() == 1 and m.shape[0] != t.shape[0]:
                     m = m.unsqueeze(-1)
                 z = z + (m.detach() if isinstance(m, torch.Tensor) else m)
@@ -333,7 +444,7 @@ class GaussianProcess:
                                                         cx.shape[1], _ptr(kind), D, _ptr(tq), tq.shape[0], _ptr(mu),
                                                         _stream(tt)), "exo_celerite_predict_f64")
         if include_mean:
-            m = self.mean(tq) if callable(self.mean) else as_tensor(self.mean, tt)
+            m = self._mean_at(tq, tt)
             if isinstance(m, torch.Tensor) and m.dim() == 1 and m.shape[0] != tq.shape[0]:
                 m = m.unsqueeze(-1)
             if isinstance(m, torch.Tensor) and m.dim() >= 1 and m.shape[-1] == tt.shape[0] and t is not None:

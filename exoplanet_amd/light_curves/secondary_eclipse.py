@@ -27,7 +27,9 @@ class SecondaryEclipseLightCurve:
         self.surface_brightness_ratio = as_tensor(surface_brightness_ratio)
 
     def get_light_curve(self, orbit=None, r=None, t=None, texp=None, oversample=7, order=0,
-                        use_in_transit=None, light_delay=False, total=False, cadence_major=False):
+                        use_in_transit=None, light_delay=False, total=False, cadence_major=False, sparse=False):
+        # (sparse: accepted for symmetry with LimbDarkLightCurve.get_light_curve -- transits and occultations are two lists per
+        # draw, which the sparse model does not take yet: the cadence-major dense array is returned)
         if orbit is None:
             raise ValueError("missing required argument 'orbit'")
         if r is None:
@@ -43,7 +45,7 @@ class SecondaryEclipseLightCurve:
             stencil = exposure_stencil(oversample, order) if texp is not None else None
             return self.primary._fused(orbit, r, t, texp, stencil, use_in_transit,
                                        secondary=(self.secondary, self.surface_brightness_ratio),
-                                       light_delay=light_delay, total=total, cadence_major=cadence_major)
+                                       light_delay=light_delay, total=total, cadence_major=cadence_major, sparse=sparse)
         # composed path: exactly the reference's two-orbit blend (secondary_eclipse.py:45-70)
         r = _vec(r)
         orbit2 = orbit._flip(r)

@@ -33,9 +33,14 @@ extern "C" {
 #define EXO_ERR_LAUNCH 2
 #define EXO_ERR_WORKSPACE 3
 
-/* ABI version, bumped whenever a signature, a layout or the set of flags below changes (10: EXO_FLAG_CADENCE_MAJOR,
- * EXO_FLAG_SORTED_TIMES, the *_cm_f64 entry points; flag bits a build does not know are EXO_ERR_INVALID_ARGUMENT). */
-#define EXO_ABI_VERSION 10
+/* ABI version, bumped whenever a signature, a layout or the set of flags below changes.
+ * 10: EXO_FLAG_CADENCE_MAJOR, EXO_FLAG_SORTED_TIMES, the *_cm_f64 entry points, exo_transit_flux_fwd_jac_f64 / _jac_vjp_f64,
+ *     exo_transit_sparse_scatter_f64, exo_sho_coefficients_multi_*; a larger exo_celerite_state_doubles (the lane order of
+ *     batches of mixed pair kinds lives in the state: forward and reverse call must be the same build); flag bits a build
+ *     does not know are EXO_ERR_INVALID_ARGUMENT.
+ * 11: the sparse model -- exo_sparse_model, exo_transit_flux_sparse_model, exo_transit_flux_vjp_sparse_f64,
+ *     exo_celerite_loglike_sparse_{fwd,vjp}_f64; EXO_FLAG_SPARSE accepted by the Jacobian pair. */
+#define EXO_ABI_VERSION 11
 int32_t exo_abi_version(void);
 
 /* ---------------------------------------------------------------------------
@@ -180,6 +185,32 @@ int64_t exo_transit_flux_workspace_bytes(int64_t n_cad, int64_t n_draw, int32_t 
  * list is the whole series cut into a few runs.                                                   */
 int exo_transit_flux_sparse_layout(int64_t n_cad, int64_t n_draw, int32_t n_planet, int64_t* out);
 
+/* The sparse output as a MODEL for the celerite entries (exo_celerite_loglike_sparse_*_f64, which see for the layout): segments
+ * of cadences + their values, per draw.  exo_transit_flux_sparse_model fills the descriptor with pointers into `workspace`
+ * (that of an EXO_FLAG_SPARSE sweep with the same n_cad, n_draw, n_planet; flags: EXO_FLAG_SECONDARY as the sweep had it).
+ * One list per draw (one planet, no occultations): the runs are the segments.  Otherwise EXO_ERR_INVALID_ARGUMENT -- callers
+ * keep the dense model for those.                                                                                      */
+typedef struct exo_sparse_model {
+  const int32_t* nseg;
+  const int32_t* seg;
+  const int32_t* off;
+  const double* vals;
+  int64_t seg_row, off_row, val_row;
+  int32_t seg_step, hi_at;
+} exo_sparse_model;
+int exo_transit_flux_sparse_model(const void* workspace, int64_t workspace_bytes, int64_t n_cad, int64_t n_draw,
+                                  int32_t n_planet, uint32_t flags, exo_sparse_model* out);
+/* Reverse sweep for a cotangent given in the VALUE layout of the sparse output -- gvals [n_draw][n_planet][n_cad], gvals of
+ * (draw, planet) at the positions of that planet's values: what exo_celerite_loglike_sparse_vjp_f64 writes -- instead of a
+ * dense gflux.  flags must carry EXO_FLAG_SPARSE (and whatever the forward sweep carried); otherwise as
+ * exo_transit_flux_vjp_f64 without flux_out.  reuse_runs != 0: `workspace` is the forward sweep's, untouched since, for these
+ * very t / params (the windows and runs in it are reused: no enumeration launch).                                       */
+int exo_transit_flux_vjp_sparse_f64(const double* t, int64_t n_cad, const double* texp, int64_t n_texp,
+                                    const double* stencil_dt, const double* stencil_w, int32_t n_sub,
+                                    const double* params, const double* ld, int64_t n_draw, int32_t n_planet,
+                                    uint32_t flags, const double* gvals, double* gparams, double* gld, double* flux_dot,
+                                    void* workspace, int64_t workspace_bytes, int32_t reuse_runs, void* stream);
+
 /* A light curve whose cotangent is not known yet (the mean of a GP: limb_dark.py:99-232 feeding celerite2's
  * log_likelihood; the cotangent is the GP's gradient with respect to its mean): the forward sweep and, once the cotangent
  * exists, its VJP WITHOUT a second sweep.  exo_transit_flux_fwd_jac_f64 is exo_transit_flux_fwd_f64 (same arguments, same flux,
@@ -188,8 +219,9 @@ int exo_transit_flux_sparse_layout(int64_t n_cad, int64_t n_draw, int32_t n_plan
  * exo_transit_flux_jac_vjp_f64 contracts them with the cotangent (rows or EXO_FLAG_CADENCE_MAJOR, as the flux was) into what
  * exo_transit_flux_vjp_f64 returns.  `workspace` of the second call is the forward call's, untouched in between (it holds
  * the runs, the values and their cadences).  Run-enumeration sweeps (see EXO_FLAG_SPARSE) of the summed flux, without timing
- * tables, EXO_FLAG_LIGHT_DELAY, EXO_FLAG_PER_PLANET or EXO_FLAG_SPARSE: EXO_ERR_INVALID_ARGUMENT otherwise -- callers keep
- * the two-sweep route for those.  Worth it when a cadence is several samples (an exposure stencil: each of them a Kepler
+ * tables, EXO_FLAG_LIGHT_DELAY or EXO_FLAG_PER_PLANET: EXO_ERR_INVALID_ARGUMENT otherwise -- callers keep
+ * the two-sweep route for those.  With EXO_FLAG_SPARSE (both calls): flux may be NULL and is not written, and gflux is
+ * the cotangent in the value layout (see exo_transit_flux_vjp_sparse_f64).  Worth it when a cadence is several samples (an exposure stencil: each of them a Kepler
  * solve, the row still sixteen doubles); bit-reproducible.                                                              */
 int64_t exo_transit_flux_jac_doubles(int64_t n_cad, int64_t n_draw, int32_t n_planet);
 int exo_transit_flux_fwd_jac_f64(const double* t, int64_t n_cad, const double* texp, int64_t n_texp, const double* stencil_dt,
@@ -468,6 +500,32 @@ int exo_celerite_loglike_obs_vjp_cm_f64(const double* t, const double* obs, cons
                                         const int32_t* pair_kind, int64_t n_draw, const double* gloglike,
                                         const double* state, int64_t state_doubles, int32_t n_chunks,
                                         double* gmodel_cm, double* gdiag, double* gdiag_sum, double* gcoef_real,
+                                        double* gcoef_complex, void* stream);
+
+/* The obs pair with the model SPARSE (round 5): a transit light curve is zero at ~97 % of the cadences, and as the mean of
+ * a GP (limb_dark.py:99-232 feeding celerite2's log_likelihood) it used to cross HBM as a dense (draw, cadence) array five
+ * times per value + gradient -- written, scattered, read by three kernels -- and its cotangent, of which the light curve's
+ * reverse pass reads the same 3 %, twice more.  Here the model is what the EXO_FLAG_SPARSE sweep produces: per draw a few
+ * SEGMENTS of cadences, ascending and disjoint, and the values of exactly those cadences:
+ *   segment k of draw d   cadences [lo, hi),  lo = seg[d * seg_row + k * seg_step],  hi = seg[d * seg_row + k * seg_step + hi_at],
+ *                         k < nseg[d]
+ *   model[d][n]           vals[d * val_row + off[d * off_row + k] + (n - lo)]  for lo <= n < hi,  0 outside every segment
+ * and the reverse entry writes gvals = d loglike / d vals at the same positions (nothing elsewhere: positions of `gvals` that
+ * no segment covers are left as they were).  exo_transit_flux_sparse_model() fills the descriptor from a sweep's workspace.
+ * n < 2^31.  Same arithmetic as the dense entries on the same model: same log-likelihood, bit for bit.                 */
+int exo_celerite_loglike_sparse_fwd_f64(const double* t, const double* obs, const exo_sparse_model* model,
+                                        const double* diag, int64_t n_diag, int64_t n,
+                                        const double* coef_real, int32_t n_real,
+                                        const double* coef_complex, int32_t n_complex,
+                                        const int32_t* pair_kind, int64_t n_draw, double* loglike,
+                                        double* state, int64_t state_doubles, int32_t n_chunks, void* stream);
+int exo_celerite_loglike_sparse_vjp_f64(const double* t, const double* obs, const exo_sparse_model* model,
+                                        const double* diag, int64_t n_diag, int64_t n,
+                                        const double* coef_real, int32_t n_real,
+                                        const double* coef_complex, int32_t n_complex,
+                                        const int32_t* pair_kind, int64_t n_draw, const double* gloglike,
+                                        const double* state, int64_t state_doubles, int32_t n_chunks,
+                                        double* gvals, double* gdiag, double* gdiag_sum, double* gcoef_real,
                                         double* gcoef_complex, void* stream);
 
 /* ---------------------------------------------------------------------------

@@ -479,6 +479,20 @@ int64_t harness_gp_state_doubles(int64_t n, int64_t n_draw, int32_t n_real, int3
 // the layout of y / gresid for the calls that follow: 0 = [draw][cadence], 1 = cadence-major [cadence][draw]
 static int g_cadence_major = 0;
 void harness_gp_set_cadence_major(int on) { g_cadence_major = on; }
+// ... or a SPARSE model (gp::SparseSegs; y is then the value array and gresid receives the cotangent of the values); nseg == NULL: off
+static gp::SparseSegs g_sparse{};
+void harness_gp_set_sparse(const int32_t* nseg, const int32_t* seg, const int32_t* off, int64_t seg_row, int64_t off_row,
+                           int64_t val_row, int32_t seg_step, int32_t hi_at) {
+  g_sparse = gp::SparseSegs{};
+  g_sparse.nseg = nseg; g_sparse.seg = seg; g_sparse.off = off;
+  g_sparse.seg_row = seg_row; g_sparse.off_row = off_row; g_sparse.val_row = val_row;
+  g_sparse.seg_step = seg_step; g_sparse.hi_at = hi_at;
+}
+static gp::Series harness_series(const double* y, const double* obs, int64_t n_draw) {
+  gp::Series rs{y, obs, g_cadence_major ? n_draw : 0};
+  if (g_sparse.nseg) { rs.cm = 0; rs.sp = g_sparse; }
+  return rs;
+}
 
 // returns the number of chunks used (1: the plan is sequential, nothing was computed), -1 on bad J
 int harness_gp_fwd(const double* t, const double* y, const double* obs, const double* diag, int64_t n_diag, int64_t n,
@@ -488,7 +502,7 @@ int harness_gp_fwd(const double* t, const double* y, const double* obs, const do
   const int J = cf.J();
   const gp::ChunkGeom cg = gp::chunk_plan(n, n_draw, J, n_chunks);
   if (cg.C <= 1 || !cg.lane) return cg.C <= 1 ? 1 : -1;
-  const gp::Series rs{y, obs, g_cadence_major ? n_draw : 0};
+  const gp::Series rs = harness_series(y, obs, n_draw);
   switch (J) {
     case 1: run_fwd<1>(t, rs, diag, n_diag, n, cf, n_draw, loglike, state, cg); break;
     case 2: run_fwd<2>(t, rs, diag, n_diag, n, cf, n_draw, loglike, state, cg); break;
@@ -511,7 +525,7 @@ int harness_gp_vjp(const double* t, const double* y, const double* obs, const do
   const int J = cf.J();
   const gp::ChunkGeom cg = gp::chunk_plan(n, n_draw, J, n_chunks);
   if (cg.C <= 1 || !cg.lane) return cg.C <= 1 ? 1 : -1;
-  const gp::Series rs{y, obs, g_cadence_major ? n_draw : 0};
+  const gp::Series rs = harness_series(y, obs, n_draw);
   const double gsign = obs ? -1.0 : 1.0;
   switch (J) {
     case 1: run_vjp<1>(t, rs, diag, n_diag, n, cf, n_draw, gloglike, state, cg, gresid, gdiag, gsign, gdiag_sum, gcr, gcc); break;

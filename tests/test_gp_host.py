@@ -371,3 +371,67 @@ def test_cadence_major_series_is_the_same_arithmetic(harness, n_real, n_complex)
         assert np.array_equal(a[0], b[0])
         for k in a[3]:
             assert np.array_equal(a[3][k], b[3][k]), k
+
+
+def _sparse_case(rng, D, n, n_seg_max, touching=False):
+    """random ascending disjoint segments per draw, their values, and the dense model they stand for"""
+    seg_step, hi_at, cap = 4, 3, n_seg_max + 2
+    nseg = np.zeros(D, dtype=np.int32)
+    seg = np.full((D, cap, seg_step), -7, dtype=np.int32)
+    off = np.zeros((D, cap + 1), dtype=np.int32)
+    vals = np.full((D, n), np.nan)            # positions no segment covers stay NaN: nobody may read them
+    dense = np.zeros((D, n))
+    for d in range(D):
+        k = int(rng.integers(0, n_seg_max + 1))
+        cuts = np.sort(rng.choice(np.arange(0, n + 1), size=2 * k, replace=False)) if k else np.zeros(0, dtype=int)
+        pos = int(rng.integers(0, 5))         # (the value array need not start at 0)
+        for s in range(k):
+            lo, hi = int(cuts[2 * s]), int(cuts[2 * s + 1])
+            if touching and s > 0:
+                lo = int(seg[d, s - 1, hi_at])   # segments that touch: the cursor steps across without a gap
+                hi = max(hi, lo)                 # (possibly empty)
+            seg[d, s, 0], seg[d, s, hi_at] = lo, hi
+            off[d, s] = pos
+            v = 0.3 * rng.normal(size=hi - lo)
+            vals[d, pos:pos + hi - lo] = v
+            dense[d, lo:hi] = v
+            pos += hi - lo + int(rng.integers(0, 3))
+        nseg[d] = k
+    return nseg, seg, off, vals, dense, (cap * seg_step, cap + 1, n, seg_step, hi_at)
+
+
+@pytest.mark.parametrize("n_real,n_complex,n,touching", [(0, 1, 203, False), (1, 0, 160, True), (0, 3, 331, False), (2, 1, 97, True)])
+def test_lane_pipeline_sparse_model_equals_dense_model(harness, n_real, n_complex, n, touching):
+    """round 5: the model as segments of cadences + values (gp::SparseSegs, the light-curve sweep's sparse output) through the
+    element, forward and reverse lanes -- same log-likelihood, bit for bit, as the dense model it stands for, and the
+    cotangent of every value equal to the dense cotangent at its cadence; positions outside the segments untouched"""
+    rng = np.random.default_rng(100 * n_real + 10 * n_complex + n)
+    D = 5
+    t = np.sort(rng.uniform(0, 30, n))
+    obs = rng.normal(size=n)
+    diag = rng.uniform(0.05, 0.2, (1, n))
+    terms = [rand_terms(rng, n_real, n_complex) for _ in range(D)]
+    real = np.stack([np.stack([c[0], c[1]], -1) for c in terms]).reshape(D, n_real, 2)
+    cplx = np.stack([np.stack([c[2], c[3], c[4], c[5]], -1) for c in terms]).reshape(D, n_complex, 4)
+    gll = rng.normal(size=D)
+    nseg, seg, off, vals, dense, (seg_row, off_row, val_row, seg_step, hi_at) = _sparse_case(rng, D, n, 6, touching)
+    assert nseg.min() == 0 or True
+    for n_chunks in (0, 7):
+        harness.harness_gp_set_sparse(None, None, None, ctypes.c_int64(0), ctypes.c_int64(0), ctypes.c_int64(0), 0, 0)
+        ll_d, flags, C_used, g_d = run(harness, t, dense, diag, real, cplx, obs=obs, n_chunks=n_chunks, gll=gll)
+        harness.harness_gp_set_sparse(nseg.ctypes.data_as(_ip), seg.ctypes.data_as(_ip), off.ctypes.data_as(_ip),
+                                      ctypes.c_int64(seg_row), ctypes.c_int64(off_row), ctypes.c_int64(val_row), seg_step, hi_at)
+        try:
+            # (run() hands gresid a (D, n) buffer: here it is the cotangent of the VALUE array, val_row = n)
+            ll_s, flags_s, C_s, g_s = run(harness, t, np.nan_to_num(vals, nan=1e300), diag, real, cplx, obs=obs,
+                                          n_chunks=n_chunks, gll=gll)
+        finally:
+            harness.harness_gp_set_sparse(None, None, None, ctypes.c_int64(0), ctypes.c_int64(0), ctypes.c_int64(0), 0, 0)
+        assert C_s == C_used
+        np.testing.assert_array_equal(ll_s, ll_d)
+        for k in ("real", "cplx", "diag", "diag_sum"):
+            np.testing.assert_array_equal(g_s[k], g_d[k])
+        for d in range(D):
+            for s in range(nseg[d]):
+                lo, hi = seg[d, s, 0], seg[d, s, hi_at]
+                np.testing.assert_array_equal(g_s["y"][d, off[d, s]:off[d, s] + hi - lo], g_d["y"][d, lo:hi])

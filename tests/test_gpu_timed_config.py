@@ -104,15 +104,23 @@ def chain_to_leaves(vals, gparams, slots, sbr=None, gld=None, u=None):
     return out
 
 
-def assert_grads(got, want, names, rel=GRAD_REL, rows=None):
+def assert_grads(got, want, names, rel=GRAD_REL, rows=None, per_draw=False):
+    """per_draw (the GP configs): every checked draw's gradient is held to `rel` of ITS OWN magnitude -- BASELINE.md's
+    1e-6 -- not to `rel` of the largest gradient in the batch; a draw whose gradient passes through zero is measured against
+    1e-3 of the batch's largest instead (an absolute floor of rel x 1e-3 x scale)"""
     for k in names:
         g, w = npy(got[k]).reshape(want[k].shape if rows is None else (-1,) + want[k].shape[1:]), want[k]
         if rows is not None:
             g = g[rows]
         scale = np.abs(w).max()
         assert scale > 0, k
-        err = np.abs(g - w).max()
-        assert err <= rel * scale, (k, err / scale)
+        if per_draw:
+            den = np.maximum(np.abs(w), 1e-3 * scale)
+            worst = (np.abs(g - w) / den).max()
+            assert worst <= rel, (k, worst)
+        else:
+            err = np.abs(g - w).max()
+            assert err <= rel * scale, (k, err / scale)
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -343,7 +351,7 @@ def test_c3_timed_step_vs_oracle(dev):
     want = chain_to_leaves(vals, gp, list(P.GRAD_SLOTS[:-1]), gld=gl, u=(u1, u2))
     for k, j in (("sigma", 0), ("rho", 1), ("Q", 2)):
         want[k] = gh[:, j]
-    assert_grads(grads, want, wl.names, rel=2e-6, rows=rows)
+    assert_grads(grads, want, wl.names, rel=1e-6, rows=rows, per_draw=True)
 
 
 @pytest.mark.parametrize("D,bright", [(128, 0), (1024, 0), (128, 2)])
@@ -391,12 +399,22 @@ def test_c5_timed_step_vs_oracle(dev, D, bright):
         want_ll.append(a); gflux.append(b); gh.append(h)
     want_ll, gh = np.array(want_ll), np.array(gh)
     assert np.abs(ll[rows] - want_ll).max() <= 1e-10 * np.abs(want_ll).max()
+    # ... and the log-likelihood of EVERY chain (8 of 128 / 1024 were compared): one sequential celerite pass
+    # per chain of the C port on a thread pool (ctypes releases the GIL)
+    from concurrent.futures import ThreadPoolExecutor
+
+    def chain_ll(d):
+        terms = [(float(npy(lv[f"s{j + 1}"])[d]), bench.C5_TERMS[j][1], bench.C5_TERMS[j][2]) for j in range(3)]
+        return C.celerite(t, y - want_f[d], diag, sho_coeffs(terms))
+    with ThreadPoolExecutor(max(1, oracle_threads())) as pool:
+        all_ll = np.array(list(pool.map(chain_ll, range(D))))
+    assert np.abs(ll - all_ll).max() <= 1e-10 * np.abs(all_ll).max(), np.abs(ll - all_ll).max() / np.abs(all_ll).max()
     sub = {k: v[rows] for k, v in vals.items()}
     _, gp, gl = C.transit(t, rec[rows], c[rows], np.stack(gflux), want_flux=False, **kw)
     want = chain_to_leaves(sub, gp, list(P.GRAD_SLOTS), sbr=sbr[rows])
     for j in range(3):
         want[f"s{j + 1}"] = gh[:, j]
-    assert_grads(grads, want, wl.names, rel=2e-6, rows=rows)
+    assert_grads(grads, want, wl.names, rel=1e-6, rows=rows, per_draw=True)
 
 
 # ---------------------------------------------------------------------------------------------------
