@@ -55,6 +55,7 @@ _SIGNATURES = {
          _c_dp, _c_dp, _c_dp, _c_dp, _c_dp, _c_dp, _c_dp, _i64, _c_dp],
     ),
     "exo_celerite_state_doubles": (_i64, [_i64, _i64, _i32, _i32, _i32]),
+    "exo_celerite_default_chunks": (_i32, [_i64, _i64, _i32, _i32, _i32]),
     # t, resid, diag, n_diag, n, coef_real, n_real, coef_complex, n_complex, pair_kind, n_draw, loglike, state,
     # state_doubles, n_chunks, stream
     "exo_celerite_loglike_fwd_f64": (

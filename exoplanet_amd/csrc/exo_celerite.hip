@@ -1349,6 +1349,47 @@ constexpr bool split_layouts(int J) { return EXO_J4_SPLIT && J == 4; }
 #ifndef EXO_ELEM_MIXED_WAVES
 #define EXO_ELEM_MIXED_WAVES 4
 #endif
+// which chunk a block of the one-lane kernels works on.  Dense series: every wave costs the same, blocks in order.  SPARSE
+// model: a wave is slow exactly while one of its draws is inside a transit, and the draws' transits drift apart away from
+// the reference transit time (their periods differ): the chunks far from it are the long ones.  They are dealt FIRST (longest
+// processing time first) and the short ones fill the tail of the launch -- C3 with t0 at the start of the series 3.83 -> 3.68 ms
+// at the dense plan's chunks, 3.58 with twice as many (exo_celerite_default_chunks).  Where "far" is, celerite_sparse_order_kernel
+// reads off the first wave's segments: 1 = the series' end (last chunk first), 2 = both ends (the two ends first, the middle
+// last), 3 = its start (in order).  EXO_SPARSE_LPT=0: always in order.
+#ifndef EXO_SPARSE_LPT
+#define EXO_SPARSE_LPT 1
+#endif
+template <int SP>
+__device__ __forceinline__ int chunk_of_block(const double* __restrict__ state, int64_t n, int64_t n_draw, int J, const ChunkGeom& cg) {
+  const int y = (int)blockIdx.y, C = (int)gridDim.y;
+  if (SP != 1 || !EXO_SPARSE_LPT) return y;
+  const int mode = *reinterpret_cast<const int32_t*>(state + chunk_ws(n, n_draw, J, cg).off_order());
+  if (mode == 1) return C - 1 - y;
+  if (mode == 2) return (y & 1) ? (y >> 1) : C - 1 - (y >> 1);
+  return y;
+}
+// One wave: how far apart the first wave's draws start their FIRST and their LAST segment -- the spread of the transit times at
+// the two ends of the series (draws without a segment do not vote)
+__global__ __launch_bounds__(kWave) void celerite_sparse_order_kernel(SparseSegs sp, int64_t n_draw, int32_t* __restrict__ mode) {
+  const int lane = threadIdx.x;
+  const bool has = lane < n_draw && sp.nseg[lane] > 0;
+  int first = 0, last = 0;
+  if (has) {
+    const int32_t* s = sp.seg + (int64_t)lane * sp.seg_row;
+    first = s[0];
+    last = s[(int64_t)(sp.nseg[lane] - 1) * sp.seg_step];
+  }
+  int lo_f = has ? first : 0x7fffffff, hi_f = has ? first : -0x7fffffff, lo_l = has ? last : 0x7fffffff, hi_l = has ? last : -0x7fffffff;
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) {
+    lo_f = min(lo_f, __shfl_xor(lo_f, m, 64)); hi_f = max(hi_f, __shfl_xor(hi_f, m, 64));
+    lo_l = min(lo_l, __shfl_xor(lo_l, m, 64)); hi_l = max(hi_l, __shfl_xor(hi_l, m, 64));
+  }
+  if (lane == 0) {
+    const int64_t sf = hi_f >= lo_f ? (int64_t)hi_f - lo_f : 0, sl = hi_l >= lo_l ? (int64_t)hi_l - lo_l : 0;
+    *mode = (2 * sf < sl) ? 1 : ((2 * sl < sf) ? 3 : 2);
+  }
+}
 // (A) the filtering element of every (draw, chunk)
 template <int J, int NR, int SP>
 __global__ __launch_bounds__(kWave, (J <= 2 ? EXO_ELEM_MIXED_WAVES : (split_layouts(J) && NR == 0 ? EXO_J4_WAVES : 1))) void celerite_elem_kernel(const double* __restrict__ t, Series rs,
@@ -1359,9 +1400,9 @@ __global__ __launch_bounds__(kWave, (J <= 2 ? EXO_ELEM_MIXED_WAVES : (split_layo
   if (draw >= n_draw) return;
   const int vote = layout_vote<J>(cf, draw);
   if constexpr (J > 2 && NR == -1 && EXO_GP_WIDE_COMPLEX_LAYOUT && !split_layouts(J)) {   // a wave of all-complex draws takes the compile-time layout
-    if (vote == 0) { elem_lane<J, 0, true, SP>(t, rs, diag, n_diag, n, cf, n_draw, state, cg, draw, (int)blockIdx.y, flag_at); return; }
+    if (vote == 0) { elem_lane<J, 0, true, SP>(t, rs, diag, n_diag, n, cf, n_draw, state, cg, draw, chunk_of_block<SP>(state, n, n_draw, J, cg), flag_at); return; }
   } else if (vote != NR) return;
-  elem_lane<J, NR, (J > 2 || EXO_ELEM_MIXED_WAVES < 4), SP>(t, rs, diag, n_diag, n, cf, n_draw, state, cg, draw, (int)blockIdx.y, flag_at);
+  elem_lane<J, NR, (J > 2 || EXO_ELEM_MIXED_WAVES < 4), SP>(t, rs, diag, n_diag, n, cf, n_draw, state, cg, draw, chunk_of_block<SP>(state, n, n_draw, J, cg), flag_at);
 }
 
 // (B), (B'): the scans over the chunks are trees of compositions (celerite_tree_kernel, celerite_compose_lds_kernel above).
@@ -1385,9 +1426,9 @@ __global__ __launch_bounds__(kWave, (split_layouts(J) && NR == 0 ? 3 : 1)) void 
   if (draw >= n_draw) return;
   const int vote = layout_vote<J>(cf, draw);
   if constexpr (J > 2 && NR == -1 && EXO_GP_WIDE_COMPLEX_LAYOUT && !split_layouts(J)) {
-    if (vote == 0) { chunk1_fwd_lane<J, 0, SP>(t, rs, diag, n_diag, n, cf, n_draw, state, cg, draw, (int)blockIdx.y, true); return; }
+    if (vote == 0) { chunk1_fwd_lane<J, 0, SP>(t, rs, diag, n_diag, n, cf, n_draw, state, cg, draw, chunk_of_block<SP>(state, n, n_draw, J, cg), true); return; }
   } else if (vote != NR) return;
-  chunk1_fwd_lane<J, NR, SP>(t, rs, diag, n_diag, n, cf, n_draw, state, cg, draw, (int)blockIdx.y, true);
+  chunk1_fwd_lane<J, NR, SP>(t, rs, diag, n_diag, n, cf, n_draw, state, cg, draw, chunk_of_block<SP>(state, n, n_draw, J, cg), true);
 }
 // (two waves per SIMD asked for: the J = 2 complex-term variant sits at 254 + 4 registers otherwise -- one wave)
 #ifndef EXO_VJP1_WAVES
@@ -1413,15 +1454,15 @@ __global__ __launch_bounds__(kWave, (J < EXO_SPAN2_MIN_J ? EXO_VJP1_WAVES : (J <
     __shared__ double gacc[4 * J + 1][kWave];
     if constexpr (kBoth) {
       if (vote == 0) {
-        chunkp_vjp_lane<J, 0, SP>(t, rs, diag, n_diag, n, cf, n_draw, gloglike, state, cg, gresid, gdiag, gsign, draw, (int)blockIdx.y,
+        chunkp_vjp_lane<J, 0, SP>(t, rs, diag, n_diag, n, cf, n_draw, gloglike, state, cg, gresid, gdiag, gsign, draw, chunk_of_block<SP>(state, n, n_draw, J, cg),
                               &gacc[0][threadIdx.x], kWave);
         return;
       }
     }
-    chunkp_vjp_lane<J, NR, SP>(t, rs, diag, n_diag, n, cf, n_draw, gloglike, state, cg, gresid, gdiag, gsign, draw, (int)blockIdx.y,
+    chunkp_vjp_lane<J, NR, SP>(t, rs, diag, n_diag, n, cf, n_draw, gloglike, state, cg, gresid, gdiag, gsign, draw, chunk_of_block<SP>(state, n, n_draw, J, cg),
                            &gacc[0][threadIdx.x], kWave);
   } else
-    chunk1_vjp_lane<J, NR, SP>(t, rs, diag, n_diag, n, cf, n_draw, gloglike, state, cg, gresid, gdiag, gsign, draw, (int)blockIdx.y);
+    chunk1_vjp_lane<J, NR, SP>(t, rs, diag, n_diag, n, cf, n_draw, gloglike, state, cg, gresid, gdiag, gsign, draw, chunk_of_block<SP>(state, n, n_draw, J, cg));
 }
 
 // ---- the ROBUST route (draws flagged kFlagRobust: exo_celerite_core.hpp, chunk_adj_lane) ---------------------------------
@@ -1648,6 +1689,20 @@ int64_t exo_celerite_state_doubles(int64_t n, int64_t n_draw, int32_t n_real, in
   return base + chunk_ws(n, n_draw, (int)J, cg).total();
 }
 
+// The number of chunks the plan takes by default -- for a caller who wants to pass it explicitly (the same value to
+// exo_celerite_state_doubles and to both calls of a pair).  sparse != 0: the plan the SPARSE entries do best with -- twice as
+// many chunks (of at least 32 cadences) as a dense series gets: the waves of a sparse launch are uneven (slow exactly while a
+// draw is inside a transit), and with two rounds of them the short ones fill the tail (C3: 3.68 -> 3.59 ms).  1: sequential.
+int32_t exo_celerite_default_chunks(int64_t n, int64_t n_draw, int32_t n_real, int32_t n_complex, int32_t sparse) {
+  const int64_t J = n_real + 2 * (int64_t)n_complex;
+  if (n < 0 || n_draw < 1 || J < 1 || J > EXO_GP_MAX_J) return 1;
+  const ChunkGeom cg = chunk_plan(n, n_draw, (int)J, 0);
+  if (cg.C <= 1 || !sparse || !cg.lane || J > 2) return cg.C;
+  int64_t C = 2 * (int64_t)cg.C;
+  if (C > n / 32) C = n / 32;
+  return chunk_plan(n, n_draw, (int)J, (int32_t)(C < 2 ? 2 : C)).C;
+}
+
 #define EXO_GP_DISPATCH_VOID(J_, CALL) \
   switch (J_) {                        \
     case 1: { constexpr int JJ = 1; CALL; } break; \
@@ -1771,7 +1826,7 @@ __global__ __launch_bounds__(kWave, EXO_ELEM_MIXED_WAVES) void celerite_elem_mix
   const int64_t draw = mixed_draw(state, n, n_draw, cg);
   if (draw < 0) return;
   const int nr = layout_vote<2>(cf, draw);
-  const int c = (int)blockIdx.y;
+  const int c = chunk_of_block<SP>(state, n, n_draw, 2, cg);
   if (blockIdx.z == 0) {
     if (nr == 0) elem_lane<2, 0, EXO_ELEM_MIXED_WAVES < 4, SP>(t, rs, diag, n_diag, n, cf, n_draw, state, cg, draw, c, flag_at);
   } else {
@@ -1790,7 +1845,7 @@ __global__ __launch_bounds__(kWave, EXO_FWD_MIXED_WAVES) void celerite_chunk1_fw
   const int64_t draw = mixed_draw(state, n, n_draw, cg);
   if (draw < 0) return;
   const int nr = layout_vote<2>(cf, draw);
-  const int c = (int)blockIdx.y;
+  const int c = chunk_of_block<SP>(state, n, n_draw, 2, cg);
   if (blockIdx.z == 0) {
     if (nr == 0) chunk1_fwd_lane<2, 0, SP>(t, rs, diag, n_diag, n, cf, n_draw, state, cg, draw, c, true);
   } else {
@@ -1806,7 +1861,7 @@ __global__ __launch_bounds__(kWave, EXO_VJP1_WAVES) void celerite_chunk1_vjp_mix
   const int64_t draw = mixed_draw(state, n, n_draw, cg);
   if (draw < 0) return;
   const int nr = layout_vote<2>(cf, draw);
-  const int c = (int)blockIdx.y;
+  const int c = chunk_of_block<SP>(state, n, n_draw, 2, cg);
   if (blockIdx.z == 0) {
     if (nr == 0) chunk1_vjp_lane<2, 0, SP>(t, rs, diag, n_diag, n, cf, n_draw, gloglike, state, cg, gresid, gdiag, gsign, draw, c);
   } else {
@@ -1893,6 +1948,9 @@ static int celerite_fwd(const double* t, Series resid, const double* diag, int64
       if (J == 2 && cf.n_real == 0 && cf.kind && EXO_GP_MIXED_ONE_LAUNCH)   // per-draw pair kinds: no wave of mixed kinds (mixed_draw)
         hipLaunchKernelGGL(celerite_kind_partition_kernel, dim3(1), dim3(1024), 0, st, cf.kind, n_draw,
                            reinterpret_cast<int32_t*>(state + ws.off_perm()), ws.perm_lanes());
+      if (resid.sp.nseg && cg.lane)   // sparse model: the order in which the one-lane kernels' blocks take the chunks (chunk_of_block)
+        hipLaunchKernelGGL(celerite_sparse_order_kernel, dim3(1), block, 0, st, resid.sp, n_draw,
+                           reinterpret_cast<int32_t*>(state + ws.off_order()));
       if (J >= EXO_ELEM_LG_MIN_J) {   // the one-lane element kernel is as fast up to J = 6 and does not fit beyond
         EXO_GP_DISPATCH(J, hipLaunchKernelGGL((celerite_elem_lg_kernel<JJ>), cgrid_f, block, 0, st, t, resid, diag, n_diag,
                                               n, cf, n_draw, state, cge, flag_at))

@@ -411,7 +411,9 @@ struct ChunkWs {
   // padded to whole waves, then those of the other (int32, -1 = no draw): celerite_kind_partition_kernel
   EXO_HDH int64_t off_perm() const { return off_polish() + (EXO_GP_POLISH ? (int64_t)4 * C * K() * n_draw : 0); }
   EXO_HDH int64_t perm_lanes() const { return ((n_draw + 63) / 64 + 1) * 64; }
-  EXO_HDH int64_t total() const { return off_perm() + (perm_lanes() + 1) / 2 - base; }
+  // sparse model: in which order the one-lane kernels' blocks take the chunks (one int32: celerite_sparse_order_kernel)
+  EXO_HDH int64_t off_order() const { return off_perm() + (perm_lanes() + 1) / 2; }
+  EXO_HDH int64_t total() const { return off_order() + 1 - base; }
 };
 
 // the series and the measurement variance of one block of four cadences [b0, b0 + 4) clipped to n1.
@@ -466,6 +468,16 @@ EXO_HD void flag_raise(double* EXO_RESTRICT flag, double v) {
   if (v > *flag) *flag = v;
 #endif
 }
+// One term of the Newton iterations' convergence measure (celerite_robust_newton_kernel): the correction d of an entry of a
+// boundary covariance against the scale sc = |P_jj P_ll| of that entry.  A correction or a scale that is not finite -- a tree
+// guess or a tangent element gone NaN / Inf -- must NOT read as "converged" (fmax drops a NaN, and NaN > 0 is false: ADVICE r4):
+// it reads as +inf, the iterations end unconverged and the draw falls through to the serial chain, which needs no guess.
+EXO_HD double newton_err_term(double d, double sc) {
+  const double x = sc > 0.0 ? fabs(d) * exo::fast_rcp(sqrt(sc)) : 0.0;
+  const bool finite = (x < INFINITY) && (d == d) && (sc < INFINITY) && (fabs(d) < INFINITY);   // (sc < inf is false for a NaN too)
+  return finite ? x : INFINITY;
+}
+
 #ifndef EXO_LANE_MAX_J
 #define EXO_LANE_MAX_J 6
 #endif

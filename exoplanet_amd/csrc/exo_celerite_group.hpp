@@ -745,12 +745,13 @@ __device__ __forceinline__ double newton_down0(const ChunkWs& ws, double* state,
 #pragma unroll
     for (int l = 0; l < J; ++l) {
       const double sc = fabs(mine * dd[l]);
-      e = fmax(e, sc > 0.0 ? fabs(d[l]) * exo::fast_rcp(sqrt(sc)) : 0.0);
+      e = fmax(e, newton_err_term(d[l], sc));   // (+inf for anything not finite: never "converged")
     }
     g.sync();
     return g.live ? e : 0.0;
   };
   double err = (a > 0) ? rel_size(dP, P) : 0.0;
+  if (a > 0 && g.live && !((dm == dm) && (m == m) && fabs(dm) < INFINITY && fabs(m) < INFINITY)) err = INFINITY;   // the means too
   if (a + 1 < ws.C) {
     TanRow<J> e;
     newton_elem_of_chunk<J>(state, ws, a, draw, g, r, e);
@@ -758,6 +759,7 @@ __device__ __forceinline__ double newton_down0(const ChunkWs& ws, double* state,
     tan_apply<J>(g, e, dm, dP, dm2, dP2);
     newton_load_state<J>(state, ws, a + 1, draw, r, mn, Pn);
     err = fmax(err, rel_size(dP2, Pn));
+    if (g.live && !((dm2 == dm2) && (mn == mn) && fabs(dm2) < INFINITY && fabs(mn) < INFINITY)) err = INFINITY;
     if (g.live) {
       state[ws.bnd(1, a + 1, r, draw)] = mn + dm2;
 #pragma unroll

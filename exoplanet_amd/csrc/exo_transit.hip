@@ -2897,6 +2897,9 @@ __global__ __launch_bounds__(kBlock) void transit_scatter_runs_kernel(RunLists r
         const int64_t v0 = vbase + pk;
         for (int i = lane; i < len; i += 64) {
           if (CLEAR) row[lo + i] = 0.0;
+          // (planet 0 stores for BOTH events: a planet's transit and occultation lists never share a cadence -- the enumeration
+          // keeps two lists only when the windows are disjoint, h0 + h1 < their separation; otherwise event 0 is "every
+          // cadence" and event 1 is empty: transit_enum_kernel.  The dense sweep relies on the same invariant, finish_draw.)
           else if (p == 0) row[lo + i] = vals[v0 + i];
           else unsafeAtomicAdd(row + lo + i, vals[v0 + i]);
         }

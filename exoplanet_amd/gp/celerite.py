@@ -151,6 +151,8 @@ class _CeleriteLogLikeSparse(torch.autograd.Function):
             raise ValueError(f"celerite state width J = {J} outside 1..{MAX_J}")
         n_chunks = int(n_chunks)
         lib = _lib.load()
+        if n_chunks == 0:     # the plan the sparse entries do best with (twice the dense plan's chunks for J <= 2: include/exoplanet_amd.h)
+            n_chunks = int(lib.exo_celerite_default_chunks(N, D, n_real, n_complex, 1))
         need_grad = any(ctx.needs_input_grad)
         loglike = torch.empty(D, dtype=torch.float64, device=t.device)
         nstate = lib.exo_celerite_state_doubles(N, D, n_real, n_complex, n_chunks)

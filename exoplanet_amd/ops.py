@@ -44,12 +44,13 @@ _VOUCHED = {}
 
 
 def _series_key(t):
-    return (t.data_ptr(), t.numel(), t.stride(0) if t.dim() else 0)
+    return (t.device.index, t.data_ptr(), t.numel(), t.stride(0) if t.dim() else 0)
 
 
 def vouch_sorted(t):
     """The caller's word that the device tensor ``t`` is non-decreasing (no NaN) and STAYS so for as long as this buffer is
-    a time array -- whatever is written into it later, by whatever means.  The sweeps then carry FLAG_SORTED_TIMES
+    a time array -- whatever is written into it later, by whatever means.  (Keyed by device, address and extent; at most
+    sixteen series are held: a seventeenth releases the oldest, with a RuntimeWarning.)  The sweeps then carry FLAG_SORTED_TIMES
     (windows and runs in one launch) also where the torch layer cannot see for itself: inside a hipGraph capture, whose
     launches keep their flags at every replay.  The array is looked at once, now (one host synchronisation; not during a
     capture); ValueError if it is not sorted.  A sampler's time array is the use: fixed for the whole run.
@@ -60,9 +61,18 @@ def vouch_sorted(t):
         raise RuntimeError("vouch_sorted looks at the array (a host synchronisation): call it before the capture")
     if t.numel() > 1 and not bool((t[1:] >= t[:-1]).all()):
         raise ValueError("vouch_sorted: the times are not non-decreasing (or hold a NaN)")
+    key = _series_key(t)
+    _VOUCHED.pop(key, None)
     if len(_VOUCHED) >= 16:
-        _VOUCHED.clear()
-    _VOUCHED[_series_key(t)] = t        # (keeps the storage alive: the address cannot pass to another series meanwhile)
+        # the table holds sixteen series (an entry keeps its time array alive): the OLDEST word is taken back, with a warning --
+        # that series falls back to the sweep's own device check inside later captures (slower, never wrong)
+        import warnings
+
+        oldest = next(iter(_VOUCHED))
+        _VOUCHED.pop(oldest)
+        warnings.warn("vouch_sorted: more than 16 vouched series; the oldest one's word has been released (release_sorted "
+                      "what you no longer use)", RuntimeWarning, stacklevel=2)
+    _VOUCHED[key] = t        # (keeps the storage alive: the address cannot pass to another series meanwhile)
     return t
 
 
@@ -306,6 +316,21 @@ def _ttv_args(ttv, D, P):
 _JAC_ROUTE = [os.environ.get("EXO_JAC_ROUTE", "1") != "0"]
 _JAC_MIN_SUB = 2
 _JAC_MAX_BYTES = 8 << 30
+
+
+def _jac_fits(nbytes, device):
+    """the rows of derivatives are worst-case sized (16 doubles per (draw, planet, cadence), a few per cent touched): take the
+    route only if they fit the cap AND half of what the device has free right now (a smaller-memory device must
+    fall back to the two-sweep route rather than run out)"""
+    if nbytes > _JAC_MAX_BYTES:
+        return False
+    try:
+        if torch.cuda.is_current_stream_capturing():
+            return True          # (the warm-up calls before the capture asked; the pool is the capture's own)
+        free, _ = torch.cuda.mem_get_info(device)
+        return 2 * nbytes <= free
+    except Exception:
+        return True
 _JAC_CALLS = [0]        # forward sweeps that took the route (tests look at it)
 
 
@@ -331,7 +356,7 @@ class _TransitFlux(torch.autograd.Function):
         # cadence is several samples, the value sweep keeps every solved cadence's row of derivatives and backward() is a
         # contraction instead of a second sweep
         n_jac = lib.exo_transit_flux_jac_doubles(N, D, P)
-        use_jac = (_JAC_ROUTE[0] and n_sub >= _JAC_MIN_SUB and not n_edge and n_texp <= 1 and 8 * n_jac <= _JAC_MAX_BYTES
+        use_jac = (_JAC_ROUTE[0] and n_sub >= _JAC_MIN_SUB and not n_edge and n_texp <= 1 and _jac_fits(8 * n_jac, t.device)
                    and not flags & (FLAG_PER_PLANET | FLAG_SPARSE | FLAG_EXACT_SCAN | FLAG_LIGHT_DELAY)
                    and (ctx.needs_input_grad[4] or ctx.needs_input_grad[5]) and grad_mode)
         ctx.jac = None
@@ -815,7 +840,7 @@ class _TransitFluxSparse(torch.autograd.Function):
         n_jac = lib.exo_transit_flux_jac_doubles(N, D, P)
         # (grad_mode: torch.is_grad_enabled() of the CALLER -- inside forward() it is always off; under no_grad the rows of
         # derivatives would be written for nothing: ADVICE r4)
-        use_jac = _JAC_ROUTE[0] and n_sub >= _JAC_MIN_SUB and 8 * n_jac <= _JAC_MAX_BYTES and need and grad_mode
+        use_jac = _JAC_ROUTE[0] and n_sub >= _JAC_MIN_SUB and _jac_fits(8 * n_jac, t.device) and need and grad_mode
         ctx.jac = None
         with torch.cuda.device(t.device):
             if use_jac:

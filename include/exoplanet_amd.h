@@ -443,6 +443,10 @@ int exo_orbit_vector_vjp_f64(const double* t, int64_t n_cad, const double* param
 #define EXO_GP_MAX_J 8
 int64_t exo_celerite_state_doubles(int64_t n, int64_t n_draw, int32_t n_real, int32_t n_complex,
                                    int32_t n_chunks);
+/* the number of chunks the default plan (n_chunks = 0) cuts the series into, for callers that pass it explicitly; sparse != 0:
+ * what the sparse entries (exo_celerite_loglike_sparse_*_f64) do best with -- twice as many for J <= 2 (their waves are uneven: two
+ * rounds of them balance).  1 = sequential recurrences.                                                               */
+int32_t exo_celerite_default_chunks(int64_t n, int64_t n_draw, int32_t n_real, int32_t n_complex, int32_t sparse);
 int exo_celerite_loglike_fwd_f64(const double* t, const double* resid, const double* diag, int64_t n_diag,
                                  int64_t n, const double* coef_real, int32_t n_real,
                                  const double* coef_complex, int32_t n_complex, const int32_t* pair_kind,

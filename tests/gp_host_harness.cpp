@@ -439,6 +439,7 @@ void harness_set_robust(int v) { g_robust = v; }
 void harness_set_adj_tree(int v) { g_adj_tree = v; }
 void harness_set_adj_roles(int v) { g_adj_roles = v; }
 void harness_set_adj_pieces(int v) { g_adj_pieces = v; }
+double harness_newton_err_term(double d, double sc) { return gp::newton_err_term(d, sc); }
 void harness_set_newton(int v, int verbose) { g_newton = v; g_newton_verbose = verbose; }
 void harness_set_newton_tree(int v) { g_newton_tree = v; }
 void harness_set_hybrid_k(int v) { g_hybrid_k = v; }

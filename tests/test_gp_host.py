@@ -435,3 +435,18 @@ def test_lane_pipeline_sparse_model_equals_dense_model(harness, n_real, n_comple
             for s in range(nseg[d]):
                 lo, hi = seg[d, s, 0], seg[d, s, hi_at]
                 np.testing.assert_array_equal(g_s["y"][d, off[d, s]:off[d, s] + hi - lo], g_d["y"][d, lo:hi])
+
+
+def test_newton_convergence_measure_never_reads_a_nan_as_converged(harness):
+    """the robust route's Newton iterations decide convergence from max |dP| / sqrt(P_jj P_ll); a NaN correction
+    (dropped by fmax) or a NaN state (NaN > 0 is false) used to read as 0 -- "converged at iteration 0" -- and skip the serial
+    chain.  The term now reports +inf for anything that is not finite (gp::newton_err_term, used by newton_down0)."""
+    f = harness.harness_newton_err_term
+    f.restype = ctypes.c_double
+    f.argtypes = [ctypes.c_double, ctypes.c_double]
+    assert abs(f(1e-9, 4.0) - 5e-10) < 1e-18
+    assert f(0.0, 0.0) == 0.0 and f(1e-3, 0.0) == 0.0          # (a zero scale: the entry carries no information)
+    for d, sc in ((np.nan, 1.0), (1.0, np.nan), (np.inf, 1.0), (-np.inf, 2.0), (1.0, np.inf), (np.nan, 0.0), (np.nan, np.nan)):
+        assert f(d, sc) == np.inf, (d, sc)
+    tol = 1e-8
+    assert not (f(np.nan, 1.0) < tol) and (f(1e-12, 1.0) < tol)

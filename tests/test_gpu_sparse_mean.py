@@ -56,9 +56,30 @@ def _kernel(xo, dev, D, which, seed):
     return kern, leaves
 
 
-def _both_routes(xo, dev, D, N, which, texp=None, seed=1, yerr=5e-4, cadence=2.0 / 1440.0, ecc=0.3, n_chunks_env=None,
+def _both_routes(xo, dev, D, N, which, texp=None, seed=1, yerr=5e-4, cadence=2.0 / 1440.0, ecc=0.3, same_plan=True,
                  use_in_transit=None, extra_real=False):
-    """log-likelihood and all leaf gradients through the dense cadence-major mean and through the sparse mean"""
+    """log-likelihood and all leaf gradients through the dense cadence-major mean and through the sparse mean.  same_plan:
+    both routes cut the series into the same chunks (the sparse route's default plan has twice the dense one's for J <= 2,
+    exo_celerite_default_chunks: other chunks, other roundings -- 1e-13 in the log-likelihood) so that the comparison is of
+    the same arithmetic on the same numbers"""
+    import os
+
+    from exoplanet_amd import _lib
+
+    saved = os.environ.get("EXO_GP_CHUNKS")
+    if same_plan and not saved:
+        kern0, _ = _kernel(xo, dev, D, which, seed + 1)
+        ar, cr, pairs, _ = kern0.pair_coefficients()
+        n_real, n_cplx = ar.shape[-1] + (1 if extra_real else 0), pairs.shape[-2]
+        os.environ["EXO_GP_CHUNKS"] = str(int(_lib.load().exo_celerite_default_chunks(N, D, n_real, n_cplx, 1)))
+    try:
+        return _both_routes_inner(xo, dev, D, N, which, texp, seed, yerr, cadence, ecc, use_in_transit, extra_real)
+    finally:
+        if same_plan and not saved:
+            del os.environ["EXO_GP_CHUNKS"]
+
+
+def _both_routes_inner(xo, dev, D, N, which, texp, seed, yerr, cadence, ecc, use_in_transit, extra_real):
     t = torch.arange(N, dtype=torch.float64, device=dev) * cadence
     rng = np.random.default_rng(seed + 7)
     y = torch.tensor(yerr * rng.normal(size=N), dtype=torch.float64, device=dev)
@@ -105,6 +126,15 @@ def test_sparse_mean_equals_dense_mean(dev, which, D, N):
     import exoplanet_amd as xo
 
     _compare(_both_routes(xo, dev, D, N, which))
+
+
+def test_sparse_mean_default_plans(dev):
+    """each route on its own default plan (the sparse one cuts a J <= 2 series into twice as many chunks): the time-parallel
+    recurrences are exact whatever the chunks -- the results differ by roundings only"""
+    import exoplanet_amd as xo
+
+    _compare(_both_routes(xo, dev, 600, 30_000, "sho", same_plan=False), ll_rtol=1e-11, g_rtol=1e-8)
+    _compare(_both_routes(xo, dev, 66, 9_001, "mixed", same_plan=False), ll_rtol=1e-11, g_rtol=1e-8)
 
 
 @pytest.mark.parametrize("which,extra_real", [("sho3", True), ("sho4", False)])

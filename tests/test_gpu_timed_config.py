@@ -414,7 +414,15 @@ def test_c5_timed_step_vs_oracle(dev, D, bright):
     want = chain_to_leaves(sub, gp, list(P.GRAD_SLOTS), sbr=sbr[rows])
     for j in range(3):
         want[f"s{j + 1}"] = gh[:, j]
-    assert_grads(grads, want, wl.names, rel=1e-6, rows=rows, per_draw=True)
+    if bright:
+        # the chains at a conditioning score of 1e6 (robust route): every gradient within 2e-6 of the largest over the checked
+        # chains -- their own gradient with respect to the faint terms' amplitudes is ~1e-2 of that, and two double-precision
+        # algorithms differ by kappa x 1e-16 of the LARGE terms there -- and the clean chains to 1e-6 each, as below
+        assert_grads(grads, want, wl.names, rel=2e-6, rows=rows)
+        clean = rows >= bright
+        assert_grads(grads, {k: v[clean] for k, v in want.items()}, wl.names, rel=1e-6, rows=rows[clean], per_draw=True)
+    else:
+        assert_grads(grads, want, wl.names, rel=1e-6, rows=rows, per_draw=True)
 
 
 # ---------------------------------------------------------------------------------------------------
