@@ -153,7 +153,8 @@ _SIGNATURES = {
 class SparseModel(ctypes.Structure):
     """exo_sparse_model of include/exoplanet_amd.h (a HOST struct of device pointers and strides)"""
     _fields_ = [("nseg", ctypes.c_void_p), ("seg", ctypes.c_void_p), ("off", ctypes.c_void_p), ("vals", ctypes.c_void_p),
-                ("seg_row", _i64), ("off_row", _i64), ("val_row", _i64), ("seg_step", _i32), ("hi_at", _i32)]
+                ("seg_row", _i64), ("off_row", _i64), ("val_row", _i64), ("seg_step", _i32), ("hi_at", _i32),
+                ("row_of_draw", ctypes.c_void_p)]
 
 
 _ERRORS = {1: "invalid argument", 2: "kernel launch failed", 3: "workspace too small"}

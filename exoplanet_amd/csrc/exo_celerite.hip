@@ -1350,44 +1350,56 @@ constexpr bool split_layouts(int J) { return EXO_J4_SPLIT && J == 4; }
 #define EXO_ELEM_MIXED_WAVES 4
 #endif
 // which chunk a block of the one-lane kernels works on.  Dense series: every wave costs the same, blocks in order.  SPARSE
-// model: a wave is slow exactly while one of its draws is inside a transit, and the draws' transits drift apart away from
-// the reference transit time (their periods differ): the chunks far from it are the long ones.  They are dealt FIRST (longest
-// processing time first) and the short ones fill the tail of the launch -- C3 with t0 at the start of the series 3.83 -> 3.68 ms
-// at the dense plan's chunks, 3.58 with twice as many (exo_celerite_default_chunks).  Where "far" is, celerite_sparse_order_kernel
-// reads off the first wave's segments: 1 = the series' end (last chunk first), 2 = both ends (the two ends first, the middle
-// last), 3 = its start (in order).  EXO_SPARSE_LPT=0: always in order.
+// model: a wave is slow exactly while one of its 64 draws is inside a transit (+ 21 % per block: measured with every block
+// forced onto either path), so the chunks that hold a transit are the long ones.  They are dealt FIRST (longest processing
+// time first) and the short ones fill the tail of the launch: celerite_sparse_order_kernel writes the order.
+// EXO_SPARSE_LPT=0: always in order.
 #ifndef EXO_SPARSE_LPT
 #define EXO_SPARSE_LPT 1
 #endif
 template <int SP>
 __device__ __forceinline__ int chunk_of_block(const double* __restrict__ state, int64_t n, int64_t n_draw, int J, const ChunkGeom& cg) {
-  const int y = (int)blockIdx.y, C = (int)gridDim.y;
+  const int y = (int)blockIdx.y;
   if (SP != 1 || !EXO_SPARSE_LPT) return y;
-  const int mode = *reinterpret_cast<const int32_t*>(state + chunk_ws(n, n_draw, J, cg).off_order());
-  if (mode == 1) return C - 1 - y;
-  if (mode == 2) return (y & 1) ? (y >> 1) : C - 1 - (y >> 1);
-  return y;
+  return reinterpret_cast<const int32_t*>(state + chunk_ws(n, n_draw, J, cg).off_order())[y];
 }
-// One wave: how far apart the first wave's draws start their FIRST and their LAST segment -- the spread of the transit times at
-// the two ends of the series (draws without a segment do not vote)
-__global__ __launch_bounds__(kWave) void celerite_sparse_order_kernel(SparseSegs sp, int64_t n_draw, int32_t* __restrict__ mode) {
-  const int lane = threadIdx.x;
-  const bool has = lane < n_draw && sp.nseg[lane] > 0;
-  int first = 0, last = 0;
-  if (has) {
-    const int32_t* s = sp.seg + (int64_t)lane * sp.seg_row;
-    first = s[0];
-    last = s[(int64_t)(sp.nseg[lane] - 1) * sp.seg_step];
-  }
-  int lo_f = has ? first : 0x7fffffff, hi_f = has ? first : -0x7fffffff, lo_l = has ? last : 0x7fffffff, hi_l = has ? last : -0x7fffffff;
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) {
-    lo_f = min(lo_f, __shfl_xor(lo_f, m, 64)); hi_f = max(hi_f, __shfl_xor(hi_f, m, 64));
-    lo_l = min(lo_l, __shfl_xor(lo_l, m, 64)); hi_l = max(hi_l, __shfl_xor(hi_l, m, 64));
-  }
-  if (lane == 0) {
-    const int64_t sf = hi_f >= lo_f ? (int64_t)hi_f - lo_f : 0, sl = hi_l >= lo_l ? (int64_t)hi_l - lo_l : 0;
-    *mode = (2 * sf < sl) ? 1 : ((2 * sl < sf) ? 3 : 2);
+// One block: a chunk is LONG if a segment of one of a few sample draws (spread over the batch: with the draws sorted by
+// transit time -- exo_sparse_model.row_of_draw -- the first, the last and those between span the transit times of all) reaches
+// into it, widened by a block either side; long chunks first, each class in order of time (a stable partition).
+constexpr int kOrderSamples = 8;
+__global__ __launch_bounds__(256) void celerite_sparse_order_kernel(SparseSegs sp, int64_t n, int64_t n_draw, ChunkGeom cg,
+                                                                    int32_t* __restrict__ order) {
+  __shared__ int s_long[1024 + 1];
+  const int C = cg.C;
+  for (int c0 = 0; c0 < C; c0 += 1024) {     // (plans hold at most 1024 chunks; written for any number)
+    const int m = C - c0 < 1024 ? C - c0 : 1024;
+    for (int i = threadIdx.x; i < m; i += 256) {
+      const int c = c0 + i;
+      const int64_t lo = (int64_t)c * cg.L - kCkptB, hi = ((int64_t)(c + 1) * cg.L < n ? (int64_t)(c + 1) * cg.L : n) + kCkptB;
+      bool lng = false;
+      for (int q = 0; q < kOrderSamples && !lng; ++q) {
+        const int64_t d = n_draw <= kOrderSamples ? (q < n_draw ? q : n_draw - 1) : (n_draw - 1) * q / (kOrderSamples - 1);
+        const int64_t row = sp.row(d);
+        const int32_t* sg = sp.seg + row * sp.seg_row;
+        int a = 0, b = sp.nseg[row];            // the first segment that ends beyond lo
+        while (a < b) {
+          const int mid = (a + b) >> 1;
+          if (sg[(int64_t)mid * sp.seg_step + sp.hi_at] <= lo) a = mid + 1; else b = mid;
+        }
+        lng = a < sp.nseg[row] && sg[(int64_t)a * sp.seg_step] < hi;
+      }
+      s_long[i] = lng ? 1 : 0;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {                      // (a serial pass over <= 1024 flags in LDS: ~2 us, once per call)
+      int n_long = 0;
+      for (int i = 0; i < m; ++i) n_long += s_long[i];
+      int at_long = c0, at_short = c0 + n_long;
+      for (int i = 0; i < m; ++i) {
+        if (s_long[i]) order[at_long++] = c0 + i; else order[at_short++] = c0 + i;
+      }
+    }
+    __syncthreads();
   }
 }
 // (A) the filtering element of every (draw, chunk)
@@ -1949,7 +1961,7 @@ static int celerite_fwd(const double* t, Series resid, const double* diag, int64
         hipLaunchKernelGGL(celerite_kind_partition_kernel, dim3(1), dim3(1024), 0, st, cf.kind, n_draw,
                            reinterpret_cast<int32_t*>(state + ws.off_perm()), ws.perm_lanes());
       if (resid.sp.nseg && cg.lane)   // sparse model: the order in which the one-lane kernels' blocks take the chunks (chunk_of_block)
-        hipLaunchKernelGGL(celerite_sparse_order_kernel, dim3(1), block, 0, st, resid.sp, n_draw,
+        hipLaunchKernelGGL(celerite_sparse_order_kernel, dim3(1), dim3(256), 0, st, resid.sp, n, n_draw, cg,
                            reinterpret_cast<int32_t*>(state + ws.off_order()));
       if (J >= EXO_ELEM_LG_MIN_J) {   // the one-lane element kernel is as fast up to J = 6 and does not fit beyond
         EXO_GP_DISPATCH(J, hipLaunchKernelGGL((celerite_elem_lg_kernel<JJ>), cgrid_f, block, 0, st, t, resid, diag, n_diag,
@@ -2212,6 +2224,7 @@ static bool sparse_series(const exo_sparse_model* m, const double* obs, int64_t 
   out->sp.nseg = m->nseg; out->sp.seg = m->seg; out->sp.off = m->off;
   out->sp.seg_row = m->seg_row; out->sp.off_row = m->off_row; out->sp.val_row = m->val_row;
   out->sp.seg_step = m->seg_step; out->sp.hi_at = m->hi_at;
+  out->sp.row_of_draw = m->row_of_draw;
   return true;
 }
 

@@ -134,6 +134,12 @@ struct SparseSegs {
   const int32_t* off = nullptr;
   int64_t seg_row = 0, off_row = 0, val_row = 0;
   int32_t seg_step = 0, hi_at = 0;
+  // row_of_draw (optional): draw d of the CALL is row row_of_draw[d] of the model's tables and value array -- a caller that
+  // hands the draws over in another order than the light-curve sweep produced them in (sorted by transit time, so that the
+  // draws of a wave are inside their transits together: exo_sparse_model) permutes the small per-draw inputs and leaves the
+  // model where it is
+  const int32_t* row_of_draw = nullptr;
+  EXO_HD int64_t row(int64_t draw) const { return row_of_draw ? (int64_t)row_of_draw[draw] : draw; }
 };
 struct Series {
   const double* y;
@@ -211,14 +217,19 @@ struct SegCursor {
   // comparison in the usual case).  Blocks come in the cursor's direction.
   EXO_HD bool enter(const SparseSegs& sp, int64_t draw, int64_t b64) {
     const int32_t b = (int32_t)b64;
+#ifdef EXO_SPARSE_FORCE   // (laboratory: what a block costs on either path -- 1: every block takes the slow path, 2: none does)
+    constexpr bool kForceSlow = EXO_SPARSE_FORCE == 1, kForceFast = EXO_SPARSE_FORCE == 2;
+#else
+    constexpr bool kForceSlow = false, kForceFast = false;
+#endif
     if (ASC) {
       if (k < 0) first(sp, draw, b);
       while (b >= hi) { ++k; fetch(sp, draw); }
-      return b + 4 > lo;
+      return kForceSlow || (!kForceFast && b + 4 > lo);
     }
     if (k == kFar) first(sp, draw, b + 3);
     while (b + 3 < lo) { --k; fetch(sp, draw); }
-    return b < hi;
+    return kForceSlow || (!kForceFast && b < hi);
   }
   // position of cadence n's value, or -1 -- after enter(), for the block's cadences in the cursor's direction (the loop only
   // turns when two segments share the block)
@@ -250,8 +261,8 @@ struct SeriesRowT {
   int64_t draw;
   mutable SegCursor<ASC> cur;
   EXO_HD SeriesRowT(const Series& rs, int64_t draw_, int64_t n)
-      : y(rs.y + (rs.sp.nseg ? draw_ * rs.sp.val_row : (rs.cm ? draw_ : draw_ * n))), obs(rs.obs), stride(rs.cm ? rs.cm : 1),
-        sp(rs.sp), draw(draw_) {}
+      : y(rs.y + (rs.sp.nseg ? rs.sp.row(draw_) * rs.sp.val_row : (rs.cm ? draw_ : draw_ * n))), obs(rs.obs),
+        stride(rs.cm ? rs.cm : 1), sp(rs.sp), draw(rs.sp.nseg ? rs.sp.row(draw_) : draw_) {}   // (draw: the model's row)
   EXO_HD bool sparse() const { return SP == 1 || (SP == -1 && sp.nseg != nullptr); }
   EXO_HD double model_at(int64_t i) const {   // sparse: the model at cadence i
     const int32_t v = cur.at(sp, draw, i);
@@ -299,8 +310,8 @@ struct GradRowT {
   SegCursor<false> cur;
   EXO_HD bool sparse() const { return SP == 1 || (SP == -1 && sp.nseg != nullptr); }
   EXO_HD GradRowT(double* gresid, const Series& rs, int64_t draw_, int64_t n)
-      : g(gresid + (rs.sp.nseg ? draw_ * rs.sp.val_row : (rs.cm ? draw_ : draw_ * n))), stride(rs.cm ? rs.cm : 1), sp(rs.sp),
-        draw(draw_) {}
+      : g(gresid + (rs.sp.nseg ? rs.sp.row(draw_) * rs.sp.val_row : (rs.cm ? draw_ : draw_ * n))), stride(rs.cm ? rs.cm : 1),
+        sp(rs.sp), draw(rs.sp.nseg ? rs.sp.row(draw_) : draw_) {}
   EXO_HD void store(int64_t i, double v) {
     if (sparse()) {
       const int32_t at = cur.at(sp, draw, i);
@@ -411,9 +422,9 @@ struct ChunkWs {
   // padded to whole waves, then those of the other (int32, -1 = no draw): celerite_kind_partition_kernel
   EXO_HDH int64_t off_perm() const { return off_polish() + (EXO_GP_POLISH ? (int64_t)4 * C * K() * n_draw : 0); }
   EXO_HDH int64_t perm_lanes() const { return ((n_draw + 63) / 64 + 1) * 64; }
-  // sparse model: in which order the one-lane kernels' blocks take the chunks (one int32: celerite_sparse_order_kernel)
+  // sparse model: the order in which the one-lane kernels' blocks take the chunks (int32 [C]: celerite_sparse_order_kernel)
   EXO_HDH int64_t off_order() const { return off_perm() + (perm_lanes() + 1) / 2; }
-  EXO_HDH int64_t total() const { return off_order() + 1 - base; }
+  EXO_HDH int64_t total() const { return off_order() + (C + 1) / 2 - base; }
 };
 
 // the series and the measurement variance of one block of four cadences [b0, b0 + 4) clipped to n1.

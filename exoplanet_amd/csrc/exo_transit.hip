@@ -3284,6 +3284,7 @@ int exo_transit_flux_sparse_model(const void* workspace, int64_t workspace_bytes
   out->seg_row = (int64_t)n_planet * n_ev * rw.rl.r_max * 4;
   out->off_row = (int64_t)n_planet * n_ev * (rw.rl.r_max + 1);
   out->val_row = (int64_t)n_planet * n_cad;
+  out->row_of_draw = nullptr;
   return EXO_OK;
 }
 

@@ -123,6 +123,24 @@ class _CeleriteLogLike(torch.autograd.Function):
         return None, gresid, gdiag, gcr, gcc, None, None, None
 
 
+_SORT_DRAWS = [os.environ.get("EXO_SPARSE_SORT", "1") != "0"]     # (0: A/B -- the draws in the caller's order)
+
+
+def _transit_order(sp):
+    """int32 (D,): the draws of a sparse light curve in the order of the mean spacing of their segments -- the period, in
+    cadences: draws with neighbouring periods keep their transits together all along the series, wherever the reference
+    transit time lies -- with the start of the first segment breaking ties (draws with fewer than two segments: by that
+    alone).  torch ops on the runs, no host synchronisation (usable inside a captured step)."""
+    lay = sp.layout()
+    D = sp.n_draw
+    nrun = lay.nrun.reshape(D).long()
+    lo = lay.runs.reshape(D, lay.r_max, 4)[:, :, 0]
+    first = lo[:, 0].double()
+    last = lo.gather(1, (nrun - 1).clamp_min(0).unsqueeze(1)).squeeze(1).double()
+    key = (last - first) / (nrun - 1).clamp_min(1).double() + 1e-9 * first
+    return torch.argsort(key, stable=True).to(torch.int32)
+
+
 class _CeleriteLogLikeSparse(torch.autograd.Function):
     """log N(obs - model | 0, K + diag) per draw for a SPARSE per-draw model (ops.SparseLightCurve: segments of cadences +
     their values; exo_celerite_loglike_sparse_*_f64): `vals` is the differentiable input, its cotangent comes back at the
@@ -162,25 +180,42 @@ class _CeleriteLogLikeSparse(torch.autograd.Function):
             if need_grad:
                 raise
             state, nstate = None, 0
+        # The kernels' lane is a draw, and a wave pays for a transit while ANY of its 64 draws is inside one: hand the draws
+        # over sorted by the time of their LAST segment (draws with neighbouring periods keep their transits together all
+        # along the series) -- the small per-draw inputs permuted here, the model left where the sweep wrote it
+        # (exo_sparse_model.row_of_draw); loglike and the coefficient cotangents come back in that order and are put back.
+        perm = _transit_order(sp) if (D > 64 and _SORT_DRAWS[0]) else None
+        if perm is not None:
+            pl = perm.long()
+            coef_real, coef_complex = coef_real[pl].contiguous(), coef_complex[pl].contiguous()
+            if pair_kind is not None:
+                pair_kind = pair_kind[pl].contiguous()
+            if diag.shape[0] == D:
+                diag = diag[pl].contiguous()
         model = sp.model_struct()
+        model.row_of_draw = _ptr(perm)
         with torch.cuda.device(t.device):
             _lib.check(lib.exo_celerite_loglike_sparse_fwd_f64(_ptr(t), _ptr(obs), ctypes.addressof(model), _ptr(diag),
                                                                diag.shape[0], N, _ptr(coef_real), n_real, _ptr(coef_complex),
                                                                n_complex, _ptr(pair_kind), D, _ptr(loglike), _ptr(state), nstate,
                                                                n_chunks, _stream(t)), "exo_celerite_loglike_sparse_fwd_f64")
         if need_grad:
-            ctx.save_for_backward(t, vals, diag, coef_real, coef_complex, state, obs, pair_kind)
+            ctx.save_for_backward(t, vals, diag, coef_real, coef_complex, state, obs, pair_kind, perm)
             ctx.dims = (D, N, n_real, n_complex, nstate, n_chunks)
             ctx.sp = sp
+        if perm is not None:
+            loglike = torch.empty_like(loglike).index_copy_(0, perm.long(), loglike)
         return loglike
 
     @staticmethod
     def backward(ctx, gll):
         import ctypes
 
-        t, vals, diag, coef_real, coef_complex, state, obs, pair_kind = ctx.saved_tensors
+        t, vals, diag, coef_real, coef_complex, state, obs, pair_kind, perm = ctx.saved_tensors
         D, N, n_real, n_complex, nstate, n_chunks = ctx.dims
         gll = _dev(gll, "gloglike")
+        if perm is not None:
+            gll = gll[perm.long()].contiguous()
         lib = _lib.load()
         # (positions no segment covers are never written and never read: the reverse sweep of the light curve walks the same runs)
         gvals = torch.empty_like(vals)
@@ -188,12 +223,19 @@ class _CeleriteLogLikeSparse(torch.autograd.Function):
         gdiag = torch.empty(D, N, dtype=torch.float64, device=t.device) if want_diag else None
         gcr, gcc = torch.empty_like(coef_real), torch.empty_like(coef_complex)
         model = ctx.sp.model_struct()
+        model.row_of_draw = _ptr(perm)
         with torch.cuda.device(t.device):
             _lib.check(lib.exo_celerite_loglike_sparse_vjp_f64(_ptr(t), _ptr(obs), ctypes.addressof(model), _ptr(diag),
                                                                diag.shape[0], N, _ptr(coef_real), n_real, _ptr(coef_complex),
                                                                n_complex, _ptr(pair_kind), D, _ptr(gll), _ptr(state), nstate,
                                                                n_chunks, _ptr(gvals), _ptr(gdiag), None, _ptr(gcr), _ptr(gcc),
                                                                _stream(t)), "exo_celerite_loglike_sparse_vjp_f64")
+        if perm is not None:     # back to the caller's order of the draws
+            pl = perm.long()
+            gcr = torch.empty_like(gcr).index_copy_(0, pl, gcr)
+            gcc = torch.empty_like(gcc).index_copy_(0, pl, gcc)
+            if want_diag and diag.shape[0] == D:     # (a shared diagonal's cotangent is summed over the draws: any order)
+                gdiag = torch.empty_like(gdiag).index_copy_(0, pl, gdiag)
         if want_diag and diag.shape[0] == 1:
             gdiag = gdiag.sum(0, keepdim=True)
         return None, gvals, gdiag, gcr, gcc, None, None, None, None
