@@ -53,7 +53,7 @@ constexpr int kWave = 64;
 // instead of the whole O(J^2) update on one lane.  A wave carries 64 / G draws.
 template <int J>
 struct Group {
-  static constexpr int G = J <= 1 ? 1 : (J <= 2 ? 2 : (J <= 4 ? 4 : 8));
+  static constexpr int G = J <= 1 ? 1 : (J <= 2 ? 2 : (J <= 4 ? 4 : (J <= 8 ? 8 : 16)));   // (16: one DPP row, J = 9 .. 16)
 };
 
 // In-register lane exchange (DPP) -- an ds_bpermute-based __shfl costs ~100+ cycles of
@@ -66,11 +66,18 @@ __device__ __forceinline__ double dpp_mov(double v) {
   return __hiloint2double(hi, lo);
 }
 constexpr int kRowShl4 = 0x104, kRowShr4 = 0x114;  // lane i reads lane i+4 / i-4 (same row of 16)
+constexpr int kRowShl8 = 0x108, kRowShr8 = 0x118;  // ... i+8 / i-8
 
 // value held by the lane at distance 4 inside an aligned group of 8 (lane ^ 4)
 __device__ __forceinline__ double xor4(double v) {
   const double up = dpp_mov<kRowShl4>(v), dn = dpp_mov<kRowShr4>(v);
   return (threadIdx.x & 4) ? dn : up;
+}
+
+// ... at distance 8 inside an aligned group (= DPP row) of 16 (lane ^ 8)
+__device__ __forceinline__ double xor8(double v) {
+  const double up = dpp_mov<kRowShl8>(v), dn = dpp_mov<kRowShr8>(v);
+  return (threadIdx.x & 8) ? dn : up;
 }
 
 // value of `v` held by lane L of this lane's aligned group of G lanes
@@ -81,9 +88,13 @@ __device__ __forceinline__ double group_get_c(double v) {
   constexpr int R = L & 3;
   const double q = dpp_mov<R * 0x55>(v);  // every quad broadcasts its own lane R
   if (G == 4) return q;
-  // G == 8: pick this quad's broadcast or the other quad's
+  // G >= 8: pick this quad's broadcast or the other quad's of the octet
   const double other = xor4(q);
-  return (((threadIdx.x >> 2) & 1) == (L >> 2)) ? q : other;
+  const double o8 = (((threadIdx.x >> 2) & 1) == ((L >> 2) & 1)) ? q : other;   // every octet broadcasts its own lane L & 7
+  if (G == 8) return o8;
+  // G == 16: this octet's or the other one's of the row
+  const double other8 = xor8(o8);
+  return (((threadIdx.x >> 3) & 1) == (L >> 3)) ? o8 : other8;
 }
 
 template <int G>
@@ -96,7 +107,15 @@ __device__ __forceinline__ double group_get(double v, int l) {
     case 4: return group_get_c<G, (G > 4 ? 4 : 0)>(v);
     case 5: return group_get_c<G, (G > 4 ? 5 : 0)>(v);
     case 6: return group_get_c<G, (G > 4 ? 6 : 0)>(v);
-    default: return group_get_c<G, (G > 4 ? 7 : 0)>(v);
+    case 7: return group_get_c<G, (G > 4 ? 7 : 0)>(v);
+    case 8: return group_get_c<G, (G > 8 ? 8 : 0)>(v);
+    case 9: return group_get_c<G, (G > 8 ? 9 : 0)>(v);
+    case 10: return group_get_c<G, (G > 8 ? 10 : 0)>(v);
+    case 11: return group_get_c<G, (G > 8 ? 11 : 0)>(v);
+    case 12: return group_get_c<G, (G > 8 ? 12 : 0)>(v);
+    case 13: return group_get_c<G, (G > 8 ? 13 : 0)>(v);
+    case 14: return group_get_c<G, (G > 8 ? 14 : 0)>(v);
+    default: return group_get_c<G, (G > 8 ? 15 : 0)>(v);
   }
 }
 
@@ -111,7 +130,8 @@ template <int M>
 __device__ __forceinline__ double xor_get(double v) {
   if (M == 1) return dpp_mov<0xB1>(v);  // quad_perm [1,0,3,2]
   if (M == 2) return dpp_mov<0x4E>(v);  // quad_perm [2,3,0,1]
-  return xor4(v);
+  if (M == 4) return xor4(v);
+  return xor8(v);
 }
 
 // sum over the G lanes of a group, result in every lane
@@ -120,6 +140,7 @@ __device__ __forceinline__ double group_sum(double v) {
   if (G >= 2) v += xor_get<1>(v);
   if (G >= 4) v += xor_get<2>(v);
   if (G >= 8) v += xor_get<4>(v);
+  if (G >= 16) v += xor_get<8>(v);
   return v;
 }
 
@@ -1768,6 +1789,30 @@ static_assert(kLaneMaxJ <= 6, "EXO_GP_DISPATCH_LANE lists the state widths of th
     case 8: { constexpr int JJ = 8; CALL; } break; \
     default: return EXO_ERR_INVALID_ARGUMENT;      \
   }
+// the SEQUENTIAL kernels (and the O(N) utilities) take state widths up to EXO_GP_MAX_J = 16 (a draw on a DPP row of 16 lanes
+// above 8): celerite2, the reference's dependency (setup.py:36), has no limit, and two RotationTerms + an SHO term -- J = 10 --
+// is an ordinary stellar-variability model.  The time-parallel path stops at 8 (kChunkMaxJ): wider states run the recurrences
+// cadence by cadence, correct and slow.
+#define EXO_GP_DISPATCH_SEQ(J_, CALL) \
+  switch (J_) {                       \
+    case 1: { constexpr int JJ = 1; CALL; } break; \
+    case 2: { constexpr int JJ = 2; CALL; } break; \
+    case 3: { constexpr int JJ = 3; CALL; } break; \
+    case 4: { constexpr int JJ = 4; CALL; } break; \
+    case 5: { constexpr int JJ = 5; CALL; } break; \
+    case 6: { constexpr int JJ = 6; CALL; } break; \
+    case 7: { constexpr int JJ = 7; CALL; } break; \
+    case 8: { constexpr int JJ = 8; CALL; } break; \
+    case 9: { constexpr int JJ = 9; CALL; } break; \
+    case 10: { constexpr int JJ = 10; CALL; } break; \
+    case 11: { constexpr int JJ = 11; CALL; } break; \
+    case 12: { constexpr int JJ = 12; CALL; } break; \
+    case 13: { constexpr int JJ = 13; CALL; } break; \
+    case 14: { constexpr int JJ = 14; CALL; } break; \
+    case 15: { constexpr int JJ = 15; CALL; } break; \
+    case 16: { constexpr int JJ = 16; CALL; } break; \
+    default: return EXO_ERR_INVALID_ARGUMENT;      \
+  }
 static_assert(kLaneMaxJ >= 2, "EXO_GP_LAYOUTS lists compile-time layouts for J <= 2; J > 2 takes run-time flags");
 // CALL with `JJ` and `NR` for every layout variant the draws of a call may need (layout_vote):
 // J = 1: one real term; J = 2: two real terms or one pair slot -- complex, or, with per-draw kinds,
@@ -1929,7 +1974,7 @@ static int celerite_fwd(const double* t, Series resid, const double* diag, int64
   if (state && state_doubles < exo_celerite_state_doubles(n, n_draw, cf.n_real, cf.n_complex, n_chunks))
     return EXO_ERR_WORKSPACE;
   const int J = cf.J();
-  const int G = J <= 1 ? 1 : (J <= 2 ? 2 : (J <= 4 ? 4 : 8));
+  const int G = J <= 1 ? 1 : (J <= 2 ? 2 : (J <= 4 ? 4 : (J <= 8 ? 8 : 16)));
   const int64_t per_wave = kWave / G;
   const dim3 grid((unsigned)((n_draw + per_wave - 1) / per_wave)), block(kWave);
   hipStream_t st = (hipStream_t)stream;
@@ -2053,10 +2098,10 @@ static int celerite_fwd(const double* t, Series resid, const double* diag, int64
       if (launch_status() != EXO_OK) return EXO_ERR_LAUNCH;
       only_flagged = state + ws.off_flag();
     }
-    EXO_GP_DISPATCH(J, hipLaunchKernelGGL((celerite_fwd_kernel<JJ, true>), grid, block, 0, st, t, resid, diag, n_diag, n,
+    EXO_GP_DISPATCH_SEQ(J, hipLaunchKernelGGL((celerite_fwd_kernel<JJ, true>), grid, block, 0, st, t, resid, diag, n_diag, n,
                                           cf, n_draw, loglike, state, only_flagged))
   } else {
-    EXO_GP_DISPATCH(J, hipLaunchKernelGGL((celerite_fwd_kernel<JJ, false>), grid, block, 0, st, t, resid, diag, n_diag, n,
+    EXO_GP_DISPATCH_SEQ(J, hipLaunchKernelGGL((celerite_fwd_kernel<JJ, false>), grid, block, 0, st, t, resid, diag, n_diag, n,
                                           cf, n_draw, loglike, state, (const double*)nullptr))
   }
   return launch_status();
@@ -2074,7 +2119,7 @@ static int celerite_vjp(const double* t, Series resid, const double* diag, int64
     return EXO_ERR_INVALID_ARGUMENT;
   if (state_doubles < exo_celerite_state_doubles(n, n_draw, cf.n_real, cf.n_complex, n_chunks)) return EXO_ERR_WORKSPACE;
   const int J = cf.J();
-  const int G = J <= 1 ? 1 : (J <= 2 ? 2 : (J <= 4 ? 4 : 8));
+  const int G = J <= 1 ? 1 : (J <= 2 ? 2 : (J <= 4 ? 4 : (J <= 8 ? 8 : 16)));
   const int64_t per_wave = kWave / G;
   const dim3 grid((unsigned)((n_draw + per_wave - 1) / per_wave)), block(kWave);
   hipStream_t st = (hipStream_t)stream;
@@ -2143,7 +2188,7 @@ static int celerite_vjp(const double* t, Series resid, const double* diag, int64
     if (launch_status() != EXO_OK) return EXO_ERR_LAUNCH;
     only_flagged = state + ws.off_flag();
   }
-  EXO_GP_DISPATCH(J, hipLaunchKernelGGL((celerite_vjp_kernel<JJ>), grid, block, 0, st, t, diag, n_diag, n, cf, n_draw,
+  EXO_GP_DISPATCH_SEQ(J, hipLaunchKernelGGL((celerite_vjp_kernel<JJ>), grid, block, 0, st, t, diag, n_diag, n, cf, n_draw,
                                         gloglike, state, gresid, gdiag, gdiag_sum, gcoef_real, gcoef_complex,
                                         only_flagged, gsign, resid))
   return launch_status();
@@ -2262,7 +2307,7 @@ int exo_celerite_dot_tril_f64(const double* t, const double* diag, int64_t n_dia
     return EXO_ERR_INVALID_ARGUMENT;
   const Coefs cf{coef_real, coef_complex, pair_kind, n_real, n_complex, n > 0 ? t : nullptr};
   const dim3 grid((unsigned)((n_draw + kWave - 1) / kWave)), block(kWave);
-  EXO_GP_DISPATCH(cf.J(), hipLaunchKernelGGL((celerite_dot_tril_kernel<JJ>), grid, block, 0, (hipStream_t)stream, t, diag,
+  EXO_GP_DISPATCH_SEQ(cf.J(), hipLaunchKernelGGL((celerite_dot_tril_kernel<JJ>), grid, block, 0, (hipStream_t)stream, t, diag,
                                              n_diag, n, cf, n_draw, x, z))
   return launch_status();
 }
@@ -2276,7 +2321,7 @@ int exo_celerite_predict_f64(const double* t, int64_t n, const double* alpha, co
     return EXO_ERR_INVALID_ARGUMENT;
   const Coefs cf{coef_real, coef_complex, pair_kind, n_real, n_complex, n > 0 ? t : nullptr};
   const dim3 grid((unsigned)((n_draw + kWave - 1) / kWave)), block(kWave);
-  EXO_GP_DISPATCH(cf.J(), hipLaunchKernelGGL((celerite_predict_kernel<JJ>), grid, block, 0, (hipStream_t)stream, t, n, alpha,
+  EXO_GP_DISPATCH_SEQ(cf.J(), hipLaunchKernelGGL((celerite_predict_kernel<JJ>), grid, block, 0, (hipStream_t)stream, t, n, alpha,
                                              cf, n_draw, tq, m, mu))
   return launch_status();
 }

@@ -450,7 +450,7 @@ EXO_HD void load_block(const RowT& y, const double* EXO_RESTRICT dg, int64_t n_d
   }
 }
 
-constexpr int kChunkMaxJ = 8;   // = EXO_GP_MAX_J (J = 7, 8: lane-group element kernel, one-lane scan kernels spill)
+constexpr int kChunkMaxJ = 8;   // the time-parallel path's widest state (J = 7, 8: lane-group element kernel, one-lane scan kernels spill); EXO_GP_MAX_J = 16 beyond it: sequential
 // conditioning score above which a draw leaves the time-parallel path (elem_lane: how it was calibrated):
 // EXO_GP_COND_MAX_J2 for state widths J <= 2, EXO_GP_COND_MAX for wider states
 #ifndef EXO_GP_COND_MAX

@@ -10,7 +10,7 @@ from .terms import Term
 
 __all__ = ["GaussianProcess", "celerite_loglike", "celerite_loglike_sparse"]
 
-MAX_J = 8
+MAX_J = 16     # (time-parallel up to 8; 9 .. 16: the sequential kernels -- include/exoplanet_amd.h)
 
 
 def default_chunks():

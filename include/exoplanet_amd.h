@@ -446,7 +446,7 @@ int exo_orbit_vector_vjp_f64(const double* t, int64_t n_cad, const double* param
  * form (a <= 0 or |b d| > a c for some term) or are ill-conditioned are redone by the sequential
  * kernels on the device.
  * ------------------------------------------------------------------------- */
-#define EXO_GP_MAX_J 8
+#define EXO_GP_MAX_J 16   /* state widths 1 .. 8 take the time-parallel path; 9 .. 16 the sequential recurrences (a draw on 16 lanes) */
 int64_t exo_celerite_state_doubles(int64_t n, int64_t n_draw, int32_t n_real, int32_t n_complex,
                                    int32_t n_chunks);
 /* the number of chunks the default plan (n_chunks = 0) cuts the series into, for callers that pass it explicitly; sparse != 0:

@@ -400,7 +400,7 @@ void oracle_transit_ttv(const double* t, int64_t n_cad, const double* texp, int6
  *   coef_real [n_real][2] = (a, c), coef_complex [n_complex][4] = (a, b, c, d)
  * If gresid != NULL also writes gresid[n], gdiag[n], gcoef_real, gcoef_complex
  * for d loglike.  Returns loglike (-inf if not positive definite).           */
-#define JMAX 8
+#define JMAX 16   /* (round 5: state widths up to 16, as the library's sequential kernels) */
 static void make_uv(int J, int n_real, const double* ka, const double* kb, const double* kd, double t,
                     double* U, double* V) {
   for (int j = 0; j < J; ++j) {

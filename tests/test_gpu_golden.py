@@ -155,6 +155,59 @@ def test_gp_hard_golden(dev, key):
                 np.testing.assert_allclose(gc[:, q], w, rtol=1e-6, atol=1e-6 * np.abs(w).max())
 
 
+@pytest.mark.parametrize("key", ["rot2_sho", "rot3", "mixed16"])
+def test_gp_wide_golden(dev, key):
+    """state widths beyond the time-parallel path's 8 (celerite2 has no limit; two RotationTerms + an SHO
+    term is J = 10): J = 10, 12, 16 on the sequential kernels, a draw on a DPP row of 16 lanes -- log-likelihood and every
+    gradient against the long-double dense definition (oracle/make_golden_r05.py), a batch of 5 copies so that a wave holds
+    several draws (4 per wave at 16 lanes each) and a partly filled one; with and without a state buffer's reverse pass"""
+    from exoplanet_amd.gp import celerite_loglike
+
+    g = np.load(os.path.join(GOLD, "gp_wide.npz"))
+    co = [g[f"{key}_{nm}"] for nm in ("ar", "cr", "ac", "bc", "cc", "dc")]
+    want = float(g[f"{key}_loglike"])
+    D = 5
+    real = np.repeat(np.stack(co[:2], -1)[None], D, 0)
+    cplx = np.repeat(np.stack(co[2:], -1)[None], D, 0)
+    assert real.shape[1] + 2 * cplx.shape[1] in (10, 12, 16)
+    yt = T(np.repeat(g[f"{key}_y"][None], D, 0), dev).requires_grad_(True)
+    dt = T(np.repeat(g[f"{key}_diag"][None], D, 0), dev).requires_grad_(True)
+    rt, ct = T(real, dev).requires_grad_(True), T(cplx, dev).requires_grad_(True)
+    ll = celerite_loglike(T(g[f"{key}_t"], dev), yt, dt, rt, ct)
+    assert np.abs(ll.detach().cpu().numpy() - want).max() <= 1e-9 * abs(want)
+    w = torch.linspace(0.5, 1.5, D, dtype=torch.float64, device=dev)
+    (ll * w).sum().backward()
+    wn = w.cpu().numpy()
+    for d in range(D):
+        for got, nm in ((yt.grad, "gy"), (dt.grad, "gdiag")):
+            ref = wn[d] * g[f"{key}_{nm}"]
+            np.testing.assert_allclose(got.cpu().numpy()[d], ref, rtol=1e-6, atol=1e-6 * np.abs(ref).max())
+        for q, nm in enumerate(("ar", "cr")):
+            if real.shape[1]:
+                ref = wn[d] * g[f"{key}_g{nm}"]
+                np.testing.assert_allclose(rt.grad.cpu().numpy()[d, :, q], ref, rtol=1e-6, atol=1e-6 * np.abs(ref).max())
+        for q, nm in enumerate(("ac", "bc", "cc", "dc")):
+            ref = wn[d] * g[f"{key}_g{nm}"]
+            np.testing.assert_allclose(ct.grad.cpu().numpy()[d, :, q], ref, rtol=1e-6, atol=1e-6 * np.abs(ref).max())
+    # the value-only entry without a state buffer and the O(N) companions take the same widths
+    import exoplanet_amd as xo
+
+    terms = xo.gp.terms
+    kern = None
+    for a, c in zip(co[0], co[1]):
+        k1 = terms.RealTerm(a=T([a], dev)[0], c=T([c], dev)[0])
+        kern = k1 if kern is None else kern + k1
+    for a, b, c, d_ in zip(*co[2:]):
+        k1 = terms.ComplexTerm(a=T([a], dev)[0], b=T([b], dev)[0], c=T([c], dev)[0], d=T([d_], dev)[0])
+        kern = k1 if kern is None else kern + k1
+    gp = xo.gp.GaussianProcess(kern, t=T(g[f"{key}_t"], dev), diag=T(g[f"{key}_diag"], dev))
+    assert abs(float(gp.log_likelihood(T(g[f"{key}_y"], dev))) - want) <= 1e-9 * abs(want)
+    alpha = gp.apply_inverse(T(g[f"{key}_y"], dev)).cpu().numpy()
+    np.testing.assert_allclose(alpha, -g[f"{key}_gy"], rtol=1e-6, atol=1e-6 * np.abs(g[f"{key}_gy"]).max())
+    mu = gp.predict(T(g[f"{key}_y"], dev)).cpu().numpy()
+    np.testing.assert_allclose(mu, g[f"{key}_y"] - g[f"{key}_diag"] * alpha, rtol=1e-9, atol=1e-9)
+
+
 def test_overdamped_draws_stay_on_the_time_parallel_path(dev):
     """a batch of SHO terms straddling Q = 1/2 through the user-level classes: the over-damped draws cost what the others
     cost (no sequential redo: the step with them is within 1.5x of the step without), and agree with the sequential

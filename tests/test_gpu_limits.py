@@ -70,9 +70,9 @@ def test_gp_max_state_width(dev):
         if n_real:
             np.testing.assert_allclose(real.grad.cpu().numpy()[0, :, 0], gw["ar"], rtol=1e-6, atol=1e-9)
             np.testing.assert_allclose(real.grad.cpu().numpy()[0, :, 1], gw["cr"], rtol=1e-6, atol=1e-9)
-    with pytest.raises(ValueError):
+    with pytest.raises(ValueError):      # J = 17 > EXO_GP_MAX_J (9 .. 16 run on the sequential kernels: test_gpu_golden.py, gp_wide)
         celerite_loglike(T(t, dev), T(y[None], dev), T(diag[None], dev), T(np.zeros((1, 1, 2)), dev),
-                         T(np.zeros((1, 4, 4)), dev))
+                         T(np.zeros((1, 8, 4)), dev))
 
 
 def test_status_codes_for_invalid_arguments(dev):
@@ -90,7 +90,7 @@ def test_status_codes_for_invalid_arguments(dev):
     assert lib.exo_transit_flux_fwd_f64(p, 4, 0, 0, 0, 0, 1, p, p, 1, 0, 0, p, p, 1 << 20, st) == 1   # n_planet = 0
     assert lib.exo_transit_flux_fwd_f64(p, 4, 0, 0, 0, 0, 1, p, p, 1, 1, 0, p, p, 8, st) == 3         # workspace too small
     assert lib.exo_transit_flux_fwd_f64(p, 4, 0, 3, 0, 0, 1, p, p, 1, 1, 0, p, p, 1 << 20, st) == 1   # n_texp not in {0,1,n}
-    assert lib.exo_celerite_loglike_fwd_f64(p, p, p, 1, 4, p, 9, p, 0, 0, 1, p, 0, 0, 0, st) == 1      # J > 8
+    assert lib.exo_celerite_loglike_fwd_f64(p, p, p, 1, 4, p, 17, p, 0, 0, 1, p, 0, 0, 0, st) == 1     # J > 16 (EXO_GP_MAX_J)
     assert lib.exo_celerite_loglike_fwd_f64(p, p, p, 1, 4, p, 0, p, 1, 0, 1, p, p, 4, 0, st) == 3      # state too small
     assert lib.exo_celerite_loglike_fwd_f64(p, p, p, 1, 4, p, 0, p, 1, 0, 1, p, 0, 0, -1, st) == 1     # n_chunks < 0
     assert lib.exo_pack_records_f64(p, p, 1, 17, 0, p, p, st) == 1
