@@ -159,6 +159,10 @@ def make_leaves(n_draw, seed, dev):
 
 
 _ONES = {}
+# The step goes through torch.autograd (flux_dot + autograd.grad), as in rounds 1-4.  EXO_BENCH_ONE_CALL=1: the one-call
+# value-and-gradient form instead (KeplerianOrbit.flux_value_and_grad: no autograd graph) -- the same three launches (packing +
+# windows + enumeration, sweep, packing VJP) and the same numbers, bit for bit; timed as the extras leg `c2_one_call`
+STEP_THROUGH_AUTOGRAD = os.environ.get("EXO_BENCH_ONE_CALL", "0") != "1"
 
 
 def step(xo, ops, leaves, t, gbar, events=(None, None), use_in_transit=False, **kw):
@@ -167,6 +171,13 @@ def step(xo, ops, leaves, t, gbar, events=(None, None), use_in_transit=False, **
     cotangent of L folded in); the cotangent of L is a constant vector of ones (d sum(L) / d leaves)."""
     orbit = xo.KeplerianOrbit(period=leaves["period"], t0=leaves["t0"], b=leaves["b"], ecc=leaves["ecc"],
                               omega=leaves["omega"])
+    if not STEP_THROUGH_AUTOGRAD:
+        # value and gradient in ONE call of the library (round 5: KeplerianOrbit.flux_value_and_grad ->
+        # exo_transit_flux_cols_vjp_f64): packing + windows + enumeration in one launch, the sweep, the packing VJP -- the same
+        # launches and the same numbers, bit for bit, as the autograd form below (tests/test_gpu_cols.py)
+        flux, L, g = orbit.flux_value_and_grad(leaves["r"], (leaves["u1"], leaves["u2"]), t, gbar, use_in_transit=use_in_transit,
+                                               events=events, **kw)
+        return flux, L, tuple(g[k] for k in leaves)
     flux, L = orbit.flux_dot(leaves["r"], (leaves["u1"], leaves["u2"]), t, gbar, use_in_transit=use_in_transit,
                              events=events, **kw)
     key = (L.shape[0], L.device)
@@ -208,10 +219,10 @@ def workload_c2(xo, ops, dev, D, rank=0, events=None):
     return Workload("c2", "BASELINE configs[1] (C2): single planet e=0.3 Kepler solve + quadratic limb-darkened transit, "
                     "150000 cadences, value+grad, use_in_transit=False: dense flux output", D, N_CAD, names,
                     list(leaves.values()), fn, 1, 2, SURVEY_BYTES_PER_UNIT, dict(t=t, gbar=gbar, leaves=leaves),
-                    "leaf params (separate tensors, read in place) -> record-packing kernel (orbit algebra + get_cl) -> window + "
-                    "run-enumeration + heavy kernels (value+VJP, one sweep; the heavy kernel's blocks finish their own draws at "
-                    ">= 512 draws, a separate finish kernel below that) -> packing VJP kernel (cotangent of L folded in) -> leaf "
-                    "gradients: five launches (six below 512 draws)")
+                    "leaf params (separate tensors, read in place) -> ONE launch packs the records (orbit algebra + get_cl), works out "
+                    "the windows and enumerates the runs -> the sweep (value + VJP; at >= 512 draws its blocks finish their own "
+                    "draws, a separate finish kernel below that) -> packing VJP kernel -> leaf gradients: three launches (four below "
+                    "512 draws); through torch.autograd (flux_dot + autograd.grad)")
 
 
 # the light curve that is the mean of a GP travels between the two ops as a [cadence][draw] array (get_light_curve's
@@ -1214,6 +1225,21 @@ def main():
                             "writes the cadences THIS step solved -- the dense sweep's array, bit for bit, without the 1.23 GB "
                             "fill of every cadence.  The headline stays the stateless dense sweep."}
 
+        def one_call():
+            global STEP_THROUGH_AUTOGRAD
+            names = list(leaves)
+            was = STEP_THROUGH_AUTOGRAD
+            STEP_THROUGH_AUTOGRAD = False
+            try:
+                q, how = graphed(xo, lambda *v: step(xo, ops, dict(zip(names, v)), t, gbar), list(leaves.values()), dev, 50)
+            finally:
+                STEP_THROUGH_AUTOGRAD = was
+            return {"evals_per_s": D / (q["median_ms"] * 1e-3), **q, "launch": how,
+                    "note": "the headline step as ONE call of the library without an autograd graph (KeplerianOrbit.flux_value_and_grad "
+                            "-> exo_transit_flux_cols_vjp_f64): what a sampler's leapfrog step would call; the same three launches and "
+                            "numbers as the headline's autograd form"}
+
+        leg("c2_one_call", one_call)
         leg("c2_white_noise_likelihood", likelihood)
         leg("c2_sparse_output", sparse_output)
         leg("c2_dense_kept_across_steps", kept_dense)
@@ -1274,6 +1300,7 @@ def main():
             "c5_128": pick("c5_secondary_eclipse_3term_gp_128_chains"), "c5b": pick("c5_128_chains_1pct_bright_star_kappa_1e6"),
             "sparse": pick("c2_sparse_output"), "chi2": pick("c2_white_noise_likelihood"),
             "hmc": pick("hmc_trajectory_c2"), "nuts_leaf": pick("nuts_transition_c2", "ms_per_leaf"),
+            "c2_one_call": pick("c2_one_call"),
             "note": "ms per value + gradient step, one MI355X, hipGraph replay; c2 / sparse / chi2 at 1024 draws x 150000 cadences",
         }
     if dist is not None:

@@ -54,6 +54,14 @@ _SIGNATURES = {
         [_c_dp, _i64, _c_dp, _i64, _c_dp, _c_dp, _i32, _c_dp, _c_dp, _i64, _i32, _u32, _c_dp, _c_dp, _i32,
          _c_dp, _c_dp, _c_dp, _c_dp, _c_dp, _c_dp, _c_dp, _i64, _c_dp],
     ),
+    # cols, draw_stride, planet_stride, defaults, ld_cols, ld_draw_stride (host), pack_flags, t, n_cad, texp, n_texp, stencil_dt,
+    # stencil_w, n_sub, n_draw, n_planet, flags, gflux, flux_out, params, ld, gparams, gld, flux_dot, fold, gscale, gcols, gld_cols
+    # (host), workspace, workspace_bytes, stream, ev_start, ev_stop
+    "exo_transit_flux_cols_vjp_f64": (
+        ctypes.c_int,
+        [_c_dp, _c_dp, _c_dp, _c_dp, _c_dp, _c_dp, _u32, _c_dp, _i64, _c_dp, _i64, _c_dp, _c_dp, _i32, _i64, _i32, _u32, _c_dp, _c_dp,
+         _c_dp, _c_dp, _c_dp, _c_dp, _c_dp, _i32, _c_dp, _c_dp, _c_dp, _c_dp, _i64, _c_dp, _c_dp, _c_dp],
+    ),
     "exo_celerite_state_doubles": (_i64, [_i64, _i64, _i32, _i32, _i32]),
     "exo_celerite_default_chunks": (_i32, [_i64, _i64, _i32, _i32, _i32]),
     # t, resid, diag, n_diag, n, coef_real, n_real, coef_complex, n_complex, pair_kind, n_draw, loglike, state,

@@ -48,6 +48,7 @@
 #include "../../include/exoplanet_amd.h"
 #include "exo_contact.hpp"
 #include "exo_math.hpp"
+#include "exo_pack_core.hpp"
 
 namespace {
 
@@ -1565,21 +1566,53 @@ __device__ __forceinline__ void enum_prefix(int (*s_len)[kRunMax + 1], int K, in
 // searches): the wave works its record's conjunction windows out itself -- every group of eight lanes the same record, lane 0
 // and lane 2 hold the result -- and the list of event 0 leaves them in `windows_out` for the sweep: no transit_window_kernel
 // launch (each of these short kernels is ~5 us of dispatch and dependent memory round trips before its first useful cycle).
-template <bool FUSED>
+// PACK (with FUSED; exo_transit_flux_cols_vjp_f64): the wave is handed the constructor's COLUMNS and packs its record itself
+// (exo_pack_core.hpp: lane 0; the list of event 0 writes it out for the sweep, the first list of a draw the limb-darkening
+// coefficients too, on lane 1) -- no pack_kernel launch in front (C2: packing 5.9 + enumeration 10.2 us -> 14.5 us).
+// (The packing VJP was folded into the sweep's last kernel as well -- the block that sums a draw's record cotangents taking them
+// back to the columns -- measured, and removed: one thread's serial chain at the tail of every block cost the sweep 12.7 us at C2,
+// the 1024-lane packing-VJP kernel it replaced costs 7.2.)
+struct PackIn {
+  exo_pack::ColsSrc src;
+  uint32_t flags;          // pack flags
+  int n_planet;
+  double* params;          // out [n_draw][n_planet][EXO_NPAR]
+  double* ld;              // out [n_draw][3 | 6]
+};
+template <bool FUSED, bool PACK = false>
 __global__ __launch_bounds__(64) void transit_enum_kernel(const double* __restrict__ t, int64_t n_cad,
                                                           const double* __restrict__ texp, int64_t n_texp,
                                                           const double* __restrict__ stencil_dt, int n_sub, uint32_t flags,
                                                           const double* __restrict__ windows,
                                                           const int32_t* __restrict__ sorted, int n_sorted, int n_ev,
                                                           RunLists rl, const double* __restrict__ params = nullptr,
-                                                          double* __restrict__ windows_out = nullptr) {
+                                                          double* __restrict__ windows_out = nullptr, PackIn pk = PackIn{}) {
+  static_assert(!PACK || FUSED, "packing rides on the fused windows + enumeration launch");
   __shared__ int s_len[2][kRunMax + 1];
+  __shared__ double s_rec[PACK ? EXO_NPAR : 1];
   const int64_t list = blockIdx.x, rec = list / n_ev;
   const int ev = (int)(list - rec * n_ev), lane = threadIdx.x;
+  if (PACK) {
+    const int64_t draw = rec / pk.n_planet;
+    const int planet = (int)(rec - draw * pk.n_planet);
+    if (lane == 0) {
+      double o[EXO_NPAR];
+      exo_pack::pack_record(pk.src, rec, draw, planet, pk.flags, o);
+#pragma unroll
+      for (int k = 0; k < EXO_NPAR; ++k) s_rec[k] = o[k];
+      if (ev == 0) {
+#pragma unroll
+        for (int k = 0; k < EXO_NPAR; ++k) pk.params[rec * EXO_NPAR + k] = o[k];
+      }
+    }
+    if (lane == 1 && ev == 0 && planet == 0)
+      exo_pack::pack_ld(pk.src, draw, pk.flags, pk.ld + draw * ((pk.flags & EXO_FLAG_SECONDARY) ? 6 : 3));
+    __syncthreads();
+  }
   double wv[kWin];
   if (FUSED) {
     double w[kWin] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-    window_lanes(params + rec * EXO_NPAR, flags, lane & 7, w);
+    window_lanes(PACK ? s_rec : params + rec * EXO_NPAR, flags, lane & 7, w);
     const bool every = flags & EXO_FLAG_WINDOW;   // (every lane holds all seven)
 #pragma unroll
     for (int q = 0; q < kWin; ++q) wv[q] = __shfl(w[q], (!every && (q == 4 || q == 6)) ? 2 : 0, 64);
@@ -2742,7 +2775,9 @@ inline int launch_runs_sweep(const double* t, int64_t n_cad, const double* texp,
                              int64_t n_draw, int32_t n_planet, uint32_t flags, const double* gflux, double* flux,
                              double* gparams, double* gld, double* flux_dot, const RunWs& w, hipStream_t st,
                              const Chi2Args* chi2 = nullptr, const Ttv* ttv = nullptr, double* jac = nullptr,
-                             const double* gvals = nullptr, bool reuse_runs = false) {
+                             const double* gvals = nullptr, bool reuse_runs = false, const PackIn* pack = nullptr) {
+  // pack: the records are not there yet -- `params` / `ld` are where the fused packing + enumeration launch will put them
+  // (requires the fused launch: sorted times on the caller's word, no timing tables)
   // gvals: the cotangent in the VALUE layout of the sparse output (exo_transit_flux_vjp_sparse_f64) instead of gflux;
   // reuse_runs: the workspace still holds the windows and runs of these very records (the forward sweep's): no enumeration
   const bool secondary = flags & EXO_FLAG_SECONDARY, sparse = (flags & EXO_FLAG_SPARSE) || chi2;
@@ -2759,7 +2794,13 @@ inline int launch_runs_sweep(const double* t, int64_t n_cad, const double* texp,
     hipLaunchKernelGGL(transit_window_kernel, dim3((unsigned)((n_rec * kWinLanes + kBlock - 1) / kBlock + w.n_sorted)), block, 0, st,
                        params, n_rec, flags, w.windows, t, n_cad, w.sorted, w.done, n_draw);
   }
+  if (pack && (!fused_enum || reuse_runs)) return EXO_ERR_INVALID_ARGUMENT;
   if (reuse_runs) {
+  } else if (pack) {
+    const PackIn pk = *pack;
+    hipLaunchKernelGGL((transit_enum_kernel<true, true>), dim3((unsigned)(n_draw * n_planet * n_ev)), dim3(64), 0, st, t, n_cad, texp,
+                       n_texp, stencil_dt, (int)n_sub, flags, (const double*)nullptr, (const int32_t*)nullptr, 0, n_ev, w.rl,
+                       params, w.windows, pk);
   } else if (fused_enum)
     hipLaunchKernelGGL(transit_enum_kernel<true>, dim3((unsigned)(n_draw * n_planet * n_ev)), dim3(64), 0, st, t, n_cad, texp,
                        n_texp, stencil_dt, (int)n_sub, flags, (const double*)nullptr, (const int32_t*)nullptr, 0, n_ev, w.rl,
@@ -3240,6 +3281,60 @@ int exo_transit_flux_jac_vjp_f64(const double* gflux, int64_t n_cad, int64_t n_d
                      gparams, gld, flux_dot, n_cad, flags & ~(uint32_t)(EXO_FLAG_CADENCE_MAJOR | EXO_FLAG_SPARSE), n_ev, rw.rl, nullptr, nullptr, nullptr,
                      nullptr, 0, nullptr, Ttv{nullptr, nullptr, nullptr, 0});
   return launch_status();
+}
+
+// columns in (as exo_pack_records_cols_f64), records + sweep + (optionally) column cotangents out
+int exo_transit_flux_cols_vjp_f64(const double* const* cols, const int64_t* draw_stride, const int64_t* planet_stride,
+                                  const double* defaults, const double* const* ld_cols, const int64_t* ld_draw_stride,
+                                  uint32_t pack_flags, const double* t, int64_t n_cad, const double* texp, int64_t n_texp,
+                                  const double* stencil_dt, const double* stencil_w, int32_t n_sub, int64_t n_draw,
+                                  int32_t n_planet, uint32_t flags, const double* gflux, double* flux_out, double* params,
+                                  double* ld, double* gparams, double* gld, double* flux_dot, int32_t fold,
+                                  const double* gscale, double* const* gcols, double* const* gld_cols, void* workspace,
+                                  int64_t workspace_bytes, void* stream, void* ev_start, void* ev_stop) {
+  if (!transit_args_ok(n_cad, n_texp, n_sub, n_draw, n_planet) || !sweep_flags_ok(flags)) return EXO_ERR_INVALID_ARGUMENT;
+  if (n_draw == 0) return EXO_OK;
+  if (!cols || !draw_stride || !planet_stride || !defaults || !ld_cols || !ld_draw_stride || !params || !ld || !gparams || !gld ||
+      (fold && (!gcols || !gld_cols)) || (n_cad > 0 && (!t || !gflux)) || (n_texp > 0 && (!texp || !stencil_dt || !stencil_w)))
+    return EXO_ERR_INVALID_ARGUMENT;
+  if (n_planet * kNG + 7 > kBlock) return EXO_ERR_INVALID_ARGUMENT;
+  if ((flags & EXO_FLAG_CADENCE_MAJOR) && (flags & EXO_FLAG_PER_PLANET)) return EXO_ERR_INVALID_ARGUMENT;
+  if (((pack_flags ^ flags) & EXO_FLAG_SECONDARY) != 0) return EXO_ERR_INVALID_ARGUMENT;   // (one answer to "occultations?")
+  hipStream_t st = (hipStream_t)stream;
+  // the launches fuse when the sweep is a run-enumeration sweep on sorted times (the caller's word: EXO_FLAG_SORTED_TIMES); anything
+  // else is the three calls one after the other -- same results
+  const bool fused = n_cad > 0 && runs_path(false, n_texp, flags) && (flags & EXO_FLAG_SORTED_TIMES) && EXO_RUNS_FOLD_FINISH != 2;
+  if (!fused) {
+    int rc = exo_pack_records_cols_f64(cols, draw_stride, planet_stride, defaults, ld_cols, ld_draw_stride, n_draw, n_planet,
+                                       pack_flags, params, ld, stream);
+    if (rc != EXO_OK) return rc;
+    rc = transit_vjp(t, n_cad, texp, n_texp, stencil_dt, stencil_w, n_sub, params, ld, n_draw, n_planet, flags,
+                     Ttv{nullptr, nullptr, nullptr, 0}, gflux, flux_out, gparams, gld, flux_dot, workspace, workspace_bytes, stream,
+                     ev_start, ev_stop);
+    if (rc != EXO_OK || !fold) return rc;
+    return exo_pack_records_cols_vjp_f64(cols, draw_stride, planet_stride, defaults, ld_cols, ld_draw_stride, n_draw, n_planet,
+                                         pack_flags, gparams, gld, gscale, gcols, gld_cols, stream);
+  }
+  PackIn pk{};
+  const int nld = (pack_flags & EXO_FLAG_SECONDARY) ? 4 : 2;
+  for (int k = 0; k < EXO_NIN; ++k) {
+    pk.src.ptr[k] = cols[k]; pk.src.ds[k] = draw_stride[k]; pk.src.ps[k] = planet_stride[k]; pk.src.def[k] = defaults[k];
+  }
+  for (int k = 0; k < 4; ++k) {
+    pk.src.ldp[k] = k < nld ? ld_cols[k] : nullptr;
+    pk.src.lds[k] = k < nld ? ld_draw_stride[k] : 0;
+    if (k < nld && !ld_cols[k]) return EXO_ERR_INVALID_ARGUMENT;
+  }
+  pk.flags = pack_flags; pk.n_planet = n_planet; pk.params = params; pk.ld = ld;
+  const RunWs rw = carve_runs(workspace, n_cad, n_draw, n_planet);
+  if (!workspace || workspace_bytes < rw.bytes) return EXO_ERR_WORKSPACE;
+  if (ev_start) (void)hipEventRecord((hipEvent_t)ev_start, st);
+  const int rc = launch_runs_sweep(t, n_cad, texp, n_texp, stencil_dt, stencil_w, n_sub, params, ld, n_draw, n_planet, flags, gflux,
+                                   flux_out, gparams, gld, flux_dot, rw, st, nullptr, nullptr, nullptr, nullptr, false, &pk);
+  if (ev_stop) (void)hipEventRecord((hipEvent_t)ev_stop, st);
+  if (rc != EXO_OK || !fold) return rc;
+  return exo_pack_records_cols_vjp_f64(cols, draw_stride, planet_stride, defaults, ld_cols, ld_draw_stride, n_draw, n_planet,
+                                       pack_flags, gparams, gld, gscale, gcols, gld_cols, stream);
 }
 
 int exo_transit_flux_vjp_sparse_f64(const double* t, int64_t n_cad, const double* texp, int64_t n_texp, const double* stencil_dt,

@@ -1321,6 +1321,140 @@ def sho_coefficients_multi(terms, eps=1e-5):
     return _ShoCoefficientsMulti.apply(tuple(int(f) for *_, f in terms), float(eps), *flat)
 
 
+def _cols_vjp(t, texp, stencil_dt, stencil_w, host, D, P, nset, flags, pack_flags, gflux, events=(None, None), fold=None):
+    """exo_transit_flux_cols_vjp_f64: the constructor's columns (``host`` = the six host arrays of _cols_host) -> records, the
+    value + VJP sweep and, ``fold = (gscale | None, gcols, gld_cols)`` (host arrays of output pointers), the packing VJP in
+    the same call.  Returns (flux | SparseFlux, gparams, gld, dot)."""
+    cp, ds, ps, df, lp, ls = host
+    t = _dev(t, "t")
+    N = t.numel()
+    if t.dim() != 1:
+        raise ValueError("t must be 1-D (n_cad,)")
+    if texp is None:
+        n_texp, n_sub, sdt, sw = 0, 1, None, None
+    else:
+        texp = _dev(texp, "texp").reshape(-1)
+        sdt, sw = _dev(stencil_dt, "stencil_dt"), _dev(stencil_w, "stencil_w")
+        n_texp, n_sub = texp.numel(), sdt.numel()
+        if n_texp not in (1, N) or sw.numel() != n_sub or not 1 <= n_sub <= MAX_SUBEXP:
+            raise ValueError("texp: a scalar or one entry per cadence; stencil: 1..%d points" % MAX_SUBEXP)
+    if not 1 <= P <= MAX_PLANETS:
+        raise ValueError(f"1 <= n_planet <= {MAX_PLANETS}")
+    flags = int(flags) | _sorted_flag(t)
+    shape = (D, N, P) if flags & FLAG_PER_PLANET else (D, N)
+    if isinstance(gflux, torch.Tensor) and tuple(gflux.shape) != shape:
+        raise ValueError(f"gflux must have shape {shape}")
+    cm_sweep = n_texp <= 1 and not flags & (FLAG_EXACT_SCAN | FLAG_PER_PLANET)
+    if is_cadence_major(gflux) and cm_sweep:
+        flags |= FLAG_CADENCE_MAJOR
+    elif flags & FLAG_CADENCE_MAJOR and cm_sweep:
+        gflux = _dev(gflux, "gflux").t().contiguous().t()
+    else:
+        flags &= ~FLAG_CADENCE_MAJOR
+        gflux = _dev(gflux, "gflux")
+    dev = t.device
+    lib = _lib.load()
+    nbytes = lib.exo_transit_flux_workspace_bytes(N, D, P)
+    ws = torch.empty(max(nbytes // 8 + 1, 1), dtype=torch.float64, device=dev)
+    params = torch.empty(D, P, NPAR, dtype=torch.float64, device=dev)
+    ld = torch.empty(D, 3 * nset, dtype=torch.float64, device=dev)
+    gparams, gld = torch.empty_like(params), torch.empty_like(ld)
+    dot = torch.empty(D, dtype=torch.float64, device=dev)
+    flux = None
+    if not flags & FLAG_SPARSE:
+        flux = (torch.empty((N, D), dtype=torch.float64, device=dev).t() if flags & FLAG_CADENCE_MAJOR
+                else torch.empty(shape, dtype=torch.float64, device=dev))
+    gscale, gcp, glp = (None, None, None) if fold is None else fold
+    with torch.cuda.device(dev):
+        _lib.check(lib.exo_transit_flux_cols_vjp_f64(cp, ds, ps, df, lp, ls, int(pack_flags), _ptr(t), N, _ptr(texp), n_texp,
+                                                     _ptr(sdt), _ptr(sw), n_sub, D, P, flags, _ptr(gflux), _ptr(flux),
+                                                     _ptr(params), _ptr(ld), _ptr(gparams), _ptr(gld), _ptr(dot),
+                                                     0 if fold is None else 1, _ptr(gscale), gcp, glp, _ptr(ws), nbytes,
+                                                     _stream(t), events[0], events[1]), "exo_transit_flux_cols_vjp_f64")
+    if flags & FLAG_SPARSE:
+        flux = _sparse_from_ws(ws, N, D, P, flags)
+    return flux, gparams, gld, dot
+
+
+def _cols_host(ocols, lcols, D, P):
+    """the host arrays exo_pack_records_cols_f64 / exo_transit_flux_cols_vjp_f64 take for a list of NIN orbit columns (None = the
+    constructor's default) and the limb-darkening columns, + the expanded views (kept alive by the caller)"""
+    import ctypes
+
+    vp, i64 = ctypes.c_void_p, ctypes.c_int64
+    cp, ds, ps, df = (vp * NIN)(), (i64 * NIN)(), (i64 * NIN)(), (ctypes.c_double * NIN)(*_PACK_DEFAULTS)
+    keep = []
+    for k, c in enumerate(ocols):
+        if c is None:
+            continue
+        c = _dev(c.detach(), "orbit parameter")
+        v = c.reshape(1, 1) if c.dim() == 0 else (c.unsqueeze(0) if c.dim() == 1 else c)
+        v = v.expand(D, P)
+        keep.append(v)
+        cp[k], ds[k], ps[k] = v.data_ptr(), v.stride(0), v.stride(1)
+    lp, ls = (vp * 4)(), (i64 * 4)()
+    for k, c in enumerate(lcols):
+        c = _dev(c.detach(), "limb-darkening coefficient")
+        v = (c.reshape(1) if c.dim() == 0 else c).expand(D)
+        keep.append(v)
+        lp[k], ls[k] = v.data_ptr(), v.stride(0)
+    return (cp, ds, ps, df, lp, ls), keep
+
+
+@torch.no_grad()
+def orbit_flux_value_and_grad(t, gflux, orbit_cols, ld_cols, flags=0, pack_flags=0, texp=None, stencil_dt=None, stencil_w=None,
+                              gscale=None, events=(None, None), wanted=None):
+    """Value AND gradient of ``L[d] = sum_n gflux[d, n] flux[d, n]`` for orbits in the standard parameterisation given column
+    by column (as :func:`orbit_flux_dot`), WITHOUT autograd: returns ``(flux, L, gcols, gld_cols)`` -- ``gcols[k]`` the
+    gradient of ``sum_d gscale[d] L[d]`` (``gscale`` None: of ``sum_d L[d]``) with respect to orbit column k in that
+    column's own shape (None where the column was None), ``gld_cols`` likewise for (u1, u2[, u1s, u2s]).  What a sampler's
+    leapfrog step needs, in ONE call of the library (exo_transit_flux_cols_vjp_f64): the packing rides on the windows +
+    enumeration launch, then the sweep, then the packing VJP -- three launches at >= 512 draws, no autograd graph.
+    ``wanted``: one bool per orbit column -- False: no gradient for it (None in ``gcols``)."""
+    import ctypes
+
+    ocols, lcols = list(orbit_cols), list(ld_cols)
+    if len(ocols) != NIN or len(lcols) not in (2, 4):
+        raise ValueError(f"{NIN} orbit columns (None = default) and 2 or 4 limb-darkening columns")
+    D = P = 1
+    for c in ocols:
+        if c is not None:
+            if c.dim() > 2:
+                raise ValueError("orbit parameters may carry at most one draw dimension here")
+            P = max(P, c.shape[-1] if c.dim() >= 1 else 1)
+            D = max(D, c.shape[0] if c.dim() == 2 else 1)
+    for c in lcols:
+        if c.dim() > 1:
+            raise ValueError("limb-darkening coefficients may carry at most one draw dimension")
+        D = max(D, c.shape[0] if c.dim() == 1 else 1)
+    host, keep = _cols_host(ocols, lcols, D, P)
+    dev = keep[0].device
+    vp = ctypes.c_void_p
+    gcp, glp = (vp * NIN)(), (vp * 4)()
+    wanted = [True] * NIN if wanted is None else list(wanted)
+    outs = [None if (c is None or not w) else torch.empty(D, P, dtype=torch.float64, device=dev) for c, w in zip(ocols, wanted)]
+    louts = [torch.empty(D, dtype=torch.float64, device=dev) for _ in lcols]
+    for k, o in enumerate(outs):
+        if o is not None:
+            gcp[k] = o.data_ptr()
+    for k, o in enumerate(louts):
+        glp[k] = o.data_ptr()
+    if gscale is not None:
+        gscale = _dev(gscale, "gscale")
+        if tuple(gscale.shape) != (D,):
+            raise ValueError("gscale: one factor per draw")
+    flux, _, _, dot = _cols_vjp(t, texp, stencil_dt, stencil_w, host, D, P, len(lcols) // 2, flags, pack_flags, gflux, events,
+                                fold=(gscale, gcp, glp))
+
+    def back(g, c):       # dense (D, P) / (D,) cotangents back to the column's own shape (sums over what was broadcast)
+        if g is None:
+            return None
+        shp = tuple(c.shape)
+        return g.reshape(shp) if g.numel() == _numel(shp) else g.sum_to_size(_bshape(shp, g.dim())).reshape(shp)
+
+    return flux, dot, [back(g, c) for g, c in zip(outs, ocols)], [back(g, c) for g, c in zip(louts, lcols)]
+
+
 class _OrbitFluxDot(torch.autograd.Function):
     """Record packing (column form: every constructor argument its own tensor), the one-sweep value + VJP light
     curve, and -- backward -- the packing VJP with the cotangent of L folded in (``gscale``): the whole
@@ -1363,14 +1497,10 @@ class _OrbitFluxDot(torch.autograd.Function):
             keep.append(v)
             lp[k], ls[k] = v.data_ptr(), v.stride(0)
         nset = n_ld // 2
-        params = torch.empty(D, P, NPAR, dtype=torch.float64, device=t.device)
-        ld = torch.empty(D, 3 * nset, dtype=torch.float64, device=t.device)
-        lib = _lib.load()
-        with torch.cuda.device(t.device):
-            _lib.check(lib.exo_pack_records_cols_f64(cp, ds, ps, df, lp, ls, D, P, pack_flags, _ptr(params), _ptr(ld),
-                                                     _stream(t)), "exo_pack_records_cols_f64")
-        t_, texp_, n_texp, sdt, sw, n_sub, params, ld, D, P = _transit_args(t, texp, stencil_dt, stencil_w, params, ld, flags)
-        flux, gparams, gld, dot, _ = _vjp(t_, texp_, n_texp, sdt, sw, n_sub, params, ld, D, P, flags, gflux, True, events)
+        # (packing, windows + enumeration in ONE launch, then the sweep: exo_transit_flux_cols_vjp_f64; the packing VJP stays in
+        # backward() -- the cotangent of L is not known before)
+        flux, gparams, gld, dot = _cols_vjp(t, texp, stencil_dt, stencil_w, (cp, ds, ps, df, lp, ls), D, P, nset, flags,
+                                            pack_flags, gflux, events)
         ctx.save_for_backward(gparams, gld, *keep)
         ctx.meta = (D, P, pack_flags, n_ld, [c is not None for c in ocols], [None if c is None else tuple(c.shape) for c in cols])
         ctx.set_materialize_grads(False)

@@ -666,6 +666,47 @@ class KeplerianOrbit:
         return ops.transit_flux_dot(t, rec, ld, weights, texp=texp, stencil_dt=sdt, stencil_w=sw,
                                     flags=fl | (ops.FLAG_SPARSE if sparse else 0), events=events)
 
+    def flux_value_and_grad(self, r, u, t, weights, use_in_transit=False, secondary=None, light_delay=False, texp=None,
+                            stencil=None, sparse=False, gscale=None, events=(None, None)):
+        """``(flux, L, grads)`` -- :meth:`flux_dot` AND the gradient of ``sum_d gscale[d] L[d]`` (``gscale`` None: of
+        ``sum_d L[d]``) in one call of the library, without autograd (ops.orbit_flux_value_and_grad: what a sampler's leapfrog
+        step asks for).  ``grads``: a dict over the constructor arguments that were given as tensors (period, t0, b, ecc,
+        omega, m_star, r_star, m_planet), ``r``, ``u1``, ``u2`` (``u1s``, ``u2s``, ``sbr`` with ``secondary``), each in its
+        argument's own shape.  Standard parameterisation with at most one draw dimension (TypeError otherwise: use
+        :meth:`flux_dot` and torch.autograd)."""
+        sdt, sw = (None, None) if stencil is None else stencil
+        flags = (ops.FLAG_WINDOW if use_in_transit else 0) | (ops.FLAG_SECONDARY if secondary is not None else 0)
+        flags |= (ops.FLAG_LIGHT_DELAY if light_delay else 0) | (ops.FLAG_SPARSE if sparse else 0)
+        if not self._standard:
+            raise TypeError("flux_value_and_grad: the standard parameterisation (period, t0, b[, ecc, omega]) only")
+        A = self._args
+        like = next((x for x in list(A.values()) + [r] if isinstance(x, torch.Tensor)), None)
+        opt = lambda x: None if x is None else _vec(x, like)  # noqa: E731
+        sbr = None
+        if secondary is not None:
+            sbr = as_tensor(secondary[1], like)
+            sbr = sbr.unsqueeze(-1) if sbr.dim() >= 1 else sbr.reshape(1)
+        names = ["period", "t0", "b", "ecc", "omega", "r", "m_star", "r_star", "m_planet", "sbr"]
+        given = [A["period"], A["t0"], A["b"], A["ecc"], A["omega"], r, A["m_star"], A["r_star"], A["m_planet"],
+                 None if secondary is None else secondary[1]]
+        cols = [opt(A["period"]), opt(A["t0"]), opt(A["b"]), opt(A["ecc"]), opt(A["omega"]), opt(r), opt(A["m_star"]),
+                opt(A["r_star"]), opt(A["m_planet"]), sbr]
+        us = [as_tensor(x, like) for x in list(u) + (list(secondary[0]) if secondary is not None else [])]
+        if not (all(c is None or c.dim() <= 2 for c in cols) and all(x.dim() <= 1 for x in us)):
+            raise TypeError("flux_value_and_grad: at most one draw dimension")
+        pack_flags = (flags & (ops.FLAG_WINDOW | ops.FLAG_SECONDARY)) | (ops.PACK_CIRCULAR if A["ecc"] is None else 0)
+        flux, L, gcols, gus = ops.orbit_flux_value_and_grad(t, weights, cols, us, flags=flags, pack_flags=pack_flags, texp=texp,
+                                                            stencil_dt=sdt, stencil_w=sw, gscale=gscale, events=events,
+                                                            wanted=[isinstance(x, torch.Tensor) for x in given])
+        grads = {}
+        for name, x, g in zip(names, given, gcols):
+            if g is not None and isinstance(x, torch.Tensor):
+                grads[name] = g.reshape(x.shape) if g.numel() == x.numel() else g.sum_to_size(x.shape)
+        for name, x, g in zip(["u1", "u2", "u1s", "u2s"], list(u) + (list(secondary[0]) if secondary is not None else []), gus):
+            if isinstance(x, torch.Tensor):
+                grads[name] = g.reshape(x.shape) if g.numel() == x.numel() else g.sum_to_size(x.shape)
+        return flux, L, grads
+
     def kernel_records(self, r, use_in_transit=False, secondary_sbr=None):
         """Pack the per-(draw, planet) parameter records of the fused transit
         kernel (layout: include/exoplanet_amd.h, EXO_P_*) from the orbit's attributes, in

@@ -39,7 +39,8 @@ extern "C" {
  *     batches of mixed pair kinds lives in the state: forward and reverse call must be the same build); flag bits a build
  *     does not know are EXO_ERR_INVALID_ARGUMENT.
  * 11: the sparse model -- exo_sparse_model, exo_transit_flux_sparse_model, exo_transit_flux_vjp_sparse_f64,
- *     exo_celerite_loglike_sparse_{fwd,vjp}_f64; EXO_FLAG_SPARSE accepted by the Jacobian pair. */
+ *     exo_celerite_loglike_sparse_{fwd,vjp}_f64, exo_celerite_default_chunks; EXO_FLAG_SPARSE accepted by the Jacobian pair;
+ *     exo_transit_flux_cols_vjp_f64; EXO_GP_MAX_J 16; a larger exo_transit_flux_workspace_bytes. */
 #define EXO_ABI_VERSION 11
 int32_t exo_abi_version(void);
 
@@ -308,6 +309,27 @@ int exo_transit_flux_vjp_ev_f64(const double* t, int64_t n_cad, const double* te
                                 double* flux_out, double* gparams, double* gld, double* flux_dot,
                                 void* workspace, int64_t workspace_bytes, void* stream, void* ev_start,
                                 void* ev_stop);
+
+/* The whole user-level step of a standard-parameterisation orbit in one call (round 5): the constructor's COLUMNS in -- as
+ * exo_pack_records_cols_f64, which see below: cols / draw_stride / planet_stride / defaults / ld_cols / ld_draw_stride are HOST
+ * arrays of device pointers, strides and defaults; pack_flags: EXO_PACK_CIRCULAR, EXO_FLAG_WINDOW, EXO_FLAG_SECONDARY (as in
+ * flags) -- the records (params, ld: written, the caller's buffers), the value + VJP sweep of exo_transit_flux_vjp_f64 (flux_out
+ * nullable or, with EXO_FLAG_SPARSE, unused; gparams, gld, flux_dot out), and, fold != 0, the packing VJP behind it:
+ *   gcols[k] [n_draw][n_planet], gld_cols[k] [n_draw]  (HOST arrays of device pointers, NULL entry = not wanted)
+ *                = gscale[d] (or 1, gscale == NULL) x d sum_n gflux flux / d column
+ * On a run-enumeration sweep with EXO_FLAG_SORTED_TIMES the packing rides on the windows + enumeration launch (every list's wave
+ * packs its own record: no packing launch in front); the packing VJP is a launch of its own behind the sweep (folded into the
+ * sweep's last kernel it was measured slower: one thread's serial chain at the tail of every block).  Anything else runs the three
+ * calls one after the other: same results, bit for bit.  ev_start / ev_stop as exo_transit_flux_vjp_ev_f64.  Reference:
+ * keplerian.py:75-281 + limb_dark.py:99-232 and their gradients, one likelihood-gradient evaluation of a sampler.      */
+int exo_transit_flux_cols_vjp_f64(const double* const* cols, const int64_t* draw_stride, const int64_t* planet_stride,
+                                  const double* defaults, const double* const* ld_cols, const int64_t* ld_draw_stride,
+                                  uint32_t pack_flags, const double* t, int64_t n_cad, const double* texp, int64_t n_texp,
+                                  const double* stencil_dt, const double* stencil_w, int32_t n_sub, int64_t n_draw,
+                                  int32_t n_planet, uint32_t flags, const double* gflux, double* flux_out, double* params,
+                                  double* ld, double* gparams, double* gld, double* flux_dot, int32_t fold,
+                                  const double* gscale, double* const* gcols, double* const* gld_cols, void* workspace,
+                                  int64_t workspace_bytes, void* stream, void* ev_start, void* ev_stop);
 
 /* ---------------------------------------------------------------------------
  * The same two sweeps for an orbit with transit-timing variations

@@ -278,4 +278,4 @@ def test_sorted_flag_policy_and_the_device_guard(dev):
     rc = lib.exo_transit_flux_fwd_f64(tbuf.data_ptr(), N, 0, 0, 0, 0, 1, recd.data_ptr(), cd.data_ptr(), D, 1, 1 << 12,
                                       flux.data_ptr(), ws.data_ptr(), nbytes, 0)
     assert rc == 1      # EXO_ERR_INVALID_ARGUMENT
-    assert lib.exo_abi_version() == 10
+    assert lib.exo_abi_version() == _lib.ABI_VERSION
