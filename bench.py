@@ -890,12 +890,12 @@ def extra_ttv(xo, ops, leaves, t, gbar, dev, D):
 
 
 def load_counters():
-    """This round's committed counter record (profiles/r04_counters.json: rocprofv3 --pmc passes, tools/profile_r04.sh),
+    """This round's committed counter record (profiles/r05_counters.json: rocprofv3 --pmc passes, tools/profile_r05.sh),
     quoted only when it was taken on the kernel sources this run executes (sha256 of the .hip / .hpp files)."""
     try:
         import hashlib
 
-        p = json.load(open(os.path.join(ROOT, "profiles", "r04_counters.json")))
+        p = json.load(open(os.path.join(ROOT, "profiles", "r05_counters.json")))
         h = hashlib.sha256()
         for f in sorted(p["kernel_sources"]):
             h.update(open(os.path.join(ROOT, "exoplanet_amd", "csrc", f), "rb").read())
@@ -1030,7 +1030,7 @@ def main():
             n_active = ops.transit_flux_sparse(t_dev, rec0.detach(), ld0.detach(), flags=flags0).n_solved()
     else:
         # GP configs: the step is a chain of ~20 kernels; the whole replayed step is timed with events on the stream it
-        # is replayed on (per-kernel averages and counters: profiles/r04_*)
+        # is replayed on (per-kernel averages and counters: profiles/r05_*)
         q = time_events(lambda: run(-1), dev, 20)
         drain()
         kernel_ms = q["median_ms"]
@@ -1120,20 +1120,33 @@ def main():
                 roof["valu"] = c.get("valu")
             out["roofline"] = roof
         else:
-            achieved = survey_bytes / (kernel_ms * 1e-3) / 1e9
+            # GP configs: `frac` is a BANDWIDTH fraction only when it is made of bytes that moved -- the
+            # counter record's HBM traffic of one step / this run's step time / 8 TB/s (null when no record matches these
+            # kernel sources) -- with the fp64-issue fractions of the kernels that bound the step beside it (`valu`); the
+            # SURVEY.md 8d count (state saved and re-read: these kernels checkpoint and recompute instead) is kept as labelled
+            # `survey_8d_*` fields, not as `frac`
             c = (counters or {}).get(cfg) if counters else None
+            if c and c.get("draws") != D:
+                c = None
+            traffic = c["traffic_bytes_per_step"] if c else None
+            step_s = kernel_ms * 1e-3
             out["roofline"] = {
-                "bound": "hbm", "kernel": "whole replayed step (celerite element / scan-tree / chunk kernels + two light-curve "
-                                          "sweeps + packing); per-kernel: profiles/r04_*",
-                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "frac_definition": f"SURVEY.md 8d count ({wl.survey_bytes_per_unit} B per (draw, cadence): the saved forward "
-                                   "state written and re-read) / median event time of one replayed step / 8 TB/s.  The J <= 6 "
-                                   "kernels keep CHECKPOINTS and recompute (DESIGN.md section 2), so they move far fewer bytes "
-                                   "than this count: see `traffic` and `valu` for what the counters say",
-                "traffic": c["traffic_bytes_per_step"] if c and c.get("draws") == D else None,
-                "traffic_source": c["source"] if c and c.get("draws") == D else None,
-                "valu": c.get("valu") if c and c.get("draws") == D else None,
-                "algorithmic_bytes_per_launch": survey_bytes, "kernel_ms": kernel_ms,
+                "bound": "hbm", "kernel": "whole replayed step (celerite element / scan-tree / chunk kernels + the light-curve "
+                                          "sweeps + packing); per-kernel: profiles/r05_*",
+                "achieved": traffic / step_s / 1e9 if traffic else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": traffic / step_s / 1e9 / HBM_PEAK_GBS if traffic else None,
+                "frac_definition": "HBM bytes of one step from the PMC counters (FETCH_SIZE x 2 on gfx950 + WRITE_SIZE, separate passes: "
+                                   "profiles/r05_counters.json, quoted only when taken on these kernel sources) / median event time of "
+                                   "one replayed step in THIS run / 8 TB/s.  The step is fp64-issue-bound, not bandwidth-bound: see `valu` "
+                                   "(SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x kernel time x 2.4 GHz) per kernel)",
+                "traffic": traffic, "traffic_source": c["source"] if c else None, "valu": c.get("valu") if c else None,
+                "kernel_ms": kernel_ms,
+                "survey_8d_bytes_per_unit": wl.survey_bytes_per_unit, "survey_8d_bytes_per_step": survey_bytes,
+                "survey_8d_GBps": survey_bytes / step_s / 1e9,
+                "survey_8d_note": "SURVEY.md 8d charges 48 + 16 (1 + J + J^2) B to every (draw, cadence) -- the forward state written "
+                                  "and re-read; the J <= 6 kernels keep CHECKPOINTS (10 B per (draw, cadence) at J = 2, 108 B at J = 6) "
+                                  "and recompute, and the light curve reaches them as runs + values: bytes NOT moved, so this figure "
+                                  "is not a fraction of anything",
             }
 
     # the extra legs are single-GPU diagnostics: under torch.distributed.run they would only add

@@ -1228,28 +1228,9 @@ __global__ __launch_bounds__(kWave) void celerite_tree_kernel(TreeOp op, double*
   tree_item_lane<J, ADJ, DOWN>(op, state, c, item - (int64_t)c * op.n_draw);
 }
 
-// A draw's WHOLE scan in one launch (exo_celerite_group.hpp): one block per draw walks the UP levels, seeds the top state,
-// walks the DOWN levels, a block barrier between levels.  Items of J >= 3 on groups of eight lanes (32 per block), items of
-// J <= 2 one lane each.  Blocks are dealt to the XCDs so that the 16 draws sharing a 128-B line of the [..][draw] arrays
-// run on ONE XCD (blockIdx.x % 8 is the XCD of a block): each line crosses the fabric once instead of up to 8 times.
-// The NARROW levels of a scan -- at most EXO_GP_FUSED_TOP positions per draw: one item's latency each, ~7 us, and a launch
-// gap -- can go in ONE launch, a block per draw with a block barrier between levels (celerite_scan_fused_kernel from level
-// f_lo up), the wide levels below keeping their own launches, coalesced over the draws.  Measured (round 4, hipGraph replay) and
-// OFF: C5 at 128 chains 1.90 against 1.91 ms, C3 3.88 against 3.82 (a block per draw: 1024 blocks of mostly idle lanes at J = 2) --
-// inside a graph the launches' gaps are already small, what a narrow level costs is its item's latency, and that stays.
-// (The whole scan in one launch, EXO_GP_FUSED_SCAN, is slower still: the wide levels' traffic, uncoalesced.)
-#ifndef EXO_GP_FUSED_TOP
-#define EXO_GP_FUSED_TOP 0
-#endif
-inline int scan_fused_from(const ChunkWs& ws) {
-  const int top = ws.tree_top();
-  int f = 0;
-  while (f < top && ws.tree_npos(f) > EXO_GP_FUSED_TOP) ++f;
-  return f;     // (== top: nothing is narrow enough)
-}
-#ifndef EXO_GP_FUSED_SCAN
-#define EXO_GP_FUSED_SCAN 0
-#endif
+// (A draw's scan in ONE launch -- a block per draw walking the levels with block barriers, all of them or the narrow top ones
+// only -- was built in round 4, measured slower inside a replayed graph (C3 3.88 against 3.82 ms, C5 1.90 against 1.91: what a
+// narrow level costs is its item's dependent latency, not its launch) and removed in round 5.)
 #ifndef EXO_GP_GROUP_TREES
 #define EXO_GP_GROUP_TREES 1
 #endif
@@ -1273,50 +1254,6 @@ __global__ __launch_bounds__(kScanBlock, EXO_GROUP_WAVES) void celerite_tree_gro
   g.live = g.r < J;
   const int c = (int)(unit / op.n_draw);
   tree_item_group<J, ADJ, DOWN>(op, state, c, unit - (int64_t)c * op.n_draw, g);
-}
-
-// f_lo: the levels below it (the wide ones) are launches of their own (celerite_tree_group_kernel: coalesced over draws);
-// this kernel walks UP from level f_lo, seeds the top, and comes back DOWN to level f_lo.
-template <int J, bool ADJ>
-__global__ __launch_bounds__(kScanBlock) void celerite_scan_fused_kernel(ChunkWs ws, double* state, const double* __restrict__ t,
-                                                                        Coefs cf, int64_t n_draw, int f_lo) {
-  constexpr bool kGroup = J >= 3;
-  __shared__ double lds[kGroup ? (kScanBlock / 8) * GroupLds<J>::S : 2];
-  const int per = (int)((n_draw + 7) / 8);
-  const int64_t draw = (int64_t)(blockIdx.x & 7) * per + (blockIdx.x >> 3);
-  if (draw >= n_draw) return;
-  const int tid = threadIdx.x;
-  Grp<J> g;
-  g.lds = lds + (kGroup ? (tid >> 3) * GroupLds<J>::S : 0);
-  g.r = tid & 7;
-  g.live = g.r < J;
-  const int unit = kGroup ? (tid >> 3) : tid, n_unit = kGroup ? kScanBlock / 8 : kScanBlock;
-  const int top = ws.tree_top();
-  // (the level's TreeOp is worked out here, in scalar registers: a table of them as a kernel argument, indexed by the
-  // level, is copied to 600 vector registers and scratch)
-  for (int f = f_lo; f + 1 < top; ++f) {
-    const TreeOp op = scan_level_op(ws, J, ADJ, f, false);
-    for (int c = unit; c < op.n_item; c += n_unit) {
-      if constexpr (kGroup) tree_item_group<J, ADJ, false>(op, state, c, draw, g);
-      else tree_item_lane<J, ADJ, false>(op, state, c, draw);
-    }
-    __syncthreads();
-  }
-  const int64_t seed = ws.tree_state(top);
-  if (ADJ) {
-    for (int k = tid; k < J + J * J; k += kScanBlock) state[seed + (int64_t)k * n_draw + draw] = 0.0;
-  } else if (tid == 0) {
-    scan_init_lane<J>(t, cf, n_draw, state + seed, draw);
-  }
-  __syncthreads();
-  for (int f = top - 1; f >= f_lo; --f) {
-    const TreeOp op = scan_level_op(ws, J, ADJ, f, true);
-    for (int c = unit; c < op.n_item; c += n_unit) {
-      if constexpr (kGroup) tree_item_group<J, ADJ, true>(op, state, c, draw, g);
-      else tree_item_lane<J, ADJ, true>(op, state, c, draw);
-    }
-    __syncthreads();
-  }
 }
 
 // the state the forward scan starts from: F = 0, P = Delta(t_0) (S_0 = 0)
@@ -2034,11 +1971,9 @@ static int celerite_fwd(const double* t, Series resid, const double* diag, int64
       hipLaunchKernelGGL(celerite_prep_flagged_kernel, dim3(8, (unsigned)n_draw), dim3(256), 0, st, t, n, cf, n_draw, J,
                          state, state + ws.off_flag());
       {
-        // (B) as a tree: compose up to one position, seed it with the initial state, apply back down -- the wide levels a launch
-        // each, the narrow ones (scan_fused_from) all in one
+        // (B) as a tree: compose up to one position, seed it with the initial state, apply back down -- a launch per level
         int rc = EXO_OK;
-        const dim3 sgrid((unsigned)(8 * ((n_draw + 7) / 8)));
-        tree_scan_split(ws, J, false, EXO_GP_FUSED_SCAN ? 0 : scan_fused_from(ws),
+        tree_scan(ws, J, false,
                   [&](const TreeOp& op, bool down) {
                     const dim3 tgrid((unsigned)(((int64_t)op.n_item * n_draw + kWave - 1) / kWave));
                     const dim3 ggrid((unsigned)(((int64_t)op.n_item * n_draw + kScanBlock / 8 - 1) / (kScanBlock / 8)));
@@ -2062,10 +1997,6 @@ static int celerite_fwd(const double* t, Series resid, const double* diag, int64
                   [&]() {
                     EXO_GP_DISPATCH_VOID(J, hipLaunchKernelGGL((celerite_scan_init_kernel<JJ>), grid, block, 0, st, t, cf, n_draw,
                                                                state + ws.tree_state(ws.tree_top())))
-                  },
-                  [&](int f_lo) {
-                    EXO_GP_DISPATCH_VOID(J, hipLaunchKernelGGL((celerite_scan_fused_kernel<JJ, false>), sgrid, dim3(kScanBlock), 0, st, ws,
-                                                               state, t, cf, n_draw, f_lo))
                   });
         if (rc != EXO_OK) return rc;
       }
@@ -2140,8 +2071,7 @@ static int celerite_vjp(const double* t, Series resid, const double* diag, int64
     {
       // (B') as a tree over positions p = C - 1 - chunk: adjoint elements of chunks C - 1 .. 1, zero initial adjoint
       bool ok = true;
-      const dim3 sgrid((unsigned)(8 * ((n_draw + 7) / 8)));
-      tree_scan_split(ws, J, true, EXO_GP_FUSED_SCAN ? 0 : scan_fused_from(ws),
+      tree_scan(ws, J, true,
                 [&](const TreeOp& op, bool down) {
                   const dim3 tgrid((unsigned)(((int64_t)op.n_item * n_draw + kWave - 1) / kWave));
                   const dim3 ggrid((unsigned)(((int64_t)op.n_item * n_draw + kScanBlock / 8 - 1) / (kScanBlock / 8)));
@@ -2159,10 +2089,6 @@ static int celerite_vjp(const double* t, Series resid, const double* diag, int64
                 },
                 [&]() {
                   ok = hipMemsetAsync(wstate + ws.tree_state(ws.tree_top()), 0, sizeof(double) * ws.B() * n_draw, st) == hipSuccess;
-                },
-                [&](int f_lo) {
-                  EXO_GP_DISPATCH_VOID(J, hipLaunchKernelGGL((celerite_scan_fused_kernel<JJ, true>), sgrid, dim3(kScanBlock), 0, st, ws,
-                                                             wstate, t, cf, n_draw, f_lo))
                 });
       if (!ok) return EXO_ERR_LAUNCH;
     }

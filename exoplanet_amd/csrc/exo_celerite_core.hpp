@@ -217,19 +217,14 @@ struct SegCursor {
   // comparison in the usual case).  Blocks come in the cursor's direction.
   EXO_HD bool enter(const SparseSegs& sp, int64_t draw, int64_t b64) {
     const int32_t b = (int32_t)b64;
-#ifdef EXO_SPARSE_FORCE   // (laboratory: what a block costs on either path -- 1: every block takes the slow path, 2: none does)
-    constexpr bool kForceSlow = EXO_SPARSE_FORCE == 1, kForceFast = EXO_SPARSE_FORCE == 2;
-#else
-    constexpr bool kForceSlow = false, kForceFast = false;
-#endif
     if (ASC) {
       if (k < 0) first(sp, draw, b);
       while (b >= hi) { ++k; fetch(sp, draw); }
-      return kForceSlow || (!kForceFast && b + 4 > lo);
+      return b + 4 > lo;
     }
     if (k == kFar) first(sp, draw, b + 3);
     while (b + 3 < lo) { --k; fetch(sp, draw); }
-    return kForceSlow || (!kForceFast && b < hi);
+    return b < hi;
   }
   // position of cadence n's value, or -1 -- after enter(), for the block's cadences in the cursor's direction (the loop only
   // turns when two segments share the block)
@@ -1656,19 +1651,12 @@ EXO_HDH TreeOp scan_level_op(const ChunkWs& ws, int J, bool adj, int f, bool dow
 
 // The levels of a scan: `launch(op, down)` is called once per level, in order (UP levels, then -- after `seed()`
 // has put the initial state at ws.tree_state(top) -- the DOWN levels).
-// f_lo < top: the levels from f_lo up -- the remaining UP levels, the seed, the DOWN levels back to f_lo -- are `fused(f_lo)`'s
-// (one launch on the device: celerite_scan_fused_kernel); f_lo >= top: every level its own launch.
-template <class Launch, class Seed, class Fused>
-EXO_HDH void tree_scan_split(const ChunkWs& ws, int J, bool adj, int f_lo, Launch&& launch, Seed&& seed, Fused&& fused) {
-  const int top = ws.tree_top();
-  for (int f = 0; f + 1 < top && f < f_lo; ++f) launch(scan_level_op(ws, J, adj, f, false), false);
-  if (f_lo < top) fused(f_lo); else seed();
-  for (int f = (f_lo < top ? f_lo : top) - 1; f >= 0; --f) launch(scan_level_op(ws, J, adj, f, true), true);
-}
 template <class Launch, class Seed>
-EXO_HDH void tree_scan(const ChunkWs& ws, const ChunkGeom& cg, int J, int64_t n_draw, bool adj, Launch&& launch, Seed&& seed) {
-  (void)cg; (void)n_draw;
-  tree_scan_split(ws, J, adj, ws.tree_top(), launch, seed, [](int) {});
+EXO_HDH void tree_scan(const ChunkWs& ws, int J, bool adj, Launch&& launch, Seed&& seed) {
+  const int top = ws.tree_top();
+  for (int f = 0; f + 1 < top; ++f) launch(scan_level_op(ws, J, adj, f, false), false);
+  seed();
+  for (int f = top - 1; f >= 0; --f) launch(scan_level_op(ws, J, adj, f, true), true);
 }
 
 // ---------------------------------------------------------------------------------------------

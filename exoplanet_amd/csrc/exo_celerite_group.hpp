@@ -12,10 +12,6 @@
 // barrier inside an item (LDS operations of one wave execute in order), and one composition costs ~50 LDS instructions
 // where the tile kernel spent 230.  The J x J solves are Gauss-Jordan with partial pivoting without moving rows: every
 // lane publishes its row, reads the pivot's and eliminates; the rows are brought into order once at the end.
-//
-// celerite_scan_fused_kernel: one BLOCK per draw walks all UP levels, seeds the top, walks all DOWN levels, a block
-// barrier between levels (the levels live in global memory, as before: a block's own stores are visible to it after
-// __syncthreads -- one CU, one L1).  34 launches become 2.
 #pragma once
 #include "exo_celerite_core.hpp"
 

@@ -528,11 +528,7 @@ __device__ __forceinline__ double eval_sample(double tt, const PlanetS& c, const
     tt -= ld_D;
   }
   const double M = (tt - c.tp) * c.n;
-#ifdef EXO_STUB_KEPLER   // (instruction-count builds: tools/transit_breakdown.sh; results are meaningless)
-  exo::KeplerHalf kh; kh.X = c.se * 0.6 + 1e-3 * M; kh.Y = c.pe * 0.01; kh.sh = 0.1; kh.ch = 0.9;
-#else
   const exo::KeplerHalf kh = exo::kepler_half(M, c.e, c.se, c.pe);
-#endif
   const double X2 = kh.X * kh.X, Y2 = kh.Y * kh.Y;
   const double cx = X2 - Y2;            // (1 - e cos E) cos f = cos E - e
   const double sx = 2.0 * kh.X * kh.Y;  // (1 - e cos E) sin f = sqrt(1-e^2) sin E
@@ -563,11 +559,7 @@ __device__ __forceinline__ double eval_sample(double tt, const PlanetS& c, const
   const double bq = occ ? b * c.iror : b;
   const double rq = occ ? c.iror : c.ror;
   exo::SV sv;
-#ifdef EXO_STUB_SV
-  sv.s0 = bq; sv.s1 = rq; sv.s2 = bq * rq; sv.db0 = sv.db1 = sv.db2 = bq; sv.dr0 = sv.dr1 = sv.dr2 = rq;
-#else
   exo::quad_sv<GRAD>(act ? bq : 2.0 + rq, rq, sv);
-#endif
   const double* cc = occ ? cld + 3 : cld;
   const double Fq = fma(sv.s0, cc[0], fma(sv.s1, cc[1], sv.s2 * cc[2])) - 1.0;
   double F;
@@ -2204,9 +2196,6 @@ __global__ __launch_bounds__(kBlock, LDELAY ? 2 : EXO_RUNS_MIN_WAVES) void trans
         const float g_lim = total > tin ? (float)m / (float)(total - tin) : 0.0f;
         struct Item { int i, v, q; double tv, g, w; };
         auto locate = [&](int j, int& i, int& v, int& qrun) {
-#ifdef EXO_STUB_LOCATE
-          { const Run r0 = s_run[0]; i = r0.lo + (j & 31); v = s_all[0] + (j & 31); qrun = 0; return; }
-#endif
           const bool in = j < tin;
           const int jj = in ? j : j - tin;
           int q = (int)((float)jj * (in ? g_in : g_lim));
@@ -2336,21 +2325,9 @@ __global__ __launch_bounds__(kBlock, LDELAY ? 2 : EXO_RUNS_MIN_WAVES) void trans
   if (GRAD && !JAC) reduce_columns(lds_acc, sh.red, kNG, 7, pout + n_planet * kNG);
   fc.issue(1 << 30);   // whatever is left of the fill (all of it for a block without work)
   if (fin.fold) {
-    // The last block of a draw to get here finishes the draw: partials -> gradients (in block order, whoever is
-    // last), values -> their cadences -- what transit_finish_kernel does otherwise, without its launch.  A draw that
-    // is one block's work needs no hand-shake; otherwise every thread publishes its stores (partials, values, zero
-    // fill, run sums), the block counts itself in, and the block that completes the count reads what the others left.
-    __shared__ int s_last;
-    if (hb > 1) {
-      __threadfence();
-      __syncthreads();
-      if (threadIdx.x == 0) s_last = (atomicAdd(fin.done + draw, 1) == hb - 1) ? 1 : 0;
-      __syncthreads();
-      if (!s_last) return;
-      __threadfence();
-    } else {
-      __syncthreads();
-    }
+    // the block owns its draw (hb = 1): partials -> gradients, values -> their cadences -- what transit_finish_kernel does
+    // otherwise, without its launch; a block barrier is all the hand-shake its own stores need
+    __syncthreads();
     finish_draw(draw, (GRAD && !JAC) ? partial : nullptr, hb, n_planet, SECONDARY, fin.gparams, fin.gld, fin.flux_dot, n_cad, flags, n_ev,
                 rl, vals, vcad, fill, nullptr, 0, nullptr,
                 (TTV && GRAD) ? ttv : Ttv{nullptr, nullptr, nullptr, 0});
@@ -2683,12 +2660,10 @@ inline ScanPlan scan_plan(uint32_t flags, int bpd, int64_t n_draw, int n_planet,
 // blocks are resident at once (two per CU), and every (planet, inside / limb) segment of a block ends in a partly
 // filled round: one generation of fuller blocks beats two generations of emptier ones (C4 at 64 draws: 11 round
 // times at 8 blocks per draw against 18 at 16).
-#ifndef EXO_RUNS_FOLD_FINISH
-// 1: draws that are one block's work are finished by that block; 0: never; 2: shared draws too, by the last block to
-// arrive (fence + counter) -- measured and NOT used: the device-scope release each block then needs writes the L2's
-// dirty zero-fill lines back before it returns (heavy kernel 54 -> 147 us at 128 draws, 102 -> 225 us on C4 at 64)
-#define EXO_RUNS_FOLD_FINISH 1
-#endif
+// A draw that is ONE block's work (hb = 1: batches of >= 512 draws) is finished by that block -- no transit_finish_kernel launch.
+// (Draws shared by several blocks finished by the last block to arrive -- fence + counter -- were measured in round 3 and
+// removed in round 5: the device-scope release each block then needs writes the L2's dirty zero-fill lines back before it
+// returns, heavy kernel 54 -> 147 us at 128 draws, 102 -> 225 us on C4 at 64.)
 #ifndef EXO_RUNS_TARGET_BLOCKS
 #define EXO_RUNS_TARGET_BLOCKS 512
 #endif
@@ -2786,7 +2761,7 @@ inline int launch_runs_sweep(const double* t, int64_t n_cad, const double* texp,
   const dim3 block(kBlock);
   const bool has_ttv = ttv && ttv->edges;
   // sorted times on the caller's word and no fence counters to clear: windows and runs in ONE launch
-  const bool fused_enum = (flags & EXO_FLAG_SORTED_TIMES) && !has_ttv && EXO_RUNS_FOLD_FINISH != 2;
+  const bool fused_enum = (flags & EXO_FLAG_SORTED_TIMES) && !has_ttv;
   if (reuse_runs) {
     // (nothing to launch)
   } else if (!fused_enum) {
@@ -2821,7 +2796,7 @@ inline int launch_runs_sweep(const double* t, int64_t n_cad, const double* texp,
   // no transit_finish_kernel launch
   // (not with a cadence-major flux: a draw's values land in lines other blocks zero-fill -- after the sweep, then)
   const bool cmaj = flags & EXO_FLAG_CADENCE_MAJOR;
-  const bool fold = !(cmaj && flux) && (EXO_RUNS_FOLD_FINISH == 2 || (EXO_RUNS_FOLD_FINISH == 1 && w.hb == 1));
+  const bool fold = !(cmaj && flux) && w.hb == 1;
   const FinishArgs fin{gparams, gld, chi2 ? chi2->chi2 : flux_dot, fold ? 1 : 0, w.done}, no_fin{nullptr, nullptr, nullptr, 0, nullptr};
 #define EXO_LAUNCH_RUNS(G, GFLUX, GSP, VALS, VCAD, FILL, PARTIAL, FIN)                                                    \
   if (secondary)                                                                                                          \
@@ -3303,7 +3278,7 @@ int exo_transit_flux_cols_vjp_f64(const double* const* cols, const int64_t* draw
   hipStream_t st = (hipStream_t)stream;
   // the launches fuse when the sweep is a run-enumeration sweep on sorted times (the caller's word: EXO_FLAG_SORTED_TIMES); anything
   // else is the three calls one after the other -- same results
-  const bool fused = n_cad > 0 && runs_path(false, n_texp, flags) && (flags & EXO_FLAG_SORTED_TIMES) && EXO_RUNS_FOLD_FINISH != 2;
+  const bool fused = n_cad > 0 && runs_path(false, n_texp, flags) && (flags & EXO_FLAG_SORTED_TIMES);
   if (!fused) {
     int rc = exo_pack_records_cols_f64(cols, draw_stride, planet_stride, defaults, ld_cols, ld_draw_stride, n_draw, n_planet,
                                        pack_flags, params, ld, stream);

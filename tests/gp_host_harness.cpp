@@ -265,7 +265,7 @@ void run_fwd(const double* t, gp::Series rs, const double* diag, int64_t n_diag,
         gp::elem_lane<J, decltype(nr)::value>(t, rs, diag, n_diag, n, cf, n_draw, state, cg, d, c);
       });
   if (cg.tree && !g_serial_scan && !g_robust) {   // the scans as trees of compositions, level by level, as the device launches them
-    gp::tree_scan(ws, cg, J, n_draw, false,
+    gp::tree_scan(ws, J, false,
                   [&](const gp::TreeOp& op, bool down) {
                     for (int c = 0; c < op.n_item; ++c)
                       for (int64_t d = 0; d < n_draw; ++d) {
@@ -385,7 +385,7 @@ void run_vjp(const double* t, gp::Series rs, const double* diag, int64_t n_diag,
       }
     }
   if (cg.tree && !g_serial_scan && (!g_robust || g_adj_tree)) {   // (the adjoint tree takes the robust draws' inputs as they are)
-    gp::tree_scan(ws, cg, J, n_draw, true,
+    gp::tree_scan(ws, J, true,
                   [&](const gp::TreeOp& op, bool down) {
                     for (int c = 0; c < op.n_item; ++c)
                       for (int64_t d = 0; d < n_draw; ++d) {

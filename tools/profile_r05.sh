@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-4 measurement record for profiles/ (run on the GPU box from the repository root: bash tools/profile_r04.sh):
+# Round-5 measurement record for profiles/ (run on the GPU box from the repository root: bash tools/profile_r05.sh):
 #   * rocprofv3 --kernel-trace --stats of the eager bench step of C2 (default), C3, C4 (64 draws), C5 (128 chains; c5b: 2 of
 #     them at a conditioning score of 1e6 -- the robust route of the GP):
 #     per-kernel average durations;
@@ -7,10 +7,10 @@
 #     FETCH_SIZE, WRITE_SIZE (HBM traffic; FETCH x 2 on gfx950, MI355X_MICROARCH.md) and SQ_INSTS_VALU + SQ_WAVES,
 #     SQ_ACTIVE_INST_VALU + SQ_BUSY_CYCLES + SQ_WAVE_CYCLES (the fp64-VALU view) for every kernel of those steps, and
 #     for the sparse / chi2 legs of the C2 sweep (tools/run_leg.py);
-#   -> gpurun_out/r04/*, summarised by tools/make_profile_r04.py into profiles/r04_counters.json,
-#      profiles/r04_bench_rocprof_summary.txt (which bench.py quotes when the kernel sources are unchanged).
+#   -> gpurun_out/r05/*, summarised by tools/make_profile_r05.py into profiles/r05_counters.json,
+#      profiles/r05_bench_rocprof_summary.txt (which bench.py quotes when the kernel sources are unchanged).
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-out=$R/gpurun_out/r04
+out=$R/gpurun_out/r05
 rm -rf $out; mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 B="--steps 10 --warmup 2 --no-cpu-baseline --no-extras --no-stats --no-graph"
@@ -32,10 +32,10 @@ for leg in c2 c3 c4 c5 c5b sparse chi2; do
   done
 done
 python $R/bench.py --steps 5 --no-extras --no-cpu-baseline --no-stats > $out/bench_pre.json 2> /dev/null
-python $R/tools/make_profile_r04.py $out $R/profiles
+python $R/tools/make_profile_r05.py $out $R/profiles
 # gpurun merges at most 64 MiB of gpurun_out back: keep the summaries (and the kernel-stats tables), drop the raw traces
-mkdir -p $out/profiles && cp $R/profiles/r04_* $out/profiles/
-for leg in c2 c3 c4 c5 c5b sparse chi2; do cp $(find $out/${leg}_trace -name "*kernel_stats.csv" | head -1) $out/profiles/r04_${leg}_kernel_stats.csv 2>/dev/null; done
+mkdir -p $out/profiles && cp $R/profiles/r05_* $out/profiles/
+for leg in c2 c3 c4 c5 c5b sparse chi2; do cp $(find $out/${leg}_trace -name "*kernel_stats.csv" | head -1) $out/profiles/r05_${leg}_kernel_stats.csv 2>/dev/null; done
 rm -rf $out/*_trace $out/*_pmc_*
 # the un-profiled bench line last, with this record's counters in place (roofline.traffic / .valu filled in from it)
 python $R/bench.py > $out/bench.json 2> $out/bench.err
