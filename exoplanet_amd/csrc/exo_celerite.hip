@@ -2088,7 +2088,7 @@ static int celerite_vjp(const double* t, Series resid, const double* diag, int64
                   }
                 },
                 [&]() {
-                  ok = hipMemsetAsync(wstate + ws.tree_state(ws.tree_top()), 0, sizeof(double) * ws.B() * n_draw, st) == hipSuccess;
+                  ok = exo::zero_fill_async(wstate + ws.tree_state(ws.tree_top()), (int64_t)ws.B() * n_draw, st);   // (never a memset node: exo_math.hpp)
                 });
       if (!ok) return EXO_ERR_LAUNCH;
     }

@@ -551,4 +551,22 @@ EXO_HD void quad_sv(double b, double r, SV& o) {
   }
 }
 
+
+// Zeros before an accumulation / a scan's seed: a KERNEL, never hipMemsetAsync.  Inside a captured step a memset becomes a
+// memset node of the hipGraph, and on ROCm 7.2 (gfx950) the kernel node after it can start before the fill has landed:
+// round 5, the adjoint scan of the celerite reverse pass read the FORWARD scan's seed at the same address in every other
+// word, once in a few thousand replays (tests/test_gpu_inject_recover.py: a sampler's odd chains collapsed).  A kernel node
+// is ordered like every other launch of the stream.
+#ifndef EXO_HOST_BUILD
+static __global__ __launch_bounds__(256) void zero_fill_kernel(double* __restrict__ p, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) p[i] = 0.0;
+}
+inline bool zero_fill_async(double* p, int64_t n, hipStream_t st) {
+  if (n <= 0) return true;
+  hipLaunchKernelGGL(zero_fill_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p, n);
+  return hipGetLastError() == hipSuccess;
+}
+#endif
+
 }  // namespace exo

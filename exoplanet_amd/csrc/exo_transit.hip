@@ -3086,13 +3086,13 @@ static int transit_vjp(const double* t, int64_t n_cad, const double* texp, int64
   const bool secondary = flags & EXO_FLAG_SECONDARY;
   hipStream_t st = (hipStream_t)stream;
   // the bins are accumulated into: start from zero
-  if (has_ttv && hipMemsetAsync(ttv.gshift, 0, sizeof(double) * n_draw * n_planet * (ttv.n_edge + 1), st) != hipSuccess)
+  if (has_ttv && !exo::zero_fill_async(ttv.gshift, (int64_t)(n_draw * n_planet * (ttv.n_edge + 1)), st))
     return EXO_ERR_LAUNCH;
   if (n_cad == 0) {
-    if (hipMemsetAsync(gparams, 0, sizeof(double) * n_draw * n_planet * EXO_NPAR, st) != hipSuccess)
+    if (!exo::zero_fill_async(gparams, (int64_t)(n_draw * n_planet * EXO_NPAR), st))
       return EXO_ERR_LAUNCH;
-    if (flux_dot && hipMemsetAsync(flux_dot, 0, sizeof(double) * n_draw, st) != hipSuccess) return EXO_ERR_LAUNCH;
-    return hipMemsetAsync(gld, 0, sizeof(double) * n_draw * (secondary ? 6 : 3), st) == hipSuccess
+    if (flux_dot && !exo::zero_fill_async(flux_dot, (int64_t)(n_draw), st)) return EXO_ERR_LAUNCH;
+    return exo::zero_fill_async(gld, (int64_t)(n_draw * (secondary ? 6 : 3)), st)
                ? EXO_OK : EXO_ERR_LAUNCH;
   }
   if (n_planet * kNG + 7 > kBlock) return EXO_ERR_INVALID_ARGUMENT;
@@ -3243,9 +3243,9 @@ int exo_transit_flux_jac_vjp_f64(const double* gflux, int64_t n_cad, int64_t n_d
   hipStream_t st = (hipStream_t)stream;
   const bool secondary = flags & EXO_FLAG_SECONDARY;
   if (n_cad == 0) {
-    if (hipMemsetAsync(gparams, 0, sizeof(double) * n_draw * n_planet * EXO_NPAR, st) != hipSuccess) return EXO_ERR_LAUNCH;
-    if (flux_dot && hipMemsetAsync(flux_dot, 0, sizeof(double) * n_draw, st) != hipSuccess) return EXO_ERR_LAUNCH;
-    return hipMemsetAsync(gld, 0, sizeof(double) * n_draw * (secondary ? 6 : 3), st) == hipSuccess ? EXO_OK : EXO_ERR_LAUNCH;
+    if (!exo::zero_fill_async(gparams, (int64_t)(n_draw * n_planet * EXO_NPAR), st)) return EXO_ERR_LAUNCH;
+    if (flux_dot && !exo::zero_fill_async(flux_dot, (int64_t)(n_draw), st)) return EXO_ERR_LAUNCH;
+    return exo::zero_fill_async(gld, (int64_t)(n_draw * (secondary ? 6 : 3)), st) ? EXO_OK : EXO_ERR_LAUNCH;
   }
   const RunWs rw = carve_runs(workspace, n_cad, n_draw, n_planet);   // the workspace of the forward call: runs, values, cadence index
   if (!workspace || workspace_bytes < rw.bytes) return EXO_ERR_WORKSPACE;
@@ -3327,9 +3327,9 @@ int exo_transit_flux_vjp_sparse_f64(const double* t, int64_t n_cad, const double
   if (n_planet * kNG + 7 > kBlock) return EXO_ERR_INVALID_ARGUMENT;
   hipStream_t st = (hipStream_t)stream;
   if (n_cad == 0) {
-    if (hipMemsetAsync(gparams, 0, sizeof(double) * n_draw * n_planet * EXO_NPAR, st) != hipSuccess) return EXO_ERR_LAUNCH;
-    if (flux_dot && hipMemsetAsync(flux_dot, 0, sizeof(double) * n_draw, st) != hipSuccess) return EXO_ERR_LAUNCH;
-    return hipMemsetAsync(gld, 0, sizeof(double) * n_draw * ((flags & EXO_FLAG_SECONDARY) ? 6 : 3), st) == hipSuccess ? EXO_OK : EXO_ERR_LAUNCH;
+    if (!exo::zero_fill_async(gparams, (int64_t)(n_draw * n_planet * EXO_NPAR), st)) return EXO_ERR_LAUNCH;
+    if (flux_dot && !exo::zero_fill_async(flux_dot, (int64_t)(n_draw), st)) return EXO_ERR_LAUNCH;
+    return exo::zero_fill_async(gld, (int64_t)(n_draw * ((flags & EXO_FLAG_SECONDARY) ? 6 : 3)), st) ? EXO_OK : EXO_ERR_LAUNCH;
   }
   const RunWs rw = carve_runs(workspace, n_cad, n_draw, n_planet);
   if (!workspace || workspace_bytes < rw.bytes) return EXO_ERR_WORKSPACE;
@@ -3397,7 +3397,7 @@ int exo_transit_chi2_ttv_vjp_f64(const double* t, int64_t n_cad, const double* t
   const RunWs rw = carve_runs(workspace, n_cad, n_draw, n_planet);
   if (!workspace || workspace_bytes < rw.bytes) return EXO_ERR_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
-  if (hipMemsetAsync(gshift, 0, sizeof(double) * n_draw * n_planet * (n_edge + 1), st) != hipSuccess) return EXO_ERR_LAUNCH;
+  if (!exo::zero_fill_async(gshift, (int64_t)(n_draw * n_planet * (n_edge + 1)), st)) return EXO_ERR_LAUNCH;
   const Chi2Args c2{obs, ivar, n_ivar, chi2};
   const Ttv ttv{ttv_edges, ttv_shift, gshift, n_edge};
   return launch_runs_sweep(t, n_cad, texp, n_texp, stencil_dt, stencil_w, n_sub, params, ld, n_draw, n_planet, flags, nullptr,

@@ -24,6 +24,17 @@ def default_chunks():
     return n
 
 
+_POISON = [None]    # tests: fill every buffer handed to the library with this value first (nothing may depend on what
+                    # a workspace or an output held before the call -- under hipGraph replay that is the previous step's)
+
+
+def _buffer(*shape, device):
+    x = torch.empty(*shape, dtype=torch.float64, device=device)
+    if _POISON[0] is not None:
+        x.fill_(_POISON[0])
+    return x
+
+
 class _CeleriteLogLike(torch.autograd.Function):
     @staticmethod
     def forward(ctx, t, resid, diag, coef_real, coef_complex, obs, pair_kind, n_chunks):
@@ -56,13 +67,13 @@ class _CeleriteLogLike(torch.autograd.Function):
         n_chunks = int(n_chunks)
         lib = _lib.load()
         need_grad = any(ctx.needs_input_grad)
-        loglike = torch.empty(D, dtype=torch.float64, device=t.device)
+        loglike = _buffer(D, device=t.device)
         # The state buffer is what the reverse pass re-reads, and it is also what lets the library run
         # the recurrences in parallel over time: a value-only call gets one too (scratch, freed on
         # return) unless the device cannot spare it, in which case the sequential kernels run.
         nstate = lib.exo_celerite_state_doubles(N, D, n_real, n_complex, n_chunks)
         try:
-            state = torch.empty(nstate, dtype=torch.float64, device=t.device)
+            state = _buffer(nstate, device=t.device)
         except torch.cuda.OutOfMemoryError:
             if need_grad:
                 raise
@@ -98,14 +109,14 @@ class _CeleriteLogLike(torch.autograd.Function):
         gll = _dev(gll, "gloglike")
         lib = _lib.load()
         if ctx.cm:     # the cotangent of a cadence-major model in the model's layout
-            gresid = torch.empty(N, D, dtype=torch.float64, device=t.device).t()
+            gresid = _buffer(N, D, device=t.device).t()
         else:
-            gresid = torch.empty(D, N, dtype=torch.float64, device=t.device)
+            gresid = _buffer(D, N, device=t.device)
         want_diag = ctx.needs_input_grad[2]
         shared_diag = diag.shape[0] == 1
-        gdiag = torch.empty(D, N, dtype=torch.float64, device=t.device) if want_diag else None
-        gcr = torch.empty_like(coef_real)
-        gcc = torch.empty_like(coef_complex)
+        gdiag = _buffer(D, N, device=t.device) if want_diag else None
+        gcr = _buffer(*coef_real.shape, device=t.device)
+        gcc = _buffer(*coef_complex.shape, device=t.device)
         with torch.cuda.device(t.device):
             tail = (_ptr(diag), diag.shape[0], N, _ptr(coef_real), n_real, _ptr(coef_complex), n_complex, _ptr(pair_kind),
                     D, _ptr(gll), _ptr(state), nstate, n_chunks, _ptr(gresid), _ptr(gdiag), None, _ptr(gcr), _ptr(gcc),
@@ -172,10 +183,10 @@ class _CeleriteLogLikeSparse(torch.autograd.Function):
         if n_chunks == 0:     # the plan the sparse entries do best with (twice the dense plan's chunks for J <= 2: include/exoplanet_amd.h)
             n_chunks = int(lib.exo_celerite_default_chunks(N, D, n_real, n_complex, 1))
         need_grad = any(ctx.needs_input_grad)
-        loglike = torch.empty(D, dtype=torch.float64, device=t.device)
+        loglike = _buffer(D, device=t.device)
         nstate = lib.exo_celerite_state_doubles(N, D, n_real, n_complex, n_chunks)
         try:
-            state = torch.empty(nstate, dtype=torch.float64, device=t.device)
+            state = _buffer(nstate, device=t.device)
         except torch.cuda.OutOfMemoryError:
             if need_grad:
                 raise
@@ -220,8 +231,8 @@ class _CeleriteLogLikeSparse(torch.autograd.Function):
         # (positions no segment covers are never written and never read: the reverse sweep of the light curve walks the same runs)
         gvals = torch.empty_like(vals)
         want_diag = ctx.needs_input_grad[2]
-        gdiag = torch.empty(D, N, dtype=torch.float64, device=t.device) if want_diag else None
-        gcr, gcc = torch.empty_like(coef_real), torch.empty_like(coef_complex)
+        gdiag = _buffer(D, N, device=t.device) if want_diag else None
+        gcr, gcc = _buffer(*coef_real.shape, device=t.device), _buffer(*coef_complex.shape, device=t.device)
         model = ctx.sp.model_struct()
         model.row_of_draw = _ptr(perm)
         with torch.cuda.device(t.device):

@@ -159,3 +159,16 @@ def test_round_two_entry_points_reject_bad_arguments(lib):
     assert lib.exo_nuts_f64(full, 0, 3, 2, 1000.0, 0, None) == 0                                           # no chains
     gap = (ctypes.c_void_p * 40)(*([8] * 39 + [None]))
     assert lib.exo_nuts_f64(gap, 4, 3, 2, 1000.0, 1, None) == INVALID
+
+
+def test_no_memset_or_copy_nodes_in_the_library():
+    """Every entry point may be captured into a hipGraph (exoplanet_amd/graph.py).  hipMemsetAsync / hipMemcpyAsync would
+    become memset / copy nodes there, and on ROCm 7.2 the kernel node after a memset node can start before the fill has landed
+    (round 5: exo_math.hpp, zero_fill_async).  Zeros come from a kernel; nothing in csrc/ enqueues anything but kernels."""
+    import glob
+
+    csrc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "exoplanet_amd", "csrc")
+    for path in glob.glob(os.path.join(csrc, "*.h*")):
+        code = "\n".join(line.split("//")[0] for line in open(path).read().splitlines())
+        for call in ("hipMemsetAsync", "hipMemcpyAsync", "hipMemset(", "hipMemcpy("):
+            assert call not in code, f"{os.path.basename(path)} calls {call}"
