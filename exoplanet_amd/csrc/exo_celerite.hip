@@ -1231,6 +1231,10 @@ __global__ __launch_bounds__(kWave) void celerite_tree_kernel(TreeOp op, double*
 // (A draw's scan in ONE launch -- a block per draw walking the levels with block barriers, all of them or the narrow top ones
 // only -- was built in round 4, measured slower inside a replayed graph (C3 3.88 against 3.82 ms, C5 1.90 against 1.91: what a
 // narrow level costs is its item's dependent latency, not its launch) and removed in round 5.)
+// (Round 5, also measured and not kept: the narrow top as a SERIAL chain -- from the level with <= 128 positions up, one lane per
+// draw applying that level's elements one after the other to the seed, elements prefetched four ahead, no compositions above
+// it: a step costs ~0.5 us -- the 2 x 2 solve's divisions and a load latency the prefetch only partly hides -- so 128 positions
+// are no cheaper than the 14 launches they replace: C3 3.63 ms against 3.57 (64 positions: 3.59, 256: 3.74).)
 #ifndef EXO_GP_GROUP_TREES
 #define EXO_GP_GROUP_TREES 1
 #endif
@@ -1324,10 +1328,28 @@ __device__ __forceinline__ int chunk_of_block(const double* __restrict__ state, 
 // One block: a chunk is LONG if a segment of one of a few sample draws (spread over the batch: with the draws sorted by
 // transit time -- exo_sparse_model.row_of_draw -- the first, the last and those between span the transit times of all) reaches
 // into it, widened by a block either side; long chunks first, each class in order of time (a stable partition).
-constexpr int kOrderSamples = 8;
+constexpr int kOrderSamples = 8, kOrderSegs = 512;
 __global__ __launch_bounds__(256) void celerite_sparse_order_kernel(SparseSegs sp, int64_t n, int64_t n_draw, ChunkGeom cg,
                                                                     int32_t* __restrict__ order) {
   __shared__ int s_long[1024 + 1];
+  // the sample draws' segments, staged once: the searches below are dependent loads -- from global memory 8 x ~6 of them per
+  // chunk made this kernel 43 us of the C3 step; from LDS ~8 (a draw with more than kOrderSegs segments is searched in place)
+  __shared__ int s_lo[kOrderSamples][kOrderSegs], s_hi[kOrderSamples][kOrderSegs], s_n[kOrderSamples];
+  {   // (32 threads per sample draw: the eight chains row -> count -> segments run side by side)
+    static_assert(kOrderSamples * 32 == 256, "a group of 32 threads per sample");
+    const int q = threadIdx.x >> 5, l = threadIdx.x & 31;
+    const int64_t d = n_draw <= kOrderSamples ? (q < n_draw ? q : n_draw - 1) : (n_draw - 1) * q / (kOrderSamples - 1);
+    const int64_t row = sp.row(d);
+    const int32_t* sg = sp.seg + row * sp.seg_row;
+    const int ns = sp.nseg[row];
+    if (l == 0) s_n[q] = ns;
+    if (ns <= kOrderSegs)
+      for (int i = l; i < ns; i += 32) {
+        s_lo[q][i] = sg[(int64_t)i * sp.seg_step];
+        s_hi[q][i] = sg[(int64_t)i * sp.seg_step + sp.hi_at];
+      }
+  }
+  __syncthreads();
   const int C = cg.C;
   for (int c0 = 0; c0 < C; c0 += 1024) {     // (plans hold at most 1024 chunks; written for any number)
     const int m = C - c0 < 1024 ? C - c0 : 1024;
@@ -1336,26 +1358,49 @@ __global__ __launch_bounds__(256) void celerite_sparse_order_kernel(SparseSegs s
       const int64_t lo = (int64_t)c * cg.L - kCkptB, hi = ((int64_t)(c + 1) * cg.L < n ? (int64_t)(c + 1) * cg.L : n) + kCkptB;
       bool lng = false;
       for (int q = 0; q < kOrderSamples && !lng; ++q) {
-        const int64_t d = n_draw <= kOrderSamples ? (q < n_draw ? q : n_draw - 1) : (n_draw - 1) * q / (kOrderSamples - 1);
-        const int64_t row = sp.row(d);
-        const int32_t* sg = sp.seg + row * sp.seg_row;
-        int a = 0, b = sp.nseg[row];            // the first segment that ends beyond lo
-        while (a < b) {
-          const int mid = (a + b) >> 1;
-          if (sg[(int64_t)mid * sp.seg_step + sp.hi_at] <= lo) a = mid + 1; else b = mid;
+        const int ns = s_n[q];
+        int a = 0, b = ns;                      // the first segment that ends beyond lo
+        if (ns <= kOrderSegs) {
+          while (a < b) {
+            const int mid = (a + b) >> 1;
+            if (s_hi[q][mid] <= lo) a = mid + 1; else b = mid;
+          }
+          lng = a < ns && s_lo[q][a] < hi;
+        } else {
+          const int64_t d = n_draw <= kOrderSamples ? (q < n_draw ? q : n_draw - 1) : (n_draw - 1) * q / (kOrderSamples - 1);
+          const int32_t* sg = sp.seg + sp.row(d) * sp.seg_row;
+          while (a < b) {
+            const int mid = (a + b) >> 1;
+            if (sg[(int64_t)mid * sp.seg_step + sp.hi_at] <= lo) a = mid + 1; else b = mid;
+          }
+          lng = a < ns && sg[(int64_t)a * sp.seg_step] < hi;
         }
-        lng = a < sp.nseg[row] && sg[(int64_t)a * sp.seg_step] < hi;
       }
       s_long[i] = lng ? 1 : 0;
     }
     __syncthreads();
-    if (threadIdx.x == 0) {                      // (a serial pass over <= 1024 flags in LDS: ~2 us, once per call)
-      int n_long = 0;
-      for (int i = 0; i < m; ++i) n_long += s_long[i];
-      int at_long = c0, at_short = c0 + n_long;
-      for (int i = 0; i < m; ++i) {
-        if (s_long[i]) order[at_long++] = c0 + i; else order[at_short++] = c0 + i;
+    {   // stable partition, long chunks first: every thread four consecutive flags, an exclusive scan of the counts over the block
+      __shared__ int s_cnt[256];
+      const int i0 = threadIdx.x * 4;
+      int mine = 0;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) mine += (i0 + u < m) ? s_long[i0 + u] : 0;
+      s_cnt[threadIdx.x] = mine;
+      __syncthreads();
+      for (int off = 1; off < 256; off <<= 1) {
+        const int add = threadIdx.x >= off ? s_cnt[threadIdx.x - off] : 0;
+        __syncthreads();
+        s_cnt[threadIdx.x] += add;
+        __syncthreads();
       }
+      const int n_long = s_cnt[255];
+      int at_long = c0 + s_cnt[threadIdx.x] - mine;            // long chunks before this thread's
+      int at_short = c0 + n_long + (i0 < m ? i0 : m) - (s_cnt[threadIdx.x] - mine);
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (i0 + u < m) {
+          if (s_long[i0 + u]) order[at_long++] = c0 + i0 + u; else order[at_short++] = c0 + i0 + u;
+        }
     }
     __syncthreads();
   }
@@ -1575,38 +1620,53 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 
-// per-draw sum of the chunk partials: one wave per draw, lane l takes chunks l, l + 64, ... in order
-__global__ __launch_bounds__(kWave) void celerite_chunk_loglike_kernel(int64_t n, int64_t n_draw, int J,
-                                                                       const double* __restrict__ state, ChunkGeom cg,
-                                                                       double* __restrict__ loglike) {
-  const int64_t draw = blockIdx.x;
-  const ChunkWs ws = chunk_ws(n, n_draw, J, cg);
-  double acc = 0.0, logdet = 0.0, bad = 0.0;
-  for (int c = threadIdx.x; c < cg.C; c += kWave) {
-    acc += state[ws.part(c, 0, draw)];
-    logdet += state[ws.part(c, 1, draw)];
-    bad += state[ws.part(c, 2, draw)];
+// Sums over the chunks of [chunk][quantity][draw] arrays (the log-likelihood's partials, the coefficient cotangents'), the DRAWS
+// ACROSS THE LANES: a row of 64 draws is 512 contiguous bytes.  (Rounds 2-4: a wave per (draw, quantity) with the chunks across its
+// lanes -- every lane its own 64-B sector, 8 useful bytes of it: 52 + 20 us of the C3 step at a tenth of the bandwidth.)  Slice
+// blockIdx.z of S adds the rows of chunks s, s + S, s + 2 S ... in order and leaves its partial sum in the slot of chunk s -- the
+// first row it read; nobody else touches that row -- and the reader adds the S partials in order (slice_total).  S grows until
+// the launch has ~2048 waves (chunk_sum_slices): a pure function of the plan, so a draw's sums do not depend on its neighbours.
+__global__ __launch_bounds__(kWave) void celerite_chunk_slice_sum_kernel(double* __restrict__ arr, int K, int C, int S,
+                                                                         int64_t n_draw) {
+  const int64_t draw = (int64_t)blockIdx.x * kWave + threadIdx.x;
+  if (draw >= n_draw) return;
+  const int k = blockIdx.y, s0 = blockIdx.z;
+  const int64_t step = (int64_t)S * K * n_draw;
+  double* __restrict__ p = arr + ((int64_t)s0 * K + k) * n_draw + draw;
+  const double* __restrict__ q = p;
+  double v = 0.0;
+  int c = s0;
+  for (; c + 7 * S < C; c += 8 * S) {     // eight loads in flight, added in order
+    double x[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) x[u] = q[(int64_t)u * step];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v += x[u];
+    q += 8 * step;
   }
-  acc = wave_sum(acc); logdet = wave_sum(logdet); bad = wave_sum(bad);
-  if (threadIdx.x == 0) loglike[draw] = (bad > 0.0) ? -INFINITY : fma(-0.5, acc + logdet, -(double)n * kHalfLog2Pi);
+  for (; c < C; c += S) { v += *q; q += step; }
+  *p = v;
 }
 
-// coefficient cotangents, step 1: sum the chunk partials of quantity blockIdx.y of draw blockIdx.x
-// over the chunks (one wave each, fixed order), total left in chunk 0's slot
-__global__ __launch_bounds__(kWave) void celerite_chunk_gsum_kernel(int64_t n, int64_t n_draw, int J,
-                                                                    double* __restrict__ state, ChunkGeom cg) {
-  const int64_t draw = blockIdx.x;
-  const int kk = blockIdx.y;
+// the log-likelihood of a draw from the slices' partial sums
+__global__ __launch_bounds__(kWave) void celerite_chunk_loglike_kernel(int64_t n, int64_t n_draw, int J,
+                                                                       const double* __restrict__ state, ChunkGeom cg, int S,
+                                                                       double* __restrict__ loglike) {
+  const int64_t draw = (int64_t)blockIdx.x * kWave + threadIdx.x;
+  if (draw >= n_draw) return;
   const ChunkWs ws = chunk_ws(n, n_draw, J, cg);
-  double v = 0.0;
-  for (int c = threadIdx.x; c < cg.C; c += kWave) v += state[ws.gpart(c, kk, draw)];
-  v = wave_sum(v);
-  if (threadIdx.x == 0) state[ws.gpart(0, kk, draw)] = v;
+  double acc = 0.0, logdet = 0.0, bad = 0.0;
+  for (int s = 0; s < S; ++s) {
+    acc += state[ws.part(s, 0, draw)];
+    logdet += state[ws.part(s, 1, draw)];
+    bad += state[ws.part(s, 2, draw)];
+  }
+  loglike[draw] = (bad > 0.0) ? -INFINITY : fma(-0.5, acc + logdet, -(double)n * kHalfLog2Pi);
 }
 
 // step 2: the same combination as the tail of celerite_vjp_kernel
 __global__ __launch_bounds__(kWave) void celerite_chunk_gcoef_kernel(int64_t n, int64_t n_draw, Coefs cf,
-                                                                     const double* __restrict__ state, ChunkGeom cg,
+                                                                     const double* __restrict__ state, ChunkGeom cg, int S,
                                                                      double* __restrict__ gdiag_sum,
                                                                      double* __restrict__ gcoef_real,
                                                                      double* __restrict__ gcoef_complex) {
@@ -1614,7 +1674,7 @@ __global__ __launch_bounds__(kWave) void celerite_chunk_gcoef_kernel(int64_t n, 
   const int64_t e = (int64_t)blockIdx.x * kWave + threadIdx.x;
   if (e >= n_draw * J) return;
   const int64_t draw = e / J;
-  gcoef_lane(cf, n, n_draw, state, cg, gdiag_sum, gcoef_real, gcoef_complex, draw, (int)(e - draw * J));
+  gcoef_lane(cf, n, n_draw, state, cg, S, gdiag_sum, gcoef_real, gcoef_complex, draw, (int)(e - draw * J));
 }
 
 // O(N) companions (exo_celerite_core.hpp): one lane per draw
@@ -2024,8 +2084,12 @@ static int celerite_fwd(const double* t, Series resid, const double* diag, int64
         EXO_GP_DISPATCH(J, hipLaunchKernelGGL((celerite_chunk_fwd_kernel<JJ>), cgrid, block, 0, st, t, resid, diag, n_diag,
                                               n, cf, n_draw, state, cg))
       }
-      hipLaunchKernelGGL(celerite_chunk_loglike_kernel, dim3((unsigned)n_draw), block, 0, st, n, n_draw, J, state, cg,
-                         loglike);
+      {
+        const int S = chunk_sum_slices(cg.C, 3, n_draw, 16);   // (the last kernel's lanes add the S partials themselves)
+        hipLaunchKernelGGL(celerite_chunk_slice_sum_kernel, dim3(per_draw.x, 3, (unsigned)S), block, 0, st, state + ws.off_part(), 3,
+                           cg.C, S, n_draw);
+        hipLaunchKernelGGL(celerite_chunk_loglike_kernel, per_draw, block, 0, st, n, n_draw, J, state, cg, S, loglike);
+      }
       if (launch_status() != EXO_OK) return EXO_ERR_LAUNCH;
       only_flagged = state + ws.off_flag();
     }
@@ -2107,10 +2171,18 @@ static int celerite_vjp(const double* t, Series resid, const double* diag, int64
       EXO_GP_DISPATCH(J, hipLaunchKernelGGL((celerite_chunk_vjp_kernel<JJ>), cgrid, block, 0, st, t, n, cf, n_draw,
                                             gloglike, wstate, cg, gresid, gdiag, gsign, resid))
     }
-    hipLaunchKernelGGL(celerite_chunk_gsum_kernel, dim3((unsigned)n_draw, (unsigned)(4 * J + 1)), block, 0, st, n, n_draw,
-                       J, wstate, cg);
-    hipLaunchKernelGGL(celerite_chunk_gcoef_kernel, dim3((unsigned)((n_draw * J + kWave - 1) / kWave)), block, 0, st, n,
-                       n_draw, cf, state, cg, gdiag_sum, gcoef_real, gcoef_complex);
+    {
+      const int K = 4 * J + 1, S = chunk_sum_slices(cg.C, K, n_draw);
+      hipLaunchKernelGGL(celerite_chunk_slice_sum_kernel, dim3(per_draw.x, (unsigned)K, (unsigned)S), block, 0, st,
+                         wstate + ws.off_gpart(), K, cg.C, S, n_draw);
+      // (the S partial sums of the 4 J + 1 quantities once more, into chunk 0's slots: a lane of the last kernel would read
+      // S rows per quantity one after the other -- 41 at the C5 shape)
+      if (S > 1)
+        hipLaunchKernelGGL(celerite_chunk_slice_sum_kernel, dim3(per_draw.x, (unsigned)K, 1), block, 0, st, wstate + ws.off_gpart(), K,
+                           S, 1, n_draw);
+      hipLaunchKernelGGL(celerite_chunk_gcoef_kernel, dim3((unsigned)((n_draw * J + kWave - 1) / kWave)), block, 0, st, n,
+                         n_draw, cf, state, cg, 1, gdiag_sum, gcoef_real, gcoef_complex);
+    }
     if (launch_status() != EXO_OK) return EXO_ERR_LAUNCH;
     only_flagged = state + ws.off_flag();
   }

@@ -2893,17 +2893,33 @@ EXO_HD void predict_lane(const double* EXO_RESTRICT t, int64_t n, const double* 
   }
 }
 
-// coefficient cotangents of one (draw, state index) from the totals over the chunks (left in chunk
-// 0's slots): the same combination as the tail of celerite_vjp_kernel
-EXO_HD void gcoef_lane(const Coefs& cf, int64_t n, int64_t n_draw, const double* EXO_RESTRICT state, const ChunkGeom& cg,
+// how many slices the sums over the chunks are cut into (celerite_chunk_slice_sum_kernel: K quantities, rows of 64 draws): until
+// the launch has ~2048 waves, at most `cap` -- a reader adds that many partials per quantity, one after the other -- and no more
+// than chunks
+EXO_HDH int chunk_sum_slices(int C, int K, int64_t n_draw, int cap = 64) {
+  const int64_t waves = ((n_draw + 63) / 64) * K;
+  int64_t S = (2048 + waves - 1) / waves;
+  if (S > cap) S = cap;
+  if (S > C) S = C;
+  return (int)(S < 1 ? 1 : S);
+}
+
+// coefficient cotangents of one (draw, state index) from the sums over the chunks -- S partial sums per quantity, in the slots of
+// chunks 0 .. S - 1 (S = 1: the totals in chunk 0's slots): the same combination as the tail of celerite_vjp_kernel
+EXO_HD void gcoef_lane(const Coefs& cf, int64_t n, int64_t n_draw, const double* EXO_RESTRICT state, const ChunkGeom& cg, int S,
                        double* EXO_RESTRICT gdiag_sum, double* EXO_RESTRICT gcoef_real, double* EXO_RESTRICT gcoef_complex,
                        int64_t draw, int j) {
   const int J = cf.J();
   const ChunkWs ws = chunk_ws(n, n_draw, J, cg);
   const LaneCoef k = lane_coef(cf, draw, j, J);
-  const double gasum = state[ws.gpart(0, 4 * J, draw)];
+  auto total = [&](int kk) {
+    double v = 0.0;
+    for (int s = 0; s < S; ++s) v += state[ws.gpart(s, kk, draw)];
+    return v;
+  };
+  const double gasum = total(4 * J);
   if (j == 0 && gdiag_sum) gdiag_sum[draw] = gasum;
-  const double ga = state[ws.gpart(0, 4 * j, draw)], gc = state[ws.gpart(0, 4 * j + 2, draw)];
+  const double ga = total(4 * j), gc = total(4 * j + 2);
   if (k.real) {
     double* o = k.slot < 0 ? gcoef_real + (draw * cf.n_real + j) * 2 : gcoef_complex + draw * cf.n_complex * 4 + k.slot;
     o[0] = ga + gasum;  // a_n = diag_n + sum a
@@ -2911,9 +2927,9 @@ EXO_HD void gcoef_lane(const Coefs& cf, int64_t n, int64_t n_draw, const double*
   } else if (!k.odd) {
     double* o = gcoef_complex + (draw * cf.n_complex + ((j - cf.n_real) >> 1)) * 4;
     o[0] = ga + gasum;
-    o[1] = state[ws.gpart(0, 4 * j + 1, draw)];
-    o[2] = gc + state[ws.gpart(0, 4 * (j + 1) + 2, draw)];   // the decay rate is shared by the pair's two indices
-    o[3] = state[ws.gpart(0, 4 * j + 3, draw)];
+    o[1] = total(4 * j + 1);
+    o[2] = gc + total(4 * (j + 1) + 2);   // the decay rate is shared by the pair's two indices
+    o[3] = total(4 * j + 3);
   }
 }
 

@@ -426,7 +426,7 @@ void run_vjp(const double* t, gp::Series rs, const double* diag, int64_t n_diag,
       state[ws.gpart(0, k, d)] = v;
     }
   for (int64_t d = 0; d < n_draw; ++d)
-    for (int j = 0; j < J; ++j) gp::gcoef_lane(cf, n, n_draw, state, cg, gdiag_sum, gcr, gcc, d, j);
+    for (int j = 0; j < J; ++j) gp::gcoef_lane(cf, n, n_draw, state, cg, 1, gdiag_sum, gcr, gcc, d, j);
 }
 
 }  // namespace
