@@ -1228,6 +1228,20 @@ __global__ __launch_bounds__(kWave) void celerite_tree_kernel(TreeOp op, double*
   tree_item_lane<J, ADJ, DOWN>(op, state, c, item - (int64_t)c * op.n_draw);
 }
 
+// two levels of a scan in one launch, one lane per item of the upper one (tree_item4_*_lane; J <= 2)
+#ifndef EXO_GP_TREE4
+#define EXO_GP_TREE4 1
+#endif
+template <int J, bool ADJ, bool DOWN>
+__global__ __launch_bounds__(kWave) void celerite_tree4_kernel(TreeOp a, TreeOp b, double* __restrict__ state) {
+  const int64_t item = (int64_t)blockIdx.x * kWave + threadIdx.x;
+  if (item >= (int64_t)b.n_item * b.n_draw) return;
+  const int i = (int)(item / b.n_draw);
+  const int64_t draw = item - (int64_t)i * b.n_draw;
+  if (DOWN) tree_item4_down_lane<J, ADJ>(a, b, state, i, draw);
+  else tree_item4_up_lane<J, ADJ>(a, b, state, i, draw);
+}
+
 // (A draw's scan in ONE launch -- a block per draw walking the levels with block barriers, all of them or the narrow top ones
 // only -- was built in round 4, measured slower inside a replayed graph (C3 3.88 against 3.82 ms, C5 1.90 against 1.91: what a
 // narrow level costs is its item's dependent latency, not its launch) and removed in round 5.)
@@ -2033,8 +2047,7 @@ static int celerite_fwd(const double* t, Series resid, const double* diag, int64
       {
         // (B) as a tree: compose up to one position, seed it with the initial state, apply back down -- a launch per level
         int rc = EXO_OK;
-        tree_scan(ws, J, false,
-                  [&](const TreeOp& op, bool down) {
+        auto launch = [&](const TreeOp& op, bool down) {
                     const dim3 tgrid((unsigned)(((int64_t)op.n_item * n_draw + kWave - 1) / kWave));
                     const dim3 ggrid((unsigned)(((int64_t)op.n_item * n_draw + kScanBlock / 8 - 1) / (kScanBlock / 8)));
                     if (EXO_GP_GROUP_TREES && J >= 3) {
@@ -2053,11 +2066,27 @@ static int celerite_fwd(const double* t, Series resid, const double* diag, int64
                     } else {
                       EXO_GP_DISPATCH_VOID(J, hipLaunchKernelGGL((celerite_tree_kernel<JJ, false, false>), tgrid, block, 0, st, op, state))
                     }
-                  },
-                  [&]() {
+                  };
+        auto seed = [&]() {
                     EXO_GP_DISPATCH_VOID(J, hipLaunchKernelGGL((celerite_scan_init_kernel<JJ>), grid, block, 0, st, t, cf, n_draw,
                                                                state + ws.tree_state(ws.tree_top())))
-                  });
+                  };
+        if (EXO_GP_TREE4 && J <= 2) {
+          tree_scan4(ws, J, false, launch,
+                     [&](const TreeOp& a, const TreeOp& b, bool down) {
+                       const dim3 tgrid((unsigned)(((int64_t)b.n_item * n_draw + kWave - 1) / kWave));
+                       if (J == 1) {
+                         if (down) hipLaunchKernelGGL((celerite_tree4_kernel<1, false, true>), tgrid, block, 0, st, a, b, state);
+                         else hipLaunchKernelGGL((celerite_tree4_kernel<1, false, false>), tgrid, block, 0, st, a, b, state);
+                       } else {
+                         if (down) hipLaunchKernelGGL((celerite_tree4_kernel<2, false, true>), tgrid, block, 0, st, a, b, state);
+                         else hipLaunchKernelGGL((celerite_tree4_kernel<2, false, false>), tgrid, block, 0, st, a, b, state);
+                       }
+                     },
+                     seed);
+        } else {
+          tree_scan(ws, J, false, launch, seed);
+        }
         if (rc != EXO_OK) return rc;
       }
       if (cg.lane) {
@@ -2135,8 +2164,7 @@ static int celerite_vjp(const double* t, Series resid, const double* diag, int64
     {
       // (B') as a tree over positions p = C - 1 - chunk: adjoint elements of chunks C - 1 .. 1, zero initial adjoint
       bool ok = true;
-      tree_scan(ws, J, true,
-                [&](const TreeOp& op, bool down) {
+      auto launch = [&](const TreeOp& op, bool down) {
                   const dim3 tgrid((unsigned)(((int64_t)op.n_item * n_draw + kWave - 1) / kWave));
                   const dim3 ggrid((unsigned)(((int64_t)op.n_item * n_draw + kScanBlock / 8 - 1) / (kScanBlock / 8)));
                   if (EXO_GP_GROUP_TREES && J >= 3) {
@@ -2150,10 +2178,26 @@ static int celerite_vjp(const double* t, Series resid, const double* diag, int64
                   } else {
                     EXO_GP_DISPATCH_VOID(J, hipLaunchKernelGGL((celerite_tree_kernel<JJ, true, false>), tgrid, block, 0, st, op, wstate))
                   }
-                },
-                [&]() {
+                };
+      auto seed = [&]() {
                   ok = exo::zero_fill_async(wstate + ws.tree_state(ws.tree_top()), (int64_t)ws.B() * n_draw, st);   // (never a memset node: exo_math.hpp)
-                });
+                };
+      if (EXO_GP_TREE4 && J <= 2) {
+        tree_scan4(ws, J, true, launch,
+                   [&](const TreeOp& a, const TreeOp& b, bool down) {
+                     const dim3 tgrid((unsigned)(((int64_t)b.n_item * n_draw + kWave - 1) / kWave));
+                     if (J == 1) {
+                       if (down) hipLaunchKernelGGL((celerite_tree4_kernel<1, true, true>), tgrid, block, 0, st, a, b, wstate);
+                       else hipLaunchKernelGGL((celerite_tree4_kernel<1, true, false>), tgrid, block, 0, st, a, b, wstate);
+                     } else {
+                       if (down) hipLaunchKernelGGL((celerite_tree4_kernel<2, true, true>), tgrid, block, 0, st, a, b, wstate);
+                       else hipLaunchKernelGGL((celerite_tree4_kernel<2, true, false>), tgrid, block, 0, st, a, b, wstate);
+                     }
+                   },
+                   seed);
+      } else {
+        tree_scan(ws, J, true, launch, seed);
+      }
       if (!ok) return EXO_ERR_LAUNCH;
     }
     if (cg.lane) {

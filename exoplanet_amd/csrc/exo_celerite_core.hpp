@@ -1351,116 +1351,88 @@ EXO_HD void tree_load_elem(const double* EXO_RESTRICT state, const TreeOp& op, i
     for (int l = 0; l < J; ++l) { const double v = p[(e++) * op.n_draw]; el.Jm[j][l] = has ? v : 0.0; }
 }
 
-// one item of a level: UP -- dst element c = src elements 2c, 2c + 1 composed; DOWN -- child states 2c, 2c + 1 from
-// parent state c and child element 2c
-template <int J, bool ADJ, bool DOWN>
-EXO_HD void tree_item_lane(const TreeOp& op, double* EXO_RESTRICT state, int c, int64_t draw) {
-  const int64_t nd = op.n_draw;
-  const int Bq = J + J * J, E = 3 * J * J + 2 * J;
-  if (DOWN) {
-    double m[J], P[J][J];
+// an element applied to a state: forward -- bscan_lane's step on (F, P); adjoint -- bscan_vjp_lane's on (Fbar, Pbar)
+template <int J, bool ADJ>
+EXO_HD void tree_apply(const Elem<J>& el, const double* m, const double (*P)[J], double* m2, double (*Ps)[J]) {
+  double P2[J][J];
+  if (ADJ) {
+    // x = Abar^T Fbar ;  Fbar' = lF + x ;  Pbar' = lP + Abar^T Pbar Abar + sym(x g^T)
+    double x[J], T[J][J];
 #pragma unroll
     for (int j = 0; j < J; ++j) {
-      m[j] = state[op.par_state + ((int64_t)c * Bq + j) * nd + draw];
+      double xj = 0.0;
 #pragma unroll
-      for (int l = 0; l < J; ++l) P[j][l] = state[op.par_state + ((int64_t)c * Bq + J + j * J + l) * nd + draw];
+      for (int l = 0; l < J; ++l) {
+        xj = fma(el.A[l][j], m[l], xj);
+        double tv = 0.0;
+#pragma unroll
+        for (int k = 0; k < J; ++k) tv = fma(P[j][k], el.A[k][l], tv);
+        T[j][l] = tv;
+      }
+      x[j] = xj;
     }
-    auto put = [&](int pos, const double* mv, const double (*Pv)[J]) {
-      const int idx = op.dst_rev ? op.dst_len - 1 - pos : pos;
-      double* EXO_RESTRICT q = state + op.dst_state + ((int64_t)idx * Bq) * nd + draw;
 #pragma unroll
-      for (int j = 0; j < J; ++j) {
-        q[(int64_t)j * nd] = mv[j];
+    for (int j = 0; j < J; ++j) {
+      m2[j] = el.eta[j] + x[j];
 #pragma unroll
-        for (int l = 0; l < J; ++l) q[(int64_t)(J + j * J + l) * nd] = op.psign * Pv[j][l];
+      for (int l = 0; l < J; ++l) {
+        double cong = el.Cm[j][l];
+#pragma unroll
+        for (int k = 0; k < J; ++k) cong = fma(el.A[k][j], T[k][l], cong);
+        P2[j][l] = cong + 0.5 * (x[j] * el.b[l] + el.b[j] * x[l]);
       }
-    };
-    put(2 * c, m, P);
-    if (2 * c + 1 >= op.dst_n) return;
-    Elem<J> el;
-    tree_load_elem<J>(state, op, 2 * c, draw, el);
-    double m2[J], P2[J][J];
-    if (ADJ) {
-      // x = Abar^T Fbar ;  Fbar' = lF + x ;  Pbar' = lP + Abar^T Pbar Abar + sym(x g^T)
-      double x[J], T[J][J];
-#pragma unroll
-      for (int j = 0; j < J; ++j) {
-        double xj = 0.0;
-#pragma unroll
-        for (int l = 0; l < J; ++l) {
-          xj = fma(el.A[l][j], m[l], xj);
-          double tv = 0.0;
-#pragma unroll
-          for (int k = 0; k < J; ++k) tv = fma(P[j][k], el.A[k][l], tv);
-          T[j][l] = tv;
-        }
-        x[j] = xj;
-      }
-#pragma unroll
-      for (int j = 0; j < J; ++j) {
-        m2[j] = el.eta[j] + x[j];
-#pragma unroll
-        for (int l = 0; l < J; ++l) {
-          double cong = el.Cm[j][l];
-#pragma unroll
-          for (int k = 0; k < J; ++k) cong = fma(el.A[k][j], T[k][l], cong);
-          P2[j][l] = cong + 0.5 * (x[j] * el.b[l] + el.b[j] * x[l]);
-        }
-      }
-    } else {
-      // X = I + P Jm ;  solve X [YP | ym] = [P | F + P eta] ;  F' = A ym + b ;  P' = A (YP) A^T + Cm
-      double X[J][J], Bm[J][J + 1];
-#pragma unroll
-      for (int j = 0; j < J; ++j) {
-        double pe = m[j];
-#pragma unroll
-        for (int l = 0; l < J; ++l) {
-          double xv = (j == l) ? 1.0 : 0.0;
-#pragma unroll
-          for (int k = 0; k < J; ++k) xv = fma(P[j][k], el.Jm[k][l], xv);
-          X[j][l] = xv;
-          Bm[j][l] = P[j][l];
-          pe = fma(P[j][l], el.eta[l], pe);
-        }
-        Bm[j][J] = pe;
-      }
-      solve_inplace<J, J + 1>(X, Bm);
-      double AY[J][J];
-#pragma unroll
-      for (int j = 0; j < J; ++j) {
-        double mj = el.b[j];
-#pragma unroll
-        for (int l = 0; l < J; ++l) {
-          mj = fma(el.A[j][l], Bm[l][J], mj);
-          double v = 0.0;
-#pragma unroll
-          for (int k = 0; k < J; ++k) v = fma(el.A[j][k], Bm[k][l], v);
-          AY[j][l] = v;
-        }
-        m2[j] = mj;
-      }
-#pragma unroll
-      for (int j = 0; j < J; ++j)
-#pragma unroll
-        for (int l = 0; l < J; ++l) {
-          double v = el.Cm[j][l];
-#pragma unroll
-          for (int k = 0; k < J; ++k) v = fma(AY[j][k], el.A[l][k], v);
-          P2[j][l] = v;
-        }
     }
-    double Ps[J][J];
+  } else {
+    // X = I + P Jm ;  solve X [YP | ym] = [P | F + P eta] ;  F' = A ym + b ;  P' = A (YP) A^T + Cm
+    double X[J][J], Bm[J][J + 1];
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      double pe = m[j];
+#pragma unroll
+      for (int l = 0; l < J; ++l) {
+        double xv = (j == l) ? 1.0 : 0.0;
+#pragma unroll
+        for (int k = 0; k < J; ++k) xv = fma(P[j][k], el.Jm[k][l], xv);
+        X[j][l] = xv;
+        Bm[j][l] = P[j][l];
+        pe = fma(P[j][l], el.eta[l], pe);
+      }
+      Bm[j][J] = pe;
+    }
+    solve_inplace<J, J + 1>(X, Bm);
+    double AY[J][J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      double mj = el.b[j];
+#pragma unroll
+      for (int l = 0; l < J; ++l) {
+        mj = fma(el.A[j][l], Bm[l][J], mj);
+        double v = 0.0;
+#pragma unroll
+        for (int k = 0; k < J; ++k) v = fma(el.A[j][k], Bm[k][l], v);
+        AY[j][l] = v;
+      }
+      m2[j] = mj;
+    }
 #pragma unroll
     for (int j = 0; j < J; ++j)
 #pragma unroll
-      for (int l = 0; l < J; ++l) Ps[j][l] = 0.5 * (P2[j][l] + P2[l][j]);
-    put(2 * c + 1, m2, Ps);
-    return;
+      for (int l = 0; l < J; ++l) {
+        double v = el.Cm[j][l];
+#pragma unroll
+        for (int k = 0; k < J; ++k) v = fma(AY[j][k], el.A[l][k], v);
+        P2[j][l] = v;
+      }
   }
-  // ---- UP
-  Elem<J> e1, e2, out;
-  tree_load_elem<J>(state, op, 2 * c, draw, e1);
-  tree_load_elem<J>(state, op, 2 * c + 1, draw, e2);
+#pragma unroll
+  for (int j = 0; j < J; ++j)
+#pragma unroll
+    for (int l = 0; l < J; ++l) Ps[j][l] = 0.5 * (P2[j][l] + P2[l][j]);
+}
+
+// two elements composed (e1 acts first), matrices symmetrised as the level arrays hold them: what the next level loads
+template <int J, bool ADJ>
+EXO_HD void tree_compose(const Elem<J>& e1, const Elem<J>& e2, Elem<J>& out) {
   if (ADJ) {
     double v[J];   // Abar2^T lF1
 #pragma unroll
@@ -1581,7 +1553,25 @@ EXO_HD void tree_item_lane(const TreeOp& op, double* EXO_RESTRICT state, int c, 
       out.eta[j] = ej;
     }
   }
-  double* EXO_RESTRICT q = state + op.dst_elem + ((int64_t)c * E) * nd + draw;
+#pragma unroll
+  for (int j = 0; j < J; ++j)
+#pragma unroll
+    for (int l = j + 1; l < J; ++l) {
+      const double cs = 0.5 * (out.Cm[j][l] + out.Cm[l][j]), js = ADJ ? 0.0 : 0.5 * (out.Jm[j][l] + out.Jm[l][j]);
+      out.Cm[j][l] = out.Cm[l][j] = cs;
+      out.Jm[j][l] = out.Jm[l][j] = js;
+    }
+  if (ADJ) {
+#pragma unroll
+    for (int j = 0; j < J; ++j) out.Jm[j][j] = 0.0;
+  }
+}
+
+// element `idx` of a level array written ([index][A, b, Cm, eta, Jm][draw])
+template <int J>
+EXO_HD void tree_store_elem(double* EXO_RESTRICT state, int64_t dst_elem, int64_t nd, int idx, int64_t draw, const Elem<J>& out) {
+  const int E = 3 * J * J + 2 * J;
+  double* EXO_RESTRICT q = state + dst_elem + ((int64_t)idx * E) * nd + draw;
   int e = 0;
 #pragma unroll
   for (int j = 0; j < J; ++j)
@@ -1592,13 +1582,129 @@ EXO_HD void tree_item_lane(const TreeOp& op, double* EXO_RESTRICT state, int c, 
 #pragma unroll
   for (int j = 0; j < J; ++j)
 #pragma unroll
-    for (int l = 0; l < J; ++l) q[(int64_t)(e++) * nd] = 0.5 * (out.Cm[j][l] + out.Cm[l][j]);
+    for (int l = 0; l < J; ++l) q[(int64_t)(e++) * nd] = out.Cm[j][l];
 #pragma unroll
   for (int j = 0; j < J; ++j) q[(int64_t)(e++) * nd] = out.eta[j];
 #pragma unroll
   for (int j = 0; j < J; ++j)
 #pragma unroll
-    for (int l = 0; l < J; ++l) q[(int64_t)(e++) * nd] = ADJ ? 0.0 : 0.5 * (out.Jm[j][l] + out.Jm[l][j]);
+    for (int l = 0; l < J; ++l) q[(int64_t)(e++) * nd] = out.Jm[j][l];
+}
+
+// one item of a level: UP -- dst element c = src elements 2c, 2c + 1 composed; DOWN -- child states 2c, 2c + 1 from
+// parent state c and child element 2c
+template <int J, bool ADJ, bool DOWN>
+EXO_HD void tree_item_lane(const TreeOp& op, double* EXO_RESTRICT state, int c, int64_t draw) {
+  const int64_t nd = op.n_draw;
+  const int Bq = J + J * J, E = 3 * J * J + 2 * J;
+  if (DOWN) {
+    double m[J], P[J][J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      m[j] = state[op.par_state + ((int64_t)c * Bq + j) * nd + draw];
+#pragma unroll
+      for (int l = 0; l < J; ++l) P[j][l] = state[op.par_state + ((int64_t)c * Bq + J + j * J + l) * nd + draw];
+    }
+    auto put = [&](int pos, const double* mv, const double (*Pv)[J]) {
+      const int idx = op.dst_rev ? op.dst_len - 1 - pos : pos;
+      double* EXO_RESTRICT q = state + op.dst_state + ((int64_t)idx * Bq) * nd + draw;
+#pragma unroll
+      for (int j = 0; j < J; ++j) {
+        q[(int64_t)j * nd] = mv[j];
+#pragma unroll
+        for (int l = 0; l < J; ++l) q[(int64_t)(J + j * J + l) * nd] = op.psign * Pv[j][l];
+      }
+    };
+    put(2 * c, m, P);
+    if (2 * c + 1 >= op.dst_n) return;
+    Elem<J> el;
+    tree_load_elem<J>(state, op, 2 * c, draw, el);
+    double m2[J], Ps[J][J];
+    tree_apply<J, ADJ>(el, m, P, m2, Ps);
+    put(2 * c + 1, m2, Ps);
+    return;
+  }
+  // ---- UP
+  Elem<J> e1, e2, out;
+  tree_load_elem<J>(state, op, 2 * c, draw, e1);
+  tree_load_elem<J>(state, op, 2 * c + 1, draw, e2);
+  tree_compose<J, ADJ>(e1, e2, out);
+  tree_store_elem<J>(state, op.dst_elem, nd, c, draw, out);
+}
+
+// TWO LEVELS IN ONE LAUNCH (round 5, J <= 2).  A narrow level costs its item's dependent latency -- loads, a composition, stores:
+// ~5.5 us at C3 whatever its size -- and a scan has 2 log2 C of them.  An item of the radix-4 form takes four elements of level f,
+// composes the two pairs (level f + 1, stored: the way down needs them) and those two (level f + 2) with the intermediate
+// elements in registers; on the way down a state of level f + 2 becomes the four of level f through those of level f + 1, which
+// nobody else reads and which are not stored.  The same compositions and applications on the same numbers as two radix-2
+// launches -- the results are bit-identical -- in half the launches.  `a`: the op of the lower level of the pair as scan_level_op
+// gives it, `b`: the upper one's.
+template <int J, bool ADJ>
+EXO_HD void tree_item4_up_lane(const TreeOp& a, const TreeOp& b, double* EXO_RESTRICT state, int i, int64_t draw) {
+  const int64_t nd = a.n_draw;
+  Elem<J> e0, e1, m0, m1, out;
+  tree_load_elem<J>(state, a, 4 * i, draw, e0);
+  tree_load_elem<J>(state, a, 4 * i + 1, draw, e1);
+  tree_compose<J, ADJ>(e0, e1, m0);
+  tree_store_elem<J>(state, a.dst_elem, nd, 2 * i, draw, m0);       // (2 i < a.n_item: i < b.n_item = ceil(a.n_item / 2))
+  if (2 * i + 1 < a.n_item) {
+    tree_load_elem<J>(state, a, 4 * i + 2, draw, e0);
+    tree_load_elem<J>(state, a, 4 * i + 3, draw, e1);
+    tree_compose<J, ADJ>(e0, e1, m1);
+    tree_store_elem<J>(state, a.dst_elem, nd, 2 * i + 1, draw, m1);
+  } else {
+    // past the end of level f + 1: the identity, as tree_load_elem hands it to a radix-2 item
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      m1.b[j] = m1.eta[j] = 0.0;
+#pragma unroll
+      for (int l = 0; l < J; ++l) { m1.A[j][l] = (j == l) ? 1.0 : 0.0; m1.Cm[j][l] = m1.Jm[j][l] = 0.0; }
+    }
+  }
+  tree_compose<J, ADJ>(m0, m1, out);
+  tree_store_elem<J>(state, b.dst_elem, nd, i, draw, out);
+}
+
+// `b`: the DOWN op of level f + 1 (parents: level f + 2), `a`: that of level f (children written as a says: level 0's order / sign)
+template <int J, bool ADJ>
+EXO_HD void tree_item4_down_lane(const TreeOp& a, const TreeOp& b, double* EXO_RESTRICT state, int i, int64_t draw) {
+  const int64_t nd = a.n_draw;
+  const int Bq = J + J * J;
+  double m[J], P[J][J];
+#pragma unroll
+  for (int j = 0; j < J; ++j) {
+    m[j] = state[b.par_state + ((int64_t)i * Bq + j) * nd + draw];
+#pragma unroll
+    for (int l = 0; l < J; ++l) P[j][l] = state[b.par_state + ((int64_t)i * Bq + J + j * J + l) * nd + draw];
+  }
+  auto put = [&](int pos, const double* mv, const double (*Pv)[J]) {
+    const int idx = a.dst_rev ? a.dst_len - 1 - pos : pos;
+    double* EXO_RESTRICT q = state + a.dst_state + ((int64_t)idx * Bq) * nd + draw;
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      q[(int64_t)j * nd] = mv[j];
+#pragma unroll
+      for (int l = 0; l < J; ++l) q[(int64_t)(J + j * J + l) * nd] = a.psign * Pv[j][l];
+    }
+  };
+  // the two children of a state of level f + 1 at position p
+  auto children = [&](int p, const double* mv, const double (*Pv)[J]) {
+    put(2 * p, mv, Pv);                      // (2 p < a.dst_n: p < b.dst_n = ceil(a.dst_n / 2))
+    if (2 * p + 1 >= a.dst_n) return;
+    Elem<J> el;
+    tree_load_elem<J>(state, a, 2 * p, draw, el);
+    double m2[J], Ps[J][J];
+    tree_apply<J, ADJ>(el, mv, Pv, m2, Ps);
+    put(2 * p + 1, m2, Ps);
+  };
+  Elem<J> eb;
+  const bool second = 2 * i + 1 < b.dst_n;
+  if (second) tree_load_elem<J>(state, b, 2 * i, draw, eb);     // (issued before the first pair's work)
+  children(2 * i, m, P);
+  if (!second) return;
+  double m1[J], P1[J][J];
+  tree_apply<J, ADJ>(eb, m, P, m1, P1);
+  children(2 * i + 1, m1, P1);
 }
 
 // the state the forward scan starts from, (F, P) = (0, Delta(t_0)) (S_0 = 0), as a state record at dst
@@ -1657,6 +1763,19 @@ EXO_HDH void tree_scan(const ChunkWs& ws, int J, bool adj, Launch&& launch, Seed
   for (int f = 0; f + 1 < top; ++f) launch(scan_level_op(ws, J, adj, f, false), false);
   seed();
   for (int f = top - 1; f >= 0; --f) launch(scan_level_op(ws, J, adj, f, true), true);
+}
+
+// the same with two levels per launch where a pair is left (tree_item4_*_lane): launch2(lower op, upper op, down)
+template <class Launch, class Launch2, class Seed>
+EXO_HDH void tree_scan4(const ChunkWs& ws, int J, bool adj, Launch&& launch, Launch2&& launch2, Seed&& seed) {
+  const int top = ws.tree_top();
+  int f = 0;
+  for (; f + 2 < top; f += 2) launch2(scan_level_op(ws, J, adj, f, false), scan_level_op(ws, J, adj, f + 1, false), false);
+  for (; f + 1 < top; ++f) launch(scan_level_op(ws, J, adj, f, false), false);
+  seed();
+  f = top - 1;
+  for (; f >= 1; f -= 2) launch2(scan_level_op(ws, J, adj, f - 1, true), scan_level_op(ws, J, adj, f, true), true);
+  for (; f >= 0; --f) launch(scan_level_op(ws, J, adj, f, true), true);
 }
 
 // ---------------------------------------------------------------------------------------------

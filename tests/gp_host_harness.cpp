@@ -17,6 +17,7 @@
 
 namespace {
 
+int g_tree4 = 0;         // 1: two levels of a scan per "launch" where a pair is left (tree_scan4, J <= 2: what the device does)
 int g_serial_scan = 0;   // 1: the serial reference scans (bscan_lane, bscan_vjp_lane) instead of the trees
 int g_robust_flags = 1;  // draws the element lanes flag kFlagRobust take the robust route (as on the device)
 int g_newton = -1;        // experiment: >= 0: that many Newton iterations instead of the serial forward scan (newton_scan)
@@ -265,17 +266,28 @@ void run_fwd(const double* t, gp::Series rs, const double* diag, int64_t n_diag,
         gp::elem_lane<J, decltype(nr)::value>(t, rs, diag, n_diag, n, cf, n_draw, state, cg, d, c);
       });
   if (cg.tree && !g_serial_scan && !g_robust) {   // the scans as trees of compositions, level by level, as the device launches them
-    gp::tree_scan(ws, J, false,
-                  [&](const gp::TreeOp& op, bool down) {
-                    for (int c = 0; c < op.n_item; ++c)
-                      for (int64_t d = 0; d < n_draw; ++d) {
-                        if (down) gp::tree_item_lane<J, false, true>(op, state, c, d);
-                        else gp::tree_item_lane<J, false, false>(op, state, c, d);
-                      }
-                  },
-                  [&]() {
-                    for (int64_t d = 0; d < n_draw; ++d) gp::scan_init_lane<J>(t, cf, n_draw, state + ws.tree_state(ws.tree_top()), d);
-                  });
+    auto launch = [&](const gp::TreeOp& op, bool down) {
+      for (int c = 0; c < op.n_item; ++c)
+        for (int64_t d = 0; d < n_draw; ++d) {
+          if (down) gp::tree_item_lane<J, false, true>(op, state, c, d);
+          else gp::tree_item_lane<J, false, false>(op, state, c, d);
+        }
+    };
+    auto seed = [&]() {
+      for (int64_t d = 0; d < n_draw; ++d) gp::scan_init_lane<J>(t, cf, n_draw, state + ws.tree_state(ws.tree_top()), d);
+    };
+    if (g_tree4)
+      gp::tree_scan4(ws, J, false, launch,
+                     [&](const gp::TreeOp& a, const gp::TreeOp& b, bool down) {
+                       for (int i = 0; i < b.n_item; ++i)
+                         for (int64_t d = 0; d < n_draw; ++d) {
+                           if (down) gp::tree_item4_down_lane<J, false>(a, b, state, i, d);
+                           else gp::tree_item4_up_lane<J, false>(a, b, state, i, d);
+                         }
+                     },
+                     seed);
+    else
+      gp::tree_scan(ws, J, false, launch, seed);
   } else if (g_robust && g_hybrid_k >= 0 && cg.tree) {
     const int top = ws.tree_top();
     const int k = g_hybrid_k < top ? g_hybrid_k : top - 1;
@@ -385,18 +397,29 @@ void run_vjp(const double* t, gp::Series rs, const double* diag, int64_t n_diag,
       }
     }
   if (cg.tree && !g_serial_scan && (!g_robust || g_adj_tree)) {   // (the adjoint tree takes the robust draws' inputs as they are)
-    gp::tree_scan(ws, J, true,
-                  [&](const gp::TreeOp& op, bool down) {
-                    for (int c = 0; c < op.n_item; ++c)
-                      for (int64_t d = 0; d < n_draw; ++d) {
-                        if (down) gp::tree_item_lane<J, true, true>(op, state, c, d);
-                        else gp::tree_item_lane<J, true, false>(op, state, c, d);
-                      }
-                  },
-                  [&]() {
-                    double* dst = state + ws.tree_state(ws.tree_top());
-                    for (int64_t k = 0; k < (int64_t)ws.B() * n_draw; ++k) dst[k] = 0.0;
-                  });
+    auto launch = [&](const gp::TreeOp& op, bool down) {
+      for (int c = 0; c < op.n_item; ++c)
+        for (int64_t d = 0; d < n_draw; ++d) {
+          if (down) gp::tree_item_lane<J, true, true>(op, state, c, d);
+          else gp::tree_item_lane<J, true, false>(op, state, c, d);
+        }
+    };
+    auto seed = [&]() {
+      double* dst = state + ws.tree_state(ws.tree_top());
+      for (int64_t k = 0; k < (int64_t)ws.B() * n_draw; ++k) dst[k] = 0.0;
+    };
+    if (g_tree4)
+      gp::tree_scan4(ws, J, true, launch,
+                     [&](const gp::TreeOp& a, const gp::TreeOp& b, bool down) {
+                       for (int i = 0; i < b.n_item; ++i)
+                         for (int64_t d = 0; d < n_draw; ++d) {
+                           if (down) gp::tree_item4_down_lane<J, true>(a, b, state, i, d);
+                           else gp::tree_item4_up_lane<J, true>(a, b, state, i, d);
+                         }
+                     },
+                     seed);
+    else
+      gp::tree_scan(ws, J, true, launch, seed);
   } else {
     for (int64_t d = 0; d < n_draw; ++d) gp::bscan_vjp_lane<J>(n, n_draw, state, cg, d);
   }
@@ -434,6 +457,7 @@ void run_vjp(const double* t, gp::Series rs, const double* diag, int64_t n_diag,
 extern "C" {
 
 void harness_set_serial_scan(int v) { g_serial_scan = v; }
+void harness_set_tree4(int v) { g_tree4 = v; }
 void harness_set_polish(int v) { g_polish = v; }
 void harness_set_robust(int v) { g_robust = v; }
 void harness_set_adj_tree(int v) { g_adj_tree = v; }

@@ -318,6 +318,32 @@ def test_tree_scans_equal_serial_scans(harness):
                 assert np.abs(g0[k] - g1[k]).max() <= 1e-10 * (np.abs(g1[k]).max() + 1e-300), (n_real, n_complex, k)
 
 
+def test_two_levels_per_launch_is_the_same_tree(harness):
+    """tree_scan4 (round 5: an item takes four elements, the intermediate level in registers; the way down skips storing the
+    intermediate states) performs the compositions and applications of two radix-2 levels on the same numbers: log-likelihood and
+    every gradient BIT-identical, chunk counts with every remainder of the pairing (odd / even numbers of levels, ragged last items)"""
+    rng = np.random.default_rng(77)
+    for n_real, n_complex, n_chunks in ((1, 0, 5), (0, 1, 8), (0, 1, 9), (2, 0, 16), (0, 1, 17), (0, 1, 31), (1, 0, 33), (0, 1, 64), (0, 1, 100), (2, 1, 13)):
+        n, D = 40 * n_chunks, 3
+        t = np.sort(rng.uniform(0, 30, n))
+        y = rng.normal(size=(D, n))
+        diag = 0.1 + 0.1 * rng.uniform(size=(D, n))
+        real = np.stack([10 ** rng.uniform(-1, 0, (D, n_real)), 10 ** rng.uniform(-1, 0.5, (D, n_real))], -1)
+        a = 10 ** rng.uniform(-1, 0, (D, n_complex)); c = 10 ** rng.uniform(-1, 0.3, (D, n_complex))
+        d = 10 ** rng.uniform(-0.5, 0.8, (D, n_complex)); b = rng.uniform(-0.9, 0.9, (D, n_complex)) * a * c / d
+        cplx = np.stack([a, b, c, d], -1)
+        gll = rng.normal(size=D)
+        res = []
+        for four in (0, 1):
+            harness.harness_set_tree4(four)
+            res.append(run(harness, t, y, diag, real, cplx, gll=gll, n_chunks=n_chunks))
+        harness.harness_set_tree4(0)
+        (ll0, _, _, g0), (ll1, _, _, g1) = res
+        assert np.array_equal(ll0, ll1), (n_real, n_complex, n_chunks)
+        for k in g0:
+            assert np.array_equal(g0[k], g1[k]), (n_real, n_complex, n_chunks, k)
+
+
 def _kernel(tau, c):
     return P.celerite_kernel(tau, *c)
 
