@@ -705,7 +705,7 @@ def extra_gp_conditioning(xo, ops, dev, D):
     """The celerite log-likelihood alone (value + gradient of the hyper-parameters and of the series) at the C3 shape for
     kernels of increasing difficulty for the time-parallel form: the clean SHO term; 1 % of the draws within 1 % of
     critical damping; a Matern-3/2 term (celerite2's eps = 0.01 approximation: b / a = 100); a RotationTerm whose
-    second mode sits near Q = 1/2 -- the cases DESIGN.md 3.5 used to send to the sequential kernels."""
+    second mode sits near Q = 1/2 -- the cases docs/DESIGN_r1_r4.md 3.5 used to send to the sequential kernels."""
     T = xo.gp.terms
     t = ops.vouch_sorted(torch.arange(N_CAD, dtype=torch.float64, device=dev) * CADENCE)   # (a fixed series: the caller's word)
     y = torch.as_tensor(5e-4 * np.random.default_rng(3).normal(size=N_CAD), device=dev)
@@ -717,7 +717,7 @@ def extra_gp_conditioning(xo, ops, dev, D):
     Qmix[1: max(2, D // 100): 2] = 0.495
     # bright-star draws: 1 % of the batch with a GP amplitude far above the white noise (conditioning score kappa = (1 + (b/a)^2)
     # sum(a) / min(diag) of 1e6 at J = 2 -- under the J <= 2 threshold of the scan trees -- and of 3e5 at J = 4 -- above the 3e4 of
-    # wider states: those draws take the ROBUST route of the time-parallel path (until round 4 the sequential
+    # wider states: those draws take the ROBUST route of the time-parallel path (docs/DESIGN_r1_r4.md 3.11; until round 4 the sequential
     # kernels redid them: 27x, the cliff VERDICT r3 item 6 asked to be timed)
     sig_b2 = np.full(D, 1e-3); sig_b2[: max(1, D // 100)] = 0.35
     sig_b4 = np.full(D, 1e-3); sig_b4[: max(1, D // 100)] = 0.25
@@ -761,7 +761,7 @@ def extra_gp_conditioning(xo, ops, dev, D):
                    "device: no wave of mixed kinds, no run-time layout; what is left of the 1.84x of round 3 is one more round of resident "
                    "waves for the second kind's wave).  `*_bright_star_*`: 1 % of the draws at a conditioning score of 1e6 "
                    "(J = 2: under the threshold of the scan trees) / 3e5 (J = 4: above the 3e4 of wider states -- those draws take the "
-                   "robust route of the time-parallel path, DESIGN.md section 3.11: Newton iterations on the chunks' entering states, the "
+                   "robust route of the time-parallel path, docs/DESIGN_r1_r4.md section 3.11: Newton iterations on the chunks' entering states, the "
                    "adjoint scan fed from the chunks' own reverse recurrences; the sequential kernels that used to redo them cost 27x)")
     return out
 

@@ -28,7 +28,7 @@
 //    cadence) at J = 2 instead of 80), the reverse pass recomputes the cadences of a block from its
 //    checkpoint in registers.  Draws too ill-conditioned for the scans' trees of element compositions (a score up to
 //    1e8) stay on this path by its ROBUST route: Newton iterations on the chunks' entering states (celerite_robust_newton_kernel), the
-//    adjoint scan fed from the chunks' own reverse recurrences (celerite_chunk_adj_kernel) -- DESIGN.md 3.11.
+//    adjoint scan fed from the chunks' own reverse recurrences (celerite_chunk_adj_kernel) -- docs/DESIGN_r1_r4.md 3.11.
 // The library keeps no state between calls: how a series is cut is a pure function of the call's
 // arguments (gp::chunk_plan), which the forward and the reverse call of a pair share.
 #include <hip/hip_runtime.h>

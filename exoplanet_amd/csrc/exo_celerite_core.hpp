@@ -6,7 +6,7 @@
 // for the host (g++, EXO_HOST_BUILD: tests/gp_host_harness.cpp runs the whole time-parallel
 // pipeline on the CPU against the oracle) and for gfx950, where a lane is a (draw, chunk) and the
 // kernels of exo_celerite.hip are thin wrappers.  Algorithm: exo_celerite.hip header comment and
-// DESIGN.md 3.4 / 3.5 (celerite2 is a dependency of the reference, /root/reference/setup.py:36;
+// docs/DESIGN_r1_r4.md 3.4 / 3.5 (celerite2 is a dependency of the reference, /root/reference/setup.py:36;
 // the recurrences are the published ones).
 #pragma once
 #include <math.h>
@@ -33,7 +33,7 @@ constexpr int kCkptB = 4;   // cadences per block of the one-lane chunk kernels 
 // recomputed states of a span in registers (J (J + 1) / 2 + 2 J + 2 doubles each), and four of them do not fit at J > 2
 // the polish passes (chunk1_fwd_lane): a laboratory result so far -- compiled into the host harness (tests/gp_host_harness.cpp,
 // tools/gp_host_lab.py), not into the device kernels: one Jacobi sweep takes the MEDIAN error of ill-conditioned draws down
-// 10-100 x but the worst kernels only 3-10 x per four sweeps
+// 10-100 x but the worst kernels only 3-10 x per four sweeps (docs/DESIGN_r1_r4.md section 3.5)
 #ifndef EXO_GP_POLISH
 #define EXO_GP_POLISH 0
 #endif
@@ -487,7 +487,7 @@ EXO_HD double newton_err_term(double d, double sc) {
 #ifndef EXO_LANE_MAX_J
 #define EXO_LANE_MAX_J 6
 #endif
-constexpr int kLaneMaxJ = EXO_LANE_MAX_J;   // one-lane chunk kernels up to this state width (registers: DESIGN.md 4)
+constexpr int kLaneMaxJ = EXO_LANE_MAX_J;   // one-lane chunk kernels up to this state width (registers: docs/DESIGN_r1_r4.md 4)
 
 // doubles of the full saved factorisation (sequential / lane-group layout) at the head of `state`
 EXO_HDH int64_t seq_state_doubles(int64_t n, int64_t n_draw, int J) {

@@ -7,7 +7,7 @@
 //   ops.kepler               (call site /root/reference/src/exoplanet/orbits/keplerian.py:333)
 //   ops.quad_solution_vector (call site /root/reference/src/exoplanet/light_curves/limb_dark.py:24)
 // The third-party sources are not available; everything here is derived from
-// the mathematical definitions and checked against
+// the mathematical definitions (see docs/DESIGN_r1_r4.md section 3) and checked against
 // oracle/mp_reference.py.
 //
 // One (cadence, sub-exposure, planet) per lane.  No MFMA: there is no dense
@@ -419,7 +419,7 @@ EXO_HD double i4_series(double k) {
 // ---------------------------------------------------------------------------
 // Solution vector s = (s0, s1, s2) = int_{visible disk} (1, mu, 4 mu^2 - 2) dA
 // for an occultor of radius r at separation b >= 0, and (optionally) ds/db,
-// ds/dr.  See DESIGN.md section 3.2 for the derivation:
+// ds/dr.  See docs/DESIGN_r1_r4.md section 3.2 for the derivation:
 //   s0 = pi - (two circular segments)
 //   s2 = -int_arc (1-rho^2) r (r + b cos phi) dphi      (field rho(1-rho^2) phi^)
 //   s1 = 2pi/3 (1 - Theta(r-b)) + 1/3 int_arc (1-rho^2)^{3/2} dtheta

@@ -163,7 +163,7 @@ __device__ __forceinline__ void window_lanes(const double* __restrict__ p, uint3
   // sin f0 = +-cos w; every angle of the refinement is carried as its sine (all lie in [0, pi/2)) and composed with f0
   // by the addition formulas; distances enter as 1 / dist = (1 + e cos f) / (a (1 - e^2)).  What is left is one atan2
   // for w, one asin for the angle reached and one atan2 for E(f).  (One thread per record with libm's sin / cos / asin
-  // in the loop: 19 us of a 320 us sweep; four threads: 11.6 us; this form: see DESIGN.md 4.)
+  // in the loop: 19 us of a 320 us sweep; four threads: 11.6 us; this form: see docs/DESIGN_r1_r4.md 4.)
   const double nrev = p[EXO_P_N] * (0.5 / exo::kPi);
   const double wn = sqrt(cw * cw + sw * sw);
   const double q = (1.0 + fabs(p[EXO_P_ROR])) / (fabs(p[EXO_P_AOR]) * (1.0 - e) * wn);

@@ -457,7 +457,7 @@ int exo_orbit_vector_vjp_f64(const double* t, int64_t n_cad, const double* param
  *                them, the library keeps NO state between calls (EXO_ERR_WORKSPACE if state_doubles
  *                is smaller than exo_celerite_state_doubles() of the same arguments)
  *
- * With a state buffer and n >= 64 the recurrences run in parallel over TIME: the
+ * With a state buffer and n >= 64 the recurrences run in parallel over TIME (docs/DESIGN_r1_r4.md 3.5): the
  * series is cut into chunks, chunk "filtering elements" and a short per-draw scan over them give
  * the recurrence state entering every chunk (and, in the reverse pass, its adjoint), and the
  * ordinary recurrences then run inside all chunks at once.  J <= 2: one lane per (draw, chunk) and

@@ -396,7 +396,7 @@ void oracle_transit_ttv(const double* t, int64_t n_cad, const double* texp, int6
 
 /* ------------------------------------------------------------------ celerite
  * log-likelihood and its reverse recurrence for ONE draw (SURVEY Appendix B;
- * adjoint derived as in numpy_port.py / DESIGN.md 3.4).  J <= 8.
+ * adjoint derived as in numpy_port.py / docs/DESIGN_r1_r4.md 3.4).  J <= 8.
  *   coef_real [n_real][2] = (a, c), coef_complex [n_complex][4] = (a, b, c, d)
  * If gresid != NULL also writes gresid[n], gdiag[n], gcoef_real, gcoef_complex
  * for d loglike.  Returns loglike (-inf if not positive definite).           */

@@ -6,7 +6,7 @@ chosen across the range the time-parallel path keeps (1e3 .. 3e6 for J = 2; 1e3,
 across the range of its robust route (1e6 .. 5e7), from the dense definition in
 x87 long double (oracle/make_golden_r02.gp_dense_ld, pinned to mpmath there).  N = 400 cadences each.
 
-What the fixture is for: the gradient with respect to the oscillation rate d of a
+What the fixture is for (docs/DESIGN_r1_r4.md section 3.5): the gradient with respect to the oscillation rate d of a
 complex term used to carry the whole conditioning tail (exo_celerite_core.hpp, phase_flux) -- and it depended on the ORIGIN of
 the time axis.  The dense definition sees time differences only, so the same values hold for t + 2457000 (BJD-style stamps): the
 tests evaluate both (the stamps sit on a 2^-20 d grid, so that the shift is exact).

@@ -1176,7 +1176,7 @@ def celerite_matrices(t, diag, coeffs):
 
 # ------------------------------------------------------------------------------------------
 # The same log-likelihood in parallel over time (restates exoplanet_amd/csrc/exo_celerite.hip,
-# second half).  The recurrences are a Kalman filter: with a symmetric Delta_n such
+# second half; docs/DESIGN_r1_r4.md 3.5).  The recurrences are a Kalman filter: with a symmetric Delta_n such
 # that Delta_n U_n = V_n,  P_n = Delta_n - S_n  is the one-step prediction covariance and F_n its
 # mean.  A run of cadences acts on the entering (F, P) as a filtering element (A, b, C, eta, J) of
 # Sarkka & Garcia-Fernandez (2021, IEEE TAC 66, "Temporal parallelization of Bayesian smoothers"):

@@ -395,7 +395,7 @@ def test_library_keeps_nothing_between_calls(dev):
 def test_robust_route_whole_batch(dev, name, D, C, N):
     """EVERY draw of the batch above the trees' conditioning thresholds (a signal 3e3 .. 3e4 x the error bars: scores of 1e7 ..
     9e8 / 10 -- under the robust route's 1e8): Newton iterations on the entering states and the adjoint inputs from the chunks' own recurrences
-     for a number of draws that fills no block evenly, state widths 2, 5 and 6, forced chunk counts down to two --
+    (docs/DESIGN_r1_r4.md 3.11) for a number of draws that fills no block evenly, state widths 2, 5 and 6, forced chunk counts down to two --
     against the sequential kernels, which since round 4 carry the oscillation-rate gradient as a phase flux too"""
     rng = np.random.default_rng(21)
     t = np.sort(rng.uniform(0, 80 * N / 2100, N))      # (the last two cases: hundreds of chunks -- the depth of the trees whose states the

@@ -361,7 +361,7 @@ def test_c5_timed_step_vs_oracle(dev, D, bright):
     draws): 65 000 long cadences x 7 sub-exposures, transit + occultation, three SHO terms (J = 6).  The light curve of
     EVERY chain against the C port; the replayed step's log-likelihood and all 10 leaf gradients for 8 chains.
     bright = 2: `extras.c5_128_chains_1pct_bright_star_kappa_1e6` -- chains 0 and 1 at a conditioning score of 1e6, finished by
-    the ROBUST route of the time-parallel path at the benchmark's own size: 512 chunks, the serial forward
+    the ROBUST route of the time-parallel path (docs/DESIGN_r1_r4.md 3.11) at the benchmark's own size: 512 chunks, the serial forward
     chain, the adjoint inputs from the chunks' own recurrences -- both among the chains checked"""
     import bench
     import exoplanet_amd as xo

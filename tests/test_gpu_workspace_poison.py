@@ -69,6 +69,7 @@ def _step(xo, dev, D, N, which, route, seed, sigma_scale=None):
     leaves = list(P.values()) + [r, yerr] + kl
     g = torch.autograd.grad(ll.sum(), leaves)
     torch.cuda.synchronize()
+    ops.release_sorted(t)
     return ll.detach().cpu().numpy(), [x.cpu().numpy() for x in g]
 
 

@@ -188,7 +188,7 @@ def test_reference_properties_on_oracle():
 
 # ---------------------------------------------------------------------------------------------
 # celerite in parallel over time: the numpy restatement of the algorithm the HIP kernels run
-# (oracle/numpy_port.py) against the sequential recurrence and the dense definition
+# (oracle/numpy_port.py, docs/DESIGN_r1_r4.md 3.5) against the sequential recurrence and the dense definition
 # ---------------------------------------------------------------------------------------------
 def _gp_case(rng, N=180):
     t = np.sort(rng.uniform(0, 30, N))
