@@ -553,10 +553,12 @@ EXO_HD void quad_sv(double b, double r, SV& o) {
 
 
 // Zeros before an accumulation / a scan's seed: a KERNEL, never hipMemsetAsync.  Inside a captured step a memset becomes a
-// memset node of the hipGraph, and on ROCm 7.2 (gfx950) the kernel node after it can start before the fill has landed:
-// round 5, the adjoint scan of the celerite reverse pass read the FORWARD scan's seed at the same address in every other
-// word, once in a few thousand replays (tests/test_gpu_inject_recover.py: a sampler's odd chains collapsed).  A kernel node
-// is ordered like every other launch of the stream.
+// memset node of the hipGraph, and on ROCm 7.2 (gfx950) such a node stops filling with its value once the process has issued
+// enough EAGER device-to-device copies between replays (the runtime's own blit kernels): from then on, every replay, it writes
+// garbage -- pointer-like bits -- instead of zeros (tools/graph_node_order.py reproduces it with torch ops alone: correct for
+// ~4700 replays, wrong ever after; memcpy nodes and kernel nodes are not affected).  Round 5: the adjoint scan of the celerite
+// reverse pass was seeded by such a node; in a NUTS run (eager copies between the leaves) the coefficient gradients of every other
+// draw became garbage after ~1000 leaves and the chains' step sizes collapsed (tests/test_gpu_inject_recover.py).
 #ifndef EXO_HOST_BUILD
 static __global__ __launch_bounds__(256) void zero_fill_kernel(double* __restrict__ p, int64_t n) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;

@@ -162,9 +162,10 @@ def test_round_two_entry_points_reject_bad_arguments(lib):
 
 
 def test_no_memset_or_copy_nodes_in_the_library():
-    """Every entry point may be captured into a hipGraph (exoplanet_amd/graph.py).  hipMemsetAsync / hipMemcpyAsync would
-    become memset / copy nodes there, and on ROCm 7.2 the kernel node after a memset node can start before the fill has landed
-    (round 5: exo_math.hpp, zero_fill_async).  Zeros come from a kernel; nothing in csrc/ enqueues anything but kernels."""
+    """Every entry point may be captured into a hipGraph (exoplanet_amd/graph.py).  hipMemsetAsync would become a memset node
+    there, and on ROCm 7.2 a memset node fills with garbage once the process has issued enough eager device-to-device copies
+    between replays (round 5: exo_math.hpp, zero_fill_async; tools/graph_node_order.py reproduces it).  Zeros come from a kernel;
+    nothing in csrc/ enqueues anything but kernels (copy nodes measured fine, kept out all the same)."""
     import glob
 
     csrc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "exoplanet_amd", "csrc")

@@ -1,4 +1,4 @@
-"""torch / library kernels of one eager C2 step (bench.step), by name and count: python tools/which_ops.py"""
+"""torch / library kernels of one eager bench step, by name and count: python tools/which_ops.py [c2|c3|c4|c5] [draws]"""
 import os
 import sys
 
@@ -10,7 +10,8 @@ import exoplanet_amd as xo  # noqa: E402
 from exoplanet_amd import ops  # noqa: E402
 
 dev = torch.device("cuda:0")
-wl = bench.workload_c2(xo, ops, dev, 256)
+which = sys.argv[1] if len(sys.argv) > 1 else "c2"
+wl = bench.WORKLOADS[which](xo, ops, dev, int(sys.argv[2]) if len(sys.argv) > 2 else 256)
 for _ in range(3):
     wl.fn(*wl.leaves)
 torch.cuda.synchronize()
