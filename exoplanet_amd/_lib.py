@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # EXOPLANET_AMD_LIB selects another in-tree build of the same ABI (A/B measurements)
 LIB_PATH = os.environ.get("EXOPLANET_AMD_LIB") or os.path.join(_HERE, "lib", "libexoplanet_amd.so")
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 _c_dp = ctypes.c_void_p  # device pointers travel as integers
 _i64 = ctypes.c_int64
@@ -64,6 +64,7 @@ _SIGNATURES = {
     ),
     "exo_celerite_state_doubles": (_i64, [_i64, _i64, _i32, _i32, _i32]),
     "exo_celerite_default_chunks": (_i32, [_i64, _i64, _i32, _i32, _i32]),
+    "exo_sparse_model_order": (ctypes.c_int, [_c_dp, _i64, _c_dp, _c_dp]),
     # t, resid, diag, n_diag, n, coef_real, n_real, coef_complex, n_complex, pair_kind, n_draw, loglike, state,
     # state_doubles, n_chunks, stream
     "exo_celerite_loglike_fwd_f64": (

@@ -249,7 +249,7 @@ __global__ __launch_bounds__(kWave) void celerite_fwd_kernel(
   const double asum = group_sum<G>((k.live && !k.odd) ? k.a : 0.0);
   const StateIdx six{n, n_draw, J};
   const SeriesRow y(rs, draw, n);
-  const double* __restrict__ dg = diag + (n_diag == 1 ? 0 : draw * n);
+  const double* __restrict__ dg = diag + (n_diag == 1 ? 0 : cf.at(draw) * n);
 
   double Srow[J], Wall[J], Uall[J], Pall[J];
 #pragma unroll
@@ -369,7 +369,7 @@ __global__ __launch_bounds__(kWave) void celerite_fwd_kernel(
   if (mine && j == 0) {
     // not positive definite -> -inf in band (a sampler rejects the point)
     const double logdet = log(lman) + (double)lsum * 0.69314718055994530942;
-    loglike[draw] = bad ? -INFINITY : fma(-0.5, acc + logdet, -(double)n * kHalfLog2Pi);
+    loglike[cf.at(draw)] = bad ? -INFINITY : fma(-0.5, acc + logdet, -(double)n * kHalfLog2Pi);
   }
 }
 
@@ -394,7 +394,7 @@ __global__ __launch_bounds__(kWave) void celerite_vjp_kernel(
   const LaneCoef k = lane_coef(cf, draw, j, J);
   const int jj = k.live ? j : 0;  // idle lanes read a valid slot and contribute zeros
   const StateIdx six{n, n_draw, J};
-  const double gL = gloglike[draw];
+  const double gL = gloglike[cf.at(draw)];
   const bool lead = live_draw && j == 0;
   GradRow grow(gresid, rs, draw, n);
   // the other state index of this lane's complex pair (itself for real terms / idle lanes)
@@ -483,7 +483,7 @@ __global__ __launch_bounds__(kWave) void celerite_vjp_kernel(
     const double dbar = db + gL * (0.5 * z_n * z_n * id * id - 0.5 * id) - wdot * id;
     if (lead) {
       grow.store(i, gsign * zbar);
-      if (gdiag) gdiag[draw * n + i] = dbar;
+      if (gdiag) gdiag[cf.at(draw) * n + i] = dbar;
     }
     gasum += dbar;
     double Ub = -zbar * F_n;
@@ -578,7 +578,7 @@ __global__ __launch_bounds__(kWave) void celerite_vjp_kernel(
     const double dbar = db + gL * (0.5 * z_n * z_n * id * id - 0.5 * id) - wdot * id;
     if (lead) {
       grow.store(0, gsign * zbar);
-      if (gdiag) gdiag[draw * n] = dbar;
+      if (gdiag) gdiag[cf.at(draw) * n] = dbar;
     }
     gasum += dbar;
     // (cadence 0's phase cotangent has no link in front of it -- the phases are counted from t_0, Coefs::origin -- and its
@@ -587,14 +587,14 @@ __global__ __launch_bounds__(kWave) void celerite_vjp_kernel(
   // the decay rate of a complex pair is shared by its two state indices
   const double gc_o = __shfl(gc, partner, 64);
   if (!live_draw || !k.live) return;
-  if (j == 0 && gdiag_sum) gdiag_sum[draw] = gasum;
+  if (j == 0 && gdiag_sum) gdiag_sum[cf.at(draw)] = gasum;
   if (k.real) {
     // a real term of its own, or one of the two real terms of a pair slot (kind 1)
-    double* o = k.slot < 0 ? gcoef_real + (draw * cf.n_real + j) * 2 : gcoef_complex + draw * cf.n_complex * 4 + k.slot;
+    double* o = k.slot < 0 ? gcoef_real + (cf.at(draw) * cf.n_real + j) * 2 : gcoef_complex + cf.at(draw) * cf.n_complex * 4 + k.slot;
     o[0] = ga + gasum;  // a_n = diag_n + sum a
     o[1] = gc;
   } else if (!k.odd) {
-    double* o = gcoef_complex + (draw * cf.n_complex + ((j - cf.n_real) >> 1)) * 4;
+    double* o = gcoef_complex + (cf.at(draw) * cf.n_complex + ((j - cf.n_real) >> 1)) * 4;
     o[0] = ga + gasum;
     o[1] = gb;
     o[2] = gc + gc_o;
@@ -725,7 +725,7 @@ __global__ __launch_bounds__(kWave) void celerite_elem_lg_kernel(
   const ChunkWs ws = chunk_ws(n, n_draw, J, cg);
   const LaneDelta ld(k);
   const SeriesRow y(rs, draw, n);
-  const double* __restrict__ dg = diag + (n_diag == 1 ? 0 : draw * n);
+  const double* __restrict__ dg = diag + (n_diag == 1 ? 0 : cf.at(draw) * n);
   // conditioning score (see celerite_elem_kernel)
   const double asum = group_sum<G>((live && !k.odd) ? fabs(k.a) : 0.0);
   double ba2 = (live && !k.real && !k.odd) ? (k.b * k.b) / (k.a * k.a) : 0.0;
@@ -825,7 +825,7 @@ __global__ __launch_bounds__(kWave) void celerite_chunk_fwd_kernel(
   const StateIdx six{n, n_draw, J};
   const ChunkWs ws = chunk_ws(n, n_draw, J, cg);
   const SeriesRow y(rs, draw, n);
-  const double* __restrict__ dg = diag + (n_diag == 1 ? 0 : draw * n);
+  const double* __restrict__ dg = diag + (n_diag == 1 ? 0 : cf.at(draw) * n);
   const int jj = k.live ? j : 0;
 
   double Srow[J], Wall[J], Uall[J], Pall[J];
@@ -923,7 +923,7 @@ __global__ __launch_bounds__(kWave) void celerite_chunk_vjp_kernel(
   const int jj = k.live ? j : 0;
   const StateIdx six{n, n_draw, J};
   const ChunkWs ws = chunk_ws(n, n_draw, J, cg);
-  const double gL = gloglike[draw];
+  const double gL = gloglike[cf.at(draw)];
   const int partner = (int)threadIdx.x + ((k.live && !k.real) ? (k.odd ? -1 : 1) : 0);
   GradRow grow(gresid, rs, draw, n);
 
@@ -1041,7 +1041,7 @@ __global__ __launch_bounds__(kWave) void celerite_chunk_vjp_kernel(
         for (int q = 0; q < kPer; ++q)
           if ((have >> q) & 1u) {
             if (!gcm) gresid[at + q] = gsign * buf_r[q];
-            if (gdiag) gdiag[at + q] = buf_d[q];
+            if (gdiag) gdiag[at + q + (cf.at(draw) - draw) * n] = buf_d[q];
           }
         have = 0u;
       }
@@ -1419,6 +1419,41 @@ __global__ __launch_bounds__(256) void celerite_sparse_order_kernel(SparseSegs s
     __syncthreads();
   }
 }
+// the order of the draws of a sparse model by the spacing of their segments (exo_sparse_model_order)
+constexpr int kOrderMaxDraws = EXO_SPARSE_ORDER_MAX_DRAWS;
+__global__ __launch_bounds__(1024) void celerite_draw_order_kernel(SparseSegs sp, int64_t n_draw, int32_t* __restrict__ order) {
+  __shared__ double s_key[kOrderMaxDraws];
+  __shared__ int s_idx[kOrderMaxDraws];
+  int M = 1;
+  while (M < n_draw) M <<= 1;
+  for (int i = threadIdx.x; i < M; i += 1024) {
+    double key = INFINITY;
+    if (i < n_draw) {
+      const int32_t* sg = sp.seg + (int64_t)i * sp.seg_row;
+      const int ns = sp.nseg[i];
+      const double first = ns > 0 ? (double)sg[0] : 0.0;
+      const double last = ns > 0 ? (double)sg[(int64_t)(ns - 1) * sp.seg_step] : 0.0;
+      key = (last - first) / (double)(ns > 1 ? ns - 1 : 1) + 1e-9 * first;
+    }
+    s_key[i] = key;
+    s_idx[i] = i;
+  }
+  __syncthreads();
+  for (int k = 2; k <= M; k <<= 1)
+    for (int j = k >> 1; j >= 1; j >>= 1) {
+      for (int i = threadIdx.x; i < M; i += 1024) {
+        const int p = i ^ j;
+        if (p > i) {
+          const double ka = s_key[i], kb = s_key[p];
+          const int ia = s_idx[i], ib = s_idx[p];
+          const bool a_after_b = ka > kb || (ka == kb && ia > ib);
+          if (a_after_b == ((i & k) == 0)) { s_key[i] = kb; s_key[p] = ka; s_idx[i] = ib; s_idx[p] = ia; }
+        }
+      }
+      __syncthreads();
+    }
+  for (int i = threadIdx.x; i < n_draw; i += 1024) order[i] = s_idx[i];
+}
 // (A) the filtering element of every (draw, chunk)
 template <int J, int NR, int SP>
 __global__ __launch_bounds__(kWave, (J <= 2 ? EXO_ELEM_MIXED_WAVES : (split_layouts(J) && NR == 0 ? EXO_J4_WAVES : 1))) void celerite_elem_kernel(const double* __restrict__ t, Series rs,
@@ -1439,10 +1474,10 @@ __global__ __launch_bounds__(kWave, (J <= 2 ? EXO_ELEM_MIXED_WAVES : (split_layo
 template <int J>
 __global__ __launch_bounds__(kWave) void celerite_badj_prep_kernel(const double* __restrict__ gloglike, int64_t n,
                                                                    int64_t n_draw, double* __restrict__ state,
-                                                                   ChunkGeom cg) {
+                                                                   ChunkGeom cg, const int32_t* __restrict__ row) {
   const int64_t draw = (int64_t)blockIdx.x * kWave + threadIdx.x;
   if (draw >= n_draw) return;
-  badj_prep_lane<J>(gloglike, n, n_draw, state, cg, draw, (int)blockIdx.y + 1);
+  badj_prep_lane<J>(gloglike, n, n_draw, state, cg, draw, (int)blockIdx.y + 1, row);
 }
 
 // (C) / (C') with a checkpointed factorisation, J <= kLaneMaxJ
@@ -1665,7 +1700,7 @@ __global__ __launch_bounds__(kWave) void celerite_chunk_slice_sum_kernel(double*
 // the log-likelihood of a draw from the slices' partial sums
 __global__ __launch_bounds__(kWave) void celerite_chunk_loglike_kernel(int64_t n, int64_t n_draw, int J,
                                                                        const double* __restrict__ state, ChunkGeom cg, int S,
-                                                                       double* __restrict__ loglike) {
+                                                                       double* __restrict__ loglike, const int32_t* __restrict__ row) {
   const int64_t draw = (int64_t)blockIdx.x * kWave + threadIdx.x;
   if (draw >= n_draw) return;
   const ChunkWs ws = chunk_ws(n, n_draw, J, cg);
@@ -1675,7 +1710,7 @@ __global__ __launch_bounds__(kWave) void celerite_chunk_loglike_kernel(int64_t n
     logdet += state[ws.part(s, 1, draw)];
     bad += state[ws.part(s, 2, draw)];
   }
-  loglike[draw] = (bad > 0.0) ? -INFINITY : fma(-0.5, acc + logdet, -(double)n * kHalfLog2Pi);
+  loglike[row ? (int64_t)row[draw] : draw] = (bad > 0.0) ? -INFINITY : fma(-0.5, acc + logdet, -(double)n * kHalfLog2Pi);
 }
 
 // step 2: the same combination as the tail of celerite_vjp_kernel
@@ -1840,15 +1875,15 @@ __device__ __forceinline__ int64_t mixed_draw(const double* __restrict__ state, 
   const int32_t* __restrict__ perm = reinterpret_cast<const int32_t*>(state + ws.off_perm());
   return perm[(int64_t)blockIdx.x * kWave + threadIdx.x];      // (the launches cover ws.perm_lanes() lanes)
 }
-__global__ __launch_bounds__(1024) void celerite_kind_partition_kernel(const int32_t* __restrict__ kind, int64_t n_draw,
-                                                                       int32_t* __restrict__ perm, int64_t lanes) {
+__global__ __launch_bounds__(1024) void celerite_kind_partition_kernel(const int32_t* __restrict__ kind, const int32_t* __restrict__ row,
+                                                                       int64_t n_draw, int32_t* __restrict__ perm, int64_t lanes) {
   __shared__ int s_cnt[2][16];
   __shared__ int s_base[2];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   for (int64_t i = tid; i < lanes; i += 1024) perm[i] = -1;
   // the complex-term draws: how many
   int mine = 0;
-  for (int64_t d = tid; d < n_draw; d += 1024) mine += kind[d] == 0 ? 1 : 0;
+  for (int64_t d = tid; d < n_draw; d += 1024) mine += kind[row ? row[d] : d] == 0 ? 1 : 0;
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) mine += __shfl_xor(mine, m, 64);
   if (lane == 0) s_cnt[0][wave] = mine;
@@ -1860,7 +1895,7 @@ __global__ __launch_bounds__(1024) void celerite_kind_partition_kernel(const int
   __syncthreads();
   for (int64_t d0 = 0; d0 < n_draw; d0 += 1024) {
     const int64_t d = d0 + tid;
-    const int k = d < n_draw ? (kind[d] == 0 ? 0 : 1) : -1;
+    const int k = d < n_draw ? (kind[row ? row[d] : d] == 0 ? 0 : 1) : -1;
     const unsigned long long m0 = __ballot(k == 0), m1 = __ballot(k == 1), below = (1ull << lane) - 1ull;
     if (lane == 0) { s_cnt[0][wave] = __popcll(m0); s_cnt[1][wave] = __popcll(m1); }
     __syncthreads();
@@ -2014,7 +2049,7 @@ static int celerite_fwd(const double* t, Series resid, const double* diag, int64
       const int64_t flag_at = ws.off_flag();
       const dim3 egrid_f(per_draw.x, (unsigned)cge.C), cgrid_f(grid.x, (unsigned)cge.C);
       if (J == 2 && cf.n_real == 0 && cf.kind && EXO_GP_MIXED_ONE_LAUNCH)   // per-draw pair kinds: no wave of mixed kinds (mixed_draw)
-        hipLaunchKernelGGL(celerite_kind_partition_kernel, dim3(1), dim3(1024), 0, st, cf.kind, n_draw,
+        hipLaunchKernelGGL(celerite_kind_partition_kernel, dim3(1), dim3(1024), 0, st, cf.kind, cf.row, n_draw,
                            reinterpret_cast<int32_t*>(state + ws.off_perm()), ws.perm_lanes());
       if (resid.sp.nseg && cg.lane)   // sparse model: the order in which the one-lane kernels' blocks take the chunks (chunk_of_block)
         hipLaunchKernelGGL(celerite_sparse_order_kernel, dim3(1), dim3(256), 0, st, resid.sp, n, n_draw, cg,
@@ -2117,7 +2152,7 @@ static int celerite_fwd(const double* t, Series resid, const double* diag, int64
         const int S = chunk_sum_slices(cg.C, 3, n_draw, 16);   // (the last kernel's lanes add the S partials themselves)
         hipLaunchKernelGGL(celerite_chunk_slice_sum_kernel, dim3(per_draw.x, 3, (unsigned)S), block, 0, st, state + ws.off_part(), 3,
                            cg.C, S, n_draw);
-        hipLaunchKernelGGL(celerite_chunk_loglike_kernel, per_draw, block, 0, st, n, n_draw, J, state, cg, S, loglike);
+        hipLaunchKernelGGL(celerite_chunk_loglike_kernel, per_draw, block, 0, st, n, n_draw, J, state, cg, S, loglike, cf.row);
       }
       if (launch_status() != EXO_OK) return EXO_ERR_LAUNCH;
       only_flagged = state + ws.off_flag();
@@ -2155,7 +2190,7 @@ static int celerite_vjp(const double* t, Series resid, const double* diag, int64
     const dim3 per_draw((unsigned)((n_draw + kWave - 1) / kWave)), cgrid(grid.x, (unsigned)cg.C),
         egrid(per_draw.x, (unsigned)cg.C);
     EXO_GP_DISPATCH(J, hipLaunchKernelGGL((celerite_badj_prep_kernel<JJ>), dim3(per_draw.x, (unsigned)(cg.C - 1)), block,
-                                          0, st, gloglike, n, n_draw, wstate, cg))
+                                          0, st, gloglike, n, n_draw, wstate, cg, cf.row))
     if (cg.lane) {
       // draws flagged kFlagRobust: those inputs once more, from the chunks' own reverse recurrences (chunk_adj_lane)
       EXO_GP_DISPATCH_LANE(J, hipLaunchKernelGGL((celerite_chunk_adj_kernel<JJ>), dim3((unsigned)(cg.C - 1), (unsigned)((n_draw + kAdjDraws - 1) / kAdjDraws)), block, 0,
@@ -2323,8 +2358,9 @@ int exo_celerite_loglike_sparse_fwd_f64(const double* t, const double* obs, cons
   if (n_draw == 0) return EXO_OK;
   Series rs{};
   if (!sparse_series(model, obs, n, &rs)) return EXO_ERR_INVALID_ARGUMENT;
-  return celerite_fwd(t, rs, diag, n_diag, n, Coefs{coef_real, coef_complex, pair_kind, n_real, n_complex}, n_draw, loglike,
-                      state, state_doubles, n_chunks, stream);
+  Coefs cf{coef_real, coef_complex, pair_kind, n_real, n_complex};
+  cf.row = model->row_of_draw;     // (every per-draw array of the call in the caller's order: Coefs::row)
+  return celerite_fwd(t, rs, diag, n_diag, n, cf, n_draw, loglike, state, state_doubles, n_chunks, stream);
 }
 
 int exo_celerite_loglike_sparse_vjp_f64(const double* t, const double* obs, const exo_sparse_model* model, const double* diag,
@@ -2336,8 +2372,24 @@ int exo_celerite_loglike_sparse_vjp_f64(const double* t, const double* obs, cons
   if (n_draw == 0) return EXO_OK;
   Series rs{};
   if (!sparse_series(model, obs, n, &rs)) return EXO_ERR_INVALID_ARGUMENT;
-  return celerite_vjp(t, rs, diag, n_diag, n, Coefs{coef_real, coef_complex, pair_kind, n_real, n_complex}, n_draw, gloglike,
-                      state, state_doubles, n_chunks, gvals, -1.0, gdiag, gdiag_sum, gcoef_real, gcoef_complex, stream);
+  Coefs cf{coef_real, coef_complex, pair_kind, n_real, n_complex};
+  cf.row = model->row_of_draw;
+  return celerite_vjp(t, rs, diag, n_diag, n, cf, n_draw, gloglike, state, state_doubles, n_chunks, gvals, -1.0, gdiag, gdiag_sum,
+                      gcoef_real, gcoef_complex, stream);
+}
+
+// The order in which a sparse model's draws are best handed to the celerite kernels (exo_sparse_model.row_of_draw): ascending
+// mean spacing of a draw's segments -- the period, in cadences: draws with neighbouring periods keep their transits together all
+// along the series -- the start of the first segment breaking ties (draws with fewer than two segments: by that alone), then the
+// draw's index.  One block: keys into LDS, a bitonic sort of (key, index) pairs.  Up to kOrderMaxDraws draws.
+int exo_sparse_model_order(const exo_sparse_model* model, int64_t n_draw, int32_t* order, void* stream) {
+  if (n_draw == 0) return EXO_OK;
+  if (!model || !order || !model->nseg || !model->seg || model->seg_step < 1 || n_draw < 0 || n_draw > kOrderMaxDraws)
+    return EXO_ERR_INVALID_ARGUMENT;
+  SparseSegs sp{};
+  sp.nseg = model->nseg; sp.seg = model->seg; sp.seg_row = model->seg_row; sp.seg_step = model->seg_step; sp.hi_at = model->hi_at;
+  hipLaunchKernelGGL(celerite_draw_order_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, sp, n_draw, order);
+  return launch_status();
 }
 
 int exo_celerite_dot_tril_f64(const double* t, const double* diag, int64_t n_diag, int64_t n, const double* coef_real,

@@ -59,7 +59,12 @@ struct Coefs {
   // has lost nine digits before the cosine is taken (round 4: the entry points point this at the series' first time stamp;
   // every kernel of a call reads the same one, the states they exchange live in the same rotating frame)
   const double* origin = nullptr;
+  // NULL, or [n_draw]: the kernels' draw d is row row[d] of every per-draw array of the CALL -- coefficients, pair kinds, per-draw
+  // diag, loglike, gloglike and the cotangents written back (round 5: exo_sparse_model.row_of_draw; the sparse entries hand the
+  // draws over sorted by transit timing without the caller permuting anything).  State and workspace are indexed by d itself.
+  const int32_t* row = nullptr;
   EXO_HDH int J() const { return n_real + 2 * n_complex; }
+  EXO_HDH int64_t at(int64_t draw) const { return row ? (int64_t)row[draw] : draw; }
 };
 
 // per-state-index view: state index j of a real term (a, c) or of a complex pair (a, b, c, d);
@@ -82,16 +87,16 @@ EXO_HD LaneCoef lane_coef(const Coefs& co, int64_t draw, int j, int J) {
   k.t0 = co.origin ? *co.origin : 0.0;
   if (!k.live) return k;
   if (k.real) {
-    const double* p = co.real + (draw * co.n_real + j) * 2;
+    const double* p = co.real + (co.at(draw) * co.n_real + j) * 2;
     k.a = p[0]; k.c = p[1];
   } else {
     const int jc = (j - co.n_real) >> 1, second = (j - co.n_real) & 1;
-    const double* p = co.cplx + (draw * co.n_complex + jc) * 4;
+    const double* p = co.cplx + (co.at(draw) * co.n_complex + jc) * 4;
     // the slot's four doubles are loaded whatever its kind and SELECTED afterwards: the kind varies
     // from lane to lane, and loads through a pointer chosen inside that divergent branch were
     // miscompiled by hipcc 7.2 for gfx950 (address register left undefined for one side)
     const double p0 = p[0], p1 = p[1], p2 = p[2], p3 = p[3];
-    const int kd = co.kind ? co.kind[draw * co.n_complex + jc] : 0;
+    const int kd = co.kind ? co.kind[co.at(draw) * co.n_complex + jc] : 0;
     const bool two_real = kd != 0;
     k.real = two_real;
     k.a = two_real ? (second ? p2 : p0) : p0;
@@ -788,7 +793,7 @@ template <int J>
 EXO_HD int layout_vote(const Coefs& cf, int64_t draw) {
   if (J == 1) return 1;
   if (J == 2) {
-    const bool rr = cf.n_real == 2 || (cf.kind != nullptr && cf.kind[draw] != 0);   // (n_complex = 1: one slot per draw)
+    const bool rr = cf.n_real == 2 || (cf.kind != nullptr && cf.kind[cf.at(draw)] != 0);   // (n_complex = 1: one slot per draw)
     if (EXO_WAVE_ALL(!rr)) return 0;
     if (EXO_WAVE_ALL(rr)) return 2;
   }
@@ -798,7 +803,7 @@ EXO_HD int layout_vote(const Coefs& cf, int64_t draw) {
     // the run-time layout are a quarter of the instructions of the J = 6 kernels
     bool allc = true;
     if (cf.kind != nullptr)
-      for (int q = 0; q < J / 2; ++q) allc = allc && (cf.kind[draw * (J / 2) + q] == 0);
+      for (int q = 0; q < J / 2; ++q) allc = allc && (cf.kind[cf.at(draw) * (J / 2) + q] == 0);
     if (EXO_WAVE_ALL(allc)) return 0;
   }
   return -1;
@@ -839,7 +844,7 @@ EXO_HD void elem_lane(const double* EXO_RESTRICT t, Series rs, const double* EXO
   DrawCoef<J, NR> co;
   co.init(cf, draw);
   const SeriesRowT<true, SP> y(rs, draw, n);
-  const double* EXO_RESTRICT dg = diag + (n_diag == 1 ? 0 : draw * n);
+  const double* EXO_RESTRICT dg = diag + (n_diag == 1 ? 0 : cf.at(draw) * n);
   double A[J][J], b[J], eta[J];
   Sym<J> Cm, Jm, Dl;
 #pragma unroll
@@ -1167,9 +1172,9 @@ EXO_HD void bscan_lane(const double* EXO_RESTRICT t, const Coefs& cf, int64_t n,
 // written over the chunk's element (A <- Abar, b <- g, eta <- local Fbar, Cm <- local Pbar).
 template <int J>
 EXO_HD void badj_prep_lane(const double* EXO_RESTRICT gloglike, int64_t n, int64_t n_draw, double* EXO_RESTRICT state,
-                           const ChunkGeom& cg, int64_t draw, int c) {
+                           const ChunkGeom& cg, int64_t draw, int c, const int32_t* row = nullptr) {
   const ChunkWs ws = chunk_ws(n, n_draw, J, cg);
-  const double gL = gloglike[draw];
+  const double gL = gloglike[row ? (int64_t)row[draw] : draw];
   Elem<J> el;
   el.load(state, ws, c, draw);
   double m[J], P[J][J];
@@ -1868,7 +1873,7 @@ EXO_HD void chunk1_fwd_lane(const double* EXO_RESTRICT t, Series rs, const doubl
   co.init(cf, draw);
   const double asum = co.asum();
   const SeriesRowT<true, SP> y(rs, draw, n);
-  const double* EXO_RESTRICT dg = diag + (n_diag == 1 ? 0 : draw * n);
+  const double* EXO_RESTRICT dg = diag + (n_diag == 1 ? 0 : cf.at(draw) * n);
   Fwd<J> f;
 #pragma unroll
   for (int j = 0; j < J; ++j) { f.U[j] = f.V[j] = f.W[j] = 0.0; }
@@ -2103,8 +2108,8 @@ EXO_HD void chunk1_vjp_lane(const double* EXO_RESTRICT t, Series rs, const doubl
   const double asum = co.asum();
   const SeriesRowT<false, SP> y(rs, draw, n);
   GradRowT<SP> grow(gresid, rs, draw, n);
-  const double* EXO_RESTRICT dg = diag + (n_diag == 1 ? 0 : draw * n);
-  const double gL = gloglike[draw];
+  const double* EXO_RESTRICT dg = diag + (n_diag == 1 ? 0 : cf.at(draw) * n);
+  const double gL = gloglike[cf.at(draw)];
   Rev<J, NR> r;
   const bool from_next = EXO_GP_POLISH && polish && n1 < n;
 #pragma unroll
@@ -2259,7 +2264,7 @@ EXO_HD void chunk1_vjp_lane(const double* EXO_RESTRICT t, Series rs, const doubl
 #pragma unroll
     for (int q = 0; q < kCkptB; ++q) zbar[q] *= gsign;
     grow.store4(b0, len, zbar);
-    if (gdiag) row_store4(gdiag + draw * n, b0, len, dbar);
+    if (gdiag) row_store4(gdiag + cf.at(draw) * n, b0, len, dbar);
     cur = nxt;
 #pragma unroll
     for (int k = 0; k < kK; ++k) ck[k] = ck_nxt[k];
@@ -2420,8 +2425,8 @@ EXO_HD void chunkp_vjp_lane(const double* EXO_RESTRICT t, Series rs, const doubl
   const double asum = co.asum();
   const SeriesRowT<false, SP> y(rs, draw, n);
   GradRowT<SP> grow(gresid, rs, draw, n);
-  const double* EXO_RESTRICT dg = diag + (n_diag == 1 ? 0 : draw * n);
-  const double gL = gloglike[draw];
+  const double* EXO_RESTRICT dg = diag + (n_diag == 1 ? 0 : cf.at(draw) * n);
+  const double gL = gloglike[cf.at(draw)];
   RevP<J, NR> r;
   const bool from_next = EXO_GP_POLISH && polish && n1 < n;   // (polish: entered with what the next chunk's reverse recurrences left, chunk1_fwd_lane)
 #pragma unroll
@@ -2593,7 +2598,7 @@ EXO_HD void chunkp_vjp_lane(const double* EXO_RESTRICT t, Series rs, const doubl
 #pragma unroll
     for (int q = 0; q < kCkptB; ++q) zbar[q] *= gsign;
     grow.store4(b0, len, zbar);
-    if (gdiag) row_store4(gdiag + draw * n, b0, len, dbar);
+    if (gdiag) row_store4(gdiag + cf.at(draw) * n, b0, len, dbar);
     cur = nxt;
     if (kAhead) {
 #pragma unroll
@@ -2649,8 +2654,8 @@ EXO_HD void chunk_adj_lane(const double* EXO_RESTRICT t, Series rs, const double
   co.init(cf, draw);
   const double asum = co.asum();
   const SeriesRowDesc y(rs, draw, n);
-  const double* EXO_RESTRICT dg = diag + (n_diag == 1 ? 0 : draw * n);
-  const double gL = gloglike[draw];
+  const double* EXO_RESTRICT dg = diag + (n_diag == 1 ? 0 : cf.at(draw) * n);
+  const double gL = gloglike[cf.at(draw)];
   constexpr bool all = ALL;
   const bool do_state = all || role == 0, is_R = all || role == J + 1, do_vec = all || role != 0;
   RevP<J, NR, true> r;
@@ -2921,7 +2926,7 @@ EXO_HD void dot_tril_lane(const double* EXO_RESTRICT t, const double* EXO_RESTRI
   DrawCoef<J> co;
   co.init(cf, draw);
   const double asum = co.asum();
-  const double* EXO_RESTRICT dg = diag + (n_diag == 1 ? 0 : draw * n);
+  const double* EXO_RESTRICT dg = diag + (n_diag == 1 ? 0 : cf.at(draw) * n);
   const double* EXO_RESTRICT xr = x + draw * n;
   double* EXO_RESTRICT zr = z + draw * n;
   Fwd<J> f;
@@ -3037,14 +3042,14 @@ EXO_HD void gcoef_lane(const Coefs& cf, int64_t n, int64_t n_draw, const double*
     return v;
   };
   const double gasum = total(4 * J);
-  if (j == 0 && gdiag_sum) gdiag_sum[draw] = gasum;
+  if (j == 0 && gdiag_sum) gdiag_sum[cf.at(draw)] = gasum;
   const double ga = total(4 * j), gc = total(4 * j + 2);
   if (k.real) {
-    double* o = k.slot < 0 ? gcoef_real + (draw * cf.n_real + j) * 2 : gcoef_complex + draw * cf.n_complex * 4 + k.slot;
+    double* o = k.slot < 0 ? gcoef_real + (cf.at(draw) * cf.n_real + j) * 2 : gcoef_complex + cf.at(draw) * cf.n_complex * 4 + k.slot;
     o[0] = ga + gasum;  // a_n = diag_n + sum a
     o[1] = gc;
   } else if (!k.odd) {
-    double* o = gcoef_complex + (draw * cf.n_complex + ((j - cf.n_real) >> 1)) * 4;
+    double* o = gcoef_complex + (cf.at(draw) * cf.n_complex + ((j - cf.n_real) >> 1)) * 4;
     o[0] = ga + gasum;
     o[1] = total(4 * j + 1);
     o[2] = gc + total(4 * (j + 1) + 2);   // the decay rate is shared by the pair's two indices

@@ -141,15 +141,29 @@ def _transit_order(sp):
     """int32 (D,): the draws of a sparse light curve in the order of the mean spacing of their segments -- the period, in
     cadences: draws with neighbouring periods keep their transits together all along the series, wherever the reference
     transit time lies -- with the start of the first segment breaking ties (draws with fewer than two segments: by that
-    alone).  torch ops on the runs, no host synchronisation (usable inside a captured step)."""
-    lay = sp.layout()
+    alone).  One launch of the library (exo_sparse_model_order); beyond its 4096 draws the same keys sorted by torch.  No host
+    synchronisation either way (usable inside a captured step)."""
+    import ctypes
+
     D = sp.n_draw
+    lib = _lib.load()
+    if D <= lib_max_order_draws():
+        order = torch.empty(D, dtype=torch.int32, device=sp.values.device)
+        model = sp.model_struct()
+        with torch.cuda.device(order.device):
+            _lib.check(lib.exo_sparse_model_order(ctypes.addressof(model), D, _ptr(order), _stream(order)), "exo_sparse_model_order")
+        return order
+    lay = sp.layout()
     nrun = lay.nrun.reshape(D).long()
     lo = lay.runs.reshape(D, lay.r_max, 4)[:, :, 0]
     first = lo[:, 0].double()
     last = lo.gather(1, (nrun - 1).clamp_min(0).unsqueeze(1)).squeeze(1).double()
     key = (last - first) / (nrun - 1).clamp_min(1).double() + 1e-9 * first
     return torch.argsort(key, stable=True).to(torch.int32)
+
+
+def lib_max_order_draws():
+    return 4096      # include/exoplanet_amd.h: EXO_SPARSE_ORDER_MAX_DRAWS
 
 
 class _CeleriteLogLikeSparse(torch.autograd.Function):
@@ -191,18 +205,10 @@ class _CeleriteLogLikeSparse(torch.autograd.Function):
             if need_grad:
                 raise
             state, nstate = None, 0
-        # The kernels' lane is a draw, and a wave pays for a transit while ANY of its 64 draws is inside one: hand the draws
-        # over sorted by the time of their LAST segment (draws with neighbouring periods keep their transits together all
-        # along the series) -- the small per-draw inputs permuted here, the model left where the sweep wrote it
-        # (exo_sparse_model.row_of_draw); loglike and the coefficient cotangents come back in that order and are put back.
+        # The kernels' lane is a draw, and a wave pays for a transit while ANY of its 64 draws is inside one: the kernels take the
+        # draws in the order of their periods (draws with neighbouring periods keep their transits together all along the series)
+        # -- exo_sparse_model.row_of_draw: every array stays in the caller's order, the library indexes through the table.
         perm = _transit_order(sp) if (D > 64 and _SORT_DRAWS[0]) else None
-        if perm is not None:
-            pl = perm.long()
-            coef_real, coef_complex = coef_real[pl].contiguous(), coef_complex[pl].contiguous()
-            if pair_kind is not None:
-                pair_kind = pair_kind[pl].contiguous()
-            if diag.shape[0] == D:
-                diag = diag[pl].contiguous()
         model = sp.model_struct()
         model.row_of_draw = _ptr(perm)
         with torch.cuda.device(t.device):
@@ -214,8 +220,6 @@ class _CeleriteLogLikeSparse(torch.autograd.Function):
             ctx.save_for_backward(t, vals, diag, coef_real, coef_complex, state, obs, pair_kind, perm)
             ctx.dims = (D, N, n_real, n_complex, nstate, n_chunks)
             ctx.sp = sp
-        if perm is not None:
-            loglike = torch.empty_like(loglike).index_copy_(0, perm.long(), loglike)
         return loglike
 
     @staticmethod
@@ -225,8 +229,6 @@ class _CeleriteLogLikeSparse(torch.autograd.Function):
         t, vals, diag, coef_real, coef_complex, state, obs, pair_kind, perm = ctx.saved_tensors
         D, N, n_real, n_complex, nstate, n_chunks = ctx.dims
         gll = _dev(gll, "gloglike")
-        if perm is not None:
-            gll = gll[perm.long()].contiguous()
         lib = _lib.load()
         # (positions no segment covers are never written and never read: the reverse sweep of the light curve walks the same runs)
         gvals = torch.empty_like(vals)
@@ -241,12 +243,6 @@ class _CeleriteLogLikeSparse(torch.autograd.Function):
                                                                n_complex, _ptr(pair_kind), D, _ptr(gll), _ptr(state), nstate,
                                                                n_chunks, _ptr(gvals), _ptr(gdiag), None, _ptr(gcr), _ptr(gcc),
                                                                _stream(t)), "exo_celerite_loglike_sparse_vjp_f64")
-        if perm is not None:     # back to the caller's order of the draws
-            pl = perm.long()
-            gcr = torch.empty_like(gcr).index_copy_(0, pl, gcr)
-            gcc = torch.empty_like(gcc).index_copy_(0, pl, gcc)
-            if want_diag and diag.shape[0] == D:     # (a shared diagonal's cotangent is summed over the draws: any order)
-                gdiag = torch.empty_like(gdiag).index_copy_(0, pl, gdiag)
         if want_diag and diag.shape[0] == 1:
             gdiag = gdiag.sum(0, keepdim=True)
         return None, gvals, gdiag, gcr, gcc, None, None, None, None

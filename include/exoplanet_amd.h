@@ -40,8 +40,10 @@ extern "C" {
  *     does not know are EXO_ERR_INVALID_ARGUMENT.
  * 11: the sparse model -- exo_sparse_model, exo_transit_flux_sparse_model, exo_transit_flux_vjp_sparse_f64,
  *     exo_celerite_loglike_sparse_{fwd,vjp}_f64, exo_celerite_default_chunks; EXO_FLAG_SPARSE accepted by the Jacobian pair;
- *     exo_transit_flux_cols_vjp_f64; EXO_GP_MAX_J 16; a larger exo_transit_flux_workspace_bytes. */
-#define EXO_ABI_VERSION 11
+ *     exo_transit_flux_cols_vjp_f64; EXO_GP_MAX_J 16; a larger exo_transit_flux_workspace_bytes.
+ * 12: exo_sparse_model.row_of_draw covers EVERY per-draw array of a sparse celerite call (coefficients, pair kinds, per-draw diag,
+ *     loglike, gloglike, the cotangents written back: all in the caller's order, nothing to permute); exo_sparse_model_order. */
+#define EXO_ABI_VERSION 12
 int32_t exo_abi_version(void);
 
 /* ---------------------------------------------------------------------------
@@ -198,15 +200,23 @@ typedef struct exo_sparse_model {
   const double* vals;
   int64_t seg_row, off_row, val_row;
   int32_t seg_step, hi_at;
-  const int32_t* row_of_draw;   /* NULL, or [n_draw]: draw d of the celerite call is row row_of_draw[d] of nseg / seg / off / vals
-                                   (and of gvals).  The kernels' lane is a draw and a wave pays for a transit while ANY of its 64
-                                   draws is inside one: a caller that passes the draws sorted by transit time (coefficients,
-                                   per-draw diag and gloglike in that order; loglike and the coefficient cotangents come back in
-                                   it) keeps a wave's transits together -- C3: 3.6 -> 3.3 ms -- and leaves the model where the
-                                   sweep wrote it.  exo_transit_flux_sparse_model sets it to NULL.                          */
+  const int32_t* row_of_draw;   /* NULL, or [n_draw], a permutation: the ORDER in which the celerite kernels take the draws -- their
+                                   draw d (a lane; 64 consecutive ones a wave) is row row_of_draw[d] of nseg / seg / off / vals / gvals
+                                   AND of every other per-draw array of the call: coefficients, pair kinds, a per-draw diag, loglike,
+                                   gloglike, gcoef_*, gdiag, gdiag_sum.  All arrays stay in the caller's order; nothing is permuted
+                                   (ABI 12; ABI 11 applied it to the model alone).  Why: a wave pays for a transit while ANY of its 64
+                                   draws is inside one; taking the draws sorted by transit timing (exo_sparse_model_order) keeps a
+                                   wave's transits together -- C3: 3.6 -> 3.3 ms of GP kernels.  exo_transit_flux_sparse_model sets it
+                                   to NULL.                                                                                     */
 } exo_sparse_model;
 int exo_transit_flux_sparse_model(const void* workspace, int64_t workspace_bytes, int64_t n_cad, int64_t n_draw,
                                   int32_t n_planet, uint32_t flags, exo_sparse_model* out);
+/* order [n_draw] (device, int32): the draws of `model` (its rows 0 .. n_draw - 1; row_of_draw ignored) by ascending mean spacing of
+ * their segments -- the period, in cadences: neighbouring periods keep their transits together all along the series -- ties by the
+ * start of the first segment, then by index: what to pass as row_of_draw.  One launch, no host synchronisation.  n_draw <=
+ * EXO_SPARSE_ORDER_MAX_DRAWS (EXO_ERR_INVALID_ARGUMENT beyond: sort on the host side, or pass NULL).                          */
+#define EXO_SPARSE_ORDER_MAX_DRAWS 4096
+int exo_sparse_model_order(const exo_sparse_model* model, int64_t n_draw, int32_t* order, void* stream);
 /* Reverse sweep for a cotangent given in the VALUE layout of the sparse output -- gvals [n_draw][n_planet][n_cad], gvals of
  * (draw, planet) at the positions of that planet's values: what exo_celerite_loglike_sparse_vjp_f64 writes -- instead of a
  * dense gflux.  flags must carry EXO_FLAG_SPARSE (and whatever the forward sweep carried); otherwise as

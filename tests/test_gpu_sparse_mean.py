@@ -286,3 +286,57 @@ def test_sparse_step_replayed_as_a_hip_graph(dev):
     for a, b in zip(eager1, outs):
         assert torch.equal(a, b)
     xo.ops.release_sorted(t)
+
+
+def test_draw_order_of_the_library_and_results_do_not_depend_on_it(dev):
+    """exo_sparse_model_order (one launch) gives the order torch's stable argsort of the same keys gives; and the order in which
+    the kernels take the draws (exo_sparse_model.row_of_draw, ABI 12: every per-draw array of the call is indexed through it,
+    nothing is permuted by the caller) changes no number: per-draw diag, mixed pair kinds, periods 10 % apart -- sorted, unsorted
+    and a random order give bit-identical log-likelihoods and gradients."""
+    import exoplanet_amd as xo
+    from exoplanet_amd.gp import celerite as C
+
+    D, N = 200, 24_000
+    rng = np.random.default_rng(11)
+    t = torch.arange(N, dtype=torch.float64, device=dev) * (2.0 / 1440.0)
+    y = torch.tensor(5e-4 * rng.normal(size=N), dtype=torch.float64, device=dev)
+
+    def run(order_fn):
+        rs = np.random.default_rng(12)
+        mk = lambda x, s: torch.tensor(x * (1 + s * rs.normal(size=(D, 1))), dtype=torch.float64, device=dev, requires_grad=True)  # noqa: E731
+        L = dict(period=mk(3.0, 0.03), t0=mk(1.0, 0.05), b=mk(0.3, 0.05))
+        r = mk(0.1, 0.02)
+        kern, kl = _kernel(xo, dev, D, "mixed", 13)
+        yerr = torch.tensor(5e-4 * (1 + 0.2 * rs.random((D, N))), dtype=torch.float64, device=dev, requires_grad=True)   # a per-draw diag
+        lc = xo.LimbDarkLightCurve(0.3, 0.2).get_light_curve(orbit=xo.KeplerianOrbit(**L), r=r, t=t, total=True, sparse=True)
+        assert isinstance(lc, xo.ops.SparseLightCurve)
+        saved = C._transit_order
+        seen = {}
+        def order(sp):
+            seen["lib"] = saved(sp)
+            return order_fn(sp, seen["lib"])
+        C._transit_order = order
+        try:
+            ll = xo.gp.GaussianProcess(kern, t=t, yerr=yerr, mean=lc).log_likelihood(y)
+            w = torch.linspace(0.5, 1.5, D, dtype=torch.float64, device=dev)
+            g = torch.autograd.grad((ll * w).sum(), list(L.values()) + [r, yerr] + kl)
+        finally:
+            C._transit_order = saved
+        return ll.detach().clone(), [x.detach().clone() for x in g], seen["lib"], lc
+
+    ll0, g0, lib_order, lc = run(lambda sp, lib: lib)
+    # the library's order against torch's stable argsort of the same keys
+    lay = lc.layout()
+    nrun = lay.nrun.reshape(D).long()
+    lo = lay.runs.reshape(D, lay.r_max, 4)[:, :, 0]
+    first = lo[:, 0].double()
+    last = lo.gather(1, (nrun - 1).clamp_min(0).unsqueeze(1)).squeeze(1).double()
+    key = (last - first) / (nrun - 1).clamp_min(1).double() + 1e-9 * first
+    assert torch.equal(lib_order.long(), torch.argsort(key, stable=True))
+    assert not torch.equal(lib_order.long(), torch.arange(D, device=dev))          # (a real permutation: the periods differ)
+    shuffled = torch.tensor(np.random.default_rng(5).permutation(D), dtype=torch.int32, device=dev)
+    for fn in (lambda sp, lib: torch.arange(D, dtype=torch.int32, device=dev), lambda sp, lib: shuffled):
+        ll1, g1, _, _ = run(fn)
+        assert torch.equal(ll1, ll0)
+        for a, b in zip(g1, g0):
+            assert torch.equal(a, b)
