@@ -1439,6 +1439,8 @@ __global__ __launch_bounds__(1024) void celerite_draw_order_kernel(SparseSegs sp
     s_idx[i] = i;
   }
   __syncthreads();
+  // (ranking every key against all others -- no barriers -- was tried for small batches: 45 us at 1024 draws against 23: the block
+  // is one CU, 5 instructions x n_draw per key)
   for (int k = 2; k <= M; k <<= 1)
     for (int j = k >> 1; j >= 1; j >>= 1) {
       for (int i = threadIdx.x; i < M; i += 1024) {

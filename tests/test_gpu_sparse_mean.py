@@ -340,3 +340,29 @@ def test_draw_order_of_the_library_and_results_do_not_depend_on_it(dev):
         assert torch.equal(ll1, ll0)
         for a, b in zip(g1, g0):
             assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("D", [65, 1024, 2048, 2049, 4096, 5000])
+def test_draw_order_sizes(dev, D):
+    """exo_sparse_model_order (a bitonic network over the next power of two) and the torch fallback past its 4096 draws, against a
+    stable argsort of the keys; periods in a few groups, so that there are ties to break"""
+    import exoplanet_amd as xo
+    from exoplanet_amd.gp import celerite as C
+
+    N = 4000
+    rng = np.random.default_rng(D)
+    t = torch.arange(N, dtype=torch.float64, device=dev) * (10.0 / 1440.0)
+    period = torch.tensor(rng.choice([2.5, 2.7, 3.1, 3.3, 40.0], size=(D, 1)), dtype=torch.float64, device=dev)
+    t0 = torch.tensor(rng.choice([0.9, 1.0, 1.1], size=(D, 1)), dtype=torch.float64, device=dev)
+    b = torch.full((D, 1), 0.3, dtype=torch.float64, device=dev)
+    lc = xo.LimbDarkLightCurve(0.3, 0.2).get_light_curve(orbit=xo.KeplerianOrbit(period=period, t0=t0, b=b), r=0.1, t=t, total=True, sparse=True)
+    assert isinstance(lc, xo.ops.SparseLightCurve)
+    got = C._transit_order(lc)
+    lay = lc.layout()
+    nrun = lay.nrun.reshape(D).long()
+    lo = lay.runs.reshape(D, lay.r_max, 4)[:, :, 0]
+    first = lo[:, 0].double()
+    last = lo.gather(1, (nrun - 1).clamp_min(0).unsqueeze(1)).squeeze(1).double()
+    key = (last - first) / (nrun - 1).clamp_min(1).double() + 1e-9 * first
+    assert int((nrun < 2).sum()) > 0                      # (the 40-day period: one transit in the series)
+    assert torch.equal(got.long(), torch.argsort(key, stable=True))
