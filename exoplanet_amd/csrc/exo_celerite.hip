@@ -1274,6 +1274,21 @@ __global__ __launch_bounds__(kScanBlock, EXO_GROUP_WAVES) void celerite_tree_gro
   tree_item_group<J, ADJ, DOWN>(op, state, c, unit - (int64_t)c * op.n_draw, g);
 }
 
+// the narrow top of a scan as a serial chain on groups of eight lanes, 32 draws per block (tree_serial_group; J >= 3)
+template <int J, bool ADJ>
+__global__ __launch_bounds__(kScanBlock, EXO_GROUP_WAVES) void celerite_tree_serial_group_kernel(TreeOp op, double* state) {
+  __shared__ double lds[(kScanBlock / 8) * GroupLds<J>::S];
+  const int tid = threadIdx.x;
+  const int64_t draw = (int64_t)blockIdx.x * (kScanBlock / 8) + (tid >> 3);
+  if (draw >= op.n_draw) return;     // (whole groups leave; nothing below needs a block barrier)
+  Grp<J> g;
+  g.lds = lds + (tid >> 3) * GroupLds<J>::S;
+  g.r = tid & 7;
+  g.live = g.r < J;
+  tree_serial_group<J, ADJ>(op, state, draw, g);
+}
+
+
 // the state the forward scan starts from: F = 0, P = Delta(t_0) (S_0 = 0)
 template <int J>
 __global__ __launch_bounds__(kWave) void celerite_scan_init_kernel(const double* __restrict__ t, Coefs cf, int64_t n_draw,
@@ -1441,6 +1456,36 @@ __global__ __launch_bounds__(1024) void celerite_draw_order_kernel(SparseSegs sp
   __syncthreads();
   // (ranking every key against all others -- no barriers -- was tried for small batches: 45 us at 1024 draws against 23: the block
   // is one CU, 5 instructions x n_draw per key)
+  if (M <= 1024) {
+    // one element per thread, in registers: the steps inside a wave (partner = lane ^ j, j < 64: 45 of the 55 steps at 1024 draws)
+    // are shuffles -- no LDS, no barrier -- and only the ten across waves go through LDS (23 -> 12 us)
+    const int i = threadIdx.x;
+    double key = i < M ? s_key[i] : INFINITY;
+    int idx = i < M ? s_idx[i] : i;
+    for (int k = 2; k <= M; k <<= 1)
+      for (int j = k >> 1; j >= 1; j >>= 1) {
+        double kp;
+        int ip;
+        if (j >= 64) {
+          __syncthreads();
+          if (i < M) { s_key[i] = key; s_idx[i] = idx; }
+          __syncthreads();
+          kp = i < M ? s_key[i ^ j] : INFINITY;
+          ip = i < M ? s_idx[i ^ j] : i;
+        } else {
+          kp = __shfl_xor(key, j, 64);
+          ip = __shfl_xor(idx, j, 64);
+        }
+        const bool lower = (i & j) == 0;                         // I am the lower index of the pair
+        const bool mine_after = key > kp || (key == kp && idx > ip);
+        const bool asc = (i & k) == 0;
+        // the pair in ascending order puts the smaller at the lower index; descending the other way round
+        const bool take = lower ? (mine_after == asc) : (mine_after != asc);
+        if (take) { key = kp; idx = ip; }
+      }
+    if (i < n_draw) order[i] = idx;
+    return;
+  }
   for (int k = 2; k <= M; k <<= 1)
     for (int j = k >> 1; j >= 1; j >>= 1) {
       for (int i = threadIdx.x; i < M; i += 1024) {
@@ -2122,7 +2167,11 @@ static int celerite_fwd(const double* t, Series resid, const double* diag, int64
                      },
                      seed);
         } else {
-          tree_scan(ws, J, false, launch, seed);
+          tree_scan_top(ws, J, false, (EXO_GP_GROUP_TREES && J >= 3 && J <= 8) ? tree_serial_level(ws, J) : ws.tree_top(), launch, seed,
+                        [&](const TreeOp& op) {
+                          const dim3 sgrid((unsigned)((n_draw + kScanBlock / 8 - 1) / (kScanBlock / 8)));
+                          EXO_GP_DISPATCH_GROUP(J, hipLaunchKernelGGL((celerite_tree_serial_group_kernel<JJ, false>), sgrid, dim3(kScanBlock), 0, st, op, state))
+                        });
         }
         if (rc != EXO_OK) return rc;
       }
@@ -2233,7 +2282,11 @@ static int celerite_vjp(const double* t, Series resid, const double* diag, int64
                    },
                    seed);
       } else {
-        tree_scan(ws, J, true, launch, seed);
+        tree_scan_top(ws, J, true, (EXO_GP_GROUP_TREES && J >= 3 && J <= 8) ? tree_serial_level(ws, J) : ws.tree_top(), launch, seed,
+                      [&](const TreeOp& op) {
+                        const dim3 sgrid((unsigned)((n_draw + kScanBlock / 8 - 1) / (kScanBlock / 8)));
+                        EXO_GP_DISPATCH_GROUP(J, hipLaunchKernelGGL((celerite_tree_serial_group_kernel<JJ, true>), sgrid, dim3(kScanBlock), 0, st, op, wstate))
+                      });
       }
       if (!ok) return EXO_ERR_LAUNCH;
     }

@@ -1712,6 +1712,47 @@ EXO_HD void tree_item4_down_lane(const TreeOp& a, const TreeOp& b, double* EXO_R
   children(2 * i + 1, m1, P1);
 }
 
+// the narrow top of a scan as a serial chain, one lane per draw: the level's elements applied one after the other to the seed
+// (`op`: the level's DOWN op with the ONE parent state).  The device runs this on groups of eight lanes for J >= 3
+// (exo_celerite_group.hpp, tree_serial_group: where it pays and why); this one-lane form is what the host harness checks the
+// schedule with.
+template <int J, bool ADJ>
+EXO_HD void tree_serial_lane(const TreeOp& op, double* EXO_RESTRICT state, int64_t draw) {
+  const int64_t nd = op.n_draw;
+  const int Bq = J + J * J;
+  double m[J], P[J][J];
+#pragma unroll
+  for (int j = 0; j < J; ++j) {
+    m[j] = state[op.par_state + (int64_t)j * nd + draw];
+#pragma unroll
+    for (int l = 0; l < J; ++l) P[j][l] = state[op.par_state + (int64_t)(J + j * J + l) * nd + draw];
+  }
+  auto put = [&](int pos, const double* mv, const double (*Pv)[J]) {
+    const int idx = op.dst_rev ? op.dst_len - 1 - pos : pos;
+    double* EXO_RESTRICT q = state + op.dst_state + ((int64_t)idx * Bq) * nd + draw;
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      q[(int64_t)j * nd] = mv[j];
+#pragma unroll
+      for (int l = 0; l < J; ++l) q[(int64_t)(J + j * J + l) * nd] = op.psign * Pv[j][l];
+    }
+  };
+  put(0, m, P);
+  for (int pos = 0; pos + 1 < op.dst_n; ++pos) {
+    Elem<J> el;
+    tree_load_elem<J>(state, op, pos, draw, el);
+    double m2[J], Ps[J][J];
+    tree_apply<J, ADJ>(el, m, P, m2, Ps);
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      m[j] = m2[j];
+#pragma unroll
+      for (int l = 0; l < J; ++l) P[j][l] = Ps[j][l];
+    }
+    put(pos + 1, m, P);
+  }
+}
+
 // the state the forward scan starts from, (F, P) = (0, Delta(t_0)) (S_0 = 0), as a state record at dst
 template <int J>
 EXO_HD void scan_init_lane(const double* EXO_RESTRICT t, const Coefs& cf, int64_t n_draw, double* EXO_RESTRICT dst, int64_t draw) {
@@ -1781,6 +1822,31 @@ EXO_HDH void tree_scan4(const ChunkWs& ws, int J, bool adj, Launch&& launch, Lau
   f = top - 1;
   for (; f >= 1; f -= 2) launch2(scan_level_op(ws, J, adj, f - 1, true), scan_level_op(ws, J, adj, f, true), true);
   for (; f >= 0; --f) launch(scan_level_op(ws, J, adj, f, true), true);
+}
+
+// the level from which a scan of J >= 3 runs as a serial chain (tree_serial_group): the lowest with at most kSerialTopGroup positions;
+// the top level (= no chain) where that would replace fewer than two levels
+#ifndef EXO_GP_SERIAL_TOP_GROUP
+#define EXO_GP_SERIAL_TOP_GROUP 8     // (measured at C5: 8 -> 1.825 ms, 16 -> 1.85, 32 -> 1.91, none 1.86-1.875)
+#endif
+EXO_HDH int tree_serial_level(const ChunkWs& ws, int J) {
+  const int top = ws.tree_top();
+  if (J < 3 || EXO_GP_SERIAL_TOP_GROUP < 2) return top;
+  int f = 0;
+  while (ws.tree_npos(f) > EXO_GP_SERIAL_TOP_GROUP) ++f;
+  return f + 2 <= top ? f : top;
+}
+// tree_scan with the levels from f0 up replaced by the chain: serial(op)
+template <class Launch, class Seed, class Serial>
+EXO_HDH void tree_scan_top(const ChunkWs& ws, int J, bool adj, int f0, Launch&& launch, Seed&& seed, Serial&& serial) {
+  const int top = ws.tree_top();
+  if (f0 >= top) { tree_scan(ws, J, adj, launch, seed); return; }
+  for (int f = 0; f < f0; ++f) launch(scan_level_op(ws, J, adj, f, false), false);   // (the elements of level f0)
+  seed();
+  TreeOp op = scan_level_op(ws, J, adj, f0, true);
+  op.par_state = ws.tree_state(top);     // the one state the chain starts from
+  serial(op);
+  for (int f = f0 - 1; f >= 0; --f) launch(scan_level_op(ws, J, adj, f, true), true);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -256,6 +256,97 @@ __device__ __forceinline__ void group_put_state(double* state, const TreeOp& op,
   for (int l = 0; l < J; ++l) q[(int64_t)(J + r * J + l) * nd] = op.psign * P[l];
 }
 
+// an element applied to a state on a group's eight lanes (my row of P / P2, my entry of m / m2): tree_apply's arithmetic
+template <int J, bool ADJ>
+__device__ __forceinline__ void group_apply(const Grp<J>& g, int r, const ElemRow<J>& el, double m, const double (&P)[J], double& m2,
+                                            double (&P2)[J]) {
+  if (ADJ) {
+    // x = Abar^T Fbar ;  Fbar' = lF + x ;  Pbar' = lP + Abar^T Pbar Abar + sym(x g^T)
+    g.put_rows(0, el.A);
+    g.put_vec(0, m);
+    g.put_vec(2, el.b);
+    g.sync();
+    const double x = g.tmv(0, 0);
+    double T[J];
+    g.mm(P, 0, T);
+    g.put_rows(1, T);
+    g.put_vec(1, x);
+    g.sync();
+    g.tmm(0, 1, P2);
+    double xa[J], ba[J];
+    g.get_vec(1, xa);
+    g.get_vec(2, ba);
+    m2 = el.eta + x;
+#pragma unroll
+    for (int l = 0; l < J; ++l) P2[l] = el.Cm[l] + P2[l] + 0.5 * (x * ba[l] + el.b * xa[l]);
+  } else {
+    // X = I + P Jm ;  solve X [YP | ym] = [P | F + P eta] ;  F' = A ym + b ;  P' = A (YP) A^T + Cm
+    g.put_rows(0, el.Jm);
+    g.put_rows(2, el.A);
+    g.put_vec(0, el.eta);
+    g.sync();
+    double X[J], Bm[J + 1];
+    g.mm(P, 0, X);
+#pragma unroll
+    for (int l = 0; l < J; ++l) X[l] = g.live ? X[l] + (l == r ? 1.0 : 0.0) : 0.0;   // (no run-time index: registers)
+#pragma unroll
+    for (int l = 0; l < J; ++l) Bm[l] = P[l];
+    Bm[J] = m + g.mv(P, 0);
+    g.template solve<J + 1>(X, Bm);
+    double YP[J];
+#pragma unroll
+    for (int l = 0; l < J; ++l) YP[l] = Bm[l];
+    g.put_rows(1, YP);
+    g.put_vec(1, Bm[J]);
+    g.sync();
+    double AY[J];
+    g.mm(el.A, 1, AY);
+    m2 = el.b + g.mv(el.A, 1);
+    g.mm_t(AY, 2, P2);
+#pragma unroll
+    for (int l = 0; l < J; ++l) P2[l] += el.Cm[l];
+  }
+  g.put_rows(3, P2);
+  g.sync();
+  g.sym_from(3, P2);
+}
+
+// The NARROW TOP of a scan as a serial chain on a group's eight lanes (round 5, J >= 3).  A level of a J = 6 scan costs its item's
+// dependent latency -- ~11 LDS exchanges and a solve: 18 us to compose, 10 to apply, 9 / 7 for the adjoint scan -- twice (up, down),
+// whatever its size.  From the level with eight positions up the chain instead: the level's elements applied one after the other
+// to the scan's seed (`op`: the level's DOWN op with the one parent state, tree_scan_top), the next element's loads issued before
+// the current application; no compositions there.  Measured at C5: an application of the chain is 4.6 us (2.3 for the adjoint
+// scan), so eight of them replace three levels' 68 + 40 us with 37 + 18: step 1.87 -> 1.83 ms; from sixteen positions up it is a
+// draw, from 32 a loss.  (For J <= 2 the same idea lost outright: a one-lane item is 5.5 us and a step of the chain 0.5 --
+// exo_celerite.hip.)  The chain is the better conditioned association of the two.
+template <int J, bool ADJ>
+__device__ __forceinline__ void tree_serial_group(const TreeOp& op, double* state, int64_t draw, const Grp<J>& g) {
+  const int64_t nd = op.n_draw;
+  int r = g.live ? g.r : 0;
+  asm volatile("" : "+v"(r));
+  double m, P[J];
+  {
+    const double* q = state + op.par_state + draw;
+    m = g.live ? q[(int64_t)r * nd] : 0.0;
+#pragma unroll
+    for (int l = 0; l < J; ++l) P[l] = g.live ? q[(int64_t)(J + r * J + l) * nd] : 0.0;
+  }
+  group_put_state<J>(state, op, 0, draw, g, r, m, P);
+  ElemRow<J> el, nxt;
+  group_load_elem<J>(state, op, 0, draw, g, r, el, !ADJ);
+#pragma unroll 1
+  for (int pos = 0; pos + 1 < op.dst_n; ++pos) {
+    group_load_elem<J>(state, op, pos + 1, draw, g, r, nxt, !ADJ);    // (in flight while this element is applied)
+    double m2, P2[J];
+    group_apply<J, ADJ>(g, r, el, m, P, m2, P2);
+    m = m2;
+#pragma unroll
+    for (int l = 0; l < J; ++l) P[l] = P2[l];
+    group_put_state<J>(state, op, pos + 1, draw, g, r, m, P);
+    el = nxt;
+  }
+}
+
 // one item of a level on eight lanes: the same arithmetic as tree_item_lane<J, ADJ, DOWN> (exo_celerite_core.hpp).
 // Everything an exchange can carry is staged at once: composing two filtering elements is 4 exchanges + the 7 of its
 // solve, applying one to a state 3 + 7, the adjoint items 3 each.
@@ -280,55 +371,7 @@ __device__ __forceinline__ void tree_item_group(const TreeOp& op, double* state,
     ElemRow<J> el;
     group_load_elem<J>(state, op, 2 * c, draw, g, r, el, !ADJ);
     double m2, P2[J];
-    if (ADJ) {
-      // x = Abar^T Fbar ;  Fbar' = lF + x ;  Pbar' = lP + Abar^T Pbar Abar + sym(x g^T)
-      g.put_rows(0, el.A);
-      g.put_vec(0, m);
-      g.put_vec(2, el.b);
-      g.sync();
-      const double x = g.tmv(0, 0);
-      double T[J];
-      g.mm(P, 0, T);
-      g.put_rows(1, T);
-      g.put_vec(1, x);
-      g.sync();
-      g.tmm(0, 1, P2);
-      double xa[J], ba[J];
-      g.get_vec(1, xa);
-      g.get_vec(2, ba);
-      m2 = el.eta + x;
-#pragma unroll
-      for (int l = 0; l < J; ++l) P2[l] = el.Cm[l] + P2[l] + 0.5 * (x * ba[l] + el.b * xa[l]);
-    } else {
-      // X = I + P Jm ;  solve X [YP | ym] = [P | F + P eta] ;  F' = A ym + b ;  P' = A (YP) A^T + Cm
-      g.put_rows(0, el.Jm);
-      g.put_rows(2, el.A);
-      g.put_vec(0, el.eta);
-      g.sync();
-      double X[J], Bm[J + 1];
-      g.mm(P, 0, X);
-#pragma unroll
-      for (int l = 0; l < J; ++l) X[l] = g.live ? X[l] + (l == r ? 1.0 : 0.0) : 0.0;   // (no run-time index: registers)
-#pragma unroll
-      for (int l = 0; l < J; ++l) Bm[l] = P[l];
-      Bm[J] = m + g.mv(P, 0);
-      g.template solve<J + 1>(X, Bm);
-      double YP[J];
-#pragma unroll
-      for (int l = 0; l < J; ++l) YP[l] = Bm[l];
-      g.put_rows(1, YP);
-      g.put_vec(1, Bm[J]);
-      g.sync();
-      double AY[J];
-      g.mm(el.A, 1, AY);
-      m2 = el.b + g.mv(el.A, 1);
-      g.mm_t(AY, 2, P2);
-#pragma unroll
-      for (int l = 0; l < J; ++l) P2[l] += el.Cm[l];
-    }
-    g.put_rows(3, P2);
-    g.sync();
-    g.sym_from(3, P2);
+    group_apply<J, ADJ>(g, r, el, m, P, m2, P2);
     group_put_state<J>(state, op, 2 * c + 1, draw, g, r, m2, P2);
     return;
   }

@@ -17,6 +17,7 @@
 
 namespace {
 
+int g_serial_top = 0;    // > 0: the scans' levels with at most this many positions (and all above) as a serial chain (tree_scan_top)
 int g_tree4 = 0;         // 1: two levels of a scan per "launch" where a pair is left (tree_scan4, J <= 2: what the device does)
 int g_serial_scan = 0;   // 1: the serial reference scans (bscan_lane, bscan_vjp_lane) instead of the trees
 int g_robust_flags = 1;  // draws the element lanes flag kFlagRobust take the robust route (as on the device)
@@ -286,7 +287,12 @@ void run_fwd(const double* t, gp::Series rs, const double* diag, int64_t n_diag,
                          }
                      },
                      seed);
-    else
+    else if (g_serial_top > 0) {
+      int f0 = 0;
+      while (ws.tree_npos(f0) > g_serial_top) ++f0;
+      gp::tree_scan_top(ws, J, false, f0 + 2 <= ws.tree_top() ? f0 : ws.tree_top(), launch, seed,
+                        [&](const gp::TreeOp& op) { for (int64_t d = 0; d < n_draw; ++d) gp::tree_serial_lane<J, false>(op, state, d); });
+    } else
       gp::tree_scan(ws, J, false, launch, seed);
   } else if (g_robust && g_hybrid_k >= 0 && cg.tree) {
     const int top = ws.tree_top();
@@ -418,7 +424,12 @@ void run_vjp(const double* t, gp::Series rs, const double* diag, int64_t n_diag,
                          }
                      },
                      seed);
-    else
+    else if (g_serial_top > 0) {
+      int f0 = 0;
+      while (ws.tree_npos(f0) > g_serial_top) ++f0;
+      gp::tree_scan_top(ws, J, true, f0 + 2 <= ws.tree_top() ? f0 : ws.tree_top(), launch, seed,
+                        [&](const gp::TreeOp& op) { for (int64_t d = 0; d < n_draw; ++d) gp::tree_serial_lane<J, true>(op, state, d); });
+    } else
       gp::tree_scan(ws, J, true, launch, seed);
   } else {
     for (int64_t d = 0; d < n_draw; ++d) gp::bscan_vjp_lane<J>(n, n_draw, state, cg, d);
@@ -458,6 +469,7 @@ extern "C" {
 
 void harness_set_serial_scan(int v) { g_serial_scan = v; }
 void harness_set_tree4(int v) { g_tree4 = v; }
+void harness_set_serial_top(int v) { g_serial_top = v; }
 void harness_set_polish(int v) { g_polish = v; }
 void harness_set_robust(int v) { g_robust = v; }
 void harness_set_adj_tree(int v) { g_adj_tree = v; }

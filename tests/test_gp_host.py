@@ -344,6 +344,33 @@ def test_two_levels_per_launch_is_the_same_tree(harness):
             assert np.array_equal(g0[k], g1[k]), (n_real, n_complex, n_chunks, k)
 
 
+def test_serial_top_of_the_scans_equals_the_trees(harness):
+    """tree_scan_top (round 5, what the device does for J >= 3): the levels with at most 16 positions -- and everything above -- as a
+    serial chain of applications from the seed, no compositions there; against the full trees, forward and adjoint, chunk counts that
+    put the cut at different levels, J = 1 .. 6: the same mathematics in another association"""
+    rng = np.random.default_rng(78)
+    for n_real, n_complex, n_chunks, top in ((1, 0, 40, 16), (0, 1, 64, 16), (2, 1, 37, 4), (0, 3, 70, 16), (1, 2, 130, 16), (0, 3, 33, 2)):
+        n, D = 30 * n_chunks, 3
+        t = np.sort(rng.uniform(0, 30, n))
+        y = rng.normal(size=(D, n))
+        diag = 0.1 + 0.1 * rng.uniform(size=(D, n))
+        real = np.stack([10 ** rng.uniform(-1, 0, (D, n_real)), 10 ** rng.uniform(-1, 0.5, (D, n_real))], -1)
+        a = 10 ** rng.uniform(-1, 0, (D, n_complex)); c = 10 ** rng.uniform(-1, 0.3, (D, n_complex))
+        d = 10 ** rng.uniform(-0.5, 0.8, (D, n_complex)); b = rng.uniform(-0.9, 0.9, (D, n_complex)) * a * c / d
+        cplx = np.stack([a, b, c, d], -1)
+        gll = rng.normal(size=D)
+        res = []
+        for st in (0, top):
+            harness.harness_set_serial_top(st)
+            res.append(run(harness, t, y, diag, real, cplx, gll=gll, n_chunks=n_chunks))
+        harness.harness_set_serial_top(0)
+        (ll0, _, _, g0), (ll1, _, _, g1) = res
+        assert np.abs(ll0 - ll1).max() <= 1e-12 * np.abs(ll1).max()
+        for k in g0:
+            if g1[k].size:
+                assert np.abs(g0[k] - g1[k]).max() <= 1e-10 * (np.abs(g1[k]).max() + 1e-300), (n_real, n_complex, n_chunks, k)
+
+
 def _kernel(tau, c):
     return P.celerite_kernel(tau, *c)
 
