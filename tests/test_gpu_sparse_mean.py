@@ -342,7 +342,7 @@ def test_draw_order_of_the_library_and_results_do_not_depend_on_it(dev):
             assert torch.equal(a, b)
 
 
-@pytest.mark.parametrize("D", [65, 1024, 2048, 2049, 4096, 5000])
+@pytest.mark.parametrize("D", [1, 5, 33, 64, 65, 1000, 1024, 1025, 2048, 4096, 5000])
 def test_draw_order_sizes(dev, D):
     """exo_sparse_model_order (a bitonic network over the next power of two) and the torch fallback past its 4096 draws, against a
     stable argsort of the keys; periods in a few groups, so that there are ties to break"""
@@ -364,5 +364,5 @@ def test_draw_order_sizes(dev, D):
     first = lo[:, 0].double()
     last = lo.gather(1, (nrun - 1).clamp_min(0).unsqueeze(1)).squeeze(1).double()
     key = (last - first) / (nrun - 1).clamp_min(1).double() + 1e-9 * first
-    assert int((nrun < 2).sum()) > 0                      # (the 40-day period: one transit in the series)
+    assert D < 33 or int((nrun < 2).sum()) > 0            # (the 40-day period: one transit in the series)
     assert torch.equal(got.long(), torch.argsort(key, stable=True))
