@@ -73,6 +73,17 @@ def test_header_layout_constants_match_python(lib):
     assert int(consts["EXO_PACK_CIRCULAR"]) == ops.PACK_CIRCULAR
     assert int(consts["EXO_MAX_PLANETS"]) == ops.MAX_PLANETS
     assert int(consts["EXO_MAX_SUBEXP"]) == ops.MAX_SUBEXP
+    from exoplanet_amd import _lib
+    from exoplanet_amd.gp import celerite
+
+    assert int(consts["EXO_SPARSE_ORDER_MAX_DRAWS"]) == celerite.lib_max_order_draws()
+    assert int(consts["EXO_GP_MAX_J"]) == celerite.MAX_J
+    # exo_sparse_model_order rejects what it cannot sort, on the host, before any launch
+    import ctypes
+
+    assert lib.exo_sparse_model_order(None, 8, None, None) != 0
+    m = _lib.SparseModel()
+    assert lib.exo_sparse_model_order(ctypes.addressof(m), 8, None, None) != 0       # (no arrays behind the struct)
 
 
 def test_rv_layout_constants_and_argument_checks(lib):
