@@ -366,3 +366,17 @@ def test_draw_order_sizes(dev, D):
     key = (last - first) / (nrun - 1).clamp_min(1).double() + 1e-9 * first
     assert D < 33 or int((nrun < 2).sum()) > 0            # (the 40-day period: one transit in the series)
     assert torch.equal(got.long(), torch.argsort(key, stable=True))
+
+
+def test_sorted_draws_on_every_route(dev, monkeypatch):
+    """more than 64 draws (the kernels take them through exo_sparse_model.row_of_draw, sorted by period) on the routes behind the
+    main one: the sequential kernels alone (EXO_GP_CHUNKS=1), draws flagged on the device and redone by the sequential kernels
+    behind the chunk kernels, J = 6 (scan trees on lane groups with their serial top), the lane-group chunk kernels (J = 8)"""
+    import exoplanet_amd as xo
+
+    _compare(_both_routes(xo, dev, 70, 6_000, "sho", yerr=1e-9), ll_rtol=1e-12, g_rtol=1e-10)
+    _compare(_both_routes(xo, dev, 70, 9_000, "sho3"))
+    _compare(_both_routes(xo, dev, 66, 6_000, "sho4"))
+    monkeypatch.setenv("EXO_GP_CHUNKS", "1")
+    _compare(_both_routes(xo, dev, 70, 5_000, "sho"))
+    _compare(_both_routes(xo, dev, 67, 3_000, "mixed"))
