@@ -110,3 +110,125 @@ def test_integration_md_perform_bodies_match_the_document():
         assert norm(line) in doc, line
         if "contact_points" not in line:       # (the contact-point helper is executed from the document itself)
             assert norm(line) in norm(CLIENT), line
+
+
+SPARSE_CLIENT = r"""
+# INTEGRATION.md section 4.1 as a torch-free client: the light curve as a SPARSE mean of a celerite GP, raw hipMalloc / hipMemcpy,
+# NULL stream -- against the dense cadence-major route through the same raw ABI.
+import re, sys, os, ctypes
+import numpy as np
+ROOT = sys.argv[1]
+text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+sec1 = text[text.index("## 1. ctypes loader"):text.index("## 2. Drop-in")]
+code = re.search(r"```python\n(.*?)```", sec1, re.S).group(1)
+code = code.replace('"libexoplanet_amd.so"', repr(os.path.join(ROOT, "exoplanet_amd", "lib", "libexoplanet_amd.so")))
+ns = {}
+exec(code, ns)
+lib, hip, dmalloc, h2d, d2h, vp = (ns[k] for k in ("lib", "hip", "dmalloc", "h2d", "d2h", "vp"))
+sec4 = text[text.index("### 4.1 The light curve as a SPARSE mean"):text.index("### 4.2")]
+struct_src = re.search(r"(class SparseModel\(ctypes.Structure\):.*?\n\n)", sec4, re.S).group(1)
+exec("from ctypes import *\n" + struct_src, ns)                    # the struct of section 4.1, verbatim
+SparseModel = ns["SparseModel"]
+i64, i32, u32, cint = ctypes.c_int64, ctypes.c_int32, ctypes.c_uint32, ctypes.c_int
+lib.exo_transit_flux_workspace_bytes.restype = i64
+lib.exo_transit_flux_workspace_bytes.argtypes = [i64, i64, i32]
+lib.exo_celerite_state_doubles.restype = i64
+lib.exo_celerite_state_doubles.argtypes = [i64, i64, i32, i32, i32]
+lib.exo_celerite_default_chunks.restype = i32
+lib.exo_celerite_default_chunks.argtypes = [i64, i64, i32, i32, i32]
+lib.exo_pack_records_f64.argtypes = [vp, vp, i64, i32, u32, vp, vp, vp]
+lib.exo_transit_flux_fwd_f64.argtypes = [vp, i64, vp, i64, vp, vp, i32, vp, vp, i64, i32, u32, vp, vp, i64, vp]
+lib.exo_transit_flux_vjp_f64.argtypes = [vp, i64, vp, i64, vp, vp, i32, vp, vp, i64, i32, u32, vp, vp, vp, vp, vp, vp, i64, vp]
+lib.exo_transit_flux_sparse_model.argtypes = [vp, i64, i64, i64, i32, u32, vp]
+lib.exo_sparse_model_order.argtypes = [vp, i64, vp, vp]
+lib.exo_transit_flux_vjp_sparse_f64.argtypes = [vp, i64, vp, i64, vp, vp, i32, vp, vp, i64, i32, u32, vp, vp, vp, vp, vp, i64, i32, vp]
+gp_fwd = [vp, vp, vp, vp, i64, i64, vp, i32, vp, i32, vp, i64, vp, vp, i64, i32, vp]
+gp_vjp = [vp, vp, vp, vp, i64, i64, vp, i32, vp, i32, vp, i64, vp, vp, i64, i32, vp, vp, vp, vp, vp, vp]
+lib.exo_celerite_loglike_sparse_fwd_f64.argtypes = gp_fwd
+lib.exo_celerite_loglike_obs_fwd_cm_f64.argtypes = gp_fwd
+lib.exo_celerite_loglike_sparse_vjp_f64.argtypes = gp_vjp
+lib.exo_celerite_loglike_obs_vjp_cm_f64.argtypes = gp_vjp
+SPARSE, CM, SORTED = 32, 128, 256
+
+rng = np.random.default_rng(4)
+D, n = 96, 6000
+t = np.arange(n) * (10.0 / 1440.0)
+orbit_in = np.zeros((D, 1, 10))
+orbit_in[:, 0, 0] = 3.0 * (1 + 0.05 * rng.normal(size=D))     # period
+orbit_in[:, 0, 1] = 1.0 + 0.05 * rng.normal(size=D)           # t0
+orbit_in[:, 0, 2] = 0.3                                        # b
+orbit_in[:, 0, 5] = 0.1 * (1 + 0.02 * rng.normal(size=D))     # r
+orbit_in[:, 0, 6] = 1.0; orbit_in[:, 0, 7] = 1.0               # m_star, r_star
+ld_in = np.tile([0.3, 0.2], (D, 1))
+y = 5e-4 * rng.normal(size=n)
+diag = np.full((1, n), 2.5e-7)
+cc = np.stack([np.full(D, 1e-6), np.full(D, 5e-8), 0.4 * (1 + 0.1 * rng.normal(size=D)), np.full(D, 2.0)], -1).reshape(D, 1, 4)
+gll = np.linspace(0.5, 1.5, D)
+
+def dev(a):
+    a = np.ascontiguousarray(a); p = dmalloc(max(a.nbytes, 8)); h2d(p, a); return p
+def host(p, shape, dtype=np.float64):
+    a = np.empty(shape, dtype=dtype); d2h(a, p); return a
+
+dt, dy, ddiag, dcc, dgll = dev(t), dev(y), dev(diag), dev(cc), dev(gll)
+params, ld = dmalloc(8 * D * 20), dmalloc(8 * D * 3)
+assert lib.exo_pack_records_f64(dev(orbit_in), dev(ld_in), D, 1, 8, params, ld, None) == 0       # EXO_PACK_CIRCULAR
+ws_bytes = lib.exo_transit_flux_workspace_bytes(n, D, 1)
+
+def zeros(nbytes):
+    p = dmalloc(nbytes); assert hip.hipMemset(p, 0, ctypes.c_size_t(nbytes)) == 0; return p
+
+out = {}
+for route in ("dense", "sparse"):
+    ws = zeros(ws_bytes)
+    sparse = route == "sparse"
+    C = lib.exo_celerite_default_chunks(n, D, 0, 1, 1)          # the same plan on both routes: the same arithmetic
+    n_state = lib.exo_celerite_state_doubles(n, D, 0, 1, C)
+    state = dmalloc(8 * n_state)
+    ll, gcc, gparams, gld = dmalloc(8 * D), dmalloc(8 * D * 4), dmalloc(8 * D * 20), dmalloc(8 * D * 3)
+    if sparse:
+        F = SPARSE | SORTED
+        assert lib.exo_transit_flux_fwd_f64(dt, n, None, 0, None, None, 1, params, ld, D, 1, F, None, ws, ws_bytes, None) == 0
+        m = SparseModel()
+        assert lib.exo_transit_flux_sparse_model(ws, ws_bytes, n, D, 1, F, ctypes.byref(m)) == 0
+        order = dmalloc(4 * D)
+        assert lib.exo_sparse_model_order(ctypes.byref(m), D, order, None) == 0
+        m.row_of_draw = order
+        assert lib.exo_celerite_loglike_sparse_fwd_f64(dt, dy, ctypes.addressof(m), ddiag, 1, n, None, 0, dcc, 1, None, D, ll, state, n_state, C, None) == 0
+        gvals = dmalloc(8 * D * n)
+        assert lib.exo_celerite_loglike_sparse_vjp_f64(dt, dy, ctypes.addressof(m), ddiag, 1, n, None, 0, dcc, 1, None, D, dgll, state, n_state, C,
+                                                       gvals, None, None, None, gcc, None) == 0
+        assert lib.exo_transit_flux_vjp_sparse_f64(dt, n, None, 0, None, None, 1, params, ld, D, 1, F, gvals, gparams, gld, None, ws, ws_bytes, 1, None) == 0
+        out["order"] = host(order, (D,), np.int32)
+    else:
+        F = CM | SORTED
+        flux = dmalloc(8 * D * n)
+        assert lib.exo_transit_flux_fwd_f64(dt, n, None, 0, None, None, 1, params, ld, D, 1, F, flux, ws, ws_bytes, None) == 0
+        assert lib.exo_celerite_loglike_obs_fwd_cm_f64(dt, dy, flux, ddiag, 1, n, None, 0, dcc, 1, None, D, ll, state, n_state, C, None) == 0
+        gflux = dmalloc(8 * D * n)
+        assert lib.exo_celerite_loglike_obs_vjp_cm_f64(dt, dy, flux, ddiag, 1, n, None, 0, dcc, 1, None, D, dgll, state, n_state, C,
+                                                       gflux, None, None, None, gcc, None) == 0
+        assert lib.exo_transit_flux_vjp_f64(dt, n, None, 0, None, None, 1, params, ld, D, 1, F, gflux, None, gparams, gld, None, ws, ws_bytes, None) == 0
+    assert hip.hipDeviceSynchronize() == 0
+    out[route] = (host(ll, (D,)), host(gcc, (D, 4)), host(gparams, (D, 20)), host(gld, (D, 3)))
+
+(ll_d, gcc_d, gp_d, gld_d), (ll_s, gcc_s, gp_s, gld_s) = out["dense"], out["sparse"]
+assert np.all(np.isfinite(ll_d)) and np.abs(gp_d).max() > 0 and np.abs(gcc_d).max() > 0
+assert np.abs(ll_s - ll_d).max() <= 1e-13 * np.abs(ll_d).max(), np.abs(ll_s - ll_d).max()
+for a, b in ((gcc_s, gcc_d), (gp_s, gp_d), (gld_s, gld_d)):
+    assert np.abs(a - b).max() <= 1e-12 * np.abs(b).max(), (np.abs(a - b).max(), np.abs(b).max())
+assert sorted(out["order"].tolist()) == list(range(D)) and out["order"].tolist() != list(range(D))    # a real permutation
+assert "torch" not in sys.modules, "the client must not need torch"
+print("SPARSE_CLIENT_OK")
+"""
+
+
+@pytest.mark.gpu
+def test_integration_md_sparse_mean_client_runs_without_torch(dev, tmp_path):
+    """INTEGRATION.md section 4.1 (ABI 11 / 12): sweep -> exo_sparse_model -> exo_sparse_model_order -> sparse celerite pair -> sparse
+    reverse sweep, a client that never imports torch, held to the dense cadence-major route through the same raw entry points"""
+    script = tmp_path / "sparse_client.py"
+    script.write_text(SPARSE_CLIENT)
+    res = subprocess.run([sys.executable, str(script), ROOT], capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    assert "SPARSE_CLIENT_OK" in res.stdout
