@@ -155,6 +155,46 @@ def test_gp_hard_golden(dev, key):
                 np.testing.assert_allclose(gc[:, q], w, rtol=1e-6, atol=1e-6 * np.abs(w).max())
 
 
+@pytest.mark.parametrize("key", ["kappa1e9", "kappa1e10", "diag0", "diag0_j4"])
+def test_gp_edge_golden(dev, key):
+    """VERDICT r4 item 7's fixture: conditioning scores of 1e9 / 1e10 (beyond the 1e8 of the robust route) and diag = 0 exactly
+    (oracle/make_golden_r05b.py, long-double dense definition).  The time-parallel path flags such draws on the device and its
+    sequential kernels redo them: the DEFAULT call and n_chunks = 1 must both hold the log-likelihood to 1e-9 and every gradient
+    to 1e-6 -- in a batch where the edge draw sits between ordinary ones (same series, error bars of 0.05), which must come out
+    as they do alone."""
+    from exoplanet_amd.gp import celerite_loglike
+
+    g = np.load(os.path.join(GOLD, "gp_edge.npz"))
+    co = [g[f"{key}_{nm}"] for nm in ("ar", "cr", "ac", "bc", "cc", "dc")]
+    want = float(g[f"{key}_loglike"])
+    D, edge = 5, (1, 3)
+    real = np.repeat(np.stack(co[:2], -1)[None], D, 0)
+    cplx = np.repeat(np.stack(co[2:], -1)[None], D, 0)
+    diag = np.repeat(np.full_like(g[f"{key}_diag"], 2.5e-3)[None], D, 0)
+    for d in edge:
+        diag[d] = g[f"{key}_diag"]
+    res = []
+    for n_chunks in (None, 1):
+        yt = T(np.repeat(g[f"{key}_y"][None], D, 0), dev).requires_grad_(True)
+        dt = T(diag, dev).requires_grad_(True)
+        rt, ct = T(real, dev).requires_grad_(True), T(cplx, dev).requires_grad_(True)
+        ll = celerite_loglike(T(g[f"{key}_t"], dev), yt, dt, rt, ct, n_chunks=n_chunks)
+        ll.sum().backward()
+        lln = ll.detach().cpu().numpy()
+        for d in edge:
+            assert abs(lln[d] - want) <= 1e-9 * abs(want), (n_chunks, d, lln[d], want)
+            for got, nm in ((yt.grad[d], "gy"), (dt.grad[d], "gdiag"), (ct.grad[d, :, 0], "gac"), (ct.grad[d, :, 1], "gbc"),
+                            (ct.grad[d, :, 2], "gcc"), (ct.grad[d, :, 3], "gdc")):
+                w = g[f"{key}_{nm}"]
+                err = float(np.abs(got.cpu().numpy() - w).max() / np.abs(w).max())
+                assert err <= 1e-6, (n_chunks, d, nm, err)
+        res.append((lln, yt.grad.cpu().numpy(), ct.grad.cpu().numpy()))
+    # the ordinary draws next to them: time-parallel and sequential kernels agree as they do in a batch of their own
+    for d in (0, 2, 4):
+        assert abs(res[0][0][d] - res[1][0][d]) <= 1e-11 * abs(res[1][0][d])
+        assert np.abs(res[0][1][d] - res[1][1][d]).max() <= 1e-8 * np.abs(res[1][1][d]).max()
+
+
 @pytest.mark.parametrize("key", ["rot2_sho", "rot3", "mixed16"])
 def test_gp_wide_golden(dev, key):
     """state widths beyond the time-parallel path's 8 (celerite2 has no limit; two RotationTerms + an SHO
