@@ -234,7 +234,7 @@ template <int J, bool SAVE>
 __global__ __launch_bounds__(kWave) void celerite_fwd_kernel(
     const double* __restrict__ t, Series rs, const double* __restrict__ diag,
     int64_t n_diag, int64_t n, Coefs cf, int64_t n_draw, double* __restrict__ loglike,
-    double* __restrict__ state, const double* __restrict__ only_flagged) {
+    double* __restrict__ state, const double* __restrict__ only_flagged, ChunkGeom cg, int n_slice) {
   constexpr int G = Group<J>::G;
   const int j = threadIdx.x & (G - 1);
   const int64_t lane_draw = ((int64_t)blockIdx.x * kWave + threadIdx.x) / G;
@@ -242,7 +242,22 @@ __global__ __launch_bounds__(kWave) void celerite_fwd_kernel(
   const int64_t draw = live_draw ? lane_draw : n_draw - 1;
   // after the time-parallel path: redo only the draws it could not take (see DeltaCoef)
   const bool mine = live_draw && (!only_flagged || only_flagged[draw] >= kFlagSeq);
-  if (only_flagged && __ballot(mine) == 0) return;
+  if (only_flagged) {
+    // ... and every other draw's log-likelihood from the chunks' partial sums (n_slice of them per quantity, in the slots of
+    // chunks 0 .. n_slice - 1: celerite_chunk_slice_sum_kernel) -- round 5: this launch is there anyway, a kernel of its own for
+    // the sums' last step was 7 us of the step
+    if (live_draw && !mine && j == 0) {
+      const ChunkWs ws = chunk_ws(n, n_draw, J, cg);
+      double acc = 0.0, logdet = 0.0, bad = 0.0;
+      for (int q = 0; q < n_slice; ++q) {
+        acc += state[ws.part(q, 0, draw)];
+        logdet += state[ws.part(q, 1, draw)];
+        bad += state[ws.part(q, 2, draw)];
+      }
+      loglike[cf.at(draw)] = (bad > 0.0) ? -INFINITY : fma(-0.5, acc + logdet, -(double)n * kHalfLog2Pi);
+    }
+    if (__ballot(mine) == 0) return;
+  }
   const LaneCoef k = lane_coef(cf, draw, j, J);
   const bool store = SAVE && mine && k.live;
   // a_n = diag_n + sum of the a coefficients (first index of each term)
@@ -384,12 +399,18 @@ __global__ __launch_bounds__(kWave) void celerite_vjp_kernel(
     int64_t n_draw, const double* __restrict__ gloglike, const double* __restrict__ state,
     double* __restrict__ gresid, double* __restrict__ gdiag, double* __restrict__ gdiag_sum,
     double* __restrict__ gcoef_real, double* __restrict__ gcoef_complex, const double* __restrict__ only_flagged,
-    double gsign, Series rs) {   // rs: the series this is the cotangent of (its layout is the cotangent's: GradRow)
+    double gsign, Series rs, ChunkGeom cg) {   // rs: the series this is the cotangent of (its layout is the cotangent's: GradRow)
   constexpr int G = Group<J>::G;
   const int j = threadIdx.x & (G - 1);
   const int64_t lane_draw = ((int64_t)blockIdx.x * kWave + threadIdx.x) / G;
   const bool live_draw = (lane_draw < n_draw) && (!only_flagged || only_flagged[lane_draw < n_draw ? lane_draw : 0] >= kFlagSeq);
-  if (only_flagged && __ballot(live_draw) == 0) return;
+  if (only_flagged) {
+    // ... and every other draw's coefficient cotangents from the sums over the chunks (totals in chunk 0's slots): gcoef_lane,
+    // the combination of this kernel's own tail, on the lanes that would otherwise leave at once
+    if (lane_draw < n_draw && !live_draw && j < J)
+      gcoef_lane(cf, n, n_draw, state, cg, 1, gdiag_sum, gcoef_real, gcoef_complex, lane_draw, j);
+    if (__ballot(live_draw) == 0) return;
+  }
   const int64_t draw = lane_draw < n_draw ? lane_draw : n_draw - 1;
   const LaneCoef k = lane_coef(cf, draw, j, J);
   const int jj = k.live ? j : 0;  // idle lanes read a valid slot and contribute zeros
@@ -1744,35 +1765,6 @@ __global__ __launch_bounds__(kWave) void celerite_chunk_slice_sum_kernel(double*
   *p = v;
 }
 
-// the log-likelihood of a draw from the slices' partial sums
-__global__ __launch_bounds__(kWave) void celerite_chunk_loglike_kernel(int64_t n, int64_t n_draw, int J,
-                                                                       const double* __restrict__ state, ChunkGeom cg, int S,
-                                                                       double* __restrict__ loglike, const int32_t* __restrict__ row) {
-  const int64_t draw = (int64_t)blockIdx.x * kWave + threadIdx.x;
-  if (draw >= n_draw) return;
-  const ChunkWs ws = chunk_ws(n, n_draw, J, cg);
-  double acc = 0.0, logdet = 0.0, bad = 0.0;
-  for (int s = 0; s < S; ++s) {
-    acc += state[ws.part(s, 0, draw)];
-    logdet += state[ws.part(s, 1, draw)];
-    bad += state[ws.part(s, 2, draw)];
-  }
-  loglike[row ? (int64_t)row[draw] : draw] = (bad > 0.0) ? -INFINITY : fma(-0.5, acc + logdet, -(double)n * kHalfLog2Pi);
-}
-
-// step 2: the same combination as the tail of celerite_vjp_kernel
-__global__ __launch_bounds__(kWave) void celerite_chunk_gcoef_kernel(int64_t n, int64_t n_draw, Coefs cf,
-                                                                     const double* __restrict__ state, ChunkGeom cg, int S,
-                                                                     double* __restrict__ gdiag_sum,
-                                                                     double* __restrict__ gcoef_real,
-                                                                     double* __restrict__ gcoef_complex) {
-  const int J = cf.J();
-  const int64_t e = (int64_t)blockIdx.x * kWave + threadIdx.x;
-  if (e >= n_draw * J) return;
-  const int64_t draw = e / J;
-  gcoef_lane(cf, n, n_draw, state, cg, S, gdiag_sum, gcoef_real, gcoef_complex, draw, (int)(e - draw * J));
-}
-
 // O(N) companions (exo_celerite_core.hpp): one lane per draw
 template <int J>
 __global__ __launch_bounds__(kWave) void celerite_dot_tril_kernel(const double* __restrict__ t,
@@ -2074,6 +2066,7 @@ static int celerite_fwd(const double* t, Series resid, const double* diag, int64
   if (state) {
     const ChunkGeom cg = chunk_plan(n, n_draw, J, n_chunks);
     const double* only_flagged = nullptr;
+    int n_slice = 0;
     if (cg.C <= 1) {
       const int64_t n_el = n * n_draw * J;
       hipLaunchKernelGGL(celerite_prep_kernel, dim3((unsigned)((n_el + 255) / 256)), dim3(256), 0, st, t, n, cf, n_draw,
@@ -2203,16 +2196,16 @@ static int celerite_fwd(const double* t, Series resid, const double* diag, int64
         const int S = chunk_sum_slices(cg.C, 3, n_draw, 16);   // (the last kernel's lanes add the S partials themselves)
         hipLaunchKernelGGL(celerite_chunk_slice_sum_kernel, dim3(per_draw.x, 3, (unsigned)S), block, 0, st, state + ws.off_part(), 3,
                            cg.C, S, n_draw);
-        hipLaunchKernelGGL(celerite_chunk_loglike_kernel, per_draw, block, 0, st, n, n_draw, J, state, cg, S, loglike, cf.row);
+        n_slice = S;   // (the sums' last step: the unflagged lanes of the sequential kernel below)
       }
       if (launch_status() != EXO_OK) return EXO_ERR_LAUNCH;
       only_flagged = state + ws.off_flag();
     }
     EXO_GP_DISPATCH_SEQ(J, hipLaunchKernelGGL((celerite_fwd_kernel<JJ, true>), grid, block, 0, st, t, resid, diag, n_diag, n,
-                                          cf, n_draw, loglike, state, only_flagged))
+                                          cf, n_draw, loglike, state, only_flagged, cg, n_slice))
   } else {
     EXO_GP_DISPATCH_SEQ(J, hipLaunchKernelGGL((celerite_fwd_kernel<JJ, false>), grid, block, 0, st, t, resid, diag, n_diag, n,
-                                          cf, n_draw, loglike, state, (const double*)nullptr))
+                                          cf, n_draw, loglike, state, (const double*)nullptr, ChunkGeom{}, 0))
   }
   return launch_status();
 }
@@ -2314,15 +2307,14 @@ static int celerite_vjp(const double* t, Series resid, const double* diag, int64
       if (S > 1)
         hipLaunchKernelGGL(celerite_chunk_slice_sum_kernel, dim3(per_draw.x, (unsigned)K, 1), block, 0, st, wstate + ws.off_gpart(), K,
                            S, 1, n_draw);
-      hipLaunchKernelGGL(celerite_chunk_gcoef_kernel, dim3((unsigned)((n_draw * J + kWave - 1) / kWave)), block, 0, st, n,
-                         n_draw, cf, state, cg, 1, gdiag_sum, gcoef_real, gcoef_complex);
+      // (the combination into gcoef_*: the unflagged lanes of the sequential kernel below)
     }
     if (launch_status() != EXO_OK) return EXO_ERR_LAUNCH;
     only_flagged = state + ws.off_flag();
   }
   EXO_GP_DISPATCH_SEQ(J, hipLaunchKernelGGL((celerite_vjp_kernel<JJ>), grid, block, 0, st, t, diag, n_diag, n, cf, n_draw,
                                         gloglike, state, gresid, gdiag, gdiag_sum, gcoef_real, gcoef_complex,
-                                        only_flagged, gsign, resid))
+                                        only_flagged, gsign, resid, cg))
   return launch_status();
 }
 
