@@ -602,10 +602,10 @@ def cpu_baseline(budget_s=27.0, config="c2"):
     head = {"c2": "one_core_in_transit", "c3": "c3_one_core", "c4": "c4_one_core", "c5": "c5_one_core"}[config]
     one = legs[head]
     return {"value": one.get("evals_per_s"), "unit": "evals/s", "cores": 1, "kind": "port", "leg": head,
-            "sample": f"{one.get('evals')} evaluations (value+VJP; {one.get('semantics')}) of the {config.upper()} workload, oracle/c "
-                      f"scalar port, {one.get('seconds', 0):.1f} s on 1 of {os.cpu_count()} host cores -- the like-for-like leg: "
-                      "the GPU sweep solves only the cadences inside its conjunction windows too.  `legs`: every-cadence "
-                      f"semantics, all {n_threads} usable cores ({usable_why}; one draw per thread), and C3 / C4 / C5",
+            "sample": f"{one.get('evals')} evaluations (value+VJP) of the {config.upper()} workload in {one.get('seconds', 0):.1f} s, oracle/c "
+                      f"scalar port on 1 of {os.cpu_count()} host cores; {one.get('semantics')}",
+            "sample_note": "the like-for-like leg: the GPU sweep solves only the cadences inside its conjunction windows too.  `legs`: "
+                           f"every-cadence semantics, all {n_threads} usable cores ({usable_why}; one draw per thread), and C3 / C4 / C5",
             "cpu_model": cpu_model(), "host_cores": os.cpu_count(), "usable_cores": usable, "usable_cores_from": usable_why,
             "legs": legs,
             "note": "the reference's own Ops (exoplanet_core, celerite2) are not installable here: kind = port"}
@@ -890,18 +890,97 @@ def extra_ttv(xo, ops, leaves, t, gbar, dev, D):
 
 
 def load_counters():
-    """This round's committed counter record (profiles/r05_counters.json: rocprofv3 --pmc passes, tools/profile_r05.sh),
+    """This round's committed counter record (profiles/r06_counters.json: rocprofv3 --pmc passes, tools/profile_r06.sh),
     quoted only when it was taken on the kernel sources this run executes (sha256 of the .hip / .hpp files)."""
     try:
         import hashlib
 
-        p = json.load(open(os.path.join(ROOT, "profiles", "r05_counters.json")))
+        p = json.load(open(os.path.join(ROOT, "profiles", "r06_counters.json")))
         h = hashlib.sha256()
         for f in sorted(p["kernel_sources"]):
             h.update(open(os.path.join(ROOT, "exoplanet_amd", "csrc", f), "rb").read())
         return p if h.hexdigest() == p["kernel_sources_sha256"] else None
     except Exception:
         return None
+
+
+COMPACT_LIMIT = 4096     # bytes of the last stdout line (tests/test_bench_line.py holds compact_line to it)
+
+
+def _short(x, n=200):
+    return x if not isinstance(x, str) or len(x) <= n else x[:n - 3] + "..."
+
+
+def _num(x, digits=6):
+    """numbers to `digits` significant figures (the full precision is in the side file)"""
+    if isinstance(x, bool) or not isinstance(x, (int, float)):
+        return x
+    if isinstance(x, int) or x == 0 or x != x or x in (float("inf"), float("-inf")):
+        return x
+    return float(f"{x:.{digits}g}")
+
+
+def compact_line(out):
+    """The contract line: the driver's keys + `config` (short strings) + `roofline` + `cpu_baseline` + `configs_ms`, nothing else.
+    Built from the full record `out` (which keeps every definition, extras leg and CPU leg: write_full_record)."""
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+            "dtype", "data")
+    line = {k: _num(out.get(k), 8) for k in keep}
+    cfg = out.get("config") or {}
+    line["config"] = {k: _short(_num(v), 200) for k, v in cfg.items()
+                      if k in ("workload", "n_cadences", "draws_per_gpu", "global_draws", "parallelism", "step")}
+    line["config"]["parallelism"] = _short(f"draws sharded over {out.get('n_gpus')} GPU(s); one collective of per-draw scalars per step", 120)
+    line["config"]["step"] = _short(cfg.get("step"), 160)
+    r = out.get("roofline")
+    if r:
+        rr = {k: _short(_num(r.get(k)), 120) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_source",
+                                                       "algorithmic_bytes_per_launch", "kernel_ms", "frac_step")}
+        pmc = r.get("pmc") or {}
+        if pmc:
+            rr["pmc_kernel_GBps"] = _num(pmc.get("dominant_kernel_GBps"))
+            rr["pmc_kernel_frac"] = _num(pmc.get("dominant_kernel_frac"))
+            rr["pmc_kernel_us"] = _num(pmc.get("dominant_kernel_rocprof_avg_us"))
+        if r.get("survey_8d_count"):
+            rr["survey_8d_GBps"] = _num(r["survey_8d_count"].get("GBps"))
+        elif r.get("survey_8d_GBps") is not None:
+            rr["survey_8d_GBps"] = _num(r.get("survey_8d_GBps"))
+        line["roofline"] = rr
+    else:
+        line["roofline"] = None
+    c = out.get("cpu_baseline")
+    if c:
+        cc = {k: _short(_num(c.get(k)), 200) for k in ("value", "unit", "cores", "kind", "leg", "sample", "cpu_model", "usable_cores")}
+        legs = c.get("legs") or {}
+        allc = legs.get((c.get("leg") or "").replace("one_core", "all_cores")) or {}
+        cc["all_cores_value"] = _num(allc.get("evals_per_s"))
+        cc["all_cores_threads"] = allc.get("threads")
+        line["cpu_baseline"] = cc
+    else:
+        line["cpu_baseline"] = None
+    cm = dict(out.get("configs_ms") or {})
+    cm.pop("note", None)
+    line["configs_ms"] = cm
+    line["full_record"] = out.get("full_record")
+    n = len(json.dumps(line))
+    if n > COMPACT_LIMIT:       # cannot happen with the caps above; never let the line outgrow the driver again
+        line["config"] = {"workload": _short(cfg.get("workload"), 100)}
+        if line.get("cpu_baseline"):
+            line["cpu_baseline"].pop("sample", None)
+    return line
+
+
+def write_full_record(out):
+    """the full record (extras, every CPU leg, the definitions) -> gpurun_out/bench_full.json, which gpurun merges back; the
+    committed copy of a round is profiles/rNN_bench_full.json.  Not to stderr: the driver's tail may interleave the streams."""
+    d = os.path.join(ROOT, "gpurun_out")
+    try:
+        os.makedirs(d, exist_ok=True)
+        name = "bench_full.json" if out.get("n_gpus", 1) == 1 else f"bench_full_{out.get('n_gpus')}gpu.json"
+        with open(os.path.join(d, name), "w") as f:
+            json.dump(out, f, indent=1)
+        out["full_record"] = "gpurun_out/" + name
+    except OSError:
+        out["full_record"] = None
 
 
 def launcher_argv(n_gpus, argv):
@@ -1030,7 +1109,7 @@ def main():
             n_active = ops.transit_flux_sparse(t_dev, rec0.detach(), ld0.detach(), flags=flags0).n_solved()
     else:
         # GP configs: the step is a chain of ~20 kernels; the whole replayed step is timed with events on the stream it
-        # is replayed on (per-kernel averages and counters: profiles/r05_*)
+        # is replayed on (per-kernel averages and counters: profiles/r06_*)
         q = time_events(lambda: run(-1), dev, 20)
         drain()
         kernel_ms = q["median_ms"]
@@ -1079,8 +1158,9 @@ def main():
             achieved = req_bytes / (kernel_ms * 1e-3) / 1e9
             roof = {
                 "bound": "hbm",
-                "kernel": "transit_runs_kernel (dominant; the sweep = transit_window_kernel + transit_enum_kernel + "
-                          "transit_runs_kernel [+ transit_finish_kernel below 512 draws])",
+                "kernel": "transit_runs_kernel",
+                "kernel_note": "dominant; kernel_ms is the hipEvent time of the whole sweep = transit_enum_kernel + transit_runs_kernel "
+                               "[+ transit_finish_kernel below 512 draws]",
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "frac_definition": "achieved / peak; achieved = bytes this design must move per sweep (algorithmic_bytes_breakdown) / "
                                    "mean hipEvent time of the sweep's launches in this run",
@@ -1132,11 +1212,11 @@ def main():
             step_s = kernel_ms * 1e-3
             out["roofline"] = {
                 "bound": "hbm", "kernel": "whole replayed step (celerite element / scan-tree / chunk kernels + the light-curve "
-                                          "sweeps + packing); per-kernel: profiles/r05_*",
+                                          "sweeps + packing); per-kernel: profiles/r06_*",
                 "achieved": traffic / step_s / 1e9 if traffic else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": traffic / step_s / 1e9 / HBM_PEAK_GBS if traffic else None,
                 "frac_definition": "HBM bytes of one step from the PMC counters (FETCH_SIZE x 2 on gfx950 + WRITE_SIZE, separate passes: "
-                                   "profiles/r05_counters.json, quoted only when taken on these kernel sources) / median event time of "
+                                   "profiles/r06_counters.json, quoted only when taken on these kernel sources) / median event time of "
                                    "one replayed step in THIS run / 8 TB/s.  The step is fp64-issue-bound, not bandwidth-bound: see `valu` "
                                    "(SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x kernel time x 2.4 GHz) per kernel)",
                 "traffic": traffic, "traffic_source": c["source"] if c else None, "valu": c.get("valu") if c else None,
@@ -1314,6 +1394,12 @@ def main():
             "sparse": pick("c2_sparse_output"), "chi2": pick("c2_white_noise_likelihood"),
             "hmc": pick("hmc_trajectory_c2"), "nuts_leaf": pick("nuts_transition_c2", "ms_per_leaf"),
             "c2_one_call": pick("c2_one_call"),
+            # the reference's standalone Ops at n = 1.5e8 (GB/s of their algorithmic bytes: 32 / 40 / 88 B per element)
+            "kepler_GBps": (round(ex["ops"]["kepler"]["GBps"], 1) if isinstance(ex.get("ops"), dict) and "kepler" in ex["ops"] else None),
+            "quad_sv_GBps": (round(ex["ops"]["quad_solution_vector_value"]["GBps"], 1)
+                             if isinstance(ex.get("ops"), dict) and "quad_solution_vector_value" in ex["ops"] else None),
+            "quad_sv_grad_GBps": (round(ex["ops"]["quad_solution_vector_with_derivs"]["GBps"], 1)
+                                  if isinstance(ex.get("ops"), dict) and "quad_solution_vector_with_derivs" in ex["ops"] else None),
             "note": "ms per value + gradient step, one MI355X, hipGraph replay; c2 / sparse / chi2 at 1024 draws x 150000 cadences",
         }
     if dist is not None:
@@ -1325,7 +1411,10 @@ def main():
             ctypes.CDLL(None).fflush(None)
         except Exception:
             pass
-        print(json.dumps(out), flush=True)
+        # The full record (extras, every CPU leg, definitions) goes to a side file and to stderr; the LAST line of stdout is the
+        # compact contract line only (a 20.8 KB line was not parsed by the driver)
+        write_full_record(out)
+        print(json.dumps(compact_line(out)), flush=True)
 
 
 if __name__ == "__main__":

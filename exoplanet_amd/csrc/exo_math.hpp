@@ -33,6 +33,31 @@
 #define EXO_WAVE_ANY(c) (__any((int)(c)))
 #endif
 
+// EXO_K(x): the fp64 constant x held in a SCALAR register pair (round 6).  gfx950's VOP3 encoding takes no 64-bit literal, so
+// the compiler materialises every polynomial coefficient with two v_mov_b32 (or a v_mov_b64 of a hoisted copy) and feeds a
+// v_fmac: a quarter of the vector instructions of the sweep's hot loop were such moves (212 of 1236), on the one pipe that
+// bounds it.  Two s_mov_b32 on the scalar unit -- which issues beside the other waves' vector instructions -- put the constant
+// into s[92:93] / s[94:95] and the v_fma_f64 reads it from there as its addend (one scalar operand per instruction: the
+// constant bus).  `volatile` keeps the moves where they are used: hoisted out of a loop they would cost ~100 live scalar
+// pairs.  Use it for addends and factors of fma chains, at most one per instruction; exact powers of two and small integers
+// are inline operands already and need nothing.
+#if defined(EXO_HOST_BUILD) || !defined(__HIP_DEVICE_COMPILE__) || defined(EXO_NO_SCALAR_CONSTANTS)
+#define EXO_K(x) (x)
+#define EXO_K2(x) (x)
+#else
+#define EXO_KP_(x, R0, R1)                                                                                             \
+  ([]() __attribute__((always_inline)) -> double {                                                                     \
+    constexpr unsigned long long u_ = __builtin_bit_cast(unsigned long long, (double)(x));                             \
+    double d_;                                                                                                         \
+    asm volatile("s_mov_b32 s" #R0 ", %1\n\ts_mov_b32 s" #R1 ", %2"                                                    \
+                 : "={s[" #R0 ":" #R1 "]}"(d_)                                                                         \
+                 : "i"((unsigned)(u_ & 0xffffffffull)), "i"((unsigned)(u_ >> 32)));                                    \
+    return d_;                                                                                                         \
+  }())
+#define EXO_K(x) EXO_KP_(x, 92, 93)
+#define EXO_K2(x) EXO_KP_(x, 94, 95)   // a second pair, for two chains side by side
+#endif
+
 namespace exo {
 
 constexpr double kPi = 3.14159265358979323846;
@@ -47,15 +72,15 @@ EXO_HD double x_minus_sin(double x, double sinx) {
   const double x2 = x * x;
   // x^3/6 (1 - x^2/20 + x^4/840 - ...): coefficients (-1)^k 6/(2k+3)!
   double s = 2.8114572543455207632e-15 * 6.0 * (1.0 / (18.0 * 19.0));   // 6/19!
-  s = fma(s, x2, -6.0 * 2.8114572543455207632e-15);                        // -6/17!
-  s = fma(s, x2, 6.0 * 7.6471637318198164759e-13);                         //  6/15!
-  s = fma(s, x2, -6.0 * 1.6059043836821614599e-10);                        // -6/13!
-  s = fma(s, x2, 6.0 * 2.5052108385441718775e-08);                         //  6/11!
-  s = fma(s, x2, -6.0 * 2.7557319223985890653e-06);                        // -6/9!
-  s = fma(s, x2, 6.0 * 1.9841269841269841270e-04);                         //  6/7!
-  s = fma(s, x2, -6.0 * 8.3333333333333333333e-03);                        // -6/5!
+  s = fma(s, x2, EXO_K(-6.0 * 2.8114572543455207632e-15));                 // -6/17!
+  s = fma(s, x2, EXO_K(6.0 * 7.6471637318198164759e-13));                  //  6/15!
+  s = fma(s, x2, EXO_K(-6.0 * 1.6059043836821614599e-10));                 // -6/13!
+  s = fma(s, x2, EXO_K(6.0 * 2.5052108385441718775e-08));                  //  6/11!
+  s = fma(s, x2, EXO_K(-6.0 * 2.7557319223985890653e-06));                 // -6/9!
+  s = fma(s, x2, EXO_K(6.0 * 1.9841269841269841270e-04));                  //  6/7!
+  s = fma(s, x2, EXO_K(-6.0 * 8.3333333333333333333e-03));                 // -6/5!
   s = fma(s, x2, 1.0);
-  s = x * x2 * (1.0 / 6.0) * s;
+  s = x * x2 * EXO_K(1.0 / 6.0) * s;
   return (x < 0.9) ? s : (x - sinx);
 }
 
@@ -163,23 +188,23 @@ EXO_HD void sincos_halfpi(double x, double* s, double* c) {
   const bool hi = x > 0.78539816339744830962;
   const double y = hi ? (1.57079632679489655800 - x) + 6.123233995736766036e-17 : x;
   const double y2 = y * y;
-  double ps = -2.8114572543455207632e-15;         // -1/17!
-  ps = fma(ps, y2, 7.6471637318198164759e-13);    //  1/15!
-  ps = fma(ps, y2, -1.6059043836821614599e-10);   // -1/13!
-  ps = fma(ps, y2, 2.5052108385441718775e-08);    //  1/11!
-  ps = fma(ps, y2, -2.7557319223985890653e-06);   // -1/9!
-  ps = fma(ps, y2, 1.9841269841269841270e-04);    //  1/7!
-  ps = fma(ps, y2, -8.3333333333333333333e-03);   // -1/5!
-  ps = fma(ps, y2, 1.6666666666666666667e-01);    //  1/3!  (sign applied below)
-  ps = fma(-ps * y2, y, y) ;                       // y - y^3/6 + ...  (ps holds +1/6 - y2/120 ...)
-  double pc = 4.7794773323873852974e-14;          //  1/16!
-  pc = fma(pc, y2, -1.1470745597729724714e-11);   // -1/14!
-  pc = fma(pc, y2, 2.0876756987868098979e-09);    //  1/12!
-  pc = fma(pc, y2, -2.7557319223985890653e-07);   // -1/10!
-  pc = fma(pc, y2, 2.4801587301587301587e-05);    //  1/8!
-  pc = fma(pc, y2, -1.3888888888888888889e-03);   // -1/6!
-  pc = fma(pc, y2, 4.1666666666666666667e-02);    //  1/4!
+  double ps = -2.8114572543455207632e-15;                   // -1/17!
+  ps = fma(ps, y2, EXO_K(7.6471637318198164759e-13));       //  1/15!
+  double pc = 4.7794773323873852974e-14;                    //  1/16!
+  pc = fma(pc, y2, EXO_K2(-1.1470745597729724714e-11));     // -1/14!
+  ps = fma(ps, y2, EXO_K(-1.6059043836821614599e-10));      // -1/13!
+  pc = fma(pc, y2, EXO_K2(2.0876756987868098979e-09));      //  1/12!
+  ps = fma(ps, y2, EXO_K(2.5052108385441718775e-08));       //  1/11!
+  pc = fma(pc, y2, EXO_K2(-2.7557319223985890653e-07));     // -1/10!
+  ps = fma(ps, y2, EXO_K(-2.7557319223985890653e-06));      // -1/9!
+  pc = fma(pc, y2, EXO_K2(2.4801587301587301587e-05));      //  1/8!
+  ps = fma(ps, y2, EXO_K(1.9841269841269841270e-04));       //  1/7!
+  pc = fma(pc, y2, EXO_K2(-1.3888888888888888889e-03));     // -1/6!
+  ps = fma(ps, y2, EXO_K(-8.3333333333333333333e-03));      // -1/5!
+  pc = fma(pc, y2, EXO_K2(4.1666666666666666667e-02));      //  1/4!
+  ps = fma(ps, y2, EXO_K(1.6666666666666666667e-01));       //  1/3!  (sign applied below)
   pc = fma(pc, y2, -0.5);
+  ps = fma(-ps * y2, y, y);                                 // y - y^3/6 + ...  (ps holds +1/6 - y2/120 ...)
   pc = fma(pc, y2, 1.0);
   *s = hi ? pc : ps;
   *c = hi ? ps : pc;
@@ -191,30 +216,30 @@ EXO_HD void sincos_halfpi(double x, double* s, double* c) {
 // add), then the Taylor polynomials of sincos_halfpi on [-pi/4, pi/4].  ~45 instructions and no
 // slow path: libm's sincos costs twice that and, inlined, the registers of its large-argument code.
 EXO_HD void sincos_any(double x, double* s, double* c) {
-  const double k = rint(x * 0.6366197723675814);
-  double y = fma(-k, 1.570796251296997, x);
-  y = fma(-k, 7.549789415861596e-08, y);
-  y = fma(-k, 5.390302529957765e-15, y);
-  y = fma(-k, 3.282003415807913e-22, y);
-  y = fma(-k, 1.270655753080676e-29, y);
+  const double k = rint(x * EXO_K(0.6366197723675814));
+  double y = fma(-k, EXO_K(1.570796251296997), x);
+  y = fma(-k, EXO_K(7.549789415861596e-08), y);
+  y = fma(-k, EXO_K(5.390302529957765e-15), y);
+  y = fma(-k, EXO_K(3.282003415807913e-22), y);
+  y = fma(-k, EXO_K(1.270655753080676e-29), y);
   const double y2 = y * y;
-  double ps = -2.8114572543455207632e-15;         // -1/17!
-  ps = fma(ps, y2, 7.6471637318198164759e-13);
-  ps = fma(ps, y2, -1.6059043836821614599e-10);
-  ps = fma(ps, y2, 2.5052108385441718775e-08);
-  ps = fma(ps, y2, -2.7557319223985890653e-06);
-  ps = fma(ps, y2, 1.9841269841269841270e-04);
-  ps = fma(ps, y2, -8.3333333333333333333e-03);
-  ps = fma(ps, y2, 1.6666666666666666667e-01);
-  ps = fma(-ps * y2, y, y);
-  double pc = 4.7794773323873852974e-14;          //  1/16!
-  pc = fma(pc, y2, -1.1470745597729724714e-11);
-  pc = fma(pc, y2, 2.0876756987868098979e-09);
-  pc = fma(pc, y2, -2.7557319223985890653e-07);
-  pc = fma(pc, y2, 2.4801587301587301587e-05);
-  pc = fma(pc, y2, -1.3888888888888888889e-03);
-  pc = fma(pc, y2, 4.1666666666666666667e-02);
+  double ps = -2.8114572543455207632e-15;                   // -1/17!
+  ps = fma(ps, y2, EXO_K(7.6471637318198164759e-13));
+  double pc = 4.7794773323873852974e-14;                    //  1/16!
+  pc = fma(pc, y2, EXO_K2(-1.1470745597729724714e-11));
+  ps = fma(ps, y2, EXO_K(-1.6059043836821614599e-10));
+  pc = fma(pc, y2, EXO_K2(2.0876756987868098979e-09));
+  ps = fma(ps, y2, EXO_K(2.5052108385441718775e-08));
+  pc = fma(pc, y2, EXO_K2(-2.7557319223985890653e-07));
+  ps = fma(ps, y2, EXO_K(-2.7557319223985890653e-06));
+  pc = fma(pc, y2, EXO_K2(2.4801587301587301587e-05));
+  ps = fma(ps, y2, EXO_K(1.9841269841269841270e-04));
+  pc = fma(pc, y2, EXO_K2(-1.3888888888888888889e-03));
+  ps = fma(ps, y2, EXO_K(-8.3333333333333333333e-03));
+  pc = fma(pc, y2, EXO_K2(4.1666666666666666667e-02));
+  ps = fma(ps, y2, EXO_K(1.6666666666666666667e-01));
   pc = fma(pc, y2, -0.5);
+  ps = fma(-ps * y2, y, y);
   pc = fma(pc, y2, 1.0);
   // quadrant k mod 4: (s, c) = (ps, pc), (pc, -ps), (-ps, -pc), (-pc, ps)
   const long long q = (long long)k;
@@ -249,9 +274,9 @@ struct KeplerHalf {
 
 EXO_HD KeplerHalf kepler_half(double M, double e, double se, double pe) {
   // two-term Cody-Waite reduction to [-pi, pi]
-  const double k = rint(M * (1.0 / kTwoPiHi));
-  double Mr = fma(-k, kTwoPiHi, M);
-  Mr = fma(-k, kTwoPiLo, Mr);
+  const double k = rint(M * EXO_K(1.0 / kTwoPiHi));
+  double Mr = fma(-k, EXO_K(kTwoPiHi), M);
+  Mr = fma(-k, EXO_K(kTwoPiLo), Mr);
   const double sgn = (Mr < 0.0) ? -1.0 : 1.0;
   Mr = fabs(Mr);
   const double ome = 1.0 - e;
@@ -280,14 +305,14 @@ EXO_HD KeplerHalf kepler_half(double M, double e, double se, double pe) {
     const double f3 = 1.0 - f1;
     // d3, d4 only steer the last denominator: ~1e-8 reciprocals are plenty there
     const double d3 = -f0 * approx_rcp(fma(-0.5 * f0 * f2, approx_rcp(f1), f1));
-    const double d4 = -f0 * approx_rcp(fma(d3 * d3 * (1.0 / 6.0), f3, fma(0.5 * d3, f2, f1)));
+    const double d4 = -f0 * approx_rcp(fma(d3 * d3 * EXO_K(1.0 / 6.0), f3, fma(0.5 * d3, f2, f1)));
     const double d42 = d4 * d4;
-    const double d5 = -fast_div(f0, fma(-d42 * d4 * (1.0 / 24.0), f2, fma(d42 * (1.0 / 6.0), f3, fma(0.5 * d4, f2, f1))));
+    const double d5 = -fast_div(f0, fma(-d42 * d4 * EXO_K(1.0 / 24.0), f2, fma(d42 * EXO_K(1.0 / 6.0), f3, fma(0.5 * d4, f2, f1))));
     // |d5| <= 4.4e-4 over the whole (M,e) domain: rotate (sh,ch) by d5/2 with
     // a 4th-order Taylor rotation instead of a second sincos
     const double h = 0.5 * d5, h2 = h * h;
-    const double sd = h * fma(-h2, 1.0 / 6.0, 1.0);
-    const double cd = fma(-h2, fma(-h2, 1.0 / 24.0, 0.5), 1.0);
+    const double sd = h * fma(-h2, EXO_K(1.0 / 6.0), 1.0);
+    const double cd = fma(-h2, fma(-h2, EXO_K(1.0 / 24.0), 0.5), 1.0);
     const double sh2 = fma(sh, cd, ch * sd);
     ch = fma(ch, cd, -sh * sd);
     sh = sh2;
@@ -354,7 +379,7 @@ struct Cel3 {
 EXO_HD Cel3 cel3(double kc, double p, double aP, double bP) {
   // floor: every caller's sin^2 coefficient vanishes with kc^2 (or the result
   // is multiplied by kc^2), so the floor costs O(1e-16 log) at most
-  kc = fmax(fabs(kc), 1e-8);
+  kc = fmax(fabs(kc), EXO_K(1e-8));
   double e = kc, em = 1.0;
   double aB = 1.0, bB = 0.0, aD = 0.0, bD = 1.0;
   double pp = fast_sqrt(p);
@@ -380,40 +405,119 @@ EXO_HD Cel3 cel3(double kc, double p, double aP, double bP) {
     pp = gP + pp;
     const double g = em;
     em += kc;
-    if (EXO_WAVE_ALL(!(fabs(g - kc) > g * 1.0e-8))) break;
+    if (EXO_WAVE_ALL(!(fabs(g - kc) > g * EXO_K(1.0e-8)))) break;
     kc = 2.0 * fast_sqrt(e);
     e = kc * em;
   }
   Cel3 o;
   // B, D: (pi/2) (a em + b) / (em (em + em));  P: (pi/2) (aP em + bP) / (em (em + pp))
   const double rj = fast_rcp(em * em * (em + pp));
-  const double q1 = (0.5 * kHalfPi) * rj * (em + pp);
+  const double q1 = EXO_K(0.5 * kHalfPi) * rj * (em + pp);
   o.B = q1 * fma(aB, em, bB);
   o.D = q1 * fma(aD, em, bD);
-  o.P = kHalfPi * fma(aP, em, bP) * (rj * em);
+  o.P = EXO_K(kHalfPi) * fma(aP, em, bP) * (rj * em);
   return o;
 }
 
 // C4 = int_0^{pi/2} cos^4/sqrt(1 - k2 sin^2): Maclaurin series in k2 (k2 < 0.1)
 EXO_HD double int_cos4_series(double k2) {
-  // c_j = (2j-1)!!/(2j)!! * (2/pi) int sin^{2j} cos^4
-  const double c[18] = {3.75000000000000000e-01, 3.12500000000000000e-02, 8.78906250000000000e-03, 3.66210937500000000e-03, 1.86920166015625000e-03, 1.08146667480468750e-03, 6.81549310684204102e-04, 4.57070767879486084e-04, 3.21377883665263653e-04, 2.34540930250659585e-04, 1.76394324626016896e-04, 1.35996323706422118e-04, 1.07056629822466221e-04, 8.57825559474889587e-05, 6.97940661670976015e-05, 5.75458918103226302e-05, 4.80048628730208747e-05, 4.04623031491638797e-05};
-  double s = c[17];
-#pragma unroll
-  for (int j = 16; j >= 0; --j) s = fma(s, k2, c[j]);
-  return kHalfPi * s;
+  // c_j = (2j-1)!!/(2j)!! * (2/pi) int sin^{2j} cos^4, j = 17 .. 0 (Horner; the coefficients from scalar registers)
+  double s = 4.04623031491638797e-05;
+  s = fma(s, k2, EXO_K(4.80048628730208747e-05));
+  s = fma(s, k2, EXO_K(5.75458918103226302e-05));
+  s = fma(s, k2, EXO_K(6.97940661670976015e-05));
+  s = fma(s, k2, EXO_K(8.57825559474889587e-05));
+  s = fma(s, k2, EXO_K(1.07056629822466221e-04));
+  s = fma(s, k2, EXO_K(1.35996323706422118e-04));
+  s = fma(s, k2, EXO_K(1.76394324626016896e-04));
+  s = fma(s, k2, EXO_K(2.34540930250659585e-04));
+  s = fma(s, k2, EXO_K(3.21377883665263653e-04));
+  s = fma(s, k2, EXO_K(4.57070767879486084e-04));
+  s = fma(s, k2, EXO_K(6.81549310684204102e-04));
+  s = fma(s, k2, EXO_K(1.08146667480468750e-03));
+  s = fma(s, k2, EXO_K(1.86920166015625000e-03));
+  s = fma(s, k2, EXO_K(3.66210937500000000e-03));
+  s = fma(s, k2, EXO_K(8.78906250000000000e-03));
+  s = fma(s, k2, EXO_K(3.12500000000000000e-02));
+  s = fma(s, k2, EXO_K(3.75000000000000000e-01));
+  return EXO_K(kHalfPi) * s;
 }
 
 // 8 (k - sin k) - (2k - sin 2k) = 32 int_0^{k/2} sin^4, series for k < 0.4
 EXO_HD double i4_series(double k) {
   const double k2 = k * k;
-  const double c[8] = {24.0 / 120, 120.0 / 5040, 504.0 / 362880, 2040.0 / 39916800,
-                       8184.0 / 6227020800.0, 32760.0 / 1307674368000.0, 131064.0 / 355687428096000.0,
-                       524280.0 / 121645100408832000.0};
-  double s = c[7];
-#pragma unroll
-  for (int j = 6; j >= 0; --j) s = fma(-k2, s, c[j]);
+  double s = 524280.0 / 121645100408832000.0;
+  s = fma(-k2, s, EXO_K(131064.0 / 355687428096000.0));
+  s = fma(-k2, s, EXO_K(32760.0 / 1307674368000.0));
+  s = fma(-k2, s, EXO_K(8184.0 / 6227020800.0));
+  s = fma(-k2, s, EXO_K(2040.0 / 39916800));
+  s = fma(-k2, s, EXO_K(504.0 / 362880));
+  s = fma(-k2, s, EXO_K(120.0 / 5040));
+  s = fma(-k2, s, EXO_K(24.0 / 120));
   return s * k2 * k2 * k;
+}
+
+// atan2(y, x0) and atan2(y, x1) for a common y >= 0 (results in [0, pi]): the two arc half-angles of the solution vector.
+// One division each (min / max, so |t| <= 1), atan t = t + t^3 q(t^2) with q of degree 19 in t^2 (interpolated at Chebyshev
+// nodes in 60-digit arithmetic, oracle-side script in docs/DESIGN_r1_r4.md's spirit: relative error 7.7e-17 with the rounded
+// coefficients, tools/atan_fit.py), the two chains side by side with their coefficients in scalar registers (EXO_K / EXO_K2).
+// libm's atan2 costs ~95 vector instructions here (19 coefficients as 38 register moves, an IEEE division); this is ~36.
+EXO_HD void atan2_pos_pair(double y, double x0, double x1, double* r0, double* r1) {
+#ifdef EXO_HOST_BUILD
+  *r0 = atan2(y, x0);
+  *r1 = atan2(y, x1);
+#else
+  const double ax0 = fabs(x0), ax1 = fabs(x1);
+  const double mx0 = fmax(ax0, y), mx1 = fmax(ax1, y);
+  const double t0 = (mx0 > 0.0) ? fast_div(fmin(ax0, y), mx0) : 0.0;
+  const double t1 = (mx1 > 0.0) ? fast_div(fmin(ax1, y), mx1) : 0.0;
+  const double a0 = t0 * t0, a1 = t1 * t1;
+  double p0 = 1.806195461861215e-05, p1 = p0;
+  p0 = fma(p0, a0, EXO_K(-0.00019996189377901382));
+  p1 = fma(p1, a1, EXO_K2(-0.00019996189377901382));
+  p0 = fma(p0, a0, EXO_K(0.0010496035084968515));
+  p1 = fma(p1, a1, EXO_K2(0.0010496035084968515));
+  p0 = fma(p0, a0, EXO_K(-0.0034958859739163094));
+  p1 = fma(p1, a1, EXO_K2(-0.0034958859739163094));
+  p0 = fma(p0, a0, EXO_K(0.008368931178450162));
+  p1 = fma(p1, a1, EXO_K2(0.008368931178450162));
+  p0 = fma(p0, a0, EXO_K(-0.015535152475414177));
+  p1 = fma(p1, a1, EXO_K2(-0.015535152475414177));
+  p0 = fma(p0, a0, EXO_K(0.023696731580048622));
+  p1 = fma(p1, a1, EXO_K2(0.023696731580048622));
+  p0 = fma(p0, a0, EXO_K(-0.031277189066996385));
+  p1 = fma(p1, a1, EXO_K2(-0.031277189066996385));
+  p0 = fma(p0, a0, EXO_K(0.03749486812535247));
+  p1 = fma(p1, a1, EXO_K2(0.03749486812535247));
+  p0 = fma(p0, a0, EXO_K(-0.04260356632601652));
+  p1 = fma(p1, a1, EXO_K2(-0.04260356632601652));
+  p0 = fma(p0, a0, EXO_K(0.04737749579527779));
+  p1 = fma(p1, a1, EXO_K2(0.04737749579527779));
+  p0 = fma(p0, a0, EXO_K(-0.052579733342841106));
+  p1 = fma(p1, a1, EXO_K2(-0.052579733342841106));
+  p0 = fma(p0, a0, EXO_K(0.05881506877793656));
+  p1 = fma(p1, a1, EXO_K2(0.05881506877793656));
+  p0 = fma(p0, a0, EXO_K(-0.06666564699289104));
+  p1 = fma(p1, a1, EXO_K2(-0.06666564699289104));
+  p0 = fma(p0, a0, EXO_K(0.07692298971033217));
+  p1 = fma(p1, a1, EXO_K2(0.07692298971033217));
+  p0 = fma(p0, a0, EXO_K(-0.09090908590891934));
+  p1 = fma(p1, a1, EXO_K2(-0.09090908590891934));
+  p0 = fma(p0, a0, EXO_K(0.11111111093490827));
+  p1 = fma(p1, a1, EXO_K2(0.11111111093490827));
+  p0 = fma(p0, a0, EXO_K(-0.14285714285384132));
+  p1 = fma(p1, a1, EXO_K2(-0.14285714285384132));
+  p0 = fma(p0, a0, EXO_K(0.1999999999999753));
+  p1 = fma(p1, a1, EXO_K2(0.1999999999999753));
+  p0 = fma(p0, a0, EXO_K(-0.3333333333333333));
+  p1 = fma(p1, a1, EXO_K2(-0.3333333333333333));
+  p0 = fma(t0 * a0, p0, t0);
+  p1 = fma(t1 * a1, p1, t1);
+  const double h0 = (y > ax0) ? kHalfPi - p0 : p0;
+  const double h1 = (y > ax1) ? kHalfPi - p1 : p1;
+  *r0 = (x0 < 0.0) ? kPi - h0 : h0;
+  *r1 = (x1 < 0.0) ? kPi - h1 : h1;
+#endif
 }
 
 // ---------------------------------------------------------------------------
@@ -470,8 +574,8 @@ EXO_HD void quad_sv(double b, double r, SV& o) {
     const double kite = fast_sqrt(fmax(0.0, A * Bm));       // 2 b r sin k0 = 2 b sin k1
     const double c0n = b2 + (r - 1.0) * (r + 1.0);      // 2 b r cos k0
     const double c1n = (1.0 - r) * (1.0 + r) + b2;      // 2 b cos k1
-    const double pk0 = atan2(kite, c0n);
-    const double pk1 = atan2(kite, c1n);
+    double pk0, pk1;
+    atan2_pos_pair(kite, c0n, c1n, &pk0, &pk1);
     const double i2br = fast_div(0.5, br), i2b = fast_div(0.5, b);
     const double s0k = kite * i2br, c0k = c0n * i2br;
     const double s1k = kite * i2b, c1k = c1n * i2b;
@@ -486,9 +590,9 @@ EXO_HD void quad_sv(double b, double r, SV& o) {
       seg = 0.5 * (r2 * xms_2k0 + xms_2k1);
     }
   }
-  if (inside) seg = kPi * r2;
+  if (inside) seg = EXO_K(kPi) * r2;
   const double q = 1.0 - 2.0 * rmb * rmb;
-  const double s0 = kPi - seg;
+  const double s0 = EXO_K(kPi) - seg;
   const double s2 = -4.0 * r * (A * rmb * u0 + (2.0 * b * A - 4.0 * br * rmb) * I2 - 8.0 * b2 * r * I4);
 
   // ---- s1: one shared AGM ladder serves both geometries
@@ -511,9 +615,9 @@ EXO_HD void quad_sv(double b, double r, SV& o) {
   double J;
   double pref = 0.0, C2 = 0.0, C4 = 0.0;
   if (inside) {
-    const double t3 = (2.0 * (2.0 - m_in) * Ek - kc2 * Kk) * (1.0 / 3.0);  // int Delta^3
-    J = (2.0 * sqA * (1.0 / 3.0)) * (A * t3 - (r2 - b2) * Ek);
-    if (!same) J += (2.0 / 3.0) * bpr * irmb * isqA * c3.P;
+    const double t3 = (2.0 * (2.0 - m_in) * Ek - kc2 * Kk) * EXO_K(1.0 / 3.0);  // int Delta^3
+    J = (sqA * EXO_K(2.0 / 3.0)) * (A * t3 - (r2 - b2) * Ek);
+    if (!same) J += EXO_K(2.0 / 3.0) * bpr * irmb * isqA * c3.P;
   } else {
     C2 = c3.B;
     // closed form loses eps/k2^2; switch to the series where that matters
@@ -524,10 +628,10 @@ EXO_HD void quad_sv(double b, double r, SV& o) {
       C4 = fast_div((3.0 * k2 - 1.0) * c3.B + kc2 * c3.D, 3.0 * k2);
     }
     pref = 4.0 * sqA * fast_sqrt(k2);
-    J = (pref * (1.0 / 6.0)) * (A * C4 - (r2 - b2) * C2);
-    if (!same) J += (bpr * irmb * (1.0 / 6.0)) * pref * c3.P;
+    J = (pref * EXO_K(1.0 / 6.0)) * (A * C4 - (r2 - b2) * C2);
+    if (!same) J += (bpr * irmb * EXO_K(1.0 / 6.0)) * pref * c3.P;
   }
-  const double s1 = kTwoThirdsPi * (1.0 - theta) + J;
+  const double s1 = fma(EXO_K(kTwoThirdsPi), 1.0 - theta, J);
 
   if (act) { o.s0 = s0; o.s1 = s1; o.s2 = s2; }
 

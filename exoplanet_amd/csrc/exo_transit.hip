@@ -2470,88 +2470,9 @@ __global__ __launch_bounds__(kBlock) void transit_residual_kernel(int64_t n_cad,
   if (threadIdx.x == 0) chi2_part[draw * nb + blockIdx.x] = red[0];
 }
 
-// ---------------------------------------------------------------------------
-// Elementwise ops (the reference's standalone Ops)
-// ---------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void kepler_kernel(const double* __restrict__ M,
-                                                        const double* __restrict__ ecc,
-                                                        double* __restrict__ sinf,
-                                                        double* __restrict__ cosf, int64_t n) {
-  const int64_t stride = (int64_t)gridDim.x * kBlock;
-  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
-    const double e = ecc[i];
-    const bool ok = (e >= 0.0) && (e < 1.0);
-    const double es = ok ? e : 0.5;
-    const exo::KeplerHalf kh = exo::kepler_half(M[i], es, sqrt(1.0 - es), sqrt(1.0 + es));
-    const double X2 = kh.X * kh.X, Y2 = kh.Y * kh.Y;
-    const double iden = 1.0 / (X2 + Y2);
-    const double nan = __builtin_nan("");
-    sinf[i] = ok ? 2.0 * kh.X * kh.Y * iden : nan;
-    cosf[i] = ok ? (X2 - Y2) * iden : nan;
-  }
-}
-
-// diagnostic: the fp32 classifier position, so that its error bound can be tested
-__global__ __launch_bounds__(kBlock) void orbit_pos_f32_kernel(const double* __restrict__ M,
-                                                               const double* __restrict__ ecc,
-                                                               double* __restrict__ cx, double* __restrict__ sx,
-                                                               int64_t n) {
-  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (i >= n) return;
-  const double e = ecc[i];
-  float a, b;
-  exo::orbit_pos_f32(M[i], (float)e, (float)(1.0 - e), (float)sqrt((1.0 - e) * (1.0 + e)), &a, &b);
-  cx[i] = a;
-  sx[i] = b;
-}
-
-template <bool GRAD>
-__global__ __launch_bounds__(kBlock) void quad_sv_kernel(const double* __restrict__ b,
-                                                         const double* __restrict__ r,
-                                                         double* __restrict__ s,
-                                                         double* __restrict__ dsdb,
-                                                         double* __restrict__ dsdr, int64_t n) {
-  const int64_t stride = (int64_t)gridDim.x * kBlock;
-  // uniform trip count so the wavefront votes inside quad_sv see whole waves
-  const int64_t n_round = (n + stride - 1) / stride * stride;
-  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n_round; i += stride) {
-    const bool v = i < n;
-    const double bs = v ? b[i] : 2.0;
-    const double rr = v ? r[i] : 0.1;
-    const double sg = bs < 0.0 ? -1.0 : 1.0;
-    exo::SV o;
-    exo::quad_sv<GRAD>(fabs(bs), rr, o);
-    if (v) {
-      s[3 * i] = o.s0; s[3 * i + 1] = o.s1; s[3 * i + 2] = o.s2;
-      if (GRAD) {
-        dsdb[3 * i] = sg * o.db0; dsdb[3 * i + 1] = sg * o.db1; dsdb[3 * i + 2] = sg * o.db2;
-        dsdr[3 * i] = o.dr0; dsdr[3 * i + 1] = o.dr1; dsdr[3 * i + 2] = o.dr2;
-      }
-    }
-  }
-}
-
-__global__ __launch_bounds__(64) void contact_points_kernel(
-    const double* __restrict__ a, const double* __restrict__ e_, const double* __restrict__ cosw,
-    const double* __restrict__ sinw, const double* __restrict__ cosi, const double* __restrict__ sini,
-    const double* __restrict__ L_, double* __restrict__ Ml, double* __restrict__ Mr,
-    int32_t* __restrict__ flag, int64_t n) {
-  const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
-  if (i >= n) return;
-  (void)sini;
-  double ml, mr;
-  const bool bad = exo::contact_solve(a[i], e_[i], cosw[i], sinw[i], cosi[i], L_[i], &ml, &mr);
-  Ml[i] = ml;
-  Mr[i] = mr;
-  flag[i] = bad ? 1 : 0;
-}
+// (the reference's standalone Ops -- kepler, quad_solution_vector, contact_points -- are exo_ops.hip)
 
 inline int launch_status() { return hipGetLastError() == hipSuccess ? EXO_OK : EXO_ERR_LAUNCH; }
-
-inline int elementwise_grid(int64_t n) {
-  const int64_t want = (n + kBlock - 1) / kBlock;
-  return (int)(want < 1 ? 1 : (want > 256 * 8 ? 256 * 8 : want));  // 8 blocks per CU, grid-stride the rest
-}
 
 // blocks per draw and tiles per block: enough blocks to fill 256 CUs several
 // times over, few enough that each block amortises its prologue / reduction
@@ -2942,46 +2863,6 @@ extern "C" {
 
 int32_t exo_abi_version(void) { return EXO_ABI_VERSION; }
 
-int exo_kepler_f64(const double* M, const double* ecc, double* sinf, double* cosf, int64_t n, void* stream) {
-  if (n < 0 || (n > 0 && (!M || !ecc || !sinf || !cosf))) return EXO_ERR_INVALID_ARGUMENT;
-  if (n == 0) return EXO_OK;
-  hipLaunchKernelGGL(kepler_kernel, dim3(elementwise_grid(n)), dim3(kBlock), 0, (hipStream_t)stream, M, ecc,
-                     sinf, cosf, n);
-  return launch_status();
-}
-
-int exo_selftest_orbit_pos_f32(const double* M, const double* ecc, double* cx, double* sx, int64_t n, void* stream) {
-  if (n < 0 || (n > 0 && (!M || !ecc || !cx || !sx))) return EXO_ERR_INVALID_ARGUMENT;
-  if (n == 0) return EXO_OK;
-  hipLaunchKernelGGL(orbit_pos_f32_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0,
-                     (hipStream_t)stream, M, ecc, cx, sx, n);
-  return launch_status();
-}
-
-int exo_quad_solution_vector_f64(const double* b, const double* r, double* s, double* dsdb, double* dsdr,
-                                 int64_t n, void* stream) {
-  if (n < 0 || (n > 0 && (!b || !r || !s)) || ((dsdb == nullptr) != (dsdr == nullptr)))
-    return EXO_ERR_INVALID_ARGUMENT;
-  if (n == 0) return EXO_OK;
-  const dim3 grid(elementwise_grid(n)), block(kBlock);
-  if (dsdb)
-    hipLaunchKernelGGL(quad_sv_kernel<true>, grid, block, 0, (hipStream_t)stream, b, r, s, dsdb, dsdr, n);
-  else
-    hipLaunchKernelGGL(quad_sv_kernel<false>, grid, block, 0, (hipStream_t)stream, b, r, s, dsdb, dsdr, n);
-  return launch_status();
-}
-
-int exo_contact_points_f64(const double* a, const double* e, const double* cosw, const double* sinw,
-                           const double* cosi, const double* sini, const double* L, double* M_left,
-                           double* M_right, int32_t* flag, int64_t n, void* stream) {
-  if (n < 0 || (n > 0 && (!a || !e || !cosw || !sinw || !cosi || !sini || !L || !M_left || !M_right || !flag)))
-    return EXO_ERR_INVALID_ARGUMENT;
-  if (n == 0) return EXO_OK;
-  hipLaunchKernelGGL(contact_points_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, (hipStream_t)stream,
-                     a, e, cosw, sinw, cosi, sini, L, M_left, M_right, flag, n);
-  return launch_status();
-}
-
 int64_t exo_transit_flux_workspace_bytes(int64_t n_cad, int64_t n_draw, int32_t n_planet) {
   if (n_cad < 0 || n_draw < 0 || n_planet < 1) return -1;
   if (n_cad == 0 || n_draw == 0) return 0;
@@ -3345,7 +3226,8 @@ int exo_transit_flux_sparse_model(const void* workspace, int64_t workspace_bytes
   if (n_planet * n_ev != 1) return EXO_ERR_INVALID_ARGUMENT;
   const RunWs rw = carve_runs(const_cast<void*>(workspace), n_cad, n_draw, n_planet);
   if (!workspace || workspace_bytes < rw.bytes) return EXO_ERR_WORKSPACE;
-  // (the workspace is sized for two events per planet: a draw's lists are 2 apart)
+  // (lists are packed with stride n_ev -- list = (draw * n_planet + planet) * n_ev + event -- so with one list per draw
+  // consecutive draws are consecutive rows, although the workspace is SIZED for two lists per record)
   out->nseg = rw.rl.nrun;
   out->seg = reinterpret_cast<const int32_t*>(rw.rl.runs);
   out->off = rw.rl.pre_all;

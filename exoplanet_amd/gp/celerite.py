@@ -230,8 +230,12 @@ class _CeleriteLogLikeSparse(torch.autograd.Function):
         D, N, n_real, n_complex, nstate, n_chunks = ctx.dims
         gll = _dev(gll, "gloglike")
         lib = _lib.load()
-        # (positions no segment covers are never written and never read: the reverse sweep of the light curve walks the same runs)
-        gvals = torch.empty_like(vals)
+        # Only the positions a segment covers are DEFINED -- in `vals` (the rest of the sweep's value array is workspace the
+        # forward never wrote either) and in this cotangent alike; the reverse sweep of the light curve walks the same runs and
+        # reads nothing else.  A zero fill would be the 1.2 GB write per step the sparse route exists to avoid (C3), so the array
+        # is not cleared; it goes through _buffer so that the poison test covers it, and
+        # SparseLightCurve.values.grad is to be read through the runs (ops.SparseLightCurve._indices), not as a dense array.
+        gvals = _buffer(*vals.shape, device=vals.device)
         want_diag = ctx.needs_input_grad[2]
         gdiag = _buffer(D, N, device=t.device) if want_diag else None
         gcr, gcc = _buffer(*coef_real.shape, device=t.device), _buffer(*coef_complex.shape, device=t.device)

@@ -318,19 +318,33 @@ _JAC_MIN_SUB = 2
 _JAC_MAX_BYTES = 8 << 30
 
 
+_JAC_DECISIONS = {}     # (device index, bytes of rows) -> bool: the first answer stands (warm-up, capture and replay agree)
+
+
 def _jac_fits(nbytes, device):
     """the rows of derivatives are worst-case sized (16 doubles per (draw, planet, cadence), a few per cent touched): take the
-    route only if they fit the cap AND half of what the device has free right now (a smaller-memory device must
-    fall back to the two-sweep route rather than run out)"""
+    route only if they fit the cap AND half of what the device can still give (a smaller-memory device must fall
+    back to the two-sweep route rather than run out).  "Can still give" = the driver's free bytes + what torch's caching
+    allocator holds but has not handed out -- a warm sampler's reserved pool would otherwise read as a full device and flip
+    the route between steps.  The decision is remembered per (device, size): a capture takes what its warm-up took."""
     if nbytes > _JAC_MAX_BYTES:
         return False
+    key = (torch.device(device).index, int(nbytes))
+    hit = _JAC_DECISIONS.get(key)
+    if hit is not None:
+        return hit
     try:
         if torch.cuda.is_current_stream_capturing():
-            return True          # (the warm-up calls before the capture asked; the pool is the capture's own)
+            return True          # (no warm-up call asked before this capture: nothing to agree with; not remembered)
         free, _ = torch.cuda.mem_get_info(device)
-        return 2 * nbytes <= free
+        free += torch.cuda.memory_reserved(device) - torch.cuda.memory_allocated(device)
+        fits = 2 * nbytes <= free
     except Exception:
-        return True
+        fits = True
+    _JAC_DECISIONS[key] = fits
+    return fits
+
+
 _JAC_CALLS = [0]        # forward sweeps that took the route (tests look at it)
 
 
@@ -356,9 +370,11 @@ class _TransitFlux(torch.autograd.Function):
         # cadence is several samples, the value sweep keeps every solved cadence's row of derivatives and backward() is a
         # contraction instead of a second sweep
         n_jac = lib.exo_transit_flux_jac_doubles(N, D, P)
-        use_jac = (_JAC_ROUTE[0] and n_sub >= _JAC_MIN_SUB and not n_edge and n_texp <= 1 and _jac_fits(8 * n_jac, t.device)
+        # (the memory question last: it is a driver call -- ADVICE r5)
+        use_jac = (_JAC_ROUTE[0] and grad_mode and (ctx.needs_input_grad[4] or ctx.needs_input_grad[5])
+                   and n_sub >= _JAC_MIN_SUB and not n_edge and n_texp <= 1
                    and not flags & (FLAG_PER_PLANET | FLAG_SPARSE | FLAG_EXACT_SCAN | FLAG_LIGHT_DELAY)
-                   and (ctx.needs_input_grad[4] or ctx.needs_input_grad[5]) and grad_mode)
+                   and _jac_fits(8 * n_jac, t.device))
         ctx.jac = None
         if use_jac:
             _JAC_CALLS[0] += 1
@@ -840,7 +856,11 @@ class _TransitFluxSparse(torch.autograd.Function):
         n_jac = lib.exo_transit_flux_jac_doubles(N, D, P)
         # (grad_mode: torch.is_grad_enabled() of the CALLER -- inside forward() it is always off; under no_grad the rows of
         # derivatives would be written for nothing: ADVICE r4)
-        use_jac = _JAC_ROUTE[0] and n_sub >= _JAC_MIN_SUB and _jac_fits(8 * n_jac, t.device) and need and grad_mode
+        # the same exclusions as _TransitFlux (per-cadence exposure times, per-planet / exact-scan / light-delay sweeps have no
+        # Jacobian form: without them the library refuses -- ADVICE r5: fall back to the two-sweep route instead)
+        use_jac = (_JAC_ROUTE[0] and need and grad_mode and n_sub >= _JAC_MIN_SUB and n_texp <= 1
+                   and not flags & (FLAG_PER_PLANET | FLAG_EXACT_SCAN | FLAG_LIGHT_DELAY)
+                   and _jac_fits(8 * n_jac, t.device))
         ctx.jac = None
         with torch.cuda.device(t.device):
             if use_jac:
@@ -906,6 +926,9 @@ class _SparseToDense(torch.autograd.Function):
         return g, None
 
 
+_MULTI_LIST_MEAN = [False]     # (the merged multi-list model of round 6 flips this when the library provides it)
+
+
 class SparseLightCurve:
     """What ``get_light_curve(total=True, sparse=True)`` returns for a batch of draws: the summed light curve as the runs
     of cadences in which a planet can overlap the disk and the flux of exactly those cadences (every other cadence: 0),
@@ -925,6 +948,11 @@ class SparseLightCurve:
         """exo_sparse_model for the celerite entries (a host struct of device pointers: keep ``self`` alive while it is used)"""
         m = _lib.SparseModel()
         import ctypes
+
+        n_ev = 2 if self.flags & FLAG_SECONDARY else 1
+        if self.n_planet * n_ev != 1 and not _MULTI_LIST_MEAN[0]:
+            raise ValueError("a sparse GaussianProcess mean is one list of runs per draw (one planet, no occultations); "
+                             f"this light curve has {self.n_planet} planet(s) x {n_ev} event(s): pass .dense()")
 
         nbytes = _lib.load().exo_transit_flux_workspace_bytes(self.n_cad, self.n_draw, self.n_planet)
         _lib.check(_lib.load().exo_transit_flux_sparse_model(_ptr(self._ws), nbytes, self.n_cad, self.n_draw, self.n_planet,
@@ -969,6 +997,18 @@ class SparseLightCurve:
 
     def detach(self):
         return SparseLightCurve(self.values.detach(), self._ws, self.n_cad, self.n_draw, self.n_planet, self.flags)
+
+    # Arithmetic: a sparse light curve in an expression -- ``offset + lc``, ``lc * depth`` -- becomes the ordinary
+    # (draws, cadences) tensor (``dense()``: differentiable), so code written for the dense return type keeps working whatever
+    # get_light_curve(sparse=True) could return for the model; only a GaussianProcess mean stays sparse.
+    def __add__(self, other): return self.dense() + other
+    def __radd__(self, other): return other + self.dense()
+    def __sub__(self, other): return self.dense() - other
+    def __rsub__(self, other): return other - self.dense()
+    def __mul__(self, other): return self.dense() * other
+    def __rmul__(self, other): return other * self.dense()
+    def __truediv__(self, other): return self.dense() / other
+    def __neg__(self): return -self.dense()
 
 
 def transit_flux_sparse_model(t, params, ld, texp=None, stencil_dt=None, stencil_w=None, flags=0):

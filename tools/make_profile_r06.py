@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""gpurun_out/r05 (tools/profile_r05.sh) -> profiles/r05_counters.json + profiles/r05_bench_rocprof_summary.txt.
+"""gpurun_out/r06 (tools/profile_r06.sh) -> profiles/r06_counters.json + profiles/r06_bench_rocprof_summary.txt.
 
 Per leg (c2 dense step, sparse / chi2 op legs, c3, c4 at 64 draws, c5 at 128 chains) and per kernel: rocprofv3 average
 duration (kernel-trace), HBM traffic = (2 x FETCH_SIZE + WRITE_SIZE) KiB (gfx950: FETCH_SIZE counts half the bytes of a
@@ -24,7 +24,7 @@ import sys
 src, dst = sys.argv[1], sys.argv[2]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 N_SIMD, CLK = 1024, 2.4e9
-SOURCES = ["exo_celerite.hip", "exo_celerite_core.hpp", "exo_celerite_group.hpp", "exo_contact.hpp", "exo_math.hpp", "exo_pack.hip", "exo_rv.hip", "exo_transit.hip"]
+SOURCES = sorted(f for f in os.listdir(os.path.join(ROOT, "exoplanet_amd", "csrc")) if f.endswith((".hip", ".hpp")))   # every kernel source
 
 
 def short(name):
@@ -93,7 +93,7 @@ h = hashlib.sha256()
 for f in SOURCES:
     h.update(open(os.path.join(ROOT, "exoplanet_amd", "csrc", f), "rb").read())
 rec = {"kernel_sources": SOURCES, "kernel_sources_sha256": h.hexdigest(),
-       "how": "tools/profile_r05.sh: rocprofv3 --kernel-trace --stats for the durations; --pmc passes one counter set per "
+       "how": "tools/profile_r06.sh: rocprofv3 --kernel-trace --stats for the durations; --pmc passes one counter set per "
               "run; gfx950 FETCH_SIZE correction x 2; denominators at the nominal 2.4 GHz (lower bounds)"}
 N_C2, D_C2 = 150_000, 1024
 solved = None
@@ -104,22 +104,32 @@ except Exception:
 solved = solved or 4.34e6
 lines = []
 for leg, D, N, J in (("c2", 1024, 150_000, 0), ("sparse", 1024, 150_000, 0), ("chi2", 1024, 150_000, 0), ("c3", 1024, 150_000, 2),
-                     ("c4", 64, 200_000, 0), ("c5", 128, 65_000, 6), ("c5b", 128, 65_000, 6)):
+                     ("c4", 64, 200_000, 0), ("c5", 128, 65_000, 6), ("c5b", 128, 65_000, 6),
+                     ("kepler", 1, 150_000_000, 0), ("quadsv", 1, 150_000_000, 0)):
     def units_of(k, D=D, N=N, leg=leg):
         if k.startswith("transit_runs_kernel") and leg in ("c2", "sparse", "chi2"):
             return solved
         if k.startswith("celerite_chunk") or k.startswith("celerite_elem"):
             return D * N
+        if leg in ("kepler", "quadsv") and (k.startswith("kepler_") or k.startswith("quad_sv")):
+            return N
         return None
     ks = leg_record(leg, units_of)
     if not ks:
         continue
-    step_kernels = {k: v for k, v in ks.items() if v["calls"] >= 3}
+    step_kernels = {k: v for k, v in ks.items() if v["calls"] >= (2 if leg in ("kepler", "quadsv") else 3)}
     dom = max(step_kernels.items(), key=lambda kv: kv[1]["calls"] * kv[1]["rocprof_avg_us"])
     # per step: a kernel launched k times per step (the levels of the scan trees) counts k times
     total_tr = sum(v.get("traffic_bytes", 0.0) * (v["calls"] / dom[1]["calls"]) for v in step_kernels.values())
-    entry = {"draws": D, "n_cadences": N, "source": f"profiles/r05_counters.json [{leg}] (tools/profile_r05.sh)", "kernels": ks,
+    entry = {"draws": D, "n_cadences": N, "source": f"profiles/r06_counters.json [{leg}] (tools/profile_r06.sh)", "kernels": ks,
              "dominant_kernel": {"name": dom[0], **{k: dom[1].get(k) for k in ("rocprof_avg_us", "traffic_bytes", "traffic_GBps")}}}
+    if leg in ("kepler", "quadsv"):
+        entry["algorithmic_bytes"] = {"kepler_pair_kernel": 32.0 * N, "kepler_kernel": 32.0 * N, "quad_sv_kernel<false>": 40.0 * N, "quad_sv_kernel<true>": 88.0 * N}
+        for k, v in ks.items():
+            ab = entry["algorithmic_bytes"].get(k)
+            if ab:
+                v["algorithmic_GBps"] = ab / (v["rocprof_avg_us"] * 1e-6) / 1e9
+                v["algorithmic_frac_of_hbm_peak"] = v["algorithmic_GBps"] / 8000.0
     if leg in ("c2", "c4"):
         entry["traffic_bytes_per_sweep"] = sum(v.get("traffic_bytes", 0.0) for k, v in step_kernels.items() if k.startswith("transit_"))
     else:
@@ -147,9 +157,9 @@ for leg in ("sparse", "chi2"):
         for k, v in rec[leg]["valu"].items():
             rec["c2"]["valu"][f"{k} [{leg} leg]"] = v
 os.makedirs(dst, exist_ok=True)
-json.dump(rec, open(os.path.join(dst, "r05_counters.json"), "w"), indent=1)
-open(os.path.join(dst, "r05_bench_rocprof_summary.txt"), "w").write(
-    "rocprofv3 record of round 5 (tools/profile_r05.sh; eager launches so that every kernel is a dispatch).  avg_us: kernel-trace\n"
+json.dump(rec, open(os.path.join(dst, "r06_counters.json"), "w"), indent=1)
+open(os.path.join(dst, "r06_bench_rocprof_summary.txt"), "w").write(
+    "rocprofv3 record of round 6 (tools/profile_r06.sh; eager launches so that every kernel is a dispatch).  avg_us: kernel-trace\n"
     "average; traffic: (2 x FETCH_SIZE + WRITE_SIZE) per dispatch; valu/pk: SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x avg x 2.4 GHz);\n"
-    "busy: SQ_ACTIVE_INST_VALU x 4 / the same.  Full numbers: r05_counters.json.\n\n" + "\n".join(lines) + "\n")
+    "busy: SQ_ACTIVE_INST_VALU x 4 / the same.  Full numbers: r06_counters.json.\n\n" + "\n".join(lines) + "\n")
 print("\n".join(lines))

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""run one op-level leg of the C2 sweep a few times (for rocprofv3 --pmc passes): tools/run_leg.py dense|sparse|chi2|value [draws] [iters]"""
+"""run one op-level leg of the C2 sweep a few times (for rocprofv3 --pmc passes): tools/run_leg.py dense|sparse|chi2|value [draws] [iters], or kepler|quadsv [elements] [iters]"""
 import os
 import sys
 
@@ -14,6 +14,25 @@ leg = sys.argv[1]
 D = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
 iters = int(sys.argv[3]) if len(sys.argv) > 3 else 10
 dev = torch.device("cuda:0")
+if leg in ("kepler", "quadsv"):
+    # the reference's standalone Ops on n = D elements (bench.py extra_ops: the same inputs)
+    n = D
+    gen = torch.Generator(device=dev).manual_seed(11)
+    with torch.no_grad():
+        if leg == "kepler":
+            M = (torch.rand(n, dtype=torch.float64, device=dev, generator=gen) - 0.5) * 800.0
+            e = torch.rand(n, dtype=torch.float64, device=dev, generator=gen) * 0.9
+            for _ in range(iters):
+                ops.kepler(M, e)
+        else:
+            b = torch.rand(n, dtype=torch.float64, device=dev, generator=gen) * 1.3
+            r = torch.full((n,), 0.1, dtype=torch.float64, device=dev)
+            for _ in range(iters):
+                ops.quad_solution_vector(b, r)
+            for _ in range(iters):
+                ops.quad_solution_vector_derivs(b, r)
+    torch.cuda.synchronize()
+    sys.exit(0)
 N = 150_000
 t = torch.arange(N, dtype=torch.float64, device=dev) * (2.0 / 1440.0)
 rng = np.random.default_rng(100)
