@@ -302,11 +302,14 @@ C5_LD = ((0.3, 0.2), (0.4, 0.1))
 C5_YERR = 3e-4
 
 
-def workload_c5(xo, ops, dev, D, rank=0, bright=0):
+def workload_c5(xo, ops, dev, D, rank=0, bright=0, bright_factor=1e3, kernel="sho3"):
     """BASELINE configs[4] (C5): 65 000 long cadences, exposure stencil x 7, secondary eclipse, three SHO terms (J = 6);
     D = this rank's share of the 1024 chains (128 on each of 8 GPUs).  bright (extras only): that many chains with the first
     term's amplitude at 1000 x the error bars -- a conditioning score of 1e6, above the 3e4 of the scan trees: those chains
-    take the robust route of the time-parallel path (exo_celerite_core.hpp, chunk_adj_lane)"""
+    take the robust route of the time-parallel path (exo_celerite_core.hpp, chunk_adj_lane); bright_factor: that amplitude in
+    error bars (1e3: score 1e6; 10^4.5: score 1e9 -- beyond the robust route, the sequential kernels).
+    kernel = "rot2_sho" (extras only): two RotationTerms + one SHO term -- J = 10, the width celerite2 users
+    reach with two spotted stars / a harmonic pair: wider than the one-lane time-parallel kernels (J <= 8 here)"""
     rng = np.random.default_rng(5 + 1000 * rank)
     n, texp = C5_NCAD, C5_TEXP
     t = ops.vouch_sorted(torch.arange(n, dtype=torch.float64, device=dev) * texp)
@@ -317,7 +320,7 @@ def workload_c5(xo, ops, dev, D, rank=0, bright=0):
     leaves.update(sbr=vec(0.3), s1=vec(C5_TERMS[0][0]), s2=vec(C5_TERMS[1][0]), s3=vec(C5_TERMS[2][0]))
     if bright:
         s1 = np.full(D, C5_TERMS[0][0])
-        s1[:bright] = 1e3 * C5_YERR
+        s1[:bright] = bright_factor * C5_YERR
         leaves["s1"] = torch.tensor(s1, dtype=torch.float64, device=dev, requires_grad=True)
     yobs = torch.as_tensor(3e-4 * np.random.default_rng(5).normal(size=n), device=dev)       # (the data: same on every rank)
     ones = torch.ones(D, dtype=torch.float64, device=dev)
@@ -331,8 +334,13 @@ def workload_c5(xo, ops, dev, D, rank=0, bright=0):
         lc = xo.SecondaryEclipseLightCurve(C5_LD[0], C5_LD[1], Lv["sbr"]).get_light_curve(
             orbit=orbit, r=Lv["r"], t=t, texp=texp, oversample=7, total=True, cadence_major=GP_MEAN_CADENCE_MAJOR,
             sparse=GP_MEAN_SPARSE)
-        kern = (T.SHOTerm(sigma=Lv["s1"], rho=fixed[0][0], Q=fixed[0][1]) + T.SHOTerm(sigma=Lv["s2"], rho=fixed[1][0], Q=fixed[1][1])
-                + T.SHOTerm(sigma=Lv["s3"], rho=fixed[2][0], Q=fixed[2][1]))
+        if kernel == "rot2_sho":
+            kern = (T.RotationTerm(sigma=Lv["s1"], period=9.0 * ones, Q0=1.5 * ones, dQ=0.4 * ones, f=0.6 * ones)
+                    + T.RotationTerm(sigma=Lv["s2"], period=23.0 * ones, Q0=2.5 * ones, dQ=0.7 * ones, f=0.3 * ones)
+                    + T.SHOTerm(sigma=Lv["s3"], rho=fixed[2][0], Q=fixed[2][1]))
+        else:
+            kern = (T.SHOTerm(sigma=Lv["s1"], rho=fixed[0][0], Q=fixed[0][1]) + T.SHOTerm(sigma=Lv["s2"], rho=fixed[1][0], Q=fixed[1][1])
+                    + T.SHOTerm(sigma=Lv["s3"], rho=fixed[2][0], Q=fixed[2][1]))
         gp = xo.gp.GaussianProcess(kern, t=t, yerr=C5_YERR, mean=lc)
         ll = gp.log_likelihood(yobs)
         return (ll.detach(),) + torch.autograd.grad(ll.sum(), vals)
@@ -1360,6 +1368,23 @@ def main():
                            "kernels (VERDICT r3 item 2b: <= 2 x the clean step); " + out["note"])
             return out
         leg("c5_128_chains_1pct_bright_star_kappa_1e6", c5_bright)
+
+        def c5_variant(note, **kw):
+            out = extra_config(xo, ops, dev, "c5", 128, 6, **kw)
+            clean = extras.get("c5_secondary_eclipse_3term_gp_128_chains", {}).get("median_ms")
+            out["over_clean"] = out["median_ms"] / clean if clean else None
+            out["same_step_as"] = None
+            out["note"] = note + "; " + out["note"]
+            return out
+        # the cliff remnants as NUMBERS: a state wider than the one-lane time-parallel kernels, and a
+        # conditioning score beyond the robust route -- both fall to the sequential kernels (all draws of the call for J = 10;
+        # the flagged chains only for kappa = 1e9)
+        leg("c5_shape_J10_two_rotation_terms_plus_sho", lambda: c5_variant(
+            "the C5 step at 128 chains with a J = 10 kernel (two RotationTerms + one SHO term): per unit of J^2 against the clean "
+            "J = 6 step = over_clean x 36 / 100", kernel="rot2_sho"))
+        leg("c5_128_chains_1pct_kappa_1e9", lambda: c5_variant(
+            "the C5 step at 128 chains with 2 of them (1 %) at a conditioning score of 1e9 (first SHO term 31 600 x the error bars): "
+            "beyond the robust route's reach -- those chains are redone by the sequential kernels", bright=2, bright_factor=10 ** 4.5))
         torch.cuda.empty_cache()
         leg("astrometry_and_velocities", lambda: extra_astrometry(xo, dev))
         def nuts_leg():
@@ -1392,6 +1417,7 @@ def main():
             "c3": pick("c3_light_curve_plus_sho_gp"), "c4_64": pick("c4_four_planets_64_draws"),
             "c5_128": pick("c5_secondary_eclipse_3term_gp_128_chains"), "c5b": pick("c5_128_chains_1pct_bright_star_kappa_1e6"),
             "sparse": pick("c2_sparse_output"), "chi2": pick("c2_white_noise_likelihood"),
+            "c5_j10": pick("c5_shape_J10_two_rotation_terms_plus_sho"), "c5_kappa1e9": pick("c5_128_chains_1pct_kappa_1e9"),
             "hmc": pick("hmc_trajectory_c2"), "nuts_leaf": pick("nuts_transition_c2", "ms_per_leaf"),
             "c2_one_call": pick("c2_one_call"),
             # the reference's standalone Ops at n = 1.5e8 (GB/s of their algorithmic bytes: 32 / 40 / 88 B per element)

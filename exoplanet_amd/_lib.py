@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # EXOPLANET_AMD_LIB selects another in-tree build of the same ABI (A/B measurements)
 LIB_PATH = os.environ.get("EXOPLANET_AMD_LIB") or os.path.join(_HERE, "lib", "libexoplanet_amd.so")
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 _c_dp = ctypes.c_void_p  # device pointers travel as integers
 _i64 = ctypes.c_int64
@@ -109,6 +109,11 @@ _SIGNATURES = {
     ),
     # workspace, workspace_bytes, n_cad, n_draw, n_planet, flags, out (host struct)
     "exo_transit_flux_sparse_model": (ctypes.c_int, [_c_dp, _i64, _i64, _i64, _i32, _u32, _c_dp]),
+    "exo_sparse_merge_workspace_bytes": (_i64, [_i64, _i64, _i32]),
+    "exo_sparse_merge_layout": (ctypes.c_int, [_i64, _i64, _i32, ctypes.POINTER(_i64)]),
+    "exo_sparse_model_merge_f64": (ctypes.c_int, [_c_dp, _i64, _i64, _i64, _i32, _u32, _c_dp, _i64, _c_dp, _c_dp]),
+    "exo_sparse_model_merged": (ctypes.c_int, [_c_dp, _i64, _i64, _i64, _i32, _c_dp]),
+    "exo_sparse_model_merge_vjp_f64": (ctypes.c_int, [_c_dp, _i64, _i64, _i64, _i32, _u32, _c_dp, _i64, _c_dp, _c_dp, _c_dp]),
     # t, n_cad, texp, n_texp, stencil_dt, stencil_w, n_sub, params, ld, n_draw, n_planet, flags, gvals, gparams, gld, flux_dot,
     # workspace, workspace_bytes, reuse_runs, stream
     "exo_transit_flux_vjp_sparse_f64": (

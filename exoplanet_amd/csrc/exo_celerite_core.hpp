@@ -2065,24 +2065,42 @@ struct Rev {
   // and the coefficient cotangents through U, V.  W = (V - S U) / d is rebuilt (the step keeps V).
   // Returns zbar (d loglike / d y_i) and dbar (d loglike / d diag_i).
   // dt_next: t_{i+1} - t_i, the link behind this cadence (0: the series ends here)
-  EXO_HD void measure(const DrawCoef<J, NR>& co, const Step<J>& s, double dt_next, double gL, double* W_out, double* zbar_out,
-                      double* dbar_out) {
-    double U[J], u[J], W[J];
+  // W = (V - S U) / d of a cadence from its saved state, with the pieces the measurement half needs again (U, u = S U, 1 / d).
+  // Round 6: computed ONCE per cadence -- for the reverse of the step out of it -- and handed to measure_w; it used to be
+  // rebuilt inside measure() as well (u_from_v, a reciprocal, a J x J product: ~8 % of the reverse kernel's instructions).
+  struct WOf {
+    double U[J], u[J], W[J], id;
+  };
+  EXO_HD static void w_of(const DrawCoef<J, NR>& co, const Step<J>& s, WOf& w) {
 #pragma unroll
-    for (int j = 0; j < J; ++j) U[j] = 0.0;
-    co.u_from_v(s.V, U);
-    const double id = exo::fast_rcp(s.d);
-    double wdot = 0.0;
+    for (int j = 0; j < J; ++j) w.U[j] = 0.0;
+    co.u_from_v(s.V, w.U);
+    w.id = exo::fast_rcp(s.d);
 #pragma unroll
     for (int j = 0; j < J; ++j) {
       double uj = 0.0;
 #pragma unroll
-      for (int l = 0; l < J; ++l) uj = fma(s.S(j, l), U[l], uj);
-      u[j] = uj;
-      W[j] = (s.V[j] - uj) * id;
-      W_out[j] = W[j];
-      wdot = fma(Wb[j], W[j], wdot);
+      for (int l = 0; l < J; ++l) uj = fma(s.S(j, l), w.U[l], uj);
+      w.u[j] = uj;
+      w.W[j] = (s.V[j] - uj) * w.id;
     }
+  }
+  EXO_HD void measure(const DrawCoef<J, NR>& co, const Step<J>& s, double dt_next, double gL, double* W_out, double* zbar_out,
+                      double* dbar_out) {
+    WOf w;
+    w_of(co, s, w);
+#pragma unroll
+    for (int j = 0; j < J; ++j) W_out[j] = w.W[j];
+    measure_w(co, s, w, dt_next, gL, zbar_out, dbar_out);
+  }
+  EXO_HD void measure_w(const DrawCoef<J, NR>& co, const Step<J>& s, const WOf& w, double dt_next, double gL, double* zbar_out,
+                        double* dbar_out) {
+    const double* U = w.U;
+    const double* u = w.u;
+    const double id = w.id;
+    double wdot = 0.0;
+#pragma unroll
+    for (int j = 0; j < J; ++j) wdot = fma(Wb[j], w.W[j], wdot);
     const double zbar = zb - gL * s.z * id;
     const double dbar = db + gL * (0.5 * s.z * s.z * id * id - 0.5 * id) - wdot * id;
     *zbar_out = zbar;
@@ -2277,50 +2295,30 @@ EXO_HD void chunk1_vjp_lane(const double* EXO_RESTRICT t, Series rs, const doubl
       }
     }
     double zbar[kCkptB], dbar[kCkptB];
+    // W (and U, S U, 1 / d) of the cadence being reversed: worked out once, when the step OUT of it is reversed -- or, for the
+    // block's last cadence, right here -- and carried into its measurement half (Rev::w_of)
+    typename Rev<J, NR>::WOf wq;
 #pragma unroll
     for (int q = kCkptB - 1; q >= 0; --q) {
       zbar[q] = dbar[q] = 0.0;
       if (q < len) {
         const int64_t i = b0 + q;
-        double W[J];
-        if (q == len - 1 && pend) {
-          // the step from cadence i into cadence i + 1 (first of the block / chunk after this one):
-          // W of cadence i from its saved state
-          double U[J];
-#pragma unroll
-          for (int j = 0; j < J; ++j) U[j] = 0.0;
-          co.u_from_v(st[q].V, U);
-          const double id = exo::fast_rcp(st[q].d);
-#pragma unroll
-          for (int j = 0; j < J; ++j) {
-            double uj = 0.0;
-#pragma unroll
-            for (int l = 0; l < J; ++l) uj = fma(st[q].S(j, l), U[l], uj);
-            W[j] = (st[q].V[j] - uj) * id;
+        if (q == len - 1) {
+          Rev<J, NR>::w_of(co, st[q], wq);
+          if (pend) {
+            // the step from cadence i into cadence i + 1 (first of the block / chunk after this one)
+            const double dt = t[i + 1] - tt[q];
+            co.step(dt, phi, false);
+            r.propagate(st[q], wq.W, phi, dt);
           }
-          const double dt = t[i + 1] - tt[q];
-          co.step(dt, phi, false);
-          r.propagate(st[q], W, phi, dt);
         }
-        r.measure(co, st[q], (q + 1 < len) ? tt[q + 1] - tt[q] : (pend ? t[i + 1] - tt[q] : 0.0), gL, W, &zbar[q], &dbar[q]);
+        r.measure_w(co, st[q], wq, (q + 1 < len) ? tt[q + 1] - tt[q] : (pend ? t[i + 1] - tt[q] : 0.0), gL, &zbar[q], &dbar[q]);
         if (q > 0) {
-          // reverse of the step (i - 1) -> i: W of cadence i - 1 is rebuilt inside the next
-          // measure() as well; the few operations are cheaper than a register per state index
-          double U[J], Wp[J];
-#pragma unroll
-          for (int j = 0; j < J; ++j) U[j] = 0.0;
-          co.u_from_v(st[q - 1].V, U);
-          const double id = exo::fast_rcp(st[q - 1].d);
-#pragma unroll
-          for (int j = 0; j < J; ++j) {
-            double uj = 0.0;
-#pragma unroll
-            for (int l = 0; l < J; ++l) uj = fma(st[q - 1].S(j, l), U[l], uj);
-            Wp[j] = (st[q - 1].V[j] - uj) * id;
-          }
+          // reverse of the step (i - 1) -> i, with W of cadence i - 1 -- which the next round's measurement half takes over
+          Rev<J, NR>::w_of(co, st[q - 1], wq);
           const double dt = tt[q] - tt[q - 1];
           co.step(dt, phi, false);
-          r.propagate(st[q - 1], Wp, phi, dt);
+          r.propagate(st[q - 1], wq.W, phi, dt);
         }
       }
     }
@@ -2375,28 +2373,44 @@ struct RevP {
   // measurement half of cadence i: adjoints of (d, z, W) of this cadence -> (S, F) of this cadence
   // and the coefficient cotangents through U, V.  W = (V - S U) / d is rebuilt (the step keeps V).
   // Returns zbar (d loglike / d y_i) and dbar (d loglike / d diag_i); U_out (if given): this cadence's U.
-  EXO_HD void measure(const DrawCoef<J, NR>& co, const Step<J>& s, double dt_next, double gL, double* W_out, double* zbar_out,
-                      double* dbar_out, double* U_out = nullptr) {
-    double U[J], u[J], W[J];
+  // (Rev::w_of: W of a cadence and the pieces the measurement half needs again, computed once per cadence)
+  struct WOf {
+    double U[J], u[J], W[J], id;
+  };
+  EXO_HD static void w_of(const DrawCoef<J, NR>& co, const Step<J>& s, WOf& w) {
 #pragma unroll
-    for (int j = 0; j < J; ++j) U[j] = 0.0;
-    co.u_from_v(s.V, U);
-    if (U_out) {
-#pragma unroll
-      for (int j = 0; j < J; ++j) U_out[j] = U[j];
-    }
-    const double id = exo::fast_rcp(s.d);
-    double wdot = 0.0;
+    for (int j = 0; j < J; ++j) w.U[j] = 0.0;
+    co.u_from_v(s.V, w.U);
+    w.id = exo::fast_rcp(s.d);
 #pragma unroll
     for (int j = 0; j < J; ++j) {
       double uj = 0.0;
 #pragma unroll
-      for (int l = 0; l < J; ++l) uj = fma(s.S(j, l), U[l], uj);
-      u[j] = uj;
-      W[j] = (s.V[j] - uj) * id;
-      W_out[j] = W[j];
-      wdot = fma(Wb[j], W[j], wdot);
+      for (int l = 0; l < J; ++l) uj = fma(s.S(j, l), w.U[l], uj);
+      w.u[j] = uj;
+      w.W[j] = (s.V[j] - uj) * w.id;
     }
+  }
+  EXO_HD void measure(const DrawCoef<J, NR>& co, const Step<J>& s, double dt_next, double gL, double* W_out, double* zbar_out,
+                      double* dbar_out, double* U_out = nullptr) {
+    WOf w;
+    w_of(co, s, w);
+#pragma unroll
+    for (int j = 0; j < J; ++j) W_out[j] = w.W[j];
+    if (U_out) {
+#pragma unroll
+      for (int j = 0; j < J; ++j) U_out[j] = w.U[j];
+    }
+    measure_w(co, s, w, dt_next, gL, zbar_out, dbar_out);
+  }
+  EXO_HD void measure_w(const DrawCoef<J, NR>& co, const Step<J>& s, const WOf& w, double dt_next, double gL, double* zbar_out,
+                        double* dbar_out) {
+    const double* U = w.U;
+    const double* u = w.u;
+    const double id = w.id;
+    double wdot = 0.0;
+#pragma unroll
+    for (int j = 0; j < J; ++j) wdot = fma(Wb[j], w.W[j], wdot);
     const double zbar = zb - gL * s.z * id;
     const double dbar = db + gL * (0.5 * s.z * s.z * id * id - 0.5 * id) - wdot * id;
     *zbar_out = zbar;
@@ -2608,51 +2622,30 @@ EXO_HD void chunkp_vjp_lane(const double* EXO_RESTRICT t, Series rs, const doubl
             }
           }
         }
+        typename RevP<J, NR>::WOf wq;     // (chunk1_vjp_lane: W of a cadence once, carried into its measurement half)
 #pragma unroll
         for (int ql = kSpan - 1; ql >= 0; --ql) {
           if (ql < slen) {
             const int q = q0 + ql;
             const int64_t i = b0 + q;
-            double W[J];
-            // the step from cadence i into cadence i + 1 when that is the first cadence of the span / block / chunk
-            // after this one (already walked): W of cadence i from its saved state
-            if (ql == slen - 1 && (q == len - 1 ? pend : true)) {
-              double U[J];
-#pragma unroll
-              for (int j = 0; j < J; ++j) U[j] = 0.0;
-              co.u_from_v(st[ql].V, U);
-              const double id = exo::fast_rcp(st[ql].d);
-#pragma unroll
-              for (int j = 0; j < J; ++j) {
-                double uj = 0.0;
-#pragma unroll
-                for (int l = 0; l < J; ++l) uj = fma(st[ql].S(j, l), U[l], uj);
-                W[j] = (st[ql].V[j] - uj) * id;
+            if (ql == slen - 1) {
+              RevP<J, NR>::w_of(co, st[ql], wq);
+              // the step from cadence i into cadence i + 1 when that is the first cadence of the span / block / chunk
+              // after this one (already walked)
+              if (q == len - 1 ? pend : true) {
+                const double dt = t[i + 1] - tt[ql];
+                co.step(dt, phi, false);
+                r.propagate(st[ql], wq.W, phi, dt);
               }
-              const double dt = t[i + 1] - tt[ql];
-              co.step(dt, phi, false);
-              r.propagate(st[ql], W, phi, dt);
             }
-            r.measure(co, st[ql], (ql + 1 < slen) ? tt[ql + 1] - tt[ql] : ((i + 1 < n) ? t[i + 1] - tt[ql] : 0.0), gL, W, &zbar[q],
-                      &dbar[q]);
+            r.measure_w(co, st[ql], wq, (ql + 1 < slen) ? tt[ql + 1] - tt[ql] : ((i + 1 < n) ? t[i + 1] - tt[ql] : 0.0), gL, &zbar[q],
+                        &dbar[q]);
             if (ql > 0) {
-              // reverse of the step (i - 1) -> i inside the span: W of cadence i - 1 is rebuilt inside the next
-              // measure() as well; the few operations are cheaper than a register per state index
-              double U[J], Wp[J];
-#pragma unroll
-              for (int j = 0; j < J; ++j) U[j] = 0.0;
-              co.u_from_v(st[ql - 1].V, U);
-              const double id = exo::fast_rcp(st[ql - 1].d);
-#pragma unroll
-              for (int j = 0; j < J; ++j) {
-                double uj = 0.0;
-#pragma unroll
-                for (int l = 0; l < J; ++l) uj = fma(st[ql - 1].S(j, l), U[l], uj);
-                Wp[j] = (st[ql - 1].V[j] - uj) * id;
-              }
+              // reverse of the step (i - 1) -> i inside the span
+              RevP<J, NR>::w_of(co, st[ql - 1], wq);
               const double dt = tt[ql] - tt[ql - 1];
               co.step(dt, phi, false);
-              r.propagate(st[ql - 1], Wp, phi, dt);
+              r.propagate(st[ql - 1], wq.W, phi, dt);
             }
           }
         }

@@ -33,15 +33,20 @@
 #define EXO_WAVE_ANY(c) (__any((int)(c)))
 #endif
 
-// EXO_K(x): the fp64 constant x held in a SCALAR register pair (round 6).  gfx950's VOP3 encoding takes no 64-bit literal, so
-// the compiler materialises every polynomial coefficient with two v_mov_b32 (or a v_mov_b64 of a hoisted copy) and feeds a
-// v_fmac: a quarter of the vector instructions of the sweep's hot loop were such moves (212 of 1236), on the one pipe that
-// bounds it.  Two s_mov_b32 on the scalar unit -- which issues beside the other waves' vector instructions -- put the constant
-// into s[92:93] / s[94:95] and the v_fma_f64 reads it from there as its addend (one scalar operand per instruction: the
-// constant bus).  `volatile` keeps the moves where they are used: hoisted out of a loop they would cost ~100 live scalar
-// pairs.  Use it for addends and factors of fma chains, at most one per instruction; exact powers of two and small integers
-// are inline operands already and need nothing.
-#if defined(EXO_HOST_BUILD) || !defined(__HIP_DEVICE_COMPILE__) || defined(EXO_NO_SCALAR_CONSTANTS)
+// EXO_K(x): the fp64 constant x held in a SCALAR register pair (round 6; opt-in per translation unit: #define
+// EXO_SCALAR_CONSTANTS before including this header).  gfx950's VOP3 encoding takes no 64-bit literal, so the compiler
+// materialises every polynomial coefficient with two v_mov_b32 and feeds a v_fmac; with EXO_K two s_mov_b32 on the scalar unit
+// put the constant into s[92:93] / s[94:95] and the v_fma_f64 reads it from there as its addend (one scalar operand per
+// instruction: the constant bus).  `volatile` keeps the moves where they are used: hoisted out of a loop they would cost ~100
+// live scalar pairs.  MEASURED (round 6, same box, alternating runs; round 3 had found the same with another form):
+//   * standalone Ops (exo_ops.hip, 4-8 waves per SIMD, VALU-issue-bound): quad_solution_vector 1.46 -> 1.70 TB/s (+16 %),
+//     kepler 3.43 -> 3.58 TB/s: ON there;
+//   * the sweep and the celerite kernels (2-3 waves per SIMD, one long dependent chain per lane): 1236 -> 1063 vector
+//     instructions in the sweep's hot loop and 4-6 % SLOWER (sparse sweep 184 -> 194 us, C3 3.36 -> 3.51 ms, C5 1.82 -> 1.95):
+//     those kernels are bound by the per-wave chain, every instruction of a wave costs it an issue slot whichever unit
+//     executes it, the independent v_movs were filling stall slots for free, and four fewer allocatable scalar registers mean
+//     more spills to lanes (14 -> 55 v_readlane in the loop).  OFF there.
+#if defined(EXO_HOST_BUILD) || !defined(__HIP_DEVICE_COMPILE__) || !defined(EXO_SCALAR_CONSTANTS)
 #define EXO_K(x) (x)
 #define EXO_K2(x) (x)
 #else
@@ -459,9 +464,11 @@ EXO_HD double i4_series(double k) {
 
 // atan2(y, x0) and atan2(y, x1) for a common y >= 0 (results in [0, pi]): the two arc half-angles of the solution vector.
 // One division each (min / max, so |t| <= 1), atan t = t + t^3 q(t^2) with q of degree 19 in t^2 (interpolated at Chebyshev
-// nodes in 60-digit arithmetic, oracle-side script in docs/DESIGN_r1_r4.md's spirit: relative error 7.7e-17 with the rounded
-// coefficients, tools/atan_fit.py), the two chains side by side with their coefficients in scalar registers (EXO_K / EXO_K2).
-// libm's atan2 costs ~95 vector instructions here (19 coefficients as 38 register moves, an IEEE division); this is ~36.
+// nodes in 60-digit arithmetic: relative error 7.7e-17 with the rounded coefficients, tools/atan_fit.py), the two chains side
+// by side.  libm's atan2 costs ~95 vector instructions here (19 coefficients as 38 register moves, an IEEE division with its
+// scale / fixup sequence); this is ~60 (~36 with the coefficients in scalar registers, exo_ops.hip).  In the sweep the ~70
+// instructions saved per wave bought nothing measurable (it is chain-bound, EXO_K above); kept because it is shorter, has no
+// slow path, and quad_solution_vector as an Op gains.
 EXO_HD void atan2_pos_pair(double y, double x0, double x1, double* r0, double* r1) {
 #ifdef EXO_HOST_BUILD
   *r0 = atan2(y, x0);

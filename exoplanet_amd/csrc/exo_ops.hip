@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#define EXO_SCALAR_CONSTANTS   // polynomial coefficients from scalar registers: pays in these kernels (exo_math.hpp, EXO_K)
 #include "../../include/exoplanet_amd.h"
 #include "exo_contact.hpp"
 #include "exo_math.hpp"
@@ -32,19 +33,32 @@ struct SinCosF {
   double s, c;
 };
 
-// (sin f, cos f) of one element; NaN outside 0 <= e < 1 (the reference requires it: keplerian.py:58)
+// (sin f, cos f) of one element; NaN outside 0 <= e < 1 (the reference requires it: keplerian.py:58).  From the half
+// angles (sh, ch) = (sin, cos)(E / 2) of the solver:  (1 - e cos E) = (1 - e) ch^2 + (1 + e) sh^2,
+// (1 - e cos E) cos f = (1 - e) ch^2 - (1 + e) sh^2,  (1 - e cos E) sin f = 2 sqrt(1 - e^2) sh ch -- ONE square root, of
+// (1 - e)(1 + e); no cancellation as e -> 1.
 __device__ __forceinline__ SinCosF kepler_one(double M, double e) {
   const bool ok = (e >= 0.0) && (e < 1.0);
   const double es = ok ? e : 0.5;
-  const exo::KeplerHalf kh = exo::kepler_half(M, es, exo::fast_sqrt(1.0 - es), exo::fast_sqrt(1.0 + es));
-  const double X2 = kh.X * kh.X, Y2 = kh.Y * kh.Y;
+  const exo::KeplerHalf kh = exo::kepler_half(M, es, 1.0, 1.0);      // X = ch, Y = sh (signed)
+  const double ome = 1.0 - es, ope = 1.0 + es;
+  const double X2 = ome * (kh.ch * kh.ch), Y2 = ope * (kh.sh * kh.sh);
   const double iden = exo::fast_rcp(X2 + Y2);
+  const double sq = exo::fast_sqrt(ome * ope);
   const double nan = __builtin_nan("");
   SinCosF o;
-  o.s = ok ? 2.0 * kh.X * kh.Y * iden : nan;
+  o.s = ok ? (2.0 * sq) * (kh.sh * kh.ch) * iden : nan;
   o.c = ok ? (X2 - Y2) * iden : nan;
   return o;
 }
+
+#ifdef EXO_KEPLER_PLAIN_ACCESS
+#define EXO_LOAD16(p) (*(p))
+#define EXO_STORE16(v, p) (*(p) = (v))
+#else
+#define EXO_LOAD16(p) __builtin_nontemporal_load(p)
+#define EXO_STORE16(v, p) __builtin_nontemporal_store(v, p)
+#endif
 
 __global__ __launch_bounds__(kBlock) void kepler_kernel(const double* __restrict__ M, const double* __restrict__ ecc,
                                                         double* __restrict__ sinf, double* __restrict__ cosf, int64_t n) {
@@ -65,19 +79,19 @@ __global__ __launch_bounds__(kBlock) void kepler_pair_kernel(const d2* __restric
   const int64_t n_round = (n2 + stride - 1) / stride * stride;
   const d2 m_idle = {0.0, 0.0}, e_idle = {0.5, 0.5};
   bool v = i < n2;
-  d2 m = v ? __builtin_nontemporal_load(&M[i]) : m_idle;
-  d2 e = v ? __builtin_nontemporal_load(&ecc[i]) : e_idle;
+  d2 m = v ? EXO_LOAD16(&M[i]) : m_idle;
+  d2 e = v ? EXO_LOAD16(&ecc[i]) : e_idle;
   for (; i < n_round; i += stride) {
     const int64_t j = i + stride;
     const bool vn = j < n2;
-    const d2 mn = vn ? __builtin_nontemporal_load(&M[j]) : m_idle;
-    const d2 en = vn ? __builtin_nontemporal_load(&ecc[j]) : e_idle;
+    const d2 mn = vn ? EXO_LOAD16(&M[j]) : m_idle;
+    const d2 en = vn ? EXO_LOAD16(&ecc[j]) : e_idle;
     const SinCosF a = kepler_one(m.x, e.x);
     const SinCosF b = kepler_one(m.y, e.y);
     if (v) {
       const d2 so = {a.s, b.s}, co = {a.c, b.c};
-      __builtin_nontemporal_store(so, &sinf[i]);
-      __builtin_nontemporal_store(co, &cosf[i]);
+      EXO_STORE16(so, &sinf[i]);
+      EXO_STORE16(co, &cosf[i]);
     }
     m = mn; e = en; v = vn;
   }
@@ -118,6 +132,50 @@ __global__ __launch_bounds__(kBlock) void quad_sv_kernel(const double* __restric
       if (GRAD) {
         dsdb[3 * i] = sg * o.db0; dsdb[3 * i + 1] = sg * o.db1; dsdb[3 * i + 2] = sg * o.db2;
         dsdr[3 * i] = o.dr0; dsdr[3 * i + 1] = o.dr1; dsdr[3 * i + 2] = o.dr2;
+      }
+    }
+  }
+}
+
+// Two consecutive elements per lane (16-byte aligned b, r, s [, ds/db, ds/dr], n2 = pairs): one 16-byte load per input, and
+// the lane's six (value) or eighteen doubles leave as 16-byte stores of CONSECUTIVE addresses (a lane owns 48 contiguous bytes
+// of s) -- the one-element kernel writes s with three 8-byte stores of stride 24 per lane.  The two elements go through quad_sv
+// one after the other (a rolled loop: the registers of one evaluation), its wave votes seeing whole waves in both passes.
+template <bool GRAD>
+__global__ __launch_bounds__(kBlock) void quad_sv_pair_kernel(const d2* __restrict__ b, const d2* __restrict__ r,
+                                                              d2* __restrict__ s, d2* __restrict__ dsdb,
+                                                              d2* __restrict__ dsdr, int64_t n2) {
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  const int64_t n_round = (n2 + stride - 1) / stride * stride;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n_round; i += stride) {
+    const bool v = i < n2;
+    const d2 idle_b = {2.0, 2.0}, idle_r = {0.1, 0.1};
+    const d2 bb = v ? EXO_LOAD16(&b[i]) : idle_b;
+    const d2 rr = v ? EXO_LOAD16(&r[i]) : idle_r;
+    double o[2][GRAD ? 9 : 3];
+#pragma unroll 1
+    for (int k = 0; k < 2; ++k) {
+      const double bs = k ? bb.y : bb.x, rk = k ? rr.y : rr.x;
+      const double sg = bs < 0.0 ? -1.0 : 1.0;
+      exo::SV q;
+      exo::quad_sv<GRAD>(fabs(bs), rk, q);
+      // (stores at compile-time indices, selected: a run-time index into a register array goes to scratch)
+      if (k == 0) {
+        o[0][0] = q.s0; o[0][1] = q.s1; o[0][2] = q.s2;
+        if (GRAD) { o[0][3] = sg * q.db0; o[0][4] = sg * q.db1; o[0][5] = sg * q.db2; o[0][6] = q.dr0; o[0][7] = q.dr1; o[0][8] = q.dr2; }
+      } else {
+        o[1][0] = q.s0; o[1][1] = q.s1; o[1][2] = q.s2;
+        if (GRAD) { o[1][3] = sg * q.db0; o[1][4] = sg * q.db1; o[1][5] = sg * q.db2; o[1][6] = q.dr0; o[1][7] = q.dr1; o[1][8] = q.dr2; }
+      }
+    }
+    if (v) {
+      const d2 s0 = {o[0][0], o[0][1]}, s1 = {o[0][2], o[1][0]}, s2 = {o[1][1], o[1][2]};
+      EXO_STORE16(s0, &s[3 * i]); EXO_STORE16(s1, &s[3 * i + 1]); EXO_STORE16(s2, &s[3 * i + 2]);
+      if (GRAD) {
+        const d2 a0 = {o[0][3], o[0][4]}, a1 = {o[0][5], o[1][3]}, a2 = {o[1][4], o[1][5]};
+        EXO_STORE16(a0, &dsdb[3 * i]); EXO_STORE16(a1, &dsdb[3 * i + 1]); EXO_STORE16(a2, &dsdb[3 * i + 2]);
+        const d2 c0 = {o[0][6], o[0][7]}, c1 = {o[0][8], o[1][6]}, c2 = {o[1][7], o[1][8]};
+        EXO_STORE16(c0, &dsdr[3 * i]); EXO_STORE16(c1, &dsdr[3 * i + 1]); EXO_STORE16(c2, &dsdr[3 * i + 2]);
       }
     }
   }
@@ -183,11 +241,27 @@ int exo_quad_solution_vector_f64(const double* b, const double* r, double* s, do
   if (n < 0 || (n > 0 && (!b || !r || !s)) || ((dsdb == nullptr) != (dsdr == nullptr)))
     return EXO_ERR_INVALID_ARGUMENT;
   if (n == 0) return EXO_OK;
-  const dim3 grid(elementwise_grid(n)), block(kBlock);
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 block(kBlock);
+  const int64_t n2 = n / 2;
+  int64_t done = 0;
+  if (n2 >= 1024 && aligned16(b) && aligned16(r) && aligned16(s) && (!dsdb || (aligned16(dsdb) && aligned16(dsdr)))) {
+    const dim3 grid2(elementwise_grid(n2));
+    if (dsdb)
+      hipLaunchKernelGGL(quad_sv_pair_kernel<true>, grid2, block, 0, st, reinterpret_cast<const d2*>(b), reinterpret_cast<const d2*>(r),
+                         reinterpret_cast<d2*>(s), reinterpret_cast<d2*>(dsdb), reinterpret_cast<d2*>(dsdr), n2);
+    else
+      hipLaunchKernelGGL(quad_sv_pair_kernel<false>, grid2, block, 0, st, reinterpret_cast<const d2*>(b), reinterpret_cast<const d2*>(r),
+                         reinterpret_cast<d2*>(s), nullptr, nullptr, n2);
+    done = 2 * n2;
+    if (done == n) return launch_status();
+  }
+  const dim3 grid(elementwise_grid(n - done));
   if (dsdb)
-    hipLaunchKernelGGL(quad_sv_kernel<true>, grid, block, 0, (hipStream_t)stream, b, r, s, dsdb, dsdr, n);
+    hipLaunchKernelGGL(quad_sv_kernel<true>, grid, block, 0, st, b + done, r + done, s + 3 * done, dsdb + 3 * done, dsdr + 3 * done,
+                       n - done);
   else
-    hipLaunchKernelGGL(quad_sv_kernel<false>, grid, block, 0, (hipStream_t)stream, b, r, s, dsdb, dsdr, n);
+    hipLaunchKernelGGL(quad_sv_kernel<false>, grid, block, 0, st, b + done, r + done, s + 3 * done, dsdb, dsdr, n - done);
   return launch_status();
 }
 

@@ -2848,6 +2848,274 @@ __global__ __launch_bounds__(kBlock) void transit_scatter_runs_kernel(RunLists r
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The merged sparse model (round 6).  A draw's lists -- (planet, event) -- each hold ascending, disjoint runs of cadences and
+// their flux values; lists of DIFFERENT planets may overlap (simultaneous transits), and a list may be the whole series (a
+// window that could not be bounded).  For the celerite kernels a draw's mean must be ONE ascending list of disjoint segments
+// with one value per cadence: the union of the runs, the values summed over the lists (limb_dark.py:228-230 sums the planets,
+// secondary_eclipse.py:67-70 blends transit and occultation -- the blend's weights are in the values already).
+//   sparse_merge_segments_kernel   a block per draw: every run's rank among all the draw's runs by binary search in the other
+//                                  lists (no sort: each list is sorted), then a prefix-maximum scan of the run ends decides
+//                                  where a new segment starts; segment bounds + the prefix sums of their lengths
+//   sparse_merge_values_kernel     a thread per merged cadence: its value = the sum over the lists that hold it (binary search)
+//   sparse_merge_vjp_kernel        a thread per value of a list: the cotangent of the merged value of its cadence
+// All O(solved cadences x lists x log runs): ~3 % of a dense pass.
+// ---------------------------------------------------------------------------------------------------------------------
+struct MergeWs {
+  int32_t* nseg;     // [n_draw]
+  int32_t* seg;      // [n_draw][cap_seg][2]      (lo, hi)
+  int32_t* off;      // [n_draw][cap_seg + 1]     exclusive prefix sums of hi - lo; [nseg] = the draw's number of values
+  int32_t* sorted;   // [n_draw][cap_run][2]      scratch: every run of the draw, by lo
+  double* vals;      // [n_draw][n_cad]
+  int cap_seg, cap_run;
+  int64_t off_nseg, off_seg, off_off, off_vals, bytes;
+};
+inline MergeWs carve_merge(void* base, int64_t n_cad, int64_t n_draw, int n_planet) {
+  MergeWs m;
+  const int64_t runs = (int64_t)n_planet * 2 * runs_r_max(n_cad);
+  m.cap_run = (int)runs;
+  m.cap_seg = (int)(runs < n_cad + 1 ? runs : n_cad + 1);       // (disjoint segments of >= 1 cadence each)
+  auto up16 = [](int64_t b) { return (b + 15) & ~(int64_t)15; };
+  char* p = (char*)base;
+  int64_t off = 0;
+  m.off_nseg = off; m.nseg = (int32_t*)(p + off); off = up16(off + 4 * n_draw);
+  m.off_seg = off; m.seg = (int32_t*)(p + off); off = up16(off + 8 * n_draw * (int64_t)m.cap_seg);
+  m.off_off = off; m.off = (int32_t*)(p + off); off = up16(off + 4 * n_draw * ((int64_t)m.cap_seg + 1));
+  m.sorted = (int32_t*)(p + off); off = up16(off + 8 * n_draw * (int64_t)m.cap_run);
+  m.off_vals = off; m.vals = (double*)(p + off); off = up16(off + 8 * n_draw * n_cad);
+  m.bytes = off;
+  return m;
+}
+inline int merge_blocks_per_draw(int64_t n_draw) {
+  const int64_t b = (4096 + n_draw - 1) / (n_draw > 0 ? n_draw : 1);
+  return (int)(b < 1 ? 1 : (b > 64 ? 64 : b));
+}
+
+// number of runs of a list whose lo is < key (strict) / <= key
+__device__ __forceinline__ int runs_lower(const Run* __restrict__ runs, int K, int key, bool or_equal) {
+  int lo = 0, hi = K;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    const int v = runs[mid].lo;
+    if (v < key || (or_equal && v == key)) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+// the run of a list that holds cadence n, or -1
+__device__ __forceinline__ int runs_find(const Run* __restrict__ runs, int K, int n) {
+  const int k = runs_lower(runs, K, n, true) - 1;     // last run with lo <= n
+  return (k >= 0 && n < runs[k].hi) ? k : -1;
+}
+
+// inclusive scans over a block of kBlock threads through LDS (s: kBlock ints): max / sum
+__device__ __forceinline__ int block_scan_max(int v, int* s) {
+  s[threadIdx.x] = v;
+  __syncthreads();
+  for (int d = 1; d < kBlock; d <<= 1) {
+    const int o = (int)threadIdx.x >= d ? s[threadIdx.x - d] : INT32_MIN;
+    __syncthreads();
+    if (o > s[threadIdx.x]) s[threadIdx.x] = o;
+    __syncthreads();
+  }
+  return s[threadIdx.x];
+}
+__device__ __forceinline__ int block_scan_sum(int v, int* s) {
+  s[threadIdx.x] = v;
+  __syncthreads();
+  for (int d = 1; d < kBlock; d <<= 1) {
+    const int o = (int)threadIdx.x >= d ? s[threadIdx.x - d] : 0;
+    __syncthreads();
+    s[threadIdx.x] += o;
+    __syncthreads();
+  }
+  return s[threadIdx.x];
+}
+
+__global__ __launch_bounds__(kBlock) void sparse_merge_segments_kernel(RunLists rl, int n_planet, int n_ev, int64_t n_cad, MergeWs m) {
+  const int64_t draw = blockIdx.x;
+  const int tid = threadIdx.x, n_lists = n_planet * n_ev;
+  __shared__ int s_first[2 * EXO_MAX_PLANETS + 1];   // runs before list l of this draw
+  __shared__ int s_scan[kBlock];
+  __shared__ int s_flag[kBlock + 1];
+  __shared__ int s_carry[2];
+  if (tid == 0) {
+    int acc = 0;
+    for (int l = 0; l < n_lists; ++l) {
+      int K = rl.nrun[draw * n_lists + l];
+      K = K < 0 ? 0 : (K > rl.r_max ? rl.r_max : K);
+      s_first[l] = acc;
+      acc += K;
+    }
+    s_first[n_lists] = acc;
+  }
+  __syncthreads();
+  const int R = s_first[n_lists];
+  int32_t* __restrict__ sorted = m.sorted + draw * (int64_t)m.cap_run * 2;
+  int32_t* __restrict__ seg = m.seg + draw * (int64_t)m.cap_seg * 2;
+  int32_t* __restrict__ off = m.off + draw * ((int64_t)m.cap_seg + 1);
+  const int ncad = (int)n_cad;
+  // 1) rank: a run's position among all runs of the draw by (lo, list)
+  for (int g = tid; g < R; g += kBlock) {
+    int l = 0;
+    while (l + 1 < n_lists && g >= s_first[l + 1]) ++l;
+    const int k = g - s_first[l];
+    const Run* __restrict__ mine = rl.runs + (draw * n_lists + l) * rl.r_max;
+    int lo = mine[k].lo, hi = mine[k].hi;
+    lo = lo < 0 ? 0 : (lo > ncad ? ncad : lo);
+    hi = hi < lo ? lo : (hi > ncad ? ncad : hi);
+    int rank = k;
+    for (int l2 = 0; l2 < n_lists; ++l2) {
+      if (l2 == l) continue;
+      const int K2 = s_first[l2 + 1] - s_first[l2];
+      rank += runs_lower(rl.runs + (draw * n_lists + l2) * rl.r_max, K2, lo, l2 < l);
+    }
+    sorted[2 * rank] = lo;
+    sorted[2 * rank + 1] = hi;
+  }
+  if (tid == 0) { s_carry[0] = INT32_MIN; s_carry[1] = 0; }
+  __syncthreads();     // (the block's global stores are visible to the block behind the barrier)
+  // 2) where segments start: a run starts one iff its lo is not below the largest hi before it (empty runs start nothing)
+  for (int base = 0; base < R; base += kBlock) {
+    const int i = base + tid;
+    const bool valid = i < R;
+    const int lo = valid ? sorted[2 * i] : INT32_MAX, hi = valid ? sorted[2 * i + 1] : INT32_MIN;
+    const bool live = valid && hi > lo;
+    const int carry_max = s_carry[0], carry_seg = s_carry[1];
+    const int incl = block_scan_max(live ? hi : INT32_MIN, s_scan);
+    int excl = tid > 0 ? s_scan[tid - 1] : INT32_MIN;
+    excl = excl > carry_max ? excl : carry_max;
+    const bool start = live && lo >= excl;
+    __syncthreads();
+    const int nstart = block_scan_sum(start ? 1 : 0, s_scan);
+    const int sidx = carry_seg + nstart - 1;          // the segment this run belongs to (live runs)
+    s_flag[tid] = start ? 1 : 0;
+    if (tid == 0) s_flag[kBlock] = 1;
+    __syncthreads();
+    if (start && sidx < m.cap_seg) seg[2 * sidx] = lo;
+    // the end of a segment = the prefix maximum at its last live run; a segment that goes on in the next round is written
+    // again there, with a maximum that includes this round's
+    if (live && sidx >= 0 && sidx < m.cap_seg) {
+      // last live run of its segment within this round: no later run of the round is live without starting a segment ... the
+      // prefix maximum is monotone, so EVERY live run may write it as long as the writes are ordered: only the last one does
+      bool last = true;
+      for (int j = tid + 1; j < kBlock && base + j < R; ++j) {
+        if (s_flag[j]) break;                          // the next segment starts: this one ended before it
+        const int hj = sorted[2 * (base + j) + 1], lj = sorted[2 * (base + j)];
+        if (hj > lj) { last = false; break; }          // a later live run of the same segment
+      }
+      const int end = incl > carry_max ? incl : carry_max;
+      if (last) seg[2 * sidx + 1] = end;
+    }
+    __syncthreads();
+    if (tid == kBlock - 1) {
+      s_carry[0] = incl > carry_max ? incl : carry_max;
+      s_carry[1] = carry_seg + nstart;
+    }
+    __syncthreads();
+  }
+  int S = s_carry[1];
+  S = S > m.cap_seg ? m.cap_seg : S;
+  // 3) prefix sums of the segment lengths
+  if (tid == 0) s_carry[0] = 0;
+  __syncthreads();
+  for (int base = 0; base < S; base += kBlock) {
+    const int i = base + tid;
+    const int len = i < S ? seg[2 * i + 1] - seg[2 * i] : 0;
+    const int carry = s_carry[0];
+    const int incl = block_scan_sum(len, s_scan);
+    if (i < S) off[i] = carry + incl - len;
+    __syncthreads();
+    if (tid == kBlock - 1) s_carry[0] = carry + incl;
+    __syncthreads();
+  }
+  if (tid == 0) {
+    off[S] = s_carry[0];
+    m.nseg[draw] = S;
+  }
+}
+
+// position of list l's values in the value array of (draw, planet): occultations behind the transits
+__device__ __forceinline__ int64_t list_vbase(const RunLists& rl, int64_t draw, int n_planet, int n_ev, int p, int ev, int64_t n_cad) {
+  int64_t vbase = (draw * n_planet + p) * n_cad;
+  if (ev > 0) {
+    const int64_t l0 = (draw * n_planet + p) * n_ev;
+    int K0 = rl.nrun[l0];
+    K0 = K0 < 0 ? 0 : (K0 > rl.r_max ? rl.r_max : K0);
+    vbase += rl.pre_all[l0 * (rl.r_max + 1) + K0];
+  }
+  return vbase;
+}
+
+__global__ __launch_bounds__(kBlock) void sparse_merge_values_kernel(RunLists rl, const double* __restrict__ vals, int n_planet, int n_ev,
+                                                                     int64_t n_cad, MergeWs m) {
+  const int64_t draw = blockIdx.y;
+  const int n_lists = n_planet * n_ev;
+  const int S = m.nseg[draw];
+  const int32_t* __restrict__ seg = m.seg + draw * (int64_t)m.cap_seg * 2;
+  const int32_t* __restrict__ off = m.off + draw * ((int64_t)m.cap_seg + 1);
+  double* __restrict__ out = m.vals + draw * n_cad;
+  const int total = off[S];
+  for (int pos = blockIdx.x * kBlock + threadIdx.x; pos < total; pos += gridDim.x * kBlock) {
+    // the segment of this position: last s with off[s] <= pos
+    int lo = 0, hi = S;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (off[mid] <= pos) lo = mid + 1; else hi = mid;
+    }
+    const int sgm = lo - 1;
+    const int n = seg[2 * sgm] + (pos - off[sgm]);
+    double v = 0.0;
+    for (int l = 0; l < n_lists; ++l) {       // in list order: the dense sweep's order of summation
+      const int64_t list = draw * n_lists + l;
+      int K = rl.nrun[list];
+      K = K < 0 ? 0 : (K > rl.r_max ? rl.r_max : K);
+      const Run* __restrict__ runs = rl.runs + list * rl.r_max;
+      const int k = runs_find(runs, K, n);
+      if (k >= 0) {
+        const int p = l / n_ev, ev = l - p * n_ev;
+        v += vals[list_vbase(rl, draw, n_planet, n_ev, p, ev, n_cad) + rl.pre_all[list * (rl.r_max + 1) + k] + (n - runs[k].lo)];
+      }
+    }
+    out[pos] = v;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void sparse_merge_vjp_kernel(RunLists rl, int n_planet, int n_ev, int64_t n_cad, MergeWs m,
+                                                                  const double* __restrict__ gm, double* __restrict__ gvals) {
+  const int64_t draw = blockIdx.y;
+  const int n_lists = n_planet * n_ev;
+  const int S = m.nseg[draw];
+  const int32_t* __restrict__ seg = m.seg + draw * (int64_t)m.cap_seg * 2;
+  const int32_t* __restrict__ off = m.off + draw * ((int64_t)m.cap_seg + 1);
+  const double* __restrict__ g = gm + draw * n_cad;
+  for (int l = 0; l < n_lists; ++l) {
+    const int64_t list = draw * n_lists + l;
+    int K = rl.nrun[list];
+    K = K < 0 ? 0 : (K > rl.r_max ? rl.r_max : K);
+    const Run* __restrict__ runs = rl.runs + list * rl.r_max;
+    const int32_t* __restrict__ pall = rl.pre_all + list * (rl.r_max + 1);
+    const int p = l / n_ev, ev = l - p * n_ev;
+    const int64_t vbase = list_vbase(rl, draw, n_planet, n_ev, p, ev, n_cad);
+    const int total = pall[K];
+    for (int e = blockIdx.x * kBlock + threadIdx.x; e < total; e += gridDim.x * kBlock) {
+      int lo = 0, hi = K;                     // the run of value e: last k with pre_all[k] <= e
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (pall[mid] <= e) lo = mid + 1; else hi = mid;
+      }
+      const int k = lo - 1;
+      const int n = runs[k].lo + (e - pall[k]);
+      lo = 0; hi = S;                         // the merged segment of cadence n: last s with seg lo <= n
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (seg[2 * mid] <= n) lo = mid + 1; else hi = mid;
+      }
+      const int sgm = lo - 1;
+      gvals[vbase + e] = (sgm >= 0 && n < seg[2 * sgm + 1]) ? g[off[sgm] + (n - seg[2 * sgm])] : 0.0;
+    }
+  }
+}
+
 // every flag bit a sweep knows; anything else is a newer header talking to this library (ABI 10: refused, not ignored --
 // a layout flag this build does not know would otherwise come back as a silently different array)
 inline bool sweep_flags_ok(uint32_t flags) { return (flags & ~(uint32_t)EXO_FLAG_SWEEP_ALL) == 0; }
@@ -3238,6 +3506,83 @@ int exo_transit_flux_sparse_model(const void* workspace, int64_t workspace_bytes
   out->val_row = (int64_t)n_planet * n_cad;
   out->row_of_draw = nullptr;
   return EXO_OK;
+}
+
+// ---- the MERGED sparse model (round 6): several lists per draw -- planets, occultations -- as one ascending list of disjoint
+// segments with the SUM of the lists' values: what exo_transit_flux_sparse_model refuses.  See include/exoplanet_amd.h.
+int64_t exo_sparse_merge_workspace_bytes(int64_t n_cad, int64_t n_draw, int32_t n_planet) {
+  if (n_cad < 0 || n_draw < 0 || n_planet < 1 || n_planet > EXO_MAX_PLANETS) return -1;
+  return carve_merge(nullptr, n_cad, n_draw, n_planet).bytes;
+}
+
+int exo_sparse_merge_layout(int64_t n_cad, int64_t n_draw, int32_t n_planet, int64_t* out) {
+  if (n_cad < 0 || n_draw < 0 || n_planet < 1 || n_planet > EXO_MAX_PLANETS || !out) return EXO_ERR_INVALID_ARGUMENT;
+  const MergeWs m = carve_merge(nullptr, n_cad, n_draw, n_planet);
+  out[0] = m.off_nseg; out[1] = m.off_seg; out[2] = m.off_off; out[3] = m.off_vals; out[4] = m.cap_seg;
+  return EXO_OK;
+}
+
+static int merge_args(const void* workspace, int64_t workspace_bytes, int64_t n_cad, int64_t n_draw, int32_t n_planet,
+                      uint32_t flags, const void* merge_ws, int64_t merge_ws_bytes, RunWs* rw, MergeWs* m) {
+  if (n_cad < 0 || n_cad >= ((int64_t)1 << 31) || n_draw < 0 || n_draw > 65535 || n_planet < 1 || n_planet > EXO_MAX_PLANETS ||
+      (flags & ~(uint32_t)EXO_FLAG_SECONDARY))
+    return EXO_ERR_INVALID_ARGUMENT;
+  *rw = carve_runs(const_cast<void*>(workspace), n_cad, n_draw, n_planet);
+  *m = carve_merge(const_cast<void*>(merge_ws), n_cad, n_draw, n_planet);
+  if (!workspace || workspace_bytes < rw->bytes || !merge_ws || merge_ws_bytes < m->bytes) return EXO_ERR_WORKSPACE;
+  return EXO_OK;
+}
+
+static void describe_merged(const MergeWs& m, int64_t n_cad, exo_sparse_model* out) {
+  out->nseg = m.nseg;
+  out->seg = m.seg;
+  out->off = m.off;
+  out->vals = m.vals;
+  out->seg_step = 2; out->hi_at = 1;
+  out->seg_row = (int64_t)m.cap_seg * 2;
+  out->off_row = (int64_t)m.cap_seg + 1;
+  out->val_row = n_cad;
+  out->row_of_draw = nullptr;
+}
+
+int exo_sparse_model_merged(const void* merge_ws, int64_t merge_ws_bytes, int64_t n_cad, int64_t n_draw, int32_t n_planet,
+                            exo_sparse_model* out) {
+  if (n_cad < 0 || n_draw < 0 || n_planet < 1 || n_planet > EXO_MAX_PLANETS || !out) return EXO_ERR_INVALID_ARGUMENT;
+  const MergeWs m = carve_merge(const_cast<void*>(merge_ws), n_cad, n_draw, n_planet);
+  if (!merge_ws || merge_ws_bytes < m.bytes) return EXO_ERR_WORKSPACE;
+  describe_merged(m, n_cad, out);
+  return EXO_OK;
+}
+
+int exo_sparse_model_merge_f64(const void* workspace, int64_t workspace_bytes, int64_t n_cad, int64_t n_draw, int32_t n_planet,
+                               uint32_t flags, void* merge_ws, int64_t merge_ws_bytes, exo_sparse_model* out, void* stream) {
+  RunWs rw;
+  MergeWs m;
+  const int rc = merge_args(workspace, workspace_bytes, n_cad, n_draw, n_planet, flags, merge_ws, merge_ws_bytes, &rw, &m);
+  if (rc != EXO_OK) return rc;
+  if (out) describe_merged(m, n_cad, out);
+  if (n_cad == 0 || n_draw == 0) return EXO_OK;
+  const int n_ev = (flags & EXO_FLAG_SECONDARY) ? 2 : 1;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(sparse_merge_segments_kernel, dim3((unsigned)n_draw), dim3(kBlock), 0, st, rw.rl, (int)n_planet, n_ev, n_cad, m);
+  hipLaunchKernelGGL(sparse_merge_values_kernel, dim3((unsigned)merge_blocks_per_draw(n_draw), (unsigned)n_draw), dim3(kBlock), 0, st,
+                     rw.rl, rw.vals, (int)n_planet, n_ev, n_cad, m);
+  return launch_status();
+}
+
+int exo_sparse_model_merge_vjp_f64(const void* workspace, int64_t workspace_bytes, int64_t n_cad, int64_t n_draw, int32_t n_planet,
+                                   uint32_t flags, const void* merge_ws, int64_t merge_ws_bytes, const double* gmvals,
+                                   double* gvals, void* stream) {
+  RunWs rw;
+  MergeWs m;
+  const int rc = merge_args(workspace, workspace_bytes, n_cad, n_draw, n_planet, flags, merge_ws, merge_ws_bytes, &rw, &m);
+  if (rc != EXO_OK) return rc;
+  if (n_cad == 0 || n_draw == 0) return EXO_OK;
+  if (!gmvals || !gvals) return EXO_ERR_INVALID_ARGUMENT;
+  const int n_ev = (flags & EXO_FLAG_SECONDARY) ? 2 : 1;
+  hipLaunchKernelGGL(sparse_merge_vjp_kernel, dim3((unsigned)merge_blocks_per_draw(n_draw), (unsigned)n_draw), dim3(kBlock), 0,
+                     (hipStream_t)stream, rw.rl, (int)n_planet, n_ev, n_cad, m, gmvals, gvals);
+  return launch_status();
 }
 
 int exo_transit_chi2_vjp_f64(const double* t, int64_t n_cad, const double* texp, int64_t n_texp, const double* stencil_dt,

@@ -153,9 +153,13 @@ def _transit_order(sp):
         with torch.cuda.device(order.device):
             _lib.check(lib.exo_sparse_model_order(ctypes.addressof(model), D, _ptr(order), _stream(order)), "exo_sparse_model_order")
         return order
-    lay = sp.layout()
-    nrun = lay.nrun.reshape(D).long()
-    lo = lay.runs.reshape(D, lay.r_max, 4)[:, :, 0]
+    if hasattr(sp, "segments"):          # a merged light curve (ops.MergedSparseLightCurve)
+        nseg, seg, _ = sp.segments()
+        nrun, lo = nseg.long(), seg[:, :, 0]
+    else:
+        lay = sp.layout()
+        nrun = lay.nrun.reshape(D).long()
+        lo = lay.runs.reshape(D, lay.r_max, 4)[:, :, 0]
     first = lo[:, 0].double()
     last = lo.gather(1, (nrun - 1).clamp_min(0).unsqueeze(1)).squeeze(1).double()
     key = (last - first) / (nrun - 1).clamp_min(1).double() + 1e-9 * first

@@ -826,11 +826,16 @@ def transit_flux_sparse(t, params, ld, gflux=None, texp=None, stencil_dt=None, s
 _SPARSE_MEAN = [os.environ.get("EXO_SPARSE_MEAN", "1") != "0"]     # (0: A/B -- get_light_curve(sparse=True) returns the dense array)
 
 
+_MULTI_LIST_MEAN = [os.environ.get("EXO_SPARSE_MULTI_LIST", "1") != "0"]    # (0: several lists per draw keep the dense mean -- A/B)
+
+
 def sparse_mean_supported(n_texp, n_edge, flags, P):
-    """can this light curve travel to the celerite kernels as runs + values?  One list per draw (one planet, no occultations:
-    exo_transit_flux_sparse_model), a run-enumeration sweep of the summed flux without timing tables or light delay"""
+    """can this light curve travel to the celerite kernels as segments + values?  A run-enumeration sweep of the summed flux
+    without timing tables or light delay.  One list per draw (one planet, no occultations): the sweep's runs ARE the segments
+    (exo_transit_flux_sparse_model); several lists -- planets, occultations -- are merged on the device first
+    (exo_sparse_model_merge_f64, round 6)"""
     n_ev = 2 if flags & FLAG_SECONDARY else 1
-    return (_SPARSE_MEAN[0] and P * n_ev == 1 and n_texp <= 1 and not n_edge
+    return (_SPARSE_MEAN[0] and (P * n_ev == 1 or _MULTI_LIST_MEAN[0]) and n_texp <= 1 and not n_edge
             and not flags & (FLAG_PER_PLANET | FLAG_EXACT_SCAN | FLAG_LIGHT_DELAY | FLAG_CADENCE_MAJOR))
 
 
@@ -926,9 +931,6 @@ class _SparseToDense(torch.autograd.Function):
         return g, None
 
 
-_MULTI_LIST_MEAN = [False]     # (the merged multi-list model of round 6 flips this when the library provides it)
-
-
 class SparseLightCurve:
     """What ``get_light_curve(total=True, sparse=True)`` returns for a batch of draws: the summed light curve as the runs
     of cadences in which a planet can overlap the disk and the flux of exactly those cadences (every other cadence: 0),
@@ -950,9 +952,9 @@ class SparseLightCurve:
         import ctypes
 
         n_ev = 2 if self.flags & FLAG_SECONDARY else 1
-        if self.n_planet * n_ev != 1 and not _MULTI_LIST_MEAN[0]:
-            raise ValueError("a sparse GaussianProcess mean is one list of runs per draw (one planet, no occultations); "
-                             f"this light curve has {self.n_planet} planet(s) x {n_ev} event(s): pass .dense()")
+        if self.n_planet * n_ev != 1:
+            raise ValueError("a sparse GaussianProcess mean is one list of segments per draw; this light curve has "
+                             f"{self.n_planet} planet(s) x {n_ev} event(s): use .merged() (or .dense())")
 
         nbytes = _lib.load().exo_transit_flux_workspace_bytes(self.n_cad, self.n_draw, self.n_planet)
         _lib.check(_lib.load().exo_transit_flux_sparse_model(_ptr(self._ws), nbytes, self.n_cad, self.n_draw, self.n_planet,
@@ -995,6 +997,17 @@ class SparseLightCurve:
         """the (draws, cadences) summed flux, differentiable"""
         return _SparseToDense.apply(self.values, self)
 
+    def merged(self):
+        """this light curve with ONE list of segments per draw (what the celerite kernels take): itself when it already is
+        (one planet, no occultations), otherwise the lists merged on the device -- union of the runs, values summed over the
+        planets / events per cadence -- as a :class:`MergedSparseLightCurve`, differentiable through ``values``"""
+        n_ev = 2 if self.flags & FLAG_SECONDARY else 1
+        if self.n_planet * n_ev == 1:
+            return self
+        box = []
+        mvals = _MergeSparse.apply(self.values, self, box)
+        return MergedSparseLightCurve(mvals, box[0], self.n_cad, self.n_draw, self.n_planet, self.flags)
+
     def detach(self):
         return SparseLightCurve(self.values.detach(), self._ws, self.n_cad, self.n_draw, self.n_planet, self.flags)
 
@@ -1011,12 +1024,135 @@ class SparseLightCurve:
     def __neg__(self): return -self.dense()
 
 
+class _MergeSparse(torch.autograd.Function):
+    """values of a several-list sparse light curve (D, P * N: the sweep's layout) -> values of the merged model (D, N), of which
+    row d's first off[d][nseg[d]] entries are defined (exo_sparse_model_merge_f64); backward: the cotangent of the merged values
+    back at the lists' value positions (exo_sparse_model_merge_vjp_f64).  `box` receives the merge workspace."""
+
+    @staticmethod
+    def forward(ctx, vals, sp, box):
+        lib = _lib.load()
+        N, D, P = sp.n_cad, sp.n_draw, sp.n_planet
+        nbytes = lib.exo_transit_flux_workspace_bytes(N, D, P)
+        mbytes = lib.exo_sparse_merge_workspace_bytes(N, D, P)
+        mws = torch.empty(max(mbytes // 8 + 1, 1), dtype=torch.float64, device=vals.device)
+        with torch.cuda.device(vals.device):
+            _lib.check(lib.exo_sparse_model_merge_f64(_ptr(sp._ws), nbytes, N, D, P, sp.flags & FLAG_SECONDARY, _ptr(mws), mbytes,
+                                                      None, _stream(vals)), "exo_sparse_model_merge_f64")
+        import ctypes
+
+        lay = (ctypes.c_int64 * 5)()
+        _lib.check(lib.exo_sparse_merge_layout(N, D, P, lay), "exo_sparse_merge_layout")
+        ctx.sp, ctx.mws, ctx.sizes = sp, mws, (nbytes, mbytes)
+        box.append(mws)
+        return mws[lay[3] // 8: lay[3] // 8 + D * N].view(D, N)
+
+    @staticmethod
+    def backward(ctx, gm):
+        sp = ctx.sp
+        N, D, P = sp.n_cad, sp.n_draw, sp.n_planet
+        nbytes, mbytes = ctx.sizes
+        if not gm.is_contiguous() or tuple(gm.shape) != (D, N):
+            raise ValueError("the cotangent of a merged sparse light curve's values must be a contiguous (n_draw, n_cad) array")
+        # (only the positions the lists cover are defined, as in `vals` itself -- gp/celerite.py, _CeleriteLogLikeSparse.backward)
+        gvals = torch.empty(D, P * N, dtype=torch.float64, device=gm.device)
+        with torch.cuda.device(gm.device):
+            _lib.check(_lib.load().exo_sparse_model_merge_vjp_f64(_ptr(sp._ws), nbytes, N, D, P, sp.flags & FLAG_SECONDARY,
+                                                                  _ptr(ctx.mws), mbytes, _ptr(gm), _ptr(gvals), _stream(gm)),
+                       "exo_sparse_model_merge_vjp_f64")
+        return gvals, None, None
+
+
+class MergedSparseLightCurve(SparseLightCurve):
+    """A sparse light curve of several lists per draw (planets, occultations) merged into one list of disjoint segments per
+    draw, a cadence's value the sum over the lists: the ``mean`` of a ``GaussianProcess`` for multi-planet and
+    secondary-eclipse models (round 6).  ``values`` is (draws, cadences) with the first ``off[nseg]`` entries of a row defined."""
+
+    def merged(self):
+        return self
+
+    def _merge_layout(self):
+        import ctypes
+
+        lay = (ctypes.c_int64 * 5)()
+        _lib.check(_lib.load().exo_sparse_merge_layout(self.n_cad, self.n_draw, self.n_planet, lay), "exo_sparse_merge_layout")
+        return list(lay)
+
+    def model_struct(self):
+        import ctypes
+
+        m = _lib.SparseModel()
+        nbytes = _lib.load().exo_sparse_merge_workspace_bytes(self.n_cad, self.n_draw, self.n_planet)
+        _lib.check(_lib.load().exo_sparse_model_merged(_ptr(self._ws), nbytes, self.n_cad, self.n_draw, self.n_planet,
+                                                       ctypes.addressof(m)), "exo_sparse_model_merged")
+        return m
+
+    def segments(self):
+        """(nseg (D,), seg (D, cap, 2), off (D, cap + 1)) int32 views of the merge workspace"""
+        o_nseg, o_seg, o_off, _, cap = self._merge_layout()
+        raw = self._ws.view(torch.int32)
+        D = self.n_draw
+        nseg = raw[o_nseg // 4: o_nseg // 4 + D]
+        seg = raw[o_seg // 4: o_seg // 4 + D * cap * 2].view(D, cap, 2)
+        off = raw[o_off // 4: o_off // 4 + D * (cap + 1)].view(D, cap + 1)
+        return nseg, seg, off
+
+    def layout(self):
+        raise NotImplementedError("a merged light curve has segments(), not the sweep's per-list runs")
+
+    def _indices(self):
+        nseg, seg, off = self.segments()
+        D, N = self.n_draw, self.n_cad
+        dev = self.values.device
+        K = int(nseg.max().item()) if nseg.numel() else 0
+        if K == 0:
+            z = torch.zeros(0, dtype=torch.long, device=dev)
+            return z, z, z
+        lo, hi = seg[:, :K, 0].long(), seg[:, :K, 1].long()
+        live = torch.arange(K, device=dev) < nseg.long().unsqueeze(-1)
+        ln = torch.where(live, hi - lo, torch.zeros_like(lo))
+        flat_len = ln.reshape(-1)
+        total = int(flat_len.sum().item())
+        rid = torch.repeat_interleave(torch.arange(flat_len.numel(), device=dev), flat_len, output_size=total)
+        start = torch.cumsum(flat_len, 0) - flat_len
+        within = torch.arange(total, device=dev) - start[rid]
+        d_i = torch.arange(D, device=dev).view(D, 1).expand(D, K).reshape(-1)[rid]
+        idx_val = d_i * N + off[:, :K].long().reshape(-1)[rid] + within
+        idx_cad = lo.reshape(-1)[rid] + within
+        return idx_val, idx_cad, d_i
+
+    def dense(self):
+        return _MergedToDense.apply(self.values, self)
+
+    def detach(self):
+        return MergedSparseLightCurve(self.values.detach(), self._ws, self.n_cad, self.n_draw, self.n_planet, self.flags)
+
+
+class _MergedToDense(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, vals, sp):
+        idx_val, idx_cad, idx_draw = sp._indices()
+        out = torch.zeros(sp.n_draw, sp.n_cad, dtype=torch.float64, device=vals.device)
+        out[idx_draw, idx_cad] = vals.reshape(-1)[idx_val]
+        ctx.sp = sp
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        sp = ctx.sp
+        idx_val, idx_cad, idx_draw = sp._indices()
+        g = torch.zeros(sp.n_draw, sp.n_cad, dtype=torch.float64, device=gout.device)
+        g.view(-1)[idx_val] = gout[idx_draw, idx_cad]
+        return g, None
+
+
 def transit_flux_sparse_model(t, params, ld, texp=None, stencil_dt=None, stencil_w=None, flags=0):
-    """the summed light curve of ``n_draw`` parameter sets as a :class:`SparseLightCurve` (differentiable w.r.t. ``params``
-    and ``ld``); see :func:`sparse_mean_supported` for what qualifies"""
+    """the summed light curve of ``n_draw`` parameter sets as a :class:`SparseLightCurve` with one list of segments per draw
+    (differentiable w.r.t. ``params`` and ``ld``): the sweep's own runs for one planet without occultations, the merged form
+    (:class:`MergedSparseLightCurve`) otherwise; see :func:`sparse_mean_supported` for what qualifies"""
     box = []
     vals = _TransitFluxSparse.apply(t, texp, stencil_dt, stencil_w, params, ld, int(flags), box, torch.is_grad_enabled())
-    return SparseLightCurve(vals, box[0], t.numel(), params.shape[0], params.shape[1], int(flags) | FLAG_SPARSE)
+    return SparseLightCurve(vals, box[0], t.numel(), params.shape[0], params.shape[1], int(flags) | FLAG_SPARSE).merged()
 
 
 class KeptDenseFlux:

@@ -42,8 +42,10 @@ extern "C" {
  *     exo_celerite_loglike_sparse_{fwd,vjp}_f64, exo_celerite_default_chunks; EXO_FLAG_SPARSE accepted by the Jacobian pair;
  *     exo_transit_flux_cols_vjp_f64; EXO_GP_MAX_J 16; a larger exo_transit_flux_workspace_bytes.
  * 12: exo_sparse_model.row_of_draw covers EVERY per-draw array of a sparse celerite call (coefficients, pair kinds, per-draw diag,
- *     loglike, gloglike, the cotangents written back: all in the caller's order, nothing to permute); exo_sparse_model_order. */
-#define EXO_ABI_VERSION 12
+ *     loglike, gloglike, the cotangents written back: all in the caller's order, nothing to permute); exo_sparse_model_order.
+ * 13: the MERGED sparse model -- exo_sparse_merge_workspace_bytes, exo_sparse_merge_layout, exo_sparse_model_merge_f64,
+ *     exo_sparse_model_merged, exo_sparse_model_merge_vjp_f64: several lists per draw (planets, occultations) as one. */
+#define EXO_ABI_VERSION 13
 int32_t exo_abi_version(void);
 
 /* ---------------------------------------------------------------------------
@@ -192,7 +194,7 @@ int exo_transit_flux_sparse_layout(int64_t n_cad, int64_t n_draw, int32_t n_plan
  * of cadences + their values, per draw.  exo_transit_flux_sparse_model fills the descriptor with pointers into `workspace`
  * (that of an EXO_FLAG_SPARSE sweep with the same n_cad, n_draw, n_planet; flags: EXO_FLAG_SECONDARY as the sweep had it).
  * One list per draw (one planet, no occultations): the runs are the segments.  Otherwise EXO_ERR_INVALID_ARGUMENT -- callers
- * keep the dense model for those.                                                                                      */
+ * merge the lists first (exo_sparse_model_merge_f64 below) or keep the dense model.                                                                                      */
 typedef struct exo_sparse_model {
   const int32_t* nseg;
   const int32_t* seg;
@@ -211,6 +213,29 @@ typedef struct exo_sparse_model {
 } exo_sparse_model;
 int exo_transit_flux_sparse_model(const void* workspace, int64_t workspace_bytes, int64_t n_cad, int64_t n_draw,
                                   int32_t n_planet, uint32_t flags, exo_sparse_model* out);
+/* The MERGED model (ABI 13): what exo_transit_flux_sparse_model refuses.  A draw with several lists -- n_planet planets, and with
+ * EXO_FLAG_SECONDARY a transit and an occultation list each -- becomes ONE ascending list of disjoint segments: the union of
+ * the lists' runs, a cadence's value the SUM of the values the lists hold for it (the reference sums the planets per cadence,
+ * limb_dark.py:228-230; a planet's transit and occultation never share a cadence, secondary_eclipse.py:67-70).  It lives in a
+ * caller-owned `merge_ws` (exo_sparse_merge_workspace_bytes; layout: exo_sparse_merge_layout out[0..4] = byte offsets of
+ * nseg int32 [n_draw], seg int32 [n_draw][cap][2] = (lo, hi), off int32 [n_draw][cap + 1], vals double [n_draw][n_cad], and cap):
+ *   exo_sparse_model_merge_f64       two launches on `stream` (segments: a block per draw, every run ranked among the draw's
+ *                                    runs by binary search, a prefix-maximum scan of the run ends; values: a thread per merged
+ *                                    cadence); `workspace` = the EXO_FLAG_SPARSE sweep's, same n_cad / n_draw / n_planet / flags;
+ *                                    fills `out` (may be NULL)
+ *   exo_sparse_model_merged          the descriptor alone (no launch): for the reverse call
+ *   exo_sparse_model_merge_vjp_f64   gvals (the sweep's value layout: what exo_transit_flux_vjp_sparse_f64 takes) from gmvals
+ *                                    [n_draw][n_cad], the cotangent the celerite reverse entry wrote for the merged values
+ * n_cad < 2^31, n_draw <= 65535.  Deterministic (no atomics): a merged value is summed in list order.                        */
+int64_t exo_sparse_merge_workspace_bytes(int64_t n_cad, int64_t n_draw, int32_t n_planet);
+int exo_sparse_merge_layout(int64_t n_cad, int64_t n_draw, int32_t n_planet, int64_t* out);
+int exo_sparse_model_merge_f64(const void* workspace, int64_t workspace_bytes, int64_t n_cad, int64_t n_draw, int32_t n_planet,
+                               uint32_t flags, void* merge_ws, int64_t merge_ws_bytes, exo_sparse_model* out, void* stream);
+int exo_sparse_model_merged(const void* merge_ws, int64_t merge_ws_bytes, int64_t n_cad, int64_t n_draw, int32_t n_planet,
+                            exo_sparse_model* out);
+int exo_sparse_model_merge_vjp_f64(const void* workspace, int64_t workspace_bytes, int64_t n_cad, int64_t n_draw, int32_t n_planet,
+                                   uint32_t flags, const void* merge_ws, int64_t merge_ws_bytes, const double* gmvals,
+                                   double* gvals, void* stream);
 /* order [n_draw] (device, int32): the draws of `model` (its rows 0 .. n_draw - 1; row_of_draw ignored) by ascending mean spacing of
  * their segments -- the period, in cadences: neighbouring periods keep their transits together all along the series -- ties by the
  * start of the first segment, then by index: what to pass as row_of_draw.  One launch, no host synchronisation.  n_draw <=

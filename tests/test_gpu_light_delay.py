@@ -1,7 +1,8 @@
 """GPU: light-travel delay inside the fused kernels (EXO_FLAG_LIGHT_DELAY; reference
 keplerian.py:411-470): flux against the oracle's restatement of _get_retarded_position, gradients
 against the composed torch path (two ops.kepler calls + autograd: an independent derivation of the
-hand-written reverse sweep through the delay)."""
+hand-written reverse sweep through the delay) AND against central differences of the oracle's light curve
+(P.LimbDarkLightCurve(...).get_light_curve(light_delay=True): nothing of the product path on that side)."""
 import numpy as np
 import pytest
 import torch
@@ -73,6 +74,39 @@ def test_fused_light_delay_gradients_vs_composed_path(dev):
                                                         use_in_transit=False)
     (f0 * g).sum().backward()
     assert abs(float(leaves["t0"].grad) - grads["fused"]["t0"]) > 1e-6 * abs(grads["fused"]["t0"])
+
+
+def test_fused_light_delay_gradients_vs_oracle_central_differences(dev):
+    """the reverse sweep through the delay against the ORACLE: L(theta) = sum(g * flux(theta)) with the
+    flux from oracle/numpy_port.py's restatement of keplerian.py:411-470, differentiated by Richardson-extrapolated central
+    differences in every parameter; the fused kernel's gradient must agree to 2e-6 (what the differences themselves hold)"""
+    import exoplanet_amd as xo
+
+    rng = np.random.default_rng(43)
+    t = np.linspace(0.0, 14.0, 9_001)
+    g = rng.normal(size=(9_001, 1))
+    base = dict(PARAMS, r=0.11, u1=0.3, u2=0.2)
+
+    def L_oracle(th):
+        kw = {k: th[k] for k in PARAMS}
+        f = P.LimbDarkLightCurve(th["u1"], th["u2"]).get_light_curve(orbit=P.KeplerianOrbit(**kw), r=th["r"], t=t, light_delay=True)
+        return float((f * g).sum())
+
+    def dL(k, h):
+        up, dn = dict(base), dict(base)
+        up[k] += h; dn[k] -= h
+        return (L_oracle(up) - L_oracle(dn)) / (2 * h)
+
+    leaves = {k: T(v, dev, True) for k, v in base.items()}
+    orbit = xo.KeplerianOrbit(**{k: leaves[k] for k in PARAMS})
+    f = xo.LimbDarkLightCurve(leaves["u1"], leaves["u2"]).get_light_curve(orbit=orbit, r=leaves["r"], t=T(t, dev), light_delay=True)
+    (f * T(g, dev)).sum().backward()
+    assert abs(float((f.detach().cpu().numpy() * g).sum()) - L_oracle(base)) <= 1e-10 * abs(L_oracle(base)) + 1e-12
+    for k, v in base.items():
+        h = 2e-5 * max(abs(v), 0.1)
+        fd = (4.0 * dL(k, h) - dL(k, 2 * h)) / 3.0          # O(h^4)
+        got = float(leaves[k].grad)
+        assert abs(got - fd) <= 2e-6 * abs(fd) + 1e-9, (k, got, fd)
 
 
 def test_fused_light_delay_secondary_eclipse_batch(dev):

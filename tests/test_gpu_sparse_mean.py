@@ -230,15 +230,25 @@ def test_sparse_light_curve_dense_and_fallbacks(dev):
     ll_sp = xo.gp.GaussianProcess(kern, t=t, yerr=5e-4, mean=sp).log_likelihood(yb)
     ll_de = xo.gp.GaussianProcess(kern, t=t, yerr=5e-4, mean=want).log_likelihood(yb)
     assert float(((ll_sp - ll_de).abs() / ll_de.abs()).max()) <= 1e-13
-    # two planets: the dense cadence-major array
+    # two planets, occultations: several lists per draw -- merged on the device since round 6 (tests/test_gpu_sparse_merged.py);
+    # with the merge switched off they come back as the dense cadence-major array, as before
     L2 = {k: torch.cat([v, v * 1.7], 1).detach().requires_grad_(True) for k, v in L.items()}
     r2 = torch.cat([r, 0.5 * r], 1).detach().requires_grad_(True)
-    lc2 = star.get_light_curve(orbit=xo.KeplerianOrbit(**L2), r=r2, t=t, total=True, sparse=True)
-    assert torch.is_tensor(lc2) and xo.ops.is_cadence_major(lc2)
-    # occultations: likewise
     sec = xo.SecondaryEclipseLightCurve((0.3, 0.2), (0.4, 0.1), torch.full((D,), 0.3, dtype=torch.float64, device=dev))
+    lc2 = star.get_light_curve(orbit=xo.KeplerianOrbit(**L2), r=r2, t=t, total=True, sparse=True)
     lc3 = sec.get_light_curve(orbit=xo.KeplerianOrbit(**L), r=r, t=t, total=True, sparse=True)
+    assert isinstance(lc2, xo.ops.MergedSparseLightCurve) and isinstance(lc3, xo.ops.MergedSparseLightCurve)
+    assert torch.equal(lc2.dense(), star.get_light_curve(orbit=xo.KeplerianOrbit(**L2), r=r2, t=t, total=True))
+    xo.ops._MULTI_LIST_MEAN[0] = False
+    try:
+        lc2 = star.get_light_curve(orbit=xo.KeplerianOrbit(**L2), r=r2, t=t, total=True, sparse=True)
+        lc3 = sec.get_light_curve(orbit=xo.KeplerianOrbit(**L), r=r, t=t, total=True, sparse=True)
+    finally:
+        xo.ops._MULTI_LIST_MEAN[0] = True
+    assert torch.is_tensor(lc2) and xo.ops.is_cadence_major(lc2)
     assert torch.is_tensor(lc3) and xo.ops.is_cadence_major(lc3)
+    # arithmetic on a sparse light curve gives the ordinary tensor
+    assert torch.equal(1.0 + sp, 1.0 + want) and torch.equal(sp * 2.0, want * 2.0) and torch.equal(-sp, -want)
 
 
 def test_sparse_step_replayed_as_a_hip_graph(dev):
