@@ -302,7 +302,7 @@ C5_LD = ((0.3, 0.2), (0.4, 0.1))
 C5_YERR = 3e-4
 
 
-def workload_c5(xo, ops, dev, D, rank=0, bright=0, bright_factor=1e3, kernel="sho3"):
+def workload_c5(xo, ops, dev, D, rank=0, bright=0, bright_factor=1e3, kernel="sho3", mean_sparse=False):
     """BASELINE configs[4] (C5): 65 000 long cadences, exposure stencil x 7, secondary eclipse, three SHO terms (J = 6);
     D = this rank's share of the 1024 chains (128 on each of 8 GPUs).  bright (extras only): that many chains with the first
     term's amplitude at 1000 x the error bars -- a conditioning score of 1e6, above the 3e4 of the scan trees: those chains
@@ -331,9 +331,13 @@ def workload_c5(xo, ops, dev, D, rank=0, bright=0, bright_factor=1e3, kernel="sh
     def fn(*vals):
         Lv = dict(zip(names, vals))
         orbit = xo.KeplerianOrbit(period=Lv["period"], t0=Lv["t0"], b=Lv["b"], ecc=Lv["ecc"], omega=Lv["omega"])
+        # the mean: the dense cadence-major array.  The merged sparse model (round 6: transit + occultation lists merged on
+        # the device, ops.MergedSparseLightCurve) is the SLOWER route at this shape -- 2.05 against 1.87 ms, same box: over 1327
+        # days the draws' 490 transits and occultations drift apart by half a period, so a wave of 64 chains is inside somebody's
+        # segment nearly everywhere and pays the segment cursor for nothing -- `mean_sparse=True` (extras leg) keeps it on record
         lc = xo.SecondaryEclipseLightCurve(C5_LD[0], C5_LD[1], Lv["sbr"]).get_light_curve(
             orbit=orbit, r=Lv["r"], t=t, texp=texp, oversample=7, total=True, cadence_major=GP_MEAN_CADENCE_MAJOR,
-            sparse=GP_MEAN_SPARSE)
+            sparse=mean_sparse and GP_MEAN_SPARSE)
         if kernel == "rot2_sho":
             kern = (T.RotationTerm(sigma=Lv["s1"], period=9.0 * ones, Q0=1.5 * ones, dQ=0.4 * ones, f=0.6 * ones)
                     + T.RotationTerm(sigma=Lv["s2"], period=23.0 * ones, Q0=2.5 * ones, dQ=0.7 * ones, f=0.3 * ones)
@@ -1382,6 +1386,9 @@ def main():
         leg("c5_shape_J10_two_rotation_terms_plus_sho", lambda: c5_variant(
             "the C5 step at 128 chains with a J = 10 kernel (two RotationTerms + one SHO term): per unit of J^2 against the clean "
             "J = 6 step = over_clean x 36 / 100", kernel="rot2_sho"))
+        leg("c5_128_chains_merged_sparse_mean", lambda: c5_variant(
+            "the C5 step at 128 chains with the light curve as a MERGED sparse mean (transit + occultation lists merged on the device, "
+            "round 6) instead of the dense cadence-major array", mean_sparse=True))
         leg("c5_128_chains_1pct_kappa_1e9", lambda: c5_variant(
             "the C5 step at 128 chains with 2 of them (1 %) at a conditioning score of 1e9 (first SHO term 31 600 x the error bars): "
             "beyond the robust route's reach -- those chains are redone by the sequential kernels", bright=2, bright_factor=10 ** 4.5))
@@ -1418,6 +1425,7 @@ def main():
             "c5_128": pick("c5_secondary_eclipse_3term_gp_128_chains"), "c5b": pick("c5_128_chains_1pct_bright_star_kappa_1e6"),
             "sparse": pick("c2_sparse_output"), "chi2": pick("c2_white_noise_likelihood"),
             "c5_j10": pick("c5_shape_J10_two_rotation_terms_plus_sho"), "c5_kappa1e9": pick("c5_128_chains_1pct_kappa_1e9"),
+            "c5_sparse_mean": pick("c5_128_chains_merged_sparse_mean"),
             "hmc": pick("hmc_trajectory_c2"), "nuts_leaf": pick("nuts_transition_c2", "ms_per_leaf"),
             "c2_one_call": pick("c2_one_call"),
             # the reference's standalone Ops at n = 1.5e8 (GB/s of their algorithmic bytes: 32 / 40 / 88 B per element)

@@ -79,12 +79,17 @@ def test_fused_light_delay_gradients_vs_composed_path(dev):
 def test_fused_light_delay_gradients_vs_oracle_central_differences(dev):
     """the reverse sweep through the delay against the ORACLE: L(theta) = sum(g * flux(theta)) with the
     flux from oracle/numpy_port.py's restatement of keplerian.py:411-470, differentiated by Richardson-extrapolated central
-    differences in every parameter; the fused kernel's gradient must agree to 2e-6 (what the differences themselves hold)"""
+    differences in every parameter.  For the differences to MEAN something L has to be smooth in the time-like parameters: the
+    flux has square-root kinks at the contacts, and on a coarse grid with a random cotangent a shift of the transit by h moves
+    cadences across them (differences of `period` then disagree with each other at 1e-2).  So two transits are sampled densely
+    (1.7 s cadence) with a smooth cotangent -- the sum is a quadrature of a smooth integral, differences at h and h / 2 agree to
+    <= 2e-6 (checked on the CPU: t0 the worst) -- and the fused kernel's gradient must agree with them to 5e-6."""
     import exoplanet_amd as xo
 
-    rng = np.random.default_rng(43)
-    t = np.linspace(0.0, 14.0, 9_001)
-    g = rng.normal(size=(9_001, 1))
+    tc = PARAMS["t0"]
+    t = np.concatenate([np.linspace(tc - 0.2, tc + 0.2, 20_001), np.linspace(tc + 2 * PARAMS["period"] - 0.2,
+                                                                            tc + 2 * PARAMS["period"] + 0.2, 20_001)])
+    g = (np.cos(30.0 * t) + 0.5)[:, None]
     base = dict(PARAMS, r=0.11, u1=0.3, u2=0.2)
 
     def L_oracle(th):
@@ -101,12 +106,13 @@ def test_fused_light_delay_gradients_vs_oracle_central_differences(dev):
     orbit = xo.KeplerianOrbit(**{k: leaves[k] for k in PARAMS})
     f = xo.LimbDarkLightCurve(leaves["u1"], leaves["u2"]).get_light_curve(orbit=orbit, r=leaves["r"], t=T(t, dev), light_delay=True)
     (f * T(g, dev)).sum().backward()
-    assert abs(float((f.detach().cpu().numpy() * g).sum()) - L_oracle(base)) <= 1e-10 * abs(L_oracle(base)) + 1e-12
+    L0 = L_oracle(base)
+    assert abs(L0) > 10.0 and abs(float((f.detach().cpu().numpy() * g).sum()) - L0) <= 1e-10 * abs(L0)
     for k, v in base.items():
-        h = 2e-5 * max(abs(v), 0.1)
+        h = 2e-5 * max(abs(v), 0.1)       # (at 1e-4 the differences in ecc / m_star disagree with themselves at 7e-6)
         fd = (4.0 * dL(k, h) - dL(k, 2 * h)) / 3.0          # O(h^4)
         got = float(leaves[k].grad)
-        assert abs(got - fd) <= 2e-6 * abs(fd) + 1e-9, (k, got, fd)
+        assert abs(got - fd) <= 5e-6 * abs(fd) + 1e-8, (k, got, fd)
 
 
 def test_fused_light_delay_secondary_eclipse_batch(dev):
