@@ -12,6 +12,10 @@
 // per input and one 16-byte store per output, the two solves interleaved by the scheduler (independent chains: the solve is a
 // fixed-cost sequence without votes), the next pair's loads issued before this pair's arithmetic.  Unaligned pointers or an
 // odd count: the scalar kernel takes them (heads, tails; whole arrays when a pointer is only 8-byte aligned).
+// MEASURED (round 6, n = 1.5e8): 3.17 (round 5: one 8-byte access per lane) -> 3.6-3.8 TB/s.  The memory side is not what
+// holds it: the circular branch (e = 0: one sincos) runs the same loads and stores at 4.6-5.5 TB/s, which is what a plain
+// copy of two arrays in and two out reaches on the same box (4.7-5.2 TB/s: tools/ops_bench.py); the eccentric solve is ~170
+// vector instructions + 13 quarter-rate ones per element = ~0.8 ms of fp64 issue at the nominal clock against 1.3 measured.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -24,7 +28,7 @@ namespace {
 
 constexpr int kBlock = 256;
 #ifndef EXO_KEPLER_BLOCKS_PER_CU
-#define EXO_KEPLER_BLOCKS_PER_CU 8
+#define EXO_KEPLER_BLOCKS_PER_CU 16     // (4 / 8 / 16 blocks per CU: 3.43 / 3.57 / 3.70 TB/s at n = 1.5e8)
 #endif
 
 typedef double d2 __attribute__((ext_vector_type(2)));   // a 16-byte access
@@ -52,7 +56,9 @@ __device__ __forceinline__ SinCosF kepler_one(double M, double e) {
   return o;
 }
 
-#ifdef EXO_KEPLER_PLAIN_ACCESS
+// 16-byte accesses: PLAIN.  Non-temporal ones (EXO_OPS_NONTEMPORAL) measured no faster for the Kepler kernel (3.55 against 3.57
+// TB/s) and much slower for quad_solution_vector on out-of-transit input, the streaming case: 2.57 against 4.19 TB/s.
+#ifndef EXO_OPS_NONTEMPORAL
 #define EXO_LOAD16(p) (*(p))
 #define EXO_STORE16(v, p) (*(p) = (v))
 #else
