@@ -338,7 +338,10 @@ def workload_c5(xo, ops, dev, D, rank=0, bright=0, bright_factor=1e3, kernel="sh
         lc = xo.SecondaryEclipseLightCurve(C5_LD[0], C5_LD[1], Lv["sbr"]).get_light_curve(
             orbit=orbit, r=Lv["r"], t=t, texp=texp, oversample=7, total=True, cadence_major=GP_MEAN_CADENCE_MAJOR,
             sparse=mean_sparse and GP_MEAN_SPARSE)
-        if kernel == "rot2_sho":
+        if kernel == "sho4":         # (J = 8: the lane-group time-parallel path, for scale)
+            kern = (T.SHOTerm(sigma=Lv["s1"], rho=fixed[0][0], Q=fixed[0][1]) + T.SHOTerm(sigma=Lv["s2"], rho=fixed[1][0], Q=fixed[1][1])
+                    + T.SHOTerm(sigma=Lv["s3"], rho=fixed[2][0], Q=fixed[2][1]) + T.SHOTerm(sigma=0.5 * Lv["s3"], rho=0.7 * ones, Q=3.0 * ones))
+        elif kernel == "rot2_sho":
             kern = (T.RotationTerm(sigma=Lv["s1"], period=9.0 * ones, Q0=1.5 * ones, dQ=0.4 * ones, f=0.6 * ones)
                     + T.RotationTerm(sigma=Lv["s2"], period=23.0 * ones, Q0=2.5 * ones, dQ=0.7 * ones, f=0.3 * ones)
                     + T.SHOTerm(sigma=Lv["s3"], rho=fixed[2][0], Q=fixed[2][1]))
@@ -946,7 +949,8 @@ def compact_line(out):
     r = out.get("roofline")
     if r:
         rr = {k: _short(_num(r.get(k)), 120) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_source",
-                                                       "algorithmic_bytes_per_launch", "kernel_ms", "frac_step")}
+                                                       "algorithmic_bytes_per_launch", "active_cadences_per_launch", "kernel_ms", "frac_step")
+              if k in r}
         pmc = r.get("pmc") or {}
         if pmc:
             rr["pmc_kernel_GBps"] = _num(pmc.get("dominant_kernel_GBps"))
@@ -1383,6 +1387,9 @@ def main():
         # the cliff remnants as NUMBERS: a state wider than the one-lane time-parallel kernels, and a
         # conditioning score beyond the robust route -- both fall to the sequential kernels (all draws of the call for J = 10;
         # the flagged chains only for kappa = 1e9)
+        leg("c5_shape_J8_four_sho_terms", lambda: c5_variant(
+            "the C5 step at 128 chains with a J = 8 kernel (four SHO terms): the lane-group time-parallel path (a draw on eight lanes)",
+            kernel="sho4"))
         leg("c5_shape_J10_two_rotation_terms_plus_sho", lambda: c5_variant(
             "the C5 step at 128 chains with a J = 10 kernel (two RotationTerms + one SHO term): per unit of J^2 against the clean "
             "J = 6 step = over_clean x 36 / 100", kernel="rot2_sho"))
@@ -1424,7 +1431,7 @@ def main():
             "c3": pick("c3_light_curve_plus_sho_gp"), "c4_64": pick("c4_four_planets_64_draws"),
             "c5_128": pick("c5_secondary_eclipse_3term_gp_128_chains"), "c5b": pick("c5_128_chains_1pct_bright_star_kappa_1e6"),
             "sparse": pick("c2_sparse_output"), "chi2": pick("c2_white_noise_likelihood"),
-            "c5_j10": pick("c5_shape_J10_two_rotation_terms_plus_sho"), "c5_kappa1e9": pick("c5_128_chains_1pct_kappa_1e9"),
+            "c5_j8": pick("c5_shape_J8_four_sho_terms"), "c5_j10": pick("c5_shape_J10_two_rotation_terms_plus_sho"), "c5_kappa1e9": pick("c5_128_chains_1pct_kappa_1e9"),
             "c5_sparse_mean": pick("c5_128_chains_merged_sparse_mean"),
             "hmc": pick("hmc_trajectory_c2"), "nuts_leaf": pick("nuts_transition_c2", "ms_per_leaf"),
             "c2_one_call": pick("c2_one_call"),

@@ -753,6 +753,7 @@ __global__ __launch_bounds__(kWave) void celerite_elem_lg_kernel(
   if (G >= 2) ba2 = fmax(ba2, xor_get<1>(ba2));
   if (G >= 4) ba2 = fmax(ba2, xor_get<2>(ba2));
   if (G >= 8) ba2 = fmax(ba2, xor_get<4>(ba2));
+  if (G >= 16) ba2 = fmax(ba2, xor_get<8>(ba2));
   const double rmin = (1.0 + ba2) * asum * (1.0 / EXO_GP_COND_MAX);
   bool ok = true;
 
@@ -970,7 +971,7 @@ __global__ __launch_bounds__(kWave) void celerite_chunk_vjp_kernel(
     }
   };
   double dt_prev = -1.0, Pcache = 1.0;
-  constexpr int kPer = 8 / G;
+  constexpr int kPer = G >= 8 ? 1 : 8 / G;   // (G = 16: lanes 0 .. 7 of the row keep one cadence each)
   double buf_r[kPer], buf_d[kPer];
   unsigned have = 0u;
 #pragma unroll
@@ -1247,6 +1248,219 @@ __global__ __launch_bounds__(kWave) void celerite_tree_kernel(TreeOp op, double*
   if (item >= (int64_t)op.n_item * op.n_draw) return;
   const int c = (int)(item / op.n_draw);
   tree_item_lane<J, ADJ, DOWN>(op, state, c, item - (int64_t)c * op.n_draw);
+}
+
+// WIDE STATES (J = 9 .. 16, round 6): an item of a scan level on a BLOCK of 256 threads, thread (j, l) owning entry (j, l) of every
+// J x J matrix, the matrices in LDS padded to 16 x 16.  One lane per item (celerite_tree_kernel) holds an element's 3 J^2 + 2 J
+// doubles -- 320 at J = 10, 800 at J = 16 -- in scratch and walks J^3 products through it: 0.4-1.4 ms per level at 128 chains x 128
+// chunks, 21 of the 33 ms of a C5-shaped step at J = 10.  Same algebra as tree_compose / tree_apply (exo_celerite_core.hpp), the
+// sums in the same order (k ascending); the solve is Gauss-Jordan with partial pivoting on [X | right-hand sides] in place (the
+// one-lane code eliminates forward and substitutes back: the same pivots, other roundings at the 1e-16 level).  J is a RUN-TIME
+// value here (op.J): one instantiation per (ADJ, DOWN) serves every width.
+#ifndef EXO_GP_WIDE_LDS
+#define EXO_GP_WIDE_LDS 1     // (0: the one-lane tree kernel for wide states too -- A/B)
+#endif
+struct WideLds {
+  double m[14][256];
+  double v[10][16];
+  int piv;
+};
+template <bool ADJ, bool DOWN>
+__global__ __launch_bounds__(256) void celerite_tree_wide_kernel(TreeOp op, double* __restrict__ state) {
+  __shared__ WideLds S;
+  const int tid = threadIdx.x, j = tid >> 4, l = tid & 15;
+  const int J = op.J;
+  const int64_t nd = op.n_draw;
+  const int64_t item = blockIdx.x;                      // (index, draw), draws fastest
+  const int c = (int)(item / nd);
+  const int64_t draw = item - (int64_t)c * nd;
+  const bool in = j < J && l < J;
+  const int E = 3 * J * J + 2 * J, Bq = J + J * J;
+  const int oA = 0, ob = J * J, oC = J * J + J, oeta = 2 * J * J + J, oJ = 2 * J * J + 2 * J;
+  auto src = [&](int pos, int e) -> double {
+    const int idx = op.src_rev ? op.src_len - 1 - pos : pos;
+    return state[op.src_elem + ((int64_t)idx * E + e) * nd + draw];
+  };
+  // element `pos` into matrices (a, cm, jm) and vectors (b, eta); the identity past the end
+  auto load_elem = [&](int pos, int a, int cm, int jm, int b, int eta) {
+    const bool has = pos >= 0 && pos < op.src_n;
+    S.m[a][tid] = in ? (has ? src(pos, oA + j * J + l) : (j == l ? 1.0 : 0.0)) : 0.0;
+    S.m[cm][tid] = (in && has) ? src(pos, oC + j * J + l) : 0.0;
+    S.m[jm][tid] = (in && has) ? src(pos, oJ + j * J + l) : 0.0;
+    if (l == 0) {
+      S.v[b][j] = (j < J && has) ? src(pos, ob + j) : 0.0;
+      S.v[eta][j] = (j < J && has) ? src(pos, oeta + j) : 0.0;
+    }
+  };
+  // sum_k op(X)[j][k] op(Y)[k][l], k ascending from `init`
+  auto mm = [&](double init, int X, bool tx, int Y, bool ty) -> double {
+    double acc = init;
+    for (int k = 0; k < J; ++k)
+      acc = fma(tx ? S.m[X][k * 16 + j] : S.m[X][j * 16 + k], ty ? S.m[Y][l * 16 + k] : S.m[Y][k * 16 + l], acc);
+    return acc;
+  };
+  // (op(X) v)_j from `init`, computed by every thread of row j
+  auto mv = [&](double init, int X, bool tx, int V) -> double {
+    double acc = init;
+    for (int k = 0; k < J; ++k) acc = fma(tx ? S.m[X][k * 16 + j] : S.m[X][j * 16 + k], S.v[V][k], acc);
+    return acc;
+  };
+  // Gauss-Jordan with partial pivoting: X (matrix slot) against right-hand sides R1, R3 (matrix slots; R3 < 0: none) and r (vector
+  // slot); on exit the right-hand sides hold the solutions.  Every thread of the block calls it.
+  auto solve = [&](int X, int R1, int R3, int r) {
+    for (int k = 0; k < J; ++k) {
+      if (tid == 0) {
+        int p = k;
+        double best = fabs(S.m[X][k * 16 + k]);
+        for (int i = k + 1; i < J; ++i) {
+          const double a = fabs(S.m[X][i * 16 + k]);
+          if (a > best) { best = a; p = i; }
+        }
+        S.piv = p;
+      }
+      __syncthreads();
+      const int p = S.piv;
+      if (p != k && j == k && l < J) {          // row k's sixteen threads swap rows k and p
+        double tmp = S.m[X][k * 16 + l]; S.m[X][k * 16 + l] = S.m[X][p * 16 + l]; S.m[X][p * 16 + l] = tmp;
+        tmp = S.m[R1][k * 16 + l]; S.m[R1][k * 16 + l] = S.m[R1][p * 16 + l]; S.m[R1][p * 16 + l] = tmp;
+        if (R3 >= 0) { tmp = S.m[R3][k * 16 + l]; S.m[R3][k * 16 + l] = S.m[R3][p * 16 + l]; S.m[R3][p * 16 + l] = tmp; }
+        if (l == 0) { tmp = S.v[r][k]; S.v[r][k] = S.v[r][p]; S.v[r][p] = tmp; }
+      }
+      __syncthreads();
+      const double f = (in && j != k) ? S.m[X][j * 16 + k] / S.m[X][k * 16 + k] : 0.0;
+      const double xk = in ? S.m[X][k * 16 + l] : 0.0, r1k = in ? S.m[R1][k * 16 + l] : 0.0;
+      const double r3k = (in && R3 >= 0) ? S.m[R3][k * 16 + l] : 0.0, rk = S.v[r][k];
+      __syncthreads();
+      if (in && j != k) {
+        S.m[X][tid] = fma(-f, xk, S.m[X][tid]);
+        S.m[R1][tid] = fma(-f, r1k, S.m[R1][tid]);
+        if (R3 >= 0) S.m[R3][tid] = fma(-f, r3k, S.m[R3][tid]);
+        if (l == 0) S.v[r][j] = fma(-f, rk, S.v[r][j]);
+      }
+      __syncthreads();
+    }
+    if (in) {
+      const double ip = 1.0 / S.m[X][j * 16 + j];
+      S.m[R1][tid] *= ip;
+      if (R3 >= 0) S.m[R3][tid] *= ip;
+      if (l == 0) S.v[r][j] *= ip;
+    }
+    __syncthreads();
+  };
+  enum { A1 = 0, C1, J1, A2, C2, J2, MM, R1, R3, T1, T2, T3, T4, T5 };
+  enum { B1 = 0, E1, B2, E2, RR, VW, VN, VX };
+  if (DOWN) {
+    // ---- child states 2c, 2c + 1 from parent state c and child element 2c
+    const double mj = (l == 0 && j < J) ? state[op.par_state + ((int64_t)c * Bq + j) * nd + draw] : 0.0;
+    const double pjl = in ? state[op.par_state + ((int64_t)c * Bq + J + j * J + l) * nd + draw] : 0.0;
+    auto put = [&](int pos, double mval, double pval) {
+      const int idx = op.dst_rev ? op.dst_len - 1 - pos : pos;
+      double* __restrict__ q = state + op.dst_state + ((int64_t)idx * Bq) * nd + draw;
+      if (l == 0 && j < J) q[(int64_t)j * nd] = mval;
+      if (in) q[(int64_t)(J + j * J + l) * nd] = op.psign * pval;
+    };
+    put(2 * c, mj, pjl);
+    if (2 * c + 1 >= op.dst_n) return;               // (uniform over the block)
+    load_elem(2 * c, A1, C1, J1, B1, E1);
+    S.m[T1][tid] = pjl;                               // P
+    if (l == 0) S.v[VW][j] = mj;                      // m
+    __syncthreads();
+    if (ADJ) {
+      // x = A^T m ;  T = P A ;  m2 = eta + x ;  P2 = Cm + A^T T + sym(x b^T)
+      const double xj = mv(0.0, A1, true, VW);
+      const double tv = mm(0.0, T1, false, A1, false);
+      if (l == 0) S.v[VX][j] = xj;
+      S.m[T2][tid] = tv;
+      __syncthreads();
+      const double cong = mm(S.m[C1][tid], A1, true, T2, false);
+      const double p2 = in ? cong + 0.5 * (S.v[VX][j] * S.v[B1][l] + S.v[B1][j] * S.v[VX][l]) : 0.0;
+      S.m[T3][tid] = p2;
+      __syncthreads();
+      put(2 * c + 1, S.v[E1][j] + S.v[VX][j], 0.5 * (S.m[T3][j * 16 + l] + S.m[T3][l * 16 + j]));
+    } else {
+      // X = I + P Jm ;  solve X [YP | ym] = [P | m + P eta] ;  m2 = b + A ym ;  P2 = Cm + (A YP) A^T
+      const double xv = mm((j == l && in) ? 1.0 : 0.0, T1, false, J1, false);
+      const double pe = mv(S.v[VW][j], T1, false, E1);
+      S.m[MM][tid] = in ? xv : 0.0;
+      S.m[R1][tid] = pjl;
+      if (l == 0) S.v[RR][j] = (j < J) ? pe : 0.0;
+      __syncthreads();
+      solve(MM, R1, -1, RR);
+      const double m2 = mv(S.v[B1][j], A1, false, RR);
+      const double ay = mm(0.0, A1, false, R1, false);
+      S.m[T2][tid] = ay;
+      __syncthreads();
+      S.m[T3][tid] = mm(S.m[C1][tid], T2, false, A1, true);
+      __syncthreads();
+      put(2 * c + 1, m2, 0.5 * (S.m[T3][j * 16 + l] + S.m[T3][l * 16 + j]));
+    }
+    return;
+  }
+  // ---- UP: dst element c = src elements 2c, 2c + 1 composed (2c acts first)
+  load_elem(2 * c, A1, C1, J1, B1, E1);
+  load_elem(2 * c + 1, A2, C2, J2, B2, E2);
+  __syncthreads();
+  double* __restrict__ dstp = state + op.dst_elem + ((int64_t)c * E) * nd + draw;
+  auto dst = [&](int e, double val) { dstp[(int64_t)e * nd] = val; };
+  if (ADJ) {
+    // Abar = Abar1 Abar2 ;  g = g2 + Abar2^T g1 ;  lF = lF2 + Abar2^T lF1 ;  lP = lP2 + Abar2^T lP1 Abar2 + sym(Abar2^T lF1 g2^T)
+    const double gj = mv(S.v[B2][j], A2, true, B1);
+    const double vj = mv(0.0, A2, true, E1);
+    const double a = mm(0.0, A1, false, A2, false);
+    S.m[T1][tid] = mm(0.0, C1, false, A2, false);        // T = lP1 Abar2
+    if (l == 0) S.v[VX][j] = vj;
+    __syncthreads();
+    const double cv = mm(in ? S.m[C2][tid] + 0.5 * (S.v[VX][j] * S.v[B2][l] + S.v[B2][j] * S.v[VX][l]) : 0.0, A2, true, T1, false);
+    S.m[T2][tid] = cv;
+    __syncthreads();
+    if (in) {
+      dst(oA + j * J + l, a);
+      dst(oC + j * J + l, 0.5 * (S.m[T2][j * 16 + l] + S.m[T2][l * 16 + j]));
+      dst(oJ + j * J + l, 0.0);
+    }
+    if (l == 0 && j < J) { dst(ob + j, gj); dst(oeta + j, S.v[E2][j] + vj); }
+    return;
+  }
+  // filtering elements:  M = I + C1 J2 ;  solve M [X1 | X3 | x2] = [A1 | C1 | b1 + C1 eta2]
+  {
+    const double mval = mm((j == l && in) ? 1.0 : 0.0, C1, false, J2, false);
+    const double r2 = mv(S.v[B1][j], C1, false, E2);
+    S.m[MM][tid] = in ? mval : 0.0;
+    S.m[R1][tid] = S.m[A1][tid];
+    S.m[R3][tid] = S.m[C1][tid];
+    if (l == 0) S.v[RR][j] = (j < J) ? r2 : 0.0;
+    __syncthreads();
+  }
+  solve(MM, R1, R3, RR);                               // R1 = X1, R3 = X3, RR = x2
+  {
+    const double bj = mv(S.v[B2][j], A2, false, RR);                   // b = b2 + A2 x2
+    const double wj = -mv(-S.v[E2][j], J2, false, B1);                 // w = eta2 - J2 b1  (same order: eta2, then -J2 b1 terms)
+    const double a = mm(0.0, A2, false, R1, false);                    // A = A2 X1
+    const double ax = mm(0.0, A2, false, R3, false);                   // A2 X3
+    const double nv = -mm((j == l && in) ? -1.0 : 0.0, J2, false, R3, false);   // N = I - J2 X3
+    S.m[T1][tid] = ax;
+    S.m[T2][tid] = in ? nv : 0.0;
+    if (l == 0) { S.v[VW][j] = wj; S.v[VN][j] = bj; }
+    __syncthreads();
+    const double nw = mv(0.0, T2, false, VW);                           // N w
+    S.m[T3][tid] = mm(0.0, T2, false, J2, false);                       // N J2
+    if (l == 0) S.v[VX][j] = nw;
+    __syncthreads();
+    S.m[T4][tid] = mm(0.0, T3, false, A1, false);                       // N J2 A1
+    __syncthreads();
+    const double ej = mv(S.v[E1][j], A1, true, VX);                     // eta = eta1 + A1^T N w
+    const double cv = mm(S.m[C2][tid], T1, false, A2, true);            // C = C2 + (A2 X3) A2^T
+    const double jv = mm(S.m[J1][tid], A1, true, T4, false);            // J = J1 + A1^T (N J2 A1)
+    S.m[T5][tid] = cv;
+    S.m[MM][tid] = jv;
+    __syncthreads();
+    if (in) {
+      dst(oA + j * J + l, a);
+      dst(oC + j * J + l, 0.5 * (S.m[T5][j * 16 + l] + S.m[T5][l * 16 + j]));
+      dst(oJ + j * J + l, 0.5 * (S.m[MM][j * 16 + l] + S.m[MM][l * 16 + j]));
+    }
+    if (l == 0 && j < J) { dst(ob + j, S.v[VN][j]); dst(oeta + j, ej); }
+  }
 }
 
 // two levels of a scan in one launch, one lane per item of the upper one (tree_item4_*_lane; J <= 2)
@@ -1831,6 +2045,14 @@ int32_t exo_celerite_default_chunks(int64_t n, int64_t n_draw, int32_t n_real, i
     case 6: { constexpr int JJ = 6; CALL; } break; \
     case 7: { constexpr int JJ = 7; CALL; } break; \
     case 8: { constexpr int JJ = 8; CALL; } break; \
+    case 9: { constexpr int JJ = 9; CALL; } break; \
+    case 10: { constexpr int JJ = 10; CALL; } break; \
+    case 11: { constexpr int JJ = 11; CALL; } break; \
+    case 12: { constexpr int JJ = 12; CALL; } break; \
+    case 13: { constexpr int JJ = 13; CALL; } break; \
+    case 14: { constexpr int JJ = 14; CALL; } break; \
+    case 15: { constexpr int JJ = 15; CALL; } break; \
+    case 16: { constexpr int JJ = 16; CALL; } break; \
     default: break;                                \
   }
 #define EXO_GP_DISPATCH_GROUP(J_, CALL) \
@@ -1872,6 +2094,14 @@ static_assert(kLaneMaxJ <= 6, "EXO_GP_DISPATCH_LANE lists the state widths of th
     case 6: { constexpr int JJ = 6; CALL; } break; \
     case 7: { constexpr int JJ = 7; CALL; } break; \
     case 8: { constexpr int JJ = 8; CALL; } break; \
+    case 9: { constexpr int JJ = 9; CALL; } break; \
+    case 10: { constexpr int JJ = 10; CALL; } break; \
+    case 11: { constexpr int JJ = 11; CALL; } break; \
+    case 12: { constexpr int JJ = 12; CALL; } break; \
+    case 13: { constexpr int JJ = 13; CALL; } break; \
+    case 14: { constexpr int JJ = 14; CALL; } break; \
+    case 15: { constexpr int JJ = 15; CALL; } break; \
+    case 16: { constexpr int JJ = 16; CALL; } break; \
     default: return EXO_ERR_INVALID_ARGUMENT;      \
   }
 // the SEQUENTIAL kernels (and the O(N) utilities) take state widths up to EXO_GP_MAX_J = 16 (a draw on a DPP row of 16 lanes
@@ -2125,15 +2355,19 @@ static int celerite_fwd(const double* t, Series resid, const double* diag, int64
         auto launch = [&](const TreeOp& op, bool down) {
                     const dim3 tgrid((unsigned)(((int64_t)op.n_item * n_draw + kWave - 1) / kWave));
                     const dim3 ggrid((unsigned)(((int64_t)op.n_item * n_draw + kScanBlock / 8 - 1) / (kScanBlock / 8)));
-                    if (EXO_GP_GROUP_TREES && J >= 3) {
+                    if (EXO_GP_GROUP_TREES && J >= 3 && J <= 8) {
                       if (down) {
                         EXO_GP_DISPATCH_GROUP(J, hipLaunchKernelGGL((celerite_tree_group_kernel<JJ, false, true>), ggrid, dim3(kScanBlock), 0, st, op, state))
                       } else {
                         EXO_GP_DISPATCH_GROUP(J, hipLaunchKernelGGL((celerite_tree_group_kernel<JJ, false, false>), ggrid, dim3(kScanBlock), 0, st, op, state))
                       }
+                    } else if (EXO_GP_WIDE_LDS && J >= kWideMinJ) {   // a block per item, matrices in LDS (celerite_tree_wide_kernel)
+                      const dim3 wgrid((unsigned)((int64_t)op.n_item * n_draw));
+                      if (down) hipLaunchKernelGGL((celerite_tree_wide_kernel<false, true>), wgrid, dim3(256), 0, st, op, state);
+                      else hipLaunchKernelGGL((celerite_tree_wide_kernel<false, false>), wgrid, dim3(256), 0, st, op, state);
                     } else if (down) {
                       EXO_GP_DISPATCH_VOID(J, hipLaunchKernelGGL((celerite_tree_kernel<JJ, false, true>), tgrid, block, 0, st, op, state))
-                    } else if (J >= 3) {
+                    } else if (J >= 3 && J <= 8) {
                       // composing two filtering elements keeps ~5 J x J matrices alive around the solve: one lane per
                       // item spills 2 KB at J = 6 and crawls (76 us per level); a wave per item with the tiles in LDS
                       hipLaunchKernelGGL(celerite_compose_lds_kernel, dim3((unsigned)(op.n_item * n_draw)), block, 0,
@@ -2246,12 +2480,16 @@ static int celerite_vjp(const double* t, Series resid, const double* diag, int64
       auto launch = [&](const TreeOp& op, bool down) {
                   const dim3 tgrid((unsigned)(((int64_t)op.n_item * n_draw + kWave - 1) / kWave));
                   const dim3 ggrid((unsigned)(((int64_t)op.n_item * n_draw + kScanBlock / 8 - 1) / (kScanBlock / 8)));
-                  if (EXO_GP_GROUP_TREES && J >= 3) {
+                  if (EXO_GP_GROUP_TREES && J >= 3 && J <= 8) {
                     if (down) {
                       EXO_GP_DISPATCH_GROUP(J, hipLaunchKernelGGL((celerite_tree_group_kernel<JJ, true, true>), ggrid, dim3(kScanBlock), 0, st, op, wstate))
                     } else {
                       EXO_GP_DISPATCH_GROUP(J, hipLaunchKernelGGL((celerite_tree_group_kernel<JJ, true, false>), ggrid, dim3(kScanBlock), 0, st, op, wstate))
                     }
+                  } else if (EXO_GP_WIDE_LDS && J >= kWideMinJ) {
+                    const dim3 wgrid((unsigned)((int64_t)op.n_item * n_draw));
+                    if (down) hipLaunchKernelGGL((celerite_tree_wide_kernel<true, true>), wgrid, dim3(256), 0, st, op, wstate);
+                    else hipLaunchKernelGGL((celerite_tree_wide_kernel<true, false>), wgrid, dim3(256), 0, st, op, wstate);
                   } else if (down) {
                     EXO_GP_DISPATCH_VOID(J, hipLaunchKernelGGL((celerite_tree_kernel<JJ, true, true>), tgrid, block, 0, st, op, wstate))
                   } else {

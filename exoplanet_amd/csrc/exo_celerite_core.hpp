@@ -450,7 +450,12 @@ EXO_HD void load_block(const RowT& y, const double* EXO_RESTRICT dg, int64_t n_d
   }
 }
 
-constexpr int kChunkMaxJ = 8;   // the time-parallel path's widest state (J = 7, 8: lane-group element kernel, one-lane scan kernels spill); EXO_GP_MAX_J = 16 beyond it: sequential
+#ifndef EXO_CHUNK_MAX_J
+#define EXO_CHUNK_MAX_J 16
+#endif
+constexpr int kChunkMaxJ = EXO_CHUNK_MAX_J;   // the time-parallel path's widest state.  J = 7, 8: lane-group element / chunk kernels on eight lanes, scans on groups of eight
+                                            // lanes; J = 9 .. 16 (round 6): the same kernels on a DPP row of sixteen lanes, the scans one lane per item (kWideMinJ)
+constexpr int kWideMinJ = 9;
 // conditioning score above which a draw leaves the time-parallel path (elem_lane: how it was calibrated):
 // EXO_GP_COND_MAX_J2 for state widths J <= 2, EXO_GP_COND_MAX for wider states
 #ifndef EXO_GP_COND_MAX
@@ -518,7 +523,7 @@ EXO_HDH ChunkGeom chunk_plan(int64_t n, int64_t n_draw, int J, int32_t n_chunks)
     if (C > 512) C = 512;
     if (C < 4) C = 4;
   } else {
-    const int G = J <= 1 ? 1 : (J <= 2 ? 2 : (J <= 4 ? 4 : 8));
+    const int G = J <= 1 ? 1 : (J <= 2 ? 2 : (J <= 4 ? 4 : (J <= 8 ? 8 : 16)));
     // ~4 waves per SIMD offered to the lane-group chunk kernels (they fit 3): the scans over the chunks are
     // trees, so more chunks cost them little
     C = (64 * 4096) / (n_draw * G);
@@ -529,11 +534,11 @@ EXO_HDH ChunkGeom chunk_plan(int64_t n, int64_t n_draw, int J, int32_t n_chunks)
   if (C < 2) return g;
   g.L = (n + C - 1) / C;
   if (lane) g.L = (g.L + kCkptB - 1) / kCkptB * kCkptB;
-  else g.L = (g.L + (1 << kFineLevels) - 1) >> kFineLevels << kFineLevels;   // whole fine chunks
+  else if (J < kWideMinJ) g.L = (g.L + (1 << kFineLevels) - 1) >> kFineLevels << kFineLevels;   // whole fine chunks
   g.C = (int)((n + g.L - 1) / g.L);
   if (g.C < 2) { g.C = 1; g.L = n; return g; }
   g.lane = lane ? 1 : 0;
-  g.fine = lane ? 0 : kFineLevels;
+  g.fine = (lane || J >= kWideMinJ) ? 0 : kFineLevels;   // (the pairwise composition of fine elements is the 8 x 8 LDS kernel: J <= 8)
   g.tree = 1;   // the scans over the chunks as trees of compositions (one lane each)
   return g;
 }
@@ -984,6 +989,11 @@ EXO_HD void elem_lane(const double* EXO_RESTRICT t, Series rs, const double* EXO
 }
 
 // solve X Z = B (J x J, NB right-hand sides) in place by Gaussian elimination with partial pivoting
+// Loops of the scan-tree items (solve, compose, apply, load / store of an element): unrolled in full for J <= 8 -- the elements
+// live in registers, a run-time index would send them to scratch -- and ROLLED for the wide states J = 9 .. 16 (round 6), whose
+// 3 J^2 + 2 J doubles per element live in scratch whatever the loops do: unrolled, the 32 wide instantiations of the tree kernel
+// (a J^3 product each, several times) took the compiler more than a quarter of an hour; rolled, seconds.
+#define EXO_UNROLL_TREE _Pragma("unroll (J <= 8 ? 64 : 1)")
 template <int J, int NB>
 EXO_HD void solve_inplace(double (&X)[J][J], double (&B)[J][NB]) {
 #if defined(EXO_HOST_BUILD) && defined(EXO_SOLVE_LD)
@@ -1007,42 +1017,42 @@ EXO_HD void solve_inplace(double (&X)[J][J], double (&B)[J][NB]) {
     return;
   }
 #endif
-#pragma unroll
+EXO_UNROLL_TREE
   for (int k = 0; k < J; ++k) {
     int piv = k;
     double best = fabs(X[k][k]);
-#pragma unroll
+EXO_UNROLL_TREE
     for (int i = k + 1; i < J; ++i) {
       const bool better = fabs(X[i][k]) > best;
       best = better ? fabs(X[i][k]) : best;
       piv = better ? i : piv;
     }
-#pragma unroll
+EXO_UNROLL_TREE
     for (int i = k + 1; i < J; ++i) {
       if (i == piv) {   // swap rows k and i (selects: piv is a run-time value)
-#pragma unroll
+EXO_UNROLL_TREE
         for (int l = 0; l < J; ++l) { const double tmp = X[k][l]; X[k][l] = X[i][l]; X[i][l] = tmp; }
-#pragma unroll
+EXO_UNROLL_TREE
         for (int l = 0; l < NB; ++l) { const double tmp = B[k][l]; B[k][l] = B[i][l]; B[i][l] = tmp; }
       }
     }
     const double ip = 1.0 / X[k][k];
-#pragma unroll
+EXO_UNROLL_TREE
     for (int i = k + 1; i < J; ++i) {
       const double f = X[i][k] * ip;
-#pragma unroll
+EXO_UNROLL_TREE
       for (int l = k + 1; l < J; ++l) X[i][l] = fma(-f, X[k][l], X[i][l]);
-#pragma unroll
+EXO_UNROLL_TREE
       for (int l = 0; l < NB; ++l) B[i][l] = fma(-f, B[k][l], B[i][l]);
     }
   }
-#pragma unroll
+EXO_UNROLL_TREE
   for (int k = J - 1; k >= 0; --k) {
     const double ip = 1.0 / X[k][k];
-#pragma unroll
+EXO_UNROLL_TREE
     for (int l = 0; l < NB; ++l) {
       double v = B[k][l];
-#pragma unroll
+EXO_UNROLL_TREE
       for (int i = k + 1; i < J; ++i) v = fma(-X[k][i], B[i][l], v);
       B[k][l] = v * ip;
     }
@@ -1133,30 +1143,30 @@ EXO_HD void bscan_lane(const double* EXO_RESTRICT t, const Coefs& cf, int64_t n,
   DrawCoef<J> co;
   co.init(cf, draw);
   double m[J], P[J][J];
-#pragma unroll
+EXO_UNROLL_TREE
   for (int j = 0; j < J; ++j) {
     m[j] = 0.0;
-#pragma unroll
+EXO_UNROLL_TREE
     for (int l = 0; l < J; ++l) P[j][l] = 0.0;
   }
 #pragma unroll 1
   for (int c = 0; c < cg.C; ++c) {
     if (c == 0) {
       double U[J], V[J];
-#pragma unroll
+EXO_UNROLL_TREE
       for (int j = 0; j < J; ++j) U[j] = V[j] = 0.0;
       co.uv(t[0], U, V);
       Sym<J> Dl;
       dc.eval(V, Dl);
-#pragma unroll
+EXO_UNROLL_TREE
       for (int j = 0; j < J; ++j)
-#pragma unroll
+EXO_UNROLL_TREE
         for (int l = 0; l < J; ++l) P[j][l] = Dl(j, l);   // S_0 = 0
     }
-#pragma unroll
+EXO_UNROLL_TREE
     for (int j = 0; j < J; ++j) {
       state[ws.bnd(1, c, j, draw)] = m[j];
-#pragma unroll
+EXO_UNROLL_TREE
       for (int l = 0; l < J; ++l) state[ws.bnd(1, c, J + j * J + l, draw)] = P[j][l];
     }
     if (c + 1 == cg.C) break;
@@ -1178,48 +1188,48 @@ EXO_HD void badj_prep_lane(const double* EXO_RESTRICT gloglike, int64_t n, int64
   Elem<J> el;
   el.load(state, ws, c, draw);
   double m[J], P[J][J];
-#pragma unroll
+EXO_UNROLL_TREE
   for (int j = 0; j < J; ++j) {
     m[j] = state[ws.bnd(1, c, j, draw)];
-#pragma unroll
+EXO_UNROLL_TREE
     for (int l = 0; l < J; ++l) P[j][l] = state[ws.bnd(1, c, J + j * J + l, draw)];
   }
   double X[J][J], Y[J][J];
-#pragma unroll
+EXO_UNROLL_TREE
   for (int j = 0; j < J; ++j)
-#pragma unroll
+EXO_UNROLL_TREE
     for (int l = 0; l < J; ++l) {
       double x = (j == l) ? 1.0 : 0.0;
-#pragma unroll
+EXO_UNROLL_TREE
       for (int k = 0; k < J; ++k) x = fma(P[j][k], el.Jm[k][l], x);
       X[j][l] = x;
       Y[j][l] = (j == l) ? 1.0 : 0.0;
     }
   solve_inplace<J, J>(X, Y);
   double u[J], v[J], w[J], Yv[J];
-#pragma unroll
+EXO_UNROLL_TREE
   for (int j = 0; j < J; ++j) {
     double uj = el.eta[j], vj = m[j];
-#pragma unroll
+EXO_UNROLL_TREE
     for (int l = 0; l < J; ++l) { uj = fma(-el.Jm[j][l], m[l], uj); vj = fma(P[j][l], el.eta[l], vj); }
     u[j] = uj; v[j] = vj;
   }
-#pragma unroll
+EXO_UNROLL_TREE
   for (int j = 0; j < J; ++j) {
     double wj = 0.0, yv = 0.0;
-#pragma unroll
+EXO_UNROLL_TREE
     for (int l = 0; l < J; ++l) { wj = fma(Y[l][j], u[l], wj); yv = fma(Y[j][l], v[l], yv); }
     w[j] = wj; Yv[j] = yv;
   }
   const int oA = 0, ob = J * J, oC = J * J + J, oeta = 2 * J * J + J;
-#pragma unroll
+EXO_UNROLL_TREE
   for (int j = 0; j < J; ++j) {
     double gj = el.eta[j];
-#pragma unroll
+EXO_UNROLL_TREE
     for (int l = 0; l < J; ++l) {
       gj = fma(-el.Jm[j][l], Yv[l], gj);
       double a = 0.0, jy = 0.0, jyt = 0.0;
-#pragma unroll
+EXO_UNROLL_TREE
       for (int k = 0; k < J; ++k) {
         a = fma(el.A[j][k], Y[k][l], a);
         jy = fma(el.Jm[j][k], Y[k][l], jy);
@@ -1338,21 +1348,21 @@ EXO_HD void tree_load_elem(const double* EXO_RESTRICT state, const TreeOp& op, i
   const int64_t E = 3 * J * J + 2 * J;
   const double* EXO_RESTRICT p = state + op.src_elem + ((int64_t)(has ? idx : 0) * E) * op.n_draw + draw;
   int e = 0;
-#pragma unroll
+EXO_UNROLL_TREE
   for (int j = 0; j < J; ++j)
-#pragma unroll
+EXO_UNROLL_TREE
     for (int l = 0; l < J; ++l) { const double v = p[(e++) * op.n_draw]; el.A[j][l] = has ? v : (j == l ? 1.0 : 0.0); }
-#pragma unroll
+EXO_UNROLL_TREE
   for (int j = 0; j < J; ++j) { const double v = p[(e++) * op.n_draw]; el.b[j] = has ? v : 0.0; }
-#pragma unroll
+EXO_UNROLL_TREE
   for (int j = 0; j < J; ++j)
-#pragma unroll
+EXO_UNROLL_TREE
     for (int l = 0; l < J; ++l) { const double v = p[(e++) * op.n_draw]; el.Cm[j][l] = has ? v : 0.0; }
-#pragma unroll
+EXO_UNROLL_TREE
   for (int j = 0; j < J; ++j) { const double v = p[(e++) * op.n_draw]; el.eta[j] = has ? v : 0.0; }
-#pragma unroll
+EXO_UNROLL_TREE
   for (int j = 0; j < J; ++j)
-#pragma unroll
+EXO_UNROLL_TREE
     for (int l = 0; l < J; ++l) { const double v = p[(e++) * op.n_draw]; el.Jm[j][l] = has ? v : 0.0; }
 }
 
@@ -1363,26 +1373,26 @@ EXO_HD void tree_apply(const Elem<J>& el, const double* m, const double (*P)[J],
   if (ADJ) {
     // x = Abar^T Fbar ;  Fbar' = lF + x ;  Pbar' = lP + Abar^T Pbar Abar + sym(x g^T)
     double x[J], T[J][J];
-#pragma unroll
+EXO_UNROLL_TREE
     for (int j = 0; j < J; ++j) {
       double xj = 0.0;
-#pragma unroll
+EXO_UNROLL_TREE
       for (int l = 0; l < J; ++l) {
         xj = fma(el.A[l][j], m[l], xj);
         double tv = 0.0;
-#pragma unroll
+EXO_UNROLL_TREE
         for (int k = 0; k < J; ++k) tv = fma(P[j][k], el.A[k][l], tv);
         T[j][l] = tv;
       }
       x[j] = xj;
     }
-#pragma unroll
+EXO_UNROLL_TREE
     for (int j = 0; j < J; ++j) {
       m2[j] = el.eta[j] + x[j];
-#pragma unroll
+EXO_UNROLL_TREE
       for (int l = 0; l < J; ++l) {
         double cong = el.Cm[j][l];
-#pragma unroll
+EXO_UNROLL_TREE
         for (int k = 0; k < J; ++k) cong = fma(el.A[k][j], T[k][l], cong);
         P2[j][l] = cong + 0.5 * (x[j] * el.b[l] + el.b[j] * x[l]);
       }
@@ -1390,13 +1400,13 @@ EXO_HD void tree_apply(const Elem<J>& el, const double* m, const double (*P)[J],
   } else {
     // X = I + P Jm ;  solve X [YP | ym] = [P | F + P eta] ;  F' = A ym + b ;  P' = A (YP) A^T + Cm
     double X[J][J], Bm[J][J + 1];
-#pragma unroll
+EXO_UNROLL_TREE
     for (int j = 0; j < J; ++j) {
       double pe = m[j];
-#pragma unroll
+EXO_UNROLL_TREE
       for (int l = 0; l < J; ++l) {
         double xv = (j == l) ? 1.0 : 0.0;
-#pragma unroll
+EXO_UNROLL_TREE
         for (int k = 0; k < J; ++k) xv = fma(P[j][k], el.Jm[k][l], xv);
         X[j][l] = xv;
         Bm[j][l] = P[j][l];
@@ -1406,32 +1416,32 @@ EXO_HD void tree_apply(const Elem<J>& el, const double* m, const double (*P)[J],
     }
     solve_inplace<J, J + 1>(X, Bm);
     double AY[J][J];
-#pragma unroll
+EXO_UNROLL_TREE
     for (int j = 0; j < J; ++j) {
       double mj = el.b[j];
-#pragma unroll
+EXO_UNROLL_TREE
       for (int l = 0; l < J; ++l) {
         mj = fma(el.A[j][l], Bm[l][J], mj);
         double v = 0.0;
-#pragma unroll
+EXO_UNROLL_TREE
         for (int k = 0; k < J; ++k) v = fma(el.A[j][k], Bm[k][l], v);
         AY[j][l] = v;
       }
       m2[j] = mj;
     }
-#pragma unroll
+EXO_UNROLL_TREE
     for (int j = 0; j < J; ++j)
-#pragma unroll
+EXO_UNROLL_TREE
       for (int l = 0; l < J; ++l) {
         double v = el.Cm[j][l];
-#pragma unroll
+EXO_UNROLL_TREE
         for (int k = 0; k < J; ++k) v = fma(AY[j][k], el.A[l][k], v);
         P2[j][l] = v;
       }
   }
-#pragma unroll
+EXO_UNROLL_TREE
   for (int j = 0; j < J; ++j)
-#pragma unroll
+EXO_UNROLL_TREE
     for (int l = 0; l < J; ++l) Ps[j][l] = 0.5 * (P2[j][l] + P2[l][j]);
 }
 
@@ -1440,15 +1450,15 @@ template <int J, bool ADJ>
 EXO_HD void tree_compose(const Elem<J>& e1, const Elem<J>& e2, Elem<J>& out) {
   if (ADJ) {
     double v[J];   // Abar2^T lF1
-#pragma unroll
+EXO_UNROLL_TREE
     for (int j = 0; j < J; ++j) {
       double gj = e2.b[j], vj = 0.0;
-#pragma unroll
+EXO_UNROLL_TREE
       for (int l = 0; l < J; ++l) {
         gj = fma(e2.A[l][j], e1.b[l], gj);
         vj = fma(e2.A[l][j], e1.eta[l], vj);
         double a = 0.0;
-#pragma unroll
+EXO_UNROLL_TREE
         for (int k = 0; k < J; ++k) a = fma(e1.A[j][k], e2.A[k][l], a);
         out.A[j][l] = a;
       }
@@ -1457,34 +1467,34 @@ EXO_HD void tree_compose(const Elem<J>& e1, const Elem<J>& e2, Elem<J>& out) {
       out.eta[j] = e2.eta[j] + vj;
     }
     double T[J][J];   // lP1 Abar2
-#pragma unroll
+EXO_UNROLL_TREE
     for (int j = 0; j < J; ++j)
-#pragma unroll
+EXO_UNROLL_TREE
       for (int l = 0; l < J; ++l) {
         double tv = 0.0;
-#pragma unroll
+EXO_UNROLL_TREE
         for (int k = 0; k < J; ++k) tv = fma(e1.Cm[j][k], e2.A[k][l], tv);
         T[j][l] = tv;
       }
-#pragma unroll
+EXO_UNROLL_TREE
     for (int j = 0; j < J; ++j)
-#pragma unroll
+EXO_UNROLL_TREE
       for (int l = 0; l < J; ++l) {
         double cv = e2.Cm[j][l] + 0.5 * (v[j] * e2.b[l] + e2.b[j] * v[l]);
-#pragma unroll
+EXO_UNROLL_TREE
         for (int k = 0; k < J; ++k) cv = fma(e2.A[k][j], T[k][l], cv);
         out.Cm[j][l] = cv;
         out.Jm[j][l] = 0.0;
       }
   } else {
     double M[J][J], R[J][2 * J + 1];   // right-hand sides [A1 | C1 | b1 + C1 eta2]
-#pragma unroll
+EXO_UNROLL_TREE
     for (int j = 0; j < J; ++j) {
       double r2 = e1.b[j];
-#pragma unroll
+EXO_UNROLL_TREE
       for (int l = 0; l < J; ++l) {
         double mv = (j == l) ? 1.0 : 0.0;
-#pragma unroll
+EXO_UNROLL_TREE
         for (int k = 0; k < J; ++k) mv = fma(e1.Cm[j][k], e2.Jm[k][l], mv);
         M[j][l] = mv;
         R[j][l] = e1.A[j][l];
@@ -1495,15 +1505,15 @@ EXO_HD void tree_compose(const Elem<J>& e1, const Elem<J>& e2, Elem<J>& out) {
     }
     solve_inplace<J, 2 * J + 1>(M, R);   // R = [X1 | X3 | x2]
     double AX3[J][J], Nm[J][J], w[J];
-#pragma unroll
+EXO_UNROLL_TREE
     for (int j = 0; j < J; ++j) {
       double bj = e2.b[j], wj = e2.eta[j];
-#pragma unroll
+EXO_UNROLL_TREE
       for (int l = 0; l < J; ++l) {
         bj = fma(e2.A[j][l], R[l][2 * J], bj);
         wj = fma(-e2.Jm[j][l], e1.b[l], wj);
         double a = 0.0, ax = 0.0, nv = (j == l) ? 1.0 : 0.0;
-#pragma unroll
+EXO_UNROLL_TREE
         for (int k = 0; k < J; ++k) {
           a = fma(e2.A[j][k], R[k][l], a);
           ax = fma(e2.A[j][k], R[k][J + l], ax);
@@ -1517,37 +1527,37 @@ EXO_HD void tree_compose(const Elem<J>& e1, const Elem<J>& e2, Elem<J>& out) {
       w[j] = wj;      // eta2 - J2 b1
     }
     double Nw[J], NJ[J][J];
-#pragma unroll
+EXO_UNROLL_TREE
     for (int j = 0; j < J; ++j) {
       double nw = 0.0;
-#pragma unroll
+EXO_UNROLL_TREE
       for (int l = 0; l < J; ++l) {
         nw = fma(Nm[j][l], w[l], nw);
         double v = 0.0;
-#pragma unroll
+EXO_UNROLL_TREE
         for (int k = 0; k < J; ++k) v = fma(Nm[j][k], e2.Jm[k][l], v);
         NJ[j][l] = v;
       }
       Nw[j] = nw;
     }
     double NJA[J][J];
-#pragma unroll
+EXO_UNROLL_TREE
     for (int j = 0; j < J; ++j)
-#pragma unroll
+EXO_UNROLL_TREE
       for (int l = 0; l < J; ++l) {
         double v = 0.0;
-#pragma unroll
+EXO_UNROLL_TREE
         for (int k = 0; k < J; ++k) v = fma(NJ[j][k], e1.A[k][l], v);
         NJA[j][l] = v;
       }
-#pragma unroll
+EXO_UNROLL_TREE
     for (int j = 0; j < J; ++j) {
       double ej = e1.eta[j];
-#pragma unroll
+EXO_UNROLL_TREE
       for (int l = 0; l < J; ++l) {
         ej = fma(e1.A[l][j], Nw[l], ej);
         double cv = e2.Cm[j][l], jv = e1.Jm[j][l];
-#pragma unroll
+EXO_UNROLL_TREE
         for (int k = 0; k < J; ++k) {
           cv = fma(AX3[j][k], e2.A[l][k], cv);
           jv = fma(e1.A[k][j], NJA[k][l], jv);
@@ -1558,16 +1568,16 @@ EXO_HD void tree_compose(const Elem<J>& e1, const Elem<J>& e2, Elem<J>& out) {
       out.eta[j] = ej;
     }
   }
-#pragma unroll
+EXO_UNROLL_TREE
   for (int j = 0; j < J; ++j)
-#pragma unroll
+EXO_UNROLL_TREE
     for (int l = j + 1; l < J; ++l) {
       const double cs = 0.5 * (out.Cm[j][l] + out.Cm[l][j]), js = ADJ ? 0.0 : 0.5 * (out.Jm[j][l] + out.Jm[l][j]);
       out.Cm[j][l] = out.Cm[l][j] = cs;
       out.Jm[j][l] = out.Jm[l][j] = js;
     }
   if (ADJ) {
-#pragma unroll
+EXO_UNROLL_TREE
     for (int j = 0; j < J; ++j) out.Jm[j][j] = 0.0;
   }
 }
@@ -1578,21 +1588,21 @@ EXO_HD void tree_store_elem(double* EXO_RESTRICT state, int64_t dst_elem, int64_
   const int E = 3 * J * J + 2 * J;
   double* EXO_RESTRICT q = state + dst_elem + ((int64_t)idx * E) * nd + draw;
   int e = 0;
-#pragma unroll
+EXO_UNROLL_TREE
   for (int j = 0; j < J; ++j)
-#pragma unroll
+EXO_UNROLL_TREE
     for (int l = 0; l < J; ++l) q[(int64_t)(e++) * nd] = out.A[j][l];
-#pragma unroll
+EXO_UNROLL_TREE
   for (int j = 0; j < J; ++j) q[(int64_t)(e++) * nd] = out.b[j];
-#pragma unroll
+EXO_UNROLL_TREE
   for (int j = 0; j < J; ++j)
-#pragma unroll
+EXO_UNROLL_TREE
     for (int l = 0; l < J; ++l) q[(int64_t)(e++) * nd] = out.Cm[j][l];
-#pragma unroll
+EXO_UNROLL_TREE
   for (int j = 0; j < J; ++j) q[(int64_t)(e++) * nd] = out.eta[j];
-#pragma unroll
+EXO_UNROLL_TREE
   for (int j = 0; j < J; ++j)
-#pragma unroll
+EXO_UNROLL_TREE
     for (int l = 0; l < J; ++l) q[(int64_t)(e++) * nd] = out.Jm[j][l];
 }
 
@@ -1604,19 +1614,19 @@ EXO_HD void tree_item_lane(const TreeOp& op, double* EXO_RESTRICT state, int c, 
   const int Bq = J + J * J, E = 3 * J * J + 2 * J;
   if (DOWN) {
     double m[J], P[J][J];
-#pragma unroll
+EXO_UNROLL_TREE
     for (int j = 0; j < J; ++j) {
       m[j] = state[op.par_state + ((int64_t)c * Bq + j) * nd + draw];
-#pragma unroll
+EXO_UNROLL_TREE
       for (int l = 0; l < J; ++l) P[j][l] = state[op.par_state + ((int64_t)c * Bq + J + j * J + l) * nd + draw];
     }
     auto put = [&](int pos, const double* mv, const double (*Pv)[J]) {
       const int idx = op.dst_rev ? op.dst_len - 1 - pos : pos;
       double* EXO_RESTRICT q = state + op.dst_state + ((int64_t)idx * Bq) * nd + draw;
-#pragma unroll
+EXO_UNROLL_TREE
       for (int j = 0; j < J; ++j) {
         q[(int64_t)j * nd] = mv[j];
-#pragma unroll
+EXO_UNROLL_TREE
         for (int l = 0; l < J; ++l) q[(int64_t)(J + j * J + l) * nd] = op.psign * Pv[j][l];
       }
     };
@@ -1761,15 +1771,15 @@ EXO_HD void scan_init_lane(const double* EXO_RESTRICT t, const Coefs& cf, int64_
   DrawCoef<J> co;
   co.init(cf, draw);
   double U[J], V[J];
-#pragma unroll
+EXO_UNROLL_TREE
   for (int j = 0; j < J; ++j) U[j] = V[j] = 0.0;
   co.uv(t[0], U, V);
   Sym<J> Dl;
   dc.eval(V, Dl);
-#pragma unroll
+EXO_UNROLL_TREE
   for (int j = 0; j < J; ++j) {
     dst[(int64_t)j * n_draw + draw] = 0.0;
-#pragma unroll
+EXO_UNROLL_TREE
     for (int l = 0; l < J; ++l) dst[(int64_t)(J + j * J + l) * n_draw + draw] = Dl(j, l);
   }
 }

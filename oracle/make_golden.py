@@ -63,29 +63,7 @@ def golden_gp():
     np.savez_compressed(os.path.join(OUT, "gp_sho.npz"), **out)
 
 
-LIGHTCURVE_CASES = {
-    # reference tests/light_curves_test.py:75-102
-    "two_planet": dict(orbit=dict(m_star=1.45, r_star=1.5, t0=[0.5, 17.4], period=[10.0, 5.3], ecc=[0.1, 0.8],
-                                  omega=[0.5, 1.3], m_planet=[0.3, 0.5]),
-                       r=[0.1, 0.01], u=[0.2, 0.3], t=("linspace", -20, 20, 1000), texp=[None, 0.1]),
-    # :148-164
-    "contact_bug": dict(orbit=dict(period=3.456, ecc=0.6, omega=-1.5), r=[0.1], u=[0.3, 0.2],
-                        t=("linspace", -0.1, 0.1, 1000), texp=[0.02]),
-    # :167-193
-    "small_star": dict(orbit=dict(r_star=0.189, m_star=0.151, period=0.4626413, t0=0.2, b=0.5, ecc=0.1, omega=0.1),
-                       r=[0.04221468 * 0.189], u=[0.2, 0.1], t=("linspace", 0, 0.4626413, 500), texp=[None]),
-    # BASELINE C1 / C2 at 2048 cadences around a transit
-    "c1_circular": dict(orbit=dict(period=3.5, t0=1.0, b=0.3), r=[0.1], u=[0.3, 0.2],
-                        t=("arange", 0.8, 2048, 2.0 / 1440.0), texp=[None]),
-    "c2_e03": dict(orbit=dict(period=3.5, t0=1.0, b=0.3, ecc=0.3, omega=1.1), r=[0.1], u=[0.3, 0.2],
-                   t=("arange", 0.8, 2048, 2.0 / 1440.0), texp=[None]),
-}
-
-
-def case_time(spec):
-    if spec[0] == "linspace":
-        return np.linspace(spec[1], spec[2], spec[3])
-    return spec[1] + np.arange(spec[2]) * spec[3]
+from .golden_cases import LIGHTCURVE_CASES, case_time  # noqa: E402,F401  (the tables: numpy only, shared with the tests)
 
 
 def golden_lightcurves():
@@ -105,10 +83,20 @@ def golden_lightcurves():
     np.savez_compressed(os.path.join(OUT, "lightcurves.npz"), **out)
 
 
+def golden_quad_sv_grid():
+    """nine points of the reference's grid b = linspace(-1.5, 1.5, 100), r = 0.1 (tests/light_curves_test.py:24-27) for
+    tests/test_gpu_reference_suite.py::test_light_curve_against_definition: the GPU box needs no mpmath"""
+    b = np.linspace(-1.5, 1.5, 100)
+    ks = [0, 17, 33, 45, 49, 50, 60, 83, 99]
+    s = np.array([[float(x) for x in R.quad_sv(abs(b[k]), 0.1)] for k in ks])
+    np.savez_compressed(os.path.join(OUT, "quad_sv_grid.npz"), k=np.array(ks), b=b[ks], r=np.array(0.1), s=s)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     golden_kepler()
     golden_quad_sv()
+    golden_quad_sv_grid()
     golden_gp()
     golden_lightcurves()
     for f in sorted(os.listdir(OUT)):

@@ -27,10 +27,7 @@ LD = np.longdouble
 
 
 # ------------------------------------------------------------------------------------------ light curves
-C4 = dict(period=[3.5, 7.9, 13.1, 29.7], t0=[1.0, 2.3, 5.1, 11.7], b=[0.3, 0.1, 0.5, 0.2], ecc=[0.05, 0.1, 0.2, 0.3],
-          omega=[1.1, -0.4, 2.0, 0.3], r=[0.1, 0.05, 0.07, 0.03], u=(0.3, 0.2))
-C5 = dict(period=2.7, t0=0.4, b=0.2, ecc=0.1, omega=0.7, r=0.08, u_p=(0.3, 0.2), u_s=(0.4, 0.1), sbr=0.3,
-          texp=29.4 / 1440.0, oversample=7, order=0)
+from .golden_cases import C4, C5  # noqa: E402,F401  (the tables: numpy only, shared with the tests)
 
 
 def c4_times():

@@ -43,7 +43,7 @@ def test_quad_sv_golden(dev):
 
 def test_lightcurves_golden(dev):
     import exoplanet_amd as xo
-    from oracle.make_golden import LIGHTCURVE_CASES, case_time
+    from oracle.golden_cases import LIGHTCURVE_CASES, case_time
 
     g = np.load(os.path.join(GOLD, "lightcurves.npz"))
     for name, case in LIGHTCURVE_CASES.items():
@@ -77,7 +77,7 @@ def test_c4_c5_light_curves_vs_mpmath_end_to_end(dev):
     cadences against fixtures generated END TO END in mpmath (oracle/mp_lightcurve.py: the reference's
     formulas restated directly, no code shared with the numpy / C ports or the kernels)"""
     import exoplanet_amd as xo
-    from oracle.make_golden_r02 import C4, C5
+    from oracle.golden_cases import C4, C5
 
     g = np.load(os.path.join(GOLD, "lightcurves_mp.npz"))
     orbit = xo.KeplerianOrbit(period=T(C4["period"], dev), t0=T(C4["t0"], dev), b=T(C4["b"], dev), ecc=T(C4["ecc"], dev),

@@ -304,6 +304,56 @@ def test_wide_state_takes_the_time_parallel_path(dev):
                 assert np.abs(g - w).max() / (np.abs(w).max() + 1e-300) < 1e-9
 
 
+@pytest.mark.parametrize("J", [9, 10, 12, 13, 16])
+def test_states_wider_than_eight_take_the_time_parallel_path(dev, J):
+    """J = 9 .. 16 (round 6): the lane-group element / chunk kernels on a DPP row of sixteen lanes, the scans on blocks of 256
+    threads with the matrices in LDS (celerite_tree_wide_kernel): chunked == sequential == dense -- on the default plan and on
+    forced ones (an odd number of chunks, a plan with a single-chunk tail), with a batch that does not fill its last wave; the
+    same at a time origin 3000 d away"""
+    from exoplanet_amd import _lib
+
+    rng = np.random.default_rng(100 + J)
+    N, D = 1500, 7
+    t = np.sort(rng.uniform(0, 60, N))
+    y = 0.4 * rng.normal(size=(D, N))
+    diag = np.full((1, N), 0.05)
+    sho = [(0.4, 20.0, 2.0), (0.3, 10.0, 1.0), (0.2, 2.0, 0.8), (0.25, 5.0, 1.5), (0.15, 1.1, 4.0), (0.2, 33.0, 0.9),
+           (0.1, 0.6, 2.5), (0.12, 7.7, 6.0)]
+    n_pair, n_real = J // 2, J % 2
+    parts = [P.sho_coefficients(*P.sho_from_sigma_rho(s_, r_, q_), q_) for s_, r_, q_ in sho[:n_pair]]
+    co = tuple(np.concatenate(x) for x in zip(*parts))
+    if n_real:
+        co = (np.array([0.3]), np.array([0.2])) + co[2:]
+    cr0, cc0 = _pack(co)
+    assert cr0.shape[1] + 2 * cc0.shape[1] == J
+    cr = np.repeat(cr0, D, 0) * (1 + 0.02 * rng.normal(size=(D,) + cr0.shape[1:]))
+    cc = np.repeat(cc0, D, 0)
+    cc[..., 0] *= 1 + 0.02 * rng.normal(size=cc[..., 0].shape)
+    cc[..., 1] = cc[..., 0] * (cc0[..., 1] / cc0[..., 0])      # keep b / a: SHO terms sit on |b d| = a c
+    assert int(_lib.load().exo_celerite_default_chunks(N, D, cr0.shape[1], cc0.shape[1], 0)) > 1     # the default plan cuts the series
+    with chunks(0):
+        want = value_and_grads(dev, t, y, diag, cr, cc)
+    co_d = (cr[0, :, 0], cr[0, :, 1], cc[0, :, 0], cc[0, :, 1], cc[0, :, 2], cc[0, :, 3])
+    ref, _ = P.gp_loglike_dense(t, y[0], diag[0], co_d)
+    for C in (None, 11, 32):
+        with chunks(C):
+            got = value_and_grads(dev, t, y, diag, cr, cc)
+        assert not np.array_equal(got[0], want[0])                 # (not the sequential kernels' numbers: the path was taken)
+        np.testing.assert_allclose(got[0], want[0], rtol=1e-12)
+        for g, w in zip(got[1:], want[1:]):
+            if w.size:
+                assert np.abs(g - w).max() / (np.abs(w).max() + 1e-300) < 5e-9
+        assert abs(got[0][0] - ref) < 1e-10 * abs(ref)
+    tq = np.round(t * 2.0 ** 20) / 2.0 ** 20
+    with chunks(11):
+        a = value_and_grads(dev, tq, y, diag, cr, cc)
+        b = value_and_grads(dev, tq + 3000.0, y, diag, cr, cc)
+    np.testing.assert_allclose(b[0], a[0], rtol=1e-12)
+    for g, w in zip(b[1:], a[1:]):
+        if w.size:
+            assert np.abs(g - w).max() / (np.abs(w).max() + 1e-300) < 1e-9
+
+
 @pytest.mark.parametrize("name", ["sho_q3", "real1", "three_sho_j6"])
 @pytest.mark.parametrize("C", [0, 5, None])
 def test_observed_series_minus_model_inside_the_kernels(dev, name, C):

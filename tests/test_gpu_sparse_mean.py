@@ -137,9 +137,10 @@ def test_sparse_mean_default_plans(dev):
     _compare(_both_routes(xo, dev, 66, 9_001, "mixed", same_plan=False), ll_rtol=1e-11, g_rtol=1e-8)
 
 
-@pytest.mark.parametrize("which,extra_real", [("sho3", True), ("sho4", False)])
+@pytest.mark.parametrize("which,extra_real", [("sho3", True), ("sho4", False), ("sho4", True)])
 def test_sparse_mean_on_the_lane_group_path(dev, which, extra_real):
-    """J = 7, 8: a draw on eight lanes, the full factorisation saved (celerite_elem_lg / chunk_fwd / chunk_vjp kernels)"""
+    """J = 7, 8: a draw on eight lanes, the full factorisation saved (celerite_elem_lg / chunk_fwd / chunk_vjp kernels); J = 9
+    (round 6): the same kernels on a DPP row of sixteen lanes, the scans on celerite_tree_wide_kernel"""
     import exoplanet_amd as xo
 
     _compare(_both_routes(xo, dev, 11, 7_000, which, extra_real=extra_real), g_rtol=1e-11)

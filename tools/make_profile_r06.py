@@ -112,7 +112,7 @@ for leg, D, N, J in (("c2", 1024, 150_000, 0), ("sparse", 1024, 150_000, 0), ("c
         if k.startswith("celerite_chunk") or k.startswith("celerite_elem"):
             return D * N
         if leg in ("kepler", "quadsv") and (k.startswith("kepler_") or k.startswith("quad_sv")):
-            return N
+            return N       # (a lane of the pair kernels holds two elements: instructions per ELEMENT = insts x 64 / N all the same)
         return None
     ks = leg_record(leg, units_of)
     if not ks:
@@ -124,7 +124,8 @@ for leg, D, N, J in (("c2", 1024, 150_000, 0), ("sparse", 1024, 150_000, 0), ("c
     entry = {"draws": D, "n_cadences": N, "source": f"profiles/r06_counters.json [{leg}] (tools/profile_r06.sh)", "kernels": ks,
              "dominant_kernel": {"name": dom[0], **{k: dom[1].get(k) for k in ("rocprof_avg_us", "traffic_bytes", "traffic_GBps")}}}
     if leg in ("kepler", "quadsv"):
-        entry["algorithmic_bytes"] = {"kepler_pair_kernel": 32.0 * N, "kepler_kernel": 32.0 * N, "quad_sv_kernel<false>": 40.0 * N, "quad_sv_kernel<true>": 88.0 * N}
+        entry["algorithmic_bytes"] = {"kepler_pair_kernel": 32.0 * N, "kepler_kernel": 32.0 * N, "quad_sv_kernel<false>": 40.0 * N, "quad_sv_kernel<true>": 88.0 * N,
+                                      "quad_sv_pair_kernel<false>": 40.0 * N, "quad_sv_pair_kernel<true>": 88.0 * N}
         for k, v in ks.items():
             ab = entry["algorithmic_bytes"].get(k)
             if ab:
