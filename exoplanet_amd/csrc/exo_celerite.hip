@@ -2055,6 +2055,23 @@ int32_t exo_celerite_default_chunks(int64_t n, int64_t n_draw, int32_t n_real, i
     case 16: { constexpr int JJ = 16; CALL; } break; \
     default: break;                                \
   }
+// the ONE-LANE tree kernel: state widths 1 .. 8; 9 .. 16 only when the LDS kernel for wide states is switched off (EXO_GP_WIDE_LDS = 0)
+#if EXO_GP_WIDE_LDS
+#define EXO_GP_DISPATCH_TREE(J_, CALL) \
+  switch (J_) {                        \
+    case 1: { constexpr int JJ = 1; CALL; } break; \
+    case 2: { constexpr int JJ = 2; CALL; } break; \
+    case 3: { constexpr int JJ = 3; CALL; } break; \
+    case 4: { constexpr int JJ = 4; CALL; } break; \
+    case 5: { constexpr int JJ = 5; CALL; } break; \
+    case 6: { constexpr int JJ = 6; CALL; } break; \
+    case 7: { constexpr int JJ = 7; CALL; } break; \
+    case 8: { constexpr int JJ = 8; CALL; } break; \
+    default: break;                                \
+  }
+#else
+#define EXO_GP_DISPATCH_TREE(J_, CALL) EXO_GP_DISPATCH_VOID(J_, CALL)
+#endif
 #define EXO_GP_DISPATCH_GROUP(J_, CALL) \
   switch (J_) {                         \
     case 3: { constexpr int JJ = 3; CALL; } break; \
@@ -2366,14 +2383,14 @@ static int celerite_fwd(const double* t, Series resid, const double* diag, int64
                       if (down) hipLaunchKernelGGL((celerite_tree_wide_kernel<false, true>), wgrid, dim3(256), 0, st, op, state);
                       else hipLaunchKernelGGL((celerite_tree_wide_kernel<false, false>), wgrid, dim3(256), 0, st, op, state);
                     } else if (down) {
-                      EXO_GP_DISPATCH_VOID(J, hipLaunchKernelGGL((celerite_tree_kernel<JJ, false, true>), tgrid, block, 0, st, op, state))
+                      EXO_GP_DISPATCH_TREE(J, hipLaunchKernelGGL((celerite_tree_kernel<JJ, false, true>), tgrid, block, 0, st, op, state))
                     } else if (J >= 3 && J <= 8) {
                       // composing two filtering elements keeps ~5 J x J matrices alive around the solve: one lane per
                       // item spills 2 KB at J = 6 and crawls (76 us per level); a wave per item with the tiles in LDS
                       hipLaunchKernelGGL(celerite_compose_lds_kernel, dim3((unsigned)(op.n_item * n_draw)), block, 0,
                                          st, op, state);
                     } else {
-                      EXO_GP_DISPATCH_VOID(J, hipLaunchKernelGGL((celerite_tree_kernel<JJ, false, false>), tgrid, block, 0, st, op, state))
+                      EXO_GP_DISPATCH_TREE(J, hipLaunchKernelGGL((celerite_tree_kernel<JJ, false, false>), tgrid, block, 0, st, op, state))
                     }
                   };
         auto seed = [&]() {
@@ -2491,9 +2508,9 @@ static int celerite_vjp(const double* t, Series resid, const double* diag, int64
                     if (down) hipLaunchKernelGGL((celerite_tree_wide_kernel<true, true>), wgrid, dim3(256), 0, st, op, wstate);
                     else hipLaunchKernelGGL((celerite_tree_wide_kernel<true, false>), wgrid, dim3(256), 0, st, op, wstate);
                   } else if (down) {
-                    EXO_GP_DISPATCH_VOID(J, hipLaunchKernelGGL((celerite_tree_kernel<JJ, true, true>), tgrid, block, 0, st, op, wstate))
+                    EXO_GP_DISPATCH_TREE(J, hipLaunchKernelGGL((celerite_tree_kernel<JJ, true, true>), tgrid, block, 0, st, op, wstate))
                   } else {
-                    EXO_GP_DISPATCH_VOID(J, hipLaunchKernelGGL((celerite_tree_kernel<JJ, true, false>), tgrid, block, 0, st, op, wstate))
+                    EXO_GP_DISPATCH_TREE(J, hipLaunchKernelGGL((celerite_tree_kernel<JJ, true, false>), tgrid, block, 0, st, op, wstate))
                   }
                 };
       auto seed = [&]() {

@@ -503,7 +503,9 @@ int exo_orbit_vector_vjp_f64(const double* t, int64_t n_cad, const double* param
  * form (a <= 0 or |b d| > a c for some term) or are ill-conditioned are redone by the sequential
  * kernels on the device.
  * ------------------------------------------------------------------------- */
-#define EXO_GP_MAX_J 16   /* state widths 1 .. 8 take the time-parallel path; 9 .. 16 the sequential recurrences (a draw on 16 lanes) */
+#define EXO_GP_MAX_J 16   /* every state width takes the time-parallel path (1 .. 6: one lane per (draw, chunk); 7, 8: a draw on 8 lanes; 9 .. 16,
+                             round 6: on a DPP row of 16 lanes, the scans on 256-thread blocks); the sequential recurrences are the
+                             fallback for flagged draws and for series too short to cut */
 int64_t exo_celerite_state_doubles(int64_t n, int64_t n_draw, int32_t n_real, int32_t n_complex,
                                    int32_t n_chunks);
 /* the number of chunks the default plan (n_chunks = 0) cuts the series into, for callers that pass it explicitly; sparse != 0:
