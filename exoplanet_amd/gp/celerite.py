@@ -10,7 +10,7 @@ from .terms import Term
 
 __all__ = ["GaussianProcess", "celerite_loglike", "celerite_loglike_sparse"]
 
-MAX_J = 16     # (time-parallel up to 8; 9 .. 16: the sequential kernels -- include/exoplanet_amd.h)
+MAX_J = 16     # (every width on the time-parallel path since round 6 -- include/exoplanet_amd.h, EXO_GP_MAX_J)
 
 
 def default_chunks():

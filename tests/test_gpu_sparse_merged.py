@@ -243,3 +243,37 @@ def test_merged_step_replayed_as_a_hip_graph(dev):
         assert float(((got[0] - want[0]).abs() / want[0].abs()).max()) <= 1e-13
         for a, b in zip(got[1:], want[1:]):
             assert float((a - b).abs().max()) <= 1e-11 * float(b.abs().max()) + 1e-300
+
+
+def test_merged_model_without_any_run(dev):
+    """two planets that never cross the disk inside the series (first transits beyond its end): no run in any list -- zero
+    segments per draw, the likelihood that of the observed series alone, zero gradients for the orbits, the same as the dense route"""
+    import exoplanet_amd as xo
+
+    N, D = 4_000, 6
+    t = torch.arange(N, dtype=torch.float64, device=dev) * (2.0 / 1440.0)          # 5.6 days
+    y = torch.tensor(5e-4 * np.random.default_rng(2).normal(size=N), dtype=torch.float64, device=dev)
+    res = {}
+    for sparse in (False, True):
+        rng = np.random.default_rng(9)
+        j = lambda v: np.asarray(v) * (1 + 1e-3 * rng.normal(size=(D, 2)))  # noqa: E731
+        L = dict(period=_T(j([50.0, 80.0]), dev), t0=_T(j([20.0, 33.0]), dev), b=_T(j([0.3, 0.2]), dev))
+        r = _T(j([0.1, 0.08]), dev)
+        u1 = torch.full((D,), 0.3, dtype=torch.float64, device=dev, requires_grad=True)
+        u2 = torch.full((D,), 0.2, dtype=torch.float64, device=dev, requires_grad=True)
+        lc = xo.LimbDarkLightCurve(u1, u2).get_light_curve(orbit=xo.KeplerianOrbit(**L), r=r, t=t, total=True,
+                                                           **(dict(sparse=True) if sparse else dict(cadence_major=True)))
+        kern, kl = _kernel(xo, dev, D, 1, 5)
+        ll = xo.gp.GaussianProcess(kern, t=t, yerr=5e-4, mean=lc).log_likelihood(y)
+        g = torch.autograd.grad(ll.sum(), list(L.values()) + [r] + kl, allow_unused=True)
+        res[sparse] = (ll.detach().clone(), g, lc)
+    sp = res[True][2]
+    assert isinstance(sp, xo.ops.MergedSparseLightCurve)
+    nseg, _, off = sp.segments()
+    assert int(nseg.abs().sum()) == 0 and int(off[:, 0].abs().sum()) == 0
+    assert float((sp.dense() != 0).sum()) == 0
+    assert float(((res[True][0] - res[False][0]).abs() / res[False][0].abs()).max()) <= 1e-13
+    for a, b in zip(res[False][1], res[True][1]):
+        if a is None or b is None:
+            continue
+        assert float((a - b).abs().max()) <= 1e-12 * float(a.abs().max()) + 1e-300
