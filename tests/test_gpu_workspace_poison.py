@@ -34,7 +34,7 @@ def _terms(xo, dev, D, which, rng):
     ps = [dict(sigma=v(4e-4), rho=v(20.0), Q=v(2.0)), dict(sigma=v(3e-4), rho=v(10.0), Q=v(1.0)),
           dict(sigma=v(2e-4), rho=v(2.0), Q=v(0.7071)), dict(sigma=v(2e-4), rho=v(0.7), Q=v(3.0)),
           dict(sigma=v(1e-4), rho=v(0.3), Q=v(1.5))]
-    n = {"sho2": 2, "sho3": 3, "sho4": 4, "sho5": 5}[which]       # J = 4, 6, 8 (lane groups), 10 (sequential kernels)
+    n = {"sho2": 2, "sho3": 3, "sho4": 4, "sho5": 5}[which]       # J = 4, 6, 8 (lane groups of eight), 10 (a DPP row of sixteen: the wide path of round 6)
     kern = T.SHOTerm(**ps[0])
     for p in ps[1:n]:
         kern = kern + T.SHOTerm(**p)
