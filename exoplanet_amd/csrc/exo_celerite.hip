@@ -125,6 +125,36 @@ __device__ __forceinline__ int group_get_int(int v, int l) {
   return __double2loint(group_get<G>(__hiloint2double(0, v), l));
 }
 
+// ALL-GATHER within a group: out[l] = the value `v` of lane l of this lane's group, l = 0 .. J - 1 (what the recurrences need
+// three times per cadence: U, W and the propagators of every state index).  By DPP broadcasts a value costs ~10 vector
+// instructions on a group of eight and ~20 on a row of sixteen (quad broadcast, xor-4 and xor-8 exchanges with their selects, twice
+// for the two halves of a double): 200 instructions per gather at J = 10 -- most of what the lane-group kernels of the wide states
+// issued (round 6: element kernel 4.3 ms of a 12.7 ms step).  Through LDS it is one ds_write_b64 of the wave's 64 values and J / 2
+// ds_read_b128 per lane (the lanes of a group read the same addresses: broadcasts).  A block of these kernels is ONE wave, so the
+// barriers below are waits on the LDS counter, not s_barrier round trips.  EXO_GATHER_LDS_MIN_G: from which group width on.
+#ifndef EXO_GATHER_LDS_MIN_G
+#define EXO_GATHER_LDS_MIN_G 16
+#endif
+template <int G, int J>
+__device__ __forceinline__ void group_gather_lds(double v, double (&out)[J]) {
+  __shared__ double s_gather[kWave];
+  s_gather[threadIdx.x] = v;
+  __syncthreads();
+  const double* __restrict__ base = s_gather + (threadIdx.x & ~(G - 1));
+#pragma unroll
+  for (int l = 0; l < J; ++l) out[l] = base[l];
+  __syncthreads();     // (the next gather overwrites the buffer)
+}
+// (narrower groups keep the DPP loop exactly as it stood: the kernels of J <= 8 compile to what rounds 2-5 validated)
+#define EXO_GROUP_GATHER(v, out)                                   \
+  do {                                                             \
+    if constexpr (G >= EXO_GATHER_LDS_MIN_G) {                     \
+      group_gather_lds<G, J>(v, out);                              \
+    } else {                                                       \
+      _Pragma("unroll") for (int l_ = 0; l_ < J; ++l_) (out)[l_] = group_get<G>(v, l_); \
+    }                                                              \
+  } while (0)
+
 // butterfly partner lane ^ M within the group
 template <int M>
 __device__ __forceinline__ double xor_get(double v) {
@@ -282,8 +312,7 @@ __global__ __launch_bounds__(kWave) void celerite_fwd_kernel(
   double z = y[0];
   bool bad = !(d > 0.0);
   double Wj = Vj / d;
-#pragma unroll
-  for (int l = 0; l < J; ++l) Wall[l] = group_get<G>(Wj, l);
+  EXO_GROUP_GATHER(Wj, Wall);
   // sum log d_n = log prod d_n: carry the product as (mantissa, exponent) -- a multiply
   // and a frexp per cadence instead of a ~45-instruction log on the sequential chain
   double acc = z * z / d;
@@ -341,12 +370,10 @@ __global__ __launch_bounds__(kWave) void celerite_fwd_kernel(
     tprev = ti;
     if (SAVE) {
       Pj = Pi;
-#pragma unroll
-      for (int l = 0; l < J; ++l) Pall[l] = group_get<G>(Pj, l);
+      EXO_GROUP_GATHER(Pj, Pall);
     } else if (dt != dt_prev) {  // wave-uniform: evenly sampled series reuse P
       Pj = k.live ? exp(-k.c * dt) : 0.0;
-#pragma unroll
-      for (int l = 0; l < J; ++l) Pall[l] = group_get<G>(Pj, l);
+      EXO_GROUP_GATHER(Pj, Pall);
       dt_prev = dt;
     }
     // row j of  S <- (P P^T) o (S + d W W^T) ;  F_j <- P_j (F_j + W_j z)
@@ -355,8 +382,7 @@ __global__ __launch_bounds__(kWave) void celerite_fwd_kernel(
 #pragma unroll
     for (int l = 0; l < J; ++l) Srow[l] = Pj * Pall[l] * fma(dwj, Wall[l], Srow[l]);
     if (SAVE) { Uj = Ui; Vj = Vi; } else { lane_uv(k, ti, &Uj, &Vj, &cs, &sn); }
-#pragma unroll
-    for (int l = 0; l < J; ++l) Uall[l] = group_get<G>(Uj, l);
+    EXO_GROUP_GATHER(Uj, Uall);
     double uj = 0.0;
 #pragma unroll
     for (int l = 0; l < J; ++l) uj = fma(Srow[l], Uall[l], uj);
@@ -367,8 +393,7 @@ __global__ __launch_bounds__(kWave) void celerite_fwd_kernel(
     bad = bad || !(d > 0.0);
     const double id = 1.0 / d;
     Wj = (Vj - uj) * id;
-#pragma unroll
-    for (int l = 0; l < J; ++l) Wall[l] = group_get<G>(Wj, l);
+    EXO_GROUP_GATHER(Wj, Wall);
     acc = fma(z * z, id, acc);
     lman = frexp(lman * (d > 0.0 ? d : 1.0), &lexp);
     lsum += lexp;
@@ -490,13 +515,12 @@ __global__ __launch_bounds__(kWave) void celerite_vjp_kernel(
     const double ti = t_n;
     const double dt = ti - t_p;
     t_n = t_p;
-#pragma unroll
-    for (int l = 0; l < J; ++l) Pall[l] = group_get<G>(Pj, l);
+    EXO_GROUP_GATHER(Pj, Pall);
     // cos / sin of this lane's complex pair: its own V and its partner's
     const double cs = k.odd ? Vo : Vj, sn = k.odd ? Vj : Vo;
     double Uall[J], Wpall[J];
-#pragma unroll
-    for (int l = 0; l < J; ++l) { Uall[l] = group_get<G>(Uj, l); Wpall[l] = group_get<G>(W_p, l); }
+    EXO_GROUP_GATHER(Uj, Uall);
+    EXO_GROUP_GATHER(W_p, Wpall);
     const double id = 1.0 / d_n;
     // (5) log-likelihood terms, (4) z_n = y_n - U.F_n
     const double zbar = zb - gL * z_n * id;
@@ -517,8 +541,7 @@ __global__ __launch_bounds__(kWave) void celerite_vjp_kernel(
     Ub = fma(-dbar, uj, Ub);
     const double ubj = -Vb - dbar * Uj;
     double uball[J];
-#pragma unroll
-    for (int l = 0; l < J; ++l) uball[l] = group_get<G>(ubj, l);
+    EXO_GROUP_GATHER(ubj, uball);
     double acc_u = 0.0;
 #pragma unroll
     for (int l = 0; l < J; ++l) {
@@ -772,8 +795,7 @@ __global__ __launch_bounds__(kWave) void celerite_elem_lg_kernel(
     const double yi = y[i], R = dg[i];
     ok = ok && (R >= rmin) && (R < INFINITY);
     double Uall[J];
-#pragma unroll
-    for (int l = 0; l < J; ++l) Uall[l] = group_get<G>(Uj, l);
+    EXO_GROUP_GATHER(Uj, Uall);
     double rj = 0.0, cuj = 0.0;
 #pragma unroll
     for (int l = 0; l < J; ++l) {
@@ -784,8 +806,7 @@ __global__ __launch_bounds__(kWave) void celerite_elem_lg_kernel(
     const double zeta = yi - group_sum<G>(Uj * bj);
     const double is = 1.0 / s;
     double rall[J];
-#pragma unroll
-    for (int l = 0; l < J; ++l) rall[l] = group_get<G>(rj, l);
+    EXO_GROUP_GATHER(rj, rall);
     etaj = fma(rj * is, zeta, etaj);
 #pragma unroll
     for (int l = 0; l < J; ++l) Jrow[l] = fma(rj * is, rall[l], Jrow[l]);
@@ -794,8 +815,7 @@ __global__ __launch_bounds__(kWave) void celerite_elem_lg_kernel(
       ti = tn;
       if (dt != dt_prev) {   // wave-uniform: evenly sampled series reuse the propagators
         phi = live ? exp(-k.c * dt) : 0.0;
-#pragma unroll
-        for (int l = 0; l < J; ++l) phiall[l] = group_get<G>(phi, l);
+        EXO_GROUP_GATHER(phi, phiall);
         dt_prev = dt;
       }
       lane_uv(k, tn, &Uj, &Vj, &cs, &sn);
@@ -803,9 +823,12 @@ __global__ __launch_bounds__(kWave) void celerite_elem_lg_kernel(
       ld.row<J>(k, j, cs, sn, Dn);
       const double kj = cuj * is;
       bj = phi * fma(kj, zeta, bj);
+      double cuall[G >= EXO_GATHER_LDS_MIN_G ? J : 1];
+      if constexpr (G >= EXO_GATHER_LDS_MIN_G) group_gather_lds<G, J>(cuj, cuall);
 #pragma unroll
       for (int l = 0; l < J; ++l) {
-        const double cul = group_get<G>(cuj, l);
+        double cul;
+        if constexpr (G >= EXO_GATHER_LDS_MIN_G) cul = cuall[l]; else cul = group_get<G>(cuj, l);
         Acol[l] = phiall[l] * fma(-cul * is, rj, Acol[l]);                       // A[l][j] = phi_l (A[l][j] - k_l r_j)
         Crow[l] = fma(phi * phiall[l], fma(-kj, cul, Crow[l]) - Dl[l], Dn[l]);   // + Q = Dn - phi phi Dl
         Dl[l] = Dn[l];
@@ -886,15 +909,13 @@ __global__ __launch_bounds__(kWave) void celerite_chunk_fwd_kernel(
     }
     const double yi = y[i], gi = dg[i];
     if (i > n0) {
-#pragma unroll
-      for (int l = 0; l < J; ++l) Pall[l] = group_get<G>(Pj, l);
+      EXO_GROUP_GATHER(Pj, Pall);
       Fj = Pj * fma(Wj, z, Fj);
       const double dwj = d * Wj;
 #pragma unroll
       for (int l = 0; l < J; ++l) Srow[l] = Pj * Pall[l] * fma(dwj, Wall[l], Srow[l]);
     }
-#pragma unroll
-    for (int l = 0; l < J; ++l) Uall[l] = group_get<G>(Uj, l);
+    EXO_GROUP_GATHER(Uj, Uall);
     double uj = 0.0;
 #pragma unroll
     for (int l = 0; l < J; ++l) uj = fma(Srow[l], Uall[l], uj);
@@ -904,8 +925,7 @@ __global__ __launch_bounds__(kWave) void celerite_chunk_fwd_kernel(
     bad = bad || !(d > 0.0);
     const double id = 1.0 / d;
     Wj = (Vj - uj) * id;
-#pragma unroll
-    for (int l = 0; l < J; ++l) Wall[l] = group_get<G>(Wj, l);
+    EXO_GROUP_GATHER(Wj, Wall);
     acc = fma(z * z, id, acc);
     int lexp;
     lman = frexp(lman * (d > 0.0 ? d : 1.0), &lexp);
@@ -987,8 +1007,8 @@ __global__ __launch_bounds__(kWave) void celerite_chunk_vjp_kernel(
     }
     const double Pj = Pcache;
     double Pall[J], Wpall[J];
-#pragma unroll
-    for (int l = 0; l < J; ++l) { Pall[l] = group_get<G>(Pj, l); Wpall[l] = group_get<G>(W_p, l); }
+    EXO_GROUP_GATHER(Pj, Pall);
+    EXO_GROUP_GATHER(W_p, Wpall);
     const double Gj = fma(W_p, z_p, F_p);
     double Pb = Fb * Gj;
     const double Gb = Fb * Pj;
@@ -1038,8 +1058,7 @@ __global__ __launch_bounds__(kWave) void celerite_chunk_vjp_kernel(
     double Uj, Vj, cs, sn;
     lane_uv(k, ti, &Uj, &Vj, &cs, &sn);
     double Uall[J];
-#pragma unroll
-    for (int l = 0; l < J; ++l) Uall[l] = group_get<G>(Uj, l);
+    EXO_GROUP_GATHER(Uj, Uall);
     const double id = 1.0 / d_n;
     const double zbar = zb - gL * z_n * id;
     const double wdot = group_sum<G>(Wb * W_n);
@@ -1078,8 +1097,7 @@ __global__ __launch_bounds__(kWave) void celerite_chunk_vjp_kernel(
     Ub = fma(-dbar, uj, Ub);
     const double ubj = -Vb - dbar * Uj;
     double uball[J];
-#pragma unroll
-    for (int l = 0; l < J; ++l) uball[l] = group_get<G>(ubj, l);
+    EXO_GROUP_GATHER(ubj, uball);
     double acc_u = 0.0;
 #pragma unroll
     for (int l = 0; l < J; ++l) {
