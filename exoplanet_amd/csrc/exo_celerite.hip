@@ -132,8 +132,11 @@ __device__ __forceinline__ int group_get_int(int v, int l) {
 // issued (round 6: element kernel 4.3 ms of a 12.7 ms step).  Through LDS it is one ds_write_b64 of the wave's 64 values and J / 2
 // ds_read_b128 per lane (the lanes of a group read the same addresses: broadcasts).  A block of these kernels is ONE wave, so the
 // barriers below are waits on the LDS counter, not s_barrier round trips.  EXO_GATHER_LDS_MIN_G: from which group width on.
+// Measured at the C5 shape, 128 chains (tools/ab_gp.py, same box, alternating): rows of sixteen (J = 10) 12.7 -> 9.5 ms; groups of
+// eight too: J = 8 5.08 -> 4.66 ms, two chains redone by the sequential kernels (J = 6 on eight lanes) 182 -> 170 ms.  Pure data
+// movement: results bit for bit.  Groups of four and two keep the DPP moves (a quad broadcast is one instruction).
 #ifndef EXO_GATHER_LDS_MIN_G
-#define EXO_GATHER_LDS_MIN_G 16
+#define EXO_GATHER_LDS_MIN_G 8
 #endif
 template <int G, int J>
 __device__ __forceinline__ void group_gather_lds(double v, double (&out)[J]) {
@@ -145,7 +148,7 @@ __device__ __forceinline__ void group_gather_lds(double v, double (&out)[J]) {
   for (int l = 0; l < J; ++l) out[l] = base[l];
   __syncthreads();     // (the next gather overwrites the buffer)
 }
-// (narrower groups keep the DPP loop exactly as it stood: the kernels of J <= 8 compile to what rounds 2-5 validated)
+// (narrower groups keep the DPP loop exactly as it stood)
 #define EXO_GROUP_GATHER(v, out)                                   \
   do {                                                             \
     if constexpr (G >= EXO_GATHER_LDS_MIN_G) {                     \

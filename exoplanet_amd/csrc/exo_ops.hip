@@ -14,8 +14,8 @@
 // odd count: the scalar kernel takes them (heads, tails; whole arrays when a pointer is only 8-byte aligned).
 // MEASURED (round 6, n = 1.5e8): 3.17 (round 5: one 8-byte access per lane) -> 3.6-3.8 TB/s.  The memory side is not what
 // holds it: the circular branch (e = 0: one sincos) runs the same loads and stores at 4.6-5.5 TB/s, which is what a plain
-// copy of two arrays in and two out reaches on the same box (4.7-5.2 TB/s: tools/ops_bench.py); the eccentric solve is ~170
-// vector instructions + 13 quarter-rate ones per element = ~0.8 ms of fp64 issue at the nominal clock against 1.3 measured.
+// copy of two arrays in and two out reaches on the same box (4.7-5.2 TB/s: tools/ops_bench.py); the eccentric solve is 197
+// vector instructions per element by the counters, 13 of them quarter-rate: ~0.9 ms of issue at the nominal clock, 1.3-1.4 measured.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
