@@ -388,6 +388,28 @@ def evaluate(mods, name, spec):
     return out
 
 
+def extras(mods):
+    """pieces of the glue the system loop does not reach, evaluated through an implementation's classes: the approximate-depth
+    inversion and its Jacobian (limb_dark.py:68-97; reference test tests/light_curves_test.py:257-282), the duration -> a
+    Jacobians of the circular `duration` parameterisation (keplerian.py:112-131,151-170), the Jacobian of `b` (:217-228)"""
+    Kep, _, LD, _ = mods
+    out = {}
+    delta = np.array([1e-3, 4e-3, 9e-3, 1.6e-2, 2.5e-2])
+    b = np.array([0.0, 0.2, 0.45, 0.7, 0.9])
+    ror, jac = LD(0.3, 0.2).get_ror_from_approx_transit_depth(delta, b, jac=True)
+    out["ror"], out["ror_jac"] = np.asarray(ror, dtype=np.float64), np.asarray(jac, dtype=np.float64)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        orbit = Kep(period=np.array([4.2, 9.1]), t0=np.array([0.7, 1.3]), b=np.array([0.35, 0.1]), duration=np.array([0.12, 0.2]),
+                    ror=np.array([0.07, 0.03]), r_star=1.1, m_planet=np.array([1e-3, 3e-4]))
+    for k in ("a", "a_star", "a_planet", "rho_star"):
+        out["jac_duration_" + k] = np.atleast_1d(np.asarray(orbit.jacobians["duration"][k], dtype=np.float64))
+    out["duration_a"] = np.atleast_1d(np.asarray(orbit.a, dtype=np.float64))
+    orbit2 = Kep(period=np.array([3.3]), t0=np.array([0.2]), b=np.array([0.4]), ecc=np.array([0.3]), omega=np.array([0.8]))
+    out["jac_b_cos_incl"] = np.atleast_1d(np.asarray(orbit2.jacobians["b"]["cos_incl"], dtype=np.float64))
+    return out
+
+
 def reference_impl():
     kep, ttv, ld, sec, _ = load_reference()
     return kep.KeplerianOrbit, ttv.TTVOrbit, ld.LimbDarkLightCurve, sec.SecondaryEclipseLightCurve
@@ -442,6 +464,8 @@ def main(argv):
                   f"max rel. difference numpy_port vs reference glue = {w:.2e}  ({where})")
             for k, v in ref.items():
                 store[f"{name}__{k}"] = v
+        for k, v in extras(ref_mods).items():       # (reference side only: oracle/numpy_port.py has no counterpart -- the product is
+            store[f"extras__{k}"] = v               #  held to these directly, tests/test_gpu_glue_ref.py)
     print(f"worst = {worst_all:.2e}")
     if worst_all > 1e-13:
         print("FAIL: oracle/numpy_port.py does not reproduce the reference's glue")

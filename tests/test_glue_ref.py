@@ -26,8 +26,9 @@ def _ref_of(gold, name):
 
 
 def test_fixture_covers_every_system(gold):
-    names = {k.split("__")[0] for k in gold.files if "__" in k}
+    names = {k.split("__")[0] for k in gold.files if "__" in k} - {"extras"}
     assert names == set(G.systems()), names ^ set(G.systems())
+    assert {"extras__ror", "extras__ror_jac", "extras__jac_duration_a", "extras__jac_b_cos_incl"} <= set(gold.files)
     # the constants are the reference's own literals (orbits/constants.py:32-37), reached through its fallback branch
     assert float(gold["const_G_grav"]) == 2942.2062175044193
     assert float(gold["const_c_light"]) == 37231.66360672704
@@ -74,6 +75,9 @@ def test_live_reference_glue_matches_fixture_and_port(gold):
             "    fx = {k[len(name) + 2:]: gold[k] for k in gold.files if k.startswith(name + '__')}\n"
             "    assert set(fx) == set(ref), name\n"
             "    w, where = G.compare(ref, fx, 0.0); worst = max(worst, w)\n"
+            "ex = G.extras(mods)\n"
+            "for k, v in ex.items():\n"
+            "    assert np.array_equal(v, gold['extras__' + k]), k\n"
             "print('WORST', worst)") % (root, GOLD)
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]

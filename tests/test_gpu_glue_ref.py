@@ -40,6 +40,8 @@ class _Proxy:
             return v.detach().cpu().numpy()
         if isinstance(v, (tuple, list)):
             return type(v)(self._to_np(x) for x in v)
+        if isinstance(v, dict):
+            return {k: self._to_np(x) for k, x in v.items()}
         if isinstance(v, (xo.KeplerianOrbit,)):
             return _Proxy(v, self._dev)
         return v
@@ -89,3 +91,16 @@ def test_hip_path_reproduces_reference_glue(dev, gold, name):
     worst, where = G.compare(ref2, {k: got[k] for k in ref2}, 1e-11)
     assert worst <= 1e-11, (name, where, worst)
     assert min(float(got[k].min()) for k in got if k.startswith("lc_")) < -1e-5
+
+
+def test_hip_side_extras_of_the_glue(dev, gold):
+    """the approximate-depth inversion with its Jacobian (limb_dark.py:68-97), the duration -> a Jacobians of the circular
+    `duration` parameterisation (keplerian.py:112-131,151-170) and d cos i / d b (:217-228): the package's classes against the
+    reference glue's own outputs (the oracle's restatement has no counterpart of these)"""
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        got = G.extras(_impl(dev))
+    for k, v in got.items():
+        ref = gold["extras__" + k]
+        assert np.squeeze(ref).shape == np.squeeze(v).shape, k
+        assert np.abs(np.squeeze(v) - np.squeeze(ref)).max() <= 1e-13 * np.abs(ref).max(), (k, v, ref)
