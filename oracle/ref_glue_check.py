@@ -410,6 +410,35 @@ def extras(mods):
     return out
 
 
+def extras_simple(Simple, LD):
+    """orbits/simple.py: SimpleTransitOrbit (period, duration, t0, b, r_star, ror) -- positions, the in-transit selection and the
+    light curve LimbDarkLightCurve draws from it (with and without an exposure time)"""
+    out = {}
+    t = np.linspace(-1.0, 9.0, 1500)
+    orbit = Simple(period=np.array([3.3, 4.7]), duration=np.array([0.12, 0.2]), t0=np.array([0.3, 1.1]), b=np.array([0.2, 0.5]),
+                   r_star=1.1, ror=np.array([0.08, 0.05]))
+    r = 1.1 * np.array([0.08, 0.05])
+    pos = orbit.get_relative_position(t)
+    for i, c in enumerate("xyz"):
+        out["simple_pos_" + c] = np.asarray(pos[i], dtype=np.float64)[::5]
+    out["simple_in_transit"] = np.asarray(orbit.in_transit(t, r=r), dtype=np.int64)
+    out["simple_in_transit_texp"] = np.asarray(orbit.in_transit(t, r=r, texp=0.05), dtype=np.int64)
+    star = LD(0.3, 0.2)
+    out["simple_lc"] = np.asarray(star.get_light_curve(orbit=orbit, r=r, t=t), dtype=np.float64)
+    out["simple_lc_texp"] = np.asarray(star.get_light_curve(orbit=orbit, r=r, t=t, texp=0.05, oversample=5, order=1), dtype=np.float64)
+    assert out["simple_lc"].min() < -1e-3 and 0 < out["simple_in_transit"].size < t.size
+    return out
+
+
+def reference_simple():
+    import importlib
+
+    install_standins()
+    m = importlib.import_module("exoplanet.orbits.simple")
+    assert os.path.abspath(m.__file__).startswith(REF_SRC)
+    return m.SimpleTransitOrbit
+
+
 def reference_impl():
     kep, ttv, ld, sec, _ = load_reference()
     return kep.KeplerianOrbit, ttv.TTVOrbit, ld.LimbDarkLightCurve, sec.SecondaryEclipseLightCurve
@@ -464,6 +493,8 @@ def main(argv):
                   f"max rel. difference numpy_port vs reference glue = {w:.2e}  ({where})")
             for k, v in ref.items():
                 store[f"{name}__{k}"] = v
+        for k, v in extras_simple(reference_simple(), ref_mods[2]).items():
+            store[f"extras__{k}"] = v
         for k, v in extras(ref_mods).items():       # (reference side only: oracle/numpy_port.py has no counterpart -- the product is
             store[f"extras__{k}"] = v               #  held to these directly, tests/test_gpu_glue_ref.py)
     print(f"worst = {worst_all:.2e}")

@@ -75,7 +75,7 @@ def test_live_reference_glue_matches_fixture_and_port(gold):
             "    fx = {k[len(name) + 2:]: gold[k] for k in gold.files if k.startswith(name + '__')}\n"
             "    assert set(fx) == set(ref), name\n"
             "    w, where = G.compare(ref, fx, 0.0); worst = max(worst, w)\n"
-            "ex = G.extras(mods)\n"
+            "ex = dict(G.extras(mods)); ex.update(G.extras_simple(G.reference_simple(), mods[2]))\n"
             "for k, v in ex.items():\n"
             "    assert np.array_equal(v, gold['extras__' + k]), k\n"
             "print('WORST', worst)") % (root, GOLD)

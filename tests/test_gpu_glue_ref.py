@@ -104,3 +104,25 @@ def test_hip_side_extras_of_the_glue(dev, gold):
         ref = gold["extras__" + k]
         assert np.squeeze(ref).shape == np.squeeze(v).shape, k
         assert np.abs(np.squeeze(v) - np.squeeze(ref)).max() <= 1e-13 * np.abs(ref).max(), (k, v, ref)
+
+
+def test_simple_transit_orbit_against_the_reference_glue(dev, gold):
+    """orbits/simple.py executed in place (oracle/ref_glue_check.py, extras_simple) against exoplanet_amd's SimpleTransitOrbit:
+    positions, in-transit indices, and the light curve LimbDarkLightCurve draws from it"""
+    import exoplanet_amd as xo
+
+    p = _Proxy(None, dev)
+
+    def simple(**k):
+        return _Proxy(xo.orbits.SimpleTransitOrbit(**{kk: p._to_t(x) for kk, x in k.items()}), dev)
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        got = G.extras_simple(simple, _impl(dev)[2])
+    for k, v in got.items():
+        ref = gold["extras__" + k]
+        if ref.dtype.kind in "iu":
+            assert len(set(ref.tolist()) ^ set(v.tolist())) <= 2, k
+            continue
+        assert np.squeeze(ref).shape == np.squeeze(v).shape, k
+        assert np.abs(np.squeeze(v) - np.squeeze(ref)).max() <= 1e-12 * max(1.0, np.abs(ref).max()), k
