@@ -1024,6 +1024,17 @@ class SparseLightCurve:
     def __neg__(self): return -self.dense()
 
 
+_POISON = [None]    # tests: fill the merge workspace and its cotangent buffer with this value first (nothing may depend on what they
+                    # held before the call -- under hipGraph replay that is the previous step's: gp/celerite.py has the same hook)
+
+
+def _scratch(n, device):
+    x = torch.empty(n, dtype=torch.float64, device=device)
+    if _POISON[0] is not None:
+        x.fill_(_POISON[0])
+    return x
+
+
 class _MergeSparse(torch.autograd.Function):
     """values of a several-list sparse light curve (D, P * N: the sweep's layout) -> values of the merged model (D, N), of which
     row d's first off[d][nseg[d]] entries are defined (exo_sparse_model_merge_f64); backward: the cotangent of the merged values
@@ -1035,7 +1046,7 @@ class _MergeSparse(torch.autograd.Function):
         N, D, P = sp.n_cad, sp.n_draw, sp.n_planet
         nbytes = lib.exo_transit_flux_workspace_bytes(N, D, P)
         mbytes = lib.exo_sparse_merge_workspace_bytes(N, D, P)
-        mws = torch.empty(max(mbytes // 8 + 1, 1), dtype=torch.float64, device=vals.device)
+        mws = _scratch(max(mbytes // 8 + 1, 1), vals.device)
         with torch.cuda.device(vals.device):
             _lib.check(lib.exo_sparse_model_merge_f64(_ptr(sp._ws), nbytes, N, D, P, sp.flags & FLAG_SECONDARY, _ptr(mws), mbytes,
                                                       None, _stream(vals)), "exo_sparse_model_merge_f64")
@@ -1055,7 +1066,7 @@ class _MergeSparse(torch.autograd.Function):
         if not gm.is_contiguous() or tuple(gm.shape) != (D, N):
             raise ValueError("the cotangent of a merged sparse light curve's values must be a contiguous (n_draw, n_cad) array")
         # (only the positions the lists cover are defined, as in `vals` itself -- gp/celerite.py, _CeleriteLogLikeSparse.backward)
-        gvals = torch.empty(D, P * N, dtype=torch.float64, device=gm.device)
+        gvals = _scratch(D * P * N, gm.device).view(D, P * N)
         with torch.cuda.device(gm.device):
             _lib.check(_lib.load().exo_sparse_model_merge_vjp_f64(_ptr(sp._ws), nbytes, N, D, P, sp.flags & FLAG_SECONDARY,
                                                                   _ptr(ctx.mws), mbytes, _ptr(gm), _ptr(gvals), _stream(gm)),

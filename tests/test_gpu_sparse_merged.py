@@ -277,3 +277,37 @@ def test_merged_model_without_any_run(dev):
         if a is None or b is None:
             continue
         assert float((a - b).abs().max()) <= 1e-12 * float(a.abs().max()) + 1e-300
+
+
+def test_merged_route_does_not_depend_on_what_its_buffers_held(dev):
+    """the merge workspace (segments, offsets, merged values), the cotangent handed back to the lists and every celerite buffer
+    filled with zeros / NaN / 1e300 / -3 before the call: log-likelihood and all gradients bit-identical (a replayed hipGraph
+    hands every step the previous step's contents)"""
+    import exoplanet_amd as xo
+    from exoplanet_amd.gp import celerite as C
+
+    D, N = 24, 6_000
+    texp = 29.4 / 1440.0
+    t = torch.arange(N, dtype=torch.float64, device=dev) * texp
+    y = torch.tensor(3e-4 * np.random.default_rng(4).normal(size=N), dtype=torch.float64, device=dev)
+    out = []
+    try:
+        for fill in (0.0, float("nan"), 1e300, -3.0):
+            C._POISON[0] = fill
+            xo.ops._POISON[0] = fill
+            L, r, u1, u2, sbr = _system(dev, D, "two_sec", 21)
+            kern, kl = _kernel(xo, dev, D, 3, 22)
+            lc = _light_curve(xo, L, r, u1, u2, sbr, t, texp, sparse=True)
+            assert isinstance(lc, xo.ops.MergedSparseLightCurve)
+            ll = xo.gp.GaussianProcess(kern, t=t, yerr=3e-4, mean=lc).log_likelihood(y)
+            g = torch.autograd.grad(ll.sum(), list(L.values()) + [r, u1, u2, sbr] + kl)
+            torch.cuda.synchronize()
+            out.append((ll.detach().clone(), [x.clone() for x in g]))
+    finally:
+        C._POISON[0] = None
+        xo.ops._POISON[0] = None
+    assert torch.isfinite(out[0][0]).all()
+    for ll, g in out[1:]:
+        assert torch.equal(ll, out[0][0])
+        for a, b in zip(g, out[0][1]):
+            assert torch.equal(a, b)
