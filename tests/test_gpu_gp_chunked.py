@@ -354,6 +354,37 @@ def test_states_wider_than_eight_take_the_time_parallel_path(dev, J):
             assert np.abs(g - w).max() / (np.abs(w).max() + 1e-300) < 1e-9
 
 
+def test_wide_state_with_pair_kinds_per_draw(dev):
+    """J = 10 from five SHO terms whose first one straddles Q = 1/2 across the batch (pair kinds per draw: a complex term for
+    some draws, two real ones for others): the wide time-parallel path against the sequential kernels, value and gradients of the
+    term parameters"""
+    import exoplanet_amd as xo
+
+    rng = np.random.default_rng(77)
+    N, D = 1800, 9
+    t = T(np.sort(rng.uniform(0, 50, N)), dev)
+    y = T(0.3 * rng.normal(size=N), dev)
+    res = {}
+    for C in (0, None):
+        v = lambda x, s=0.03: torch.tensor(x * (1 + s * np.random.default_rng(5).normal(size=D)), dtype=torch.float64, device=dev,  # noqa: E731
+                                           requires_grad=True)
+        q0 = torch.tensor(np.where(np.arange(D) % 3 == 0, 0.3, 2.0), dtype=torch.float64, device=dev, requires_grad=True)
+        ps = [dict(sigma=v(0.4), rho=v(20.0), Q=q0), dict(sigma=v(0.3), rho=v(10.0), Q=v(1.0)), dict(sigma=v(0.2), rho=v(2.0), Q=v(0.8)),
+              dict(sigma=v(0.25), rho=v(5.0), Q=v(1.5)), dict(sigma=v(0.15), rho=v(1.1), Q=v(4.0))]
+        kern = xo.gp.terms.SHOTerm(**ps[0])
+        for p_ in ps[1:]:
+            kern = kern + xo.gp.terms.SHOTerm(**p_)
+        leaves = [x for p_ in ps for x in p_.values()]
+        with chunks(C):
+            ll = xo.gp.GaussianProcess(kern, t=t, yerr=0.2).log_likelihood(y)
+            g = torch.autograd.grad(ll.sum(), leaves)
+        res[C] = (ll.detach().cpu().numpy(), [x.cpu().numpy() for x in g])
+    assert not np.array_equal(res[None][0], res[0][0])
+    np.testing.assert_allclose(res[None][0], res[0][0], rtol=1e-12)
+    for a, b in zip(res[None][1], res[0][1]):
+        assert np.abs(a - b).max() <= 5e-9 * np.abs(b).max() + 1e-300
+
+
 @pytest.mark.parametrize("name", ["sho_q3", "real1", "three_sho_j6"])
 @pytest.mark.parametrize("C", [0, 5, None])
 def test_observed_series_minus_model_inside_the_kernels(dev, name, C):
