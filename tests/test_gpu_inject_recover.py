@@ -124,3 +124,43 @@ def test_nuts_recovers_transit_and_gp_amplitude_c3_model(dev, mean, seed):
     check(draws, ("t0", "r", "log sigma"), (0.0, 0.0, 0.0), smp)
     # the GP's amplitude is measured, not just carried along: a 27-day series with rho = 1.5 d pins it to a few tens of %
     assert draws[:, :, 2].std() * 0.1 < 0.5
+
+
+def test_nuts_recovers_transit_and_amplitude_with_a_wide_kernel(dev):
+    """round 6: the noise model is two RotationTerms + an SHO term -- J = 10, on the time-parallel path for wide states (a draw on a
+    DPP row of sixteen lanes, the scans on celerite_tree_wide_kernel) -- sampled for 128 chains with the native NUTS, the leaf
+    replayed as a hipGraph a few thousand times: transit time, radius and the first term's amplitude come back"""
+    import exoplanet_amd as xo
+    from exoplanet_amd import ops
+
+    D, yerr = 128, 3e-4
+    t = ops.vouch_sorted(torch.arange(N, dtype=torch.float64, device=dev) * CAD)
+    gen = torch.Generator(device=dev).manual_seed(311)
+    f = truth_curve(xo, t, dev)
+    T = xo.gp.terms
+    sig1 = 8e-4
+
+    def kernel(s1, like):
+        one = torch.ones_like(like)
+        return (T.RotationTerm(sigma=s1, period=2.3 * one, Q0=1.5 * one, dQ=0.4 * one, f=0.6 * one)
+                + T.RotationTerm(sigma=3e-4 * one, period=5.9 * one, Q0=2.5 * one, dQ=0.7 * one, f=0.3 * one)
+                + T.SHOTerm(sigma=2e-4 * one, rho=0.6 * one, Q=0.7071 * one))
+
+    with torch.no_grad():
+        one1 = torch.ones(1, dtype=torch.float64, device=dev)
+        noise = xo.gp.GaussianProcess(kernel(sig1 * one1, one1), t=t, yerr=yerr).sample(generator=gen).reshape(-1)
+    assert 0.3 * sig1 < float(noise.std()) < 3 * sig1
+    y = f + noise
+
+    def logp(q):
+        orbit, r, b = orbit_of(xo, torch.cat([q[:, :2], torch.zeros_like(q[:, :1])], dim=1), dev)      # b fixed at its truth
+        lc = xo.LimbDarkLightCurve(0.3, 0.2).get_light_curve(orbit=orbit, r=r, t=t, total=True, cadence_major=True)
+        s = sig1 * torch.exp(0.1 * q[:, 2])
+        gp = xo.gp.GaussianProcess(kernel(s, s), t=t, yerr=yerr, mean=lc)
+        assert gp.kernel.pair_coefficients()[2].shape[-2] == 5          # five pair slots: J = 10
+        return gp.log_likelihood(y) + 0.1 * q[:, 2]
+
+    q0 = 1.5 * torch.randn(D, 3, dtype=torch.float64, device=dev, generator=gen)
+    draws, smp = run_nuts(xo, logp, q0, gen, 150, 200)
+    check(draws, ("t0", "r", "log sigma"), (0.0, 0.0, 0.0), smp)
+    assert draws[:, :, 2].std() * 0.1 < 0.5
