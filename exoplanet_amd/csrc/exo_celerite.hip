@@ -1484,6 +1484,99 @@ __global__ __launch_bounds__(256) void celerite_tree_wide_kernel(TreeOp op, doub
   }
 }
 
+// (B') part 1 for wide states: the adjoint element of chunk c from its filtering element and the state entering it (badj_prep_lane:
+// X = I + P Jm, Y = X^-1, ...), a block of 256 threads per (draw, chunk) like celerite_tree_wide_kernel -- one lane per item walks
+// 5 KB of scratch (0.86 of a 9.8 ms step at J = 10).  Same sums in the same order; the element is overwritten in place.
+__global__ __launch_bounds__(256) void celerite_badj_prep_wide_kernel(const double* __restrict__ gloglike, int64_t n, int64_t n_draw,
+                                                                      int J, double* __restrict__ state, ChunkGeom cg,
+                                                                      const int32_t* __restrict__ row) {
+  __shared__ WideLds S;
+  const int tid = threadIdx.x, j = tid >> 4, l = tid & 15;
+  const int64_t draw = blockIdx.x;
+  const int c = (int)blockIdx.y + 1;
+  const bool in = j < J && l < J;
+  const ChunkWs ws = chunk_ws(n, n_draw, J, cg);
+  const double gL = gloglike[row ? (int64_t)row[draw] : draw];
+  const int oA = 0, ob = J * J, oC = J * J + J, oeta = 2 * J * J + J, oJ = 2 * J * J + 2 * J;
+  enum { MA = 0, MJ, MP, MX, MY, MT };
+  enum { VM = 0, VETA, VU, VV, VW, VYV, VD };
+  S.m[MA][tid] = in ? state[ws.elem(c, oA + j * J + l, draw)] : 0.0;
+  S.m[MJ][tid] = in ? state[ws.elem(c, oJ + j * J + l, draw)] : 0.0;
+  S.m[MP][tid] = in ? state[ws.bnd(1, c, J + j * J + l, draw)] : 0.0;
+  S.m[MY][tid] = (in && j == l) ? 1.0 : 0.0;
+  if (l == 0) {
+    S.v[VM][j] = j < J ? state[ws.bnd(1, c, j, draw)] : 0.0;
+    S.v[VETA][j] = j < J ? state[ws.elem(c, oeta + j, draw)] : 0.0;
+    S.v[VD][j] = 0.0;
+  }
+  __syncthreads();
+  auto mm = [&](double init, int X, bool tx, int Y, bool ty) -> double {
+    double acc = init;
+    for (int k = 0; k < J; ++k)
+      acc = fma(tx ? S.m[X][k * 16 + j] : S.m[X][j * 16 + k], ty ? S.m[Y][l * 16 + k] : S.m[Y][k * 16 + l], acc);
+    return acc;
+  };
+  auto mv = [&](double init, int X, bool tx, int V) -> double {
+    double acc = init;
+    for (int k = 0; k < J; ++k) acc = fma(tx ? S.m[X][k * 16 + j] : S.m[X][j * 16 + k], S.v[V][k], acc);
+    return acc;
+  };
+  {
+    const double xv = mm((j == l && in) ? 1.0 : 0.0, MP, false, MJ, false);      // X = I + P Jm
+    const double uj = -mv(-S.v[VETA][j], MJ, false, VM);                        // u = eta - Jm m
+    const double vj = mv(S.v[VM][j], MP, false, VETA);                          // v = m + P eta
+    S.m[MX][tid] = in ? xv : 0.0;
+    if (l == 0) { S.v[VU][j] = uj; S.v[VV][j] = vj; }
+    __syncthreads();
+  }
+  // Y = X^-1: Gauss-Jordan with partial pivoting on [X | I] (celerite_tree_wide_kernel's solve, one right-hand side)
+  for (int k = 0; k < J; ++k) {
+    if (tid == 0) {
+      int p = k;
+      double best = fabs(S.m[MX][k * 16 + k]);
+      for (int i = k + 1; i < J; ++i) {
+        const double a = fabs(S.m[MX][i * 16 + k]);
+        if (a > best) { best = a; p = i; }
+      }
+      S.piv = p;
+    }
+    __syncthreads();
+    const int p = S.piv;
+    if (p != k && j == k && l < J) {
+      double tmp = S.m[MX][k * 16 + l]; S.m[MX][k * 16 + l] = S.m[MX][p * 16 + l]; S.m[MX][p * 16 + l] = tmp;
+      tmp = S.m[MY][k * 16 + l]; S.m[MY][k * 16 + l] = S.m[MY][p * 16 + l]; S.m[MY][p * 16 + l] = tmp;
+    }
+    __syncthreads();
+    const double f = (in && j != k) ? S.m[MX][j * 16 + k] / S.m[MX][k * 16 + k] : 0.0;
+    const double xk = in ? S.m[MX][k * 16 + l] : 0.0, yk = in ? S.m[MY][k * 16 + l] : 0.0;
+    __syncthreads();
+    if (in && j != k) {
+      S.m[MX][tid] = fma(-f, xk, S.m[MX][tid]);
+      S.m[MY][tid] = fma(-f, yk, S.m[MY][tid]);
+    }
+    __syncthreads();
+  }
+  if (in) S.m[MY][tid] *= 1.0 / S.m[MX][j * 16 + j];
+  __syncthreads();
+  {
+    const double wj = mv(0.0, MY, true, VU);                                    // w = Y^T u
+    const double yv = mv(0.0, MY, false, VV);                                   // Y v
+    const double a = mm(0.0, MA, false, MY, false);                             // A Y
+    S.m[MT][tid] = mm(0.0, MJ, false, MY, false);                               // Jm Y
+    if (l == 0) { S.v[VW][j] = wj; S.v[VYV][j] = yv; }
+    __syncthreads();
+    const double gj = -mv(-S.v[VETA][j], MJ, false, VYV);                       // g = eta - Jm (Y v)
+    if (in) {
+      state[ws.elem(c, oA + j * J + l, draw)] = a;
+      state[ws.elem(c, oC + j * J + l, draw)] = 0.5 * gL * (S.v[VW][j] * S.v[VW][l] - 0.5 * (S.m[MT][j * 16 + l] + S.m[MT][l * 16 + j]));
+    }
+    if (l == 0 && j < J) {
+      state[ws.elem(c, ob + j, draw)] = gj;
+      state[ws.elem(c, oeta + j, draw)] = gL * S.v[VW][j];
+    }
+  }
+}
+
 // two levels of a scan in one launch, one lane per item of the upper one (tree_item4_*_lane; J <= 2)
 #ifndef EXO_GP_TREE4
 #define EXO_GP_TREE4 1
@@ -2142,6 +2235,23 @@ static_assert(kLaneMaxJ <= 6, "EXO_GP_DISPATCH_LANE lists the state widths of th
     case 16: { constexpr int JJ = 16; CALL; } break; \
     default: return EXO_ERR_INVALID_ARGUMENT;      \
   }
+// kernels whose wide instantiations exist only when the LDS kernels for wide states are switched off (EXO_GP_WIDE_LDS = 0)
+#if EXO_GP_WIDE_LDS
+#define EXO_GP_DISPATCH_LE8(J_, CALL) \
+  switch (J_) {                       \
+    case 1: { constexpr int JJ = 1; CALL; } break; \
+    case 2: { constexpr int JJ = 2; CALL; } break; \
+    case 3: { constexpr int JJ = 3; CALL; } break; \
+    case 4: { constexpr int JJ = 4; CALL; } break; \
+    case 5: { constexpr int JJ = 5; CALL; } break; \
+    case 6: { constexpr int JJ = 6; CALL; } break; \
+    case 7: { constexpr int JJ = 7; CALL; } break; \
+    case 8: { constexpr int JJ = 8; CALL; } break; \
+    default: return EXO_ERR_INVALID_ARGUMENT;      \
+  }
+#else
+#define EXO_GP_DISPATCH_LE8(J_, CALL) EXO_GP_DISPATCH(J_, CALL)
+#endif
 // the SEQUENTIAL kernels (and the O(N) utilities) take state widths up to EXO_GP_MAX_J = 16 (a draw on a DPP row of 16 lanes
 // above 8): celerite2, the reference's dependency (setup.py:36), has no limit, and two RotationTerms + an SHO term -- J = 10 --
 // is an ordinary stellar-variability model.  The time-parallel path stops at 8 (kChunkMaxJ): wider states run the recurrences
@@ -2505,8 +2615,13 @@ static int celerite_vjp(const double* t, Series resid, const double* diag, int64
     const ChunkWs ws = chunk_ws(n, n_draw, J, cg);
     const dim3 per_draw((unsigned)((n_draw + kWave - 1) / kWave)), cgrid(grid.x, (unsigned)cg.C),
         egrid(per_draw.x, (unsigned)cg.C);
-    EXO_GP_DISPATCH(J, hipLaunchKernelGGL((celerite_badj_prep_kernel<JJ>), dim3(per_draw.x, (unsigned)(cg.C - 1)), block,
-                                          0, st, gloglike, n, n_draw, wstate, cg, cf.row))
+    if (EXO_GP_WIDE_LDS && J >= kWideMinJ) {
+      hipLaunchKernelGGL(celerite_badj_prep_wide_kernel, dim3((unsigned)n_draw, (unsigned)(cg.C - 1)), dim3(256), 0, st, gloglike, n,
+                         n_draw, J, wstate, cg, cf.row);
+    } else {
+      EXO_GP_DISPATCH_LE8(J, hipLaunchKernelGGL((celerite_badj_prep_kernel<JJ>), dim3(per_draw.x, (unsigned)(cg.C - 1)), block,
+                                                0, st, gloglike, n, n_draw, wstate, cg, cf.row))
+    }
     if (cg.lane) {
       // draws flagged kFlagRobust: those inputs once more, from the chunks' own reverse recurrences (chunk_adj_lane)
       EXO_GP_DISPATCH_LANE(J, hipLaunchKernelGGL((celerite_chunk_adj_kernel<JJ>), dim3((unsigned)(cg.C - 1), (unsigned)((n_draw + kAdjDraws - 1) / kAdjDraws)), block, 0,
