@@ -58,15 +58,18 @@ struct Group {
 
 // In-register lane exchange (DPP) -- an ds_bpermute-based __shfl costs ~100+ cycles of
 // latency on the sequential chain; quad_perm / row_shl / row_shr moves cost a few.
+// (bound_ctrl: a lane whose source lies outside its row reads 0 -- what `old` = 0 gave; with it the destination needs no
+// zero written first: two moves fewer per exchanged double, a fifth of a butterfly step)
 template <int CTRL>
 __device__ __forceinline__ double dpp_mov(double v) {
   int lo = __double2loint(v), hi = __double2hiint(v);
-  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, false);
-  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, false);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
   return __hiloint2double(hi, lo);
 }
 constexpr int kRowShl4 = 0x104, kRowShr4 = 0x114;  // lane i reads lane i+4 / i-4 (same row of 16)
 constexpr int kRowShl8 = 0x108, kRowShr8 = 0x118;  // ... i+8 / i-8
+constexpr int kRowMirror = 0x140, kRowHalfMirror = 0x141;   // lane i reads lane 15 - i of its row / lane 7 - i of its half row
 
 // value held by the lane at distance 4 inside an aligned group of 8 (lane ^ 4)
 __device__ __forceinline__ double xor4(double v) {
@@ -168,12 +171,15 @@ __device__ __forceinline__ double xor_get(double v) {
 }
 
 // sum over the G lanes of a group, result in every lane
+// (after the two quad steps every lane of a quad holds the quad's sum, so the partner of the later steps may be ANY lane of the
+// other quad / the other half row: the mirrored lane, one DPP move -- lane ^ 4 and lane ^ 8 take a shift each way and a select.
+// The same two numbers are added: bit for bit the butterfly's sums.  Five of these per cadence in the reverse kernel.)
 template <int G>
 __device__ __forceinline__ double group_sum(double v) {
   if (G >= 2) v += xor_get<1>(v);
   if (G >= 4) v += xor_get<2>(v);
-  if (G >= 8) v += xor_get<4>(v);
-  if (G >= 16) v += xor_get<8>(v);
+  if (G >= 8) v += dpp_mov<kRowHalfMirror>(v);
+  if (G >= 16) v += dpp_mov<kRowMirror>(v);
   return v;
 }
 
@@ -729,26 +735,88 @@ struct LaneDelta {
     }
   }
   // cs, sn: cos / sin (d t_n) of the lane's pair (from lane_uv)
+  // Branch-free: a row has its diagonal entry and, for a pair, the entry of the pair's other index -- two values worked out once,
+  // then two selects per entry.  (A real or idle lane has dq = dr = 0 and (cs, sn) = (1, 0) from lane_uv: the pair formulas give
+  // dp and 0 there.)  As nested ifs inside the unrolled loop this was ~4 divergent branch regions per ENTRY in the element
+  // kernel's cadence loop: 47 of them per cadence at J = 10, a third of the 1030 instructions it issued.
   template <int J>
   __device__ __forceinline__ void row(const LaneCoef& k, int j, double cs, double sn, double* D) const {
+    const double v_even = dp * cs * cs + 2.0 * dq * cs * sn + dr * sn * sn;
+    const double v_odd = dp * sn * sn - 2.0 * dq * cs * sn + dr * cs * cs;
+    const double v_off = (dp - dr) * cs * sn + dq * (sn * sn - cs * cs);
+    const bool pair = k.live && !k.real;
+    const double vd = k.live ? (k.real ? dp : (k.odd ? v_odd : v_even)) : 0.0;
+    const double vo = pair ? v_off : 0.0;
+    const int jo = pair ? (k.odd ? j - 1 : j + 1) : -1;
 #pragma unroll
-    for (int l = 0; l < J; ++l) {
-      double v = 0.0;
-      if (k.live) {
-        if (k.real) {
-          if (l == j) v = dp;
-        } else if (!k.odd) {
-          if (l == j) v = dp * cs * cs + 2.0 * dq * cs * sn + dr * sn * sn;
-          if (l == j + 1) v = (dp - dr) * cs * sn + dq * (sn * sn - cs * cs);
-        } else {
-          if (l == j - 1) v = (dp - dr) * cs * sn + dq * (sn * sn - cs * cs);
-          if (l == j) v = dp * sn * sn - 2.0 * dq * cs * sn + dr * cs * cs;
-        }
-      }
-      D[l] = v;
-    }
+    for (int l = 0; l < J; ++l) D[l] = (l == j) ? vd : ((l == jo) ? vo : 0.0);
   }
 };
+
+// The REFERENCE STEP of a chunk for one state index (DrawCoef::step / rot_uv of the one-lane kernels, on a lane).  The lane-group
+// kernels used to take sin / cos of d (t - t0) and exp(-c dt) afresh at every cadence -- ~130 of the 500-700 instructions a
+// cadence issued at J = 10, the propagators re-evaluated two steps out of three because "evenly sampled" steps differ in their
+// last bits.  Here the chunk's first step is the reference: exp(-c dt_ref), (cos, sin)(d dt_ref) once, and a step within 2^-20
+// of it takes them corrected to second order in del = dt - dt_ref (exact to 1e-16 when max(|c|, |d|) dt_ref <= 8); the pair's
+// (cos, sin) are ROTATED from the neighbouring cadence and taken exactly at every fourth cadence of the chunk (three rotations
+// in a row drift by ~3e-16), at gaps, and for terms too fast for the correction.  Two equal steps off the reference in a row
+// become the new reference.
+#ifndef EXO_LG_REF_STEP
+#define EXO_LG_REF_STEP 1
+#endif
+struct LaneStepper {
+  double dt_ref = -1.0, dt_miss = -1.0, ph = 1.0, rc = 1.0, rs = 0.0;
+  bool near_ok = false;
+  __device__ __forceinline__ void set_ref(const LaneCoef& k, double dt) {
+    dt_ref = dt;
+    ph = k.live ? exp(-k.c * dt) : 0.0;
+    rc = 1.0; rs = 0.0;
+    if (k.live && !k.real) exo::sincos_any(k.d * dt, &rs, &rc);
+    near_ok = fmax(fabs(k.c), fabs(k.d)) * dt <= 8.0 && dt > 0.0;
+  }
+  // the propagator of the step dt; true: the step is near the reference (rot / rot_back may follow)
+  __device__ __forceinline__ bool step(const LaneCoef& k, double dt, double* P) {
+    constexpr double kTol = 9.5367431640625e-07;   // 2^-20
+    if (!EXO_LG_REF_STEP) {
+      *P = k.live ? exp(-k.c * dt) : 0.0;
+      return false;
+    }
+    if (dt_ref < 0.0) set_ref(k, dt);
+    bool near = near_ok && fabs(dt - dt_ref) <= kTol * dt_ref;
+    if (!near) {
+      if (dt_miss > 0.0 && fabs(dt - dt_miss) <= kTol * dt_miss) {
+        set_ref(k, dt);
+        near = near_ok;
+      }
+      dt_miss = dt;
+    }
+    if (near) {
+      const double x = k.c * (dt - dt_ref);
+      *P = ph * fma(x, fma(0.5, x, -1.0), 1.0);
+    } else {
+      *P = k.live ? exp(-k.c * dt) : 0.0;
+    }
+    return near;
+  }
+  // the pair's (cos, sin) one near step dt LATER / EARLIER than the cadence they belong to (a real or idle lane's (1, 0) stays)
+  __device__ __forceinline__ void rot(const LaneCoef& k, double dt, double& cs, double& sn) const {
+    const double c1 = fma(cs, rc, -sn * rs), s1 = fma(sn, rc, cs * rs);
+    const double e = k.d * (dt - dt_ref), h = fma(-0.5 * e, e, 1.0);
+    cs = fma(-e, s1, c1 * h);
+    sn = fma(e, c1, s1 * h);
+  }
+  __device__ __forceinline__ void rot_back(const LaneCoef& k, double dt, double& cs, double& sn) const {
+    const double c1 = fma(cs, rc, sn * rs), s1 = fma(sn, rc, -cs * rs);
+    const double e = k.d * (dt - dt_ref), h = fma(-0.5 * e, e, 1.0);
+    cs = fma(e, s1, c1 * h);
+    sn = fma(-e, c1, s1 * h);
+  }
+};
+// U_j, V_j from the pair's (cos, sin) (lane_uv's last lines)
+__device__ __forceinline__ void lane_uv_from(const LaneCoef& k, double cs, double sn, double* U, double* V) {
+  *U = k.odd ? (k.a * sn - k.b * cs) : (k.a * cs + k.b * sn);
+  *V = k.live ? (k.odd ? sn : cs) : 0.0;
+}
 
 // (A) in lane-group form: the element of a (draw, chunk) on the draw's G lanes, lane j owning row j of
 // A, Cm, Jm.  Same arithmetic as celerite_elem_kernel; the column sums A^T U travel by a butterfly,
@@ -788,11 +856,12 @@ __global__ __launch_bounds__(kWave) void celerite_elem_lg_kernel(
   double Acol[J], Crow[J], Jrow[J], Dl[J], phiall[J];
 #pragma unroll
   for (int l = 0; l < J; ++l) { Acol[l] = (live && l == j) ? 1.0 : 0.0; Crow[l] = 0.0; Jrow[l] = 0.0; phiall[l] = 1.0; }
-  double bj = 0.0, etaj = 0.0, phi = 1.0, dt_prev = -1.0;
+  double bj = 0.0, etaj = 0.0, phi = 1.0;
   double ti = t[n0];
   double Uj, Vj, cs, sn;
   lane_uv(k, ti, &Uj, &Vj, &cs, &sn);
   ld.row<J>(k, j, cs, sn, Dl);
+  LaneStepper stp;
 #pragma unroll 1
   for (int64_t i = n0; i < n1; ++i) {
     const double yi = y[i], R = dg[i];
@@ -807,33 +876,36 @@ __global__ __launch_bounds__(kWave) void celerite_elem_lg_kernel(
     }
     const double s = R + group_sum<G>(Uj * cuj);
     const double zeta = yi - group_sum<G>(Uj * bj);
-    const double is = 1.0 / s;
+    const double is = exo::fast_rcp(s);
     double rall[J];
     EXO_GROUP_GATHER(rj, rall);
-    etaj = fma(rj * is, zeta, etaj);
+    const double ris = rj * is;
+    etaj = fma(ris, zeta, etaj);
 #pragma unroll
-    for (int l = 0; l < J; ++l) Jrow[l] = fma(rj * is, rall[l], Jrow[l]);
+    for (int l = 0; l < J; ++l) Jrow[l] = fma(ris, rall[l], Jrow[l]);
     if (i + 1 < n) {
       const double tn = t[i + 1], dt = tn - ti;
       ti = tn;
-      if (dt != dt_prev) {   // wave-uniform: evenly sampled series reuse the propagators
-        phi = live ? exp(-k.c * dt) : 0.0;
-        EXO_GROUP_GATHER(phi, phiall);
-        dt_prev = dt;
+      const bool near = stp.step(k, dt, &phi);
+      EXO_GROUP_GATHER(phi, phiall);
+      if (near && ((i + 1 - n0) & 3) != 0) {
+        stp.rot(k, dt, cs, sn);
+        lane_uv_from(k, cs, sn, &Uj, &Vj);
+      } else {
+        lane_uv(k, tn, &Uj, &Vj, &cs, &sn);
       }
-      lane_uv(k, tn, &Uj, &Vj, &cs, &sn);
       double Dn[J];
       ld.row<J>(k, j, cs, sn, Dn);
-      const double kj = cuj * is;
+      const double kj = cuj * is;            // the gain of my state index
       bj = phi * fma(kj, zeta, bj);
-      double cuall[G >= EXO_GATHER_LDS_MIN_G ? J : 1];
-      if constexpr (G >= EXO_GATHER_LDS_MIN_G) group_gather_lds<G, J>(cuj, cuall);
+      // what the updates need of the OTHER indices is their gains k_l = (Cm U)_l / s (gathered once, instead of (Cm U)_l with a
+      // multiplication by 1 / s per entry):  A[l][j] = phi_l (A[l][j] - k_l r_j),   Cm[j][l] = phi_j phi_l (Cm[j][l] - (Cm U)_j k_l) + Q
+      double kall[J];
+      EXO_GROUP_GATHER(kj, kall);
 #pragma unroll
       for (int l = 0; l < J; ++l) {
-        double cul;
-        if constexpr (G >= EXO_GATHER_LDS_MIN_G) cul = cuall[l]; else cul = group_get<G>(cuj, l);
-        Acol[l] = phiall[l] * fma(-cul * is, rj, Acol[l]);                       // A[l][j] = phi_l (A[l][j] - k_l r_j)
-        Crow[l] = fma(phi * phiall[l], fma(-kj, cul, Crow[l]) - Dl[l], Dn[l]);   // + Q = Dn - phi phi Dl
+        Acol[l] = phiall[l] * fma(-kall[l], rj, Acol[l]);
+        Crow[l] = fma(phi * phiall[l], fma(-cuj, kall[l], Crow[l]) - Dl[l], Dn[l]);   // + Q = Dn - phi phi Dl
         Dl[l] = Dn[l];
       }
     }
@@ -894,21 +966,22 @@ __global__ __launch_bounds__(kWave) void celerite_chunk_fwd_kernel(
   const int64_t rstride = n_draw * J * (int64_t)(2 + J);   // one cadence of (W, F, S row) records
   double* __restrict__ p_vec = state + six.rec(n0, draw, jj);
   double* __restrict__ p_scal = state + six.scal(0, n0, draw);
-  double tprev = t[n0 > 0 ? n0 - 1 : 0], dt_prev = -1.0, Pj = 1.0;
+  double tprev = t[n0], Pj = 1.0;
+  double cs_ = 1.0, sn_ = 0.0;
+  LaneStepper stp;
 #pragma unroll 1
   for (int64_t i = n0; i < n1; ++i) {
-    // U, V, P recomputed (same arithmetic as the pre-pass): three arrays fewer through HBM
+    // U, V, P recomputed, not read: three arrays fewer through HBM (LaneStepper: from the chunk's reference step)
     const double ti = t[i], dt = ti - tprev;
     tprev = ti;
-    double Uj, Vj, cs_, sn_;
-#ifdef EXO_EXP_NOTRIG
-    Uj = k.a + 1e-9 * ti; Vj = 1.0;
-#else
-    lane_uv(k, ti, &Uj, &Vj, &cs_, &sn_);
-#endif
-    if (dt != dt_prev) {   // wave-uniform: evenly sampled series reuse P
-      Pj = k.live ? exp(-k.c * dt) : 0.0;
-      dt_prev = dt;
+    double Uj, Vj;
+    bool near = false;
+    if (i > n0) near = stp.step(k, dt, &Pj);
+    if (near && ((i - n0) & 3) != 0) {
+      stp.rot(k, dt, cs_, sn_);
+      lane_uv_from(k, cs_, sn_, &Uj, &Vj);
+    } else {
+      lane_uv(k, ti, &Uj, &Vj, &cs_, &sn_);
     }
     const double yi = y[i], gi = dg[i];
     if (i > n0) {
@@ -926,7 +999,7 @@ __global__ __launch_bounds__(kWave) void celerite_chunk_fwd_kernel(
     d = gi + asum - pd;
     z = yi - pz;
     bad = bad || !(d > 0.0);
-    const double id = 1.0 / d;
+    const double id = exo::fast_rcp(d);
     Wj = (Vj - uj) * id;
     EXO_GROUP_GATHER(Wj, Wall);
     acc = fma(z * z, id, acc);
@@ -993,7 +1066,8 @@ __global__ __launch_bounds__(kWave) void celerite_chunk_vjp_kernel(
       for (int l = 0; l < J; ++l) S_[l] = 0.0;
     }
   };
-  double dt_prev = -1.0, Pcache = 1.0;
+  LaneStepper stp;
+  bool near_last = false;   // the step reversed last -- (i - 1) -> i -- was near the reference: cadence i - 1's (cos, sin) by rot_back
   constexpr int kPer = G >= 8 ? 1 : 8 / G;   // (G = 16: lanes 0 .. 7 of the row keep one cadence each)
   double buf_r[kPer], buf_d[kPer];
   unsigned have = 0u;
@@ -1004,11 +1078,8 @@ __global__ __launch_bounds__(kWave) void celerite_chunk_vjp_kernel(
   // those of W_{i-1}, d_{i-1}, z_{i-1}
   auto propagate_adjoint = [&](int64_t i, double d_p, double z_p, double W_p, double F_p, const double* S_p) {
     const double dt = t[i] - t[i - 1];
-    if (dt != dt_prev) {   // wave-uniform: evenly sampled series reuse P
-      Pcache = k.live ? exp(-k.c * dt) : 0.0;
-      dt_prev = dt;
-    }
-    const double Pj = Pcache;
+    double Pj;
+    near_last = stp.step(k, dt, &Pj);
     double Pall[J], Wpall[J];
     EXO_GROUP_GATHER(Pj, Pall);
     EXO_GROUP_GATHER(W_p, Wpall);
@@ -1017,18 +1088,21 @@ __global__ __launch_bounds__(kWave) void celerite_chunk_vjp_kernel(
     const double Gb = Fb * Pj;
     double Wb_prev = Gb * z_p;
     const double zb_prev = group_sum<G>(Gb * W_p);
-    double psum = 0.0, wsum = 0.0, dsum = 0.0;
+    // (five operations per entry: q = Sb P_l serves the adjoint of T and the propagator's cotangent, and the two sums over
+    // Tb W_l -- for Wb and for db -- are one sum; nine as first written, of the ~570 vector instructions a cadence issued at J = 10)
+    double psum = 0.0, dsum = 0.0;
+    const double dw = d_p * W_p;
 #pragma unroll
     for (int l = 0; l < J; ++l) {
-      const double T = fma(d_p * W_p, Wpall[l], S_p[l]);
-      const double Tb = Sb[l] * Pj * Pall[l];
-      psum = fma(2.0 * Sb[l] * T, Pall[l], psum);
-      wsum = fma(2.0 * Tb, Wpall[l], wsum);
+      const double T = fma(dw, Wpall[l], S_p[l]);
+      const double q = Sb[l] * Pall[l];
+      const double Tb = q * Pj;
+      psum = fma(q, T, psum);
       dsum = fma(Tb, Wpall[l], dsum);
       Sb[l] = Tb;
     }
-    Pb += psum;
-    Wb_prev = fma(d_p, wsum, Wb_prev);
+    Pb = fma(2.0, psum, Pb);
+    Wb_prev = fma(2.0 * d_p, dsum, Wb_prev);
     const double db_prev = group_sum<G>(dsum * W_p);
     gc = fma(-dt * Pj, Pb, gc);
     db = db_prev; zb = zb_prev; Fb = Gb; Wb = Wb_prev;
@@ -1053,16 +1127,22 @@ __global__ __launch_bounds__(kWave) void celerite_chunk_vjp_kernel(
   double d_n, z_n, W_n, F_n, S_n[J];
   load(n1 - 1, d_n, z_n, W_n, F_n, S_n);
   if (n1 < n) propagate_adjoint(n1, d_n, z_n, W_n, F_n, S_n);
+  double cs = 1.0, sn = 0.0;
 #pragma unroll 1
   for (int64_t i = n1 - 1; i >= n0; --i) {
     // measurement half of cadence i
     const double ti = t[i];
     const double dt_next = (i + 1 < n) ? t[i + 1] - ti : 0.0;
-    double Uj, Vj, cs, sn;
-    lane_uv(k, ti, &Uj, &Vj, &cs, &sn);
+    double Uj, Vj;
+    if (i < n1 - 1 && near_last && ((i - n0) & 3) != 0) {   // (cos, sin) of cadence i from cadence i + 1's, one near step back
+      stp.rot_back(k, dt_next, cs, sn);
+      lane_uv_from(k, cs, sn, &Uj, &Vj);
+    } else {
+      lane_uv(k, ti, &Uj, &Vj, &cs, &sn);
+    }
     double Uall[J];
     EXO_GROUP_GATHER(Uj, Uall);
-    const double id = 1.0 / d_n;
+    const double id = exo::fast_rcp(d_n);   // (seed + two Newton steps, as the one-lane kernels: a third of the IEEE sequence)
     const double zbar = zb - gL * z_n * id;
     const double wdot = group_sum<G>(Wb * W_n);
     const double dbar = db + gL * (0.5 * z_n * z_n * id * id - 0.5 * id) - wdot * id;
@@ -1102,9 +1182,10 @@ __global__ __launch_bounds__(kWave) void celerite_chunk_vjp_kernel(
     double uball[J];
     EXO_GROUP_GATHER(ubj, uball);
     double acc_u = 0.0;
+    const double ubh = 0.5 * ubj, Uh = 0.5 * Uj;
 #pragma unroll
     for (int l = 0; l < J; ++l) {
-      Sb[l] = fma(0.5, fma(ubj, Uall[l], uball[l] * Uj), Sb[l]);
+      Sb[l] = fma(ubh, Uall[l], fma(uball[l], Uh, Sb[l]));   // symmetrised  ub U^T
       acc_u = fma(S_n[l], uball[l], acc_u);
     }
     Ub += acc_u;
