@@ -1045,10 +1045,11 @@ __global__ __launch_bounds__(kWave) void celerite_chunk_vjp_kernel(
   const int partner = (int)threadIdx.x + ((k.live && !k.real) ? (k.odd ? -1 : 1) : 0);
   GradRow grow(gresid, rs, draw, n);
 
+  const double gsc = cg.prep ? gL : 1.0;   // (ChunkGeom::prep: the scan's adjoints are those of a cotangent of one)
   double Sb[J];
 #pragma unroll
-  for (int l = 0; l < J; ++l) Sb[l] = k.live ? state[ws.bnd(2, c, J + jj * J + l, draw)] : 0.0;
-  double Fb = k.live ? state[ws.bnd(2, c, jj, draw)] : 0.0;
+  for (int l = 0; l < J; ++l) Sb[l] = k.live ? gsc * state[ws.bnd(2, c, J + jj * J + l, draw)] : 0.0;
+  double Fb = k.live ? gsc * state[ws.bnd(2, c, jj, draw)] : 0.0;
   double Wb = 0.0, db = 0.0, zb = 0.0, gasum = 0.0;
   double ga = 0.0, gb = 0.0, gc = 0.0, gd = 0.0;
 
@@ -1577,7 +1578,7 @@ __global__ __launch_bounds__(256) void celerite_badj_prep_wide_kernel(const doub
   const int c = (int)blockIdx.y + 1;
   const bool in = j < J && l < J;
   const ChunkWs ws = chunk_ws(n, n_draw, J, cg);
-  const double gL = gloglike[row ? (int64_t)row[draw] : draw];
+  const double gL = gloglike ? gloglike[row ? (int64_t)row[draw] : draw] : 1.0;   // (null: a cotangent of one -- ChunkGeom::prep)
   const int oA = 0, ob = J * J, oC = J * J + J, oeta = 2 * J * J + J, oJ = 2 * J * J + 2 * J;
   enum { MA = 0, MJ, MP, MX, MY, MT };
   enum { VM = 0, VETA, VU, VV, VW, VYV, VD };
@@ -2208,6 +2209,7 @@ extern "C" {
 
 int64_t exo_celerite_state_doubles(int64_t n, int64_t n_draw, int32_t n_real, int32_t n_complex, int32_t n_chunks) {
   const int64_t J = n_real + 2 * (int64_t)n_complex;
+  if (n_chunks >= 0) n_chunks &= ~EXO_GP_PREPARE_ADJOINT;   // (the flag changes nothing in the workspace)
   if (n < 0 || n_draw < 0 || J < 1 || J > EXO_GP_MAX_J || n_chunks < 0) return -1;
   const int64_t base = seq_state_doubles(n, n_draw, (int)J);
   if (n == 0 || n_draw == 0) return base;
@@ -2507,10 +2509,124 @@ __global__ __launch_bounds__(kWave, EXO_VJP1_WAVES) void celerite_chunk1_vjp_mix
     if (rc_ != EXO_OK) return rc_;                                                                        \
   }
 
+// ---- the adjoint scan beside the forward chunk kernel (EXO_GP_PREPARE_ADJOINT, include/exoplanet_amd.h) -------------------------
+// What the reverse call does before its chunk kernel -- adjoint elements (badj_prep), the robust route's own (chunk_adj), the
+// scan (B') as a tree: 14-26 short launches, each an item's dependent latency, 0.13-0.17 ms at the C5 shape -- needs nothing of
+// the forward chunk kernel: the elements and the entering states (B) are there before it starts, and the adjoint is LINEAR in
+// the cotangent of the log-likelihood.  With the flag the forward call works it out for a cotangent of ONE, the scan on a second
+// stream while the chunk kernel (one wave per SIMD at J >= 4, bound by its checkpoint stores) runs on the caller's, and the
+// reverse chunk kernels scale the adjoint states by the draw's cotangent as they load them (ChunkGeom::prep; a cotangent of
+// exactly 1 -- loglike.sum().backward() -- gives the bits of the serial order).  What goes where is decided by registers: a kernel
+// that needs more than the forward chunk kernel's waves leave free on a SIMD (badj_prep 482, chunk_adj 512 at J = 6 against 280
+// taken of 512) does not run beside it, it waits for it -- and everything queued behind it on its stream with it; those stay on the
+// caller's stream, in front of the fork.  chunk_adj reads the forward checkpoints of the draws on the robust route, so those
+// draws' recurrences run first and alone (ChunkGeom::which).  Inside a stream capture the second stream joins the capture
+// through the two events, so a replayed graph carries the fork; eagerly they order the streams the same way.
+#ifndef EXO_GP_SIDE_MAX_DEVICES
+#define EXO_GP_SIDE_MAX_DEVICES 64
+#endif
+struct SideStream {
+  hipStream_t s = nullptr;
+  hipEvent_t fork = nullptr, join = nullptr;
+};
+static SideStream* side_stream() {
+  // one per host thread and device: an event recorded by two threads at once would order the wrong streams
+  thread_local SideStream tl[EXO_GP_SIDE_MAX_DEVICES];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= EXO_GP_SIDE_MAX_DEVICES) return nullptr;
+  SideStream& ss = tl[dev];
+  if (!ss.s) {
+    if (hipStreamCreateWithFlags(&ss.s, hipStreamNonBlocking) != hipSuccess) { ss.s = nullptr; (void)hipGetLastError(); return nullptr; }
+    if (hipEventCreateWithFlags(&ss.fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ss.join, hipEventDisableTiming) != hipSuccess) {
+      (void)hipGetLastError();
+      return nullptr;
+    }
+  }
+  return (ss.fork && ss.join) ? &ss : nullptr;
+}
+
+// gloglike == nullptr: for a cotangent of one (the forward call's; ChunkGeom::prep)
+// parts: 1 = the adjoint elements (badj_prep, chunk_adj), 2 = the scan over them, 3 = both
+static int celerite_adjoint_scan(const double* t, Series resid, const double* diag, int64_t n_diag, int64_t n, Coefs cf,
+                                 int64_t n_draw, const double* gloglike, double* wstate, const ChunkGeom& cg, hipStream_t st,
+                                 int parts = 3) {
+  const int J = cf.J();
+  const dim3 block(kWave);
+  const ChunkWs ws = chunk_ws(n, n_draw, J, cg);
+  const dim3 per_draw((unsigned)((n_draw + kWave - 1) / kWave));
+  if (parts & 1) {
+    if (EXO_GP_WIDE_LDS && J >= kWideMinJ) {
+      hipLaunchKernelGGL(celerite_badj_prep_wide_kernel, dim3((unsigned)n_draw, (unsigned)(cg.C - 1)), dim3(256), 0, st, gloglike, n,
+                         n_draw, J, wstate, cg, cf.row);
+    } else {
+      EXO_GP_DISPATCH_LE8(J, hipLaunchKernelGGL((celerite_badj_prep_kernel<JJ>), dim3(per_draw.x, (unsigned)(cg.C - 1)), block,
+                                                0, st, gloglike, n, n_draw, wstate, cg, cf.row))
+    }
+    if (cg.lane) {
+      // draws flagged kFlagRobust: those inputs once more, from the chunks' own reverse recurrences (chunk_adj_lane)
+      EXO_GP_DISPATCH_LANE(J, hipLaunchKernelGGL((celerite_chunk_adj_kernel<JJ>), dim3((unsigned)(cg.C - 1), (unsigned)((n_draw + kAdjDraws - 1) / kAdjDraws)), block, 0,
+                                                 st, t, resid, diag, n_diag, n, cf, n_draw, gloglike, wstate, cg))
+    }
+  }
+  if (parts & 2) {
+    {
+      // (B') as a tree over positions p = C - 1 - chunk: adjoint elements of chunks C - 1 .. 1, zero initial adjoint
+      bool ok = true;
+      auto launch = [&](const TreeOp& op, bool down) {
+                  const dim3 tgrid((unsigned)(((int64_t)op.n_item * n_draw + kWave - 1) / kWave));
+                  const dim3 ggrid((unsigned)(((int64_t)op.n_item * n_draw + kScanBlock / 8 - 1) / (kScanBlock / 8)));
+                  if (EXO_GP_GROUP_TREES && J >= 3 && J <= 8) {
+                    if (down) {
+                      EXO_GP_DISPATCH_GROUP(J, hipLaunchKernelGGL((celerite_tree_group_kernel<JJ, true, true>), ggrid, dim3(kScanBlock), 0, st, op, wstate))
+                    } else {
+                      EXO_GP_DISPATCH_GROUP(J, hipLaunchKernelGGL((celerite_tree_group_kernel<JJ, true, false>), ggrid, dim3(kScanBlock), 0, st, op, wstate))
+                    }
+                  } else if (EXO_GP_WIDE_LDS && J >= kWideMinJ) {
+                    const dim3 wgrid((unsigned)((int64_t)op.n_item * n_draw));
+                    if (down) hipLaunchKernelGGL((celerite_tree_wide_kernel<true, true>), wgrid, dim3(256), 0, st, op, wstate);
+                    else hipLaunchKernelGGL((celerite_tree_wide_kernel<true, false>), wgrid, dim3(256), 0, st, op, wstate);
+                  } else if (down) {
+                    EXO_GP_DISPATCH_TREE(J, hipLaunchKernelGGL((celerite_tree_kernel<JJ, true, true>), tgrid, block, 0, st, op, wstate))
+                  } else {
+                    EXO_GP_DISPATCH_TREE(J, hipLaunchKernelGGL((celerite_tree_kernel<JJ, true, false>), tgrid, block, 0, st, op, wstate))
+                  }
+                };
+      auto seed = [&]() {
+                  ok = exo::zero_fill_async(wstate + ws.tree_state(ws.tree_top()), (int64_t)ws.B() * n_draw, st);   // (never a memset node: exo_math.hpp)
+                };
+      if (EXO_GP_TREE4 && J <= 2) {
+        tree_scan4(ws, J, true, launch,
+                   [&](const TreeOp& a, const TreeOp& b, bool down) {
+                     const dim3 tgrid((unsigned)(((int64_t)b.n_item * n_draw + kWave - 1) / kWave));
+                     if (J == 1) {
+                       if (down) hipLaunchKernelGGL((celerite_tree4_kernel<1, true, true>), tgrid, block, 0, st, a, b, wstate);
+                       else hipLaunchKernelGGL((celerite_tree4_kernel<1, true, false>), tgrid, block, 0, st, a, b, wstate);
+                     } else {
+                       if (down) hipLaunchKernelGGL((celerite_tree4_kernel<2, true, true>), tgrid, block, 0, st, a, b, wstate);
+                       else hipLaunchKernelGGL((celerite_tree4_kernel<2, true, false>), tgrid, block, 0, st, a, b, wstate);
+                     }
+                   },
+                   seed);
+      } else {
+        tree_scan_top(ws, J, true, (EXO_GP_GROUP_TREES && J >= 3 && J <= 8) ? tree_serial_level(ws, J) : ws.tree_top(), launch, seed,
+                      [&](const TreeOp& op) {
+                        const dim3 sgrid((unsigned)((n_draw + kScanBlock / 8 - 1) / (kScanBlock / 8)));
+                        EXO_GP_DISPATCH_GROUP(J, hipLaunchKernelGGL((celerite_tree_serial_group_kernel<JJ, true>), sgrid, dim3(kScanBlock), 0, st, op, wstate))
+                      });
+      }
+      if (!ok) return EXO_ERR_LAUNCH;
+    }
+  }
+  return launch_status();
+}
+
 static int celerite_fwd(const double* t, Series resid, const double* diag, int64_t n_diag, int64_t n, Coefs cf,
                         int64_t n_draw, double* loglike, double* state, int64_t state_doubles, int32_t n_chunks,
                         void* stream) {
   if (n_draw == 0) return EXO_OK;
+  const bool want_prep = n_chunks >= 0 && (n_chunks & EXO_GP_PREPARE_ADJOINT) != 0;   // (a flag riding on n_chunks: the same in both calls of a pair)
+  if (want_prep) n_chunks &= ~EXO_GP_PREPARE_ADJOINT;
   cf.origin = n > 0 ? t : nullptr;   // phases from the first time stamp (Coefs::origin)
   if (!gp_args_ok(n, n_diag, cf.n_real, cf.n_complex, n_draw, n_chunks) || !t || !resid.y || !diag || !loglike ||
       (cf.n_real > 0 && !cf.real) || (cf.n_complex > 0 && !cf.cplx))
@@ -2526,6 +2642,15 @@ static int celerite_fwd(const double* t, Series resid, const double* diag, int64
     const ChunkGeom cg = chunk_plan(n, n_draw, J, n_chunks);
     const double* only_flagged = nullptr;
     int n_slice = 0;
+    SideStream* ss = nullptr;
+    auto fork_side = [&]() -> SideStream* {   // the second stream, ordered behind everything issued on `st` so far
+      SideStream* q = side_stream();
+      if (q && (hipEventRecord(q->fork, st) != hipSuccess || hipStreamWaitEvent(q->s, q->fork, 0) != hipSuccess)) {
+        (void)hipGetLastError();
+        q = nullptr;
+      }
+      return q;
+    };
     if (cg.C <= 1) {
       const int64_t n_el = n * n_draw * J;
       hipLaunchKernelGGL(celerite_prep_kernel, dim3((unsigned)((n_el + 255) / 256)), dim3(256), 0, st, t, n, cf, n_draw,
@@ -2642,19 +2767,52 @@ static int celerite_fwd(const double* t, Series resid, const double* diag, int64
           EXO_GP_DISPATCH_LANE(J, hipLaunchKernelGGL((celerite_robust_scan_kernel<JJ>), rgrid, block, 0, st, t, cf, n, cg, n_draw,
                                                      state))
         }
+        // (fwd_st, fwd_cg: the stream and the draws -- ChunkGeom::which -- of this launch)
+        hipStream_t fwd_st = st;
+        ChunkGeom fwd_cg = cg;
         auto launch_fwd = [&](auto sp_tag) -> int {
           constexpr int SP = decltype(sp_tag)::value;
           EXO_GP_LAYOUTS(J, cf, hipLaunchKernelGGL((celerite_chunk1_fwd_kernel<(JJ <= kLaneMaxJ ? JJ : 1), NR, SP>), egrid, block, 0,
-                                                   st, t, resid, diag, n_diag, n, cf, n_draw, state, cg),
-                         hipLaunchKernelGGL(celerite_chunk1_fwd_mixed_kernel<SP>, dim3(egrid.x + 1, egrid.y, 2), block, 0, st, t, resid, diag,
-                                            n_diag, n, cf, n_draw, state, cg))
+                                                   fwd_st, t, resid, diag, n_diag, n, cf, n_draw, state, fwd_cg),
+                         hipLaunchKernelGGL(celerite_chunk1_fwd_mixed_kernel<SP>, dim3(egrid.x + 1, egrid.y, 2), block, 0, fwd_st, t, resid, diag,
+                                            n_diag, n, cf, n_draw, state, fwd_cg))
           return EXO_OK;
         };
+        if (want_prep) {
+          // the adjoint elements first, on the caller's stream: badj_prep and chunk_adj take a SIMD's whole register file (482 /
+          // 512 registers at J = 6), so beside the forward chunk kernel -- a resident wave on every SIMD -- they would only wait
+          // for it, the scan behind them.  chunk_adj reads the forward checkpoints of the draws on the robust route: their
+          // recurrences run now (ChunkGeom::which = 1; no such draw: two launches that return at once), everybody else's beside
+          // the scan.
+          int rc;
+          fwd_cg.which = 1;
+          EXO_GP_BY_SERIES(resid, launch_fwd)
+          rc = celerite_adjoint_scan(t, resid, diag, n_diag, n, cf, n_draw, nullptr, state, cg, st, 1);
+          if (rc != EXO_OK) return rc;
+          fwd_cg.which = 2;
+          ss = fork_side();
+          rc = celerite_adjoint_scan(t, resid, diag, n_diag, n, cf, n_draw, nullptr, state, cg, ss ? ss->s : st, 2);
+          if (rc != EXO_OK) return rc;
+        }
         EXO_GP_BY_SERIES(resid, launch_fwd)
       } else {
+        if (want_prep) {
+          // lane-group kernels: J = 7, 8 -- badj_prep fills the register file: first, on the caller's stream; J >= 9 -- a
+          // block per item, 81 registers: with the scan on the second stream
+          const bool wide = EXO_GP_WIDE_LDS && J >= kWideMinJ;
+          int rc = EXO_OK;
+          if (!wide) rc = celerite_adjoint_scan(t, resid, diag, n_diag, n, cf, n_draw, nullptr, state, cg, st, 1);
+          if (rc != EXO_OK) return rc;
+          ss = fork_side();
+          rc = celerite_adjoint_scan(t, resid, diag, n_diag, n, cf, n_draw, nullptr, state, cg, ss ? ss->s : st, wide ? 3 : 2);
+          if (rc != EXO_OK) return rc;
+        }
         EXO_GP_DISPATCH(J, hipLaunchKernelGGL((celerite_chunk_fwd_kernel<JJ>), cgrid, block, 0, st, t, resid, diag, n_diag,
                                               n, cf, n_draw, state, cg))
       }
+      if (ss) {   // join: the sums below (and the caller) wait for the second stream
+        if (hipEventRecord(ss->join, ss->s) != hipSuccess || hipStreamWaitEvent(st, ss->join, 0) != hipSuccess) return EXO_ERR_LAUNCH;
+      }   // (no second stream to be had: the scan went in line, before the chunk kernel -- the reverse call expects it done)
       {
         const int S = chunk_sum_slices(cg.C, 3, n_draw, 16);   // (the last kernel's lanes add the S partials themselves)
         hipLaunchKernelGGL(celerite_chunk_slice_sum_kernel, dim3(per_draw.x, 3, (unsigned)S), block, 0, st, state + ws.off_part(), 3,
@@ -2678,6 +2836,8 @@ static int celerite_vjp(const double* t, Series resid, const double* diag, int64
                         int32_t n_chunks, double* gresid, double gsign, double* gdiag, double* gdiag_sum,
                         double* gcoef_real, double* gcoef_complex, void* stream) {
   if (n_draw == 0) return EXO_OK;
+  const bool prepared = n_chunks >= 0 && (n_chunks & EXO_GP_PREPARE_ADJOINT) != 0;   // the forward call ran the adjoint scan (celerite_adjoint_scan)
+  if (prepared) n_chunks &= ~EXO_GP_PREPARE_ADJOINT;
   cf.origin = n > 0 ? t : nullptr;   // (the forward call's)
   if (!gp_args_ok(n, n_diag, cf.n_real, cf.n_complex, n_draw, n_chunks) || !t || !resid.y || !diag || !gloglike ||
       !state || !gresid || (cf.n_real > 0 && (!cf.real || !gcoef_real)) ||
@@ -2689,71 +2849,17 @@ static int celerite_vjp(const double* t, Series resid, const double* diag, int64
   const int64_t per_wave = kWave / G;
   const dim3 grid((unsigned)((n_draw + per_wave - 1) / per_wave)), block(kWave);
   hipStream_t st = (hipStream_t)stream;
-  const ChunkGeom cg = chunk_plan(n, n_draw, J, n_chunks);   // the same plan as the forward call's
+  ChunkGeom cg = chunk_plan(n, n_draw, J, n_chunks);   // the same plan as the forward call's
+  cg.prep = prepared ? 1 : 0;
   const double* only_flagged = nullptr;
   if (cg.C > 1) {
     double* wstate = const_cast<double*>(state);   // the chunk workspace lives behind the saved factorisation
     const ChunkWs ws = chunk_ws(n, n_draw, J, cg);
     const dim3 per_draw((unsigned)((n_draw + kWave - 1) / kWave)), cgrid(grid.x, (unsigned)cg.C),
         egrid(per_draw.x, (unsigned)cg.C);
-    if (EXO_GP_WIDE_LDS && J >= kWideMinJ) {
-      hipLaunchKernelGGL(celerite_badj_prep_wide_kernel, dim3((unsigned)n_draw, (unsigned)(cg.C - 1)), dim3(256), 0, st, gloglike, n,
-                         n_draw, J, wstate, cg, cf.row);
-    } else {
-      EXO_GP_DISPATCH_LE8(J, hipLaunchKernelGGL((celerite_badj_prep_kernel<JJ>), dim3(per_draw.x, (unsigned)(cg.C - 1)), block,
-                                                0, st, gloglike, n, n_draw, wstate, cg, cf.row))
-    }
-    if (cg.lane) {
-      // draws flagged kFlagRobust: those inputs once more, from the chunks' own reverse recurrences (chunk_adj_lane)
-      EXO_GP_DISPATCH_LANE(J, hipLaunchKernelGGL((celerite_chunk_adj_kernel<JJ>), dim3((unsigned)(cg.C - 1), (unsigned)((n_draw + kAdjDraws - 1) / kAdjDraws)), block, 0,
-                                                 st, t, resid, diag, n_diag, n, cf, n_draw, gloglike, wstate, cg))
-    }
-    {
-      // (B') as a tree over positions p = C - 1 - chunk: adjoint elements of chunks C - 1 .. 1, zero initial adjoint
-      bool ok = true;
-      auto launch = [&](const TreeOp& op, bool down) {
-                  const dim3 tgrid((unsigned)(((int64_t)op.n_item * n_draw + kWave - 1) / kWave));
-                  const dim3 ggrid((unsigned)(((int64_t)op.n_item * n_draw + kScanBlock / 8 - 1) / (kScanBlock / 8)));
-                  if (EXO_GP_GROUP_TREES && J >= 3 && J <= 8) {
-                    if (down) {
-                      EXO_GP_DISPATCH_GROUP(J, hipLaunchKernelGGL((celerite_tree_group_kernel<JJ, true, true>), ggrid, dim3(kScanBlock), 0, st, op, wstate))
-                    } else {
-                      EXO_GP_DISPATCH_GROUP(J, hipLaunchKernelGGL((celerite_tree_group_kernel<JJ, true, false>), ggrid, dim3(kScanBlock), 0, st, op, wstate))
-                    }
-                  } else if (EXO_GP_WIDE_LDS && J >= kWideMinJ) {
-                    const dim3 wgrid((unsigned)((int64_t)op.n_item * n_draw));
-                    if (down) hipLaunchKernelGGL((celerite_tree_wide_kernel<true, true>), wgrid, dim3(256), 0, st, op, wstate);
-                    else hipLaunchKernelGGL((celerite_tree_wide_kernel<true, false>), wgrid, dim3(256), 0, st, op, wstate);
-                  } else if (down) {
-                    EXO_GP_DISPATCH_TREE(J, hipLaunchKernelGGL((celerite_tree_kernel<JJ, true, true>), tgrid, block, 0, st, op, wstate))
-                  } else {
-                    EXO_GP_DISPATCH_TREE(J, hipLaunchKernelGGL((celerite_tree_kernel<JJ, true, false>), tgrid, block, 0, st, op, wstate))
-                  }
-                };
-      auto seed = [&]() {
-                  ok = exo::zero_fill_async(wstate + ws.tree_state(ws.tree_top()), (int64_t)ws.B() * n_draw, st);   // (never a memset node: exo_math.hpp)
-                };
-      if (EXO_GP_TREE4 && J <= 2) {
-        tree_scan4(ws, J, true, launch,
-                   [&](const TreeOp& a, const TreeOp& b, bool down) {
-                     const dim3 tgrid((unsigned)(((int64_t)b.n_item * n_draw + kWave - 1) / kWave));
-                     if (J == 1) {
-                       if (down) hipLaunchKernelGGL((celerite_tree4_kernel<1, true, true>), tgrid, block, 0, st, a, b, wstate);
-                       else hipLaunchKernelGGL((celerite_tree4_kernel<1, true, false>), tgrid, block, 0, st, a, b, wstate);
-                     } else {
-                       if (down) hipLaunchKernelGGL((celerite_tree4_kernel<2, true, true>), tgrid, block, 0, st, a, b, wstate);
-                       else hipLaunchKernelGGL((celerite_tree4_kernel<2, true, false>), tgrid, block, 0, st, a, b, wstate);
-                     }
-                   },
-                   seed);
-      } else {
-        tree_scan_top(ws, J, true, (EXO_GP_GROUP_TREES && J >= 3 && J <= 8) ? tree_serial_level(ws, J) : ws.tree_top(), launch, seed,
-                      [&](const TreeOp& op) {
-                        const dim3 sgrid((unsigned)((n_draw + kScanBlock / 8 - 1) / (kScanBlock / 8)));
-                        EXO_GP_DISPATCH_GROUP(J, hipLaunchKernelGGL((celerite_tree_serial_group_kernel<JJ, true>), sgrid, dim3(kScanBlock), 0, st, op, wstate))
-                      });
-      }
-      if (!ok) return EXO_ERR_LAUNCH;
+    if (!prepared) {
+      const int rc = celerite_adjoint_scan(t, resid, diag, n_diag, n, cf, n_draw, gloglike, wstate, cg, st);
+      if (rc != EXO_OK) return rc;
     }
     if (cg.lane) {
       auto launch_vjp = [&](auto sp_tag) -> int {

@@ -347,6 +347,10 @@ struct ChunkGeom {
   int fine;     // levels of pairwise element composition: the elements are BUILT for C << fine chunks of L >> fine
                 // cadences (that many times more lanes for the element kernel) and composed back up (0: built directly)
   int tree;     // 1: the scans over the chunks (B), (B') are trees of element compositions (lane-group path), 0: serial
+  // Set by the host per launch, not by chunk_plan (EXO_GP_PREPARE_ADJOINT: the adjoint scan runs beside the forward chunk kernel):
+  int prep;     // reverse chunk kernels: 1 = the adjoint states in bnd(2, .) were worked out for a cotangent of ONE (inside the
+                // forward call): scale them by the draw's cotangent as they are loaded (the adjoint scan is linear in it)
+  int which;    // forward chunk kernel: 0 = every draw, 1 = only draws flagged kFlagRobust, 2 = only the others
 };
 
 // chunk workspace, all [chunk][quantity][draw] (a lane is a draw: coalesced)
@@ -1184,7 +1188,7 @@ template <int J>
 EXO_HD void badj_prep_lane(const double* EXO_RESTRICT gloglike, int64_t n, int64_t n_draw, double* EXO_RESTRICT state,
                            const ChunkGeom& cg, int64_t draw, int c, const int32_t* row = nullptr) {
   const ChunkWs ws = chunk_ws(n, n_draw, J, cg);
-  const double gL = gloglike[row ? (int64_t)row[draw] : draw];
+  const double gL = gloglike ? gloglike[row ? (int64_t)row[draw] : draw] : 1.0;   // (null: a cotangent of one -- ChunkGeom::prep)
   Elem<J> el;
   el.load(state, ws, c, draw);
   double m[J], P[J][J];
@@ -1945,6 +1949,7 @@ EXO_HD void chunk1_fwd_lane(const double* EXO_RESTRICT t, Series rs, const doubl
   // the exact recurrences, all chunks at once; the scans have become the initial guess.
   const int64_t n0 = c * cg.L, n1 = (n0 + cg.L < n) ? n0 + cg.L : n;
   const ChunkWs ws = chunk_ws(n, n_draw, J, cg);
+  if (cg.which && (state[ws.off_flag() + draw] == kFlagRobust) != (cg.which == 1)) return;   // (ChunkGeom::which)
   DrawCoef<J, NR> co;
   co.init(cf, draw);
   const double asum = co.asum();
@@ -2206,15 +2211,16 @@ EXO_HD void chunk1_vjp_lane(const double* EXO_RESTRICT t, Series rs, const doubl
   const double gL = gloglike[cf.at(draw)];
   Rev<J, NR> r;
   const bool from_next = EXO_GP_POLISH && polish && n1 < n;
+  const double gsc = cg.prep ? gL : 1.0;   // (ChunkGeom::prep: the scan's adjoints are those of a cotangent of one)
 #pragma unroll
   for (int j = 0; j < J; ++j) {
-    r.Fb[j] = from_next ? state[ws.polish((polish & 1) ? 1 : 3, c + 1, j, draw)] : state[ws.bnd(2, c, j, draw)];
+    r.Fb[j] = from_next ? state[ws.polish((polish & 1) ? 1 : 3, c + 1, j, draw)] : gsc * state[ws.bnd(2, c, j, draw)];
     r.Wb[j] = 0.0;
     r.ga[j] = r.gb[j] = r.gc[j] = r.gd[j] = 0.0;
 #pragma unroll
     for (int l = 0; l < J; ++l)
       r.Sb[j][l] = from_next ? state[ws.polish((polish & 1) ? 1 : 3, c + 1, J + Sym<J>::idx(j, l), draw)]
-                             : state[ws.bnd(2, c, J + j * J + l, draw)];
+                             : gsc * state[ws.bnd(2, c, J + j * J + l, draw)];
   }
   r.db = r.zb = r.gasum = 0.0;
   double phi[J];
@@ -2519,14 +2525,15 @@ EXO_HD void chunkp_vjp_lane(const double* EXO_RESTRICT t, Series rs, const doubl
   const double gL = gloglike[cf.at(draw)];
   RevP<J, NR> r;
   const bool from_next = EXO_GP_POLISH && polish && n1 < n;   // (polish: entered with what the next chunk's reverse recurrences left, chunk1_fwd_lane)
+  const double gsc = cg.prep ? gL : 1.0, hsc = 0.5 * gsc;   // (ChunkGeom::prep: the scan's adjoints are those of a cotangent of one)
 #pragma unroll
   for (int j = 0; j < J; ++j) {
-    r.Fb[j] = from_next ? state[ws.polish((polish & 1) ? 1 : 3, c + 1, j, draw)] : state[ws.bnd(2, c, j, draw)];
+    r.Fb[j] = from_next ? state[ws.polish((polish & 1) ? 1 : 3, c + 1, j, draw)] : gsc * state[ws.bnd(2, c, j, draw)];
     r.Wb[j] = 0.0;
 #pragma unroll
     for (int l = j; l < J; ++l)   // (the adjoint scan leaves a symmetric matrix)
       r.Sb(j, l) = from_next ? state[ws.polish((polish & 1) ? 1 : 3, c + 1, J + Sym<J>::idx(j, l), draw)]
-                             : 0.5 * (state[ws.bnd(2, c, J + j * J + l, draw)] + state[ws.bnd(2, c, J + l * J + j, draw)]);
+                             : hsc * (state[ws.bnd(2, c, J + j * J + l, draw)] + state[ws.bnd(2, c, J + l * J + j, draw)]);
   }
   r.db = r.zb = 0.0;
   r.g = gacc; r.gs = gstride;
@@ -2724,7 +2731,7 @@ EXO_HD void chunk_adj_lane(const double* EXO_RESTRICT t, Series rs, const double
   const double asum = co.asum();
   const SeriesRowDesc y(rs, draw, n);
   const double* EXO_RESTRICT dg = diag + (n_diag == 1 ? 0 : cf.at(draw) * n);
-  const double gL = gloglike[cf.at(draw)];
+  const double gL = gloglike ? gloglike[cf.at(draw)] : 1.0;   // (null: a cotangent of one -- ChunkGeom::prep)
   constexpr bool all = ALL;
   const bool do_state = all || role == 0, is_R = all || role == J + 1, do_vec = all || role != 0;
   RevP<J, NR, true> r;

@@ -11,6 +11,13 @@ from .terms import Term
 __all__ = ["GaussianProcess", "celerite_loglike", "celerite_loglike_sparse"]
 
 MAX_J = 16     # (every width on the time-parallel path since round 6 -- include/exoplanet_amd.h, EXO_GP_MAX_J)
+PREPARE_ADJOINT = 0x40000000   # EXO_GP_PREPARE_ADJOINT: or-ed into n_chunks of both calls of a pair (include/exoplanet_amd.h)
+# A forward call that autograd will follow with a reverse call may ask the library to run the adjoint scan beside the forward
+# chunk kernel.  OFF unless EXO_GP_PREPARE_ADJOINT=1 (or gp.celerite._PREPARE[0] = True): measured at the bench shapes it is a
+# wash to a loss -- the scan's short kernels are bound by memory latency, which a neighbour saturating HBM with checkpoint stores
+# stretches by about what the overlap hides (C5 -2 %, J = 10 -3 %, sparse mean -3.5 %; C3 +2.5 %, a batch with draws on the
+# robust route +11 %: DESIGN.md section 7).
+_PREPARE = [os.environ.get("EXO_GP_PREPARE_ADJOINT", "0").strip() not in ("0", "")]
 
 
 def default_chunks():
@@ -67,6 +74,8 @@ class _CeleriteLogLike(torch.autograd.Function):
         n_chunks = int(n_chunks)
         lib = _lib.load()
         need_grad = any(ctx.needs_input_grad)
+        if need_grad and _PREPARE[0]:
+            n_chunks |= PREPARE_ADJOINT     # (travels to the reverse call through ctx.dims)
         loglike = _buffer(D, device=t.device)
         # The state buffer is what the reverse pass re-reads, and it is also what lets the library run
         # the recurrences in parallel over time: a value-only call gets one too (scratch, freed on
@@ -201,6 +210,8 @@ class _CeleriteLogLikeSparse(torch.autograd.Function):
         if n_chunks == 0:     # the plan the sparse entries do best with (twice the dense plan's chunks for J <= 2: include/exoplanet_amd.h)
             n_chunks = int(lib.exo_celerite_default_chunks(N, D, n_real, n_complex, 1))
         need_grad = any(ctx.needs_input_grad)
+        if need_grad and _PREPARE[0]:
+            n_chunks |= PREPARE_ADJOINT     # (travels to the reverse call through ctx.dims)
         loglike = _buffer(D, device=t.device)
         nstate = lib.exo_celerite_state_doubles(N, D, n_real, n_complex, n_chunks)
         try:

@@ -44,8 +44,9 @@ extern "C" {
  * 12: exo_sparse_model.row_of_draw covers EVERY per-draw array of a sparse celerite call (coefficients, pair kinds, per-draw diag,
  *     loglike, gloglike, the cotangents written back: all in the caller's order, nothing to permute); exo_sparse_model_order.
  * 13: the MERGED sparse model -- exo_sparse_merge_workspace_bytes, exo_sparse_merge_layout, exo_sparse_model_merge_f64,
- *     exo_sparse_model_merged, exo_sparse_model_merge_vjp_f64: several lists per draw (planets, occultations) as one. */
-#define EXO_ABI_VERSION 13
+ *     exo_sparse_model_merged, exo_sparse_model_merge_vjp_f64: several lists per draw (planets, occultations) as one.
+ * 14: EXO_GP_PREPARE_ADJOINT, a flag or-ed into n_chunks of a celerite pair (the adjoint scan beside the forward chunk kernel). */
+#define EXO_ABI_VERSION 14
 int32_t exo_abi_version(void);
 
 /* ---------------------------------------------------------------------------
@@ -490,7 +491,18 @@ int exo_orbit_vector_vjp_f64(const double* t, int64_t n_cad, const double* param
  *                calls of a pair -- exo_celerite_state_doubles, forward, reverse -- must be given
  *                the same value (and n, n_draw, n_real, n_complex): the plan is a pure function of
  *                them, the library keeps NO state between calls (EXO_ERR_WORKSPACE if state_doubles
- *                is smaller than exo_celerite_state_doubles() of the same arguments)
+ *                is smaller than exo_celerite_state_doubles() of the same arguments).
+ *                EXO_GP_PREPARE_ADJOINT may be or-ed into it (ABI 14), again in every call of the pair: the FORWARD call then
+ *                also runs everything of the reverse pass that does not need the cotangent -- the adjoint elements of the
+ *                chunks and the scan over them, a dozen or two short, latency-bound launches -- for a cotangent of one, on a
+ *                stream of the library's own BESIDE the forward chunk kernel (forked from and joined back into `stream` by
+ *                events, so it is legal inside a stream capture and a replayed graph keeps the fork), and the REVERSE call
+ *                starts at its chunk kernel, scaling by the actual cotangent (the adjoint is linear in it; a cotangent of
+ *                exactly 1 gives the bits of the unflagged pair).  For callers that know the reverse call will follow (a
+ *                sampler's value-and-gradient step) -- and that have MEASURED it: the scan's kernels are bound by memory
+ *                latency, and beside a chunk kernel that saturates HBM with its checkpoint stores they slow down by about
+ *                what the overlap hides (C5 -2 %, J = 10 -3 %; C3 +2.5 %): the Python host side leaves
+ *                it off.  A forward call with the flag and no reverse call after it has only done work nobody reads.
  *
  * With a state buffer and n >= 64 the recurrences run in parallel over TIME (docs/DESIGN_r1_r4.md 3.5): the
  * series is cut into chunks, chunk "filtering elements" and a short per-draw scan over them give
@@ -503,6 +515,7 @@ int exo_orbit_vector_vjp_f64(const double* t, int64_t n_cad, const double* param
  * form (a <= 0 or |b d| > a c for some term) or are ill-conditioned are redone by the sequential
  * kernels on the device.
  * ------------------------------------------------------------------------- */
+#define EXO_GP_PREPARE_ADJOINT 0x40000000   /* or-ed into n_chunks: see above */
 #define EXO_GP_MAX_J 16   /* every state width takes the time-parallel path (1 .. 6: one lane per (draw, chunk); 7, 8: a draw on 8 lanes; 9 .. 16,
                              round 6: on a DPP row of 16 lanes, the scans on 256-thread blocks); the sequential recurrences are the
                              fallback for flagged draws and for series too short to cut */

@@ -78,6 +78,7 @@ def test_header_layout_constants_match_python(lib):
 
     assert int(consts["EXO_SPARSE_ORDER_MAX_DRAWS"]) == celerite.lib_max_order_draws()
     assert int(consts["EXO_GP_MAX_J"]) == celerite.MAX_J
+    assert int(re.search(r"#define\s+EXO_GP_PREPARE_ADJOINT\s+0x([0-9a-fA-F]+)", text).group(1), 16) == celerite.PREPARE_ADJOINT
     # exo_sparse_model_order rejects what it cannot sort, on the host, before any launch
     import ctypes
 
