@@ -1041,8 +1041,13 @@ def main():
         os.execv(sys.executable, launcher_argv(args.gpus, sys.argv))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE={world}")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # EXO_BENCH_SHARE_GPU=1 (test aid, tests/test_gpu_bench_ranks.py): every rank on the devices there are (rank % count) and the
+    # collective over gloo -- RCCL wants a device per rank -- so that a 1-GPU box runs the whole N-rank control flow (shards,
+    # barrier, max over ranks, rank 0's line); the aggregate is then one GPU's, shared
+    share_gpu = os.environ.get("EXO_BENCH_SHARE_GPU") == "1"
+    dev_index = local_rank % max(torch.cuda.device_count(), 1) if share_gpu else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     dist = None
     if world > 1 or os.environ.get("EXO_BENCH_FORCE_DIST") == "1":   # the env switch lets a 1-GPU box exercise the RCCL path
         import torch.distributed as dist_mod
@@ -1051,7 +1056,10 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist_mod.init_process_group("nccl", device_id=dev)
+        if share_gpu:
+            dist_mod.init_process_group("gloo")
+        else:
+            dist_mod.init_process_group("nccl", device_id=dev)
         dist = dist_mod
 
     import exoplanet_amd as xo
