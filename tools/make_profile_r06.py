@@ -105,6 +105,7 @@ solved = solved or 4.34e6
 lines = []
 for leg, D, N, J in (("c2", 1024, 150_000, 0), ("sparse", 1024, 150_000, 0), ("chi2", 1024, 150_000, 0), ("c3", 1024, 150_000, 2),
                      ("c4", 64, 200_000, 0), ("c5", 128, 65_000, 6), ("c5b", 128, 65_000, 6),
+                     ("j8", 128, 65_000, 8), ("j10", 128, 65_000, 10),
                      ("kepler", 1, 150_000_000, 0), ("quadsv", 1, 150_000_000, 0)):
     def units_of(k, D=D, N=N, leg=leg):
         if k.startswith("transit_runs_kernel") and leg in ("c2", "sparse", "chi2"):

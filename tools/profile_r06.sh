@@ -21,15 +21,18 @@ CMD[c3]="python $R/bench.py --config c3 --steps 3 --warmup 1 --no-cpu-baseline -
 CMD[c4]="python $R/bench.py --config c4 --global-draws 64 $B"
 CMD[c5]="python $R/bench.py --config c5 --global-draws 128 --steps 3 --warmup 1 --no-cpu-baseline --no-extras --no-stats --no-graph"
 CMD[c5b]="python $R/bench.py --config c5 --global-draws 128 --c5-bright 2 --steps 3 --warmup 1 --no-cpu-baseline --no-extras --no-stats --no-graph"
+CMD[j8]="python $R/tools/wide_step.py sho4 128 3"          # the C5 shape with a J = 8 kernel (four SHO terms): lane groups of eight
+CMD[j10]="python $R/tools/wide_step.py rot2_sho 128 3"     # ... J = 10 (two RotationTerms + SHO): a DPP row of sixteen, wide trees
 CMD[sparse]="python $R/tools/run_leg.py sparse 1024 10"
 CMD[chi2]="python $R/tools/run_leg.py chi2 1024 10"
 CMD[kepler]="python $R/tools/run_leg.py kepler 150000000 6"
 CMD[quadsv]="python $R/tools/run_leg.py quadsv 150000000 4"
-for leg in c2 c3 c4 c5 c5b sparse chi2 kepler quadsv; do
+for leg in c2 c3 c4 c5 c5b j8 j10 sparse chi2 kepler quadsv; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $out/${leg}_trace -o p -- ${CMD[$leg]} > $out/${leg}_trace.log 2>&1
   for c in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_WAVES SQ_INSTS_SALU" "SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY"; do
     if [ "$leg" = c4 ] && [ "$c" != "FETCH_SIZE" ] && [ "$c" != "WRITE_SIZE" ]; then continue; fi
     if [ "$leg" = c5b ] && [ "$c" != "SQ_INSTS_VALU SQ_WAVES SQ_INSTS_SALU" ]; then continue; fi   # (the robust route's kernels: durations + instructions)
+    if { [ "$leg" = j8 ] || [ "$leg" = j10 ]; } && [ "$c" = "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" ]; then continue; fi
     d=$out/${leg}_pmc_$(echo $c | tr ' ' '_' | cut -c1-30)
     rocprofv3 --pmc $c --kernel-trace --output-format csv -d $d -o p -- ${CMD[$leg]} > /dev/null 2>&1
   done
@@ -38,7 +41,7 @@ python $R/bench.py --steps 5 --no-extras --no-cpu-baseline --no-stats > $out/ben
 python $R/tools/make_profile_r06.py $out $R/profiles
 # gpurun merges at most 64 MiB of gpurun_out back: keep the summaries (and the kernel-stats tables), drop the raw traces
 mkdir -p $out/profiles && cp $R/profiles/r06_* $out/profiles/
-for leg in c2 c3 c4 c5 c5b sparse chi2 kepler quadsv; do cp $(find $out/${leg}_trace -name "*kernel_stats.csv" | head -1) $out/profiles/r06_${leg}_kernel_stats.csv 2>/dev/null; done
+for leg in c2 c3 c4 c5 c5b j8 j10 sparse chi2 kepler quadsv; do cp $(find $out/${leg}_trace -name "*kernel_stats.csv" | head -1) $out/profiles/r06_${leg}_kernel_stats.csv 2>/dev/null; done
 rm -rf $out/*_trace $out/*_pmc_*
 # the un-profiled bench line last, with this record's counters in place (roofline.traffic / .valu filled in from it)
 python $R/bench.py > $out/bench.json 2> $out/bench.err
