@@ -248,6 +248,58 @@ __device__ __forceinline__ void load_record(const double* __restrict__ p, int64_
   for (int l = 0; l < J; ++l) S[l] = v[2 + l];
 }
 
+// The lane-group CHUNK kernels (celerite_chunk_fwd_kernel / celerite_chunk_vjp_kernel) keep the S row of a record only at every
+// lg_span-th cadence of a chunk -- a CHECKPOINT -- and the reverse kernel recomputes the rows in between (one fused multiply-add
+// per entry and two all-gathers per cadence): the saved factorisation was 83 doubles per (draw, cadence) at J = 8, 123 at J = 10,
+// written at 5.5 and read back at 4.8 TB/s -- both kernels sat on the HBM ceiling at 0.24-0.45 of their issue rate
+// (profiles/r06_counters.json, legs j8 / j10).  The records keep their places (pieces 1 .. of the cadences in between are holes
+// nobody touches; piece 0 -- (W, F) of every lane -- stays one contiguous run per cadence), so the sequential kernels, which
+// write and read every S row of the draws they redo, share the layout unchanged.
+// The span is a matter of registers: the reverse kernel holds span rows of J doubles (and span records) on top of its own 170-230,
+// and what counts is staying at two waves per SIMD (256 registers): J = 10 with a span of 4 took 268 -- one wave -- and the step went
+// from 7.5 to 8.7 ms where J = 8 (240: two waves, down from three) went from 4.04 to 3.59.
+#ifndef EXO_LG_SPAN
+#define EXO_LG_SPAN 0   // (> 0: that span for every width -- A/B builds)
+#endif
+template <int J>
+constexpr int lg_span() { return EXO_LG_SPAN > 0 ? EXO_LG_SPAN : (J <= 9 ? 4 : (J <= 11 ? 3 : (J <= 14 ? 2 : 1))); }
+// (W, F) of a record alone
+template <int J>
+__device__ __forceinline__ void store_record_wf(double* __restrict__ p, int64_t ps, double W, double F) {
+  typedef double v2d __attribute__((ext_vector_type(2)));
+  if ((2 + J) % 2 == 0) {
+    const v2d x = {W, F};
+    __builtin_nontemporal_store(x, reinterpret_cast<v2d*>(p));
+  } else {
+    __builtin_nontemporal_store(W, p);
+    __builtin_nontemporal_store(F, p + ps);
+  }
+}
+template <int J>
+__device__ __forceinline__ void load_record_wf(const double* __restrict__ p, int64_t ps, double& W, double& F) {
+  if ((2 + J) % 2 == 0) {
+    const double2 x = *reinterpret_cast<const double2*>(p);
+    W = x.x; F = x.y;
+  } else {
+    W = p[0]; F = p[ps];
+  }
+}
+// the S row of a record alone
+template <int J>
+__device__ __forceinline__ void load_record_s(const double* __restrict__ p, int64_t ps, double* S) {
+  constexpr int R = 2 + J;
+  if (R % 2 == 0) {
+#pragma unroll
+    for (int q = 1; q < R / 2; ++q) {
+      const double2 x = *reinterpret_cast<const double2*>(p + q * ps);
+      S[2 * q - 2] = x.x; S[2 * q - 1] = x.y;
+    }
+  } else {
+#pragma unroll
+    for (int q = 2; q < R; ++q) S[q - 2] = p[q * ps];
+  }
+}
+
 // Pre-pass, fully parallel over (cadence, draw, state index): everything in the
 // recurrences that does not depend on the recurrence itself.
 __global__ __launch_bounds__(256) void celerite_prep_kernel(const double* __restrict__ t, int64_t n,
@@ -1009,7 +1061,8 @@ __global__ __launch_bounds__(kWave) void celerite_chunk_fwd_kernel(
 #ifndef EXO_EXP_NOSTORE
     if (store) {
       if (j == 0) *reinterpret_cast<double2*>(p_scal) = double2{d, z};
-      store_record<J>(p_vec, six.piece(), Wj, Fj, Srow);
+      if ((i - n0) % lg_span<J>() == 0) store_record<J>(p_vec, six.piece(), Wj, Fj, Srow);   // a checkpoint: the S row too
+      else store_record_wf<J>(p_vec, six.piece(), Wj, Fj);
     }
 #endif
     p_vec += rstride; p_scal += 2 * n_draw;
@@ -1057,17 +1110,21 @@ __global__ __launch_bounds__(kWave) void celerite_chunk_vjp_kernel(
   const double* __restrict__ sc0 = state + six.scal(0, 0, draw);
   const double* __restrict__ ve0 = state + six.rec(0, draw, jj);
   const int64_t rstride = vstride * (2 + J);   // one cadence of (W, F, S row) records
-  auto load = [&](int64_t i, double& d_, double& z_, double& W_, double& F_, double* S_) {
+  // (d, z, W, F) of cadence i; the S row of a CHECKPOINT cadence (lg_span: every span-th of a chunk)
+  auto load_wf = [&](int64_t i, double& d_, double& z_, double& W_, double& F_) {
     const double2 dz = *reinterpret_cast<const double2*>(sc0 + i * 2 * n_draw);
     d_ = dz.x; z_ = dz.y;
-    load_record<J>(ve0 + i * rstride, six.piece(), W_, F_, S_);   // idle lanes read lane 0's record: harmless, zeroed below
+    load_record_wf<J>(ve0 + i * rstride, six.piece(), W_, F_);   // idle lanes read lane 0's record: harmless, zeroed below
+    if (!k.live) W_ = F_ = 0.0;
+  };
+  auto load_s = [&](int64_t i, double* S_) {
+    load_record_s<J>(ve0 + i * rstride, six.piece(), S_);
     if (!k.live) {
-      W_ = F_ = 0.0;
 #pragma unroll
       for (int l = 0; l < J; ++l) S_[l] = 0.0;
     }
   };
-  LaneStepper stp;
+  LaneStepper stp, stf;   // (stf: the propagators of the recomputed steps, taken in forward order)
   bool near_last = false;   // the step reversed last -- (i - 1) -> i -- was near the reference: cadence i - 1's (cos, sin) by rot_back
   constexpr int kPer = G >= 8 ? 1 : 8 / G;   // (G = 16: lanes 0 .. 7 of the row keep one cadence each)
   double buf_r[kPer], buf_d[kPer];
@@ -1115,7 +1172,8 @@ __global__ __launch_bounds__(kWave) void celerite_chunk_vjp_kernel(
   double flux = 0.0;
   if (n1 < n) {
     double d1, z1, W1, F1, S1[J];
-    load(n1, d1, z1, W1, F1, S1);
+    load_wf(n1, d1, z1, W1, F1);
+    load_s(n1, S1);   // (the next chunk's first cadence: a checkpoint)
     const double Fb_o = __shfl(Fb, partner, 64), F1_o = __shfl(F1, partner, 64);
     double acc = Fb_o * F1 - Fb * F1_o;
 #pragma unroll
@@ -1125,12 +1183,9 @@ __global__ __launch_bounds__(kWave) void celerite_chunk_vjp_kernel(
     }
     flux = (k.live && !k.real && !k.odd) ? acc : 0.0;
   }
-  double d_n, z_n, W_n, F_n, S_n[J];
-  load(n1 - 1, d_n, z_n, W_n, F_n, S_n);
-  if (n1 < n) propagate_adjoint(n1, d_n, z_n, W_n, F_n, S_n);
   double cs = 1.0, sn = 0.0;
-#pragma unroll 1
-  for (int64_t i = n1 - 1; i >= n0; --i) {
+  // the measurement half of cadence i from its record (d, z, W, F, S row)
+  auto measure = [&](int64_t i, double d_n, double z_n, double W_n, double F_n, const double* S_n) {
     // measurement half of cadence i
     const double ti = t[i];
     const double dt_next = (i + 1 < n) ? t[i + 1] - ti : 0.0;
@@ -1201,14 +1256,48 @@ __global__ __launch_bounds__(kWave) void celerite_chunk_vjp_kernel(
         flux -= Ub * (-k.a * sn + k.b * cs) + Ub_o * (k.a * cs + k.b * sn) - Vb * sn + Vb_o * cs;
       }
     }
-    if (i == n0) break;
-    // reverse of the step (i - 1) -> i
-    double d_p, z_p, W_p, F_p, S_p[J];
-    load(i - 1, d_p, z_p, W_p, F_p, S_p);
-    propagate_adjoint(i, d_p, z_p, W_p, F_p, S_p);
-    d_n = d_p; z_n = z_p; W_n = W_p; F_n = F_p;
+  };
+  // Blocks of lg_span cadences, last to first.  A block's records are loaded at once (all in flight together), its S rows
+  // recomputed forward from the checkpoint at its first cadence -- S_i = P_i P_i^T o (S_(i-1) + d_(i-1) W_(i-1) W_(i-1)^T), the
+  // forward kernel's own line -- and its cadences walked backwards: the reverse of the step OUT of cadence i, then the
+  // measurement half of cadence i, both from cadence i's record alone.
+  constexpr int K = lg_span<J>();
+  const int64_t nblk = (n1 - n0 + K - 1) / K;
+#pragma unroll 1
+  for (int64_t bb = nblk - 1; bb >= 0; --bb) {
+    const int64_t b0 = n0 + bb * K;
+    const int len = (int)((n1 - b0 < K) ? n1 - b0 : K);   // (block-uniform: c is blockIdx.y)
+    double rd[K], rz[K], rW[K], rF[K], Sblk[K][J];
 #pragma unroll
-    for (int l = 0; l < J; ++l) S_n[l] = S_p[l];
+    for (int q = 0; q < K; ++q) {
+      if (q < len) load_wf(b0 + q, rd[q], rz[q], rW[q], rF[q]);
+      else { rd[q] = 1.0; rz[q] = rW[q] = rF[q] = 0.0; }
+    }
+    load_s(b0, Sblk[0]);
+#pragma unroll
+    for (int q = 1; q < K; ++q) {
+      if (q < len) {
+        double Pj;
+        stf.step(k, t[b0 + q] - t[b0 + q - 1], &Pj);
+        double Pall[J], Wall[J];
+        EXO_GROUP_GATHER(Pj, Pall);
+        EXO_GROUP_GATHER(rW[q - 1], Wall);
+        const double dwj = rd[q - 1] * rW[q - 1];
+#pragma unroll
+        for (int l = 0; l < J; ++l) Sblk[q][l] = Pj * Pall[l] * fma(dwj, Wall[l], Sblk[q - 1][l]);
+      } else {
+#pragma unroll
+        for (int l = 0; l < J; ++l) Sblk[q][l] = 0.0;
+      }
+    }
+#pragma unroll
+    for (int q = K - 1; q >= 0; --q) {
+      if (q < len) {
+        const int64_t i = b0 + q;
+        if (i + 1 < n) propagate_adjoint(i + 1, rd[q], rz[q], rW[q], rF[q], Sblk[q]);   // reverse of the step i -> i + 1
+        measure(i, rd[q], rz[q], rW[q], rF[q], Sblk[q]);
+      }
+    }
   }
   if (live_draw && k.live) {
     state[ws.gpart(c, 4 * j + 0, draw)] = ga;
