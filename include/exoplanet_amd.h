@@ -507,10 +507,11 @@ int exo_orbit_vector_vjp_f64(const double* t, int64_t n_cad, const double* param
  * With a state buffer and n >= 64 the recurrences run in parallel over TIME (docs/DESIGN_r1_r4.md 3.5): the
  * series is cut into chunks, chunk "filtering elements" and a short per-draw scan over them give
  * the recurrence state entering every chunk (and, in the reverse pass, its adjoint), and the
- * ordinary recurrences then run inside all chunks at once.  J <= 2: one lane per (draw, chunk) and
- * a CHECKPOINTED factorisation -- the forward pass stores the recurrence state every 4 cadences,
- * the reverse pass recomputes the cadences in between (which is why it takes the series again);
- * J > 2: a draw on next_pow2(J) lanes, the full factorisation saved.  Same results as the
+ * ordinary recurrences then run inside all chunks at once.  J <= 6: one lane per (draw, chunk) and
+ * a CHECKPOINTED factorisation -- the forward pass stores the recurrence state every 4 cadences (J <= 2) or every 2
+ * (J = 3 .. 6), the reverse pass recomputes the cadences in between (which is why it takes the series again);
+ * J > 6: a draw on 8 (J = 7, 8) or 16 lanes, (d, z, W, F) of every cadence saved and the S rows at every 2nd to 4th.
+ * Same results as the
  * sequential recurrences (1e-14 relative in loglike); draws whose terms do not admit the filter
  * form (a <= 0 or |b d| > a c for some term) or are ill-conditioned are redone by the sequential
  * kernels on the device.
