@@ -141,15 +141,23 @@ __device__ __forceinline__ int group_get_int(int v, int l) {
 #ifndef EXO_GATHER_LDS_MIN_G
 #define EXO_GATHER_LDS_MIN_G 8
 #endif
+// EXO_GATHER_SYNC = 0: no barrier at all.  A block is one wave, and the LDS operations of ONE wave execute in the order they were
+// issued: the reads see the write in front of them, and the next gather's write cannot overtake these reads.  The two
+// __syncthreads() this had were each a wait for the LDS counter to drain to zero -- every gather a full write -> read round
+// trip with nothing else in flight, 7-9 of them per cadence in the reverse kernel; without them the compiler waits only where
+// a value is used, and consecutive gathers overlap.
+#ifndef EXO_GATHER_SYNC
+#define EXO_GATHER_SYNC 0
+#endif
 template <int G, int J>
 __device__ __forceinline__ void group_gather_lds(double v, double (&out)[J]) {
   __shared__ double s_gather[kWave];
   s_gather[threadIdx.x] = v;
-  __syncthreads();
+  if (EXO_GATHER_SYNC) __syncthreads(); else __atomic_signal_fence(__ATOMIC_SEQ_CST);   // (the compiler keeps the order too; no instruction)
   const double* __restrict__ base = s_gather + (threadIdx.x & ~(G - 1));
 #pragma unroll
   for (int l = 0; l < J; ++l) out[l] = base[l];
-  __syncthreads();     // (the next gather overwrites the buffer)
+  if (EXO_GATHER_SYNC) __syncthreads(); else __atomic_signal_fence(__ATOMIC_SEQ_CST);   // (the next gather overwrites the buffer)
 }
 // (narrower groups keep the DPP loop exactly as it stood)
 #define EXO_GROUP_GATHER(v, out)                                   \
