@@ -528,9 +528,12 @@ EXO_HDH ChunkGeom chunk_plan(int64_t n, int64_t n_draw, int J, int32_t n_chunks)
     if (C < 4) C = 4;
   } else {
     const int G = J <= 1 ? 1 : (J <= 2 ? 2 : (J <= 4 ? 4 : (J <= 8 ? 8 : 16)));
-    // ~4 waves per SIMD offered to the lane-group chunk kernels (they fit 3): the scans over the chunks are
-    // trees, so more chunks cost them little
-    C = (64 * 4096) / (n_draw * G);
+    // ~4 waves per SIMD offered to the lane-group chunk kernels of a group of eight (they fit 2-4): the scans over the chunks
+    // are trees, so more chunks cost them little.  A row of sixteen (J >= 9): TWO -- its element and reverse kernels fit two
+    // waves per SIMD, so 2048 waves are one full round of them, and its wide scan items (a block of 256 threads each) are
+    // not cheap: measured at the C5 shape, J = 10 (tools/wide_chunks.py): 128 chains 6.76 -> 6.33 ms (64 chunks against 128;
+    // 48: 7.5, 80: 7.7), 32 chains 2.87 -> 2.40, 512 chains 23.0 -> 22.8; J = 8 at half its chunks: 128 chains -2 %, 512 +7 %.
+    C = (64 * (int64_t)(G >= 16 ? 2048 : 4096)) / (n_draw * G);
     if (C > 512) C = 512;
     if (C < 4) C = 1;
   }
