@@ -1780,6 +1780,9 @@ __global__ __launch_bounds__(kWave) void celerite_tree4_kernel(TreeOp a, TreeOp 
 #ifndef EXO_GP_GROUP_TREES
 #define EXO_GP_GROUP_TREES 1
 #endif
+#ifndef EXO_GP_FINE_GROUP
+#define EXO_GP_FINE_GROUP 1   // the pairwise composition of the fine elements (ChunkGeom::fine; J = 7, 8) by celerite_tree_group_kernel too
+#endif
 constexpr int kScanBlock = 256;
 // One level of a scan, items of J >= 3 on groups of eight lanes (tree_item_group): a block is 32 groups = 32 CONSECUTIVE
 // DRAWS of one item (draws fastest), so that each of an item's ~100 strided accesses covers, per row, 64 contiguous bytes of
@@ -2795,7 +2798,14 @@ static int celerite_fwd(const double* t, Series resid, const double* diag, int64
         op.src_elem = ws.off_fine(f); op.src_n = op.src_len = cg.C << f;
         op.dst_elem = f > 1 ? ws.off_fine(f - 1) : ws.elem(0, 0, 0);
         op.n_item = cg.C << (f - 1);
-        hipLaunchKernelGGL(celerite_compose_lds_kernel, dim3((unsigned)(op.n_item * n_draw)), block, 0, st, op, state);
+        if (EXO_GP_GROUP_TREES && EXO_GP_FINE_GROUP && J >= 3 && J <= 8) {
+          // the scan trees' own item kernel (eight lanes per composition, 32 draws per block): the wave-per-composition LDS kernel
+          // took 227 us for the 32 768 compositions of the C5 shape at J = 8, a level of the tree 26 us for 16 384
+          const dim3 ggrid((unsigned)(((int64_t)op.n_item * n_draw + kScanBlock / 8 - 1) / (kScanBlock / 8)));
+          EXO_GP_DISPATCH_GROUP(J, hipLaunchKernelGGL((celerite_tree_group_kernel<JJ, false, false>), ggrid, dim3(kScanBlock), 0, st, op, state))
+        } else {
+          hipLaunchKernelGGL(celerite_compose_lds_kernel, dim3((unsigned)(op.n_item * n_draw)), block, 0, st, op, state);
+        }
       }
       // after the element kernel: it may flag more draws (measurement variance too small)
       hipLaunchKernelGGL(celerite_prep_flagged_kernel, dim3(8, (unsigned)n_draw), dim3(256), 0, st, t, n, cf, n_draw, J,
