@@ -1805,6 +1805,29 @@ __global__ __launch_bounds__(kScanBlock, EXO_GROUP_WAVES) void celerite_tree_gro
   tree_item_group<J, ADJ, DOWN>(op, state, c, unit - (int64_t)c * op.n_draw, g);
 }
 
+// the adjoint elements (B') part 1 on groups of eight lanes, 32 draws per block (badj_prep_group; J = 7, 8)
+// From J = 7: one lane per (draw, chunk) holds 512 registers + 1.8 KB of scratch there (137 us at the C5 shape, J = 8: this kernel
+// ~35); at J = 6 the one-lane kernel takes all 65 408 units in one round of 40 us and THIS one, four rounds of two waves per SIMD,
+// was slower (C5 1.895 -> 1.948 ms).
+#ifndef EXO_GP_BADJ_GROUP_MIN_J
+#define EXO_GP_BADJ_GROUP_MIN_J 7
+#endif
+template <int J>
+__global__ __launch_bounds__(kScanBlock, EXO_GROUP_WAVES) void celerite_badj_prep_group_kernel(const double* __restrict__ gloglike, int64_t n,
+                                                                                             int64_t n_draw, double* state, ChunkGeom cg,
+                                                                                             const int32_t* __restrict__ row) {
+  __shared__ double lds[(kScanBlock / 8) * GroupLds<J>::S];
+  const int tid = threadIdx.x;
+  const int64_t unit = (int64_t)blockIdx.x * (kScanBlock / 8) + (tid >> 3);
+  if (unit >= (int64_t)(cg.C - 1) * n_draw) return;     // (whole groups leave; nothing below needs a block barrier)
+  Grp<J> g;
+  g.lds = lds + (tid >> 3) * GroupLds<J>::S;
+  g.r = tid & 7;
+  g.live = g.r < J;
+  const int c = (int)(unit / n_draw) + 1;
+  badj_prep_group<J>(gloglike, state, chunk_ws(n, n_draw, J, cg), c, unit - (int64_t)(c - 1) * n_draw, g, row);
+}
+
 // the narrow top of a scan as a serial chain on groups of eight lanes, 32 draws per block (tree_serial_group; J >= 3)
 template <int J, bool ADJ>
 __global__ __launch_bounds__(kScanBlock, EXO_GROUP_WAVES) void celerite_tree_serial_group_kernel(TreeOp op, double* state) {
@@ -2659,6 +2682,10 @@ static int celerite_adjoint_scan(const double* t, Series resid, const double* di
     if (EXO_GP_WIDE_LDS && J >= kWideMinJ) {
       hipLaunchKernelGGL(celerite_badj_prep_wide_kernel, dim3((unsigned)n_draw, (unsigned)(cg.C - 1)), dim3(256), 0, st, gloglike, n,
                          n_draw, J, wstate, cg, cf.row);
+    } else if (EXO_GP_GROUP_TREES && J >= EXO_GP_BADJ_GROUP_MIN_J && J <= 8) {
+      const dim3 ggrid((unsigned)(((int64_t)(cg.C - 1) * n_draw + kScanBlock / 8 - 1) / (kScanBlock / 8)));
+      EXO_GP_DISPATCH_GROUP(J, hipLaunchKernelGGL((celerite_badj_prep_group_kernel<JJ>), ggrid, dim3(kScanBlock), 0, st, gloglike, n, n_draw,
+                                                  wstate, cg, cf.row))
     } else {
       EXO_GP_DISPATCH_LE8(J, hipLaunchKernelGGL((celerite_badj_prep_kernel<JJ>), dim3(per_draw.x, (unsigned)(cg.C - 1)), block,
                                                 0, st, gloglike, n, n_draw, wstate, cg, cf.row))

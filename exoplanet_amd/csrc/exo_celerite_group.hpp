@@ -499,6 +499,71 @@ __device__ __forceinline__ void chain_load_elem(const double* state, const Chunk
   el.eta = p[(int64_t)(2 * J * J + J + r) * nd];
 }
 
+// (B'), part 1 on a group's eight lanes -- badj_prep_lane's arithmetic (exo_celerite_core.hpp): the adjoint element of chunk c from
+// its filtering element and the state entering it,
+//     X = I + P Jm,  Y = X^-1,  u = eta - Jm m,  v = m + P eta,  w = Y^T u,
+//     A <- A Y,  b <- eta - Jm (Y v),  eta <- gL w,  Cm <- gL / 2 (w w^T - sym(Jm Y)),
+// written over the element.  One lane per (draw, chunk) keeps ~5 J x J matrices alive around the solve: 482 registers + scratch at
+// J = 6 (40 us at the C5 shape, a wave per SIMD, and nothing runs beside it), 512 + 1.8 KB of scratch at J = 8 (137 us).  Here:
+// lane r owns row r, three exchanges and the Gauss-Jordan solve of the scan items ([I | v] as right-hand sides).
+template <int J>
+__device__ __forceinline__ void badj_prep_group(const double* gloglike, double* state, const ChunkWs& ws, int c, int64_t draw,
+                                                const Grp<J>& g, const int32_t* row) {
+  const int64_t nd = ws.n_draw;
+  int r = g.live ? g.r : 0;
+  asm volatile("" : "+v"(r));   // (tree_item_group: keeps the ~100 strided addresses from being hoisted into registers)
+  const double gL = gloglike ? gloglike[row ? (int64_t)row[draw] : draw] : 1.0;   // (null: a cotangent of one -- ChunkGeom::prep)
+  ElemRow<J> el;
+  chain_load_elem<J>(state, ws, c, draw, r, el);
+  double m, P[J];
+  {
+    const double* q = state + ws.bnd(1, c, 0, draw);
+    m = q[(int64_t)r * nd];
+#pragma unroll
+    for (int l = 0; l < J; ++l) P[l] = q[(int64_t)(J + r * J + l) * nd];
+  }
+  g.put_rows(0, el.Jm);
+  g.put_vec(0, el.eta);
+  g.put_vec(1, m);
+  g.sync();
+  double X[J], R[J + 1];
+  g.mm(P, 0, X);
+#pragma unroll
+  for (int l = 0; l < J; ++l) {
+    X[l] = g.live ? X[l] + (l == r ? 1.0 : 0.0) : 0.0;
+    R[l] = (g.live && l == r) ? 1.0 : 0.0;
+  }
+  const double u = el.eta - g.mv(el.Jm, 1);
+  R[J] = m + g.mv(P, 0);
+  g.template solve<J + 1>(X, R);
+  double Y[J];
+#pragma unroll
+  for (int l = 0; l < J; ++l) Y[l] = R[l];
+  g.put_rows(1, Y);
+  g.put_vec(2, u);
+  g.put_vec(3, R[J]);
+  g.sync();
+  const double w = g.tmv(1, 2);
+  const double gj = el.eta - g.mv(el.Jm, 3);
+  double Ab[J], JY[J], wall[J];
+  g.mm(el.A, 1, Ab);
+  g.mm(el.Jm, 1, JY);
+  g.put_rows(2, JY);
+  g.put_vec(4, w);
+  g.sync();
+  g.sym_from(2, JY);
+  g.get_vec(4, wall);
+  if (!g.live) return;
+  double* q = state + ws.elem(c, 0, draw);
+#pragma unroll
+  for (int l = 0; l < J; ++l) {
+    q[(int64_t)(r * J + l) * nd] = Ab[l];
+    q[(int64_t)(J * J + J + r * J + l) * nd] = 0.5 * gL * (w * wall[l] - JY[l]);
+  }
+  q[(int64_t)(J * J + r) * nd] = gj;
+  q[(int64_t)(2 * J * J + J + r) * nd] = gL * w;
+}
+
 template <int J>
 __device__ __forceinline__ void robust_fwd_chain_group(const ChunkWs& ws, double* state, int64_t draw, double* lds, int lane8) {
   using L = ChainLds<J>;
