@@ -345,6 +345,10 @@ def workload_c5(xo, ops, dev, D, rank=0, bright=0, bright_factor=1e3, kernel="sh
             kern = (T.RotationTerm(sigma=Lv["s1"], period=9.0 * ones, Q0=1.5 * ones, dQ=0.4 * ones, f=0.6 * ones)
                     + T.RotationTerm(sigma=Lv["s2"], period=23.0 * ones, Q0=2.5 * ones, dQ=0.7 * ones, f=0.3 * ones)
                     + T.SHOTerm(sigma=Lv["s3"], rho=fixed[2][0], Q=fixed[2][1]))
+        elif kernel == "rot3":       # (J = 12; tools only)
+            kern = (T.RotationTerm(sigma=Lv["s1"], period=9.0 * ones, Q0=1.5 * ones, dQ=0.4 * ones, f=0.6 * ones)
+                    + T.RotationTerm(sigma=Lv["s2"], period=23.0 * ones, Q0=2.5 * ones, dQ=0.7 * ones, f=0.3 * ones)
+                    + T.RotationTerm(sigma=Lv["s3"], period=3.1 * ones, Q0=2.0 * ones, dQ=0.5 * ones, f=0.5 * ones))
         else:
             kern = (T.SHOTerm(sigma=Lv["s1"], rho=fixed[0][0], Q=fixed[0][1]) + T.SHOTerm(sigma=Lv["s2"], rho=fixed[1][0], Q=fixed[1][1])
                     + T.SHOTerm(sigma=Lv["s3"], rho=fixed[2][0], Q=fixed[2][1]))

@@ -799,15 +799,21 @@ struct LaneDelta {
   // then two selects per entry.  (A real or idle lane has dq = dr = 0 and (cs, sn) = (1, 0) from lane_uv: the pair formulas give
   // dp and 0 there.)  As nested ifs inside the unrolled loop this was ~4 divergent branch regions per ENTRY in the element
   // kernel's cadence loop: 47 of them per cadence at J = 10, a third of the 1030 instructions it issued.
-  template <int J>
-  __device__ __forceinline__ void row(const LaneCoef& k, int j, double cs, double sn, double* D) const {
+  // the two entries of my row that are not zero: the diagonal one, vd, and (a pair) the one at the pair's other index, vo
+  __device__ __forceinline__ void two(const LaneCoef& k, double cs, double sn, double* vd, double* vo) const {
     const double v_even = dp * cs * cs + 2.0 * dq * cs * sn + dr * sn * sn;
     const double v_odd = dp * sn * sn - 2.0 * dq * cs * sn + dr * cs * cs;
     const double v_off = (dp - dr) * cs * sn + dq * (sn * sn - cs * cs);
-    const bool pair = k.live && !k.real;
-    const double vd = k.live ? (k.real ? dp : (k.odd ? v_odd : v_even)) : 0.0;
-    const double vo = pair ? v_off : 0.0;
-    const int jo = pair ? (k.odd ? j - 1 : j + 1) : -1;
+    *vd = k.live ? (k.real ? dp : (k.odd ? v_odd : v_even)) : 0.0;
+    *vo = (k.live && !k.real) ? v_off : 0.0;
+  }
+  // the pair's other index (-1: none)
+  static __device__ __forceinline__ int other(const LaneCoef& k, int j) { return (k.live && !k.real) ? (k.odd ? j - 1 : j + 1) : -1; }
+  template <int J>
+  __device__ __forceinline__ void row(const LaneCoef& k, int j, double cs, double sn, double* D) const {
+    double vd, vo;
+    two(k, cs, sn, &vd, &vo);
+    const int jo = other(k, j);
 #pragma unroll
     for (int l = 0; l < J; ++l) D[l] = (l == j) ? vd : ((l == jo) ? vo : 0.0);
   }
@@ -913,14 +919,18 @@ __global__ __launch_bounds__(kWave) void celerite_elem_lg_kernel(
 
   // lane j holds COLUMN j of A (so that (A^T U)_j is a local dot product: no butterfly) and rows j of
   // Cm, Jm
-  double Acol[J], Crow[J], Jrow[J], Dl[J], phiall[J];
+  // (my row of Delta has two entries that are not zero -- LaneDelta::two: the previous cadence's are two doubles, not a row of J:
+  // the kernel held 80 + 16 J registers, one wave per SIMD from J = 11 and two from J = 6)
+  double Acol[J], Crow[J], Jrow[J], phiall[J];
 #pragma unroll
   for (int l = 0; l < J; ++l) { Acol[l] = (live && l == j) ? 1.0 : 0.0; Crow[l] = 0.0; Jrow[l] = 0.0; phiall[l] = 1.0; }
   double bj = 0.0, etaj = 0.0, phi = 1.0;
   double ti = t[n0];
   double Uj, Vj, cs, sn;
   lane_uv(k, ti, &Uj, &Vj, &cs, &sn);
-  ld.row<J>(k, j, cs, sn, Dl);
+  const int jo = LaneDelta::other(k, j);
+  double vd_l, vo_l;
+  ld.two(k, cs, sn, &vd_l, &vo_l);
   LaneStepper stp;
 #pragma unroll 1
   for (int64_t i = n0; i < n1; ++i) {
@@ -954,8 +964,8 @@ __global__ __launch_bounds__(kWave) void celerite_elem_lg_kernel(
       } else {
         lane_uv(k, tn, &Uj, &Vj, &cs, &sn);
       }
-      double Dn[J];
-      ld.row<J>(k, j, cs, sn, Dn);
+      double vd_n, vo_n;
+      ld.two(k, cs, sn, &vd_n, &vo_n);
       const double kj = cuj * is;            // the gain of my state index
       bj = phi * fma(kj, zeta, bj);
       // what the updates need of the OTHER indices is their gains k_l = (Cm U)_l / s (gathered once, instead of (Cm U)_l with a
@@ -965,9 +975,10 @@ __global__ __launch_bounds__(kWave) void celerite_elem_lg_kernel(
 #pragma unroll
       for (int l = 0; l < J; ++l) {
         Acol[l] = phiall[l] * fma(-kall[l], rj, Acol[l]);
-        Crow[l] = fma(phi * phiall[l], fma(-cuj, kall[l], Crow[l]) - Dl[l], Dn[l]);   // + Q = Dn - phi phi Dl
-        Dl[l] = Dn[l];
+        const double dl = (l == j) ? vd_l : ((l == jo) ? vo_l : 0.0), dn = (l == j) ? vd_n : ((l == jo) ? vo_n : 0.0);
+        Crow[l] = fma(phi * phiall[l], fma(-cuj, kall[l], Crow[l]) - dl, dn);   // + Q = Dn - phi phi Dl
       }
+      vd_l = vd_n; vo_l = vo_n;
     }
   }
   if (!live_draw || !live) return;
