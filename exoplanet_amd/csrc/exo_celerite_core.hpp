@@ -539,13 +539,18 @@ EXO_HDH ChunkGeom chunk_plan(int64_t n, int64_t n_draw, int J, int32_t n_chunks)
   }
   if (C > n / 32) C = n / 32;        // chunks of at least 32 cadences
   if (C < 2) return g;
+  // J = 7, 8: the elements on half chunks (composed pairwise back up) only where the batch leaves the element kernel short of one
+  // round of waves -- it fits two per SIMD since round 6, and with 2048 waves or more the finer level only adds its composition:
+  // measured at the C5 shape, J = 8 (same box, alternating): 128 chains 3.31 -> 3.19 ms without it, 32 chains 1.38 -> 1.31,
+  // 512 chains 10.93 -> 10.81; 16 chains (1024 waves) 1.13 -> 1.16: kept there
+  const int fine = (lane || J >= kWideMinJ) ? 0 : ((n_draw * 8 * C) / 64 < 2048 ? kFineLevels : 0);
   g.L = (n + C - 1) / C;
   if (lane) g.L = (g.L + kCkptB - 1) / kCkptB * kCkptB;
-  else if (J < kWideMinJ) g.L = (g.L + (1 << kFineLevels) - 1) >> kFineLevels << kFineLevels;   // whole fine chunks
+  else if (fine) g.L = (g.L + (1 << fine) - 1) >> fine << fine;   // whole fine chunks
   g.C = (int)((n + g.L - 1) / g.L);
   if (g.C < 2) { g.C = 1; g.L = n; return g; }
   g.lane = lane ? 1 : 0;
-  g.fine = (lane || J >= kWideMinJ) ? 0 : kFineLevels;   // (the pairwise composition of fine elements is the 8 x 8 LDS kernel: J <= 8)
+  g.fine = fine;   // (the pairwise composition of fine elements: the scan trees' group kernel, J <= 8)
   g.tree = 1;   // the scans over the chunks as trees of compositions (one lane each)
   return g;
 }
