@@ -304,7 +304,7 @@ def test_wide_state_takes_the_time_parallel_path(dev):
                 assert np.abs(g - w).max() / (np.abs(w).max() + 1e-300) < 1e-9
 
 
-@pytest.mark.parametrize("J", [9, 10, 12, 13, 16])
+@pytest.mark.parametrize("J", [9, 10, 11, 12, 13, 14, 15, 16])
 def test_states_wider_than_eight_take_the_time_parallel_path(dev, J):
     """J = 9 .. 16 (round 6): the lane-group element / chunk kernels on a DPP row of sixteen lanes, the scans on blocks of 256
     threads with the matrices in LDS (celerite_tree_wide_kernel): chunked == sequential == dense -- on the default plan and on
