@@ -2390,8 +2390,19 @@ struct RevP {
   // memory per lane (slot k at g[k * gs]), on the host a plain array (gs = 1): k = 4 j + {a, b, c, d}; 4 J = sum of dbar
   double* g;
   int gs;
+  // (device: the accumulators are columns of LDS, and `+=` there is a read -> add -> write round trip the lane waits for, 25 of them
+  // per cadence at J = 6; the LDS unit's own add -- ds_add_f64, nothing returned -- is fire and forget.  A lane's column is its
+  // own and LDS operations of a wave execute in order: no atomicity is asked for, only the unit that does the add.)
+#ifndef EXO_GACC_LDS_ADD
+#define EXO_GACC_LDS_ADD 1
+#endif
   EXO_HD void gadd(int k, double v) {
-    if (!STATE_ONLY) g[k * gs] += v;
+    if (STATE_ONLY) return;
+#if defined(__HIP_DEVICE_COMPILE__) && EXO_GACC_LDS_ADD
+    (void)__hip_atomic_fetch_add(g + k * gs, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+#else
+    g[k * gs] += v;
+#endif
   }
 
   // measurement half of cadence i: adjoints of (d, z, W) of this cadence -> (S, F) of this cadence
