@@ -34,6 +34,14 @@ constexpr int kCkptB = 4;   // cadences per block of the one-lane chunk kernels 
 // the polish passes (chunk1_fwd_lane): a laboratory result so far -- compiled into the host harness (tests/gp_host_harness.cpp,
 // tools/gp_host_lab.py), not into the device kernels: one Jacobi sweep takes the MEDIAN error of ill-conditioned draws down
 // 10-100 x but the worst kernels only 3-10 x per four sweeps (docs/DESIGN_r1_r4.md section 3.5)
+// the checkpoints of the one-lane forward kernel -- written once, read once by the reverse kernel a millisecond later -- by
+// non-temporal stores: C3 3.314 -> 3.260 ms, C5 1.827 -> 1.798 (same box, alternating)
+#ifndef EXO_CKPT_NT_STORE
+#define EXO_CKPT_NT_STORE 1
+#endif
+#ifndef EXO_CKPT_NT_LOAD
+#define EXO_CKPT_NT_LOAD 0
+#endif
 #ifndef EXO_GP_POLISH
 #define EXO_GP_POLISH 0
 #endif
@@ -434,6 +442,13 @@ struct ChunkWs {
 // the series and the measurement variance of one block of four cadences [b0, b0 + 4) clipped to n1.
 // The chunk kernels load the NEXT block's before they work through the current one: a lane's row
 // accesses miss every cache, and with 2-4 waves per SIMD nothing else hides ~1 us of latency per block.
+EXO_HD double ckpt_load(const double* p) {
+#if defined(__HIP_DEVICE_COMPILE__) && EXO_CKPT_NT_LOAD
+  return __builtin_nontemporal_load(p);
+#else
+  return *p;
+#endif
+}
 struct BlockIn {
   double y[4], g[4];
 };
@@ -2018,10 +2033,17 @@ EXO_HD void chunk1_fwd_lane(const double* EXO_RESTRICT t, Series rs, const doubl
         }
         if (q % ckpt_span(J) == 0 && save) {   // checkpoint: the state AT the span's first cadence (after the step into it)
           const int64_t g = i / ckpt_span(J);
+#if defined(__HIP_DEVICE_COMPILE__) && EXO_CKPT_NT_STORE
+#pragma unroll
+          for (int j = 0; j < J; ++j) __builtin_nontemporal_store(f.F[j], state + ws.ckpt(g, j, draw));
+#pragma unroll
+          for (int k = 0; k < J * (J + 1) / 2; ++k) __builtin_nontemporal_store(f.S.v[k], state + ws.ckpt(g, J + k, draw));
+#else
 #pragma unroll
           for (int j = 0; j < J; ++j) state[ws.ckpt(g, j, draw)] = f.F[j];
 #pragma unroll
           for (int k = 0; k < J * (J + 1) / 2; ++k) state[ws.ckpt(g, J + k, draw)] = f.S.v[k];
+#endif
         }
         f.measure(cur.y[q], cur.g[q] + asum);
         bad = bad || !(f.d > 0.0);
@@ -2261,7 +2283,7 @@ EXO_HD void chunk1_vjp_lane(const double* EXO_RESTRICT t, Series rs, const doubl
   auto load_ckpt = [&](int64_t b0, double* dst) {
     const int64_t g = b0 / kCkptB;
 #pragma unroll
-    for (int k = 0; k < kK; ++k) dst[k] = state[ws.ckpt(g, k, draw)];
+    for (int k = 0; k < kK; ++k) dst[k] = ckpt_load(state + ws.ckpt(g, k, draw));
   };
   load_block(y, dg, n_diag, n0 + (nb - 1) * kCkptB, n1, cur);
   load_ckpt(n0 + (nb - 1) * kCkptB, ck);
@@ -2589,7 +2611,7 @@ EXO_HD void chunkp_vjp_lane(const double* EXO_RESTRICT t, Series rs, const doubl
   auto load_ckpt = [&](int64_t i0, double* dst) {   // the checkpoint at cadence i0 (a multiple of kSpan from the chunk start)
     const int64_t g = i0 / kSpan;
 #pragma unroll
-    for (int k = 0; k < kK; ++k) dst[k] = state[ws.ckpt(g, k, draw)];
+    for (int k = 0; k < kK; ++k) dst[k] = ckpt_load(state + ws.ckpt(g, k, draw));
   };
   load_block(y, dg, n_diag, n0 + (nb - 1) * kCkptB, n1, cur);
   if (kAhead) {
